@@ -1,0 +1,862 @@
+/*
+ * dtof_oracle.c -- scalar CPU restatement of the reference's Doppler-ToF path
+ * tracer (`dopplertofpath` integrator + `correlated` sampler and everything they
+ * call per lane).  TEST INFRASTRUCTURE ONLY -- see dtof_oracle.h.
+ *
+ * Reference = /root/reference (juhyeonkim95/Mitsuba3DopplerToF @ 2024_08_07), JIT
+ * ("llvm_rgb") semantics: one lane per (pixel, sample), Float = float32,
+ * Spectrum = Color3f.  Citations are relative to the reference root.
+ *
+ * PARITY: unpinned for the path as a whole (the reference has no test/fixture for
+ * it and cannot be built here); pinned building blocks: TEA, PCG32, Kensler,
+ * waveforms (tests/test_oracle_kat.py).
+ *
+ * Arithmetic conventions (compiled with -ffp-contract=off; every fused
+ * multiply-add below is an explicit fmaf(), placed where the reference calls
+ * dr::fmadd or where Dr.Jit's array primitives are fmadd chains):
+ *   dot(a,b)      = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))       (Dr.Jit dot_ = fmadd chain)
+ *   cross(a,b)    = fmsub(a.yzx, b.zxy, a.zxy*b.yzx)
+ *   normalize(v)  = v * rsqrt(dot(v,v)),  rsqrt(x) = sqrt(1/x)  (Dr.Jit LLVM lowering)
+ *   rcp(x)        = 1/x ;  array / lower-depth value = array * rcp(value)
+ *   sincos/cos    = Cephes single-precision polynomials (Dr.Jit's own approximations
+ *                   are Cephes-based; the source is absent, so this is a restatement
+ *                   of the published Cephes algorithm, identical on CPU and GPU)
+ *   Third-party pieces absent from the tree (Dr.Jit 0.4.0 PCG32, Embree 3 traversal
+ *   and instance-matrix interpolation) are restated from their published
+ *   algorithms; see SURVEY.md Appendix C.
+ */
+#define _GNU_SOURCE
+#include "dtof_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+typedef struct { float x, y, z; } v3;
+
+#define ORC_PI_F        3.14159265358979323846f
+#define ORC_INV_PI_F    0.31830988618379067154f
+#define ORC_RAY_EPS     (1500.f * 5.9604644775390625e-8f)   /* math.h:17-22: 1500 * 2^-24 */
+#define ORC_SHADOW_EPS  (ORC_RAY_EPS * 10.f)
+#define ORC_LARGEST     3.40282346638528859812e+38f         /* dr::Largest<float> */
+
+/* ------------------------------------------------------------------ helpers */
+static inline float f_rcp(float x)   { return 1.0f / x; }
+static inline float f_rsqrt(float x) { return sqrtf(1.0f / x); }
+static inline float f_sqr(float x)   { return x * x; }
+static inline uint32_t f2u(float f)  { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u)  { float f; memcpy(&f, &u, 4); return f; }
+/* dr::mulsign(a, b): a with its sign flipped when b's sign bit is set */
+static inline float f_mulsign(float a, float b) { return u2f(f2u(a) ^ (f2u(b) & 0x80000000u)); }
+static inline float f_mulsign_neg(float a, float b) { return u2f(f2u(a) ^ (~f2u(b) & 0x80000000u)); }
+static inline float f_sign(float x) { return u2f(0x3f800000u | (f2u(x) & 0x80000000u)); } /* dr::sign: +-1 */
+static inline float f_min(float a, float b) { return a < b ? a : b; }
+static inline float f_max(float a, float b) { return a > b ? a : b; }
+
+static inline v3 V(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 v_add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 v_sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v_mul(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 v_neg(v3 a) { return V(-a.x, -a.y, -a.z); }
+static inline v3 v_fma(v3 a, float s, v3 c) { return V(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z)); }
+static inline float v_dot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline v3 v_cross(v3 a, v3 b) {
+    return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+static inline v3 v_normalize(v3 a) { return v_mul(a, f_rsqrt(v_dot(a, a))); }
+static inline float v_norm(v3 a) { return sqrtf(v_dot(a, a)); }
+
+/* Transform::transform_affine(Point) -- include/mitsuba/core/transform.h:97-105 */
+static inline v3 m_point(const float *m, v3 p) {
+    return V(fmaf(m[2], p.z, fmaf(m[1], p.y, fmaf(m[0], p.x, m[3]))),
+             fmaf(m[6], p.z, fmaf(m[5], p.y, fmaf(m[4], p.x, m[7]))),
+             fmaf(m[10], p.z, fmaf(m[9], p.y, fmaf(m[8], p.x, m[11]))));
+}
+/* Transform::operator*(Vector) -- transform.h:125-134 */
+static inline v3 m_vector(const float *m, v3 v) {
+    return V(fmaf(m[2], v.z, fmaf(m[1], v.y, m[0] * v.x)),
+             fmaf(m[6], v.z, fmaf(m[5], v.y, m[4] * v.x)),
+             fmaf(m[10], v.z, fmaf(m[9], v.y, m[8] * v.x)));
+}
+/* Transform::operator*(Normal) with inverse_transpose = inv^T -- transform.h:140-149.
+ * `inv` is the (row-major) inverse matrix, so inverse_transpose(r,c) = inv(c,r). */
+static inline v3 m_normal(const float *inv, v3 n) {
+    return V(fmaf(inv[8], n.z, fmaf(inv[4], n.y, inv[0] * n.x)),
+             fmaf(inv[9], n.z, fmaf(inv[5], n.y, inv[1] * n.x)),
+             fmaf(inv[10], n.z, fmaf(inv[6], n.y, inv[2] * n.x)));
+}
+
+/* Inverse of an affine 4x4 (last row taken as 0,0,0,1).  The reference inverts the
+ * full 4x4 (dr::inverse_transpose inside Transform(Matrix), transform.h:54-56) and
+ * then only ever uses the affine part (transform_affine); Dr.Jit's source is
+ * absent, so the exact operation order is this file's own, shared with the GPU. */
+static void m_affine_inverse(const float *m, float *inv) {
+    float a00 = m[0], a01 = m[1], a02 = m[2], a10 = m[4], a11 = m[5], a12 = m[6],
+          a20 = m[8], a21 = m[9], a22 = m[10];
+    float c00 = fmaf(a11, a22, -(a12 * a21)), c01 = fmaf(a12, a20, -(a10 * a22)),
+          c02 = fmaf(a10, a21, -(a11 * a20));
+    float det = fmaf(a02, c02, fmaf(a01, c01, a00 * c00));
+    float id = 1.0f / det;
+    float i00 = c00 * id, i01 = fmaf(a02, a21, -(a01 * a22)) * id, i02 = fmaf(a01, a12, -(a02 * a11)) * id;
+    float i10 = c01 * id, i11 = fmaf(a00, a22, -(a02 * a20)) * id, i12 = fmaf(a02, a10, -(a00 * a12)) * id;
+    float i20 = c02 * id, i21 = fmaf(a01, a20, -(a00 * a21)) * id, i22 = fmaf(a00, a11, -(a01 * a10)) * id;
+    float tx = m[3], ty = m[7], tz = m[11];
+    inv[0] = i00; inv[1] = i01; inv[2] = i02;  inv[3]  = -fmaf(i02, tz, fmaf(i01, ty, i00 * tx));
+    inv[4] = i10; inv[5] = i11; inv[6] = i12;  inv[7]  = -fmaf(i12, tz, fmaf(i11, ty, i10 * tx));
+    inv[8] = i20; inv[9] = i21; inv[10] = i22; inv[11] = -fmaf(i22, tz, fmaf(i21, ty, i20 * tx));
+    inv[12] = 0.f; inv[13] = 0.f; inv[14] = 0.f; inv[15] = 1.f;
+}
+
+/* ------------------------------------------------------------ sincos (Cephes) */
+/* Restatement of the Cephes sinf/cosf kernel that Dr.Jit's dr::sincos is based on
+ * (drjit/math.h, absent): range reduction by pi/4 octants with a 3-term Cody-Waite
+ * split, degree-3 polynomials in z=y*y (Estrin form). */
+void orc_sincos(float x, float *s_out, float *c_out) {
+    float xa = fabsf(x);
+    int32_t j = (int32_t) (xa * 1.2732395447351626862f);
+    j = (j + 1) & ~1;
+    float y = (float) j;
+    uint32_t sign_sin = ((uint32_t) j << 29) ^ f2u(x);
+    uint32_t sign_cos = (uint32_t) (~(j - 2)) << 29;
+    y = xa - y * 0.78515625f;
+    y = y - (float) j * 2.4187564849853515625e-4f;
+    y = y - (float) j * 3.77489497744594108e-8f;
+    float z = y * y;
+    float s = fmaf(z * z, -1.9515295891e-4f, fmaf(z, 8.3321608736e-3f, -1.6666654611e-1f)) * z;
+    float c = fmaf(z * z, 2.443315711809948e-5f, fmaf(z, -1.388731625493765e-3f, 4.166664568298827e-2f)) * z;
+    s = fmaf(s, y, y);
+    c = fmaf(c, z, fmaf(z, -0.5f, 1.0f));
+    int poly = (j & 2) == 0;
+    *s_out = u2f(f2u(poly ? s : c) ^ (sign_sin & 0x80000000u));
+    *c_out = u2f(f2u(poly ? c : s) ^ (sign_cos & 0x80000000u));
+}
+static inline float orc_cos(float x) { float s, c; orc_sincos(x, &s, &c); return c; }
+
+/* ------------------------------------------------------------------ RNG */
+/* sample_tea_32 -- include/mitsuba/core/random.h:33-47 */
+void orc_tea32(uint32_t v0, uint32_t v1, int rounds, uint32_t *o0, uint32_t *o1) {
+    uint32_t sum = 0;
+    for (int i = 0; i < rounds; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    *o0 = v0; *o1 = v1;
+}
+/* sample_tea_float32 -- random.h:63-67 */
+float orc_tea_float32(uint32_t v0, uint32_t v1, int rounds) {
+    uint32_t a, b; orc_tea32(v0, v1, rounds, &a, &b);
+    return u2f((b >> 9) | 0x3f800000u) - 1.f;
+}
+/* dr::PCG32 (Dr.Jit 0.4.0 drjit/random.h, absent; O'Neill's PCG-XSH-RR 64/32) */
+#define PCG32_MULT 0x5851f42d4c957f2dULL
+uint32_t orc_pcg32_next_u32(uint64_t *state, uint64_t inc) {
+    uint64_t old = *state;
+    *state = old * PCG32_MULT + inc;
+    uint32_t xorshift = (uint32_t) (((old >> 18) ^ old) >> 27);
+    uint32_t rot = (uint32_t) (old >> 59);
+    return (xorshift >> rot) | (xorshift << ((~rot + 1u) & 31));
+}
+/* PCG32::seed(size=1, initstate, initseq): inc = (initseq<<1)|1, two warm-up steps */
+void orc_pcg32_seed(uint64_t initstate, uint64_t initseq, uint64_t *state, uint64_t *inc) {
+    *state = 0; *inc = (initseq << 1) | 1u;
+    orc_pcg32_next_u32(state, *inc);
+    *state += initstate;
+    orc_pcg32_next_u32(state, *inc);
+}
+float orc_pcg32_next_f32(uint64_t *state, uint64_t inc) {
+    return u2f((orc_pcg32_next_u32(state, inc) >> 9) | 0x3f800000u) - 1.f;
+}
+/* permute_kensler -- random.h:113-171 (cycle-walking form of the JIT loop :151-158) */
+uint32_t orc_permute_kensler(uint32_t index, uint32_t n, uint32_t seed) {
+    if (n == 1) return 0;
+    uint32_t w = n - 1;
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    do {
+        uint32_t tmp = index;
+        tmp ^= seed;            tmp *= 0xe170893du;
+        tmp ^= seed >> 16;      tmp ^= (tmp & w) >> 4;
+        tmp ^= seed >> 8;       tmp *= 0x0929eb3fu;
+        tmp ^= seed >> 23;      tmp ^= (tmp & w) >> 1;
+        tmp *= 1 | seed >> 27;  tmp *= 0x6935fa69u;
+        tmp ^= (tmp & w) >> 11; tmp *= 0x74dcb303u;
+        tmp ^= (tmp & w) >> 2;  tmp *= 0x9e501cc3u;
+        tmp ^= (tmp & w) >> 2;  tmp *= 0xc860a3dfu;
+        tmp &= w;               tmp ^= tmp >> 5;
+        index = tmp;
+    } while (index >= n);
+    return (index + seed) % n;
+}
+
+/* ------------------------------------------------------------------ sampler */
+typedef struct {
+    uint64_t s_main, i_main, s_time, i_time, s_path, i_path;
+    uint32_t perm_seed, dim, sample_index;
+} orc_sampler;
+
+/* CorrelatedSampler::seed -- src/samplers/correlated.cpp:38-64, PCG32Sampler::seed
+ * src/render/sampler.cpp:115-134, compute_per_sequence_seed :85-92 */
+static void sampler_seed(orc_sampler *s, const orc_params *p, uint32_t seed, uint32_t spp, uint32_t lane) {
+    uint32_t sv = p->base_seed + seed, v0, v1;
+    orc_tea32(sv, lane, 4, &v0, &v1);
+    orc_pcg32_seed(v0, v1, &s->s_main, &s->i_main);
+    orc_tea32(sv + 1, lane / (uint32_t) p->time_correlate_number, 4, &v0, &v1);
+    orc_pcg32_seed(v0, v1, &s->s_time, &s->i_time);
+    orc_tea32(sv + 2, lane / (uint32_t) p->path_correlate_number, 4, &v0, &v1);
+    orc_pcg32_seed(v0, v1, &s->s_path, &s->i_path);
+    orc_tea32(p->base_seed, spp * (lane / spp) + seed, 4, &v0, &v1);
+    s->perm_seed = v0;
+    s->dim = 0;
+    s->sample_index = spp > 1 ? lane % spp : 0;  /* sampler.cpp:94-103, m_sample_index = 0 */
+}
+/* next_1d_correlate -- correlated.cpp:156-161: both streams always advance */
+static inline float sampler_next_1d_correlate(orc_sampler *s, int correlate) {
+    float r1 = orc_pcg32_next_f32(&s->s_path, s->i_path);
+    float r2 = orc_pcg32_next_f32(&s->s_main, s->i_main);
+    return correlate ? r1 : r2;
+}
+/* next_1d_time -- correlated.cpp:92-153 */
+static float sampler_next_1d_time(orc_sampler *s, const orc_params *p, uint32_t spp) {
+    int strategy = p->time_sampling;
+    uint32_t tcn = (uint32_t) p->time_correlate_number;
+    if (strategy == ORC_TIME_UNIFORM)
+        return orc_pcg32_next_f32(&s->s_main, s->i_main);
+    uint32_t si = s->sample_index;
+    float r = (strategy == ORC_TIME_STRATIFIED) ? orc_pcg32_next_f32(&s->s_main, s->i_main)
+                                                : orc_pcg32_next_f32(&s->s_time, s->i_time);
+    if (p->stratify_each_interval) {
+        int n_stratum = (int) (spp / tcn);
+        float inv_n = 1.0f / (float) n_stratum;     /* array / scalar = array * rcp(scalar) */
+        if (strategy == ORC_TIME_STRATIFIED) {
+            uint32_t ps = s->perm_seed + s->dim++;
+            uint32_t p1 = orc_permute_kensler(si / tcn, (uint32_t) n_stratum, ps);
+            ps = s->perm_seed + s->dim++;
+            uint32_t p2 = orc_permute_kensler(si / tcn, (uint32_t) n_stratum, ps);
+            uint32_t pp = (si % tcn != 0) ? p1 : p2;
+            r = ((float) pp + r) * inv_n;
+        } else {
+            uint32_t pp = si / tcn;
+            r = ((float) pp + r) * inv_n;
+        }
+    }
+    if (strategy == ORC_TIME_STRATIFIED) {
+        uint32_t pp = si % tcn;
+        return ((float) pp + r) * (1.0f / (float) tcn);
+    } else if (strategy == ORC_TIME_ANTITHETIC) {
+        uint32_t rem = si % tcn;
+        if (tcn == 2) { float r2 = r + p->antithetic_shift; return rem != 1 ? r : r2; }
+        return r + (float) rem / (float) tcn;
+    } else if (strategy == ORC_TIME_ANTITHETIC_MIRROR) {
+        float r2 = 1.0f - r + p->antithetic_shift;
+        uint32_t rem = si % tcn;
+        return rem != 1 ? r : r2;
+    }
+    return r;
+}
+
+/* ------------------------------------------------------------------ waveforms */
+/* eval_modulation_function_value -- include/mitsuba/render/waveform_utils.h:24-33 */
+float orc_waveform(float _t, int type) {
+    float t = fmodf(_t, 2.f * ORC_PI_F);
+    switch (type) {
+        case ORC_WAVE_RECT: return fabsf(t - ORC_PI_F) > 0.5f * ORC_PI_F ? 1.f : -1.f;
+        case ORC_WAVE_TRI:  return t < ORC_PI_F ? 1.f - 2.f * t * (1.0f / ORC_PI_F)
+                                                : -3.f + 2.f * t * (1.0f / ORC_PI_F);
+        default: return orc_cos(t);   /* sinusoidal; trapezoidal falls through (:27-32) */
+    }
+}
+/* eval_modulation_function_value_low_pass -- waveform_utils.h:36-62 */
+float orc_waveform_low_pass(float _t, int type) {
+    float t = fmodf(_t, 2.f * ORC_PI_F);
+    if (type == ORC_WAVE_SIN) return orc_cos(t);
+    float a = t * (1.0f / ORC_PI_F), b = 2.f - a, c = a < b ? a : b;
+    switch (type) {
+        case ORC_WAVE_RECT: return 2.f - 4.f * c;
+        case ORC_WAVE_TRI:  return (4.f * c * c * c - 6.f * c * c + 1.f) * 2.0f * (1.0f / 3.0f);
+        case ORC_WAVE_TRAP: { float r = 2.f - 4.f * c; return f_min(f_max(2.0f * r, -2.0f), 2.0f); }
+    }
+    return orc_cos(t);
+}
+/* eval_modulation_weight -- src/integrators/dopplertofpath.cpp:60-77.  The scalar
+ * prefactors are folded in double and rounded once to float (they multiply a JIT
+ * Float, so Dr.Jit converts the double scalar to float32 first). */
+float orc_modulation_weight(const orc_params *p, float ray_time, float path_length) {
+    float w_g = (float) (2 * M_PI * (double) p->w_g_mhz * 1e6);
+    float w_d = (float) (2 * M_PI / (double) p->time * (double) p->hetero_frequency);
+    float phi = (float) ((2 * M_PI * (double) p->w_g_mhz) / 300) * path_length;
+    if (p->low_frequency_component_only) {
+        float t = w_d * ray_time + p->phase_offset + phi;
+        return (float) (0.5 * (double) p->g_1) * orc_waveform_low_pass(t, p->wave_type);
+    }
+    float t1 = w_g * ray_time - phi;
+    float t2 = (w_g + w_d) * ray_time + p->phase_offset;
+    float g_t = p->g_1 * orc_waveform(t1, p->wave_type) + p->g_0;
+    float s_t = orc_waveform(t2, p->wave_type);
+    return s_t * g_t;
+}
+
+/* ------------------------------------------------------------------ camera */
+/* 4x4 helpers for the camera set-up (column-major Dr.Jit product: fmadd chain over k) */
+static void m4_mul(const float *a, const float *b, float *out) {
+    float r[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float s = a[4 * i + 0] * b[0 + j];
+            for (int k = 1; k < 4; ++k) s = fmaf(a[4 * i + k], b[4 * k + j], s);
+            r[4 * i + j] = s;
+        }
+    memcpy(out, r, sizeof r);
+}
+static void m4_identity(float *m) { memset(m, 0, 64); m[0] = m[5] = m[10] = m[15] = 1.f; }
+
+/* sample_to_camera = inverse of perspective_projection(...) (include/mitsuba/render/sensor.h:226-262,
+ * Transform::perspective transform.h:215-233, PerspectiveCamera::update_camera_transforms
+ * src/sensors/perspective.cpp:172-198).  Transform keeps analytic inverses, so the
+ * inverse is the reversed product of the factors' inverses, in float32. */
+static void camera_sample_to_camera(const orc_sensor *s, float *inv_out) {
+    float fw = (float) s->film_w, fh = (float) s->film_h;
+    float rel_sx = (float) s->crop_w / fw, rel_sy = (float) s->crop_h / fh;
+    float rel_ox = (float) s->crop_x / fw, rel_oy = (float) s->crop_y / fh;
+    float aspect = fw / fh;
+    float near_ = s->near_clip, far_ = s->far_clip;
+    /* tan is evaluated in double and rounded (Dr.Jit's own float32 tan is absent) */
+    float tanv = (float) tan((double) (s->x_fov * .5f) * (M_PI / 180.0));
+    float S1i[16], T1i[16], S2i[16], T2i[16], Pi[16], tmp[16];
+    m4_identity(S1i); S1i[0] = f_rcp(1.f / rel_sx); S1i[5] = f_rcp(1.f / rel_sy);
+    m4_identity(T1i); T1i[3] = rel_ox; T1i[7] = rel_oy;          /* inverse of translate(-rel_offset) */
+    m4_identity(S2i); S2i[0] = f_rcp(-0.5f); S2i[5] = f_rcp(-0.5f * aspect);
+    m4_identity(T2i); T2i[3] = 1.f; T2i[7] = 1.f / aspect;        /* inverse of translate(-1,-1/aspect,0) */
+    memset(Pi, 0, 64);                                            /* transform.h:226-230 inv_trafo */
+    Pi[0] = tanv; Pi[5] = tanv; Pi[10] = 0.f; Pi[15] = f_rcp(near_);
+    Pi[11] = 1.f; Pi[14] = (near_ - far_) / (far_ * near_);
+    /* (S1*T1*S2*T2*P)^-1 = P^-1*(T2^-1*(S2^-1*(T1^-1*S1^-1))) */
+    m4_mul(T1i, S1i, tmp); m4_mul(S2i, tmp, tmp); m4_mul(T2i, tmp, tmp); m4_mul(Pi, tmp, inv_out);
+}
+
+/* PerspectiveCamera::sample_ray_differential -- src/sensors/perspective.cpp:238-279
+ * (differentials are not needed by diffuse BSDFs and are not produced). */
+typedef struct { v3 o, d; float maxt; } orc_ray;
+static orc_ray camera_ray(const orc_sensor *s, const float *s2c, float ux, float uy) {
+    /* Transform::operator*(Point): homogeneous, then head<3>(r) / r.w = head * rcp(w) */
+    float r0 = fmaf(s2c[2], 0.f, fmaf(s2c[1], uy, fmaf(s2c[0], ux, s2c[3])));
+    float r1 = fmaf(s2c[6], 0.f, fmaf(s2c[5], uy, fmaf(s2c[4], ux, s2c[7])));
+    float r2 = fmaf(s2c[10], 0.f, fmaf(s2c[9], uy, fmaf(s2c[8], ux, s2c[11])));
+    float r3 = fmaf(s2c[14], 0.f, fmaf(s2c[13], uy, fmaf(s2c[12], ux, s2c[15])));
+    float iw = f_rcp(r3);
+    v3 near_p = V(r0 * iw, r1 * iw, r2 * iw);
+    v3 d = v_normalize(near_p);
+    orc_ray ray;
+    ray.o = V(s->to_world[3], s->to_world[7], s->to_world[11]);
+    ray.d = m_vector(s->to_world, d);
+    float inv_z = f_rcp(d.z);
+    float near_t = s->near_clip * inv_z, far_t = s->far_clip * inv_z;
+    ray.o = v_add(ray.o, v_mul(ray.d, near_t));
+    ray.maxt = far_t - near_t;
+    return ray;
+}
+void orc_camera_ray(const orc_sensor *s, float px, float py, float *out) {
+    float s2c[16]; camera_sample_to_camera(s, s2c);
+    float sx = 1.f / (float) s->crop_w, sy = 1.f / (float) s->crop_h;
+    float ux = fmaf(px, sx, -(float) s->crop_x * sx), uy = fmaf(py, sy, -(float) s->crop_y * sy);
+    orc_ray r = camera_ray(s, s2c, ux, uy);
+    out[0] = r.o.x; out[1] = r.o.y; out[2] = r.o.z; out[3] = r.d.x; out[4] = r.d.y; out[5] = r.d.z;
+    out[6] = r.maxt;
+}
+
+/* ------------------------------------------------------------------ geometry */
+typedef struct { float t, u, v; int32_t obj, shape, prim; } orc_hit;
+
+/* AnimatedTransform::eval -- include/mitsuba/core/transform.h:439-466: component-wise
+ * lerp of the two keyframe matrices, t clamped to [0,1]. */
+static void instance_to_world(const orc_object *o, float time, float *m) {
+    if (o->n_keys <= 1) { memcpy(m, o->key[0], 64); return; }
+    float t0 = o->key_time[0], t1 = o->key_time[1];
+    float t = f_min(f_max((time - t0) / (t1 - t0), 0.f), 1.f);
+    float omt = 1 - t;
+    for (int i = 0; i < 16; ++i) m[i] = o->key[0][i] * omt + o->key[1][i] * t;
+}
+
+/* Rectangle::ray_intersect_preliminary_impl -- src/shapes/rectangle.cpp:201-224 */
+static int rect_intersect(const orc_shape *sh, v3 o, v3 d, float maxt, float *t_out, float *u, float *v) {
+    v3 lo = m_point(sh->to_object, o), ld = m_vector(sh->to_object, d);
+    float t = -lo.z / ld.z;
+    float lx = fmaf(ld.x, t, lo.x), ly = fmaf(ld.y, t, lo.y);
+    if (t >= 0.f && t <= maxt && fabsf(lx) <= 1.f && fabsf(ly) <= 1.f) {
+        *t_out = t; *u = lx; *v = ly; return 1;
+    }
+    return 0;
+}
+/* Triangle test: Embree 3's Moeller-Trumbore intersector (source absent; published
+ * algorithm, kernels/geometry/triangle_intersector_moeller.h): tnear < t <= tfar,
+ * u/v are the barycentrics of vertices 1 and 2. */
+static int tri_intersect(v3 p0, v3 p1, v3 p2, v3 o, v3 d, float maxt, float *t_out, float *u, float *v) {
+    v3 e1 = v_sub(p0, p1), e2 = v_sub(p2, p0), ng = v_cross(e2, e1);
+    v3 c = v_sub(p0, o), r = v_cross(c, d);
+    float den = v_dot(ng, d), aden = fabsf(den);
+    uint32_t sgn = f2u(den) & 0x80000000u;
+    float U = u2f(f2u(v_dot(r, e2)) ^ sgn), Vv = u2f(f2u(v_dot(r, e1)) ^ sgn);
+    if (!(den != 0.f && U >= 0.f && Vv >= 0.f && U + Vv <= aden)) return 0;
+    float T = u2f(f2u(v_dot(ng, c)) ^ sgn);
+    if (!(0.f < T && T <= aden * maxt)) return 0;
+    float rc = 1.0f / aden;
+    *u = U * rc; *v = Vv * rc; *t_out = T * rc;
+    return 1;
+}
+static inline v3 mesh_pos(const orc_shape *sh, uint32_t i) { return V(sh->positions[3 * i], sh->positions[3 * i + 1], sh->positions[3 * i + 2]); }
+
+/* closest hit in one shape; candidate accepted if strictly closer, or equal t with a
+ * lower (object, shape, prim) id (deterministic tie rule shared with the GPU path) */
+static void shape_closest(const orc_shape *sh, v3 o, v3 d, int32_t obj, int32_t shape_idx, orc_hit *best) {
+    float t, u, v;
+    if (sh->kind == ORC_SHAPE_RECT) {
+        if (rect_intersect(sh, o, d, best->t, &t, &u, &v) && t < best->t) {
+            best->t = t; best->u = u; best->v = v; best->obj = obj; best->shape = shape_idx; best->prim = 0;
+        }
+    } else {
+        for (int32_t f = 0; f < sh->n_faces; ++f) {
+            const uint32_t *fi = sh->faces + 3 * f;
+            if (tri_intersect(mesh_pos(sh, fi[0]), mesh_pos(sh, fi[1]), mesh_pos(sh, fi[2]), o, d, best->t, &t, &u, &v)
+                && t < best->t) {
+                best->t = t; best->u = u; best->v = v; best->obj = obj; best->shape = shape_idx; best->prim = f;
+            }
+        }
+    }
+}
+static int shape_any(const orc_shape *sh, v3 o, v3 d, float maxt) {
+    float t, u, v;
+    if (sh->kind == ORC_SHAPE_RECT) return rect_intersect(sh, o, d, maxt, &t, &u, &v);
+    for (int32_t f = 0; f < sh->n_faces; ++f) {
+        const uint32_t *fi = sh->faces + 3 * f;
+        if (tri_intersect(mesh_pos(sh, fi[0]), mesh_pos(sh, fi[1]), mesh_pos(sh, fi[2]), o, d, maxt, &t, &u, &v)) return 1;
+    }
+    return 0;
+}
+
+/* Scene::ray_intersect_preliminary (src/render/scene_embree.inl:202-333): closest hit over
+ * all top-level objects; instances intersect their group in object space with the ray
+ * transformed by inverse(lerp(M0,M1,time)) (src/shapes/instance.cpp:295-311 + Embree). */
+static orc_hit scene_closest(const orc_scene *sc, v3 o, v3 d, float time, float maxt) {
+    orc_hit best; best.t = maxt; best.u = best.v = 0.f; best.obj = best.shape = best.prim = -1;
+    for (int32_t i = 0; i < sc->n_objects; ++i) {
+        const orc_object *ob = &sc->objects[i];
+        if (ob->kind == ORC_OBJ_SHAPE) {
+            shape_closest(&sc->shapes[ob->index], o, d, i, 0, &best);
+        } else {
+            float m[16], inv[16];
+            instance_to_world(ob, time, m);
+            m_affine_inverse(m, inv);
+            v3 lo = m_point(inv, o), ld = m_vector(inv, d);
+            const orc_group *g = &sc->groups[ob->index];
+            for (int32_t k = 0; k < g->n_shapes; ++k)
+                shape_closest(&sc->shapes[g->first_shape + k], lo, ld, i, k, &best);
+        }
+    }
+    if (best.obj < 0) best.t = INFINITY;   /* hit = (t != maxt), scene_embree.inl:313-315 */
+    return best;
+}
+static int scene_occluded(const orc_scene *sc, v3 o, v3 d, float time, float maxt) {
+    for (int32_t i = 0; i < sc->n_objects; ++i) {
+        const orc_object *ob = &sc->objects[i];
+        if (ob->kind == ORC_OBJ_SHAPE) {
+            if (shape_any(&sc->shapes[ob->index], o, d, maxt)) return 1;
+        } else {
+            float m[16], inv[16];
+            instance_to_world(ob, time, m);
+            m_affine_inverse(m, inv);
+            v3 lo = m_point(inv, o), ld = m_vector(inv, d);
+            const orc_group *g = &sc->groups[ob->index];
+            for (int32_t k = 0; k < g->n_shapes; ++k)
+                if (shape_any(&sc->shapes[g->first_shape + k], lo, ld, maxt)) return 1;
+        }
+    }
+    return 0;
+}
+int orc_intersect(const orc_scene *sc, const float *o, const float *d, float time, float maxt, float *hit, int32_t *ids) {
+    orc_hit h = scene_closest(sc, V(o[0], o[1], o[2]), V(d[0], d[1], d[2]), time, maxt);
+    hit[0] = h.t; hit[1] = h.u; hit[2] = h.v; ids[0] = h.obj; ids[1] = h.shape; ids[2] = h.prim;
+    return h.obj >= 0;
+}
+int orc_occluded(const orc_scene *sc, const float *o, const float *d, float time, float maxt) {
+    return scene_occluded(sc, V(o[0], o[1], o[2]), V(d[0], d[1], d[2]), time, maxt);
+}
+
+/* coordinate_system -- include/mitsuba/core/vector.h:116-136 (Duff et al.) */
+static void coordinate_system(v3 n, v3 *s, v3 *t) {
+    float sign = f_sign(n.z), a = -f_rcp(sign + n.z), b = n.x * n.y * a;
+    *s = V(f_mulsign(f_sqr(n.x) * a, n.z) + 1.f, f_mulsign(b, n.z), f_mulsign_neg(n.x, n.z));
+    *t = V(b, fmaf(n.y, n.y * a, sign), -n.y);
+}
+
+typedef struct {
+    v3 p, n, sh_n, sh_s, sh_t, dp_du, dp_dv, wi;
+    const orc_shape *shape;
+} orc_si;
+
+/* Rectangle::compute_surface_interaction -- src/shapes/rectangle.cpp:250-323 (non-diff
+ * branch :289-294) with the frame of Rectangle::update :101-113 */
+static void rect_si(const orc_shape *sh, v3 o, v3 d, float t, orc_si *si) {
+    v3 dp_du = m_vector(sh->to_world, V(2.f, 0.f, 0.f));
+    v3 dp_dv = m_vector(sh->to_world, V(0.f, 2.f, 0.f));
+    v3 n = v_normalize(m_normal(sh->to_object, V(0.f, 0.f, 1.f)));
+    v3 p = v_fma(d, t, o);
+    v3 tr = V(sh->to_world[3], sh->to_world[7], sh->to_world[11]);
+    float dist = v_dot(v_sub(tr, p), n);
+    si->p = v_add(p, v_mul(n, dist));
+    si->n = n; si->sh_n = n; si->dp_du = dp_du; si->dp_dv = dp_dv;
+}
+/* Mesh::compute_surface_interaction -- src/render/mesh.cpp:632-864 (primal branch) */
+static void mesh_si(const orc_shape *sh, int32_t prim, float b1, float b2, orc_si *si) {
+    const uint32_t *fi = sh->faces + 3 * prim;
+    v3 p0 = mesh_pos(sh, fi[0]), p1 = mesh_pos(sh, fi[1]), p2 = mesh_pos(sh, fi[2]);
+    float b0 = 1.f - b1 - b2;
+    v3 dp0 = v_sub(p1, p0), dp1 = v_sub(p2, p0);
+    si->p = v_fma(p0, b0, v_fma(p1, b1, v_mul(p2, b2)));
+    si->n = v_normalize(v_cross(dp0, dp1));
+    coordinate_system(si->n, &si->dp_du, &si->dp_dv);
+    if (sh->texcoords) {
+        const float *uv = sh->texcoords;
+        float u0x = uv[2 * fi[0]], u0y = uv[2 * fi[0] + 1], u1x = uv[2 * fi[1]], u1y = uv[2 * fi[1] + 1],
+              u2x = uv[2 * fi[2]], u2y = uv[2 * fi[2] + 1];
+        float d0x = u1x - u0x, d0y = u1y - u0y, d1x = u2x - u0x, d1y = u2y - u0y;
+        float det = fmaf(d0x, d1y, -(d0y * d1x)), inv_det = f_rcp(det);
+        if (det != 0.f) {
+            /* dp_du = fmsub(duv1.y, dp0, duv0.y*dp1) * inv_det ; dp_dv = fnmadd(duv1.x, dp0, duv0.x*dp1) * inv_det */
+            si->dp_du = v_mul(V(fmaf(d1y, dp0.x, -(d0y * dp1.x)), fmaf(d1y, dp0.y, -(d0y * dp1.y)), fmaf(d1y, dp0.z, -(d0y * dp1.z))), inv_det);
+            si->dp_dv = v_mul(V(fmaf(-d1x, dp0.x, d0x * dp1.x), fmaf(-d1x, dp0.y, d0x * dp1.y), fmaf(-d1x, dp0.z, d0x * dp1.z)), inv_det);
+        }
+    }
+    if (sh->normals && !sh->face_normals) {
+        const float *nn = sh->normals;
+        v3 n0 = V(nn[3 * fi[0]], nn[3 * fi[0] + 1], nn[3 * fi[0] + 2]);
+        v3 n1 = V(nn[3 * fi[1]], nn[3 * fi[1] + 1], nn[3 * fi[1] + 2]);
+        v3 n2 = V(nn[3 * fi[2]], nn[3 * fi[2] + 1], nn[3 * fi[2] + 2]);
+        v3 n = v_fma(n2, b2, v_fma(n1, b1, v_mul(n0, b0)));
+        si->sh_n = v_mul(n, f_rsqrt(v_dot(n, n)));
+    } else {
+        si->sh_n = si->n;
+    }
+    if (sh->flip_normals) { si->n = v_neg(si->n); si->sh_n = v_neg(si->sh_n); }
+}
+/* PreliminaryIntersection::compute_surface_interaction (include/mitsuba/render/interaction.h:675-701)
+ * -> Instance::compute_surface_interaction (src/shapes/instance.cpp:155-250) / shape CSI
+ * -> finalize_surface_interaction (interaction.h:493-513) + initialize_sh_frame (:258-268) */
+static void compute_si(const orc_scene *sc, const orc_hit *h, v3 o, v3 d, float time, orc_si *si) {
+    const orc_object *ob = &sc->objects[h->obj];
+    if (ob->kind == ORC_OBJ_SHAPE) {
+        const orc_shape *sh = &sc->shapes[ob->index];
+        si->shape = sh;
+        if (sh->kind == ORC_SHAPE_RECT) rect_si(sh, o, d, h->t, si); else mesh_si(sh, h->prim, h->u, h->v, si);
+    } else {
+        float m[16], inv[16];
+        instance_to_world(ob, time, m);
+        m_affine_inverse(m, inv);
+        const orc_shape *sh = &sc->shapes[sc->groups[ob->index].first_shape + h->shape];
+        si->shape = sh;
+        v3 lo = m_point(inv, o), ld = m_vector(inv, d);
+        if (sh->kind == ORC_SHAPE_RECT) rect_si(sh, lo, ld, h->t, si); else mesh_si(sh, h->prim, h->u, h->v, si);
+        si->p = m_point(m, si->p);
+        si->n = v_normalize(m_normal(inv, si->n));
+        si->sh_n = v_normalize(m_normal(inv, si->sh_n));
+        si->dp_du = m_vector(m, si->dp_du);
+        si->dp_dv = m_vector(m, si->dp_dv);
+    }
+    /* initialize_sh_frame */
+    v3 s = v_normalize(v_fma(si->sh_n, -v_dot(si->sh_n, si->dp_du), si->dp_du));
+    if (si->dp_du.x == 0.f && si->dp_du.y == 0.f && si->dp_du.z == 0.f) { v3 tt; coordinate_system(si->sh_n, &s, &tt); }
+    si->sh_s = s;
+    si->sh_t = v_cross(si->sh_n, s);
+    v3 md = v_neg(d);
+    si->wi = V(v_dot(md, si->sh_s), v_dot(md, si->sh_t), v_dot(md, si->sh_n));
+}
+static inline v3 si_to_local(const orc_si *si, v3 v) { return V(v_dot(v, si->sh_s), v_dot(v, si->sh_t), v_dot(v, si->sh_n)); }
+/* Frame::to_world -- include/mitsuba/core/frame.h:44-46 */
+static inline v3 si_to_world(const orc_si *si, v3 v) { return v_fma(si->sh_n, v.z, v_fma(si->sh_t, v.y, v_mul(si->sh_s, v.x))); }
+/* Interaction::offset_p -- interaction.h:161-165 */
+static inline v3 offset_p(const orc_si *si, v3 d) {
+    float mag = (1.f + f_max(f_max(fabsf(si->p.x), fabsf(si->p.y)), fabsf(si->p.z))) * ORC_RAY_EPS;
+    mag = f_mulsign(mag, v_dot(si->n, d));
+    return v_fma(si->n, mag, si->p);
+}
+
+/* warp::square_to_uniform_disk_concentric / square_to_cosine_hemisphere -- warp.h:54-86,320-344 */
+static v3 square_to_cosine_hemisphere(float sx, float sy) {
+    float x = fmaf(2.f, sx, -1.f), y = fmaf(2.f, sy, -1.f);
+    int is_zero = (x == 0.f && y == 0.f), q13 = fabsf(x) < fabsf(y);
+    float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = 0.25f * ORC_PI_F * rp / r;
+    if (q13) phi = 0.5f * ORC_PI_F - phi;
+    if (is_zero) phi = 0.f;
+    float s, c; orc_sincos(phi, &s, &c);
+    float px = r * c, py = r * s;
+    float z = sqrtf(f_max(1.f - fmaf(py, py, px * px), 0.f));
+    return V(px, py, z);
+}
+
+/* ------------------------------------------------------------------ integrator */
+/* mis_weight -- dopplertofpath.cpp:296-301 */
+static inline float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
+
+typedef struct { const orc_scene *sc; const orc_params *p; uint32_t seed, spp; float s2c[16]; } orc_ctx;
+
+/* One lane: SamplingIntegrator::render (lane->pixel, src/render/integrator.cpp:273-290),
+ * render_sample Doppler branch (:476-542), DopplerToFPathIntegrator::sample
+ * (src/integrators/dopplertofpath.cpp:79-283). */
+static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
+    const orc_scene *sc = cx->sc; const orc_params *p = cx->p; const orc_sensor *se = &sc->sensor;
+    uint32_t lane = (uint32_t) lane64, spp = cx->spp;
+    orc_sampler smp; sampler_seed(&smp, p, cx->seed, spp, lane);
+
+    uint32_t pix = lane / spp, W = (uint32_t) se->crop_w;
+    uint32_t py = pix / W, px = pix - W * py;
+    float posx = (float) (px + (uint32_t) se->crop_x), posy = (float) (py + (uint32_t) se->crop_y);
+
+    int correlate_pixel = p->path_correlation_depth > 0;
+    float jx = sampler_next_1d_correlate(&smp, correlate_pixel);
+    float jy = sampler_next_1d_correlate(&smp, correlate_pixel);
+    float spx = posx + jx, spy = posy + jy;
+    float scx = 1.f / (float) se->crop_w, scy = 1.f / (float) se->crop_h;
+    float ax = fmaf(spx, scx, -(float) se->crop_x * scx), ay = fmaf(spy, scy, -(float) se->crop_y * scy);
+
+    float time = se->shutter_open;
+    float shutter_open_time = se->shutter_close - se->shutter_open;
+    if (shutter_open_time > 0.f)
+        time += sampler_next_1d_time(&smp, p, spp) * shutter_open_time;
+
+    orc_ray ray = camera_ray(se, cx->s2c, ax, ay);
+    /* dopplertofpath.cpp:93 */
+    time = time < p->time ? time : time - p->time;
+
+    out->sample_pos[0] = spx; out->sample_pos[1] = spy; out->time = time;
+    out->ray_o[0] = ray.o.x; out->ray_o[1] = ray.o.y; out->ray_o[2] = ray.o.z;
+    out->ray_d[0] = ray.d.x; out->ray_d[1] = ray.d.y; out->ray_d[2] = ray.d.z;
+
+    v3 thr = V(1.f, 1.f, 1.f), res = V(0.f, 0.f, 0.f);
+    float path_length = 0.f, eta = 1.f;
+    uint32_t depth = 0; int valid_ray = 0, active = p->max_depth != 0;
+    v3 o = ray.o, d = ray.d; float maxt = ray.maxt;
+
+    while (active) {
+        int correlate = (depth + 1) < p->path_correlation_depth;
+        orc_hit h = scene_closest(sc, o, d, time, maxt);
+        int hit = h.obj >= 0;
+        if (hit) path_length += h.t * eta;
+        /* emitter hit (:150-168): only surface/environment emitters contribute; the
+         * supported emitter set is {point} whose eval() is 0 (src/emitters/point.cpp:186-188). */
+        int active_next = (depth + 1 < p->max_depth) && hit;
+
+        orc_si si; memset(&si, 0, sizeof si);
+        v3 em_weight = V(0, 0, 0), wo = V(0, 0, 0); float ds_pdf = 0.f, ds_dist = 0.f; int ds_delta = 0;
+        if (hit) compute_si(sc, &h, o, d, time, &si);
+        int active_em = active_next;   /* diffuse => BSDFFlags::Smooth */
+
+        /* emitter sampling: Scene::sample_emitter_direction src/render/scene.cpp:235-291 */
+        float e1 = sampler_next_1d_correlate(&smp, correlate);
+        float e2 = sampler_next_1d_correlate(&smp, correlate);
+        (void) e2;
+        if (active_em && sc->n_emitters > 0) {
+            uint32_t ne = (uint32_t) sc->n_emitters, idx = 0; float em_w = 1.f, pmf = 1.f;
+            if (ne > 1) {   /* sample_emitter :171-189 */
+                float scaled = e1 * (float) ne;
+                idx = (uint32_t) scaled; if (idx > ne - 1) idx = ne - 1;
+                em_w = (float) ne; pmf = 1.f / (float) ne;
+            }
+            const orc_emitter *em = &sc->emitters[idx];
+            /* PointLight::sample_direction src/emitters/point.cpp:118-147 */
+            v3 dsp = V(em->position[0], em->position[1], em->position[2]);
+            v3 dd = v_sub(dsp, si.p);
+            float dist2 = v_dot(dd, dd), inv_dist = f_rsqrt(dist2);
+            ds_dist = sqrtf(dist2);
+            dd = v_mul(dd, inv_dist);
+            float id2 = f_sqr(inv_dist);
+            em_weight = V(em->intensity[0] * id2, em->intensity[1] * id2, em->intensity[2] * id2);
+            ds_pdf = 1.f; ds_delta = 1;
+            ds_pdf *= pmf; em_weight = v_mul(em_weight, em_w);
+            if (ds_pdf != 0.f) {
+                /* Interaction::spawn_ray_to interaction.h:141-149 + ray_test */
+                v3 so = offset_p(&si, v_sub(dsp, si.p));
+                v3 sd = v_sub(dsp, so);
+                float sdist = v_norm(sd);
+                sd = v_mul(sd, f_rcp(sdist));
+                if (scene_occluded(sc, so, sd, time, sdist * (1.f - ORC_SHADOW_EPS))) { em_weight = V(0, 0, 0); ds_pdf = 0.f; }
+            }
+            active_em = active_em && ds_pdf != 0.f;
+            wo = si_to_local(&si, dd);
+        } else {
+            active_em = 0;
+        }
+
+        float sample_1 = sampler_next_1d_correlate(&smp, correlate); (void) sample_1;
+        float s2x = sampler_next_1d_correlate(&smp, correlate);
+        float s2y = sampler_next_1d_correlate(&smp, correlate);
+
+        /* BSDF::eval_pdf_sample src/render/bsdf.cpp:20-29 over twosided{diffuse} / diffuse
+         * (src/bsdfs/twosided.cpp:111-148,219-258; src/bsdfs/diffuse.cpp:101-125,160-180) */
+        v3 bsdf_val = V(0, 0, 0), bsdf_weight = V(0, 0, 0), bs_wo = V(0, 0, 0);
+        float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f;
+        if (hit) {
+            const orc_shape *sh = si.shape;
+            float wiz = si.wi.z, woz = wo.z;
+            if (sh->twosided) { woz = f_mulsign(woz, wiz); wiz = fabsf(wiz); }
+            if (wiz > 0.f && woz > 0.f) {
+                bsdf_val = V(sh->reflectance[0] * ORC_INV_PI_F * woz, sh->reflectance[1] * ORC_INV_PI_F * woz,
+                             sh->reflectance[2] * ORC_INV_PI_F * woz);
+                bsdf_pdf = ORC_INV_PI_F * woz;
+            }
+            if (wiz > 0.f) {
+                bs_wo = square_to_cosine_hemisphere(s2x, s2y);
+                bs_pdf = ORC_INV_PI_F * bs_wo.z;
+                bs_eta = 1.f;
+                if (bs_pdf > 0.f) bsdf_weight = V(sh->reflectance[0], sh->reflectance[1], sh->reflectance[2]);
+                if (sh->twosided) bs_wo.z = f_mulsign(bs_wo.z, si.wi.z);
+            }
+        }
+        if (active_em) {   /* :214-226 */
+            float mis_em = ds_delta ? 1.f : mis_weight(ds_pdf, bsdf_pdf);
+            float lw = orc_modulation_weight(p, time, path_length + ds_dist);
+            res = V(fmaf(thr.x, bsdf_val.x * em_weight.x * mis_em * lw, res.x),
+                    fmaf(thr.y, bsdf_val.y * em_weight.y * mis_em * lw, res.y),
+                    fmaf(thr.z, bsdf_val.z * em_weight.z * mis_em * lw, res.z));
+        }
+        /* :232-262 */
+        if (hit) {
+            v3 nd = si_to_world(&si, bs_wo);
+            o = offset_p(&si, nd); d = nd; maxt = ORC_LARGEST;
+        }
+        thr = V(thr.x * bsdf_weight.x, thr.y * bsdf_weight.y, thr.z * bsdf_weight.z);
+        eta *= bs_eta;
+        valid_ray |= hit;
+        if (hit) depth += 1;
+        /* :264-276 */
+        float thr_max = f_max(f_max(thr.x, thr.y), thr.z);
+        float rr_prob = f_min(thr_max * f_sqr(eta), .95f);
+        int rr_active = depth >= p->rr_depth;
+        int rr_continue = sampler_next_1d_correlate(&smp, correlate) < rr_prob;
+        if (rr_active) { float ir = f_rcp(rr_prob); thr = v_mul(thr, ir); }
+        active = active_next && (!rr_active || rr_continue) && thr_max != 0.f;
+    }
+    out->rgb[0] = valid_ray ? res.x : 0.f; out->rgb[1] = valid_ray ? res.y : 0.f; out->rgb[2] = valid_ray ? res.z : 0.f;
+    out->path_length = path_length; out->depth = depth; out->valid = (uint32_t) valid_ray;
+}
+
+void orc_sampler_lane(const orc_params *p, uint32_t seed, uint32_t spp, uint32_t lane, uint32_t *ou, float *of) {
+    orc_sampler s; sampler_seed(&s, p, seed, spp, lane);
+    ou[0] = (uint32_t) s.s_main; ou[1] = (uint32_t) (s.s_main >> 32);
+    ou[2] = (uint32_t) s.s_time; ou[3] = (uint32_t) (s.s_time >> 32);
+    ou[4] = (uint32_t) s.s_path; ou[5] = (uint32_t) (s.s_path >> 32);
+    ou[6] = s.perm_seed;
+    int cp = p->path_correlation_depth > 0;
+    of[0] = sampler_next_1d_correlate(&s, cp);
+    of[1] = sampler_next_1d_correlate(&s, cp);
+    of[2] = sampler_next_1d_time(&s, p, spp);
+}
+
+/* ------------------------------------------------------------------ threading */
+typedef struct { const orc_ctx *cx; uint64_t begin, n; orc_lane *out; int tid, nt; } orc_job;
+static void *lane_worker(void *arg) {
+    orc_job *j = (orc_job *) arg;
+    /* interleaved blocks of 256 lanes for load balance */
+    uint64_t nblk = (j->n + 255) / 256;
+    for (uint64_t b = (uint64_t) j->tid; b < nblk; b += (uint64_t) j->nt) {
+        uint64_t s = b * 256, e = s + 256 < j->n ? s + 256 : j->n;
+        for (uint64_t i = s; i < e; ++i) eval_lane(j->cx, j->begin + i, &j->out[i]);
+    }
+    return NULL;
+}
+static void run_lanes(const orc_ctx *cx, uint64_t begin, uint64_t n, orc_lane *out, int nt) {
+    if (nt < 1) nt = 1;
+    if (nt > 256) nt = 256;
+    pthread_t th[256]; orc_job jobs[256];
+    for (int t = 0; t < nt; ++t) {
+        jobs[t].cx = cx; jobs[t].begin = begin; jobs[t].n = n; jobs[t].out = out; jobs[t].tid = t; jobs[t].nt = nt;
+        if (nt == 1) lane_worker(&jobs[t]); else pthread_create(&th[t], NULL, lane_worker, &jobs[t]);
+    }
+    if (nt > 1) for (int t = 0; t < nt; ++t) pthread_join(th[t], NULL);
+}
+static void make_ctx(orc_ctx *cx, const orc_scene *sc, const orc_params *p, uint32_t seed, uint32_t spp) {
+    cx->sc = sc; cx->p = p; cx->seed = seed; cx->spp = spp;
+    camera_sample_to_camera(&sc->sensor, cx->s2c);
+}
+void orc_render_lanes(const orc_scene *sc, const orc_params *p, uint32_t seed, uint32_t spp,
+                      uint64_t lane_begin, uint64_t n, orc_lane *out, int n_threads) {
+    orc_ctx cx; make_ctx(&cx, sc, p, seed, spp);
+    run_lanes(&cx, lane_begin, n, out, n_threads);
+}
+
+/* ImageBlock::put, coalesced path -- src/render/imageblock.cpp:414-531 (2.1/2.2), with the
+ * box-filter special case :201-224; TentFilter::eval src/rfilters/tent.cpp:53-55.
+ * aovs = [R,G,B,1] (integrator.cpp:528-541).  Accumulation is sequential in lane order
+ * (the reference's atomic scatter order is unspecified). */
+static void splat(const orc_sensor *se, float *film, float spx, float spy, const float *rgb) {
+    int W = se->crop_w, H = se->crop_h;
+    float vals[4] = { rgb[0], rgb[1], rgb[2], 1.f };
+    if (se->filter == ORC_FILTER_BOX) {
+        int x = (int) floorf(spx) - se->crop_x, y = (int) floorf(spy) - se->crop_y;
+        if ((unsigned) x < (unsigned) W && (unsigned) y < (unsigned) H)
+            for (int k = 0; k < 4; ++k) film[4 * ((size_t) y * W + x) + k] += vals[k];
+        return;
+    }
+    float radius = se->filter_radius, inv_r = 1.f / radius;
+    int n = (int) ceilf(radius - .5f), count = 2 * n + 1;
+    int pix = (int) floorf(spx) - n, piy = (int) floorf(spy) - n;
+    float relx = (float) pix + .5f - spx, rely = (float) piy + .5f - spy;
+    int lx = pix - se->crop_x, ly = piy - se->crop_y;
+    for (int ys = 0; ys < count; ++ys) {
+        float wy = f_max(0.f, 1.f - fabsf((rely + (float) ys) * inv_r));
+        for (int xs = 0; xs < count; ++xs) {
+            float wx = f_max(0.f, 1.f - fabsf((relx + (float) xs) * inv_r));
+            float w = wx * wy;
+            int x = lx + xs, y = ly + ys;
+            if ((unsigned) x < (unsigned) W && (unsigned) y < (unsigned) H)
+                for (int k = 0; k < 4; ++k) film[4 * ((size_t) y * W + x) + k] += vals[k] * w;
+        }
+    }
+}
+/* HDRFilm::develop -- src/films/hdrfilm.cpp:305-406: RGB / W unless W == 0 */
+void orc_develop(const float *film, float *out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        float w = film[4 * i + 3]; w = w == 0.f ? 1.f : w;
+        out[3 * i] = film[4 * i] / w; out[3 * i + 1] = film[4 * i + 1] / w; out[3 * i + 2] = film[4 * i + 2] / w;
+    }
+}
+uint64_t orc_render(const orc_scene *sc, const orc_params *p, uint32_t seed, uint32_t spp,
+                    int32_t row_begin, int32_t row_end, float *film, float *out_rgb, int nt) {
+    orc_ctx cx; make_ctx(&cx, sc, p, seed, spp);
+    int W = sc->sensor.crop_w, H = sc->sensor.crop_h;
+    if (row_begin < 0) row_begin = 0;
+    if (row_end > H) row_end = H;
+    uint64_t lanes_per_row = (uint64_t) W * spp, total = 0;
+    int chunk_rows = (int) (4000000ull / lanes_per_row); if (chunk_rows < 1) chunk_rows = 1;
+    orc_lane *buf = (orc_lane *) malloc(sizeof(orc_lane) * lanes_per_row * (size_t) chunk_rows);
+    for (int r = row_begin; r < row_end; r += chunk_rows) {
+        int re = r + chunk_rows < row_end ? r + chunk_rows : row_end;
+        uint64_t n = lanes_per_row * (uint64_t) (re - r);
+        run_lanes(&cx, lanes_per_row * (uint64_t) r, n, buf, nt);
+        for (uint64_t i = 0; i < n; ++i) splat(&sc->sensor, film, buf[i].sample_pos[0], buf[i].sample_pos[1], buf[i].rgb);
+        total += n;
+    }
+    free(buf);
+    if (out_rgb) orc_develop(film, out_rgb, (int64_t) W * H);
+    return total;
+}
+
+/* Cube vertex baking -- src/shapes/cube.cpp:114-160 (scalar float32: positions through
+ * to_world, normals through its inverse transpose then normalised with 1/sqrt). */
+void orc_bake_cube(const float *to_world, const float *to_object, float *pos, float *nrm, float *uv, uint32_t *faces) {
+    static const float vtx[24][3] = {
+        { 1,-1,-1},{ 1,-1, 1},{-1,-1, 1},{-1,-1,-1},{ 1, 1,-1},{-1, 1,-1},{-1, 1, 1},{ 1, 1, 1},
+        { 1,-1,-1},{ 1, 1,-1},{ 1, 1, 1},{ 1,-1, 1},{ 1,-1, 1},{ 1, 1, 1},{-1, 1, 1},{-1,-1, 1},
+        {-1,-1, 1},{-1, 1, 1},{-1, 1,-1},{-1,-1,-1},{ 1, 1,-1},{ 1,-1,-1},{-1,-1,-1},{-1, 1,-1} };
+    static const float nr[6][3] = { {0,-1,0},{0,1,0},{1,0,0},{0,0,1},{-1,0,0},{0,0,-1} };
+    static const float tc[4][2] = { {0,1},{1,1},{1,0},{0,0} };
+    static const uint32_t tri[12][3] = { {0,1,2},{3,0,2},{4,5,6},{7,4,6},{8,9,10},{11,8,10},
+        {12,13,14},{15,12,14},{16,17,18},{19,16,18},{20,21,22},{23,20,22} };
+    for (int i = 0; i < 24; ++i) {
+        v3 p = m_point(to_world, V(vtx[i][0], vtx[i][1], vtx[i][2]));
+        v3 n = m_normal(to_object, V(nr[i / 4][0], nr[i / 4][1], nr[i / 4][2]));
+        n = v_mul(n, 1.0f / sqrtf(v_dot(n, n)));
+        pos[3 * i] = p.x; pos[3 * i + 1] = p.y; pos[3 * i + 2] = p.z;
+        nrm[3 * i] = n.x; nrm[3 * i + 1] = n.y; nrm[3 * i + 2] = n.z;
+        uv[2 * i] = tc[i % 4][0]; uv[2 * i + 1] = tc[i % 4][1];
+    }
+    memcpy(faces, tri, sizeof tri);
+}

@@ -1,0 +1,168 @@
+/*
+ * dtof_oracle.h -- flat scene/parameter records consumed by the CPU oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product; only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * The oracle is a scalar restatement of the reference's `dopplertofpath`
+ * integrator + `correlated` sampler (juhyeonkim95/Mitsuba3DopplerToF @ 2024_08_07).
+ * Every function in dtof_oracle.c cites the reference file:line it follows.
+ *
+ * PARITY STATUS: the reference ships no test, golden vector or fixture for this
+ * path and cannot be built or imported here (Dr.Jit/Embree/pugixml submodules are
+ * empty).  The oracle is therefore pinned only by the known-answer vectors that
+ * do exist for its building blocks (TEA: src/core/tests/test_random.py:8-16,
+ * PCG32: O'Neill's published demo vector, Kensler bijection property, closed-form
+ * waveform values) -- for the path as a whole: "parity unpinned".
+ */
+#ifndef DTOF_ORACLE_H
+#define DTOF_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_SHAPE_RECT = 0, ORC_SHAPE_MESH = 1 };
+enum { ORC_OBJ_SHAPE = 0, ORC_OBJ_INSTANCE = 1 };
+enum { ORC_EMITTER_POINT = 0 };
+enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 };
+enum { ORC_TIME_UNIFORM = 0, ORC_TIME_STRATIFIED = 1, ORC_TIME_ANTITHETIC = 2,
+       ORC_TIME_ANTITHETIC_MIRROR = 3 };
+enum { ORC_FILTER_BOX = 0, ORC_FILTER_TENT = 1 };
+
+/* All 4x4 matrices are row-major float32: m[4*r + c]. */
+
+typedef struct {
+    int32_t kind;            /* ORC_SHAPE_* */
+    int32_t twosided;        /* BSDF is twosided{diffuse} (1) or plain diffuse (0) */
+    int32_t flip_normals;
+    int32_t face_normals;    /* mesh: ignore vertex normals */
+    float   reflectance[3];
+    float   to_world[16];    /* rectangle: shape's own to_world (identity for instanced children) */
+    float   to_object[16];   /* rectangle: float cast of the double-precision inverse */
+    /* mesh data (already in the shape's world space, cube.cpp:150-160) */
+    int32_t n_vertices, n_faces;
+    const float    *positions;  /* n_vertices*3 */
+    const float    *normals;    /* n_vertices*3 or NULL */
+    const float    *texcoords;  /* n_vertices*2 or NULL */
+    const uint32_t *faces;      /* n_faces*3 */
+} orc_shape;
+
+typedef struct {
+    int32_t first_shape, n_shapes;   /* children = shapes[first_shape .. +n_shapes) */
+} orc_group;
+
+typedef struct {
+    int32_t kind;            /* ORC_OBJ_* */
+    int32_t index;           /* shape index (SHAPE) or group index (INSTANCE) */
+    int32_t n_keys;          /* INSTANCE: 1 (static transform) or 2 (animated) */
+    float   key_time[2];
+    float   key[2][16];      /* keyframe matrices (float cast of the double compose) */
+} orc_object;
+
+typedef struct {
+    int32_t kind;            /* ORC_EMITTER_POINT */
+    float   position[3];
+    float   intensity[3];
+} orc_emitter;
+
+typedef struct {
+    float   to_world[16];
+    float   x_fov;           /* degrees, float cast of parse_fov() */
+    float   near_clip, far_clip;
+    float   shutter_open, shutter_close;
+    int32_t film_w, film_h;
+    int32_t crop_x, crop_y, crop_w, crop_h;
+    int32_t filter;          /* ORC_FILTER_* */
+    float   filter_radius;
+} orc_sensor;
+
+typedef struct {
+    /* dopplertofpath.cpp:19-57 (all already rounded the way the ctor rounds them) */
+    float   time;                 /* T */
+    float   w_g_mhz, g_1, g_0, w_s_mhz;
+    float   phase_offset;         /* m_sensor_modulation_phase_offset */
+    float   hetero_frequency;     /* m_hetero_frequency */
+    int32_t wave_type;
+    int32_t low_frequency_component_only;
+    /* integrator.cpp:54-100, 568-585 */
+    int32_t time_sampling;
+    float   antithetic_shift;
+    int32_t stratify_each_interval;
+    uint32_t path_correlation_depth;
+    uint32_t max_depth;           /* -1 -> 0xffffffff */
+    uint32_t rr_depth;
+    int32_t hide_emitters;
+    /* sampler (correlated.cpp:17-23, sampler.cpp:11-20) */
+    uint32_t base_seed;
+    int32_t time_correlate_number, path_correlate_number;
+} orc_params;
+
+typedef struct {
+    const orc_shape   *shapes;   int32_t n_shapes;
+    const orc_group   *groups;   int32_t n_groups;
+    const orc_object  *objects;  int32_t n_objects;
+    const orc_emitter *emitters; int32_t n_emitters;
+    orc_sensor sensor;
+} orc_scene;
+
+/* Per-lane debug record: everything a lane-for-lane parity test wants. */
+typedef struct {
+    float    sample_pos[2];
+    float    time;           /* after the wrap of dopplertofpath.cpp:93 */
+    float    ray_o[3], ray_d[3];
+    float    rgb[3];
+    float    path_length;    /* at loop exit */
+    uint32_t depth;          /* at loop exit */
+    uint32_t valid;
+} orc_lane;
+
+/* ---- known-answer building blocks (exported for the KAT tests) ---- */
+void     orc_tea32(uint32_t v0, uint32_t v1, int rounds, uint32_t *o0, uint32_t *o1);
+float    orc_tea_float32(uint32_t v0, uint32_t v1, int rounds);
+void     orc_pcg32_seed(uint64_t initstate, uint64_t initseq, uint64_t *state, uint64_t *inc);
+uint32_t orc_pcg32_next_u32(uint64_t *state, uint64_t inc);
+float    orc_pcg32_next_f32(uint64_t *state, uint64_t inc);
+uint32_t orc_permute_kensler(uint32_t index, uint32_t n, uint32_t seed);
+float    orc_waveform(float t, int wave_type);
+float    orc_waveform_low_pass(float t, int wave_type);
+float    orc_modulation_weight(const orc_params *p, float ray_time, float path_length);
+void     orc_sincos(float x, float *s, float *c);
+
+/* Sampler stream for one lane (KAT / lane parity): fills seeds and the first draws.
+ * out_u32[0..5] = (rng.state, rng_time.state, rng_path.state) as lo,hi pairs after seeding,
+ * out_u32[6] = permutation seed; out_f[0..1] = pixel jitter, out_f[2] = next_1d_time. */
+void     orc_sampler_lane(const orc_params *p, uint32_t seed, uint32_t spp, uint32_t lane,
+                          uint32_t *out_u32, float *out_f);
+
+/* Camera ray for a film position (perspective.cpp:238-279). out[0..2]=o, [3..5]=d, [6]=maxt */
+void     orc_camera_ray(const orc_sensor *s, float px, float py, float *out);
+
+/* Closest hit / occlusion against the flat scene (brute force).
+ * hit[0]=t (inf if none), hit[1]=u, hit[2]=v; ids[0]=object, ids[1]=shape_in_group, ids[2]=prim */
+int      orc_intersect(const orc_scene *sc, const float *o, const float *d, float time, float maxt,
+                       float *hit, int32_t *ids);
+int      orc_occluded(const orc_scene *sc, const float *o, const float *d, float time, float maxt);
+
+/* Evaluate lanes [lane_begin, lane_begin+n) of the wavefront of W*H*spp lanes. */
+void     orc_render_lanes(const orc_scene *sc, const orc_params *p, uint32_t seed, uint32_t spp,
+                          uint64_t lane_begin, uint64_t n, orc_lane *out, int n_threads);
+
+/* Full render of pixel rows [row_begin,row_end) (whole film: 0,H).
+ * film_rgbw: crop_h*crop_w*4 floats (accumulated, must be zeroed by the caller);
+ * out_rgb: crop_h*crop_w*3 developed image or NULL. Returns number of paths traced. */
+uint64_t orc_render(const orc_scene *sc, const orc_params *p, uint32_t seed, uint32_t spp,
+                    int32_t row_begin, int32_t row_end, float *film_rgbw, float *out_rgb,
+                    int n_threads);
+
+void     orc_develop(const float *film_rgbw, float *out_rgb, int64_t n_pixels);
+
+/* Cube mesh baking (cube.cpp:114-160): pos[72], nrm[72], uv[48], faces[36] */
+void     orc_bake_cube(const float *to_world, const float *to_object, float *pos, float *nrm,
+                       float *uv, uint32_t *faces);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

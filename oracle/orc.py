@@ -1,0 +1,214 @@
+"""ctypes glue around oracle/libdtof_oracle.so (TEST INFRASTRUCTURE ONLY -- see dtof_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import scene_xml
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+M16 = C.c_float * 16
+
+
+class OrcShape(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("twosided", C.c_int32), ("flip_normals", C.c_int32), ("face_normals", C.c_int32),
+                ("reflectance", C.c_float * 3), ("to_world", M16), ("to_object", M16),
+                ("n_vertices", C.c_int32), ("n_faces", C.c_int32),
+                ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
+                ("texcoords", C.POINTER(C.c_float)), ("faces", C.POINTER(C.c_uint32))]
+
+
+class OrcGroup(C.Structure):
+    _fields_ = [("first_shape", C.c_int32), ("n_shapes", C.c_int32)]
+
+
+class OrcObject(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("index", C.c_int32), ("n_keys", C.c_int32),
+                ("key_time", C.c_float * 2), ("key", (C.c_float * 16) * 2)]
+
+
+class OrcEmitter(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("position", C.c_float * 3), ("intensity", C.c_float * 3)]
+
+
+class OrcSensor(C.Structure):
+    _fields_ = [("to_world", M16), ("x_fov", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float),
+                ("shutter_open", C.c_float), ("shutter_close", C.c_float),
+                ("film_w", C.c_int32), ("film_h", C.c_int32),
+                ("crop_x", C.c_int32), ("crop_y", C.c_int32), ("crop_w", C.c_int32), ("crop_h", C.c_int32),
+                ("filter", C.c_int32), ("filter_radius", C.c_float)]
+
+
+class OrcParams(C.Structure):
+    _fields_ = [("time", C.c_float), ("w_g_mhz", C.c_float), ("g_1", C.c_float), ("g_0", C.c_float),
+                ("w_s_mhz", C.c_float), ("phase_offset", C.c_float), ("hetero_frequency", C.c_float),
+                ("wave_type", C.c_int32), ("low_frequency_component_only", C.c_int32),
+                ("time_sampling", C.c_int32), ("antithetic_shift", C.c_float), ("stratify_each_interval", C.c_int32),
+                ("path_correlation_depth", C.c_uint32), ("max_depth", C.c_uint32), ("rr_depth", C.c_uint32),
+                ("hide_emitters", C.c_int32), ("base_seed", C.c_uint32),
+                ("time_correlate_number", C.c_int32), ("path_correlate_number", C.c_int32)]
+
+
+class OrcScene(C.Structure):
+    _fields_ = [("shapes", C.POINTER(OrcShape)), ("n_shapes", C.c_int32),
+                ("groups", C.POINTER(OrcGroup)), ("n_groups", C.c_int32),
+                ("objects", C.POINTER(OrcObject)), ("n_objects", C.c_int32),
+                ("emitters", C.POINTER(OrcEmitter)), ("n_emitters", C.c_int32),
+                ("sensor", OrcSensor)]
+
+
+class OrcLane(C.Structure):
+    _fields_ = [("sample_pos", C.c_float * 2), ("time", C.c_float), ("ray_o", C.c_float * 3), ("ray_d", C.c_float * 3),
+                ("rgb", C.c_float * 3), ("path_length", C.c_float), ("depth", C.c_uint32), ("valid", C.c_uint32)]
+
+
+LANE_DTYPE = np.dtype([("sample_pos", "<f4", 2), ("time", "<f4"), ("ray_o", "<f4", 3), ("ray_d", "<f4", 3),
+                       ("rgb", "<f4", 3), ("path_length", "<f4"), ("depth", "<u4"), ("valid", "<u4")])
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    so = os.path.join(_HERE, "libdtof_oracle.so")
+    src = os.path.join(_HERE, "dtof_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src),
+                                                                    os.path.getmtime(os.path.join(_HERE, "dtof_oracle.h"))):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libdtof_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_tea_float32.restype = C.c_float
+        L.orc_tea_float32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+        L.orc_tea32.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_pcg32_seed.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_pcg32_next_u32.restype = C.c_uint32
+        L.orc_pcg32_next_u32.argtypes = [C.POINTER(C.c_uint64), C.c_uint64]
+        L.orc_pcg32_next_f32.restype = C.c_float
+        L.orc_pcg32_next_f32.argtypes = [C.POINTER(C.c_uint64), C.c_uint64]
+        L.orc_permute_kensler.restype = C.c_uint32
+        L.orc_permute_kensler.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_waveform.restype = C.c_float
+        L.orc_waveform.argtypes = [C.c_float, C.c_int]
+        L.orc_waveform_low_pass.restype = C.c_float
+        L.orc_waveform_low_pass.argtypes = [C.c_float, C.c_int]
+        L.orc_modulation_weight.restype = C.c_float
+        L.orc_modulation_weight.argtypes = [C.POINTER(OrcParams), C.c_float, C.c_float]
+        L.orc_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_sampler_lane.argtypes = [C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+        L.orc_camera_ray.argtypes = [C.POINTER(OrcSensor), C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.orc_intersect.restype = C.c_int
+        L.orc_intersect.argtypes = [C.POINTER(OrcScene), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float,
+                                    C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        L.orc_occluded.restype = C.c_int
+        L.orc_occluded.argtypes = [C.POINTER(OrcScene), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float]
+        L.orc_render_lanes.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcParams), C.c_uint32, C.c_uint32,
+                                       C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
+        L.orc_render.restype = C.c_uint64
+        L.orc_render.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
+                                 C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_bake_cube.argtypes = [C.c_void_p] * 6
+        _LIB = L
+    return _LIB
+
+
+def _m16(a):
+    return M16(*np.asarray(a, dtype=np.float32).reshape(16).tolist())
+
+
+def make_params(d):
+    p = OrcParams()
+    for name, _ in OrcParams._fields_:
+        setattr(p, name, d[name].item() if hasattr(d[name], "item") else d[name])
+    return p
+
+
+class Scene:
+    """Oracle-side scene: FlatScene (scene_xml.load) marshalled into the C records."""
+
+    def __init__(self, source, params=None, is_string=False):
+        self.flat = scene_xml.load(source, params, is_string)
+        fs = self.flat
+        self._keep = []
+        L = lib()
+        shapes = (OrcShape * max(1, len(fs.shapes)))()
+        for i, s in enumerate(fs.shapes):
+            o = shapes[i]
+            o.kind, o.twosided, o.flip_normals, o.face_normals = s["kind"], s["twosided"], s["flip_normals"], s["face_normals"]
+            o.reflectance = (C.c_float * 3)(*s["reflectance"].tolist())
+            o.to_world, o.to_object = _m16(s["to_world"]), _m16(s["to_object"])
+            if s["kind"] == 1:   # cube
+                pos, nrm = np.zeros(72, np.float32), np.zeros(72, np.float32)
+                uv, faces = np.zeros(48, np.float32), np.zeros(36, np.uint32)
+                tw = np.ascontiguousarray(s["to_world"], dtype=np.float32)
+                to = np.ascontiguousarray(s["to_object"], dtype=np.float32)
+                L.orc_bake_cube(tw.ctypes.data, to.ctypes.data, pos.ctypes.data, nrm.ctypes.data, uv.ctypes.data, faces.ctypes.data)
+                self._keep += [pos, nrm, uv, faces]
+                s["positions"], s["normals"], s["texcoords"], s["faces"] = pos, nrm, uv, faces
+                o.n_vertices, o.n_faces = 24, 12
+                o.positions = pos.ctypes.data_as(C.POINTER(C.c_float))
+                o.normals = nrm.ctypes.data_as(C.POINTER(C.c_float))
+                o.texcoords = uv.ctypes.data_as(C.POINTER(C.c_float))
+                o.faces = faces.ctypes.data_as(C.POINTER(C.c_uint32))
+        groups = (OrcGroup * max(1, len(fs.groups)))()
+        for i, g in enumerate(fs.groups):
+            groups[i].first_shape, groups[i].n_shapes = g["first_shape"], g["n_shapes"]
+        objects = (OrcObject * max(1, len(fs.objects)))()
+        for i, ob in enumerate(fs.objects):
+            o = objects[i]
+            o.kind, o.index, o.n_keys = ob["kind"], ob["index"], ob["n_keys"]
+            o.key_time = (C.c_float * 2)(*np.asarray(ob["key_time"], np.float32).tolist())
+            o.key[0], o.key[1] = _m16(ob["key"][0]), _m16(ob["key"][1])
+        emitters = (OrcEmitter * max(1, len(fs.emitters)))()
+        for i, e in enumerate(fs.emitters):
+            emitters[i].kind = e["kind"]
+            emitters[i].position = (C.c_float * 3)(*e["position"].tolist())
+            emitters[i].intensity = (C.c_float * 3)(*e["intensity"].tolist())
+        sc = OrcScene()
+        sc.shapes, sc.n_shapes = shapes, len(fs.shapes)
+        sc.groups, sc.n_groups = groups, len(fs.groups)
+        sc.objects, sc.n_objects = objects, len(fs.objects)
+        sc.emitters, sc.n_emitters = emitters, len(fs.emitters)
+        se = fs.sensor
+        sc.sensor.to_world = _m16(se["to_world"])
+        for k in ("x_fov", "near_clip", "far_clip", "shutter_open", "shutter_close", "filter_radius"):
+            setattr(sc.sensor, k, float(se[k]))
+        for k in ("film_w", "film_h", "crop_x", "crop_y", "crop_w", "crop_h", "filter"):
+            setattr(sc.sensor, k, int(se[k]))
+        self._keep += [shapes, groups, objects, emitters]
+        self.c = sc
+
+    @property
+    def size(self):
+        return self.flat.sensor["crop_w"], self.flat.sensor["crop_h"]
+
+    def params(self, integrator=None, sampler=None):
+        """integrator/sampler: dict overriding the XML's plugin (mirrors mi.load_dict({...}))."""
+        d = scene_xml.integrator_params(integrator if integrator is not None else self.flat.integrator,
+                                        sampler if sampler is not None else self.flat.sampler)
+        return d
+
+    def render_lanes(self, pd, seed, spp, lane_begin, n, threads=1):
+        out = np.zeros(n, dtype=LANE_DTYPE)
+        p = make_params(pd)
+        lib().orc_render_lanes(C.byref(self.c), C.byref(p), seed, spp, lane_begin, n, out.ctypes.data, threads)
+        return out
+
+    def render(self, pd, seed=0, spp=None, rows=None, threads=1, raw=False):
+        spp = spp or pd["sample_count"]
+        w, h = self.size
+        film = np.zeros((h, w, 4), np.float32)
+        img = np.zeros((h, w, 3), np.float32)
+        r0, r1 = rows if rows else (0, h)
+        p = make_params(pd)
+        n = lib().orc_render(C.byref(self.c), C.byref(p), seed, spp, r0, r1, film.ctypes.data, img.ctypes.data, threads)
+        return (film if raw else img), n

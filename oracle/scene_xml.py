@@ -1,0 +1,516 @@
+"""Oracle restatement of the reference's scene-XML semantics for the hot path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/dtof_oracle.h).  Pure Python / numpy, written
+independently of the product's C++ loader so the two can be compared.
+
+Follows (reference paths relative to /root/reference):
+  * src/core/xml.cpp:441-456,630-648   <default> + $param substitution (longest name first)
+  * src/core/xml.cpp:882-1007          <transform>/<animation>, ops left-multiply, composed in double
+  * src/core/xml.cpp:792-822           <rgb> with 1 or 3 tokens
+  * src/core/xml.cpp:1165-1195         animated shape -> shapegroup + instance rewrite
+  * src/core/transform.cpp:22-36       AnimatedTransform::append (keyframes cast to float32)
+  * src/render/sensor.cpp:14-20,127-203, src/sensors/perspective.cpp:139-152   sensor parameters
+  * src/render/film.cpp:7-54, src/rfilters/tent.cpp:47-55                        film / filter
+  * src/integrators/dopplertofpath.cpp:19-57, src/render/integrator.cpp:54-100,568-585,
+    src/samplers/correlated.cpp:17-23, src/render/sampler.cpp:11-20             plugin parameters
+"""
+import math
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+F32 = np.float32
+
+
+# ----------------------------------------------------------------------------- transforms (double)
+def _translate(v):
+    m = np.eye(4)
+    m[:3, 3] = v
+    return m
+
+
+def _scale(v):
+    return np.diag([v[0], v[1], v[2], 1.0])
+
+
+def _rotate(axis, angle_deg):
+    # Transform4f::rotate (transform.h:180-184) -> dr::rotate<Matrix4>(axis, rad): Rodrigues, axis used as given
+    a = np.asarray(axis, dtype=np.float64)
+    th = math.radians(angle_deg)
+    s, c = math.sin(th), math.cos(th)
+    cm = 1.0 - c
+    x, y, z = a
+    m = np.eye(4)
+    m[0, 0] = x * x * cm + c
+    m[1, 1] = y * y * cm + c
+    m[2, 2] = z * z * cm + c
+    m[1, 0] = x * y * cm + z * s
+    m[0, 1] = x * y * cm - z * s
+    m[2, 0] = x * z * cm - y * s
+    m[0, 2] = x * z * cm + y * s
+    m[2, 1] = y * z * cm + x * s
+    m[1, 2] = y * z * cm - x * s
+    return m
+
+
+def _coordinate_system(n):
+    # include/mitsuba/core/vector.h:116-136 (double)
+    sign = math.copysign(1.0, n[2])
+    a = -1.0 / (sign + n[2])
+    b = n[0] * n[1] * a
+    return np.array([(n[0] * n[0] * a) * sign + 1.0, b * sign, -n[0] * sign])
+
+
+def _look_at(origin, target, up):
+    # transform.h:255-283
+    o, t, u = (np.asarray(v, dtype=np.float64) for v in (origin, target, up))
+    d = t - o
+    d = d / np.linalg.norm(d)
+    left = np.cross(u, d)
+    left = left / np.linalg.norm(left)
+    new_up = np.cross(d, left)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = left, new_up, d, o
+    return m
+
+
+def _tokens(s):
+    return [t for t in s.replace(",", " ").split() if t]
+
+
+def _vec(node, default=0.0):
+    # detail::expand_value_to_xyz + parse_vector (xml.cpp)
+    if node.get("value") is not None:
+        t = _tokens(node.get("value"))
+        if len(t) == 1:
+            t = t * 3
+        return [float(x) for x in t]
+    return [float(node.get(k, default)) for k in ("x", "y", "z")]
+
+
+def _parse_transform(node):
+    m = np.eye(4)
+    for op in node:
+        tag = op.tag
+        if tag == "matrix":
+            t = [float(x) for x in _tokens(op.get("value"))]
+            if len(t) == 16:
+                mm = np.array(t).reshape(4, 4)
+            elif len(t) == 9:
+                mm = np.eye(4)
+                mm[:3, :3] = np.array(t).reshape(3, 3)
+            else:
+                raise ValueError("matrix: expected 16 or 9 values")
+        elif tag == "translate":
+            mm = _translate(_vec(op))
+        elif tag == "scale":
+            mm = _scale(_vec(op, 1.0))
+        elif tag == "rotate":
+            mm = _rotate(_vec(op), float(op.get("angle")))
+        elif tag == "lookat":
+            o = [float(x) for x in _tokens(op.get("origin"))]
+            t = [float(x) for x in _tokens(op.get("target"))]
+            u = [float(x) for x in _tokens(op.get("up", "0,0,0"))]
+            if sum(x * x for x in u) == 0:
+                dd = np.array(t) - np.array(o)
+                u = list(_coordinate_system(dd / np.linalg.norm(dd)))
+            mm = _look_at(o, t, u)
+        else:
+            raise ValueError("transform nodes can only contain transform operations (got <%s>)" % tag)
+        m = mm @ m   # ctx.transform = T(op) * ctx.transform
+    return m
+
+
+# ----------------------------------------------------------------------------- property bags
+class Props(dict):
+    """name -> (type, value); type in {float,int,bool,string,rgb,transform,animation,object,ref}"""
+
+    def __init__(self, plugin, ident=None):
+        super().__init__()
+        self.plugin = plugin
+        self.id = ident
+        self.children = []   # nested objects in document order: (tag, Props)
+        self.queried = set()
+
+    def get_f(self, name, default):
+        if name in self:
+            self.queried.add(name)
+            t, v = self[name]
+            if t not in ("float", "int"):
+                raise ValueError('property "%s" has the wrong type' % name)
+            return float(v)
+        return default
+
+    def get_i(self, name, default):
+        if name in self:
+            self.queried.add(name)
+            t, v = self[name]
+            if t != "int":
+                raise ValueError('property "%s" has the wrong type (expected <integer>)' % name)
+            return int(v)
+        return default
+
+    def get_b(self, name, default):
+        if name in self:
+            self.queried.add(name)
+            t, v = self[name]
+            if t != "bool":
+                raise ValueError('property "%s" has the wrong type (expected <boolean>)' % name)
+            return bool(v)
+        return default
+
+    def get_s(self, name, default):
+        if name in self:
+            self.queried.add(name)
+            t, v = self[name]
+            if t != "string":
+                raise ValueError('property "%s" has the wrong type (expected <string>)' % name)
+            return v
+        return default
+
+
+_OBJECT_TAGS = {"scene", "integrator", "sensor", "sampler", "film", "rfilter", "bsdf", "shape", "emitter", "texture"}
+
+
+def _substitute(root, params):
+    # xml.cpp:441-456: replace $name in every attribute, longest names first; undefined => error
+    defaults = {}
+    def walk(node):
+        names = sorted(defaults, key=len, reverse=True)
+        for k, v in list(node.attrib.items()):
+            if "$" in v:
+                for n in names:
+                    v = v.replace("$" + n, defaults[n])
+                if "$" in v:
+                    raise ValueError('undefined parameter(s) in string: "%s"!' % v)
+                node.set(k, v)
+        if node.tag == "default":
+            n = node.get("name")
+            if n not in defaults:
+                defaults[n] = node.get("value")
+        for ch in node:
+            walk(ch)
+    defaults.update({k: str(v) for k, v in params.items()})
+    walk(root)
+
+
+def _parse_object(node, registry):
+    p = Props(node.get("type"), node.get("id"))
+    for ch in node:
+        tag, name = ch.tag, ch.get("name")
+        if tag == "default":
+            continue
+        if tag in _OBJECT_TAGS:
+            child = _parse_object(ch, registry)
+            p.children.append((tag, child, name))
+        elif tag == "ref":
+            p.children.append(("ref", ch.get("id"), name))
+        elif tag == "float":
+            p[name] = ("float", float(ch.get("value")))
+        elif tag == "integer":
+            p[name] = ("int", int(ch.get("value")))
+        elif tag == "boolean":
+            v = ch.get("value").lower()
+            if v not in ("true", "false"):
+                raise ValueError('could not parse boolean value "%s"' % v)
+            p[name] = ("bool", v == "true")
+        elif tag == "string":
+            p[name] = ("string", ch.get("value"))
+        elif tag in ("point", "vector"):
+            p[name] = ("vector", _vec(ch))
+        elif tag == "rgb":
+            t = _tokens(ch.get("value"))
+            if len(t) == 1:
+                t = t * 3
+            if len(t) != 3:
+                raise ValueError("'rgb' tag requires one or three values")
+            p[name] = ("rgb", [float(x) for x in t])
+        elif tag == "spectrum":
+            t = _tokens(ch.get("value"))
+            if len(t) != 1:
+                raise ValueError("only constant <spectrum> values are supported")
+            p[name] = ("rgb", [float(t[0])] * 3)
+        elif tag == "transform":
+            p[name] = ("transform", _parse_transform(ch))
+        elif tag == "animation":
+            keys = [(F32(float(tr.get("time"))), _parse_transform(tr)) for tr in ch]
+            for a, b in zip(keys, keys[1:]):
+                if not b[0] > a[0]:
+                    raise ValueError("AnimatedTransform::append(): time values must be strictly monotonically increasing!")
+            p[name] = ("animation", keys)
+        else:
+            raise ValueError('unexpected tag "%s"' % tag)
+    if p.id is not None:
+        registry[p.id] = (node.tag, p)
+    return p
+
+
+# ----------------------------------------------------------------------------- flat description
+def _m32(m):
+    return np.asarray(m, dtype=np.float64).astype(F32)
+
+
+def _inv32(m):
+    return np.linalg.inv(np.asarray(m, dtype=np.float64)).astype(F32)
+
+
+def _bsdf_of(props, registry):
+    """returns (twosided, reflectance float32[3]) for a diffuse / twosided{diffuse} BSDF"""
+    if props.plugin == "twosided":
+        inner = [c for c in props.children if c[0] in ("bsdf", "ref")]
+        if len(inner) != 1:
+            raise ValueError("twosided: exactly one nested BSDF is supported")
+        ip = inner[0][1] if inner[0][0] == "bsdf" else registry[inner[0][1]][1]
+        ts, refl = _bsdf_of(ip, registry)
+        return 1, refl
+    if props.plugin != "diffuse":
+        raise ValueError('unsupported BSDF plugin "%s"' % props.plugin)
+    if "reflectance" in props:
+        t, v = props["reflectance"]
+        refl = [v] * 3 if t in ("float", "int") else v
+    else:
+        refl = [0.5] * 3
+    return 0, np.asarray(refl, dtype=np.float64).astype(F32)
+
+
+class FlatScene:
+    def __init__(self):
+        self.shapes, self.groups, self.objects, self.emitters = [], [], [], []
+        self.sensor = None
+        self.integrator = None   # Props
+        self.sampler = None      # Props
+
+
+def _shape_record(sp, registry, strip_to_world):
+    kind = {"rectangle": 0, "cube": 1}.get(sp.plugin)
+    if kind is None:
+        raise ValueError('unsupported shape plugin "%s"' % sp.plugin)
+    tw = np.eye(4)
+    if not strip_to_world and "to_world" in sp and sp["to_world"][0] == "transform":
+        tw = sp["to_world"][1]
+    flip = sp.get_b("flip_normals", False)
+    if kind == 0 and flip:   # rectangle.cpp:91-99
+        tw = tw @ _scale([1.0, 1.0, -1.0])
+        flip = False
+    bsdfs = [c for c in sp.children if c[0] in ("bsdf", "ref")]
+    if any(c[0] == "emitter" for c in sp.children):
+        raise ValueError("area emitters are not supported")
+    if bsdfs:
+        bp = bsdfs[0][1] if bsdfs[0][0] == "bsdf" else registry[bsdfs[0][1]][1]
+        twosided, refl = _bsdf_of(bp, registry)
+    else:
+        twosided, refl = 0, np.array([0.5] * 3, dtype=F32)   # shape.cpp:66-72 default diffuse
+    return dict(kind=kind, twosided=twosided, flip_normals=int(flip), face_normals=int(sp.get_b("face_normals", False)),
+                reflectance=refl, to_world=_m32(tw), to_object=_inv32(tw))
+
+
+def load(source, params=None, is_string=False):
+    """Parse a scene XML (file path or string) into a FlatScene."""
+    root = ET.fromstring(source) if is_string else ET.parse(source).getroot()
+    if root.tag != "scene" or root.get("version") is None:
+        raise ValueError('missing version attribute in root element "%s"' % root.tag)
+    _substitute(root, params or {})
+    registry = {}
+    top = _parse_object(root, registry)
+    fs = FlatScene()
+    group_of = {}   # id(props of shapegroup) -> group index
+    for tag, child, _name in top.children:
+        if tag == "ref":
+            tag, child = registry[child]
+        if tag == "integrator":
+            fs.integrator = child
+        elif tag == "sensor":
+            fs.sensor = _sensor_record(child)
+            fs.sampler = next((c[1] for c in child.children if c[0] == "sampler"), None)
+        elif tag == "emitter":
+            if child.plugin != "point":
+                raise ValueError('unsupported emitter plugin "%s"' % child.plugin)
+            if "position" in child:
+                pos = np.asarray(child["position"][1], dtype=np.float64).astype(F32)
+            else:
+                tw = child["to_world"][1] if "to_world" in child else np.eye(4)
+                pos = _m32(tw)[:3, 3]
+            inten = child["intensity"] if "intensity" in child else ("float", 1.0)
+            iv = [inten[1]] * 3 if inten[0] in ("float", "int") else inten[1]
+            fs.emitters.append(dict(kind=0, position=pos, intensity=np.asarray(iv, dtype=np.float64).astype(F32)))
+        elif tag == "shape":
+            if child.plugin == "shapegroup":
+                first = len(fs.shapes)
+                for t2, c2, _n in child.children:
+                    if t2 == "ref":
+                        t2, c2 = registry[c2]
+                    if t2 == "shape":
+                        fs.shapes.append(_shape_record(c2, registry, False))
+                group_of[id(child)] = len(fs.groups)
+                fs.groups.append(dict(first_shape=first, n_shapes=len(fs.shapes) - first))
+            elif child.plugin == "instance":
+                grp = None
+                for t2, c2, _n in child.children:
+                    if t2 == "ref":
+                        t2, c2 = registry[c2]
+                    if t2 == "shape" and c2.plugin == "shapegroup":
+                        grp = group_of[id(c2)]
+                if grp is None:
+                    raise ValueError("A reference to a 'shapegroup' must be specified!")
+                fs.objects.append(_instance_record(child.get("to_world"), grp))
+            elif "to_world" in child and child["to_world"][0] == "animation":
+                # xml.cpp:1165-1195: shape{animated to_world} -> shapegroup{shape} + instance
+                first = len(fs.shapes)
+                fs.shapes.append(_shape_record(child, registry, True))
+                fs.groups.append(dict(first_shape=first, n_shapes=1))
+                fs.objects.append(_instance_record(child["to_world"], len(fs.groups) - 1))
+            else:
+                fs.shapes.append(_shape_record(child, registry, False))
+                fs.objects.append(dict(kind=0, index=len(fs.shapes) - 1, n_keys=0,
+                                       key_time=np.zeros(2, F32), key=np.zeros((2, 4, 4), F32)))
+    if fs.sensor is None:
+        raise ValueError("scene has no sensor")
+    return fs
+
+
+def _instance_record(tw, group):
+    key = np.zeros((2, 4, 4), F32)
+    kt = np.zeros(2, F32)
+    if tw is None:
+        key[0] = np.eye(4)
+        n = 1
+    elif tw[0] == "transform":
+        key[0] = _m32(tw[1])
+        n = 1
+    else:
+        keys = tw[1]
+        n = min(len(keys), 2)   # AnimatedTransform::eval only looks at keyframes 0 and 1 (transform.h:458-466)
+        for i in range(n):
+            kt[i] = keys[i][0]
+            key[i] = _m32(keys[i][1])
+    return dict(kind=1, index=group, n_keys=n, key_time=kt, key=key)
+
+
+def _parse_fov(sp, aspect):
+    # src/render/sensor.cpp:149-203
+    if "fov" in sp and "focal_length" in sp:
+        raise ValueError("Please specify either a focal length ('focal_length') or a field of view ('fov')!")
+    if "fov" in sp:
+        fov = sp.get_f("fov", None)
+        axis = sp.get_s("fov_axis", "x").lower()
+        if axis == "smaller":
+            axis = "y" if aspect > 1 else "x"
+        elif axis == "larger":
+            axis = "x" if aspect > 1 else "y"
+    else:
+        f = sp.get_s("focal_length", "50mm")
+        if f.endswith("mm"):
+            f = f[:-2]
+        fov = 2.0 * math.degrees(math.atan(math.sqrt(36.0 * 36 + 24 * 24) / (2.0 * float(f))))
+        axis = "diagonal"
+    if axis == "x":
+        r = fov
+    elif axis == "y":
+        r = math.degrees(2.0 * math.atan(math.tan(0.5 * math.radians(fov)) * aspect))
+    elif axis == "diagonal":
+        diag = 2.0 * math.tan(0.5 * math.radians(fov))
+        width = diag / math.sqrt(1.0 + 1.0 / (aspect * aspect))
+        r = math.degrees(2.0 * math.atan(width * 0.5))
+    else:
+        raise ValueError("The 'fov_axis' parameter must be set to one of 'smaller', 'larger', 'diagonal', 'x', or 'y'!")
+    if r <= 0.0 or r >= 180.0:
+        raise ValueError("The horizontal field of view must be in the range [0, 180]!")
+    return r
+
+
+def _sensor_record(sp):
+    if sp.plugin != "perspective":
+        raise ValueError('unsupported sensor plugin "%s"' % sp.plugin)
+    film = next((c[1] for c in sp.children if c[0] == "film"), None)
+    w, h, cx, cy = 768, 576, 0, 0
+    filt, radius = None, 0.0
+    if film is not None:
+        w, h = film.get_i("width", 768), film.get_i("height", 576)
+        cw, ch = film.get_i("crop_width", w), film.get_i("crop_height", h)
+        cx, cy = film.get_i("crop_offset_x", 0), film.get_i("crop_offset_y", 0)
+        rf = next((c[1] for c in film.children if c[0] == "rfilter"), None)
+        if rf is not None:
+            if rf.plugin == "tent":
+                filt, radius = 1, rf.get_f("radius", 1.0)
+            elif rf.plugin == "box":
+                filt, radius = 0, 0.5
+            else:
+                raise ValueError('unsupported rfilter plugin "%s"' % rf.plugin)
+    else:
+        cw, ch = w, h
+    if filt is None:
+        raise ValueError('unsupported rfilter plugin "gaussian" (film default)')
+    tw = sp["to_world"][1] if "to_world" in sp else np.eye(4)
+    so = sp.get_f("shutter_open", 0.0)
+    sc = sp.get_f("shutter_close", 0.0)
+    near, far = sp.get_f("near_clip", 1e-2), sp.get_f("far_clip", 1e4)
+    return dict(to_world=_m32(tw), x_fov=F32(_parse_fov(sp, w / float(h))), near_clip=F32(near), far_clip=F32(far),
+                shutter_open=F32(so), shutter_close=F32(sc), film_w=w, film_h=h, crop_x=cx, crop_y=cy,
+                crop_w=cw, crop_h=ch, filter=filt, filter_radius=F32(radius))
+
+
+# ----------------------------------------------------------------------------- plugin parameters
+WAVE = {"sinusoidal": 0, "rectangular": 1, "triangular": 2, "trapezoidal": 3}
+TIME = {"uniform": 0, "stratified": 1, "antithetic": 2, "antithetic_mirror": 3}
+
+
+def integrator_params(ip, sp):
+    """Restates the constructors (dopplertofpath.cpp:19-57, integrator.cpp:22-28,54-100,568-585,
+    correlated.cpp:17-23, sampler.cpp:11-20) with their float32 roundings. ip/sp: Props or dict."""
+    def as_props(x, plugin):
+        if isinstance(x, Props):
+            return x
+        p = Props(plugin)
+        for k, v in (x or {}).items():
+            if k == "type":
+                p.plugin = v
+            elif isinstance(v, bool):
+                p[k] = ("bool", v)
+            elif isinstance(v, int):
+                p[k] = ("int", v)
+            elif isinstance(v, float):
+                p[k] = ("float", v)
+            else:
+                p[k] = ("string", v)
+        return p
+    ip, sp = as_props(ip, "dopplertofpath"), as_props(sp, "correlated")
+    if ip.plugin != "dopplertofpath":
+        raise ValueError('unsupported integrator plugin "%s"' % ip.plugin)
+    if sp.plugin != "correlated":
+        raise ValueError('unsupported sampler plugin "%s"' % sp.plugin)
+    T = F32(ip.get_f("time", 0.0015))
+    w_g = F32(ip.get_f("w_g", 30.0))
+    g_1, g_0 = F32(ip.get_f("g_1", 0.5)), F32(ip.get_f("g_0", 0.5))
+    w_s = F32(ip.get_f("w_s", 30.0))
+    phase = F32(ip.get_f("sensor_phase_offset", 0.0))
+    if "hetero_offset" in ip:
+        phase = F32(np.float64(F32(ip.get_f("hetero_offset", 0.0)) * F32(2)) * math.pi)
+    if "hetero_frequency" in ip:
+        hf = F32(ip.get_f("hetero_frequency", 1.0))
+        w_s = F32(np.float64(w_g) + np.float64(hf / T) * 1e-6)
+    else:
+        hf = F32(np.float64(w_s - w_g) * 1e6 * np.float64(T))
+    wave = ip.get_s("wave_function_type", "sinusoidal")
+    if wave not in WAVE:
+        raise ValueError('unknown wave_function_type "%s"' % wave)   # documented deviation
+    tsm = ip.get_s("time_sampling_method", "antithetic")
+    if tsm not in TIME:
+        raise ValueError('unknown time_sampling_method "%s"' % tsm)
+    shift = F32(ip.get_f("antithetic_shift", 0.5 if tsm == "antithetic" else 0.0))
+    max_depth = ip.get_i("max_depth", -1)
+    if max_depth < 0 and max_depth != -1:
+        raise ValueError('"max_depth" must be set to -1 (infinite) or a value >= 0')
+    rr_depth = ip.get_i("rr_depth", 5)
+    if rr_depth <= 0:
+        raise ValueError('"rr_depth" must be set to a value greater than zero!')
+    tcn = sp.get_i("time_correlate_number", 2)
+    return dict(
+        time=T, w_g_mhz=w_g, g_1=g_1, g_0=g_0, w_s_mhz=w_s, phase_offset=phase, hetero_frequency=hf,
+        wave_type=WAVE[wave], low_frequency_component_only=int(ip.get_b("low_frequency_component_only", True)),
+        time_sampling=TIME[tsm], antithetic_shift=shift,
+        stratify_each_interval=int(ip.get_b("use_stratified_sampling_for_each_interval", True)),
+        path_correlation_depth=ip.get_i("path_correlation_depth", 0) & 0xffffffff,
+        max_depth=max_depth & 0xffffffff, rr_depth=rr_depth, hide_emitters=int(ip.get_b("hide_emitters", False)),
+        base_seed=sp.get_i("seed", 0) & 0xffffffff, time_correlate_number=tcn,
+        path_correlate_number=sp.get_i("path_correlate_number", tcn),
+        sample_count=sp.get_i("sample_count", 4))
