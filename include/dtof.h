@@ -1,0 +1,151 @@
+/*
+ * dtof.h -- C ABI of libdtof: the MI355X-native `dopplertofpath` integrator and
+ * `correlated` sampler (drop-in for that hot path of juhyeonkim95/Mitsuba3DopplerToF).
+ *
+ * Plain C, opaque handles, caller-owned buffers, integer status codes (0 = ok) with a
+ * thread-local message in dtof_last_error().  No C++ or torch types cross this boundary.
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repository root).  All compute runs in hand-written HIP kernels on the
+ * current HIP device; there is no CPU fallback -- without a GPU every compute entry
+ * point returns DTOF_ERR_HIP.
+ */
+#ifndef DTOF_H
+#define DTOF_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTOF_OK            0
+#define DTOF_ERR_INVALID   1   /* bad argument / unsupported scene feature / parse error (reference: Throw(...)) */
+#define DTOF_ERR_HIP       2   /* HIP runtime failure (no device, out of memory, launch failure) */
+#define DTOF_ERR_CANCELLED 3   /* Integrator::cancel() was called */
+
+typedef struct dtof_scene   dtof_scene;     /* Scene + Sensor + Film + the two plugins' parameters */
+typedef struct dtof_sampler dtof_sampler;   /* CorrelatedSampler state for n lanes (device resident) */
+
+/* Version / capability string, e.g. "dtof 0.1 (gfx950)". */
+const char *dtof_version(void);
+/* Message of the last failing call on this thread (reference: the what() of the C++ exception). */
+const char *dtof_last_error(void);
+
+/* ---------------------------------------------------------------- scene loading
+ * Replaces xml::load_file / xml::load_string (src/core/xml.cpp:1348-1429, called from
+ * src/mitsuba/mitsuba.cpp:355-357 and mi.load_file in doppler_tutorials/src/program_runner.py:142).
+ * `param_names/values` are the -Dname=value substitutions (src/mitsuba/mitsuba.cpp:241-248). */
+int dtof_scene_load_file(const char *path, const char *const *param_names, const char *const *param_values,
+                         int n_params, dtof_scene **out);
+int dtof_scene_load_string(const char *xml, const char *const *param_names, const char *const *param_values,
+                           int n_params, dtof_scene **out);
+void dtof_scene_destroy(dtof_scene *scene);
+
+/* Plugin construction: replaces PluginManager::create_object -> new DopplerToFPathIntegrator(props)
+ * (src/integrators/dopplertofpath.cpp:19-57 + bases src/render/integrator.cpp:22-28,54-100,568-585) and
+ * new CorrelatedSampler(props) (src/samplers/correlated.cpp:17-23, src/render/sampler.cpp:11-20), and
+ * mi.load_dict({'type':'dopplertofpath', ...}) of doppler_tutorials/src/program_runner.py:127-141.
+ * Properties are given as parallel arrays; `types[i]` is one of 'f' (float), 'i' (integer), 'b' (boolean,
+ * value "true"/"false"), 's' (string).  The plugin name goes in `plugin` ("dopplertofpath"/"correlated").
+ * Unknown plugin names, wrong types and unreferenced properties fail like the reference's loader. */
+int dtof_scene_set_integrator(dtof_scene *scene, const char *plugin, const char *const *names,
+                              const char *types, const char *const *values, int n);
+int dtof_scene_set_sampler(dtof_scene *scene, const char *plugin, const char *const *names,
+                           const char *types, const char *const *values, int n);
+
+typedef struct {
+    int32_t  film_width, film_height, crop_x, crop_y, crop_width, crop_height;
+    uint32_t sample_count;          /* Sampler::sample_count() */
+    uint32_t n_shapes, n_groups, n_objects, n_emitters, n_triangles, n_bvh_nodes;
+    uint32_t scene_blob_bytes;
+    /* constructor-rounded plugin parameters (for parity checks of the constructors) */
+    float    time, w_g, g_1, g_0, w_s, phase_offset, hetero_frequency, antithetic_shift;
+    int32_t  wave_type, low_frequency_component_only, time_sampling, stratify_each_interval;
+    uint32_t path_correlation_depth, max_depth, rr_depth, base_seed;
+    int32_t  time_correlate_number, path_correlate_number;
+} dtof_scene_info;
+int dtof_scene_get_info(const dtof_scene *scene, dtof_scene_info *info);
+
+/* Flat float32 export of what the loader produced (parity of the XML semantics, row X1):
+ * kind 0: object keyframes  -> per object 2+32 floats (t0,t1, key0[16], key1[16]) , rows of `out`
+ * kind 1: shape transforms  -> per shape 32 floats (to_world[16], to_object[16])
+ * kind 2: sensor            -> to_world[16], x_fov, near, far, shutter_open, shutter_close
+ * kind 3: emitters          -> per emitter position[3], intensity[3]
+ * Returns the number of floats written (<= capacity) through *n_written. */
+int dtof_scene_export(const dtof_scene *scene, int kind, float *out, size_t capacity, size_t *n_written);
+
+/* ---------------------------------------------------------------- rendering
+ * Replaces Integrator::render(Scene*, uint32_t sensor_index, uint32_t seed, uint32_t spp, bool develop,
+ * bool evaluate) (include/mitsuba/render/integrator.h:74-79; src/render/integrator.cpp:104-347), i.e.
+ * integrator.render(scene, seed=i, spp=n) of program_runner.py:15,23.  spp == 0 uses the sampler's
+ * sample_count (integrator.cpp:121-124). */
+typedef struct {
+    uint64_t n_paths;            /* W*H*spp lanes evaluated by this call */
+    uint64_t n_bounces;          /* closest-hit rays traced (path-bounces through the trace+shade loop) */
+    uint64_t n_shadow_rays;      /* occlusion rays traced */
+    double   ms_total;           /* generate .. develop, HIP events on the library's stream */
+    double   ms_generate, ms_trace, ms_shade, ms_shadow, ms_splat;   /* per-stage sums (HIP events) */
+    uint32_t n_launches_trace, n_launches_shade, n_launches_shadow;
+    uint32_t n_batches;
+} dtof_render_stats;
+
+/* out_rgb: caller-owned host buffer, crop_height*crop_width*3 float32, developed (RGB / W). */
+int dtof_render(dtof_scene *scene, uint32_t sensor_index, uint32_t seed, uint32_t spp,
+                float *out_rgb, dtof_render_stats *stats);
+
+/* Tile / shard entry point (no reference counterpart: the reference is single-device).
+ * Renders pixel rows [row_begin,row_end) of the crop window and ACCUMULATES the undeveloped R,G,B,W
+ * film (hdrfilm.cpp:235-279 channel layout) into `d_film_rgbw`, a DEVICE buffer of
+ * crop_height*crop_width*4 float32 the caller zeroed (rows row_begin-r..row_end+r receive splats,
+ * r = filter footprint).  n_offsets > 1 evaluates several `hetero_offset` values (in units of 2*pi
+ * like the plugin property) in ONE traversal; film k lives at d_film_rgbw + k*crop_h*crop_w*4.
+ * offsets == NULL / n_offsets == 0 uses the integrator's own phase offset. */
+int dtof_render_rows(dtof_scene *scene, uint32_t seed, uint32_t spp, int32_t row_begin, int32_t row_end,
+                     const float *offsets, int n_offsets, float *d_film_rgbw, dtof_render_stats *stats);
+/* HDRFilm::develop (src/films/hdrfilm.cpp:305-406) on device buffers: rgb = RGB / (W == 0 ? 1 : W). */
+int dtof_develop(const float *d_film_rgbw, float *d_rgb, int64_t n_pixels);
+/* Same as dtof_render but with n_offsets batched modulation offsets; out_rgb holds n_offsets images. */
+int dtof_render_offsets(dtof_scene *scene, uint32_t seed, uint32_t spp, const float *offsets, int n_offsets,
+                        float *out_rgb, dtof_render_stats *stats);
+
+/* Integrator::cancel / should_stop (include/mitsuba/render/integrator.h:96-109). */
+void dtof_cancel(dtof_scene *scene);
+
+/* Per-lane debugging entry (SURVEY 8b "dtof_sample_lanes"): evaluates wavefront lanes
+ * [lane_begin, lane_begin+n) exactly as dtof_render would and returns, per lane,
+ * sample_pos[2], time, ray_o[3], ray_d[3], rgb[3] (12 floats) -- the (Spectrum, position) pair that
+ * render_sample hands to ImageBlock::put (src/render/integrator.cpp:509-541). */
+int dtof_sample_lanes(dtof_scene *scene, uint32_t seed, uint32_t spp, uint64_t lane_begin, uint64_t n, float *out_lanes12);
+
+/* ---------------------------------------------------------------- sampler surface
+ * Array-of-lanes form of the Sampler interface (include/mitsuba/render/sampler.h:99-168) for the
+ * correlated sampler; state lives on the GPU, results are copied to caller-owned host arrays of n floats. */
+int  dtof_sampler_create(uint32_t sample_count, uint32_t base_seed, int32_t time_correlate_number,
+                         int32_t path_correlate_number, dtof_sampler **out);          /* correlated.cpp:17-23 */
+void dtof_sampler_destroy(dtof_sampler *s);
+int  dtof_sampler_seed(dtof_sampler *s, uint32_t seed, uint32_t wavefront_size);       /* correlated.cpp:38-64 */
+int  dtof_sampler_set_samples_per_wavefront(dtof_sampler *s, uint32_t spw);            /* sampler.cpp:75-83 */
+int  dtof_sampler_advance(dtof_sampler *s);                                            /* sampler.cpp:52-55 */
+int  dtof_sampler_next_1d(dtof_sampler *s, float *out);                                /* correlated.cpp:79-84 */
+int  dtof_sampler_next_2d(dtof_sampler *s, float *out_xy);                             /* correlated.cpp:86-90, n*2 */
+/* correlate: per-lane flags (n bytes) or NULL to use `correlate_all` for every lane. */
+int  dtof_sampler_next_1d_correlate(dtof_sampler *s, const uint8_t *correlate, int correlate_all, float *out);  /* :156-161 */
+int  dtof_sampler_next_2d_correlate(dtof_sampler *s, const uint8_t *correlate, int correlate_all, float *out_xy); /* :163-167 */
+/* strategy: 0 uniform, 1 stratified, 2 antithetic, 3 antithetic_mirror (sampler.h:27-34) */
+int  dtof_sampler_next_1d_time(dtof_sampler *s, int strategy, float antithetic_shift, int stratify_each_interval, float *out); /* :92-153 */
+/* state readback: 7 uint32 per lane = rng.state lo,hi, rng_time.state lo,hi, rng_path.state lo,hi, permutation seed */
+int  dtof_sampler_get_state(dtof_sampler *s, uint32_t *out7);
+uint32_t dtof_sampler_wavefront_size(const dtof_sampler *s);
+uint32_t dtof_sampler_sample_count(const dtof_sampler *s);
+
+/* ---------------------------------------------------------------- modulation functions
+ * eval_modulation_weight (dopplertofpath.cpp:60-77) and the waveform library
+ * (include/mitsuba/render/waveform_utils.h:24-62) over arrays, evaluated by the same device functions the
+ * shade kernel uses.  mode 0: weight(ray_time=t[i], path_length=len[i]) with the scene's integrator;
+ * mode 1: eval_modulation_function_value(t[i]); mode 2: ..._low_pass(t[i]). */
+int dtof_eval_modulation(dtof_scene *scene, int mode, const float *t, const float *len, float *out, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

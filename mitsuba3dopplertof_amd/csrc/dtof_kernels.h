@@ -1,0 +1,83 @@
+// dtof_kernels.h -- kernel parameter blocks and queue layout shared by the host
+// orchestration (dtof_render.hip) and the kernels (dtof_kernels.hip).
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+namespace dtof {
+
+constexpr int kMaxOffsets = 4;      // modulation offsets evaluated per traversal (K)
+
+// Everything a kernel needs besides the scene blob and the queues; passed by value.
+struct RenderParams {
+    // ---- camera (PerspectiveCamera, src/sensors/perspective.cpp:172-279)
+    float s2c[16];                  // sample_to_camera
+    float cam_to_world[12];
+    float near_clip, far_clip, shutter_open, shutter_open_time;
+    // ---- film (lane -> pixel mapping src/render/integrator.cpp:273-290; splat imageblock.cpp:414-531)
+    int32_t crop_x, crop_y, crop_w, crop_h;
+    float scale_x, scale_y, offset_x, offset_y;   // render_sample: scale = 1/crop_size, offset = -crop_offset*scale
+    int32_t filter; float filter_radius, inv_radius;
+    // ---- sampler (src/samplers/correlated.cpp, src/render/sampler.cpp)
+    uint32_t base_seed, seed, seed_value;         // seed_value = base_seed + seed
+    uint32_t spp, spp_log2;                       // spp_log2 = 0xffffffff when spp is not a power of two
+    uint32_t tcn, pcn;
+    int32_t time_sampling; float antithetic_shift; int32_t stratify;
+    uint32_t n_stratum; float inv_n_stratum, inv_tcn;
+    // ---- integrator (src/integrators/dopplertofpath.cpp:19-77)
+    float T, w_d, w_g, phi_coef, amp, g_1, g_0;
+    float phase[kMaxOffsets]; int32_t n_offsets;
+    int32_t wave_type, low_pass;
+    uint32_t path_correlation_depth, max_depth, rr_depth;
+    // ---- batch
+    uint32_t lane_base, n_lanes;                  // this batch covers global lanes [lane_base, lane_base + n_lanes)
+};
+
+// SoA wavefront state for one batch (device pointers; all arrays have `capacity` entries and are
+// indexed by the lane's position inside the batch).
+struct Queues {
+    float4 *ray_a;       // o.xyz, time
+    float4 *ray_b;       // d.xyz, maxt
+    uint4  *hit;         // t, u, v (float bits), prim
+    uint32_t *hit_id;    // object (low 24 bits) | shape-in-group (high 8 bits); 0xffffffff = miss
+    float4 *st_a;        // throughput.xyz, path_length
+    uint4  *rng_a;       // rng.state (lo,hi), rng_path.state (lo,hi)
+    uint2  *rng_b;       // rng_time.state
+    float4 *res;         // [K][capacity] accumulated result rgb (w unused)
+    float2 *pos;         // sample position on the film
+    float4 *sh_a;        // shadow ray o.xyz, maxt
+    float4 *sh_b;        // shadow ray d.xyz, time
+    float4 *sh_c;        // [K][capacity] candidate result rgb, w = as_float(lane position)
+    uint32_t *q[2];      // active-lane index queues (ping-pong)
+    uint32_t *counts;    // [iteration][2]: (alive after shade, shadow rays)
+    uint32_t capacity;
+};
+
+struct LaneDebug {       // mirrors orc_lane's comparable fields
+    float sample_pos[2]; float time; float ray_o[3]; float ray_d[3]; float rgb[3];
+};
+
+// kernels (dtof_kernels.hip)
+void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s);
+void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
+                  const uint32_t *qin, const uint32_t *count_in, uint32_t upper, hipStream_t s);
+void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
+                  const uint32_t *qin, const uint32_t *count_in, uint32_t upper, uint32_t *qout,
+                  uint32_t *counts_out, uint32_t depth, hipStream_t s);
+void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
+                   const uint32_t *count_in, uint32_t upper, hipStream_t s);
+void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t film_w, int32_t film_h, hipStream_t s);
+void launch_develop(const float *film, float *rgb, int64_t n_pixels, hipStream_t s);
+void launch_lane_dump(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s);
+void launch_lane_dump_rays(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s);
+
+// sampler KAT kernels
+struct SamplerState { uint2 *rng, *rng_time, *rng_path; uint32_t *perm_seed, *dim; uint32_t n; };
+void launch_sampler_seed(const RenderParams &rp, const SamplerState &st, hipStream_t s);
+void launch_sampler_next_correlate(const RenderParams &rp, const SamplerState &st, const uint8_t *correlate, int correlate_all,
+                                   float *out, hipStream_t s);
+void launch_sampler_next_1d(const RenderParams &rp, const SamplerState &st, float *out, hipStream_t s);
+void launch_sampler_next_time(const RenderParams &rp, const SamplerState &st, uint32_t sample_index_base, float *out, hipStream_t s);
+void launch_waveform_eval(const RenderParams &rp, const float *t, const float *len, float *out, int mode, uint32_t n, hipStream_t s);
+
+}  // namespace dtof

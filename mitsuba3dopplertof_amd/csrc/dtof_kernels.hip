@@ -1,0 +1,795 @@
+// dtof_kernels.hip -- hand-written HIP kernels (gfx950) of the wavefront Doppler-ToF path tracer.
+//
+// Stages (one kernel each, SoA queues in HBM, see dtof_kernels.h):
+//   generate : sampler seeding + pixel jitter + time sample + camera ray
+//              (src/render/integrator.cpp:273-290, 476-502; src/samplers/correlated.cpp:38-64,92-167;
+//               src/sensors/perspective.cpp:238-279)
+//   trace    : closest hit through the TLAS, motion-blur instances re-lerped per ray
+//              (src/render/scene_embree.inl:202-333 semantics; src/shapes/instance.cpp:295-311)
+//   shade    : surface interaction, point-light NEE set-up, diffuse BSDF eval+sample, modulation
+//              weight, Russian roulette, wave-ballot compaction of survivors and shadow rays
+//              (src/integrators/dopplertofpath.cpp:130-277)
+//   shadow   : occlusion query; visible lanes commit their candidate result
+//              (src/render/scene.cpp:235-291 test_visibility branch)
+//   splat    : reconstruction-filter splat with per-pixel wave reduction, then float atomics
+//              (src/render/imageblock.cpp:414-531)
+//   develop  : RGB / W (src/films/hdrfilm.cpp:305-406)
+//
+// Compiled with -ffp-contract=off: an fma is issued exactly where fmaf() is written, so a lane's
+// arithmetic is bit-identical to the scalar restatement in oracle/ (same helper algebra in dtof_math.h).
+#include "dtof_kernels.h"
+#include "dtof_scene.h"
+#include "dtof_math.h"
+
+namespace dtof {
+
+#define DTOF_D __device__ __forceinline__
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------- scene view
+struct SceneView {
+    const BvhNode *nodes; const DObject *objects; const DGroup *groups; const DShape *shapes;
+    const DTri *tris; const DTriShade *shading; const DEmitter *emitters;
+    uint32_t n_nodes, n_emitters;
+};
+DTOF_D SceneView make_view(const uint8_t *base) {
+    const BlobHeader *h = (const BlobHeader *) base;
+    SceneView v;
+    v.nodes = (const BvhNode *) (base + h->off_nodes);
+    v.objects = (const DObject *) (base + h->off_objects);
+    v.groups = (const DGroup *) (base + h->off_groups);
+    v.shapes = (const DShape *) (base + h->off_shapes);
+    v.tris = (const DTri *) (base + h->off_tris);
+    v.shading = (const DTriShade *) (base + h->off_shading);
+    v.emitters = (const DEmitter *) (base + h->off_emitters);
+    v.n_nodes = h->n_nodes; v.n_emitters = h->n_emitters;
+    return v;
+}
+// Stage the whole scene blob into LDS (small scenes: the Cornell blob is ~5 KB).
+DTOF_D const uint8_t *stage_scene(const uint8_t *g, uint32_t bytes, uint4 *lds) {
+    const uint4 *src = (const uint4 *) g;
+    for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) lds[i] = src[i];
+    __syncthreads();
+    return (const uint8_t *) lds;
+}
+
+struct Hit { float t, u, v; uint32_t obj, shape, prim; };
+
+// ---------------------------------------------------------------------------- primitives
+// Rectangle::ray_intersect_preliminary_impl, src/shapes/rectangle.cpp:201-224
+DTOF_D bool rect_hit(const DShape &sh, V3 o, V3 d, float maxt, float &t, float &u, float &v) {
+    V3 lo = xf_point(sh.to_object, o), ld = xf_vector(sh.to_object, d);
+    t = -lo.z / ld.z;
+    u = fmaf(ld.x, t, lo.x); v = fmaf(ld.y, t, lo.y);
+    return t >= 0.f && t <= maxt && fabsf(u) <= 1.f && fabsf(v) <= 1.f;
+}
+// Moeller-Trumbore as in Embree 3's triangle intersector (tnear < t <= tfar; u,v weight vertices 1,2)
+DTOF_D bool tri_hit(const DTri &tr, V3 o, V3 d, float maxt, float &t, float &u, float &v) {
+    V3 p0 = mk(tr.p0[0], tr.p0[1], tr.p0[2]), p1 = mk(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = mk(tr.p2[0], tr.p2[1], tr.p2[2]);
+    V3 e1 = p0 - p1, e2 = p2 - p0, ng = cross(e2, e1);
+    V3 c = p0 - o, r = cross(c, d);
+    float den = dot(ng, d), aden = fabsf(den);
+    uint32_t sgn = f2u(den) & 0x80000000u;
+    float U = u2f(f2u(dot(r, e2)) ^ sgn), Vv = u2f(f2u(dot(r, e1)) ^ sgn);
+    if (!(den != 0.f && U >= 0.f && Vv >= 0.f && U + Vv <= aden)) return false;
+    float T = u2f(f2u(dot(ng, c)) ^ sgn);
+    if (!(0.f < T && T <= aden * maxt)) return false;
+    float rc = 1.0f / aden;
+    u = U * rc; v = Vv * rc; t = T * rc;
+    return true;
+}
+// AnimatedTransform::eval, include/mitsuba/core/transform.h:439-466
+DTOF_D void instance_matrix(const DObject &ob, float time, float *m) {
+    if (ob.n_keys <= 1) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) m[i] = ob.key0[i];
+        return;
+    }
+    float t = fmin_(fmax_((time - ob.t0) / (ob.t1 - ob.t0), 0.f), 1.f), omt = 1 - t;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) m[i] = ob.key0[i] * omt + ob.key1[i] * t;
+}
+
+// Closest hit (ANY=false) or occlusion (ANY=true) of one top-level object.  Candidates are every
+// primitive hit with t <= maxt; the winner is the smallest t, ties going to the lowest
+// (object, shape, primitive) -- the rule the oracle uses, independent of traversal order.
+template <bool ANY>
+DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float time, float maxt, Hit &best) {
+    const DObject &ob = sv.objects[oi];
+    uint32_t first = ob.index, count = 1;
+    V3 lo = o, ld = d;
+    if (ob.kind == OBJ_INSTANCE) {
+        float m[12], inv[12];
+        instance_matrix(ob, time, m);
+        affine_inverse(m, inv);
+        lo = xf_point(inv, o); ld = xf_vector(inv, d);
+        const DGroup &g = sv.groups[ob.index];
+        first = g.first_shape; count = g.n_shapes;
+    }
+    bool found = false;
+    for (uint32_t k = 0; k < count; ++k) {
+        const DShape &sh = sv.shapes[first + k];
+        float t, u, v;
+        if (sh.kind == SHAPE_RECT) {
+            if (rect_hit(sh, lo, ld, maxt, t, u, v)) {
+                if (ANY) return true;
+                if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
+                    best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = 0; found = true;
+                }
+            }
+        } else {
+            for (uint32_t f = 0; f < sh.n_tris; ++f) {
+                if (tri_hit(sv.tris[sh.first_tri + f], lo, ld, maxt, t, u, v)) {
+                    if (ANY) return true;
+                    if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
+                        best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = f; found = true;
+                    }
+                }
+            }
+        }
+    }
+    return found;
+}
+
+// Slab test against a padded box; NaNs (0*inf) fall out of the min/max chain conservatively.
+DTOF_D float box_entry(const float *bmin, const float *bmax, V3 o, V3 id, float tbest) {
+    float tx0 = (bmin[0] - o.x) * id.x, tx1 = (bmax[0] - o.x) * id.x;
+    float ty0 = (bmin[1] - o.y) * id.y, ty1 = (bmax[1] - o.y) * id.y;
+    float tz0 = (bmin[2] - o.z) * id.z, tz1 = (bmax[2] - o.z) * id.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
+    return tn <= tf ? tn : INFINITY;
+}
+
+// TLAS traversal; `stack` is a per-thread LDS column (stride blockDim.x).
+template <bool ANY>
+DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best) {
+    best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
+    if (sv.n_nodes == 0) return false;
+    // direction reciprocal for the slab test only (exact zero components are nudged)
+    V3 id = mk(1.0f / (d.x == 0.f ? 1e-30f : d.x), 1.0f / (d.y == 0.f ? 1e-30f : d.y), 1.0f / (d.z == 0.f ? 1e-30f : d.z));
+    int sp = 0;
+    uint32_t cur = 0;
+    const uint32_t stride = blockDim.x;
+    for (;;) {
+        if (cur & kLeafFlag) {
+            if (intersect_object<ANY>(sv, cur & ~kLeafFlag, o, d, time, maxt, best) && ANY) return true;
+        } else {
+            const BvhNode &n = sv.nodes[cur];
+            float tl = box_entry(n.lmin, n.lmax, o, id, best.t);
+            float tr = n.right != kNoChild ? box_entry(n.rmin, n.rmax, o, id, best.t) : INFINITY;
+            bool hl = tl < INFINITY, hr = tr < INFINITY;
+            if (hl && hr) {
+                uint32_t nearc = tl <= tr ? n.left : n.right, farc = tl <= tr ? n.right : n.left;
+                stack[sp * stride] = farc; ++sp;
+                cur = nearc; continue;
+            } else if (hl) { cur = n.left; continue; }
+            else if (hr) { cur = n.right; continue; }
+        }
+        if (sp == 0) break;
+        --sp; cur = stack[sp * stride];
+    }
+    return best.obj != 0xffffffffu;
+}
+
+// ---------------------------------------------------------------------------- sampler
+struct Rng { uint64_t state, inc; };
+DTOF_D float next_f32(Rng &r) { return pcg_next_f32(r.state, r.inc); }
+// PCG32Sampler::seed / CorrelatedSampler::seed -- sampler.cpp:115-134, correlated.cpp:38-64
+DTOF_D Rng seed_stream(uint32_t seed_value, uint32_t index) {
+    uint32_t v0, v1; tea32(seed_value, index, v0, v1);
+    Rng r; pcg_seed(v0, v1, r.state, r.inc); return r;
+}
+DTOF_D uint64_t stream_inc(uint32_t seed_value, uint32_t index) {
+    uint32_t v0, v1; tea32(seed_value, index, v0, v1);
+    return ((uint64_t) v1 << 1) | 1u;
+}
+// next_1d_correlate -- correlated.cpp:156-161
+DTOF_D float next_correlate(Rng &main, Rng &path, bool correlate) {
+    float r1 = next_f32(path), r2 = next_f32(main);
+    return correlate ? r1 : r2;
+}
+// next_1d_time -- correlated.cpp:92-153; si = current_sample_index (sampler.cpp:94-103)
+DTOF_D float next_time(const RenderParams &rp, Rng &main, Rng &tm, uint32_t si, uint32_t perm_seed, uint32_t &dim) {
+    int strategy = rp.time_sampling; uint32_t tcn = rp.tcn;
+    if (strategy == TIME_UNIFORM) return next_f32(main);
+    float r = strategy == TIME_STRATIFIED ? next_f32(main) : next_f32(tm);
+    if (rp.stratify) {
+        if (strategy == TIME_STRATIFIED) {
+            uint32_t ps = perm_seed + dim++;
+            uint32_t p1 = permute_kensler(si / tcn, rp.n_stratum, ps);
+            ps = perm_seed + dim++;
+            uint32_t p2 = permute_kensler(si / tcn, rp.n_stratum, ps);
+            uint32_t p = (si % tcn != 0) ? p1 : p2;
+            r = ((float) p + r) * rp.inv_n_stratum;
+        } else {
+            r = ((float) (si / tcn) + r) * rp.inv_n_stratum;
+        }
+    }
+    if (strategy == TIME_STRATIFIED) return ((float) (si % tcn) + r) * rp.inv_tcn;
+    if (strategy == TIME_ANTITHETIC) {
+        uint32_t rem = si % tcn;
+        if (tcn == 2) { float r2 = r + rp.antithetic_shift; return rem != 1 ? r : r2; }
+        return r + (float) rem / (float) tcn;
+    }
+    // TIME_ANTITHETIC_MIRROR
+    float r2 = 1.0f - r + rp.antithetic_shift;
+    return (si % tcn) != 1 ? r : r2;
+}
+
+// ---------------------------------------------------------------------------- modulation
+// waveform_utils.h:24-33
+DTOF_D float waveform(float _t, int type) {
+    float t = fmodf(_t, 2.f * kPi);
+    if (type == WAVE_RECT) return fabsf(t - kPi) > 0.5f * kPi ? 1.f : -1.f;
+    if (type == WAVE_TRI) return t < kPi ? 1.f - 2.f * t * (1.0f / kPi) : -3.f + 2.f * t * (1.0f / kPi);
+    return cos_(t);
+}
+// waveform_utils.h:36-62
+DTOF_D float waveform_low_pass(float _t, int type) {
+    float t = fmodf(_t, 2.f * kPi);
+    if (type == WAVE_SIN) return cos_(t);
+    float a = t * (1.0f / kPi), b = 2.f - a, c = a < b ? a : b;
+    if (type == WAVE_RECT) return 2.f - 4.f * c;
+    if (type == WAVE_TRI) return (4.f * c * c * c - 6.f * c * c + 1.f) * 2.0f * (1.0f / 3.0f);
+    float r = 2.f - 4.f * c;
+    return fmin_(fmax_(2.0f * r, -2.0f), 2.0f);
+}
+// eval_modulation_weight -- dopplertofpath.cpp:60-77
+DTOF_D float modulation_weight(const RenderParams &rp, float phase, float ray_time, float path_length) {
+    float phi = rp.phi_coef * path_length;
+    if (rp.low_pass) {
+        float t = rp.w_d * ray_time + phase + phi;
+        return rp.amp * waveform_low_pass(t, rp.wave_type);
+    }
+    float t1 = rp.w_g * ray_time - phi;
+    float t2 = (rp.w_g + rp.w_d) * ray_time + phase;
+    float g_t = rp.g_1 * waveform(t1, rp.wave_type) + rp.g_0;
+    float s_t = waveform(t2, rp.wave_type);
+    return s_t * g_t;
+}
+
+// ---------------------------------------------------------------------------- generate
+__global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= rp.n_lanes) return;
+    uint32_t lane = rp.lane_base + i;
+    Rng main = seed_stream(rp.seed_value, lane);
+    Rng tm = seed_stream(rp.seed_value + 1, lane / rp.tcn);
+    Rng path = seed_stream(rp.seed_value + 2, lane / rp.pcn);
+    uint32_t pix = rp.spp_log2 != 0xffffffffu ? lane >> rp.spp_log2 : lane / rp.spp;
+    uint32_t si = rp.spp > 1 ? lane - pix * rp.spp : 0;
+    uint32_t perm_seed, tmp; tea32(rp.base_seed, rp.spp * pix + rp.seed, perm_seed, tmp);
+    uint32_t dim = 0;
+
+    uint32_t W = (uint32_t) rp.crop_w;
+    uint32_t py = pix / W, px = pix - W * py;
+    float posx = (float) (px + (uint32_t) rp.crop_x), posy = (float) (py + (uint32_t) rp.crop_y);
+    bool cp = rp.path_correlation_depth > 0;
+    float jx = next_correlate(main, path, cp), jy = next_correlate(main, path, cp);
+    float spx = posx + jx, spy = posy + jy;
+    float ax = fmaf(spx, rp.scale_x, rp.offset_x), ay = fmaf(spy, rp.scale_y, rp.offset_y);
+    float time = rp.shutter_open;
+    if (rp.shutter_open_time > 0.f) time += next_time(rp, main, tm, si, perm_seed, dim) * rp.shutter_open_time;
+
+    // PerspectiveCamera::sample_ray_differential (perspective.cpp:238-279)
+    const float *m = rp.s2c;
+    float r0 = fmaf(m[2], 0.f, fmaf(m[1], ay, fmaf(m[0], ax, m[3])));
+    float r1 = fmaf(m[6], 0.f, fmaf(m[5], ay, fmaf(m[4], ax, m[7])));
+    float r2 = fmaf(m[10], 0.f, fmaf(m[9], ay, fmaf(m[8], ax, m[11])));
+    float r3 = fmaf(m[14], 0.f, fmaf(m[13], ay, fmaf(m[12], ax, m[15])));
+    float iw = rcp(r3);
+    V3 d = normalize(mk(r0 * iw, r1 * iw, r2 * iw));
+    V3 o = mk(rp.cam_to_world[3], rp.cam_to_world[7], rp.cam_to_world[11]);
+    V3 dw = xf_vector(rp.cam_to_world, d);
+    float inv_z = rcp(d.z), near_t = rp.near_clip * inv_z, far_t = rp.far_clip * inv_z;
+    o = o + dw * near_t;
+    float maxt = far_t - near_t;
+    time = time < rp.T ? time : time - rp.T;   // dopplertofpath.cpp:93
+
+    q.ray_a[i] = make_float4(o.x, o.y, o.z, time);
+    q.ray_b[i] = make_float4(dw.x, dw.y, dw.z, maxt);
+    q.st_a[i] = make_float4(1.f, 1.f, 1.f, 0.f);
+    q.rng_a[i] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
+    q.pos[i] = make_float2(spx, spy);
+    for (int k = 0; k < rp.n_offsets; ++k) q.res[(size_t) k * q.capacity + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---------------------------------------------------------------------------- trace
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void k_trace(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words,
+                                                  Queues q, const uint32_t *qin, const uint32_t *count_in, uint32_t upper) {
+    extern __shared__ uint4 lds[];
+    uint32_t count = count_in ? *count_in : upper;
+    if (blockIdx.x * kBlock >= count) return;
+    const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
+    uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
+    SceneView sv = make_view(base);
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    uint32_t l = qin ? qin[i] : i;
+    float4 a = q.ray_a[l], b = q.ray_b[l];
+    Hit h;
+    bool found = trace_scene<false>(sv, stack, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h);
+    q.hit[l] = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
+    q.hit_id[l] = found ? (h.obj | (h.shape << 24)) : 0xffffffffu;
+}
+
+// ---------------------------------------------------------------------------- shade
+struct Surface { V3 p, n, sh_n, sh_s, sh_t, wi; const DShape *shape; };
+
+// Shape::compute_surface_interaction for rectangle (rectangle.cpp:250-323) / mesh (mesh.cpp:632-864),
+// Instance::compute_surface_interaction (instance.cpp:155-250), finalize (interaction.h:493-513)
+DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, uint32_t prim, float t, float b1, float b2,
+                            V3 o, V3 d, float time, Surface &si) {
+    const DObject &ob = sv.objects[oi];
+    bool inst = ob.kind == OBJ_INSTANCE;
+    float m[12], inv[12];
+    V3 lo = o, ld = d;
+    const DShape *sh;
+    if (inst) {
+        instance_matrix(ob, time, m);
+        affine_inverse(m, inv);
+        lo = xf_point(inv, o); ld = xf_vector(inv, d);
+        sh = &sv.shapes[sv.groups[ob.index].first_shape + shape_k];
+    } else sh = &sv.shapes[ob.index];
+    si.shape = sh;
+    V3 dp_du, dp_dv;
+    if (sh->kind == SHAPE_RECT) {
+        V3 n = mk(sh->n[0], sh->n[1], sh->n[2]);
+        V3 p = vfma(ld, t, lo);
+        V3 tr = mk(sh->to_world[3], sh->to_world[7], sh->to_world[11]);
+        float dist = dot(tr - p, n);
+        si.p = p + n * dist; si.n = n; si.sh_n = n;
+        dp_du = mk(sh->dp_du[0], sh->dp_du[1], sh->dp_du[2]);
+        dp_dv = mk(sh->dp_dv[0], sh->dp_dv[1], sh->dp_dv[2]);
+    } else {
+        const DTri &tr = sv.tris[sh->first_tri + prim];
+        const DTriShade &ts = sv.shading[sh->first_tri + prim];
+        V3 p0 = mk(tr.p0[0], tr.p0[1], tr.p0[2]), p1 = mk(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = mk(tr.p2[0], tr.p2[1], tr.p2[2]);
+        float b0 = 1.f - b1 - b2;
+        V3 dp0 = p1 - p0, dp1 = p2 - p0;
+        si.p = vfma(p0, b0, vfma(p1, b1, p2 * b2));
+        si.n = normalize(cross(dp0, dp1));
+        coordinate_system(si.n, dp_du, dp_dv);
+        float d0x = ts.uv1[0] - ts.uv0[0], d0y = ts.uv1[1] - ts.uv0[1], d1x = ts.uv2[0] - ts.uv0[0], d1y = ts.uv2[1] - ts.uv0[1];
+        float det = fmaf(d0x, d1y, -(d0y * d1x)), inv_det = rcp(det);
+        if (det != 0.f) {
+            dp_du = mk(fmaf(d1y, dp0.x, -(d0y * dp1.x)), fmaf(d1y, dp0.y, -(d0y * dp1.y)), fmaf(d1y, dp0.z, -(d0y * dp1.z))) * inv_det;
+            dp_dv = mk(fmaf(-d1x, dp0.x, d0x * dp1.x), fmaf(-d1x, dp0.y, d0x * dp1.y), fmaf(-d1x, dp0.z, d0x * dp1.z)) * inv_det;
+        }
+        if (!(sh->flags & SF_FACE_NORMALS)) {
+            V3 n0 = mk(ts.n0[0], ts.n0[1], ts.n0[2]), n1 = mk(ts.n1[0], ts.n1[1], ts.n1[2]), n2 = mk(ts.n2[0], ts.n2[1], ts.n2[2]);
+            V3 n = vfma(n2, b2, vfma(n1, b1, n0 * b0));
+            si.sh_n = n * rsqrt_(dot(n, n));
+        } else si.sh_n = si.n;
+        if (sh->flags & SF_FLIP_NORMALS) { si.n = -si.n; si.sh_n = -si.sh_n; }
+    }
+    if (inst) {
+        si.p = xf_point(m, si.p);
+        si.n = normalize(xf_normal(inv, si.n));
+        si.sh_n = normalize(xf_normal(inv, si.sh_n));
+        dp_du = xf_vector(m, dp_du);
+    }
+    // initialize_sh_frame (interaction.h:258-268)
+    V3 s = normalize(vfma(si.sh_n, -dot(si.sh_n, dp_du), dp_du));
+    if (dp_du.x == 0.f && dp_du.y == 0.f && dp_du.z == 0.f) { V3 tt; coordinate_system(si.sh_n, s, tt); }
+    si.sh_s = s; si.sh_t = cross(si.sh_n, s);
+    V3 md = -d;
+    si.wi = mk(dot(md, si.sh_s), dot(md, si.sh_t), dot(md, si.sh_n));
+}
+// Interaction::offset_p (interaction.h:161-165)
+DTOF_D V3 offset_p(const Surface &si, V3 d) {
+    float mag = (1.f + fmax_(fmax_(fabsf(si.p.x), fabsf(si.p.y)), fabsf(si.p.z))) * kRayEps;
+    mag = mulsign(mag, dot(si.n, d));
+    return vfma(si.n, mag, si.p);
+}
+// warp::square_to_cosine_hemisphere (warp.h:54-86, 320-344)
+DTOF_D V3 cosine_hemisphere(float sx, float sy) {
+    float x = fmaf(2.f, sx, -1.f), y = fmaf(2.f, sy, -1.f);
+    bool is_zero = x == 0.f && y == 0.f, q13 = fabsf(x) < fabsf(y);
+    float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = 0.25f * kPi * rp / r;
+    if (q13) phi = 0.5f * kPi - phi;
+    if (is_zero) phi = 0.f;
+    float s, c; sincos_(phi, s, c);
+    float px = r * c, py = r * s;
+    return mk(px, py, sqrtf(fmax_(1.f - fmaf(py, py, px * px), 0.f)));
+}
+DTOF_D float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
+
+// wave-aggregated append: one atomic per wave (ballot + prefix popcount)
+DTOF_D uint32_t wave_append(bool pred, uint32_t *counter) {
+    uint64_t mask = __ballot(pred);
+    uint32_t lane = __lane_id();
+    uint32_t base = 0;
+    if (mask != 0) {
+        uint32_t leader = (uint32_t) __ffsll((unsigned long long) mask) - 1;
+        if (lane == leader) base = atomicAdd(counter, (uint32_t) __popcll(mask));
+        base = __shfl(base, leader);
+    }
+    return base + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void k_shade(const uint8_t *scene, uint32_t scene_bytes, RenderParams rp, Queues q,
+                                                  const uint32_t *qin, const uint32_t *count_in, uint32_t upper,
+                                                  uint32_t *qout, uint32_t *counts_out, uint32_t depth) {
+    extern __shared__ uint4 lds[];
+    uint32_t count = count_in ? *count_in : upper;
+    if (blockIdx.x * kBlock >= count) return;
+    const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
+    SceneView sv = make_view(base);
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    bool in_range = i < count;
+    bool alive = false, want_shadow = false;
+    uint32_t l = 0;
+    float4 sha, shb; float3 cand[kMaxOffsets];
+    if (in_range) {
+        l = qin ? qin[i] : i;
+        uint32_t hid = q.hit_id[l];
+        if (hid != 0xffffffffu) {   // a miss ends the path (active_next = false, dopplertofpath.cpp:171)
+            uint32_t lane = rp.lane_base + l;
+            float4 ra = q.ray_a[l], rb = q.ray_b[l]; uint4 hh = q.hit[l]; float4 st = q.st_a[l]; uint4 rs = q.rng_a[l];
+            V3 o = mk(ra.x, ra.y, ra.z), d = mk(rb.x, rb.y, rb.z); float time = ra.w;
+            V3 thr = mk(st.x, st.y, st.z); float path_length = st.w;
+            Rng main, path;
+            main.state = (uint64_t) rs.x | ((uint64_t) rs.y << 32); main.inc = stream_inc(rp.seed_value, lane);
+            path.state = (uint64_t) rs.z | ((uint64_t) rs.w << 32); path.inc = stream_inc(rp.seed_value + 2, lane / rp.pcn);
+            bool correlate = (depth + 1) < rp.path_correlation_depth;
+            float t = u2f(hh.x);
+            path_length += t * 1.f;   // eta == 1 for every supported BSDF (dopplertofpath.cpp:141)
+            bool active_next = depth + 1 < rp.max_depth;
+
+            Surface si;
+            compute_surface(sv, hid & 0xffffffu, hid >> 24, hh.w, t, u2f(hh.y), u2f(hh.z), o, d, time, si);
+            const DShape *sh = si.shape;
+
+            // ---- emitter sampling (scene.cpp:235-291, point.cpp:118-147)
+            float e1 = next_correlate(main, path, correlate), e2 = next_correlate(main, path, correlate); (void) e2;
+            bool active_em = active_next && sv.n_emitters > 0;
+            V3 em_weight = mk(0, 0, 0), wo = mk(0, 0, 0); float ds_dist = 0.f;
+            if (active_em) {
+                uint32_t ne = sv.n_emitters, idx = 0; float em_w = 1.f, pmf = 1.f;
+                if (ne > 1) { float scaled = e1 * (float) ne; idx = (uint32_t) scaled; if (idx > ne - 1) idx = ne - 1; em_w = (float) ne; pmf = 1.f / (float) ne; }
+                const DEmitter &em = sv.emitters[idx];
+                V3 dsp = mk(em.pos[0], em.pos[1], em.pos[2]);
+                V3 dd = dsp - si.p;
+                float dist2 = dot(dd, dd), inv_dist = rsqrt_(dist2);
+                ds_dist = sqrtf(dist2);
+                dd = dd * inv_dist;
+                float id2 = sqr(inv_dist);
+                em_weight = mk(em.intensity[0] * id2, em.intensity[1] * id2, em.intensity[2] * id2) * em_w;
+                float ds_pdf = 1.f * pmf;
+                active_em = ds_pdf != 0.f;
+                // Interaction::spawn_ray_to (interaction.h:141-149)
+                V3 so = offset_p(si, dsp - si.p);
+                V3 sd = dsp - so;
+                float sdist = norm(sd);
+                sd = sd * rcp(sdist);
+                sha = make_float4(so.x, so.y, so.z, sdist * (1.f - kShadowEps));
+                shb = make_float4(sd.x, sd.y, sd.z, time);
+                wo = mk(dot(dd, si.sh_s), dot(dd, si.sh_t), dot(dd, si.sh_n));
+            }
+            float sample_1 = next_correlate(main, path, correlate); (void) sample_1;
+            float s2x = next_correlate(main, path, correlate), s2y = next_correlate(main, path, correlate);
+
+            // ---- BSDF eval_pdf + sample (twosided.cpp:111-148,219-258; diffuse.cpp:101-125,160-180)
+            bool twosided = sh->flags & SF_TWOSIDED;
+            float wiz = si.wi.z, woz = wo.z;
+            if (twosided) { woz = mulsign(woz, wiz); wiz = fabsf(wiz); }
+            V3 refl = mk(sh->refl[0], sh->refl[1], sh->refl[2]);
+            V3 bsdf_val = mk(0, 0, 0), bsdf_weight = mk(0, 0, 0), bs_wo = mk(0, 0, 0);
+            if (wiz > 0.f && woz > 0.f) bsdf_val = mk(refl.x * kInvPi * woz, refl.y * kInvPi * woz, refl.z * kInvPi * woz);
+            if (wiz > 0.f) {
+                bs_wo = cosine_hemisphere(s2x, s2y);
+                float bs_pdf = kInvPi * bs_wo.z;
+                if (bs_pdf > 0.f) bsdf_weight = refl;
+                if (twosided) bs_wo.z = mulsign(bs_wo.z, si.wi.z);
+            }
+            // ---- emitter contribution candidate (dopplertofpath.cpp:214-226); committed by k_shadow if unoccluded
+            if (active_em) {
+                const float mis_em = 1.f;   // ds.delta
+                bool nonzero = false;
+#pragma unroll
+                for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) {
+                    float lw = modulation_weight(rp, rp.phase[k], time, path_length + ds_dist);
+                    float4 r = q.res[(size_t) k * q.capacity + l];
+                    V3 v = mk(bsdf_val.x * em_weight.x * mis_em * lw, bsdf_val.y * em_weight.y * mis_em * lw, bsdf_val.z * em_weight.z * mis_em * lw);
+                    float3 c = make_float3(fmaf(thr.x, v.x, r.x), fmaf(thr.y, v.y, r.y), fmaf(thr.z, v.z, r.z));
+                    cand[k] = c;
+                    nonzero |= f2u(c.x) != f2u(r.x) || f2u(c.y) != f2u(r.y) || f2u(c.z) != f2u(r.z);
+                }
+                want_shadow = nonzero;   // a candidate identical to the current result needs no visibility test
+            }
+            // ---- continuation (dopplertofpath.cpp:232-276)
+            V3 nd = vfma(si.sh_n, bs_wo.z, vfma(si.sh_t, bs_wo.y, si.sh_s * bs_wo.x));   // Frame::to_world
+            V3 no = offset_p(si, nd);
+            thr = mk(thr.x * bsdf_weight.x, thr.y * bsdf_weight.y, thr.z * bsdf_weight.z);
+            float eta = wiz > 0.f ? 1.f : 0.f;   // bs.eta of the zero-initialised sample when cos_theta_i <= 0
+            uint32_t ndepth = depth + 1;
+            float thr_max = fmax_(fmax_(thr.x, thr.y), thr.z);
+            float rr_prob = fmin_(thr_max * sqr(eta), .95f);
+            bool rr_active = ndepth >= rp.rr_depth;
+            bool rr_continue = next_correlate(main, path, correlate) < rr_prob;
+            if (rr_active) thr = thr * rcp(rr_prob);
+            alive = active_next && (!rr_active || rr_continue) && thr_max != 0.f;
+            if (alive) {
+                q.ray_a[l] = make_float4(no.x, no.y, no.z, time);
+                q.ray_b[l] = make_float4(nd.x, nd.y, nd.z, kLargest);
+                q.st_a[l] = make_float4(thr.x, thr.y, thr.z, path_length);
+                q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
+            }
+        }
+    }
+    uint32_t slot = wave_append(alive, &counts_out[0]);
+    if (alive) qout[slot] = l;
+    uint32_t sslot = wave_append(want_shadow, &counts_out[1]);
+    if (want_shadow) {
+        q.sh_a[sslot] = sha; q.sh_b[sslot] = shb;
+#pragma unroll
+        for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets)
+            q.sh_c[(size_t) k * q.capacity + sslot] = make_float4(cand[k].x, cand[k].y, cand[k].z, u2f(l));
+    }
+}
+
+// ---------------------------------------------------------------------------- shadow
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void k_shadow(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp,
+                                                   Queues q, const uint32_t *count_in, uint32_t upper) {
+    extern __shared__ uint4 lds[];
+    uint32_t count = count_in ? *count_in : upper;
+    if (blockIdx.x * kBlock >= count) return;
+    const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
+    uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
+    SceneView sv = make_view(base);
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    float4 a = q.sh_a[i], b = q.sh_b[i];
+    Hit h;
+    bool occluded = trace_scene<true>(sv, stack, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h);
+    if (!occluded) {
+        for (int k = 0; k < rp.n_offsets; ++k) {
+            float4 c = q.sh_c[(size_t) k * q.capacity + i];
+            uint32_t l = f2u(c.w);
+            q.res[(size_t) k * q.capacity + l] = make_float4(c.x, c.y, c.z, 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- splat
+DTOF_D float tent(float x, float inv_r) { return fmax_(0.f, 1.f - fabsf(x * inv_r)); }
+
+// Generic per-lane splat (any filter radius / any spp): direct float atomics.
+DTOF_D void splat_lane(const RenderParams &rp, float *film, float spx, float spy, float r, float g, float b) {
+    int W = rp.crop_w, H = rp.crop_h;
+    if (rp.filter == FILTER_BOX) {
+        int x = (int) floorf(spx) - rp.crop_x, y = (int) floorf(spy) - rp.crop_y;
+        if ((unsigned) x < (unsigned) W && (unsigned) y < (unsigned) H) {
+            float *p = film + 4 * ((size_t) y * W + x);
+            atomicAdd(p, r); atomicAdd(p + 1, g); atomicAdd(p + 2, b); atomicAdd(p + 3, 1.f);
+        }
+        return;
+    }
+    int n = (int) ceilf(rp.filter_radius - .5f), cnt = 2 * n + 1;
+    int pix = (int) floorf(spx) - n, piy = (int) floorf(spy) - n;
+    float relx = (float) pix + .5f - spx, rely = (float) piy + .5f - spy;
+    int lx = pix - rp.crop_x, ly = piy - rp.crop_y;
+    for (int ys = 0; ys < cnt; ++ys) {
+        float wy = tent(rely + (float) ys, rp.inv_radius);
+        for (int xs = 0; xs < cnt; ++xs) {
+            float w = tent(relx + (float) xs, rp.inv_radius) * wy;
+            int x = lx + xs, y = ly + ys;
+            if ((unsigned) x < (unsigned) W && (unsigned) y < (unsigned) H) {
+                float *p = film + 4 * ((size_t) y * W + x);
+                atomicAdd(p, r * w); atomicAdd(p + 1, g * w); atomicAdd(p + 2, b * w); atomicAdd(p + 3, w);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_splat_generic(RenderParams rp, Queues q, float *film, size_t film_stride) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= rp.n_lanes) return;
+    float2 p = q.pos[i];
+    for (int k = 0; k < rp.n_offsets; ++k) {
+        float4 r = q.res[(size_t) k * q.capacity + i];
+        splat_lane(rp, film + (size_t) k * film_stride, p.x, p.y, r.x, r.y, r.z);
+    }
+}
+
+// Fast path: tent filter with radius <= 1 (3x3 footprint) and power-of-two spp.  All samples of a
+// pixel are SEG = min(spp,64) consecutive lanes of one wave and (almost always) share the footprint
+// anchored at the pixel, so the 36 footprint values are reduced across the segment with DPP/shuffles
+// and one lane issues the 36 atomics.  The rare sample whose float position rounds up to the next
+// pixel splats by itself.
+__global__ __launch_bounds__(kBlock) void k_splat_tent3(RenderParams rp, Queues q, float *film, size_t film_stride, uint32_t seg) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    bool in_range = i < rp.n_lanes;
+    uint32_t lane = rp.lane_base + (in_range ? i : 0);
+    uint32_t pix = lane >> rp.spp_log2;
+    uint32_t W = (uint32_t) rp.crop_w;
+    int py = (int) (pix / W), px = (int) (pix - W * (uint32_t) py);
+    float2 p = in_range ? q.pos[i] : make_float2(0.f, 0.f);
+    int fx = (int) floorf(p.x) - rp.crop_x, fy = (int) floorf(p.y) - rp.crop_y;
+    bool regular = in_range && fx == px && fy == py;
+    float wx[3], wy[3];
+    {
+        float relx = (float) (px + rp.crop_x - 1) + .5f - p.x, rely = (float) (py + rp.crop_y - 1) + .5f - p.y;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { wx[a] = tent(relx + (float) a, rp.inv_radius); wy[a] = tent(rely + (float) a, rp.inv_radius); }
+    }
+    for (int k = 0; k < rp.n_offsets; ++k) {
+        float4 r = in_range ? q.res[(size_t) k * q.capacity + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float *fk = film + (size_t) k * film_stride;
+        if (in_range && !regular) splat_lane(rp, fk, p.x, p.y, r.x, r.y, r.z);
+        float acc[36];
+#pragma unroll
+        for (int ys = 0; ys < 3; ++ys)
+#pragma unroll
+            for (int xs = 0; xs < 3; ++xs) {
+                float w = regular ? wx[xs] * wy[ys] : 0.f;
+                acc[4 * (3 * ys + xs) + 0] = r.x * w; acc[4 * (3 * ys + xs) + 1] = r.y * w;
+                acc[4 * (3 * ys + xs) + 2] = r.z * w; acc[4 * (3 * ys + xs) + 3] = w;
+            }
+        for (uint32_t off = seg >> 1; off > 0; off >>= 1)
+#pragma unroll
+            for (int c = 0; c < 36; ++c) acc[c] += __shfl_down(acc[c], off);
+        if (in_range && (threadIdx.x & (seg - 1)) == 0) {
+#pragma unroll
+            for (int ys = 0; ys < 3; ++ys)
+#pragma unroll
+                for (int xs = 0; xs < 3; ++xs) {
+                    int x = px - 1 + xs, y = py - 1 + ys;
+                    if ((unsigned) x < W && (unsigned) y < (unsigned) rp.crop_h) {
+                        float *dst = fk + 4 * ((size_t) y * W + (size_t) x);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { float v = acc[4 * (3 * ys + xs) + c]; if (v != 0.f) atomicAdd(dst + c, v); }
+                    }
+                }
+        }
+    }
+}
+
+__global__ void k_develop(const float *film, float *rgb, int64_t n) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 f = ((const float4 *) film)[i];
+    float w = f.w == 0.f ? 1.f : f.w;
+    rgb[3 * i] = f.x / w; rgb[3 * i + 1] = f.y / w; rgb[3 * i + 2] = f.z / w;
+}
+
+__global__ void k_lane_dump(RenderParams rp, Queues q, LaneDebug *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rp.n_lanes) return;
+    float2 p = q.pos[i]; float4 r = q.res[i];
+    LaneDebug &o = out[i];
+    o.sample_pos[0] = p.x; o.sample_pos[1] = p.y;
+    o.rgb[0] = r.x; o.rgb[1] = r.y; o.rgb[2] = r.z;
+}
+// primary-ray snapshot taken right after generate (ray buffers are overwritten by the first shade)
+__global__ void k_lane_dump_rays(RenderParams rp, Queues q, LaneDebug *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rp.n_lanes) return;
+    float4 a = q.ray_a[i], b = q.ray_b[i];
+    LaneDebug &o = out[i];
+    o.time = a.w; o.ray_o[0] = a.x; o.ray_o[1] = a.y; o.ray_o[2] = a.z; o.ray_d[0] = b.x; o.ray_d[1] = b.y; o.ray_d[2] = b.z;
+}
+
+// ---------------------------------------------------------------------------- launchers
+static inline uint32_t nblk(uint32_t n) { return (n + kBlock - 1) / kBlock; }
+constexpr uint32_t kLdsSceneLimit = 48 * 1024;
+constexpr uint32_t kStackDepth = 32;
+
+void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s) {
+    if (rp.n_lanes == 0) return;
+    hipLaunchKernelGGL(k_generate, dim3(nblk(rp.n_lanes)), dim3(kBlock), 0, s, rp, q);
+}
+static inline uint32_t stage_words_for(uint32_t scene_bytes) { return scene_bytes <= kLdsSceneLimit ? (scene_bytes + 15) / 16 : 0; }
+
+void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &, const Queues &q,
+                  const uint32_t *qin, const uint32_t *count_in, uint32_t upper, hipStream_t s) {
+    if (upper == 0) return;
+    uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + kStackDepth * kBlock * 4;
+    if (sw) hipLaunchKernelGGL(k_trace<true>, dim3(nblk(upper)), dim3(kBlock), lds, s, scene, scene_bytes, sw, q, qin, count_in, upper);
+    else hipLaunchKernelGGL(k_trace<false>, dim3(nblk(upper)), dim3(kBlock), lds, s, scene, scene_bytes, sw, q, qin, count_in, upper);
+}
+void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
+                  const uint32_t *qin, const uint32_t *count_in, uint32_t upper, uint32_t *qout,
+                  uint32_t *counts_out, uint32_t depth, hipStream_t s) {
+    if (upper == 0) return;
+    uint32_t sw = stage_words_for(scene_bytes);
+    if (sw) hipLaunchKernelGGL(k_shade<true>, dim3(nblk(upper)), dim3(kBlock), sw * 16, s, scene, scene_bytes, rp, q, qin, count_in, upper, qout, counts_out, depth);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(nblk(upper)), dim3(kBlock), 0, s, scene, scene_bytes, rp, q, qin, count_in, upper, qout, counts_out, depth);
+}
+void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
+                   const uint32_t *count_in, uint32_t upper, hipStream_t s) {
+    if (upper == 0) return;
+    uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + kStackDepth * kBlock * 4;
+    if (sw) hipLaunchKernelGGL(k_shadow<true>, dim3(nblk(upper)), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in, upper);
+    else hipLaunchKernelGGL(k_shadow<false>, dim3(nblk(upper)), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in, upper);
+}
+void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t film_w, int32_t film_h, hipStream_t s) {
+    if (rp.n_lanes == 0) return;
+    size_t stride = (size_t) film_w * film_h * 4;
+    bool fast = rp.filter == FILTER_TENT && rp.filter_radius <= 1.f && rp.filter_radius > .5f && rp.spp_log2 != 0xffffffffu && rp.spp >= 2;
+    if (fast) {
+        uint32_t seg = rp.spp < 64 ? rp.spp : 64;
+        hipLaunchKernelGGL(k_splat_tent3, dim3(nblk(rp.n_lanes)), dim3(kBlock), 0, s, rp, q, film, stride, seg);
+    } else {
+        hipLaunchKernelGGL(k_splat_generic, dim3(nblk(rp.n_lanes)), dim3(kBlock), 0, s, rp, q, film, stride);
+    }
+}
+void launch_develop(const float *film, float *rgb, int64_t n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_develop, dim3((uint32_t) ((n + 255) / 256)), dim3(256), 0, s, film, rgb, n);
+}
+void launch_lane_dump(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s) {
+    if (rp.n_lanes == 0) return;
+    hipLaunchKernelGGL(k_lane_dump, dim3(nblk(rp.n_lanes)), dim3(kBlock), 0, s, rp, q, out);
+}
+void launch_lane_dump_rays(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s) {
+    if (rp.n_lanes == 0) return;
+    hipLaunchKernelGGL(k_lane_dump_rays, dim3(nblk(rp.n_lanes)), dim3(kBlock), 0, s, rp, q, out);
+}
+
+// ---------------------------------------------------------------------------- sampler / waveform KAT kernels
+__global__ void k_sampler_seed(RenderParams rp, SamplerState st) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= st.n) return;
+    Rng a = seed_stream(rp.seed_value, i), b = seed_stream(rp.seed_value + 1, i / rp.tcn), c = seed_stream(rp.seed_value + 2, i / rp.pcn);
+    st.rng[i] = make_uint2((uint32_t) a.state, (uint32_t) (a.state >> 32));
+    st.rng_time[i] = make_uint2((uint32_t) b.state, (uint32_t) (b.state >> 32));
+    st.rng_path[i] = make_uint2((uint32_t) c.state, (uint32_t) (c.state >> 32));
+    uint32_t ps, tmp; tea32(rp.base_seed, rp.spp * (i / rp.spp) + rp.seed, ps, tmp);   // compute_per_sequence_seed, sampler.cpp:85-92
+    st.perm_seed[i] = ps; st.dim[i] = 0;
+}
+DTOF_D Rng load_rng(const uint2 *arr, uint32_t i, uint64_t inc) { Rng r; uint2 v = arr[i]; r.state = (uint64_t) v.x | ((uint64_t) v.y << 32); r.inc = inc; return r; }
+DTOF_D void store_rng(uint2 *arr, uint32_t i, const Rng &r) { arr[i] = make_uint2((uint32_t) r.state, (uint32_t) (r.state >> 32)); }
+
+__global__ void k_sampler_next_correlate(RenderParams rp, SamplerState st, const uint8_t *correlate, int correlate_all, float *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= st.n) return;
+    Rng m = load_rng(st.rng, i, stream_inc(rp.seed_value, i)), p = load_rng(st.rng_path, i, stream_inc(rp.seed_value + 2, i / rp.pcn));
+    out[i] = next_correlate(m, p, correlate ? correlate[i] != 0 : correlate_all != 0);
+    store_rng(st.rng, i, m); store_rng(st.rng_path, i, p);
+}
+__global__ void k_sampler_next_1d(RenderParams rp, SamplerState st, float *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= st.n) return;
+    Rng m = load_rng(st.rng, i, stream_inc(rp.seed_value, i));
+    out[i] = next_f32(m);
+    store_rng(st.rng, i, m);
+}
+__global__ void k_sampler_next_time(RenderParams rp, SamplerState st, uint32_t sample_index_base, float *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= st.n) return;
+    Rng m = load_rng(st.rng, i, stream_inc(rp.seed_value, i)), t = load_rng(st.rng_time, i, stream_inc(rp.seed_value + 1, i / rp.tcn));
+    uint32_t si = sample_index_base + (rp.spp > 1 ? i % rp.spp : 0), dim = st.dim[i];
+    out[i] = next_time(rp, m, t, si, st.perm_seed[i], dim);
+    st.dim[i] = dim;
+    store_rng(st.rng, i, m); store_rng(st.rng_time, i, t);
+}
+// mode 0: eval_modulation_weight(t, len) ; 1: waveform(t) ; 2: waveform_low_pass(t)
+__global__ void k_waveform_eval(RenderParams rp, const float *t, const float *len, float *out, int mode, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = mode == 0 ? modulation_weight(rp, rp.phase[0], t[i], len[i]) : mode == 1 ? waveform(t[i], rp.wave_type) : waveform_low_pass(t[i], rp.wave_type);
+}
+void launch_sampler_seed(const RenderParams &rp, const SamplerState &st, hipStream_t s) {
+    if (st.n) hipLaunchKernelGGL(k_sampler_seed, dim3(nblk(st.n)), dim3(kBlock), 0, s, rp, st);
+}
+void launch_sampler_next_correlate(const RenderParams &rp, const SamplerState &st, const uint8_t *correlate, int correlate_all, float *out, hipStream_t s) {
+    if (st.n) hipLaunchKernelGGL(k_sampler_next_correlate, dim3(nblk(st.n)), dim3(kBlock), 0, s, rp, st, correlate, correlate_all, out);
+}
+void launch_sampler_next_1d(const RenderParams &rp, const SamplerState &st, float *out, hipStream_t s) {
+    if (st.n) hipLaunchKernelGGL(k_sampler_next_1d, dim3(nblk(st.n)), dim3(kBlock), 0, s, rp, st, out);
+}
+void launch_sampler_next_time(const RenderParams &rp, const SamplerState &st, uint32_t sample_index_base, float *out, hipStream_t s) {
+    if (st.n) hipLaunchKernelGGL(k_sampler_next_time, dim3(nblk(st.n)), dim3(kBlock), 0, s, rp, st, sample_index_base, out);
+}
+void launch_waveform_eval(const RenderParams &rp, const float *t, const float *len, float *out, int mode, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_waveform_eval, dim3(nblk(n)), dim3(kBlock), 0, s, rp, t, len, out, mode, n);
+}
+
+}  // namespace dtof

@@ -1,0 +1,182 @@
+// dtof_math.h -- float32 building blocks shared by the host set-up code and the HIP
+// kernels (everything is compiled by hipcc with -ffp-contract=off, so an fma happens
+// exactly where fmaf() is written).
+//
+// The operation order of every helper mirrors the Dr.Jit primitive the reference
+// uses at that point (reference paths relative to the Mitsuba3DopplerToF root):
+//   dot       -> fmadd chain            (Frame::to_local, include/mitsuba/core/frame.h:34-36)
+//   cross     -> fmsub(a.yzx*b.zxy ...) (interaction.h:267)
+//   normalize -> v * rsqrt(dot(v,v))    (rsqrt = sqrt(1/x), the LLVM back end's lowering)
+//   xf_point  -> Transform::transform_affine(Point)  include/mitsuba/core/transform.h:97-105
+//   xf_vector -> Transform::operator*(Vector)        transform.h:125-134
+//   xf_normal -> Transform::operator*(Normal)        transform.h:140-149
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#define DTOF_HD __host__ __device__ __forceinline__
+
+namespace dtof {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 0.31830988618379067154f;
+constexpr float kRayEps = 1500.f * 5.9604644775390625e-8f;   // include/mitsuba/core/math.h:17-22
+constexpr float kShadowEps = kRayEps * 10.f;
+constexpr float kLargest = 3.40282346638528859812e+38f;       // dr::Largest<float>
+
+struct V3 { float x, y, z; };
+
+DTOF_HD uint32_t f2u(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    uint32_t u; __builtin_memcpy(&u, &f, 4); return u;
+#endif
+}
+DTOF_HD float u2f(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f; __builtin_memcpy(&f, &u, 4); return f;
+#endif
+}
+DTOF_HD float rcp(float x) { return 1.0f / x; }
+DTOF_HD float rsqrt_(float x) { return sqrtf(1.0f / x); }
+DTOF_HD float sqr(float x) { return x * x; }
+DTOF_HD float mulsign(float a, float b) { return u2f(f2u(a) ^ (f2u(b) & 0x80000000u)); }
+DTOF_HD float mulsign_neg(float a, float b) { return u2f(f2u(a) ^ (~f2u(b) & 0x80000000u)); }
+DTOF_HD float signf(float x) { return u2f(0x3f800000u | (f2u(x) & 0x80000000u)); }
+DTOF_HD float fmin_(float a, float b) { return a < b ? a : b; }
+DTOF_HD float fmax_(float a, float b) { return a > b ? a : b; }
+
+DTOF_HD V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+DTOF_HD V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DTOF_HD V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DTOF_HD V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+DTOF_HD V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+DTOF_HD V3 vfma(V3 a, float s, V3 c) { return mk(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z)); }
+DTOF_HD float dot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+DTOF_HD V3 cross(V3 a, V3 b) {
+    return mk(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+DTOF_HD V3 normalize(V3 a) { return a * rsqrt_(dot(a, a)); }
+DTOF_HD float norm(V3 a) { return sqrtf(dot(a, a)); }
+
+// 3x4 affine matrix, row-major: m[4*r + c], r < 3
+struct M34 { float m[12]; };
+
+DTOF_HD V3 xf_point(const float *m, V3 p) {
+    return mk(fmaf(m[2], p.z, fmaf(m[1], p.y, fmaf(m[0], p.x, m[3]))),
+              fmaf(m[6], p.z, fmaf(m[5], p.y, fmaf(m[4], p.x, m[7]))),
+              fmaf(m[10], p.z, fmaf(m[9], p.y, fmaf(m[8], p.x, m[11]))));
+}
+DTOF_HD V3 xf_vector(const float *m, V3 v) {
+    return mk(fmaf(m[2], v.z, fmaf(m[1], v.y, m[0] * v.x)),
+              fmaf(m[6], v.z, fmaf(m[5], v.y, m[4] * v.x)),
+              fmaf(m[10], v.z, fmaf(m[9], v.y, m[8] * v.x)));
+}
+// normal transform with the INVERSE matrix given (inverse_transpose(r,c) = inv(c,r))
+DTOF_HD V3 xf_normal(const float *inv, V3 n) {
+    return mk(fmaf(inv[8], n.z, fmaf(inv[4], n.y, inv[0] * n.x)),
+              fmaf(inv[9], n.z, fmaf(inv[5], n.y, inv[1] * n.x)),
+              fmaf(inv[10], n.z, fmaf(inv[6], n.y, inv[2] * n.x)));
+}
+// Inverse of an affine matrix (the reference builds Transform(Matrix) per hit on an
+// instance, transform.h:54-56 via instance.cpp:161-162, and then only uses the affine part).
+DTOF_HD void affine_inverse(const float *m, float *inv) {
+    float a00 = m[0], a01 = m[1], a02 = m[2], a10 = m[4], a11 = m[5], a12 = m[6], a20 = m[8], a21 = m[9], a22 = m[10];
+    float c00 = fmaf(a11, a22, -(a12 * a21)), c01 = fmaf(a12, a20, -(a10 * a22)), c02 = fmaf(a10, a21, -(a11 * a20));
+    float det = fmaf(a02, c02, fmaf(a01, c01, a00 * c00));
+    float id = 1.0f / det;
+    float i00 = c00 * id, i01 = fmaf(a02, a21, -(a01 * a22)) * id, i02 = fmaf(a01, a12, -(a02 * a11)) * id;
+    float i10 = c01 * id, i11 = fmaf(a00, a22, -(a02 * a20)) * id, i12 = fmaf(a02, a10, -(a00 * a12)) * id;
+    float i20 = c02 * id, i21 = fmaf(a01, a20, -(a00 * a21)) * id, i22 = fmaf(a00, a11, -(a01 * a10)) * id;
+    float tx = m[3], ty = m[7], tz = m[11];
+    inv[0] = i00; inv[1] = i01; inv[2] = i02;  inv[3]  = -fmaf(i02, tz, fmaf(i01, ty, i00 * tx));
+    inv[4] = i10; inv[5] = i11; inv[6] = i12;  inv[7]  = -fmaf(i12, tz, fmaf(i11, ty, i10 * tx));
+    inv[8] = i20; inv[9] = i21; inv[10] = i22; inv[11] = -fmaf(i22, tz, fmaf(i21, ty, i20 * tx));
+}
+
+// Cephes single-precision sincos kernel (what dr::sincos is built on; Dr.Jit's source is
+// not in the reference tree).  Only mul/sub/fma/int ops => bit-identical on host and device.
+DTOF_HD void sincos_(float x, float &s_out, float &c_out) {
+    float xa = fabsf(x);
+    int32_t j = (int32_t) (xa * 1.2732395447351626862f);
+    j = (j + 1) & ~1;
+    float y = (float) j;
+    uint32_t sign_sin = ((uint32_t) j << 29) ^ f2u(x);
+    uint32_t sign_cos = (uint32_t) (~(j - 2)) << 29;
+    y = xa - y * 0.78515625f;
+    y = y - (float) j * 2.4187564849853515625e-4f;
+    y = y - (float) j * 3.77489497744594108e-8f;
+    float z = y * y;
+    float s = fmaf(z * z, -1.9515295891e-4f, fmaf(z, 8.3321608736e-3f, -1.6666654611e-1f)) * z;
+    float c = fmaf(z * z, 2.443315711809948e-5f, fmaf(z, -1.388731625493765e-3f, 4.166664568298827e-2f)) * z;
+    s = fmaf(s, y, y);
+    c = fmaf(c, z, fmaf(z, -0.5f, 1.0f));
+    bool poly = (j & 2) == 0;
+    s_out = u2f(f2u(poly ? s : c) ^ (sign_sin & 0x80000000u));
+    c_out = u2f(f2u(poly ? c : s) ^ (sign_cos & 0x80000000u));
+}
+DTOF_HD float cos_(float x) { float s, c; sincos_(x, s, c); return c; }
+
+// coordinate_system -- include/mitsuba/core/vector.h:116-136
+DTOF_HD void coordinate_system(V3 n, V3 &s, V3 &t) {
+    float sign = signf(n.z), a = -rcp(sign + n.z), b = n.x * n.y * a;
+    s = mk(mulsign(sqr(n.x) * a, n.z) + 1.f, mulsign(b, n.z), mulsign_neg(n.x, n.z));
+    t = mk(b, fmaf(n.y, n.y * a, sign), -n.y);
+}
+
+// ---------------------------------------------------------------- RNG (integer exact)
+// sample_tea_32 -- include/mitsuba/core/random.h:33-47
+DTOF_HD void tea32(uint32_t v0, uint32_t v1, uint32_t &o0, uint32_t &o1) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    o0 = v0; o1 = v1;
+}
+// dr::PCG32 (Dr.Jit 0.4.0, PCG-XSH-RR 64/32)
+constexpr uint64_t kPcgMult = 0x5851f42d4c957f2dULL;
+DTOF_HD uint32_t pcg_next_u32(uint64_t &state, uint64_t inc) {
+    uint64_t old = state;
+    state = old * kPcgMult + inc;
+    uint32_t xs = (uint32_t) (((old >> 18) ^ old) >> 27), rot = (uint32_t) (old >> 59);
+    return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+}
+DTOF_HD float pcg_next_f32(uint64_t &state, uint64_t inc) {
+    return u2f((pcg_next_u32(state, inc) >> 9) | 0x3f800000u) - 1.f;
+}
+// PCG32::seed(1, initstate, initseq)
+DTOF_HD void pcg_seed(uint32_t initstate, uint32_t initseq, uint64_t &state, uint64_t &inc) {
+    state = 0; inc = ((uint64_t) initseq << 1) | 1u;
+    pcg_next_u32(state, inc);
+    state += (uint64_t) initstate;
+    pcg_next_u32(state, inc);
+}
+// permute_kensler -- random.h:113-171
+DTOF_HD uint32_t permute_kensler(uint32_t index, uint32_t n, uint32_t seed) {
+    if (n == 1) return 0;
+    uint32_t w = n - 1;
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    do {
+        uint32_t tmp = index;
+        tmp ^= seed;            tmp *= 0xe170893du;
+        tmp ^= seed >> 16;      tmp ^= (tmp & w) >> 4;
+        tmp ^= seed >> 8;       tmp *= 0x0929eb3fu;
+        tmp ^= seed >> 23;      tmp ^= (tmp & w) >> 1;
+        tmp *= 1 | seed >> 27;  tmp *= 0x6935fa69u;
+        tmp ^= (tmp & w) >> 11; tmp *= 0x74dcb303u;
+        tmp ^= (tmp & w) >> 2;  tmp *= 0x9e501cc3u;
+        tmp ^= (tmp & w) >> 2;  tmp *= 0xc860a3dfu;
+        tmp &= w;               tmp ^= tmp >> 5;
+        index = tmp;
+    } while (index >= n);
+    return (index + seed) % n;
+}
+
+}  // namespace dtof

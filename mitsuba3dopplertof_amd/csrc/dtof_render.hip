@@ -1,0 +1,558 @@
+// dtof_render.hip -- host orchestration of the wavefront renderer and the C ABI (include/dtof.h).
+//
+// Replaces, for the `dopplertofpath` + `correlated` path only, SamplingIntegrator::render
+// (src/render/integrator.cpp:104-347, JIT branch :226-340): wavefront set-up, sampler seeding,
+// lane->pixel mapping, the bounce loop and the film develop.  One host thread drives one HIP
+// stream; the wavefront of W*H*spp lanes is cut into row-band batches (results are invariant to
+// the cut because every lane's RNG streams are pure functions of its global lane index,
+// sampler.cpp:115-134 / correlated.cpp:38-64).
+#include "../../include/dtof.h"
+#include "dtof_kernels.h"
+#include "dtof_scene.h"
+#include "dtof_math.h"
+#include <atomic>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+
+using namespace dtof;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+#define HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    throw HipError(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+template <typename F> int guarded(F &&f) {
+    try { f(); return DTOF_OK; }
+    catch (const HipError &e) { g_last_error = e.what(); return DTOF_ERR_HIP; }
+    catch (const std::exception &e) { g_last_error = e.what(); return DTOF_ERR_INVALID; }
+    catch (...) { g_last_error = "unknown error"; return DTOF_ERR_INVALID; }
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    void ensure(size_t count) {
+        if (count <= n) return;
+        release();
+        HIP_CHECK(hipMalloc((void **) &p, count * sizeof(T))); n = count;
+    }
+    void release() { if (p) { (void) hipFree(p); p = nullptr; n = 0; } }
+    ~DevBuf() { release(); }
+};
+
+constexpr uint32_t kMaxIter = 256;           // counts slots per batch
+constexpr uint64_t kTargetBatchLanes = 1ull << 22;
+
+struct Workspace {
+    DevBuf<float4> ray_a, ray_b, st_a, res, sh_a, sh_b, sh_c;
+    DevBuf<uint4> hit, rng_a;
+    DevBuf<uint32_t> hit_id, q0, q1, counts;
+    DevBuf<float2> pos;
+    DevBuf<LaneDebug> dbg;
+    uint32_t capacity = 0; int k = 0;
+    void ensure(uint32_t cap, int n_offsets) {
+        if (cap <= capacity && n_offsets <= k) return;
+        capacity = std::max(cap, capacity); k = std::max(n_offsets, k);
+        ray_a.ensure(capacity); ray_b.ensure(capacity); st_a.ensure(capacity);
+        res.ensure((size_t) capacity * k); sh_a.ensure(capacity); sh_b.ensure(capacity); sh_c.ensure((size_t) capacity * k);
+        hit.ensure(capacity); rng_a.ensure(capacity); hit_id.ensure(capacity); q0.ensure(capacity); q1.ensure(capacity);
+        counts.ensure(2 * kMaxIter); pos.ensure(capacity);
+    }
+    Queues queues() {
+        Queues q; memset(&q, 0, sizeof q);
+        q.ray_a = ray_a.p; q.ray_b = ray_b.p; q.hit = hit.p; q.hit_id = hit_id.p; q.st_a = st_a.p; q.rng_a = rng_a.p;
+        q.res = res.p; q.pos = pos.p; q.sh_a = sh_a.p; q.sh_b = sh_b.p; q.sh_c = sh_c.p; q.q[0] = q0.p; q.q[1] = q1.p;
+        q.counts = counts.p; q.capacity = capacity;
+        return q;
+    }
+};
+
+}  // namespace
+
+struct dtof_scene {
+    HostScene host;
+    PluginParams pp;
+    std::vector<uint8_t> blob;
+    DevBuf<uint8_t> d_blob; bool uploaded = false;
+    Workspace ws;
+    DevBuf<float> d_film, d_rgb;
+    hipStream_t stream = nullptr;
+    std::atomic<bool> stop { false };
+    ~dtof_scene() { if (stream) (void) hipStreamDestroy(stream); }
+};
+
+struct dtof_sampler {
+    uint32_t sample_count = 4, base_seed = 0; int32_t tcn = 2, pcn = 2;
+    uint32_t seed = 0, wavefront = 0, spw = 1, sample_index = 0; bool seeded = false;
+    DevBuf<uint2> rng, rng_time, rng_path; DevBuf<uint32_t> perm, dim; DevBuf<float> out; DevBuf<uint8_t> flags;
+};
+
+namespace {
+
+void ensure_device(dtof_scene *sc) {
+    if (!sc->stream) HIP_CHECK(hipStreamCreate(&sc->stream));
+    if (!sc->uploaded) {
+        sc->d_blob.ensure(sc->blob.size());
+        HIP_CHECK(hipMemcpy(sc->d_blob.p, sc->blob.data(), sc->blob.size(), hipMemcpyHostToDevice));
+        sc->uploaded = true;
+    }
+}
+
+// 4x4 float product with the fmadd chain of Dr.Jit's column-major matrix product
+void m4_mul(const float *a, const float *b, float *out) {
+    float r[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        float s = a[4 * i] * b[j];
+        for (int k = 1; k < 4; ++k) s = fmaf(a[4 * i + k], b[4 * k + j], s);
+        r[4 * i + j] = s;
+    }
+    memcpy(out, r, sizeof r);
+}
+void m4_identity(float *m) { memset(m, 0, 64); m[0] = m[5] = m[10] = m[15] = 1.f; }
+
+// sample_to_camera: inverse of perspective_projection (include/mitsuba/render/sensor.h:226-262) as
+// PerspectiveCamera::update_camera_transforms builds it (src/sensors/perspective.cpp:172-198); the
+// Transform class carries analytic inverses, so this is the reversed product of the factor inverses.
+void sample_to_camera(const HostSensor &s, float *inv_out) {
+    float fw = (float) s.film_w, fh = (float) s.film_h;
+    float rel_sx = (float) s.crop_w / fw, rel_sy = (float) s.crop_h / fh;
+    float rel_ox = (float) s.crop_x / fw, rel_oy = (float) s.crop_y / fh;
+    float aspect = fw / fh, near_ = s.near_clip, far_ = s.far_clip;
+    float tanv = (float) std::tan((double) (s.x_fov * .5f) * (M_PI / 180.0));
+    float S1i[16], T1i[16], S2i[16], T2i[16], Pi[16], tmp[16];
+    m4_identity(S1i); S1i[0] = rcp(1.f / rel_sx); S1i[5] = rcp(1.f / rel_sy);
+    m4_identity(T1i); T1i[3] = rel_ox; T1i[7] = rel_oy;
+    m4_identity(S2i); S2i[0] = rcp(-0.5f); S2i[5] = rcp(-0.5f * aspect);
+    m4_identity(T2i); T2i[3] = 1.f; T2i[7] = 1.f / aspect;
+    memset(Pi, 0, 64); Pi[0] = tanv; Pi[5] = tanv; Pi[15] = rcp(near_); Pi[11] = 1.f; Pi[14] = (near_ - far_) / (far_ * near_);
+    m4_mul(T1i, S1i, tmp); m4_mul(S2i, tmp, tmp); m4_mul(T2i, tmp, tmp); m4_mul(Pi, tmp, inv_out);
+}
+
+RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, const float *offsets, int n_offsets) {
+    const HostSensor &se = sc->host.sensor; const PluginParams &pp = sc->pp;
+    RenderParams rp; memset(&rp, 0, sizeof rp);
+    sample_to_camera(se, rp.s2c);
+    memcpy(rp.cam_to_world, se.to_world, 48);
+    rp.near_clip = se.near_clip; rp.far_clip = se.far_clip; rp.shutter_open = se.shutter_open;
+    rp.shutter_open_time = se.shutter_close - se.shutter_open;
+    rp.crop_x = se.crop_x; rp.crop_y = se.crop_y; rp.crop_w = se.crop_w; rp.crop_h = se.crop_h;
+    rp.scale_x = 1.f / (float) se.crop_w; rp.scale_y = 1.f / (float) se.crop_h;
+    rp.offset_x = -(float) se.crop_x * rp.scale_x; rp.offset_y = -(float) se.crop_y * rp.scale_y;
+    rp.filter = se.filter; rp.filter_radius = se.filter_radius; rp.inv_radius = 1.f / se.filter_radius;
+    rp.base_seed = pp.base_seed; rp.seed = seed; rp.seed_value = pp.base_seed + seed;
+    rp.spp = spp; rp.spp_log2 = 0xffffffffu;
+    for (uint32_t b = 0; b < 32; ++b) if ((1u << b) == spp) rp.spp_log2 = b;
+    rp.tcn = (uint32_t) pp.time_correlate_number; rp.pcn = (uint32_t) pp.path_correlate_number;
+    rp.time_sampling = pp.time_sampling; rp.antithetic_shift = pp.antithetic_shift; rp.stratify = pp.stratify_each_interval;
+    rp.n_stratum = spp / rp.tcn;                                   // int n_stratum = m_sample_count / tcn (correlated.cpp:112)
+    rp.inv_n_stratum = rp.n_stratum ? 1.0f / (float) (int) rp.n_stratum : 0.f;
+    rp.inv_tcn = 1.0f / (float) pp.time_correlate_number;
+    // eval_modulation_weight's scalar prefactors are folded in double and rounded to float32 once
+    // (they multiply JIT float32 arrays), dopplertofpath.cpp:62-69
+    rp.T = pp.time;
+    rp.w_g = (float) (2 * M_PI * (double) pp.w_g_mhz * 1e6);
+    rp.w_d = (float) (2 * M_PI / (double) pp.time * (double) pp.hetero_frequency);
+    rp.phi_coef = (float) ((2 * M_PI * (double) pp.w_g_mhz) / 300);
+    rp.amp = (float) (0.5 * (double) pp.g_1);
+    rp.g_1 = pp.g_1; rp.g_0 = pp.g_0;
+    rp.wave_type = pp.wave_type; rp.low_pass = pp.low_frequency_component_only;
+    if (n_offsets <= 0) { rp.n_offsets = 1; rp.phase[0] = pp.phase_offset; }
+    else {
+        if (n_offsets > kMaxOffsets) throw std::runtime_error("at most 4 modulation offsets can be batched per traversal");
+        rp.n_offsets = n_offsets;
+        for (int k = 0; k < n_offsets; ++k) rp.phase[k] = (float) ((double) (offsets[k] * 2) * M_PI);   // dopplertofpath.cpp:30-32
+    }
+    rp.path_correlation_depth = pp.path_correlation_depth; rp.max_depth = pp.max_depth; rp.rr_depth = pp.rr_depth;
+    return rp;
+}
+
+struct StageTimer {
+    bool on; hipStream_t s; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
+    StageTimer(bool enabled, hipStream_t st) : on(enabled), s(st) {}
+    int begin(int stage) {
+        if (!on) return -1;
+        hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+        ev[stage].emplace_back(a, b); HIP_CHECK(hipEventRecord(a, s));
+        return (int) ev[stage].size() - 1;
+    }
+    void end(int stage, int idx) { if (on) HIP_CHECK(hipEventRecord(ev[stage][idx].second, s)); }
+    double total(int stage) {
+        double ms = 0;
+        for (auto &p : ev[stage]) { float t = 0; HIP_CHECK(hipEventElapsedTime(&t, p.first, p.second)); ms += t; }
+        return ms;
+    }
+    ~StageTimer() { for (auto &v : ev) for (auto &p : v) { (void) hipEventDestroy(p.first); (void) hipEventDestroy(p.second); } }
+};
+
+// The wavefront loop over pixel rows [row_begin,row_end); accumulates into d_film (K films).
+// lane_dump != nullptr: evaluate only lanes [dump_begin, dump_begin + dump_n) and copy their records out.
+void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin, int32_t row_end,
+                 const float *offsets, int n_offsets, float *d_film, dtof_render_stats *stats,
+                 LaneDebug *lane_dump = nullptr, uint64_t dump_begin = 0, uint64_t dump_n = 0) {
+    ensure_device(sc);
+    const HostSensor &se = sc->host.sensor;
+    if (spp == 0) spp = sc->pp.sample_count;
+    if (spp == 0) throw std::runtime_error("sample count must be positive");
+    uint64_t total_lanes = (uint64_t) se.crop_w * se.crop_h * spp;
+    if (total_lanes > 0xffffffffull) throw std::runtime_error("wavefront exceeds 2^32-1 lanes; multi-pass rendering is not supported");
+    if (sc->pp.time_sampling != TIME_UNIFORM && sc->pp.stratify_each_interval && spp < (uint32_t) sc->pp.time_correlate_number)
+        throw std::runtime_error("sample count must be at least time_correlate_number when per-interval stratification is on");
+    RenderParams rp = make_params(sc, seed, spp, offsets, n_offsets);
+    row_begin = std::max(row_begin, 0); row_end = std::min(row_end, se.crop_h);
+    uint64_t lanes_per_row = (uint64_t) se.crop_w * spp;
+    uint64_t first = lane_dump ? dump_begin : lanes_per_row * (uint64_t) row_begin;
+    uint64_t last = lane_dump ? dump_begin + dump_n : lanes_per_row * (uint64_t) std::max(row_end, row_begin);
+    if (last > total_lanes) throw std::runtime_error("lane range exceeds the wavefront");
+    uint64_t batch = lane_dump ? std::min<uint64_t>(kTargetBatchLanes, std::max<uint64_t>(dump_n, 1))
+                               : std::max<uint64_t>(1, kTargetBatchLanes / lanes_per_row) * lanes_per_row;
+    batch = std::min<uint64_t>(batch, std::max<uint64_t>(last - first, 1));
+    sc->ws.ensure((uint32_t) batch, rp.n_offsets);
+    if (lane_dump) sc->ws.dbg.ensure(batch);
+    Queues q = sc->ws.queues();
+    hipStream_t s = sc->stream;
+    const uint8_t *blob = sc->d_blob.p; uint32_t blob_bytes = (uint32_t) sc->blob.size();
+    const bool has_surface_emitters = false;   // supported emitters: point (no emitter-hit term, point.cpp:186-188)
+    StageTimer tm(stats != nullptr, s);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (stats) { memset(stats, 0, sizeof *stats); HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); HIP_CHECK(hipEventRecord(ev0, s)); }
+    std::vector<uint32_t> h_counts; std::vector<uint32_t> batch_lanes, batch_iters;
+
+    for (uint64_t b0 = first; b0 < last; b0 += batch) {
+        if (sc->stop.load()) break;
+        rp.lane_base = (uint32_t) b0; rp.n_lanes = (uint32_t) std::min<uint64_t>(batch, last - b0);
+        HIP_CHECK(hipMemsetAsync(q.counts, 0, 2 * kMaxIter * sizeof(uint32_t), s));
+        int t = tm.begin(0); launch_generate(rp, q, s); tm.end(0, t);
+        if (lane_dump) launch_lane_dump_rays(rp, q, sc->ws.dbg.p, s);
+        const uint32_t *qin = nullptr, *count_in = nullptr; uint32_t upper = rp.n_lanes, it = 0;
+        for (;; ++it) {
+            if (it >= rp.max_depth) break;
+            // the last iteration of the reference only looks for emitter hits (dopplertofpath.cpp:136-171);
+            // without surface emitters it cannot contribute and is skipped
+            if (it + 1 >= rp.max_depth && !has_surface_emitters) break;
+            if (it >= kMaxIter) break;
+            if (it >= 8 && (it & 3) == 0) {   // unbounded depth: stop once the queue has drained
+                uint32_t alive = 0;
+                HIP_CHECK(hipMemcpyAsync(&alive, q.counts + 2 * (it - 1), 4, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                if (alive == 0) break;
+            }
+            t = tm.begin(1); launch_trace(blob, blob_bytes, rp, q, qin, count_in, upper, s); tm.end(1, t);
+            uint32_t *qout = q.q[it & 1], *cout = q.counts + 2 * it;
+            t = tm.begin(2); launch_shade(blob, blob_bytes, rp, q, qin, count_in, upper, qout, cout, it, s); tm.end(2, t);
+            t = tm.begin(3); launch_shadow(blob, blob_bytes, rp, q, cout + 1, upper, s); tm.end(3, t);
+            qin = qout; count_in = cout;
+            if (stats) { stats->n_launches_trace++; stats->n_launches_shade++; stats->n_launches_shadow++; }
+        }
+        if (lane_dump) {
+            launch_lane_dump(rp, q, sc->ws.dbg.p, s);
+            HIP_CHECK(hipMemcpyAsync(lane_dump + (b0 - first), sc->ws.dbg.p, (size_t) rp.n_lanes * sizeof(LaneDebug), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        } else {
+            t = tm.begin(4); launch_splat(rp, q, d_film, se.crop_w, se.crop_h, s); tm.end(4, t);
+        }
+        if (stats) {
+            size_t off = h_counts.size(); h_counts.resize(off + 2 * (size_t) it);
+            if (it) { HIP_CHECK(hipMemcpyAsync(h_counts.data() + off, q.counts, 2 * (size_t) it * 4, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s)); }
+            batch_lanes.push_back(rp.n_lanes); batch_iters.push_back(it);
+            stats->n_batches++;
+        }
+    }
+    if (stats) {
+        HIP_CHECK(hipEventRecord(ev1, s)); HIP_CHECK(hipEventSynchronize(ev1));
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); stats->ms_total = ms;
+        (void) hipEventDestroy(ev0); (void) hipEventDestroy(ev1);
+        stats->ms_generate = tm.total(0); stats->ms_trace = tm.total(1); stats->ms_shade = tm.total(2);
+        stats->ms_shadow = tm.total(3); stats->ms_splat = tm.total(4);
+        size_t off = 0;
+        for (size_t b = 0; b < batch_lanes.size(); ++b) {
+            stats->n_paths += batch_lanes[b];
+            uint64_t in = batch_lanes[b];
+            for (uint32_t i = 0; i < batch_iters[b]; ++i) {
+                stats->n_bounces += in; stats->n_shadow_rays += h_counts[off + 2 * i + 1]; in = h_counts[off + 2 * i];
+            }
+            off += 2 * (size_t) batch_iters[b];
+        }
+    } else {
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+    if (sc->stop.load()) throw std::runtime_error("cancelled");
+}
+
+std::map<std::string, std::string> to_map(const char *const *names, const char *const *values, int n) {
+    std::map<std::string, std::string> m;
+    for (int i = 0; i < n; ++i) m[names[i]] = values[i];
+    return m;
+}
+
+PropBag make_bag(const char *plugin, const char *const *names, const char *types, const char *const *values, int n) {
+    PropBag b; b.plugin = plugin ? plugin : "";
+    for (int i = 0; i < n; ++i) {
+        PropValue v; std::string val = values[i];
+        switch (types[i]) {
+            case 'f': v.type = PropValue::Float; v.f = std::stod(val); break;
+            case 'i': v.type = PropValue::Int; v.i = std::stoll(val); break;
+            case 'b': v.type = PropValue::Bool; if (val != "true" && val != "false") throw std::runtime_error("could not parse boolean value \"" + val + "\""); v.b = val == "true"; break;
+            case 's': v.type = PropValue::String; v.s = val; break;
+            default: throw std::runtime_error(std::string("unknown property type '") + types[i] + "'");
+        }
+        b.values[names[i]] = v;
+    }
+    return b;
+}
+
+dtof_scene *finish_scene(HostScene &&hs) {
+    auto sc = new dtof_scene();
+    try {
+        sc->host = std::move(hs);
+        sc->pp = make_plugin_params(sc->host.integrator, sc->host.sampler);
+        if (sc->host.objects.size() >= (1u << 24)) throw std::runtime_error("too many scene objects");
+        for (auto &g : sc->host.groups) if (g.n_shapes > 255) throw std::runtime_error("a shapegroup may hold at most 255 shapes");
+        sc->blob = build_scene_blob(sc->host);
+    } catch (...) { delete sc; throw; }
+    return sc;
+}
+
+}  // namespace
+
+// ================================================================================ C ABI
+extern "C" {
+
+const char *dtof_version(void) { return "dtof 0.1 (HIP, gfx950; dopplertofpath + correlated)"; }
+const char *dtof_last_error(void) { return g_last_error.c_str(); }
+
+int dtof_scene_load_string(const char *xml, const char *const *pn, const char *const *pv, int n, dtof_scene **out) {
+    return guarded([&] {
+        if (!xml || !out) throw std::runtime_error("null argument");
+        *out = finish_scene(load_scene_xml(xml, to_map(pn, pv, n)));
+    });
+}
+int dtof_scene_load_file(const char *path, const char *const *pn, const char *const *pv, int n, dtof_scene **out) {
+    return guarded([&] {
+        if (!path || !out) throw std::runtime_error("null argument");
+        *out = finish_scene(load_scene_xml(read_file(path), to_map(pn, pv, n)));
+    });
+}
+void dtof_scene_destroy(dtof_scene *scene) { delete scene; }
+
+int dtof_scene_set_integrator(dtof_scene *sc, const char *plugin, const char *const *names, const char *types, const char *const *values, int n) {
+    return guarded([&] {
+        if (!sc) throw std::runtime_error("null scene");
+        PropBag b = make_bag(plugin, names, types, values, n);
+        PluginParams p = make_plugin_params(b, sc->host.sampler);
+        sc->host.integrator = b; sc->pp = p;
+    });
+}
+int dtof_scene_set_sampler(dtof_scene *sc, const char *plugin, const char *const *names, const char *types, const char *const *values, int n) {
+    return guarded([&] {
+        if (!sc) throw std::runtime_error("null scene");
+        PropBag b = make_bag(plugin, names, types, values, n);
+        PluginParams p = make_plugin_params(sc->host.integrator, b);
+        sc->host.sampler = b; sc->pp = p;
+    });
+}
+
+int dtof_scene_get_info(const dtof_scene *sc, dtof_scene_info *info) {
+    return guarded([&] {
+        if (!sc || !info) throw std::runtime_error("null argument");
+        const HostSensor &se = sc->host.sensor; const PluginParams &p = sc->pp;
+        const BlobHeader *h = (const BlobHeader *) sc->blob.data();
+        memset(info, 0, sizeof *info);
+        info->film_width = se.film_w; info->film_height = se.film_h; info->crop_x = se.crop_x; info->crop_y = se.crop_y;
+        info->crop_width = se.crop_w; info->crop_height = se.crop_h; info->sample_count = p.sample_count;
+        info->n_shapes = h->n_shapes; info->n_groups = h->n_groups; info->n_objects = h->n_objects; info->n_emitters = h->n_emitters;
+        info->n_triangles = h->n_tris; info->n_bvh_nodes = h->n_nodes; info->scene_blob_bytes = h->total_bytes;
+        info->time = p.time; info->w_g = p.w_g_mhz; info->g_1 = p.g_1; info->g_0 = p.g_0; info->w_s = p.w_s_mhz;
+        info->phase_offset = p.phase_offset; info->hetero_frequency = p.hetero_frequency; info->antithetic_shift = p.antithetic_shift;
+        info->wave_type = p.wave_type; info->low_frequency_component_only = p.low_frequency_component_only;
+        info->time_sampling = p.time_sampling; info->stratify_each_interval = p.stratify_each_interval;
+        info->path_correlation_depth = p.path_correlation_depth; info->max_depth = p.max_depth; info->rr_depth = p.rr_depth;
+        info->base_seed = p.base_seed; info->time_correlate_number = p.time_correlate_number; info->path_correlate_number = p.path_correlate_number;
+    });
+}
+
+int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, size_t *n_written) {
+    return guarded([&] {
+        if (!sc || !n_written) throw std::runtime_error("null argument");
+        std::vector<float> v;
+        if (kind == 0) for (auto &o : sc->host.objects) {
+            v.push_back(o.key_time[0]); v.push_back(o.key_time[1]);
+            v.insert(v.end(), o.key[0], o.key[0] + 16); v.insert(v.end(), o.key[1], o.key[1] + 16);
+        } else if (kind == 1) for (auto &s : sc->host.shapes) {
+            v.insert(v.end(), s.to_world, s.to_world + 16); v.insert(v.end(), s.to_object, s.to_object + 16);
+        } else if (kind == 2) {
+            const HostSensor &s = sc->host.sensor;
+            v.insert(v.end(), s.to_world, s.to_world + 16);
+            v.push_back(s.x_fov); v.push_back(s.near_clip); v.push_back(s.far_clip); v.push_back(s.shutter_open); v.push_back(s.shutter_close);
+        } else if (kind == 3) for (auto &e : sc->host.emitters) {
+            v.insert(v.end(), e.pos, e.pos + 3); v.insert(v.end(), e.intensity, e.intensity + 3);
+        } else throw std::runtime_error("unknown export kind");
+        *n_written = v.size();
+        if (out) { if (v.size() > cap) throw std::runtime_error("export buffer too small"); memcpy(out, v.data(), v.size() * 4); }
+    });
+}
+
+int dtof_render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin, int32_t row_end,
+                     const float *offsets, int n_offsets, float *d_film, dtof_render_stats *stats) {
+    return guarded([&] {
+        if (!sc || !d_film) throw std::runtime_error("null argument");
+        sc->stop = false;
+        render_rows(sc, seed, spp, row_begin, row_end, offsets, n_offsets, d_film, stats);
+    });
+}
+
+int dtof_develop(const float *d_film, float *d_rgb, int64_t n_pixels) {
+    return guarded([&] {
+        if (!d_film || !d_rgb) throw std::runtime_error("null argument");
+        launch_develop(d_film, d_rgb, n_pixels, nullptr);
+        HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(nullptr));
+    });
+}
+
+int dtof_render_offsets(dtof_scene *sc, uint32_t seed, uint32_t spp, const float *offsets, int n_offsets, float *out_rgb, dtof_render_stats *stats) {
+    return guarded([&] {
+        if (!sc || !out_rgb) throw std::runtime_error("null argument");
+        ensure_device(sc);
+        sc->stop = false;
+        int k = n_offsets <= 0 ? 1 : n_offsets;
+        const HostSensor &se = sc->host.sensor;
+        size_t px = (size_t) se.crop_w * se.crop_h;
+        sc->d_film.ensure(px * 4 * k); sc->d_rgb.ensure(px * 3 * k);
+        HIP_CHECK(hipMemsetAsync(sc->d_film.p, 0, px * 4 * k * sizeof(float), sc->stream));
+        render_rows(sc, seed, spp, 0, se.crop_h, offsets, n_offsets, sc->d_film.p, stats);
+        launch_develop(sc->d_film.p, sc->d_rgb.p, (int64_t) px * k, sc->stream);
+        HIP_CHECK(hipMemcpyAsync(out_rgb, sc->d_rgb.p, px * 3 * k * sizeof(float), hipMemcpyDeviceToHost, sc->stream));
+        HIP_CHECK(hipStreamSynchronize(sc->stream));
+    });
+}
+
+int dtof_render(dtof_scene *sc, uint32_t sensor_index, uint32_t seed, uint32_t spp, float *out_rgb, dtof_render_stats *stats) {
+    if (sensor_index != 0) { g_last_error = "Scene::render(): sensor index " + std::to_string(sensor_index) + " is out of bounds!"; return DTOF_ERR_INVALID; }
+    return dtof_render_offsets(sc, seed, spp, nullptr, 0, out_rgb, stats);
+}
+
+void dtof_cancel(dtof_scene *sc) { if (sc) sc->stop = true; }
+
+int dtof_sample_lanes(dtof_scene *sc, uint32_t seed, uint32_t spp, uint64_t lane_begin, uint64_t n, float *out) {
+    return guarded([&] {
+        if (!sc || !out) throw std::runtime_error("null argument");
+        static_assert(sizeof(LaneDebug) == 48, "LaneDebug is 12 floats");
+        sc->stop = false;
+        if (n == 0) return;
+        render_rows(sc, seed, spp, 0, 0, nullptr, 0, nullptr, nullptr, (LaneDebug *) out, lane_begin, n);
+    });
+}
+
+// ---------------------------------------------------------------- sampler
+static RenderParams sampler_params(const dtof_sampler *s) {
+    RenderParams rp; memset(&rp, 0, sizeof rp);
+    rp.base_seed = s->base_seed; rp.seed = s->seed; rp.seed_value = s->base_seed + s->seed;
+    rp.spp = s->spw; rp.tcn = (uint32_t) s->tcn; rp.pcn = (uint32_t) s->pcn;
+    rp.n_stratum = s->sample_count / (uint32_t) s->tcn;
+    rp.inv_n_stratum = rp.n_stratum ? 1.0f / (float) (int) rp.n_stratum : 0.f;
+    rp.inv_tcn = 1.0f / (float) s->tcn;
+    return rp;
+}
+static SamplerState sampler_state(dtof_sampler *s) {
+    SamplerState st; st.rng = s->rng.p; st.rng_time = s->rng_time.p; st.rng_path = s->rng_path.p; st.perm_seed = s->perm.p; st.dim = s->dim.p; st.n = s->wavefront;
+    return st;
+}
+static void need_seeded(const dtof_sampler *s) { if (!s) throw std::runtime_error("null sampler"); if (!s->seeded) throw std::runtime_error("sampler is not seeded"); }
+
+int dtof_sampler_create(uint32_t sample_count, uint32_t base_seed, int32_t tcn, int32_t pcn, dtof_sampler **out) {
+    return guarded([&] {
+        if (!out) throw std::runtime_error("null argument");
+        if (tcn <= 0 || pcn <= 0) throw std::runtime_error("correlate numbers must be positive");
+        auto s = new dtof_sampler(); s->sample_count = sample_count; s->base_seed = base_seed; s->tcn = tcn; s->pcn = pcn;
+        *out = s;
+    });
+}
+void dtof_sampler_destroy(dtof_sampler *s) { delete s; }
+int dtof_sampler_set_samples_per_wavefront(dtof_sampler *s, uint32_t spw) {
+    return guarded([&] {
+        if (!s) throw std::runtime_error("null sampler");
+        if (spw == 0 || s->sample_count % spw != 0) throw std::runtime_error("sample_count should be a multiple of samples_per_wavefront!");
+        s->spw = spw;
+    });
+}
+int dtof_sampler_seed(dtof_sampler *s, uint32_t seed, uint32_t wavefront_size) {
+    return guarded([&] {
+        if (!s) throw std::runtime_error("null sampler");
+        if (wavefront_size == 0xffffffffu) { if (s->wavefront == 0) throw std::runtime_error("Sampler::seed(): wavefront_size should be specified!"); }
+        else s->wavefront = wavefront_size;
+        s->seed = seed; s->sample_index = 0;
+        uint32_t n = s->wavefront;
+        s->rng.ensure(n); s->rng_time.ensure(n); s->rng_path.ensure(n); s->perm.ensure(n); s->dim.ensure(n); s->out.ensure(2 * (size_t) n); s->flags.ensure(n);
+        launch_sampler_seed(sampler_params(s), sampler_state(s), nullptr);
+        HIP_CHECK(hipGetLastError()); HIP_CHECK(hipDeviceSynchronize());
+        s->seeded = true;
+    });
+}
+int dtof_sampler_advance(dtof_sampler *s) {
+    return guarded([&] { need_seeded(s); s->sample_index++; HIP_CHECK(hipMemset(s->dim.p, 0, (size_t) s->wavefront * 4)); });
+}
+static void sampler_draw(dtof_sampler *s, const uint8_t *correlate, int all, int mode, float *out, int stride, int offset) {
+    uint32_t n = s->wavefront;
+    if (correlate) HIP_CHECK(hipMemcpy(s->flags.p, correlate, n, hipMemcpyHostToDevice));
+    if (mode == 0) launch_sampler_next_1d(sampler_params(s), sampler_state(s), s->out.p, nullptr);
+    else launch_sampler_next_correlate(sampler_params(s), sampler_state(s), correlate ? s->flags.p : nullptr, all, s->out.p, nullptr);
+    HIP_CHECK(hipGetLastError());
+    std::vector<float> tmp(n);
+    HIP_CHECK(hipMemcpy(tmp.data(), s->out.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) out[(size_t) i * stride + offset] = tmp[i];
+}
+int dtof_sampler_next_1d(dtof_sampler *s, float *out) { return guarded([&] { need_seeded(s); sampler_draw(s, nullptr, 0, 0, out, 1, 0); }); }
+int dtof_sampler_next_2d(dtof_sampler *s, float *out) {
+    return guarded([&] { need_seeded(s); sampler_draw(s, nullptr, 0, 0, out, 2, 0); sampler_draw(s, nullptr, 0, 0, out, 2, 1); });
+}
+int dtof_sampler_next_1d_correlate(dtof_sampler *s, const uint8_t *c, int all, float *out) {
+    return guarded([&] { need_seeded(s); sampler_draw(s, c, all, 1, out, 1, 0); });
+}
+int dtof_sampler_next_2d_correlate(dtof_sampler *s, const uint8_t *c, int all, float *out) {
+    return guarded([&] { need_seeded(s); sampler_draw(s, c, all, 1, out, 2, 0); sampler_draw(s, c, all, 1, out, 2, 1); });
+}
+int dtof_sampler_next_1d_time(dtof_sampler *s, int strategy, float shift, int stratify, float *out) {
+    return guarded([&] {
+        need_seeded(s);
+        if (strategy < 0 || strategy > 3) throw std::runtime_error("unknown time sampling strategy");
+        RenderParams rp = sampler_params(s); rp.time_sampling = strategy; rp.antithetic_shift = shift; rp.stratify = stratify;
+        launch_sampler_next_time(rp, sampler_state(s), s->sample_index * s->spw, s->out.p, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(out, s->out.p, (size_t) s->wavefront * 4, hipMemcpyDeviceToHost));
+    });
+}
+int dtof_sampler_get_state(dtof_sampler *s, uint32_t *out7) {
+    return guarded([&] {
+        need_seeded(s);
+        uint32_t n = s->wavefront; std::vector<uint2> a(n), b(n), c(n); std::vector<uint32_t> p(n);
+        HIP_CHECK(hipMemcpy(a.data(), s->rng.p, (size_t) n * 8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(b.data(), s->rng_time.p, (size_t) n * 8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(c.data(), s->rng_path.p, (size_t) n * 8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(p.data(), s->perm.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t *o = out7 + 7 * (size_t) i;
+            o[0] = a[i].x; o[1] = a[i].y; o[2] = b[i].x; o[3] = b[i].y; o[4] = c[i].x; o[5] = c[i].y; o[6] = p[i];
+        }
+    });
+}
+uint32_t dtof_sampler_wavefront_size(const dtof_sampler *s) { return s ? s->wavefront : 0; }
+uint32_t dtof_sampler_sample_count(const dtof_sampler *s) { return s ? s->sample_count : 0; }
+
+int dtof_eval_modulation(dtof_scene *sc, int mode, const float *t, const float *len, float *out, uint32_t n) {
+    return guarded([&] {
+        if (!sc || !t || !out || (mode == 0 && !len)) throw std::runtime_error("null argument");
+        if (mode < 0 || mode > 2) throw std::runtime_error("unknown mode");
+        RenderParams rp = make_params(sc, 0, sc->pp.sample_count ? sc->pp.sample_count : 1, nullptr, 0);
+        DevBuf<float> dt, dl, dout; dt.ensure(n); dl.ensure(n); dout.ensure(n);
+        HIP_CHECK(hipMemcpy(dt.p, t, (size_t) n * 4, hipMemcpyHostToDevice));
+        if (len) HIP_CHECK(hipMemcpy(dl.p, len, (size_t) n * 4, hipMemcpyHostToDevice));
+        launch_waveform_eval(rp, dt.p, dl.p, dout.p, mode, n, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(out, dout.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+}  // extern "C"

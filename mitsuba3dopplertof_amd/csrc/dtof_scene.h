@@ -1,0 +1,129 @@
+// dtof_scene.h -- host-side scene description, plugin parameters, and the flat device
+// "scene blob" the HIP kernels traverse.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <stdexcept>
+
+namespace dtof {
+
+// ---------------------------------------------------------------------------- enums
+enum ShapeKind : uint32_t { SHAPE_RECT = 0, SHAPE_MESH = 1 };
+enum ObjectKind : uint32_t { OBJ_SHAPE = 0, OBJ_INSTANCE = 1 };
+enum WaveType : int32_t { WAVE_SIN = 0, WAVE_RECT = 1, WAVE_TRI = 2, WAVE_TRAP = 3 };
+// ETimeSampling -- include/mitsuba/render/sampler.h:27-34
+enum TimeSampling : int32_t { TIME_UNIFORM = 0, TIME_STRATIFIED = 1, TIME_ANTITHETIC = 2, TIME_ANTITHETIC_MIRROR = 3 };
+enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1 };
+enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4 };
+
+// ---------------------------------------------------------------------------- device blob records
+// One contiguous byte blob (offsets from its base) so that small scenes can be staged
+// whole into LDS and large ones can stage just the top of the TLAS.
+struct BlobHeader {
+    uint32_t n_nodes, n_objects, n_groups, n_shapes, n_tris, n_emitters;
+    uint32_t off_nodes, off_objects, off_groups, off_shapes, off_tris, off_shading, off_emitters;
+    uint32_t total_bytes, has_instances, pad1;
+};
+static_assert(sizeof(BlobHeader) == 64, "BlobHeader");
+
+constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr uint32_t kNoChild = 0xffffffffu;
+// TLAS node (64 B): the bounds of BOTH children live in the parent, so one fetch decides both
+// descents.  child = kLeafFlag | object index for a leaf, inner-node index otherwise, kNoChild if absent.
+struct BvhNode {
+    float lmin[3]; uint32_t left;
+    float lmax[3]; uint32_t right;
+    float rmin[3]; uint32_t pad0;
+    float rmax[3]; uint32_t pad1;
+};
+struct DObject {            // 128 B
+    uint32_t kind, index, n_keys; float t0;
+    float t1, pad[3];
+    float key0[12], key1[12];
+};
+struct DGroup { uint32_t first_shape, n_shapes, pad[2]; };
+struct DShape {             // 176 B
+    uint32_t kind, flags, first_tri, n_tris;
+    float refl[3], pad0;
+    float to_world[12], to_object[12];
+    float n[3], pad1, dp_du[3], pad2, dp_dv[3], pad3;   // rectangle frame (Rectangle::update, rectangle.cpp:101-113)
+};
+struct DTri { float p0[4], p1[4], p2[4]; };                              // 48 B
+struct DTriShade { float n0[3], n1[3], n2[3], uv0[2], uv1[2], uv2[2], pad; };   // 64 B
+struct DEmitter { uint32_t kind; float pos[3]; float intensity[3]; float pad; };
+static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 176 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64, "blob records");
+
+// ---------------------------------------------------------------------------- host description
+struct Mat4d { double m[16]; };   // row-major
+
+struct HostShape {
+    uint32_t kind = SHAPE_RECT;
+    bool twosided = false, flip_normals = false, face_normals = false;
+    float refl[3] = { .5f, .5f, .5f };
+    float to_world[16], to_object[16];     // float casts of the double transform and its double inverse
+    // mesh (cube): baked like src/shapes/cube.cpp:114-160
+    std::vector<float> positions, normals, texcoords;
+    std::vector<uint32_t> faces;
+    std::string id;
+};
+struct HostGroup { uint32_t first_shape = 0, n_shapes = 0; };
+struct HostObject {
+    uint32_t kind = OBJ_SHAPE, index = 0, n_keys = 0;
+    float key_time[2] = { 0, 0 };
+    float key[2][16];
+};
+struct HostEmitter { uint32_t kind = 0; float pos[3]; float intensity[3]; };
+struct HostSensor {
+    float to_world[16];
+    float x_fov = 0, near_clip = 1e-2f, far_clip = 1e4f, shutter_open = 0, shutter_close = 0;
+    int32_t film_w = 768, film_h = 576, crop_x = 0, crop_y = 0, crop_w = 768, crop_h = 576;
+    int32_t filter = FILTER_TENT; float filter_radius = 1.f;
+};
+
+// A typed property bag (what the reference's Properties carries for a plugin).
+struct PropValue { enum Type { Float, Int, Bool, String } type; double f = 0; int64_t i = 0; bool b = false; std::string s; };
+struct PropBag {
+    std::string plugin;
+    std::map<std::string, PropValue> values;
+    mutable std::map<std::string, bool> queried;
+    bool has(const std::string &n) const { return values.count(n) != 0; }
+    double get_float(const std::string &n, double def) const;
+    int64_t get_int(const std::string &n, int64_t def) const;
+    bool get_bool(const std::string &n, bool def) const;
+    std::string get_string(const std::string &n, const std::string &def) const;
+    std::vector<std::string> unqueried() const;
+};
+
+// Constructor-time parameters of DopplerToFPathIntegrator (+ bases) and CorrelatedSampler, rounded
+// exactly as the reference's constructors round them.
+struct PluginParams {
+    // src/integrators/dopplertofpath.cpp:19-57
+    float time = 0.0015f, w_g_mhz = 30.f, g_1 = .5f, g_0 = .5f, w_s_mhz = 30.f, phase_offset = 0.f, hetero_frequency = 0.f;
+    int32_t wave_type = WAVE_SIN; bool low_frequency_component_only = true;
+    // src/render/integrator.cpp:22-28, 54-100, 568-585
+    int32_t time_sampling = TIME_ANTITHETIC; float antithetic_shift = .5f; bool stratify_each_interval = true;
+    uint32_t path_correlation_depth = 0, max_depth = 0xffffffffu, rr_depth = 5; bool hide_emitters = false;
+    // src/samplers/correlated.cpp:17-23, src/render/sampler.cpp:11-20
+    uint32_t base_seed = 0, sample_count = 4; int32_t time_correlate_number = 2, path_correlate_number = 2;
+};
+PluginParams make_plugin_params(const PropBag &integrator, const PropBag &sampler);   // throws std::runtime_error
+
+struct HostScene {
+    std::vector<HostShape> shapes;
+    std::vector<HostGroup> groups;
+    std::vector<HostObject> objects;
+    std::vector<HostEmitter> emitters;
+    HostSensor sensor;
+    PropBag integrator, sampler;
+};
+
+// XML front end (scene_loader.cpp): the tag subset of SURVEY §8a row X1.
+HostScene load_scene_xml(const std::string &text, const std::map<std::string, std::string> &params);
+std::string read_file(const std::string &path);
+
+// Blob + BVH (scene_build.cpp)
+std::vector<uint8_t> build_scene_blob(const HostScene &scene);
+
+}  // namespace dtof

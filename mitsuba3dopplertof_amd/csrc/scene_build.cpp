@@ -1,0 +1,210 @@
+// scene_build.cpp -- flattens a HostScene into the device scene blob and builds the
+// top-level BVH (TLAS) over scene objects.
+//
+// Instance bounds follow Instance::bbox (src/shapes/instance.cpp:101-114): the union of the
+// shapegroup's 8 bbox corners transformed by the first and the last keyframe.  Because the
+// per-ray transform is the component-wise lerp of the two keyframe matrices
+// (include/mitsuba/core/transform.h:462-466), a point's position at any time is the lerp of
+// its two end positions, so that union bounds the whole motion.
+#include "dtof_scene.h"
+#include "dtof_math.h"
+#include <algorithm>
+#include <cstring>
+#include <cfloat>
+#include <numeric>
+
+namespace dtof {
+
+struct Box {
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    void add(V3 p) { lo[0] = std::min(lo[0], p.x); lo[1] = std::min(lo[1], p.y); lo[2] = std::min(lo[2], p.z);
+                     hi[0] = std::max(hi[0], p.x); hi[1] = std::max(hi[1], p.y); hi[2] = std::max(hi[2], p.z); }
+    void add(const Box &b) { for (int i = 0; i < 3; ++i) { lo[i] = std::min(lo[i], b.lo[i]); hi[i] = std::max(hi[i], b.hi[i]); } }
+    float area() const { float d[3] = { hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2] }; return 2.f * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]); }
+    bool valid() const { return lo[0] <= hi[0]; }
+    V3 corner(int i) const { return mk(i & 1 ? hi[0] : lo[0], i & 2 ? hi[1] : lo[1], i & 4 ? hi[2] : lo[2]); }
+    // conservative padding so that slab-test rounding can never cull a primitive lying on a face
+    void pad() {
+        for (int i = 0; i < 3; ++i) {
+            float e = std::max(std::max(std::fabs(lo[i]), std::fabs(hi[i])), hi[i] - lo[i]) * 1e-5f + 1e-6f;
+            lo[i] -= e; hi[i] += e;
+        }
+    }
+};
+
+static Box shape_box(const HostShape &s) {
+    Box b;
+    if (s.kind == SHAPE_RECT) {   // Rectangle::bbox, src/shapes/rectangle.cpp:115-125
+        const float c[4][2] = { { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+        for (auto &k : c) b.add(xf_point(s.to_world, mk(k[0], k[1], 0.f)));
+    } else {
+        for (size_t i = 0; i + 2 < s.positions.size(); i += 3) b.add(mk(s.positions[i], s.positions[i + 1], s.positions[i + 2]));
+    }
+    return b;
+}
+
+struct BuildItem { Box box; float c[3]; uint32_t obj; };
+
+static uint32_t build_node(std::vector<BvhNode> &nodes, std::vector<BuildItem> &items, size_t b, size_t e);
+
+static uint32_t child_ref(std::vector<BvhNode> &nodes, std::vector<BuildItem> &items, size_t b, size_t e) {
+    if (e - b == 1) return kLeafFlag | items[b].obj;
+    return build_node(nodes, items, b, e);
+}
+
+// binned SAH split over centroids (16 bins), falling back to a median split
+static uint32_t build_node(std::vector<BvhNode> &nodes, std::vector<BuildItem> &items, size_t b, size_t e) {
+    uint32_t idx = (uint32_t) nodes.size();
+    nodes.emplace_back();
+    Box cb;
+    for (size_t i = b; i < e; ++i) cb.add(mk(items[i].c[0], items[i].c[1], items[i].c[2]));
+    int best_axis = -1, best_bin = -1; float best_cost = FLT_MAX;
+    constexpr int NB = 16;
+    for (int ax = 0; ax < 3; ++ax) {
+        float lo = cb.lo[ax], ext = cb.hi[ax] - cb.lo[ax];
+        if (!(ext > 0.f)) continue;
+        Box bb[NB]; int cnt[NB] = { 0 };
+        for (size_t i = b; i < e; ++i) {
+            int k = std::min(NB - 1, (int) ((items[i].c[ax] - lo) / ext * NB));
+            bb[k].add(items[i].box); cnt[k]++;
+        }
+        Box acc; int n = 0; float la[NB]; int ln[NB];
+        for (int k = 0; k < NB; ++k) { acc.add(bb[k]); n += cnt[k]; la[k] = n ? acc.area() : 0.f; ln[k] = n; }
+        Box racc; int rn = 0;
+        for (int k = NB - 1; k >= 1; --k) {
+            racc.add(bb[k]); rn += cnt[k];
+            if (ln[k - 1] == 0 || rn == 0) continue;
+            float cost = la[k - 1] * ln[k - 1] + racc.area() * rn;
+            if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = k; }
+        }
+    }
+    size_t mid;
+    if (best_axis >= 0) {
+        float lo = cb.lo[best_axis], ext = cb.hi[best_axis] - cb.lo[best_axis]; int ax = best_axis, bin = best_bin;
+        auto it = std::stable_partition(items.begin() + b, items.begin() + e, [&](const BuildItem &it2) {
+            return std::min(NB - 1, (int) ((it2.c[ax] - lo) / ext * NB)) < bin; });
+        mid = (size_t) (it - items.begin());
+    } else {
+        mid = (b + e) / 2;
+    }
+    if (mid == b || mid == e) mid = (b + e) / 2;
+    Box lb, rb;
+    for (size_t i = b; i < mid; ++i) lb.add(items[i].box);
+    for (size_t i = mid; i < e; ++i) rb.add(items[i].box);
+    uint32_t l = child_ref(nodes, items, b, mid), r = child_ref(nodes, items, mid, e);
+    BvhNode &n = nodes[idx];
+    for (int i = 0; i < 3; ++i) { n.lmin[i] = lb.lo[i]; n.lmax[i] = lb.hi[i]; n.rmin[i] = rb.lo[i]; n.rmax[i] = rb.hi[i]; }
+    n.left = l; n.right = r; n.pad0 = n.pad1 = 0;
+    return idx;
+}
+
+static uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
+
+std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
+    // ---- shapes / triangles
+    std::vector<DShape> shapes(sc.shapes.size());
+    std::vector<DTri> tris; std::vector<DTriShade> shading;
+    std::vector<Box> shape_boxes(sc.shapes.size());
+    for (size_t i = 0; i < sc.shapes.size(); ++i) {
+        const HostShape &h = sc.shapes[i]; DShape &d = shapes[i];
+        memset(&d, 0, sizeof d);
+        d.kind = h.kind;
+        d.flags = (h.twosided ? SF_TWOSIDED : 0) | (h.flip_normals ? SF_FLIP_NORMALS : 0) | (h.face_normals ? SF_FACE_NORMALS : 0);
+        memcpy(d.refl, h.refl, 12);
+        memcpy(d.to_world, h.to_world, 48); memcpy(d.to_object, h.to_object, 48);
+        if (h.kind == SHAPE_RECT) {   // Rectangle::update, rectangle.cpp:101-113
+            V3 du = xf_vector(h.to_world, mk(2.f, 0.f, 0.f)), dv = xf_vector(h.to_world, mk(0.f, 2.f, 0.f));
+            V3 n = normalize(xf_normal(h.to_object, mk(0.f, 0.f, 1.f)));
+            d.n[0] = n.x; d.n[1] = n.y; d.n[2] = n.z;
+            d.dp_du[0] = du.x; d.dp_du[1] = du.y; d.dp_du[2] = du.z;
+            d.dp_dv[0] = dv.x; d.dp_dv[1] = dv.y; d.dp_dv[2] = dv.z;
+        } else {
+            d.first_tri = (uint32_t) tris.size(); d.n_tris = (uint32_t) (h.faces.size() / 3);
+            for (uint32_t f = 0; f < d.n_tris; ++f) {
+                DTri t; DTriShade s; memset(&t, 0, sizeof t); memset(&s, 0, sizeof s);
+                const uint32_t *fi = &h.faces[3 * f];
+                float *tp[3] = { t.p0, t.p1, t.p2 }; float *sn[3] = { s.n0, s.n1, s.n2 }; float *su[3] = { s.uv0, s.uv1, s.uv2 };
+                for (int k = 0; k < 3; ++k) {
+                    memcpy(tp[k], &h.positions[3 * fi[k]], 12);
+                    if (!h.normals.empty()) memcpy(sn[k], &h.normals[3 * fi[k]], 12);
+                    if (!h.texcoords.empty()) memcpy(su[k], &h.texcoords[2 * fi[k]], 8);
+                }
+                tris.push_back(t); shading.push_back(s);
+            }
+        }
+        shape_boxes[i] = shape_box(h);
+    }
+    // ---- groups
+    std::vector<DGroup> groups(sc.groups.size());
+    std::vector<Box> group_boxes(sc.groups.size());
+    for (size_t g = 0; g < sc.groups.size(); ++g) {
+        groups[g].first_shape = sc.groups[g].first_shape; groups[g].n_shapes = sc.groups[g].n_shapes; groups[g].pad[0] = groups[g].pad[1] = 0;
+        for (uint32_t k = 0; k < sc.groups[g].n_shapes; ++k) group_boxes[g].add(shape_boxes[sc.groups[g].first_shape + k]);
+    }
+    // ---- objects + TLAS items
+    std::vector<DObject> objects(sc.objects.size());
+    std::vector<BuildItem> items;
+    bool has_instances = false;
+    for (size_t i = 0; i < sc.objects.size(); ++i) {
+        const HostObject &h = sc.objects[i]; DObject &d = objects[i];
+        memset(&d, 0, sizeof d);
+        d.kind = h.kind; d.index = h.index; d.n_keys = h.n_keys; d.t0 = h.key_time[0]; d.t1 = h.key_time[1];
+        memcpy(d.key0, h.key[0], 48); memcpy(d.key1, h.key[1], 48);
+        Box b;
+        if (h.kind == OBJ_SHAPE) b = shape_boxes[h.index];
+        else {
+            has_instances = true;
+            const Box &gb = group_boxes[h.index];
+            if (gb.valid()) for (int c = 0; c < 8; ++c) {
+                b.add(xf_point(h.key[0], gb.corner(c)));
+                if (h.n_keys > 1) b.add(xf_point(h.key[1], gb.corner(c)));
+            }
+        }
+        if (!b.valid()) continue;   // empty shapegroup: never hit
+        b.pad();
+        BuildItem it; it.box = b; it.obj = (uint32_t) i;
+        for (int k = 0; k < 3; ++k) it.c[k] = 0.5f * (b.lo[k] + b.hi[k]);
+        items.push_back(it);
+    }
+    std::vector<BvhNode> nodes;
+    if (items.size() == 1) {
+        BvhNode n; memset(&n, 0, sizeof n);
+        for (int i = 0; i < 3; ++i) { n.lmin[i] = items[0].box.lo[i]; n.lmax[i] = items[0].box.hi[i]; n.rmin[i] = FLT_MAX; n.rmax[i] = -FLT_MAX; }
+        n.left = kLeafFlag | items[0].obj; n.right = kNoChild;
+        nodes.push_back(n);
+    } else if (items.size() > 1) {
+        build_node(nodes, items, 0, items.size());
+    }
+    // ---- emitters
+    std::vector<DEmitter> emitters(sc.emitters.size());
+    for (size_t i = 0; i < sc.emitters.size(); ++i) {
+        emitters[i].kind = sc.emitters[i].kind; emitters[i].pad = 0;
+        memcpy(emitters[i].pos, sc.emitters[i].pos, 12); memcpy(emitters[i].intensity, sc.emitters[i].intensity, 12);
+    }
+    // ---- pack: nodes first (so that "the first N bytes" = header + top of the TLAS in BFS-ish order)
+    BlobHeader h; memset(&h, 0, sizeof h);
+    h.n_nodes = (uint32_t) nodes.size(); h.n_objects = (uint32_t) objects.size(); h.n_groups = (uint32_t) groups.size();
+    h.n_shapes = (uint32_t) shapes.size(); h.n_tris = (uint32_t) tris.size(); h.n_emitters = (uint32_t) emitters.size();
+    h.has_instances = has_instances;
+    uint32_t off = sizeof(BlobHeader);
+    h.off_nodes = off;    off = align16(off + (uint32_t) (nodes.size() * sizeof(BvhNode)));
+    h.off_objects = off;  off = align16(off + (uint32_t) (objects.size() * sizeof(DObject)));
+    h.off_groups = off;   off = align16(off + (uint32_t) (groups.size() * sizeof(DGroup)));
+    h.off_shapes = off;   off = align16(off + (uint32_t) (shapes.size() * sizeof(DShape)));
+    h.off_emitters = off; off = align16(off + (uint32_t) (emitters.size() * sizeof(DEmitter)));
+    h.off_tris = off;     off = align16(off + (uint32_t) (tris.size() * sizeof(DTri)));
+    h.off_shading = off;  off = align16(off + (uint32_t) (shading.size() * sizeof(DTriShade)));
+    h.total_bytes = off;
+    std::vector<uint8_t> blob(off, 0);
+    memcpy(blob.data(), &h, sizeof h);
+    if (!nodes.empty()) memcpy(blob.data() + h.off_nodes, nodes.data(), nodes.size() * sizeof(BvhNode));
+    if (!objects.empty()) memcpy(blob.data() + h.off_objects, objects.data(), objects.size() * sizeof(DObject));
+    if (!groups.empty()) memcpy(blob.data() + h.off_groups, groups.data(), groups.size() * sizeof(DGroup));
+    if (!shapes.empty()) memcpy(blob.data() + h.off_shapes, shapes.data(), shapes.size() * sizeof(DShape));
+    if (!emitters.empty()) memcpy(blob.data() + h.off_emitters, emitters.data(), emitters.size() * sizeof(DEmitter));
+    if (!tris.empty()) memcpy(blob.data() + h.off_tris, tris.data(), tris.size() * sizeof(DTri));
+    if (!shading.empty()) memcpy(blob.data() + h.off_shading, shading.data(), shading.size() * sizeof(DTriShade));
+    return blob;
+}
+
+}  // namespace dtof

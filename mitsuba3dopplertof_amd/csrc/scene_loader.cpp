@@ -1,0 +1,653 @@
+// scene_loader.cpp -- scene.xml front end for the Doppler-ToF hot path.
+//
+// Implements the subset of Mitsuba 3's scene format that the reference's hot path
+// consumes, with the reference's semantics (paths relative to the reference root):
+//   <default>/$param substitution             src/core/xml.cpp:441-456, 630-648
+//   <transform>/<animation> composition       src/core/xml.cpp:882-1007 (ops left-multiply, double precision)
+//   <rgb>                                     src/core/xml.cpp:792-822
+//   animated shape -> shapegroup + instance   src/core/xml.cpp:1165-1195
+//   keyframes cast to float32                 src/core/transform.cpp:22-36, include/mitsuba/core/transform.h:384
+//   plugin constructors                       src/integrators/dopplertofpath.cpp:19-57, src/render/integrator.cpp:54-100,568-585,
+//                                             src/samplers/correlated.cpp:17-23, src/render/sampler.cpp:11-20,
+//                                             src/render/sensor.cpp:14-20,127-203, src/sensors/perspective.cpp:139-152,
+//                                             src/render/film.cpp:7-54, src/rfilters/tent.cpp:47-55, src/shapes/cube.cpp:114-160,
+//                                             src/shapes/rectangle.cpp:91-113
+// Unsupported plugins / tags raise std::runtime_error (surfaced through the C ABI as a
+// status code + dtof_last_error()).
+#include "dtof_scene.h"
+#include "dtof_math.h"
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <memory>
+#include <algorithm>
+
+namespace dtof {
+
+[[noreturn]] static void fail(const std::string &msg) { throw std::runtime_error(msg); }
+
+// ---------------------------------------------------------------------------- tiny XML DOM
+struct XNode {
+    std::string tag;
+    std::vector<std::pair<std::string, std::string>> attrs;
+    std::vector<std::unique_ptr<XNode>> children;
+    const std::string *attr(const char *n) const {
+        for (auto &a : attrs) if (a.first == n) return &a.second;
+        return nullptr;
+    }
+    std::string get(const char *n, const std::string &def = "") const { auto *a = attr(n); return a ? *a : def; }
+};
+
+struct XParser {
+    const std::string &s; size_t p = 0;
+    explicit XParser(const std::string &text) : s(text) {}
+    void skip_ws() { while (p < s.size() && isspace((unsigned char) s[p])) ++p; }
+    bool starts(const char *lit) const { return s.compare(p, strlen(lit), lit) == 0; }
+    void skip_misc() {
+        for (;;) {
+            skip_ws();
+            if (starts("<!--")) { size_t e = s.find("-->", p); if (e == std::string::npos) fail("xml: unterminated comment"); p = e + 3; }
+            else if (starts("<?")) { size_t e = s.find("?>", p); if (e == std::string::npos) fail("xml: unterminated declaration"); p = e + 2; }
+            else if (starts("<!DOCTYPE")) { size_t e = s.find('>', p); if (e == std::string::npos) fail("xml: bad doctype"); p = e + 1; }
+            else break;
+        }
+    }
+    static std::string unescape(const std::string &v) {
+        std::string o; o.reserve(v.size());
+        for (size_t i = 0; i < v.size(); ++i) {
+            if (v[i] == '&') {
+                if (!v.compare(i, 4, "&lt;")) { o += '<'; i += 3; }
+                else if (!v.compare(i, 4, "&gt;")) { o += '>'; i += 3; }
+                else if (!v.compare(i, 5, "&amp;")) { o += '&'; i += 4; }
+                else if (!v.compare(i, 6, "&quot;")) { o += '"'; i += 5; }
+                else if (!v.compare(i, 6, "&apos;")) { o += '\''; i += 5; }
+                else o += v[i];
+            } else o += v[i];
+        }
+        return o;
+    }
+    std::string name() {
+        size_t b = p;
+        while (p < s.size() && (isalnum((unsigned char) s[p]) || s[p] == '_' || s[p] == '-' || s[p] == ':' || s[p] == '.')) ++p;
+        if (p == b) fail("xml: expected a name at offset " + std::to_string(p));
+        return s.substr(b, p - b);
+    }
+    std::unique_ptr<XNode> element() {
+        if (p >= s.size() || s[p] != '<') fail("xml: expected '<' at offset " + std::to_string(p));
+        ++p;
+        auto n = std::make_unique<XNode>();
+        n->tag = name();
+        for (;;) {
+            skip_ws();
+            if (p >= s.size()) fail("xml: unexpected end of input in <" + n->tag + ">");
+            if (s[p] == '/') { if (p + 1 >= s.size() || s[p + 1] != '>') fail("xml: malformed tag"); p += 2; return n; }
+            if (s[p] == '>') { ++p; break; }
+            std::string an = name();
+            skip_ws();
+            if (p >= s.size() || s[p] != '=') fail("xml: expected '=' after attribute " + an);
+            ++p; skip_ws();
+            char q = p < s.size() ? s[p] : 0;
+            if (q != '"' && q != '\'') fail("xml: expected quoted value for attribute " + an);
+            size_t e = s.find(q, p + 1);
+            if (e == std::string::npos) fail("xml: unterminated attribute value");
+            n->attrs.emplace_back(an, unescape(s.substr(p + 1, e - p - 1)));
+            p = e + 1;
+        }
+        for (;;) {
+            skip_misc();
+            if (p >= s.size()) fail("xml: missing </" + n->tag + ">");
+            if (starts("</")) {
+                p += 2; std::string cn = name(); skip_ws();
+                if (cn != n->tag || p >= s.size() || s[p] != '>') fail("xml: mismatched closing tag </" + cn + "> for <" + n->tag + ">");
+                ++p; return n;
+            }
+            if (s[p] != '<') fail("unexpected content");   // xml.cpp:463-464
+            n->children.push_back(element());
+        }
+    }
+    std::unique_ptr<XNode> document() { skip_misc(); auto r = element(); skip_misc(); return r; }
+};
+
+// ---------------------------------------------------------------------------- double 4x4 helpers
+static Mat4d m_identity() { Mat4d r; for (int i = 0; i < 16; ++i) r.m[i] = (i % 5 == 0) ? 1.0 : 0.0; return r; }
+static Mat4d m_mul(const Mat4d &a, const Mat4d &b) {
+    Mat4d r;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        double s = 0; for (int k = 0; k < 4; ++k) s += a.m[4 * i + k] * b.m[4 * k + j];
+        r.m[4 * i + j] = s;
+    }
+    return r;
+}
+// Gauss-Jordan with partial pivoting (the reference keeps analytic inverses for translate/scale/rotate
+// and inverts <matrix> values numerically in double; either way the float32 cast below agrees)
+static Mat4d m_inverse(const Mat4d &a) {
+    double w[4][8];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { w[i][j] = a.m[4 * i + j]; w[i][4 + j] = i == j; }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r) if (std::fabs(w[r][c]) > std::fabs(w[piv][c])) piv = r;
+        if (w[piv][c] == 0.0) fail("singular transformation matrix");
+        if (piv != c) for (int j = 0; j < 8; ++j) std::swap(w[piv][j], w[c][j]);
+        double d = 1.0 / w[c][c];
+        for (int j = 0; j < 8; ++j) w[c][j] *= d;
+        for (int r = 0; r < 4; ++r) if (r != c) { double f = w[r][c]; if (f != 0.0) for (int j = 0; j < 8; ++j) w[r][j] -= f * w[c][j]; }
+    }
+    Mat4d r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[4 * i + j] = w[i][4 + j];
+    return r;
+}
+static void to_f32(const Mat4d &a, float *out) { for (int i = 0; i < 16; ++i) out[i] = (float) a.m[i]; }
+
+static std::vector<std::string> tokenize(const std::string &v) {   // string::tokenize(value, ", ")
+    std::vector<std::string> t; std::string cur;
+    for (char c : v) { if (c == ',' || isspace((unsigned char) c)) { if (!cur.empty()) { t.push_back(cur); cur.clear(); } } else cur += c; }
+    if (!cur.empty()) t.push_back(cur);
+    return t;
+}
+static double parse_double(const std::string &v) {
+    size_t pos = 0; double d;
+    try { d = std::stod(v, &pos); } catch (...) { fail("could not parse floating point value \"" + v + "\""); }
+    while (pos < v.size() && isspace((unsigned char) v[pos])) ++pos;
+    if (pos != v.size()) fail("could not parse floating point value \"" + v + "\"");
+    return d;
+}
+static int64_t parse_int(const std::string &v) {
+    size_t pos = 0; long long d;
+    try { d = std::stoll(v, &pos); } catch (...) { fail("could not parse integer value \"" + v + "\""); }
+    while (pos < v.size() && isspace((unsigned char) v[pos])) ++pos;
+    if (pos != v.size()) fail("could not parse integer value \"" + v + "\"");
+    return d;
+}
+static void parse_xyz(const XNode &n, double def, double out[3]) {   // detail::expand_value_to_xyz + parse_vector
+    if (auto *v = n.attr("value")) {
+        auto t = tokenize(*v);
+        if (t.size() == 1) { t.push_back(t[0]); t.push_back(t[0]); }
+        if (t.size() != 3) fail("\"value\" attribute must have exactly 1 or 3 elements");
+        for (int i = 0; i < 3; ++i) out[i] = parse_double(t[i]);
+        return;
+    }
+    const char *k[3] = { "x", "y", "z" };
+    for (int i = 0; i < 3; ++i) { auto *a = n.attr(k[i]); out[i] = a ? parse_double(*a) : def; }
+}
+static void parse_named3(const XNode &n, const char *attr, double out[3]) {
+    auto t = tokenize(n.get(attr));
+    if (t.size() != 3) fail(std::string("could not parse 3D vector attribute \"") + attr + "\"");
+    for (int i = 0; i < 3; ++i) out[i] = parse_double(t[i]);
+}
+
+static Mat4d parse_transform(const XNode &node) {
+    Mat4d cur = m_identity();
+    for (auto &opp : node.children) {
+        const XNode &op = *opp; Mat4d t = m_identity();
+        if (op.tag == "matrix") {
+            auto tok = tokenize(op.get("value"));
+            if (tok.size() == 16) { for (int i = 0; i < 16; ++i) t.m[i] = parse_double(tok[i]); }
+            else if (tok.size() == 9) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t.m[4 * i + j] = parse_double(tok[3 * i + j]); }
+            else fail("matrix: expected 16 or 9 values");
+        } else if (op.tag == "translate") {
+            double v[3]; parse_xyz(op, 0.0, v); t.m[3] = v[0]; t.m[7] = v[1]; t.m[11] = v[2];
+        } else if (op.tag == "scale") {
+            double v[3]; parse_xyz(op, 1.0, v); t.m[0] = v[0]; t.m[5] = v[1]; t.m[10] = v[2];
+        } else if (op.tag == "rotate") {
+            double a[3]; parse_xyz(op, 0.0, a);
+            if (!op.attr("angle")) fail("rotate: missing \"angle\" attribute");
+            double th = parse_double(op.get("angle")) * (M_PI / 180.0), s = std::sin(th), c = std::cos(th), cm = 1.0 - c;
+            t.m[0] = a[0] * a[0] * cm + c;        t.m[1] = a[0] * a[1] * cm - a[2] * s; t.m[2] = a[0] * a[2] * cm + a[1] * s;
+            t.m[4] = a[0] * a[1] * cm + a[2] * s; t.m[5] = a[1] * a[1] * cm + c;        t.m[6] = a[1] * a[2] * cm - a[0] * s;
+            t.m[8] = a[0] * a[2] * cm - a[1] * s; t.m[9] = a[1] * a[2] * cm + a[0] * s; t.m[10] = a[2] * a[2] * cm + c;
+        } else if (op.tag == "lookat") {
+            double o[3], tg[3], up[3] = { 0, 0, 0 };
+            parse_named3(op, "origin", o); parse_named3(op, "target", tg);
+            if (op.attr("up")) parse_named3(op, "up", up);
+            double d[3] = { tg[0] - o[0], tg[1] - o[1], tg[2] - o[2] };
+            double dl = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            for (double &x : d) x /= dl;
+            if (up[0] * up[0] + up[1] * up[1] + up[2] * up[2] == 0) {   // coordinate_system(dir).first
+                double sg = std::copysign(1.0, d[2]), a = -1.0 / (sg + d[2]), b = d[0] * d[1] * a;
+                up[0] = d[0] * d[0] * a * sg + 1.0; up[1] = b * sg; up[2] = -d[0] * sg;
+            }
+            double l[3] = { up[1] * d[2] - up[2] * d[1], up[2] * d[0] - up[0] * d[2], up[0] * d[1] - up[1] * d[0] };
+            double ll = std::sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+            for (double &x : l) x /= ll;
+            double nu[3] = { d[1] * l[2] - d[2] * l[1], d[2] * l[0] - d[0] * l[2], d[0] * l[1] - d[1] * l[0] };
+            for (int r = 0; r < 3; ++r) { t.m[4 * r] = l[r]; t.m[4 * r + 1] = nu[r]; t.m[4 * r + 2] = d[r]; t.m[4 * r + 3] = o[r]; }
+            for (double x : t.m) if (std::isnan(x)) fail("invalid lookat transformation");
+        } else {
+            fail("transform nodes can only contain transform operations");
+        }
+        cur = m_mul(t, cur);   // ctx.transform = T(op) * ctx.transform
+    }
+    return cur;
+}
+
+// ---------------------------------------------------------------------------- PropBag
+double PropBag::get_float(const std::string &n, double def) const {
+    auto it = values.find(n); if (it == values.end()) return def;
+    queried[n] = true;
+    if (it->second.type == PropValue::Float) return it->second.f;
+    if (it->second.type == PropValue::Int) return (double) it->second.i;
+    fail("The property \"" + n + "\" has the wrong type (expected <float>).");
+}
+int64_t PropBag::get_int(const std::string &n, int64_t def) const {
+    auto it = values.find(n); if (it == values.end()) return def;
+    queried[n] = true;
+    if (it->second.type != PropValue::Int) fail("The property \"" + n + "\" has the wrong type (expected <integer>).");
+    return it->second.i;
+}
+bool PropBag::get_bool(const std::string &n, bool def) const {
+    auto it = values.find(n); if (it == values.end()) return def;
+    queried[n] = true;
+    if (it->second.type != PropValue::Bool) fail("The property \"" + n + "\" has the wrong type (expected <boolean>).");
+    return it->second.b;
+}
+std::string PropBag::get_string(const std::string &n, const std::string &def) const {
+    auto it = values.find(n); if (it == values.end()) return def;
+    queried[n] = true;
+    if (it->second.type != PropValue::String) fail("The property \"" + n + "\" has the wrong type (expected <string>).");
+    return it->second.s;
+}
+std::vector<std::string> PropBag::unqueried() const {
+    std::vector<std::string> r;
+    for (auto &kv : values) if (!queried.count(kv.first)) r.push_back(kv.first);
+    return r;
+}
+
+PluginParams make_plugin_params(const PropBag &ip, const PropBag &sp) {
+    if (ip.plugin != "dopplertofpath") fail("unsupported integrator plugin \"" + ip.plugin + "\" (this library implements \"dopplertofpath\")");
+    if (sp.plugin != "correlated") fail("unsupported sampler plugin \"" + sp.plugin + "\" (this library implements \"correlated\")");
+    PluginParams p;
+    p.time = (float) ip.get_float("time", 0.0015f);
+    p.w_g_mhz = (float) ip.get_float("w_g", 30.0f);
+    p.g_1 = (float) ip.get_float("g_1", 0.5f);
+    p.g_0 = (float) ip.get_float("g_0", 0.5f);
+    p.w_s_mhz = (float) ip.get_float("w_s", 30.0f);
+    p.phase_offset = (float) ip.get_float("sensor_phase_offset", 0.0f);
+    if (ip.has("hetero_offset"))        // float * 2 (float) * M_PI (double) -> float
+        p.phase_offset = (float) ((double) ((float) ip.get_float("hetero_offset", 0.0) * 2) * M_PI);
+    if (ip.has("hetero_frequency")) {
+        p.hetero_frequency = (float) ip.get_float("hetero_frequency", 1.0);
+        p.w_s_mhz = (float) ((double) p.w_g_mhz + (double) (p.hetero_frequency / p.time) * 1e-6);
+    } else {
+        p.hetero_frequency = (float) ((double) (p.w_s_mhz - p.w_g_mhz) * 1e6 * (double) p.time);
+    }
+    std::string wf = ip.get_string("wave_function_type", "sinusoidal");
+    if (wf == "sinusoidal") p.wave_type = WAVE_SIN; else if (wf == "rectangular") p.wave_type = WAVE_RECT;
+    else if (wf == "triangular") p.wave_type = WAVE_TRI; else if (wf == "trapezoidal") p.wave_type = WAVE_TRAP;
+    else fail("unknown wave_function_type \"" + wf + "\"");   // the reference leaves the enum uninitialised here
+    p.low_frequency_component_only = ip.get_bool("low_frequency_component_only", true);
+    (void) ip.get_bool("is_doppler_integrator", false);
+    std::string ts = ip.get_string("time_sampling_method", "antithetic");
+    if (ts == "uniform") p.time_sampling = TIME_UNIFORM; else if (ts == "stratified") p.time_sampling = TIME_STRATIFIED;
+    else if (ts == "antithetic") p.time_sampling = TIME_ANTITHETIC; else if (ts == "antithetic_mirror") p.time_sampling = TIME_ANTITHETIC_MIRROR;
+    else fail("unknown time_sampling_method \"" + ts + "\"");
+    p.antithetic_shift = (float) ip.get_float("antithetic_shift", p.time_sampling == TIME_ANTITHETIC ? 0.5 : 0.0);
+    p.stratify_each_interval = ip.get_bool("use_stratified_sampling_for_each_interval", true);
+    p.path_correlation_depth = (uint32_t) ip.get_int("path_correlation_depth", 0);
+    if (ip.get_int("samples_per_pass", -1) != -1) fail("\"samples_per_pass\" is not supported (single-pass wavefront only)");
+    (void) ip.get_int("block_size", 0); (void) ip.get_float("timeout", -1.0);
+    int64_t md = ip.get_int("max_depth", -1);
+    if (md < 0 && md != -1) fail("\"max_depth\" must be set to -1 (infinite) or a value >= 0");
+    p.max_depth = (uint32_t) md;
+    int64_t rr = ip.get_int("rr_depth", 5);
+    if (rr <= 0) fail("\"rr_depth\" must be set to a value greater than zero!");
+    p.rr_depth = (uint32_t) rr;
+    p.hide_emitters = ip.get_bool("hide_emitters", false);
+    p.sample_count = (uint32_t) sp.get_int("sample_count", 4);
+    p.base_seed = (uint32_t) sp.get_int("seed", 0);
+    p.time_correlate_number = (int32_t) sp.get_int("time_correlate_number", 2);
+    p.path_correlate_number = (int32_t) sp.get_int("path_correlate_number", p.time_correlate_number);
+    if (p.time_correlate_number <= 0 || p.path_correlate_number <= 0) fail("correlate numbers must be positive");
+    for (const PropBag *b : { &ip, &sp }) {
+        auto u = b->unqueried();
+        if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in plugin of type \"" + b->plugin + "\"");   // xml.cpp:1204-1215
+    }
+    return p;
+}
+
+// ---------------------------------------------------------------------------- object tree
+struct Obj {
+    std::string tag, plugin, id;
+    PropBag props;
+    std::map<std::string, std::vector<double>> colors;            // <rgb>/<spectrum>
+    std::map<std::string, std::vector<double>> vectors;           // <point>/<vector>
+    std::map<std::string, Mat4d> transforms;
+    std::map<std::string, std::vector<std::pair<float, Mat4d>>> animations;
+    std::vector<std::pair<std::string, std::shared_ptr<Obj>>> children;   // document order; refs resolved later
+    std::vector<std::pair<size_t, std::string>> refs;                     // (position in children, id)
+};
+static bool is_object_tag(const std::string &t) {
+    static const char *tags[] = { "scene", "integrator", "sensor", "sampler", "film", "rfilter", "bsdf", "shape", "emitter", "texture" };
+    for (auto *x : tags) if (t == x) return true;
+    return false;
+}
+
+struct LoadCtx {
+    std::map<std::string, std::shared_ptr<Obj>> registry;
+    std::vector<std::pair<std::string, std::string>> defaults;   // (name, value)
+};
+
+static void substitute(XNode &n, LoadCtx &ctx) {
+    if (!ctx.defaults.empty()) {
+        auto sorted = ctx.defaults;
+        std::stable_sort(sorted.begin(), sorted.end(), [](auto &a, auto &b) { return a.first.size() > b.first.size(); });
+        for (auto &a : n.attrs) {
+            if (a.second.find('$') == std::string::npos) continue;
+            for (auto &d : sorted) {
+                std::string key = "$" + d.first; size_t pos = 0;
+                while ((pos = a.second.find(key, pos)) != std::string::npos) { a.second.replace(pos, key.size(), d.second); pos += d.second.size(); }
+            }
+            if (a.second.find('$') != std::string::npos) fail("undefined parameter(s) in string: \"" + a.second + "\"!");
+        }
+    } else {
+        for (auto &a : n.attrs) if (a.second.find('$') != std::string::npos) fail("undefined parameter(s) in string: \"" + a.second + "\"!");
+    }
+    if (n.tag == "default") {
+        std::string name = n.get("name"), value = n.get("value");
+        if (name.empty()) fail("<default>: name must by nonempty");
+        bool found = false; for (auto &d : ctx.defaults) if (d.first == name) found = true;
+        if (!found) ctx.defaults.emplace_back(name, value);
+    }
+    for (auto &c : n.children) substitute(*c, ctx);
+}
+
+static std::shared_ptr<Obj> parse_object(const XNode &n, LoadCtx &ctx) {
+    auto o = std::make_shared<Obj>();
+    o->tag = n.tag; o->plugin = n.get("type"); o->id = n.get("id"); o->props.plugin = o->plugin;
+    for (auto &cp : n.children) {
+        const XNode &c = *cp; std::string name = c.get("name");
+        if (!name.empty() && name[0] == '_') fail("invalid parameter name \"" + name + "\": leading underscores are reserved");
+        PropValue v;
+        if (c.tag == "default") continue;
+        else if (is_object_tag(c.tag)) { o->children.emplace_back(c.tag, parse_object(c, ctx)); }
+        else if (c.tag == "ref") {
+            if (!c.attr("id")) fail("<ref>: missing \"id\" attribute");
+            o->refs.emplace_back(o->children.size(), c.get("id")); o->children.emplace_back("ref", nullptr);
+        }
+        else if (c.tag == "float") { v.type = PropValue::Float; v.f = parse_double(c.get("value")); o->props.values[name] = v; }
+        else if (c.tag == "integer") { v.type = PropValue::Int; v.i = parse_int(c.get("value")); o->props.values[name] = v; }
+        else if (c.tag == "boolean") {
+            std::string b = c.get("value"); std::transform(b.begin(), b.end(), b.begin(), ::tolower);
+            if (b != "true" && b != "false") fail("could not parse boolean value \"" + b + "\" -- must be \"true\" or \"false\"");
+            v.type = PropValue::Bool; v.b = b == "true"; o->props.values[name] = v;
+        }
+        else if (c.tag == "string") { v.type = PropValue::String; v.s = c.get("value"); o->props.values[name] = v; }
+        else if (c.tag == "point" || c.tag == "vector") { double x[3]; parse_xyz(c, 0.0, x); o->vectors[name] = { x[0], x[1], x[2] }; }
+        else if (c.tag == "rgb") {
+            auto t = tokenize(c.get("value"));
+            if (t.size() == 1) { t.push_back(t[0]); t.push_back(t[0]); }
+            if (t.size() != 3) fail("'rgb' tag requires one or three values (got \"" + c.get("value") + "\")");
+            o->colors[name] = { parse_double(t[0]), parse_double(t[1]), parse_double(t[2]) };
+        }
+        else if (c.tag == "spectrum") {
+            auto t = tokenize(c.get("value"));
+            if (t.size() != 1) fail("only constant <spectrum> values are supported");
+            double d = parse_double(t[0]); o->colors[name] = { d, d, d };
+        }
+        else if (c.tag == "transform") { o->transforms[name] = parse_transform(c); }
+        else if (c.tag == "animation") {
+            std::vector<std::pair<float, Mat4d>> keys;
+            for (auto &tr : c.children) {
+                if (tr->tag != "transform" || !tr->attr("time")) fail("<animation> may only contain <transform time=...> nodes");
+                float time = (float) parse_double(tr->get("time"));
+                if (!keys.empty() && time <= keys.back().first)
+                    fail("AnimatedTransform::append(): time values must be strictly monotonically increasing!");
+                keys.emplace_back(time, parse_transform(*tr));
+            }
+            o->animations[name] = keys;
+        }
+        else fail("unexpected tag \"" + c.tag + "\"");
+    }
+    if (!o->id.empty()) {
+        if (ctx.registry.count(o->id)) fail("\"" + o->tag + "\" has duplicate id \"" + o->id + "\"");
+        ctx.registry[o->id] = o;
+    }
+    return o;
+}
+static void resolve_refs(Obj &o, LoadCtx &ctx) {
+    for (auto &r : o.refs) {
+        auto it = ctx.registry.find(r.second);
+        if (it == ctx.registry.end()) fail("reference to unknown object \"" + r.second + "\"!");
+        o.children[r.first] = { it->second->tag, it->second };
+    }
+    o.refs.clear();
+    for (auto &c : o.children) if (c.second) resolve_refs(*c.second, ctx);
+}
+
+// ---------------------------------------------------------------------------- assembly
+static void bsdf_of(const Obj &b, bool &twosided, float refl[3]) {
+    if (b.plugin == "twosided") {
+        const Obj *inner = nullptr; int n = 0;
+        for (auto &c : b.children) if (c.first == "bsdf") { inner = c.second.get(); ++n; }
+        if (n != 1) fail("twosided: exactly one nested BSDF is supported");
+        bool ts; bsdf_of(*inner, ts, refl); twosided = true; return;
+    }
+    if (b.plugin != "diffuse") fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, twosided)");
+    twosided = false;
+    auto c = b.colors.find("reflectance");
+    if (c != b.colors.end()) { for (int i = 0; i < 3; ++i) refl[i] = (float) c->second[i]; }
+    else { float r = (float) b.props.get_float("reflectance", 0.5); refl[0] = refl[1] = refl[2] = r; }
+}
+
+static void bake_cube(HostShape &s) {   // src/shapes/cube.cpp:114-160
+    static const float vtx[24][3] = {
+        { 1,-1,-1},{ 1,-1, 1},{-1,-1, 1},{-1,-1,-1},{ 1, 1,-1},{-1, 1,-1},{-1, 1, 1},{ 1, 1, 1},
+        { 1,-1,-1},{ 1, 1,-1},{ 1, 1, 1},{ 1,-1, 1},{ 1,-1, 1},{ 1, 1, 1},{-1, 1, 1},{-1,-1, 1},
+        {-1,-1, 1},{-1, 1, 1},{-1, 1,-1},{-1,-1,-1},{ 1, 1,-1},{ 1,-1,-1},{-1,-1,-1},{-1, 1,-1} };
+    static const float nr[6][3] = { {0,-1,0},{0,1,0},{1,0,0},{0,0,1},{-1,0,0},{0,0,-1} };
+    static const float tc[4][2] = { {0,1},{1,1},{1,0},{0,0} };
+    static const uint32_t tri[36] = { 0,1,2, 3,0,2, 4,5,6, 7,4,6, 8,9,10, 11,8,10, 12,13,14, 15,12,14, 16,17,18, 19,16,18, 20,21,22, 23,20,22 };
+    s.positions.resize(72); s.normals.resize(72); s.texcoords.resize(48); s.faces.assign(tri, tri + 36);
+    for (int i = 0; i < 24; ++i) {
+        V3 p = xf_point(s.to_world, mk(vtx[i][0], vtx[i][1], vtx[i][2]));
+        V3 n = xf_normal(s.to_object, mk(nr[i / 4][0], nr[i / 4][1], nr[i / 4][2]));
+        n = n * (1.0f / sqrtf(dot(n, n)));     // scalar-mode dr::normalize
+        s.positions[3 * i] = p.x; s.positions[3 * i + 1] = p.y; s.positions[3 * i + 2] = p.z;
+        s.normals[3 * i] = n.x; s.normals[3 * i + 1] = n.y; s.normals[3 * i + 2] = n.z;
+        s.texcoords[2 * i] = tc[i % 4][0]; s.texcoords[2 * i + 1] = tc[i % 4][1];
+    }
+}
+
+static HostShape make_shape(const Obj &o, bool strip_to_world) {
+    HostShape s; s.id = o.id;
+    if (o.plugin == "rectangle") s.kind = SHAPE_RECT; else if (o.plugin == "cube") s.kind = SHAPE_MESH;
+    else fail("unsupported shape plugin \"" + o.plugin + "\" (supported: rectangle, cube, shapegroup, instance)");
+    Mat4d tw = m_identity();
+    if (!strip_to_world) { auto t = o.transforms.find("to_world"); if (t != o.transforms.end()) tw = t->second; }
+    s.flip_normals = o.props.get_bool("flip_normals", false);
+    s.face_normals = o.props.get_bool("face_normals", false);
+    if (s.kind == SHAPE_RECT && s.flip_normals) {   // rectangle.cpp:91-99
+        Mat4d f = m_identity(); f.m[10] = -1.0; tw = m_mul(tw, f); s.flip_normals = false;
+    }
+    to_f32(tw, s.to_world); to_f32(m_inverse(tw), s.to_object);
+    const Obj *bsdf = nullptr;
+    for (auto &c : o.children) {
+        if (c.first == "bsdf") { if (bsdf) fail("Only a single BSDF child object can be specified per shape."); bsdf = c.second.get(); }
+        else if (c.first == "emitter") fail("area emitters are not supported by this library");
+        else fail("unsupported child <" + c.first + "> in shape");
+    }
+    if (bsdf) bsdf_of(*bsdf, s.twosided, s.refl);   // else default diffuse(0.5), src/render/shape.cpp:66-72
+    auto u = o.props.unqueried();
+    if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in shape plugin of type \"" + o.plugin + "\"");
+    if (s.kind == SHAPE_MESH) bake_cube(s);
+    return s;
+}
+
+static HostObject make_instance(const Obj &o, uint32_t group) {
+    HostObject ob; ob.kind = OBJ_INSTANCE; ob.index = group;
+    memset(ob.key, 0, sizeof ob.key);
+    auto a = o.animations.find("to_world");
+    if (a != o.animations.end()) {
+        // AnimatedTransform::eval only interpolates keyframes 0 and 1 (include/mitsuba/core/transform.h:458-466)
+        ob.n_keys = (uint32_t) std::min<size_t>(a->second.size(), 2);
+        if (ob.n_keys == 0) { ob.n_keys = 1; to_f32(m_identity(), ob.key[0]); }
+        for (uint32_t i = 0; i < ob.n_keys && i < a->second.size(); ++i) { ob.key_time[i] = a->second[i].first; to_f32(a->second[i].second, ob.key[i]); }
+    } else {
+        auto t = o.transforms.find("to_world");
+        ob.n_keys = 1; to_f32(t != o.transforms.end() ? t->second : m_identity(), ob.key[0]);
+    }
+    return ob;
+}
+
+static double parse_fov(const Obj &s, double aspect) {   // src/render/sensor.cpp:149-203
+    bool has_fov = s.props.has("fov"), has_fl = s.props.has("focal_length");
+    if (has_fov && has_fl) fail("Please specify either a focal length ('focal_length') or a field of view ('fov')!");
+    double fov; std::string axis;
+    if (has_fov) {
+        fov = s.props.get_float("fov", 0);
+        axis = s.props.get_string("fov_axis", "x");
+        std::transform(axis.begin(), axis.end(), axis.begin(), ::tolower);
+        if (axis == "smaller") axis = aspect > 1 ? "y" : "x"; else if (axis == "larger") axis = aspect > 1 ? "x" : "y";
+    } else {
+        std::string f = s.props.get_string("focal_length", "50mm");
+        if (f.size() > 2 && f.substr(f.size() - 2) == "mm") f = f.substr(0, f.size() - 2);
+        double value = parse_double(f);
+        fov = 2.0 * (std::atan(std::sqrt(double(36 * 36 + 24 * 24)) / (2.0 * value)) * (180.0 / M_PI));
+        axis = "diagonal";
+    }
+    double r;
+    if (axis == "x") r = fov;
+    else if (axis == "y") r = (2.0 * std::atan(std::tan(0.5 * (fov * (M_PI / 180.0))) * aspect)) * (180.0 / M_PI);
+    else if (axis == "diagonal") {
+        double diagonal = 2.0 * std::tan(0.5 * (fov * (M_PI / 180.0)));
+        double width = diagonal / std::sqrt(1.0 + 1.0 / (aspect * aspect));
+        r = (2.0 * std::atan(width * 0.5)) * (180.0 / M_PI);
+    } else fail("The 'fov_axis' parameter must be set to one of 'smaller', 'larger', 'diagonal', 'x', or 'y'!");
+    if (r <= 0.0 || r >= 180.0) fail("The horizontal field of view must be in the range [0, 180]!");
+    return r;
+}
+
+static void make_sensor(const Obj &o, HostScene &sc) {
+    if (o.plugin != "perspective") fail("unsupported sensor plugin \"" + o.plugin + "\" (supported: perspective)");
+    HostSensor &se = sc.sensor;
+    const Obj *film = nullptr, *sampler = nullptr;
+    for (auto &c : o.children) {
+        if (c.first == "film") { if (film) fail("Only one film can be specified per sensor."); film = c.second.get(); }
+        else if (c.first == "sampler") { if (sampler) fail("Only one sampler can be specified per sensor."); sampler = c.second.get(); }
+        else fail("unsupported child <" + c.first + "> in sensor");
+    }
+    bool have_filter = false;
+    if (film) {
+        if (film->plugin != "hdrfilm") fail("unsupported film plugin \"" + film->plugin + "\" (supported: hdrfilm)");
+        se.film_w = (int32_t) film->props.get_int("width", 768); se.film_h = (int32_t) film->props.get_int("height", 576);
+        se.crop_w = (int32_t) film->props.get_int("crop_width", se.film_w); se.crop_h = (int32_t) film->props.get_int("crop_height", se.film_h);
+        se.crop_x = (int32_t) film->props.get_int("crop_offset_x", 0); se.crop_y = (int32_t) film->props.get_int("crop_offset_y", 0);
+        std::string pf = film->props.get_string("pixel_format", "rgb");
+        if (pf != "rgb") fail("unsupported pixel_format \"" + pf + "\" (supported: rgb)");
+        (void) film->props.get_string("file_format", "openexr"); (void) film->props.get_string("component_format", "float16");
+        if (film->props.get_bool("sample_border", false)) fail("sample_border=true is not supported");
+        (void) film->props.get_bool("compensate", false);
+        for (auto &c : film->children) {
+            if (c.first != "rfilter") fail("unsupported child <" + c.first + "> in film");
+            const Obj &rf = *c.second;
+            if (rf.plugin == "tent") { se.filter = FILTER_TENT; se.filter_radius = (float) rf.props.get_float("radius", 1.0); }
+            else if (rf.plugin == "box") { se.filter = FILTER_BOX; se.filter_radius = .5f; }
+            else fail("unsupported rfilter plugin \"" + rf.plugin + "\" (supported: tent, box)");
+            have_filter = true;
+        }
+        auto u = film->props.unqueried();
+        if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in film plugin");
+        if (se.film_w <= 0 || se.film_h <= 0 || se.crop_w <= 0 || se.crop_h <= 0 || se.crop_x < 0 || se.crop_y < 0 ||
+            se.crop_x + se.crop_w > se.film_w || se.crop_y + se.crop_h > se.film_h) fail("invalid film size / crop window");
+    }
+    if (!have_filter) fail("unsupported rfilter plugin \"gaussian\" (the film default); specify <rfilter type=\"tent\"/> or \"box\"");
+    auto t = o.transforms.find("to_world");
+    to_f32(t != o.transforms.end() ? t->second : m_identity(), se.to_world);
+    se.shutter_open = (float) o.props.get_float("shutter_open", 0.0);
+    se.shutter_close = (float) o.props.get_float("shutter_close", 0.0);
+    if (se.shutter_close - se.shutter_open < 0) fail("Shutter opening time must be less than or equal to the shutter closing time!");
+    se.near_clip = (float) o.props.get_float("near_clip", 1e-2f);
+    se.far_clip = (float) o.props.get_float("far_clip", 1e4f);
+    if (se.near_clip <= 0.f) fail("The 'near_clip' parameter must be greater than zero!");
+    if (se.near_clip >= se.far_clip) fail("The 'near_clip' parameter must be smaller than 'far_clip'.");
+    se.x_fov = (float) parse_fov(o, se.film_w / (double) se.film_h);
+    (void) o.props.get_float("principal_point_offset_x", 0.0); (void) o.props.get_float("principal_point_offset_y", 0.0);
+    if (sampler) sc.sampler = sampler->props; else { sc.sampler = PropBag(); sc.sampler.plugin = "independent"; }
+    auto u = o.props.unqueried();
+    if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in sensor plugin");
+}
+
+HostScene load_scene_xml(const std::string &text, const std::map<std::string, std::string> &params) {
+    XParser xp(text);
+    auto root = xp.document();
+    if (root->tag != "scene") fail("root element \"" + root->tag + "\" must be a <scene>");
+    if (!root->attr("version")) fail("missing version attribute in root element \"scene\"");
+    LoadCtx ctx;
+    for (auto &kv : params) ctx.defaults.emplace_back(kv.first, kv.second);
+    substitute(*root, ctx);
+    auto top = parse_object(*root, ctx);
+    resolve_refs(*top, ctx);
+
+    HostScene sc; bool have_sensor = false, have_integrator = false;
+    std::map<const Obj *, uint32_t> group_of;
+    for (auto &c : top->children) {
+        const Obj &o = *c.second;
+        if (o.tag == "integrator") {
+            if (have_integrator) fail("Only one integrator can be specified per scene.");
+            sc.integrator = o.props; have_integrator = true;
+        } else if (o.tag == "sensor") {
+            if (have_sensor) fail("only one sensor is supported");
+            make_sensor(o, sc); have_sensor = true;
+        } else if (o.tag == "emitter") {
+            if (o.plugin != "point") fail("unsupported emitter plugin \"" + o.plugin + "\" (supported: point)");
+            HostEmitter e; e.kind = 0;
+            auto pv = o.vectors.find("position"); auto tw = o.transforms.find("to_world");
+            if (pv != o.vectors.end()) {
+                if (tw != o.transforms.end()) fail("Only one of the parameters 'position' and 'to_world' can be specified at the same time!'");
+                for (int i = 0; i < 3; ++i) e.pos[i] = (float) pv->second[i];
+            } else {
+                float m[16]; to_f32(tw != o.transforms.end() ? tw->second : m_identity(), m);
+                e.pos[0] = m[3]; e.pos[1] = m[7]; e.pos[2] = m[11];
+            }
+            auto ic = o.colors.find("intensity");
+            if (ic != o.colors.end()) for (int i = 0; i < 3; ++i) e.intensity[i] = (float) ic->second[i];
+            else { float v = (float) o.props.get_float("intensity", 1.0); e.intensity[0] = e.intensity[1] = e.intensity[2] = v; }
+            sc.emitters.push_back(e);
+        } else if (o.tag == "shape") {
+            if (o.plugin == "shapegroup") {
+                HostGroup g; g.first_shape = (uint32_t) sc.shapes.size();
+                for (auto &ch : o.children) {
+                    if (ch.first != "shape") fail("Tried to add an unsupported object to a shapegroup");
+                    if (ch.second->plugin == "instance") fail("Nested instancing is not permitted");
+                    if (ch.second->plugin == "shapegroup") fail("Nested ShapeGroup is not permitted");
+                    sc.shapes.push_back(make_shape(*ch.second, false));
+                }
+                g.n_shapes = (uint32_t) sc.shapes.size() - g.first_shape;
+                group_of[&o] = (uint32_t) sc.groups.size(); sc.groups.push_back(g);
+            } else if (o.plugin == "instance") {
+                const Obj *grp = nullptr;
+                for (auto &ch : o.children) if (ch.first == "shape" && ch.second->plugin == "shapegroup") {
+                    if (grp) fail("Only a single shapegroup can be specified per instance.");
+                    grp = ch.second.get();
+                }
+                if (!grp) fail("A reference to a 'shapegroup' must be specified!");
+                auto g = group_of.find(grp);
+                if (g == group_of.end()) fail("an instance must reference a shapegroup declared before it at scene level");
+                sc.objects.push_back(make_instance(o, g->second));
+            } else if (o.animations.count("to_world")) {
+                // xml.cpp:1165-1195: shape with an animated to_world => shapegroup{shape} + instance{animated to_world}
+                HostGroup g; g.first_shape = (uint32_t) sc.shapes.size(); g.n_shapes = 1;
+                sc.shapes.push_back(make_shape(o, true));
+                sc.groups.push_back(g);
+                sc.objects.push_back(make_instance(o, (uint32_t) sc.groups.size() - 1));
+            } else {
+                HostObject ob; ob.kind = OBJ_SHAPE; ob.index = (uint32_t) sc.shapes.size(); ob.n_keys = 0; memset(ob.key, 0, sizeof ob.key);
+                sc.shapes.push_back(make_shape(o, false));
+                sc.objects.push_back(ob);
+            }
+        } else if (o.tag == "bsdf" || o.tag == "texture") {
+            // top-level declarations referenced by id
+        } else fail("unsupported top-level element <" + o.tag + ">");
+    }
+    if (!have_sensor) fail("the scene does not contain a sensor");
+    if (!have_integrator) { sc.integrator = PropBag(); sc.integrator.plugin = "path"; }
+    return sc;
+}
+
+std::string read_file(const std::string &path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) fail("could not open \"" + path + "\"");
+    std::ostringstream ss; ss << f.rdbuf();
+    return ss.str();
+}
+
+}  // namespace dtof

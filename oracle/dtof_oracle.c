@@ -404,18 +404,21 @@ static int tri_intersect(v3 p0, v3 p1, v3 p2, v3 o, v3 d, float maxt, float *t_o
 }
 static inline v3 mesh_pos(const orc_shape *sh, uint32_t i) { return V(sh->positions[3 * i], sh->positions[3 * i + 1], sh->positions[3 * i + 2]); }
 
-/* closest hit in one shape; candidate accepted if strictly closer, or equal t with a
- * lower (object, shape, prim) id (deterministic tie rule shared with the GPU path) */
-static void shape_closest(const orc_shape *sh, v3 o, v3 d, int32_t obj, int32_t shape_idx, orc_hit *best) {
+/* closest hit in one shape.  Candidates are all primitives hit with t <= the ray's maxt; the
+ * winner is the smallest t, exact ties going to the lowest (object, shape, prim) index (objects
+ * are visited in index order and the comparison is strict).  A hit at exactly t == maxt counts
+ * as a miss (hit = t != maxt, scene_embree.inl:313).  Traversal-order independent, so the GPU's
+ * BVH walk reproduces it exactly. */
+static void shape_closest(const orc_shape *sh, v3 o, v3 d, float maxt, int32_t obj, int32_t shape_idx, orc_hit *best) {
     float t, u, v;
     if (sh->kind == ORC_SHAPE_RECT) {
-        if (rect_intersect(sh, o, d, best->t, &t, &u, &v) && t < best->t) {
+        if (rect_intersect(sh, o, d, maxt, &t, &u, &v) && t < best->t) {
             best->t = t; best->u = u; best->v = v; best->obj = obj; best->shape = shape_idx; best->prim = 0;
         }
     } else {
         for (int32_t f = 0; f < sh->n_faces; ++f) {
             const uint32_t *fi = sh->faces + 3 * f;
-            if (tri_intersect(mesh_pos(sh, fi[0]), mesh_pos(sh, fi[1]), mesh_pos(sh, fi[2]), o, d, best->t, &t, &u, &v)
+            if (tri_intersect(mesh_pos(sh, fi[0]), mesh_pos(sh, fi[1]), mesh_pos(sh, fi[2]), o, d, maxt, &t, &u, &v)
                 && t < best->t) {
                 best->t = t; best->u = u; best->v = v; best->obj = obj; best->shape = shape_idx; best->prim = f;
             }
@@ -440,7 +443,7 @@ static orc_hit scene_closest(const orc_scene *sc, v3 o, v3 d, float time, float 
     for (int32_t i = 0; i < sc->n_objects; ++i) {
         const orc_object *ob = &sc->objects[i];
         if (ob->kind == ORC_OBJ_SHAPE) {
-            shape_closest(&sc->shapes[ob->index], o, d, i, 0, &best);
+            shape_closest(&sc->shapes[ob->index], o, d, maxt, i, 0, &best);
         } else {
             float m[16], inv[16];
             instance_to_world(ob, time, m);
@@ -448,7 +451,7 @@ static orc_hit scene_closest(const orc_scene *sc, v3 o, v3 d, float time, float 
             v3 lo = m_point(inv, o), ld = m_vector(inv, d);
             const orc_group *g = &sc->groups[ob->index];
             for (int32_t k = 0; k < g->n_shapes; ++k)
-                shape_closest(&sc->shapes[g->first_shape + k], lo, ld, i, k, &best);
+                shape_closest(&sc->shapes[g->first_shape + k], lo, ld, maxt, i, k, &best);
         }
     }
     if (best.obj < 0) best.t = INFINITY;   /* hit = (t != maxt), scene_embree.inl:313-315 */

@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Deterministic generator of the benchmark / parity scenes.
+
+    python scenes/make_scenes.py            # (re)writes scenes/*.xml
+
+  cornell_boxes.xml  C1: the geometry, materials, light and camera of the reference's
+                     configs_example/scene.xml (Cornell box, two linearly translating cubes, point light at
+                     the camera); resolution / spp / integrator settings are <default> parameters.
+  cornell_wall.xml   C2/C3: same room, the two boxes replaced by ONE rectangle (the back wall) that translates
+                     0.015 towards the camera over the 1.5 ms exposure (10 m/s).
+  domino.xml         C4/C5: ground rectangle + 32x32 cubes instanced from one shapegroup, each with its own
+                     pair of keyframes (toppling: rotation about the bottom edge + drift), motion-blur BVH stress.
+"""
+import math
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+HEADER = """<scene version="3.0.0">
+	<default name="spp" value="{spp}" />
+	<default name="resx" value="{res}" />
+	<default name="resy" value="{res}" />
+	<default name="max_depth" value="4" />
+	<default name="wave_function_type" value="sinusoidal" />
+	<default name="time_sampling_method" value="{tsm}" />
+	<default name="antithetic_shift" value="{shift}" />
+	<default name="hetero_frequency" value="1.0" />
+	<default name="hetero_offset" value="0.0" />
+	<default name="path_correlation_depth" value="$max_depth" />
+	<default name="time_correlate_number" value="2" />
+	<integrator type="dopplertofpath">
+		<integer name="max_depth" value="$max_depth" />
+		<float name="w_g" value="30" />
+		<float name="hetero_frequency" value="$hetero_frequency" />
+		<float name="hetero_offset" value="$hetero_offset" />
+		<float name="antithetic_shift" value="$antithetic_shift" />
+		<integer name="path_correlation_depth" value="$path_correlation_depth" />
+		<string name="time_sampling_method" value="$time_sampling_method" />
+		<string name="wave_function_type" value="$wave_function_type" />
+	</integrator>
+"""
+
+SENSOR = """	<sensor type="perspective">
+		<float name="fov" value="{fov}" />
+		<transform name="to_world">
+{cam}
+		</transform>
+		<sampler type="correlated">
+			<integer name="sample_count" value="$spp" />
+			<integer name="time_correlate_number" value="$time_correlate_number" />
+		</sampler>
+		<film type="hdrfilm">
+			<integer name="width" value="$resx" />
+			<integer name="height" value="$resy" />
+			<string name="file_format" value="openexr" />
+			<string name="pixel_format" value="rgb" />
+			<rfilter type="tent" />
+		</film>
+		<float name="shutter_open" value="0.0" />
+		<float name="shutter_close" value="0.0015" />
+	</sensor>
+"""
+
+
+def bsdf(ident, rgb):
+    return ('\t<bsdf type="twosided" id="%s">\n\t\t<bsdf type="diffuse">\n\t\t\t<rgb name="reflectance" value="%s" />\n'
+            '\t\t</bsdf>\n\t</bsdf>\n' % (ident, rgb))
+
+
+def rect(ident, matrix, bsdf_id, anim_dz=None):
+    s = '\t<shape type="rectangle" id="%s">\n' % ident
+    if anim_dz is None:
+        s += '\t\t<transform name="to_world">\n\t\t\t<matrix value="%s" />\n\t\t</transform>\n' % matrix
+    else:
+        s += ('\t\t<animation name="to_world">\n\t\t\t<transform time="0">\n\t\t\t\t<matrix value="%s" />\n\t\t\t</transform>\n'
+              '\t\t\t<transform time="0.0015">\n\t\t\t\t<matrix value="%s" />\n\t\t\t\t<translate x="0.0" y="0.0" z="%s" />\n'
+              '\t\t\t</transform>\n\t\t</animation>\n' % (matrix, matrix, anim_dz))
+    s += '\t\t<ref id="%s" />\n\t</shape>\n' % bsdf_id
+    return s
+
+
+def cube(ident, matrix, bsdf_id, dz):
+    return ('\t<shape type="cube" id="%s">\n\t\t<ref id="%s" />\n\t\t<animation name="to_world">\n'
+            '\t\t\t<transform time="0">\n\t\t\t\t<matrix value="%s" />\n\t\t\t</transform>\n'
+            '\t\t\t<transform time="0.0015">\n\t\t\t\t<matrix value="%s" />\n\t\t\t\t<translate x="0.0" y="0.0" z="%s" />\n'
+            '\t\t\t</transform>\n\t\t</animation>\n\t</shape>\n' % (ident, bsdf_id, matrix, matrix, dz))
+
+
+# room of the reference's example scene (configs_example/scene.xml:33-102,127-132): values are data, kept verbatim
+CAM = '\t\t\t<matrix value="-1 0 0 0 0 1 0 1 0 0 -1 6.8 0 0 0 1" />'
+WALLS = [
+    ("Floor", "-4.37114e-008 1 4.37114e-008 0 0 -8.74228e-008 2 0 1 4.37114e-008 1.91069e-015 0 0 0 0 1", "FloorBSDF"),
+    ("Ceiling", "-1 7.64274e-015 -1.74846e-007 0 8.74228e-008 8.74228e-008 -2 2 0 -1 -4.37114e-008 0 0 0 0 1", "CeilingBSDF"),
+    ("BackWall", "1.91069e-015 1 1.31134e-007 0 1 3.82137e-015 -8.74228e-008 1 -4.37114e-008 1.31134e-007 -2 -1 0 0 0 1", "BackWallBSDF"),
+    ("RightWall", "4.37114e-008 -1.74846e-007 2 1 1 3.82137e-015 -8.74228e-008 1 3.82137e-015 1 2.18557e-007 0 0 0 0 1", "RightWallBSDF"),
+    ("LeftWall", "-4.37114e-008 8.74228e-008 -2 -1 1 3.82137e-015 -8.74228e-008 1 0 -1 -4.37114e-008 0 0 0 0 1", "LeftWallBSDF"),
+]
+BSDFS = [("LeftWallBSDF", "0.63, 0.065, 0.05"), ("RightWallBSDF", "0.14, 0.45, 0.091"), ("FloorBSDF", "0.725, 0.71, 0.68"),
+         ("CeilingBSDF", "0.725, 0.71, 0.68"), ("BackWallBSDF", "0.725, 0.71, 0.68"), ("ShortBoxBSDF", "0.725, 0.71, 0.68"),
+         ("TallBoxBSDF", "0.725, 0.71, 0.68")]
+SHORT = "0.0851643 0.289542 1.31134e-008 0.328631 3.72265e-009 1.26563e-008 -0.3 0.3 -0.284951 0.0865363 5.73206e-016 0.374592 0 0 0 1"
+TALL = "0.286776 0.098229 -2.29282e-015 -0.335439 -4.36233e-009 1.23382e-008 -0.6 0.6 -0.0997984 0.282266 2.62268e-008 -0.291415 0 0 0 1"
+LIGHT = ('\t<emitter type="point">\n\t\t<transform name="to_world">\n' + CAM + '\n\t\t</transform>\n'
+         '\t\t<rgb name="intensity" value="100" />\n\t</emitter>\n')
+
+
+def cornell(moving_wall, res, spp, tsm, shift):
+    s = HEADER.format(spp=spp, res=res, tsm=tsm, shift=shift) + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        s += bsdf(*b)
+    for name, m, b in WALLS:
+        s += rect(name, m, b, anim_dz="0.015" if (moving_wall and name == "BackWall") else None)
+    if not moving_wall:
+        s += cube("ShortBox", SHORT, "ShortBoxBSDF", "0.015")
+        s += cube("TallBox", TALL, "TallBoxBSDF", "-0.015")
+    return s + LIGHT + "</scene>\n"
+
+
+def domino(n_side=32, res=1024, spp=128):
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5").replace('value="sinusoidal"', 'value="rectangular"')
+    cam = '\t\t\t<lookat origin="0, 9, 16" target="0, 0.3, 0" up="0, 1, 0" />'
+    s += SENSOR.format(fov="40", cam=cam)
+    s += bsdf("GroundBSDF", "0.6, 0.6, 0.6") + bsdf("DominoBSDF", "0.75, 0.55, 0.35")
+    s += ('\t<shape type="rectangle" id="Ground">\n\t\t<transform name="to_world">\n\t\t\t<rotate x="1" angle="-90" />\n'
+          '\t\t\t<scale value="10" />\n\t\t</transform>\n\t\t<ref id="GroundBSDF" />\n\t</shape>\n')
+    s += ('\t<shape type="shapegroup" id="DominoGroup">\n\t\t<shape type="cube">\n\t\t\t<transform name="to_world">\n'
+          '\t\t\t\t<scale x="0.05" y="0.5" z="0.25" />\n\t\t\t\t<translate y="0.5" />\n\t\t\t</transform>\n'
+          '\t\t\t<ref id="DominoBSDF" />\n\t\t</shape>\n\t</shape>\n')
+    lcg = 1234
+    for k in range(n_side * n_side):
+        lcg = (lcg * 1664525 + 1013904223) & 0xffffffff
+        jitter = ((lcg >> 8) & 0xffff) / 65536.0 - 0.5
+        ix, iz = k % n_side, k // n_side
+        x = (ix - (n_side - 1) / 2.0) * 0.6 + 0.1 * jitter
+        z = (iz - (n_side - 1) / 2.0) * 0.6
+        theta = math.degrees(0.02 * (1.0 + math.sin(0.1 * k)))
+        yaw = 10.0 * jitter
+        base = '\t\t\t\t<rotate y="1" angle="%.6f" />\n\t\t\t\t<translate x="%.6f" y="0" z="%.6f" />\n' % (yaw, x, z)
+        s += ('\t<shape type="instance">\n\t\t<ref id="DominoGroup" />\n\t\t<animation name="to_world">\n'
+              '\t\t\t<transform time="0">\n' + base + '\t\t\t</transform>\n\t\t\t<transform time="0.0015">\n'
+              '\t\t\t\t<rotate z="1" angle="%.6f" />\n' % (-theta) + base +
+              '\t\t\t\t<translate x="%.6f" y="0" z="0" />\n' % (0.004 * (1.0 + math.sin(0.1 * k))) +
+              '\t\t\t</transform>\n\t\t</animation>\n\t</shape>\n')
+    s += ('\t<emitter type="point">\n\t\t<point name="position" x="0" y="9" z="16" />\n'
+          '\t\t<rgb name="intensity" value="400" />\n\t</emitter>\n</scene>\n')
+    return s
+
+
+def main():
+    out = {
+        "cornell_boxes.xml": cornell(False, 256, 16, "antithetic", "0.5"),
+        "cornell_wall.xml": cornell(True, 512, 64, "stratified", "0.0"),
+        "domino.xml": domino(),
+        "domino_small.xml": domino(n_side=6, res=128, spp=16),
+    }
+    for name, text in out.items():
+        with open(os.path.join(HERE, name), "w") as f:
+            f.write(text)
+        print("wrote", name, len(text), "bytes")
+
+
+if __name__ == "__main__":
+    main()
