@@ -48,8 +48,8 @@ struct Queues {
     float4 *sh_a;        // shadow ray o.xyz, maxt
     float4 *sh_b;        // shadow ray d.xyz, time
     float4 *sh_c;        // [K][capacity] candidate result rgb, w = as_float(lane position)
-    uint32_t *q[2];      // active-lane index queues (ping-pong)
-    uint32_t *counts;    // [iteration][2]: (alive after shade, shadow rays)
+    uint32_t *q[2];      // active-lane index queues (ping-pong), segmented: entry j of segment S at S*1024 + j
+    uint32_t *counts;    // [iteration][2][n_segments]: survivors / shadow rays per segment
     uint32_t capacity;
 };
 
@@ -59,13 +59,14 @@ struct LaneDebug {       // mirrors orc_lane's comparable fields
 
 // kernels (dtof_kernels.hip)
 void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s);
+uint32_t segments_for(uint32_t n_lanes);   // number of queue segments (count slots) for a batch
 void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
-                  const uint32_t *qin, const uint32_t *count_in, uint32_t upper, hipStream_t s);
+                  const uint32_t *qin, const uint32_t *count_in, hipStream_t s);
 void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
-                  const uint32_t *qin, const uint32_t *count_in, uint32_t upper, uint32_t *qout,
-                  uint32_t *counts_out, uint32_t depth, hipStream_t s);
+                  const uint32_t *qin, const uint32_t *count_in, uint32_t *qout,
+                  uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, hipStream_t s);
 void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
-                   const uint32_t *count_in, uint32_t upper, hipStream_t s);
+                   const uint32_t *count_in, hipStream_t s);
 void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t film_w, int32_t film_h, hipStream_t s);
 void launch_develop(const float *film, float *rgb, int64_t n_pixels, hipStream_t s);
 void launch_lane_dump(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s);

@@ -296,18 +296,29 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) 
 }
 
 // ---------------------------------------------------------------------------- trace
+// Segmented queues: the wavefront is cut into segments of kSeg lanes.  A shade block owns one
+// segment: it compacts the survivors (and the shadow rays) of its segment to the front of the same
+// segment of the output queue and records the count -- order preserving, deterministic and without a
+// single global atomic (a shared counter serialises at ~88 returning atomics/us on MI355X, which
+// made the first version of this kernel 10x slower than its memory traffic).
+constexpr uint32_t kSeg = 1024, kSub = kSeg / kBlock;
+DTOF_D uint32_t seg_count(const uint32_t *counts, uint32_t seg, uint32_t n_lanes) {
+    return counts ? counts[seg] : min(kSeg, n_lanes - seg * kSeg);
+}
+
 template <bool LDS>
 __global__ __launch_bounds__(kBlock) void k_trace(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words,
-                                                  Queues q, const uint32_t *qin, const uint32_t *count_in, uint32_t upper) {
+                                                  Queues q, const uint32_t *qin, const uint32_t *count_in, uint32_t n_lanes) {
     extern __shared__ uint4 lds[];
-    uint32_t count = count_in ? *count_in : upper;
-    if (blockIdx.x * kBlock >= count) return;
+    uint32_t seg = blockIdx.x / kSub, sub = blockIdx.x % kSub;
+    uint32_t count = seg_count(count_in, seg, n_lanes);
+    if (sub * kBlock >= count) return;
     const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
     uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
     SceneView sv = make_view(base);
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= count) return;
-    uint32_t l = qin ? qin[i] : i;
+    uint32_t j = sub * kBlock + threadIdx.x;
+    if (j >= count) return;
+    uint32_t l = qin ? qin[seg * kSeg + j] : seg * kSeg + j;
     float4 a = q.ray_a[l], b = q.ray_b[l];
     Hit h;
     bool found = trace_scene<false>(sv, stack, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h);
@@ -398,35 +409,41 @@ DTOF_D V3 cosine_hemisphere(float sx, float sy) {
 }
 DTOF_D float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
-// wave-aggregated append: one atomic per wave (ballot + prefix popcount)
-DTOF_D uint32_t wave_append(bool pred, uint32_t *counter) {
+// Block-wide exclusive prefix of a predicate (ballot + popcount per wave, 4 wave totals through LDS).
+// Returns this lane's slot relative to `running` and advances `running` by the block total.
+DTOF_D uint32_t block_append(bool pred, uint32_t *s_cnt, uint32_t &running) {
     uint64_t mask = __ballot(pred);
-    uint32_t lane = __lane_id();
-    uint32_t base = 0;
-    if (mask != 0) {
-        uint32_t leader = (uint32_t) __ffsll((unsigned long long) mask) - 1;
-        if (lane == leader) base = atomicAdd(counter, (uint32_t) __popcll(mask));
-        base = __shfl(base, leader);
-    }
-    return base + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+    uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = (uint32_t) __popcll(mask);
+    __syncthreads();
+    uint32_t c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3];
+    __syncthreads();
+    uint32_t before = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+    uint32_t slot = running + before + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+    running += c0 + c1 + c2 + c3;
+    return slot;
 }
 
 template <bool LDS>
 __global__ __launch_bounds__(kBlock) void k_shade(const uint8_t *scene, uint32_t scene_bytes, RenderParams rp, Queues q,
-                                                  const uint32_t *qin, const uint32_t *count_in, uint32_t upper,
-                                                  uint32_t *qout, uint32_t *counts_out, uint32_t depth) {
+                                                  const uint32_t *qin, const uint32_t *count_in,
+                                                  uint32_t *qout, uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth) {
     extern __shared__ uint4 lds[];
-    uint32_t count = count_in ? *count_in : upper;
-    if (blockIdx.x * kBlock >= count) return;
+    __shared__ uint32_t s_cnt[4];
+    const uint32_t seg = blockIdx.x;
+    const uint32_t count = seg_count(count_in, seg, rp.n_lanes);
+    uint32_t n_alive = 0, n_shadow = 0;
+    if (count != 0) {
     const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
     SceneView sv = make_view(base);
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    bool in_range = i < count;
+    for (uint32_t cbase = 0; cbase < count; cbase += kBlock) {
+    uint32_t j = cbase + threadIdx.x;
+    bool in_range = j < count;
     bool alive = false, want_shadow = false;
     uint32_t l = 0;
     float4 sha, shb; float3 cand[kMaxOffsets];
     if (in_range) {
-        l = qin ? qin[i] : i;
+        l = qin ? qin[seg * kSeg + j] : seg * kSeg + j;
         uint32_t hid = q.hit_id[l];
         if (hid != 0xffffffffu) {   // a miss ends the path (active_next = false, dopplertofpath.cpp:171)
             uint32_t lane = rp.lane_base + l;
@@ -522,34 +539,40 @@ __global__ __launch_bounds__(kBlock) void k_shade(const uint8_t *scene, uint32_t
             }
         }
     }
-    uint32_t slot = wave_append(alive, &counts_out[0]);
-    if (alive) qout[slot] = l;
-    uint32_t sslot = wave_append(want_shadow, &counts_out[1]);
+    uint32_t slot = block_append(alive, s_cnt, n_alive);
+    if (alive) qout[seg * kSeg + slot] = l;
+    uint32_t sslot = seg * kSeg + block_append(want_shadow, s_cnt, n_shadow);
     if (want_shadow) {
         q.sh_a[sslot] = sha; q.sh_b[sslot] = shb;
 #pragma unroll
         for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets)
             q.sh_c[(size_t) k * q.capacity + sslot] = make_float4(cand[k].x, cand[k].y, cand[k].z, u2f(l));
     }
+    }   // chunk loop
+    }   // count != 0
+    if (threadIdx.x == 0) { alive_out[seg] = n_alive; shadow_out[seg] = n_shadow; }
 }
 
 // ---------------------------------------------------------------------------- shadow
 template <bool LDS>
 __global__ __launch_bounds__(kBlock) void k_shadow(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp,
-                                                   Queues q, const uint32_t *count_in, uint32_t upper) {
+                                                   Queues q, const uint32_t *count_in) {
     extern __shared__ uint4 lds[];
-    uint32_t count = count_in ? *count_in : upper;
-    if (blockIdx.x * kBlock >= count) return;
+    uint32_t seg = blockIdx.x / kSub, sub = blockIdx.x % kSub;
+    uint32_t count = count_in[seg];
+    if (sub * kBlock >= count) return;
     const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
     uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
     SceneView sv = make_view(base);
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= count) return;
+    uint32_t j = sub * kBlock + threadIdx.x;
+    if (j >= count) return;
+    uint32_t i = seg * kSeg + j;
     float4 a = q.sh_a[i], b = q.sh_b[i];
     Hit h;
     bool occluded = trace_scene<true>(sv, stack, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h);
     if (!occluded) {
-        for (int k = 0; k < rp.n_offsets; ++k) {
+#pragma unroll
+        for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) {
             float4 c = q.sh_c[(size_t) k * q.capacity + i];
             uint32_t l = f2u(c.w);
             q.res[(size_t) k * q.capacity + l] = make_float4(c.x, c.y, c.z, 0.f);
@@ -687,27 +710,30 @@ void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s) {
 }
 static inline uint32_t stage_words_for(uint32_t scene_bytes) { return scene_bytes <= kLdsSceneLimit ? (scene_bytes + 15) / 16 : 0; }
 
-void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &, const Queues &q,
-                  const uint32_t *qin, const uint32_t *count_in, uint32_t upper, hipStream_t s) {
-    if (upper == 0) return;
-    uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + kStackDepth * kBlock * 4;
-    if (sw) hipLaunchKernelGGL(k_trace<true>, dim3(nblk(upper)), dim3(kBlock), lds, s, scene, scene_bytes, sw, q, qin, count_in, upper);
-    else hipLaunchKernelGGL(k_trace<false>, dim3(nblk(upper)), dim3(kBlock), lds, s, scene, scene_bytes, sw, q, qin, count_in, upper);
+static inline uint32_t nseg(uint32_t n) { return (n + kSeg - 1) / kSeg; }
+uint32_t segments_for(uint32_t n_lanes) { return nseg(n_lanes); }
+
+void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
+                  const uint32_t *qin, const uint32_t *count_in, hipStream_t s) {
+    if (rp.n_lanes == 0) return;
+    uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + kStackDepth * kBlock * 4, grid = nseg(rp.n_lanes) * kSub;
+    if (sw) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, q, qin, count_in, rp.n_lanes);
+    else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, q, qin, count_in, rp.n_lanes);
 }
 void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
-                  const uint32_t *qin, const uint32_t *count_in, uint32_t upper, uint32_t *qout,
-                  uint32_t *counts_out, uint32_t depth, hipStream_t s) {
-    if (upper == 0) return;
-    uint32_t sw = stage_words_for(scene_bytes);
-    if (sw) hipLaunchKernelGGL(k_shade<true>, dim3(nblk(upper)), dim3(kBlock), sw * 16, s, scene, scene_bytes, rp, q, qin, count_in, upper, qout, counts_out, depth);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(nblk(upper)), dim3(kBlock), 0, s, scene, scene_bytes, rp, q, qin, count_in, upper, qout, counts_out, depth);
+                  const uint32_t *qin, const uint32_t *count_in, uint32_t *qout,
+                  uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, hipStream_t s) {
+    if (rp.n_lanes == 0) return;
+    uint32_t sw = stage_words_for(scene_bytes), grid = nseg(rp.n_lanes);
+    if (sw) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kBlock), sw * 16, s, scene, scene_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, depth);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kBlock), 0, s, scene, scene_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, depth);
 }
 void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
-                   const uint32_t *count_in, uint32_t upper, hipStream_t s) {
-    if (upper == 0) return;
-    uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + kStackDepth * kBlock * 4;
-    if (sw) hipLaunchKernelGGL(k_shadow<true>, dim3(nblk(upper)), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in, upper);
-    else hipLaunchKernelGGL(k_shadow<false>, dim3(nblk(upper)), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in, upper);
+                   const uint32_t *count_in, hipStream_t s) {
+    if (rp.n_lanes == 0) return;
+    uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + kStackDepth * kBlock * 4, grid = nseg(rp.n_lanes) * kSub;
+    if (sw) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in);
+    else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in);
 }
 void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t film_w, int32_t film_h, hipStream_t s) {
     if (rp.n_lanes == 0) return;

@@ -60,7 +60,7 @@ struct Workspace {
         ray_a.ensure(capacity); ray_b.ensure(capacity); st_a.ensure(capacity);
         res.ensure((size_t) capacity * k); sh_a.ensure(capacity); sh_b.ensure(capacity); sh_c.ensure((size_t) capacity * k);
         hit.ensure(capacity); rng_a.ensure(capacity); hit_id.ensure(capacity); q0.ensure(capacity); q1.ensure(capacity);
-        counts.ensure(2 * kMaxIter); pos.ensure(capacity);
+        counts.ensure(2 * (size_t) kMaxIter * segments_for(capacity)); pos.ensure(capacity);
     }
     Queues queues() {
         Queues q; memset(&q, 0, sizeof q);
@@ -219,32 +219,33 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     StageTimer tm(stats != nullptr, s);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (stats) { memset(stats, 0, sizeof *stats); HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); HIP_CHECK(hipEventRecord(ev0, s)); }
-    std::vector<uint32_t> h_counts; std::vector<uint32_t> batch_lanes, batch_iters;
+    std::vector<uint64_t> h_counts; std::vector<uint32_t> batch_lanes, batch_iters;
 
     for (uint64_t b0 = first; b0 < last; b0 += batch) {
         if (sc->stop.load()) break;
         rp.lane_base = (uint32_t) b0; rp.n_lanes = (uint32_t) std::min<uint64_t>(batch, last - b0);
-        HIP_CHECK(hipMemsetAsync(q.counts, 0, 2 * kMaxIter * sizeof(uint32_t), s));
+        const uint32_t n_seg = segments_for(rp.n_lanes);
         int t = tm.begin(0); launch_generate(rp, q, s); tm.end(0, t);
         if (lane_dump) launch_lane_dump_rays(rp, q, sc->ws.dbg.p, s);
-        const uint32_t *qin = nullptr, *count_in = nullptr; uint32_t upper = rp.n_lanes, it = 0;
+        const uint32_t *qin = nullptr, *count_in = nullptr; uint32_t it = 0;
         for (;; ++it) {
             if (it >= rp.max_depth) break;
             // the last iteration of the reference only looks for emitter hits (dopplertofpath.cpp:136-171);
             // without surface emitters it cannot contribute and is skipped
             if (it + 1 >= rp.max_depth && !has_surface_emitters) break;
             if (it >= kMaxIter) break;
-            if (it >= 8 && (it & 3) == 0) {   // unbounded depth: stop once the queue has drained
-                uint32_t alive = 0;
-                HIP_CHECK(hipMemcpyAsync(&alive, q.counts + 2 * (it - 1), 4, hipMemcpyDeviceToHost, s));
+            if (it >= 8 && (it & 3) == 0) {   // unbounded depth: stop once every segment has drained
+                std::vector<uint32_t> alive(n_seg);
+                HIP_CHECK(hipMemcpyAsync(alive.data(), count_in, (size_t) n_seg * 4, hipMemcpyDeviceToHost, s));
                 HIP_CHECK(hipStreamSynchronize(s));
-                if (alive == 0) break;
+                uint64_t sum = 0; for (uint32_t v : alive) sum += v;
+                if (sum == 0) break;
             }
-            t = tm.begin(1); launch_trace(blob, blob_bytes, rp, q, qin, count_in, upper, s); tm.end(1, t);
-            uint32_t *qout = q.q[it & 1], *cout = q.counts + 2 * it;
-            t = tm.begin(2); launch_shade(blob, blob_bytes, rp, q, qin, count_in, upper, qout, cout, it, s); tm.end(2, t);
-            t = tm.begin(3); launch_shadow(blob, blob_bytes, rp, q, cout + 1, upper, s); tm.end(3, t);
-            qin = qout; count_in = cout;
+            t = tm.begin(1); launch_trace(blob, blob_bytes, rp, q, qin, count_in, s); tm.end(1, t);
+            uint32_t *qout = q.q[it & 1], *alive_out = q.counts + (size_t) (2 * it) * n_seg, *shadow_out = alive_out + n_seg;
+            t = tm.begin(2); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it, s); tm.end(2, t);
+            t = tm.begin(3); launch_shadow(blob, blob_bytes, rp, q, shadow_out, s); tm.end(3, t);
+            qin = qout; count_in = alive_out;
             if (stats) { stats->n_launches_trace++; stats->n_launches_shade++; stats->n_launches_shadow++; }
         }
         if (lane_dump) {
@@ -254,9 +255,13 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         } else {
             t = tm.begin(4); launch_splat(rp, q, d_film, se.crop_w, se.crop_h, s); tm.end(4, t);
         }
-        if (stats) {
-            size_t off = h_counts.size(); h_counts.resize(off + 2 * (size_t) it);
-            if (it) { HIP_CHECK(hipMemcpyAsync(h_counts.data() + off, q.counts, 2 * (size_t) it * 4, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s)); }
+        if (stats) {   // per-iteration totals of this batch: (survivors, shadow rays)
+            std::vector<uint32_t> tmp((size_t) 2 * it * n_seg);
+            if (it) { HIP_CHECK(hipMemcpyAsync(tmp.data(), q.counts, tmp.size() * 4, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s)); }
+            for (uint32_t i = 0; i < 2 * it; ++i) {
+                uint64_t sum = 0; for (uint32_t g = 0; g < n_seg; ++g) sum += tmp[(size_t) i * n_seg + g];
+                h_counts.push_back(sum);
+            }
             batch_lanes.push_back(rp.n_lanes); batch_iters.push_back(it);
             stats->n_batches++;
         }
