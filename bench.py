@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native `dopplertofpath` + `correlated` path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete render of the workload: generate -> [trace -> shade -> shadow] x depth -> splat on every
+rank, ONE film gather to rank 0 (RCCL over xGMI) and the develop (RGB/W).  Scene, BVH and all queues are resident
+in HBM before the timed region; the developed image stays on the device (the PCIe-inclusive rate of the
+host-buffer entry point dtof_render is noted in DESIGN.md).
+
+Workload (BASELINE.json configs[1]): synthetic Cornell box with one linearly translating wall
+(scenes/cornell_wall.xml), 512x512, sinusoidal heterodyne (hetero_frequency=1), stratified time sampling,
+max_depth 4.  N=1: 64 spp.  N>1 ("weak"): the pixel rows are sharded one band per GPU and the sample count
+grows with N (spp = 64*N), so every GPU traces the same number of paths as the single-GPU run and the result
+is the 64*N-spp image.  `--scaling strong` keeps 64 spp in total instead.
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant kernel, HIP-event
+timed inside the library on its own stream) and, at N=1, `cpu_baseline` (the CPU oracle port timed on the host
+cores on a bounded sample of the same workload).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+# SURVEY 8(d) algorithmic byte model (K = 1 offsets): bytes per path-bounce
+B_TRACE, B_SHADE, B_SHADOW = 48, 260 + 36, 32 + 36
+B_BOUNCE = B_TRACE + B_SHADE + B_SHADOW          # 412
+HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default=os.path.join(HERE, "scenes", "cornell_wall.xml"))
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU (weak) / in total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU oracle sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene_path, res, spp, target_s):
+    """Oracle (CPU port of the same algorithm) on all host cores, on a bounded band of rows of the same workload."""
+    from oracle import orc
+    cores = os.cpu_count() or 1
+    osc = orc.Scene(scene_path, dict(resx=res, resy=res))
+    pd = osc.params()
+    mid = res // 2
+    t0 = time.time()
+    _, n = osc.render(pd, seed=0, spp=spp, rows=(mid, mid + 2), threads=cores, raw=True)
+    rate = n / max(time.time() - t0, 1e-6)
+    rows = int(max(2, min(res, target_s * rate / (res * spp))))
+    r0 = max(0, mid - rows // 2)
+    t0 = time.time()
+    _, n = osc.render(pd, seed=0, spp=spp, rows=(r0, r0 + rows), threads=cores, raw=True)
+    dt = time.time() - t0
+    return {"value": round(n / dt / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
+            "sample": "oracle/dtof_oracle.c (scalar C restatement, pthreads over lanes), rows [%d,%d) of the %dx%d %d-spp "
+                      "frame = %d paths in %.1f s" % (r0, r0 + rows, res, res, spp, n, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import mitsuba3dopplertof_amd as mi
+    from mitsuba3dopplertof_amd import distributed as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus (%d) does not match WORLD_SIZE (%d)" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                         % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    scene = mi.load_file(args.scene, resx=args.res, resy=args.res)
+    W, H = scene.size
+    halo = 1                                     # tent filter, radius 1 (imageblock.cpp:423-426)
+    spp = args.spp * world if args.scaling == "weak" else args.spp
+    r0, r1 = D.row_band(H, world, rank)
+    pad_rows = D.padded_rows(H, world, halo)
+    film = torch.zeros((pad_rows, W, 4), dtype=torch.float32, device=dev)
+    film_ptr = film.data_ptr() + halo * W * 4 * 4
+    p0, p1 = D.slab_range(H, world, rank, halo)
+    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    lib = mi._lib()
+
+    acc = {"ms_trace": 0.0, "ms_shade": 0.0, "ms_shadow": 0.0, "ms_generate": 0.0, "ms_splat": 0.0, "ms_total": 0.0,
+           "n_bounces": 0, "n_shadow_rays": 0, "n_paths": 0, "launches": 0}
+
+    def step(record):
+        film.zero_()
+        torch.cuda.synchronize()
+        st = scene.render_rows(film_ptr, seed=0, spp=spp, row_begin=r0, row_end=r1)   # synchronises the library's stream
+        slabs = D.gather_film(film[p0:p1], rank, world)
+        if rank == 0:
+            full = D.overlap_add(slabs, H, world, halo, xp=torch) if world > 1 else film[halo:halo + H]
+            full = full.contiguous()
+            rc = lib.dtof_develop(full.data_ptr(), rgb.data_ptr(), H * W)
+            if rc != 0:
+                raise RuntimeError(lib.dtof_last_error().decode())
+        if record:
+            for k in ("ms_trace", "ms_shade", "ms_shadow", "ms_generate", "ms_splat", "ms_total", "n_bounces", "n_shadow_rays", "n_paths"):
+                acc[k] += st[k]
+            acc["launches"] += st["n_launches_shade"]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    total_paths = W * H * spp
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_paths * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        img = rgb.cpu().numpy()
+        shade_lanes = acc["n_bounces"]                         # lanes processed by the shade launches of this rank
+        shade_s = acc["ms_shade"] * 1e-3
+        loop_s = (acc["ms_trace"] + acc["ms_shade"] + acc["ms_shadow"]) * 1e-3
+        achieved = B_SHADE * shade_lanes / max(shade_s, 1e-12) / 1e9
+        traffic = None
+        tfile = os.path.join(HERE, "profiles", "roofline_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("k_shade", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "hbm", "kernel": "k_shade", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_path_bounce": B_SHADE,
+            "path_bounces_per_launch": round(shade_lanes / max(acc["launches"], 1), 1),
+            "avg_launch_ms": round(acc["ms_shade"] / max(acc["launches"], 1), 5),
+            "loop": {"bytes_per_path_bounce": B_BOUNCE,
+                     "achieved": round(B_BOUNCE * acc["n_bounces"] / max(loop_s, 1e-12) / 1e9, 1),
+                     "frac": round(B_BOUNCE * acc["n_bounces"] / max(loop_s, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+                     "ms_trace": round(acc["ms_trace"] / args.steps, 4), "ms_shade": round(acc["ms_shade"] / args.steps, 4),
+                     "ms_shadow": round(acc["ms_shadow"] / args.steps, 4), "ms_generate": round(acc["ms_generate"] / args.steps, 4),
+                     "ms_splat": round(acc["ms_splat"] / args.steps, 4)},
+        }
+        out = {
+            "metric": "Mpaths/s (whole node), Doppler Cornell 512x512 64spp", "value": round(value, 2), "unit": "Mpaths/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cornell_wall (Cornell box, one linearly translating wall) %dx%d, %d spp%s, sinusoidal "
+                                   "heterodyne hetero_frequency=1, stratified time sampling, max_depth 4, tent filter"
+                                   % (W, H, spp, " (= %d per GPU x %d GPUs, rows sharded)" % (args.spp, world) if world > 1 and args.scaling == "weak" else ""),
+                       "paths_per_step": total_paths, "sharding": "row bands, 1 film gather" if world > 1 else "none",
+                       "image_checksum": float(np.abs(img).sum())},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.scene, args.res, args.spp, args.cpu_seconds)
+            out["cpu_baseline"]["gpu_over_cpu"] = round(value / max(out["cpu_baseline"]["value"], 1e-9), 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

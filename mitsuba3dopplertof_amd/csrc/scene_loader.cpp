@@ -175,19 +175,32 @@ static void parse_named3(const XNode &n, const char *attr, double out[3]) {
     for (int i = 0; i < 3; ++i) out[i] = parse_double(t[i]);
 }
 
-static Mat4d parse_transform(const XNode &node) {
-    Mat4d cur = m_identity();
+// A transform is the pair (matrix, inverse), like the reference's Transform (matrix + inverse_transpose,
+// include/mitsuba/core/transform.h:43-70): translate / scale / rotate / lookat carry analytic inverses and
+// composition multiplies both; only <matrix> is inverted numerically.
+struct Xf { Mat4d m, inv; };
+static Mat4d m_transpose(const Mat4d &a) { Mat4d r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[4 * i + j] = a.m[4 * j + i]; return r; }
+static void normalize3(double v[3]) { double il = 1.0 / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] *= il; v[1] *= il; v[2] *= il; }
+static void cross3(const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+static Xf parse_transform(const XNode &node) {
+    Xf cur { m_identity(), m_identity() };
     for (auto &opp : node.children) {
-        const XNode &op = *opp; Mat4d t = m_identity();
+        const XNode &op = *opp; Mat4d t = m_identity(), ti = m_identity();
         if (op.tag == "matrix") {
             auto tok = tokenize(op.get("value"));
             if (tok.size() == 16) { for (int i = 0; i < 16; ++i) t.m[i] = parse_double(tok[i]); }
             else if (tok.size() == 9) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t.m[4 * i + j] = parse_double(tok[3 * i + j]); }
             else fail("matrix: expected 16 or 9 values");
+            ti = m_inverse(t);
         } else if (op.tag == "translate") {
             double v[3]; parse_xyz(op, 0.0, v); t.m[3] = v[0]; t.m[7] = v[1]; t.m[11] = v[2];
+            ti.m[3] = -v[0]; ti.m[7] = -v[1]; ti.m[11] = -v[2];
         } else if (op.tag == "scale") {
             double v[3]; parse_xyz(op, 1.0, v); t.m[0] = v[0]; t.m[5] = v[1]; t.m[10] = v[2];
+            ti.m[0] = 1.0 / v[0]; ti.m[5] = 1.0 / v[1]; ti.m[10] = 1.0 / v[2];
         } else if (op.tag == "rotate") {
             double a[3]; parse_xyz(op, 0.0, a);
             if (!op.attr("angle")) fail("rotate: missing \"angle\" attribute");
@@ -195,27 +208,31 @@ static Mat4d parse_transform(const XNode &node) {
             t.m[0] = a[0] * a[0] * cm + c;        t.m[1] = a[0] * a[1] * cm - a[2] * s; t.m[2] = a[0] * a[2] * cm + a[1] * s;
             t.m[4] = a[0] * a[1] * cm + a[2] * s; t.m[5] = a[1] * a[1] * cm + c;        t.m[6] = a[1] * a[2] * cm - a[0] * s;
             t.m[8] = a[0] * a[2] * cm - a[1] * s; t.m[9] = a[1] * a[2] * cm + a[0] * s; t.m[10] = a[2] * a[2] * cm + c;
+            ti = m_transpose(t);
         } else if (op.tag == "lookat") {
             double o[3], tg[3], up[3] = { 0, 0, 0 };
             parse_named3(op, "origin", o); parse_named3(op, "target", tg);
             if (op.attr("up")) parse_named3(op, "up", up);
             double d[3] = { tg[0] - o[0], tg[1] - o[1], tg[2] - o[2] };
-            double dl = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-            for (double &x : d) x /= dl;
+            normalize3(d);
             if (up[0] * up[0] + up[1] * up[1] + up[2] * up[2] == 0) {   // coordinate_system(dir).first
                 double sg = std::copysign(1.0, d[2]), a = -1.0 / (sg + d[2]), b = d[0] * d[1] * a;
-                up[0] = d[0] * d[0] * a * sg + 1.0; up[1] = b * sg; up[2] = -d[0] * sg;
+                up[0] = (d[0] * d[0] * a) * sg + 1.0; up[1] = b * sg; up[2] = -d[0] * sg;
             }
-            double l[3] = { up[1] * d[2] - up[2] * d[1], up[2] * d[0] - up[0] * d[2], up[0] * d[1] - up[1] * d[0] };
-            double ll = std::sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
-            for (double &x : l) x /= ll;
-            double nu[3] = { d[1] * l[2] - d[2] * l[1], d[2] * l[0] - d[0] * l[2], d[0] * l[1] - d[1] * l[0] };
+            double l[3], nu[3];
+            cross3(up, d, l); normalize3(l); cross3(d, l, nu);
+            const double *rows[3] = { l, nu, d };
             for (int r = 0; r < 3; ++r) { t.m[4 * r] = l[r]; t.m[4 * r + 1] = nu[r]; t.m[4 * r + 2] = d[r]; t.m[4 * r + 3] = o[r]; }
+            for (int r = 0; r < 3; ++r) {
+                ti.m[4 * r] = rows[r][0]; ti.m[4 * r + 1] = rows[r][1]; ti.m[4 * r + 2] = rows[r][2];
+                ti.m[4 * r + 3] = -(rows[r][0] * o[0] + rows[r][1] * o[1] + rows[r][2] * o[2]);
+            }
             for (double x : t.m) if (std::isnan(x)) fail("invalid lookat transformation");
         } else {
             fail("transform nodes can only contain transform operations");
         }
-        cur = m_mul(t, cur);   // ctx.transform = T(op) * ctx.transform
+        cur.m = m_mul(t, cur.m);       // ctx.transform = T(op) * ctx.transform
+        cur.inv = m_mul(cur.inv, ti);
     }
     return cur;
 }
@@ -310,8 +327,8 @@ struct Obj {
     PropBag props;
     std::map<std::string, std::vector<double>> colors;            // <rgb>/<spectrum>
     std::map<std::string, std::vector<double>> vectors;           // <point>/<vector>
-    std::map<std::string, Mat4d> transforms;
-    std::map<std::string, std::vector<std::pair<float, Mat4d>>> animations;
+    std::map<std::string, Xf> transforms;
+    std::map<std::string, std::vector<std::pair<float, Xf>>> animations;
     std::vector<std::pair<std::string, std::shared_ptr<Obj>>> children;   // document order; refs resolved later
     std::vector<std::pair<size_t, std::string>> refs;                     // (position in children, id)
 };
@@ -385,7 +402,7 @@ static std::shared_ptr<Obj> parse_object(const XNode &n, LoadCtx &ctx) {
         }
         else if (c.tag == "transform") { o->transforms[name] = parse_transform(c); }
         else if (c.tag == "animation") {
-            std::vector<std::pair<float, Mat4d>> keys;
+            std::vector<std::pair<float, Xf>> keys;
             for (auto &tr : c.children) {
                 if (tr->tag != "transform" || !tr->attr("time")) fail("<animation> may only contain <transform time=...> nodes");
                 float time = (float) parse_double(tr->get("time"));
@@ -451,14 +468,15 @@ static HostShape make_shape(const Obj &o, bool strip_to_world) {
     HostShape s; s.id = o.id;
     if (o.plugin == "rectangle") s.kind = SHAPE_RECT; else if (o.plugin == "cube") s.kind = SHAPE_MESH;
     else fail("unsupported shape plugin \"" + o.plugin + "\" (supported: rectangle, cube, shapegroup, instance)");
-    Mat4d tw = m_identity();
+    Xf tw { m_identity(), m_identity() };
     if (!strip_to_world) { auto t = o.transforms.find("to_world"); if (t != o.transforms.end()) tw = t->second; }
     s.flip_normals = o.props.get_bool("flip_normals", false);
     s.face_normals = o.props.get_bool("face_normals", false);
     if (s.kind == SHAPE_RECT && s.flip_normals) {   // rectangle.cpp:91-99
-        Mat4d f = m_identity(); f.m[10] = -1.0; tw = m_mul(tw, f); s.flip_normals = false;
+        Mat4d f = m_identity(); f.m[10] = -1.0; Mat4d fi = m_identity(); fi.m[10] = 1.0 / -1.0;
+        tw.m = m_mul(tw.m, f); tw.inv = m_mul(fi, tw.inv); s.flip_normals = false;
     }
-    to_f32(tw, s.to_world); to_f32(m_inverse(tw), s.to_object);
+    to_f32(tw.m, s.to_world); to_f32(tw.inv, s.to_object);
     const Obj *bsdf = nullptr;
     for (auto &c : o.children) {
         if (c.first == "bsdf") { if (bsdf) fail("Only a single BSDF child object can be specified per shape."); bsdf = c.second.get(); }
@@ -480,10 +498,10 @@ static HostObject make_instance(const Obj &o, uint32_t group) {
         // AnimatedTransform::eval only interpolates keyframes 0 and 1 (include/mitsuba/core/transform.h:458-466)
         ob.n_keys = (uint32_t) std::min<size_t>(a->second.size(), 2);
         if (ob.n_keys == 0) { ob.n_keys = 1; to_f32(m_identity(), ob.key[0]); }
-        for (uint32_t i = 0; i < ob.n_keys && i < a->second.size(); ++i) { ob.key_time[i] = a->second[i].first; to_f32(a->second[i].second, ob.key[i]); }
+        for (uint32_t i = 0; i < ob.n_keys && i < a->second.size(); ++i) { ob.key_time[i] = a->second[i].first; to_f32(a->second[i].second.m, ob.key[i]); }
     } else {
         auto t = o.transforms.find("to_world");
-        ob.n_keys = 1; to_f32(t != o.transforms.end() ? t->second : m_identity(), ob.key[0]);
+        ob.n_keys = 1; to_f32(t != o.transforms.end() ? t->second.m : m_identity(), ob.key[0]);
     }
     return ob;
 }
@@ -551,7 +569,7 @@ static void make_sensor(const Obj &o, HostScene &sc) {
     }
     if (!have_filter) fail("unsupported rfilter plugin \"gaussian\" (the film default); specify <rfilter type=\"tent\"/> or \"box\"");
     auto t = o.transforms.find("to_world");
-    to_f32(t != o.transforms.end() ? t->second : m_identity(), se.to_world);
+    to_f32(t != o.transforms.end() ? t->second.m : m_identity(), se.to_world);
     se.shutter_open = (float) o.props.get_float("shutter_open", 0.0);
     se.shutter_close = (float) o.props.get_float("shutter_close", 0.0);
     if (se.shutter_close - se.shutter_open < 0) fail("Shutter opening time must be less than or equal to the shutter closing time!");
@@ -595,7 +613,7 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
                 if (tw != o.transforms.end()) fail("Only one of the parameters 'position' and 'to_world' can be specified at the same time!'");
                 for (int i = 0; i < 3; ++i) e.pos[i] = (float) pv->second[i];
             } else {
-                float m[16]; to_f32(tw != o.transforms.end() ? tw->second : m_identity(), m);
+                float m[16]; to_f32(tw != o.transforms.end() ? tw->second.m : m_identity(), m);
                 e.pos[0] = m[3]; e.pos[1] = m[7]; e.pos[2] = m[11];
             }
             auto ic = o.colors.find("intensity");

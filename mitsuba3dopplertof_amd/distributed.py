@@ -1,0 +1,62 @@
+"""Pixel-row sharding of one render across the GPUs of a node and the single film gather.
+
+The reference has no distributed layer; the partition is sound because every lane's RNG
+streams are pure functions of its global lane index (src/render/sampler.cpp:115-134,
+src/samplers/correlated.cpp:38-64) and lanes of one pixel are contiguous
+(src/render/integrator.cpp:273-285), so any pixel partition reproduces the single-device image up to
+the (already unordered) float accumulation order of the splat.
+
+Rank r renders crop rows [r0, r1).  With a reconstruction filter of footprint radius `halo` pixels
+(tent r=1 -> 1) its splats touch rows [r0-halo, r1+halo), so each rank keeps a zero-padded slab of
+(rows_per_rank + 2*halo) rows; ONE gather (RCCL over xGMI: torch.distributed backend "nccl") brings the
+slabs to rank 0, which overlap-adds them and develops RGB/W.
+"""
+import numpy as np
+
+
+def rows_per_rank(height, world):
+    return (height + world - 1) // world
+
+
+def row_band(height, world, rank):
+    """[r0, r1) of `rank`; trailing ranks may get a shorter (or empty) band."""
+    n = rows_per_rank(height, world)
+    r0 = min(rank * n, height)
+    return r0, min(r0 + n, height)
+
+
+def padded_rows(height, world, halo):
+    """rows of the padded film every rank allocates: film row y lives at padded row y + halo"""
+    return rows_per_rank(height, world) * world + 2 * halo
+
+
+def slab_range(height, world, rank, halo):
+    """padded-row range [p0, p1) that holds everything `rank` splats; the same size on every rank"""
+    n = rows_per_rank(height, world)
+    p0 = rank * n
+    return p0, p0 + n + 2 * halo
+
+
+def overlap_add(slabs, height, world, halo, xp=np):
+    """slabs[r]: (rows_per_rank + 2*halo, W, C) -> full film (height, W, C).  `xp` = numpy or torch."""
+    n = rows_per_rank(height, world)
+    s0 = slabs[0]
+    if xp is np:
+        out = np.zeros((n * world + 2 * halo,) + tuple(s0.shape[1:]), dtype=s0.dtype)
+    else:
+        out = xp.zeros((n * world + 2 * halo,) + tuple(s0.shape[1:]), dtype=s0.dtype, device=s0.device)
+    for r, s in enumerate(slabs):
+        p0, p1 = slab_range(height, world, r, halo)
+        out[p0:p1] += s
+    return out[halo:halo + height]
+
+
+def gather_film(slab, rank, world, group=None):
+    """The one collective of a frame: gather equal-sized slabs on rank 0 (torch.distributed)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return [slab]
+    dst = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
+    dist.gather(slab, dst, dst=0, group=group)
+    return dst

@@ -23,55 +23,109 @@ F32 = np.float32
 
 
 # ----------------------------------------------------------------------------- transforms (double)
+# A transform is a pair (matrix, inverse) of row-major 4x4 lists of Python floats (IEEE double), like the
+# reference's Transform (matrix + inverse_transpose, include/mitsuba/core/transform.h:43-70): translate / scale /
+# rotate / lookat carry ANALYTIC inverses and composition multiplies both, only <matrix> is inverted numerically.
+# Products are plain multiply-add loops in k order so that the C++ loader can mirror them bit for bit.
+def _ident():
+    return [1.0 if i % 5 == 0 else 0.0 for i in range(16)]
+
+
+def _mul(a, b):
+    r = [0.0] * 16
+    for i in range(4):
+        for j in range(4):
+            acc = 0.0
+            for k in range(4):
+                acc += a[4 * i + k] * b[4 * k + j]
+            r[4 * i + j] = acc
+    return r
+
+
+def _transpose(a):
+    return [a[4 * (i % 4) + i // 4] for i in range(16)]
+
+
+def _inverse(a):
+    """Gauss-Jordan with partial pivoting (same algorithm as the product's m_inverse)"""
+    w = [[a[4 * i + j] for j in range(4)] + [1.0 if i == j else 0.0 for j in range(4)] for i in range(4)]
+    for c in range(4):
+        piv = c
+        for r in range(c + 1, 4):
+            if abs(w[r][c]) > abs(w[piv][c]):
+                piv = r
+        if w[piv][c] == 0.0:
+            raise ValueError("singular transformation matrix")
+        if piv != c:
+            w[piv], w[c] = w[c], w[piv]
+        d = 1.0 / w[c][c]
+        w[c] = [x * d for x in w[c]]
+        for r in range(4):
+            if r != c:
+                f = w[r][c]
+                if f != 0.0:
+                    w[r] = [x - f * y for x, y in zip(w[r], w[c])]
+    return [w[i][4 + j] for i in range(4) for j in range(4)]
+
+
 def _translate(v):
-    m = np.eye(4)
-    m[:3, 3] = v
-    return m
+    m, inv = _ident(), _ident()
+    m[3], m[7], m[11] = v
+    inv[3], inv[7], inv[11] = -v[0], -v[1], -v[2]
+    return m, inv
 
 
 def _scale(v):
-    return np.diag([v[0], v[1], v[2], 1.0])
+    m, inv = _ident(), _ident()
+    m[0], m[5], m[10] = v
+    inv[0], inv[5], inv[10] = 1.0 / v[0], 1.0 / v[1], 1.0 / v[2]
+    return m, inv
 
 
 def _rotate(axis, angle_deg):
-    # Transform4f::rotate (transform.h:180-184) -> dr::rotate<Matrix4>(axis, rad): Rodrigues, axis used as given
-    a = np.asarray(axis, dtype=np.float64)
-    th = math.radians(angle_deg)
+    # Transform4f::rotate (transform.h:180-184) -> dr::rotate<Matrix4>(axis, rad): Rodrigues, axis used as given;
+    # inverse = transpose
+    x, y, z = axis
+    th = angle_deg * (math.pi / 180.0)
     s, c = math.sin(th), math.cos(th)
     cm = 1.0 - c
-    x, y, z = a
-    m = np.eye(4)
-    m[0, 0] = x * x * cm + c
-    m[1, 1] = y * y * cm + c
-    m[2, 2] = z * z * cm + c
-    m[1, 0] = x * y * cm + z * s
-    m[0, 1] = x * y * cm - z * s
-    m[2, 0] = x * z * cm - y * s
-    m[0, 2] = x * z * cm + y * s
-    m[2, 1] = y * z * cm + x * s
-    m[1, 2] = y * z * cm - x * s
-    return m
+    m = _ident()
+    m[0] = x * x * cm + c;      m[1] = x * y * cm - z * s;  m[2] = x * z * cm + y * s
+    m[4] = x * y * cm + z * s;  m[5] = y * y * cm + c;      m[6] = y * z * cm - x * s
+    m[8] = x * z * cm - y * s;  m[9] = y * z * cm + x * s;  m[10] = z * z * cm + c
+    return m, _transpose(m)
+
+
+def _normalize(v):
+    il = 1.0 / math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+    return [v[0] * il, v[1] * il, v[2] * il]
+
+
+def _cross(a, b):
+    return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
 
 
 def _coordinate_system(n):
-    # include/mitsuba/core/vector.h:116-136 (double)
+    # include/mitsuba/core/vector.h:116-136 (double); returns the first vector only
     sign = math.copysign(1.0, n[2])
     a = -1.0 / (sign + n[2])
     b = n[0] * n[1] * a
-    return np.array([(n[0] * n[0] * a) * sign + 1.0, b * sign, -n[0] * sign])
+    return [(n[0] * n[0] * a) * sign + 1.0, b * sign, -n[0] * sign]
 
 
-def _look_at(origin, target, up):
-    # transform.h:255-283
-    o, t, u = (np.asarray(v, dtype=np.float64) for v in (origin, target, up))
-    d = t - o
-    d = d / np.linalg.norm(d)
-    left = np.cross(u, d)
-    left = left / np.linalg.norm(left)
-    new_up = np.cross(d, left)
-    m = np.eye(4)
-    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = left, new_up, d, o
-    return m
+def _look_at(o, t, u):
+    # transform.h:255-283: columns left, new_up, dir, origin; inverse = [R^T | -R^T o]
+    d = _normalize([t[0] - o[0], t[1] - o[1], t[2] - o[2]])
+    left = _normalize(_cross(u, d))
+    nu = _cross(d, left)
+    m, inv = _ident(), _ident()
+    for r in range(3):
+        m[4 * r], m[4 * r + 1], m[4 * r + 2], m[4 * r + 3] = left[r], nu[r], d[r], o[r]
+    rows = (left, nu, d)
+    for r in range(3):
+        inv[4 * r], inv[4 * r + 1], inv[4 * r + 2] = rows[r]
+        inv[4 * r + 3] = -(rows[r][0] * o[0] + rows[r][1] * o[1] + rows[r][2] * o[2])
+    return m, inv
 
 
 def _tokens(s):
@@ -89,36 +143,40 @@ def _vec(node, default=0.0):
 
 
 def _parse_transform(node):
-    m = np.eye(4)
+    m, inv = _ident(), _ident()
     for op in node:
         tag = op.tag
         if tag == "matrix":
             t = [float(x) for x in _tokens(op.get("value"))]
             if len(t) == 16:
-                mm = np.array(t).reshape(4, 4)
+                mm = t
             elif len(t) == 9:
-                mm = np.eye(4)
-                mm[:3, :3] = np.array(t).reshape(3, 3)
+                mm = _ident()
+                for i in range(3):
+                    for j in range(3):
+                        mm[4 * i + j] = t[3 * i + j]
             else:
                 raise ValueError("matrix: expected 16 or 9 values")
+            mi = _inverse(mm)
         elif tag == "translate":
-            mm = _translate(_vec(op))
+            mm, mi = _translate(_vec(op))
         elif tag == "scale":
-            mm = _scale(_vec(op, 1.0))
+            mm, mi = _scale(_vec(op, 1.0))
         elif tag == "rotate":
-            mm = _rotate(_vec(op), float(op.get("angle")))
+            mm, mi = _rotate(_vec(op), float(op.get("angle")))
         elif tag == "lookat":
             o = [float(x) for x in _tokens(op.get("origin"))]
             t = [float(x) for x in _tokens(op.get("target"))]
             u = [float(x) for x in _tokens(op.get("up", "0,0,0"))]
-            if sum(x * x for x in u) == 0:
-                dd = np.array(t) - np.array(o)
-                u = list(_coordinate_system(dd / np.linalg.norm(dd)))
-            mm = _look_at(o, t, u)
+            if u[0] * u[0] + u[1] * u[1] + u[2] * u[2] == 0:
+                u = _coordinate_system(_normalize([t[0] - o[0], t[1] - o[1], t[2] - o[2]]))
+            mm, mi = _look_at(o, t, u)
+            if any(math.isnan(x) for x in mm):
+                raise ValueError("invalid lookat transformation")
         else:
             raise ValueError("transform nodes can only contain transform operations (got <%s>)" % tag)
-        m = mm @ m   # ctx.transform = T(op) * ctx.transform
-    return m
+        m, inv = _mul(mm, m), _mul(inv, mi)   # ctx.transform = T(op) * ctx.transform (matrix and inverse)
+    return m, inv
 
 
 # ----------------------------------------------------------------------------- property bags
@@ -247,11 +305,7 @@ def _parse_object(node, registry):
 
 # ----------------------------------------------------------------------------- flat description
 def _m32(m):
-    return np.asarray(m, dtype=np.float64).astype(F32)
-
-
-def _inv32(m):
-    return np.linalg.inv(np.asarray(m, dtype=np.float64)).astype(F32)
+    return np.asarray(m, dtype=np.float64).reshape(4, 4).astype(F32)
 
 
 def _bsdf_of(props, registry):
@@ -285,12 +339,13 @@ def _shape_record(sp, registry, strip_to_world):
     kind = {"rectangle": 0, "cube": 1}.get(sp.plugin)
     if kind is None:
         raise ValueError('unsupported shape plugin "%s"' % sp.plugin)
-    tw = np.eye(4)
+    tw, tinv = _ident(), _ident()
     if not strip_to_world and "to_world" in sp and sp["to_world"][0] == "transform":
-        tw = sp["to_world"][1]
+        tw, tinv = sp["to_world"][1]
     flip = sp.get_b("flip_normals", False)
-    if kind == 0 and flip:   # rectangle.cpp:91-99
-        tw = tw @ _scale([1.0, 1.0, -1.0])
+    if kind == 0 and flip:   # rectangle.cpp:91-99: to_world * scale(1, 1, -1)
+        fm, fi = _scale([1.0, 1.0, -1.0])
+        tw, tinv = _mul(tw, fm), _mul(fi, tinv)
         flip = False
     bsdfs = [c for c in sp.children if c[0] in ("bsdf", "ref")]
     if any(c[0] == "emitter" for c in sp.children):
@@ -301,7 +356,7 @@ def _shape_record(sp, registry, strip_to_world):
     else:
         twosided, refl = 0, np.array([0.5] * 3, dtype=F32)   # shape.cpp:66-72 default diffuse
     return dict(kind=kind, twosided=twosided, flip_normals=int(flip), face_normals=int(sp.get_b("face_normals", False)),
-                reflectance=refl, to_world=_m32(tw), to_object=_inv32(tw))
+                reflectance=refl, to_world=_m32(tw), to_object=_m32(tinv))
 
 
 def load(source, params=None, is_string=False):
@@ -328,7 +383,7 @@ def load(source, params=None, is_string=False):
             if "position" in child:
                 pos = np.asarray(child["position"][1], dtype=np.float64).astype(F32)
             else:
-                tw = child["to_world"][1] if "to_world" in child else np.eye(4)
+                tw = child["to_world"][1][0] if "to_world" in child else _ident()
                 pos = _m32(tw)[:3, 3]
             inten = child["intensity"] if "intensity" in child else ("float", 1.0)
             iv = [inten[1]] * 3 if inten[0] in ("float", "int") else inten[1]
@@ -375,14 +430,14 @@ def _instance_record(tw, group):
         key[0] = np.eye(4)
         n = 1
     elif tw[0] == "transform":
-        key[0] = _m32(tw[1])
+        key[0] = _m32(tw[1][0])
         n = 1
     else:
         keys = tw[1]
         n = min(len(keys), 2)   # AnimatedTransform::eval only looks at keyframes 0 and 1 (transform.h:458-466)
         for i in range(n):
             kt[i] = keys[i][0]
-            key[i] = _m32(keys[i][1])
+            key[i] = _m32(keys[i][1][0])
     return dict(kind=1, index=group, n_keys=n, key_time=kt, key=key)
 
 
@@ -440,7 +495,7 @@ def _sensor_record(sp):
         cw, ch = w, h
     if filt is None:
         raise ValueError('unsupported rfilter plugin "gaussian" (film default)')
-    tw = sp["to_world"][1] if "to_world" in sp else np.eye(4)
+    tw = sp["to_world"][1][0] if "to_world" in sp else _ident()
     so = sp.get_f("shutter_open", 0.0)
     sc = sp.get_f("shutter_close", 0.0)
     near, far = sp.get_f("near_clip", 1e-2), sp.get_f("far_clip", 1e4)

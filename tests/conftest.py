@@ -1,0 +1,53 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SCENES = os.path.join(ROOT, "scenes")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure)."""
+    from oracle import orc as _orc
+    _orc.lib()
+    return _orc
+
+
+@pytest.fixture(scope="session")
+def mi():
+    import mitsuba3dopplertof_amd as _mi
+    if not os.path.exists(_mi.lib_path()):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "mitsuba3dopplertof_amd", "csrc"), "-j4"])
+    _mi._lib()
+    return _mi
+
+
+# The parity configurations: (name, scene file, -D parameters, spp).  Sizes are chosen so that the oracle
+# finishes in seconds; they cover every waveform, every time-sampling strategy, correlated/uncorrelated paths,
+# odd (non power-of-two) spp, a crop-free non-square film and the instanced Domino scene.
+CONFIGS = [
+    ("c1_boxes_antithetic", "cornell_boxes.xml", dict(resx=32, resy=32), 16),
+    ("c2_wall_stratified", "cornell_wall.xml", dict(resx=32, resy=32), 16),
+    ("c3_wall_mirror", "cornell_wall.xml", dict(resx=32, resy=24, time_sampling_method="antithetic_mirror", antithetic_shift=0.0), 8),
+    ("boxes_uniform_rect", "cornell_boxes.xml", dict(resx=24, resy=32, time_sampling_method="uniform", wave_function_type="rectangular"), 8),
+    ("boxes_tri_uncorrelated", "cornell_boxes.xml", dict(resx=32, resy=32, wave_function_type="triangular", path_correlation_depth=0), 8),
+    ("boxes_trap_depth6_spp6", "cornell_boxes.xml", dict(resx=16, resy=16, wave_function_type="trapezoidal", max_depth=6, path_correlation_depth=2, time_sampling_method="stratified"), 6),
+    ("boxes_tcn4", "cornell_boxes.xml", dict(resx=16, resy=16, time_correlate_number=4, time_sampling_method="antithetic"), 8),
+    ("domino_small", "domino_small.xml", dict(resx=48, resy=48), 4),
+]
+
+
+@pytest.fixture(scope="session")
+def configs():
+    return CONFIGS

@@ -1,0 +1,159 @@
+"""Host logic of the product (no GPU): the C++ scene.xml loader against the oracle's independent Python
+restatement (bit-exact float32 exports), constructor parity, the reference loader's error behaviour, and that
+the C-ABI library loads and exports every symbol include/dtof.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENES
+
+
+def _export_all(sc):
+    return [sc.export(k) for k in range(4)]
+
+
+def _oracle_all(fs):
+    obj = np.concatenate([np.concatenate([np.asarray(o["key_time"], np.float32), np.asarray(o["key"], np.float32).reshape(-1)])
+                          for o in fs.objects]) if fs.objects else np.zeros(0, np.float32)
+    shp = np.concatenate([np.concatenate([s["to_world"].reshape(-1), s["to_object"].reshape(-1)]) for s in fs.shapes])
+    se = fs.sensor
+    sen = np.concatenate([se["to_world"].reshape(-1), np.array([se["x_fov"], se["near_clip"], se["far_clip"],
+                                                                 se["shutter_open"], se["shutter_close"]], np.float32)])
+    em = np.concatenate([np.concatenate([e["position"], e["intensity"]]) for e in fs.emitters]) if fs.emitters else np.zeros(0, np.float32)
+    return [obj.astype(np.float32), shp.astype(np.float32), sen.astype(np.float32), em.astype(np.float32)]
+
+
+@pytest.mark.parametrize("xml,params", [
+    ("cornell_boxes.xml", dict(resx=64, resy=48)),
+    ("cornell_wall.xml", dict()),
+    ("domino_small.xml", dict()),
+    ("domino.xml", dict()),
+])
+def test_loader_matches_oracle_loader_bit_exact(mi, orc, xml, params):
+    path = os.path.join(SCENES, xml)
+    sc = mi.load_file(path, **params)
+    from oracle import scene_xml
+    fs = scene_xml.load(path, params)
+    for got, exp in zip(_export_all(sc), _oracle_all(fs)):
+        assert got.shape == exp.shape
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    info = sc.info()
+    assert (info["n_shapes"], info["n_groups"], info["n_objects"], info["n_emitters"]) == \
+        (len(fs.shapes), len(fs.groups), len(fs.objects), len(fs.emitters))
+    assert info["crop_width"] == fs.sensor["crop_w"] and info["crop_height"] == fs.sensor["crop_h"]
+
+
+def test_transform_ops_compose_like_the_reference(mi):
+    """ops left-multiply (xml.cpp:902-1007): translate after rotate after scale; lookat; 3x3 matrix."""
+    from oracle import scene_xml
+    xml = """<scene version="3.0.0">
+      <integrator type="dopplertofpath"/>
+      <sensor type="perspective"><float name="fov" value="35"/><string name="fov_axis" value="y"/>
+        <transform name="to_world"><lookat origin="1, 2, 3" target="0, 0.5, -1" up="0, 1, 0"/></transform>
+        <sampler type="correlated"/><film type="hdrfilm"><integer name="width" value="40"/><integer name="height" value="20"/>
+        <rfilter type="box"/></film></sensor>
+      <shape type="rectangle"><transform name="to_world"><scale x="2" y="3" z="1"/><rotate x="0.3" y="1" z="0.2" angle="33"/>
+        <translate x="1" y="-2" z="0.5"/></transform></shape>
+      <shape type="cube"><boolean name="flip_normals" value="true"/><transform name="to_world">
+        <matrix value="0 1 0 0 0 2 0 0 0 3"/><translate value="0.25"/></transform>
+        <bsdf type="diffuse"><rgb name="reflectance" value="0.2"/></bsdf></shape>
+      <emitter type="point"><point name="position" x="1" y="2" z="3"/><spectrum name="intensity" value="7"/></emitter>
+    </scene>""".replace('value="0 1 0 0 0 2 0 0 0 3"', 'value="0 1 0 1 0 0 0 0 2"')
+    sc = mi.load_string(xml)
+    fs = scene_xml.load(xml, {}, is_string=True)
+    for got, exp in zip(_export_all(sc), _oracle_all(fs)):
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    assert sc.size == (40, 20)
+    assert sc.export(3).tolist() == [1, 2, 3, 7, 7, 7]
+
+
+def test_constructor_parameters_match_oracle(mi, orc):
+    path = os.path.join(SCENES, "cornell_boxes.xml")
+    cases = [None,
+             dict(type="dopplertofpath", max_depth=7, w_g=24.0, hetero_frequency=0.5, hetero_offset=0.25, wave_function_type="triangular",
+                  time_sampling_method="stratified", path_correlation_depth=3, rr_depth=3),
+             dict(type="dopplertofpath", w_s=30.002, g_1=0.7, g_0=0.3, low_frequency_component_only=False, time_sampling_method="antithetic_mirror"),
+             dict(type="dopplertofpath", sensor_phase_offset=0.3, time=0.002, use_stratified_sampling_for_each_interval=False)]
+    sc = mi.load_file(path)
+    osc = orc.Scene(path)
+    for c in cases:
+        if c is not None:
+            sc.set_integrator(c)
+        pd = osc.params(integrator=c) if c is not None else osc.params()
+        info = sc.info()
+        for ok, ik in [("time", "time"), ("w_g_mhz", "w_g"), ("g_1", "g_1"), ("g_0", "g_0"), ("w_s_mhz", "w_s"), ("phase_offset", "phase_offset"),
+                       ("hetero_frequency", "hetero_frequency"), ("antithetic_shift", "antithetic_shift")]:
+            assert np.float32(pd[ok]).view(np.uint32) == np.float32(info[ik]).view(np.uint32), (c, ok)
+        for ok, ik in [("wave_type", "wave_type"), ("low_frequency_component_only", "low_frequency_component_only"),
+                       ("time_sampling", "time_sampling"), ("stratify_each_interval", "stratify_each_interval"),
+                       ("path_correlation_depth", "path_correlation_depth"), ("max_depth", "max_depth"), ("rr_depth", "rr_depth"),
+                       ("time_correlate_number", "time_correlate_number"), ("path_correlate_number", "path_correlate_number")]:
+            assert int(pd[ok]) == int(info[ik]), (c, ok)
+
+
+def test_error_behaviour_mirrors_the_reference_loader(mi):
+    path = os.path.join(SCENES, "cornell_boxes.xml")
+    text = open(path).read()
+    with pytest.raises(mi.DtofError, match="undefined parameter"):
+        mi.load_string(text.replace("$resx", "$nosuchparam"))
+    with pytest.raises(mi.DtofError, match="missing version"):
+        mi.load_string(text.replace(' version="3.0.0"', ""))
+    with pytest.raises(mi.DtofError, match="unsupported integrator plugin"):
+        mi.load_string(text.replace('type="dopplertofpath"', 'type="path"'))
+    with pytest.raises(mi.DtofError, match="unsupported sampler plugin"):
+        mi.load_string(text.replace('type="correlated"', 'type="independent"'))
+    with pytest.raises(mi.DtofError, match="unreferenced property"):
+        mi.load_string(text.replace('<float name="w_g" value="30" />', '<float name="w_g" value="30" /><float name="bogus" value="1" />'))
+    with pytest.raises(mi.DtofError, match="wrong type"):
+        mi.load_string(text.replace('<integer name="max_depth" value="$max_depth" />', '<float name="max_depth" value="4.0" />'))
+    with pytest.raises(mi.DtofError, match="unknown wave_function_type"):
+        mi.load_string(text, wave_function_type="sawtooth")
+    with pytest.raises(mi.DtofError, match="unknown object"):
+        mi.load_string(text.replace('<ref id="FloorBSDF" />', '<ref id="NoSuchBSDF" />'))
+    with pytest.raises(mi.DtofError, match="strictly monotonically increasing"):
+        mi.load_string(text.replace('<transform time="0.0015">', '<transform time="0">'))
+    with pytest.raises(mi.DtofError, match="max_depth"):
+        mi.load_string(text, max_depth=-3)
+    with pytest.raises(mi.DtofError):
+        mi.load_file(os.path.join(SCENES, "does_not_exist.xml"))
+    with pytest.raises(mi.DtofError, match="unsupported"):
+        mi.load_dict({"type": "path"})
+    sc = mi.load_string(text)
+    with pytest.raises(mi.DtofError, match="rr_depth"):
+        sc.set_integrator(dict(type="dopplertofpath", rr_depth=0))
+    with pytest.raises(mi.DtofError, match="out of bounds"):
+        sc.render(spp=2, sensor=3)
+
+
+def test_capi_exports_every_declared_symbol(mi):
+    hdr = open(os.path.join(ROOT, "include", "dtof.h")).read()
+    names = set(re.findall(r"\b(dtof_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 28
+    lib = ctypes.CDLL(mi.lib_path())
+    for n in sorted(names):
+        assert hasattr(lib, n), n
+    lib.dtof_version.restype = ctypes.c_char_p
+    assert b"dopplertofpath" in lib.dtof_version()
+
+
+def test_plugin_shims_export_the_discovery_symbols(mi):
+    """MI_EXPORT_PLUGIN's two extern "C" symbols with the reference's strings (dopplertofpath.cpp:330, correlated.cpp:195)."""
+    for so, name, descr in [("dopplertofpath", b"DopplerToFPathIntegrator", b"Doppler ToF Path Tracer integrator"),
+                            ("correlated", b"CorrelatedSampler", b"Independent Sampler")]:
+        lib = ctypes.CDLL(os.path.join(ROOT, "mitsuba3dopplertof_amd", "plugins", so + ".so"))
+        lib.plugin_name.restype = ctypes.c_char_p
+        lib.plugin_descr.restype = ctypes.c_char_p
+        assert lib.plugin_name() == name and lib.plugin_descr() == descr
+
+
+def test_no_cpu_fallback_in_the_product_path():
+    """The product may not import or link anything under oracle/."""
+    pkg = os.path.join(ROOT, "mitsuba3dopplertof_amd")
+    for base, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(base, f), errors="replace").read()
+                assert "import oracle" not in text and "from oracle" not in text and "dtof_oracle" not in text, f

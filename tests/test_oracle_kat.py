@@ -1,0 +1,167 @@
+"""Pins the CPU oracle (oracle/) against every known-answer vector that exists for the building blocks of the
+hot path and against the committed golden vectors.  CPU only.
+
+The reference ships no test or fixture for dopplertofpath/correlated themselves, so the path as a
+whole stays "parity unpinned"; what CAN be pinned is pinned here:
+  K1  sample_tea_float32 -- the 8 exact values of src/core/tests/test_random.py:8-16
+  K2  PCG32 -- O'Neill's published pcg32 demo vector (seed 42, stream 54) and the Dr.Jit default-seed stream
+  K3  permute_kensler bijection for n = 2^(p+1)+p, p<3, 75 seeds (test_random.py:69-75)
+  K4  closed-form waveform values (include/mitsuba/render/waveform_utils.h:24-62)
+  K5  analytic properties of the modulation weight and of antithetic sampling
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SCENES
+
+
+def test_k1_tea_known_answers(orc):
+    L = orc.lib()
+    exp = {(1, 1): 0.5424730777740479, (1, 2): 0.5079904794692993, (1, 3): 0.4171961545944214,
+           (1, 4): 0.008385419845581055, (1, 5): 0.8085528612136841, (2, 1): 0.6939879655838013,
+           (3, 1): 0.6978365182876587, (4, 1): 0.4897364377975464}
+    for (a, b), v in exp.items():
+        assert L.orc_tea_float32(a, b, 4) == np.float32(v)
+
+
+def test_k2_pcg32_known_answers(orc):
+    L = orc.lib()
+    st, inc = C.c_uint64(), C.c_uint64()
+    L.orc_pcg32_seed(42, 54, C.byref(st), C.byref(inc))
+    got = [L.orc_pcg32_next_u32(C.byref(st), inc) for _ in range(6)]
+    assert got == [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293, 0xbfa4784b, 0xcbed606e]
+    # seed() must leave state/inc exactly as the published pcg32_srandom_r does
+    L.orc_pcg32_seed(42, 54, C.byref(st), C.byref(inc))
+    assert inc.value == (54 << 1) | 1
+    # next_float32 = (u >> 9 | 0x3f800000) - 1 in [0, 1)
+    f = [L.orc_pcg32_next_f32(C.byref(st), inc) for _ in range(1000)]
+    assert min(f) >= 0.0 and max(f) < 1.0
+    u = 0xa15c02b7
+    assert f[0] == np.uint32((u >> 9) | 0x3f800000).view(np.float32) - np.float32(1)
+
+
+def test_k3_kensler_is_a_permutation(orc):
+    L = orc.lib()
+    for p in range(3):
+        n = 2 ** (p + 1) + p
+        for seed in range(75):
+            perm = sorted(L.orc_permute_kensler(i, n, seed) for i in range(n))
+            assert perm == list(range(n))
+    for n in (1, 2, 7, 32, 100, 513):
+        for seed in (0, 1, 0xdeadbeef):
+            assert sorted(L.orc_permute_kensler(i, n, seed) for i in range(n)) == list(range(n))
+
+
+def test_k4_waveforms_closed_form(orc):
+    L = orc.lib()
+    pts = [0.0, math.pi / 2, math.pi, 3 * math.pi / 2]
+    lp = {0: [1, 0, -1, 0], 1: [2, 0, -2, 0], 2: [2 / 3, 0, -2 / 3, 0], 3: [2, 0, -2, 0]}
+    for wave, exp in lp.items():
+        for t, e in zip(pts, exp):
+            assert abs(L.orc_waveform_low_pass(t, wave) - e) < 2e-6, (wave, t)
+    # non-low-pass: cos / square / triangle; trapezoid has no case and evaluates cos (waveform_utils.h:27-32)
+    assert abs(L.orc_waveform(0.3, 0) - math.cos(0.3)) < 1e-6
+    assert L.orc_waveform(0.1, 1) == 1.0 and L.orc_waveform(math.pi, 1) == -1.0 and L.orc_waveform(6.0, 1) == 1.0
+    assert abs(L.orc_waveform(0.0, 2) - 1.0) < 1e-6 and abs(L.orc_waveform(math.pi, 2) + 1.0) < 1e-6
+    assert abs(L.orc_waveform(0.3, 3) - math.cos(0.3)) < 1e-6
+    # periodicity through fmod(t, 2pi)
+    for wave in range(4):
+        assert abs(L.orc_waveform_low_pass(1.0, wave) - L.orc_waveform_low_pass(1.0 + 2 * math.pi, wave)) < 1e-5
+    # trapezoid is the clamped, doubled rectangle low-pass
+    for t in np.linspace(0, 6.2, 50):
+        r = L.orc_waveform_low_pass(float(t), 1)
+        assert abs(L.orc_waveform_low_pass(float(t), 3) - min(max(2 * r, -2), 2)) < 1e-6
+
+
+def test_sincos_matches_libm(orc):
+    L = orc.lib()
+    s, c = C.c_float(), C.c_float()
+    worst = 0.0
+    for x in np.linspace(-20, 20, 8001).astype(np.float32):
+        L.orc_sincos(float(x), C.byref(s), C.byref(c))
+        worst = max(worst, abs(s.value - math.sin(float(x))), abs(c.value - math.cos(float(x))))
+    assert worst < 2.5e-7
+
+
+def test_k5_modulation_weight_properties(orc):
+    L = orc.lib()
+    sc = orc.Scene(os.path.join(SCENES, "cornell_boxes.xml"), dict(resx=8, resy=8))
+    p0 = orc.make_params(sc.params(integrator=dict(type="dopplertofpath", hetero_frequency=1.0, hetero_offset=0.0)))
+    p5 = orc.make_params(sc.params(integrator=dict(type="dopplertofpath", hetero_frequency=1.0, hetero_offset=0.5)))
+    ph = orc.make_params(sc.params(integrator=dict(type="dopplertofpath", hetero_frequency=0.0)))
+    for t, ln in [(0.0, 1.0), (0.0004, 7.3), (0.0012, 13.9)]:
+        w0 = L.orc_modulation_weight(C.byref(p0), t, ln)
+        w5 = L.orc_modulation_weight(C.byref(p5), t, ln)
+        assert abs(w0 + w5) < 2e-6                       # hetero_offset 0 vs 0.5: sign flip (sinusoidal)
+        # W = 0.25 cos(w_d t + phi), phi = 2 pi f/c L with f = 30 MHz, c = 300 m/us
+        wd = 2 * math.pi / 0.0015
+        assert abs(w0 - 0.25 * math.cos(wd * t + 2 * math.pi * 30 / 300 * ln)) < 5e-6
+        assert abs(L.orc_modulation_weight(C.byref(ph), t, ln) - 0.25 * math.cos(2 * math.pi * 30 / 300 * ln)) < 5e-6
+
+
+def test_constructor_rounding(orc):
+    sc = orc.Scene(os.path.join(SCENES, "cornell_boxes.xml"), dict(resx=8, resy=8))
+    pd = sc.params()
+    assert pd["time"] == np.float32(0.0015) and pd["hetero_frequency"] == np.float32(1.0)
+    assert pd["w_s_mhz"] == np.float32(30.0 + float(np.float32(1.0) / np.float32(0.0015)) * 1e-6)
+    pd = sc.params(integrator=dict(type="dopplertofpath", w_s=30.001))
+    assert pd["hetero_frequency"] == np.float32(float(np.float32(30.001) - np.float32(30.0)) * 1e6 * float(np.float32(0.0015)))
+    # defaults: time_sampling_method "antithetic" with shift 0.5, other methods shift 0 (integrator.cpp:58,72-76)
+    assert pd["time_sampling"] == 2 and pd["antithetic_shift"] == 0.5 and pd["max_depth"] == 0xffffffff and pd["rr_depth"] == 5
+    assert sc.params(integrator=dict(type="dopplertofpath", time_sampling_method="stratified"))["antithetic_shift"] == 0.0
+    with pytest.raises(ValueError):
+        sc.params(integrator=dict(type="dopplertofpath", wave_function_type="sawtooth"))
+    with pytest.raises(ValueError):
+        sc.params(integrator=dict(type="path"))
+
+
+def test_antithetic_pairs_cancel_on_a_static_scene(orc):
+    """With shift 0.5 and hetero_frequency 1 the two lanes of a pair see cos(x) and cos(x + pi); with fully
+    correlated paths a static scene integrates to ~0 (float32 rounding only), while uniform sampling does not."""
+    xml = open(os.path.join(SCENES, "cornell_boxes.xml")).read().replace('z="0.015"', 'z="0.0"').replace('z="-0.015"', 'z="0.0"')
+    sc = orc.Scene(xml, dict(resx=16, resy=16), is_string=True)
+    img, _ = sc.render(sc.params(), seed=0, spp=16, threads=os.cpu_count())
+    uni, _ = sc.render(sc.params(integrator=dict(type="dopplertofpath", max_depth=4, hetero_frequency=1.0,
+                                                 time_sampling_method="uniform")), seed=0, spp=16, threads=os.cpu_count())
+    assert np.abs(img).max() < 1e-6 < 1e-3 < np.abs(uni).max()
+
+
+def test_lane_streams_are_tile_invariant(orc):
+    """Every lane is a pure function of its global index: evaluating a sub-range reproduces the full wavefront."""
+    sc = orc.Scene(os.path.join(SCENES, "cornell_wall.xml"), dict(resx=16, resy=16))
+    pd = sc.params()
+    full = sc.render_lanes(pd, 1, 8, 0, 16 * 16 * 8)
+    part = sc.render_lanes(pd, 1, 8, 777, 300)
+    assert np.array_equal(full[777:1077].tobytes(), part.tobytes())
+    film_a, _ = sc.render(pd, seed=1, spp=8, raw=True)
+    film_b, _ = sc.render(pd, seed=1, spp=8, rows=(0, 7), raw=True)
+    film_c, _ = sc.render(pd, seed=1, spp=8, rows=(7, 16), raw=True)
+    assert np.abs(film_a - (film_b + film_c)).max() <= 1e-5 * np.abs(film_a[..., :3]).max()
+
+
+def test_film_weights_sum_to_spp_in_the_interior(orc):
+    sc = orc.Scene(os.path.join(SCENES, "cornell_wall.xml"), dict(resx=16, resy=16))
+    film, n = sc.render(sc.params(), seed=0, spp=8, raw=True)
+    assert n == 16 * 16 * 8
+    # the tent weights of a sample sum to 1 unless part of its footprint falls off the film
+    assert 0.9 * n < film[..., 3].sum() <= n * (1 + 1e-5)
+    assert np.all(film[2:-2, 2:-2, 3] > 0)
+
+
+def test_oracle_reproduces_golden_vectors(orc, configs):
+    """Regression pin: the committed vectors (tests/golden/make_golden.py) are what this oracle produces."""
+    for name, xml, params, spp in configs:
+        g = np.load(os.path.join(GOLDEN, name + ".npz"))
+        sc = orc.Scene(os.path.join(SCENES, xml), params)
+        pd = sc.params()
+        n = g["lane_rgb"].shape[0]
+        lanes = sc.render_lanes(pd, 3, spp, 0, n)
+        for key, field in (("lane_rgb", "rgb"), ("lane_pos", "sample_pos"), ("lane_time", "time"), ("lane_ray_d", "ray_d")):
+            assert np.array_equal(g[key].view(np.uint32), np.ascontiguousarray(lanes[field]).view(np.uint32)), (name, key)
+        if name in ("c1_boxes_antithetic", "boxes_trap_depth6_spp6"):
+            img, _ = sc.render(pd, seed=3, spp=spp, threads=os.cpu_count())
+            assert np.array_equal(img, g["image"]), name
