@@ -63,6 +63,13 @@ def _lib():
     if _LIB is not None:
         return _LIB
     path = lib_path()
+    try:
+        # PyTorch wheels ship their own HIP runtime (torch/lib/libamdhip64.so).  One process can host only one
+        # runtime, so when torch is installed it must be the first to load it; libdtof.so then binds to the same
+        # runtime by soname.  (torch is plumbing for device buffers / torch.distributed, never compute.)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise ImportError("%s is missing -- build it with `make -C %s/csrc` (or __graft_entry__.build()); "
                           "there is no CPU fallback" % (path, _HERE))

@@ -61,12 +61,12 @@ struct LaneDebug {       // mirrors orc_lane's comparable fields
 void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s);
 uint32_t segments_for(uint32_t n_lanes);   // number of queue segments (count slots) for a batch
 void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
-                  const uint32_t *qin, const uint32_t *count_in, hipStream_t s);
+                  const uint32_t *qin, const uint32_t *count_in, uint32_t stack_depth, hipStream_t s);
 void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                   const uint32_t *qin, const uint32_t *count_in, uint32_t *qout,
                   uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, hipStream_t s);
 void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
-                   const uint32_t *count_in, hipStream_t s);
+                   const uint32_t *count_in, uint32_t stack_depth, hipStream_t s);
 void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t film_w, int32_t film_h, hipStream_t s);
 void launch_develop(const float *film, float *rgb, int64_t n_pixels, hipStream_t s);
 void launch_lane_dump(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s);

@@ -147,7 +147,8 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
     best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
     if (sv.n_nodes == 0) return false;
     // direction reciprocal for the slab test only (exact zero components are nudged)
-    V3 id = mk(1.0f / (d.x == 0.f ? 1e-30f : d.x), 1.0f / (d.y == 0.f ? 1e-30f : d.y), 1.0f / (d.z == 0.f ? 1e-30f : d.z));
+    // v_rcp_f32 (1 ulp) is enough here: the boxes are padded by 1e-5 relative on the host
+    V3 id = mk(__builtin_amdgcn_rcpf(d.x == 0.f ? 1e-30f : d.x), __builtin_amdgcn_rcpf(d.y == 0.f ? 1e-30f : d.y), __builtin_amdgcn_rcpf(d.z == 0.f ? 1e-30f : d.z));
     int sp = 0;
     uint32_t cur = 0;
     const uint32_t stride = blockDim.x;
@@ -702,7 +703,7 @@ __global__ void k_lane_dump_rays(RenderParams rp, Queues q, LaneDebug *out) {
 // ---------------------------------------------------------------------------- launchers
 static inline uint32_t nblk(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 constexpr uint32_t kLdsSceneLimit = 48 * 1024;
-constexpr uint32_t kStackDepth = 32;
+static inline uint32_t stack_bytes(uint32_t depth) { return (depth < 2 ? 2 : depth) * kBlock * 4; }
 
 void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s) {
     if (rp.n_lanes == 0) return;
@@ -714,9 +715,9 @@ static inline uint32_t nseg(uint32_t n) { return (n + kSeg - 1) / kSeg; }
 uint32_t segments_for(uint32_t n_lanes) { return nseg(n_lanes); }
 
 void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
-                  const uint32_t *qin, const uint32_t *count_in, hipStream_t s) {
+                  const uint32_t *qin, const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
-    uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + kStackDepth * kBlock * 4, grid = nseg(rp.n_lanes) * kSub;
+    uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + stack_bytes(stack_depth), grid = nseg(rp.n_lanes) * kSub;
     if (sw) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, q, qin, count_in, rp.n_lanes);
     else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, q, qin, count_in, rp.n_lanes);
 }
@@ -729,9 +730,9 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
     else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kBlock), 0, s, scene, scene_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, depth);
 }
 void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
-                   const uint32_t *count_in, hipStream_t s) {
+                   const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
-    uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + kStackDepth * kBlock * 4, grid = nseg(rp.n_lanes) * kSub;
+    uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + stack_bytes(stack_depth), grid = nseg(rp.n_lanes) * kSub;
     if (sw) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in);
     else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in);
 }

@@ -12,6 +12,7 @@
 #include "dtof_math.h"
 #include <atomic>
 #include <cstring>
+#include <cstdlib>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -45,7 +46,10 @@ template <typename T> struct DevBuf {
 };
 
 constexpr uint32_t kMaxIter = 256;           // counts slots per batch
-constexpr uint64_t kTargetBatchLanes = 1ull << 22;
+static uint64_t target_batch_lanes() {   // lanes per wavefront batch (DTOF_BATCH_LANES overrides)
+    static uint64_t v = [] { const char *e = getenv("DTOF_BATCH_LANES"); uint64_t x = e ? strtoull(e, nullptr, 10) : 0; return x ? x : (1ull << 24); }();
+    return v;
+}
 
 struct Workspace {
     DevBuf<float4> ray_a, ray_b, st_a, res, sh_a, sh_b, sh_c;
@@ -207,19 +211,21 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     uint64_t first = lane_dump ? dump_begin : lanes_per_row * (uint64_t) row_begin;
     uint64_t last = lane_dump ? dump_begin + dump_n : lanes_per_row * (uint64_t) std::max(row_end, row_begin);
     if (last > total_lanes) throw std::runtime_error("lane range exceeds the wavefront");
-    uint64_t batch = lane_dump ? std::min<uint64_t>(kTargetBatchLanes, std::max<uint64_t>(dump_n, 1))
-                               : std::max<uint64_t>(1, kTargetBatchLanes / lanes_per_row) * lanes_per_row;
+    uint64_t batch = lane_dump ? std::min<uint64_t>(target_batch_lanes(), std::max<uint64_t>(dump_n, 1))
+                               : std::max<uint64_t>(1, target_batch_lanes() / lanes_per_row) * lanes_per_row;
     batch = std::min<uint64_t>(batch, std::max<uint64_t>(last - first, 1));
     sc->ws.ensure((uint32_t) batch, rp.n_offsets);
     if (lane_dump) sc->ws.dbg.ensure(batch);
     Queues q = sc->ws.queues();
     hipStream_t s = sc->stream;
     const uint8_t *blob = sc->d_blob.p; uint32_t blob_bytes = (uint32_t) sc->blob.size();
+    const uint32_t stack_depth = ((const BlobHeader *) sc->blob.data())->tlas_depth;
     const bool has_surface_emitters = false;   // supported emitters: point (no emitter-hit term, point.cpp:186-188)
     StageTimer tm(stats != nullptr, s);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (stats) { memset(stats, 0, sizeof *stats); HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); HIP_CHECK(hipEventRecord(ev0, s)); }
-    std::vector<uint64_t> h_counts; std::vector<uint32_t> batch_lanes, batch_iters;
+    struct Pinned { uint32_t *p; uint32_t iters, n_seg; };
+    std::vector<Pinned> pinned; std::vector<uint64_t> h_counts; std::vector<uint32_t> batch_lanes, batch_iters;
 
     for (uint64_t b0 = first; b0 < last; b0 += batch) {
         if (sc->stop.load()) break;
@@ -241,10 +247,10 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
                 uint64_t sum = 0; for (uint32_t v : alive) sum += v;
                 if (sum == 0) break;
             }
-            t = tm.begin(1); launch_trace(blob, blob_bytes, rp, q, qin, count_in, s); tm.end(1, t);
+            t = tm.begin(1); launch_trace(blob, blob_bytes, rp, q, qin, count_in, stack_depth, s); tm.end(1, t);
             uint32_t *qout = q.q[it & 1], *alive_out = q.counts + (size_t) (2 * it) * n_seg, *shadow_out = alive_out + n_seg;
             t = tm.begin(2); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it, s); tm.end(2, t);
-            t = tm.begin(3); launch_shadow(blob, blob_bytes, rp, q, shadow_out, s); tm.end(3, t);
+            t = tm.begin(3); launch_shadow(blob, blob_bytes, rp, q, shadow_out, stack_depth, s); tm.end(3, t);
             qin = qout; count_in = alive_out;
             if (stats) { stats->n_launches_trace++; stats->n_launches_shade++; stats->n_launches_shadow++; }
         }
@@ -255,21 +261,27 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         } else {
             t = tm.begin(4); launch_splat(rp, q, d_film, se.crop_w, se.crop_h, s); tm.end(4, t);
         }
-        if (stats) {   // per-iteration totals of this batch: (survivors, shadow rays)
-            std::vector<uint32_t> tmp((size_t) 2 * it * n_seg);
-            if (it) { HIP_CHECK(hipMemcpyAsync(tmp.data(), q.counts, tmp.size() * 4, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s)); }
-            for (uint32_t i = 0; i < 2 * it; ++i) {
-                uint64_t sum = 0; for (uint32_t g = 0; g < n_seg; ++g) sum += tmp[(size_t) i * n_seg + g];
-                h_counts.push_back(sum);
-            }
+        if (stats) {   // per-iteration per-segment counts of this batch -> pinned host staging (summed after the final sync)
+            size_t words = (size_t) 2 * it * n_seg;
+            if (words) {
+                uint32_t *dst = nullptr;
+                HIP_CHECK(hipHostMalloc((void **) &dst, words * 4, hipHostMallocDefault));
+                HIP_CHECK(hipMemcpyAsync(dst, q.counts, words * 4, hipMemcpyDeviceToHost, s));
+                pinned.push_back({ dst, it, n_seg });
+            } else pinned.push_back({ nullptr, 0, n_seg });
             batch_lanes.push_back(rp.n_lanes); batch_iters.push_back(it);
             stats->n_batches++;
+            // the next batch reuses q.counts: order its first shade after this copy (same stream => already ordered)
         }
     }
     if (stats) {
         HIP_CHECK(hipEventRecord(ev1, s)); HIP_CHECK(hipEventSynchronize(ev1));
         float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); stats->ms_total = ms;
         (void) hipEventDestroy(ev0); (void) hipEventDestroy(ev1);
+        for (auto &pb : pinned) {
+            for (uint32_t i = 0; i < 2 * pb.iters; ++i) { uint64_t sum = 0; for (uint32_t g = 0; g < pb.n_seg; ++g) sum += pb.p[(size_t) i * pb.n_seg + g]; h_counts.push_back(sum); }
+            if (pb.p) (void) hipHostFree(pb.p);
+        }
         stats->ms_generate = tm.total(0); stats->ms_trace = tm.total(1); stats->ms_shade = tm.total(2);
         stats->ms_shadow = tm.total(3); stats->ms_splat = tm.total(4);
         size_t off = 0;

@@ -24,7 +24,7 @@ enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMA
 struct BlobHeader {
     uint32_t n_nodes, n_objects, n_groups, n_shapes, n_tris, n_emitters;
     uint32_t off_nodes, off_objects, off_groups, off_shapes, off_tris, off_shading, off_emitters;
-    uint32_t total_bytes, has_instances, pad1;
+    uint32_t total_bytes, has_instances, tlas_depth;   // tlas_depth: deepest leaf (stack entries a traversal can need)
 };
 static_assert(sizeof(BlobHeader) == 64, "BlobHeader");
 

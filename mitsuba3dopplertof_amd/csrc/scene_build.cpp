@@ -186,6 +186,17 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     h.n_nodes = (uint32_t) nodes.size(); h.n_objects = (uint32_t) objects.size(); h.n_groups = (uint32_t) groups.size();
     h.n_shapes = (uint32_t) shapes.size(); h.n_tris = (uint32_t) tris.size(); h.n_emitters = (uint32_t) emitters.size();
     h.has_instances = has_instances;
+    {   // deepest leaf below the root = stack entries a depth-first traversal can hold
+        uint32_t deepest = 1;
+        std::vector<std::pair<uint32_t, uint32_t>> todo; if (!nodes.empty()) todo.emplace_back(0u, 1u);
+        while (!todo.empty()) {
+            auto [ni, d] = todo.back(); todo.pop_back();
+            deepest = std::max(deepest, d);
+            for (uint32_t c : { nodes[ni].left, nodes[ni].right })
+                if (c != kNoChild && !(c & kLeafFlag)) todo.emplace_back(c, d + 1);
+        }
+        h.tlas_depth = deepest + 1;
+    }
     uint32_t off = sizeof(BlobHeader);
     h.off_nodes = off;    off = align16(off + (uint32_t) (nodes.size() * sizeof(BvhNode)));
     h.off_objects = off;  off = align16(off + (uint32_t) (objects.size() * sizeof(DObject)));

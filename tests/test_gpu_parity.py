@@ -227,7 +227,7 @@ def test_multi_pass_harness_is_the_mean_over_seeds(mi):
     assert np.allclose(avg, sum(parts) / 4, rtol=1e-6, atol=1e-12)
     tof = mi.to_tof_image(avg)
     assert tof.shape == (16, 16) and np.allclose(tof, (0.2126 * avg[..., 0] + 0.7152 * avg[..., 1] + 0.0722 * avg[..., 2]) * 0.0015)
-    assert np.array_equal(mi.render(sc, spp=16, seed=1, integrator=integ), parts[1])
+    assert rel_linf(mi.render(sc, spp=16, seed=1, integrator=integ), parts[1]) <= IMG_TOL   # film atomics are unordered
 
 
 # --------------------------------------------------------------------------- full-size properties (BASELINE configs[1])
