@@ -90,6 +90,16 @@ DTOF_D void instance_matrix(const DObject &ob, float time, float *m) {
     for (int i = 0; i < 12; ++i) m[i] = ob.key0[i] * omt + ob.key1[i] * t;
 }
 
+// Slab test against a padded box; NaNs (0*inf) fall out of the min/max chain conservatively.
+DTOF_D float box_entry(const float *bmin, const float *bmax, V3 o, V3 id, float tbest) {
+    float tx0 = (bmin[0] - o.x) * id.x, tx1 = (bmax[0] - o.x) * id.x;
+    float ty0 = (bmin[1] - o.y) * id.y, ty1 = (bmax[1] - o.y) * id.y;
+    float tz0 = (bmin[2] - o.z) * id.z, tz1 = (bmax[2] - o.z) * id.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
+    return tn <= tf ? tn : INFINITY;
+}
+
 // Closest hit (ANY=false) or occlusion (ANY=true) of one top-level object.  Candidates are every
 // primitive hit with t <= maxt; the winner is the smallest t, ties going to the lowest
 // (object, shape, primitive) -- the rule the oracle uses, independent of traversal order.
@@ -118,6 +128,10 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
                 }
             }
         } else {
+            // cull the triangle loop with the mesh's own (padded) bounds: TLAS boxes of moving instances are the
+            // union over the whole motion and let many rays through that miss the mesh at their time
+            V3 lid = mk(__builtin_amdgcn_rcpf(ld.x == 0.f ? 1e-30f : ld.x), __builtin_amdgcn_rcpf(ld.y == 0.f ? 1e-30f : ld.y), __builtin_amdgcn_rcpf(ld.z == 0.f ? 1e-30f : ld.z));
+            if (!(box_entry(sh.bmin, sh.bmax, lo, lid, ANY ? maxt : best.t) < INFINITY)) continue;
             for (uint32_t f = 0; f < sh.n_tris; ++f) {
                 if (tri_hit(sv.tris[sh.first_tri + f], lo, ld, maxt, t, u, v)) {
                     if (ANY) return true;
@@ -131,16 +145,6 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
     return found;
 }
 
-// Slab test against a padded box; NaNs (0*inf) fall out of the min/max chain conservatively.
-DTOF_D float box_entry(const float *bmin, const float *bmax, V3 o, V3 id, float tbest) {
-    float tx0 = (bmin[0] - o.x) * id.x, tx1 = (bmax[0] - o.x) * id.x;
-    float ty0 = (bmin[1] - o.y) * id.y, ty1 = (bmax[1] - o.y) * id.y;
-    float tz0 = (bmin[2] - o.z) * id.z, tz1 = (bmax[2] - o.z) * id.z;
-    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
-    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
-    return tn <= tf ? tn : INFINITY;
-}
-
 // TLAS traversal; `stack` is a per-thread LDS column (stride blockDim.x).
 template <bool ANY>
 DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best) {
@@ -149,13 +153,15 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
     // direction reciprocal for the slab test only (exact zero components are nudged)
     // v_rcp_f32 (1 ulp) is enough here: the boxes are padded by 1e-5 relative on the host
     V3 id = mk(__builtin_amdgcn_rcpf(d.x == 0.f ? 1e-30f : d.x), __builtin_amdgcn_rcpf(d.y == 0.f ? 1e-30f : d.y), __builtin_amdgcn_rcpf(d.z == 0.f ? 1e-30f : d.z));
+    // "while-while" traversal: every lane first descends inner nodes until it holds a leaf (or is done), THEN the
+    // lanes that hold a leaf run the expensive object intersection together -- the wave does not pay the leaf
+    // body once per node step of its slowest lane.
+    constexpr uint32_t kDone = 0x7fffffffu;
     int sp = 0;
     uint32_t cur = 0;
     const uint32_t stride = blockDim.x;
     for (;;) {
-        if (cur & kLeafFlag) {
-            if (intersect_object<ANY>(sv, cur & ~kLeafFlag, o, d, time, maxt, best) && ANY) return true;
-        } else {
+        while (!(cur & kLeafFlag) && cur != kDone) {
             const BvhNode &n = sv.nodes[cur];
             float tl = box_entry(n.lmin, n.lmax, o, id, best.t);
             float tr = n.right != kNoChild ? box_entry(n.rmin, n.rmax, o, id, best.t) : INFINITY;
@@ -163,10 +169,14 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
             if (hl && hr) {
                 uint32_t nearc = tl <= tr ? n.left : n.right, farc = tl <= tr ? n.right : n.left;
                 stack[sp * stride] = farc; ++sp;
-                cur = nearc; continue;
-            } else if (hl) { cur = n.left; continue; }
-            else if (hr) { cur = n.right; continue; }
+                cur = nearc;
+            } else if (hl) cur = n.left;
+            else if (hr) cur = n.right;
+            else if (sp == 0) cur = kDone;
+            else { --sp; cur = stack[sp * stride]; }
         }
+        if (cur == kDone) break;
+        if (intersect_object<ANY>(sv, cur & ~kLeafFlag, o, d, time, maxt, best) && ANY) return true;
         if (sp == 0) break;
         --sp; cur = stack[sp * stride];
     }
@@ -425,12 +435,20 @@ DTOF_D uint32_t block_append(bool pred, uint32_t *s_cnt, uint32_t &running) {
     return slot;
 }
 
-template <bool LDS>
-__global__ __launch_bounds__(kBlock) void k_shade(const uint8_t *scene, uint32_t scene_bytes, RenderParams rp, Queues q,
+// FUSED = false: the "split" pipeline -- shadow rays go to the shadow queue (k_shadow commits them) and the
+//                 continuation ray is traced by the next k_trace launch.
+// FUSED = true : one kernel per bounce -- the occlusion query and the closest-hit query of the continuation ray
+//                 run inline, so neither the shadow queue nor a separate trace launch exists; the state streams
+//                 through HBM once per bounce (this is the default: the split kernels are latency-bound on small
+//                 scenes and the shadow records alone cost 96 B per path-bounce).
+template <bool LDS, bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_shade(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp, Queues q,
                                                   const uint32_t *qin, const uint32_t *count_in,
-                                                  uint32_t *qout, uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth) {
+                                                  uint32_t *qout, uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth,
+                                                  uint32_t trace_next) {
     extern __shared__ uint4 lds[];
     __shared__ uint32_t s_cnt[4];
+    uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
     const uint32_t seg = blockIdx.x;
     const uint32_t count = seg_count(count_in, seg, rp.n_lanes);
     uint32_t n_alive = 0, n_shadow = 0;
@@ -442,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(const uint8_t *scene, uint32_t
     bool in_range = j < count;
     bool alive = false, want_shadow = false;
     uint32_t l = 0;
-    float4 sha, shb; float3 cand[kMaxOffsets];
+    float4 sha, shb, nra, nrb; float3 cand[kMaxOffsets];
     if (in_range) {
         l = qin ? qin[seg * kSeg + j] : seg * kSeg + j;
         uint32_t hid = q.hit_id[l];
@@ -533,8 +551,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(const uint8_t *scene, uint32_t
             if (rr_active) thr = thr * rcp(rr_prob);
             alive = active_next && (!rr_active || rr_continue) && thr_max != 0.f;
             if (alive) {
-                q.ray_a[l] = make_float4(no.x, no.y, no.z, time);
-                q.ray_b[l] = make_float4(nd.x, nd.y, nd.z, kLargest);
+                nra = make_float4(no.x, no.y, no.z, time); nrb = make_float4(nd.x, nd.y, nd.z, kLargest);
+                q.ray_a[l] = nra;
+                q.ray_b[l] = nrb;
                 q.st_a[l] = make_float4(thr.x, thr.y, thr.z, path_length);
                 q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
             }
@@ -542,15 +561,39 @@ __global__ __launch_bounds__(kBlock) void k_shade(const uint8_t *scene, uint32_t
     }
     uint32_t slot = block_append(alive, s_cnt, n_alive);
     if (alive) qout[seg * kSeg + slot] = l;
-    uint32_t sslot = seg * kSeg + block_append(want_shadow, s_cnt, n_shadow);
-    if (want_shadow) {
-        q.sh_a[sslot] = sha; q.sh_b[sslot] = shb;
+    if (FUSED) {
+        if (want_shadow) {   // test_visibility (scene.cpp:266-271): an unoccluded sample commits its candidate result
+            Hit hs;
+            if (!trace_scene<true>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs)) {
 #pragma unroll
-        for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets)
-            q.sh_c[(size_t) k * q.capacity + sslot] = make_float4(cand[k].x, cand[k].y, cand[k].z, u2f(l));
+                for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets)
+                    q.res[(size_t) k * q.capacity + l] = make_float4(cand[k].x, cand[k].y, cand[k].z, 0.f);
+            }
+        }
+        if (alive && trace_next) {   // closest hit of the continuation ray, consumed by the next bounce
+            Hit h;
+            bool found = trace_scene<false>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
+            q.hit[l] = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
+            q.hit_id[l] = found ? (h.obj | (h.shape << 24)) : 0xffffffffu;
+        }
+        n_shadow += (uint32_t) __popcll(__ballot(want_shadow)) * ((threadIdx.x & 63) == 0 ? 1u : 0u);   // per-wave partial (stats only)
+    } else {
+        uint32_t sslot = seg * kSeg + block_append(want_shadow, s_cnt, n_shadow);
+        if (want_shadow) {
+            q.sh_a[sslot] = sha; q.sh_b[sslot] = shb;
+#pragma unroll
+            for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets)
+                q.sh_c[(size_t) k * q.capacity + sslot] = make_float4(cand[k].x, cand[k].y, cand[k].z, u2f(l));
+        }
     }
     }   // chunk loop
     }   // count != 0
+    if (FUSED) {   // shadow-ray count for the statistics: sum the four per-wave partials
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = n_shadow;
+        __syncthreads();
+        n_shadow = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    }
     if (threadIdx.x == 0) { alive_out[seg] = n_alive; shadow_out[seg] = n_shadow; }
 }
 
@@ -723,11 +766,16 @@ void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
 }
 void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                   const uint32_t *qin, const uint32_t *count_in, uint32_t *qout,
-                  uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, hipStream_t s) {
+                  uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, bool fused, bool trace_next,
+                  uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
-    uint32_t sw = stage_words_for(scene_bytes), grid = nseg(rp.n_lanes);
-    if (sw) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kBlock), sw * 16, s, scene, scene_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, depth);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kBlock), 0, s, scene, scene_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, depth);
+    uint32_t sw = stage_words_for(scene_bytes), grid = nseg(rp.n_lanes), lds = sw * 16 + (fused ? stack_bytes(stack_depth) : 0);
+    uint32_t tn = trace_next ? 1u : 0u;
+#define DTOF_LAUNCH_SHADE(L, F) hipLaunchKernelGGL((k_shade<L, F>), dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, qin, \
+                                                   count_in, qout, alive_out, shadow_out, depth, tn)
+    if (sw) { if (fused) DTOF_LAUNCH_SHADE(true, true); else DTOF_LAUNCH_SHADE(true, false); }
+    else    { if (fused) DTOF_LAUNCH_SHADE(false, true); else DTOF_LAUNCH_SHADE(false, false); }
+#undef DTOF_LAUNCH_SHADE
 }
 void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                    const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {

@@ -82,11 +82,11 @@ struct dtof_scene {
     PluginParams pp;
     std::vector<uint8_t> blob;
     DevBuf<uint8_t> d_blob; bool uploaded = false;
-    Workspace ws;
+    Workspace ws, ws2;                       // one per in-flight batch
     DevBuf<float> d_film, d_rgb;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
     std::atomic<bool> stop { false };
-    ~dtof_scene() { if (stream) (void) hipStreamDestroy(stream); }
+    ~dtof_scene() { if (stream) (void) hipStreamDestroy(stream); if (stream2) (void) hipStreamDestroy(stream2); }
 };
 
 struct dtof_sampler {
@@ -99,6 +99,7 @@ namespace {
 
 void ensure_device(dtof_scene *sc) {
     if (!sc->stream) HIP_CHECK(hipStreamCreate(&sc->stream));
+    if (!sc->stream2) HIP_CHECK(hipStreamCreate(&sc->stream2));
     if (!sc->uploaded) {
         sc->d_blob.ensure(sc->blob.size());
         HIP_CHECK(hipMemcpy(sc->d_blob.p, sc->blob.data(), sc->blob.size(), hipMemcpyHostToDevice));
@@ -175,15 +176,15 @@ RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, cons
 }
 
 struct StageTimer {
-    bool on; hipStream_t s; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
-    StageTimer(bool enabled, hipStream_t st) : on(enabled), s(st) {}
-    int begin(int stage) {
+    bool on; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
+    explicit StageTimer(bool enabled) : on(enabled) {}
+    int begin(int stage, hipStream_t s) {
         if (!on) return -1;
         hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
         ev[stage].emplace_back(a, b); HIP_CHECK(hipEventRecord(a, s));
         return (int) ev[stage].size() - 1;
     }
-    void end(int stage, int idx) { if (on) HIP_CHECK(hipEventRecord(ev[stage][idx].second, s)); }
+    void end(int stage, int idx, hipStream_t s) { if (on) HIP_CHECK(hipEventRecord(ev[stage][idx].second, s)); }
     double total(int stage) {
         double ms = 0;
         for (auto &p : ev[stage]) { float t = 0; HIP_CHECK(hipEventElapsedTime(&t, p.first, p.second)); ms += t; }
@@ -214,24 +215,44 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     uint64_t batch = lane_dump ? std::min<uint64_t>(target_batch_lanes(), std::max<uint64_t>(dump_n, 1))
                                : std::max<uint64_t>(1, target_batch_lanes() / lanes_per_row) * lanes_per_row;
     batch = std::min<uint64_t>(batch, std::max<uint64_t>(last - first, 1));
+    // Two batches are kept in flight on two HIP streams (each with its own workspace): the VALU-bound
+    // trace/shadow kernels of one batch overlap the HBM-bound shade kernel of the other.
+    static const int env_streams = [] { const char *e = getenv("DTOF_STREAMS"); int v = e ? atoi(e) : 1; return v == 2 ? 2 : 1; }();   // default 1: measured gain of 2 is 0% (Cornell) .. 7% (Domino) and it blurs per-stage timing
+    const int n_streams = lane_dump ? 1 : env_streams;
+    // Pipeline choice.  "fused" runs occlusion + continuation traversal inside the shade kernel (one kernel per bounce);
+    // it wins when traversal is trivial (measured: Cornell-wall 4.00 vs 4.71 ms) and loses when traversal dominates
+    // (Cornell-boxes 2.20 vs 1.97 ms, Domino 116 vs 102 ms) because the heavy shade kernel then diverges at 3 waves/SIMD.
+    // auto = fused for scenes without triangle meshes and with at most 16 objects.  DTOF_PIPELINE=split|fused overrides.
+    static const int env_pipeline = [] { const char *e = getenv("DTOF_PIPELINE"); std::string v = e ? e : ""; return v == "split" ? 0 : v == "fused" ? 1 : 2; }();
+    const BlobHeader *bh = (const BlobHeader *) sc->blob.data();
+    const bool fused = env_pipeline == 2 ? (bh->n_tris == 0 && bh->n_objects <= 16) : env_pipeline == 1;
+    if (n_streams == 2 && !lane_dump && last - first <= batch && last - first >= 2 * lanes_per_row) {
+        uint64_t rows = (last - first) / lanes_per_row;
+        batch = ((rows + 1) / 2) * lanes_per_row;                // one batch would serialise: cut it in two row bands
+    }
     sc->ws.ensure((uint32_t) batch, rp.n_offsets);
+    if (n_streams == 2) sc->ws2.ensure((uint32_t) batch, rp.n_offsets);
     if (lane_dump) sc->ws.dbg.ensure(batch);
-    Queues q = sc->ws.queues();
-    hipStream_t s = sc->stream;
+    Queues qs[2] = { sc->ws.queues(), n_streams == 2 ? sc->ws2.queues() : sc->ws.queues() };
+    hipStream_t ss[2] = { sc->stream, n_streams == 2 ? sc->stream2 : sc->stream };
     const uint8_t *blob = sc->d_blob.p; uint32_t blob_bytes = (uint32_t) sc->blob.size();
     const uint32_t stack_depth = ((const BlobHeader *) sc->blob.data())->tlas_depth;
     const bool has_surface_emitters = false;   // supported emitters: point (no emitter-hit term, point.cpp:186-188)
-    StageTimer tm(stats != nullptr, s);
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (stats) { memset(stats, 0, sizeof *stats); HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); HIP_CHECK(hipEventRecord(ev0, s)); }
+    StageTimer tm(stats != nullptr);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    if (stats) { memset(stats, 0, sizeof *stats); HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); HIP_CHECK(hipEventRecord(ev0, ss[0])); }
+    if (n_streams == 2) { HIP_CHECK(hipEventRecord(ev_fork, ss[0])); HIP_CHECK(hipStreamWaitEvent(ss[1], ev_fork, 0)); }
     struct Pinned { uint32_t *p; uint32_t iters, n_seg; };
     std::vector<Pinned> pinned; std::vector<uint64_t> h_counts; std::vector<uint32_t> batch_lanes, batch_iters;
 
-    for (uint64_t b0 = first; b0 < last; b0 += batch) {
+    uint32_t batch_index = 0;
+    for (uint64_t b0 = first; b0 < last; b0 += batch, ++batch_index) {
         if (sc->stop.load()) break;
+        const Queues &q = qs[batch_index & 1]; hipStream_t s = ss[batch_index & 1];
         rp.lane_base = (uint32_t) b0; rp.n_lanes = (uint32_t) std::min<uint64_t>(batch, last - b0);
         const uint32_t n_seg = segments_for(rp.n_lanes);
-        int t = tm.begin(0); launch_generate(rp, q, s); tm.end(0, t);
+        int t = tm.begin(0, s); launch_generate(rp, q, s); tm.end(0, t, s);
         if (lane_dump) launch_lane_dump_rays(rp, q, sc->ws.dbg.p, s);
         const uint32_t *qin = nullptr, *count_in = nullptr; uint32_t it = 0;
         for (;; ++it) {
@@ -247,19 +268,21 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
                 uint64_t sum = 0; for (uint32_t v : alive) sum += v;
                 if (sum == 0) break;
             }
-            t = tm.begin(1); launch_trace(blob, blob_bytes, rp, q, qin, count_in, stack_depth, s); tm.end(1, t);
+            // does iteration it+1 run?  (same conditions as the loop head)
+            const bool next_runs = (it + 1 < rp.max_depth) && !(it + 2 >= rp.max_depth && !has_surface_emitters) && it + 1 < kMaxIter;
+            if (!fused || it == 0) { t = tm.begin(1, s); launch_trace(blob, blob_bytes, rp, q, qin, count_in, stack_depth, s); tm.end(1, t, s); if (stats) stats->n_launches_trace++; }
             uint32_t *qout = q.q[it & 1], *alive_out = q.counts + (size_t) (2 * it) * n_seg, *shadow_out = alive_out + n_seg;
-            t = tm.begin(2); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it, s); tm.end(2, t);
-            t = tm.begin(3); launch_shadow(blob, blob_bytes, rp, q, shadow_out, stack_depth, s); tm.end(3, t);
+            t = tm.begin(2, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it, fused, next_runs, stack_depth, s); tm.end(2, t, s);
+            if (!fused) { t = tm.begin(3, s); launch_shadow(blob, blob_bytes, rp, q, shadow_out, stack_depth, s); tm.end(3, t, s); if (stats) stats->n_launches_shadow++; }
+            if (stats) stats->n_launches_shade++;
             qin = qout; count_in = alive_out;
-            if (stats) { stats->n_launches_trace++; stats->n_launches_shade++; stats->n_launches_shadow++; }
         }
         if (lane_dump) {
             launch_lane_dump(rp, q, sc->ws.dbg.p, s);
             HIP_CHECK(hipMemcpyAsync(lane_dump + (b0 - first), sc->ws.dbg.p, (size_t) rp.n_lanes * sizeof(LaneDebug), hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
         } else {
-            t = tm.begin(4); launch_splat(rp, q, d_film, se.crop_w, se.crop_h, s); tm.end(4, t);
+            t = tm.begin(4, s); launch_splat(rp, q, d_film, se.crop_w, se.crop_h, s); tm.end(4, t, s);
         }
         if (stats) {   // per-iteration per-segment counts of this batch -> pinned host staging (summed after the final sync)
             size_t words = (size_t) 2 * it * n_seg;
@@ -274,6 +297,8 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             // the next batch reuses q.counts: order its first shade after this copy (same stream => already ordered)
         }
     }
+    if (n_streams == 2) { HIP_CHECK(hipEventRecord(ev_join, ss[1])); HIP_CHECK(hipStreamWaitEvent(ss[0], ev_join, 0)); }
+    hipStream_t s = ss[0];
     if (stats) {
         HIP_CHECK(hipEventRecord(ev1, s)); HIP_CHECK(hipEventSynchronize(ev1));
         float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); stats->ms_total = ms;
@@ -296,6 +321,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     } else {
         HIP_CHECK(hipStreamSynchronize(s));
     }
+    (void) hipEventDestroy(ev_fork); (void) hipEventDestroy(ev_join);
     if (sc->stop.load()) throw std::runtime_error("cancelled");
 }
 

@@ -44,16 +44,17 @@ struct DObject {            // 128 B
     float key0[12], key1[12];
 };
 struct DGroup { uint32_t first_shape, n_shapes, pad[2]; };
-struct DShape {             // 176 B
+struct DShape {             // 208 B
     uint32_t kind, flags, first_tri, n_tris;
     float refl[3], pad0;
     float to_world[12], to_object[12];
     float n[3], pad1, dp_du[3], pad2, dp_dv[3], pad3;   // rectangle frame (Rectangle::update, rectangle.cpp:101-113)
+    float bmin[3], pad4, bmax[3], pad5;                 // padded bounds of the shape in ITS space (mesh: culls the triangle loop)
 };
 struct DTri { float p0[4], p1[4], p2[4]; };                              // 48 B
 struct DTriShade { float n0[3], n1[3], n2[3], uv0[2], uv1[2], uv2[2], pad; };   // 64 B
 struct DEmitter { uint32_t kind; float pos[3]; float intensity[3]; float pad; };
-static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 176 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64, "blob records");
+static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 208 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64, "blob records");
 
 // ---------------------------------------------------------------------------- host description
 struct Mat4d { double m[16]; };   // row-major

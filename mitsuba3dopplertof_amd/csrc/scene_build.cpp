@@ -133,6 +133,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
             }
         }
         shape_boxes[i] = shape_box(h);
+        { Box pb = shape_boxes[i]; pb.pad(); for (int k = 0; k < 3; ++k) { d.bmin[k] = pb.lo[k]; d.bmax[k] = pb.hi[k]; } }
     }
     // ---- groups
     std::vector<DGroup> groups(sc.groups.size());
