@@ -626,6 +626,11 @@ __global__ __launch_bounds__(kBlock) void k_shadow(const uint8_t *scene, uint32_
 
 // ---------------------------------------------------------------------------- splat
 DTOF_D float tent(float x, float inv_r) { return fmax_(0.f, 1.f - fabsf(x * inv_r)); }
+// v + (v moved by the DPP control); lanes without a valid source (or in rows masked off) add 0
+template <int CTRL, int ROW_MASK = 0xf>
+DTOF_D float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 
 // Generic per-lane splat (any filter radius / any spp): direct float atomics.
 DTOF_D void splat_lane(const RenderParams &rp, float *film, float spx, float spy, float r, float g, float b) {
@@ -671,6 +676,7 @@ __global__ __launch_bounds__(kBlock) void k_splat_generic(RenderParams rp, Queue
 // and one lane issues the 36 atomics.  The rare sample whose float position rounds up to the next
 // pixel splats by itself.
 __global__ __launch_bounds__(kBlock) void k_splat_tent3(RenderParams rp, Queues q, float *film, size_t film_stride, uint32_t seg) {
+    __shared__ float4 s_acc4[(kBlock / 2) * 9];
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool in_range = i < rp.n_lanes;
     uint32_t lane = rp.lane_base + (in_range ? i : 0);
@@ -699,21 +705,42 @@ __global__ __launch_bounds__(kBlock) void k_splat_tent3(RenderParams rp, Queues 
                 acc[4 * (3 * ys + xs) + 0] = r.x * w; acc[4 * (3 * ys + xs) + 1] = r.y * w;
                 acc[4 * (3 * ys + xs) + 2] = r.z * w; acc[4 * (3 * ys + xs) + 3] = w;
             }
-        for (uint32_t off = seg >> 1; off > 0; off >>= 1)
+        // segment sums with DPP adds (one v_add_f32_dpp each, no LDS traffic): pairs, quads, row_ror 4/8 give every
+        // lane of a 16-lane row the row total; row_bcast:15 / :31 carry it into the last lane of 32 / 64 lanes.
+        // The total of a segment therefore ends up in the segment's LAST lane.
 #pragma unroll
-            for (int c = 0; c < 36; ++c) acc[c] += __shfl_down(acc[c], off);
-        if (in_range && (threadIdx.x & (seg - 1)) == 0) {
+        for (int c = 0; c < 36; ++c) {
+            float v = acc[c];
+            v = dpp_add<0xb1>(v);
+            if (seg >= 4) v = dpp_add<0x4e>(v);
+            if (seg >= 8) v = dpp_add<0x124>(v);
+            if (seg >= 16) v = dpp_add<0x128>(v);
+            if (seg >= 32) v = dpp_add<0x142, 0xa>(v);
+            if (seg >= 64) v = dpp_add<0x143, 0xc>(v);
+            acc[c] = v;
+        }
+        // Stage the per-segment sums in LDS (9 ds_write_b128 by the segment's last lane) and let the whole block issue
+        // the atomics: 36 values per segment become lanes of a few full wave-instructions instead of 36 single-lane
+        // atomics that stall their wave once 16 are outstanding.
+        if (k > 0) __syncthreads();
+        const uint32_t sidx_mine = threadIdx.x / seg;
+        if ((threadIdx.x & (seg - 1)) == seg - 1) {
 #pragma unroll
-            for (int ys = 0; ys < 3; ++ys)
-#pragma unroll
-                for (int xs = 0; xs < 3; ++xs) {
-                    int x = px - 1 + xs, y = py - 1 + ys;
-                    if ((unsigned) x < W && (unsigned) y < (unsigned) rp.crop_h) {
-                        float *dst = fk + 4 * ((size_t) y * W + (size_t) x);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) { float v = acc[4 * (3 * ys + xs) + c]; if (v != 0.f) atomicAdd(dst + c, v); }
-                    }
-                }
+            for (int c = 0; c < 9; ++c) s_acc4[sidx_mine * 9 + c] = make_float4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
+        }
+        __syncthreads();
+        const uint32_t total = (kBlock / seg) * 36;
+        const float *s_acc = (const float *) s_acc4;
+        for (uint32_t idx = threadIdx.x; idx < total; idx += kBlock) {
+            uint32_t sidx = idx / 36, c = idx - sidx * 36;
+            uint32_t first_lane = blockIdx.x * kBlock + sidx * seg;
+            if (first_lane >= rp.n_lanes) continue;
+            uint32_t spix = (rp.lane_base + first_lane) >> rp.spp_log2;
+            int sy = (int) (spix / W), sx = (int) (spix - W * (uint32_t) sy);
+            int x = sx - 1 + (int) ((c % 12) >> 2), y = sy - 1 + (int) (c / 12);
+            float v = s_acc[idx];
+            if ((unsigned) x < W && (unsigned) y < (unsigned) rp.crop_h && v != 0.f)
+                atomicAdd(fk + 4 * ((size_t) y * W + (size_t) x) + (c & 3), v);
         }
     }
 }
