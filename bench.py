@@ -158,18 +158,28 @@ def main():
         shade_lanes = acc["n_bounces"]                         # lanes processed by the shade launches of this rank
         shade_s = acc["ms_shade"] * 1e-3
         loop_s = (acc["ms_trace"] + acc["ms_shade"] + acc["ms_shadow"]) * 1e-3
-        achieved = B_SHADE * shade_lanes / max(shade_s, 1e-12) / 1e9
+        fused = acc["ms_shadow"] == 0.0                          # one kernel per bounce (occlusion + next closest hit inline)
+        if fused:
+            # the bounce kernel does the model's shade + shadow stages of its bounce and the trace stage of the NEXT one;
+            # the primary rays' trace stage (48 B x paths) is the separate k_trace launch
+            kernel_bytes = B_BOUNCE * shade_lanes - B_TRACE * acc["n_paths"]
+            kernel_name, kernel_key = "k_shade<fused: shade + occlusion + next closest hit>", "k_shade"
+        else:
+            kernel_bytes = B_SHADE * shade_lanes
+            kernel_name, kernel_key = "k_shade", "k_shade"
+        achieved = kernel_bytes / max(shade_s, 1e-12) / 1e9
         traffic = None
         tfile = os.path.join(HERE, "profiles", "roofline_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("k_shade", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tfile)).get(kernel_key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {
-            "bound": "hbm", "kernel": "k_shade", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_path_bounce": B_SHADE,
+            "algorithmic_bytes_per_launch": round(kernel_bytes / max(acc["launches"], 1), 1),
+            "algorithmic_bytes_per_path_bounce": round(kernel_bytes / max(shade_lanes, 1), 1),
             "path_bounces_per_launch": round(shade_lanes / max(acc["launches"], 1), 1),
             "avg_launch_ms": round(acc["ms_shade"] / max(acc["launches"], 1), 5),
             "loop": {"bytes_per_path_bounce": B_BOUNCE,
