@@ -38,11 +38,11 @@ def test_oracle_render_is_unbiased_against_the_reference_exr(orc):
 
 @pytest.mark.gpu
 def test_reference_exr_is_statistically_one_of_our_renders(mi):
-    """GPU: 24 seeds x 1024 spp.  Summary statistics of the reference image must fall inside our seed-to-seed
+    """GPU: 32 seeds x 1024 spp.  Summary statistics of the reference image must fall inside our seed-to-seed
     distribution and the per-pixel z-scores must be standard normal (cf. the z-test of src/render/tests/test_renders.py)."""
     ref = np.load(REF).astype(np.float64)
     sc = mi.load_file(os.path.join(SCENES, "cornell_boxes.xml"), resx=256, resy=256)
-    n = 24
+    n = 32
     imgs = np.stack([sc.render(seed=100 + s, spp=1024).astype(np.float64) for s in range(n)])
     mean, sd = imgs.mean(0), imgs.std(0, ddof=1)
     for name, (ys, xs) in REGIONS.items():
@@ -52,4 +52,6 @@ def test_reference_exr_is_statistically_one_of_our_renders(mi):
             assert abs(z) < 4.5, (name, c, z)
     z = (ref - mean) / np.sqrt(sd ** 2 * (1 + 1.0 / n) + (np.abs(ref) * 2.0 ** -11) ** 2 + 1e-30)
     assert abs(z.mean()) < 0.05 and 0.85 < z.std() < 1.2
-    assert (np.abs(z) < 4).mean() > 0.998 and (np.abs(z) < 6).mean() > 0.99995
+    # the per-pixel sample distribution is heavy tailed and sd is itself estimated from n seeds: one of OUR seeds against
+    # the others gives 0.997 / 0.9998 here
+    assert (np.abs(z) < 4).mean() > 0.995 and (np.abs(z) < 6).mean() > 0.9995
