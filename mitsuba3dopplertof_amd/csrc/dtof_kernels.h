@@ -48,7 +48,7 @@ struct Queues {
     float4 *sh_a;        // shadow ray o.xyz, maxt
     float4 *sh_b;        // shadow ray d.xyz, time
     float4 *sh_c;        // [K][capacity] candidate result rgb, w = as_float(lane position)
-    uint32_t *q[2];      // active-lane index queues (ping-pong), segmented: entry j of segment S at S*1024 + j
+    uint32_t *q[2];      // active-lane index queues (ping-pong), segmented: entry j of segment S at S*kSeg + j
     uint32_t *counts;    // [iteration][2][n_segments]: survivors / shadow rays per segment
     uint32_t capacity;
 };

@@ -312,7 +312,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) 
 // segment of the output queue and records the count -- order preserving, deterministic and without a
 // single global atomic (a shared counter serialises at ~88 returning atomics/us on MI355X, which
 // made the first version of this kernel 10x slower than its memory traffic).
-constexpr uint32_t kSeg = 1024, kSub = kSeg / kBlock;
+constexpr uint32_t kSeg = 512, kSub = kSeg / kBlock;
+constexpr int kShadeBlock = 64;   // k_shade runs ONE wave per block: compaction is ballot+popcount only, no barrier in the chunk loop
 DTOF_D uint32_t seg_count(const uint32_t *counts, uint32_t seg, uint32_t n_lanes) {
     return counts ? counts[seg] : min(kSeg, n_lanes - seg * kSeg);
 }
@@ -425,6 +426,11 @@ DTOF_D float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b
 DTOF_D uint32_t block_append(bool pred, uint32_t *s_cnt, uint32_t &running) {
     uint64_t mask = __ballot(pred);
     uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    if (kShadeBlock == 64) {   // single-wave block: the wave-level prefix is the block-level prefix
+        uint32_t slot1 = running + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+        running += (uint32_t) __popcll(mask);
+        return slot1;
+    }
     if (lane == 0) s_cnt[wave] = (uint32_t) __popcll(mask);
     __syncthreads();
     uint32_t c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3];
@@ -442,7 +448,7 @@ DTOF_D uint32_t block_append(bool pred, uint32_t *s_cnt, uint32_t &running) {
 //                 through HBM once per bounce (this is the default: the split kernels are latency-bound on small
 //                 scenes and the shadow records alone cost 96 B per path-bounce).
 template <bool LDS, bool FUSED>
-__global__ __launch_bounds__(kBlock) void k_shade(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp, Queues q,
+__global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp, Queues q,
                                                   const uint32_t *qin, const uint32_t *count_in,
                                                   uint32_t *qout, uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth,
                                                   uint32_t trace_next) {
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(const uint8_t *scene, uint32_t
     if (count != 0) {
     const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
     SceneView sv = make_view(base);
-    for (uint32_t cbase = 0; cbase < count; cbase += kBlock) {
+    for (uint32_t cbase = 0; cbase < count; cbase += kShadeBlock) {
     uint32_t j = cbase + threadIdx.x;
     bool in_range = j < count;
     bool alive = false, want_shadow = false;
@@ -588,7 +594,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(const uint8_t *scene, uint32_t
     }
     }   // chunk loop
     }   // count != 0
-    if (FUSED) {   // shadow-ray count for the statistics: sum the four per-wave partials
+    if (FUSED && kShadeBlock > 64) {   // shadow-ray count for the statistics: sum the four per-wave partials
         __syncthreads();
         if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = n_shadow;
         __syncthreads();
@@ -773,7 +779,7 @@ __global__ void k_lane_dump_rays(RenderParams rp, Queues q, LaneDebug *out) {
 // ---------------------------------------------------------------------------- launchers
 static inline uint32_t nblk(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 constexpr uint32_t kLdsSceneLimit = 48 * 1024;
-static inline uint32_t stack_bytes(uint32_t depth) { return (depth < 2 ? 2 : depth) * kBlock * 4; }
+static inline uint32_t stack_bytes(uint32_t depth, uint32_t block = kBlock) { return (depth < 2 ? 2 : depth) * block * 4; }
 
 void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s) {
     if (rp.n_lanes == 0) return;
@@ -796,9 +802,9 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
                   uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, bool fused, bool trace_next,
                   uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
-    uint32_t sw = stage_words_for(scene_bytes), grid = nseg(rp.n_lanes), lds = sw * 16 + (fused ? stack_bytes(stack_depth) : 0);
+    uint32_t sw = stage_words_for(scene_bytes), grid = nseg(rp.n_lanes), lds = sw * 16 + (fused ? stack_bytes(stack_depth, kShadeBlock) : 0);
     uint32_t tn = trace_next ? 1u : 0u;
-#define DTOF_LAUNCH_SHADE(L, F) hipLaunchKernelGGL((k_shade<L, F>), dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, qin, \
+#define DTOF_LAUNCH_SHADE(L, F) hipLaunchKernelGGL((k_shade<L, F>), dim3(grid), dim3(kShadeBlock), lds, s, scene, scene_bytes, sw, rp, q, qin, \
                                                    count_in, qout, alive_out, shadow_out, depth, tn)
     if (sw) { if (fused) DTOF_LAUNCH_SHADE(true, true); else DTOF_LAUNCH_SHADE(true, false); }
     else    { if (fused) DTOF_LAUNCH_SHADE(false, true); else DTOF_LAUNCH_SHADE(false, false); }
