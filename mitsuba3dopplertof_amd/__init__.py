@@ -233,9 +233,9 @@ class Integrator:
 
     def __init__(self, props):
         self.props = dict(props)
-        if self.props.get("type") != "dopplertofpath":
-            raise DtofError('unsupported integrator plugin "%s" (this library implements "dopplertofpath")'
-                            % self.props.get("type"))
+        if self.props.get("type") not in ("dopplertofpath", "path", "velocity"):
+            raise DtofError('unsupported integrator plugin "%s" (this library implements "dopplertofpath", "path" and '
+                            '"velocity")' % self.props.get("type"))
 
     def render(self, scene, seed=0, spp=0, sensor=0, offsets=None):
         scene.set_integrator(self.props)
@@ -258,9 +258,9 @@ def load_string(xml, **params):
 
 def load_dict(d):
     t = d.get("type")
-    if t == "dopplertofpath":
+    if t in ("dopplertofpath", "path", "velocity"):
         return Integrator(d)
-    raise DtofError('load_dict: unsupported plugin type "%s" (supported: dopplertofpath)' % t)
+    raise DtofError('load_dict: unsupported plugin type "%s" (supported: dopplertofpath, path, velocity)' % t)
 
 
 def render(scene, spp=0, seed=0, integrator=None, sensor=0):

@@ -29,6 +29,7 @@ struct RenderParams {
     float phase[kMaxOffsets]; int32_t n_offsets;
     int32_t wave_type, low_pass;
     uint32_t path_correlation_depth, max_depth, rr_depth;
+    int32_t integrator;                           // 0 dopplertofpath, 1 path (src/integrators/path.cpp), 2 velocity (velocity.cpp)
     // ---- batch
     uint32_t lane_base, n_lanes;                  // this batch covers global lanes [lane_base, lane_base + n_lanes)
 };
@@ -68,6 +69,7 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
                   uint32_t stack_depth, hipStream_t s);
 void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                    const uint32_t *count_in, uint32_t stack_depth, hipStream_t s);
+void launch_velocity(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q, uint32_t stack_depth, hipStream_t s);
 void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t film_w, int32_t film_h, hipStream_t s);
 void launch_develop(const float *film, float *rgb, int64_t n_pixels, hipStream_t s);
 void launch_lane_dump(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s);

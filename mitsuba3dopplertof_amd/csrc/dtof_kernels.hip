@@ -277,11 +277,14 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) 
     uint32_t py = pix / W, px = pix - W * py;
     float posx = (float) (px + (uint32_t) rp.crop_x), posy = (float) (py + (uint32_t) rp.crop_y);
     bool cp = rp.path_correlation_depth > 0;
-    float jx = next_correlate(main, path, cp), jy = next_correlate(main, path, cp);
+    const bool doppler = rp.integrator == 0;
+    // Doppler branch of render_sample (integrator.cpp:476-495) vs the plain one (:416-431: next_2d / next_1d = main stream only)
+    float jx = doppler ? next_correlate(main, path, cp) : next_f32(main), jy = doppler ? next_correlate(main, path, cp) : next_f32(main);
     float spx = posx + jx, spy = posy + jy;
     float ax = fmaf(spx, rp.scale_x, rp.offset_x), ay = fmaf(spy, rp.scale_y, rp.offset_y);
     float time = rp.shutter_open;
-    if (rp.shutter_open_time > 0.f) time += next_time(rp, main, tm, si, perm_seed, dim) * rp.shutter_open_time;
+    if (rp.shutter_open_time > 0.f)
+        time += (doppler ? next_time(rp, main, tm, si, perm_seed, dim) : next_f32(main)) * rp.shutter_open_time;
 
     // PerspectiveCamera::sample_ray_differential (perspective.cpp:238-279)
     const float *m = rp.s2c;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) 
     float inv_z = rcp(d.z), near_t = rp.near_clip * inv_z, far_t = rp.far_clip * inv_z;
     o = o + dw * near_t;
     float maxt = far_t - near_t;
-    time = time < rp.T ? time : time - rp.T;   // dopplertofpath.cpp:93
+    if (doppler) time = time < rp.T ? time : time - rp.T;   // dopplertofpath.cpp:93
 
     q.ray_a[i] = make_float4(o.x, o.y, o.z, time);
     q.ray_b[i] = make_float4(dw.x, dw.y, dw.z, maxt);
@@ -479,6 +482,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             main.state = (uint64_t) rs.x | ((uint64_t) rs.y << 32); main.inc = stream_inc(rp.seed_value, lane);
             path.state = (uint64_t) rs.z | ((uint64_t) rs.w << 32); path.inc = stream_inc(rp.seed_value + 2, lane / rp.pcn);
             bool correlate = (depth + 1) < rp.path_correlation_depth;
+            const bool plain = rp.integrator != 0;   // `path`: sampler->next_1d/2d, main stream only (path.cpp:197,213-214,273)
             float t = u2f(hh.x);
             path_length += t * 1.f;   // eta == 1 for every supported BSDF (dopplertofpath.cpp:141)
             bool active_next = depth + 1 < rp.max_depth;
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             const DShape *sh = si.shape;
 
             // ---- emitter sampling (scene.cpp:235-291, point.cpp:118-147)
-            float e1 = next_correlate(main, path, correlate), e2 = next_correlate(main, path, correlate); (void) e2;
+            float e1 = plain ? next_f32(main) : next_correlate(main, path, correlate), e2 = plain ? next_f32(main) : next_correlate(main, path, correlate); (void) e2;
             bool active_em = active_next && sv.n_emitters > 0;
             V3 em_weight = mk(0, 0, 0), wo = mk(0, 0, 0); float ds_dist = 0.f;
             if (active_em) {
@@ -513,8 +517,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 shb = make_float4(sd.x, sd.y, sd.z, time);
                 wo = mk(dot(dd, si.sh_s), dot(dd, si.sh_t), dot(dd, si.sh_n));
             }
-            float sample_1 = next_correlate(main, path, correlate); (void) sample_1;
-            float s2x = next_correlate(main, path, correlate), s2y = next_correlate(main, path, correlate);
+            float sample_1 = plain ? next_f32(main) : next_correlate(main, path, correlate); (void) sample_1;
+            float s2x = plain ? next_f32(main) : next_correlate(main, path, correlate), s2y = plain ? next_f32(main) : next_correlate(main, path, correlate);
 
             // ---- BSDF eval_pdf + sample (twosided.cpp:111-148,219-258; diffuse.cpp:101-125,160-180)
             bool twosided = sh->flags & SF_TWOSIDED;
@@ -535,9 +539,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 bool nonzero = false;
 #pragma unroll
                 for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) {
-                    float lw = modulation_weight(rp, rp.phase[k], time, path_length + ds_dist);
                     float4 r = q.res[(size_t) k * q.capacity + l];
-                    V3 v = mk(bsdf_val.x * em_weight.x * mis_em * lw, bsdf_val.y * em_weight.y * mis_em * lw, bsdf_val.z * em_weight.z * mis_em * lw);
+                    V3 v = mk(bsdf_val.x * em_weight.x * mis_em, bsdf_val.y * em_weight.y * mis_em, bsdf_val.z * em_weight.z * mis_em);
+                    if (!plain) { float lw = modulation_weight(rp, rp.phase[k], time, path_length + ds_dist); v = v * lw; }
                     float3 c = make_float3(fmaf(thr.x, v.x, r.x), fmaf(thr.y, v.y, r.y), fmaf(thr.z, v.z, r.z));
                     cand[k] = c;
                     nonzero |= f2u(c.x) != f2u(r.x) || f2u(c.y) != f2u(r.y) || f2u(c.z) != f2u(r.z);
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             float thr_max = fmax_(fmax_(thr.x, thr.y), thr.z);
             float rr_prob = fmin_(thr_max * sqr(eta), .95f);
             bool rr_active = ndepth >= rp.rr_depth;
-            bool rr_continue = next_correlate(main, path, correlate) < rr_prob;
+            bool rr_continue = (plain ? next_f32(main) : next_correlate(main, path, correlate)) < rr_prob;
             if (rr_active) thr = thr * rcp(rr_prob);
             alive = active_next && (!rr_active || rr_continue) && thr_max != 0.f;
             if (alive) {
@@ -628,6 +632,27 @@ __global__ __launch_bounds__(kBlock) void k_shadow(const uint8_t *scene, uint32_
             q.res[(size_t) k * q.capacity + l] = make_float4(c.x, c.y, c.z, 0.f);
         }
     }
+}
+
+// ---------------------------------------------------------------------------- velocity
+// VelocityIntegrator::sample (src/integrators/velocity.cpp:125-142): the primary ray is intersected at time 0 and at
+// time T; radial velocity = (t2 - t1) / T where both hit, 0 otherwise, in all three channels.
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void k_velocity(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp, Queues q) {
+    extern __shared__ uint4 lds[];
+    const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
+    uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
+    SceneView sv = make_view(base);
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= rp.n_lanes) return;
+    float4 a = q.ray_a[i], b = q.ray_b[i];
+    V3 o = mk(a.x, a.y, a.z), d = mk(b.x, b.y, b.z);
+    Hit h1, h2;
+    bool v1 = trace_scene<false>(sv, stack, o, d, 0.f, b.w, h1);
+    bool v2 = trace_scene<false>(sv, stack, o, d, rp.T, b.w, h2);
+    float vel = ((v2 ? h2.t : 0.f) - (v1 ? h1.t : 0.f)) * (1.0f / rp.T);
+    vel = (v1 && v2) ? vel : 0.f;
+    q.res[i] = make_float4(vel, vel, vel, 0.f);
 }
 
 // ---------------------------------------------------------------------------- splat
@@ -816,6 +841,12 @@ void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParam
     uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + stack_bytes(stack_depth), grid = nseg(rp.n_lanes) * kSub;
     if (sw) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in);
     else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in);
+}
+void launch_velocity(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q, uint32_t stack_depth, hipStream_t s) {
+    if (rp.n_lanes == 0) return;
+    uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + stack_bytes(stack_depth);
+    if (sw) hipLaunchKernelGGL(k_velocity<true>, dim3(nblk(rp.n_lanes)), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q);
+    else hipLaunchKernelGGL(k_velocity<false>, dim3(nblk(rp.n_lanes)), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q);
 }
 void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t film_w, int32_t film_h, hipStream_t s) {
     if (rp.n_lanes == 0) return;

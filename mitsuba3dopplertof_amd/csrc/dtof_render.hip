@@ -172,6 +172,8 @@ RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, cons
         for (int k = 0; k < n_offsets; ++k) rp.phase[k] = (float) ((double) (offsets[k] * 2) * M_PI);   // dopplertofpath.cpp:30-32
     }
     rp.path_correlation_depth = pp.path_correlation_depth; rp.max_depth = pp.max_depth; rp.rr_depth = pp.rr_depth;
+    rp.integrator = pp.integrator;
+    if (pp.integrator != INTEGRATOR_DOPPLER && n_offsets > 0) throw std::runtime_error("modulation offsets only apply to the dopplertofpath integrator");
     return rp;
 }
 
@@ -255,7 +257,9 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         int t = tm.begin(0, s); launch_generate(rp, q, s); tm.end(0, t, s);
         if (lane_dump) launch_lane_dump_rays(rp, q, sc->ws.dbg.p, s);
         const uint32_t *qin = nullptr, *count_in = nullptr; uint32_t it = 0;
+        if (rp.integrator == INTEGRATOR_VELOCITY) { t = tm.begin(1, s); launch_velocity(blob, blob_bytes, rp, q, stack_depth, s); tm.end(1, t, s); }
         for (;; ++it) {
+            if (rp.integrator == INTEGRATOR_VELOCITY) break;
             if (it >= rp.max_depth) break;
             // the last iteration of the reference only looks for emitter hits (dopplertofpath.cpp:136-171);
             // without surface emitters it cannot contribute and is skipped

@@ -99,7 +99,10 @@ struct PropBag {
 
 // Constructor-time parameters of DopplerToFPathIntegrator (+ bases) and CorrelatedSampler, rounded
 // exactly as the reference's constructors round them.
+enum IntegratorKind : int32_t { INTEGRATOR_DOPPLER = 0, INTEGRATOR_PATH = 1, INTEGRATOR_VELOCITY = 2 };
 struct PluginParams {
+    int32_t integrator = INTEGRATOR_DOPPLER;   // dopplertofpath | path | velocity
+    bool independent_sampler = false;          // `independent` is accepted for path / velocity (it is the correlated sampler's main stream)
     // src/integrators/dopplertofpath.cpp:19-57
     float time = 0.0015f, w_g_mhz = 30.f, g_1 = .5f, g_0 = .5f, w_s_mhz = 30.f, phase_offset = 0.f, hetero_frequency = 0.f;
     int32_t wave_type = WAVE_SIN; bool low_frequency_component_only = true;

@@ -215,6 +215,12 @@ static inline float sampler_next_1d_correlate(orc_sampler *s, int correlate) {
     float r2 = orc_pcg32_next_f32(&s->s_main, s->i_main);
     return correlate ? r1 : r2;
 }
+/* Sampler::next_1d -- correlated.cpp:79-84: the independent (main) stream only; what the `path` / `velocity`
+ * integrators and the non-Doppler branch of render_sample draw (integrator.cpp:416-431, path.cpp:197,213-214,273) */
+static inline float sampler_next_1d(orc_sampler *s) { return orc_pcg32_next_f32(&s->s_main, s->i_main); }
+static inline float sampler_draw(orc_sampler *s, int correlate, int plain) {
+    return plain ? sampler_next_1d(s) : sampler_next_1d_correlate(s, correlate);
+}
 /* next_1d_time -- correlated.cpp:92-153 */
 static float sampler_next_1d_time(orc_sampler *s, const orc_params *p, uint32_t spp) {
     int strategy = p->time_sampling;
@@ -614,8 +620,9 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
     float posx = (float) (px + (uint32_t) se->crop_x), posy = (float) (py + (uint32_t) se->crop_y);
 
     int correlate_pixel = p->path_correlation_depth > 0;
-    float jx = sampler_next_1d_correlate(&smp, correlate_pixel);
-    float jy = sampler_next_1d_correlate(&smp, correlate_pixel);
+    const int plain = p->integrator != 0;   /* m_is_doppler_integrator == false: plain branch of render_sample */
+    float jx = sampler_draw(&smp, correlate_pixel, plain);
+    float jy = sampler_draw(&smp, correlate_pixel, plain);
     float spx = posx + jx, spy = posy + jy;
     float scx = 1.f / (float) se->crop_w, scy = 1.f / (float) se->crop_h;
     float ax = fmaf(spx, scx, -(float) se->crop_x * scx), ay = fmaf(spy, scy, -(float) se->crop_y * scy);
@@ -623,11 +630,11 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
     float time = se->shutter_open;
     float shutter_open_time = se->shutter_close - se->shutter_open;
     if (shutter_open_time > 0.f)
-        time += sampler_next_1d_time(&smp, p, spp) * shutter_open_time;
+        time += (plain ? sampler_next_1d(&smp) : sampler_next_1d_time(&smp, p, spp)) * shutter_open_time;
 
     orc_ray ray = camera_ray(se, cx->s2c, ax, ay);
     /* dopplertofpath.cpp:93 */
-    time = time < p->time ? time : time - p->time;
+    if (!plain) time = time < p->time ? time : time - p->time;
 
     out->sample_pos[0] = spx; out->sample_pos[1] = spy; out->time = time;
     out->ray_o[0] = ray.o.x; out->ray_o[1] = ray.o.y; out->ray_o[2] = ray.o.z;
@@ -637,6 +644,16 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
     float path_length = 0.f, eta = 1.f;
     uint32_t depth = 0; int valid_ray = 0, active = p->max_depth != 0;
     v3 o = ray.o, d = ray.d; float maxt = ray.maxt;
+
+    if (p->integrator == 2) {   /* VelocityIntegrator::sample, src/integrators/velocity.cpp:125-142 */
+        orc_hit h1 = scene_closest(sc, o, d, 0.f, maxt), h2 = scene_closest(sc, o, d, p->time, maxt);
+        int v1 = h1.obj >= 0, v2 = h2.obj >= 0;
+        float vel = ((v2 ? h2.t : 0.f) - (v1 ? h1.t : 0.f)) * (1.0f / p->time);
+        vel = (v1 && v2) ? vel : 0.f;
+        out->rgb[0] = out->rgb[1] = out->rgb[2] = vel;
+        out->path_length = 0.f; out->depth = 0; out->valid = (uint32_t) (v1 && v2);
+        return;
+    }
 
     while (active) {
         int correlate = (depth + 1) < p->path_correlation_depth;
@@ -653,8 +670,8 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         int active_em = active_next;   /* diffuse => BSDFFlags::Smooth */
 
         /* emitter sampling: Scene::sample_emitter_direction src/render/scene.cpp:235-291 */
-        float e1 = sampler_next_1d_correlate(&smp, correlate);
-        float e2 = sampler_next_1d_correlate(&smp, correlate);
+        float e1 = sampler_draw(&smp, correlate, plain);
+        float e2 = sampler_draw(&smp, correlate, plain);
         (void) e2;
         if (active_em && sc->n_emitters > 0) {
             uint32_t ne = (uint32_t) sc->n_emitters, idx = 0; float em_w = 1.f, pmf = 1.f;
@@ -688,9 +705,9 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
             active_em = 0;
         }
 
-        float sample_1 = sampler_next_1d_correlate(&smp, correlate); (void) sample_1;
-        float s2x = sampler_next_1d_correlate(&smp, correlate);
-        float s2y = sampler_next_1d_correlate(&smp, correlate);
+        float sample_1 = sampler_draw(&smp, correlate, plain); (void) sample_1;
+        float s2x = sampler_draw(&smp, correlate, plain);
+        float s2y = sampler_draw(&smp, correlate, plain);
 
         /* BSDF::eval_pdf_sample src/render/bsdf.cpp:20-29 over twosided{diffuse} / diffuse
          * (src/bsdfs/twosided.cpp:111-148,219-258; src/bsdfs/diffuse.cpp:101-125,160-180) */
@@ -715,10 +732,9 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         }
         if (active_em) {   /* :214-226 */
             float mis_em = ds_delta ? 1.f : mis_weight(ds_pdf, bsdf_pdf);
-            float lw = orc_modulation_weight(p, time, path_length + ds_dist);
-            res = V(fmaf(thr.x, bsdf_val.x * em_weight.x * mis_em * lw, res.x),
-                    fmaf(thr.y, bsdf_val.y * em_weight.y * mis_em * lw, res.y),
-                    fmaf(thr.z, bsdf_val.z * em_weight.z * mis_em * lw, res.z));
+            v3 v = V(bsdf_val.x * em_weight.x * mis_em, bsdf_val.y * em_weight.y * mis_em, bsdf_val.z * em_weight.z * mis_em);
+            if (!plain) v = v_mul(v, orc_modulation_weight(p, time, path_length + ds_dist));   /* path.cpp has no length weight */
+            res = V(fmaf(thr.x, v.x, res.x), fmaf(thr.y, v.y, res.y), fmaf(thr.z, v.z, res.z));
         }
         /* :232-262 */
         if (hit) {
@@ -733,7 +749,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         float thr_max = f_max(f_max(thr.x, thr.y), thr.z);
         float rr_prob = f_min(thr_max * f_sqr(eta), .95f);
         int rr_active = depth >= p->rr_depth;
-        int rr_continue = sampler_next_1d_correlate(&smp, correlate) < rr_prob;
+        int rr_continue = sampler_draw(&smp, correlate, plain) < rr_prob;
         if (rr_active) { float ir = f_rcp(rr_prob); thr = v_mul(thr, ir); }
         active = active_next && (!rr_active || rr_continue) && thr_max != 0.f;
     }

@@ -97,6 +97,8 @@ typedef struct {
     /* sampler (correlated.cpp:17-23, sampler.cpp:11-20) */
     uint32_t base_seed;
     int32_t time_correlate_number, path_correlate_number;
+    /* 0 dopplertofpath | 1 path (src/integrators/path.cpp) | 2 velocity (src/integrators/velocity.cpp) -- SURVEY 8(f) #1 */
+    int32_t integrator;
 } orc_params;
 
 typedef struct {

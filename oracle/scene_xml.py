@@ -529,9 +529,10 @@ def integrator_params(ip, sp):
                 p[k] = ("string", v)
         return p
     ip, sp = as_props(ip, "dopplertofpath"), as_props(sp, "correlated")
-    if ip.plugin != "dopplertofpath":
+    kinds = {"dopplertofpath": 0, "path": 1, "velocity": 2}   # path / velocity: SURVEY 8(f) #1
+    if ip.plugin not in kinds:
         raise ValueError('unsupported integrator plugin "%s"' % ip.plugin)
-    if sp.plugin != "correlated":
+    if not (sp.plugin == "correlated" or (sp.plugin == "independent" and kinds[ip.plugin] != 0)):
         raise ValueError('unsupported sampler plugin "%s"' % sp.plugin)
     T = F32(ip.get_f("time", 0.0015))
     w_g = F32(ip.get_f("w_g", 30.0))
@@ -568,4 +569,4 @@ def integrator_params(ip, sp):
         max_depth=max_depth & 0xffffffff, rr_depth=rr_depth, hide_emitters=int(ip.get_b("hide_emitters", False)),
         base_seed=sp.get_i("seed", 0) & 0xffffffff, time_correlate_number=tcn,
         path_correlate_number=sp.get_i("path_correlate_number", tcn),
-        sample_count=sp.get_i("sample_count", 4))
+        sample_count=sp.get_i("sample_count", 4), integrator=kinds[ip.plugin])

@@ -261,3 +261,38 @@ def test_full_size_properties_512x512x64(mi, orc):
     other = sc.render(seed=1, spp=64)
     assert not np.array_equal(other, both[0])
     assert abs(other.mean() - both[0].mean()) < 0.05 * np.abs(both[0]).mean() + 1e-6
+
+
+# --------------------------------------------------------------------------- path + velocity on the same kernels
+@pytest.mark.parametrize("integ,sampler", [
+    (dict(type="path", max_depth=4), None),
+    (dict(type="path", max_depth=-1, rr_depth=2), dict(type="independent", sample_count=8)),
+    (dict(type="velocity"), None),
+    (dict(type="velocity", time=0.003), dict(type="independent")),
+])
+def test_path_and_velocity_integrators_match_oracle(mi, orc, integ, sampler):
+    """`path` (src/integrators/path.cpp: the same loop without the modulation weight, plain sampler draws) and `velocity`
+    (src/integrators/velocity.cpp:125-142: two primary-ray hits at t=0 and t=T) -- what the tutorials render next to every
+    Doppler image (program_runner.py:33-80)."""
+    path = os.path.join(SCENES, "cornell_boxes.xml")
+    params = dict(resx=32, resy=32)
+    sc = mi.load_file(path, **params)
+    osc = orc.Scene(path, params)
+    sc.set_integrator(integ)
+    if sampler is not None:
+        sc.set_sampler(sampler)     # `independent` is only accepted next to a non-Doppler integrator
+    pd = osc.params(integrator=integ, sampler=sampler)
+    spp, n = 8, 32 * 32 * 8
+    g = sc.sample_lanes(2, spp, 0, n)
+    o = osc.render_lanes(pd, 2, spp, 0, n, threads=NCPU)
+    for k in ("sample_pos", "time", "ray_d", "rgb"):
+        assert np.array_equal(bits(g[k]), bits(o[k])), (integ, k)
+    img = mi.load_dict(integ).render(sc, seed=2, spp=spp)
+    ref, _ = osc.render(pd, seed=2, spp=spp, threads=NCPU)
+    assert rel_linf(img, ref) <= IMG_TOL
+    if integ["type"] == "velocity":
+        assert np.array_equal(img[..., 0], img[..., 1])
+    else:
+        assert img.min() >= 0 and img.mean() > 0.05
+    with pytest.raises(mi.DtofError, match="offsets"):
+        sc.render(seed=0, spp=spp, offsets=[0.0, 0.5])

@@ -102,7 +102,7 @@ def test_error_behaviour_mirrors_the_reference_loader(mi):
     with pytest.raises(mi.DtofError, match="missing version"):
         mi.load_string(text.replace(' version="3.0.0"', ""))
     with pytest.raises(mi.DtofError, match="unsupported integrator plugin"):
-        mi.load_string(text.replace('type="dopplertofpath"', 'type="path"'))
+        mi.load_string(text.replace('type="dopplertofpath"', 'type="volpath"'))
     with pytest.raises(mi.DtofError, match="unsupported sampler plugin"):
         mi.load_string(text.replace('type="correlated"', 'type="independent"'))
     with pytest.raises(mi.DtofError, match="unreferenced property"):
@@ -120,7 +120,7 @@ def test_error_behaviour_mirrors_the_reference_loader(mi):
     with pytest.raises(mi.DtofError):
         mi.load_file(os.path.join(SCENES, "does_not_exist.xml"))
     with pytest.raises(mi.DtofError, match="unsupported"):
-        mi.load_dict({"type": "path"})
+        mi.load_dict({"type": "volpath"})
     sc = mi.load_string(text)
     with pytest.raises(mi.DtofError, match="rr_depth"):
         sc.set_integrator(dict(type="dopplertofpath", rr_depth=0))

@@ -116,7 +116,7 @@ def test_constructor_rounding(orc):
     with pytest.raises(ValueError):
         sc.params(integrator=dict(type="dopplertofpath", wave_function_type="sawtooth"))
     with pytest.raises(ValueError):
-        sc.params(integrator=dict(type="path"))
+        sc.params(integrator=dict(type="volpath"))
 
 
 def test_antithetic_pairs_cancel_on_a_static_scene(orc):
@@ -165,3 +165,20 @@ def test_oracle_reproduces_golden_vectors(orc, configs):
         if name in ("c1_boxes_antithetic", "boxes_trap_depth6_spp6"):
             img, _ = sc.render(pd, seed=3, spp=spp, threads=os.cpu_count())
             assert np.array_equal(img, g["image"]), name
+
+
+def test_velocity_and_path_integrators_physical_sanity(orc):
+    """SURVEY 8(f) #1.  The back wall of cornell_wall translates 0.015 towards the camera in 1.5 ms: the velocity integrator
+    must report -10 m/s / cos(angle to the optical axis) there; `path` is the radiance image (positive, seed-stable mean)."""
+    sc = orc.Scene(os.path.join(SCENES, "cornell_wall.xml"), dict(resx=32, resy=32))
+    vel, _ = sc.render(sc.params(integrator=dict(type="velocity")), seed=0, spp=4, threads=os.cpu_count())
+    centre = vel[12:20, 12:20, 0]
+    assert np.all(np.abs(centre + 10.0) < 0.15)
+    rad0, _ = sc.render(sc.params(integrator=dict(type="path", max_depth=4)), seed=0, spp=16, threads=os.cpu_count())
+    rad1, _ = sc.render(sc.params(integrator=dict(type="path", max_depth=4)), seed=1, spp=16, threads=os.cpu_count())
+    assert rad0.min() >= 0 and abs(rad0.mean() - rad1.mean()) < 0.03 * rad0.mean()
+    # the Doppler image with w_g -> 0 and homodyne detection is 0.25 x the radiance image (W = 0.25 cos(0)) -- same streams
+    # when the path integrator's plain draws are replaced by fully uncorrelated Doppler draws? No: different streams; compare means.
+    dop, _ = sc.render(sc.params(integrator=dict(type="dopplertofpath", max_depth=4, w_g=0.0, hetero_frequency=0.0,
+                                                 time_sampling_method="uniform")), seed=0, spp=16, threads=os.cpu_count())
+    assert abs(4.0 * dop.mean() - rad0.mean()) < 0.05 * rad0.mean()
