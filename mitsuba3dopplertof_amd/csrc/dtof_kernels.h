@@ -18,6 +18,7 @@ struct RenderParams {
     int32_t crop_x, crop_y, crop_w, crop_h;
     float scale_x, scale_y, offset_x, offset_y;   // render_sample: scale = 1/crop_size, offset = -crop_offset*scale
     int32_t filter; float filter_radius, inv_radius;
+    float gauss_coeff[10];                        // GaussianFilter's Remez fit, scaled and shifted like gaussian.cpp:60-89
     // ---- sampler (src/samplers/correlated.cpp, src/render/sampler.cpp)
     uint32_t base_seed, seed, seed_value;         // seed_value = base_seed + seed
     uint32_t spp, spp_log2;                       // spp_log2 = 0xffffffff when spp is not a power of two

@@ -657,6 +657,10 @@ __global__ __launch_bounds__(kBlock) void k_velocity(const uint8_t *scene, uint3
 
 // ---------------------------------------------------------------------------- splat
 DTOF_D float tent(float x, float inv_r) { return fmax_(0.f, 1.f - fabsf(x * inv_r)); }
+// ReconstructionFilter::eval: tent (tent.cpp:53-55) or gaussian (gaussian.cpp:94-96, polynomial branch)
+DTOF_D float filter_weight(const RenderParams &rp, float x) {
+    return rp.filter == FILTER_GAUSSIAN ? fmax_(estrin10(sqr(x), rp.gauss_coeff), 0.f) : tent(x, rp.inv_radius);
+}
 // v + (v moved by the DPP control); lanes without a valid source (or in rows masked off) add 0
 template <int CTRL, int ROW_MASK = 0xf>
 DTOF_D float dpp_add(float v) {
@@ -664,10 +668,11 @@ DTOF_D float dpp_add(float v) {
 }
 
 // Generic per-lane splat (any filter radius / any spp): direct float atomics.
-DTOF_D void splat_lane(const RenderParams &rp, float *film, float spx, float spy, float r, float g, float b) {
+DTOF_D void splat_lane(const RenderParams &rp, float *film, float spx, float spy, int pixel_x, int pixel_y, float r, float g, float b) {
     int W = rp.crop_w, H = rp.crop_h;
     if (rp.filter == FILTER_BOX) {
-        int x = (int) floorf(spx) - rp.crop_x, y = (int) floorf(spy) - rp.crop_y;
+        // block->put(box_filter ? pos : sample_pos) (integrator.cpp:540-541): the box filter splats at the lane's own pixel
+        int x = pixel_x, y = pixel_y;
         if ((unsigned) x < (unsigned) W && (unsigned) y < (unsigned) H) {
             float *p = film + 4 * ((size_t) y * W + x);
             atomicAdd(p, r); atomicAdd(p + 1, g); atomicAdd(p + 2, b); atomicAdd(p + 3, 1.f);
@@ -679,9 +684,9 @@ DTOF_D void splat_lane(const RenderParams &rp, float *film, float spx, float spy
     float relx = (float) pix + .5f - spx, rely = (float) piy + .5f - spy;
     int lx = pix - rp.crop_x, ly = piy - rp.crop_y;
     for (int ys = 0; ys < cnt; ++ys) {
-        float wy = tent(rely + (float) ys, rp.inv_radius);
+        float wy = filter_weight(rp, rely + (float) ys);
         for (int xs = 0; xs < cnt; ++xs) {
-            float w = tent(relx + (float) xs, rp.inv_radius) * wy;
+            float w = filter_weight(rp, relx + (float) xs) * wy;
             int x = lx + xs, y = ly + ys;
             if ((unsigned) x < (unsigned) W && (unsigned) y < (unsigned) H) {
                 float *p = film + 4 * ((size_t) y * W + x);
@@ -695,9 +700,12 @@ __global__ __launch_bounds__(kBlock) void k_splat_generic(RenderParams rp, Queue
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= rp.n_lanes) return;
     float2 p = q.pos[i];
+    uint32_t lane = rp.lane_base + i;
+    uint32_t pix = rp.spp_log2 != 0xffffffffu ? lane >> rp.spp_log2 : lane / rp.spp, W = (uint32_t) rp.crop_w;
+    int py = (int) (pix / W), px = (int) (pix - W * (uint32_t) py);
     for (int k = 0; k < rp.n_offsets; ++k) {
         float4 r = q.res[(size_t) k * q.capacity + i];
-        splat_lane(rp, film + (size_t) k * film_stride, p.x, p.y, r.x, r.y, r.z);
+        splat_lane(rp, film + (size_t) k * film_stride, p.x, p.y, px, py, r.x, r.y, r.z);
     }
 }
 
@@ -726,7 +734,7 @@ __global__ __launch_bounds__(kBlock) void k_splat_tent3(RenderParams rp, Queues 
     for (int k = 0; k < rp.n_offsets; ++k) {
         float4 r = in_range ? q.res[(size_t) k * q.capacity + i] : make_float4(0.f, 0.f, 0.f, 0.f);
         float *fk = film + (size_t) k * film_stride;
-        if (in_range && !regular) splat_lane(rp, fk, p.x, p.y, r.x, r.y, r.z);
+        if (in_range && !regular) splat_lane(rp, fk, p.x, p.y, px, py, r.x, r.y, r.z);
         float acc[36];
 #pragma unroll
         for (int ys = 0; ys < 3; ++ys)

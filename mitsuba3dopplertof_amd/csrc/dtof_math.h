@@ -121,6 +121,15 @@ DTOF_HD void sincos_(float x, float &s_out, float &c_out) {
 }
 DTOF_HD float cos_(float x) { float s, c; sincos_(x, s, c); return c; }
 
+// dr::detail::estrin_impl for 10 coefficients (what GaussianFilter::eval evaluates, src/rfilters/gaussian.cpp:94-96)
+DTOF_HD float estrin10(float x, const float *c) {
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+    float a0 = fmaf(x, c[1], c[0]), a1 = fmaf(x, c[3], c[2]), a2 = fmaf(x, c[5], c[4]), a3 = fmaf(x, c[7], c[6]), a4 = fmaf(x, c[9], c[8]);
+    float b0 = fmaf(x2, a1, a0), b1 = fmaf(x2, a3, a2);
+    float c0 = fmaf(x4, b1, b0);
+    return fmaf(x8, a4, c0);
+}
+
 // coordinate_system -- include/mitsuba/core/vector.h:116-136
 DTOF_HD void coordinate_system(V3 n, V3 &s, V3 &t) {
     float sign = signf(n.z), a = -rcp(sign + n.z), b = n.x * n.y * a;

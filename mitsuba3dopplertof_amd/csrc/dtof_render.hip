@@ -148,6 +148,13 @@ RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, cons
     rp.scale_x = 1.f / (float) se.crop_w; rp.scale_y = 1.f / (float) se.crop_h;
     rp.offset_x = -(float) se.crop_x * rp.scale_x; rp.offset_y = -(float) se.crop_y * rp.scale_y;
     rp.filter = se.filter; rp.filter_radius = se.filter_radius; rp.inv_radius = 1.f / se.filter_radius;
+    if (se.filter == FILTER_GAUSSIAN) {   // GaussianFilter ctor (src/rfilters/gaussian.cpp:60-89), non-CUDA branch
+        static const double coeff[10] = { 9.992604880e-1, -4.977025247e-1, 1.222248550e-1, -1.932406282e-2, 2.136713061e-3,
+                                          -1.679873860e-4, 9.202145248e-6, -3.329417433e-7, 7.128382794e-9, -6.821193280e-11 };
+        double scale = 1;
+        for (int i = 0; i < 10; ++i) { rp.gauss_coeff[i] = (float) (coeff[i] * scale); scale /= (double) se.filter_stddev * (double) se.filter_stddev; }
+        rp.gauss_coeff[0] -= estrin10(se.filter_radius * se.filter_radius, rp.gauss_coeff);
+    }
     rp.base_seed = pp.base_seed; rp.seed = seed; rp.seed_value = pp.base_seed + seed;
     rp.spp = spp; rp.spp_log2 = 0xffffffffu;
     for (uint32_t b = 0; b < 32; ++b) if ((1u << b) == spp) rp.spp_log2 = b;

@@ -564,7 +564,10 @@ static void make_sensor(const Obj &o, HostScene &sc) {
             const Obj &rf = *c.second;
             if (rf.plugin == "tent") { se.filter = FILTER_TENT; se.filter_radius = (float) rf.props.get_float("radius", 1.0); }
             else if (rf.plugin == "box") { se.filter = FILTER_BOX; se.filter_radius = .5f; }
-            else fail("unsupported rfilter plugin \"" + rf.plugin + "\" (supported: tent, box)");
+            else if (rf.plugin == "gaussian") {   // src/rfilters/gaussian.cpp:48-53: cut off after 4 standard deviations
+                se.filter = FILTER_GAUSSIAN; se.filter_stddev = (float) rf.props.get_float("stddev", .5f); se.filter_radius = 4 * se.filter_stddev;
+            }
+            else fail("unsupported rfilter plugin \"" + rf.plugin + "\" (supported: tent, box, gaussian)");
             have_filter = true;
         }
         auto u = film->props.unqueried();
@@ -572,7 +575,7 @@ static void make_sensor(const Obj &o, HostScene &sc) {
         if (se.film_w <= 0 || se.film_h <= 0 || se.crop_w <= 0 || se.crop_h <= 0 || se.crop_x < 0 || se.crop_y < 0 ||
             se.crop_x + se.crop_w > se.film_w || se.crop_y + se.crop_h > se.film_h) fail("invalid film size / crop window");
     }
-    if (!have_filter) fail("unsupported rfilter plugin \"gaussian\" (the film default); specify <rfilter type=\"tent\"/> or \"box\"");
+    if (!have_filter) { se.filter = FILTER_GAUSSIAN; se.filter_stddev = .5f; se.filter_radius = 2.f; }   // film.cpp:49-53: default gaussian
     auto t = o.transforms.find("to_world");
     to_f32(t != o.transforms.end() ? t->second.m : m_identity(), se.to_world);
     se.shutter_open = (float) o.props.get_float("shutter_open", 0.0);

@@ -805,24 +805,45 @@ void orc_render_lanes(const orc_scene *sc, const orc_params *p, uint32_t seed, u
  * box-filter special case :201-224; TentFilter::eval src/rfilters/tent.cpp:53-55.
  * aovs = [R,G,B,1] (integrator.cpp:528-541).  Accumulation is sequential in lane order
  * (the reference's atomic scatter order is unspecified). */
-static void splat(const orc_sensor *se, float *film, float spx, float spy, const float *rgb) {
+/* dr::detail::estrin_impl, 10 coefficients (drjit/math.h; Estrin pairing) */
+static float estrin10(float x, const float *c) {
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+    float a0 = fmaf(x, c[1], c[0]), a1 = fmaf(x, c[3], c[2]), a2 = fmaf(x, c[5], c[4]), a3 = fmaf(x, c[7], c[6]), a4 = fmaf(x, c[9], c[8]);
+    float b0 = fmaf(x2, a1, a0), b1 = fmaf(x2, a3, a2);
+    return fmaf(x8, a4, fmaf(x4, b1, b0));
+}
+/* GaussianFilter ctor + eval, non-CUDA branch -- src/rfilters/gaussian.cpp:48-96 */
+static void gaussian_coeffs(float stddev, float radius, float *out) {
+    static const double coeff[10] = { 9.992604880e-1, -4.977025247e-1, 1.222248550e-1, -1.932406282e-2, 2.136713061e-3,
+                                      -1.679873860e-4, 9.202145248e-6, -3.329417433e-7, 7.128382794e-9, -6.821193280e-11 };
+    double scale = 1;
+    for (int i = 0; i < 10; ++i) { out[i] = (float) (coeff[i] * scale); scale /= (double) stddev * (double) stddev; }
+    out[0] -= estrin10(radius * radius, out);
+}
+static void splat(const orc_sensor *se, float *film, float spx, float spy, int pixel_x, int pixel_y, const float *rgb) {
     int W = se->crop_w, H = se->crop_h;
     float vals[4] = { rgb[0], rgb[1], rgb[2], 1.f };
     if (se->filter == ORC_FILTER_BOX) {
-        int x = (int) floorf(spx) - se->crop_x, y = (int) floorf(spy) - se->crop_y;
+        /* "With box filter, ignore random offset": block->put(box_filter ? pos : sample_pos) (integrator.cpp:540-541);
+         * pos is the lane's integer pixel, so floor(pos) - offset is the pixel itself */
+        int x = pixel_x, y = pixel_y;
         if ((unsigned) x < (unsigned) W && (unsigned) y < (unsigned) H)
             for (int k = 0; k < 4; ++k) film[4 * ((size_t) y * W + x) + k] += vals[k];
         return;
     }
-    float radius = se->filter_radius, inv_r = 1.f / radius;
+    float radius = se->filter_radius, inv_r = 1.f / radius, gc[10];
+    const int gauss = se->filter == ORC_FILTER_GAUSSIAN;
+    if (gauss) gaussian_coeffs(se->filter_stddev, radius, gc);
     int n = (int) ceilf(radius - .5f), count = 2 * n + 1;
     int pix = (int) floorf(spx) - n, piy = (int) floorf(spy) - n;
     float relx = (float) pix + .5f - spx, rely = (float) piy + .5f - spy;
     int lx = pix - se->crop_x, ly = piy - se->crop_y;
     for (int ys = 0; ys < count; ++ys) {
-        float wy = f_max(0.f, 1.f - fabsf((rely + (float) ys) * inv_r));
+        float ry = rely + (float) ys;
+        float wy = gauss ? f_max(estrin10(ry * ry, gc), 0.f) : f_max(0.f, 1.f - fabsf(ry * inv_r));
         for (int xs = 0; xs < count; ++xs) {
-            float wx = f_max(0.f, 1.f - fabsf((relx + (float) xs) * inv_r));
+            float rx = relx + (float) xs;
+            float wx = gauss ? f_max(estrin10(rx * rx, gc), 0.f) : f_max(0.f, 1.f - fabsf(rx * inv_r));
             float w = wx * wy;
             int x = lx + xs, y = ly + ys;
             if ((unsigned) x < (unsigned) W && (unsigned) y < (unsigned) H)
@@ -850,7 +871,10 @@ uint64_t orc_render(const orc_scene *sc, const orc_params *p, uint32_t seed, uin
         int re = r + chunk_rows < row_end ? r + chunk_rows : row_end;
         uint64_t n = lanes_per_row * (uint64_t) (re - r);
         run_lanes(&cx, lanes_per_row * (uint64_t) r, n, buf, nt);
-        for (uint64_t i = 0; i < n; ++i) splat(&sc->sensor, film, buf[i].sample_pos[0], buf[i].sample_pos[1], buf[i].rgb);
+        for (uint64_t i = 0; i < n; ++i) {
+            uint64_t pix = (lanes_per_row * (uint64_t) r + i) / spp;
+            splat(&sc->sensor, film, buf[i].sample_pos[0], buf[i].sample_pos[1], (int) (pix % (uint64_t) W), (int) (pix / (uint64_t) W), buf[i].rgb);
+        }
         total += n;
     }
     free(buf);

@@ -29,7 +29,7 @@ enum { ORC_EMITTER_POINT = 0 };
 enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 };
 enum { ORC_TIME_UNIFORM = 0, ORC_TIME_STRATIFIED = 1, ORC_TIME_ANTITHETIC = 2,
        ORC_TIME_ANTITHETIC_MIRROR = 3 };
-enum { ORC_FILTER_BOX = 0, ORC_FILTER_TENT = 1 };
+enum { ORC_FILTER_BOX = 0, ORC_FILTER_TENT = 1, ORC_FILTER_GAUSSIAN = 2 };
 
 /* All 4x4 matrices are row-major float32: m[4*r + c]. */
 
@@ -76,6 +76,7 @@ typedef struct {
     int32_t crop_x, crop_y, crop_w, crop_h;
     int32_t filter;          /* ORC_FILTER_* */
     float   filter_radius;
+    float   filter_stddev;   /* gaussian only (radius = 4 stddev, src/rfilters/gaussian.cpp:48-53) */
 } orc_sensor;
 
 typedef struct {

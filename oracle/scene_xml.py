@@ -478,7 +478,7 @@ def _sensor_record(sp):
         raise ValueError('unsupported sensor plugin "%s"' % sp.plugin)
     film = next((c[1] for c in sp.children if c[0] == "film"), None)
     w, h, cx, cy = 768, 576, 0, 0
-    filt, radius = None, 0.0
+    filt, radius, stddev = None, 0.0, 0.5
     if film is not None:
         w, h = film.get_i("width", 768), film.get_i("height", 576)
         cw, ch = film.get_i("crop_width", w), film.get_i("crop_height", h)
@@ -489,19 +489,22 @@ def _sensor_record(sp):
                 filt, radius = 1, rf.get_f("radius", 1.0)
             elif rf.plugin == "box":
                 filt, radius = 0, 0.5
+            elif rf.plugin == "gaussian":   # gaussian.cpp:48-53
+                stddev = rf.get_f("stddev", 0.5)
+                filt, radius = 2, float(F32(4) * F32(stddev))
             else:
                 raise ValueError('unsupported rfilter plugin "%s"' % rf.plugin)
     else:
         cw, ch = w, h
-    if filt is None:
-        raise ValueError('unsupported rfilter plugin "gaussian" (film default)')
+    if filt is None:   # film.cpp:49-53: gaussian by default
+        filt, radius, stddev = 2, 2.0, 0.5
     tw = sp["to_world"][1][0] if "to_world" in sp else _ident()
     so = sp.get_f("shutter_open", 0.0)
     sc = sp.get_f("shutter_close", 0.0)
     near, far = sp.get_f("near_clip", 1e-2), sp.get_f("far_clip", 1e4)
     return dict(to_world=_m32(tw), x_fov=F32(_parse_fov(sp, w / float(h))), near_clip=F32(near), far_clip=F32(far),
                 shutter_open=F32(so), shutter_close=F32(sc), film_w=w, film_h=h, crop_x=cx, crop_y=cy,
-                crop_w=cw, crop_h=ch, filter=filt, filter_radius=F32(radius))
+                crop_w=cw, crop_h=ch, filter=filt, filter_radius=F32(radius), filter_stddev=F32(stddev))
 
 
 # ----------------------------------------------------------------------------- plugin parameters

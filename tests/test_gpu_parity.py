@@ -168,7 +168,7 @@ def test_modulation_functions_match_oracle(mi, orc):
             assert np.array_equal(bits(sc.eval_modulation(2, x)), bits(np.array([L.orc_waveform_low_pass(float(v), wt) for v in x], np.float32)))
 
 
-@pytest.mark.parametrize("case", ["spp1", "spp3_box", "crop", "depth1", "depth2", "unbounded_rr", "two_lights", "onesided", "tent_wide"])
+@pytest.mark.parametrize("case", ["spp1", "spp3_box", "crop", "depth1", "depth2", "unbounded_rr", "two_lights", "onesided", "tent_wide", "gaussian_default"])
 def test_edge_cases_against_oracle(mi, orc, case):
     base = open(os.path.join(SCENES, "cornell_boxes.xml")).read()
     params, spp, xml = dict(resx=24, resy=24), 8, base
@@ -193,6 +193,8 @@ def test_edge_cases_against_oracle(mi, orc, case):
         xml = base.replace('<bsdf type="twosided" id="BackWallBSDF">\n\t\t<bsdf type="diffuse">\n\t\t\t<rgb name="reflectance" value="0.725, 0.71, 0.68" />\n\t\t</bsdf>\n\t</bsdf>',
                            '<bsdf type="diffuse" id="BackWallBSDF"><rgb name="reflectance" value="0.3, 0.5, 0.7" /></bsdf>')
         assert 'id="BackWallBSDF"><rgb' in xml
+    elif case == "gaussian_default":   # no <rfilter>: hdrfilm falls back to gaussian(stddev 0.5), radius 2 -> 5x5 footprint
+        xml = base.replace('<rfilter type="tent" />', '')
     elif case == "tent_wide":
         xml = base.replace('<rfilter type="tent" />', '<rfilter type="tent"><float name="radius" value="2.0" /></rfilter>')
     sc = mi.load_string(xml, **params)
@@ -224,7 +226,7 @@ def test_multi_pass_harness_is_the_mean_over_seeds(mi):
                           "time_sampling_method": "antithetic", "path_correlation_depth": 4})
     avg = mi.render_multi_pass(sc, integ, total_spp=64, single_pass_spp=16)
     parts = [integ.render(sc, seed=i, spp=16) for i in range(4)]
-    assert np.allclose(avg, sum(parts) / 4, rtol=1e-6, atol=1e-12)
+    assert rel_linf(avg, sum(parts) / 4) <= IMG_TOL            # each render's film atomics are unordered
     tof = mi.to_tof_image(avg)
     assert tof.shape == (16, 16) and np.allclose(tof, (0.2126 * avg[..., 0] + 0.7152 * avg[..., 1] + 0.0722 * avg[..., 2]) * 0.0015)
     assert rel_linf(mi.render(sc, spp=16, seed=1, integrator=integ), parts[1]) <= IMG_TOL   # film atomics are unordered
