@@ -38,25 +38,44 @@ B_BOUNCE = B_TRACE + B_SHADE + B_SHADOW          # 412
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+# (scene, resolution, spp, -D overrides, batched hetero offsets)
+CONFIGS = {
+    "c1": ("cornell_boxes.xml", 256, 16, dict(hetero_frequency=0.0, time_sampling_method="uniform", antithetic_shift=0.0), None),
+    "c2": ("cornell_wall.xml", 512, 64, dict(), None),
+    "c3": ("cornell_wall.xml", 512, 256, dict(time_sampling_method="antithetic_mirror", antithetic_shift=0.0), None),
+    "c4": ("domino.xml", 1024, 128, dict(wave_function_type="rectangular"), None),
+    "c5": ("domino.xml", 1024, 512, dict(wave_function_type="trapezoidal"), [0.0, 0.25, 0.5, 0.75]),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scene", default=os.path.join(HERE, "scenes", "cornell_wall.xml"))
-    ap.add_argument("--res", type=int, default=512)
-    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU (weak) / in total (strong)")
+    ap.add_argument("--scene", default=None)
+    ap.add_argument("--res", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel per GPU (weak) / in total (strong)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="BASELINE.json configs[0..4] as concretised in SURVEY 8(d); c2 is the headline (default). The others "
+                         "are parity-test cases that can also be timed; --res/--spp still override.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU oracle sample")
-    return ap.parse_args()
+    args = ap.parse_args()
+    scene, res, spp, defines, offsets = CONFIGS[args.config]
+    args.scene = args.scene or os.path.join(HERE, "scenes", scene)
+    args.res = args.res or res
+    args.spp = args.spp or spp
+    args.defines, args.offsets = dict(defines), offsets
+    return args
 
 
-def cpu_baseline(scene_path, res, spp, target_s):
+def cpu_baseline(scene_path, res, spp, target_s, defines):
     """Oracle (CPU port of the same algorithm) on all host cores, on a bounded band of rows of the same workload."""
     from oracle import orc
     cores = os.cpu_count() or 1
-    osc = orc.Scene(scene_path, dict(resx=res, resy=res))
+    osc = orc.Scene(scene_path, dict(defines, resx=res, resy=res))
     pd = osc.params()
     mid = res // 2
     t0 = time.time()
@@ -72,7 +91,10 @@ def cpu_baseline(scene_path, res, spp, target_s):
         _, n = osc.render(pd, seed=seed, spp=spp, rows=(r0, r0 + rows), threads=cores, raw=True)
         total += n
     dt = time.time() - t0
-    return {"value": round(total / dt / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
+    t1 = time.time()                                              # the same code on ONE thread (report both)
+    _, n1 = osc.render(pd, seed=0, spp=spp, rows=(mid, mid + max(1, min(8, int(2.0 * rate / cores / (res * spp)) or 1))), threads=1, raw=True)
+    one = n1 / max(time.time() - t1, 1e-9) / 1e6
+    return {"value": round(total / dt / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port", "value_1_core": round(one, 4),
             "sample": "oracle/dtof_oracle.c (scalar C restatement of the same algorithm, pthreads over lanes): rows [%d,%d) of "
                       "the %dx%d %d-spp frame x %d seeds = %d paths in %.1f s" % (r0, r0 + rows, res, res, spp, reps, total, dt)}
 
@@ -100,7 +122,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    scene = mi.load_file(args.scene, resx=args.res, resy=args.res)
+    scene = mi.load_file(args.scene, **dict(args.defines, resx=args.res, resy=args.res))
+    if args.offsets and world > 1:
+        raise SystemExit("batched-offset configs are timed on one GPU here (the film gather below carries one film)")
     W, H = scene.size
     halo = 1                                     # tent filter, radius 1 (imageblock.cpp:423-426)
     spp = args.spp * world if args.scaling == "weak" else args.spp
@@ -115,9 +139,25 @@ def main():
     acc = {"ms_trace": 0.0, "ms_shade": 0.0, "ms_shadow": 0.0, "ms_generate": 0.0, "ms_splat": 0.0, "ms_total": 0.0,
            "n_bounces": 0, "n_shadow_rays": 0, "n_paths": 0, "launches": 0}
 
+    if args.offsets:
+        kfilm = torch.zeros((len(args.offsets), H, W, 4), dtype=torch.float32, device=dev)
+        krgb = torch.zeros((len(args.offsets), H, W, 3), dtype=torch.float32, device=dev)
+
     def step(record):
         film.zero_()
+        if args.offsets:
+            kfilm.zero_()
         torch.cuda.synchronize()
+        if args.offsets:   # K films in ONE traversal (config c5): library-native [K][H][W][4] layout, single GPU
+            st = scene.render_rows(kfilm.data_ptr(), seed=0, spp=spp, row_begin=0, row_end=H, offsets=args.offsets)
+            rc = lib.dtof_develop(kfilm.data_ptr(), krgb.data_ptr(), H * W * len(args.offsets))
+            if rc != 0:
+                raise RuntimeError(lib.dtof_last_error().decode())
+            if record:
+                for k in ("ms_trace", "ms_shade", "ms_shadow", "ms_generate", "ms_splat", "ms_total", "n_bounces", "n_shadow_rays", "n_paths"):
+                    acc[k] += st[k]
+                acc["launches"] += st["n_launches_shade"]
+            return
         st = scene.render_rows(film_ptr, seed=0, spp=spp, row_begin=r0, row_end=r1)   # synchronises the library's stream
         slabs = D.gather_film(film[p0:p1], rank, world)
         if rank == 0:
@@ -154,7 +194,7 @@ def main():
     value = total_paths * args.steps / elapsed / 1e6
 
     if rank == 0:
-        img = rgb.cpu().numpy()
+        img = (krgb if args.offsets else rgb).cpu().numpy()
         shade_lanes = acc["n_bounces"]                         # lanes processed by the shade launches of this rank
         shade_s = acc["ms_shade"] * 1e-3
         loop_s = (acc["ms_trace"] + acc["ms_shade"] + acc["ms_shadow"]) * 1e-3
@@ -190,18 +230,21 @@ def main():
                      "ms_splat": round(acc["ms_splat"] / args.steps, 4)},
         }
         out = {
-            "metric": "Mpaths/s (whole node), Doppler Cornell 512x512 64spp", "value": round(value, 2), "unit": "Mpaths/s",
+            "metric": "Mpaths/s (whole node), Doppler Cornell 512x512 64spp" if args.config == "c2" else
+                      "Mpaths/s (whole node), BASELINE config %s" % args.config, "value": round(value, 2), "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cornell_wall (Cornell box, one linearly translating wall) %dx%d, %d spp%s, sinusoidal "
-                                   "heterodyne hetero_frequency=1, stratified time sampling, max_depth 4, tent filter"
+            "config": {"workload": (("cornell_wall (Cornell box, one linearly translating wall) %dx%d, %d spp%s, sinusoidal "
+                                    "heterodyne hetero_frequency=1, stratified time sampling, max_depth 4, tent filter") if args.config == "c2" else
+                                    (os.path.basename(args.scene) + " %dx%d, %d spp%s, " + json.dumps(args.defines) +
+                                     (", offsets %s batched" % args.offsets if args.offsets else "")))
                                    % (W, H, spp, " (= %d per GPU x %d GPUs, rows sharded)" % (args.spp, world) if world > 1 and args.scaling == "weak" else ""),
                        "paths_per_step": total_paths, "sharding": "row bands, 1 film gather" if world > 1 else "none",
                        "image_checksum": float(np.abs(img).sum())},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.scene, args.res, args.spp, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args.scene, args.res, args.spp, args.cpu_seconds, args.defines)
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / max(out["cpu_baseline"]["value"], 1e-9), 1)
         print(json.dumps(out))
     if world > 1:
