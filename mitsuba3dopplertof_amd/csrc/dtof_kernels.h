@@ -30,6 +30,7 @@ struct RenderParams {
     float phase[kMaxOffsets]; int32_t n_offsets;
     int32_t wave_type, low_pass;
     uint32_t path_correlation_depth, max_depth, rr_depth;
+    int32_t has_area;                             // scene has area emitters: emitter-hit term + prev_si / prev_bsdf_pdf state
     int32_t integrator;                           // 0 dopplertofpath, 1 path (src/integrators/path.cpp), 2 velocity (velocity.cpp)
     // ---- batch
     uint32_t lane_base, n_lanes;                  // this batch covers global lanes [lane_base, lane_base + n_lanes)
@@ -43,6 +44,7 @@ struct Queues {
     uint4  *hit;         // t, u, v (float bits), prim
     uint32_t *hit_id;    // object (low 24 bits) | shape-in-group (high 8 bits); 0xffffffff = miss
     float4 *st_a;        // throughput.xyz, path_length
+    float4 *st_b;        // prev_si.p, prev_bsdf_pdf (only touched when the scene has area emitters)
     uint4  *rng_a;       // rng.state (lo,hi), rng_path.state (lo,hi)
     uint2  *rng_b;       // rng_time.state
     float4 *res;         // [K][capacity] accumulated result rgb (w unused)

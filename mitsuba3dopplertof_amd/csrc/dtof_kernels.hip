@@ -491,23 +491,71 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             compute_surface(sv, hid & 0xffffffu, hid >> 24, hh.w, t, u2f(hh.y), u2f(hh.z), o, d, time, si);
             const DShape *sh = si.shape;
 
-            // ---- emitter sampling (scene.cpp:235-291, point.cpp:118-147)
-            float e1 = plain ? next_f32(main) : next_correlate(main, path, correlate), e2 = plain ? next_f32(main) : next_correlate(main, path, correlate); (void) e2;
+            const float pmf = sv.n_emitters ? 1.f / (float) sv.n_emitters : 0.f;   // m_emitter_pmf (scene.cpp:96)
+            // ---- direct emission (dopplertofpath.cpp:150-168 / path.cpp): the hit shape carries an area emitter
+            bool res_dirty = false;
+            float4 rcur[kMaxOffsets];
+            if (rp.has_area) {
+#pragma unroll
+                for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) rcur[k] = q.res[(size_t) k * q.capacity + l];
+                if (sh->flags & SF_EMITTER) {
+                    float4 pb = depth > 0 ? q.st_b[l] : make_float4(0.f, 0.f, 0.f, 1.f);   // prev_si.p, prev_bsdf_pdf
+                    V3 rel = si.p - mk(pb.x, pb.y, pb.z);                      // DirectionSample(scene, si, prev_si), records.h:173-180
+                    float dist = norm(rel);
+                    V3 dsd = rel * rcp(dist);
+                    float em_pdf = 0.f;
+                    if (depth > 0) {                                             // !prev_bsdf_delta: AreaLight::pdf_direction (area.cpp:161-180)
+                        float dp = dot(dsd, si.n);
+                        if (dp < 0.f) { float adp = fabsf(dp); em_pdf = sh->inv_area * (adp != 0.f ? (dist * dist) / adp : 0.f) * pmf; }
+                    }
+                    float mis_bsdf = mis_weight(pb.w, em_pdf);
+                    bool on = si.wi.z > 0.f && pb.w > 0.f;                       // AreaLight::eval (area.cpp:82-89), mask prev_bsdf_pdf > 0
+                    V3 le = on ? mk(sh->radiance[0], sh->radiance[1], sh->radiance[2]) : mk(0, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) {
+                        V3 v = le * mis_bsdf;
+                        if (!plain) v = v * modulation_weight(rp, rp.phase[k], time, path_length);
+                        rcur[k] = make_float4(fmaf(thr.x, v.x, rcur[k].x), fmaf(thr.y, v.y, rcur[k].y), fmaf(thr.z, v.z, rcur[k].z), 0.f);
+                    }
+                    res_dirty = true;
+                }
+            }
+
+            // ---- emitter sampling (scene.cpp:235-291; point.cpp:118-147; area.cpp:116-159 + shape.cpp:370-384 + rectangle.cpp:152-166)
+            float e1 = plain ? next_f32(main) : next_correlate(main, path, correlate), e2 = plain ? next_f32(main) : next_correlate(main, path, correlate);
             bool active_em = active_next && sv.n_emitters > 0;
-            V3 em_weight = mk(0, 0, 0), wo = mk(0, 0, 0); float ds_dist = 0.f;
+            V3 em_weight = mk(0, 0, 0), wo = mk(0, 0, 0); float ds_dist = 0.f, ds_pdf = 0.f; bool ds_delta = true;
             if (active_em) {
-                uint32_t ne = sv.n_emitters, idx = 0; float em_w = 1.f, pmf = 1.f;
-                if (ne > 1) { float scaled = e1 * (float) ne; idx = (uint32_t) scaled; if (idx > ne - 1) idx = ne - 1; em_w = (float) ne; pmf = 1.f / (float) ne; }
+                uint32_t ne = sv.n_emitters, idx = 0; float em_w = 1.f, sx = e1;
+                if (ne > 1) { float scaled = e1 * (float) ne; idx = (uint32_t) scaled; if (idx > ne - 1) idx = ne - 1; em_w = (float) ne; sx = scaled - (float) idx; }
                 const DEmitter &em = sv.emitters[idx];
-                V3 dsp = mk(em.pos[0], em.pos[1], em.pos[2]);
-                V3 dd = dsp - si.p;
-                float dist2 = dot(dd, dd), inv_dist = rsqrt_(dist2);
-                ds_dist = sqrtf(dist2);
-                dd = dd * inv_dist;
-                float id2 = sqr(inv_dist);
-                em_weight = mk(em.intensity[0] * id2, em.intensity[1] * id2, em.intensity[2] * id2) * em_w;
-                float ds_pdf = 1.f * pmf;
-                active_em = ds_pdf != 0.f;
+                V3 dsp, dd; bool em_active = true;
+                if (em.kind == EMITTER_POINT) {
+                    dsp = mk(em.pos[0], em.pos[1], em.pos[2]);
+                    dd = dsp - si.p;
+                    float dist2 = dot(dd, dd), inv_dist = rsqrt_(dist2);
+                    ds_dist = sqrtf(dist2);
+                    dd = dd * inv_dist;
+                    float id2 = sqr(inv_dist);
+                    em_weight = mk(em.intensity[0] * id2, em.intensity[1] * id2, em.intensity[2] * id2);
+                    ds_pdf = 1.f;
+                } else {
+                    const DShape &es = sv.shapes[em.shape];
+                    dsp = xf_point(es.to_world, mk(sx * 2.f - 1.f, e2 * 2.f - 1.f, 0.f));
+                    V3 en = mk(es.n[0], es.n[1], es.n[2]);
+                    dd = dsp - si.p;
+                    float dist2 = dot(dd, dd);
+                    ds_dist = sqrtf(dist2);
+                    dd = dd * rcp(ds_dist);
+                    float dp = fabsf(dot(dd, en)), x = dist2 / dp;
+                    ds_pdf = es.inv_area * (isfinite(x) ? x : 0.f);
+                    ds_delta = false;
+                    em_active = dot(dd, en) < 0.f && ds_pdf != 0.f;
+                    float ip = rcp(ds_pdf);
+                    em_weight = em_active ? mk(em.intensity[0] * ip, em.intensity[1] * ip, em.intensity[2] * ip) : mk(0, 0, 0);
+                }
+                ds_pdf *= pmf; em_weight = em_weight * em_w;
+                active_em = ds_pdf != 0.f && em_active;
                 // Interaction::spawn_ray_to (interaction.h:141-149)
                 V3 so = offset_p(si, dsp - si.p);
                 V3 sd = dsp - so;
@@ -526,20 +574,21 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             if (twosided) { woz = mulsign(woz, wiz); wiz = fabsf(wiz); }
             V3 refl = mk(sh->refl[0], sh->refl[1], sh->refl[2]);
             V3 bsdf_val = mk(0, 0, 0), bsdf_weight = mk(0, 0, 0), bs_wo = mk(0, 0, 0);
-            if (wiz > 0.f && woz > 0.f) bsdf_val = mk(refl.x * kInvPi * woz, refl.y * kInvPi * woz, refl.z * kInvPi * woz);
+            float bsdf_pdf = 0.f, bs_pdf = 0.f;
+            if (wiz > 0.f && woz > 0.f) { bsdf_val = mk(refl.x * kInvPi * woz, refl.y * kInvPi * woz, refl.z * kInvPi * woz); bsdf_pdf = kInvPi * woz; }
             if (wiz > 0.f) {
                 bs_wo = cosine_hemisphere(s2x, s2y);
-                float bs_pdf = kInvPi * bs_wo.z;
+                bs_pdf = kInvPi * bs_wo.z;
                 if (bs_pdf > 0.f) bsdf_weight = refl;
                 if (twosided) bs_wo.z = mulsign(bs_wo.z, si.wi.z);
             }
             // ---- emitter contribution candidate (dopplertofpath.cpp:214-226); committed by k_shadow if unoccluded
             if (active_em) {
-                const float mis_em = 1.f;   // ds.delta
+                const float mis_em = ds_delta ? 1.f : mis_weight(ds_pdf, bsdf_pdf);   // dopplertofpath.cpp:218-219
                 bool nonzero = false;
 #pragma unroll
                 for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) {
-                    float4 r = q.res[(size_t) k * q.capacity + l];
+                    float4 r = rp.has_area ? rcur[k] : q.res[(size_t) k * q.capacity + l];
                     V3 v = mk(bsdf_val.x * em_weight.x * mis_em, bsdf_val.y * em_weight.y * mis_em, bsdf_val.z * em_weight.z * mis_em);
                     if (!plain) { float lw = modulation_weight(rp, rp.phase[k], time, path_length + ds_dist); v = v * lw; }
                     float3 c = make_float3(fmaf(thr.x, v.x, r.x), fmaf(thr.y, v.y, r.y), fmaf(thr.z, v.z, r.z));
@@ -547,6 +596,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                     nonzero |= f2u(c.x) != f2u(r.x) || f2u(c.y) != f2u(r.y) || f2u(c.z) != f2u(r.z);
                 }
                 want_shadow = nonzero;   // a candidate identical to the current result needs no visibility test
+            }
+            if (res_dirty) {   // the emitter-hit term stands whether or not the NEE candidate is later committed
+#pragma unroll
+                for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) q.res[(size_t) k * q.capacity + l] = rcur[k];
             }
             // ---- continuation (dopplertofpath.cpp:232-276)
             V3 nd = vfma(si.sh_n, bs_wo.z, vfma(si.sh_t, bs_wo.y, si.sh_s * bs_wo.x));   // Frame::to_world
@@ -565,6 +618,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 q.ray_a[l] = nra;
                 q.ray_b[l] = nrb;
                 q.st_a[l] = make_float4(thr.x, thr.y, thr.z, path_length);
+                if (rp.has_area) q.st_b[l] = make_float4(si.p.x, si.p.y, si.p.z, bs_pdf);   // prev_si, prev_bsdf_pdf (:256-257)
                 q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
             }
         }

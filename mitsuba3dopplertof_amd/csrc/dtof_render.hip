@@ -52,7 +52,7 @@ static uint64_t target_batch_lanes() {   // lanes per wavefront batch (DTOF_BATC
 }
 
 struct Workspace {
-    DevBuf<float4> ray_a, ray_b, st_a, res, sh_a, sh_b, sh_c;
+    DevBuf<float4> ray_a, ray_b, st_a, st_b, res, sh_a, sh_b, sh_c;
     DevBuf<uint4> hit, rng_a;
     DevBuf<uint32_t> hit_id, q0, q1, counts;
     DevBuf<float2> pos;
@@ -61,14 +61,14 @@ struct Workspace {
     void ensure(uint32_t cap, int n_offsets) {
         if (cap <= capacity && n_offsets <= k) return;
         capacity = std::max(cap, capacity); k = std::max(n_offsets, k);
-        ray_a.ensure(capacity); ray_b.ensure(capacity); st_a.ensure(capacity);
+        ray_a.ensure(capacity); ray_b.ensure(capacity); st_a.ensure(capacity); st_b.ensure(capacity);
         res.ensure((size_t) capacity * k); sh_a.ensure(capacity); sh_b.ensure(capacity); sh_c.ensure((size_t) capacity * k);
         hit.ensure(capacity); rng_a.ensure(capacity); hit_id.ensure(capacity); q0.ensure(capacity); q1.ensure(capacity);
         counts.ensure(2 * (size_t) kMaxIter * segments_for(capacity)); pos.ensure(capacity);
     }
     Queues queues() {
         Queues q; memset(&q, 0, sizeof q);
-        q.ray_a = ray_a.p; q.ray_b = ray_b.p; q.hit = hit.p; q.hit_id = hit_id.p; q.st_a = st_a.p; q.rng_a = rng_a.p;
+        q.ray_a = ray_a.p; q.ray_b = ray_b.p; q.hit = hit.p; q.hit_id = hit_id.p; q.st_a = st_a.p; q.st_b = st_b.p; q.rng_a = rng_a.p;
         q.res = res.p; q.pos = pos.p; q.sh_a = sh_a.p; q.sh_b = sh_b.p; q.sh_c = sh_c.p; q.q[0] = q0.p; q.q[1] = q1.p;
         q.counts = counts.p; q.capacity = capacity;
         return q;
@@ -246,7 +246,9 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     hipStream_t ss[2] = { sc->stream, n_streams == 2 ? sc->stream2 : sc->stream };
     const uint8_t *blob = sc->d_blob.p; uint32_t blob_bytes = (uint32_t) sc->blob.size();
     const uint32_t stack_depth = ((const BlobHeader *) sc->blob.data())->tlas_depth;
-    const bool has_surface_emitters = false;   // supported emitters: point (no emitter-hit term, point.cpp:186-188)
+    bool has_surface_emitters = false;          // area emitters make the emitter-hit term (and the last iteration) live
+    for (auto &e : sc->host.emitters) has_surface_emitters |= e.kind == EMITTER_AREA;
+    rp.has_area = has_surface_emitters;
     StageTimer tm(stats != nullptr);
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));

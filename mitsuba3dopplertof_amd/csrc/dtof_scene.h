@@ -16,7 +16,8 @@ enum WaveType : int32_t { WAVE_SIN = 0, WAVE_RECT = 1, WAVE_TRI = 2, WAVE_TRAP =
 // ETimeSampling -- include/mitsuba/render/sampler.h:27-34
 enum TimeSampling : int32_t { TIME_UNIFORM = 0, TIME_STRATIFIED = 1, TIME_ANTITHETIC = 2, TIME_ANTITHETIC_MIRROR = 3 };
 enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1, FILTER_GAUSSIAN = 2 };
-enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4 };
+enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4, SF_EMITTER = 8 };
+enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1 };
 
 // ---------------------------------------------------------------------------- device blob records
 // One contiguous byte blob (offsets from its base) so that small scenes can be staged
@@ -44,17 +45,18 @@ struct DObject {            // 128 B
     float key0[12], key1[12];
 };
 struct DGroup { uint32_t first_shape, n_shapes, pad[2]; };
-struct DShape {             // 208 B
+struct DShape {             // 224 B
     uint32_t kind, flags, first_tri, n_tris;
     float refl[3], pad0;
     float to_world[12], to_object[12];
     float n[3], pad1, dp_du[3], pad2, dp_dv[3], pad3;   // rectangle frame (Rectangle::update, rectangle.cpp:101-113)
     float bmin[3], pad4, bmax[3], pad5;                 // padded bounds of the shape in ITS space (mesh: culls the triangle loop)
+    float radiance[3], inv_area;                        // SF_EMITTER: AreaLight radiance, Rectangle::m_inv_surface_area
 };
 struct DTri { float p0[4], p1[4], p2[4]; };                              // 48 B
 struct DTriShade { float n0[3], n1[3], n2[3], uv0[2], uv1[2], uv2[2], pad; };   // 64 B
-struct DEmitter { uint32_t kind; float pos[3]; float intensity[3]; float pad; };
-static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 208 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64, "blob records");
+struct DEmitter { uint32_t kind; float pos[3]; float intensity[3]; uint32_t shape; };   // area: intensity = radiance, shape = index into shapes[]
+static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 224 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64, "blob records");
 
 // ---------------------------------------------------------------------------- host description
 struct Mat4d { double m[16]; };   // row-major
@@ -68,6 +70,7 @@ struct HostShape {
     std::vector<float> positions, normals, texcoords;
     std::vector<uint32_t> faces;
     std::string id;
+    bool emitter = false; float radiance[3] = { 0, 0, 0 };   // area emitter attached to the shape (src/emitters/area.cpp)
 };
 struct HostGroup { uint32_t first_shape = 0, n_shapes = 0; };
 struct HostObject {
@@ -75,7 +78,7 @@ struct HostObject {
     float key_time[2] = { 0, 0 };
     float key[2][16];
 };
-struct HostEmitter { uint32_t kind = 0; float pos[3]; float intensity[3]; };
+struct HostEmitter { uint32_t kind = 0; float pos[3] = { 0, 0, 0 }; float intensity[3] = { 0, 0, 0 }; uint32_t shape = 0xffffffffu; };
 struct HostSensor {
     float to_world[16];
     float x_fov = 0, near_clip = 1e-2f, far_clip = 1e4f, shutter_open = 0, shutter_close = 0;

@@ -111,6 +111,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         d.kind = h.kind;
         d.flags = (h.twosided ? SF_TWOSIDED : 0) | (h.flip_normals ? SF_FLIP_NORMALS : 0) | (h.face_normals ? SF_FACE_NORMALS : 0);
         memcpy(d.refl, h.refl, 12);
+        if (h.emitter) { d.flags |= SF_EMITTER; memcpy(d.radiance, h.radiance, 12); }
         memcpy(d.to_world, h.to_world, 48); memcpy(d.to_object, h.to_object, 48);
         if (h.kind == SHAPE_RECT) {   // Rectangle::update, rectangle.cpp:101-113
             V3 du = xf_vector(h.to_world, mk(2.f, 0.f, 0.f)), dv = xf_vector(h.to_world, mk(0.f, 2.f, 0.f));
@@ -118,6 +119,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
             d.n[0] = n.x; d.n[1] = n.y; d.n[2] = n.z;
             d.dp_du[0] = du.x; d.dp_du[1] = du.y; d.dp_du[2] = du.z;
             d.dp_dv[0] = dv.x; d.dp_dv[1] = dv.y; d.dp_dv[2] = dv.z;
+            d.inv_area = rcp(norm(cross(du, dv)));   // Rectangle::surface_area / m_inv_surface_area (rectangle.cpp:109,127-129)
         } else {
             d.first_tri = (uint32_t) tris.size(); d.n_tris = (uint32_t) (h.faces.size() / 3);
             for (uint32_t f = 0; f < d.n_tris; ++f) {
@@ -179,7 +181,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     // ---- emitters
     std::vector<DEmitter> emitters(sc.emitters.size());
     for (size_t i = 0; i < sc.emitters.size(); ++i) {
-        emitters[i].kind = sc.emitters[i].kind; emitters[i].pad = 0;
+        emitters[i].kind = sc.emitters[i].kind; emitters[i].shape = sc.emitters[i].shape;
         memcpy(emitters[i].pos, sc.emitters[i].pos, 12); memcpy(emitters[i].intensity, sc.emitters[i].intensity, 12);
     }
     // ---- pack: nodes first (so that "the first N bytes" = header + top of the TLAS in BFS-ish order)

@@ -485,10 +485,21 @@ static HostShape make_shape(const Obj &o, bool strip_to_world) {
     const Obj *bsdf = nullptr;
     for (auto &c : o.children) {
         if (c.first == "bsdf") { if (bsdf) fail("Only a single BSDF child object can be specified per shape."); bsdf = c.second.get(); }
-        else if (c.first == "emitter") fail("area emitters are not supported by this library");
+        else if (c.first == "emitter") {   // src/emitters/area.cpp:64-76; supported on static rectangles
+            const Obj &e = *c.second;
+            if (s.emitter) fail("Only a single Emitter child object can be specified per shape.");
+            if (e.plugin != "area") fail("unsupported emitter plugin \"" + e.plugin + "\" inside a shape (supported: area)");
+            if (s.kind != SHAPE_RECT || strip_to_world) fail("area emitters are supported on static rectangles only");
+            if (e.transforms.count("to_world")) fail("Found a 'to_world' transformation -- this is not allowed. The area light inherits this transformation from its parent shape.");
+            auto rc = e.colors.find("radiance");
+            if (rc != e.colors.end()) for (int i = 0; i < 3; ++i) s.radiance[i] = (float) rc->second[i];
+            else { float v = (float) e.props.get_float("radiance", 1.0); s.radiance[0] = s.radiance[1] = s.radiance[2] = v; }
+            s.emitter = true;
+        }
         else fail("unsupported child <" + c.first + "> in shape");
     }
-    if (bsdf) bsdf_of(*bsdf, s.twosided, s.refl);   // else default diffuse(0.5), src/render/shape.cpp:66-72
+    if (bsdf) bsdf_of(*bsdf, s.twosided, s.refl);   // else default diffuse: 0.5, or 0 for an emitter (src/render/shape.cpp:66-72)
+    else if (s.emitter) s.refl[0] = s.refl[1] = s.refl[2] = 0.f;
     auto u = o.props.unqueried();
     if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in shape plugin of type \"" + o.plugin + "\"");
     if (s.kind == SHAPE_MESH) bake_cube(s);
@@ -636,6 +647,7 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
                     if (ch.second->plugin == "instance") fail("Nested instancing is not permitted");
                     if (ch.second->plugin == "shapegroup") fail("Nested ShapeGroup is not permitted");
                     sc.shapes.push_back(make_shape(*ch.second, false));
+                    if (sc.shapes.back().emitter) fail("Instancing of emitters is not supported");
                 }
                 g.n_shapes = (uint32_t) sc.shapes.size() - g.first_shape;
                 group_of[&o] = (uint32_t) sc.groups.size(); sc.groups.push_back(g);
@@ -659,6 +671,10 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
                 HostObject ob; ob.kind = OBJ_SHAPE; ob.index = (uint32_t) sc.shapes.size(); ob.n_keys = 0; memset(ob.key, 0, sizeof ob.key);
                 sc.shapes.push_back(make_shape(o, false));
                 sc.objects.push_back(ob);
+                if (sc.shapes.back().emitter) {   // scene.cpp:33-35: the shape's emitter joins the list at the shape's position
+                    HostEmitter e; e.kind = EMITTER_AREA; e.shape = ob.index; memcpy(e.intensity, sc.shapes.back().radiance, 12);
+                    sc.emitters.push_back(e);
+                }
             }
         } else if (o.tag == "bsdf" || o.tag == "texture") {
             // top-level declarations referenced by id

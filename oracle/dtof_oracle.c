@@ -602,6 +602,11 @@ static v3 square_to_cosine_hemisphere(float sx, float sy) {
 }
 
 /* ------------------------------------------------------------------ integrator */
+/* Rectangle::surface_area = |dp_du x dp_dv| (rectangle.cpp:127-129) and m_inv_surface_area = rcp(area) (:109) */
+static float rect_inv_area(const orc_shape *sh) {
+    v3 du = m_vector(sh->to_world, V(2.f, 0.f, 0.f)), dv = m_vector(sh->to_world, V(0.f, 2.f, 0.f));
+    return f_rcp(v_norm(v_cross(du, dv)));
+}
 /* mis_weight -- dopplertofpath.cpp:296-301 */
 static inline float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
@@ -644,6 +649,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
     float path_length = 0.f, eta = 1.f;
     uint32_t depth = 0; int valid_ray = 0, active = p->max_depth != 0;
     v3 o = ray.o, d = ray.d; float maxt = ray.maxt;
+    v3 prev_p = V(0, 0, 0); float prev_bsdf_pdf = 1.f; int prev_delta = 1;   /* dopplertofpath.cpp:106-108 */
 
     if (p->integrator == 2) {   /* VelocityIntegrator::sample, src/integrators/velocity.cpp:125-142 */
         orc_hit h1 = scene_closest(sc, o, d, 0.f, maxt), h2 = scene_closest(sc, o, d, p->time, maxt);
@@ -660,38 +666,80 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         orc_hit h = scene_closest(sc, o, d, time, maxt);
         int hit = h.obj >= 0;
         if (hit) path_length += h.t * eta;
-        /* emitter hit (:150-168): only surface/environment emitters contribute; the
-         * supported emitter set is {point} whose eval() is 0 (src/emitters/point.cpp:186-188). */
         int active_next = (depth + 1 < p->max_depth) && hit;
 
         orc_si si; memset(&si, 0, sizeof si);
         v3 em_weight = V(0, 0, 0), wo = V(0, 0, 0); float ds_pdf = 0.f, ds_dist = 0.f; int ds_delta = 0;
         if (hit) compute_si(sc, &h, o, d, time, &si);
+        const float pmf = sc->n_emitters ? 1.f / (float) sc->n_emitters : 0.f;   /* m_emitter_pmf, scene.cpp:96 */
+
+        /* ---- direct emission (dopplertofpath.cpp:150-168 / path.cpp): the hit shape carries an area emitter */
+        if (hit && si.shape->emitter) {
+            /* DirectionSample(scene, si, prev_si) -- include/mitsuba/render/records.h:173-180 */
+            v3 rel = v_sub(si.p, prev_p);
+            float dist = v_norm(rel);
+            v3 dsd = v_mul(rel, f_rcp(dist));
+            float em_pdf = 0.f;
+            if (!prev_delta) {   /* Scene::pdf_emitter_direction scene.cpp:293-299 -> AreaLight::pdf_direction area.cpp:161-180 */
+                float dp = v_dot(dsd, si.n);
+                if (dp < 0.f) {   /* Shape::pdf_direction shape.cpp:386-396, Rectangle::pdf_position = 1/area */
+                    float adp = fabsf(dp);
+                    float pdf = rect_inv_area(si.shape) * (adp != 0.f ? (dist * dist) / adp : 0.f);
+                    em_pdf = pdf * pmf;
+                }
+            }
+            float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
+            /* AreaLight::eval area.cpp:82-89, masked by prev_bsdf_pdf > 0 */
+            int on = si.wi.z > 0.f && prev_bsdf_pdf > 0.f;
+            v3 le = on ? V(si.shape->radiance[0], si.shape->radiance[1], si.shape->radiance[2]) : V(0, 0, 0);
+            v3 v = v_mul(le, mis_bsdf);
+            if (!plain) v = v_mul(v, orc_modulation_weight(p, time, path_length));
+            res = V(fmaf(thr.x, v.x, res.x), fmaf(thr.y, v.y, res.y), fmaf(thr.z, v.z, res.z));
+        }
+
         int active_em = active_next;   /* diffuse => BSDFFlags::Smooth */
 
         /* emitter sampling: Scene::sample_emitter_direction src/render/scene.cpp:235-291 */
         float e1 = sampler_draw(&smp, correlate, plain);
         float e2 = sampler_draw(&smp, correlate, plain);
-        (void) e2;
         if (active_em && sc->n_emitters > 0) {
-            uint32_t ne = (uint32_t) sc->n_emitters, idx = 0; float em_w = 1.f, pmf = 1.f;
+            uint32_t ne = (uint32_t) sc->n_emitters, idx = 0; float em_w = 1.f, sx = e1;
             if (ne > 1) {   /* sample_emitter :171-189 */
                 float scaled = e1 * (float) ne;
                 idx = (uint32_t) scaled; if (idx > ne - 1) idx = ne - 1;
-                em_w = (float) ne; pmf = 1.f / (float) ne;
+                em_w = (float) ne; sx = scaled - (float) idx;
             }
             const orc_emitter *em = &sc->emitters[idx];
-            /* PointLight::sample_direction src/emitters/point.cpp:118-147 */
-            v3 dsp = V(em->position[0], em->position[1], em->position[2]);
-            v3 dd = v_sub(dsp, si.p);
-            float dist2 = v_dot(dd, dd), inv_dist = f_rsqrt(dist2);
-            ds_dist = sqrtf(dist2);
-            dd = v_mul(dd, inv_dist);
-            float id2 = f_sqr(inv_dist);
-            em_weight = V(em->intensity[0] * id2, em->intensity[1] * id2, em->intensity[2] * id2);
-            ds_pdf = 1.f; ds_delta = 1;
+            v3 dsp, dd; int em_active = 1;
+            if (em->kind == ORC_EMITTER_POINT) {
+                /* PointLight::sample_direction src/emitters/point.cpp:118-147 */
+                dsp = V(em->position[0], em->position[1], em->position[2]);
+                dd = v_sub(dsp, si.p);
+                float dist2 = v_dot(dd, dd), inv_dist = f_rsqrt(dist2);
+                ds_dist = sqrtf(dist2);
+                dd = v_mul(dd, inv_dist);
+                float id2 = f_sqr(inv_dist);
+                em_weight = V(em->intensity[0] * id2, em->intensity[1] * id2, em->intensity[2] * id2);
+                ds_pdf = 1.f; ds_delta = 1;
+            } else {
+                /* AreaLight::sample_direction area.cpp:116-159 -> Shape::sample_direction shape.cpp:370-384 ->
+                 * Rectangle::sample_position rectangle.cpp:152-166 */
+                const orc_shape *es = &sc->shapes[em->shape];
+                dsp = m_point(es->to_world, V(sx * 2.f - 1.f, e2 * 2.f - 1.f, 0.f));
+                v3 en = v_normalize(m_normal(es->to_object, V(0.f, 0.f, 1.f)));
+                dd = v_sub(dsp, si.p);
+                float dist2 = v_dot(dd, dd);
+                ds_dist = sqrtf(dist2);
+                dd = v_mul(dd, f_rcp(ds_dist));
+                float dp = fabsf(v_dot(dd, en)), x = dist2 / dp;
+                ds_pdf = rect_inv_area(es) * (isfinite(x) ? x : 0.f);
+                ds_delta = 0;
+                em_active = v_dot(dd, en) < 0.f && ds_pdf != 0.f;
+                float ip = f_rcp(ds_pdf);
+                em_weight = em_active ? V(em->intensity[0] * ip, em->intensity[1] * ip, em->intensity[2] * ip) : V(0, 0, 0);
+            }
             ds_pdf *= pmf; em_weight = v_mul(em_weight, em_w);
-            if (ds_pdf != 0.f) {
+            if (ds_pdf != 0.f && em_active) {
                 /* Interaction::spawn_ray_to interaction.h:141-149 + ray_test */
                 v3 so = offset_p(&si, v_sub(dsp, si.p));
                 v3 sd = v_sub(dsp, so);
@@ -744,6 +792,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         thr = V(thr.x * bsdf_weight.x, thr.y * bsdf_weight.y, thr.z * bsdf_weight.z);
         eta *= bs_eta;
         valid_ray |= hit;
+        prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_delta = 0;   /* :256-258 (diffuse lobes are never delta) */
         if (hit) depth += 1;
         /* :264-276 */
         float thr_max = f_max(f_max(thr.x, thr.y), thr.z);

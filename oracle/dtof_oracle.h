@@ -25,7 +25,7 @@ extern "C" {
 
 enum { ORC_SHAPE_RECT = 0, ORC_SHAPE_MESH = 1 };
 enum { ORC_OBJ_SHAPE = 0, ORC_OBJ_INSTANCE = 1 };
-enum { ORC_EMITTER_POINT = 0 };
+enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1 };
 enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 };
 enum { ORC_TIME_UNIFORM = 0, ORC_TIME_STRATIFIED = 1, ORC_TIME_ANTITHETIC = 2,
        ORC_TIME_ANTITHETIC_MIRROR = 3 };
@@ -47,6 +47,9 @@ typedef struct {
     const float    *normals;    /* n_vertices*3 or NULL */
     const float    *texcoords;  /* n_vertices*2 or NULL */
     const uint32_t *faces;      /* n_faces*3 */
+    /* area emitter attached to this (static, top-level rectangle) shape: src/emitters/area.cpp */
+    int32_t emitter;            /* 0 / 1 */
+    float   radiance[3];
 } orc_shape;
 
 typedef struct {
@@ -62,9 +65,10 @@ typedef struct {
 } orc_object;
 
 typedef struct {
-    int32_t kind;            /* ORC_EMITTER_POINT */
-    float   position[3];
-    float   intensity[3];
+    int32_t kind;            /* ORC_EMITTER_* */
+    float   position[3];     /* point */
+    float   intensity[3];    /* point: intensity; area: radiance */
+    int32_t shape;           /* area: index into shapes[] of the rectangle that carries it */
 } orc_emitter;
 
 typedef struct {

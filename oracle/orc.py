@@ -21,7 +21,8 @@ class OrcShape(C.Structure):
                 ("reflectance", C.c_float * 3), ("to_world", M16), ("to_object", M16),
                 ("n_vertices", C.c_int32), ("n_faces", C.c_int32),
                 ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
-                ("texcoords", C.POINTER(C.c_float)), ("faces", C.POINTER(C.c_uint32))]
+                ("texcoords", C.POINTER(C.c_float)), ("faces", C.POINTER(C.c_uint32)),
+                ("emitter", C.c_int32), ("radiance", C.c_float * 3)]
 
 
 class OrcGroup(C.Structure):
@@ -34,7 +35,7 @@ class OrcObject(C.Structure):
 
 
 class OrcEmitter(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("position", C.c_float * 3), ("intensity", C.c_float * 3)]
+    _fields_ = [("kind", C.c_int32), ("position", C.c_float * 3), ("intensity", C.c_float * 3), ("shape", C.c_int32)]
 
 
 class OrcSensor(C.Structure):
@@ -147,6 +148,8 @@ class Scene:
             o.kind, o.twosided, o.flip_normals, o.face_normals = s["kind"], s["twosided"], s["flip_normals"], s["face_normals"]
             o.reflectance = (C.c_float * 3)(*s["reflectance"].tolist())
             o.to_world, o.to_object = _m16(s["to_world"]), _m16(s["to_object"])
+            o.emitter = int(s.get("emitter", 0))
+            o.radiance = (C.c_float * 3)(*np.asarray(s.get("radiance", [0, 0, 0]), np.float32).tolist())
             if s["kind"] == 1:   # cube
                 pos, nrm = np.zeros(72, np.float32), np.zeros(72, np.float32)
                 uv, faces = np.zeros(48, np.float32), np.zeros(36, np.uint32)
@@ -174,6 +177,7 @@ class Scene:
             emitters[i].kind = e["kind"]
             emitters[i].position = (C.c_float * 3)(*e["position"].tolist())
             emitters[i].intensity = (C.c_float * 3)(*e["intensity"].tolist())
+            emitters[i].shape = int(e.get("shape", -1))
         sc = OrcScene()
         sc.shapes, sc.n_shapes = shapes, len(fs.shapes)
         sc.groups, sc.n_groups = groups, len(fs.groups)

@@ -347,16 +347,26 @@ def _shape_record(sp, registry, strip_to_world):
         fm, fi = _scale([1.0, 1.0, -1.0])
         tw, tinv = _mul(tw, fm), _mul(fi, tinv)
         flip = False
-    bsdfs = [c for c in sp.children if c[0] in ("bsdf", "ref")]
-    if any(c[0] == "emitter" for c in sp.children):
-        raise ValueError("area emitters are not supported")
+    bsdfs = [c for c in sp.children if c[0] == "bsdf" or (c[0] == "ref" and registry[c[1]][0] == "bsdf")]
+    ems = [c[1] for c in sp.children if c[0] == "emitter"]
+    emitter, radiance = 0, np.zeros(3, F32)
+    if ems:   # src/emitters/area.cpp:64-76 on a static rectangle
+        if len(ems) > 1:
+            raise ValueError("Only a single Emitter child object can be specified per shape.")
+        if ems[0].plugin != "area" or kind != 0 or strip_to_world:
+            raise ValueError("only area emitters on static rectangles are supported")
+        if "to_world" in ems[0]:
+            raise ValueError("Found a 'to_world' transformation -- this is not allowed.")
+        rad = ems[0]["radiance"] if "radiance" in ems[0] else ("float", 1.0)
+        radiance = np.asarray([rad[1]] * 3 if rad[0] in ("float", "int") else rad[1], dtype=np.float64).astype(F32)
+        emitter = 1
     if bsdfs:
         bp = bsdfs[0][1] if bsdfs[0][0] == "bsdf" else registry[bsdfs[0][1]][1]
         twosided, refl = _bsdf_of(bp, registry)
-    else:
-        twosided, refl = 0, np.array([0.5] * 3, dtype=F32)   # shape.cpp:66-72 default diffuse
+    else:   # shape.cpp:66-72: default diffuse, reflectance 0 when the shape is an emitter
+        twosided, refl = 0, np.array([0.0 if emitter else 0.5] * 3, dtype=F32)
     return dict(kind=kind, twosided=twosided, flip_normals=int(flip), face_normals=int(sp.get_b("face_normals", False)),
-                reflectance=refl, to_world=_m32(tw), to_object=_m32(tinv))
+                reflectance=refl, to_world=_m32(tw), to_object=_m32(tinv), emitter=emitter, radiance=radiance)
 
 
 def load(source, params=None, is_string=False):
@@ -418,6 +428,9 @@ def load(source, params=None, is_string=False):
                 fs.shapes.append(_shape_record(child, registry, False))
                 fs.objects.append(dict(kind=0, index=len(fs.shapes) - 1, n_keys=0,
                                        key_time=np.zeros(2, F32), key=np.zeros((2, 4, 4), F32)))
+                if fs.shapes[-1]["emitter"]:   # scene.cpp:33-35: a shape's emitter joins the list at the shape's position
+                    fs.emitters.append(dict(kind=1, position=np.zeros(3, F32), intensity=fs.shapes[-1]["radiance"],
+                                            shape=len(fs.shapes) - 1))
     if fs.sensor is None:
         raise ValueError("scene has no sensor")
     return fs

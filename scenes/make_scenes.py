@@ -8,6 +8,8 @@
                      the camera); resolution / spp / integrator settings are <default> parameters.
   cornell_wall.xml   C2/C3: same room, the two boxes replaced by ONE rectangle (the back wall) that translates
                      0.015 towards the camera over the 1.5 ms exposure (10 m/s).
+  cornell_area.xml   the C1 room lit by the classic ceiling AREA light instead of the point light (emitter-hit + MIS terms of
+                     dopplertofpath.cpp:150-168,214-226; the tutorials' "cornell-box doppler_area" setting).
   domino.xml         C4/C5: ground rectangle + 32x32 cubes instanced from one shapegroup, each with its own
                      pair of keyframes (toppling: rotation about the bottom edge + drift), motion-blur BVH stress.
 """
@@ -104,7 +106,12 @@ LIGHT = ('\t<emitter type="point">\n\t\t<transform name="to_world">\n' + CAM + '
          '\t\t<rgb name="intensity" value="100" />\n\t</emitter>\n')
 
 
-def cornell(moving_wall, res, spp, tsm, shift):
+AREA_LIGHT = ('\t<shape type="rectangle" id="Light">\n\t\t<transform name="to_world">\n\t\t\t<scale x="0.25" y="0.2" z="1" />\n'
+              '\t\t\t<rotate x="1" angle="90" />\n\t\t\t<translate x="0" y="1.98" z="0" />\n\t\t</transform>\n'
+              '\t\t<emitter type="area">\n\t\t\t<rgb name="radiance" value="17, 12, 4" />\n\t\t</emitter>\n\t</shape>\n')
+
+
+def cornell(moving_wall, res, spp, tsm, shift, area_light=False):
     s = HEADER.format(spp=spp, res=res, tsm=tsm, shift=shift) + SENSOR.format(fov="19.5", cam=CAM)
     for b in BSDFS:
         s += bsdf(*b)
@@ -113,7 +120,7 @@ def cornell(moving_wall, res, spp, tsm, shift):
     if not moving_wall:
         s += cube("ShortBox", SHORT, "ShortBoxBSDF", "0.015")
         s += cube("TallBox", TALL, "TallBoxBSDF", "-0.015")
-    return s + LIGHT + "</scene>\n"
+    return s + (AREA_LIGHT if area_light else LIGHT) + "</scene>\n"
 
 
 def domino(n_side=32, res=1024, spp=128):
@@ -150,6 +157,7 @@ def main():
     out = {
         "cornell_boxes.xml": cornell(False, 256, 16, "antithetic", "0.5"),
         "cornell_wall.xml": cornell(True, 512, 64, "stratified", "0.0"),
+        "cornell_area.xml": cornell(False, 256, 64, "antithetic", "0.5", area_light=True),
         "domino.xml": domino(),
         "domino_small.xml": domino(n_side=6, res=128, spp=16),
     }

@@ -45,6 +45,8 @@ CONFIGS = [
     ("boxes_trap_depth6_spp6", "cornell_boxes.xml", dict(resx=16, resy=16, wave_function_type="trapezoidal", max_depth=6, path_correlation_depth=2, time_sampling_method="stratified"), 6),
     ("boxes_tcn4", "cornell_boxes.xml", dict(resx=16, resy=16, time_correlate_number=4, time_sampling_method="antithetic"), 8),
     ("domino_small", "domino_small.xml", dict(resx=48, resy=48), 4),
+    ("area_light_doppler", "cornell_area.xml", dict(resx=32, resy=32), 16),
+    ("area_light_depth6_rr", "cornell_area.xml", dict(resx=24, resy=24, max_depth=6, time_sampling_method="stratified", path_correlation_depth=2), 8),
 ]
 
 

@@ -168,7 +168,7 @@ def test_modulation_functions_match_oracle(mi, orc):
             assert np.array_equal(bits(sc.eval_modulation(2, x)), bits(np.array([L.orc_waveform_low_pass(float(v), wt) for v in x], np.float32)))
 
 
-@pytest.mark.parametrize("case", ["spp1", "spp3_box", "crop", "depth1", "depth2", "unbounded_rr", "two_lights", "onesided", "tent_wide", "gaussian_default"])
+@pytest.mark.parametrize("case", ["spp1", "spp3_box", "crop", "depth1", "depth2", "unbounded_rr", "two_lights", "onesided", "tent_wide", "gaussian_default", "area_and_point", "area_path"])
 def test_edge_cases_against_oracle(mi, orc, case):
     base = open(os.path.join(SCENES, "cornell_boxes.xml")).read()
     params, spp, xml = dict(resx=24, resy=24), 8, base
@@ -195,6 +195,13 @@ def test_edge_cases_against_oracle(mi, orc, case):
         assert 'id="BackWallBSDF"><rgb' in xml
     elif case == "gaussian_default":   # no <rfilter>: hdrfilm falls back to gaussian(stddev 0.5), radius 2 -> 5x5 footprint
         xml = base.replace('<rfilter type="tent" />', '')
+    elif case in ("area_and_point", "area_path"):   # area + point emitters: emitter pick, sample re-use, MIS on both strategies
+        base = open(os.path.join(SCENES, "cornell_area.xml")).read()
+        xml = base.replace("</scene>", '<emitter type="point"><point name="position" x="0.3" y="1.2" z="1.5" /><rgb name="intensity" value="2, 3, 4" /></emitter></scene>')
+        if case == "area_path":
+            xml = xml.replace('<integrator type="dopplertofpath">', '<integrator type="path">')
+            for prop in ("w_g", "hetero_frequency", "hetero_offset"):
+                pass
     elif case == "tent_wide":
         xml = base.replace('<rfilter type="tent" />', '<rfilter type="tent"><float name="radius" value="2.0" /></rfilter>')
     sc = mi.load_string(xml, **params)

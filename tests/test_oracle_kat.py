@@ -182,3 +182,43 @@ def test_velocity_and_path_integrators_physical_sanity(orc):
     dop, _ = sc.render(sc.params(integrator=dict(type="dopplertofpath", max_depth=4, w_g=0.0, hetero_frequency=0.0,
                                                  time_sampling_method="uniform")), seed=0, spp=16, threads=os.cpu_count())
     assert abs(4.0 * dop.mean() - rad0.mean()) < 0.05 * rad0.mean()
+
+
+def test_area_light_mis_reproduces_the_analytic_direct_illumination(orc):
+    """Emitter-hit + NEE combined by the power heuristic (dopplertofpath.cpp:150-168,214-226; here through `path`, max_depth 2)
+    against a brute-force quadrature of the rendering equation: L_o = rho/pi * L_e * sum over the light of V cos cos' / r^2 dA,
+    with V from the oracle's own occlusion query.  Wrong pdfs or MIS weights would break the energy balance."""
+    L = orc.lib()
+    xml = open(os.path.join(SCENES, "cornell_area.xml")).read().replace('<rfilter type="tent" />', '<rfilter type="box" />')
+    sc = orc.Scene(xml, dict(resx=64, resy=64), is_string=True)
+    img, _ = sc.render(sc.params(integrator=dict(type="path", max_depth=2)), seed=0, spp=1024, threads=os.cpu_count(), rows=(60, 61))
+    radiance = np.array([17.0, 12.0, 4.0])
+    checked = 0
+    for px in (6, 10, 14):   # lit floor left of the boxes (penumbra pixels would need a much finer quadrature)
+        expect, ok, sub = np.zeros(3), True, 6
+        for sx in range(sub):                      # a pixel of row 60 covers ~0.2 of floor depth: integrate over its footprint
+            for sy in range(sub):
+                out = (C.c_float * 7)()
+                L.orc_camera_ray(C.byref(sc.c.sensor), px + (sx + .5) / sub, 60 + (sy + .5) / sub, out)
+                o, d = np.array(out[0:3], np.float64), np.array(out[3:6], np.float64)
+                hit, ids = (C.c_float * 3)(), (C.c_int32 * 3)()
+                L.orc_intersect(C.byref(sc.c), (C.c_float * 3)(*o), (C.c_float * 3)(*d), 0.0, out[6], hit, ids)
+                if ids[0] != 0:      # object 0 is the floor (reflectance 0.725, 0.71, 0.68, normal +y)
+                    ok = False
+                    continue
+                p = o + d * hit[0]
+                acc, n = 0.0, 20
+                for ix in range(n):
+                    for iz in range(n):
+                        q = np.array([-0.25 + 0.5 * (ix + .5) / n, 1.98, -0.2 + 0.4 * (iz + .5) / n])
+                        w = q - p; r = np.linalg.norm(w); w /= r
+                        so = p + np.array([0, 1e-3, 0])
+                        if not L.orc_occluded(C.byref(sc.c), (C.c_float * 3)(*so), (C.c_float * 3)(*w), 0.0, float(r * 0.999)):
+                            acc += w[1] * w[1] / (r * r)          # cos at the floor = cos at the light = w.y
+                expect += np.array([0.725, 0.71, 0.68]) / np.pi * radiance * acc * (0.5 * 0.4 / (n * n)) / (sub * sub)
+        if not ok:
+            continue
+        got = img[60, px]
+        assert np.all(np.abs(got / expect - 1) < 0.05), (px, got, expect)
+        checked += 1
+    assert checked >= 3
