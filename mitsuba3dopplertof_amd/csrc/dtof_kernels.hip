@@ -450,7 +450,9 @@ DTOF_D uint32_t block_append(bool pred, uint32_t *s_cnt, uint32_t &running) {
 //                 run inline, so neither the shadow queue nor a separate trace launch exists; the state streams
 //                 through HBM once per bounce (this is the default: the split kernels are latency-bound on small
 //                 scenes and the shadow records alone cost 96 B per path-bounce).
-template <bool LDS, bool FUSED>
+// AREA: the scene has area emitters (emitter-hit term, prev_si state).  KMAX: compile-time bound of the batched offsets (1 or 4);
+// both keep the common case -- point lights, one offset -- free of the extra registers.
+template <bool LDS, bool FUSED, bool AREA, int KMAX>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp, Queues q,
                                                   const uint32_t *qin, const uint32_t *count_in,
                                                   uint32_t *qout, uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth,
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
     bool in_range = j < count;
     bool alive = false, want_shadow = false;
     uint32_t l = 0;
-    float4 sha, shb, nra, nrb; float3 cand[kMaxOffsets];
+    float4 sha, shb, nra, nrb; float3 cand[KMAX];
     if (in_range) {
         l = qin ? qin[seg * kSeg + j] : seg * kSeg + j;
         uint32_t hid = q.hit_id[l];
@@ -494,10 +496,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             const float pmf = sv.n_emitters ? 1.f / (float) sv.n_emitters : 0.f;   // m_emitter_pmf (scene.cpp:96)
             // ---- direct emission (dopplertofpath.cpp:150-168 / path.cpp): the hit shape carries an area emitter
             bool res_dirty = false;
-            float4 rcur[kMaxOffsets];
-            if (rp.has_area) {
+            float4 rcur[KMAX];
+            if (AREA) {
 #pragma unroll
-                for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) rcur[k] = q.res[(size_t) k * q.capacity + l];
+                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) rcur[k] = q.res[(size_t) k * q.capacity + l];
                 if (sh->flags & SF_EMITTER) {
                     float4 pb = depth > 0 ? q.st_b[l] : make_float4(0.f, 0.f, 0.f, 1.f);   // prev_si.p, prev_bsdf_pdf
                     V3 rel = si.p - mk(pb.x, pb.y, pb.z);                      // DirectionSample(scene, si, prev_si), records.h:173-180
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                     bool on = si.wi.z > 0.f && pb.w > 0.f;                       // AreaLight::eval (area.cpp:82-89), mask prev_bsdf_pdf > 0
                     V3 le = on ? mk(sh->radiance[0], sh->radiance[1], sh->radiance[2]) : mk(0, 0, 0);
 #pragma unroll
-                    for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) {
+                    for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
                         V3 v = le * mis_bsdf;
                         if (!plain) v = v * modulation_weight(rp, rp.phase[k], time, path_length);
                         rcur[k] = make_float4(fmaf(thr.x, v.x, rcur[k].x), fmaf(thr.y, v.y, rcur[k].y), fmaf(thr.z, v.z, rcur[k].z), 0.f);
@@ -587,8 +589,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 const float mis_em = ds_delta ? 1.f : mis_weight(ds_pdf, bsdf_pdf);   // dopplertofpath.cpp:218-219
                 bool nonzero = false;
 #pragma unroll
-                for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) {
-                    float4 r = rp.has_area ? rcur[k] : q.res[(size_t) k * q.capacity + l];
+                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
+                    float4 r = AREA ? rcur[k] : q.res[(size_t) k * q.capacity + l];
                     V3 v = mk(bsdf_val.x * em_weight.x * mis_em, bsdf_val.y * em_weight.y * mis_em, bsdf_val.z * em_weight.z * mis_em);
                     if (!plain) { float lw = modulation_weight(rp, rp.phase[k], time, path_length + ds_dist); v = v * lw; }
                     float3 c = make_float3(fmaf(thr.x, v.x, r.x), fmaf(thr.y, v.y, r.y), fmaf(thr.z, v.z, r.z));
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             }
             if (res_dirty) {   // the emitter-hit term stands whether or not the NEE candidate is later committed
 #pragma unroll
-                for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) q.res[(size_t) k * q.capacity + l] = rcur[k];
+                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) q.res[(size_t) k * q.capacity + l] = rcur[k];
             }
             // ---- continuation (dopplertofpath.cpp:232-276)
             V3 nd = vfma(si.sh_n, bs_wo.z, vfma(si.sh_t, bs_wo.y, si.sh_s * bs_wo.x));   // Frame::to_world
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 q.ray_a[l] = nra;
                 q.ray_b[l] = nrb;
                 q.st_a[l] = make_float4(thr.x, thr.y, thr.z, path_length);
-                if (rp.has_area) q.st_b[l] = make_float4(si.p.x, si.p.y, si.p.z, bs_pdf);   // prev_si, prev_bsdf_pdf (:256-257)
+                if (AREA) q.st_b[l] = make_float4(si.p.x, si.p.y, si.p.z, bs_pdf);   // prev_si, prev_bsdf_pdf (:256-257)
                 q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
             }
         }
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             Hit hs;
             if (!trace_scene<true>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs)) {
 #pragma unroll
-                for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets)
+                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets)
                     q.res[(size_t) k * q.capacity + l] = make_float4(cand[k].x, cand[k].y, cand[k].z, 0.f);
             }
         }
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
         if (want_shadow) {
             q.sh_a[sslot] = sha; q.sh_b[sslot] = shb;
 #pragma unroll
-            for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets)
+            for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets)
                 q.sh_c[(size_t) k * q.capacity + sslot] = make_float4(cand[k].x, cand[k].y, cand[k].z, u2f(l));
         }
     }
@@ -891,10 +893,13 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
     if (rp.n_lanes == 0) return;
     uint32_t sw = stage_words_for(scene_bytes), grid = nseg(rp.n_lanes), lds = sw * 16 + (fused ? stack_bytes(stack_depth, kShadeBlock) : 0);
     uint32_t tn = trace_next ? 1u : 0u;
-#define DTOF_LAUNCH_SHADE(L, F) hipLaunchKernelGGL((k_shade<L, F>), dim3(grid), dim3(kShadeBlock), lds, s, scene, scene_bytes, sw, rp, q, qin, \
-                                                   count_in, qout, alive_out, shadow_out, depth, tn)
-    if (sw) { if (fused) DTOF_LAUNCH_SHADE(true, true); else DTOF_LAUNCH_SHADE(true, false); }
-    else    { if (fused) DTOF_LAUNCH_SHADE(false, true); else DTOF_LAUNCH_SHADE(false, false); }
+#define DTOF_LAUNCH_SHADE(L, F, A, K) hipLaunchKernelGGL((k_shade<L, F, A, K>), dim3(grid), dim3(kShadeBlock), lds, s, scene, scene_bytes, sw, rp, q, qin, \
+                                                         count_in, qout, alive_out, shadow_out, depth, tn)
+#define DTOF_SHADE_AK(L, F) do { if (rp.has_area) { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE(L, F, true, 1); else DTOF_LAUNCH_SHADE(L, F, true, kMaxOffsets); } \
+                                 else { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE(L, F, false, 1); else DTOF_LAUNCH_SHADE(L, F, false, kMaxOffsets); } } while (0)
+    if (sw) { if (fused) DTOF_SHADE_AK(true, true); else DTOF_SHADE_AK(true, false); }
+    else    { if (fused) DTOF_SHADE_AK(false, true); else DTOF_SHADE_AK(false, false); }
+#undef DTOF_SHADE_AK
 #undef DTOF_LAUNCH_SHADE
 }
 void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
