@@ -63,6 +63,7 @@ struct LaneDebug {       // mirrors orc_lane's comparable fields
 
 // kernels (dtof_kernels.hip)
 void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s);
+void launch_sum_counts(const uint32_t *counts, uint32_t n_seg, uint32_t n_rows, unsigned long long *out, hipStream_t s);
 uint32_t segments_for(uint32_t n_lanes);   // number of queue segments (count slots) for a batch
 void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                   const uint32_t *qin, const uint32_t *count_in, uint32_t stack_depth, hipStream_t s);

@@ -876,6 +876,20 @@ void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s) {
 }
 static inline uint32_t stage_words_for(uint32_t scene_bytes) { return scene_bytes <= kLdsSceneLimit ? (scene_bytes + 15) / 16 : 0; }
 
+// out[row] = sum of counts[row][0..n_seg): the statistics' per-iteration totals (one block per row)
+__global__ void k_sum_counts(const uint32_t *counts, uint32_t n_seg, unsigned long long *out) {
+    __shared__ unsigned long long s_part[4];
+    const uint32_t *row = counts + (size_t) blockIdx.x * n_seg;
+    unsigned long long acc = 0;
+    for (uint32_t i = threadIdx.x; i < n_seg; i += blockDim.x) acc += row[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+void launch_sum_counts(const uint32_t *counts, uint32_t n_seg, uint32_t n_rows, unsigned long long *out, hipStream_t s) {
+    if (n_rows) hipLaunchKernelGGL(k_sum_counts, dim3(n_rows), dim3(256), 0, s, counts, n_seg, out);
+}
 static inline uint32_t nseg(uint32_t n) { return (n + kSeg - 1) / kSeg; }
 uint32_t segments_for(uint32_t n_lanes) { return nseg(n_lanes); }
 

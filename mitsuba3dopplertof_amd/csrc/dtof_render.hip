@@ -84,9 +84,30 @@ struct dtof_scene {
     DevBuf<uint8_t> d_blob; bool uploaded = false;
     Workspace ws, ws2;                       // one per in-flight batch
     DevBuf<float> d_film, d_rgb;
+    DevBuf<unsigned long long> d_sums;       // [batch][2*kMaxIter] per-iteration totals (survivors, shadow rays)
     hipStream_t stream = nullptr, stream2 = nullptr;
     std::atomic<bool> stop { false };
-    ~dtof_scene() { if (stream) (void) hipStreamDestroy(stream); if (stream2) (void) hipStreamDestroy(stream2); }
+    // reusable statistics plumbing (creating events / pinned memory per call costs ~0.3 ms)
+    std::vector<hipEvent_t> event_pool; size_t events_used = 0;
+    uint32_t *pinned_counts = nullptr; size_t pinned_words = 0;
+    hipEvent_t take_event() {
+        if (events_used == event_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) throw std::runtime_error("hipEventCreate failed"); event_pool.push_back(e); }
+        return event_pool[events_used++];
+    }
+    uint32_t *pinned(size_t words) {
+        if (words > pinned_words) {
+            if (pinned_counts) (void) hipHostFree(pinned_counts);
+            pinned_counts = nullptr; pinned_words = 0;
+            if (hipHostMalloc((void **) &pinned_counts, words * 4, hipHostMallocDefault) != hipSuccess) throw std::runtime_error("hipHostMalloc failed");
+            pinned_words = words;
+        }
+        return pinned_counts;
+    }
+    ~dtof_scene() {
+        if (stream) (void) hipStreamDestroy(stream); if (stream2) (void) hipStreamDestroy(stream2);
+        for (auto e : event_pool) (void) hipEventDestroy(e);
+        if (pinned_counts) (void) hipHostFree(pinned_counts);
+    }
 };
 
 struct dtof_sampler {
@@ -185,11 +206,11 @@ RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, cons
 }
 
 struct StageTimer {
-    bool on; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
-    explicit StageTimer(bool enabled) : on(enabled) {}
+    bool on; dtof_scene *sc; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
+    StageTimer(bool enabled, dtof_scene *scene) : on(enabled), sc(scene) { sc->events_used = 0; }
     int begin(int stage, hipStream_t s) {
         if (!on) return -1;
-        hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+        hipEvent_t a = sc->take_event(), b = sc->take_event();
         ev[stage].emplace_back(a, b); HIP_CHECK(hipEventRecord(a, s));
         return (int) ev[stage].size() - 1;
     }
@@ -199,7 +220,6 @@ struct StageTimer {
         for (auto &p : ev[stage]) { float t = 0; HIP_CHECK(hipEventElapsedTime(&t, p.first, p.second)); ms += t; }
         return ms;
     }
-    ~StageTimer() { for (auto &v : ev) for (auto &p : v) { (void) hipEventDestroy(p.first); (void) hipEventDestroy(p.second); } }
 };
 
 // The wavefront loop over pixel rows [row_begin,row_end); accumulates into d_film (K films).
@@ -249,13 +269,12 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     bool has_surface_emitters = false;          // area emitters make the emitter-hit term (and the last iteration) live
     for (auto &e : sc->host.emitters) has_surface_emitters |= e.kind == EMITTER_AREA;
     rp.has_area = has_surface_emitters;
-    StageTimer tm(stats != nullptr);
+    StageTimer tm(stats != nullptr, sc);
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-    if (stats) { memset(stats, 0, sizeof *stats); HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); HIP_CHECK(hipEventRecord(ev0, ss[0])); }
+    if (stats) { memset(stats, 0, sizeof *stats); ev0 = sc->take_event(); ev1 = sc->take_event(); HIP_CHECK(hipEventRecord(ev0, ss[0])); }
     if (n_streams == 2) { HIP_CHECK(hipEventRecord(ev_fork, ss[0])); HIP_CHECK(hipStreamWaitEvent(ss[1], ev_fork, 0)); }
-    struct Pinned { uint32_t *p; uint32_t iters, n_seg; };
-    std::vector<Pinned> pinned; std::vector<uint64_t> h_counts; std::vector<uint32_t> batch_lanes, batch_iters;
+    std::vector<uint64_t> h_counts; std::vector<uint32_t> batch_lanes, batch_iters;
 
     uint32_t batch_index = 0;
     for (uint64_t b0 = first; b0 < last; b0 += batch, ++batch_index) {
@@ -297,17 +316,11 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         } else {
             t = tm.begin(4, s); launch_splat(rp, q, d_film, se.crop_w, se.crop_h, s); tm.end(4, t, s);
         }
-        if (stats) {   // per-iteration per-segment counts of this batch -> pinned host staging (summed after the final sync)
-            size_t words = (size_t) 2 * it * n_seg;
-            if (words) {
-                uint32_t *dst = nullptr;
-                HIP_CHECK(hipHostMalloc((void **) &dst, words * 4, hipHostMallocDefault));
-                HIP_CHECK(hipMemcpyAsync(dst, q.counts, words * 4, hipMemcpyDeviceToHost, s));
-                pinned.push_back({ dst, it, n_seg });
-            } else pinned.push_back({ nullptr, 0, n_seg });
+        if (stats) {   // per-iteration totals of this batch are reduced on the device; one small copy after the last batch
+            sc->d_sums.ensure((size_t) (batch_index + 1) * 2 * kMaxIter);
+            if (it) launch_sum_counts(q.counts, n_seg, 2 * it, sc->d_sums.p + (size_t) batch_index * 2 * kMaxIter, s);
             batch_lanes.push_back(rp.n_lanes); batch_iters.push_back(it);
             stats->n_batches++;
-            // the next batch reuses q.counts: order its first shade after this copy (same stream => already ordered)
         }
     }
     if (n_streams == 2) { HIP_CHECK(hipEventRecord(ev_join, ss[1])); HIP_CHECK(hipStreamWaitEvent(ss[0], ev_join, 0)); }
@@ -315,11 +328,10 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     if (stats) {
         HIP_CHECK(hipEventRecord(ev1, s)); HIP_CHECK(hipEventSynchronize(ev1));
         float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); stats->ms_total = ms;
-        (void) hipEventDestroy(ev0); (void) hipEventDestroy(ev1);
-        for (auto &pb : pinned) {
-            for (uint32_t i = 0; i < 2 * pb.iters; ++i) { uint64_t sum = 0; for (uint32_t g = 0; g < pb.n_seg; ++g) sum += pb.p[(size_t) i * pb.n_seg + g]; h_counts.push_back(sum); }
-            if (pb.p) (void) hipHostFree(pb.p);
-        }
+        std::vector<unsigned long long> sums(batch_lanes.size() * 2 * (size_t) kMaxIter);
+        if (!sums.empty()) HIP_CHECK(hipMemcpy(sums.data(), sc->d_sums.p, sums.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < batch_lanes.size(); ++b)
+            for (uint32_t i = 0; i < 2 * batch_iters[b]; ++i) h_counts.push_back(sums[b * 2 * kMaxIter + i]);
         stats->ms_generate = tm.total(0); stats->ms_trace = tm.total(1); stats->ms_shade = tm.total(2);
         stats->ms_shadow = tm.total(3); stats->ms_splat = tm.total(4);
         size_t off = 0;
