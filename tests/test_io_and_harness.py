@@ -97,3 +97,18 @@ def test_cli_and_harness_on_the_gpu(mi, tmp_path):
     v = harness.calc_velocity_from_homo_hetero(homo, hetero)
     centre = v[12:20, 12:20]
     assert abs(np.median(centre) + 10.0) < 2.5, np.median(centre)
+
+
+@pytest.mark.gpu
+def test_native_cli_writes_the_same_image(mi, tmp_path):
+    """mitsuba3dopplertof_amd/dtof-render (C++ over the C ABI) == the Python binding, byte for byte up to film atomics."""
+    exe = os.path.join(ROOT, "mitsuba3dopplertof_amd", "dtof-render")
+    out = str(tmp_path / "o.npy")
+    r = subprocess.run([exe, os.path.join(SCENES, "cornell_wall.xml"), "-D", "resx=40", "-D", "resy=24", "--spp", "8", "--seed", "5", "-o", out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    img = np.load(out)
+    ref = mi.load_file(os.path.join(SCENES, "cornell_wall.xml"), resx=40, resy=24).render(seed=5, spp=8)
+    assert img.shape == (24, 40, 3) and np.abs(img - ref).max() <= 1e-5 * np.abs(ref).max()
+    bad = subprocess.run([exe, os.path.join(SCENES, "cornell_wall.xml"), "-D", "wave_function_type=sawtooth"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "unknown wave_function_type" in bad.stderr
