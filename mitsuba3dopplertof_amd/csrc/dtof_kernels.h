@@ -46,7 +46,7 @@ struct Queues {
     float4 *st_a;        // throughput.xyz, path_length
     float4 *st_b;        // prev_si.p, prev_bsdf_pdf (only touched when the scene has area emitters)
     uint4  *rng_a;       // rng.state (lo,hi), rng_path.state (lo,hi)
-    uint2  *rng_b;       // rng_time.state
+    uint2  *rng_b;       // (main, path) stream selectors v1 of the TEA seeding: inc = (v1 << 1) | 1, constant per lane
     float4 *res;         // [K][capacity] accumulated result rgb (w unused)
     float2 *pos;         // sample position on the film
     float4 *sh_a;        // shadow ray o.xyz, maxt

@@ -305,6 +305,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) 
     q.ray_b[i] = make_float4(dw.x, dw.y, dw.z, maxt);
     q.st_a[i] = make_float4(1.f, 1.f, 1.f, 0.f);
     q.rng_a[i] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
+    q.rng_b[i] = make_uint2((uint32_t) (main.inc >> 1), (uint32_t) (path.inc >> 1));
     q.pos[i] = make_float2(spx, spy);
     for (int k = 0; k < rp.n_offsets; ++k) q.res[(size_t) k * q.capacity + i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -476,13 +477,12 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
         l = qin ? qin[seg * kSeg + j] : seg * kSeg + j;
         uint32_t hid = q.hit_id[l];
         if (hid != 0xffffffffu) {   // a miss ends the path (active_next = false, dopplertofpath.cpp:171)
-            uint32_t lane = rp.lane_base + l;
-            float4 ra = q.ray_a[l], rb = q.ray_b[l]; uint4 hh = q.hit[l]; float4 st = q.st_a[l]; uint4 rs = q.rng_a[l];
+            float4 ra = q.ray_a[l], rb = q.ray_b[l]; uint4 hh = q.hit[l]; float4 st = q.st_a[l]; uint4 rs = q.rng_a[l]; uint2 ri = q.rng_b[l];
             V3 o = mk(ra.x, ra.y, ra.z), d = mk(rb.x, rb.y, rb.z); float time = ra.w;
             V3 thr = mk(st.x, st.y, st.z); float path_length = st.w;
             Rng main, path;
-            main.state = (uint64_t) rs.x | ((uint64_t) rs.y << 32); main.inc = stream_inc(rp.seed_value, lane);
-            path.state = (uint64_t) rs.z | ((uint64_t) rs.w << 32); path.inc = stream_inc(rp.seed_value + 2, lane / rp.pcn);
+            main.state = (uint64_t) rs.x | ((uint64_t) rs.y << 32); main.inc = ((uint64_t) ri.x << 1) | 1u;
+            path.state = (uint64_t) rs.z | ((uint64_t) rs.w << 32); path.inc = ((uint64_t) ri.y << 1) | 1u;
             bool correlate = (depth + 1) < rp.path_correlation_depth;
             const bool plain = rp.integrator != 0;   // `path`: sampler->next_1d/2d, main stream only (path.cpp:197,213-214,273)
             float t = u2f(hh.x);
