@@ -71,6 +71,8 @@ int dtof_scene_get_info(const dtof_scene *scene, dtof_scene_info *info);
  * kind 1: shape transforms  -> per shape 32 floats (to_world[16], to_object[16])
  * kind 2: sensor            -> to_world[16], x_fov, near, far, shutter_open, shutter_close
  * kind 3: emitters          -> per emitter position[3], intensity[3]
+ * kind 4..7: baked mesh data -> positions / vertex normals / texcoords / faces (uint32 bit patterns) of all mesh
+ *                             shapes (cube, obj, ply) concatenated in shape order (cube.cpp:114-160, obj.cpp, ply.cpp)
  * Returns the number of floats written (<= capacity) through *n_written. */
 int dtof_scene_export(const dtof_scene *scene, int kind, float *out, size_t capacity, size_t *n_written);
 

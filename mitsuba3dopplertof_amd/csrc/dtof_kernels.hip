@@ -102,9 +102,11 @@ DTOF_D float box_entry(const float *bmin, const float *bmax, V3 o, V3 id, float 
 
 // Closest hit (ANY=false) or occlusion (ANY=true) of one top-level object.  Candidates are every
 // primitive hit with t <= maxt; the winner is the smallest t, ties going to the lowest
-// (object, shape, primitive) -- the rule the oracle uses, independent of traversal order.
-template <bool ANY>
-DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float time, float maxt, Hit &best) {
+// (object, shape, face) -- the rule the oracle uses, independent of traversal order.
+// `stack + sp * stride` onwards is free for the BLAS traversal of a mesh.
+template <bool ANY, bool MESH>
+DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float time, float maxt, Hit &best,
+                             uint32_t *stack, int sp, uint32_t stride) {
     const DObject &ob = sv.objects[oi];
     uint32_t first = ob.index, count = 1;
     V3 lo = o, ld = d;
@@ -127,26 +129,59 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
                     best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = 0; found = true;
                 }
             }
-        } else {
-            // cull the triangle loop with the mesh's own (padded) bounds: TLAS boxes of moving instances are the
-            // union over the whole motion and let many rays through that miss the mesh at their time
-            V3 lid = mk(__builtin_amdgcn_rcpf(ld.x == 0.f ? 1e-30f : ld.x), __builtin_amdgcn_rcpf(ld.y == 0.f ? 1e-30f : ld.y), __builtin_amdgcn_rcpf(ld.z == 0.f ? 1e-30f : ld.z));
-            if (!(box_entry(sh.bmin, sh.bmax, lo, lid, ANY ? maxt : best.t) < INFINITY)) continue;
-            for (uint32_t f = 0; f < sh.n_tris; ++f) {
-                if (tri_hit(sv.tris[sh.first_tri + f], lo, ld, maxt, t, u, v)) {
-                    if (ANY) return true;
-                    if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
-                        best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = f; found = true;
-                    }
-                }
+            continue;
+        }
+        if (!MESH) continue;   // instantiations for scenes without a single triangle carry no mesh code at all
+        // cull with the mesh's own (padded) bounds: TLAS boxes of moving instances are the union over the whole
+        // motion and let many rays through that miss the mesh at their time
+        V3 lid = mk(__builtin_amdgcn_rcpf(ld.x == 0.f ? 1e-30f : ld.x), __builtin_amdgcn_rcpf(ld.y == 0.f ? 1e-30f : ld.y), __builtin_amdgcn_rcpf(ld.z == 0.f ? 1e-30f : ld.z));
+        if (!(box_entry(sh.bmin, sh.bmax, lo, lid, ANY ? maxt : best.t) < INFINITY)) continue;
+        // `face` of the best hit so far IF it lies on this very mesh (ties between two of its triangles go to the lower face)
+        uint32_t best_face = 0xffffffffu;
+        auto test = [&](uint32_t f) -> bool {
+            const DTri &tr = sv.tris[sh.first_tri + f];
+            if (!tri_hit(tr, lo, ld, maxt, t, u, v)) return false;
+            if (ANY) return true;
+            bool take = t < best.t;
+            if (t == best.t) take = best_face != 0xffffffffu ? tr.face < best_face : (!found && best.obj != 0xffffffffu && oi < best.obj);
+            if (take) { best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = f; best_face = tr.face; found = true; }
+            return false;
+        };
+        if (sh.blas_root == kNoChild) {
+            for (uint32_t f = 0; f < sh.n_tris; ++f) if (test(f)) return true;
+            continue;
+        }
+        // BLAS: same node format and while-while shape as the TLAS loop below
+        constexpr uint32_t kDone = 0x7fffffffu;
+        uint32_t cur = sh.blas_root; int bsp = sp;
+        for (;;) {
+            while (!(cur & kLeafFlag) && cur != kDone) {
+                const BvhNode &n = sv.nodes[cur];
+                const float lim = ANY ? maxt : best.t;
+                float tl = box_entry(n.lmin, n.lmax, lo, lid, lim);
+                float tr = n.right != kNoChild ? box_entry(n.rmin, n.rmax, lo, lid, lim) : INFINITY;
+                bool hl = tl < INFINITY, hr = tr < INFINITY;
+                if (hl && hr) {
+                    uint32_t nearc = tl <= tr ? n.left : n.right, farc = tl <= tr ? n.right : n.left;
+                    stack[bsp * stride] = farc; ++bsp;
+                    cur = nearc;
+                } else if (hl) cur = n.left;
+                else if (hr) cur = n.right;
+                else if (bsp == sp) cur = kDone;
+                else { --bsp; cur = stack[bsp * stride]; }
             }
+            if (cur == kDone) break;
+            uint32_t f0 = (cur & ~kLeafFlag) >> kBlasLeafBits, fn = (cur & ((1u << kBlasLeafBits) - 1u)) + 1u;
+            for (uint32_t f = f0; f < f0 + fn; ++f) if (test(f)) return true;
+            if (bsp == sp) break;
+            --bsp; cur = stack[bsp * stride];
         }
     }
     return found;
 }
 
 // TLAS traversal; `stack` is a per-thread LDS column (stride blockDim.x).
-template <bool ANY>
+template <bool ANY, bool MESH>
 DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best) {
     best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
     if (sv.n_nodes == 0) return false;
@@ -176,7 +211,7 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
             else { --sp; cur = stack[sp * stride]; }
         }
         if (cur == kDone) break;
-        if (intersect_object<ANY>(sv, cur & ~kLeafFlag, o, d, time, maxt, best) && ANY) return true;
+        if (intersect_object<ANY, MESH>(sv, cur & ~kLeafFlag, o, d, time, maxt, best, stack, sp, stride) && ANY) return true;
         if (sp == 0) break;
         --sp; cur = stack[sp * stride];
     }
@@ -322,7 +357,7 @@ DTOF_D uint32_t seg_count(const uint32_t *counts, uint32_t seg, uint32_t n_lanes
     return counts ? counts[seg] : min(kSeg, n_lanes - seg * kSeg);
 }
 
-template <bool LDS>
+template <bool LDS, bool MESH>
 __global__ __launch_bounds__(kBlock) void k_trace(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words,
                                                   Queues q, const uint32_t *qin, const uint32_t *count_in, uint32_t n_lanes) {
     extern __shared__ uint4 lds[];
@@ -337,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const uint8_t *scene, uint32_t
     uint32_t l = qin ? qin[seg * kSeg + j] : seg * kSeg + j;
     float4 a = q.ray_a[l], b = q.ray_b[l];
     Hit h;
-    bool found = trace_scene<false>(sv, stack, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h);
+    bool found = trace_scene<false, MESH>(sv, stack, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h);
     q.hit[l] = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
     q.hit_id[l] = found ? (h.obj | (h.shape << 24)) : 0xffffffffu;
 }
@@ -347,6 +382,7 @@ struct Surface { V3 p, n, sh_n, sh_s, sh_t, wi; const DShape *shape; };
 
 // Shape::compute_surface_interaction for rectangle (rectangle.cpp:250-323) / mesh (mesh.cpp:632-864),
 // Instance::compute_surface_interaction (instance.cpp:155-250), finalize (interaction.h:493-513)
+template <bool MESH>
 DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, uint32_t prim, float t, float b1, float b2,
                             V3 o, V3 d, float time, Surface &si) {
     const DObject &ob = sv.objects[oi];
@@ -362,7 +398,7 @@ DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, 
     } else sh = &sv.shapes[ob.index];
     si.shape = sh;
     V3 dp_du, dp_dv;
-    if (sh->kind == SHAPE_RECT) {
+    if (!MESH || sh->kind == SHAPE_RECT) {
         V3 n = mk(sh->n[0], sh->n[1], sh->n[2]);
         V3 p = vfma(ld, t, lo);
         V3 tr = mk(sh->to_world[3], sh->to_world[7], sh->to_world[11]);
@@ -453,7 +489,7 @@ DTOF_D uint32_t block_append(bool pred, uint32_t *s_cnt, uint32_t &running) {
 //                 scenes and the shadow records alone cost 96 B per path-bounce).
 // AREA: the scene has area emitters (emitter-hit term, prev_si state).  KMAX: compile-time bound of the batched offsets (1 or 4);
 // both keep the common case -- point lights, one offset -- free of the extra registers.
-template <bool LDS, bool FUSED, bool AREA, int KMAX>
+template <bool LDS, bool FUSED, bool AREA, int KMAX, bool MESH>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp, Queues q,
                                                   const uint32_t *qin, const uint32_t *count_in,
                                                   uint32_t *qout, uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth,
@@ -490,7 +526,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             bool active_next = depth + 1 < rp.max_depth;
 
             Surface si;
-            compute_surface(sv, hid & 0xffffffu, hid >> 24, hh.w, t, u2f(hh.y), u2f(hh.z), o, d, time, si);
+            compute_surface<MESH>(sv, hid & 0xffffffu, hid >> 24, hh.w, t, u2f(hh.y), u2f(hh.z), o, d, time, si);
             const DShape *sh = si.shape;
 
             const float pmf = sv.n_emitters ? 1.f / (float) sv.n_emitters : 0.f;   // m_emitter_pmf (scene.cpp:96)
@@ -630,7 +666,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
     if (FUSED) {
         if (want_shadow) {   // test_visibility (scene.cpp:266-271): an unoccluded sample commits its candidate result
             Hit hs;
-            if (!trace_scene<true>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs)) {
+            if (!trace_scene<true, MESH>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs)) {
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets)
                     q.res[(size_t) k * q.capacity + l] = make_float4(cand[k].x, cand[k].y, cand[k].z, 0.f);
@@ -638,7 +674,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
         }
         if (alive && trace_next) {   // closest hit of the continuation ray, consumed by the next bounce
             Hit h;
-            bool found = trace_scene<false>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
+            bool found = trace_scene<false, MESH>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
             q.hit[l] = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
             q.hit_id[l] = found ? (h.obj | (h.shape << 24)) : 0xffffffffu;
         }
@@ -664,7 +700,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
 }
 
 // ---------------------------------------------------------------------------- shadow
-template <bool LDS>
+template <bool LDS, bool MESH>
 __global__ __launch_bounds__(kBlock) void k_shadow(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp,
                                                    Queues q, const uint32_t *count_in) {
     extern __shared__ uint4 lds[];
@@ -679,7 +715,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow(const uint8_t *scene, uint32_
     uint32_t i = seg * kSeg + j;
     float4 a = q.sh_a[i], b = q.sh_b[i];
     Hit h;
-    bool occluded = trace_scene<true>(sv, stack, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h);
+    bool occluded = trace_scene<true, MESH>(sv, stack, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h);
     if (!occluded) {
 #pragma unroll
         for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) {
@@ -704,8 +740,8 @@ __global__ __launch_bounds__(kBlock) void k_velocity(const uint8_t *scene, uint3
     float4 a = q.ray_a[i], b = q.ray_b[i];
     V3 o = mk(a.x, a.y, a.z), d = mk(b.x, b.y, b.z);
     Hit h1, h2;
-    bool v1 = trace_scene<false>(sv, stack, o, d, 0.f, b.w, h1);
-    bool v2 = trace_scene<false>(sv, stack, o, d, rp.T, b.w, h2);
+    bool v1 = trace_scene<false, true>(sv, stack, o, d, 0.f, b.w, h1);
+    bool v2 = trace_scene<false, true>(sv, stack, o, d, rp.T, b.w, h2);
     float vel = ((v2 ? h2.t : 0.f) - (v1 ? h1.t : 0.f)) * (1.0f / rp.T);
     vel = (v1 && v2) ? vel : 0.f;
     q.res[i] = make_float4(vel, vel, vel, 0.f);
@@ -876,19 +912,22 @@ void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s) {
 }
 static inline uint32_t stage_words_for(uint32_t scene_bytes) { return scene_bytes <= kLdsSceneLimit ? (scene_bytes + 15) / 16 : 0; }
 
-// out[row] = sum of counts[row][0..n_seg): the statistics' per-iteration totals (one block per row)
+// out[row] = sum of counts[row][0..n_seg): the statistics' per-iteration totals (kSumSlices blocks per row, one atomic each)
+constexpr uint32_t kSumSlices = 32;
 __global__ void k_sum_counts(const uint32_t *counts, uint32_t n_seg, unsigned long long *out) {
     __shared__ unsigned long long s_part[4];
     const uint32_t *row = counts + (size_t) blockIdx.x * n_seg;
     unsigned long long acc = 0;
-    for (uint32_t i = threadIdx.x; i < n_seg; i += blockDim.x) acc += row[i];
+    for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < n_seg; i += blockDim.x * kSumSlices) acc += row[i];
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (threadIdx.x == 0) atomicAdd(&out[blockIdx.x], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 void launch_sum_counts(const uint32_t *counts, uint32_t n_seg, uint32_t n_rows, unsigned long long *out, hipStream_t s) {
-    if (n_rows) hipLaunchKernelGGL(k_sum_counts, dim3(n_rows), dim3(256), 0, s, counts, n_seg, out);
+    if (!n_rows) return;
+    (void) hipMemsetAsync(out, 0, (size_t) n_rows * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(k_sum_counts, dim3(n_rows, kSumSlices), dim3(256), 0, s, counts, n_seg, out);
 }
 static inline uint32_t nseg(uint32_t n) { return (n + kSeg - 1) / kSeg; }
 uint32_t segments_for(uint32_t n_lanes) { return nseg(n_lanes); }
@@ -897,8 +936,10 @@ void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
                   const uint32_t *qin, const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
     uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + stack_bytes(stack_depth), grid = nseg(rp.n_lanes) * kSub;
-    if (sw) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, q, qin, count_in, rp.n_lanes);
-    else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, q, qin, count_in, rp.n_lanes);
+#define DTOF_LAUNCH_TRACE(L, M) hipLaunchKernelGGL((k_trace<L, M>), dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, q, qin, count_in, rp.n_lanes)
+    if (sw) { if (rp.has_tris) DTOF_LAUNCH_TRACE(true, true); else DTOF_LAUNCH_TRACE(true, false); }
+    else    { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true); else DTOF_LAUNCH_TRACE(false, false); }
+#undef DTOF_LAUNCH_TRACE
 }
 void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                   const uint32_t *qin, const uint32_t *count_in, uint32_t *qout,
@@ -907,7 +948,8 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
     if (rp.n_lanes == 0) return;
     uint32_t sw = stage_words_for(scene_bytes), grid = nseg(rp.n_lanes), lds = sw * 16 + (fused ? stack_bytes(stack_depth, kShadeBlock) : 0);
     uint32_t tn = trace_next ? 1u : 0u;
-#define DTOF_LAUNCH_SHADE(L, F, A, K) hipLaunchKernelGGL((k_shade<L, F, A, K>), dim3(grid), dim3(kShadeBlock), lds, s, scene, scene_bytes, sw, rp, q, qin, \
+#define DTOF_LAUNCH_SHADE(L, F, A, K) do { if (rp.has_tris) DTOF_LAUNCH_SHADE_M(L, F, A, K, true); else DTOF_LAUNCH_SHADE_M(L, F, A, K, false); } while (0)
+#define DTOF_LAUNCH_SHADE_M(L, F, A, K, M) hipLaunchKernelGGL((k_shade<L, F, A, K, M>), dim3(grid), dim3(kShadeBlock), lds, s, scene, scene_bytes, sw, rp, q, qin, \
                                                          count_in, qout, alive_out, shadow_out, depth, tn)
 #define DTOF_SHADE_AK(L, F) do { if (rp.has_area) { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE(L, F, true, 1); else DTOF_LAUNCH_SHADE(L, F, true, kMaxOffsets); } \
                                  else { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE(L, F, false, 1); else DTOF_LAUNCH_SHADE(L, F, false, kMaxOffsets); } } while (0)
@@ -915,13 +957,16 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
     else    { if (fused) DTOF_SHADE_AK(false, true); else DTOF_SHADE_AK(false, false); }
 #undef DTOF_SHADE_AK
 #undef DTOF_LAUNCH_SHADE
+#undef DTOF_LAUNCH_SHADE_M
 }
 void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                    const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
     uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + stack_bytes(stack_depth), grid = nseg(rp.n_lanes) * kSub;
-    if (sw) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in);
-    else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in);
+#define DTOF_LAUNCH_SHADOW(L, M) hipLaunchKernelGGL((k_shadow<L, M>), dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in)
+    if (sw) { if (rp.has_tris) DTOF_LAUNCH_SHADOW(true, true); else DTOF_LAUNCH_SHADOW(true, false); }
+    else    { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true); else DTOF_LAUNCH_SHADOW(false, false); }
+#undef DTOF_LAUNCH_SHADOW
 }
 void launch_velocity(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;

@@ -270,6 +270,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     bool has_surface_emitters = false;          // area emitters make the emitter-hit term (and the last iteration) live
     for (auto &e : sc->host.emitters) has_surface_emitters |= e.kind == EMITTER_AREA;
     rp.has_area = has_surface_emitters;
+    rp.has_tris = bh->n_tris != 0;
     StageTimer tm(stats != nullptr, sc);
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
@@ -402,7 +403,9 @@ int dtof_scene_load_string(const char *xml, const char *const *pn, const char *c
 int dtof_scene_load_file(const char *path, const char *const *pn, const char *const *pv, int n, dtof_scene **out) {
     return guarded([&] {
         if (!path || !out) throw std::runtime_error("null argument");
-        *out = finish_scene(load_scene_xml(read_file(path), to_map(pn, pv, n)));
+        std::string p = path, dir = ".";
+        size_t k = p.find_last_of('/'); if (k != std::string::npos) dir = k ? p.substr(0, k) : "/";
+        *out = finish_scene(load_scene_xml(read_file(path), to_map(pn, pv, n), dir));
     });
 }
 void dtof_scene_destroy(dtof_scene *scene) { delete scene; }
@@ -458,6 +461,12 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
             v.push_back(s.x_fov); v.push_back(s.near_clip); v.push_back(s.far_clip); v.push_back(s.shutter_open); v.push_back(s.shutter_close);
         } else if (kind == 3) for (auto &e : sc->host.emitters) {
             v.insert(v.end(), e.pos, e.pos + 3); v.insert(v.end(), e.intensity, e.intensity + 3);
+        } else if (kind >= 4 && kind <= 7) for (auto &s : sc->host.shapes) {
+            if (s.kind != SHAPE_MESH) continue;
+            if (kind == 4) v.insert(v.end(), s.positions.begin(), s.positions.end());
+            else if (kind == 5) v.insert(v.end(), s.normals.begin(), s.normals.end());
+            else if (kind == 6) v.insert(v.end(), s.texcoords.begin(), s.texcoords.end());
+            else for (uint32_t f : s.faces) { float b; memcpy(&b, &f, 4); v.push_back(b); }
         } else throw std::runtime_error("unknown export kind");
         *n_written = v.size();
         if (out) { if (v.size() > cap) throw std::runtime_error("export buffer too small"); memcpy(out, v.data(), v.size() * 4); }

@@ -25,12 +25,15 @@ enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1 };
 struct BlobHeader {
     uint32_t n_nodes, n_objects, n_groups, n_shapes, n_tris, n_emitters;
     uint32_t off_nodes, off_objects, off_groups, off_shapes, off_tris, off_shading, off_emitters;
-    uint32_t total_bytes, has_instances, tlas_depth;   // tlas_depth: deepest leaf (stack entries a traversal can need)
+    uint32_t total_bytes, has_instances, tlas_depth;   // tlas_depth: stack entries a traversal can need (TLAS depth + deepest BLAS)
 };
 static_assert(sizeof(BlobHeader) == 64, "BlobHeader");
 
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kNoChild = 0xffffffffu;
+// BLAS (per triangle mesh, nodes appended to the same array): a leaf is kLeafFlag | (first triangle, relative to the mesh's
+// first_tri) << kBlasLeafBits | (count - 1); meshes of at most kBlasMinTris triangles are looped over instead.
+constexpr uint32_t kBlasLeafBits = 2, kBlasLeaf = 4, kBlasMinTris = 16;
 // TLAS node (64 B): the bounds of BOTH children live in the parent, so one fetch decides both
 // descents.  child = kLeafFlag | object index for a leaf, inner-node index otherwise, kNoChild if absent.
 struct BvhNode {
@@ -47,13 +50,13 @@ struct DObject {            // 128 B
 struct DGroup { uint32_t first_shape, n_shapes, pad[2]; };
 struct DShape {             // 224 B
     uint32_t kind, flags, first_tri, n_tris;
-    float refl[3], pad0;
+    float refl[3]; uint32_t blas_root;                   // mesh: root node of its BLAS, kNoChild = loop over the triangles
     float to_world[12], to_object[12];
     float n[3], pad1, dp_du[3], pad2, dp_dv[3], pad3;   // rectangle frame (Rectangle::update, rectangle.cpp:101-113)
     float bmin[3], pad4, bmax[3], pad5;                 // padded bounds of the shape in ITS space (mesh: culls the triangle loop)
     float radiance[3], inv_area;                        // SF_EMITTER: AreaLight radiance, Rectangle::m_inv_surface_area
 };
-struct DTri { float p0[4], p1[4], p2[4]; };                              // 48 B
+struct DTri { float p0[3]; uint32_t face; float p1[4], p2[4]; };         // 48 B; face = index in the mesh's own order (tie rule)
 struct DTriShade { float n0[3], n1[3], n2[3], uv0[2], uv1[2], uv2[2], pad; };   // 64 B
 struct DEmitter { uint32_t kind; float pos[3]; float intensity[3]; uint32_t shape; };   // area: intensity = radiance, shape = index into shapes[]
 static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 224 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64, "blob records");
@@ -66,7 +69,7 @@ struct HostShape {
     bool twosided = false, flip_normals = false, face_normals = false;
     float refl[3] = { .5f, .5f, .5f };
     float to_world[16], to_object[16];     // float casts of the double transform and its double inverse
-    // mesh (cube): baked like src/shapes/cube.cpp:114-160
+    // mesh: cube baked like src/shapes/cube.cpp:114-160; obj / ply through mesh_io.cpp
     std::vector<float> positions, normals, texcoords;
     std::vector<uint32_t> faces;
     std::string id;
@@ -126,9 +129,19 @@ struct HostScene {
     PropBag integrator, sampler;
 };
 
-// XML front end (scene_loader.cpp): the tag subset of SURVEY §8a row X1.
-HostScene load_scene_xml(const std::string &text, const std::map<std::string, std::string> &params);
+// XML front end (scene_loader.cpp): the tag subset of SURVEY §8a row X1.  `base_dir` is what the reference's FileResolver
+// holds for a scene file (its directory): relative `filename` properties of obj / ply shapes resolve against it.
+HostScene load_scene_xml(const std::string &text, const std::map<std::string, std::string> &params, const std::string &base_dir = "");
 std::string read_file(const std::string &path);
+
+// Mesh files (mesh_io.cpp): raw object-space arrays of an .obj / .ply file, and the constructor-time baking
+struct RawMesh {
+    std::vector<float> positions, normals, texcoords; std::vector<uint32_t> faces;
+    bool has_normals = false, has_texcoords = false;
+};
+RawMesh load_obj(const std::string &path, bool flip_tex_coords, bool face_normals);   // src/shapes/obj.cpp
+RawMesh load_ply(const std::string &path, bool face_normals);                         // src/shapes/ply.cpp
+void bake_mesh(HostShape &s, const RawMesh &raw);   // to_world / normals / Mesh::recompute_vertex_normals
 
 // Blob + BVH (scene_build.cpp)
 std::vector<uint8_t> build_scene_blob(const HostScene &scene);

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstring>
 #include <cfloat>
+#include <cstdlib>
 #include <numeric>
 
 namespace dtof {
@@ -45,15 +46,23 @@ static Box shape_box(const HostShape &s) {
 
 struct BuildItem { Box box; float c[3]; uint32_t obj; };
 
-static uint32_t build_node(std::vector<BvhNode> &nodes, std::vector<BuildItem> &items, size_t b, size_t e);
+// One builder for both levels.  TLAS (max_leaf = 1): a leaf is kLeafFlag | object index.  BLAS (max_leaf = kBlasLeaf): the
+// items (triangles) end up permuted so that every leaf is a contiguous range, a leaf is
+// kLeafFlag | (first position in the mesh << kBlasLeafBits) | (count - 1).
+struct BuildCtx { std::vector<BvhNode> &nodes; std::vector<BuildItem> &items; uint32_t max_leaf; uint32_t depth = 0, deepest = 0; };
 
-static uint32_t child_ref(std::vector<BvhNode> &nodes, std::vector<BuildItem> &items, size_t b, size_t e) {
-    if (e - b == 1) return kLeafFlag | items[b].obj;
-    return build_node(nodes, items, b, e);
+static uint32_t build_node(BuildCtx &cx, size_t b, size_t e);
+
+static uint32_t child_ref(BuildCtx &cx, size_t b, size_t e) {
+    if (cx.max_leaf == 1) { if (e - b == 1) return kLeafFlag | cx.items[b].obj; }
+    else if (e - b <= cx.max_leaf) return kLeafFlag | ((uint32_t) b << kBlasLeafBits) | (uint32_t) (e - b - 1);
+    return build_node(cx, b, e);
 }
 
 // binned SAH split over centroids (16 bins), falling back to a median split
-static uint32_t build_node(std::vector<BvhNode> &nodes, std::vector<BuildItem> &items, size_t b, size_t e) {
+static uint32_t build_node(BuildCtx &cx, size_t b, size_t e) {
+    std::vector<BvhNode> &nodes = cx.nodes; std::vector<BuildItem> &items = cx.items;
+    cx.deepest = std::max(cx.deepest, ++cx.depth);
     uint32_t idx = (uint32_t) nodes.size();
     nodes.emplace_back();
     Box cb;
@@ -91,7 +100,8 @@ static uint32_t build_node(std::vector<BvhNode> &nodes, std::vector<BuildItem> &
     Box lb, rb;
     for (size_t i = b; i < mid; ++i) lb.add(items[i].box);
     for (size_t i = mid; i < e; ++i) rb.add(items[i].box);
-    uint32_t l = child_ref(nodes, items, b, mid), r = child_ref(nodes, items, mid, e);
+    uint32_t l = child_ref(cx, b, mid), r = child_ref(cx, mid, e);
+    --cx.depth;
     BvhNode &n = nodes[idx];
     for (int i = 0; i < 3; ++i) { n.lmin[i] = lb.lo[i]; n.lmax[i] = lb.hi[i]; n.rmin[i] = rb.lo[i]; n.rmax[i] = rb.hi[i]; }
     n.left = l; n.right = r; n.pad0 = n.pad1 = 0;
@@ -100,17 +110,23 @@ static uint32_t build_node(std::vector<BvhNode> &nodes, std::vector<BuildItem> &
 
 static uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
+static Box tri_box(const DTri &t) {
+    Box b; b.add(mk(t.p0[0], t.p0[1], t.p0[2])); b.add(mk(t.p1[0], t.p1[1], t.p1[2])); b.add(mk(t.p2[0], t.p2[1], t.p2[2])); return b;
+}
+
 std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
-    // ---- shapes / triangles
+    // ---- shapes / triangles (+ one BLAS per larger mesh; its nodes follow the TLAS in the same array)
     std::vector<DShape> shapes(sc.shapes.size());
     std::vector<DTri> tris; std::vector<DTriShade> shading;
+    std::vector<BvhNode> blas_nodes; uint32_t blas_depth = 0;
+    const char *blas_env = getenv("DTOF_BLAS"); const bool use_blas = !(blas_env && blas_env[0] == '0');   // DTOF_BLAS=0: loop over every triangle (debug)
     std::vector<Box> shape_boxes(sc.shapes.size());
     for (size_t i = 0; i < sc.shapes.size(); ++i) {
         const HostShape &h = sc.shapes[i]; DShape &d = shapes[i];
         memset(&d, 0, sizeof d);
         d.kind = h.kind;
         d.flags = (h.twosided ? SF_TWOSIDED : 0) | (h.flip_normals ? SF_FLIP_NORMALS : 0) | (h.face_normals ? SF_FACE_NORMALS : 0);
-        memcpy(d.refl, h.refl, 12);
+        memcpy(d.refl, h.refl, 12); d.blas_root = kNoChild;
         if (h.emitter) { d.flags |= SF_EMITTER; memcpy(d.radiance, h.radiance, 12); }
         memcpy(d.to_world, h.to_world, 48); memcpy(d.to_object, h.to_object, 48);
         if (h.kind == SHAPE_RECT) {   // Rectangle::update, rectangle.cpp:101-113
@@ -126,12 +142,27 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
                 DTri t; DTriShade s; memset(&t, 0, sizeof t); memset(&s, 0, sizeof s);
                 const uint32_t *fi = &h.faces[3 * f];
                 float *tp[3] = { t.p0, t.p1, t.p2 }; float *sn[3] = { s.n0, s.n1, s.n2 }; float *su[3] = { s.uv0, s.uv1, s.uv2 };
+                t.face = f;
                 for (int k = 0; k < 3; ++k) {
                     memcpy(tp[k], &h.positions[3 * fi[k]], 12);
                     if (!h.normals.empty()) memcpy(sn[k], &h.normals[3 * fi[k]], 12);
                     if (!h.texcoords.empty()) memcpy(su[k], &h.texcoords[2 * fi[k]], 8);
                 }
                 tris.push_back(t); shading.push_back(s);
+            }
+            if (use_blas && d.n_tris > kBlasMinTris) {
+                std::vector<BuildItem> items(d.n_tris);
+                for (uint32_t f = 0; f < d.n_tris; ++f) {
+                    BuildItem &it = items[f]; it.box = tri_box(tris[d.first_tri + f]); it.obj = f;
+                    for (int k = 0; k < 3; ++k) it.c[k] = 0.5f * (it.box.lo[k] + it.box.hi[k]);
+                    it.box.pad();
+                }
+                BuildCtx cx { blas_nodes, items, kBlasLeaf };
+                d.blas_root = build_node(cx, 0, items.size());   // index within blas_nodes; rebased behind the TLAS below
+                blas_depth = std::max(blas_depth, cx.deepest);
+                std::vector<DTri> t2(d.n_tris); std::vector<DTriShade> s2(d.n_tris);
+                for (uint32_t f = 0; f < d.n_tris; ++f) { t2[f] = tris[d.first_tri + items[f].obj]; s2[f] = shading[d.first_tri + items[f].obj]; }
+                std::copy(t2.begin(), t2.end(), tris.begin() + d.first_tri); std::copy(s2.begin(), s2.end(), shading.begin() + d.first_tri);
             }
         }
         shape_boxes[i] = shape_box(h);
@@ -176,8 +207,16 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         n.left = kLeafFlag | items[0].obj; n.right = kNoChild;
         nodes.push_back(n);
     } else if (items.size() > 1) {
-        build_node(nodes, items, 0, items.size());
+        BuildCtx cx { nodes, items, 1 };
+        build_node(cx, 0, items.size());
     }
+    const uint32_t tlas_nodes = (uint32_t) nodes.size();
+    for (BvhNode n : blas_nodes) {   // BLAS node indices (children and roots) move behind the TLAS
+        if (n.left != kNoChild && !(n.left & kLeafFlag)) n.left += tlas_nodes;
+        if (n.right != kNoChild && !(n.right & kLeafFlag)) n.right += tlas_nodes;
+        nodes.push_back(n);
+    }
+    for (DShape &d : shapes) if (d.blas_root != kNoChild) d.blas_root += tlas_nodes;
     // ---- emitters
     std::vector<DEmitter> emitters(sc.emitters.size());
     for (size_t i = 0; i < sc.emitters.size(); ++i) {
@@ -191,14 +230,14 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     h.has_instances = has_instances;
     {   // deepest leaf below the root = stack entries a depth-first traversal can hold
         uint32_t deepest = 1;
-        std::vector<std::pair<uint32_t, uint32_t>> todo; if (!nodes.empty()) todo.emplace_back(0u, 1u);
+        std::vector<std::pair<uint32_t, uint32_t>> todo; if (tlas_nodes) todo.emplace_back(0u, 1u);
         while (!todo.empty()) {
             auto [ni, d] = todo.back(); todo.pop_back();
             deepest = std::max(deepest, d);
             for (uint32_t c : { nodes[ni].left, nodes[ni].right })
                 if (c != kNoChild && !(c & kLeafFlag)) todo.emplace_back(c, d + 1);
         }
-        h.tlas_depth = deepest + 1;
+        h.tlas_depth = deepest + 1 + (blas_depth ? blas_depth + 1 : 0);
     }
     uint32_t off = sizeof(BlobHeader);
     h.off_nodes = off;    off = align16(off + (uint32_t) (nodes.size() * sizeof(BvhNode)));

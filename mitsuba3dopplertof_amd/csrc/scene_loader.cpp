@@ -469,10 +469,11 @@ static void bake_cube(HostShape &s) {   // src/shapes/cube.cpp:114-160
     }
 }
 
-static HostShape make_shape(const Obj &o, bool strip_to_world) {
+static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string &base_dir) {
     HostShape s; s.id = o.id;
-    if (o.plugin == "rectangle") s.kind = SHAPE_RECT; else if (o.plugin == "cube") s.kind = SHAPE_MESH;
-    else fail("unsupported shape plugin \"" + o.plugin + "\" (supported: rectangle, cube, shapegroup, instance)");
+    const bool mesh_file = o.plugin == "obj" || o.plugin == "ply";
+    if (o.plugin == "rectangle") s.kind = SHAPE_RECT; else if (o.plugin == "cube" || mesh_file) s.kind = SHAPE_MESH;
+    else fail("unsupported shape plugin \"" + o.plugin + "\" (supported: rectangle, cube, obj, ply, shapegroup, instance)");
     Xf tw { m_identity(), m_identity() };
     if (!strip_to_world) { auto t = o.transforms.find("to_world"); if (t != o.transforms.end()) tw = t->second; }
     s.flip_normals = o.props.get_bool("flip_normals", false);
@@ -500,9 +501,17 @@ static HostShape make_shape(const Obj &o, bool strip_to_world) {
     }
     if (bsdf) bsdf_of(*bsdf, s.twosided, s.refl);   // else default diffuse: 0.5, or 0 for an emitter (src/render/shape.cpp:66-72)
     else if (s.emitter) s.refl[0] = s.refl[1] = s.refl[2] = 0.f;
+    RawMesh raw;
+    if (mesh_file) {   // src/shapes/obj.cpp:139-143, ply.cpp:160-166: `filename` through the file resolver
+        if (!o.props.has("filename")) fail("Property \"filename\" has not been specified!");
+        std::string fn = o.props.get_string("filename", "");
+        std::string path = (!fn.empty() && fn[0] == '/') || base_dir.empty() ? fn : base_dir + "/" + fn;
+        raw = o.plugin == "obj" ? load_obj(path, o.props.get_bool("flip_tex_coords", true), s.face_normals) : load_ply(path, s.face_normals);
+    }
     auto u = o.props.unqueried();
     if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in shape plugin of type \"" + o.plugin + "\"");
-    if (s.kind == SHAPE_MESH) bake_cube(s);
+    if (mesh_file) bake_mesh(s, raw);
+    else if (s.kind == SHAPE_MESH) bake_cube(s);
     return s;
 }
 
@@ -603,7 +612,7 @@ static void make_sensor(const Obj &o, HostScene &sc) {
     if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in sensor plugin");
 }
 
-HostScene load_scene_xml(const std::string &text, const std::map<std::string, std::string> &params) {
+HostScene load_scene_xml(const std::string &text, const std::map<std::string, std::string> &params, const std::string &base_dir) {
     XParser xp(text);
     auto root = xp.document();
     if (root->tag != "scene") fail("root element \"" + root->tag + "\" must be a <scene>");
@@ -646,7 +655,7 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
                     if (ch.first != "shape") fail("Tried to add an unsupported object to a shapegroup");
                     if (ch.second->plugin == "instance") fail("Nested instancing is not permitted");
                     if (ch.second->plugin == "shapegroup") fail("Nested ShapeGroup is not permitted");
-                    sc.shapes.push_back(make_shape(*ch.second, false));
+                    sc.shapes.push_back(make_shape(*ch.second, false, base_dir));
                     if (sc.shapes.back().emitter) fail("Instancing of emitters is not supported");
                 }
                 g.n_shapes = (uint32_t) sc.shapes.size() - g.first_shape;
@@ -664,12 +673,12 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
             } else if (o.animations.count("to_world")) {
                 // xml.cpp:1165-1195: shape with an animated to_world => shapegroup{shape} + instance{animated to_world}
                 HostGroup g; g.first_shape = (uint32_t) sc.shapes.size(); g.n_shapes = 1;
-                sc.shapes.push_back(make_shape(o, true));
+                sc.shapes.push_back(make_shape(o, true, base_dir));
                 sc.groups.push_back(g);
                 sc.objects.push_back(make_instance(o, (uint32_t) sc.groups.size() - 1));
             } else {
                 HostObject ob; ob.kind = OBJ_SHAPE; ob.index = (uint32_t) sc.shapes.size(); ob.n_keys = 0; memset(ob.key, 0, sizeof ob.key);
-                sc.shapes.push_back(make_shape(o, false));
+                sc.shapes.push_back(make_shape(o, false, base_dir));
                 sc.objects.push_back(ob);
                 if (sc.shapes.back().emitter) {   // scene.cpp:33-35: the shape's emitter joins the list at the shape's position
                     HostEmitter e; e.kind = EMITTER_AREA; e.shape = ob.index; memcpy(e.intensity, sc.shapes.back().radiance, 12);

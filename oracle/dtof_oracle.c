@@ -952,3 +952,48 @@ void orc_bake_cube(const float *to_world, const float *to_object, float *pos, fl
     }
     memcpy(faces, tri, sizeof tri);
 }
+
+/* Mesh vertex baking -- obj.cpp:218-246 / ply.cpp:284-300 + mesh.cpp:257-345 (see the header). */
+void orc_bake_mesh(const float *to_world, const float *to_object, int32_t n_vertices, const float *pos_in,
+                   const float *nrm_in, int32_t n_faces, const uint32_t *faces, int32_t face_normals,
+                   float *pos_out, float *nrm_out) {
+    for (int32_t i = 0; i < n_vertices; ++i) {
+        v3 p = m_point(to_world, V(pos_in[3 * i], pos_in[3 * i + 1], pos_in[3 * i + 2]));
+        pos_out[3 * i] = p.x; pos_out[3 * i + 1] = p.y; pos_out[3 * i + 2] = p.z;
+    }
+    if (face_normals || !nrm_out) return;
+    if (nrm_in) {
+        for (int32_t i = 0; i < n_vertices; ++i) {
+            v3 n = v_normalize(m_normal(to_object, V(nrm_in[3 * i], nrm_in[3 * i + 1], nrm_in[3 * i + 2])));
+            nrm_out[3 * i] = n.x; nrm_out[3 * i + 1] = n.y; nrm_out[3 * i + 2] = n.z;
+        }
+        return;
+    }
+    double *acc = (double *) calloc((size_t) n_vertices * 3 + 1, sizeof(double));
+    for (int32_t f = 0; f < n_faces; ++f) {
+        const uint32_t *fi = faces + 3 * (size_t) f;
+        double v[3][3];
+        for (int k = 0; k < 3; ++k) for (int c = 0; c < 3; ++c) v[k][c] = (double) pos_out[3 * (size_t) fi[k] + c];
+        double s0[3], s1[3], n[3];
+        for (int c = 0; c < 3; ++c) { s0[c] = v[1][c] - v[0][c]; s1[c] = v[2][c] - v[0][c]; }
+        n[0] = s0[1] * s1[2] - s0[2] * s1[1]; n[1] = s0[2] * s1[0] - s0[0] * s1[2]; n[2] = s0[0] * s1[1] - s0[1] * s1[0];
+        double l2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+        if (!(l2 > 0.0)) continue;
+        double il = 1.0 / sqrt(l2);
+        for (int c = 0; c < 3; ++c) n[c] *= il;
+        for (int k = 0; k < 3; ++k) {
+            double d0[3], d1[3], l0 = 0, l1 = 0, dt = 0;
+            for (int c = 0; c < 3; ++c) { d0[c] = v[(k + 1) % 3][c] - v[k][c]; d1[c] = v[(k + 2) % 3][c] - v[k][c]; l0 += d0[c] * d0[c]; l1 += d1[c] * d1[c]; }
+            l0 = 1.0 / sqrt(l0); l1 = 1.0 / sqrt(l1);
+            for (int c = 0; c < 3; ++c) dt += (d0[c] * l0) * (d1[c] * l1);
+            double ang = acos(dt > 1.0 ? 1.0 : (dt < -1.0 ? -1.0 : dt));
+            for (int c = 0; c < 3; ++c) acc[3 * (size_t) fi[k] + c] += n[c] * ang;
+        }
+    }
+    for (int32_t i = 0; i < n_vertices; ++i) {
+        double *a = acc + 3 * (size_t) i, l = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+        if (l != 0.0 && l == l) { nrm_out[3 * i] = (float) (a[0] / l); nrm_out[3 * i + 1] = (float) (a[1] / l); nrm_out[3 * i + 2] = (float) (a[2] / l); }
+        else { nrm_out[3 * i] = 1.f; nrm_out[3 * i + 1] = 0.f; nrm_out[3 * i + 2] = 0.f; }
+    }
+    free(acc);
+}

@@ -169,6 +169,14 @@ void     orc_develop(const float *film_rgbw, float *out_rgb, int64_t n_pixels);
 void     orc_bake_cube(const float *to_world, const float *to_object, float *pos, float *nrm,
                        float *uv, uint32_t *faces);
 
+/* OBJMesh / PLYMesh vertex baking (obj.cpp:218-246, ply.cpp:284-300): positions through to_world, vertex normals
+ * through its inverse transpose then normalised.  nrm_in == NULL and !face_normals: the normals are computed as
+ * Mesh::recompute_vertex_normals does (mesh.cpp:257-345, angle-weighted face normals; the reference accumulates them
+ * with unordered float atomics, here: in face order, in double, rounded once).  nrm_out may be NULL iff face_normals. */
+void     orc_bake_mesh(const float *to_world, const float *to_object, int32_t n_vertices, const float *pos_in,
+                       const float *nrm_in, int32_t n_faces, const uint32_t *faces, int32_t face_normals,
+                       float *pos_out, float *nrm_out);
+
 #ifdef __cplusplus
 }
 #endif

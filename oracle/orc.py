@@ -118,6 +118,8 @@ def lib():
         L.orc_render.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_int]
         L.orc_bake_cube.argtypes = [C.c_void_p] * 6
+        L.orc_bake_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                    C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -150,7 +152,31 @@ class Scene:
             o.to_world, o.to_object = _m16(s["to_world"]), _m16(s["to_object"])
             o.emitter = int(s.get("emitter", 0))
             o.radiance = (C.c_float * 3)(*np.asarray(s.get("radiance", [0, 0, 0]), np.float32).tolist())
-            if s["kind"] == 1:   # cube
+            if s["kind"] == 1 and s.get("mesh_raw") is not None:   # obj / ply: bake in C (orc_bake_mesh)
+                raw = s["mesh_raw"]
+                pin = np.ascontiguousarray(raw["positions"], dtype=np.float32).reshape(-1)
+                faces = np.ascontiguousarray(raw["faces"], dtype=np.uint32).reshape(-1)
+                nv, nf = pin.size // 3, faces.size // 3
+                if nf and int(faces.max()) >= nv:
+                    raise ValueError("mesh face references a vertex out of range")
+                nin = None if raw["normals"] is None else np.ascontiguousarray(raw["normals"], dtype=np.float32).reshape(-1)
+                pos = np.zeros(max(3 * nv, 1), np.float32)
+                nrm = None if s["face_normals"] else np.zeros(max(3 * nv, 1), np.float32)
+                tw = np.ascontiguousarray(s["to_world"], dtype=np.float32)
+                to = np.ascontiguousarray(s["to_object"], dtype=np.float32)
+                L.orc_bake_mesh(tw.ctypes.data, to.ctypes.data, nv, pin.ctypes.data, None if nin is None else nin.ctypes.data,
+                                nf, faces.ctypes.data, int(s["face_normals"]), pos.ctypes.data, None if nrm is None else nrm.ctypes.data)
+                uv = None if raw["texcoords"] is None else np.ascontiguousarray(raw["texcoords"], dtype=np.float32).reshape(-1)
+                self._keep += [pos, nrm, uv, faces, pin, nin]
+                s["positions"], s["normals"], s["texcoords"], s["faces"] = pos, nrm, uv, faces
+                o.n_vertices, o.n_faces = nv, nf
+                o.positions = pos.ctypes.data_as(C.POINTER(C.c_float))
+                if nrm is not None:
+                    o.normals = nrm.ctypes.data_as(C.POINTER(C.c_float))
+                if uv is not None:
+                    o.texcoords = uv.ctypes.data_as(C.POINTER(C.c_float))
+                o.faces = faces.ctypes.data_as(C.POINTER(C.c_uint32))
+            elif s["kind"] == 1:   # cube
                 pos, nrm = np.zeros(72, np.float32), np.zeros(72, np.float32)
                 uv, faces = np.zeros(48, np.float32), np.zeros(36, np.uint32)
                 tw = np.ascontiguousarray(s["to_world"], dtype=np.float32)

@@ -15,6 +15,7 @@ Follows (reference paths relative to /root/reference):
     src/samplers/correlated.cpp:17-23, src/render/sampler.cpp:11-20             plugin parameters
 """
 import math
+import os
 import xml.etree.ElementTree as ET
 
 import numpy as np
@@ -335,10 +336,20 @@ class FlatScene:
         self.sampler = None      # Props
 
 
-def _shape_record(sp, registry, strip_to_world):
-    kind = {"rectangle": 0, "cube": 1}.get(sp.plugin)
+def _shape_record(sp, registry, strip_to_world, base_dir=""):
+    kind = {"rectangle": 0, "cube": 1, "obj": 1, "ply": 1}.get(sp.plugin)
     if kind is None:
         raise ValueError('unsupported shape plugin "%s"' % sp.plugin)
+    mesh_raw = None
+    if sp.plugin in ("obj", "ply"):   # src/shapes/obj.cpp:139-143, ply.cpp:160-166: filename through the file resolver
+        from . import mesh_io
+        fn = sp.get_s("filename", None)
+        if fn is None:
+            raise ValueError('Property "filename" has not been specified!')
+        path = fn if os.path.isabs(fn) else os.path.join(base_dir, fn)
+        fnorm = sp.get_b("face_normals", False)
+        mesh_raw = (mesh_io.read_obj(path, sp.get_b("flip_tex_coords", True), fnorm) if sp.plugin == "obj"
+                    else mesh_io.read_ply(path, fnorm))
     tw, tinv = _ident(), _ident()
     if not strip_to_world and "to_world" in sp and sp["to_world"][0] == "transform":
         tw, tinv = sp["to_world"][1]
@@ -366,12 +377,13 @@ def _shape_record(sp, registry, strip_to_world):
     else:   # shape.cpp:66-72: default diffuse, reflectance 0 when the shape is an emitter
         twosided, refl = 0, np.array([0.0 if emitter else 0.5] * 3, dtype=F32)
     return dict(kind=kind, twosided=twosided, flip_normals=int(flip), face_normals=int(sp.get_b("face_normals", False)),
-                reflectance=refl, to_world=_m32(tw), to_object=_m32(tinv), emitter=emitter, radiance=radiance)
+                reflectance=refl, to_world=_m32(tw), to_object=_m32(tinv), emitter=emitter, radiance=radiance, mesh_raw=mesh_raw)
 
 
 def load(source, params=None, is_string=False):
     """Parse a scene XML (file path or string) into a FlatScene."""
     root = ET.fromstring(source) if is_string else ET.parse(source).getroot()
+    base_dir = "" if is_string else os.path.dirname(os.path.abspath(source))
     if root.tag != "scene" or root.get("version") is None:
         raise ValueError('missing version attribute in root element "%s"' % root.tag)
     _substitute(root, params or {})
@@ -405,7 +417,7 @@ def load(source, params=None, is_string=False):
                     if t2 == "ref":
                         t2, c2 = registry[c2]
                     if t2 == "shape":
-                        fs.shapes.append(_shape_record(c2, registry, False))
+                        fs.shapes.append(_shape_record(c2, registry, False, base_dir))
                 group_of[id(child)] = len(fs.groups)
                 fs.groups.append(dict(first_shape=first, n_shapes=len(fs.shapes) - first))
             elif child.plugin == "instance":
@@ -421,11 +433,11 @@ def load(source, params=None, is_string=False):
             elif "to_world" in child and child["to_world"][0] == "animation":
                 # xml.cpp:1165-1195: shape{animated to_world} -> shapegroup{shape} + instance
                 first = len(fs.shapes)
-                fs.shapes.append(_shape_record(child, registry, True))
+                fs.shapes.append(_shape_record(child, registry, True, base_dir))
                 fs.groups.append(dict(first_shape=first, n_shapes=1))
                 fs.objects.append(_instance_record(child["to_world"], len(fs.groups) - 1))
             else:
-                fs.shapes.append(_shape_record(child, registry, False))
+                fs.shapes.append(_shape_record(child, registry, False, base_dir))
                 fs.objects.append(dict(kind=0, index=len(fs.shapes) - 1, n_keys=0,
                                        key_time=np.zeros(2, F32), key=np.zeros((2, 4, 4), F32)))
                 if fs.shapes[-1]["emitter"]:   # scene.cpp:33-35: a shape's emitter joins the list at the shape's position

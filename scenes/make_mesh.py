@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Deterministic triangle-mesh test assets (obj / ply meshes behind a BLAS).
+
+There is no network and the tutorial scenes' meshes are not in the reference tree, so the meshes are procedural:
+a "blob" = sphere of radius r displaced by a few low-frequency sines, tessellated n_u x n_v (2*n_u*(n_v-1) triangles).
+
+    python scenes/make_mesh.py OUT_DIR [n_u n_v]     # writes blob.obj, blob_n.obj, blob.ply, blob_ascii.ply, cornell_mesh.xml
+
+  cornell_mesh.xml   the Cornell room of cornell_boxes.xml with the two cubes replaced by
+                       * a static  `ply` blob (binary little endian, with vertex normals) and
+                       * a moving  `obj` blob (no normals in the file => computed; animated to_world => instance),
+                     both diffuse, lit by the point light at the camera.
+"""
+import math
+import os
+import struct
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import make_scenes as ms   # noqa: E402
+
+
+def blob(n_u, n_v, seed=1, radius=1.0):
+    """returns (positions, normals, uvs, faces); vertices on the poles are shared, the seam is duplicated for uv"""
+    ph = [0.37 * seed, 1.1 + 0.21 * seed, 2.3 - 0.13 * seed]
+    def r_of(th, ph_):
+        return radius * (1.0 + 0.18 * math.sin(3 * th + ph[0]) * math.sin(2 * ph_ + ph[1]) + 0.08 * math.sin(5 * ph_ + ph[2]) * math.sin(th) ** 2)
+    pos, uv = [], []
+    for j in range(n_v + 1):
+        th = math.pi * j / n_v
+        for i in range(n_u + 1):
+            p = 2 * math.pi * i / n_u
+            r = r_of(th, p)
+            pos.append((r * math.sin(th) * math.cos(p), r * math.cos(th), r * math.sin(th) * math.sin(p)))
+            uv.append((i / n_u, j / n_v))
+    faces = []
+    W = n_u + 1
+    for j in range(n_v):
+        for i in range(n_u):
+            a, b, c, d = j * W + i, j * W + i + 1, (j + 1) * W + i, (j + 1) * W + i + 1
+            if j != 0:
+                faces.append((a, b, c))
+            if j != n_v - 1:
+                faces.append((b, d, c))
+    # outward-ish analytic normals: normalised position gradient approximated by the position (good enough as DATA)
+    nrm = []
+    for (x, y, z) in pos:
+        l = math.sqrt(x * x + y * y + z * z) or 1.0
+        nrm.append((x / l, y / l, z / l))
+    return pos, nrm, uv, faces
+
+
+def write_obj(path, pos, nrm, uv, faces, with_normals=False, with_uv=True, quads_as_polygons=False):
+    with open(path, "w") as f:
+        f.write("# procedural blob\n")
+        for p in pos:
+            f.write("v %.6f %.6f %.6f\n" % p)
+        if with_uv:
+            for t in uv:
+                f.write("vt %.6f %.6f\n" % t)
+        if with_normals:
+            for n in nrm:
+                f.write("vn %.6f %.6f %.6f\n" % n)
+        for tri in faces:
+            def ref(i):
+                i += 1
+                if with_uv and with_normals:
+                    return "%d/%d/%d" % (i, i, i)
+                if with_uv:
+                    return "%d/%d" % (i, i)
+                if with_normals:
+                    return "%d//%d" % (i, i)
+                return "%d" % i
+            f.write("f %s %s %s\n" % tuple(ref(i) for i in tri))
+
+
+def write_ply(path, pos, nrm, uv, faces, binary=True, with_normals=True, with_uv=False, big_endian=False):
+    props = ["x", "y", "z"] + (["nx", "ny", "nz"] if with_normals else []) + (["u", "v"] if with_uv else [])
+    hdr = "ply\nformat %s 1.0\ncomment procedural blob\nelement vertex %d\n" % (
+        ("binary_big_endian" if big_endian else "binary_little_endian") if binary else "ascii", len(pos))
+    hdr += "".join("property float %s\n" % p for p in props)
+    hdr += "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % len(faces)
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        e = ">" if big_endian else "<"
+        for i in range(len(pos)):
+            row = list(pos[i]) + (list(nrm[i]) if with_normals else []) + (list(uv[i]) if with_uv else [])
+            if binary:
+                f.write(struct.pack(e + "%df" % len(row), *row))
+            else:
+                f.write((" ".join("%.6f" % v for v in row) + "\n").encode())
+        for tri in faces:
+            if binary:
+                f.write(struct.pack(e + "B3i", 3, *tri))
+            else:
+                f.write(("3 %d %d %d\n" % tri).encode())
+
+
+def mesh_shape(plugin, ident, filename, bsdf_id, scale, translate, anim_dz=None, extra=""):
+    tf = ('\t\t\t<scale value="%s" />\n\t\t\t<translate x="%s" y="%s" z="%s" />\n' % ((scale,) + tuple(translate)))
+    s = '\t<shape type="%s" id="%s">\n\t\t<string name="filename" value="%s" />\n%s' % (plugin, ident, filename, extra)
+    if anim_dz is None:
+        s += '\t\t<transform name="to_world">\n' + tf + '\t\t</transform>\n'
+    else:
+        s += ('\t\t<animation name="to_world">\n\t\t\t<transform time="0">\n' + tf.replace("\t\t\t<", "\t\t\t\t<") + '\t\t\t</transform>\n'
+              '\t\t\t<transform time="0.0015">\n' + tf.replace("\t\t\t<", "\t\t\t\t<") +
+              '\t\t\t\t<translate x="0.0" y="0.0" z="%s" />\n\t\t\t</transform>\n\t\t</animation>\n' % anim_dz)
+    return s + '\t\t<ref id="%s" />\n\t</shape>\n' % bsdf_id
+
+
+def cornell_mesh_xml(static_file="blob.ply", moving_file="blob.obj", res=128, spp=16):
+    s = ms.HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + ms.SENSOR.format(fov="19.5", cam=ms.CAM)
+    for b in ms.BSDFS:
+        s += ms.bsdf(*b)
+    for name, m, b in ms.WALLS:
+        s += ms.rect(name, m, b)
+    s += mesh_shape("ply", "StaticBlob", static_file, "TallBoxBSDF", "0.38", ("-0.38", "0.45", "-0.25"))
+    s += mesh_shape("obj", "MovingBlob", moving_file, "ShortBoxBSDF", "0.3", ("0.4", "0.33", "0.35"), anim_dz="0.015")
+    return s + ms.LIGHT + "</scene>\n"
+
+
+def write_all(out_dir, n_u=24, n_v=12):
+    os.makedirs(out_dir, exist_ok=True)
+    pos, nrm, uv, faces = blob(n_u, n_v)
+    write_obj(os.path.join(out_dir, "blob.obj"), pos, nrm, uv, faces)                                   # uv, no normals
+    write_obj(os.path.join(out_dir, "blob_n.obj"), pos, nrm, uv, faces, with_normals=True, with_uv=False)
+    write_ply(os.path.join(out_dir, "blob.ply"), pos, nrm, uv, faces)                                   # binary LE + normals
+    write_ply(os.path.join(out_dir, "blob_ascii.ply"), pos, nrm, uv, faces, binary=False, with_normals=False, with_uv=True)
+    write_ply(os.path.join(out_dir, "blob_be.ply"), pos, nrm, uv, faces, big_endian=True)
+    with open(os.path.join(out_dir, "cornell_mesh.xml"), "w") as f:
+        f.write(cornell_mesh_xml())
+    return len(faces)
+
+
+if __name__ == "__main__":
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "mesh")
+    nu, nv = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (24, 12)
+    print("wrote", write_all(out, nu, nv), "triangles per blob to", out)
