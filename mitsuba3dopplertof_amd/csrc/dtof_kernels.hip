@@ -63,9 +63,13 @@ DTOF_D bool rect_hit(const DShape &sh, V3 o, V3 d, float maxt, float &t, float &
     u = fmaf(ld.x, t, lo.x); v = fmaf(ld.y, t, lo.y);
     return t >= 0.f && t <= maxt && fabsf(u) <= 1.f && fabsf(v) <= 1.f;
 }
-// Moeller-Trumbore as in Embree 3's triangle intersector (tnear < t <= tfar; u,v weight vertices 1,2)
-DTOF_D bool tri_hit(const DTri &tr, V3 o, V3 d, float maxt, float &t, float &u, float &v) {
-    V3 p0 = mk(tr.p0[0], tr.p0[1], tr.p0[2]), p1 = mk(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = mk(tr.p2[0], tr.p2[1], tr.p2[2]);
+// Moeller-Trumbore as in Embree 3's triangle intersector (tnear < t <= tfar; u,v weight vertices 1,2).
+// The 48-byte record is fetched with three 16-byte loads issued together; `face` rides in p0.w.
+DTOF_D bool tri_hit(const DTri &tr, V3 o, V3 d, float maxt, float &t, float &u, float &v, uint32_t &face) {
+    const uint4 *tp = (const uint4 *) &tr;
+    const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+    face = q0.w;
+    V3 p0 = mk(u2f(q0.x), u2f(q0.y), u2f(q0.z)), p1 = mk(u2f(q1.x), u2f(q1.y), u2f(q1.z)), p2 = mk(u2f(q2.x), u2f(q2.y), u2f(q2.z));
     V3 e1 = p0 - p1, e2 = p2 - p0, ng = cross(e2, e1);
     V3 c = p0 - o, r = cross(c, d);
     float den = dot(ng, d), aden = fabsf(den);
@@ -98,6 +102,18 @@ DTOF_D float box_entry(const float *bmin, const float *bmax, V3 o, V3 id, float 
     float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
     float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
     return tn <= tf ? tn : INFINITY;
+}
+// One BVH node = four 16-byte loads issued together (no load depends on a field of the node); entry distances of both
+// children, INFINITY = missed / absent.
+DTOF_D void node_test(const BvhNode *node, V3 o, V3 id, float tbest, float &tl, float &tr, uint32_t &left, uint32_t &right) {
+    const uint4 *np = (const uint4 *) node;
+    const uint4 a = np[0], b = np[1], c = np[2], d = np[3];
+    const float lmin[3] = { u2f(a.x), u2f(a.y), u2f(a.z) }, lmax[3] = { u2f(b.x), u2f(b.y), u2f(b.z) };
+    const float rmin[3] = { u2f(c.x), u2f(c.y), u2f(c.z) }, rmax[3] = { u2f(d.x), u2f(d.y), u2f(d.z) };
+    left = a.w; right = b.w;
+    tl = box_entry(lmin, lmax, o, id, tbest);
+    tr = box_entry(rmin, rmax, o, id, tbest);
+    if (right == kNoChild) tr = INFINITY;
 }
 
 // Closest hit (ANY=false) or occlusion (ANY=true) of one top-level object.  Candidates are every
@@ -139,12 +155,12 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
         // `face` of the best hit so far IF it lies on this very mesh (ties between two of its triangles go to the lower face)
         uint32_t best_face = 0xffffffffu;
         auto test = [&](uint32_t f) -> bool {
-            const DTri &tr = sv.tris[sh.first_tri + f];
-            if (!tri_hit(tr, lo, ld, maxt, t, u, v)) return false;
+            uint32_t face;
+            if (!tri_hit(sv.tris[sh.first_tri + f], lo, ld, maxt, t, u, v, face)) return false;
             if (ANY) return true;
             bool take = t < best.t;
-            if (t == best.t) take = best_face != 0xffffffffu ? tr.face < best_face : (!found && best.obj != 0xffffffffu && oi < best.obj);
-            if (take) { best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = f; best_face = tr.face; found = true; }
+            if (t == best.t) take = best_face != 0xffffffffu ? face < best_face : (!found && best.obj != 0xffffffffu && oi < best.obj);
+            if (take) { best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = f; best_face = face; found = true; }
             return false;
         };
         if (sh.blas_root == kNoChild) {
@@ -156,17 +172,15 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
         uint32_t cur = sh.blas_root; int bsp = sp;
         for (;;) {
             while (!(cur & kLeafFlag) && cur != kDone) {
-                const BvhNode &n = sv.nodes[cur];
-                const float lim = ANY ? maxt : best.t;
-                float tl = box_entry(n.lmin, n.lmax, lo, lid, lim);
-                float tr = n.right != kNoChild ? box_entry(n.rmin, n.rmax, lo, lid, lim) : INFINITY;
+                float tl, tr; uint32_t left, right;
+                node_test(sv.nodes + cur, lo, lid, ANY ? maxt : best.t, tl, tr, left, right);
                 bool hl = tl < INFINITY, hr = tr < INFINITY;
                 if (hl && hr) {
-                    uint32_t nearc = tl <= tr ? n.left : n.right, farc = tl <= tr ? n.right : n.left;
+                    uint32_t nearc = tl <= tr ? left : right, farc = tl <= tr ? right : left;
                     stack[bsp * stride] = farc; ++bsp;
                     cur = nearc;
-                } else if (hl) cur = n.left;
-                else if (hr) cur = n.right;
+                } else if (hl) cur = left;
+                else if (hr) cur = right;
                 else if (bsp == sp) cur = kDone;
                 else { --bsp; cur = stack[bsp * stride]; }
             }
@@ -197,16 +211,15 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
     const uint32_t stride = blockDim.x;
     for (;;) {
         while (!(cur & kLeafFlag) && cur != kDone) {
-            const BvhNode &n = sv.nodes[cur];
-            float tl = box_entry(n.lmin, n.lmax, o, id, best.t);
-            float tr = n.right != kNoChild ? box_entry(n.rmin, n.rmax, o, id, best.t) : INFINITY;
+            float tl, tr; uint32_t left, right;
+            node_test(sv.nodes + cur, o, id, best.t, tl, tr, left, right);
             bool hl = tl < INFINITY, hr = tr < INFINITY;
             if (hl && hr) {
-                uint32_t nearc = tl <= tr ? n.left : n.right, farc = tl <= tr ? n.right : n.left;
+                uint32_t nearc = tl <= tr ? left : right, farc = tl <= tr ? right : left;
                 stack[sp * stride] = farc; ++sp;
                 cur = nearc;
-            } else if (hl) cur = n.left;
-            else if (hr) cur = n.right;
+            } else if (hl) cur = left;
+            else if (hr) cur = right;
             else if (sp == 0) cur = kDone;
             else { --sp; cur = stack[sp * stride]; }
         }
