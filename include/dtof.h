@@ -46,7 +46,9 @@ void dtof_scene_destroy(dtof_scene *scene);
  * new CorrelatedSampler(props) (src/samplers/correlated.cpp:17-23, src/render/sampler.cpp:11-20), and
  * mi.load_dict({'type':'dopplertofpath', ...}) of doppler_tutorials/src/program_runner.py:127-141.
  * Properties are given as parallel arrays; `types[i]` is one of 'f' (float), 'i' (integer), 'b' (boolean,
- * value "true"/"false"), 's' (string).  The plugin name goes in `plugin` ("dopplertofpath"/"correlated").
+ * value "true"/"false"), 's' (string).  The plugin name goes in `plugin`: integrators "dopplertofpath", "path"
+ * (src/integrators/path.cpp), "velocity" (src/integrators/velocity.cpp:125-142); samplers "correlated", "independent"
+ * (src/samplers/independent.cpp) and "timestratified" (src/samplers/timestratified.cpp:67-129).
  * Unknown plugin names, wrong types and unreferenced properties fail like the reference's loader. */
 int dtof_scene_set_integrator(dtof_scene *scene, const char *plugin, const char *const *names,
                               const char *types, const char *const *values, int n);

@@ -31,6 +31,7 @@ struct RenderParams {
     int32_t wave_type, low_pass;
     uint32_t path_correlation_depth, max_depth, rr_depth;
     int32_t has_area;                             // scene has area emitters: emitter-hit term + prev_si / prev_bsdf_pdf state
+    int32_t sampler_kind, jitter; float inv_spp;  // SamplerKind; timestratified: jitter, 1 / sample_count (timestratified.cpp:78-82)
     int32_t has_tris;                             // scene has triangle meshes (selects the kernel instantiations that carry mesh code)
     int32_t integrator;                           // 0 dopplertofpath, 1 path (src/integrators/path.cpp), 2 velocity (velocity.cpp)
     // ---- batch

@@ -326,13 +326,24 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) 
     float posx = (float) (px + (uint32_t) rp.crop_x), posy = (float) (py + (uint32_t) rp.crop_y);
     bool cp = rp.path_correlation_depth > 0;
     const bool doppler = rp.integrator == 0;
-    // Doppler branch of render_sample (integrator.cpp:476-495) vs the plain one (:416-431: next_2d / next_1d = main stream only)
-    float jx = doppler ? next_correlate(main, path, cp) : next_f32(main), jy = doppler ? next_correlate(main, path, cp) : next_f32(main);
+    // one stream only: the plain branch of render_sample (integrator.cpp:416-431: next_2d / next_1d), and every sampler but
+    // `correlated` (Sampler::next_*_correlate default to next_1d / next_2d, include/mitsuba/render/sampler.h:141-144)
+    const bool single = !doppler || rp.sampler_kind != SAMPLER_CORRELATED;
+    float jx = single ? next_f32(main) : next_correlate(main, path, cp), jy = single ? next_f32(main) : next_correlate(main, path, cp);
     float spx = posx + jx, spy = posy + jy;
     float ax = fmaf(spx, rp.scale_x, rp.offset_x), ay = fmaf(spy, rp.scale_y, rp.offset_y);
     float time = rp.shutter_open;
-    if (rp.shutter_open_time > 0.f)
-        time += (doppler ? next_time(rp, main, tm, si, perm_seed, dim) : next_f32(main)) * rp.shutter_open_time;
+    if (rp.shutter_open_time > 0.f) {
+        float u;
+        if (!doppler || rp.sampler_kind == SAMPLER_INDEPENDENT) u = next_f32(main);   // Sampler::next_1d_time -> next_1d (sampler.h:131-132)
+        else if (rp.sampler_kind == SAMPLER_CORRELATED) u = next_time(rp, main, tm, si, perm_seed, dim);
+        else {   // TimeStratifiedSampler::next_1d_time (timestratified.cpp:117-129): the strategy arguments are ignored
+            uint32_t p = permute_kensler(si, rp.spp, perm_seed + dim++);
+            float j = rp.jitter ? next_f32(main) : .5f;
+            u = ((float) p + j) * rp.inv_spp;
+        }
+        time += u * rp.shutter_open_time;
+    }
 
     // PerspectiveCamera::sample_ray_differential (perspective.cpp:238-279)
     const float *m = rp.s2c;
@@ -533,7 +544,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             main.state = (uint64_t) rs.x | ((uint64_t) rs.y << 32); main.inc = ((uint64_t) ri.x << 1) | 1u;
             path.state = (uint64_t) rs.z | ((uint64_t) rs.w << 32); path.inc = ((uint64_t) ri.y << 1) | 1u;
             bool correlate = (depth + 1) < rp.path_correlation_depth;
-            const bool plain = rp.integrator != 0;   // `path`: sampler->next_1d/2d, main stream only (path.cpp:197,213-214,273)
+            const bool plain = rp.integrator != 0;   // `path`: no modulation weight
+            const bool single = plain || rp.sampler_kind != SAMPLER_CORRELATED;   // main stream only (path.cpp:197,213-214,273; sampler.h:141-144)
             float t = u2f(hh.x);
             path_length += t * 1.f;   // eta == 1 for every supported BSDF (dopplertofpath.cpp:141)
             bool active_next = depth + 1 < rp.max_depth;
@@ -573,7 +585,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             }
 
             // ---- emitter sampling (scene.cpp:235-291; point.cpp:118-147; area.cpp:116-159 + shape.cpp:370-384 + rectangle.cpp:152-166)
-            float e1 = plain ? next_f32(main) : next_correlate(main, path, correlate), e2 = plain ? next_f32(main) : next_correlate(main, path, correlate);
+            float e1 = single ? next_f32(main) : next_correlate(main, path, correlate), e2 = single ? next_f32(main) : next_correlate(main, path, correlate);
             bool active_em = active_next && sv.n_emitters > 0;
             V3 em_weight = mk(0, 0, 0), wo = mk(0, 0, 0); float ds_dist = 0.f, ds_pdf = 0.f; bool ds_delta = true;
             if (active_em) {
@@ -616,8 +628,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 shb = make_float4(sd.x, sd.y, sd.z, time);
                 wo = mk(dot(dd, si.sh_s), dot(dd, si.sh_t), dot(dd, si.sh_n));
             }
-            float sample_1 = plain ? next_f32(main) : next_correlate(main, path, correlate); (void) sample_1;
-            float s2x = plain ? next_f32(main) : next_correlate(main, path, correlate), s2y = plain ? next_f32(main) : next_correlate(main, path, correlate);
+            float sample_1 = single ? next_f32(main) : next_correlate(main, path, correlate); (void) sample_1;
+            float s2x = single ? next_f32(main) : next_correlate(main, path, correlate), s2y = single ? next_f32(main) : next_correlate(main, path, correlate);
 
             // ---- BSDF eval_pdf + sample (twosided.cpp:111-148,219-258; diffuse.cpp:101-125,160-180)
             bool twosided = sh->flags & SF_TWOSIDED;
@@ -661,7 +673,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             float thr_max = fmax_(fmax_(thr.x, thr.y), thr.z);
             float rr_prob = fmin_(thr_max * sqr(eta), .95f);
             bool rr_active = ndepth >= rp.rr_depth;
-            bool rr_continue = (plain ? next_f32(main) : next_correlate(main, path, correlate)) < rr_prob;
+            bool rr_continue = (single ? next_f32(main) : next_correlate(main, path, correlate)) < rr_prob;
             if (rr_active) thr = thr * rcp(rr_prob);
             alive = active_next && (!rr_active || rr_continue) && thr_max != 0.f;
             if (alive) {

@@ -202,6 +202,7 @@ RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, cons
     }
     rp.path_correlation_depth = pp.path_correlation_depth; rp.max_depth = pp.max_depth; rp.rr_depth = pp.rr_depth;
     rp.integrator = pp.integrator;
+    rp.sampler_kind = pp.sampler_kind; rp.jitter = pp.jitter; rp.inv_spp = 1.0f / (float) spp;   // dr::rcp(ScalarFloat(m_sample_count))
     if (pp.integrator != INTEGRATOR_DOPPLER && n_offsets > 0) throw std::runtime_error("modulation offsets only apply to the dopplertofpath integrator");
     return rp;
 }

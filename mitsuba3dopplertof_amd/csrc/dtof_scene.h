@@ -105,10 +105,13 @@ struct PropBag {
 
 // Constructor-time parameters of DopplerToFPathIntegrator (+ bases) and CorrelatedSampler, rounded
 // exactly as the reference's constructors round them.
+enum SamplerKind : int32_t { SAMPLER_CORRELATED = 0, SAMPLER_INDEPENDENT = 1, SAMPLER_TIMESTRATIFIED = 2 };
 enum IntegratorKind : int32_t { INTEGRATOR_DOPPLER = 0, INTEGRATOR_PATH = 1, INTEGRATOR_VELOCITY = 2 };
 struct PluginParams {
     int32_t integrator = INTEGRATOR_DOPPLER;   // dopplertofpath | path | velocity
-    bool independent_sampler = false;          // `independent` is accepted for path / velocity (it is the correlated sampler's main stream)
+    // sampler plugin: correlated | independent (src/samplers/independent.cpp: the main stream only; Sampler::next_1d_time and
+    // next_*_correlate fall back to next_1d, include/mitsuba/render/sampler.h:131-144) | timestratified (src/samplers/timestratified.cpp)
+    int32_t sampler_kind = SAMPLER_CORRELATED; bool jitter = true;
     // src/integrators/dopplertofpath.cpp:19-57
     float time = 0.0015f, w_g_mhz = 30.f, g_1 = .5f, g_0 = .5f, w_s_mhz = 30.f, phase_offset = 0.f, hetero_frequency = 0.f;
     int32_t wave_type = WAVE_SIN; bool low_frequency_component_only = true;

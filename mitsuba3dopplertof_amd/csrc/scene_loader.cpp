@@ -275,9 +275,10 @@ PluginParams make_plugin_params(const PropBag &ip, const PropBag &sp) {
     else if (ip.plugin == "path") p.integrator = INTEGRATOR_PATH;           // src/integrators/path.cpp
     else if (ip.plugin == "velocity") p.integrator = INTEGRATOR_VELOCITY;   // src/integrators/velocity.cpp
     else fail("unsupported integrator plugin \"" + ip.plugin + "\" (this library implements \"dopplertofpath\", \"path\" and \"velocity\")");
-    if (sp.plugin == "independent" && p.integrator != INTEGRATOR_DOPPLER) p.independent_sampler = true;
-    else if (sp.plugin != "correlated") fail("unsupported sampler plugin \"" + sp.plugin + "\" (this library implements \"correlated\"" +
-                                             std::string(p.integrator != INTEGRATOR_DOPPLER ? " and \"independent\"" : "") + ")");
+    if (sp.plugin == "correlated") p.sampler_kind = SAMPLER_CORRELATED;
+    else if (sp.plugin == "independent") p.sampler_kind = SAMPLER_INDEPENDENT;
+    else if (sp.plugin == "timestratified") p.sampler_kind = SAMPLER_TIMESTRATIFIED;
+    else fail("unsupported sampler plugin \"" + sp.plugin + "\" (this library implements \"correlated\", \"independent\" and \"timestratified\")");
     p.time = (float) ip.get_float("time", 0.0015f);
     p.w_g_mhz = (float) ip.get_float("w_g", 30.0f);
     p.g_1 = (float) ip.get_float("g_1", 0.5f);
@@ -316,8 +317,10 @@ PluginParams make_plugin_params(const PropBag &ip, const PropBag &sp) {
     p.hide_emitters = ip.get_bool("hide_emitters", false);
     p.sample_count = (uint32_t) sp.get_int("sample_count", 4);
     p.base_seed = (uint32_t) sp.get_int("seed", 0);
-    p.time_correlate_number = p.independent_sampler ? 2 : (int32_t) sp.get_int("time_correlate_number", 2);
-    p.path_correlate_number = p.independent_sampler ? 2 : (int32_t) sp.get_int("path_correlate_number", p.time_correlate_number);
+    const bool corr = p.sampler_kind == SAMPLER_CORRELATED;
+    p.time_correlate_number = corr ? (int32_t) sp.get_int("time_correlate_number", 2) : 2;
+    p.path_correlate_number = corr ? (int32_t) sp.get_int("path_correlate_number", p.time_correlate_number) : 2;
+    if (p.sampler_kind == SAMPLER_TIMESTRATIFIED) p.jitter = sp.get_bool("jitter", true);   // timestratified.cpp:73-74
     if (p.time_correlate_number <= 0 || p.path_correlate_number <= 0) fail("correlate numbers must be positive");
     for (const PropBag *b : { &ip, &sp }) {
         auto u = b->unqueried();

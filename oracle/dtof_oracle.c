@@ -626,16 +626,28 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
 
     int correlate_pixel = p->path_correlation_depth > 0;
     const int plain = p->integrator != 0;   /* m_is_doppler_integrator == false: plain branch of render_sample */
-    float jx = sampler_draw(&smp, correlate_pixel, plain);
-    float jy = sampler_draw(&smp, correlate_pixel, plain);
+    /* one stream only: the plain branch, and every sampler but `correlated` -- Sampler::next_1d_correlate / next_2d_correlate
+     * default to next_1d / next_2d (include/mitsuba/render/sampler.h:141-144) */
+    const int single = plain || p->sampler != 0;
+    float jx = sampler_draw(&smp, correlate_pixel, single);
+    float jy = sampler_draw(&smp, correlate_pixel, single);
     float spx = posx + jx, spy = posy + jy;
     float scx = 1.f / (float) se->crop_w, scy = 1.f / (float) se->crop_h;
     float ax = fmaf(spx, scx, -(float) se->crop_x * scx), ay = fmaf(spy, scy, -(float) se->crop_y * scy);
 
     float time = se->shutter_open;
     float shutter_open_time = se->shutter_close - se->shutter_open;
-    if (shutter_open_time > 0.f)
-        time += (plain ? sampler_next_1d(&smp) : sampler_next_1d_time(&smp, p, spp)) * shutter_open_time;
+    if (shutter_open_time > 0.f) {
+        float u;
+        if (plain || p->sampler == 1) u = sampler_next_1d(&smp);          /* Sampler::next_1d_time -> next_1d (sampler.h:131-132) */
+        else if (p->sampler == 0) u = sampler_next_1d_time(&smp, p, spp);
+        else {   /* TimeStratifiedSampler::next_1d_time (timestratified.cpp:117-129); m_inv_sample_count = rcp(float(spp)) (:78-82) */
+            uint32_t q = orc_permute_kensler(smp.sample_index, spp, smp.perm_seed + smp.dim++);
+            float j = p->jitter ? sampler_next_1d(&smp) : .5f;
+            u = ((float) q + j) * (1.0f / (float) spp);
+        }
+        time += u * shutter_open_time;
+    }
 
     orc_ray ray = camera_ray(se, cx->s2c, ax, ay);
     /* dopplertofpath.cpp:93 */
@@ -700,8 +712,8 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         int active_em = active_next;   /* diffuse => BSDFFlags::Smooth */
 
         /* emitter sampling: Scene::sample_emitter_direction src/render/scene.cpp:235-291 */
-        float e1 = sampler_draw(&smp, correlate, plain);
-        float e2 = sampler_draw(&smp, correlate, plain);
+        float e1 = sampler_draw(&smp, correlate, single);
+        float e2 = sampler_draw(&smp, correlate, single);
         if (active_em && sc->n_emitters > 0) {
             uint32_t ne = (uint32_t) sc->n_emitters, idx = 0; float em_w = 1.f, sx = e1;
             if (ne > 1) {   /* sample_emitter :171-189 */
@@ -753,9 +765,9 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
             active_em = 0;
         }
 
-        float sample_1 = sampler_draw(&smp, correlate, plain); (void) sample_1;
-        float s2x = sampler_draw(&smp, correlate, plain);
-        float s2y = sampler_draw(&smp, correlate, plain);
+        float sample_1 = sampler_draw(&smp, correlate, single); (void) sample_1;
+        float s2x = sampler_draw(&smp, correlate, single);
+        float s2y = sampler_draw(&smp, correlate, single);
 
         /* BSDF::eval_pdf_sample src/render/bsdf.cpp:20-29 over twosided{diffuse} / diffuse
          * (src/bsdfs/twosided.cpp:111-148,219-258; src/bsdfs/diffuse.cpp:101-125,160-180) */
@@ -798,7 +810,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         float thr_max = f_max(f_max(thr.x, thr.y), thr.z);
         float rr_prob = f_min(thr_max * f_sqr(eta), .95f);
         int rr_active = depth >= p->rr_depth;
-        int rr_continue = sampler_draw(&smp, correlate, plain) < rr_prob;
+        int rr_continue = sampler_draw(&smp, correlate, single) < rr_prob;
         if (rr_active) { float ir = f_rcp(rr_prob); thr = v_mul(thr, ir); }
         active = active_next && (!rr_active || rr_continue) && thr_max != 0.f;
     }

@@ -104,6 +104,8 @@ typedef struct {
     int32_t time_correlate_number, path_correlate_number;
     /* 0 dopplertofpath | 1 path (src/integrators/path.cpp) | 2 velocity (src/integrators/velocity.cpp) -- SURVEY 8(f) #1 */
     int32_t integrator;
+    int32_t sampler;         /* 0 correlated | 1 independent | 2 timestratified (src/samplers/{independent,timestratified}.cpp) */
+    int32_t jitter;          /* timestratified.cpp:73 */
 } orc_params;
 
 typedef struct {

@@ -53,7 +53,7 @@ class OrcParams(C.Structure):
                 ("time_sampling", C.c_int32), ("antithetic_shift", C.c_float), ("stratify_each_interval", C.c_int32),
                 ("path_correlation_depth", C.c_uint32), ("max_depth", C.c_uint32), ("rr_depth", C.c_uint32),
                 ("hide_emitters", C.c_int32), ("base_seed", C.c_uint32),
-                ("time_correlate_number", C.c_int32), ("path_correlate_number", C.c_int32), ("integrator", C.c_int32)]
+                ("time_correlate_number", C.c_int32), ("path_correlate_number", C.c_int32), ("integrator", C.c_int32), ("sampler", C.c_int32), ("jitter", C.c_int32)]
 
 
 class OrcScene(C.Structure):

@@ -560,7 +560,8 @@ def integrator_params(ip, sp):
     kinds = {"dopplertofpath": 0, "path": 1, "velocity": 2}   # path / velocity: SURVEY 8(f) #1
     if ip.plugin not in kinds:
         raise ValueError('unsupported integrator plugin "%s"' % ip.plugin)
-    if not (sp.plugin == "correlated" or (sp.plugin == "independent" and kinds[ip.plugin] != 0)):
+    samplers = {"correlated": 0, "independent": 1, "timestratified": 2}   # src/samplers/{correlated,independent,timestratified}.cpp
+    if sp.plugin not in samplers:
         raise ValueError('unsupported sampler plugin "%s"' % sp.plugin)
     T = F32(ip.get_f("time", 0.0015))
     w_g = F32(ip.get_f("w_g", 30.0))
@@ -587,7 +588,7 @@ def integrator_params(ip, sp):
     rr_depth = ip.get_i("rr_depth", 5)
     if rr_depth <= 0:
         raise ValueError('"rr_depth" must be set to a value greater than zero!')
-    tcn = sp.get_i("time_correlate_number", 2)
+    tcn = sp.get_i("time_correlate_number", 2) if sp.plugin == "correlated" else 2
     return dict(
         time=T, w_g_mhz=w_g, g_1=g_1, g_0=g_0, w_s_mhz=w_s, phase_offset=phase, hetero_frequency=hf,
         wave_type=WAVE[wave], low_frequency_component_only=int(ip.get_b("low_frequency_component_only", True)),
@@ -596,5 +597,6 @@ def integrator_params(ip, sp):
         path_correlation_depth=ip.get_i("path_correlation_depth", 0) & 0xffffffff,
         max_depth=max_depth & 0xffffffff, rr_depth=rr_depth, hide_emitters=int(ip.get_b("hide_emitters", False)),
         base_seed=sp.get_i("seed", 0) & 0xffffffff, time_correlate_number=tcn,
-        path_correlate_number=sp.get_i("path_correlate_number", tcn),
-        sample_count=sp.get_i("sample_count", 4), integrator=kinds[ip.plugin])
+        path_correlate_number=sp.get_i("path_correlate_number", tcn) if sp.plugin == "correlated" else 2,
+        sample_count=sp.get_i("sample_count", 4), integrator=kinds[ip.plugin], sampler=samplers[sp.plugin],
+        jitter=int(sp.get_b("jitter", True)) if sp.plugin == "timestratified" else 1)

@@ -278,6 +278,12 @@ def test_full_size_properties_512x512x64(mi, orc):
     (dict(type="path", max_depth=-1, rr_depth=2), dict(type="independent", sample_count=8)),
     (dict(type="velocity"), None),
     (dict(type="velocity", time=0.003), dict(type="independent")),
+    # the Doppler integrator under the other two samplers the fork ships (sampler.h:131-144 fallbacks,
+    # src/samplers/timestratified.cpp:117-129)
+    (dict(type="dopplertofpath", max_depth=4, hetero_frequency=1.0), dict(type="independent", sample_count=8)),
+    (dict(type="dopplertofpath", max_depth=4, hetero_frequency=1.0, wave_function_type="triangular"), dict(type="timestratified")),
+    (dict(type="dopplertofpath", max_depth=3, hetero_frequency=0.0), dict(type="timestratified", jitter=False)),
+    (dict(type="path", max_depth=3), dict(type="timestratified")),
 ])
 def test_path_and_velocity_integrators_match_oracle(mi, orc, integ, sampler):
     """`path` (src/integrators/path.cpp: the same loop without the modulation weight, plain sampler draws) and `velocity`
@@ -289,7 +295,7 @@ def test_path_and_velocity_integrators_match_oracle(mi, orc, integ, sampler):
     osc = orc.Scene(path, params)
     sc.set_integrator(integ)
     if sampler is not None:
-        sc.set_sampler(sampler)     # `independent` is only accepted next to a non-Doppler integrator
+        sc.set_sampler(sampler)
     pd = osc.params(integrator=integ, sampler=sampler)
     spp, n = 8, 32 * 32 * 8
     g = sc.sample_lanes(2, spp, 0, n)
@@ -301,7 +307,12 @@ def test_path_and_velocity_integrators_match_oracle(mi, orc, integ, sampler):
     assert rel_linf(img, ref) <= IMG_TOL
     if integ["type"] == "velocity":
         assert np.array_equal(img[..., 0], img[..., 1])
-    else:
+    elif integ["type"] == "path":
         assert img.min() >= 0 and img.mean() > 0.05
-    with pytest.raises(mi.DtofError, match="offsets"):
-        sc.render(seed=0, spp=spp, offsets=[0.0, 0.5])
+    if integ["type"] != "dopplertofpath":
+        with pytest.raises(mi.DtofError, match="offsets"):
+            sc.render(seed=0, spp=spp, offsets=[0.0, 0.5])
+    if sampler is not None and sampler["type"] == "timestratified":   # one time sample per stratum and pixel
+        t = g["time"].reshape(-1, spp) / 0.0015
+        if integ["type"] == "dopplertofpath":
+            assert np.array_equal(np.sort(np.floor(t * spp).astype(int), axis=1), np.tile(np.arange(spp), (t.shape[0], 1)))

@@ -104,6 +104,8 @@ def test_error_behaviour_mirrors_the_reference_loader(mi):
     with pytest.raises(mi.DtofError, match="unsupported integrator plugin"):
         mi.load_string(text.replace('type="dopplertofpath"', 'type="volpath"'))
     with pytest.raises(mi.DtofError, match="unsupported sampler plugin"):
+        mi.load_string(text.replace('type="correlated"', 'type="ldsampler"'))
+    with pytest.raises(mi.DtofError, match="unreferenced property"):   # `independent` has no time_correlate_number (independent.cpp:70-74)
         mi.load_string(text.replace('type="correlated"', 'type="independent"'))
     with pytest.raises(mi.DtofError, match="unreferenced property"):
         mi.load_string(text.replace('<float name="w_g" value="30" />', '<float name="w_g" value="30" /><float name="bogus" value="1" />'))

@@ -222,3 +222,29 @@ def test_area_light_mis_reproduces_the_analytic_direct_illumination(orc):
         assert np.all(np.abs(got / expect - 1) < 0.05), (px, got, expect)
         checked += 1
     assert checked >= 3
+
+
+def test_independent_and_timestratified_samplers(orc):
+    """SURVEY 8(f) #4.  `independent` under the Doppler integrator = the main PCG32 stream only, uniform time
+    (sampler.h:131-144); `timestratified` = one time sample per stratum of every pixel, strata visited in a Kensler
+    permutation, jitter optional (timestratified.cpp:117-129); all other draws come from the same main stream."""
+    osc = orc.Scene(os.path.join(SCENES, "cornell_boxes.xml"), dict(resx=8, resy=8))
+    spp, n, T = 16, 8 * 8 * 16, np.float32(0.0015)
+    ind = osc.render_lanes(osc.params(sampler=dict(type="independent")), 3, spp, 0, n)
+    ts = osc.render_lanes(osc.params(sampler=dict(type="timestratified")), 3, spp, 0, n)
+    nj = osc.render_lanes(osc.params(sampler=dict(type="timestratified", jitter=False)), 3, spp, 0, n)
+    cor = osc.render_lanes(osc.params(integrator=dict(type="dopplertofpath", time_sampling_method="uniform", path_correlation_depth=0, max_depth=4)), 3, spp, 0, n)
+    # pixel jitter = the first two draws of the main stream in all of them
+    assert np.array_equal(ind["sample_pos"], ts["sample_pos"]) and np.array_equal(ind["sample_pos"], nj["sample_pos"])
+    # correlated draws BOTH streams per call and returns main when uncorrelated: x is the same first draw, y is not
+    assert np.array_equal(cor["sample_pos"][:, 0], ind["sample_pos"][:, 0])
+    for lanes, exact in ((ts, False), (nj, True)):
+        strata = np.floor(lanes["time"].reshape(-1, spp).astype(np.float64) / float(T) * spp + (1e-4 if exact else 0.0)).astype(int)
+        assert np.array_equal(np.sort(strata, axis=1), np.tile(np.arange(spp), (strata.shape[0], 1)))
+        if exact:
+            assert np.allclose(lanes["time"].reshape(-1, spp) / T * spp - strata, 0.5, atol=1e-3)
+    assert not np.array_equal(np.argsort(nj["time"].reshape(-1, spp), axis=1)[0], np.arange(spp))   # permuted, not in order
+    u = ind["time"] / T
+    assert 0.4 < u.mean() < 0.6 and u.min() >= 0 and u.max() < 1
+    for lanes in (ind, ts, nj):
+        assert np.isfinite(lanes["rgb"]).all() and (lanes["rgb"] != 0).any()
