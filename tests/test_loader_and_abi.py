@@ -159,3 +159,36 @@ def test_no_cpu_fallback_in_the_product_path():
             if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
                 text = open(os.path.join(base, f), errors="replace").read()
                 assert "import oracle" not in text and "from oracle" not in text and "dtof_oracle" not in text, f
+
+
+def test_header_is_plain_c_and_links_from_a_c_program(mi, tmp_path):
+    """The boundary is a C ABI: include/dtof.h compiles as strict C99 and a C program linked against libdtof.so can load a
+    scene and read it back (host-side calls only -- no GPU here)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "dtof.h"
+int main(int argc, char **argv) {
+    dtof_scene *sc = NULL; dtof_scene_info info; const char *n[1] = { "resx" }, *v[1] = { "40" };
+    if (argc < 2) return 2;
+    if (dtof_scene_load_file(argv[1], n, v, 1, &sc) != 0) { fprintf(stderr, "%s\n", dtof_last_error()); return 3; }
+    if (dtof_scene_get_info(sc, &info) != 0) return 4;
+    printf("%d %d %u %s\n", info.crop_width, info.crop_height, info.n_objects, dtof_version());
+    if (dtof_scene_load_file("/nonexistent.xml", NULL, NULL, 0, &sc) == 0 || strlen(dtof_last_error()) == 0) return 5;
+    dtof_scene_destroy(sc);
+    return 0;
+}
+''')
+    libdir = os.path.dirname(mi.lib_path())
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", libdir, "-ldtof", "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe), os.path.join(SCENES, "cornell_boxes.xml")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    w, h, nobj = out.stdout.split()[:3]
+    assert (int(w), int(h), int(nobj)) == (40, 256, 7)
