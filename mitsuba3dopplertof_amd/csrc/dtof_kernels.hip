@@ -29,7 +29,7 @@ constexpr int kBlock = 256;
 // ---------------------------------------------------------------------------- scene view
 struct SceneView {
     const BvhNode *nodes; const DObject *objects; const DGroup *groups; const DShape *shapes;
-    const DTri *tris; const DTriShade *shading; const DEmitter *emitters;
+    const DTri *tris; const DTriShade *shading; const DEmitter *emitters; const uint8_t *base;
     uint32_t n_nodes, n_emitters;
 };
 DTOF_D SceneView make_view(const uint8_t *base) {
@@ -42,6 +42,7 @@ DTOF_D SceneView make_view(const uint8_t *base) {
     v.tris = (const DTri *) (base + h->off_tris);
     v.shading = (const DTriShade *) (base + h->off_shading);
     v.emitters = (const DEmitter *) (base + h->off_emitters);
+    v.base = base;
     v.n_nodes = h->n_nodes; v.n_emitters = h->n_emitters;
     return v;
 }
@@ -483,6 +484,34 @@ DTOF_D V3 cosine_hemisphere(float sx, float sy) {
     float px = r * c, py = r * s;
     return mk(px, py, sqrtf(fmax_(1.f - fmaf(py, py, px * px), 0.f)));
 }
+// Mesh::sample_position (mesh.cpp:513-568): face by DiscreteDistribution::sample_reuse on sample.y (distr_1d.h:113-160,
+// dr::binary_search over [m_valid.x, m_valid.y]), point by warp::square_to_uniform_triangle (warp.h:153-156), normal from
+// the vertex normals if the mesh has them.
+DTOF_D void mesh_sample_position(const SceneView &sv, const DShape &es, float s_x, float s_y, V3 &p, V3 &n) {
+    const float *cdf = (const float *) (sv.base + es.emit_table), *pmf = cdf + es.n_tris;
+    const uint32_t *slot = (const uint32_t *) (pmf + es.n_tris);
+    const float v = s_y * es.emit_sum;
+    uint32_t lo = es.emit_lo, hi = es.emit_hi;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] < v) lo = mid + 1 < hi ? mid + 1 : hi; else hi = mid;
+    }
+    const float pm = pmf[lo] * es.inv_area, cd = lo > 0 ? cdf[lo - 1] * es.inv_area : 0.f;
+    const float y = (s_y - cd) / pm;
+    const uint32_t k = es.first_tri + slot[lo];
+    const DTri &tr = sv.tris[k];
+    V3 p0 = mk(tr.p0[0], tr.p0[1], tr.p0[2]), p1 = mk(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = mk(tr.p2[0], tr.p2[1], tr.p2[2]);
+    V3 e0 = p1 - p0, e1 = p2 - p0;
+    const float t = sqrtf(fmax_(1.f - s_x, 0.f)), bx = 1.f - t, by = t * y;
+    p = vfma(e0, bx, vfma(e1, by, p0));
+    if (!(es.flags & SF_FACE_NORMALS)) {
+        const DTriShade &ts = sv.shading[k];
+        V3 n0 = mk(ts.n0[0], ts.n0[1], ts.n0[2]), n1 = mk(ts.n1[0], ts.n1[1], ts.n1[2]), n2 = mk(ts.n2[0], ts.n2[1], ts.n2[2]);
+        n = vfma(n0, 1.f - bx - by, vfma(n1, bx, n2 * by));
+    } else n = cross(e0, e1);
+    n = normalize(n);
+    if (es.flags & SF_FLIP_NORMALS) n = -n;
+}
 DTOF_D float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
 // Block-wide exclusive prefix of a predicate (ballot + popcount per wave, 4 wave totals through LDS).
@@ -568,7 +597,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                     V3 dsd = rel * rcp(dist);
                     float em_pdf = 0.f;
                     if (depth > 0) {                                             // !prev_bsdf_delta: AreaLight::pdf_direction (area.cpp:161-180)
-                        float dp = dot(dsd, si.n);
+                        float dp = dot(dsd, si.sh_n);   // ds.n = si.sh_frame.n (PositionSample(si), records.h:63-65)
                         if (dp < 0.f) { float adp = fabsf(dp); em_pdf = sh->inv_area * (adp != 0.f ? (dist * dist) / adp : 0.f) * pmf; }
                     }
                     float mis_bsdf = mis_weight(pb.w, em_pdf);
@@ -604,8 +633,11 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                     ds_pdf = 1.f;
                 } else {
                     const DShape &es = sv.shapes[em.shape];
-                    dsp = xf_point(es.to_world, mk(sx * 2.f - 1.f, e2 * 2.f - 1.f, 0.f));
-                    V3 en = mk(es.n[0], es.n[1], es.n[2]);
+                    V3 en;
+                    if (!MESH || es.kind == SHAPE_RECT) {
+                        dsp = xf_point(es.to_world, mk(sx * 2.f - 1.f, e2 * 2.f - 1.f, 0.f));
+                        en = mk(es.n[0], es.n[1], es.n[2]);
+                    } else mesh_sample_position(sv, es, sx, e2, dsp, en);
                     dd = dsp - si.p;
                     float dist2 = dot(dd, dd);
                     ds_dist = sqrtf(dist2);

@@ -25,7 +25,7 @@ enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1 };
 struct BlobHeader {
     uint32_t n_nodes, n_objects, n_groups, n_shapes, n_tris, n_emitters;
     uint32_t off_nodes, off_objects, off_groups, off_shapes, off_tris, off_shading, off_emitters;
-    uint32_t total_bytes, has_instances, tlas_depth;   // tlas_depth: stack entries a traversal can need (TLAS depth + deepest BLAS)
+    uint32_t total_bytes, off_tables, tlas_depth;      // off_tables: face distributions of mesh emitters (float / uint32 words)   // tlas_depth: stack entries a traversal can need (TLAS depth + deepest BLAS)
 };
 static_assert(sizeof(BlobHeader) == 64, "BlobHeader");
 
@@ -52,9 +52,12 @@ struct DShape {             // 224 B
     uint32_t kind, flags, first_tri, n_tris;
     float refl[3]; uint32_t blas_root;                   // mesh: root node of its BLAS, kNoChild = loop over the triangles
     float to_world[12], to_object[12];
-    float n[3], pad1, dp_du[3], pad2, dp_dv[3], pad3;   // rectangle frame (Rectangle::update, rectangle.cpp:101-113)
-    float bmin[3], pad4, bmax[3], pad5;                 // padded bounds of the shape in ITS space (mesh: culls the triangle loop)
-    float radiance[3], inv_area;                        // SF_EMITTER: AreaLight radiance, Rectangle::m_inv_surface_area
+    // rectangle frame (Rectangle::update, rectangle.cpp:101-113).  Mesh emitters use the three spare words for the face
+    // distribution (Mesh::build_pmf, mesh.cpp:478-511): byte offset of its table in the blob = cdf[n] | pmf[n] | slot[n]
+    // (slot = position of face i in the BLAS-ordered triangle array), and m_valid = [emit_lo, emit_hi]
+    float n[3]; uint32_t emit_table; float dp_du[3]; uint32_t emit_lo; float dp_dv[3]; uint32_t emit_hi;
+    float bmin[3], emit_sum, bmax[3], pad5;             // padded bounds of the shape in ITS space (mesh: culls the triangle loop); emit_sum = float(sum of areas)
+    float radiance[3], inv_area;                        // SF_EMITTER: AreaLight radiance, 1 / area (Rectangle::m_inv_surface_area, DiscreteDistribution::normalization)
 };
 struct DTri { float p0[3]; uint32_t face; float p1[4], p2[4]; };         // 48 B; face = index in the mesh's own order (tie rule)
 struct DTriShade { float n0[3], n1[3], n2[3], uv0[2], uv1[2], uv2[2], pad; };   // 64 B

@@ -119,6 +119,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     std::vector<DShape> shapes(sc.shapes.size());
     std::vector<DTri> tris; std::vector<DTriShade> shading;
     std::vector<BvhNode> blas_nodes; uint32_t blas_depth = 0;
+    std::vector<uint32_t> tables;   // mesh emitters: cdf[n] | pmf[n] (float bits) | slot[n]
     const char *blas_env = getenv("DTOF_BLAS"); const bool use_blas = !(blas_env && blas_env[0] == '0');   // DTOF_BLAS=0: loop over every triangle (debug)
     std::vector<Box> shape_boxes(sc.shapes.size());
     for (size_t i = 0; i < sc.shapes.size(); ++i) {
@@ -150,6 +151,8 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
                 }
                 tris.push_back(t); shading.push_back(s);
             }
+            std::vector<uint32_t> slot_of_face(d.n_tris);
+            for (uint32_t f = 0; f < d.n_tris; ++f) slot_of_face[f] = f;
             if (use_blas && d.n_tris > kBlasMinTris) {
                 std::vector<BuildItem> items(d.n_tris);
                 for (uint32_t f = 0; f < d.n_tris; ++f) {
@@ -163,6 +166,26 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
                 std::vector<DTri> t2(d.n_tris); std::vector<DTriShade> s2(d.n_tris);
                 for (uint32_t f = 0; f < d.n_tris; ++f) { t2[f] = tris[d.first_tri + items[f].obj]; s2[f] = shading[d.first_tri + items[f].obj]; }
                 std::copy(t2.begin(), t2.end(), tris.begin() + d.first_tri); std::copy(s2.begin(), s2.end(), shading.begin() + d.first_tri);
+                for (uint32_t f = 0; f < d.n_tris; ++f) slot_of_face[items[f].obj] = f;
+            }
+            if (h.emitter) {   // Mesh::build_pmf (mesh.cpp:478-511) + DiscreteDistribution::compute_cdf (distr_1d.h:205-240)
+                if (d.n_tris == 0) throw std::runtime_error("Cannot create sampling table for an empty mesh");
+                std::vector<float> pmf(d.n_tris), cdf(d.n_tris);
+                double sum = 0.0; int64_t lo = -1, hi = -1;
+                for (uint32_t f = 0; f < d.n_tris; ++f) {
+                    const uint32_t *fi = &h.faces[3 * f]; const float *P = h.positions.data();
+                    V3 p0 = mk(P[3 * fi[0]], P[3 * fi[0] + 1], P[3 * fi[0] + 2]), p1 = mk(P[3 * fi[1]], P[3 * fi[1] + 1], P[3 * fi[1] + 2]),
+                       p2 = mk(P[3 * fi[2]], P[3 * fi[2] + 1], P[3 * fi[2] + 2]);
+                    pmf[f] = .5f * norm(cross(p1 - p0, p2 - p0));
+                    sum += (double) pmf[f]; cdf[f] = (float) sum;
+                    if (pmf[f] > 0.f) { if (lo < 0) lo = f; hi = f; }
+                }
+                if (lo < 0) throw std::runtime_error("DiscreteDistribution: no probability mass found!");
+                d.emit_table = (uint32_t) tables.size() * 4u;   // rebased to a blob offset below
+                d.emit_lo = (uint32_t) lo; d.emit_hi = (uint32_t) hi; d.emit_sum = (float) sum; d.inv_area = (float) (1.0 / sum);
+                for (float v : cdf) { uint32_t b; memcpy(&b, &v, 4); tables.push_back(b); }
+                for (float v : pmf) { uint32_t b; memcpy(&b, &v, 4); tables.push_back(b); }
+                tables.insert(tables.end(), slot_of_face.begin(), slot_of_face.end());
             }
         }
         shape_boxes[i] = shape_box(h);
@@ -227,7 +250,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     BlobHeader h; memset(&h, 0, sizeof h);
     h.n_nodes = (uint32_t) nodes.size(); h.n_objects = (uint32_t) objects.size(); h.n_groups = (uint32_t) groups.size();
     h.n_shapes = (uint32_t) shapes.size(); h.n_tris = (uint32_t) tris.size(); h.n_emitters = (uint32_t) emitters.size();
-    h.has_instances = has_instances;
+    (void) has_instances;
     {   // deepest leaf below the root = stack entries a depth-first traversal can hold
         uint32_t deepest = 1;
         std::vector<std::pair<uint32_t, uint32_t>> todo; if (tlas_nodes) todo.emplace_back(0u, 1u);
@@ -247,7 +270,9 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     h.off_emitters = off; off = align16(off + (uint32_t) (emitters.size() * sizeof(DEmitter)));
     h.off_tris = off;     off = align16(off + (uint32_t) (tris.size() * sizeof(DTri)));
     h.off_shading = off;  off = align16(off + (uint32_t) (shading.size() * sizeof(DTriShade)));
+    h.off_tables = off;   off = align16(off + (uint32_t) (tables.size() * 4));
     h.total_bytes = off;
+    for (DShape &d : shapes) if (d.kind == SHAPE_MESH && (d.flags & SF_EMITTER)) d.emit_table += h.off_tables;
     std::vector<uint8_t> blob(off, 0);
     memcpy(blob.data(), &h, sizeof h);
     if (!nodes.empty()) memcpy(blob.data() + h.off_nodes, nodes.data(), nodes.size() * sizeof(BvhNode));
@@ -257,6 +282,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     if (!emitters.empty()) memcpy(blob.data() + h.off_emitters, emitters.data(), emitters.size() * sizeof(DEmitter));
     if (!tris.empty()) memcpy(blob.data() + h.off_tris, tris.data(), tris.size() * sizeof(DTri));
     if (!shading.empty()) memcpy(blob.data() + h.off_shading, shading.data(), shading.size() * sizeof(DTriShade));
+    if (!tables.empty()) memcpy(blob.data() + h.off_tables, tables.data(), tables.size() * 4);
     return blob;
 }
 

@@ -607,6 +607,44 @@ static float rect_inv_area(const orc_shape *sh) {
     v3 du = m_vector(sh->to_world, V(2.f, 0.f, 0.f)), dv = m_vector(sh->to_world, V(0.f, 2.f, 0.f));
     return f_rcp(v_norm(v_cross(du, dv)));
 }
+static float shape_inv_area(const orc_shape *sh) { return sh->kind == ORC_SHAPE_RECT ? rect_inv_area(sh) : sh->area_norm; }
+/* DiscreteDistribution::sample_reuse (distr_1d.h:113-160): first face in [lo, hi] whose cdf is not < value * sum
+ * (dr::binary_search), then the sample re-stretched over that face's interval */
+static uint32_t mesh_sample_face(const orc_shape *sh, float value, float *reuse) {
+    float v = value * sh->area_sum;
+    int32_t lo = sh->area_lo, hi = sh->area_hi;
+    while (lo < hi) {
+        int32_t mid = (int32_t) (((uint32_t) lo + (uint32_t) hi) >> 1);
+        if (sh->area_cdf[mid] < v) lo = mid + 1 < hi ? mid + 1 : hi; else hi = mid;
+    }
+    float pmf = sh->area_pmf[lo] * sh->area_norm;
+    float cdf = lo > 0 ? sh->area_cdf[lo - 1] * sh->area_norm : 0.f;
+    *reuse = (value - cdf) / pmf;
+    return (uint32_t) lo;
+}
+/* Mesh::sample_position (mesh.cpp:513-568) + warp::square_to_uniform_triangle (warp.h:153-156) */
+static void mesh_sample_position(const orc_shape *sh, float s_x, float s_y, v3 *p_out, v3 *n_out) {
+    float y;
+    uint32_t f = mesh_sample_face(sh, s_y, &y);
+    const uint32_t *fi = sh->faces + 3 * (size_t) f;
+    const float *P = sh->positions;
+    v3 p0 = V(P[3 * fi[0]], P[3 * fi[0] + 1], P[3 * fi[0] + 2]), p1 = V(P[3 * fi[1]], P[3 * fi[1] + 1], P[3 * fi[1] + 2]),
+       p2 = V(P[3 * fi[2]], P[3 * fi[2] + 1], P[3 * fi[2] + 2]);
+    v3 e0 = v_sub(p1, p0), e1 = v_sub(p2, p0);
+    float t = sqrtf(f_max(1.f - s_x, 0.f));
+    float bx = 1.f - t, by = t * y;
+    *p_out = v_fma(e0, bx, v_fma(e1, by, p0));
+    v3 n;
+    if (sh->normals && !sh->face_normals) {
+        const float *N = sh->normals;
+        v3 n0 = V(N[3 * fi[0]], N[3 * fi[0] + 1], N[3 * fi[0] + 2]), n1 = V(N[3 * fi[1]], N[3 * fi[1] + 1], N[3 * fi[1] + 2]),
+           n2 = V(N[3 * fi[2]], N[3 * fi[2] + 1], N[3 * fi[2] + 2]);
+        n = v_fma(n0, 1.f - bx - by, v_fma(n1, bx, v_mul(n2, by)));
+    } else n = v_cross(e0, e1);
+    n = v_normalize(n);
+    if (sh->flip_normals) n = v_neg(n);
+    *n_out = n;
+}
 /* mis_weight -- dopplertofpath.cpp:296-301 */
 static inline float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
@@ -693,10 +731,10 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
             v3 dsd = v_mul(rel, f_rcp(dist));
             float em_pdf = 0.f;
             if (!prev_delta) {   /* Scene::pdf_emitter_direction scene.cpp:293-299 -> AreaLight::pdf_direction area.cpp:161-180 */
-                float dp = v_dot(dsd, si.n);
-                if (dp < 0.f) {   /* Shape::pdf_direction shape.cpp:386-396, Rectangle::pdf_position = 1/area */
+                float dp = v_dot(dsd, si.sh_n);   /* ds.n = si.sh_frame.n: PositionSample(si), records.h:63-65 */
+                if (dp < 0.f) {   /* Shape::pdf_direction shape.cpp:386-396; pdf_position = 1/area (rectangle.cpp:168-171, mesh.cpp:570-573) */
                     float adp = fabsf(dp);
-                    float pdf = rect_inv_area(si.shape) * (adp != 0.f ? (dist * dist) / adp : 0.f);
+                    float pdf = shape_inv_area(si.shape) * (adp != 0.f ? (dist * dist) / adp : 0.f);
                     em_pdf = pdf * pmf;
                 }
             }
@@ -737,14 +775,17 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
                 /* AreaLight::sample_direction area.cpp:116-159 -> Shape::sample_direction shape.cpp:370-384 ->
                  * Rectangle::sample_position rectangle.cpp:152-166 */
                 const orc_shape *es = &sc->shapes[em->shape];
-                dsp = m_point(es->to_world, V(sx * 2.f - 1.f, e2 * 2.f - 1.f, 0.f));
-                v3 en = v_normalize(m_normal(es->to_object, V(0.f, 0.f, 1.f)));
+                v3 en;
+                if (es->kind == ORC_SHAPE_RECT) {
+                    dsp = m_point(es->to_world, V(sx * 2.f - 1.f, e2 * 2.f - 1.f, 0.f));
+                    en = v_normalize(m_normal(es->to_object, V(0.f, 0.f, 1.f)));
+                } else mesh_sample_position(es, sx, e2, &dsp, &en);
                 dd = v_sub(dsp, si.p);
                 float dist2 = v_dot(dd, dd);
                 ds_dist = sqrtf(dist2);
                 dd = v_mul(dd, f_rcp(ds_dist));
                 float dp = fabsf(v_dot(dd, en)), x = dist2 / dp;
-                ds_pdf = rect_inv_area(es) * (isfinite(x) ? x : 0.f);
+                ds_pdf = shape_inv_area(es) * (isfinite(x) ? x : 0.f);
                 ds_delta = 0;
                 em_active = v_dot(dd, en) < 0.f && ds_pdf != 0.f;
                 float ip = f_rcp(ds_pdf);
@@ -1008,4 +1049,24 @@ void orc_bake_mesh(const float *to_world, const float *to_object, int32_t n_vert
         else { nrm_out[3 * i] = 1.f; nrm_out[3 * i + 1] = 0.f; nrm_out[3 * i + 2] = 0.f; }
     }
     free(acc);
+}
+
+/* Mesh::build_pmf + DiscreteDistribution::compute_cdf -- see the header */
+int orc_mesh_area_table(const float *P, int32_t n_faces, const uint32_t *faces, float *pmf, float *cdf,
+                        float *sum_out, float *norm_out, int32_t *lo, int32_t *hi) {
+    if (n_faces <= 0) return -1;
+    double sum = 0.0; *lo = -1; *hi = -1;
+    for (int32_t i = 0; i < n_faces; ++i) {
+        const uint32_t *fi = faces + 3 * (size_t) i;
+        v3 p0 = V(P[3 * fi[0]], P[3 * fi[0] + 1], P[3 * fi[0] + 2]), p1 = V(P[3 * fi[1]], P[3 * fi[1] + 1], P[3 * fi[1] + 2]),
+           p2 = V(P[3 * fi[2]], P[3 * fi[2] + 1], P[3 * fi[2] + 2]);
+        pmf[i] = .5f * v_norm(v_cross(v_sub(p1, p0), v_sub(p2, p0)));
+        double value = (double) pmf[i];
+        sum += value;
+        cdf[i] = (float) sum;
+        if (value > 0.0) { if (*lo < 0) *lo = i; *hi = i; }
+    }
+    if (*lo < 0) return -1;
+    *sum_out = (float) sum; *norm_out = (float) (1.0 / sum);
+    return 0;
 }

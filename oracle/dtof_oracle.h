@@ -47,9 +47,14 @@ typedef struct {
     const float    *normals;    /* n_vertices*3 or NULL */
     const float    *texcoords;  /* n_vertices*2 or NULL */
     const uint32_t *faces;      /* n_faces*3 */
-    /* area emitter attached to this (static, top-level rectangle) shape: src/emitters/area.cpp */
+    /* area emitter attached to this (static, top-level) shape: src/emitters/area.cpp */
     int32_t emitter;            /* 0 / 1 */
     float   radiance[3];
+    /* mesh emitters: Mesh::build_pmf (mesh.cpp:478-511) -> DiscreteDistribution over the faces (distr_1d.h:20-240),
+     * filled by orc_mesh_area_table */
+    const float *area_pmf, *area_cdf;   /* n_faces each */
+    float   area_sum, area_norm;        /* float(sum), float(1 / sum) */
+    int32_t area_lo, area_hi;           /* m_valid: first / last face with non-zero area */
 } orc_shape;
 
 typedef struct {
@@ -178,6 +183,12 @@ void     orc_bake_cube(const float *to_world, const float *to_object, float *pos
 void     orc_bake_mesh(const float *to_world, const float *to_object, int32_t n_vertices, const float *pos_in,
                        const float *nrm_in, int32_t n_faces, const uint32_t *faces, int32_t face_normals,
                        float *pos_out, float *nrm_out);
+
+/* Mesh::build_pmf + DiscreteDistribution::compute_cdf (mesh.cpp:478-511, distr_1d.h:205-240): pmf[i] = .5 |e0 x e1| in
+ * float32, running sum in double, cdf[i] = float(sum), sum / normalization rounded to float32 once. Returns 0 on success,
+ * -1 for an empty mesh / no probability mass. */
+int      orc_mesh_area_table(const float *positions, int32_t n_faces, const uint32_t *faces, float *pmf, float *cdf,
+                             float *sum, float *norm, int32_t *lo, int32_t *hi);
 
 #ifdef __cplusplus
 }

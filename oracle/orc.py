@@ -22,7 +22,9 @@ class OrcShape(C.Structure):
                 ("n_vertices", C.c_int32), ("n_faces", C.c_int32),
                 ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
                 ("texcoords", C.POINTER(C.c_float)), ("faces", C.POINTER(C.c_uint32)),
-                ("emitter", C.c_int32), ("radiance", C.c_float * 3)]
+                ("emitter", C.c_int32), ("radiance", C.c_float * 3),
+                ("area_pmf", C.POINTER(C.c_float)), ("area_cdf", C.POINTER(C.c_float)),
+                ("area_sum", C.c_float), ("area_norm", C.c_float), ("area_lo", C.c_int32), ("area_hi", C.c_int32)]
 
 
 class OrcGroup(C.Structure):
@@ -118,6 +120,8 @@ def lib():
         L.orc_render.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_int]
         L.orc_bake_cube.argtypes = [C.c_void_p] * 6
+        L.orc_mesh_area_table.restype = C.c_int
+        L.orc_mesh_area_table.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_bake_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                     C.c_void_p, C.c_void_p]
         _LIB = L
@@ -189,6 +193,17 @@ class Scene:
                 o.normals = nrm.ctypes.data_as(C.POINTER(C.c_float))
                 o.texcoords = uv.ctypes.data_as(C.POINTER(C.c_float))
                 o.faces = faces.ctypes.data_as(C.POINTER(C.c_uint32))
+            if s["kind"] == 1 and o.emitter:   # Mesh::build_pmf (mesh.cpp:478-511)
+                nf = int(o.n_faces)
+                pmf, cdf = np.zeros(max(nf, 1), np.float32), np.zeros(max(nf, 1), np.float32)
+                sm, nm, lo, hi = C.c_float(0), C.c_float(0), C.c_int32(0), C.c_int32(0)
+                if L.orc_mesh_area_table(s["positions"].ctypes.data, nf, s["faces"].ctypes.data, pmf.ctypes.data, cdf.ctypes.data,
+                                         C.byref(sm), C.byref(nm), C.byref(lo), C.byref(hi)) != 0:
+                    raise ValueError("DiscreteDistribution: no probability mass found!")
+                self._keep += [pmf, cdf]
+                s["area_pmf"], s["area_cdf"] = pmf, cdf
+                o.area_pmf, o.area_cdf = pmf.ctypes.data_as(C.POINTER(C.c_float)), cdf.ctypes.data_as(C.POINTER(C.c_float))
+                o.area_sum, o.area_norm, o.area_lo, o.area_hi = sm.value, nm.value, lo.value, hi.value
         groups = (OrcGroup * max(1, len(fs.groups)))()
         for i, g in enumerate(fs.groups):
             groups[i].first_shape, groups[i].n_shapes = g["first_shape"], g["n_shapes"]

@@ -361,11 +361,11 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
     bsdfs = [c for c in sp.children if c[0] == "bsdf" or (c[0] == "ref" and registry[c[1]][0] == "bsdf")]
     ems = [c[1] for c in sp.children if c[0] == "emitter"]
     emitter, radiance = 0, np.zeros(3, F32)
-    if ems:   # src/emitters/area.cpp:64-76 on a static rectangle
+    if ems:   # src/emitters/area.cpp:64-76 on a static shape (rectangle or triangle mesh)
         if len(ems) > 1:
             raise ValueError("Only a single Emitter child object can be specified per shape.")
-        if ems[0].plugin != "area" or kind != 0 or strip_to_world:
-            raise ValueError("only area emitters on static rectangles are supported")
+        if ems[0].plugin != "area" or strip_to_world:
+            raise ValueError("only area emitters on static shapes are supported")
         if "to_world" in ems[0]:
             raise ValueError("Found a 'to_world' transformation -- this is not allowed.")
         rad = ems[0]["radiance"] if "radiance" in ems[0] else ("float", 1.0)

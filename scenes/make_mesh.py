@@ -119,6 +119,31 @@ def cornell_mesh_xml(static_file="blob.ply", moving_file="blob.obj", res=128, sp
     return s + ms.LIGHT + "</scene>\n"
 
 
+def mesh_light(plugin, filename, scale, translate, radiance="17, 12, 4", extra=""):
+    return ('\t<shape type="%s" id="Light">\n\t\t<string name="filename" value="%s" />\n%s\t\t<transform name="to_world">\n'
+            '\t\t\t<scale x="%s" y="%s" z="%s" />\n\t\t\t<translate x="%s" y="%s" z="%s" />\n\t\t</transform>\n'
+            '\t\t<emitter type="area">\n\t\t\t<rgb name="radiance" value="%s" />\n\t\t</emitter>\n\t</shape>\n'
+            % ((plugin, filename, extra) + tuple(scale) + tuple(translate) + (radiance,)))
+
+
+def cornell_mesh_light_xml(light_file="blob.ply", plugin="ply", res=64, spp=16, extra="", scale=("0.25", "0.08", "0.2"),
+                           translate=("0", "1.8", "0")):
+    """the Cornell room with its two moving boxes, lit by a MESH area light (a flattened blob under the ceiling)"""
+    s = ms.HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + ms.SENSOR.format(fov="19.5", cam=ms.CAM)
+    for b in ms.BSDFS:
+        s += ms.bsdf(*b)
+    for name, m, b in ms.WALLS:
+        s += ms.rect(name, m, b)
+    s += ms.cube("ShortBox", ms.SHORT, "ShortBoxBSDF", "0.015") + ms.cube("TallBox", ms.TALL, "TallBoxBSDF", "-0.015")
+    return s + mesh_light(plugin, light_file, scale, translate, extra=extra) + "</scene>\n"
+
+
+def quad_obj(path):
+    """the unit square [-1,1]^2 in the xy plane, normal +z, as two triangles (same footprint as a `rectangle`)"""
+    with open(path, "w") as f:
+        f.write("v -1 -1 0\nv 1 -1 0\nv 1 1 0\nv -1 1 0\nf 1 2 3\nf 1 3 4\n")
+
+
 def write_all(out_dir, n_u=24, n_v=12):
     os.makedirs(out_dir, exist_ok=True)
     pos, nrm, uv, faces = blob(n_u, n_v)
@@ -129,6 +154,9 @@ def write_all(out_dir, n_u=24, n_v=12):
     write_ply(os.path.join(out_dir, "blob_be.ply"), pos, nrm, uv, faces, big_endian=True)
     with open(os.path.join(out_dir, "cornell_mesh.xml"), "w") as f:
         f.write(cornell_mesh_xml())
+    with open(os.path.join(out_dir, "cornell_mesh_light.xml"), "w") as f:
+        f.write(cornell_mesh_light_xml())
+    quad_obj(os.path.join(out_dir, "quad.obj"))
     return len(faces)
 
 

@@ -178,3 +178,53 @@ def test_blas_equals_the_loop_over_all_triangles_on_a_large_mesh(mi, orc, tmp_pa
     m = 2048
     o = osc.render_lanes(osc.params(), 5, 4, 6000, m, threads=NCPU)
     assert np.array_equal(bits(a["rgb"][6000:6000 + m]), bits(o["rgb"]))
+
+
+# ------------------------------------------------------------------------------------------------ mesh area emitters
+def test_quad_mesh_light_equals_the_rectangle_light_in_expectation(orc, mesh_dir):
+    """Mesh::sample_position / pdf (mesh.cpp:478-573) against Rectangle's: the same square light once as a `rectangle`, once
+    as a two-triangle obj mesh -- different sampling code, same integrand; the face table is the DiscreteDistribution
+    of distr_1d.h:205-240."""
+    from conftest import SCENES
+    area = open(os.path.join(SCENES, "cornell_area.xml")).read()
+    quad = area.replace('<shape type="rectangle" id="Light">', '<shape type="obj" id="Light">\n\t\t<string name="filename" value="quad.obj" />')
+    assert quad != area
+    path = os.path.join(mesh_dir, "area_quad.xml")
+    open(path, "w").write(quad)
+    P, integ = dict(resx=16, resy=16), dict(type="path", max_depth=4)
+    a, b = orc.Scene(os.path.join(SCENES, "cornell_area.xml"), P), orc.Scene(path, P)
+    light = [s for s in b.flat.shapes if s["kind"] == 1][-1]
+    assert np.allclose(light["area_pmf"], [0.1, 0.1]) and np.allclose(light["area_cdf"], [0.1, 0.2])   # 0.5 x 0.4 square, two halves
+    ia = np.mean([a.render(a.params(integrator=integ), seed=s, spp=256, threads=NCPU)[0] for s in range(3)], axis=0)
+    ib = np.mean([b.render(b.params(integrator=integ), seed=s, spp=256, threads=NCPU)[0] for s in range(3)], axis=0)
+    assert abs(ia.mean() - ib.mean()) < 0.01 * ia.mean()
+    assert np.abs(ia - ib).mean() < 0.05 * ia.mean()
+
+
+LIGHT_CASES = [("blob_ply_normals", dict(), dict(resx=32, resy=32), 8),
+               ("blob_obj_computed_normals", dict(light_file="blob.obj", plugin="obj"), dict(resx=24, resy=24, max_depth=6, time_sampling_method="stratified"), 8),
+               ("blob_face_normals_flipped", dict(extra='\t\t<boolean name="face_normals" value="true" />\n'), dict(resx=24, resy=24), 4),
+               ("quad_obj", dict(light_file="quad.obj", plugin="obj", scale=("0.25", "0.2", "1"), translate=("0", "1.0", "-0.95")), dict(resx=24, resy=24), 8)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw,params,spp", LIGHT_CASES, ids=[c[0] for c in LIGHT_CASES])
+def test_mesh_area_lights_are_bit_exact_per_lane(mi, orc, mesh_dir, name, kw, params, spp):
+    path = os.path.join(mesh_dir, "light_" + name + ".xml")
+    open(path, "w").write(make_mesh.cornell_mesh_light_xml(**kw))
+    sc, osc = mi.load_file(path, **params), orc.Scene(path, params)
+    assert sc.info()["n_emitters"] == 1
+    w, h = sc.size
+    n = w * h * spp
+    for integ in (None, dict(type="path", max_depth=5)):
+        if integ:
+            sc.set_integrator(integ)
+        pd = osc.params(integrator=integ) if integ else osc.params()
+        g = sc.sample_lanes(4, spp, 0, n)
+        o = osc.render_lanes(pd, 4, spp, 0, n, threads=NCPU)
+        for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+            assert np.array_equal(bits(g[k]), bits(o[k])), (name, integ, k, int((bits(g[k]) != bits(o[k])).sum()))
+        assert (g["rgb"] != 0).mean() > 0.3
+    img = sc.render(seed=4, spp=spp)
+    ref, _ = osc.render(pd, seed=4, spp=spp, threads=NCPU)
+    assert float(np.abs(img - ref).max() / np.abs(ref).max()) <= 1e-5
