@@ -91,6 +91,10 @@ typedef struct {
     double   ms_generate, ms_trace, ms_shade, ms_shadow, ms_splat;   /* per-stage sums (HIP events) */
     uint32_t n_launches_trace, n_launches_shade, n_launches_shadow;
     uint32_t n_batches;
+    /* fused pipeline: the first-bounce launches (lane generation + primary ray + bounce 0 in one kernel) are also counted
+     * in ms_shade / n_launches_shade; these two fields single them out */
+    uint32_t n_launches_first;
+    double   ms_first;
 } dtof_render_stats;
 
 /* out_rgb: caller-owned host buffer, crop_height*crop_width*3 float32, developed (RGB / W). */

@@ -35,7 +35,7 @@ class _Stats(C.Structure):
                 ("ms_total", C.c_double), ("ms_generate", C.c_double), ("ms_trace", C.c_double),
                 ("ms_shade", C.c_double), ("ms_shadow", C.c_double), ("ms_splat", C.c_double),
                 ("n_launches_trace", C.c_uint32), ("n_launches_shade", C.c_uint32), ("n_launches_shadow", C.c_uint32),
-                ("n_batches", C.c_uint32)]
+                ("n_batches", C.c_uint32), ("n_launches_first", C.c_uint32), ("ms_first", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -55,7 +55,7 @@ class _Info(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libdtof.so")
+    return os.environ.get("DTOF_LIB") or os.path.join(_HERE, "libdtof.so")   # DTOF_LIB: A/B timing of two builds (tools/ab_time.sh)
 
 
 def _lib():

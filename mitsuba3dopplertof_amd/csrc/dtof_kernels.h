@@ -72,7 +72,7 @@ void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
 void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                   const uint32_t *qin, const uint32_t *count_in, uint32_t *qout,
                   uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, bool fused, bool trace_next,
-                  uint32_t stack_depth, hipStream_t s);
+                  uint32_t stack_depth, hipStream_t s, bool first = false, LaneDebug *dbg = nullptr);   // first: generate + primary trace inline (fused only)
 void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                    const uint32_t *count_in, uint32_t stack_depth, hipStream_t s);
 void launch_velocity(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q, uint32_t stack_depth, hipStream_t s);

@@ -21,6 +21,8 @@
 #include "dtof_scene.h"
 #include "dtof_math.h"
 
+#include <stdexcept>
+
 namespace dtof {
 
 #define DTOF_D __device__ __forceinline__
@@ -310,10 +312,9 @@ DTOF_D float modulation_weight(const RenderParams &rp, float phase, float ray_ti
 }
 
 // ---------------------------------------------------------------------------- generate
-__global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) {
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= rp.n_lanes) return;
-    uint32_t lane = rp.lane_base + i;
+// One lane of render_sample's head (integrator.cpp:476-495 / :416-431): sampler seeding, pixel jitter, time sample, camera ray.
+struct PrimaryLane { float4 ray_a, ray_b; Rng main, path; float2 pos; };
+DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane) {
     Rng main = seed_stream(rp.seed_value, lane);
     Rng tm = seed_stream(rp.seed_value + 1, lane / rp.tcn);
     Rng path = seed_stream(rp.seed_value + 2, lane / rp.pcn);
@@ -361,12 +362,22 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) 
     float maxt = far_t - near_t;
     if (doppler) time = time < rp.T ? time : time - rp.T;   // dopplertofpath.cpp:93
 
-    q.ray_a[i] = make_float4(o.x, o.y, o.z, time);
-    q.ray_b[i] = make_float4(dw.x, dw.y, dw.z, maxt);
+    PrimaryLane pl;
+    pl.ray_a = make_float4(o.x, o.y, o.z, time);
+    pl.ray_b = make_float4(dw.x, dw.y, dw.z, maxt);
+    pl.main = main; pl.path = path; pl.pos = make_float2(spx, spy);
+    return pl;
+}
+__global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= rp.n_lanes) return;
+    const PrimaryLane pl = generate_lane(rp, rp.lane_base + i);
+    q.ray_a[i] = pl.ray_a;
+    q.ray_b[i] = pl.ray_b;
     q.st_a[i] = make_float4(1.f, 1.f, 1.f, 0.f);
-    q.rng_a[i] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
-    q.rng_b[i] = make_uint2((uint32_t) (main.inc >> 1), (uint32_t) (path.inc >> 1));
-    q.pos[i] = make_float2(spx, spy);
+    q.rng_a[i] = make_uint4((uint32_t) pl.main.state, (uint32_t) (pl.main.state >> 32), (uint32_t) pl.path.state, (uint32_t) (pl.path.state >> 32));
+    q.rng_b[i] = make_uint2((uint32_t) (pl.main.inc >> 1), (uint32_t) (pl.path.inc >> 1));
+    q.pos[i] = pl.pos;
     for (int k = 0; k < rp.n_offsets; ++k) q.res[(size_t) k * q.capacity + i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
@@ -542,11 +553,15 @@ DTOF_D uint32_t block_append(bool pred, uint32_t *s_cnt, uint32_t &running) {
 //                 scenes and the shadow records alone cost 96 B per path-bounce).
 // AREA: the scene has area emitters (emitter-hit term, prev_si state).  KMAX: compile-time bound of the batched offsets (1 or 4);
 // both keep the common case -- point lights, one offset -- free of the extra registers.
-template <bool LDS, bool FUSED, bool AREA, int KMAX, bool MESH>
+// MODE 0 = split, 1 = fused, 2 = fused AND first bounce: the lane is generated (sampler seeding, camera ray) and its primary
+// ray traced right here, so the 96-byte primary state never makes the round trip through HBM and neither k_generate nor the
+// primary k_trace launch exists (`dbg`, if given, receives the camera ray for the lane-dump entry point).
+template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp, Queues q,
                                                   const uint32_t *qin, const uint32_t *count_in,
                                                   uint32_t *qout, uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth,
-                                                  uint32_t trace_next) {
+                                                  uint32_t trace_next, LaneDebug *dbg) {
+    constexpr bool FUSED = MODE != 0, FIRST = MODE == 2;
     extern __shared__ uint4 lds[];
     __shared__ uint32_t s_cnt[4];
     uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
@@ -562,16 +577,37 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
     bool alive = false, want_shadow = false;
     uint32_t l = 0;
     float4 sha, shb, nra, nrb; float3 cand[KMAX];
+    float3 rbase[KMAX];   // FIRST: the result a lane ends this launch with if its NEE candidate is not committed
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) rbase[k] = make_float3(0.f, 0.f, 0.f);
     if (in_range) {
         l = qin ? qin[seg * kSeg + j] : seg * kSeg + j;
-        uint32_t hid = q.hit_id[l];
+        uint32_t hid; float4 ra, rb, st; uint4 hh; Rng main, path;
+        if (FIRST) {
+            const PrimaryLane pl = generate_lane(rp, rp.lane_base + l);
+            ra = pl.ray_a; rb = pl.ray_b; main = pl.main; path = pl.path; st = make_float4(1.f, 1.f, 1.f, 0.f);
+            q.pos[l] = pl.pos;
+            q.rng_b[l] = make_uint2((uint32_t) (main.inc >> 1), (uint32_t) (path.inc >> 1));
+            if (dbg) {
+                LaneDebug &o = dbg[l];
+                o.time = ra.w; o.ray_o[0] = ra.x; o.ray_o[1] = ra.y; o.ray_o[2] = ra.z; o.ray_d[0] = rb.x; o.ray_d[1] = rb.y; o.ray_d[2] = rb.z;
+            }
+            Hit h;
+            bool found = trace_scene<false, MESH>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
+            hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
+            hid = found ? (h.obj | (h.shape << 24)) : 0xffffffffu;
+        } else {
+            hid = q.hit_id[l];
+            if (hid != 0xffffffffu) {
+                ra = q.ray_a[l]; rb = q.ray_b[l]; hh = q.hit[l]; st = q.st_a[l];
+                const uint4 rs = q.rng_a[l]; const uint2 ri = q.rng_b[l];
+                main.state = (uint64_t) rs.x | ((uint64_t) rs.y << 32); main.inc = ((uint64_t) ri.x << 1) | 1u;
+                path.state = (uint64_t) rs.z | ((uint64_t) rs.w << 32); path.inc = ((uint64_t) ri.y << 1) | 1u;
+            }
+        }
         if (hid != 0xffffffffu) {   // a miss ends the path (active_next = false, dopplertofpath.cpp:171)
-            float4 ra = q.ray_a[l], rb = q.ray_b[l]; uint4 hh = q.hit[l]; float4 st = q.st_a[l]; uint4 rs = q.rng_a[l]; uint2 ri = q.rng_b[l];
             V3 o = mk(ra.x, ra.y, ra.z), d = mk(rb.x, rb.y, rb.z); float time = ra.w;
             V3 thr = mk(st.x, st.y, st.z); float path_length = st.w;
-            Rng main, path;
-            main.state = (uint64_t) rs.x | ((uint64_t) rs.y << 32); main.inc = ((uint64_t) ri.x << 1) | 1u;
-            path.state = (uint64_t) rs.z | ((uint64_t) rs.w << 32); path.inc = ((uint64_t) ri.y << 1) | 1u;
             bool correlate = (depth + 1) < rp.path_correlation_depth;
             const bool plain = rp.integrator != 0;   // `path`: no modulation weight
             const bool single = plain || rp.sampler_kind != SAMPLER_CORRELATED;   // main stream only (path.cpp:197,213-214,273; sampler.h:141-144)
@@ -589,7 +625,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             float4 rcur[KMAX];
             if (AREA) {
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) rcur[k] = q.res[(size_t) k * q.capacity + l];
+                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) rcur[k] = FIRST ? make_float4(0.f, 0.f, 0.f, 0.f) : q.res[(size_t) k * q.capacity + l];
                 if (sh->flags & SF_EMITTER) {
                     float4 pb = depth > 0 ? q.st_b[l] : make_float4(0.f, 0.f, 0.f, 1.f);   // prev_si.p, prev_bsdf_pdf
                     V3 rel = si.p - mk(pb.x, pb.y, pb.z);                      // DirectionSample(scene, si, prev_si), records.h:173-180
@@ -683,7 +719,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 bool nonzero = false;
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
-                    float4 r = AREA ? rcur[k] : q.res[(size_t) k * q.capacity + l];
+                    float4 r = AREA ? rcur[k] : (FIRST ? make_float4(0.f, 0.f, 0.f, 0.f) : q.res[(size_t) k * q.capacity + l]);
                     V3 v = mk(bsdf_val.x * em_weight.x * mis_em, bsdf_val.y * em_weight.y * mis_em, bsdf_val.z * em_weight.z * mis_em);
                     if (!plain) { float lw = modulation_weight(rp, rp.phase[k], time, path_length + ds_dist); v = v * lw; }
                     float3 c = make_float3(fmaf(thr.x, v.x, r.x), fmaf(thr.y, v.y, r.y), fmaf(thr.z, v.z, r.z));
@@ -694,7 +730,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             }
             if (res_dirty) {   // the emitter-hit term stands whether or not the NEE candidate is later committed
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) q.res[(size_t) k * q.capacity + l] = rcur[k];
+                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
+                    if (FIRST) rbase[k] = make_float3(rcur[k].x, rcur[k].y, rcur[k].z);
+                    else q.res[(size_t) k * q.capacity + l] = rcur[k];
+                }
             }
             // ---- continuation (dopplertofpath.cpp:232-276)
             V3 nd = vfma(si.sh_n, bs_wo.z, vfma(si.sh_t, bs_wo.y, si.sh_s * bs_wo.x));   // Frame::to_world
@@ -721,12 +760,16 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
     uint32_t slot = block_append(alive, s_cnt, n_alive);
     if (alive) qout[seg * kSeg + slot] = l;
     if (FUSED) {
+        bool commit = false;
         if (want_shadow) {   // test_visibility (scene.cpp:266-271): an unoccluded sample commits its candidate result
             Hit hs;
-            if (!trace_scene<true, MESH>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs)) {
+            commit = !trace_scene<true, MESH>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
+        }
+        if (FIRST ? in_range : commit) {   // FIRST: every lane's result is defined here (nothing zeroed it beforehand)
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets)
-                    q.res[(size_t) k * q.capacity + l] = make_float4(cand[k].x, cand[k].y, cand[k].z, 0.f);
+            for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
+                const float3 v = commit ? cand[k] : rbase[k];
+                q.res[(size_t) k * q.capacity + l] = make_float4(v.x, v.y, v.z, 0.f);
             }
         }
         if (alive && trace_next) {   // closest hit of the continuation ray, consumed by the next bounce
@@ -1001,17 +1044,18 @@ void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
 void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                   const uint32_t *qin, const uint32_t *count_in, uint32_t *qout,
                   uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, bool fused, bool trace_next,
-                  uint32_t stack_depth, hipStream_t s) {
+                  uint32_t stack_depth, hipStream_t s, bool first, LaneDebug *dbg) {
     if (rp.n_lanes == 0) return;
     uint32_t sw = stage_words_for(scene_bytes), grid = nseg(rp.n_lanes), lds = sw * 16 + (fused ? stack_bytes(stack_depth, kShadeBlock) : 0);
     uint32_t tn = trace_next ? 1u : 0u;
 #define DTOF_LAUNCH_SHADE(L, F, A, K) do { if (rp.has_tris) DTOF_LAUNCH_SHADE_M(L, F, A, K, true); else DTOF_LAUNCH_SHADE_M(L, F, A, K, false); } while (0)
 #define DTOF_LAUNCH_SHADE_M(L, F, A, K, M) hipLaunchKernelGGL((k_shade<L, F, A, K, M>), dim3(grid), dim3(kShadeBlock), lds, s, scene, scene_bytes, sw, rp, q, qin, \
-                                                         count_in, qout, alive_out, shadow_out, depth, tn)
+                                                         count_in, qout, alive_out, shadow_out, depth, tn, dbg)
 #define DTOF_SHADE_AK(L, F) do { if (rp.has_area) { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE(L, F, true, 1); else DTOF_LAUNCH_SHADE(L, F, true, kMaxOffsets); } \
                                  else { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE(L, F, false, 1); else DTOF_LAUNCH_SHADE(L, F, false, kMaxOffsets); } } while (0)
-    if (sw) { if (fused) DTOF_SHADE_AK(true, true); else DTOF_SHADE_AK(true, false); }
-    else    { if (fused) DTOF_SHADE_AK(false, true); else DTOF_SHADE_AK(false, false); }
+    if (first && !fused) throw std::runtime_error("the first-bounce kernel exists in the fused pipeline only");
+    if (sw) { if (first) DTOF_SHADE_AK(true, 2); else if (fused) DTOF_SHADE_AK(true, 1); else DTOF_SHADE_AK(true, 0); }
+    else    { if (first) DTOF_SHADE_AK(false, 2); else if (fused) DTOF_SHADE_AK(false, 1); else DTOF_SHADE_AK(false, 0); }
 #undef DTOF_SHADE_AK
 #undef DTOF_LAUNCH_SHADE
 #undef DTOF_LAUNCH_SHADE_M

@@ -208,7 +208,7 @@ RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, cons
 }
 
 struct StageTimer {
-    bool on; dtof_scene *sc; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
+    bool on; dtof_scene *sc; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[6];
     StageTimer(bool enabled, dtof_scene *scene) : on(enabled), sc(scene) { sc->events_used = 0; }
     int begin(int stage, hipStream_t s) {
         if (!on) return -1;
@@ -256,6 +256,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     // auto = fused for scenes without triangle meshes and with at most 16 objects.  DTOF_PIPELINE=split|fused overrides.
     static const int env_pipeline = [] { const char *e = getenv("DTOF_PIPELINE"); std::string v = e ? e : ""; return v == "split" ? 0 : v == "fused" ? 1 : 2; }();
     const BlobHeader *bh = (const BlobHeader *) sc->blob.data();
+    static const bool env_fuse_first = [] { const char *e = getenv("DTOF_FUSE_FIRST"); return !(e && e[0] == '0'); }();
     const bool fused = env_pipeline == 2 ? (bh->n_tris == 0 && bh->n_objects <= 16) : env_pipeline == 1;
     if (n_streams == 2 && !lane_dump && last - first <= batch && last - first >= 2 * lanes_per_row) {
         uint64_t rows = (last - first) / lanes_per_row;
@@ -285,8 +286,16 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         const Queues &q = qs[batch_index & 1]; hipStream_t s = ss[batch_index & 1];
         rp.lane_base = (uint32_t) b0; rp.n_lanes = (uint32_t) std::min<uint64_t>(batch, last - b0);
         const uint32_t n_seg = segments_for(rp.n_lanes);
-        int t = tm.begin(0, s); launch_generate(rp, q, s); tm.end(0, t, s);
-        if (lane_dump) launch_lane_dump_rays(rp, q, sc->ws.dbg.p, s);
+        // does iteration 0 of the bounce loop run at all?  (same conditions as the loop head below)
+        const bool loop_runs = rp.integrator != INTEGRATOR_VELOCITY && rp.max_depth > 0 && !(1 >= rp.max_depth && !has_surface_emitters);
+        // fused pipeline: the first bounce kernel generates the lanes and traces the primary rays itself (DTOF_FUSE_FIRST=0 keeps
+        // the separate k_generate + k_trace launches)
+        const bool first_inline = fused && loop_runs && env_fuse_first;
+        int t = -1;
+        if (!first_inline) {
+            t = tm.begin(0, s); launch_generate(rp, q, s); tm.end(0, t, s);
+            if (lane_dump) launch_lane_dump_rays(rp, q, sc->ws.dbg.p, s);
+        }
         const uint32_t *qin = nullptr, *count_in = nullptr; uint32_t it = 0;
         if (rp.integrator == INTEGRATOR_VELOCITY) { t = tm.begin(1, s); launch_velocity(blob, blob_bytes, rp, q, stack_depth, s); tm.end(1, t, s); }
         for (;; ++it) {
@@ -305,9 +314,12 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             }
             // does iteration it+1 run?  (same conditions as the loop head)
             const bool next_runs = (it + 1 < rp.max_depth) && !(it + 2 >= rp.max_depth && !has_surface_emitters) && it + 1 < kMaxIter;
-            if (!fused || it == 0) { t = tm.begin(1, s); launch_trace(blob, blob_bytes, rp, q, qin, count_in, stack_depth, s); tm.end(1, t, s); if (stats) stats->n_launches_trace++; }
+            const bool first = first_inline && it == 0;
+            if (!fused || (it == 0 && !first)) { t = tm.begin(1, s); launch_trace(blob, blob_bytes, rp, q, qin, count_in, stack_depth, s); tm.end(1, t, s); if (stats) stats->n_launches_trace++; }
             uint32_t *qout = q.q[it & 1], *alive_out = q.counts + (size_t) (2 * it) * n_seg, *shadow_out = alive_out + n_seg;
-            t = tm.begin(2, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it, fused, next_runs, stack_depth, s); tm.end(2, t, s);
+            const int st_shade = first ? 5 : 2;
+            t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it, fused, next_runs, stack_depth, s, first, first && lane_dump ? sc->ws.dbg.p : nullptr); tm.end(st_shade, t, s);
+            if (stats && first) stats->n_launches_first++;
             if (!fused) { t = tm.begin(3, s); launch_shadow(blob, blob_bytes, rp, q, shadow_out, stack_depth, s); tm.end(3, t, s); if (stats) stats->n_launches_shadow++; }
             if (stats) stats->n_launches_shade++;
             qin = qout; count_in = alive_out;
@@ -335,7 +347,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         if (!sums.empty()) HIP_CHECK(hipMemcpy(sums.data(), sc->d_sums.p, sums.size() * 8, hipMemcpyDeviceToHost));
         for (size_t b = 0; b < batch_lanes.size(); ++b)
             for (uint32_t i = 0; i < 2 * batch_iters[b]; ++i) h_counts.push_back(sums[b * 2 * kMaxIter + i]);
-        stats->ms_generate = tm.total(0); stats->ms_trace = tm.total(1); stats->ms_shade = tm.total(2);
+        stats->ms_generate = tm.total(0); stats->ms_trace = tm.total(1); stats->ms_first = tm.total(5); stats->ms_shade = tm.total(2) + stats->ms_first;
         stats->ms_shadow = tm.total(3); stats->ms_splat = tm.total(4);
         size_t off = 0;
         for (size_t b = 0; b < batch_lanes.size(); ++b) {

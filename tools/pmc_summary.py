@@ -19,6 +19,10 @@ def collect(d, counter):
     return acc
 
 def short(name):
+    import re
+    m = re.search(r"k_shade<\w+, (\d)", name)     # k_shade<LDS, MODE, AREA, KMAX, MESH>: MODE 2 = the first-bounce instantiation
+    if m:
+        return "k_shade_first" if m.group(1) == "2" else "k_shade"
     for k in ("k_shade", "k_trace", "k_shadow", "k_generate", "k_splat_tent3", "k_splat_generic", "k_develop", "k_bounce"):
         if k in name:
             return k
