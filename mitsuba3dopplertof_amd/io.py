@@ -68,3 +68,67 @@ def write_image(path, img):
         write_exr(path, img)
     else:
         raise ValueError('unsupported output format "%s" (use .npy, .pfm or .exr)' % path)
+
+
+# ------------------------------------------------------------------------------------------------ PNG previews
+# The tutorials store a .png next to every .npy (doppler_tutorials/src/utils/image_utils.py:62-135: matplotlib colour maps +
+# cv2.imwrite).  Neither matplotlib nor cv2 is a dependency here: a zlib PNG writer and piecewise-linear colour maps through
+# the published anchor colours of `viridis` and `RdBu`.
+_VIRIDIS = [(0.267, 0.005, 0.329), (0.283, 0.141, 0.458), (0.254, 0.265, 0.530), (0.207, 0.372, 0.553), (0.164, 0.471, 0.558),
+            (0.128, 0.567, 0.551), (0.135, 0.659, 0.518), (0.267, 0.749, 0.441), (0.478, 0.821, 0.318), (0.741, 0.873, 0.150),
+            (0.993, 0.906, 0.144)]
+_RDBU = [(0.404, 0.000, 0.122), (0.698, 0.094, 0.169), (0.839, 0.376, 0.302), (0.957, 0.647, 0.510), (0.992, 0.859, 0.780),
+         (0.969, 0.969, 0.969), (0.820, 0.898, 0.941), (0.573, 0.773, 0.871), (0.263, 0.576, 0.765), (0.129, 0.400, 0.675),
+         (0.020, 0.188, 0.380)]
+
+
+def _colormap(x, anchors):
+    a = np.asarray(anchors, dtype=np.float64)
+    t = np.clip(np.nan_to_num(np.asarray(x, dtype=np.float64)), 0.0, 1.0) * (len(a) - 1)
+    i = np.minimum(t.astype(int), len(a) - 2)
+    f = (t - i)[..., None]
+    return a[i] * (1 - f) + a[i + 1] * f
+
+
+def write_png(path, rgb8):
+    """8-bit RGB (H, W, 3) uint8 -> PNG (zlib, filter 0)"""
+    import zlib
+    a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, _ = a.shape
+    raw = b"".join(b"\x00" + a[y].tobytes() for y in range(h))
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def rgb2luminance(img):
+    img = np.asarray(img)
+    return 0.2126 * img[..., 0] + 0.7152 * img[..., 1] + 0.0722 * img[..., 2]       # image_utils.py:20-21
+
+
+def save_tof_image(image, path, vmin=None, vmax=None, vmin_percentile=5, vmax_percentile=95):
+    """image_utils.py:108-135: viridis between the 5th and 95th percentile"""
+    image = np.asarray(image)
+    if image.ndim == 3:
+        image = rgb2luminance(image)
+    vmin = np.percentile(image, vmin_percentile) if vmin is None else vmin
+    vmax = np.percentile(image, vmax_percentile) if vmax is None else vmax
+    write_png(path, (_colormap((image - vmin) / max(vmax - vmin, 1e-30), _VIRIDIS) * 255.0).astype(np.uint8))
+
+
+def save_speed_image(image, path, velocity_range=5):
+    """image_utils.py:90-106: RdBu over [-velocity_range, +velocity_range] m/s"""
+    image = np.asarray(image)
+    if image.ndim == 3:
+        image = image[..., 0]
+    write_png(path, (_colormap((image + velocity_range) / (2.0 * velocity_range), _RDBU) * 255.0).astype(np.uint8))
+
+
+def save_hdr_image(image, path):
+    """image_utils.py:6-18,72-88: Reinhard-style tone map (limit 1.5) + gamma 2.2"""
+    c = np.asarray(image, dtype=np.float64)[..., :3]
+    lum = (0.3 * c[..., 0] + 0.6 * c[..., 1] + 0.1 * c[..., 2])[..., None]
+    c = np.power(np.maximum(c / (1.0 + lum / 1.5), 0.0), 1.0 / 2.2)
+    write_png(path, np.clip(c * 255.0, 0, 255).astype(np.uint8))

@@ -112,3 +112,102 @@ def test_native_cli_writes_the_same_image(mi, tmp_path):
     assert img.shape == (24, 40, 3) and np.abs(img - ref).max() <= 1e-5 * np.abs(ref).max()
     bad = subprocess.run([exe, os.path.join(SCENES, "cornell_wall.xml"), "-D", "wave_function_type=sawtooth"], capture_output=True, text=True)
     assert bad.returncode != 0 and "unknown wave_function_type" in bad.stderr
+
+
+def _read_png(path):
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body) & 0xffffffff
+        if tag == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
+            assert (depth, ctype) == (8, 2)
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 3)
+
+
+def test_png_previews_and_experiment_grids(tmp_path):
+    """image_utils.py:90-135 (colour-mapped previews) and main_experiment.py:74-139 (the four experiment grids)"""
+    from mitsuba3dopplertof_amd import experiments as E, io
+    ramp = np.tile(np.linspace(-5, 5, 64, dtype=np.float32), (8, 1))
+    io.save_speed_image(ramp, str(tmp_path / "v.png"))
+    px = _read_png(str(tmp_path / "v.png")).astype(int)
+    assert px.shape == (8, 64, 3)
+    assert px[0, 0, 0] > px[0, 0, 2] + 50 and px[0, -1, 2] > px[0, -1, 0] + 50 and px[0, 32].min() > 220     # red .. white .. blue
+    io.save_tof_image(ramp, str(tmp_path / "t.png"))
+    t = _read_png(str(tmp_path / "t.png")).astype(int)
+    assert t[0, 2, 2] > t[0, 2, 1] and t[0, -2, 0] > 200 and t[0, -2, 1] > 200                                # purple .. yellow
+    io.save_hdr_image(np.abs(ramp)[..., None] * np.ones(3), str(tmp_path / "h.png"))
+    assert _read_png(str(tmp_path / "h.png")).shape == (8, 64, 3)
+    assert [len(E.experiment_settings(i)) for i in range(4)] == [1, 16, 12, 22]
+    names = [s[1] for s in E.experiment_settings(2)]
+    assert names[0] == "stratified_path_corr_depth_0_no_further_stratification" and all("uniform" not in n for n in names)
+    s3 = E.experiment_settings(3)
+    assert s3[5][1] == "antithetic_shift_0.5" and s3[5][3]["antithetic_shift"] == 0.5 and s3[-1][1] == "antithetic_mirror_shift_1.0"
+    assert E.SCENE_CONFIGS["veach-ajar"] == {"max_depth": 8, "reference_spp": 131072, "spp": 1024}
+
+
+@pytest.mark.gpu
+def test_experiment_driver_layout_and_resume(mi, tmp_path):
+    from mitsuba3dopplertof_amd import experiments as E
+    base = str(tmp_path)
+    scene = mi.load_file(os.path.join(SCENES, "cornell_boxes.xml"), resx=16, resy=16)
+    log = []
+    files = E.run_experiment(scene, "cornell-box", 3, base, grid=2, spp=8, log=log.append)
+    # grid=2: frequencies {0,1} x offsets {0,1} x (2 methods x 2 shifts)
+    assert len(files) == 16 and not log
+    d = os.path.join(base, "results", "antithetic_shift_comparison", "cornell-box", "sinusoidal", "freq_1.000_offset_0.000")
+    assert sorted(os.listdir(d)) == sorted(n + e for n in ("antithetic_shift_0.0", "antithetic_shift_1.0", "antithetic_mirror_shift_0.0",
+                                                             "antithetic_mirror_shift_1.0") for e in (".npy", ".png"))
+    a = np.load(os.path.join(d, "antithetic_shift_0.0.npy"))
+    ref = mi.harness.run_scene_doppler_tof(scene, total_spp=8, hetero_frequency=1.0, hetero_offset=0.0, time_sampling_method="antithetic",
+                                           path_correlation_depth=16, antithetic_shift=0.0, max_depth=4) if hasattr(mi, "harness") else None
+    if ref is not None:
+        assert np.abs(a - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert a.shape == (16, 16, 3) and np.isfinite(a).all()
+    assert E.run_experiment(scene, "cornell-box", 3, base, grid=2, spp=8, log=log.append) == [] and len(log) == 16   # resumes
+    # the command line (program entry of main_experiment.py)
+    out = subprocess.run([sys.executable, "-m", "mitsuba3dopplertof_amd.experiments", "--scene_name", "cornell-box", "--expnumber", "0",
+                          "--basedir", base, "--scene", os.path.join(SCENES, "cornell_boxes.xml"), "--grid", "2", "--reference_spp", "4",
+                          "-D", "resx=8", "-D", "resy=8"], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0 and "wrote 4 files" in out.stdout, out.stderr
+    assert os.path.exists(os.path.join(base, "results", "gt_images", "cornell-box", "sinusoidal", "freq_0.000_offset_1.000", "reference.png"))
+
+
+@pytest.mark.gpu
+def test_animation_driver_reconstructs_the_wall_velocity(mi, tmp_path):
+    """main_animation.py:58-157 on one synthetic frame: the Cornell room whose back wall moves at 10 m/s towards the camera.
+    Ground-truth radial velocity on the wall = -10 m/s (velocity.cpp:125-142) and the heterodyne/homodyne reconstruction
+    (image_utils.py:140-199) lands on it."""
+    import shutil
+    from mitsuba3dopplertof_amd import experiments as E
+    base = str(tmp_path)
+    d = os.path.join(base, "scenes_animation", "wall")
+    os.makedirs(d)
+    shutil.copy(os.path.join(SCENES, "cornell_wall.xml"), os.path.join(d, "animation_0.xml"))
+    shutil.copy(os.path.join(SCENES, "cornell_wall.xml"), os.path.join(d, "no_animation_0.xml"))
+    cfg = dict(max_depth=2, total_spp=512, animation_length=2, intervals=1, w_g=30, homodyne_spp=512)
+    files = E.run_animation("wall", base, config=cfg, defines=dict(resx=24, resy=24), log=lambda m: None)
+    assert len(files) == 2 + 2 + 6
+    out = os.path.join(base, "results_animation", "wall")
+    vel = np.load(os.path.join(out, "velocity_gt", "frame_0.npy"))
+    centre = vel[8:16, 8:16, 0]
+    assert np.allclose(centre, -10.0, atol=0.05)                       # the back wall fills the centre of the frame
+    for name in ("velocity_gt/frame_0.png", "radiance/frame_0.png", "sinusoidal/freq_0.000_offset_0.250/frame_0.png",
+                 "sinusoidal/antithetic_path_corr_depth_16/velocity/frame_0.png", "sinusoidal/uniform_path_corr_depth_0/velocity_0.000/frame_0.png"):
+        assert os.path.getsize(os.path.join(out, name)) > 100, name
+    T = 0.0015
+    homo = [mi.to_tof_image(np.load(os.path.join(out, "sinusoidal", "freq_0.000_offset_%.3f" % o, "frame_0.npy")), T) for o in (0.0, 0.25)]
+    het = [mi.to_tof_image(np.load(os.path.join(out, "sinusoidal", "antithetic_path_corr_depth_16", "freq_1.000_offset_%.3f" % o, "frame_0.npy")), T) for o in (0.0, 0.25)]
+    v = E.calc_velocity_from_homo_heteros(homo, het, exposure_time=T, w_g=30)[8:16, 8:16]
+    assert abs(np.median(v) + 10.0) < 2.5, np.median(v)
+    assert E.run_animation("wall", base, config=cfg, defines=dict(resx=24, resy=24), log=lambda m: None) == []   # everything cached
