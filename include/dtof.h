@@ -75,6 +75,8 @@ int dtof_scene_get_info(const dtof_scene *scene, dtof_scene_info *info);
  * kind 3: emitters          -> per emitter position[3], intensity[3]
  * kind 4..7: baked mesh data -> positions / vertex normals / texcoords / faces (uint32 bit patterns) of all mesh
  *                             shapes (cube, obj, ply) concatenated in shape order (cube.cpp:114-160, obj.cpp, ply.cpp)
+ * kind 8: spheres           -> per sphere m_center[3], m_radius, m_inv_surface_area, flip_normals (sphere.cpp:138-160);
+ *                             their composed to_world / to_object are in kind 1
  * Returns the number of floats written (<= capacity) through *n_written. */
 int dtof_scene_export(const dtof_scene *scene, int kind, float *out, size_t capacity, size_t *n_written);
 

@@ -85,6 +85,48 @@ DTOF_D bool tri_hit(const DTri &tr, V3 o, V3 d, float maxt, float &t, float &u, 
     u = U * rc; v = Vv * rc; t = T * rc;
     return true;
 }
+// math::solve_quadratic (include/mitsuba/core/math.h:357-401), float64
+DTOF_D bool solve_quadratic_d(double a, double b, double c, double &x0, double &x1) {
+    const bool linear = a == 0.0, valid_linear = linear && b != 0.0;
+    x0 = x1 = -c / b;
+    const double discrim = fma(b, b, -(4.0 * a * c));
+    const bool valid_quadratic = !linear && discrim >= 0.0;
+    if (valid_quadratic) {
+        const double sq = sqrt(discrim), temp = -0.5 * (b + copysign(sq, b));
+        const double x0p = temp / a, x1p = c / temp;
+        x0 = x0p < x1p ? x0p : x1p; x1 = x0p < x1p ? x1p : x0p;
+    }
+    return valid_linear || valid_quadratic;
+}
+DTOF_D double dot3d(double ax, double ay, double az, double bx, double by, double bz) { return fma(az, bz, fma(ay, by, ax * bx)); }
+// Sphere::ray_intersect_preliminary_impl (src/shapes/sphere.cpp:338-394) / ray_test_impl (:396-431): float64 on the llvm back
+// end; the point of the ray closest to the centre is evaluated with the FLOAT ray (Ray::operator() takes a Float, ray.h:61).
+template <bool ANY>
+DTOF_D bool sphere_hit(const DShape &sh, V3 o, V3 d, float maxt_f, float &t_out) {
+    const double radius = sh.dp_du[0], cx = sh.n[0], cy = sh.n[1], cz = sh.n[2], maxt = maxt_f;
+    const double dx = d.x, dy = d.y, dz = d.z;
+    double near_t, far_t;
+    if (ANY) {
+        const double ox = (double) o.x - cx, oy = (double) o.y - cy, oz = (double) o.z - cz;
+        const double A = dot3d(dx, dy, dz, dx, dy, dz), B = 2.0 * dot3d(ox, oy, oz, dx, dy, dz), C = dot3d(ox, oy, oz, ox, oy, oz) - radius * radius;
+        const bool found = solve_quadratic_d(A, B, C, near_t, far_t);
+        const bool out_bounds = !(near_t <= maxt && far_t >= 0.0), in_bounds = near_t < 0.0 && far_t > maxt;
+        return found && !out_bounds && !in_bounds;
+    }
+    const double lx = (double) o.x - cx, ly = (double) o.y - cy, lz = (double) o.z - cz;
+    const double plane_t = dot3d(-lx, -ly, -lz, dx, dy, dz) / sqrt(dot3d(dx, dy, dz, dx, dy, dz));
+    bool no_hit = plane_t == 0.0 && (o.x != sh.n[0] && o.y != sh.n[1] && o.z != sh.n[2]);
+    const V3 pp = vfma(d, (float) plane_t, o);
+    const double ox = (double) pp.x - cx, oy = (double) pp.y - cy, oz = (double) pp.z - cz;
+    no_hit = no_hit && sqrt(dot3d(ox, oy, oz, ox, oy, oz)) > radius;
+    const double A = dot3d(dx, dy, dz, dx, dy, dz), B = 2.0 * dot3d(ox, oy, oz, dx, dy, dz), C = dot3d(ox, oy, oz, ox, oy, oz) - radius * radius;
+    const bool found = solve_quadratic_d(A, B, C, near_t, far_t);
+    near_t += plane_t; far_t += plane_t;
+    const bool out_bounds = !(near_t <= maxt && far_t >= 0.0), in_bounds = near_t < 0.0 && far_t > maxt;
+    if (!(found && !no_hit && !out_bounds && !in_bounds)) return false;
+    t_out = near_t < 0.0 ? (float) far_t : (float) near_t;
+    return true;
+}
 // AnimatedTransform::eval, include/mitsuba/core/transform.h:439-466
 DTOF_D void instance_matrix(const DObject &ob, float time, float *m) {
     if (ob.n_keys <= 1) {
@@ -150,7 +192,16 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
             }
             continue;
         }
-        if (!MESH) continue;   // instantiations for scenes without a single triangle carry no mesh code at all
+        if (!MESH) continue;   // instantiations for rectangle-only scenes carry no triangle / sphere code at all
+        if (sh.kind == SHAPE_SPHERE) {
+            if (sphere_hit<ANY>(sh, lo, ld, maxt, t)) {
+                if (ANY) return true;
+                if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
+                    best.t = t; best.u = 0.f; best.v = 0.f; best.obj = oi; best.shape = k; best.prim = 0; found = true;
+                }
+            }
+            continue;
+        }
         // cull with the mesh's own (padded) bounds: TLAS boxes of moving instances are the union over the whole
         // motion and let many rays through that miss the mesh at their time
         V3 lid = mk(__builtin_amdgcn_rcpf(ld.x == 0.f ? 1e-30f : ld.x), __builtin_amdgcn_rcpf(ld.y == 0.f ? 1e-30f : ld.y), __builtin_amdgcn_rcpf(ld.z == 0.f ? 1e-30f : ld.z));
@@ -442,6 +493,18 @@ DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, 
         si.p = p + n * dist; si.n = n; si.sh_n = n;
         dp_du = mk(sh->dp_du[0], sh->dp_du[1], sh->dp_du[2]);
         dp_dv = mk(sh->dp_dv[0], sh->dp_dv[1], sh->dp_dv[2]);
+    } else if (sh->kind == SHAPE_SPHERE) {   // Sphere::compute_surface_interaction (sphere.cpp:509-513, 527-551)
+        const V3 c = mk(sh->n[0], sh->n[1], sh->n[2]); const float radius = sh->dp_du[0];
+        V3 n = normalize(vfma(ld, t, lo) - c);
+        si.p = vfma(n, radius, c);
+        const V3 local = xf_point(sh->to_object, si.p);
+        const float rd = sqrtf(sqr(local.x) + sqr(local.y)), inv_rd = rcp(rd);
+        V3 dpv = mk(local.z * (local.x * inv_rd), local.z * (local.y * inv_rd), -rd);
+        if (rd == 0.f) dpv = mk(1.f, 0.f, 0.f);
+        dp_du = xf_vector(sh->to_world, mk(-local.y, local.x, 0.f)) * (2.f * kPi);
+        dp_dv = xf_vector(sh->to_world, dpv) * kPi;
+        if (sh->flags & SF_FLIP_NORMALS) n = -n;
+        si.n = n; si.sh_n = n;
     } else {
         const DTri &tr = sv.tris[sh->first_tri + prim];
         const DTriShade &ts = sv.shading[sh->first_tri + prim];
@@ -522,6 +585,49 @@ DTOF_D void mesh_sample_position(const SceneView &sv, const DShape &es, float s_
     } else n = cross(e0, e1);
     n = normalize(n);
     if (es.flags & SF_FLIP_NORMALS) n = -n;
+}
+DTOF_D float safe_sqrt(float x) { return sqrtf(fmax_(x, 0.f)); }
+constexpr float kInvTwoPi = 0.15915494309189533577f;
+DTOF_D float uniform_cone_pdf(float cos_cutoff) { return kInvTwoPi / (1.f - cos_cutoff); }   // warp::square_to_uniform_cone_pdf (warp.h:475-485)
+// Sphere::sample_direction (sphere.cpp:222-296): cone sampling of the visible cap from outside, uniform sphere from inside
+DTOF_D void sphere_sample_direction(const DShape &sh, V3 ref, float s_x, float s_y, V3 &p, V3 &n, V3 &dd, float &dist, float &pdf) {
+    const V3 center = mk(sh.n[0], sh.n[1], sh.n[2]); const float radius = sh.dp_du[0];
+    const bool flip = sh.flags & SF_FLIP_NORMALS;
+    const V3 dc_v = center - ref;
+    const float dc_2 = dot(dc_v, dc_v), radius_adj = radius * (flip ? (1.f + kRayEps) : (1.f - kRayEps));
+    const bool outside = dc_2 > sqr(radius_adj);
+    V3 dloc;
+    if (outside) {
+        const float inv_dc = rsqrt_(dc_2), sin_theta_max = radius * inv_dc, sin_theta_max_2 = sqr(sin_theta_max),
+                    inv_sin_theta_max = rcp(sin_theta_max), cos_theta_max = safe_sqrt(1.f - sin_theta_max_2);
+        const float sin_theta_2 = sin_theta_max_2 > 0.00068523f ? 1.f - sqr(fmaf(cos_theta_max - 1.f, s_x, 1.f)) : sin_theta_max_2 * s_x;
+        const float cos_theta = safe_sqrt(1.f - sin_theta_2);
+        const float cos_alpha = sin_theta_2 * inv_sin_theta_max + cos_theta * safe_sqrt(fmaf(-sin_theta_2, sqr(inv_sin_theta_max), 1.f));
+        const float sin_alpha = safe_sqrt(fmaf(-cos_alpha, cos_alpha, 1.f));
+        float sin_phi, cos_phi; sincos_(s_y * (2.f * kPi), sin_phi, cos_phi);
+        const V3 fn = dc_v * -inv_dc; V3 fs, ft;
+        coordinate_system(fn, fs, ft);
+        dloc = vfma(fn, cos_alpha, vfma(ft, sin_phi * sin_alpha, fs * (cos_phi * sin_alpha)));
+        pdf = uniform_cone_pdf(cos_theta_max);
+    } else {   // warp::square_to_uniform_sphere (warp.h:250-255)
+        const float z = fmaf(-2.f, s_y, 1.f), r = safe_sqrt(fmaf(-z, z, 1.f)); float sn, cs;
+        sincos_(2.f * kPi * s_x, sn, cs);
+        dloc = mk(r * cs, r * sn, z);
+        pdf = 0.f;
+    }
+    p = vfma(dloc, radius, center); dd = p - ref;
+    const float dist2 = dot(dd, dd);
+    dist = sqrtf(dist2);
+    dd = dd * rcp(dist);
+    if (outside) { if (dist == 0.f) pdf = 0.f; }
+    else pdf = sh.inv_area * dist2 / fabsf(dot(dd, dloc));
+    n = flip ? -dloc : dloc;
+}
+// Sphere::pdf_direction (sphere.cpp:298-310)
+DTOF_D float sphere_pdf_direction(const DShape &sh, V3 ref, V3 ds_d, V3 ds_n, float ds_dist) {
+    const V3 center = mk(sh.n[0], sh.n[1], sh.n[2]);
+    const float sin_alpha = sh.dp_du[0] * rcp(norm(center - ref)), cos_alpha = safe_sqrt(1.f - sin_alpha * sin_alpha);
+    return sin_alpha < 0.99999994f ? uniform_cone_pdf(cos_alpha) : sh.inv_area * sqr(ds_dist) / fabsf(dot(ds_d, ds_n));
 }
 DTOF_D float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
@@ -634,7 +740,12 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                     float em_pdf = 0.f;
                     if (depth > 0) {                                             // !prev_bsdf_delta: AreaLight::pdf_direction (area.cpp:161-180)
                         float dp = dot(dsd, si.sh_n);   // ds.n = si.sh_frame.n (PositionSample(si), records.h:63-65)
-                        if (dp < 0.f) { float adp = fabsf(dp); em_pdf = sh->inv_area * (adp != 0.f ? (dist * dist) / adp : 0.f) * pmf; }
+                        if (dp < 0.f) {
+                            const float adp = fabsf(dp);
+                            const float pdf = MESH && sh->kind == SHAPE_SPHERE ? sphere_pdf_direction(*sh, mk(pb.x, pb.y, pb.z), dsd, si.sh_n, dist)
+                                                                               : sh->inv_area * (adp != 0.f ? (dist * dist) / adp : 0.f);
+                            em_pdf = pdf * pmf;
+                        }
                     }
                     float mis_bsdf = mis_weight(pb.w, em_pdf);
                     bool on = si.wi.z > 0.f && pb.w > 0.f;                       // AreaLight::eval (area.cpp:82-89), mask prev_bsdf_pdf > 0
@@ -670,16 +781,20 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 } else {
                     const DShape &es = sv.shapes[em.shape];
                     V3 en;
-                    if (!MESH || es.kind == SHAPE_RECT) {
-                        dsp = xf_point(es.to_world, mk(sx * 2.f - 1.f, e2 * 2.f - 1.f, 0.f));
-                        en = mk(es.n[0], es.n[1], es.n[2]);
-                    } else mesh_sample_position(sv, es, sx, e2, dsp, en);
-                    dd = dsp - si.p;
-                    float dist2 = dot(dd, dd);
-                    ds_dist = sqrtf(dist2);
-                    dd = dd * rcp(ds_dist);
-                    float dp = fabsf(dot(dd, en)), x = dist2 / dp;
-                    ds_pdf = es.inv_area * (isfinite(x) ? x : 0.f);
+                    if (MESH && es.kind == SHAPE_SPHERE) {   // Sphere overrides Shape::sample_direction
+                        sphere_sample_direction(es, si.p, sx, e2, dsp, en, dd, ds_dist, ds_pdf);
+                    } else {
+                        if (!MESH || es.kind == SHAPE_RECT) {
+                            dsp = xf_point(es.to_world, mk(sx * 2.f - 1.f, e2 * 2.f - 1.f, 0.f));
+                            en = mk(es.n[0], es.n[1], es.n[2]);
+                        } else mesh_sample_position(sv, es, sx, e2, dsp, en);
+                        dd = dsp - si.p;
+                        float dist2 = dot(dd, dd);
+                        ds_dist = sqrtf(dist2);
+                        dd = dd * rcp(ds_dist);
+                        float dp = fabsf(dot(dd, en)), x = dist2 / dp;
+                        ds_pdf = es.inv_area * (isfinite(x) ? x : 0.f);
+                    }
                     ds_delta = false;
                     em_active = dot(dd, en) < 0.f && ds_pdf != 0.f;
                     float ip = rcp(ds_pdf);

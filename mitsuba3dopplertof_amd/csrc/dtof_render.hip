@@ -257,7 +257,9 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     static const int env_pipeline = [] { const char *e = getenv("DTOF_PIPELINE"); std::string v = e ? e : ""; return v == "split" ? 0 : v == "fused" ? 1 : 2; }();
     const BlobHeader *bh = (const BlobHeader *) sc->blob.data();
     static const bool env_fuse_first = [] { const char *e = getenv("DTOF_FUSE_FIRST"); return !(e && e[0] == '0'); }();
-    const bool fused = env_pipeline == 2 ? (bh->n_tris == 0 && bh->n_objects <= 16) : env_pipeline == 1;
+    bool only_rectangles = bh->n_tris == 0;
+    for (auto &sh : sc->host.shapes) only_rectangles &= sh.kind == SHAPE_RECT;
+    const bool fused = env_pipeline == 2 ? (only_rectangles && bh->n_objects <= 16) : env_pipeline == 1;
     if (n_streams == 2 && !lane_dump && last - first <= batch && last - first >= 2 * lanes_per_row) {
         uint64_t rows = (last - first) / lanes_per_row;
         batch = ((rows + 1) / 2) * lanes_per_row;                // one batch would serialise: cut it in two row bands
@@ -272,7 +274,9 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     bool has_surface_emitters = false;          // area emitters make the emitter-hit term (and the last iteration) live
     for (auto &e : sc->host.emitters) has_surface_emitters |= e.kind == EMITTER_AREA;
     rp.has_area = has_surface_emitters;
-    rp.has_tris = bh->n_tris != 0;
+    bool has_spheres = false;
+    for (auto &sh : sc->host.shapes) has_spheres |= sh.kind == SHAPE_SPHERE;
+    rp.has_tris = bh->n_tris != 0 || has_spheres;   // anything but rectangles: the instantiations with triangle / sphere code
     StageTimer tm(stats != nullptr, sc);
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
@@ -480,6 +484,9 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
             else if (kind == 5) v.insert(v.end(), s.normals.begin(), s.normals.end());
             else if (kind == 6) v.insert(v.end(), s.texcoords.begin(), s.texcoords.end());
             else for (uint32_t f : s.faces) { float b; memcpy(&b, &f, 4); v.push_back(b); }
+        } else if (kind == 8) for (auto &s : sc->host.shapes) {
+            if (s.kind != SHAPE_SPHERE) continue;
+            v.insert(v.end(), s.center, s.center + 3); v.push_back(s.radius); v.push_back(s.sphere_inv_area); v.push_back(s.flip_normals ? 1.f : 0.f);
         } else throw std::runtime_error("unknown export kind");
         *n_written = v.size();
         if (out) { if (v.size() > cap) throw std::runtime_error("export buffer too small"); memcpy(out, v.data(), v.size() * 4); }

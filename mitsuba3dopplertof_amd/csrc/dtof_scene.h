@@ -10,7 +10,7 @@
 namespace dtof {
 
 // ---------------------------------------------------------------------------- enums
-enum ShapeKind : uint32_t { SHAPE_RECT = 0, SHAPE_MESH = 1 };
+enum ShapeKind : uint32_t { SHAPE_RECT = 0, SHAPE_MESH = 1, SHAPE_SPHERE = 2 };
 enum ObjectKind : uint32_t { OBJ_SHAPE = 0, OBJ_INSTANCE = 1 };
 enum WaveType : int32_t { WAVE_SIN = 0, WAVE_RECT = 1, WAVE_TRI = 2, WAVE_TRAP = 3 };
 // ETimeSampling -- include/mitsuba/render/sampler.h:27-34
@@ -55,6 +55,8 @@ struct DShape {             // 224 B
     // rectangle frame (Rectangle::update, rectangle.cpp:101-113).  Mesh emitters use the three spare words for the face
     // distribution (Mesh::build_pmf, mesh.cpp:478-511): byte offset of its table in the blob = cdf[n] | pmf[n] | slot[n]
     // (slot = position of face i in the BLAS-ordered triangle array), and m_valid = [emit_lo, emit_hi]
+    // Spheres (src/shapes/sphere.cpp:138-160) keep m_center in n[] and m_radius in dp_du[0]; to_world / to_object are the composed
+    // to_world * translate(center) * scale(radius) and its inverse.
     float n[3]; uint32_t emit_table; float dp_du[3]; uint32_t emit_lo; float dp_dv[3]; uint32_t emit_hi;
     float bmin[3], emit_sum, bmax[3], pad5;             // padded bounds of the shape in ITS space (mesh: culls the triangle loop); emit_sum = float(sum of areas)
     float radiance[3], inv_area;                        // SF_EMITTER: AreaLight radiance, 1 / area (Rectangle::m_inv_surface_area, DiscreteDistribution::normalization)
@@ -75,6 +77,7 @@ struct HostShape {
     // mesh: cube baked like src/shapes/cube.cpp:114-160; obj / ply through mesh_io.cpp
     std::vector<float> positions, normals, texcoords;
     std::vector<uint32_t> faces;
+    float center[3] = { 0, 0, 0 }, radius = 1.f, sphere_inv_area = 0.f;   // sphere: m_center, m_radius, m_inv_surface_area after update()
     std::string id;
     bool emitter = false; float radiance[3] = { 0, 0, 0 };   // area emitter attached to the shape (src/emitters/area.cpp)
 };

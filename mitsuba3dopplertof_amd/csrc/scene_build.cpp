@@ -38,6 +38,9 @@ static Box shape_box(const HostShape &s) {
     if (s.kind == SHAPE_RECT) {   // Rectangle::bbox, src/shapes/rectangle.cpp:115-125
         const float c[4][2] = { { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
         for (auto &k : c) b.add(xf_point(s.to_world, mk(k[0], k[1], 0.f)));
+    } else if (s.kind == SHAPE_SPHERE) {   // Sphere::bbox, src/shapes/sphere.cpp:177-182
+        b.add(mk(s.center[0] - s.radius, s.center[1] - s.radius, s.center[2] - s.radius));
+        b.add(mk(s.center[0] + s.radius, s.center[1] + s.radius, s.center[2] + s.radius));
     } else {
         for (size_t i = 0; i + 2 < s.positions.size(); i += 3) b.add(mk(s.positions[i], s.positions[i + 1], s.positions[i + 2]));
     }
@@ -137,6 +140,8 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
             d.dp_du[0] = du.x; d.dp_du[1] = du.y; d.dp_du[2] = du.z;
             d.dp_dv[0] = dv.x; d.dp_dv[1] = dv.y; d.dp_dv[2] = dv.z;
             d.inv_area = rcp(norm(cross(du, dv)));   // Rectangle::surface_area / m_inv_surface_area (rectangle.cpp:109,127-129)
+        } else if (h.kind == SHAPE_SPHERE) {
+            memcpy(d.n, h.center, 12); d.dp_du[0] = h.radius; d.inv_area = h.sphere_inv_area;
         } else {
             d.first_tri = (uint32_t) tris.size(); d.n_tris = (uint32_t) (h.faces.size() / 3);
             for (uint32_t f = 0; f < d.n_tris; ++f) {

@@ -472,11 +472,45 @@ static void bake_cube(HostShape &s) {   // src/shapes/cube.cpp:114-160
     }
 }
 
+// Sphere ctor + update (src/shapes/sphere.cpp:121-160), in float32 like ScalarTransform4f: composed = to_world * translate(center)
+// * scale(radius) (4x4 products accumulate with fmadd over k, Dr.Jit's Matrix operator*), the inverse from the factors' analytic
+// inverses in reverse order; m_radius = |composed * (1,0,0)|, m_center = composed * (0,0,0); a mirroring transform toggles flip_normals.
+static void m4_mul_f32(const float *a, const float *b, float *out) {
+    float r[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        float sum = a[4 * i] * b[j];
+        for (int k = 1; k < 4; ++k) sum = fmaf(a[4 * i + k], b[4 * k + j], sum);
+        r[4 * i + j] = sum;
+    }
+    memcpy(out, r, sizeof r);
+}
+static void bake_sphere(HostShape &s, const Obj &o) {
+    double c[3] = { 0, 0, 0 };
+    auto pv = o.vectors.find("center");
+    if (pv != o.vectors.end()) for (int i = 0; i < 3; ++i) c[i] = pv->second[i];
+    const float center[3] = { (float) c[0], (float) c[1], (float) c[2] }, radius = (float) o.props.get_float("radius", 1.0);
+    float T[16] = { 1, 0, 0, center[0], 0, 1, 0, center[1], 0, 0, 1, center[2], 0, 0, 0, 1 };
+    float Ti[16] = { 1, 0, 0, -center[0], 0, 1, 0, -center[1], 0, 0, 1, -center[2], 0, 0, 0, 1 };
+    const float ir = 1.0f / radius;
+    float S[16] = { radius, 0, 0, 0, 0, radius, 0, 0, 0, 0, radius, 0, 0, 0, 0, 1 }, Si[16] = { ir, 0, 0, 0, 0, ir, 0, 0, 0, 0, ir, 0, 0, 0, 0, 1 };
+    float tmp[16], comp[16], comp_inv[16];
+    m4_mul_f32(s.to_world, T, tmp); m4_mul_f32(tmp, S, comp);
+    m4_mul_f32(Ti, s.to_object, tmp); m4_mul_f32(Si, tmp, comp_inv);
+    memcpy(s.to_world, comp, sizeof comp); memcpy(s.to_object, comp_inv, sizeof comp_inv);
+    s.radius = norm(mk(comp[0], comp[4], comp[8]));
+    s.center[0] = comp[3]; s.center[1] = comp[7]; s.center[2] = comp[11];
+    const float *m = comp;
+    float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+    if (det < 0.f) s.flip_normals = !s.flip_normals;
+    s.sphere_inv_area = 1.0f / ((4.f * kPi) * sqr(s.radius));
+}
+
 static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string &base_dir) {
     HostShape s; s.id = o.id;
     const bool mesh_file = o.plugin == "obj" || o.plugin == "ply";
     if (o.plugin == "rectangle") s.kind = SHAPE_RECT; else if (o.plugin == "cube" || mesh_file) s.kind = SHAPE_MESH;
-    else fail("unsupported shape plugin \"" + o.plugin + "\" (supported: rectangle, cube, obj, ply, shapegroup, instance)");
+    else if (o.plugin == "sphere") s.kind = SHAPE_SPHERE;
+    else fail("unsupported shape plugin \"" + o.plugin + "\" (supported: rectangle, cube, obj, ply, sphere, shapegroup, instance)");
     Xf tw { m_identity(), m_identity() };
     if (!strip_to_world) { auto t = o.transforms.find("to_world"); if (t != o.transforms.end()) tw = t->second; }
     s.flip_normals = o.props.get_bool("flip_normals", false);
@@ -486,6 +520,7 @@ static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string
         tw.m = m_mul(tw.m, f); tw.inv = m_mul(fi, tw.inv); s.flip_normals = false;
     }
     to_f32(tw.m, s.to_world); to_f32(tw.inv, s.to_object);
+    if (s.kind == SHAPE_SPHERE) bake_sphere(s, o);
     const Obj *bsdf = nullptr;
     for (auto &c : o.children) {
         if (c.first == "bsdf") { if (bsdf) fail("Only a single BSDF child object can be specified per shape."); bsdf = c.second.get(); }

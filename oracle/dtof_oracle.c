@@ -408,6 +408,49 @@ static int tri_intersect(v3 p0, v3 p1, v3 p2, v3 o, v3 d, float maxt, float *t_o
     *u = U * rc; *v = Vv * rc; *t_out = T * rc;
     return 1;
 }
+/* math::solve_quadratic (include/mitsuba/core/math.h:357-401) in double */
+static int solve_quadratic_d(double a, double b, double c, double *x0, double *x1) {
+    int linear = a == 0.0, valid_linear = linear && b != 0.0;
+    *x0 = *x1 = -c / b;
+    double discrim = fma(b, b, -(4.0 * a * c));
+    int valid_quadratic = !linear && discrim >= 0.0;
+    if (valid_quadratic) {
+        double sq = sqrt(discrim);
+        double temp = -0.5 * (b + copysign(sq, b));
+        double x0p = temp / a, x1p = c / temp;
+        *x0 = x0p < x1p ? x0p : x1p; *x1 = x0p < x1p ? x1p : x0p;
+    }
+    return valid_linear || valid_quadratic;
+}
+static inline double dot3d(const double *a, const double *b) { return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0])); }
+/* Sphere::ray_intersect_preliminary_impl (sphere.cpp:338-394): float64 on the llvm back end; the point on the ray closest
+ * to the centre is evaluated with the FLOAT ray (Ray::operator() takes a Float, ray.h:61) */
+static int sphere_intersect(const orc_shape *sh, v3 o, v3 d, float maxt_f, float *t_out) {
+    const double radius = sh->radius, ctr[3] = { sh->center[0], sh->center[1], sh->center[2] }, maxt = maxt_f;
+    const double dd[3] = { d.x, d.y, d.z }, l[3] = { (double) o.x - ctr[0], (double) o.y - ctr[1], (double) o.z - ctr[2] };
+    const double nl[3] = { -l[0], -l[1], -l[2] };
+    double plane_t = dot3d(nl, dd) / sqrt(dot3d(dd, dd));
+    int no_hit = plane_t == 0.0 && (o.x != sh->center[0] && o.y != sh->center[1] && o.z != sh->center[2]);
+    v3 pp = v_fma(d, (float) plane_t, o);
+    const double oo[3] = { (double) pp.x - ctr[0], (double) pp.y - ctr[1], (double) pp.z - ctr[2] };
+    no_hit = no_hit && sqrt(dot3d(oo, oo)) > radius;
+    double A = dot3d(dd, dd), B = 2.0 * dot3d(oo, dd), C = dot3d(oo, oo) - radius * radius, near_t, far_t;
+    int found = solve_quadratic_d(A, B, C, &near_t, &far_t);
+    near_t += plane_t; far_t += plane_t;
+    int out_bounds = !(near_t <= maxt && far_t >= 0.0), in_bounds = near_t < 0.0 && far_t > maxt;
+    if (!(found && !no_hit && !out_bounds && !in_bounds)) return 0;
+    *t_out = near_t < 0.0 ? (float) far_t : (float) near_t;
+    return 1;
+}
+/* Sphere::ray_test_impl (sphere.cpp:396-431) */
+static int sphere_test(const orc_shape *sh, v3 o, v3 d, float maxt_f) {
+    const double radius = sh->radius, maxt = maxt_f, dd[3] = { d.x, d.y, d.z };
+    const double oo[3] = { (double) o.x - (double) sh->center[0], (double) o.y - (double) sh->center[1], (double) o.z - (double) sh->center[2] };
+    double A = dot3d(dd, dd), B = 2.0 * dot3d(oo, dd), C = dot3d(oo, oo) - radius * radius, near_t, far_t;
+    int found = solve_quadratic_d(A, B, C, &near_t, &far_t);
+    int out_bounds = !(near_t <= maxt && far_t >= 0.0), in_bounds = near_t < 0.0 && far_t > maxt;
+    return found && !out_bounds && !in_bounds;
+}
 static inline v3 mesh_pos(const orc_shape *sh, uint32_t i) { return V(sh->positions[3 * i], sh->positions[3 * i + 1], sh->positions[3 * i + 2]); }
 
 /* closest hit in one shape.  Candidates are all primitives hit with t <= the ray's maxt; the
@@ -420,6 +463,10 @@ static void shape_closest(const orc_shape *sh, v3 o, v3 d, float maxt, int32_t o
     if (sh->kind == ORC_SHAPE_RECT) {
         if (rect_intersect(sh, o, d, maxt, &t, &u, &v) && t < best->t) {
             best->t = t; best->u = u; best->v = v; best->obj = obj; best->shape = shape_idx; best->prim = 0;
+        }
+    } else if (sh->kind == ORC_SHAPE_SPHERE) {
+        if (sphere_intersect(sh, o, d, maxt, &t) && t < best->t) {
+            best->t = t; best->u = 0.f; best->v = 0.f; best->obj = obj; best->shape = shape_idx; best->prim = 0;
         }
     } else {
         for (int32_t f = 0; f < sh->n_faces; ++f) {
@@ -434,6 +481,7 @@ static void shape_closest(const orc_shape *sh, v3 o, v3 d, float maxt, int32_t o
 static int shape_any(const orc_shape *sh, v3 o, v3 d, float maxt) {
     float t, u, v;
     if (sh->kind == ORC_SHAPE_RECT) return rect_intersect(sh, o, d, maxt, &t, &u, &v);
+    if (sh->kind == ORC_SHAPE_SPHERE) return sphere_test(sh, o, d, maxt);
     for (int32_t f = 0; f < sh->n_faces; ++f) {
         const uint32_t *fi = sh->faces + 3 * f;
         if (tri_intersect(mesh_pos(sh, fi[0]), mesh_pos(sh, fi[1]), mesh_pos(sh, fi[2]), o, d, maxt, &t, &u, &v)) return 1;
@@ -513,6 +561,20 @@ static void rect_si(const orc_shape *sh, v3 o, v3 d, float t, orc_si *si) {
     si->p = v_add(p, v_mul(n, dist));
     si->n = n; si->sh_n = n; si->dp_du = dp_du; si->dp_dv = dp_dv;
 }
+/* Sphere::compute_surface_interaction -- src/shapes/sphere.cpp:435-560 (primal branch :509-513, dp_du :527-545) */
+static void sphere_si(const orc_shape *sh, v3 o, v3 d, float t, orc_si *si) {
+    v3 c = V(sh->center[0], sh->center[1], sh->center[2]);
+    v3 n = v_normalize(v_sub(v_fma(d, t, o), c));
+    si->p = v_fma(n, sh->radius, c);
+    v3 local = m_point(sh->to_object, si->p);
+    float rd = sqrtf(f_sqr(local.x) + f_sqr(local.y)), inv_rd = f_rcp(rd);
+    v3 dpv = V(local.z * (local.x * inv_rd), local.z * (local.y * inv_rd), -rd);
+    if (rd == 0.f) dpv = V(1.f, 0.f, 0.f);
+    si->dp_du = v_mul(m_vector(sh->to_world, V(-local.y, local.x, 0.f)), 2.f * ORC_PI_F);
+    si->dp_dv = v_mul(m_vector(sh->to_world, dpv), ORC_PI_F);
+    if (sh->flip_normals) n = v_neg(n);
+    si->sh_n = n; si->n = n;
+}
 /* Mesh::compute_surface_interaction -- src/render/mesh.cpp:632-864 (primal branch) */
 static void mesh_si(const orc_shape *sh, int32_t prim, float b1, float b2, orc_si *si) {
     const uint32_t *fi = sh->faces + 3 * prim;
@@ -554,7 +616,9 @@ static void compute_si(const orc_scene *sc, const orc_hit *h, v3 o, v3 d, float 
     if (ob->kind == ORC_OBJ_SHAPE) {
         const orc_shape *sh = &sc->shapes[ob->index];
         si->shape = sh;
-        if (sh->kind == ORC_SHAPE_RECT) rect_si(sh, o, d, h->t, si); else mesh_si(sh, h->prim, h->u, h->v, si);
+        if (sh->kind == ORC_SHAPE_RECT) rect_si(sh, o, d, h->t, si);
+        else if (sh->kind == ORC_SHAPE_SPHERE) sphere_si(sh, o, d, h->t, si);
+        else mesh_si(sh, h->prim, h->u, h->v, si);
     } else {
         float m[16], inv[16];
         instance_to_world(ob, time, m);
@@ -562,7 +626,9 @@ static void compute_si(const orc_scene *sc, const orc_hit *h, v3 o, v3 d, float 
         const orc_shape *sh = &sc->shapes[sc->groups[ob->index].first_shape + h->shape];
         si->shape = sh;
         v3 lo = m_point(inv, o), ld = m_vector(inv, d);
-        if (sh->kind == ORC_SHAPE_RECT) rect_si(sh, lo, ld, h->t, si); else mesh_si(sh, h->prim, h->u, h->v, si);
+        if (sh->kind == ORC_SHAPE_RECT) rect_si(sh, lo, ld, h->t, si);
+        else if (sh->kind == ORC_SHAPE_SPHERE) sphere_si(sh, lo, ld, h->t, si);
+        else mesh_si(sh, h->prim, h->u, h->v, si);
         si->p = m_point(m, si->p);
         si->n = v_normalize(m_normal(inv, si->n));
         si->sh_n = v_normalize(m_normal(inv, si->sh_n));
@@ -607,7 +673,56 @@ static float rect_inv_area(const orc_shape *sh) {
     v3 du = m_vector(sh->to_world, V(2.f, 0.f, 0.f)), dv = m_vector(sh->to_world, V(0.f, 2.f, 0.f));
     return f_rcp(v_norm(v_cross(du, dv)));
 }
-static float shape_inv_area(const orc_shape *sh) { return sh->kind == ORC_SHAPE_RECT ? rect_inv_area(sh) : sh->area_norm; }
+static float shape_inv_area(const orc_shape *sh) {
+    return sh->kind == ORC_SHAPE_RECT ? rect_inv_area(sh) : sh->kind == ORC_SHAPE_SPHERE ? sh->sphere_inv_area : sh->area_norm;
+}
+static inline float f_safe_sqrt(float x) { return sqrtf(f_max(x, 0.f)); }
+#define ORC_INV_TWO_PI_F 0.15915494309189533577f
+/* warp::square_to_uniform_cone_pdf (warp.h:475-485) */
+static inline float uniform_cone_pdf(float cos_cutoff) { return ORC_INV_TWO_PI_F / (1.f - cos_cutoff); }
+/* Sphere::sample_direction (sphere.cpp:222-296): cone sampling of the visible cap from outside, uniform sphere from inside.
+ * Outputs the sampled point, its normal, the unit direction, distance and solid-angle density. */
+static void sphere_sample_direction(const orc_shape *sh, v3 ref, float s_x, float s_y, v3 *p_out, v3 *n_out, v3 *d_out,
+                                    float *dist_out, float *pdf_out) {
+    const v3 center = V(sh->center[0], sh->center[1], sh->center[2]);
+    const float radius = sh->radius;
+    v3 dc_v = v_sub(center, ref);
+    float dc_2 = v_dot(dc_v, dc_v);
+    float radius_adj = radius * (sh->flip_normals ? (1.f + ORC_RAY_EPS) : (1.f - ORC_RAY_EPS));
+    v3 dloc; float pdf;
+    int outside = dc_2 > f_sqr(radius_adj);
+    if (outside) {
+        float inv_dc = f_rsqrt(dc_2), sin_theta_max = radius * inv_dc, sin_theta_max_2 = f_sqr(sin_theta_max),
+              inv_sin_theta_max = f_rcp(sin_theta_max), cos_theta_max = f_safe_sqrt(1.f - sin_theta_max_2);
+        float sin_theta_2 = sin_theta_max_2 > 0.00068523f ? 1.f - f_sqr(fmaf(cos_theta_max - 1.f, s_x, 1.f)) : sin_theta_max_2 * s_x;
+        float cos_theta = f_safe_sqrt(1.f - sin_theta_2);
+        float cos_alpha = sin_theta_2 * inv_sin_theta_max + cos_theta * f_safe_sqrt(fmaf(-sin_theta_2, f_sqr(inv_sin_theta_max), 1.f));
+        float sin_alpha = f_safe_sqrt(fmaf(-cos_alpha, cos_alpha, 1.f));
+        float sin_phi, cos_phi; orc_sincos(s_y * (2.f * ORC_PI_F), &sin_phi, &cos_phi);
+        v3 fn = v_mul(dc_v, -inv_dc), fs, ft;
+        coordinate_system(fn, &fs, &ft);
+        v3 loc = V(cos_phi * sin_alpha, sin_phi * sin_alpha, cos_alpha);
+        dloc = v_fma(fn, loc.z, v_fma(ft, loc.y, v_mul(fs, loc.x)));
+        pdf = uniform_cone_pdf(cos_theta_max);
+    } else {   /* warp::square_to_uniform_sphere (warp.h:250-255) */
+        float z = fmaf(-2.f, s_y, 1.f), r = f_safe_sqrt(fmaf(-z, z, 1.f)), sn, cs;
+        orc_sincos(2.f * ORC_PI_F * s_x, &sn, &cs);
+        dloc = V(r * cs, r * sn, z);
+        pdf = 0.f;
+    }
+    v3 p = v_fma(dloc, radius, center), dd = v_sub(p, ref);
+    float dist2 = v_dot(dd, dd), dist = sqrtf(dist2);
+    dd = v_mul(dd, f_rcp(dist));
+    if (outside) { if (dist == 0.f) pdf = 0.f; }
+    else pdf = sh->sphere_inv_area * dist2 / fabsf(v_dot(dd, dloc));
+    *p_out = p; *n_out = sh->flip_normals ? v_neg(dloc) : dloc; *d_out = dd; *dist_out = dist; *pdf_out = pdf;
+}
+/* Sphere::pdf_direction (sphere.cpp:298-310) */
+static float sphere_pdf_direction(const orc_shape *sh, v3 ref, v3 ds_d, v3 ds_n, float ds_dist) {
+    const v3 center = V(sh->center[0], sh->center[1], sh->center[2]);
+    float sin_alpha = sh->radius * f_rcp(v_norm(v_sub(center, ref))), cos_alpha = f_safe_sqrt(1.f - sin_alpha * sin_alpha);
+    return sin_alpha < 0.99999994f ? uniform_cone_pdf(cos_alpha) : sh->sphere_inv_area * f_sqr(ds_dist) / fabsf(v_dot(ds_d, ds_n));
+}
 /* DiscreteDistribution::sample_reuse (distr_1d.h:113-160): first face in [lo, hi] whose cdf is not < value * sum
  * (dr::binary_search), then the sample re-stretched over that face's interval */
 static uint32_t mesh_sample_face(const orc_shape *sh, float value, float *reuse) {
@@ -734,7 +849,8 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
                 float dp = v_dot(dsd, si.sh_n);   /* ds.n = si.sh_frame.n: PositionSample(si), records.h:63-65 */
                 if (dp < 0.f) {   /* Shape::pdf_direction shape.cpp:386-396; pdf_position = 1/area (rectangle.cpp:168-171, mesh.cpp:570-573) */
                     float adp = fabsf(dp);
-                    float pdf = shape_inv_area(si.shape) * (adp != 0.f ? (dist * dist) / adp : 0.f);
+                    float pdf = si.shape->kind == ORC_SHAPE_SPHERE ? sphere_pdf_direction(si.shape, prev_p, dsd, si.sh_n, dist)
+                              : shape_inv_area(si.shape) * (adp != 0.f ? (dist * dist) / adp : 0.f);
                     em_pdf = pdf * pmf;
                 }
             }
@@ -776,6 +892,9 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
                  * Rectangle::sample_position rectangle.cpp:152-166 */
                 const orc_shape *es = &sc->shapes[em->shape];
                 v3 en;
+                if (es->kind == ORC_SHAPE_SPHERE) {   /* Sphere overrides Shape::sample_direction */
+                    sphere_sample_direction(es, si.p, sx, e2, &dsp, &en, &dd, &ds_dist, &ds_pdf);
+                } else {
                 if (es->kind == ORC_SHAPE_RECT) {
                     dsp = m_point(es->to_world, V(sx * 2.f - 1.f, e2 * 2.f - 1.f, 0.f));
                     en = v_normalize(m_normal(es->to_object, V(0.f, 0.f, 1.f)));
@@ -786,6 +905,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
                 dd = v_mul(dd, f_rcp(ds_dist));
                 float dp = fabsf(v_dot(dd, en)), x = dist2 / dp;
                 ds_pdf = shape_inv_area(es) * (isfinite(x) ? x : 0.f);
+                }
                 ds_delta = 0;
                 em_active = v_dot(dd, en) < 0.f && ds_pdf != 0.f;
                 float ip = f_rcp(ds_pdf);
@@ -1069,4 +1189,33 @@ int orc_mesh_area_table(const float *P, int32_t n_faces, const uint32_t *faces, 
     if (*lo < 0) return -1;
     *sum_out = (float) sum; *norm_out = (float) (1.0 / sum);
     return 0;
+}
+
+/* Sphere ctor + update -- see the header */
+static void m4_mul_f32(const float *a, const float *b, float *out) {   /* out_ij = fmadd chain over k (Dr.Jit Matrix operator*) */
+    float r[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        float sum = a[4 * i] * b[j];
+        for (int k = 1; k < 4; ++k) sum = fmaf(a[4 * i + k], b[4 * k + j], sum);
+        r[4 * i + j] = sum;
+    }
+    memcpy(out, r, sizeof r);
+}
+void orc_bake_sphere(const float *to_world, const float *to_object, const float *center, float radius, int32_t flip_normals,
+                     float *composed, float *composed_inv, float *out8) {
+    float T[16] = { 1, 0, 0, center[0], 0, 1, 0, center[1], 0, 0, 1, center[2], 0, 0, 0, 1 };
+    float Ti[16] = { 1, 0, 0, -center[0], 0, 1, 0, -center[1], 0, 0, 1, -center[2], 0, 0, 0, 1 };
+    float ir = 1.0f / radius;
+    float S[16] = { radius, 0, 0, 0, 0, radius, 0, 0, 0, 0, radius, 0, 0, 0, 0, 1 }, Si[16] = { ir, 0, 0, 0, 0, ir, 0, 0, 0, 0, ir, 0, 0, 0, 0, 1 };
+    float tmp[16];
+    m4_mul_f32(to_world, T, tmp); m4_mul_f32(tmp, S, composed);
+    m4_mul_f32(Ti, to_object, tmp); m4_mul_f32(Si, tmp, composed_inv);
+    v3 c0 = V(composed[0], composed[4], composed[8]);
+    float r = v_norm(c0);
+    const float *m = composed;
+    float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+    int flip = flip_normals != 0;
+    if (det < 0.f) flip = !flip;
+    out8[0] = composed[3]; out8[1] = composed[7]; out8[2] = composed[11]; out8[3] = r;
+    out8[4] = 1.0f / ((4.f * ORC_PI_F) * f_sqr(r)); out8[5] = flip ? 1.f : 0.f; out8[6] = out8[7] = 0.f;
 }

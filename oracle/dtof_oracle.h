@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-enum { ORC_SHAPE_RECT = 0, ORC_SHAPE_MESH = 1 };
+enum { ORC_SHAPE_RECT = 0, ORC_SHAPE_MESH = 1, ORC_SHAPE_SPHERE = 2 };
 enum { ORC_OBJ_SHAPE = 0, ORC_OBJ_INSTANCE = 1 };
 enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1 };
 enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 };
@@ -55,6 +55,9 @@ typedef struct {
     const float *area_pmf, *area_cdf;   /* n_faces each */
     float   area_sum, area_norm;        /* float(sum), float(1 / sum) */
     int32_t area_lo, area_hi;           /* m_valid: first / last face with non-zero area */
+    /* sphere (src/shapes/sphere.cpp:117-160), filled by orc_bake_sphere; to_world / to_object above hold the composed
+     * to_world * translate(center) * scale(radius) and its inverse */
+    float   center[3], radius, sphere_inv_area;
 } orc_shape;
 
 typedef struct {
@@ -183,6 +186,13 @@ void     orc_bake_cube(const float *to_world, const float *to_object, float *pos
 void     orc_bake_mesh(const float *to_world, const float *to_object, int32_t n_vertices, const float *pos_in,
                        const float *nrm_in, int32_t n_faces, const uint32_t *faces, int32_t face_normals,
                        float *pos_out, float *nrm_out);
+
+/* Sphere ctor + update (sphere.cpp:121-160), all in float32 as ScalarTransform4f is: composed = to_world * translate(center) *
+ * scale(radius) (4x4 products, fmadd accumulation over k), its inverse from the factors' analytic inverses in the reverse
+ * order; radius = |composed * (1,0,0)|, center = composed * (0,0,0); a mirroring transform (negative determinant) toggles
+ * flip_normals; inv_area = rcp(4 pi r^2).  out8 = center[3], radius, inv_area, flip (as float 0/1), 2 spare. */
+void     orc_bake_sphere(const float *to_world, const float *to_object, const float *center, float radius, int32_t flip_normals,
+                         float *composed, float *composed_inv, float *out8);
 
 /* Mesh::build_pmf + DiscreteDistribution::compute_cdf (mesh.cpp:478-511, distr_1d.h:205-240): pmf[i] = .5 |e0 x e1| in
  * float32, running sum in double, cdf[i] = float(sum), sum / normalization rounded to float32 once. Returns 0 on success,

@@ -24,7 +24,8 @@ class OrcShape(C.Structure):
                 ("texcoords", C.POINTER(C.c_float)), ("faces", C.POINTER(C.c_uint32)),
                 ("emitter", C.c_int32), ("radiance", C.c_float * 3),
                 ("area_pmf", C.POINTER(C.c_float)), ("area_cdf", C.POINTER(C.c_float)),
-                ("area_sum", C.c_float), ("area_norm", C.c_float), ("area_lo", C.c_int32), ("area_hi", C.c_int32)]
+                ("area_sum", C.c_float), ("area_norm", C.c_float), ("area_lo", C.c_int32), ("area_hi", C.c_int32),
+                ("center", C.c_float * 3), ("radius", C.c_float), ("sphere_inv_area", C.c_float)]
 
 
 class OrcGroup(C.Structure):
@@ -120,6 +121,7 @@ def lib():
         L.orc_render.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_int]
         L.orc_bake_cube.argtypes = [C.c_void_p] * 6
+        L.orc_bake_sphere.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mesh_area_table.restype = C.c_int
         L.orc_mesh_area_table.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_bake_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
@@ -156,6 +158,18 @@ class Scene:
             o.to_world, o.to_object = _m16(s["to_world"]), _m16(s["to_object"])
             o.emitter = int(s.get("emitter", 0))
             o.radiance = (C.c_float * 3)(*np.asarray(s.get("radiance", [0, 0, 0]), np.float32).tolist())
+            if s["kind"] == 2:   # sphere: compose / decompose the transform in C float32 (orc_bake_sphere)
+                tw = np.ascontiguousarray(s["to_world"], dtype=np.float32)
+                to = np.ascontiguousarray(s["to_object"], dtype=np.float32)
+                ctr = np.ascontiguousarray(s["sphere"]["center"], dtype=np.float32)
+                comp, comp_inv, out8 = np.zeros(16, np.float32), np.zeros(16, np.float32), np.zeros(8, np.float32)
+                L.orc_bake_sphere(tw.ctypes.data, to.ctypes.data, ctr.ctypes.data, C.c_float(float(s["sphere"]["radius"])),
+                                  int(s["flip_normals"]), comp.ctypes.data, comp_inv.ctypes.data, out8.ctypes.data)
+                s["to_world"], s["to_object"] = comp.reshape(4, 4), comp_inv.reshape(4, 4)
+                s["sphere_baked"] = out8
+                o.to_world, o.to_object = _m16(comp), _m16(comp_inv)
+                o.center = (C.c_float * 3)(*out8[:3].tolist())
+                o.radius, o.sphere_inv_area, o.flip_normals = float(out8[3]), float(out8[4]), int(out8[5])
             if s["kind"] == 1 and s.get("mesh_raw") is not None:   # obj / ply: bake in C (orc_bake_mesh)
                 raw = s["mesh_raw"]
                 pin = np.ascontiguousarray(raw["positions"], dtype=np.float32).reshape(-1)

@@ -337,7 +337,7 @@ class FlatScene:
 
 
 def _shape_record(sp, registry, strip_to_world, base_dir=""):
-    kind = {"rectangle": 0, "cube": 1, "obj": 1, "ply": 1}.get(sp.plugin)
+    kind = {"rectangle": 0, "cube": 1, "obj": 1, "ply": 1, "sphere": 2}.get(sp.plugin)
     if kind is None:
         raise ValueError('unsupported shape plugin "%s"' % sp.plugin)
     mesh_raw = None
@@ -376,8 +376,14 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
         twosided, refl = _bsdf_of(bp, registry)
     else:   # shape.cpp:66-72: default diffuse, reflectance 0 when the shape is an emitter
         twosided, refl = 0, np.array([0.0 if emitter else 0.5] * 3, dtype=F32)
+    sphere = None
+    if kind == 2:   # src/shapes/sphere.cpp:121-131: center (point, default 0) and radius (default 1) on top of to_world
+        c = sp["center"][1] if "center" in sp else [0.0, 0.0, 0.0]
+        sp.queried.add("center")
+        sphere = dict(center=np.asarray(c, dtype=np.float64).astype(F32), radius=F32(sp.get_f("radius", 1.0)))
     return dict(kind=kind, twosided=twosided, flip_normals=int(flip), face_normals=int(sp.get_b("face_normals", False)),
-                reflectance=refl, to_world=_m32(tw), to_object=_m32(tinv), emitter=emitter, radiance=radiance, mesh_raw=mesh_raw)
+                reflectance=refl, to_world=_m32(tw), to_object=_m32(tinv), emitter=emitter, radiance=radiance, mesh_raw=mesh_raw,
+                sphere=sphere)
 
 
 def load(source, params=None, is_string=False):

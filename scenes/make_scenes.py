@@ -123,6 +123,36 @@ def cornell(moving_wall, res, spp, tsm, shift, area_light=False):
     return s + (AREA_LIGHT if area_light else LIGHT) + "</scene>\n"
 
 
+def sphere(ident, bsdf_id, center, radius, anim_dz=None, emitter=None, extra=""):
+    s = '\t<shape type="sphere" id="%s">\n\t\t<point name="center" x="%s" y="%s" z="%s" />\n\t\t<float name="radius" value="%s" />\n%s' % (
+        (ident,) + tuple(center) + (radius, extra))
+    if anim_dz is not None:
+        s += ('\t\t<animation name="to_world">\n\t\t\t<transform time="0">\n\t\t\t\t<translate x="0" y="0" z="0" />\n\t\t\t</transform>\n'
+              '\t\t\t<transform time="0.0015">\n\t\t\t\t<translate x="0.0" y="0.0" z="%s" />\n\t\t\t</transform>\n\t\t</animation>\n' % anim_dz)
+    if emitter:
+        s += '\t\t<emitter type="area">\n\t\t\t<rgb name="radiance" value="%s" />\n\t\t</emitter>\n' % emitter
+    if bsdf_id:
+        s += '\t\t<ref id="%s" />\n' % bsdf_id
+    return s + '\t</shape>\n'
+
+
+def cornell_spheres(res=128, spp=16, sphere_light=False):
+    """the Cornell room with two analytic spheres (one static, one moving towards the camera); lit by the point light at the
+    camera, or (sphere_light) by a small spherical area light under the ceiling"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        s += bsdf(*b)
+    for name, m, b in WALLS:
+        s += rect(name, m, b)
+    s += sphere("StaticSphere", "TallBoxBSDF", ("-0.4", "0.4", "-0.3"), "0.4")
+    s += sphere("MovingSphere", "ShortBoxBSDF", ("0.45", "0.3", "0.35"), "0.3", anim_dz="0.015")
+    if sphere_light:
+        s += sphere("Light", None, ("0", "1.7", "0"), "0.12", emitter="40, 30, 12")
+    else:
+        s += LIGHT
+    return s + "</scene>\n"
+
+
 def domino(n_side=32, res=1024, spp=128):
     s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5").replace('value="sinusoidal"', 'value="rectangular"')
     cam = '\t\t\t<lookat origin="0, 9, 16" target="0, 0.3, 0" up="0, 1, 0" />'
@@ -158,6 +188,8 @@ def main():
         "cornell_boxes.xml": cornell(False, 256, 16, "antithetic", "0.5"),
         "cornell_wall.xml": cornell(True, 512, 64, "stratified", "0.0"),
         "cornell_area.xml": cornell(False, 256, 64, "antithetic", "0.5", area_light=True),
+        "cornell_spheres.xml": cornell_spheres(),
+        "cornell_sphere_light.xml": cornell_spheres(sphere_light=True),
         "domino.xml": domino(),
         "domino_small.xml": domino(n_side=6, res=128, spp=16),
     }
