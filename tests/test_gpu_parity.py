@@ -272,6 +272,25 @@ def test_full_size_properties_512x512x64(mi, orc):
     assert abs(other.mean() - both[0].mean()) < 0.05 * np.abs(both[0]).mean() + 1e-6
 
 
+def test_full_frame_every_lane_bit_exact_512x512x64(mi, orc):
+    """BASELINE configs[1] at FULL size, every one of its 16 777 216 lanes against the oracle (the GPU box has 256 host
+    threads: ~2 s of oracle time; on a small host only every 8th band of rows is compared)."""
+    path = os.path.join(SCENES, "cornell_wall.xml")
+    sc, osc = mi.load_file(path), orc.Scene(path)
+    pd = osc.params()
+    rows_per_chunk, lanes_per_row = 32, 512 * 64
+    step = 1 if NCPU >= 64 else 8
+    compared = 0
+    for r0 in range(0, 512, rows_per_chunk * step):
+        lane0, n = r0 * lanes_per_row, rows_per_chunk * lanes_per_row
+        g = sc.sample_lanes(0, 64, lane0, n)
+        o = osc.render_lanes(pd, 0, 64, lane0, n, threads=NCPU)
+        for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+            assert np.array_equal(bits(g[k]), bits(o[k])), (r0, k, int((bits(g[k]) != bits(o[k])).sum()))
+        compared += n
+    assert compared == 512 * 512 * 64 // step
+
+
 # --------------------------------------------------------------------------- SURVEY 8(f) #1: path + velocity on the same kernels
 @pytest.mark.parametrize("integ,sampler", [
     (dict(type="path", max_depth=4), None),
