@@ -32,6 +32,7 @@ struct RenderParams {
     uint32_t path_correlation_depth, max_depth, rr_depth;
     int32_t has_area;                             // scene has area emitters: emitter-hit term + prev_si / prev_bsdf_pdf state
     int32_t sampler_kind, jitter; float inv_spp;  // SamplerKind; timestratified: jitter, 1 / sample_count (timestratified.cpp:78-82)
+    int32_t has_spec;                             // scene has delta BSDFs (conductor / dielectric): eta and prev_bsdf_delta become per-lane state
     int32_t has_tris;                             // scene has triangle meshes (selects the kernel instantiations that carry mesh code)
     int32_t integrator;                           // 0 dopplertofpath, 1 path (src/integrators/path.cpp), 2 velocity (velocity.cpp)
     // ---- batch
@@ -48,6 +49,7 @@ struct Queues {
     float4 *st_a;        // throughput.xyz, path_length
     float4 *st_b;        // prev_si.p, prev_bsdf_pdf (only touched when the scene has area emitters)
     uint4  *rng_a;       // rng.state (lo,hi), rng_path.state (lo,hi)
+    float2 *st_c;        // SPEC: (eta along the path, prev_bsdf_delta)
     uint2  *rng_b;       // (main, path) stream selectors v1 of the TEA seeding: inc = (v1 << 1) | 1, constant per lane
     float4 *res;         // [K][capacity] accumulated result rgb (w unused)
     float2 *pos;         // sample position on the film

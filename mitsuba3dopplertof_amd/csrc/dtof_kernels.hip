@@ -629,6 +629,32 @@ DTOF_D float sphere_pdf_direction(const DShape &sh, V3 ref, V3 ds_d, V3 ds_n, fl
     const float sin_alpha = sh.dp_du[0] * rcp(norm(center - ref)), cos_alpha = safe_sqrt(1.f - sin_alpha * sin_alpha);
     return sin_alpha < 0.99999994f ? uniform_cone_pdf(cos_alpha) : sh.inv_area * sqr(ds_dist) / fabsf(dot(ds_d, ds_n));
 }
+// fresnel_conductor -- include/mitsuba/render/fresnel.h:93-117 (one colour channel)
+DTOF_D float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
+    const float cos_theta_i_2 = cos_theta_i * cos_theta_i, sin_theta_i_2 = 1.f - cos_theta_i_2, sin_theta_i_4 = sin_theta_i_2 * sin_theta_i_2;
+    const float temp_1 = eta_r * eta_r - eta_i * eta_i - sin_theta_i_2,
+                a_2_pb_2 = safe_sqrt(temp_1 * temp_1 + 4.f * eta_i * eta_i * eta_r * eta_r),
+                a = safe_sqrt(.5f * (a_2_pb_2 + temp_1));
+    const float term_1 = a_2_pb_2 + cos_theta_i_2, term_2 = 2.f * cos_theta_i * a;
+    const float r_s = (term_1 - term_2) / (term_1 + term_2);
+    const float term_3 = a_2_pb_2 * cos_theta_i_2 + sin_theta_i_4, term_4 = term_2 * sin_theta_i_2;
+    const float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return 0.5f * (r_s + r_p);
+}
+// fresnel -- include/mitsuba/render/fresnel.h:21-63
+DTOF_D void fresnel_dielectric(float cos_theta_i, float eta, float &r, float &cos_theta_t, float &eta_it, float &eta_ti) {
+    const bool outside = cos_theta_i >= 0.f;
+    const float rcp_eta = rcp(eta);
+    eta_it = outside ? eta : rcp_eta; eta_ti = outside ? rcp_eta : eta;
+    const float cos_theta_t_sqr = fmaf(-fmaf(-cos_theta_i, cos_theta_i, 1.f), eta_ti * eta_ti, 1.f);
+    const float cos_theta_i_abs = fabsf(cos_theta_i), cos_theta_t_abs = safe_sqrt(cos_theta_t_sqr);
+    const bool index_matched = eta == 1.f, special_case = index_matched || cos_theta_i_abs == 0.f;
+    const float a_s = fmaf(-eta_it, cos_theta_t_abs, cos_theta_i_abs) / fmaf(eta_it, cos_theta_t_abs, cos_theta_i_abs);
+    const float a_p = fmaf(-eta_it, cos_theta_i_abs, cos_theta_t_abs) / fmaf(eta_it, cos_theta_i_abs, cos_theta_t_abs);
+    r = 0.5f * (sqr(a_s) + sqr(a_p));
+    if (special_case) r = index_matched ? 0.f : 1.f;
+    cos_theta_t = mulsign_neg(cos_theta_t_abs, cos_theta_i);
+}
 DTOF_D float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
 // Block-wide exclusive prefix of a predicate (ballot + popcount per wave, 4 wave totals through LDS).
@@ -662,7 +688,9 @@ DTOF_D uint32_t block_append(bool pred, uint32_t *s_cnt, uint32_t &running) {
 // MODE 0 = split, 1 = fused, 2 = fused AND first bounce: the lane is generated (sampler seeding, camera ray) and its primary
 // ray traced right here, so the 96-byte primary state never makes the round trip through HBM and neither k_generate nor the
 // primary k_trace launch exists (`dbg`, if given, receives the camera ray for the lane-dump entry point).
-template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH>
+// SPEC: the scene has delta BSDFs (conductor / dielectric): the relative index of refraction along the path and the
+// "previous lobe was a delta" flag travel in st_c; instantiated together with AREA and MESH only.
+template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, bool SPEC>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp, Queues q,
                                                   const uint32_t *qin, const uint32_t *count_in,
                                                   uint32_t *qout, uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth,
@@ -714,11 +742,13 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
         if (hid != 0xffffffffu) {   // a miss ends the path (active_next = false, dopplertofpath.cpp:171)
             V3 o = mk(ra.x, ra.y, ra.z), d = mk(rb.x, rb.y, rb.z); float time = ra.w;
             V3 thr = mk(st.x, st.y, st.z); float path_length = st.w;
+            float eta_path = 1.f; bool prev_delta = depth == 0;   // dopplertofpath.cpp:103-108: eta = 1, prev_bsdf_delta = true
+            if (SPEC && depth > 0) { const float2 sc = q.st_c[l]; eta_path = sc.x; prev_delta = sc.y != 0.f; }
             bool correlate = (depth + 1) < rp.path_correlation_depth;
             const bool plain = rp.integrator != 0;   // `path`: no modulation weight
             const bool single = plain || rp.sampler_kind != SAMPLER_CORRELATED;   // main stream only (path.cpp:197,213-214,273; sampler.h:141-144)
             float t = u2f(hh.x);
-            path_length += t * 1.f;   // eta == 1 for every supported BSDF (dopplertofpath.cpp:141)
+            path_length += t * eta_path;   // dopplertofpath.cpp:141 (eta stays 1 without dielectrics)
             bool active_next = depth + 1 < rp.max_depth;
 
             Surface si;
@@ -738,7 +768,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                     float dist = norm(rel);
                     V3 dsd = rel * rcp(dist);
                     float em_pdf = 0.f;
-                    if (depth > 0) {                                             // !prev_bsdf_delta: AreaLight::pdf_direction (area.cpp:161-180)
+                    if (!prev_delta) {                                          // !prev_bsdf_delta: AreaLight::pdf_direction (area.cpp:161-180)
                         float dp = dot(dsd, si.sh_n);   // ds.n = si.sh_frame.n (PositionSample(si), records.h:63-65)
                         if (dp < 0.f) {
                             const float adp = fabsf(dp);
@@ -762,7 +792,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
 
             // ---- emitter sampling (scene.cpp:235-291; point.cpp:118-147; area.cpp:116-159 + shape.cpp:370-384 + rectangle.cpp:152-166)
             float e1 = single ? next_f32(main) : next_correlate(main, path, correlate), e2 = single ? next_f32(main) : next_correlate(main, path, correlate);
-            bool active_em = active_next && sv.n_emitters > 0;
+            bool active_em = active_next && sv.n_emitters > 0 && (!SPEC || sh->bsdf == BSDF_DIFFUSE);   // has_flag(bsdf->flags(), Smooth) (:178)
             V3 em_weight = mk(0, 0, 0), wo = mk(0, 0, 0); float ds_dist = 0.f, ds_pdf = 0.f; bool ds_delta = true;
             if (active_em) {
                 uint32_t ne = sv.n_emitters, idx = 0; float em_w = 1.f, sx = e1;
@@ -811,7 +841,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 shb = make_float4(sd.x, sd.y, sd.z, time);
                 wo = mk(dot(dd, si.sh_s), dot(dd, si.sh_t), dot(dd, si.sh_n));
             }
-            float sample_1 = single ? next_f32(main) : next_correlate(main, path, correlate); (void) sample_1;
+            const float sample_1 = single ? next_f32(main) : next_correlate(main, path, correlate); (void) sample_1;
             float s2x = single ? next_f32(main) : next_correlate(main, path, correlate), s2y = single ? next_f32(main) : next_correlate(main, path, correlate);
 
             // ---- BSDF eval_pdf + sample (twosided.cpp:111-148,219-258; diffuse.cpp:101-125,160-180)
@@ -820,13 +850,38 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             if (twosided) { woz = mulsign(woz, wiz); wiz = fabsf(wiz); }
             V3 refl = mk(sh->refl[0], sh->refl[1], sh->refl[2]);
             V3 bsdf_val = mk(0, 0, 0), bsdf_weight = mk(0, 0, 0), bs_wo = mk(0, 0, 0);
-            float bsdf_pdf = 0.f, bs_pdf = 0.f;
-            if (wiz > 0.f && woz > 0.f) { bsdf_val = mk(refl.x * kInvPi * woz, refl.y * kInvPi * woz, refl.z * kInvPi * woz); bsdf_pdf = kInvPi * woz; }
-            if (wiz > 0.f) {
-                bs_wo = cosine_hemisphere(s2x, s2y);
-                bs_pdf = kInvPi * bs_wo.z;
-                if (bs_pdf > 0.f) bsdf_weight = refl;
-                if (twosided) bs_wo.z = mulsign(bs_wo.z, si.wi.z);
+            float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; bool bs_delta = false;
+            if (SPEC && sh->bsdf == BSDF_CONDUCTOR) {
+                // SmoothConductor::sample (conductor.cpp:226-277) under TwoSidedBRDF::sample; eval / pdf of a delta lobe are zero
+                const float cos_theta_i = twosided ? fabsf(si.wi.z) : si.wi.z;
+                if (cos_theta_i > 0.f) {
+                    bs_wo = mk(-si.wi.x, -si.wi.y, si.wi.z);   // reflect(wi); the two-sided flips of wi.z and wo.z cancel
+                    bs_eta = 1.f; bs_pdf = 1.f; bs_delta = true;
+                    bsdf_weight = mk(sh->spec_refl[0] * fresnel_conductor(cos_theta_i, sh->cond_eta[0], sh->cond_k[0]),
+                                     sh->spec_refl[1] * fresnel_conductor(cos_theta_i, sh->cond_eta[1], sh->cond_k[1]),
+                                     sh->spec_refl[2] * fresnel_conductor(cos_theta_i, sh->cond_eta[2], sh->cond_k[2]));
+                }
+            } else if (SPEC && sh->bsdf == BSDF_DIELECTRIC) {
+                // SmoothDielectric::sample (dielectric.cpp:231-338), TransportMode::Radiance
+                float r_i, cos_theta_t, eta_it, eta_ti;
+                fresnel_dielectric(si.wi.z, sh->diel_eta, r_i, cos_theta_t, eta_it, eta_ti);
+                const float t_i = 1.f - r_i;
+                const bool selected_r = sample_1 <= r_i;
+                bs_pdf = selected_r ? r_i : t_i; bs_delta = true;
+                bs_wo = selected_r ? mk(-si.wi.x, -si.wi.y, si.wi.z) : mk(-eta_ti * si.wi.x, -eta_ti * si.wi.y, cos_theta_t);
+                bs_eta = selected_r ? 1.f : eta_it;
+                const float f2 = sqr(eta_ti);
+                bsdf_weight = selected_r ? mk(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2])
+                                         : mk(sh->spec_trans[0] * f2, sh->spec_trans[1] * f2, sh->spec_trans[2] * f2);
+            } else {
+                if (wiz > 0.f && woz > 0.f) { bsdf_val = mk(refl.x * kInvPi * woz, refl.y * kInvPi * woz, refl.z * kInvPi * woz); bsdf_pdf = kInvPi * woz; }
+                if (wiz > 0.f) {
+                    bs_wo = cosine_hemisphere(s2x, s2y);
+                    bs_pdf = kInvPi * bs_wo.z;
+                    bs_eta = 1.f;
+                    if (bs_pdf > 0.f) bsdf_weight = refl;
+                    if (twosided) bs_wo.z = mulsign(bs_wo.z, si.wi.z);
+                }
             }
             // ---- emitter contribution candidate (dopplertofpath.cpp:214-226); committed by k_shadow if unoccluded
             if (active_em) {
@@ -854,7 +909,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             V3 nd = vfma(si.sh_n, bs_wo.z, vfma(si.sh_t, bs_wo.y, si.sh_s * bs_wo.x));   // Frame::to_world
             V3 no = offset_p(si, nd);
             thr = mk(thr.x * bsdf_weight.x, thr.y * bsdf_weight.y, thr.z * bsdf_weight.z);
-            float eta = wiz > 0.f ? 1.f : 0.f;   // bs.eta of the zero-initialised sample when cos_theta_i <= 0
+            const float eta = eta_path * bs_eta;   // eta *= bs.eta (:252); bs.eta = 0 for the zero-initialised sample when cos_theta_i <= 0
             uint32_t ndepth = depth + 1;
             float thr_max = fmax_(fmax_(thr.x, thr.y), thr.z);
             float rr_prob = fmin_(thr_max * sqr(eta), .95f);
@@ -868,6 +923,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 q.ray_b[l] = nrb;
                 q.st_a[l] = make_float4(thr.x, thr.y, thr.z, path_length);
                 if (AREA) q.st_b[l] = make_float4(si.p.x, si.p.y, si.p.z, bs_pdf);   // prev_si, prev_bsdf_pdf (:256-257)
+                if (SPEC) q.st_c[l] = make_float2(eta, bs_delta ? 1.f : 0.f);         // eta, prev_bsdf_delta (:252,258)
                 q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
             }
         }
@@ -1163,10 +1219,11 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
     if (rp.n_lanes == 0) return;
     uint32_t sw = stage_words_for(scene_bytes), grid = nseg(rp.n_lanes), lds = sw * 16 + (fused ? stack_bytes(stack_depth, kShadeBlock) : 0);
     uint32_t tn = trace_next ? 1u : 0u;
-#define DTOF_LAUNCH_SHADE(L, F, A, K) do { if (rp.has_tris) DTOF_LAUNCH_SHADE_M(L, F, A, K, true); else DTOF_LAUNCH_SHADE_M(L, F, A, K, false); } while (0)
-#define DTOF_LAUNCH_SHADE_M(L, F, A, K, M) hipLaunchKernelGGL((k_shade<L, F, A, K, M>), dim3(grid), dim3(kShadeBlock), lds, s, scene, scene_bytes, sw, rp, q, qin, \
+#define DTOF_LAUNCH_SHADE(L, F, A, K) do { if (rp.has_tris) DTOF_LAUNCH_SHADE_M(L, F, A, K, true, false); else DTOF_LAUNCH_SHADE_M(L, F, A, K, false, false); } while (0)
+#define DTOF_LAUNCH_SHADE_M(L, F, A, K, M, S) hipLaunchKernelGGL((k_shade<L, F, A, K, M, S>), dim3(grid), dim3(kShadeBlock), lds, s, scene, scene_bytes, sw, rp, q, qin, \
                                                          count_in, qout, alive_out, shadow_out, depth, tn, dbg)
-#define DTOF_SHADE_AK(L, F) do { if (rp.has_area) { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE(L, F, true, 1); else DTOF_LAUNCH_SHADE(L, F, true, kMaxOffsets); } \
+#define DTOF_SHADE_AK(L, F) do { if (rp.has_spec) { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE_M(L, F, true, 1, true, true); else DTOF_LAUNCH_SHADE_M(L, F, true, kMaxOffsets, true, true); } \
+                                 else if (rp.has_area) { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE(L, F, true, 1); else DTOF_LAUNCH_SHADE(L, F, true, kMaxOffsets); } \
                                  else { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE(L, F, false, 1); else DTOF_LAUNCH_SHADE(L, F, false, kMaxOffsets); } } while (0)
     if (first && !fused) throw std::runtime_error("the first-bounce kernel exists in the fused pipeline only");
     if (sw) { if (first) DTOF_SHADE_AK(true, 2); else if (fused) DTOF_SHADE_AK(true, 1); else DTOF_SHADE_AK(true, 0); }

@@ -55,7 +55,7 @@ struct Workspace {
     DevBuf<float4> ray_a, ray_b, st_a, st_b, res, sh_a, sh_b, sh_c;
     DevBuf<uint4> hit, rng_a;
     DevBuf<uint32_t> hit_id, q0, q1, counts;
-    DevBuf<float2> pos;
+    DevBuf<float2> pos, st_c;
     DevBuf<uint2> rng_b;
     DevBuf<LaneDebug> dbg;
     uint32_t capacity = 0; int k = 0;
@@ -65,11 +65,11 @@ struct Workspace {
         ray_a.ensure(capacity); ray_b.ensure(capacity); st_a.ensure(capacity); st_b.ensure(capacity);
         res.ensure((size_t) capacity * k); sh_a.ensure(capacity); sh_b.ensure(capacity); sh_c.ensure((size_t) capacity * k);
         hit.ensure(capacity); rng_a.ensure(capacity); hit_id.ensure(capacity); q0.ensure(capacity); q1.ensure(capacity);
-        counts.ensure(2 * (size_t) kMaxIter * segments_for(capacity)); pos.ensure(capacity); rng_b.ensure(capacity);
+        counts.ensure(2 * (size_t) kMaxIter * segments_for(capacity)); pos.ensure(capacity); rng_b.ensure(capacity); st_c.ensure(capacity);
     }
     Queues queues() {
         Queues q; memset(&q, 0, sizeof q);
-        q.ray_a = ray_a.p; q.ray_b = ray_b.p; q.hit = hit.p; q.hit_id = hit_id.p; q.st_a = st_a.p; q.st_b = st_b.p; q.rng_a = rng_a.p; q.rng_b = rng_b.p;
+        q.ray_a = ray_a.p; q.ray_b = ray_b.p; q.hit = hit.p; q.hit_id = hit_id.p; q.st_a = st_a.p; q.st_b = st_b.p; q.rng_a = rng_a.p; q.rng_b = rng_b.p; q.st_c = st_c.p;
         q.res = res.p; q.pos = pos.p; q.sh_a = sh_a.p; q.sh_b = sh_b.p; q.sh_c = sh_c.p; q.q[0] = q0.p; q.q[1] = q1.p;
         q.counts = counts.p; q.capacity = capacity;
         return q;
@@ -274,6 +274,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     bool has_surface_emitters = false;          // area emitters make the emitter-hit term (and the last iteration) live
     for (auto &e : sc->host.emitters) has_surface_emitters |= e.kind == EMITTER_AREA;
     rp.has_area = has_surface_emitters;
+    for (auto &sh : sc->host.shapes) rp.has_spec |= sh.bsdf != BSDF_DIFFUSE;
     bool has_spheres = false;
     for (auto &sh : sc->host.shapes) has_spheres |= sh.kind == SHAPE_SPHERE;
     rp.has_tris = bh->n_tris != 0 || has_spheres;   // anything but rectangles: the instantiations with triangle / sphere code

@@ -17,6 +17,7 @@ enum WaveType : int32_t { WAVE_SIN = 0, WAVE_RECT = 1, WAVE_TRI = 2, WAVE_TRAP =
 enum TimeSampling : int32_t { TIME_UNIFORM = 0, TIME_STRATIFIED = 1, TIME_ANTITHETIC = 2, TIME_ANTITHETIC_MIRROR = 3 };
 enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1, FILTER_GAUSSIAN = 2 };
 enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4, SF_EMITTER = 8 };
+enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2 };
 enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1 };
 
 // ---------------------------------------------------------------------------- device blob records
@@ -48,7 +49,7 @@ struct DObject {            // 128 B
     float key0[12], key1[12];
 };
 struct DGroup { uint32_t first_shape, n_shapes, pad[2]; };
-struct DShape {             // 224 B
+struct DShape {             // 304 B
     uint32_t kind, flags, first_tri, n_tris;
     float refl[3]; uint32_t blas_root;                   // mesh: root node of its BLAS, kNoChild = loop over the triangles
     float to_world[12], to_object[12];
@@ -60,11 +61,15 @@ struct DShape {             // 224 B
     float n[3]; uint32_t emit_table; float dp_du[3]; uint32_t emit_lo; float dp_dv[3]; uint32_t emit_hi;
     float bmin[3], emit_sum, bmax[3], pad5;             // padded bounds of the shape in ITS space (mesh: culls the triangle loop); emit_sum = float(sum of areas)
     float radiance[3], inv_area;                        // SF_EMITTER: AreaLight radiance, 1 / area (Rectangle::m_inv_surface_area, DiscreteDistribution::normalization)
+    // BSDF: BSDF_DIFFUSE uses refl; BSDF_CONDUCTOR (src/bsdfs/conductor.cpp) cond_eta / cond_k / spec_refl; BSDF_DIELECTRIC
+    // (src/bsdfs/dielectric.cpp) diel_eta = int_ior / ext_ior, spec_refl, spec_trans
+    uint32_t bsdf; float diel_eta, pad6[2];
+    float cond_eta[3], pad7, cond_k[3], pad8, spec_refl[3], pad9, spec_trans[3], pad10;
 };
 struct DTri { float p0[3]; uint32_t face; float p1[4], p2[4]; };         // 48 B; face = index in the mesh's own order (tie rule)
 struct DTriShade { float n0[3], n1[3], n2[3], uv0[2], uv1[2], uv2[2], pad; };   // 64 B
 struct DEmitter { uint32_t kind; float pos[3]; float intensity[3]; uint32_t shape; };   // area: intensity = radiance, shape = index into shapes[]
-static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 224 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64, "blob records");
+static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 304 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64, "blob records");
 
 // ---------------------------------------------------------------------------- host description
 struct Mat4d { double m[16]; };   // row-major
@@ -73,6 +78,8 @@ struct HostShape {
     uint32_t kind = SHAPE_RECT;
     bool twosided = false, flip_normals = false, face_normals = false;
     float refl[3] = { .5f, .5f, .5f };
+    uint32_t bsdf = BSDF_DIFFUSE;   // + the parameters of the specular BSDFs
+    float cond_eta[3] = { 0, 0, 0 }, cond_k[3] = { 1, 1, 1 }, spec_refl[3] = { 1, 1, 1 }, spec_trans[3] = { 1, 1, 1 }, diel_eta = 1.f;
     float to_world[16], to_object[16];     // float casts of the double transform and its double inverse
     // mesh: cube baked like src/shapes/cube.cpp:114-160; obj / ply through mesh_io.cpp
     std::vector<float> positions, normals, texcoords;

@@ -439,18 +439,51 @@ static void resolve_refs(Obj &o, LoadCtx &ctx) {
 }
 
 // ---------------------------------------------------------------------------- assembly
-static void bsdf_of(const Obj &b, bool &twosided, float refl[3]) {
+// include/mitsuba/render/ior.h:16-44 (physical constants) + lookup_ior :71-77
+static float lookup_ior(const Obj &b, const char *name, const char *def) {
+    auto it = b.props.values.find(name);
+    if (it != b.props.values.end() && (it->second.type == PropValue::Float || it->second.type == PropValue::Int)) return (float) b.props.get_float(name, 0.0);
+    static const std::pair<const char *, float> table[] = { { "vacuum", 1.0f }, { "helium", 1.000036f }, { "hydrogen", 1.000132f }, { "air", 1.000277f },
+        { "carbon dioxide", 1.00045f }, { "water", 1.3330f }, { "acetone", 1.36f }, { "ethanol", 1.361f }, { "carbon tetrachloride", 1.461f },
+        { "glycerol", 1.4729f }, { "benzene", 1.501f }, { "silicone oil", 1.52045f }, { "bromine", 1.661f }, { "water ice", 1.31f },
+        { "fused quartz", 1.458f }, { "pyrex", 1.470f }, { "acrylic glass", 1.49f }, { "polypropylene", 1.49f }, { "bk7", 1.5046f },
+        { "sodium chloride", 1.544f }, { "amber", 1.55f }, { "pet", 1.5750f }, { "diamond", 2.419f } };
+    std::string key = b.props.get_string(name, def);
+    std::transform(key.begin(), key.end(), key.begin(), ::tolower);
+    for (auto &e : table) if (key == e.first) return e.second;
+    fail("Unable to find an IOR value for \"" + key + "\"!");
+}
+static void color_of(const Obj &b, const char *name, float def, float out[3]) {
+    auto c = b.colors.find(name);
+    if (c != b.colors.end()) { for (int i = 0; i < 3; ++i) out[i] = (float) c->second[i]; }
+    else { float r = (float) b.props.get_float(name, def); out[0] = out[1] = out[2] = r; }
+}
+// diffuse (src/bsdfs/diffuse.cpp), conductor (conductor.cpp:171-188), dielectric (dielectric.cpp:176-203), twosided{...} (twosided.cpp:40-70)
+static void bsdf_of(const Obj &b, HostShape &s) {
     if (b.plugin == "twosided") {
         const Obj *inner = nullptr; int n = 0;
         for (auto &c : b.children) if (c.first == "bsdf") { inner = c.second.get(); ++n; }
         if (n != 1) fail("twosided: exactly one nested BSDF is supported");
-        bool ts; bsdf_of(*inner, ts, refl); twosided = true; return;
+        bsdf_of(*inner, s);
+        if (s.bsdf == BSDF_DIELECTRIC) fail("Only materials without a transmission component can be nested!");
+        s.twosided = true; return;
     }
-    if (b.plugin != "diffuse") fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, twosided)");
-    twosided = false;
-    auto c = b.colors.find("reflectance");
-    if (c != b.colors.end()) { for (int i = 0; i < 3; ++i) refl[i] = (float) c->second[i]; }
-    else { float r = (float) b.props.get_float("reflectance", 0.5); refl[0] = refl[1] = refl[2] = r; }
+    s.twosided = false;
+    if (b.plugin == "diffuse") { s.bsdf = BSDF_DIFFUSE; color_of(b, "reflectance", 0.5f, s.refl); }
+    else if (b.plugin == "conductor") {
+        std::string material = b.props.get_string("material", "none");
+        if (material != "none") fail(b.props.has("eta") || b.colors.count("eta") ? "Should specify either (eta, k) or material, not both."
+            : "conductor: named materials need the spectral IOR data files, which this build does not ship; give \"eta\" and \"k\"");
+        s.bsdf = BSDF_CONDUCTOR;
+        color_of(b, "eta", 0.f, s.cond_eta); color_of(b, "k", 1.f, s.cond_k); color_of(b, "specular_reflectance", 1.f, s.spec_refl);
+    } else if (b.plugin == "dielectric") {
+        const float int_ior = lookup_ior(b, "int_ior", "bk7"), ext_ior = lookup_ior(b, "ext_ior", "air");
+        if (int_ior < 0 || ext_ior < 0) fail("The interior and exterior indices of refraction must be positive!");
+        s.bsdf = BSDF_DIELECTRIC; s.diel_eta = int_ior / ext_ior;
+        color_of(b, "specular_reflectance", 1.f, s.spec_refl); color_of(b, "specular_transmittance", 1.f, s.spec_trans);
+    } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, conductor, dielectric, twosided)");
+    auto u = b.props.unqueried();
+    if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in plugin of type \"" + b.plugin + "\"");
 }
 
 static void bake_cube(HostShape &s) {   // src/shapes/cube.cpp:114-160
@@ -537,7 +570,7 @@ static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string
         }
         else fail("unsupported child <" + c.first + "> in shape");
     }
-    if (bsdf) bsdf_of(*bsdf, s.twosided, s.refl);   // else default diffuse: 0.5, or 0 for an emitter (src/render/shape.cpp:66-72)
+    if (bsdf) bsdf_of(*bsdf, s);   // else default diffuse: 0.5, or 0 for an emitter (src/render/shape.cpp:66-72)
     else if (s.emitter) s.refl[0] = s.refl[1] = s.refl[2] = 0.f;
     RawMesh raw;
     if (mesh_file) {   // src/shapes/obj.cpp:139-143, ply.cpp:160-166: `filename` through the file resolver

@@ -760,6 +760,32 @@ static void mesh_sample_position(const orc_shape *sh, float s_x, float s_y, v3 *
     if (sh->flip_normals) n = v_neg(n);
     *n_out = n;
 }
+/* fresnel_conductor -- include/mitsuba/render/fresnel.h:93-117 (one colour channel) */
+static float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
+    float cos_theta_i_2 = cos_theta_i * cos_theta_i, sin_theta_i_2 = 1.f - cos_theta_i_2, sin_theta_i_4 = sin_theta_i_2 * sin_theta_i_2;
+    float temp_1 = eta_r * eta_r - eta_i * eta_i - sin_theta_i_2,
+          a_2_pb_2 = f_safe_sqrt(temp_1 * temp_1 + 4.f * eta_i * eta_i * eta_r * eta_r),
+          a = f_safe_sqrt(.5f * (a_2_pb_2 + temp_1));
+    float term_1 = a_2_pb_2 + cos_theta_i_2, term_2 = 2.f * cos_theta_i * a;
+    float r_s = (term_1 - term_2) / (term_1 + term_2);
+    float term_3 = a_2_pb_2 * cos_theta_i_2 + sin_theta_i_4, term_4 = term_2 * sin_theta_i_2;
+    float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return 0.5f * (r_s + r_p);
+}
+/* fresnel -- include/mitsuba/render/fresnel.h:21-63: (r, cos_theta_t, eta_it, eta_ti) */
+static void fresnel_dielectric(float cos_theta_i, float eta, float *r_out, float *cos_theta_t, float *eta_it_out, float *eta_ti_out) {
+    int outside = cos_theta_i >= 0.f;
+    float rcp_eta = f_rcp(eta), eta_it = outside ? eta : rcp_eta, eta_ti = outside ? rcp_eta : eta;
+    float cos_theta_t_sqr = fmaf(-fmaf(-cos_theta_i, cos_theta_i, 1.f), eta_ti * eta_ti, 1.f);
+    float cos_theta_i_abs = fabsf(cos_theta_i), cos_theta_t_abs = f_safe_sqrt(cos_theta_t_sqr);
+    int index_matched = eta == 1.f, special_case = index_matched || cos_theta_i_abs == 0.f;
+    float r_sc = index_matched ? 0.f : 1.f;
+    float a_s = fmaf(-eta_it, cos_theta_t_abs, cos_theta_i_abs) / fmaf(eta_it, cos_theta_t_abs, cos_theta_i_abs);
+    float a_p = fmaf(-eta_it, cos_theta_i_abs, cos_theta_t_abs) / fmaf(eta_it, cos_theta_i_abs, cos_theta_t_abs);
+    float r = 0.5f * (f_sqr(a_s) + f_sqr(a_p));
+    if (special_case) r = r_sc;
+    *r_out = r; *cos_theta_t = f_mulsign_neg(cos_theta_t_abs, cos_theta_i); *eta_it_out = eta_it; *eta_ti_out = eta_ti;
+}
 /* mis_weight -- dopplertofpath.cpp:296-301 */
 static inline float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
@@ -863,7 +889,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
             res = V(fmaf(thr.x, v.x, res.x), fmaf(thr.y, v.y, res.y), fmaf(thr.z, v.z, res.z));
         }
 
-        int active_em = active_next;   /* diffuse => BSDFFlags::Smooth */
+        int active_em = active_next && hit && si.shape->bsdf == ORC_BSDF_DIFFUSE;   /* has_flag(bsdf->flags(), BSDFFlags::Smooth), :178 */
 
         /* emitter sampling: Scene::sample_emitter_direction src/render/scene.cpp:235-291 */
         float e1 = sampler_draw(&smp, correlate, single);
@@ -926,15 +952,39 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
             active_em = 0;
         }
 
-        float sample_1 = sampler_draw(&smp, correlate, single); (void) sample_1;
+        float sample_1 = sampler_draw(&smp, correlate, single);
         float s2x = sampler_draw(&smp, correlate, single);
         float s2y = sampler_draw(&smp, correlate, single);
 
         /* BSDF::eval_pdf_sample src/render/bsdf.cpp:20-29 over twosided{diffuse} / diffuse
          * (src/bsdfs/twosided.cpp:111-148,219-258; src/bsdfs/diffuse.cpp:101-125,160-180) */
         v3 bsdf_val = V(0, 0, 0), bsdf_weight = V(0, 0, 0), bs_wo = V(0, 0, 0);
-        float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f;
-        if (hit) {
+        float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; int bs_delta = 0;
+        if (hit && si.shape->bsdf == ORC_BSDF_CONDUCTOR) {
+            /* SmoothConductor::sample (conductor.cpp:226-277) under TwoSidedBRDF::sample (twosided.cpp:111-148): eval / pdf of a
+             * delta lobe are zero (conductor.cpp:279-290) */
+            const orc_shape *sh = si.shape;
+            float cos_theta_i = sh->twosided ? fabsf(si.wi.z) : si.wi.z;
+            if (cos_theta_i > 0.f) {
+                bs_wo = V(-si.wi.x, -si.wi.y, si.wi.z);   /* reflect(wi); the two-sided flip of wi.z and of wo.z cancel */
+                bs_eta = 1.f; bs_pdf = 1.f; bs_delta = 1;
+                bsdf_weight = V(sh->spec_refl[0] * fresnel_conductor(cos_theta_i, sh->cond_eta[0], sh->cond_k[0]),
+                                sh->spec_refl[1] * fresnel_conductor(cos_theta_i, sh->cond_eta[1], sh->cond_k[1]),
+                                sh->spec_refl[2] * fresnel_conductor(cos_theta_i, sh->cond_eta[2], sh->cond_k[2]));
+            }
+        } else if (hit && si.shape->bsdf == ORC_BSDF_DIELECTRIC) {
+            /* SmoothDielectric::sample (dielectric.cpp:231-338), TransportMode::Radiance */
+            const orc_shape *sh = si.shape;
+            float r_i, cos_theta_t, eta_it, eta_ti;
+            fresnel_dielectric(si.wi.z, sh->diel_eta, &r_i, &cos_theta_t, &eta_it, &eta_ti);
+            float t_i = 1.f - r_i;
+            int selected_r = sample_1 <= r_i;
+            bs_pdf = selected_r ? r_i : t_i; bs_delta = 1;
+            bs_wo = selected_r ? V(-si.wi.x, -si.wi.y, si.wi.z) : V(-eta_ti * si.wi.x, -eta_ti * si.wi.y, cos_theta_t);
+            bs_eta = selected_r ? 1.f : eta_it;
+            if (selected_r) bsdf_weight = V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]);
+            else { float f2 = f_sqr(eta_ti); bsdf_weight = V(sh->spec_trans[0] * f2, sh->spec_trans[1] * f2, sh->spec_trans[2] * f2); }
+        } else if (hit) {
             const orc_shape *sh = si.shape;
             float wiz = si.wi.z, woz = wo.z;
             if (sh->twosided) { woz = f_mulsign(woz, wiz); wiz = fabsf(wiz); }
@@ -965,7 +1015,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         thr = V(thr.x * bsdf_weight.x, thr.y * bsdf_weight.y, thr.z * bsdf_weight.z);
         eta *= bs_eta;
         valid_ray |= hit;
-        prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_delta = 0;   /* :256-258 (diffuse lobes are never delta) */
+        prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_delta = bs_delta;   /* :256-258 */
         if (hit) depth += 1;
         /* :264-276 */
         float thr_max = f_max(f_max(thr.x, thr.y), thr.z);
@@ -1219,3 +1269,6 @@ void orc_bake_sphere(const float *to_world, const float *to_object, const float 
     out8[0] = composed[3]; out8[1] = composed[7]; out8[2] = composed[11]; out8[3] = r;
     out8[4] = 1.0f / ((4.f * ORC_PI_F) * f_sqr(r)); out8[5] = flip ? 1.f : 0.f; out8[6] = out8[7] = 0.f;
 }
+
+void orc_fresnel_dielectric(float cos_theta_i, float eta, float *out4) { fresnel_dielectric(cos_theta_i, eta, out4, out4 + 1, out4 + 2, out4 + 3); }
+float orc_fresnel_conductor(float cos_theta_i, float eta, float k) { return fresnel_conductor(cos_theta_i, eta, k); }

@@ -29,6 +29,7 @@ enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1 };
 enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 };
 enum { ORC_TIME_UNIFORM = 0, ORC_TIME_STRATIFIED = 1, ORC_TIME_ANTITHETIC = 2,
        ORC_TIME_ANTITHETIC_MIRROR = 3 };
+enum { ORC_BSDF_DIFFUSE = 0, ORC_BSDF_CONDUCTOR = 1, ORC_BSDF_DIELECTRIC = 2 };
 enum { ORC_FILTER_BOX = 0, ORC_FILTER_TENT = 1, ORC_FILTER_GAUSSIAN = 2 };
 
 /* All 4x4 matrices are row-major float32: m[4*r + c]. */
@@ -58,6 +59,12 @@ typedef struct {
     /* sphere (src/shapes/sphere.cpp:117-160), filled by orc_bake_sphere; to_world / to_object above hold the composed
      * to_world * translate(center) * scale(radius) and its inverse */
     float   center[3], radius, sphere_inv_area;
+    /* BSDF: 0 diffuse (reflectance above) | 1 conductor (src/bsdfs/conductor.cpp) | 2 dielectric (src/bsdfs/dielectric.cpp);
+     * `twosided` wraps kinds 0 and 1 (src/bsdfs/twosided.cpp) */
+    int32_t bsdf;
+    float   cond_eta[3], cond_k[3];            /* complex index of refraction per RGB channel */
+    float   spec_refl[3], spec_trans[3];       /* specular_reflectance / specular_transmittance */
+    float   diel_eta;                          /* int_ior / ext_ior */
 } orc_shape;
 
 typedef struct {
@@ -186,6 +193,10 @@ void     orc_bake_cube(const float *to_world, const float *to_object, float *pos
 void     orc_bake_mesh(const float *to_world, const float *to_object, int32_t n_vertices, const float *pos_in,
                        const float *nrm_in, int32_t n_faces, const uint32_t *faces, int32_t face_normals,
                        float *pos_out, float *nrm_out);
+
+/* fresnel (fresnel.h:21-63) -> out4 = r, cos_theta_t, eta_it, eta_ti ; fresnel_conductor (fresnel.h:93-117), one channel */
+void     orc_fresnel_dielectric(float cos_theta_i, float eta, float *out4);
+float    orc_fresnel_conductor(float cos_theta_i, float eta, float k);
 
 /* Sphere ctor + update (sphere.cpp:121-160), all in float32 as ScalarTransform4f is: composed = to_world * translate(center) *
  * scale(radius) (4x4 products, fmadd accumulation over k), its inverse from the factors' analytic inverses in the reverse

@@ -25,7 +25,9 @@ class OrcShape(C.Structure):
                 ("emitter", C.c_int32), ("radiance", C.c_float * 3),
                 ("area_pmf", C.POINTER(C.c_float)), ("area_cdf", C.POINTER(C.c_float)),
                 ("area_sum", C.c_float), ("area_norm", C.c_float), ("area_lo", C.c_int32), ("area_hi", C.c_int32),
-                ("center", C.c_float * 3), ("radius", C.c_float), ("sphere_inv_area", C.c_float)]
+                ("center", C.c_float * 3), ("radius", C.c_float), ("sphere_inv_area", C.c_float),
+                ("bsdf", C.c_int32), ("cond_eta", C.c_float * 3), ("cond_k", C.c_float * 3), ("spec_refl", C.c_float * 3),
+                ("spec_trans", C.c_float * 3), ("diel_eta", C.c_float)]
 
 
 class OrcGroup(C.Structure):
@@ -121,6 +123,9 @@ def lib():
         L.orc_render.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_int]
         L.orc_bake_cube.argtypes = [C.c_void_p] * 6
+        L.orc_fresnel_dielectric.argtypes = [C.c_float, C.c_float, C.c_void_p]
+        L.orc_fresnel_conductor.restype = C.c_float
+        L.orc_fresnel_conductor.argtypes = [C.c_float, C.c_float, C.c_float]
         L.orc_bake_sphere.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mesh_area_table.restype = C.c_int
         L.orc_mesh_area_table.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -157,6 +162,10 @@ class Scene:
             o.reflectance = (C.c_float * 3)(*s["reflectance"].tolist())
             o.to_world, o.to_object = _m16(s["to_world"]), _m16(s["to_object"])
             o.emitter = int(s.get("emitter", 0))
+            o.bsdf = int(s.get("bsdf", 0))
+            for key in ("cond_eta", "cond_k", "spec_refl", "spec_trans"):
+                setattr(o, key, (C.c_float * 3)(*np.asarray(s.get(key, [0, 0, 0]), np.float32).tolist()))
+            o.diel_eta = float(s.get("diel_eta", 1.0))
             o.radiance = (C.c_float * 3)(*np.asarray(s.get("radiance", [0, 0, 0]), np.float32).tolist())
             if s["kind"] == 2:   # sphere: compose / decompose the transform in C float32 (orc_bake_sphere)
                 tw = np.ascontiguousarray(s["to_world"], dtype=np.float32)

@@ -309,23 +309,62 @@ def _m32(m):
     return np.asarray(m, dtype=np.float64).reshape(4, 4).astype(F32)
 
 
+# include/mitsuba/render/ior.h:16-44 (physical constants)
+IOR_TABLE = {"vacuum": 1.0, "helium": 1.000036, "hydrogen": 1.000132, "air": 1.000277, "carbon dioxide": 1.00045, "water": 1.3330,
+             "acetone": 1.36, "ethanol": 1.361, "carbon tetrachloride": 1.461, "glycerol": 1.4729, "benzene": 1.501,
+             "silicone oil": 1.52045, "bromine": 1.661, "water ice": 1.31, "fused quartz": 1.458, "pyrex": 1.470, "acrylic glass": 1.49,
+             "polypropylene": 1.49, "bk7": 1.5046, "sodium chloride": 1.544, "amber": 1.55, "pet": 1.5750, "diamond": 2.419}
+
+
+def _lookup_ior(props, name, default):
+    """lookup_ior (ior.h:71-77): a <float> is taken as is, a <string> is a material name"""
+    if name in props and props[name][0] in ("float", "int"):
+        return F32(props.get_f(name, 0.0))
+    key = props.get_s(name, default).lower()
+    if key not in IOR_TABLE:
+        raise ValueError('Unable to find an IOR value for "%s"!' % key)
+    return F32(IOR_TABLE[key])
+
+
+def _color(props, name, default):
+    if name in props:
+        t, v = props[name]
+        props.queried.add(name)
+        return np.asarray([v] * 3 if t in ("float", "int") else v, dtype=np.float64).astype(F32)
+    return np.asarray([default] * 3, dtype=np.float64).astype(F32)
+
+
 def _bsdf_of(props, registry):
-    """returns (twosided, reflectance float32[3]) for a diffuse / twosided{diffuse} BSDF"""
+    """BSDF record of a diffuse / conductor / dielectric BSDF, optionally inside twosided{...}"""
     if props.plugin == "twosided":
         inner = [c for c in props.children if c[0] in ("bsdf", "ref")]
         if len(inner) != 1:
             raise ValueError("twosided: exactly one nested BSDF is supported")
         ip = inner[0][1] if inner[0][0] == "bsdf" else registry[inner[0][1]][1]
-        ts, refl = _bsdf_of(ip, registry)
-        return 1, refl
-    if props.plugin != "diffuse":
-        raise ValueError('unsupported BSDF plugin "%s"' % props.plugin)
-    if "reflectance" in props:
-        t, v = props["reflectance"]
-        refl = [v] * 3 if t in ("float", "int") else v
+        rec = _bsdf_of(ip, registry)
+        if rec["bsdf"] == 2:   # twosided.cpp:47-52
+            raise ValueError("Only materials without a transmission component can be nested!")
+        rec["twosided"] = 1
+        return rec
+    rec = dict(twosided=0, bsdf=0, reflectance=np.array([0.5] * 3, F32), cond_eta=np.zeros(3, F32), cond_k=np.ones(3, F32),
+               spec_refl=np.ones(3, F32), spec_trans=np.ones(3, F32), diel_eta=F32(1.0))
+    if props.plugin == "diffuse":
+        rec["reflectance"] = _color(props, "reflectance", 0.5)
+    elif props.plugin == "conductor":   # src/bsdfs/conductor.cpp:171-188
+        material = props.get_s("material", "none")
+        if material != "none":
+            raise ValueError("Should specify either (eta, k) or material, not both." if "eta" in props else
+                             'conductor: named materials need the spectral IOR data files, which this build does not ship; give "eta" and "k"')
+        rec.update(bsdf=1, cond_eta=_color(props, "eta", 0.0), cond_k=_color(props, "k", 1.0), spec_refl=_color(props, "specular_reflectance", 1.0))
+    elif props.plugin == "dielectric":  # src/bsdfs/dielectric.cpp:176-203
+        int_ior, ext_ior = _lookup_ior(props, "int_ior", "bk7"), _lookup_ior(props, "ext_ior", "air")
+        if int_ior < 0 or ext_ior < 0:
+            raise ValueError("The interior and exterior indices of refraction must be positive!")
+        rec.update(bsdf=2, diel_eta=F32(int_ior / ext_ior), spec_refl=_color(props, "specular_reflectance", 1.0),
+                   spec_trans=_color(props, "specular_transmittance", 1.0))
     else:
-        refl = [0.5] * 3
-    return 0, np.asarray(refl, dtype=np.float64).astype(F32)
+        raise ValueError('unsupported BSDF plugin "%s"' % props.plugin)
+    return rec
 
 
 class FlatScene:
@@ -373,9 +412,11 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
         emitter = 1
     if bsdfs:
         bp = bsdfs[0][1] if bsdfs[0][0] == "bsdf" else registry[bsdfs[0][1]][1]
-        twosided, refl = _bsdf_of(bp, registry)
+        brec = _bsdf_of(bp, registry)
     else:   # shape.cpp:66-72: default diffuse, reflectance 0 when the shape is an emitter
-        twosided, refl = 0, np.array([0.0 if emitter else 0.5] * 3, dtype=F32)
+        brec = dict(twosided=0, bsdf=0, reflectance=np.array([0.0 if emitter else 0.5] * 3, dtype=F32), cond_eta=np.zeros(3, F32),
+                    cond_k=np.ones(3, F32), spec_refl=np.ones(3, F32), spec_trans=np.ones(3, F32), diel_eta=F32(1.0))
+    twosided, refl = brec["twosided"], brec["reflectance"]
     sphere = None
     if kind == 2:   # src/shapes/sphere.cpp:121-131: center (point, default 0) and radius (default 1) on top of to_world
         c = sp["center"][1] if "center" in sp else [0.0, 0.0, 0.0]
@@ -383,7 +424,8 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
         sphere = dict(center=np.asarray(c, dtype=np.float64).astype(F32), radius=F32(sp.get_f("radius", 1.0)))
     return dict(kind=kind, twosided=twosided, flip_normals=int(flip), face_normals=int(sp.get_b("face_normals", False)),
                 reflectance=refl, to_world=_m32(tw), to_object=_m32(tinv), emitter=emitter, radiance=radiance, mesh_raw=mesh_raw,
-                sphere=sphere)
+                sphere=sphere, bsdf=brec["bsdf"], cond_eta=brec["cond_eta"], cond_k=brec["cond_k"], spec_refl=brec["spec_refl"],
+                spec_trans=brec["spec_trans"], diel_eta=brec["diel_eta"])
 
 
 def load(source, params=None, is_string=False):

@@ -153,6 +153,25 @@ def cornell_spheres(res=128, spp=16, sphere_light=False):
     return s + "</scene>\n"
 
 
+MIRROR = ('\t<bsdf type="twosided" id="MirrorBSDF">\n\t\t<bsdf type="conductor">\n\t\t\t<rgb name="eta" value="0.2, 0.92, 1.1" />\n'
+          '\t\t\t<rgb name="k" value="3.9, 2.45, 2.14" />\n\t\t</bsdf>\n\t</bsdf>\n')     # copper-like RGB index of refraction
+GLASS = '\t<bsdf type="dielectric" id="GlassBSDF">\n\t\t<float name="int_ior" value="1.5" />\n\t\t<string name="ext_ior" value="air" />\n\t</bsdf>\n'
+
+
+def cornell_specular(res=128, spp=16, area_light=True):
+    """the Cornell room with a copper-like mirror box (moving), a glass sphere (static) and a mirror back wall section; lit by the
+    ceiling area light (so that specular chains reach an emitter: delta lobes get no next-event estimation)"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        s += bsdf(*b)
+    s += MIRROR + GLASS
+    for name, m, b in WALLS:
+        s += rect(name, m, b)
+    s += cube("MirrorBox", TALL, "MirrorBSDF", "-0.015")
+    s += sphere("GlassBall", "GlassBSDF", ("0.4", "0.35", "0.3"), "0.35")
+    return s + (AREA_LIGHT if area_light else LIGHT) + "</scene>\n"
+
+
 def domino(n_side=32, res=1024, spp=128):
     s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5").replace('value="sinusoidal"', 'value="rectangular"')
     cam = '\t\t\t<lookat origin="0, 9, 16" target="0, 0.3, 0" up="0, 1, 0" />'
@@ -188,6 +207,7 @@ def main():
         "cornell_boxes.xml": cornell(False, 256, 16, "antithetic", "0.5"),
         "cornell_wall.xml": cornell(True, 512, 64, "stratified", "0.0"),
         "cornell_area.xml": cornell(False, 256, 64, "antithetic", "0.5", area_light=True),
+        "cornell_specular.xml": cornell_specular(),
         "cornell_spheres.xml": cornell_spheres(),
         "cornell_sphere_light.xml": cornell_spheres(sphere_light=True),
         "domino.xml": domino(),

@@ -1,0 +1,134 @@
+"""Smooth conductor / dielectric BSDFs (src/bsdfs/{conductor,dielectric,twosided}.cpp, fresnel.h):
+closed-form Fresnel known answers, loader behaviour, physical sanity of the oracle, GPU-vs-oracle bit-exact lanes."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENES
+
+sys.path.insert(0, os.path.join(ROOT, "scenes"))
+import make_scenes as ms  # noqa: E402
+
+NCPU = os.cpu_count() or 1
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_fresnel_known_answers(orc):
+    L = orc.lib()
+    def diel(c, eta):
+        out = (C.c_float * 4)()
+        L.orc_fresnel_dielectric(c, eta, out)
+        return list(out)
+    r, ct, eit, eti = diel(1.0, 1.5)                      # normal incidence: ((eta-1)/(eta+1))^2 = 0.04, straight through
+    assert abs(r - 0.04) < 1e-6 and abs(ct + 1.0) < 1e-6 and eit == 1.5 and abs(eti - 1 / 1.5) < 1e-7
+    r, ct, eit, eti = diel(-1.0, 1.5)                     # from inside: same reflectance, eta swapped, transmitted upwards
+    assert abs(r - 0.04) < 1e-6 and abs(ct - 1.0) < 1e-6 and abs(eit - 1 / 1.5) < 1e-7 and eti == 1.5
+    assert diel(-0.5, 1.5)[0] == 1.0                      # beyond the critical angle (sin = 0.866 > 1/1.5): total internal reflection
+    brewster = float(np.cos(np.arctan(1.5)))
+    r = diel(brewster, 1.5)[0]                            # Brewster angle: the p wave vanishes, r = a_s^2 / 2
+    a_s = (brewster - 1.5 * np.sqrt(1 - (1 - brewster ** 2) / 2.25)) / (brewster + 1.5 * np.sqrt(1 - (1 - brewster ** 2) / 2.25))
+    assert abs(r - 0.5 * a_s ** 2) < 1e-6
+    assert diel(0.3, 1.0)[0] == 0.0 and diel(0.0, 1.5)[0] == 1.0          # index matched / grazing special cases
+    for c in (1.0, 0.7, 0.2, 0.01):
+        assert abs(L.orc_fresnel_conductor(c, 0.0, 1.0) - 1.0) < 1e-6     # eta = 0, k = 1 (the plugin's default): a perfect mirror
+    assert abs(L.orc_fresnel_conductor(1.0, 1.5, 0.0) - 0.04) < 1e-6      # k = 0: the dielectric value at normal incidence
+    assert 0.5 < L.orc_fresnel_conductor(1.0, 0.2, 3.9) < 1.0             # copper-like: highly reflective
+
+
+def test_loader_semantics_of_the_specular_bsdfs(mi, orc):
+    path = os.path.join(SCENES, "cornell_specular.xml")
+    osc = orc.Scene(path, {})
+    glass = [s for s in osc.flat.shapes if s["bsdf"] == 2][0]
+    mirror = [s for s in osc.flat.shapes if s["bsdf"] == 1][0]
+    assert abs(float(glass["diel_eta"]) - 1.5 / 1.000277) < 1e-6 and glass["twosided"] == 0
+    assert mirror["twosided"] == 1 and np.allclose(mirror["cond_k"], [3.9, 2.45, 2.14])
+    mi.load_file(path)                                                     # the product's loader accepts the same file
+    text = open(path).read()
+    with pytest.raises(mi.DtofError, match="Only materials without a transmission component can be nested"):
+        mi.load_string(text.replace('<bsdf type="conductor">', '<bsdf type="dielectric">').replace(
+            '<rgb name="eta" value="0.2, 0.92, 1.1" />', "").replace('<rgb name="k" value="3.9, 2.45, 2.14" />', ""))
+    with pytest.raises(mi.DtofError, match="Unable to find an IOR value"):
+        mi.load_string(text.replace('value="air"', 'value="unobtainium"'))
+    with pytest.raises(mi.DtofError, match="named materials"):
+        mi.load_string(text.replace('<rgb name="eta" value="0.2, 0.92, 1.1" />', '<string name="material" value="Cu" />').replace(
+            '<rgb name="k" value="3.9, 2.45, 2.14" />', ""))
+    with pytest.raises(mi.DtofError, match="unsupported BSDF plugin"):
+        mi.load_string(text.replace('type="dielectric"', 'type="roughplastic"'))
+
+
+def mirror_room(mirror_bsdf):
+    """the Cornell room with the area light; the back wall is either diffuse white or the given BSDF"""
+    s = ms.HEADER.format(spp=16, res=32, tsm="antithetic", shift="0.5") + ms.SENSOR.format(fov="19.5", cam=ms.CAM)
+    for b in ms.BSDFS:
+        s += ms.bsdf(*b)
+    s += mirror_bsdf
+    for name, m, b in ms.WALLS:
+        s += ms.rect(name, m, "M" if name == "BackWall" else b)
+    return s + ms.AREA_LIGHT + "</scene>\n"
+
+
+def test_oracle_physical_sanity(orc, tmp_path):
+    """(1) a glass pane with index-matched glass (int_ior = ext_ior) is invisible; (2) a black conductor (specular_reflectance 0)
+    kills every path that touches it; (3) a perfect mirror wall conserves energy: brighter than the black wall, and the mean over
+    the room stays finite and positive; (4) radiance through a real glass pane = (1 - r)^2 + ... <= 1 of the unobstructed one."""
+    integ = dict(type="path", max_depth=6)
+    def render(xml, name, spp=128, depth=6):
+        p = str(tmp_path / name)
+        open(p, "w").write(xml)
+        sc = orc.Scene(p, dict(resx=16, resy=16))
+        pd = sc.params(integrator=dict(integ, max_depth=depth))
+        return np.mean([sc.render(pd, seed=s, spp=spp, threads=NCPU)[0] for s in range(2)], axis=0)
+    base = open(os.path.join(SCENES, "cornell_area.xml")).read()
+    ref = render(base, "ref.xml")
+    pane = ('\t<bsdf type="dielectric" id="G"><float name="int_ior" value="%s" /><float name="ext_ior" value="1.0" /></bsdf>\n'
+            '\t<shape type="rectangle" id="Front"><transform name="to_world"><translate x="0" y="1" z="2.5" /></transform><ref id="G" /></shape>\n'
+            '\t<shape type="rectangle" id="Back"><transform name="to_world"><rotate y="1" angle="180" /><translate x="0" y="1" z="2.4" /></transform>'
+            '<ref id="G" /></shape>\n')   # a slab: entering through Front (normal towards the camera), leaving through Back (normal away)
+    # every path of the room now starts with two extra (delta) vertices: depth 8 behind the slab == depth 6 without it
+    same = render(base.replace("</scene>", pane % "1.0" + "</scene>"), "matched.xml", depth=8)
+    assert abs(same.mean() - ref.mean()) < 0.03 * ref.mean()          # different random numbers (the pane consumes draws), same expectation
+    glass = render(base.replace("</scene>", pane % "1.5" + "</scene>"), "glass.xml", depth=8)
+    assert 0.80 * ref.mean() < glass.mean() < 1.0 * ref.mean()        # ~8 % reflected away at the two interfaces (and the 1/eta^2 radiance
+                                                                      # compression inside the slab is undone on the way out), never brighter
+    black = render(mirror_room('\t<bsdf type="twosided" id="M"><bsdf type="conductor"><rgb name="specular_reflectance" value="0" /></bsdf></bsdf>\n'), "black.xml")
+    perfect = render(mirror_room('\t<bsdf type="twosided" id="M"><bsdf type="conductor" /></bsdf>\n'), "perfect.xml")
+    white = render(mirror_room(ms.bsdf("M", "0.725, 0.71, 0.68")), "white.xml")
+    assert black[6:10, 6:10].max() == 0.0                               # the wall itself is black
+    assert perfect.mean() > 1.15 * black.mean() and np.isfinite(perfect).all()
+    assert 0.6 * white.mean() < perfect.mean() < 1.6 * white.mean()
+
+
+GPU_CASES = [("cornell_specular", os.path.join(SCENES, "cornell_specular.xml"), dict(resx=48, resy=48), 8, dict(type="path", max_depth=8)),
+             ("cornell_specular_doppler", os.path.join(SCENES, "cornell_specular.xml"), dict(resx=32, resy=32, max_depth=6), 8, None),
+             ("specular_rr", os.path.join(SCENES, "cornell_specular.xml"), dict(resx=24, resy=24), 8, dict(type="path", max_depth=-1, rr_depth=2)),
+             ("mirror_wall_fused", None, dict(resx=32, resy=32), 8, dict(type="path", max_depth=5)),
+             ("mirror_wall_doppler", None, dict(resx=32, resy=32, max_depth=5, time_sampling_method="stratified"), 8, None)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,path,params,spp,integ", GPU_CASES, ids=[c[0] for c in GPU_CASES])
+def test_specular_scenes_are_bit_exact_per_lane(mi, orc, tmp_path, name, path, params, spp, integ):
+    if path is None:     # rectangles only -> the fused pipeline, SPEC instantiation
+        path = str(tmp_path / "mirror.xml")
+        open(path, "w").write(mirror_room('\t<bsdf type="twosided" id="M"><bsdf type="conductor"><rgb name="eta" value="0.2, 0.92, 1.1" />'
+                                          '<rgb name="k" value="3.9, 2.45, 2.14" /></bsdf></bsdf>\n'))
+    sc, osc = mi.load_file(path, **params), orc.Scene(path, params)
+    if integ:
+        sc.set_integrator(integ)
+    pd = osc.params(integrator=integ) if integ else osc.params()
+    w, h = sc.size
+    n = w * h * spp
+    g = sc.sample_lanes(9, spp, 0, n)
+    o = osc.render_lanes(pd, 9, spp, 0, n, threads=NCPU)
+    for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+        assert np.array_equal(bits(g[k]), bits(o[k])), (name, k, int((bits(g[k]) != bits(o[k])).sum()))
+    assert (g["rgb"] != 0).mean() > 0.05
+    img = sc.render(seed=9, spp=spp)
+    ref, _ = osc.render(pd, seed=9, spp=spp, threads=NCPU)
+    assert float(np.abs(img - ref).max() / np.abs(ref).max()) <= 1e-5
