@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mitsuba3dopplertof_amd as mi
 from oracle import orc
-S = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes")
+S = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "scenes")
 xml = S + "/domino.xml"
 params = dict(resx=64, resy=64)
 sc = mi.load_file(xml, **params); print(sc.info())

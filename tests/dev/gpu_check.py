@@ -2,7 +2,7 @@
 """Quick GPU-vs-oracle check + timing (development helper; the real tests are tests/ -m gpu)."""
 import sys, time, json, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mitsuba3dopplertof_amd as mi
 from oracle import orc
 
@@ -31,7 +31,7 @@ def lanes_check(xml, params, spp, seed=0, integ=None):
 
 if __name__ == "__main__":
     print(mi._lib().dtof_version().decode())
-    S = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes")
+    S = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "scenes")
     lanes_check(S + "/cornell_boxes.xml", dict(resx=64, resy=64), 16)
     lanes_check(S + "/cornell_wall.xml", dict(resx=64, resy=64), 16)
     lanes_check(S + "/cornell_boxes.xml", dict(resx=48, resy=32, time_sampling_method="uniform"), 8)
