@@ -3,6 +3,8 @@ plugins this library implements:
 
     python -m mitsuba3dopplertof_amd scene.xml [-D key=value ...] [-o out.exr|.npy|.pfm] [--spp N] [--seed S]
                                                [--offsets 0,0.25,0.5,0.75] [-v]
+    python -m torch.distributed.run --nproc-per-node G --master-addr 127.0.0.1 -m mitsuba3dopplertof_amd scene.xml ...
+        one process per GPU: the pixel rows are sharded across the G ranks, rank 0 gathers and writes the image
 """
 import argparse
 import os
@@ -36,7 +38,23 @@ def main(argv=None):
         scene = mi.load_file(args.scene, **defines)
         t0 = time.time()
         offsets = [float(x) for x in args.offsets.split(",")] if args.offsets else None
-        img = scene.render(seed=args.seed, spp=args.spp, offsets=offsets)
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1:   # launched by torch.distributed.run: shard the rows, one film gather (distributed.py)
+            import torch
+            import torch.distributed as dist
+            from mitsuba3dopplertof_amd import distributed as D
+            if offsets is not None:
+                ap.error("--offsets is a single-GPU feature")
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl")
+            img = D.render_sharded(scene, seed=args.seed, spp=args.spp)
+            dist.barrier()
+            dist.destroy_process_group()
+            if img is None:
+                return 0
+        else:
+            img = scene.render(seed=args.seed, spp=args.spp, offsets=offsets)
         dt = time.time() - t0
     except mi.DtofError as e:
         print("Error: %s" % e, file=sys.stderr)

@@ -60,3 +60,30 @@ def gather_film(slab, rank, world, group=None):
     dst = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
     dist.gather(slab, dst, dst=0, group=group)
     return dst
+
+
+def render_sharded(scene, seed=0, spp=0, halo=None, group=None):
+    """One frame across the ranks of an initialised torch.distributed job (one process per GPU, backend "nccl" = RCCL): every
+    rank renders its band of pixel rows into a zero-padded device slab (dtof_render_rows), ONE gather brings the slabs to
+    rank 0, which overlap-adds the shared halo rows and develops RGB / W.  Returns the (H, W, 3) image on rank 0, None elsewhere.
+    World size 1 (or no process group) renders the whole frame on the current device."""
+    import torch
+    import torch.distributed as dist
+    from . import _check, _lib
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    W, H = scene.size
+    halo = 2 if halo is None else halo            # tent r=1 needs 1, the default gaussian (radius 2) needs 2
+    dev = torch.device("cuda", torch.cuda.current_device())
+    r0, r1 = row_band(H, world, rank)
+    film = torch.zeros((padded_rows(H, world, halo), W, 4), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    scene.render_rows(film.data_ptr() + halo * W * 4 * 4, seed=seed, spp=spp, row_begin=r0, row_end=r1)
+    p0, p1 = slab_range(H, world, rank, halo)
+    slabs = gather_film(film[p0:p1], rank, world, group)
+    if rank != 0:
+        return None
+    full = (overlap_add(slabs, H, world, halo, xp=torch) if world > 1 else film[halo:halo + H]).contiguous()
+    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    _check(_lib().dtof_develop(full.data_ptr(), rgb.data_ptr(), H * W))
+    return rgb.cpu().numpy()

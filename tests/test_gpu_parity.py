@@ -335,3 +335,14 @@ def test_path_and_velocity_integrators_match_oracle(mi, orc, integ, sampler):
         t = g["time"].reshape(-1, spp) / 0.0015
         if integ["type"] == "dopplertofpath":
             assert np.array_equal(np.sort(np.floor(t * spp).astype(int), axis=1), np.tile(np.arange(spp), (t.shape[0], 1)))
+
+
+def test_render_sharded_single_rank_equals_render(mi):
+    """distributed.render_sharded without a process group (world size 1) == Scene.render; with N ranks the same code renders
+    bands (covered by the gloo world-2 test of the gather / overlap-add and by test_row_tiles_reproduce_the_full_frame)."""
+    from mitsuba3dopplertof_amd import distributed as D
+    for name in ("cornell_wall.xml", "cornell_area.xml"):          # tent filter / default gaussian filter? (both tent here) + area light
+        sc = mi.load_file(os.path.join(SCENES, name), resx=40, resy=24)
+        a = D.render_sharded(sc, seed=3, spp=8)
+        b = sc.render(seed=3, spp=8)
+        assert a.shape == b.shape == (24, 40, 3) and rel_linf(a, b) <= IMG_TOL
