@@ -45,7 +45,9 @@ template <typename T> struct DevBuf {
     ~DevBuf() { release(); }
 };
 
-constexpr uint32_t kMaxIter = 256;           // counts slots per batch
+// per-iteration count slots of a batch (statistics + the queue counts of the previous iteration); reused cyclically beyond that.
+// DTOF_STAT_SLOTS shrinks it so that the tests can exercise the wrap-around with short paths.
+static const uint32_t kMaxIter = [] { const char *e = getenv("DTOF_STAT_SLOTS"); int v = e ? atoi(e) : 0; return (uint32_t) (v >= 2 ? v : 256); }();
 static uint64_t target_batch_lanes() {   // lanes per wavefront batch (DTOF_BATCH_LANES overrides)
     static uint64_t v = [] { const char *e = getenv("DTOF_BATCH_LANES"); uint64_t x = e ? strtoull(e, nullptr, 10) : 0; return x ? x : (1ull << 24); }();
     return v;
@@ -309,7 +311,6 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             // the last iteration of the reference only looks for emitter hits (dopplertofpath.cpp:136-171);
             // without surface emitters it cannot contribute and is skipped
             if (it + 1 >= rp.max_depth && !has_surface_emitters) break;
-            if (it >= kMaxIter) break;
             if (it >= 8 && (it & 3) == 0) {   // unbounded depth: stop once every segment has drained
                 std::vector<uint32_t> alive(n_seg);
                 HIP_CHECK(hipMemcpyAsync(alive.data(), count_in, (size_t) n_seg * 4, hipMemcpyDeviceToHost, s));
@@ -318,10 +319,12 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
                 if (sum == 0) break;
             }
             // does iteration it+1 run?  (same conditions as the loop head)
-            const bool next_runs = (it + 1 < rp.max_depth) && !(it + 2 >= rp.max_depth && !has_surface_emitters) && it + 1 < kMaxIter;
+            const bool next_runs = (it + 1 < rp.max_depth) && !(it + 2 >= rp.max_depth && !has_surface_emitters);
             const bool first = first_inline && it == 0;
             if (!fused || (it == 0 && !first)) { t = tm.begin(1, s); launch_trace(blob, blob_bytes, rp, q, qin, count_in, stack_depth, s); tm.end(1, t, s); if (stats) stats->n_launches_trace++; }
-            uint32_t *qout = q.q[it & 1], *alive_out = q.counts + (size_t) (2 * it) * n_seg, *shadow_out = alive_out + n_seg;
+            // per-iteration count slots; beyond kMaxIter iterations (unbounded depth, paths that russian roulette keeps alive that long)
+            // the slots are reused -- only the statistics lose those iterations, no path is cut short
+            uint32_t *qout = q.q[it & 1], *alive_out = q.counts + (size_t) (2 * (it % kMaxIter)) * n_seg, *shadow_out = alive_out + n_seg;
             const int st_shade = first ? 5 : 2;
             t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it, fused, next_runs, stack_depth, s, first, first && lane_dump ? sc->ws.dbg.p : nullptr); tm.end(st_shade, t, s);
             if (stats && first) stats->n_launches_first++;
@@ -338,8 +341,9 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         }
         if (stats) {   // per-iteration totals of this batch are reduced on the device; one small copy after the last batch
             sc->d_sums.ensure((size_t) (batch_index + 1) * 2 * kMaxIter);
-            if (it) launch_sum_counts(q.counts, n_seg, 2 * it, sc->d_sums.p + (size_t) batch_index * 2 * kMaxIter, s);
-            batch_lanes.push_back(rp.n_lanes); batch_iters.push_back(it);
+            const uint32_t it_counted = std::min<uint32_t>(it, kMaxIter);
+            if (it_counted) launch_sum_counts(q.counts, n_seg, 2 * it_counted, sc->d_sums.p + (size_t) batch_index * 2 * kMaxIter, s);
+            batch_lanes.push_back(rp.n_lanes); batch_iters.push_back(it_counted);
             stats->n_batches++;
         }
     }

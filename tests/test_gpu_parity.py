@@ -346,3 +346,41 @@ def test_render_sharded_single_rank_equals_render(mi):
         a = D.render_sharded(sc, seed=3, spp=8)
         b = sc.render(seed=3, spp=8)
         assert a.shape == b.shape == (24, 40, 3) and rel_linf(a, b) <= IMG_TOL
+
+
+def test_unbounded_depth_in_a_mirror_box_is_not_truncated(mi, orc, tmp_path):
+    """max_depth = -1 inside a box of perfect mirrors: russian roulette (rr_prob <= 0.95) and the light are the only ways a path
+    ends, so lanes live for 100+ bounces.  The per-iteration count slots of the library are reused cyclically beyond their number
+    (256; shrunk to 8 here through DTOF_STAT_SLOTS, in a child process because it is read once): every lane must still match."""
+    import subprocess
+    import sys
+    sys.path.insert(0, SCENES)
+    import make_scenes as ms
+    cam = '\t\t\t<matrix value="-1 0 0 0 0 1 0 1 0 0 -1 0.9 0 0 0 1" />'       # inside the room, just in front of the sixth mirror
+    s = ms.HEADER.format(spp=16, res=16, tsm="antithetic", shift="0.5") + ms.SENSOR.format(fov="60", cam=cam)
+    s += '\t<bsdf type="twosided" id="M"><bsdf type="conductor" /></bsdf>\n'
+    for name, m, _b in ms.WALLS:
+        s += ms.rect(name, m, "M")
+    s += ('\t<shape type="rectangle" id="Front"><transform name="to_world"><translate x="0" y="1" z="1" /></transform><ref id="M" /></shape>\n')
+    s += ms.AREA_LIGHT + "</scene>\n"
+    path = str(tmp_path / "mirrors.xml")
+    open(path, "w").write(s)
+    integ = dict(type="path", max_depth=-1, rr_depth=3)
+    osc = orc.Scene(path)
+    n = 16 * 16 * 16
+    o = osc.render_lanes(osc.params(integrator=integ), 1, 16, 0, n, threads=NCPU)
+    assert int(o["depth"].max()) > 64
+    np.save(str(tmp_path / "want.npy"), o["rgb"])
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import mitsuba3dopplertof_amd as mi\n"
+            "sc = mi.load_file(%r); sc.set_integrator(dict(type='path', max_depth=-1, rr_depth=3))\n"
+            "g = sc.sample_lanes(1, 16, 0, %d); want = np.load(%r)\n"
+            "assert np.array_equal(g['rgb'].view(np.uint32), want.view(np.uint32)), int((g['rgb'] != want).sum())\n"
+            "img = sc.render(seed=1, spp=16); assert np.isfinite(img).all(); print('ok', sc.last_stats['n_launches_shade'])\n"
+            % (os.path.dirname(SCENES), path, n, str(tmp_path / "want.npy")))
+    for slots in ("8", None):
+        env = dict(os.environ)
+        if slots:
+            env["DTOF_STAT_SLOTS"] = slots
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-2000:]
+        assert int(out.stdout.split()[1]) > 64
