@@ -4,6 +4,5 @@ for round in 1 2; do
   for lib in tools/ab/*.so; do
     echo "== $(basename $lib)"
     DTOF_LIB=$PWD/$lib python tools/time_c2.py cornell_wall.xml 2>/dev/null | tail -1
-    DTOF_FUSE_FIRST=0 DTOF_LIB=$PWD/$lib python tools/time_c2.py cornell_wall.xml 2>/dev/null | tail -1
   done
 done
