@@ -55,6 +55,20 @@ int dtof_scene_set_integrator(dtof_scene *scene, const char *plugin, const char 
 int dtof_scene_set_sampler(dtof_scene *scene, const char *plugin, const char *const *names,
                            const char *types, const char *const *values, int n);
 
+/* Scene-independent plugin objects, as the reference constructs them: PluginManager::create_object -> `new T(props)`
+ * (src/core/plugin.cpp:174-208; mi.load_dict({...}), program_runner.py:142).  The constructor validates the properties exactly
+ * like dtof_scene_set_integrator / _sampler; dtof_integrator_render is Integrator::render(scene, sensor, seed, spp)
+ * (include/mitsuba/render/integrator.h:74-79): it installs the integrator (and, if given, the sampler -- NULL keeps the one of
+ * the scene file) on `scene` and renders.  Destroy with the matching *_destroy. */
+typedef struct dtof_integrator dtof_integrator;
+typedef struct dtof_sampler_plugin dtof_sampler_plugin;
+int  dtof_integrator_create(const char *plugin, const char *const *names, const char *types, const char *const *values, int n,
+                            dtof_integrator **out);
+void dtof_integrator_destroy(dtof_integrator *integrator);
+int  dtof_sampler_plugin_create(const char *plugin, const char *const *names, const char *types, const char *const *values, int n,
+                                dtof_sampler_plugin **out);
+void dtof_sampler_plugin_destroy(dtof_sampler_plugin *sampler);
+
 typedef struct {
     int32_t  film_width, film_height, crop_x, crop_y, crop_width, crop_height;
     uint32_t sample_count;          /* Sampler::sample_count() */
@@ -102,6 +116,9 @@ typedef struct {
 /* out_rgb: caller-owned host buffer, crop_height*crop_width*3 float32, developed (RGB / W). */
 int dtof_render(dtof_scene *scene, uint32_t sensor_index, uint32_t seed, uint32_t spp,
                 float *out_rgb, dtof_render_stats *stats);
+
+int dtof_integrator_render(const dtof_integrator *integrator, const dtof_sampler_plugin *sampler_or_null, dtof_scene *scene,
+                           uint32_t sensor_index, uint32_t seed, uint32_t spp, float *out_rgb, dtof_render_stats *stats);
 
 /* Tile / shard entry point (no reference counterpart: the reference is single-device).
  * Renders pixel rows [row_begin,row_end) of the crop window and ACCUMULATES the undeveloped R,G,B,W

@@ -84,6 +84,11 @@ def _lib():
     L.dtof_scene_destroy.restype = None
     L.dtof_scene_set_integrator.argtypes = [vp, C.c_char_p, cpp, C.c_char_p, cpp, C.c_int]
     L.dtof_scene_set_sampler.argtypes = [vp, C.c_char_p, cpp, C.c_char_p, cpp, C.c_int]
+    L.dtof_integrator_create.argtypes = [C.c_char_p, cpp, C.c_char_p, cpp, C.c_int, C.POINTER(C.c_void_p)]
+    L.dtof_sampler_plugin_create.argtypes = [C.c_char_p, cpp, C.c_char_p, cpp, C.c_int, C.POINTER(C.c_void_p)]
+    L.dtof_integrator_destroy.argtypes = [vp]; L.dtof_integrator_destroy.restype = None
+    L.dtof_sampler_plugin_destroy.argtypes = [vp]; L.dtof_sampler_plugin_destroy.restype = None
+    L.dtof_integrator_render.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.POINTER(_Stats)]
     L.dtof_scene_get_info.argtypes = [vp, C.POINTER(_Info)]
     L.dtof_scene_export.argtypes = [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.dtof_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.POINTER(_Stats)]
@@ -233,13 +238,23 @@ class Integrator:
 
     def __init__(self, props):
         self.props = dict(props)
-        if self.props.get("type") not in ("dopplertofpath", "path", "velocity"):
-            raise DtofError('unsupported integrator plugin "%s" (this library implements "dopplertofpath", "path" and '
-                            '"velocity")' % self.props.get("type"))
+        self._h = C.c_void_p()
+        _check(_lib().dtof_integrator_create(*(_plugin_args(self.props) + (C.byref(self._h),))))   # constructor-time validation
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value and _LIB is not None:
+            _LIB.dtof_integrator_destroy(self._h)
+            self._h = C.c_void_p()
 
     def render(self, scene, seed=0, spp=0, sensor=0, offsets=None):
-        scene.set_integrator(self.props)
-        return scene.render(seed=seed, spp=spp, sensor=sensor, offsets=offsets)
+        if offsets is not None:
+            scene.set_integrator(self.props)
+            return scene.render(seed=seed, spp=spp, sensor=sensor, offsets=offsets)
+        w, h = scene.size
+        st, out = _Stats(), np.zeros((h, w, 3), np.float32)
+        _check(_lib().dtof_integrator_render(self._h, None, scene._h, sensor, seed, spp, out.ctypes.data, C.byref(st)))
+        scene.last_stats = st.as_dict()
+        return out
 
 
 def load_file(path, **params):

@@ -449,6 +449,39 @@ int dtof_scene_set_sampler(dtof_scene *sc, const char *plugin, const char *const
     });
 }
 
+struct dtof_integrator { PropBag bag; };
+struct dtof_sampler_plugin { PropBag bag; };
+static PropBag default_sampler_bag() { PropBag b; b.plugin = "correlated"; return b; }
+static PropBag default_integrator_bag() { PropBag b; b.plugin = "dopplertofpath"; return b; }
+int dtof_integrator_create(const char *plugin, const char *const *names, const char *types, const char *const *values, int n, dtof_integrator **out) {
+    return guarded([&] {
+        if (!out) throw std::runtime_error("null argument");
+        PropBag b = make_bag(plugin, names, types, values, n);
+        (void) make_plugin_params(b, default_sampler_bag());   // the constructor's checks (names, types, value ranges)
+        *out = new dtof_integrator { b };
+    });
+}
+void dtof_integrator_destroy(dtof_integrator *i) { delete i; }
+int dtof_sampler_plugin_create(const char *plugin, const char *const *names, const char *types, const char *const *values, int n, dtof_sampler_plugin **out) {
+    return guarded([&] {
+        if (!out) throw std::runtime_error("null argument");
+        PropBag b = make_bag(plugin, names, types, values, n);
+        (void) make_plugin_params(default_integrator_bag(), b);
+        *out = new dtof_sampler_plugin { b };
+    });
+}
+void dtof_sampler_plugin_destroy(dtof_sampler_plugin *s) { delete s; }
+int dtof_integrator_render(const dtof_integrator *integ, const dtof_sampler_plugin *smp, dtof_scene *sc, uint32_t sensor_index,
+                           uint32_t seed, uint32_t spp, float *out_rgb, dtof_render_stats *stats) {
+    int rc = guarded([&] {
+        if (!integ || !sc) throw std::runtime_error("null argument");
+        const PropBag &sb = smp ? smp->bag : sc->host.sampler;
+        PluginParams p = make_plugin_params(integ->bag, sb);
+        sc->host.integrator = integ->bag; sc->host.sampler = sb; sc->pp = p;
+    });
+    return rc ? rc : dtof_render(sc, sensor_index, seed, spp, out_rgb, stats);
+}
+
 int dtof_scene_get_info(const dtof_scene *sc, dtof_scene_info *info) {
     return guarded([&] {
         if (!sc || !info) throw std::runtime_error("null argument");

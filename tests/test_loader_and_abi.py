@@ -195,3 +195,24 @@ int main(int argc, char **argv) {
     assert out.returncode == 0, out.stderr
     w, h, nobj = out.stdout.split()[:3]
     assert (int(w), int(h), int(nobj)) == (40, 256, 7)
+
+
+def test_plugin_objects_validate_like_the_reference_constructors(mi):
+    """dtof_integrator_create / dtof_sampler_plugin_create = PluginManager::create_object -> new T(props): unknown plugins,
+    unknown or mistyped properties and out-of-range values fail at construction (no scene, no GPU involved)."""
+    ok = mi.load_dict(dict(type="dopplertofpath", max_depth=4, w_g=30.0, time_sampling_method="antithetic_mirror"))
+    assert ok._h.value
+    for bad, msg in ((dict(type="volpath"), "unsupported plugin type"),
+                     (dict(type="dopplertofpath", bogus=1), "unreferenced property"),
+                     (dict(type="dopplertofpath", max_depth=4.0), "wrong type"),
+                     (dict(type="dopplertofpath", rr_depth=0), "rr_depth"),
+                     (dict(type="dopplertofpath", wave_function_type="sawtooth"), "unknown wave_function_type"),
+                     (dict(type="path", max_depth=-2), "max_depth")):
+        with pytest.raises(mi.DtofError, match=msg):
+            mi.load_dict(bad)
+    L, h = mi._lib(), ctypes.c_void_p()
+    args = mi._plugin_args(dict(type="timestratified", sample_count=16, jitter=False))
+    assert L.dtof_sampler_plugin_create(*(args + (ctypes.byref(h),))) == 0 and h.value
+    L.dtof_sampler_plugin_destroy(h)
+    args = mi._plugin_args(dict(type="independent", time_correlate_number=2))
+    assert L.dtof_sampler_plugin_create(*(args + (ctypes.byref(h),))) != 0 and b"unreferenced property" in L.dtof_last_error()
