@@ -792,7 +792,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
 
             // ---- emitter sampling (scene.cpp:235-291; point.cpp:118-147; area.cpp:116-159 + shape.cpp:370-384 + rectangle.cpp:152-166)
             float e1 = single ? next_f32(main) : next_correlate(main, path, correlate), e2 = single ? next_f32(main) : next_correlate(main, path, correlate);
-            bool active_em = active_next && sv.n_emitters > 0 && (!SPEC || sh->bsdf == BSDF_DIFFUSE);   // has_flag(bsdf->flags(), Smooth) (:178)
+            // has_flag(bsdf->flags(), BSDFFlags::Smooth) (:178): diffuse and plastic have a smooth lobe
+            bool active_em = active_next && sv.n_emitters > 0 && (!SPEC || sh->bsdf == BSDF_DIFFUSE || sh->bsdf == BSDF_PLASTIC);
             V3 em_weight = mk(0, 0, 0), wo = mk(0, 0, 0); float ds_dist = 0.f, ds_pdf = 0.f; bool ds_delta = true;
             if (active_em) {
                 uint32_t ne = sv.n_emitters, idx = 0; float em_w = 1.f, sx = e1;
@@ -873,6 +874,40 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 const float f2 = sqr(eta_ti);
                 bsdf_weight = selected_r ? mk(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2])
                                          : mk(sh->spec_trans[0] * f2, sh->spec_trans[1] * f2, sh->spec_trans[2] * f2);
+            } else if (SPEC && sh->bsdf == BSDF_PLASTIC) {
+                // SmoothPlastic::eval / pdf / sample (plastic.cpp:219-360) under TwoSidedBRDF; wiz / woz are already flipped
+                float f_i, t1, t2, t3;
+                fresnel_dielectric(wiz, sh->diel_eta, f_i, t1, t2, t3);
+                const float w = sh->spec_sampling_weight, fdr = sh->fdr_int;
+                const V3 diff = sh->nonlinear ? mk(refl.x / (1.f - refl.x * fdr), refl.y / (1.f - refl.y * fdr), refl.z / (1.f - refl.z * fdr))
+                                              : mk(refl.x / (1.f - fdr), refl.y / (1.f - fdr), refl.z / (1.f - fdr));
+                if (wiz > 0.f && woz > 0.f) {
+                    float f_o; fresnel_dielectric(woz, sh->diel_eta, f_o, t1, t2, t3);
+                    const float k = kInvPi * woz * sh->inv_eta_2 * (1.f - f_i) * (1.f - f_o);
+                    bsdf_val = mk(diff.x * k, diff.y * k, diff.z * k);
+                    const float prob_specular = f_i * w; float prob_diffuse = (1.f - f_i) * (1.f - w);
+                    prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
+                    bsdf_pdf = kInvPi * woz * prob_diffuse;
+                }
+                if (wiz > 0.f) {
+                    float prob_specular = f_i * w, prob_diffuse = (1.f - f_i) * (1.f - w);
+                    prob_specular = prob_specular / (prob_specular + prob_diffuse);
+                    prob_diffuse = 1.f - prob_specular;
+                    bs_eta = 1.f;
+                    if (sample_1 < prob_specular) {
+                        bs_wo = mk(-si.wi.x, -si.wi.y, wiz);
+                        bs_pdf = prob_specular; bs_delta = true;
+                        const float value = f_i / bs_pdf;
+                        bsdf_weight = mk(value * sh->spec_refl[0], value * sh->spec_refl[1], value * sh->spec_refl[2]);
+                    } else {
+                        bs_wo = cosine_hemisphere(s2x, s2y);
+                        bs_pdf = prob_diffuse * (kInvPi * bs_wo.z);
+                        float f_o; fresnel_dielectric(bs_wo.z, sh->diel_eta, f_o, t1, t2, t3);
+                        const float k = sh->inv_eta_2 * (1.f - f_i) * (1.f - f_o) / prob_diffuse;
+                        bsdf_weight = mk(diff.x * k, diff.y * k, diff.z * k);
+                    }
+                    if (twosided) bs_wo.z = mulsign(bs_wo.z, si.wi.z);
+                }
             } else {
                 if (wiz > 0.f && woz > 0.f) { bsdf_val = mk(refl.x * kInvPi * woz, refl.y * kInvPi * woz, refl.z * kInvPi * woz); bsdf_pdf = kInvPi * woz; }
                 if (wiz > 0.f) {

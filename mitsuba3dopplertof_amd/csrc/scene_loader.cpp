@@ -481,7 +481,24 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         if (int_ior < 0 || ext_ior < 0) fail("The interior and exterior indices of refraction must be positive!");
         s.bsdf = BSDF_DIELECTRIC; s.diel_eta = int_ior / ext_ior;
         color_of(b, "specular_reflectance", 1.f, s.spec_refl); color_of(b, "specular_transmittance", 1.f, s.spec_trans);
-    } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, conductor, dielectric, twosided)");
+    } else if (b.plugin == "plastic") {   // src/bsdfs/plastic.cpp:167-217
+        const float int_ior = lookup_ior(b, "int_ior", "polypropylene"), ext_ior = lookup_ior(b, "ext_ior", "air");
+        if (int_ior < 0 || ext_ior < 0) fail("The interior and exterior indices of refraction must be positive!");
+        s.bsdf = BSDF_PLASTIC; s.diel_eta = int_ior / ext_ior;
+        color_of(b, "diffuse_reflectance", 0.5f, s.refl); color_of(b, "specular_reflectance", 1.f, s.spec_refl);
+        s.nonlinear = b.props.get_bool("nonlinear", false);
+        const float eta = s.diel_eta;
+        s.inv_eta_2 = 1.f / (eta * eta);
+        {   // fresnel_diffuse_reflectance(1 / eta), include/mitsuba/render/fresnel.h:328-355
+            const float e = 1.f / eta, inv_e = 1.0f / e;
+            const float approx_1 = fmaf(0.0636f, inv_e, fmaf(e, fmaf(e, -1.4399f, 0.7099f), 0.6681f));
+            float h = -1.36881f;
+            h = fmaf(h, inv_e, 4.98554f); h = fmaf(h, inv_e, -7.80989f); h = fmaf(h, inv_e, 6.75335f); h = fmaf(h, inv_e, -3.4793f); h = fmaf(h, inv_e, 0.919317f);
+            s.fdr_int = e < 1.f ? approx_1 : h;
+        }
+        const float d_mean = ((s.refl[0] + s.refl[1]) + s.refl[2]) * (1.0f / 3.0f), s_mean = ((s.spec_refl[0] + s.spec_refl[1]) + s.spec_refl[2]) * (1.0f / 3.0f);
+        s.spec_sampling_weight = s_mean / (d_mean + s_mean);
+    } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, plastic, conductor, dielectric, twosided)");
     auto u = b.props.unqueried();
     if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in plugin of type \"" + b.plugin + "\"");
 }

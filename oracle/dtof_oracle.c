@@ -889,7 +889,8 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
             res = V(fmaf(thr.x, v.x, res.x), fmaf(thr.y, v.y, res.y), fmaf(thr.z, v.z, res.z));
         }
 
-        int active_em = active_next && hit && si.shape->bsdf == ORC_BSDF_DIFFUSE;   /* has_flag(bsdf->flags(), BSDFFlags::Smooth), :178 */
+        /* has_flag(bsdf->flags(), BSDFFlags::Smooth), :178 -- diffuse and plastic have a smooth lobe */
+        int active_em = active_next && hit && (si.shape->bsdf == ORC_BSDF_DIFFUSE || si.shape->bsdf == ORC_BSDF_PLASTIC);
 
         /* emitter sampling: Scene::sample_emitter_direction src/render/scene.cpp:235-291 */
         float e1 = sampler_draw(&smp, correlate, single);
@@ -984,6 +985,44 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
             bs_eta = selected_r ? 1.f : eta_it;
             if (selected_r) bsdf_weight = V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]);
             else { float f2 = f_sqr(eta_ti); bsdf_weight = V(sh->spec_trans[0] * f2, sh->spec_trans[1] * f2, sh->spec_trans[2] * f2); }
+        } else if (hit && si.shape->bsdf == ORC_BSDF_PLASTIC) {
+            /* SmoothPlastic::eval / pdf / sample (plastic.cpp:219-360) under TwoSidedBRDF (twosided.cpp:111-148,219-258) */
+            const orc_shape *sh = si.shape;
+            float wiz = si.wi.z, woz = wo.z;
+            if (sh->twosided) { woz = f_mulsign(woz, wiz); wiz = fabsf(wiz); }
+            float f_i, tmp1, tmp2, tmp3;
+            fresnel_dielectric(wiz, sh->diel_eta, &f_i, &tmp1, &tmp2, &tmp3);
+            const float w = sh->spec_sampling_weight;
+            v3 diff = V(sh->reflectance[0], sh->reflectance[1], sh->reflectance[2]);
+            diff = sh->nonlinear ? V(diff.x / (1.f - diff.x * sh->fdr_int), diff.y / (1.f - diff.y * sh->fdr_int), diff.z / (1.f - diff.z * sh->fdr_int))
+                                 : V(diff.x / (1.f - sh->fdr_int), diff.y / (1.f - sh->fdr_int), diff.z / (1.f - sh->fdr_int));
+            if (wiz > 0.f && woz > 0.f) {   /* eval (:309-332) and pdf (:334-360) of the diffuse lobe */
+                float f_o; fresnel_dielectric(woz, sh->diel_eta, &f_o, &tmp1, &tmp2, &tmp3);
+                float k = ORC_INV_PI_F * woz * sh->inv_eta_2 * (1.f - f_i) * (1.f - f_o);
+                bsdf_val = V(diff.x * k, diff.y * k, diff.z * k);
+                float prob_specular = f_i * w, prob_diffuse = (1.f - f_i) * (1.f - w);
+                prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
+                bsdf_pdf = ORC_INV_PI_F * woz * prob_diffuse;
+            }
+            if (wiz > 0.f) {                /* sample (:219-307) */
+                float prob_specular = f_i * w, prob_diffuse = (1.f - f_i) * (1.f - w);
+                prob_specular = prob_specular / (prob_specular + prob_diffuse);
+                prob_diffuse = 1.f - prob_specular;
+                bs_eta = 1.f;
+                if (sample_1 < prob_specular) {
+                    bs_wo = V(-si.wi.x, -si.wi.y, wiz);   /* reflect() of the (possibly flipped) wi */
+                    bs_pdf = prob_specular; bs_delta = 1;
+                    float value = f_i / bs_pdf;
+                    bsdf_weight = V(value * sh->spec_refl[0], value * sh->spec_refl[1], value * sh->spec_refl[2]);
+                } else {
+                    bs_wo = square_to_cosine_hemisphere(s2x, s2y);
+                    bs_pdf = prob_diffuse * (ORC_INV_PI_F * bs_wo.z);
+                    float f_o; fresnel_dielectric(bs_wo.z, sh->diel_eta, &f_o, &tmp1, &tmp2, &tmp3);
+                    float k = sh->inv_eta_2 * (1.f - f_i) * (1.f - f_o) / prob_diffuse;
+                    bsdf_weight = V(diff.x * k, diff.y * k, diff.z * k);
+                }
+                if (sh->twosided) bs_wo.z = f_mulsign(bs_wo.z, si.wi.z);
+            }
         } else if (hit) {
             const orc_shape *sh = si.shape;
             float wiz = si.wi.z, woz = wo.z;
@@ -1272,3 +1311,20 @@ void orc_bake_sphere(const float *to_world, const float *to_object, const float 
 
 void orc_fresnel_dielectric(float cos_theta_i, float eta, float *out4) { fresnel_dielectric(cos_theta_i, eta, out4, out4 + 1, out4 + 2, out4 + 3); }
 float orc_fresnel_conductor(float cos_theta_i, float eta, float k) { return fresnel_conductor(cos_theta_i, eta, k); }
+
+/* SmoothPlastic::parameters_changed + fresnel_diffuse_reflectance -- see the header */
+static float fresnel_diffuse_reflectance(float eta) {
+    float inv_eta = 1.0f / eta;
+    float approx_1 = fmaf(0.0636f, inv_eta, fmaf(eta, fmaf(eta, -1.4399f, 0.7099f), 0.6681f));
+    /* dr::horner(x, c0, ..., c5) = c0 + x (c1 + x (c2 + ...)), evaluated with fmadd from the highest coefficient down */
+    float h = -1.36881f;
+    h = fmaf(h, inv_eta, 4.98554f); h = fmaf(h, inv_eta, -7.80989f); h = fmaf(h, inv_eta, 6.75335f);
+    h = fmaf(h, inv_eta, -3.4793f); h = fmaf(h, inv_eta, 0.919317f);
+    return eta < 1.f ? approx_1 : h;
+}
+void orc_plastic_params(float eta, const float *d, const float *sp, float *out3) {
+    out3[0] = 1.f / (eta * eta);
+    out3[1] = fresnel_diffuse_reflectance(1.f / eta);
+    float d_mean = ((d[0] + d[1]) + d[2]) * (1.0f / 3.0f), s_mean = ((sp[0] + sp[1]) + sp[2]) * (1.0f / 3.0f);
+    out3[2] = s_mean / (d_mean + s_mean);
+}

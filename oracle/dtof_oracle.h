@@ -29,7 +29,7 @@ enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1 };
 enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 };
 enum { ORC_TIME_UNIFORM = 0, ORC_TIME_STRATIFIED = 1, ORC_TIME_ANTITHETIC = 2,
        ORC_TIME_ANTITHETIC_MIRROR = 3 };
-enum { ORC_BSDF_DIFFUSE = 0, ORC_BSDF_CONDUCTOR = 1, ORC_BSDF_DIELECTRIC = 2 };
+enum { ORC_BSDF_DIFFUSE = 0, ORC_BSDF_CONDUCTOR = 1, ORC_BSDF_DIELECTRIC = 2, ORC_BSDF_PLASTIC = 3 };
 enum { ORC_FILTER_BOX = 0, ORC_FILTER_TENT = 1, ORC_FILTER_GAUSSIAN = 2 };
 
 /* All 4x4 matrices are row-major float32: m[4*r + c]. */
@@ -65,6 +65,10 @@ typedef struct {
     float   cond_eta[3], cond_k[3];            /* complex index of refraction per RGB channel */
     float   spec_refl[3], spec_trans[3];       /* specular_reflectance / specular_transmittance */
     float   diel_eta;                          /* int_ior / ext_ior */
+    /* plastic (src/bsdfs/plastic.cpp): diffuse_reflectance = reflectance above, specular_reflectance = spec_refl, eta = diel_eta,
+     * and the constants of SmoothPlastic::parameters_changed (:201-217), filled by orc_plastic_params */
+    int32_t nonlinear;
+    float   inv_eta_2, fdr_int, spec_sampling_weight;
 } orc_shape;
 
 typedef struct {
@@ -197,6 +201,10 @@ void     orc_bake_mesh(const float *to_world, const float *to_object, int32_t n_
 /* fresnel (fresnel.h:21-63) -> out4 = r, cos_theta_t, eta_it, eta_ti ; fresnel_conductor (fresnel.h:93-117), one channel */
 void     orc_fresnel_dielectric(float cos_theta_i, float eta, float *out4);
 float    orc_fresnel_conductor(float cos_theta_i, float eta, float k);
+
+/* SmoothPlastic::parameters_changed (plastic.cpp:201-217) + fresnel_diffuse_reflectance (fresnel.h:328-355), float32:
+ * out3 = 1 / eta^2, fdr_int = fresnel_diffuse_reflectance(1 / eta), specular sampling weight s_mean / (d_mean + s_mean) */
+void     orc_plastic_params(float eta, const float *diffuse3, const float *specular3, float *out3);
 
 /* Sphere ctor + update (sphere.cpp:121-160), all in float32 as ScalarTransform4f is: composed = to_world * translate(center) *
  * scale(radius) (4x4 products, fmadd accumulation over k), its inverse from the factors' analytic inverses in the reverse

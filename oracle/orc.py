@@ -27,7 +27,8 @@ class OrcShape(C.Structure):
                 ("area_sum", C.c_float), ("area_norm", C.c_float), ("area_lo", C.c_int32), ("area_hi", C.c_int32),
                 ("center", C.c_float * 3), ("radius", C.c_float), ("sphere_inv_area", C.c_float),
                 ("bsdf", C.c_int32), ("cond_eta", C.c_float * 3), ("cond_k", C.c_float * 3), ("spec_refl", C.c_float * 3),
-                ("spec_trans", C.c_float * 3), ("diel_eta", C.c_float)]
+                ("spec_trans", C.c_float * 3), ("diel_eta", C.c_float), ("nonlinear", C.c_int32),
+                ("inv_eta_2", C.c_float), ("fdr_int", C.c_float), ("spec_sampling_weight", C.c_float)]
 
 
 class OrcGroup(C.Structure):
@@ -123,6 +124,7 @@ def lib():
         L.orc_render.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_int]
         L.orc_bake_cube.argtypes = [C.c_void_p] * 6
+        L.orc_plastic_params.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_fresnel_dielectric.argtypes = [C.c_float, C.c_float, C.c_void_p]
         L.orc_fresnel_conductor.restype = C.c_float
         L.orc_fresnel_conductor.argtypes = [C.c_float, C.c_float, C.c_float]
@@ -166,6 +168,12 @@ class Scene:
             for key in ("cond_eta", "cond_k", "spec_refl", "spec_trans"):
                 setattr(o, key, (C.c_float * 3)(*np.asarray(s.get(key, [0, 0, 0]), np.float32).tolist()))
             o.diel_eta = float(s.get("diel_eta", 1.0))
+            if o.bsdf == 3:   # plastic: SmoothPlastic::parameters_changed in C float32
+                o.nonlinear = int(s.get("nonlinear", 0))
+                out3 = (C.c_float * 3)()
+                L.orc_plastic_params(C.c_float(o.diel_eta), o.reflectance, o.spec_refl, out3)
+                o.inv_eta_2, o.fdr_int, o.spec_sampling_weight = out3[0], out3[1], out3[2]
+                s["plastic_params"] = np.array(list(out3), np.float32)
             o.radiance = (C.c_float * 3)(*np.asarray(s.get("radiance", [0, 0, 0]), np.float32).tolist())
             if s["kind"] == 2:   # sphere: compose / decompose the transform in C float32 (orc_bake_sphere)
                 tw = np.ascontiguousarray(s["to_world"], dtype=np.float32)

@@ -347,7 +347,7 @@ def _bsdf_of(props, registry):
         rec["twosided"] = 1
         return rec
     rec = dict(twosided=0, bsdf=0, reflectance=np.array([0.5] * 3, F32), cond_eta=np.zeros(3, F32), cond_k=np.ones(3, F32),
-               spec_refl=np.ones(3, F32), spec_trans=np.ones(3, F32), diel_eta=F32(1.0))
+               spec_refl=np.ones(3, F32), spec_trans=np.ones(3, F32), diel_eta=F32(1.0), nonlinear=0)
     if props.plugin == "diffuse":
         rec["reflectance"] = _color(props, "reflectance", 0.5)
     elif props.plugin == "conductor":   # src/bsdfs/conductor.cpp:171-188
@@ -362,6 +362,12 @@ def _bsdf_of(props, registry):
             raise ValueError("The interior and exterior indices of refraction must be positive!")
         rec.update(bsdf=2, diel_eta=F32(int_ior / ext_ior), spec_refl=_color(props, "specular_reflectance", 1.0),
                    spec_trans=_color(props, "specular_transmittance", 1.0))
+    elif props.plugin == "plastic":     # src/bsdfs/plastic.cpp:167-199
+        int_ior, ext_ior = _lookup_ior(props, "int_ior", "polypropylene"), _lookup_ior(props, "ext_ior", "air")
+        if int_ior < 0 or ext_ior < 0:
+            raise ValueError("The interior and exterior indices of refraction must be positive!")
+        rec.update(bsdf=3, diel_eta=F32(int_ior / ext_ior), reflectance=_color(props, "diffuse_reflectance", 0.5),
+                   spec_refl=_color(props, "specular_reflectance", 1.0), nonlinear=int(props.get_b("nonlinear", False)))
     else:
         raise ValueError('unsupported BSDF plugin "%s"' % props.plugin)
     return rec
@@ -415,7 +421,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
         brec = _bsdf_of(bp, registry)
     else:   # shape.cpp:66-72: default diffuse, reflectance 0 when the shape is an emitter
         brec = dict(twosided=0, bsdf=0, reflectance=np.array([0.0 if emitter else 0.5] * 3, dtype=F32), cond_eta=np.zeros(3, F32),
-                    cond_k=np.ones(3, F32), spec_refl=np.ones(3, F32), spec_trans=np.ones(3, F32), diel_eta=F32(1.0))
+                    cond_k=np.ones(3, F32), spec_refl=np.ones(3, F32), spec_trans=np.ones(3, F32), diel_eta=F32(1.0), nonlinear=0)
     twosided, refl = brec["twosided"], brec["reflectance"]
     sphere = None
     if kind == 2:   # src/shapes/sphere.cpp:121-131: center (point, default 0) and radius (default 1) on top of to_world
@@ -425,7 +431,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
     return dict(kind=kind, twosided=twosided, flip_normals=int(flip), face_normals=int(sp.get_b("face_normals", False)),
                 reflectance=refl, to_world=_m32(tw), to_object=_m32(tinv), emitter=emitter, radiance=radiance, mesh_raw=mesh_raw,
                 sphere=sphere, bsdf=brec["bsdf"], cond_eta=brec["cond_eta"], cond_k=brec["cond_k"], spec_refl=brec["spec_refl"],
-                spec_trans=brec["spec_trans"], diel_eta=brec["diel_eta"])
+                spec_trans=brec["spec_trans"], diel_eta=brec["diel_eta"], nonlinear=brec.get("nonlinear", 0))
 
 
 def load(source, params=None, is_string=False):

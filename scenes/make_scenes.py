@@ -158,6 +158,22 @@ MIRROR = ('\t<bsdf type="twosided" id="MirrorBSDF">\n\t\t<bsdf type="conductor">
 GLASS = '\t<bsdf type="dielectric" id="GlassBSDF">\n\t\t<float name="int_ior" value="1.5" />\n\t\t<string name="ext_ior" value="air" />\n\t</bsdf>\n'
 
 
+PLASTIC = ('\t<bsdf type="twosided" id="PlasticBSDF">\n\t\t<bsdf type="plastic">\n\t\t\t<rgb name="diffuse_reflectance" value="0.1, 0.27, 0.36" />\n'
+           '\t\t\t<float name="int_ior" value="1.9" />\n\t\t</bsdf>\n\t</bsdf>\n')
+
+
+def cornell_plastic(res=128, spp=16):
+    """cornell_boxes.xml with glossy-coated (smooth `plastic`) boxes and a plastic floor, point light at the camera"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        s += bsdf(*b)
+    s += PLASTIC
+    for name, m, b in WALLS:
+        s += rect(name, m, "PlasticBSDF" if name == "Floor" else b)
+    s += cube("ShortBox", SHORT, "PlasticBSDF", "0.015") + cube("TallBox", TALL, "PlasticBSDF", "-0.015")
+    return s + LIGHT + "</scene>\n"
+
+
 def cornell_specular(res=128, spp=16, area_light=True):
     """the Cornell room with a copper-like mirror box (moving), a glass sphere (static) and a mirror back wall section; lit by the
     ceiling area light (so that specular chains reach an emitter: delta lobes get no next-event estimation)"""
@@ -208,6 +224,7 @@ def main():
         "cornell_wall.xml": cornell(True, 512, 64, "stratified", "0.0"),
         "cornell_area.xml": cornell(False, 256, 64, "antithetic", "0.5", area_light=True),
         "cornell_specular.xml": cornell_specular(),
+        "cornell_plastic.xml": cornell_plastic(),
         "cornell_spheres.xml": cornell_spheres(),
         "cornell_sphere_light.xml": cornell_spheres(sphere_light=True),
         "domino.xml": domino(),

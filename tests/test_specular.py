@@ -132,3 +132,62 @@ def test_specular_scenes_are_bit_exact_per_lane(mi, orc, tmp_path, name, path, p
     img = sc.render(seed=9, spp=spp)
     ref, _ = osc.render(pd, seed=9, spp=spp, threads=NCPU)
     assert float(np.abs(img - ref).max() / np.abs(ref).max()) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ smooth plastic
+def test_plastic_loader_constants_and_limits(mi, orc, tmp_path):
+    """SmoothPlastic (plastic.cpp:167-217): the constructor constants computed by the product's loader are bit-identical to the
+    oracle's; int_ior = ext_ior degenerates to a plain diffuse BSDF in expectation."""
+    path = os.path.join(SCENES, "cornell_plastic.xml")
+    sc, osc = mi.load_file(path), orc.Scene(path, {})
+    rec = sc.export(9).reshape(-1, 22)
+    pl = [(i, s) for i, s in enumerate(osc.flat.shapes) if s["bsdf"] == 3]
+    assert len(pl) == 3
+    for i, s in pl:
+        assert rec[i, 0] == 3 and rec[i, 1] == 1 and np.array_equal(bits(rec[i, 4:7]), bits(s["plastic_params"]))
+        assert np.array_equal(bits(rec[i, 7:10]), bits(s["reflectance"])) and bits(rec[i, 2]) == bits(np.float32(s["diel_eta"]))
+    eta = np.float32(1.9) / np.float32(1.000277)
+    assert abs(rec[pl[0][0], 4] - 1 / eta ** 2) < 1e-6 and 0.7 < rec[pl[0][0], 5] < 0.8      # fdr_int(1/1.9) ~ 0.76
+    assert abs(rec[pl[0][0], 6] - 1.0 / (1.0 + (0.1 + 0.27 + 0.36) / 3)) < 1e-6               # s_mean / (d_mean + s_mean)
+    # index-matched plastic == diffuse (fresnel 0, fdr_int ~ 0): same expectation, different sampling code
+    base = open(os.path.join(SCENES, "cornell_area.xml")).read()
+    plastic = base.replace('<bsdf type="twosided" id="FloorBSDF">\n\t\t<bsdf type="diffuse">\n\t\t\t<rgb name="reflectance" value="0.725, 0.71, 0.68" />',
+                           '<bsdf type="twosided" id="FloorBSDF">\n\t\t<bsdf type="plastic">\n\t\t\t<rgb name="diffuse_reflectance" value="0.725, 0.71, 0.68" />'
+                           '\n\t\t\t<float name="int_ior" value="1.0" />\n\t\t\t<float name="ext_ior" value="1.0" />')
+    assert plastic != base
+    p2 = str(tmp_path / "matched.xml")
+    open(p2, "w").write(plastic)
+    P, integ = dict(resx=16, resy=16), dict(type="path", max_depth=4)
+    a, b = orc.Scene(os.path.join(SCENES, "cornell_area.xml"), P), orc.Scene(p2, P)
+    ia = np.mean([a.render(a.params(integrator=integ), seed=s, spp=256, threads=NCPU)[0] for s in range(2)], axis=0)
+    ib = np.mean([b.render(b.params(integrator=integ), seed=s, spp=256, threads=NCPU)[0] for s in range(2)], axis=0)
+    assert abs(ia.mean() - ib.mean()) < 0.02 * ia.mean()
+
+
+PLASTIC_CASES = [("plastic_doppler", dict(resx=48, resy=48), 8, None), ("plastic_path_depth6", dict(resx=32, resy=32), 8, dict(type="path", max_depth=6)),
+                 ("plastic_nonlinear", dict(resx=24, resy=24), 8, dict(type="path", max_depth=4))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,params,spp,integ", PLASTIC_CASES, ids=[c[0] for c in PLASTIC_CASES])
+def test_plastic_scenes_are_bit_exact_per_lane(mi, orc, tmp_path, name, params, spp, integ):
+    path = os.path.join(SCENES, "cornell_plastic.xml")
+    if "nonlinear" in name:
+        text = open(path).read().replace('<float name="int_ior" value="1.9" />', '<string name="int_ior" value="diamond" />\n\t\t\t<boolean name="nonlinear" value="true" />'
+                                                                                 '\n\t\t\t<rgb name="specular_reflectance" value="0.9, 0.8, 0.7" />')
+        path = str(tmp_path / "nl.xml")
+        open(path, "w").write(text)
+    sc, osc = mi.load_file(path, **params), orc.Scene(path, params)
+    if integ:
+        sc.set_integrator(integ)
+    pd = osc.params(integrator=integ) if integ else osc.params()
+    w, h = sc.size
+    n = w * h * spp
+    g = sc.sample_lanes(11, spp, 0, n)
+    o = osc.render_lanes(pd, 11, spp, 0, n, threads=NCPU)
+    for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+        assert np.array_equal(bits(g[k]), bits(o[k])), (name, k, int((bits(g[k]) != bits(o[k])).sum()))
+    assert (g["rgb"] != 0).mean() > 0.3
+    img = sc.render(seed=11, spp=spp)
+    ref, _ = osc.render(pd, seed=11, spp=spp, threads=NCPU)
+    assert float(np.abs(img - ref).max() / np.abs(ref).max()) <= 1e-5
