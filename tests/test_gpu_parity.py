@@ -384,3 +384,25 @@ def test_unbounded_depth_in_a_mirror_box_is_not_truncated(mi, orc, tmp_path):
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
         assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-2000:]
         assert int(out.stdout.split()[1]) > 64
+
+
+def test_full_domino_scene_1025_objects(mi, orc):
+    """BASELINE configs[3]/[4] scene (1 024 motion-blurred cube instances + ground; TLAS of depth ~11, split pipeline) at reduced
+    resolution: every lane against the oracle, which tests all 1 025 objects for every ray; plus the K = 4 batched
+    hetero_offset films of configs[4] against four separate oracle renders."""
+    path = os.path.join(SCENES, "domino.xml")
+    params = dict(resx=96, resy=64, wave_function_type="trapezoidal")
+    sc, osc = mi.load_file(path, **params), orc.Scene(path, params)
+    assert sc.info()["n_objects"] == 1025
+    spp, n = 4, 96 * 64 * 4
+    g = sc.sample_lanes(0, spp, 0, n)
+    o = osc.render_lanes(osc.params(), 0, spp, 0, n, threads=NCPU)
+    for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+        assert np.array_equal(bits(g[k]), bits(o[k])), (k, int((bits(g[k]) != bits(o[k])).sum()))
+    offsets = [0.0, 0.25, 0.5, 0.75]
+    imgs = sc.render(seed=0, spp=spp, offsets=offsets)
+    for k, off in enumerate(offsets):
+        pd = osc.params(integrator=dict(type="dopplertofpath", max_depth=4, w_g=30.0, hetero_frequency=1.0, hetero_offset=off, antithetic_shift=0.5,
+                                        path_correlation_depth=4, time_sampling_method="antithetic", wave_function_type="trapezoidal"))
+        ref, _ = osc.render(pd, seed=0, spp=spp, threads=NCPU)
+        assert rel_linf(imgs[k], ref) <= IMG_TOL, (off, rel_linf(imgs[k], ref))
