@@ -224,7 +224,7 @@ def main():
         achieved = kernel_bytes / max(shade_s, 1e-12) / 1e9
         traffic = None
         tfile = os.path.join(HERE, "profiles", "roofline_traffic.json")
-        if os.path.exists(tfile) and args.config == "c2" and fused and world == 1:   # the PMC passes were taken on exactly this workload
+        if os.path.exists(tfile) and args.config == "c2" and fused:   # the PMC passes were taken on exactly this workload (per rank and launch)
             try:
                 traffic = json.load(open(tfile)).get(kernel_key, {}).get("hbm_bytes_per_launch")
             except Exception:
