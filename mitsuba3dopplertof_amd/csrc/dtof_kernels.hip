@@ -1216,7 +1216,15 @@ void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s) {
     if (rp.n_lanes == 0) return;
     hipLaunchKernelGGL(k_generate, dim3(nblk(rp.n_lanes)), dim3(kBlock), 0, s, rp, q);
 }
-static inline uint32_t stage_words_for(uint32_t scene_bytes) { return scene_bytes <= kLdsSceneLimit ? (scene_bytes + 15) / 16 : 0; }
+// the scene is staged into LDS if it is small AND leaves room for the traversal stacks within the 64 KiB a block may ask for
+constexpr uint32_t kLdsBlockLimit = 64 * 1024;
+static inline uint32_t stage_words_for(uint32_t scene_bytes, uint32_t stack = 0) {
+    const uint32_t w = (scene_bytes + 15) / 16;
+    return scene_bytes <= kLdsSceneLimit && w * 16 + stack + 64 <= kLdsBlockLimit ? w : 0;
+}
+static inline void check_lds(uint32_t lds) {
+    if (lds + 64 > kLdsBlockLimit) throw std::runtime_error("the BVH of this scene is too deep for the LDS traversal stack");
+}
 
 // out[row] = sum of counts[row][0..n_seg): the statistics' per-iteration totals (kSumSlices blocks per row, one atomic each)
 constexpr uint32_t kSumSlices = 32;
@@ -1241,7 +1249,8 @@ uint32_t segments_for(uint32_t n_lanes) { return nseg(n_lanes); }
 void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                   const uint32_t *qin, const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
-    uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + stack_bytes(stack_depth), grid = nseg(rp.n_lanes) * kSub;
+    uint32_t sw = stage_words_for(scene_bytes, stack_bytes(stack_depth)), lds = sw * 16 + stack_bytes(stack_depth), grid = nseg(rp.n_lanes) * kSub;
+    check_lds(lds);
 #define DTOF_LAUNCH_TRACE(L, M) hipLaunchKernelGGL((k_trace<L, M>), dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, q, qin, count_in, rp.n_lanes)
     if (sw) { if (rp.has_tris) DTOF_LAUNCH_TRACE(true, true); else DTOF_LAUNCH_TRACE(true, false); }
     else    { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true); else DTOF_LAUNCH_TRACE(false, false); }
@@ -1252,7 +1261,9 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
                   uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, bool fused, bool trace_next,
                   uint32_t stack_depth, hipStream_t s, bool first, LaneDebug *dbg) {
     if (rp.n_lanes == 0) return;
-    uint32_t sw = stage_words_for(scene_bytes), grid = nseg(rp.n_lanes), lds = sw * 16 + (fused ? stack_bytes(stack_depth, kShadeBlock) : 0);
+    const uint32_t shade_stack = fused ? stack_bytes(stack_depth, kShadeBlock) : 0;
+    uint32_t sw = stage_words_for(scene_bytes, shade_stack), grid = nseg(rp.n_lanes), lds = sw * 16 + shade_stack;
+    check_lds(lds);
     uint32_t tn = trace_next ? 1u : 0u;
 #define DTOF_LAUNCH_SHADE(L, F, A, K) do { if (rp.has_tris) DTOF_LAUNCH_SHADE_M(L, F, A, K, true, false); else DTOF_LAUNCH_SHADE_M(L, F, A, K, false, false); } while (0)
 #define DTOF_LAUNCH_SHADE_M(L, F, A, K, M, S) hipLaunchKernelGGL((k_shade<L, F, A, K, M, S>), dim3(grid), dim3(kShadeBlock), lds, s, scene, scene_bytes, sw, rp, q, qin, \
@@ -1270,7 +1281,8 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
 void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                    const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
-    uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + stack_bytes(stack_depth), grid = nseg(rp.n_lanes) * kSub;
+    uint32_t sw = stage_words_for(scene_bytes, stack_bytes(stack_depth)), lds = sw * 16 + stack_bytes(stack_depth), grid = nseg(rp.n_lanes) * kSub;
+    check_lds(lds);
 #define DTOF_LAUNCH_SHADOW(L, M) hipLaunchKernelGGL((k_shadow<L, M>), dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in)
     if (sw) { if (rp.has_tris) DTOF_LAUNCH_SHADOW(true, true); else DTOF_LAUNCH_SHADOW(true, false); }
     else    { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true); else DTOF_LAUNCH_SHADOW(false, false); }
@@ -1278,7 +1290,8 @@ void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParam
 }
 void launch_velocity(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
-    uint32_t sw = stage_words_for(scene_bytes), lds = sw * 16 + stack_bytes(stack_depth);
+    uint32_t sw = stage_words_for(scene_bytes, stack_bytes(stack_depth)), lds = sw * 16 + stack_bytes(stack_depth);
+    check_lds(lds);
     if (sw) hipLaunchKernelGGL(k_velocity<true>, dim3(nblk(rp.n_lanes)), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q);
     else hipLaunchKernelGGL(k_velocity<false>, dim3(nblk(rp.n_lanes)), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q);
 }
