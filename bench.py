@@ -114,6 +114,10 @@ def cpu_baseline(scene_path, res, spp, target_s, defines):
 
 def main():
     args = parse()
+    sys.path.insert(0, os.path.join(HERE, "scenes"))
+    import make_scenes
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        make_scenes.ensure()      # scenes/*.xml are generated files
     import torch
     import torch.distributed as dist
     import mitsuba3dopplertof_amd as mi
@@ -135,6 +139,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if world > 1:
+        dist.barrier()            # rank 0 may just have written the scene files
     scene = mi.load_file(args.scene, **dict(args.defines, resx=args.res, resy=args.res))
     if args.offsets and world > 1:
         raise SystemExit("batched-offset configs are timed on one GPU here (the film gather below carries one film)")

@@ -236,5 +236,21 @@ def main():
         print("wrote", name, len(text), "bytes")
 
 
+def ensure(quiet=True):
+    """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
+    names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml",
+             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml"]
+    me = os.path.getmtime(os.path.abspath(__file__))
+    if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
+        return
+    if quiet:
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            main()
+    else:
+        main()
+
+
 if __name__ == "__main__":
     main()

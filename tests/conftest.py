@@ -8,6 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 SCENES = os.path.join(ROOT, "scenes")
+sys.path.insert(0, SCENES)
+import make_scenes as _make_scenes  # noqa: E402
+
+_make_scenes.ensure()   # scenes/*.xml are generated files (scenes/make_scenes.py), not tracked
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

@@ -3,6 +3,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mitsuba3dopplertof_amd as mi
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes")); import make_scenes; make_scenes.ensure()
 S = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes")
 scene = sys.argv[1] if len(sys.argv) > 1 else "cornell_wall.xml"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 0

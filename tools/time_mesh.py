@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scenes"))
 import make_mesh
 import mitsuba3dopplertof_amd as mi
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes")); import make_scenes; make_scenes.ensure()
 
 n_u, n_v, res, spp = [int(x) for x in (sys.argv[1:5] + ["512", "256", "512", "64"][len(sys.argv) - 1:])]
 d = tempfile.mkdtemp(prefix="dtof_mesh_")
