@@ -57,6 +57,11 @@ def gather_film(slab, rank, world, group=None):
     import torch.distributed as dist
     if world == 1:
         return [slab]
+    if slab.is_cuda and dist.get_backend(group) == "gloo":   # test set-ups without RCCL: stage through host memory
+        host = slab.cpu()
+        dst = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+        dist.gather(host, dst, dst=0, group=group)
+        return [d.to(slab.device) for d in dst] if rank == 0 else None
     dst = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
     dist.gather(slab, dst, dst=0, group=group)
     return dst

@@ -406,3 +406,33 @@ def test_full_domino_scene_1025_objects(mi, orc):
                                         path_correlation_depth=4, time_sampling_method="antithetic", wave_function_type="trapezoidal"))
         ref, _ = osc.render(pd, seed=0, spp=spp, threads=NCPU)
         assert rel_linf(imgs[k], ref) <= IMG_TOL, (off, rel_linf(imgs[k], ref))
+
+
+def test_two_ranks_on_one_gpu_reproduce_the_single_rank_image(mi, tmp_path):
+    """The whole N > 1 path on real kernels: two processes (torch.distributed, gloo for the one gather since both share the only
+    GPU of this box) each render their band of rows with dtof_render_rows, rank 0 overlap-adds the halo rows and develops.
+    The result must equal the single-process render (lane streams depend on the global lane index only)."""
+    import subprocess
+    import sys
+    script = tmp_path / "two_ranks.py"
+    script.write_text(
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "import mitsuba3dopplertof_amd as mi\n"
+        "from mitsuba3dopplertof_amd import distributed as D\n"
+        "dist.init_process_group('gloo')\n"
+        "torch.cuda.set_device(0)\n"
+        "for name, spp in (('cornell_wall.xml', 16), ('cornell_area.xml', 8), ('cornell_spheres.xml', 8)):\n"
+        "    sc = mi.load_file(os.path.join(%r, name), resx=40, resy=26)\n"     # 26 rows: bands of 13, halo rows overlap
+        "    img = D.render_sharded(sc, seed=5, spp=spp)\n"
+        "    if dist.get_rank() == 0:\n"
+        "        np.save(os.path.join(%r, name + '.npy'), img)\n"
+        "dist.barrier(); dist.destroy_process_group()\n" % (os.path.dirname(SCENES), SCENES, str(tmp_path)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    for name, spp in (("cornell_wall.xml", 16), ("cornell_area.xml", 8), ("cornell_spheres.xml", 8)):
+        sc = mi.load_file(os.path.join(SCENES, name), resx=40, resy=26)
+        ref = sc.render(seed=5, spp=spp)
+        got = np.load(str(tmp_path / (name + ".npy")))
+        assert got.shape == ref.shape and rel_linf(got, ref) <= IMG_TOL, (name, rel_linf(got, ref))
