@@ -133,11 +133,18 @@ def main():
                          % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # DTOF_BENCH_SHARE_GPU=1 (development only): all ranks use GPU 0 and gloo carries the gather, so that the N > 1 code path can
+    # be exercised on a single-GPU box; the numbers of such a run mean nothing.
+    share = os.environ.get("DTOF_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if world > 1:
         dist.barrier()            # rank 0 may just have written the scene files
