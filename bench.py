@@ -160,6 +160,7 @@ def main():
     film_ptr = film.data_ptr() + halo * W * 4 * 4
     p0, p1 = D.slab_range(H, world, rank, halo)
     rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    gather_buf = torch.empty((world, p1 - p0, W, 4), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
     lib = mi._lib()
 
     acc = {"ms_trace": 0.0, "ms_shade": 0.0, "ms_shadow": 0.0, "ms_generate": 0.0, "ms_splat": 0.0, "ms_total": 0.0, "ms_first": 0.0,
@@ -185,9 +186,9 @@ def main():
                 acc["launches"] += st["n_launches_shade"]; acc["first_launches"] += st["n_launches_first"]
             return
         st = scene.render_rows(film_ptr, seed=0, spp=spp, row_begin=r0, row_end=r1)   # synchronises the library's stream
-        slabs = D.gather_film(film[p0:p1], rank, world)
+        stack = D.gather_film_stacked(film[p0:p1], rank, world, out=gather_buf)
         if rank == 0:
-            full = D.overlap_add(slabs, H, world, halo, xp=torch) if world > 1 else film[halo:halo + H]
+            full = D.overlap_add_stacked(stack, H, world, halo) if world > 1 else film[halo:halo + H]
             full = full.contiguous()
             rc = lib.dtof_develop(full.data_ptr(), rgb.data_ptr(), H * W)
             if rc != 0:

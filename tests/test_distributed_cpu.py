@@ -41,9 +41,12 @@ def _worker(rank, world, port, q):
     padded[1:1 + H] = band
     p0, p1 = D.slab_range(H, world, rank, 1)
     assert np.count_nonzero(padded[:p0]) == 0 and np.count_nonzero(padded[p1:]) == 0   # a rank only writes inside its slab
-    slabs = D.gather_film(torch.from_numpy(np.ascontiguousarray(padded[p0:p1])), rank, world)
+    mine = torch.from_numpy(np.ascontiguousarray(padded[p0:p1]))
+    slabs = D.gather_film(mine, rank, world)
+    stack = D.gather_film_stacked(mine, rank, world)
     if rank == 0:
         full = D.overlap_add(slabs, H, world, 1, xp=torch).numpy()
+        assert np.array_equal(D.overlap_add_stacked(stack, H, world, 1).numpy(), full)
         ref, _ = sc.render(pd, seed=5, spp=4, raw=True)
         q.put(float(np.abs(full - ref).max() / np.abs(ref).max()))
     dist.barrier()
