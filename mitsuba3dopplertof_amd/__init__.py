@@ -377,3 +377,27 @@ class Sampler:
         o = np.zeros((n, 7), np.uint32)
         _check(_lib().dtof_sampler_get_state(self._h, o.ctypes.data))
         return o
+
+
+# ------------------------------------------------------------------------------------------------ variant selection
+# `import mitsuba as mi; mi.set_variant('cuda_rgb')` opens every tutorial script (program_runner.py:1-2).  This library has
+# exactly one back end: RGB colour, float32 arithmetic, HIP kernels -- the counterpart of the reference's *_rgb variants.
+_VARIANT = "hip_rgb"
+
+
+def variants():
+    return ["hip_rgb"]
+
+
+def variant():
+    return _VARIANT
+
+
+def set_variant(*names):
+    """Accepts the first usable of `names`; every scalar_/llvm_/cuda_ *_rgb variant of the reference maps onto hip_rgb
+    (src/python/python/__init__.py: mi.set_variant).  Spectral, polarised, mono and double-precision variants do not exist here."""
+    for n in names:
+        if n == "hip_rgb" or (n.split("_", 1)[0] in ("scalar", "llvm", "cuda") and n.endswith("_rgb") and "_ad_" not in "_" + n.split("_", 1)[1] + "_"):
+            return
+    raise ImportError("Requested an unsupported variant \"%s\". The following variants are available: hip_rgb (the *_rgb variants of "
+                      "the reference map onto it)." % ", ".join(names))

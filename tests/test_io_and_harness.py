@@ -211,3 +211,34 @@ def test_animation_driver_reconstructs_the_wall_velocity(mi, tmp_path):
     v = E.calc_velocity_from_homo_heteros(homo, het, exposure_time=T, w_g=30)[8:16, 8:16]
     assert abs(np.median(v) + 10.0) < 2.5, np.median(v)
     assert E.run_animation("wall", base, config=cfg, defines=dict(resx=24, resy=24), log=lambda m: None) == []   # everything cached
+
+
+def test_variant_selection_mirrors_the_tutorials_preamble(mi):
+    mi.set_variant("cuda_rgb")                       # program_runner.py:2
+    mi.set_variant("scalar_spectral", "llvm_rgb")    # first usable wins
+    assert mi.variant() == "hip_rgb" and mi.variants() == ["hip_rgb"]
+    for bad in ("cuda_spectral", "cuda_ad_rgb", "llvm_mono_polarized"):
+        with pytest.raises(ImportError, match="unsupported variant"):
+            mi.set_variant(bad)
+
+
+@pytest.mark.gpu
+def test_the_tutorial_call_sequence_runs_as_is(mi):
+    """What program_runner.py:11-31,124-146 does with `mitsuba`, done with this package under the same alias: set_variant,
+    load_file, load_dict of the integrator dictionary, integrator.render(scene, seed=i, spp=n) per pass, in-place accumulation."""
+    mi.set_variant("cuda_rgb")
+    scene = mi.load_file(os.path.join(SCENES, "cornell_boxes.xml"), resx=24, resy=24)
+    integrator = mi.load_dict({"type": "dopplertofpath", "is_doppler_integrator": True, "max_depth": 4, "w_g": 30, "time": 0.0015,
+                               "hetero_frequency": 1.0, "hetero_offset": 0.0, "antithetic_shift": 0.5, "time_sampling_method": "antithetic",
+                               "path_correlation_depth": 16, "low_frequency_component_only": True, "wave_function_type": "sinusoidal",
+                               "use_stratified_sampling_for_each_interval": True})
+    total = None
+    for i in range(3):
+        img = integrator.render(scene, seed=i, spp=16)
+        if i == 0:
+            total = img
+        else:
+            total += img
+    mean = total / 3
+    assert mean.shape == (24, 24, 3) and np.isfinite(mean).all()
+    assert np.allclose(mean, mi.render_multi_pass(scene, integrator, 48, 16), rtol=0, atol=1e-6 * np.abs(mean).max())
