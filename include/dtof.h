@@ -91,9 +91,10 @@ int dtof_scene_get_info(const dtof_scene *scene, dtof_scene_info *info);
  *                             shapes (cube, obj, ply) concatenated in shape order (cube.cpp:114-160, obj.cpp, ply.cpp)
  * kind 8: spheres           -> per sphere m_center[3], m_radius, m_inv_surface_area, flip_normals (sphere.cpp:138-160);
  *                             their composed to_world / to_object are in kind 1
- * kind 9: BSDF records      -> per shape 22 floats: kind (0 diffuse, 1 conductor, 2 dielectric, 3 plastic), twosided, eta,
+ * kind 9: BSDF records      -> per shape 24 floats: kind (0 diffuse, 1 conductor, 2 dielectric, 3 plastic, 4 roughconductor), twosided, eta,
  *                             nonlinear, 1/eta^2, fdr_int, specular sampling weight, reflectance[3], specular_reflectance[3],
- *                             specular_transmittance[3], conductor eta[3], k[3] (src/bsdfs/{diffuse,conductor,dielectric,plastic}.cpp)
+ *                             specular_transmittance[3], conductor eta[3], k[3], alpha_u, alpha_v
+ *                             (src/bsdfs/{diffuse,conductor,dielectric,plastic,roughconductor}.cpp)
  * Returns the number of floats written (<= capacity) through *n_written. */
 int dtof_scene_export(const dtof_scene *scene, int kind, float *out, size_t capacity, size_t *n_written);
 

@@ -641,6 +641,46 @@ DTOF_D float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
     const float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
     return 0.5f * (r_s + r_p);
 }
+// ---- MicrofacetDistribution, GGX, sample_visible = true (include/mitsuba/render/microfacet.h)
+struct Ggx { float au, av; };
+DTOF_D Ggx ggx_make(float au, float av) { Ggx g; g.au = fmax_(au, 1e-4f); g.av = fmax_(av, 1e-4f); return g; }   // configure() :425-428
+DTOF_D float ggx_eval(Ggx g, V3 m) {   // eval() :176-196
+    const float result = rcp(kPi * (g.au * g.av) * sqr(sqr(m.x / g.au) + sqr(m.y / g.av) + sqr(m.z)));
+    return result * m.z > 1e-20f ? result : 0.f;
+}
+DTOF_D float ggx_smith_g1(Ggx g, V3 v, V3 m) {   // smith_g1() :341-365
+    const float xy_alpha_2 = sqr(g.au * v.x) + sqr(g.av * v.y), tan_theta_alpha_2 = xy_alpha_2 / sqr(v.z);
+    float result = 2.f / (1.f + sqrtf(1.f + tan_theta_alpha_2));
+    if (xy_alpha_2 == 0.f) result = 1.f;
+    if (dot(v, m) * v.z <= 0.f) result = 0.f;
+    return result;
+}
+// sample(), visible-normal branch :296-325 + sample_visible_11, GGX branch :405-420: microfacet normal and its density
+DTOF_D V3 ggx_sample(Ggx g, V3 wi, float s_x, float s_y, float &pdf) {
+    const V3 wi_p = normalize(mk(g.au * wi.x, g.av * wi.y, wi.z));
+    const float sin_theta_2 = fmaf(wi_p.x, wi_p.x, sqr(wi_p.y)), inv_sin_theta = rsqrt_(sin_theta_2);   // Frame3f::sincos_phi (frame.h:111-122)
+    float rx = fmin_(fmax_(wi_p.x * inv_sin_theta, -1.f), 1.f), ry = fmin_(fmax_(wi_p.y * inv_sin_theta, -1.f), 1.f);
+    if (fabsf(sin_theta_2) <= 4.f * 5.9604644775390625e-8f) { rx = 1.f; ry = 0.f; }
+    const float sin_phi = ry, cos_phi = rx, cos_theta = wi_p.z;
+    const float x = fmaf(2.f, s_x, -1.f), y = fmaf(2.f, s_y, -1.f);   // square_to_uniform_disk_concentric (warp.h:54-90)
+    const bool is_zero = x == 0.f && y == 0.f, q13 = fabsf(x) < fabsf(y);
+    const float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = 0.25f * kPi * rp / r;
+    if (q13) phi = 0.5f * kPi - phi;
+    if (is_zero) phi = 0.f;
+    float sn, cs; sincos_(phi, sn, cs);
+    const float px = r * cs; float py = r * sn;
+    const float s = 0.5f * (1.f + cos_theta), a = safe_sqrt(1.f - sqr(px));
+    py = fmaf(py, s, fmaf(-a, s, a));                              // dr::lerp(a, py, s)
+    const float pz = safe_sqrt(1.f - fmaf(py, py, px * px));
+    const float sin_theta_i = safe_sqrt(1.f - sqr(cos_theta));
+    const float norm_ = rcp(fmaf(sin_theta_i, py, cos_theta * pz));
+    const float slope_x = fmaf(cos_theta, py, -(sin_theta_i * pz)) * norm_, slope_y = px * norm_;
+    const float sx = fmaf(cos_phi, slope_x, -(sin_phi * slope_y)) * g.au, sy = fmaf(sin_phi, slope_x, cos_phi * slope_y) * g.av;
+    const V3 m = normalize(mk(-sx, -sy, 1.f));
+    pdf = ggx_eval(g, m) * ggx_smith_g1(g, wi, m) * fabsf(dot(wi, m)) / wi.z;
+    return m;
+}
 // fresnel -- include/mitsuba/render/fresnel.h:21-63
 DTOF_D void fresnel_dielectric(float cos_theta_i, float eta, float &r, float &cos_theta_t, float &eta_it, float &eta_ti) {
     const bool outside = cos_theta_i >= 0.f;
@@ -793,7 +833,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             // ---- emitter sampling (scene.cpp:235-291; point.cpp:118-147; area.cpp:116-159 + shape.cpp:370-384 + rectangle.cpp:152-166)
             float e1 = single ? next_f32(main) : next_correlate(main, path, correlate), e2 = single ? next_f32(main) : next_correlate(main, path, correlate);
             // has_flag(bsdf->flags(), BSDFFlags::Smooth) (:178): diffuse and plastic have a smooth lobe
-            bool active_em = active_next && sv.n_emitters > 0 && (!SPEC || sh->bsdf == BSDF_DIFFUSE || sh->bsdf == BSDF_PLASTIC);
+            bool active_em = active_next && sv.n_emitters > 0 && (!SPEC || sh->bsdf == BSDF_DIFFUSE || sh->bsdf == BSDF_PLASTIC || sh->bsdf == BSDF_ROUGHCONDUCTOR);
             V3 em_weight = mk(0, 0, 0), wo = mk(0, 0, 0); float ds_dist = 0.f, ds_pdf = 0.f; bool ds_delta = true;
             if (active_em) {
                 uint32_t ne = sv.n_emitters, idx = 0; float em_w = 1.f, sx = e1;
@@ -874,6 +914,37 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 const float f2 = sqr(eta_ti);
                 bsdf_weight = selected_r ? mk(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2])
                                          : mk(sh->spec_trans[0] * f2, sh->spec_trans[1] * f2, sh->spec_trans[2] * f2);
+            } else if (SPEC && sh->bsdf == BSDF_ROUGHCONDUCTOR) {
+                // RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF
+                V3 wi = si.wi, wo_l = wo;
+                if (twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
+                const Ggx g = ggx_make(sh->alpha_u, sh->alpha_v);
+                if (wi.z > 0.f && wo_l.z > 0.f) {
+                    const V3 H = normalize(wo_l + wi);
+                    const float D = ggx_eval(g, H);
+                    if (D != 0.f) {
+                        const float G = ggx_smith_g1(g, wi, H) * ggx_smith_g1(g, wo_l, H);
+                        const float result = D * G / (4.f * wi.z), c = dot(wi, H);
+                        bsdf_val = mk(fresnel_conductor(c, sh->cond_eta[0], sh->cond_k[0]) * (result * sh->spec_refl[0]),
+                                      fresnel_conductor(c, sh->cond_eta[1], sh->cond_k[1]) * (result * sh->spec_refl[1]),
+                                      fresnel_conductor(c, sh->cond_eta[2], sh->cond_k[2]) * (result * sh->spec_refl[2]));
+                    }
+                    if (dot(wi, H) > 0.f && dot(wo_l, H) > 0.f) bsdf_pdf = ggx_eval(g, H) * ggx_smith_g1(g, wi, H) / (4.f * wi.z);
+                }
+                if (wi.z > 0.f) {
+                    float mpdf;
+                    const V3 m = ggx_sample(g, wi, s2x, s2y, mpdf);
+                    const float dwm = dot(wi, m);
+                    const V3 r = mk(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   // reflect(wi, m)
+                    bs_wo = r; bs_eta = 1.f;
+                    const bool ok = mpdf != 0.f && r.z > 0.f;
+                    const float weight = ggx_smith_g1(g, r, m);
+                    bs_pdf = mpdf / (4.f * dot(r, m));
+                    if (ok) bsdf_weight = mk(fresnel_conductor(dwm, sh->cond_eta[0], sh->cond_k[0]) * (weight * sh->spec_refl[0]),
+                                             fresnel_conductor(dwm, sh->cond_eta[1], sh->cond_k[1]) * (weight * sh->spec_refl[1]),
+                                             fresnel_conductor(dwm, sh->cond_eta[2], sh->cond_k[2]) * (weight * sh->spec_refl[2]));
+                    if (twosided && si.wi.z < 0.f) bs_wo.z = -bs_wo.z;
+                }
             } else if (SPEC && sh->bsdf == BSDF_PLASTIC) {
                 // SmoothPlastic::eval / pdf / sample (plastic.cpp:219-360) under TwoSidedBRDF; wiz / woz are already flipped
                 float f_i, t1, t2, t3;

@@ -17,7 +17,7 @@ enum WaveType : int32_t { WAVE_SIN = 0, WAVE_RECT = 1, WAVE_TRI = 2, WAVE_TRAP =
 enum TimeSampling : int32_t { TIME_UNIFORM = 0, TIME_STRATIFIED = 1, TIME_ANTITHETIC = 2, TIME_ANTITHETIC_MIRROR = 3 };
 enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1, FILTER_GAUSSIAN = 2 };
 enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4, SF_EMITTER = 8 };
-enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3 };
+enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4 };
 enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1 };
 
 // ---------------------------------------------------------------------------- device blob records
@@ -65,7 +65,8 @@ struct DShape {             // 304 B
     // (src/bsdfs/dielectric.cpp) diel_eta = int_ior / ext_ior, spec_refl, spec_trans
     // BSDF_PLASTIC (src/bsdfs/plastic.cpp): refl = diffuse_reflectance, spec_refl, diel_eta and the constants of parameters_changed
     uint32_t bsdf; float diel_eta; uint32_t nonlinear; float inv_eta_2;
-    float cond_eta[3], fdr_int, cond_k[3], spec_sampling_weight, spec_refl[3], pad9, spec_trans[3], pad10;
+    // BSDF_ROUGHCONDUCTOR (src/bsdfs/roughconductor.cpp, GGX + visible normals): cond_eta / cond_k / spec_refl + alpha_u, alpha_v
+    float cond_eta[3], fdr_int, cond_k[3], spec_sampling_weight, spec_refl[3], alpha_u, spec_trans[3], alpha_v;
 };
 struct DTri { float p0[3]; uint32_t face; float p1[4], p2[4]; };         // 48 B; face = index in the mesh's own order (tie rule)
 struct DTriShade { float n0[3], n1[3], n2[3], uv0[2], uv1[2], uv2[2], pad; };   // 64 B
@@ -82,6 +83,7 @@ struct HostShape {
     uint32_t bsdf = BSDF_DIFFUSE;   // + the parameters of the specular BSDFs
     float cond_eta[3] = { 0, 0, 0 }, cond_k[3] = { 1, 1, 1 }, spec_refl[3] = { 1, 1, 1 }, spec_trans[3] = { 1, 1, 1 }, diel_eta = 1.f;
     bool nonlinear = false; float inv_eta_2 = 1.f, fdr_int = 0.f, spec_sampling_weight = 0.f;   // plastic
+    float alpha_u = .1f, alpha_v = .1f;   // roughconductor
     float to_world[16], to_object[16];     // float casts of the double transform and its double inverse
     // mesh: cube baked like src/shapes/cube.cpp:114-160; obj / ply through mesh_io.cpp
     std::vector<float> positions, normals, texcoords;

@@ -131,7 +131,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         d.kind = h.kind;
         d.flags = (h.twosided ? SF_TWOSIDED : 0) | (h.flip_normals ? SF_FLIP_NORMALS : 0) | (h.face_normals ? SF_FACE_NORMALS : 0);
         memcpy(d.refl, h.refl, 12); d.blas_root = kNoChild;
-        d.bsdf = h.bsdf; d.diel_eta = h.diel_eta; d.nonlinear = h.nonlinear; d.inv_eta_2 = h.inv_eta_2; d.fdr_int = h.fdr_int; d.spec_sampling_weight = h.spec_sampling_weight;
+        d.bsdf = h.bsdf; d.diel_eta = h.diel_eta; d.nonlinear = h.nonlinear; d.inv_eta_2 = h.inv_eta_2; d.fdr_int = h.fdr_int; d.spec_sampling_weight = h.spec_sampling_weight; d.alpha_u = h.alpha_u; d.alpha_v = h.alpha_v;
         memcpy(d.cond_eta, h.cond_eta, 12); memcpy(d.cond_k, h.cond_k, 12); memcpy(d.spec_refl, h.spec_refl, 12); memcpy(d.spec_trans, h.spec_trans, 12);
         if (h.emitter) { d.flags |= SF_EMITTER; memcpy(d.radiance, h.radiance, 12); }
         memcpy(d.to_world, h.to_world, 48); memcpy(d.to_object, h.to_object, 48);

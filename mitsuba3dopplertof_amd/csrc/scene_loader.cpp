@@ -481,6 +481,23 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         if (int_ior < 0 || ext_ior < 0) fail("The interior and exterior indices of refraction must be positive!");
         s.bsdf = BSDF_DIELECTRIC; s.diel_eta = int_ior / ext_ior;
         color_of(b, "specular_reflectance", 1.f, s.spec_refl); color_of(b, "specular_transmittance", 1.f, s.spec_trans);
+    } else if (b.plugin == "roughconductor") {   // src/bsdfs/roughconductor.cpp:177-227
+        std::string material = b.props.get_string("material", "none");
+        if (material != "none") fail(b.props.has("eta") || b.colors.count("eta") ? "Should specify either (eta, k) or material, not both."
+            : "roughconductor: named materials need the spectral IOR data files, which this build does not ship; give \"eta\" and \"k\"");
+        std::string distr = b.props.get_string("distribution", "beckmann");
+        std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
+        if (distr != "beckmann" && distr != "ggx") fail("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"!");
+        if (distr != "ggx") fail("roughconductor: only distribution \"ggx\" is implemented (the Beckmann distribution needs Dr.Jit's erf / erfinv "
+                                 "approximations, whose source is not part of the reference tree)");
+        if (!b.props.get_bool("sample_visible", true)) fail("roughconductor: only sample_visible = true is implemented");
+        if (b.props.has("alpha_u") || b.props.has("alpha_v")) {
+            if (!b.props.has("alpha_u") || !b.props.has("alpha_v")) fail("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
+            if (b.props.has("alpha")) fail("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.");
+            s.alpha_u = (float) b.props.get_float("alpha_u", 0.1); s.alpha_v = (float) b.props.get_float("alpha_v", 0.1);
+        } else s.alpha_u = s.alpha_v = (float) b.props.get_float("alpha", 0.1);
+        s.bsdf = BSDF_ROUGHCONDUCTOR;
+        color_of(b, "eta", 0.f, s.cond_eta); color_of(b, "k", 1.f, s.cond_k); color_of(b, "specular_reflectance", 1.f, s.spec_refl);
     } else if (b.plugin == "plastic") {   // src/bsdfs/plastic.cpp:167-217
         const float int_ior = lookup_ior(b, "int_ior", "polypropylene"), ext_ior = lookup_ior(b, "ext_ior", "air");
         if (int_ior < 0 || ext_ior < 0) fail("The interior and exterior indices of refraction must be positive!");
@@ -498,7 +515,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         }
         const float d_mean = ((s.refl[0] + s.refl[1]) + s.refl[2]) * (1.0f / 3.0f), s_mean = ((s.spec_refl[0] + s.spec_refl[1]) + s.spec_refl[2]) * (1.0f / 3.0f);
         s.spec_sampling_weight = s_mean / (d_mean + s_mean);
-    } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, plastic, conductor, dielectric, twosided)");
+    } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, plastic, conductor, roughconductor, dielectric, twosided)");
     auto u = b.props.unqueried();
     if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in plugin of type \"" + b.plugin + "\"");
 }

@@ -786,6 +786,52 @@ static void fresnel_dielectric(float cos_theta_i, float eta, float *r_out, float
     if (special_case) r = r_sc;
     *r_out = r; *cos_theta_t = f_mulsign_neg(cos_theta_t_abs, cos_theta_i); *eta_it_out = eta_it; *eta_ti_out = eta_ti;
 }
+/* ---- MicrofacetDistribution, GGX, sample_visible = true (include/mitsuba/render/microfacet.h) */
+typedef struct { float au, av; } ggx_t;
+static ggx_t ggx_make(float au, float av) { ggx_t g; g.au = f_max(au, 1e-4f); g.av = f_max(av, 1e-4f); return g; }   /* configure() :425-428 */
+static float ggx_eval(ggx_t g, v3 m) {   /* eval() :176-196 */
+    float alpha_uv = g.au * g.av, cos_theta = m.z;
+    float result = f_rcp(ORC_PI_F * alpha_uv * f_sqr(f_sqr(m.x / g.au) + f_sqr(m.y / g.av) + f_sqr(m.z)));
+    return result * cos_theta > 1e-20f ? result : 0.f;
+}
+static float ggx_smith_g1(ggx_t g, v3 v, v3 m) {   /* smith_g1() :341-365 */
+    float xy_alpha_2 = f_sqr(g.au * v.x) + f_sqr(g.av * v.y), tan_theta_alpha_2 = xy_alpha_2 / f_sqr(v.z);
+    float result = 2.f / (1.f + sqrtf(1.f + tan_theta_alpha_2));
+    if (xy_alpha_2 == 0.f) result = 1.f;
+    if (v_dot(v, m) * v.z <= 0.f) result = 0.f;
+    return result;
+}
+/* sample() visible-normal branch :296-325 + sample_visible_11 GGX branch :405-420; returns m and the density of m */
+static v3 ggx_sample(ggx_t g, v3 wi, float s_x, float s_y, float *pdf_out) {
+    v3 wi_p = v_normalize(V(g.au * wi.x, g.av * wi.y, wi.z));
+    /* Frame3f::sincos_phi (frame.h:111-122) */
+    float sin_theta_2 = fmaf(wi_p.x, wi_p.x, f_sqr(wi_p.y)), inv_sin_theta = f_rsqrt(sin_theta_2);
+    float rx = wi_p.x * inv_sin_theta, ry = wi_p.y * inv_sin_theta;
+    rx = f_min(f_max(rx, -1.f), 1.f); ry = f_min(f_max(ry, -1.f), 1.f);
+    if (fabsf(sin_theta_2) <= 4.f * 5.9604644775390625e-8f) { rx = 1.f; ry = 0.f; }
+    float sin_phi = ry, cos_phi = rx, cos_theta = wi_p.z;
+    /* sample_visible_11: square_to_uniform_disk_concentric (warp.h:54-90) */
+    float x = fmaf(2.f, s_x, -1.f), y = fmaf(2.f, s_y, -1.f);
+    int is_zero = x == 0.f && y == 0.f, q13 = fabsf(x) < fabsf(y);
+    float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = 0.25f * ORC_PI_F * rp / r;
+    if (q13) phi = 0.5f * ORC_PI_F - phi;
+    if (is_zero) phi = 0.f;
+    float sn, cs; orc_sincos(phi, &sn, &cs);
+    float px = r * cs, py = r * sn;
+    float s = 0.5f * (1.f + cos_theta);
+    float a = f_safe_sqrt(1.f - f_sqr(px));
+    py = fmaf(py, s, fmaf(-a, s, a));                      /* dr::lerp(a, py, s) = fmadd(py, s, fnmadd(a, s, a)) */
+    float pz = f_safe_sqrt(1.f - fmaf(py, py, px * px));   /* squared_norm(p) = fmadd chain */
+    float sin_theta_i = f_safe_sqrt(1.f - f_sqr(cos_theta));
+    float norm = f_rcp(fmaf(sin_theta_i, py, cos_theta * pz));
+    float slope_x = fmaf(cos_theta, py, -(sin_theta_i * pz)) * norm, slope_y = px * norm;
+    /* rotate & unstretch, normal, density */
+    float sx = fmaf(cos_phi, slope_x, -(sin_phi * slope_y)) * g.au, sy = fmaf(sin_phi, slope_x, cos_phi * slope_y) * g.av;
+    v3 m = v_normalize(V(-sx, -sy, 1.f));
+    *pdf_out = ggx_eval(g, m) * ggx_smith_g1(g, wi, m) * fabsf(v_dot(wi, m)) / wi.z;
+    return m;
+}
 /* mis_weight -- dopplertofpath.cpp:296-301 */
 static inline float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
@@ -890,7 +936,8 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         }
 
         /* has_flag(bsdf->flags(), BSDFFlags::Smooth), :178 -- diffuse and plastic have a smooth lobe */
-        int active_em = active_next && hit && (si.shape->bsdf == ORC_BSDF_DIFFUSE || si.shape->bsdf == ORC_BSDF_PLASTIC);
+        int active_em = active_next && hit && (si.shape->bsdf == ORC_BSDF_DIFFUSE || si.shape->bsdf == ORC_BSDF_PLASTIC ||
+                                               si.shape->bsdf == ORC_BSDF_ROUGHCONDUCTOR);
 
         /* emitter sampling: Scene::sample_emitter_direction src/render/scene.cpp:235-291 */
         float e1 = sampler_draw(&smp, correlate, single);
@@ -985,6 +1032,39 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
             bs_eta = selected_r ? 1.f : eta_it;
             if (selected_r) bsdf_weight = V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]);
             else { float f2 = f_sqr(eta_ti); bsdf_weight = V(sh->spec_trans[0] * f2, sh->spec_trans[1] * f2, sh->spec_trans[2] * f2); }
+        } else if (hit && si.shape->bsdf == ORC_BSDF_ROUGHCONDUCTOR) {
+            /* RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF */
+            const orc_shape *sh = si.shape;
+            v3 wi = si.wi, wo_l = wo;
+            if (sh->twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }   /* twosided.cpp:219-258 flips both */
+            ggx_t g = ggx_make(sh->alpha_u, sh->alpha_v);
+            if (wi.z > 0.f && wo_l.z > 0.f) {
+                v3 H = v_normalize(v_add(wo_l, wi));
+                float D = ggx_eval(g, H);
+                if (D != 0.f) {   /* eval :317-375 */
+                    float G = ggx_smith_g1(g, wi, H) * ggx_smith_g1(g, wo_l, H);
+                    float result = D * G / (4.f * wi.z), c = v_dot(wi, H);
+                    bsdf_val = V(fresnel_conductor(c, sh->cond_eta[0], sh->cond_k[0]) * (result * sh->spec_refl[0]),
+                                 fresnel_conductor(c, sh->cond_eta[1], sh->cond_k[1]) * (result * sh->spec_refl[1]),
+                                 fresnel_conductor(c, sh->cond_eta[2], sh->cond_k[2]) * (result * sh->spec_refl[2]));
+                }
+                if (v_dot(wi, H) > 0.f && v_dot(wo_l, H) > 0.f)   /* pdf :377-415 */
+                    bsdf_pdf = ggx_eval(g, H) * ggx_smith_g1(g, wi, H) / (4.f * wi.z);
+            }
+            if (wi.z > 0.f) {   /* sample :229-315 */
+                float mpdf;
+                v3 m = ggx_sample(g, wi, s2x, s2y, &mpdf);
+                float dwm = v_dot(wi, m);
+                v3 r = V(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   /* reflect(wi, m) fresnel.h:282-284 */
+                bs_wo = r; bs_eta = 1.f;
+                int ok = mpdf != 0.f && r.z > 0.f;
+                float weight = ggx_smith_g1(g, r, m);
+                bs_pdf = mpdf / (4.f * v_dot(r, m));
+                if (ok) bsdf_weight = V(fresnel_conductor(dwm, sh->cond_eta[0], sh->cond_k[0]) * (weight * sh->spec_refl[0]),
+                                        fresnel_conductor(dwm, sh->cond_eta[1], sh->cond_k[1]) * (weight * sh->spec_refl[1]),
+                                        fresnel_conductor(dwm, sh->cond_eta[2], sh->cond_k[2]) * (weight * sh->spec_refl[2]));
+                if (sh->twosided && si.wi.z < 0.f) bs_wo.z = -bs_wo.z;
+            }
         } else if (hit && si.shape->bsdf == ORC_BSDF_PLASTIC) {
             /* SmoothPlastic::eval / pdf / sample (plastic.cpp:219-360) under TwoSidedBRDF (twosided.cpp:111-148,219-258) */
             const orc_shape *sh = si.shape;

@@ -29,7 +29,7 @@ enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1 };
 enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 };
 enum { ORC_TIME_UNIFORM = 0, ORC_TIME_STRATIFIED = 1, ORC_TIME_ANTITHETIC = 2,
        ORC_TIME_ANTITHETIC_MIRROR = 3 };
-enum { ORC_BSDF_DIFFUSE = 0, ORC_BSDF_CONDUCTOR = 1, ORC_BSDF_DIELECTRIC = 2, ORC_BSDF_PLASTIC = 3 };
+enum { ORC_BSDF_DIFFUSE = 0, ORC_BSDF_CONDUCTOR = 1, ORC_BSDF_DIELECTRIC = 2, ORC_BSDF_PLASTIC = 3, ORC_BSDF_ROUGHCONDUCTOR = 4 };
 enum { ORC_FILTER_BOX = 0, ORC_FILTER_TENT = 1, ORC_FILTER_GAUSSIAN = 2 };
 
 /* All 4x4 matrices are row-major float32: m[4*r + c]. */
@@ -69,6 +69,9 @@ typedef struct {
      * and the constants of SmoothPlastic::parameters_changed (:201-217), filled by orc_plastic_params */
     int32_t nonlinear;
     float   inv_eta_2, fdr_int, spec_sampling_weight;
+    /* roughconductor (src/bsdfs/roughconductor.cpp) with the GGX distribution and visible-normal sampling
+     * (include/mitsuba/render/microfacet.h): cond_eta / cond_k / spec_refl as for the conductor + the two roughness values */
+    float   alpha_u, alpha_v;
 } orc_shape;
 
 typedef struct {

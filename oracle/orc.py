@@ -28,7 +28,8 @@ class OrcShape(C.Structure):
                 ("center", C.c_float * 3), ("radius", C.c_float), ("sphere_inv_area", C.c_float),
                 ("bsdf", C.c_int32), ("cond_eta", C.c_float * 3), ("cond_k", C.c_float * 3), ("spec_refl", C.c_float * 3),
                 ("spec_trans", C.c_float * 3), ("diel_eta", C.c_float), ("nonlinear", C.c_int32),
-                ("inv_eta_2", C.c_float), ("fdr_int", C.c_float), ("spec_sampling_weight", C.c_float)]
+                ("inv_eta_2", C.c_float), ("fdr_int", C.c_float), ("spec_sampling_weight", C.c_float),
+                ("alpha_u", C.c_float), ("alpha_v", C.c_float)]
 
 
 class OrcGroup(C.Structure):
@@ -168,6 +169,7 @@ class Scene:
             for key in ("cond_eta", "cond_k", "spec_refl", "spec_trans"):
                 setattr(o, key, (C.c_float * 3)(*np.asarray(s.get(key, [0, 0, 0]), np.float32).tolist()))
             o.diel_eta = float(s.get("diel_eta", 1.0))
+            o.alpha_u, o.alpha_v = float(s.get("alpha_u", 0.1)), float(s.get("alpha_v", 0.1))
             if o.bsdf == 3:   # plastic: SmoothPlastic::parameters_changed in C float32
                 o.nonlinear = int(s.get("nonlinear", 0))
                 out3 = (C.c_float * 3)()

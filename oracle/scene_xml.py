@@ -347,7 +347,7 @@ def _bsdf_of(props, registry):
         rec["twosided"] = 1
         return rec
     rec = dict(twosided=0, bsdf=0, reflectance=np.array([0.5] * 3, F32), cond_eta=np.zeros(3, F32), cond_k=np.ones(3, F32),
-               spec_refl=np.ones(3, F32), spec_trans=np.ones(3, F32), diel_eta=F32(1.0), nonlinear=0)
+               spec_refl=np.ones(3, F32), spec_trans=np.ones(3, F32), diel_eta=F32(1.0), nonlinear=0, alpha_u=F32(0.1), alpha_v=F32(0.1))
     if props.plugin == "diffuse":
         rec["reflectance"] = _color(props, "reflectance", 0.5)
     elif props.plugin == "conductor":   # src/bsdfs/conductor.cpp:171-188
@@ -362,6 +362,29 @@ def _bsdf_of(props, registry):
             raise ValueError("The interior and exterior indices of refraction must be positive!")
         rec.update(bsdf=2, diel_eta=F32(int_ior / ext_ior), spec_refl=_color(props, "specular_reflectance", 1.0),
                    spec_trans=_color(props, "specular_transmittance", 1.0))
+    elif props.plugin == "roughconductor":   # src/bsdfs/roughconductor.cpp:177-227
+        material = props.get_s("material", "none")
+        if material != "none":
+            raise ValueError("Should specify either (eta, k) or material, not both." if "eta" in props else
+                             'roughconductor: named materials need the spectral IOR data files, which this build does not ship; give "eta" and "k"')
+        distr = props.get_s("distribution", "beckmann").lower()
+        if distr not in ("beckmann", "ggx"):
+            raise ValueError('Specified an invalid distribution "%s", must be "beckmann" or "ggx"!' % distr)
+        if distr != "ggx":
+            raise ValueError('roughconductor: only distribution "ggx" is implemented (the Beckmann distribution needs Dr.Jit\'s erf / erfinv '
+                             'approximations, whose source is not part of the reference tree)')
+        if not props.get_b("sample_visible", True):
+            raise ValueError("roughconductor: only sample_visible = true is implemented")
+        if "alpha_u" in props or "alpha_v" in props:
+            if not ("alpha_u" in props and "alpha_v" in props):
+                raise ValueError("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.")
+            if "alpha" in props:
+                raise ValueError("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.")
+            au, av = F32(props.get_f("alpha_u", 0.1)), F32(props.get_f("alpha_v", 0.1))
+        else:
+            au = av = F32(props.get_f("alpha", 0.1))
+        rec.update(bsdf=4, cond_eta=_color(props, "eta", 0.0), cond_k=_color(props, "k", 1.0), spec_refl=_color(props, "specular_reflectance", 1.0),
+                   alpha_u=au, alpha_v=av)
     elif props.plugin == "plastic":     # src/bsdfs/plastic.cpp:167-199
         int_ior, ext_ior = _lookup_ior(props, "int_ior", "polypropylene"), _lookup_ior(props, "ext_ior", "air")
         if int_ior < 0 or ext_ior < 0:
@@ -431,7 +454,8 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
     return dict(kind=kind, twosided=twosided, flip_normals=int(flip), face_normals=int(sp.get_b("face_normals", False)),
                 reflectance=refl, to_world=_m32(tw), to_object=_m32(tinv), emitter=emitter, radiance=radiance, mesh_raw=mesh_raw,
                 sphere=sphere, bsdf=brec["bsdf"], cond_eta=brec["cond_eta"], cond_k=brec["cond_k"], spec_refl=brec["spec_refl"],
-                spec_trans=brec["spec_trans"], diel_eta=brec["diel_eta"], nonlinear=brec.get("nonlinear", 0))
+                spec_trans=brec["spec_trans"], diel_eta=brec["diel_eta"], nonlinear=brec.get("nonlinear", 0),
+                alpha_u=brec.get("alpha_u", F32(0.1)), alpha_v=brec.get("alpha_v", F32(0.1)))
 
 
 def load(source, params=None, is_string=False):

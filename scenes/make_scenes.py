@@ -174,6 +174,27 @@ def cornell_plastic(res=128, spp=16):
     return s + LIGHT + "</scene>\n"
 
 
+ROUGH = ('\t<bsdf type="twosided" id="RoughCopperBSDF">\n\t\t<bsdf type="roughconductor">\n\t\t\t<string name="distribution" value="ggx" />\n'
+         '\t\t\t<float name="alpha" value="0.2" />\n\t\t\t<rgb name="eta" value="0.2, 0.92, 1.1" />\n\t\t\t<rgb name="k" value="3.9, 2.45, 2.14" />\n'
+         '\t\t</bsdf>\n\t</bsdf>\n'
+         '\t<bsdf type="twosided" id="BrushedBSDF">\n\t\t<bsdf type="roughconductor">\n\t\t\t<string name="distribution" value="ggx" />\n'
+         '\t\t\t<float name="alpha_u" value="0.05" />\n\t\t\t<float name="alpha_v" value="0.3" />\n\t\t\t<rgb name="eta" value="1.5, 1.5, 1.5" />\n'
+         '\t\t\t<rgb name="k" value="7.6, 6.3, 5.4" />\n\t\t\t<rgb name="specular_reflectance" value="0.9, 0.9, 0.95" />\n\t\t</bsdf>\n\t</bsdf>\n')
+
+
+def cornell_rough(res=128, spp=16):
+    """cornell_boxes.xml with rough-copper (GGX) boxes and a brushed-metal (anisotropic GGX) floor under the ceiling area light:
+    glossy lobes get next-event estimation AND emitter hits, i.e. both directions of the MIS"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        s += bsdf(*b)
+    s += ROUGH
+    for name, m, b in WALLS:
+        s += rect(name, m, "BrushedBSDF" if name == "Floor" else b)
+    s += cube("ShortBox", SHORT, "RoughCopperBSDF", "0.015") + cube("TallBox", TALL, "RoughCopperBSDF", "-0.015")
+    return s + AREA_LIGHT + "</scene>\n"
+
+
 def cornell_specular(res=128, spp=16, area_light=True):
     """the Cornell room with a copper-like mirror box (moving), a glass sphere (static) and a mirror back wall section; lit by the
     ceiling area light (so that specular chains reach an emitter: delta lobes get no next-event estimation)"""
@@ -225,6 +246,7 @@ def main():
         "cornell_area.xml": cornell(False, 256, 64, "antithetic", "0.5", area_light=True),
         "cornell_specular.xml": cornell_specular(),
         "cornell_plastic.xml": cornell_plastic(),
+        "cornell_rough.xml": cornell_rough(),
         "cornell_spheres.xml": cornell_spheres(),
         "cornell_sphere_light.xml": cornell_spheres(sphere_light=True),
         "domino.xml": domino(),
@@ -238,7 +260,7 @@ def main():
 
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
-    names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml",
+    names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml",
              "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):

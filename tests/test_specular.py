@@ -140,7 +140,7 @@ def test_plastic_loader_constants_and_limits(mi, orc, tmp_path):
     oracle's; int_ior = ext_ior degenerates to a plain diffuse BSDF in expectation."""
     path = os.path.join(SCENES, "cornell_plastic.xml")
     sc, osc = mi.load_file(path), orc.Scene(path, {})
-    rec = sc.export(9).reshape(-1, 22)
+    rec = sc.export(9).reshape(-1, 24)
     pl = [(i, s) for i, s in enumerate(osc.flat.shapes) if s["bsdf"] == 3]
     assert len(pl) == 3
     for i, s in pl:
@@ -190,4 +190,65 @@ def test_plastic_scenes_are_bit_exact_per_lane(mi, orc, tmp_path, name, params, 
     assert (g["rgb"] != 0).mean() > 0.3
     img = sc.render(seed=11, spp=spp)
     ref, _ = osc.render(pd, seed=11, spp=spp, threads=NCPU)
+    assert float(np.abs(img - ref).max() / np.abs(ref).max()) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ rough conductor (GGX)
+def test_roughconductor_limits_and_loader(mi, orc, tmp_path):
+    """RoughConductor with the GGX distribution (roughconductor.cpp, microfacet.h): (1) the loader record matches the oracle's;
+    (2) alpha -> 1e-4 converges to the smooth conductor (glossy lobe with NEE + MIS vs a delta lobe: different estimators, same
+    expectation); (3) a visibly rough wall stays finite and of the same order; (4) Beckmann is rejected with a reason."""
+    path = os.path.join(SCENES, "cornell_rough.xml")
+    sc, osc = mi.load_file(path), orc.Scene(path, {})
+    rec = sc.export(9).reshape(-1, 24)
+    rough = [(i, s) for i, s in enumerate(osc.flat.shapes) if s["bsdf"] == 4]
+    assert len(rough) == 3
+    for i, s in rough:
+        assert rec[i, 0] == 4 and rec[i, 1] == 1 and bits(rec[i, 22]) == bits(np.float32(s["alpha_u"])) and bits(rec[i, 23]) == bits(np.float32(s["alpha_v"]))
+        assert np.array_equal(bits(rec[i, 16:19]), bits(s["cond_eta"])) and np.array_equal(bits(rec[i, 19:22]), bits(s["cond_k"]))
+    assert any(rec[i, 22] != rec[i, 23] for i, _ in rough)             # the brushed floor is anisotropic
+    with pytest.raises(mi.DtofError, match="only distribution \"ggx\" is implemented"):
+        mi.load_string(open(path).read().replace('value="ggx"', 'value="beckmann"'))
+    with pytest.raises(mi.DtofError, match="invalid distribution"):
+        mi.load_string(open(path).read().replace('value="ggx"', 'value="phong"'))
+    with pytest.raises(mi.DtofError, match="both 'alpha_u' and 'alpha_v'"):
+        mi.load_string(open(path).read().replace('<float name="alpha_v" value="0.3" />', ""))
+
+    def render(bsdf_xml, name):
+        p = str(tmp_path / name)
+        open(p, "w").write(mirror_room(bsdf_xml))
+        s = orc.Scene(p, dict(resx=16, resy=16))
+        pd = s.params(integrator=dict(type="path", max_depth=5))
+        return np.mean([s.render(pd, seed=k, spp=256, threads=NCPU)[0] for k in range(2)], axis=0)
+    copper = '<rgb name="eta" value="0.2, 0.92, 1.1" /><rgb name="k" value="3.9, 2.45, 2.14" />'
+    smooth = render('\t<bsdf type="twosided" id="M"><bsdf type="conductor">%s</bsdf></bsdf>\n' % copper, "smooth.xml")
+    sharp = render('\t<bsdf type="twosided" id="M"><bsdf type="roughconductor"><string name="distribution" value="ggx" />'
+                   '<float name="alpha" value="0.00001" />%s</bsdf></bsdf>\n' % copper, "sharp.xml")
+    blurry = render('\t<bsdf type="twosided" id="M"><bsdf type="roughconductor"><string name="distribution" value="ggx" />'
+                    '<float name="alpha" value="0.3" />%s</bsdf></bsdf>\n' % copper, "blurry.xml")
+    assert abs(sharp.mean() - smooth.mean()) < 0.03 * smooth.mean(), (sharp.mean(), smooth.mean())
+    assert np.isfinite(blurry).all() and 0.5 * smooth.mean() < blurry.mean() < 2.0 * smooth.mean()   # a rough wall also scatters the lamp towards the camera
+
+
+ROUGH_CASES = [("rough_doppler", dict(resx=40, resy=40), 8, None), ("rough_path_depth6", dict(resx=32, resy=32), 8, dict(type="path", max_depth=6)),
+               ("rough_rr", dict(resx=24, resy=24), 8, dict(type="path", max_depth=-1, rr_depth=2))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,params,spp,integ", ROUGH_CASES, ids=[c[0] for c in ROUGH_CASES])
+def test_rough_conductor_scenes_are_bit_exact_per_lane(mi, orc, name, params, spp, integ):
+    path = os.path.join(SCENES, "cornell_rough.xml")
+    sc, osc = mi.load_file(path, **params), orc.Scene(path, params)
+    if integ:
+        sc.set_integrator(integ)
+    pd = osc.params(integrator=integ) if integ else osc.params()
+    w, h = sc.size
+    n = w * h * spp
+    g = sc.sample_lanes(13, spp, 0, n)
+    o = osc.render_lanes(pd, 13, spp, 0, n, threads=NCPU)
+    for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+        assert np.array_equal(bits(g[k]), bits(o[k])), (name, k, int((bits(g[k]) != bits(o[k])).sum()))
+    assert (g["rgb"] != 0).mean() > 0.3
+    img = sc.render(seed=13, spp=spp)
+    ref, _ = osc.render(pd, seed=13, spp=spp, threads=NCPU)
     assert float(np.abs(img - ref).max() / np.abs(ref).max()) <= 1e-5
