@@ -309,11 +309,11 @@ DTOF_D float next_time(const RenderParams &rp, Rng &main, Rng &tm, uint32_t si, 
     float r = strategy == TIME_STRATIFIED ? next_f32(main) : next_f32(tm);
     if (rp.stratify) {
         if (strategy == TIME_STRATIFIED) {
-            uint32_t ps = perm_seed + dim++;
-            uint32_t p1 = permute_kensler(si / tcn, rp.n_stratum, ps);
-            ps = perm_seed + dim++;
-            uint32_t p2 = permute_kensler(si / tcn, rp.n_stratum, ps);
-            uint32_t p = (si % tcn != 0) ? p1 : p2;
+            // the reference evaluates p1 (seed + dim) and p2 (seed + dim + 1) and selects; the permutation is a pure function,
+            // so only the selected one is computed
+            const uint32_t ps = perm_seed + dim + ((si % tcn != 0) ? 0u : 1u);
+            dim += 2;
+            const uint32_t p = permute_kensler(si / tcn, rp.n_stratum, ps);
             r = ((float) p + r) * rp.inv_n_stratum;
         } else {
             r = ((float) (si / tcn) + r) * rp.inv_n_stratum;
@@ -367,7 +367,10 @@ DTOF_D float modulation_weight(const RenderParams &rp, float phase, float ray_ti
 struct PrimaryLane { float4 ray_a, ray_b; Rng main, path; float2 pos; };
 DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane) {
     Rng main = seed_stream(rp.seed_value, lane);
-    Rng tm = seed_stream(rp.seed_value + 1, lane / rp.tcn);
+    // m_rng_time is only drawn from by the antithetic strategies of the correlated sampler (correlated.cpp:96-106)
+    const bool needs_tm = rp.integrator == 0 && rp.sampler_kind == SAMPLER_CORRELATED && (rp.time_sampling == TIME_ANTITHETIC || rp.time_sampling == TIME_ANTITHETIC_MIRROR);
+    Rng tm; tm.state = 0; tm.inc = 1;
+    if (needs_tm) tm = seed_stream(rp.seed_value + 1, lane / rp.tcn);
     Rng path = seed_stream(rp.seed_value + 2, lane / rp.pcn);
     uint32_t pix = rp.spp_log2 != 0xffffffffu ? lane >> rp.spp_log2 : lane / rp.spp;
     uint32_t si = rp.spp > 1 ? lane - pix * rp.spp : 0;
