@@ -99,14 +99,18 @@ def cpu_baseline(scene_path, res, spp, target_s, defines):
     reps = int(max(1, min(64, round(want / (rows * res * spp)))))
     r0 = max(0, mid - rows // 2)
     total = 0
+    band0 = None
     t0 = time.time()
     for seed in range(reps):                                  # whole-frame passes with seeds 0..reps-1, like the multi-pass harness
-        _, n = osc.render(pd, seed=seed, spp=spp, rows=(r0, r0 + rows), threads=cores, raw=True)
+        film_band, n = osc.render(pd, seed=seed, spp=spp, rows=(r0, r0 + rows), threads=cores, raw=True)
+        if seed == 0:
+            band0 = (film_band, r0, r0 + rows)               # kept for the parity figure of the bench line
         total += n
     dt = time.time() - t0
     t1 = time.time()                                              # the same code on ONE thread (report both)
     _, n1 = osc.render(pd, seed=0, spp=spp, rows=(mid, mid + max(1, min(8, int(2.0 * rate / cores / (res * spp)) or 1))), threads=1, raw=True)
     one = n1 / max(time.time() - t1, 1e-9) / 1e6
+    cpu_baseline.band0 = band0
     return {"value": round(total / dt / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port", "value_1_core": round(one, 4),
             "sample": "oracle/dtof_oracle.c (scalar C restatement of the same algorithm, pthreads over lanes): rows [%d,%d) of "
                       "the %dx%d %d-spp frame x %d seeds = %d paths in %.1f s" % (r0, r0 + rows, res, res, spp, reps, total, dt)}
@@ -276,6 +280,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.scene, args.res, args.spp, args.cpu_seconds, args.defines)
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / max(out["cpu_baseline"]["value"], 1e-9), 1)
+            if not args.offsets and getattr(cpu_baseline, "band0", None) is not None:
+                # parity of THIS frame: the rows of the oracle's seed-0 pass against the same rows of the film the timed steps
+                # left on the GPU (same seed, same spp); the band's first and last row miss the splats of their outer neighbours
+                # in the oracle's partial render and are left out.  SURVEY 8(d): per-pixel relative L-inf, target <= 1e-3.
+                band, b0, b1 = cpu_baseline.band0
+                gpu = film[halo:halo + H].cpu().numpy()
+                dev_img = lambda f: np.where(f[..., 3:4] != 0, f[..., :3] / np.where(f[..., 3:4] != 0, f[..., 3:4], 1), 0)
+                a, b = dev_img(gpu[b0 + 1:b1 - 1]), dev_img(band[b0 + 1:b1 - 1])
+                if a.size:
+                    out["parity"] = {"rel_linf_vs_oracle": float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)), "rows": [b0 + 1, b1 - 1],
+                                     "tolerance": 1e-3, "what": "developed image rows of the benchmark frame, GPU vs CPU oracle, same seed"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
