@@ -168,7 +168,8 @@ def test_modulation_functions_match_oracle(mi, orc):
             assert np.array_equal(bits(sc.eval_modulation(2, x)), bits(np.array([L.orc_waveform_low_pass(float(v), wt) for v in x], np.float32)))
 
 
-@pytest.mark.parametrize("case", ["spp1", "spp3_box", "crop", "depth1", "depth2", "unbounded_rr", "two_lights", "onesided", "tent_wide", "gaussian_default", "area_and_point", "area_path"])
+@pytest.mark.parametrize("case", ["spp1", "spp3_box", "crop", "depth1", "depth2", "unbounded_rr", "two_lights", "onesided", "tent_wide", "gaussian_default", "area_and_point", "area_path",
+                                  "depth0", "no_emitters", "no_shapes", "one_pixel", "odd_17x13x5"])
 def test_edge_cases_against_oracle(mi, orc, case):
     base = open(os.path.join(SCENES, "cornell_boxes.xml")).read()
     params, spp, xml = dict(resx=24, resy=24), 8, base
@@ -204,6 +205,17 @@ def test_edge_cases_against_oracle(mi, orc, case):
                 pass
     elif case == "tent_wide":
         xml = base.replace('<rfilter type="tent" />', '<rfilter type="tent"><float name="radius" value="2.0" /></rfilter>')
+    elif case == "depth0":            # max_depth = 0: the loop never runs (dopplertofpath.cpp:96-98)
+        params["max_depth"] = 0
+    elif case == "no_emitters":       # nothing to sample, nothing to hit: all-zero image, the sampler still draws
+        xml = base[:base.index("\t<emitter type=\"point\">")] + "</scene>\n"
+    elif case == "no_shapes":         # every primary ray misses
+        xml = base[:base.index('\t<shape type="rectangle" id="Floor">')] + base[base.index("\t<emitter type=\"point\">"):]
+        assert "<shape" not in xml
+    elif case == "one_pixel":
+        params = dict(resx=1, resy=1); spp = 16
+    elif case == "odd_17x13x5":       # lane counts that are no multiple of a wave, a segment or a pixel group
+        params = dict(resx=17, resy=13, time_sampling_method="uniform"); spp = 5
     sc = mi.load_string(xml, **params)
     osc = orc.Scene(xml, params, is_string=True)
     pd = osc.params()
@@ -215,14 +227,14 @@ def test_edge_cases_against_oracle(mi, orc, case):
         assert np.array_equal(bits(g[k]), bits(o[k])), (case, k)
     img = sc.render(seed=4, spp=spp)
     ref, _ = osc.render(pd, seed=4, spp=spp, threads=NCPU)
-    if case == "depth1":
+    if case in ("depth1", "depth0", "no_emitters", "no_shapes"):
         assert np.abs(img).max() == 0 and np.abs(ref).max() == 0
     else:
         assert rel_linf(img, ref) <= IMG_TOL
     # empty row range and spp=0 (use the sampler's count)
     import torch
     film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda"); torch.cuda.synchronize()
-    st = sc.render_rows(film.data_ptr(), 0, spp, 5, 5)
+    st = sc.render_rows(film.data_ptr(), 0, spp, min(5, h), min(5, h))
     assert st["n_paths"] == 0 and float(film.abs().sum()) == 0.0
 
 
