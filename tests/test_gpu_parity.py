@@ -448,3 +448,47 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_image(mi, tmp_path):
         ref = sc.render(seed=5, spp=spp)
         got = np.load(str(tmp_path / (name + ".npy")))
         assert got.shape == ref.shape and rel_linf(got, ref) <= IMG_TOL, (name, rel_linf(got, ref))
+
+
+def _random_config(rng):
+    waves = ["sinusoidal", "rectangular", "triangular", "trapezoidal"]
+    tsm = ["uniform", "stratified", "antithetic", "antithetic_mirror"]
+    tcn = int(rng.choice([1, 2, 4]))
+    spp = int(tcn * rng.choice([1, 2, 3, 4, 8]))
+    integ = dict(type="dopplertofpath", max_depth=int(rng.choice([-1, 1, 2, 3, 5, 7])), rr_depth=int(rng.choice([1, 2, 5])),
+                 wave_function_type=str(rng.choice(waves)), time_sampling_method=str(rng.choice(tsm)),
+                 antithetic_shift=float(rng.choice([0.0, 0.25, 0.5, 0.9])), hetero_frequency=float(rng.choice([0.0, 0.5, 1.0, 2.0])),
+                 hetero_offset=float(rng.choice([0.0, 0.125, 0.5])), path_correlation_depth=int(rng.choice([0, 1, 2, 16])),
+                 low_frequency_component_only=bool(rng.choice([True, True, False])), w_g=float(rng.choice([30.0, 150.0])),
+                 use_stratified_sampling_for_each_interval=bool(rng.choice([True, False])), time=float(rng.choice([0.0015, 0.003])))
+    sampler = dict(type="correlated", sample_count=spp, time_correlate_number=tcn, path_correlate_number=int(rng.choice([tcn, 1, 2 * tcn])),
+                   seed=int(rng.choice([0, 7])))
+    if spp % sampler["path_correlate_number"]:
+        sampler["path_correlate_number"] = tcn
+    scene = str(rng.choice(["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_spheres.xml", "cornell_specular.xml",
+                            "cornell_plastic.xml", "cornell_rough.xml", "domino_small.xml"]))
+    return scene, dict(resx=int(rng.choice([8, 13, 24])), resy=int(rng.choice([8, 11, 16]))), spp, integ, sampler
+
+
+@pytest.mark.parametrize("index", range(24))
+def test_random_parameter_combinations_are_bit_exact(mi, orc, index):
+    """24 seeded random draws from the plugin parameter space x scene set (all waveforms, time strategies, correlation numbers,
+    depths incl. unbounded, russian-roulette depths, full / low-pass modulation, every material and light type)."""
+    rng = np.random.RandomState(1000 + index)
+    scene, params, spp, integ, sampler = _random_config(rng)
+    path = os.path.join(SCENES, scene)
+    sc, osc = mi.load_file(path, **params), orc.Scene(path, params)
+    sc.set_integrator(integ)
+    sc.set_sampler(sampler)
+    pd = osc.params(integrator=integ, sampler=sampler)
+    w, h = sc.size
+    n = w * h * spp
+    seed = int(rng.randint(0, 100))
+    g = sc.sample_lanes(seed, spp, 0, n)
+    o = osc.render_lanes(pd, seed, spp, 0, n, threads=NCPU)
+    for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+        assert np.array_equal(bits(g[k]), bits(o[k])), (index, scene, integ, sampler, k, int((bits(g[k]) != bits(o[k])).sum()))
+    img = sc.render(seed=seed, spp=spp)
+    ref, _ = osc.render(pd, seed=seed, spp=spp, threads=NCPU)
+    scale = max(float(np.abs(o["rgb"]).max()), 1e-30)          # images of cancelling (static / antithetic) set-ups are ~0: scale by the lanes
+    assert float(np.abs(img - ref).max()) <= 1e-5 * scale * max(1.0, spp / 4)
