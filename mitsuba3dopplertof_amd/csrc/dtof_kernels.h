@@ -19,6 +19,7 @@ struct RenderParams {
     float scale_x, scale_y, offset_x, offset_y;   // render_sample: scale = 1/crop_size, offset = -crop_offset*scale
     int32_t filter; float filter_radius, inv_radius;
     float gauss_coeff[10];                        // GaussianFilter's Remez fit, scaled and shifted like gaussian.cpp:60-89
+    float filter_b, filter_c;       // mitchell: B, C (src/rfilters/mitchell.cpp)
     // ---- sampler (src/samplers/correlated.cpp, src/render/sampler.cpp)
     uint32_t base_seed, seed, seed_value;         // seed_value = base_seed + seed
     uint32_t spp, spp_log2;                       // spp_log2 = 0xffffffff when spp is not a power of two

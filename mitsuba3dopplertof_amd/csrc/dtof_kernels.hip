@@ -1131,7 +1131,23 @@ __global__ __launch_bounds__(kBlock) void k_velocity(const uint8_t *scene, uint3
 DTOF_D float tent(float x, float inv_r) { return fmax_(0.f, 1.f - fabsf(x * inv_r)); }
 // ReconstructionFilter::eval: tent (tent.cpp:53-55) or gaussian (gaussian.cpp:94-96, polynomial branch)
 DTOF_D float filter_weight(const RenderParams &rp, float x) {
-    return rp.filter == FILTER_GAUSSIAN ? fmax_(estrin10(sqr(x), rp.gauss_coeff), 0.f) : tent(x, rp.inv_radius);
+    if (rp.filter == FILTER_GAUSSIAN) return fmax_(estrin10(sqr(x), rp.gauss_coeff), 0.f);
+    if (rp.filter == FILTER_MITCHELL) {   // MitchellNetravaliFilter::eval (mitchell.cpp:47-67): coefficients in ScalarFloat, Horner with fmadd
+        x = fabsf(x);
+        const float x2 = x * x, x3 = x2 * x, B = rp.filter_b, C = rp.filter_c;
+        const float a3 = (12.f - 9.f * B - 6.f * C), a2 = (-18.f + 12.f * B + 6.f * C), a0 = (6.f - 2.f * B),
+                    b3 = (-B - 6.f * C), b2 = (6.f * B + 30.f * C), b1 = (-12.f * B - 48.f * C), b0 = (8.f * B + 24.f * C);
+        const float r = (1.f / 6.f) * (x < 1.f ? fmaf(a3, x3, fmaf(a2, x2, a0)) : fmaf(b3, x3, fmaf(b2, x2, fmaf(b1, x, b0))));
+        return x < 2.f ? r : 0.f;
+    }
+    if (rp.filter == FILTER_CATMULLROM) {   // CatmullRomFilter::eval (catmullrom.cpp:38-53): B = 0, C = 1/2, plain multiplies and adds
+        x = fabsf(x);
+        const float x2 = x * x, x3 = x2 * x, B = 0.f, C = .5f;
+        const float r = (1.f / 6.f) * (x < 1.f ? (12.f - 9.f * B - 6.f * C) * x3 + (-18.f + 12.f * B + 6.f * C) * x2 + (6.f - 2.f * B)
+                                               : (-B - 6.f * C) * x3 + (6.f * B + 30.f * C) * x2 + (-12.f * B - 48.f * C) * x + (8.f * B + 24.f * C));
+        return x < 2.f ? r : 0.f;
+    }
+    return tent(x, rp.inv_radius);
 }
 // v + (v moved by the DPP control); lanes without a valid source (or in rows masked off) add 0
 template <int CTRL, int ROW_MASK = 0xf>

@@ -172,6 +172,7 @@ RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, cons
     rp.scale_x = 1.f / (float) se.crop_w; rp.scale_y = 1.f / (float) se.crop_h;
     rp.offset_x = -(float) se.crop_x * rp.scale_x; rp.offset_y = -(float) se.crop_y * rp.scale_y;
     rp.filter = se.filter; rp.filter_radius = se.filter_radius; rp.inv_radius = 1.f / se.filter_radius;
+    rp.filter_b = se.filter_b; rp.filter_c = se.filter_c;
     if (se.filter == FILTER_GAUSSIAN) {   // GaussianFilter ctor (src/rfilters/gaussian.cpp:60-89), non-CUDA branch
         static const double coeff[10] = { 9.992604880e-1, -4.977025247e-1, 1.222248550e-1, -1.932406282e-2, 2.136713061e-3,
                                           -1.679873860e-4, 9.202145248e-6, -3.329417433e-7, 7.128382794e-9, -6.821193280e-11 };

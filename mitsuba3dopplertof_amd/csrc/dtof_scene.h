@@ -15,7 +15,7 @@ enum ObjectKind : uint32_t { OBJ_SHAPE = 0, OBJ_INSTANCE = 1 };
 enum WaveType : int32_t { WAVE_SIN = 0, WAVE_RECT = 1, WAVE_TRI = 2, WAVE_TRAP = 3 };
 // ETimeSampling -- include/mitsuba/render/sampler.h:27-34
 enum TimeSampling : int32_t { TIME_UNIFORM = 0, TIME_STRATIFIED = 1, TIME_ANTITHETIC = 2, TIME_ANTITHETIC_MIRROR = 3 };
-enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1, FILTER_GAUSSIAN = 2 };
+enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1, FILTER_GAUSSIAN = 2, FILTER_MITCHELL = 3, FILTER_CATMULLROM = 4 };
 enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4, SF_EMITTER = 8 };
 enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4 };
 enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1 };
@@ -103,7 +103,7 @@ struct HostSensor {
     float to_world[16];
     float x_fov = 0, near_clip = 1e-2f, far_clip = 1e4f, shutter_open = 0, shutter_close = 0;
     int32_t film_w = 768, film_h = 576, crop_x = 0, crop_y = 0, crop_w = 768, crop_h = 576;
-    int32_t filter = FILTER_TENT; float filter_radius = 1.f, filter_stddev = .5f;
+    int32_t filter = FILTER_TENT; float filter_radius = 1.f, filter_stddev = .5f, filter_b = 1.f / 3.f, filter_c = 1.f / 3.f;   // B, C: mitchell
 };
 
 // A typed property bag (what the reference's Properties carries for a plugin).

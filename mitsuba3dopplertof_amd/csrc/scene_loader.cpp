@@ -692,7 +692,12 @@ static void make_sensor(const Obj &o, HostScene &sc) {
             else if (rf.plugin == "gaussian") {   // src/rfilters/gaussian.cpp:48-53: cut off after 4 standard deviations
                 se.filter = FILTER_GAUSSIAN; se.filter_stddev = (float) rf.props.get_float("stddev", .5f); se.filter_radius = 4 * se.filter_stddev;
             }
-            else fail("unsupported rfilter plugin \"" + rf.plugin + "\" (supported: tent, box, gaussian)");
+            else if (rf.plugin == "mitchell") {   // src/rfilters/mitchell.cpp:38-45
+                se.filter = FILTER_MITCHELL; se.filter_radius = 2.f;
+                se.filter_b = (float) rf.props.get_float("B", 1.f / 3.f); se.filter_c = (float) rf.props.get_float("C", 1.f / 3.f);
+            }
+            else if (rf.plugin == "catmullrom") { se.filter = FILTER_CATMULLROM; se.filter_radius = 2.f; }   // src/rfilters/catmullrom.cpp:33-36
+            else fail("unsupported rfilter plugin \"" + rf.plugin + "\" (supported: tent, box, gaussian, mitchell, catmullrom)");
             have_filter = true;
         }
         auto u = film->props.unqueried();

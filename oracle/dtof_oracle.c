@@ -1211,6 +1211,31 @@ static void gaussian_coeffs(float stddev, float radius, float *out) {
     for (int i = 0; i < 10; ++i) { out[i] = (float) (coeff[i] * scale); scale /= (double) stddev * (double) stddev; }
     out[0] -= estrin10(radius * radius, out);
 }
+/* MitchellNetravaliFilter::eval (src/rfilters/mitchell.cpp:47-67; coefficients in ScalarFloat, Horner with fmadd) and
+ * CatmullRomFilter::eval (src/rfilters/catmullrom.cpp:38-53; B = 0, C = 1/2 as float32 arrays, plain multiplies and adds) */
+static float mitchell_eval(float x, float B, float C) {
+    x = fabsf(x);
+    float x2 = x * x, x3 = x2 * x;
+    float a3 = (12.f - 9.f * B - 6.f * C), a2 = (-18.f + 12.f * B + 6.f * C), a0 = (6.f - 2.f * B),
+          b3 = (-B - 6.f * C), b2 = (6.f * B + 30.f * C), b1 = (-12.f * B - 48.f * C), b0 = (8.f * B + 24.f * C);
+    float r = (1.f / 6.f) * (x < 1.f ? fmaf(a3, x3, fmaf(a2, x2, a0)) : fmaf(b3, x3, fmaf(b2, x2, fmaf(b1, x, b0))));
+    return x < 2.f ? r : 0.f;
+}
+static float catmullrom_eval(float x) {
+    x = fabsf(x);
+    float x2 = x * x, x3 = x2 * x, B = 0.f, C = .5f;
+    float r = (1.f / 6.f) * (x < 1.f ? (12.f - 9.f * B - 6.f * C) * x3 + (-18.f + 12.f * B + 6.f * C) * x2 + (6.f - 2.f * B)
+                                     : (-B - 6.f * C) * x3 + (6.f * B + 30.f * C) * x2 + (-12.f * B - 48.f * C) * x + (8.f * B + 24.f * C));
+    return x < 2.f ? r : 0.f;
+}
+static float filter_eval(const orc_sensor *se, float x, float inv_r, const float *gc) {
+    switch (se->filter) {
+        case ORC_FILTER_GAUSSIAN:   return f_max(estrin10(x * x, gc), 0.f);
+        case ORC_FILTER_MITCHELL:   return mitchell_eval(x, se->filter_b, se->filter_c);
+        case ORC_FILTER_CATMULLROM: return catmullrom_eval(x);
+        default:                    return f_max(0.f, 1.f - fabsf(x * inv_r));
+    }
+}
 static void splat(const orc_sensor *se, float *film, float spx, float spy, int pixel_x, int pixel_y, const float *rgb) {
     int W = se->crop_w, H = se->crop_h;
     float vals[4] = { rgb[0], rgb[1], rgb[2], 1.f };
@@ -1231,10 +1256,10 @@ static void splat(const orc_sensor *se, float *film, float spx, float spy, int p
     int lx = pix - se->crop_x, ly = piy - se->crop_y;
     for (int ys = 0; ys < count; ++ys) {
         float ry = rely + (float) ys;
-        float wy = gauss ? f_max(estrin10(ry * ry, gc), 0.f) : f_max(0.f, 1.f - fabsf(ry * inv_r));
+        float wy = filter_eval(se, ry, inv_r, gc);
         for (int xs = 0; xs < count; ++xs) {
             float rx = relx + (float) xs;
-            float wx = gauss ? f_max(estrin10(rx * rx, gc), 0.f) : f_max(0.f, 1.f - fabsf(rx * inv_r));
+            float wx = filter_eval(se, rx, inv_r, gc);
             float w = wx * wy;
             int x = lx + xs, y = ly + ys;
             if ((unsigned) x < (unsigned) W && (unsigned) y < (unsigned) H)

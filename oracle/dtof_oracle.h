@@ -30,7 +30,7 @@ enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 
 enum { ORC_TIME_UNIFORM = 0, ORC_TIME_STRATIFIED = 1, ORC_TIME_ANTITHETIC = 2,
        ORC_TIME_ANTITHETIC_MIRROR = 3 };
 enum { ORC_BSDF_DIFFUSE = 0, ORC_BSDF_CONDUCTOR = 1, ORC_BSDF_DIELECTRIC = 2, ORC_BSDF_PLASTIC = 3, ORC_BSDF_ROUGHCONDUCTOR = 4 };
-enum { ORC_FILTER_BOX = 0, ORC_FILTER_TENT = 1, ORC_FILTER_GAUSSIAN = 2 };
+enum { ORC_FILTER_BOX = 0, ORC_FILTER_TENT = 1, ORC_FILTER_GAUSSIAN = 2, ORC_FILTER_MITCHELL = 3, ORC_FILTER_CATMULLROM = 4 };
 
 /* All 4x4 matrices are row-major float32: m[4*r + c]. */
 
@@ -103,6 +103,7 @@ typedef struct {
     int32_t filter;          /* ORC_FILTER_* */
     float   filter_radius;
     float   filter_stddev;   /* gaussian only (radius = 4 stddev, src/rfilters/gaussian.cpp:48-53) */
+    float   filter_b, filter_c;   /* mitchell only: the B and C of the paper (src/rfilters/mitchell.cpp:38-45), radius 2 */
 } orc_sensor;
 
 typedef struct {

@@ -50,7 +50,8 @@ class OrcSensor(C.Structure):
                 ("shutter_open", C.c_float), ("shutter_close", C.c_float),
                 ("film_w", C.c_int32), ("film_h", C.c_int32),
                 ("crop_x", C.c_int32), ("crop_y", C.c_int32), ("crop_w", C.c_int32), ("crop_h", C.c_int32),
-                ("filter", C.c_int32), ("filter_radius", C.c_float), ("filter_stddev", C.c_float)]
+                ("filter", C.c_int32), ("filter_radius", C.c_float), ("filter_stddev", C.c_float),
+                ("filter_b", C.c_float), ("filter_c", C.c_float)]
 
 
 class OrcParams(C.Structure):
@@ -259,7 +260,7 @@ class Scene:
         sc.emitters, sc.n_emitters = emitters, len(fs.emitters)
         se = fs.sensor
         sc.sensor.to_world = _m16(se["to_world"])
-        for k in ("x_fov", "near_clip", "far_clip", "shutter_open", "shutter_close", "filter_radius", "filter_stddev"):
+        for k in ("x_fov", "near_clip", "far_clip", "shutter_open", "shutter_close", "filter_radius", "filter_stddev", "filter_b", "filter_c"):
             setattr(sc.sensor, k, float(se[k]))
         for k in ("film_w", "film_h", "crop_x", "crop_y", "crop_w", "crop_h", "filter"):
             setattr(sc.sensor, k, int(se[k]))

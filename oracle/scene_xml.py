@@ -582,6 +582,7 @@ def _sensor_record(sp):
     film = next((c[1] for c in sp.children if c[0] == "film"), None)
     w, h, cx, cy = 768, 576, 0, 0
     filt, radius, stddev = None, 0.0, 0.5
+    fb = fc = 1.0 / 3.0
     if film is not None:
         w, h = film.get_i("width", 768), film.get_i("height", 576)
         cw, ch = film.get_i("crop_width", w), film.get_i("crop_height", h)
@@ -595,6 +596,11 @@ def _sensor_record(sp):
             elif rf.plugin == "gaussian":   # gaussian.cpp:48-53
                 stddev = rf.get_f("stddev", 0.5)
                 filt, radius = 2, float(F32(4) * F32(stddev))
+            elif rf.plugin == "mitchell":   # mitchell.cpp:38-45
+                filt, radius = 3, 2.0
+                fb, fc = float(F32(rf.get_f("B", float(F32(1.0) / F32(3.0))))), float(F32(rf.get_f("C", float(F32(1.0) / F32(3.0)))))
+            elif rf.plugin == "catmullrom":  # catmullrom.cpp:33-36
+                filt, radius = 4, 2.0
             else:
                 raise ValueError('unsupported rfilter plugin "%s"' % rf.plugin)
     else:
@@ -607,7 +613,7 @@ def _sensor_record(sp):
     near, far = sp.get_f("near_clip", 1e-2), sp.get_f("far_clip", 1e4)
     return dict(to_world=_m32(tw), x_fov=F32(_parse_fov(sp, w / float(h))), near_clip=F32(near), far_clip=F32(far),
                 shutter_open=F32(so), shutter_close=F32(sc), film_w=w, film_h=h, crop_x=cx, crop_y=cy,
-                crop_w=cw, crop_h=ch, filter=filt, filter_radius=F32(radius), filter_stddev=F32(stddev))
+                crop_w=cw, crop_h=ch, filter=filt, filter_radius=F32(radius), filter_stddev=F32(stddev), filter_b=F32(fb), filter_c=F32(fc))
 
 
 # ----------------------------------------------------------------------------- plugin parameters

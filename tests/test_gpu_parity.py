@@ -169,7 +169,7 @@ def test_modulation_functions_match_oracle(mi, orc):
 
 
 @pytest.mark.parametrize("case", ["spp1", "spp3_box", "crop", "depth1", "depth2", "unbounded_rr", "two_lights", "onesided", "tent_wide", "gaussian_default", "area_and_point", "area_path",
-                                  "depth0", "no_emitters", "no_shapes", "one_pixel", "odd_17x13x5"])
+                                  "depth0", "no_emitters", "no_shapes", "one_pixel", "odd_17x13x5", "mitchell", "mitchell_bc", "catmullrom"])
 def test_edge_cases_against_oracle(mi, orc, case):
     base = open(os.path.join(SCENES, "cornell_boxes.xml")).read()
     params, spp, xml = dict(resx=24, resy=24), 8, base
@@ -205,6 +205,12 @@ def test_edge_cases_against_oracle(mi, orc, case):
                 pass
     elif case == "tent_wide":
         xml = base.replace('<rfilter type="tent" />', '<rfilter type="tent"><float name="radius" value="2.0" /></rfilter>')
+    elif case == "mitchell":          # src/rfilters/mitchell.cpp: radius 2, negative lobes
+        xml = base.replace('<rfilter type="tent" />', '<rfilter type="mitchell" />')
+    elif case == "mitchell_bc":
+        xml = base.replace('<rfilter type="tent" />', '<rfilter type="mitchell"><float name="B" value="0.2" /><float name="C" value="0.7" /></rfilter>')
+    elif case == "catmullrom":
+        xml = base.replace('<rfilter type="tent" />', '<rfilter type="catmullrom" />')
     elif case == "depth0":            # max_depth = 0: the loop never runs (dopplertofpath.cpp:96-98)
         params["max_depth"] = 0
     elif case == "no_emitters":       # nothing to sample, nothing to hit: all-zero image, the sampler still draws

@@ -248,3 +248,23 @@ def test_independent_and_timestratified_samplers(orc):
     assert 0.4 < u.mean() < 0.6 and u.min() >= 0 and u.max() < 1
     for lanes in (ind, ts, nj):
         assert np.isfinite(lanes["rgb"]).all() and (lanes["rgb"] != 0).any()
+
+
+@pytest.mark.parametrize("rfilter,exact", [('<rfilter type="tent" />', True), ('<rfilter type="mitchell" />', True),
+                                           ('<rfilter type="catmullrom" />', True), ('<rfilter type="mitchell"><float name="B" value="0.2" /><float name="C" value="0.7" /></rfilter>', True),
+                                           ("", False)])
+def test_reconstruction_filters_are_partitions_of_unity(orc, rfilter, exact):
+    """tent, Mitchell-Netravali (any B, C) and Catmull-Rom satisfy sum_k f(x + k) = 1, so the weight channel of a sample whose
+    footprint lies inside the film sums to exactly one sample (src/rfilters/{tent,mitchell,catmullrom}.cpp); the default
+    gaussian (stddev 0.5, cut at 4 sigma) only approximately."""
+    text = open(os.path.join(SCENES, "cornell_wall.xml")).read().replace('<rfilter type="tent" />', rfilter)
+    sc = orc.Scene(text, dict(resx=16, resy=16), is_string=True)
+    film, n = sc.render(sc.params(), seed=0, spp=8, raw=True)
+    # every sample of the 12 x 12 interior pixels spreads its unit weight inside the film: total = samples of ... not separable per
+    # pixel, so compare the grand total over the film with the count of samples whose footprint (radius <= 2) cannot leave it
+    total, inner = film[..., 3].sum(), film[3:-3, 3:-3, 3].sum()
+    assert total <= n * (1 + (1e-5 if exact else 1.0))      # the unnormalised gaussian integrates to ~1.57 per sample
+    if exact:
+        # weights of samples in pixel rows/cols 3..12 land within rows/cols 1..14 and sum to 1 each: the mass that reaches the
+        # 10 x 10 centre from outside equals the mass that leaves it, up to the random sample positions -> within 2 %
+        assert abs(inner / (10 * 10 * 8) - 1.0) < 0.02
