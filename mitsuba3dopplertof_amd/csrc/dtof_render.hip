@@ -282,8 +282,10 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     for (auto &sh : sc->host.shapes) has_spheres |= sh.kind == SHAPE_SPHERE;
     rp.has_tris = bh->n_tris != 0 || has_spheres;   // anything but rectangles: the instantiations with triangle / sphere code
     StageTimer tm(stats != nullptr, sc);
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
-    HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct EventGuard { hipEvent_t e = nullptr; ~EventGuard() { if (e) (void) hipEventDestroy(e); } } g_fork, g_join;   // released on every exit path
+    if (n_streams == 2) { HIP_CHECK(hipEventCreateWithFlags(&g_fork.e, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&g_join.e, hipEventDisableTiming)); }
+    hipEvent_t ev_fork = g_fork.e, ev_join = g_join.e;
     if (stats) { memset(stats, 0, sizeof *stats); ev0 = sc->take_event(); ev1 = sc->take_event(); HIP_CHECK(hipEventRecord(ev0, ss[0])); }
     if (n_streams == 2) { HIP_CHECK(hipEventRecord(ev_fork, ss[0])); HIP_CHECK(hipStreamWaitEvent(ss[1], ev_fork, 0)); }
     std::vector<uint64_t> h_counts; std::vector<uint32_t> batch_lanes, batch_iters;
@@ -371,7 +373,6 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     } else {
         HIP_CHECK(hipStreamSynchronize(s));
     }
-    (void) hipEventDestroy(ev_fork); (void) hipEventDestroy(ev_join);
     if (sc->stop.load()) throw std::runtime_error("cancelled");
 }
 
