@@ -15,14 +15,13 @@ Mirrors doppler_tutorials/src/main_experiment.py:21-139 and program_runner.py:82
 `--spp`, `--reference_spp`, `--grid N` shrink the run (the defaults are the paper's: 1024 / 131072 spp, N = 11).
 """
 import argparse
-import itertools
 import os
 
 import numpy as np
 
 from . import load_file, to_tof_image
-from .harness import (calc_velocity_from_homo_hetero, calc_velocity_from_homo_heteros, run_scene_doppler_tof, run_scene_radiance,
-                      run_scene_velocity)
+from .harness import (calc_velocity_from_homo_hetero, calc_velocity_from_homo_heteros, run_scene_doppler_tof, run_scene_doppler_tof_offsets,
+                      run_scene_radiance, run_scene_velocity)
 from .io import save_hdr_image, save_speed_image, save_tof_image
 
 # doppler_tutorials/src/utils/common_configs.py:32-65
@@ -66,20 +65,28 @@ def run_experiment(scene, scene_name, expnumber, basedir, wave_function_type="si
     freqs = np.linspace(0.0, 1.0, grid)
     offsets = np.linspace(0.0, 0.5, 6) if part == 1 else np.linspace(0.6, 1.0, 5) if part == 2 else np.linspace(0.0, 1.0, grid)
     written = []
-    for f, o in itertools.product(freqs, offsets):
+    # The reference loops over (frequency, offset) and renders every file on its own.  The files are the same here, but all
+    # pending offsets of one (frequency, setting) row share their traversals, four offsets at a time (harness.py).
+    for f in freqs:
         for family, expname, spp_key, kw in experiment_settings(expnumber, grid):
-            out_dir = os.path.join(basedir, "results", family, scene_name, wave_function_type, "freq_%.3f_offset_%.3f" % (f, o))
-            out_file = os.path.join(out_dir, "%s.npy" % expname)
-            if os.path.exists(out_file) and expnumber != 0:          # exit_if_file_exists (False for the reference image)
-                log("File already exists!")
+            pending = []
+            for o in offsets:
+                out_dir = os.path.join(basedir, "results", family, scene_name, wave_function_type, "freq_%.3f_offset_%.3f" % (f, o))
+                out_file = os.path.join(out_dir, "%s.npy" % expname)
+                if os.path.exists(out_file) and expnumber != 0:      # exit_if_file_exists (False for the reference image)
+                    log("File already exists!")
+                    continue
+                os.makedirs(out_dir, exist_ok=True)
+                pending.append((float(o), out_dir, out_file))
+            if not pending:
                 continue
-            os.makedirs(out_dir, exist_ok=True)
-            img = run_scene_doppler_tof(scene, total_spp=cfg[spp_key], output_file=out_file, wave_function_type=wave_function_type,
-                                        low_frequency_component_only=low_frequency_component_only, hetero_frequency=float(f),
-                                        hetero_offset=float(o), max_depth=cfg["max_depth"], **kw)
-            if export_png:
-                save_tof_image(to_tof_image(img), os.path.join(out_dir, "%s.png" % expname))
-            written.append(out_file)
+            images = run_scene_doppler_tof_offsets(scene, [p[0] for p in pending], total_spp=cfg[spp_key], output_files=[p[2] for p in pending],
+                                                   wave_function_type=wave_function_type, low_frequency_component_only=low_frequency_component_only,
+                                                   hetero_frequency=float(f), max_depth=cfg["max_depth"], **kw)
+            for (o, out_dir, out_file), img in zip(pending, images):
+                if export_png:
+                    save_tof_image(to_tof_image(img), os.path.join(out_dir, "%s.png" % expname))
+                written.append(out_file)
     return written
 
 
