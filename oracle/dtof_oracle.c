@@ -1274,22 +1274,68 @@ void orc_develop(const float *film, float *out, int64_t n) {
         out[3 * i] = film[4 * i] / w; out[3 * i + 1] = film[4 * i + 1] / w; out[3 * i + 2] = film[4 * i + 2] / w;
     }
 }
+/* Splatting is parallel too: the rows of a chunk are cut into one band per thread, every thread splats the lanes of its
+ * band (in lane order) into a private film of band + 2 * border rows, and the bands are added to the film in band order.
+ * With one thread this is the plain sequential accumulation in lane order; with more, only the order of the float additions
+ * across band borders differs (the reference's atomic scatter order is unspecified anyway). */
+typedef struct { const orc_sensor *se; const orc_lane *lanes; uint64_t lane0, n; uint32_t spp; int W, H, row0, rows, border; float *band; } splat_job;
+static void *splat_worker(void *arg) {
+    splat_job *j = (splat_job *) arg;
+    orc_sensor se = *j->se;                 /* a sensor whose film is the band: crop origin moved, height = band + borders */
+    const int band_h = j->rows + 2 * j->border;
+    se.crop_y = j->se->crop_y + j->row0 - j->border; se.crop_h = band_h;
+    for (uint64_t i = 0; i < j->n; ++i) {
+        uint64_t pix = (j->lane0 + i) / j->spp;
+        int px = (int) (pix % (uint64_t) j->W), py = (int) (pix / (uint64_t) j->W) - (j->row0 - j->border);
+        splat(&se, j->band, j->lanes[i].sample_pos[0], j->lanes[i].sample_pos[1], px, py, j->lanes[i].rgb);
+    }
+    return NULL;
+}
 uint64_t orc_render(const orc_scene *sc, const orc_params *p, uint32_t seed, uint32_t spp,
                     int32_t row_begin, int32_t row_end, float *film, float *out_rgb, int nt) {
     orc_ctx cx; make_ctx(&cx, sc, p, seed, spp);
     int W = sc->sensor.crop_w, H = sc->sensor.crop_h;
     if (row_begin < 0) row_begin = 0;
     if (row_end > H) row_end = H;
+    if (nt < 1) nt = 1;
+    if (nt > 256) nt = 256;
     uint64_t lanes_per_row = (uint64_t) W * spp, total = 0;
-    int chunk_rows = (int) (4000000ull / lanes_per_row); if (chunk_rows < 1) chunk_rows = 1;
+    int chunk_rows = (int) (8000000ull / lanes_per_row); if (chunk_rows < 1) chunk_rows = 1;
+    const int border = sc->sensor.filter == ORC_FILTER_BOX ? 0 : (int) ceilf(sc->sensor.filter_radius - .5f);
     orc_lane *buf = (orc_lane *) malloc(sizeof(orc_lane) * lanes_per_row * (size_t) chunk_rows);
     for (int r = row_begin; r < row_end; r += chunk_rows) {
         int re = r + chunk_rows < row_end ? r + chunk_rows : row_end;
         uint64_t n = lanes_per_row * (uint64_t) (re - r);
         run_lanes(&cx, lanes_per_row * (uint64_t) r, n, buf, nt);
-        for (uint64_t i = 0; i < n; ++i) {
-            uint64_t pix = (lanes_per_row * (uint64_t) r + i) / spp;
-            splat(&sc->sensor, film, buf[i].sample_pos[0], buf[i].sample_pos[1], (int) (pix % (uint64_t) W), (int) (pix / (uint64_t) W), buf[i].rgb);
+        int bands = nt < re - r ? nt : re - r;
+        if (bands == 1) {                       /* one thread: straight into the film, lane order */
+            for (uint64_t i = 0; i < n; ++i) {
+                uint64_t pix = (lanes_per_row * (uint64_t) r + i) / spp;
+                splat(&sc->sensor, film, buf[i].sample_pos[0], buf[i].sample_pos[1], (int) (pix % (uint64_t) W), (int) (pix / (uint64_t) W), buf[i].rgb);
+            }
+            total += n;
+            continue;
+        }
+        splat_job jobs[256]; pthread_t th[256];
+        for (int b = 0; b < bands; ++b) {
+            int b0 = r + (int) ((int64_t) (re - r) * b / bands), b1 = r + (int) ((int64_t) (re - r) * (b + 1) / bands);
+            splat_job *j = &jobs[b];
+            j->se = &sc->sensor; j->spp = spp; j->W = W; j->H = H; j->row0 = b0; j->rows = b1 - b0; j->border = border;
+            j->lane0 = lanes_per_row * (uint64_t) b0; j->n = lanes_per_row * (uint64_t) (b1 - b0);
+            j->lanes = buf + (j->lane0 - lanes_per_row * (uint64_t) r);
+            j->band = (float *) calloc((size_t) (j->rows + 2 * border) * W * 4 + 4, sizeof(float));
+            pthread_create(&th[b], NULL, splat_worker, j);
+        }
+        for (int b = 0; b < bands; ++b) {
+            splat_job *j = &jobs[b];
+            pthread_join(th[b], NULL);
+            for (int y = 0; y < j->rows + 2 * border; ++y) {
+                int fy = j->row0 - border + y;
+                if (fy < 0 || fy >= H) continue;
+                float *dst = film + (size_t) fy * W * 4; const float *src = j->band + (size_t) y * W * 4;
+                for (int x = 0; x < W * 4; ++x) dst[x] += src[x];
+            }
+            free(j->band);
         }
         total += n;
     }

@@ -163,8 +163,10 @@ def test_oracle_reproduces_golden_vectors(orc, configs):
         for key, field in (("lane_rgb", "rgb"), ("lane_pos", "sample_pos"), ("lane_time", "time"), ("lane_ray_d", "ray_d")):
             assert np.array_equal(g[key].view(np.uint32), np.ascontiguousarray(lanes[field]).view(np.uint32)), (name, key)
         if name in ("c1_boxes_antithetic", "boxes_trap_depth6_spp6"):
-            img, _ = sc.render(pd, seed=3, spp=spp, threads=os.cpu_count())
+            img, _ = sc.render(pd, seed=3, spp=spp, threads=1)         # one thread splats in lane order: bit-exact
             assert np.array_equal(img, g["image"]), name
+            par, _ = sc.render(pd, seed=3, spp=spp, threads=os.cpu_count())   # row bands per thread: float addition order only
+            assert np.abs(par - g["image"]).max() <= 1e-5 * np.abs(g["image"]).max(), name
 
 
 def test_velocity_and_path_integrators_physical_sanity(orc):
