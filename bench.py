@@ -84,10 +84,28 @@ def parse():
     return args
 
 
+def usable_cores():
+    """CPUs this process may actually run on: the affinity mask, capped by the cgroup CPU quota (the GPU boxes report 256
+    logical CPUs but run a job under a 16-CPU quota, and 256 runnable threads under that quota are slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(scene_path, res, spp, target_s, defines):
-    """Oracle (CPU port of the same algorithm) on all host cores, on a bounded band of rows of the same workload."""
+    """Oracle (CPU port of the same algorithm) on all the host cores this job may use, on a bounded band of rows of the same workload."""
     from oracle import orc
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     osc = orc.Scene(scene_path, dict(defines, resx=res, resy=res))
     pd = osc.params()
     mid = res // 2
