@@ -589,7 +589,7 @@ DTOF_D void mesh_sample_position(const SceneView &sv, const DShape &es, float s_
     n = normalize(n);
     if (es.flags & SF_FLIP_NORMALS) n = -n;
 }
-DTOF_D float safe_sqrt(float x) { return sqrtf(fmax_(x, 0.f)); }
+
 constexpr float kInvTwoPi = 0.15915494309189533577f;
 DTOF_D float uniform_cone_pdf(float cos_cutoff) { return kInvTwoPi / (1.f - cos_cutoff); }   // warp::square_to_uniform_cone_pdf (warp.h:475-485)
 // Sphere::sample_direction (sphere.cpp:222-296): cone sampling of the visible cap from outside, uniform sphere from inside
@@ -632,6 +632,28 @@ DTOF_D float sphere_pdf_direction(const DShape &sh, V3 ref, V3 ds_d, V3 ds_n, fl
     const float sin_alpha = sh.dp_du[0] * rcp(norm(center - ref)), cos_alpha = safe_sqrt(1.f - sin_alpha * sin_alpha);
     return sin_alpha < 0.99999994f ? uniform_cone_pdf(cos_alpha) : sh.inv_area * sqr(ds_dist) / fabsf(dot(ds_d, ds_n));
 }
+// RoughPlastic::lerp_gather (roughplastic.cpp:373-383) on the 64-entry transmittance table
+DTOF_D float lerp_gather64(const float *data, float x) {
+    x *= 63.f;
+    uint32_t index = (uint32_t) x; if (index > 62u) index = 62u;
+    const float v0 = data[index], v1 = data[index + 1], t = x - (float) index;
+    return fmaf(v1, t, fmaf(-v0, t, v0));                        // dr::lerp(v0, v1, t)
+}
+// RoughPlastic::eval (:333-371) and pdf (:385-421) for wi.z > 0 and wo.z > 0
+DTOF_D void rough_plastic_eval_pdf(Ggx g, const DShape *sh, const float *table, V3 diff, V3 wi, V3 wo, float t_i, float prob_specular,
+                                   float prob_diffuse, V3 &value, float &pdf) {
+    const V3 H = normalize(wo + wi);
+    const float D = ggx_eval(g, H);
+    float F, t1, t2, t3; fresnel_dielectric(dot(wi, H), sh->diel_eta, F, t1, t2, t3);
+    const float G = ggx_smith_g1(g, wi, H) * ggx_smith_g1(g, wo, H);
+    const float spec = F * D * G / (4.f * wi.z);
+    const float t_o = lerp_gather64(table, wo.z);
+    const float k = kInvPi * sh->inv_eta_2 * wo.z * t_i * t_o;
+    value = mk(spec * sh->spec_refl[0] + diff.x * k, spec * sh->spec_refl[1] + diff.y * k, spec * sh->spec_refl[2] + diff.z * k);
+    float result = D * ggx_smith_g1(g, wi, H) / (4.f * wi.z);
+    result *= prob_specular;
+    pdf = result + prob_diffuse * (kInvPi * wo.z);
+}
 // fresnel_conductor -- include/mitsuba/render/fresnel.h:93-117 (one colour channel)
 DTOF_D float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
     const float cos_theta_i_2 = cos_theta_i * cos_theta_i, sin_theta_i_2 = 1.f - cos_theta_i_2, sin_theta_i_4 = sin_theta_i_2 * sin_theta_i_2;
@@ -643,60 +665,6 @@ DTOF_D float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
     const float term_3 = a_2_pb_2 * cos_theta_i_2 + sin_theta_i_4, term_4 = term_2 * sin_theta_i_2;
     const float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
     return 0.5f * (r_s + r_p);
-}
-// ---- MicrofacetDistribution, GGX, sample_visible = true (include/mitsuba/render/microfacet.h)
-struct Ggx { float au, av; };
-DTOF_D Ggx ggx_make(float au, float av) { Ggx g; g.au = fmax_(au, 1e-4f); g.av = fmax_(av, 1e-4f); return g; }   // configure() :425-428
-DTOF_D float ggx_eval(Ggx g, V3 m) {   // eval() :176-196
-    const float result = rcp(kPi * (g.au * g.av) * sqr(sqr(m.x / g.au) + sqr(m.y / g.av) + sqr(m.z)));
-    return result * m.z > 1e-20f ? result : 0.f;
-}
-DTOF_D float ggx_smith_g1(Ggx g, V3 v, V3 m) {   // smith_g1() :341-365
-    const float xy_alpha_2 = sqr(g.au * v.x) + sqr(g.av * v.y), tan_theta_alpha_2 = xy_alpha_2 / sqr(v.z);
-    float result = 2.f / (1.f + sqrtf(1.f + tan_theta_alpha_2));
-    if (xy_alpha_2 == 0.f) result = 1.f;
-    if (dot(v, m) * v.z <= 0.f) result = 0.f;
-    return result;
-}
-// sample(), visible-normal branch :296-325 + sample_visible_11, GGX branch :405-420: microfacet normal and its density
-DTOF_D V3 ggx_sample(Ggx g, V3 wi, float s_x, float s_y, float &pdf) {
-    const V3 wi_p = normalize(mk(g.au * wi.x, g.av * wi.y, wi.z));
-    const float sin_theta_2 = fmaf(wi_p.x, wi_p.x, sqr(wi_p.y)), inv_sin_theta = rsqrt_(sin_theta_2);   // Frame3f::sincos_phi (frame.h:111-122)
-    float rx = fmin_(fmax_(wi_p.x * inv_sin_theta, -1.f), 1.f), ry = fmin_(fmax_(wi_p.y * inv_sin_theta, -1.f), 1.f);
-    if (fabsf(sin_theta_2) <= 4.f * 5.9604644775390625e-8f) { rx = 1.f; ry = 0.f; }
-    const float sin_phi = ry, cos_phi = rx, cos_theta = wi_p.z;
-    const float x = fmaf(2.f, s_x, -1.f), y = fmaf(2.f, s_y, -1.f);   // square_to_uniform_disk_concentric (warp.h:54-90)
-    const bool is_zero = x == 0.f && y == 0.f, q13 = fabsf(x) < fabsf(y);
-    const float r = q13 ? y : x, rp = q13 ? x : y;
-    float phi = 0.25f * kPi * rp / r;
-    if (q13) phi = 0.5f * kPi - phi;
-    if (is_zero) phi = 0.f;
-    float sn, cs; sincos_(phi, sn, cs);
-    const float px = r * cs; float py = r * sn;
-    const float s = 0.5f * (1.f + cos_theta), a = safe_sqrt(1.f - sqr(px));
-    py = fmaf(py, s, fmaf(-a, s, a));                              // dr::lerp(a, py, s)
-    const float pz = safe_sqrt(1.f - fmaf(py, py, px * px));
-    const float sin_theta_i = safe_sqrt(1.f - sqr(cos_theta));
-    const float norm_ = rcp(fmaf(sin_theta_i, py, cos_theta * pz));
-    const float slope_x = fmaf(cos_theta, py, -(sin_theta_i * pz)) * norm_, slope_y = px * norm_;
-    const float sx = fmaf(cos_phi, slope_x, -(sin_phi * slope_y)) * g.au, sy = fmaf(sin_phi, slope_x, cos_phi * slope_y) * g.av;
-    const V3 m = normalize(mk(-sx, -sy, 1.f));
-    pdf = ggx_eval(g, m) * ggx_smith_g1(g, wi, m) * fabsf(dot(wi, m)) / wi.z;
-    return m;
-}
-// fresnel -- include/mitsuba/render/fresnel.h:21-63
-DTOF_D void fresnel_dielectric(float cos_theta_i, float eta, float &r, float &cos_theta_t, float &eta_it, float &eta_ti) {
-    const bool outside = cos_theta_i >= 0.f;
-    const float rcp_eta = rcp(eta);
-    eta_it = outside ? eta : rcp_eta; eta_ti = outside ? rcp_eta : eta;
-    const float cos_theta_t_sqr = fmaf(-fmaf(-cos_theta_i, cos_theta_i, 1.f), eta_ti * eta_ti, 1.f);
-    const float cos_theta_i_abs = fabsf(cos_theta_i), cos_theta_t_abs = safe_sqrt(cos_theta_t_sqr);
-    const bool index_matched = eta == 1.f, special_case = index_matched || cos_theta_i_abs == 0.f;
-    const float a_s = fmaf(-eta_it, cos_theta_t_abs, cos_theta_i_abs) / fmaf(eta_it, cos_theta_t_abs, cos_theta_i_abs);
-    const float a_p = fmaf(-eta_it, cos_theta_i_abs, cos_theta_t_abs) / fmaf(eta_it, cos_theta_i_abs, cos_theta_t_abs);
-    r = 0.5f * (sqr(a_s) + sqr(a_p));
-    if (special_case) r = index_matched ? 0.f : 1.f;
-    cos_theta_t = mulsign_neg(cos_theta_t_abs, cos_theta_i);
 }
 DTOF_D float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
@@ -835,8 +803,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
 
             // ---- emitter sampling (scene.cpp:235-291; point.cpp:118-147; area.cpp:116-159 + shape.cpp:370-384 + rectangle.cpp:152-166)
             float e1 = single ? next_f32(main) : next_correlate(main, path, correlate), e2 = single ? next_f32(main) : next_correlate(main, path, correlate);
-            // has_flag(bsdf->flags(), BSDFFlags::Smooth) (:178): diffuse and plastic have a smooth lobe
-            bool active_em = active_next && sv.n_emitters > 0 && (!SPEC || sh->bsdf == BSDF_DIFFUSE || sh->bsdf == BSDF_PLASTIC || sh->bsdf == BSDF_ROUGHCONDUCTOR);
+            // has_flag(bsdf->flags(), BSDFFlags::Smooth) (:178): diffuse, (rough)plastic and roughconductor have a smooth lobe
+            bool active_em = active_next && sv.n_emitters > 0 && (!SPEC || sh->bsdf == BSDF_DIFFUSE || sh->bsdf == BSDF_PLASTIC || sh->bsdf == BSDF_ROUGHCONDUCTOR || sh->bsdf == BSDF_ROUGHPLASTIC);
             V3 em_weight = mk(0, 0, 0), wo = mk(0, 0, 0); float ds_dist = 0.f, ds_pdf = 0.f; bool ds_delta = true;
             if (active_em) {
                 uint32_t ne = sv.n_emitters, idx = 0; float em_w = 1.f, sx = e1;
@@ -946,6 +914,32 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                     if (ok) bsdf_weight = mk(fresnel_conductor(dwm, sh->cond_eta[0], sh->cond_k[0]) * (weight * sh->spec_refl[0]),
                                              fresnel_conductor(dwm, sh->cond_eta[1], sh->cond_k[1]) * (weight * sh->spec_refl[1]),
                                              fresnel_conductor(dwm, sh->cond_eta[2], sh->cond_k[2]) * (weight * sh->spec_refl[2]));
+                    if (twosided && si.wi.z < 0.f) bs_wo.z = -bs_wo.z;
+                }
+            } else if (SPEC && sh->bsdf == BSDF_ROUGHPLASTIC) {
+                // RoughPlastic::eval / pdf / sample (roughplastic.cpp:259-421), GGX + visible normals, under TwoSidedBRDF
+                V3 wi = si.wi, wo_l = wo;
+                if (twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
+                const Ggx g = ggx_make(sh->alpha_u, sh->alpha_u);
+                const float *table = (const float *) (sv.base + sh->rough_table);
+                const float w = sh->spec_sampling_weight, ir = sh->fdr_int;
+                const V3 diff = sh->nonlinear ? mk(refl.x / (1.f - refl.x * ir), refl.y / (1.f - refl.y * ir), refl.z / (1.f - refl.z * ir))
+                                              : mk(refl.x / (1.f - ir), refl.y / (1.f - ir), refl.z / (1.f - ir));
+                if (wi.z > 0.f) {
+                    const float t_i = lerp_gather64(table, wi.z);
+                    float prob_specular = (1.f - t_i) * w, prob_diffuse = t_i * (1.f - w);
+                    prob_specular = prob_specular / (prob_specular + prob_diffuse);
+                    prob_diffuse = 1.f - prob_specular;
+                    if (wo_l.z > 0.f) rough_plastic_eval_pdf(g, sh, table, diff, wi, wo_l, t_i, prob_specular, prob_diffuse, bsdf_val, bsdf_pdf);
+                    if (sample_1 < prob_specular) {
+                        float mpdf; const V3 m = ggx_sample(g, wi, s2x, s2y, mpdf);
+                        const float dwm = dot(wi, m);
+                        bs_wo = mk(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   // reflect(wi, m)
+                    } else bs_wo = cosine_hemisphere(s2x, s2y);
+                    bs_eta = 1.f;
+                    V3 value = mk(0, 0, 0);
+                    if (bs_wo.z > 0.f) rough_plastic_eval_pdf(g, sh, table, diff, wi, bs_wo, t_i, prob_specular, prob_diffuse, value, bs_pdf);
+                    if (bs_pdf > 0.f) bsdf_weight = value * rcp(bs_pdf);                  // Spectrum / Float = multiplication by the reciprocal
                     if (twosided && si.wi.z < 0.f) bs_wo.z = -bs_wo.z;
                 }
             } else if (SPEC && sh->bsdf == BSDF_PLASTIC) {

@@ -137,6 +137,62 @@ DTOF_HD void coordinate_system(V3 n, V3 &s, V3 &t) {
     t = mk(b, fmaf(n.y, n.y * a, sign), -n.y);
 }
 
+DTOF_HD float safe_sqrt(float x) { return sqrtf(fmax_(x, 0.f)); }
+// fresnel -- include/mitsuba/render/fresnel.h:21-63
+DTOF_HD void fresnel_dielectric(float cos_theta_i, float eta, float &r, float &cos_theta_t, float &eta_it, float &eta_ti) {
+    const bool outside = cos_theta_i >= 0.f;
+    const float rcp_eta = rcp(eta);
+    eta_it = outside ? eta : rcp_eta; eta_ti = outside ? rcp_eta : eta;
+    const float cos_theta_t_sqr = fmaf(-fmaf(-cos_theta_i, cos_theta_i, 1.f), eta_ti * eta_ti, 1.f);
+    const float cos_theta_i_abs = fabsf(cos_theta_i), cos_theta_t_abs = safe_sqrt(cos_theta_t_sqr);
+    const bool index_matched = eta == 1.f, special_case = index_matched || cos_theta_i_abs == 0.f;
+    const float a_s = fmaf(-eta_it, cos_theta_t_abs, cos_theta_i_abs) / fmaf(eta_it, cos_theta_t_abs, cos_theta_i_abs);
+    const float a_p = fmaf(-eta_it, cos_theta_i_abs, cos_theta_t_abs) / fmaf(eta_it, cos_theta_i_abs, cos_theta_t_abs);
+    r = 0.5f * (sqr(a_s) + sqr(a_p));
+    if (special_case) r = index_matched ? 0.f : 1.f;
+    cos_theta_t = mulsign_neg(cos_theta_t_abs, cos_theta_i);
+}
+// ---- MicrofacetDistribution, GGX, sample_visible = true (include/mitsuba/render/microfacet.h)
+struct Ggx { float au, av; };
+DTOF_HD Ggx ggx_make(float au, float av) { Ggx g; g.au = fmax_(au, 1e-4f); g.av = fmax_(av, 1e-4f); return g; }   // configure() :425-428
+DTOF_HD float ggx_eval(Ggx g, V3 m) {   // eval() :176-196
+    const float result = rcp(kPi * (g.au * g.av) * sqr(sqr(m.x / g.au) + sqr(m.y / g.av) + sqr(m.z)));
+    return result * m.z > 1e-20f ? result : 0.f;
+}
+DTOF_HD float ggx_smith_g1(Ggx g, V3 v, V3 m) {   // smith_g1() :341-365
+    const float xy_alpha_2 = sqr(g.au * v.x) + sqr(g.av * v.y), tan_theta_alpha_2 = xy_alpha_2 / sqr(v.z);
+    float result = 2.f / (1.f + sqrtf(1.f + tan_theta_alpha_2));
+    if (xy_alpha_2 == 0.f) result = 1.f;
+    if (dot(v, m) * v.z <= 0.f) result = 0.f;
+    return result;
+}
+// sample(), visible-normal branch :296-325 + sample_visible_11, GGX branch :405-420: microfacet normal and its density
+DTOF_HD V3 ggx_sample(Ggx g, V3 wi, float s_x, float s_y, float &pdf) {
+    const V3 wi_p = normalize(mk(g.au * wi.x, g.av * wi.y, wi.z));
+    const float sin_theta_2 = fmaf(wi_p.x, wi_p.x, sqr(wi_p.y)), inv_sin_theta = rsqrt_(sin_theta_2);   // Frame3f::sincos_phi (frame.h:111-122)
+    float rx = fmin_(fmax_(wi_p.x * inv_sin_theta, -1.f), 1.f), ry = fmin_(fmax_(wi_p.y * inv_sin_theta, -1.f), 1.f);
+    if (fabsf(sin_theta_2) <= 4.f * 5.9604644775390625e-8f) { rx = 1.f; ry = 0.f; }
+    const float sin_phi = ry, cos_phi = rx, cos_theta = wi_p.z;
+    const float x = fmaf(2.f, s_x, -1.f), y = fmaf(2.f, s_y, -1.f);   // square_to_uniform_disk_concentric (warp.h:54-90)
+    const bool is_zero = x == 0.f && y == 0.f, q13 = fabsf(x) < fabsf(y);
+    const float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = 0.25f * kPi * rp / r;
+    if (q13) phi = 0.5f * kPi - phi;
+    if (is_zero) phi = 0.f;
+    float sn, cs; sincos_(phi, sn, cs);
+    const float px = r * cs; float py = r * sn;
+    const float s = 0.5f * (1.f + cos_theta), a = safe_sqrt(1.f - sqr(px));
+    py = fmaf(py, s, fmaf(-a, s, a));                              // dr::lerp(a, py, s)
+    const float pz = safe_sqrt(1.f - fmaf(py, py, px * px));
+    const float sin_theta_i = safe_sqrt(1.f - sqr(cos_theta));
+    const float norm_ = rcp(fmaf(sin_theta_i, py, cos_theta * pz));
+    const float slope_x = fmaf(cos_theta, py, -(sin_theta_i * pz)) * norm_, slope_y = px * norm_;
+    const float sx = fmaf(cos_phi, slope_x, -(sin_phi * slope_y)) * g.au, sy = fmaf(sin_phi, slope_x, cos_phi * slope_y) * g.av;
+    const V3 m = normalize(mk(-sx, -sy, 1.f));
+    pdf = ggx_eval(g, m) * ggx_smith_g1(g, wi, m) * fabsf(dot(wi, m)) / wi.z;
+    return m;
+}
+
 // ---------------------------------------------------------------- RNG (integer exact)
 // sample_tea_32 -- include/mitsuba/core/random.h:33-47
 DTOF_HD void tea32(uint32_t v0, uint32_t v1, uint32_t &o0, uint32_t &o1) {

@@ -532,6 +532,8 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
             v.push_back(s.inv_eta_2); v.push_back(s.fdr_int); v.push_back(s.spec_sampling_weight);
             v.insert(v.end(), s.refl, s.refl + 3); v.insert(v.end(), s.spec_refl, s.spec_refl + 3); v.insert(v.end(), s.spec_trans, s.spec_trans + 3);
             v.insert(v.end(), s.cond_eta, s.cond_eta + 3); v.insert(v.end(), s.cond_k, s.cond_k + 3); v.push_back(s.alpha_u); v.push_back(s.alpha_v);
+        } else if (kind == 10) for (auto &s : sc->host.shapes) {
+            if (s.bsdf == BSDF_ROUGHPLASTIC) v.insert(v.end(), s.rough_table.begin(), s.rough_table.end());
         } else throw std::runtime_error("unknown export kind");
         *n_written = v.size();
         if (out) { if (v.size() > cap) throw std::runtime_error("export buffer too small"); memcpy(out, v.data(), v.size() * 4); }

@@ -17,7 +17,7 @@ enum WaveType : int32_t { WAVE_SIN = 0, WAVE_RECT = 1, WAVE_TRI = 2, WAVE_TRAP =
 enum TimeSampling : int32_t { TIME_UNIFORM = 0, TIME_STRATIFIED = 1, TIME_ANTITHETIC = 2, TIME_ANTITHETIC_MIRROR = 3 };
 enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1, FILTER_GAUSSIAN = 2, FILTER_MITCHELL = 3, FILTER_CATMULLROM = 4 };
 enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4, SF_EMITTER = 8 };
-enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4 };
+enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4, BSDF_ROUGHPLASTIC = 5 };
 enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1 };
 
 // ---------------------------------------------------------------------------- device blob records
@@ -59,13 +59,15 @@ struct DShape {             // 304 B
     // Spheres (src/shapes/sphere.cpp:138-160) keep m_center in n[] and m_radius in dp_du[0]; to_world / to_object are the composed
     // to_world * translate(center) * scale(radius) and its inverse.
     float n[3]; uint32_t emit_table; float dp_du[3]; uint32_t emit_lo; float dp_dv[3]; uint32_t emit_hi;
-    float bmin[3], emit_sum, bmax[3], pad5;             // padded bounds of the shape in ITS space (mesh: culls the triangle loop); emit_sum = float(sum of areas)
+    float bmin[3], emit_sum, bmax[3]; uint32_t rough_table;             // padded bounds of the shape in ITS space (mesh: culls the triangle loop); emit_sum = float(sum of areas)
     float radiance[3], inv_area;                        // SF_EMITTER: AreaLight radiance, 1 / area (Rectangle::m_inv_surface_area, DiscreteDistribution::normalization)
     // BSDF: BSDF_DIFFUSE uses refl; BSDF_CONDUCTOR (src/bsdfs/conductor.cpp) cond_eta / cond_k / spec_refl; BSDF_DIELECTRIC
     // (src/bsdfs/dielectric.cpp) diel_eta = int_ior / ext_ior, spec_refl, spec_trans
     // BSDF_PLASTIC (src/bsdfs/plastic.cpp): refl = diffuse_reflectance, spec_refl, diel_eta and the constants of parameters_changed
     uint32_t bsdf; float diel_eta; uint32_t nonlinear; float inv_eta_2;
     // BSDF_ROUGHCONDUCTOR (src/bsdfs/roughconductor.cpp, GGX + visible normals): cond_eta / cond_k / spec_refl + alpha_u, alpha_v
+    // BSDF_ROUGHPLASTIC (src/bsdfs/roughplastic.cpp, GGX + visible normals): the plastic fields + alpha_u; fdr_int = m_internal_reflectance;
+    // rough_table = byte offset in the blob of m_external_transmittance (64 floats)
     float cond_eta[3], fdr_int, cond_k[3], spec_sampling_weight, spec_refl[3], alpha_u, spec_trans[3], alpha_v;
 };
 struct DTri { float p0[3]; uint32_t face; float p1[4], p2[4]; };         // 48 B; face = index in the mesh's own order (tie rule)
@@ -83,7 +85,8 @@ struct HostShape {
     uint32_t bsdf = BSDF_DIFFUSE;   // + the parameters of the specular BSDFs
     float cond_eta[3] = { 0, 0, 0 }, cond_k[3] = { 1, 1, 1 }, spec_refl[3] = { 1, 1, 1 }, spec_trans[3] = { 1, 1, 1 }, diel_eta = 1.f;
     bool nonlinear = false; float inv_eta_2 = 1.f, fdr_int = 0.f, spec_sampling_weight = 0.f;   // plastic
-    float alpha_u = .1f, alpha_v = .1f;   // roughconductor
+    float alpha_u = .1f, alpha_v = .1f;   // roughconductor, roughplastic
+    std::vector<float> rough_table;        // roughplastic: m_external_transmittance (64 values)
     float to_world[16], to_object[16];     // float casts of the double transform and its double inverse
     // mesh: cube baked like src/shapes/cube.cpp:114-160; obj / ply through mesh_io.cpp
     std::vector<float> positions, normals, texcoords;

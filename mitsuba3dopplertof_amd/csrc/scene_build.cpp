@@ -122,7 +122,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     std::vector<DShape> shapes(sc.shapes.size());
     std::vector<DTri> tris; std::vector<DTriShade> shading;
     std::vector<BvhNode> blas_nodes; uint32_t blas_depth = 0;
-    std::vector<uint32_t> tables;   // mesh emitters: cdf[n] | pmf[n] (float bits) | slot[n]
+    std::vector<uint32_t> tables;   // mesh emitters: cdf[n] | pmf[n] (float bits) | slot[n]; roughplastic: 64 transmittances
     const char *blas_env = getenv("DTOF_BLAS"); const bool use_blas = !(blas_env && blas_env[0] == '0');   // DTOF_BLAS=0: loop over every triangle (debug)
     std::vector<Box> shape_boxes(sc.shapes.size());
     for (size_t i = 0; i < sc.shapes.size(); ++i) {
@@ -133,6 +133,10 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         memcpy(d.refl, h.refl, 12); d.blas_root = kNoChild;
         d.bsdf = h.bsdf; d.diel_eta = h.diel_eta; d.nonlinear = h.nonlinear; d.inv_eta_2 = h.inv_eta_2; d.fdr_int = h.fdr_int; d.spec_sampling_weight = h.spec_sampling_weight; d.alpha_u = h.alpha_u; d.alpha_v = h.alpha_v;
         memcpy(d.cond_eta, h.cond_eta, 12); memcpy(d.cond_k, h.cond_k, 12); memcpy(d.spec_refl, h.spec_refl, 12); memcpy(d.spec_trans, h.spec_trans, 12);
+        if (h.bsdf == BSDF_ROUGHPLASTIC) {   // m_external_transmittance; rebased to a blob offset below
+            d.rough_table = (uint32_t) tables.size() * 4u;
+            for (float v : h.rough_table) { uint32_t b; memcpy(&b, &v, 4); tables.push_back(b); }
+        }
         if (h.emitter) { d.flags |= SF_EMITTER; memcpy(d.radiance, h.radiance, 12); }
         memcpy(d.to_world, h.to_world, 48); memcpy(d.to_object, h.to_object, 48);
         if (h.kind == SHAPE_RECT) {   // Rectangle::update, rectangle.cpp:101-113
@@ -280,6 +284,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     h.off_tables = off;   off = align16(off + (uint32_t) (tables.size() * 4));
     h.total_bytes = off;
     for (DShape &d : shapes) if (d.kind == SHAPE_MESH && (d.flags & SF_EMITTER)) d.emit_table += h.off_tables;
+    for (DShape &d : shapes) if (d.bsdf == BSDF_ROUGHPLASTIC) d.rough_table += h.off_tables;
     std::vector<uint8_t> blob(off, 0);
     memcpy(blob.data(), &h, sizeof h);
     if (!nodes.empty()) memcpy(blob.data() + h.off_nodes, nodes.data(), nodes.size() * sizeof(BvhNode));

@@ -458,6 +458,86 @@ static void color_of(const Obj &b, const char *name, float def, float out[3]) {
     if (c != b.colors.end()) { for (int i = 0; i < 3; ++i) out[i] = (float) c->second[i]; }
     else { float r = (float) b.props.get_float(name, def); out[0] = out[1] = out[2] = r; }
 }
+// quad::gauss_legendre (include/mitsuba/core/quad.h:27-86) with math::legendre_pd (math.h:92-119): nodes and weights on [-1, 1],
+// Newton iteration in double, stored as float
+static void legendre_pd(int l, double x, double &lv, double &dv) {
+    if (l == 0) { lv = 1; dv = 0; return; }
+    if (l == 1) { lv = x; dv = 1; return; }
+    double l_p_pred = 1, l_pred = x, d_p_pred = 0, d_pred = 1, k0 = 3, k1 = 2, k2 = 1; lv = 0; dv = 0;
+    for (int ki = 2; ki <= l; ++ki) {
+        lv = (k0 * x * l_pred - k2 * l_p_pred) / k1;
+        dv = d_p_pred + k0 * l_pred;
+        l_p_pred = l_pred; l_pred = lv; d_p_pred = d_pred; d_pred = dv;
+        k2 = k1; k0 += 2; k1 += 1;
+    }
+}
+static void gauss_legendre(int n, std::vector<float> &nodes, std::vector<float> &weights) {
+    nodes.assign(n, 0.f); weights.assign(n, 0.f);
+    n--;
+    if (n == 0) { nodes[0] = 0.f; weights[0] = 2.f; }
+    else if (n == 1) { nodes[0] = (float) -std::sqrt(1.0 / 3.0); nodes[1] = -nodes[0]; weights[0] = weights[1] = 1.f; }
+    const int m = (n + 1) / 2;
+    for (int i = 0; i < m; ++i) {
+        double x = -std::cos((double) (2 * i + 1) / (double) (2 * n + 2) * 3.14159265358979323846), lv, dv;
+        for (int it = 1; ; ++it) {
+            if (it > 20) fail("gauss_legendre(" + std::to_string(n) + "): did not converge after 20 iterations!");
+            legendre_pd(n + 1, x, lv, dv);
+            const double step = lv / dv;
+            x -= step;
+            if (std::fabs(step) <= 4 * std::fabs(x) * (2.220446049250313e-16 / 2)) break;     // dr::Epsilon<double> = 2^-53
+        }
+        legendre_pd(n + 1, x, lv, dv);
+        weights[i] = weights[n - i] = (float) (2 / ((1 - x * x) * (dv * dv)));
+        nodes[i] = (float) x; nodes[n - i] = (float) -x;
+    }
+    if ((n % 2) == 0) {
+        double lv, dv; legendre_pd(n + 1, 0.0, lv, dv);
+        weights[n / 2] = (float) (2.0 / (dv * dv)); nodes[n / 2] = 0.f;
+    }
+}
+// eval_transmittance / eval_reflectance (include/mitsuba/render/microfacet.h:464-566) of a GGX distribution with visible-normal
+// sampling for ONE incident direction: tensor Gauss-Legendre rule over the sample square (32 x 32 nodes for eta > 1, else 128 x 128;
+// dr::meshgrid order: x runs fastest), accumulated in float in node order.
+static float rough_integral(Ggx g, V3 wi, float eta, bool transmit) {
+    const int res = eta > 1.f ? 32 : 128;
+    static thread_local std::vector<float> nodes, weights; static thread_local int have = 0;
+    if (have != res) { gauss_legendre(res, nodes, weights); have = res; }
+    float result = 0.f;
+    for (int j = 0; j < res * res; ++j) {
+        const float nx = fmaf(nodes[j % res], 0.5f, 0.5f), ny = fmaf(nodes[j / res], 0.5f, 0.5f), w = weights[j % res] * weights[j / res];
+        float pdf, f, cos_theta_t, eta_it, eta_ti;
+        const V3 m = ggx_sample(g, wi, nx, ny, pdf);
+        const float dwm = dot(wi, m);
+        fresnel_dielectric(dwm, eta, f, cos_theta_t, eta_it, eta_ti);
+        float smith;
+        if (transmit) {
+            const float k = fmaf(dwm, eta_ti, cos_theta_t);                                     // refract(wi, m, cos_theta_t, eta_ti), fresnel.h:311-314
+            const V3 wo = mk(fmaf(m.x, k, -(wi.x * eta_ti)), fmaf(m.y, k, -(wi.y * eta_ti)), fmaf(m.z, k, -(wi.z * eta_ti)));
+            smith = ggx_smith_g1(g, wo, m) * (1.f - f);
+            if (wo.z * wi.z >= 0.f) smith = 0.f;
+        } else {
+            const V3 wo = mk(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   // reflect(wi, m)
+            smith = ggx_smith_g1(g, wo, m) * f;
+            if (wo.z <= 0.f || wi.z <= 0.f) smith = 0.f;
+        }
+        result += smith * w * 0.25f;
+    }
+    return result;
+}
+// RoughPlastic::parameters_changed (src/bsdfs/roughplastic.cpp:222-257): m_external_transmittance on MI_ROUGH_TRANSMITTANCE_RES = 64
+// cosines mu = max(1e-6, linspace(0, 1, 64)) and m_internal_reflectance = mean(eval_reflectance(1 / eta) * mu) * 2
+void rough_plastic_tables(float alpha, float eta, float *table, float *internal_reflectance) {
+    const Ggx g = ggx_make(alpha, alpha);
+    float sum = 0.f;
+    for (int i = 0; i < 64; ++i) {
+        const float mu = fmax_(1e-6f, fmaf((float) i, 1.f / 63.f, 0.f));
+        const V3 wi = mk(sqrtf(1.f - mu * mu), 0.f, mu);
+        table[i] = rough_integral(g, wi, eta, true);
+        sum += rough_integral(g, wi, 1.f / eta, false) * wi.z;
+    }
+    *internal_reflectance = sum * (1.f / 64.f) * 2.f;
+}
+
 // diffuse (src/bsdfs/diffuse.cpp), conductor (conductor.cpp:171-188), dielectric (dielectric.cpp:176-203), twosided{...} (twosided.cpp:40-70)
 static void bsdf_of(const Obj &b, HostShape &s) {
     if (b.plugin == "twosided") {
@@ -515,7 +595,32 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         }
         const float d_mean = ((s.refl[0] + s.refl[1]) + s.refl[2]) * (1.0f / 3.0f), s_mean = ((s.spec_refl[0] + s.spec_refl[1]) + s.spec_refl[2]) * (1.0f / 3.0f);
         s.spec_sampling_weight = s_mean / (d_mean + s_mean);
-    } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, plastic, conductor, roughconductor, dielectric, twosided)");
+    } else if (b.plugin == "roughplastic") {   // src/bsdfs/roughplastic.cpp:170-257
+        const float int_ior = lookup_ior(b, "int_ior", "polypropylene"), ext_ior = lookup_ior(b, "ext_ior", "air");
+        if (int_ior < 0 || ext_ior < 0 || int_ior == ext_ior) fail("The interior and exterior indices of refraction must be positive and differ!");
+        s.bsdf = BSDF_ROUGHPLASTIC; s.diel_eta = int_ior / ext_ior;
+        color_of(b, "diffuse_reflectance", 0.5f, s.refl); color_of(b, "specular_reflectance", 1.f, s.spec_refl);
+        const bool has_spec = b.props.has("specular_reflectance") || b.colors.count("specular_reflectance");
+        s.nonlinear = b.props.get_bool("nonlinear", false);
+        std::string distr = b.props.get_string("distribution", "beckmann");
+        std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
+        if (distr != "beckmann" && distr != "ggx") fail("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"!");
+        if (distr != "ggx") fail("roughplastic: only distribution \"ggx\" is implemented (the Beckmann distribution needs Dr.Jit's erf / erfinv "
+                                 "approximations, whose source is not part of the reference tree)");
+        if (!b.props.get_bool("sample_visible", true)) fail("roughplastic: only sample_visible = true is implemented");
+        if (b.props.has("alpha_u") || b.props.has("alpha_v")) {
+            if (!b.props.has("alpha_u") || !b.props.has("alpha_v")) fail("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
+            if (b.props.has("alpha")) fail("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.");
+            s.alpha_u = (float) b.props.get_float("alpha_u", 0.1); s.alpha_v = (float) b.props.get_float("alpha_v", 0.1);
+            if (s.alpha_u != s.alpha_v) fail("The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!");
+        } else s.alpha_u = s.alpha_v = (float) b.props.get_float("alpha", 0.1);
+        s.inv_eta_2 = 1.f / (s.diel_eta * s.diel_eta);
+        const float d_mean = ((s.refl[0] + s.refl[1]) + s.refl[2]) * (1.0f / 3.0f),
+                    s_mean = has_spec ? ((s.spec_refl[0] + s.spec_refl[1]) + s.spec_refl[2]) * (1.0f / 3.0f) : 1.f;
+        s.spec_sampling_weight = s_mean / (d_mean + s_mean);
+        s.rough_table.resize(64);
+        rough_plastic_tables(s.alpha_u, s.diel_eta, s.rough_table.data(), &s.fdr_int);       // fdr_int carries m_internal_reflectance
+    } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, plastic, roughplastic, conductor, roughconductor, dielectric, twosided)");
     auto u = b.props.unqueried();
     if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in plugin of type \"" + b.plugin + "\"");
 }

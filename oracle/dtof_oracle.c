@@ -832,6 +832,32 @@ static v3 ggx_sample(ggx_t g, v3 wi, float s_x, float s_y, float *pdf_out) {
     *pdf_out = ggx_eval(g, m) * ggx_smith_g1(g, wi, m) * fabsf(v_dot(wi, m)) / wi.z;
     return m;
 }
+/* RoughPlastic::lerp_gather (roughplastic.cpp:373-383) on the 64-entry table */
+static float lerp_gather64(const float *data, float x) {
+    x *= 63.f;
+    uint32_t index = (uint32_t) x; if (index > 62u) index = 62u;
+    float v0 = data[index], v1 = data[index + 1], t = x - (float) index;
+    return fmaf(v1, t, fmaf(-v0, t, v0));   /* dr::lerp */
+}
+/* RoughPlastic::eval (:333-371) and pdf (:385-421), both cosines positive */
+static void rough_plastic_eval_pdf(ggx_t g, const orc_shape *sh, v3 wi, v3 wo, float t_i, float prob_specular, float prob_diffuse,
+                                   v3 *value, float *pdf) {
+    v3 H = v_normalize(v_add(wo, wi));
+    float D = ggx_eval(g, H), F, t1, t2, t3;
+    fresnel_dielectric(v_dot(wi, H), sh->diel_eta, &F, &t1, &t2, &t3);
+    float G = ggx_smith_g1(g, wi, H) * ggx_smith_g1(g, wo, H);
+    float spec = F * D * G / (4.f * wi.z);
+    float t_o = lerp_gather64(sh->rough_table, wo.z);
+    v3 diff = V(sh->reflectance[0], sh->reflectance[1], sh->reflectance[2]);
+    float ir = sh->fdr_int;
+    diff = sh->nonlinear ? V(diff.x / (1.f - diff.x * ir), diff.y / (1.f - diff.y * ir), diff.z / (1.f - diff.z * ir))
+                         : V(diff.x / (1.f - ir), diff.y / (1.f - ir), diff.z / (1.f - ir));
+    float k = ORC_INV_PI_F * sh->inv_eta_2 * wo.z * t_i * t_o;
+    *value = V(spec * sh->spec_refl[0] + diff.x * k, spec * sh->spec_refl[1] + diff.y * k, spec * sh->spec_refl[2] + diff.z * k);
+    float result = D * ggx_smith_g1(g, wi, H) / (4.f * wi.z);
+    result *= prob_specular;
+    *pdf = result + prob_diffuse * (ORC_INV_PI_F * wo.z);
+}
 /* mis_weight -- dopplertofpath.cpp:296-301 */
 static inline float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
@@ -937,7 +963,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
 
         /* has_flag(bsdf->flags(), BSDFFlags::Smooth), :178 -- diffuse and plastic have a smooth lobe */
         int active_em = active_next && hit && (si.shape->bsdf == ORC_BSDF_DIFFUSE || si.shape->bsdf == ORC_BSDF_PLASTIC ||
-                                               si.shape->bsdf == ORC_BSDF_ROUGHCONDUCTOR);
+                                               si.shape->bsdf == ORC_BSDF_ROUGHCONDUCTOR || si.shape->bsdf == ORC_BSDF_ROUGHPLASTIC);
 
         /* emitter sampling: Scene::sample_emitter_direction src/render/scene.cpp:235-291 */
         float e1 = sampler_draw(&smp, correlate, single);
@@ -1063,6 +1089,29 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
                 if (ok) bsdf_weight = V(fresnel_conductor(dwm, sh->cond_eta[0], sh->cond_k[0]) * (weight * sh->spec_refl[0]),
                                         fresnel_conductor(dwm, sh->cond_eta[1], sh->cond_k[1]) * (weight * sh->spec_refl[1]),
                                         fresnel_conductor(dwm, sh->cond_eta[2], sh->cond_k[2]) * (weight * sh->spec_refl[2]));
+                if (sh->twosided && si.wi.z < 0.f) bs_wo.z = -bs_wo.z;
+            }
+        } else if (hit && si.shape->bsdf == ORC_BSDF_ROUGHPLASTIC) {
+            /* RoughPlastic::sample (roughplastic.cpp:259-331) under TwoSidedBRDF; eval / pdf in rough_plastic_eval_pdf */
+            const orc_shape *sh = si.shape;
+            v3 wi = si.wi, wo_l = wo;
+            if (sh->twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
+            ggx_t g = ggx_make(sh->alpha_u, sh->alpha_u);
+            if (wi.z > 0.f) {
+                float t_i = lerp_gather64(sh->rough_table, wi.z);
+                float prob_specular = (1.f - t_i) * sh->spec_sampling_weight, prob_diffuse = t_i * (1.f - sh->spec_sampling_weight);
+                prob_specular = prob_specular / (prob_specular + prob_diffuse);
+                prob_diffuse = 1.f - prob_specular;
+                if (wo_l.z > 0.f) rough_plastic_eval_pdf(g, sh, wi, wo_l, t_i, prob_specular, prob_diffuse, &bsdf_val, &bsdf_pdf);
+                if (sample_1 < prob_specular) {
+                    float mpdf; v3 m = ggx_sample(g, wi, s2x, s2y, &mpdf);
+                    float dwm = v_dot(wi, m);
+                    bs_wo = V(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   /* reflect(wi, m) */
+                } else bs_wo = square_to_cosine_hemisphere(s2x, s2y);
+                bs_eta = 1.f;
+                v3 value = V(0, 0, 0);
+                if (bs_wo.z > 0.f) rough_plastic_eval_pdf(g, sh, wi, bs_wo, t_i, prob_specular, prob_diffuse, &value, &bs_pdf);
+                if (bs_pdf > 0.f) bsdf_weight = v_mul(value, f_rcp(bs_pdf));   /* Spectrum / Float: times the reciprocal */
                 if (sh->twosided && si.wi.z < 0.f) bs_wo.z = -bs_wo.z;
             }
         } else if (hit && si.shape->bsdf == ORC_BSDF_PLASTIC) {
@@ -1478,4 +1527,76 @@ void orc_plastic_params(float eta, const float *d, const float *sp, float *out3)
     out3[1] = fresnel_diffuse_reflectance(1.f / eta);
     float d_mean = ((d[0] + d[1]) + d[2]) * (1.0f / 3.0f), s_mean = ((sp[0] + sp[1]) + sp[2]) * (1.0f / 3.0f);
     out3[2] = s_mean / (d_mean + s_mean);
+}
+/* quad::gauss_legendre (include/mitsuba/core/quad.h:27-86), math::legendre_pd (include/mitsuba/core/math.h:92-119) */
+static void legendre_pd(int l, double x, double *lv, double *dv) {
+    if (l == 0) { *lv = 1; *dv = 0; return; }
+    if (l == 1) { *lv = x; *dv = 1; return; }
+    double l_p_pred = 1, l_pred = x, d_p_pred = 0, d_pred = 1, k0 = 3, k1 = 2, k2 = 1, l_cur = 0, d_cur = 0;
+    for (int ki = 2; ki <= l; ++ki) {
+        l_cur = (k0 * x * l_pred - k2 * l_p_pred) / k1;
+        d_cur = d_p_pred + k0 * l_pred;
+        l_p_pred = l_pred; l_pred = l_cur; d_p_pred = d_pred; d_pred = d_cur;
+        k2 = k1; k0 += 2; k1 += 1;
+    }
+    *lv = l_cur; *dv = d_cur;
+}
+void orc_gauss_legendre(int n, float *nodes, float *weights) {
+    n--;
+    if (n == 0) { nodes[0] = 0.f; weights[0] = 2.f; }
+    else if (n == 1) { nodes[0] = (float) -sqrt(1.0 / 3.0); nodes[1] = -nodes[0]; weights[0] = weights[1] = 1.f; }
+    int m = (n + 1) / 2;
+    for (int i = 0; i < m; ++i) {
+        double x = -cos((double) (2 * i + 1) / (double) (2 * n + 2) * 3.14159265358979323846), lv, dv;
+        for (int it = 1; it <= 20; ++it) {   /* the reference throws after 20 iterations; it converges in a handful */
+            legendre_pd(n + 1, x, &lv, &dv);
+            double step = lv / dv;
+            x -= step;
+            if (fabs(step) <= 4 * fabs(x) * (2.220446049250313e-16 / 2)) break;
+        }
+        legendre_pd(n + 1, x, &lv, &dv);
+        weights[i] = weights[n - i] = (float) (2 / ((1 - x * x) * (dv * dv)));
+        nodes[i] = (float) x; nodes[n - i] = (float) -x;
+    }
+    if ((n % 2) == 0) {
+        double lv, dv; legendre_pd(n + 1, 0.0, &lv, &dv);
+        weights[n / 2] = (float) (2.0 / (dv * dv)); nodes[n / 2] = 0.f;
+    }
+}
+/* eval_transmittance (transmit) / eval_reflectance for one incident direction: microfacet.h:463-566 */
+static float rough_integral(ggx_t g, v3 wi, float eta, int transmit) {
+    int res = eta > 1.f ? 32 : 128;
+    float nodes[128], weights[128];
+    orc_gauss_legendre(res, nodes, weights);
+    float result = 0.f;
+    for (int j = 0; j < res * res; ++j) {   /* dr::meshgrid: x runs fastest */
+        float nx = fmaf(nodes[j % res], 0.5f, 0.5f), ny = fmaf(nodes[j / res], 0.5f, 0.5f), w = weights[j % res] * weights[j / res];
+        float pdf, f, cos_theta_t, eta_it, eta_ti, smith;
+        v3 m = ggx_sample(g, wi, nx, ny, &pdf);
+        float dwm = v_dot(wi, m);
+        fresnel_dielectric(dwm, eta, &f, &cos_theta_t, &eta_it, &eta_ti);
+        if (transmit) {   /* refract(wi, m, cos_theta_t, eta_ti), fresnel.h:311-314 */
+            float k = fmaf(dwm, eta_ti, cos_theta_t);
+            v3 wo = V(fmaf(m.x, k, -(wi.x * eta_ti)), fmaf(m.y, k, -(wi.y * eta_ti)), fmaf(m.z, k, -(wi.z * eta_ti)));
+            smith = ggx_smith_g1(g, wo, m) * (1.f - f);
+            if (wo.z * wi.z >= 0.f) smith = 0.f;
+        } else {
+            v3 wo = V(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));
+            smith = ggx_smith_g1(g, wo, m) * f;
+            if (wo.z <= 0.f || wi.z <= 0.f) smith = 0.f;
+        }
+        result += smith * w * 0.25f;
+    }
+    return result;
+}
+void orc_roughplastic_tables(float alpha, float eta, float *table64, float *internal_reflectance) {
+    ggx_t g = ggx_make(alpha, alpha);
+    float sum = 0.f;
+    for (int i = 0; i < 64; ++i) {
+        float mu = f_max(1e-6f, fmaf((float) i, 1.f / 63.f, 0.f));
+        v3 wi = V(sqrtf(1.f - mu * mu), 0.f, mu);
+        table64[i] = rough_integral(g, wi, eta, 1);
+        sum += rough_integral(g, wi, 1.f / eta, 0) * wi.z;
+    }
+    *internal_reflectance = sum * (1.f / 64.f) * 2.f;
 }

@@ -29,7 +29,7 @@ enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1 };
 enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 };
 enum { ORC_TIME_UNIFORM = 0, ORC_TIME_STRATIFIED = 1, ORC_TIME_ANTITHETIC = 2,
        ORC_TIME_ANTITHETIC_MIRROR = 3 };
-enum { ORC_BSDF_DIFFUSE = 0, ORC_BSDF_CONDUCTOR = 1, ORC_BSDF_DIELECTRIC = 2, ORC_BSDF_PLASTIC = 3, ORC_BSDF_ROUGHCONDUCTOR = 4 };
+enum { ORC_BSDF_DIFFUSE = 0, ORC_BSDF_CONDUCTOR = 1, ORC_BSDF_DIELECTRIC = 2, ORC_BSDF_PLASTIC = 3, ORC_BSDF_ROUGHCONDUCTOR = 4, ORC_BSDF_ROUGHPLASTIC = 5 };
 enum { ORC_FILTER_BOX = 0, ORC_FILTER_TENT = 1, ORC_FILTER_GAUSSIAN = 2, ORC_FILTER_MITCHELL = 3, ORC_FILTER_CATMULLROM = 4 };
 
 /* All 4x4 matrices are row-major float32: m[4*r + c]. */
@@ -72,6 +72,9 @@ typedef struct {
     /* roughconductor (src/bsdfs/roughconductor.cpp) with the GGX distribution and visible-normal sampling
      * (include/mitsuba/render/microfacet.h): cond_eta / cond_k / spec_refl as for the conductor + the two roughness values */
     float   alpha_u, alpha_v;
+    /* roughplastic (src/bsdfs/roughplastic.cpp), GGX + visible normals: the plastic fields with fdr_int = m_internal_reflectance,
+     * alpha_u = alpha, and m_external_transmittance (64 values, orc_roughplastic_tables) */
+    const float *rough_table;
 } orc_shape;
 
 typedef struct {
@@ -208,6 +211,11 @@ float    orc_fresnel_conductor(float cos_theta_i, float eta, float k);
 
 /* SmoothPlastic::parameters_changed (plastic.cpp:201-217) + fresnel_diffuse_reflectance (fresnel.h:328-355), float32:
  * out3 = 1 / eta^2, fdr_int = fresnel_diffuse_reflectance(1 / eta), specular sampling weight s_mean / (d_mean + s_mean) */
+/* RoughPlastic::parameters_changed (src/bsdfs/roughplastic.cpp:222-257) for a GGX distribution: table64 = m_external_transmittance
+ * (eval_transmittance, include/mitsuba/render/microfacet.h:515-566, on mu = max(1e-6, linspace(0, 1, 64))), *internal_reflectance =
+ * mean(eval_reflectance(1 / eta) * mu) * 2 (microfacet.h:463-512); Gauss-Legendre nodes from core/quad.h:27-86 */
+void     orc_roughplastic_tables(float alpha, float eta, float *table64, float *internal_reflectance);
+void     orc_gauss_legendre(int n, float *nodes, float *weights);
 void     orc_plastic_params(float eta, const float *diffuse3, const float *specular3, float *out3);
 
 /* Sphere ctor + update (sphere.cpp:121-160), all in float32 as ScalarTransform4f is: composed = to_world * translate(center) *

@@ -29,7 +29,7 @@ class OrcShape(C.Structure):
                 ("bsdf", C.c_int32), ("cond_eta", C.c_float * 3), ("cond_k", C.c_float * 3), ("spec_refl", C.c_float * 3),
                 ("spec_trans", C.c_float * 3), ("diel_eta", C.c_float), ("nonlinear", C.c_int32),
                 ("inv_eta_2", C.c_float), ("fdr_int", C.c_float), ("spec_sampling_weight", C.c_float),
-                ("alpha_u", C.c_float), ("alpha_v", C.c_float)]
+                ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("rough_table", C.POINTER(C.c_float))]
 
 
 class OrcGroup(C.Structure):
@@ -81,6 +81,19 @@ LANE_DTYPE = np.dtype([("sample_pos", "<f4", 2), ("time", "<f4"), ("ray_o", "<f4
                        ("rgb", "<f4", 3), ("path_length", "<f4"), ("depth", "<u4"), ("valid", "<u4")])
 
 
+_ROUGH_CACHE = {}
+
+
+def rough_plastic_tables(alpha, eta):
+    """(m_external_transmittance[64], m_internal_reflectance) of a GGX roughplastic -- orc_roughplastic_tables"""
+    key = (float(np.float32(alpha)), float(np.float32(eta)))
+    if key not in _ROUGH_CACHE:
+        table, ir = np.zeros(64, np.float32), C.c_float()
+        lib().orc_roughplastic_tables(C.c_float(key[0]), C.c_float(key[1]), table.ctypes.data, C.byref(ir))
+        _ROUGH_CACHE[key] = (table, np.float32(ir.value))
+    return _ROUGH_CACHE[key]
+
+
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
     so = os.path.join(_HERE, "libdtof_oracle.so")
@@ -127,6 +140,8 @@ def lib():
                                  C.c_void_p, C.c_void_p, C.c_int]
         L.orc_bake_cube.argtypes = [C.c_void_p] * 6
         L.orc_plastic_params.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_roughplastic_tables.argtypes = [C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_float)]
+        L.orc_gauss_legendre.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.orc_fresnel_dielectric.argtypes = [C.c_float, C.c_float, C.c_void_p]
         L.orc_fresnel_conductor.restype = C.c_float
         L.orc_fresnel_conductor.argtypes = [C.c_float, C.c_float, C.c_float]
@@ -177,6 +192,19 @@ class Scene:
                 L.orc_plastic_params(C.c_float(o.diel_eta), o.reflectance, o.spec_refl, out3)
                 o.inv_eta_2, o.fdr_int, o.spec_sampling_weight = out3[0], out3[1], out3[2]
                 s["plastic_params"] = np.array(list(out3), np.float32)
+            if o.bsdf == 5:   # roughplastic: RoughPlastic::parameters_changed in C float32 (cached per (alpha, eta))
+                o.nonlinear = int(s.get("nonlinear", 0))
+                table, ir = rough_plastic_tables(o.alpha_u, o.diel_eta)
+                self._keep.append(table)
+                o.rough_table = C.cast(table.ctypes.data, C.POINTER(C.c_float))
+                eta = np.float32(o.diel_eta)
+                o.inv_eta_2 = float(np.float32(1.0) / (eta * eta))
+                d, sp = np.asarray(s["reflectance"], np.float32), np.asarray(s["spec_refl"], np.float32)
+                third = np.float32(1.0 / 3.0)
+                d_mean = ((d[0] + d[1]) + d[2]) * third
+                s_mean = ((sp[0] + sp[1]) + sp[2]) * third if s.get("has_spec_refl") else np.float32(1.0)
+                o.fdr_int, o.spec_sampling_weight = float(ir), float(s_mean / (d_mean + s_mean))
+                s["rough_table"], s["plastic_params"] = table, np.array([o.inv_eta_2, o.fdr_int, o.spec_sampling_weight], np.float32)
             o.radiance = (C.c_float * 3)(*np.asarray(s.get("radiance", [0, 0, 0]), np.float32).tolist())
             if s["kind"] == 2:   # sphere: compose / decompose the transform in C float32 (orc_bake_sphere)
                 tw = np.ascontiguousarray(s["to_world"], dtype=np.float32)

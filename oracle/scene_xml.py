@@ -391,6 +391,32 @@ def _bsdf_of(props, registry):
             raise ValueError("The interior and exterior indices of refraction must be positive!")
         rec.update(bsdf=3, diel_eta=F32(int_ior / ext_ior), reflectance=_color(props, "diffuse_reflectance", 0.5),
                    spec_refl=_color(props, "specular_reflectance", 1.0), nonlinear=int(props.get_b("nonlinear", False)))
+    elif props.plugin == "roughplastic":   # src/bsdfs/roughplastic.cpp:170-220
+        int_ior, ext_ior = _lookup_ior(props, "int_ior", "polypropylene"), _lookup_ior(props, "ext_ior", "air")
+        if int_ior < 0 or ext_ior < 0 or int_ior == ext_ior:
+            raise ValueError("The interior and exterior indices of refraction must be positive and differ!")
+        rec.update(bsdf=5, diel_eta=F32(int_ior / ext_ior), reflectance=_color(props, "diffuse_reflectance", 0.5),
+                   has_spec_refl=int("specular_reflectance" in props), spec_refl=_color(props, "specular_reflectance", 1.0),
+                   nonlinear=int(props.get_b("nonlinear", False)))
+        distr = props.get_s("distribution", "beckmann").lower()
+        if distr not in ("beckmann", "ggx"):
+            raise ValueError('Specified an invalid distribution "%s", must be "beckmann" or "ggx"!' % distr)
+        if distr != "ggx":
+            raise ValueError('roughplastic: only distribution "ggx" is implemented (the Beckmann distribution needs Dr.Jit\'s erf / erfinv '
+                             'approximations, whose source is not part of the reference tree)')
+        if not props.get_b("sample_visible", True):
+            raise ValueError("roughplastic: only sample_visible = true is implemented")
+        if "alpha_u" in props or "alpha_v" in props:
+            if not ("alpha_u" in props and "alpha_v" in props):
+                raise ValueError("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.")
+            if "alpha" in props:
+                raise ValueError("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.")
+            au, av = F32(props.get_f("alpha_u", 0.1)), F32(props.get_f("alpha_v", 0.1))
+            if au != av:
+                raise ValueError("The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!")
+        else:
+            au = av = F32(props.get_f("alpha", 0.1))
+        rec.update(alpha_u=au, alpha_v=av)
     else:
         raise ValueError('unsupported BSDF plugin "%s"' % props.plugin)
     return rec
@@ -455,7 +481,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
                 reflectance=refl, to_world=_m32(tw), to_object=_m32(tinv), emitter=emitter, radiance=radiance, mesh_raw=mesh_raw,
                 sphere=sphere, bsdf=brec["bsdf"], cond_eta=brec["cond_eta"], cond_k=brec["cond_k"], spec_refl=brec["spec_refl"],
                 spec_trans=brec["spec_trans"], diel_eta=brec["diel_eta"], nonlinear=brec.get("nonlinear", 0),
-                alpha_u=brec.get("alpha_u", F32(0.1)), alpha_v=brec.get("alpha_v", F32(0.1)))
+                alpha_u=brec.get("alpha_u", F32(0.1)), alpha_v=brec.get("alpha_v", F32(0.1)), has_spec_refl=brec.get("has_spec_refl", 0))
 
 
 def load(source, params=None, is_string=False):

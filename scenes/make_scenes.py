@@ -182,6 +182,26 @@ ROUGH = ('\t<bsdf type="twosided" id="RoughCopperBSDF">\n\t\t<bsdf type="roughco
          '\t\t\t<rgb name="k" value="7.6, 6.3, 5.4" />\n\t\t\t<rgb name="specular_reflectance" value="0.9, 0.9, 0.95" />\n\t\t</bsdf>\n\t</bsdf>\n')
 
 
+ROUGHPLASTIC = ('\t<bsdf type="twosided" id="GlossyPaintBSDF">\n\t\t<bsdf type="roughplastic">\n\t\t\t<string name="distribution" value="ggx" />\n'
+                '\t\t\t<float name="alpha" value="0.15" />\n\t\t\t<rgb name="diffuse_reflectance" value="0.1, 0.27, 0.36" />\n'
+                '\t\t\t<float name="int_ior" value="1.9" />\n\t\t</bsdf>\n\t</bsdf>\n'
+                '\t<bsdf type="twosided" id="SatinFloorBSDF">\n\t\t<bsdf type="roughplastic">\n\t\t\t<string name="distribution" value="ggx" />\n'
+                '\t\t\t<float name="alpha" value="0.35" />\n\t\t\t<rgb name="diffuse_reflectance" value="0.6, 0.55, 0.5" />\n'
+                '\t\t\t<rgb name="specular_reflectance" value="0.9, 0.85, 0.8" />\n\t\t\t<boolean name="nonlinear" value="true" />\n\t\t</bsdf>\n\t</bsdf>\n')
+
+
+def cornell_roughplastic(res=128, spp=16):
+    """cornell_boxes.xml with rough-plastic (GGX coating over a diffuse base) boxes and floor under the ceiling area light"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        s += bsdf(*b)
+    s += ROUGHPLASTIC
+    for name, m, b in WALLS:
+        s += rect(name, m, "SatinFloorBSDF" if name == "Floor" else b)
+    s += cube("ShortBox", SHORT, "GlossyPaintBSDF", "0.015") + cube("TallBox", TALL, "GlossyPaintBSDF", "-0.015")
+    return s + AREA_LIGHT + "</scene>\n"
+
+
 def cornell_rough(res=128, spp=16):
     """cornell_boxes.xml with rough-copper (GGX) boxes and a brushed-metal (anisotropic GGX) floor under the ceiling area light:
     glossy lobes get next-event estimation AND emitter hits, i.e. both directions of the MIS"""
@@ -247,6 +267,7 @@ def main():
         "cornell_specular.xml": cornell_specular(),
         "cornell_plastic.xml": cornell_plastic(),
         "cornell_rough.xml": cornell_rough(),
+        "cornell_roughplastic.xml": cornell_roughplastic(),
         "cornell_spheres.xml": cornell_spheres(),
         "cornell_sphere_light.xml": cornell_spheres(sphere_light=True),
         "domino.xml": domino(),
@@ -260,7 +281,7 @@ def main():
 
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
-    names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml",
+    names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml",
              "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
