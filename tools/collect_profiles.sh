@@ -10,3 +10,17 @@ stats=$(find "$out/${tag}_stats" -name '*kernel_stats.csv' | head -1)
 cp "$stats" "profiles/${tag}_bench_n1_kernel_stats.csv"
 python3 tools/pmc_summary.py "$out/${tag}_pmc_fetch" "$out/${tag}_pmc_write" profiles/roofline_traffic.json
 ls -la profiles
+# the other configs (tools/profile_configs.sh), when present
+for c in c1 c3 c4 c5; do
+    if [ -f "$out/${tag}_cfg_${c}_bench.json" ]; then
+        cp "$out/${tag}_cfg_${c}_bench.json" "profiles/${tag}_bench_${c}.json"
+        s=$(find "$out/${tag}_cfg_${c}_stats" -name '*kernel_stats.csv' | head -1)
+        [ -n "$s" ] && cp "$s" "profiles/${tag}_bench_${c}_kernel_stats.csv"
+    fi
+done
+if [ -f "$out/${tag}_cfg_mesh_time.txt" ]; then
+    tail -1 "$out/${tag}_cfg_mesh_time.txt" > "profiles/${tag}_mesh_522k_tris.txt"
+    s=$(find "$out/${tag}_cfg_mesh_stats" -name '*kernel_stats.csv' | head -1)
+    [ -n "$s" ] && cp "$s" "profiles/${tag}_mesh_522k_tris_kernel_stats.csv"
+fi
+ls -la profiles
