@@ -79,6 +79,7 @@ typedef struct {
     int32_t  wave_type, low_frequency_component_only, time_sampling, stratify_each_interval;
     uint32_t path_correlation_depth, max_depth, rr_depth, base_seed;
     int32_t  time_correlate_number, path_correlate_number;
+    uint32_t bvh_stack_depth;       /* entries a traversal stack can need: TLAS depth + deepest per-mesh BLAS */
 } dtof_scene_info;
 int dtof_scene_get_info(const dtof_scene *scene, dtof_scene_info *info);
 
@@ -168,6 +169,13 @@ int  dtof_sampler_next_2d_correlate(dtof_sampler *s, const uint8_t *correlate, i
 int  dtof_sampler_next_1d_time(dtof_sampler *s, int strategy, float antithetic_shift, int stratify_each_interval, float *out); /* :92-153 */
 /* state readback: 7 uint32 per lane = rng.state lo,hi, rng_time.state lo,hi, rng_path.state lo,hi, permutation seed */
 int  dtof_sampler_get_state(dtof_sampler *s, uint32_t *out7);
+/* Sampler::fork (src/samplers/correlated.cpp:25-32): same configuration, unseeded.  Sampler::clone (:34-36): same configuration and
+ * the same per-lane state, so both produce the same numbers from here on.  set_sample_count / seeded: include/mitsuba/render/sampler.h:129,141.
+ * (schedule_state / loop_put of the reference are Dr.Jit loop plumbing and have no counterpart here.) */
+int  dtof_sampler_fork(const dtof_sampler *s, dtof_sampler **out);
+int  dtof_sampler_clone(const dtof_sampler *s, dtof_sampler **out);
+int  dtof_sampler_set_sample_count(dtof_sampler *s, uint32_t sample_count);
+int  dtof_sampler_seeded(const dtof_sampler *s);
 uint32_t dtof_sampler_wavefront_size(const dtof_sampler *s);
 uint32_t dtof_sampler_sample_count(const dtof_sampler *s);
 

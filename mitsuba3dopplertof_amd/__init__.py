@@ -51,7 +51,7 @@ class _Info(C.Structure):
                 ("wave_type", C.c_int32), ("low_frequency_component_only", C.c_int32), ("time_sampling", C.c_int32),
                 ("stratify_each_interval", C.c_int32), ("path_correlation_depth", C.c_uint32), ("max_depth", C.c_uint32),
                 ("rr_depth", C.c_uint32), ("base_seed", C.c_uint32), ("time_correlate_number", C.c_int32),
-                ("path_correlate_number", C.c_int32)]
+                ("path_correlate_number", C.c_int32), ("bvh_stack_depth", C.c_uint32)]
 
 
 def lib_path():
@@ -114,6 +114,10 @@ def _lib():
     L.dtof_sampler_wavefront_size.restype = C.c_uint32
     L.dtof_sampler_sample_count.argtypes = [vp]
     L.dtof_sampler_sample_count.restype = C.c_uint32
+    L.dtof_sampler_fork.argtypes = [vp, C.POINTER(vp)]
+    L.dtof_sampler_clone.argtypes = [vp, C.POINTER(vp)]
+    L.dtof_sampler_set_sample_count.argtypes = [vp, C.c_uint32]
+    L.dtof_sampler_seeded.argtypes = [vp]
     L.dtof_eval_modulation.argtypes = [vp, C.c_int, vp, vp, vp, C.c_uint32]
     _LIB = L
     return L
@@ -327,6 +331,26 @@ class Sampler:
 
     def set_samples_per_wavefront(self, spw):
         _check(_lib().dtof_sampler_set_samples_per_wavefront(self._h, spw))
+
+    def set_sample_count(self, spp):
+        _check(_lib().dtof_sampler_set_sample_count(self._h, spp))
+
+    def seeded(self):
+        return bool(_lib().dtof_sampler_seeded(self._h))
+
+    def _from_handle(self, fn):
+        other = Sampler.__new__(Sampler)
+        other._h = C.c_void_p()
+        _check(fn(self._h, C.byref(other._h)))
+        return other
+
+    def fork(self):
+        """same configuration, unseeded (src/samplers/correlated.cpp:25-32)"""
+        return self._from_handle(_lib().dtof_sampler_fork)
+
+    def clone(self):
+        """same configuration and the same per-lane state (src/samplers/correlated.cpp:34-36)"""
+        return self._from_handle(_lib().dtof_sampler_clone)
 
     def seed(self, seed, wavefront_size=0xffffffff):
         _check(_lib().dtof_sampler_seed(self._h, seed, wavefront_size))

@@ -35,6 +35,7 @@ struct RenderParams {
     int32_t sampler_kind, jitter; float inv_spp;  // SamplerKind; timestratified: jitter, 1 / sample_count (timestratified.cpp:78-82)
     int32_t has_spec;                             // scene has delta BSDFs (conductor / dielectric): eta and prev_bsdf_delta become per-lane state
     int32_t has_tris;                             // scene has triangle meshes (selects the kernel instantiations that carry mesh code)
+    int32_t has_blas;                             // some mesh is traversed through its own BLAS: the unstaged k_trace / k_shadow run one wave per block
     int32_t integrator;                           // 0 dopplertofpath, 1 path (src/integrators/path.cpp), 2 velocity (velocity.cpp)
     // ---- batch
     uint32_t lane_base, n_lanes;                  // this batch covers global lanes [lane_base, lane_base + n_lanes)

@@ -441,15 +441,19 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) 
 // segment of the output queue and records the count -- order preserving, deterministic and without a
 // single global atomic (a shared counter serialises at ~88 returning atomics/us on MI355X, which
 // made the first version of this kernel 10x slower than its memory traffic).
-constexpr uint32_t kSeg = 512, kSub = kSeg / kBlock;
+constexpr uint32_t kSeg = 512;
 constexpr int kShadeBlock = 64;   // k_shade runs ONE wave per block: compaction is ballot+popcount only, no barrier in the chunk loop
 DTOF_D uint32_t seg_count(const uint32_t *counts, uint32_t seg, uint32_t n_lanes) {
     return counts ? counts[seg] : min(kSeg, n_lanes - seg * kSeg);
 }
 
-template <bool LDS, bool MESH>
-__global__ __launch_bounds__(kBlock) void k_trace(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words,
-                                                  Queues q, const uint32_t *qin, const uint32_t *count_in, uint32_t n_lanes) {
+// BLOCK: 256 threads when the scene is staged into LDS (the staging is shared by four waves), ONE wave otherwise -- the waves of a
+// block share nothing then, and a block only frees its LDS and wave slots when its slowest wave is done, which costs occupancy
+// on divergent traversals (large scenes).
+template <bool LDS, bool MESH, int BLOCK>
+__global__ __launch_bounds__(BLOCK, BLOCK == 64 ? 6 : 1) void k_trace(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words,
+                                                 Queues q, const uint32_t *qin, const uint32_t *count_in, uint32_t n_lanes) {
+    constexpr uint32_t kBlock = BLOCK, kSub = kSeg / BLOCK;
     extern __shared__ uint4 lds[];
     uint32_t seg = blockIdx.x / kSub, sub = blockIdx.x % kSub;
     uint32_t count = seg_count(count_in, seg, n_lanes);
@@ -1074,9 +1078,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
 }
 
 // ---------------------------------------------------------------------------- shadow
-template <bool LDS, bool MESH>
-__global__ __launch_bounds__(kBlock) void k_shadow(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp,
-                                                   Queues q, const uint32_t *count_in) {
+template <bool LDS, bool MESH, int BLOCK>
+__global__ __launch_bounds__(BLOCK, BLOCK == 64 ? 6 : 1) void k_shadow(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp,
+                                                  Queues q, const uint32_t *count_in) {
+    constexpr uint32_t kBlock = BLOCK, kSub = kSeg / BLOCK;
     extern __shared__ uint4 lds[];
     uint32_t seg = blockIdx.x / kSub, sub = blockIdx.x % kSub;
     uint32_t count = count_in[seg];
@@ -1294,6 +1299,16 @@ __global__ void k_lane_dump_rays(RenderParams rp, Queues q, LaneDebug *out) {
 // ---------------------------------------------------------------------------- launchers
 static inline uint32_t nblk(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 constexpr uint32_t kLdsSceneLimit = 48 * 1024;
+// Block size of the unstaged k_trace / k_shadow instantiations.  One wave per block when some mesh has its own BLAS: those
+// traversals are long and divergent, and a 256-thread block keeps its LDS and wave slots until its slowest wave is done (mesh room,
+// 522 k triangles: 20.1 -> 16.6 ms per frame).  Scenes of many small objects (Domino: 1 025 instances of a 12-triangle cube) are
+// faster with four waves sharing a CU's L1 on the same TLAS / object records (71.3 vs 75.3 ms).  DTOF_TRACE_BLOCK = 64 | 128 | 256
+// overrides (experiments).
+static inline uint32_t unstaged_block(const RenderParams &rp) {
+    static const uint32_t env = [] { const char *e = getenv("DTOF_TRACE_BLOCK"); int b = e ? atoi(e) : 0; return (uint32_t) (b == 64 || b == 128 || b == 256 ? b : 0); }();
+    return env ? env : (rp.has_blas ? 64u : (uint32_t) kBlock);
+}
+
 static inline uint32_t stack_bytes(uint32_t depth, uint32_t block = kBlock) { return (depth < 2 ? 2 : depth) * block * 4; }
 
 void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s) {
@@ -1333,11 +1348,14 @@ uint32_t segments_for(uint32_t n_lanes) { return nseg(n_lanes); }
 void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                   const uint32_t *qin, const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
-    uint32_t sw = stage_words_for(scene_bytes, stack_bytes(stack_depth)), lds = sw * 16 + stack_bytes(stack_depth), grid = nseg(rp.n_lanes) * kSub;
+    const uint32_t sw = stage_words_for(scene_bytes, stack_bytes(stack_depth)), block = sw ? kBlock : unstaged_block(rp);
+    const uint32_t lds = sw * 16 + stack_bytes(stack_depth, block), grid = nseg(rp.n_lanes) * (kSeg / block);
     check_lds(lds);
-#define DTOF_LAUNCH_TRACE(L, M) hipLaunchKernelGGL((k_trace<L, M>), dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, q, qin, count_in, rp.n_lanes)
-    if (sw) { if (rp.has_tris) DTOF_LAUNCH_TRACE(true, true); else DTOF_LAUNCH_TRACE(true, false); }
-    else    { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true); else DTOF_LAUNCH_TRACE(false, false); }
+#define DTOF_LAUNCH_TRACE(L, M, B) hipLaunchKernelGGL((k_trace<L, M, B>), dim3(grid), dim3(B), lds, s, scene, scene_bytes, sw, q, qin, count_in, rp.n_lanes)
+    if (sw) { if (rp.has_tris) DTOF_LAUNCH_TRACE(true, true, kBlock); else DTOF_LAUNCH_TRACE(true, false, kBlock); }
+    else if (block == 64)  { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true, 64); else DTOF_LAUNCH_TRACE(false, false, 64); }
+    else if (block == 128) { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true, 128); else DTOF_LAUNCH_TRACE(false, false, 128); }
+    else                   { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true, kBlock); else DTOF_LAUNCH_TRACE(false, false, kBlock); }
 #undef DTOF_LAUNCH_TRACE
 }
 void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
@@ -1365,11 +1383,14 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
 void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                    const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
-    uint32_t sw = stage_words_for(scene_bytes, stack_bytes(stack_depth)), lds = sw * 16 + stack_bytes(stack_depth), grid = nseg(rp.n_lanes) * kSub;
+    const uint32_t sw = stage_words_for(scene_bytes, stack_bytes(stack_depth)), block = sw ? kBlock : unstaged_block(rp);
+    const uint32_t lds = sw * 16 + stack_bytes(stack_depth, block), grid = nseg(rp.n_lanes) * (kSeg / block);
     check_lds(lds);
-#define DTOF_LAUNCH_SHADOW(L, M) hipLaunchKernelGGL((k_shadow<L, M>), dim3(grid), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q, count_in)
-    if (sw) { if (rp.has_tris) DTOF_LAUNCH_SHADOW(true, true); else DTOF_LAUNCH_SHADOW(true, false); }
-    else    { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true); else DTOF_LAUNCH_SHADOW(false, false); }
+#define DTOF_LAUNCH_SHADOW(L, M, B) hipLaunchKernelGGL((k_shadow<L, M, B>), dim3(grid), dim3(B), lds, s, scene, scene_bytes, sw, rp, q, count_in)
+    if (sw) { if (rp.has_tris) DTOF_LAUNCH_SHADOW(true, true, kBlock); else DTOF_LAUNCH_SHADOW(true, false, kBlock); }
+    else if (block == 64)  { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true, 64); else DTOF_LAUNCH_SHADOW(false, false, 64); }
+    else if (block == 128) { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true, 128); else DTOF_LAUNCH_SHADOW(false, false, 128); }
+    else                   { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true, kBlock); else DTOF_LAUNCH_SHADOW(false, false, kBlock); }
 #undef DTOF_LAUNCH_SHADOW
 }
 void launch_velocity(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q, uint32_t stack_depth, hipStream_t s) {

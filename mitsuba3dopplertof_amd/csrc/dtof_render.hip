@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <string>
+#include <memory>
 #include <vector>
 
 using namespace dtof;
@@ -281,6 +282,10 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     bool has_spheres = false;
     for (auto &sh : sc->host.shapes) has_spheres |= sh.kind == SHAPE_SPHERE;
     rp.has_tris = bh->n_tris != 0 || has_spheres;   // anything but rectangles: the instantiations with triangle / sphere code
+    {   // deep per-mesh traversals diverge: see unstaged_block() in dtof_kernels.hip
+        const DShape *dshapes = (const DShape *) (sc->blob.data() + bh->off_shapes);
+        for (uint32_t i = 0; i < bh->n_shapes; ++i) rp.has_blas |= dshapes[i].kind == SHAPE_MESH && dshapes[i].blas_root != kNoChild;
+    }
     StageTimer tm(stats != nullptr, sc);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     struct EventGuard { hipEvent_t e = nullptr; ~EventGuard() { if (e) (void) hipEventDestroy(e); } } g_fork, g_join;   // released on every exit path
@@ -500,6 +505,7 @@ int dtof_scene_get_info(const dtof_scene *sc, dtof_scene_info *info) {
         info->time_sampling = p.time_sampling; info->stratify_each_interval = p.stratify_each_interval;
         info->path_correlation_depth = p.path_correlation_depth; info->max_depth = p.max_depth; info->rr_depth = p.rr_depth;
         info->base_seed = p.base_seed; info->time_correlate_number = p.time_correlate_number; info->path_correlate_number = p.path_correlate_number;
+        info->bvh_stack_depth = h->tlas_depth;
     });
 }
 
@@ -683,6 +689,41 @@ int dtof_sampler_get_state(dtof_sampler *s, uint32_t *out7) {
         }
     });
 }
+// Sampler::fork (correlated.cpp:25-32: same configuration, fresh unseeded state) and Sampler::clone (:34-36: same configuration AND
+// the current per-lane state: three PCG streams, permutation seed, dimension / sample index)
+int dtof_sampler_fork(const dtof_sampler *s, dtof_sampler **out) {
+    return guarded([&] {
+        if (!s || !out) throw std::runtime_error("null argument");
+        auto f = new dtof_sampler(); f->sample_count = s->sample_count; f->base_seed = s->base_seed; f->tcn = s->tcn; f->pcn = s->pcn;
+        *out = f;
+    });
+}
+int dtof_sampler_clone(const dtof_sampler *s, dtof_sampler **out) {
+    return guarded([&] {
+        if (!s || !out) throw std::runtime_error("null argument");
+        std::unique_ptr<dtof_sampler> c(new dtof_sampler());
+        c->sample_count = s->sample_count; c->base_seed = s->base_seed; c->tcn = s->tcn; c->pcn = s->pcn;
+        c->seed = s->seed; c->wavefront = s->wavefront; c->spw = s->spw; c->sample_index = s->sample_index; c->seeded = s->seeded;
+        if (s->seeded) {
+            const size_t n = s->wavefront;
+            c->rng.ensure(n); c->rng_time.ensure(n); c->rng_path.ensure(n); c->perm.ensure(n); c->dim.ensure(n); c->out.ensure(2 * n); c->flags.ensure(n);
+            HIP_CHECK(hipMemcpy(c->rng.p, s->rng.p, n * 8, hipMemcpyDeviceToDevice));
+            HIP_CHECK(hipMemcpy(c->rng_time.p, s->rng_time.p, n * 8, hipMemcpyDeviceToDevice));
+            HIP_CHECK(hipMemcpy(c->rng_path.p, s->rng_path.p, n * 8, hipMemcpyDeviceToDevice));
+            HIP_CHECK(hipMemcpy(c->perm.p, s->perm.p, n * 4, hipMemcpyDeviceToDevice));
+            HIP_CHECK(hipMemcpy(c->dim.p, s->dim.p, n * 4, hipMemcpyDeviceToDevice));
+        }
+        *out = c.release();
+    });
+}
+int dtof_sampler_set_sample_count(dtof_sampler *s, uint32_t spp) {   // Sampler::set_sample_count (sampler.h:129)
+    return guarded([&] {
+        if (!s) throw std::runtime_error("null sampler");
+        if (spp == 0 || spp % s->spw != 0) throw std::runtime_error("sample_count should be a multiple of samples_per_wavefront!");
+        s->sample_count = spp;
+    });
+}
+int dtof_sampler_seeded(const dtof_sampler *s) { return s && s->seeded ? 1 : 0; }   // Sampler::seeded (sampler.h:141)
 uint32_t dtof_sampler_wavefront_size(const dtof_sampler *s) { return s ? s->wavefront : 0; }
 uint32_t dtof_sampler_sample_count(const dtof_sampler *s) { return s ? s->sample_count : 0; }
 

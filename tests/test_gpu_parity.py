@@ -143,6 +143,20 @@ def test_sampler_abi_streams_match_oracle(mi, orc):
     assert np.array_equal(pair[:, 0], pair[:, 1])
     with pytest.raises(mi.DtofError):
         mi.Sampler(sample_count=4).next_1d()                     # not seeded
+    # fork: same configuration, unseeded; clone: same state, so the streams continue identically (correlated.cpp:25-36)
+    f = s.fork()
+    assert not f.seeded() and f.sample_count() == 4 and s.seeded()
+    with pytest.raises(mi.DtofError):
+        f.next_1d()
+    f.seed(0, 256)
+    assert np.array_equal(f.next_1d_correlate(flags), mixed)     # a freshly seeded fork replays the first draw of `s`
+    c = s.clone()
+    assert c.seeded() and c.wavefront_size() == 256 and np.array_equal(c.state(), s.state())
+    assert np.array_equal(c.next_2d_correlate(flags), s.next_2d_correlate(flags)) and np.array_equal(c.next_1d_time(2, 0.5, True), s.next_1d_time(2, 0.5, True))
+    c.advance()
+    assert not np.array_equal(c.next_1d_time(1, 0.0, True), s.next_1d_time(1, 0.0, True))   # different sample index from here on
+    s.set_sample_count(8)
+    assert s.sample_count() == 8 and c.sample_count() == 4
 
 
 def test_modulation_functions_match_oracle(mi, orc):
