@@ -51,6 +51,13 @@ CONFIGS = [
     ("domino_small", "domino_small.xml", dict(resx=48, resy=48), 4),
     ("area_light_doppler", "cornell_area.xml", dict(resx=32, resy=32), 16),
     ("area_light_depth6_rr", "cornell_area.xml", dict(resx=24, resy=24, max_depth=6, time_sampling_method="stratified", path_correlation_depth=2), 8),
+    # SURVEY 8(f)#3 material / shape families (their own test files hold the analytic checks; these pin the streams)
+    ("specular_mirror_glass", "cornell_specular.xml", dict(resx=24, resy=24, max_depth=8), 8),
+    ("plastic_boxes", "cornell_plastic.xml", dict(resx=24, resy=24), 8),
+    ("rough_conductor_boxes", "cornell_rough.xml", dict(resx=24, resy=24, max_depth=5), 8),
+    ("rough_plastic_boxes", "cornell_roughplastic.xml", dict(resx=24, resy=24, max_depth=5), 8),
+    ("spheres", "cornell_spheres.xml", dict(resx=24, resy=24), 8),
+    ("sphere_light", "cornell_sphere_light.xml", dict(resx=24, resy=24, max_depth=5), 8),
 ]
 
 
