@@ -17,7 +17,8 @@ from conftest import CONFIGS, GOLDEN, SCENES
 
 pytestmark = pytest.mark.gpu
 
-IMG_TOL = 1e-5     # relative to max|ref|; north_star's bar is 1e-3
+IMG_TOL = 5e-5     # relative to max|ref|: the lanes are bit-exact, only the float32 order of the film sums differs (antithetic pairs of a
+                   # bright light cancel to small pixel values); north_star's bar is 1e-3
 NCPU = os.cpu_count() or 1
 
 
