@@ -225,7 +225,7 @@ DTOF_HD void pcg_seed(uint32_t initstate, uint32_t initseq, uint64_t &state, uin
 }
 // permute_kensler -- random.h:113-171
 DTOF_HD uint32_t permute_kensler(uint32_t index, uint32_t n, uint32_t seed) {
-    if (n == 1) return 0;
+    if (n <= 1) return 0;   // n == 0 (sample_count < time_correlate_number) would never leave the cycle-walking loop below
     uint32_t w = n - 1;
     w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
     do {

@@ -669,6 +669,8 @@ int dtof_sampler_next_1d_time(dtof_sampler *s, int strategy, float shift, int st
     return guarded([&] {
         need_seeded(s);
         if (strategy < 0 || strategy > 3) throw std::runtime_error("unknown time sampling strategy");
+        if (strategy != TIME_UNIFORM && stratify && s->sample_count < (uint32_t) s->tcn)
+            throw std::runtime_error("sample count must be at least time_correlate_number when per-interval stratification is on");
         RenderParams rp = sampler_params(s); rp.time_sampling = strategy; rp.antithetic_shift = shift; rp.stratify = stratify;
         launch_sampler_next_time(rp, sampler_state(s), s->sample_index * s->spw, s->out.p, nullptr);
         HIP_CHECK(hipGetLastError());

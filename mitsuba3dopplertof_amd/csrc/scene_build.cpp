@@ -62,6 +62,10 @@ static uint32_t child_ref(BuildCtx &cx, size_t b, size_t e) {
     return build_node(cx, b, e);
 }
 
+static inline int bin_of(float c, float lo, float ext, int nb) {   // clamped on both sides, NaN -> 0
+    const float v = (c - lo) / ext * (float) nb;
+    return v >= 0.f ? (v < (float) (nb - 1) ? (int) v : nb - 1) : 0;
+}
 // binned SAH split over centroids (16 bins), falling back to a median split
 static uint32_t build_node(BuildCtx &cx, size_t b, size_t e) {
     std::vector<BvhNode> &nodes = cx.nodes; std::vector<BuildItem> &items = cx.items;
@@ -77,7 +81,7 @@ static uint32_t build_node(BuildCtx &cx, size_t b, size_t e) {
         if (!(ext > 0.f)) continue;
         Box bb[NB]; int cnt[NB] = { 0 };
         for (size_t i = b; i < e; ++i) {
-            int k = std::min(NB - 1, (int) ((items[i].c[ax] - lo) / ext * NB));
+            int k = bin_of(items[i].c[ax], lo, ext, NB);
             bb[k].add(items[i].box); cnt[k]++;
         }
         Box acc; int n = 0; float la[NB]; int ln[NB];
@@ -94,7 +98,7 @@ static uint32_t build_node(BuildCtx &cx, size_t b, size_t e) {
     if (best_axis >= 0) {
         float lo = cb.lo[best_axis], ext = cb.hi[best_axis] - cb.lo[best_axis]; int ax = best_axis, bin = best_bin;
         auto it = std::stable_partition(items.begin() + b, items.begin() + e, [&](const BuildItem &it2) {
-            return std::min(NB - 1, (int) ((it2.c[ax] - lo) / ext * NB)) < bin; });
+            return bin_of(it2.c[ax], lo, ext, NB) < bin; });
         mid = (size_t) (it - items.begin());
     } else {
         mid = (b + e) / 2;
@@ -199,6 +203,11 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
                 tables.insert(tables.end(), slot_of_face.begin(), slot_of_face.end());
             }
         }
+        for (float v : h.positions) if (!std::isfinite(v)) throw std::runtime_error("shape \"" + h.id + "\": non-finite vertex position (check its to_world transform)");
+        for (int k = 0; k < 12; ++k) if (!std::isfinite(h.to_world[k]) || !std::isfinite(h.to_object[k]))
+            throw std::runtime_error("shape \"" + h.id + "\": non-finite or singular to_world transform");
+        if (h.kind == SHAPE_SPHERE && !(std::isfinite(h.radius) && std::isfinite(h.center[0]) && std::isfinite(h.center[1]) && std::isfinite(h.center[2])))
+            throw std::runtime_error("shape \"" + h.id + "\": non-finite sphere centre or radius");
         shape_boxes[i] = shape_box(h);
         { Box pb = shape_boxes[i]; pb.pad(); for (int k = 0; k < 3; ++k) { d.bmin[k] = pb.lo[k]; d.bmax[k] = pb.hi[k]; } }
     }
@@ -218,6 +227,8 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         memset(&d, 0, sizeof d);
         d.kind = h.kind; d.index = h.index; d.n_keys = h.n_keys; d.t0 = h.key_time[0]; d.t1 = h.key_time[1];
         memcpy(d.key0, h.key[0], 48); memcpy(d.key1, h.key[1], 48);
+        for (uint32_t kk = 0; kk < std::min(h.n_keys, 2u); ++kk) for (int c = 0; c < 12; ++c) if (!std::isfinite(h.key[kk][c]))
+            throw std::runtime_error("object " + std::to_string(i) + ": non-finite instance / animation matrix");
         Box b;
         if (h.kind == OBJ_SHAPE) b = shape_boxes[h.index];
         else {

@@ -169,7 +169,7 @@ float orc_pcg32_next_f32(uint64_t *state, uint64_t inc) {
 }
 /* permute_kensler -- random.h:113-171 (cycle-walking form of the JIT loop :151-158) */
 uint32_t orc_permute_kensler(uint32_t index, uint32_t n, uint32_t seed) {
-    if (n == 1) return 0;
+    if (n <= 1) return 0;   /* n == 0 never leaves the cycle-walking loop (the reference hangs there too): callers reject it */
     uint32_t w = n - 1;
     w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
     do {

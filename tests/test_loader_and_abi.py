@@ -216,3 +216,23 @@ def test_plugin_objects_validate_like_the_reference_constructors(mi):
     L.dtof_sampler_plugin_destroy(h)
     args = mi._plugin_args(dict(type="independent", time_correlate_number=2))
     assert L.dtof_sampler_plugin_create(*(args + (ctypes.byref(h),))) != 0 and b"unreferenced property" in L.dtof_last_error()
+
+
+def test_non_finite_geometry_is_rejected_not_crashed(mi):
+    """Found by tests/dev/gpu_fuzz.py: a matrix entry that overflows float32 used to reach the BVH builder as inf / NaN and crash
+    it; non-finite vertices, transforms and animation keys are load errors now."""
+    text = open(os.path.join(SCENES, "cornell_boxes.xml")).read()
+    import re
+    m = re.search(r'<matrix value="([^"]+)"', text[text.index('type="cube"'):])
+    first = m.group(1).split()
+    for bad in ("1e39", "nan", "-inf"):
+        broken = text.replace(m.group(1), " ".join([bad] + first[1:]), 1)
+        assert broken != text
+        with pytest.raises(mi.DtofError, match="non-finite"):
+            mi.load_string(broken)
+    wall = open(os.path.join(SCENES, "cornell_wall.xml")).read()
+    i = wall.index("<animation")
+    k = re.search(r'<translate[^>]*z="([^"]+)"', wall[i:]) or re.search(r'<matrix value="([^"]+)"', wall[i:])
+    broken = wall[:i] + wall[i:].replace(k.group(1), "1e39" if " " not in k.group(1) else " ".join(["1e39"] + k.group(1).split()[1:]), 1)
+    with pytest.raises(mi.DtofError, match="non-finite"):
+        mi.load_string(broken)
