@@ -12,6 +12,7 @@
 //              float atomics, here they are accumulated in face order in double and rounded once
 #include "dtof_scene.h"
 #include "dtof_math.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -169,17 +170,24 @@ RawMesh load_ply(const std::string &path, bool face_normals) {
         const char *b = tp; while (tp < tend && !is_blank(*tp) && *tp != '\n') ++tp;
         tok.assign(b, tp - b); return true;
     };
+    // integer view of a value read as floating point: out-of-range / NaN become an index no mesh has (checked by the callers)
+    auto to_u64 = [](double v) -> uint64_t { return v >= 0.0 && v < 18446744073709549568.0 ? (uint64_t) v : ~0ull; };
     auto ascii_value = [&](int type, float &f, uint64_t &u) {
         std::string tok; if (!next_token(tok)) fail("unexpected end of file");
-        if (type >= 6) { f = strtof(tok.c_str(), nullptr); u = (uint64_t) f; }
+        if (type >= 6) { f = strtof(tok.c_str(), nullptr); u = to_u64((double) f); }
         else { long long v = strtoll(tok.c_str(), nullptr, 10); u = (uint64_t) v; f = (float) (double) v; }
     };
     auto binary_value = [&](int type, float &f, uint64_t &u) {
         if (off + (size_t) kPlySize[type] > body_size) fail("unexpected end of file");
         double v = ply_read(body + off, type, big); off += kPlySize[type];
-        f = (float) v; u = (uint64_t) (long long) v;
+        f = (float) v; u = to_u64(v);
     };
     RawMesh out; bool have_vertices = false, have_faces = false;
+    for (auto &el : elements) {   // a (corrupted) count the file cannot hold would otherwise be allocated before the first read fails
+        size_t min_bytes = 0;
+        for (auto &p : el.props) min_bytes += ascii ? 2 : (size_t) kPlySize[p.list ? p.count_type : p.type];
+        if (el.count > body_size / std::max<size_t>(1, min_bytes)) fail("invalid PLY header: element \"" + el.name + "\" has more entries than the file can hold");
+    }
     for (auto &el : elements) {
         if (el.name == "vertex") {
             int ix[8] = { -1, -1, -1, -1, -1, -1, -1, -1 };   // x y z nx ny nz u v
@@ -221,7 +229,10 @@ RawMesh load_ply(const std::string &path, bool face_normals) {
                     if (is_face && (int) j == li && cnt != 3) fail("incompatible contents -- is this a triangle mesh?");
                     for (uint64_t k = 0; k < cnt; ++k) {
                         if (ascii) ascii_value(p.type, f, u); else binary_value(p.type, f, u);
-                        if (is_face && (int) j == li) out.faces[3 * i + k] = (uint32_t) u;
+                        if (is_face && (int) j == li) {
+                            if (u > 0xffffffffull) fail("mesh face references a vertex out of range");
+                            out.faces[3 * i + k] = (uint32_t) u;
+                        }
                     }
                 }
             if (is_face) have_faces = true;

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Writes a corpus of damaged scene files for tools/sanitize_loader.sh:  python tests/dev/fuzz_corpus.py SEED COUNT OUTDIR
+35 % numeric attribute values replaced by extreme ones, 25 % character-level damage of the XML, 40 % damaged obj / ply mesh files."""
+import os, sys, random, re
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scenes"))
+import make_scenes, make_mesh; make_scenes.ensure()
+random.seed(int(sys.argv[1])); N = int(sys.argv[2]); out = sys.argv[3]
+os.makedirs(out, exist_ok=True)
+names = ("cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_roughplastic.xml", "cornell_sphere_light.xml", "cornell_rough.xml", "cornell_plastic.xml", "cornell_spheres.xml", "domino_small.xml")
+texts = [open(os.path.join(ROOT, "scenes", n)).read() for n in names]
+num = re.compile(r'-?\d+\.?\d*(?:e-?\d+)?')
+vals = ['0', '-0', '1e-30', '1e30', '1e39', 'nan', 'inf', '-1', '4294967296', '1e-45', '0.5', '-1e39', '2', '1', '1e-8', '1e8', '3', '7', '', 'x']
+pos, nrm, uv, faces = make_mesh.blob(6, 5)
+make_mesh.write_ply(os.path.join(out, "blob.ply"), pos, nrm, uv, faces)
+make_mesh.write_obj(os.path.join(out, "a.obj"), pos, nrm, uv, faces); make_mesh.write_ply(os.path.join(out, "b.ply"), pos, nrm, uv, faces)
+make_mesh.write_ply(os.path.join(out, "c.ply"), pos, nrm, uv, faces, binary=False); make_mesh.write_ply(os.path.join(out, "d.ply"), pos, nrm, uv, faces, big_endian=True, with_uv=True)
+make_mesh.write_obj(os.path.join(out, "e.obj"), pos, nrm, uv, faces, with_normals=True, quads_as_polygons=True)
+orig = {n: open(os.path.join(out, n), "rb").read() for n in ("a.obj", "b.ply", "c.ply", "d.ply", "e.obj")}
+xml0 = make_mesh.cornell_mesh_xml(moving_file="MOVING", res=16, spp=4)
+for it in range(N):
+    r = random.random()
+    if r < 0.35:      # numeric value fuzz
+        t = random.choice(texts)
+        spans = [m.span() for m in num.finditer(t) if 'value=' in t[max(0, m.start() - 200):m.start()].split('<')[-1]]
+        for a, b in sorted(random.sample(spans, random.randint(1, 3)), reverse=True):
+            t = t[:a] + random.choice(vals) + t[b:]
+    elif r < 0.6:     # character-level fuzz
+        t = random.choice(texts)
+        if len(t) > 20000: t = t[:20000] + "</scene>"
+        b = list(t)
+        for _ in range(random.randint(1, 4)):
+            op = random.random(); i = random.randrange(len(b))
+            if op < 0.3: del b[i:i + random.randint(1, 12)]
+            elif op < 0.7: b.insert(i, random.choice(['<', '>', '"', '/', '$', '0', '-', 'e', ' ', '&', ';', '<!--', ']]>', '<?']))
+            else: b[i:i+1] = list(random.choice(['<rgb/>', '<ref id="x"/>', '<shape type="obj"/>', '<transform name="to_world"/>', '<animation name="to_world"/>']))
+        t = "".join(b)
+    else:             # mesh file fuzz
+        n = random.choice(list(orig)); typ = n.split(".")[1]
+        b = bytearray(orig[n])
+        for _ in range(random.randint(1, 5)):
+            op = random.random(); i = random.randrange(len(b))
+            if op < 0.25: del b[i:i + random.randint(1, 40)]
+            elif op < 0.5: b[i] = random.randrange(256)
+            elif op < 0.7: b[i:i] = random.choice([b"-1", b"999999999", b"4294967295", b"/", b"//", b" ", b"\n", b"f 1 2\n", b"f -1 -2 -3\n", b"f 0 0 0\n", b"nan", b"1e39", b"\x00\x00\x00\x80", b"\xff\xff\xff\xff"])
+            elif op < 0.85: b = b[:i]
+            else: b[i:i+4] = random.choice([b"\xff\xff\xff\x7f", b"\x00\x00\x80\x7f", b"\x00\x00\xc0\x7f", b"\x01\x00\x00\x00"])
+            if not b: b = bytearray(b" ")
+        fn = "m%d.%s" % (it, typ)
+        open(os.path.join(out, fn), "wb").write(bytes(b))
+        t = xml0.replace("MOVING", fn).replace('<shape type="obj" id="MovingBlob">', '<shape type="%s" id="MovingBlob">' % typ)
+    open(os.path.join(out, "s%d.xml" % it), "w", errors="ignore").write(t)

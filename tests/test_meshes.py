@@ -104,6 +104,16 @@ def test_mesh_errors_follow_the_reference(mi, tmp_path):
                                         "element face 1\nproperty list uchar int vertex_index\nend_header\n0 0 0\n1 0 0\n1 1 0\n3 0 1 2\n9 9\n")
     with pytest.raises(RuntimeError, match="trailing content"):
         load("ply", "trail.ply")
+    # found with tools/sanitize_loader.sh: a damaged header count must not be allocated (terabytes) before the first read fails,
+    # and indices that are negative, fractional-huge or not numbers must not wrap into valid ones
+    head = "ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nelement face %s\nproperty list uchar %s vertex_index\nend_header\n0 0 0\n1 0 0\n1 1 0\n3 %s\n"
+    (tmp_path / "huge.ply").write_text(head % ("300000000000", "int", "0 1 2"))
+    with pytest.raises(RuntimeError, match="more entries than the file can hold"):
+        load("ply", "huge.ply")
+    for k, idx in enumerate(("0 1 -2", "0 1 4294967298", "0 1 1e30", "0 nan 2")):
+        (tmp_path / ("idx%d.ply" % k)).write_text(head % ("1", "float" if "e" in idx or "nan" in idx else "int", idx))
+        with pytest.raises(RuntimeError, match="out of range"):
+            load("ply", "idx%d.ply" % k)
     (tmp_path / "nofile.xml").write_text(one_mesh_xml("ply", "x.ply").replace('<string name="filename" value="x.ply" />', ""))
     with pytest.raises(RuntimeError, match="filename"):
         mi.load_file(str(tmp_path / "nofile.xml"))
