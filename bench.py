@@ -73,6 +73,10 @@ def parse():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="BASELINE.json configs[0..4] as concretised in SURVEY 8(d); c2 is the headline (default). The others "
                          "are parity-test cases that can also be timed; --res/--spp still override.")
+    ap.add_argument("--sharding", choices=["auto", "bands", "stripes"], default="auto",
+                    help="N > 1: contiguous row bands + one film gather (north_star; default for the Cornell configs) or interleaved "
+                         "4-row stripes + one film reduce(sum) (load balance, SURVEY 8e; default for the Domino configs c4 / c5)")
+    ap.add_argument("--stripe-rows", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU oracle sample")
     args = ap.parse_args()
@@ -81,6 +85,8 @@ def parse():
     args.res = args.res or res
     args.spp = args.spp or spp
     args.defines, args.offsets = dict(defines), offsets
+    if args.sharding == "auto":
+        args.sharding = "stripes" if os.path.basename(args.scene).startswith("domino") else "bands"
     return args
 
 
@@ -171,8 +177,9 @@ def main():
     if world > 1:
         dist.barrier()            # rank 0 may just have written the scene files
     scene = mi.load_file(args.scene, **dict(args.defines, resx=args.res, resy=args.res))
-    if args.offsets and world > 1:
-        raise SystemExit("batched-offset configs are timed on one GPU here (the film gather below carries one film)")
+    striped = world > 1 and args.sharding == "stripes"
+    if args.offsets and world > 1 and not striped:
+        raise SystemExit("batched-offset configs shard with --sharding stripes (the band gather carries one film)")
     W, H = scene.size
     halo = 1                                     # tent filter, radius 1 (imageblock.cpp:423-426)
     spp = args.spp * world if args.scaling == "weak" else args.spp
@@ -188,20 +195,31 @@ def main():
     acc = {"ms_trace": 0.0, "ms_shade": 0.0, "ms_shadow": 0.0, "ms_generate": 0.0, "ms_splat": 0.0, "ms_total": 0.0, "ms_first": 0.0,
            "n_bounces": 0, "n_shadow_rays": 0, "n_paths": 0, "launches": 0, "first_launches": 0}
 
-    if args.offsets:
-        kfilm = torch.zeros((len(args.offsets), H, W, 4), dtype=torch.float32, device=dev)
-        krgb = torch.zeros((len(args.offsets), H, W, 3), dtype=torch.float32, device=dev)
+    K = len(args.offsets) if args.offsets else 1
+    if args.offsets or striped:
+        kfilm = torch.zeros((K, H, W, 4), dtype=torch.float32, device=dev)
+        krgb = torch.zeros((K, H, W, 3), dtype=torch.float32, device=dev)
 
     def step(record):
         film.zero_()
-        if args.offsets:
+        if args.offsets or striped:
             kfilm.zero_()
         torch.cuda.synchronize()
-        if args.offsets:   # K films in ONE traversal (config c5): library-native [K][H][W][4] layout, single GPU
-            st = scene.render_rows(kfilm.data_ptr(), seed=0, spp=spp, row_begin=0, row_end=H, offsets=args.offsets)
-            rc = lib.dtof_develop(kfilm.data_ptr(), krgb.data_ptr(), H * W * len(args.offsets))
-            if rc != 0:
-                raise RuntimeError(lib.dtof_last_error().decode())
+        if args.offsets or striped:   # library-native [K][H][W][4] films (K offsets in ONE traversal, config c5)
+            if striped:               # interleaved stripes of rows per rank, ONE reduce(sum) of the full-size films to rank 0
+                st = scene.render_stripes(kfilm.data_ptr(), 0, spp, *D.stripe_layout(world, rank, args.stripe_rows), offsets=args.offsets)
+                if share:
+                    host = kfilm.cpu(); dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                    if rank == 0:
+                        kfilm.copy_(host)
+                else:
+                    dist.reduce(kfilm, dst=0, op=dist.ReduceOp.SUM)
+            else:
+                st = scene.render_rows(kfilm.data_ptr(), seed=0, spp=spp, row_begin=0, row_end=H, offsets=args.offsets)
+            if rank == 0:
+                rc = lib.dtof_develop(kfilm.data_ptr(), krgb.data_ptr(), H * W * K)
+                if rc != 0:
+                    raise RuntimeError(lib.dtof_last_error().decode())
             if record:
                 for k in ("ms_trace", "ms_shade", "ms_shadow", "ms_generate", "ms_splat", "ms_total", "ms_first", "n_bounces", "n_shadow_rays", "n_paths"):
                     acc[k] += st[k]
@@ -243,7 +261,7 @@ def main():
     value = total_paths * args.steps / elapsed / 1e6
 
     if rank == 0:
-        img = (krgb if args.offsets else rgb).cpu().numpy()
+        img = (krgb if (args.offsets or striped) else rgb).cpu().numpy()
         # the dominant kernel = the bounce kernel k_shade<MODE 1|0>.  In the fused pipeline the FIRST launch of a frame is another
         # instantiation (MODE 2: lane generation + primary ray + bounce 0, reads no state at all); it is timed separately
         # (ms_first) and kept out of the roofline figure, as rocprofv3 lists it as a separate kernel too.
@@ -291,7 +309,7 @@ def main():
                                     (os.path.basename(args.scene) + " %dx%d, %d spp%s, " + json.dumps(args.defines) +
                                      (", offsets %s batched" % args.offsets if args.offsets else "")))
                                    % (W, H, spp, " (= %d per GPU x %d GPUs, rows sharded)" % (args.spp, world) if world > 1 and args.scaling == "weak" else ""),
-                       "paths_per_step": total_paths, "sharding": "row bands, 1 film gather" if world > 1 else "none",
+                       "paths_per_step": total_paths, "sharding": ("interleaved %d-row stripes, 1 film reduce" % args.stripe_rows if striped else "row bands, 1 film gather") if world > 1 else "none",
                        "image_checksum": float(np.abs(img).sum())},
             "roofline": roofline,
         }

@@ -136,6 +136,12 @@ int dtof_integrator_render(const dtof_integrator *integrator, const dtof_sampler
  * offsets == NULL / n_offsets == 0 uses the integrator's own phase offset. */
 int dtof_render_rows(dtof_scene *scene, uint32_t seed, uint32_t spp, int32_t row_begin, int32_t row_end,
                      const float *offsets, int n_offsets, float *d_film_rgbw, dtof_render_stats *stats);
+/* Interleaved shards (load balance when the cost of a row depends on what it sees): renders the stripes of rows
+ * [first_row + k * stripe_period, first_row + k * stripe_period + stripe_rows), k = 0, 1, ..., below crop_height and accumulates
+ * like dtof_render_rows.  Rank r of N uses first_row = r * stripe_rows, stripe_period = N * stripe_rows; the union over the
+ * ranks is the full frame, lane for lane what a single device renders. */
+int dtof_render_stripes(dtof_scene *scene, uint32_t seed, uint32_t spp, int32_t first_row, int32_t stripe_rows, int32_t stripe_period,
+                        const float *offsets, int n_offsets, float *d_film_rgbw, dtof_render_stats *stats);
 /* HDRFilm::develop (src/films/hdrfilm.cpp:305-406) on device buffers: rgb = RGB / (W == 0 ? 1 : W). */
 int dtof_develop(const float *d_film_rgbw, float *d_rgb, int64_t n_pixels);
 /* Same as dtof_render but with n_offsets batched modulation offsets; out_rgb holds n_offsets images. */

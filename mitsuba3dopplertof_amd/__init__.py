@@ -93,6 +93,7 @@ def _lib():
     L.dtof_scene_export.argtypes = [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.dtof_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.POINTER(_Stats)]
     L.dtof_render_rows.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, vp, C.c_int, vp, C.POINTER(_Stats)]
+    L.dtof_render_stripes.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int, vp, C.POINTER(_Stats)]
     L.dtof_develop.argtypes = [vp, vp, C.c_int64]
     L.dtof_render_offsets.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_int, vp, C.POINTER(_Stats)]
     L.dtof_cancel.argtypes = [vp]
@@ -216,6 +217,15 @@ class Scene:
         else:
             off = np.ascontiguousarray(offsets, dtype=np.float32)
             _check(_lib().dtof_render_rows(self._h, seed, spp, row_begin, row_end, off.ctypes.data, len(off), d_film_ptr, C.byref(st)))
+        self.last_stats = st.as_dict()
+        return self.last_stats
+
+    def render_stripes(self, d_film_ptr, seed, spp, first_row, stripe_rows, stripe_period, offsets=None):
+        """Accumulate the rows of the stripes [first_row + k * stripe_period, ... + stripe_rows) (interleaved shard of one rank)."""
+        st = _Stats()
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float32)
+        _check(_lib().dtof_render_stripes(self._h, seed, spp, first_row, stripe_rows, stripe_period,
+                                          None if off is None else off.ctypes.data, 0 if off is None else len(off), d_film_ptr, C.byref(st)))
         self.last_stats = st.as_dict()
         return self.last_stats
 

@@ -38,7 +38,11 @@ struct RenderParams {
     int32_t has_blas;                             // some mesh is traversed through its own BLAS: the unstaged k_trace / k_shadow run one wave per block
     int32_t integrator;                           // 0 dopplertofpath, 1 path (src/integrators/path.cpp), 2 velocity (velocity.cpp)
     // ---- batch
-    uint32_t lane_base, n_lanes;                  // this batch covers global lanes [lane_base, lane_base + n_lanes)
+    uint32_t lane_base, n_lanes;                  // this batch covers (virtual) lanes [lane_base, lane_base + n_lanes)
+    // striped shards (dtof_render_stripes): virtual row v of this shard is film row stripe_first + (v / stripe_rows) * stripe_period
+    // + v % stripe_rows, and the GLOBAL lane index (what every RNG stream is a function of) follows from it.  stripe_rows == 0:
+    // virtual = global (contiguous rows).
+    uint32_t stripe_rows, stripe_period, stripe_first, lanes_per_row;
 };
 
 // SoA wavefront state for one batch (device pointers; all arrays have `capacity` entries and are

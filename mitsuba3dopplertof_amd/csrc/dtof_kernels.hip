@@ -365,6 +365,13 @@ DTOF_D float modulation_weight(const RenderParams &rp, float phase, float ray_ti
 // ---------------------------------------------------------------------------- generate
 // One lane of render_sample's head (integrator.cpp:476-495 / :416-431): sampler seeding, pixel jitter, time sample, camera ray.
 struct PrimaryLane { float4 ray_a, ray_b; Rng main, path; float2 pos; };
+// global lane index (pixel-major, the index every stream of the sampler is seeded with) of a lane of this launch
+DTOF_D uint32_t global_lane(const RenderParams &rp, uint32_t virtual_lane) {
+    if (rp.stripe_rows == 0) return virtual_lane;
+    const uint32_t v = virtual_lane / rp.lanes_per_row, in_row = virtual_lane - v * rp.lanes_per_row;
+    const uint32_t s = v / rp.stripe_rows, y = rp.stripe_first + s * rp.stripe_period + (v - s * rp.stripe_rows);
+    return y * rp.lanes_per_row + in_row;
+}
 DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane) {
     Rng main = seed_stream(rp.seed_value, lane);
     // m_rng_time is only drawn from by the antithetic strategies of the correlated sampler (correlated.cpp:96-106)
@@ -425,7 +432,7 @@ DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane) {
 __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= rp.n_lanes) return;
-    const PrimaryLane pl = generate_lane(rp, rp.lane_base + i);
+    const PrimaryLane pl = generate_lane(rp, global_lane(rp, rp.lane_base + i));
     q.ray_a[i] = pl.ray_a;
     q.ray_b[i] = pl.ray_b;
     q.st_a[i] = make_float4(1.f, 1.f, 1.f, 0.f);
@@ -733,7 +740,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
         l = qin ? qin[seg * kSeg + j] : seg * kSeg + j;
         uint32_t hid; float4 ra, rb, st; uint4 hh; Rng main, path;
         if (FIRST) {
-            const PrimaryLane pl = generate_lane(rp, rp.lane_base + l);
+            const PrimaryLane pl = generate_lane(rp, global_lane(rp, rp.lane_base + l));
             ra = pl.ray_a; rb = pl.ray_b; main = pl.main; path = pl.path; st = make_float4(1.f, 1.f, 1.f, 0.f);
             q.pos[l] = pl.pos;
             q.rng_b[l] = make_uint2((uint32_t) (main.inc >> 1), (uint32_t) (path.inc >> 1));
@@ -1187,7 +1194,7 @@ __global__ __launch_bounds__(kBlock) void k_splat_generic(RenderParams rp, Queue
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= rp.n_lanes) return;
     float2 p = q.pos[i];
-    uint32_t lane = rp.lane_base + i;
+    uint32_t lane = global_lane(rp, rp.lane_base + i);
     uint32_t pix = rp.spp_log2 != 0xffffffffu ? lane >> rp.spp_log2 : lane / rp.spp, W = (uint32_t) rp.crop_w;
     int py = (int) (pix / W), px = (int) (pix - W * (uint32_t) py);
     for (int k = 0; k < rp.n_offsets; ++k) {
@@ -1205,7 +1212,7 @@ __global__ __launch_bounds__(kBlock) void k_splat_tent3(RenderParams rp, Queues 
     __shared__ float4 s_acc4[(kBlock / 2) * 9];
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool in_range = i < rp.n_lanes;
-    uint32_t lane = rp.lane_base + (in_range ? i : 0);
+    uint32_t lane = global_lane(rp, rp.lane_base + (in_range ? i : 0));
     uint32_t pix = lane >> rp.spp_log2;
     uint32_t W = (uint32_t) rp.crop_w;
     int py = (int) (pix / W), px = (int) (pix - W * (uint32_t) py);
@@ -1261,7 +1268,7 @@ __global__ __launch_bounds__(kBlock) void k_splat_tent3(RenderParams rp, Queues 
             uint32_t sidx = idx / 36, c = idx - sidx * 36;
             uint32_t first_lane = blockIdx.x * kBlock + sidx * seg;
             if (first_lane >= rp.n_lanes) continue;
-            uint32_t spix = (rp.lane_base + first_lane) >> rp.spp_log2;
+            uint32_t spix = global_lane(rp, rp.lane_base + first_lane) >> rp.spp_log2;
             int sy = (int) (spix / W), sx = (int) (spix - W * (uint32_t) sy);
             int x = sx - 1 + (int) ((c % 12) >> 2), y = sy - 1 + (int) (c / 12);
             float v = s_acc[idx];

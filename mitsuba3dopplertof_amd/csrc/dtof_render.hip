@@ -230,9 +230,11 @@ struct StageTimer {
 
 // The wavefront loop over pixel rows [row_begin,row_end); accumulates into d_film (K films).
 // lane_dump != nullptr: evaluate only lanes [dump_begin, dump_begin + dump_n) and copy their records out.
+// stripe_rows > 0: the rows are the stripes [row_begin + k * stripe_period, ... + stripe_rows) below row_end (interleaved shards).
 void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin, int32_t row_end,
                  const float *offsets, int n_offsets, float *d_film, dtof_render_stats *stats,
-                 LaneDebug *lane_dump = nullptr, uint64_t dump_begin = 0, uint64_t dump_n = 0) {
+                 LaneDebug *lane_dump = nullptr, uint64_t dump_begin = 0, uint64_t dump_n = 0,
+                 uint32_t stripe_rows = 0, uint32_t stripe_period = 0) {
     ensure_device(sc);
     const HostSensor &se = sc->host.sensor;
     if (spp == 0) spp = sc->pp.sample_count;
@@ -247,6 +249,13 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     uint64_t first = lane_dump ? dump_begin : lanes_per_row * (uint64_t) row_begin;
     uint64_t last = lane_dump ? dump_begin + dump_n : lanes_per_row * (uint64_t) std::max(row_end, row_begin);
     if (last > total_lanes) throw std::runtime_error("lane range exceeds the wavefront");
+    if (stripe_rows) {   // virtual rows [0, V): the rows of this shard's stripes in ascending order
+        if (stripe_period < stripe_rows) throw std::runtime_error("stripe period must be at least the stripe height");
+        const uint64_t span = (uint64_t) std::max(row_end - row_begin, 0), full = span / stripe_period, rest = span % stripe_period;
+        const uint64_t v_rows = full * stripe_rows + std::min<uint64_t>(rest, stripe_rows);
+        rp.stripe_rows = stripe_rows; rp.stripe_period = stripe_period; rp.stripe_first = (uint32_t) row_begin; rp.lanes_per_row = (uint32_t) lanes_per_row;
+        first = 0; last = v_rows * lanes_per_row;
+    }
     uint64_t batch = lane_dump ? std::min<uint64_t>(target_batch_lanes(), std::max<uint64_t>(dump_n, 1))
                                : std::max<uint64_t>(1, target_batch_lanes() / lanes_per_row) * lanes_per_row;
     batch = std::min<uint64_t>(batch, std::max<uint64_t>(last - first, 1));
@@ -552,6 +561,16 @@ int dtof_render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_be
         if (!sc || !d_film) throw std::runtime_error("null argument");
         sc->stop = false;
         render_rows(sc, seed, spp, row_begin, row_end, offsets, n_offsets, d_film, stats);
+    });
+}
+
+int dtof_render_stripes(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t first_row, int32_t stripe_rows, int32_t stripe_period,
+                        const float *offsets, int n_offsets, float *d_film, dtof_render_stats *stats) {
+    return guarded([&] {
+        if (!sc || !d_film) throw std::runtime_error("null argument");
+        if (first_row < 0 || stripe_rows <= 0 || stripe_period < stripe_rows) throw std::runtime_error("invalid stripe layout");
+        sc->stop = false;
+        render_rows(sc, seed, spp, first_row, sc->host.sensor.crop_h, offsets, n_offsets, d_film, stats, nullptr, 0, 0, (uint32_t) stripe_rows, (uint32_t) stripe_period);
     });
 }
 

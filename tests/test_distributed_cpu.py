@@ -53,6 +53,17 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_stripe_bookkeeping():
+    """interleaved shards: the stripes of all ranks partition the rows, whatever the frame height"""
+    from mitsuba3dopplertof_amd import distributed as D
+    for height, world, stripe in [(48, 3, 5), (37, 4, 4), (50, 8, 3), (1024, 8, 32), (7, 8, 16), (1, 2, 1)]:
+        rows = [D.stripe_rows_of(height, world, r, stripe) for r in range(world)]
+        assert sorted(y for rr in rows for y in rr) == list(range(height))
+        first, n, period = D.stripe_layout(world, 1 % world, stripe)
+        assert period == world * stripe and n == stripe and first == (1 % world) * stripe
+        assert max(len(rr) for rr in rows) - min(len(rr) for rr in rows) <= stripe
+
+
 def test_two_rank_gloo_film_gather_reproduces_the_single_rank_film():
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()

@@ -84,6 +84,42 @@ def test_row_tiles_reproduce_the_full_frame(mi):
     assert abs(f[..., 3].sum() - w * h * 16) < 0.02 * w * h * 16      # tent weights sum to ~1 per sample
 
 
+def test_interleaved_stripes_reproduce_the_full_frame(mi):
+    """dtof_render_stripes (load-balanced shards): the stripes of 3 'ranks' accumulated into one film == one full render, for stripe
+    heights that do and do not divide the frame, spp that is and is not a power of two (both splat kernels), and 4 batched offsets;
+    the rows a rank touches are exactly distributed.stripe_rows_of."""
+    import torch
+    from mitsuba3dopplertof_amd import distributed as D
+    for scene, res, spp, world, stripe, offsets in (("cornell_wall.xml", (64, 48), 16, 3, 5, None), ("cornell_boxes.xml", (40, 37), 6, 4, 4, None),
+                                                   ("cornell_area.xml", (32, 32), 8, 2, 16, [0.0, 0.25, 0.5, 0.75]), ("domino_small.xml", (48, 50), 4, 8, 3, None)):
+        sc = mi.load_file(os.path.join(SCENES, scene), resx=res[0], resy=res[1])
+        w, h = sc.size
+        k = len(offsets) if offsets else 1
+        ref = sc.render(seed=9, spp=spp, offsets=offsets) if offsets else sc.render(seed=9, spp=spp)[None]
+        film = torch.zeros((k, h, w, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        lanes = 0
+        for r in range(world):
+            one = torch.zeros_like(film)
+            torch.cuda.synchronize()
+            st = sc.render_stripes(one.data_ptr(), 9, spp, *D.stripe_layout(world, r, stripe), offsets=offsets)
+            rows = D.stripe_rows_of(h, world, r, stripe)
+            assert st["n_paths"] == len(rows) * w * spp
+            touched = np.nonzero(one[0, :, :, 3].sum(dim=1).cpu().numpy() > 0)[0]
+            inner = [y for y in touched if y in rows]                      # the tent footprint also reaches the neighbouring rows
+            assert sorted(inner) == rows and all(min(abs(y - r_) for r_ in rows) <= 1 for y in touched)
+            film += one
+            lanes += st["n_paths"]
+        assert lanes == w * h * spp
+        rgb = torch.zeros((k, h, w, 3), dtype=torch.float32, device="cuda")
+        assert mi._lib().dtof_develop(film.data_ptr(), rgb.data_ptr(), k * w * h) == 0
+        torch.cuda.synchronize()
+        assert rel_linf(rgb.cpu().numpy(), np.asarray(ref)) <= IMG_TOL, scene
+    sc = mi.load_file(os.path.join(SCENES, "cornell_wall.xml"), resx=16, resy=16)
+    with pytest.raises(mi.DtofError, match="invalid stripe layout"):
+        sc.render_stripes(film.data_ptr(), 0, 4, 0, 4, 2)
+
+
 def test_batched_offsets_equal_separate_renders(mi, orc):
     """K modulation offsets evaluated in one traversal (BASELINE config 5) == K separate renders; offsets 0 and 0.5
     are exact negatives for the sinusoidal waveform up to rounding."""
@@ -458,9 +494,11 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_image(mi, tmp_path):
         "for name, spp in (('cornell_wall.xml', 16), ('cornell_area.xml', 8), ('cornell_spheres.xml', 8)):\n"
         "    sc = mi.load_file(os.path.join(%r, name), resx=40, resy=26)\n"     # 26 rows: bands of 13, halo rows overlap
         "    img = D.render_sharded(sc, seed=5, spp=spp)\n"
+        "    striped = D.render_striped(sc, seed=5, spp=spp, stripe_rows=4)\n"
         "    if dist.get_rank() == 0:\n"
         "        np.save(os.path.join(%r, name + '.npy'), img)\n"
-        "dist.barrier(); dist.destroy_process_group()\n" % (os.path.dirname(SCENES), SCENES, str(tmp_path)))
+        "        np.save(os.path.join(%r, name + '.striped.npy'), striped)\n"
+        "dist.barrier(); dist.destroy_process_group()\n" % (os.path.dirname(SCENES), SCENES, str(tmp_path), str(tmp_path)))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29533", str(script)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -469,6 +507,8 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_image(mi, tmp_path):
         ref = sc.render(seed=5, spp=spp)
         got = np.load(str(tmp_path / (name + ".npy")))
         assert got.shape == ref.shape and rel_linf(got, ref) <= IMG_TOL, (name, rel_linf(got, ref))
+        striped = np.load(str(tmp_path / (name + ".striped.npy")))      # interleaved stripes + one reduce(sum)
+        assert striped.shape == ref.shape and rel_linf(striped, ref) <= IMG_TOL, (name, rel_linf(striped, ref))
 
 
 def _random_config(rng):
