@@ -23,6 +23,8 @@ def main(argv=None):
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel (0 = the sampler's sample_count)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--offsets", default=None, help="comma separated hetero_offset values evaluated in ONE traversal")
+    ap.add_argument("--stripes", type=int, default=0, metavar="ROWS",
+                    help="multi-GPU runs: interleave stripes of ROWS pixel rows across the ranks (load balance) instead of one contiguous band per rank")
     ap.add_argument("-m", "--mode", default="hip_rgb", help="accepted for command-line compatibility (only hip_rgb exists)")
     ap.add_argument("-v", "--verbose", action="store_true")
     args = ap.parse_args(argv)
@@ -48,7 +50,8 @@ def main(argv=None):
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group("nccl")
-            img = D.render_sharded(scene, seed=args.seed, spp=args.spp)
+            img = (D.render_striped(scene, seed=args.seed, spp=args.spp, stripe_rows=args.stripes) if args.stripes > 0
+                   else D.render_sharded(scene, seed=args.seed, spp=args.spp))
             dist.barrier()
             dist.destroy_process_group()
             if img is None:
