@@ -1,14 +1,20 @@
 // dtof-render -- native command line front end over the C ABI (include/dtof.h), the counterpart of
 // `mitsuba scene.xml -m <variant> -D key=value -o out` (src/mitsuba/mitsuba.cpp:150-423) for the plugins libdtof implements.
 //
-//   dtof-render scene.xml [-D key=value ...] [-o out.npy|out.pfm] [--spp N] [--seed S] [-m hip_rgb]
+//   dtof-render scene.xml [-D key=value ...] [-o out.npy|out.pfm] [--spp N] [--seed S] [-m hip_rgb] [--gpus G [--stripes ROWS]]
+//
+// --gpus G: one host thread per GPU of this node, each with its own scene handle; thread g renders the interleaved stripes of pixel
+// rows g owns (dtof_render_stripes) into a film on its device, the films are summed on the host and developed (RGB / W).  The
+// torch.distributed launcher (python -m mitsuba3dopplertof_amd under torch.distributed.run) does the same with one RCCL reduce.
 //
 // Exit code -1 and "Error: ..." on stderr when loading or rendering fails (mitsuba.cpp:366-397,423).
 #include "../../include/dtof.h"
+#include <hip/hip_runtime_api.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 static bool write_npy(const char *path, const float *img, int h, int w) {
@@ -28,7 +34,7 @@ static bool write_pfm(const char *path, const float *img, int h, int w) {
 }
 
 int main(int argc, char **argv) {
-    std::string scene, out; std::vector<std::string> names, values; unsigned spp = 0, seed = 0;
+    std::string scene, out; std::vector<std::string> names, values; unsigned spp = 0, seed = 0; int gpus = 1, stripes = 4;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&](const char *what) -> std::string { if (i + 1 >= argc) { fprintf(stderr, "Error: %s expects a value\n", what); exit(-1); } return argv[++i]; };
@@ -39,8 +45,10 @@ int main(int argc, char **argv) {
         else if (a == "-o") out = next("-o");
         else if (a == "--spp") spp = (unsigned) atoi(next("--spp").c_str());
         else if (a == "--seed") seed = (unsigned) atoi(next("--seed").c_str());
+        else if (a == "--gpus") gpus = atoi(next("--gpus").c_str());
+        else if (a == "--stripes") stripes = atoi(next("--stripes").c_str());
         else if (a == "-m") (void) next("-m");   // variant: only hip_rgb exists
-        else if (a == "-h" || a == "--help") { printf("usage: dtof-render scene.xml [-D key=value ...] [-o out.npy|out.pfm] [--spp N] [--seed S]\n%s\n", dtof_version()); return 0; }
+        else if (a == "-h" || a == "--help") { printf("usage: dtof-render scene.xml [-D key=value ...] [-o out.npy|out.pfm] [--spp N] [--seed S] [--gpus G [--stripes ROWS]]\n%s\n", dtof_version()); return 0; }
         else if (scene.empty()) scene = a;
         else { fprintf(stderr, "Error: unexpected argument \"%s\"\n", a.c_str()); return -1; }
     }
@@ -52,6 +60,36 @@ int main(int argc, char **argv) {
     dtof_scene_info info; dtof_scene_get_info(sc, &info);
     std::vector<float> img((size_t) info.crop_width * info.crop_height * 3);
     dtof_render_stats st;
+    if (gpus > 1) {
+        int visible = 0; (void) hipGetDeviceCount(&visible);
+        const bool share = getenv("DTOF_CLI_SHARE_GPU") != nullptr;   // development: all shards on GPU 0 (one-GPU boxes)
+        if (gpus > visible && !share) { fprintf(stderr, "Error: --gpus %d but only %d GPU(s) are visible\n", gpus, visible); dtof_scene_destroy(sc); return -1; }
+        if (stripes <= 0) { fprintf(stderr, "Error: --stripes expects a positive number of rows\n"); dtof_scene_destroy(sc); return -1; }
+        const size_t film_floats = (size_t) info.crop_width * info.crop_height * 4;
+        std::vector<std::vector<float>> films(gpus, std::vector<float>(film_floats));
+        std::vector<std::string> errors(gpus); std::vector<dtof_render_stats> stats(gpus);
+        std::vector<std::thread> workers;
+        for (int g = 0; g < gpus; ++g) workers.emplace_back([&, g] {
+            if (hipSetDevice(share ? 0 : g) != hipSuccess) { errors[g] = "hipSetDevice failed"; return; }
+            dtof_scene *mine = nullptr; float *d_film = nullptr;
+            if (dtof_scene_load_file(scene.c_str(), n.data(), v.data(), (int) n.size(), &mine)) { errors[g] = dtof_last_error(); return; }
+            if (hipMalloc((void **) &d_film, film_floats * 4) != hipSuccess || hipMemset(d_film, 0, film_floats * 4) != hipSuccess) errors[g] = "device film allocation failed";
+            else if (dtof_render_stripes(mine, seed, spp, g * stripes, stripes, gpus * stripes, nullptr, 0, d_film, &stats[g])) errors[g] = dtof_last_error();
+            else if (hipMemcpy(films[g].data(), d_film, film_floats * 4, hipMemcpyDeviceToHost) != hipSuccess) errors[g] = "film download failed";
+            if (d_film) (void) hipFree(d_film);
+            dtof_scene_destroy(mine);
+        });
+        for (auto &w : workers) w.join();
+        for (int g = 0; g < gpus; ++g) if (!errors[g].empty()) { fprintf(stderr, "Error: GPU %d: %s\n", g, errors[g].c_str()); dtof_scene_destroy(sc); return -1; }
+        st = stats[0];
+        for (int g = 1; g < gpus; ++g) { st.n_paths += stats[g].n_paths; if (stats[g].ms_total > st.ms_total) st.ms_total = stats[g].ms_total; }
+        for (size_t p = 0; p < film_floats / 4; ++p) {   // HDRFilm::develop (hdrfilm.cpp:305-406) of the summed films
+            float r = 0.f, gch = 0.f, b = 0.f, wgt = 0.f;
+            for (int g = 0; g < gpus; ++g) { const float *f = films[g].data() + 4 * p; r += f[0]; gch += f[1]; b += f[2]; wgt += f[3]; }
+            if (wgt == 0.f) wgt = 1.f;
+            img[3 * p] = r / wgt; img[3 * p + 1] = gch / wgt; img[3 * p + 2] = b / wgt;
+        }
+    } else
     if (dtof_render(sc, 0, seed, spp, img.data(), &st)) { fprintf(stderr, "Error: %s\n", dtof_last_error()); dtof_scene_destroy(sc); return -1; }
     bool pfm = out.size() > 4 && out.substr(out.size() - 4) == ".pfm";
     bool ok = pfm ? write_pfm(out.c_str(), img.data(), info.crop_height, info.crop_width) : write_npy(out.c_str(), img.data(), info.crop_height, info.crop_width);

@@ -112,6 +112,16 @@ def test_native_cli_writes_the_same_image(mi, tmp_path):
     assert img.shape == (24, 40, 3) and np.abs(img - ref).max() <= 1e-5 * np.abs(ref).max()
     bad = subprocess.run([exe, os.path.join(SCENES, "cornell_wall.xml"), "-D", "wave_function_type=sawtooth"], capture_output=True, text=True)
     assert bad.returncode != 0 and "unknown wave_function_type" in bad.stderr
+    # --gpus G: one host thread per GPU, interleaved stripes, films summed on the host.  This box has one GPU: more is an error, and
+    # DTOF_CLI_SHARE_GPU (development switch) puts all three shards on GPU 0 so that the thread / stripe / sum logic runs.
+    many = subprocess.run([exe, os.path.join(SCENES, "cornell_wall.xml"), "--gpus", "64"], capture_output=True, text=True)
+    assert many.returncode != 0 and "GPU(s) are visible" in many.stderr
+    out3 = str(tmp_path / "o3.npy")
+    r = subprocess.run([exe, os.path.join(SCENES, "cornell_wall.xml"), "-D", "resx=40", "-D", "resy=24", "--spp", "8", "--seed", "5", "-o", out3,
+                        "--gpus", "3", "--stripes", "5"], capture_output=True, text=True, env=dict(os.environ, DTOF_CLI_SHARE_GPU="1"))
+    assert r.returncode == 0, r.stderr
+    img3 = np.load(out3)
+    assert img3.shape == (24, 40, 3) and np.abs(img3 - ref).max() <= 5e-5 * np.abs(ref).max()
 
 
 def _read_png(path):
