@@ -896,6 +896,15 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 const float f2 = sqr(eta_ti);
                 bsdf_weight = selected_r ? mk(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2])
                                          : mk(sh->spec_trans[0] * f2, sh->spec_trans[1] * f2, sh->spec_trans[2] * f2);
+            } else if (SPEC && sh->bsdf == BSDF_THINDIELECTRIC) {
+                // ThinDielectric::sample (thindielectric.cpp:173-226): the reflectance of the slab with all internal bounces, wo = -wi
+                float r, t1, t2, t3;
+                fresnel_dielectric(fabsf(si.wi.z), sh->diel_eta, r, t1, t2, t3);
+                r *= 2.f / (1.f + r);
+                const bool selected_r = sample_1 <= r;
+                bs_pdf = selected_r ? r : 1.f - r; bs_delta = true; bs_eta = 1.f;
+                bs_wo = selected_r ? mk(-si.wi.x, -si.wi.y, si.wi.z) : mk(-si.wi.x, -si.wi.y, -si.wi.z);
+                bsdf_weight = selected_r ? mk(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]) : mk(sh->spec_trans[0], sh->spec_trans[1], sh->spec_trans[2]);
             } else if (SPEC && sh->bsdf == BSDF_ROUGHCONDUCTOR) {
                 // RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF
                 V3 wi = si.wi, wo_l = wo;

@@ -545,7 +545,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         for (auto &c : b.children) if (c.first == "bsdf") { inner = c.second.get(); ++n; }
         if (n != 1) fail("twosided: exactly one nested BSDF is supported");
         bsdf_of(*inner, s);
-        if (s.bsdf == BSDF_DIELECTRIC) fail("Only materials without a transmission component can be nested!");
+        if (s.bsdf == BSDF_DIELECTRIC || s.bsdf == BSDF_THINDIELECTRIC) fail("Only materials without a transmission component can be nested!");
         s.twosided = true; return;
     }
     s.twosided = false;
@@ -560,6 +560,11 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         const float int_ior = lookup_ior(b, "int_ior", "bk7"), ext_ior = lookup_ior(b, "ext_ior", "air");
         if (int_ior < 0 || ext_ior < 0) fail("The interior and exterior indices of refraction must be positive!");
         s.bsdf = BSDF_DIELECTRIC; s.diel_eta = int_ior / ext_ior;
+        color_of(b, "specular_reflectance", 1.f, s.spec_refl); color_of(b, "specular_transmittance", 1.f, s.spec_trans);
+    } else if (b.plugin == "thindielectric") {   // src/bsdfs/thindielectric.cpp:137-158
+        const float int_ior = lookup_ior(b, "int_ior", "bk7"), ext_ior = lookup_ior(b, "ext_ior", "air");
+        if (int_ior < 0 || ext_ior < 0) fail("The interior and exterior indices of refraction must be positive!");
+        s.bsdf = BSDF_THINDIELECTRIC; s.diel_eta = int_ior / ext_ior;
         color_of(b, "specular_reflectance", 1.f, s.spec_refl); color_of(b, "specular_transmittance", 1.f, s.spec_trans);
     } else if (b.plugin == "roughconductor") {   // src/bsdfs/roughconductor.cpp:177-227
         std::string material = b.props.get_string("material", "none");
@@ -620,7 +625,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         s.spec_sampling_weight = s_mean / (d_mean + s_mean);
         s.rough_table.resize(64);
         rough_plastic_tables(s.alpha_u, s.diel_eta, s.rough_table.data(), &s.fdr_int);       // fdr_int carries m_internal_reflectance
-    } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, plastic, roughplastic, conductor, roughconductor, dielectric, twosided)");
+    } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, plastic, roughplastic, conductor, roughconductor, dielectric, thindielectric, twosided)");
     auto u = b.props.unqueried();
     if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in plugin of type \"" + b.plugin + "\"");
 }

@@ -1058,6 +1058,16 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
             bs_eta = selected_r ? 1.f : eta_it;
             if (selected_r) bsdf_weight = V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]);
             else { float f2 = f_sqr(eta_ti); bsdf_weight = V(sh->spec_trans[0] * f2, sh->spec_trans[1] * f2, sh->spec_trans[2] * f2); }
+        } else if (hit && si.shape->bsdf == ORC_BSDF_THINDIELECTRIC) {
+            /* ThinDielectric::sample (thindielectric.cpp:173-226); eval / pdf are zero (:228-236) */
+            const orc_shape *sh = si.shape;
+            float r, t1, t2, t3;
+            fresnel_dielectric(fabsf(si.wi.z), sh->diel_eta, &r, &t1, &t2, &t3);
+            r *= 2.f / (1.f + r);
+            int selected_r = sample_1 <= r;
+            bs_pdf = selected_r ? r : 1.f - r; bs_delta = 1; bs_eta = 1.f;
+            bs_wo = selected_r ? V(-si.wi.x, -si.wi.y, si.wi.z) : V(-si.wi.x, -si.wi.y, -si.wi.z);
+            bsdf_weight = selected_r ? V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]) : V(sh->spec_trans[0], sh->spec_trans[1], sh->spec_trans[2]);
         } else if (hit && si.shape->bsdf == ORC_BSDF_ROUGHCONDUCTOR) {
             /* RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF */
             const orc_shape *sh = si.shape;

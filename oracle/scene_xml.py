@@ -342,7 +342,7 @@ def _bsdf_of(props, registry):
             raise ValueError("twosided: exactly one nested BSDF is supported")
         ip = inner[0][1] if inner[0][0] == "bsdf" else registry[inner[0][1]][1]
         rec = _bsdf_of(ip, registry)
-        if rec["bsdf"] == 2:   # twosided.cpp:47-52
+        if rec["bsdf"] in (2, 6):   # twosided.cpp:47-52
             raise ValueError("Only materials without a transmission component can be nested!")
         rec["twosided"] = 1
         return rec
@@ -361,6 +361,12 @@ def _bsdf_of(props, registry):
         if int_ior < 0 or ext_ior < 0:
             raise ValueError("The interior and exterior indices of refraction must be positive!")
         rec.update(bsdf=2, diel_eta=F32(int_ior / ext_ior), spec_refl=_color(props, "specular_reflectance", 1.0),
+                   spec_trans=_color(props, "specular_transmittance", 1.0))
+    elif props.plugin == "thindielectric":   # src/bsdfs/thindielectric.cpp:137-158
+        int_ior, ext_ior = _lookup_ior(props, "int_ior", "bk7"), _lookup_ior(props, "ext_ior", "air")
+        if int_ior < 0 or ext_ior < 0:
+            raise ValueError("The interior and exterior indices of refraction must be positive!")
+        rec.update(bsdf=6, diel_eta=F32(int_ior / ext_ior), spec_refl=_color(props, "specular_reflectance", 1.0),
                    spec_trans=_color(props, "specular_transmittance", 1.0))
     elif props.plugin == "roughconductor":   # src/bsdfs/roughconductor.cpp:177-227
         material = props.get_s("material", "none")

@@ -341,3 +341,64 @@ def test_rough_plastic_scenes_are_bit_exact_per_lane(mi, orc, name, params, spp,
     img = sc.render(seed=17, spp=spp)
     ref, _ = osc.render(pd, seed=17, spp=spp, threads=NCPU)
     assert float(np.abs(img - ref).max() / np.abs(ref).max()) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ thin dielectric
+THIN_PANE = ('\t<bsdf type="thindielectric" id="T"><float name="int_ior" value="%s" /><float name="ext_ior" value="1.0" />%s</bsdf>\n'
+             '\t<shape type="rectangle" id="Pane"><transform name="to_world"><translate x="0" y="1" z="2.5" /></transform><ref id="T" /></shape>\n')
+
+
+def test_thindielectric_window(mi, orc, tmp_path):
+    """ThinDielectric (thindielectric.cpp:137-226): one rectangle stands for a pane with both interfaces and all internal bounces,
+    reflectance R' = 2r / (1 + r), transmission straight through.  (1) index-matched: invisible (one extra delta vertex per crossing);
+    (2) eta = 1.5: darker than the open room by roughly the 7.7 % reflected away at normal incidence, never brighter; (3) a pane with
+    specular_transmittance 0 in front of the camera blacks the image out, except for what it mirrors (nothing lit is in front of it);
+    (4) twosided{thindielectric} is refused like twosided{dielectric}."""
+    def render(xml, name, depth):
+        p = str(tmp_path / name)
+        open(p, "w").write(xml)
+        sc = orc.Scene(p, dict(resx=16, resy=16))
+        pd = sc.params(integrator=dict(type="path", max_depth=depth))
+        return np.mean([sc.render(pd, seed=s, spp=128, threads=NCPU)[0] for s in range(2)], axis=0)
+    base = open(os.path.join(SCENES, "cornell_area.xml")).read()
+    ref = render(base, "ref.xml", 6)
+    same = render(base.replace("</scene>", THIN_PANE % ("1.0", "") + "</scene>"), "matched.xml", 7)
+    assert abs(same.mean() - ref.mean()) < 0.03 * ref.mean()
+    glass = render(base.replace("</scene>", THIN_PANE % ("1.5", "") + "</scene>"), "glass.xml", 7)
+    assert 0.85 * ref.mean() < glass.mean() < 1.0 * ref.mean()
+    opaque = render(base.replace("</scene>", THIN_PANE % ("1.5", '<rgb name="specular_transmittance" value="0" />') + "</scene>"), "opaque.xml", 7)
+    assert opaque.max() == 0.0
+    text = base.replace("</scene>", THIN_PANE % ("1.5", "") + "</scene>")
+    sc = mi.load_string(text)
+    rec = sc.export(9).reshape(-1, 24)
+    assert rec[-1, 0] == 6 and rec[-1, 1] == 0 and abs(rec[-1, 2] - 1.5) < 1e-6
+    with pytest.raises(mi.DtofError, match="Only materials without a transmission component can be nested"):
+        mi.load_string(text.replace('<bsdf type="thindielectric" id="T">', '<bsdf type="twosided" id="T"><bsdf type="thindielectric">').replace(
+            '<float name="ext_ior" value="1.0" /></bsdf>', '<float name="ext_ior" value="1.0" /></bsdf></bsdf>'))
+
+
+THIN_CASES = [("thin_pane_path", "cornell_area.xml", dict(resx=32, resy=32), 8, dict(type="path", max_depth=7)),       # rectangles only: fused pipeline
+              ("thin_pane_doppler", "cornell_area.xml", dict(resx=24, resy=24, max_depth=6), 8, None),
+              ("thin_pane_with_meshes_rr", "cornell_specular.xml", dict(resx=24, resy=24), 8, dict(type="path", max_depth=-1, rr_depth=3))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,scene,params,spp,integ", THIN_CASES, ids=[c[0] for c in THIN_CASES])
+def test_thindielectric_scenes_are_bit_exact_per_lane(mi, orc, tmp_path, name, scene, params, spp, integ):
+    pane = THIN_PANE % ("1.5", '<rgb name="specular_reflectance" value="0.9, 0.95, 1.0" /><rgb name="specular_transmittance" value="0.95, 0.9, 0.85" />')
+    path = str(tmp_path / "thin.xml")
+    open(path, "w").write(open(os.path.join(SCENES, scene)).read().replace("</scene>", pane + "</scene>"))
+    sc, osc = mi.load_file(path, **params), orc.Scene(path, params)
+    if integ:
+        sc.set_integrator(integ)
+    pd = osc.params(integrator=integ) if integ else osc.params()
+    w, h = sc.size
+    n = w * h * spp
+    g = sc.sample_lanes(19, spp, 0, n)
+    o = osc.render_lanes(pd, 19, spp, 0, n, threads=NCPU)
+    for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+        assert np.array_equal(bits(g[k]), bits(o[k])), (name, k, int((bits(g[k]) != bits(o[k])).sum()))
+    assert (g["rgb"] != 0).mean() > 0.05
+    img = sc.render(seed=19, spp=spp)
+    ref, _ = osc.render(pd, seed=19, spp=spp, threads=NCPU)
+    assert float(np.abs(img - ref).max() / np.abs(ref).max()) <= 5e-5
