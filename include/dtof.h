@@ -95,7 +95,7 @@ int dtof_scene_get_info(const dtof_scene *scene, dtof_scene_info *info);
  * kind 9: BSDF records      -> per shape 24 floats: kind (0 diffuse, 1 conductor, 2 dielectric, 3 plastic, 4 roughconductor), twosided, eta,
  *                             nonlinear, 1/eta^2, fdr_int, specular sampling weight, reflectance[3], specular_reflectance[3],
  *                             specular_transmittance[3], conductor eta[3], k[3], alpha_u, alpha_v
- *                             (src/bsdfs/{diffuse,conductor,dielectric,plastic,roughconductor,roughplastic}.cpp; 5 = roughplastic, 6 = thindielectric,
+ *                             (src/bsdfs/{diffuse,conductor,dielectric,plastic,roughconductor,roughplastic}.cpp; 5 = roughplastic, 6 = thindielectric, 7 = roughdielectric,
  *                             whose fdr_int slot carries m_internal_reflectance)
  * kind 10: roughplastic tables -> per roughplastic shape the 64 values of m_external_transmittance (roughplastic.cpp:222-257)
  * Returns the number of floats written (<= capacity) through *n_written. */

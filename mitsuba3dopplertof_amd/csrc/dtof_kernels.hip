@@ -665,6 +665,33 @@ DTOF_D void rough_plastic_eval_pdf(Ggx g, const DShape *sh, const float *table, 
     result *= prob_specular;
     pdf = result + prob_diffuse * (kInvPi * wo.z);
 }
+// RoughDielectric::eval_pdf (roughdielectric.cpp:503-611), GGX + visible normals, TransportMode::Radiance
+DTOF_D void rough_dielectric_eval_pdf(Ggx g, const DShape *sh, V3 wi, V3 wo, V3 &value, float &pdf) {
+    const float cti = wi.z, cto = wo.z, m_eta = sh->diel_eta, m_inv_eta = rcp(m_eta);
+    const bool reflect = cti * cto > 0.f;
+    const float eta = cti > 0.f ? m_eta : m_inv_eta, inv_eta = cti > 0.f ? m_inv_eta : m_eta;
+    V3 m = normalize(wi + wo * (reflect ? 1.f : eta));
+    m = mk(mulsign(m.x, m.z), mulsign(m.y, m.z), mulsign(m.z, m.z));
+    const float dwm = dot(wi, m), dom = dot(wo, m);
+    const bool active = cti != 0.f && dwm * cti > 0.f && dom * cto > 0.f;
+    const float D = ggx_eval(g, m);
+    float F, t1, t2, t3; fresnel_dielectric(dwm, m_eta, F, t1, t2, t3);
+    const float G = ggx_smith_g1(g, wi, m) * ggx_smith_g1(g, wo, m);
+    value = mk(0, 0, 0); pdf = 0.f;
+    if (!active) return;
+    if (reflect) {
+        const float v = F * D * G / (4.f * fabsf(cti));
+        value = mk(v * sh->spec_refl[0], v * sh->spec_refl[1], v * sh->spec_refl[2]);
+    } else {
+        const float scale = sqr(inv_eta);
+        const float v = fabsf((scale * (1.f - F) * D * G * eta * eta * dwm * dom) / (cti * sqr(dwm + eta * dom)));
+        value = mk(v * sh->spec_trans[0], v * sh->spec_trans[1], v * sh->spec_trans[2]);
+    }
+    float p = ggx_pdf(g, mk(mulsign(wi.x, cti), mulsign(wi.y, cti), mulsign(wi.z, cti)), m);
+    p *= reflect ? F : 1.f - F;
+    const float dwh_dwo = reflect ? rcp(4.f * dom) : (eta * eta * dom) / sqr(dwm + eta * dom);
+    pdf = p * fabsf(dwh_dwo);
+}
 // fresnel_conductor -- include/mitsuba/render/fresnel.h:93-117 (one colour channel)
 DTOF_D float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
     const float cos_theta_i_2 = cos_theta_i * cos_theta_i, sin_theta_i_2 = 1.f - cos_theta_i_2, sin_theta_i_4 = sin_theta_i_2 * sin_theta_i_2;
@@ -815,7 +842,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             // ---- emitter sampling (scene.cpp:235-291; point.cpp:118-147; area.cpp:116-159 + shape.cpp:370-384 + rectangle.cpp:152-166)
             float e1 = single ? next_f32(main) : next_correlate(main, path, correlate), e2 = single ? next_f32(main) : next_correlate(main, path, correlate);
             // has_flag(bsdf->flags(), BSDFFlags::Smooth) (:178): diffuse, (rough)plastic and roughconductor have a smooth lobe
-            bool active_em = active_next && sv.n_emitters > 0 && (!SPEC || sh->bsdf == BSDF_DIFFUSE || sh->bsdf == BSDF_PLASTIC || sh->bsdf == BSDF_ROUGHCONDUCTOR || sh->bsdf == BSDF_ROUGHPLASTIC);
+            bool active_em = active_next && sv.n_emitters > 0 && (!SPEC || sh->bsdf == BSDF_DIFFUSE || sh->bsdf == BSDF_PLASTIC || sh->bsdf == BSDF_ROUGHCONDUCTOR || sh->bsdf == BSDF_ROUGHPLASTIC || sh->bsdf == BSDF_ROUGHDIELECTRIC);
             V3 em_weight = mk(0, 0, 0), wo = mk(0, 0, 0); float ds_dist = 0.f, ds_pdf = 0.f; bool ds_delta = true;
             if (active_em) {
                 uint32_t ne = sv.n_emitters, idx = 0; float em_w = 1.f, sx = e1;
@@ -905,6 +932,36 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 bs_pdf = selected_r ? r : 1.f - r; bs_delta = true; bs_eta = 1.f;
                 bs_wo = selected_r ? mk(-si.wi.x, -si.wi.y, si.wi.z) : mk(-si.wi.x, -si.wi.y, -si.wi.z);
                 bsdf_weight = selected_r ? mk(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]) : mk(sh->spec_trans[0], sh->spec_trans[1], sh->spec_trans[2]);
+            } else if (SPEC && sh->bsdf == BSDF_ROUGHDIELECTRIC) {
+                // RoughDielectric::eval_pdf / sample (roughdielectric.cpp:240-346,503-611): glossy reflection and transmission lobes
+                const Ggx g = ggx_make(sh->alpha_u, sh->alpha_v);
+                const V3 wi = si.wi;
+                if (active_em) rough_dielectric_eval_pdf(g, sh, wi, wo, bsdf_val, bsdf_pdf);
+                if (wi.z != 0.f) {
+                    float mpdf;
+                    const V3 m = ggx_sample(g, mk(mulsign(wi.x, wi.z), mulsign(wi.y, wi.z), mulsign(wi.z, wi.z)), s2x, s2y, mpdf);
+                    const float dwm = dot(wi, m);
+                    float F, cos_theta_t, eta_it, eta_ti; fresnel_dielectric(dwm, sh->diel_eta, F, cos_theta_t, eta_it, eta_ti);
+                    const bool selected_r = sample_1 <= F;
+                    bs_pdf = mpdf * (selected_r ? F : 1.f - F);
+                    bs_eta = selected_r ? 1.f : eta_it;
+                    float dwh_dwo; V3 w;
+                    if (selected_r) {
+                        bs_wo = mk(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   // reflect(wi, m)
+                        w = mk(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]);
+                        dwh_dwo = rcp(4.f * dot(bs_wo, m));
+                    } else {
+                        const float k = fmaf(dwm, eta_ti, cos_theta_t);                                                         // refract(wi, m, cos_theta_t, eta_ti)
+                        bs_wo = mk(fmaf(m.x, k, -(wi.x * eta_ti)), fmaf(m.y, k, -(wi.y * eta_ti)), fmaf(m.z, k, -(wi.z * eta_ti)));
+                        const float f2 = sqr(eta_ti);
+                        w = mk(f2 * sh->spec_trans[0], f2 * sh->spec_trans[1], f2 * sh->spec_trans[2]);
+                        const float dom = dot(bs_wo, m);
+                        dwh_dwo = (sqr(bs_eta) * dom) / sqr(dwm + bs_eta * dom);
+                    }
+                    const float g1 = ggx_smith_g1(g, bs_wo, m);
+                    bs_pdf *= fabsf(dwh_dwo);
+                    if (mpdf != 0.f) bsdf_weight = w * g1;
+                }
             } else if (SPEC && sh->bsdf == BSDF_ROUGHCONDUCTOR) {
                 // RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF
                 V3 wi = si.wi, wo_l = wo;

@@ -166,6 +166,8 @@ DTOF_HD float ggx_smith_g1(Ggx g, V3 v, V3 m) {   // smith_g1() :341-365
     if (dot(v, m) * v.z <= 0.f) result = 0.f;
     return result;
 }
+// pdf() :219-228, visible-normal branch (note the association: D * ((G1 * |wi.m|) / cos_theta_i), unlike the density sample() returns)
+DTOF_HD float ggx_pdf(Ggx g, V3 wi, V3 m) { return ggx_eval(g, m) * (ggx_smith_g1(g, wi, m) * fabsf(dot(wi, m)) / wi.z); }
 // sample(), visible-normal branch :296-325 + sample_visible_11, GGX branch :405-420: microfacet normal and its density
 DTOF_HD V3 ggx_sample(Ggx g, V3 wi, float s_x, float s_y, float &pdf) {
     const V3 wi_p = normalize(mk(g.au * wi.x, g.av * wi.y, wi.z));

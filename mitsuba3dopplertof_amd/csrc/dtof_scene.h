@@ -17,7 +17,7 @@ enum WaveType : int32_t { WAVE_SIN = 0, WAVE_RECT = 1, WAVE_TRI = 2, WAVE_TRAP =
 enum TimeSampling : int32_t { TIME_UNIFORM = 0, TIME_STRATIFIED = 1, TIME_ANTITHETIC = 2, TIME_ANTITHETIC_MIRROR = 3 };
 enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1, FILTER_GAUSSIAN = 2, FILTER_MITCHELL = 3, FILTER_CATMULLROM = 4 };
 enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4, SF_EMITTER = 8 };
-enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4, BSDF_ROUGHPLASTIC = 5, BSDF_THINDIELECTRIC = 6 };
+enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4, BSDF_ROUGHPLASTIC = 5, BSDF_THINDIELECTRIC = 6, BSDF_ROUGHDIELECTRIC = 7 };
 enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1 };
 
 // ---------------------------------------------------------------------------- device blob records

@@ -545,7 +545,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         for (auto &c : b.children) if (c.first == "bsdf") { inner = c.second.get(); ++n; }
         if (n != 1) fail("twosided: exactly one nested BSDF is supported");
         bsdf_of(*inner, s);
-        if (s.bsdf == BSDF_DIELECTRIC || s.bsdf == BSDF_THINDIELECTRIC) fail("Only materials without a transmission component can be nested!");
+        if (s.bsdf == BSDF_DIELECTRIC || s.bsdf == BSDF_THINDIELECTRIC || s.bsdf == BSDF_ROUGHDIELECTRIC) fail("Only materials without a transmission component can be nested!");
         s.twosided = true; return;
     }
     s.twosided = false;
@@ -566,6 +566,22 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         if (int_ior < 0 || ext_ior < 0) fail("The interior and exterior indices of refraction must be positive!");
         s.bsdf = BSDF_THINDIELECTRIC; s.diel_eta = int_ior / ext_ior;
         color_of(b, "specular_reflectance", 1.f, s.spec_refl); color_of(b, "specular_transmittance", 1.f, s.spec_trans);
+    } else if (b.plugin == "roughdielectric") {   // src/bsdfs/roughdielectric.cpp:163-238
+        const float int_ior = lookup_ior(b, "int_ior", "bk7"), ext_ior = lookup_ior(b, "ext_ior", "air");
+        if (int_ior < 0 || ext_ior < 0 || int_ior == ext_ior) fail("The interior and exterior indices of refraction must be positive and differ!");
+        s.bsdf = BSDF_ROUGHDIELECTRIC; s.diel_eta = int_ior / ext_ior;
+        color_of(b, "specular_reflectance", 1.f, s.spec_refl); color_of(b, "specular_transmittance", 1.f, s.spec_trans);
+        std::string distr = b.props.get_string("distribution", "beckmann");
+        std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
+        if (distr != "beckmann" && distr != "ggx") fail("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"!");
+        if (distr != "ggx") fail("roughdielectric: only distribution \"ggx\" is implemented (the Beckmann distribution needs Dr.Jit's erf / erfinv "
+                                 "approximations, whose source is not part of the reference tree)");
+        if (!b.props.get_bool("sample_visible", true)) fail("roughdielectric: only sample_visible = true is implemented");
+        if (b.props.has("alpha_u") || b.props.has("alpha_v")) {
+            if (!b.props.has("alpha_u") || !b.props.has("alpha_v")) fail("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
+            if (b.props.has("alpha")) fail("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.");
+            s.alpha_u = (float) b.props.get_float("alpha_u", 0.1); s.alpha_v = (float) b.props.get_float("alpha_v", 0.1);
+        } else s.alpha_u = s.alpha_v = (float) b.props.get_float("alpha", 0.1);
     } else if (b.plugin == "roughconductor") {   // src/bsdfs/roughconductor.cpp:177-227
         std::string material = b.props.get_string("material", "none");
         if (material != "none") fail(b.props.has("eta") || b.colors.count("eta") ? "Should specify either (eta, k) or material, not both."
@@ -625,7 +641,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         s.spec_sampling_weight = s_mean / (d_mean + s_mean);
         s.rough_table.resize(64);
         rough_plastic_tables(s.alpha_u, s.diel_eta, s.rough_table.data(), &s.fdr_int);       // fdr_int carries m_internal_reflectance
-    } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, plastic, roughplastic, conductor, roughconductor, dielectric, thindielectric, twosided)");
+    } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, plastic, roughplastic, conductor, roughconductor, dielectric, thindielectric, roughdielectric, twosided)");
     auto u = b.props.unqueried();
     if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in plugin of type \"" + b.plugin + "\"");
 }

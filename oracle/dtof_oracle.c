@@ -858,6 +858,35 @@ static void rough_plastic_eval_pdf(ggx_t g, const orc_shape *sh, v3 wi, v3 wo, f
     result *= prob_specular;
     *pdf = result + prob_diffuse * (ORC_INV_PI_F * wo.z);
 }
+/* MicrofacetDistribution::pdf (microfacet.h:219-228), visible normals: D * ((G1 * |wi.m|) / cos_theta_i) */
+static float ggx_pdf(ggx_t g, v3 wi, v3 m) { return ggx_eval(g, m) * (ggx_smith_g1(g, wi, m) * fabsf(v_dot(wi, m)) / wi.z); }
+/* RoughDielectric::eval_pdf (roughdielectric.cpp:503-611), TransportMode::Radiance */
+static void rough_dielectric_eval_pdf(ggx_t g, const orc_shape *sh, v3 wi, v3 wo, v3 *value, float *pdf) {
+    float cti = wi.z, cto = wo.z, m_eta = sh->diel_eta, m_inv_eta = f_rcp(m_eta);
+    int reflect = cti * cto > 0.f;
+    float eta = cti > 0.f ? m_eta : m_inv_eta, inv_eta = cti > 0.f ? m_inv_eta : m_eta;
+    v3 m = v_normalize(v_add(wi, v_mul(wo, reflect ? 1.f : eta)));
+    m = V(f_mulsign(m.x, m.z), f_mulsign(m.y, m.z), f_mulsign(m.z, m.z));
+    float dwm = v_dot(wi, m), dom = v_dot(wo, m);
+    int active = cti != 0.f && dwm * cti > 0.f && dom * cto > 0.f;
+    float D = ggx_eval(g, m), F, t1, t2, t3;
+    fresnel_dielectric(dwm, m_eta, &F, &t1, &t2, &t3);
+    float G = ggx_smith_g1(g, wi, m) * ggx_smith_g1(g, wo, m);
+    *value = V(0, 0, 0); *pdf = 0.f;
+    if (!active) return;
+    if (reflect) {
+        float v = F * D * G / (4.f * fabsf(cti));
+        *value = V(v * sh->spec_refl[0], v * sh->spec_refl[1], v * sh->spec_refl[2]);
+    } else {
+        float scale = f_sqr(inv_eta);
+        float v = fabsf((scale * (1.f - F) * D * G * eta * eta * dwm * dom) / (cti * f_sqr(dwm + eta * dom)));
+        *value = V(v * sh->spec_trans[0], v * sh->spec_trans[1], v * sh->spec_trans[2]);
+    }
+    float p = ggx_pdf(g, V(f_mulsign(wi.x, cti), f_mulsign(wi.y, cti), f_mulsign(wi.z, cti)), m);
+    p *= reflect ? F : 1.f - F;
+    float dwh_dwo = reflect ? f_rcp(4.f * dom) : (eta * eta * dom) / f_sqr(dwm + eta * dom);
+    *pdf = p * fabsf(dwh_dwo);
+}
 /* mis_weight -- dopplertofpath.cpp:296-301 */
 static inline float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
@@ -963,7 +992,8 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
 
         /* has_flag(bsdf->flags(), BSDFFlags::Smooth), :178 -- diffuse and plastic have a smooth lobe */
         int active_em = active_next && hit && (si.shape->bsdf == ORC_BSDF_DIFFUSE || si.shape->bsdf == ORC_BSDF_PLASTIC ||
-                                               si.shape->bsdf == ORC_BSDF_ROUGHCONDUCTOR || si.shape->bsdf == ORC_BSDF_ROUGHPLASTIC);
+                                               si.shape->bsdf == ORC_BSDF_ROUGHCONDUCTOR || si.shape->bsdf == ORC_BSDF_ROUGHPLASTIC ||
+                                               si.shape->bsdf == ORC_BSDF_ROUGHDIELECTRIC);
 
         /* emitter sampling: Scene::sample_emitter_direction src/render/scene.cpp:235-291 */
         float e1 = sampler_draw(&smp, correlate, single);
@@ -1068,6 +1098,37 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
             bs_pdf = selected_r ? r : 1.f - r; bs_delta = 1; bs_eta = 1.f;
             bs_wo = selected_r ? V(-si.wi.x, -si.wi.y, si.wi.z) : V(-si.wi.x, -si.wi.y, -si.wi.z);
             bsdf_weight = selected_r ? V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]) : V(sh->spec_trans[0], sh->spec_trans[1], sh->spec_trans[2]);
+        } else if (hit && si.shape->bsdf == ORC_BSDF_ROUGHDIELECTRIC) {
+            /* RoughDielectric::sample (roughdielectric.cpp:240-346); eval_pdf above for the emitter sample */
+            const orc_shape *sh = si.shape;
+            ggx_t g = ggx_make(sh->alpha_u, sh->alpha_v);
+            v3 wi = si.wi;
+            if (active_em) rough_dielectric_eval_pdf(g, sh, wi, wo, &bsdf_val, &bsdf_pdf);
+            if (wi.z != 0.f) {
+                float mpdf;
+                v3 m = ggx_sample(g, V(f_mulsign(wi.x, wi.z), f_mulsign(wi.y, wi.z), f_mulsign(wi.z, wi.z)), s2x, s2y, &mpdf);
+                float dwm = v_dot(wi, m), F, cos_theta_t, eta_it, eta_ti;
+                fresnel_dielectric(dwm, sh->diel_eta, &F, &cos_theta_t, &eta_it, &eta_ti);
+                int selected_r = sample_1 <= F;
+                bs_pdf = mpdf * (selected_r ? F : 1.f - F);
+                bs_eta = selected_r ? 1.f : eta_it;
+                float dwh_dwo; v3 w;
+                if (selected_r) {
+                    bs_wo = V(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));
+                    w = V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]);
+                    dwh_dwo = f_rcp(4.f * v_dot(bs_wo, m));
+                } else {
+                    float k = fmaf(dwm, eta_ti, cos_theta_t);
+                    bs_wo = V(fmaf(m.x, k, -(wi.x * eta_ti)), fmaf(m.y, k, -(wi.y * eta_ti)), fmaf(m.z, k, -(wi.z * eta_ti)));
+                    float f2 = f_sqr(eta_ti);
+                    w = V(f2 * sh->spec_trans[0], f2 * sh->spec_trans[1], f2 * sh->spec_trans[2]);
+                    float dom = v_dot(bs_wo, m);
+                    dwh_dwo = (f_sqr(bs_eta) * dom) / f_sqr(dwm + bs_eta * dom);
+                }
+                float g1 = ggx_smith_g1(g, bs_wo, m);
+                bs_pdf *= fabsf(dwh_dwo);
+                if (mpdf != 0.f) bsdf_weight = v_mul(w, g1);
+            }
         } else if (hit && si.shape->bsdf == ORC_BSDF_ROUGHCONDUCTOR) {
             /* RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF */
             const orc_shape *sh = si.shape;

@@ -342,7 +342,7 @@ def _bsdf_of(props, registry):
             raise ValueError("twosided: exactly one nested BSDF is supported")
         ip = inner[0][1] if inner[0][0] == "bsdf" else registry[inner[0][1]][1]
         rec = _bsdf_of(ip, registry)
-        if rec["bsdf"] in (2, 6):   # twosided.cpp:47-52
+        if rec["bsdf"] in (2, 6, 7):   # twosided.cpp:47-52
             raise ValueError("Only materials without a transmission component can be nested!")
         rec["twosided"] = 1
         return rec
@@ -368,6 +368,29 @@ def _bsdf_of(props, registry):
             raise ValueError("The interior and exterior indices of refraction must be positive!")
         rec.update(bsdf=6, diel_eta=F32(int_ior / ext_ior), spec_refl=_color(props, "specular_reflectance", 1.0),
                    spec_trans=_color(props, "specular_transmittance", 1.0))
+    elif props.plugin == "roughdielectric":   # src/bsdfs/roughdielectric.cpp:163-238
+        int_ior, ext_ior = _lookup_ior(props, "int_ior", "bk7"), _lookup_ior(props, "ext_ior", "air")
+        if int_ior < 0 or ext_ior < 0 or int_ior == ext_ior:
+            raise ValueError("The interior and exterior indices of refraction must be positive and differ!")
+        rec.update(bsdf=7, diel_eta=F32(int_ior / ext_ior), spec_refl=_color(props, "specular_reflectance", 1.0),
+                   spec_trans=_color(props, "specular_transmittance", 1.0))
+        distr = props.get_s("distribution", "beckmann").lower()
+        if distr not in ("beckmann", "ggx"):
+            raise ValueError('Specified an invalid distribution "%s", must be "beckmann" or "ggx"!' % distr)
+        if distr != "ggx":
+            raise ValueError('roughdielectric: only distribution "ggx" is implemented (the Beckmann distribution needs Dr.Jit\'s erf / erfinv '
+                             'approximations, whose source is not part of the reference tree)')
+        if not props.get_b("sample_visible", True):
+            raise ValueError("roughdielectric: only sample_visible = true is implemented")
+        if "alpha_u" in props or "alpha_v" in props:
+            if not ("alpha_u" in props and "alpha_v" in props):
+                raise ValueError("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.")
+            if "alpha" in props:
+                raise ValueError("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.")
+            rec.update(alpha_u=F32(props.get_f("alpha_u", 0.1)), alpha_v=F32(props.get_f("alpha_v", 0.1)))
+        else:
+            a = F32(props.get_f("alpha", 0.1))
+            rec.update(alpha_u=a, alpha_v=a)
     elif props.plugin == "roughconductor":   # src/bsdfs/roughconductor.cpp:177-227
         material = props.get_s("material", "none")
         if material != "none":

@@ -229,6 +229,27 @@ def cornell_specular(res=128, spp=16, area_light=True):
     return s + (AREA_LIGHT if area_light else LIGHT) + "</scene>\n"
 
 
+FROSTED = ('\t<bsdf type="roughdielectric" id="FrostedBSDF">\n\t\t<string name="distribution" value="ggx" />\n\t\t<float name="alpha" value="0.15" />\n'
+           '\t\t<float name="int_ior" value="1.5" />\n\t\t<string name="ext_ior" value="air" />\n\t</bsdf>\n'
+           '\t<bsdf type="roughdielectric" id="BrushedGlassBSDF">\n\t\t<string name="distribution" value="ggx" />\n\t\t<float name="alpha_u" value="0.05" />\n'
+           '\t\t<float name="alpha_v" value="0.3" />\n\t\t<string name="int_ior" value="diamond" />\n\t\t<rgb name="specular_reflectance" value="0.9, 0.95, 1.0" />\n'
+           '\t\t<rgb name="specular_transmittance" value="0.95, 0.9, 0.85" />\n\t</bsdf>\n')
+
+
+def cornell_frosted(res=128, spp=16):
+    """the Cornell room with a frosted-glass ball (static), a moving box of anisotropically brushed diamond-index glass, under the ceiling
+    area light: rough transmission takes part in next-event estimation and the MIS (a glossy lobe), and eta changes along the paths"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        s += bsdf(*b)
+    s += FROSTED
+    for name, m, b in WALLS:
+        s += rect(name, m, b)
+    s += cube("BrushedBox", TALL, "BrushedGlassBSDF", "-0.015")
+    s += sphere("FrostedBall", "FrostedBSDF", ("0.4", "0.35", "0.3"), "0.35")
+    return s + AREA_LIGHT + "</scene>\n"
+
+
 def domino(n_side=32, res=1024, spp=128):
     s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5").replace('value="sinusoidal"', 'value="rectangular"')
     cam = '\t\t\t<lookat origin="0, 9, 16" target="0, 0.3, 0" up="0, 1, 0" />'
@@ -268,6 +289,7 @@ def main():
         "cornell_plastic.xml": cornell_plastic(),
         "cornell_rough.xml": cornell_rough(),
         "cornell_roughplastic.xml": cornell_roughplastic(),
+        "cornell_frosted.xml": cornell_frosted(),
         "cornell_spheres.xml": cornell_spheres(),
         "cornell_sphere_light.xml": cornell_spheres(sphere_light=True),
         "domino.xml": domino(),
@@ -281,7 +303,7 @@ def main():
 
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
-    names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml",
+    names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml",
              "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):

@@ -56,6 +56,7 @@ CONFIGS = [
     ("plastic_boxes", "cornell_plastic.xml", dict(resx=24, resy=24), 8),
     ("rough_conductor_boxes", "cornell_rough.xml", dict(resx=24, resy=24, max_depth=5), 8),
     ("rough_plastic_boxes", "cornell_roughplastic.xml", dict(resx=24, resy=24, max_depth=5), 8),
+    ("frosted_glass", "cornell_frosted.xml", dict(resx=24, resy=24, max_depth=6), 8),
     ("spheres", "cornell_spheres.xml", dict(resx=24, resy=24), 8),
     ("sphere_light", "cornell_sphere_light.xml", dict(resx=24, resy=24, max_depth=5), 8),
 ]
