@@ -21,414 +21,17 @@
 #include "dtof_scene.h"
 #include "dtof_math.h"
 
+#define DTOF_D __device__ __forceinline__
+namespace dtof { constexpr int kBlock = 256; }
+#include "dtof_traverse.h"
+#include "dtof_sampling.h"
+#include "dtof_shading.h"
+
 #include <stdexcept>
 
 namespace dtof {
 
-#define DTOF_D __device__ __forceinline__
-constexpr int kBlock = 256;
-
-// ---------------------------------------------------------------------------- scene view
-struct SceneView {
-    const BvhNode *nodes; const DObject *objects; const DGroup *groups; const DShape *shapes;
-    const DTri *tris; const DTriShade *shading; const DEmitter *emitters; const uint8_t *base;
-    uint32_t n_nodes, n_emitters;
-};
-DTOF_D SceneView make_view(const uint8_t *base) {
-    const BlobHeader *h = (const BlobHeader *) base;
-    SceneView v;
-    v.nodes = (const BvhNode *) (base + h->off_nodes);
-    v.objects = (const DObject *) (base + h->off_objects);
-    v.groups = (const DGroup *) (base + h->off_groups);
-    v.shapes = (const DShape *) (base + h->off_shapes);
-    v.tris = (const DTri *) (base + h->off_tris);
-    v.shading = (const DTriShade *) (base + h->off_shading);
-    v.emitters = (const DEmitter *) (base + h->off_emitters);
-    v.base = base;
-    v.n_nodes = h->n_nodes; v.n_emitters = h->n_emitters;
-    return v;
-}
-// Stage the whole scene blob into LDS (small scenes: the Cornell blob is ~5 KB).
-DTOF_D const uint8_t *stage_scene(const uint8_t *g, uint32_t bytes, uint4 *lds) {
-    const uint4 *src = (const uint4 *) g;
-    for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) lds[i] = src[i];
-    __syncthreads();
-    return (const uint8_t *) lds;
-}
-
-struct Hit { float t, u, v; uint32_t obj, shape, prim; };
-
-// ---------------------------------------------------------------------------- primitives
-// Rectangle::ray_intersect_preliminary_impl, src/shapes/rectangle.cpp:201-224
-DTOF_D bool rect_hit(const DShape &sh, V3 o, V3 d, float maxt, float &t, float &u, float &v) {
-    V3 lo = xf_point(sh.to_object, o), ld = xf_vector(sh.to_object, d);
-    t = -lo.z / ld.z;
-    u = fmaf(ld.x, t, lo.x); v = fmaf(ld.y, t, lo.y);
-    return t >= 0.f && t <= maxt && fabsf(u) <= 1.f && fabsf(v) <= 1.f;
-}
-// Moeller-Trumbore as in Embree 3's triangle intersector (tnear < t <= tfar; u,v weight vertices 1,2).
-// The 48-byte record is fetched with three 16-byte loads issued together; `face` rides in p0.w.
-DTOF_D bool tri_hit(const DTri &tr, V3 o, V3 d, float maxt, float &t, float &u, float &v, uint32_t &face) {
-    const uint4 *tp = (const uint4 *) &tr;
-    const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-    face = q0.w;
-    V3 p0 = mk(u2f(q0.x), u2f(q0.y), u2f(q0.z)), p1 = mk(u2f(q1.x), u2f(q1.y), u2f(q1.z)), p2 = mk(u2f(q2.x), u2f(q2.y), u2f(q2.z));
-    V3 e1 = p0 - p1, e2 = p2 - p0, ng = cross(e2, e1);
-    V3 c = p0 - o, r = cross(c, d);
-    float den = dot(ng, d), aden = fabsf(den);
-    uint32_t sgn = f2u(den) & 0x80000000u;
-    float U = u2f(f2u(dot(r, e2)) ^ sgn), Vv = u2f(f2u(dot(r, e1)) ^ sgn);
-    if (!(den != 0.f && U >= 0.f && Vv >= 0.f && U + Vv <= aden)) return false;
-    float T = u2f(f2u(dot(ng, c)) ^ sgn);
-    if (!(0.f < T && T <= aden * maxt)) return false;
-    float rc = 1.0f / aden;
-    u = U * rc; v = Vv * rc; t = T * rc;
-    return true;
-}
-// math::solve_quadratic (include/mitsuba/core/math.h:357-401), float64
-DTOF_D bool solve_quadratic_d(double a, double b, double c, double &x0, double &x1) {
-    const bool linear = a == 0.0, valid_linear = linear && b != 0.0;
-    x0 = x1 = -c / b;
-    const double discrim = fma(b, b, -(4.0 * a * c));
-    const bool valid_quadratic = !linear && discrim >= 0.0;
-    if (valid_quadratic) {
-        const double sq = sqrt(discrim), temp = -0.5 * (b + copysign(sq, b));
-        const double x0p = temp / a, x1p = c / temp;
-        x0 = x0p < x1p ? x0p : x1p; x1 = x0p < x1p ? x1p : x0p;
-    }
-    return valid_linear || valid_quadratic;
-}
-DTOF_D double dot3d(double ax, double ay, double az, double bx, double by, double bz) { return fma(az, bz, fma(ay, by, ax * bx)); }
-// Sphere::ray_intersect_preliminary_impl (src/shapes/sphere.cpp:338-394) / ray_test_impl (:396-431): float64 on the llvm back
-// end; the point of the ray closest to the centre is evaluated with the FLOAT ray (Ray::operator() takes a Float, ray.h:61).
-template <bool ANY>
-DTOF_D bool sphere_hit(const DShape &sh, V3 o, V3 d, float maxt_f, float &t_out) {
-    const double radius = sh.dp_du[0], cx = sh.n[0], cy = sh.n[1], cz = sh.n[2], maxt = maxt_f;
-    const double dx = d.x, dy = d.y, dz = d.z;
-    double near_t, far_t;
-    if (ANY) {
-        const double ox = (double) o.x - cx, oy = (double) o.y - cy, oz = (double) o.z - cz;
-        const double A = dot3d(dx, dy, dz, dx, dy, dz), B = 2.0 * dot3d(ox, oy, oz, dx, dy, dz), C = dot3d(ox, oy, oz, ox, oy, oz) - radius * radius;
-        const bool found = solve_quadratic_d(A, B, C, near_t, far_t);
-        const bool out_bounds = !(near_t <= maxt && far_t >= 0.0), in_bounds = near_t < 0.0 && far_t > maxt;
-        return found && !out_bounds && !in_bounds;
-    }
-    const double lx = (double) o.x - cx, ly = (double) o.y - cy, lz = (double) o.z - cz;
-    const double plane_t = dot3d(-lx, -ly, -lz, dx, dy, dz) / sqrt(dot3d(dx, dy, dz, dx, dy, dz));
-    bool no_hit = plane_t == 0.0 && (o.x != sh.n[0] && o.y != sh.n[1] && o.z != sh.n[2]);
-    const V3 pp = vfma(d, (float) plane_t, o);
-    const double ox = (double) pp.x - cx, oy = (double) pp.y - cy, oz = (double) pp.z - cz;
-    no_hit = no_hit && sqrt(dot3d(ox, oy, oz, ox, oy, oz)) > radius;
-    const double A = dot3d(dx, dy, dz, dx, dy, dz), B = 2.0 * dot3d(ox, oy, oz, dx, dy, dz), C = dot3d(ox, oy, oz, ox, oy, oz) - radius * radius;
-    const bool found = solve_quadratic_d(A, B, C, near_t, far_t);
-    near_t += plane_t; far_t += plane_t;
-    const bool out_bounds = !(near_t <= maxt && far_t >= 0.0), in_bounds = near_t < 0.0 && far_t > maxt;
-    if (!(found && !no_hit && !out_bounds && !in_bounds)) return false;
-    t_out = near_t < 0.0 ? (float) far_t : (float) near_t;
-    return true;
-}
-// AnimatedTransform::eval, include/mitsuba/core/transform.h:439-466
-DTOF_D void instance_matrix(const DObject &ob, float time, float *m) {
-    if (ob.n_keys <= 1) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) m[i] = ob.key0[i];
-        return;
-    }
-    float t = fmin_(fmax_((time - ob.t0) / (ob.t1 - ob.t0), 0.f), 1.f), omt = 1 - t;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) m[i] = ob.key0[i] * omt + ob.key1[i] * t;
-}
-
-// Slab test against a padded box; NaNs (0*inf) fall out of the min/max chain conservatively.
-DTOF_D float box_entry(const float *bmin, const float *bmax, V3 o, V3 id, float tbest) {
-    float tx0 = (bmin[0] - o.x) * id.x, tx1 = (bmax[0] - o.x) * id.x;
-    float ty0 = (bmin[1] - o.y) * id.y, ty1 = (bmax[1] - o.y) * id.y;
-    float tz0 = (bmin[2] - o.z) * id.z, tz1 = (bmax[2] - o.z) * id.z;
-    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
-    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
-    return tn <= tf ? tn : INFINITY;
-}
-// One BVH node = four 16-byte loads issued together (no load depends on a field of the node); entry distances of both
-// children, INFINITY = missed / absent.
-DTOF_D void node_test(const BvhNode *node, V3 o, V3 id, float tbest, float &tl, float &tr, uint32_t &left, uint32_t &right) {
-    const uint4 *np = (const uint4 *) node;
-    const uint4 a = np[0], b = np[1], c = np[2], d = np[3];
-    const float lmin[3] = { u2f(a.x), u2f(a.y), u2f(a.z) }, lmax[3] = { u2f(b.x), u2f(b.y), u2f(b.z) };
-    const float rmin[3] = { u2f(c.x), u2f(c.y), u2f(c.z) }, rmax[3] = { u2f(d.x), u2f(d.y), u2f(d.z) };
-    left = a.w; right = b.w;
-    tl = box_entry(lmin, lmax, o, id, tbest);
-    tr = box_entry(rmin, rmax, o, id, tbest);
-    if (right == kNoChild) tr = INFINITY;
-}
-
-// Closest hit (ANY=false) or occlusion (ANY=true) of one top-level object.  Candidates are every
-// primitive hit with t <= maxt; the winner is the smallest t, ties going to the lowest
-// (object, shape, face) -- the rule the oracle uses, independent of traversal order.
-// `stack + sp * stride` onwards is free for the BLAS traversal of a mesh.
-template <bool ANY, bool MESH>
-DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float time, float maxt, Hit &best,
-                             uint32_t *stack, int sp, uint32_t stride) {
-    const DObject &ob = sv.objects[oi];
-    uint32_t first = ob.index, count = 1;
-    V3 lo = o, ld = d;
-    if (ob.kind == OBJ_INSTANCE) {
-        float m[12], inv[12];
-        instance_matrix(ob, time, m);
-        affine_inverse(m, inv);
-        lo = xf_point(inv, o); ld = xf_vector(inv, d);
-        const DGroup &g = sv.groups[ob.index];
-        first = g.first_shape; count = g.n_shapes;
-    }
-    bool found = false;
-    for (uint32_t k = 0; k < count; ++k) {
-        const DShape &sh = sv.shapes[first + k];
-        float t, u, v;
-        if (sh.kind == SHAPE_RECT) {
-            if (rect_hit(sh, lo, ld, maxt, t, u, v)) {
-                if (ANY) return true;
-                if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
-                    best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = 0; found = true;
-                }
-            }
-            continue;
-        }
-        if (!MESH) continue;   // instantiations for rectangle-only scenes carry no triangle / sphere code at all
-        if (sh.kind == SHAPE_SPHERE) {
-            if (sphere_hit<ANY>(sh, lo, ld, maxt, t)) {
-                if (ANY) return true;
-                if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
-                    best.t = t; best.u = 0.f; best.v = 0.f; best.obj = oi; best.shape = k; best.prim = 0; found = true;
-                }
-            }
-            continue;
-        }
-        // cull with the mesh's own (padded) bounds: TLAS boxes of moving instances are the union over the whole
-        // motion and let many rays through that miss the mesh at their time
-        V3 lid = mk(__builtin_amdgcn_rcpf(ld.x == 0.f ? 1e-30f : ld.x), __builtin_amdgcn_rcpf(ld.y == 0.f ? 1e-30f : ld.y), __builtin_amdgcn_rcpf(ld.z == 0.f ? 1e-30f : ld.z));
-        if (!(box_entry(sh.bmin, sh.bmax, lo, lid, ANY ? maxt : best.t) < INFINITY)) continue;
-        // `face` of the best hit so far IF it lies on this very mesh (ties between two of its triangles go to the lower face)
-        uint32_t best_face = 0xffffffffu;
-        auto test = [&](uint32_t f) -> bool {
-            uint32_t face;
-            if (!tri_hit(sv.tris[sh.first_tri + f], lo, ld, maxt, t, u, v, face)) return false;
-            if (ANY) return true;
-            bool take = t < best.t;
-            if (t == best.t) take = best_face != 0xffffffffu ? face < best_face : (!found && best.obj != 0xffffffffu && oi < best.obj);
-            if (take) { best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = f; best_face = face; found = true; }
-            return false;
-        };
-        if (sh.blas_root == kNoChild) {
-            for (uint32_t f = 0; f < sh.n_tris; ++f) if (test(f)) return true;
-            continue;
-        }
-        // BLAS: same node format and while-while shape as the TLAS loop below
-        constexpr uint32_t kDone = 0x7fffffffu;
-        uint32_t cur = sh.blas_root; int bsp = sp;
-        for (;;) {
-            while (!(cur & kLeafFlag) && cur != kDone) {
-                float tl, tr; uint32_t left, right;
-                node_test(sv.nodes + cur, lo, lid, ANY ? maxt : best.t, tl, tr, left, right);
-                bool hl = tl < INFINITY, hr = tr < INFINITY;
-                if (hl && hr) {
-                    uint32_t nearc = tl <= tr ? left : right, farc = tl <= tr ? right : left;
-                    stack[bsp * stride] = farc; ++bsp;
-                    cur = nearc;
-                } else if (hl) cur = left;
-                else if (hr) cur = right;
-                else if (bsp == sp) cur = kDone;
-                else { --bsp; cur = stack[bsp * stride]; }
-            }
-            if (cur == kDone) break;
-            uint32_t f0 = (cur & ~kLeafFlag) >> kBlasLeafBits, fn = (cur & ((1u << kBlasLeafBits) - 1u)) + 1u;
-            for (uint32_t f = f0; f < f0 + fn; ++f) if (test(f)) return true;
-            if (bsp == sp) break;
-            --bsp; cur = stack[bsp * stride];
-        }
-    }
-    return found;
-}
-
-// TLAS traversal; `stack` is a per-thread LDS column (stride blockDim.x).
-template <bool ANY, bool MESH>
-DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best) {
-    best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
-    if (sv.n_nodes == 0) return false;
-    // direction reciprocal for the slab test only (exact zero components are nudged)
-    // v_rcp_f32 (1 ulp) is enough here: the boxes are padded by 1e-5 relative on the host
-    V3 id = mk(__builtin_amdgcn_rcpf(d.x == 0.f ? 1e-30f : d.x), __builtin_amdgcn_rcpf(d.y == 0.f ? 1e-30f : d.y), __builtin_amdgcn_rcpf(d.z == 0.f ? 1e-30f : d.z));
-    // "while-while" traversal: every lane first descends inner nodes until it holds a leaf (or is done), THEN the
-    // lanes that hold a leaf run the expensive object intersection together -- the wave does not pay the leaf
-    // body once per node step of its slowest lane.
-    constexpr uint32_t kDone = 0x7fffffffu;
-    int sp = 0;
-    uint32_t cur = 0;
-    const uint32_t stride = blockDim.x;
-    for (;;) {
-        while (!(cur & kLeafFlag) && cur != kDone) {
-            float tl, tr; uint32_t left, right;
-            node_test(sv.nodes + cur, o, id, best.t, tl, tr, left, right);
-            bool hl = tl < INFINITY, hr = tr < INFINITY;
-            if (hl && hr) {
-                uint32_t nearc = tl <= tr ? left : right, farc = tl <= tr ? right : left;
-                stack[sp * stride] = farc; ++sp;
-                cur = nearc;
-            } else if (hl) cur = left;
-            else if (hr) cur = right;
-            else if (sp == 0) cur = kDone;
-            else { --sp; cur = stack[sp * stride]; }
-        }
-        if (cur == kDone) break;
-        if (intersect_object<ANY, MESH>(sv, cur & ~kLeafFlag, o, d, time, maxt, best, stack, sp, stride) && ANY) return true;
-        if (sp == 0) break;
-        --sp; cur = stack[sp * stride];
-    }
-    return best.obj != 0xffffffffu;
-}
-
-// ---------------------------------------------------------------------------- sampler
-struct Rng { uint64_t state, inc; };
-DTOF_D float next_f32(Rng &r) { return pcg_next_f32(r.state, r.inc); }
-// PCG32Sampler::seed / CorrelatedSampler::seed -- sampler.cpp:115-134, correlated.cpp:38-64
-DTOF_D Rng seed_stream(uint32_t seed_value, uint32_t index) {
-    uint32_t v0, v1; tea32(seed_value, index, v0, v1);
-    Rng r; pcg_seed(v0, v1, r.state, r.inc); return r;
-}
-DTOF_D uint64_t stream_inc(uint32_t seed_value, uint32_t index) {
-    uint32_t v0, v1; tea32(seed_value, index, v0, v1);
-    return ((uint64_t) v1 << 1) | 1u;
-}
-// next_1d_correlate -- correlated.cpp:156-161
-DTOF_D float next_correlate(Rng &main, Rng &path, bool correlate) {
-    float r1 = next_f32(path), r2 = next_f32(main);
-    return correlate ? r1 : r2;
-}
-// next_1d_time -- correlated.cpp:92-153; si = current_sample_index (sampler.cpp:94-103)
-DTOF_D float next_time(const RenderParams &rp, Rng &main, Rng &tm, uint32_t si, uint32_t perm_seed, uint32_t &dim) {
-    int strategy = rp.time_sampling; uint32_t tcn = rp.tcn;
-    if (strategy == TIME_UNIFORM) return next_f32(main);
-    float r = strategy == TIME_STRATIFIED ? next_f32(main) : next_f32(tm);
-    if (rp.stratify) {
-        if (strategy == TIME_STRATIFIED) {
-            // the reference evaluates p1 (seed + dim) and p2 (seed + dim + 1) and selects; the permutation is a pure function,
-            // so only the selected one is computed
-            const uint32_t ps = perm_seed + dim + ((si % tcn != 0) ? 0u : 1u);
-            dim += 2;
-            const uint32_t p = permute_kensler(si / tcn, rp.n_stratum, ps);
-            r = ((float) p + r) * rp.inv_n_stratum;
-        } else {
-            r = ((float) (si / tcn) + r) * rp.inv_n_stratum;
-        }
-    }
-    if (strategy == TIME_STRATIFIED) return ((float) (si % tcn) + r) * rp.inv_tcn;
-    if (strategy == TIME_ANTITHETIC) {
-        uint32_t rem = si % tcn;
-        if (tcn == 2) { float r2 = r + rp.antithetic_shift; return rem != 1 ? r : r2; }
-        return r + (float) rem / (float) tcn;
-    }
-    // TIME_ANTITHETIC_MIRROR
-    float r2 = 1.0f - r + rp.antithetic_shift;
-    return (si % tcn) != 1 ? r : r2;
-}
-
-// ---------------------------------------------------------------------------- modulation
-// waveform_utils.h:24-33
-DTOF_D float waveform(float _t, int type) {
-    float t = fmodf(_t, 2.f * kPi);
-    if (type == WAVE_RECT) return fabsf(t - kPi) > 0.5f * kPi ? 1.f : -1.f;
-    if (type == WAVE_TRI) return t < kPi ? 1.f - 2.f * t * (1.0f / kPi) : -3.f + 2.f * t * (1.0f / kPi);
-    return cos_(t);
-}
-// waveform_utils.h:36-62
-DTOF_D float waveform_low_pass(float _t, int type) {
-    float t = fmodf(_t, 2.f * kPi);
-    if (type == WAVE_SIN) return cos_(t);
-    float a = t * (1.0f / kPi), b = 2.f - a, c = a < b ? a : b;
-    if (type == WAVE_RECT) return 2.f - 4.f * c;
-    if (type == WAVE_TRI) return (4.f * c * c * c - 6.f * c * c + 1.f) * 2.0f * (1.0f / 3.0f);
-    float r = 2.f - 4.f * c;
-    return fmin_(fmax_(2.0f * r, -2.0f), 2.0f);
-}
-// eval_modulation_weight -- dopplertofpath.cpp:60-77
-DTOF_D float modulation_weight(const RenderParams &rp, float phase, float ray_time, float path_length) {
-    float phi = rp.phi_coef * path_length;
-    if (rp.low_pass) {
-        float t = rp.w_d * ray_time + phase + phi;
-        return rp.amp * waveform_low_pass(t, rp.wave_type);
-    }
-    float t1 = rp.w_g * ray_time - phi;
-    float t2 = (rp.w_g + rp.w_d) * ray_time + phase;
-    float g_t = rp.g_1 * waveform(t1, rp.wave_type) + rp.g_0;
-    float s_t = waveform(t2, rp.wave_type);
-    return s_t * g_t;
-}
-
 // ---------------------------------------------------------------------------- generate
-// One lane of render_sample's head (integrator.cpp:476-495 / :416-431): sampler seeding, pixel jitter, time sample, camera ray.
-struct PrimaryLane { float4 ray_a, ray_b; Rng main, path; float2 pos; };
-// global lane index (pixel-major, the index every stream of the sampler is seeded with) of a lane of this launch
-DTOF_D uint32_t global_lane(const RenderParams &rp, uint32_t virtual_lane) {
-    if (rp.stripe_rows == 0) return virtual_lane;
-    const uint32_t v = virtual_lane / rp.lanes_per_row, in_row = virtual_lane - v * rp.lanes_per_row;
-    const uint32_t s = v / rp.stripe_rows, y = rp.stripe_first + s * rp.stripe_period + (v - s * rp.stripe_rows);
-    return y * rp.lanes_per_row + in_row;
-}
-DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane) {
-    Rng main = seed_stream(rp.seed_value, lane);
-    // m_rng_time is only drawn from by the antithetic strategies of the correlated sampler (correlated.cpp:96-106)
-    const bool needs_tm = rp.integrator == 0 && rp.sampler_kind == SAMPLER_CORRELATED && (rp.time_sampling == TIME_ANTITHETIC || rp.time_sampling == TIME_ANTITHETIC_MIRROR);
-    Rng tm; tm.state = 0; tm.inc = 1;
-    if (needs_tm) tm = seed_stream(rp.seed_value + 1, lane / rp.tcn);
-    Rng path = seed_stream(rp.seed_value + 2, lane / rp.pcn);
-    uint32_t pix = rp.spp_log2 != 0xffffffffu ? lane >> rp.spp_log2 : lane / rp.spp;
-    uint32_t si = rp.spp > 1 ? lane - pix * rp.spp : 0;
-    uint32_t perm_seed, tmp; tea32(rp.base_seed, rp.spp * pix + rp.seed, perm_seed, tmp);
-    uint32_t dim = 0;
-
-    uint32_t W = (uint32_t) rp.crop_w;
-    uint32_t py = pix / W, px = pix - W * py;
-    float posx = (float) (px + (uint32_t) rp.crop_x), posy = (float) (py + (uint32_t) rp.crop_y);
-    bool cp = rp.path_correlation_depth > 0;
-    const bool doppler = rp.integrator == 0;
-    // one stream only: the plain branch of render_sample (integrator.cpp:416-431: next_2d / next_1d), and every sampler but
-    // `correlated` (Sampler::next_*_correlate default to next_1d / next_2d, include/mitsuba/render/sampler.h:141-144)
-    const bool single = !doppler || rp.sampler_kind != SAMPLER_CORRELATED;
-    float jx = single ? next_f32(main) : next_correlate(main, path, cp), jy = single ? next_f32(main) : next_correlate(main, path, cp);
-    float spx = posx + jx, spy = posy + jy;
-    float ax = fmaf(spx, rp.scale_x, rp.offset_x), ay = fmaf(spy, rp.scale_y, rp.offset_y);
-    float time = rp.shutter_open;
-    if (rp.shutter_open_time > 0.f) {
-        float u;
-        if (!doppler || rp.sampler_kind == SAMPLER_INDEPENDENT) u = next_f32(main);   // Sampler::next_1d_time -> next_1d (sampler.h:131-132)
-        else if (rp.sampler_kind == SAMPLER_CORRELATED) u = next_time(rp, main, tm, si, perm_seed, dim);
-        else {   // TimeStratifiedSampler::next_1d_time (timestratified.cpp:117-129): the strategy arguments are ignored
-            uint32_t p = permute_kensler(si, rp.spp, perm_seed + dim++);
-            float j = rp.jitter ? next_f32(main) : .5f;
-            u = ((float) p + j) * rp.inv_spp;
-        }
-        time += u * rp.shutter_open_time;
-    }
-
-    // PerspectiveCamera::sample_ray_differential (perspective.cpp:238-279)
-    const float *m = rp.s2c;
-    float r0 = fmaf(m[2], 0.f, fmaf(m[1], ay, fmaf(m[0], ax, m[3])));
-    float r1 = fmaf(m[6], 0.f, fmaf(m[5], ay, fmaf(m[4], ax, m[7])));
-    float r2 = fmaf(m[10], 0.f, fmaf(m[9], ay, fmaf(m[8], ax, m[11])));
-    float r3 = fmaf(m[14], 0.f, fmaf(m[13], ay, fmaf(m[12], ax, m[15])));
-    float iw = rcp(r3);
-    V3 d = normalize(mk(r0 * iw, r1 * iw, r2 * iw));
-    V3 o = mk(rp.cam_to_world[3], rp.cam_to_world[7], rp.cam_to_world[11]);
-    V3 dw = xf_vector(rp.cam_to_world, d);
-    float inv_z = rcp(d.z), near_t = rp.near_clip * inv_z, far_t = rp.far_clip * inv_z;
-    o = o + dw * near_t;
-    float maxt = far_t - near_t;
-    if (doppler) time = time < rp.T ? time : time - rp.T;   // dopplertofpath.cpp:93
-
-    PrimaryLane pl;
-    pl.ray_a = make_float4(o.x, o.y, o.z, time);
-    pl.ray_b = make_float4(dw.x, dw.y, dw.z, maxt);
-    pl.main = main; pl.path = path; pl.pos = make_float2(spx, spy);
-    return pl;
-}
 __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= rp.n_lanes) return;
@@ -479,232 +82,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 64 ? 6 : 1) void k_trace(const uint
 }
 
 // ---------------------------------------------------------------------------- shade
-struct Surface { V3 p, n, sh_n, sh_s, sh_t, wi; const DShape *shape; };
-
-// Shape::compute_surface_interaction for rectangle (rectangle.cpp:250-323) / mesh (mesh.cpp:632-864),
-// Instance::compute_surface_interaction (instance.cpp:155-250), finalize (interaction.h:493-513)
-template <bool MESH>
-DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, uint32_t prim, float t, float b1, float b2,
-                            V3 o, V3 d, float time, Surface &si) {
-    const DObject &ob = sv.objects[oi];
-    bool inst = ob.kind == OBJ_INSTANCE;
-    float m[12], inv[12];
-    V3 lo = o, ld = d;
-    const DShape *sh;
-    if (inst) {
-        instance_matrix(ob, time, m);
-        affine_inverse(m, inv);
-        lo = xf_point(inv, o); ld = xf_vector(inv, d);
-        sh = &sv.shapes[sv.groups[ob.index].first_shape + shape_k];
-    } else sh = &sv.shapes[ob.index];
-    si.shape = sh;
-    V3 dp_du, dp_dv;
-    if (!MESH || sh->kind == SHAPE_RECT) {
-        V3 n = mk(sh->n[0], sh->n[1], sh->n[2]);
-        V3 p = vfma(ld, t, lo);
-        V3 tr = mk(sh->to_world[3], sh->to_world[7], sh->to_world[11]);
-        float dist = dot(tr - p, n);
-        si.p = p + n * dist; si.n = n; si.sh_n = n;
-        dp_du = mk(sh->dp_du[0], sh->dp_du[1], sh->dp_du[2]);
-        dp_dv = mk(sh->dp_dv[0], sh->dp_dv[1], sh->dp_dv[2]);
-    } else if (sh->kind == SHAPE_SPHERE) {   // Sphere::compute_surface_interaction (sphere.cpp:509-513, 527-551)
-        const V3 c = mk(sh->n[0], sh->n[1], sh->n[2]); const float radius = sh->dp_du[0];
-        V3 n = normalize(vfma(ld, t, lo) - c);
-        si.p = vfma(n, radius, c);
-        const V3 local = xf_point(sh->to_object, si.p);
-        const float rd = sqrtf(sqr(local.x) + sqr(local.y)), inv_rd = rcp(rd);
-        V3 dpv = mk(local.z * (local.x * inv_rd), local.z * (local.y * inv_rd), -rd);
-        if (rd == 0.f) dpv = mk(1.f, 0.f, 0.f);
-        dp_du = xf_vector(sh->to_world, mk(-local.y, local.x, 0.f)) * (2.f * kPi);
-        dp_dv = xf_vector(sh->to_world, dpv) * kPi;
-        if (sh->flags & SF_FLIP_NORMALS) n = -n;
-        si.n = n; si.sh_n = n;
-    } else {
-        const DTri &tr = sv.tris[sh->first_tri + prim];
-        const DTriShade &ts = sv.shading[sh->first_tri + prim];
-        V3 p0 = mk(tr.p0[0], tr.p0[1], tr.p0[2]), p1 = mk(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = mk(tr.p2[0], tr.p2[1], tr.p2[2]);
-        float b0 = 1.f - b1 - b2;
-        V3 dp0 = p1 - p0, dp1 = p2 - p0;
-        si.p = vfma(p0, b0, vfma(p1, b1, p2 * b2));
-        si.n = normalize(cross(dp0, dp1));
-        coordinate_system(si.n, dp_du, dp_dv);
-        float d0x = ts.uv1[0] - ts.uv0[0], d0y = ts.uv1[1] - ts.uv0[1], d1x = ts.uv2[0] - ts.uv0[0], d1y = ts.uv2[1] - ts.uv0[1];
-        float det = fmaf(d0x, d1y, -(d0y * d1x)), inv_det = rcp(det);
-        if (det != 0.f) {
-            dp_du = mk(fmaf(d1y, dp0.x, -(d0y * dp1.x)), fmaf(d1y, dp0.y, -(d0y * dp1.y)), fmaf(d1y, dp0.z, -(d0y * dp1.z))) * inv_det;
-            dp_dv = mk(fmaf(-d1x, dp0.x, d0x * dp1.x), fmaf(-d1x, dp0.y, d0x * dp1.y), fmaf(-d1x, dp0.z, d0x * dp1.z)) * inv_det;
-        }
-        if (!(sh->flags & SF_FACE_NORMALS)) {
-            V3 n0 = mk(ts.n0[0], ts.n0[1], ts.n0[2]), n1 = mk(ts.n1[0], ts.n1[1], ts.n1[2]), n2 = mk(ts.n2[0], ts.n2[1], ts.n2[2]);
-            V3 n = vfma(n2, b2, vfma(n1, b1, n0 * b0));
-            si.sh_n = n * rsqrt_(dot(n, n));
-        } else si.sh_n = si.n;
-        if (sh->flags & SF_FLIP_NORMALS) { si.n = -si.n; si.sh_n = -si.sh_n; }
-    }
-    if (inst) {
-        si.p = xf_point(m, si.p);
-        si.n = normalize(xf_normal(inv, si.n));
-        si.sh_n = normalize(xf_normal(inv, si.sh_n));
-        dp_du = xf_vector(m, dp_du);
-    }
-    // initialize_sh_frame (interaction.h:258-268)
-    V3 s = normalize(vfma(si.sh_n, -dot(si.sh_n, dp_du), dp_du));
-    if (dp_du.x == 0.f && dp_du.y == 0.f && dp_du.z == 0.f) { V3 tt; coordinate_system(si.sh_n, s, tt); }
-    si.sh_s = s; si.sh_t = cross(si.sh_n, s);
-    V3 md = -d;
-    si.wi = mk(dot(md, si.sh_s), dot(md, si.sh_t), dot(md, si.sh_n));
-}
-// Interaction::offset_p (interaction.h:161-165)
-DTOF_D V3 offset_p(const Surface &si, V3 d) {
-    float mag = (1.f + fmax_(fmax_(fabsf(si.p.x), fabsf(si.p.y)), fabsf(si.p.z))) * kRayEps;
-    mag = mulsign(mag, dot(si.n, d));
-    return vfma(si.n, mag, si.p);
-}
-// warp::square_to_cosine_hemisphere (warp.h:54-86, 320-344)
-DTOF_D V3 cosine_hemisphere(float sx, float sy) {
-    float x = fmaf(2.f, sx, -1.f), y = fmaf(2.f, sy, -1.f);
-    bool is_zero = x == 0.f && y == 0.f, q13 = fabsf(x) < fabsf(y);
-    float r = q13 ? y : x, rp = q13 ? x : y;
-    float phi = 0.25f * kPi * rp / r;
-    if (q13) phi = 0.5f * kPi - phi;
-    if (is_zero) phi = 0.f;
-    float s, c; sincos_(phi, s, c);
-    float px = r * c, py = r * s;
-    return mk(px, py, sqrtf(fmax_(1.f - fmaf(py, py, px * px), 0.f)));
-}
-// Mesh::sample_position (mesh.cpp:513-568): face by DiscreteDistribution::sample_reuse on sample.y (distr_1d.h:113-160,
-// dr::binary_search over [m_valid.x, m_valid.y]), point by warp::square_to_uniform_triangle (warp.h:153-156), normal from
-// the vertex normals if the mesh has them.
-DTOF_D void mesh_sample_position(const SceneView &sv, const DShape &es, float s_x, float s_y, V3 &p, V3 &n) {
-    const float *cdf = (const float *) (sv.base + es.emit_table), *pmf = cdf + es.n_tris;
-    const uint32_t *slot = (const uint32_t *) (pmf + es.n_tris);
-    const float v = s_y * es.emit_sum;
-    uint32_t lo = es.emit_lo, hi = es.emit_hi;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (cdf[mid] < v) lo = mid + 1 < hi ? mid + 1 : hi; else hi = mid;
-    }
-    const float pm = pmf[lo] * es.inv_area, cd = lo > 0 ? cdf[lo - 1] * es.inv_area : 0.f;
-    const float y = (s_y - cd) / pm;
-    const uint32_t k = es.first_tri + slot[lo];
-    const DTri &tr = sv.tris[k];
-    V3 p0 = mk(tr.p0[0], tr.p0[1], tr.p0[2]), p1 = mk(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = mk(tr.p2[0], tr.p2[1], tr.p2[2]);
-    V3 e0 = p1 - p0, e1 = p2 - p0;
-    const float t = sqrtf(fmax_(1.f - s_x, 0.f)), bx = 1.f - t, by = t * y;
-    p = vfma(e0, bx, vfma(e1, by, p0));
-    if (!(es.flags & SF_FACE_NORMALS)) {
-        const DTriShade &ts = sv.shading[k];
-        V3 n0 = mk(ts.n0[0], ts.n0[1], ts.n0[2]), n1 = mk(ts.n1[0], ts.n1[1], ts.n1[2]), n2 = mk(ts.n2[0], ts.n2[1], ts.n2[2]);
-        n = vfma(n0, 1.f - bx - by, vfma(n1, bx, n2 * by));
-    } else n = cross(e0, e1);
-    n = normalize(n);
-    if (es.flags & SF_FLIP_NORMALS) n = -n;
-}
-
-constexpr float kInvTwoPi = 0.15915494309189533577f;
-DTOF_D float uniform_cone_pdf(float cos_cutoff) { return kInvTwoPi / (1.f - cos_cutoff); }   // warp::square_to_uniform_cone_pdf (warp.h:475-485)
-// Sphere::sample_direction (sphere.cpp:222-296): cone sampling of the visible cap from outside, uniform sphere from inside
-DTOF_D void sphere_sample_direction(const DShape &sh, V3 ref, float s_x, float s_y, V3 &p, V3 &n, V3 &dd, float &dist, float &pdf) {
-    const V3 center = mk(sh.n[0], sh.n[1], sh.n[2]); const float radius = sh.dp_du[0];
-    const bool flip = sh.flags & SF_FLIP_NORMALS;
-    const V3 dc_v = center - ref;
-    const float dc_2 = dot(dc_v, dc_v), radius_adj = radius * (flip ? (1.f + kRayEps) : (1.f - kRayEps));
-    const bool outside = dc_2 > sqr(radius_adj);
-    V3 dloc;
-    if (outside) {
-        const float inv_dc = rsqrt_(dc_2), sin_theta_max = radius * inv_dc, sin_theta_max_2 = sqr(sin_theta_max),
-                    inv_sin_theta_max = rcp(sin_theta_max), cos_theta_max = safe_sqrt(1.f - sin_theta_max_2);
-        const float sin_theta_2 = sin_theta_max_2 > 0.00068523f ? 1.f - sqr(fmaf(cos_theta_max - 1.f, s_x, 1.f)) : sin_theta_max_2 * s_x;
-        const float cos_theta = safe_sqrt(1.f - sin_theta_2);
-        const float cos_alpha = sin_theta_2 * inv_sin_theta_max + cos_theta * safe_sqrt(fmaf(-sin_theta_2, sqr(inv_sin_theta_max), 1.f));
-        const float sin_alpha = safe_sqrt(fmaf(-cos_alpha, cos_alpha, 1.f));
-        float sin_phi, cos_phi; sincos_(s_y * (2.f * kPi), sin_phi, cos_phi);
-        const V3 fn = dc_v * -inv_dc; V3 fs, ft;
-        coordinate_system(fn, fs, ft);
-        dloc = vfma(fn, cos_alpha, vfma(ft, sin_phi * sin_alpha, fs * (cos_phi * sin_alpha)));
-        pdf = uniform_cone_pdf(cos_theta_max);
-    } else {   // warp::square_to_uniform_sphere (warp.h:250-255)
-        const float z = fmaf(-2.f, s_y, 1.f), r = safe_sqrt(fmaf(-z, z, 1.f)); float sn, cs;
-        sincos_(2.f * kPi * s_x, sn, cs);
-        dloc = mk(r * cs, r * sn, z);
-        pdf = 0.f;
-    }
-    p = vfma(dloc, radius, center); dd = p - ref;
-    const float dist2 = dot(dd, dd);
-    dist = sqrtf(dist2);
-    dd = dd * rcp(dist);
-    if (outside) { if (dist == 0.f) pdf = 0.f; }
-    else pdf = sh.inv_area * dist2 / fabsf(dot(dd, dloc));
-    n = flip ? -dloc : dloc;
-}
-// Sphere::pdf_direction (sphere.cpp:298-310)
-DTOF_D float sphere_pdf_direction(const DShape &sh, V3 ref, V3 ds_d, V3 ds_n, float ds_dist) {
-    const V3 center = mk(sh.n[0], sh.n[1], sh.n[2]);
-    const float sin_alpha = sh.dp_du[0] * rcp(norm(center - ref)), cos_alpha = safe_sqrt(1.f - sin_alpha * sin_alpha);
-    return sin_alpha < 0.99999994f ? uniform_cone_pdf(cos_alpha) : sh.inv_area * sqr(ds_dist) / fabsf(dot(ds_d, ds_n));
-}
-// RoughPlastic::lerp_gather (roughplastic.cpp:373-383) on the 64-entry transmittance table
-DTOF_D float lerp_gather64(const float *data, float x) {
-    x *= 63.f;
-    uint32_t index = (uint32_t) x; if (index > 62u) index = 62u;
-    const float v0 = data[index], v1 = data[index + 1], t = x - (float) index;
-    return fmaf(v1, t, fmaf(-v0, t, v0));                        // dr::lerp(v0, v1, t)
-}
-// RoughPlastic::eval (:333-371) and pdf (:385-421) for wi.z > 0 and wo.z > 0
-DTOF_D void rough_plastic_eval_pdf(Ggx g, const DShape *sh, const float *table, V3 diff, V3 wi, V3 wo, float t_i, float prob_specular,
-                                   float prob_diffuse, V3 &value, float &pdf) {
-    const V3 H = normalize(wo + wi);
-    const float D = ggx_eval(g, H);
-    float F, t1, t2, t3; fresnel_dielectric(dot(wi, H), sh->diel_eta, F, t1, t2, t3);
-    const float G = ggx_smith_g1(g, wi, H) * ggx_smith_g1(g, wo, H);
-    const float spec = F * D * G / (4.f * wi.z);
-    const float t_o = lerp_gather64(table, wo.z);
-    const float k = kInvPi * sh->inv_eta_2 * wo.z * t_i * t_o;
-    value = mk(spec * sh->spec_refl[0] + diff.x * k, spec * sh->spec_refl[1] + diff.y * k, spec * sh->spec_refl[2] + diff.z * k);
-    float result = D * ggx_smith_g1(g, wi, H) / (4.f * wi.z);
-    result *= prob_specular;
-    pdf = result + prob_diffuse * (kInvPi * wo.z);
-}
-// RoughDielectric::eval_pdf (roughdielectric.cpp:503-611), GGX + visible normals, TransportMode::Radiance
-DTOF_D void rough_dielectric_eval_pdf(Ggx g, const DShape *sh, V3 wi, V3 wo, V3 &value, float &pdf) {
-    const float cti = wi.z, cto = wo.z, m_eta = sh->diel_eta, m_inv_eta = rcp(m_eta);
-    const bool reflect = cti * cto > 0.f;
-    const float eta = cti > 0.f ? m_eta : m_inv_eta, inv_eta = cti > 0.f ? m_inv_eta : m_eta;
-    V3 m = normalize(wi + wo * (reflect ? 1.f : eta));
-    m = mk(mulsign(m.x, m.z), mulsign(m.y, m.z), mulsign(m.z, m.z));
-    const float dwm = dot(wi, m), dom = dot(wo, m);
-    const bool active = cti != 0.f && dwm * cti > 0.f && dom * cto > 0.f;
-    const float D = ggx_eval(g, m);
-    float F, t1, t2, t3; fresnel_dielectric(dwm, m_eta, F, t1, t2, t3);
-    const float G = ggx_smith_g1(g, wi, m) * ggx_smith_g1(g, wo, m);
-    value = mk(0, 0, 0); pdf = 0.f;
-    if (!active) return;
-    if (reflect) {
-        const float v = F * D * G / (4.f * fabsf(cti));
-        value = mk(v * sh->spec_refl[0], v * sh->spec_refl[1], v * sh->spec_refl[2]);
-    } else {
-        const float scale = sqr(inv_eta);
-        const float v = fabsf((scale * (1.f - F) * D * G * eta * eta * dwm * dom) / (cti * sqr(dwm + eta * dom)));
-        value = mk(v * sh->spec_trans[0], v * sh->spec_trans[1], v * sh->spec_trans[2]);
-    }
-    float p = ggx_pdf(g, mk(mulsign(wi.x, cti), mulsign(wi.y, cti), mulsign(wi.z, cti)), m);
-    p *= reflect ? F : 1.f - F;
-    const float dwh_dwo = reflect ? rcp(4.f * dom) : (eta * eta * dom) / sqr(dwm + eta * dom);
-    pdf = p * fabsf(dwh_dwo);
-}
-// fresnel_conductor -- include/mitsuba/render/fresnel.h:93-117 (one colour channel)
-DTOF_D float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
-    const float cos_theta_i_2 = cos_theta_i * cos_theta_i, sin_theta_i_2 = 1.f - cos_theta_i_2, sin_theta_i_4 = sin_theta_i_2 * sin_theta_i_2;
-    const float temp_1 = eta_r * eta_r - eta_i * eta_i - sin_theta_i_2,
-                a_2_pb_2 = safe_sqrt(temp_1 * temp_1 + 4.f * eta_i * eta_i * eta_r * eta_r),
-                a = safe_sqrt(.5f * (a_2_pb_2 + temp_1));
-    const float term_1 = a_2_pb_2 + cos_theta_i_2, term_2 = 2.f * cos_theta_i * a;
-    const float r_s = (term_1 - term_2) / (term_1 + term_2);
-    const float term_3 = a_2_pb_2 * cos_theta_i_2 + sin_theta_i_4, term_4 = term_2 * sin_theta_i_2;
-    const float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
-    return 0.5f * (r_s + r_p);
-}
-DTOF_D float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
 // Block-wide exclusive prefix of a predicate (ballot + popcount per wave, 4 wave totals through LDS).
 // Returns this lane's slot relative to `running` and advances `running` by the block total.

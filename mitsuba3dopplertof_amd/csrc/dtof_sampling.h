@@ -1,0 +1,160 @@
+#pragma once
+// dtof_sampling.h -- device side of the samplers and of the integrator's modulation: PCG streams, correlated / time draws
+// (src/samplers/correlated.cpp), waveforms (include/mitsuba/render/waveform_utils.h), modulation weight
+// (src/integrators/dopplertofpath.cpp:60-77) and the generation of a lane (sampler seeding, jitter, time, camera ray).
+#include "dtof_kernels.h"
+#include "dtof_scene.h"
+#include "dtof_math.h"
+
+#ifndef DTOF_D
+#define DTOF_D __device__ __forceinline__
+#endif
+
+namespace dtof {
+
+// ---------------------------------------------------------------------------- sampler
+struct Rng { uint64_t state, inc; };
+DTOF_D float next_f32(Rng &r) { return pcg_next_f32(r.state, r.inc); }
+// PCG32Sampler::seed / CorrelatedSampler::seed -- sampler.cpp:115-134, correlated.cpp:38-64
+DTOF_D Rng seed_stream(uint32_t seed_value, uint32_t index) {
+    uint32_t v0, v1; tea32(seed_value, index, v0, v1);
+    Rng r; pcg_seed(v0, v1, r.state, r.inc); return r;
+}
+DTOF_D uint64_t stream_inc(uint32_t seed_value, uint32_t index) {
+    uint32_t v0, v1; tea32(seed_value, index, v0, v1);
+    return ((uint64_t) v1 << 1) | 1u;
+}
+// next_1d_correlate -- correlated.cpp:156-161
+DTOF_D float next_correlate(Rng &main, Rng &path, bool correlate) {
+    float r1 = next_f32(path), r2 = next_f32(main);
+    return correlate ? r1 : r2;
+}
+// next_1d_time -- correlated.cpp:92-153; si = current_sample_index (sampler.cpp:94-103)
+DTOF_D float next_time(const RenderParams &rp, Rng &main, Rng &tm, uint32_t si, uint32_t perm_seed, uint32_t &dim) {
+    int strategy = rp.time_sampling; uint32_t tcn = rp.tcn;
+    if (strategy == TIME_UNIFORM) return next_f32(main);
+    float r = strategy == TIME_STRATIFIED ? next_f32(main) : next_f32(tm);
+    if (rp.stratify) {
+        if (strategy == TIME_STRATIFIED) {
+            // the reference evaluates p1 (seed + dim) and p2 (seed + dim + 1) and selects; the permutation is a pure function,
+            // so only the selected one is computed
+            const uint32_t ps = perm_seed + dim + ((si % tcn != 0) ? 0u : 1u);
+            dim += 2;
+            const uint32_t p = permute_kensler(si / tcn, rp.n_stratum, ps);
+            r = ((float) p + r) * rp.inv_n_stratum;
+        } else {
+            r = ((float) (si / tcn) + r) * rp.inv_n_stratum;
+        }
+    }
+    if (strategy == TIME_STRATIFIED) return ((float) (si % tcn) + r) * rp.inv_tcn;
+    if (strategy == TIME_ANTITHETIC) {
+        uint32_t rem = si % tcn;
+        if (tcn == 2) { float r2 = r + rp.antithetic_shift; return rem != 1 ? r : r2; }
+        return r + (float) rem / (float) tcn;
+    }
+    // TIME_ANTITHETIC_MIRROR
+    float r2 = 1.0f - r + rp.antithetic_shift;
+    return (si % tcn) != 1 ? r : r2;
+}
+
+// ---------------------------------------------------------------------------- modulation
+// waveform_utils.h:24-33
+DTOF_D float waveform(float _t, int type) {
+    float t = fmodf(_t, 2.f * kPi);
+    if (type == WAVE_RECT) return fabsf(t - kPi) > 0.5f * kPi ? 1.f : -1.f;
+    if (type == WAVE_TRI) return t < kPi ? 1.f - 2.f * t * (1.0f / kPi) : -3.f + 2.f * t * (1.0f / kPi);
+    return cos_(t);
+}
+// waveform_utils.h:36-62
+DTOF_D float waveform_low_pass(float _t, int type) {
+    float t = fmodf(_t, 2.f * kPi);
+    if (type == WAVE_SIN) return cos_(t);
+    float a = t * (1.0f / kPi), b = 2.f - a, c = a < b ? a : b;
+    if (type == WAVE_RECT) return 2.f - 4.f * c;
+    if (type == WAVE_TRI) return (4.f * c * c * c - 6.f * c * c + 1.f) * 2.0f * (1.0f / 3.0f);
+    float r = 2.f - 4.f * c;
+    return fmin_(fmax_(2.0f * r, -2.0f), 2.0f);
+}
+// eval_modulation_weight -- dopplertofpath.cpp:60-77
+DTOF_D float modulation_weight(const RenderParams &rp, float phase, float ray_time, float path_length) {
+    float phi = rp.phi_coef * path_length;
+    if (rp.low_pass) {
+        float t = rp.w_d * ray_time + phase + phi;
+        return rp.amp * waveform_low_pass(t, rp.wave_type);
+    }
+    float t1 = rp.w_g * ray_time - phi;
+    float t2 = (rp.w_g + rp.w_d) * ray_time + phase;
+    float g_t = rp.g_1 * waveform(t1, rp.wave_type) + rp.g_0;
+    float s_t = waveform(t2, rp.wave_type);
+    return s_t * g_t;
+}
+
+// ---------------------------------------------------------------------------- generate
+// One lane of render_sample's head (integrator.cpp:476-495 / :416-431): sampler seeding, pixel jitter, time sample, camera ray.
+struct PrimaryLane { float4 ray_a, ray_b; Rng main, path; float2 pos; };
+// global lane index (pixel-major, the index every stream of the sampler is seeded with) of a lane of this launch
+DTOF_D uint32_t global_lane(const RenderParams &rp, uint32_t virtual_lane) {
+    if (rp.stripe_rows == 0) return virtual_lane;
+    const uint32_t v = virtual_lane / rp.lanes_per_row, in_row = virtual_lane - v * rp.lanes_per_row;
+    const uint32_t s = v / rp.stripe_rows, y = rp.stripe_first + s * rp.stripe_period + (v - s * rp.stripe_rows);
+    return y * rp.lanes_per_row + in_row;
+}
+DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane) {
+    Rng main = seed_stream(rp.seed_value, lane);
+    // m_rng_time is only drawn from by the antithetic strategies of the correlated sampler (correlated.cpp:96-106)
+    const bool needs_tm = rp.integrator == 0 && rp.sampler_kind == SAMPLER_CORRELATED && (rp.time_sampling == TIME_ANTITHETIC || rp.time_sampling == TIME_ANTITHETIC_MIRROR);
+    Rng tm; tm.state = 0; tm.inc = 1;
+    if (needs_tm) tm = seed_stream(rp.seed_value + 1, lane / rp.tcn);
+    Rng path = seed_stream(rp.seed_value + 2, lane / rp.pcn);
+    uint32_t pix = rp.spp_log2 != 0xffffffffu ? lane >> rp.spp_log2 : lane / rp.spp;
+    uint32_t si = rp.spp > 1 ? lane - pix * rp.spp : 0;
+    uint32_t perm_seed, tmp; tea32(rp.base_seed, rp.spp * pix + rp.seed, perm_seed, tmp);
+    uint32_t dim = 0;
+
+    uint32_t W = (uint32_t) rp.crop_w;
+    uint32_t py = pix / W, px = pix - W * py;
+    float posx = (float) (px + (uint32_t) rp.crop_x), posy = (float) (py + (uint32_t) rp.crop_y);
+    bool cp = rp.path_correlation_depth > 0;
+    const bool doppler = rp.integrator == 0;
+    // one stream only: the plain branch of render_sample (integrator.cpp:416-431: next_2d / next_1d), and every sampler but
+    // `correlated` (Sampler::next_*_correlate default to next_1d / next_2d, include/mitsuba/render/sampler.h:141-144)
+    const bool single = !doppler || rp.sampler_kind != SAMPLER_CORRELATED;
+    float jx = single ? next_f32(main) : next_correlate(main, path, cp), jy = single ? next_f32(main) : next_correlate(main, path, cp);
+    float spx = posx + jx, spy = posy + jy;
+    float ax = fmaf(spx, rp.scale_x, rp.offset_x), ay = fmaf(spy, rp.scale_y, rp.offset_y);
+    float time = rp.shutter_open;
+    if (rp.shutter_open_time > 0.f) {
+        float u;
+        if (!doppler || rp.sampler_kind == SAMPLER_INDEPENDENT) u = next_f32(main);   // Sampler::next_1d_time -> next_1d (sampler.h:131-132)
+        else if (rp.sampler_kind == SAMPLER_CORRELATED) u = next_time(rp, main, tm, si, perm_seed, dim);
+        else {   // TimeStratifiedSampler::next_1d_time (timestratified.cpp:117-129): the strategy arguments are ignored
+            uint32_t p = permute_kensler(si, rp.spp, perm_seed + dim++);
+            float j = rp.jitter ? next_f32(main) : .5f;
+            u = ((float) p + j) * rp.inv_spp;
+        }
+        time += u * rp.shutter_open_time;
+    }
+
+    // PerspectiveCamera::sample_ray_differential (perspective.cpp:238-279)
+    const float *m = rp.s2c;
+    float r0 = fmaf(m[2], 0.f, fmaf(m[1], ay, fmaf(m[0], ax, m[3])));
+    float r1 = fmaf(m[6], 0.f, fmaf(m[5], ay, fmaf(m[4], ax, m[7])));
+    float r2 = fmaf(m[10], 0.f, fmaf(m[9], ay, fmaf(m[8], ax, m[11])));
+    float r3 = fmaf(m[14], 0.f, fmaf(m[13], ay, fmaf(m[12], ax, m[15])));
+    float iw = rcp(r3);
+    V3 d = normalize(mk(r0 * iw, r1 * iw, r2 * iw));
+    V3 o = mk(rp.cam_to_world[3], rp.cam_to_world[7], rp.cam_to_world[11]);
+    V3 dw = xf_vector(rp.cam_to_world, d);
+    float inv_z = rcp(d.z), near_t = rp.near_clip * inv_z, far_t = rp.far_clip * inv_z;
+    o = o + dw * near_t;
+    float maxt = far_t - near_t;
+    if (doppler) time = time < rp.T ? time : time - rp.T;   // dopplertofpath.cpp:93
+
+    PrimaryLane pl;
+    pl.ray_a = make_float4(o.x, o.y, o.z, time);
+    pl.ray_b = make_float4(dw.x, dw.y, dw.z, maxt);
+    pl.main = main; pl.path = path; pl.pos = make_float2(spx, spy);
+    return pl;
+}
+
+}  // namespace dtof

@@ -1,0 +1,239 @@
+#pragma once
+// dtof_shading.h -- device side of a surface interaction: compute_surface (rectangle / mesh / sphere, through instances), ray
+// spawning, emitter sampling helpers (mesh and sphere area lights) and the evaluation helpers of the microfacet BSDFs.
+#include "dtof_traverse.h"
+
+#ifndef DTOF_D
+#define DTOF_D __device__ __forceinline__
+#endif
+
+namespace dtof {
+
+struct Surface { V3 p, n, sh_n, sh_s, sh_t, wi; const DShape *shape; };
+
+// Shape::compute_surface_interaction for rectangle (rectangle.cpp:250-323) / mesh (mesh.cpp:632-864),
+// Instance::compute_surface_interaction (instance.cpp:155-250), finalize (interaction.h:493-513)
+template <bool MESH>
+DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, uint32_t prim, float t, float b1, float b2,
+                            V3 o, V3 d, float time, Surface &si) {
+    const DObject &ob = sv.objects[oi];
+    bool inst = ob.kind == OBJ_INSTANCE;
+    float m[12], inv[12];
+    V3 lo = o, ld = d;
+    const DShape *sh;
+    if (inst) {
+        instance_matrix(ob, time, m);
+        affine_inverse(m, inv);
+        lo = xf_point(inv, o); ld = xf_vector(inv, d);
+        sh = &sv.shapes[sv.groups[ob.index].first_shape + shape_k];
+    } else sh = &sv.shapes[ob.index];
+    si.shape = sh;
+    V3 dp_du, dp_dv;
+    if (!MESH || sh->kind == SHAPE_RECT) {
+        V3 n = mk(sh->n[0], sh->n[1], sh->n[2]);
+        V3 p = vfma(ld, t, lo);
+        V3 tr = mk(sh->to_world[3], sh->to_world[7], sh->to_world[11]);
+        float dist = dot(tr - p, n);
+        si.p = p + n * dist; si.n = n; si.sh_n = n;
+        dp_du = mk(sh->dp_du[0], sh->dp_du[1], sh->dp_du[2]);
+        dp_dv = mk(sh->dp_dv[0], sh->dp_dv[1], sh->dp_dv[2]);
+    } else if (sh->kind == SHAPE_SPHERE) {   // Sphere::compute_surface_interaction (sphere.cpp:509-513, 527-551)
+        const V3 c = mk(sh->n[0], sh->n[1], sh->n[2]); const float radius = sh->dp_du[0];
+        V3 n = normalize(vfma(ld, t, lo) - c);
+        si.p = vfma(n, radius, c);
+        const V3 local = xf_point(sh->to_object, si.p);
+        const float rd = sqrtf(sqr(local.x) + sqr(local.y)), inv_rd = rcp(rd);
+        V3 dpv = mk(local.z * (local.x * inv_rd), local.z * (local.y * inv_rd), -rd);
+        if (rd == 0.f) dpv = mk(1.f, 0.f, 0.f);
+        dp_du = xf_vector(sh->to_world, mk(-local.y, local.x, 0.f)) * (2.f * kPi);
+        dp_dv = xf_vector(sh->to_world, dpv) * kPi;
+        if (sh->flags & SF_FLIP_NORMALS) n = -n;
+        si.n = n; si.sh_n = n;
+    } else {
+        const DTri &tr = sv.tris[sh->first_tri + prim];
+        const DTriShade &ts = sv.shading[sh->first_tri + prim];
+        V3 p0 = mk(tr.p0[0], tr.p0[1], tr.p0[2]), p1 = mk(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = mk(tr.p2[0], tr.p2[1], tr.p2[2]);
+        float b0 = 1.f - b1 - b2;
+        V3 dp0 = p1 - p0, dp1 = p2 - p0;
+        si.p = vfma(p0, b0, vfma(p1, b1, p2 * b2));
+        si.n = normalize(cross(dp0, dp1));
+        coordinate_system(si.n, dp_du, dp_dv);
+        float d0x = ts.uv1[0] - ts.uv0[0], d0y = ts.uv1[1] - ts.uv0[1], d1x = ts.uv2[0] - ts.uv0[0], d1y = ts.uv2[1] - ts.uv0[1];
+        float det = fmaf(d0x, d1y, -(d0y * d1x)), inv_det = rcp(det);
+        if (det != 0.f) {
+            dp_du = mk(fmaf(d1y, dp0.x, -(d0y * dp1.x)), fmaf(d1y, dp0.y, -(d0y * dp1.y)), fmaf(d1y, dp0.z, -(d0y * dp1.z))) * inv_det;
+            dp_dv = mk(fmaf(-d1x, dp0.x, d0x * dp1.x), fmaf(-d1x, dp0.y, d0x * dp1.y), fmaf(-d1x, dp0.z, d0x * dp1.z)) * inv_det;
+        }
+        if (!(sh->flags & SF_FACE_NORMALS)) {
+            V3 n0 = mk(ts.n0[0], ts.n0[1], ts.n0[2]), n1 = mk(ts.n1[0], ts.n1[1], ts.n1[2]), n2 = mk(ts.n2[0], ts.n2[1], ts.n2[2]);
+            V3 n = vfma(n2, b2, vfma(n1, b1, n0 * b0));
+            si.sh_n = n * rsqrt_(dot(n, n));
+        } else si.sh_n = si.n;
+        if (sh->flags & SF_FLIP_NORMALS) { si.n = -si.n; si.sh_n = -si.sh_n; }
+    }
+    if (inst) {
+        si.p = xf_point(m, si.p);
+        si.n = normalize(xf_normal(inv, si.n));
+        si.sh_n = normalize(xf_normal(inv, si.sh_n));
+        dp_du = xf_vector(m, dp_du);
+    }
+    // initialize_sh_frame (interaction.h:258-268)
+    V3 s = normalize(vfma(si.sh_n, -dot(si.sh_n, dp_du), dp_du));
+    if (dp_du.x == 0.f && dp_du.y == 0.f && dp_du.z == 0.f) { V3 tt; coordinate_system(si.sh_n, s, tt); }
+    si.sh_s = s; si.sh_t = cross(si.sh_n, s);
+    V3 md = -d;
+    si.wi = mk(dot(md, si.sh_s), dot(md, si.sh_t), dot(md, si.sh_n));
+}
+// Interaction::offset_p (interaction.h:161-165)
+DTOF_D V3 offset_p(const Surface &si, V3 d) {
+    float mag = (1.f + fmax_(fmax_(fabsf(si.p.x), fabsf(si.p.y)), fabsf(si.p.z))) * kRayEps;
+    mag = mulsign(mag, dot(si.n, d));
+    return vfma(si.n, mag, si.p);
+}
+// warp::square_to_cosine_hemisphere (warp.h:54-86, 320-344)
+DTOF_D V3 cosine_hemisphere(float sx, float sy) {
+    float x = fmaf(2.f, sx, -1.f), y = fmaf(2.f, sy, -1.f);
+    bool is_zero = x == 0.f && y == 0.f, q13 = fabsf(x) < fabsf(y);
+    float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = 0.25f * kPi * rp / r;
+    if (q13) phi = 0.5f * kPi - phi;
+    if (is_zero) phi = 0.f;
+    float s, c; sincos_(phi, s, c);
+    float px = r * c, py = r * s;
+    return mk(px, py, sqrtf(fmax_(1.f - fmaf(py, py, px * px), 0.f)));
+}
+// Mesh::sample_position (mesh.cpp:513-568): face by DiscreteDistribution::sample_reuse on sample.y (distr_1d.h:113-160,
+// dr::binary_search over [m_valid.x, m_valid.y]), point by warp::square_to_uniform_triangle (warp.h:153-156), normal from
+// the vertex normals if the mesh has them.
+DTOF_D void mesh_sample_position(const SceneView &sv, const DShape &es, float s_x, float s_y, V3 &p, V3 &n) {
+    const float *cdf = (const float *) (sv.base + es.emit_table), *pmf = cdf + es.n_tris;
+    const uint32_t *slot = (const uint32_t *) (pmf + es.n_tris);
+    const float v = s_y * es.emit_sum;
+    uint32_t lo = es.emit_lo, hi = es.emit_hi;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] < v) lo = mid + 1 < hi ? mid + 1 : hi; else hi = mid;
+    }
+    const float pm = pmf[lo] * es.inv_area, cd = lo > 0 ? cdf[lo - 1] * es.inv_area : 0.f;
+    const float y = (s_y - cd) / pm;
+    const uint32_t k = es.first_tri + slot[lo];
+    const DTri &tr = sv.tris[k];
+    V3 p0 = mk(tr.p0[0], tr.p0[1], tr.p0[2]), p1 = mk(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = mk(tr.p2[0], tr.p2[1], tr.p2[2]);
+    V3 e0 = p1 - p0, e1 = p2 - p0;
+    const float t = sqrtf(fmax_(1.f - s_x, 0.f)), bx = 1.f - t, by = t * y;
+    p = vfma(e0, bx, vfma(e1, by, p0));
+    if (!(es.flags & SF_FACE_NORMALS)) {
+        const DTriShade &ts = sv.shading[k];
+        V3 n0 = mk(ts.n0[0], ts.n0[1], ts.n0[2]), n1 = mk(ts.n1[0], ts.n1[1], ts.n1[2]), n2 = mk(ts.n2[0], ts.n2[1], ts.n2[2]);
+        n = vfma(n0, 1.f - bx - by, vfma(n1, bx, n2 * by));
+    } else n = cross(e0, e1);
+    n = normalize(n);
+    if (es.flags & SF_FLIP_NORMALS) n = -n;
+}
+
+constexpr float kInvTwoPi = 0.15915494309189533577f;
+DTOF_D float uniform_cone_pdf(float cos_cutoff) { return kInvTwoPi / (1.f - cos_cutoff); }   // warp::square_to_uniform_cone_pdf (warp.h:475-485)
+// Sphere::sample_direction (sphere.cpp:222-296): cone sampling of the visible cap from outside, uniform sphere from inside
+DTOF_D void sphere_sample_direction(const DShape &sh, V3 ref, float s_x, float s_y, V3 &p, V3 &n, V3 &dd, float &dist, float &pdf) {
+    const V3 center = mk(sh.n[0], sh.n[1], sh.n[2]); const float radius = sh.dp_du[0];
+    const bool flip = sh.flags & SF_FLIP_NORMALS;
+    const V3 dc_v = center - ref;
+    const float dc_2 = dot(dc_v, dc_v), radius_adj = radius * (flip ? (1.f + kRayEps) : (1.f - kRayEps));
+    const bool outside = dc_2 > sqr(radius_adj);
+    V3 dloc;
+    if (outside) {
+        const float inv_dc = rsqrt_(dc_2), sin_theta_max = radius * inv_dc, sin_theta_max_2 = sqr(sin_theta_max),
+                    inv_sin_theta_max = rcp(sin_theta_max), cos_theta_max = safe_sqrt(1.f - sin_theta_max_2);
+        const float sin_theta_2 = sin_theta_max_2 > 0.00068523f ? 1.f - sqr(fmaf(cos_theta_max - 1.f, s_x, 1.f)) : sin_theta_max_2 * s_x;
+        const float cos_theta = safe_sqrt(1.f - sin_theta_2);
+        const float cos_alpha = sin_theta_2 * inv_sin_theta_max + cos_theta * safe_sqrt(fmaf(-sin_theta_2, sqr(inv_sin_theta_max), 1.f));
+        const float sin_alpha = safe_sqrt(fmaf(-cos_alpha, cos_alpha, 1.f));
+        float sin_phi, cos_phi; sincos_(s_y * (2.f * kPi), sin_phi, cos_phi);
+        const V3 fn = dc_v * -inv_dc; V3 fs, ft;
+        coordinate_system(fn, fs, ft);
+        dloc = vfma(fn, cos_alpha, vfma(ft, sin_phi * sin_alpha, fs * (cos_phi * sin_alpha)));
+        pdf = uniform_cone_pdf(cos_theta_max);
+    } else {   // warp::square_to_uniform_sphere (warp.h:250-255)
+        const float z = fmaf(-2.f, s_y, 1.f), r = safe_sqrt(fmaf(-z, z, 1.f)); float sn, cs;
+        sincos_(2.f * kPi * s_x, sn, cs);
+        dloc = mk(r * cs, r * sn, z);
+        pdf = 0.f;
+    }
+    p = vfma(dloc, radius, center); dd = p - ref;
+    const float dist2 = dot(dd, dd);
+    dist = sqrtf(dist2);
+    dd = dd * rcp(dist);
+    if (outside) { if (dist == 0.f) pdf = 0.f; }
+    else pdf = sh.inv_area * dist2 / fabsf(dot(dd, dloc));
+    n = flip ? -dloc : dloc;
+}
+// Sphere::pdf_direction (sphere.cpp:298-310)
+DTOF_D float sphere_pdf_direction(const DShape &sh, V3 ref, V3 ds_d, V3 ds_n, float ds_dist) {
+    const V3 center = mk(sh.n[0], sh.n[1], sh.n[2]);
+    const float sin_alpha = sh.dp_du[0] * rcp(norm(center - ref)), cos_alpha = safe_sqrt(1.f - sin_alpha * sin_alpha);
+    return sin_alpha < 0.99999994f ? uniform_cone_pdf(cos_alpha) : sh.inv_area * sqr(ds_dist) / fabsf(dot(ds_d, ds_n));
+}
+// RoughPlastic::lerp_gather (roughplastic.cpp:373-383) on the 64-entry transmittance table
+DTOF_D float lerp_gather64(const float *data, float x) {
+    x *= 63.f;
+    uint32_t index = (uint32_t) x; if (index > 62u) index = 62u;
+    const float v0 = data[index], v1 = data[index + 1], t = x - (float) index;
+    return fmaf(v1, t, fmaf(-v0, t, v0));                        // dr::lerp(v0, v1, t)
+}
+// RoughPlastic::eval (:333-371) and pdf (:385-421) for wi.z > 0 and wo.z > 0
+DTOF_D void rough_plastic_eval_pdf(Ggx g, const DShape *sh, const float *table, V3 diff, V3 wi, V3 wo, float t_i, float prob_specular,
+                                   float prob_diffuse, V3 &value, float &pdf) {
+    const V3 H = normalize(wo + wi);
+    const float D = ggx_eval(g, H);
+    float F, t1, t2, t3; fresnel_dielectric(dot(wi, H), sh->diel_eta, F, t1, t2, t3);
+    const float G = ggx_smith_g1(g, wi, H) * ggx_smith_g1(g, wo, H);
+    const float spec = F * D * G / (4.f * wi.z);
+    const float t_o = lerp_gather64(table, wo.z);
+    const float k = kInvPi * sh->inv_eta_2 * wo.z * t_i * t_o;
+    value = mk(spec * sh->spec_refl[0] + diff.x * k, spec * sh->spec_refl[1] + diff.y * k, spec * sh->spec_refl[2] + diff.z * k);
+    float result = D * ggx_smith_g1(g, wi, H) / (4.f * wi.z);
+    result *= prob_specular;
+    pdf = result + prob_diffuse * (kInvPi * wo.z);
+}
+// RoughDielectric::eval_pdf (roughdielectric.cpp:503-611), GGX + visible normals, TransportMode::Radiance
+DTOF_D void rough_dielectric_eval_pdf(Ggx g, const DShape *sh, V3 wi, V3 wo, V3 &value, float &pdf) {
+    const float cti = wi.z, cto = wo.z, m_eta = sh->diel_eta, m_inv_eta = rcp(m_eta);
+    const bool reflect = cti * cto > 0.f;
+    const float eta = cti > 0.f ? m_eta : m_inv_eta, inv_eta = cti > 0.f ? m_inv_eta : m_eta;
+    V3 m = normalize(wi + wo * (reflect ? 1.f : eta));
+    m = mk(mulsign(m.x, m.z), mulsign(m.y, m.z), mulsign(m.z, m.z));
+    const float dwm = dot(wi, m), dom = dot(wo, m);
+    const bool active = cti != 0.f && dwm * cti > 0.f && dom * cto > 0.f;
+    const float D = ggx_eval(g, m);
+    float F, t1, t2, t3; fresnel_dielectric(dwm, m_eta, F, t1, t2, t3);
+    const float G = ggx_smith_g1(g, wi, m) * ggx_smith_g1(g, wo, m);
+    value = mk(0, 0, 0); pdf = 0.f;
+    if (!active) return;
+    if (reflect) {
+        const float v = F * D * G / (4.f * fabsf(cti));
+        value = mk(v * sh->spec_refl[0], v * sh->spec_refl[1], v * sh->spec_refl[2]);
+    } else {
+        const float scale = sqr(inv_eta);
+        const float v = fabsf((scale * (1.f - F) * D * G * eta * eta * dwm * dom) / (cti * sqr(dwm + eta * dom)));
+        value = mk(v * sh->spec_trans[0], v * sh->spec_trans[1], v * sh->spec_trans[2]);
+    }
+    float p = ggx_pdf(g, mk(mulsign(wi.x, cti), mulsign(wi.y, cti), mulsign(wi.z, cti)), m);
+    p *= reflect ? F : 1.f - F;
+    const float dwh_dwo = reflect ? rcp(4.f * dom) : (eta * eta * dom) / sqr(dwm + eta * dom);
+    pdf = p * fabsf(dwh_dwo);
+}
+// fresnel_conductor -- include/mitsuba/render/fresnel.h:93-117 (one colour channel)
+DTOF_D float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
+    const float cos_theta_i_2 = cos_theta_i * cos_theta_i, sin_theta_i_2 = 1.f - cos_theta_i_2, sin_theta_i_4 = sin_theta_i_2 * sin_theta_i_2;
+    const float temp_1 = eta_r * eta_r - eta_i * eta_i - sin_theta_i_2,
+                a_2_pb_2 = safe_sqrt(temp_1 * temp_1 + 4.f * eta_i * eta_i * eta_r * eta_r),
+                a = safe_sqrt(.5f * (a_2_pb_2 + temp_1));
+    const float term_1 = a_2_pb_2 + cos_theta_i_2, term_2 = 2.f * cos_theta_i * a;
+    const float r_s = (term_1 - term_2) / (term_1 + term_2);
+    const float term_3 = a_2_pb_2 * cos_theta_i_2 + sin_theta_i_4, term_4 = term_2 * sin_theta_i_2;
+    const float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return 0.5f * (r_s + r_p);
+}
+DTOF_D float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
+
+}  // namespace dtof

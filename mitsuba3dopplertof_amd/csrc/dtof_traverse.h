@@ -1,0 +1,271 @@
+#pragma once
+// dtof_traverse.h -- device side of the scene: blob view, LDS staging, primitive tests (rectangle, triangle, sphere), motion-blur
+// instance matrices and the TLAS / BLAS traversal (closest hit and occlusion).  Included by dtof_kernels.hip only.
+#include "dtof_kernels.h"
+#include "dtof_scene.h"
+#include "dtof_math.h"
+
+#ifndef DTOF_D
+#define DTOF_D __device__ __forceinline__
+#endif
+
+namespace dtof {
+
+// ---------------------------------------------------------------------------- scene view
+struct SceneView {
+    const BvhNode *nodes; const DObject *objects; const DGroup *groups; const DShape *shapes;
+    const DTri *tris; const DTriShade *shading; const DEmitter *emitters; const uint8_t *base;
+    uint32_t n_nodes, n_emitters;
+};
+DTOF_D SceneView make_view(const uint8_t *base) {
+    const BlobHeader *h = (const BlobHeader *) base;
+    SceneView v;
+    v.nodes = (const BvhNode *) (base + h->off_nodes);
+    v.objects = (const DObject *) (base + h->off_objects);
+    v.groups = (const DGroup *) (base + h->off_groups);
+    v.shapes = (const DShape *) (base + h->off_shapes);
+    v.tris = (const DTri *) (base + h->off_tris);
+    v.shading = (const DTriShade *) (base + h->off_shading);
+    v.emitters = (const DEmitter *) (base + h->off_emitters);
+    v.base = base;
+    v.n_nodes = h->n_nodes; v.n_emitters = h->n_emitters;
+    return v;
+}
+// Stage the whole scene blob into LDS (small scenes: the Cornell blob is ~5 KB).
+DTOF_D const uint8_t *stage_scene(const uint8_t *g, uint32_t bytes, uint4 *lds) {
+    const uint4 *src = (const uint4 *) g;
+    for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) lds[i] = src[i];
+    __syncthreads();
+    return (const uint8_t *) lds;
+}
+
+struct Hit { float t, u, v; uint32_t obj, shape, prim; };
+
+// ---------------------------------------------------------------------------- primitives
+// Rectangle::ray_intersect_preliminary_impl, src/shapes/rectangle.cpp:201-224
+DTOF_D bool rect_hit(const DShape &sh, V3 o, V3 d, float maxt, float &t, float &u, float &v) {
+    V3 lo = xf_point(sh.to_object, o), ld = xf_vector(sh.to_object, d);
+    t = -lo.z / ld.z;
+    u = fmaf(ld.x, t, lo.x); v = fmaf(ld.y, t, lo.y);
+    return t >= 0.f && t <= maxt && fabsf(u) <= 1.f && fabsf(v) <= 1.f;
+}
+// Moeller-Trumbore as in Embree 3's triangle intersector (tnear < t <= tfar; u,v weight vertices 1,2).
+// The 48-byte record is fetched with three 16-byte loads issued together; `face` rides in p0.w.
+DTOF_D bool tri_hit(const DTri &tr, V3 o, V3 d, float maxt, float &t, float &u, float &v, uint32_t &face) {
+    const uint4 *tp = (const uint4 *) &tr;
+    const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+    face = q0.w;
+    V3 p0 = mk(u2f(q0.x), u2f(q0.y), u2f(q0.z)), p1 = mk(u2f(q1.x), u2f(q1.y), u2f(q1.z)), p2 = mk(u2f(q2.x), u2f(q2.y), u2f(q2.z));
+    V3 e1 = p0 - p1, e2 = p2 - p0, ng = cross(e2, e1);
+    V3 c = p0 - o, r = cross(c, d);
+    float den = dot(ng, d), aden = fabsf(den);
+    uint32_t sgn = f2u(den) & 0x80000000u;
+    float U = u2f(f2u(dot(r, e2)) ^ sgn), Vv = u2f(f2u(dot(r, e1)) ^ sgn);
+    if (!(den != 0.f && U >= 0.f && Vv >= 0.f && U + Vv <= aden)) return false;
+    float T = u2f(f2u(dot(ng, c)) ^ sgn);
+    if (!(0.f < T && T <= aden * maxt)) return false;
+    float rc = 1.0f / aden;
+    u = U * rc; v = Vv * rc; t = T * rc;
+    return true;
+}
+// math::solve_quadratic (include/mitsuba/core/math.h:357-401), float64
+DTOF_D bool solve_quadratic_d(double a, double b, double c, double &x0, double &x1) {
+    const bool linear = a == 0.0, valid_linear = linear && b != 0.0;
+    x0 = x1 = -c / b;
+    const double discrim = fma(b, b, -(4.0 * a * c));
+    const bool valid_quadratic = !linear && discrim >= 0.0;
+    if (valid_quadratic) {
+        const double sq = sqrt(discrim), temp = -0.5 * (b + copysign(sq, b));
+        const double x0p = temp / a, x1p = c / temp;
+        x0 = x0p < x1p ? x0p : x1p; x1 = x0p < x1p ? x1p : x0p;
+    }
+    return valid_linear || valid_quadratic;
+}
+DTOF_D double dot3d(double ax, double ay, double az, double bx, double by, double bz) { return fma(az, bz, fma(ay, by, ax * bx)); }
+// Sphere::ray_intersect_preliminary_impl (src/shapes/sphere.cpp:338-394) / ray_test_impl (:396-431): float64 on the llvm back
+// end; the point of the ray closest to the centre is evaluated with the FLOAT ray (Ray::operator() takes a Float, ray.h:61).
+template <bool ANY>
+DTOF_D bool sphere_hit(const DShape &sh, V3 o, V3 d, float maxt_f, float &t_out) {
+    const double radius = sh.dp_du[0], cx = sh.n[0], cy = sh.n[1], cz = sh.n[2], maxt = maxt_f;
+    const double dx = d.x, dy = d.y, dz = d.z;
+    double near_t, far_t;
+    if (ANY) {
+        const double ox = (double) o.x - cx, oy = (double) o.y - cy, oz = (double) o.z - cz;
+        const double A = dot3d(dx, dy, dz, dx, dy, dz), B = 2.0 * dot3d(ox, oy, oz, dx, dy, dz), C = dot3d(ox, oy, oz, ox, oy, oz) - radius * radius;
+        const bool found = solve_quadratic_d(A, B, C, near_t, far_t);
+        const bool out_bounds = !(near_t <= maxt && far_t >= 0.0), in_bounds = near_t < 0.0 && far_t > maxt;
+        return found && !out_bounds && !in_bounds;
+    }
+    const double lx = (double) o.x - cx, ly = (double) o.y - cy, lz = (double) o.z - cz;
+    const double plane_t = dot3d(-lx, -ly, -lz, dx, dy, dz) / sqrt(dot3d(dx, dy, dz, dx, dy, dz));
+    bool no_hit = plane_t == 0.0 && (o.x != sh.n[0] && o.y != sh.n[1] && o.z != sh.n[2]);
+    const V3 pp = vfma(d, (float) plane_t, o);
+    const double ox = (double) pp.x - cx, oy = (double) pp.y - cy, oz = (double) pp.z - cz;
+    no_hit = no_hit && sqrt(dot3d(ox, oy, oz, ox, oy, oz)) > radius;
+    const double A = dot3d(dx, dy, dz, dx, dy, dz), B = 2.0 * dot3d(ox, oy, oz, dx, dy, dz), C = dot3d(ox, oy, oz, ox, oy, oz) - radius * radius;
+    const bool found = solve_quadratic_d(A, B, C, near_t, far_t);
+    near_t += plane_t; far_t += plane_t;
+    const bool out_bounds = !(near_t <= maxt && far_t >= 0.0), in_bounds = near_t < 0.0 && far_t > maxt;
+    if (!(found && !no_hit && !out_bounds && !in_bounds)) return false;
+    t_out = near_t < 0.0 ? (float) far_t : (float) near_t;
+    return true;
+}
+// AnimatedTransform::eval, include/mitsuba/core/transform.h:439-466
+DTOF_D void instance_matrix(const DObject &ob, float time, float *m) {
+    if (ob.n_keys <= 1) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) m[i] = ob.key0[i];
+        return;
+    }
+    float t = fmin_(fmax_((time - ob.t0) / (ob.t1 - ob.t0), 0.f), 1.f), omt = 1 - t;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) m[i] = ob.key0[i] * omt + ob.key1[i] * t;
+}
+
+// Slab test against a padded box; NaNs (0*inf) fall out of the min/max chain conservatively.
+DTOF_D float box_entry(const float *bmin, const float *bmax, V3 o, V3 id, float tbest) {
+    float tx0 = (bmin[0] - o.x) * id.x, tx1 = (bmax[0] - o.x) * id.x;
+    float ty0 = (bmin[1] - o.y) * id.y, ty1 = (bmax[1] - o.y) * id.y;
+    float tz0 = (bmin[2] - o.z) * id.z, tz1 = (bmax[2] - o.z) * id.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
+    return tn <= tf ? tn : INFINITY;
+}
+// One BVH node = four 16-byte loads issued together (no load depends on a field of the node); entry distances of both
+// children, INFINITY = missed / absent.
+DTOF_D void node_test(const BvhNode *node, V3 o, V3 id, float tbest, float &tl, float &tr, uint32_t &left, uint32_t &right) {
+    const uint4 *np = (const uint4 *) node;
+    const uint4 a = np[0], b = np[1], c = np[2], d = np[3];
+    const float lmin[3] = { u2f(a.x), u2f(a.y), u2f(a.z) }, lmax[3] = { u2f(b.x), u2f(b.y), u2f(b.z) };
+    const float rmin[3] = { u2f(c.x), u2f(c.y), u2f(c.z) }, rmax[3] = { u2f(d.x), u2f(d.y), u2f(d.z) };
+    left = a.w; right = b.w;
+    tl = box_entry(lmin, lmax, o, id, tbest);
+    tr = box_entry(rmin, rmax, o, id, tbest);
+    if (right == kNoChild) tr = INFINITY;
+}
+
+// Closest hit (ANY=false) or occlusion (ANY=true) of one top-level object.  Candidates are every
+// primitive hit with t <= maxt; the winner is the smallest t, ties going to the lowest
+// (object, shape, face) -- the rule the oracle uses, independent of traversal order.
+// `stack + sp * stride` onwards is free for the BLAS traversal of a mesh.
+template <bool ANY, bool MESH>
+DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float time, float maxt, Hit &best,
+                             uint32_t *stack, int sp, uint32_t stride) {
+    const DObject &ob = sv.objects[oi];
+    uint32_t first = ob.index, count = 1;
+    V3 lo = o, ld = d;
+    if (ob.kind == OBJ_INSTANCE) {
+        float m[12], inv[12];
+        instance_matrix(ob, time, m);
+        affine_inverse(m, inv);
+        lo = xf_point(inv, o); ld = xf_vector(inv, d);
+        const DGroup &g = sv.groups[ob.index];
+        first = g.first_shape; count = g.n_shapes;
+    }
+    bool found = false;
+    for (uint32_t k = 0; k < count; ++k) {
+        const DShape &sh = sv.shapes[first + k];
+        float t, u, v;
+        if (sh.kind == SHAPE_RECT) {
+            if (rect_hit(sh, lo, ld, maxt, t, u, v)) {
+                if (ANY) return true;
+                if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
+                    best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = 0; found = true;
+                }
+            }
+            continue;
+        }
+        if (!MESH) continue;   // instantiations for rectangle-only scenes carry no triangle / sphere code at all
+        if (sh.kind == SHAPE_SPHERE) {
+            if (sphere_hit<ANY>(sh, lo, ld, maxt, t)) {
+                if (ANY) return true;
+                if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
+                    best.t = t; best.u = 0.f; best.v = 0.f; best.obj = oi; best.shape = k; best.prim = 0; found = true;
+                }
+            }
+            continue;
+        }
+        // cull with the mesh's own (padded) bounds: TLAS boxes of moving instances are the union over the whole
+        // motion and let many rays through that miss the mesh at their time
+        V3 lid = mk(__builtin_amdgcn_rcpf(ld.x == 0.f ? 1e-30f : ld.x), __builtin_amdgcn_rcpf(ld.y == 0.f ? 1e-30f : ld.y), __builtin_amdgcn_rcpf(ld.z == 0.f ? 1e-30f : ld.z));
+        if (!(box_entry(sh.bmin, sh.bmax, lo, lid, ANY ? maxt : best.t) < INFINITY)) continue;
+        // `face` of the best hit so far IF it lies on this very mesh (ties between two of its triangles go to the lower face)
+        uint32_t best_face = 0xffffffffu;
+        auto test = [&](uint32_t f) -> bool {
+            uint32_t face;
+            if (!tri_hit(sv.tris[sh.first_tri + f], lo, ld, maxt, t, u, v, face)) return false;
+            if (ANY) return true;
+            bool take = t < best.t;
+            if (t == best.t) take = best_face != 0xffffffffu ? face < best_face : (!found && best.obj != 0xffffffffu && oi < best.obj);
+            if (take) { best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = f; best_face = face; found = true; }
+            return false;
+        };
+        if (sh.blas_root == kNoChild) {
+            for (uint32_t f = 0; f < sh.n_tris; ++f) if (test(f)) return true;
+            continue;
+        }
+        // BLAS: same node format and while-while shape as the TLAS loop below
+        constexpr uint32_t kDone = 0x7fffffffu;
+        uint32_t cur = sh.blas_root; int bsp = sp;
+        for (;;) {
+            while (!(cur & kLeafFlag) && cur != kDone) {
+                float tl, tr; uint32_t left, right;
+                node_test(sv.nodes + cur, lo, lid, ANY ? maxt : best.t, tl, tr, left, right);
+                bool hl = tl < INFINITY, hr = tr < INFINITY;
+                if (hl && hr) {
+                    uint32_t nearc = tl <= tr ? left : right, farc = tl <= tr ? right : left;
+                    stack[bsp * stride] = farc; ++bsp;
+                    cur = nearc;
+                } else if (hl) cur = left;
+                else if (hr) cur = right;
+                else if (bsp == sp) cur = kDone;
+                else { --bsp; cur = stack[bsp * stride]; }
+            }
+            if (cur == kDone) break;
+            uint32_t f0 = (cur & ~kLeafFlag) >> kBlasLeafBits, fn = (cur & ((1u << kBlasLeafBits) - 1u)) + 1u;
+            for (uint32_t f = f0; f < f0 + fn; ++f) if (test(f)) return true;
+            if (bsp == sp) break;
+            --bsp; cur = stack[bsp * stride];
+        }
+    }
+    return found;
+}
+
+// TLAS traversal; `stack` is a per-thread LDS column (stride blockDim.x).
+template <bool ANY, bool MESH>
+DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best) {
+    best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
+    if (sv.n_nodes == 0) return false;
+    // direction reciprocal for the slab test only (exact zero components are nudged)
+    // v_rcp_f32 (1 ulp) is enough here: the boxes are padded by 1e-5 relative on the host
+    V3 id = mk(__builtin_amdgcn_rcpf(d.x == 0.f ? 1e-30f : d.x), __builtin_amdgcn_rcpf(d.y == 0.f ? 1e-30f : d.y), __builtin_amdgcn_rcpf(d.z == 0.f ? 1e-30f : d.z));
+    // "while-while" traversal: every lane first descends inner nodes until it holds a leaf (or is done), THEN the
+    // lanes that hold a leaf run the expensive object intersection together -- the wave does not pay the leaf
+    // body once per node step of its slowest lane.
+    constexpr uint32_t kDone = 0x7fffffffu;
+    int sp = 0;
+    uint32_t cur = 0;
+    const uint32_t stride = blockDim.x;
+    for (;;) {
+        while (!(cur & kLeafFlag) && cur != kDone) {
+            float tl, tr; uint32_t left, right;
+            node_test(sv.nodes + cur, o, id, best.t, tl, tr, left, right);
+            bool hl = tl < INFINITY, hr = tr < INFINITY;
+            if (hl && hr) {
+                uint32_t nearc = tl <= tr ? left : right, farc = tl <= tr ? right : left;
+                stack[sp * stride] = farc; ++sp;
+                cur = nearc;
+            } else if (hl) cur = left;
+            else if (hr) cur = right;
+            else if (sp == 0) cur = kDone;
+            else { --sp; cur = stack[sp * stride]; }
+        }
+        if (cur == kDone) break;
+        if (intersect_object<ANY, MESH>(sv, cur & ~kLeafFlag, o, d, time, maxt, best, stack, sp, stride) && ANY) return true;
+        if (sp == 0) break;
+        --sp; cur = stack[sp * stride];
+    }
+    return best.obj != 0xffffffffu;
+}
+
+}  // namespace dtof
