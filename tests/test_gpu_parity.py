@@ -361,6 +361,25 @@ def test_full_frame_every_lane_bit_exact_512x512x64(mi, orc):
 
 
 # --------------------------------------------------------------------------- path + velocity on the same kernels
+def test_full_size_c3_multi_batch_frame_matches_oracle(mi, orc):
+    """BASELINE configs[2] at FULL size: 512 x 512 x 256 spp, antithetic_mirror, 67 108 864 lanes = 4 wavefront batches.  The whole
+    developed image against the oracle's (the batch seams must be invisible) and the lanes across the first seam bit-exact."""
+    path = os.path.join(SCENES, "cornell_wall.xml")
+    P = dict(time_sampling_method="antithetic_mirror", antithetic_shift=0.0)
+    sc, osc = mi.load_file(path, **P), orc.Scene(path, P)
+    pd = osc.params()
+    img = sc.render(seed=2, spp=256)
+    st = sc.last_stats
+    assert st["n_paths"] == 512 * 512 * 256 and st["n_batches"] >= 4
+    ref, n = osc.render(pd, seed=2, spp=256, threads=NCPU)
+    assert n == 512 * 512 * 256 and rel_linf(img, ref) <= IMG_TOL
+    seam = 128 * 512 * 256                                      # first lane of the second batch (batches are whole rows)
+    g = sc.sample_lanes(2, 256, seam - 65536, 131072)
+    o = osc.render_lanes(pd, 2, 256, seam - 65536, 131072, threads=NCPU)
+    for k in ("sample_pos", "time", "ray_d", "rgb"):
+        assert np.array_equal(bits(g[k]), bits(o[k])), k
+
+
 @pytest.mark.parametrize("integ,sampler", [
     (dict(type="path", max_depth=4), None),
     (dict(type="path", max_depth=-1, rr_depth=2), dict(type="independent", sample_count=8)),
