@@ -731,6 +731,9 @@ static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string
         else fail("unsupported child <" + c.first + "> in shape");
     }
     if (bsdf) bsdf_of(*bsdf, s);   // else default diffuse: 0.5, or 0 for an emitter (src/render/shape.cpp:66-72)
+    // the integrators zero a path whose every sampled lobe was BSDFFlags::Null (valid_ray, dopplertofpath.cpp:252-253,280); the only way
+    // such a path can carry radiance is an emitter ON a thindielectric shape, and the kernels keep no valid_ray flag for that corner
+    if (s.emitter && s.bsdf == BSDF_THINDIELECTRIC) fail("an area emitter on a thindielectric shape is not supported");
     else if (s.emitter) s.refl[0] = s.refl[1] = s.refl[2] = 0.f;
     RawMesh raw;
     if (mesh_file) {   // src/shapes/obj.cpp:139-143, ply.cpp:160-166: `filename` through the file resolver

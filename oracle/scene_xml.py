@@ -500,6 +500,8 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
     else:   # shape.cpp:66-72: default diffuse, reflectance 0 when the shape is an emitter
         brec = dict(twosided=0, bsdf=0, reflectance=np.array([0.0 if emitter else 0.5] * 3, dtype=F32), cond_eta=np.zeros(3, F32),
                     cond_k=np.ones(3, F32), spec_refl=np.ones(3, F32), spec_trans=np.ones(3, F32), diel_eta=F32(1.0), nonlinear=0)
+    if emitter and brec["bsdf"] == 6:   # valid_ray (dopplertofpath.cpp:252-253,280) would zero such paths; not modelled
+        raise ValueError("an area emitter on a thindielectric shape is not supported")
     twosided, refl = brec["twosided"], brec["reflectance"]
     sphere = None
     if kind == 2:   # src/shapes/sphere.cpp:121-131: center (point, default 0) and radius (default 1) on top of to_world

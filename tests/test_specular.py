@@ -372,6 +372,8 @@ def test_thindielectric_window(mi, orc, tmp_path):
     sc = mi.load_string(text)
     rec = sc.export(9).reshape(-1, 24)
     assert rec[-1, 0] == 6 and rec[-1, 1] == 0 and abs(rec[-1, 2] - 1.5) < 1e-6
+    with pytest.raises(mi.DtofError, match="area emitter on a thindielectric"):
+        mi.load_string(text.replace('<ref id="T" /></shape>', '<ref id="T" /><emitter type="area"><rgb name="radiance" value="1" /></emitter></shape>'))
     with pytest.raises(mi.DtofError, match="Only materials without a transmission component can be nested"):
         mi.load_string(text.replace('<bsdf type="thindielectric" id="T">', '<bsdf type="twosided" id="T"><bsdf type="thindielectric">').replace(
             '<float name="ext_ior" value="1.0" /></bsdf>', '<float name="ext_ior" value="1.0" /></bsdf></bsdf>'))
