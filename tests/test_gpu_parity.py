@@ -361,6 +361,34 @@ def test_full_frame_every_lane_bit_exact_512x512x64(mi, orc):
 
 
 # --------------------------------------------------------------------------- path + velocity on the same kernels
+def test_cancel_stops_a_render_between_batches(mi):
+    """Integrator::cancel / should_stop (include/mitsuba/render/integrator.h:96-109): dtof_cancel from another thread ends a running
+    render at the next batch boundary with the error "cancelled"; the handle renders normally afterwards."""
+    import threading
+    import time
+    sc = mi.load_file(os.path.join(SCENES, "domino.xml"), resx=1024, resy=1024)
+    ref = sc.render(seed=1, spp=64)                       # 4 batches of 16.7 M lanes, tens of milliseconds
+    t_full = sc.last_stats["ms_total"]
+    outcome = {}
+    def run():
+        try:
+            sc.render(seed=1, spp=512)                    # 32 batches
+            outcome["done"] = True
+        except mi.DtofError as e:
+            outcome["error"] = str(e)
+    th = threading.Thread(target=run)
+    t0 = time.perf_counter()
+    th.start()
+    time.sleep(max(0.02, 2e-3 * t_full))
+    sc.cancel()
+    th.join(timeout=60)
+    elapsed = time.perf_counter() - t0
+    assert not th.is_alive() and "cancelled" in outcome.get("error", ""), outcome
+    assert elapsed < 8 * 1e-3 * t_full * 0.9              # well short of the 8x longer uncancelled render
+    again = sc.render(seed=1, spp=64)
+    assert rel_linf(again, ref) <= IMG_TOL
+
+
 def test_full_size_c3_multi_batch_frame_matches_oracle(mi, orc):
     """BASELINE configs[2] at FULL size: 512 x 512 x 256 spp, antithetic_mirror, 67 108 864 lanes = 4 wavefront batches.  The whole
     developed image against the oracle's (the batch seams must be invisible) and the lanes across the first seam bit-exact."""
