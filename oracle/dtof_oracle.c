@@ -158,12 +158,14 @@ uint32_t orc_pcg32_next_u32(uint64_t *state, uint64_t inc) {
     return (xorshift >> rot) | (xorshift << ((~rot + 1u) & 31));
 }
 /* PCG32::seed(size=1, initstate, initseq): inc = (initseq<<1)|1, two warm-up steps */
+/* (Dr.Jit 0.4.0 drjit/random.h, not in the tree; call sites src/render/sampler.cpp:130, src/samplers/correlated.cpp:57-62) */
 void orc_pcg32_seed(uint64_t initstate, uint64_t initseq, uint64_t *state, uint64_t *inc) {
     *state = 0; *inc = (initseq << 1) | 1u;
     orc_pcg32_next_u32(state, *inc);
     *state += initstate;
     orc_pcg32_next_u32(state, *inc);
 }
+/* PCG32::next_float32: bitcast((next_u32 >> 9) | 0x3f800000) - 1 (drjit/random.h; used through include/mitsuba/core/random.h:28) */
 float orc_pcg32_next_f32(uint64_t *state, uint64_t inc) {
     return u2f((orc_pcg32_next_u32(state, inc) >> 9) | 0x3f800000u) - 1.f;
 }
@@ -360,6 +362,7 @@ static orc_ray camera_ray(const orc_sensor *s, const float *s2c, float ux, float
     ray.maxt = far_t - near_t;
     return ray;
 }
+/* test entry: PerspectiveCamera::sample_ray_differential (src/sensors/perspective.cpp:238-279) at time 0 for a film position */
 void orc_camera_ray(const orc_sensor *s, float px, float py, float *out) {
     float s2c[16]; camera_sample_to_camera(s, s2c);
     float sx = 1.f / (float) s->crop_w, sy = 1.f / (float) s->crop_h;
@@ -1341,6 +1344,7 @@ static float mitchell_eval(float x, float B, float C) {
     float r = (1.f / 6.f) * (x < 1.f ? fmaf(a3, x3, fmaf(a2, x2, a0)) : fmaf(b3, x3, fmaf(b2, x2, fmaf(b1, x, b0))));
     return x < 2.f ? r : 0.f;
 }
+/* CatmullRomFilter::eval (src/rfilters/catmullrom.cpp:39-52) */
 static float catmullrom_eval(float x) {
     x = fabsf(x);
     float x2 = x * x, x3 = x2 * x, B = 0.f, C = .5f;
@@ -1348,6 +1352,7 @@ static float catmullrom_eval(float x) {
                                      : (-B - 6.f * C) * x3 + (6.f * B + 30.f * C) * x2 + (-12.f * B - 48.f * C) * x + (8.f * B + 24.f * C));
     return x < 2.f ? r : 0.f;
 }
+/* ReconstructionFilter::eval of the film's filter: src/rfilters/tent.cpp:53-55, gaussian.cpp:94-98, mitchell.cpp:60-79, catmullrom.cpp:39-52 */
 static float filter_eval(const orc_sensor *se, float x, float inv_r, const float *gc) {
     switch (se->filter) {
         case ORC_FILTER_GAUSSIAN:   return f_max(estrin10(x * x, gc), 0.f);
@@ -1356,6 +1361,7 @@ static float filter_eval(const orc_sensor *se, float x, float inv_r, const float
         default:                    return f_max(0.f, 1.f - fabsf(x * inv_r));
     }
 }
+/* ImageBlock::put, non-coalesced accumulation of one sample into its filter footprint (src/render/imageblock.cpp:414-531; box filter: :119-133) */
 static void splat(const orc_sensor *se, float *film, float spx, float spy, int pixel_x, int pixel_y, const float *rgb) {
     int W = se->crop_w, H = se->crop_h;
     float vals[4] = { rgb[0], rgb[1], rgb[2], 1.f };
@@ -1583,7 +1589,7 @@ void orc_bake_sphere(const float *to_world, const float *to_object, const float 
 void orc_fresnel_dielectric(float cos_theta_i, float eta, float *out4) { fresnel_dielectric(cos_theta_i, eta, out4, out4 + 1, out4 + 2, out4 + 3); }
 float orc_fresnel_conductor(float cos_theta_i, float eta, float k) { return fresnel_conductor(cos_theta_i, eta, k); }
 
-/* SmoothPlastic::parameters_changed + fresnel_diffuse_reflectance -- see the header */
+/* fresnel_diffuse_reflectance (include/mitsuba/render/fresnel.h:328-355) and SmoothPlastic::parameters_changed (src/bsdfs/plastic.cpp:201-217) */
 static float fresnel_diffuse_reflectance(float eta) {
     float inv_eta = 1.0f / eta;
     float approx_1 = fmaf(0.0636f, inv_eta, fmaf(eta, fmaf(eta, -1.4399f, 0.7099f), 0.6681f));
