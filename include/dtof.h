@@ -81,6 +81,8 @@ typedef struct {
     int32_t  time_correlate_number, path_correlate_number;
     uint32_t bvh_stack_depth;       /* entries a traversal stack can need: TLAS depth + deepest per-mesh BLAS */
 } dtof_scene_info;
+/* What Film::crop_size / Sampler::sample_count / the plugins' to_string() report (src/films/hdrfilm.cpp:235-279, src/render/sampler.cpp:13-14,
+ * src/integrators/dopplertofpath.cpp:315-328), plus the sizes of the packed scene. */
 int dtof_scene_get_info(const dtof_scene *scene, dtof_scene_info *info);
 
 /* Flat float32 export of what the loader produced (parity of the XML semantics, row X1):
@@ -124,6 +126,8 @@ typedef struct {
 int dtof_render(dtof_scene *scene, uint32_t sensor_index, uint32_t seed, uint32_t spp,
                 float *out_rgb, dtof_render_stats *stats);
 
+/* Integrator::render on a scene-independent plugin object (include/mitsuba/render/integrator.h:74-79): the integrator created by
+ * dtof_integrator_create renders `scene` with its own parameters and, if given, the sampler plugin object's (else the scene's). */
 int dtof_integrator_render(const dtof_integrator *integrator, const dtof_sampler_plugin *sampler_or_null, dtof_scene *scene,
                            uint32_t sensor_index, uint32_t seed, uint32_t spp, float *out_rgb, dtof_render_stats *stats);
 
