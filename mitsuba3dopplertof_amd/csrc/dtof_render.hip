@@ -11,6 +11,7 @@
 #include "dtof_scene.h"
 #include "dtof_math.h"
 #include <atomic>
+#include <dlfcn.h>
 #include <cstring>
 #include <cstdlib>
 #include <cmath>
@@ -211,16 +212,36 @@ RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, cons
     return rp;
 }
 
+// Optional roctx ranges around the stage launches (the counterpart of the reference's ScopedPhase / NVTX ranges,
+// include/mitsuba/core/profiler.h): DTOF_ROCTX=1 loads the roctx library at run time, `rocprofv3 --marker-trace` then shows
+// "dtof:generate|trace|shade|shadow|splat|first" ranges on the host timeline.  No link-time dependency.
+struct Roctx {
+    int (*push)(const char *) = nullptr; int (*pop)() = nullptr;
+    Roctx() {
+        const char *e = getenv("DTOF_ROCTX");
+        if (!e || e[0] == '0') return;
+        void *h = nullptr;   // rocprofv3 listens to the SDK's roctx; the older libroctx64 serves rocprof v1 / v2
+        for (const char *name : { "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so", "/opt/rocm/lib/libroctx64.so" })
+            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) return;
+        push = (int (*)(const char *)) dlsym(h, "roctxRangePushA"); pop = (int (*)()) dlsym(h, "roctxRangePop");
+        if (!push || !pop) push = nullptr;
+    }
+};
+static const Roctx &roctx() { static const Roctx r; return r; }
+static const char *const kStageNames[6] = { "dtof:generate", "dtof:trace", "dtof:shade", "dtof:shadow", "dtof:splat", "dtof:first" };
+
 struct StageTimer {
     bool on; dtof_scene *sc; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[6];
     StageTimer(bool enabled, dtof_scene *scene) : on(enabled), sc(scene) { sc->events_used = 0; }
     int begin(int stage, hipStream_t s) {
+        if (roctx().push) roctx().push(kStageNames[stage]);
         if (!on) return -1;
         hipEvent_t a = sc->take_event(), b = sc->take_event();
         ev[stage].emplace_back(a, b); HIP_CHECK(hipEventRecord(a, s));
         return (int) ev[stage].size() - 1;
     }
-    void end(int stage, int idx, hipStream_t s) { if (on) HIP_CHECK(hipEventRecord(ev[stage][idx].second, s)); }
+    void end(int stage, int idx, hipStream_t s) { if (on) HIP_CHECK(hipEventRecord(ev[stage][idx].second, s)); if (roctx().push) roctx().pop(); }
     double total(int stage) {
         double ms = 0;
         for (auto &p : ev[stage]) { float t = 0; HIP_CHECK(hipEventElapsedTime(&t, p.first, p.second)); ms += t; }
