@@ -99,6 +99,8 @@ int dtof_scene_get_info(const dtof_scene *scene, dtof_scene_info *info);
  *                             specular_transmittance[3], conductor eta[3], k[3], alpha_u, alpha_v
  *                             (src/bsdfs/{diffuse,conductor,dielectric,plastic,roughconductor,roughplastic}.cpp; 5 = roughplastic, 6 = thindielectric, 7 = roughdielectric,
  *                             whose fdr_int slot carries m_internal_reflectance)
+ * kind 11: spot emitters   -> per spot 22 floats: position[3], intensity[3], world-to-local[12], cutoff angle (rad), cos(cutoff), cos(beam width),
+ *                             1 / (cutoff - beam width) (src/emitters/spot.cpp:75-100)
  * kind 10: roughplastic tables -> per roughplastic shape the 64 values of m_external_transmittance (roughplastic.cpp:222-257)
  * Returns the number of floats written (<= capacity) through *n_written. */
 int dtof_scene_export(const dtof_scene *scene, int kind, float *out, size_t capacity, size_t *n_written);

@@ -235,6 +235,19 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                     float id2 = sqr(inv_dist);
                     em_weight = mk(em.intensity[0] * id2, em.intensity[1] * id2, em.intensity[2] * id2);
                     ds_pdf = 1.f;
+                } else if (SPEC && em.kind == EMITTER_SPOT) {   // SpotLight::sample_direction (spot.cpp:152-187), falloff_curve (:116-126)
+                    dsp = mk(em.pos[0], em.pos[1], em.pos[2]);
+                    dd = dsp - si.p;
+                    ds_dist = norm(dd);
+                    const float inv_dist = rcp(ds_dist);
+                    dd = dd * inv_dist;
+                    const V3 local = normalize(xf_vector(em.to_local, -dd));
+                    const float cos_theta = local.z;
+                    const float beam = cos_theta >= em.cos_beam ? 1.f : (em.cutoff_angle - acos_(cos_theta)) * em.inv_transition;
+                    const float falloff = cos_theta > em.cos_cutoff ? beam : 0.f;
+                    const float k = falloff * sqr(inv_dist);
+                    em_weight = falloff > 0.f ? mk(em.intensity[0] * k, em.intensity[1] * k, em.intensity[2] * k) : mk(0, 0, 0);
+                    ds_pdf = 1.f;
                 } else {
                     const DShape &es = sv.shapes[em.shape];
                     V3 en;

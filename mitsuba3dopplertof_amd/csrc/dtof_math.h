@@ -121,6 +121,19 @@ DTOF_HD void sincos_(float x, float &s_out, float &c_out) {
 }
 DTOF_HD float cos_(float x) { float s, c; sincos_(x, s, c); return c; }
 
+// acos, restated from the Cephes asinf kernel Dr.Jit's dr::acos builds on (its source is not in the reference tree): minimax polynomial
+// in x^2 (|x| < 0.5) or in (1 - |x|) / 2 with a square root, evaluated in Estrin form with fmadd.  Used by SpotLight::falloff_curve.
+DTOF_HD float acos_(float x) {
+    const float xa = fabsf(x), x2 = x * x;
+    const bool big = xa >= 0.5f;
+    const float x1 = 0.5f * (1.f - xa), x3 = big ? x1 : x2, x4 = big ? sqrtf(x1) : x;
+    const float a0 = fmaf(x3, 7.4953002686e-2f, 1.6666752422e-1f), a1 = fmaf(x3, 2.4181311049e-2f, 4.5470025998e-2f), y2 = x3 * x3;
+    float z1 = fmaf(y2 * y2, 4.2163199048e-2f, fmaf(y2, a1, a0));
+    z1 = fmaf(z1, x3 * x4, x4);
+    const float z2 = 2.f * z1, z3 = x < 0.f ? kPi - z2 : z2, z4 = 0.5f * kPi - z1;
+    return big ? z3 : z4;
+}
+
 // dr::detail::estrin_impl for 10 coefficients (what GaussianFilter::eval evaluates, src/rfilters/gaussian.cpp:94-96)
 DTOF_HD float estrin10(float x, const float *c) {
     float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;

@@ -309,6 +309,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     for (auto &e : sc->host.emitters) has_surface_emitters |= e.kind == EMITTER_AREA;
     rp.has_area = has_surface_emitters;
     for (auto &sh : sc->host.shapes) rp.has_spec |= sh.bsdf != BSDF_DIFFUSE;
+    for (auto &e : sc->host.emitters) rp.has_spec |= e.kind == EMITTER_SPOT;   // the spot branch lives in the SPEC instantiations (keeps the common kernels lean)
     bool has_spheres = false;
     for (auto &sh : sc->host.shapes) has_spheres |= sh.kind == SHAPE_SPHERE;
     rp.has_tris = bh->n_tris != 0 || has_spheres;   // anything but rectangles: the instantiations with triangle / sphere code
@@ -570,6 +571,10 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
             v.insert(v.end(), s.cond_eta, s.cond_eta + 3); v.insert(v.end(), s.cond_k, s.cond_k + 3); v.push_back(s.alpha_u); v.push_back(s.alpha_v);
         } else if (kind == 10) for (auto &s : sc->host.shapes) {
             if (s.bsdf == BSDF_ROUGHPLASTIC) v.insert(v.end(), s.rough_table.begin(), s.rough_table.end());
+        } else if (kind == 11) for (auto &e : sc->host.emitters) {
+            if (e.kind != EMITTER_SPOT) continue;
+            v.insert(v.end(), e.pos, e.pos + 3); v.insert(v.end(), e.intensity, e.intensity + 3); v.insert(v.end(), e.to_local, e.to_local + 12);
+            v.push_back(e.cutoff_angle); v.push_back(e.cos_cutoff); v.push_back(e.cos_beam); v.push_back(e.inv_transition);
         } else throw std::runtime_error("unknown export kind");
         *n_written = v.size();
         if (out) { if (v.size() > cap) throw std::runtime_error("export buffer too small"); memcpy(out, v.data(), v.size() * 4); }

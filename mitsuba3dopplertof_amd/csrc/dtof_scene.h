@@ -18,7 +18,7 @@ enum TimeSampling : int32_t { TIME_UNIFORM = 0, TIME_STRATIFIED = 1, TIME_ANTITH
 enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1, FILTER_GAUSSIAN = 2, FILTER_MITCHELL = 3, FILTER_CATMULLROM = 4 };
 enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4, SF_EMITTER = 8 };
 enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4, BSDF_ROUGHPLASTIC = 5, BSDF_THINDIELECTRIC = 6, BSDF_ROUGHDIELECTRIC = 7 };
-enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1 };
+enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1, EMITTER_SPOT = 2 };
 
 // ---------------------------------------------------------------------------- device blob records
 // One contiguous byte blob (offsets from its base) so that small scenes can be staged
@@ -72,8 +72,12 @@ struct DShape {             // 304 B
 };
 struct DTri { float p0[3]; uint32_t face; float p1[4], p2[4]; };         // 48 B; face = index in the mesh's own order (tie rule)
 struct DTriShade { float n0[3], n1[3], n2[3], uv0[2], uv1[2], uv2[2], pad; };   // 64 B
-struct DEmitter { uint32_t kind; float pos[3]; float intensity[3]; uint32_t shape; };   // area: intensity = radiance, shape = index into shapes[]
-static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 304 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64, "blob records");
+struct DEmitter {           // 96 B
+    uint32_t kind; float pos[3]; float intensity[3]; uint32_t shape;   // area: intensity = radiance, shape = index into shapes[]
+    // spot (src/emitters/spot.cpp:75-100): world -> local (3x4 affine part of to_world's inverse) and the constants of the falloff curve
+    float to_local[12]; float cutoff_angle, cos_cutoff, cos_beam, inv_transition;
+};
+static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 304 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64 && sizeof(DEmitter) == 96, "blob records");
 
 // ---------------------------------------------------------------------------- host description
 struct Mat4d { double m[16]; };   // row-major
@@ -101,7 +105,8 @@ struct HostObject {
     float key_time[2] = { 0, 0 };
     float key[2][16];
 };
-struct HostEmitter { uint32_t kind = 0; float pos[3] = { 0, 0, 0 }; float intensity[3] = { 0, 0, 0 }; uint32_t shape = 0xffffffffu; };
+struct HostEmitter { uint32_t kind = 0; float pos[3] = { 0, 0, 0 }; float intensity[3] = { 0, 0, 0 }; uint32_t shape = 0xffffffffu;
+                     float to_local[12] = { 0 }, cutoff_angle = 0, cos_cutoff = 0, cos_beam = 0, inv_transition = 0; };   // spot
 struct HostSensor {
     float to_world[16];
     float x_fov = 0, near_clip = 1e-2f, far_clip = 1e4f, shutter_open = 0, shutter_close = 0;

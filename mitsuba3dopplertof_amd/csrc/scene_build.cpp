@@ -267,6 +267,9 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     for (size_t i = 0; i < sc.emitters.size(); ++i) {
         emitters[i].kind = sc.emitters[i].kind; emitters[i].shape = sc.emitters[i].shape;
         memcpy(emitters[i].pos, sc.emitters[i].pos, 12); memcpy(emitters[i].intensity, sc.emitters[i].intensity, 12);
+        memcpy(emitters[i].to_local, sc.emitters[i].to_local, 48);
+        emitters[i].cutoff_angle = sc.emitters[i].cutoff_angle; emitters[i].cos_cutoff = sc.emitters[i].cos_cutoff;
+        emitters[i].cos_beam = sc.emitters[i].cos_beam; emitters[i].inv_transition = sc.emitters[i].inv_transition;
     }
     // ---- pack: nodes first (so that "the first N bytes" = header + top of the TLAS in BFS-ish order)
     BlobHeader h; memset(&h, 0, sizeof h);

@@ -873,8 +873,26 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
             if (have_sensor) fail("only one sensor is supported");
             make_sensor(o, sc); have_sensor = true;
         } else if (o.tag == "emitter") {
-            if (o.plugin != "point") fail("unsupported emitter plugin \"" + o.plugin + "\" (supported: point)");
+            if (o.plugin != "point" && o.plugin != "spot") fail("unsupported emitter plugin \"" + o.plugin + "\" (supported: point, spot; area inside a shape)");
             HostEmitter e; e.kind = 0;
+            if (o.plugin == "spot") {   // src/emitters/spot.cpp:75-100; position = translation of to_world, axis = its +z
+                e.kind = EMITTER_SPOT;
+                auto tws = o.transforms.find("to_world");
+                Xf xf; if (tws != o.transforms.end()) xf = tws->second; else { xf.m = m_identity(); xf.inv = m_identity(); }
+                float m[16], inv[16]; to_f32(xf.m, m); to_f32(xf.inv, inv);
+                e.pos[0] = m[3]; e.pos[1] = m[7]; e.pos[2] = m[11];
+                for (int k = 0; k < 12; ++k) e.to_local[k] = inv[k];
+                float cutoff = (float) o.props.get_float("cutoff_angle", 20.0);
+                float beam = (float) o.props.get_float("beam_width", (double) (cutoff * 3.0f / 4.0f));
+                cutoff = cutoff * (kPi / 180.f); beam = beam * (kPi / 180.f);                     // dr::deg_to_rad
+                e.cutoff_angle = cutoff; e.inv_transition = 1.0f / (cutoff - beam);
+                e.cos_cutoff = cos_(cutoff); e.cos_beam = cos_(beam);
+                if (!(cutoff >= beam)) fail("spot: cutoff_angle must not be smaller than beam_width");
+                if (o.props.has("texture") || o.colors.count("texture")) fail("spot: textured spot lights are not supported");
+                auto ics = o.colors.find("intensity");
+                if (ics != o.colors.end()) for (int i = 0; i < 3; ++i) e.intensity[i] = (float) ics->second[i];
+                else { float v = (float) o.props.get_float("intensity", 1.0); e.intensity[0] = e.intensity[1] = e.intensity[2] = v; }
+            } else {
             auto pv = o.vectors.find("position"); auto tw = o.transforms.find("to_world");
             if (pv != o.vectors.end()) {
                 if (tw != o.transforms.end()) fail("Only one of the parameters 'position' and 'to_world' can be specified at the same time!'");
@@ -886,6 +904,11 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
             auto ic = o.colors.find("intensity");
             if (ic != o.colors.end()) for (int i = 0; i < 3; ++i) e.intensity[i] = (float) ic->second[i];
             else { float v = (float) o.props.get_float("intensity", 1.0); e.intensity[0] = e.intensity[1] = e.intensity[2] = v; }
+            }
+            {
+                auto u = o.props.unqueried();
+                if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in emitter plugin of type \"" + o.plugin + "\"");
+            }
             sc.emitters.push_back(e);
         } else if (o.tag == "shape") {
             if (o.plugin == "shapegroup") {

@@ -131,6 +131,21 @@ void orc_sincos(float x, float *s_out, float *c_out) {
     *c_out = u2f(f2u(poly ? c : s) ^ (sign_cos & 0x80000000u));
 }
 static inline float orc_cos(float x) { float s, c; orc_sincos(x, &s, &c); return c; }
+/* acos: the Cephes asinf kernel dr::acos builds on (Dr.Jit's source is not in the tree), Estrin form with fmadd -- SpotLight::falloff_curve */
+float orc_acos(float x) {
+    float xa = fabsf(x), x2 = x * x;
+    int big = xa >= 0.5f;
+    float x1 = 0.5f * (1.f - xa), x3 = big ? x1 : x2, x4 = big ? sqrtf(x1) : x;
+    float a0 = fmaf(x3, 7.4953002686e-2f, 1.6666752422e-1f), a1 = fmaf(x3, 2.4181311049e-2f, 4.5470025998e-2f), y2 = x3 * x3;
+    float z1 = fmaf(y2 * y2, 4.2163199048e-2f, fmaf(y2, a1, a0));
+    z1 = fmaf(z1, x3 * x4, x4);
+    float z2 = 2.f * z1, z3 = x < 0.f ? ORC_PI_F - z2 : z2, z4 = 0.5f * ORC_PI_F - z1;
+    return big ? z3 : z4;
+}
+void orc_spot_params(float cutoff_deg, float beam_deg, float *out4) {
+    float cutoff = cutoff_deg * (ORC_PI_F / 180.f), beam = beam_deg * (ORC_PI_F / 180.f);
+    out4[0] = cutoff; out4[1] = orc_cos(cutoff); out4[2] = orc_cos(beam); out4[3] = 1.0f / (cutoff - beam);
+}
 
 /* ------------------------------------------------------------------ RNG */
 /* sample_tea_32 -- include/mitsuba/core/random.h:33-47 */
@@ -1019,6 +1034,20 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
                 dd = v_mul(dd, inv_dist);
                 float id2 = f_sqr(inv_dist);
                 em_weight = V(em->intensity[0] * id2, em->intensity[1] * id2, em->intensity[2] * id2);
+                ds_pdf = 1.f; ds_delta = 1;
+            } else if (em->kind == ORC_EMITTER_SPOT) {
+                /* SpotLight::sample_direction (src/emitters/spot.cpp:152-187) with falloff_curve (:116-126) */
+                dsp = V(em->position[0], em->position[1], em->position[2]);
+                dd = v_sub(dsp, si.p);
+                ds_dist = sqrtf(v_dot(dd, dd));
+                float inv_dist = f_rcp(ds_dist);
+                dd = v_mul(dd, inv_dist);
+                v3 local = v_normalize(m_vector(em->to_local, v_neg(dd)));
+                float cos_theta = local.z;
+                float beam = cos_theta >= em->cos_beam ? 1.f : (em->cutoff_angle - orc_acos(cos_theta)) * em->inv_transition;
+                float falloff = cos_theta > em->cos_cutoff ? beam : 0.f;
+                float k = falloff * f_sqr(inv_dist);
+                em_weight = falloff > 0.f ? V(em->intensity[0] * k, em->intensity[1] * k, em->intensity[2] * k) : V(0, 0, 0);
                 ds_pdf = 1.f; ds_delta = 1;
             } else {
                 /* AreaLight::sample_direction area.cpp:116-159 -> Shape::sample_direction shape.cpp:370-384 ->

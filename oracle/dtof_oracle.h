@@ -25,7 +25,7 @@ extern "C" {
 
 enum { ORC_SHAPE_RECT = 0, ORC_SHAPE_MESH = 1, ORC_SHAPE_SPHERE = 2 };
 enum { ORC_OBJ_SHAPE = 0, ORC_OBJ_INSTANCE = 1 };
-enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1 };
+enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1, ORC_EMITTER_SPOT = 2 };
 enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 };
 enum { ORC_TIME_UNIFORM = 0, ORC_TIME_STRATIFIED = 1, ORC_TIME_ANTITHETIC = 2,
        ORC_TIME_ANTITHETIC_MIRROR = 3 };
@@ -94,6 +94,8 @@ typedef struct {
     float   position[3];     /* point */
     float   intensity[3];    /* point: intensity; area: radiance */
     int32_t shape;           /* area: index into shapes[] of the rectangle that carries it */
+    /* spot (src/emitters/spot.cpp:75-100): inverse of to_world (float cast of the double inverse), falloff constants (orc_spot_params) */
+    float   to_local[16], cutoff_angle, cos_cutoff, cos_beam, inv_transition;
 } orc_emitter;
 
 typedef struct {
@@ -216,6 +218,9 @@ float    orc_fresnel_conductor(float cos_theta_i, float eta, float k);
  * mean(eval_reflectance(1 / eta) * mu) * 2 (microfacet.h:463-512); Gauss-Legendre nodes from core/quad.h:27-86 */
 void     orc_roughplastic_tables(float alpha, float eta, float *table64, float *internal_reflectance);
 void     orc_gauss_legendre(int n, float *nodes, float *weights);
+/* SpotLight constructor (src/emitters/spot.cpp:91-99) in float32: degrees -> out4 = cutoff (rad), cos(cutoff), cos(beam), 1 / (cutoff - beam) */
+void     orc_spot_params(float cutoff_deg, float beam_deg, float *out4);
+float    orc_acos(float x);
 void     orc_plastic_params(float eta, const float *diffuse3, const float *specular3, float *out3);
 
 /* Sphere ctor + update (sphere.cpp:121-160), all in float32 as ScalarTransform4f is: composed = to_world * translate(center) *

@@ -42,7 +42,8 @@ class OrcObject(C.Structure):
 
 
 class OrcEmitter(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("position", C.c_float * 3), ("intensity", C.c_float * 3), ("shape", C.c_int32)]
+    _fields_ = [("kind", C.c_int32), ("position", C.c_float * 3), ("intensity", C.c_float * 3), ("shape", C.c_int32),
+                ("to_local", M16), ("cutoff_angle", C.c_float), ("cos_cutoff", C.c_float), ("cos_beam", C.c_float), ("inv_transition", C.c_float)]
 
 
 class OrcSensor(C.Structure):
@@ -140,6 +141,9 @@ def lib():
                                  C.c_void_p, C.c_void_p, C.c_int]
         L.orc_bake_cube.argtypes = [C.c_void_p] * 6
         L.orc_plastic_params.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_spot_params.argtypes = [C.c_float, C.c_float, C.c_void_p]
+        L.orc_acos.restype = C.c_float
+        L.orc_acos.argtypes = [C.c_float]
         L.orc_roughplastic_tables.argtypes = [C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_float)]
         L.orc_gauss_legendre.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.orc_fresnel_dielectric.argtypes = [C.c_float, C.c_float, C.c_void_p]
@@ -281,6 +285,12 @@ class Scene:
             emitters[i].position = (C.c_float * 3)(*e["position"].tolist())
             emitters[i].intensity = (C.c_float * 3)(*e["intensity"].tolist())
             emitters[i].shape = int(e.get("shape", -1))
+            if e["kind"] == 2:   # spot: constructor constants in C float32 (orc_spot_params)
+                emitters[i].to_local = _m16(e["to_local"])
+                out4 = (C.c_float * 4)()
+                L.orc_spot_params(C.c_float(float(e["cutoff_deg"])), C.c_float(float(e["beam_deg"])), out4)
+                emitters[i].cutoff_angle, emitters[i].cos_cutoff, emitters[i].cos_beam, emitters[i].inv_transition = out4[0], out4[1], out4[2], out4[3]
+                e["spot_params"] = np.array(list(out4), np.float32)
         sc = OrcScene()
         sc.shapes, sc.n_shapes = shapes, len(fs.shapes)
         sc.groups, sc.n_groups = groups, len(fs.groups)

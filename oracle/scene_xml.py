@@ -535,6 +535,20 @@ def load(source, params=None, is_string=False):
             fs.sensor = _sensor_record(child)
             fs.sampler = next((c[1] for c in child.children if c[0] == "sampler"), None)
         elif tag == "emitter":
+            if child.plugin == "spot":   # src/emitters/spot.cpp:75-100
+                tw, tinv = child["to_world"][1] if "to_world" in child else (_ident(), _ident())
+                cutoff = F32(child.get_f("cutoff_angle", 20.0))
+                beam = F32(child.get_f("beam_width", float(cutoff * F32(3.0) / F32(4.0))))
+                if "texture" in child:
+                    raise ValueError("spot: textured spot lights are not supported")
+                if not cutoff >= beam:
+                    raise ValueError("spot: cutoff_angle must not be smaller than beam_width")
+                inten = child["intensity"] if "intensity" in child else ("float", 1.0)
+                child.queried.add("intensity"); child.queried.add("to_world")
+                iv = [inten[1]] * 3 if inten[0] in ("float", "int") else inten[1]
+                fs.emitters.append(dict(kind=2, position=_m32(tw)[:3, 3].copy(), intensity=np.asarray(iv, dtype=np.float64).astype(F32),
+                                        to_local=_m32(tinv), cutoff_deg=cutoff, beam_deg=beam))
+                continue
             if child.plugin != "point":
                 raise ValueError('unsupported emitter plugin "%s"' % child.plugin)
             if "position" in child:

@@ -250,6 +250,22 @@ def cornell_frosted(res=128, spp=16):
     return s + AREA_LIGHT + "</scene>\n"
 
 
+SPOT = ('\t<emitter type="spot">\n\t\t<transform name="to_world">\n\t\t\t<lookat origin="0.3, 1.9, 0.4" target="-0.2, 0.0, -0.3" up="0, 0, 1" />\n\t\t</transform>\n'
+        '\t\t<rgb name="intensity" value="60, 55, 45" />\n\t\t<float name="cutoff_angle" value="35" />\n\t\t<float name="beam_width" value="20" />\n\t</emitter>\n')
+
+
+def cornell_spot(res=128, spp=16):
+    """cornell_boxes.xml lit by a spot light under the ceiling (35 degree cone, smooth falloff from 20 degrees) and a weak point light
+    at the camera: two delta emitters of different kinds"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        s += bsdf(*b)
+    for name, m, b in WALLS:
+        s += rect(name, m, b)
+    s += cube("ShortBox", SHORT, "ShortBoxBSDF", "0.015") + cube("TallBox", TALL, "TallBoxBSDF", "-0.015")
+    return s + SPOT + LIGHT.replace('value="100"', 'value="10"') + "</scene>\n"
+
+
 def domino(n_side=32, res=1024, spp=128):
     s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5").replace('value="sinusoidal"', 'value="rectangular"')
     cam = '\t\t\t<lookat origin="0, 9, 16" target="0, 0.3, 0" up="0, 1, 0" />'
@@ -290,6 +306,7 @@ def main():
         "cornell_rough.xml": cornell_rough(),
         "cornell_roughplastic.xml": cornell_roughplastic(),
         "cornell_frosted.xml": cornell_frosted(),
+        "cornell_spot.xml": cornell_spot(),
         "cornell_spheres.xml": cornell_spheres(),
         "cornell_sphere_light.xml": cornell_spheres(sphere_light=True),
         "domino.xml": domino(),
@@ -303,7 +320,7 @@ def main():
 
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
-    names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml",
+    names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml",
              "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
