@@ -389,6 +389,28 @@ def test_cancel_stops_a_render_between_batches(mi):
     assert rel_linf(again, ref) <= IMG_TOL
 
 
+def test_repeated_renders_and_handles_do_not_leak_device_memory(mi):
+    """Workspaces are per handle and reused; destroying a handle returns its device memory (hipMemGetInfo through torch)."""
+    import gc
+    import torch
+    path = os.path.join(SCENES, "cornell_boxes.xml")
+    sc = mi.load_file(path, resx=128, resy=128)
+    sc.render(seed=0, spp=16); sc.render(seed=0, spp=64)          # the larger wavefront sizes the workspace
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for i in range(60):
+        sc.render(seed=i, spp=64 if i % 2 else 16)
+        sc.sample_lanes(i, 16, 0, 4096)
+    torch.cuda.synchronize()
+    assert abs(torch.cuda.mem_get_info()[0] - free0) <= 8 << 20
+    for i in range(12):                                           # handles come and go
+        tmp = mi.load_file(path, resx=96, resy=96)
+        tmp.render(seed=i, spp=32)
+        del tmp
+    gc.collect(); torch.cuda.synchronize()
+    assert abs(torch.cuda.mem_get_info()[0] - free0) <= 8 << 20
+
+
 def test_full_size_c3_multi_batch_frame_matches_oracle(mi, orc):
     """BASELINE configs[2] at FULL size: 512 x 512 x 256 spp, antithetic_mirror, 67 108 864 lanes = 4 wavefront batches.  The whole
     developed image against the oracle's (the batch seams must be invisible) and the lanes across the first seam bit-exact."""
