@@ -257,6 +257,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                         if (!MESH || es.kind == SHAPE_RECT) {
                             dsp = xf_point(es.to_world, mk(sx * 2.f - 1.f, e2 * 2.f - 1.f, 0.f));
                             en = mk(es.n[0], es.n[1], es.n[2]);
+                        } else if (es.kind == SHAPE_DISK) {   // Disk::sample_position (disk.cpp:158-177)
+                            float px, py; concentric_disk(sx, e2, px, py);
+                            dsp = xf_point(es.to_world, mk(px, py, 0.f));
+                            en = mk(es.n[0], es.n[1], es.n[2]);
                         } else mesh_sample_position(sv, es, sx, e2, dsp, en);
                         dd = dsp - si.p;
                         float dist2 = dot(dd, dd);

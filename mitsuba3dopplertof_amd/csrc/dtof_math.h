@@ -181,6 +181,17 @@ DTOF_HD float ggx_smith_g1(Ggx g, V3 v, V3 m) {   // smith_g1() :341-365
 }
 // pdf() :219-228, visible-normal branch (note the association: D * ((G1 * |wi.m|) / cos_theta_i), unlike the density sample() returns)
 DTOF_HD float ggx_pdf(Ggx g, V3 wi, V3 m) { return ggx_eval(g, m) * (ggx_smith_g1(g, wi, m) * fabsf(dot(wi, m)) / wi.z); }
+// warp::square_to_uniform_disk_concentric (include/mitsuba/core/warp.h:54-90)
+DTOF_HD void concentric_disk(float s_x, float s_y, float &px, float &py) {
+    const float x = fmaf(2.f, s_x, -1.f), y = fmaf(2.f, s_y, -1.f);
+    const bool is_zero = x == 0.f && y == 0.f, q13 = fabsf(x) < fabsf(y);
+    const float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = 0.25f * kPi * rp / r;
+    if (q13) phi = 0.5f * kPi - phi;
+    if (is_zero) phi = 0.f;
+    float sn, cs; sincos_(phi, sn, cs);
+    px = r * cs; py = r * sn;
+}
 // sample(), visible-normal branch :296-325 + sample_visible_11, GGX branch :405-420: microfacet normal and its density
 DTOF_HD V3 ggx_sample(Ggx g, V3 wi, float s_x, float s_y, float &pdf) {
     const V3 wi_p = normalize(mk(g.au * wi.x, g.av * wi.y, wi.z));
@@ -188,14 +199,7 @@ DTOF_HD V3 ggx_sample(Ggx g, V3 wi, float s_x, float s_y, float &pdf) {
     float rx = fmin_(fmax_(wi_p.x * inv_sin_theta, -1.f), 1.f), ry = fmin_(fmax_(wi_p.y * inv_sin_theta, -1.f), 1.f);
     if (fabsf(sin_theta_2) <= 4.f * 5.9604644775390625e-8f) { rx = 1.f; ry = 0.f; }
     const float sin_phi = ry, cos_phi = rx, cos_theta = wi_p.z;
-    const float x = fmaf(2.f, s_x, -1.f), y = fmaf(2.f, s_y, -1.f);   // square_to_uniform_disk_concentric (warp.h:54-90)
-    const bool is_zero = x == 0.f && y == 0.f, q13 = fabsf(x) < fabsf(y);
-    const float r = q13 ? y : x, rp = q13 ? x : y;
-    float phi = 0.25f * kPi * rp / r;
-    if (q13) phi = 0.5f * kPi - phi;
-    if (is_zero) phi = 0.f;
-    float sn, cs; sincos_(phi, sn, cs);
-    const float px = r * cs; float py = r * sn;
+    float px, py; concentric_disk(s_x, s_y, px, py);
     const float s = 0.5f * (1.f + cos_theta), a = safe_sqrt(1.f - sqr(px));
     py = fmaf(py, s, fmaf(-a, s, a));                              // dr::lerp(a, py, s)
     const float pz = safe_sqrt(1.f - fmaf(py, py, px * px));

@@ -311,7 +311,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     for (auto &sh : sc->host.shapes) rp.has_spec |= sh.bsdf != BSDF_DIFFUSE;
     for (auto &e : sc->host.emitters) rp.has_spec |= e.kind == EMITTER_SPOT;   // the spot branch lives in the SPEC instantiations (keeps the common kernels lean)
     bool has_spheres = false;
-    for (auto &sh : sc->host.shapes) has_spheres |= sh.kind == SHAPE_SPHERE;
+    for (auto &sh : sc->host.shapes) has_spheres |= sh.kind == SHAPE_SPHERE || sh.kind == SHAPE_DISK;   // analytic shapes of the MESH instantiations
     rp.has_tris = bh->n_tris != 0 || has_spheres;   // anything but rectangles: the instantiations with triangle / sphere code
     {   // deep per-mesh traversals diverge: see unstaged_block() in dtof_kernels.hip
         const DShape *dshapes = (const DShape *) (sc->blob.data() + bh->off_shapes);

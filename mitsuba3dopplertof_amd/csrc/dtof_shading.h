@@ -37,6 +37,16 @@ DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, 
         si.p = p + n * dist; si.n = n; si.sh_n = n;
         dp_du = mk(sh->dp_du[0], sh->dp_du[1], sh->dp_du[2]);
         dp_dv = mk(sh->dp_dv[0], sh->dp_dv[1], sh->dp_dv[2]);
+    } else if (sh->kind == SHAPE_DISK) {   // Disk::compute_surface_interaction (disk.cpp:305-336); prim_uv = the local hit position
+        V3 n = mk(sh->n[0], sh->n[1], sh->n[2]);
+        V3 p = vfma(ld, t, lo);
+        V3 tr = mk(sh->to_world[3], sh->to_world[7], sh->to_world[11]);
+        float dist = dot(tr - p, n);
+        si.p = p + n * dist; si.n = n; si.sh_n = n;
+        const float r = sqrtf(fmaf(b2, b2, b1 * b1)), inv_r = rcp(r);
+        const float cos_phi = r != 0.f ? b1 * inv_r : 1.f, sin_phi = r != 0.f ? b2 * inv_r : 0.f;
+        dp_du = xf_vector(sh->to_world, mk(cos_phi, sin_phi, 0.f));
+        dp_dv = xf_vector(sh->to_world, mk(-sin_phi, cos_phi, 0.f));
     } else if (sh->kind == SHAPE_SPHERE) {   // Sphere::compute_surface_interaction (sphere.cpp:509-513, 527-551)
         const V3 c = mk(sh->n[0], sh->n[1], sh->n[2]); const float radius = sh->dp_du[0];
         V3 n = normalize(vfma(ld, t, lo) - c);

@@ -49,6 +49,13 @@ DTOF_D bool rect_hit(const DShape &sh, V3 o, V3 d, float maxt, float &t, float &
     u = fmaf(ld.x, t, lo.x); v = fmaf(ld.y, t, lo.y);
     return t >= 0.f && t <= maxt && fabsf(u) <= 1.f && fabsf(v) <= 1.f;
 }
+// Disk::ray_intersect_preliminary_impl, src/shapes/disk.cpp:216-232: the rectangle's plane test with a circular bound
+DTOF_D bool disk_hit(const DShape &sh, V3 o, V3 d, float maxt, float &t, float &u, float &v) {
+    V3 lo = xf_point(sh.to_object, o), ld = xf_vector(sh.to_object, d);
+    t = -lo.z / ld.z;
+    u = fmaf(ld.x, t, lo.x); v = fmaf(ld.y, t, lo.y);
+    return t >= 0.f && t <= maxt && u * u + v * v <= 1.f;
+}
 // Moeller-Trumbore as in Embree 3's triangle intersector (tnear < t <= tfar; u,v weight vertices 1,2).
 // The 48-byte record is fetched with three 16-byte loads issued together; `face` rides in p0.w.
 DTOF_D bool tri_hit(const DTri &tr, V3 o, V3 d, float maxt, float &t, float &u, float &v, uint32_t &face) {
@@ -176,6 +183,15 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
             continue;
         }
         if (!MESH) continue;   // instantiations for rectangle-only scenes carry no triangle / sphere code at all
+        if (sh.kind == SHAPE_DISK) {
+            if (disk_hit(sh, lo, ld, maxt, t, u, v)) {
+                if (ANY) return true;
+                if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
+                    best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = 0; found = true;
+                }
+            }
+            continue;
+        }
         if (sh.kind == SHAPE_SPHERE) {
             if (sphere_hit<ANY>(sh, lo, ld, maxt, t)) {
                 if (ANY) return true;

@@ -35,7 +35,7 @@ struct Box {
 
 static Box shape_box(const HostShape &s) {
     Box b;
-    if (s.kind == SHAPE_RECT) {   // Rectangle::bbox, src/shapes/rectangle.cpp:115-125
+    if (s.kind == SHAPE_RECT || s.kind == SHAPE_DISK) {   // Rectangle::bbox (rectangle.cpp:115-125), Disk::bbox (disk.cpp:136-146): the same four corners
         const float c[4][2] = { { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
         for (auto &k : c) b.add(xf_point(s.to_world, mk(k[0], k[1], 0.f)));
     } else if (s.kind == SHAPE_SPHERE) {   // Sphere::bbox, src/shapes/sphere.cpp:177-182
@@ -150,6 +150,13 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
             d.dp_du[0] = du.x; d.dp_du[1] = du.y; d.dp_du[2] = du.z;
             d.dp_dv[0] = dv.x; d.dp_dv[1] = dv.y; d.dp_dv[2] = dv.z;
             d.inv_area = rcp(norm(cross(du, dv)));   // Rectangle::surface_area / m_inv_surface_area (rectangle.cpp:109,127-129)
+        } else if (h.kind == SHAPE_DISK) {   // Disk::update + surface_area (src/shapes/disk.cpp:100-115,148-152)
+            const V3 du = xf_vector(h.to_world, mk(1.f, 0.f, 0.f)), dv = xf_vector(h.to_world, mk(0.f, 1.f, 0.f));
+            const float m_du = norm(du), m_dv = norm(dv);
+            const V3 n = normalize(xf_normal(h.to_object, mk(0.f, 0.f, 1.f))), fs = du * rcp(m_du), ft = dv * rcp(m_dv);
+            d.n[0] = n.x; d.n[1] = n.y; d.n[2] = n.z;
+            const float hh = sqrtf(sqr(m_dv) - sqr(dot(ft * m_dv, fs)));
+            d.inv_area = rcp(kPi * m_du * hh);
         } else if (h.kind == SHAPE_SPHERE) {
             memcpy(d.n, h.center, 12); d.dp_du[0] = h.radius; d.inv_area = h.sphere_inv_area;
         } else {

@@ -703,12 +703,13 @@ static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string
     const bool mesh_file = o.plugin == "obj" || o.plugin == "ply";
     if (o.plugin == "rectangle") s.kind = SHAPE_RECT; else if (o.plugin == "cube" || mesh_file) s.kind = SHAPE_MESH;
     else if (o.plugin == "sphere") s.kind = SHAPE_SPHERE;
-    else fail("unsupported shape plugin \"" + o.plugin + "\" (supported: rectangle, cube, obj, ply, sphere, shapegroup, instance)");
+    else if (o.plugin == "disk") s.kind = SHAPE_DISK;
+    else fail("unsupported shape plugin \"" + o.plugin + "\" (supported: rectangle, disk, cube, obj, ply, sphere, shapegroup, instance)");
     Xf tw { m_identity(), m_identity() };
     if (!strip_to_world) { auto t = o.transforms.find("to_world"); if (t != o.transforms.end()) tw = t->second; }
     s.flip_normals = o.props.get_bool("flip_normals", false);
     s.face_normals = o.props.get_bool("face_normals", false);
-    if (s.kind == SHAPE_RECT && s.flip_normals) {   // rectangle.cpp:91-99
+    if ((s.kind == SHAPE_RECT || s.kind == SHAPE_DISK) && s.flip_normals) {   // rectangle.cpp:91-99, disk.cpp:91-95
         Mat4d f = m_identity(); f.m[10] = -1.0; Mat4d fi = m_identity(); fi.m[10] = 1.0 / -1.0;
         tw.m = m_mul(tw.m, f); tw.inv = m_mul(fi, tw.inv); s.flip_normals = false;
     }
@@ -884,6 +885,7 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
                 for (int k = 0; k < 12; ++k) e.to_local[k] = inv[k];
                 float cutoff = (float) o.props.get_float("cutoff_angle", 20.0);
                 float beam = (float) o.props.get_float("beam_width", (double) (cutoff * 3.0f / 4.0f));
+                if (!std::isfinite(cutoff) || !std::isfinite(beam) || std::fabs(cutoff) > 360.f || std::fabs(beam) > 360.f) fail("spot: cutoff_angle and beam_width must be finite angles in degrees");
                 cutoff = cutoff * (kPi / 180.f); beam = beam * (kPi / 180.f);                     // dr::deg_to_rad
                 e.cutoff_angle = cutoff; e.inv_transition = 1.0f / (cutoff - beam);
                 e.cos_cutoff = cos_(cutoff); e.cos_beam = cos_(beam);

@@ -410,6 +410,16 @@ static int rect_intersect(const orc_shape *sh, v3 o, v3 d, float maxt, float *t_
     }
     return 0;
 }
+/* Disk::ray_intersect_preliminary_impl -- src/shapes/disk.cpp:216-232 */
+static int disk_intersect(const orc_shape *sh, v3 o, v3 d, float maxt, float *t_out, float *u, float *v) {
+    v3 lo = m_point(sh->to_object, o), ld = m_vector(sh->to_object, d);
+    float t = -lo.z / ld.z;
+    float lx = fmaf(ld.x, t, lo.x), ly = fmaf(ld.y, t, lo.y);
+    if (t >= 0.f && t <= maxt && lx * lx + ly * ly <= 1.f) {
+        *t_out = t; *u = lx; *v = ly; return 1;
+    }
+    return 0;
+}
 /* Triangle test: Embree 3's Moeller-Trumbore intersector (source absent; published
  * algorithm, kernels/geometry/triangle_intersector_moeller.h): tnear < t <= tfar,
  * u/v are the barycentrics of vertices 1 and 2. */
@@ -482,6 +492,10 @@ static void shape_closest(const orc_shape *sh, v3 o, v3 d, float maxt, int32_t o
         if (rect_intersect(sh, o, d, maxt, &t, &u, &v) && t < best->t) {
             best->t = t; best->u = u; best->v = v; best->obj = obj; best->shape = shape_idx; best->prim = 0;
         }
+    } else if (sh->kind == ORC_SHAPE_DISK) {
+        if (disk_intersect(sh, o, d, maxt, &t, &u, &v) && t < best->t) {
+            best->t = t; best->u = u; best->v = v; best->obj = obj; best->shape = shape_idx; best->prim = 0;
+        }
     } else if (sh->kind == ORC_SHAPE_SPHERE) {
         if (sphere_intersect(sh, o, d, maxt, &t) && t < best->t) {
             best->t = t; best->u = 0.f; best->v = 0.f; best->obj = obj; best->shape = shape_idx; best->prim = 0;
@@ -499,6 +513,7 @@ static void shape_closest(const orc_shape *sh, v3 o, v3 d, float maxt, int32_t o
 static int shape_any(const orc_shape *sh, v3 o, v3 d, float maxt) {
     float t, u, v;
     if (sh->kind == ORC_SHAPE_RECT) return rect_intersect(sh, o, d, maxt, &t, &u, &v);
+    if (sh->kind == ORC_SHAPE_DISK) return disk_intersect(sh, o, d, maxt, &t, &u, &v);
     if (sh->kind == ORC_SHAPE_SPHERE) return sphere_test(sh, o, d, maxt);
     for (int32_t f = 0; f < sh->n_faces; ++f) {
         const uint32_t *fi = sh->faces + 3 * f;
@@ -579,6 +594,19 @@ static void rect_si(const orc_shape *sh, v3 o, v3 d, float t, orc_si *si) {
     si->p = v_add(p, v_mul(n, dist));
     si->n = n; si->sh_n = n; si->dp_du = dp_du; si->dp_dv = dp_dv;
 }
+/* Disk::compute_surface_interaction -- src/shapes/disk.cpp:276-345 (primal branch :305-310, frame :316-336); (u, v) = local hit position */
+static void disk_si(const orc_shape *sh, v3 o, v3 d, float t, float u, float v, orc_si *si) {
+    v3 n = v_normalize(m_normal(sh->to_object, V(0.f, 0.f, 1.f)));
+    v3 p = v_fma(d, t, o);
+    v3 tr = V(sh->to_world[3], sh->to_world[7], sh->to_world[11]);
+    float dist = v_dot(v_sub(tr, p), n);
+    si->p = v_add(p, v_mul(n, dist));
+    float r = sqrtf(fmaf(v, v, u * u)), inv_r = f_rcp(r);
+    float cos_phi = r != 0.f ? u * inv_r : 1.f, sin_phi = r != 0.f ? v * inv_r : 0.f;
+    si->n = n; si->sh_n = n;
+    si->dp_du = m_vector(sh->to_world, V(cos_phi, sin_phi, 0.f));
+    si->dp_dv = m_vector(sh->to_world, V(-sin_phi, cos_phi, 0.f));
+}
 /* Sphere::compute_surface_interaction -- src/shapes/sphere.cpp:435-560 (primal branch :509-513, dp_du :527-545) */
 static void sphere_si(const orc_shape *sh, v3 o, v3 d, float t, orc_si *si) {
     v3 c = V(sh->center[0], sh->center[1], sh->center[2]);
@@ -635,6 +663,7 @@ static void compute_si(const orc_scene *sc, const orc_hit *h, v3 o, v3 d, float 
         const orc_shape *sh = &sc->shapes[ob->index];
         si->shape = sh;
         if (sh->kind == ORC_SHAPE_RECT) rect_si(sh, o, d, h->t, si);
+        else if (sh->kind == ORC_SHAPE_DISK) disk_si(sh, o, d, h->t, h->u, h->v, si);
         else if (sh->kind == ORC_SHAPE_SPHERE) sphere_si(sh, o, d, h->t, si);
         else mesh_si(sh, h->prim, h->u, h->v, si);
     } else {
@@ -645,6 +674,7 @@ static void compute_si(const orc_scene *sc, const orc_hit *h, v3 o, v3 d, float 
         si->shape = sh;
         v3 lo = m_point(inv, o), ld = m_vector(inv, d);
         if (sh->kind == ORC_SHAPE_RECT) rect_si(sh, lo, ld, h->t, si);
+        else if (sh->kind == ORC_SHAPE_DISK) disk_si(sh, lo, ld, h->t, h->u, h->v, si);
         else if (sh->kind == ORC_SHAPE_SPHERE) sphere_si(sh, lo, ld, h->t, si);
         else mesh_si(sh, h->prim, h->u, h->v, si);
         si->p = m_point(m, si->p);
@@ -691,8 +721,16 @@ static float rect_inv_area(const orc_shape *sh) {
     v3 du = m_vector(sh->to_world, V(2.f, 0.f, 0.f)), dv = m_vector(sh->to_world, V(0.f, 2.f, 0.f));
     return f_rcp(v_norm(v_cross(du, dv)));
 }
+/* Disk::update + surface_area (src/shapes/disk.cpp:100-115,148-152) */
+static float disk_inv_area(const orc_shape *sh) {
+    v3 du = m_vector(sh->to_world, V(1.f, 0.f, 0.f)), dv = m_vector(sh->to_world, V(0.f, 1.f, 0.f));
+    float m_du = v_norm(du), m_dv = v_norm(dv);
+    v3 fs = v_mul(du, f_rcp(m_du)), ft = v_mul(dv, f_rcp(m_dv));
+    float h = sqrtf(f_sqr(m_dv) - f_sqr(v_dot(v_mul(ft, m_dv), fs)));
+    return f_rcp(ORC_PI_F * m_du * h);
+}
 static float shape_inv_area(const orc_shape *sh) {
-    return sh->kind == ORC_SHAPE_RECT ? rect_inv_area(sh) : sh->kind == ORC_SHAPE_SPHERE ? sh->sphere_inv_area : sh->area_norm;
+    return sh->kind == ORC_SHAPE_RECT ? rect_inv_area(sh) : sh->kind == ORC_SHAPE_DISK ? disk_inv_area(sh) : sh->kind == ORC_SHAPE_SPHERE ? sh->sphere_inv_area : sh->area_norm;
 }
 static inline float f_safe_sqrt(float x) { return sqrtf(f_max(x, 0.f)); }
 #define ORC_INV_TWO_PI_F 0.15915494309189533577f
@@ -1059,6 +1097,10 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
                 } else {
                 if (es->kind == ORC_SHAPE_RECT) {
                     dsp = m_point(es->to_world, V(sx * 2.f - 1.f, e2 * 2.f - 1.f, 0.f));
+                    en = v_normalize(m_normal(es->to_object, V(0.f, 0.f, 1.f)));
+                } else if (es->kind == ORC_SHAPE_DISK) {   /* Disk::sample_position (disk.cpp:158-177) */
+                    v3 pd = square_to_cosine_hemisphere(sx, e2);   /* its x, y ARE square_to_uniform_disk_concentric */
+                    dsp = m_point(es->to_world, V(pd.x, pd.y, 0.f));
                     en = v_normalize(m_normal(es->to_object, V(0.f, 0.f, 1.f)));
                 } else mesh_sample_position(es, sx, e2, &dsp, &en);
                 dd = v_sub(dsp, si.p);

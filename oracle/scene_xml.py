@@ -460,7 +460,7 @@ class FlatScene:
 
 
 def _shape_record(sp, registry, strip_to_world, base_dir=""):
-    kind = {"rectangle": 0, "cube": 1, "obj": 1, "ply": 1, "sphere": 2}.get(sp.plugin)
+    kind = {"rectangle": 0, "cube": 1, "obj": 1, "ply": 1, "sphere": 2, "disk": 3}.get(sp.plugin)
     if kind is None:
         raise ValueError('unsupported shape plugin "%s"' % sp.plugin)
     mesh_raw = None
@@ -477,7 +477,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
     if not strip_to_world and "to_world" in sp and sp["to_world"][0] == "transform":
         tw, tinv = sp["to_world"][1]
     flip = sp.get_b("flip_normals", False)
-    if kind == 0 and flip:   # rectangle.cpp:91-99: to_world * scale(1, 1, -1)
+    if kind in (0, 3) and flip:   # rectangle.cpp:91-99, disk.cpp:91-95: to_world * scale(1, 1, -1)
         fm, fi = _scale([1.0, 1.0, -1.0])
         tw, tinv = _mul(tw, fm), _mul(fi, tinv)
         flip = False
@@ -539,6 +539,8 @@ def load(source, params=None, is_string=False):
                 tw, tinv = child["to_world"][1] if "to_world" in child else (_ident(), _ident())
                 cutoff = F32(child.get_f("cutoff_angle", 20.0))
                 beam = F32(child.get_f("beam_width", float(cutoff * F32(3.0) / F32(4.0))))
+                if not (np.isfinite(cutoff) and np.isfinite(beam) and abs(cutoff) <= 360 and abs(beam) <= 360):
+                    raise ValueError("spot: cutoff_angle and beam_width must be finite angles in degrees")
                 if "texture" in child:
                     raise ValueError("spot: textured spot lights are not supported")
                 if not cutoff >= beam:

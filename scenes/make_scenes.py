@@ -266,6 +266,29 @@ def cornell_spot(res=128, spp=16):
     return s + SPOT + LIGHT.replace('value="100"', 'value="10"') + "</scene>\n"
 
 
+DISK_LIGHT = ('\t<shape type="disk" id="DiskLight">\n\t\t<transform name="to_world">\n\t\t\t<scale x="0.3" y="0.2" z="1" />\n'
+              '\t\t\t<rotate x="1" angle="90" />\n\t\t\t<translate x="0" y="1.98" z="0" />\n\t\t</transform>\n'
+              '\t\t<emitter type="area">\n\t\t\t<rgb name="radiance" value="17, 12, 4" />\n\t\t</emitter>\n\t</shape>\n')
+
+
+def cornell_disk(res=128, spp=16):
+    """the Cornell room under an elliptic disk light, with a tilted two-sided disk that sweeps through the room (animated) and a static
+    disk with flipped normals leaning against the back wall"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        s += bsdf(*b)
+    for name, m, b in WALLS:
+        s += rect(name, m, b)
+    s += ('\t<shape type="disk" id="MovingDisk">\n\t\t<animation name="to_world">\n'
+          '\t\t\t<transform time="0">\n\t\t\t\t<scale value="0.4" />\n\t\t\t\t<rotate x="1" angle="-60" />\n\t\t\t\t<translate x="-0.35" y="0.6" z="0.1" />\n\t\t\t</transform>\n'
+          '\t\t\t<transform time="0.0015">\n\t\t\t\t<scale value="0.4" />\n\t\t\t\t<rotate x="1" angle="-58" />\n\t\t\t\t<translate x="-0.35" y="0.6" z="0.115" />\n\t\t\t</transform>\n'
+          '\t\t</animation>\n\t\t<ref id="ShortBoxBSDF" />\n\t</shape>\n')
+    s += ('\t<shape type="disk" id="LeaningDisk">\n\t\t<boolean name="flip_normals" value="true" />\n\t\t<transform name="to_world">\n'
+          '\t\t\t<scale x="0.35" y="0.5" z="1" />\n\t\t\t<rotate y="1" angle="160" />\n\t\t\t<translate x="0.45" y="0.55" z="-0.6" />\n\t\t</transform>\n'
+          '\t\t<ref id="TallBoxBSDF" />\n\t</shape>\n')
+    return s + DISK_LIGHT + "</scene>\n"
+
+
 def domino(n_side=32, res=1024, spp=128):
     s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5").replace('value="sinusoidal"', 'value="rectangular"')
     cam = '\t\t\t<lookat origin="0, 9, 16" target="0, 0.3, 0" up="0, 1, 0" />'
@@ -307,6 +330,7 @@ def main():
         "cornell_roughplastic.xml": cornell_roughplastic(),
         "cornell_frosted.xml": cornell_frosted(),
         "cornell_spot.xml": cornell_spot(),
+        "cornell_disk.xml": cornell_disk(),
         "cornell_spheres.xml": cornell_spheres(),
         "cornell_sphere_light.xml": cornell_spheres(sphere_light=True),
         "domino.xml": domino(),
@@ -320,7 +344,7 @@ def main():
 
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
-    names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml",
+    names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml",
              "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):

@@ -58,6 +58,7 @@ CONFIGS = [
     ("rough_plastic_boxes", "cornell_roughplastic.xml", dict(resx=24, resy=24, max_depth=5), 8),
     ("frosted_glass", "cornell_frosted.xml", dict(resx=24, resy=24, max_depth=6), 8),
     ("spot_light", "cornell_spot.xml", dict(resx=24, resy=24), 8),
+    ("disks", "cornell_disk.xml", dict(resx=24, resy=24, max_depth=5), 8),
     ("spheres", "cornell_spheres.xml", dict(resx=24, resy=24), 8),
     ("sphere_light", "cornell_sphere_light.xml", dict(resx=24, resy=24, max_depth=5), 8),
 ]

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scenes"))
 import make_scenes, make_mesh; make_scenes.ensure()
 random.seed(int(sys.argv[1])); N = int(sys.argv[2]); out = sys.argv[3]
 os.makedirs(out, exist_ok=True)
-names = ("cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_roughplastic.xml", "cornell_sphere_light.xml", "cornell_rough.xml", "cornell_plastic.xml", "cornell_spheres.xml", "cornell_frosted.xml", "cornell_spot.xml", "domino_small.xml")
+names = ("cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_roughplastic.xml", "cornell_sphere_light.xml", "cornell_rough.xml", "cornell_plastic.xml", "cornell_spheres.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml", "domino_small.xml")
 texts = [open(os.path.join(ROOT, "scenes", n)).read() for n in names]
 num = re.compile(r'-?\d+\.?\d*(?:e-?\d+)?')
 vals = ['0', '-0', '1e-30', '1e30', '1e39', 'nan', 'inf', '-1', '4294967296', '1e-45', '0.5', '-1e39', '2', '1', '1e-8', '1e8', '3', '7', '', 'x']

@@ -13,7 +13,7 @@ import mitsuba3dopplertof_amd as mi
 random.seed(int(sys.argv[1]))
 render = "--no-render" not in sys.argv
 names = ("cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_roughplastic.xml", "cornell_sphere_light.xml",
-         "cornell_rough.xml", "cornell_plastic.xml", "cornell_spheres.xml", "cornell_frosted.xml", "cornell_spot.xml", "domino_small.xml")
+         "cornell_rough.xml", "cornell_plastic.xml", "cornell_spheres.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml", "domino_small.xml")
 texts = [open(os.path.join(ROOT, "scenes", n)).read() for n in names]
 num = re.compile(r'-?\d+\.?\d*(?:e-?\d+)?')
 vals = ['0', '-0', '1e-30', '1e30', '1e39', 'nan', 'inf', '-1', '4294967296', '1e-45', '0.5', '-1e39', '2', '1', '1e-8', '1e8', '3', '7']
