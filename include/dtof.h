@@ -80,6 +80,11 @@ typedef struct {
     uint32_t path_correlation_depth, max_depth, rr_depth, base_seed;
     int32_t  time_correlate_number, path_correlate_number;
     uint32_t bvh_stack_depth;       /* entries a traversal stack can need: TLAS depth + deepest per-mesh BLAS */
+    /* reconstruction filter (ReconstructionFilter::radius(), include/mitsuba/render/rfilter.h) and the rows a splat can reach beyond
+     * the pixel of its sample: ceil(radius - 0.5) (ImageBlock::put, src/render/imageblock.cpp:423-426; 0 for the box filter, which
+     * splats at the lane's own pixel, integrator.cpp:540-541).  A row-band shard must carry `filter_halo` padding rows on each side. */
+    float    filter_radius;
+    int32_t  filter_halo;
 } dtof_scene_info;
 /* What Film::crop_size / Sampler::sample_count / the plugins' to_string() report (src/films/hdrfilm.cpp:235-279, src/render/sampler.cpp:13-14,
  * src/integrators/dopplertofpath.cpp:315-328), plus the sizes of the packed scene. */

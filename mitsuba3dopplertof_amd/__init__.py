@@ -51,7 +51,8 @@ class _Info(C.Structure):
                 ("wave_type", C.c_int32), ("low_frequency_component_only", C.c_int32), ("time_sampling", C.c_int32),
                 ("stratify_each_interval", C.c_int32), ("path_correlation_depth", C.c_uint32), ("max_depth", C.c_uint32),
                 ("rr_depth", C.c_uint32), ("base_seed", C.c_uint32), ("time_correlate_number", C.c_int32),
-                ("path_correlate_number", C.c_int32), ("bvh_stack_depth", C.c_uint32)]
+                ("path_correlate_number", C.c_int32), ("bvh_stack_depth", C.c_uint32),
+                ("filter_radius", C.c_float), ("filter_halo", C.c_int32)]
 
 
 def lib_path():

@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 #include <hip/hip_runtime.h>
+#include "dtof_math.h"
 
 namespace dtof {
 
@@ -43,6 +44,12 @@ struct RenderParams {
     // + v % stripe_rows, and the GLOBAL lane index (what every RNG stream is a function of) follows from it.  stripe_rows == 0:
     // virtual = global (contiguous rows).
     uint32_t stripe_rows, stripe_period, stripe_first, lanes_per_row;
+    // exact division by the launch-invariant divisors of the lane mappings (dtof_math.h: FastDiv)
+    FastDiv d_spp, d_w, d_tcn, d_pcn, d_stratum, d_lanes_per_row, d_stripe_rows;
+    // wavefronts of more than 2^32 - 1 lanes / samples_per_pass (integrator.cpp:121-124,227-245): pass `pass` of `n_passes`, each of
+    // `spp` samples per pixel (= samples per wavefront); the sampler's streams are seeded in pass 0 and carried across the passes
+    uint32_t pass, n_passes;
+    uint32_t memo_obj;                            // fused pipeline: the scene's only instance object (instance memo, dtof_traverse.h) or 0xffffffff
 };
 
 // SoA wavefront state for one batch (device pointers; all arrays have `capacity` entries and are
@@ -51,6 +58,7 @@ struct Queues {
     float4 *ray_a;       // o.xyz, time
     float4 *ray_b;       // d.xyz, maxt
     uint4  *hit;         // t, u, v (float bits), prim
+    float  *hit_t;       // rectangle-only scenes: t alone replaces `hit`
     uint32_t *hit_id;    // object (low 24 bits) | shape-in-group (high 8 bits); 0xffffffff = miss
     float4 *st_a;        // throughput.xyz, path_length
     float4 *st_b;        // prev_si.p, prev_bsdf_pdf (only touched when the scene has area emitters)

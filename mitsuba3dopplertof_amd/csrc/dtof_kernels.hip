@@ -53,6 +53,18 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) 
 // made the first version of this kernel 10x slower than its memory traffic).
 constexpr uint32_t kSeg = 512;
 constexpr int kShadeBlock = 64;   // k_shade runs ONE wave per block: compaction is ballot+popcount only, no barrier in the chunk loop
+// The closest-hit record between the trace and the shade of a bounce: (t, u, v, primitive) + the object / shape id.  Rectangle-only
+// instantiations (MESH = false) keep the distance alone: a rectangle's surface interaction is rebuilt from the ray and t
+// (rectangle.cpp:250-323 recomputes the local hit point), its primitive index is 0 -- 12 bytes less to write and to read per path vertex.
+template <bool MESH> DTOF_D void store_hit(const Queues &q, uint32_t l, const Hit &h, bool found) {
+    if (MESH) q.hit[l] = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
+    else q.hit_t[l] = h.t;
+    q.hit_id[l] = found ? (h.obj | (h.shape << 24)) : 0xffffffffu;
+}
+template <bool MESH> DTOF_D uint4 load_hit(const Queues &q, uint32_t l) {
+    if (MESH) return q.hit[l];
+    return make_uint4(f2u(q.hit_t[l]), 0u, 0u, 0u);
+}
 DTOF_D uint32_t seg_count(const uint32_t *counts, uint32_t seg, uint32_t n_lanes) {
     return counts ? counts[seg] : min(kSeg, n_lanes - seg * kSeg);
 }
@@ -77,8 +89,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 64 ? 6 : 1) void k_trace(const uint
     float4 a = q.ray_a[l], b = q.ray_b[l];
     Hit h;
     bool found = trace_scene<false, MESH>(sv, stack, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h);
-    q.hit[l] = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
-    q.hit_id[l] = found ? (h.obj | (h.shape << 24)) : 0xffffffffu;
+    store_hit<MESH>(q, l, h, found);
 }
 
 // ---------------------------------------------------------------------------- shade
@@ -116,22 +127,39 @@ DTOF_D uint32_t block_append(bool pred, uint32_t *s_cnt, uint32_t &running) {
 // primary k_trace launch exists (`dbg`, if given, receives the camera ray for the lane-dump entry point).
 // SPEC: the scene has delta BSDFs (conductor / dielectric): the relative index of refraction along the path and the
 // "previous lobe was a delta" flag travel in st_c; instantiated together with AREA and MESH only.
+// The arguments of k_shade travel as ONE by-value block and are read through the kernarg segment pointer, re-based once per chunk
+// on an offset the compiler cannot see through: the ~170 dwords of parameters (camera matrices, sampler and modulation constants, 17
+// queue pointers) are then fetched by scalar loads where they are used, instead of being loaded once ahead of the chunk loop and
+// kept alive across it -- which, in the first-bounce instantiation, spilled ~120 SGPRs to VGPR lanes (350 v_writelane / v_readlane).
+struct ShadeArgs {
+    const uint8_t *scene; uint32_t scene_bytes, stage_words; RenderParams rp; Queues q;
+    const uint32_t *qin, *count_in; uint32_t *qout, *alive_out, *shadow_out; uint32_t depth, trace_next; LaneDebug *dbg;
+};
 template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, bool SPEC>
-__global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp, Queues q,
-                                                  const uint32_t *qin, const uint32_t *count_in,
-                                                  uint32_t *qout, uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth,
-                                                  uint32_t trace_next, LaneDebug *dbg) {
+__global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) {
     constexpr bool FUSED = MODE != 0, FIRST = MODE == 2;
     extern __shared__ uint4 lds[];
     __shared__ uint32_t s_cnt[4];
-    uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
+    typedef const char __attribute__((address_space(4))) *KernargBytes;
+    const KernargBytes kernarg = (KernargBytes) __builtin_amdgcn_kernarg_segment_ptr();
+    const ShadeArgs &A0 = *(const ShadeArgs *) kernarg;
+    const uint32_t stage_words = A0.stage_words;
+    // dynamic LDS: [staged scene][fused: instance memo, kMemoWords x 64 words][traversal stack columns]
+    uint32_t *stack = (uint32_t *) (lds + stage_words) + (FUSED ? kMemoWords * kMemoStride : 0u) + threadIdx.x;
     const uint32_t seg = blockIdx.x;
-    const uint32_t count = seg_count(count_in, seg, rp.n_lanes);
+    const uint32_t count = seg_count(A0.count_in, seg, A0.rp.n_lanes);
     uint32_t n_alive = 0, n_shadow = 0;
     if (count != 0) {
-    const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
+    const uint8_t *base = LDS ? stage_scene(A0.scene, A0.scene_bytes, lds) : A0.scene;
     SceneView sv = make_view(base);
+    if (FUSED) { sv.memo_obj = A0.rp.memo_obj; sv.memo = (float *) (lds + stage_words) + threadIdx.x; }
+    const bool have_memo = FUSED && sv.memo_obj != 0xffffffffu;
     for (uint32_t cbase = 0; cbase < count; cbase += kShadeBlock) {
+    uint32_t rebase = 0;
+    asm volatile("" : "+s"(rebase));
+    const ShadeArgs &A = *(const ShadeArgs *) (kernarg + rebase);
+    const RenderParams &rp = A.rp; const Queues &q = A.q;
+    const uint32_t *const qin = A.qin; uint32_t *const qout = A.qout; const uint32_t depth = A.depth, trace_next = A.trace_next; LaneDebug *const dbg = A.dbg;
     uint32_t j = cbase + threadIdx.x;
     bool in_range = j < count;
     bool alive = false, want_shadow = false;
@@ -143,8 +171,11 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
     if (in_range) {
         l = qin ? qin[seg * kSeg + j] : seg * kSeg + j;
         uint32_t hid; float4 ra, rb, st; uint4 hh; Rng main, path;
+        float memo_m[12], memo_inv[12];   // instance memo: the one instance's matrix and inverse at this lane's ray time
         if (FIRST) {
-            const PrimaryLane pl = generate_lane(rp, global_lane(rp, rp.lane_base + l));
+            // the wave's 64 lanes are the 64-aligned lanes [lane_base + seg * 512 + cbase, + 64): samples of one pixel if spp is a multiple of 64
+            const bool wave_pixel = rp.spp_log2 != 0xffffffffu && rp.spp_log2 >= 6 && (rp.lane_base & 63u) == 0;
+            const PrimaryLane pl = generate_lane(rp, global_lane(rp, rp.lane_base + l), wave_pixel);
             ra = pl.ray_a; rb = pl.ray_b; main = pl.main; path = pl.path; st = make_float4(1.f, 1.f, 1.f, 0.f);
             q.pos[l] = pl.pos;
             q.rng_b[l] = make_uint2((uint32_t) (main.inc >> 1), (uint32_t) (path.inc >> 1));
@@ -152,14 +183,15 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
                 LaneDebug &o = dbg[l];
                 o.time = ra.w; o.ray_o[0] = ra.x; o.ray_o[1] = ra.y; o.ray_o[2] = ra.z; o.ray_d[0] = rb.x; o.ray_d[1] = rb.y; o.ray_d[2] = rb.z;
             }
+            if (have_memo) instance_memo_fill(sv, ra.w, memo_m, memo_inv);
             Hit h;
-            bool found = trace_scene<false, MESH>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
+            bool found = trace_scene<false, MESH, FUSED>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
             hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
             hid = found ? (h.obj | (h.shape << 24)) : 0xffffffffu;
         } else {
             hid = q.hit_id[l];
             if (hid != 0xffffffffu) {
-                ra = q.ray_a[l]; rb = q.ray_b[l]; hh = q.hit[l]; st = q.st_a[l];
+                ra = q.ray_a[l]; rb = q.ray_b[l]; hh = load_hit<MESH>(q, l); st = q.st_a[l];
                 const uint4 rs = q.rng_a[l]; const uint2 ri = q.rng_b[l];
                 main.state = (uint64_t) rs.x | ((uint64_t) rs.y << 32); main.inc = ((uint64_t) ri.x << 1) | 1u;
                 path.state = (uint64_t) rs.z | ((uint64_t) rs.w << 32); path.inc = ((uint64_t) ri.y << 1) | 1u;
@@ -178,7 +210,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
             bool active_next = depth + 1 < rp.max_depth;
 
             Surface si;
-            compute_surface<MESH>(sv, hid & 0xffffffu, hid >> 24, hh.w, t, u2f(hh.y), u2f(hh.z), o, d, time, si);
+            if (!FIRST && have_memo) instance_memo_fill(sv, time, memo_m, memo_inv);
+            compute_surface<MESH>(sv, hid & 0xffffffu, hid >> 24, hh.w, t, u2f(hh.y), u2f(hh.z), o, d, time, si, have_memo, memo_m, memo_inv);
             const DShape *sh = si.shape;
 
             const float pmf = sv.n_emitters ? 1.f / (float) sv.n_emitters : 0.f;   // m_emitter_pmf (scene.cpp:96)
@@ -508,7 +541,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
         bool commit = false;
         if (want_shadow) {   // test_visibility (scene.cpp:266-271): an unoccluded sample commits its candidate result
             Hit hs;
-            commit = !trace_scene<true, MESH>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
+            commit = !trace_scene<true, MESH, true>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
         }
         if (FIRST ? in_range : commit) {   // FIRST: every lane's result is defined here (nothing zeroed it beforehand)
 #pragma unroll
@@ -519,9 +552,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
         }
         if (alive && trace_next) {   // closest hit of the continuation ray, consumed by the next bounce
             Hit h;
-            bool found = trace_scene<false, MESH>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
-            q.hit[l] = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
-            q.hit_id[l] = found ? (h.obj | (h.shape << 24)) : 0xffffffffu;
+            bool found = trace_scene<false, MESH, true>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
+            store_hit<MESH>(q, l, h, found);
         }
         n_shadow += (uint32_t) __popcll(__ballot(want_shadow)) * ((threadIdx.x & 63) == 0 ? 1u : 0u);   // per-wave partial (stats only)
     } else {
@@ -541,7 +573,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const uint8_t *scene, uin
         __syncthreads();
         n_shadow = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     }
-    if (threadIdx.x == 0) { alive_out[seg] = n_alive; shadow_out[seg] = n_shadow; }
+    if (threadIdx.x == 0) { A0.alive_out[seg] = n_alive; A0.shadow_out[seg] = n_shadow; }
 }
 
 // ---------------------------------------------------------------------------- shadow
@@ -655,8 +687,8 @@ __global__ __launch_bounds__(kBlock) void k_splat_generic(RenderParams rp, Queue
     if (i >= rp.n_lanes) return;
     float2 p = q.pos[i];
     uint32_t lane = global_lane(rp, rp.lane_base + i);
-    uint32_t pix = rp.spp_log2 != 0xffffffffu ? lane >> rp.spp_log2 : lane / rp.spp, W = (uint32_t) rp.crop_w;
-    int py = (int) (pix / W), px = (int) (pix - W * (uint32_t) py);
+    uint32_t pix = fdiv(lane, rp.d_spp), W = (uint32_t) rp.crop_w;
+    int py = (int) fdiv(pix, rp.d_w), px = (int) (pix - W * (uint32_t) py);
     for (int k = 0; k < rp.n_offsets; ++k) {
         float4 r = q.res[(size_t) k * q.capacity + i];
         splat_lane(rp, film + (size_t) k * film_stride, p.x, p.y, px, py, r.x, r.y, r.z);
@@ -675,7 +707,7 @@ __global__ __launch_bounds__(kBlock) void k_splat_tent3(RenderParams rp, Queues 
     uint32_t lane = global_lane(rp, rp.lane_base + (in_range ? i : 0));
     uint32_t pix = lane >> rp.spp_log2;
     uint32_t W = (uint32_t) rp.crop_w;
-    int py = (int) (pix / W), px = (int) (pix - W * (uint32_t) py);
+    int py = (int) fdiv(pix, rp.d_w), px = (int) (pix - W * (uint32_t) py);
     float2 p = in_range ? q.pos[i] : make_float2(0.f, 0.f);
     int fx = (int) floorf(p.x) - rp.crop_x, fy = (int) floorf(p.y) - rp.crop_y;
     bool regular = in_range && fx == px && fy == py;
@@ -729,7 +761,7 @@ __global__ __launch_bounds__(kBlock) void k_splat_tent3(RenderParams rp, Queues 
             uint32_t first_lane = blockIdx.x * kBlock + sidx * seg;
             if (first_lane >= rp.n_lanes) continue;
             uint32_t spix = global_lane(rp, rp.lane_base + first_lane) >> rp.spp_log2;
-            int sy = (int) (spix / W), sx = (int) (spix - W * (uint32_t) sy);
+            int sy = (int) fdiv(spix, rp.d_w), sx = (int) (spix - W * (uint32_t) sy);
             int x = sx - 1 + (int) ((c % 12) >> 2), y = sy - 1 + (int) (c / 12);
             float v = s_acc[idx];
             if ((unsigned) x < W && (unsigned) y < (unsigned) rp.crop_h && v != 0.f)
@@ -830,13 +862,13 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
                   uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, bool fused, bool trace_next,
                   uint32_t stack_depth, hipStream_t s, bool first, LaneDebug *dbg) {
     if (rp.n_lanes == 0) return;
-    const uint32_t shade_stack = fused ? stack_bytes(stack_depth, kShadeBlock) : 0;
+    const uint32_t shade_stack = fused ? stack_bytes(stack_depth, kShadeBlock) + kMemoWords * kMemoStride * 4 : 0;   // + the instance memo
     uint32_t sw = stage_words_for(scene_bytes, shade_stack), grid = nseg(rp.n_lanes), lds = sw * 16 + shade_stack;
     check_lds(lds);
     uint32_t tn = trace_next ? 1u : 0u;
 #define DTOF_LAUNCH_SHADE(L, F, A, K) do { if (rp.has_tris) DTOF_LAUNCH_SHADE_M(L, F, A, K, true, false); else DTOF_LAUNCH_SHADE_M(L, F, A, K, false, false); } while (0)
-#define DTOF_LAUNCH_SHADE_M(L, F, A, K, M, S) hipLaunchKernelGGL((k_shade<L, F, A, K, M, S>), dim3(grid), dim3(kShadeBlock), lds, s, scene, scene_bytes, sw, rp, q, qin, \
-                                                         count_in, qout, alive_out, shadow_out, depth, tn, dbg)
+    const ShadeArgs sa = { scene, scene_bytes, sw, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, tn, dbg };
+#define DTOF_LAUNCH_SHADE_M(L, F, A, K, M, S) hipLaunchKernelGGL((k_shade<L, F, A, K, M, S>), dim3(grid), dim3(kShadeBlock), lds, s, sa)
 #define DTOF_SHADE_AK(L, F) do { if (rp.has_spec) { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE_M(L, F, true, 1, true, true); else DTOF_LAUNCH_SHADE_M(L, F, true, kMaxOffsets, true, true); } \
                                  else if (rp.has_area) { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE(L, F, true, 1); else DTOF_LAUNCH_SHADE(L, F, true, kMaxOffsets); } \
                                  else { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE(L, F, false, 1); else DTOF_LAUNCH_SHADE(L, F, false, kMaxOffsets); } } while (0)
@@ -895,11 +927,11 @@ void launch_lane_dump_rays(const RenderParams &rp, const Queues &q, LaneDebug *o
 __global__ void k_sampler_seed(RenderParams rp, SamplerState st) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= st.n) return;
-    Rng a = seed_stream(rp.seed_value, i), b = seed_stream(rp.seed_value + 1, i / rp.tcn), c = seed_stream(rp.seed_value + 2, i / rp.pcn);
+    Rng a = seed_stream(rp.seed_value, i), b = seed_stream(rp.seed_value + 1, fdiv(i, rp.d_tcn)), c = seed_stream(rp.seed_value + 2, fdiv(i, rp.d_pcn));
     st.rng[i] = make_uint2((uint32_t) a.state, (uint32_t) (a.state >> 32));
     st.rng_time[i] = make_uint2((uint32_t) b.state, (uint32_t) (b.state >> 32));
     st.rng_path[i] = make_uint2((uint32_t) c.state, (uint32_t) (c.state >> 32));
-    uint32_t ps, tmp; tea32(rp.base_seed, rp.spp * (i / rp.spp) + rp.seed, ps, tmp);   // compute_per_sequence_seed, sampler.cpp:85-92
+    uint32_t ps, tmp; tea32(rp.base_seed, rp.spp * fdiv(i, rp.d_spp) + rp.seed, ps, tmp);   // compute_per_sequence_seed, sampler.cpp:85-92
     st.perm_seed[i] = ps; st.dim[i] = 0;
 }
 DTOF_D Rng load_rng(const uint2 *arr, uint32_t i, uint64_t inc) { Rng r; uint2 v = arr[i]; r.state = (uint64_t) v.x | ((uint64_t) v.y << 32); r.inc = inc; return r; }
@@ -908,7 +940,7 @@ DTOF_D void store_rng(uint2 *arr, uint32_t i, const Rng &r) { arr[i] = make_uint
 __global__ void k_sampler_next_correlate(RenderParams rp, SamplerState st, const uint8_t *correlate, int correlate_all, float *out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= st.n) return;
-    Rng m = load_rng(st.rng, i, stream_inc(rp.seed_value, i)), p = load_rng(st.rng_path, i, stream_inc(rp.seed_value + 2, i / rp.pcn));
+    Rng m = load_rng(st.rng, i, stream_inc(rp.seed_value, i)), p = load_rng(st.rng_path, i, stream_inc(rp.seed_value + 2, fdiv(i, rp.d_pcn)));
     out[i] = next_correlate(m, p, correlate ? correlate[i] != 0 : correlate_all != 0);
     store_rng(st.rng, i, m); store_rng(st.rng_path, i, p);
 }
@@ -922,8 +954,8 @@ __global__ void k_sampler_next_1d(RenderParams rp, SamplerState st, float *out) 
 __global__ void k_sampler_next_time(RenderParams rp, SamplerState st, uint32_t sample_index_base, float *out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= st.n) return;
-    Rng m = load_rng(st.rng, i, stream_inc(rp.seed_value, i)), t = load_rng(st.rng_time, i, stream_inc(rp.seed_value + 1, i / rp.tcn));
-    uint32_t si = sample_index_base + (rp.spp > 1 ? i % rp.spp : 0), dim = st.dim[i];
+    Rng m = load_rng(st.rng, i, stream_inc(rp.seed_value, i)), t = load_rng(st.rng_time, i, stream_inc(rp.seed_value + 1, fdiv(i, rp.d_tcn)));
+    uint32_t si = sample_index_base + (rp.spp > 1 ? i - rp.spp * fdiv(i, rp.d_spp) : 0), dim = st.dim[i];
     out[i] = next_time(rp, m, t, si, st.perm_seed[i], dim);
     st.dim[i] = dim;
     store_rng(st.rng, i, m); store_rng(st.rng_time, i, t);

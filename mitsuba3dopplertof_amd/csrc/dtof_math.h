@@ -212,6 +212,43 @@ DTOF_HD V3 ggx_sample(Ggx g, V3 wi, float s_x, float s_y, float &pdf) {
     return m;
 }
 
+// ---------------------------------------------------------------- integer helpers
+// Division of a 32-bit unsigned by a launch-invariant divisor (Granlund-Montgomery / "round-up" form): the hardware has no integer
+// divide and the generic expansion costs ~17 VALU instructions per quotient; this is one v_mul_hi_u32 + 4 simple ops and exact for every
+// n < 2^32, d >= 1.  The lane -> pixel / pair / stratum mappings of integrator.cpp:273-285 and correlated.cpp:47-64,112-124 are
+// all of this form (the reference leaves them to Dr.Jit's own division-by-opaque-constant code).
+struct FastDiv { uint32_t mul, shifts; };   // shifts = sh1 | sh2 << 8
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f; f.mul = 1; f.shifts = 0;
+    if (d <= 1) return f;                    // d == 1: q = mulhi(n, 1) = 0, t = n  (d == 0 never divides: callers guard)
+    uint32_t L = 0; while ((1ull << L) < d) ++L;      // ceil(log2 d)
+    f.mul = (uint32_t) ((((1ull << L) - d) << 32) / d + 1);
+    f.shifts = 1u | ((L - 1) << 8);
+    return f;
+}
+DTOF_HD uint32_t fdiv(uint32_t n, FastDiv d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t q = __umulhi(n, d.mul);
+#else
+    const uint32_t q = (uint32_t) (((uint64_t) n * d.mul) >> 32);
+#endif
+    return (((n - q) >> (d.shifts & 0xffu)) + q) >> (d.shifts >> 8);
+}
+
+// fmodf(x, y) for y > 0, exact like the C library's (the result of fmod is always representable): for |x| < 2^22 y the quotient
+// estimate trunc(|x| * (1 / y)) is off by at most one, the remainder fma(-q, y, |x|) of an off-by-one quotient has the sign / size that
+// tells which way, and the remainder of the right quotient is exact.  Everything else (huge, NaN, inf) takes the library path.
+// ocml's generic fmodf is ~70 VALU instructions; eval_modulation_weight calls it once or twice per path vertex
+// (waveform_utils.h:24-62 via dopplertofpath.cpp:60-77).
+DTOF_HD float fmod_pos(float x, float y, float inv_y) {
+    const float ax = fabsf(x);
+    if (!(ax < 4194304.f * y)) return fmodf(x, y);
+    float q = truncf(ax * inv_y), r = fmaf(-q, y, ax);
+    if (r < 0.f) { q -= 1.f; r = fmaf(-q, y, ax); }
+    else if (r >= y) { q += 1.f; r = fmaf(-q, y, ax); }
+    return u2f(f2u(r) | (f2u(x) & 0x80000000u));
+}
+
 // ---------------------------------------------------------------- RNG (integer exact)
 // sample_tea_32 -- include/mitsuba/core/random.h:33-47
 DTOF_HD void tea32(uint32_t v0, uint32_t v1, uint32_t &o0, uint32_t &o1) {
@@ -235,6 +272,11 @@ DTOF_HD uint32_t pcg_next_u32(uint64_t &state, uint64_t inc) {
 DTOF_HD float pcg_next_f32(uint64_t &state, uint64_t inc) {
     return u2f((pcg_next_u32(state, inc) >> 9) | 0x3f800000u) - 1.f;
 }
+// the float draw that belongs to the state `old` the generator was in before its step
+DTOF_HD float pcg_output_f32(uint64_t old) {
+    uint32_t xs = (uint32_t) (((old >> 18) ^ old) >> 27), rot = (uint32_t) (old >> 59);
+    return u2f((((xs >> rot) | (xs << ((~rot + 1u) & 31))) >> 9) | 0x3f800000u) - 1.f;
+}
 // PCG32::seed(1, initstate, initseq)
 DTOF_HD void pcg_seed(uint32_t initstate, uint32_t initseq, uint64_t &state, uint64_t &inc) {
     state = 0; inc = ((uint64_t) initseq << 1) | 1u;
@@ -243,7 +285,7 @@ DTOF_HD void pcg_seed(uint32_t initstate, uint32_t initseq, uint64_t &state, uin
     pcg_next_u32(state, inc);
 }
 // permute_kensler -- random.h:113-171
-DTOF_HD uint32_t permute_kensler(uint32_t index, uint32_t n, uint32_t seed) {
+DTOF_HD uint32_t permute_kensler(uint32_t index, uint32_t n, uint32_t seed, FastDiv dn) {   // dn = make_fastdiv(n)
     if (n <= 1) return 0;   // n == 0 (sample_count < time_correlate_number) would never leave the cycle-walking loop below
     uint32_t w = n - 1;
     w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
@@ -260,7 +302,8 @@ DTOF_HD uint32_t permute_kensler(uint32_t index, uint32_t n, uint32_t seed) {
         tmp &= w;               tmp ^= tmp >> 5;
         index = tmp;
     } while (index >= n);
-    return (index + seed) % n;
+    const uint32_t v = index + seed;
+    return v - n * fdiv(v, dn);
 }
 
 }  // namespace dtof

@@ -59,6 +59,7 @@ struct Workspace {
     DevBuf<float4> ray_a, ray_b, st_a, st_b, res, sh_a, sh_b, sh_c;
     DevBuf<uint4> hit, rng_a;
     DevBuf<uint32_t> hit_id, q0, q1, counts;
+    DevBuf<float> hit_t;
     DevBuf<float2> pos, st_c;
     DevBuf<uint2> rng_b;
     DevBuf<LaneDebug> dbg;
@@ -68,12 +69,12 @@ struct Workspace {
         capacity = std::max(cap, capacity); k = std::max(n_offsets, k);
         ray_a.ensure(capacity); ray_b.ensure(capacity); st_a.ensure(capacity); st_b.ensure(capacity);
         res.ensure((size_t) capacity * k); sh_a.ensure(capacity); sh_b.ensure(capacity); sh_c.ensure((size_t) capacity * k);
-        hit.ensure(capacity); rng_a.ensure(capacity); hit_id.ensure(capacity); q0.ensure(capacity); q1.ensure(capacity);
+        hit.ensure(capacity); hit_t.ensure(capacity); rng_a.ensure(capacity); hit_id.ensure(capacity); q0.ensure(capacity); q1.ensure(capacity);
         counts.ensure(2 * (size_t) kMaxIter * segments_for(capacity)); pos.ensure(capacity); rng_b.ensure(capacity); st_c.ensure(capacity);
     }
     Queues queues() {
         Queues q; memset(&q, 0, sizeof q);
-        q.ray_a = ray_a.p; q.ray_b = ray_b.p; q.hit = hit.p; q.hit_id = hit_id.p; q.st_a = st_a.p; q.st_b = st_b.p; q.rng_a = rng_a.p; q.rng_b = rng_b.p; q.st_c = st_c.p;
+        q.ray_a = ray_a.p; q.ray_b = ray_b.p; q.hit = hit.p; q.hit_t = hit_t.p; q.hit_id = hit_id.p; q.st_a = st_a.p; q.st_b = st_b.p; q.rng_a = rng_a.p; q.rng_b = rng_b.p; q.st_c = st_c.p;
         q.res = res.p; q.pos = pos.p; q.sh_a = sh_a.p; q.sh_b = sh_b.p; q.sh_c = sh_c.p; q.q[0] = q0.p; q.q[1] = q1.p;
         q.counts = counts.p; q.capacity = capacity;
         return q;
@@ -190,6 +191,12 @@ RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, cons
     rp.n_stratum = spp / rp.tcn;                                   // int n_stratum = m_sample_count / tcn (correlated.cpp:112)
     rp.inv_n_stratum = rp.n_stratum ? 1.0f / (float) (int) rp.n_stratum : 0.f;
     rp.inv_tcn = 1.0f / (float) pp.time_correlate_number;
+    rp.d_spp = make_fastdiv(spp); rp.d_w = make_fastdiv((uint32_t) se.crop_w); rp.d_tcn = make_fastdiv(rp.tcn); rp.d_pcn = make_fastdiv(rp.pcn);
+    rp.d_stratum = make_fastdiv(rp.n_stratum);
+    for (uint32_t d : { spp, (uint32_t) se.crop_w, rp.tcn, rp.pcn, rp.n_stratum })   // the kernels have no other division: fail loudly
+        for (uint32_t n : { 0u, 1u, d - 1, d, d + 1, 2 * d - 1, 0x7fffffffu, 0xfffffffeu, 0xffffffffu })
+            if (d && fdiv(n, make_fastdiv(d)) != n / d) throw std::runtime_error("internal error: fast division self-check failed");
+    rp.n_passes = 1;
     // eval_modulation_weight's scalar prefactors are folded in double and rounded to float32 once
     // (they multiply JIT float32 arrays), dopplertofpath.cpp:62-69
     rp.T = pp.time;
@@ -275,6 +282,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         const uint64_t span = (uint64_t) std::max(row_end - row_begin, 0), full = span / stripe_period, rest = span % stripe_period;
         const uint64_t v_rows = full * stripe_rows + std::min<uint64_t>(rest, stripe_rows);
         rp.stripe_rows = stripe_rows; rp.stripe_period = stripe_period; rp.stripe_first = (uint32_t) row_begin; rp.lanes_per_row = (uint32_t) lanes_per_row;
+        rp.d_lanes_per_row = make_fastdiv(rp.lanes_per_row); rp.d_stripe_rows = make_fastdiv(stripe_rows);
         first = 0; last = v_rows * lanes_per_row;
     }
     uint64_t batch = lane_dump ? std::min<uint64_t>(target_batch_lanes(), std::max<uint64_t>(dump_n, 1))
@@ -317,6 +325,14 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         const DShape *dshapes = (const DShape *) (sc->blob.data() + bh->off_shapes);
         for (uint32_t i = 0; i < bh->n_shapes; ++i) rp.has_blas |= dshapes[i].kind == SHAPE_MESH && dshapes[i].blas_root != kNoChild;
     }
+    rp.memo_obj = 0xffffffffu;
+    {   // instance memo (dtof_traverse.h): pays when there is exactly one instance object, which then nearly every ray visits
+        const DObject *dobj = (const DObject *) (sc->blob.data() + bh->off_objects);
+        uint32_t n_inst = 0, last_inst = 0;
+        for (uint32_t i = 0; i < bh->n_objects; ++i) if (dobj[i].kind == OBJ_INSTANCE) { ++n_inst; last_inst = i; }
+        static const bool env_memo = [] { const char *e = getenv("DTOF_INSTANCE_MEMO"); return !(e && e[0] == '0'); }();
+        if (fused && n_inst == 1 && env_memo) rp.memo_obj = last_inst;
+    }
     StageTimer tm(stats != nullptr, sc);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     struct EventGuard { hipEvent_t e = nullptr; ~EventGuard() { if (e) (void) hipEventDestroy(e); } } g_fork, g_join;   // released on every exit path
@@ -325,9 +341,16 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     if (stats) { memset(stats, 0, sizeof *stats); ev0 = sc->take_event(); ev1 = sc->take_event(); HIP_CHECK(hipEventRecord(ev0, ss[0])); }
     if (n_streams == 2) { HIP_CHECK(hipEventRecord(ev_fork, ss[0])); HIP_CHECK(hipStreamWaitEvent(ss[1], ev_fork, 0)); }
     std::vector<uint64_t> h_counts; std::vector<uint32_t> batch_lanes, batch_iters;
+    // per-iteration totals of every batch: sized ONCE (DevBuf::ensure reallocates without copying, and a hipFree in the middle of the
+    // frame would also synchronise the device)
+    if (stats && last > first) sc->d_sums.ensure((size_t) ((last - first + batch - 1) / batch) * 2 * kMaxIter);
 
+    // The host runs at most two batches ahead of the device: dtof_cancel (Integrator::cancel, integrator.h:96-109) is looked at when a
+    // batch is enqueued, so an unbounded run-ahead would leave nothing to cancel once the launches of a long render are queued.
+    hipEvent_t batch_done[2] = { sc->take_event(), sc->take_event() };
     uint32_t batch_index = 0;
     for (uint64_t b0 = first; b0 < last; b0 += batch, ++batch_index) {
+        if (batch_index >= 2) HIP_CHECK(hipEventSynchronize(batch_done[batch_index & 1]));
         if (sc->stop.load()) break;
         const Queues &q = qs[batch_index & 1]; hipStream_t s = ss[batch_index & 1];
         rp.lane_base = (uint32_t) b0; rp.n_lanes = (uint32_t) std::min<uint64_t>(batch, last - b0);
@@ -378,8 +401,9 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         } else {
             t = tm.begin(4, s); launch_splat(rp, q, d_film, se.crop_w, se.crop_h, s); tm.end(4, t, s);
         }
+        HIP_CHECK(hipGetLastError());   // a rejected launch (LDS size, launch bounds, grid) must not pass for an empty film
+        HIP_CHECK(hipEventRecord(batch_done[batch_index & 1], s));
         if (stats) {   // per-iteration totals of this batch are reduced on the device; one small copy after the last batch
-            sc->d_sums.ensure((size_t) (batch_index + 1) * 2 * kMaxIter);
             const uint32_t it_counted = std::min<uint32_t>(it, kMaxIter);
             if (it_counted) launch_sum_counts(q.counts, n_seg, 2 * it_counted, sc->d_sums.p + (size_t) batch_index * 2 * kMaxIter, s);
             batch_lanes.push_back(rp.n_lanes); batch_iters.push_back(it_counted);
@@ -537,6 +561,8 @@ int dtof_scene_get_info(const dtof_scene *sc, dtof_scene_info *info) {
         info->path_correlation_depth = p.path_correlation_depth; info->max_depth = p.max_depth; info->rr_depth = p.rr_depth;
         info->base_seed = p.base_seed; info->time_correlate_number = p.time_correlate_number; info->path_correlate_number = p.path_correlate_number;
         info->bvh_stack_depth = h->tlas_depth;
+        info->filter_radius = se.filter_radius;
+        info->filter_halo = se.filter == FILTER_BOX ? 0 : (int32_t) std::ceil(se.filter_radius - .5f);
     });
 }
 
@@ -650,6 +676,8 @@ static RenderParams sampler_params(const dtof_sampler *s) {
     rp.n_stratum = s->sample_count / (uint32_t) s->tcn;
     rp.inv_n_stratum = rp.n_stratum ? 1.0f / (float) (int) rp.n_stratum : 0.f;
     rp.inv_tcn = 1.0f / (float) s->tcn;
+    rp.d_spp = make_fastdiv(rp.spp); rp.d_tcn = make_fastdiv(rp.tcn); rp.d_pcn = make_fastdiv(rp.pcn); rp.d_stratum = make_fastdiv(rp.n_stratum);
+    rp.d_w = make_fastdiv(1); rp.n_passes = 1;
     return rp;
 }
 static SamplerState sampler_state(dtof_sampler *s) {

@@ -24,50 +24,54 @@ DTOF_D uint64_t stream_inc(uint32_t seed_value, uint32_t index) {
     uint32_t v0, v1; tea32(seed_value, index, v0, v1);
     return ((uint64_t) v1 << 1) | 1u;
 }
-// next_1d_correlate -- correlated.cpp:156-161
+// next_1d_correlate -- correlated.cpp:156-161: both streams advance, the draw of one of them is returned.  The output permutation
+// of PCG (xorshift, rotation, float conversion) is evaluated once, on the state of the selected stream.
 DTOF_D float next_correlate(Rng &main, Rng &path, bool correlate) {
-    float r1 = next_f32(path), r2 = next_f32(main);
-    return correlate ? r1 : r2;
+    uint64_t old = correlate ? path.state : main.state;
+    path.state = path.state * kPcgMult + path.inc;
+    main.state = main.state * kPcgMult + main.inc;
+    return pcg_output_f32(old);
 }
 // next_1d_time -- correlated.cpp:92-153; si = current_sample_index (sampler.cpp:94-103)
 DTOF_D float next_time(const RenderParams &rp, Rng &main, Rng &tm, uint32_t si, uint32_t perm_seed, uint32_t &dim) {
     int strategy = rp.time_sampling; uint32_t tcn = rp.tcn;
     if (strategy == TIME_UNIFORM) return next_f32(main);
     float r = strategy == TIME_STRATIFIED ? next_f32(main) : next_f32(tm);
+    const uint32_t quo = fdiv(si, rp.d_tcn), rem = si - quo * tcn;   // si / tcn, si % tcn
     if (rp.stratify) {
         if (strategy == TIME_STRATIFIED) {
             // the reference evaluates p1 (seed + dim) and p2 (seed + dim + 1) and selects; the permutation is a pure function,
             // so only the selected one is computed
-            const uint32_t ps = perm_seed + dim + ((si % tcn != 0) ? 0u : 1u);
+            const uint32_t ps = perm_seed + dim + ((rem != 0) ? 0u : 1u);
             dim += 2;
-            const uint32_t p = permute_kensler(si / tcn, rp.n_stratum, ps);
+            const uint32_t p = permute_kensler(quo, rp.n_stratum, ps, rp.d_stratum);
             r = ((float) p + r) * rp.inv_n_stratum;
         } else {
-            r = ((float) (si / tcn) + r) * rp.inv_n_stratum;
+            r = ((float) quo + r) * rp.inv_n_stratum;
         }
     }
-    if (strategy == TIME_STRATIFIED) return ((float) (si % tcn) + r) * rp.inv_tcn;
+    if (strategy == TIME_STRATIFIED) return ((float) rem + r) * rp.inv_tcn;
     if (strategy == TIME_ANTITHETIC) {
-        uint32_t rem = si % tcn;
         if (tcn == 2) { float r2 = r + rp.antithetic_shift; return rem != 1 ? r : r2; }
         return r + (float) rem / (float) tcn;
     }
     // TIME_ANTITHETIC_MIRROR
     float r2 = 1.0f - r + rp.antithetic_shift;
-    return (si % tcn) != 1 ? r : r2;
+    return rem != 1 ? r : r2;
 }
 
 // ---------------------------------------------------------------------------- modulation
+constexpr float kInvTwoPiF = 0.15915494309189533577f;   // quotient estimate of the exact fmod (dtof_math.h: fmod_pos)
 // waveform_utils.h:24-33
 DTOF_D float waveform(float _t, int type) {
-    float t = fmodf(_t, 2.f * kPi);
+    float t = fmod_pos(_t, 2.f * kPi, kInvTwoPiF);
     if (type == WAVE_RECT) return fabsf(t - kPi) > 0.5f * kPi ? 1.f : -1.f;
     if (type == WAVE_TRI) return t < kPi ? 1.f - 2.f * t * (1.0f / kPi) : -3.f + 2.f * t * (1.0f / kPi);
     return cos_(t);
 }
 // waveform_utils.h:36-62
 DTOF_D float waveform_low_pass(float _t, int type) {
-    float t = fmodf(_t, 2.f * kPi);
+    float t = fmod_pos(_t, 2.f * kPi, kInvTwoPiF);
     if (type == WAVE_SIN) return cos_(t);
     float a = t * (1.0f / kPi), b = 2.f - a, c = a < b ? a : b;
     if (type == WAVE_RECT) return 2.f - 4.f * c;
@@ -95,25 +99,37 @@ struct PrimaryLane { float4 ray_a, ray_b; Rng main, path; float2 pos; };
 // global lane index (pixel-major, the index every stream of the sampler is seeded with) of a lane of this launch
 DTOF_D uint32_t global_lane(const RenderParams &rp, uint32_t virtual_lane) {
     if (rp.stripe_rows == 0) return virtual_lane;
-    const uint32_t v = virtual_lane / rp.lanes_per_row, in_row = virtual_lane - v * rp.lanes_per_row;
-    const uint32_t s = v / rp.stripe_rows, y = rp.stripe_first + s * rp.stripe_period + (v - s * rp.stripe_rows);
+    const uint32_t v = fdiv(virtual_lane, rp.d_lanes_per_row), in_row = virtual_lane - v * rp.lanes_per_row;
+    const uint32_t s = fdiv(v, rp.d_stripe_rows), y = rp.stripe_first + s * rp.stripe_period + (v - s * rp.stripe_rows);
     return y * rp.lanes_per_row + in_row;
 }
-DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane) {
+// Per-pixel part of a lane: the permutation seed of its sample sequence (compute_per_sequence_seed, sampler.cpp:85-92) and the
+// pixel position (integrator.cpp:278-285).  UNIFORM: the 64 lanes of the wave hold samples of ONE pixel -- the TEA evaluation and the
+// coordinates are then computed once per wave on the scalar unit instead of 64 times on the vector unit (same integers).
+struct PixelInfo { uint32_t perm_seed; float posx, posy; };
+template <bool UNIFORM>
+DTOF_D PixelInfo pixel_info(const RenderParams &rp, uint32_t pix) {
+    if (UNIFORM) pix = __builtin_amdgcn_readfirstlane(pix);
+    PixelInfo pi; uint32_t tmp;
+    tea32(rp.base_seed, rp.spp * pix + rp.seed, pi.perm_seed, tmp);
+    const uint32_t W = (uint32_t) rp.crop_w, py = fdiv(pix, rp.d_w), px = pix - W * py;
+    pi.posx = (float) (px + (uint32_t) rp.crop_x); pi.posy = (float) (py + (uint32_t) rp.crop_y);
+    return pi;
+}
+// wave_pixel (uniform): see pixel_info; true only if spp is a multiple of 64 and the wave's lanes are 64 consecutive, 64-aligned lanes
+DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane, bool wave_pixel = false) {
     Rng main = seed_stream(rp.seed_value, lane);
     // m_rng_time is only drawn from by the antithetic strategies of the correlated sampler (correlated.cpp:96-106)
     const bool needs_tm = rp.integrator == 0 && rp.sampler_kind == SAMPLER_CORRELATED && (rp.time_sampling == TIME_ANTITHETIC || rp.time_sampling == TIME_ANTITHETIC_MIRROR);
     Rng tm; tm.state = 0; tm.inc = 1;
-    if (needs_tm) tm = seed_stream(rp.seed_value + 1, lane / rp.tcn);
-    Rng path = seed_stream(rp.seed_value + 2, lane / rp.pcn);
-    uint32_t pix = rp.spp_log2 != 0xffffffffu ? lane >> rp.spp_log2 : lane / rp.spp;
+    if (needs_tm) tm = seed_stream(rp.seed_value + 1, fdiv(lane, rp.d_tcn));
+    Rng path = seed_stream(rp.seed_value + 2, fdiv(lane, rp.d_pcn));
+    const uint32_t pix = fdiv(lane, rp.d_spp);
     uint32_t si = rp.spp > 1 ? lane - pix * rp.spp : 0;
-    uint32_t perm_seed, tmp; tea32(rp.base_seed, rp.spp * pix + rp.seed, perm_seed, tmp);
+    const PixelInfo pi = wave_pixel ? pixel_info<true>(rp, pix) : pixel_info<false>(rp, pix);
+    const uint32_t perm_seed = pi.perm_seed; const float posx = pi.posx, posy = pi.posy;
     uint32_t dim = 0;
 
-    uint32_t W = (uint32_t) rp.crop_w;
-    uint32_t py = pix / W, px = pix - W * py;
-    float posx = (float) (px + (uint32_t) rp.crop_x), posy = (float) (py + (uint32_t) rp.crop_y);
     bool cp = rp.path_correlation_depth > 0;
     const bool doppler = rp.integrator == 0;
     // one stream only: the plain branch of render_sample (integrator.cpp:416-431: next_2d / next_1d), and every sampler but
@@ -128,7 +144,7 @@ DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane) {
         if (!doppler || rp.sampler_kind == SAMPLER_INDEPENDENT) u = next_f32(main);   // Sampler::next_1d_time -> next_1d (sampler.h:131-132)
         else if (rp.sampler_kind == SAMPLER_CORRELATED) u = next_time(rp, main, tm, si, perm_seed, dim);
         else {   // TimeStratifiedSampler::next_1d_time (timestratified.cpp:117-129): the strategy arguments are ignored
-            uint32_t p = permute_kensler(si, rp.spp, perm_seed + dim++);
+            uint32_t p = permute_kensler(si, rp.spp, perm_seed + dim++, rp.d_spp);
             float j = rp.jitter ? next_f32(main) : .5f;
             u = ((float) p + j) * rp.inv_spp;
         }

@@ -13,17 +13,23 @@ struct Surface { V3 p, n, sh_n, sh_s, sh_t, wi; const DShape *shape; };
 
 // Shape::compute_surface_interaction for rectangle (rectangle.cpp:250-323) / mesh (mesh.cpp:632-864),
 // Instance::compute_surface_interaction (instance.cpp:155-250), finalize (interaction.h:493-513)
+// memo_m / memo_inv: the instance matrix and its inverse of object sv.memo_obj at this ray time, if the caller has them (instance memo)
 template <bool MESH>
 DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, uint32_t prim, float t, float b1, float b2,
-                            V3 o, V3 d, float time, Surface &si) {
+                            V3 o, V3 d, float time, Surface &si, bool use_memo, const float (&memo_m)[12], const float (&memo_inv)[12]) {
     const DObject &ob = sv.objects[oi];
     bool inst = ob.kind == OBJ_INSTANCE;
     float m[12], inv[12];
     V3 lo = o, ld = d;
     const DShape *sh;
     if (inst) {
-        instance_matrix(ob, time, m);
-        affine_inverse(m, inv);
+        if (use_memo && oi == sv.memo_obj) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { m[i] = memo_m[i]; inv[i] = memo_inv[i]; }
+        } else {
+            instance_matrix(ob, time, m);
+            affine_inverse(m, inv);
+        }
         lo = xf_point(inv, o); ld = xf_vector(inv, d);
         sh = &sv.shapes[sv.groups[ob.index].first_shape + shape_k];
     } else sh = &sv.shapes[ob.index];
@@ -93,6 +99,12 @@ DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, 
     si.sh_s = s; si.sh_t = cross(si.sh_n, s);
     V3 md = -d;
     si.wi = mk(dot(md, si.sh_s), dot(md, si.sh_t), dot(md, si.sh_n));
+}
+template <bool MESH>
+DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, uint32_t prim, float t, float b1, float b2,
+                            V3 o, V3 d, float time, Surface &si) {
+    const float none[12] = { 0 };
+    compute_surface<MESH>(sv, oi, shape_k, prim, t, b1, b2, o, d, time, si, false, none, none);
 }
 // Interaction::offset_p (interaction.h:161-165)
 DTOF_D V3 offset_p(const Surface &si, V3 d) {

@@ -16,6 +16,11 @@ struct SceneView {
     const BvhNode *nodes; const DObject *objects; const DGroup *groups; const DShape *shapes;
     const DTri *tris; const DTriShade *shading; const DEmitter *emitters; const uint8_t *base;
     uint32_t n_nodes, n_emitters;
+    // Fused shade kernels, scenes with ONE instance object: the world -> object matrix of that instance at the lane's ray time is
+    // computed once per path vertex (instance_memo_fill) and kept in a per-thread LDS column; the closest-hit and occlusion queries of
+    // the vertex and its surface interaction read it back instead of re-deriving it (a ray's time does not change along a path,
+    // dopplertofpath.cpp:93,240-244).  memo_obj = 0xffffffff: no memo.
+    uint32_t memo_obj; float *memo;
 };
 DTOF_D SceneView make_view(const uint8_t *base) {
     const BlobHeader *h = (const BlobHeader *) base;
@@ -29,6 +34,7 @@ DTOF_D SceneView make_view(const uint8_t *base) {
     v.emitters = (const DEmitter *) (base + h->off_emitters);
     v.base = base;
     v.n_nodes = h->n_nodes; v.n_emitters = h->n_emitters;
+    v.memo_obj = 0xffffffffu; v.memo = nullptr;
     return v;
 }
 // Stage the whole scene blob into LDS (small scenes: the Cornell blob is ~5 KB).
@@ -129,6 +135,19 @@ DTOF_D void instance_matrix(const DObject &ob, float time, float *m) {
     for (int i = 0; i < 12; ++i) m[i] = ob.key0[i] * omt + ob.key1[i] * t;
 }
 
+// instance memo (see SceneView): 12 words per thread, word k of thread t at memo[k * kMemoStride + t]
+constexpr uint32_t kMemoStride = 64, kMemoWords = 12;
+DTOF_D void instance_memo_fill(const SceneView &sv, float time, float *m, float *inv) {
+    instance_matrix(sv.objects[sv.memo_obj], time, m);
+    affine_inverse(m, inv);
+#pragma unroll
+    for (uint32_t k = 0; k < kMemoWords; ++k) sv.memo[k * kMemoStride] = inv[k];
+}
+DTOF_D void instance_memo_load(const SceneView &sv, float *inv) {
+#pragma unroll
+    for (uint32_t k = 0; k < kMemoWords; ++k) inv[k] = sv.memo[k * kMemoStride];
+}
+
 // Slab test against a padded box; NaNs (0*inf) fall out of the min/max chain conservatively.
 DTOF_D float box_entry(const float *bmin, const float *bmax, V3 o, V3 id, float tbest) {
     float tx0 = (bmin[0] - o.x) * id.x, tx1 = (bmax[0] - o.x) * id.x;
@@ -155,7 +174,7 @@ DTOF_D void node_test(const BvhNode *node, V3 o, V3 id, float tbest, float &tl, 
 // primitive hit with t <= maxt; the winner is the smallest t, ties going to the lowest
 // (object, shape, face) -- the rule the oracle uses, independent of traversal order.
 // `stack + sp * stride` onwards is free for the BLAS traversal of a mesh.
-template <bool ANY, bool MESH>
+template <bool ANY, bool MESH, bool MEMO = false>
 DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float time, float maxt, Hit &best,
                              uint32_t *stack, int sp, uint32_t stride) {
     const DObject &ob = sv.objects[oi];
@@ -163,8 +182,11 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
     V3 lo = o, ld = d;
     if (ob.kind == OBJ_INSTANCE) {
         float m[12], inv[12];
-        instance_matrix(ob, time, m);
-        affine_inverse(m, inv);
+        if (MEMO && oi == sv.memo_obj) instance_memo_load(sv, inv);
+        else {
+            instance_matrix(ob, time, m);
+            affine_inverse(m, inv);
+        }
         lo = xf_point(inv, o); ld = xf_vector(inv, d);
         const DGroup &g = sv.groups[ob.index];
         first = g.first_shape; count = g.n_shapes;
@@ -248,7 +270,7 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
 }
 
 // TLAS traversal; `stack` is a per-thread LDS column (stride blockDim.x).
-template <bool ANY, bool MESH>
+template <bool ANY, bool MESH, bool MEMO = false>
 DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best) {
     best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
     if (sv.n_nodes == 0) return false;
@@ -277,7 +299,7 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
             else { --sp; cur = stack[sp * stride]; }
         }
         if (cur == kDone) break;
-        if (intersect_object<ANY, MESH>(sv, cur & ~kLeafFlag, o, d, time, maxt, best, stack, sp, stride) && ANY) return true;
+        if (intersect_object<ANY, MESH, MEMO>(sv, cur & ~kLeafFlag, o, d, time, maxt, best, stack, sp, stride) && ANY) return true;
         if (sp == 0) break;
         --sp; cur = stack[sp * stride];
     }

@@ -153,7 +153,11 @@ def render_sharded(scene, seed=0, spp=0, halo=None, group=None):
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     W, H = scene.size
-    halo = 2 if halo is None else halo            # tent r=1 needs 1, the default gaussian (radius 2) needs 2
+    need = int(scene.info()["filter_halo"])       # ceil(radius - 0.5): tent r=1 -> 1, the default gaussian (radius 2) -> 2
+    halo = need if halo is None else halo
+    if halo < need:
+        raise ValueError("halo of %d rows is smaller than the reconstruction filter's reach of %d rows: splats across the band "
+                         "seams would be dropped" % (halo, need))
     dev = torch.device("cuda", torch.cuda.current_device())
     r0, r1 = row_band(H, world, rank)
     film = torch.zeros((padded_rows(H, world, halo), W, 4), dtype=torch.float32, device=dev)
