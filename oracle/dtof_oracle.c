@@ -142,6 +142,119 @@ float orc_acos(float x) {
     float z2 = 2.f * z1, z3 = x < 0.f ? ORC_PI_F - z2 : z2, z4 = 0.5f * ORC_PI_F - z1;
     return big ? z3 : z4;
 }
+/* ------------------------------------------------------------ exp / log / tan / erf / erfinv
+ * Dr.Jit's dr::exp, dr::log, dr::tan, dr::erf and dr::erfinv (drjit/math.h) are not in the tree.  They are restated from the
+ * published single-precision kernels Dr.Jit's math library derives from: Cephes expf / logf / tanf (S. Moshier), the Cephes
+ * erff series inside |x| < 1 with Abramowitz & Stegun 7.1.26 outside, and M. Giles' single-precision erfinv polynomial
+ * ("Approximating the erfinv function", GPU Computing Gems 2).  Needed by the Beckmann microfacet distribution
+ * (include/mitsuba/render/microfacet.h:176-196,240-290,341-403).  The product's dtof_math.h states the same operations. */
+float orc_expf(float x) {
+    if (x > 88.72283905206835f) return INFINITY;
+    if (x < -103.278929903431851103f) return 0.f;
+    float z = floorf(fmaf(1.44269504088896341f, x, 0.5f));
+    x = fmaf(z, -0.693359375f, x);
+    x = fmaf(z, 2.12194440e-4f, x);
+    int32_t n = (int32_t) z;
+    float x2 = x * x;
+    float p = fmaf(1.9875691500e-4f, x, 1.3981999507e-3f);
+    p = fmaf(p, x, 8.3334519073e-3f);
+    p = fmaf(p, x, 4.1665795894e-2f);
+    p = fmaf(p, x, 1.6666665459e-1f);
+    p = fmaf(p, x, 5.0000001201e-1f);
+    float r = fmaf(p, x2, x) + 1.f;
+    /* ldexpf(r, n), n in [-149, 128]: two exact power-of-two factors keep the intermediate normal */
+    int32_t n1 = n / 2, n2 = n - n1;
+    return r * u2f((uint32_t) (n1 + 127) << 23) * u2f((uint32_t) (n2 + 127) << 23);
+}
+float orc_logf(float x) {
+    if (x < 0.f) return NAN;
+    if (x == 0.f) return -INFINITY;
+    if (!(x < INFINITY)) return x;
+    uint32_t u = f2u(x); int32_t e = 0;
+    if (u < 0x00800000u) { x *= 8388608.f; u = f2u(x); e = -23; }   /* subnormal */
+    e += (int32_t) (u >> 23) - 126;
+    float m = u2f((u & 0x007fffffu) | 0x3f000000u);                   /* frexp: m in [0.5, 1) */
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.f; } else m = m - 1.f;
+    float z = m * m;
+    float y = fmaf(7.0376836292e-2f, m, -1.1514610310e-1f);
+    y = fmaf(y, m, 1.1676998740e-1f);
+    y = fmaf(y, m, -1.2420140846e-1f);
+    y = fmaf(y, m, 1.4249322787e-1f);
+    y = fmaf(y, m, -1.6668057665e-1f);
+    y = fmaf(y, m, 2.0000714765e-1f);
+    y = fmaf(y, m, -2.4999993993e-1f);
+    y = fmaf(y, m, 3.3333331174e-1f);
+    y = y * m * z;
+    float fe = (float) e;
+    y = fmaf(-2.12194440e-4f, fe, y);
+    y = fmaf(-0.5f, z, y);
+    return fmaf(0.693359375f, fe, m + y);
+}
+float orc_tanf(float xx) {
+    float x = fabsf(xx);
+    int32_t j = (int32_t) (x * 1.2732395447351626862f);
+    j = (j + 1) & ~1;
+    float y = (float) j;
+    float z = x - y * 0.78515625f;
+    z = z - y * 2.4187564849853515625e-4f;
+    z = z - y * 3.77489497744594108e-8f;
+    float zz = z * z;
+    float p = fmaf(9.38540185543e-3f, zz, 3.11992232697e-3f);
+    p = fmaf(p, zz, 2.44301354525e-2f);
+    p = fmaf(p, zz, 5.34112807005e-2f);
+    p = fmaf(p, zz, 1.33387994085e-1f);
+    p = fmaf(p, zz, 3.33331568548e-1f);
+    float r = x > 1.0e-4f ? fmaf(p * zz, z, z) : z;
+    if (j & 2) r = -1.f / r;
+    return u2f(f2u(r) ^ (f2u(xx) & 0x80000000u));
+}
+float orc_erff(float x) {
+    float xa = fabsf(x);
+    if (xa < 1.f) {
+        float z = x * x;
+        float p = fmaf(7.853861353153693e-5f, z, -8.010193625184903e-4f);
+        p = fmaf(p, z, 5.188327685732524e-3f);
+        p = fmaf(p, z, -2.685381193529856e-2f);
+        p = fmaf(p, z, 1.128358514861418e-1f);
+        p = fmaf(p, z, -3.761262582423300e-1f);
+        p = fmaf(p, z, 1.128379165726710e+0f);
+        return x * p;
+    }
+    float t = 1.f / fmaf(0.3275911f, xa, 1.f);
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    float r = fmaf(-(p * t), orc_expf(-(xa * xa)), 1.f);
+    return u2f(f2u(r) | (f2u(x) & 0x80000000u));
+}
+float orc_erfinvf(float x) {
+    float w = -orc_logf((1.f - x) * (1.f + x)), p;
+    if (w < 5.f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = fmaf(p, w, 3.43273939e-07f);
+        p = fmaf(p, w, -3.5233877e-06f);
+        p = fmaf(p, w, -4.39150654e-06f);
+        p = fmaf(p, w, 0.00021858087f);
+        p = fmaf(p, w, -0.00125372503f);
+        p = fmaf(p, w, -0.00417768164f);
+        p = fmaf(p, w, 0.246640727f);
+        p = fmaf(p, w, 1.50140941f);
+    } else {
+        w = sqrtf(w) - 3.f;
+        p = -0.000200214257f;
+        p = fmaf(p, w, 0.000100950558f);
+        p = fmaf(p, w, 0.00134934322f);
+        p = fmaf(p, w, -0.00367342844f);
+        p = fmaf(p, w, 0.00573950773f);
+        p = fmaf(p, w, -0.0076224613f);
+        p = fmaf(p, w, 0.00943887047f);
+        p = fmaf(p, w, 1.00167406f);
+        p = fmaf(p, w, 2.83297682f);
+    }
+    return p * x;
+}
 void orc_spot_params(float cutoff_deg, float beam_deg, float *out4) {
     float cutoff = cutoff_deg * (ORC_PI_F / 180.f), beam = beam_deg * (ORC_PI_F / 180.f);
     out4[0] = cutoff; out4[1] = orc_cos(cutoff); out4[2] = orc_cos(beam); out4[3] = 1.0f / (cutoff - beam);
@@ -736,6 +849,17 @@ static inline float f_safe_sqrt(float x) { return sqrtf(f_max(x, 0.f)); }
 #define ORC_INV_TWO_PI_F 0.15915494309189533577f
 /* warp::square_to_uniform_cone_pdf (warp.h:475-485) */
 static inline float uniform_cone_pdf(float cos_cutoff) { return ORC_INV_TWO_PI_F / (1.f - cos_cutoff); }
+/* warp::square_to_uniform_sphere (warp.h:250-255) */
+static v3 square_to_uniform_sphere(float s_x, float s_y) {
+    float z = fmaf(-2.f, s_y, 1.f), r = f_safe_sqrt(fmaf(-z, z, 1.f)), sn, cs;
+    orc_sincos(2.f * ORC_PI_F * s_x, &sn, &cs);
+    return V(r * cs, r * sn, z);
+}
+/* warp::square_to_uniform_triangle (warp.h:153-156) */
+static void square_to_uniform_triangle(float s_x, float s_y, float *bx, float *by) {
+    float t = sqrtf(f_max(1.f - s_x, 0.f));
+    *bx = 1.f - t; *by = t * s_y;
+}
 /* Sphere::sample_direction (sphere.cpp:222-296): cone sampling of the visible cap from outside, uniform sphere from inside.
  * Outputs the sampled point, its normal, the unit direction, distance and solid-angle density. */
 static void sphere_sample_direction(const orc_shape *sh, v3 ref, float s_x, float s_y, v3 *p_out, v3 *n_out, v3 *d_out,
@@ -761,9 +885,7 @@ static void sphere_sample_direction(const orc_shape *sh, v3 ref, float s_x, floa
         dloc = v_fma(fn, loc.z, v_fma(ft, loc.y, v_mul(fs, loc.x)));
         pdf = uniform_cone_pdf(cos_theta_max);
     } else {   /* warp::square_to_uniform_sphere (warp.h:250-255) */
-        float z = fmaf(-2.f, s_y, 1.f), r = f_safe_sqrt(fmaf(-z, z, 1.f)), sn, cs;
-        orc_sincos(2.f * ORC_PI_F * s_x, &sn, &cs);
-        dloc = V(r * cs, r * sn, z);
+        dloc = square_to_uniform_sphere(s_x, s_y);
         pdf = 0.f;
     }
     v3 p = v_fma(dloc, radius, center), dd = v_sub(p, ref);
@@ -802,8 +924,7 @@ static void mesh_sample_position(const orc_shape *sh, float s_x, float s_y, v3 *
     v3 p0 = V(P[3 * fi[0]], P[3 * fi[0] + 1], P[3 * fi[0] + 2]), p1 = V(P[3 * fi[1]], P[3 * fi[1] + 1], P[3 * fi[1] + 2]),
        p2 = V(P[3 * fi[2]], P[3 * fi[2] + 1], P[3 * fi[2] + 2]);
     v3 e0 = v_sub(p1, p0), e1 = v_sub(p2, p0);
-    float t = sqrtf(f_max(1.f - s_x, 0.f));
-    float bx = 1.f - t, by = t * y;
+    float bx, by; square_to_uniform_triangle(s_x, y, &bx, &by);
     *p_out = v_fma(e0, bx, v_fma(e1, by, p0));
     v3 n;
     if (sh->normals && !sh->face_normals) {
@@ -842,31 +963,55 @@ static void fresnel_dielectric(float cos_theta_i, float eta, float *r_out, float
     if (special_case) r = r_sc;
     *r_out = r; *cos_theta_t = f_mulsign_neg(cos_theta_t_abs, cos_theta_i); *eta_it_out = eta_it; *eta_ti_out = eta_ti;
 }
-/* ---- MicrofacetDistribution, GGX, sample_visible = true (include/mitsuba/render/microfacet.h) */
-typedef struct { float au, av; } ggx_t;
-static ggx_t ggx_make(float au, float av) { ggx_t g; g.au = f_max(au, 1e-4f); g.av = f_max(av, 1e-4f); return g; }   /* configure() :425-428 */
+/* ---- MicrofacetDistribution (include/mitsuba/render/microfacet.h): Beckmann (type 0) and GGX (type 1); visible-normal
+ * sampling is what the BSDF plugins use (sample_visible = true, their default), the plain sampling of all normals
+ * (sample_visible = false) exists for the reference's own known answers (src/render/tests/test_microfacet.py) */
+enum { ORC_MF_BECKMANN = 0, ORC_MF_GGX = 1 };
+typedef struct { float au, av; int type, visible; } ggx_t;
+static ggx_t mf_make(int type, float au, float av, int visible) {   /* configure() :425-428 */
+    ggx_t g; g.au = f_max(au, 1e-4f); g.av = f_max(av, 1e-4f); g.type = type; g.visible = visible; return g;
+}
 static float ggx_eval(ggx_t g, v3 m) {   /* eval() :176-196 */
-    float alpha_uv = g.au * g.av, cos_theta = m.z;
-    float result = f_rcp(ORC_PI_F * alpha_uv * f_sqr(f_sqr(m.x / g.au) + f_sqr(m.y / g.av) + f_sqr(m.z)));
+    float alpha_uv = g.au * g.av, cos_theta = m.z, cos_theta_2 = f_sqr(cos_theta), result;
+    if (g.type == ORC_MF_BECKMANN)
+        result = orc_expf(-(f_sqr(m.x / g.au) + f_sqr(m.y / g.av)) / cos_theta_2) / (ORC_PI_F * alpha_uv * f_sqr(cos_theta_2));
+    else
+        result = f_rcp(ORC_PI_F * alpha_uv * f_sqr(f_sqr(m.x / g.au) + f_sqr(m.y / g.av) + f_sqr(m.z)));
     return result * cos_theta > 1e-20f ? result : 0.f;
 }
 static float ggx_smith_g1(ggx_t g, v3 v, v3 m) {   /* smith_g1() :341-365 */
-    float xy_alpha_2 = f_sqr(g.au * v.x) + f_sqr(g.av * v.y), tan_theta_alpha_2 = xy_alpha_2 / f_sqr(v.z);
-    float result = 2.f / (1.f + sqrtf(1.f + tan_theta_alpha_2));
+    float xy_alpha_2 = f_sqr(g.au * v.x) + f_sqr(g.av * v.y), tan_theta_alpha_2 = xy_alpha_2 / f_sqr(v.z), result;
+    if (g.type == ORC_MF_BECKMANN) {
+        float a = f_rsqrt(tan_theta_alpha_2), a_sqr = f_sqr(a);
+        result = a >= 1.6f ? 1.f : (3.535f * a + 2.181f * a_sqr) / (1.f + 2.276f * a + 2.577f * a_sqr);
+    } else
+        result = 2.f / (1.f + sqrtf(1.f + tan_theta_alpha_2));
     if (xy_alpha_2 == 0.f) result = 1.f;
     if (v_dot(v, m) * v.z <= 0.f) result = 0.f;
     return result;
 }
-/* sample() visible-normal branch :296-325 + sample_visible_11 GGX branch :405-420; returns m and the density of m */
-static v3 ggx_sample(ggx_t g, v3 wi, float s_x, float s_y, float *pdf_out) {
-    v3 wi_p = v_normalize(V(g.au * wi.x, g.av * wi.y, wi.z));
-    /* Frame3f::sincos_phi (frame.h:111-122) */
-    float sin_theta_2 = fmaf(wi_p.x, wi_p.x, f_sqr(wi_p.y)), inv_sin_theta = f_rsqrt(sin_theta_2);
-    float rx = wi_p.x * inv_sin_theta, ry = wi_p.y * inv_sin_theta;
-    rx = f_min(f_max(rx, -1.f), 1.f); ry = f_min(f_max(ry, -1.f), 1.f);
-    if (fabsf(sin_theta_2) <= 4.f * 5.9604644775390625e-8f) { rx = 1.f; ry = 0.f; }
-    float sin_phi = ry, cos_phi = rx, cos_theta = wi_p.z;
-    /* sample_visible_11: square_to_uniform_disk_concentric (warp.h:54-90) */
+/* MicrofacetDistribution::pdf (microfacet.h:219-228): visible normals D * ((G1 * |wi.m|) / cos_theta_i), all normals D * cos_theta_m */
+static float ggx_pdf(ggx_t g, v3 wi, v3 m) {
+    return g.visible ? ggx_eval(g, m) * (ggx_smith_g1(g, wi, m) * fabsf(v_dot(wi, m)) / wi.z) : ggx_eval(g, m) * m.z;
+}
+/* sample_visible_11 (:368-420): slope of the visible normal for alpha = 1 */
+static void mf_sample_visible_11(int type, float cos_theta_i, float s_x, float s_y, float *slope_x, float *slope_y) {
+    if (type == ORC_MF_BECKMANN) {
+        const float inv_sqrt_pi = 0.56418958354775628695f;
+        float tan_theta_i = f_safe_sqrt(fmaf(-cos_theta_i, cos_theta_i, 1.f)) / cos_theta_i, cot_theta_i = f_rcp(tan_theta_i);
+        float maxval = orc_erff(cot_theta_i);
+        s_x = f_max(f_min(s_x, 1.f - 1e-6f), 1e-6f); s_y = f_max(f_min(s_y, 1.f - 1e-6f), 1e-6f);
+        float x = maxval - (maxval + 1.f) * orc_erff(sqrtf(-orc_logf(s_x)));
+        s_x *= 1.f + maxval + inv_sqrt_pi * tan_theta_i * orc_expf(-f_sqr(cot_theta_i));
+        for (int i = 0; i < 3; ++i) {   /* three Newton iterations */
+            float slope = orc_erfinvf(x);
+            float value = 1.f + x + inv_sqrt_pi * tan_theta_i * orc_expf(-f_sqr(slope)) - s_x, derivative = 1.f - slope * tan_theta_i;
+            x -= value / derivative;
+        }
+        *slope_x = orc_erfinvf(x); *slope_y = orc_erfinvf(fmaf(2.f, s_y, -1.f));
+        return;
+    }
+    /* GGX: square_to_uniform_disk_concentric (warp.h:54-90), projection onto the chosen side of the hemisphere */
     float x = fmaf(2.f, s_x, -1.f), y = fmaf(2.f, s_y, -1.f);
     int is_zero = x == 0.f && y == 0.f, q13 = fabsf(x) < fabsf(y);
     float r = q13 ? y : x, rp = q13 ? x : y;
@@ -875,13 +1020,53 @@ static v3 ggx_sample(ggx_t g, v3 wi, float s_x, float s_y, float *pdf_out) {
     if (is_zero) phi = 0.f;
     float sn, cs; orc_sincos(phi, &sn, &cs);
     float px = r * cs, py = r * sn;
-    float s = 0.5f * (1.f + cos_theta);
+    float s = 0.5f * (1.f + cos_theta_i);
     float a = f_safe_sqrt(1.f - f_sqr(px));
     py = fmaf(py, s, fmaf(-a, s, a));                      /* dr::lerp(a, py, s) = fmadd(py, s, fnmadd(a, s, a)) */
     float pz = f_safe_sqrt(1.f - fmaf(py, py, px * px));   /* squared_norm(p) = fmadd chain */
-    float sin_theta_i = f_safe_sqrt(1.f - f_sqr(cos_theta));
-    float norm = f_rcp(fmaf(sin_theta_i, py, cos_theta * pz));
-    float slope_x = fmaf(cos_theta, py, -(sin_theta_i * pz)) * norm, slope_y = px * norm;
+    float sin_theta_i = f_safe_sqrt(1.f - f_sqr(cos_theta_i));
+    float norm = f_rcp(fmaf(sin_theta_i, py, cos_theta_i * pz));
+    *slope_x = fmaf(cos_theta_i, py, -(sin_theta_i * pz)) * norm; *slope_y = px * norm;
+}
+/* sample() :240-325; returns m and the density of m */
+static v3 ggx_sample(ggx_t g, v3 wi, float s_x, float s_y, float *pdf_out) {
+    if (!g.visible) {   /* all normals :242-290 */
+        float sin_phi, cos_phi, cos_theta, cos_theta_2, alpha_2, pdf;
+        if (g.au == g.av) {
+            orc_sincos((2.f * ORC_PI_F) * s_y, &sin_phi, &cos_phi);
+            alpha_2 = g.au * g.au;
+        } else {
+            float ratio = g.av / g.au, tmp = ratio * orc_tanf((2.f * ORC_PI_F) * s_y);
+            cos_phi = f_rsqrt(fmaf(tmp, tmp, 1.f));
+            cos_phi = f_mulsign(cos_phi, fabsf(s_y - .5f) - .25f);
+            sin_phi = cos_phi * tmp;
+            alpha_2 = f_rcp(f_sqr(cos_phi / g.au) + f_sqr(sin_phi / g.av));
+        }
+        if (g.type == ORC_MF_BECKMANN) {
+            cos_theta = f_rsqrt(fmaf(-alpha_2, orc_logf(1.f - s_x), 1.f));
+            cos_theta_2 = f_sqr(cos_theta);
+            float cos_theta_3 = f_max(cos_theta_2 * cos_theta, 1e-20f);
+            pdf = (1.f - s_x) / (ORC_PI_F * g.au * g.av * cos_theta_3);
+        } else {
+            float tan_theta_m_2 = alpha_2 * s_x / (1.f - s_x);
+            cos_theta = f_rsqrt(1.f + tan_theta_m_2);
+            cos_theta_2 = f_sqr(cos_theta);
+            float temp = 1.f + tan_theta_m_2 / alpha_2, cos_theta_3 = f_max(cos_theta_2 * cos_theta, 1e-20f);
+            pdf = f_rcp(ORC_PI_F * g.au * g.av * cos_theta_3 * f_sqr(temp));
+        }
+        float sin_theta = sqrtf(1.f - cos_theta_2);
+        *pdf_out = pdf;
+        return V(cos_phi * sin_theta, sin_phi * sin_theta, cos_theta);
+    }
+    v3 wi_p = v_normalize(V(g.au * wi.x, g.av * wi.y, wi.z));
+    /* Frame3f::sincos_phi (frame.h:111-122) */
+    float sin_theta_2 = fmaf(wi_p.x, wi_p.x, f_sqr(wi_p.y)), inv_sin_theta = f_rsqrt(sin_theta_2);
+    float rx = wi_p.x * inv_sin_theta, ry = wi_p.y * inv_sin_theta;
+    rx = f_min(f_max(rx, -1.f), 1.f); ry = f_min(f_max(ry, -1.f), 1.f);
+    if (fabsf(sin_theta_2) <= 4.f * 5.9604644775390625e-8f) { rx = 1.f; ry = 0.f; }
+    float sin_phi = ry, cos_phi = rx, cos_theta = wi_p.z;
+    float slope_x, slope_y;
+    mf_sample_visible_11(g.type, cos_theta, s_x, s_y, &slope_x, &slope_y);
     /* rotate & unstretch, normal, density */
     float sx = fmaf(cos_phi, slope_x, -(sin_phi * slope_y)) * g.au, sy = fmaf(sin_phi, slope_x, cos_phi * slope_y) * g.av;
     v3 m = v_normalize(V(-sx, -sy, 1.f));
@@ -914,8 +1099,6 @@ static void rough_plastic_eval_pdf(ggx_t g, const orc_shape *sh, v3 wi, v3 wo, f
     result *= prob_specular;
     *pdf = result + prob_diffuse * (ORC_INV_PI_F * wo.z);
 }
-/* MicrofacetDistribution::pdf (microfacet.h:219-228), visible normals: D * ((G1 * |wi.m|) / cos_theta_i) */
-static float ggx_pdf(ggx_t g, v3 wi, v3 m) { return ggx_eval(g, m) * (ggx_smith_g1(g, wi, m) * fabsf(v_dot(wi, m)) / wi.z); }
 /* RoughDielectric::eval_pdf (roughdielectric.cpp:503-611), TransportMode::Radiance */
 static void rough_dielectric_eval_pdf(ggx_t g, const orc_shape *sh, v3 wi, v3 wo, v3 *value, float *pdf) {
     float cti = wi.z, cto = wo.z, m_eta = sh->diel_eta, m_inv_eta = f_rcp(m_eta);
@@ -942,6 +1125,185 @@ static void rough_dielectric_eval_pdf(ggx_t g, const orc_shape *sh, v3 wi, v3 wo
     p *= reflect ? F : 1.f - F;
     float dwh_dwo = reflect ? f_rcp(4.f * dom) : (eta * eta * dom) / f_sqr(dwm + eta * dom);
     *pdf = p * fabsf(dwh_dwo);
+}
+/* One BSDF interaction of the bounce loop: value and density for the emitter direction `wo` (only when `active_em`), and the
+ * sampled continuation (BSDF::eval_pdf_sample, src/render/bsdf.cpp:20-29).  wi_in / wo / bs_wo are in the local shading frame. */
+typedef struct { v3 val; float pdf; v3 weight; v3 wo; float bs_pdf, bs_eta; int bs_delta; } orc_bsdf_out;
+static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, orc_bsdf_out *out) {
+    /* BSDF::eval_pdf_sample src/render/bsdf.cpp:20-29 over twosided{diffuse} / diffuse
+     * (src/bsdfs/twosided.cpp:111-148,219-258; src/bsdfs/diffuse.cpp:101-125,160-180) */
+    v3 bsdf_val = V(0, 0, 0), bsdf_weight = V(0, 0, 0), bs_wo = V(0, 0, 0);
+    float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; int bs_delta = 0;
+    if (sh->bsdf == ORC_BSDF_CONDUCTOR) {
+        /* SmoothConductor::sample (conductor.cpp:226-277) under TwoSidedBRDF::sample (twosided.cpp:111-148): eval / pdf of a
+         * delta lobe are zero (conductor.cpp:279-290) */
+        float cos_theta_i = sh->twosided ? fabsf(wi_in.z) : wi_in.z;
+        if (cos_theta_i > 0.f) {
+            bs_wo = V(-wi_in.x, -wi_in.y, wi_in.z);   /* reflect(wi); the two-sided flip of wi.z and of wo.z cancel */
+            bs_eta = 1.f; bs_pdf = 1.f; bs_delta = 1;
+            bsdf_weight = V(sh->spec_refl[0] * fresnel_conductor(cos_theta_i, sh->cond_eta[0], sh->cond_k[0]),
+                            sh->spec_refl[1] * fresnel_conductor(cos_theta_i, sh->cond_eta[1], sh->cond_k[1]),
+                            sh->spec_refl[2] * fresnel_conductor(cos_theta_i, sh->cond_eta[2], sh->cond_k[2]));
+        }
+    } else if (sh->bsdf == ORC_BSDF_DIELECTRIC) {
+        /* SmoothDielectric::sample (dielectric.cpp:231-338), TransportMode::Radiance */
+        float r_i, cos_theta_t, eta_it, eta_ti;
+        fresnel_dielectric(wi_in.z, sh->diel_eta, &r_i, &cos_theta_t, &eta_it, &eta_ti);
+        float t_i = 1.f - r_i;
+        int selected_r = sample_1 <= r_i;
+        bs_pdf = selected_r ? r_i : t_i; bs_delta = 1;
+        bs_wo = selected_r ? V(-wi_in.x, -wi_in.y, wi_in.z) : V(-eta_ti * wi_in.x, -eta_ti * wi_in.y, cos_theta_t);
+        bs_eta = selected_r ? 1.f : eta_it;
+        if (selected_r) bsdf_weight = V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]);
+        else { float f2 = f_sqr(eta_ti); bsdf_weight = V(sh->spec_trans[0] * f2, sh->spec_trans[1] * f2, sh->spec_trans[2] * f2); }
+    } else if (sh->bsdf == ORC_BSDF_THINDIELECTRIC) {
+        /* ThinDielectric::sample (thindielectric.cpp:173-226); eval / pdf are zero (:228-236) */
+        float r, t1, t2, t3;
+        fresnel_dielectric(fabsf(wi_in.z), sh->diel_eta, &r, &t1, &t2, &t3);
+        r *= 2.f / (1.f + r);
+        int selected_r = sample_1 <= r;
+        bs_pdf = selected_r ? r : 1.f - r; bs_delta = 1; bs_eta = 1.f;
+        bs_wo = selected_r ? V(-wi_in.x, -wi_in.y, wi_in.z) : V(-wi_in.x, -wi_in.y, -wi_in.z);
+        bsdf_weight = selected_r ? V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]) : V(sh->spec_trans[0], sh->spec_trans[1], sh->spec_trans[2]);
+    } else if (sh->bsdf == ORC_BSDF_ROUGHDIELECTRIC) {
+        /* RoughDielectric::sample (roughdielectric.cpp:240-346); eval_pdf above for the emitter sample */
+        ggx_t g = mf_make(sh->mf_type, sh->alpha_u, sh->alpha_v, 1);
+        v3 wi = wi_in;
+        if (active_em) rough_dielectric_eval_pdf(g, sh, wi, wo, &bsdf_val, &bsdf_pdf);
+        if (wi.z != 0.f) {
+            float mpdf;
+            v3 m = ggx_sample(g, V(f_mulsign(wi.x, wi.z), f_mulsign(wi.y, wi.z), f_mulsign(wi.z, wi.z)), s2x, s2y, &mpdf);
+            float dwm = v_dot(wi, m), F, cos_theta_t, eta_it, eta_ti;
+            fresnel_dielectric(dwm, sh->diel_eta, &F, &cos_theta_t, &eta_it, &eta_ti);
+            int selected_r = sample_1 <= F;
+            bs_pdf = mpdf * (selected_r ? F : 1.f - F);
+            bs_eta = selected_r ? 1.f : eta_it;
+            float dwh_dwo; v3 w;
+            if (selected_r) {
+                bs_wo = V(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));
+                w = V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]);
+                dwh_dwo = f_rcp(4.f * v_dot(bs_wo, m));
+            } else {
+                float k = fmaf(dwm, eta_ti, cos_theta_t);
+                bs_wo = V(fmaf(m.x, k, -(wi.x * eta_ti)), fmaf(m.y, k, -(wi.y * eta_ti)), fmaf(m.z, k, -(wi.z * eta_ti)));
+                float f2 = f_sqr(eta_ti);
+                w = V(f2 * sh->spec_trans[0], f2 * sh->spec_trans[1], f2 * sh->spec_trans[2]);
+                float dom = v_dot(bs_wo, m);
+                dwh_dwo = (f_sqr(bs_eta) * dom) / f_sqr(dwm + bs_eta * dom);
+            }
+            float g1 = ggx_smith_g1(g, bs_wo, m);
+            bs_pdf *= fabsf(dwh_dwo);
+            if (mpdf != 0.f) bsdf_weight = v_mul(w, g1);
+        }
+    } else if (sh->bsdf == ORC_BSDF_ROUGHCONDUCTOR) {
+        /* RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF */
+        v3 wi = wi_in, wo_l = wo;
+        if (sh->twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }   /* twosided.cpp:219-258 flips both */
+        ggx_t g = mf_make(sh->mf_type, sh->alpha_u, sh->alpha_v, 1);
+        if (wi.z > 0.f && wo_l.z > 0.f) {
+            v3 H = v_normalize(v_add(wo_l, wi));
+            float D = ggx_eval(g, H);
+            if (D != 0.f) {   /* eval :317-375 */
+                float G = ggx_smith_g1(g, wi, H) * ggx_smith_g1(g, wo_l, H);
+                float result = D * G / (4.f * wi.z), c = v_dot(wi, H);
+                bsdf_val = V(fresnel_conductor(c, sh->cond_eta[0], sh->cond_k[0]) * (result * sh->spec_refl[0]),
+                             fresnel_conductor(c, sh->cond_eta[1], sh->cond_k[1]) * (result * sh->spec_refl[1]),
+                             fresnel_conductor(c, sh->cond_eta[2], sh->cond_k[2]) * (result * sh->spec_refl[2]));
+            }
+            if (v_dot(wi, H) > 0.f && v_dot(wo_l, H) > 0.f)   /* pdf :377-415 */
+                bsdf_pdf = ggx_eval(g, H) * ggx_smith_g1(g, wi, H) / (4.f * wi.z);
+        }
+        if (wi.z > 0.f) {   /* sample :229-315 */
+            float mpdf;
+            v3 m = ggx_sample(g, wi, s2x, s2y, &mpdf);
+            float dwm = v_dot(wi, m);
+            v3 r = V(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   /* reflect(wi, m) fresnel.h:282-284 */
+            bs_wo = r; bs_eta = 1.f;
+            int ok = mpdf != 0.f && r.z > 0.f;
+            float weight = ggx_smith_g1(g, r, m);
+            bs_pdf = mpdf / (4.f * v_dot(r, m));
+            if (ok) bsdf_weight = V(fresnel_conductor(dwm, sh->cond_eta[0], sh->cond_k[0]) * (weight * sh->spec_refl[0]),
+                                    fresnel_conductor(dwm, sh->cond_eta[1], sh->cond_k[1]) * (weight * sh->spec_refl[1]),
+                                    fresnel_conductor(dwm, sh->cond_eta[2], sh->cond_k[2]) * (weight * sh->spec_refl[2]));
+            if (sh->twosided && wi_in.z < 0.f) bs_wo.z = -bs_wo.z;
+        }
+    } else if (sh->bsdf == ORC_BSDF_ROUGHPLASTIC) {
+        /* RoughPlastic::sample (roughplastic.cpp:259-331) under TwoSidedBRDF; eval / pdf in rough_plastic_eval_pdf */
+        v3 wi = wi_in, wo_l = wo;
+        if (sh->twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
+        ggx_t g = mf_make(sh->mf_type, sh->alpha_u, sh->alpha_u, 1);
+        if (wi.z > 0.f) {
+            float t_i = lerp_gather64(sh->rough_table, wi.z);
+            float prob_specular = (1.f - t_i) * sh->spec_sampling_weight, prob_diffuse = t_i * (1.f - sh->spec_sampling_weight);
+            prob_specular = prob_specular / (prob_specular + prob_diffuse);
+            prob_diffuse = 1.f - prob_specular;
+            if (wo_l.z > 0.f) rough_plastic_eval_pdf(g, sh, wi, wo_l, t_i, prob_specular, prob_diffuse, &bsdf_val, &bsdf_pdf);
+            if (sample_1 < prob_specular) {
+                float mpdf; v3 m = ggx_sample(g, wi, s2x, s2y, &mpdf);
+                float dwm = v_dot(wi, m);
+                bs_wo = V(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   /* reflect(wi, m) */
+            } else bs_wo = square_to_cosine_hemisphere(s2x, s2y);
+            bs_eta = 1.f;
+            v3 value = V(0, 0, 0);
+            if (bs_wo.z > 0.f) rough_plastic_eval_pdf(g, sh, wi, bs_wo, t_i, prob_specular, prob_diffuse, &value, &bs_pdf);
+            if (bs_pdf > 0.f) bsdf_weight = v_mul(value, f_rcp(bs_pdf));   /* Spectrum / Float: times the reciprocal */
+            if (sh->twosided && wi_in.z < 0.f) bs_wo.z = -bs_wo.z;
+        }
+    } else if (sh->bsdf == ORC_BSDF_PLASTIC) {
+        /* SmoothPlastic::eval / pdf / sample (plastic.cpp:219-360) under TwoSidedBRDF (twosided.cpp:111-148,219-258) */
+        float wiz = wi_in.z, woz = wo.z;
+        if (sh->twosided) { woz = f_mulsign(woz, wiz); wiz = fabsf(wiz); }
+        float f_i, tmp1, tmp2, tmp3;
+        fresnel_dielectric(wiz, sh->diel_eta, &f_i, &tmp1, &tmp2, &tmp3);
+        const float w = sh->spec_sampling_weight;
+        v3 diff = V(sh->reflectance[0], sh->reflectance[1], sh->reflectance[2]);
+        diff = sh->nonlinear ? V(diff.x / (1.f - diff.x * sh->fdr_int), diff.y / (1.f - diff.y * sh->fdr_int), diff.z / (1.f - diff.z * sh->fdr_int))
+                             : V(diff.x / (1.f - sh->fdr_int), diff.y / (1.f - sh->fdr_int), diff.z / (1.f - sh->fdr_int));
+        if (wiz > 0.f && woz > 0.f) {   /* eval (:309-332) and pdf (:334-360) of the diffuse lobe */
+            float f_o; fresnel_dielectric(woz, sh->diel_eta, &f_o, &tmp1, &tmp2, &tmp3);
+            float k = ORC_INV_PI_F * woz * sh->inv_eta_2 * (1.f - f_i) * (1.f - f_o);
+            bsdf_val = V(diff.x * k, diff.y * k, diff.z * k);
+            float prob_specular = f_i * w, prob_diffuse = (1.f - f_i) * (1.f - w);
+            prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
+            bsdf_pdf = ORC_INV_PI_F * woz * prob_diffuse;
+        }
+        if (wiz > 0.f) {                /* sample (:219-307) */
+            float prob_specular = f_i * w, prob_diffuse = (1.f - f_i) * (1.f - w);
+            prob_specular = prob_specular / (prob_specular + prob_diffuse);
+            prob_diffuse = 1.f - prob_specular;
+            bs_eta = 1.f;
+            if (sample_1 < prob_specular) {
+                bs_wo = V(-wi_in.x, -wi_in.y, wiz);   /* reflect() of the (possibly flipped) wi */
+                bs_pdf = prob_specular; bs_delta = 1;
+                float value = f_i / bs_pdf;
+                bsdf_weight = V(value * sh->spec_refl[0], value * sh->spec_refl[1], value * sh->spec_refl[2]);
+            } else {
+                bs_wo = square_to_cosine_hemisphere(s2x, s2y);
+                bs_pdf = prob_diffuse * (ORC_INV_PI_F * bs_wo.z);
+                float f_o; fresnel_dielectric(bs_wo.z, sh->diel_eta, &f_o, &tmp1, &tmp2, &tmp3);
+                float k = sh->inv_eta_2 * (1.f - f_i) * (1.f - f_o) / prob_diffuse;
+                bsdf_weight = V(diff.x * k, diff.y * k, diff.z * k);
+            }
+            if (sh->twosided) bs_wo.z = f_mulsign(bs_wo.z, wi_in.z);
+        }
+    } else {
+        float wiz = wi_in.z, woz = wo.z;
+        if (sh->twosided) { woz = f_mulsign(woz, wiz); wiz = fabsf(wiz); }
+        if (wiz > 0.f && woz > 0.f) {
+            bsdf_val = V(sh->reflectance[0] * ORC_INV_PI_F * woz, sh->reflectance[1] * ORC_INV_PI_F * woz,
+                         sh->reflectance[2] * ORC_INV_PI_F * woz);
+            bsdf_pdf = ORC_INV_PI_F * woz;
+        }
+        if (wiz > 0.f) {
+            bs_wo = square_to_cosine_hemisphere(s2x, s2y);
+            bs_pdf = ORC_INV_PI_F * bs_wo.z;
+            bs_eta = 1.f;
+            if (bs_pdf > 0.f) bsdf_weight = V(sh->reflectance[0], sh->reflectance[1], sh->reflectance[2]);
+            if (sh->twosided) bs_wo.z = f_mulsign(bs_wo.z, wi_in.z);
+        }
+    }
+    out->val = bsdf_val; out->pdf = bsdf_pdf; out->weight = bsdf_weight; out->wo = bs_wo;
+    out->bs_pdf = bs_pdf; out->bs_eta = bs_eta; out->bs_delta = bs_delta;
 }
 /* mis_weight -- dopplertofpath.cpp:296-301 */
 static inline float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
@@ -1134,185 +1496,12 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         float s2x = sampler_draw(&smp, correlate, single);
         float s2y = sampler_draw(&smp, correlate, single);
 
-        /* BSDF::eval_pdf_sample src/render/bsdf.cpp:20-29 over twosided{diffuse} / diffuse
-         * (src/bsdfs/twosided.cpp:111-148,219-258; src/bsdfs/diffuse.cpp:101-125,160-180) */
         v3 bsdf_val = V(0, 0, 0), bsdf_weight = V(0, 0, 0), bs_wo = V(0, 0, 0);
         float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; int bs_delta = 0;
-        if (hit && si.shape->bsdf == ORC_BSDF_CONDUCTOR) {
-            /* SmoothConductor::sample (conductor.cpp:226-277) under TwoSidedBRDF::sample (twosided.cpp:111-148): eval / pdf of a
-             * delta lobe are zero (conductor.cpp:279-290) */
-            const orc_shape *sh = si.shape;
-            float cos_theta_i = sh->twosided ? fabsf(si.wi.z) : si.wi.z;
-            if (cos_theta_i > 0.f) {
-                bs_wo = V(-si.wi.x, -si.wi.y, si.wi.z);   /* reflect(wi); the two-sided flip of wi.z and of wo.z cancel */
-                bs_eta = 1.f; bs_pdf = 1.f; bs_delta = 1;
-                bsdf_weight = V(sh->spec_refl[0] * fresnel_conductor(cos_theta_i, sh->cond_eta[0], sh->cond_k[0]),
-                                sh->spec_refl[1] * fresnel_conductor(cos_theta_i, sh->cond_eta[1], sh->cond_k[1]),
-                                sh->spec_refl[2] * fresnel_conductor(cos_theta_i, sh->cond_eta[2], sh->cond_k[2]));
-            }
-        } else if (hit && si.shape->bsdf == ORC_BSDF_DIELECTRIC) {
-            /* SmoothDielectric::sample (dielectric.cpp:231-338), TransportMode::Radiance */
-            const orc_shape *sh = si.shape;
-            float r_i, cos_theta_t, eta_it, eta_ti;
-            fresnel_dielectric(si.wi.z, sh->diel_eta, &r_i, &cos_theta_t, &eta_it, &eta_ti);
-            float t_i = 1.f - r_i;
-            int selected_r = sample_1 <= r_i;
-            bs_pdf = selected_r ? r_i : t_i; bs_delta = 1;
-            bs_wo = selected_r ? V(-si.wi.x, -si.wi.y, si.wi.z) : V(-eta_ti * si.wi.x, -eta_ti * si.wi.y, cos_theta_t);
-            bs_eta = selected_r ? 1.f : eta_it;
-            if (selected_r) bsdf_weight = V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]);
-            else { float f2 = f_sqr(eta_ti); bsdf_weight = V(sh->spec_trans[0] * f2, sh->spec_trans[1] * f2, sh->spec_trans[2] * f2); }
-        } else if (hit && si.shape->bsdf == ORC_BSDF_THINDIELECTRIC) {
-            /* ThinDielectric::sample (thindielectric.cpp:173-226); eval / pdf are zero (:228-236) */
-            const orc_shape *sh = si.shape;
-            float r, t1, t2, t3;
-            fresnel_dielectric(fabsf(si.wi.z), sh->diel_eta, &r, &t1, &t2, &t3);
-            r *= 2.f / (1.f + r);
-            int selected_r = sample_1 <= r;
-            bs_pdf = selected_r ? r : 1.f - r; bs_delta = 1; bs_eta = 1.f;
-            bs_wo = selected_r ? V(-si.wi.x, -si.wi.y, si.wi.z) : V(-si.wi.x, -si.wi.y, -si.wi.z);
-            bsdf_weight = selected_r ? V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]) : V(sh->spec_trans[0], sh->spec_trans[1], sh->spec_trans[2]);
-        } else if (hit && si.shape->bsdf == ORC_BSDF_ROUGHDIELECTRIC) {
-            /* RoughDielectric::sample (roughdielectric.cpp:240-346); eval_pdf above for the emitter sample */
-            const orc_shape *sh = si.shape;
-            ggx_t g = ggx_make(sh->alpha_u, sh->alpha_v);
-            v3 wi = si.wi;
-            if (active_em) rough_dielectric_eval_pdf(g, sh, wi, wo, &bsdf_val, &bsdf_pdf);
-            if (wi.z != 0.f) {
-                float mpdf;
-                v3 m = ggx_sample(g, V(f_mulsign(wi.x, wi.z), f_mulsign(wi.y, wi.z), f_mulsign(wi.z, wi.z)), s2x, s2y, &mpdf);
-                float dwm = v_dot(wi, m), F, cos_theta_t, eta_it, eta_ti;
-                fresnel_dielectric(dwm, sh->diel_eta, &F, &cos_theta_t, &eta_it, &eta_ti);
-                int selected_r = sample_1 <= F;
-                bs_pdf = mpdf * (selected_r ? F : 1.f - F);
-                bs_eta = selected_r ? 1.f : eta_it;
-                float dwh_dwo; v3 w;
-                if (selected_r) {
-                    bs_wo = V(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));
-                    w = V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]);
-                    dwh_dwo = f_rcp(4.f * v_dot(bs_wo, m));
-                } else {
-                    float k = fmaf(dwm, eta_ti, cos_theta_t);
-                    bs_wo = V(fmaf(m.x, k, -(wi.x * eta_ti)), fmaf(m.y, k, -(wi.y * eta_ti)), fmaf(m.z, k, -(wi.z * eta_ti)));
-                    float f2 = f_sqr(eta_ti);
-                    w = V(f2 * sh->spec_trans[0], f2 * sh->spec_trans[1], f2 * sh->spec_trans[2]);
-                    float dom = v_dot(bs_wo, m);
-                    dwh_dwo = (f_sqr(bs_eta) * dom) / f_sqr(dwm + bs_eta * dom);
-                }
-                float g1 = ggx_smith_g1(g, bs_wo, m);
-                bs_pdf *= fabsf(dwh_dwo);
-                if (mpdf != 0.f) bsdf_weight = v_mul(w, g1);
-            }
-        } else if (hit && si.shape->bsdf == ORC_BSDF_ROUGHCONDUCTOR) {
-            /* RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF */
-            const orc_shape *sh = si.shape;
-            v3 wi = si.wi, wo_l = wo;
-            if (sh->twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }   /* twosided.cpp:219-258 flips both */
-            ggx_t g = ggx_make(sh->alpha_u, sh->alpha_v);
-            if (wi.z > 0.f && wo_l.z > 0.f) {
-                v3 H = v_normalize(v_add(wo_l, wi));
-                float D = ggx_eval(g, H);
-                if (D != 0.f) {   /* eval :317-375 */
-                    float G = ggx_smith_g1(g, wi, H) * ggx_smith_g1(g, wo_l, H);
-                    float result = D * G / (4.f * wi.z), c = v_dot(wi, H);
-                    bsdf_val = V(fresnel_conductor(c, sh->cond_eta[0], sh->cond_k[0]) * (result * sh->spec_refl[0]),
-                                 fresnel_conductor(c, sh->cond_eta[1], sh->cond_k[1]) * (result * sh->spec_refl[1]),
-                                 fresnel_conductor(c, sh->cond_eta[2], sh->cond_k[2]) * (result * sh->spec_refl[2]));
-                }
-                if (v_dot(wi, H) > 0.f && v_dot(wo_l, H) > 0.f)   /* pdf :377-415 */
-                    bsdf_pdf = ggx_eval(g, H) * ggx_smith_g1(g, wi, H) / (4.f * wi.z);
-            }
-            if (wi.z > 0.f) {   /* sample :229-315 */
-                float mpdf;
-                v3 m = ggx_sample(g, wi, s2x, s2y, &mpdf);
-                float dwm = v_dot(wi, m);
-                v3 r = V(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   /* reflect(wi, m) fresnel.h:282-284 */
-                bs_wo = r; bs_eta = 1.f;
-                int ok = mpdf != 0.f && r.z > 0.f;
-                float weight = ggx_smith_g1(g, r, m);
-                bs_pdf = mpdf / (4.f * v_dot(r, m));
-                if (ok) bsdf_weight = V(fresnel_conductor(dwm, sh->cond_eta[0], sh->cond_k[0]) * (weight * sh->spec_refl[0]),
-                                        fresnel_conductor(dwm, sh->cond_eta[1], sh->cond_k[1]) * (weight * sh->spec_refl[1]),
-                                        fresnel_conductor(dwm, sh->cond_eta[2], sh->cond_k[2]) * (weight * sh->spec_refl[2]));
-                if (sh->twosided && si.wi.z < 0.f) bs_wo.z = -bs_wo.z;
-            }
-        } else if (hit && si.shape->bsdf == ORC_BSDF_ROUGHPLASTIC) {
-            /* RoughPlastic::sample (roughplastic.cpp:259-331) under TwoSidedBRDF; eval / pdf in rough_plastic_eval_pdf */
-            const orc_shape *sh = si.shape;
-            v3 wi = si.wi, wo_l = wo;
-            if (sh->twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
-            ggx_t g = ggx_make(sh->alpha_u, sh->alpha_u);
-            if (wi.z > 0.f) {
-                float t_i = lerp_gather64(sh->rough_table, wi.z);
-                float prob_specular = (1.f - t_i) * sh->spec_sampling_weight, prob_diffuse = t_i * (1.f - sh->spec_sampling_weight);
-                prob_specular = prob_specular / (prob_specular + prob_diffuse);
-                prob_diffuse = 1.f - prob_specular;
-                if (wo_l.z > 0.f) rough_plastic_eval_pdf(g, sh, wi, wo_l, t_i, prob_specular, prob_diffuse, &bsdf_val, &bsdf_pdf);
-                if (sample_1 < prob_specular) {
-                    float mpdf; v3 m = ggx_sample(g, wi, s2x, s2y, &mpdf);
-                    float dwm = v_dot(wi, m);
-                    bs_wo = V(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   /* reflect(wi, m) */
-                } else bs_wo = square_to_cosine_hemisphere(s2x, s2y);
-                bs_eta = 1.f;
-                v3 value = V(0, 0, 0);
-                if (bs_wo.z > 0.f) rough_plastic_eval_pdf(g, sh, wi, bs_wo, t_i, prob_specular, prob_diffuse, &value, &bs_pdf);
-                if (bs_pdf > 0.f) bsdf_weight = v_mul(value, f_rcp(bs_pdf));   /* Spectrum / Float: times the reciprocal */
-                if (sh->twosided && si.wi.z < 0.f) bs_wo.z = -bs_wo.z;
-            }
-        } else if (hit && si.shape->bsdf == ORC_BSDF_PLASTIC) {
-            /* SmoothPlastic::eval / pdf / sample (plastic.cpp:219-360) under TwoSidedBRDF (twosided.cpp:111-148,219-258) */
-            const orc_shape *sh = si.shape;
-            float wiz = si.wi.z, woz = wo.z;
-            if (sh->twosided) { woz = f_mulsign(woz, wiz); wiz = fabsf(wiz); }
-            float f_i, tmp1, tmp2, tmp3;
-            fresnel_dielectric(wiz, sh->diel_eta, &f_i, &tmp1, &tmp2, &tmp3);
-            const float w = sh->spec_sampling_weight;
-            v3 diff = V(sh->reflectance[0], sh->reflectance[1], sh->reflectance[2]);
-            diff = sh->nonlinear ? V(diff.x / (1.f - diff.x * sh->fdr_int), diff.y / (1.f - diff.y * sh->fdr_int), diff.z / (1.f - diff.z * sh->fdr_int))
-                                 : V(diff.x / (1.f - sh->fdr_int), diff.y / (1.f - sh->fdr_int), diff.z / (1.f - sh->fdr_int));
-            if (wiz > 0.f && woz > 0.f) {   /* eval (:309-332) and pdf (:334-360) of the diffuse lobe */
-                float f_o; fresnel_dielectric(woz, sh->diel_eta, &f_o, &tmp1, &tmp2, &tmp3);
-                float k = ORC_INV_PI_F * woz * sh->inv_eta_2 * (1.f - f_i) * (1.f - f_o);
-                bsdf_val = V(diff.x * k, diff.y * k, diff.z * k);
-                float prob_specular = f_i * w, prob_diffuse = (1.f - f_i) * (1.f - w);
-                prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
-                bsdf_pdf = ORC_INV_PI_F * woz * prob_diffuse;
-            }
-            if (wiz > 0.f) {                /* sample (:219-307) */
-                float prob_specular = f_i * w, prob_diffuse = (1.f - f_i) * (1.f - w);
-                prob_specular = prob_specular / (prob_specular + prob_diffuse);
-                prob_diffuse = 1.f - prob_specular;
-                bs_eta = 1.f;
-                if (sample_1 < prob_specular) {
-                    bs_wo = V(-si.wi.x, -si.wi.y, wiz);   /* reflect() of the (possibly flipped) wi */
-                    bs_pdf = prob_specular; bs_delta = 1;
-                    float value = f_i / bs_pdf;
-                    bsdf_weight = V(value * sh->spec_refl[0], value * sh->spec_refl[1], value * sh->spec_refl[2]);
-                } else {
-                    bs_wo = square_to_cosine_hemisphere(s2x, s2y);
-                    bs_pdf = prob_diffuse * (ORC_INV_PI_F * bs_wo.z);
-                    float f_o; fresnel_dielectric(bs_wo.z, sh->diel_eta, &f_o, &tmp1, &tmp2, &tmp3);
-                    float k = sh->inv_eta_2 * (1.f - f_i) * (1.f - f_o) / prob_diffuse;
-                    bsdf_weight = V(diff.x * k, diff.y * k, diff.z * k);
-                }
-                if (sh->twosided) bs_wo.z = f_mulsign(bs_wo.z, si.wi.z);
-            }
-        } else if (hit) {
-            const orc_shape *sh = si.shape;
-            float wiz = si.wi.z, woz = wo.z;
-            if (sh->twosided) { woz = f_mulsign(woz, wiz); wiz = fabsf(wiz); }
-            if (wiz > 0.f && woz > 0.f) {
-                bsdf_val = V(sh->reflectance[0] * ORC_INV_PI_F * woz, sh->reflectance[1] * ORC_INV_PI_F * woz,
-                             sh->reflectance[2] * ORC_INV_PI_F * woz);
-                bsdf_pdf = ORC_INV_PI_F * woz;
-            }
-            if (wiz > 0.f) {
-                bs_wo = square_to_cosine_hemisphere(s2x, s2y);
-                bs_pdf = ORC_INV_PI_F * bs_wo.z;
-                bs_eta = 1.f;
-                if (bs_pdf > 0.f) bsdf_weight = V(sh->reflectance[0], sh->reflectance[1], sh->reflectance[2]);
-                if (sh->twosided) bs_wo.z = f_mulsign(bs_wo.z, si.wi.z);
-            }
+        if (hit) {
+            orc_bsdf_out bo;
+            bsdf_eval_pdf_sample(si.shape, si.wi, wo, active_em, sample_1, s2x, s2y, &bo);
+            bsdf_val = bo.val; bsdf_pdf = bo.pdf; bsdf_weight = bo.weight; bs_wo = bo.wo; bs_pdf = bo.bs_pdf; bs_eta = bo.bs_eta; bs_delta = bo.bs_delta;
         }
         if (active_em) {   /* :214-226 */
             float mis_em = ds_delta ? 1.f : mis_weight(ds_pdf, bsdf_pdf);
@@ -1737,8 +1926,8 @@ static float rough_integral(ggx_t g, v3 wi, float eta, int transmit) {
     }
     return result;
 }
-void orc_roughplastic_tables(float alpha, float eta, float *table64, float *internal_reflectance) {
-    ggx_t g = ggx_make(alpha, alpha);
+void orc_roughplastic_tables(int type, float alpha, float eta, float *table64, float *internal_reflectance) {
+    ggx_t g = mf_make(type, alpha, alpha, 1);
     float sum = 0.f;
     for (int i = 0; i < 64; ++i) {
         float mu = f_max(1e-6f, fmaf((float) i, 1.f / 63.f, 0.f));
@@ -1748,3 +1937,73 @@ void orc_roughplastic_tables(float alpha, float eta, float *table64, float *inte
     }
     *internal_reflectance = sum * (1.f / 64.f) * 2.f;
 }
+
+/* ------------------------------------------------------------------ known-answer entry points
+ * Thin wrappers that expose the building blocks eval_lane is made of, so that tests/test_oracle_reference_kats.py can hold
+ * them against the numbers of the reference's own unit tests (tests/golden/reference_kats.json.gz). */
+void orc_kat_microfacet(int type, float au, float av, int visible, int fn, const float *in, float *out) {
+    ggx_t g = mf_make(type, au, av, visible);
+    switch (fn) {
+        case 0: out[0] = ggx_eval(g, V(in[0], in[1], in[2])); break;
+        case 1: out[0] = ggx_pdf(g, V(in[0], in[1], in[2]), V(in[3], in[4], in[5])); break;
+        case 2: out[0] = ggx_smith_g1(g, V(in[0], in[1], in[2]), V(in[3], in[4], in[5])); break;
+        default: { v3 m = ggx_sample(g, V(in[0], in[1], in[2]), in[3], in[4], out + 3); out[0] = m.x; out[1] = m.y; out[2] = m.z; }
+    }
+}
+float orc_kat_filter(int kind, float radius, float stddev, float B, float C, float x) {
+    orc_sensor se; memset(&se, 0, sizeof se);
+    se.filter = kind; se.filter_radius = radius; se.filter_stddev = stddev; se.filter_b = B; se.filter_c = C;
+    float gc[10];
+    if (kind == ORC_FILTER_BOX) return (x >= -radius && x < radius) ? 1.f : 0.f;   /* BoxFilter::eval (src/rfilters/box.cpp) */
+    if (kind == ORC_FILTER_GAUSSIAN) gaussian_coeffs(stddev, radius, gc);
+    float v = filter_eval(&se, x, 1.f / radius, gc);
+    return fabsf(x) < radius ? v : 0.f;
+}
+void orc_kat_warp(int fn, const float *in, float *out) {
+    switch (fn) {
+        case 0: { v3 d = square_to_cosine_hemisphere(in[0], in[1]); out[0] = d.x; out[1] = d.y; out[2] = d.z; } break;
+        case 1: { v3 d = square_to_cosine_hemisphere(in[0], in[1]); out[0] = d.x; out[1] = d.y; } break;   /* x, y = the concentric disk */
+        case 3: square_to_uniform_triangle(in[0], in[1], out, out + 1); break;
+        default: { v3 d = square_to_uniform_sphere(in[0], in[1]); out[0] = d.x; out[1] = d.y; out[2] = d.z; }
+    }
+}
+void orc_kat_frame(const float *n, float *out6) {
+    v3 s, t; coordinate_system(V(n[0], n[1], n[2]), &s, &t);
+    out6[0] = s.x; out6[1] = s.y; out6[2] = s.z; out6[3] = t.x; out6[4] = t.y; out6[5] = t.z;
+}
+/* Scene::ray_intersect: out = t, p[3], n[3], sh_n[3], sh_s[3], sh_t[3], dp_du[3], dp_dv[3], wi[3] (25 floats); returns hit */
+int orc_kat_ray_intersect(const orc_scene *sc, const float *o, const float *d, float time, float maxt, float *out, int32_t *ids) {
+    v3 ro = V(o[0], o[1], o[2]), rd = V(d[0], d[1], d[2]);
+    orc_hit h = scene_closest(sc, ro, rd, time, maxt);
+    ids[0] = h.obj; ids[1] = h.shape; ids[2] = h.prim;
+    memset(out, 0, 25 * sizeof(float));
+    if (h.obj < 0) { out[0] = INFINITY; return 0; }
+    orc_si si; memset(&si, 0, sizeof si);
+    compute_si(sc, &h, ro, rd, time, &si);
+    const v3 *f[8] = { &si.p, &si.n, &si.sh_n, &si.sh_s, &si.sh_t, &si.dp_du, &si.dp_dv, &si.wi };
+    out[0] = h.t;
+    for (int i = 0; i < 8; ++i) { out[1 + 3 * i] = f[i]->x; out[2 + 3 * i] = f[i]->y; out[3 + 3 * i] = f[i]->z; }
+    return 1;
+}
+/* BSDF::eval / pdf for `wo` and BSDF::sample with (sample1, sample2) of shape `sh`'s BSDF at local incident direction wi:
+ * out = value[3], pdf, bs.wo[3], bs.pdf, bs.eta, bs.delta, weight[3] (13 floats) */
+void orc_kat_bsdf(const orc_shape *sh, const float *wi, const float *wo, const float *s3, float *out) {
+    orc_bsdf_out r;
+    bsdf_eval_pdf_sample(sh, V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]), 1, s3[0], s3[1], s3[2], &r);
+    out[0] = r.val.x; out[1] = r.val.y; out[2] = r.val.z; out[3] = r.pdf;
+    out[4] = r.wo.x; out[5] = r.wo.y; out[6] = r.wo.z; out[7] = r.bs_pdf; out[8] = r.bs_eta; out[9] = (float) r.bs_delta;
+    out[10] = r.weight.x; out[11] = r.weight.y; out[12] = r.weight.z;
+}
+/* Sphere::sample_direction: out = p[3], n[3], d[3], dist, pdf */
+void orc_kat_sphere_sample_direction(const orc_shape *sh, const float *ref, float s_x, float s_y, float *out) {
+    v3 p, n, d; float dist, pdf;
+    sphere_sample_direction(sh, V(ref[0], ref[1], ref[2]), s_x, s_y, &p, &n, &d, &dist, &pdf);
+    out[0] = p.x; out[1] = p.y; out[2] = p.z; out[3] = n.x; out[4] = n.y; out[5] = n.z; out[6] = d.x; out[7] = d.y; out[8] = d.z;
+    out[9] = dist; out[10] = pdf;
+}
+float orc_kat_shape_area(const orc_shape *sh) { return f_rcp(shape_inv_area(sh)); }
+/* ImageBlock::put of one sample with values (rgb, 1) into a crop_w x crop_h x 4 film */
+void orc_kat_splat(const orc_sensor *se, float *film, float x, float y, const float *rgb) {
+    splat(se, film, x, y, (int) floorf(x), (int) floorf(y), rgb);
+}
+int orc_kat_solve_quadratic(double a, double b, double c, double *out2) { return solve_quadratic_d(a, b, c, out2, out2 + 1); }

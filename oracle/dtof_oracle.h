@@ -75,6 +75,7 @@ typedef struct {
     /* roughplastic (src/bsdfs/roughplastic.cpp), GGX + visible normals: the plastic fields with fdr_int = m_internal_reflectance,
      * alpha_u = alpha, and m_external_transmittance (64 values, orc_roughplastic_tables) */
     const float *rough_table;
+    int32_t mf_type;         /* microfacet distribution of the rough BSDFs: 0 beckmann, 1 ggx (microfacet.h MicrofacetType) */
 } orc_shape;
 
 typedef struct {
@@ -216,7 +217,7 @@ float    orc_fresnel_conductor(float cos_theta_i, float eta, float k);
 /* RoughPlastic::parameters_changed (src/bsdfs/roughplastic.cpp:222-257) for a GGX distribution: table64 = m_external_transmittance
  * (eval_transmittance, include/mitsuba/render/microfacet.h:515-566, on mu = max(1e-6, linspace(0, 1, 64))), *internal_reflectance =
  * mean(eval_reflectance(1 / eta) * mu) * 2 (microfacet.h:463-512); Gauss-Legendre nodes from core/quad.h:27-86 */
-void     orc_roughplastic_tables(float alpha, float eta, float *table64, float *internal_reflectance);
+void     orc_roughplastic_tables(int type, float alpha, float eta, float *table64, float *internal_reflectance);
 void     orc_gauss_legendre(int n, float *nodes, float *weights);
 /* SpotLight constructor (src/emitters/spot.cpp:91-99) in float32: degrees -> out4 = cutoff (rad), cos(cutoff), cos(beam), 1 / (cutoff - beam) */
 void     orc_spot_params(float cutoff_deg, float beam_deg, float *out4);
@@ -235,6 +236,25 @@ void     orc_bake_sphere(const float *to_world, const float *to_object, const fl
  * -1 for an empty mesh / no probability mass. */
 int      orc_mesh_area_table(const float *positions, int32_t n_faces, const uint32_t *faces, float *pmf, float *cdf,
                              float *sum, float *norm, int32_t *lo, int32_t *hi);
+
+/* ---- restated Dr.Jit math (Cephes expf / logf / tanf, Cephes series + A&S 7.1.26 erf, Giles erfinv) */
+float    orc_expf(float x);
+float    orc_logf(float x);
+float    orc_tanf(float x);
+float    orc_erff(float x);
+float    orc_erfinvf(float x);
+
+/* ---- known-answer entry points (see the end of dtof_oracle.c) */
+void     orc_kat_microfacet(int type, float au, float av, int visible, int fn, const float *in, float *out);
+float    orc_kat_filter(int kind, float radius, float stddev, float B, float C, float x);
+void     orc_kat_warp(int fn, const float *in, float *out);
+void     orc_kat_frame(const float *n, float *out6);
+int      orc_kat_ray_intersect(const orc_scene *sc, const float *o, const float *d, float time, float maxt, float *out25, int32_t *ids);
+void     orc_kat_bsdf(const orc_shape *sh, const float *wi, const float *wo, const float *s3, float *out13);
+void     orc_kat_sphere_sample_direction(const orc_shape *sh, const float *ref, float s_x, float s_y, float *out11);
+float    orc_kat_shape_area(const orc_shape *sh);
+void     orc_kat_splat(const orc_sensor *se, float *film, float x, float y, const float *rgb);
+int      orc_kat_solve_quadratic(double a, double b, double c, double *out2);
 
 #ifdef __cplusplus
 }

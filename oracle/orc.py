@@ -29,7 +29,7 @@ class OrcShape(C.Structure):
                 ("bsdf", C.c_int32), ("cond_eta", C.c_float * 3), ("cond_k", C.c_float * 3), ("spec_refl", C.c_float * 3),
                 ("spec_trans", C.c_float * 3), ("diel_eta", C.c_float), ("nonlinear", C.c_int32),
                 ("inv_eta_2", C.c_float), ("fdr_int", C.c_float), ("spec_sampling_weight", C.c_float),
-                ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("rough_table", C.POINTER(C.c_float))]
+                ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("rough_table", C.POINTER(C.c_float)), ("mf_type", C.c_int32)]
 
 
 class OrcGroup(C.Structure):
@@ -85,12 +85,12 @@ LANE_DTYPE = np.dtype([("sample_pos", "<f4", 2), ("time", "<f4"), ("ray_o", "<f4
 _ROUGH_CACHE = {}
 
 
-def rough_plastic_tables(alpha, eta):
-    """(m_external_transmittance[64], m_internal_reflectance) of a GGX roughplastic -- orc_roughplastic_tables"""
-    key = (float(np.float32(alpha)), float(np.float32(eta)))
+def rough_plastic_tables(alpha, eta, mf_type=1):
+    """(m_external_transmittance[64], m_internal_reflectance) of a roughplastic -- orc_roughplastic_tables"""
+    key = (float(np.float32(alpha)), float(np.float32(eta)), int(mf_type))
     if key not in _ROUGH_CACHE:
         table, ir = np.zeros(64, np.float32), C.c_float()
-        lib().orc_roughplastic_tables(C.c_float(key[0]), C.c_float(key[1]), table.ctypes.data, C.byref(ir))
+        lib().orc_roughplastic_tables(int(mf_type), C.c_float(key[0]), C.c_float(key[1]), table.ctypes.data, C.byref(ir))
         _ROUGH_CACHE[key] = (table, np.float32(ir.value))
     return _ROUGH_CACHE[key]
 
@@ -144,7 +144,7 @@ def lib():
         L.orc_spot_params.argtypes = [C.c_float, C.c_float, C.c_void_p]
         L.orc_acos.restype = C.c_float
         L.orc_acos.argtypes = [C.c_float]
-        L.orc_roughplastic_tables.argtypes = [C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_float)]
+        L.orc_roughplastic_tables.argtypes = [C.c_int, C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_float)]
         L.orc_gauss_legendre.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.orc_fresnel_dielectric.argtypes = [C.c_float, C.c_float, C.c_void_p]
         L.orc_fresnel_conductor.restype = C.c_float
@@ -154,6 +154,23 @@ def lib():
         L.orc_mesh_area_table.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_bake_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                     C.c_void_p, C.c_void_p]
+        for nm in ("orc_expf", "orc_logf", "orc_tanf", "orc_erff", "orc_erfinvf"):
+            getattr(L, nm).restype = C.c_float
+            getattr(L, nm).argtypes = [C.c_float]
+        L.orc_kat_microfacet.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_kat_filter.restype = C.c_float
+        L.orc_kat_filter.argtypes = [C.c_int] + [C.c_float] * 5
+        L.orc_kat_warp.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_kat_frame.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_kat_ray_intersect.restype = C.c_int
+        L.orc_kat_ray_intersect.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_kat_bsdf.argtypes = [C.POINTER(OrcShape), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_kat_sphere_sample_direction.argtypes = [C.POINTER(OrcShape), C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.orc_kat_shape_area.restype = C.c_float
+        L.orc_kat_shape_area.argtypes = [C.POINTER(OrcShape)]
+        L.orc_kat_splat.argtypes = [C.POINTER(OrcSensor), C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.orc_kat_solve_quadratic.restype = C.c_int
+        L.orc_kat_solve_quadratic.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -190,6 +207,7 @@ class Scene:
                 setattr(o, key, (C.c_float * 3)(*np.asarray(s.get(key, [0, 0, 0]), np.float32).tolist()))
             o.diel_eta = float(s.get("diel_eta", 1.0))
             o.alpha_u, o.alpha_v = float(s.get("alpha_u", 0.1)), float(s.get("alpha_v", 0.1))
+            o.mf_type = int(s.get("mf_type", 1))
             if o.bsdf == 3:   # plastic: SmoothPlastic::parameters_changed in C float32
                 o.nonlinear = int(s.get("nonlinear", 0))
                 out3 = (C.c_float * 3)()
@@ -198,7 +216,7 @@ class Scene:
                 s["plastic_params"] = np.array(list(out3), np.float32)
             if o.bsdf == 5:   # roughplastic: RoughPlastic::parameters_changed in C float32 (cached per (alpha, eta))
                 o.nonlinear = int(s.get("nonlinear", 0))
-                table, ir = rough_plastic_tables(o.alpha_u, o.diel_eta)
+                table, ir = rough_plastic_tables(o.alpha_u, o.diel_eta, o.mf_type)
                 self._keep.append(table)
                 o.rough_table = C.cast(table.ctypes.data, C.POINTER(C.c_float))
                 eta = np.float32(o.diel_eta)

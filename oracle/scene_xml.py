@@ -377,9 +377,7 @@ def _bsdf_of(props, registry):
         distr = props.get_s("distribution", "beckmann").lower()
         if distr not in ("beckmann", "ggx"):
             raise ValueError('Specified an invalid distribution "%s", must be "beckmann" or "ggx"!' % distr)
-        if distr != "ggx":
-            raise ValueError('roughdielectric: only distribution "ggx" is implemented (the Beckmann distribution needs Dr.Jit\'s erf / erfinv '
-                             'approximations, whose source is not part of the reference tree)')
+        rec.update(mf_type=int(distr == "ggx"))   # MicrofacetType: 0 beckmann, 1 ggx
         if not props.get_b("sample_visible", True):
             raise ValueError("roughdielectric: only sample_visible = true is implemented")
         if "alpha_u" in props or "alpha_v" in props:
@@ -399,9 +397,7 @@ def _bsdf_of(props, registry):
         distr = props.get_s("distribution", "beckmann").lower()
         if distr not in ("beckmann", "ggx"):
             raise ValueError('Specified an invalid distribution "%s", must be "beckmann" or "ggx"!' % distr)
-        if distr != "ggx":
-            raise ValueError('roughconductor: only distribution "ggx" is implemented (the Beckmann distribution needs Dr.Jit\'s erf / erfinv '
-                             'approximations, whose source is not part of the reference tree)')
+        rec.update(mf_type=int(distr == "ggx"))   # MicrofacetType: 0 beckmann, 1 ggx
         if not props.get_b("sample_visible", True):
             raise ValueError("roughconductor: only sample_visible = true is implemented")
         if "alpha_u" in props or "alpha_v" in props:
@@ -430,9 +426,7 @@ def _bsdf_of(props, registry):
         distr = props.get_s("distribution", "beckmann").lower()
         if distr not in ("beckmann", "ggx"):
             raise ValueError('Specified an invalid distribution "%s", must be "beckmann" or "ggx"!' % distr)
-        if distr != "ggx":
-            raise ValueError('roughplastic: only distribution "ggx" is implemented (the Beckmann distribution needs Dr.Jit\'s erf / erfinv '
-                             'approximations, whose source is not part of the reference tree)')
+        rec.update(mf_type=int(distr == "ggx"))   # MicrofacetType: 0 beckmann, 1 ggx
         if not props.get_b("sample_visible", True):
             raise ValueError("roughplastic: only sample_visible = true is implemented")
         if "alpha_u" in props or "alpha_v" in props:

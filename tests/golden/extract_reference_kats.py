@@ -67,6 +67,9 @@ FILES = [
     "src/films/tests/test_hdrfilm.py",          # I1
 ]
 
+# files whose assertions relate two Mitsuba computations to each other (instanced == plain shape): kept as relations
+RELATIONS = ("src/shapes/tests/test_instance.py",)
+
 MAX_LOOP = 700          # iterations of one `for`
 MAX_RECORDS_PER_TEST = 3000
 MAX_PARAM_COMBOS = 64
@@ -176,7 +179,10 @@ def f32(x):
 
 
 def _linspace(_t, a, b, n, endpoint=True):
-    return np.linspace(float(a), float(b), int(n), endpoint=bool(endpoint)).astype(F32)
+    # drjit linspace: step = (max - min) / (n - endpoint) in float32, value_i = fmadd(i, step, min)
+    lo, hi = F32(a), F32(b)
+    step = F32((hi - lo) / F32(int(n) - (1 if endpoint else 0))) if int(n) > 1 else F32(0)
+    return (np.arange(int(n), dtype=np.float64) * np.float64(step) + np.float64(lo)).astype(F32)
 
 
 def _meshgrid(x, y):     # drjit.meshgrid default indexing 'xy': x varies fastest
@@ -216,11 +222,20 @@ DR = {
     "select": lambda c, a, b: np.where(c, a, b), "clamp": lambda x, a, b: np.clip(x, a, b), "clip": lambda x, a, b: np.clip(x, a, b),
     "eval": lambda *a: None,
 }
+def _named(name, fn):
+    def g(*a, **k):
+        return fn(*a, **k)
+    g.__name__ = name
+    return g
+
+
+DR = {k: (_named("dr." + k, v) if callable(v) else v) for k, v in DR.items()}
 FLOAT = object()      # the type token mi.Float / drjit.scalar.ArrayXf
 UINT = object()
 
 
 def mi_vector(*a):
+    """mi.Vector3f / Point3f / ... : plain numbers"""
     if len(a) == 1:
         a = a[0]
     if has_sym(a):
@@ -478,7 +493,7 @@ class Interp:
             if a in ("astype", "reshape", "tolist", "copy", "flatten", "ravel"):
                 return getattr(base, a)
             raise Unknown("ndarray." + a)
-        if isinstance(base, dict) and a in ("keys", "values", "items", "get"):
+        if isinstance(base, dict) and a in ("keys", "values", "items", "get", "copy"):
             return getattr(base, a)
         if isinstance(base, (list, tuple)):
             comp = {"x": 0, "y": 1, "z": 2, "w": 3}
@@ -516,7 +531,11 @@ class Interp:
             if has_sym(args) or has_sym(kwargs):
                 # numeric helper applied to symbolic data (e.g. dr.abs(si.t - 1)): keep it symbolic
                 nm = getattr(fn, "__name__", "fn")
-                return Sym("call", Sym("name", name="fn." + nm), args=[freeze(a) for a in args], kwargs=kwargs)
+                if fn is mi_vector:
+                    nm = "vector"
+                if not nm.startswith("dr."):
+                    nm = "fn." + nm
+                return Sym("call", Sym("name", name=nm), args=[freeze(a) for a in args], kwargs=kwargs)
             try:
                 with np.errstate(all="ignore"):
                     return fn(*args, **kwargs)
@@ -615,7 +634,16 @@ class Interp:
                     self.poison(st.target, env, str(e))
             elif isinstance(st, ast.Expr):
                 try:
-                    self.ev(st.value, env)
+                    v = self.ev(st.value, env)
+                    if isinstance(v, Sym) and isinstance(st.value, ast.Call):
+                        for a in list(st.value.args) + [k.value for k in st.value.keywords]:
+                            if isinstance(a, ast.Name) and isinstance(env.get(a.id), (np.ndarray, list)):
+                                env[a.id] = Unknown("possibly written by a Mitsuba call")
+                    # a method called for its side effect on a Mitsuba object (`ib.put(pos=..., values=...)`): remember it on the object
+                    if isinstance(v, Sym) and v.kind == "call" and isinstance(v.base, Sym) and v.base.kind == "attr" \
+                            and isinstance(v.base.base, Sym) and v.base.base.kind == "call":
+                        v.base.base.attrs.setdefault("__calls__", []).append(
+                            {"method": v.base.name, "args": [freeze(a) for a in v.args], "kwargs": {k: freeze(x) for k, x in v.kwargs.items()}})
                 except Unknown:
                     pass
             elif isinstance(st, ast.Assert):
@@ -630,7 +658,7 @@ class Interp:
                     self.poison(st.target, env, "loop")
                     return None
                 for v in it[:MAX_LOOP]:
-                    if self.n_test_records >= MAX_RECORDS_PER_TEST:
+                    if self.n_test_records >= (700 if self.relpath in RELATIONS else MAX_RECORDS_PER_TEST):
                         break
                     try:
                         self.bind(st.target, v, env)
@@ -647,9 +675,11 @@ class Interp:
                 if has_sym(c):
                     # a branch taken only if Mitsuba says so (e.g. `if si_found:`): its assertions are conditional
                     self.cond_depth = getattr(self, "cond_depth", 0) + 1
+                    self.cond_stack = getattr(self, "cond_stack", []) + [freeze(c)]
                     e2 = dict(env)
                     self.run_block(st.body, e2)
                     self.cond_depth -= 1
+                    self.cond_stack = self.cond_stack[:-1]
                     for k in e2:
                         if k not in env or e2[k] is not env.get(k):
                             env[k] = Unknown("assigned under a symbolic condition")
@@ -685,6 +715,10 @@ class Interp:
                     env[nm] = UINT
                 elif mod == "math":
                     env[nm] = getattr(math, a.name)
+                elif mod == "mitsuba" and a.name in MI_NUMERIC:
+                    env[nm] = MI_NUMERIC[a.name]
+                elif mod == "mitsuba" and a.name in ("Transform4f", "ScalarTransform4f"):
+                    env[nm] = XFTYPE
                 elif mod.startswith("mitsuba"):
                     env[nm] = Sym("name", name="mi." + mod[len("mitsuba"):].lstrip(".") + ("." if len(mod) > 7 else "") + a.name)
 
@@ -724,7 +758,8 @@ class Interp:
                 rec = dict(kind="truth", lhs=v, rhs=True)
         except Unknown:
             return
-        if rec is None or has_sym(rec["lhs"]) == has_sym(rec["rhs"]):
+        both = has_sym(rec["lhs"]) and has_sym(rec["rhs"]) if rec is not None else False
+        if rec is None or (has_sym(rec["lhs"]) == has_sym(rec["rhs"]) and not (both and self.relpath in RELATIONS)):
             return      # a known answer relates something Mitsuba computes (one side) to plain numbers (the other side)
         if rec["kind"] in ("Is", "IsNot"):
             return      # `x is not None`
@@ -732,8 +767,9 @@ class Interp:
             return      # statistical tests need the reference's own sampler loop
         if getattr(self, "cond_depth", 0) > 1:
             return      # nested Mitsuba-dependent conditions (finite-difference checks inside `if hit: if hit2:`)
-        rec.update(file=self.relpath, line=st.lineno, test=self.test, params=self.binding,
-                   conditional=getattr(self, "cond_depth", 0) > 0)
+        rec.update(file=self.relpath, line=st.lineno, test=self.test, params=self.binding)
+        if getattr(self, "cond_depth", 0) > 0:
+            rec["conditions"] = list(self.cond_stack)     # the assertion only applies when Mitsuba makes all of these true
         try:
             rec = to_json(rec)
         except Unknown:
@@ -783,12 +819,16 @@ def to_json(v):
     if isinstance(v, Xf):
         return {"transform": v.m.tolist()}
     if isinstance(v, np.ndarray):
+        if v.ndim >= 2:
+            return {"nd": v.astype(np.float64).tolist()}      # a numpy matrix (row-major), as opposed to a Dr.Jit array of components
         if v.dtype == np.float32:
             return {"f32": v.tolist()}
         if v.dtype.kind in "iu":
             return v.tolist()
         if v.dtype.kind == "b":
             return v.tolist()
+        if v.ndim >= 2:
+            return {"nd": v.astype(np.float64).tolist()}      # a numpy matrix (row-major), as opposed to a Dr.Jit array of components
         return v.astype(np.float64).tolist()
     if isinstance(v, np.generic):
         return v.item()
@@ -866,7 +906,7 @@ def harvest(relpath):
                 except Unknown:
                     clean[k] = None
             it.test, it.binding, it.n_test_records = st.name, clean or None, 0
-            it.cond_depth = 0
+            it.cond_depth, it.cond_stack = 0, []
             it.run_block(st.body, e)
     return it.records
 
