@@ -78,15 +78,10 @@ def parse():
                          "4-row stripes + one film reduce(sum) (load balance, SURVEY 8e; default for the Domino configs c4 / c5)")
     ap.add_argument("--stripe-rows", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra scaling figures (the other scaling mode of c2, strong-scaling c4)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU oracle sample")
     args = ap.parse_args()
-    scene, res, spp, defines, offsets = CONFIGS[args.config]
-    args.scene = args.scene or os.path.join(HERE, "scenes", scene)
-    args.res = args.res or res
-    args.spp = args.spp or spp
-    args.defines, args.offsets = dict(defines), offsets
-    if args.sharding == "auto":
-        args.sharding = "stripes" if os.path.basename(args.scene).startswith("domino") else "bands"
+    args.scene_given, args.res_given, args.spp_given = args.scene, args.res, args.spp
     return args
 
 
@@ -140,7 +135,111 @@ def cpu_baseline(scene_path, res, spp, target_s, defines):
                       "the %dx%d %d-spp frame x %d seeds = %d paths in %.1f s" % (r0, r0 + rows, res, res, spp, reps, total, dt)}
 
 
+def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_override=None, res_override=None, scene_override=None):
+    """Times `steps` renders of one workload on the ranks of ctx (after `warmup` untimed ones), barrier + synchronize on both
+    sides, MAX over ranks.  Returns the raw figures; rank 0 also gets the developed image and the undeveloped film."""
+    import torch
+    import torch.distributed as dist
+    mi, D, dev, world, rank, share = ctx["mi"], ctx["D"], ctx["dev"], ctx["world"], ctx["rank"], ctx["share"]
+    scene_file, res, spp0, defines, offsets = CONFIGS[cfg]
+    scene_path = scene_override or os.path.join(HERE, "scenes", scene_file)
+    res = res_override or res
+    spp0 = spp_override or spp0
+    if sharding == "auto":
+        sharding = "stripes" if os.path.basename(scene_path).startswith("domino") else "bands"
+    scene = mi.load_file(scene_path, **dict(defines, resx=res, resy=res))
+    striped = world > 1 and sharding == "stripes"
+    if offsets and world > 1 and not striped:
+        raise SystemExit("batched-offset configs shard with --sharding stripes (the band gather carries one film)")
+    W, H = scene.size
+    halo = int(scene.info()["filter_halo"])      # rows a splat reaches beyond its pixel: ceil(radius - 0.5) (imageblock.cpp:423-426)
+    spp = spp0 * world if scaling == "weak" else spp0
+    r0, r1 = D.row_band(H, world, rank)
+    pad_rows = D.padded_rows(H, world, halo)
+    film = torch.zeros((pad_rows, W, 4), dtype=torch.float32, device=dev)
+    film_ptr = film.data_ptr() + halo * W * 4 * 4
+    p0, p1 = D.slab_range(H, world, rank, halo)
+    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    gather_buf = torch.empty((world, p1 - p0, W, 4), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+    lib = mi._lib()
+    keys = ("ms_trace", "ms_shade", "ms_shadow", "ms_generate", "ms_splat", "ms_total", "ms_first", "n_bounces", "n_shadow_rays", "n_paths")
+    acc = dict.fromkeys(keys, 0.0)
+    acc.update(launches=0, first_launches=0)
+    K = len(offsets) if offsets else 1
+    native = bool(offsets) or striped            # library-native [K][H][W][4] films (K offsets in ONE traversal, config c5)
+    if native:
+        kfilm = torch.zeros((K, H, W, 4), dtype=torch.float32, device=dev)
+        krgb = torch.zeros((K, H, W, 3), dtype=torch.float32, device=dev)
+
+    def develop(src, dst, n):
+        if lib.dtof_develop(src.data_ptr(), dst.data_ptr(), n) != 0:
+            raise RuntimeError(lib.dtof_last_error().decode())
+
+    def step(record):
+        film.zero_()
+        if native:
+            kfilm.zero_()
+        torch.cuda.synchronize()
+        if native:
+            if striped:               # interleaved stripes of rows per rank, ONE reduce(sum) of the full-size films to rank 0
+                st = scene.render_stripes(kfilm.data_ptr(), 0, spp, *D.stripe_layout(world, rank, stripe_rows), offsets=offsets)
+                if share:
+                    host = kfilm.cpu(); dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                    if rank == 0:
+                        kfilm.copy_(host)
+                else:
+                    dist.reduce(kfilm, dst=0, op=dist.ReduceOp.SUM)
+            else:
+                st = scene.render_rows(kfilm.data_ptr(), seed=0, spp=spp, row_begin=0, row_end=H, offsets=offsets)
+            if rank == 0:
+                develop(kfilm, krgb, H * W * K)
+        else:
+            st = scene.render_rows(film_ptr, seed=0, spp=spp, row_begin=r0, row_end=r1)   # synchronises the library's stream
+            stack = D.gather_film_stacked(film[p0:p1], rank, world, out=gather_buf)
+            if rank == 0:
+                full = D.overlap_add_stacked(stack, H, world, halo) if world > 1 else film[halo:halo + H]
+                develop(full.contiguous(), rgb, H * W)
+        if record:
+            for k in keys:
+                acc[k] += st[k]
+            acc["launches"] += st["n_launches_shade"]; acc["first_launches"] += st["n_launches_first"]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step(False)
+    barrier()
+    per_step = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts = time.perf_counter()
+        step(True)
+        torch.cuda.synchronize()
+        per_step.append(time.perf_counter() - ts)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed] + per_step, dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = t.cpu().numpy()
+    elapsed, per_step = float(t[0]), np.sort(t[1:])
+    total_paths = W * H * spp
+    out = dict(acc=acc, elapsed=elapsed, steps=steps, W=W, H=H, spp=spp, spp_per_gpu=spp0, total_paths=total_paths, halo=halo, striped=striped, offsets=offsets,
+               defines=defines, scene_path=scene_path, res=res,
+               value=total_paths * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3,
+               ms_per_step_min=float(per_step[0]) * 1e3, ms_per_step_median=float(np.median(per_step)) * 1e3)
+    if rank == 0:
+        out["image"] = (krgb if native else rgb).cpu().numpy()
+        out["film"] = None if native else film[halo:halo + H].cpu().numpy()
+    return out
+
+
 def main():
+    # the host driver only supports dmabuf IPC: must be in the environment BEFORE the HIP / HSA runtime initialises
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse()
     sys.path.insert(0, os.path.join(HERE, "scenes"))
     import make_scenes
@@ -167,101 +266,42 @@ def main():
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    backend = None
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = "gloo" if share else "nccl"
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    if world > 1:
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
         dist.barrier()            # rank 0 may just have written the scene files
-    scene = mi.load_file(args.scene, **dict(args.defines, resx=args.res, resy=args.res))
-    striped = world > 1 and args.sharding == "stripes"
-    if args.offsets and world > 1 and not striped:
-        raise SystemExit("batched-offset configs shard with --sharding stripes (the band gather carries one film)")
-    W, H = scene.size
-    halo = 1                                     # tent filter, radius 1 (imageblock.cpp:423-426)
-    spp = args.spp * world if args.scaling == "weak" else args.spp
-    r0, r1 = D.row_band(H, world, rank)
-    pad_rows = D.padded_rows(H, world, halo)
-    film = torch.zeros((pad_rows, W, 4), dtype=torch.float32, device=dev)
-    film_ptr = film.data_ptr() + halo * W * 4 * 4
-    p0, p1 = D.slab_range(H, world, rank, halo)
-    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    gather_buf = torch.empty((world, p1 - p0, W, 4), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
-    lib = mi._lib()
+    ctx = dict(mi=mi, D=D, dev=dev, world=world, rank=rank, share=share)
 
-    acc = {"ms_trace": 0.0, "ms_shade": 0.0, "ms_shadow": 0.0, "ms_generate": 0.0, "ms_splat": 0.0, "ms_total": 0.0, "ms_first": 0.0,
-           "n_bounces": 0, "n_shadow_rays": 0, "n_paths": 0, "launches": 0, "first_launches": 0}
-
-    K = len(args.offsets) if args.offsets else 1
-    if args.offsets or striped:
-        kfilm = torch.zeros((K, H, W, 4), dtype=torch.float32, device=dev)
-        krgb = torch.zeros((K, H, W, 3), dtype=torch.float32, device=dev)
-
-    def step(record):
-        film.zero_()
-        if args.offsets or striped:
-            kfilm.zero_()
-        torch.cuda.synchronize()
-        if args.offsets or striped:   # library-native [K][H][W][4] films (K offsets in ONE traversal, config c5)
-            if striped:               # interleaved stripes of rows per rank, ONE reduce(sum) of the full-size films to rank 0
-                st = scene.render_stripes(kfilm.data_ptr(), 0, spp, *D.stripe_layout(world, rank, args.stripe_rows), offsets=args.offsets)
-                if share:
-                    host = kfilm.cpu(); dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-                    if rank == 0:
-                        kfilm.copy_(host)
-                else:
-                    dist.reduce(kfilm, dst=0, op=dist.ReduceOp.SUM)
-            else:
-                st = scene.render_rows(kfilm.data_ptr(), seed=0, spp=spp, row_begin=0, row_end=H, offsets=args.offsets)
-            if rank == 0:
-                rc = lib.dtof_develop(kfilm.data_ptr(), krgb.data_ptr(), H * W * K)
-                if rc != 0:
-                    raise RuntimeError(lib.dtof_last_error().decode())
-            if record:
-                for k in ("ms_trace", "ms_shade", "ms_shadow", "ms_generate", "ms_splat", "ms_total", "ms_first", "n_bounces", "n_shadow_rays", "n_paths"):
-                    acc[k] += st[k]
-                acc["launches"] += st["n_launches_shade"]; acc["first_launches"] += st["n_launches_first"]
-            return
-        st = scene.render_rows(film_ptr, seed=0, spp=spp, row_begin=r0, row_end=r1)   # synchronises the library's stream
-        stack = D.gather_film_stacked(film[p0:p1], rank, world, out=gather_buf)
-        if rank == 0:
-            full = D.overlap_add_stacked(stack, H, world, halo) if world > 1 else film[halo:halo + H]
-            full = full.contiguous()
-            rc = lib.dtof_develop(full.data_ptr(), rgb.data_ptr(), H * W)
-            if rc != 0:
-                raise RuntimeError(lib.dtof_last_error().decode())
-        if record:
-            for k in ("ms_trace", "ms_shade", "ms_shadow", "ms_generate", "ms_splat", "ms_total", "ms_first", "n_bounces", "n_shadow_rays", "n_paths"):
-                acc[k] += st[k]
-            acc["launches"] += st["n_launches_shade"]; acc["first_launches"] += st["n_launches_first"]
-
-    def barrier():
+    r = run_workload(ctx, args.config, args.scaling, args.steps, args.warmup, args.sharding, args.stripe_rows,
+                     spp_override=args.spp_given, res_override=args.res_given, scene_override=args.scene_given)
+    # Besides the headline line: the OTHER scaling mode of the same workload and BASELINE configs[3] (Domino, 1024^2 x 128 spp, a fixed
+    # frame sharded in interleaved stripes = strong scaling; north_star's ">= 0.9 parallel efficiency" refers to this one), a few steps
+    # each, so that one driver run per N yields weak AND strong curves.  Skipped with --no-extra and for non-default workloads.
+    extra = {}
+    default_run = args.config == "c2" and not (args.spp_given or args.res_given or args.scene_given)
+    if default_run and not args.no_extra:
+        other = "strong" if args.scaling == "weak" else "weak"
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            e = run_workload(ctx, "c2", other, max(5, args.steps // 2), 2, "bands", args.stripe_rows)
+            extra["c2_" + other] = {"value": round(e["value"], 2), "unit": "Mpaths/s", "scaling": other, "ms_per_step": round(e["ms_per_step"], 4),
+                                     "ms_per_step_min": round(e["ms_per_step_min"], 4), "spp_total": e["spp"], "paths_per_step": e["total_paths"]}
+        e = run_workload(ctx, "c4", "strong", 4, 1, "stripes", args.stripe_rows)
+        extra["c4_strong"] = {"value": round(e["value"], 2), "unit": "Mpaths/s", "scaling": "strong", "ms_per_step": round(e["ms_per_step"], 4),
+                              "ms_per_step_min": round(e["ms_per_step_min"], 4), "paths_per_step": e["total_paths"],
+                              "workload": "BASELINE configs[3]: domino.xml 1024x1024, 128 spp in total, rectangular low-pass, interleaved %d-row stripes, 1 film reduce"
+                                          % args.stripe_rows}
 
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-    total_paths = W * H * spp
-    ms_per_step = elapsed / args.steps * 1e3
-    value = total_paths * args.steps / elapsed / 1e6
-
+    acc, W, H, spp, striped, halo = r["acc"], r["W"], r["H"], r["spp"], r["striped"], r["halo"]
+    total_paths, ms_per_step, value = r["total_paths"], r["ms_per_step"], r["value"]
+    args.offsets, args.defines, args.scene, args.res, args.spp = r["offsets"], r["defines"], r["scene_path"], r["res"], r["spp_per_gpu"]
     if rank == 0:
-        img = (krgb if (args.offsets or striped) else rgb).cpu().numpy()
+        img, film_host = r["image"], r["film"]
         # the dominant kernel = the bounce kernel k_shade<MODE 1|0>.  In the fused pipeline the FIRST launch of a frame is another
         # instantiation (MODE 2: lane generation + primary ray + bounce 0, reads no state at all); it is timed separately
         # (ms_first) and kept out of the roofline figure, as rocprofv3 lists it as a separate kernel too.
@@ -303,6 +343,7 @@ def main():
             "metric": "Mpaths/s (whole node), Doppler Cornell 512x512 64spp" if args.config == "c2" else
                       "Mpaths/s (whole node), BASELINE config %s" % args.config, "value": round(value, 2), "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_min": round(r["ms_per_step_min"], 4), "ms_per_step_median": round(r["ms_per_step_median"], 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (("cornell_wall (Cornell box, one linearly translating wall) %dx%d, %d spp%s, sinusoidal "
                                     "heterodyne hetero_frequency=1, stratified time sampling, max_depth 4, tent filter") if args.config == "c2" else
@@ -312,6 +353,8 @@ def main():
                        "paths_per_step": total_paths, "sharding": ("interleaved %d-row stripes, 1 film reduce" % args.stripe_rows if striped else "row bands, 1 film gather") if world > 1 else "none",
                        "image_checksum": float(np.abs(img).sum())},
             "roofline": roofline,
+            "extra": extra,
+            "process_group": {"backend": backend, "world_size": world},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.scene, args.res, args.spp, args.cpu_seconds, args.defines)
@@ -321,7 +364,7 @@ def main():
                 # left on the GPU (same seed, same spp); the band's first and last row miss the splats of their outer neighbours
                 # in the oracle's partial render and are left out.  SURVEY 8(d): per-pixel relative L-inf, target <= 1e-3.
                 band, b0, b1 = cpu_baseline.band0
-                gpu = film[halo:halo + H].cpu().numpy()
+                gpu = film_host
                 dev_img = lambda f: np.where(f[..., 3:4] != 0, f[..., :3] / np.where(f[..., 3:4] != 0, f[..., 3:4], 1), 0)
                 a, b = dev_img(gpu[b0 + 1:b1 - 1]), dev_img(band[b0 + 1:b1 - 1])
                 if a.size:

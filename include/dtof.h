@@ -106,6 +106,7 @@ int dtof_scene_get_info(const dtof_scene *scene, dtof_scene_info *info);
  *                             whose fdr_int slot carries m_internal_reflectance)
  * kind 11: spot emitters   -> per spot 22 floats: position[3], intensity[3], world-to-local[12], cutoff angle (rad), cos(cutoff), cos(beam width),
  *                             1 / (cutoff - beam width) (src/emitters/spot.cpp:75-100)
+ * kind 12: microfacet distribution of the rough BSDFs -> per shape 1 float: 0 beckmann, 1 ggx (MicrofacetType, include/mitsuba/render/microfacet.h:30-36)
  * kind 10: roughplastic tables -> per roughplastic shape the 64 values of m_external_transmittance (roughplastic.cpp:222-257)
  * Returns the number of floats written (<= capacity) through *n_written. */
 int dtof_scene_export(const dtof_scene *scene, int kind, float *out, size_t capacity, size_t *n_written);
@@ -202,6 +203,35 @@ uint32_t dtof_sampler_sample_count(const dtof_sampler *s);
  * shade kernel uses.  mode 0: weight(ray_time=t[i], path_length=len[i]) with the scene's integrator;
  * mode 1: eval_modulation_function_value(t[i]); mode 2: ..._low_pass(t[i]). */
 int dtof_eval_modulation(dtof_scene *scene, int mode, const float *t, const float *len, float *out, uint32_t n);
+
+/* ---------------------------------------------------------------- ray queries
+ * Scene::ray_intersect / Scene::ray_test (include/mitsuba/render/scene.h; src/render/scene.cpp -> scene_embree.inl:202-333,349-426) over
+ * arrays, through the same TLAS / BLAS traversal and surface-interaction code the render kernels use.  rays8: per ray o[3], d[3], time,
+ * maxt.  out19: t (inf on a miss), p[3], n[3], sh_frame.n[3], sh_frame.s[3], sh_frame.t[3], wi[3]; ids3: object, shape-in-group,
+ * primitive (-1 on a miss).  dtof_ray_test writes 1 / 0 per ray. */
+int dtof_ray_intersect(dtof_scene *scene, uint32_t n, const float *rays8, float *out19, int32_t *ids3);
+int dtof_ray_test(dtof_scene *scene, uint32_t n, const float *rays8, int32_t *occluded);
+
+/* ---------------------------------------------------------------- component evaluation
+ * The device functions the shade and splat kernels are built from, evaluated over arrays on the GPU: the counterpart of the
+ * free functions / small classes the reference exposes to its unit tests (mi.fresnel, mi.MicrofacetDistribution, mi.warp.*,
+ * ReconstructionFilter::eval, ...), so that the reference's own known answers (tests/golden/reference_kats.json.gz) can be held
+ * against the GPU code.  Element i reads in[i * in_stride ...] and writes out[i * out_stride ...]; `params` are per-call scalars. */
+#define DTOF_COMP_MICROFACET_EVAL          0   /* MicrofacetDistribution::eval (microfacet.h:176-196). params: type (0 beckmann, 1 ggx), alpha_u, alpha_v, sample_visible; in m[3]; out 1 */
+#define DTOF_COMP_MICROFACET_PDF           1   /* ::pdf (:219-228); in wi[3], m[3]; out 1 */
+#define DTOF_COMP_MICROFACET_G1            2   /* ::smith_g1 (:341-365); in v[3], m[3]; out 1 */
+#define DTOF_COMP_MICROFACET_SAMPLE        3   /* ::sample (:240-325); in wi[3], sample[2]; out m[3], pdf */
+#define DTOF_COMP_FRESNEL                  4   /* fresnel (fresnel.h:21-63). params: eta; in cos_theta_i; out r, cos_theta_t, eta_it, eta_ti */
+#define DTOF_COMP_FRESNEL_CONDUCTOR        5   /* fresnel_conductor (fresnel.h:93-117). params: eta, k; in cos_theta_i; out 1 */
+#define DTOF_COMP_RFILTER                  6   /* ReconstructionFilter::eval. params: kind (0 box, 1 tent, 2 gaussian, 3 mitchell, 4 catmullrom), radius, stddev, B, C; in x; out 1 */
+#define DTOF_COMP_WARP_COSINE_HEMISPHERE   7   /* warp::square_to_cosine_hemisphere (warp.h:320-344); in sample[2]; out 3 */
+#define DTOF_COMP_WARP_DISK_CONCENTRIC     8   /* warp::square_to_uniform_disk_concentric (warp.h:54-90); out 2 */
+#define DTOF_COMP_WARP_UNIFORM_TRIANGLE    9   /* warp::square_to_uniform_triangle (warp.h:153-156); out 2 */
+#define DTOF_COMP_WARP_UNIFORM_SPHERE     10   /* warp::square_to_uniform_sphere (warp.h:250-255); out 3 */
+#define DTOF_COMP_COORDINATE_SYSTEM       11   /* coordinate_system (vector.h:116-136) = Frame3f(n); in n[3]; out s[3], t[3] */
+#define DTOF_COMP_TEA_FLOAT32             12   /* sample_tea_float32 (random.h:33-67), 4 rounds; in v0, v1 (uint32 bit patterns); out 1 */
+#define DTOF_COMP_MATH                    13   /* restated Dr.Jit math. params: 0 exp, 1 log, 2 tan, 3 erf, 4 erfinv, 5 sin, 6 cos, 7 acos; in x; out 1 */
+int dtof_eval_component(int component, const float *params, int n_params, const float *in, int in_stride, float *out, int out_stride, uint32_t n);
 
 #ifdef __cplusplus
 }

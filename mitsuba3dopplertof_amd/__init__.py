@@ -121,6 +121,9 @@ def _lib():
     L.dtof_sampler_set_sample_count.argtypes = [vp, C.c_uint32]
     L.dtof_sampler_seeded.argtypes = [vp]
     L.dtof_eval_modulation.argtypes = [vp, C.c_int, vp, vp, vp, C.c_uint32]
+    L.dtof_eval_component.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_uint32]
+    L.dtof_ray_intersect.argtypes = [vp, C.c_uint32, vp, vp, vp]
+    L.dtof_ray_test.argtypes = [vp, C.c_uint32, vp, vp]
     _LIB = L
     return L
 
@@ -243,8 +246,48 @@ class Scene:
                                            out.ctypes.data, t.size))
         return out
 
+    @staticmethod
+    def _rays(o, d, time, maxt):
+        o, d = np.atleast_2d(np.asarray(o, np.float32)), np.atleast_2d(np.asarray(d, np.float32))
+        n = max(len(o), len(d))
+        rays = np.zeros((n, 8), np.float32)
+        rays[:, 0:3], rays[:, 3:6], rays[:, 6] = o, d, time
+        rays[:, 7] = np.finfo(np.float32).max if maxt is None else maxt
+        return rays
+
+    def ray_intersect(self, o, d, time=0.0, maxt=None):
+        """Scene::ray_intersect over arrays of rays -> dict(t, p, n, sh_n, sh_s, sh_t, wi, ids) (dtof_ray_intersect)"""
+        rays = self._rays(o, d, time, maxt)
+        out, ids = np.zeros((len(rays), 19), np.float32), np.zeros((len(rays), 3), np.int32)
+        _check(_lib().dtof_ray_intersect(self._h, len(rays), rays.ctypes.data, out.ctypes.data, ids.ctypes.data))
+        return {"t": out[:, 0], "p": out[:, 1:4], "n": out[:, 4:7], "sh_n": out[:, 7:10], "sh_s": out[:, 10:13], "sh_t": out[:, 13:16],
+                "wi": out[:, 16:19], "ids": ids}
+
+    def ray_test(self, o, d, time=0.0, maxt=None):
+        """Scene::ray_test over arrays of rays -> bool array (dtof_ray_test)"""
+        rays = self._rays(o, d, time, maxt)
+        occ = np.zeros(len(rays), np.int32)
+        _check(_lib().dtof_ray_test(self._h, len(rays), rays.ctypes.data, occ.ctypes.data))
+        return occ != 0
+
     def cancel(self):
         _lib().dtof_cancel(self._h)
+
+
+# DTOF_COMP_* of include/dtof.h
+COMPONENTS = {"microfacet_eval": (0, 1), "microfacet_pdf": (1, 1), "microfacet_g1": (2, 1), "microfacet_sample": (3, 4), "fresnel": (4, 4),
+              "fresnel_conductor": (5, 1), "rfilter": (6, 1), "warp_cosine_hemisphere": (7, 3), "warp_disk_concentric": (8, 2),
+              "warp_uniform_triangle": (9, 2), "warp_uniform_sphere": (10, 3), "coordinate_system": (11, 6), "tea_float32": (12, 1), "math": (13, 1)}
+
+
+def eval_component(name, inputs, params=()):
+    """dtof_eval_component: one of the device functions the kernels are built from, over the rows of `inputs` (n x k float32)"""
+    comp, n_out = COMPONENTS[name]
+    x = np.ascontiguousarray(np.atleast_2d(np.asarray(inputs, np.float32)))
+    p = np.ascontiguousarray(np.asarray(params, np.float32).reshape(-1))
+    out = np.zeros((len(x), n_out), np.float32)
+    _check(_lib().dtof_eval_component(comp, p.ctypes.data if p.size else None, p.size, x.ctypes.data, x.shape[1], out.ctypes.data, n_out, len(x)))
+    return out
 
 
 class Integrator:

@@ -106,4 +106,14 @@ void launch_sampler_next_1d(const RenderParams &rp, const SamplerState &st, floa
 void launch_sampler_next_time(const RenderParams &rp, const SamplerState &st, uint32_t sample_index_base, float *out, hipStream_t s);
 void launch_waveform_eval(const RenderParams &rp, const float *t, const float *len, float *out, int mode, uint32_t n, hipStream_t s);
 
+// component evaluation (dtof_eval_component; the ids are the DTOF_COMP_* values of include/dtof.h)
+enum { COMP_MICROFACET_EVAL = 0, COMP_MICROFACET_PDF = 1, COMP_MICROFACET_G1 = 2, COMP_MICROFACET_SAMPLE = 3, COMP_FRESNEL = 4,
+       COMP_FRESNEL_CONDUCTOR = 5, COMP_RFILTER = 6, COMP_WARP_COSINE_HEMISPHERE = 7, COMP_WARP_DISK_CONCENTRIC = 8,
+       COMP_WARP_UNIFORM_TRIANGLE = 9, COMP_WARP_UNIFORM_SPHERE = 10, COMP_COORDINATE_SYSTEM = 11, COMP_TEA_FLOAT32 = 12, COMP_MATH = 13,
+       COMP_COUNT = 14 };
+struct ComponentArgs { int component; float p[8]; const float *in; int in_stride; float *out; int out_stride; uint32_t n; };
+void launch_component(const ComponentArgs &a, const RenderParams &rp, hipStream_t s);
+// Scene::ray_intersect / ray_test over arrays
+void launch_ray_query(const uint8_t *scene, const float *rays, float *out, int32_t *ids, uint32_t n, bool any, uint32_t stack_depth, hipStream_t s);
+
 }  // namespace dtof

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
                 bsdf_weight = selected_r ? mk(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]) : mk(sh->spec_trans[0], sh->spec_trans[1], sh->spec_trans[2]);
             } else if (SPEC && sh->bsdf == BSDF_ROUGHDIELECTRIC) {
                 // RoughDielectric::eval_pdf / sample (roughdielectric.cpp:240-346,503-611): glossy reflection and transmission lobes
-                const Ggx g = ggx_make(sh->alpha_u, sh->alpha_v);
+                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, sh->alpha_u, sh->alpha_v);
                 const V3 wi = si.wi;
                 if (active_em) rough_dielectric_eval_pdf(g, sh, wi, wo, bsdf_val, bsdf_pdf);
                 if (wi.z != 0.f) {
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
                 // RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF
                 V3 wi = si.wi, wo_l = wo;
                 if (twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
-                const Ggx g = ggx_make(sh->alpha_u, sh->alpha_v);
+                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, sh->alpha_u, sh->alpha_v);
                 if (wi.z > 0.f && wo_l.z > 0.f) {
                     const V3 H = normalize(wo_l + wi);
                     const float D = ggx_eval(g, H);
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
                 // RoughPlastic::eval / pdf / sample (roughplastic.cpp:259-421), GGX + visible normals, under TwoSidedBRDF
                 V3 wi = si.wi, wo_l = wo;
                 if (twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
-                const Ggx g = ggx_make(sh->alpha_u, sh->alpha_u);
+                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, sh->alpha_u, sh->alpha_u);
                 const float *table = (const float *) (sv.base + sh->rough_table);
                 const float w = sh->spec_sampling_weight, ir = sh->fdr_int;
                 const V3 diff = sh->nonlinear ? mk(refl.x / (1.f - refl.x * ir), refl.y / (1.f - refl.y * ir), refl.z / (1.f - refl.z * ir))
@@ -980,6 +980,77 @@ void launch_sampler_next_time(const RenderParams &rp, const SamplerState &st, ui
 }
 void launch_waveform_eval(const RenderParams &rp, const float *t, const float *len, float *out, int mode, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_waveform_eval, dim3(nblk(n)), dim3(kBlock), 0, s, rp, t, len, out, mode, n);
+}
+
+// ---------------------------------------------------------------------------- component evaluation (known-answer entry points)
+// dtof_eval_component: the device functions the shade / splat kernels are made of, over arrays.  One thread per element.
+__global__ void k_component(ComponentArgs a, RenderParams rp) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const float *in = a.in + (size_t) i * a.in_stride; float *out = a.out + (size_t) i * a.out_stride;
+    switch (a.component) {
+        case COMP_MICROFACET_EVAL: case COMP_MICROFACET_PDF: case COMP_MICROFACET_G1: case COMP_MICROFACET_SAMPLE: {
+            const Ggx g = mf_make((int) a.p[0], a.p[1], a.p[2], (int) a.p[3]);
+            if (a.component == COMP_MICROFACET_EVAL) out[0] = ggx_eval(g, mk(in[0], in[1], in[2]));
+            else if (a.component == COMP_MICROFACET_PDF) out[0] = ggx_pdf(g, mk(in[0], in[1], in[2]), mk(in[3], in[4], in[5]));
+            else if (a.component == COMP_MICROFACET_G1) out[0] = ggx_smith_g1(g, mk(in[0], in[1], in[2]), mk(in[3], in[4], in[5]));
+            else { float pdf; const V3 m = ggx_sample(g, mk(in[0], in[1], in[2]), in[3], in[4], pdf); out[0] = m.x; out[1] = m.y; out[2] = m.z; out[3] = pdf; }
+        } break;
+        case COMP_FRESNEL: fresnel_dielectric(in[0], a.p[0], out[0], out[1], out[2], out[3]); break;
+        case COMP_FRESNEL_CONDUCTOR: out[0] = fresnel_conductor(in[0], a.p[0], a.p[1]); break;
+        case COMP_RFILTER: {
+            const float x = in[0], r = rp.filter_radius;
+            if (rp.filter == FILTER_BOX) out[0] = (x >= -r && x < r) ? 1.f : 0.f;     // BoxFilter::eval (src/rfilters/box.cpp)
+            else out[0] = fabsf(x) < r ? filter_weight(rp, x) : 0.f;
+        } break;
+        case COMP_WARP_COSINE_HEMISPHERE: { const V3 d = cosine_hemisphere(in[0], in[1]); out[0] = d.x; out[1] = d.y; out[2] = d.z; } break;
+        case COMP_WARP_DISK_CONCENTRIC: concentric_disk(in[0], in[1], out[0], out[1]); break;
+        case COMP_WARP_UNIFORM_TRIANGLE: uniform_triangle(in[0], in[1], out[0], out[1]); break;
+        case COMP_WARP_UNIFORM_SPHERE: { const V3 d = uniform_sphere(in[0], in[1]); out[0] = d.x; out[1] = d.y; out[2] = d.z; } break;
+        case COMP_COORDINATE_SYSTEM: { V3 s, t; coordinate_system(mk(in[0], in[1], in[2]), s, t); out[0] = s.x; out[1] = s.y; out[2] = s.z; out[3] = t.x; out[4] = t.y; out[5] = t.z; } break;
+        case COMP_TEA_FLOAT32: { uint32_t v0, v1; tea32(f2u(in[0]), f2u(in[1]), v0, v1); out[0] = u2f((v1 >> 9) | 0x3f800000u) - 1.f; } break;   // sample_tea_float32 (random.h:63-67): the second word
+        case COMP_MATH: {
+            const float x = in[0]; const int fn = (int) a.p[0]; float s_, c_;
+            out[0] = fn == 0 ? exp_(x) : fn == 1 ? log_(x) : fn == 2 ? tan_(x) : fn == 3 ? erf_(x) : fn == 4 ? erfinv_(x)
+                   : fn == 5 ? (sincos_(x, s_, c_), s_) : fn == 6 ? cos_(x) : acos_(x);
+        } break;
+        default: break;
+    }
+}
+void launch_component(const ComponentArgs &a, const RenderParams &rp, hipStream_t s) {
+    if (a.n) hipLaunchKernelGGL(k_component, dim3(nblk(a.n)), dim3(kBlock), 0, s, a, rp);
+}
+
+// Scene::ray_intersect / ray_test over arrays (dtof_ray_intersect): closest hit + surface interaction, or occlusion only.
+// rays: o[3], d[3], time, maxt (8 floats); out: t, p[3], n[3], sh_n[3], sh_s[3], sh_t[3], wi[3] (19 floats); ids: object, shape, prim
+template <bool ANY>
+__global__ __launch_bounds__(64) void k_ray_query(const uint8_t *scene, const float *rays, float *out, int32_t *ids, uint32_t n) {
+    extern __shared__ uint4 lds[];
+    uint32_t *stack = (uint32_t *) lds + threadIdx.x;
+    const SceneView sv = make_view(scene);
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *r = rays + (size_t) i * 8;
+    const V3 o = mk(r[0], r[1], r[2]), d = mk(r[3], r[4], r[5]);
+    Hit h;
+    const bool found = trace_scene<ANY, true>(sv, stack, o, d, r[6], r[7], h);
+    if (ANY) { ids[i] = found ? 1 : 0; return; }
+    float *w = out + (size_t) i * 19;
+    for (int k = 0; k < 19; ++k) w[k] = 0.f;
+    ids[3 * i] = found ? (int32_t) h.obj : -1; ids[3 * i + 1] = found ? (int32_t) h.shape : -1; ids[3 * i + 2] = found ? (int32_t) h.prim : -1;
+    if (!found) { w[0] = u2f(0x7f800000u); return; }
+    Surface si;
+    compute_surface<true>(sv, h.obj, h.shape, h.prim, h.t, h.u, h.v, o, d, r[6], si);
+    w[0] = h.t;
+    const V3 f[6] = { si.p, si.n, si.sh_n, si.sh_s, si.sh_t, si.wi };
+    for (int k = 0; k < 6; ++k) { w[1 + 3 * k] = f[k].x; w[2 + 3 * k] = f[k].y; w[3 + 3 * k] = f[k].z; }
+}
+void launch_ray_query(const uint8_t *scene, const float *rays, float *out, int32_t *ids, uint32_t n, bool any, uint32_t stack_depth, hipStream_t s) {
+    if (!n) return;
+    const uint32_t lds = stack_bytes(stack_depth, 64);
+    check_lds(lds);
+    if (any) hipLaunchKernelGGL(k_ray_query<true>, dim3((n + 63) / 64), dim3(64), lds, s, scene, rays, out, ids, n);
+    else hipLaunchKernelGGL(k_ray_query<false>, dim3((n + 63) / 64), dim3(64), lds, s, scene, rays, out, ids, n);
 }
 
 }  // namespace dtof

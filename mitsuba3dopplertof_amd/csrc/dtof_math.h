@@ -165,22 +165,146 @@ DTOF_HD void fresnel_dielectric(float cos_theta_i, float eta, float &r, float &c
     if (special_case) r = index_matched ? 0.f : 1.f;
     cos_theta_t = mulsign_neg(cos_theta_t_abs, cos_theta_i);
 }
-// ---- MicrofacetDistribution, GGX, sample_visible = true (include/mitsuba/render/microfacet.h)
-struct Ggx { float au, av; };
-DTOF_HD Ggx ggx_make(float au, float av) { Ggx g; g.au = fmax_(au, 1e-4f); g.av = fmax_(av, 1e-4f); return g; }   // configure() :425-428
+// exp / log / tan / erf / erfinv: Dr.Jit's dr::exp, dr::log, dr::tan, dr::erf, dr::erfinv (drjit/math.h) are not in the reference tree.
+// Restated from the published single-precision kernels Dr.Jit's math library derives from -- Cephes expf / logf / tanf, the Cephes erff
+// series inside |x| < 1 with Abramowitz & Stegun 7.1.26 outside, M. Giles' single-precision erfinv polynomial -- with explicit fmaf, so
+// that host, device and the oracle produce the same bits.  Needed by the Beckmann distribution (microfacet.h:176-196,240-290,341-403).
+DTOF_HD float exp_(float x) {
+    if (x > 88.72283905206835f) return u2f(0x7f800000u);
+    if (x < -103.278929903431851103f) return 0.f;
+    const float z = floorf(fmaf(1.44269504088896341f, x, 0.5f));
+    x = fmaf(z, -0.693359375f, x);
+    x = fmaf(z, 2.12194440e-4f, x);
+    const int32_t n = (int32_t) z;
+    const float x2 = x * x;
+    float p = fmaf(1.9875691500e-4f, x, 1.3981999507e-3f);
+    p = fmaf(p, x, 8.3334519073e-3f);
+    p = fmaf(p, x, 4.1665795894e-2f);
+    p = fmaf(p, x, 1.6666665459e-1f);
+    p = fmaf(p, x, 5.0000001201e-1f);
+    const float r = fmaf(p, x2, x) + 1.f;
+    const int32_t n1 = n / 2, n2 = n - n1;          // ldexp in two exact power-of-two factors
+    return r * u2f((uint32_t) (n1 + 127) << 23) * u2f((uint32_t) (n2 + 127) << 23);
+}
+DTOF_HD float log_(float x) {
+    if (x < 0.f) return u2f(0x7fc00000u);
+    if (x == 0.f) return u2f(0xff800000u);
+    if (!(x < u2f(0x7f800000u))) return x;
+    uint32_t u = f2u(x); int32_t e = 0;
+    if (u < 0x00800000u) { x *= 8388608.f; u = f2u(x); e = -23; }
+    e += (int32_t) (u >> 23) - 126;
+    float m = u2f((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.f; } else m = m - 1.f;
+    const float z = m * m;
+    float y = fmaf(7.0376836292e-2f, m, -1.1514610310e-1f);
+    y = fmaf(y, m, 1.1676998740e-1f);
+    y = fmaf(y, m, -1.2420140846e-1f);
+    y = fmaf(y, m, 1.4249322787e-1f);
+    y = fmaf(y, m, -1.6668057665e-1f);
+    y = fmaf(y, m, 2.0000714765e-1f);
+    y = fmaf(y, m, -2.4999993993e-1f);
+    y = fmaf(y, m, 3.3333331174e-1f);
+    y = y * m * z;
+    const float fe = (float) e;
+    y = fmaf(-2.12194440e-4f, fe, y);
+    y = fmaf(-0.5f, z, y);
+    return fmaf(0.693359375f, fe, m + y);
+}
+DTOF_HD float tan_(float xx) {
+    const float x = fabsf(xx);
+    int32_t j = (int32_t) (x * 1.2732395447351626862f);
+    j = (j + 1) & ~1;
+    const float y = (float) j;
+    float z = x - y * 0.78515625f;
+    z = z - y * 2.4187564849853515625e-4f;
+    z = z - y * 3.77489497744594108e-8f;
+    const float zz = z * z;
+    float p = fmaf(9.38540185543e-3f, zz, 3.11992232697e-3f);
+    p = fmaf(p, zz, 2.44301354525e-2f);
+    p = fmaf(p, zz, 5.34112807005e-2f);
+    p = fmaf(p, zz, 1.33387994085e-1f);
+    p = fmaf(p, zz, 3.33331568548e-1f);
+    float r = x > 1.0e-4f ? fmaf(p * zz, z, z) : z;
+    if (j & 2) r = -1.f / r;
+    return u2f(f2u(r) ^ (f2u(xx) & 0x80000000u));
+}
+DTOF_HD float erf_(float x) {
+    const float xa = fabsf(x);
+    if (xa < 1.f) {
+        const float z = x * x;
+        float p = fmaf(7.853861353153693e-5f, z, -8.010193625184903e-4f);
+        p = fmaf(p, z, 5.188327685732524e-3f);
+        p = fmaf(p, z, -2.685381193529856e-2f);
+        p = fmaf(p, z, 1.128358514861418e-1f);
+        p = fmaf(p, z, -3.761262582423300e-1f);
+        p = fmaf(p, z, 1.128379165726710e+0f);
+        return x * p;
+    }
+    const float t = 1.f / fmaf(0.3275911f, xa, 1.f);
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float r = fmaf(-(p * t), exp_(-(xa * xa)), 1.f);
+    return u2f(f2u(r) | (f2u(x) & 0x80000000u));
+}
+DTOF_HD float erfinv_(float x) {
+    float w = -log_((1.f - x) * (1.f + x)), p;
+    if (w < 5.f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = fmaf(p, w, 3.43273939e-07f);
+        p = fmaf(p, w, -3.5233877e-06f);
+        p = fmaf(p, w, -4.39150654e-06f);
+        p = fmaf(p, w, 0.00021858087f);
+        p = fmaf(p, w, -0.00125372503f);
+        p = fmaf(p, w, -0.00417768164f);
+        p = fmaf(p, w, 0.246640727f);
+        p = fmaf(p, w, 1.50140941f);
+    } else {
+        w = sqrtf(w) - 3.f;
+        p = -0.000200214257f;
+        p = fmaf(p, w, 0.000100950558f);
+        p = fmaf(p, w, 0.00134934322f);
+        p = fmaf(p, w, -0.00367342844f);
+        p = fmaf(p, w, 0.00573950773f);
+        p = fmaf(p, w, -0.0076224613f);
+        p = fmaf(p, w, 0.00943887047f);
+        p = fmaf(p, w, 1.00167406f);
+        p = fmaf(p, w, 2.83297682f);
+    }
+    return p * x;
+}
+// ---- MicrofacetDistribution (include/mitsuba/render/microfacet.h): Beckmann (type 0) and GGX (type 1).  The BSDF plugins sample
+// visible normals (their default, sample_visible = true); sampling all normals exists for the reference's known answers
+// (src/render/tests/test_microfacet.py) through dtof_eval_component.
+enum { MF_BECKMANN = 0, MF_GGX = 1 };
+struct Ggx { float au, av; int type; int visible; };
+DTOF_HD Ggx mf_make(int type, float au, float av, int visible = 1) {   // configure() :425-428
+    Ggx g; g.au = fmax_(au, 1e-4f); g.av = fmax_(av, 1e-4f); g.type = type; g.visible = visible; return g;
+}
 DTOF_HD float ggx_eval(Ggx g, V3 m) {   // eval() :176-196
-    const float result = rcp(kPi * (g.au * g.av) * sqr(sqr(m.x / g.au) + sqr(m.y / g.av) + sqr(m.z)));
+    const float alpha_uv = g.au * g.av, cos_theta_2 = sqr(m.z);
+    float result;
+    if (g.type == MF_BECKMANN) result = exp_(-(sqr(m.x / g.au) + sqr(m.y / g.av)) / cos_theta_2) / (kPi * alpha_uv * sqr(cos_theta_2));
+    else result = rcp(kPi * alpha_uv * sqr(sqr(m.x / g.au) + sqr(m.y / g.av) + sqr(m.z)));
     return result * m.z > 1e-20f ? result : 0.f;
 }
 DTOF_HD float ggx_smith_g1(Ggx g, V3 v, V3 m) {   // smith_g1() :341-365
     const float xy_alpha_2 = sqr(g.au * v.x) + sqr(g.av * v.y), tan_theta_alpha_2 = xy_alpha_2 / sqr(v.z);
-    float result = 2.f / (1.f + sqrtf(1.f + tan_theta_alpha_2));
+    float result;
+    if (g.type == MF_BECKMANN) {
+        const float a = rsqrt_(tan_theta_alpha_2), a_sqr = sqr(a);
+        result = a >= 1.6f ? 1.f : (3.535f * a + 2.181f * a_sqr) / (1.f + 2.276f * a + 2.577f * a_sqr);
+    } else result = 2.f / (1.f + sqrtf(1.f + tan_theta_alpha_2));
     if (xy_alpha_2 == 0.f) result = 1.f;
     if (dot(v, m) * v.z <= 0.f) result = 0.f;
     return result;
 }
-// pdf() :219-228, visible-normal branch (note the association: D * ((G1 * |wi.m|) / cos_theta_i), unlike the density sample() returns)
-DTOF_HD float ggx_pdf(Ggx g, V3 wi, V3 m) { return ggx_eval(g, m) * (ggx_smith_g1(g, wi, m) * fabsf(dot(wi, m)) / wi.z); }
+// pdf() :219-228 (note the association of the visible-normal branch: D * ((G1 * |wi.m|) / cos_theta_i), unlike the density sample() returns)
+DTOF_HD float ggx_pdf(Ggx g, V3 wi, V3 m) {
+    return g.visible ? ggx_eval(g, m) * (ggx_smith_g1(g, wi, m) * fabsf(dot(wi, m)) / wi.z) : ggx_eval(g, m) * m.z;
+}
 // warp::square_to_uniform_disk_concentric (include/mitsuba/core/warp.h:54-90)
 DTOF_HD void concentric_disk(float s_x, float s_y, float &px, float &py) {
     const float x = fmaf(2.f, s_x, -1.f), y = fmaf(2.f, s_y, -1.f);
@@ -192,20 +316,67 @@ DTOF_HD void concentric_disk(float s_x, float s_y, float &px, float &py) {
     float sn, cs; sincos_(phi, sn, cs);
     px = r * cs; py = r * sn;
 }
-// sample(), visible-normal branch :296-325 + sample_visible_11, GGX branch :405-420: microfacet normal and its density
+// sample_visible_11 (:368-420): slope of the visible normal for alpha = 1
+DTOF_HD void mf_sample_visible_11(int type, float cos_theta_i, float s_x, float s_y, float &slope_x, float &slope_y) {
+    if (type == MF_BECKMANN) {
+        const float inv_sqrt_pi = 0.56418958354775628695f;
+        const float tan_theta_i = safe_sqrt(fmaf(-cos_theta_i, cos_theta_i, 1.f)) / cos_theta_i, cot_theta_i = rcp(tan_theta_i);
+        const float maxval = erf_(cot_theta_i);
+        s_x = fmax_(fmin_(s_x, 1.f - 1e-6f), 1e-6f); s_y = fmax_(fmin_(s_y, 1.f - 1e-6f), 1e-6f);
+        float x = maxval - (maxval + 1.f) * erf_(sqrtf(-log_(s_x)));
+        s_x *= 1.f + maxval + inv_sqrt_pi * tan_theta_i * exp_(-sqr(cot_theta_i));
+        for (int i = 0; i < 3; ++i) {   // three Newton iterations
+            const float slope = erfinv_(x);
+            const float value = 1.f + x + inv_sqrt_pi * tan_theta_i * exp_(-sqr(slope)) - s_x, derivative = 1.f - slope * tan_theta_i;
+            x -= value / derivative;
+        }
+        slope_x = erfinv_(x); slope_y = erfinv_(fmaf(2.f, s_y, -1.f));
+        return;
+    }
+    float px, py; concentric_disk(s_x, s_y, px, py);
+    const float s = 0.5f * (1.f + cos_theta_i), a = safe_sqrt(1.f - sqr(px));
+    py = fmaf(py, s, fmaf(-a, s, a));                              // dr::lerp(a, py, s)
+    const float pz = safe_sqrt(1.f - fmaf(py, py, px * px));
+    const float sin_theta_i = safe_sqrt(1.f - sqr(cos_theta_i));
+    const float norm_ = rcp(fmaf(sin_theta_i, py, cos_theta_i * pz));
+    slope_x = fmaf(cos_theta_i, py, -(sin_theta_i * pz)) * norm_; slope_y = px * norm_;
+}
+// sample() :240-325: microfacet normal and its density
 DTOF_HD V3 ggx_sample(Ggx g, V3 wi, float s_x, float s_y, float &pdf) {
+    if (!g.visible) {   // all normals :242-290
+        float sin_phi, cos_phi, cos_theta, cos_theta_2, alpha_2;
+        if (g.au == g.av) {
+            sincos_((2.f * kPi) * s_y, sin_phi, cos_phi);
+            alpha_2 = g.au * g.au;
+        } else {
+            const float ratio = g.av / g.au, tmp = ratio * tan_((2.f * kPi) * s_y);
+            cos_phi = rsqrt_(fmaf(tmp, tmp, 1.f));
+            cos_phi = mulsign(cos_phi, fabsf(s_y - .5f) - .25f);
+            sin_phi = cos_phi * tmp;
+            alpha_2 = rcp(sqr(cos_phi / g.au) + sqr(sin_phi / g.av));
+        }
+        if (g.type == MF_BECKMANN) {
+            cos_theta = rsqrt_(fmaf(-alpha_2, log_(1.f - s_x), 1.f));
+            cos_theta_2 = sqr(cos_theta);
+            const float cos_theta_3 = fmax_(cos_theta_2 * cos_theta, 1e-20f);
+            pdf = (1.f - s_x) / (kPi * g.au * g.av * cos_theta_3);
+        } else {
+            const float tan_theta_m_2 = alpha_2 * s_x / (1.f - s_x);
+            cos_theta = rsqrt_(1.f + tan_theta_m_2);
+            cos_theta_2 = sqr(cos_theta);
+            const float temp = 1.f + tan_theta_m_2 / alpha_2, cos_theta_3 = fmax_(cos_theta_2 * cos_theta, 1e-20f);
+            pdf = rcp(kPi * g.au * g.av * cos_theta_3 * sqr(temp));
+        }
+        const float sin_theta = sqrtf(1.f - cos_theta_2);
+        return mk(cos_phi * sin_theta, sin_phi * sin_theta, cos_theta);
+    }
     const V3 wi_p = normalize(mk(g.au * wi.x, g.av * wi.y, wi.z));
     const float sin_theta_2 = fmaf(wi_p.x, wi_p.x, sqr(wi_p.y)), inv_sin_theta = rsqrt_(sin_theta_2);   // Frame3f::sincos_phi (frame.h:111-122)
     float rx = fmin_(fmax_(wi_p.x * inv_sin_theta, -1.f), 1.f), ry = fmin_(fmax_(wi_p.y * inv_sin_theta, -1.f), 1.f);
     if (fabsf(sin_theta_2) <= 4.f * 5.9604644775390625e-8f) { rx = 1.f; ry = 0.f; }
     const float sin_phi = ry, cos_phi = rx, cos_theta = wi_p.z;
-    float px, py; concentric_disk(s_x, s_y, px, py);
-    const float s = 0.5f * (1.f + cos_theta), a = safe_sqrt(1.f - sqr(px));
-    py = fmaf(py, s, fmaf(-a, s, a));                              // dr::lerp(a, py, s)
-    const float pz = safe_sqrt(1.f - fmaf(py, py, px * px));
-    const float sin_theta_i = safe_sqrt(1.f - sqr(cos_theta));
-    const float norm_ = rcp(fmaf(sin_theta_i, py, cos_theta * pz));
-    const float slope_x = fmaf(cos_theta, py, -(sin_theta_i * pz)) * norm_, slope_y = px * norm_;
+    float slope_x, slope_y;
+    mf_sample_visible_11(g.type, cos_theta, s_x, s_y, slope_x, slope_y);
     const float sx = fmaf(cos_phi, slope_x, -(sin_phi * slope_y)) * g.au, sy = fmaf(sin_phi, slope_x, cos_phi * slope_y) * g.av;
     const V3 m = normalize(mk(-sx, -sy, 1.f));
     pdf = ggx_eval(g, m) * ggx_smith_g1(g, wi, m) * fabsf(dot(wi, m)) / wi.z;

@@ -164,6 +164,18 @@ void sample_to_camera(const HostSensor &s, float *inv_out) {
     m4_mul(T1i, S1i, tmp); m4_mul(S2i, tmp, tmp); m4_mul(T2i, tmp, tmp); m4_mul(Pi, tmp, inv_out);
 }
 
+// the film's reconstruction filter as the splat kernels see it
+void set_filter(RenderParams &rp, int32_t filter, float radius, float stddev, float B, float C) {
+    rp.filter = filter; rp.filter_radius = radius; rp.inv_radius = 1.f / radius;
+    rp.filter_b = B; rp.filter_c = C;
+    if (filter == FILTER_GAUSSIAN) {   // GaussianFilter ctor (src/rfilters/gaussian.cpp:60-89), non-CUDA branch
+        static const double coeff[10] = { 9.992604880e-1, -4.977025247e-1, 1.222248550e-1, -1.932406282e-2, 2.136713061e-3,
+                                          -1.679873860e-4, 9.202145248e-6, -3.329417433e-7, 7.128382794e-9, -6.821193280e-11 };
+        double scale = 1;
+        for (int i = 0; i < 10; ++i) { rp.gauss_coeff[i] = (float) (coeff[i] * scale); scale /= (double) stddev * (double) stddev; }
+        rp.gauss_coeff[0] -= estrin10(radius * radius, rp.gauss_coeff);
+    }
+}
 RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, const float *offsets, int n_offsets) {
     const HostSensor &se = sc->host.sensor; const PluginParams &pp = sc->pp;
     RenderParams rp; memset(&rp, 0, sizeof rp);
@@ -174,15 +186,7 @@ RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, cons
     rp.crop_x = se.crop_x; rp.crop_y = se.crop_y; rp.crop_w = se.crop_w; rp.crop_h = se.crop_h;
     rp.scale_x = 1.f / (float) se.crop_w; rp.scale_y = 1.f / (float) se.crop_h;
     rp.offset_x = -(float) se.crop_x * rp.scale_x; rp.offset_y = -(float) se.crop_y * rp.scale_y;
-    rp.filter = se.filter; rp.filter_radius = se.filter_radius; rp.inv_radius = 1.f / se.filter_radius;
-    rp.filter_b = se.filter_b; rp.filter_c = se.filter_c;
-    if (se.filter == FILTER_GAUSSIAN) {   // GaussianFilter ctor (src/rfilters/gaussian.cpp:60-89), non-CUDA branch
-        static const double coeff[10] = { 9.992604880e-1, -4.977025247e-1, 1.222248550e-1, -1.932406282e-2, 2.136713061e-3,
-                                          -1.679873860e-4, 9.202145248e-6, -3.329417433e-7, 7.128382794e-9, -6.821193280e-11 };
-        double scale = 1;
-        for (int i = 0; i < 10; ++i) { rp.gauss_coeff[i] = (float) (coeff[i] * scale); scale /= (double) se.filter_stddev * (double) se.filter_stddev; }
-        rp.gauss_coeff[0] -= estrin10(se.filter_radius * se.filter_radius, rp.gauss_coeff);
-    }
+    set_filter(rp, se.filter, se.filter_radius, se.filter_stddev, se.filter_b, se.filter_c);
     rp.base_seed = pp.base_seed; rp.seed = seed; rp.seed_value = pp.base_seed + seed;
     rp.spp = spp; rp.spp_log2 = 0xffffffffu;
     for (uint32_t b = 0; b < 32; ++b) if ((1u << b) == spp) rp.spp_log2 = b;
@@ -595,6 +599,8 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
             v.push_back(s.inv_eta_2); v.push_back(s.fdr_int); v.push_back(s.spec_sampling_weight);
             v.insert(v.end(), s.refl, s.refl + 3); v.insert(v.end(), s.spec_refl, s.spec_refl + 3); v.insert(v.end(), s.spec_trans, s.spec_trans + 3);
             v.insert(v.end(), s.cond_eta, s.cond_eta + 3); v.insert(v.end(), s.cond_k, s.cond_k + 3); v.push_back(s.alpha_u); v.push_back(s.alpha_v);
+        } else if (kind == 12) for (auto &s : sc->host.shapes) {
+            v.push_back(s.beckmann ? 0.f : 1.f);
         } else if (kind == 10) for (auto &s : sc->host.shapes) {
             if (s.bsdf == BSDF_ROUGHPLASTIC) v.insert(v.end(), s.rough_table.begin(), s.rough_table.end());
         } else if (kind == 11) for (auto &e : sc->host.emitters) {
@@ -815,5 +821,52 @@ int dtof_eval_modulation(dtof_scene *sc, int mode, const float *t, const float *
         HIP_CHECK(hipMemcpy(out, dout.p, (size_t) n * 4, hipMemcpyDeviceToHost));
     });
 }
+
+int dtof_eval_component(int component, const float *params, int n_params, const float *in, int in_stride, float *out, int out_stride, uint32_t n) {
+    return guarded([&] {
+        if ((!in || !out) && n) throw std::runtime_error("null argument");
+        if (component < 0 || component >= COMP_COUNT) throw std::runtime_error("unknown component");
+        if (n_params < 0 || n_params > 8 || (n_params && !params)) throw std::runtime_error("a component takes at most 8 parameters");
+        static const int need_in[COMP_COUNT] = { 3, 6, 6, 5, 1, 1, 1, 2, 2, 2, 2, 3, 2, 1 }, need_out[COMP_COUNT] = { 1, 1, 1, 4, 4, 1, 1, 3, 2, 2, 3, 6, 1, 1 };
+        static const int need_par[COMP_COUNT] = { 4, 4, 4, 4, 1, 2, 5, 0, 0, 0, 0, 0, 0, 1 };
+        if (in_stride < need_in[component] || out_stride < need_out[component] || n_params < need_par[component])
+            throw std::runtime_error("strides / parameter count too small for this component");
+        int dev_count = 0;
+        if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count == 0) { (void) hipGetLastError(); throw HipError("hipGetDeviceCount: no ROCm-capable device is detected"); }
+        ComponentArgs a; memset(&a, 0, sizeof a);
+        a.component = component; a.in_stride = in_stride; a.out_stride = out_stride; a.n = n;
+        for (int i = 0; i < n_params; ++i) a.p[i] = params[i];
+        RenderParams rp; memset(&rp, 0, sizeof rp);
+        if (component == COMP_RFILTER) {
+            const int kind = (int) a.p[0];
+            if (kind < FILTER_BOX || kind > FILTER_CATMULLROM || !(a.p[1] > 0.f)) throw std::runtime_error("unknown filter / non-positive radius");
+            set_filter(rp, kind, a.p[1], a.p[2], a.p[3], a.p[4]);
+        }
+        DevBuf<float> din, dout; din.ensure((size_t) n * in_stride); dout.ensure((size_t) n * out_stride);
+        HIP_CHECK(hipMemcpy(din.p, in, (size_t) n * in_stride * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(dout.p, 0, (size_t) n * out_stride * 4));
+        a.in = din.p; a.out = dout.p;
+        launch_component(a, rp, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(out, dout.p, (size_t) n * out_stride * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+static int ray_query(dtof_scene *sc, uint32_t n, const float *rays8, float *out19, int32_t *ids, bool any) {
+    return guarded([&] {
+        if (!sc || (n && (!rays8 || !ids || (!any && !out19)))) throw std::runtime_error("null argument");
+        ensure_device(sc);
+        const BlobHeader *bh = (const BlobHeader *) sc->blob.data();
+        DevBuf<float> dr, dout; DevBuf<int32_t> dids;
+        dr.ensure((size_t) n * 8); dout.ensure(any ? 1 : (size_t) n * 19); dids.ensure((size_t) n * (any ? 1 : 3));
+        HIP_CHECK(hipMemcpy(dr.p, rays8, (size_t) n * 32, hipMemcpyHostToDevice));
+        launch_ray_query(sc->d_blob.p, dr.p, dout.p, dids.p, n, any, bh->tlas_depth, nullptr);
+        HIP_CHECK(hipGetLastError());
+        if (!any) HIP_CHECK(hipMemcpy(out19, dout.p, (size_t) n * 19 * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(ids, dids.p, (size_t) n * (any ? 1 : 3) * 4, hipMemcpyDeviceToHost));
+    });
+}
+int dtof_ray_intersect(dtof_scene *sc, uint32_t n, const float *rays8, float *out19, int32_t *ids3) { return ray_query(sc, n, rays8, out19, ids3, false); }
+int dtof_ray_test(dtof_scene *sc, uint32_t n, const float *rays8, int32_t *occluded) { return ray_query(sc, n, rays8, nullptr, occluded, true); }
 
 }  // extern "C"

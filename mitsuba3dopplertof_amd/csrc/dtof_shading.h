@@ -124,6 +124,16 @@ DTOF_D V3 cosine_hemisphere(float sx, float sy) {
     float px = r * c, py = r * s;
     return mk(px, py, sqrtf(fmax_(1.f - fmaf(py, py, px * px), 0.f)));
 }
+// warp::square_to_uniform_triangle (warp.h:153-156) and warp::square_to_uniform_sphere (warp.h:250-255)
+DTOF_D void uniform_triangle(float s_x, float s_y, float &bx, float &by) {
+    const float t = sqrtf(fmax_(1.f - s_x, 0.f));
+    bx = 1.f - t; by = t * s_y;
+}
+DTOF_D V3 uniform_sphere(float s_x, float s_y) {
+    const float z = fmaf(-2.f, s_y, 1.f), r = safe_sqrt(fmaf(-z, z, 1.f)); float sn, cs;
+    sincos_(2.f * kPi * s_x, sn, cs);
+    return mk(r * cs, r * sn, z);
+}
 // Mesh::sample_position (mesh.cpp:513-568): face by DiscreteDistribution::sample_reuse on sample.y (distr_1d.h:113-160,
 // dr::binary_search over [m_valid.x, m_valid.y]), point by warp::square_to_uniform_triangle (warp.h:153-156), normal from
 // the vertex normals if the mesh has them.
@@ -142,7 +152,7 @@ DTOF_D void mesh_sample_position(const SceneView &sv, const DShape &es, float s_
     const DTri &tr = sv.tris[k];
     V3 p0 = mk(tr.p0[0], tr.p0[1], tr.p0[2]), p1 = mk(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = mk(tr.p2[0], tr.p2[1], tr.p2[2]);
     V3 e0 = p1 - p0, e1 = p2 - p0;
-    const float t = sqrtf(fmax_(1.f - s_x, 0.f)), bx = 1.f - t, by = t * y;
+    float bx, by; uniform_triangle(s_x, y, bx, by);
     p = vfma(e0, bx, vfma(e1, by, p0));
     if (!(es.flags & SF_FACE_NORMALS)) {
         const DTriShade &ts = sv.shading[k];
@@ -176,9 +186,7 @@ DTOF_D void sphere_sample_direction(const DShape &sh, V3 ref, float s_x, float s
         dloc = vfma(fn, cos_alpha, vfma(ft, sin_phi * sin_alpha, fs * (cos_phi * sin_alpha)));
         pdf = uniform_cone_pdf(cos_theta_max);
     } else {   // warp::square_to_uniform_sphere (warp.h:250-255)
-        const float z = fmaf(-2.f, s_y, 1.f), r = safe_sqrt(fmaf(-z, z, 1.f)); float sn, cs;
-        sincos_(2.f * kPi * s_x, sn, cs);
-        dloc = mk(r * cs, r * sn, z);
+        dloc = uniform_sphere(s_x, s_y);
         pdf = 0.f;
     }
     p = vfma(dloc, radius, center); dd = p - ref;

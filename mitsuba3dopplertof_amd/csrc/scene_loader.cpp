@@ -495,7 +495,7 @@ static void gauss_legendre(int n, std::vector<float> &nodes, std::vector<float> 
         weights[n / 2] = (float) (2.0 / (dv * dv)); nodes[n / 2] = 0.f;
     }
 }
-// eval_transmittance / eval_reflectance (include/mitsuba/render/microfacet.h:464-566) of a GGX distribution with visible-normal
+// eval_transmittance / eval_reflectance (include/mitsuba/render/microfacet.h:464-566) of a microfacet distribution with visible-normal
 // sampling for ONE incident direction: tensor Gauss-Legendre rule over the sample square (32 x 32 nodes for eta > 1, else 128 x 128;
 // dr::meshgrid order: x runs fastest), accumulated in float in node order.
 static float rough_integral(Ggx g, V3 wi, float eta, bool transmit) {
@@ -526,8 +526,8 @@ static float rough_integral(Ggx g, V3 wi, float eta, bool transmit) {
 }
 // RoughPlastic::parameters_changed (src/bsdfs/roughplastic.cpp:222-257): m_external_transmittance on MI_ROUGH_TRANSMITTANCE_RES = 64
 // cosines mu = max(1e-6, linspace(0, 1, 64)) and m_internal_reflectance = mean(eval_reflectance(1 / eta) * mu) * 2
-void rough_plastic_tables(float alpha, float eta, float *table, float *internal_reflectance) {
-    const Ggx g = ggx_make(alpha, alpha);
+void rough_plastic_tables(int type, float alpha, float eta, float *table, float *internal_reflectance) {
+    const Ggx g = mf_make(type, alpha, alpha);
     float sum = 0.f;
     for (int i = 0; i < 64; ++i) {
         const float mu = fmax_(1e-6f, fmaf((float) i, 1.f / 63.f, 0.f));
@@ -574,8 +574,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         std::string distr = b.props.get_string("distribution", "beckmann");
         std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
         if (distr != "beckmann" && distr != "ggx") fail("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"!");
-        if (distr != "ggx") fail("roughdielectric: only distribution \"ggx\" is implemented (the Beckmann distribution needs Dr.Jit's erf / erfinv "
-                                 "approximations, whose source is not part of the reference tree)");
+        s.beckmann = distr != "ggx";   // MicrofacetType (microfacet.h:30-36)
         if (!b.props.get_bool("sample_visible", true)) fail("roughdielectric: only sample_visible = true is implemented");
         if (b.props.has("alpha_u") || b.props.has("alpha_v")) {
             if (!b.props.has("alpha_u") || !b.props.has("alpha_v")) fail("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
@@ -589,8 +588,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         std::string distr = b.props.get_string("distribution", "beckmann");
         std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
         if (distr != "beckmann" && distr != "ggx") fail("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"!");
-        if (distr != "ggx") fail("roughconductor: only distribution \"ggx\" is implemented (the Beckmann distribution needs Dr.Jit's erf / erfinv "
-                                 "approximations, whose source is not part of the reference tree)");
+        s.beckmann = distr != "ggx";   // MicrofacetType (microfacet.h:30-36)
         if (!b.props.get_bool("sample_visible", true)) fail("roughconductor: only sample_visible = true is implemented");
         if (b.props.has("alpha_u") || b.props.has("alpha_v")) {
             if (!b.props.has("alpha_u") || !b.props.has("alpha_v")) fail("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
@@ -626,8 +624,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         std::string distr = b.props.get_string("distribution", "beckmann");
         std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
         if (distr != "beckmann" && distr != "ggx") fail("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"!");
-        if (distr != "ggx") fail("roughplastic: only distribution \"ggx\" is implemented (the Beckmann distribution needs Dr.Jit's erf / erfinv "
-                                 "approximations, whose source is not part of the reference tree)");
+        s.beckmann = distr != "ggx";   // MicrofacetType (microfacet.h:30-36)
         if (!b.props.get_bool("sample_visible", true)) fail("roughplastic: only sample_visible = true is implemented");
         if (b.props.has("alpha_u") || b.props.has("alpha_v")) {
             if (!b.props.has("alpha_u") || !b.props.has("alpha_v")) fail("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
@@ -640,7 +637,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
                     s_mean = has_spec ? ((s.spec_refl[0] + s.spec_refl[1]) + s.spec_refl[2]) * (1.0f / 3.0f) : 1.f;
         s.spec_sampling_weight = s_mean / (d_mean + s_mean);
         s.rough_table.resize(64);
-        rough_plastic_tables(s.alpha_u, s.diel_eta, s.rough_table.data(), &s.fdr_int);       // fdr_int carries m_internal_reflectance
+        rough_plastic_tables(s.beckmann ? MF_BECKMANN : MF_GGX, s.alpha_u, s.diel_eta, s.rough_table.data(), &s.fdr_int);       // fdr_int carries m_internal_reflectance
     } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, plastic, roughplastic, conductor, roughconductor, dielectric, thindielectric, roughdielectric, twosided)");
     auto u = b.props.unqueried();
     if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in plugin of type \"" + b.plugin + "\"");

@@ -506,7 +506,8 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
                 reflectance=refl, to_world=_m32(tw), to_object=_m32(tinv), emitter=emitter, radiance=radiance, mesh_raw=mesh_raw,
                 sphere=sphere, bsdf=brec["bsdf"], cond_eta=brec["cond_eta"], cond_k=brec["cond_k"], spec_refl=brec["spec_refl"],
                 spec_trans=brec["spec_trans"], diel_eta=brec["diel_eta"], nonlinear=brec.get("nonlinear", 0),
-                alpha_u=brec.get("alpha_u", F32(0.1)), alpha_v=brec.get("alpha_v", F32(0.1)), has_spec_refl=brec.get("has_spec_refl", 0))
+                alpha_u=brec.get("alpha_u", F32(0.1)), alpha_v=brec.get("alpha_v", F32(0.1)), has_spec_refl=brec.get("has_spec_refl", 0),
+                mf_type=brec.get("mf_type", 1))
 
 
 def load(source, params=None, is_string=False):

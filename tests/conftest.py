@@ -19,6 +19,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """gpu-marked tests need a HIP device: without one (a build host, a plain `pytest`) they are skipped instead of failing.
+    torch.cuda.device_count() does not initialise the HIP runtime on this image."""
+    try:
+        import torch
+        have_gpu = torch.cuda.device_count() > 0
+    except Exception:      # noqa: BLE001
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible (GPU tests run with -m gpu on an MI355X box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def orc():
     """The CPU oracle (test infrastructure)."""
@@ -42,6 +58,12 @@ def mi():
 # odd (non power-of-two) spp, a crop-free non-square film and the instanced Domino scene.
 CONFIGS = [
     ("c1_boxes_antithetic", "cornell_boxes.xml", dict(resx=32, resy=32), 16),
+    # BASELINE configs[0] exactly: configs_example/scene.xml's room (cornell_boxes), sinusoidal HOMODYNE (hetero_frequency = 0), uniform time sampling
+    ("c1_boxes_uniform_homodyne", "cornell_boxes.xml", dict(resx=32, resy=32, time_sampling_method="uniform", hetero_frequency=0.0,
+                                                            wave_function_type="sinusoidal"), 16),
+    # BASELINE configs[3] exactly: Domino (1 025 objects), rectangular low-pass, antithetic 0.5
+    ("c4_domino_rectangular", "domino.xml", dict(resx=96, resy=64, wave_function_type="rectangular", time_sampling_method="antithetic",
+                                                 antithetic_shift=0.5), 4),
     ("c2_wall_stratified", "cornell_wall.xml", dict(resx=32, resy=32), 16),
     ("c3_wall_mirror", "cornell_wall.xml", dict(resx=32, resy=24, time_sampling_method="antithetic_mirror", antithetic_shift=0.0), 8),
     ("boxes_uniform_rect", "cornell_boxes.xml", dict(resx=24, resy=32, time_sampling_method="uniform", wave_function_type="rectangular"), 8),
@@ -57,6 +79,10 @@ CONFIGS = [
     ("rough_conductor_boxes", "cornell_rough.xml", dict(resx=24, resy=24, max_depth=5), 8),
     ("rough_plastic_boxes", "cornell_roughplastic.xml", dict(resx=24, resy=24, max_depth=5), 8),
     ("frosted_glass", "cornell_frosted.xml", dict(resx=24, resy=24, max_depth=6), 8),
+    # the Beckmann distribution (the plugins' default `distribution`; restated exp / log / erf / erfinv, see oracle header)
+    ("rough_conductor_beckmann", "cornell_rough.xml", dict(resx=24, resy=24, max_depth=5, distribution="beckmann"), 8),
+    ("rough_plastic_beckmann", "cornell_roughplastic.xml", dict(resx=24, resy=24, max_depth=5, distribution="beckmann"), 8),
+    ("frosted_glass_beckmann", "cornell_frosted.xml", dict(resx=24, resy=24, max_depth=6, distribution="beckmann"), 8),
     ("spot_light", "cornell_spot.xml", dict(resx=24, resy=24), 8),
     ("disks", "cornell_disk.xml", dict(resx=24, resy=24, max_depth=5), 8),
     ("spheres", "cornell_spheres.xml", dict(resx=24, resy=24), 8),

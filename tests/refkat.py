@@ -174,6 +174,8 @@ class SurfaceHit:
         if k == "uv":
             raise Skip("si.uv is not computed on the hot path (no textures)")
         if k in self._f:
+            if k in ("dp_du", "dp_dv") and np.isnan(self._f[k]).any():
+                raise Skip("dp_du / dp_dv are internal to the GPU's surface interaction")
             return self._f[k]
         raise Skip("SurfaceInteraction3f.%s is not part of the hot path" % k)
 

@@ -25,7 +25,7 @@ def test_row_band_bookkeeping():
     assert out.shape == (4, 3, 2) and out[:, 0, 0].tolist() == [1, 2, 2, 1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, gaussian=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -33,20 +33,25 @@ def _worker(rank, world, port, q):
     from oracle import orc
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     H = W = 20
-    sc = orc.Scene(os.path.join(SCENES, "cornell_wall.xml"), dict(resx=W, resy=H))
+    text = open(os.path.join(SCENES, "cornell_wall.xml")).read()
+    if gaussian:     # a film WITHOUT an rfilter child: the default gaussian, radius 2 -> splats reach two rows beyond their pixel
+        text = text.replace('<rfilter type="tent" />', "")
+    sc = orc.Scene(text, dict(resx=W, resy=H), is_string=True)
     pd = sc.params()
+    halo = int(np.ceil(sc.flat.sensor["filter_radius"] - 0.5))                 # what dtof_scene_info.filter_halo reports
+    assert halo == (2 if gaussian else 1)
     r0, r1 = D.row_band(H, world, rank)
-    band, _ = sc.render(pd, seed=5, spp=4, rows=(r0, r1), raw=True)            # (H, W, 4) with only rows r0-1..r1 touched
-    padded = np.zeros((D.padded_rows(H, world, 1), W, 4), np.float32)
-    padded[1:1 + H] = band
-    p0, p1 = D.slab_range(H, world, rank, 1)
+    band, _ = sc.render(pd, seed=5, spp=4, rows=(r0, r1), raw=True)            # (H, W, 4) with only rows r0-halo..r1+halo touched
+    padded = np.zeros((D.padded_rows(H, world, halo), W, 4), np.float32)
+    padded[halo:halo + H] = band
+    p0, p1 = D.slab_range(H, world, rank, halo)
     assert np.count_nonzero(padded[:p0]) == 0 and np.count_nonzero(padded[p1:]) == 0   # a rank only writes inside its slab
     mine = torch.from_numpy(np.ascontiguousarray(padded[p0:p1]))
     slabs = D.gather_film(mine, rank, world)
     stack = D.gather_film_stacked(mine, rank, world)
     if rank == 0:
-        full = D.overlap_add(slabs, H, world, 1, xp=torch).numpy()
-        assert np.array_equal(D.overlap_add_stacked(stack, H, world, 1).numpy(), full)
+        full = D.overlap_add(slabs, H, world, halo, xp=torch).numpy()
+        assert np.array_equal(D.overlap_add_stacked(stack, H, world, halo).numpy(), full)
         ref, _ = sc.render(pd, seed=5, spp=4, raw=True)
         q.put(float(np.abs(full - ref).max() / np.abs(ref).max()))
     dist.barrier()
@@ -64,12 +69,13 @@ def test_stripe_bookkeeping():
         assert max(len(rr) for rr in rows) - min(len(rr) for rr in rows) <= stripe
 
 
-def test_two_rank_gloo_film_gather_reproduces_the_single_rank_film():
+@pytest.mark.parametrize("gaussian", [False, True], ids=["tent_halo1", "default_gaussian_halo2"])
+def test_two_rank_gloo_film_gather_reproduces_the_single_rank_film(gaussian):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, gaussian)) for r in range(2)]
     for p in procs:
         p.start()
     err = q.get(timeout=240)

@@ -546,6 +546,30 @@ def test_full_domino_scene_1025_objects(mi, orc):
         assert rel_linf(imgs[k], ref) <= IMG_TOL, (off, rel_linf(imgs[k], ref))
 
 
+def test_full_size_c4_domino_rectangular_1024x1024x128(mi, orc):
+    """BASELINE configs[3] at FULL size (Domino, rectangular low-pass, antithetic 0.5, 1024 x 1024 x 128 spp = 134 217 728 lanes, eight
+    wavefront batches), through size-independent properties: (1) hetero_offset 0 vs 0.5 are negatives of each other -- the rectangular
+    low-pass correlation 2 - 4c (waveform_utils.h:44-47) flips sign under a half-period shift exactly like the cosine; (2) path / bounce /
+    shadow-ray counts; (3) finiteness; (4) a 4-row band of lanes, across a batch seam, bit-exact against the oracle."""
+    path = os.path.join(SCENES, "domino.xml")
+    params = dict(wave_function_type="rectangular", time_sampling_method="antithetic", antithetic_shift=0.5)
+    sc = mi.load_file(path, **params)
+    assert sc.size == (1024, 1024) and sc.info()["n_objects"] == 1025
+    both = sc.render(seed=0, spp=128, offsets=[0.0, 0.5])
+    st = sc.last_stats
+    assert st["n_paths"] == 1024 * 1024 * 128 and st["n_batches"] == 8
+    assert 0 < st["n_bounces"] <= 4 * st["n_paths"] and 0 < st["n_shadow_rays"] <= st["n_bounces"]
+    assert np.isfinite(both).all() and np.abs(both[0]).max() > 0
+    assert rel_linf(both[0], -both[1]) <= 2e-4, rel_linf(both[0], -both[1])
+    osc = orc.Scene(path, params)
+    lanes_per_row = 1024 * 128
+    lane0 = 639 * lanes_per_row            # rows 639..642: the seam between batches 5 and 6 (128 rows each) lies between rows 639 and 640
+    g = sc.sample_lanes(0, 128, lane0, 4 * lanes_per_row)
+    o = osc.render_lanes(osc.params(), 0, 128, lane0, 4 * lanes_per_row, threads=NCPU)
+    for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+        assert np.array_equal(bits(g[k]), bits(o[k])), (k, int((bits(g[k]) != bits(o[k])).sum()))
+
+
 def test_two_ranks_on_one_gpu_reproduce_the_single_rank_image(mi, tmp_path):
     """The whole N > 1 path on real kernels: two processes (torch.distributed, gloo for the one gather since both share the only
     GPU of this box) each render their band of rows with dtof_render_rows, rank 0 overlap-adds the halo rows and develops.
@@ -578,6 +602,76 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_image(mi, tmp_path):
         assert got.shape == ref.shape and rel_linf(got, ref) <= IMG_TOL, (name, rel_linf(got, ref))
         striped = np.load(str(tmp_path / (name + ".striped.npy")))      # interleaved stripes + one reduce(sum)
         assert striped.shape == ref.shape and rel_linf(striped, ref) <= IMG_TOL, (name, rel_linf(striped, ref))
+
+
+def test_two_ranks_over_rccl_reproduce_the_single_rank_image(mi, tmp_path):
+    """The same N = 2 path with backend "nccl" (= RCCL over xGMI), one GPU per rank: runs wherever the box has two or more GPUs
+    (the driver's 8-GPU node), so that RCCL sees N > 1 ranks before the scaling bench does; skipped on one-GPU boxes."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (backend nccl = RCCL, one rank per device)")
+    script = tmp_path / "two_ranks_rccl.py"
+    script.write_text(
+        "import os, sys, numpy as np\n"
+        "os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')\n"
+        "import torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "import mitsuba3dopplertof_amd as mi\n"
+        "from mitsuba3dopplertof_amd import distributed as D\n"
+        "lr = int(os.environ['LOCAL_RANK']); torch.cuda.set_device(lr)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', lr))\n"
+        "assert dist.get_world_size() == 2 and dist.get_backend() == 'nccl'\n"
+        "for name, spp in (('cornell_wall.xml', 16), ('domino_small.xml', 8)):\n"
+        "    sc = mi.load_file(os.path.join(%r, name), resx=40, resy=26)\n"
+        "    img = D.render_sharded(sc, seed=5, spp=spp)\n"
+        "    striped = D.render_striped(sc, seed=5, spp=spp, stripe_rows=4)\n"
+        "    if dist.get_rank() == 0:\n"
+        "        np.save(os.path.join(%r, name + '.npy'), img)\n"
+        "        np.save(os.path.join(%r, name + '.striped.npy'), striped)\n"
+        "dist.barrier(); dist.destroy_process_group()\n" % (os.path.dirname(SCENES), SCENES, str(tmp_path), str(tmp_path)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    for name, spp in (("cornell_wall.xml", 16), ("domino_small.xml", 8)):
+        ref = mi.load_file(os.path.join(SCENES, name), resx=40, resy=26).render(seed=5, spp=spp)
+        for suffix in (".npy", ".striped.npy"):
+            got = np.load(str(tmp_path / (name + suffix)))
+            assert got.shape == ref.shape and rel_linf(got, ref) <= IMG_TOL, (name, suffix, rel_linf(got, ref))
+
+
+def test_statistics_of_a_multi_batch_render_equal_the_single_batch_ones(mi, tmp_path):
+    """The per-iteration counters (n_bounces, n_shadow_rays: they price the roofline in bench.py) are summed over the batches of a
+    frame: a render cut into many small batches (DTOF_BATCH_LANES, read when the library is first used -> a fresh process) reports
+    the numbers of the one-batch render, and the same image."""
+    import json
+    import subprocess
+    import sys
+    script = tmp_path / "stats.py"
+    script.write_text(
+        "import os, sys, json, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import mitsuba3dopplertof_amd as mi\n"
+        "out = {}\n"
+        "for name in ('cornell_wall.xml', 'cornell_boxes.xml'):\n"
+        "    sc = mi.load_file(os.path.join(%r, name), resx=64, resy=48)\n"
+        "    img = sc.render(seed=2, spp=16)\n"
+        "    st = sc.last_stats\n"
+        "    out[name] = dict(n_paths=st['n_paths'], n_bounces=st['n_bounces'], n_shadow_rays=st['n_shadow_rays'], n_batches=st['n_batches'], checksum=float(np.abs(img).sum()))\n"
+        "print(json.dumps(out))\n" % (os.path.dirname(SCENES), SCENES))
+    res = []
+    for lanes in ("16777216", "4096"):
+        env = dict(os.environ, DTOF_BATCH_LANES=lanes)
+        p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    one, many = res
+    for name in one:
+        assert one[name]["n_batches"] == 1 and many[name]["n_batches"] >= 12, (one[name], many[name])
+        for k in ("n_paths", "n_bounces", "n_shadow_rays"):
+            assert one[name][k] == many[name][k] and one[name][k] > 0, (name, k, one[name], many[name])
+        assert abs(one[name]["checksum"] - many[name]["checksum"]) <= 1e-4 * one[name]["checksum"]
 
 
 def _random_config(rng):

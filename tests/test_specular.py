@@ -197,7 +197,7 @@ def test_plastic_scenes_are_bit_exact_per_lane(mi, orc, tmp_path, name, params, 
 def test_roughconductor_limits_and_loader(mi, orc, tmp_path):
     """RoughConductor with the GGX distribution (roughconductor.cpp, microfacet.h): (1) the loader record matches the oracle's;
     (2) alpha -> 1e-4 converges to the smooth conductor (glossy lobe with NEE + MIS vs a delta lobe: different estimators, same
-    expectation); (3) a visibly rough wall stays finite and of the same order; (4) Beckmann is rejected with a reason."""
+    expectation); (3) a visibly rough wall stays finite and of the same order; (4) both distributions load; sample_visible = false is rejected with a reason."""
     path = os.path.join(SCENES, "cornell_rough.xml")
     sc, osc = mi.load_file(path), orc.Scene(path, {})
     rec = sc.export(9).reshape(-1, 24)
@@ -207,8 +207,10 @@ def test_roughconductor_limits_and_loader(mi, orc, tmp_path):
         assert rec[i, 0] == 4 and rec[i, 1] == 1 and bits(rec[i, 22]) == bits(np.float32(s["alpha_u"])) and bits(rec[i, 23]) == bits(np.float32(s["alpha_v"]))
         assert np.array_equal(bits(rec[i, 16:19]), bits(s["cond_eta"])) and np.array_equal(bits(rec[i, 19:22]), bits(s["cond_k"]))
     assert any(rec[i, 22] != rec[i, 23] for i, _ in rough)             # the brushed floor is anisotropic
-    with pytest.raises(mi.DtofError, match="only distribution \"ggx\" is implemented"):
-        mi.load_string(open(path).read().replace('value="ggx"', 'value="beckmann"'))
+    beck = mi.load_string(open(path).read().replace('value="ggx"', 'value="beckmann"'))     # the plugins' default distribution
+    assert [beck.export(12)[i] for i, _ in rough] == [0.0] * 3 and [sc.export(12)[i] for i, _ in rough] == [1.0] * 3
+    with pytest.raises(mi.DtofError, match="only sample_visible = true"):
+        mi.load_string(open(path).read().replace('<string name="distribution" value="$distribution" />', '<boolean name="sample_visible" value="false" />', 1))
     with pytest.raises(mi.DtofError, match="invalid distribution"):
         mi.load_string(open(path).read().replace('value="ggx"', 'value="phong"'))
     with pytest.raises(mi.DtofError, match="both 'alpha_u' and 'alpha_v'"):
@@ -288,8 +290,7 @@ def test_roughplastic_tables_loader_and_limits(mi, orc, tmp_path):
         orc.lib().orc_fresnel_dielectric(C.c_float(i / 63.0), C.c_float(eta), r.ctypes.data)
         assert abs(table[i] - (1 - r[0])) < 2e-3, (i, table[i], 1 - r[0])
     text = open(path).read()
-    with pytest.raises(mi.DtofError, match="only distribution \"ggx\" is implemented"):
-        mi.load_string(text.replace('value="ggx"', 'value="beckmann"'))
+    assert 0.0 in mi.load_string(text.replace('value="ggx"', 'value="beckmann"')).export(12)   # Beckmann loads (MicrofacetType 0)
     with pytest.raises(mi.DtofError, match="does not support anisotropic"):
         mi.load_string(text.replace('<float name="alpha" value="0.15" />', '<float name="alpha_u" value="0.15" /><float name="alpha_v" value="0.3" />'))
     with pytest.raises(mi.DtofError, match="must be positive and differ"):
@@ -443,8 +444,7 @@ def test_roughdielectric_limits_and_loader(mi, orc, tmp_path):
         assert np.array_equal(bits(rec[i, 10:13]), bits(s["spec_refl"])) and np.array_equal(bits(rec[i, 13:16]), bits(s["spec_trans"]))
     assert any(rec[i, 22] != rec[i, 23] for i, _ in rd) and any(abs(rec[i, 2] - 2.419 / 1.000277) < 1e-5 for i, _ in rd)
     text = open(path).read()
-    with pytest.raises(mi.DtofError, match="only distribution \"ggx\" is implemented"):
-        mi.load_string(text.replace('value="ggx"', 'value="beckmann"'))
+    assert 0.0 in mi.load_string(text.replace('value="ggx"', 'value="beckmann"')).export(12)   # Beckmann loads (MicrofacetType 0)
     with pytest.raises(mi.DtofError, match="must be positive and differ"):
         mi.load_string(text.replace('<float name="int_ior" value="1.5" />', '<float name="int_ior" value="1.000277" />'))
     with pytest.raises(mi.DtofError, match="Only materials without a transmission component can be nested"):
@@ -479,3 +479,44 @@ def test_rough_dielectric_scenes_are_bit_exact_per_lane(mi, orc, tmp_path, name,
     img = sc.render(seed=23, spp=spp)
     ref, _ = osc.render(pd, seed=23, spp=spp, threads=NCPU)
     assert float(np.abs(img - ref).max() / np.abs(ref).max()) <= 5e-5
+
+
+def test_microfacet_sampling_matches_its_density(orc):
+    """MicrofacetDistribution::sample draws normals with the density ::pdf reports (what the reference checks with its chi^2 tests,
+    src/render/tests/test_microfacet.py:288-309): for Beckmann and GGX, visible and plain sampling, the sample means of a few test
+    functions agree with their quadrature against pdf().  This is the only pin of the Beckmann visible-normal inversion (erf / erfinv)."""
+    L = orc.lib()
+    rng = np.random.default_rng(7)
+    for mf_type in (0, 1):
+        for visible in (1, 0):
+            for angle in (15.0, 80.0):
+                au, av = np.float32(0.25), np.float32(0.4)
+                wi = np.array([np.sin(np.radians(angle)), 0.0, np.cos(np.radians(angle))], np.float32)
+                n = 40000
+                u = rng.random((n, 2)).astype(np.float32)
+                m = np.zeros((n, 4), np.float32)
+                for i in range(n):
+                    inp = np.array([wi[0], wi[1], wi[2], u[i, 0], u[i, 1]], np.float32)
+                    L.orc_kat_microfacet(mf_type, au, av, visible, 3, inp.ctypes.data, m[i].ctypes.data)
+                # the density sample() returns is the density pdf() reports
+                chk = np.zeros(1, np.float32)
+                for i in range(0, n, 997):
+                    inp = np.concatenate([wi, m[i, :3]]).astype(np.float32)
+                    L.orc_kat_microfacet(mf_type, au, av, visible, 1, inp.ctypes.data, chk.ctypes.data)
+                    assert abs(chk[0] - m[i, 3]) <= 2e-4 * max(m[i, 3], 1e-3), (mf_type, visible, angle, chk[0], m[i, 3])
+                # quadrature of pdf over the hemisphere of normals
+                nt, npf = 300, 240
+                ct = (np.arange(nt) + 0.5) / nt
+                ph = (np.arange(npf) + 0.5) / npf * 2 * np.pi
+                st = np.sqrt(1 - ct * ct)
+                acc = np.zeros(4)
+                for c, s_ in zip(ct, st):
+                    for p in ph:
+                        mm = np.array([s_ * np.cos(p), s_ * np.sin(p), c], np.float32)
+                        inp = np.concatenate([wi, mm]).astype(np.float32)
+                        L.orc_kat_microfacet(mf_type, au, av, visible, 1, inp.ctypes.data, chk.ctypes.data)
+                        acc += chk[0] * np.array([1.0, mm[0], mm[1] * mm[1], mm[2]])
+                acc *= (1.0 / nt) * (2 * np.pi / npf)
+                assert abs(acc[0] - 1) < 2e-2, (mf_type, visible, angle, acc[0])           # a density
+                est = np.array([1.0, m[:, 0].mean(), (m[:, 1] ** 2).mean(), m[:, 2].mean()])
+                assert np.all(np.abs(est[1:] - acc[1:] / acc[0]) < 6e-3), (mf_type, visible, angle, est, acc)
