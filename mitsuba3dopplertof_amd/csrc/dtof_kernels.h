@@ -116,4 +116,8 @@ void launch_component(const ComponentArgs &a, const RenderParams &rp, hipStream_
 // Scene::ray_intersect / ray_test over arrays
 void launch_ray_query(const uint8_t *scene, const float *rays, float *out, int32_t *ids, uint32_t n, bool any, uint32_t stack_depth, hipStream_t s);
 
+#ifdef DTOF_TRAVERSAL_STATS
+bool read_traversal_stats(unsigned long long *out8);
+#endif
+
 }  // namespace dtof

@@ -797,7 +797,10 @@ __global__ void k_lane_dump_rays(RenderParams rp, Queues q, LaneDebug *out) {
 
 // ---------------------------------------------------------------------------- launchers
 static inline uint32_t nblk(uint32_t n) { return (n + kBlock - 1) / kBlock; }
-constexpr uint32_t kLdsSceneLimit = 48 * 1024;
+// Whole-blob staging pays while the blob is small against what a block's lanes read from it: measured on Domino fields (split pipeline,
+// 1024^2 x 32 spp, one box): 4 KB blob staged 3.84 ms vs 4.28 ms unstaged, 9 KB 4.63 vs 5.16, 30 KB 10.39 vs 7.90 (every 64-lane shade
+// block and every 256-lane trace block copies the blob; the L1 hit rate of the unstaged kernels is 99 % on such scenes).
+constexpr uint32_t kLdsSceneLimit = 16 * 1024;
 // Block size of the unstaged k_trace / k_shadow instantiations.  One wave per block when some mesh has its own BLAS: those
 // traversals are long and divergent, and a 256-thread block keeps its LDS and wave slots until its slowest wave is done (mesh room,
 // 522 k triangles: 20.1 -> 16.6 ms per frame).  Scenes of many small objects (Domino: 1 025 instances of a 12-triangle cube) are
@@ -817,6 +820,8 @@ void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s) {
 // the scene is staged into LDS if it is small AND leaves room for the traversal stacks within the 64 KiB a block may ask for
 constexpr uint32_t kLdsBlockLimit = 64 * 1024;
 static inline uint32_t stage_words_for(uint32_t scene_bytes, uint32_t stack = 0) {
+    static const bool off = [] { const char *e = getenv("DTOF_STAGE"); return e && e[0] == '0'; }();   // DTOF_STAGE=0: never stage the scene into LDS (measurement)
+    if (off) return 0;
     const uint32_t w = (scene_bytes + 15) / 16;
     return scene_bytes <= kLdsSceneLimit && w * 16 + stack + 64 <= kLdsBlockLimit ? w : 0;
 }
@@ -1052,5 +1057,12 @@ void launch_ray_query(const uint8_t *scene, const float *rays, float *out, int32
     if (any) hipLaunchKernelGGL(k_ray_query<true>, dim3((n + 63) / 64), dim3(64), lds, s, scene, rays, out, ids, n);
     else hipLaunchKernelGGL(k_ray_query<false>, dim3((n + 63) / 64), dim3(64), lds, s, scene, rays, out, ids, n);
 }
+
+#ifdef DTOF_TRAVERSAL_STATS
+bool read_traversal_stats(unsigned long long *out8) {
+    unsigned long long zero[8] = { 0 };
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_trav_stats), 64) == hipSuccess && hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), zero, 64) == hipSuccess;
+}
+#endif
 
 }  // namespace dtof

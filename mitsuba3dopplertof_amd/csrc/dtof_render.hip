@@ -869,4 +869,14 @@ static int ray_query(dtof_scene *sc, uint32_t n, const float *rays8, float *out1
 int dtof_ray_intersect(dtof_scene *sc, uint32_t n, const float *rays8, float *out19, int32_t *ids3) { return ray_query(sc, n, rays8, out19, ids3, false); }
 int dtof_ray_test(dtof_scene *sc, uint32_t n, const float *rays8, int32_t *occluded) { return ray_query(sc, n, rays8, nullptr, occluded, true); }
 
+#ifdef DTOF_TRAVERSAL_STATS
+// development builds (make STATS=1): read and reset the traversal counters of dtof_traverse.h
+int dtof_debug_traversal_stats(unsigned long long *out8) {
+    return guarded([&] {
+        HIP_CHECK(hipDeviceSynchronize());
+        if (!read_traversal_stats(out8)) throw HipError("hipMemcpyFromSymbol(g_trav_stats) failed");
+    });
+}
+#endif
+
 }  // extern "C"

@@ -43,6 +43,24 @@ struct BvhNode {
     float rmin[3]; uint32_t pad0;
     float rmax[3]; uint32_t pad1;
 };
+// 4-wide node (128 B, one cache line; the traversal's node format when the library is built with -DDTOF_BVH4 -- `make bvh4`; measured
+// against the binary nodes on one box: Domino k_trace 4.37 vs 4.65 ms, the 522 k-triangle mesh room 9.24 vs 8.17 ms, Cornell boxes 0.606 vs
+// 0.558 ms: the traversal kernels are bound by VALU issue at ~0.55 lane utilisation, and a 4-wide step costs about two binary steps'
+// instructions plus the ordering network, at 104 instead of 94 VGPRs -- so the binary nodes stay the default): the bounds of
+// up to FOUR children live in the parent, component-major, so one fetch (seven 16-byte loads issued together) decides four
+// descents and a path to a leaf has half as many dependent fetches.  Built by collapsing the binary SAH tree (scene_build.cpp:
+// the child with the largest box is replaced by its own two children until four are held).  An absent child is the point box at
+// +inf, which no ray enters, with child = kNoChild.
+struct BvhNode4 {
+    float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4];
+    uint32_t child[4];
+    uint32_t pad[4];
+};
+#ifndef DTOF_BVH4
+typedef BvhNode DNode;
+#else
+typedef BvhNode4 DNode;
+#endif
 struct DObject {            // 128 B
     uint32_t kind, index, n_keys; float t0;
     float t1, pad[3];
@@ -77,6 +95,7 @@ struct DEmitter {           // 96 B
     // spot (src/emitters/spot.cpp:75-100): world -> local (3x4 affine part of to_world's inverse) and the constants of the falloff curve
     float to_local[12]; float cutoff_angle, cos_cutoff, cos_beam, inv_transition;
 };
+static_assert(sizeof(BvhNode4) == 128, "BvhNode4");
 static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 304 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64 && sizeof(DEmitter) == 96, "blob records");
 
 // ---------------------------------------------------------------------------- host description

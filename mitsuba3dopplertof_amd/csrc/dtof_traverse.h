@@ -13,7 +13,7 @@ namespace dtof {
 
 // ---------------------------------------------------------------------------- scene view
 struct SceneView {
-    const BvhNode *nodes; const DObject *objects; const DGroup *groups; const DShape *shapes;
+    const DNode *nodes; const DObject *objects; const DGroup *groups; const DShape *shapes;
     const DTri *tris; const DTriShade *shading; const DEmitter *emitters; const uint8_t *base;
     uint32_t n_nodes, n_emitters;
     // Fused shade kernels, scenes with ONE instance object: the world -> object matrix of that instance at the lane's ray time is
@@ -25,7 +25,7 @@ struct SceneView {
 DTOF_D SceneView make_view(const uint8_t *base) {
     const BlobHeader *h = (const BlobHeader *) base;
     SceneView v;
-    v.nodes = (const BvhNode *) (base + h->off_nodes);
+    v.nodes = (const DNode *) (base + h->off_nodes);
     v.objects = (const DObject *) (base + h->off_objects);
     v.groups = (const DGroup *) (base + h->off_groups);
     v.shapes = (const DShape *) (base + h->off_shapes);
@@ -46,6 +46,18 @@ DTOF_D const uint8_t *stage_scene(const uint8_t *g, uint32_t bytes, uint4 *lds) 
 }
 
 struct Hit { float t, u, v; uint32_t obj, shape, prim; };
+
+// Traversal statistics (development builds only: make STATS=1 -> libdtof_stats.so, read by tools/traversal_stats.py).
+// [0] rays  [1] node steps (lane)  [2] node iterations (wave)  [3] leaf visits (lane)  [4] leaf rounds (wave)  [5] mesh loops entered (lane)
+// [6] triangle tests (lane)  [7] BLAS node steps (lane)
+#ifdef DTOF_TRAVERSAL_STATS
+__device__ unsigned long long g_trav_stats[8];
+#define DTOF_STAT(i) atomicAdd(&g_trav_stats[i], 1ull)
+#define DTOF_STAT_WAVE(i) do { if (__lane_id() == (uint32_t) __ffsll((long long) __ballot(1)) - 1u) atomicAdd(&g_trav_stats[i], 1ull); } while (0)
+#else
+#define DTOF_STAT(i) ((void) 0)
+#define DTOF_STAT_WAVE(i) ((void) 0)
+#endif
 
 // ---------------------------------------------------------------------------- primitives
 // Rectangle::ray_intersect_preliminary_impl, src/shapes/rectangle.cpp:201-224
@@ -157,6 +169,7 @@ DTOF_D float box_entry(const float *bmin, const float *bmax, V3 o, V3 id, float 
     float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
     return tn <= tf ? tn : INFINITY;
 }
+#ifndef DTOF_BVH4
 // One BVH node = four 16-byte loads issued together (no load depends on a field of the node); entry distances of both
 // children, INFINITY = missed / absent.
 DTOF_D void node_test(const BvhNode *node, V3 o, V3 id, float tbest, float &tl, float &tr, uint32_t &left, uint32_t &right) {
@@ -169,6 +182,56 @@ DTOF_D void node_test(const BvhNode *node, V3 o, V3 id, float tbest, float &tl, 
     tr = box_entry(rmin, rmax, o, id, tbest);
     if (right == kNoChild) tr = INFINITY;
 }
+// one traversal step at inner node `cur`: continue with the nearest child that is hit, push the other, pop when nothing is hit
+DTOF_D uint32_t node_step(const BvhNode *nodes, uint32_t cur, V3 o, V3 id, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride, uint32_t done) {
+    float tl, tr; uint32_t left, right;
+    node_test(nodes + cur, o, id, tbest, tl, tr, left, right);
+    const bool hl = tl < INFINITY, hr = tr < INFINITY;
+    if (hl && hr) {
+        const uint32_t nearc = tl <= tr ? left : right, farc = tl <= tr ? right : left;
+        stack[sp * stride] = farc; ++sp;
+        return nearc;
+    }
+    if (hl) return left;
+    if (hr) return right;
+    if (sp == sp_floor) return done;
+    --sp; return stack[sp * stride];
+}
+#else
+DTOF_D void cswap(float &ta, uint32_t &ca, float &tb, uint32_t &cb) {   // compare-exchange of (distance, child) pairs
+    const bool sw = tb < ta;
+    const float t = sw ? tb : ta; const uint32_t c = sw ? cb : ca;
+    tb = sw ? ta : tb; cb = sw ? ca : cb; ta = t; ca = c;
+}
+// One traversal step at the 4-wide inner node `cur` (seven 16-byte loads issued together, none depends on a field of the node):
+// the children whose boxes the ray enters before `tbest` are ordered by entry distance with a five-comparator network; the nearest
+// is returned, the others are pushed far-first; nothing hit: pop (or `done` at the floor of this traversal's stack).
+DTOF_D uint32_t node_step(const BvhNode4 *nodes, uint32_t cur, V3 o, V3 id, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride, uint32_t done) {
+    const uint4 *np = (const uint4 *) (nodes + cur);
+    const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4], q5 = np[5], q6 = np[6];
+    float t[4]; uint32_t c[4] = { q6.x, q6.y, q6.z, q6.w };
+    const uint32_t mnx[4] = { q0.x, q0.y, q0.z, q0.w }, mny[4] = { q1.x, q1.y, q1.z, q1.w }, mnz[4] = { q2.x, q2.y, q2.z, q2.w };
+    const uint32_t mxx[4] = { q3.x, q3.y, q3.z, q3.w }, mxy[4] = { q4.x, q4.y, q4.z, q4.w }, mxz[4] = { q5.x, q5.y, q5.z, q5.w };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float tx0 = (u2f(mnx[k]) - o.x) * id.x, tx1 = (u2f(mxx[k]) - o.x) * id.x;
+        const float ty0 = (u2f(mny[k]) - o.y) * id.y, ty1 = (u2f(mxy[k]) - o.y) * id.y;
+        const float tz0 = (u2f(mnz[k]) - o.z) * id.z, tz1 = (u2f(mxz[k]) - o.z) * id.z;
+        const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
+        const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
+        t[k] = tn <= tf ? tn : INFINITY;
+    }
+    cswap(t[0], c[0], t[1], c[1]); cswap(t[2], c[2], t[3], c[3]); cswap(t[0], c[0], t[2], c[2]); cswap(t[1], c[1], t[3], c[3]); cswap(t[1], c[1], t[2], c[2]);
+    if (t[0] < INFINITY) {
+        if (t[3] < INFINITY) { stack[sp * stride] = c[3]; ++sp; }
+        if (t[2] < INFINITY) { stack[sp * stride] = c[2]; ++sp; }
+        if (t[1] < INFINITY) { stack[sp * stride] = c[1]; ++sp; }
+        return c[0];
+    }
+    if (sp == sp_floor) return done;
+    --sp; return stack[sp * stride];
+}
+#endif
 
 // Closest hit (ANY=false) or occlusion (ANY=true) of one top-level object.  Candidates are every
 // primitive hit with t <= maxt; the winner is the smallest t, ties going to the lowest
@@ -229,8 +292,10 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
         if (!(box_entry(sh.bmin, sh.bmax, lo, lid, ANY ? maxt : best.t) < INFINITY)) continue;
         // `face` of the best hit so far IF it lies on this very mesh (ties between two of its triangles go to the lower face)
         uint32_t best_face = 0xffffffffu;
+        DTOF_STAT(5);
         auto test = [&](uint32_t f) -> bool {
             uint32_t face;
+            DTOF_STAT(6);
             if (!tri_hit(sv.tris[sh.first_tri + f], lo, ld, maxt, t, u, v, face)) return false;
             if (ANY) return true;
             bool take = t < best.t;
@@ -247,17 +312,8 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
         uint32_t cur = sh.blas_root; int bsp = sp;
         for (;;) {
             while (!(cur & kLeafFlag) && cur != kDone) {
-                float tl, tr; uint32_t left, right;
-                node_test(sv.nodes + cur, lo, lid, ANY ? maxt : best.t, tl, tr, left, right);
-                bool hl = tl < INFINITY, hr = tr < INFINITY;
-                if (hl && hr) {
-                    uint32_t nearc = tl <= tr ? left : right, farc = tl <= tr ? right : left;
-                    stack[bsp * stride] = farc; ++bsp;
-                    cur = nearc;
-                } else if (hl) cur = left;
-                else if (hr) cur = right;
-                else if (bsp == sp) cur = kDone;
-                else { --bsp; cur = stack[bsp * stride]; }
+                DTOF_STAT(7);
+                cur = node_step(sv.nodes, cur, lo, lid, ANY ? maxt : best.t, stack, bsp, sp, stride, kDone);
             }
             if (cur == kDone) break;
             uint32_t f0 = (cur & ~kLeafFlag) >> kBlasLeafBits, fn = (cur & ((1u << kBlasLeafBits) - 1u)) + 1u;
@@ -284,21 +340,14 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
     int sp = 0;
     uint32_t cur = 0;
     const uint32_t stride = blockDim.x;
+    DTOF_STAT(0);
     for (;;) {
         while (!(cur & kLeafFlag) && cur != kDone) {
-            float tl, tr; uint32_t left, right;
-            node_test(sv.nodes + cur, o, id, best.t, tl, tr, left, right);
-            bool hl = tl < INFINITY, hr = tr < INFINITY;
-            if (hl && hr) {
-                uint32_t nearc = tl <= tr ? left : right, farc = tl <= tr ? right : left;
-                stack[sp * stride] = farc; ++sp;
-                cur = nearc;
-            } else if (hl) cur = left;
-            else if (hr) cur = right;
-            else if (sp == 0) cur = kDone;
-            else { --sp; cur = stack[sp * stride]; }
+            DTOF_STAT(1); DTOF_STAT_WAVE(2);
+            cur = node_step(sv.nodes, cur, o, id, best.t, stack, sp, 0, stride, kDone);
         }
         if (cur == kDone) break;
+        DTOF_STAT(3); DTOF_STAT_WAVE(4);
         if (intersect_object<ANY, MESH, MEMO>(sv, cur & ~kLeafFlag, o, d, time, maxt, best, stack, sp, stride) && ANY) return true;
         if (sp == 0) break;
         --sp; cur = stack[sp * stride];

@@ -13,6 +13,7 @@
 #include <cfloat>
 #include <cstdlib>
 #include <numeric>
+#include <limits>
 
 namespace dtof {
 
@@ -114,6 +115,55 @@ static uint32_t build_node(BuildCtx &cx, size_t b, size_t e) {
     n.left = l; n.right = r; n.pad0 = n.pad1 = 0;
     return idx;
 }
+
+#ifdef DTOF_BVH4
+// Binary tree -> 4-wide tree: a wide node starts with the two children of a binary node; while it holds fewer than four, its
+// inner child with the largest box is replaced by that child's own two children.  Leaves keep their encoding.
+static uint32_t collapse(const std::vector<BvhNode> &bin, uint32_t ni, std::vector<BvhNode4> &out) {
+    struct Ent { float lo[3], hi[3]; uint32_t ref; };
+    std::vector<Ent> ents;
+    auto push = [&](const float *lo, const float *hi, uint32_t ref) {
+        if (ref == kNoChild) return;
+        Ent e; memcpy(e.lo, lo, 12); memcpy(e.hi, hi, 12); e.ref = ref; ents.push_back(e);
+    };
+    push(bin[ni].lmin, bin[ni].lmax, bin[ni].left); push(bin[ni].rmin, bin[ni].rmax, bin[ni].right);
+    while (ents.size() < 4) {
+        int pick = -1; float best = -1.f;
+        for (size_t i = 0; i < ents.size(); ++i) {
+            if (ents[i].ref & kLeafFlag) continue;
+            const float d[3] = { ents[i].hi[0] - ents[i].lo[0], ents[i].hi[1] - ents[i].lo[1], ents[i].hi[2] - ents[i].lo[2] };
+            const float a = d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+            if (a > best) { best = a; pick = (int) i; }
+        }
+        if (pick < 0) break;
+        const BvhNode n = bin[ents[pick].ref];
+        ents.erase(ents.begin() + pick);
+        push(n.lmin, n.lmax, n.left); push(n.rmin, n.rmax, n.right);
+    }
+    const uint32_t idx = (uint32_t) out.size();
+    out.emplace_back();
+    BvhNode4 w; memset(&w, 0, sizeof w);
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int k = 0; k < 4; ++k) { w.minx[k] = w.miny[k] = w.minz[k] = w.maxx[k] = w.maxy[k] = w.maxz[k] = inf; w.child[k] = kNoChild; }
+    for (size_t k = 0; k < ents.size(); ++k) {
+        w.minx[k] = ents[k].lo[0]; w.miny[k] = ents[k].lo[1]; w.minz[k] = ents[k].lo[2];
+        w.maxx[k] = ents[k].hi[0]; w.maxy[k] = ents[k].hi[1]; w.maxz[k] = ents[k].hi[2];
+        w.child[k] = (ents[k].ref & kLeafFlag) ? ents[k].ref : collapse(bin, ents[k].ref, out);
+    }
+    out[idx] = w;
+    return idx;
+}
+// stack entries a depth-first traversal below `ni` can hold: every node visit pushes at most (children - 1) entries
+static uint32_t stack_need(const std::vector<BvhNode4> &nodes, uint32_t ni) {
+    uint32_t n = 0, deepest = 0;
+    for (int k = 0; k < 4; ++k) if (nodes[ni].child[k] != kNoChild) ++n;
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t c = nodes[ni].child[k];
+        if (c != kNoChild && !(c & kLeafFlag)) deepest = std::max(deepest, stack_need(nodes, c));
+    }
+    return (n ? n - 1 : 0) + deepest;
+}
+#endif
 
 static uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
@@ -262,6 +312,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         BuildCtx cx { nodes, items, 1 };
         build_node(cx, 0, items.size());
     }
+#ifndef DTOF_BVH4
     const uint32_t tlas_nodes = (uint32_t) nodes.size();
     for (BvhNode n : blas_nodes) {   // BLAS node indices (children and roots) move behind the TLAS
         if (n.left != kNoChild && !(n.left & kLeafFlag)) n.left += tlas_nodes;
@@ -269,6 +320,29 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         nodes.push_back(n);
     }
     for (DShape &d : shapes) if (d.blas_root != kNoChild) d.blas_root += tlas_nodes;
+    std::vector<BvhNode> &dev_nodes = nodes;
+    uint32_t need_tlas = 0, need_blas = blas_depth ? blas_depth + 1 : 0;
+    {   // deepest leaf below the root = stack entries a depth-first traversal can hold
+        uint32_t deepest = 1;
+        std::vector<std::pair<uint32_t, uint32_t>> todo; if (tlas_nodes) todo.emplace_back(0u, 1u);
+        while (!todo.empty()) {
+            auto [ni, d] = todo.back(); todo.pop_back();
+            deepest = std::max(deepest, d);
+            for (uint32_t c : { nodes[ni].left, nodes[ni].right })
+                if (c != kNoChild && !(c & kLeafFlag)) todo.emplace_back(c, d + 1);
+        }
+        need_tlas = deepest + 1;
+    }
+#else
+    // the traversal's 4-wide nodes: TLAS first, then the BLAS of every mesh (their roots re-based into the same array)
+    std::vector<BvhNode4> dev_nodes;
+    uint32_t need_tlas = 1, need_blas = 0;
+    if (!nodes.empty()) { collapse(nodes, 0, dev_nodes); need_tlas = stack_need(dev_nodes, 0) + 1; }
+    for (DShape &d : shapes) if (d.blas_root != kNoChild) {
+        d.blas_root = collapse(blas_nodes, d.blas_root, dev_nodes);
+        need_blas = std::max(need_blas, stack_need(dev_nodes, d.blas_root) + 1);
+    }
+#endif
     // ---- emitters
     std::vector<DEmitter> emitters(sc.emitters.size());
     for (size_t i = 0; i < sc.emitters.size(); ++i) {
@@ -280,22 +354,12 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     }
     // ---- pack: nodes first (so that "the first N bytes" = header + top of the TLAS in BFS-ish order)
     BlobHeader h; memset(&h, 0, sizeof h);
-    h.n_nodes = (uint32_t) nodes.size(); h.n_objects = (uint32_t) objects.size(); h.n_groups = (uint32_t) groups.size();
+    h.n_nodes = (uint32_t) dev_nodes.size(); h.n_objects = (uint32_t) objects.size(); h.n_groups = (uint32_t) groups.size();
     h.n_shapes = (uint32_t) shapes.size(); h.n_tris = (uint32_t) tris.size(); h.n_emitters = (uint32_t) emitters.size();
     (void) has_instances;
-    {   // deepest leaf below the root = stack entries a depth-first traversal can hold
-        uint32_t deepest = 1;
-        std::vector<std::pair<uint32_t, uint32_t>> todo; if (tlas_nodes) todo.emplace_back(0u, 1u);
-        while (!todo.empty()) {
-            auto [ni, d] = todo.back(); todo.pop_back();
-            deepest = std::max(deepest, d);
-            for (uint32_t c : { nodes[ni].left, nodes[ni].right })
-                if (c != kNoChild && !(c & kLeafFlag)) todo.emplace_back(c, d + 1);
-        }
-        h.tlas_depth = deepest + 1 + (blas_depth ? blas_depth + 1 : 0);
-    }
+    h.tlas_depth = need_tlas + need_blas;
     uint32_t off = sizeof(BlobHeader);
-    h.off_nodes = off;    off = align16(off + (uint32_t) (nodes.size() * sizeof(BvhNode)));
+    h.off_nodes = off;    off = align16(off + (uint32_t) (dev_nodes.size() * sizeof(DNode)));
     h.off_objects = off;  off = align16(off + (uint32_t) (objects.size() * sizeof(DObject)));
     h.off_groups = off;   off = align16(off + (uint32_t) (groups.size() * sizeof(DGroup)));
     h.off_shapes = off;   off = align16(off + (uint32_t) (shapes.size() * sizeof(DShape)));
@@ -308,7 +372,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     for (DShape &d : shapes) if (d.bsdf == BSDF_ROUGHPLASTIC) d.rough_table += h.off_tables;
     std::vector<uint8_t> blob(off, 0);
     memcpy(blob.data(), &h, sizeof h);
-    if (!nodes.empty()) memcpy(blob.data() + h.off_nodes, nodes.data(), nodes.size() * sizeof(BvhNode));
+    if (!dev_nodes.empty()) memcpy(blob.data() + h.off_nodes, dev_nodes.data(), dev_nodes.size() * sizeof(DNode));
     if (!objects.empty()) memcpy(blob.data() + h.off_objects, objects.data(), objects.size() * sizeof(DObject));
     if (!groups.empty()) memcpy(blob.data() + h.off_groups, groups.data(), groups.size() * sizeof(DGroup));
     if (!shapes.empty()) memcpy(blob.data() + h.off_shapes, shapes.data(), shapes.size() * sizeof(DShape));

@@ -1308,17 +1308,26 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
 /* mis_weight -- dopplertofpath.cpp:296-301 */
 static inline float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
-typedef struct { const orc_scene *sc; const orc_params *p; uint32_t seed, spp; float s2c[16]; } orc_ctx;
+/* spp = Sampler::sample_count (all passes), spw = samples per wavefront = spp_per_pass, n_passes = spp / spw (integrator.cpp:121-135,227-245) */
+typedef struct { const orc_scene *sc; const orc_params *p; uint32_t seed, spp, spw, n_passes; float s2c[16]; } orc_ctx;
 
 /* One lane: SamplingIntegrator::render (lane->pixel, src/render/integrator.cpp:273-290),
  * render_sample Doppler branch (:476-542), DopplerToFPathIntegrator::sample
  * (src/integrators/dopplertofpath.cpp:79-283). */
 static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
     const orc_scene *sc = cx->sc; const orc_params *p = cx->p; const orc_sensor *se = &sc->sensor;
-    uint32_t lane = (uint32_t) lane64, spp = cx->spp;
-    orc_sampler smp; sampler_seed(&smp, p, cx->seed, spp, lane);
+    /* lane64 = pass * wavefront_size + lane: the sampler is seeded once per wavefront lane (integrator.cpp:265) and its three RNG
+     * streams run on through the passes (Sampler::advance only resets the dimension index and bumps the sample index,
+     * sampler.cpp:52-55), so pass k of a lane is evaluated after its passes 0 .. k-1 */
+    const uint32_t spp = cx->spp, spw = cx->spw;
+    const uint64_t wavefront = (uint64_t) se->crop_w * (uint64_t) se->crop_h * spw;
+    const uint32_t lane = (uint32_t) (lane64 % wavefront), pass_target = (uint32_t) (lane64 / wavefront);
+    orc_sampler smp; sampler_seed(&smp, p, cx->seed, spw, lane);
+    for (uint32_t pass = 0; pass <= pass_target; ++pass) {
+    smp.dim = 0;
+    smp.sample_index = pass * spw + (spw > 1 ? lane % spw : 0);   /* current_sample_index, sampler.cpp:94-103 */
 
-    uint32_t pix = lane / spp, W = (uint32_t) se->crop_w;
+    uint32_t pix = lane / spw, W = (uint32_t) se->crop_w;
     uint32_t py = pix / W, px = pix - W * py;
     float posx = (float) (px + (uint32_t) se->crop_x), posy = (float) (py + (uint32_t) se->crop_y);
 
@@ -1368,7 +1377,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         vel = (v1 && v2) ? vel : 0.f;
         out->rgb[0] = out->rgb[1] = out->rgb[2] = vel;
         out->path_length = 0.f; out->depth = 0; out->valid = (uint32_t) (v1 && v2);
-        return;
+        continue;
     }
 
     while (active) {
@@ -1529,6 +1538,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
     }
     out->rgb[0] = valid_ray ? res.x : 0.f; out->rgb[1] = valid_ray ? res.y : 0.f; out->rgb[2] = valid_ray ? res.z : 0.f;
     out->path_length = path_length; out->depth = depth; out->valid = (uint32_t) valid_ray;
+    }   /* passes */
 }
 
 void orc_sampler_lane(const orc_params *p, uint32_t seed, uint32_t spp, uint32_t lane, uint32_t *ou, float *of) {
@@ -1565,8 +1575,24 @@ static void run_lanes(const orc_ctx *cx, uint64_t begin, uint64_t n, orc_lane *o
     }
     if (nt > 1) for (int t = 0; t < nt; ++t) pthread_join(th[t], NULL);
 }
+/* SamplingIntegrator::render (integrator.cpp:121-135,227-245): spp_per_pass = min(samples_per_pass, spp), which must divide spp;
+ * a wavefront of more than 2^32 - 1 lanes is split further (integer division, as written there); Sampler::set_samples_per_wavefront
+ * (sampler.cpp:75-83) then insists that sample_count is a multiple of it.  Returns 0, or -1 where the reference throws. */
+int orc_pass_layout(int32_t crop_w, int32_t crop_h, uint32_t spp, uint32_t samples_per_pass, uint32_t *spw_out, uint32_t *n_passes_out) {
+    if (spp == 0) return -1;
+    uint32_t spp_per_pass = samples_per_pass == 0xffffffffu || samples_per_pass == 0 ? spp : (samples_per_pass < spp ? samples_per_pass : spp);
+    if (spp % spp_per_pass != 0) return -1;
+    uint64_t wavefront = (uint64_t) crop_w * (uint64_t) crop_h * spp_per_pass, limit = 0xffffffffull;
+    if (wavefront > limit) {
+        spp_per_pass /= (uint32_t) ((wavefront + limit - 1) / limit);
+        if (spp_per_pass == 0 || spp % spp_per_pass != 0) return -1;
+    }
+    *spw_out = spp_per_pass; *n_passes_out = spp / spp_per_pass;
+    return 0;
+}
 static void make_ctx(orc_ctx *cx, const orc_scene *sc, const orc_params *p, uint32_t seed, uint32_t spp) {
-    cx->sc = sc; cx->p = p; cx->seed = seed; cx->spp = spp;
+    cx->sc = sc; cx->p = p; cx->seed = seed; cx->spp = spp; cx->spw = spp; cx->n_passes = 1;
+    orc_pass_layout(sc->sensor.crop_w, sc->sensor.crop_h, spp, p->samples_per_pass, &cx->spw, &cx->n_passes);
     camera_sample_to_camera(&sc->sensor, cx->s2c);
 }
 void orc_render_lanes(const orc_scene *sc, const orc_params *p, uint32_t seed, uint32_t spp,
@@ -1685,18 +1711,21 @@ uint64_t orc_render(const orc_scene *sc, const orc_params *p, uint32_t seed, uin
     if (row_end > H) row_end = H;
     if (nt < 1) nt = 1;
     if (nt > 256) nt = 256;
-    uint64_t lanes_per_row = (uint64_t) W * spp, total = 0;
+    const uint32_t spw = cx.spw;
+    const uint64_t wavefront = (uint64_t) W * (uint64_t) H * spw;
+    uint64_t lanes_per_row = (uint64_t) W * spw, total = 0;
     int chunk_rows = (int) (8000000ull / lanes_per_row); if (chunk_rows < 1) chunk_rows = 1;
     const int border = sc->sensor.filter == ORC_FILTER_BOX ? 0 : (int) ceilf(sc->sensor.filter_radius - .5f);
     orc_lane *buf = (orc_lane *) malloc(sizeof(orc_lane) * lanes_per_row * (size_t) chunk_rows);
+    for (uint32_t pass = 0; pass < cx.n_passes; ++pass)
     for (int r = row_begin; r < row_end; r += chunk_rows) {
         int re = r + chunk_rows < row_end ? r + chunk_rows : row_end;
         uint64_t n = lanes_per_row * (uint64_t) (re - r);
-        run_lanes(&cx, lanes_per_row * (uint64_t) r, n, buf, nt);
+        run_lanes(&cx, (uint64_t) pass * wavefront + lanes_per_row * (uint64_t) r, n, buf, nt);
         int bands = nt < re - r ? nt : re - r;
         if (bands == 1) {                       /* one thread: straight into the film, lane order */
             for (uint64_t i = 0; i < n; ++i) {
-                uint64_t pix = (lanes_per_row * (uint64_t) r + i) / spp;
+                uint64_t pix = (lanes_per_row * (uint64_t) r + i) / spw;
                 splat(&sc->sensor, film, buf[i].sample_pos[0], buf[i].sample_pos[1], (int) (pix % (uint64_t) W), (int) (pix / (uint64_t) W), buf[i].rgb);
             }
             total += n;
@@ -1706,7 +1735,7 @@ uint64_t orc_render(const orc_scene *sc, const orc_params *p, uint32_t seed, uin
         for (int b = 0; b < bands; ++b) {
             int b0 = r + (int) ((int64_t) (re - r) * b / bands), b1 = r + (int) ((int64_t) (re - r) * (b + 1) / bands);
             splat_job *j = &jobs[b];
-            j->se = &sc->sensor; j->spp = spp; j->W = W; j->H = H; j->row0 = b0; j->rows = b1 - b0; j->border = border;
+            j->se = &sc->sensor; j->spp = spw; j->W = W; j->H = H; j->row0 = b0; j->rows = b1 - b0; j->border = border;
             j->lane0 = lanes_per_row * (uint64_t) b0; j->n = lanes_per_row * (uint64_t) (b1 - b0);
             j->lanes = buf + (j->lane0 - lanes_per_row * (uint64_t) r);
             j->band = (float *) calloc((size_t) (j->rows + 2 * border) * W * 4 + 4, sizeof(float));

@@ -135,6 +135,7 @@ typedef struct {
     int32_t integrator;
     int32_t sampler;         /* 0 correlated | 1 independent | 2 timestratified (src/samplers/{independent,timestratified}.cpp) */
     int32_t jitter;          /* timestratified.cpp:73 */
+    uint32_t samples_per_pass;   /* SamplingIntegrator::m_samples_per_pass (integrator.cpp:54-56): 0xffffffff = one pass */
 } orc_params;
 
 typedef struct {
@@ -183,7 +184,9 @@ int      orc_intersect(const orc_scene *sc, const float *o, const float *d, floa
                        float *hit, int32_t *ids);
 int      orc_occluded(const orc_scene *sc, const float *o, const float *d, float time, float maxt);
 
-/* Evaluate lanes [lane_begin, lane_begin+n) of the wavefront of W*H*spp lanes. */
+/* Evaluate lanes [lane_begin, lane_begin+n) of the wavefront of W*H*spp lanes.  With several passes (samples_per_pass, or a wavefront
+ * beyond 2^32 - 1 lanes) the index is pass * wavefront_size + lane, wavefront_size = W*H*spp_per_pass (orc_pass_layout). */
+int      orc_pass_layout(int32_t crop_w, int32_t crop_h, uint32_t spp, uint32_t samples_per_pass, uint32_t *spp_per_pass, uint32_t *n_passes);
 void     orc_render_lanes(const orc_scene *sc, const orc_params *p, uint32_t seed, uint32_t spp,
                           uint64_t lane_begin, uint64_t n, orc_lane *out, int n_threads);
 

@@ -62,7 +62,7 @@ class OrcParams(C.Structure):
                 ("time_sampling", C.c_int32), ("antithetic_shift", C.c_float), ("stratify_each_interval", C.c_int32),
                 ("path_correlation_depth", C.c_uint32), ("max_depth", C.c_uint32), ("rr_depth", C.c_uint32),
                 ("hide_emitters", C.c_int32), ("base_seed", C.c_uint32),
-                ("time_correlate_number", C.c_int32), ("path_correlate_number", C.c_int32), ("integrator", C.c_int32), ("sampler", C.c_int32), ("jitter", C.c_int32)]
+                ("time_correlate_number", C.c_int32), ("path_correlate_number", C.c_int32), ("integrator", C.c_int32), ("sampler", C.c_int32), ("jitter", C.c_int32), ("samples_per_pass", C.c_uint32)]
 
 
 class OrcScene(C.Structure):
@@ -154,6 +154,8 @@ def lib():
         L.orc_mesh_area_table.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_bake_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                     C.c_void_p, C.c_void_p]
+        L.orc_pass_layout.restype = C.c_int
+        L.orc_pass_layout.argtypes = [C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         for nm in ("orc_expf", "orc_logf", "orc_tanf", "orc_erff", "orc_erfinvf"):
             getattr(L, nm).restype = C.c_float
             getattr(L, nm).argtypes = [C.c_float]
