@@ -115,7 +115,9 @@ int dtof_scene_export(const dtof_scene *scene, int kind, float *out, size_t capa
  * Replaces Integrator::render(Scene*, uint32_t sensor_index, uint32_t seed, uint32_t spp, bool develop,
  * bool evaluate) (include/mitsuba/render/integrator.h:74-79; src/render/integrator.cpp:104-347), i.e.
  * integrator.render(scene, seed=i, spp=n) of program_runner.py:15,23.  spp == 0 uses the sampler's
- * sample_count (integrator.cpp:121-124). */
+ * sample_count (integrator.cpp:121-124).  Passes: the integrator's `samples_per_pass` property, or a wavefront of more than
+ * 2^32 - 1 lanes, splits the render into spp / spp_per_pass passes exactly as integrator.cpp:121-135,227-245 does -- the sampler is
+ * seeded once, its streams run on from pass to pass (Sampler::advance, sampler.cpp:52-55), the film accumulates all passes. */
 typedef struct {
     uint64_t n_paths;            /* W*H*spp lanes evaluated by this call */
     uint64_t n_bounces;          /* closest-hit rays traced (path-bounces through the trace+shade loop) */
@@ -164,7 +166,8 @@ int dtof_render_offsets(dtof_scene *scene, uint32_t seed, uint32_t spp, const fl
 void dtof_cancel(dtof_scene *scene);
 
 /* Per-lane debugging entry (SURVEY 8b "dtof_sample_lanes"): evaluates wavefront lanes
- * [lane_begin, lane_begin+n) exactly as dtof_render would and returns, per lane,
+ * [lane_begin, lane_begin+n) exactly as dtof_render would (multi-pass renders: index = pass * wavefront_size + lane, a range must stay
+ * inside one pass) and returns, per lane,
  * sample_pos[2], time, ray_o[3], ray_d[3], rgb[3] (12 floats) -- the (Spectrum, position) pair that
  * render_sample hands to ImageBlock::put (src/render/integrator.cpp:509-541). */
 int dtof_sample_lanes(dtof_scene *scene, uint32_t seed, uint32_t spp, uint64_t lane_begin, uint64_t n, float *out_lanes12);

@@ -49,6 +49,9 @@ struct RenderParams {
     // wavefronts of more than 2^32 - 1 lanes / samples_per_pass (integrator.cpp:121-124,227-245): pass `pass` of `n_passes`, each of
     // `spp` samples per pixel (= samples per wavefront); the sampler's streams are seeded in pass 0 and carried across the passes
     uint32_t pass, n_passes;
+    uint32_t sample_count; FastDiv d_sample_count;   // Sampler::sample_count() of the whole render (spp = samples per wavefront = per pass)
+    uint2 *pass_rng;                              // n_passes > 1: [lane - pass_first][3] = states of the main / time / path streams between passes
+    uint32_t pass_first;                          // virtual lane the pass_rng array starts at
     uint32_t memo_obj;                            // fused pipeline: the scene's only instance object (instance memo, dtof_traverse.h) or 0xffffffff
 };
 
@@ -95,6 +98,7 @@ void launch_velocity(const uint8_t *scene, uint32_t scene_bytes, const RenderPar
 void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t film_w, int32_t film_h, hipStream_t s);
 void launch_develop(const float *film, float *rgb, int64_t n_pixels, hipStream_t s);
 void launch_lane_dump(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s);
+void launch_pass_save(const RenderParams &rp, const Queues &q, hipStream_t s);   // multi-pass: main / path stream states of the batch -> rp.pass_rng
 void launch_lane_dump_rays(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s);
 
 // sampler KAT kernels

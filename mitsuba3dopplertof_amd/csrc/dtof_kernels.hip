@@ -35,7 +35,7 @@ namespace dtof {
 __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= rp.n_lanes) return;
-    const PrimaryLane pl = generate_lane(rp, global_lane(rp, rp.lane_base + i));
+    const PrimaryLane pl = generate_lane(rp, global_lane(rp, rp.lane_base + i), false, rp.lane_base + i);
     q.ray_a[i] = pl.ray_a;
     q.ray_b[i] = pl.ray_b;
     q.st_a[i] = make_float4(1.f, 1.f, 1.f, 0.f);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
         if (FIRST) {
             // the wave's 64 lanes are the 64-aligned lanes [lane_base + seg * 512 + cbase, + 64): samples of one pixel if spp is a multiple of 64
             const bool wave_pixel = rp.spp_log2 != 0xffffffffu && rp.spp_log2 >= 6 && (rp.lane_base & 63u) == 0;
-            const PrimaryLane pl = generate_lane(rp, global_lane(rp, rp.lane_base + l), wave_pixel);
+            const PrimaryLane pl = generate_lane(rp, global_lane(rp, rp.lane_base + l), wave_pixel, rp.lane_base + l);
             ra = pl.ray_a; rb = pl.ray_b; main = pl.main; path = pl.path; st = make_float4(1.f, 1.f, 1.f, 0.f);
             q.pos[l] = pl.pos;
             q.rng_b[l] = make_uint2((uint32_t) (main.inc >> 1), (uint32_t) (path.inc >> 1));
@@ -196,6 +196,19 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
                 main.state = (uint64_t) rs.x | ((uint64_t) rs.y << 32); main.inc = ((uint64_t) ri.x << 1) | 1u;
                 path.state = (uint64_t) rs.z | ((uint64_t) rs.w << 32); path.inc = ((uint64_t) ri.y << 1) | 1u;
             }
+        }
+        if (hid == 0xffffffffu && rp.n_passes > 1) {
+            // several passes: the streams are carried into the next pass, so the six draws the reference makes for EVERY lane that is
+            // active at the entry of an iteration (App. A step 5; both streams advance on each, correlated.cpp:156-161) also happen
+            // for the lanes whose ray misses (single-pass renders drop the state of a finished path instead)
+            if (!FIRST) {
+                const uint4 rs = q.rng_a[l]; const uint2 ri = q.rng_b[l];
+                main.state = (uint64_t) rs.x | ((uint64_t) rs.y << 32); main.inc = ((uint64_t) ri.x << 1) | 1u;
+                path.state = (uint64_t) rs.z | ((uint64_t) rs.w << 32); path.inc = ((uint64_t) ri.y << 1) | 1u;
+            }
+            const bool one = rp.integrator != 0 || rp.sampler_kind != SAMPLER_CORRELATED;
+            for (int k = 0; k < 6; ++k) { main.state = main.state * kPcgMult + main.inc; if (!one) path.state = path.state * kPcgMult + path.inc; }
+            q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
         }
         if (hid != 0xffffffffu) {   // a miss ends the path (active_next = false, dopplertofpath.cpp:171)
             V3 o = mk(ra.x, ra.y, ra.z), d = mk(rb.x, rb.y, rb.z); float time = ra.w;
@@ -531,8 +544,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
                 q.st_a[l] = make_float4(thr.x, thr.y, thr.z, path_length);
                 if (AREA) q.st_b[l] = make_float4(si.p.x, si.p.y, si.p.z, bs_pdf);   // prev_si, prev_bsdf_pdf (:256-257)
                 if (SPEC) q.st_c[l] = make_float2(eta, bs_delta ? 1.f : 0.f);         // eta, prev_bsdf_delta (:252,258)
-                q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
             }
+            if (alive || rp.n_passes > 1)   // several passes: the state of a finished path is what its lane starts the next pass with
+                q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
         }
     }
     uint32_t slot = block_append(alive, s_cnt, n_alive);
@@ -918,6 +932,17 @@ void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t 
 void launch_develop(const float *film, float *rgb, int64_t n, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_develop, dim3((uint32_t) ((n + 255) / 256)), dim3(256), 0, s, film, rgb, n);
+}
+// multi-pass renders: the main / path stream states the lanes of this batch ended the pass with (generate_lane wrote the time stream's)
+__global__ void k_pass_save(RenderParams rp, Queues q) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rp.n_lanes) return;
+    const uint4 rs = q.rng_a[i];
+    uint2 *dst = rp.pass_rng + (size_t) (rp.lane_base + i - rp.pass_first) * 3;
+    dst[0] = make_uint2(rs.x, rs.y); dst[2] = make_uint2(rs.z, rs.w);
+}
+void launch_pass_save(const RenderParams &rp, const Queues &q, hipStream_t s) {
+    if (rp.n_lanes && rp.pass_rng) hipLaunchKernelGGL(k_pass_save, dim3(nblk(rp.n_lanes)), dim3(kBlock), 0, s, rp, q);
 }
 void launch_lane_dump(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s) {
     if (rp.n_lanes == 0) return;

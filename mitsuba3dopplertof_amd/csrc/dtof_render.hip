@@ -91,6 +91,7 @@ struct dtof_scene {
     Workspace ws, ws2;                       // one per in-flight batch
     DevBuf<float> d_film, d_rgb;
     DevBuf<unsigned long long> d_sums;       // [batch][2*kMaxIter] per-iteration totals (survivors, shadow rays)
+    DevBuf<uint2> d_pass_rng;                // multi-pass renders: [lane][3] stream states between the passes
     hipStream_t stream = nullptr, stream2 = nullptr;
     std::atomic<bool> stop { false };
     // reusable statistics plumbing (creating events / pinned memory per call costs ~0.3 ms)
@@ -176,7 +177,8 @@ void set_filter(RenderParams &rp, int32_t filter, float radius, float stddev, fl
         rp.gauss_coeff[0] -= estrin10(radius * radius, rp.gauss_coeff);
     }
 }
-RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, const float *offsets, int n_offsets) {
+// spp = samples per wavefront (per pass); sample_count = Sampler::sample_count() of the whole render (0: the same)
+RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, const float *offsets, int n_offsets, uint32_t sample_count = 0) {
     const HostSensor &se = sc->host.sensor; const PluginParams &pp = sc->pp;
     RenderParams rp; memset(&rp, 0, sizeof rp);
     sample_to_camera(se, rp.s2c);
@@ -192,12 +194,14 @@ RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, cons
     for (uint32_t b = 0; b < 32; ++b) if ((1u << b) == spp) rp.spp_log2 = b;
     rp.tcn = (uint32_t) pp.time_correlate_number; rp.pcn = (uint32_t) pp.path_correlate_number;
     rp.time_sampling = pp.time_sampling; rp.antithetic_shift = pp.antithetic_shift; rp.stratify = pp.stratify_each_interval;
-    rp.n_stratum = spp / rp.tcn;                                   // int n_stratum = m_sample_count / tcn (correlated.cpp:112)
+    if (sample_count == 0) sample_count = spp;
+    rp.sample_count = sample_count; rp.d_sample_count = make_fastdiv(sample_count);
+    rp.n_stratum = sample_count / rp.tcn;                          // int n_stratum = m_sample_count / tcn (correlated.cpp:112)
     rp.inv_n_stratum = rp.n_stratum ? 1.0f / (float) (int) rp.n_stratum : 0.f;
     rp.inv_tcn = 1.0f / (float) pp.time_correlate_number;
     rp.d_spp = make_fastdiv(spp); rp.d_w = make_fastdiv((uint32_t) se.crop_w); rp.d_tcn = make_fastdiv(rp.tcn); rp.d_pcn = make_fastdiv(rp.pcn);
     rp.d_stratum = make_fastdiv(rp.n_stratum);
-    for (uint32_t d : { spp, (uint32_t) se.crop_w, rp.tcn, rp.pcn, rp.n_stratum })   // the kernels have no other division: fail loudly
+    for (uint32_t d : { spp, sample_count, (uint32_t) se.crop_w, rp.tcn, rp.pcn, rp.n_stratum })   // the kernels have no other division: fail loudly
         for (uint32_t n : { 0u, 1u, d - 1, d, d + 1, 2 * d - 1, 0x7fffffffu, 0xfffffffeu, 0xffffffffu })
             if (d && fdiv(n, make_fastdiv(d)) != n / d) throw std::runtime_error("internal error: fast division self-check failed");
     rp.n_passes = 1;
@@ -218,7 +222,7 @@ RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, cons
     }
     rp.path_correlation_depth = pp.path_correlation_depth; rp.max_depth = pp.max_depth; rp.rr_depth = pp.rr_depth;
     rp.integrator = pp.integrator;
-    rp.sampler_kind = pp.sampler_kind; rp.jitter = pp.jitter; rp.inv_spp = 1.0f / (float) spp;   // dr::rcp(ScalarFloat(m_sample_count))
+    rp.sampler_kind = pp.sampler_kind; rp.jitter = pp.jitter; rp.inv_spp = 1.0f / (float) sample_count;   // dr::rcp(ScalarFloat(m_sample_count))
     if (pp.integrator != INTEGRATOR_DOPPLER && n_offsets > 0) throw std::runtime_error("modulation offsets only apply to the dopplertofpath integrator");
     return rp;
 }
@@ -271,11 +275,32 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     const HostSensor &se = sc->host.sensor;
     if (spp == 0) spp = sc->pp.sample_count;
     if (spp == 0) throw std::runtime_error("sample count must be positive");
-    uint64_t total_lanes = (uint64_t) se.crop_w * se.crop_h * spp;
-    if (total_lanes > 0xffffffffull) throw std::runtime_error("wavefront exceeds 2^32-1 lanes; multi-pass rendering is not supported");
-    if (sc->pp.time_sampling != TIME_UNIFORM && sc->pp.stratify_each_interval && spp < (uint32_t) sc->pp.time_correlate_number)
+    // SamplingIntegrator::render (integrator.cpp:121-135,227-245): spp_per_pass = min(samples_per_pass, spp) must divide spp; a wavefront
+    // of more than 2^32 - 1 lanes is split into more passes (integer division, as written there), and Sampler::set_samples_per_wavefront
+    // (sampler.cpp:75-83) insists that the sample count is a multiple of the samples per pass.  `spp` below is the samples per PASS.
+    const uint32_t sample_count = spp;
+    uint32_t n_passes = 1;
+    {
+        uint32_t per_pass = sc->pp.samples_per_pass == 0xffffffffu || sc->pp.samples_per_pass == 0 ? spp : std::min(sc->pp.samples_per_pass, spp);
+        if (spp % per_pass != 0) throw std::runtime_error("sample_count (" + std::to_string(spp) + ") must be a multiple of spp_per_pass (" + std::to_string(per_pass) + ").");
+        const uint64_t wavefront = (uint64_t) se.crop_w * se.crop_h * per_pass, limit = 0xffffffffull;
+        if (wavefront > limit) {
+            per_pass /= (uint32_t) ((wavefront + limit - 1) / limit);
+            if (per_pass == 0 || spp % per_pass != 0) throw std::runtime_error("sample_count should be a multiple of samples_per_wavefront!");
+        }
+        n_passes = spp / per_pass; spp = per_pass;
+    }
+    uint64_t total_lanes = (uint64_t) se.crop_w * se.crop_h * spp;   // lanes of one pass (the wavefront)
+    if (sc->pp.time_sampling != TIME_UNIFORM && sc->pp.stratify_each_interval && sample_count < (uint32_t) sc->pp.time_correlate_number)
         throw std::runtime_error("sample count must be at least time_correlate_number when per-interval stratification is on");
-    RenderParams rp = make_params(sc, seed, spp, offsets, n_offsets);
+    RenderParams rp = make_params(sc, seed, spp, offsets, n_offsets, sample_count);
+    rp.n_passes = n_passes;
+    // lane dumps address (pass, lane) as pass * wavefront + lane and must stay inside one pass
+    uint32_t dump_pass = 0;
+    if (lane_dump) {
+        dump_pass = (uint32_t) (dump_begin / total_lanes); dump_begin %= total_lanes;
+        if (dump_pass >= n_passes || dump_begin + dump_n > total_lanes) throw std::runtime_error("lane range exceeds the wavefront");
+    }
     row_begin = std::max(row_begin, 0); row_end = std::min(row_end, se.crop_h);
     uint64_t lanes_per_row = (uint64_t) se.crop_w * spp;
     uint64_t first = lane_dump ? dump_begin : lanes_per_row * (uint64_t) row_begin;
@@ -295,7 +320,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     // Two batches are kept in flight on two HIP streams (each with its own workspace): the VALU-bound
     // trace/shadow kernels of one batch overlap the HBM-bound shade kernel of the other.
     static const int env_streams = [] { const char *e = getenv("DTOF_STREAMS"); int v = e ? atoi(e) : 1; return v == 2 ? 2 : 1; }();   // default 1: measured gain of 2 is 0% (Cornell) .. 7% (Domino) and it blurs per-stage timing
-    const int n_streams = lane_dump ? 1 : env_streams;
+    const int n_streams = (lane_dump || n_passes > 1) ? 1 : env_streams;   // the passes of a lane follow each other on one stream
     // Pipeline choice.  "fused" runs occlusion + continuation traversal inside the shade kernel (one kernel per bounce);
     // it wins when traversal is trivial (measured: Cornell-wall 4.00 vs 4.71 ms) and loses when traversal dominates
     // (Cornell-boxes 2.20 vs 1.97 ms, Domino 116 vs 102 ms) because the heavy shade kernel then diverges at 3 waves/SIMD.
@@ -347,27 +372,38 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     std::vector<uint64_t> h_counts; std::vector<uint32_t> batch_lanes, batch_iters;
     // per-iteration totals of every batch: sized ONCE (DevBuf::ensure reallocates without copying, and a hipFree in the middle of the
     // frame would also synchronise the device)
-    if (stats && last > first) sc->d_sums.ensure((size_t) ((last - first + batch - 1) / batch) * 2 * kMaxIter);
+    const uint32_t run_passes = lane_dump ? dump_pass + 1 : n_passes;   // a lane dump of pass k needs the stream states passes 0 .. k-1 leave
+    if (stats && last > first) sc->d_sums.ensure((size_t) ((last - first + batch - 1) / batch) * run_passes * 2 * kMaxIter);
+    if (n_passes > 1 && last > first) {   // stream states carried from pass to pass (Sampler::advance keeps the RNGs running, sampler.cpp:52-55)
+        sc->d_pass_rng.ensure((size_t) (last - first) * 3);
+        rp.pass_rng = sc->d_pass_rng.p; rp.pass_first = (uint32_t) first;
+    }
+    // the reference's last iteration only looks for emitter hits; without surface emitters it contributes nothing and is skipped --
+    // unless further passes follow, whose streams depend on the six draws every active lane makes in it
+    const bool skip_tail = !has_surface_emitters && n_passes == 1;
 
     // The host runs at most two batches ahead of the device: dtof_cancel (Integrator::cancel, integrator.h:96-109) is looked at when a
     // batch is enqueued, so an unbounded run-ahead would leave nothing to cancel once the launches of a long render are queued.
     hipEvent_t batch_done[2] = { sc->take_event(), sc->take_event() };
     uint32_t batch_index = 0;
+    for (uint32_t pass = 0; pass < run_passes; ++pass)
     for (uint64_t b0 = first; b0 < last; b0 += batch, ++batch_index) {
+        rp.pass = pass;
+        const bool dump_now = lane_dump && pass == dump_pass;
         if (batch_index >= 2) HIP_CHECK(hipEventSynchronize(batch_done[batch_index & 1]));
         if (sc->stop.load()) break;
         const Queues &q = qs[batch_index & 1]; hipStream_t s = ss[batch_index & 1];
         rp.lane_base = (uint32_t) b0; rp.n_lanes = (uint32_t) std::min<uint64_t>(batch, last - b0);
         const uint32_t n_seg = segments_for(rp.n_lanes);
         // does iteration 0 of the bounce loop run at all?  (same conditions as the loop head below)
-        const bool loop_runs = rp.integrator != INTEGRATOR_VELOCITY && rp.max_depth > 0 && !(1 >= rp.max_depth && !has_surface_emitters);
+        const bool loop_runs = rp.integrator != INTEGRATOR_VELOCITY && rp.max_depth > 0 && !(1 >= rp.max_depth && skip_tail);
         // fused pipeline: the first bounce kernel generates the lanes and traces the primary rays itself (DTOF_FUSE_FIRST=0 keeps
         // the separate k_generate + k_trace launches)
         const bool first_inline = fused && loop_runs && env_fuse_first;
         int t = -1;
         if (!first_inline) {
             t = tm.begin(0, s); launch_generate(rp, q, s); tm.end(0, t, s);
-            if (lane_dump) launch_lane_dump_rays(rp, q, sc->ws.dbg.p, s);
+            if (dump_now) launch_lane_dump_rays(rp, q, sc->ws.dbg.p, s);
         }
         const uint32_t *qin = nullptr, *count_in = nullptr; uint32_t it = 0;
         if (rp.integrator == INTEGRATOR_VELOCITY) { t = tm.begin(1, s); launch_velocity(blob, blob_bytes, rp, q, stack_depth, s); tm.end(1, t, s); }
@@ -376,7 +412,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             if (it >= rp.max_depth) break;
             // the last iteration of the reference only looks for emitter hits (dopplertofpath.cpp:136-171);
             // without surface emitters it cannot contribute and is skipped
-            if (it + 1 >= rp.max_depth && !has_surface_emitters) break;
+            if (it + 1 >= rp.max_depth && skip_tail) break;
             if (it >= 8 && (it & 3) == 0) {   // unbounded depth: stop once every segment has drained
                 std::vector<uint32_t> alive(n_seg);
                 HIP_CHECK(hipMemcpyAsync(alive.data(), count_in, (size_t) n_seg * 4, hipMemcpyDeviceToHost, s));
@@ -385,24 +421,25 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
                 if (sum == 0) break;
             }
             // does iteration it+1 run?  (same conditions as the loop head)
-            const bool next_runs = (it + 1 < rp.max_depth) && !(it + 2 >= rp.max_depth && !has_surface_emitters);
+            const bool next_runs = (it + 1 < rp.max_depth) && !(it + 2 >= rp.max_depth && skip_tail);
             const bool first = first_inline && it == 0;
             if (!fused || (it == 0 && !first)) { t = tm.begin(1, s); launch_trace(blob, blob_bytes, rp, q, qin, count_in, stack_depth, s); tm.end(1, t, s); if (stats) stats->n_launches_trace++; }
             // per-iteration count slots; beyond kMaxIter iterations (unbounded depth, paths that russian roulette keeps alive that long)
             // the slots are reused -- only the statistics lose those iterations, no path is cut short
             uint32_t *qout = q.q[it & 1], *alive_out = q.counts + (size_t) (2 * (it % kMaxIter)) * n_seg, *shadow_out = alive_out + n_seg;
             const int st_shade = first ? 5 : 2;
-            t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it, fused, next_runs, stack_depth, s, first, first && lane_dump ? sc->ws.dbg.p : nullptr); tm.end(st_shade, t, s);
+            t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it, fused, next_runs, stack_depth, s, first, first && dump_now ? sc->ws.dbg.p : nullptr); tm.end(st_shade, t, s);
             if (stats && first) stats->n_launches_first++;
             if (!fused) { t = tm.begin(3, s); launch_shadow(blob, blob_bytes, rp, q, shadow_out, stack_depth, s); tm.end(3, t, s); if (stats) stats->n_launches_shadow++; }
             if (stats) stats->n_launches_shade++;
             qin = qout; count_in = alive_out;
         }
-        if (lane_dump) {
+        if (n_passes > 1 && pass + 1 < run_passes) launch_pass_save(rp, q, s);
+        if (dump_now) {
             launch_lane_dump(rp, q, sc->ws.dbg.p, s);
             HIP_CHECK(hipMemcpyAsync(lane_dump + (b0 - first), sc->ws.dbg.p, (size_t) rp.n_lanes * sizeof(LaneDebug), hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
-        } else {
+        } else if (!lane_dump) {
             t = tm.begin(4, s); launch_splat(rp, q, d_film, se.crop_w, se.crop_h, s); tm.end(4, t, s);
         }
         HIP_CHECK(hipGetLastError());   // a rejected launch (LDS size, launch bounds, grid) must not pass for an empty film

@@ -117,15 +117,26 @@ DTOF_D PixelInfo pixel_info(const RenderParams &rp, uint32_t pix) {
     return pi;
 }
 // wave_pixel (uniform): see pixel_info; true only if spp is a multiple of 64 and the wave's lanes are 64 consecutive, 64-aligned lanes
-DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane, bool wave_pixel = false) {
-    Rng main = seed_stream(rp.seed_value, lane);
+// `vlane`: the lane's position in the rendered range (what the between-pass stream states are indexed by)
+DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane, bool wave_pixel = false, uint32_t vlane = 0) {
     // m_rng_time is only drawn from by the antithetic strategies of the correlated sampler (correlated.cpp:96-106)
     const bool needs_tm = rp.integrator == 0 && rp.sampler_kind == SAMPLER_CORRELATED && (rp.time_sampling == TIME_ANTITHETIC || rp.time_sampling == TIME_ANTITHETIC_MIRROR);
-    Rng tm; tm.state = 0; tm.inc = 1;
-    if (needs_tm) tm = seed_stream(rp.seed_value + 1, fdiv(lane, rp.d_tcn));
-    Rng path = seed_stream(rp.seed_value + 2, fdiv(lane, rp.d_pcn));
+    Rng main, tm, path; tm.state = 0; tm.inc = 1;
+    uint2 *const carried = rp.n_passes > 1 ? rp.pass_rng + (size_t) (vlane - rp.pass_first) * 3 : nullptr;
+    if (rp.pass == 0) {
+        main = seed_stream(rp.seed_value, lane);
+        if (needs_tm) tm = seed_stream(rp.seed_value + 1, fdiv(lane, rp.d_tcn));
+        path = seed_stream(rp.seed_value + 2, fdiv(lane, rp.d_pcn));
+    } else {   // later passes: the sampler was seeded once (integrator.cpp:265); its streams run on where the previous pass left them
+        const uint2 a = carried[0], b = carried[1], c = carried[2];
+        main.state = (uint64_t) a.x | ((uint64_t) a.y << 32); main.inc = stream_inc(rp.seed_value, lane);
+        if (needs_tm) { tm.state = (uint64_t) b.x | ((uint64_t) b.y << 32); tm.inc = stream_inc(rp.seed_value + 1, fdiv(lane, rp.d_tcn)); }
+        path.state = (uint64_t) c.x | ((uint64_t) c.y << 32); path.inc = stream_inc(rp.seed_value + 2, fdiv(lane, rp.d_pcn));
+    }
     const uint32_t pix = fdiv(lane, rp.d_spp);
-    uint32_t si = rp.spp > 1 ? lane - pix * rp.spp : 0;
+    // current_sample_index = m_sample_index * samples_per_wavefront + lane % samples_per_wavefront (sampler.cpp:94-103); Sampler::advance
+    // bumps m_sample_index once per pass (sampler.cpp:52-55)
+    uint32_t si = (rp.spp > 1 ? lane - pix * rp.spp : 0) + rp.pass * rp.spp;
     const PixelInfo pi = wave_pixel ? pixel_info<true>(rp, pix) : pixel_info<false>(rp, pix);
     const uint32_t perm_seed = pi.perm_seed; const float posx = pi.posx, posy = pi.posy;
     uint32_t dim = 0;
@@ -144,12 +155,13 @@ DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane, bool wav
         if (!doppler || rp.sampler_kind == SAMPLER_INDEPENDENT) u = next_f32(main);   // Sampler::next_1d_time -> next_1d (sampler.h:131-132)
         else if (rp.sampler_kind == SAMPLER_CORRELATED) u = next_time(rp, main, tm, si, perm_seed, dim);
         else {   // TimeStratifiedSampler::next_1d_time (timestratified.cpp:117-129): the strategy arguments are ignored
-            uint32_t p = permute_kensler(si, rp.spp, perm_seed + dim++, rp.d_spp);
+            uint32_t p = permute_kensler(si, rp.sample_count, perm_seed + dim++, rp.d_sample_count);
             float j = rp.jitter ? next_f32(main) : .5f;
             u = ((float) p + j) * rp.inv_spp;
         }
         time += u * rp.shutter_open_time;
     }
+    if (carried && needs_tm) carried[1] = make_uint2((uint32_t) tm.state, (uint32_t) (tm.state >> 32));
 
     // PerspectiveCamera::sample_ray_differential (perspective.cpp:238-279)
     const float *m = rp.s2c;

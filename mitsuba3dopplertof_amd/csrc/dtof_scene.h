@@ -163,6 +163,7 @@ struct PluginParams {
     // src/render/integrator.cpp:22-28, 54-100, 568-585
     int32_t time_sampling = TIME_ANTITHETIC; float antithetic_shift = .5f; bool stratify_each_interval = true;
     uint32_t path_correlation_depth = 0, max_depth = 0xffffffffu, rr_depth = 5; bool hide_emitters = false;
+    uint32_t samples_per_pass = 0xffffffffu;   // (uint32_t) -1: one pass
     // src/samplers/correlated.cpp:17-23, src/render/sampler.cpp:11-20
     uint32_t base_seed = 0, sample_count = 4; int32_t time_correlate_number = 2, path_correlate_number = 2;
 };

@@ -306,7 +306,7 @@ PluginParams make_plugin_params(const PropBag &ip, const PropBag &sp) {
     p.antithetic_shift = (float) ip.get_float("antithetic_shift", p.time_sampling == TIME_ANTITHETIC ? 0.5 : 0.0);
     p.stratify_each_interval = ip.get_bool("use_stratified_sampling_for_each_interval", true);
     p.path_correlation_depth = (uint32_t) ip.get_int("path_correlation_depth", 0);
-    if (ip.get_int("samples_per_pass", -1) != -1) fail("\"samples_per_pass\" is not supported (single-pass wavefront only)");
+    p.samples_per_pass = (uint32_t) ip.get_int("samples_per_pass", -1);   // SamplingIntegrator::m_samples_per_pass (integrator.cpp:54-56); -1 = one pass
     (void) ip.get_int("block_size", 0); (void) ip.get_float("timeout", -1.0);
     int64_t md = ip.get_int("max_depth", -1);
     if (md < 0 && md != -1) fail("\"max_depth\" must be set to -1 (infinite) or a value >= 0");

@@ -751,4 +751,6 @@ def integrator_params(ip, sp):
         base_seed=sp.get_i("seed", 0) & 0xffffffff, time_correlate_number=tcn,
         path_correlate_number=sp.get_i("path_correlate_number", tcn) if sp.plugin == "correlated" else 2,
         sample_count=sp.get_i("sample_count", 4), integrator=kinds[ip.plugin], sampler=samplers[sp.plugin],
-        jitter=int(sp.get_b("jitter", True)) if sp.plugin == "timestratified" else 1)
+        jitter=int(sp.get_b("jitter", True)) if sp.plugin == "timestratified" else 1,
+        # SamplingIntegrator::m_samples_per_pass (integrator.cpp:54-56): -1 -> (uint32_t) -1 = one pass
+        samples_per_pass=int(ip.get_i("samples_per_pass", -1)) & 0xffffffff)

@@ -604,6 +604,49 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_rank_image(mi, tmp_path):
         assert striped.shape == ref.shape and rel_linf(striped, ref) <= IMG_TOL, (name, rel_linf(striped, ref))
 
 
+@pytest.mark.parametrize("scene,integ,sampler,spp,per_pass", [
+    ("cornell_wall.xml", dict(type="dopplertofpath", max_depth=4, path_correlation_depth=4, time_sampling_method="stratified", hetero_frequency=1.0), None, 16, 4),
+    ("cornell_boxes.xml", dict(type="dopplertofpath", max_depth=3, path_correlation_depth=2, time_sampling_method="antithetic", hetero_frequency=1.0), None, 8, 2),
+    ("cornell_area.xml", dict(type="dopplertofpath", max_depth=5, rr_depth=2, time_sampling_method="antithetic_mirror", antithetic_shift=0.0), None, 12, 4),
+    ("cornell_boxes.xml", dict(type="dopplertofpath", max_depth=4, hetero_frequency=1.0), dict(type="timestratified"), 8, 4),
+    ("cornell_wall.xml", dict(type="path", max_depth=3), dict(type="independent", sample_count=8), 8, 2),
+])
+def test_multi_pass_wavefronts_match_the_oracle(mi, orc, scene, integ, sampler, spp, per_pass):
+    """samples_per_pass (SamplingIntegrator::render, integrator.cpp:121-135,227-245): the wavefront holds spp_per_pass samples per pixel, the
+    sampler is seeded once and its three streams run on from pass to pass (Sampler::advance, sampler.cpp:52-55), the sample index used
+    by the stratified time strategies counts through the passes.  Every (pass, lane) bit-exact against the oracle, in the fused and
+    the split pipeline (scenes with and without meshes), with area lights (the emitter-hit iteration) and without (the iteration that
+    single-pass renders skip must still advance the streams)."""
+    path = os.path.join(SCENES, scene)
+    params = dict(resx=24, resy=16)
+    sc, osc = mi.load_file(path, **params), orc.Scene(path, params)
+    multi = dict(integ, samples_per_pass=per_pass)
+    sc.set_integrator(multi)
+    if sampler is not None:
+        sc.set_sampler(sampler)
+    pd = osc.params(integrator=multi, sampler=sampler)
+    wavefront, n_passes = 24 * 16 * per_pass, spp // per_pass
+    for k in range(n_passes):
+        g = sc.sample_lanes(4, spp, k * wavefront, wavefront)
+        o = osc.render_lanes(pd, 4, spp, k * wavefront, wavefront, threads=NCPU)
+        for f in ("sample_pos", "time", "ray_d", "rgb"):
+            assert np.array_equal(bits(g[f]), bits(o[f])), (scene, "pass", k, f, int((bits(g[f]) != bits(o[f])).sum()))
+    img = sc.render(seed=4, spp=spp)
+    assert sc.last_stats["n_paths"] == 24 * 16 * spp
+    ref, n = osc.render(pd, seed=4, spp=spp, threads=NCPU)
+    assert n == 24 * 16 * spp and rel_linf(img, ref) <= IMG_TOL
+    # one pass that holds all samples is the plain render; a pass size that does not divide the sample count is refused like the reference does
+    sc.set_integrator(dict(integ, samples_per_pass=spp))
+    whole = sc.render(seed=4, spp=spp)
+    sc.set_integrator(integ)
+    assert rel_linf(whole, sc.render(seed=4, spp=spp)) <= IMG_TOL and not np.array_equal(whole, img)
+    sc.set_integrator(dict(integ, samples_per_pass=3))
+    with pytest.raises(mi.DtofError, match="must be a multiple of spp_per_pass"):
+        sc.render(seed=0, spp=8)
+    with pytest.raises(mi.DtofError, match="exceeds the wavefront"):
+        sc.sample_lanes(0, 9, 24 * 16 * 3 - 4, 8)      # a lane dump may not straddle two passes
+
+
 def test_two_ranks_over_rccl_reproduce_the_single_rank_image(mi, tmp_path):
     """The same N = 2 path with backend "nccl" (= RCCL over xGMI), one GPU per rank: runs wherever the box has two or more GPUs
     (the driver's 8-GPU node), so that RCCL sees N > 1 ranks before the scaling bench does; skipped on one-GPU boxes."""

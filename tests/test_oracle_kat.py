@@ -270,3 +270,28 @@ def test_reconstruction_filters_are_partitions_of_unity(orc, rfilter, exact):
         # weights of samples in pixel rows/cols 3..12 land within rows/cols 1..14 and sum to 1 each: the mass that reaches the
         # 10 x 10 centre from outside equals the mass that leaves it, up to the random sample positions -> within 2 %
         assert abs(inner / (10 * 10 * 8) - 1.0) < 0.02
+
+
+def test_multi_pass_layout_and_sample_index(orc):
+    """orc_pass_layout restates integrator.cpp:121-135,227-245; one pass holding every sample equals the plain render; with stratified
+    time sampling the strata of a pixel are still hit exactly once each over all passes (the sample index runs through the passes)."""
+    import ctypes as C
+    L = orc.lib()
+    def layout(w, h, spp, per_pass):
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        rc = L.orc_pass_layout(w, h, spp, per_pass & 0xffffffff, C.byref(a), C.byref(b))
+        return rc, a.value, b.value
+    assert layout(64, 64, 16, -1) == (0, 16, 1) and layout(64, 64, 16, 4) == (0, 4, 4) and layout(64, 64, 16, 64) == (0, 16, 1)
+    assert layout(64, 64, 10, 4)[0] == -1                                        # spp % spp_per_pass != 0
+    # 2^33 lanes: ceil(2^33 / (2^32 - 1)) = 3 passes, 512 / 3 = 170 does not divide 512 -> the reference throws (sampler.cpp:75-83)
+    assert layout(4096, 4096, 512, -1)[0] == -1
+    assert layout(4096, 4096, 768, -1) == (0, 192, 4) and layout(4096, 4096, 255, -1) == (0, 255, 1)   # ceil(3.0000000007) = 4
+    sc = orc.Scene(os.path.join(SCENES, "cornell_wall.xml"), dict(resx=6, resy=5))
+    integ = dict(type="dopplertofpath", max_depth=3, path_correlation_depth=3, time_sampling_method="stratified")
+    one, _ = sc.render(sc.params(integrator=integ), seed=2, spp=16)
+    same, _ = sc.render(sc.params(integrator=dict(integ, samples_per_pass=16)), seed=2, spp=16)
+    assert np.array_equal(one, same)
+    pd = sc.params(integrator=dict(integ, samples_per_pass=4))
+    lanes = sc.render_lanes(pd, 2, 16, 0, 6 * 5 * 16)                           # 4 passes x 120 lanes
+    t = lanes["time"].reshape(4, 30, 4).transpose(1, 0, 2).reshape(30, 16) / 0.0015
+    assert np.array_equal(np.sort(np.floor(t * 16).astype(int), axis=1), np.tile(np.arange(16), (30, 1)))
