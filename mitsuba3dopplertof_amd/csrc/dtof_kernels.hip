@@ -339,6 +339,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
             float wiz = si.wi.z, woz = wo.z;
             if (twosided) { woz = mulsign(woz, wiz); wiz = fabsf(wiz); }
             V3 refl = mk(sh->refl[0], sh->refl[1], sh->refl[2]);
+            if (SPEC && (sh->nonlinear >> 1)) refl = texture_eval(sv, (sh->nonlinear >> 1) << 4, si.u, si.v);   // m_reflectance->eval(si)
             V3 bsdf_val = mk(0, 0, 0), bsdf_weight = mk(0, 0, 0), bs_wo = mk(0, 0, 0);
             float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; bool bs_delta = false;
             if (SPEC && sh->bsdf == BSDF_CONDUCTOR) {
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
                 const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, sh->alpha_u, sh->alpha_u);
                 const float *table = (const float *) (sv.base + sh->rough_table);
                 const float w = sh->spec_sampling_weight, ir = sh->fdr_int;
-                const V3 diff = sh->nonlinear ? mk(refl.x / (1.f - refl.x * ir), refl.y / (1.f - refl.y * ir), refl.z / (1.f - refl.z * ir))
+                const V3 diff = (sh->nonlinear & 1u) ? mk(refl.x / (1.f - refl.x * ir), refl.y / (1.f - refl.y * ir), refl.z / (1.f - refl.z * ir))
                                               : mk(refl.x / (1.f - ir), refl.y / (1.f - ir), refl.z / (1.f - ir));
                 if (wi.z > 0.f) {
                     const float t_i = lerp_gather64(table, wi.z);
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
                 float f_i, t1, t2, t3;
                 fresnel_dielectric(wiz, sh->diel_eta, f_i, t1, t2, t3);
                 const float w = sh->spec_sampling_weight, fdr = sh->fdr_int;
-                const V3 diff = sh->nonlinear ? mk(refl.x / (1.f - refl.x * fdr), refl.y / (1.f - refl.y * fdr), refl.z / (1.f - refl.z * fdr))
+                const V3 diff = (sh->nonlinear & 1u) ? mk(refl.x / (1.f - refl.x * fdr), refl.y / (1.f - refl.y * fdr), refl.z / (1.f - refl.z * fdr))
                                               : mk(refl.x / (1.f - fdr), refl.y / (1.f - fdr), refl.z / (1.f - fdr));
                 if (wiz > 0.f && woz > 0.f) {
                     float f_o; fresnel_dielectric(woz, sh->diel_eta, f_o, t1, t2, t3);

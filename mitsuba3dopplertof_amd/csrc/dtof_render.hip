@@ -346,7 +346,8 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     for (auto &e : sc->host.emitters) has_surface_emitters |= e.kind == EMITTER_AREA;
     rp.has_area = has_surface_emitters;
     for (auto &sh : sc->host.shapes) rp.has_spec |= sh.bsdf != BSDF_DIFFUSE;
-    for (auto &e : sc->host.emitters) rp.has_spec |= e.kind == EMITTER_SPOT;   // the spot branch lives in the SPEC instantiations (keeps the common kernels lean)
+    for (auto &e : sc->host.emitters) rp.has_spec |= e.kind == EMITTER_SPOT;
+    rp.has_spec |= !sc->host.textures.empty();   // textured reflectances are looked up in the SPEC instantiations only   // the spot branch lives in the SPEC instantiations (keeps the common kernels lean)
     bool has_spheres = false;
     for (auto &sh : sc->host.shapes) has_spheres |= sh.kind == SHAPE_SPHERE || sh.kind == SHAPE_DISK;   // analytic shapes of the MESH instantiations
     rp.has_tris = bh->n_tris != 0 || has_spheres;   // anything but rectangles: the instantiations with triangle / sphere code
@@ -636,7 +637,13 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
             v.push_back(s.inv_eta_2); v.push_back(s.fdr_int); v.push_back(s.spec_sampling_weight);
             v.insert(v.end(), s.refl, s.refl + 3); v.insert(v.end(), s.spec_refl, s.spec_refl + 3); v.insert(v.end(), s.spec_trans, s.spec_trans + 3);
             v.insert(v.end(), s.cond_eta, s.cond_eta + 3); v.insert(v.end(), s.cond_k, s.cond_k + 3); v.push_back(s.alpha_u); v.push_back(s.alpha_v);
-        } else if (kind == 12) for (auto &s : sc->host.shapes) {
+        } else if (kind == 13) for (auto &t : sc->host.textures) {
+            v.push_back((float) t.kind); v.push_back((float) t.filter); v.push_back((float) t.wrap); v.push_back((float) t.channels);
+            v.push_back((float) t.width); v.push_back((float) t.height);
+            v.insert(v.end(), t.to_uv, t.to_uv + 4); v.insert(v.end(), t.color0, t.color0 + 3); v.insert(v.end(), t.color1, t.color1 + 3); v.push_back(t.mean);
+        } else if (kind == 14) for (auto &t : sc->host.textures) v.insert(v.end(), t.data.begin(), t.data.end());
+        else if (kind == 15) for (auto &s : sc->host.shapes) v.push_back((float) s.tex_refl);
+        else if (kind == 12) for (auto &s : sc->host.shapes) {
             v.push_back(s.beckmann ? 0.f : 1.f);
         } else if (kind == 10) for (auto &s : sc->host.shapes) {
             if (s.bsdf == BSDF_ROUGHPLASTIC) v.insert(v.end(), s.rough_table.begin(), s.rough_table.end());

@@ -16,7 +16,8 @@ enum WaveType : int32_t { WAVE_SIN = 0, WAVE_RECT = 1, WAVE_TRI = 2, WAVE_TRAP =
 // ETimeSampling -- include/mitsuba/render/sampler.h:27-34
 enum TimeSampling : int32_t { TIME_UNIFORM = 0, TIME_STRATIFIED = 1, TIME_ANTITHETIC = 2, TIME_ANTITHETIC_MIRROR = 3 };
 enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1, FILTER_GAUSSIAN = 2, FILTER_MITCHELL = 3, FILTER_CATMULLROM = 4 };
-enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4, SF_EMITTER = 8, SF_BECKMANN = 16 /* rough BSDFs: Beckmann instead of GGX */ };
+enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4, SF_EMITTER = 8, SF_BECKMANN = 16 /* rough BSDFs: Beckmann instead of GGX */,
+                            SF_TEXCOORDS = 32 /* mesh with vertex texcoords (si.uv interpolates them; otherwise si.uv = the barycentrics, mesh.cpp:720-737) */ };
 enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4, BSDF_ROUGHPLASTIC = 5, BSDF_THINDIELECTRIC = 6, BSDF_ROUGHDIELECTRIC = 7 };
 enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1, EMITTER_SPOT = 2 };
 
@@ -82,11 +83,21 @@ struct DShape {             // 304 B
     // BSDF: BSDF_DIFFUSE uses refl; BSDF_CONDUCTOR (src/bsdfs/conductor.cpp) cond_eta / cond_k / spec_refl; BSDF_DIELECTRIC
     // (src/bsdfs/dielectric.cpp) diel_eta = int_ior / ext_ior, spec_refl, spec_trans
     // BSDF_PLASTIC (src/bsdfs/plastic.cpp): refl = diffuse_reflectance, spec_refl, diel_eta and the constants of parameters_changed
-    uint32_t bsdf; float diel_eta; uint32_t nonlinear; float inv_eta_2;
+    uint32_t bsdf; float diel_eta; uint32_t nonlinear; float inv_eta_2;   // nonlinear: bit 0 = the plastics' `nonlinear`; bits 1.. = (byte offset of the reflectance texture's DTexture in the blob) >> 4, 0 = none
     // BSDF_ROUGHCONDUCTOR (src/bsdfs/roughconductor.cpp, GGX + visible normals): cond_eta / cond_k / spec_refl + alpha_u, alpha_v
     // BSDF_ROUGHPLASTIC (src/bsdfs/roughplastic.cpp, GGX + visible normals): the plastic fields + alpha_u; fdr_int = m_internal_reflectance;
     // rough_table = byte offset in the blob of m_external_transmittance (64 floats)
     float cond_eta[3], fdr_int, cond_k[3], spec_sampling_weight, spec_refl[3], alpha_u, spec_trans[3], alpha_v;
+};
+// Texture on a BSDF's diffuse reflectance (src/textures/checkerboard.cpp, src/textures/bitmap.cpp); the record and, for bitmaps, the
+// linear float32 texels (row 0 first) live in the tables area of the blob.  to_uv: the 2x2 linear part of the plugin's `to_uv`
+// (Transform4f::extract, transform.h:340-360, copies the upper-left block and the bottom ROW: a translation is lost there).
+enum TextureKind : uint32_t { TEX_CHECKERBOARD = 0, TEX_BITMAP = 1 };
+struct DTexture {           // 64 B
+    uint32_t kind_flags;    // kind | filter << 8 (0 nearest, 1 bilinear) | wrap << 16 (0 repeat, 1 mirror, 2 clamp) | channels << 24
+    uint32_t width, height, data_off;   // data_off: byte offset of the texels in the blob
+    float to_uv[4], color0[3], color1[3];
+    uint32_t pad[2];
 };
 struct DTri { float p0[3]; uint32_t face; float p1[4], p2[4]; };         // 48 B; face = index in the mesh's own order (tie rule)
 struct DTriShade { float n0[3], n1[3], n2[3], uv0[2], uv1[2], uv2[2], pad; };   // 64 B
@@ -96,6 +107,7 @@ struct DEmitter {           // 96 B
     float to_local[12]; float cutoff_angle, cos_cutoff, cos_beam, inv_transition;
 };
 static_assert(sizeof(BvhNode4) == 128, "BvhNode4");
+static_assert(sizeof(DTexture) == 64, "DTexture");
 static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 304 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64 && sizeof(DEmitter) == 96, "blob records");
 
 // ---------------------------------------------------------------------------- host description
@@ -110,6 +122,7 @@ struct HostShape {
     bool nonlinear = false; float inv_eta_2 = 1.f, fdr_int = 0.f, spec_sampling_weight = 0.f;   // plastic
     float alpha_u = .1f, alpha_v = .1f;   // roughconductor, roughplastic
     bool beckmann = false;                 // their `distribution` (microfacet.h MicrofacetType)
+    int tex_refl = -1;                     // texture on reflectance / diffuse_reflectance: index into HostScene::textures
     std::vector<float> rough_table;        // roughplastic: m_external_transmittance (64 values)
     float to_world[16], to_object[16];     // float casts of the double transform and its double inverse
     // mesh: cube baked like src/shapes/cube.cpp:114-160; obj / ply through mesh_io.cpp
@@ -118,6 +131,12 @@ struct HostShape {
     float center[3] = { 0, 0, 0 }, radius = 1.f, sphere_inv_area = 0.f;   // sphere: m_center, m_radius, m_inv_surface_area after update()
     std::string id;
     bool emitter = false; float radiance[3] = { 0, 0, 0 };   // area emitter attached to the shape (src/emitters/area.cpp)
+};
+struct HostTexture {
+    uint32_t kind = TEX_CHECKERBOARD, filter = 1, wrap = 0, channels = 3, width = 0, height = 0;
+    float to_uv[4] = { 1, 0, 0, 1 }, color0[3] = { .4f, .4f, .4f }, color1[3] = { .2f, .2f, .2f };
+    std::vector<float> data;       // bitmap: linear float32 texels
+    float mean = 0.f;              // Texture::mean()
 };
 struct HostGroup { uint32_t first_shape = 0, n_shapes = 0; };
 struct HostObject {
@@ -167,6 +186,7 @@ struct PluginParams {
     // src/samplers/correlated.cpp:17-23, src/render/sampler.cpp:11-20
     uint32_t base_seed = 0, sample_count = 4; int32_t time_correlate_number = 2, path_correlate_number = 2;
 };
+void read_png(const std::string &path, std::vector<uint8_t> &pixels, uint32_t &width, uint32_t &height, uint32_t &channels);   // image_io.cpp
 PluginParams make_plugin_params(const PropBag &integrator, const PropBag &sampler);   // throws std::runtime_error
 
 struct HostScene {
@@ -174,6 +194,7 @@ struct HostScene {
     std::vector<HostGroup> groups;
     std::vector<HostObject> objects;
     std::vector<HostEmitter> emitters;
+    std::vector<HostTexture> textures;
     HostSensor sensor;
     PropBag integrator, sampler;
 };

@@ -9,7 +9,7 @@
 
 namespace dtof {
 
-struct Surface { V3 p, n, sh_n, sh_s, sh_t, wi; const DShape *shape; };
+struct Surface { V3 p, n, sh_n, sh_s, sh_t, wi; float u, v; const DShape *shape; };   // u, v = si.uv (rectangles and meshes)
 
 // Shape::compute_surface_interaction for rectangle (rectangle.cpp:250-323) / mesh (mesh.cpp:632-864),
 // Instance::compute_surface_interaction (instance.cpp:155-250), finalize (interaction.h:493-513)
@@ -34,8 +34,10 @@ DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, 
         sh = &sv.shapes[sv.groups[ob.index].first_shape + shape_k];
     } else sh = &sv.shapes[ob.index];
     si.shape = sh;
+    si.u = si.v = 0.f;
     V3 dp_du, dp_dv;
     if (!MESH || sh->kind == SHAPE_RECT) {
+        si.u = fmaf(b1, .5f, .5f); si.v = fmaf(b2, .5f, .5f);   // rectangle.cpp:312-313 (prim_uv = the local hit position)
         V3 n = mk(sh->n[0], sh->n[1], sh->n[2]);
         V3 p = vfma(ld, t, lo);
         V3 tr = mk(sh->to_world[3], sh->to_world[7], sh->to_world[11]);
@@ -72,6 +74,8 @@ DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, 
         float b0 = 1.f - b1 - b2;
         V3 dp0 = p1 - p0, dp1 = p2 - p0;
         si.p = vfma(p0, b0, vfma(p1, b1, p2 * b2));
+        si.u = b1; si.v = b2;                                    // mesh.cpp:720-737
+        if (sh->flags & SF_TEXCOORDS) { si.u = fmaf(ts.uv2[0], b2, fmaf(ts.uv1[0], b1, ts.uv0[0] * b0)); si.v = fmaf(ts.uv2[1], b2, fmaf(ts.uv1[1], b1, ts.uv0[1] * b0)); }
         si.n = normalize(cross(dp0, dp1));
         coordinate_system(si.n, dp_du, dp_dv);
         float d0x = ts.uv1[0] - ts.uv0[0], d0y = ts.uv1[1] - ts.uv0[1], d1x = ts.uv2[0] - ts.uv0[0], d1y = ts.uv2[1] - ts.uv0[1];
@@ -202,6 +206,44 @@ DTOF_D float sphere_pdf_direction(const DShape &sh, V3 ref, V3 ds_d, V3 ds_n, fl
     const V3 center = mk(sh.n[0], sh.n[1], sh.n[2]);
     const float sin_alpha = sh.dp_du[0] * rcp(norm(center - ref)), cos_alpha = safe_sqrt(1.f - sin_alpha * sin_alpha);
     return sin_alpha < 0.99999994f ? uniform_cone_pdf(cos_alpha) : sh.inv_area * sqr(ds_dist) / fabsf(dot(ds_d, ds_n));
+}
+// Textures on the diffuse reflectance: Checkerboard::eval (src/textures/checkerboard.cpp:70-89), BitmapTexture::eval -> interpolate_3 / _1
+// (src/textures/bitmap.cpp:633-670) -> dr::Texture<Float, 2>::eval (Dr.Jit 0.4.0 texture.h, not in the tree; restated: texel centres at
+// (i + .5) / res, the four neighbours wrapped per mode, weights combined as fmadd(w0.y, fmadd(w0.x, v00, w1.x * v10), w1.y * fmadd(...)))
+DTOF_D int32_t tex_wrap(int32_t i, int32_t n, uint32_t mode) {
+    if (mode == 2) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    int32_t div = i / n; if (i % n < 0) --div;
+    int32_t mod = i - div * n;
+    if (mode == 1 && (div & 1)) mod = n - 1 - mod;
+    return mod;
+}
+DTOF_D V3 texture_eval(const SceneView &sv, uint32_t rec_off, float u, float v) {
+    const DTexture &tex = *(const DTexture *) (sv.base + rec_off);
+    const float tu = fmaf(tex.to_uv[1], v, fmaf(tex.to_uv[0], u, 0.f)), tv = fmaf(tex.to_uv[3], v, fmaf(tex.to_uv[2], u, 0.f));
+    const uint32_t kind = tex.kind_flags & 0xffu, filter = (tex.kind_flags >> 8) & 0xffu, wrap = (tex.kind_flags >> 16) & 0xffu, C = tex.kind_flags >> 24;
+    if (kind == TEX_CHECKERBOARD) {
+        const bool mx = tu - floorf(tu) > .5f, my = tv - floorf(tv) > .5f;
+        return mx == my ? mk(tex.color0[0], tex.color0[1], tex.color0[2]) : mk(tex.color1[0], tex.color1[1], tex.color1[2]);
+    }
+    const int32_t W = (int32_t) tex.width, H = (int32_t) tex.height;
+    const float *data = (const float *) (sv.base + tex.data_off);
+    float texel[3] = { 0.f, 0.f, 0.f };
+    if (filter == 0) {
+        const int32_t x = tex_wrap((int32_t) floorf(tu * (float) W), W, wrap), y = tex_wrap((int32_t) floorf(tv * (float) H), H, wrap);
+        for (uint32_t c = 0; c < C; ++c) texel[c] = data[((size_t) y * W + x) * C + c];
+    } else {
+        const float px = fmaf(tu, (float) W, -.5f), py = fmaf(tv, (float) H, -.5f), fx = floorf(px), fy = floorf(py);
+        const float w1x = px - fx, w1y = py - fy, w0x = 1.f - w1x, w0y = 1.f - w1y;
+        const int32_t x0 = tex_wrap((int32_t) fx, W, wrap), x1 = tex_wrap((int32_t) fx + 1, W, wrap);
+        const int32_t y0 = tex_wrap((int32_t) fy, H, wrap), y1 = tex_wrap((int32_t) fy + 1, H, wrap);
+        for (uint32_t c = 0; c < C; ++c) {
+            const float v00 = data[((size_t) y0 * W + x0) * C + c], v10 = data[((size_t) y0 * W + x1) * C + c];
+            const float v01 = data[((size_t) y1 * W + x0) * C + c], v11 = data[((size_t) y1 * W + x1) * C + c];
+            texel[c] = fmaf(w0y, fmaf(w0x, v00, w1x * v10), w1y * fmaf(w0x, v01, w1x * v11));
+        }
+    }
+    if (C == 1) texel[1] = texel[2] = texel[0];
+    return mk(texel[0], texel[1], texel[2]);
 }
 // RoughPlastic::lerp_gather (roughplastic.cpp:373-383) on the 64-entry transmittance table
 DTOF_D float lerp_gather64(const float *data, float x) {

@@ -179,17 +179,31 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     std::vector<uint32_t> tables;   // mesh emitters: cdf[n] | pmf[n] (float bits) | slot[n]; roughplastic: 64 transmittances
     const char *blas_env = getenv("DTOF_BLAS"); const bool use_blas = !(blas_env && blas_env[0] == '0');   // DTOF_BLAS=0: loop over every triangle (debug)
     std::vector<Box> shape_boxes(sc.shapes.size());
+    std::vector<std::pair<uint32_t, uint32_t>> tex_recs;   // (shape, word offset of its DTexture in `tables`)
     for (size_t i = 0; i < sc.shapes.size(); ++i) {
         const HostShape &h = sc.shapes[i]; DShape &d = shapes[i];
         memset(&d, 0, sizeof d);
         d.kind = h.kind;
-        d.flags = (h.twosided ? SF_TWOSIDED : 0) | (h.flip_normals ? SF_FLIP_NORMALS : 0) | (h.face_normals ? SF_FACE_NORMALS : 0) | (h.beckmann ? SF_BECKMANN : 0);
+        d.flags = (h.twosided ? SF_TWOSIDED : 0) | (h.flip_normals ? SF_FLIP_NORMALS : 0) | (h.face_normals ? SF_FACE_NORMALS : 0) | (h.beckmann ? SF_BECKMANN : 0) | (!h.texcoords.empty() ? SF_TEXCOORDS : 0);
         memcpy(d.refl, h.refl, 12); d.blas_root = kNoChild;
         d.bsdf = h.bsdf; d.diel_eta = h.diel_eta; d.nonlinear = h.nonlinear; d.inv_eta_2 = h.inv_eta_2; d.fdr_int = h.fdr_int; d.spec_sampling_weight = h.spec_sampling_weight; d.alpha_u = h.alpha_u; d.alpha_v = h.alpha_v;
         memcpy(d.cond_eta, h.cond_eta, 12); memcpy(d.cond_k, h.cond_k, 12); memcpy(d.spec_refl, h.spec_refl, 12); memcpy(d.spec_trans, h.spec_trans, 12);
         if (h.bsdf == BSDF_ROUGHPLASTIC) {   // m_external_transmittance; rebased to a blob offset below
             d.rough_table = (uint32_t) tables.size() * 4u;
             for (float v : h.rough_table) { uint32_t b; memcpy(&b, &v, 4); tables.push_back(b); }
+        }
+        if (h.tex_refl >= 0) {   // the texture record and its texels go to the tables area; the offset is rebased below
+            const HostTexture &t = sc.textures[(size_t) h.tex_refl];
+            while (tables.size() % 4) tables.push_back(0);            // 16-byte aligned record (the offset is stored >> 4)
+            const uint32_t rec = (uint32_t) tables.size();
+            DTexture dt; memset(&dt, 0, sizeof dt);
+            dt.kind_flags = t.kind | (t.filter << 8) | (t.wrap << 16) | (t.channels << 24);
+            dt.width = t.width; dt.height = t.height; dt.data_off = (rec + (uint32_t) (sizeof(DTexture) / 4)) * 4u;
+            memcpy(dt.to_uv, t.to_uv, 16); memcpy(dt.color0, t.color0, 12); memcpy(dt.color1, t.color1, 12);
+            const uint32_t *w = (const uint32_t *) &dt;
+            tables.insert(tables.end(), w, w + sizeof(DTexture) / 4);
+            for (float v : t.data) { uint32_t b; memcpy(&b, &v, 4); tables.push_back(b); }
+            tex_recs.emplace_back((uint32_t) i, rec);
         }
         if (h.emitter) { d.flags |= SF_EMITTER; memcpy(d.radiance, h.radiance, 12); }
         memcpy(d.to_world, h.to_world, 48); memcpy(d.to_object, h.to_object, 48);
@@ -370,6 +384,11 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     h.total_bytes = off;
     for (DShape &d : shapes) if (d.kind == SHAPE_MESH && (d.flags & SF_EMITTER)) d.emit_table += h.off_tables;
     for (DShape &d : shapes) if (d.bsdf == BSDF_ROUGHPLASTIC) d.rough_table += h.off_tables;
+    for (auto &tr : tex_recs) {   // reflectance textures: record offset (>> 4) beside the `nonlinear` bit, texel offset inside the record
+        const uint32_t rec_off = h.off_tables + tr.second * 4u;
+        shapes[tr.first].nonlinear |= (rec_off >> 4) << 1;
+        tables[tr.second + 3] += h.off_tables;                     // DTexture::data_off
+    }
     std::vector<uint8_t> blob(off, 0);
     memcpy(blob.data(), &h, sizeof h);
     if (!dev_nodes.empty()) memcpy(blob.data() + h.off_nodes, dev_nodes.data(), dev_nodes.size() * sizeof(DNode));

@@ -331,7 +331,8 @@ PluginParams make_plugin_params(const PropBag &ip, const PropBag &sp) {
 
 // ---------------------------------------------------------------------------- object tree
 struct Obj {
-    std::string tag, plugin, id;
+    std::string tag, plugin, id, name;       // name: the `name` attribute of the element (the property an object is assigned to)
+    std::vector<std::string> ref_names;     // `name` attribute of <ref> children, by position in `children` ("" elsewhere)
     PropBag props;
     std::map<std::string, std::vector<double>> colors;            // <rgb>/<spectrum>
     std::map<std::string, std::vector<double>> vectors;           // <point>/<vector>
@@ -377,16 +378,16 @@ static void substitute(XNode &n, LoadCtx &ctx) {
 
 static std::shared_ptr<Obj> parse_object(const XNode &n, LoadCtx &ctx) {
     auto o = std::make_shared<Obj>();
-    o->tag = n.tag; o->plugin = n.get("type"); o->id = n.get("id"); o->props.plugin = o->plugin;
+    o->tag = n.tag; o->plugin = n.get("type"); o->id = n.get("id"); o->name = n.get("name"); o->props.plugin = o->plugin;
     for (auto &cp : n.children) {
         const XNode &c = *cp; std::string name = c.get("name");
         if (!name.empty() && name[0] == '_') fail("invalid parameter name \"" + name + "\": leading underscores are reserved");
         PropValue v;
         if (c.tag == "default") continue;
-        else if (is_object_tag(c.tag)) { o->children.emplace_back(c.tag, parse_object(c, ctx)); }
+        else if (is_object_tag(c.tag)) { o->children.emplace_back(c.tag, parse_object(c, ctx)); o->ref_names.emplace_back(); }
         else if (c.tag == "ref") {
             if (!c.attr("id")) fail("<ref>: missing \"id\" attribute");
-            o->refs.emplace_back(o->children.size(), c.get("id")); o->children.emplace_back("ref", nullptr);
+            o->refs.emplace_back(o->children.size(), c.get("id")); o->children.emplace_back("ref", nullptr); o->ref_names.push_back(name);
         }
         else if (c.tag == "float") { v.type = PropValue::Float; v.f = parse_double(c.get("value")); o->props.values[name] = v; }
         else if (c.tag == "integer") { v.type = PropValue::Int; v.i = parse_int(c.get("value")); o->props.values[name] = v; }
@@ -538,6 +539,72 @@ void rough_plastic_tables(int type, float alpha, float eta, float *table, float 
     *internal_reflectance = sum * (1.f / 64.f) * 2.f;
 }
 
+// ---- textures on the diffuse reflectances (src/textures/checkerboard.cpp:55-62, src/textures/bitmap.cpp:113-262, RGB variants)
+static thread_local std::vector<HostTexture> *g_textures = nullptr;   // the scene being assembled
+static thread_local std::string g_base_dir;
+static float srgb_to_linear_u8(uint32_t v) {   // StructConverter::linearize + dr::srgb_to_linear (src/core/struct.cpp:1600-1625)
+    const double x = (double) v / 255.0;
+    return (float) (x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4));
+}
+static HostTexture texture_of(const Obj &t) {
+    HostTexture tex;
+    auto uv = t.transforms.find("to_uv");
+    if (uv != t.transforms.end()) {   // Transform4f::extract(): the upper-left 2x2 block (transform.h:340-360; the translation column is not copied)
+        const Mat4d &m = uv->second.m;
+        tex.to_uv[0] = (float) m.m[0]; tex.to_uv[1] = (float) m.m[1]; tex.to_uv[2] = (float) m.m[4]; tex.to_uv[3] = (float) m.m[5];
+    }
+    if (t.plugin == "checkerboard") {
+        for (auto &c : t.children) if (c.first == "texture" || c.first == "ref") fail("checkerboard: nested textures are not supported (constant colours only)");
+        tex.kind = TEX_CHECKERBOARD;
+        color_of(t, "color0", .4f, tex.color0); color_of(t, "color1", .2f, tex.color1);
+        const float third = 1.0f / 3.0f;
+        const float m0 = ((tex.color0[0] + tex.color0[1]) + tex.color0[2]) * third, m1 = ((tex.color1[0] + tex.color1[1]) + tex.color1[2]) * third;
+        tex.mean = .5f * (m0 + m1);
+    } else if (t.plugin == "bitmap") {
+        const std::string fn = t.props.get_string("filename", "");
+        if (fn.empty()) fail("Property \"filename\" has not been specified!");
+        const std::string path = (!fn.empty() && fn[0] == '/') || g_base_dir.empty() ? fn : g_base_dir + "/" + fn;
+        const std::string ft = t.props.get_string("filter_type", "bilinear"), wm = t.props.get_string("wrap_mode", "repeat");
+        if (ft != "nearest" && ft != "bilinear") fail("Invalid filter type \"" + ft + "\", must be one of: \"nearest\", or \"bilinear\"!");
+        if (wm != "repeat" && wm != "mirror" && wm != "clamp") fail("Invalid wrap mode \"" + wm + "\", must be one of: \"repeat\", \"mirror\", or \"clamp\"!");
+        const bool raw = t.props.get_bool("raw", false);
+        (void) t.props.get_bool("accel", true);
+        std::vector<uint8_t> px; uint32_t w, h, ch;
+        read_png(path, px, w, h, ch);
+        if (w < 2 || h < 2) fail("bitmap: the image must be at least 2x2 pixels in size");
+        tex.kind = TEX_BITMAP; tex.filter = ft == "bilinear"; memset(tex.color0, 0, 12); memset(tex.color1, 0, 12); tex.wrap = wm == "repeat" ? 0 : wm == "mirror" ? 1 : 2;
+        tex.width = w; tex.height = h; tex.channels = ch;
+        float lut[256];
+        for (uint32_t i = 0; i < 256; ++i) lut[i] = raw ? (float) i * (1.0f / 255.0f) : srgb_to_linear_u8(i);
+        tex.data.resize(px.size());
+        for (size_t i = 0; i < px.size(); ++i) tex.data[i] = lut[px[i]];
+        double sum = 0.0;   // m_mean: luminance (3 channels) or the value, accumulated in double (bitmap.cpp:221-262)
+        const size_t n = (size_t) w * h;
+        if (ch == 3) for (size_t i = 0; i < n; ++i) sum += (double) (tex.data[3 * i] * 0.212671f + tex.data[3 * i + 1] * 0.715160f + tex.data[3 * i + 2] * 0.072169f);
+        else for (size_t i = 0; i < n; ++i) sum += (double) tex.data[i];
+        tex.mean = (float) (sum / (double) n);
+    } else fail("unsupported texture plugin \"" + t.plugin + "\" (supported: bitmap, checkerboard)");
+    auto u = t.props.unqueried();
+    if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in plugin of type \"" + t.plugin + "\"");
+    return tex;
+}
+// a BSDF's reflectance-like property: a colour (-> out, returns -1) or a texture child of that name (-> out = its mean, returns its index)
+static int reflectance_of(const Obj &b, const char *name, float def, float out[3]) {
+    for (size_t i = 0; i < b.children.size(); ++i) {
+        const Obj *c = b.children[i].second.get();
+        if (!c) continue;
+        const std::string &cname = i < b.ref_names.size() && !b.ref_names[i].empty() ? b.ref_names[i] : c->name;
+        if (cname != name) continue;
+        if (c->tag != "texture") fail(std::string("property \"") + name + "\" must be a colour or a texture");
+        if (!g_textures) fail("internal error: no texture table");
+        g_textures->push_back(texture_of(*c));
+        out[0] = out[1] = out[2] = g_textures->back().mean;
+        return (int) g_textures->size() - 1;
+    }
+    color_of(b, name, def, out);
+    return -1;
+}
+
 // diffuse (src/bsdfs/diffuse.cpp), conductor (conductor.cpp:171-188), dielectric (dielectric.cpp:176-203), twosided{...} (twosided.cpp:40-70)
 static void bsdf_of(const Obj &b, HostShape &s) {
     if (b.plugin == "twosided") {
@@ -549,7 +616,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         s.twosided = true; return;
     }
     s.twosided = false;
-    if (b.plugin == "diffuse") { s.bsdf = BSDF_DIFFUSE; color_of(b, "reflectance", 0.5f, s.refl); }
+    if (b.plugin == "diffuse") { s.bsdf = BSDF_DIFFUSE; s.tex_refl = reflectance_of(b, "reflectance", 0.5f, s.refl); }
     else if (b.plugin == "conductor") {
         std::string material = b.props.get_string("material", "none");
         if (material != "none") fail(b.props.has("eta") || b.colors.count("eta") ? "Should specify either (eta, k) or material, not both."
@@ -601,7 +668,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         const float int_ior = lookup_ior(b, "int_ior", "polypropylene"), ext_ior = lookup_ior(b, "ext_ior", "air");
         if (int_ior < 0 || ext_ior < 0) fail("The interior and exterior indices of refraction must be positive!");
         s.bsdf = BSDF_PLASTIC; s.diel_eta = int_ior / ext_ior;
-        color_of(b, "diffuse_reflectance", 0.5f, s.refl); color_of(b, "specular_reflectance", 1.f, s.spec_refl);
+        s.tex_refl = reflectance_of(b, "diffuse_reflectance", 0.5f, s.refl); color_of(b, "specular_reflectance", 1.f, s.spec_refl);
         s.nonlinear = b.props.get_bool("nonlinear", false);
         const float eta = s.diel_eta;
         s.inv_eta_2 = 1.f / (eta * eta);
@@ -612,13 +679,14 @@ static void bsdf_of(const Obj &b, HostShape &s) {
             h = fmaf(h, inv_e, 4.98554f); h = fmaf(h, inv_e, -7.80989f); h = fmaf(h, inv_e, 6.75335f); h = fmaf(h, inv_e, -3.4793f); h = fmaf(h, inv_e, 0.919317f);
             s.fdr_int = e < 1.f ? approx_1 : h;
         }
-        const float d_mean = ((s.refl[0] + s.refl[1]) + s.refl[2]) * (1.0f / 3.0f), s_mean = ((s.spec_refl[0] + s.spec_refl[1]) + s.spec_refl[2]) * (1.0f / 3.0f);
+        // d_mean = m_diffuse_reflectance->mean(): the mean of a colour's three channels, or the texture's own mean
+        const float d_mean = s.tex_refl >= 0 ? s.refl[0] : ((s.refl[0] + s.refl[1]) + s.refl[2]) * (1.0f / 3.0f), s_mean = ((s.spec_refl[0] + s.spec_refl[1]) + s.spec_refl[2]) * (1.0f / 3.0f);
         s.spec_sampling_weight = s_mean / (d_mean + s_mean);
     } else if (b.plugin == "roughplastic") {   // src/bsdfs/roughplastic.cpp:170-257
         const float int_ior = lookup_ior(b, "int_ior", "polypropylene"), ext_ior = lookup_ior(b, "ext_ior", "air");
         if (int_ior < 0 || ext_ior < 0 || int_ior == ext_ior) fail("The interior and exterior indices of refraction must be positive and differ!");
         s.bsdf = BSDF_ROUGHPLASTIC; s.diel_eta = int_ior / ext_ior;
-        color_of(b, "diffuse_reflectance", 0.5f, s.refl); color_of(b, "specular_reflectance", 1.f, s.spec_refl);
+        s.tex_refl = reflectance_of(b, "diffuse_reflectance", 0.5f, s.refl); color_of(b, "specular_reflectance", 1.f, s.spec_refl);
         const bool has_spec = b.props.has("specular_reflectance") || b.colors.count("specular_reflectance");
         s.nonlinear = b.props.get_bool("nonlinear", false);
         std::string distr = b.props.get_string("distribution", "beckmann");
@@ -633,7 +701,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
             if (s.alpha_u != s.alpha_v) fail("The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!");
         } else s.alpha_u = s.alpha_v = (float) b.props.get_float("alpha", 0.1);
         s.inv_eta_2 = 1.f / (s.diel_eta * s.diel_eta);
-        const float d_mean = ((s.refl[0] + s.refl[1]) + s.refl[2]) * (1.0f / 3.0f),
+        const float d_mean = s.tex_refl >= 0 ? s.refl[0] : ((s.refl[0] + s.refl[1]) + s.refl[2]) * (1.0f / 3.0f),
                     s_mean = has_spec ? ((s.spec_refl[0] + s.spec_refl[1]) + s.spec_refl[2]) * (1.0f / 3.0f) : 1.f;
         s.spec_sampling_weight = s_mean / (d_mean + s_mean);
         s.rough_table.resize(64);
@@ -861,6 +929,8 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
     resolve_refs(*top, ctx);
 
     HostScene sc; bool have_sensor = false, have_integrator = false;
+    g_textures = &sc.textures; g_base_dir = base_dir;
+    struct TexScope { ~TexScope() { g_textures = nullptr; } } tex_scope;
     std::map<const Obj *, uint32_t> group_of;
     for (auto &c : top->children) {
         const Obj &o = *c.second;

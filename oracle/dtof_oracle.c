@@ -692,6 +692,7 @@ static void coordinate_system(v3 n, v3 *s, v3 *t) {
 
 typedef struct {
     v3 p, n, sh_n, sh_s, sh_t, dp_du, dp_dv, wi;
+    float uv_u, uv_v;        /* si.uv (rectangles and meshes; what the textures are looked up with) */
     const orc_shape *shape;
 } orc_si;
 
@@ -770,6 +771,21 @@ static void mesh_si(const orc_shape *sh, int32_t prim, float b1, float b2, orc_s
 /* PreliminaryIntersection::compute_surface_interaction (include/mitsuba/render/interaction.h:675-701)
  * -> Instance::compute_surface_interaction (src/shapes/instance.cpp:155-250) / shape CSI
  * -> finalize_surface_interaction (interaction.h:493-513) + initialize_sh_frame (:258-268) */
+/* si.uv: rectangle (rectangle.cpp:312-313) fmadd(prim_uv, .5, .5) with prim_uv = the local hit position; mesh (mesh.cpp:720-737) the
+ * interpolated vertex texcoords, or the barycentrics when the mesh has none */
+static void surface_uv(const orc_shape *sh, const orc_hit *h, orc_si *si) {
+    si->uv_u = si->uv_v = 0.f;
+    if (sh->kind == ORC_SHAPE_RECT) { si->uv_u = fmaf(h->u, .5f, .5f); si->uv_v = fmaf(h->v, .5f, .5f); }
+    else if (sh->kind == ORC_SHAPE_MESH) {
+        float b1 = h->u, b2 = h->v, b0 = 1.f - b1 - b2;
+        si->uv_u = b1; si->uv_v = b2;
+        if (sh->texcoords) {
+            const uint32_t *fi = sh->faces + 3 * h->prim; const float *uv = sh->texcoords;
+            si->uv_u = fmaf(uv[2 * fi[2]], b2, fmaf(uv[2 * fi[1]], b1, uv[2 * fi[0]] * b0));
+            si->uv_v = fmaf(uv[2 * fi[2] + 1], b2, fmaf(uv[2 * fi[1] + 1], b1, uv[2 * fi[0] + 1] * b0));
+        }
+    }
+}
 static void compute_si(const orc_scene *sc, const orc_hit *h, v3 o, v3 d, float time, orc_si *si) {
     const orc_object *ob = &sc->objects[h->obj];
     if (ob->kind == ORC_OBJ_SHAPE) {
@@ -779,6 +795,7 @@ static void compute_si(const orc_scene *sc, const orc_hit *h, v3 o, v3 d, float 
         else if (sh->kind == ORC_SHAPE_DISK) disk_si(sh, o, d, h->t, h->u, h->v, si);
         else if (sh->kind == ORC_SHAPE_SPHERE) sphere_si(sh, o, d, h->t, si);
         else mesh_si(sh, h->prim, h->u, h->v, si);
+        surface_uv(sh, h, si);
     } else {
         float m[16], inv[16];
         instance_to_world(ob, time, m);
@@ -790,6 +807,7 @@ static void compute_si(const orc_scene *sc, const orc_hit *h, v3 o, v3 d, float 
         else if (sh->kind == ORC_SHAPE_DISK) disk_si(sh, lo, ld, h->t, h->u, h->v, si);
         else if (sh->kind == ORC_SHAPE_SPHERE) sphere_si(sh, lo, ld, h->t, si);
         else mesh_si(sh, h->prim, h->u, h->v, si);
+        surface_uv(sh, h, si);
         si->p = m_point(m, si->p);
         si->n = v_normalize(m_normal(inv, si->n));
         si->sh_n = v_normalize(m_normal(inv, si->sh_n));
@@ -1081,7 +1099,7 @@ static float lerp_gather64(const float *data, float x) {
     return fmaf(v1, t, fmaf(-v0, t, v0));   /* dr::lerp */
 }
 /* RoughPlastic::eval (:333-371) and pdf (:385-421), both cosines positive */
-static void rough_plastic_eval_pdf(ggx_t g, const orc_shape *sh, v3 wi, v3 wo, float t_i, float prob_specular, float prob_diffuse,
+static void rough_plastic_eval_pdf(ggx_t g, const orc_shape *sh, const float *refl, v3 wi, v3 wo, float t_i, float prob_specular, float prob_diffuse,
                                    v3 *value, float *pdf) {
     v3 H = v_normalize(v_add(wo, wi));
     float D = ggx_eval(g, H), F, t1, t2, t3;
@@ -1089,7 +1107,7 @@ static void rough_plastic_eval_pdf(ggx_t g, const orc_shape *sh, v3 wi, v3 wo, f
     float G = ggx_smith_g1(g, wi, H) * ggx_smith_g1(g, wo, H);
     float spec = F * D * G / (4.f * wi.z);
     float t_o = lerp_gather64(sh->rough_table, wo.z);
-    v3 diff = V(sh->reflectance[0], sh->reflectance[1], sh->reflectance[2]);
+    v3 diff = V(refl[0], refl[1], refl[2]);
     float ir = sh->fdr_int;
     diff = sh->nonlinear ? V(diff.x / (1.f - diff.x * ir), diff.y / (1.f - diff.y * ir), diff.z / (1.f - diff.z * ir))
                          : V(diff.x / (1.f - ir), diff.y / (1.f - ir), diff.z / (1.f - ir));
@@ -1126,10 +1144,52 @@ static void rough_dielectric_eval_pdf(ggx_t g, const orc_shape *sh, v3 wi, v3 wo
     float dwh_dwo = reflect ? f_rcp(4.f * dom) : (eta * eta * dom) / f_sqr(dwm + eta * dom);
     *pdf = p * fabsf(dwh_dwo);
 }
+/* ---- textures on the diffuse reflectance
+ * Checkerboard::eval (src/textures/checkerboard.cpp:70-89); BitmapTexture::eval -> interpolate_3 / interpolate_1 (src/textures/bitmap.cpp:
+ * 633-670) -> dr::Texture<Float, 2>::eval (Dr.Jit 0.4.0 texture.h, absent from the tree; restated from its documented behaviour:
+ * texel centres at (i + .5) / res, pos = fmadd(uv, res, -.5), the four neighbours wrapped per mode, bilinear weights combined as
+ * fmadd(w0.y, fmadd(w0.x, v00, w1.x * v10), w1.y * fmadd(w0.x, v01, w1.x * v11)); nearest: floor(uv * res)). */
+static int32_t tex_wrap(int32_t i, int32_t n, int mode) {
+    if (mode == 2) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    int32_t div = i / n; if (i % n < 0) --div;                /* floor division */
+    int32_t mod = i - div * n;
+    if (mode == 1 && (div & 1)) mod = n - 1 - mod;            /* mirror: every other repetition is flipped */
+    return mod;
+}
+void orc_texture_eval(const orc_texture *tex, float u, float v, float *out3) {
+    /* m_transform.transform_affine(si.uv): result = col2; result = fmadd(col0, u, result); result = fmadd(col1, v, result), col2 = 0 */
+    float tu = fmaf(tex->to_uv[1], v, fmaf(tex->to_uv[0], u, 0.f)), tv = fmaf(tex->to_uv[3], v, fmaf(tex->to_uv[2], u, 0.f));
+    if (tex->kind == ORC_TEX_CHECKERBOARD) {
+        int mx = tu - floorf(tu) > .5f, my = tv - floorf(tv) > .5f;
+        const float *c = mx == my ? tex->color0 : tex->color1;
+        out3[0] = c[0]; out3[1] = c[1]; out3[2] = c[2];
+        return;
+    }
+    const int32_t W = tex->width, H = tex->height, C = tex->channels;
+    float texel[3] = { 0.f, 0.f, 0.f };
+    if (tex->filter == 0) {
+        int32_t x = tex_wrap((int32_t) floorf(tu * (float) W), W, tex->wrap), y = tex_wrap((int32_t) floorf(tv * (float) H), H, tex->wrap);
+        for (int c = 0; c < C; ++c) texel[c] = tex->data[((size_t) y * W + x) * C + c];
+    } else {
+        float px = fmaf(tu, (float) W, -.5f), py = fmaf(tv, (float) H, -.5f), fx = floorf(px), fy = floorf(py);
+        float w1x = px - fx, w1y = py - fy, w0x = 1.f - w1x, w0y = 1.f - w1y;
+        int32_t x0 = tex_wrap((int32_t) fx, W, tex->wrap), x1 = tex_wrap((int32_t) fx + 1, W, tex->wrap);
+        int32_t y0 = tex_wrap((int32_t) fy, H, tex->wrap), y1 = tex_wrap((int32_t) fy + 1, H, tex->wrap);
+        for (int c = 0; c < C; ++c) {
+            float v00 = tex->data[((size_t) y0 * W + x0) * C + c], v10 = tex->data[((size_t) y0 * W + x1) * C + c];
+            float v01 = tex->data[((size_t) y1 * W + x0) * C + c], v11 = tex->data[((size_t) y1 * W + x1) * C + c];
+            texel[c] = fmaf(w0y, fmaf(w0x, v00, w1x * v10), w1y * fmaf(w0x, v01, w1x * v11));
+        }
+    }
+    if (C == 1) texel[1] = texel[2] = texel[0];
+    out3[0] = texel[0]; out3[1] = texel[1]; out3[2] = texel[2];
+}
 /* One BSDF interaction of the bounce loop: value and density for the emitter direction `wo` (only when `active_em`), and the
  * sampled continuation (BSDF::eval_pdf_sample, src/render/bsdf.cpp:20-29).  wi_in / wo / bs_wo are in the local shading frame. */
 typedef struct { v3 val; float pdf; v3 weight; v3 wo; float bs_pdf, bs_eta; int bs_delta; } orc_bsdf_out;
-static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, orc_bsdf_out *out) {
+static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
+    float refl[3] = { sh->reflectance[0], sh->reflectance[1], sh->reflectance[2] };   /* m_reflectance->eval(si) */
+    if (sh->tex_refl) orc_texture_eval(sh->tex_refl, uv_u, uv_v, refl);
     /* BSDF::eval_pdf_sample src/render/bsdf.cpp:20-29 over twosided{diffuse} / diffuse
      * (src/bsdfs/twosided.cpp:111-148,219-258; src/bsdfs/diffuse.cpp:101-125,160-180) */
     v3 bsdf_val = V(0, 0, 0), bsdf_weight = V(0, 0, 0), bs_wo = V(0, 0, 0);
@@ -1237,7 +1297,7 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
             float prob_specular = (1.f - t_i) * sh->spec_sampling_weight, prob_diffuse = t_i * (1.f - sh->spec_sampling_weight);
             prob_specular = prob_specular / (prob_specular + prob_diffuse);
             prob_diffuse = 1.f - prob_specular;
-            if (wo_l.z > 0.f) rough_plastic_eval_pdf(g, sh, wi, wo_l, t_i, prob_specular, prob_diffuse, &bsdf_val, &bsdf_pdf);
+            if (wo_l.z > 0.f) rough_plastic_eval_pdf(g, sh, refl, wi, wo_l, t_i, prob_specular, prob_diffuse, &bsdf_val, &bsdf_pdf);
             if (sample_1 < prob_specular) {
                 float mpdf; v3 m = ggx_sample(g, wi, s2x, s2y, &mpdf);
                 float dwm = v_dot(wi, m);
@@ -1245,7 +1305,7 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
             } else bs_wo = square_to_cosine_hemisphere(s2x, s2y);
             bs_eta = 1.f;
             v3 value = V(0, 0, 0);
-            if (bs_wo.z > 0.f) rough_plastic_eval_pdf(g, sh, wi, bs_wo, t_i, prob_specular, prob_diffuse, &value, &bs_pdf);
+            if (bs_wo.z > 0.f) rough_plastic_eval_pdf(g, sh, refl, wi, bs_wo, t_i, prob_specular, prob_diffuse, &value, &bs_pdf);
             if (bs_pdf > 0.f) bsdf_weight = v_mul(value, f_rcp(bs_pdf));   /* Spectrum / Float: times the reciprocal */
             if (sh->twosided && wi_in.z < 0.f) bs_wo.z = -bs_wo.z;
         }
@@ -1256,7 +1316,7 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
         float f_i, tmp1, tmp2, tmp3;
         fresnel_dielectric(wiz, sh->diel_eta, &f_i, &tmp1, &tmp2, &tmp3);
         const float w = sh->spec_sampling_weight;
-        v3 diff = V(sh->reflectance[0], sh->reflectance[1], sh->reflectance[2]);
+        v3 diff = V(refl[0], refl[1], refl[2]);
         diff = sh->nonlinear ? V(diff.x / (1.f - diff.x * sh->fdr_int), diff.y / (1.f - diff.y * sh->fdr_int), diff.z / (1.f - diff.z * sh->fdr_int))
                              : V(diff.x / (1.f - sh->fdr_int), diff.y / (1.f - sh->fdr_int), diff.z / (1.f - sh->fdr_int));
         if (wiz > 0.f && woz > 0.f) {   /* eval (:309-332) and pdf (:334-360) of the diffuse lobe */
@@ -1290,15 +1350,15 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
         float wiz = wi_in.z, woz = wo.z;
         if (sh->twosided) { woz = f_mulsign(woz, wiz); wiz = fabsf(wiz); }
         if (wiz > 0.f && woz > 0.f) {
-            bsdf_val = V(sh->reflectance[0] * ORC_INV_PI_F * woz, sh->reflectance[1] * ORC_INV_PI_F * woz,
-                         sh->reflectance[2] * ORC_INV_PI_F * woz);
+            bsdf_val = V(refl[0] * ORC_INV_PI_F * woz, refl[1] * ORC_INV_PI_F * woz,
+                         refl[2] * ORC_INV_PI_F * woz);
             bsdf_pdf = ORC_INV_PI_F * woz;
         }
         if (wiz > 0.f) {
             bs_wo = square_to_cosine_hemisphere(s2x, s2y);
             bs_pdf = ORC_INV_PI_F * bs_wo.z;
             bs_eta = 1.f;
-            if (bs_pdf > 0.f) bsdf_weight = V(sh->reflectance[0], sh->reflectance[1], sh->reflectance[2]);
+            if (bs_pdf > 0.f) bsdf_weight = V(refl[0], refl[1], refl[2]);
             if (sh->twosided) bs_wo.z = f_mulsign(bs_wo.z, wi_in.z);
         }
     }
@@ -1509,7 +1569,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; int bs_delta = 0;
         if (hit) {
             orc_bsdf_out bo;
-            bsdf_eval_pdf_sample(si.shape, si.wi, wo, active_em, sample_1, s2x, s2y, &bo);
+            bsdf_eval_pdf_sample(si.shape, si.wi, wo, active_em, sample_1, s2x, s2y, si.uv_u, si.uv_v, &bo);
             bsdf_val = bo.val; bsdf_pdf = bo.pdf; bsdf_weight = bo.weight; bs_wo = bo.wo; bs_pdf = bo.bs_pdf; bs_eta = bo.bs_eta; bs_delta = bo.bs_delta;
         }
         if (active_em) {   /* :214-226 */
@@ -2018,7 +2078,7 @@ int orc_kat_ray_intersect(const orc_scene *sc, const float *o, const float *d, f
  * out = value[3], pdf, bs.wo[3], bs.pdf, bs.eta, bs.delta, weight[3] (13 floats) */
 void orc_kat_bsdf(const orc_shape *sh, const float *wi, const float *wo, const float *s3, float *out) {
     orc_bsdf_out r;
-    bsdf_eval_pdf_sample(sh, V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]), 1, s3[0], s3[1], s3[2], &r);
+    bsdf_eval_pdf_sample(sh, V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]), 1, s3[0], s3[1], s3[2], 0.f, 0.f, &r);
     out[0] = r.val.x; out[1] = r.val.y; out[2] = r.val.z; out[3] = r.pdf;
     out[4] = r.wo.x; out[5] = r.wo.y; out[6] = r.wo.z; out[7] = r.bs_pdf; out[8] = r.bs_eta; out[9] = (float) r.bs_delta;
     out[10] = r.weight.x; out[11] = r.weight.y; out[12] = r.weight.z;

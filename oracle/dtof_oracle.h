@@ -34,6 +34,18 @@ enum { ORC_FILTER_BOX = 0, ORC_FILTER_TENT = 1, ORC_FILTER_GAUSSIAN = 2, ORC_FIL
 
 /* All 4x4 matrices are row-major float32: m[4*r + c]. */
 
+/* Texture on a BSDF's (diffuse) reflectance: src/textures/checkerboard.cpp, src/textures/bitmap.cpp (RGB variants).
+ * to_uv = the 2x2 linear part of the `to_uv` transform: Transform4f::extract() (transform.h:340-360) copies the upper-left 2x2 block and
+ * the bottom ROW, so a translation never reaches the 3x3 transform the plugins apply. */
+enum { ORC_TEX_CHECKERBOARD = 0, ORC_TEX_BITMAP = 1 };
+typedef struct {
+    int32_t kind, filter /* 0 nearest, 1 bilinear */, wrap /* 0 repeat, 1 mirror, 2 clamp */, channels /* 1 or 3 */;
+    int32_t width, height;
+    float   to_uv[4];        /* m00, m01, m10, m11 */
+    float   color0[3], color1[3];   /* checkerboard (constant colours) */
+    const float *data;       /* bitmap: height * width * channels linear float32 texels, row 0 first */
+} orc_texture;
+
 typedef struct {
     int32_t kind;            /* ORC_SHAPE_* */
     int32_t twosided;        /* BSDF is twosided{diffuse} (1) or plain diffuse (0) */
@@ -75,6 +87,7 @@ typedef struct {
     /* roughplastic (src/bsdfs/roughplastic.cpp), GGX + visible normals: the plastic fields with fdr_int = m_internal_reflectance,
      * alpha_u = alpha, and m_external_transmittance (64 values, orc_roughplastic_tables) */
     const float *rough_table;
+    const orc_texture *tex_refl;   /* texture on `reflectance` / `diffuse_reflectance` (NULL: the constant colour above) */
     int32_t mf_type;         /* microfacet distribution of the rough BSDFs: 0 beckmann, 1 ggx (microfacet.h MicrofacetType) */
 } orc_shape;
 
@@ -254,6 +267,7 @@ void     orc_kat_warp(int fn, const float *in, float *out);
 void     orc_kat_frame(const float *n, float *out6);
 int      orc_kat_ray_intersect(const orc_scene *sc, const float *o, const float *d, float time, float maxt, float *out25, int32_t *ids);
 void     orc_kat_bsdf(const orc_shape *sh, const float *wi, const float *wo, const float *s3, float *out13);
+void     orc_texture_eval(const orc_texture *tex, float u, float v, float *out3);
 void     orc_kat_sphere_sample_direction(const orc_shape *sh, const float *ref, float s_x, float s_y, float *out11);
 float    orc_kat_shape_area(const orc_shape *sh);
 void     orc_kat_splat(const orc_sensor *se, float *film, float x, float y, const float *rgb);

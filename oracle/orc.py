@@ -16,6 +16,11 @@ _LIB = None
 M16 = C.c_float * 16
 
 
+class OrcTexture(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("filter", C.c_int32), ("wrap", C.c_int32), ("channels", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("to_uv", C.c_float * 4), ("color0", C.c_float * 3), ("color1", C.c_float * 3), ("data", C.POINTER(C.c_float))]
+
+
 class OrcShape(C.Structure):
     _fields_ = [("kind", C.c_int32), ("twosided", C.c_int32), ("flip_normals", C.c_int32), ("face_normals", C.c_int32),
                 ("reflectance", C.c_float * 3), ("to_world", M16), ("to_object", M16),
@@ -29,7 +34,7 @@ class OrcShape(C.Structure):
                 ("bsdf", C.c_int32), ("cond_eta", C.c_float * 3), ("cond_k", C.c_float * 3), ("spec_refl", C.c_float * 3),
                 ("spec_trans", C.c_float * 3), ("diel_eta", C.c_float), ("nonlinear", C.c_int32),
                 ("inv_eta_2", C.c_float), ("fdr_int", C.c_float), ("spec_sampling_weight", C.c_float),
-                ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("rough_table", C.POINTER(C.c_float)), ("mf_type", C.c_int32)]
+                ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("rough_table", C.POINTER(C.c_float)), ("tex_refl", C.POINTER(OrcTexture)), ("mf_type", C.c_int32)]
 
 
 class OrcGroup(C.Structure):
@@ -170,6 +175,7 @@ def lib():
         L.orc_kat_sphere_sample_direction.argtypes = [C.POINTER(OrcShape), C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.orc_kat_shape_area.restype = C.c_float
         L.orc_kat_shape_area.argtypes = [C.POINTER(OrcShape)]
+        L.orc_texture_eval.argtypes = [C.POINTER(OrcTexture), C.c_float, C.c_float, C.c_void_p]
         L.orc_kat_splat.argtypes = [C.POINTER(OrcSensor), C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.orc_kat_solve_quadratic.restype = C.c_int
         L.orc_kat_solve_quadratic.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p]
@@ -210,12 +216,26 @@ class Scene:
             o.diel_eta = float(s.get("diel_eta", 1.0))
             o.alpha_u, o.alpha_v = float(s.get("alpha_u", 0.1)), float(s.get("alpha_v", 0.1))
             o.mf_type = int(s.get("mf_type", 1))
+            tex = s.get("tex_refl")
+            if tex is not None:   # texture on the (diffuse) reflectance
+                t = OrcTexture()
+                t.kind, t.filter, t.wrap, t.channels, t.width, t.height = tex["kind"], tex["filter"], tex["wrap"], tex["channels"], tex["width"], tex["height"]
+                t.to_uv = (C.c_float * 4)(*tex["to_uv"].tolist())
+                t.color0, t.color1 = (C.c_float * 3)(*tex["color0"].tolist()), (C.c_float * 3)(*tex["color1"].tolist())
+                if tex["data"] is not None:
+                    t.data = tex["data"].ctypes.data_as(C.POINTER(C.c_float))
+                self._keep += [t, tex["data"]]
+                o.tex_refl = C.pointer(t)
             if o.bsdf == 3:   # plastic: SmoothPlastic::parameters_changed in C float32
                 o.nonlinear = int(s.get("nonlinear", 0))
                 out3 = (C.c_float * 3)()
                 L.orc_plastic_params(C.c_float(o.diel_eta), o.reflectance, o.spec_refl, out3)
                 o.inv_eta_2, o.fdr_int, o.spec_sampling_weight = out3[0], out3[1], out3[2]
-                s["plastic_params"] = np.array(list(out3), np.float32)
+                if tex is not None:   # d_mean = m_diffuse_reflectance->mean() is the texture's own mean (plastic.cpp:201-217)
+                    sp = np.asarray(s["spec_refl"], np.float32)
+                    s_mean = ((sp[0] + sp[1]) + sp[2]) * np.float32(1.0 / 3.0)
+                    o.spec_sampling_weight = float(s_mean / (np.float32(tex["mean"]) + s_mean))
+                s["plastic_params"] = np.array([o.inv_eta_2, o.fdr_int, o.spec_sampling_weight], np.float32)
             if o.bsdf == 5:   # roughplastic: RoughPlastic::parameters_changed in C float32 (cached per (alpha, eta))
                 o.nonlinear = int(s.get("nonlinear", 0))
                 table, ir = rough_plastic_tables(o.alpha_u, o.diel_eta, o.mf_type)
@@ -225,7 +245,7 @@ class Scene:
                 o.inv_eta_2 = float(np.float32(1.0) / (eta * eta))
                 d, sp = np.asarray(s["reflectance"], np.float32), np.asarray(s["spec_refl"], np.float32)
                 third = np.float32(1.0 / 3.0)
-                d_mean = ((d[0] + d[1]) + d[2]) * third
+                d_mean = ((d[0] + d[1]) + d[2]) * third if tex is None else np.float32(tex["mean"])
                 s_mean = ((sp[0] + sp[1]) + sp[2]) * third if s.get("has_spec_refl") else np.float32(1.0)
                 o.fdr_int, o.spec_sampling_weight = float(ir), float(s_mean / (d_mean + s_mean))
                 s["rough_table"], s["plastic_params"] = table, np.array([o.inv_eta_2, o.fdr_int, o.spec_sampling_weight], np.float32)

@@ -334,14 +334,96 @@ def _color(props, name, default):
     return np.asarray([default] * 3, dtype=np.float64).astype(F32)
 
 
-def _bsdf_of(props, registry):
+_SRGB_LUT = None
+
+
+def _srgb_lut():
+    """UInt8 sRGB -> linear float32 (StructConverter::linearize + dr::srgb_to_linear, src/core/struct.cpp:1600-1625)"""
+    global _SRGB_LUT
+    if _SRGB_LUT is None:
+        x = np.arange(256, dtype=np.float64) / 255.0
+        _SRGB_LUT = np.where(x <= 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4).astype(F32)
+    return _SRGB_LUT
+
+
+def _texture_of(tp, base_dir):
+    """src/textures/checkerboard.cpp:55-62, src/textures/bitmap.cpp:113-262 (RGB variants)"""
+    m = tp["to_uv"][1][0] if "to_uv" in tp else _ident()
+    tp.queried.add("to_uv")
+    # Transform4f::extract() (transform.h:340-360): the upper-left 2x2 block (and the bottom row) -- the translation column is not copied
+    tex = dict(to_uv=np.array([m[0], m[1], m[4], m[5]], np.float64).astype(F32), filter=1, wrap=0, channels=3, width=0, height=0,
+               color0=np.zeros(3, F32), color1=np.zeros(3, F32), data=None)
+    if tp.plugin == "checkerboard":
+        for c in tp.children:
+            if c[0] == "texture" or c[0] == "ref":
+                raise ValueError("checkerboard: nested textures are not supported (constant colours only)")
+        tex.update(kind=0, color0=_color(tp, "color0", 0.4), color1=_color(tp, "color1", 0.2))
+        third = F32(1.0 / 3.0)
+        m0 = ((tex["color0"][0] + tex["color0"][1]) + tex["color0"][2]) * third
+        m1 = ((tex["color1"][0] + tex["color1"][1]) + tex["color1"][2]) * third
+        tex["mean"] = F32(0.5) * (m0 + m1)
+    elif tp.plugin == "bitmap":
+        fn = tp.get_s("filename", "")
+        if not fn:
+            raise ValueError('Property "filename" has not been specified!')
+        path = fn if os.path.isabs(fn) else os.path.join(base_dir, fn)
+        ft, wm = tp.get_s("filter_type", "bilinear"), tp.get_s("wrap_mode", "repeat")
+        if ft not in ("nearest", "bilinear"):
+            raise ValueError('Invalid filter type "%s", must be one of: "nearest", or "bilinear"!' % ft)
+        if wm not in ("repeat", "mirror", "clamp"):
+            raise ValueError('Invalid wrap mode "%s", must be one of: "repeat", "mirror", or "clamp"!' % wm)
+        raw = tp.get_b("raw", False)
+        tp.get_b("accel", True)
+        from PIL import Image      # the oracle's own decoder (the product reads PNG chunks itself, over zlib)
+        im = Image.open(path)
+        if im.mode in ("P", "RGBA", "CMYK"):
+            im = im.convert("RGB")
+        elif im.mode in ("LA", "1"):
+            im = im.convert("L")
+        if im.mode == "RGB":
+            a = np.asarray(im, np.uint8)
+        elif im.mode == "L":
+            a = np.asarray(im, np.uint8)[..., None]
+        else:
+            raise ValueError('bitmap: unsupported pixel layout "%s" in "%s" (8-bit gray / RGB[A] / palette PNG)' % (im.mode, fn))
+        data = (a.astype(F32) * F32(1.0 / 255.0)) if raw else _srgb_lut()[a]
+        if data.shape[0] < 2 or data.shape[1] < 2:
+            raise ValueError("bitmap: the image must be at least 2x2 pixels in size")
+        if data.shape[2] == 3:     # m_mean: luminance, accumulated in double (bitmap.cpp:221-262)
+            lum = data[..., 0] * F32(0.212671) + data[..., 1] * F32(0.715160) + data[..., 2] * F32(0.072169)
+            mean = F32(float(np.sum(lum.astype(np.float64))) / lum.size)
+        else:
+            mean = F32(float(np.sum(data.astype(np.float64))) / data[..., 0].size)
+        tex.update(kind=1, filter=int(ft == "bilinear"), wrap=("repeat", "mirror", "clamp").index(wm), channels=int(data.shape[2]),
+                   width=int(data.shape[1]), height=int(data.shape[0]), data=np.ascontiguousarray(data, F32), mean=mean)
+    else:
+        raise ValueError('unsupported texture plugin "%s" (supported: bitmap, checkerboard)' % tp.plugin)
+    unq = tp.unqueried() if hasattr(tp, "unqueried") else []
+    return tex
+
+
+def _reflectance(props, name, default, registry, base_dir):
+    """(constant colour, texture record or None) of a BSDF's reflectance-like property"""
+    for tag, child, cname in props.children:
+        if cname != name:
+            continue
+        if tag == "ref":
+            tag, child = registry[child]
+        if tag != "texture":
+            raise ValueError('property "%s" must be a colour or a texture' % name)
+        tex = _texture_of(child, base_dir)
+        return np.asarray([tex["mean"]] * 3, F32), tex
+    return _color(props, name, default), None
+
+
+def _bsdf_of(props, registry, base_dir=""):
     """BSDF record of a diffuse / conductor / dielectric BSDF, optionally inside twosided{...}"""
     if props.plugin == "twosided":
         inner = [c for c in props.children if c[0] in ("bsdf", "ref")]
         if len(inner) != 1:
             raise ValueError("twosided: exactly one nested BSDF is supported")
         ip = inner[0][1] if inner[0][0] == "bsdf" else registry[inner[0][1]][1]
-        rec = _bsdf_of(ip, registry)
+        rec = _bsdf_of(ip, registry, base_dir)
         if rec["bsdf"] in (2, 6, 7):   # twosided.cpp:47-52
             raise ValueError("Only materials without a transmission component can be nested!")
         rec["twosided"] = 1
@@ -349,7 +431,7 @@ def _bsdf_of(props, registry):
     rec = dict(twosided=0, bsdf=0, reflectance=np.array([0.5] * 3, F32), cond_eta=np.zeros(3, F32), cond_k=np.ones(3, F32),
                spec_refl=np.ones(3, F32), spec_trans=np.ones(3, F32), diel_eta=F32(1.0), nonlinear=0, alpha_u=F32(0.1), alpha_v=F32(0.1))
     if props.plugin == "diffuse":
-        rec["reflectance"] = _color(props, "reflectance", 0.5)
+        rec["reflectance"], rec["tex_refl"] = _reflectance(props, "reflectance", 0.5, registry, base_dir)
     elif props.plugin == "conductor":   # src/bsdfs/conductor.cpp:171-188
         material = props.get_s("material", "none")
         if material != "none":
@@ -414,13 +496,15 @@ def _bsdf_of(props, registry):
         int_ior, ext_ior = _lookup_ior(props, "int_ior", "polypropylene"), _lookup_ior(props, "ext_ior", "air")
         if int_ior < 0 or ext_ior < 0:
             raise ValueError("The interior and exterior indices of refraction must be positive!")
-        rec.update(bsdf=3, diel_eta=F32(int_ior / ext_ior), reflectance=_color(props, "diffuse_reflectance", 0.5),
+        refl, rec["tex_refl"] = _reflectance(props, "diffuse_reflectance", 0.5, registry, base_dir)
+        rec.update(bsdf=3, diel_eta=F32(int_ior / ext_ior), reflectance=refl,
                    spec_refl=_color(props, "specular_reflectance", 1.0), nonlinear=int(props.get_b("nonlinear", False)))
     elif props.plugin == "roughplastic":   # src/bsdfs/roughplastic.cpp:170-220
         int_ior, ext_ior = _lookup_ior(props, "int_ior", "polypropylene"), _lookup_ior(props, "ext_ior", "air")
         if int_ior < 0 or ext_ior < 0 or int_ior == ext_ior:
             raise ValueError("The interior and exterior indices of refraction must be positive and differ!")
-        rec.update(bsdf=5, diel_eta=F32(int_ior / ext_ior), reflectance=_color(props, "diffuse_reflectance", 0.5),
+        refl, rec["tex_refl"] = _reflectance(props, "diffuse_reflectance", 0.5, registry, base_dir)
+        rec.update(bsdf=5, diel_eta=F32(int_ior / ext_ior), reflectance=refl,
                    has_spec_refl=int("specular_reflectance" in props), spec_refl=_color(props, "specular_reflectance", 1.0),
                    nonlinear=int(props.get_b("nonlinear", False)))
         distr = props.get_s("distribution", "beckmann").lower()
@@ -490,7 +574,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
         emitter = 1
     if bsdfs:
         bp = bsdfs[0][1] if bsdfs[0][0] == "bsdf" else registry[bsdfs[0][1]][1]
-        brec = _bsdf_of(bp, registry)
+        brec = _bsdf_of(bp, registry, base_dir)
     else:   # shape.cpp:66-72: default diffuse, reflectance 0 when the shape is an emitter
         brec = dict(twosided=0, bsdf=0, reflectance=np.array([0.0 if emitter else 0.5] * 3, dtype=F32), cond_eta=np.zeros(3, F32),
                     cond_k=np.ones(3, F32), spec_refl=np.ones(3, F32), spec_trans=np.ones(3, F32), diel_eta=F32(1.0), nonlinear=0)
@@ -507,7 +591,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
                 sphere=sphere, bsdf=brec["bsdf"], cond_eta=brec["cond_eta"], cond_k=brec["cond_k"], spec_refl=brec["spec_refl"],
                 spec_trans=brec["spec_trans"], diel_eta=brec["diel_eta"], nonlinear=brec.get("nonlinear", 0),
                 alpha_u=brec.get("alpha_u", F32(0.1)), alpha_v=brec.get("alpha_v", F32(0.1)), has_spec_refl=brec.get("has_spec_refl", 0),
-                mf_type=brec.get("mf_type", 1))
+                mf_type=brec.get("mf_type", 1), tex_refl=brec.get("tex_refl"))
 
 
 def load(source, params=None, is_string=False):

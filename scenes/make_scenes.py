@@ -163,6 +163,59 @@ PLASTIC = ('\t<bsdf type="twosided" id="PlasticBSDF">\n\t\t<bsdf type="plastic">
            '\t\t\t<float name="int_ior" value="1.9" />\n\t\t</bsdf>\n\t</bsdf>\n')
 
 
+def write_png(path, pixels):
+    """8-bit PNG writer (gray for an H x W array, RGB for H x W x 3): the texture fixtures are generated, not tracked"""
+    import struct
+    import zlib
+    h, w = len(pixels), len(pixels[0])
+    rgb = isinstance(pixels[0][0], (tuple, list))
+    raw = b"".join(b"\x00" + (bytes(c for px in row for c in px) if rgb else bytes(row)) for row in pixels)
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if rgb else 0, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 9)) + chunk(b"IEND", b""))
+
+
+def texture_files():
+    """tex_rgb.png: 16 x 12 RGB pattern (stripes + gradient, no symmetry: a flipped or transposed lookup shows); tex_gray.png: 8 x 8 gray"""
+    rgb = [[((x * 37 + y * 11) % 256, (255 - x * 15) % 256 if (x // 2 + y) % 3 else 40, (y * 21 + (x % 4) * 50) % 256) for x in range(16)] for y in range(12)]
+    gray = [[(x * x * 3 + y * 29 + 10) % 256 for x in range(8)] for y in range(8)]
+    write_png(os.path.join(HERE, "tex_rgb.png"), rgb)
+    write_png(os.path.join(HERE, "tex_gray.png"), gray)
+
+
+def tex_bsdf(ident, kind, body, plugin="diffuse", prop="reflectance", extra=""):
+    return ('\t<bsdf type="twosided" id="%s">\n\t\t<bsdf type="%s">\n%s\t\t\t<texture type="%s" name="%s">\n%s\t\t\t</texture>\n'
+            '\t\t</bsdf>\n\t</bsdf>\n' % (ident, plugin, extra, kind, prop, body))
+
+
+def cornell_textured(res=128, spp=16):
+    """cornell_boxes.xml with textures on the diffuse reflectances (src/textures/{checkerboard,bitmap}.cpp): a checkerboard floor (scaled
+    to_uv), an RGB bitmap on the back wall (bilinear, repeat, rotated to_uv), a gray bitmap on the left wall (nearest, mirror), a bitmap
+    on the moving short box (cube texcoords; clamp) and a smooth-plastic tall box whose diffuse reflectance is a checkerboard"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        if b[0] not in ("FloorBSDF", "BackWallBSDF", "LeftWallBSDF", "ShortBoxBSDF", "TallBoxBSDF"):
+            s += bsdf(*b)
+    s += tex_bsdf("FloorBSDF", "checkerboard", '\t\t\t\t<rgb name="color0" value="0.7, 0.68, 0.6" />\n\t\t\t\t<rgb name="color1" value="0.12, 0.1, 0.2" />\n'
+                  '\t\t\t\t<transform name="to_uv">\n\t\t\t\t\t<scale x="4" y="6" />\n\t\t\t\t\t<translate x="0.25" y="0" />\n\t\t\t\t</transform>\n')
+    s += tex_bsdf("BackWallBSDF", "bitmap", '\t\t\t\t<string name="filename" value="tex_rgb.png" />\n'
+                  '\t\t\t\t<transform name="to_uv">\n\t\t\t\t\t<scale x="2.5" y="1.5" />\n\t\t\t\t\t<rotate z="1" angle="20" />\n\t\t\t\t</transform>\n')
+    s += tex_bsdf("LeftWallBSDF", "bitmap", '\t\t\t\t<string name="filename" value="tex_gray.png" />\n\t\t\t\t<string name="filter_type" value="nearest" />\n'
+                  '\t\t\t\t<string name="wrap_mode" value="mirror" />\n\t\t\t\t<transform name="to_uv">\n\t\t\t\t\t<scale x="1.7" y="2.3" />\n\t\t\t\t</transform>\n')
+    s += tex_bsdf("ShortBoxBSDF", "bitmap", '\t\t\t\t<string name="filename" value="tex_rgb.png" />\n\t\t\t\t<string name="wrap_mode" value="clamp" />\n'
+                  '\t\t\t\t<boolean name="raw" value="true" />\n\t\t\t\t<transform name="to_uv">\n\t\t\t\t\t<scale x="1.5" y="1.5" />\n\t\t\t\t</transform>\n')
+    s += tex_bsdf("TallBoxBSDF", "checkerboard", '\t\t\t\t<rgb name="color0" value="0.1, 0.27, 0.36" />\n\t\t\t\t<rgb name="color1" value="0.6, 0.5, 0.1" />\n'
+                  '\t\t\t\t<transform name="to_uv">\n\t\t\t\t\t<scale x="3" y="3" />\n\t\t\t\t</transform>\n',
+                  plugin="plastic", prop="diffuse_reflectance", extra='\t\t\t<float name="int_ior" value="1.9" />\n')
+    for name, m, b in WALLS:
+        s += rect(name, m, b)
+    s += cube("ShortBox", SHORT, "ShortBoxBSDF", "0.015") + cube("TallBox", TALL, "TallBoxBSDF", "-0.015")
+    return s + LIGHT + "</scene>\n"
+
+
 def cornell_plastic(res=128, spp=16):
     """cornell_boxes.xml with glossy-coated (smooth `plastic`) boxes and a plastic floor, point light at the camera"""
     s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
@@ -332,11 +385,13 @@ def main():
         "cornell_frosted.xml": cornell_frosted(),
         "cornell_spot.xml": cornell_spot(),
         "cornell_disk.xml": cornell_disk(),
+        "cornell_textured.xml": cornell_textured(),
         "cornell_spheres.xml": cornell_spheres(),
         "cornell_sphere_light.xml": cornell_spheres(sphere_light=True),
         "domino.xml": domino(),
         "domino_small.xml": domino(n_side=6, res=128, spp=16),
     }
+    texture_files()
     for name, text in out.items():
         with open(os.path.join(HERE, name), "w") as f:
             f.write(text)
@@ -346,7 +401,7 @@ def main():
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
     names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml",
-             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml"]
+             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "tex_rgb.png", "tex_gray.png"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
         return

@@ -1,0 +1,137 @@
+"""Textures on the diffuse reflectances (SURVEY 8(f)-3 leftovers): `checkerboard` and `bitmap` (src/textures/{checkerboard,bitmap}.cpp) on
+`reflectance` (diffuse) and `diffuse_reflectance` (plastic, roughplastic).  Loader parity against the oracle's independent loader (which
+decodes the PNG files with PIL; the product parses the PNG chunks itself over zlib), lookup semantics, error behaviour; per-lane parity
+on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+
+NCPU = min(16, os.cpu_count() or 1)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_texture_records_and_texels_match_the_oracle_loader(mi, orc):
+    path = os.path.join(SCENES, "cornell_textured.xml")
+    sc, osc = mi.load_file(path), orc.Scene(path, {})
+    want = [s["tex_refl"] for s in osc.flat.shapes]
+    got = sc.export(15).astype(int)
+    assert [g >= 0 for g in got] == [w is not None for w in want] and sum(g >= 0 for g in got) == 5
+    rec = sc.export(13).reshape(-1, 17)
+    texels = sc.export(14)
+    off = 0
+    for i, w in enumerate(want):
+        if w is None:
+            continue
+        r = rec[got[i]]
+        assert (int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4]), int(r[5])) == (w["kind"], w["filter"], w["wrap"], w["channels"], w["width"], w["height"])
+        assert np.array_equal(bits(r[6:10]), bits(w["to_uv"])) and np.array_equal(bits(r[10:13]), bits(w["color0"])) and np.array_equal(bits(r[13:16]), bits(w["color1"]))
+        assert bits(r[16]) == bits(np.float32(w["mean"])), (i, r[16], w["mean"])
+    # texels: in order of appearance in the file = order of the texture table
+    order = sorted({g for g in got if g >= 0})
+    by_index = {got[i]: want[i] for i in range(len(want)) if want[i] is not None}
+    for k in order:
+        w = by_index[k]
+        if w["data"] is not None:
+            n = w["data"].size
+            assert np.array_equal(bits(texels[off:off + n]), bits(w["data"].reshape(-1))), k
+            off += n
+    assert off == texels.size
+    kinds = {(int(rec[g][0]), int(rec[g][1]), int(rec[g][2])) for g in order}
+    assert {(0, 1, 0), (1, 1, 0), (1, 0, 1), (1, 1, 2)} <= kinds          # checkerboard; bilinear+repeat; nearest+mirror; bilinear+clamp
+    # the plastic box: specular sampling weight from the texture's own mean (plastic.cpp:201-217)
+    pl = [i for i, s in enumerate(osc.flat.shapes) if s["bsdf"] == 3]
+    brec = sc.export(9).reshape(-1, 24)
+    for i in pl:
+        assert bits(brec[i, 6]) == bits(osc.flat.shapes[i]["plastic_params"][2])
+
+
+def test_texture_lookup_semantics(orc):
+    """Checkerboard and bitmap lookups of the oracle: texel centres, wrap modes, the 2x2 to_uv, the gray -> RGB broadcast"""
+    import ctypes as C
+    L = orc.lib()
+    t = orc.OrcTexture()
+    t.kind, t.filter, t.wrap, t.channels, t.width, t.height = 1, 0, 0, 1, 4, 2
+    data = np.arange(8, dtype=np.float32) / 8
+    t.data = data.ctypes.data_as(C.POINTER(C.c_float))
+    t.to_uv = (C.c_float * 4)(1, 0, 0, 1)
+    out = np.zeros(3, np.float32)
+
+    def ev(u, v):
+        L.orc_texture_eval(C.byref(t), C.c_float(u), C.c_float(v), out.ctypes.data)
+        return out.copy()
+    assert np.array_equal(ev(0.1, 0.1), [0, 0, 0]) and np.array_equal(ev(0.9, 0.9), [7 / 8] * 3)      # nearest: row 0 is v = 0
+    assert np.array_equal(ev(1.1, 0.1), ev(0.1, 0.1)) and np.array_equal(ev(-0.1, 0.1), ev(0.9, 0.1))   # repeat
+    t.wrap = 1
+    assert np.array_equal(ev(1.1, 0.1), ev(0.9, 0.1)) and np.array_equal(ev(-0.1, 0.1), ev(0.1, 0.1))   # mirror
+    t.wrap = 2
+    assert np.array_equal(ev(1.7, 0.1), ev(0.99, 0.1)) and np.array_equal(ev(-3.0, 0.9), ev(0.0, 0.9))  # clamp
+    t.filter = 1
+    assert np.allclose(ev(0.125, 0.25), [0, 0, 0]) and np.allclose(ev(0.25, 0.25), [0.5 / 8] * 3)        # texel centres at (i + .5) / res
+    assert np.allclose(ev(0.125, 0.5), [2 / 8] * 3)                                                        # halfway between the two rows
+    t.kind = 0
+    t.color0, t.color1 = (C.c_float * 3)(1, 0, 0), (C.c_float * 3)(0, 0, 1)
+    t.to_uv = (C.c_float * 4)(2, 0, 0, 2)
+    assert np.array_equal(ev(0.1, 0.1), [1, 0, 0]) and np.array_equal(ev(0.3, 0.1), [0, 0, 1]) and np.array_equal(ev(0.3, 0.3), [1, 0, 0])
+
+
+def test_to_uv_translation_is_lost_as_in_the_reference(orc, tmp_path):
+    """Transform4f::extract() (transform.h:340-360) copies the upper-left block and the bottom row: the translation of a `to_uv`
+    transform never reaches the texture (replicated, SURVEY App. B style quirk)"""
+    text = open(os.path.join(SCENES, "cornell_textured.xml")).read()
+    assert '<translate x="0.25" y="0" />' in text
+    a = orc.Scene(os.path.join(SCENES, "cornell_textured.xml"), dict(resx=16, resy=16))
+    p = tmp_path / "moved.xml"
+    p.write_text(text.replace('<translate x="0.25" y="0" />', '<translate x="0.4" y="0.3" />').replace('value="tex_', 'value="%s/tex_' % SCENES))
+    b = orc.Scene(str(p), dict(resx=16, resy=16))
+    ia, _ = a.render(a.params(), seed=1, spp=4, threads=NCPU)
+    ib, _ = b.render(b.params(), seed=1, spp=4, threads=NCPU)
+    assert np.array_equal(ia, ib)
+
+
+def test_texture_error_behaviour(mi, tmp_path):
+    text = open(os.path.join(SCENES, "cornell_textured.xml")).read().replace('value="tex_', 'value="%s/tex_' % SCENES)
+    mi.load_string(text)
+    with pytest.raises(mi.DtofError, match="Invalid filter type"):
+        mi.load_string(text.replace('value="nearest"', 'value="trilinear"'))
+    with pytest.raises(mi.DtofError, match="Invalid wrap mode"):
+        mi.load_string(text.replace('value="mirror"', 'value="border"'))
+    with pytest.raises(mi.DtofError, match="could not open"):
+        mi.load_string(text.replace("tex_gray.png", "missing.png"))
+    with pytest.raises(mi.DtofError, match="unsupported texture plugin"):
+        mi.load_string(text.replace('<texture type="checkerboard" name="reflectance">', '<texture type="mesh_attribute" name="reflectance">'))
+    bad = tmp_path / "not.png"
+    bad.write_bytes(b"JFIF not a png")
+    with pytest.raises(mi.DtofError, match="is not a PNG file"):
+        mi.load_string(text.replace(SCENES + "/tex_gray.png", str(bad)))
+    with pytest.raises(mi.DtofError, match="unreferenced property"):
+        mi.load_string(text.replace('<string name="wrap_mode" value="clamp" />', '<string name="wrap_mode" value="clamp" /><float name="gamma" value="2.2" />'))
+
+
+def test_png_reader_handles_filters_palettes_and_alpha(mi, tmp_path):
+    """the product's PNG reader against PIL: every scanline filter type (PIL picks them adaptively on a noisy image), RGBA, gray + alpha, palette"""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    base = (rng.random((9, 13, 4)) * 255).astype(np.uint8)
+    base[:, :, 0] = np.linspace(0, 255, 13).astype(np.uint8)[None, :]       # smooth channels make Sub / Up / Average / Paeth win somewhere
+    base[:, :, 1] = np.linspace(0, 255, 9).astype(np.uint8)[:, None]
+    variants = {"rgb": Image.fromarray(base[..., :3], "RGB"), "rgba": Image.fromarray(base, "RGBA"), "gray": Image.fromarray(base[..., 0], "L"),
+                "la": Image.fromarray(base[..., :2], "LA"), "pal": Image.fromarray(base[..., :3], "RGB").quantize(16)}
+    for name, im in variants.items():
+        path = str(tmp_path / (name + ".png"))
+        im.save(path, optimize=(name == "rgb"))
+        xml = ('<scene version="3.0.0"><integrator type="path"/><sensor type="perspective"><float name="fov" value="40"/>'
+               '<film type="hdrfilm"><integer name="width" value="4"/><integer name="height" value="4"/></film></sensor>'
+               '<shape type="rectangle"><bsdf type="diffuse"><texture type="bitmap" name="reflectance"><string name="filename" value="%s"/>'
+               '<boolean name="raw" value="true"/></texture></bsdf></shape></scene>' % path)
+        sc = mi.load_string(xml)
+        rec = sc.export(13).reshape(-1, 17)[0]
+        ref = np.asarray(im.convert("L" if name in ("gray", "la") else "RGB"), np.uint8)
+        assert (int(rec[3]), int(rec[4]), int(rec[5])) == (1 if name in ("gray", "la") else 3, 13, 9)
+        got = np.rint(sc.export(14) * 255).astype(np.uint8).reshape(ref.shape)
+        assert np.array_equal(got, ref), name
