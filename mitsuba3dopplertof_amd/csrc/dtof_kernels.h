@@ -52,6 +52,7 @@ struct RenderParams {
     uint32_t sample_count; FastDiv d_sample_count;   // Sampler::sample_count() of the whole render (spp = samples per wavefront = per pass)
     uint2 *pass_rng;                              // n_passes > 1: [lane - pass_first][3] = states of the main / time / path streams between passes
     uint32_t pass_first;                          // virtual lane the pass_rng array starts at
+    int32_t has_env, hide_emitters; uint32_t env_index;   // `constant` environment emitter (scene.cpp:53-57), SamplingIntegrator::m_hide_emitters
     uint32_t memo_obj;                            // fused pipeline: the scene's only instance object (instance memo, dtof_traverse.h) or 0xffffffff
 };
 

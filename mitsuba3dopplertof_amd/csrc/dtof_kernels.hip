@@ -210,6 +210,27 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
             for (int k = 0; k < 6; ++k) { main.state = main.state * kPcgMult + main.inc; if (!one) path.state = path.state * kPcgMult + path.inc; }
             q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
         }
+        if (SPEC && hid == 0xffffffffu && rp.has_env && !(depth == 0 && rp.hide_emitters)) {
+            // The ray left the scene: si.emitter(scene) is the environment (dopplertofpath.cpp:150-168).  DirectionSample(scene, si, prev_si)
+            // points along the ray; ConstantBackgroundEmitter::pdf_direction is the uniform-sphere density (constant.cpp:150-155).  A primary
+            // ray that sees the environment directly only counts if emitters are not hidden (valid_ray, :101-102,279-282).
+            const float4 stv = FIRST ? make_float4(1.f, 1.f, 1.f, 0.f) : q.st_a[l];
+            const float time_ = FIRST ? ra.w : q.ray_a[l].w;
+            float prev_pdf = 1.f; bool pdelta = true;
+            if (depth > 0) { prev_pdf = q.st_b[l].w; pdelta = q.st_c[l].y != 0.f; }
+            const DEmitter &env = sv.emitters[rp.env_index];
+            const float em_pdf = pdelta ? 0.f : kInvFourPi * (1.f / (float) sv.n_emitters);
+            const float mis_bsdf = mis_weight(prev_pdf, em_pdf);
+            const V3 le = prev_pdf > 0.f ? mk(env.intensity[0], env.intensity[1], env.intensity[2]) : mk(0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
+                V3 v = le * mis_bsdf;
+                if (rp.integrator == 0) v = v * modulation_weight(rp, rp.phase[k], time_, stv.w);
+                const float4 r = FIRST ? make_float4(0.f, 0.f, 0.f, 0.f) : q.res[(size_t) k * q.capacity + l];
+                const float4 acc = make_float4(fmaf(stv.x, v.x, r.x), fmaf(stv.y, v.y, r.y), fmaf(stv.z, v.z, r.z), 0.f);
+                if (FIRST) rbase[k] = make_float3(acc.x, acc.y, acc.z); else q.res[(size_t) k * q.capacity + l] = acc;
+            }
+        }
         if (hid != 0xffffffffu) {   // a miss ends the path (active_next = false, dopplertofpath.cpp:171)
             V3 o = mk(ra.x, ra.y, ra.z), d = mk(rb.x, rb.y, rb.z); float time = ra.w;
             V3 thr = mk(st.x, st.y, st.z); float path_length = st.w;
@@ -281,6 +302,14 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
                     float id2 = sqr(inv_dist);
                     em_weight = mk(em.intensity[0] * id2, em.intensity[1] * id2, em.intensity[2] * id2);
                     ds_pdf = 1.f;
+                } else if (SPEC && em.kind == EMITTER_CONSTANT) {   // ConstantBackgroundEmitter::sample_direction (constant.cpp:118-148)
+                    dd = uniform_sphere(sx, e2);
+                    const float radius = fmax_(em.cutoff_angle, norm(si.p - mk(em.pos[0], em.pos[1], em.pos[2])));   // m_bsphere, enlarged to hold the reference point
+                    ds_dist = 2.f * radius;
+                    dsp = vfma(dd, ds_dist, si.p);
+                    ds_pdf = kInvFourPi; ds_delta = false;
+                    const float ip = rcp(ds_pdf);
+                    em_weight = mk(em.intensity[0] * ip, em.intensity[1] * ip, em.intensity[2] * ip);
                 } else if (SPEC && em.kind == EMITTER_SPOT) {   // SpotLight::sample_direction (spot.cpp:152-187), falloff_curve (:116-126)
                     dsp = mk(em.pos[0], em.pos[1], em.pos[2]);
                     dd = dsp - si.p;

@@ -343,11 +343,13 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     const uint8_t *blob = sc->d_blob.p; uint32_t blob_bytes = (uint32_t) sc->blob.size();
     const uint32_t stack_depth = ((const BlobHeader *) sc->blob.data())->tlas_depth;
     bool has_surface_emitters = false;          // area emitters make the emitter-hit term (and the last iteration) live
-    for (auto &e : sc->host.emitters) has_surface_emitters |= e.kind == EMITTER_AREA;
+    for (auto &e : sc->host.emitters) has_surface_emitters |= e.kind == EMITTER_AREA || e.kind == EMITTER_CONSTANT;   // the environment is "hit" by the rays that leave the scene
     rp.has_area = has_surface_emitters;
     for (auto &sh : sc->host.shapes) rp.has_spec |= sh.bsdf != BSDF_DIFFUSE;
     for (auto &e : sc->host.emitters) rp.has_spec |= e.kind == EMITTER_SPOT;
-    rp.has_spec |= !sc->host.textures.empty();   // textured reflectances are looked up in the SPEC instantiations only   // the spot branch lives in the SPEC instantiations (keeps the common kernels lean)
+    rp.has_spec |= !sc->host.textures.empty();
+    for (size_t ei = 0; ei < sc->host.emitters.size(); ++ei) if (sc->host.emitters[ei].kind == EMITTER_CONSTANT) { rp.has_env = 1; rp.env_index = (uint32_t) ei; rp.has_spec = 1; }
+    rp.hide_emitters = sc->pp.hide_emitters;   // textured reflectances are looked up in the SPEC instantiations only   // the spot branch lives in the SPEC instantiations (keeps the common kernels lean)
     bool has_spheres = false;
     for (auto &sh : sc->host.shapes) has_spheres |= sh.kind == SHAPE_SPHERE || sh.kind == SHAPE_DISK;   // analytic shapes of the MESH instantiations
     rp.has_tris = bh->n_tris != 0 || has_spheres;   // anything but rectangles: the instantiations with triangle / sphere code

@@ -168,6 +168,7 @@ DTOF_D void mesh_sample_position(const SceneView &sv, const DShape &es, float s_
 }
 
 constexpr float kInvTwoPi = 0.15915494309189533577f;
+constexpr float kInvFourPi = 0.07957747154594766788f;   // warp::square_to_uniform_sphere_pdf (warp.h:257-266)
 DTOF_D float uniform_cone_pdf(float cos_cutoff) { return kInvTwoPi / (1.f - cos_cutoff); }   // warp::square_to_uniform_cone_pdf (warp.h:475-485)
 // Sphere::sample_direction (sphere.cpp:222-296): cone sampling of the visible cap from outside, uniform sphere from inside
 DTOF_D void sphere_sample_direction(const DShape &sh, V3 ref, float s_x, float s_y, V3 &p, V3 &n, V3 &dd, float &dist, float &pdf) {

@@ -316,6 +316,26 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         for (int k = 0; k < 3; ++k) it.c[k] = 0.5f * (b.lo[k] + b.hi[k]);
         items.push_back(it);
     }
+    // ConstantBackgroundEmitter::set_scene (constant.cpp:73-83): the bounding sphere of Scene::bbox() (the shapes' bboxes; instances over their
+    // first and last keyframe), radius = max(RayEpsilon, r * (1 + RayEpsilon)); an empty scene: centre 0, radius 1
+    float env_sphere[4] = { 0.f, 0.f, 0.f, 1.f };
+    {
+        Box all;
+        for (size_t i = 0; i < sc.objects.size(); ++i) {
+            const HostObject &ho = sc.objects[i]; Box b;
+            if (ho.kind == OBJ_SHAPE) b = shape_boxes[ho.index];
+            else {
+                const Box &gb = group_boxes[ho.index];
+                if (gb.valid()) for (int c = 0; c < 8; ++c) { b.add(xf_point(ho.key[0], gb.corner(c))); if (ho.n_keys > 1) b.add(xf_point(ho.key[1], gb.corner(c))); }
+            }
+            if (b.valid()) all.add(b);
+        }
+        if (all.valid()) {
+            const V3 c = mk((all.lo[0] + all.hi[0]) * .5f, (all.lo[1] + all.hi[1]) * .5f, (all.lo[2] + all.hi[2]) * .5f);
+            const float r = norm(c - mk(all.hi[0], all.hi[1], all.hi[2]));
+            env_sphere[0] = c.x; env_sphere[1] = c.y; env_sphere[2] = c.z; env_sphere[3] = fmax_(kRayEps, r * (1.f + kRayEps));
+        }
+    }
     std::vector<BvhNode> nodes;
     if (items.size() == 1) {
         BvhNode n; memset(&n, 0, sizeof n);
@@ -365,6 +385,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         memcpy(emitters[i].to_local, sc.emitters[i].to_local, 48);
         emitters[i].cutoff_angle = sc.emitters[i].cutoff_angle; emitters[i].cos_cutoff = sc.emitters[i].cos_cutoff;
         emitters[i].cos_beam = sc.emitters[i].cos_beam; emitters[i].inv_transition = sc.emitters[i].inv_transition;
+        if (sc.emitters[i].kind == EMITTER_CONSTANT) { memcpy(emitters[i].pos, env_sphere, 12); emitters[i].cutoff_angle = env_sphere[3]; }
     }
     // ---- pack: nodes first (so that "the first N bytes" = header + top of the TLAS in BFS-ish order)
     BlobHeader h; memset(&h, 0, sizeof h);

@@ -941,9 +941,15 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
             if (have_sensor) fail("only one sensor is supported");
             make_sensor(o, sc); have_sensor = true;
         } else if (o.tag == "emitter") {
-            if (o.plugin != "point" && o.plugin != "spot") fail("unsupported emitter plugin \"" + o.plugin + "\" (supported: point, spot; area inside a shape)");
+            if (o.plugin != "point" && o.plugin != "spot" && o.plugin != "constant") fail("unsupported emitter plugin \"" + o.plugin + "\" (supported: point, spot, constant; area inside a shape)");
             HostEmitter e; e.kind = 0;
-            if (o.plugin == "spot") {   // src/emitters/spot.cpp:75-100; position = translation of to_world, axis = its +z
+            if (o.plugin == "constant") {   // src/emitters/constant.cpp:58-67: the scene's environment (scene.cpp:53-57); its bounding sphere follows in build_scene_blob
+                for (auto &pe : sc.emitters) if (pe.kind == EMITTER_CONSTANT) fail("Only one environment emitter can be specified per scene.");
+                e.kind = EMITTER_CONSTANT;
+                auto rc = o.colors.find("radiance");
+                if (rc != o.colors.end()) for (int i = 0; i < 3; ++i) e.intensity[i] = (float) rc->second[i];
+                else { float v = (float) o.props.get_float("radiance", 1.0); e.intensity[0] = e.intensity[1] = e.intensity[2] = v; }
+            } else if (o.plugin == "spot") {   // src/emitters/spot.cpp:75-100; position = translation of to_world, axis = its +z
                 e.kind = EMITTER_SPOT;
                 auto tws = o.transforms.find("to_world");
                 Xf xf; if (tws != o.transforms.end()) xf = tws->second; else { xf.m = m_identity(); xf.inv = m_identity(); }

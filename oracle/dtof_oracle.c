@@ -865,6 +865,7 @@ static float shape_inv_area(const orc_shape *sh) {
 }
 static inline float f_safe_sqrt(float x) { return sqrtf(f_max(x, 0.f)); }
 #define ORC_INV_TWO_PI_F 0.15915494309189533577f
+#define ORC_INV_FOUR_PI_F 0.07957747154594766788f   /* warp::square_to_uniform_sphere_pdf (warp.h:257-266) */
 /* warp::square_to_uniform_cone_pdf (warp.h:475-485) */
 static inline float uniform_cone_pdf(float cos_cutoff) { return ORC_INV_TWO_PI_F / (1.f - cos_cutoff); }
 /* warp::square_to_uniform_sphere (warp.h:250-255) */
@@ -1426,7 +1427,10 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
 
     v3 thr = V(1.f, 1.f, 1.f), res = V(0.f, 0.f, 0.f);
     float path_length = 0.f, eta = 1.f;
-    uint32_t depth = 0; int valid_ray = 0, active = p->max_depth != 0;
+    /* the environment emitter, if any (scene.cpp:53-57); valid_ray starts as !m_hide_emitters && environment != nullptr (dopplertofpath.cpp:101-102) */
+    const orc_emitter *env = NULL;
+    for (int32_t ei = 0; ei < sc->n_emitters; ++ei) if (sc->emitters[ei].kind == ORC_EMITTER_CONSTANT) env = &sc->emitters[ei];
+    uint32_t depth = 0; int valid_ray = env && !p->hide_emitters, active = p->max_depth != 0;
     v3 o = ray.o, d = ray.d; float maxt = ray.maxt;
     v3 prev_p = V(0, 0, 0); float prev_bsdf_pdf = 1.f; int prev_delta = 1;   /* dopplertofpath.cpp:106-108 */
 
@@ -1453,6 +1457,16 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         const float pmf = sc->n_emitters ? 1.f / (float) sc->n_emitters : 0.f;   /* m_emitter_pmf, scene.cpp:96 */
 
         /* ---- direct emission (dopplertofpath.cpp:150-168 / path.cpp): the hit shape carries an area emitter */
+        if (!hit && env) {
+            /* si.emitter(scene) of a missed ray is the environment (interaction.h); DirectionSample(scene, si, prev_si): d = -si.wi = the ray
+             * direction; Scene::pdf_emitter_direction -> ConstantBackgroundEmitter::pdf_direction = square_to_uniform_sphere_pdf (constant.cpp:150-155) */
+            float em_pdf = prev_delta ? 0.f : ORC_INV_FOUR_PI_F * pmf;
+            float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
+            v3 le = prev_bsdf_pdf > 0.f ? V(env->intensity[0], env->intensity[1], env->intensity[2]) : V(0, 0, 0);
+            v3 v = v_mul(le, mis_bsdf);
+            if (!plain) v = v_mul(v, orc_modulation_weight(p, time, path_length));
+            res = V(fmaf(thr.x, v.x, res.x), fmaf(thr.y, v.y, res.y), fmaf(thr.z, v.z, res.z));
+        }
         if (hit && si.shape->emitter) {
             /* DirectionSample(scene, si, prev_si) -- include/mitsuba/render/records.h:173-180 */
             v3 rel = v_sub(si.p, prev_p);
@@ -1504,6 +1518,17 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
                 float id2 = f_sqr(inv_dist);
                 em_weight = V(em->intensity[0] * id2, em->intensity[1] * id2, em->intensity[2] * id2);
                 ds_pdf = 1.f; ds_delta = 1;
+            } else if (em->kind == ORC_EMITTER_CONSTANT) {
+                /* ConstantBackgroundEmitter::sample_direction (constant.cpp:118-148): a uniform direction; the sample point lies on a sphere
+                 * of twice the (enlarged) bounding radius around the reference point */
+                dd = square_to_uniform_sphere(sx, e2);
+                v3 c = V(em->bsphere[0], em->bsphere[1], em->bsphere[2]);
+                float radius = f_max(em->bsphere[3], v_norm(v_sub(si.p, c)));
+                ds_dist = 2.f * radius;
+                dsp = v_fma(dd, ds_dist, si.p);
+                ds_pdf = ORC_INV_FOUR_PI_F; ds_delta = 0;
+                float ip = f_rcp(ds_pdf);
+                em_weight = V(em->intensity[0] * ip, em->intensity[1] * ip, em->intensity[2] * ip);
             } else if (em->kind == ORC_EMITTER_SPOT) {
                 /* SpotLight::sample_direction (src/emitters/spot.cpp:152-187) with falloff_curve (:116-126) */
                 dsp = V(em->position[0], em->position[1], em->position[2]);
@@ -2096,3 +2121,50 @@ void orc_kat_splat(const orc_sensor *se, float *film, float x, float y, const fl
     splat(se, film, x, y, (int) floorf(x), (int) floorf(y), rgb);
 }
 int orc_kat_solve_quadratic(double a, double b, double c, double *out2) { return solve_quadratic_d(a, b, c, out2, out2 + 1); }
+
+/* ---- Scene::bbox() and the environment emitter's bounding sphere */
+typedef struct { float lo[3], hi[3]; } orc_box;
+static void box_init(orc_box *b) { for (int i = 0; i < 3; ++i) { b->lo[i] = INFINITY; b->hi[i] = -INFINITY; } }
+static void box_add(orc_box *b, v3 p) {
+    const float c[3] = { p.x, p.y, p.z };
+    for (int i = 0; i < 3; ++i) { if (c[i] < b->lo[i]) b->lo[i] = c[i]; if (c[i] > b->hi[i]) b->hi[i] = c[i]; }
+}
+/* Rectangle::bbox (rectangle.cpp:115-125), Disk::bbox (disk.cpp:136-146), Sphere::bbox (sphere.cpp:177-182), Mesh::bbox (the vertices) */
+static void shape_bbox(const orc_shape *sh, orc_box *b) {
+    box_init(b);
+    if (sh->kind == ORC_SHAPE_RECT || sh->kind == ORC_SHAPE_DISK) {
+        static const float c[4][2] = { { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+        for (int k = 0; k < 4; ++k) box_add(b, m_point(sh->to_world, V(c[k][0], c[k][1], 0.f)));
+    } else if (sh->kind == ORC_SHAPE_SPHERE) {
+        box_add(b, V(sh->center[0] - sh->radius, sh->center[1] - sh->radius, sh->center[2] - sh->radius));
+        box_add(b, V(sh->center[0] + sh->radius, sh->center[1] + sh->radius, sh->center[2] + sh->radius));
+    } else for (int32_t i = 0; i < sh->n_vertices; ++i) box_add(b, mesh_pos(sh, (uint32_t) i));
+}
+void orc_scene_bsphere(const orc_scene *sc, float *out4) {
+    orc_box all; box_init(&all);
+    for (int32_t i = 0; i < sc->n_objects; ++i) {
+        const orc_object *ob = &sc->objects[i];
+        orc_box b;
+        if (ob->kind == ORC_OBJ_SHAPE) shape_bbox(&sc->shapes[ob->index], &b);
+        else {   /* Instance::bbox (instance.cpp:101-114): the group's box under the first and the last keyframe */
+            orc_box g; box_init(&g);
+            const orc_group *gr = &sc->groups[ob->index];
+            for (int32_t k = 0; k < gr->n_shapes; ++k) {
+                orc_box cb; shape_bbox(&sc->shapes[gr->first_shape + k], &cb);
+                if (cb.lo[0] <= cb.hi[0]) { box_add(&g, V(cb.lo[0], cb.lo[1], cb.lo[2])); box_add(&g, V(cb.hi[0], cb.hi[1], cb.hi[2])); }
+            }
+            box_init(&b);
+            if (g.lo[0] <= g.hi[0]) for (int c = 0; c < 8; ++c) {
+                v3 corner = V(c & 1 ? g.hi[0] : g.lo[0], c & 2 ? g.hi[1] : g.lo[1], c & 4 ? g.hi[2] : g.lo[2]);
+                box_add(&b, m_point(ob->key[0], corner));
+                if (ob->n_keys > 1) box_add(&b, m_point(ob->key[1], corner));
+            }
+        }
+        if (b.lo[0] <= b.hi[0]) { box_add(&all, V(b.lo[0], b.lo[1], b.lo[2])); box_add(&all, V(b.hi[0], b.hi[1], b.hi[2])); }
+    }
+    if (!(all.lo[0] <= all.hi[0])) { out4[0] = out4[1] = out4[2] = 0.f; out4[3] = 1.f; return; }
+    /* BoundingBox::bounding_sphere (bbox.h:330-333): centre = (min + max) * .5, radius = |centre - max| */
+    v3 c = V((all.lo[0] + all.hi[0]) * .5f, (all.lo[1] + all.hi[1]) * .5f, (all.lo[2] + all.hi[2]) * .5f);
+    float r = v_norm(v_sub(c, V(all.hi[0], all.hi[1], all.hi[2])));
+    out4[0] = c.x; out4[1] = c.y; out4[2] = c.z; out4[3] = f_max(ORC_RAY_EPS, r * (1.f + ORC_RAY_EPS));
+}

@@ -25,7 +25,7 @@ extern "C" {
 
 enum { ORC_SHAPE_RECT = 0, ORC_SHAPE_MESH = 1, ORC_SHAPE_SPHERE = 2, ORC_SHAPE_DISK = 3 };
 enum { ORC_OBJ_SHAPE = 0, ORC_OBJ_INSTANCE = 1 };
-enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1, ORC_EMITTER_SPOT = 2 };
+enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1, ORC_EMITTER_SPOT = 2, ORC_EMITTER_CONSTANT = 3 };
 enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 };
 enum { ORC_TIME_UNIFORM = 0, ORC_TIME_STRATIFIED = 1, ORC_TIME_ANTITHETIC = 2,
        ORC_TIME_ANTITHETIC_MIRROR = 3 };
@@ -110,6 +110,9 @@ typedef struct {
     int32_t shape;           /* area: index into shapes[] of the rectangle that carries it */
     /* spot (src/emitters/spot.cpp:75-100): inverse of to_world (float cast of the double inverse), falloff constants (orc_spot_params) */
     float   to_local[16], cutoff_angle, cos_cutoff, cos_beam, inv_transition;
+    /* constant (src/emitters/constant.cpp): intensity = radiance; m_bsphere = the scene's bounding sphere, enlarged (set_scene, :73-83): centre[3], radius
+     * (orc_scene_bsphere) */
+    float   bsphere[4];
 } orc_emitter;
 
 typedef struct {
@@ -199,6 +202,9 @@ int      orc_occluded(const orc_scene *sc, const float *o, const float *d, float
 
 /* Evaluate lanes [lane_begin, lane_begin+n) of the wavefront of W*H*spp lanes.  With several passes (samples_per_pass, or a wavefront
  * beyond 2^32 - 1 lanes) the index is pass * wavefront_size + lane, wavefront_size = W*H*spp_per_pass (orc_pass_layout). */
+/* ConstantBackgroundEmitter::set_scene (constant.cpp:73-83): bounding sphere of Scene::bbox() (the union of the shapes' bboxes, instances over
+ * their first and last keyframe, scene.cpp:42, instance.cpp:101-114), radius = max(RayEpsilon, r * (1 + RayEpsilon)); an empty scene: centre 0, radius 1 */
+void     orc_scene_bsphere(const orc_scene *sc, float *out4);
 int      orc_pass_layout(int32_t crop_w, int32_t crop_h, uint32_t spp, uint32_t samples_per_pass, uint32_t *spp_per_pass, uint32_t *n_passes);
 void     orc_render_lanes(const orc_scene *sc, const orc_params *p, uint32_t seed, uint32_t spp,
                           uint64_t lane_begin, uint64_t n, orc_lane *out, int n_threads);

@@ -48,7 +48,8 @@ class OrcObject(C.Structure):
 
 class OrcEmitter(C.Structure):
     _fields_ = [("kind", C.c_int32), ("position", C.c_float * 3), ("intensity", C.c_float * 3), ("shape", C.c_int32),
-                ("to_local", M16), ("cutoff_angle", C.c_float), ("cos_cutoff", C.c_float), ("cos_beam", C.c_float), ("inv_transition", C.c_float)]
+                ("to_local", M16), ("cutoff_angle", C.c_float), ("cos_cutoff", C.c_float), ("cos_beam", C.c_float), ("inv_transition", C.c_float),
+                ("bsphere", C.c_float * 4)]
 
 
 class OrcSensor(C.Structure):
@@ -175,6 +176,7 @@ def lib():
         L.orc_kat_sphere_sample_direction.argtypes = [C.POINTER(OrcShape), C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.orc_kat_shape_area.restype = C.c_float
         L.orc_kat_shape_area.argtypes = [C.POINTER(OrcShape)]
+        L.orc_scene_bsphere.argtypes = [C.POINTER(OrcScene), C.c_void_p]
         L.orc_texture_eval.argtypes = [C.POINTER(OrcTexture), C.c_float, C.c_float, C.c_void_p]
         L.orc_kat_splat.argtypes = [C.POINTER(OrcSensor), C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.orc_kat_solve_quadratic.restype = C.c_int
@@ -344,6 +346,12 @@ class Scene:
             setattr(sc.sensor, k, int(se[k]))
         self._keep += [shapes, groups, objects, emitters]
         self.c = sc
+        for i, e in enumerate(fs.emitters):
+            if e["kind"] == 3:   # constant environment: ConstantBackgroundEmitter::set_scene (constant.cpp:73-83)
+                bs = (C.c_float * 4)()
+                L.orc_scene_bsphere(C.byref(sc), bs)
+                emitters[i].bsphere = bs
+                e["bsphere"] = np.array(list(bs), np.float32)
 
     @property
     def size(self):

@@ -630,6 +630,14 @@ def load(source, params=None, is_string=False):
                 fs.emitters.append(dict(kind=2, position=_m32(tw)[:3, 3].copy(), intensity=np.asarray(iv, dtype=np.float64).astype(F32),
                                         to_local=_m32(tinv), cutoff_deg=cutoff, beam_deg=beam))
                 continue
+            if child.plugin == "constant":   # src/emitters/constant.cpp:58-67; the environment of the scene (scene.cpp:53-57)
+                if any(e["kind"] == 3 for e in fs.emitters):
+                    raise ValueError("Only one environment emitter can be specified per scene.")
+                rad = child["radiance"] if "radiance" in child else ("float", 1.0)
+                child.queried.add("radiance")
+                rv = [rad[1]] * 3 if rad[0] in ("float", "int") else rad[1]
+                fs.emitters.append(dict(kind=3, position=np.zeros(3, F32), intensity=np.asarray(rv, dtype=np.float64).astype(F32)))
+                continue
             if child.plugin != "point":
                 raise ValueError('unsupported emitter plugin "%s"' % child.plugin)
             if "position" in child:

@@ -216,6 +216,20 @@ def cornell_textured(res=128, spp=16):
     return s + LIGHT + "</scene>\n"
 
 
+def cornell_env(res=128, spp=16):
+    """the Cornell room without ceiling and back wall, under a `constant` environment emitter (src/emitters/constant.cpp) beside the
+    point light: rays leave the scene (environment term with MIS, valid_ray) and the environment is sampled as an emitter"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        s += bsdf(*b)
+    for name, m, b in WALLS:
+        if name not in ("Ceiling", "BackWall"):
+            s += rect(name, m, b)
+    s += cube("ShortBox", SHORT, "ShortBoxBSDF", "0.015") + cube("TallBox", TALL, "TallBoxBSDF", "-0.015")
+    s += '\t<emitter type="constant">\n\t\t<rgb name="radiance" value="0.8, 0.9, 1.2" />\n\t</emitter>\n'
+    return s + LIGHT + "</scene>\n"
+
+
 def cornell_plastic(res=128, spp=16):
     """cornell_boxes.xml with glossy-coated (smooth `plastic`) boxes and a plastic floor, point light at the camera"""
     s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
@@ -386,6 +400,7 @@ def main():
         "cornell_spot.xml": cornell_spot(),
         "cornell_disk.xml": cornell_disk(),
         "cornell_textured.xml": cornell_textured(),
+        "cornell_env.xml": cornell_env(),
         "cornell_spheres.xml": cornell_spheres(),
         "cornell_sphere_light.xml": cornell_spheres(sphere_light=True),
         "domino.xml": domino(),
@@ -401,7 +416,7 @@ def main():
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
     names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml",
-             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "tex_rgb.png", "tex_gray.png"]
+             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml", "tex_rgb.png", "tex_gray.png"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
         return

@@ -85,6 +85,8 @@ CONFIGS = [
     ("frosted_glass_beckmann", "cornell_frosted.xml", dict(resx=24, resy=24, max_depth=6, distribution="beckmann"), 8),
     # checkerboard / bitmap textures on the diffuse reflectances (rectangles, cube texcoords, a plastic's diffuse_reflectance)
     ("textured", "cornell_textured.xml", dict(resx=32, resy=32, max_depth=4), 8),
+    # `constant` environment emitter: rays that leave the scene, environment sampling with MIS, valid_ray
+    ("environment", "cornell_env.xml", dict(resx=32, resy=32, max_depth=4), 8),
     ("spot_light", "cornell_spot.xml", dict(resx=24, resy=24), 8),
     ("disks", "cornell_disk.xml", dict(resx=24, resy=24, max_depth=5), 8),
     ("spheres", "cornell_spheres.xml", dict(resx=24, resy=24), 8),

@@ -101,3 +101,32 @@ def test_spot_scenes_are_bit_exact_per_lane(mi, orc, tmp_path, name, scene, para
     img = sc.render(seed=29, spp=spp)
     ref, _ = osc.render(pd, seed=29, spp=spp, threads=NCPU)
     assert float(np.abs(img - ref).max() / np.abs(ref).max()) <= 5e-5
+
+
+def test_constant_environment(mi, orc):
+    """`constant` emitter (src/emitters/constant.cpp): loader parity (radiance, the scene's enlarged bounding sphere), a furnace check with
+    the oracle -- inside a closed sphere of radiance L every primary ray returns L times the reflected series -- and hide_emitters."""
+    path = os.path.join(SCENES, "cornell_env.xml")
+    osc = orc.Scene(path, dict(resx=16, resy=16))
+    env = [e for e in osc.flat.emitters if e["kind"] == 3]
+    assert len(env) == 1 and np.allclose(env[0]["intensity"], [0.8, 0.9, 1.2])
+    c, r = env[0]["bsphere"][:3], env[0]["bsphere"][3]
+    assert np.allclose(c, [0, 1, 0], atol=1e-6) and 1.73 < r < 1.7323        # the room spans [-1, 1] x [0, 2] x [-1, 1]: radius sqrt(3) * (1 + eps)
+    # sky pixels: the developed image shows the radiance itself (plain path integrator); hidden emitters: black
+    pd = osc.params(integrator=dict(type="path", max_depth=4))
+    img, _ = osc.render(pd, seed=0, spp=8, threads=NCPU)
+    assert np.allclose(img[0, 8], [0.8, 0.9, 1.2], rtol=1e-5)
+    hidden, _ = osc.render(osc.params(integrator=dict(type="path", max_depth=4, hide_emitters=True)), seed=0, spp=8, threads=NCPU)
+    assert np.array_equal(hidden[0, 8], [0, 0, 0]) and hidden[12, 8].sum() > 0
+    # white furnace: a diffuse sphere of albedo a around the camera, radiance L from the environment only:
+    # pixel = L * (a + a^2 + ...) truncated at max_depth - 1 bounces of the light path
+    xml = ('<scene version="3.0.0"><integrator type="path"><integer name="max_depth" value="%d"/></integrator>'
+           '<sensor type="perspective"><float name="fov" value="40"/><sampler type="independent"><integer name="sample_count" value="64"/></sampler>'
+           '<film type="hdrfilm"><integer name="width" value="4"/><integer name="height" value="4"/><rfilter type="box"/></film></sensor>'
+           '<shape type="sphere"><float name="radius" value="2"/><boolean name="flip_normals" value="true"/>'
+           '<bsdf type="diffuse"><rgb name="reflectance" value="0.5"/></bsdf></shape>'
+           '<emitter type="constant"><rgb name="radiance" value="2"/></emitter></scene>')
+    # from inside a closed sphere the environment is never seen: every path is absorbed -> black (the emitter is sampled but always occluded)
+    closed = orc.Scene(xml % 6, is_string=True)
+    img, _ = closed.render(closed.params(), seed=1, spp=64, threads=NCPU)
+    assert np.abs(img).max() == 0.0

@@ -733,7 +733,7 @@ def _random_config(rng):
     if spp % sampler["path_correlate_number"]:
         sampler["path_correlate_number"] = tcn
     scene = str(rng.choice(["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_spheres.xml", "cornell_specular.xml",
-                            "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml", "domino_small.xml"]))
+                            "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml"]))
     return scene, dict(resx=int(rng.choice([8, 13, 24])), resy=int(rng.choice([8, 11, 16]))), spp, integ, sampler
 
 
