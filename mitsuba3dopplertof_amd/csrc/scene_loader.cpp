@@ -787,7 +787,7 @@ static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string
             const Obj &e = *c.second;
             if (s.emitter) fail("Only a single Emitter child object can be specified per shape.");
             if (e.plugin != "area") fail("unsupported emitter plugin \"" + e.plugin + "\" inside a shape (supported: area)");
-            if (strip_to_world) fail("area emitters are supported on static shapes only");
+            if (strip_to_world) fail("Instancing of emitters is not supported");   // shapegroup.cpp:27-28: an animated (or grouped) shape becomes an instance (xml.cpp:1165-1195), which cannot carry an emitter in the reference either
             if (e.transforms.count("to_world")) fail("Found a 'to_world' transformation -- this is not allowed. The area light inherits this transformation from its parent shape.");
             auto rc = e.colors.find("radiance");
             if (rc != e.colors.end()) for (int i = 0; i < 3; ++i) s.radiance[i] = (float) rc->second[i];

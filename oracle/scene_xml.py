@@ -565,8 +565,10 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
     if ems:   # src/emitters/area.cpp:64-76 on a static shape (rectangle or triangle mesh)
         if len(ems) > 1:
             raise ValueError("Only a single Emitter child object can be specified per shape.")
-        if ems[0].plugin != "area" or strip_to_world:
-            raise ValueError("only area emitters on static shapes are supported")
+        if ems[0].plugin != "area":
+            raise ValueError('unsupported emitter plugin "%s" inside a shape (supported: area)' % ems[0].plugin)
+        if strip_to_world:
+            raise ValueError("Instancing of emitters is not supported")   # shapegroup.cpp:27-28 (an animated shape becomes an instance, xml.cpp:1165-1195)
         if "to_world" in ems[0]:
             raise ValueError("Found a 'to_world' transformation -- this is not allowed.")
         rad = ems[0]["radiance"] if "radiance" in ems[0] else ("float", 1.0)
