@@ -351,7 +351,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     for (size_t ei = 0; ei < sc->host.emitters.size(); ++ei) if (sc->host.emitters[ei].kind == EMITTER_CONSTANT) { rp.has_env = 1; rp.env_index = (uint32_t) ei; rp.has_spec = 1; }
     rp.hide_emitters = sc->pp.hide_emitters;   // textured reflectances are looked up in the SPEC instantiations only   // the spot branch lives in the SPEC instantiations (keeps the common kernels lean)
     bool has_spheres = false;
-    for (auto &sh : sc->host.shapes) has_spheres |= sh.kind == SHAPE_SPHERE || sh.kind == SHAPE_DISK;   // analytic shapes of the MESH instantiations
+    for (auto &sh : sc->host.shapes) has_spheres |= sh.kind == SHAPE_SPHERE || sh.kind == SHAPE_DISK || sh.kind == SHAPE_CYLINDER;   // analytic shapes of the MESH instantiations
     rp.has_tris = bh->n_tris != 0 || has_spheres;   // anything but rectangles: the instantiations with triangle / sphere code
     {   // deep per-mesh traversals diverge: see unstaged_block() in dtof_kernels.hip
         const DShape *dshapes = (const DShape *) (sc->blob.data() + bh->off_shapes);

@@ -10,7 +10,7 @@
 namespace dtof {
 
 // ---------------------------------------------------------------------------- enums
-enum ShapeKind : uint32_t { SHAPE_RECT = 0, SHAPE_MESH = 1, SHAPE_SPHERE = 2, SHAPE_DISK = 3 };
+enum ShapeKind : uint32_t { SHAPE_RECT = 0, SHAPE_MESH = 1, SHAPE_SPHERE = 2, SHAPE_DISK = 3, SHAPE_CYLINDER = 4 };
 enum ObjectKind : uint32_t { OBJ_SHAPE = 0, OBJ_INSTANCE = 1 };
 enum WaveType : int32_t { WAVE_SIN = 0, WAVE_RECT = 1, WAVE_TRI = 2, WAVE_TRAP = 3 };
 // ETimeSampling -- include/mitsuba/render/sampler.h:27-34

@@ -55,6 +55,14 @@ DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, 
         const float cos_phi = r != 0.f ? b1 * inv_r : 1.f, sin_phi = r != 0.f ? b2 * inv_r : 0.f;
         dp_du = xf_vector(sh->to_world, mk(cos_phi, sin_phi, 0.f));
         dp_dv = xf_vector(sh->to_world, mk(-sin_phi, cos_phi, 0.f));
+    } else if (sh->kind == SHAPE_CYLINDER) {   // Cylinder::compute_surface_interaction (cylinder.cpp:395-500, non-diff branch; its normal shift adds
+        const V3 p = vfma(ld, t, lo);            // a zero vector: si.n is still unset where it runs, :471-475)
+        const V3 local = xf_point(sh->to_object, p);
+        dp_du = xf_vector(sh->to_world, mk(-local.y, local.x, 0.f) * (2.f * kPi));
+        dp_dv = xf_vector(sh->to_world, mk(0.f, 0.f, 1.f));
+        V3 n = normalize(cross(dp_du, dp_dv));
+        if (sh->flags & SF_FLIP_NORMALS) n = -n;
+        si.p = p; si.n = n; si.sh_n = n;
     } else if (sh->kind == SHAPE_SPHERE) {   // Sphere::compute_surface_interaction (sphere.cpp:509-513, 527-551)
         const V3 c = mk(sh->n[0], sh->n[1], sh->n[2]); const float radius = sh->dp_du[0];
         V3 n = normalize(vfma(ld, t, lo) - c);

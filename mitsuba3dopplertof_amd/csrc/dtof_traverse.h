@@ -135,6 +135,21 @@ DTOF_D bool sphere_hit(const DShape &sh, V3 o, V3 d, float maxt_f, float &t_out)
     t_out = near_t < 0.0 ? (float) far_t : (float) near_t;
     return true;
 }
+// Cylinder::ray_intersect_preliminary_impl / ray_test_impl (src/shapes/cylinder.cpp:300-391): the unit cylinder in object space, float64 on the
+// llvm back end (the ray is transformed in float32, then widened)
+DTOF_D bool cylinder_hit(const DShape &sh, V3 o, V3 d, float maxt_f, float &t_out) {
+    const V3 lo = xf_point(sh.to_object, o), ld = xf_vector(sh.to_object, d);
+    const double ox = lo.x, oy = lo.y, oz = lo.z, dx = ld.x, dy = ld.y, dz = ld.z, maxt = maxt_f;
+    const double A = dx * dx + dy * dy, B = 2.0 * (dx * ox + dy * oy), C = ox * ox + oy * oy - 1.0;
+    double near_t, far_t;
+    const bool found = solve_quadratic_d(A, B, C, near_t, far_t);
+    const bool out_bounds = !(near_t <= maxt && far_t >= 0.0), in_bounds = near_t < 0.0 && far_t > maxt;
+    const double z_near = oz + dz * near_t, z_far = oz + dz * far_t;
+    const bool near_ok = z_near >= 0.0 && z_near <= 1.0 && near_t >= 0.0, far_ok = z_far >= 0.0 && z_far <= 1.0 && far_t <= maxt;
+    if (!(found && !out_bounds && !in_bounds && (near_ok || far_ok))) return false;
+    t_out = near_ok ? (float) near_t : (float) far_t;
+    return true;
+}
 // AnimatedTransform::eval, include/mitsuba/core/transform.h:439-466
 DTOF_D void instance_matrix(const DObject &ob, float time, float *m) {
     if (ob.n_keys <= 1) {
@@ -273,6 +288,15 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
                 if (ANY) return true;
                 if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
                     best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = 0; found = true;
+                }
+            }
+            continue;
+        }
+        if (sh.kind == SHAPE_CYLINDER) {
+            if (cylinder_hit(sh, lo, ld, maxt, t)) {
+                if (ANY) return true;
+                if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
+                    best.t = t; best.u = 0.f; best.v = 0.f; best.obj = oi; best.shape = k; best.prim = 0; found = true;
                 }
             }
             continue;

@@ -39,6 +39,11 @@ static Box shape_box(const HostShape &s) {
     if (s.kind == SHAPE_RECT || s.kind == SHAPE_DISK) {   // Rectangle::bbox (rectangle.cpp:115-125), Disk::bbox (disk.cpp:136-146): the same four corners
         const float c[4][2] = { { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
         for (auto &k : c) b.add(xf_point(s.to_world, mk(k[0], k[1], 0.f)));
+    } else if (s.kind == SHAPE_CYLINDER) {   // Cylinder::bbox (src/shapes/cylinder.cpp:166-179): the two end circles
+        const V3 x1 = xf_vector(s.to_world, mk(1.f, 0.f, 0.f)), x2 = xf_vector(s.to_world, mk(0.f, 1.f, 0.f));
+        const V3 x = mk(sqrtf(sqr(x1.x) + sqr(x2.x)), sqrtf(sqr(x1.y) + sqr(x2.y)), sqrtf(sqr(x1.z) + sqr(x2.z)));
+        const V3 p0 = xf_point(s.to_world, mk(0.f, 0.f, 0.f)), p1 = xf_point(s.to_world, mk(0.f, 0.f, 1.f));
+        b.add(p0 - x); b.add(p1 - x); b.add(p0 + x); b.add(p1 + x);
     } else if (s.kind == SHAPE_SPHERE) {   // Sphere::bbox, src/shapes/sphere.cpp:177-182
         b.add(mk(s.center[0] - s.radius, s.center[1] - s.radius, s.center[2] - s.radius));
         b.add(mk(s.center[0] + s.radius, s.center[1] + s.radius, s.center[2] + s.radius));
@@ -223,6 +228,8 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
             d.inv_area = rcp(kPi * m_du * hh);
         } else if (h.kind == SHAPE_SPHERE) {
             memcpy(d.n, h.center, 12); d.dp_du[0] = h.radius; d.inv_area = h.sphere_inv_area;
+        } else if (h.kind == SHAPE_CYLINDER) {
+            d.dp_du[0] = h.radius;      // everything else is in the composed to_world / to_object
         } else {
             d.first_tri = (uint32_t) tris.size(); d.n_tris = (uint32_t) (h.faces.size() / 3);
             for (uint32_t f = 0; f < d.n_tris; ++f) {

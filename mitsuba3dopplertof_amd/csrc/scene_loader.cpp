@@ -763,13 +763,41 @@ static void bake_sphere(HostShape &s, const Obj &o) {
     s.sphere_inv_area = 1.0f / ((4.f * kPi) * sqr(s.radius));
 }
 
+// Cylinder ctor + update (src/shapes/cylinder.cpp:100-147), in float32 like ScalarTransform4f: composed = to_world * translate(p0) *
+// to_frame(Frame3f((p1 - p0) / |p1 - p0|)) * scale(radius, radius, |p1 - p0|); the unit cylinder x^2 + y^2 = 1, 0 <= z <= 1 lives in object space
+static void bake_cylinder(HostShape &s, const Obj &o) {
+    double a[3] = { 0, 0, 0 }, b[3] = { 0, 0, 1 };
+    auto pa = o.vectors.find("p0"), pb = o.vectors.find("p1");
+    if (pa != o.vectors.end()) for (int i = 0; i < 3; ++i) a[i] = pa->second[i];
+    if (pb != o.vectors.end()) for (int i = 0; i < 3; ++i) b[i] = pb->second[i];
+    const float p0[3] = { (float) a[0], (float) a[1], (float) a[2] }, p1[3] = { (float) b[0], (float) b[1], (float) b[2] }, radius = (float) o.props.get_float("radius", 1.0);
+    const V3 d = mk(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]);
+    const float length = norm(d);
+    const V3 n = d * rcp(length); V3 fs, ft;
+    coordinate_system(n, fs, ft);
+    float T[16] = { 1, 0, 0, p0[0], 0, 1, 0, p0[1], 0, 0, 1, p0[2], 0, 0, 0, 1 }, Ti[16] = { 1, 0, 0, -p0[0], 0, 1, 0, -p0[1], 0, 0, 1, -p0[2], 0, 0, 0, 1 };
+    float F[16] = { fs.x, ft.x, n.x, 0, fs.y, ft.y, n.y, 0, fs.z, ft.z, n.z, 0, 0, 0, 0, 1 };       // columns s, t, n (transform.h:286-296)
+    float Fi[16] = { fs.x, fs.y, fs.z, 0, ft.x, ft.y, ft.z, 0, n.x, n.y, n.z, 0, 0, 0, 0, 1 };
+    const float ir = 1.0f / radius, il = 1.0f / length;
+    float S[16] = { radius, 0, 0, 0, 0, radius, 0, 0, 0, 0, length, 0, 0, 0, 0, 1 }, Si[16] = { ir, 0, 0, 0, 0, ir, 0, 0, 0, 0, il, 0, 0, 0, 0, 1 };
+    float t1[16], t2[16], comp[16], comp_inv[16];
+    m4_mul_f32(s.to_world, T, t1); m4_mul_f32(t1, F, t2); m4_mul_f32(t2, S, comp);
+    m4_mul_f32(Ti, s.to_object, t1); m4_mul_f32(Fi, t1, t2); m4_mul_f32(Si, t2, comp_inv);
+    memcpy(s.to_world, comp, sizeof comp); memcpy(s.to_object, comp_inv, sizeof comp_inv);
+    s.radius = norm(mk(comp[0], comp[4], comp[8]));
+    const float *m = comp;
+    float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+    if (det < 0.f) s.flip_normals = !s.flip_normals;
+}
+
 static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string &base_dir) {
     HostShape s; s.id = o.id;
     const bool mesh_file = o.plugin == "obj" || o.plugin == "ply";
     if (o.plugin == "rectangle") s.kind = SHAPE_RECT; else if (o.plugin == "cube" || mesh_file) s.kind = SHAPE_MESH;
     else if (o.plugin == "sphere") s.kind = SHAPE_SPHERE;
     else if (o.plugin == "disk") s.kind = SHAPE_DISK;
-    else fail("unsupported shape plugin \"" + o.plugin + "\" (supported: rectangle, disk, cube, obj, ply, sphere, shapegroup, instance)");
+    else if (o.plugin == "cylinder") s.kind = SHAPE_CYLINDER;
+    else fail("unsupported shape plugin \"" + o.plugin + "\" (supported: rectangle, disk, cube, obj, ply, sphere, cylinder, shapegroup, instance)");
     Xf tw { m_identity(), m_identity() };
     if (!strip_to_world) { auto t = o.transforms.find("to_world"); if (t != o.transforms.end()) tw = t->second; }
     s.flip_normals = o.props.get_bool("flip_normals", false);
@@ -780,6 +808,7 @@ static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string
     }
     to_f32(tw.m, s.to_world); to_f32(tw.inv, s.to_object);
     if (s.kind == SHAPE_SPHERE) bake_sphere(s, o);
+    if (s.kind == SHAPE_CYLINDER) bake_cylinder(s, o);
     const Obj *bsdf = nullptr;
     for (auto &c : o.children) {
         if (c.first == "bsdf") { if (bsdf) fail("Only a single BSDF child object can be specified per shape."); bsdf = c.second.get(); }
@@ -799,6 +828,7 @@ static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string
     if (bsdf) bsdf_of(*bsdf, s);   // else default diffuse: 0.5, or 0 for an emitter (src/render/shape.cpp:66-72)
     // the integrators zero a path whose every sampled lobe was BSDFFlags::Null (valid_ray, dopplertofpath.cpp:252-253,280); the only way
     // such a path can carry radiance is an emitter ON a thindielectric shape, and the kernels keep no valid_ray flag for that corner
+    if (s.emitter && s.kind == SHAPE_CYLINDER) fail("cylinder: area emitters on cylinders are not supported");
     if (s.emitter && s.bsdf == BSDF_THINDIELECTRIC) fail("an area emitter on a thindielectric shape is not supported");
     else if (s.emitter) s.refl[0] = s.refl[1] = s.refl[2] = 0.f;
     RawMesh raw;

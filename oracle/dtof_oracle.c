@@ -592,6 +592,20 @@ static int sphere_test(const orc_shape *sh, v3 o, v3 d, float maxt_f) {
     int out_bounds = !(near_t <= maxt && far_t >= 0.0), in_bounds = near_t < 0.0 && far_t > maxt;
     return found && !out_bounds && !in_bounds;
 }
+/* Cylinder::ray_intersect_preliminary_impl / ray_test_impl (src/shapes/cylinder.cpp:300-391): the unit cylinder in object space, float64
+ * on the llvm back end (the ray is transformed in float32, then widened) */
+static int cylinder_query(const orc_shape *sh, v3 o, v3 d, float maxt_f, float *t_out) {
+    v3 lo = m_point(sh->to_object, o), ld = m_vector(sh->to_object, d);
+    const double ox = lo.x, oy = lo.y, oz = lo.z, dx = ld.x, dy = ld.y, dz = ld.z, maxt = maxt_f;
+    double A = dx * dx + dy * dy, B = 2.0 * (dx * ox + dy * oy), C = ox * ox + oy * oy - 1.0, near_t, far_t;
+    int found = solve_quadratic_d(A, B, C, &near_t, &far_t);
+    int out_bounds = !(near_t <= maxt && far_t >= 0.0), in_bounds = near_t < 0.0 && far_t > maxt;
+    double z_near = oz + dz * near_t, z_far = oz + dz * far_t;
+    int near_ok = z_near >= 0.0 && z_near <= 1.0 && near_t >= 0.0, far_ok = z_far >= 0.0 && z_far <= 1.0 && far_t <= maxt;
+    if (!(found && !out_bounds && !in_bounds && (near_ok || far_ok))) return 0;
+    *t_out = near_ok ? (float) near_t : (float) far_t;
+    return 1;
+}
 static inline v3 mesh_pos(const orc_shape *sh, uint32_t i) { return V(sh->positions[3 * i], sh->positions[3 * i + 1], sh->positions[3 * i + 2]); }
 
 /* closest hit in one shape.  Candidates are all primitives hit with t <= the ray's maxt; the
@@ -613,6 +627,10 @@ static void shape_closest(const orc_shape *sh, v3 o, v3 d, float maxt, int32_t o
         if (sphere_intersect(sh, o, d, maxt, &t) && t < best->t) {
             best->t = t; best->u = 0.f; best->v = 0.f; best->obj = obj; best->shape = shape_idx; best->prim = 0;
         }
+    } else if (sh->kind == ORC_SHAPE_CYLINDER) {
+        if (cylinder_query(sh, o, d, maxt, &t) && t < best->t) {
+            best->t = t; best->u = 0.f; best->v = 0.f; best->obj = obj; best->shape = shape_idx; best->prim = 0;
+        }
     } else {
         for (int32_t f = 0; f < sh->n_faces; ++f) {
             const uint32_t *fi = sh->faces + 3 * f;
@@ -628,6 +646,7 @@ static int shape_any(const orc_shape *sh, v3 o, v3 d, float maxt) {
     if (sh->kind == ORC_SHAPE_RECT) return rect_intersect(sh, o, d, maxt, &t, &u, &v);
     if (sh->kind == ORC_SHAPE_DISK) return disk_intersect(sh, o, d, maxt, &t, &u, &v);
     if (sh->kind == ORC_SHAPE_SPHERE) return sphere_test(sh, o, d, maxt);
+    if (sh->kind == ORC_SHAPE_CYLINDER) return cylinder_query(sh, o, d, maxt, &t);
     for (int32_t f = 0; f < sh->n_faces; ++f) {
         const uint32_t *fi = sh->faces + 3 * f;
         if (tri_intersect(mesh_pos(sh, fi[0]), mesh_pos(sh, fi[1]), mesh_pos(sh, fi[2]), o, d, maxt, &t, &u, &v)) return 1;
@@ -736,6 +755,19 @@ static void sphere_si(const orc_shape *sh, v3 o, v3 d, float t, orc_si *si) {
     si->sh_n = n; si->n = n;
 }
 /* Mesh::compute_surface_interaction -- src/render/mesh.cpp:632-864 (primal branch) */
+/* Cylinder::compute_surface_interaction (cylinder.cpp:395-500, non-diff branch): the frame from the local hit point, the point shifted onto the surface */
+static void cylinder_si(const orc_shape *sh, v3 o, v3 d, float t, orc_si *si) {
+    v3 p = v_fma(d, t, o);
+    v3 local = m_point(sh->to_object, p);
+    si->dp_du = m_vector(sh->to_world, v_mul(V(-local.y, local.x, 0.f), 2.f * ORC_PI_F));
+    si->dp_dv = m_vector(sh->to_world, V(0.f, 0.f, 1.f));
+    v3 n = v_normalize(v_cross(si->dp_du, si->dp_dv));
+    /* the shift uses the UNFLIPPED normal of the frame? no: `si.p += si.n * (1 - norm(head<2>(local)))` runs before si.n is assigned in this
+     * branch of the reference -- si is zero-initialised there, so the shift adds nothing (cylinder.cpp:471-475 precede :487) */
+    si->p = p;
+    if (sh->flip_normals) n = v_neg(n);
+    si->n = n; si->sh_n = n;
+}
 static void mesh_si(const orc_shape *sh, int32_t prim, float b1, float b2, orc_si *si) {
     const uint32_t *fi = sh->faces + 3 * prim;
     v3 p0 = mesh_pos(sh, fi[0]), p1 = mesh_pos(sh, fi[1]), p2 = mesh_pos(sh, fi[2]);
@@ -794,6 +826,7 @@ static void compute_si(const orc_scene *sc, const orc_hit *h, v3 o, v3 d, float 
         if (sh->kind == ORC_SHAPE_RECT) rect_si(sh, o, d, h->t, si);
         else if (sh->kind == ORC_SHAPE_DISK) disk_si(sh, o, d, h->t, h->u, h->v, si);
         else if (sh->kind == ORC_SHAPE_SPHERE) sphere_si(sh, o, d, h->t, si);
+        else if (sh->kind == ORC_SHAPE_CYLINDER) cylinder_si(sh, o, d, h->t, si);
         else mesh_si(sh, h->prim, h->u, h->v, si);
         surface_uv(sh, h, si);
     } else {
@@ -806,6 +839,7 @@ static void compute_si(const orc_scene *sc, const orc_hit *h, v3 o, v3 d, float 
         if (sh->kind == ORC_SHAPE_RECT) rect_si(sh, lo, ld, h->t, si);
         else if (sh->kind == ORC_SHAPE_DISK) disk_si(sh, lo, ld, h->t, h->u, h->v, si);
         else if (sh->kind == ORC_SHAPE_SPHERE) sphere_si(sh, lo, ld, h->t, si);
+        else if (sh->kind == ORC_SHAPE_CYLINDER) cylinder_si(sh, lo, ld, h->t, si);
         else mesh_si(sh, h->prim, h->u, h->v, si);
         surface_uv(sh, h, si);
         si->p = m_point(m, si->p);
@@ -860,7 +894,13 @@ static float disk_inv_area(const orc_shape *sh) {
     float h = sqrtf(f_sqr(m_dv) - f_sqr(v_dot(v_mul(ft, m_dv), fs)));
     return f_rcp(ORC_PI_F * m_du * h);
 }
+/* Cylinder::surface_area (cylinder.cpp:243-245): 2 pi r l with r = |to_world x|, l = |to_world z| (update(), :131-132) */
+static float cylinder_inv_area(const orc_shape *sh) {
+    float r = v_norm(m_vector(sh->to_world, V(1.f, 0.f, 0.f))), l = v_norm(m_vector(sh->to_world, V(0.f, 0.f, 1.f)));
+    return f_rcp((2.f * ORC_PI_F) * r * l);
+}
 static float shape_inv_area(const orc_shape *sh) {
+    if (sh->kind == ORC_SHAPE_CYLINDER) return cylinder_inv_area(sh);
     return sh->kind == ORC_SHAPE_RECT ? rect_inv_area(sh) : sh->kind == ORC_SHAPE_DISK ? disk_inv_area(sh) : sh->kind == ORC_SHAPE_SPHERE ? sh->sphere_inv_area : sh->area_norm;
 }
 static inline float f_safe_sqrt(float x) { return sqrtf(f_max(x, 0.f)); }
@@ -1960,6 +2000,27 @@ void orc_bake_sphere(const float *to_world, const float *to_object, const float 
     out8[4] = 1.0f / ((4.f * ORC_PI_F) * f_sqr(r)); out8[5] = flip ? 1.f : 0.f; out8[6] = out8[7] = 0.f;
 }
 
+void orc_bake_cylinder(const float *to_world, const float *to_object, const float *p0, const float *p1, float radius, int32_t flip_normals,
+                       float *composed, float *composed_inv, float *out8) {
+    v3 d = V(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]);
+    float length = v_norm(d);
+    v3 n = v_mul(d, f_rcp(length)), fs, ft;
+    coordinate_system(n, &fs, &ft);
+    float T[16] = { 1, 0, 0, p0[0], 0, 1, 0, p0[1], 0, 0, 1, p0[2], 0, 0, 0, 1 }, Ti[16] = { 1, 0, 0, -p0[0], 0, 1, 0, -p0[1], 0, 0, 1, -p0[2], 0, 0, 0, 1 };
+    float F[16] = { fs.x, ft.x, n.x, 0, fs.y, ft.y, n.y, 0, fs.z, ft.z, n.z, 0, 0, 0, 0, 1 };       /* columns s, t, n (transform.h:286-296) */
+    float Fi[16] = { fs.x, fs.y, fs.z, 0, ft.x, ft.y, ft.z, 0, n.x, n.y, n.z, 0, 0, 0, 0, 1 };
+    float ir = 1.0f / radius, il = 1.0f / length;
+    float S[16] = { radius, 0, 0, 0, 0, radius, 0, 0, 0, 0, length, 0, 0, 0, 0, 1 }, Si[16] = { ir, 0, 0, 0, 0, ir, 0, 0, 0, 0, il, 0, 0, 0, 0, 1 };
+    float a[16], b[16];
+    m4_mul_f32(to_world, T, a); m4_mul_f32(a, F, b); m4_mul_f32(b, S, composed);
+    m4_mul_f32(Ti, to_object, a); m4_mul_f32(Fi, a, b); m4_mul_f32(Si, b, composed_inv);
+    float r = v_norm(V(composed[0], composed[4], composed[8])), l = v_norm(V(composed[2], composed[6], composed[10]));
+    const float *m = composed;
+    float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+    int flip = flip_normals != 0;
+    if (det < 0.f) flip = !flip;
+    out8[0] = r; out8[1] = l; out8[2] = 1.0f / ((2.f * ORC_PI_F) * r * l); out8[3] = flip ? 1.f : 0.f; out8[4] = out8[5] = out8[6] = out8[7] = 0.f;
+}
 void orc_fresnel_dielectric(float cos_theta_i, float eta, float *out4) { fresnel_dielectric(cos_theta_i, eta, out4, out4 + 1, out4 + 2, out4 + 3); }
 float orc_fresnel_conductor(float cos_theta_i, float eta, float k) { return fresnel_conductor(cos_theta_i, eta, k); }
 
@@ -2138,6 +2199,11 @@ static void shape_bbox(const orc_shape *sh, orc_box *b) {
     } else if (sh->kind == ORC_SHAPE_SPHERE) {
         box_add(b, V(sh->center[0] - sh->radius, sh->center[1] - sh->radius, sh->center[2] - sh->radius));
         box_add(b, V(sh->center[0] + sh->radius, sh->center[1] + sh->radius, sh->center[2] + sh->radius));
+    } else if (sh->kind == ORC_SHAPE_CYLINDER) {   /* Cylinder::bbox (cylinder.cpp:166-179): the two end circles */
+        v3 x1 = m_vector(sh->to_world, V(1.f, 0.f, 0.f)), x2 = m_vector(sh->to_world, V(0.f, 1.f, 0.f));
+        v3 x = V(sqrtf(f_sqr(x1.x) + f_sqr(x2.x)), sqrtf(f_sqr(x1.y) + f_sqr(x2.y)), sqrtf(f_sqr(x1.z) + f_sqr(x2.z)));
+        v3 p0 = m_point(sh->to_world, V(0.f, 0.f, 0.f)), p1 = m_point(sh->to_world, V(0.f, 0.f, 1.f));
+        box_add(b, v_sub(p0, x)); box_add(b, v_sub(p1, x)); box_add(b, v_add(p0, x)); box_add(b, v_add(p1, x));
     } else for (int32_t i = 0; i < sh->n_vertices; ++i) box_add(b, mesh_pos(sh, (uint32_t) i));
 }
 void orc_scene_bsphere(const orc_scene *sc, float *out4) {

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-enum { ORC_SHAPE_RECT = 0, ORC_SHAPE_MESH = 1, ORC_SHAPE_SPHERE = 2, ORC_SHAPE_DISK = 3 };
+enum { ORC_SHAPE_RECT = 0, ORC_SHAPE_MESH = 1, ORC_SHAPE_SPHERE = 2, ORC_SHAPE_DISK = 3, ORC_SHAPE_CYLINDER = 4 };
 enum { ORC_OBJ_SHAPE = 0, ORC_OBJ_INSTANCE = 1 };
 enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1, ORC_EMITTER_SPOT = 2, ORC_EMITTER_CONSTANT = 3 };
 enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 };
@@ -252,6 +252,12 @@ void     orc_plastic_params(float eta, const float *diffuse3, const float *specu
  * flip_normals; inv_area = rcp(4 pi r^2).  out8 = center[3], radius, inv_area, flip (as float 0/1), 2 spare. */
 void     orc_bake_sphere(const float *to_world, const float *to_object, const float *center, float radius, int32_t flip_normals,
                          float *composed, float *composed_inv, float *out8);
+
+/* Cylinder ctor + update (src/shapes/cylinder.cpp:100-147) in float32: composed = to_world * translate(p0) * to_frame(Frame3f((p1 - p0) / |p1 - p0|)) *
+ * scale(radius, radius, |p1 - p0|), its inverse from the factors' inverses; out8 = m_radius (|composed * x|), m_length (|composed * z|), 1 / (2 pi r l),
+ * flip (as float 0 / 1; a mirroring transform toggles it), 4 spare.  The unit cylinder x^2 + y^2 = 1, 0 <= z <= 1 lives in object space. */
+void     orc_bake_cylinder(const float *to_world, const float *to_object, const float *p0, const float *p1, float radius, int32_t flip_normals,
+                           float *composed, float *composed_inv, float *out8);
 
 /* Mesh::build_pmf + DiscreteDistribution::compute_cdf (mesh.cpp:478-511, distr_1d.h:205-240): pmf[i] = .5 |e0 x e1| in
  * float32, running sum in double, cdf[i] = float(sum), sum / normalization rounded to float32 once. Returns 0 on success,

@@ -156,6 +156,7 @@ def lib():
         L.orc_fresnel_conductor.restype = C.c_float
         L.orc_fresnel_conductor.argtypes = [C.c_float, C.c_float, C.c_float]
         L.orc_bake_sphere.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_bake_cylinder.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mesh_area_table.restype = C.c_int
         L.orc_mesh_area_table.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_bake_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
@@ -264,6 +265,18 @@ class Scene:
                 o.to_world, o.to_object = _m16(comp), _m16(comp_inv)
                 o.center = (C.c_float * 3)(*out8[:3].tolist())
                 o.radius, o.sphere_inv_area, o.flip_normals = float(out8[3]), float(out8[4]), int(out8[5])
+            if s["kind"] == 4:   # cylinder: compose the transform in C float32 (orc_bake_cylinder)
+                tw = np.ascontiguousarray(s["to_world"], dtype=np.float32)
+                to = np.ascontiguousarray(s["to_object"], dtype=np.float32)
+                cy = s["cylinder"]
+                p0, p1 = np.ascontiguousarray(cy["p0"], np.float32), np.ascontiguousarray(cy["p1"], np.float32)
+                comp, comp_inv, out8 = np.zeros(16, np.float32), np.zeros(16, np.float32), np.zeros(8, np.float32)
+                L.orc_bake_cylinder(tw.ctypes.data, to.ctypes.data, p0.ctypes.data, p1.ctypes.data, C.c_float(float(cy["radius"])),
+                                    int(s["flip_normals"]), comp.ctypes.data, comp_inv.ctypes.data, out8.ctypes.data)
+                s["to_world"], s["to_object"] = comp.reshape(4, 4), comp_inv.reshape(4, 4)
+                s["cylinder_baked"] = out8
+                o.to_world, o.to_object = _m16(comp), _m16(comp_inv)
+                o.radius, o.flip_normals = float(out8[0]), int(out8[3])
             if s["kind"] == 1 and s.get("mesh_raw") is not None:   # obj / ply: bake in C (orc_bake_mesh)
                 raw = s["mesh_raw"]
                 pin = np.ascontiguousarray(raw["positions"], dtype=np.float32).reshape(-1)

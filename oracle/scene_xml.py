@@ -538,7 +538,7 @@ class FlatScene:
 
 
 def _shape_record(sp, registry, strip_to_world, base_dir=""):
-    kind = {"rectangle": 0, "cube": 1, "obj": 1, "ply": 1, "sphere": 2, "disk": 3}.get(sp.plugin)
+    kind = {"rectangle": 0, "cube": 1, "obj": 1, "ply": 1, "sphere": 2, "disk": 3, "cylinder": 4}.get(sp.plugin)
     if kind is None:
         raise ValueError('unsupported shape plugin "%s"' % sp.plugin)
     mesh_raw = None
@@ -588,7 +588,15 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
         c = sp["center"][1] if "center" in sp else [0.0, 0.0, 0.0]
         sp.queried.add("center")
         sphere = dict(center=np.asarray(c, dtype=np.float64).astype(F32), radius=F32(sp.get_f("radius", 1.0)))
-    return dict(kind=kind, twosided=twosided, flip_normals=int(flip), face_normals=int(sp.get_b("face_normals", False)),
+    cylinder = None
+    if kind == 4:   # src/shapes/cylinder.cpp:100-118: p0 (default 0), p1 (default (0, 0, 1)), radius (default 1) on top of to_world
+        p0 = sp["p0"][1] if "p0" in sp else [0.0, 0.0, 0.0]
+        p1 = sp["p1"][1] if "p1" in sp else [0.0, 0.0, 1.0]
+        sp.queried.add("p0"); sp.queried.add("p1")
+        cylinder = dict(p0=np.asarray(p0, dtype=np.float64).astype(F32), p1=np.asarray(p1, dtype=np.float64).astype(F32), radius=F32(sp.get_f("radius", 1.0)))
+        if emitter:
+            raise ValueError("cylinder: area emitters on cylinders are not supported")
+    return dict(kind=kind, twosided=twosided, flip_normals=int(flip), face_normals=int(sp.get_b("face_normals", False)), cylinder=cylinder,
                 reflectance=refl, to_world=_m32(tw), to_object=_m32(tinv), emitter=emitter, radiance=radiance, mesh_raw=mesh_raw,
                 sphere=sphere, bsdf=brec["bsdf"], cond_eta=brec["cond_eta"], cond_k=brec["cond_k"], spec_refl=brec["spec_refl"],
                 spec_trans=brec["spec_trans"], diel_eta=brec["diel_eta"], nonlinear=brec.get("nonlinear", 0),

@@ -230,6 +230,30 @@ def cornell_env(res=128, spp=16):
     return s + LIGHT + "</scene>\n"
 
 
+def cylinder(ident, bsdf_id, p0, p1, radius, anim_dz=None, extra=""):
+    s = ('\t<shape type="cylinder" id="%s">\n\t\t<point name="p0" x="%s" y="%s" z="%s" />\n\t\t<point name="p1" x="%s" y="%s" z="%s" />\n'
+         '\t\t<float name="radius" value="%s" />\n%s' % ((ident,) + tuple(p0) + tuple(p1) + (radius, extra)))
+    if anim_dz is not None:
+        s += ('\t\t<animation name="to_world">\n\t\t\t<transform time="0">\n\t\t\t\t<translate x="0" y="0" z="0" />\n\t\t\t</transform>\n'
+              '\t\t\t<transform time="0.0015">\n\t\t\t\t<translate x="0.0" y="0.0" z="%s" />\n\t\t\t</transform>\n\t\t</animation>\n' % anim_dz)
+    return s + '\t\t<ref id="%s" />\n\t</shape>\n' % bsdf_id
+
+
+def cornell_cylinders(res=128, spp=16):
+    """the Cornell room with analytic cylinders (src/shapes/cylinder.cpp): an upright pillar, a tilted moving pipe (seen from outside and,
+    through its open ends, from inside) and a scaled, rotated one given by a to_world transform"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        s += bsdf(*b)
+    for name, m, b in WALLS:
+        s += rect(name, m, b)
+    s += cylinder("Pillar", "TallBoxBSDF", ("-0.45", "0", "-0.35"), ("-0.45", "1.3", "-0.35"), "0.28")
+    s += cylinder("Pipe", "ShortBoxBSDF", ("0.15", "0.25", "0.5"), ("0.75", "0.6", "-0.1"), "0.22", anim_dz="0.015")
+    s += ('\t<shape type="cylinder" id="Squat">\n\t\t<transform name="to_world">\n\t\t\t<scale x="0.3" y="0.3" z="0.25" />\n\t\t\t<rotate x="1" angle="-70" />\n'
+          '\t\t\t<translate x="0.1" y="1.2" z="0.2" />\n\t\t</transform>\n\t\t<boolean name="flip_normals" value="true" />\n\t\t<ref id="LeftWallBSDF" />\n\t</shape>\n')
+    return s + LIGHT + "</scene>\n"
+
+
 def cornell_plastic(res=128, spp=16):
     """cornell_boxes.xml with glossy-coated (smooth `plastic`) boxes and a plastic floor, point light at the camera"""
     s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
@@ -401,6 +425,7 @@ def main():
         "cornell_disk.xml": cornell_disk(),
         "cornell_textured.xml": cornell_textured(),
         "cornell_env.xml": cornell_env(),
+        "cornell_cylinders.xml": cornell_cylinders(),
         "cornell_spheres.xml": cornell_spheres(),
         "cornell_sphere_light.xml": cornell_spheres(sphere_light=True),
         "domino.xml": domino(),
@@ -416,7 +441,7 @@ def main():
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
     names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml",
-             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml", "tex_rgb.png", "tex_gray.png"]
+             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
         return

@@ -47,6 +47,7 @@ FILES = [
     "src/shapes/tests/test_sphere.py",
     "src/shapes/tests/test_disk.py",
     "src/shapes/tests/test_cube.py",
+    "src/shapes/tests/test_cylinder.py",
     "src/shapes/tests/test_instance.py",        # G2
     "src/shapes/tests/test_mesh.py",
     "src/emitters/tests/test_point.py",         # E1
@@ -68,7 +69,7 @@ FILES = [
 ]
 
 # files whose assertions relate two Mitsuba computations to each other (instanced == plain shape): kept as relations
-RELATIONS = ("src/shapes/tests/test_instance.py",)
+RELATIONS = ("src/shapes/tests/test_instance.py", "src/shapes/tests/test_cylinder.py")
 
 MAX_LOOP = 700          # iterations of one `for`
 MAX_RECORDS_PER_TEST = 3000

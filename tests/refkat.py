@@ -36,11 +36,11 @@ class Transform:
         return self.m
 
 
-_SHAPES = ("rectangle", "sphere", "disk", "cube", "obj", "ply")
+_SHAPES = ("rectangle", "sphere", "disk", "cube", "cylinder", "obj", "ply")
 _BSDFS = ("diffuse", "twosided", "conductor", "dielectric", "plastic", "thindielectric", "roughconductor", "roughdielectric", "roughplastic")
 _EMITTERS = ("point", "area", "spot")
 _FILTERS = ("box", "tent", "gaussian", "mitchell", "catmullrom")
-_POINT_NAMES = ("center", "position", "origin", "target")
+_POINT_NAMES = ("center", "position", "origin", "target", "p0", "p1")
 
 
 def _tag_of(plugin):
@@ -215,7 +215,7 @@ class ShapeFacade:
         kind = self.shapes[0]["type"]
         if kind == "cube":
             return 12
-        if kind in ("rectangle", "sphere", "disk"):
+        if kind in ("rectangle", "sphere", "disk", "cylinder"):
             return 1
         raise Skip("primitive_count of " + kind)
 
@@ -500,6 +500,7 @@ _DRFN = {
     "dr.max": np.max, "dr.min": np.min, "dr.sum": np.sum, "dr.exp": np.exp, "dr.log": np.log, "fn.vector": lambda *a: np.asarray(a[0] if len(a) == 1 else a, np.float64),
     "dr.isnan": np.isnan, "dr.all": np.all, "dr.any": np.any, "dr.cross": lambda a, b: np.cross(np.asarray(a, np.float64), np.asarray(b, np.float64)),
     "dr.rsqrt": lambda x: 1.0 / np.sqrt(x), "dr.atan2": np.arctan2,
+    "dr.allclose": lambda a, b, rtol=1e-5, atol=1e-8: allclose(a, b, rtol, atol),
 }
 
 

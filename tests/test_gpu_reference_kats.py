@@ -85,7 +85,7 @@ PINNED = {
     "src/render/tests/test_microfacet.py": 20, "src/render/tests/test_fresnel.py": 10, "src/rfilters/tests/test_rfilter.py": 8,
     "src/core/tests/test_warp.py": 10, "src/core/tests/test_random.py": 8, "src/core/tests/test_frame.py": 3,
     "src/shapes/tests/test_rectangle.py": 15, "src/shapes/tests/test_sphere.py": 500, "src/shapes/tests/test_disk.py": 500,
-    "src/shapes/tests/test_cube.py": 100, "src/shapes/tests/test_instance.py": 400,
+    "src/shapes/tests/test_cube.py": 100, "src/shapes/tests/test_instance.py": 400, "src/shapes/tests/test_cylinder.py": 60,
 }
 
 

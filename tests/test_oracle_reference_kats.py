@@ -129,6 +129,7 @@ PINNED = {
     "src/shapes/tests/test_sphere.py": ("8(f)-3 sphere", 500),
     "src/shapes/tests/test_disk.py": ("8(f)-3 disk", 500),
     "src/shapes/tests/test_cube.py": ("G3 cube mesh", 100),
+    "src/shapes/tests/test_cylinder.py": ("8(f)-3 cylinder", 300),
     "src/sensors/tests/test_perspective.py": ("C1 perspective camera", 20),
     "src/render/tests/test_imageblock.py": ("I1 ImageBlock::put", 1),
     "src/bsdfs/tests/test_diffuse.py": ("M1 diffuse", 30),
