@@ -63,7 +63,7 @@ struct Queues {
     float4 *ray_b;       // d.xyz, maxt
     uint4  *hit;         // t, u, v (float bits), prim
     float  *hit_t;       // rectangle-only scenes: t alone replaces `hit`
-    uint32_t *hit_id;    // object (low 24 bits) | shape-in-group (high 8 bits); 0xffffffff = miss
+    uint32_t *hit_id;    // object (low id_shift bits) | shape-in-group (the bits above); 0xffffffff = miss
     float4 *st_a;        // throughput.xyz, path_length
     float4 *st_b;        // prev_si.p, prev_bsdf_pdf (only touched when the scene has area emitters)
     uint4  *rng_a;       // rng.state (lo,hi), rng_path.state (lo,hi)
@@ -77,6 +77,7 @@ struct Queues {
     uint32_t *q[2];      // active-lane index queues (ping-pong), segmented: entry j of segment S at S*kSeg + j
     uint32_t *counts;    // [iteration][2][n_segments]: survivors / shadow rays per segment
     uint32_t capacity;
+    uint32_t id_shift;   // bits of hit_id that hold the object index: 24 unless the scene needs more shapes per group than 8 bits hold (render_rows)
 };
 
 struct LaneDebug {       // mirrors orc_lane's comparable fields

@@ -59,7 +59,7 @@ constexpr int kShadeBlock = 64;   // k_shade runs ONE wave per block: compaction
 template <bool MESH> DTOF_D void store_hit(const Queues &q, uint32_t l, const Hit &h, bool found) {
     if (MESH) q.hit[l] = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
     else q.hit_t[l] = h.t;
-    q.hit_id[l] = found ? (h.obj | (h.shape << 24)) : 0xffffffffu;
+    q.hit_id[l] = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu;
 }
 template <bool MESH> DTOF_D uint4 load_hit(const Queues &q, uint32_t l) {
     if (MESH) return q.hit[l];
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
             Hit h;
             bool found = trace_scene<false, MESH, FUSED>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
             hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
-            hid = found ? (h.obj | (h.shape << 24)) : 0xffffffffu;
+            hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu;
         } else {
             hid = q.hit_id[l];
             if (hid != 0xffffffffu) {
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
 
             Surface si;
             if (!FIRST && have_memo) instance_memo_fill(sv, time, memo_m, memo_inv);
-            compute_surface<MESH>(sv, hid & 0xffffffu, hid >> 24, hh.w, t, u2f(hh.y), u2f(hh.z), o, d, time, si, have_memo, memo_m, memo_inv);
+            compute_surface<MESH>(sv, hid & ((1u << q.id_shift) - 1u), hid >> q.id_shift, hh.w, t, u2f(hh.y), u2f(hh.z), o, d, time, si, have_memo, memo_m, memo_inv);
             const DShape *sh = si.shape;
 
             const float pmf = sv.n_emitters ? 1.f / (float) sv.n_emitters : 0.f;   // m_emitter_pmf (scene.cpp:96)

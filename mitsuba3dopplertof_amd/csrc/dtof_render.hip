@@ -92,6 +92,7 @@ struct dtof_scene {
     DevBuf<float> d_film, d_rgb;
     DevBuf<unsigned long long> d_sums;       // [batch][2*kMaxIter] per-iteration totals (survivors, shadow rays)
     DevBuf<uint2> d_pass_rng;                // multi-pass renders: [lane][3] stream states between the passes
+    uint32_t id_shift = 24;                  // Queues::id_shift of this scene
     hipStream_t stream = nullptr, stream2 = nullptr;
     std::atomic<bool> stop { false };
     // reusable statistics plumbing (creating events / pinned memory per call costs ~0.3 ms)
@@ -339,6 +340,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     if (n_streams == 2) sc->ws2.ensure((uint32_t) batch, rp.n_offsets);
     if (lane_dump) sc->ws.dbg.ensure(batch);
     Queues qs[2] = { sc->ws.queues(), n_streams == 2 ? sc->ws2.queues() : sc->ws.queues() };
+    qs[0].id_shift = qs[1].id_shift = sc->id_shift;
     hipStream_t ss[2] = { sc->stream, n_streams == 2 ? sc->stream2 : sc->stream };
     const uint8_t *blob = sc->d_blob.p; uint32_t blob_bytes = (uint32_t) sc->blob.size();
     const uint32_t stack_depth = ((const BlobHeader *) sc->blob.data())->tlas_depth;
@@ -507,8 +509,14 @@ dtof_scene *finish_scene(HostScene &&hs) {
     try {
         sc->host = std::move(hs);
         sc->pp = make_plugin_params(sc->host.integrator, sc->host.sampler);
-        if (sc->host.objects.size() >= (1u << 24)) throw std::runtime_error("too many scene objects");
-        for (auto &g : sc->host.groups) if (g.n_shapes > 255) throw std::runtime_error("a shapegroup may hold at most 255 shapes");
+        {   // the hit record packs (object, shape in its group) into 32 bits (Queues::hit_id): the object index gets 24 bits unless a shapegroup
+            // needs more than the remaining 8 for its shapes; 0xffffffff stays free as the "miss" value
+            uint32_t max_shapes = 1; for (auto &g : sc->host.groups) max_shapes = std::max(max_shapes, g.n_shapes);
+            uint32_t shape_bits = 0; while ((1ull << shape_bits) < max_shapes) ++shape_bits;
+            uint32_t obj_bits = 1; while ((1ull << obj_bits) < sc->host.objects.size() + 1ull) ++obj_bits;
+            if (obj_bits + shape_bits > 31) throw std::runtime_error("too many scene objects / shapes per shapegroup: object index and shape index must fit 31 bits together");
+            sc->id_shift = shape_bits <= 8 && obj_bits <= 24 ? 24 : 31 - shape_bits;
+        }
         sc->blob = build_scene_blob(sc->host);
     } catch (...) { delete sc; throw; }
     return sc;

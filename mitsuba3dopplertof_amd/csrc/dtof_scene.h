@@ -212,6 +212,7 @@ struct RawMesh {
 };
 RawMesh load_obj(const std::string &path, bool flip_tex_coords, bool face_normals);   // src/shapes/obj.cpp
 RawMesh load_ply(const std::string &path, bool face_normals);                         // src/shapes/ply.cpp
+RawMesh load_serialized(const std::string &path, int shape_index, bool face_normals); // src/shapes/serialized.cpp
 void bake_mesh(HostShape &s, const RawMesh &raw);   // to_world / normals / Mesh::recompute_vertex_normals
 
 // Blob + BVH (scene_build.cpp)

@@ -11,6 +11,7 @@
 //              (src/render/mesh.cpp:257-345): angle-weighted face normals -- the reference adds them with unordered
 //              float atomics, here they are accumulated in face order in double and rounded once
 #include "dtof_scene.h"
+#include <zlib.h>
 #include "dtof_math.h"
 #include <algorithm>
 #include <cmath>
@@ -289,6 +290,75 @@ void bake_mesh(HostShape &s, const RawMesh &raw) {
         if (l != 0.0 && l == l) { s.normals[3 * i] = (float) (a[0] / l); s.normals[3 * i + 1] = (float) (a[1] / l); s.normals[3 * i + 2] = (float) (a[2] / l); }
         else { s.normals[3 * i] = 1.f; s.normals[3 * i + 1] = 0.f; s.normals[3 * i + 2] = 0.f; }
     }
+}
+
+// ---------------------------------------------------------------------------- .serialized (src/shapes/serialized.cpp:234-390)
+// Little-endian stream: uint16 0x041C, uint16 version (3 | 4), then ONE zlib stream per sub-mesh: uint32 flags, [v4: zero-terminated
+// name], uint64 vertex count, uint64 face count, positions (3 floats or doubles per vertex), [normals], [texcoords], [colours],
+// uint32 indices.  The file ends with the offsets of its sub-meshes (uint64 in v4, uint32 in v3) and their count (uint32).
+RawMesh load_serialized(const std::string &path, int shape_index, bool face_normals) {
+    const std::string name = base_name(path);
+    auto fail = [&](const std::string &m) { throw std::runtime_error("Error while loading serialized file \"" + name + "\": " + m + "!"); };
+    std::string data;
+    if (!slurp(path, data)) fail("file not found");
+    if (shape_index < 0) fail("shape index must be nonnegative");
+    auto rd16 = [&](size_t at) { if (at + 2 > data.size()) fail("premature end of file"); uint16_t v; memcpy(&v, &data[at], 2); return v; };
+    auto rd32 = [&](size_t at) { if (at + 4 > data.size()) fail("premature end of file"); uint32_t v; memcpy(&v, &data[at], 4); return v; };
+    auto rd64 = [&](size_t at) { if (at + 8 > data.size()) fail("premature end of file"); uint64_t v; memcpy(&v, &data[at], 8); return v; };
+    const uint16_t format = rd16(0), version = rd16(2);
+    if (format != 0x041C) fail("encountered an invalid file format");
+    if (version != 3 && version != 4) fail("encountered an incompatible file version");
+    size_t start = 4;
+    if (shape_index != 0) {
+        const uint32_t count = rd32(data.size() - 4);
+        if ((uint32_t) shape_index > count) fail("Unable to unserialize mesh, shape index is out of range! (requested " + std::to_string(shape_index) + " out of 0.." + std::to_string((int) count - 1) + ")");
+        const size_t off = version == 4 ? (size_t) rd64(data.size() - 8 * (size_t) (count - (uint32_t) shape_index) - 4)
+                                        : (size_t) rd32(data.size() - 4 * (size_t) (count - (uint32_t) shape_index + 1));
+        start = off + 4;   // the sub-mesh repeats the 4-byte header
+    }
+    if (start > data.size()) fail("premature end of file");
+    // inflate the sub-mesh's zlib stream (its compressed length is not stored)
+    std::string raw;
+    {
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        if (inflateInit(&zs) != Z_OK) fail("inflateInit failed");
+        zs.next_in = (Bytef *) &data[start]; zs.avail_in = (uInt) std::min<size_t>(data.size() - start, 0xffffffffu);
+        char buf[1 << 16]; int rc;
+        do {
+            zs.next_out = (Bytef *) buf; zs.avail_out = sizeof buf;
+            rc = inflate(&zs, Z_NO_FLUSH);
+            if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); fail("inflate(): stream error"); }
+            raw.append(buf, sizeof buf - zs.avail_out);
+        } while (rc != Z_STREAM_END);
+        inflateEnd(&zs);
+    }
+    size_t pos = 0;
+    auto need = [&](size_t n) { if (pos + n > raw.size()) fail("premature end of the compressed stream"); };
+    need(4); uint32_t flags; memcpy(&flags, &raw[pos], 4); pos += 4;
+    if (version == 4) { while (true) { need(1); if (raw[pos++] == 0) break; } }
+    need(16); uint64_t nv, nf; memcpy(&nv, &raw[pos], 8); memcpy(&nf, &raw[pos + 8], 8); pos += 16;
+    if (nv > (1ull << 31) || nf > (1ull << 31)) fail("implausible vertex / face count");
+    const bool dp = flags & 0x2000, has_n = flags & 0x0001, has_uv = flags & 0x0002, has_col = flags & 0x0008;
+    auto read_floats = [&](std::vector<float> *dst, size_t dim) {
+        const size_t n = (size_t) nv * dim;
+        need(n * (dp ? 8 : 4));
+        if (dst) {
+            dst->resize(n);
+            if (dp) for (size_t i = 0; i < n; ++i) { double v; memcpy(&v, &raw[pos + 8 * i], 8); (*dst)[i] = (float) v; }
+            else memcpy(dst->data(), &raw[pos], n * 4);
+        }
+        pos += n * (dp ? 8 : 4);
+    };
+    RawMesh m;
+    read_floats(&m.positions, 3);
+    if (has_n) read_floats(face_normals ? nullptr : &m.normals, 3);
+    if (has_uv) read_floats(&m.texcoords, 2);
+    if (has_col) read_floats(nullptr, 3);
+    need((size_t) nf * 12);
+    m.faces.resize((size_t) nf * 3); memcpy(m.faces.data(), &raw[pos], (size_t) nf * 12);
+    for (uint32_t f : m.faces) if (f >= nv) fail("face references a vertex out of range");
+    m.has_normals = has_n && !face_normals; m.has_texcoords = has_uv;
+    return m;
 }
 
 }  // namespace dtof

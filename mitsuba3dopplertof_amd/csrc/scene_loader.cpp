@@ -792,12 +792,12 @@ static void bake_cylinder(HostShape &s, const Obj &o) {
 
 static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string &base_dir) {
     HostShape s; s.id = o.id;
-    const bool mesh_file = o.plugin == "obj" || o.plugin == "ply";
+    const bool mesh_file = o.plugin == "obj" || o.plugin == "ply" || o.plugin == "serialized";
     if (o.plugin == "rectangle") s.kind = SHAPE_RECT; else if (o.plugin == "cube" || mesh_file) s.kind = SHAPE_MESH;
     else if (o.plugin == "sphere") s.kind = SHAPE_SPHERE;
     else if (o.plugin == "disk") s.kind = SHAPE_DISK;
     else if (o.plugin == "cylinder") s.kind = SHAPE_CYLINDER;
-    else fail("unsupported shape plugin \"" + o.plugin + "\" (supported: rectangle, disk, cube, obj, ply, sphere, cylinder, shapegroup, instance)");
+    else fail("unsupported shape plugin \"" + o.plugin + "\" (supported: rectangle, disk, cube, obj, ply, serialized, sphere, cylinder, shapegroup, instance)");
     Xf tw { m_identity(), m_identity() };
     if (!strip_to_world) { auto t = o.transforms.find("to_world"); if (t != o.transforms.end()) tw = t->second; }
     s.flip_normals = o.props.get_bool("flip_normals", false);
@@ -836,7 +836,8 @@ static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string
         if (!o.props.has("filename")) fail("Property \"filename\" has not been specified!");
         std::string fn = o.props.get_string("filename", "");
         std::string path = (!fn.empty() && fn[0] == '/') || base_dir.empty() ? fn : base_dir + "/" + fn;
-        raw = o.plugin == "obj" ? load_obj(path, o.props.get_bool("flip_tex_coords", true), s.face_normals) : load_ply(path, s.face_normals);
+        raw = o.plugin == "obj" ? load_obj(path, o.props.get_bool("flip_tex_coords", true), s.face_normals)
+            : o.plugin == "ply" ? load_ply(path, s.face_normals) : load_serialized(path, (int) o.props.get_int("shape_index", 0), s.face_normals);
     }
     auto u = o.props.unqueried();
     if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in shape plugin of type \"" + o.plugin + "\"");

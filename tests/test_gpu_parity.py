@@ -684,6 +684,32 @@ def test_two_ranks_over_rccl_reproduce_the_single_rank_image(mi, tmp_path):
             assert got.shape == ref.shape and rel_linf(got, ref) <= IMG_TOL, (name, suffix, rel_linf(got, ref))
 
 
+def test_shapegroup_with_more_than_255_shapes(mi, orc, tmp_path):
+    """the hit record packs (object, shape in its group) into 32 bits; the split follows the scene (Queues::id_shift): a moving instance of a
+    shapegroup of 400 rectangles, every lane against the oracle"""
+    text = open(os.path.join(SCENES, "cornell_wall.xml")).read()
+    tiles = ""
+    for k in range(400):
+        x, y = (k % 20) / 10.0 - 0.95, (k // 20) / 10.0 + 0.05
+        tiles += ('<shape type="rectangle"><transform name="to_world"><scale x="0.04" y="0.04" z="1"/><rotate y="1" angle="%d"/>'
+                  '<translate x="%.3f" y="%.3f" z="%.3f"/></transform><ref id="%s"/></shape>\n' % ((k * 7) % 60 - 30, x, y, -0.2 + 0.001 * k, "LeftWallBSDF" if k % 2 else "RightWallBSDF"))
+    group = ('<shape type="shapegroup" id="tiles">\n' + tiles + '</shape>\n<shape type="instance"><ref id="tiles"/><animation name="to_world">'
+             '<transform time="0"><translate x="0" y="0" z="0"/></transform><transform time="0.0015"><translate x="0" y="0" z="0.015"/></transform></animation></shape>\n')
+    p = tmp_path / "tiles.xml"
+    p.write_text(text.replace("</scene>", group + "</scene>"))
+    params = dict(resx=40, resy=40)
+    sc, osc = mi.load_file(str(p), **params), orc.Scene(str(p), params)
+    assert sc.info()["n_shapes"] >= 405
+    spp, n = 4, 40 * 40 * 4
+    g = sc.sample_lanes(1, spp, 0, n)
+    o = osc.render_lanes(osc.params(), 1, spp, 0, n, threads=NCPU)
+    for k in ("sample_pos", "time", "ray_d", "rgb"):
+        assert np.array_equal(bits(g[k]), bits(o[k])), (k, int((bits(g[k]) != bits(o[k])).sum()))
+    img = sc.render(seed=1, spp=spp)
+    ref, _ = osc.render(osc.params(), seed=1, spp=spp, threads=NCPU)
+    assert rel_linf(img, ref) <= IMG_TOL
+
+
 def test_statistics_of_a_multi_batch_render_equal_the_single_batch_ones(mi, tmp_path):
     """The per-iteration counters (n_bounces, n_shadow_rays: they price the roofline in bench.py) are summed over the batches of a
     frame: a render cut into many small batches (DTOF_BATCH_LANES, read when the library is first used -> a fresh process) reports

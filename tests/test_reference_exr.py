@@ -55,3 +55,21 @@ def test_reference_exr_is_statistically_one_of_our_renders(mi):
     # the per-pixel sample distribution is heavy tailed and sd is itself estimated from n seeds: one of OUR seeds against
     # the others gives 0.997 / 0.9998 here
     assert (np.abs(z) < 4).mean() > 0.995 and (np.abs(z) < 6).mean() > 0.9995
+    # VARIANCE per region: the antithetic time pairs and the correlated paths change the variance of a Doppler image, not its mean.  The
+    # reference's residual against our mean must carry OUR per-pixel variance in every region and channel (z-scores of unit spread) ...
+    for name, (ys, xs) in REGIONS.items():
+        for c in range(3):
+            zs = z[ys, xs, c].std()
+            assert 0.8 < zs < 1.25, (name, c, zs)
+    # ... and the check has power: with uncorrelated uniform time sampling (same mean, same scene) the per-pixel variance is several times
+    # larger, and the reference's residual is NOT compatible with it
+    sc.set_integrator(dict(type="dopplertofpath", max_depth=4, w_g=30.0, hetero_frequency=1.0, hetero_offset=0.0, time_sampling_method="uniform",
+                           path_correlation_depth=0, wave_function_type="sinusoidal"))
+    uni = np.stack([sc.render(seed=300 + s, spp=1024).astype(np.float64) for s in range(8)])
+    var_uni, var_anti = uni.var(0, ddof=1), sd ** 2
+    for name in ("back_wall", "tall_box", "short_box"):
+        ys, xs = REGIONS[name]
+        ratio = var_uni[ys, xs].mean() / var_anti[ys, xs].mean()
+        resid = ((ref - mean)[ys, xs] ** 2).mean()
+        assert ratio > 2.0, (name, ratio)
+        assert 0.75 < resid / var_anti[ys, xs].mean() < 1.35 and resid / var_uni[ys, xs].mean() < 0.6, (name, resid / var_anti[ys, xs].mean(), resid / var_uni[ys, xs].mean())
