@@ -301,19 +301,21 @@ RawMesh load_serialized(const std::string &path, int shape_index, bool face_norm
     auto fail = [&](const std::string &m) { throw std::runtime_error("Error while loading serialized file \"" + name + "\": " + m + "!"); };
     std::string data;
     if (!slurp(path, data)) fail("file not found");
-    if (shape_index < 0) fail("shape index must be nonnegative");
-    auto rd16 = [&](size_t at) { if (at + 2 > data.size()) fail("premature end of file"); uint16_t v; memcpy(&v, &data[at], 2); return v; };
-    auto rd32 = [&](size_t at) { if (at + 4 > data.size()) fail("premature end of file"); uint32_t v; memcpy(&v, &data[at], 4); return v; };
-    auto rd64 = [&](size_t at) { if (at + 8 > data.size()) fail("premature end of file"); uint64_t v; memcpy(&v, &data[at], 8); return v; };
+    if (shape_index < 0) fail("shape index must be nonnegative!");
+    auto rd16 = [&](size_t at) { if (at > data.size() || data.size() - at < 2) fail("premature end of file"); uint16_t v; memcpy(&v, &data[at], 2); return v; };
+    auto rd32 = [&](size_t at) { if (at > data.size() || data.size() - at < 4) fail("premature end of file"); uint32_t v; memcpy(&v, &data[at], 4); return v; };
+    auto rd64 = [&](size_t at) { if (at > data.size() || data.size() - at < 8) fail("premature end of file"); uint64_t v; memcpy(&v, &data[at], 8); return v; };
     const uint16_t format = rd16(0), version = rd16(2);
-    if (format != 0x041C) fail("encountered an invalid file format");
-    if (version != 3 && version != 4) fail("encountered an incompatible file version");
+    if (format != 0x041C) fail("encountered an invalid file format!");
+    if (version != 3 && version != 4) fail("encountered an incompatible file version!");
     size_t start = 4;
     if (shape_index != 0) {
         const uint32_t count = rd32(data.size() - 4);
         if ((uint32_t) shape_index > count) fail("Unable to unserialize mesh, shape index is out of range! (requested " + std::to_string(shape_index) + " out of 0.." + std::to_string((int) count - 1) + ")");
-        const size_t off = version == 4 ? (size_t) rd64(data.size() - 8 * (size_t) (count - (uint32_t) shape_index) - 4)
-                                        : (size_t) rd32(data.size() - 4 * (size_t) (count - (uint32_t) shape_index + 1));
+        const size_t back = version == 4 ? 8 * (size_t) (count - (uint32_t) shape_index) + 4 : 4 * ((size_t) (count - (uint32_t) shape_index) + 1);
+        if (back > data.size()) fail("premature end of file");
+        const size_t off = version == 4 ? (size_t) rd64(data.size() - back) : (size_t) rd32(data.size() - back);
+        if (off > data.size()) fail("premature end of file");
         start = off + 4;   // the sub-mesh repeats the 4-byte header
     }
     if (start > data.size()) fail("premature end of file");

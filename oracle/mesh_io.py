@@ -262,6 +262,75 @@ def read_ply(path, face_normals=False):
     return out
 
 
+def read_serialized(path, shape_index=0, face_normals=False):
+    """src/shapes/serialized.cpp:237-372: uint16 0x041C + version (3 | 4), one zlib stream per sub-mesh (flags, [v4 name], u64 vertex
+    and face counts, positions, [normals], [texcoords], [colours], u32 indices), sub-mesh offsets + count at the end of the file."""
+    import zlib
+    name = path.split("/")[-1]
+    def fail(msg):
+        raise MeshError('Error while loading serialized file "%s": %s!' % (name, msg))
+    try:
+        data = open(path, "rb").read()
+    except OSError:
+        fail("file not found")
+    if shape_index < 0:
+        fail("shape index must be nonnegative!")
+    if len(data) < 4:
+        fail("premature end of file")
+    fmt, version = struct.unpack_from("<HH", data, 0)
+    if fmt != 0x041C:
+        fail("encountered an invalid file format!")
+    if version not in (3, 4):
+        fail("encountered an incompatible file version!")
+    start = 4
+    if shape_index != 0:
+        count = struct.unpack_from("<I", data, len(data) - 4)[0]
+        if shape_index > count:
+            fail("Unable to unserialize mesh, shape index is out of range! (requested %d out of 0..%d)" % (shape_index, count - 1))
+        try:
+            if version == 4:
+                start = struct.unpack_from("<Q", data, len(data) - 8 * (count - shape_index) - 4)[0] + 4
+            else:
+                start = struct.unpack_from("<I", data, len(data) - 4 * (count - shape_index + 1))[0] + 4
+        except struct.error:
+            fail("premature end of file")
+    try:
+        raw = zlib.decompressobj().decompress(data[start:])
+    except zlib.error:
+        fail("inflate(): stream error")
+    pos = [0]
+    def take(n):
+        if pos[0] + n > len(raw):
+            fail("premature end of the compressed stream")
+        b = raw[pos[0]:pos[0] + n]
+        pos[0] += n
+        return b
+    flags = struct.unpack("<I", take(4))[0]
+    if version == 4:
+        while take(1) != b"\0":
+            pass
+    nv, nf = struct.unpack("<QQ", take(16))
+    if nv > 2 ** 31 or nf > 2 ** 31:
+        fail("implausible vertex / face count")
+    dp = bool(flags & 0x2000)
+    def floats(dim):
+        a = np.frombuffer(take(nv * dim * (8 if dp else 4)), "<f8" if dp else "<f4")
+        return a.astype(np.float32).reshape(nv, dim)
+    out = {"positions": floats(3), "normals": None, "texcoords": None, "faces": None}
+    if flags & 0x1:
+        n = floats(3)
+        if not face_normals:
+            out["normals"] = n
+    if flags & 0x2:
+        out["texcoords"] = floats(2)
+    if flags & 0x8:
+        floats(3)
+    out["faces"] = np.frombuffer(take(nf * 12), "<u4").reshape(nf, 3).copy()
+    if nf and out["faces"].max() >= nv:
+        fail("face references a vertex out of range")
+    return out
+
+
 def _np_type(endian, ply_type):
     c = _PLY_TYPES[ply_type]
     return {"b": "i1", "B": "u1", "h": endian + "i2", "H": endian + "u2", "i": endian + "i4", "I": endian + "u4",

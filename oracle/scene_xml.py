@@ -538,11 +538,11 @@ class FlatScene:
 
 
 def _shape_record(sp, registry, strip_to_world, base_dir=""):
-    kind = {"rectangle": 0, "cube": 1, "obj": 1, "ply": 1, "sphere": 2, "disk": 3, "cylinder": 4}.get(sp.plugin)
+    kind = {"rectangle": 0, "cube": 1, "obj": 1, "ply": 1, "serialized": 1, "sphere": 2, "disk": 3, "cylinder": 4}.get(sp.plugin)
     if kind is None:
         raise ValueError('unsupported shape plugin "%s"' % sp.plugin)
     mesh_raw = None
-    if sp.plugin in ("obj", "ply"):   # src/shapes/obj.cpp:139-143, ply.cpp:160-166: filename through the file resolver
+    if sp.plugin in ("obj", "ply", "serialized"):   # src/shapes/obj.cpp:139-143, ply.cpp:160-166, serialized.cpp:242-244: filename through the file resolver
         from . import mesh_io
         fn = sp.get_s("filename", None)
         if fn is None:
@@ -550,7 +550,8 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
         path = fn if os.path.isabs(fn) else os.path.join(base_dir, fn)
         fnorm = sp.get_b("face_normals", False)
         mesh_raw = (mesh_io.read_obj(path, sp.get_b("flip_tex_coords", True), fnorm) if sp.plugin == "obj"
-                    else mesh_io.read_ply(path, fnorm))
+                    else mesh_io.read_ply(path, fnorm) if sp.plugin == "ply"
+                    else mesh_io.read_serialized(path, sp.get_i("shape_index", 0), fnorm))
     tw, tinv = _ident(), _ident()
     if not strip_to_world and "to_world" in sp and sp["to_world"][0] == "transform":
         tw, tinv = sp["to_world"][1]

@@ -96,6 +96,31 @@ def write_ply(path, pos, nrm, uv, faces, binary=True, with_normals=True, with_uv
                 f.write(("3 %d %d %d\n" % tri).encode())
 
 
+def write_serialized(path, meshes, version=4, double_precision=False):
+    """Mitsuba's .serialized container: `meshes` = [(pos, nrm | None, uv | None, faces), ...], one zlib stream each."""
+    import zlib
+    blob_, offsets = b"", []
+    for k, (pos, nrm, uv, faces) in enumerate(meshes):
+        offsets.append(len(blob_))
+        flags = (0x2000 if double_precision else 0x1000) | (1 if nrm is not None else 0) | (2 if uv is not None else 0)
+        fl = "<%dd" if double_precision else "<%df"
+        body = struct.pack("<I", flags)
+        if version == 4:
+            body += b"mesh%d\0" % k
+        body += struct.pack("<QQ", len(pos), len(faces))
+        for arr in (pos, nrm, uv):
+            if arr is not None:
+                flat = [c for v in arr for c in v]
+                body += struct.pack(fl % len(flat), *flat)
+        flat = [i for f in faces for i in f]
+        body += struct.pack("<%dI" % len(flat), *flat)
+        blob_ += struct.pack("<HH", 0x041C, version) + zlib.compress(body, 6)
+    for o in offsets:
+        blob_ += struct.pack("<Q" if version == 4 else "<I", o)
+    blob_ += struct.pack("<I", len(meshes))
+    open(path, "wb").write(blob_)
+
+
 def mesh_shape(plugin, ident, filename, bsdf_id, scale, translate, anim_dz=None, extra=""):
     tf = ('\t\t\t<scale value="%s" />\n\t\t\t<translate x="%s" y="%s" z="%s" />\n' % ((scale,) + tuple(translate)))
     s = '\t<shape type="%s" id="%s">\n\t\t<string name="filename" value="%s" />\n%s' % (plugin, ident, filename, extra)
@@ -152,6 +177,9 @@ def write_all(out_dir, n_u=24, n_v=12):
     write_ply(os.path.join(out_dir, "blob.ply"), pos, nrm, uv, faces)                                   # binary LE + normals
     write_ply(os.path.join(out_dir, "blob_ascii.ply"), pos, nrm, uv, faces, binary=False, with_normals=False, with_uv=True)
     write_ply(os.path.join(out_dir, "blob_be.ply"), pos, nrm, uv, faces, big_endian=True)
+    pos2, nrm2, uv2, faces2 = blob(n_u, n_v, seed=2)
+    write_serialized(os.path.join(out_dir, "blob.serialized"), [(pos2, None, None, faces2), (pos, nrm, uv, faces)])              # v4, two sub-meshes
+    write_serialized(os.path.join(out_dir, "blob_v3.serialized"), [(pos2, None, uv2, faces2), (pos, nrm, None, faces)], version=3, double_precision=True)
     with open(os.path.join(out_dir, "cornell_mesh.xml"), "w") as f:
         f.write(cornell_mesh_xml())
     with open(os.path.join(out_dir, "cornell_mesh_light.xml"), "w") as f:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes a corpus of damaged scene files for tools/sanitize_loader.sh:  python tests/dev/fuzz_corpus.py SEED COUNT OUTDIR
-35 % numeric attribute values replaced by extreme ones, 25 % character-level damage of the XML, 40 % damaged obj / ply mesh files."""
+35 % numeric attribute values replaced by extreme ones, 25 % character-level damage of the XML, 40 % damaged obj / ply / serialized mesh files."""
 import os, sys, random, re
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scenes"))
@@ -16,7 +16,10 @@ make_mesh.write_ply(os.path.join(out, "blob.ply"), pos, nrm, uv, faces)
 make_mesh.write_obj(os.path.join(out, "a.obj"), pos, nrm, uv, faces); make_mesh.write_ply(os.path.join(out, "b.ply"), pos, nrm, uv, faces)
 make_mesh.write_ply(os.path.join(out, "c.ply"), pos, nrm, uv, faces, binary=False); make_mesh.write_ply(os.path.join(out, "d.ply"), pos, nrm, uv, faces, big_endian=True, with_uv=True)
 make_mesh.write_obj(os.path.join(out, "e.obj"), pos, nrm, uv, faces, with_normals=True, quads_as_polygons=True)
-orig = {n: open(os.path.join(out, n), "rb").read() for n in ("a.obj", "b.ply", "c.ply", "d.ply", "e.obj")}
+make_mesh.write_serialized(os.path.join(out, "f.serialized"), [(pos, nrm, uv, faces), (pos, None, None, faces)])
+make_mesh.write_serialized(os.path.join(out, "g.serialized"), [(pos, None, uv, faces)], version=3, double_precision=True)
+orig = {n: open(os.path.join(out, n), "rb").read() for n in ("a.obj", "b.ply", "c.ply", "d.ply", "e.obj", "f.serialized", "g.serialized")}
+import zlib
 xml0 = make_mesh.cornell_mesh_xml(moving_file="MOVING", res=16, spp=4)
 for it in range(N):
     r = random.random()
@@ -38,6 +41,9 @@ for it in range(N):
     else:             # mesh file fuzz
         n = random.choice(list(orig)); typ = n.split(".")[1]
         b = bytearray(orig[n])
+        inner = typ == "serialized" and random.random() < 0.6     # damage the deflated body, not the zlib framing
+        if inner:
+            d = zlib.decompressobj(); b = bytearray(d.decompress(bytes(b[4:]))); tail = d.unused_data
         for _ in range(random.randint(1, 5)):
             op = random.random(); i = random.randrange(len(b))
             if op < 0.25: del b[i:i + random.randint(1, 40)]
@@ -46,7 +52,9 @@ for it in range(N):
             elif op < 0.85: b = b[:i]
             else: b[i:i+4] = random.choice([b"\xff\xff\xff\x7f", b"\x00\x00\x80\x7f", b"\x00\x00\xc0\x7f", b"\x01\x00\x00\x00"])
             if not b: b = bytearray(b" ")
+        if inner: b = bytearray(orig[n][:4] + zlib.compress(bytes(b)) + (tail if random.random() < 0.7 else b""))
         fn = "m%d.%s" % (it, typ)
         open(os.path.join(out, fn), "wb").write(bytes(b))
+        if typ == "serialized" and random.random() < 0.5: fn += '" />\n\t\t<integer name="shape_index" value="%d' % random.choice([1, 1, 2, 7, -1])
         t = xml0.replace("MOVING", fn).replace('<shape type="obj" id="MovingBlob">', '<shape type="%s" id="MovingBlob">' % typ)
     open(os.path.join(out, "s%d.xml" % it), "w", errors="ignore").write(t)

@@ -39,7 +39,10 @@ def one_mesh_xml(plugin, filename, extra=""):
 FLAVOURS = [("ply", "blob.ply", ""), ("ply", "blob_ascii.ply", ""), ("ply", "blob_be.ply", ""), ("obj", "blob.obj", ""),
             ("obj", "blob_n.obj", ""), ("obj", "blob.obj", '\t\t<boolean name="face_normals" value="true" />\n'),
             ("obj", "blob.obj", '\t\t<boolean name="flip_tex_coords" value="false" />\n\t\t<boolean name="flip_normals" value="true" />\n'),
-            ("ply", "blob.ply", '\t\t<boolean name="face_normals" value="true" />\n')]
+            ("ply", "blob.ply", '\t\t<boolean name="face_normals" value="true" />\n'),
+            ("serialized", "blob.serialized", ""), ("serialized", "blob.serialized", '\t\t<integer name="shape_index" value="1" />\n'),
+            ("serialized", "blob_v3.serialized", '\t\t<integer name="shape_index" value="1" />\n'),
+            ("serialized", "blob_v3.serialized", '\t\t<boolean name="face_normals" value="true" />\n')]
 
 
 def mesh_arrays_of_oracle(osc):
@@ -114,6 +117,30 @@ def test_mesh_errors_follow_the_reference(mi, tmp_path):
         (tmp_path / ("idx%d.ply" % k)).write_text(head % ("1", "float" if "e" in idx or "nan" in idx else "int", idx))
         with pytest.raises(RuntimeError, match="out of range"):
             load("ply", "idx%d.ply" % k)
+    # serialized.cpp:246-296 (the reference's messages end in "!!": the text carries one "!", fail() adds the other)
+    with pytest.raises(RuntimeError, match='Error while loading serialized file "nope.serialized": file not found!'):
+        load("serialized", "nope.serialized")
+    (tmp_path / "bad.serialized").write_bytes(b"\x1c\x05\x04\x00abcd")
+    with pytest.raises(RuntimeError, match="encountered an invalid file format!!"):
+        load("serialized", "bad.serialized")
+    (tmp_path / "v5.serialized").write_bytes(b"\x1c\x04\x05\x00abcd")
+    with pytest.raises(RuntimeError, match="encountered an incompatible file version!!"):
+        load("serialized", "v5.serialized")
+    (tmp_path / "junk.serialized").write_bytes(b"\x1c\x04\x04\x00" + b"not a zlib stream at all")
+    with pytest.raises(RuntimeError, match="inflate"):
+        load("serialized", "junk.serialized")
+    make_mesh.write_serialized(str(tmp_path / "one.serialized"), [([(0, 0, 0), (1, 0, 0), (0, 1, 0)], None, None, [(0, 1, 2)])])
+    (tmp_path / "idx.xml").write_text(one_mesh_xml("serialized", "one.serialized", '\t\t<integer name="shape_index" value="3" />\n'))
+    with pytest.raises(RuntimeError, match=r"shape index is out of range! \(requested 3 out of 0..0\)"):
+        mi.load_file(str(tmp_path / "idx.xml"))
+    make_mesh.write_serialized(str(tmp_path / "oob.serialized"), [([(0, 0, 0), (1, 0, 0), (0, 1, 0)], None, None, [(0, 1, 5)])])
+    with pytest.raises(RuntimeError, match="out of range"):
+        load("serialized", "oob.serialized")
+    import zlib, struct
+    short = struct.pack("<HH", 0x041C, 4) + zlib.compress(struct.pack("<I", 0x1000) + b"m\0" + struct.pack("<QQ", 100, 100) + b"\0" * 40)
+    (tmp_path / "short.serialized").write_bytes(short)
+    with pytest.raises(RuntimeError, match="premature end"):
+        load("serialized", "short.serialized")
     (tmp_path / "nofile.xml").write_text(one_mesh_xml("ply", "x.ply").replace('<string name="filename" value="x.ply" />', ""))
     with pytest.raises(RuntimeError, match="filename"):
         mi.load_file(str(tmp_path / "nofile.xml"))

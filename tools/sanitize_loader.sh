@@ -9,7 +9,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 work=$(mktemp -d /tmp/dtof_asan.XXXXXX)
 cd "$root/mitsuba3dopplertof_amd/csrc"
 /opt/rocm/bin/hipcc -x hip --offload-host-only -O1 -g -std=c++17 -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -I. \
-    scene_loader.cpp scene_build.cpp mesh_io.cpp "$root/tests/dev/asan_loader.cpp" -o "$work/loader"
+    scene_loader.cpp scene_build.cpp mesh_io.cpp image_io.cpp "$root/tests/dev/asan_loader.cpp" -o "$work/loader" -lz
 python3 "$root/tests/dev/fuzz_corpus.py" "$seed" "$count" "$work/corpus"
 cd "$work"
 ls corpus/*.xml | xargs -n 200 ./loader > log.txt 2>&1 || true
