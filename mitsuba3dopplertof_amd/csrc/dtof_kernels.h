@@ -53,6 +53,7 @@ struct RenderParams {
     uint2 *pass_rng;                              // n_passes > 1: [lane - pass_first][3] = states of the main / time / path streams between passes
     uint32_t pass_first;                          // virtual lane the pass_rng array starts at
     int32_t has_env, hide_emitters; uint32_t env_index;   // `constant` environment emitter (scene.cpp:53-57), SamplingIntegrator::m_hide_emitters
+    uint32_t flat_objects, flat_off;                        // fused pipeline, rectangle-only scenes of at most kFlatObjects objects: their number (trace_flat), else 0
     uint32_t memo_obj;                            // fused pipeline: the scene's only instance object (instance memo, dtof_traverse.h) or 0xffffffff
 };
 

@@ -160,6 +160,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
     const ShadeArgs &A = *(const ShadeArgs *) (kernarg + rebase);
     const RenderParams &rp = A.rp; const Queues &q = A.q;
     const uint32_t *const qin = A.qin; uint32_t *const qout = A.qout; const uint32_t depth = A.depth, trace_next = A.trace_next; LaneDebug *const dbg = A.dbg;
+    const uint32_t flat = FUSED && !MESH ? rp.flat_objects : 0u;   // != 0: the scene's object count, every ray tests them all (trace_flat)
     uint32_t j = cbase + threadIdx.x;
     bool in_range = j < count;
     bool alive = false, want_shadow = false;
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
             }
             if (have_memo) instance_memo_fill(sv, ra.w, memo_m, memo_inv);
             Hit h;
-            bool found = trace_scene<false, MESH, FUSED>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
+            bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h)
+                              : trace_scene<false, MESH, FUSED>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
             hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
             hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu;
         } else {
@@ -585,7 +587,12 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
         bool commit = false;
         if (want_shadow) {   // test_visibility (scene.cpp:266-271): an unoccluded sample commits its candidate result
             Hit hs;
-            commit = !trace_scene<true, MESH, true>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
+#if defined(DTOF_ABLATE) && (DTOF_ABLATE & 1)
+            commit = sha.w > 0.f;
+#else
+            commit = flat ? !trace_flat<true, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs)
+                          : !trace_scene<true, MESH, true>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
+#endif
         }
         if (FIRST ? in_range : commit) {   // FIRST: every lane's result is defined here (nothing zeroed it beforehand)
 #pragma unroll
@@ -596,7 +603,12 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
         }
         if (alive && trace_next) {   // closest hit of the continuation ray, consumed by the next bounce
             Hit h;
-            bool found = trace_scene<false, MESH, true>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
+#if defined(DTOF_ABLATE) && (DTOF_ABLATE & 2)
+            bool found = nra.x < 1e30f; h.t = 0.5f + 0.1f * nrb.x; h.u = nrb.y; h.v = nrb.z; h.obj = nrb.x > 0.3f ? 3 : nrb.y > 0.f ? 1 : 0; h.shape = 0; h.prim = 0;
+#else
+            bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h)
+                              : trace_scene<false, MESH, true>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
+#endif
             store_hit<MESH>(q, l, h, found);
         }
         n_shadow += (uint32_t) __popcll(__ballot(want_shadow)) * ((threadIdx.x & 63) == 0 ? 1u : 0u);   // per-wave partial (stats only)
@@ -814,6 +826,96 @@ __global__ __launch_bounds__(kBlock) void k_splat_tent3(RenderParams rp, Queues 
     }
 }
 
+// The same sums with EIGHT SAMPLES PER LANE (spp a power of two >= 16): a lane accumulates the 36 footprint values of eight samples of
+// its pixel serially in registers (~70 VALU per sample), and only then are the seg8 = min(spp / 8, 64) lanes that share a pixel reduced
+// with DPP adds -- log2(seg8) steps of 36 adds per EIGHT samples instead of log2(min(spp, 64)) steps per sample (C2, 64 spp: 13.5 instead
+// of 216 DPP adds per sample).  Which samples a lane takes does not matter for the sums: lane `sub` of a segment takes the samples
+// sub, sub + seg8, sub + 2 seg8, ... of the segment's 8 seg8 consecutive ones, so each load instruction reads seg8 consecutive records
+// per segment (64 spp: whole 128-byte lines of q.res).  Segment totals leave through LDS and block-wide atomics as in k_splat_tent3.
+constexpr uint32_t kSplatPer = 8;
+__global__ __launch_bounds__(kBlock) void k_splat_tent3x8(RenderParams rp, Queues q, float *film, size_t film_stride, uint32_t seg8) {
+    __shared__ float4 s_acc4[(kBlock / 2) * 9];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x, sub = i & (seg8 - 1);
+    const uint32_t first = (i - sub) * kSplatPer;           // first sample of this lane's segment (8 seg8 consecutive samples of one pixel)
+    const bool in_range = first < rp.n_lanes;               // n_lanes is a multiple of spp, spp of 8 seg8
+    const uint32_t lane = global_lane(rp, rp.lane_base + (in_range ? first : 0));
+    const uint32_t pix = lane >> rp.spp_log2, W = (uint32_t) rp.crop_w;
+    const int py = (int) fdiv(pix, rp.d_w), px = (int) (pix - W * (uint32_t) py);
+    const float bx = (float) (px + rp.crop_x - 1) + .5f, by = (float) (py + rp.crop_y - 1) + .5f;
+    for (int k = 0; k < rp.n_offsets; ++k) {
+        float *fk = film + (size_t) k * film_stride;
+        const float4 *res = q.res + (size_t) k * q.capacity + first + sub;
+        const float2 *pos = q.pos + first + sub;
+        float acc[36];
+#pragma unroll
+        for (int c = 0; c < 36; ++c) acc[c] = 0.f;
+        uint32_t irregular = 0;
+#pragma unroll 1
+        for (uint32_t h = 0; h < kSplatPer; h += 4) {   // four samples at a time: their eight loads are issued together
+            float4 r[4]; float2 pp[4];
+#pragma unroll
+            for (uint32_t m = 0; m < 4; ++m) {
+                r[m] = in_range ? res[(size_t) (h + m) * seg8] : make_float4(0.f, 0.f, 0.f, 0.f);
+                pp[m] = in_range ? pos[(size_t) (h + m) * seg8] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (uint32_t m = 0; m < 4; ++m) {
+                const float sx = pp[m].x, sy = pp[m].y;
+                const int fx = (int) floorf(sx) - rp.crop_x, fy = (int) floorf(sy) - rp.crop_y;
+                const bool regular = in_range && fx == px && fy == py;
+                if (in_range && !regular) irregular |= 1u << (h + m);
+                const float relx = bx - sx, rely = by - sy;
+                float wx[3], wy[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { wx[a] = regular ? tent(relx + (float) a, rp.inv_radius) : 0.f; wy[a] = tent(rely + (float) a, rp.inv_radius); }
+#pragma unroll
+                for (int ys = 0; ys < 3; ++ys)
+#pragma unroll
+                    for (int xs = 0; xs < 3; ++xs) {
+                        const float w = wx[xs] * wy[ys]; const int c = 4 * (3 * ys + xs);
+                        acc[c] = fmaf(r[m].x, w, acc[c]); acc[c + 1] = fmaf(r[m].y, w, acc[c + 1]); acc[c + 2] = fmaf(r[m].z, w, acc[c + 2]); acc[c + 3] += w;
+                    }
+            }
+        }
+#pragma unroll 1
+        for (uint32_t m = 0; irregular >> m; ++m) if ((irregular >> m) & 1u) {   // positions that rounded into the next pixel (rare): splat by themselves
+            const float2 sp = pos[(size_t) m * seg8]; const float4 sr = res[(size_t) m * seg8];
+            splat_lane(rp, fk, sp.x, sp.y, px, py, sr.x, sr.y, sr.z);
+        }
+#pragma unroll
+        for (int c = 0; c < 36; ++c) {   // segment totals end up in the segment's LAST lane (see k_splat_tent3)
+            float v = acc[c];
+            v = dpp_add<0xb1>(v);
+            if (seg8 >= 4) v = dpp_add<0x4e>(v);
+            if (seg8 >= 8) v = dpp_add<0x124>(v);
+            if (seg8 >= 16) v = dpp_add<0x128>(v);
+            if (seg8 >= 32) v = dpp_add<0x142, 0xa>(v);
+            if (seg8 >= 64) v = dpp_add<0x143, 0xc>(v);
+            acc[c] = v;
+        }
+        if (k > 0) __syncthreads();
+        const uint32_t sidx_mine = threadIdx.x / seg8;
+        if ((threadIdx.x & (seg8 - 1)) == seg8 - 1) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) s_acc4[sidx_mine * 9 + c] = make_float4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
+        }
+        __syncthreads();
+        const uint32_t total = (kBlock / seg8) * 36;
+        const float *s_acc = (const float *) s_acc4;
+        for (uint32_t idx = threadIdx.x; idx < total; idx += kBlock) {
+            const uint32_t sidx = idx / 36, c = idx - sidx * 36;
+            const uint32_t seg_first = (blockIdx.x * kBlock + sidx * seg8) * kSplatPer;
+            if (seg_first >= rp.n_lanes) continue;
+            const uint32_t spix = global_lane(rp, rp.lane_base + seg_first) >> rp.spp_log2;
+            const int sy = (int) fdiv(spix, rp.d_w), sx = (int) (spix - W * (uint32_t) sy);
+            const int x = sx - 1 + (int) ((c % 12) >> 2), y = sy - 1 + (int) (c / 12);
+            const float v = s_acc[idx];
+            if ((unsigned) x < W && (unsigned) y < (unsigned) rp.crop_h && v != 0.f)
+                atomicAdd(fk + 4 * ((size_t) y * W + (size_t) x) + (c & 3), v);
+        }
+    }
+}
+
 __global__ void k_develop(const float *film, float *rgb, int64_t n) {
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -952,7 +1054,11 @@ void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t 
     if (rp.n_lanes == 0) return;
     size_t stride = (size_t) film_w * film_h * 4;
     bool fast = rp.filter == FILTER_TENT && rp.filter_radius <= 1.f && rp.filter_radius > .5f && rp.spp_log2 != 0xffffffffu && rp.spp >= 2;
-    if (fast) {
+    static const int env_splat = [] { const char *e = getenv("DTOF_SPLAT"); std::string v = e ? e : ""; return v == "dpp" ? 1 : v == "generic" ? 2 : 0; }();   // A/B switches
+    if (fast && rp.spp >= 2 * kSplatPer && env_splat == 0) {   // eight samples per lane, then the DPP reduction over the spp / 8 lanes of a pixel
+        const uint32_t groups = rp.n_lanes / kSplatPer, seg8 = rp.spp / kSplatPer < 64 ? rp.spp / kSplatPer : 64;
+        hipLaunchKernelGGL(k_splat_tent3x8, dim3(nblk(groups)), dim3(kBlock), 0, s, rp, q, film, stride, seg8);
+    } else if (fast && env_splat != 2) {
         uint32_t seg = rp.spp < 64 ? rp.spp : 64;
         hipLaunchKernelGGL(k_splat_tent3, dim3(nblk(rp.n_lanes)), dim3(kBlock), 0, s, rp, q, film, stride, seg);
     } else {

@@ -367,6 +367,11 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         static const bool env_memo = [] { const char *e = getenv("DTOF_INSTANCE_MEMO"); return !(e && e[0] == '0'); }();
         if (fused && n_inst == 1 && env_memo) rp.memo_obj = last_inst;
     }
+    {   // a handful of rectangles: test them all instead of walking a tree (trace_flat in dtof_traverse.h; DTOF_FLAT=0 keeps the TLAS)
+        static const bool env_flat = [] { const char *e = getenv("DTOF_FLAT"); return !(e && e[0] == '0'); }();
+        rp.flat_objects = fused && !rp.has_tris && bh->off_flat != 0 && env_flat ? bh->n_objects : 0u;
+        rp.flat_off = bh->off_flat;
+    }
     StageTimer tm(stats != nullptr, sc);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     struct EventGuard { hipEvent_t e = nullptr; ~EventGuard() { if (e) (void) hipEventDestroy(e); } } g_fork, g_join;   // released on every exit path

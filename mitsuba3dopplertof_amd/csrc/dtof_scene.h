@@ -27,9 +27,15 @@ enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1, EMITTER_SPOT 
 struct BlobHeader {
     uint32_t n_nodes, n_objects, n_groups, n_shapes, n_tris, n_emitters;
     uint32_t off_nodes, off_objects, off_groups, off_shapes, off_tris, off_shading, off_emitters;
-    uint32_t total_bytes, off_tables, tlas_depth;      // off_tables: face distributions of mesh emitters (float / uint32 words)   // tlas_depth: stack entries a traversal can need (TLAS depth + deepest BLAS)
+    uint32_t total_bytes, off_tables, tlas_depth, off_flat;      // off_tables: face distributions of mesh emitters (float / uint32 words)   // tlas_depth: stack entries a traversal can need (TLAS depth + deepest BLAS)
+    uint32_t pad[3];                                   // off_flat: DFlatObject[n_objects] of a rectangle-only scene of at most kFlatObjects objects, else 0
 };
-static_assert(sizeof(BlobHeader) == 64, "BlobHeader");
+static_assert(sizeof(BlobHeader) == 80, "BlobHeader");
+// One top-level object of a small rectangle-only scene as trace_flat (dtof_traverse.h) reads it with ONE scalar load: a plain rectangle's
+// world -> object matrix (a copy of its DShape::to_object), or the mark of an instance (which takes the general intersect_object).
+constexpr uint32_t kFlatObjects = 8;
+struct DFlatObject { uint32_t instance, pad[3]; float to_object[12]; };   // 64 B
+static_assert(sizeof(DFlatObject) == 64, "DFlatObject");
 
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kNoChild = 0xffffffffu;

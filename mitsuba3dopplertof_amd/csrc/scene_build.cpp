@@ -409,6 +409,18 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     h.off_tris = off;     off = align16(off + (uint32_t) (tris.size() * sizeof(DTri)));
     h.off_shading = off;  off = align16(off + (uint32_t) (shading.size() * sizeof(DTriShade)));
     h.off_tables = off;   off = align16(off + (uint32_t) (tables.size() * 4));
+    std::vector<DFlatObject> flat;   // small rectangle-only scenes: one 64-byte record per object for trace_flat
+    {
+        bool ok = !objects.empty() && objects.size() <= kFlatObjects && tris.empty();
+        for (const DShape &d : shapes) ok &= d.kind == SHAPE_RECT;
+        if (ok) for (const DObject &ob : objects) {
+            DFlatObject f; memset(&f, 0, sizeof f);
+            f.instance = ob.kind == OBJ_INSTANCE;
+            if (!f.instance) memcpy(f.to_object, shapes[ob.index].to_object, 48);
+            flat.push_back(f);
+        }
+    }
+    h.off_flat = flat.empty() ? 0u : off; off = align16(off + (uint32_t) (flat.size() * sizeof(DFlatObject)));
     h.total_bytes = off;
     for (DShape &d : shapes) if (d.kind == SHAPE_MESH && (d.flags & SF_EMITTER)) d.emit_table += h.off_tables;
     for (DShape &d : shapes) if (d.bsdf == BSDF_ROUGHPLASTIC) d.rough_table += h.off_tables;
@@ -427,6 +439,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     if (!tris.empty()) memcpy(blob.data() + h.off_tris, tris.data(), tris.size() * sizeof(DTri));
     if (!shading.empty()) memcpy(blob.data() + h.off_shading, shading.data(), shading.size() * sizeof(DTriShade));
     if (!tables.empty()) memcpy(blob.data() + h.off_tables, tables.data(), tables.size() * 4);
+    if (!flat.empty()) memcpy(blob.data() + h.off_flat, flat.data(), flat.size() * sizeof(DFlatObject));
     return blob;
 }
 
