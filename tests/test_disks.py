@@ -70,7 +70,7 @@ def test_disk_semantics(mi, orc, tmp_path):
     sc = mi.load_file(os.path.join(SCENES, "cornell_disk.xml"))
     assert sc.info()["n_shapes"] == 8 and sc.info()["n_emitters"] == 1
     with pytest.raises(mi.DtofError, match="supported: rectangle, disk"):
-        mi.load_string(lit_room('\t<shape type="cylinder" />\n'))
+        mi.load_string(lit_room('\t<shape type="sdfgrid" />\n'))
 
 
 DISK_CASES = [("disk_doppler", dict(resx=40, resy=40), 8, None), ("disk_path_depth6", dict(resx=32, resy=32), 8, dict(type="path", max_depth=6)),
