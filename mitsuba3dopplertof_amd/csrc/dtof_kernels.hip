@@ -286,7 +286,12 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
             }
 
             // ---- emitter sampling (scene.cpp:235-291; point.cpp:118-147; area.cpp:116-159 + shape.cpp:370-384 + rectangle.cpp:152-166)
-            float e1 = single ? next_f32(main) : next_correlate(main, path, correlate), e2 = single ? next_f32(main) : next_correlate(main, path, correlate);
+            // The six draws of this iteration (App. A step 5) come from ONE stream: the main one (`path`, other samplers, correlate = false) or
+            // the path-correlated one; next_1d_correlate advances both on every draw (correlated.cpp:156-161), so the stream that is not read
+            // is moved six steps at once at the end (pcg_jump6: the same integers as six single steps).
+            const bool use_path = !single && correlate;
+            Rng sel = use_path ? path : main;
+            float e1 = next_f32(sel), e2 = next_f32(sel);
             // has_flag(bsdf->flags(), BSDFFlags::Smooth) (:178): diffuse, (rough)plastic and roughconductor have a smooth lobe
             bool active_em = active_next && sv.n_emitters > 0 && (!SPEC || sh->bsdf == BSDF_DIFFUSE || sh->bsdf == BSDF_PLASTIC || sh->bsdf == BSDF_ROUGHCONDUCTOR || sh->bsdf == BSDF_ROUGHPLASTIC || sh->bsdf == BSDF_ROUGHDIELECTRIC);
             V3 em_weight = mk(0, 0, 0), wo = mk(0, 0, 0); float ds_dist = 0.f, ds_pdf = 0.f; bool ds_delta = true;
@@ -362,8 +367,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
                 shb = make_float4(sd.x, sd.y, sd.z, time);
                 wo = mk(dot(dd, si.sh_s), dot(dd, si.sh_t), dot(dd, si.sh_n));
             }
-            const float sample_1 = single ? next_f32(main) : next_correlate(main, path, correlate); (void) sample_1;
-            float s2x = single ? next_f32(main) : next_correlate(main, path, correlate), s2y = single ? next_f32(main) : next_correlate(main, path, correlate);
+            const float sample_1 = next_f32(sel); (void) sample_1;
+            float s2x = next_f32(sel), s2y = next_f32(sel);
 
             // ---- BSDF eval_pdf + sample (twosided.cpp:111-148,219-258; diffuse.cpp:101-125,160-180)
             bool twosided = sh->flags & SF_TWOSIDED;
@@ -566,7 +571,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
             float thr_max = fmax_(fmax_(thr.x, thr.y), thr.z);
             float rr_prob = fmin_(thr_max * sqr(eta), .95f);
             bool rr_active = ndepth >= rp.rr_depth;
-            bool rr_continue = (single ? next_f32(main) : next_correlate(main, path, correlate)) < rr_prob;
+            bool rr_continue = next_f32(sel) < rr_prob;
+            if (use_path) { path.state = sel.state; main.state = pcg_jump6(main.state, main.inc); }
+            else { main.state = sel.state; if (!single) path.state = pcg_jump6(path.state, path.inc); }
             if (rr_active) thr = thr * rcp(rr_prob);
             alive = active_next && (!rr_active || rr_continue) && thr_max != 0.f;
             if (alive) {

@@ -448,6 +448,10 @@ DTOF_HD float pcg_output_f32(uint64_t old) {
     uint32_t xs = (uint32_t) (((old >> 18) ^ old) >> 27), rot = (uint32_t) (old >> 59);
     return u2f((((xs >> rot) | (xs << ((~rot + 1u) & 31))) >> 9) | 0x3f800000u) - 1.f;
 }
+// six LCG steps at once: state * M^6 + inc * (M^5 + M^4 + M^3 + M^2 + M + 1)  (mod 2^64)
+constexpr uint64_t pcg_pow(int n) { uint64_t r = 1; for (int i = 0; i < n; ++i) r *= kPcgMult; return r; }
+constexpr uint64_t kPcgMult6 = pcg_pow(6), kPcgGeom6 = 1 + pcg_pow(1) + pcg_pow(2) + pcg_pow(3) + pcg_pow(4) + pcg_pow(5);
+DTOF_HD uint64_t pcg_jump6(uint64_t state, uint64_t inc) { return state * kPcgMult6 + inc * kPcgGeom6; }
 // PCG32::seed(1, initstate, initseq)
 DTOF_HD void pcg_seed(uint32_t initstate, uint32_t initseq, uint64_t &state, uint64_t &inc) {
     state = 0; inc = ((uint64_t) initseq << 1) | 1u;

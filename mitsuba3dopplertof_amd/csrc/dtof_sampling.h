@@ -123,7 +123,18 @@ DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane, bool wav
     const bool needs_tm = rp.integrator == 0 && rp.sampler_kind == SAMPLER_CORRELATED && (rp.time_sampling == TIME_ANTITHETIC || rp.time_sampling == TIME_ANTITHETIC_MIRROR);
     Rng main, tm, path; tm.state = 0; tm.inc = 1;
     uint2 *const carried = rp.n_passes > 1 ? rp.pass_rng + (size_t) (vlane - rp.pass_first) * 3 : nullptr;
-    if (rp.pass == 0) {
+    if (rp.pass == 0 && wave_pixel && needs_tm && rp.tcn == 2 && rp.pcn == 2) {
+        // Correlated pairs (the default time_correlate_number = path_correlate_number = 2): lanes 2k and 2k + 1 share their time stream
+        // TEA(seed + 1, k) and their path stream TEA(seed + 2, k) (correlated.cpp:54-63).  The even lane evaluates the first, the odd lane the
+        // second, and the two swap results (quad_perm [1, 0, 3, 2]): one TEA evaluation per lane instead of two, same integers.
+        // wave_pixel: the wave's lanes are consecutive, 64-aligned and all active or all inactive in pairs.
+        main = seed_stream(rp.seed_value, lane);
+        const bool odd = lane & 1u;
+        uint32_t a0, a1; tea32(rp.seed_value + (odd ? 2u : 1u), lane >> 1, a0, a1);
+        const uint32_t b0 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) a0, 0xb1, 0xf, 0xf, false), b1 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) a1, 0xb1, 0xf, 0xf, false);
+        pcg_seed(odd ? b0 : a0, odd ? b1 : a1, tm.state, tm.inc);
+        pcg_seed(odd ? a0 : b0, odd ? a1 : b1, path.state, path.inc);
+    } else if (rp.pass == 0) {
         main = seed_stream(rp.seed_value, lane);
         if (needs_tm) tm = seed_stream(rp.seed_value + 1, fdiv(lane, rp.d_tcn));
         path = seed_stream(rp.seed_value + 2, fdiv(lane, rp.d_pcn));
