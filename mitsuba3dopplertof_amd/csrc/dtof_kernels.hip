@@ -221,9 +221,11 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
             float prev_pdf = 1.f; bool pdelta = true;
             if (depth > 0) { prev_pdf = q.st_b[l].w; pdelta = q.st_c[l].y != 0.f; }
             const DEmitter &env = sv.emitters[rp.env_index];
-            const float em_pdf = pdelta ? 0.f : kInvFourPi * (1.f / (float) sv.n_emitters);
+            const bool is_map = env.kind == EMITTER_ENVMAP;   // EnvironmentMapEmitter::pdf_direction / eval (envmap.cpp:408-425,299-310) with ds.d = -si.wi = the ray direction
+            const V3 rd = FIRST ? mk(rb.x, rb.y, rb.z) : [&] { const float4 b4 = q.ray_b[l]; return mk(b4.x, b4.y, b4.z); }();
+            const float em_pdf = pdelta ? 0.f : (is_map ? env_pdf_direction(sv.base, env, rd) : kInvFourPi) * (1.f / (float) sv.n_emitters);
             const float mis_bsdf = mis_weight(prev_pdf, em_pdf);
-            const V3 le = prev_pdf > 0.f ? mk(env.intensity[0], env.intensity[1], env.intensity[2]) : mk(0, 0, 0);
+            const V3 le = prev_pdf > 0.f ? (is_map ? env_eval(sv.base, env, rd) : mk(env.intensity[0], env.intensity[1], env.intensity[2])) : mk(0, 0, 0);
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
                 V3 v = le * mis_bsdf;
@@ -317,6 +319,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
                     ds_pdf = kInvFourPi; ds_delta = false;
                     const float ip = rcp(ds_pdf);
                     em_weight = mk(em.intensity[0] * ip, em.intensity[1] * ip, em.intensity[2] * ip);
+                } else if (SPEC && em.kind == EMITTER_ENVMAP) {   // EnvironmentMapEmitter::sample_direction (envmap.cpp:363-406)
+                    env_sample_direction(sv.base, em, si.p, sx, e2, dd, ds_dist, ds_pdf, em_weight, em_active);
+                    dsp = si.p + dd * ds_dist;
+                    ds_delta = false;
                 } else if (SPEC && em.kind == EMITTER_SPOT) {   // SpotLight::sample_direction (spot.cpp:152-187), falloff_curve (:116-126)
                     dsp = mk(em.pos[0], em.pos[1], em.pos[2]);
                     dd = dsp - si.p;

@@ -134,6 +134,23 @@ DTOF_HD float acos_(float x) {
     return big ? z3 : z4;
 }
 
+// dr::atan2 (Dr.Jit's source is not in the reference tree): minimax fit of atan(sqrt(z)) / sqrt(z) in z = (min / max)^2, Estrin form with
+// fmadd, unfolded by octant.  Used by the environment map's direction -> latitude-longitude lookup (envmap.cpp:303-306,414-416).
+DTOF_HD float atan2_(float y, float x) {
+    const float xa = fabsf(x), ya = fabsf(y), mn = ya < xa ? ya : xa, mx = xa > ya ? xa : ya;
+    const float scale = mn / mx, z = scale * scale;
+    const float z2 = z * z, z4 = z2 * z2;
+    const float p01 = fmaf(z, -0.33326497518773606976f, 0.99999934166683966009f), p23 = fmaf(z, -0.13486708938456973185f, 0.19881342388439013552f);
+    const float p45 = fmaf(z, -0.37006525670417265220e-1f, 0.83863120428809689910e-1f), p6 = 0.78613793713198150252e-2f;
+    const float poly = fmaf(z4, fmaf(z2, p6, p45), fmaf(z2, p23, p01));
+    float t = scale * poly;
+    t = ya > xa ? 0.5f * kPi - t : t;
+    t = x < 0.f ? kPi - t : t;
+    const float r = y < 0.f ? -t : t;
+    return mx != 0.f ? r : 0.f;
+}
+DTOF_HD float lerp_(float a, float b, float t) { return fmaf(b, t, fmaf(-a, t, a)); }   // dr::lerp = fmadd(b, t, fnmadd(a, t, a))
+
 // dr::detail::estrin_impl for 10 coefficients (what GaussianFilter::eval evaluates, src/rfilters/gaussian.cpp:94-96)
 DTOF_HD float estrin10(float x, const float *c) {
     float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;

@@ -345,12 +345,12 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     const uint8_t *blob = sc->d_blob.p; uint32_t blob_bytes = (uint32_t) sc->blob.size();
     const uint32_t stack_depth = ((const BlobHeader *) sc->blob.data())->tlas_depth;
     bool has_surface_emitters = false;          // area emitters make the emitter-hit term (and the last iteration) live
-    for (auto &e : sc->host.emitters) has_surface_emitters |= e.kind == EMITTER_AREA || e.kind == EMITTER_CONSTANT;   // the environment is "hit" by the rays that leave the scene
+    for (auto &e : sc->host.emitters) has_surface_emitters |= e.kind == EMITTER_AREA || e.kind == EMITTER_CONSTANT || e.kind == EMITTER_ENVMAP;   // the environment is "hit" by the rays that leave the scene
     rp.has_area = has_surface_emitters;
     for (auto &sh : sc->host.shapes) rp.has_spec |= sh.bsdf != BSDF_DIFFUSE;
     for (auto &e : sc->host.emitters) rp.has_spec |= e.kind == EMITTER_SPOT;
     rp.has_spec |= !sc->host.textures.empty();
-    for (size_t ei = 0; ei < sc->host.emitters.size(); ++ei) if (sc->host.emitters[ei].kind == EMITTER_CONSTANT) { rp.has_env = 1; rp.env_index = (uint32_t) ei; rp.has_spec = 1; }
+    for (size_t ei = 0; ei < sc->host.emitters.size(); ++ei) if (sc->host.emitters[ei].kind == EMITTER_CONSTANT || sc->host.emitters[ei].kind == EMITTER_ENVMAP) { rp.has_env = 1; rp.env_index = (uint32_t) ei; rp.has_spec = 1; }
     rp.hide_emitters = sc->pp.hide_emitters;   // textured reflectances are looked up in the SPEC instantiations only   // the spot branch lives in the SPEC instantiations (keeps the common kernels lean)
     bool has_spheres = false;
     for (auto &sh : sc->host.shapes) has_spheres |= sh.kind == SHAPE_SPHERE || sh.kind == SHAPE_DISK || sh.kind == SHAPE_CYLINDER;   // analytic shapes of the MESH instantiations
@@ -658,6 +658,27 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
             v.insert(v.end(), t.to_uv, t.to_uv + 4); v.insert(v.end(), t.color0, t.color0 + 3); v.insert(v.end(), t.color1, t.color1 + 3); v.push_back(t.mean);
         } else if (kind == 14) for (auto &t : sc->host.textures) v.insert(v.end(), t.data.begin(), t.data.end());
         else if (kind == 15) for (auto &s : sc->host.shapes) v.push_back((float) s.tex_refl);
+        else if (kind == 16) {   // the environment map as packed into the blob: header words, m_data, then every level of the hierarchical warp
+            const BlobHeader *bh = (const BlobHeader *) sc->blob.data();
+            const DEmitter *de = (const DEmitter *) (sc->blob.data() + bh->off_emitters);
+            for (uint32_t i = 0; i < bh->n_emitters; ++i) if (de[i].kind == EMITTER_ENVMAP) {
+                const DEnvmap *e = (const DEnvmap *) (sc->blob.data() + de[i].shape);
+                v.push_back((float) e->w); v.push_back((float) e->h); v.push_back((float) e->n_levels); v.push_back(e->scale);
+                v.insert(v.end(), de[i].pos, de[i].pos + 3); v.push_back(de[i].cutoff_angle);
+                v.insert(v.end(), e->to_world, e->to_world + 12); v.insert(v.end(), de[i].to_local, de[i].to_local + 12);
+                const float *d = (const float *) (sc->blob.data() + e->data_off);
+                v.insert(v.end(), d, d + (size_t) e->w * e->h * 3);
+                for (uint32_t k = 0; k < e->n_levels; ++k) {
+                    const uint32_t end = k + 1 < e->n_levels ? e->level_off[k + 1] : bh->total_bytes;
+                    const float *lv = (const float *) (sc->blob.data() + e->level_off[k]);
+                    size_t count = k == 0 ? (size_t) e->w * e->h : 0;
+                    if (k > 0) { uint32_t lx = e->w - 1, ly = e->h - 1; for (uint32_t j = 1; j <= k; ++j) { lx += lx & 1u; ly += ly & 1u; if (j < k) { lx >>= 1; ly >>= 1; } } count = (size_t) lx * ly; }
+                    (void) end;
+                    v.push_back((float) e->level_w[k]); v.push_back((float) count);
+                    v.insert(v.end(), lv, lv + count);
+                }
+            }
+        }
         else if (kind == 12) for (auto &s : sc->host.shapes) {
             v.push_back(s.beckmann ? 0.f : 1.f);
         } else if (kind == 10) for (auto &s : sc->host.shapes) {

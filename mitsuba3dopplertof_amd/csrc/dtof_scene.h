@@ -19,7 +19,7 @@ enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1, FILTER_GAUSSIAN = 2
 enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4, SF_EMITTER = 8, SF_BECKMANN = 16 /* rough BSDFs: Beckmann instead of GGX */,
                             SF_TEXCOORDS = 32 /* mesh with vertex texcoords (si.uv interpolates them; otherwise si.uv = the barycentrics, mesh.cpp:720-737) */ };
 enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4, BSDF_ROUGHPLASTIC = 5, BSDF_THINDIELECTRIC = 6, BSDF_ROUGHDIELECTRIC = 7 };
-enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1, EMITTER_SPOT = 2, EMITTER_CONSTANT = 3 };
+enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1, EMITTER_SPOT = 2, EMITTER_CONSTANT = 3, EMITTER_ENVMAP = 4 };
 
 // ---------------------------------------------------------------------------- device blob records
 // One contiguous byte blob (offsets from its base) so that small scenes can be staged
@@ -113,6 +113,19 @@ struct DEmitter {           // 96 B
     float to_local[12]; float cutoff_angle, cos_cutoff, cos_beam, inv_transition;
     // constant (src/emitters/constant.cpp): intensity = radiance, pos = centre of m_bsphere, cutoff_angle = its (enlarged) radius (set_scene, :73-83)
 };
+// EnvironmentMapEmitter (src/emitters/envmap.cpp) in the tables area: m_data (h rows of w = bitmap width + 1 RGB texels) and the levels of its
+// Hierarchical2D<Float, 0> warp (include/mitsuba/core/distr_2d.h:376-482; level 0 = the normalised luminance x sin(theta) grid, level k >= 1 in
+// 2 x 2-block order, Level::index :766-770).  DEmitter::shape holds the byte offset of this record in the blob; pos / cutoff_angle the bounding
+// sphere as for `constant`; to_local the world -> emitter rotation.
+constexpr uint32_t kEnvMaxLevels = 24;
+struct DEnvmap {
+    uint32_t w, h, n_levels, data_off;                       // data_off and level_off: byte offsets in the blob
+    float scale, patch_x, patch_y, inv_patch_x;
+    float inv_patch_y; uint32_t max_px, max_py, pad;
+    float to_world[12];
+    uint32_t level_off[kEnvMaxLevels], level_w[kEnvMaxLevels];
+};
+static_assert(sizeof(DEnvmap) % 16 == 0, "DEnvmap");
 static_assert(sizeof(BvhNode4) == 128, "BvhNode4");
 static_assert(sizeof(DTexture) == 64, "DTexture");
 static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 304 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64 && sizeof(DEmitter) == 96, "blob records");
@@ -152,7 +165,8 @@ struct HostObject {
     float key[2][16];
 };
 struct HostEmitter { uint32_t kind = 0; float pos[3] = { 0, 0, 0 }; float intensity[3] = { 0, 0, 0 }; uint32_t shape = 0xffffffffu;
-                     float to_local[12] = { 0 }, cutoff_angle = 0, cos_cutoff = 0, cos_beam = 0, inv_transition = 0; };   // spot
+                     float to_local[12] = { 0 }, cutoff_angle = 0, cos_cutoff = 0, cos_beam = 0, inv_transition = 0;    // spot
+                     std::vector<float> image; uint32_t image_w = 0, image_h = 0; float scale = 1.f, to_world[12] = { 0 }; };   // envmap: linear RGB rows (top first), m_scale, emitter -> world
 struct HostSensor {
     float to_world[16];
     float x_fov = 0, near_clip = 1e-2f, far_clip = 1e4f, shutter_open = 0, shutter_close = 0;
@@ -194,6 +208,7 @@ struct PluginParams {
     uint32_t base_seed = 0, sample_count = 4; int32_t time_correlate_number = 2, path_correlate_number = 2;
 };
 void read_png(const std::string &path, std::vector<uint8_t> &pixels, uint32_t &width, uint32_t &height, uint32_t &channels);   // image_io.cpp
+void read_radiance_image(const std::string &path, std::vector<float> &rgb, uint32_t &width, uint32_t &height, float (*srgb_to_linear_u8)(uint32_t));   // image_io.cpp: RGBE, PFM, PNG
 PluginParams make_plugin_params(const PropBag &integrator, const PropBag &sampler);   // throws std::runtime_error
 
 struct HostScene {

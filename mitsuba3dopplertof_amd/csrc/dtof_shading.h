@@ -317,4 +317,111 @@ DTOF_D float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
 }
 DTOF_D float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
+
+// ---------------------------------------------------------------------------- environment map (src/emitters/envmap.cpp, rgb)
+// Hierarchical2D<Float, 0> (include/mitsuba/core/distr_2d.h): sample :490-575, eval :668-699; bilinear warps warp.h:355-429.
+DTOF_D uint32_t env_level_index(uint32_t x, uint32_t y, uint32_t width) { return ((x & 1u) | (((x & ~1u) | (y & 1u)) << 1)) + ((y & ~1u) * width); }
+DTOF_D float clamp01(float x) { return fmin_(fmax_(x, 0.f), 1.f); }
+DTOF_D float interval_to_linear(float v0, float v1, float sample) {
+    const float val = (v0 - safe_sqrt(lerp_(sqr(v0), sqr(v1), sample))) / (v0 - v1);
+    return fabsf(v0 - v1) > 1e-4f * (v0 + v1) ? val : sample;
+}
+DTOF_D void env_warp_sample(const uint8_t *base, const DEnvmap &e, float sx, float sy, float &ux, float &uy, float &pdf) {
+    sx = clamp01(sx); sy = clamp01(sy);
+    uint32_t ox = 0, oy = 0;
+    for (int l = (int) e.n_levels - 2; l > 0; --l) {
+        ox <<= 1; oy <<= 1;
+        const float4 v = *(const float4 *) ((const float *) (base + e.level_off[l]) + env_level_index(ox, oy, e.level_w[l]));   // one 2 x 2 block = 16 contiguous bytes
+        const float v00 = v.x, v10 = v.y, v01 = v.z, v11 = v.w;
+        sx = clamp01(sx); sy = clamp01(sy);
+        const float r0 = v00 + v10, r1 = v01 + v11;
+        sy *= r0 + r1;
+        bool mask = sy > r0;
+        if (mask) { oy += 1u; sy -= r0; }
+        sy /= mask ? r1 : r0;
+        const float c0 = mask ? v01 : v00, c1 = mask ? v11 : v10;
+        sx *= c0 + c1;
+        mask = sx > c0;
+        if (mask) sx -= c0;
+        sx /= mask ? c1 : c0;
+        if (mask) ox += 1u;
+    }
+    const uint32_t W = e.level_w[0], i = ox + oy * W;
+    const float *L = (const float *) (base + e.level_off[0]);
+    const float v00 = L[i], v10 = L[i + 1u], v01 = L[i + W], v11 = L[i + W + 1u];
+    const float r0 = v00 + v10, r1 = v01 + v11;   // warp::square_to_bilinear
+    sy = interval_to_linear(r0, r1, sy);
+    const float c0 = lerp_(v00, v01, sy), c1 = lerp_(v10, v11, sy);
+    sx = interval_to_linear(c0, c1, sx);
+    pdf = lerp_(c0, c1, sx);
+    ux = ((float) (int32_t) ox + sx) * e.patch_x; uy = ((float) (int32_t) oy + sy) * e.patch_y;
+}
+DTOF_D float env_warp_eval(const uint8_t *base, const DEnvmap &e, float x, float y) {
+    x = clamp01(x) * e.inv_patch_x; y = clamp01(y) * e.inv_patch_y;
+    uint32_t ox = (uint32_t) (int32_t) x, oy = (uint32_t) (int32_t) y;
+    if (ox > e.max_px) ox = e.max_px;
+    if (oy > e.max_py) oy = e.max_py;
+    x -= (float) (int32_t) ox; y -= (float) (int32_t) oy;
+    const uint32_t W = e.level_w[0], i = ox + oy * W;
+    const float *L = (const float *) (base + e.level_off[0]);
+    return lerp_(lerp_(L[i], L[i + 1u], x), lerp_(L[i + W], L[i + W + 1u], x), y);   // square_to_bilinear_pdf
+}
+// eval_spectrum (envmap.cpp:487-553)
+DTOF_D V3 env_eval_uv(const uint8_t *base, const DEnvmap &e, float u, float v) {
+    const uint32_t rx = e.w, ry = e.h;
+    u -= .5f / (float) (rx - 1u);
+    u -= floorf(u); v -= floorf(v);
+    u *= (float) (rx - 1u); v *= (float) (ry - 1u);
+    uint32_t px = (uint32_t) u, py = (uint32_t) v;
+    if (px > rx - 2u) px = rx - 2u;
+    if (py > ry - 2u) py = ry - 2u;
+    const float w1x = u - (float) px, w1y = v - (float) py, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    const float *d = (const float *) (base + e.data_off) + 3u * (py * rx + px);
+    float out[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v00 = d[c], v10 = d[3 + c], v01 = d[3u * rx + c], v11 = d[3u * rx + 3 + c];
+        const float a = fmaf(w0x, v00, w1x * v10), b = fmaf(w0x, v01, w1x * v11);
+        out[c] = fmaf(w0y, a, w1y * b) * e.scale;
+    }
+    return mk(out[0], out[1], out[2]);
+}
+constexpr float kEpsilonF = 5.9604644775390625e-8f;   // dr::Epsilon<float> = 2^-24
+DTOF_D void env_dir_to_uv(V3 d, float &u, float &v) { u = atan2_(d.x, -d.z) * kInvTwoPi; v = acos_(fmin_(fmax_(d.y, -1.f), 1.f)) * kInvPi; }
+DTOF_D float env_inv_sin_theta(V3 d) { return rsqrt_(fmax_(fmax_(sqr(d.x) + sqr(d.z), sqr(kEpsilonF)), 0.f)); }
+// EnvironmentMapEmitter::eval (:299-310): d = -si.wi, the direction of the ray that left the scene
+DTOF_D V3 env_eval(const uint8_t *base, const DEmitter &em, V3 d) {
+    const DEnvmap &e = *(const DEnvmap *) (base + em.shape);
+    float u, v; env_dir_to_uv(xf_vector(em.to_local, d), u, v);
+    return env_eval_uv(base, e, u, v);
+}
+// pdf_direction (:408-425)
+DTOF_D float env_pdf_direction(const uint8_t *base, const DEmitter &em, V3 dw) {
+    const DEnvmap &e = *(const DEnvmap *) (base + em.shape);
+    const V3 d = xf_vector(em.to_local, dw);
+    float u, v; env_dir_to_uv(d, u, v);
+    u -= .5f / (float) (e.w - 1u);
+    u -= floorf(u); v -= floorf(v);
+    return env_warp_eval(base, e, u, v) * env_inv_sin_theta(d) * (1.f / (2.f * sqr(kPi)));
+}
+// sample_direction (:363-406)
+DTOF_D void env_sample_direction(const uint8_t *base, const DEmitter &em, V3 ref_p, float sx, float sy, V3 &d_out, float &dist, float &pdf_out, V3 &weight, bool &active) {
+    const DEnvmap &e = *(const DEnvmap *) (base + em.shape);
+    float u, v, pdf; env_warp_sample(base, e, sx, sy, u, v, pdf);
+    u += .5f / (float) (e.w - 1u);
+    active = pdf > 0.f;
+    const float theta = v * kPi, phi = u * (2.f * kPi);
+    float st, ct, sp, cp; sincos_(theta, st, ct); sincos_(phi, sp, cp);
+    V3 d = mk(cp * st, sp * st, ct);   // dr::sphdir
+    d = mk(d.y, d.z, -d.x);
+    const float radius = fmax_(em.cutoff_angle, norm(ref_p - mk(em.pos[0], em.pos[1], em.pos[2])));
+    dist = 2.f * radius;
+    const float ist = env_inv_sin_theta(d);
+    d_out = xf_vector(e.to_world, d);
+    pdf_out = active ? pdf * ist * (1.f / (2.f * sqr(kPi))) : 0.f;
+    const V3 rad = env_eval_uv(base, e, u, v);
+    const float ip = rcp(pdf_out);
+    weight = active ? mk(rad.x * ip, rad.y * ip, rad.z * ip) : mk(0, 0, 0);
+}
+
 }  // namespace dtof

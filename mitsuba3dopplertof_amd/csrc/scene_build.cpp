@@ -385,6 +385,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     }
 #endif
     // ---- emitters
+    std::vector<uint32_t> env_records;   // emitters whose `shape` is the table offset of a DEnvmap
     std::vector<DEmitter> emitters(sc.emitters.size());
     for (size_t i = 0; i < sc.emitters.size(); ++i) {
         emitters[i].kind = sc.emitters[i].kind; emitters[i].shape = sc.emitters[i].shape;
@@ -392,7 +393,65 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         memcpy(emitters[i].to_local, sc.emitters[i].to_local, 48);
         emitters[i].cutoff_angle = sc.emitters[i].cutoff_angle; emitters[i].cos_cutoff = sc.emitters[i].cos_cutoff;
         emitters[i].cos_beam = sc.emitters[i].cos_beam; emitters[i].inv_transition = sc.emitters[i].inv_transition;
-        if (sc.emitters[i].kind == EMITTER_CONSTANT) { memcpy(emitters[i].pos, env_sphere, 12); emitters[i].cutoff_angle = env_sphere[3]; }
+        if (sc.emitters[i].kind == EMITTER_CONSTANT || sc.emitters[i].kind == EMITTER_ENVMAP) { memcpy(emitters[i].pos, env_sphere, 12); emitters[i].cutoff_angle = env_sphere[3]; }
+        if (sc.emitters[i].kind == EMITTER_ENVMAP) {
+            // EnvironmentMapEmitter's constructor (envmap.cpp:130-224): a periodic extra column, luminance x sin(theta) as the sampling density, and the
+            // Hierarchical2D<Float, 0> built over it (distr_2d.h:376-482): level 0 = the normalised grid, level 1 = patch averages, then 2 x 2 sums
+            const HostEmitter &he = sc.emitters[i];
+            const uint32_t bw = he.image_w, W = bw + 1, H = he.image_h;
+            std::vector<float> data((size_t) W * H * 3), lum((size_t) W * H);
+            const float theta_scale = 1.f / (float) (H - 1) * kPi;
+            for (uint32_t y = 0; y < H; ++y) {
+                const float sin_theta = sinf((float) y * theta_scale);   // ScalarFloat dr::sin
+                for (uint32_t x = 0; x < bw; ++x) {
+                    const float *in = &he.image[((size_t) y * bw + x) * 3];
+                    const float l = fmax_(in[0] * 0.212671f + in[1] * 0.715160f + in[2] * 0.072169f, 0.f);   // mitsuba::luminance (spectrum.h:431-434)
+                    lum[(size_t) y * W + x] = l * sin_theta;
+                    memcpy(&data[((size_t) y * W + x) * 3], in, 12);
+                }
+                lum[(size_t) y * W + bw] = lum[(size_t) y * W];
+                memcpy(&data[((size_t) y * W + bw) * 3], &data[(size_t) y * W * 3], 12);
+            }
+            const uint32_t npx = W - 1, npy = H - 1;
+            uint32_t max_level = 0; { const uint32_t v = std::max(npx, npy); while ((1u << max_level) < v) ++max_level; }   // math::log2i_ceil
+            if (max_level + 2 > kEnvMaxLevels) throw std::runtime_error("envmap: the image is too large");
+            auto index_of = [](uint32_t x, uint32_t y, uint32_t width) { return ((x & 1u) | (((x & ~1u) | (y & 1u)) << 1)) + ((y & ~1u) * width); };
+            std::vector<std::vector<float>> levels(max_level + 2); std::vector<uint32_t> level_w(max_level + 2);
+            levels[0].assign((size_t) W * H, 0.f); level_w[0] = W;
+            { uint32_t lx = npx, ly = npy; for (uint32_t k = 1; k <= max_level + 1; ++k) { lx += lx & 1u; ly += ly & 1u; levels[k].assign((size_t) lx * ly, 0.f); level_w[k] = lx; lx >>= 1; ly >>= 1; } }
+            double sum = 0.0;
+            for (uint32_t y = 0; y < npy; ++y) for (uint32_t x = 0; x < npx; ++x) {
+                const float *in = &lum[(size_t) y * W + x];
+                const float avg = .25f * (in[0] + in[1] + in[W] + in[W + 1]);
+                sum += (double) avg;
+                levels[1][index_of(x, y, level_w[1])] = avg;
+            }
+            const float norm = (float) ((double) (npx * npy) / sum);
+            for (size_t k = 0; k < lum.size(); ++k) levels[0][k] = lum[k] * norm;
+            for (float &v : levels[1]) v *= norm;
+            { uint32_t lx = npx, ly = npy;
+              for (uint32_t level = 2; level <= max_level + 1; ++level) {
+                  lx = (lx + 1) >> 1; ly = (ly + 1) >> 1;
+                  for (uint32_t y = 0; y < ly; ++y) for (uint32_t x = 0; x < lx; ++x) {
+                      const float *d0 = &levels[level - 1][index_of(x * 2, y * 2, level_w[level - 1])];
+                      levels[level][index_of(x, y, level_w[level])] = d0[0] + d0[1] + d0[2] + d0[3];
+                  }
+              } }
+            DEnvmap rec; memset(&rec, 0, sizeof rec);
+            rec.w = W; rec.h = H; rec.n_levels = max_level + 2; rec.scale = he.scale;
+            rec.patch_x = 1.f / (float) npx; rec.patch_y = 1.f / (float) npy; rec.inv_patch_x = (float) npx; rec.inv_patch_y = (float) npy;
+            rec.max_px = npx - 1; rec.max_py = npy - 1;
+            memcpy(rec.to_world, he.to_world, 48);
+            while (tables.size() % 4) tables.push_back(0);
+            const uint32_t rec_word = (uint32_t) tables.size();
+            tables.resize(tables.size() + sizeof(DEnvmap) / 4);
+            auto append = [&](const std::vector<float> &v) { while (tables.size() % 4) tables.push_back(0); const uint32_t at = (uint32_t) tables.size() * 4u; for (float f : v) { uint32_t b; memcpy(&b, &f, 4); tables.push_back(b); } return at; };
+            rec.data_off = append(data);
+            for (uint32_t k = 0; k < rec.n_levels; ++k) { rec.level_off[k] = append(levels[k]); rec.level_w[k] = level_w[k]; }
+            memcpy(&tables[rec_word], &rec, sizeof rec);
+            emitters[i].shape = rec_word * 4u;   // rebased to a blob offset (and the offsets inside the record with it) once off_tables is known
+            env_records.push_back((uint32_t) i);
+        }
     }
     // ---- pack: nodes first (so that "the first N bytes" = header + top of the TLAS in BFS-ish order)
     BlobHeader h; memset(&h, 0, sizeof h);
@@ -424,6 +483,12 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     h.total_bytes = off;
     for (DShape &d : shapes) if (d.kind == SHAPE_MESH && (d.flags & SF_EMITTER)) d.emit_table += h.off_tables;
     for (DShape &d : shapes) if (d.bsdf == BSDF_ROUGHPLASTIC) d.rough_table += h.off_tables;
+    for (uint32_t ei : env_records) {
+        DEnvmap *rec = (DEnvmap *) &tables[emitters[ei].shape / 4u];
+        rec->data_off += h.off_tables;
+        for (uint32_t k = 0; k < rec->n_levels; ++k) rec->level_off[k] += h.off_tables;
+        emitters[ei].shape += h.off_tables;
+    }
     for (auto &tr : tex_recs) {   // reflectance textures: record offset (>> 4) beside the `nonlinear` bit, texel offset inside the record
         const uint32_t rec_off = h.off_tables + tr.second * 4u;
         shapes[tr.first].nonlinear |= (rec_off >> 4) << 1;

@@ -972,14 +972,28 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
             if (have_sensor) fail("only one sensor is supported");
             make_sensor(o, sc); have_sensor = true;
         } else if (o.tag == "emitter") {
-            if (o.plugin != "point" && o.plugin != "spot" && o.plugin != "constant") fail("unsupported emitter plugin \"" + o.plugin + "\" (supported: point, spot, constant; area inside a shape)");
+            if (o.plugin != "point" && o.plugin != "spot" && o.plugin != "constant" && o.plugin != "envmap") fail("unsupported emitter plugin \"" + o.plugin + "\" (supported: point, spot, constant, envmap; area inside a shape)");
             HostEmitter e; e.kind = 0;
             if (o.plugin == "constant") {   // src/emitters/constant.cpp:58-67: the scene's environment (scene.cpp:53-57); its bounding sphere follows in build_scene_blob
-                for (auto &pe : sc.emitters) if (pe.kind == EMITTER_CONSTANT) fail("Only one environment emitter can be specified per scene.");
+                for (auto &pe : sc.emitters) if (pe.kind == EMITTER_CONSTANT || pe.kind == EMITTER_ENVMAP) fail("Only one environment emitter can be specified per scene.");
                 e.kind = EMITTER_CONSTANT;
                 auto rc = o.colors.find("radiance");
                 if (rc != o.colors.end()) for (int i = 0; i < 3; ++i) e.intensity[i] = (float) rc->second[i];
                 else { float v = (float) o.props.get_float("radiance", 1.0); e.intensity[0] = e.intensity[1] = e.intensity[2] = v; }
+            } else if (o.plugin == "envmap") {   // src/emitters/envmap.cpp:116-224; tables and bounding sphere follow in build_scene_blob
+                for (auto &pe : sc.emitters) if (pe.kind == EMITTER_CONSTANT || pe.kind == EMITTER_ENVMAP) fail("Only one environment emitter can be specified per scene.");
+                e.kind = EMITTER_ENVMAP;
+                const std::string fn = o.props.get_string("filename", "");
+                if (fn.empty()) fail("Property \"filename\" has not been specified!");
+                if (o.props.get_bool("mis_compensation", false)) fail("envmap: \"mis_compensation\" is not supported");
+                const std::string path = fn[0] == '/' || base_dir.empty() ? fn : base_dir + "/" + fn;
+                read_radiance_image(path, e.image, e.image_w, e.image_h, srgb_to_linear_u8);
+                if (e.image_w < 2 || e.image_h < 3) fail("\"" + fn.substr(fn.find_last_of('/') == std::string::npos ? 0 : fn.find_last_of('/') + 1) + "\": the environment map resolution must be at least 2x3 pixels");
+                e.scale = (float) o.props.get_float("scale", 1.0);
+                auto tws = o.transforms.find("to_world");
+                Xf xf; if (tws != o.transforms.end()) xf = tws->second; else { xf.m = m_identity(); xf.inv = m_identity(); }
+                float m[16], inv[16]; to_f32(xf.m, m); to_f32(xf.inv, inv);
+                for (int k = 0; k < 12; ++k) { e.to_world[k] = m[k]; e.to_local[k] = inv[k]; }
             } else if (o.plugin == "spot") {   // src/emitters/spot.cpp:75-100; position = translation of to_world, axis = its +z
                 e.kind = EMITTER_SPOT;
                 auto tws = o.transforms.find("to_world");

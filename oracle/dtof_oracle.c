@@ -142,6 +142,213 @@ float orc_acos(float x) {
     float z2 = 2.f * z1, z3 = x < 0.f ? ORC_PI_F - z2 : z2, z4 = 0.5f * ORC_PI_F - z1;
     return big ? z3 : z4;
 }
+
+/* dr::atan2 (Dr.Jit 0.4 math.h; the submodule is empty in the reference tree): minimax fit of atan(sqrt(z)) / sqrt(z) in z = (min / max)^2,
+ * evaluated in Estrin form with fmadd, then unfolded by octant. */
+float orc_atan2f(float y, float x) {
+    const float xa = fabsf(x), ya = fabsf(y), mn = ya < xa ? ya : xa, mx = xa > ya ? xa : ya;
+    const float scale = mn / mx, z = scale * scale;
+    const float z2 = z * z, z4 = z2 * z2;
+    const float p01 = fmaf(z, -0.33326497518773606976f, 0.99999934166683966009f), p23 = fmaf(z, -0.13486708938456973185f, 0.19881342388439013552f);
+    const float p45 = fmaf(z, -0.37006525670417265220e-1f, 0.83863120428809689910e-1f), p6 = 0.78613793713198150252e-2f;
+    const float poly = fmaf(z4, fmaf(z2, p6, p45), fmaf(z2, p23, p01));
+    float t = scale * poly;
+    t = ya > xa ? 0.5f * ORC_PI_F - t : t;
+    t = x < 0.f ? ORC_PI_F - t : t;
+    float r = y < 0.f ? -t : t;
+    return mx != 0.f ? r : 0.f;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------- envmap
+ * EnvironmentMapEmitter (src/emitters/envmap.cpp) in the rgb variant: the constructor (:130-224: periodic column, luminance x sin(theta),
+ * Hierarchical2D), eval (:299-310), sample_direction (:363-406), pdf_direction (:408-425), eval_spectrum (:487-553); Hierarchical2D<Float, 0>
+ * (include/mitsuba/core/distr_2d.h: constructor :376-482, sample :490-575, eval :668-699, Level::index :766-770) and the bilinear warps
+ * (include/mitsuba/core/warp.h:355-429). */
+static inline uint32_t env_level_index(uint32_t x, uint32_t y, uint32_t width) { return ((x & 1u) | (((x & ~1u) | (y & 1u)) << 1)) + ((y & ~1u) * width); }
+static inline float f_lerp(float a, float b, float t) { return fmaf(b, t, fmaf(-a, t, a)); }   /* dr::lerp = fmadd(b, t, fnmadd(a, t, a)) */
+static inline float f_clamp01(float x) { return f_min(f_max(x, 0.f), 1.f); }
+static inline float interval_to_linear(float v0, float v1, float sample) {
+    const float val = (v0 - sqrtf(f_max(f_lerp(f_sqr(v0), f_sqr(v1), sample), 0.f))) / (v0 - v1);
+    return fabsf(v0 - v1) > 1e-4f * (v0 + v1) ? val : sample;
+}
+static uint32_t log2i_ceil_u32(uint32_t v) { uint32_t r = 31u - (uint32_t) __builtin_clz(v); if (v & (v - 1u)) r += 1u; return r; }
+
+orc_envmap *orc_envmap_create(const float *rgb, int32_t width, int32_t height, float scale) {
+    if (width < 2 || height < 3) return NULL;
+    orc_envmap *e = (orc_envmap *) calloc(1, sizeof *e);
+    const uint32_t W = (uint32_t) width + 1u, H = (uint32_t) height;
+    e->w = (int32_t) W; e->h = (int32_t) H; e->scale = scale;
+    e->data = (float *) malloc(sizeof(float) * 3u * W * H);
+    float *lum = (float *) malloc(sizeof(float) * W * H);
+    const float theta_scale = 1.f / (float) (H - 1u) * ORC_PI_F;
+    for (uint32_t y = 0; y < H; ++y) {
+        const float sin_theta = sinf((float) y * theta_scale);
+        for (uint32_t x = 0; x < (uint32_t) width; ++x) {
+            const float *in = rgb + 3u * (y * (uint32_t) width + x);
+            float l = in[0] * 0.212671f + in[1] * 0.715160f + in[2] * 0.072169f;   /* mitsuba::luminance (spectrum.h:431-434) */
+            l = f_max(l - 0.f, 0.f);
+            lum[y * W + x] = l * sin_theta;
+            memcpy(e->data + 3u * (y * W + x), in, 12);
+        }
+        lum[y * W + (W - 1u)] = lum[y * W];                                      /* the last column mirrors the first */
+        memcpy(e->data + 3u * (y * W + (W - 1u)), e->data + 3u * (y * W), 12);
+    }
+    /* Hierarchical2D(data, size) */
+    const uint32_t npx = W - 1u, npy = H - 1u, max_level = log2i_ceil_u32(npx > npy ? npx : npy);
+    e->patch_size[0] = 1.f / (float) npx; e->patch_size[1] = 1.f / (float) npy;
+    e->inv_patch_size[0] = (float) npx; e->inv_patch_size[1] = (float) npy;
+    e->max_patch[0] = npx - 1u; e->max_patch[1] = npy - 1u;
+    e->n_levels = (int32_t) max_level + 2;
+    e->level_w[0] = (int32_t) W; e->level_size[0] = (int32_t) (W * H);
+    e->level[0] = (float *) calloc((size_t) W * H, sizeof(float));
+    {
+        uint32_t lx = npx, ly = npy; int32_t k = 1;
+        for (int32_t level = (int32_t) max_level; level >= 0; --level, ++k) {
+            lx += lx & 1u; ly += ly & 1u;
+            e->level_w[k] = (int32_t) lx; e->level_size[k] = (int32_t) (lx * ly);
+            e->level[k] = (float *) calloc((size_t) lx * ly, sizeof(float));
+            lx >>= 1; ly >>= 1;
+        }
+    }
+    double sum = 0.0;
+    for (uint32_t y = 0; y < npy; ++y)
+        for (uint32_t x = 0; x < npx; ++x) {
+            const float *in = lum + y * W + x;
+            const float avg = .25f * (in[0] + in[1] + in[W] + in[W + 1u]);
+            sum += (double) avg;
+            e->level[1][env_level_index(x, y, (uint32_t) e->level_w[1])] = avg;
+        }
+    const float norm = (float) ((double) (npx * npy) / sum);
+    for (uint32_t i = 0; i < W * H; ++i) e->level[0][i] = lum[i] * norm;
+    for (int32_t i = 0; i < e->level_size[1]; ++i) e->level[1][i] *= norm;
+    {
+        uint32_t lx = npx, ly = npy;
+        for (uint32_t level = 2; level <= max_level + 1u; ++level) {
+            lx = (lx + 1u) >> 1; ly = (ly + 1u) >> 1;
+            for (uint32_t y = 0; y < ly; ++y)
+                for (uint32_t x = 0; x < lx; ++x) {
+                    const float *d0 = e->level[level - 1u] + env_level_index(x * 2u, y * 2u, (uint32_t) e->level_w[level - 1u]);
+                    e->level[level][env_level_index(x, y, (uint32_t) e->level_w[level])] = d0[0] + d0[1] + d0[2] + d0[3];
+                }
+        }
+    }
+    free(lum);
+    return e;
+}
+void orc_envmap_free(orc_envmap *e) {
+    if (!e) return;
+    for (int32_t i = 0; i < e->n_levels; ++i) free(e->level[i]);
+    free(e->data); free(e);
+}
+/* Hierarchical2D::sample (distr_2d.h:490-575) */
+static void env_warp_sample(const orc_envmap *e, float sx, float sy, float *ux, float *uy, float *pdf) {
+    sx = f_clamp01(sx); sy = f_clamp01(sy);
+    uint32_t ox = 0, oy = 0;
+    for (int32_t l = e->n_levels - 2; l > 0; --l) {
+        ox <<= 1; oy <<= 1;
+        const float *v = e->level[l] + env_level_index(ox, oy, (uint32_t) e->level_w[l]);
+        const float v00 = v[0], v10 = v[1], v01 = v[2], v11 = v[3];
+        sx = f_clamp01(sx); sy = f_clamp01(sy);
+        const float r0 = v00 + v10, r1 = v01 + v11;
+        sy *= r0 + r1;
+        int mask = sy > r0;
+        if (mask) { oy += 1u; sy -= r0; }
+        sy /= mask ? r1 : r0;
+        const float c0 = mask ? v01 : v00, c1 = mask ? v11 : v10;
+        sx *= c0 + c1;
+        mask = sx > c0;
+        if (mask) sx -= c0;
+        sx /= mask ? c1 : c0;
+        if (mask) ox += 1u;
+    }
+    const uint32_t W = (uint32_t) e->level_w[0], i = ox + oy * W;
+    const float *L = e->level[0];
+    const float v00 = L[i], v10 = L[i + 1u], v01 = L[i + W], v11 = L[i + W + 1u];
+    /* warp::square_to_bilinear (warp.h:388-402) */
+    const float r0 = v00 + v10, r1 = v01 + v11;
+    sy = interval_to_linear(r0, r1, sy);
+    const float c0 = f_lerp(v00, v01, sy), c1 = f_lerp(v10, v11, sy);
+    sx = interval_to_linear(c0, c1, sx);
+    *pdf = f_lerp(c0, c1, sx);
+    *ux = ((float) (int32_t) ox + sx) * e->patch_size[0]; *uy = ((float) (int32_t) oy + sy) * e->patch_size[1];
+}
+/* Hierarchical2D::eval (distr_2d.h:668-699) */
+static float env_warp_eval(const orc_envmap *e, float x, float y) {
+    x = f_clamp01(x) * e->inv_patch_size[0]; y = f_clamp01(y) * e->inv_patch_size[1];
+    uint32_t ox = (uint32_t) (int32_t) x, oy = (uint32_t) (int32_t) y;
+    if (ox > e->max_patch[0]) ox = e->max_patch[0];
+    if (oy > e->max_patch[1]) oy = e->max_patch[1];
+    x -= (float) (int32_t) ox; y -= (float) (int32_t) oy;
+    const uint32_t W = (uint32_t) e->level_w[0], i = ox + oy * W;
+    const float *L = e->level[0];
+    return f_lerp(f_lerp(L[i], L[i + 1u], x), f_lerp(L[i + W], L[i + W + 1u], x), y);   /* square_to_bilinear_pdf */
+}
+/* eval_spectrum (envmap.cpp:487-553), rgb */
+static v3 env_eval_uv(const orc_envmap *e, float u, float v) {
+    const uint32_t rx = (uint32_t) e->w, ry = (uint32_t) e->h;
+    u -= .5f / (float) (rx - 1u);
+    u -= floorf(u); v -= floorf(v);
+    u *= (float) (rx - 1u); v *= (float) (ry - 1u);
+    uint32_t px = (uint32_t) u, py = (uint32_t) v;
+    if (px > rx - 2u) px = rx - 2u;
+    if (py > ry - 2u) py = ry - 2u;
+    const float w1x = u - (float) px, w1y = v - (float) py, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    const float *d = e->data + 3u * (py * rx + px);
+    float out[3];
+    for (int c = 0; c < 3; ++c) {
+        const float v00 = d[c], v10 = d[3 + c], v01 = d[3u * rx + c], v11 = d[3u * rx + 3 + c];
+        const float a = fmaf(w0x, v00, w1x * v10), b = fmaf(w0x, v01, w1x * v11);
+        out[c] = fmaf(w0y, a, w1y * b) * e->scale;
+    }
+    return V(out[0], out[1], out[2]);
+}
+#define ORC_INV_PI_F      0.31830988618379067154f
+#define ORC_INV_TWO_PI_F  0.15915494309189533577f
+#define ORC_EPSILON_F     5.9604644775390625e-8f   /* dr::Epsilon<float> = 2^-24 */
+static inline float orc_safe_acos(float x) { return orc_acos(f_min(f_max(x, -1.f), 1.f)); }
+static inline void env_dir_to_uv(v3 d, float *u, float *v) { *u = orc_atan2f(d.x, -d.z) * ORC_INV_TWO_PI_F; *v = orc_safe_acos(d.y) * ORC_INV_PI_F; }
+static inline float env_inv_sin_theta(v3 d) { return f_rsqrt(f_max(f_max(f_sqr(d.x) + f_sqr(d.z), f_sqr(ORC_EPSILON_F)), 0.f)); }
+/* EnvironmentMapEmitter::eval (envmap.cpp:299-310): d = -si.wi = the direction of the ray that left the scene */
+static v3 env_eval(const orc_emitter *em, v3 d) {
+    const v3 l = m_vector(em->to_local, d);
+    float u, v; env_dir_to_uv(l, &u, &v);
+    return env_eval_uv(em->envmap, u, v);
+}
+/* pdf_direction (:408-425) */
+static float env_pdf_direction(const orc_emitter *em, v3 dw) {
+    const v3 d = m_vector(em->to_local, dw);
+    float u, v; env_dir_to_uv(d, &u, &v);
+    u -= .5f / (float) ((uint32_t) em->envmap->w - 1u);
+    u -= floorf(u); v -= floorf(v);
+    return env_warp_eval(em->envmap, u, v) * env_inv_sin_theta(d) * (1.f / (2.f * f_sqr(ORC_PI_F)));
+}
+/* sample_direction (:363-406); *active = pdf > 0 */
+static void env_sample_direction(const orc_emitter *em, v3 ref_p, float sx, float sy, v3 *d_out, float *dist, float *pdf_out, v3 *weight, int *active) {
+    float u, v, pdf; env_warp_sample(em->envmap, sx, sy, &u, &v, &pdf);
+    u += .5f / (float) ((uint32_t) em->envmap->w - 1u);
+    *active = pdf > 0.f;
+    const float theta = v * ORC_PI_F, phi = u * (2.f * ORC_PI_F);
+    float st, ct, sp, cp; orc_sincos(theta, &st, &ct); orc_sincos(phi, &sp, &cp);
+    v3 d = V(cp * st, sp * st, ct);          /* dr::sphdir */
+    d = V(d.y, d.z, -d.x);
+    const float radius = f_max(em->bsphere[3], v_norm(v_sub(ref_p, V(em->bsphere[0], em->bsphere[1], em->bsphere[2]))));
+    *dist = 2.f * radius;
+    const float ist = env_inv_sin_theta(d);
+    *d_out = m_vector(em->env_to_world, d);
+    *pdf_out = *active ? pdf * ist * (1.f / (2.f * f_sqr(ORC_PI_F))) : 0.f;
+    const v3 rad = env_eval_uv(em->envmap, u, v);
+    const float ip = f_rcp(*pdf_out);         /* Spectrum / Float: multiplication by the reciprocal */
+    *weight = *active ? V(rad.x * ip, rad.y * ip, rad.z * ip) : V(0, 0, 0);
+}
+void orc_envmap_warp_sample(const orc_envmap *e, float sx, float sy, float *out) { env_warp_sample(e, sx, sy, &out[0], &out[1], &out[2]); }
+float orc_envmap_warp_eval(const orc_envmap *e, float x, float y) { return env_warp_eval(e, x, y); }
+void orc_envmap_sample_direction(const orc_emitter *em, const float *p, float sx, float sy, float *out) {
+    v3 d, w; float dist, pdf; int active;
+    env_sample_direction(em, V(p[0], p[1], p[2]), sx, sy, &d, &dist, &pdf, &w, &active);
+    out[0] = d.x; out[1] = d.y; out[2] = d.z; out[3] = dist; out[4] = pdf; out[5] = w.x; out[6] = w.y; out[7] = w.z;
+}
+float orc_envmap_pdf_direction(const orc_emitter *em, const float *d) { return env_pdf_direction(em, V(d[0], d[1], d[2])); }
+void orc_envmap_eval(const orc_emitter *em, const float *d, float *rgb) { v3 r = env_eval(em, V(d[0], d[1], d[2])); rgb[0] = r.x; rgb[1] = r.y; rgb[2] = r.z; }
 /* ------------------------------------------------------------ exp / log / tan / erf / erfinv
  * Dr.Jit's dr::exp, dr::log, dr::tan, dr::erf and dr::erfinv (drjit/math.h) are not in the tree.  They are restated from the
  * published single-precision kernels Dr.Jit's math library derives from: Cephes expf / logf / tanf (S. Moshier), the Cephes
@@ -1469,7 +1676,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
     float path_length = 0.f, eta = 1.f;
     /* the environment emitter, if any (scene.cpp:53-57); valid_ray starts as !m_hide_emitters && environment != nullptr (dopplertofpath.cpp:101-102) */
     const orc_emitter *env = NULL;
-    for (int32_t ei = 0; ei < sc->n_emitters; ++ei) if (sc->emitters[ei].kind == ORC_EMITTER_CONSTANT) env = &sc->emitters[ei];
+    for (int32_t ei = 0; ei < sc->n_emitters; ++ei) if (sc->emitters[ei].kind == ORC_EMITTER_CONSTANT || sc->emitters[ei].kind == ORC_EMITTER_ENVMAP) env = &sc->emitters[ei];
     uint32_t depth = 0; int valid_ray = env && !p->hide_emitters, active = p->max_depth != 0;
     v3 o = ray.o, d = ray.d; float maxt = ray.maxt;
     v3 prev_p = V(0, 0, 0); float prev_bsdf_pdf = 1.f; int prev_delta = 1;   /* dopplertofpath.cpp:106-108 */
@@ -1500,9 +1707,10 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         if (!hit && env) {
             /* si.emitter(scene) of a missed ray is the environment (interaction.h); DirectionSample(scene, si, prev_si): d = -si.wi = the ray
              * direction; Scene::pdf_emitter_direction -> ConstantBackgroundEmitter::pdf_direction = square_to_uniform_sphere_pdf (constant.cpp:150-155) */
-            float em_pdf = prev_delta ? 0.f : ORC_INV_FOUR_PI_F * pmf;
+            const int is_map = env->kind == ORC_EMITTER_ENVMAP;   /* EnvironmentMapEmitter::pdf_direction / eval (envmap.cpp:408-425,299-310) with ds.d = -si.wi = d */
+            float em_pdf = prev_delta ? 0.f : (is_map ? env_pdf_direction(env, d) : ORC_INV_FOUR_PI_F) * pmf;
             float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
-            v3 le = prev_bsdf_pdf > 0.f ? V(env->intensity[0], env->intensity[1], env->intensity[2]) : V(0, 0, 0);
+            v3 le = prev_bsdf_pdf > 0.f ? (is_map ? env_eval(env, d) : V(env->intensity[0], env->intensity[1], env->intensity[2])) : V(0, 0, 0);
             v3 v = v_mul(le, mis_bsdf);
             if (!plain) v = v_mul(v, orc_modulation_weight(p, time, path_length));
             res = V(fmaf(thr.x, v.x, res.x), fmaf(thr.y, v.y, res.y), fmaf(thr.z, v.z, res.z));
@@ -1569,6 +1777,11 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
                 ds_pdf = ORC_INV_FOUR_PI_F; ds_delta = 0;
                 float ip = f_rcp(ds_pdf);
                 em_weight = V(em->intensity[0] * ip, em->intensity[1] * ip, em->intensity[2] * ip);
+            } else if (em->kind == ORC_EMITTER_ENVMAP) {
+                /* EnvironmentMapEmitter::sample_direction (envmap.cpp:363-406) */
+                env_sample_direction(em, si.p, sx, e2, &dd, &ds_dist, &ds_pdf, &em_weight, &em_active);
+                dsp = v_add(si.p, v_mul(dd, ds_dist));
+                ds_delta = 0;
             } else if (em->kind == ORC_EMITTER_SPOT) {
                 /* SpotLight::sample_direction (src/emitters/spot.cpp:152-187) with falloff_curve (:116-126) */
                 dsp = V(em->position[0], em->position[1], em->position[2]);

@@ -25,7 +25,7 @@ extern "C" {
 
 enum { ORC_SHAPE_RECT = 0, ORC_SHAPE_MESH = 1, ORC_SHAPE_SPHERE = 2, ORC_SHAPE_DISK = 3, ORC_SHAPE_CYLINDER = 4 };
 enum { ORC_OBJ_SHAPE = 0, ORC_OBJ_INSTANCE = 1 };
-enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1, ORC_EMITTER_SPOT = 2, ORC_EMITTER_CONSTANT = 3 };
+enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1, ORC_EMITTER_SPOT = 2, ORC_EMITTER_CONSTANT = 3, ORC_EMITTER_ENVMAP = 4 };
 enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 };
 enum { ORC_TIME_UNIFORM = 0, ORC_TIME_STRATIFIED = 1, ORC_TIME_ANTITHETIC = 2,
        ORC_TIME_ANTITHETIC_MIRROR = 3 };
@@ -113,7 +113,30 @@ typedef struct {
     /* constant (src/emitters/constant.cpp): intensity = radiance; m_bsphere = the scene's bounding sphere, enlarged (set_scene, :73-83): centre[3], radius
      * (orc_scene_bsphere) */
     float   bsphere[4];
+    /* envmap (src/emitters/envmap.cpp): the tables built by orc_envmap_create; to_local = inverse of to_world, bsphere as above */
+    const struct orc_envmap *envmap;
+    float   env_to_world[16];
 } orc_emitter;
+
+/* EnvironmentMapEmitter (src/emitters/envmap.cpp:130-224) with its Hierarchical2D<Float, 0> warp (include/mitsuba/core/distr_2d.h:376-482) */
+#define ORC_ENV_MAX_LEVELS 32
+typedef struct orc_envmap {
+    int32_t w, h;             /* resolution of m_data: bitmap width + 1 (periodic column), bitmap height */
+    float   scale;            /* m_scale */
+    float  *data;             /* h * w * 3 */
+    int32_t n_levels;         /* m_levels.size() */
+    float  *level[ORC_ENV_MAX_LEVELS]; int32_t level_w[ORC_ENV_MAX_LEVELS], level_size[ORC_ENV_MAX_LEVELS];
+    float   patch_size[2], inv_patch_size[2]; uint32_t max_patch[2];
+} orc_envmap;
+orc_envmap *orc_envmap_create(const float *rgb, int32_t width, int32_t height, float scale);
+void     orc_envmap_free(orc_envmap *e);
+/* known-answer entry points: Hierarchical2D::sample / eval, the emitter's sample_direction / pdf_direction / eval */
+void     orc_envmap_warp_sample(const orc_envmap *e, float sx, float sy, float *uv2_pdf);
+float    orc_envmap_warp_eval(const orc_envmap *e, float x, float y);
+void     orc_envmap_sample_direction(const orc_emitter *em, const float *ref_p, float sx, float sy, float *d_dist_pdf_w8);
+float    orc_envmap_pdf_direction(const orc_emitter *em, const float *d);
+void     orc_envmap_eval(const orc_emitter *em, const float *d, float *rgb);
+float    orc_atan2f(float y, float x);
 
 typedef struct {
     float   to_world[16];

@@ -49,7 +49,24 @@ class OrcObject(C.Structure):
 class OrcEmitter(C.Structure):
     _fields_ = [("kind", C.c_int32), ("position", C.c_float * 3), ("intensity", C.c_float * 3), ("shape", C.c_int32),
                 ("to_local", M16), ("cutoff_angle", C.c_float), ("cos_cutoff", C.c_float), ("cos_beam", C.c_float), ("inv_transition", C.c_float),
-                ("bsphere", C.c_float * 4)]
+                ("bsphere", C.c_float * 4), ("envmap", C.c_void_p), ("env_to_world", M16)]
+
+
+class OrcEnvmap(C.Structure):
+    _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("scale", C.c_float), ("data", C.POINTER(C.c_float)), ("n_levels", C.c_int32),
+                ("level", C.POINTER(C.c_float) * 32), ("level_w", C.c_int32 * 32), ("level_size", C.c_int32 * 32),
+                ("patch_size", C.c_float * 2), ("inv_patch_size", C.c_float * 2), ("max_patch", C.c_uint32 * 2)]
+
+
+def envmap_export(em):
+    """the tables of an OrcEmitter of kind 4 in the layout of the product's export kind 16"""
+    e = C.cast(em.envmap, C.POINTER(OrcEnvmap)).contents
+    out = [np.float32([e.w, e.h, e.n_levels, e.scale]), np.float32(list(em.bsphere)),
+           np.float32(list(em.env_to_world)).reshape(4, 4)[:3].ravel(), np.float32(list(em.to_local)).reshape(4, 4)[:3].ravel(),
+           np.ctypeslib.as_array(e.data, (e.w * e.h * 3,)).copy()]
+    for k in range(e.n_levels):
+        out += [np.float32([e.level_w[k], e.level_size[k]]), np.ctypeslib.as_array(e.level[k], (e.level_size[k],)).copy()]
+    return np.concatenate(out)
 
 
 class OrcSensor(C.Structure):
@@ -205,6 +222,7 @@ class Scene:
         self.flat = scene_xml.load(source, params, is_string)
         fs = self.flat
         self._keep = []
+        self._envmaps = []
         L = lib()
         shapes = (OrcShape * max(1, len(fs.shapes)))()
         for i, s in enumerate(fs.shapes):
@@ -360,7 +378,15 @@ class Scene:
         self._keep += [shapes, groups, objects, emitters]
         self.c = sc
         for i, e in enumerate(fs.emitters):
-            if e["kind"] == 3:   # constant environment: ConstantBackgroundEmitter::set_scene (constant.cpp:73-83)
+            if e["kind"] == 4:   # envmap: the tables of the constructor (envmap.cpp:130-224), built by the C side
+                img = np.ascontiguousarray(e["image"], np.float32)
+                L.orc_envmap_create.restype = C.c_void_p
+                L.orc_envmap_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float]
+                h = L.orc_envmap_create(img.ctypes.data, img.shape[1], img.shape[0], C.c_float(float(e["scale"])))
+                emitters[i].envmap = h
+                emitters[i].env_to_world = _m16(e["to_world"]); emitters[i].to_local = _m16(e["to_local"])
+                self._envmaps.append(h)
+            if e["kind"] in (3, 4):   # environment: ConstantBackgroundEmitter / EnvironmentMapEmitter::set_scene (constant.cpp:73-83, envmap.cpp:286-297)
                 bs = (C.c_float * 4)()
                 L.orc_scene_bsphere(C.byref(sc), bs)
                 emitters[i].bsphere = bs

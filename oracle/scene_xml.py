@@ -346,6 +346,79 @@ def _srgb_lut():
     return _SRGB_LUT
 
 
+def read_radiance_image(path):
+    """Bitmap(path).convert(RGB, Float32, srgb_gamma=false) for the formats the envmap fixtures use: PFM (bitmap.cpp:2164-2217), RGBE
+    (:1988-2096), and 8-bit PNG / JPEG through PIL (sRGB -> linear).  Returns float32 (height, width, 3), row 0 = top."""
+    import struct as _st
+    data = open(path, "rb").read()
+    if data[:2] in (b"PF", b"Pf"):
+        tok, pos = [], 2
+        while len(tok) < 3:
+            while data[pos:pos + 1].isspace():
+                pos += 1
+            q = pos
+            while not data[q:q + 1].isspace():
+                q += 1
+            tok.append(data[pos:q]); pos = q
+        pos += 1
+        w, h, so = int(tok[0]), int(tok[1]), float(tok[2])
+        ch = 3 if data[1:2] == b"F" else 1
+        a = np.frombuffer(data, "<f4" if so <= 0 else ">f4", w * h * ch, pos).astype(F32).reshape(h, w, ch)
+        if abs(so) != 1:
+            a = a * F32(abs(so))
+        a = a[::-1]
+        return np.ascontiguousarray(np.repeat(a, 3, axis=2) if ch == 1 else a)
+    if data[:2] == b"#?":
+        lines, pos, w, h, ok = [], 0, 0, 0, False
+        while True:
+            e = data.index(b"\n", pos); line = data[pos:e].decode("latin-1"); pos = e + 1
+            if line.startswith("FORMAT=32-bit_rle_rgbe"):
+                ok = True
+            t = line.split()
+            if len(t) == 4 and t[0] == "-Y" and t[2] == "+X":
+                h, w = int(t[1]), int(t[3]); break
+        if not ok:
+            raise ValueError("read_rgbe(): unrecognized format!")
+        px = np.zeros((h * w, 4), np.uint8)
+        def flat(count, at):
+            return np.frombuffer(data, np.uint8, 4 * count, at).reshape(count, 4)
+        if w < 8 or w > 0x7fff:
+            px[:] = flat(h * w, pos)
+        else:
+            y = 0
+            while y < h:
+                r = data[pos:pos + 4]
+                if r[0] != 2 or r[1] != 2 or r[2] & 0x80:      # not run-length encoded from here on
+                    px[y * w:] = flat(h * w - y * w, pos); break
+                pos += 4
+                if ((r[2] << 8) | r[3]) != w:
+                    raise ValueError("read_rgbe(): wrong scanline width!")
+                row = bytearray()
+                for c in range(4):
+                    end = (c + 1) * w
+                    while len(row) < end:
+                        n, v = data[pos], data[pos + 1]; pos += 2
+                        if n > 128:
+                            n -= 128
+                            if n == 0 or n > end - len(row):
+                                raise ValueError("read_rgbe(): bad scanline data!")
+                            row += bytes([v]) * n
+                        else:
+                            if n == 0 or n > end - len(row):
+                                raise ValueError("read_rgbe(): bad scanline data!")
+                            row += bytes([v]) + data[pos:pos + n - 1]; pos += n - 1
+                px[y * w:(y + 1) * w] = np.frombuffer(bytes(row), np.uint8).reshape(4, w).T
+                y += 1
+        f = np.ldexp(F32(1.0), px[:, 3].astype(np.int32) - 136).astype(F32)
+        out = px[:, :3].astype(F32) * f[:, None]
+        out[px[:, 3] == 0] = 0
+        return out.reshape(h, w, 3)
+    from PIL import Image
+    im = Image.open(path)
+    im = im.convert("RGB")
+    return np.ascontiguousarray(_srgb_lut()[np.asarray(im)])
+
+
 def _texture_of(tp, base_dir):
     """src/textures/checkerboard.cpp:55-62, src/textures/bitmap.cpp:113-262 (RGB variants)"""
     m = tp["to_uv"][1][0] if "to_uv" in tp else _ident()
@@ -642,12 +715,28 @@ def load(source, params=None, is_string=False):
                                         to_local=_m32(tinv), cutoff_deg=cutoff, beam_deg=beam))
                 continue
             if child.plugin == "constant":   # src/emitters/constant.cpp:58-67; the environment of the scene (scene.cpp:53-57)
-                if any(e["kind"] == 3 for e in fs.emitters):
+                if any(e["kind"] in (3, 4) for e in fs.emitters):
                     raise ValueError("Only one environment emitter can be specified per scene.")
                 rad = child["radiance"] if "radiance" in child else ("float", 1.0)
                 child.queried.add("radiance")
                 rv = [rad[1]] * 3 if rad[0] in ("float", "int") else rad[1]
                 fs.emitters.append(dict(kind=3, position=np.zeros(3, F32), intensity=np.asarray(rv, dtype=np.float64).astype(F32)))
+                continue
+            if child.plugin == "envmap":     # src/emitters/envmap.cpp:116-224
+                if any(e["kind"] in (3, 4) for e in fs.emitters):
+                    raise ValueError("Only one environment emitter can be specified per scene.")
+                fn = child.get_s("filename", None)
+                if fn is None:
+                    raise ValueError('Property "filename" has not been specified!')
+                if child.get_b("mis_compensation", False):
+                    raise ValueError('envmap: "mis_compensation" is not supported')
+                img = read_radiance_image(fn if os.path.isabs(fn) else os.path.join(base_dir, fn))
+                if img.shape[1] < 2 or img.shape[0] < 3:
+                    raise ValueError('"%s": the environment map resolution must be at least 2x3 pixels' % os.path.basename(fn))
+                tw, tinv = child["to_world"][1] if "to_world" in child and child["to_world"][0] == "transform" else (_ident(), _ident())
+                child.queried.add("to_world")
+                fs.emitters.append(dict(kind=4, position=np.zeros(3, F32), intensity=np.zeros(3, F32), image=img, scale=F32(child.get_f("scale", 1.0)),
+                                        to_world=_m32(tw), to_local=_m32(tinv)))
                 continue
             if child.plugin != "point":
                 raise ValueError('unsupported emitter plugin "%s"' % child.plugin)

@@ -184,6 +184,77 @@ def texture_files():
     gray = [[(x * x * 3 + y * 29 + 10) % 256 for x in range(8)] for y in range(8)]
     write_png(os.path.join(HERE, "tex_rgb.png"), rgb)
     write_png(os.path.join(HERE, "tex_gray.png"), gray)
+    sky = env_pixels()
+    write_rgbe(os.path.join(HERE, "env_sky.hdr"), sky)
+    write_pfm(os.path.join(HERE, "env_sky.pfm"), sky)
+    write_png(os.path.join(HERE, "env_sky.png"), [[tuple(min(255, int(255 * min(c, 1.0) ** 0.45)) for c in px) for px in row] for row in sky])
+
+
+def env_pixels(w=32, h=16):
+    """a small sky: blue gradient, a bright warm sun patch, a dim ground -- float RGB rows, top row first"""
+    rows = []
+    for y in range(h):
+        row = []
+        for x in range(w):
+            up = 1.0 - y / (h - 1)
+            r, g, b = 0.15 + 0.35 * up, 0.2 + 0.5 * up, 0.25 + 0.9 * up
+            if y > h // 2:
+                r, g, b = 0.12 + 0.01 * (x % 5), 0.1, 0.07
+            if 3 <= y <= 5 and 20 <= x <= 23:
+                r, g, b = 40.0 + 3 * (x - 20), 32.0 + y, 18.0
+            row.append((r, g, b))
+        rows.append(row)
+    return rows
+
+
+def write_pfm(path, rows):
+    import struct
+    h, w = len(rows), len(rows[0])
+    with open(path, "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (w, h))
+        for row in reversed(rows):          # PFM stores the bottom row first
+            f.write(struct.pack("<%df" % (3 * w), *[c for px in row for c in px]))
+
+
+def write_rgbe(path, rows, rle=True):
+    """Radiance .hdr (32-bit_rle_rgbe), new-style run-length encoded scanlines (as the reference's reader expects for widths 8 .. 32767)"""
+    h, w = len(rows), len(rows[0])
+    def enc(px):
+        m = max(px)
+        if m < 1e-32:
+            return (0, 0, 0, 0)
+        man, e = math.frexp(m)
+        k = man * 256.0 / m
+        return (int(px[0] * k), int(px[1] * k), int(px[2] * k), e + 128)
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        for row in rows:
+            px = [enc(p) for p in row]
+            if not rle:
+                f.write(bytes(c for p in px for c in p)); continue
+            f.write(bytes([2, 2, w >> 8, w & 255]))
+            for c in range(4):
+                ch, i = [p[c] for p in px], 0
+                while i < w:
+                    run = 1
+                    while i + run < w and run < 127 and ch[i + run] == ch[i]:
+                        run += 1
+                    if run >= 3:
+                        f.write(bytes([128 + run, ch[i]])); i += run
+                    else:
+                        j = i
+                        while j < w and j - i < 128 and not (j + 2 < w and ch[j] == ch[j + 1] == ch[j + 2]):
+                            j += 1
+                        f.write(bytes([j - i]) + bytes(ch[i:j])); i = j
+
+
+def cornell_envmap(res=128, spp=16, filename="env_sky.hdr", extra=""):
+    """cornell_env.xml under an `envmap` emitter (src/emitters/envmap.cpp): a latitude-longitude radiance map, rotated, importance-sampled"""
+    s = cornell_env(res, spp)
+    a = s.index('\t<emitter type="constant">'); b = s.index('</emitter>', a) + len('</emitter>\n')
+    em = ('\t<emitter type="envmap">\n\t\t<string name="filename" value="%s" />\n\t\t<float name="scale" value="0.6" />\n%s'
+          '\t\t<transform name="to_world">\n\t\t\t<rotate y="1" angle="40" />\n\t\t\t<rotate x="1" angle="-15" />\n\t\t</transform>\n\t</emitter>\n' % (filename, extra))
+    return s[:a] + em + s[b:]
 
 
 def tex_bsdf(ident, kind, body, plugin="diffuse", prop="reflectance", extra=""):
@@ -425,6 +496,7 @@ def main():
         "cornell_disk.xml": cornell_disk(),
         "cornell_textured.xml": cornell_textured(),
         "cornell_env.xml": cornell_env(),
+        "cornell_envmap.xml": cornell_envmap(),
         "cornell_cylinders.xml": cornell_cylinders(),
         "cornell_spheres.xml": cornell_spheres(),
         "cornell_sphere_light.xml": cornell_spheres(sphere_light=True),
@@ -441,7 +513,7 @@ def main():
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
     names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml",
-             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png"]
+             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml", "cornell_envmap.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
         return

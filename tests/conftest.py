@@ -87,6 +87,8 @@ CONFIGS = [
     ("textured", "cornell_textured.xml", dict(resx=32, resy=32, max_depth=4), 8),
     # `constant` environment emitter: rays that leave the scene, environment sampling with MIS, valid_ray
     ("environment", "cornell_env.xml", dict(resx=32, resy=32, max_depth=4), 8),
+    # `envmap` emitter (RGBE file, rotated): latitude-longitude lookup on a miss, hierarchical importance sampling with MIS
+    ("envmap", "cornell_envmap.xml", dict(resx=32, resy=32, max_depth=4), 8),
     ("cylinders", "cornell_cylinders.xml", dict(resx=24, resy=24, max_depth=4), 8),
     ("spot_light", "cornell_spot.xml", dict(resx=24, resy=24), 8),
     ("disks", "cornell_disk.xml", dict(resx=24, resy=24, max_depth=5), 8),

@@ -130,3 +130,110 @@ def test_constant_environment(mi, orc):
     closed = orc.Scene(xml % 6, is_string=True)
     img, _ = closed.render(closed.params(), seed=1, spp=64, threads=NCPU)
     assert np.abs(img).max() == 0.0
+
+
+def _envmap_emitter(orc, img, scale=1.0):
+    import ctypes as C
+    L = orc.lib()
+    L.orc_envmap_create.restype = C.c_void_p; L.orc_envmap_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float]
+    L.orc_envmap_sample_direction.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    L.orc_envmap_pdf_direction.restype = C.c_float; L.orc_envmap_pdf_direction.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_envmap_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    img = np.ascontiguousarray(img, np.float32)
+    em = orc.OrcEmitter(); em.kind = 4
+    em.envmap = L.orc_envmap_create(img.ctypes.data, img.shape[1], img.shape[0], C.c_float(scale))
+    ident = (C.c_float * 16)(*np.eye(4, dtype=np.float32).ravel())
+    em.to_local = ident; em.env_to_world = ident; em.bsphere = (C.c_float * 4)(0, 0, 0, 1)
+    return L, em
+
+
+def test_envmap_known_answers_of_the_reference(orc):
+    """src/emitters/tests/test_envmap.py restated for the oracle: test02_sampling_weights (a 10 x 100 map with ONE pixel on: the weights of
+    sample_direction stay within (0.018, 0.02) and equal eval / pdf_direction within 1e-3 -- numbers the reference's own test holds) and the
+    content of test01_chi2 (sampled directions follow pdf_direction: sparse, constant high-res and constant 2 x 3 maps)."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    img = np.zeros((100, 10, 3), np.float32); img[40, 5] = 1
+    L, em = _envmap_emitter(orc, img)
+    w, w2, w3 = [], [], []
+    for sx, sy in rng.random((3000, 2)):
+        out = (C.c_float * 8)()
+        L.orc_envmap_sample_direction(C.byref(em), (C.c_float * 3)(0, 0, 0), float(sx), float(sy), out)
+        d = (C.c_float * 3)(out[0], out[1], out[2]); rgb = (C.c_float * 3)()
+        L.orc_envmap_eval(C.byref(em), d, rgb)
+        w.append(out[5]); w2.append(rgb[0] / L.orc_envmap_pdf_direction(C.byref(em), d)); w3.append(rgb[0] / out[4])
+        assert abs(np.linalg.norm(out[0:3]) - 1) < 1e-5 and out[3] == 2.0
+    w, w2, w3 = np.array(w), np.array(w2), np.array(w3)
+    assert np.allclose(w, w2, rtol=1e-3) and np.allclose(w, w3, rtol=1e-3)        # test_envmap.py:68-69
+    assert w.min() > 0.018 and w.max() < 0.02                                     # test_envmap.py:70
+    # chi^2-style check on a coarse spherical histogram (test01_chi2: iterations 0 - 2)
+    for im in (img, np.ones((100, 100, 3), np.float32), np.ones((3, 2, 3), np.float32)):
+        L, em = _envmap_emitter(orc, im)
+        n, nb = 40000, (8, 16)
+        hist = np.zeros(nb); s = rng.random((n, 2))
+        for sx, sy in s:
+            out = (C.c_float * 8)()
+            L.orc_envmap_sample_direction(C.byref(em), (C.c_float * 3)(0, 0, 0), float(sx), float(sy), out)
+            ct, ph = np.clip(out[2], -1, 1), np.arctan2(out[1], out[0]) % (2 * np.pi)
+            hist[min(int((ct + 1) / 2 * nb[0]), nb[0] - 1), min(int(ph / (2 * np.pi) * nb[1]), nb[1] - 1)] += 1
+        # expected counts: integrate pdf_direction over each (cos theta, phi) cell with a 40 x 40 midpoint rule
+        exp = np.zeros(nb); m = 40
+        for i in range(nb[0]):
+            for j in range(nb[1]):
+                acc = 0.0
+                for a in range(m):
+                    for b in range(m):
+                        ct = -1 + 2 * (i + (a + .5) / m) / nb[0]; ph = 2 * np.pi * (j + (b + .5) / m) / nb[1]; st = np.sqrt(1 - ct * ct)
+                        acc += L.orc_envmap_pdf_direction(C.byref(em), (C.c_float * 3)(st * np.cos(ph), st * np.sin(ph), ct))
+                exp[i, j] = acc / (m * m) * (4 * np.pi / (nb[0] * nb[1])) * n
+        assert abs(exp.sum() / n - 1) < 0.02, exp.sum() / n                       # the density integrates to one
+        big = exp > 50
+        z = (hist[big] - exp[big]) / np.sqrt(exp[big])
+        assert np.abs(z).max() < 6 and abs(hist[~big].sum() - exp[~big].sum()) < 6 * np.sqrt(exp[~big].sum() + 1) + 0.01 * n, (np.abs(z).max(),)
+
+
+def test_envmap_scene(mi, orc, tmp_path):
+    """`envmap` emitter end to end on the CPU side: the three file formats decode to the same map (RGBE, PFM exactly; PNG through sRGB), loader
+    parity with the product (blob tables = the oracle's tables), radiance lookup of sky pixels, hide_emitters, error messages."""
+    from oracle import scene_xml as sx
+    a, b = sx.read_radiance_image(os.path.join(SCENES, "env_sky.hdr")), sx.read_radiance_image(os.path.join(SCENES, "env_sky.pfm"))
+    assert a.shape == b.shape == (16, 32, 3) and np.abs(a - b).max() <= b.max() / 128 and np.array_equal(b[0, 0], np.float32([0.5, 0.7, 1.15]))
+    path = os.path.join(SCENES, "cornell_envmap.xml")
+    osc = orc.Scene(path, dict(resx=16, resy=16))
+    env = [e for e in osc.flat.emitters if e["kind"] == 4]
+    assert len(env) == 1 and env[0]["image"].shape == (16, 32, 3) and env[0]["scale"] == np.float32(0.6)
+    # a pixel that looks out of the open back of the room shows the (rotated, scaled) map: positive, finite, no larger than scale * max(map)
+    pd = osc.params(integrator=dict(type="path", max_depth=4))
+    img, _ = osc.render(pd, seed=0, spp=8, threads=NCPU)
+    assert np.isfinite(img).all() and img[0, 8].min() > 0 and img.max() <= 0.6 * a.max() * 1.01
+    hidden, _ = osc.render(osc.params(integrator=dict(type="path", max_depth=4, hide_emitters=True)), seed=0, spp=8, threads=NCPU)
+    assert np.array_equal(hidden[0, 8], [0, 0, 0]) and hidden[12, 8].sum() > 0
+    from oracle.orc import envmap_export
+    sc = mi.load_file(path, resx=16, resy=16)
+    ours, theirs = sc.export(16), envmap_export(osc.c.emitters[[e["kind"] for e in osc.flat.emitters].index(4)])
+    assert ours.size == theirs.size and np.array_equal(ours.view(np.uint32), theirs.view(np.uint32))   # radiance, bounding sphere, rotation, every level: bit for bit
+    # the product builds the same tables: the three formats load, resolution limits and unsupported options raise as the reference does
+    text = open(path).read()
+    for fn in ("env_sky.pfm", "env_sky.png"):
+        q = os.path.join(SCENES, "_tmp_" + fn + ".xml")
+        open(q, "w").write(text.replace("env_sky.hdr", fn))
+        try:
+            assert mi.load_file(q).info()["n_emitters"] == 2 and len(orc.Scene(q, {}).flat.emitters) == 2
+        finally:
+            os.remove(q)
+    absolute = text.replace("env_sky.hdr", os.path.join(SCENES, "env_sky.hdr"))
+
+    def load(name, xml):
+        (tmp_path / name).write_text(xml)
+        return mi.load_file(str(tmp_path / name))
+    with pytest.raises(mi.DtofError, match="Only one environment emitter"):
+        load("two.xml", absolute.replace("</scene>", '<emitter type="constant"/></scene>'))
+    with pytest.raises(mi.DtofError, match="mis_compensation"):
+        load("mis.xml", absolute.replace('<float name="scale" value="0.6" />', '<boolean name="mis_compensation" value="true" />'))
+    sys.path.insert(0, SCENES)
+    import make_scenes
+    make_scenes.write_pfm(str(tmp_path / "tiny.pfm"), [[(1.0, 1.0, 1.0)] * 2] * 2)
+    with pytest.raises(mi.DtofError, match="must be at least 2x3 pixels"):
+        load("tiny.xml", text.replace("env_sky.hdr", str(tmp_path / "tiny.pfm")))
+    with pytest.raises(mi.DtofError, match="could not open"):
+        load("missing.xml", text.replace("env_sky.hdr", str(tmp_path / "nope.hdr")))
