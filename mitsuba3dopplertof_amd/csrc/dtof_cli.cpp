@@ -3,13 +3,16 @@
 //
 //   dtof-render scene.xml [-D key=value ...] [-o out.npy|out.pfm] [--spp N] [--seed S] [-m hip_rgb] [--gpus G [--stripes ROWS]]
 //
-// --gpus G: one host thread per GPU of this node, each with its own scene handle; thread g renders the interleaved stripes of pixel
-// rows g owns (dtof_render_stripes) into a film on its device, the films are summed on the host and developed (RGB / W).  The
-// torch.distributed launcher (python -m mitsuba3dopplertof_amd under torch.distributed.run) does the same with one RCCL reduce.
+// --gpus G: one host thread per GPU of this node, each with its own scene handle and its own RCCL communicator (ncclCommInitAll); thread g
+// renders the interleaved stripes of pixel rows g owns (dtof_render_stripes) into a film on its device, ONE ncclReduce(sum) over xGMI brings
+// the films to GPU 0, which develops (RGB / W) and downloads the image -- the film never touches host memory.  The torch.distributed
+// launcher (python -m mitsuba3dopplertof_amd under torch.distributed.run) is the same exchange with one process per GPU.
+// DTOF_CLI_SHARE_GPU=1 (development on one-GPU boxes): all shards run on GPU 0 and are summed on the host, RCCL cannot place two ranks on one device.
 //
 // Exit code -1 and "Error: ..." on stderr when loading or rendering fails (mitsuba.cpp:366-397,423).
 #include "../../include/dtof.h"
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -60,30 +63,59 @@ int main(int argc, char **argv) {
     dtof_scene_info info; dtof_scene_get_info(sc, &info);
     std::vector<float> img((size_t) info.crop_width * info.crop_height * 3);
     dtof_render_stats st;
-    if (gpus > 1) {
+    const bool force_collective = getenv("DTOF_CLI_FORCE_RCCL") != nullptr;   // take the multi-GPU path with --gpus 1 too (a one-rank communicator)
+    if (gpus > 1 || force_collective) {
         int visible = 0; (void) hipGetDeviceCount(&visible);
-        const bool share = getenv("DTOF_CLI_SHARE_GPU") != nullptr;   // development: all shards on GPU 0 (one-GPU boxes)
+        const bool share = getenv("DTOF_CLI_SHARE_GPU") != nullptr;   // development: all shards on GPU 0 (one-GPU boxes), host sum
         if (gpus > visible && !share) { fprintf(stderr, "Error: --gpus %d but only %d GPU(s) are visible\n", gpus, visible); dtof_scene_destroy(sc); return -1; }
         if (stripes <= 0) { fprintf(stderr, "Error: --stripes expects a positive number of rows\n"); dtof_scene_destroy(sc); return -1; }
-        const size_t film_floats = (size_t) info.crop_width * info.crop_height * 4;
-        std::vector<std::vector<float>> films(gpus, std::vector<float>(film_floats));
+        const size_t n_pixels = (size_t) info.crop_width * info.crop_height, film_floats = n_pixels * 4;
+        std::vector<ncclComm_t> comms(gpus, nullptr);
+        if (!share) {
+            std::vector<int> devs(gpus); for (int g = 0; g < gpus; ++g) devs[g] = g;
+            const ncclResult_t rc = ncclCommInitAll(comms.data(), gpus, devs.data());
+            if (rc != ncclSuccess) { fprintf(stderr, "Error: ncclCommInitAll: %s\n", ncclGetErrorString(rc)); dtof_scene_destroy(sc); return -1; }
+        }
+        std::vector<std::vector<float>> films(share ? gpus : 0, std::vector<float>(film_floats));
         std::vector<std::string> errors(gpus); std::vector<dtof_render_stats> stats(gpus);
         std::vector<std::thread> workers;
         for (int g = 0; g < gpus; ++g) workers.emplace_back([&, g] {
             if (hipSetDevice(share ? 0 : g) != hipSuccess) { errors[g] = "hipSetDevice failed"; return; }
-            dtof_scene *mine = nullptr; float *d_film = nullptr;
-            if (dtof_scene_load_file(scene.c_str(), n.data(), v.data(), (int) n.size(), &mine)) { errors[g] = dtof_last_error(); return; }
-            if (hipMalloc((void **) &d_film, film_floats * 4) != hipSuccess || hipMemset(d_film, 0, film_floats * 4) != hipSuccess) errors[g] = "device film allocation failed";
+            dtof_scene *mine = nullptr; float *d_film = nullptr, *d_rgb = nullptr; hipStream_t stream = nullptr;
+            if (dtof_scene_load_file(scene.c_str(), n.data(), v.data(), (int) n.size(), &mine)) { errors[g] = dtof_last_error(); }
+            else if (hipMalloc((void **) &d_film, film_floats * 4) != hipSuccess || hipMemset(d_film, 0, film_floats * 4) != hipSuccess) errors[g] = "device film allocation failed";
             else if (dtof_render_stripes(mine, seed, spp, g * stripes, stripes, gpus * stripes, nullptr, 0, d_film, &stats[g])) errors[g] = dtof_last_error();
-            else if (hipMemcpy(films[g].data(), d_film, film_floats * 4, hipMemcpyDeviceToHost) != hipSuccess) errors[g] = "film download failed";
+            if (share) {
+                if (errors[g].empty() && hipMemcpy(films[g].data(), d_film, film_floats * 4, hipMemcpyDeviceToHost) != hipSuccess) errors[g] = "film download failed";
+            } else {
+                // every rank enters the collective, also one whose render failed (its film is zero or partial; the error is reported afterwards):
+                // a rank that stays away would leave the others waiting in ncclReduce
+                if (!d_film && hipMalloc((void **) &d_film, film_floats * 4) == hipSuccess) (void) hipMemset(d_film, 0, film_floats * 4);
+                ncclResult_t rc = ncclSuccess;
+                if (!d_film || hipStreamCreate(&stream) != hipSuccess) { if (errors[g].empty()) errors[g] = "stream / film allocation failed"; }
+                else {
+                    (void) hipDeviceSynchronize();   // the library renders on its own stream
+                    rc = ncclReduce(d_film, d_film, film_floats, ncclFloat, ncclSum, 0, comms[g], stream);
+                    if (rc == ncclSuccess && hipStreamSynchronize(stream) != hipSuccess && errors[g].empty()) errors[g] = "film reduce failed";
+                    if (rc != ncclSuccess && errors[g].empty()) errors[g] = std::string("ncclReduce: ") + ncclGetErrorString(rc);
+                }
+                if (g == 0 && errors[g].empty()) {   // HDRFilm::develop (hdrfilm.cpp:305-406) of the summed film, on the device
+                    if (hipMalloc((void **) &d_rgb, n_pixels * 12) != hipSuccess) errors[g] = "image allocation failed";
+                    else if (dtof_develop(d_film, d_rgb, (int64_t) n_pixels)) errors[g] = dtof_last_error();
+                    else if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(img.data(), d_rgb, n_pixels * 12, hipMemcpyDeviceToHost) != hipSuccess) errors[g] = "image download failed";
+                }
+            }
+            if (stream) (void) hipStreamDestroy(stream);
+            if (d_rgb) (void) hipFree(d_rgb);
             if (d_film) (void) hipFree(d_film);
-            dtof_scene_destroy(mine);
+            if (mine) dtof_scene_destroy(mine);
         });
         for (auto &w : workers) w.join();
+        for (auto &c : comms) if (c) (void) ncclCommDestroy(c);
         for (int g = 0; g < gpus; ++g) if (!errors[g].empty()) { fprintf(stderr, "Error: GPU %d: %s\n", g, errors[g].c_str()); dtof_scene_destroy(sc); return -1; }
         st = stats[0];
         for (int g = 1; g < gpus; ++g) { st.n_paths += stats[g].n_paths; if (stats[g].ms_total > st.ms_total) st.ms_total = stats[g].ms_total; }
-        for (size_t p = 0; p < film_floats / 4; ++p) {   // HDRFilm::develop (hdrfilm.cpp:305-406) of the summed films
+        if (share) for (size_t p = 0; p < n_pixels; ++p) {   // development mode: develop the host sum
             float r = 0.f, gch = 0.f, b = 0.f, wgt = 0.f;
             for (int g = 0; g < gpus; ++g) { const float *f = films[g].data() + 4 * p; r += f[0]; gch += f[1]; b += f[2]; wgt += f[3]; }
             if (wgt == 0.f) wgt = 1.f;

@@ -112,8 +112,16 @@ def test_native_cli_writes_the_same_image(mi, tmp_path):
     assert img.shape == (24, 40, 3) and np.abs(img - ref).max() <= 1e-5 * np.abs(ref).max()
     bad = subprocess.run([exe, os.path.join(SCENES, "cornell_wall.xml"), "-D", "wave_function_type=sawtooth"], capture_output=True, text=True)
     assert bad.returncode != 0 and "unknown wave_function_type" in bad.stderr
-    # --gpus G: one host thread per GPU, interleaved stripes, films summed on the host.  This box has one GPU: more is an error, and
-    # DTOF_CLI_SHARE_GPU (development switch) puts all three shards on GPU 0 so that the thread / stripe / sum logic runs.
+    # --gpus G: one host thread per GPU, interleaved stripes, one RCCL reduce of the films to GPU 0.  This box has one GPU: more is an error;
+    # DTOF_CLI_FORCE_RCCL takes the collective path with a one-rank communicator (ncclCommInitAll, ncclReduce, device-side develop), and
+    # DTOF_CLI_SHARE_GPU (development switch) puts three shards on GPU 0 so that the thread / stripe logic runs (host sum: RCCL cannot
+    # place two ranks on one device).
+    out1 = str(tmp_path / "o1.npy")
+    r = subprocess.run([exe, os.path.join(SCENES, "cornell_wall.xml"), "-D", "resx=40", "-D", "resy=24", "--spp", "8", "--seed", "5", "-o", out1, "--gpus", "1"],
+                       capture_output=True, text=True, env=dict(os.environ, DTOF_CLI_FORCE_RCCL="1"))
+    assert r.returncode == 0, r.stderr
+    img1 = np.load(out1)
+    assert img1.shape == (24, 40, 3) and np.abs(img1 - ref).max() <= 5e-5 * np.abs(ref).max()
     many = subprocess.run([exe, os.path.join(SCENES, "cornell_wall.xml"), "--gpus", "64"], capture_output=True, text=True)
     assert many.returncode != 0 and "GPU(s) are visible" in many.stderr
     out3 = str(tmp_path / "o3.npy")
