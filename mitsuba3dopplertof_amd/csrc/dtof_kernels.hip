@@ -697,9 +697,11 @@ __global__ __launch_bounds__(kBlock) void k_velocity(const uint8_t *scene, uint3
 // ---------------------------------------------------------------------------- splat
 DTOF_D float tent(float x, float inv_r) { return fmax_(0.f, 1.f - fabsf(x * inv_r)); }
 // ReconstructionFilter::eval: tent (tent.cpp:53-55) or gaussian (gaussian.cpp:94-96, polynomial branch)
+template <int F = -1>   // F >= 0: the filter is known at compile time (the branches fold away)
 DTOF_D float filter_weight(const RenderParams &rp, float x) {
-    if (rp.filter == FILTER_GAUSSIAN) return fmax_(estrin10(sqr(x), rp.gauss_coeff), 0.f);
-    if (rp.filter == FILTER_MITCHELL) {   // MitchellNetravaliFilter::eval (mitchell.cpp:47-67): coefficients in ScalarFloat, Horner with fmadd
+    const int filter = F >= 0 ? F : (int) rp.filter;
+    if (filter == FILTER_GAUSSIAN) return fmax_(estrin10(sqr(x), rp.gauss_coeff), 0.f);
+    if (filter == FILTER_MITCHELL) {   // MitchellNetravaliFilter::eval (mitchell.cpp:47-67): coefficients in ScalarFloat, Horner with fmadd
         x = fabsf(x);
         const float x2 = x * x, x3 = x2 * x, B = rp.filter_b, C = rp.filter_c;
         const float a3 = (12.f - 9.f * B - 6.f * C), a2 = (-18.f + 12.f * B + 6.f * C), a0 = (6.f - 2.f * B),
@@ -707,7 +709,7 @@ DTOF_D float filter_weight(const RenderParams &rp, float x) {
         const float r = (1.f / 6.f) * (x < 1.f ? fmaf(a3, x3, fmaf(a2, x2, a0)) : fmaf(b3, x3, fmaf(b2, x2, fmaf(b1, x, b0))));
         return x < 2.f ? r : 0.f;
     }
-    if (rp.filter == FILTER_CATMULLROM) {   // CatmullRomFilter::eval (catmullrom.cpp:38-53): B = 0, C = 1/2, plain multiplies and adds
+    if (filter == FILTER_CATMULLROM) {   // CatmullRomFilter::eval (catmullrom.cpp:38-53): B = 0, C = 1/2, plain multiplies and adds
         x = fabsf(x);
         const float x2 = x * x, x3 = x2 * x, B = 0.f, C = .5f;
         const float r = (1.f / 6.f) * (x < 1.f ? (12.f - 9.f * B - 6.f * C) * x3 + (-18.f + 12.f * B + 6.f * C) * x2 + (6.f - 2.f * B)
@@ -839,29 +841,33 @@ __global__ __launch_bounds__(kBlock) void k_splat_tent3(RenderParams rp, Queues 
     }
 }
 
-// The same sums with EIGHT SAMPLES PER LANE (spp a power of two >= 16): a lane accumulates the 36 footprint values of eight samples of
-// its pixel serially in registers (~70 VALU per sample), and only then are the seg8 = min(spp / 8, 64) lanes that share a pixel reduced
-// with DPP adds -- log2(seg8) steps of 36 adds per EIGHT samples instead of log2(min(spp, 64)) steps per sample (C2, 64 spp: 13.5 instead
-// of 216 DPP adds per sample).  Which samples a lane takes does not matter for the sums: lane `sub` of a segment takes the samples
-// sub, sub + seg8, sub + 2 seg8, ... of the segment's 8 seg8 consecutive ones, so each load instruction reads seg8 consecutive records
-// per segment (64 spp: whole 128-byte lines of q.res).  Segment totals leave through LDS and block-wide atomics as in k_splat_tent3.
+// The same sums with EIGHT SAMPLES PER LANE (spp a power of two >= 16), for every filter whose footprint is N x N pixels with N = 1 (box: the
+// sample's own pixel), 3 (tent of radius <= 1) or 5 (radius <= 2: the default gaussian of hdrfilm, mitchell, catmullrom, wider tents): a lane
+// accumulates the 4 N^2 footprint values of eight samples of its pixel serially in registers, and only then are the seg8 = min(spp / 8, 64)
+// lanes that share a pixel reduced with DPP adds -- log2(seg8) steps of 4 N^2 adds per EIGHT samples instead of log2(min(spp, 64)) steps per
+// sample (C2, 64 spp, tent: 13.5 instead of 216 DPP adds per sample).  Which samples a lane takes does not matter for the sums: lane `sub` of a
+// segment takes the samples sub, sub + seg8, sub + 2 seg8, ... of the segment's 8 seg8 consecutive ones, so each load instruction reads seg8
+// consecutive records per segment (64 spp: whole 128-byte lines of q.res).  Segment totals leave through LDS ((kBlock / seg8) x N^2 float4) and
+// block-wide atomics as in k_splat_tent3.  The per-sample atomics of k_splat_generic cost 58x the rest of the frame on C2 with a gaussian.
 constexpr uint32_t kSplatPer = 8;
-__global__ __launch_bounds__(kBlock) void k_splat_tent3x8(RenderParams rp, Queues q, float *film, size_t film_stride, uint32_t seg8) {
-    __shared__ float4 s_acc4[(kBlock / 2) * 9];
+template <int N, int F>
+__global__ __launch_bounds__(kBlock) void k_splat_x8(RenderParams rp, Queues q, float *film, size_t film_stride, uint32_t seg8) {
+    constexpr int NN = N * N, HALF = N / 2;
+    extern __shared__ float4 s_acc4[];   // (kBlock / seg8) * NN
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x, sub = i & (seg8 - 1);
     const uint32_t first = (i - sub) * kSplatPer;           // first sample of this lane's segment (8 seg8 consecutive samples of one pixel)
     const bool in_range = first < rp.n_lanes;               // n_lanes is a multiple of spp, spp of 8 seg8
     const uint32_t lane = global_lane(rp, rp.lane_base + (in_range ? first : 0));
     const uint32_t pix = lane >> rp.spp_log2, W = (uint32_t) rp.crop_w;
     const int py = (int) fdiv(pix, rp.d_w), px = (int) (pix - W * (uint32_t) py);
-    const float bx = (float) (px + rp.crop_x - 1) + .5f, by = (float) (py + rp.crop_y - 1) + .5f;
+    const float bx = (float) (px + rp.crop_x - HALF) + .5f, by = (float) (py + rp.crop_y - HALF) + .5f;
     for (int k = 0; k < rp.n_offsets; ++k) {
         float *fk = film + (size_t) k * film_stride;
         const float4 *res = q.res + (size_t) k * q.capacity + first + sub;
         const float2 *pos = q.pos + first + sub;
-        float acc[36];
+        float acc[4 * NN];
 #pragma unroll
-        for (int c = 0; c < 36; ++c) acc[c] = 0.f;
+        for (int c = 0; c < 4 * NN; ++c) acc[c] = 0.f;
         uint32_t irregular = 0;
 #pragma unroll 1
         for (uint32_t h = 0; h < kSplatPer; h += 4) {   // four samples at a time: their eight loads are issued together
@@ -869,23 +875,28 @@ __global__ __launch_bounds__(kBlock) void k_splat_tent3x8(RenderParams rp, Queue
 #pragma unroll
             for (uint32_t m = 0; m < 4; ++m) {
                 r[m] = in_range ? res[(size_t) (h + m) * seg8] : make_float4(0.f, 0.f, 0.f, 0.f);
-                pp[m] = in_range ? pos[(size_t) (h + m) * seg8] : make_float2(0.f, 0.f);
+                pp[m] = in_range && N > 1 ? pos[(size_t) (h + m) * seg8] : make_float2(0.f, 0.f);
             }
 #pragma unroll
             for (uint32_t m = 0; m < 4; ++m) {
+                if (N == 1) {   // box: block->put(pos) -- the lane's own pixel, weight 1 (integrator.cpp:540-541)
+                    const float w = in_range ? 1.f : 0.f;
+                    acc[0] += r[m].x; acc[1] += r[m].y; acc[2] += r[m].z; acc[3] += w;
+                    continue;
+                }
                 const float sx = pp[m].x, sy = pp[m].y;
                 const int fx = (int) floorf(sx) - rp.crop_x, fy = (int) floorf(sy) - rp.crop_y;
                 const bool regular = in_range && fx == px && fy == py;
                 if (in_range && !regular) irregular |= 1u << (h + m);
                 const float relx = bx - sx, rely = by - sy;
-                float wx[3], wy[3];
+                float wx[N], wy[N];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { wx[a] = regular ? tent(relx + (float) a, rp.inv_radius) : 0.f; wy[a] = tent(rely + (float) a, rp.inv_radius); }
+                for (int a = 0; a < N; ++a) { wx[a] = regular ? filter_weight<F>(rp, relx + (float) a) : 0.f; wy[a] = filter_weight<F>(rp, rely + (float) a); }
 #pragma unroll
-                for (int ys = 0; ys < 3; ++ys)
+                for (int ys = 0; ys < N; ++ys)
 #pragma unroll
-                    for (int xs = 0; xs < 3; ++xs) {
-                        const float w = wx[xs] * wy[ys]; const int c = 4 * (3 * ys + xs);
+                    for (int xs = 0; xs < N; ++xs) {
+                        const float w = wx[xs] * wy[ys]; const int c = 4 * (N * ys + xs);
                         acc[c] = fmaf(r[m].x, w, acc[c]); acc[c + 1] = fmaf(r[m].y, w, acc[c + 1]); acc[c + 2] = fmaf(r[m].z, w, acc[c + 2]); acc[c + 3] += w;
                     }
             }
@@ -896,7 +907,7 @@ __global__ __launch_bounds__(kBlock) void k_splat_tent3x8(RenderParams rp, Queue
             splat_lane(rp, fk, sp.x, sp.y, px, py, sr.x, sr.y, sr.z);
         }
 #pragma unroll
-        for (int c = 0; c < 36; ++c) {   // segment totals end up in the segment's LAST lane (see k_splat_tent3)
+        for (int c = 0; c < 4 * NN; ++c) {   // segment totals end up in the segment's LAST lane (see k_splat_tent3)
             float v = acc[c];
             v = dpp_add<0xb1>(v);
             if (seg8 >= 4) v = dpp_add<0x4e>(v);
@@ -910,18 +921,18 @@ __global__ __launch_bounds__(kBlock) void k_splat_tent3x8(RenderParams rp, Queue
         const uint32_t sidx_mine = threadIdx.x / seg8;
         if ((threadIdx.x & (seg8 - 1)) == seg8 - 1) {
 #pragma unroll
-            for (int c = 0; c < 9; ++c) s_acc4[sidx_mine * 9 + c] = make_float4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
+            for (int c = 0; c < NN; ++c) s_acc4[sidx_mine * NN + c] = make_float4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
         }
         __syncthreads();
-        const uint32_t total = (kBlock / seg8) * 36;
+        const uint32_t total = (kBlock / seg8) * 4 * NN;
         const float *s_acc = (const float *) s_acc4;
         for (uint32_t idx = threadIdx.x; idx < total; idx += kBlock) {
-            const uint32_t sidx = idx / 36, c = idx - sidx * 36;
+            const uint32_t sidx = idx / (4 * NN), c = idx - sidx * (4 * NN), tap = c >> 2;
             const uint32_t seg_first = (blockIdx.x * kBlock + sidx * seg8) * kSplatPer;
             if (seg_first >= rp.n_lanes) continue;
             const uint32_t spix = global_lane(rp, rp.lane_base + seg_first) >> rp.spp_log2;
             const int sy = (int) fdiv(spix, rp.d_w), sx = (int) (spix - W * (uint32_t) sy);
-            const int x = sx - 1 + (int) ((c % 12) >> 2), y = sy - 1 + (int) (c / 12);
+            const int x = sx - HALF + (int) (tap % N), y = sy - HALF + (int) (tap / N);
             const float v = s_acc[idx];
             if ((unsigned) x < W && (unsigned) y < (unsigned) rp.crop_h && v != 0.f)
                 atomicAdd(fk + 4 * ((size_t) y * W + (size_t) x) + (c & 3), v);
@@ -1068,10 +1079,25 @@ void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t 
     size_t stride = (size_t) film_w * film_h * 4;
     bool fast = rp.filter == FILTER_TENT && rp.filter_radius <= 1.f && rp.filter_radius > .5f && rp.spp_log2 != 0xffffffffu && rp.spp >= 2;
     static const int env_splat = [] { const char *e = getenv("DTOF_SPLAT"); std::string v = e ? e : ""; return v == "dpp" ? 1 : v == "generic" ? 2 : 0; }();   // A/B switches
-    if (fast && rp.spp >= 2 * kSplatPer && env_splat == 0) {   // eight samples per lane, then the DPP reduction over the spp / 8 lanes of a pixel
+    // footprint of the filter in pixels (ImageBlock::put: the pixels within ceil(radius - 0.5) of the sample's): 1 (box), 3 or 5 take the
+    // eight-samples-per-lane kernel when spp is a power of two >= 16
+    const int reach = rp.filter == FILTER_BOX ? 0 : (int) ceilf(rp.filter_radius - .5f);
+    if ((rp.filter == FILTER_BOX || (reach >= 1 && reach <= 2)) && rp.spp_log2 != 0xffffffffu && rp.spp >= 2 * kSplatPer && env_splat == 0) {
         const uint32_t groups = rp.n_lanes / kSplatPer, seg8 = rp.spp / kSplatPer < 64 ? rp.spp / kSplatPer : 64;
-        hipLaunchKernelGGL(k_splat_tent3x8, dim3(nblk(groups)), dim3(kBlock), 0, s, rp, q, film, stride, seg8);
-    } else if (fast && env_splat != 2) {
+        const int n = 2 * reach + 1;
+        const uint32_t lds = (kBlock / seg8) * n * n * 16u;
+        if (lds <= 64u * 1024u) {
+#define DTOF_SPLAT_X8(NN_, F_) hipLaunchKernelGGL((k_splat_x8<NN_, F_>), dim3(nblk(groups)), dim3(kBlock), lds, s, rp, q, film, stride, seg8)
+            if (n == 1) DTOF_SPLAT_X8(1, FILTER_BOX);
+            else if (rp.filter == FILTER_TENT) { if (n == 3) DTOF_SPLAT_X8(3, FILTER_TENT); else DTOF_SPLAT_X8(5, FILTER_TENT); }
+            else if (rp.filter == FILTER_GAUSSIAN) { if (n == 3) DTOF_SPLAT_X8(3, FILTER_GAUSSIAN); else DTOF_SPLAT_X8(5, FILTER_GAUSSIAN); }
+            else if (rp.filter == FILTER_MITCHELL) { if (n == 3) DTOF_SPLAT_X8(3, FILTER_MITCHELL); else DTOF_SPLAT_X8(5, FILTER_MITCHELL); }
+            else { if (n == 3) DTOF_SPLAT_X8(3, FILTER_CATMULLROM); else DTOF_SPLAT_X8(5, FILTER_CATMULLROM); }
+#undef DTOF_SPLAT_X8
+            return;
+        }
+    }
+    if (fast && env_splat != 2) {
         uint32_t seg = rp.spp < 64 ? rp.spp : 64;
         hipLaunchKernelGGL(k_splat_tent3, dim3(nblk(rp.n_lanes)), dim3(kBlock), 0, s, rp, q, film, stride, seg);
     } else {
