@@ -134,7 +134,8 @@ static void read_rgbe(const std::vector<uint8_t> &file, const std::string &path,
         }
     }
     if (!ok) throw std::runtime_error("read_rgbe(): unrecognized format!");
-    if (w == 0 || h == 0 || w > 65536 || h > 65536) throw std::runtime_error("read_rgbe(): implausible size in \"" + path + "\"");
+    // a damaged header must not be allocated before the first read fails: at most 64 Mpixels, and no more than run-length coding can pack into the file
+    if (w == 0 || h == 0 || (uint64_t) w * h > (1ull << 26) || (uint64_t) w * h / 64 > file.size()) throw std::runtime_error("read_rgbe(): implausible size in \"" + path + "\"");
     std::vector<uint8_t> px((size_t) w * h * 4);
     auto need = [&](size_t n) { if (pos + n > file.size()) throw std::runtime_error("read_rgbe(): \"" + path + "\" is truncated"); };
     auto flat_from = [&](size_t first_pixel) { const size_t n = ((size_t) w * h - first_pixel) * 4; need(n); memcpy(&px[first_pixel * 4], &file[pos], n); pos += n; };

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes a corpus of damaged scene files for tools/sanitize_loader.sh:  python tests/dev/fuzz_corpus.py SEED COUNT OUTDIR
-35 % numeric attribute values replaced by extreme ones, 25 % character-level damage of the XML, 40 % damaged obj / ply / serialized mesh files."""
+35 % numeric attribute values replaced by extreme ones, 25 % character-level damage of the XML, 10 % damaged radiance maps (RGBE / PFM / PNG), 30 % damaged obj / ply / serialized mesh files."""
 import os, sys, random, re
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scenes"))
@@ -21,6 +21,12 @@ make_mesh.write_serialized(os.path.join(out, "g.serialized"), [(pos, None, uv, f
 orig = {n: open(os.path.join(out, n), "rb").read() for n in ("a.obj", "b.ply", "c.ply", "d.ply", "e.obj", "f.serialized", "g.serialized")}
 import zlib
 xml0 = make_mesh.cornell_mesh_xml(moving_file="MOVING", res=16, spp=4)
+# radiance maps of the envmap emitter (RGBE with and without run-length encoding, PFM colour and gray, PNG) and bitmap textures
+sky = make_scenes.env_pixels(16, 8)
+make_scenes.write_rgbe(os.path.join(out, "h.hdr"), sky); make_scenes.write_rgbe(os.path.join(out, "i.hdr"), sky, rle=False); make_scenes.write_pfm(os.path.join(out, "j.pfm"), sky)
+make_scenes.write_png(os.path.join(out, "k.png"), [[tuple(min(255, int(40 * c)) for c in px) for px in row] for row in sky])
+images = {n: open(os.path.join(out, n), "rb").read() for n in ("h.hdr", "i.hdr", "j.pfm", "k.png")}
+env0 = make_scenes.cornell_envmap(16, 4, filename="IMAGE")
 for it in range(N):
     r = random.random()
     if r < 0.35:      # numeric value fuzz
@@ -38,6 +44,18 @@ for it in range(N):
             elif op < 0.7: b.insert(i, random.choice(['<', '>', '"', '/', '$', '0', '-', 'e', ' ', '&', ';', '<!--', ']]>', '<?']))
             else: b[i:i+1] = list(random.choice(['<rgb/>', '<ref id="x"/>', '<shape type="obj"/>', '<transform name="to_world"/>', '<animation name="to_world"/>']))
         t = "".join(b)
+    elif r < 0.7:     # image file fuzz (envmap)
+        n = random.choice(list(images)); b = bytearray(images[n])
+        for _ in range(random.randint(1, 4)):
+            op = random.random(); i = random.randrange(len(b))
+            if op < 0.3: del b[i:i + random.randint(1, 30)]
+            elif op < 0.6: b[i] = random.randrange(256)
+            elif op < 0.8: b[i:i] = random.choice([b"-1", b"99999999", b" ", b"\n", b"\x02\x02\x7f\xff", b"\xff\xff", b"\x80\x00", b"-Y 8 +X 100000\n", b"1e39"])
+            else: b = b[:i]
+            if not b: b = bytearray(b" ")
+        fn = "img%d.%s" % (it, n.split(".")[1])
+        open(os.path.join(out, fn), "wb").write(bytes(b))
+        t = env0.replace("IMAGE", fn)
     else:             # mesh file fuzz
         n = random.choice(list(orig)); typ = n.split(".")[1]
         b = bytearray(orig[n])
