@@ -163,7 +163,7 @@ def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_ov
     gather_buf = torch.empty((world, p1 - p0, W, 4), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
     lib = mi._lib()
     keys = ("ms_trace", "ms_shade", "ms_shadow", "ms_generate", "ms_splat", "ms_total", "ms_first", "n_bounces", "n_shadow_rays", "n_paths")
-    acc = dict.fromkeys(keys, 0.0)
+    acc = dict.fromkeys(keys + ("launches", "first_launches", "launches_equiv", "inline_bounces"), 0.0)
     acc.update(launches=0, first_launches=0)
     K = len(offsets) if offsets else 1
     native = bool(offsets) or striped            # library-native [K][H][W][4] films (K offsets in ONE traversal, config c5)
@@ -203,6 +203,7 @@ def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_ov
             for k in keys:
                 acc[k] += st[k]
             acc["launches"] += st["n_launches_shade"]; acc["first_launches"] += st["n_launches_first"]
+            acc["launches_equiv"] += st["n_inline_iterations"]; acc["inline_bounces"] += st["n_bounces_inline"]
 
     def barrier():
         if world > 1:
@@ -302,43 +303,68 @@ def main():
     args.offsets, args.defines, args.scene, args.res, args.spp = r["offsets"], r["defines"], r["scene_path"], r["res"], r["spp_per_gpu"]
     if rank == 0:
         img, film_host = r["image"], r["film"]
-        # the dominant kernel = the bounce kernel k_shade<MODE 1|0>.  In the fused pipeline the FIRST launch of a frame is another
-        # instantiation (MODE 2: lane generation + primary ray + bounce 0, reads no state at all); it is timed separately
-        # (ms_first) and kept out of the roofline figure, as rocprofv3 lists it as a separate kernel too.
+        # The dominant kernel.  Fused pipeline (C2): k_shade<MODE 2> generates the lanes, traces the primary rays and runs up to four
+        # iterations of the bounce loop with the path state in registers -- for C2 (max_depth 4) that is the whole path, no bounce-kernel
+        # launch is left and the kernel is bound by VALU issue, not by HBM.  Split pipeline / longer paths: the bounce kernel
+        # k_shade<MODE 1|0> streams the path state through HBM once per iteration and is priced by its algorithmic bytes.
         n_first = acc["first_launches"]
-        shade_lanes = acc["n_bounces"] - (acc["n_paths"] if n_first else 0)   # lanes entering the bounce-kernel launches
-        shade_s = (acc["ms_shade"] - acc["ms_first"]) * 1e-3
-        bounce_launches = acc["launches"] - n_first
-        loop_s = (acc["ms_trace"] + acc["ms_shade"] + acc["ms_shadow"]) * 1e-3
         fused = acc["ms_shadow"] == 0.0                          # one kernel per bounce (occlusion + next closest hit inline)
         k_off = len(args.offsets) if args.offsets else 1
         per_bounce = kernel_bytes_per_bounce(fused, k_off)
-        kernel_bytes = per_bounce * shade_lanes
-        kernel_name, kernel_key = ("k_shade<MODE 1 = fused: shade + occlusion + next closest hit>" if fused else "k_shade<MODE 0>"), "k_shade"
-        achieved = kernel_bytes / max(shade_s, 1e-12) / 1e9
-        traffic = None
+        bounce_launches = acc["launches"] - n_first
+        loop_s = (acc["ms_trace"] + acc["ms_shade"] + acc["ms_shadow"]) * 1e-3
         tfile = os.path.join(HERE, "profiles", "roofline_traffic.json")
+        pmc = {}
         if os.path.exists(tfile) and args.config == "c2" and fused:   # the PMC passes were taken on exactly this workload (per rank and launch)
             try:
-                traffic = json.load(open(tfile)).get(kernel_key, {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(tfile))
             except Exception:
-                traffic = None
-        roofline = {
-            "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": round(kernel_bytes / max(bounce_launches, 1), 1),
-            "algorithmic_bytes_per_path_bounce": per_bounce,
-            "path_bounces_per_launch": round(shade_lanes / max(bounce_launches, 1), 1),
-            "avg_launch_ms": round(shade_s * 1e3 / max(bounce_launches, 1), 5), "launches_per_step": bounce_launches / args.steps,
-            "survey_model": {"what": "SURVEY 8(d): 412 B per path-bounce over ALL loop kernels (trace+shade+shadow time)",
-                             "bytes_per_path_bounce": B_BOUNCE,
-                             "achieved": round(B_BOUNCE * acc["n_bounces"] / max(loop_s, 1e-12) / 1e9, 1),
-                             "frac": round(B_BOUNCE * acc["n_bounces"] / max(loop_s, 1e-12) / 1e9 / HBM_PEAK_GBS, 4)},
-            "stages": {"ms_first_bounce": round(acc["ms_first"] / args.steps, 4),
-                       "ms_trace": round(acc["ms_trace"] / args.steps, 4), "ms_shade": round(acc["ms_shade"] / args.steps, 4),
-                     "ms_shadow": round(acc["ms_shadow"] / args.steps, 4), "ms_generate": round(acc["ms_generate"] / args.steps, 4),
-                     "ms_splat": round(acc["ms_splat"] / args.steps, 4)},
-        }
+                pmc = {}
+        stages = {"ms_first_bounce": round(acc["ms_first"] / args.steps, 4),
+                  "ms_trace": round(acc["ms_trace"] / args.steps, 4), "ms_shade": round(acc["ms_shade"] / args.steps, 4),
+                  "ms_shadow": round(acc["ms_shadow"] / args.steps, 4), "ms_generate": round(acc["ms_generate"] / args.steps, 4),
+                  "ms_splat": round(acc["ms_splat"] / args.steps, 4)}
+        survey_model = {"what": "SURVEY 8(d): 412 B per path-bounce over ALL loop kernels (trace+shade+shadow time)", "bytes_per_path_bounce": B_BOUNCE,
+                        "achieved": round(B_BOUNCE * acc["n_bounces"] / max(loop_s, 1e-12) / 1e9, 1),
+                        "frac": round(B_BOUNCE * acc["n_bounces"] / max(loop_s, 1e-12) / 1e9 / HBM_PEAK_GBS, 4)}
+        if n_first and bounce_launches == 0:
+            # every iteration ran inside the first-bounce kernel: VALU-issue roofline (256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions per second,
+            # /opt/skills/guides/MI355X_MICROARCH.md "Wave scheduling"); executed instructions from the SQ_INSTS_VALU pass under profiles/
+            first_s = acc["ms_first"] * 1e-3 / max(n_first, 1)                       # average launch
+            paths_per_launch = acc["n_paths"] / max(n_first, 1)
+            out_bytes = (8 + 8 + 16 * k_off) * paths_per_launch                       # sample position, stream selectors, result
+            wave_insts = pmc.get("k_shade_first", {}).get("valu_wave_insts_per_launch")
+            valu_peak = 256 * 4 * 32 * 2.4e9 / 1e12                                   # T lane-instructions / s
+            achieved = (wave_insts * 64 / first_s / 1e12) if wave_insts else None
+            roofline = {
+                "bound": "valu", "kernel": "k_shade<MODE 2: lane generation + primary ray + ALL %d bounce iterations, path state in registers>" % round(acc["launches_equiv"] / max(n_first, 1)),
+                "achieved": round(achieved, 2) if achieved else None, "peak": round(valu_peak, 1), "unit": "T lane-instr/s",
+                "frac": round(achieved / valu_peak, 4) if achieved else None,
+                "traffic": pmc.get("k_shade_first", {}).get("hbm_bytes_per_launch"),
+                "algorithmic_bytes_per_launch": round(out_bytes, 1), "avg_launch_ms": round(first_s * 1e3, 5), "launches_per_step": n_first / args.steps,
+                "valu_lane_instructions_per_path": round(wave_insts * 64 / paths_per_launch, 1) if wave_insts else None,
+                "path_bounces_per_launch": round(acc["n_bounces"] / max(n_first, 1), 1),
+                "hbm_view": {"what": "the same launch against the HBM roofline: it only writes its outputs (%d B per path); the %d B per path-bounce of the "
+                                     "wavefront pipeline no longer exist" % (8 + 8 + 16 * k_off, per_bounce),
+                             "achieved_GBs": round(out_bytes / first_s / 1e9, 1), "frac": round(out_bytes / first_s / 1e9 / HBM_PEAK_GBS, 4),
+                             "state_stream_avoided_GBs": round(per_bounce * (acc["n_bounces"] - acc["n_paths"]) / max(n_first, 1) / first_s / 1e9, 1)},
+                "survey_model": survey_model, "stages": stages,
+            }
+        else:
+            shade_lanes = acc["n_bounces"] - acc["inline_bounces"]   # lanes entering the bounce-kernel launches
+            shade_s = (acc["ms_shade"] - acc["ms_first"]) * 1e-3
+            kernel_bytes = per_bounce * shade_lanes
+            kernel_name = "k_shade<MODE 1 = fused: shade + occlusion + next closest hit>" if fused else "k_shade<MODE 0>"
+            achieved = kernel_bytes / max(shade_s, 1e-12) / 1e9
+            roofline = {
+                "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("k_shade", {}).get("hbm_bytes_per_launch"),
+                "algorithmic_bytes_per_launch": round(kernel_bytes / max(bounce_launches, 1), 1),
+                "algorithmic_bytes_per_path_bounce": per_bounce,
+                "path_bounces_per_launch": round(shade_lanes / max(bounce_launches, 1), 1),
+                "avg_launch_ms": round(shade_s * 1e3 / max(bounce_launches, 1), 5), "launches_per_step": bounce_launches / args.steps,
+                "survey_model": survey_model, "stages": stages,
+            }
         out = {
             "metric": "Mpaths/s (whole node), Doppler Cornell 512x512 64spp" if args.config == "c2" else
                       "Mpaths/s (whole node), BASELINE config %s" % args.config, "value": round(value, 2), "unit": "Mpaths/s",

@@ -136,6 +136,10 @@ typedef struct {
      * in ms_shade / n_launches_shade; these two fields single them out */
     uint32_t n_launches_first;
     double   ms_first;
+    /* the first-bounce kernel runs up to four iterations of the bounce loop itself, the path state in registers: iterations covered by
+     * the first-bounce launches (summed over the batches) and the path-bounces among n_bounces that ran there */
+    uint32_t n_inline_iterations;
+    uint64_t n_bounces_inline;
 } dtof_render_stats;
 
 /* out_rgb: caller-owned host buffer, crop_height*crop_width*3 float32, developed (RGB / W). */

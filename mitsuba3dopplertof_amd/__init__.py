@@ -35,7 +35,8 @@ class _Stats(C.Structure):
                 ("ms_total", C.c_double), ("ms_generate", C.c_double), ("ms_trace", C.c_double),
                 ("ms_shade", C.c_double), ("ms_shadow", C.c_double), ("ms_splat", C.c_double),
                 ("n_launches_trace", C.c_uint32), ("n_launches_shade", C.c_uint32), ("n_launches_shadow", C.c_uint32),
-                ("n_batches", C.c_uint32), ("n_launches_first", C.c_uint32), ("ms_first", C.c_double)]
+                ("n_batches", C.c_uint32), ("n_launches_first", C.c_uint32), ("ms_first", C.c_double),
+                ("n_inline_iterations", C.c_uint32), ("n_bounces_inline", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -136,10 +136,11 @@ struct ShadeArgs {
     const uint32_t *qin, *count_in; uint32_t *qout, *alive_out, *shadow_out; uint32_t depth, trace_next; LaneDebug *dbg;
 };
 template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, bool SPEC>
-__global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) {
+__global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : 1) void k_shade(ShadeArgs args_by_value) {
     constexpr bool FUSED = MODE != 0, FIRST = MODE == 2;
     extern __shared__ uint4 lds[];
     __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_inline[2 * kMaxInline];   // FIRST: lanes alive after / shadow rays of every inline iteration but the last (statistics)
     typedef const char __attribute__((address_space(4))) *KernargBytes;
     const KernargBytes kernarg = (KernargBytes) __builtin_amdgcn_kernarg_segment_ptr();
     const ShadeArgs &A0 = *(const ShadeArgs *) kernarg;
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
     const uint32_t seg = blockIdx.x;
     const uint32_t count = seg_count(A0.count_in, seg, A0.rp.n_lanes);
     uint32_t n_alive = 0, n_shadow = 0;
+    if (FIRST && threadIdx.x < 2 * kMaxInline) s_inline[threadIdx.x] = 0;   // one wave per block: no barrier needed
     if (count != 0) {
     const uint8_t *base = LDS ? stage_scene(A0.scene, A0.scene_bytes, lds) : A0.scene;
     SceneView sv = make_view(base);
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
     asm volatile("" : "+s"(rebase));
     const ShadeArgs &A = *(const ShadeArgs *) (kernarg + rebase);
     const RenderParams &rp = A.rp; const Queues &q = A.q;
-    const uint32_t *const qin = A.qin; uint32_t *const qout = A.qout; const uint32_t depth = A.depth, trace_next = A.trace_next; LaneDebug *const dbg = A.dbg;
+    const uint32_t *const qin = A.qin; uint32_t *const qout = A.qout; const uint32_t depth0 = A.depth, trace_next_last = A.trace_next; LaneDebug *const dbg = A.dbg;
     const uint32_t flat = FUSED && !MESH ? rp.flat_objects : 0u;   // != 0: the scene's object count, every ray tests them all (trace_flat)
     uint32_t j = cbase + threadIdx.x;
     bool in_range = j < count;
@@ -169,10 +171,15 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
     float3 rbase[KMAX];   // FIRST: the result a lane ends this launch with if its NEE candidate is not committed
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) rbase[k] = make_float3(0.f, 0.f, 0.f);
+    // Path state of the lane.  MODE 2 runs rp.inline_iters iterations of the bounce loop right here ("megakernel" head): between them the
+    // state stays in these registers instead of making the round trip through the queues in HBM; after the last one the survivors are
+    // written out and compacted exactly as before, for the bounce kernels (MODE 1) to continue with.
+    uint32_t hid = 0xffffffffu; float4 ra, rb, st; uint4 hh; Rng main, path;
+    float4 stb_reg = make_float4(0.f, 0.f, 0.f, 1.f); float2 stc_reg = make_float2(1.f, 1.f);   // prev_si.p | prev_bsdf_pdf, eta | prev_bsdf_delta
+    float memo_m[12], memo_inv[12];   // instance memo: the one instance's matrix and inverse at this lane's ray time
+    bool lane_on = in_range;
     if (in_range) {
         l = qin ? qin[seg * kSeg + j] : seg * kSeg + j;
-        uint32_t hid; float4 ra, rb, st; uint4 hh; Rng main, path;
-        float memo_m[12], memo_inv[12];   // instance memo: the one instance's matrix and inverse at this lane's ray time
         if (FIRST) {
             // the wave's 64 lanes are the 64-aligned lanes [lane_base + seg * 512 + cbase, + 64): samples of one pixel if spp is a multiple of 64
             const bool wave_pixel = rp.spp_log2 != 0xffffffffu && rp.spp_log2 >= 6 && (rp.lane_base & 63u) == 0;
@@ -190,7 +197,16 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
                               : trace_scene<false, MESH, FUSED>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
             hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
             hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu;
-        } else {
+        }
+    }
+    const uint32_t n_inline = FIRST ? rp.inline_iters : 1u;
+    for (uint32_t it = 0; ; ++it) {
+    const uint32_t depth = depth0 + it;
+    const bool last = it + 1 >= n_inline;                 // uniform
+    const uint32_t trace_next = last ? trace_next_last : 1u;
+    alive = false; want_shadow = false;
+    if (lane_on) {
+        if (!FIRST) {
             hid = q.hit_id[l];
             if (hid != 0xffffffffu) {
                 ra = q.ray_a[l]; rb = q.ray_b[l]; hh = load_hit<MESH>(q, l); st = q.st_a[l];
@@ -216,10 +232,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
             // The ray left the scene: si.emitter(scene) is the environment (dopplertofpath.cpp:150-168).  DirectionSample(scene, si, prev_si)
             // points along the ray; ConstantBackgroundEmitter::pdf_direction is the uniform-sphere density (constant.cpp:150-155).  A primary
             // ray that sees the environment directly only counts if emitters are not hidden (valid_ray, :101-102,279-282).
-            const float4 stv = FIRST ? make_float4(1.f, 1.f, 1.f, 0.f) : q.st_a[l];
+            const float4 stv = FIRST ? st : q.st_a[l];
             const float time_ = FIRST ? ra.w : q.ray_a[l].w;
             float prev_pdf = 1.f; bool pdelta = true;
-            if (depth > 0) { prev_pdf = q.st_b[l].w; pdelta = q.st_c[l].y != 0.f; }
+            if (depth > 0) { prev_pdf = FIRST ? stb_reg.w : q.st_b[l].w; pdelta = (FIRST ? stc_reg.y : q.st_c[l].y) != 0.f; }
             const DEmitter &env = sv.emitters[rp.env_index];
             const bool is_map = env.kind == EMITTER_ENVMAP;   // EnvironmentMapEmitter::pdf_direction / eval (envmap.cpp:408-425,299-310) with ds.d = -si.wi = the ray direction
             const V3 rd = FIRST ? mk(rb.x, rb.y, rb.z) : [&] { const float4 b4 = q.ray_b[l]; return mk(b4.x, b4.y, b4.z); }();
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
             for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
                 V3 v = le * mis_bsdf;
                 if (rp.integrator == 0) v = v * modulation_weight(rp, rp.phase[k], time_, stv.w);
-                const float4 r = FIRST ? make_float4(0.f, 0.f, 0.f, 0.f) : q.res[(size_t) k * q.capacity + l];
+                const float4 r = FIRST ? make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f) : q.res[(size_t) k * q.capacity + l];
                 const float4 acc = make_float4(fmaf(stv.x, v.x, r.x), fmaf(stv.y, v.y, r.y), fmaf(stv.z, v.z, r.z), 0.f);
                 if (FIRST) rbase[k] = make_float3(acc.x, acc.y, acc.z); else q.res[(size_t) k * q.capacity + l] = acc;
             }
@@ -239,7 +255,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
             V3 o = mk(ra.x, ra.y, ra.z), d = mk(rb.x, rb.y, rb.z); float time = ra.w;
             V3 thr = mk(st.x, st.y, st.z); float path_length = st.w;
             float eta_path = 1.f; bool prev_delta = depth == 0;   // dopplertofpath.cpp:103-108: eta = 1, prev_bsdf_delta = true
-            if (SPEC && depth > 0) { const float2 sc = q.st_c[l]; eta_path = sc.x; prev_delta = sc.y != 0.f; }
+            if (SPEC && depth > 0) { const float2 sc = FIRST ? stc_reg : q.st_c[l]; eta_path = sc.x; prev_delta = sc.y != 0.f; }
             bool correlate = (depth + 1) < rp.path_correlation_depth;
             const bool plain = rp.integrator != 0;   // `path`: no modulation weight
             const bool single = plain || rp.sampler_kind != SAMPLER_CORRELATED;   // main stream only (path.cpp:197,213-214,273; sampler.h:141-144)
@@ -249,6 +265,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
 
             Surface si;
             if (!FIRST && have_memo) instance_memo_fill(sv, time, memo_m, memo_inv);
+            if (FIRST && it > 0 && have_memo) {   // a ray's time does not change along its path: the inverse filled at generation still sits in the LDS column
+                instance_matrix(sv.objects[sv.memo_obj], time, memo_m); instance_memo_load(sv, memo_inv);
+            }
             compute_surface<MESH>(sv, hid & ((1u << q.id_shift) - 1u), hid >> q.id_shift, hh.w, t, u2f(hh.y), u2f(hh.z), o, d, time, si, have_memo, memo_m, memo_inv);
             const DShape *sh = si.shape;
 
@@ -258,9 +277,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
             float4 rcur[KMAX];
             if (AREA) {
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) rcur[k] = FIRST ? make_float4(0.f, 0.f, 0.f, 0.f) : q.res[(size_t) k * q.capacity + l];
+                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) rcur[k] = FIRST ? make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f) : q.res[(size_t) k * q.capacity + l];
                 if (sh->flags & SF_EMITTER) {
-                    float4 pb = depth > 0 ? q.st_b[l] : make_float4(0.f, 0.f, 0.f, 1.f);   // prev_si.p, prev_bsdf_pdf
+                    float4 pb = depth > 0 ? (FIRST ? stb_reg : q.st_b[l]) : make_float4(0.f, 0.f, 0.f, 1.f);   // prev_si.p, prev_bsdf_pdf
                     V3 rel = si.p - mk(pb.x, pb.y, pb.z);                      // DirectionSample(scene, si, prev_si), records.h:173-180
                     float dist = norm(rel);
                     V3 dsd = rel * rcp(dist);
@@ -552,7 +571,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
                 bool nonzero = false;
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
-                    float4 r = AREA ? rcur[k] : (FIRST ? make_float4(0.f, 0.f, 0.f, 0.f) : q.res[(size_t) k * q.capacity + l]);
+                    float4 r = AREA ? rcur[k] : (FIRST ? make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f) : q.res[(size_t) k * q.capacity + l]);
                     V3 v = mk(bsdf_val.x * em_weight.x * mis_em, bsdf_val.y * em_weight.y * mis_em, bsdf_val.z * em_weight.z * mis_em);
                     if (!plain) { float lw = modulation_weight(rp, rp.phase[k], time, path_length + ds_dist); v = v * lw; }
                     float3 c = make_float3(fmaf(thr.x, v.x, r.x), fmaf(thr.y, v.y, r.y), fmaf(thr.z, v.z, r.z));
@@ -584,18 +603,28 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
             alive = active_next && (!rr_active || rr_continue) && thr_max != 0.f;
             if (alive) {
                 nra = make_float4(no.x, no.y, no.z, time); nrb = make_float4(nd.x, nd.y, nd.z, kLargest);
-                q.ray_a[l] = nra;
-                q.ray_b[l] = nrb;
-                q.st_a[l] = make_float4(thr.x, thr.y, thr.z, path_length);
-                if (AREA) q.st_b[l] = make_float4(si.p.x, si.p.y, si.p.z, bs_pdf);   // prev_si, prev_bsdf_pdf (:256-257)
-                if (SPEC) q.st_c[l] = make_float2(eta, bs_delta ? 1.f : 0.f);         // eta, prev_bsdf_delta (:252,258)
+                const float4 sta = make_float4(thr.x, thr.y, thr.z, path_length), stb = make_float4(si.p.x, si.p.y, si.p.z, bs_pdf);
+                const float2 stc = make_float2(eta, bs_delta ? 1.f : 0.f);
+                if (!FIRST || last) {   // the state leaves for the queues (an inline iteration keeps it in registers)
+                    q.ray_a[l] = nra;
+                    q.ray_b[l] = nrb;
+                    q.st_a[l] = sta;
+                    if (AREA) q.st_b[l] = stb;   // prev_si, prev_bsdf_pdf (:256-257)
+                    if (SPEC) q.st_c[l] = stc;   // eta, prev_bsdf_delta (:252,258)
+                }
+                if (FIRST) { st = sta; stb_reg = stb; stc_reg = stc; }
             }
-            if (alive || rp.n_passes > 1)   // several passes: the state of a finished path is what its lane starts the next pass with
+            if ((alive && (!FIRST || last)) || rp.n_passes > 1)   // several passes: the state of a finished path is what its lane starts the next pass with
                 q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
         }
     }
-    uint32_t slot = block_append(alive, s_cnt, n_alive);
-    if (alive) qout[seg * kSeg + slot] = l;
+    if (last) {
+        uint32_t slot = block_append(alive, s_cnt, n_alive);
+        if (alive) qout[seg * kSeg + slot] = l;
+    } else {   // FIRST, one wave per block
+        const uint32_t n_on = (uint32_t) __popcll(__ballot(alive));
+        if (threadIdx.x == 0) s_inline[2 * it] += n_on;
+    }
     if (FUSED) {
         bool commit = false;
         if (want_shadow) {   // test_visibility (scene.cpp:266-271): an unoccluded sample commits its candidate result
@@ -607,12 +636,15 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
                           : !trace_scene<true, MESH, true>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
 #endif
         }
-        if (FIRST ? in_range : commit) {   // FIRST: every lane's result is defined here (nothing zeroed it beforehand)
+        if (FIRST) {   // the running result stays in rbase over the inline iterations; every lane's result is defined after the last (nothing zeroed it)
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
-                const float3 v = commit ? cand[k] : rbase[k];
-                q.res[(size_t) k * q.capacity + l] = make_float4(v.x, v.y, v.z, 0.f);
+                if (commit) rbase[k] = cand[k];
+                if (last && in_range) q.res[(size_t) k * q.capacity + l] = make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f);
             }
+        } else if (commit) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) q.res[(size_t) k * q.capacity + l] = make_float4(cand[k].x, cand[k].y, cand[k].z, 0.f);
         }
         if (alive && trace_next) {   // closest hit of the continuation ray, consumed by the next bounce
             Hit h;
@@ -622,9 +654,11 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
             bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h)
                               : trace_scene<false, MESH, true>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
 #endif
-            store_hit<MESH>(q, l, h, found);
+            if (!FIRST || last) store_hit<MESH>(q, l, h, found);
+            if (FIRST) { hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim); hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu; }
         }
-        n_shadow += (uint32_t) __popcll(__ballot(want_shadow)) * ((threadIdx.x & 63) == 0 ? 1u : 0u);   // per-wave partial (stats only)
+        const uint32_t n_sh = (uint32_t) __popcll(__ballot(want_shadow)) * ((threadIdx.x & 63) == 0 ? 1u : 0u);   // per-wave partial (stats only)
+        if (last) n_shadow += n_sh; else if (threadIdx.x == 0) s_inline[2 * it + 1] += n_sh;
     } else {
         uint32_t sslot = seg * kSeg + block_append(want_shadow, s_cnt, n_shadow);
         if (want_shadow) {
@@ -634,6 +668,12 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
                 q.sh_c[(size_t) k * q.capacity + sslot] = make_float4(cand[k].x, cand[k].y, cand[k].z, u2f(l));
         }
     }
+    if (last) break;
+    // next inline iteration: the continuation ray and its closest hit become the lane's current ray (st / stb / stc were set where the
+    // bounce computed them); a lane whose path ended sits out the remaining iterations
+    lane_on = alive;
+    if (alive) { ra = nra; rb = nrb; }
+    }   // inline iterations
     }   // chunk loop
     }   // count != 0
     if (FUSED && kShadeBlock > 64) {   // shadow-ray count for the statistics: sum the four per-wave partials
@@ -642,7 +682,16 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs args_by_value) 
         __syncthreads();
         n_shadow = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     }
-    if (threadIdx.x == 0) { A0.alive_out[seg] = n_alive; A0.shadow_out[seg] = n_shadow; }
+    if (threadIdx.x == 0) {
+        A0.alive_out[seg] = n_alive; A0.shadow_out[seg] = n_shadow;
+        if (FIRST) {   // the count slots of the inline iterations before the last lie 2 * n_seg words apart below the last one's (render_rows)
+            const uint32_t n_inl = A0.rp.inline_iters, n_seg = gridDim.x;
+            for (uint32_t i = 0; i + 1 < n_inl; ++i) {
+                uint32_t *slot = A0.alive_out - (size_t) 2 * (n_inl - 1 - i) * n_seg;
+                slot[seg] = s_inline[2 * i]; slot[n_seg + seg] = s_inline[2 * i + 1];
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------- shadow

@@ -379,7 +379,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     hipEvent_t ev_fork = g_fork.e, ev_join = g_join.e;
     if (stats) { memset(stats, 0, sizeof *stats); ev0 = sc->take_event(); ev1 = sc->take_event(); HIP_CHECK(hipEventRecord(ev0, ss[0])); }
     if (n_streams == 2) { HIP_CHECK(hipEventRecord(ev_fork, ss[0])); HIP_CHECK(hipStreamWaitEvent(ss[1], ev_fork, 0)); }
-    std::vector<uint64_t> h_counts; std::vector<uint32_t> batch_lanes, batch_iters;
+    std::vector<uint64_t> h_counts; std::vector<uint32_t> batch_lanes, batch_iters, batch_inline;   // batch_inline: iterations the first-bounce launch of the batch covered (fused pipeline)
     // per-iteration totals of every batch: sized ONCE (DevBuf::ensure reallocates without copying, and a hipFree in the middle of the
     // frame would also synchronise the device)
     const uint32_t run_passes = lane_dump ? dump_pass + 1 : n_passes;   // a lane dump of pass k needs the stream states passes 0 .. k-1 leave
@@ -430,16 +430,26 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
                 uint64_t sum = 0; for (uint32_t v : alive) sum += v;
                 if (sum == 0) break;
             }
+            const bool first = first_inline && it == 0;
+            // The first-bounce kernel of the fused pipeline runs up to kMaxInline iterations of the loop itself, the path state in registers
+            // (RenderParams::inline_iters; DTOF_INLINE_ITERS=1 keeps one launch per iteration).  Lane dumps and multi-pass renders, whose
+            // per-iteration state must be visible in memory, take one iteration per launch.
+            uint32_t span = 1;
+            if (first && !lane_dump && n_passes == 1) {
+                static const uint32_t env_inline = [] { const char *e = getenv("DTOF_INLINE_ITERS"); const int v = e ? atoi(e) : (int) kMaxInline; return (uint32_t) (v < 1 ? 1 : v > (int) kMaxInline ? (int) kMaxInline : v); }();
+                while (span < env_inline && (it + span) < rp.max_depth && !(it + span + 1 >= rp.max_depth && skip_tail)) ++span;   // the loop head's conditions for iteration it + span
+            }
+            rp.inline_iters = span;
+            it += span - 1;   // `it` is now the last iteration this launch covers
             // does iteration it+1 run?  (same conditions as the loop head)
             const bool next_runs = (it + 1 < rp.max_depth) && !(it + 2 >= rp.max_depth && skip_tail);
-            const bool first = first_inline && it == 0;
             if (!fused || (it == 0 && !first)) { t = tm.begin(1, s); launch_trace(blob, blob_bytes, rp, q, qin, count_in, stack_depth, s); tm.end(1, t, s); if (stats) stats->n_launches_trace++; }
             // per-iteration count slots; beyond kMaxIter iterations (unbounded depth, paths that russian roulette keeps alive that long)
             // the slots are reused -- only the statistics lose those iterations, no path is cut short
             uint32_t *qout = q.q[it & 1], *alive_out = q.counts + (size_t) (2 * (it % kMaxIter)) * n_seg, *shadow_out = alive_out + n_seg;
             const int st_shade = first ? 5 : 2;
-            t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it, fused, next_runs, stack_depth, s, first, first && dump_now ? sc->ws.dbg.p : nullptr); tm.end(st_shade, t, s);
-            if (stats && first) stats->n_launches_first++;
+            t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it + 1 - span, fused, next_runs, stack_depth, s, first, first && dump_now ? sc->ws.dbg.p : nullptr); tm.end(st_shade, t, s);
+            if (stats && first) { stats->n_launches_first++; stats->n_inline_iterations += span; batch_inline.push_back(span); }
             if (!fused) { t = tm.begin(3, s); launch_shadow(blob, blob_bytes, rp, q, shadow_out, stack_depth, s); tm.end(3, t, s); if (stats) stats->n_launches_shadow++; }
             if (stats) stats->n_launches_shade++;
             qin = qout; count_in = alive_out;
@@ -477,7 +487,9 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             stats->n_paths += batch_lanes[b];
             uint64_t in = batch_lanes[b];
             for (uint32_t i = 0; i < batch_iters[b]; ++i) {
-                stats->n_bounces += in; stats->n_shadow_rays += h_counts[off + 2 * i + 1]; in = h_counts[off + 2 * i];
+                stats->n_bounces += in; stats->n_shadow_rays += h_counts[off + 2 * i + 1];
+                if (b < batch_inline.size() && i < batch_inline[b]) stats->n_bounces_inline += in;
+                in = h_counts[off + 2 * i];
             }
             off += 2 * (size_t) batch_iters[b];
         }

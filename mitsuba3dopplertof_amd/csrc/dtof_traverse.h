@@ -402,21 +402,31 @@ DTOF_D bool trace_flat(const SceneView &sv, ConstBytes flat_table, uint32_t n_ob
     best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
     bool occluded = false;
     DTOF_STAT(0);
-    FlatRecord next = flat_load(table);
-    for (uint32_t oi = 0; oi < n_objects; ++oi) {
-        const FlatRecord cur = next;
-        if (oi + 1 < n_objects) next = flat_load(table + oi + 1);   // the next record's scalar load flies while this one is tested
-        if (cur.instance) {
-            const bool hit = intersect_object<ANY, false, MEMO>(sv, oi, o, d, time, maxt, best, stack, 0, blockDim.x);
-            if (ANY) occluded |= hit;
-            continue;
-        }
-        const V3 lo = xf_point(cur.m, o), ld = xf_vector(cur.m, d);   // rect_hit
+    auto test = [&](const FlatRecord &rec, uint32_t oi) {   // rect_hit on a plain rectangle's record
+        const V3 lo = xf_point(rec.m, o), ld = xf_vector(rec.m, d);
         const float t = -lo.z / ld.z;
         const float u = fmaf(ld.x, t, lo.x), v = fmaf(ld.y, t, lo.y);
         const bool hit = t >= 0.f && t <= maxt && fabsf(u) <= 1.f && fabsf(v) <= 1.f;
         if (ANY) occluded |= hit;
         else if (hit && t < best.t) { best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = 0; }
+    };
+    // Two record buffers take turns (the loop is unrolled by two), so the next record's scalar load flies while the current one is tested
+    // and no register is copied from one iteration to the next.  Instances are noted in a mask and intersected after the rectangles: the
+    // tie rule of intersect_object (equal t goes to the lower object index) does not depend on the order of the visits.
+    uint32_t instances = 0, oi = 0;
+    FlatRecord a = flat_load(table), b = a;
+    for (;;) {
+        if (oi + 1 < n_objects) b = flat_load(table + oi + 1);
+        if (a.instance) instances |= 1u << oi; else test(a, oi);
+        if (++oi >= n_objects) break;
+        if (oi + 1 < n_objects) a = flat_load(table + oi + 1);
+        if (b.instance) instances |= 1u << oi; else test(b, oi);
+        if (++oi >= n_objects) break;
+    }
+    while (instances) {   // uniform
+        const uint32_t k = (uint32_t) __builtin_ctz(instances); instances &= instances - 1u;
+        const bool hit = intersect_object<ANY, false, MEMO>(sv, k, o, d, time, maxt, best, stack, 0, blockDim.x);
+        if (ANY) occluded |= hit;
     }
     return ANY ? occluded : best.obj != 0xffffffffu;
 }

@@ -8,7 +8,7 @@ cp "$out/${tag}_bench_n1.json" "profiles/${tag}_bench_n1.json"
 cp "$out/${tag}_bench_n1_under_rocprof.json" "profiles/${tag}_bench_n1_under_rocprof.json"
 stats=$(find "$out/${tag}_stats" -name '*kernel_stats.csv' | head -1)
 cp "$stats" "profiles/${tag}_bench_n1_kernel_stats.csv"
-python3 tools/pmc_summary.py "$out/${tag}_pmc_fetch" "$out/${tag}_pmc_write" profiles/roofline_traffic.json
+if [ -d "$out/${tag}_pmc_valu" ]; then python3 tools/pmc_summary.py "$out/${tag}_pmc_fetch" "$out/${tag}_pmc_write" profiles/roofline_traffic.json "$out/${tag}_pmc_valu"; else python3 tools/pmc_summary.py "$out/${tag}_pmc_fetch" "$out/${tag}_pmc_write" profiles/roofline_traffic.json; fi
 ls -la profiles
 # the other configs (tools/profile_configs.sh), when present
 for c in c1 c3 c4 c5; do

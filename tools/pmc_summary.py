@@ -23,12 +23,14 @@ def short(name):
     m = re.search(r"k_shade<\w+, (\d)", name)     # k_shade<LDS, MODE, AREA, KMAX, MESH>: MODE 2 = the first-bounce instantiation
     if m:
         return "k_shade_first" if m.group(1) == "2" else "k_shade"
-    for k in ("k_shade", "k_trace", "k_shadow", "k_generate", "k_splat_tent3", "k_splat_generic", "k_develop", "k_bounce"):
+    for k in ("k_shade", "k_trace", "k_shadow", "k_generate", "k_splat_x8", "k_splat_pixel", "k_splat_tent3", "k_splat_generic", "k_develop", "k_bounce"):
         if k in name:
             return k
     return None
 
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+# optional third pass: SQ_INSTS_VALU (wave-instructions; x 64 = lane-instructions) for the VALU-issue roofline of the compute-bound kernels
+valu = collect(sys.argv[4], "SQ_INSTS_VALU") if len(sys.argv) > 4 else {}
 out = {}
 for name in set(fetch) | set(write):
     k = short(name)
@@ -40,5 +42,7 @@ for name in set(fetch) | set(write):
               "hbm_read_bytes_per_launch": int(2 * fk * 1024), "hbm_write_bytes_per_launch": int(wk * 1024),
               "hbm_bytes_per_launch": int((2 * fk + wk) * 1024),
               "note": "reads = 2*FETCH_SIZE*1024 (gfx950 half-count correction), writes = WRITE_SIZE*1024"}
+    if valu.get(name):
+        out[k]["valu_wave_insts_per_launch"] = int(sum(valu[name]) / len(valu[name]))
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))
