@@ -325,13 +325,17 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     // Pipeline choice.  "fused" runs occlusion + continuation traversal inside the shade kernel (one kernel per bounce);
     // it wins when traversal is trivial (measured: Cornell-wall 4.00 vs 4.71 ms) and loses when traversal dominates
     // (Cornell-boxes 2.20 vs 1.97 ms, Domino 116 vs 102 ms) because the heavy shade kernel then diverges at 3 waves/SIMD.
-    // auto = fused for scenes without triangle meshes and with at most 16 objects.  DTOF_PIPELINE=split|fused overrides.
+    // auto = fused for scenes of at most 16 objects without triangle meshes (see below).  DTOF_PIPELINE=split|fused overrides.
     static const int env_pipeline = [] { const char *e = getenv("DTOF_PIPELINE"); std::string v = e ? e : ""; return v == "split" ? 0 : v == "fused" ? 1 : 2; }();
     const BlobHeader *bh = (const BlobHeader *) sc->blob.data();
     static const bool env_fuse_first = [] { const char *e = getenv("DTOF_FUSE_FIRST"); return !(e && e[0] == '0'); }();
     bool only_rectangles = bh->n_tris == 0;
     for (auto &sh : sc->host.shapes) only_rectangles &= sh.kind == SHAPE_RECT;
-    const bool fused = env_pipeline == 2 ? (only_rectangles && bh->n_objects <= 16) : env_pipeline == 1;
+    bool analytic_only = bh->n_tris == 0, area_lights = false;   // spheres / disks / cylinders beside rectangles, no triangle mesh
+    for (auto &e : sc->host.emitters) area_lights |= e.kind == EMITTER_AREA;
+    // auto: rectangle-only scenes, and scenes of analytic shapes without area lights (measured at 512 x 512 x 64 with the inline iterations:
+    // spheres 4.96 -> 4.24 ms, disk 5.87 -> 5.19, cylinders 5.16 -> 4.69; a sphere light 5.92 -> 6.34 and the triangle boxes 5.29 -> 6.22 stay split)
+    const bool fused = env_pipeline == 2 ? ((only_rectangles || (analytic_only && !area_lights)) && bh->n_objects <= 16) : env_pipeline == 1;
     if (n_streams == 2 && !lane_dump && last - first <= batch && last - first >= 2 * lanes_per_row) {
         uint64_t rows = (last - first) / lanes_per_row;
         batch = ((rows + 1) / 2) * lanes_per_row;                // one batch would serialise: cut it in two row bands

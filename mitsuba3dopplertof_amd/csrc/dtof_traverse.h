@@ -406,22 +406,31 @@ DTOF_D bool trace_flat(const SceneView &sv, ConstBytes flat_table, uint32_t n_ob
         const V3 lo = xf_point(rec.m, o), ld = xf_vector(rec.m, d);
         const float t = -lo.z / ld.z;
         const float u = fmaf(ld.x, t, lo.x), v = fmaf(ld.y, t, lo.y);
-        const bool hit = t >= 0.f && t <= maxt && fabsf(u) <= 1.f && fabsf(v) <= 1.f;
+        // no short-circuit: four compares and three mask ANDs instead of three exec-mask branches per rectangle (the scalar unit is as busy as the vector units here)
+        const bool hit = (t >= 0.f) & (t <= maxt) & (fabsf(u) <= 1.f) & (fabsf(v) <= 1.f);
         if (ANY) occluded |= hit;
-        else if (hit && t < best.t) { best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = 0; }
+        else {
+            const bool take = hit & (t < best.t);
+            best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v; best.obj = take ? oi : best.obj; best.shape = take ? 0u : best.shape;
+        }
     };
     // Two record buffers take turns (the loop is unrolled by two), so the next record's scalar load flies while the current one is tested
     // and no register is copied from one iteration to the next.  Instances are noted in a mask and intersected after the rectangles: the
     // tie rule of intersect_object (equal t goes to the lower object index) does not depend on the order of the visits.
     uint32_t instances = 0, oi = 0;
-    FlatRecord a = flat_load(table), b = a;
+    FlatRecord a = flat_load(table);
     for (;;) {
-        if (oi + 1 < n_objects) b = flat_load(table + oi + 1);
+        FlatRecord b;
+        const bool more_b = oi + 1 < n_objects;
+        if (more_b) b = flat_load(table + oi + 1);
         if (a.instance) instances |= 1u << oi; else test(a, oi);
-        if (++oi >= n_objects) break;
-        if (oi + 1 < n_objects) a = flat_load(table + oi + 1);
+        if (!more_b) break;
+        ++oi;
+        const bool more_a = oi + 1 < n_objects;
+        if (more_a) a = flat_load(table + oi + 1);
         if (b.instance) instances |= 1u << oi; else test(b, oi);
-        if (++oi >= n_objects) break;
+        if (!more_a) break;
+        ++oi;
     }
     while (instances) {   // uniform
         const uint32_t k = (uint32_t) __builtin_ctz(instances); instances &= instances - 1u;
