@@ -605,7 +605,7 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
                 nra = make_float4(no.x, no.y, no.z, time); nrb = make_float4(nd.x, nd.y, nd.z, kLargest);
                 const float4 sta = make_float4(thr.x, thr.y, thr.z, path_length), stb = make_float4(si.p.x, si.p.y, si.p.z, bs_pdf);
                 const float2 stc = make_float2(eta, bs_delta ? 1.f : 0.f);
-                if (!FIRST || last) {   // the state leaves for the queues (an inline iteration keeps it in registers)
+                if ((!FIRST || last) && trace_next) {   // the state leaves for the queues (an inline iteration keeps it in registers; after the last iteration of the loop nobody reads it)
                     q.ray_a[l] = nra;
                     q.ray_b[l] = nrb;
                     q.st_a[l] = sta;
@@ -614,13 +614,13 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
                 }
                 if (FIRST) { st = sta; stb_reg = stb; stc_reg = stc; }
             }
-            if ((alive && (!FIRST || last)) || rp.n_passes > 1)   // several passes: the state of a finished path is what its lane starts the next pass with
+            if ((alive && (!FIRST || last) && trace_next) || rp.n_passes > 1)   // several passes: the state of a finished path is what its lane starts the next pass with
                 q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
         }
     }
     if (last) {
         uint32_t slot = block_append(alive, s_cnt, n_alive);
-        if (alive) qout[seg * kSeg + slot] = l;
+        if (alive && trace_next) qout[seg * kSeg + slot] = l;
     } else {   // FIRST, one wave per block
         const uint32_t n_on = (uint32_t) __popcll(__ballot(alive));
         if (threadIdx.x == 0) s_inline[2 * it] += n_on;
