@@ -34,7 +34,7 @@ static_assert(sizeof(BlobHeader) == 80, "BlobHeader");
 // One top-level object of a small rectangle-only scene as trace_flat (dtof_traverse.h) reads it with ONE scalar load: a plain rectangle's
 // world -> object matrix (a copy of its DShape::to_object), or the mark of an instance (which takes the general intersect_object).
 constexpr uint32_t kFlatObjects = 8;
-struct DFlatObject { uint32_t instance, pad[3]; float to_object[12]; };   // 64 B
+struct DFlatObject { uint32_t instance, pad[3]; float to_object[12]; };   // 64 B; instance: 0 plain rectangle, 1 instance (general path), 2 instance of ONE rectangle (to_object = that rectangle's, in the group's space)
 static_assert(sizeof(DFlatObject) == 64, "DFlatObject");
 
 constexpr uint32_t kLeafFlag = 0x80000000u;

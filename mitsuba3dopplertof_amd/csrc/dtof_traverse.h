@@ -403,7 +403,12 @@ DTOF_D bool trace_flat(const SceneView &sv, ConstBytes flat_table, uint32_t n_ob
     bool occluded = false;
     DTOF_STAT(0);
     auto test = [&](const FlatRecord &rec, uint32_t oi) {   // rect_hit on a plain rectangle's record
-        const V3 lo = xf_point(rec.m, o), ld = xf_vector(rec.m, d);
+        V3 ro = o, rd = d;
+        if (rec.instance == 2) {   // (uniform) the one memoised instance: into its space first, as intersect_object does (instance.cpp:101-114)
+            float inv[12]; instance_memo_load(sv, inv);
+            ro = xf_point(inv, o); rd = xf_vector(inv, d);
+        }
+        const V3 lo = xf_point(rec.m, ro), ld = xf_vector(rec.m, rd);
         const float t = -lo.z / ld.z;
         const float u = fmaf(ld.x, t, lo.x), v = fmaf(ld.y, t, lo.y);
         // no short-circuit: four compares and three mask ANDs instead of three exec-mask branches per rectangle (the scalar unit is as busy as the vector units here)
@@ -423,12 +428,12 @@ DTOF_D bool trace_flat(const SceneView &sv, ConstBytes flat_table, uint32_t n_ob
         FlatRecord b;
         const bool more_b = oi + 1 < n_objects;
         if (more_b) b = flat_load(table + oi + 1);
-        if (a.instance) instances |= 1u << oi; else test(a, oi);
+        if (a.instance == 1 || (a.instance == 2 && !(MEMO && sv.memo_obj == oi))) instances |= 1u << oi; else test(a, oi);
         if (!more_b) break;
         ++oi;
         const bool more_a = oi + 1 < n_objects;
         if (more_a) a = flat_load(table + oi + 1);
-        if (b.instance) instances |= 1u << oi; else test(b, oi);
+        if (b.instance == 1 || (b.instance == 2 && !(MEMO && sv.memo_obj == oi))) instances |= 1u << oi; else test(b, oi);
         if (!more_a) break;
         ++oi;
     }

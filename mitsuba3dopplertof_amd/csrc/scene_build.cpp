@@ -476,6 +476,9 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
             DFlatObject f; memset(&f, 0, sizeof f);
             f.instance = ob.kind == OBJ_INSTANCE;
             if (!f.instance) memcpy(f.to_object, shapes[ob.index].to_object, 48);
+            else if (groups[ob.index].n_shapes == 1) {   // an instance of one rectangle: its object-space matrix rides along (mark 2), the ray is moved there with the memoised inverse
+                f.instance = 2; memcpy(f.to_object, shapes[groups[ob.index].first_shape].to_object, 48);
+            }
             flat.push_back(f);
         }
     }
