@@ -436,10 +436,10 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             }
             const bool first = first_inline && it == 0;
             // The first-bounce kernel of the fused pipeline runs up to kMaxInline iterations of the loop itself, the path state in registers
-            // (RenderParams::inline_iters; DTOF_INLINE_ITERS=1 keeps one launch per iteration).  Lane dumps and multi-pass renders, whose
-            // per-iteration state must be visible in memory, take one iteration per launch.
+            // (RenderParams::inline_iters; DTOF_INLINE_ITERS=1 keeps one launch per iteration).  Multi-pass renders, whose stream states must be
+            // in memory between the passes, take one iteration per launch; lane dumps (dtof_sample_lanes) run the same inline kernel as renders.
             uint32_t span = 1;
-            if (first && !lane_dump && n_passes == 1) {
+            if (first && n_passes == 1) {
                 static const uint32_t env_inline = [] { const char *e = getenv("DTOF_INLINE_ITERS"); const int v = e ? atoi(e) : (int) kMaxInline; return (uint32_t) (v < 1 ? 1 : v > (int) kMaxInline ? (int) kMaxInline : v); }();
                 while (span < env_inline && (it + span) < rp.max_depth && !(it + span + 1 >= rp.max_depth && skip_tail)) ++span;   // the loop head's conditions for iteration it + span
             }
