@@ -322,20 +322,26 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     // trace/shadow kernels of one batch overlap the HBM-bound shade kernel of the other.
     static const int env_streams = [] { const char *e = getenv("DTOF_STREAMS"); int v = e ? atoi(e) : 1; return v == 2 ? 2 : 1; }();   // default 1: measured gain of 2 is 0% (Cornell) .. 7% (Domino) and it blurs per-stage timing
     const int n_streams = (lane_dump || n_passes > 1) ? 1 : env_streams;   // the passes of a lane follow each other on one stream
-    // Pipeline choice.  "fused" runs occlusion + continuation traversal inside the shade kernel (one kernel per bounce);
-    // it wins when traversal is trivial (measured: Cornell-wall 4.00 vs 4.71 ms) and loses when traversal dominates
-    // (Cornell-boxes 2.20 vs 1.97 ms, Domino 116 vs 102 ms) because the heavy shade kernel then diverges at 3 waves/SIMD.
-    // auto = fused for scenes of at most 16 objects without triangle meshes (see below).  DTOF_PIPELINE=split|fused overrides.
+    // Pipeline choice.  "fused" runs occlusion + continuation traversal inside the shade kernel (one kernel per bounce), "split" runs
+    // k_trace -> k_shade -> k_shadow per bounce.
+    // DTOF_PIPELINE=split|fused overrides the automatic choice below.
     static const int env_pipeline = [] { const char *e = getenv("DTOF_PIPELINE"); std::string v = e ? e : ""; return v == "split" ? 0 : v == "fused" ? 1 : 2; }();
     const BlobHeader *bh = (const BlobHeader *) sc->blob.data();
     static const bool env_fuse_first = [] { const char *e = getenv("DTOF_FUSE_FIRST"); return !(e && e[0] == '0'); }();
     bool only_rectangles = bh->n_tris == 0;
     for (auto &sh : sc->host.shapes) only_rectangles &= sh.kind == SHAPE_RECT;
-    bool analytic_only = bh->n_tris == 0, area_lights = false;   // spheres / disks / cylinders beside rectangles, no triangle mesh
-    for (auto &e : sc->host.emitters) area_lights |= e.kind == EMITTER_AREA;
-    // auto: rectangle-only scenes, and scenes of analytic shapes without area lights (measured at 512 x 512 x 64 with the inline iterations:
-    // spheres 4.96 -> 4.24 ms, disk 5.87 -> 5.19, cylinders 5.16 -> 4.69; a sphere light 5.92 -> 6.34 and the triangle boxes 5.29 -> 6.22 stay split)
-    const bool fused = env_pipeline == 2 ? ((only_rectangles || (analytic_only && !area_lights)) && bh->n_objects <= 16) : env_pipeline == 1;
+    // auto: fused (one kernel per bounce, and the first-bounce kernel running up to four iterations with the path state in registers) unless a
+    // mesh sits behind its own BLAS -- deep per-mesh traversals diverge inside the fat shade kernel (mesh room, 522 k triangles: 19.8 ms fused
+    // vs 16.1 ms split) -- or reflectances are textured (6.7 vs 5.8 ms).  Everything else measured faster fused once the fused kernels were
+    // capped at 168 VGPRs = 3 waves / SIMD (512 x 512 x 64: Cornell boxes 5.26 -> 4.60 ms, area light 7.12 -> 6.13, sphere light 6.42 -> 4.83,
+    // disk 5.30 -> 3.90, Domino 1024 x 1024 x 128 with its 1 025 instances 69.5 -> 62.2 ms; profiles/r02_pipeline_choice.txt).
+    bool blas_meshes = false;
+    {
+        const DShape *dshapes = (const DShape *) (sc->blob.data() + bh->off_shapes);
+        for (uint32_t i = 0; i < bh->n_shapes; ++i) blas_meshes |= dshapes[i].kind == SHAPE_MESH && dshapes[i].blas_root != kNoChild;
+    }
+    (void) only_rectangles;
+    const bool fused = env_pipeline == 2 ? (!blas_meshes && sc->host.textures.empty()) : env_pipeline == 1;
     if (n_streams == 2 && !lane_dump && last - first <= batch && last - first >= 2 * lanes_per_row) {
         uint64_t rows = (last - first) / lanes_per_row;
         batch = ((rows + 1) / 2) * lanes_per_row;                // one batch would serialise: cut it in two row bands

@@ -28,4 +28,4 @@ loop = best["ms_trace"] + best["ms_shade"] + best["ms_shadow"]
 print("mesh %dx%d: %d tris, %d nodes, blob %.1f MB | gen %.1fs load+build %.2fs | %dx%dx%d: total %.2f ms Mpaths/s %.0f | gen %.2f trace %.2f shade %.2f shadow %.2f splat %.2f | bounces %d shadow rays %d -> %.0f Mrays/s" % (
     n_u, n_v, info["n_triangles"], info["n_bvh_nodes"], info["scene_blob_bytes"] / 1e6, t_gen, t_load, res, res, spp, best["ms_total"],
     best["n_paths"] / best["ms_total"] / 1e3, best["ms_generate"], best["ms_trace"], best["ms_shade"], best["ms_shadow"], best["ms_splat"],
-    best["n_bounces"], best["n_shadow_rays"], (best["n_bounces"] + best["n_shadow_rays"]) / (best["ms_trace"] + best["ms_shadow"]) / 1e3))
+    best["n_bounces"], best["n_shadow_rays"], (best["n_bounces"] + best["n_shadow_rays"]) / ((best["ms_trace"] + best["ms_shadow"]) or best["ms_shade"]) / 1e3))
