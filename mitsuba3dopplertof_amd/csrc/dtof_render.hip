@@ -330,18 +330,18 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     static const bool env_fuse_first = [] { const char *e = getenv("DTOF_FUSE_FIRST"); return !(e && e[0] == '0'); }();
     bool only_rectangles = bh->n_tris == 0;
     for (auto &sh : sc->host.shapes) only_rectangles &= sh.kind == SHAPE_RECT;
-    // auto: fused (one kernel per bounce, and the first-bounce kernel running up to four iterations with the path state in registers) unless a
-    // mesh sits behind its own BLAS -- deep per-mesh traversals diverge inside the fat shade kernel (mesh room, 522 k triangles: 19.8 ms fused
+    // auto: fused (one kernel per bounce, and the first-bounce kernel running up to four iterations with the path state in registers) unless large
+    // meshes sit behind their own BLAS -- deep per-mesh traversals diverge inside the fat shade kernel (mesh room, 522 k triangles: 19.8 ms fused
     // vs 16.1 ms split) -- or reflectances are textured (6.7 vs 5.8 ms).  Everything else measured faster fused once the fused kernels were
     // capped at 168 VGPRs = 3 waves / SIMD (512 x 512 x 64: Cornell boxes 5.26 -> 4.60 ms, area light 7.12 -> 6.13, sphere light 6.42 -> 4.83,
     // disk 5.30 -> 3.90, Domino 1024 x 1024 x 128 with its 1 025 instances 69.5 -> 62.2 ms; profiles/r02_pipeline_choice.txt).
-    bool blas_meshes = false;
+    uint64_t blas_triangles = 0;   // triangles behind per-mesh BLASes: 18 k still run faster fused (11.2 vs 12.1 ms), 132 k do not (16.1 vs 13.7 ms)
     {
         const DShape *dshapes = (const DShape *) (sc->blob.data() + bh->off_shapes);
-        for (uint32_t i = 0; i < bh->n_shapes; ++i) blas_meshes |= dshapes[i].kind == SHAPE_MESH && dshapes[i].blas_root != kNoChild;
+        for (uint32_t i = 0; i < bh->n_shapes; ++i) if (dshapes[i].kind == SHAPE_MESH && dshapes[i].blas_root != kNoChild) blas_triangles += dshapes[i].n_tris;
     }
     (void) only_rectangles;
-    const bool fused = env_pipeline == 2 ? (!blas_meshes && sc->host.textures.empty()) : env_pipeline == 1;
+    const bool fused = env_pipeline == 2 ? (blas_triangles <= 32768 && sc->host.textures.empty()) : env_pipeline == 1;
     if (n_streams == 2 && !lane_dump && last - first <= batch && last - first >= 2 * lanes_per_row) {
         uint64_t rows = (last - first) / lanes_per_row;
         batch = ((rows + 1) / 2) * lanes_per_row;                // one batch would serialise: cut it in two row bands
