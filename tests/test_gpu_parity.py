@@ -772,11 +772,11 @@ def _random_config(rng):
     if spp % sampler["path_correlate_number"]:
         sampler["path_correlate_number"] = tcn
     scene = str(rng.choice(["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_spheres.xml", "cornell_specular.xml",
-                            "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml"]))
+                            "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml", "cornell_envmap.xml", "cornell_cylinders.xml", "cornell_sphere_light.xml"]))
     return scene, dict(resx=int(rng.choice([8, 13, 24])), resy=int(rng.choice([8, 11, 16]))), spp, integ, sampler
 
 
-@pytest.mark.parametrize("index", range(24))
+@pytest.mark.parametrize("index", range(int(os.environ.get("DTOF_SWEEP", "24"))))   # DTOF_SWEEP=N: a longer sweep (development)
 def test_random_parameter_combinations_are_bit_exact(mi, orc, index):
     """24 seeded random draws from the plugin parameter space x scene set (all waveforms, time strategies, correlation numbers,
     depths incl. unbounded, russian-roulette depths, full / low-pass modulation, every material and light type)."""
