@@ -7,6 +7,7 @@
 
 namespace dtof {
 
+constexpr uint32_t kChunkBlocks = 8; // 64-lane chunks of a 512-lane queue segment (RenderParams::chunk_blocks)
 constexpr uint32_t kMaxInline = 4;  // iterations of the bounce loop the fused first-bounce kernel may run itself (RenderParams::inline_iters)
 constexpr int kMaxOffsets = 4;      // modulation offsets evaluated per traversal (K)
 
@@ -54,6 +55,7 @@ struct RenderParams {
     uint2 *pass_rng;                              // n_passes > 1: [lane - pass_first][3] = states of the main / time / path streams between passes
     uint32_t pass_first;                          // virtual lane the pass_rng array starts at
     int32_t has_env, hide_emitters; uint32_t env_index;   // `constant` environment emitter (scene.cpp:53-57), SamplingIntegrator::m_hide_emitters
+    uint32_t chunk_blocks;                        // first-bounce kernel: blocks per 512-lane segment, 1 or 8 (small frames whose whole path runs inline)
     uint32_t inline_iters;                        // fused first-bounce kernel: iterations of the bounce loop it runs back to back with the path state in registers (1 .. kMaxInline)
     uint32_t flat_objects, flat_off;                        // fused pipeline, rectangle-only scenes of at most kFlatObjects objects: their number (trace_flat), else 0
     uint32_t memo_obj;                            // fused pipeline: the scene's only instance object (instance memo, dtof_traverse.h) or 0xffffffff

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) 
 // single global atomic (a shared counter serialises at ~88 returning atomics/us on MI355X, which
 // made the first version of this kernel 10x slower than its memory traffic).
 constexpr uint32_t kSeg = 512;
+static_assert(kSeg / 64 == kChunkBlocks, "chunks per segment");
 constexpr int kShadeBlock = 64;   // k_shade runs ONE wave per block: compaction is ballot+popcount only, no barrier in the chunk loop
 // The closest-hit record between the trace and the shade of a bounce: (t, u, v, primitive) + the object / shape id.  Rectangle-only
 // instantiations (MESH = false) keep the distance alone: a rectangle's surface interaction is rebuilt from the ray and t
@@ -147,7 +148,11 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
     const uint32_t stage_words = A0.stage_words;
     // dynamic LDS: [staged scene][fused: instance memo, kMemoWords x 64 words][traversal stack columns]
     uint32_t *stack = (uint32_t *) (lds + stage_words) + (FUSED ? kMemoWords * kMemoStride : 0u) + threadIdx.x;
-    const uint32_t seg = blockIdx.x;
+    // One block per 512-lane segment -- or, for a small frame whose whole path runs inline (rp.chunk_blocks = 8: nothing is compacted for a
+    // later launch), one block per 64-lane chunk, so that a 1 M-lane frame is 16 384 waves instead of 2 048; the per-segment statistics are
+    // then accumulated with atomics into slots the host has zeroed.
+    const uint32_t sub = FIRST ? A0.rp.chunk_blocks : 1u;                 // blocks per segment: 1 or kSeg / kShadeBlock
+    const uint32_t seg = sub > 1 ? blockIdx.x / sub : blockIdx.x, sub_index = sub > 1 ? blockIdx.x - seg * sub : 0u;
     const uint32_t count = seg_count(A0.count_in, seg, A0.rp.n_lanes);
     uint32_t n_alive = 0, n_shadow = 0;
     if (FIRST && threadIdx.x < 2 * kMaxInline) s_inline[threadIdx.x] = 0;   // one wave per block: no barrier needed
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
     SceneView sv = make_view(base);
     if (FUSED) { sv.memo_obj = A0.rp.memo_obj; sv.memo = (float *) (lds + stage_words) + threadIdx.x; }
     const bool have_memo = FUSED && sv.memo_obj != 0xffffffffu;
-    for (uint32_t cbase = 0; cbase < count; cbase += kShadeBlock) {
+    for (uint32_t cbase = sub > 1 ? sub_index * kShadeBlock : 0u; cbase < (sub > 1 ? (sub_index + 1) * kShadeBlock < count ? (sub_index + 1) * kShadeBlock : count : count); cbase += kShadeBlock) {
     uint32_t rebase = 0;
     asm volatile("" : "+s"(rebase));
     const ShadeArgs &A = *(const ShadeArgs *) (kernarg + rebase);
@@ -683,12 +688,14 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
         n_shadow = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     }
     if (threadIdx.x == 0) {
-        A0.alive_out[seg] = n_alive; A0.shadow_out[seg] = n_shadow;
+        if (sub > 1) { atomicAdd(&A0.alive_out[seg], n_alive); atomicAdd(&A0.shadow_out[seg], n_shadow); }
+        else { A0.alive_out[seg] = n_alive; A0.shadow_out[seg] = n_shadow; }
         if (FIRST) {   // the count slots of the inline iterations before the last lie 2 * n_seg words apart below the last one's (render_rows)
-            const uint32_t n_inl = A0.rp.inline_iters, n_seg = gridDim.x;
+            const uint32_t n_inl = A0.rp.inline_iters, n_seg = gridDim.x / sub;
             for (uint32_t i = 0; i + 1 < n_inl; ++i) {
                 uint32_t *slot = A0.alive_out - (size_t) 2 * (n_inl - 1 - i) * n_seg;
-                slot[seg] = s_inline[2 * i]; slot[n_seg + seg] = s_inline[2 * i + 1];
+                if (sub > 1) { atomicAdd(&slot[seg], s_inline[2 * i]); atomicAdd(&slot[n_seg + seg], s_inline[2 * i + 1]); }
+                else { slot[seg] = s_inline[2 * i]; slot[n_seg + seg] = s_inline[2 * i + 1]; }
             }
         }
     }
@@ -1175,7 +1182,7 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
                   uint32_t stack_depth, hipStream_t s, bool first, LaneDebug *dbg) {
     if (rp.n_lanes == 0) return;
     const uint32_t shade_stack = fused ? stack_bytes(stack_depth, kShadeBlock) + kMemoWords * kMemoStride * 4 : 0;   // + the instance memo
-    uint32_t sw = stage_words_for(scene_bytes, shade_stack), grid = nseg(rp.n_lanes), lds = sw * 16 + shade_stack;
+    uint32_t sw = stage_words_for(scene_bytes, shade_stack), grid = nseg(rp.n_lanes) * (first && rp.chunk_blocks > 1 ? rp.chunk_blocks : 1u), lds = sw * 16 + shade_stack;
     check_lds(lds);
     uint32_t tn = trace_next ? 1u : 0u;
 #define DTOF_LAUNCH_SHADE(L, F, A, K) do { if (rp.has_tris) DTOF_LAUNCH_SHADE_M(L, F, A, K, true, false); else DTOF_LAUNCH_SHADE_M(L, F, A, K, false, false); } while (0)

@@ -451,6 +451,12 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             }
             rp.inline_iters = span;
             it += span - 1;   // `it` is now the last iteration this launch covers
+            {   // small frames whose whole path runs inline: one block per 64-lane chunk (8 x the waves); the count slots it adds into are zeroed first
+                const bool whole_path = first && !((it + 1 < rp.max_depth) && !(it + 2 >= rp.max_depth && skip_tail));
+                static const uint32_t env_chunk_segs = [] { const char *e = getenv("DTOF_CHUNK_SEGS"); return e ? (uint32_t) atoi(e) : 8192u; }();   // frames up to this many segments (A/B switch)
+                rp.chunk_blocks = whole_path && n_seg <= env_chunk_segs ? kChunkBlocks : 1u;
+                if (rp.chunk_blocks > 1) HIP_CHECK(hipMemsetAsync(q.counts, 0, (size_t) 2 * (it + 1) * n_seg * 4, s));
+            }
             // does iteration it+1 run?  (same conditions as the loop head)
             const bool next_runs = (it + 1 < rp.max_depth) && !(it + 2 >= rp.max_depth && skip_tail);
             if (!fused || (it == 0 && !first)) { t = tm.begin(1, s); launch_trace(blob, blob_bytes, rp, q, qin, count_in, stack_depth, s); tm.end(1, t, s); if (stats) stats->n_launches_trace++; }
