@@ -441,12 +441,14 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
                 bsdf_weight = selected_r ? mk(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]) : mk(sh->spec_trans[0], sh->spec_trans[1], sh->spec_trans[2]);
             } else if (SPEC && sh->bsdf == BSDF_ROUGHDIELECTRIC) {
                 // RoughDielectric::eval_pdf / sample (roughdielectric.cpp:240-346,503-611): glossy reflection and transmission lobes
-                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, sh->alpha_u, sh->alpha_v);
+                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, sh->alpha_u, sh->alpha_v, !(sh->flags & SF_SAMPLE_ALL));
                 const V3 wi = si.wi;
                 if (active_em) rough_dielectric_eval_pdf(g, sh, wi, wo, bsdf_val, bsdf_pdf);
                 if (wi.z != 0.f) {
                     float mpdf;
-                    const V3 m = ggx_sample(g, mk(mulsign(wi.x, wi.z), mulsign(wi.y, wi.z), mulsign(wi.z, wi.z)), s2x, s2y, mpdf);
+                    Ggx gs = g;   // sample_distr (:266-269)
+                    if (!g.visible) { const float sc = 1.2f - .2f * sqrtf(fabsf(wi.z)); gs.au *= sc; gs.av *= sc; }
+                    const V3 m = ggx_sample(gs, mk(mulsign(wi.x, wi.z), mulsign(wi.y, wi.z), mulsign(wi.z, wi.z)), s2x, s2y, mpdf);
                     const float dwm = dot(wi, m);
                     float F, cos_theta_t, eta_it, eta_ti; fresnel_dielectric(dwm, sh->diel_eta, F, cos_theta_t, eta_it, eta_ti);
                     const bool selected_r = sample_1 <= F;
@@ -465,7 +467,8 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
                         const float dom = dot(bs_wo, m);
                         dwh_dwo = (sqr(bs_eta) * dom) / sqr(dwm + bs_eta * dom);
                     }
-                    const float g1 = ggx_smith_g1(g, bs_wo, m);
+                    // :345-349: smith_g1(wo, m) with visible normals, else G(wi, wo, m) dot(wi, m) / (cos_theta_i cos_theta(m))
+                    const float g1 = g.visible ? ggx_smith_g1(g, bs_wo, m) : ggx_smith_g1(g, wi, m) * ggx_smith_g1(g, bs_wo, m) * dwm / (wi.z * m.z);
                     bs_pdf *= fabsf(dwh_dwo);
                     if (mpdf != 0.f) bsdf_weight = w * g1;
                 }
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
                 // RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF
                 V3 wi = si.wi, wo_l = wo;
                 if (twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
-                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, sh->alpha_u, sh->alpha_v);
+                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, sh->alpha_u, sh->alpha_v, !(sh->flags & SF_SAMPLE_ALL));
                 if (wi.z > 0.f && wo_l.z > 0.f) {
                     const V3 H = normalize(wo_l + wi);
                     const float D = ggx_eval(g, H);
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
                                       fresnel_conductor(c, sh->cond_eta[1], sh->cond_k[1]) * (result * sh->spec_refl[1]),
                                       fresnel_conductor(c, sh->cond_eta[2], sh->cond_k[2]) * (result * sh->spec_refl[2]));
                     }
-                    if (dot(wi, H) > 0.f && dot(wo_l, H) > 0.f) bsdf_pdf = ggx_eval(g, H) * ggx_smith_g1(g, wi, H) / (4.f * wi.z);
+                    if (dot(wi, H) > 0.f && dot(wo_l, H) > 0.f) bsdf_pdf = g.visible ? ggx_eval(g, H) * ggx_smith_g1(g, wi, H) / (4.f * wi.z) : ggx_pdf(g, wi, H) / (4.f * dot(wo_l, H));   // :405-409
                 }
                 if (wi.z > 0.f) {
                     float mpdf;
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
                     const V3 r = mk(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   // reflect(wi, m)
                     bs_wo = r; bs_eta = 1.f;
                     const bool ok = mpdf != 0.f && r.z > 0.f;
-                    const float weight = ggx_smith_g1(g, r, m);
+                    const float weight = g.visible ? ggx_smith_g1(g, r, m) : ggx_smith_g1(g, wi, m) * ggx_smith_g1(g, r, m) * dwm / (wi.z * m.z);   // :260-265
                     bs_pdf = mpdf / (4.f * dot(r, m));
                     if (ok) bsdf_weight = mk(fresnel_conductor(dwm, sh->cond_eta[0], sh->cond_k[0]) * (weight * sh->spec_refl[0]),
                                              fresnel_conductor(dwm, sh->cond_eta[1], sh->cond_k[1]) * (weight * sh->spec_refl[1]),
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
                 // RoughPlastic::eval / pdf / sample (roughplastic.cpp:259-421), GGX + visible normals, under TwoSidedBRDF
                 V3 wi = si.wi, wo_l = wo;
                 if (twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
-                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, sh->alpha_u, sh->alpha_u);
+                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, sh->alpha_u, sh->alpha_u, !(sh->flags & SF_SAMPLE_ALL));
                 const float *table = (const float *) (sv.base + sh->rough_table);
                 const float w = sh->spec_sampling_weight, ir = sh->fdr_int;
                 const V3 diff = (sh->nonlinear & 1u) ? mk(refl.x / (1.f - refl.x * ir), refl.y / (1.f - refl.y * ir), refl.z / (1.f - refl.z * ir))

@@ -686,6 +686,7 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
             v.insert(v.end(), t.to_uv, t.to_uv + 4); v.insert(v.end(), t.color0, t.color0 + 3); v.insert(v.end(), t.color1, t.color1 + 3); v.push_back(t.mean);
         } else if (kind == 14) for (auto &t : sc->host.textures) v.insert(v.end(), t.data.begin(), t.data.end());
         else if (kind == 15) for (auto &s : sc->host.shapes) v.push_back((float) s.tex_refl);
+        else if (kind == 17) for (auto &s : sc->host.shapes) v.push_back(s.sample_all ? 1.f : 0.f);
         else if (kind == 16) {   // the environment map as packed into the blob: header words, m_data, then every level of the hierarchical warp
             const BlobHeader *bh = (const BlobHeader *) sc->blob.data();
             const DEmitter *de = (const DEmitter *) (sc->blob.data() + bh->off_emitters);

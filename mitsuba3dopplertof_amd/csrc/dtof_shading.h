@@ -272,7 +272,7 @@ DTOF_D void rough_plastic_eval_pdf(Ggx g, const DShape *sh, const float *table, 
     const float t_o = lerp_gather64(table, wo.z);
     const float k = kInvPi * sh->inv_eta_2 * wo.z * t_i * t_o;
     value = mk(spec * sh->spec_refl[0] + diff.x * k, spec * sh->spec_refl[1] + diff.y * k, spec * sh->spec_refl[2] + diff.z * k);
-    float result = D * ggx_smith_g1(g, wi, H) / (4.f * wi.z);
+    float result = g.visible ? D * ggx_smith_g1(g, wi, H) / (4.f * wi.z) : ggx_pdf(g, wi, H) / (4.f * dot(wo, H));   // roughplastic.cpp:467-470
     result *= prob_specular;
     pdf = result + prob_diffuse * (kInvPi * wo.z);
 }
@@ -298,7 +298,9 @@ DTOF_D void rough_dielectric_eval_pdf(Ggx g, const DShape *sh, V3 wi, V3 wo, V3 
         const float v = fabsf((scale * (1.f - F) * D * G * eta * eta * dwm * dom) / (cti * sqr(dwm + eta * dom)));
         value = mk(v * sh->spec_trans[0], v * sh->spec_trans[1], v * sh->spec_trans[2]);
     }
-    float p = ggx_pdf(g, mk(mulsign(wi.x, cti), mulsign(wi.y, cti), mulsign(wi.z, cti)), m);
+    Ggx gs = g;   // sample_distr: Walter et al.'s roughness scaling when all normals are sampled (roughdielectric.cpp:584-589)
+    if (!g.visible) { const float sc = 1.2f - .2f * sqrtf(fabsf(cti)); gs.au *= sc; gs.av *= sc; }
+    float p = ggx_pdf(gs, mk(mulsign(wi.x, cti), mulsign(wi.y, cti), mulsign(wi.z, cti)), m);
     p *= reflect ? F : 1.f - F;
     const float dwh_dwo = reflect ? rcp(4.f * dom) : (eta * eta * dom) / sqr(dwm + eta * dom);
     pdf = p * fabsf(dwh_dwo);

@@ -642,7 +642,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
         if (distr != "beckmann" && distr != "ggx") fail("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"!");
         s.beckmann = distr != "ggx";   // MicrofacetType (microfacet.h:30-36)
-        if (!b.props.get_bool("sample_visible", true)) fail("roughdielectric: only sample_visible = true is implemented");
+        s.sample_all = !b.props.get_bool("sample_visible", true);
         if (b.props.has("alpha_u") || b.props.has("alpha_v")) {
             if (!b.props.has("alpha_u") || !b.props.has("alpha_v")) fail("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
             if (b.props.has("alpha")) fail("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.");
@@ -656,7 +656,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
         if (distr != "beckmann" && distr != "ggx") fail("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"!");
         s.beckmann = distr != "ggx";   // MicrofacetType (microfacet.h:30-36)
-        if (!b.props.get_bool("sample_visible", true)) fail("roughconductor: only sample_visible = true is implemented");
+        s.sample_all = !b.props.get_bool("sample_visible", true);
         if (b.props.has("alpha_u") || b.props.has("alpha_v")) {
             if (!b.props.has("alpha_u") || !b.props.has("alpha_v")) fail("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
             if (b.props.has("alpha")) fail("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.");
@@ -693,7 +693,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
         if (distr != "beckmann" && distr != "ggx") fail("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"!");
         s.beckmann = distr != "ggx";   // MicrofacetType (microfacet.h:30-36)
-        if (!b.props.get_bool("sample_visible", true)) fail("roughplastic: only sample_visible = true is implemented");
+        s.sample_all = !b.props.get_bool("sample_visible", true);
         if (b.props.has("alpha_u") || b.props.has("alpha_v")) {
             if (!b.props.has("alpha_u") || !b.props.has("alpha_v")) fail("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
             if (b.props.has("alpha")) fail("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.");

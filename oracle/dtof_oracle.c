@@ -1361,7 +1361,7 @@ static void rough_plastic_eval_pdf(ggx_t g, const orc_shape *sh, const float *re
                          : V(diff.x / (1.f - ir), diff.y / (1.f - ir), diff.z / (1.f - ir));
     float k = ORC_INV_PI_F * sh->inv_eta_2 * wo.z * t_i * t_o;
     *value = V(spec * sh->spec_refl[0] + diff.x * k, spec * sh->spec_refl[1] + diff.y * k, spec * sh->spec_refl[2] + diff.z * k);
-    float result = D * ggx_smith_g1(g, wi, H) / (4.f * wi.z);
+    float result = g.visible ? D * ggx_smith_g1(g, wi, H) / (4.f * wi.z) : ggx_pdf(g, wi, H) / (4.f * v_dot(wo, H));   /* roughplastic.cpp:467-470 */
     result *= prob_specular;
     *pdf = result + prob_diffuse * (ORC_INV_PI_F * wo.z);
 }
@@ -1387,7 +1387,9 @@ static void rough_dielectric_eval_pdf(ggx_t g, const orc_shape *sh, v3 wi, v3 wo
         float v = fabsf((scale * (1.f - F) * D * G * eta * eta * dwm * dom) / (cti * f_sqr(dwm + eta * dom)));
         *value = V(v * sh->spec_trans[0], v * sh->spec_trans[1], v * sh->spec_trans[2]);
     }
-    float p = ggx_pdf(g, V(f_mulsign(wi.x, cti), f_mulsign(wi.y, cti), f_mulsign(wi.z, cti)), m);
+    ggx_t gs = g;   /* sample_distr: Walter et al.'s roughness scaling when all normals are sampled (roughdielectric.cpp:584-589) */
+    if (!g.visible) { const float sc = 1.2f - .2f * sqrtf(fabsf(cti)); gs.au *= sc; gs.av *= sc; }
+    float p = ggx_pdf(gs, V(f_mulsign(wi.x, cti), f_mulsign(wi.y, cti), f_mulsign(wi.z, cti)), m);
     p *= reflect ? F : 1.f - F;
     float dwh_dwo = reflect ? f_rcp(4.f * dom) : (eta * eta * dom) / f_sqr(dwm + eta * dom);
     *pdf = p * fabsf(dwh_dwo);
@@ -1475,12 +1477,14 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
         bsdf_weight = selected_r ? V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]) : V(sh->spec_trans[0], sh->spec_trans[1], sh->spec_trans[2]);
     } else if (sh->bsdf == ORC_BSDF_ROUGHDIELECTRIC) {
         /* RoughDielectric::sample (roughdielectric.cpp:240-346); eval_pdf above for the emitter sample */
-        ggx_t g = mf_make(sh->mf_type, sh->alpha_u, sh->alpha_v, 1);
+        ggx_t g = mf_make(sh->mf_type, sh->alpha_u, sh->alpha_v, !sh->sample_all);
         v3 wi = wi_in;
         if (active_em) rough_dielectric_eval_pdf(g, sh, wi, wo, &bsdf_val, &bsdf_pdf);
         if (wi.z != 0.f) {
             float mpdf;
-            v3 m = ggx_sample(g, V(f_mulsign(wi.x, wi.z), f_mulsign(wi.y, wi.z), f_mulsign(wi.z, wi.z)), s2x, s2y, &mpdf);
+            ggx_t gs = g;   /* sample_distr (:266-269) */
+            if (!g.visible) { const float sc = 1.2f - .2f * sqrtf(fabsf(wi.z)); gs.au *= sc; gs.av *= sc; }
+            v3 m = ggx_sample(gs, V(f_mulsign(wi.x, wi.z), f_mulsign(wi.y, wi.z), f_mulsign(wi.z, wi.z)), s2x, s2y, &mpdf);
             float dwm = v_dot(wi, m), F, cos_theta_t, eta_it, eta_ti;
             fresnel_dielectric(dwm, sh->diel_eta, &F, &cos_theta_t, &eta_it, &eta_ti);
             int selected_r = sample_1 <= F;
@@ -1499,7 +1503,9 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
                 float dom = v_dot(bs_wo, m);
                 dwh_dwo = (f_sqr(bs_eta) * dom) / f_sqr(dwm + bs_eta * dom);
             }
-            float g1 = ggx_smith_g1(g, bs_wo, m);
+            /* :345-349: smith_g1(wo, m) with visible normals, else G(wi, wo, m) dot(wi, m) / (cos_theta_i cos_theta(m)) */
+            float g1 = g.visible ? ggx_smith_g1(g, bs_wo, m)
+                                 : ggx_smith_g1(g, wi, m) * ggx_smith_g1(g, bs_wo, m) * dwm / (wi.z * m.z);
             bs_pdf *= fabsf(dwh_dwo);
             if (mpdf != 0.f) bsdf_weight = v_mul(w, g1);
         }
@@ -1507,7 +1513,7 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
         /* RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF */
         v3 wi = wi_in, wo_l = wo;
         if (sh->twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }   /* twosided.cpp:219-258 flips both */
-        ggx_t g = mf_make(sh->mf_type, sh->alpha_u, sh->alpha_v, 1);
+        ggx_t g = mf_make(sh->mf_type, sh->alpha_u, sh->alpha_v, !sh->sample_all);
         if (wi.z > 0.f && wo_l.z > 0.f) {
             v3 H = v_normalize(v_add(wo_l, wi));
             float D = ggx_eval(g, H);
@@ -1519,7 +1525,7 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
                              fresnel_conductor(c, sh->cond_eta[2], sh->cond_k[2]) * (result * sh->spec_refl[2]));
             }
             if (v_dot(wi, H) > 0.f && v_dot(wo_l, H) > 0.f)   /* pdf :377-415 */
-                bsdf_pdf = ggx_eval(g, H) * ggx_smith_g1(g, wi, H) / (4.f * wi.z);
+                bsdf_pdf = g.visible ? ggx_eval(g, H) * ggx_smith_g1(g, wi, H) / (4.f * wi.z) : ggx_pdf(g, wi, H) / (4.f * v_dot(wo_l, H));   /* :405-409 */
         }
         if (wi.z > 0.f) {   /* sample :229-315 */
             float mpdf;
@@ -1528,7 +1534,7 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
             v3 r = V(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   /* reflect(wi, m) fresnel.h:282-284 */
             bs_wo = r; bs_eta = 1.f;
             int ok = mpdf != 0.f && r.z > 0.f;
-            float weight = ggx_smith_g1(g, r, m);
+            float weight = g.visible ? ggx_smith_g1(g, r, m) : ggx_smith_g1(g, wi, m) * ggx_smith_g1(g, r, m) * dwm / (wi.z * m.z);   /* :260-265 */
             bs_pdf = mpdf / (4.f * v_dot(r, m));
             if (ok) bsdf_weight = V(fresnel_conductor(dwm, sh->cond_eta[0], sh->cond_k[0]) * (weight * sh->spec_refl[0]),
                                     fresnel_conductor(dwm, sh->cond_eta[1], sh->cond_k[1]) * (weight * sh->spec_refl[1]),
@@ -1539,7 +1545,7 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
         /* RoughPlastic::sample (roughplastic.cpp:259-331) under TwoSidedBRDF; eval / pdf in rough_plastic_eval_pdf */
         v3 wi = wi_in, wo_l = wo;
         if (sh->twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
-        ggx_t g = mf_make(sh->mf_type, sh->alpha_u, sh->alpha_u, 1);
+        ggx_t g = mf_make(sh->mf_type, sh->alpha_u, sh->alpha_u, !sh->sample_all);
         if (wi.z > 0.f) {
             float t_i = lerp_gather64(sh->rough_table, wi.z);
             float prob_specular = (1.f - t_i) * sh->spec_sampling_weight, prob_diffuse = t_i * (1.f - sh->spec_sampling_weight);

@@ -89,6 +89,7 @@ typedef struct {
     const float *rough_table;
     const orc_texture *tex_refl;   /* texture on `reflectance` / `diffuse_reflectance` (NULL: the constant colour above) */
     int32_t mf_type;         /* microfacet distribution of the rough BSDFs: 0 beckmann, 1 ggx (microfacet.h MicrofacetType) */
+    int32_t sample_all;      /* rough BSDFs: sample_visible = false (sample all normals, Walter et al.'s roughness scaling; microfacet.h:240-290) */
 } orc_shape;
 
 typedef struct {

@@ -34,7 +34,7 @@ class OrcShape(C.Structure):
                 ("bsdf", C.c_int32), ("cond_eta", C.c_float * 3), ("cond_k", C.c_float * 3), ("spec_refl", C.c_float * 3),
                 ("spec_trans", C.c_float * 3), ("diel_eta", C.c_float), ("nonlinear", C.c_int32),
                 ("inv_eta_2", C.c_float), ("fdr_int", C.c_float), ("spec_sampling_weight", C.c_float),
-                ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("rough_table", C.POINTER(C.c_float)), ("tex_refl", C.POINTER(OrcTexture)), ("mf_type", C.c_int32)]
+                ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("rough_table", C.POINTER(C.c_float)), ("tex_refl", C.POINTER(OrcTexture)), ("mf_type", C.c_int32), ("sample_all", C.c_int32)]
 
 
 class OrcGroup(C.Structure):
@@ -237,6 +237,7 @@ class Scene:
             o.diel_eta = float(s.get("diel_eta", 1.0))
             o.alpha_u, o.alpha_v = float(s.get("alpha_u", 0.1)), float(s.get("alpha_v", 0.1))
             o.mf_type = int(s.get("mf_type", 1))
+            o.sample_all = int(s.get("sample_all", 0))
             tex = s.get("tex_refl")
             if tex is not None:   # texture on the (diffuse) reflectance
                 t = OrcTexture()

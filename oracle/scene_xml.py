@@ -533,8 +533,7 @@ def _bsdf_of(props, registry, base_dir=""):
         if distr not in ("beckmann", "ggx"):
             raise ValueError('Specified an invalid distribution "%s", must be "beckmann" or "ggx"!' % distr)
         rec.update(mf_type=int(distr == "ggx"))   # MicrofacetType: 0 beckmann, 1 ggx
-        if not props.get_b("sample_visible", True):
-            raise ValueError("roughdielectric: only sample_visible = true is implemented")
+        rec.update(sample_all=int(not props.get_b("sample_visible", True)))
         if "alpha_u" in props or "alpha_v" in props:
             if not ("alpha_u" in props and "alpha_v" in props):
                 raise ValueError("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.")
@@ -553,8 +552,7 @@ def _bsdf_of(props, registry, base_dir=""):
         if distr not in ("beckmann", "ggx"):
             raise ValueError('Specified an invalid distribution "%s", must be "beckmann" or "ggx"!' % distr)
         rec.update(mf_type=int(distr == "ggx"))   # MicrofacetType: 0 beckmann, 1 ggx
-        if not props.get_b("sample_visible", True):
-            raise ValueError("roughconductor: only sample_visible = true is implemented")
+        rec.update(sample_all=int(not props.get_b("sample_visible", True)))
         if "alpha_u" in props or "alpha_v" in props:
             if not ("alpha_u" in props and "alpha_v" in props):
                 raise ValueError("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.")
@@ -584,8 +582,7 @@ def _bsdf_of(props, registry, base_dir=""):
         if distr not in ("beckmann", "ggx"):
             raise ValueError('Specified an invalid distribution "%s", must be "beckmann" or "ggx"!' % distr)
         rec.update(mf_type=int(distr == "ggx"))   # MicrofacetType: 0 beckmann, 1 ggx
-        if not props.get_b("sample_visible", True):
-            raise ValueError("roughplastic: only sample_visible = true is implemented")
+        rec.update(sample_all=int(not props.get_b("sample_visible", True)))
         if "alpha_u" in props or "alpha_v" in props:
             if not ("alpha_u" in props and "alpha_v" in props):
                 raise ValueError("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.")
@@ -675,7 +672,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
                 sphere=sphere, bsdf=brec["bsdf"], cond_eta=brec["cond_eta"], cond_k=brec["cond_k"], spec_refl=brec["spec_refl"],
                 spec_trans=brec["spec_trans"], diel_eta=brec["diel_eta"], nonlinear=brec.get("nonlinear", 0),
                 alpha_u=brec.get("alpha_u", F32(0.1)), alpha_v=brec.get("alpha_v", F32(0.1)), has_spec_refl=brec.get("has_spec_refl", 0),
-                mf_type=brec.get("mf_type", 1), tex_refl=brec.get("tex_refl"))
+                mf_type=brec.get("mf_type", 1), sample_all=brec.get("sample_all", 0), tex_refl=brec.get("tex_refl"))
 
 
 def load(source, params=None, is_string=False):

@@ -31,6 +31,7 @@ HEADER = """<scene version="3.0.0">
 	<default name="path_correlation_depth" value="$max_depth" />
 	<default name="time_correlate_number" value="2" />
 	<default name="distribution" value="ggx" />
+	<default name="sample_visible" value="true" />
 	<integrator type="dopplertofpath">
 		<integer name="max_depth" value="$max_depth" />
 		<float name="w_g" value="30" />
@@ -337,18 +338,18 @@ def cornell_plastic(res=128, spp=16):
     return s + LIGHT + "</scene>\n"
 
 
-ROUGH = ('\t<bsdf type="twosided" id="RoughCopperBSDF">\n\t\t<bsdf type="roughconductor">\n\t\t\t<string name="distribution" value="$distribution" />\n'
+ROUGH = ('\t<bsdf type="twosided" id="RoughCopperBSDF">\n\t\t<bsdf type="roughconductor">\n\t\t\t<string name="distribution" value="$distribution" /><boolean name="sample_visible" value="$sample_visible" />\n'
          '\t\t\t<float name="alpha" value="0.2" />\n\t\t\t<rgb name="eta" value="0.2, 0.92, 1.1" />\n\t\t\t<rgb name="k" value="3.9, 2.45, 2.14" />\n'
          '\t\t</bsdf>\n\t</bsdf>\n'
-         '\t<bsdf type="twosided" id="BrushedBSDF">\n\t\t<bsdf type="roughconductor">\n\t\t\t<string name="distribution" value="$distribution" />\n'
+         '\t<bsdf type="twosided" id="BrushedBSDF">\n\t\t<bsdf type="roughconductor">\n\t\t\t<string name="distribution" value="$distribution" /><boolean name="sample_visible" value="$sample_visible" />\n'
          '\t\t\t<float name="alpha_u" value="0.05" />\n\t\t\t<float name="alpha_v" value="0.3" />\n\t\t\t<rgb name="eta" value="1.5, 1.5, 1.5" />\n'
          '\t\t\t<rgb name="k" value="7.6, 6.3, 5.4" />\n\t\t\t<rgb name="specular_reflectance" value="0.9, 0.9, 0.95" />\n\t\t</bsdf>\n\t</bsdf>\n')
 
 
-ROUGHPLASTIC = ('\t<bsdf type="twosided" id="GlossyPaintBSDF">\n\t\t<bsdf type="roughplastic">\n\t\t\t<string name="distribution" value="$distribution" />\n'
+ROUGHPLASTIC = ('\t<bsdf type="twosided" id="GlossyPaintBSDF">\n\t\t<bsdf type="roughplastic">\n\t\t\t<string name="distribution" value="$distribution" /><boolean name="sample_visible" value="$sample_visible" />\n'
                 '\t\t\t<float name="alpha" value="0.15" />\n\t\t\t<rgb name="diffuse_reflectance" value="0.1, 0.27, 0.36" />\n'
                 '\t\t\t<float name="int_ior" value="1.9" />\n\t\t</bsdf>\n\t</bsdf>\n'
-                '\t<bsdf type="twosided" id="SatinFloorBSDF">\n\t\t<bsdf type="roughplastic">\n\t\t\t<string name="distribution" value="$distribution" />\n'
+                '\t<bsdf type="twosided" id="SatinFloorBSDF">\n\t\t<bsdf type="roughplastic">\n\t\t\t<string name="distribution" value="$distribution" /><boolean name="sample_visible" value="$sample_visible" />\n'
                 '\t\t\t<float name="alpha" value="0.35" />\n\t\t\t<rgb name="diffuse_reflectance" value="0.6, 0.55, 0.5" />\n'
                 '\t\t\t<rgb name="specular_reflectance" value="0.9, 0.85, 0.8" />\n\t\t\t<boolean name="nonlinear" value="true" />\n\t\t</bsdf>\n\t</bsdf>\n')
 
@@ -392,9 +393,9 @@ def cornell_specular(res=128, spp=16, area_light=True):
     return s + (AREA_LIGHT if area_light else LIGHT) + "</scene>\n"
 
 
-FROSTED = ('\t<bsdf type="roughdielectric" id="FrostedBSDF">\n\t\t<string name="distribution" value="$distribution" />\n\t\t<float name="alpha" value="0.15" />\n'
+FROSTED = ('\t<bsdf type="roughdielectric" id="FrostedBSDF">\n\t\t<string name="distribution" value="$distribution" /><boolean name="sample_visible" value="$sample_visible" />\n\t\t<float name="alpha" value="0.15" />\n'
            '\t\t<float name="int_ior" value="1.5" />\n\t\t<string name="ext_ior" value="air" />\n\t</bsdf>\n'
-           '\t<bsdf type="roughdielectric" id="BrushedGlassBSDF">\n\t\t<string name="distribution" value="$distribution" />\n\t\t<float name="alpha_u" value="0.05" />\n'
+           '\t<bsdf type="roughdielectric" id="BrushedGlassBSDF">\n\t\t<string name="distribution" value="$distribution" /><boolean name="sample_visible" value="$sample_visible" />\n\t\t<float name="alpha_u" value="0.05" />\n'
            '\t\t<float name="alpha_v" value="0.3" />\n\t\t<string name="int_ior" value="diamond" />\n\t\t<rgb name="specular_reflectance" value="0.9, 0.95, 1.0" />\n'
            '\t\t<rgb name="specular_transmittance" value="0.95, 0.9, 0.85" />\n\t</bsdf>\n')
 

@@ -86,6 +86,11 @@ CONFIGS = [
     # checkerboard / bitmap textures on the diffuse reflectances (rectangles, cube texcoords, a plastic's diffuse_reflectance)
     ("textured", "cornell_textured.xml", dict(resx=32, resy=32, max_depth=4), 8),
     # `constant` environment emitter: rays that leave the scene, environment sampling with MIS, valid_ray
+    # sample_visible = false: all microfacet normals are sampled (roughconductor / roughplastic weights and densities, roughdielectric with
+    # Walter et al.'s roughness scaling)
+    ("rough_conductor_all_normals", "cornell_rough.xml", dict(resx=32, resy=32, sample_visible="false", max_depth=5), 8),
+    ("rough_plastic_all_normals", "cornell_roughplastic.xml", dict(resx=32, resy=32, sample_visible="false", distribution="beckmann"), 8),
+    ("frosted_glass_all_normals", "cornell_frosted.xml", dict(resx=32, resy=32, sample_visible="false", max_depth=6), 8),
     ("environment", "cornell_env.xml", dict(resx=32, resy=32, max_depth=4), 8),
     # `envmap` emitter (RGBE file, rotated): latitude-longitude lookup on a miss, hierarchical importance sampling with MIS
     ("envmap", "cornell_envmap.xml", dict(resx=32, resy=32, max_depth=4), 8),

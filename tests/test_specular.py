@@ -197,7 +197,7 @@ def test_plastic_scenes_are_bit_exact_per_lane(mi, orc, tmp_path, name, params, 
 def test_roughconductor_limits_and_loader(mi, orc, tmp_path):
     """RoughConductor with the GGX distribution (roughconductor.cpp, microfacet.h): (1) the loader record matches the oracle's;
     (2) alpha -> 1e-4 converges to the smooth conductor (glossy lobe with NEE + MIS vs a delta lobe: different estimators, same
-    expectation); (3) a visibly rough wall stays finite and of the same order; (4) both distributions load; sample_visible = false is rejected with a reason."""
+    expectation); (3) a visibly rough wall stays finite and of the same order; (4) both distributions and both sampling modes (sample_visible) load."""
     path = os.path.join(SCENES, "cornell_rough.xml")
     sc, osc = mi.load_file(path), orc.Scene(path, {})
     rec = sc.export(9).reshape(-1, 24)
@@ -209,8 +209,8 @@ def test_roughconductor_limits_and_loader(mi, orc, tmp_path):
     assert any(rec[i, 22] != rec[i, 23] for i, _ in rough)             # the brushed floor is anisotropic
     beck = mi.load_string(open(path).read().replace('value="ggx"', 'value="beckmann"'))     # the plugins' default distribution
     assert [beck.export(12)[i] for i, _ in rough] == [0.0] * 3 and [sc.export(12)[i] for i, _ in rough] == [1.0] * 3
-    with pytest.raises(mi.DtofError, match="only sample_visible = true"):
-        mi.load_string(open(path).read().replace('<string name="distribution" value="$distribution" />', '<boolean name="sample_visible" value="false" />', 1))
+    allnorm = mi.load_file(path, sample_visible="false")
+    assert [allnorm.export(17)[i] for i, _ in rough] == [1.0] * len(rough) and not sc.export(17).any()
     with pytest.raises(mi.DtofError, match="invalid distribution"):
         mi.load_string(open(path).read().replace('value="ggx"', 'value="phong"'))
     with pytest.raises(mi.DtofError, match="both 'alpha_u' and 'alpha_v'"):
@@ -520,3 +520,42 @@ def test_microfacet_sampling_matches_its_density(orc):
                 assert abs(acc[0] - 1) < 2e-2, (mf_type, visible, angle, acc[0])           # a density
                 est = np.array([1.0, m[:, 0].mean(), (m[:, 1] ** 2).mean(), m[:, 2].mean()])
                 assert np.all(np.abs(est[1:] - acc[1:] / acc[0]) < 6e-3), (mf_type, visible, angle, est, acc)
+
+
+def test_sampling_all_normals_is_consistent(orc):
+    """sample_visible = false (roughconductor.cpp:260-265,405-409; roughplastic.cpp:413-417,467-470; roughdielectric.cpp:266-269,345-349,
+    584-589): for every rough BSDF (a) the weight of a sample equals eval / pdf of the sampled direction, (b) the sampled directions follow pdf
+    (the mean of 1 / pdf over the samples is the measure of the support: 2 pi for the reflecting ones), and (c) the albedo estimated with the
+    two sampling modes agrees -- they are two estimators of the same integral."""
+    import ctypes as C
+    L = orc.lib()
+    rng = np.random.default_rng(11)
+    albedo = {}
+    for scene, bsdf in (("cornell_rough.xml", 4), ("cornell_roughplastic.xml", 5), ("cornell_frosted.xml", 7)):
+        for mode in ("true", "false"):
+            osc = orc.Scene(os.path.join(SCENES, scene), dict(sample_visible=mode))
+            i = [k for k, sh in enumerate(osc.flat.shapes) if sh["bsdf"] == bsdf][0]
+            assert osc.flat.shapes[i]["sample_all"] == int(mode == "false")
+            wi = np.float32([0.35, -0.2, 0.0]); wi[2] = np.sqrt(1 - wi[0] ** 2 - wi[1] ** 2)
+            n, acc, inv, worst = 20000, 0.0, 0.0, 0.0
+            for s3 in rng.random((n, 3)).astype(np.float32):
+                out = np.zeros(13, np.float32)
+                L.orc_kat_bsdf(C.byref(osc.c.shapes[i]), wi.ctypes.data, np.float32([0, 0, 1]).ctypes.data, s3.ctypes.data, out.ctypes.data)
+                wo, bs_pdf, w = out[4:7].copy(), float(out[7]), out[10:13].astype(np.float64)
+                if bs_pdf <= 0 or not w.any():
+                    continue
+                chk = np.zeros(13, np.float32)
+                L.orc_kat_bsdf(C.byref(osc.c.shapes[i]), wi.ctypes.data, wo.ctypes.data, s3.ctypes.data, chk.ctypes.data)
+                val, pdf = chk[0:3].astype(np.float64), float(chk[3])
+                assert abs(pdf - bs_pdf) <= 2e-3 * max(pdf, bs_pdf), (scene, mode, pdf, bs_pdf)          # BSDF::pdf of the sampled direction is the sample's density
+                # roughdielectric samples a distribution of scaled roughness but weights with the unscaled one (roughdielectric.cpp:266-269 vs
+                # :345-349): there the weight is deliberately not eval / pdf
+                if not (bsdf == 7 and mode == "false"):
+                    worst = max(worst, float(np.abs(val / pdf - w).max() / max(np.abs(w).max(), 1e-6)))
+                acc += w.mean(); inv += 1.0 / bs_pdf
+            assert worst < 5e-3, (scene, mode, worst)
+            albedo[scene, mode] = acc / n
+            if bsdf != 7:
+                assert abs(inv / n / (2 * np.pi) - 1) < 0.1, (scene, mode, inv / n)   # heavy-tailed estimator: loose bound
+        a, b = albedo[scene, "true"], albedo[scene, "false"]
+        assert 0.05 < a <= 1.05 and abs(a - b) < (0.06 if scene == "cornell_frosted.xml" else 0.04) * max(a, b), (scene, a, b)
