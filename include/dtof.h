@@ -109,6 +109,7 @@ int dtof_scene_get_info(const dtof_scene *scene, dtof_scene_info *info);
  * kind 12: microfacet distribution of the rough BSDFs -> per shape 1 float: 0 beckmann, 1 ggx (MicrofacetType, include/mitsuba/render/microfacet.h:30-36)
  * kind 13: textures        -> per texture (in order of appearance) 17 floats: kind (0 checkerboard, 1 bitmap), filter (0 nearest, 1 bilinear), wrap (0 repeat,
  *                             1 mirror, 2 clamp), channels, width, height, to_uv 2x2, color0[3], color1[3], mean (src/textures/{checkerboard,bitmap}.cpp)
+ * kind 18: per emitter 10 floats: kind, position[3], intensity | radiance | irradiance[3], direction of travel[3] (directional emitters)
  * kind 17: per shape 1 float: 1 if its rough BSDF samples all normals (sample_visible = false), else 0
  * kind 16: the environment map (src/emitters/envmap.cpp) as packed: w, h, levels, scale, bounding sphere[4], to_world[12], to_local[12], m_data[h*w*3], then
  *          per level of the Hierarchical2D warp (distr_2d.h:376-482): width, count, values[count]

@@ -343,6 +343,14 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
                     ds_pdf = kInvFourPi; ds_delta = false;
                     const float ip = rcp(ds_pdf);
                     em_weight = mk(em.intensity[0] * ip, em.intensity[1] * ip, em.intensity[2] * ip);
+                } else if (SPEC && em.kind == EMITTER_DIRECTIONAL) {   // DirectionalEmitter::sample_direction (directional.cpp:148-176)
+                    const V3 dir = mk(em.to_local[0], em.to_local[1], em.to_local[2]);
+                    const float radius = fmax_(em.cutoff_angle, norm(si.p - mk(em.pos[0], em.pos[1], em.pos[2])));
+                    ds_dist = 2.f * radius;
+                    dsp = si.p - dir * ds_dist;
+                    dd = -dir;
+                    ds_pdf = 1.f;
+                    em_weight = mk(em.intensity[0], em.intensity[1], em.intensity[2]);
                 } else if (SPEC && em.kind == EMITTER_ENVMAP) {   // EnvironmentMapEmitter::sample_direction (envmap.cpp:363-406)
                     env_sample_direction(sv.base, em, si.p, sx, e2, dd, ds_dist, ds_pdf, em_weight, em_active);
                     dsp = si.p + dd * ds_dist;

@@ -358,7 +358,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     for (auto &e : sc->host.emitters) has_surface_emitters |= e.kind == EMITTER_AREA || e.kind == EMITTER_CONSTANT || e.kind == EMITTER_ENVMAP;   // the environment is "hit" by the rays that leave the scene
     rp.has_area = has_surface_emitters;
     for (auto &sh : sc->host.shapes) rp.has_spec |= sh.bsdf != BSDF_DIFFUSE;
-    for (auto &e : sc->host.emitters) rp.has_spec |= e.kind == EMITTER_SPOT;
+    for (auto &e : sc->host.emitters) rp.has_spec |= e.kind == EMITTER_SPOT || e.kind == EMITTER_DIRECTIONAL;
     rp.has_spec |= !sc->host.textures.empty();
     for (size_t ei = 0; ei < sc->host.emitters.size(); ++ei) if (sc->host.emitters[ei].kind == EMITTER_CONSTANT || sc->host.emitters[ei].kind == EMITTER_ENVMAP) { rp.has_env = 1; rp.env_index = (uint32_t) ei; rp.has_spec = 1; }
     rp.hide_emitters = sc->pp.hide_emitters;   // textured reflectances are looked up in the SPEC instantiations only   // the spot branch lives in the SPEC instantiations (keeps the common kernels lean)
@@ -687,6 +687,9 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
         } else if (kind == 14) for (auto &t : sc->host.textures) v.insert(v.end(), t.data.begin(), t.data.end());
         else if (kind == 15) for (auto &s : sc->host.shapes) v.push_back((float) s.tex_refl);
         else if (kind == 17) for (auto &s : sc->host.shapes) v.push_back(s.sample_all ? 1.f : 0.f);
+        else if (kind == 18) for (auto &e : sc->host.emitters) {   // every emitter: kind, pos, intensity, first row of to_local (directional: its direction)
+            v.push_back((float) e.kind); v.insert(v.end(), e.pos, e.pos + 3); v.insert(v.end(), e.intensity, e.intensity + 3); v.insert(v.end(), e.to_local, e.to_local + 3);
+        }
         else if (kind == 16) {   // the environment map as packed into the blob: header words, m_data, then every level of the hierarchical warp
             const BlobHeader *bh = (const BlobHeader *) sc->blob.data();
             const DEmitter *de = (const DEmitter *) (sc->blob.data() + bh->off_emitters);

@@ -19,7 +19,7 @@ enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1, FILTER_GAUSSIAN = 2
 enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4, SF_EMITTER = 8, SF_BECKMANN = 16 /* rough BSDFs: Beckmann instead of GGX */, SF_SAMPLE_ALL = 64 /* rough BSDFs: sample_visible = false */,
                             SF_TEXCOORDS = 32 /* mesh with vertex texcoords (si.uv interpolates them; otherwise si.uv = the barycentrics, mesh.cpp:720-737) */ };
 enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4, BSDF_ROUGHPLASTIC = 5, BSDF_THINDIELECTRIC = 6, BSDF_ROUGHDIELECTRIC = 7 };
-enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1, EMITTER_SPOT = 2, EMITTER_CONSTANT = 3, EMITTER_ENVMAP = 4 };
+enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1, EMITTER_SPOT = 2, EMITTER_CONSTANT = 3, EMITTER_ENVMAP = 4, EMITTER_DIRECTIONAL = 5 };
 
 // ---------------------------------------------------------------------------- device blob records
 // One contiguous byte blob (offsets from its base) so that small scenes can be staged
@@ -111,6 +111,7 @@ struct DEmitter {           // 96 B
     uint32_t kind; float pos[3]; float intensity[3]; uint32_t shape;   // area: intensity = radiance, shape = index into shapes[]
     // spot (src/emitters/spot.cpp:75-100): world -> local (3x4 affine part of to_world's inverse) and the constants of the falloff curve
     float to_local[12]; float cutoff_angle, cos_cutoff, cos_beam, inv_transition;
+    // directional (src/emitters/directional.cpp): intensity = irradiance, to_local[0..2] = the direction of travel, pos / cutoff_angle = m_bsphere as for `constant`
     // constant (src/emitters/constant.cpp): intensity = radiance, pos = centre of m_bsphere, cutoff_angle = its (enlarged) radius (set_scene, :73-83)
 };
 // EnvironmentMapEmitter (src/emitters/envmap.cpp) in the tables area: m_data (h rows of w = bitmap width + 1 RGB texels) and the levels of its

@@ -393,7 +393,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         memcpy(emitters[i].to_local, sc.emitters[i].to_local, 48);
         emitters[i].cutoff_angle = sc.emitters[i].cutoff_angle; emitters[i].cos_cutoff = sc.emitters[i].cos_cutoff;
         emitters[i].cos_beam = sc.emitters[i].cos_beam; emitters[i].inv_transition = sc.emitters[i].inv_transition;
-        if (sc.emitters[i].kind == EMITTER_CONSTANT || sc.emitters[i].kind == EMITTER_ENVMAP) { memcpy(emitters[i].pos, env_sphere, 12); emitters[i].cutoff_angle = env_sphere[3]; }
+        if (sc.emitters[i].kind == EMITTER_CONSTANT || sc.emitters[i].kind == EMITTER_ENVMAP || sc.emitters[i].kind == EMITTER_DIRECTIONAL) { memcpy(emitters[i].pos, env_sphere, 12); emitters[i].cutoff_angle = env_sphere[3]; }
         if (sc.emitters[i].kind == EMITTER_ENVMAP) {
             // EnvironmentMapEmitter's constructor (envmap.cpp:130-224): a periodic extra column, luminance x sin(theta) as the sampling density, and the
             // Hierarchical2D<Float, 0> built over it (distr_2d.h:376-482): level 0 = the normalised grid, level 1 = patch averages, then 2 x 2 sums

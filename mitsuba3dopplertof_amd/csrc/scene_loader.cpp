@@ -972,7 +972,7 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
             if (have_sensor) fail("only one sensor is supported");
             make_sensor(o, sc); have_sensor = true;
         } else if (o.tag == "emitter") {
-            if (o.plugin != "point" && o.plugin != "spot" && o.plugin != "constant" && o.plugin != "envmap") fail("unsupported emitter plugin \"" + o.plugin + "\" (supported: point, spot, constant, envmap; area inside a shape)");
+            if (o.plugin != "point" && o.plugin != "spot" && o.plugin != "constant" && o.plugin != "envmap" && o.plugin != "directional") fail("unsupported emitter plugin \"" + o.plugin + "\" (supported: point, spot, directional, constant, envmap; area inside a shape)");
             HostEmitter e; e.kind = 0;
             if (o.plugin == "constant") {   // src/emitters/constant.cpp:58-67: the scene's environment (scene.cpp:53-57); its bounding sphere follows in build_scene_blob
                 for (auto &pe : sc.emitters) if (pe.kind == EMITTER_CONSTANT || pe.kind == EMITTER_ENVMAP) fail("Only one environment emitter can be specified per scene.");
@@ -980,6 +980,25 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
                 auto rc = o.colors.find("radiance");
                 if (rc != o.colors.end()) for (int i = 0; i < 3; ++i) e.intensity[i] = (float) rc->second[i];
                 else { float v = (float) o.props.get_float("radiance", 1.0); e.intensity[0] = e.intensity[1] = e.intensity[2] = v; }
+            } else if (o.plugin == "directional") {   // src/emitters/directional.cpp:65-91: direction of travel = to_world * (0, 0, 1), or the normalised `direction`
+                e.kind = EMITTER_DIRECTIONAL;
+                auto dv = o.vectors.find("direction"); auto tws = o.transforms.find("to_world");
+                if (dv != o.vectors.end()) {
+                    if (tws != o.transforms.end()) fail("Only one of the parameters 'direction' and 'to_world' can be specified at the same time!'");
+                    float v[3] = { (float) dv->second[0], (float) dv->second[1], (float) dv->second[2] };
+                    for (int pass = 0; pass < 2; ++pass) {   // dr::normalize of the property, then look_at normalises target - origin once more (both in float32)
+                        const float inv = 1.0f / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                        for (int k = 0; k < 3; ++k) v[k] *= inv;
+                    }
+                    for (int k = 0; k < 3; ++k) e.to_local[k] = v[k];
+                } else {
+                    Xf xf; if (tws != o.transforms.end()) xf = tws->second; else { xf.m = m_identity(); xf.inv = m_identity(); }
+                    float m[16]; to_f32(xf.m, m);
+                    e.to_local[0] = m[2]; e.to_local[1] = m[6]; e.to_local[2] = m[10];
+                }
+                auto ics = o.colors.find("irradiance");
+                if (ics != o.colors.end()) for (int i = 0; i < 3; ++i) e.intensity[i] = (float) ics->second[i];
+                else { float v = (float) o.props.get_float("irradiance", 1.0); e.intensity[0] = e.intensity[1] = e.intensity[2] = v; }
             } else if (o.plugin == "envmap") {   // src/emitters/envmap.cpp:116-224; tables and bounding sphere follow in build_scene_blob
                 for (auto &pe : sc.emitters) if (pe.kind == EMITTER_CONSTANT || pe.kind == EMITTER_ENVMAP) fail("Only one environment emitter can be specified per scene.");
                 e.kind = EMITTER_ENVMAP;

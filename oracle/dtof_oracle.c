@@ -1783,6 +1783,16 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
                 ds_pdf = ORC_INV_FOUR_PI_F; ds_delta = 0;
                 float ip = f_rcp(ds_pdf);
                 em_weight = V(em->intensity[0] * ip, em->intensity[1] * ip, em->intensity[2] * ip);
+            } else if (em->kind == ORC_EMITTER_DIRECTIONAL) {
+                /* DirectionalEmitter::sample_direction (directional.cpp:148-176): a delta direction; the sample point lies outside the scene's bounding sphere */
+                v3 dir = V(em->position[0], em->position[1], em->position[2]);
+                v3 c = V(em->bsphere[0], em->bsphere[1], em->bsphere[2]);
+                float radius = f_max(em->bsphere[3], v_norm(v_sub(si.p, c)));
+                ds_dist = 2.f * radius;
+                dsp = v_sub(si.p, v_mul(dir, ds_dist));
+                dd = v_neg(dir);
+                ds_pdf = 1.f; ds_delta = 1;
+                em_weight = V(em->intensity[0], em->intensity[1], em->intensity[2]);
             } else if (em->kind == ORC_EMITTER_ENVMAP) {
                 /* EnvironmentMapEmitter::sample_direction (envmap.cpp:363-406) */
                 env_sample_direction(em, si.p, sx, e2, &dd, &ds_dist, &ds_pdf, &em_weight, &em_active);

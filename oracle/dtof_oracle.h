@@ -25,7 +25,8 @@ extern "C" {
 
 enum { ORC_SHAPE_RECT = 0, ORC_SHAPE_MESH = 1, ORC_SHAPE_SPHERE = 2, ORC_SHAPE_DISK = 3, ORC_SHAPE_CYLINDER = 4 };
 enum { ORC_OBJ_SHAPE = 0, ORC_OBJ_INSTANCE = 1 };
-enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1, ORC_EMITTER_SPOT = 2, ORC_EMITTER_CONSTANT = 3, ORC_EMITTER_ENVMAP = 4 };
+enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1, ORC_EMITTER_SPOT = 2, ORC_EMITTER_CONSTANT = 3, ORC_EMITTER_ENVMAP = 4, ORC_EMITTER_DIRECTIONAL = 5 };
+/* directional (src/emitters/directional.cpp): position = the direction of travel d (unit), intensity = irradiance, bsphere as for the environment */
 enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 };
 enum { ORC_TIME_UNIFORM = 0, ORC_TIME_STRATIFIED = 1, ORC_TIME_ANTITHETIC = 2,
        ORC_TIME_ANTITHETIC_MIRROR = 3 };

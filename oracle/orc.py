@@ -387,7 +387,7 @@ class Scene:
                 emitters[i].envmap = h
                 emitters[i].env_to_world = _m16(e["to_world"]); emitters[i].to_local = _m16(e["to_local"])
                 self._envmaps.append(h)
-            if e["kind"] in (3, 4):   # environment: ConstantBackgroundEmitter / EnvironmentMapEmitter::set_scene (constant.cpp:73-83, envmap.cpp:286-297)
+            if e["kind"] in (3, 4, 5):   # environment / directional: ConstantBackgroundEmitter / EnvironmentMapEmitter::set_scene (constant.cpp:73-83, envmap.cpp:286-297)
                 bs = (C.c_float * 4)()
                 L.orc_scene_bsphere(C.byref(sc), bs)
                 emitters[i].bsphere = bs

@@ -695,6 +695,23 @@ def load(source, params=None, is_string=False):
             fs.sensor = _sensor_record(child)
             fs.sampler = next((c[1] for c in child.children if c[0] == "sampler"), None)
         elif tag == "emitter":
+            if child.plugin == "directional":   # src/emitters/directional.cpp:65-91
+                if "direction" in child:
+                    if "to_world" in child:
+                        raise ValueError("Only one of the parameters 'direction' and 'to_world' can be specified at the same time!'")
+                    v = np.asarray(child["direction"][1], dtype=np.float64).astype(F32)
+                    for _ in range(2):   # dr::normalize of the property, then look_at normalises target - origin once more (both in float32)
+                        v = (v * (F32(1.0) / np.sqrt(F32(v[0] * v[0]) + F32(v[1] * v[1]) + F32(v[2] * v[2]), dtype=F32))).astype(F32)
+                    d = v
+                else:
+                    tw = child["to_world"][1][0] if "to_world" in child else _ident()
+                    d = _m32(tw)[:3, 2].copy()     # to_world * (0, 0, 1)
+                child.queried.add("to_world"); child.queried.add("direction")
+                irr = child["irradiance"] if "irradiance" in child else ("float", 1.0)
+                child.queried.add("irradiance")
+                iv = [irr[1]] * 3 if irr[0] in ("float", "int") else irr[1]
+                fs.emitters.append(dict(kind=5, position=np.asarray(d, F32), intensity=np.asarray(iv, dtype=np.float64).astype(F32)))
+                continue
             if child.plugin == "spot":   # src/emitters/spot.cpp:75-100
                 tw, tinv = child["to_world"][1] if "to_world" in child else (_ident(), _ident())
                 cutoff = F32(child.get_f("cutoff_angle", 20.0))

@@ -249,6 +249,17 @@ def write_rgbe(path, rows, rle=True):
                         f.write(bytes([j - i]) + bytes(ch[i:j])); i = j
 
 
+def cornell_sun(res=128, spp=16):
+    """cornell_env.xml (no ceiling, no back wall) under a `directional` emitter (src/emitters/directional.cpp) given by `direction`, plus a second one
+    given by a to_world rotation, beside the point light: delta directions, shadow rays that leave through the open sides"""
+    s = cornell_env(res, spp)
+    a = s.index('\t<emitter type="constant">'); b = s.index('</emitter>', a) + len('</emitter>\n')
+    em = ('\t<emitter type="directional">\n\t\t<vector name="direction" x="-0.3" y="-1" z="-0.4" />\n\t\t<rgb name="irradiance" value="3.0, 2.6, 2.0" />\n\t</emitter>\n'
+          '\t<emitter type="directional">\n\t\t<transform name="to_world">\n\t\t\t<rotate x="1" angle="110" />\n\t\t\t<rotate y="1" angle="25" />\n\t\t</transform>\n'
+          '\t\t<float name="irradiance" value="0.8" />\n\t</emitter>\n')
+    return s[:a] + em + s[b:]
+
+
 def cornell_envmap(res=128, spp=16, filename="env_sky.hdr", extra=""):
     """cornell_env.xml under an `envmap` emitter (src/emitters/envmap.cpp): a latitude-longitude radiance map, rotated, importance-sampled"""
     s = cornell_env(res, spp)
@@ -498,6 +509,7 @@ def main():
         "cornell_textured.xml": cornell_textured(),
         "cornell_env.xml": cornell_env(),
         "cornell_envmap.xml": cornell_envmap(),
+        "cornell_sun.xml": cornell_sun(),
         "cornell_cylinders.xml": cornell_cylinders(),
         "cornell_spheres.xml": cornell_spheres(),
         "cornell_sphere_light.xml": cornell_spheres(sphere_light=True),
@@ -514,7 +526,7 @@ def main():
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
     names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml",
-             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml", "cornell_envmap.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png"]
+             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
         return

@@ -94,6 +94,8 @@ CONFIGS = [
     ("environment", "cornell_env.xml", dict(resx=32, resy=32, max_depth=4), 8),
     # `envmap` emitter (RGBE file, rotated): latitude-longitude lookup on a miss, hierarchical importance sampling with MIS
     ("envmap", "cornell_envmap.xml", dict(resx=32, resy=32, max_depth=4), 8),
+    # `directional` emitters (one by `direction`, one by `to_world`): delta directions sampled from outside the bounding sphere
+    ("directional", "cornell_sun.xml", dict(resx=32, resy=32, max_depth=4), 8),
     ("cylinders", "cornell_cylinders.xml", dict(resx=24, resy=24, max_depth=4), 8),
     ("spot_light", "cornell_spot.xml", dict(resx=24, resy=24), 8),
     ("disks", "cornell_disk.xml", dict(resx=24, resy=24, max_depth=5), 8),

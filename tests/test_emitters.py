@@ -237,3 +237,32 @@ def test_envmap_scene(mi, orc, tmp_path):
         load("tiny.xml", text.replace("env_sky.hdr", str(tmp_path / "tiny.pfm")))
     with pytest.raises(mi.DtofError, match="could not open"):
         load("missing.xml", text.replace("env_sky.hdr", str(tmp_path / "nope.hdr")))
+
+
+def test_directional_emitter(mi, orc, tmp_path):
+    """`directional` (src/emitters/directional.cpp): loader parity (direction by `direction` -- normalised twice in float32, as the constructor's
+    normalize + look_at do -- and by `to_world`; irradiance), the analytic irradiance of an unoccluded patch (E cos(theta) rho / pi), the refusal
+    of both parameters at once."""
+    path = os.path.join(SCENES, "cornell_sun.xml")
+    sc, osc = mi.load_file(path), orc.Scene(path, {})
+    ours = sc.export(18).reshape(-1, 10)
+    suns = [e for e in osc.flat.emitters if e["kind"] == 5]
+    assert len(suns) == 2 and [int(k) for k in ours[:, 0]] == [e["kind"] for e in osc.flat.emitters]
+    for row, e in zip(ours[ours[:, 0] == 5], suns):
+        assert np.array_equal(row[7:10].view(np.uint32), np.float32(e["position"]).view(np.uint32))      # the direction, bit for bit
+        assert np.array_equal(row[4:7].view(np.uint32), np.float32(e["intensity"]).view(np.uint32))
+        assert abs(np.linalg.norm(row[7:10]) - 1) < 1e-6
+    assert np.allclose(ours[0, 7:10], np.float32([-0.3, -1, -0.4]) / np.linalg.norm([-0.3, -1, -0.4]), atol=1e-7)
+    # one white diffuse floor under a vertical sun of irradiance E, seen from above: radiance = E * rho / pi at depth 2 (direct light only)
+    xml = ('<scene version="3.0.0"><integrator type="path"><integer name="max_depth" value="2"/></integrator>'
+           '<sensor type="perspective"><float name="fov" value="20"/><transform name="to_world"><lookat origin="0, 4, 0.001" target="0, 0, 0" up="0, 1, 0"/></transform>'
+           '<sampler type="independent"><integer name="sample_count" value="16"/></sampler>'
+           '<film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/><rfilter type="box"/></film></sensor>'
+           '<shape type="rectangle"><transform name="to_world"><rotate x="1" angle="-90"/><scale value="10"/></transform>'
+           '<bsdf type="diffuse"><rgb name="reflectance" value="0.5"/></bsdf></shape>'
+           '<emitter type="directional"><vector name="direction" x="0" y="-1" z="0"/><rgb name="irradiance" value="2.0, 4.0, 6.0"/></emitter></scene>')
+    flat = orc.Scene(xml, is_string=True)
+    img, _ = flat.render(flat.params(), seed=1, spp=16, threads=NCPU)
+    assert np.allclose(img[4, 4], np.float32([2.0, 4.0, 6.0]) * 0.5 / np.pi, rtol=1e-5)
+    with pytest.raises(mi.DtofError, match="Only one of the parameters 'direction' and 'to_world'"):
+        mi.load_string(xml.replace('<vector name="direction" x="0" y="-1" z="0"/>', '<vector name="direction" x="0" y="-1" z="0"/><transform name="to_world"><rotate x="1" angle="10"/></transform>'))
