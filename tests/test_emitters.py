@@ -71,7 +71,7 @@ def test_spot_light_semantics(mi, orc, tmp_path):
     with pytest.raises(mi.DtofError, match="unreferenced property"):
         mi.load_string(room(DOWN % ("50", "30", '<float name="beamwidth" value="15" />')))
     with pytest.raises(mi.DtofError, match="unsupported emitter plugin"):
-        mi.load_string(room('\t<emitter type="directional" />\n'))
+        mi.load_string(room('\t<emitter type="projector" />\n'))
 
 
 SPOT_CASES = [("spot_room_fused", None, dict(resx=32, resy=32), 8, dict(type="path", max_depth=5)),
