@@ -210,6 +210,7 @@ struct PluginParams {
     uint32_t base_seed = 0, sample_count = 4; int32_t time_correlate_number = 2, path_correlate_number = 2;
 };
 void read_png(const std::string &path, std::vector<uint8_t> &pixels, uint32_t &width, uint32_t &height, uint32_t &channels);   // image_io.cpp
+void read_jpeg(const std::string &path, std::vector<uint8_t> &pixels, uint32_t &width, uint32_t &height, uint32_t &channels);   // image_io.cpp: baseline JPEG
 void read_radiance_image(const std::string &path, std::vector<float> &rgb, uint32_t &width, uint32_t &height, float (*srgb_to_linear_u8)(uint32_t));   // image_io.cpp: RGBE, PFM, PNG
 PluginParams make_plugin_params(const PropBag &integrator, const PropBag &sampler);   // throws std::runtime_error
 

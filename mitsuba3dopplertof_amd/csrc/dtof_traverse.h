@@ -412,10 +412,10 @@ DTOF_D bool trace_flat(const SceneView &sv, ConstBytes flat_table, uint32_t n_ob
         const float t = -lo.z / ld.z;
         const float u = fmaf(ld.x, t, lo.x), v = fmaf(ld.y, t, lo.y);
         // no short-circuit: four compares and three mask ANDs instead of three exec-mask branches per rectangle (the scalar unit is as busy as the vector units here)
-        const bool hit = (t >= 0.f) & (t <= maxt) & (fabsf(u) <= 1.f) & (fabsf(v) <= 1.f);
+        const bool hit = (int) (t >= 0.f) & (int) (t <= maxt) & (int) (fabsf(u) <= 1.f) & (int) (fabsf(v) <= 1.f);
         if (ANY) occluded |= hit;
         else {
-            const bool take = hit & (t < best.t);
+            const bool take = (int) hit & (int) (t < best.t);
             best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v; best.obj = take ? oi : best.obj; best.shape = take ? 0u : best.shape;
         }
     };

@@ -3,6 +3,7 @@
 // payload is inflated with zlib, the scanline filters (PNG specification, section 9) are undone in place.
 #include "dtof_scene.h"
 #include <zlib.h>
+#include <algorithm>
 #include <cstring>
 #include <cmath>
 #include <cstdio>
@@ -89,6 +90,242 @@ void read_png(const std::string &path, std::vector<uint8_t> &pixels, uint32_t &w
     width = w; height = h;
 }
 
+
+// ---------------------------------------------------------------------------- JPEG (baseline sequential DCT, Huffman, 8 bit)
+// What src/core/bitmap.cpp reads through libjpeg with its default settings (JDCT_ISLOW, fancy upsampling): the entropy decoder of ITU T.81
+// annex F, the "slow but accurate" integer inverse DCT of the IJG library (jidctint.c: 13-bit constants, 2 extra bits after the column pass),
+// its triangle-filter chroma upsampling for 2x1 and 2x2 subsampled components (jdsample.c: h2v1_fancy / h2v2_fancy) and its fixed-point
+// YCbCr -> RGB tables (jdcolor.c) -- integer arithmetic throughout, so the samples are those of libjpeg-turbo / libjpeg 6b bit for bit.
+// Progressive, arithmetic-coded, 12-bit, CMYK and other subsampling layouts are refused.
+namespace {
+struct JpegComponent { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int dc_pred = 0; int bw = 0, bh = 0; std::vector<uint8_t> plane; };
+struct JpegHuff { uint8_t bits[17] = { 0 }; uint8_t vals[256] = { 0 }; int mincode[17], maxcode[18], valptr[17]; bool present = false;
+    void build() {
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) { valptr[l] = k; mincode[l] = code; code += bits[l]; k += bits[l]; maxcode[l] = bits[l] ? code - 1 : -1; code <<= 1; }
+        maxcode[17] = 0x7fffffff;
+    } };
+struct JpegBits {
+    const uint8_t *p, *end; uint32_t acc = 0; int n = 0; bool hit_marker = false;
+    void fill() {
+        while (n <= 24) {
+            uint32_t b = 0;
+            if (!hit_marker && p < end) {
+                b = *p;
+                if (b == 0xff) { if (p + 1 < end && p[1] == 0) p += 2; else { hit_marker = true; b = 0; } }
+                else ++p;
+            }
+            acc |= b << (24 - n); n += 8;
+        }
+    }
+    int get(int count) { if (count == 0) return 0; if (n < count) fill(); const int v = (int) (acc >> (32 - count)); acc <<= count; n -= count; return v; }
+    int decode(const JpegHuff &h) {
+        int code = 0;
+        for (int l = 1; l <= 16; ++l) { code = (code << 1) | get(1); if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]]; }
+        throw std::runtime_error("read_jpeg(): corrupt Huffman code");
+    }
+    void reset() { acc = 0; n = 0; hit_marker = false; }
+};
+inline int jpeg_extend(int v, int t) { return t == 0 ? 0 : (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v); }
+inline uint8_t jpeg_clamp(int v) { return (uint8_t) (v < 0 ? 0 : v > 255 ? 255 : v); }
+const int kZigzag[64] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30,
+                          37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
+// jpeg_idct_islow (jidctint.c): coef = dequantised coefficients in natural order; out = 8 x 8 samples
+void jpeg_idct(const int *coef, uint8_t *out, int stride) {
+    constexpr int CB = 13, P1 = 2;
+    constexpr long F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299, F1847 = 15137, F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172;
+    auto descale = [](long x, int n) { return (x + (1L << (n - 1))) >> n; };
+    long ws[64];
+    for (int c = 0; c < 8; ++c) {
+        const int *in = coef + c;
+        if (!in[8] && !in[16] && !in[24] && !in[32] && !in[40] && !in[48] && !in[56]) { const long dc = (long) in[0] * (1L << P1); for (int r = 0; r < 8; ++r) ws[r * 8 + c] = dc; continue; }
+        long z2 = in[16], z3 = in[48];
+        long z1 = (z2 + z3) * F0541, tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+        z2 = in[0]; z3 = in[32];
+        long tmp0 = (z2 + z3) * (1L << CB), tmp1 = (z2 - z3) * (1L << CB);
+        const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = in[56]; tmp1 = in[40]; tmp2 = in[24]; tmp3 = in[8];
+        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; long z4 = tmp1 + tmp3; const long z5 = (z3 + z4) * F1175;
+        tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
+        z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390; z3 += z5; z4 += z5;
+        tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+        ws[0 * 8 + c] = descale(tmp10 + tmp3, CB - P1); ws[7 * 8 + c] = descale(tmp10 - tmp3, CB - P1);
+        ws[1 * 8 + c] = descale(tmp11 + tmp2, CB - P1); ws[6 * 8 + c] = descale(tmp11 - tmp2, CB - P1);
+        ws[2 * 8 + c] = descale(tmp12 + tmp1, CB - P1); ws[5 * 8 + c] = descale(tmp12 - tmp1, CB - P1);
+        ws[3 * 8 + c] = descale(tmp13 + tmp0, CB - P1); ws[4 * 8 + c] = descale(tmp13 - tmp0, CB - P1);
+    }
+    for (int r = 0; r < 8; ++r) {
+        const long *w = ws + r * 8; uint8_t *o = out + (size_t) r * stride;
+        if (!w[1] && !w[2] && !w[3] && !w[4] && !w[5] && !w[6] && !w[7]) { const uint8_t dc = jpeg_clamp((int) descale(w[0], P1 + 3) + 128); for (int c = 0; c < 8; ++c) o[c] = dc; continue; }
+        long z2 = w[2], z3 = w[6];
+        long z1 = (z2 + z3) * F0541, tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+        long tmp0 = (w[0] + w[4]) * (1L << CB), tmp1 = (w[0] - w[4]) * (1L << CB);
+        const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
+        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; long z4 = tmp1 + tmp3; const long z5 = (z3 + z4) * F1175;
+        tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
+        z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390; z3 += z5; z4 += z5;
+        tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+        constexpr int S = CB + P1 + 3;
+        o[0] = jpeg_clamp((int) descale(tmp10 + tmp3, S) + 128); o[7] = jpeg_clamp((int) descale(tmp10 - tmp3, S) + 128);
+        o[1] = jpeg_clamp((int) descale(tmp11 + tmp2, S) + 128); o[6] = jpeg_clamp((int) descale(tmp11 - tmp2, S) + 128);
+        o[2] = jpeg_clamp((int) descale(tmp12 + tmp1, S) + 128); o[5] = jpeg_clamp((int) descale(tmp12 - tmp1, S) + 128);
+        o[3] = jpeg_clamp((int) descale(tmp13 + tmp0, S) + 128); o[4] = jpeg_clamp((int) descale(tmp13 - tmp0, S) + 128);
+    }
+}
+}  // namespace
+
+// -> pixels: height * width * channels bytes, channels = 1 (grayscale file) or 3 (RGB)
+void read_jpeg(const std::string &path, std::vector<uint8_t> &pixels, uint32_t &width, uint32_t &height, uint32_t &channels) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("could not open \"" + path + "\"");
+    std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    auto fail = [&](const std::string &m) { throw std::runtime_error("read_jpeg(): \"" + path + "\": " + m); };
+    if (file.size() < 4 || file[0] != 0xff || file[1] != 0xd8) fail("not a JPEG file");
+    int qt[4][64]; bool have_qt[4] = { false, false, false, false }; JpegHuff dc[4], ac[4];
+    std::vector<JpegComponent> comp; uint32_t w = 0, h = 0; int restart = 0; bool adobe = false; int adobe_transform = -1;
+    size_t pos = 2;
+    auto be16 = [&](size_t at) { if (at + 2 > file.size()) fail("truncated"); return (int) (file[at] << 8 | file[at + 1]); };
+    for (;;) {
+        while (pos < file.size() && file[pos] != 0xff) ++pos;
+        while (pos < file.size() && file[pos] == 0xff) ++pos;
+        if (pos >= file.size()) fail("no image data");
+        const int marker = file[pos++];
+        if (marker == 0xd8 || (marker >= 0xd0 && marker <= 0xd7) || marker == 0x01) continue;
+        if (marker == 0xd9) fail("no image data");
+        const int len = be16(pos); if (len < 2 || pos + len > file.size()) fail("truncated segment");
+        const uint8_t *seg = &file[pos + 2]; const int n = len - 2;
+        if (marker == 0xdb) {           // DQT
+            for (int k = 0; k < n;) {
+                const int pq = seg[k] >> 4, tq = seg[k] & 15; ++k;
+                if (tq > 3 || k + (pq ? 128 : 64) > n) fail("bad quantisation table");
+                for (int i = 0; i < 64; ++i) { qt[tq][kZigzag[i]] = pq ? (seg[k] << 8 | seg[k + 1]) : seg[k]; k += pq ? 2 : 1; }
+                have_qt[tq] = true;
+            }
+        } else if (marker == 0xc4) {    // DHT
+            for (int k = 0; k < n;) {
+                if (k + 17 > n) fail("bad Huffman table");
+                const int tc = seg[k] >> 4, th = seg[k] & 15; ++k;
+                if (tc > 1 || th > 3) fail("bad Huffman table");
+                JpegHuff &t = tc ? ac[th] : dc[th]; int total = 0;
+                for (int l = 1; l <= 16; ++l) { t.bits[l] = seg[k++]; total += t.bits[l]; }
+                if (total > 256 || k + total > n) fail("bad Huffman table");
+                for (int i = 0; i < total; ++i) t.vals[i] = seg[k++];
+                t.build(); t.present = true;
+            }
+        } else if (marker == 0xc0 || marker == 0xc1) {   // SOF0 / SOF1: baseline / extended sequential, Huffman
+            if (n < 6 || seg[0] != 8) fail("only 8-bit JPEG files are supported");
+            h = (uint32_t) (seg[1] << 8 | seg[2]); w = (uint32_t) (seg[3] << 8 | seg[4]);
+            const int nc = seg[5];
+            if ((nc != 1 && nc != 3) || n < 6 + 3 * nc) fail("only grayscale and YCbCr JPEG files are supported");
+            comp.resize(nc);
+            for (int c = 0; c < nc; ++c) { comp[c].id = seg[6 + 3 * c]; comp[c].h = seg[7 + 3 * c] >> 4; comp[c].v = seg[7 + 3 * c] & 15; comp[c].tq = seg[8 + 3 * c]; if (comp[c].tq > 3) fail("bad frame header"); }
+        } else if (marker == 0xc2 || (marker >= 0xc3 && marker <= 0xcf && marker != 0xc4 && marker != 0xc8 && marker != 0xcc)) {
+            fail("progressive, lossless and arithmetic-coded JPEG files are not supported (baseline sequential only)");
+        } else if (marker == 0xdd) { if (n < 2) fail("bad DRI"); restart = seg[0] << 8 | seg[1]; }
+        else if (marker == 0xee && n >= 12 && !memcmp(seg, "Adobe", 5)) { adobe = true; adobe_transform = seg[11]; }
+        else if (marker == 0xda) {      // SOS: the one scan of a baseline file
+            if (comp.empty() || w == 0 || h == 0) fail("scan before frame header");
+            if (n < 1 || seg[0] != (int) comp.size() || n < 1 + 2 * (int) comp.size() + 3) fail("only single-scan (interleaved) baseline files are supported");
+            for (size_t c = 0; c < comp.size(); ++c) {
+                size_t which = comp.size();
+                for (size_t j = 0; j < comp.size(); ++j) if (comp[j].id == seg[1 + 2 * c]) which = j;
+                if (which != c) fail("unexpected component order in the scan");
+                comp[c].td = seg[2 + 2 * c] >> 4; comp[c].ta = seg[2 + 2 * c] & 15;
+                if (comp[c].td > 3 || comp[c].ta > 3 || !dc[comp[c].td].present || !ac[comp[c].ta].present || !have_qt[comp[c].tq]) fail("scan refers to a missing table");
+            }
+            pos += len;
+            break;
+        }
+        pos += len;
+    }
+    if ((uint64_t) w * h > (1ull << 28)) fail("image too large");
+    const bool colour = comp.size() == 3;
+    if (colour && adobe && adobe_transform == 0) fail("RGB-coded (Adobe transform 0) JPEG files are not supported");
+    int hmax = 1, vmax = 1; for (auto &c : comp) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+    if (!colour) { comp[0].h = comp[0].v = 1; hmax = vmax = 1; }   // a single-component scan is not interleaved: its sampling factors do not matter
+    else {
+        if (comp[1].h != 1 || comp[1].v != 1 || comp[2].h != 1 || comp[2].v != 1 || !((comp[0].h == 1 && comp[0].v == 1) || (comp[0].h == 2 && comp[0].v == 1) || (comp[0].h == 2 && comp[0].v == 2)))
+            fail("only 4:4:4, 4:2:2 (2x1) and 4:2:0 (2x2) chroma subsampling are supported");
+    }
+    const uint32_t mcux = (w + 8 * hmax - 1) / (8 * hmax), mcuy = (h + 8 * vmax - 1) / (8 * vmax);
+    for (auto &c : comp) { c.bw = (int) mcux * c.h * 8; c.bh = (int) mcuy * c.v * 8; c.plane.assign((size_t) c.bw * c.bh, 0); c.dc_pred = 0; }
+    JpegBits br; br.p = &file[pos]; br.end = file.data() + file.size();
+    int coef[64], until_restart = restart;
+    for (uint32_t my = 0; my < mcuy; ++my) for (uint32_t mx = 0; mx < mcux; ++mx) {
+        if (restart && until_restart == 0) {   // RSTn: byte-align, skip the marker, reset the predictors
+            br.reset();
+            while (br.p + 1 < br.end && !(br.p[0] == 0xff && br.p[1] >= 0xd0 && br.p[1] <= 0xd7)) ++br.p;
+            if (br.p + 1 >= br.end) fail("missing restart marker");
+            br.p += 2; for (auto &c : comp) c.dc_pred = 0; until_restart = restart;
+        }
+        for (auto &c : comp) for (int by = 0; by < c.v; ++by) for (int bx = 0; bx < c.h; ++bx) {
+            memset(coef, 0, sizeof coef);
+            const int t = br.decode(dc[c.td]);
+            if (t > 11) fail("corrupt DC coefficient");
+            c.dc_pred = (int) ((unsigned) c.dc_pred + (unsigned) jpeg_extend(br.get(t), t));   // wraps instead of overflowing on a damaged stream
+            coef[0] = (int) ((unsigned) c.dc_pred * (unsigned) qt[c.tq][0]);
+            for (int k = 1; k < 64;) {
+                const int rs = br.decode(ac[c.ta]), r = rs >> 4, s2 = rs & 15;
+                if (s2 == 0) { if (r == 15) { k += 16; continue; } break; }
+                k += r; if (k > 63) fail("corrupt AC coefficients");
+                coef[kZigzag[k]] = jpeg_extend(br.get(s2), s2) * qt[c.tq][kZigzag[k]]; ++k;
+            }
+            jpeg_idct(coef, &c.plane[(size_t) ((my * c.v + by) * 8) * c.bw + (size_t) (mx * c.h + bx) * 8], c.bw);
+        }
+        if (restart) --until_restart;
+    }
+    width = w; height = h; channels = colour ? 3 : 1;
+    pixels.resize((size_t) w * h * channels);
+    if (!colour) { for (uint32_t y = 0; y < h; ++y) memcpy(&pixels[(size_t) y * w], &comp[0].plane[(size_t) y * comp[0].bw], w); return; }
+    // chroma to full resolution (jdsample.c); cw / chh = the downsampled dimensions libjpeg works on (ceil(w * h_i / hmax), likewise the height)
+    std::vector<uint8_t> up[2];
+    for (int ci = 1; ci <= 2; ++ci) {
+        const JpegComponent &c = comp[ci]; std::vector<uint8_t> &o = up[ci - 1];
+        const int cw = (int) ((w + hmax - 1) / hmax), chh = (int) ((h + vmax - 1) / vmax);
+        o.assign((size_t) w * h, 0);
+        auto row = [&](int y) { y = y < 0 ? 0 : y >= chh ? chh - 1 : y; return &c.plane[(size_t) y * c.bw]; };
+        if (hmax == 1 && vmax == 1) { for (uint32_t y = 0; y < h; ++y) memcpy(&o[(size_t) y * w], row((int) y), w); continue; }
+        std::vector<uint8_t> line((size_t) cw * 2 + 2);
+        for (uint32_t y = 0; y < h; ++y) {
+            if (cw <= 2) {              // jinit_upsampler: the fancy (triangle) filters need more than two columns, else h2v1_upsample / h2v2_upsample replicate
+                const uint8_t *in = row((int) y / vmax);
+                for (int x = 0; x < cw; ++x) line[2 * x] = line[2 * x + 1] = in[x];
+            } else if (vmax == 1) {     // h2v1_fancy_upsample
+                const uint8_t *in = row((int) y);
+                if (cw == 1) { line[0] = line[1] = in[0]; }
+                else {
+                    line[0] = in[0]; line[1] = (uint8_t) ((in[0] * 3 + in[1] + 2) >> 2);
+                    for (int x = 1; x < cw - 1; ++x) { const int v = in[x] * 3; line[2 * x] = (uint8_t) ((v + in[x - 1] + 1) >> 2); line[2 * x + 1] = (uint8_t) ((v + in[x + 1] + 2) >> 2); }
+                    line[2 * cw - 2] = (uint8_t) ((in[cw - 1] * 3 + in[cw - 2] + 1) >> 2); line[2 * cw - 1] = in[cw - 1];
+                }
+            } else {                    // h2v2_fancy_upsample: the nearer neighbour row is the one above for even output rows, below for odd ones
+                const int cy = (int) y / 2; const uint8_t *in0 = row(cy), *in1 = row((y & 1) ? cy + 1 : cy - 1);
+                if (cw == 1) { const int s = in0[0] * 3 + in1[0]; line[0] = (uint8_t) ((s * 4 + 8) >> 4); line[1] = (uint8_t) ((s * 4 + 7) >> 4); }
+                else {
+                    int thiss = in0[0] * 3 + in1[0], nexts = in0[1] * 3 + in1[1], lasts;
+                    line[0] = (uint8_t) ((thiss * 4 + 8) >> 4); line[1] = (uint8_t) ((thiss * 3 + nexts + 7) >> 4);
+                    lasts = thiss; thiss = nexts;
+                    for (int x = 1; x < cw - 1; ++x) {
+                        nexts = in0[x + 1] * 3 + in1[x + 1];
+                        line[2 * x] = (uint8_t) ((thiss * 3 + lasts + 8) >> 4); line[2 * x + 1] = (uint8_t) ((thiss * 3 + nexts + 7) >> 4);
+                        lasts = thiss; thiss = nexts;
+                    }
+                    line[2 * cw - 2] = (uint8_t) ((thiss * 3 + lasts + 8) >> 4); line[2 * cw - 1] = (uint8_t) ((thiss * 4 + 7) >> 4);
+                }
+            }
+            memcpy(&o[(size_t) y * w], line.data(), w);
+        }
+    }
+    // ycc_rgb_convert (jdcolor.c): 16-bit fixed point, ONE_HALF folded into the Cb-to-G table
+    for (uint32_t y = 0; y < h; ++y) for (uint32_t x = 0; x < w; ++x) {
+        const int Y = comp[0].plane[(size_t) y * comp[0].bw + x], cb = up[0][(size_t) y * w + x] - 128, cr = up[1][(size_t) y * w + x] - 128;
+        uint8_t *o = &pixels[((size_t) y * w + x) * 3];
+        o[0] = jpeg_clamp(Y + (int) ((91881L * cr + 32768) >> 16));
+        o[1] = jpeg_clamp(Y + (int) ((-22554L * cb + 32768 - 46802L * cr) >> 16));
+        o[2] = jpeg_clamp(Y + (int) ((116130L * cb + 32768) >> 16));
+    }
+}
 
 // ---------------------------------------------------------------------------- radiance maps (envmap)
 // PFM (src/core/bitmap.cpp:2164-2217): "PF" | "Pf", width, height, scale-and-byte-order, then float rows BOTTOM row first.
@@ -182,15 +419,16 @@ void read_radiance_image(const std::string &path, std::vector<float> &rgb, uint3
     std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     if (file.size() >= 8 && file[0] == 'P' && (file[1] == 'F' || file[1] == 'f')) return read_pfm(file, path, rgb, width, height);
     if (file.size() >= 8 && file[0] == '#' && file[1] == '?') return read_rgbe(file, path, rgb, width, height);
-    if (file.size() >= 8 && file[0] == 0x89 && file[1] == 'P') {   // 8-bit PNG: sRGB -> linear (Bitmap::convert to Float32 with srgb_gamma = false)
+    const bool jpeg = file.size() >= 8 && file[0] == 0xff && file[1] == 0xd8;
+    if (jpeg || (file.size() >= 8 && file[0] == 0x89 && file[1] == 'P')) {   // 8-bit PNG / JPEG: sRGB -> linear (Bitmap::convert to Float32 with srgb_gamma = false)
         std::vector<uint8_t> px; uint32_t ch;
-        read_png(path, px, width, height, ch);
+        if (jpeg) read_jpeg(path, px, width, height, ch); else read_png(path, px, width, height, ch);
         float lut[256]; for (uint32_t i = 0; i < 256; ++i) lut[i] = srgb_to_linear_u8(i);
         rgb.resize((size_t) width * height * 3);
         for (size_t i = 0; i < (size_t) width * height; ++i) for (uint32_t c = 0; c < 3; ++c) rgb[i * 3 + c] = lut[px[i * ch + (ch == 3 ? c : 0)]];
         return;
     }
-    throw std::runtime_error("envmap: \"" + path + "\": unsupported image format (this build reads RGBE .hdr, PFM and 8-bit PNG radiance maps)");
+    throw std::runtime_error("envmap: \"" + path + "\": unsupported image format (this build reads RGBE .hdr, PFM, 8-bit PNG and baseline JPEG radiance maps)");
 }
 
 }  // namespace dtof

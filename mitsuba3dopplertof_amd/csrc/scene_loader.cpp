@@ -570,7 +570,11 @@ static HostTexture texture_of(const Obj &t) {
         const bool raw = t.props.get_bool("raw", false);
         (void) t.props.get_bool("accel", true);
         std::vector<uint8_t> px; uint32_t w, h, ch;
-        read_png(path, px, w, h, ch);
+        {   // by signature, as Bitmap::detect_file_format does (bitmap.cpp:700-734): JPEG (FF D8) or PNG
+            FILE *probe = fopen(path.c_str(), "rb"); unsigned char sig[2] = { 0, 0 };
+            if (probe) { if (fread(sig, 1, 2, probe) != 2) sig[0] = 0; fclose(probe); }
+            if (sig[0] == 0xff && sig[1] == 0xd8) read_jpeg(path, px, w, h, ch); else read_png(path, px, w, h, ch);
+        }
         if (w < 2 || h < 2) fail("bitmap: the image must be at least 2x2 pixels in size");
         tex.kind = TEX_BITMAP; tex.filter = ft == "bilinear"; memset(tex.color0, 0, 12); memset(tex.color1, 0, 12); tex.wrap = wm == "repeat" ? 0 : wm == "mirror" ? 1 : 2;
         tex.width = w; tex.height = h; tex.channels = ch;

@@ -32,6 +32,7 @@ HEADER = """<scene version="3.0.0">
 	<default name="time_correlate_number" value="2" />
 	<default name="distribution" value="ggx" />
 	<default name="sample_visible" value="true" />
+	<default name="texfile" value="tex_rgb.png" />
 	<integrator type="dopplertofpath">
 		<integer name="max_depth" value="$max_depth" />
 		<float name="w_g" value="30" />
@@ -185,6 +186,12 @@ def texture_files():
     gray = [[(x * x * 3 + y * 29 + 10) % 256 for x in range(8)] for y in range(8)]
     write_png(os.path.join(HERE, "tex_rgb.png"), rgb)
     write_png(os.path.join(HERE, "tex_gray.png"), gray)
+    try:   # the same pattern, enlarged and JPEG-coded (4:2:0), for the baseline JPEG reader; PIL is test infrastructure
+        from PIL import Image
+        big = [[rgb[y // 4][x // 4] for x in range(64)] for y in range(48)]
+        Image.frombytes("RGB", (64, 48), bytes(c for row in big for px in row for c in px)).save(os.path.join(HERE, "tex_rgb.jpg"), "JPEG", quality=85, subsampling=2)
+    except ImportError:
+        pass
     sky = env_pixels()
     write_rgbe(os.path.join(HERE, "env_sky.hdr"), sky)
     write_pfm(os.path.join(HERE, "env_sky.pfm"), sky)
@@ -284,11 +291,11 @@ def cornell_textured(res=128, spp=16):
             s += bsdf(*b)
     s += tex_bsdf("FloorBSDF", "checkerboard", '\t\t\t\t<rgb name="color0" value="0.7, 0.68, 0.6" />\n\t\t\t\t<rgb name="color1" value="0.12, 0.1, 0.2" />\n'
                   '\t\t\t\t<transform name="to_uv">\n\t\t\t\t\t<scale x="4" y="6" />\n\t\t\t\t\t<translate x="0.25" y="0" />\n\t\t\t\t</transform>\n')
-    s += tex_bsdf("BackWallBSDF", "bitmap", '\t\t\t\t<string name="filename" value="tex_rgb.png" />\n'
+    s += tex_bsdf("BackWallBSDF", "bitmap", '\t\t\t\t<string name="filename" value="$texfile" />\n'
                   '\t\t\t\t<transform name="to_uv">\n\t\t\t\t\t<scale x="2.5" y="1.5" />\n\t\t\t\t\t<rotate z="1" angle="20" />\n\t\t\t\t</transform>\n')
     s += tex_bsdf("LeftWallBSDF", "bitmap", '\t\t\t\t<string name="filename" value="tex_gray.png" />\n\t\t\t\t<string name="filter_type" value="nearest" />\n'
                   '\t\t\t\t<string name="wrap_mode" value="mirror" />\n\t\t\t\t<transform name="to_uv">\n\t\t\t\t\t<scale x="1.7" y="2.3" />\n\t\t\t\t</transform>\n')
-    s += tex_bsdf("ShortBoxBSDF", "bitmap", '\t\t\t\t<string name="filename" value="tex_rgb.png" />\n\t\t\t\t<string name="wrap_mode" value="clamp" />\n'
+    s += tex_bsdf("ShortBoxBSDF", "bitmap", '\t\t\t\t<string name="filename" value="$texfile" />\n\t\t\t\t<string name="wrap_mode" value="clamp" />\n'
                   '\t\t\t\t<boolean name="raw" value="true" />\n\t\t\t\t<transform name="to_uv">\n\t\t\t\t\t<scale x="1.5" y="1.5" />\n\t\t\t\t</transform>\n')
     s += tex_bsdf("TallBoxBSDF", "checkerboard", '\t\t\t\t<rgb name="color0" value="0.1, 0.27, 0.36" />\n\t\t\t\t<rgb name="color1" value="0.6, 0.5, 0.1" />\n'
                   '\t\t\t\t<transform name="to_uv">\n\t\t\t\t\t<scale x="3" y="3" />\n\t\t\t\t</transform>\n',

@@ -91,6 +91,8 @@ CONFIGS = [
     ("rough_conductor_all_normals", "cornell_rough.xml", dict(resx=32, resy=32, sample_visible="false", max_depth=5), 8),
     ("rough_plastic_all_normals", "cornell_roughplastic.xml", dict(resx=32, resy=32, sample_visible="false", distribution="beckmann"), 8),
     ("frosted_glass_all_normals", "cornell_frosted.xml", dict(resx=32, resy=32, sample_visible="false", max_depth=6), 8),
+    # the bitmap texture from a baseline JPEG file (4:2:0): the product's own decoder against PIL's in the oracle loader
+    ("textured_jpeg", "cornell_textured.xml", dict(resx=32, resy=32, texfile="tex_rgb.jpg"), 8),
     ("environment", "cornell_env.xml", dict(resx=32, resy=32, max_depth=4), 8),
     # `envmap` emitter (RGBE file, rotated): latitude-longitude lookup on a miss, hierarchical importance sampling with MIS
     ("envmap", "cornell_envmap.xml", dict(resx=32, resy=32, max_depth=4), 8),

@@ -25,7 +25,17 @@ xml0 = make_mesh.cornell_mesh_xml(moving_file="MOVING", res=16, spp=4)
 sky = make_scenes.env_pixels(16, 8)
 make_scenes.write_rgbe(os.path.join(out, "h.hdr"), sky); make_scenes.write_rgbe(os.path.join(out, "i.hdr"), sky, rle=False); make_scenes.write_pfm(os.path.join(out, "j.pfm"), sky)
 make_scenes.write_png(os.path.join(out, "k.png"), [[tuple(min(255, int(40 * c)) for c in px) for px in row] for row in sky])
-images = {n: open(os.path.join(out, n), "rb").read() for n in ("h.hdr", "i.hdr", "j.pfm", "k.png")}
+try:   # baseline JPEG fixtures (4:2:0 with restart markers, 4:4:4, grayscale) for the decoder of image_io.cpp
+    from PIL import Image
+    import numpy as np
+    arr = (np.random.default_rng(3).random((24, 40, 3)) * 255).astype("uint8")
+    Image.fromarray(arr).save(os.path.join(out, "l.jpg"), quality=70, subsampling=2, restart_marker_blocks=2)
+    Image.fromarray(arr).save(os.path.join(out, "m.jpg"), quality=90, subsampling=0)
+    Image.fromarray(arr[..., 0]).save(os.path.join(out, "n.jpg"), quality=50)
+    jpegs = ("l.jpg", "m.jpg", "n.jpg")
+except Exception:
+    jpegs = ()
+images = {n: open(os.path.join(out, n), "rb").read() for n in ("h.hdr", "i.hdr", "j.pfm", "k.png") + jpegs}
 env0 = make_scenes.cornell_envmap(16, 4, filename="IMAGE")
 for it in range(N):
     r = random.random()

@@ -106,7 +106,7 @@ def test_texture_error_behaviour(mi, tmp_path):
     with pytest.raises(mi.DtofError, match="unsupported texture plugin"):
         mi.load_string(text.replace('<texture type="checkerboard" name="reflectance">', '<texture type="mesh_attribute" name="reflectance">'))
     bad = tmp_path / "not.png"
-    bad.write_bytes(b"JFIF not a png")
+    bad.write_bytes(b"neither a png nor a jpeg")
     with pytest.raises(mi.DtofError, match="is not a PNG file"):
         mi.load_string(text.replace(SCENES + "/tex_gray.png", str(bad)))
     with pytest.raises(mi.DtofError, match="unreferenced property"):
@@ -135,3 +135,65 @@ def test_png_reader_handles_filters_palettes_and_alpha(mi, tmp_path):
         assert (int(rec[3]), int(rec[4]), int(rec[5])) == (1 if name in ("gray", "la") else 3, 13, 9)
         got = np.rint(sc.export(14) * 255).astype(np.uint8).reshape(ref.shape)
         assert np.array_equal(got, ref), name
+
+
+def test_jpeg_reader_matches_libjpeg_byte_for_byte(mi, tmp_path):
+    """the product's baseline JPEG decoder (image_io.cpp: Huffman decoding, IJG's slow-but-accurate integer IDCT, fancy chroma upsampling,
+    fixed-point YCbCr -> RGB) against PIL / libjpeg-turbo with its default settings -- what the reference's Bitmap reads through libjpeg:
+    4:4:4, 4:2:2, 4:2:0 and grayscale files, several qualities, sizes that are no multiple of the MCU (down to the widths at which libjpeg stops filtering the chroma), restart intervals, optimised tables;
+    progressive files are refused."""
+    from PIL import Image
+    rng = np.random.default_rng(9)
+    def picture(w, h):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([127 + 120 * np.sin(x / 5.0 + y / 9.0), 127 + 120 * np.cos(x / 3.0) * np.sin(y / 4.0), (x * 7 + y * 13) % 256], -1)
+        img += rng.normal(0, 12, img.shape)          # texture: exercises long runs of AC coefficients
+        img[h // 3: h // 2, w // 4: w // 2] = (250, 10, 30)   # saturated patch: range limiting and chroma edges
+        return np.clip(img, 0, 255).astype(np.uint8)
+    cases = []
+    for (w, h) in ((16, 16), (37, 29), (8, 5), (64, 48), (3, 2), (17, 1 + 16)):
+        for sub, quality in ((0, 92), (1, 75), (2, 60), (2, 98), (0, 30)):
+            cases.append((w, h, "RGB", dict(quality=quality, subsampling=sub)))
+        cases.append((w, h, "L", dict(quality=85)))
+    cases.append((40, 33, "RGB", dict(quality=80, subsampling=2, optimize=True)))
+    cases.append((45, 70, "RGB", dict(quality=70, subsampling=1, optimize=True)))
+    cases.append((56, 40, "RGB", dict(quality=80, subsampling=2, restart_marker_blocks=2)))      # DRI + RSTn markers: predictors reset, bytes realigned
+    cases.append((56, 40, "RGB", dict(quality=80, subsampling=0, restart_marker_rows=1)))
+    cases.append((23, 31, "L", dict(quality=60, restart_marker_blocks=1)))
+    xml = ('<scene version="3.0.0"><integrator type="path"/><sensor type="perspective"><float name="fov" value="40"/>'
+           '<film type="hdrfilm"><integer name="width" value="4"/><integer name="height" value="4"/></film></sensor>'
+           '<shape type="rectangle"><bsdf type="diffuse"><texture type="bitmap" name="reflectance"><string name="filename" value="%s"/>'
+           '<boolean name="raw" value="true"/></texture></bsdf></shape></scene>')
+    for k, (w, h, mode, opts) in enumerate(cases):
+        if w < 2 or h < 2:
+            continue
+        src = picture(w, h)
+        im = Image.fromarray(src if mode == "RGB" else src[..., 0], mode)
+        path = str(tmp_path / ("j%d.jpg" % k))
+        im.save(path, "JPEG", **opts)
+        ref = np.asarray(Image.open(path).convert(mode), np.uint8)
+        sc = mi.load_string(xml % path)
+        got = np.rint(sc.export(14) * 255).astype(np.uint8).reshape(ref.shape)
+        assert np.array_equal(got, ref), (k, w, h, mode, opts, int(np.abs(got.astype(int) - ref.astype(int)).max()), int((got != ref).sum()))
+    prog = str(tmp_path / "prog.jpg")
+    Image.fromarray(picture(24, 24), "RGB").save(prog, "JPEG", progressive=True)
+    with pytest.raises(mi.DtofError, match="progressive"):
+        mi.load_string(xml % prog)
+    trunc = str(tmp_path / "trunc.jpg")
+    data = open(str(tmp_path / "j0.jpg"), "rb").read()
+    open(trunc, "wb").write(data[:len(data) // 2])
+    try:
+        mi.load_string(xml % trunc)      # a truncated scan decodes as far as it goes (zeros beyond), like libjpeg does, or is refused -- it must not crash
+    except mi.DtofError:
+        pass
+
+
+def test_jpeg_texture_texels_match_the_oracle_loader(mi, orc):
+    """cornell_textured.xml with its bitmap from a 4:2:0 JPEG file: the linear texels the product decodes (own decoder + sRGB LUT) equal the
+    oracle loader's (PIL + the same LUT) bit for bit"""
+    path = os.path.join(SCENES, "cornell_textured.xml")
+    sc, osc = mi.load_file(path, texfile="tex_rgb.jpg"), orc.Scene(path, dict(texfile="tex_rgb.jpg"))
+    theirs = np.concatenate([np.asarray(s["tex_refl"]["data"], np.float32).ravel() for s in osc.flat.shapes
+                             if s.get("tex_refl") is not None and s["tex_refl"].get("data") is not None])
+    ours = sc.export(14)
+    assert ours.size == theirs.size == 2 * 64 * 48 * 3 + (ours.size - 2 * 64 * 48 * 3) and np.array_equal(bits(ours), bits(theirs))
