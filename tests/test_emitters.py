@@ -226,6 +226,12 @@ def test_envmap_scene(mi, orc, tmp_path):
     def load(name, xml):
         (tmp_path / name).write_text(xml)
         return mi.load_file(str(tmp_path / name))
+    # a JPEG radiance map (4:2:0): product decoder vs PIL, then the same tables bit for bit
+    from PIL import Image
+    Image.open(os.path.join(SCENES, "env_sky.png")).convert("RGB").resize((40, 22)).save(str(tmp_path / "sky.jpg"), "JPEG", quality=88, subsampling=2)
+    (tmp_path / "jpg.xml").write_text(text.replace("env_sky.hdr", str(tmp_path / "sky.jpg")))
+    scj, oscj = mi.load_file(str(tmp_path / "jpg.xml")), orc.Scene(str(tmp_path / "jpg.xml"), {})
+    assert np.array_equal(scj.export(16).view(np.uint32), envmap_export(oscj.c.emitters[[e["kind"] for e in oscj.flat.emitters].index(4)]).view(np.uint32))
     with pytest.raises(mi.DtofError, match="Only one environment emitter"):
         load("two.xml", absolute.replace("</scene>", '<emitter type="constant"/></scene>'))
     with pytest.raises(mi.DtofError, match="mis_compensation"):
