@@ -413,12 +413,110 @@ static void read_rgbe(const std::vector<uint8_t> &file, const std::string &path,
         for (int c = 0; c < 3; ++c) rgb[i * 3 + c] = q[3] ? (float) q[c] * f : 0.f;
     }
 }
+// OpenEXR (Bitmap::read_exr, src/core/bitmap.cpp, through the OpenEXR library): single-part scan-line files, compression NONE, ZIPS (one
+// line per chunk) or ZIP (16 lines), channels R, G, B (or Y) as HALF, FLOAT or UINT; other channels (A, ...) are skipped.  ZIP chunks are zlib
+// streams of the byte-reordered (even bytes, then odd bytes), delta-coded scan lines (ImfZipCompressor).  PIZ / PXR24 / B44 / DWA files, tiles
+// and deep data are refused by name.
+static float half_to_float(uint16_t hbits) {
+    const uint32_t sign = (uint32_t) (hbits & 0x8000u) << 16, e = (hbits >> 10) & 31u, m = hbits & 1023u;
+    uint32_t bits;
+    if (e == 0) {
+        if (m == 0) bits = sign;
+        else { int sh = 0; uint32_t mm = m; while (!(mm & 1024u)) { mm <<= 1; ++sh; } bits = sign | ((uint32_t) (113 - sh) << 23) | ((mm & 1023u) << 13); }
+    } else if (e == 31) bits = sign | 0x7f800000u | (m << 13);
+    else bits = sign | ((e + 112u) << 23) | (m << 13);
+    float f; memcpy(&f, &bits, 4); return f;
+}
+static void read_exr(const std::vector<uint8_t> &file, const std::string &path, std::vector<float> &rgb, uint32_t &w, uint32_t &h) {
+    auto fail = [&](const std::string &m) { throw std::runtime_error("read_exr(): \"" + path + "\": " + m); };
+    auto need = [&](size_t at, size_t n) { if (at > file.size() || file.size() - at < n) fail("truncated file"); };
+    auto rd32 = [&](size_t at) { need(at, 4); uint32_t v; memcpy(&v, &file[at], 4); return v; };
+    need(0, 8);
+    const uint32_t version = rd32(4);
+    if ((version & 0xff) != 2 || (version & 0x1a00)) fail("only single-part scan-line OpenEXR 2 files are supported (no tiles, deep data or multi-part files)");
+    size_t pos = 8;
+    struct Chan { std::string name; int type; }; std::vector<Chan> chans;
+    int comp = -1, x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+    for (;;) {
+        need(pos, 1);
+        if (file[pos] == 0) { ++pos; break; }
+        std::string name, type;
+        while (pos < file.size() && file[pos]) name += (char) file[pos++];
+        ++pos;
+        while (pos < file.size() && file[pos]) type += (char) file[pos++];
+        ++pos;
+        const uint32_t size = rd32(pos); pos += 4; need(pos, size);
+        if (name == "compression" && size >= 1) comp = file[pos];
+        else if (name == "dataWindow" && size >= 16) { x0 = (int) rd32(pos); y0 = (int) rd32(pos + 4); x1 = (int) rd32(pos + 8); y1 = (int) rd32(pos + 12); }
+        else if (name == "channels") {
+            size_t p = pos; const size_t end = pos + size;
+            while (p < end && file[p]) {
+                Chan c; while (p < end && file[p]) c.name += (char) file[p++];
+                if (p + 17 > end) fail("bad channel list");
+                c.type = (int) rd32(p + 1); p += 17;
+                if (c.type < 0 || c.type > 2) fail("bad channel type");
+                if (rd32(p - 8) != 1 || rd32(p - 4) != 1) fail("subsampled channels are not supported");
+                chans.push_back(c);
+            }
+        }
+        pos += size;
+    }
+    if (comp != 0 && comp != 2 && comp != 3) fail(comp == 4 ? "PIZ-compressed files are not supported (uncompressed and ZIP only)" : "only uncompressed and ZIP-compressed files are supported");
+    if (x1 < x0 || y1 < y0 || chans.empty()) fail("bad header");
+    const uint64_t W = (uint64_t) ((int64_t) x1 - x0 + 1), H = (uint64_t) ((int64_t) y1 - y0 + 1);
+    if (W > 65536 || H > 65536 || W * H > (1ull << 26)) fail("implausible size");
+    int ir = -1, ig = -1, ib = -1, iy = -1;
+    for (size_t c = 0; c < chans.size(); ++c) { if (chans[c].name == "R") ir = (int) c; if (chans[c].name == "G") ig = (int) c; if (chans[c].name == "B") ib = (int) c; if (chans[c].name == "Y") iy = (int) c; }
+    const bool colour = ir >= 0 && ig >= 0 && ib >= 0;
+    if (!colour && iy < 0) fail("no R, G, B or Y channels");
+    size_t line_bytes = 0; for (auto &c : chans) line_bytes += (c.type == 1 ? 2 : 4) * (size_t) W;
+    const uint32_t lines = comp == 3 ? 16 : 1; const size_t n_chunks = (size_t) ((H + lines - 1) / lines);
+    need(pos, n_chunks * 8);
+    if (line_bytes * H / 1024 > file.size() && comp == 0) fail("truncated file");     // a damaged size must not be allocated before the first read fails
+    w = (uint32_t) W; h = (uint32_t) H; rgb.assign((size_t) W * H * 3, 0.f);
+    std::vector<uint8_t> raw, tmp;
+    for (size_t k = 0; k < n_chunks; ++k) {
+        uint64_t off; memcpy(&off, &file[pos + 8 * k], 8);
+        if (off > file.size()) fail("bad chunk offset");
+        need((size_t) off, 8);
+        const int y = (int) rd32((size_t) off); const uint32_t size = rd32((size_t) off + 4);
+        need((size_t) off + 8, size);
+        if (y < y0 || y > y1) fail("bad chunk");
+        const uint32_t ny = (uint32_t) std::min<int64_t>(lines, (int64_t) y1 - y + 1);
+        const size_t raw_len = line_bytes * ny;
+        const uint8_t *src = &file[(size_t) off + 8];
+        if (comp != 0 && size < raw_len) {
+            tmp.resize(raw_len); uLongf got = (uLongf) raw_len;
+            if (uncompress(tmp.data(), &got, src, size) != Z_OK || got != raw_len) fail("corrupt ZIP chunk");
+            for (size_t i = 1; i < raw_len; ++i) tmp[i] = (uint8_t) (tmp[i - 1] + tmp[i] - 128);      // undo the predictor
+            raw.resize(raw_len);
+            const size_t half = (raw_len + 1) / 2;
+            for (size_t i = 0; i < raw_len; ++i) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];    // re-interleave
+            src = raw.data();
+        } else if (size != raw_len) fail("bad chunk size");
+        size_t q = 0;
+        for (uint32_t r = 0; r < ny; ++r) for (size_t c = 0; c < chans.size(); ++c) {
+            const int t = chans[c].type; const size_t bpp = t == 1 ? 2 : 4;
+            int dst = -1; if (colour) dst = (int) c == ir ? 0 : (int) c == ig ? 1 : (int) c == ib ? 2 : -1; else if ((int) c == iy) dst = 3;
+            if (dst >= 0) for (uint64_t x = 0; x < W; ++x) {
+                float v;
+                if (t == 1) { uint16_t hb; memcpy(&hb, src + q + 2 * x, 2); v = half_to_float(hb); }
+                else if (t == 2) memcpy(&v, src + q + 4 * x, 4);
+                else { uint32_t u; memcpy(&u, src + q + 4 * x, 4); v = (float) u; }
+                float *px = &rgb[((size_t) (y - y0 + (int) r) * W + x) * 3];
+                if (dst == 3) px[0] = px[1] = px[2] = v; else px[dst] = v;
+            }
+            q += bpp * (size_t) W;
+        }
+    }
+}
 void read_radiance_image(const std::string &path, std::vector<float> &rgb, uint32_t &width, uint32_t &height, float (*srgb_to_linear_u8)(uint32_t)) {
     std::ifstream f(path, std::ios::binary);
     if (!f) throw std::runtime_error("could not open \"" + path + "\"");
     std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     if (file.size() >= 8 && file[0] == 'P' && (file[1] == 'F' || file[1] == 'f')) return read_pfm(file, path, rgb, width, height);
     if (file.size() >= 8 && file[0] == '#' && file[1] == '?') return read_rgbe(file, path, rgb, width, height);
+    if (file.size() >= 8 && file[0] == 0x76 && file[1] == 0x2f && file[2] == 0x31 && file[3] == 0x01) return read_exr(file, path, rgb, width, height);
     const bool jpeg = file.size() >= 8 && file[0] == 0xff && file[1] == 0xd8;
     if (jpeg || (file.size() >= 8 && file[0] == 0x89 && file[1] == 'P')) {   // 8-bit PNG / JPEG: sRGB -> linear (Bitmap::convert to Float32 with srgb_gamma = false)
         std::vector<uint8_t> px; uint32_t ch;
@@ -428,7 +526,7 @@ void read_radiance_image(const std::string &path, std::vector<float> &rgb, uint3
         for (size_t i = 0; i < (size_t) width * height; ++i) for (uint32_t c = 0; c < 3; ++c) rgb[i * 3 + c] = lut[px[i * ch + (ch == 3 ? c : 0)]];
         return;
     }
-    throw std::runtime_error("envmap: \"" + path + "\": unsupported image format (this build reads RGBE .hdr, PFM, 8-bit PNG and baseline JPEG radiance maps)");
+    throw std::runtime_error("envmap: \"" + path + "\": unsupported image format (this build reads RGBE .hdr, PFM, OpenEXR without or with ZIP compression, 8-bit PNG and baseline JPEG radiance maps)");
 }
 
 }  // namespace dtof

@@ -413,6 +413,48 @@ def read_radiance_image(path):
         out = px[:, :3].astype(F32) * f[:, None]
         out[px[:, 3] == 0] = 0
         return out.reshape(h, w, 3)
+    if data[:4] == b"\x76\x2f\x31\x01":      # OpenEXR, scan lines, compression NONE / ZIPS / ZIP, channels R G B (or Y), HALF or FLOAT
+        import zlib
+        pos, attrs = 8, {}
+        while data[pos] != 0:
+            e = data.index(b"\0", pos); name = data[pos:e].decode(); pos = e + 1
+            e = data.index(b"\0", pos); pos = e + 1
+            size = _st.unpack_from("<i", data, pos)[0]; pos += 4
+            attrs[name] = data[pos:pos + size]; pos += size
+        pos += 1
+        comp = attrs["compression"][0]
+        if comp not in (0, 2, 3):
+            raise ValueError("read_exr(): only uncompressed and ZIP-compressed scan-line files are supported")
+        x0, y0, x1, y1 = _st.unpack("<4i", attrs["dataWindow"])
+        w, h = x1 - x0 + 1, y1 - y0 + 1
+        chans, cd, p = [], attrs["channels"], 0
+        while cd[p] != 0:
+            e = cd.index(b"\0", p); chans.append((cd[p:e].decode(), _st.unpack_from("<i", cd, e + 1)[0])); p = e + 17
+        lines = 16 if comp == 3 else 1
+        planes = {n: np.zeros((h, w), F32) for n, _ in chans}
+        for off in _st.unpack_from("<%dQ" % ((h + lines - 1) // lines), data, pos):
+            y, size = _st.unpack_from("<2i", data, off)
+            ny = min(lines, y1 - y + 1)
+            raw_len = sum(2 if t == 1 else 4 for _, t in chans) * w * ny
+            buf = data[off + 8:off + 8 + size]
+            if comp and size < raw_len:
+                d = np.frombuffer(zlib.decompress(buf), np.uint8).astype(np.int64)
+                t = ((np.cumsum(d) - 128 * np.arange(len(d))) & 255).astype(np.uint8)     # undo the predictor: t[i] = t[i-1] + d[i] - 128
+                half = (len(t) + 1) // 2
+                b = np.empty(len(t), np.uint8); b[0::2] = t[:half]; b[1::2] = t[half:]
+                buf = b.tobytes()
+            q = 0
+            for r in range(ny):
+                for n, t in chans:
+                    if t == 1:
+                        planes[n][y - y0 + r] = np.frombuffer(buf, "<f2", w, q).astype(F32); q += 2 * w
+                    else:
+                        planes[n][y - y0 + r] = np.frombuffer(buf, "<f4" if t == 2 else "<u4", w, q).astype(F32); q += 4 * w
+        if all(c in planes for c in "RGB"):
+            return np.ascontiguousarray(np.stack([planes["R"], planes["G"], planes["B"]], -1))
+        if "Y" in planes:
+            return np.ascontiguousarray(np.repeat(planes["Y"][..., None], 3, axis=2))
+        raise ValueError("read_exr(): no R, G, B or Y channels")
     from PIL import Image
     im = Image.open(path)
     im = im.convert("RGB")

@@ -195,6 +195,7 @@ def texture_files():
     sky = env_pixels()
     write_rgbe(os.path.join(HERE, "env_sky.hdr"), sky)
     write_pfm(os.path.join(HERE, "env_sky.pfm"), sky)
+    write_exr(os.path.join(HERE, "env_sky.exr"), sky, compression=3, half=False)
     write_png(os.path.join(HERE, "env_sky.png"), [[tuple(min(255, int(255 * min(c, 1.0) ** 0.45)) for c in px) for px in row] for row in sky])
 
 
@@ -254,6 +255,51 @@ def write_rgbe(path, rows, rle=True):
                         while j < w and j - i < 128 and not (j + 2 < w and ch[j] == ch[j + 1] == ch[j + 2]):
                             j += 1
                         f.write(bytes([j - i]) + bytes(ch[i:j])); i = j
+
+
+def write_exr(path, rows, compression=3, half=True, decreasing_y=False, alpha=False):
+    """scan-line OpenEXR 2.0: channels (A,) B, G, R, HALF or FLOAT, compression 0 (none), 2 (ZIPS: one line per chunk) or 3 (ZIP: 16 lines)"""
+    import struct
+    import zlib
+    import numpy as np
+    a = np.asarray(rows, np.float32)
+    h, w, _ = a.shape
+    names = ([b"A"] if alpha else []) + [b"B", b"G", b"R"]
+    planes = ([np.ones((h, w), np.float32)] if alpha else []) + [a[..., 2], a[..., 1], a[..., 0]]
+    ptype, dt = (1, "<f2") if half else (2, "<f4")
+    def attr(name, typ, payload):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(payload)) + payload
+    chlist = b"".join(n + b"\0" + struct.pack("<iBBBBii", ptype, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    box = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    header = (attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([compression])) + attr("dataWindow", "box2i", box) +
+              attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", bytes([1 if decreasing_y else 0])) +
+              attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0.0, 0.0)) +
+              attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
+    lines = {0: 1, 2: 1, 3: 16}[compression]
+    chunks = []
+    for y0 in range(0, h, lines):
+        raw = b"".join(pl[y].astype(dt).tobytes() for y in range(y0, min(y0 + lines, h)) for pl in planes)
+        if compression:
+            b = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([b[0::2], b[1::2]]).astype(np.int32)          # reorder: even bytes, then odd bytes
+            d = t.copy(); d[1:] = (t[1:] - t[:-1] + 128 + 256) & 255           # predictor
+            z = zlib.compress(d.astype(np.uint8).tobytes(), 6)
+            payload = z if len(z) < len(raw) else raw
+        else:
+            payload = raw
+        chunks.append((y0, payload))
+    if decreasing_y:
+        chunks.reverse()
+    head = struct.pack("<II", 20000630, 2) + header
+    pos = len(head) + 8 * len(chunks)
+    table = {}
+    body = b""
+    for y0, payload in chunks:
+        table[y0] = pos + len(body)
+        body += struct.pack("<ii", y0, len(payload)) + payload
+    order = sorted(table)          # the offset table is always in increasing-y order
+    with open(path, "wb") as f:
+        f.write(head + struct.pack("<%dQ" % len(order), *[table[y] for y in order]) + body)
 
 
 def cornell_sun(res=128, spp=16):
@@ -533,7 +579,7 @@ def main():
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
     names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml",
-             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png"]
+             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
         return

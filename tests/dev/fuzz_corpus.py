@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes a corpus of damaged scene files for tools/sanitize_loader.sh:  python tests/dev/fuzz_corpus.py SEED COUNT OUTDIR
-35 % numeric attribute values replaced by extreme ones, 25 % character-level damage of the XML, 10 % damaged radiance maps (RGBE / PFM / PNG), 30 % damaged obj / ply / serialized mesh files."""
+35 % numeric attribute values replaced by extreme ones, 25 % character-level damage of the XML, 10 % damaged radiance maps (RGBE / PFM / PNG / JPEG / OpenEXR), 30 % damaged obj / ply / serialized mesh files."""
 import os, sys, random, re
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scenes"))
@@ -35,7 +35,9 @@ try:   # baseline JPEG fixtures (4:2:0 with restart markers, 4:4:4, grayscale) f
     jpegs = ("l.jpg", "m.jpg", "n.jpg")
 except Exception:
     jpegs = ()
-images = {n: open(os.path.join(out, n), "rb").read() for n in ("h.hdr", "i.hdr", "j.pfm", "k.png") + jpegs}
+make_scenes.write_exr(os.path.join(out, "o.exr"), sky, compression=3); make_scenes.write_exr(os.path.join(out, "p.exr"), sky, compression=0, half=False)
+make_scenes.write_exr(os.path.join(out, "q.exr"), sky, compression=2, alpha=True, decreasing_y=True)
+images = {n: open(os.path.join(out, n), "rb").read() for n in ("h.hdr", "i.hdr", "j.pfm", "k.png", "o.exr", "p.exr", "q.exr") + jpegs}
 env0 = make_scenes.cornell_envmap(16, 4, filename="IMAGE")
 for it in range(N):
     r = random.random()

@@ -192,6 +192,17 @@ def test_envmap_known_answers_of_the_reference(orc):
         assert np.abs(z).max() < 6 and abs(hist[~big].sum() - exp[~big].sum()) < 6 * np.sqrt(exp[~big].sum() + 1) + 0.01 * n, (np.abs(z).max(),)
 
 
+def _piz_stub(tmp_path):
+    """an EXR header that declares PIZ compression (the reader must refuse it by name before touching any chunk)"""
+    import make_scenes
+    q = str(tmp_path / "piz.exr")
+    make_scenes.write_exr(q, make_scenes.env_pixels(8, 4), compression=0)
+    d = open(q, "rb").read()
+    i = d.index(b"compression\0compression\0") + 24 + 4
+    open(q, "wb").write(d[:i] + b"\x04" + d[i + 1:])
+    return q
+
+
 def test_envmap_scene(mi, orc, tmp_path):
     """`envmap` emitter end to end on the CPU side: the three file formats decode to the same map (RGBE, PFM exactly; PNG through sRGB), loader
     parity with the product (blob tables = the oracle's tables), radiance lookup of sky pixels, hide_emitters, error messages."""
@@ -226,6 +237,26 @@ def test_envmap_scene(mi, orc, tmp_path):
     def load(name, xml):
         (tmp_path / name).write_text(xml)
         return mi.load_file(str(tmp_path / name))
+    # OpenEXR radiance maps: uncompressed, ZIPS and ZIP chunks, HALF and FLOAT, decreasing line order, an extra alpha channel -- the same tables again;
+    # the uncompressed container also decodes with the independent reader of tools/exr_piz.py (the one that decoded the authors' scene.exr)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import exr_piz
+    sky = ms.env_pixels(37, 19)
+    for k, kw in enumerate((dict(compression=0), dict(compression=2, half=False), dict(compression=3), dict(compression=3, decreasing_y=True, alpha=True, half=False))):
+        q = str(tmp_path / ("sky%d.exr" % k))
+        ms.write_exr(q, sky, **kw)
+        if kw["compression"] == 0:
+            ch, _ = exr_piz.read_exr(q)
+            assert np.array_equal(ch["R"], np.asarray(sky, np.float32)[..., 0].astype(np.float16).astype(np.float32))
+        (tmp_path / ("exr%d.xml" % k)).write_text(text.replace("env_sky.hdr", q))
+        sce, osce = mi.load_file(str(tmp_path / ("exr%d.xml" % k))), orc.Scene(str(tmp_path / ("exr%d.xml" % k)), {})
+        theirs = envmap_export(osce.c.emitters[[e["kind"] for e in osce.flat.emitters].index(4)])
+        assert np.array_equal(sce.export(16).view(np.uint32), theirs.view(np.uint32)), kw
+        ref = np.asarray(sky, np.float32) if not kw.get("half", True) else np.asarray(sky, np.float32).astype(np.float16).astype(np.float32)
+        assert np.array_equal(theirs[32:32 + 38 * 19 * 3].reshape(19, 38, 3)[:, :37], ref), kw        # m_data: the decoded pixels (+ the periodic column)
+    with pytest.raises(mi.DtofError, match="PIZ"):
+        (tmp_path / "piz.xml").write_text(text.replace("env_sky.hdr", _piz_stub(tmp_path)))
+        mi.load_file(str(tmp_path / "piz.xml"))
     # a JPEG radiance map (4:2:0): product decoder vs PIL, then the same tables bit for bit
     from PIL import Image
     Image.open(os.path.join(SCENES, "env_sky.png")).convert("RGB").resize((40, 22)).save(str(tmp_path / "sky.jpg"), "JPEG", quality=88, subsampling=2)
