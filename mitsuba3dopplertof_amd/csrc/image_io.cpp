@@ -414,9 +414,9 @@ static void read_rgbe(const std::vector<uint8_t> &file, const std::string &path,
     }
 }
 // OpenEXR (Bitmap::read_exr, src/core/bitmap.cpp, through the OpenEXR library): single-part scan-line files, compression NONE, ZIPS (one
-// line per chunk) or ZIP (16 lines), channels R, G, B (or Y) as HALF, FLOAT or UINT; other channels (A, ...) are skipped.  ZIP chunks are zlib
-// streams of the byte-reordered (even bytes, then odd bytes), delta-coded scan lines (ImfZipCompressor).  PIZ / PXR24 / B44 / DWA files, tiles
-// and deep data are refused by name.
+// line per chunk), ZIP (16 lines) or PIZ (32 lines), channels R, G, B (or Y) as HALF, FLOAT or UINT; other channels (A, ...) are skipped.  ZIP
+// chunks are zlib streams of the byte-reordered (even bytes, then odd bytes), delta-coded scan lines (ImfZipCompressor); PIZ: below.  RLE / PXR24 /
+// B44 / DWA files, tiles and deep data are refused.
 static float half_to_float(uint16_t hbits) {
     const uint32_t sign = (uint32_t) (hbits & 0x8000u) << 16, e = (hbits >> 10) & 31u, m = hbits & 1023u;
     uint32_t bits;
@@ -427,6 +427,78 @@ static float half_to_float(uint16_t hbits) {
     else bits = sign | ((e + 112u) << 23) | (m << 13);
     float f; memcpy(&f, &bits, 4); return f;
 }
+// PIZ chunks (ImfPizCompressor): a bitmap of the 16-bit values that occur -> LUT, canonical Huffman coding of the wavelet coefficients (code
+// lengths packed with zero runs, one symbol = "repeat the previous value n times"; ImfHuf), 2-D Haar-like wavelet per channel in a 14-bit or a
+// 16-bit variant (ImfWav).  Decodes into the chunk's channel-planar uint16 buffer.
+namespace {
+struct PizBits { const uint8_t *d; size_t p, end; uint64_t c = 0; int lc = 0;
+    uint32_t get(int n) { while (lc < n) { if (p >= end) throw std::runtime_error("read_exr(): truncated PIZ data"); c = (c << 8) | d[p++]; lc += 8; } lc -= n; return (uint32_t) ((c >> lc) & ((1ull << n) - 1)); } };
+void piz_huf_uncompress(const uint8_t *data, size_t size, uint16_t *out, size_t n_raw) {
+    if (size < 20) throw std::runtime_error("read_exr(): truncated PIZ data");
+    uint32_t hd[5]; memcpy(hd, data, 20);
+    const uint32_t im = hd[0], iM = hd[1], n_bits = hd[3];
+    constexpr uint32_t kEnc = (1u << 16) + 1;
+    if (im >= kEnc || iM >= kEnc || im > iM) throw std::runtime_error("read_exr(): bad PIZ Huffman table");
+    std::vector<uint8_t> len(kEnc, 0);
+    PizBits br { data, 20, size };
+    for (uint32_t i = im; i <= iM;) {                    // hufUnpackEncTable
+        const uint32_t l = br.get(6);
+        if (l == 63) i += br.get(8) + 6;                 // LONG_ZEROCODE_RUN: 8 more bits + SHORTEST_LONG_RUN
+        else if (l >= 59) i += l - 59 + 2;               // SHORT_ZEROCODE_RUN
+        else len[i++] = (uint8_t) l;
+    }
+    const size_t table_end = br.p;
+    uint64_t count[59] = { 0 }, base[59];
+    for (uint32_t i = im; i <= iM; ++i) ++count[len[i]];
+    { uint64_t c = 0; for (int k = 58; k > 0; --k) { const uint64_t nc = (c + count[k]) >> 1; base[k] = c; c = nc; } }   // hufCanonicalCodeTable
+    std::vector<uint32_t> syms; uint64_t first_index[59] = { 0 };
+    { uint64_t at = 0; for (int k = 1; k <= 58; ++k) { first_index[k] = at; at += count[k]; } syms.resize((size_t) at); uint64_t fill[59]; memcpy(fill, first_index, sizeof fill);
+      for (uint32_t i = im; i <= iM; ++i) if (len[i]) syms[(size_t) fill[len[i]]++] = i; }
+    PizBits bits { data, table_end, size };
+    size_t pos = 0; uint64_t code = 0; int length = 0; uint64_t used = 0;
+    while (used < n_bits && pos < n_raw) {
+        code = (code << 1) | bits.get(1); ++length; ++used;
+        if (length > 58) throw std::runtime_error("read_exr(): invalid PIZ Huffman code");
+        if (count[length] == 0 || code < base[length] || code - base[length] >= count[length]) continue;
+        const uint32_t sym = syms[(size_t) (first_index[length] + (code - base[length]))];
+        if (sym == iM) {                                 // the run-length symbol
+            const uint32_t run = bits.get(8); used += 8;
+            if (pos == 0 || pos + run > n_raw) throw std::runtime_error("read_exr(): invalid PIZ run");
+            for (uint32_t r = 0; r < run; ++r) out[pos + r] = out[pos - 1];
+            pos += run;
+        } else out[pos++] = (uint16_t) sym;
+        code = 0; length = 0;
+    }
+    if (pos != n_raw) throw std::runtime_error("read_exr(): PIZ chunk decodes to the wrong size");
+}
+inline void wdec14(uint16_t l, uint16_t hh, uint16_t &a, uint16_t &b) { const int ls = (int16_t) l, hs = (int16_t) hh; const int ai = ls + (hs & 1) + (hs >> 1); a = (uint16_t) ai; b = (uint16_t) (ai - hs); }
+inline void wdec16(uint16_t l, uint16_t hh, uint16_t &a, uint16_t &b) { const int m = l, d = hh; const int bb = (m - (d >> 1)) & 0xffff; const int aa = (d + bb - 0x8000) & 0xffff; b = (uint16_t) bb; a = (uint16_t) aa; }
+void piz_wav2_decode(uint16_t *in, int nx, int ox, int ny, int oy, uint16_t mx) {   // ImfWav wav2Decode
+    const bool w14 = mx < (1 << 14);
+    const int n = nx > ny ? ny : nx; int p = 1, p2;
+    while (p <= n) p <<= 1;
+    p >>= 1; p2 = p; p >>= 1;
+    auto dec = [&](uint16_t l, uint16_t hh, uint16_t &a, uint16_t &b) { if (w14) wdec14(l, hh, a, b); else wdec16(l, hh, a, b); };
+    while (p >= 1) {
+        uint16_t *py = in; uint16_t *const ey = in + (ptrdiff_t) oy * (ny - p2);
+        const ptrdiff_t oy1 = (ptrdiff_t) oy * p, oy2 = (ptrdiff_t) oy * p2, ox1 = (ptrdiff_t) ox * p, ox2 = (ptrdiff_t) ox * p2;
+        uint16_t i00, i01, i10, i11;
+        for (; py <= ey; py += oy2) {
+            uint16_t *px = py; uint16_t *const ex = py + (ptrdiff_t) ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t *p01 = px + ox1, *p10 = px + oy1, *p11 = p10 + ox1;
+                dec(*px, *p10, i00, i10); dec(*p01, *p11, i01, i11); dec(i00, i01, *px, *p01); dec(i10, i11, *p10, *p11);
+            }
+            if (nx & p) { uint16_t *p10 = px + oy1; dec(*px, *p10, i00, *p10); *px = i00; }
+        }
+        if (ny & p) {
+            uint16_t *px = py; uint16_t *const ex = py + (ptrdiff_t) ox * (nx - p2);
+            for (; px <= ex; px += ox2) { uint16_t *p01 = px + ox1; dec(*px, *p01, i00, *p01); *px = i00; }
+        }
+        p2 = p; p >>= 1;
+    }
+}
+}  // namespace
 static void read_exr(const std::vector<uint8_t> &file, const std::string &path, std::vector<float> &rgb, uint32_t &w, uint32_t &h) {
     auto fail = [&](const std::string &m) { throw std::runtime_error("read_exr(): \"" + path + "\": " + m); };
     auto need = [&](size_t at, size_t n) { if (at > file.size() || file.size() - at < n) fail("truncated file"); };
@@ -461,7 +533,7 @@ static void read_exr(const std::vector<uint8_t> &file, const std::string &path, 
         }
         pos += size;
     }
-    if (comp != 0 && comp != 2 && comp != 3) fail(comp == 4 ? "PIZ-compressed files are not supported (uncompressed and ZIP only)" : "only uncompressed and ZIP-compressed files are supported");
+    if (comp != 0 && comp != 2 && comp != 3 && comp != 4) fail("only uncompressed, ZIP- and PIZ-compressed files are supported (not RLE, PXR24, B44 or DWA)");
     if (x1 < x0 || y1 < y0 || chans.empty()) fail("bad header");
     const uint64_t W = (uint64_t) ((int64_t) x1 - x0 + 1), H = (uint64_t) ((int64_t) y1 - y0 + 1);
     if (W > 65536 || H > 65536 || W * H > (1ull << 26)) fail("implausible size");
@@ -470,7 +542,7 @@ static void read_exr(const std::vector<uint8_t> &file, const std::string &path, 
     const bool colour = ir >= 0 && ig >= 0 && ib >= 0;
     if (!colour && iy < 0) fail("no R, G, B or Y channels");
     size_t line_bytes = 0; for (auto &c : chans) line_bytes += (c.type == 1 ? 2 : 4) * (size_t) W;
-    const uint32_t lines = comp == 3 ? 16 : 1; const size_t n_chunks = (size_t) ((H + lines - 1) / lines);
+    const uint32_t lines = comp == 3 ? 16 : comp == 4 ? 32 : 1; const size_t n_chunks = (size_t) ((H + lines - 1) / lines);
     need(pos, n_chunks * 8);
     if (line_bytes * H / 1024 > file.size() && comp == 0) fail("truncated file");     // a damaged size must not be allocated before the first read fails
     w = (uint32_t) W; h = (uint32_t) H; rgb.assign((size_t) W * H * 3, 0.f);
@@ -485,7 +557,31 @@ static void read_exr(const std::vector<uint8_t> &file, const std::string &path, 
         const uint32_t ny = (uint32_t) std::min<int64_t>(lines, (int64_t) y1 - y + 1);
         const size_t raw_len = line_bytes * ny;
         const uint8_t *src = &file[(size_t) off + 8];
-        if (comp != 0 && size < raw_len) {
+        bool planar = false;   // PIZ leaves the chunk channel by channel (all rows of the first channel, then the next)
+        if (comp == 4 && size < raw_len) {
+            if (size < 8) fail("truncated PIZ chunk");
+            uint16_t mn, mxv; memcpy(&mn, src, 2); memcpy(&mxv, src + 2, 2);
+            size_t p = 4;
+            std::vector<uint8_t> bitmap(8192, 0);
+            if (mn <= mxv) { if (mxv >= 8192 || p + (size_t) (mxv - mn + 1) > size) fail("bad PIZ bitmap"); memcpy(&bitmap[mn], src + p, (size_t) (mxv - mn + 1)); p += (size_t) (mxv - mn + 1); }
+            std::vector<uint16_t> lut; lut.reserve(65536);
+            for (uint32_t v = 0; v < 65536; ++v) if (v == 0 || (bitmap[v >> 3] & (1u << (v & 7)))) lut.push_back((uint16_t) v);
+            const uint16_t max_value = (uint16_t) (lut.size() - 1);
+            if (p + 4 > size) fail("truncated PIZ chunk");
+            int32_t length; memcpy(&length, src + p, 4); p += 4;
+            if (length < 0 || p + (size_t) length > size) fail("bad PIZ chunk");
+            std::vector<uint16_t> sym(raw_len / 2);
+            piz_huf_uncompress(src + p, (size_t) length, sym.data(), sym.size());
+            size_t q = 0;
+            for (auto &c : chans) {
+                const int sz = c.type == 1 ? 1 : 2;
+                for (int j = 0; j < sz; ++j) piz_wav2_decode(sym.data() + q + j, (int) W, sz, (int) ny, (int) W * sz, max_value);
+                q += (size_t) W * ny * sz;
+            }
+            for (uint16_t &v : sym) v = v < lut.size() ? lut[v] : 0;
+            raw.resize(raw_len); memcpy(raw.data(), sym.data(), raw_len);
+            src = raw.data(); planar = true;
+        } else if (comp != 0 && comp != 4 && size < raw_len) {
             tmp.resize(raw_len); uLongf got = (uLongf) raw_len;
             if (uncompress(tmp.data(), &got, src, size) != Z_OK || got != raw_len) fail("corrupt ZIP chunk");
             for (size_t i = 1; i < raw_len; ++i) tmp[i] = (uint8_t) (tmp[i - 1] + tmp[i] - 128);      // undo the predictor
@@ -495,7 +591,7 @@ static void read_exr(const std::vector<uint8_t> &file, const std::string &path, 
             src = raw.data();
         } else if (size != raw_len) fail("bad chunk size");
         size_t q = 0;
-        for (uint32_t r = 0; r < ny; ++r) for (size_t c = 0; c < chans.size(); ++c) {
+        for (uint32_t rr = 0; rr < (planar ? 1u : ny); ++rr) for (size_t c = 0; c < chans.size(); ++c) for (uint32_t r = planar ? 0 : rr; r < (planar ? ny : rr + 1); ++r) {
             const int t = chans[c].type; const size_t bpp = t == 1 ? 2 : 4;
             int dst = -1; if (colour) dst = (int) c == ir ? 0 : (int) c == ig ? 1 : (int) c == ib ? 2 : -1; else if ((int) c == iy) dst = 3;
             if (dst >= 0) for (uint64_t x = 0; x < W; ++x) {

@@ -423,8 +423,18 @@ def read_radiance_image(path):
             attrs[name] = data[pos:pos + size]; pos += size
         pos += 1
         comp = attrs["compression"][0]
+        if comp == 4:      # PIZ: the stand-alone reader that decoded the authors' scene.exr (tools/exr_piz.py, test infrastructure like this file)
+            import sys as _sys
+            _sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+            import exr_piz
+            ch, _ = exr_piz.read_exr(path)
+            if all(c in ch for c in "RGB"):
+                return np.ascontiguousarray(np.stack([ch["R"], ch["G"], ch["B"]], -1).astype(F32))
+            if "Y" in ch:
+                return np.ascontiguousarray(np.repeat(ch["Y"][..., None], 3, axis=2).astype(F32))
+            raise ValueError("read_exr(): no R, G, B or Y channels")
         if comp not in (0, 2, 3):
-            raise ValueError("read_exr(): only uncompressed and ZIP-compressed scan-line files are supported")
+            raise ValueError("read_exr(): only uncompressed, ZIP- and PIZ-compressed scan-line files are supported")
         x0, y0, x1, y1 = _st.unpack("<4i", attrs["dataWindow"])
         w, h = x1 - x0 + 1, y1 - y0 + 1
         chans, cd, p = [], attrs["channels"], 0

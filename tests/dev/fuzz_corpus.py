@@ -38,6 +38,9 @@ except Exception:
 make_scenes.write_exr(os.path.join(out, "o.exr"), sky, compression=3); make_scenes.write_exr(os.path.join(out, "p.exr"), sky, compression=0, half=False)
 make_scenes.write_exr(os.path.join(out, "q.exr"), sky, compression=2, alpha=True, decreasing_y=True)
 images = {n: open(os.path.join(out, n), "rb").read() for n in ("h.hdr", "i.hdr", "j.pfm", "k.png", "o.exr", "p.exr", "q.exr") + jpegs}
+_piz = "/root/reference/configs_example/scene.exr"     # the one PIZ-compressed file at hand (build container only)
+if os.path.exists(_piz):
+    images["r.exr"] = open(_piz, "rb").read()
 env0 = make_scenes.cornell_envmap(16, 4, filename="IMAGE")
 for it in range(N):
     r = random.random()
