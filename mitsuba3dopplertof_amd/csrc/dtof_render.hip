@@ -186,6 +186,7 @@ RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, cons
     memcpy(rp.cam_to_world, se.to_world, 48);
     rp.near_clip = se.near_clip; rp.far_clip = se.far_clip; rp.shutter_open = se.shutter_open;
     rp.shutter_open_time = se.shutter_close - se.shutter_open;
+    rp.aperture_radius = se.thinlens ? se.aperture_radius : 0.f; rp.focus_distance = se.focus_distance;
     rp.crop_x = se.crop_x; rp.crop_y = se.crop_y; rp.crop_w = se.crop_w; rp.crop_h = se.crop_h;
     rp.scale_x = 1.f / (float) se.crop_w; rp.scale_y = 1.f / (float) se.crop_h;
     rp.offset_x = -(float) se.crop_x * rp.scale_x; rp.offset_y = -(float) se.crop_y * rp.scale_y;
@@ -664,6 +665,7 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
             const HostSensor &s = sc->host.sensor;
             v.insert(v.end(), s.to_world, s.to_world + 16);
             v.push_back(s.x_fov); v.push_back(s.near_clip); v.push_back(s.far_clip); v.push_back(s.shutter_open); v.push_back(s.shutter_close);
+            v.push_back(s.thinlens ? 1.f : 0.f); v.push_back(s.aperture_radius); v.push_back(s.focus_distance);
         } else if (kind == 3) for (auto &e : sc->host.emitters) {
             v.insert(v.end(), e.pos, e.pos + 3); v.insert(v.end(), e.intensity, e.intensity + 3);
         } else if (kind >= 4 && kind <= 7) for (auto &s : sc->host.shapes) {

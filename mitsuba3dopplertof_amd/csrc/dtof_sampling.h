@@ -160,6 +160,10 @@ DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane, bool wav
     float jx = single ? next_f32(main) : next_correlate(main, path, cp), jy = single ? next_f32(main) : next_correlate(main, path, cp);
     float spx = posx + jx, spy = posy + jy;
     float ax = fmaf(spx, rp.scale_x, rp.offset_x), ay = fmaf(spy, rp.scale_y, rp.offset_y);
+    // needs_aperture_sample() (thinlens.cpp:155): a second 2-D draw of the same kind (integrator.cpp:421-423,490-492)
+    const bool lens = rp.aperture_radius != 0.f;
+    float apx = .5f, apy = .5f;
+    if (lens) { apx = single ? next_f32(main) : next_correlate(main, path, cp); apy = single ? next_f32(main) : next_correlate(main, path, cp); }
     float time = rp.shutter_open;
     if (rp.shutter_open_time > 0.f) {
         float u;
@@ -181,8 +185,18 @@ DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane, bool wav
     float r2 = fmaf(m[10], 0.f, fmaf(m[9], ay, fmaf(m[8], ax, m[11])));
     float r3 = fmaf(m[14], 0.f, fmaf(m[13], ay, fmaf(m[12], ax, m[15])));
     float iw = rcp(r3);
-    V3 d = normalize(mk(r0 * iw, r1 * iw, r2 * iw));
-    V3 o = mk(rp.cam_to_world[3], rp.cam_to_world[7], rp.cam_to_world[11]);
+    V3 near_p = mk(r0 * iw, r1 * iw, r2 * iw);
+    V3 d, o;
+    if (lens) {   // ThinLensCamera::sample_ray_differential_impl (thinlens.cpp:257-305)
+        float tx, ty; concentric_disk(apx, apy, tx, ty);
+        const V3 aperture_p = mk(rp.aperture_radius * tx, rp.aperture_radius * ty, 0.f);
+        const float f_dist = rp.focus_distance / near_p.z;
+        d = normalize(near_p * f_dist - aperture_p);
+        o = xf_point(rp.cam_to_world, aperture_p);
+    } else {
+        d = normalize(near_p);
+        o = mk(rp.cam_to_world[3], rp.cam_to_world[7], rp.cam_to_world[11]);
+    }
     V3 dw = xf_vector(rp.cam_to_world, d);
     float inv_z = rcp(d.z), near_t = rp.near_clip * inv_z, far_t = rp.far_clip * inv_z;
     o = o + dw * near_t;

@@ -895,7 +895,7 @@ static double parse_fov(const Obj &s, double aspect) {   // src/render/sensor.cp
 }
 
 static void make_sensor(const Obj &o, HostScene &sc) {
-    if (o.plugin != "perspective") fail("unsupported sensor plugin \"" + o.plugin + "\" (supported: perspective)");
+    if (o.plugin != "perspective" && o.plugin != "thinlens") fail("unsupported sensor plugin \"" + o.plugin + "\" (supported: perspective, thinlens)");
     HostSensor &se = sc.sensor;
     const Obj *film = nullptr, *sampler = nullptr;
     for (auto &c : o.children) {
@@ -938,6 +938,12 @@ static void make_sensor(const Obj &o, HostScene &sc) {
     if (!have_filter) { se.filter = FILTER_GAUSSIAN; se.filter_stddev = .5f; se.filter_radius = 2.f; }   // film.cpp:49-53: default gaussian
     auto t = o.transforms.find("to_world");
     to_f32(t != o.transforms.end() ? t->second.m : m_identity(), se.to_world);
+    // perspective.cpp:143-144 / thinlens.cpp:149-150: Transform::has_scale (transform.h:325-337)
+    for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) {
+        float sum = 0.f;
+        for (int k = 0; k < 3; ++k) sum += se.to_world[4 * i + k] * se.to_world[4 * j + k];
+        if (std::fabs(sum - (i == j ? 1.f : 0.f)) > 1e-3f) fail("Scale factors in the camera-to-world transformation are not allowed!");
+    }
     se.shutter_open = (float) o.props.get_float("shutter_open", 0.0);
     se.shutter_close = (float) o.props.get_float("shutter_close", 0.0);
     if (se.shutter_close - se.shutter_open < 0) fail("Shutter opening time must be less than or equal to the shutter closing time!");
@@ -946,6 +952,13 @@ static void make_sensor(const Obj &o, HostScene &sc) {
     if (se.near_clip <= 0.f) fail("The 'near_clip' parameter must be greater than zero!");
     if (se.near_clip >= se.far_clip) fail("The 'near_clip' parameter must be smaller than 'far_clip'.");
     se.x_fov = (float) parse_fov(o, se.film_w / (double) se.film_h);
+    se.focus_distance = (float) o.props.get_float("focus_distance", se.far_clip);   // ProjectiveCamera (sensor.cpp:134): read by both cameras
+    if (o.plugin == "thinlens") {   // thinlens.cpp:138-156
+        if (!o.props.has("aperture_radius")) fail("Property \"aperture_radius\" has not been specified!");
+        se.thinlens = true;
+        se.aperture_radius = (float) o.props.get_float("aperture_radius", 0.0);
+        if (se.aperture_radius == 0.f) se.aperture_radius = 5.9604644775390625e-8f;   // dr::Epsilon<float>
+    }
     (void) o.props.get_float("principal_point_offset_x", 0.0); (void) o.props.get_float("principal_point_offset_y", 0.0);
     if (sampler) sc.sampler = sampler->props; else { sc.sampler = PropBag(); sc.sampler.plugin = "independent"; }
     auto u = o.props.unqueried();

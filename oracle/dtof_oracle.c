@@ -676,10 +676,12 @@ static void camera_sample_to_camera(const orc_sensor *s, float *inv_out) {
     m4_mul(T1i, S1i, tmp); m4_mul(S2i, tmp, tmp); m4_mul(T2i, tmp, tmp); m4_mul(Pi, tmp, inv_out);
 }
 
-/* PerspectiveCamera::sample_ray_differential -- src/sensors/perspective.cpp:238-279
- * (differentials are not needed by diffuse BSDFs and are not produced). */
+/* PerspectiveCamera::sample_ray_differential -- src/sensors/perspective.cpp:238-279, and
+ * ThinLensCamera::sample_ray_differential_impl -- src/sensors/thinlens.cpp:257-305 (a_x, a_y: the aperture sample)
+ * (differentials are not needed by the BSDFs of this path and are not produced). */
 typedef struct { v3 o, d; float maxt; } orc_ray;
-static orc_ray camera_ray(const orc_sensor *s, const float *s2c, float ux, float uy) {
+static void concentric_disk(float sx, float sy, float *px, float *py);
+static orc_ray camera_ray(const orc_sensor *s, const float *s2c, float ux, float uy, float a_x, float a_y) {
     /* Transform::operator*(Point): homogeneous, then head<3>(r) / r.w = head * rcp(w) */
     float r0 = fmaf(s2c[2], 0.f, fmaf(s2c[1], uy, fmaf(s2c[0], ux, s2c[3])));
     float r1 = fmaf(s2c[6], 0.f, fmaf(s2c[5], uy, fmaf(s2c[4], ux, s2c[7])));
@@ -687,9 +689,18 @@ static orc_ray camera_ray(const orc_sensor *s, const float *s2c, float ux, float
     float r3 = fmaf(s2c[14], 0.f, fmaf(s2c[13], uy, fmaf(s2c[12], ux, s2c[15])));
     float iw = f_rcp(r3);
     v3 near_p = V(r0 * iw, r1 * iw, r2 * iw);
-    v3 d = v_normalize(near_p);
-    orc_ray ray;
-    ray.o = V(s->to_world[3], s->to_world[7], s->to_world[11]);
+    orc_ray ray; v3 d;
+    if (s->kind == ORC_SENSOR_THINLENS) {
+        float tx, ty; concentric_disk(a_x, a_y, &tx, &ty);
+        v3 aperture_p = V(s->aperture_radius * tx, s->aperture_radius * ty, 0.f);
+        float f_dist = s->focus_distance / near_p.z;
+        v3 focus_p = v_mul(near_p, f_dist);
+        d = v_normalize(v_sub(focus_p, aperture_p));
+        ray.o = m_point(s->to_world, aperture_p);
+    } else {
+        d = v_normalize(near_p);
+        ray.o = V(s->to_world[3], s->to_world[7], s->to_world[11]);
+    }
     ray.d = m_vector(s->to_world, d);
     float inv_z = f_rcp(d.z);
     float near_t = s->near_clip * inv_z, far_t = s->far_clip * inv_z;
@@ -702,7 +713,15 @@ void orc_camera_ray(const orc_sensor *s, float px, float py, float *out) {
     float s2c[16]; camera_sample_to_camera(s, s2c);
     float sx = 1.f / (float) s->crop_w, sy = 1.f / (float) s->crop_h;
     float ux = fmaf(px, sx, -(float) s->crop_x * sx), uy = fmaf(py, sy, -(float) s->crop_y * sy);
-    orc_ray r = camera_ray(s, s2c, ux, uy);
+    orc_ray r = camera_ray(s, s2c, ux, uy, .5f, .5f);
+    out[0] = r.o.x; out[1] = r.o.y; out[2] = r.o.z; out[3] = r.d.x; out[4] = r.d.y; out[5] = r.d.z;
+    out[6] = r.maxt;
+}
+
+/* test entry: Sensor::sample_ray(time, wavelength_sample, position_sample, aperture_sample) of either camera: o(3), d(3), maxt */
+void orc_camera_sample_ray(const orc_sensor *s, float ux, float uy, float a_x, float a_y, float *out) {
+    float s2c[16]; camera_sample_to_camera(s, s2c);
+    orc_ray r = camera_ray(s, s2c, ux, uy, a_x, a_y);
     out[0] = r.o.x; out[1] = r.o.y; out[2] = r.o.z; out[3] = r.d.x; out[4] = r.d.y; out[5] = r.d.z;
     out[6] = r.maxt;
 }
@@ -1074,7 +1093,7 @@ static inline v3 offset_p(const orc_si *si, v3 d) {
 }
 
 /* warp::square_to_uniform_disk_concentric / square_to_cosine_hemisphere -- warp.h:54-86,320-344 */
-static v3 square_to_cosine_hemisphere(float sx, float sy) {
+static void concentric_disk(float sx, float sy, float *px, float *py) {
     float x = fmaf(2.f, sx, -1.f), y = fmaf(2.f, sy, -1.f);
     int is_zero = (x == 0.f && y == 0.f), q13 = fabsf(x) < fabsf(y);
     float r = q13 ? y : x, rp = q13 ? x : y;
@@ -1082,7 +1101,10 @@ static v3 square_to_cosine_hemisphere(float sx, float sy) {
     if (q13) phi = 0.5f * ORC_PI_F - phi;
     if (is_zero) phi = 0.f;
     float s, c; orc_sincos(phi, &s, &c);
-    float px = r * c, py = r * s;
+    *px = r * c; *py = r * s;
+}
+static v3 square_to_cosine_hemisphere(float sx, float sy) {
+    float px, py; concentric_disk(sx, sy, &px, &py);
     float z = sqrtf(f_max(1.f - fmaf(py, py, px * px), 0.f));
     return V(px, py, z);
 }
@@ -1656,6 +1678,10 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
     float scx = 1.f / (float) se->crop_w, scy = 1.f / (float) se->crop_h;
     float ax = fmaf(spx, scx, -(float) se->crop_x * scx), ay = fmaf(spy, scy, -(float) se->crop_y * scy);
 
+    /* needs_aperture_sample() (m_needs_sample_3, thinlens.cpp:155): a second 2-D draw of the same kind (integrator.cpp:421-423,490-492) */
+    float apx = .5f, apy = .5f;
+    if (se->kind == ORC_SENSOR_THINLENS) { apx = sampler_draw(&smp, correlate_pixel, single); apy = sampler_draw(&smp, correlate_pixel, single); }
+
     float time = se->shutter_open;
     float shutter_open_time = se->shutter_close - se->shutter_open;
     if (shutter_open_time > 0.f) {
@@ -1670,7 +1696,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         time += u * shutter_open_time;
     }
 
-    orc_ray ray = camera_ray(se, cx->s2c, ax, ay);
+    orc_ray ray = camera_ray(se, cx->s2c, ax, ay, apx, apy);
     /* dopplertofpath.cpp:93 */
     if (!plain) time = time < p->time ? time : time - p->time;
 

@@ -151,7 +151,11 @@ typedef struct {
     float   filter_radius;
     float   filter_stddev;   /* gaussian only (radius = 4 stddev, src/rfilters/gaussian.cpp:48-53) */
     float   filter_b, filter_c;   /* mitchell only: the B and C of the paper (src/rfilters/mitchell.cpp:38-45), radius 2 */
+    int32_t kind;            /* ORC_SENSOR_*: perspective (src/sensors/perspective.cpp) or thinlens (src/sensors/thinlens.cpp) */
+    float   aperture_radius; /* thinlens only (thinlens.cpp:142-147: 0 becomes dr::Epsilon<Float>) */
+    float   focus_distance;  /* thinlens only (src/render/sensor.cpp:134: default far_clip) */
 } orc_sensor;
+enum { ORC_SENSOR_PERSPECTIVE = 0, ORC_SENSOR_THINLENS = 1 };
 
 typedef struct {
     /* dopplertofpath.cpp:19-57 (all already rounded the way the ctor rounds them) */
@@ -218,6 +222,7 @@ void     orc_sampler_lane(const orc_params *p, uint32_t seed, uint32_t spp, uint
 
 /* Camera ray for a film position (perspective.cpp:238-279). out[0..2]=o, [3..5]=d, [6]=maxt */
 void     orc_camera_ray(const orc_sensor *s, float px, float py, float *out);
+void     orc_camera_sample_ray(const orc_sensor *s, float ux, float uy, float a_x, float a_y, float *out);
 
 /* Closest hit / occlusion against the flat scene (brute force).
  * hit[0]=t (inf if none), hit[1]=u, hit[2]=v; ids[0]=object, ids[1]=shape_in_group, ids[2]=prim */

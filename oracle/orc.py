@@ -75,7 +75,8 @@ class OrcSensor(C.Structure):
                 ("film_w", C.c_int32), ("film_h", C.c_int32),
                 ("crop_x", C.c_int32), ("crop_y", C.c_int32), ("crop_w", C.c_int32), ("crop_h", C.c_int32),
                 ("filter", C.c_int32), ("filter_radius", C.c_float), ("filter_stddev", C.c_float),
-                ("filter_b", C.c_float), ("filter_c", C.c_float)]
+                ("filter_b", C.c_float), ("filter_c", C.c_float),
+                ("kind", C.c_int32), ("aperture_radius", C.c_float), ("focus_distance", C.c_float)]
 
 
 class OrcParams(C.Structure):
@@ -152,6 +153,7 @@ def lib():
         L.orc_sampler_lane.argtypes = [C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
         L.orc_camera_ray.argtypes = [C.POINTER(OrcSensor), C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.orc_camera_sample_ray.argtypes = [C.POINTER(OrcSensor)] + [C.c_float] * 4 + [C.POINTER(C.c_float)]
         L.orc_intersect.restype = C.c_int
         L.orc_intersect.argtypes = [C.POINTER(OrcScene), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float,
                                     C.POINTER(C.c_float), C.POINTER(C.c_int32)]
@@ -374,6 +376,7 @@ class Scene:
         sc.sensor.to_world = _m16(se["to_world"])
         for k in ("x_fov", "near_clip", "far_clip", "shutter_open", "shutter_close", "filter_radius", "filter_stddev", "filter_b", "filter_c"):
             setattr(sc.sensor, k, float(se[k]))
+        sc.sensor.kind, sc.sensor.aperture_radius, sc.sensor.focus_distance = int(se.get("kind", 0)), float(se.get("aperture_radius", 0.0)), float(se.get("focus_distance", 0.0))
         for k in ("film_w", "film_h", "crop_x", "crop_y", "crop_w", "crop_h", "filter"):
             setattr(sc.sensor, k, int(se[k]))
         self._keep += [shapes, groups, objects, emitters]

@@ -302,6 +302,15 @@ def write_exr(path, rows, compression=3, half=True, decreasing_y=False, alpha=Fa
         f.write(head + struct.pack("<%dQ" % len(order), *[table[y] for y in order]) + body)
 
 
+def cornell_thinlens(res=128, spp=16):
+    """cornell_boxes.xml seen through a `thinlens` sensor (src/sensors/thinlens.cpp): a 12 cm aperture focused on the front of the short box, so that
+    every lane draws an aperture sample between its pixel jitter and its time sample"""
+    s = cornell(False, res, spp, "antithetic", "0.5")
+    s = s.replace('<sensor type="perspective">', '<sensor type="thinlens">\n\t\t<float name="aperture_radius" value="0.12" />\n\t\t<float name="focus_distance" value="6.2" />')
+    assert "thinlens" in s
+    return s
+
+
 def cornell_sun(res=128, spp=16):
     """cornell_env.xml (no ceiling, no back wall) under a `directional` emitter (src/emitters/directional.cpp) given by `direction`, plus a second one
     given by a to_world rotation, beside the point light: delta directions, shadow rays that leave through the open sides"""
@@ -563,6 +572,7 @@ def main():
         "cornell_env.xml": cornell_env(),
         "cornell_envmap.xml": cornell_envmap(),
         "cornell_sun.xml": cornell_sun(),
+        "cornell_thinlens.xml": cornell_thinlens(),
         "cornell_cylinders.xml": cornell_cylinders(),
         "cornell_spheres.xml": cornell_spheres(),
         "cornell_sphere_light.xml": cornell_spheres(sphere_light=True),
@@ -579,7 +589,7 @@ def main():
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
     names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml",
-             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
+             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_thinlens.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
         return

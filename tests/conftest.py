@@ -98,6 +98,8 @@ CONFIGS = [
     ("envmap", "cornell_envmap.xml", dict(resx=32, resy=32, max_depth=4), 8),
     # `directional` emitters (one by `direction`, one by `to_world`): delta directions sampled from outside the bounding sphere
     ("directional", "cornell_sun.xml", dict(resx=32, resy=32, max_depth=4), 8),
+    # `thinlens` sensor: one more correlated 2-D draw per lane (the aperture sample), rays that start on the lens
+    ("thinlens", "cornell_thinlens.xml", dict(resx=32, resy=32, max_depth=4, path_correlation_depth=2), 8),
     ("cylinders", "cornell_cylinders.xml", dict(resx=24, resy=24, max_depth=4), 8),
     ("spot_light", "cornell_spot.xml", dict(resx=24, resy=24), 8),
     ("disks", "cornell_disk.xml", dict(resx=24, resy=24, max_depth=5), 8),

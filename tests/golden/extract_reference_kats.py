@@ -54,6 +54,7 @@ FILES = [
     "src/emitters/tests/test_area.py",
     "src/emitters/tests/test_spot.py",
     "src/sensors/tests/test_perspective.py",    # C1
+    "src/sensors/tests/test_thinlens.py",       # D2 (the aperture draw), 8(f) thinlens sensor
     "src/render/tests/test_imageblock.py",      # I1
     "src/bsdfs/tests/test_diffuse.py",          # M1
     "src/bsdfs/tests/test_twosided.py",

@@ -54,7 +54,7 @@ def _tag_of(plugin):
         return "rfilter"
     if plugin == "hdrfilm":
         return "film"
-    if plugin == "perspective":
+    if plugin in ("perspective", "thinlens"):
         return "sensor"
     if plugin in ("independent", "correlated"):
         return "sampler"
@@ -414,29 +414,40 @@ class Sensor:
         return i["shutter_close"] - i["shutter_open"]
 
     def needs_aperture_sample(self):
-        return False
+        return self.d["type"] == "thinlens"
 
     def focus_distance(self):
-        raise Skip("focus_distance is not used by the perspective (pinhole) camera")
+        if self.d["type"] != "thinlens":
+            raise Skip("focus_distance is not used by the perspective (pinhole) camera")
+        return self.be.sensor_info(self.scene)["focus_distance"]
+
+    def bbox(self):
+        raise Skip("Sensor::bbox")
 
     def world_transform(self):
         return Transform(self.be.sensor_info(self.scene)["to_world"])
 
-    def _ray(self, time, pos):
-        pos = np.asarray(pos, np.float64)
-        if pos.ndim == 2:      # vectorised variants: [[x0, x1, ..], [y0, y1, ..]]
-            rays = [self.be.camera_ray(self.scene, float(px) * self.film_size[0], float(py) * self.film_size[1]) for px, py in zip(pos[0], pos[1])]
+    def _ray(self, time, pos, ap=(.5, .5)):
+        pos, ap = np.asarray(pos, np.float64), np.asarray(ap, np.float64)
+        if ap.ndim == 0:
+            ap = np.array([float(ap), float(ap)])
+        if pos.ndim == 2 or ap.ndim == 2:      # vectorised variants: [[x0, x1, ..], [y0, y1, ..]]
+            n = pos.shape[1] if pos.ndim == 2 else ap.shape[1]
+            pos = pos if pos.ndim == 2 else np.repeat(pos[:, None], n, axis=1)
+            ap = ap if ap.ndim == 2 else np.repeat(ap[:, None], n, axis=1)
+            rays = [self.be.camera_ray(self.scene, float(px) * self.film_size[0], float(py) * self.film_size[1], float(ax), float(ay))
+                    for px, py, ax, ay in zip(pos[0], pos[1], ap[0], ap[1])]
             o = np.stack([r[0] for r in rays], axis=1)
             d = np.stack([r[1] for r in rays], axis=1)
         else:
-            o, d = self.be.camera_ray(self.scene, float(pos[0]) * self.film_size[0], float(pos[1]) * self.film_size[1])
+            o, d = self.be.camera_ray(self.scene, float(pos[0]) * self.film_size[0], float(pos[1]) * self.film_size[1], float(ap[0]), float(ap[1]))
         return Rec("Ray3f", attrs=dict(o=o, d=d, time=np.float32(time))), Skipper("spectral weight of sample_ray")
 
     def sample_ray(self, time, wav, pos, ap, *a):
-        return self._ray(time, pos)
+        return self._ray(time, pos, ap)
 
     def sample_ray_differential(self, time, wav, pos, ap, *a):
-        r, w = self._ray(time, pos)
+        r, w = self._ray(time, pos, ap)
         return r, w
 
 
@@ -692,7 +703,7 @@ class Evaluator:
             return BsdfFacade(self.be, to_xml(None, d, "    "))
         if t in _FILTERS or t == "lanczos":
             return FilterFacade(self.be, d)
-        if t == "perspective":
+        if t in ("perspective", "thinlens"):
             return Sensor(self.be, d)
         raise Skip("load_dict of plugin '%s'" % t)
 

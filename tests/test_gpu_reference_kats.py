@@ -64,7 +64,7 @@ class ProductBackend:
 
     def sensor_info(self, sc):
         s = sc.export(2)
-        return dict(shutter_open=float(s[19]), shutter_close=float(s[20]), to_world=s[:16].astype(np.float64).reshape(4, 4))
+        return dict(shutter_open=float(s[19]), shutter_close=float(s[20]), focus_distance=float(s[23]), to_world=s[:16].astype(np.float64).reshape(4, 4))
 
     def film_info(self, sc):
         i = sc.info()

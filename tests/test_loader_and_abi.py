@@ -21,7 +21,8 @@ def _oracle_all(fs):
     shp = np.concatenate([np.concatenate([s["to_world"].reshape(-1), s["to_object"].reshape(-1)]) for s in fs.shapes])
     se = fs.sensor
     sen = np.concatenate([se["to_world"].reshape(-1), np.array([se["x_fov"], se["near_clip"], se["far_clip"],
-                                                                 se["shutter_open"], se["shutter_close"]], np.float32)])
+                                                                 se["shutter_open"], se["shutter_close"],
+                                                                 se["kind"], se["aperture_radius"], se["focus_distance"]], np.float32)])
     em = np.concatenate([np.concatenate([e["position"], e["intensity"]]) for e in fs.emitters]) if fs.emitters else np.zeros(0, np.float32)
     return [obj.astype(np.float32), shp.astype(np.float32), sen.astype(np.float32), em.astype(np.float32)]
 
@@ -31,6 +32,7 @@ def _oracle_all(fs):
     ("cornell_wall.xml", dict()),
     ("domino_small.xml", dict()),
     ("domino.xml", dict()),
+    ("cornell_thinlens.xml", dict()),
 ])
 def test_loader_matches_oracle_loader_bit_exact(mi, orc, xml, params):
     path = os.path.join(SCENES, xml)

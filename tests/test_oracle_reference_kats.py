@@ -97,7 +97,7 @@ class OracleBackend:
 
     def sensor_info(self, sc):
         se = sc.flat.sensor
-        return dict(shutter_open=float(se["shutter_open"]), shutter_close=float(se["shutter_close"]),
+        return dict(shutter_open=float(se["shutter_open"]), shutter_close=float(se["shutter_close"]), focus_distance=float(se["focus_distance"]),
                     to_world=np.asarray(se["to_world"], np.float64).reshape(4, 4))
 
     def film_info(self, sc):
@@ -105,9 +105,13 @@ class OracleBackend:
         return dict(size=(int(se["film_w"]), int(se["film_h"])), crop_size=(int(se["crop_w"]), int(se["crop_h"])),
                     crop_offset=(int(se["crop_x"]), int(se["crop_y"])))
 
-    def camera_ray(self, sc, px, py):
+    def camera_ray(self, sc, px, py, ax=.5, ay=.5):
         out = np.zeros(7, np.float32)
-        self.L.orc_camera_ray(C.byref(sc.c.sensor), px, py, out.ctypes.data_as(C.POINTER(C.c_float)))
+        if sc.c.sensor.kind == 0:
+            self.L.orc_camera_ray(C.byref(sc.c.sensor), px, py, out.ctypes.data_as(C.POINTER(C.c_float)))
+        else:   # ThinLensCamera: position sample in [0, 1]^2 of the crop window, aperture sample
+            se = sc.c.sensor
+            self.L.orc_camera_sample_ray(C.byref(se), (px - se.crop_x) / se.crop_w, (py - se.crop_y) / se.crop_h, ax, ay, out.ctypes.data_as(C.POINTER(C.c_float)))
         return out[0:3].copy(), out[3:6].copy()
 
 
@@ -131,6 +135,7 @@ PINNED = {
     "src/shapes/tests/test_cube.py": ("G3 cube mesh", 100),
     "src/shapes/tests/test_cylinder.py": ("8(f)-3 cylinder", 300),
     "src/sensors/tests/test_perspective.py": ("C1 perspective camera", 20),
+    "src/sensors/tests/test_thinlens.py": ("D2 aperture sample / thinlens camera: constructor, sample_ray with aperture samples, fov axes", 200),
     "src/render/tests/test_imageblock.py": ("I1 ImageBlock::put", 1),
     "src/bsdfs/tests/test_diffuse.py": ("M1 diffuse", 30),
     "src/bsdfs/tests/test_twosided.py": ("M1 twosided", 2),
