@@ -238,7 +238,7 @@ int dtof_ray_test(dtof_scene *scene, uint32_t n, const float *rays8, int32_t *oc
 #define DTOF_COMP_MICROFACET_SAMPLE        3   /* ::sample (:240-325); in wi[3], sample[2]; out m[3], pdf */
 #define DTOF_COMP_FRESNEL                  4   /* fresnel (fresnel.h:21-63). params: eta; in cos_theta_i; out r, cos_theta_t, eta_it, eta_ti */
 #define DTOF_COMP_FRESNEL_CONDUCTOR        5   /* fresnel_conductor (fresnel.h:93-117). params: eta, k; in cos_theta_i; out 1 */
-#define DTOF_COMP_RFILTER                  6   /* ReconstructionFilter::eval. params: kind (0 box, 1 tent, 2 gaussian, 3 mitchell, 4 catmullrom), radius, stddev, B, C; in x; out 1 */
+#define DTOF_COMP_RFILTER                  6   /* ReconstructionFilter::eval. params: kind (0 box, 1 tent, 2 gaussian, 3 mitchell, 4 catmullrom, 5 lanczos: radius = lobes), radius, stddev, B, C; in x; out 1 */
 #define DTOF_COMP_WARP_COSINE_HEMISPHERE   7   /* warp::square_to_cosine_hemisphere (warp.h:320-344); in sample[2]; out 3 */
 #define DTOF_COMP_WARP_DISK_CONCENTRIC     8   /* warp::square_to_uniform_disk_concentric (warp.h:54-90); out 2 */
 #define DTOF_COMP_WARP_UNIFORM_TRIANGLE    9   /* warp::square_to_uniform_triangle (warp.h:153-156); out 2 */

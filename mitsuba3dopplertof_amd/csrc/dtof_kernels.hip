@@ -783,6 +783,13 @@ DTOF_D float filter_weight(const RenderParams &rp, float x) {
                                                : (-B - 6.f * C) * x3 + (6.f * B + 30.f * C) * x2 + (-12.f * B - 48.f * C) * x + (8.f * B + 24.f * C));
         return x < 2.f ? r : 0.f;
     }
+    if (filter == FILTER_LANCZOS) {   // LanczosSincFilter::eval (lanczos.cpp:52-63): radius = lobes
+        x = fabsf(x);
+        const float x1 = kPi * x, x2 = x1 / rp.filter_radius;
+        float s1, s2, c; sincos_(x1, s1, c); sincos_(x2, s2, c);
+        const float result = (s1 * s2) / (x1 * x2);
+        return x < 5.9604644775390625e-8f ? 1.f : (x > rp.filter_radius ? 0.f : result);
+    }
     return tent(x, rp.inv_radius);
 }
 // v + (v moved by the DPP control); lanes without a valid source (or in rows masked off) add 0
@@ -1237,7 +1244,9 @@ void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t 
     // footprint of the filter in pixels (ImageBlock::put: the pixels within ceil(radius - 0.5) of the sample's): 1 (box), 3 or 5 take the
     // eight-samples-per-lane kernel when spp is a power of two >= 16
     const int reach = rp.filter == FILTER_BOX ? 0 : (int) ceilf(rp.filter_radius - .5f);
-    if ((rp.filter == FILTER_BOX || (reach >= 1 && reach <= 2)) && rp.spp_log2 != 0xffffffffu && rp.spp >= 2 * kSplatPer && env_splat == 0) {
+    // the Lanczos filter (default radius 3: a 7 x 7 footprint) always takes the per-lane kernel
+    const bool lanczos = rp.filter == FILTER_LANCZOS;
+    if ((rp.filter == FILTER_BOX || (reach >= 1 && reach <= 2)) && !lanczos && rp.spp_log2 != 0xffffffffu && rp.spp >= 2 * kSplatPer && env_splat == 0) {
         const uint32_t groups = rp.n_lanes / kSplatPer, seg8 = rp.spp / kSplatPer < 64 ? rp.spp / kSplatPer : 64;
         const int n = 2 * reach + 1;
         const uint32_t lds = (kBlock / seg8) * n * n * 16u;
@@ -1253,7 +1262,7 @@ void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t 
         }
     }
     const bool small_pow2_tent = fast && rp.spp < 2 * kSplatPer;   // 2, 4, 8 spp under the radius-1 tent: k_splat_tent3 (one DPP segment per pixel)
-    if ((rp.filter == FILTER_BOX || (reach >= 1 && reach <= 2)) && !small_pow2_tent && env_splat == 0) {
+    if ((rp.filter == FILTER_BOX || (reach >= 1 && reach <= 2)) && !lanczos && !small_pow2_tent && env_splat == 0) {
         // any other sample count: one thread per pixel; enough threads to fill the chip (parts of a pixel's samples, each >= 8, when the frame is small)
         const uint32_t n_pixels = rp.n_lanes / rp.spp, n = 2 * reach + 1;
         uint32_t parts = 1;

@@ -953,7 +953,7 @@ int dtof_eval_component(int component, const float *params, int n_params, const 
         RenderParams rp; memset(&rp, 0, sizeof rp);
         if (component == COMP_RFILTER) {
             const int kind = (int) a.p[0];
-            if (kind < FILTER_BOX || kind > FILTER_CATMULLROM || !(a.p[1] > 0.f)) throw std::runtime_error("unknown filter / non-positive radius");
+            if (kind < FILTER_BOX || kind > FILTER_LANCZOS || !(a.p[1] > 0.f)) throw std::runtime_error("unknown filter / non-positive radius");
             set_filter(rp, kind, a.p[1], a.p[2], a.p[3], a.p[4]);
         }
         DevBuf<float> din, dout; din.ensure((size_t) n * in_stride); dout.ensure((size_t) n * out_stride);

@@ -927,7 +927,8 @@ static void make_sensor(const Obj &o, HostScene &sc) {
                 se.filter_b = (float) rf.props.get_float("B", 1.f / 3.f); se.filter_c = (float) rf.props.get_float("C", 1.f / 3.f);
             }
             else if (rf.plugin == "catmullrom") { se.filter = FILTER_CATMULLROM; se.filter_radius = 2.f; }   // src/rfilters/catmullrom.cpp:33-36
-            else fail("unsupported rfilter plugin \"" + rf.plugin + "\" (supported: tent, box, gaussian, mitchell, catmullrom)");
+            else if (rf.plugin == "lanczos") { se.filter = FILTER_LANCZOS; se.filter_radius = (float) rf.props.get_int("lobes", 3); }   // src/rfilters/lanczos.cpp:47-50
+            else fail("unsupported rfilter plugin \"" + rf.plugin + "\" (supported: tent, box, gaussian, mitchell, catmullrom, lanczos)");
             have_filter = true;
         }
         auto u = film->props.unqueried();

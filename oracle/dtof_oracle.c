@@ -2019,8 +2019,17 @@ static float catmullrom_eval(float x) {
     return x < 2.f ? r : 0.f;
 }
 /* ReconstructionFilter::eval of the film's filter: src/rfilters/tent.cpp:53-55, gaussian.cpp:94-98, mitchell.cpp:60-79, catmullrom.cpp:39-52 */
+/* LanczosSincFilter::eval (src/rfilters/lanczos.cpp:52-63): radius = lobes; dr::sin is the sine of orc_sincos */
+static float lanczos_eval(float x, float radius) {
+    x = fabsf(x);
+    float x1 = ORC_PI_F * x, x2 = x1 / radius, s1, s2, c;
+    orc_sincos(x1, &s1, &c); orc_sincos(x2, &s2, &c);
+    float result = (s1 * s2) / (x1 * x2);
+    return x < ORC_EPSILON_F ? 1.f : (x > radius ? 0.f : result);
+}
 static float filter_eval(const orc_sensor *se, float x, float inv_r, const float *gc) {
     switch (se->filter) {
+        case ORC_FILTER_LANCZOS:    return lanczos_eval(x, se->filter_radius);
         case ORC_FILTER_GAUSSIAN:   return f_max(estrin10(x * x, gc), 0.f);
         case ORC_FILTER_MITCHELL:   return mitchell_eval(x, se->filter_b, se->filter_c);
         case ORC_FILTER_CATMULLROM: return catmullrom_eval(x);

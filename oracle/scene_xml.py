@@ -927,6 +927,8 @@ def _sensor_record(sp):
                 fb, fc = float(F32(rf.get_f("B", float(F32(1.0) / F32(3.0))))), float(F32(rf.get_f("C", float(F32(1.0) / F32(3.0)))))
             elif rf.plugin == "catmullrom":  # catmullrom.cpp:33-36
                 filt, radius = 4, 2.0
+            elif rf.plugin == "lanczos":     # lanczos.cpp:47-50: radius = lobes
+                filt, radius = 5, float(rf.get_i("lobes", 3))
             else:
                 raise ValueError('unsupported rfilter plugin "%s"' % rf.plugin)
     else:

@@ -39,7 +39,7 @@ class Transform:
 _SHAPES = ("rectangle", "sphere", "disk", "cube", "cylinder", "obj", "ply")
 _BSDFS = ("diffuse", "twosided", "conductor", "dielectric", "plastic", "thindielectric", "roughconductor", "roughdielectric", "roughplastic")
 _EMITTERS = ("point", "area", "spot")
-_FILTERS = ("box", "tent", "gaussian", "mitchell", "catmullrom")
+_FILTERS = ("box", "tent", "gaussian", "mitchell", "catmullrom", "lanczos")
 _POINT_NAMES = ("center", "position", "origin", "target", "p0", "p1")
 
 
@@ -286,7 +286,7 @@ class FilterFacade:
         self.kind = _FILTERS.index(kind)
         self.stddev = float(d.get("stddev", 0.5))
         self.B, self.C = float(d.get("B", 1 / 3)), float(d.get("C", 1 / 3))
-        self.radius = float({"box": 0.5, "tent": d.get("radius", 1.0), "gaussian": 4 * self.stddev, "mitchell": 2.0, "catmullrom": 2.0}[kind])
+        self.radius = float({"box": 0.5, "tent": d.get("radius", 1.0), "gaussian": 4 * self.stddev, "mitchell": 2.0, "catmullrom": 2.0, "lanczos": d.get("lobes", 3)}[kind])
 
     def eval(self, x, *a):
         return self.be.filter_eval(self.kind, self.radius, self.stddev, self.B, self.C, float(x))

@@ -224,7 +224,9 @@ def test_modulation_functions_match_oracle(mi, orc):
                                   # the same filters at power-of-two spp >= 16: the eight-samples-per-lane splat (k_splat_x8) instead of per-sample atomics
                                   "gaussian_default@16", "mitchell@32", "catmullrom@64", "tent_wide@16", "box@16", "box@128", "gaussian_narrow@16",
                                   # sample counts that are no power of two, or below 16: one thread per pixel (k_splat_pixel)
-                                  "tent@48", "tent@12", "gaussian_default@12", "gaussian_default@4", "mitchell@5", "catmullrom@24", "tent_wide@6", "box@24", "gaussian_narrow@100"])
+                                  "tent@48", "tent@12", "gaussian_default@12", "gaussian_default@4", "mitchell@5", "catmullrom@24", "tent_wide@6", "box@24", "gaussian_narrow@100",
+                                  # the windowed sinc (src/rfilters/lanczos.cpp): radius = lobes, 7 x 7 footprint by default, negative lobes
+                                  "lanczos", "lanczos@16", "lanczos_2lobes@16", "lanczos_1lobe@5"])
 def test_edge_cases_against_oracle(mi, orc, case):
     base = open(os.path.join(SCENES, "cornell_boxes.xml")).read()
     params, spp, xml = dict(resx=24, resy=24), 8, base
@@ -275,6 +277,9 @@ def test_edge_cases_against_oracle(mi, orc, case):
         xml = base.replace('<rfilter type="tent" />', '<rfilter type="mitchell"><float name="B" value="0.2" /><float name="C" value="0.7" /></rfilter>')
     elif case == "catmullrom":
         xml = base.replace('<rfilter type="tent" />', '<rfilter type="catmullrom" />')
+    elif case.startswith("lanczos"):
+        lobes = {"lanczos": "", "lanczos_2lobes": '<integer name="lobes" value="2" />', "lanczos_1lobe": '<integer name="lobes" value="1" />'}[case]
+        xml = base.replace('<rfilter type="tent" />', '<rfilter type="lanczos">%s</rfilter>' % lobes)
     elif case == "depth0":            # max_depth = 0: the loop never runs (dopplertofpath.cpp:96-98)
         params["max_depth"] = 0
     elif case == "no_emitters":       # nothing to sample, nothing to hit: all-zero image, the sampler still draws

@@ -254,7 +254,7 @@ def test_independent_and_timestratified_samplers(orc):
 
 @pytest.mark.parametrize("rfilter,exact", [('<rfilter type="tent" />', True), ('<rfilter type="mitchell" />', True),
                                            ('<rfilter type="catmullrom" />', True), ('<rfilter type="mitchell"><float name="B" value="0.2" /><float name="C" value="0.7" /></rfilter>', True),
-                                           ("", False)])
+                                           ("", False), ('<rfilter type="lanczos" />', False)])
 def test_reconstruction_filters_are_partitions_of_unity(orc, rfilter, exact):
     """tent, Mitchell-Netravali (any B, C) and Catmull-Rom satisfy sum_k f(x + k) = 1, so the weight channel of a sample whose
     footprint lies inside the film sums to exactly one sample (src/rfilters/{tent,mitchell,catmullrom}.cpp); the default
