@@ -93,7 +93,7 @@ int dtof_scene_get_info(const dtof_scene *scene, dtof_scene_info *info);
 /* Flat float32 export of what the loader produced (parity of the XML semantics, row X1):
  * kind 0: object keyframes  -> per object 2+32 floats (t0,t1, key0[16], key1[16]) , rows of `out`
  * kind 1: shape transforms  -> per shape 32 floats (to_world[16], to_object[16])
- * kind 2: sensor            -> to_world[16], x_fov, near, far, shutter_open, shutter_close, thinlens (0 / 1), aperture_radius, focus_distance
+ * kind 2: sensor            -> to_world[16], x_fov, near, far, shutter_open, shutter_close, sensor kind (0 perspective, 1 thinlens, 2 orthographic), aperture_radius, focus_distance
  * kind 3: emitters          -> per emitter position[3], intensity[3]
  * kind 4..7: baked mesh data -> positions / vertex normals / texcoords / faces (uint32 bit patterns) of all mesh
  *                             shapes (cube, obj, ply) concatenated in shape order (cube.cpp:114-160, obj.cpp, ply.cpp)

@@ -17,6 +17,7 @@ struct RenderParams {
     float s2c[16];                  // sample_to_camera
     float cam_to_world[12];
     float near_clip, far_clip, shutter_open, shutter_open_time;
+    int32_t orthographic;                    // OrthographicCamera (src/sensors/orthographic.cpp:169-196)
     float aperture_radius, focus_distance;   // ThinLensCamera (src/sensors/thinlens.cpp:257-305); aperture_radius == 0: perspective
     // ---- film (lane -> pixel mapping src/render/integrator.cpp:273-290; splat imageblock.cpp:414-531)
     int32_t crop_x, crop_y, crop_w, crop_h;

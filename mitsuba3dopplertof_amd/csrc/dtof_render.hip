@@ -163,6 +163,12 @@ void sample_to_camera(const HostSensor &s, float *inv_out) {
     m4_identity(S2i); S2i[0] = rcp(-0.5f); S2i[5] = rcp(-0.5f * aspect);
     m4_identity(T2i); T2i[3] = 1.f; T2i[7] = 1.f / aspect;
     memset(Pi, 0, 64); Pi[0] = tanv; Pi[5] = tanv; Pi[15] = rcp(near_); Pi[11] = 1.f; Pi[14] = (near_ - far_) / (far_ * near_);
+    if (s.orthographic) {   // orthographic_projection (sensor.h:266-299): the last factor is scale(1, 1, 1 / (far - near)) * translate(0, 0, -near) (transform.h:242-245)
+        float OT[16], OS[16];
+        m4_identity(OT); OT[11] = near_;
+        m4_identity(OS); OS[0] = rcp(1.f); OS[5] = rcp(1.f); OS[10] = rcp(1.f / (far_ - near_));
+        m4_mul(OT, OS, Pi);
+    }
     m4_mul(T1i, S1i, tmp); m4_mul(S2i, tmp, tmp); m4_mul(T2i, tmp, tmp); m4_mul(Pi, tmp, inv_out);
 }
 
@@ -186,6 +192,7 @@ RenderParams make_params(const dtof_scene *sc, uint32_t seed, uint32_t spp, cons
     memcpy(rp.cam_to_world, se.to_world, 48);
     rp.near_clip = se.near_clip; rp.far_clip = se.far_clip; rp.shutter_open = se.shutter_open;
     rp.shutter_open_time = se.shutter_close - se.shutter_open;
+    rp.orthographic = se.orthographic ? 1 : 0;
     rp.aperture_radius = se.thinlens ? se.aperture_radius : 0.f; rp.focus_distance = se.focus_distance;
     rp.crop_x = se.crop_x; rp.crop_y = se.crop_y; rp.crop_w = se.crop_w; rp.crop_h = se.crop_h;
     rp.scale_x = 1.f / (float) se.crop_w; rp.scale_y = 1.f / (float) se.crop_h;
@@ -665,7 +672,7 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
             const HostSensor &s = sc->host.sensor;
             v.insert(v.end(), s.to_world, s.to_world + 16);
             v.push_back(s.x_fov); v.push_back(s.near_clip); v.push_back(s.far_clip); v.push_back(s.shutter_open); v.push_back(s.shutter_close);
-            v.push_back(s.thinlens ? 1.f : 0.f); v.push_back(s.aperture_radius); v.push_back(s.focus_distance);
+            v.push_back(s.orthographic ? 2.f : s.thinlens ? 1.f : 0.f); v.push_back(s.aperture_radius); v.push_back(s.focus_distance);
         } else if (kind == 3) for (auto &e : sc->host.emitters) {
             v.insert(v.end(), e.pos, e.pos + 3); v.insert(v.end(), e.intensity, e.intensity + 3);
         } else if (kind >= 4 && kind <= 7) for (auto &s : sc->host.shapes) {

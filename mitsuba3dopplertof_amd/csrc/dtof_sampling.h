@@ -187,6 +187,16 @@ DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane, bool wav
     float iw = rcp(r3);
     V3 near_p = mk(r0 * iw, r1 * iw, r2 * iw);
     V3 d, o;
+    if (rp.orthographic) {   // OrthographicCamera::sample_ray_differential (orthographic.cpp:169-196): parallel rays from the near plane
+        if (doppler) time = time < rp.T ? time : time - rp.T;   // dopplertofpath.cpp:93
+        o = xf_point(rp.cam_to_world, near_p);
+        const V3 dir = normalize(xf_vector(rp.cam_to_world, mk(0.f, 0.f, 1.f)));
+        PrimaryLane po;
+        po.ray_a = make_float4(o.x, o.y, o.z, time);
+        po.ray_b = make_float4(dir.x, dir.y, dir.z, rp.far_clip - rp.near_clip);
+        po.main = main; po.path = path; po.pos = make_float2(spx, spy);
+        return po;
+    }
     if (lens) {   // ThinLensCamera::sample_ray_differential_impl (thinlens.cpp:257-305)
         float tx, ty; concentric_disk(apx, apy, tx, ty);
         const V3 aperture_p = mk(rp.aperture_radius * tx, rp.aperture_radius * ty, 0.f);

@@ -174,6 +174,7 @@ struct HostSensor {
     float x_fov = 0, near_clip = 1e-2f, far_clip = 1e4f, shutter_open = 0, shutter_close = 0;
     int32_t film_w = 768, film_h = 576, crop_x = 0, crop_y = 0, crop_w = 768, crop_h = 576;
     int32_t filter = FILTER_TENT; float filter_radius = 1.f, filter_stddev = .5f, filter_b = 1.f / 3.f, filter_c = 1.f / 3.f;   // B, C: mitchell
+    bool orthographic = false;   // src/sensors/orthographic.cpp
     bool thinlens = false; float aperture_radius = 0.f, focus_distance = 0.f;   // src/sensors/thinlens.cpp:138-156, src/render/sensor.cpp:134
 };
 

@@ -895,8 +895,10 @@ static double parse_fov(const Obj &s, double aspect) {   // src/render/sensor.cp
 }
 
 static void make_sensor(const Obj &o, HostScene &sc) {
-    if (o.plugin != "perspective" && o.plugin != "thinlens") fail("unsupported sensor plugin \"" + o.plugin + "\" (supported: perspective, thinlens)");
+    if (o.plugin != "perspective" && o.plugin != "thinlens" && o.plugin != "orthographic")
+        fail("unsupported sensor plugin \"" + o.plugin + "\" (supported: perspective, thinlens, orthographic)");
     HostSensor &se = sc.sensor;
+    se.orthographic = o.plugin == "orthographic";
     const Obj *film = nullptr, *sampler = nullptr;
     for (auto &c : o.children) {
         if (c.first == "film") { if (film) fail("Only one film can be specified per sensor."); film = c.second.get(); }
@@ -940,7 +942,7 @@ static void make_sensor(const Obj &o, HostScene &sc) {
     auto t = o.transforms.find("to_world");
     to_f32(t != o.transforms.end() ? t->second.m : m_identity(), se.to_world);
     // perspective.cpp:143-144 / thinlens.cpp:149-150: Transform::has_scale (transform.h:325-337)
-    for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) {
+    for (int i = 0; i < 3 && !se.orthographic; ++i) for (int j = i; j < 3; ++j) {   // the orthographic camera takes its extent from the scale of to_world
         float sum = 0.f;
         for (int k = 0; k < 3; ++k) sum += se.to_world[4 * i + k] * se.to_world[4 * j + k];
         if (std::fabs(sum - (i == j ? 1.f : 0.f)) > 1e-3f) fail("Scale factors in the camera-to-world transformation are not allowed!");
@@ -952,7 +954,7 @@ static void make_sensor(const Obj &o, HostScene &sc) {
     se.far_clip = (float) o.props.get_float("far_clip", 1e4f);
     if (se.near_clip <= 0.f) fail("The 'near_clip' parameter must be greater than zero!");
     if (se.near_clip >= se.far_clip) fail("The 'near_clip' parameter must be smaller than 'far_clip'.");
-    se.x_fov = (float) parse_fov(o, se.film_w / (double) se.film_h);
+    se.x_fov = se.orthographic ? 0.f : (float) parse_fov(o, se.film_w / (double) se.film_h);
     se.focus_distance = (float) o.props.get_float("focus_distance", se.far_clip);   // ProjectiveCamera (sensor.cpp:134): read by both cameras
     if (o.plugin == "thinlens") {   // thinlens.cpp:138-156
         if (!o.props.has("aperture_radius")) fail("Property \"aperture_radius\" has not been specified!");

@@ -672,6 +672,14 @@ static void camera_sample_to_camera(const orc_sensor *s, float *inv_out) {
     memset(Pi, 0, 64);                                            /* transform.h:226-230 inv_trafo */
     Pi[0] = tanv; Pi[5] = tanv; Pi[10] = 0.f; Pi[15] = f_rcp(near_);
     Pi[11] = 1.f; Pi[14] = (near_ - far_) / (far_ * near_);
+    if (s->kind == ORC_SENSOR_ORTHOGRAPHIC) {
+        /* orthographic_projection (sensor.h:266-299) ends in Transform::orthographic = scale(1, 1, 1 / (far - near)) * translate(0, 0, -near)
+         * (transform.h:242-245); its inverse is translate(0, 0, near) * scale(rcp of the factors) */
+        float OT[16], OS[16];
+        m4_identity(OT); OT[11] = near_;
+        m4_identity(OS); OS[0] = f_rcp(1.f); OS[5] = f_rcp(1.f); OS[10] = f_rcp(1.f / (far_ - near_));
+        m4_mul(OT, OS, Pi);
+    }
     /* (S1*T1*S2*T2*P)^-1 = P^-1*(T2^-1*(S2^-1*(T1^-1*S1^-1))) */
     m4_mul(T1i, S1i, tmp); m4_mul(S2i, tmp, tmp); m4_mul(T2i, tmp, tmp); m4_mul(Pi, tmp, inv_out);
 }
@@ -690,6 +698,12 @@ static orc_ray camera_ray(const orc_sensor *s, const float *s2c, float ux, float
     float iw = f_rcp(r3);
     v3 near_p = V(r0 * iw, r1 * iw, r2 * iw);
     orc_ray ray; v3 d;
+    if (s->kind == ORC_SENSOR_ORTHOGRAPHIC) {   /* OrthographicCamera::sample_ray_differential (src/sensors/orthographic.cpp:169-196) */
+        ray.o = m_point(s->to_world, near_p);
+        ray.d = v_normalize(m_vector(s->to_world, V(0.f, 0.f, 1.f)));
+        ray.maxt = s->far_clip - s->near_clip;
+        return ray;
+    }
     if (s->kind == ORC_SENSOR_THINLENS) {
         float tx, ty; concentric_disk(a_x, a_y, &tx, &ty);
         v3 aperture_p = V(s->aperture_radius * tx, s->aperture_radius * ty, 0.f);

@@ -151,11 +151,11 @@ typedef struct {
     float   filter_radius;
     float   filter_stddev;   /* gaussian only (radius = 4 stddev, src/rfilters/gaussian.cpp:48-53) */
     float   filter_b, filter_c;   /* mitchell only: the B and C of the paper (src/rfilters/mitchell.cpp:38-45), radius 2 */
-    int32_t kind;            /* ORC_SENSOR_*: perspective (src/sensors/perspective.cpp) or thinlens (src/sensors/thinlens.cpp) */
+    int32_t kind;            /* ORC_SENSOR_*: src/sensors/{perspective,thinlens,orthographic}.cpp */
     float   aperture_radius; /* thinlens only (thinlens.cpp:142-147: 0 becomes dr::Epsilon<Float>) */
     float   focus_distance;  /* thinlens only (src/render/sensor.cpp:134: default far_clip) */
 } orc_sensor;
-enum { ORC_SENSOR_PERSPECTIVE = 0, ORC_SENSOR_THINLENS = 1 };
+enum { ORC_SENSOR_PERSPECTIVE = 0, ORC_SENSOR_THINLENS = 1, ORC_SENSOR_ORTHOGRAPHIC = 2 };
 
 typedef struct {
     /* dopplertofpath.cpp:19-57 (all already rounded the way the ctor rounds them) */

@@ -903,7 +903,7 @@ def _parse_fov(sp, aspect):
 
 
 def _sensor_record(sp):
-    if sp.plugin not in ("perspective", "thinlens"):
+    if sp.plugin not in ("perspective", "thinlens", "orthographic"):
         raise ValueError('unsupported sensor plugin "%s"' % sp.plugin)
     film = next((c[1] for c in sp.children if c[0] == "film"), None)
     w, h, cx, cy = 768, 576, 0, 0
@@ -941,9 +941,9 @@ def _sensor_record(sp):
     near, far = sp.get_f("near_clip", 1e-2), sp.get_f("far_clip", 1e4)
     # perspective.cpp:143-144 / thinlens.cpp:149-150 (Transform::has_scale, transform.h:325-337)
     m3 = np.asarray(_m32(tw), np.float32).reshape(4, 4)[:3, :3]
-    if np.any(np.abs(m3 @ m3.T - np.eye(3, dtype=np.float32)) > 1e-3):
+    if sp.plugin != "orthographic" and np.any(np.abs(m3 @ m3.T - np.eye(3, dtype=np.float32)) > 1e-3):
         raise ValueError("Scale factors in the camera-to-world transformation are not allowed!")
-    lens = dict(kind=0, aperture_radius=F32(0), focus_distance=F32(sp.get_f("focus_distance", float(F32(far)))))
+    lens = dict(kind=2 if sp.plugin == "orthographic" else 0, aperture_radius=F32(0), focus_distance=F32(sp.get_f("focus_distance", float(F32(far)))))
     if sp.plugin == "thinlens":   # thinlens.cpp:138-156; focus_distance: sensor.cpp:134
         if "aperture_radius" not in sp:
             raise ValueError('Property "aperture_radius" has not been specified!')
@@ -951,7 +951,7 @@ def _sensor_record(sp):
         if ar == 0:
             ar = F32(2.0 ** -24)   # dr::Epsilon<float>
         lens = dict(kind=1, aperture_radius=ar, focus_distance=F32(sp.get_f("focus_distance", float(F32(far)))))
-    return dict(**lens, to_world=_m32(tw), x_fov=F32(_parse_fov(sp, w / float(h))), near_clip=F32(near), far_clip=F32(far),
+    return dict(**lens, to_world=_m32(tw), x_fov=F32(0 if sp.plugin == "orthographic" else _parse_fov(sp, w / float(h))), near_clip=F32(near), far_clip=F32(far),
                 shutter_open=F32(so), shutter_close=F32(sc), film_w=w, film_h=h, crop_x=cx, crop_y=cy,
                 crop_w=cw, crop_h=ch, filter=filt, filter_radius=F32(radius), filter_stddev=F32(stddev), filter_b=F32(fb), filter_c=F32(fc))
 

@@ -55,6 +55,7 @@ FILES = [
     "src/emitters/tests/test_spot.py",
     "src/sensors/tests/test_perspective.py",    # C1
     "src/sensors/tests/test_thinlens.py",       # D2 (the aperture draw), 8(f) thinlens sensor
+    "src/sensors/tests/test_orthographic.py",   # 8(f) orthographic sensor
     "src/render/tests/test_imageblock.py",      # I1
     "src/bsdfs/tests/test_diffuse.py",          # M1
     "src/bsdfs/tests/test_twosided.py",
@@ -463,9 +464,9 @@ class Interp:
                     return lambda v, **kw: v
                 raise Unknown(full)
             if base.name.startswith("mi"):
-                if base.name == "mi" and a in MI_NUMERIC:
+                if base.name in ("mi", "mi.scalar_rgb") and a in MI_NUMERIC:
                     return MI_NUMERIC[a]
-                if base.name == "mi" and a in ("Transform4f", "ScalarTransform4f"):
+                if base.name in ("mi", "mi.scalar_rgb") and a in ("Transform4f", "ScalarTransform4f"):
                     return XFTYPE
                 return Namespace(full) if a[0].islower() and a in ("warp", "chi2", "math", "quad", "spline", "scalar_rgb", "test", "util", "mueller", "xml", "python") \
                     else Sym("name", name=full)

@@ -54,7 +54,7 @@ def _tag_of(plugin):
         return "rfilter"
     if plugin == "hdrfilm":
         return "film"
-    if plugin in ("perspective", "thinlens"):
+    if plugin in ("perspective", "thinlens", "orthographic"):
         return "sensor"
     if plugin in ("independent", "correlated"):
         return "sampler"
@@ -503,9 +503,21 @@ _OPS = {
     "GtE": lambda a, b: a >= b, "And": lambda a, b: np.logical_and(a, b), "Or": lambda a, b: np.logical_or(a, b),
     "USub": lambda a: -a, "Not": lambda a: np.logical_not(a), "Mod": lambda a, b: a % b,
 }
+def _dot(a, b):
+    """dr.dot of Dr.Jit vectors: coordinates first, so a (3, n) array of n vectors dotted with one (3,) vector gives n values"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if a.ndim == 2 and b.ndim == 1:
+        return (a * b[:, None]).sum(axis=0)
+    if a.ndim == 1 and b.ndim == 2:
+        return (a[:, None] * b).sum(axis=0)
+    if a.ndim == 2 and b.ndim == 2:
+        return (a * b).sum(axis=0)
+    return np.dot(a, b)
+
+
 _DRFN = {
     "dr.abs": np.abs, "dr.sqrt": np.sqrt, "dr.cos": np.cos, "dr.sin": np.sin, "dr.acos": np.arccos, "dr.asin": np.arcsin, "dr.tan": np.tan,
-    "dr.norm": lambda v: np.linalg.norm(np.asarray(v, np.float64)), "dr.dot": lambda a, b: np.dot(np.asarray(a, np.float64), np.asarray(b, np.float64)),
+    "dr.norm": lambda v: np.linalg.norm(np.asarray(v, np.float64)), "dr.dot": lambda a, b: _dot(a, b),
     "dr.normalize": lambda v: np.asarray(v, np.float64) / np.linalg.norm(np.asarray(v, np.float64)), "dr.rcp": lambda x: 1.0 / x,
     "dr.select": lambda c, a, b: np.where(c, a, b), "dr.sqr": lambda x: x * x, "dr.maximum": np.maximum, "dr.minimum": np.minimum,
     "dr.max": np.max, "dr.min": np.min, "dr.sum": np.sum, "dr.exp": np.exp, "dr.log": np.log, "fn.vector": lambda *a: np.asarray(a[0] if len(a) == 1 else a, np.float64),
@@ -703,7 +715,7 @@ class Evaluator:
             return BsdfFacade(self.be, to_xml(None, d, "    "))
         if t in _FILTERS or t == "lanczos":
             return FilterFacade(self.be, d)
-        if t in ("perspective", "thinlens"):
+        if t in ("perspective", "thinlens", "orthographic"):
             return Sensor(self.be, d)
         raise Skip("load_dict of plugin '%s'" % t)
 

@@ -107,9 +107,9 @@ class OracleBackend:
 
     def camera_ray(self, sc, px, py, ax=.5, ay=.5):
         out = np.zeros(7, np.float32)
-        if sc.c.sensor.kind == 0:
+        if sc.c.sensor.kind == 0:   # film position in pixels
             self.L.orc_camera_ray(C.byref(sc.c.sensor), px, py, out.ctypes.data_as(C.POINTER(C.c_float)))
-        else:   # ThinLensCamera: position sample in [0, 1]^2 of the crop window, aperture sample
+        else:   # ThinLensCamera / OrthographicCamera: position sample in [0, 1]^2 of the crop window, aperture sample
             se = sc.c.sensor
             self.L.orc_camera_sample_ray(C.byref(se), (px - se.crop_x) / se.crop_w, (py - se.crop_y) / se.crop_h, ax, ay, out.ctypes.data_as(C.POINTER(C.c_float)))
         return out[0:3].copy(), out[3:6].copy()
@@ -135,6 +135,7 @@ PINNED = {
     "src/shapes/tests/test_cube.py": ("G3 cube mesh", 100),
     "src/shapes/tests/test_cylinder.py": ("8(f)-3 cylinder", 300),
     "src/sensors/tests/test_perspective.py": ("C1 perspective camera", 20),
+    "src/sensors/tests/test_orthographic.py": ("8(f) orthographic sensor: constructor, ray origins on the near plane, parallel directions", 40),
     "src/sensors/tests/test_thinlens.py": ("D2 aperture sample / thinlens camera: constructor, sample_ray with aperture samples, fov axes", 200),
     "src/render/tests/test_imageblock.py": ("I1 ImageBlock::put", 1),
     "src/bsdfs/tests/test_diffuse.py": ("M1 diffuse", 30),

@@ -1,4 +1,5 @@
-"""`thinlens` sensor (src/sensors/thinlens.cpp) and the aperture draw of render_sample (src/render/integrator.cpp:421-423,490-492).
+"""`thinlens` and `orthographic` sensors (src/sensors/{thinlens,orthographic}.cpp) and the aperture draw of render_sample
+(src/render/integrator.cpp:421-423,490-492).
 
 CPU: the oracle's camera against closed forms (rays through one film point meet on the focal plane; the origin lies on the lens, pushed to the
 near plane), the draw order of a lane (pixel jitter, aperture sample, time sample) and the loader's error behaviour.  The reference's own
@@ -114,6 +115,57 @@ def test_thinlens_loader_errors(who, orc, request):
     if who == "product":   # ... while aperture_radius is nobody's there (xml.cpp:1204-1215; the oracle's reader does not track queried properties)
         with pytest.raises(err, match='unreferenced property "aperture_radius"'):
             load(scene_text("perspective", LENS))
+
+
+ORTHO_XF = '<scale x="2.5" y="2" z="1"/>'   # the extent of an orthographic view is the scale of to_world: a 5 x 4 window here
+
+
+def ortho_text(pcd=2):
+    return scene_text("orthographic", "", ORTHO_XF, pcd).replace('<float name="fov" value="30"/>', "")
+
+
+def test_orthographic_rays_are_parallel_and_start_on_the_near_plane(orc):
+    """orthographic.cpp:169-196 with orthographic_projection (sensor.h:266-299): one direction (the normalised image of +z), origins on the plane
+    z = near_clip of camera space, spread linearly over [-1, 1] x [-1 / aspect, 1 / aspect] (x flipped: sample (0, 0) is the top-left pixel, camera +x
+    points left) times the scale of to_world; maxt = far - near; no aperture draw."""
+    sc = orc.Scene(ortho_text(), is_string=True)
+    se = sc.flat.sensor
+    assert se["kind"] == 2
+    to_world = np.asarray(se["to_world"], np.float64).reshape(4, 4)
+    inv = np.linalg.inv(to_world)
+    zdir = to_world[:3, 2] / np.linalg.norm(to_world[:3, 2])
+    aspect = 24 / 16
+    for ux, uy in [(0, 0), (1, 1), (.5, .5), (.25, .8)]:
+        o, d, maxt = oracle_ray(orc, sc, ux, uy, .1, .9)
+        assert np.allclose(d, zdir, atol=1e-6) and abs(maxt - 49.5) < 1e-4
+        ol = (inv @ np.append(o, 1))[:3]
+        assert np.allclose(ol, [1 - 2 * ux, (1 - 2 * uy) / aspect, 0.5], atol=1e-5)
+    lanes = sc.render_lanes(sc.params(), 7, 8, 0, 64, threads=1)
+    pin = orc.Scene(scene_text("perspective", ""), is_string=True)
+    ref = pin.render_lanes(pin.params(), 7, 8, 0, 64, threads=1)
+    assert np.array_equal(lanes["sample_pos"], ref["sample_pos"]) and np.array_equal(lanes["time"], ref["time"])   # same draws as the pinhole camera
+    assert np.all(lanes["ray_d"] == lanes["ray_d"][0])
+
+
+@pytest.mark.gpu
+def test_orthographic_lanes_and_image_match_the_oracle(mi, orc):
+    """bit-identical lanes and an image within 1e-3 for the orthographic camera (Doppler and plain path integrators); the loader takes the scale
+    in to_world that the perspective cameras refuse"""
+    for integ in ("dopplertofpath", "path"):
+        text = ortho_text().replace('type="dopplertofpath"', 'type="%s"' % integ)
+        if integ == "path":
+            text = text.replace('<integer name="path_correlation_depth" value="2"/>', "")
+        sc, osc = mi.load_string(text), orc.Scene(text, is_string=True)
+        assert float(sc.export(2)[21]) == 2.0
+        n = 24 * 16 * 8
+        ours = sc.sample_lanes(3, 8, 0, n)
+        ref = osc.render_lanes(osc.params(), 3, 8, 0, n, threads=NCPU)
+        for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+            assert np.array_equal(np.ascontiguousarray(ours[k]).view(np.uint32), np.ascontiguousarray(ref[k], np.float32).view(np.uint32)), (integ, k)
+        assert (ref["rgb"] != 0).any()
+        img = sc.render(seed=3, spp=8)
+        exp, _ = osc.render(osc.params(), seed=3, spp=8, threads=NCPU)
+        assert rel_linf(img, exp) <= IMG_TOL
 
 
 @pytest.mark.gpu
