@@ -137,7 +137,10 @@ struct ShadeArgs {
     const uint32_t *qin, *count_in; uint32_t *qout, *alive_out, *shadow_out; uint32_t depth, trace_next; LaneDebug *dbg;
 };
 template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, bool SPEC>
-__global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : (MODE != 0 && MESH) ? 3 : 1) void k_shade(ShadeArgs args_by_value) {
+#ifndef DTOF_MESH_WAVES
+#define DTOF_MESH_WAVES 3   // waves / SIMD the fused kernels with triangle code are compiled for (A/B: make variant DEFS=-DDTOF_MESH_WAVES=4)
+#endif
+__global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : (MODE != 0 && MESH) ? DTOF_MESH_WAVES : 1) void k_shade(ShadeArgs args_by_value) {
     constexpr bool FUSED = MODE != 0, FIRST = MODE == 2;
     extern __shared__ uint4 lds[];
     __shared__ uint32_t s_cnt[4];
