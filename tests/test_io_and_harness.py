@@ -260,3 +260,71 @@ def test_the_tutorial_call_sequence_runs_as_is(mi):
     mean = total / 3
     assert mean.shape == (24, 24, 3) and np.isfinite(mean).all()
     assert np.allclose(mean, mi.render_multi_pass(scene, integrator, 48, 16), rtol=0, atol=1e-6 * np.abs(mean).max())
+
+
+def test_error_tables_of_the_experiment_grids(tmp_path):
+    """analysis.export_error / error_curves / plot_experiment against main_plot.py:20-104 restated with plain numpy on a synthetic 3 x 3 grid:
+    the six error columns (PSNR = 10 log10(range^2 / MSE) of the exposure-scaled images), the per-frequency mean and ddof-1 deviation over the
+    offsets, the experiment names and folders of the three figures, the resume switch."""
+    from mitsuba3dopplertof_amd import analysis
+    rng = np.random.default_rng(11)
+    base = str(tmp_path)
+    family, out_family, names = analysis.experiment_expnames(1)
+    assert family == "time_spatial_sampling_comparison" and out_family == "time_spatial_sampling_comparison_full_plot"
+    assert names[:3] == ["uniform_path_corr_depth_0", "uniform_path_corr_depth_16", "stratified_path_corr_depth_0"] and len(names) == 8
+    assert analysis.experiment_expnames(2)[2][:3] == ["uniform_path_corr_depth_16", "stratified_path_corr_depth_16", "stratified_path_corr_depth_16_no_further_stratification"]
+    assert analysis.experiment_expnames(3, "antithetic_mirror")[2][3] == "antithetic_mirror_shift_0.3" and len(analysis.experiment_expnames(3)[2]) == 11
+    grid, T = 3, 0.0015
+    images = {}
+    for f in np.linspace(0, 1, grid):
+        for o in np.linspace(0, 1, grid):
+            cell = "freq_%.3f_offset_%.3f" % (f, o)
+            ref = rng.normal(size=(6, 5, 3)).astype(np.float32)
+            d = os.path.join(base, "results", "gt_images", "cornell-box", "sinusoidal", cell); os.makedirs(d)
+            np.save(os.path.join(d, "reference.npy"), ref)
+            d = os.path.join(base, "results", family, "cornell-box", "sinusoidal", cell); os.makedirs(d)
+            for k, n in enumerate(names):
+                img = (ref + rng.normal(scale=0.05 * (k + 1), size=ref.shape)).astype(np.float32)
+                np.save(os.path.join(d, n + ".npy"), img)
+                images[(round(float(f), 3), round(float(o), 3), n)] = (img, ref)
+    tables = analysis.plot_experiment(1, base, ["cornell-box"], ["sinusoidal"], grid=grid, log=lambda *_: None)
+    rows = tables["cornell-box/sinusoidal"]
+    assert len(rows) == grid * grid * len(names)
+    out_dir = os.path.join(base, "results", out_family, "cornell-box", "sinusoidal")
+    back = analysis.read_result(os.path.join(out_dir, "result.csv"))
+    assert back == rows and list(back[0]) == list(analysis.COLUMNS)
+    for r in rows[::7]:
+        img, ref = images[(round(r["freq"], 3), round(r["offset"], 3), r["expname"])]
+        a, b = img * np.float32(T), ref * np.float32(T)
+        mae, rmse = np.mean(np.abs(a - b)), np.sqrt(np.mean((a - b) ** 2))
+        assert np.isclose(r["MAE"], mae, rtol=1e-6) and np.isclose(r["RMSE"], rmse, rtol=1e-6)
+        assert np.isclose(r["RelativeMAE"], mae / np.mean(np.abs(b)), rtol=1e-6) and np.isclose(r["RelativeRMSE"], rmse / np.mean(np.abs(b)), rtol=1e-6)
+        assert np.isclose(r["SNR"], -10 * np.log10(rmse / np.mean(np.abs(b))), rtol=1e-6)
+        mse64 = np.mean((b.astype(np.float64) - a.astype(np.float64)) ** 2)
+        assert np.isclose(r["PSNR"], 10 * np.log10(float(b.max() - b.min()) ** 2 / mse64), rtol=1e-9)
+    curves = analysis.error_curves(rows, names, "freq", "RMSE")
+    x, y, sd = curves[names[2]]
+    assert x.tolist() == [0.0, 0.5, 1.0]
+    v = np.array([r["RMSE"] for r in rows if r["expname"] == names[2] and r["freq"] == 0.5])
+    assert len(v) == grid and np.isclose(y[1], v.mean()) and np.isclose(sd[1], v.std(ddof=1))
+    assert curves[names[7]][1].mean() > curves[names[0]][1].mean()          # the noisier experiment has the larger error
+    xs, ys, ss = analysis.error_curves(rows, names, "offset", "PSNR", other_value=0.5)[names[0]]
+    assert np.all(ss == 0) and np.isclose(ys[0], [r["PSNR"] for r in rows if r["expname"] == names[0] and r["freq"] == 0.5 and r["offset"] == 0.0][0])
+    try:
+        import matplotlib  # noqa: F401
+        assert os.path.getsize(os.path.join(base, "results", out_family, "plot_total.png")) > 10000
+    except ImportError:
+        pass
+    # main_show_image.py: relative RMSE of the luminance images at offset 0 over the frequencies
+    strip = analysis.show_image(names[:2], os.path.join(base, "results", family), "cornell-box/sinusoidal", os.path.join(base, "results", "images_over_hetero_frequency"),
+                                os.path.join(base, "results", "gt_images"), grid=grid, log=lambda *_: None)
+    img, ref = images[(0.5, 0.0, names[1])]
+    lum = lambda v: (0.2126 * v[..., 0] + 0.7152 * v[..., 1] + 0.0722 * v[..., 2]) * T
+    assert np.isclose(strip[names[1]][1], np.sqrt(np.mean((lum(img) - lum(ref)) ** 2)) / np.sqrt(np.mean(lum(ref) ** 2)), rtol=1e-5) and len(strip[names[0]]) == grid
+    assert analysis.main(["--expnumber", "1", "--basedir", base, "--scene_names", "cornell-box", "--grid", str(grid), "--show_images", "--no_plots"]) == 0
+    # exit_if_file_exists: the table is read back, not recomputed
+    os.remove(os.path.join(base, "results", "gt_images", "cornell-box", "sinusoidal", "freq_0.000_offset_0.000", "reference.npy"))
+    again = analysis.export_error(os.path.join(base, "results", family), "cornell-box/sinusoidal", names, os.path.join(base, "results", out_family),
+                                  os.path.join(base, "results", "gt_images"), grid - 1, grid - 1, exit_if_file_exists=True)
+    assert again == rows
+    assert analysis.main(["--expnumber", "1", "--basedir", base, "--scene_names", "cornell-box", "--grid", str(grid), "--no_plots"]) == 0
