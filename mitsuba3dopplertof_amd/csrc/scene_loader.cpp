@@ -18,6 +18,7 @@
 #include "dtof_math.h"
 #include <cmath>
 #include <cstring>
+#include <sys/stat.h>
 #include <fstream>
 #include <sstream>
 #include <memory>
@@ -352,7 +353,27 @@ struct LoadCtx {
     std::vector<std::pair<std::string, std::string>> defaults;   // (name, value)
 };
 
-static void substitute(XNode &n, LoadCtx &ctx) {
+// FileResolver (src/core/fresolver.cpp): the directories a relative file name is looked up in, first match wins; holds the scene file's
+// directory (src/mitsuba/mitsuba.cpp, python load_file) and whatever <path value=".."/> prepends (xml.cpp:651-668)
+static thread_local std::vector<std::string> g_search_paths;
+static bool file_exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+static std::string resolve_path(const std::string &fn) {
+    if (fn.empty() || fn[0] == '/') return fn;
+    for (auto &d : g_search_paths) if (file_exists(d + "/" + fn)) return d + "/" + fn;
+    return g_search_paths.empty() ? fn : g_search_paths.back() + "/" + fn;   // not found: the name under the scene's directory, for the error message
+}
+static std::string slurp(const std::string &path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) fail("could not open \"" + path + "\"");
+    std::stringstream ss; ss << f.rdbuf(); return ss.str();
+}
+constexpr int kMaxIncludeDepth = 15;   // MI_XML_INCLUDE_MAX_RECURSION (xml.cpp:40)
+
+// $parameter substitution in document order (xml.cpp:441-456,630-648), with the two tags that change what later nodes see:
+// <path> (resolver directories, xml.cpp:651-668) and <include> (xml.cpp:670-725: the children of an included <scene>, or the included object itself,
+// take the place of the tag; parameters defined so far carry over, <default>s of the included file stay defined afterwards)
+static void expand_children(XNode &n, LoadCtx &ctx, int depth, int include_depth, const std::string &src_dir);
+static void substitute(XNode &n, LoadCtx &ctx, int depth = 0, int include_depth = 0, const std::string &src_dir = "") {
     if (!ctx.defaults.empty()) {
         auto sorted = ctx.defaults;
         std::stable_sort(sorted.begin(), sorted.end(), [](auto &a, auto &b) { return a.first.size() > b.first.size(); });
@@ -373,7 +394,44 @@ static void substitute(XNode &n, LoadCtx &ctx) {
         bool found = false; for (auto &d : ctx.defaults) if (d.first == name) found = true;
         if (!found) ctx.defaults.emplace_back(name, value);
     }
-    for (auto &c : n.children) substitute(*c, ctx);
+    if (n.tag == "path") {
+        if (depth != 1) fail("<path>: path can only be child of root");
+        std::string p = n.get("value");
+        if (!p.empty() && p[0] != '/') {
+            const std::string local = src_dir.empty() ? p : src_dir + "/" + p;
+            p = file_exists(local) ? local : resolve_path(p);
+        }
+        if (!file_exists(p)) fail("<path>: folder \"" + p + "\" not found");
+        g_search_paths.insert(g_search_paths.begin(), p);
+    }
+    expand_children(n, ctx, depth, include_depth, src_dir);
+}
+static void expand_children(XNode &n, LoadCtx &ctx, int depth, int include_depth, const std::string &src_dir) {
+    for (size_t i = 0; i < n.children.size(); ++i) {
+        XNode &c = *n.children[i];
+        substitute(c, ctx, depth + 1, include_depth, src_dir);
+        if (c.tag != "include") continue;
+        for (auto &a : c.attrs) if (a.first != "filename") fail("unexpected attribute \"" + a.first + "\" in element \"include\"");
+        if (!c.attr("filename")) fail("missing attribute \"filename\" in element \"include\"");
+        const std::string file = resolve_path(c.get("filename"));
+        if (!file_exists(file)) fail("included file \"" + file + "\" not found");
+        if (include_depth + 1 > kMaxIncludeDepth) fail("Exceeded <include> recursion limit of " + std::to_string(kMaxIncludeDepth));
+        const std::string text = slurp(file);
+        XParser xp(text);
+        std::unique_ptr<XNode> root;
+        try { root = xp.document(); } catch (const std::exception &e) { fail("error while loading \"" + file + "\": " + e.what()); }
+        const size_t slash = file.find_last_of('/');
+        const std::string dir = slash == std::string::npos ? std::string(".") : file.substr(0, slash);
+        XNode holder;   // the nodes that take the tag's place: the children of an included <scene> (parsed at depth 1), or the included object (depth 0)
+        int holder_depth = 0;
+        if (root->tag == "scene") holder.children = std::move(root->children);
+        else { holder.children.push_back(std::move(root)); holder_depth = -1; }
+        expand_children(holder, ctx, holder_depth, include_depth + 1, dir);
+        const size_t count = holder.children.size();
+        n.children.erase(n.children.begin() + (long) i);
+        n.children.insert(n.children.begin() + (long) i, std::make_move_iterator(holder.children.begin()), std::make_move_iterator(holder.children.end()));
+        i += count; --i;   // (size_t wrap-around at count == 0, i == 0 is undone by the loop's ++i)
+    }
 }
 
 static std::shared_ptr<Obj> parse_object(const XNode &n, LoadCtx &ctx) {
@@ -383,7 +441,15 @@ static std::shared_ptr<Obj> parse_object(const XNode &n, LoadCtx &ctx) {
         const XNode &c = *cp; std::string name = c.get("name");
         if (!name.empty() && name[0] == '_') fail("invalid parameter name \"" + name + "\": leading underscores are reserved");
         PropValue v;
-        if (c.tag == "default") continue;
+        if (c.tag == "default" || c.tag == "path") continue;
+        else if (c.tag == "alias") {   // xml.cpp:608-628: a second id for an object declared earlier
+            for (auto &a : c.attrs) if (a.first != "id" && a.first != "as") fail("unexpected attribute \"" + a.first + "\" in element \"alias\"");
+            const std::string src = c.get("id"), dst = c.get("as");
+            if (ctx.registry.count(dst)) fail("\"alias\" has duplicate id \"" + dst + "\"");
+            auto it = ctx.registry.find(src);
+            if (it == ctx.registry.end()) fail("referenced id \"" + src + "\" not found");
+            ctx.registry[dst] = it->second;
+        }
         else if (is_object_tag(c.tag)) { o->children.emplace_back(c.tag, parse_object(c, ctx)); o->ref_names.emplace_back(); }
         else if (c.tag == "ref") {
             if (!c.attr("id")) fail("<ref>: missing \"id\" attribute");
@@ -563,7 +629,7 @@ static HostTexture texture_of(const Obj &t) {
     } else if (t.plugin == "bitmap") {
         const std::string fn = t.props.get_string("filename", "");
         if (fn.empty()) fail("Property \"filename\" has not been specified!");
-        const std::string path = (!fn.empty() && fn[0] == '/') || g_base_dir.empty() ? fn : g_base_dir + "/" + fn;
+        const std::string path = resolve_path(fn);
         const std::string ft = t.props.get_string("filter_type", "bilinear"), wm = t.props.get_string("wrap_mode", "repeat");
         if (ft != "nearest" && ft != "bilinear") fail("Invalid filter type \"" + ft + "\", must be one of: \"nearest\", or \"bilinear\"!");
         if (wm != "repeat" && wm != "mirror" && wm != "clamp") fail("Invalid wrap mode \"" + wm + "\", must be one of: \"repeat\", \"mirror\", or \"clamp\"!");
@@ -839,7 +905,7 @@ static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string
     if (mesh_file) {   // src/shapes/obj.cpp:139-143, ply.cpp:160-166: `filename` through the file resolver
         if (!o.props.has("filename")) fail("Property \"filename\" has not been specified!");
         std::string fn = o.props.get_string("filename", "");
-        std::string path = (!fn.empty() && fn[0] == '/') || base_dir.empty() ? fn : base_dir + "/" + fn;
+        std::string path = resolve_path(fn);
         raw = o.plugin == "obj" ? load_obj(path, o.props.get_bool("flip_tex_coords", true), s.face_normals)
             : o.plugin == "ply" ? load_ply(path, s.face_normals) : load_serialized(path, (int) o.props.get_int("shape_index", 0), s.face_normals);
     }
@@ -975,7 +1041,9 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
     if (!root->attr("version")) fail("missing version attribute in root element \"scene\"");
     LoadCtx ctx;
     for (auto &kv : params) ctx.defaults.emplace_back(kv.first, kv.second);
-    substitute(*root, ctx);
+    g_search_paths.clear();
+    if (!base_dir.empty()) g_search_paths.push_back(base_dir);
+    substitute(*root, ctx, 0, 0, base_dir);
     auto top = parse_object(*root, ctx);
     resolve_refs(*top, ctx);
 
@@ -1025,7 +1093,7 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
                 const std::string fn = o.props.get_string("filename", "");
                 if (fn.empty()) fail("Property \"filename\" has not been specified!");
                 if (o.props.get_bool("mis_compensation", false)) fail("envmap: \"mis_compensation\" is not supported");
-                const std::string path = fn[0] == '/' || base_dir.empty() ? fn : base_dir + "/" + fn;
+                const std::string path = resolve_path(fn);
                 read_radiance_image(path, e.image, e.image_w, e.image_h, srgb_to_linear_u8);
                 if (e.image_w < 2 || e.image_h < 3) fail("\"" + fn.substr(fn.find_last_of('/') == std::string::npos ? 0 : fn.find_last_of('/') + 1) + "\": the environment map resolution must be at least 2x3 pixels");
                 e.scale = (float) o.props.get_float("scale", 1.0);

@@ -231,10 +231,56 @@ class Props(dict):
 _OBJECT_TAGS = {"scene", "integrator", "sensor", "sampler", "film", "rfilter", "bsdf", "shape", "emitter", "texture"}
 
 
-def _substitute(root, params):
-    # xml.cpp:441-456: replace $name in every attribute, longest names first; undefined => error
+_SEARCH_PATHS = []   # FileResolver (src/core/fresolver.cpp): the scene file's directory and whatever <path> prepends (xml.cpp:651-668)
+MAX_INCLUDE_DEPTH = 15   # MI_XML_INCLUDE_MAX_RECURSION
+
+
+def resolve_path(fn):
+    if not fn or os.path.isabs(fn):
+        return fn
+    for d in _SEARCH_PATHS:
+        if os.path.exists(os.path.join(d, fn)):
+            return os.path.join(d, fn)
+    return os.path.join(_SEARCH_PATHS[-1], fn) if _SEARCH_PATHS else fn
+
+
+def _substitute(root, params, base_dir=""):
+    # xml.cpp:441-456: replace $name in every attribute, longest names first; undefined => error.  In the same document-order walk:
+    # <path> (xml.cpp:651-668) and <include> (xml.cpp:670-725: the children of an included <scene>, or the included object itself, replace the tag)
     defaults = {}
-    def walk(node):
+    def expand(node, depth, inc_depth, src_dir):
+        i = 0
+        while i < len(node):
+            ch = node[i]
+            walk(ch, depth + 1, inc_depth, src_dir)
+            if ch.tag != "include":
+                i += 1
+                continue
+            extra = [k for k in ch.attrib if k != "filename"]
+            if extra:
+                raise ValueError('unexpected attribute "%s" in element "include"' % extra[0])
+            if ch.get("filename") is None:
+                raise ValueError('missing attribute "filename" in element "include"')
+            path = resolve_path(ch.get("filename"))
+            if not os.path.exists(path):
+                raise ValueError('included file "%s" not found' % path)
+            if inc_depth + 1 > MAX_INCLUDE_DEPTH:
+                raise ValueError("Exceeded <include> recursion limit of %d" % MAX_INCLUDE_DEPTH)
+            try:
+                inc_root = ET.parse(path).getroot()
+            except ET.ParseError as e:
+                raise ValueError('error while loading "%s": %s' % (path, e))
+            holder = ET.Element("holder")
+            if inc_root.tag == "scene":
+                holder.extend(list(inc_root)); hd = 0
+            else:
+                holder.append(inc_root); hd = -1
+            expand(holder, hd, inc_depth + 1, os.path.dirname(os.path.abspath(path)))
+            node.remove(ch)
+            for k, new in enumerate(list(holder)):
+                node.insert(i + k, new)
+            i += len(holder)
+    def walk(node, depth=0, inc_depth=0, src_dir=""):
         names = sorted(defaults, key=len, reverse=True)
         for k, v in list(node.attrib.items()):
             if "$" in v:
@@ -247,17 +293,37 @@ def _substitute(root, params):
             n = node.get("name")
             if n not in defaults:
                 defaults[n] = node.get("value")
-        for ch in node:
-            walk(ch)
+        if node.tag == "path":
+            if depth != 1:
+                raise ValueError("<path>: path can only be child of root")
+            p = node.get("value")
+            if not os.path.isabs(p):
+                local = os.path.join(src_dir, p) if src_dir else p
+                p = local if os.path.exists(local) else resolve_path(p)
+            if not os.path.exists(p):
+                raise ValueError('<path>: folder "%s" not found' % p)
+            _SEARCH_PATHS.insert(0, p)
+        expand(node, depth, inc_depth, src_dir)
     defaults.update({k: str(v) for k, v in params.items()})
-    walk(root)
+    del _SEARCH_PATHS[:]
+    if base_dir:
+        _SEARCH_PATHS.append(base_dir)
+    walk(root, 0, 0, base_dir)
 
 
 def _parse_object(node, registry):
     p = Props(node.get("type"), node.get("id"))
     for ch in node:
         tag, name = ch.tag, ch.get("name")
-        if tag == "default":
+        if tag in ("default", "path"):
+            continue
+        if tag == "alias":   # xml.cpp:608-628: a second id for an object declared earlier
+            src, dst = ch.get("id"), ch.get("as")
+            if dst in registry:
+                raise ValueError('"alias" has duplicate id "%s"' % dst)
+            if src not in registry:
+                raise ValueError('referenced id "%s" not found' % src)
+            registry[dst] = registry[src]
             continue
         if tag in _OBJECT_TAGS:
             child = _parse_object(ch, registry)
@@ -491,7 +557,7 @@ def _texture_of(tp, base_dir):
         fn = tp.get_s("filename", "")
         if not fn:
             raise ValueError('Property "filename" has not been specified!')
-        path = fn if os.path.isabs(fn) else os.path.join(base_dir, fn)
+        path = resolve_path(fn)
         ft, wm = tp.get_s("filter_type", "bilinear"), tp.get_s("wrap_mode", "repeat")
         if ft not in ("nearest", "bilinear"):
             raise ValueError('Invalid filter type "%s", must be one of: "nearest", or "bilinear"!' % ft)
@@ -669,7 +735,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
         fn = sp.get_s("filename", None)
         if fn is None:
             raise ValueError('Property "filename" has not been specified!')
-        path = fn if os.path.isabs(fn) else os.path.join(base_dir, fn)
+        path = resolve_path(fn)
         fnorm = sp.get_b("face_normals", False)
         mesh_raw = (mesh_io.read_obj(path, sp.get_b("flip_tex_coords", True), fnorm) if sp.plugin == "obj"
                     else mesh_io.read_ply(path, fnorm) if sp.plugin == "ply"
@@ -733,7 +799,7 @@ def load(source, params=None, is_string=False):
     base_dir = "" if is_string else os.path.dirname(os.path.abspath(source))
     if root.tag != "scene" or root.get("version") is None:
         raise ValueError('missing version attribute in root element "%s"' % root.tag)
-    _substitute(root, params or {})
+    _substitute(root, params or {}, base_dir)
     registry = {}
     top = _parse_object(root, registry)
     fs = FlatScene()
@@ -796,7 +862,7 @@ def load(source, params=None, is_string=False):
                     raise ValueError('Property "filename" has not been specified!')
                 if child.get_b("mis_compensation", False):
                     raise ValueError('envmap: "mis_compensation" is not supported')
-                img = read_radiance_image(fn if os.path.isabs(fn) else os.path.join(base_dir, fn))
+                img = read_radiance_image(resolve_path(fn))
                 if img.shape[1] < 2 or img.shape[0] < 3:
                     raise ValueError('"%s": the environment map resolution must be at least 2x3 pixels' % os.path.basename(fn))
                 tw, tinv = child["to_world"][1] if "to_world" in child and child["to_world"][0] == "transform" else (_ident(), _ident())

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes a corpus of damaged scene files for tools/sanitize_loader.sh:  python tests/dev/fuzz_corpus.py SEED COUNT OUTDIR
-35 % numeric attribute values replaced by extreme ones, 25 % character-level damage of the XML, 10 % damaged radiance maps (RGBE / PFM / PNG / JPEG / OpenEXR), 30 % damaged obj / ply / serialized mesh files."""
+35 % numeric attribute values replaced by extreme ones, 25 % character-level damage of the XML (including stray <include> / <alias> / <path> tags), 10 % damaged radiance maps (RGBE / PFM / PNG / JPEG / OpenEXR), 30 % damaged obj / ply / serialized mesh files."""
 import os, sys, random, re
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scenes"))
@@ -42,6 +42,10 @@ _piz = "/root/reference/configs_example/scene.exr"     # the one PIZ-compressed 
 if os.path.exists(_piz):
     images["r.exr"] = open(_piz, "rb").read()
 env0 = make_scenes.cornell_envmap(16, 4, filename="IMAGE")
+# files for the <include> tag: a <scene> root (with a nested include and a <default>), an object root, a file that includes itself
+open(os.path.join(out, "part.xml"), "w").write('<scene version="3.0.0"><default name="extra" value="0.3"/><bsdf type="diffuse" id="included"><rgb name="reflectance" value="$extra"/></bsdf><include filename="part_object.xml"/></scene>')
+open(os.path.join(out, "part_object.xml"), "w").write('<shape type="sphere"><float name="radius" value="0.1"/><bsdf type="diffuse"/></shape>')
+open(os.path.join(out, "loop.xml"), "w").write('<scene version="3.0.0"><include filename="loop.xml"/></scene>')
 for it in range(N):
     r = random.random()
     if r < 0.35:      # numeric value fuzz
@@ -57,7 +61,9 @@ for it in range(N):
             op = random.random(); i = random.randrange(len(b))
             if op < 0.3: del b[i:i + random.randint(1, 12)]
             elif op < 0.7: b.insert(i, random.choice(['<', '>', '"', '/', '$', '0', '-', 'e', ' ', '&', ';', '<!--', ']]>', '<?']))
-            else: b[i:i+1] = list(random.choice(['<rgb/>', '<ref id="x"/>', '<shape type="obj"/>', '<transform name="to_world"/>', '<animation name="to_world"/>']))
+            else: b[i:i+1] = list(random.choice(['<rgb/>', '<ref id="x"/>', '<shape type="obj"/>', '<transform name="to_world"/>', '<animation name="to_world"/>',
+                                                   '<include filename="part.xml"/>', '<include filename="part_object.xml"/>', '<include filename="loop.xml"/>', '<include filename="s%d.xml"/>' % max(it - 1, 0),
+                                                   '<include/>', '<alias id="Light" as="x"/>', '<alias id="x" as="Light"/>', '<path value="."/>', '<path value="nowhere"/>']))
         t = "".join(b)
     elif r < 0.7:     # image file fuzz (envmap)
         n = random.choice(list(images)); b = bytearray(images[n])

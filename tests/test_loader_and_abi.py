@@ -238,3 +238,78 @@ def test_non_finite_geometry_is_rejected_not_crashed(mi):
     broken = wall[:i] + wall[i:].replace(k.group(1), "1e39" if " " not in k.group(1) else " ".join(["1e39"] + k.group(1).split()[1:]), 1)
     with pytest.raises(mi.DtofError, match="non-finite"):
         mi.load_string(broken)
+
+
+def _write_include_scene(d, which="a"):
+    """a Cornell-like scene split over files the way scene packs are: main.xml includes the geometry (a <scene> root, chosen by a $parameter),
+    the sensor (an object root) and, from a <path> directory, the light; a texture is found through the same <path>; an <alias> renames a BSDF"""
+    from scenes import make_scenes as ms
+    os.makedirs(os.path.join(d, "assets"))
+    ms.write_png(os.path.join(d, "assets", "checker.png"), [[(255, 0, 0), (0, 255, 0)], [(0, 0, 255), (255, 255, 255)]])
+    sensor = ('<sensor type="perspective"><float name="fov" value="35"/><transform name="to_world"><lookat origin="0, 1, 5" target="0, 1, 0" up="0, 1, 0"/></transform>'
+              '<sampler type="correlated"><integer name="sample_count" value="$spp"/></sampler>'
+              '<film type="hdrfilm"><integer name="width" value="$res"/><integer name="height" value="$res"/><rfilter type="tent"/></film>'
+              '<float name="shutter_close" value="0.0015"/></sensor>')
+    light = '<emitter type="point"><point name="position" x="0" y="1.8" z="1"/><rgb name="intensity" value="$power"/></emitter>'
+    bsdfs = ('<bsdf type="twosided" id="white"><bsdf type="diffuse"><rgb name="reflectance" value="0.7"/></bsdf></bsdf>'
+             '<bsdf type="twosided" id="tex"><bsdf type="diffuse"><texture type="bitmap" name="reflectance"><string name="filename" value="checker.png"/></texture></bsdf></bsdf>')
+    shapes = ('<shape type="rectangle" id="floor"><transform name="to_world"><rotate x="1" angle="-90"/><scale value="2"/></transform><ref id="floor_material"/></shape>'
+              '<shape type="rectangle" id="back"><transform name="to_world"><scale value="2"/><translate z="-2" y="1"/></transform><ref id="tex"/></shape>')
+    geometry = '<scene version="3.0.0"><default name="res" value="12"/>%s<alias id="white" as="floor_material"/>%s<include filename="light.xml"/></scene>' % (bsdfs, shapes)
+    integrator = '<integrator type="dopplertofpath"><integer name="max_depth" value="3"/></integrator>'
+    files = {"main.xml": '<scene version="3.0.0"><default name="spp" value="4"/><default name="which" value="%s"/><path value="assets"/>%s'
+                         '<include filename="geometry_$which.xml"/><include filename="sensor.xml"/></scene>' % (which, integrator),
+             "geometry_a.xml": geometry, "sensor.xml": sensor, os.path.join("assets", "light.xml"): light}
+    for name, text in files.items():
+        with open(os.path.join(d, name), "w") as f:
+            f.write(text)
+    flat = ('<scene version="3.0.0"><default name="spp" value="4"/><default name="res" value="12"/>%s%s%s%s%s</scene>'
+            % (integrator, bsdfs.replace("checker.png", os.path.join(d, "assets", "checker.png")), shapes.replace("floor_material", "white"), light, sensor))
+    return os.path.join(d, "main.xml"), flat
+
+
+def test_include_alias_and_path_tags(mi, orc, tmp_path):
+    """xml.cpp:608-628 (<alias>), :651-668 (<path>), :670-725 (<include>): a scene split over files loads to the same records as its flattened
+    text, in both loaders; parameters cross file boundaries in both directions; the reference's error cases."""
+    from oracle import scene_xml
+    d = str(tmp_path / "pack")
+    main, flat = _write_include_scene(d)
+    for params in (dict(power="20"), dict(power="5", res=8, spp=2)):
+        split, whole = mi.load_file(main, **params), mi.load_string(flat, **params)
+        for a, b in zip(_export_all(split), _export_all(whole)):
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert split.info() == whole.info() and np.array_equal(split.export(10), whole.export(10))       # texture table (the PNG found through <path>)
+        fs = scene_xml.load(main, params)
+        for got, exp in zip(_export_all(split), _oracle_all(fs)):
+            assert got.shape == exp.shape and np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+        assert split.info()["crop_width"] == (8 if "res" in params else 12)
+    with pytest.raises(mi.DtofError, match="undefined parameter"):                        # $power has no default anywhere
+        mi.load_file(main)
+    with pytest.raises(ValueError, match="undefined parameter"):
+        scene_xml.load(main, {})
+
+    def both(text, match, name="bad.xml", params=None):
+        p = os.path.join(d, name)
+        with open(p, "w") as f:
+            f.write(text)
+        with pytest.raises(mi.DtofError, match=match):
+            mi.load_file(p, **(params or {}))
+        with pytest.raises(ValueError, match=match):
+            scene_xml.load(p, params or {})
+    both('<scene version="3.0.0"><include filename="nope.xml"/></scene>', 'included file ".*nope.xml" not found')
+    both('<scene version="3.0.0"><include filename="loop.xml"/></scene>', "Exceeded <include> recursion limit of 15", name="loop.xml")
+    both('<scene version="3.0.0"><include filename="sensor.xml" id="x"/></scene>', 'unexpected attribute "id" in element "include"', params=dict(spp=1, res=4))
+    both('<scene version="3.0.0"><path value="no_such_dir"/></scene>', '<path>: folder ".*no_such_dir" not found')
+    both('<scene version="3.0.0"><shape type="rectangle"><path value="assets"/></shape></scene>', "<path>: path can only be child of root")
+    both('<scene version="3.0.0"><alias id="ghost" as="b"/></scene>', 'referenced id "ghost" not found')
+    both('<scene version="3.0.0"><bsdf type="diffuse" id="a"/><bsdf type="diffuse" id="b"/><alias id="a" as="b"/></scene>', '"alias" has duplicate id "b"')
+
+
+@pytest.mark.gpu
+def test_included_scene_renders_like_its_flattened_text(mi, tmp_path):
+    main, flat = _write_include_scene(str(tmp_path / "pack"))
+    split, whole = mi.load_file(main, power="20"), mi.load_string(flat, power="20")
+    a, b = split.sample_lanes(2, 4, 0, 12 * 12 * 4), whole.sample_lanes(2, 4, 0, 12 * 12 * 4)
+    for k in a:
+        assert np.array_equal(np.ascontiguousarray(a[k]).view(np.uint32), np.ascontiguousarray(b[k]).view(np.uint32)), k
+    assert (a["rgb"] != 0).any()
