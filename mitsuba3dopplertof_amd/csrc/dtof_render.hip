@@ -333,7 +333,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     // Pipeline choice.  "fused" runs occlusion + continuation traversal inside the shade kernel (one kernel per bounce), "split" runs
     // k_trace -> k_shade -> k_shadow per bounce.
     // DTOF_PIPELINE=split|fused overrides the automatic choice below.
-    static const int env_pipeline = [] { const char *e = getenv("DTOF_PIPELINE"); std::string v = e ? e : ""; return v == "split" ? 0 : v == "fused" ? 1 : 2; }();
+    const int env_pipeline = [] { const char *e = getenv("DTOF_PIPELINE"); std::string v = e ? e : ""; return v == "split" ? 0 : v == "fused" ? 1 : 2; }();   // read per call: tests switch it
     const BlobHeader *bh = (const BlobHeader *) sc->blob.data();
     static const bool env_fuse_first = [] { const char *e = getenv("DTOF_FUSE_FIRST"); return !(e && e[0] == '0'); }();
     bool only_rectangles = bh->n_tris == 0;
@@ -372,7 +372,10 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     rp.hide_emitters = sc->pp.hide_emitters;   // textured reflectances are looked up in the SPEC instantiations only   // the spot branch lives in the SPEC instantiations (keeps the common kernels lean)
     bool has_spheres = false;
     for (auto &sh : sc->host.shapes) has_spheres |= sh.kind == SHAPE_SPHERE || sh.kind == SHAPE_DISK || sh.kind == SHAPE_CYLINDER;   // analytic shapes of the MESH instantiations
-    rp.has_tris = bh->n_tris != 0 || has_spheres;   // anything but rectangles: the instantiations with triangle / sphere code
+    // anything but rectangles: the instantiations with triangle / sphere code.  The SPEC shade kernels are MESH instantiations (full 16-byte hit
+    // record), so the trace kernels of the split pipeline must write that record for them too: a rectangle-only scene with textures (or any other
+    // SPEC feature) counts as "has_tris" -- the compact 4-byte record is for the plain rectangle-only kernels
+    rp.has_tris = bh->n_tris != 0 || has_spheres || rp.has_spec;
     {   // deep per-mesh traversals diverge: see unstaged_block() in dtof_kernels.hip
         const DShape *dshapes = (const DShape *) (sc->blob.data() + bh->off_shapes);
         for (uint32_t i = 0; i < bh->n_shapes; ++i) rp.has_blas |= dshapes[i].kind == SHAPE_MESH && dshapes[i].blas_root != kNoChild;

@@ -197,3 +197,30 @@ def test_jpeg_texture_texels_match_the_oracle_loader(mi, orc):
                              if s.get("tex_refl") is not None and s["tex_refl"].get("data") is not None])
     ours = sc.export(14)
     assert ours.size == theirs.size == 2 * 64 * 48 * 3 + (ours.size - 2 * 64 * 48 * 3) and np.array_equal(bits(ours), bits(theirs))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", ["auto", "split", "fused"])
+def test_textured_rectangle_only_scene(mi, orc, pipeline, monkeypatch):
+    """a scene of rectangles alone with a bitmap texture: the split pipeline's trace kernels must hand the full hit record (u, v) to the textured
+    shade kernels (the 4-byte record of the plain rectangle-only kernels carries the distance only); every pipeline gives the oracle's lanes"""
+    import tempfile
+    from scenes import make_scenes as ms
+    d = tempfile.mkdtemp()
+    ms.write_png(os.path.join(d, "t.png"), [[((x * 37) % 256, (y * 91) % 256, (x * y * 5) % 256) for x in range(8)] for y in range(8)])
+    xml = ('<scene version="3.0.0"><integrator type="dopplertofpath"><integer name="max_depth" value="6"/></integrator>'
+           '<sensor type="perspective"><float name="fov" value="35"/><transform name="to_world"><lookat origin="0, 1, 5" target="0, 1, 0" up="0, 1, 0"/></transform>'
+           '<sampler type="correlated"><integer name="sample_count" value="4"/></sampler>'
+           '<film type="hdrfilm"><integer name="width" value="12"/><integer name="height" value="12"/><rfilter type="tent"/></film><float name="shutter_close" value="0.0015"/></sensor>'
+           '<bsdf type="twosided" id="tex"><bsdf type="diffuse"><texture type="bitmap" name="reflectance"><string name="filename" value="%s"/></texture></bsdf></bsdf>'
+           '<shape type="rectangle"><transform name="to_world"><rotate x="1" angle="-90"/><scale value="2"/></transform><bsdf type="diffuse"><rgb name="reflectance" value="0.7"/></bsdf></shape>'
+           '<shape type="rectangle"><transform name="to_world"><scale value="2"/><translate z="-2" y="1"/></transform><ref id="tex"/></shape>'
+           '<emitter type="point"><point name="position" x="0" y="1.8" z="1"/><rgb name="intensity" value="20"/></emitter></scene>' % os.path.join(d, "t.png"))
+    if pipeline != "auto":
+        monkeypatch.setenv("DTOF_PIPELINE", pipeline)
+    sc, osc = mi.load_string(xml), orc.Scene(xml, is_string=True)
+    n = 12 * 12 * 4
+    ours, ref = sc.sample_lanes(2, 4, 0, n), osc.render_lanes(osc.params(), 2, 4, 0, n, threads=4)
+    for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+        assert np.array_equal(np.ascontiguousarray(ours[k]).view(np.uint32), np.ascontiguousarray(ref[k], np.float32).view(np.uint32)), (pipeline, k)
+    assert (ref["rgb"][:, 0] != ref["rgb"][:, 1]).any()                  # the texture colours the radiance
