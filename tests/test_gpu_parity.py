@@ -219,6 +219,24 @@ def test_modulation_functions_match_oracle(mi, orc):
             assert np.array_equal(bits(sc.eval_modulation(2, x)), bits(np.array([L.orc_waveform_low_pass(float(v), wt) for v in x], np.float32)))
 
 
+@pytest.mark.parametrize("pipeline", ["split", "fused"])
+@pytest.mark.parametrize("name,xml,params,spp", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_both_pipelines_reproduce_the_golden_lanes(mi, name, xml, params, spp, pipeline, monkeypatch):
+    """every parity configuration under the pipeline the automatic choice would NOT necessarily take (DTOF_PIPELINE=split | fused): the kernels of
+    the two pipelines pair differently (trace / shade / shadow kernels vs the fused shade kernels, compact vs full hit records, inline iterations),
+    and both must give the committed lanes bit for bit and the committed image"""
+    monkeypatch.setenv("DTOF_PIPELINE", pipeline)
+    sc = mi.load_file(os.path.join(SCENES, xml), **params)
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    m = gold["lane_rgb"].shape[0]
+    g = sc.sample_lanes(3, spp, 0, m)
+    assert np.array_equal(bits(g["rgb"]), bits(gold["lane_rgb"])) and np.array_equal(bits(g["sample_pos"]), bits(gold["lane_pos"])), (name, pipeline)
+    assert np.array_equal(bits(g["ray_o"]), bits(gold["lane_ray_o"])) and np.array_equal(bits(g["time"]), bits(gold["lane_time"]))
+    assert rel_linf(sc.render(seed=3, spp=spp), gold["image"]) <= IMG_TOL
+    st = sc.last_stats
+    assert (st["ms_trace"] > 0) == (pipeline == "split")                 # the requested pipeline is the one that ran
+
+
 @pytest.mark.parametrize("case", ["spp1", "spp3_box", "crop", "depth1", "depth2", "unbounded_rr", "two_lights", "onesided", "tent_wide", "gaussian_default", "area_and_point", "area_path",
                                   "depth0", "no_emitters", "no_shapes", "one_pixel", "odd_17x13x5", "mitchell", "mitchell_bc", "catmullrom",
                                   # the same filters at power-of-two spp >= 16: the eight-samples-per-lane splat (k_splat_x8) instead of per-sample atomics

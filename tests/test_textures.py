@@ -200,8 +200,9 @@ def test_jpeg_texture_texels_match_the_oracle_loader(mi, orc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("feature", ["texture", "spot_light", "rough_metal", "glass_and_envmap"])
 @pytest.mark.parametrize("pipeline", ["auto", "split", "fused"])
-def test_textured_rectangle_only_scene(mi, orc, pipeline, monkeypatch):
+def test_textured_rectangle_only_scene(mi, orc, pipeline, feature, monkeypatch):
     """a scene of rectangles alone with a bitmap texture: the split pipeline's trace kernels must hand the full hit record (u, v) to the textured
     shade kernels (the 4-byte record of the plain rectangle-only kernels carries the distance only); every pipeline gives the oracle's lanes"""
     import tempfile
@@ -216,6 +217,17 @@ def test_textured_rectangle_only_scene(mi, orc, pipeline, monkeypatch):
            '<shape type="rectangle"><transform name="to_world"><rotate x="1" angle="-90"/><scale value="2"/></transform><bsdf type="diffuse"><rgb name="reflectance" value="0.7"/></bsdf></shape>'
            '<shape type="rectangle"><transform name="to_world"><scale value="2"/><translate z="-2" y="1"/></transform><ref id="tex"/></shape>'
            '<emitter type="point"><point name="position" x="0" y="1.8" z="1"/><rgb name="intensity" value="20"/></emitter></scene>' % os.path.join(d, "t.png"))
+    # the other features that select the SPEC shade kernels, on the same rectangles
+    plain = '<bsdf type="twosided" id="tex"><bsdf type="diffuse"><rgb name="reflectance" value="0.3, 0.6, 0.2"/></bsdf></bsdf>'
+    textured = xml[xml.index('<bsdf type="twosided" id="tex">'):xml.index('<shape type="rectangle">')]
+    if feature == "spot_light":
+        xml = xml.replace(textured, plain).replace('<emitter type="point"><point name="position" x="0" y="1.8" z="1"/><rgb name="intensity" value="20"/></emitter>',
+                                                   '<emitter type="spot"><transform name="to_world"><lookat origin="0, 1.8, 1" target="0, 0.5, -1.5" up="0, 1, 0"/></transform>'
+                                                   '<rgb name="intensity" value="40"/><float name="cutoff_angle" value="40"/></emitter>')
+    elif feature == "rough_metal":
+        xml = xml.replace(textured, '<bsdf type="twosided" id="tex"><bsdf type="roughconductor"><rgb name="eta" value="0.2, 0.92, 1.1"/><rgb name="k" value="3.9, 2.45, 2.14"/><float name="alpha" value="0.2"/></bsdf></bsdf>')
+    elif feature == "glass_and_envmap":
+        xml = xml.replace(textured, '<bsdf type="dielectric" id="tex"/>').replace("</scene>", '<emitter type="constant"><rgb name="radiance" value="0.4, 0.5, 0.7"/></emitter></scene>')
     if pipeline != "auto":
         monkeypatch.setenv("DTOF_PIPELINE", pipeline)
     sc, osc = mi.load_string(xml), orc.Scene(xml, is_string=True)
