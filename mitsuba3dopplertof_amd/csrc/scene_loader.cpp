@@ -900,7 +900,7 @@ static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string
     // such a path can carry radiance is an emitter ON a thindielectric shape, and the kernels keep no valid_ray flag for that corner
     if (s.emitter && s.kind == SHAPE_CYLINDER) fail("cylinder: area emitters on cylinders are not supported");
     if (s.emitter && s.bsdf == BSDF_THINDIELECTRIC) fail("an area emitter on a thindielectric shape is not supported");
-    else if (s.emitter) s.refl[0] = s.refl[1] = s.refl[2] = 0.f;
+    if (s.emitter && !bsdf) s.refl[0] = s.refl[1] = s.refl[2] = 0.f;   // only the DEFAULT BSDF of an emitter is black: a given one keeps its reflectance
     RawMesh raw;
     if (mesh_file) {   // src/shapes/obj.cpp:139-143, ply.cpp:160-166: `filename` through the file resolver
         if (!o.props.has("filename")) fail("Property \"filename\" has not been specified!");

@@ -821,3 +821,116 @@ def test_random_parameter_combinations_are_bit_exact(mi, orc, index):
     ref, _ = osc.render(pd, seed=seed, spp=spp, threads=NCPU)
     scale = max(float(np.abs(o["rgb"]).max()), 1e-30)          # images of cancelling (static / antithetic) set-ups are ~0: scale by the lanes
     assert float(np.abs(img - ref).max()) <= 1e-5 * scale * max(1.0, spp / 4)
+
+
+def _random_scene(rng):
+    """a small random scene over the supported plugin set: sensor, filter, integrator, 2 - 5 objects of random kind / material / motion, 1 - 2 lights"""
+    def f(lo, hi):
+        return "%.4f" % rng.uniform(lo, hi)
+    def rgb(lo=0.1, hi=0.9):
+        return "%s, %s, %s" % (f(lo, hi), f(lo, hi), f(lo, hi))
+    sensor_kind = rng.choice(["perspective", "perspective", "thinlens", "orthographic"])
+    lens = {"perspective": '<float name="fov" value="%s"/>' % f(25, 50),
+            "thinlens": '<float name="fov" value="%s"/><float name="aperture_radius" value="%s"/><float name="focus_distance" value="%s"/>' % (f(25, 50), f(0.02, 0.3), f(3, 7)),
+            "orthographic": ""}[sensor_kind]
+    cam_scale = '<scale x="%s" y="%s"/>' % (f(1.5, 3), f(1.5, 3)) if sensor_kind == "orthographic" else ""
+    rfilter = rng.choice(['<rfilter type="tent"/>', '<rfilter type="box"/>', '<rfilter type="gaussian"/>', '<rfilter type="mitchell"/>', '<rfilter type="catmullrom"/>',
+                          '<rfilter type="lanczos"/>', '<rfilter type="tent"><float name="radius" value="1.7"/></rfilter>'])
+    sampler = rng.choice(['<sampler type="correlated"><integer name="sample_count" value="4"/></sampler>'] * 3 + ['<sampler type="independent"><integer name="sample_count" value="4"/></sampler>'])
+    if rng.random() < 0.8:
+        integ = ('<integrator type="dopplertofpath"><integer name="max_depth" value="%d"/><integer name="path_correlation_depth" value="%d"/><string name="time_sampling_method" value="%s"/>'
+                 '<string name="wave_function_type" value="%s"/><float name="hetero_frequency" value="%s"/><integer name="rr_depth" value="%d"/></integrator>'
+                 % (rng.integers(1, 8), rng.integers(0, 4), rng.choice(["uniform", "stratified", "antithetic", "antithetic_mirror"]),
+                    rng.choice(["sinusoidal", "rectangular", "triangular", "trapezoidal"]), rng.choice(["0.0", "1.0", "0.37"]), rng.integers(2, 6)))
+    else:
+        integ = '<integrator type="path"><integer name="max_depth" value="%d"/></integrator>' % rng.integers(2, 7)
+    def material(two_sided_ok=True):
+        k = rng.choice(["diffuse", "diffuse", "conductor", "dielectric", "thindielectric", "plastic", "roughconductor", "roughdielectric", "roughplastic"])
+        dist = '<string name="distribution" value="%s"/>' % rng.choice(["ggx", "beckmann"])
+        body = {"diffuse": '<bsdf type="diffuse"><rgb name="reflectance" value="%s"/></bsdf>' % rgb(),
+                "conductor": '<bsdf type="conductor"><rgb name="eta" value="0.2, 0.9, 1.1"/><rgb name="k" value="3.9, 2.4, 2.1"/></bsdf>',
+                "dielectric": '<bsdf type="dielectric"><float name="int_ior" value="%s"/></bsdf>' % f(1.2, 1.8),
+                "thindielectric": '<bsdf type="thindielectric"/>',
+                "plastic": '<bsdf type="plastic"><rgb name="diffuse_reflectance" value="%s"/></bsdf>' % rgb(),
+                "roughconductor": '<bsdf type="roughconductor"><float name="alpha" value="%s"/>%s</bsdf>' % (f(0.05, 0.5), dist),
+                "roughdielectric": '<bsdf type="roughdielectric"><float name="alpha" value="%s"/>%s</bsdf>' % (f(0.05, 0.5), dist),
+                "roughplastic": '<bsdf type="roughplastic"><float name="alpha" value="%s"/><rgb name="diffuse_reflectance" value="%s"/>%s</bsdf>' % (f(0.05, 0.5), rgb(), dist)}[k]
+        if k in ("diffuse", "conductor", "plastic", "roughconductor", "roughplastic") and rng.random() < 0.7:
+            body = '<bsdf type="twosided">%s</bsdf>' % body
+        return body
+    def placement(moving):
+        # unit axes only: Transform::rotate takes the axis as given (transform.h:188-191, xml.cpp:902-914) and a non-unit one makes to_object differ
+        # from the inverse of to_world -- what a ray then hits depends on the acceleration structure, in the reference as much as here
+        axes = ['x="1"', 'y="1"', 'z="1"']
+        rot = '<rotate %s angle="%s"/><rotate %s angle="%s"/>' % (axes[int(rng.integers(0, 3))], f(0, 360), axes[int(rng.integers(0, 3))], f(0, 360))
+        s0 = '<scale value="%s"/>%s<translate x="%s" y="%s" z="%s"/>' % (f(0.25, 0.6), rot, f(-1.3, 1.3), f(0.3, 1.7), f(-1.5, 1.0))
+        if not moving:
+            return '<transform name="to_world">%s</transform>' % s0
+        return ('<animation name="to_world"><transform time="0">%s</transform><transform time="0.0015">%s<translate x="%s" y="%s" z="%s"/></transform></animation>'
+                % (s0, s0, f(-0.03, 0.03), f(-0.03, 0.03), f(-0.03, 0.03)))
+    shapes = ['<shape type="rectangle"><transform name="to_world"><rotate x="1" angle="-90"/><scale value="3"/></transform><bsdf type="diffuse"><rgb name="reflectance" value="%s"/></bsdf></shape>' % rgb()]
+    light_on = -1
+    n_obj = int(rng.integers(2, 6))
+    if rng.random() < 0.4:
+        light_on = int(rng.integers(0, n_obj))
+    for i in range(n_obj):
+        kind = rng.choice(["rectangle", "cube", "sphere", "disk", "cylinder"])
+        moving = rng.random() < 0.35
+        if i == light_on:      # area lights sit on static shapes (moving ones would be instanced emitters, which the reference refuses), not on cylinders
+            moving, kind = False, rng.choice(["rectangle", "cube", "sphere", "disk"])
+        area = '<emitter type="area"><rgb name="radiance" value="%s"/></emitter>' % rgb(2, 8) if i == light_on else ""
+        mat = '<bsdf type="diffuse"/>' if area else material()
+        if kind == "cylinder":
+            geo = '<point name="p0" x="0" y="0" z="-1"/><point name="p1" x="0" y="0" z="1"/><float name="radius" value="0.5"/>'
+        else:
+            geo = ""
+        shapes.append('<shape type="%s">%s%s%s%s</shape>' % (kind, geo, placement(moving), mat, area))
+    lights = []
+    for _ in range(int(rng.integers(1, 3)) if light_on < 0 else int(rng.integers(0, 2))):
+        k = rng.choice(["point", "spot", "directional", "constant"])
+        lights.append({"point": '<emitter type="point"><point name="position" x="%s" y="%s" z="%s"/><rgb name="intensity" value="%s"/></emitter>' % (f(-1, 1), f(1.5, 2.5), f(0, 3), rgb(5, 30)),
+                       "spot": '<emitter type="spot"><transform name="to_world"><lookat origin="%s, 2.5, 2" target="%s, 0.5, -0.5" up="0, 1, 0"/></transform><rgb name="intensity" value="%s"/>'
+                               '<float name="cutoff_angle" value="%s"/></emitter>' % (f(-1, 1), f(-0.5, 0.5), rgb(10, 60), f(20, 50)),
+                       "directional": '<emitter type="directional"><vector name="direction" x="%s" y="-1" z="%s"/><rgb name="irradiance" value="%s"/></emitter>' % (f(-0.5, 0.5), f(-0.5, 0.5), rgb(1, 4)),
+                       "constant": '<emitter type="constant"><rgb name="radiance" value="%s"/></emitter>' % rgb(0.2, 1.0)}[k])
+        if k == "constant":
+            break
+    if sum("constant" in l for l in lights) > 1:
+        lights = lights[:1]
+    return ('<scene version="3.0.0">%s<sensor type="%s">%s<transform name="to_world">%s<lookat origin="%s, %s, 5" target="0, 0.8, 0" up="0, 1, 0"/></transform>%s'
+            '<film type="hdrfilm"><integer name="width" value="10"/><integer name="height" value="8"/>%s</film><float name="shutter_close" value="0.0015"/></sensor>%s%s</scene>'
+            % (integ, sensor_kind, lens, cam_scale, f(-1, 1), f(0.5, 2), sampler, rfilter, "".join(shapes), "".join(lights)))
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_scene_structures(mi, orc, block):
+    """random small scenes over the whole supported plugin set (sensors, filters, shapes, motion, BSDFs, lights, integrators), each rendered by the
+    pipeline of the automatic choice and by the other one: every lane bit-exact against the oracle, images within 1e-3.  Parameter sweeps keep
+    the scene fixed (test_random_parameter_sweep); this one varies what the kernels are instantiated and paired for.  DTOF_SCENE_SWEEP=N scenes per block."""
+    count = int(os.environ.get("DTOF_SCENE_SWEEP", "12"))
+    rng = np.random.default_rng(1000 + block)
+    for it in range(count):
+        xml = _random_scene(rng)
+        try:
+            osc = orc.Scene(xml, is_string=True)
+        except ValueError as e:      # a combination the loaders refuse (both must): e.g. two environment emitters
+            with pytest.raises(mi.DtofError):
+                mi.load_string(xml)
+            continue
+        pd = osc.params()
+        n = 10 * 8 * 4
+        ref = osc.render_lanes(pd, 5, 4, 0, n, threads=NCPU)
+        img_ref, _ = osc.render(pd, seed=5, spp=4, threads=NCPU)
+        for pipeline in ("auto", "split" if it % 2 else "fused"):
+            if pipeline == "auto":
+                os.environ.pop("DTOF_PIPELINE", None)
+            else:
+                os.environ["DTOF_PIPELINE"] = pipeline
+            try:
+                sc = mi.load_string(xml)
+                g = sc.sample_lanes(5, 4, 0, n)
+                for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+                    assert np.array_equal(bits(g[k]), bits(ref[k])), (block, it, pipeline, k, int((bits(g[k]) != bits(ref[k])).any(axis=-1).sum() if g[k].ndim > 1 else 0), xml)
+                assert rel_linf(sc.render(seed=5, spp=4), img_ref) <= IMG_TOL or np.abs(img_ref).max() == 0, (block, it, pipeline, xml)
+            finally:
+                os.environ.pop("DTOF_PIPELINE", None)

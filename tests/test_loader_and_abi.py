@@ -313,3 +313,21 @@ def test_included_scene_renders_like_its_flattened_text(mi, tmp_path):
     for k in a:
         assert np.array_equal(np.ascontiguousarray(a[k]).view(np.uint32), np.ascontiguousarray(b[k]).view(np.uint32)), k
     assert (a["rgb"] != 0).any()
+
+
+def test_bsdf_of_an_emitter_shape_keeps_its_reflectance(mi, orc):
+    """Shape::Shape (src/render/shape.cpp:66-72): only the DEFAULT BSDF of an emitter shape is black (reflectance 0); a BSDF given in the file keeps
+    its reflectance whether or not the shape emits -- paths that reach a light source go on from its surface"""
+    def scene(bsdf, emitter):
+        return ('<scene version="3.0.0"><sensor type="perspective"><film type="hdrfilm"><integer name="width" value="4"/><integer name="height" value="4"/></film></sensor>'
+                '<shape type="rectangle">%s%s</shape></scene>'
+                % (bsdf, '<emitter type="area"><rgb name="radiance" value="3"/></emitter>' if emitter else ""))
+    given = '<bsdf type="diffuse"><rgb name="reflectance" value="0.3, 0.5, 0.7"/></bsdf>'
+    black = '<bsdf type="diffuse"><rgb name="reflectance" value="0"/></bsdf>'
+    rec = lambda xml: mi.load_string(xml).export(9)
+    assert np.array_equal(rec(scene(given, True)), rec(scene(given, False)))
+    assert np.array_equal(rec(scene("", True)), rec(scene(black, True))) and not np.array_equal(rec(scene("", True)), rec(scene("", False)))
+    from oracle import scene_xml
+    for bsdf, emitter, want in ((given, True, [0.3, 0.5, 0.7]), ("", True, [0, 0, 0]), ("", False, [0.5, 0.5, 0.5])):
+        assert np.allclose(scene_xml.load(scene(bsdf, emitter), {}, is_string=True).shapes[0]["reflectance"], want)
+        assert np.allclose(sorted(set(np.float32(want).tolist())), sorted(set(v for v in rec(scene(bsdf, emitter)).tolist() if v in np.float32(want).tolist())))
