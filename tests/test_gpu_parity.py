@@ -9,6 +9,7 @@ Tolerances (stated per the task: north_star allows 1e-3 relative per-pixel L-inf
     float splat, which the reference itself leaves unordered, imageblock.cpp:119-133).
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -823,8 +824,9 @@ def test_random_parameter_combinations_are_bit_exact(mi, orc, index):
     assert float(np.abs(img - ref).max()) <= 1e-5 * scale * max(1.0, spp / 4)
 
 
-def _random_scene(rng):
-    """a small random scene over the supported plugin set: sensor, filter, integrator, 2 - 5 objects of random kind / material / motion, 1 - 2 lights"""
+def _random_scene(rng, mesh_dir=None):
+    """a small random scene over the supported plugin set: sensor, filter, integrator, 2 - 5 objects of random kind / material / motion (obj / ply
+    meshes and an instanced shapegroup when `mesh_dir` holds the files of scenes/make_mesh.py), 1 - 2 lights"""
     def f(lo, hi):
         return "%.4f" % rng.uniform(lo, hi)
     def rgb(lo=0.1, hi=0.9):
@@ -882,7 +884,7 @@ def _random_scene(rng):
     if rng.random() < 0.4:
         light_on = int(rng.integers(0, n_obj))
     for i in range(n_obj):
-        kind = rng.choice(["rectangle", "cube", "sphere", "disk", "cylinder"])
+        kind = rng.choice(["rectangle", "cube", "sphere", "disk", "cylinder"] + (["obj", "ply"] if mesh_dir else []))
         moving = rng.random() < 0.35
         if i == light_on:      # area lights sit on static shapes (moving ones would be instanced emitters, which the reference refuses), not on cylinders
             moving, kind = False, rng.choice(["rectangle", "cube", "sphere", "disk"])
@@ -890,9 +892,18 @@ def _random_scene(rng):
         mat = '<bsdf type="diffuse"/>' if area else material()
         if kind == "cylinder":
             geo = '<point name="p0" x="0" y="0" z="-1"/><point name="p1" x="0" y="0" z="1"/><float name="radius" value="0.5"/>'
+        elif kind in ("obj", "ply"):
+            geo = '<string name="filename" value="%s"/>' % os.path.join(mesh_dir, str(rng.choice(["blob.obj", "blob_n.obj"] if kind == "obj" else ["blob.ply", "blob_ascii.ply"])))
+            if rng.random() < 0.3:
+                geo += '<boolean name="face_normals" value="true"/>'
         else:
             geo = ""
         shapes.append('<shape type="%s">%s%s%s%s</shape>' % (kind, geo, placement(moving), mat, area))
+    if mesh_dir and rng.random() < 0.3:    # a shapegroup instanced twice (shapegroup.cpp, instance.cpp), one of the instances moving
+        members = "".join('<shape type="%s">%s%s</shape>' % (k_, placement(False), material()) for k_ in rng.choice(["rectangle", "cube", "sphere", "disk"], size=2))
+        shapes.append('<shape type="shapegroup" id="group">%s</shape>' % members)
+        for moving in (False, True):
+            shapes.append('<shape type="instance"><ref id="group"/>%s</shape>' % placement(moving).replace('<scale value="0.', '<scale value="1.'))
     lights = []
     for _ in range(int(rng.integers(1, 3)) if light_on < 0 else int(rng.integers(0, 2))):
         k = rng.choice(["point", "spot", "directional", "constant", "envmap"])
@@ -917,8 +928,13 @@ def test_random_scene_structures(mi, orc, block):
     the scene fixed (test_random_parameter_sweep); this one varies what the kernels are instantiated and paired for.  DTOF_SCENE_SWEEP=N scenes per block."""
     count = int(os.environ.get("DTOF_SCENE_SWEEP", "12"))
     rng = np.random.default_rng(1000 + block)
+    import tempfile
+    sys.path.insert(0, SCENES)
+    import make_mesh
+    mesh_dir = tempfile.mkdtemp(prefix="dtof_sweep_")
+    make_mesh.write_all(mesh_dir, 8, 5)
     for it in range(count):
-        xml = _random_scene(rng)
+        xml = _random_scene(rng, mesh_dir if block % 2 else None)
         try:
             osc = orc.Scene(xml, is_string=True)
         except ValueError as e:      # a combination the loaders refuse (both must): e.g. two environment emitters
