@@ -20,9 +20,11 @@ def collect(d, counter):
 
 def short(name):
     import re
-    m = re.search(r"k_shade<\w+, (\d)", name)     # k_shade<LDS, MODE, AREA, KMAX, MESH>: MODE 2 = the first-bounce instantiation
-    if m:
-        return "k_shade_first" if m.group(1) == "2" else "k_shade"
+    m = re.search(r"k_shade<\w+, (\d), \w+, \d+, (\w+)", name)     # k_shade<LDS, MODE, AREA, KMAX, MESH, SPEC>: MODE 2 = the first-bounce instantiation
+    if m:   # the headline workload (rectangle-only Cornell scene) runs the MESH = false instantiation; the Domino extra of bench.py the MESH = true one
+        if m.group(1) == "2":
+            return "k_shade_first" if m.group(2) == "false" else "k_shade_first_mesh"
+        return "k_shade"
     for k in ("k_shade", "k_trace", "k_shadow", "k_generate", "k_splat_x8", "k_splat_pixel", "k_splat_tent3", "k_splat_generic", "k_develop", "k_bounce"):
         if k in name:
             return k
