@@ -19,6 +19,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <mutex>
+#include <condition_variable>
+#include <atomic>
 
 static bool write_npy(const char *path, const float *img, int h, int w) {
     FILE *f = fopen(path, "wb"); if (!f) return false;
@@ -79,30 +82,33 @@ int main(int argc, char **argv) {
         std::vector<std::vector<float>> films(share ? gpus : 0, std::vector<float>(film_floats));
         std::vector<std::string> errors(gpus); std::vector<dtof_render_stats> stats(gpus);
         std::vector<std::thread> workers;
+        // The collective is entered by every rank or by none: each worker finishes what can fail before it (device, scene, film, stream, render), all
+        // meet at a host barrier, and the reduce runs only if nobody reported an error -- a rank that stayed away would leave the others waiting in
+        // ncclReduce forever, and the image of a failed render is discarded anyway.
+        std::mutex gate_mutex; std::condition_variable gate_cv; int arrived = 0; std::atomic<int> failed { 0 };
+        auto meet = [&] { std::unique_lock<std::mutex> lock(gate_mutex); if (++arrived == gpus) gate_cv.notify_all(); else gate_cv.wait(lock, [&] { return arrived == gpus; }); };
         for (int g = 0; g < gpus; ++g) workers.emplace_back([&, g] {
-            if (hipSetDevice(share ? 0 : g) != hipSuccess) { errors[g] = "hipSetDevice failed"; return; }
             dtof_scene *mine = nullptr; float *d_film = nullptr, *d_rgb = nullptr; hipStream_t stream = nullptr;
-            if (dtof_scene_load_file(scene.c_str(), n.data(), v.data(), (int) n.size(), &mine)) { errors[g] = dtof_last_error(); }
+            if (hipSetDevice(share ? 0 : g) != hipSuccess) errors[g] = "hipSetDevice failed";
+            else if (dtof_scene_load_file(scene.c_str(), n.data(), v.data(), (int) n.size(), &mine)) errors[g] = dtof_last_error();
             else if (hipMalloc((void **) &d_film, film_floats * 4) != hipSuccess || hipMemset(d_film, 0, film_floats * 4) != hipSuccess) errors[g] = "device film allocation failed";
+            else if (!share && hipStreamCreate(&stream) != hipSuccess) errors[g] = "stream creation failed";
             else if (dtof_render_stripes(mine, seed, spp, g * stripes, stripes, gpus * stripes, nullptr, 0, d_film, &stats[g])) errors[g] = dtof_last_error();
-            if (share) {
-                if (errors[g].empty() && hipMemcpy(films[g].data(), d_film, film_floats * 4, hipMemcpyDeviceToHost) != hipSuccess) errors[g] = "film download failed";
-            } else {
-                // every rank enters the collective, also one whose render failed (its film is zero or partial; the error is reported afterwards):
-                // a rank that stays away would leave the others waiting in ncclReduce
-                if (!d_film && hipMalloc((void **) &d_film, film_floats * 4) == hipSuccess) (void) hipMemset(d_film, 0, film_floats * 4);
-                ncclResult_t rc = ncclSuccess;
-                if (!d_film || hipStreamCreate(&stream) != hipSuccess) { if (errors[g].empty()) errors[g] = "stream / film allocation failed"; }
-                else {
-                    (void) hipDeviceSynchronize();   // the library renders on its own stream
-                    rc = ncclReduce(d_film, d_film, film_floats, ncclFloat, ncclSum, 0, comms[g], stream);
-                    if (rc == ncclSuccess && hipStreamSynchronize(stream) != hipSuccess && errors[g].empty()) errors[g] = "film reduce failed";
-                    if (rc != ncclSuccess && errors[g].empty()) errors[g] = std::string("ncclReduce: ") + ncclGetErrorString(rc);
-                }
-                if (g == 0 && errors[g].empty()) {   // HDRFilm::develop (hdrfilm.cpp:305-406) of the summed film, on the device
-                    if (hipMalloc((void **) &d_rgb, n_pixels * 12) != hipSuccess) errors[g] = "image allocation failed";
-                    else if (dtof_develop(d_film, d_rgb, (int64_t) n_pixels)) errors[g] = dtof_last_error();
-                    else if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(img.data(), d_rgb, n_pixels * 12, hipMemcpyDeviceToHost) != hipSuccess) errors[g] = "image download failed";
+            else if (hipDeviceSynchronize() != hipSuccess) errors[g] = "device synchronisation failed";   // the library renders on its own stream
+            if (!errors[g].empty()) failed.fetch_add(1);
+            meet();
+            if (failed.load() == 0) {
+                if (share) {
+                    if (hipMemcpy(films[g].data(), d_film, film_floats * 4, hipMemcpyDeviceToHost) != hipSuccess) errors[g] = "film download failed";
+                } else {
+                    const ncclResult_t rc = ncclReduce(d_film, d_film, film_floats, ncclFloat, ncclSum, 0, comms[g], stream);
+                    if (rc != ncclSuccess) errors[g] = std::string("ncclReduce: ") + ncclGetErrorString(rc);
+                    else if (hipStreamSynchronize(stream) != hipSuccess) errors[g] = "film reduce failed";
+                    if (g == 0 && errors[g].empty()) {   // HDRFilm::develop (hdrfilm.cpp:305-406) of the summed film, on the device
+                        if (hipMalloc((void **) &d_rgb, n_pixels * 12) != hipSuccess) errors[g] = "image allocation failed";
+                        else if (dtof_develop(d_film, d_rgb, (int64_t) n_pixels)) errors[g] = dtof_last_error();
+                        else if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(img.data(), d_rgb, n_pixels * 12, hipMemcpyDeviceToHost) != hipSuccess) errors[g] = "image download failed";
+                    }
                 }
             }
             if (stream) (void) hipStreamDestroy(stream);

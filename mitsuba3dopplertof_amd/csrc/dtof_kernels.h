@@ -83,6 +83,7 @@ struct Queues {
     float4 *sh_c;        // [K][capacity] candidate result rgb, w = as_float(lane position)
     uint32_t *q[2];      // active-lane index queues (ping-pong), segmented: entry j of segment S at S*kSeg + j
     uint32_t *counts;    // [iteration][2][n_segments]: survivors / shadow rays per segment
+    uint32_t *seg_counter;   // resident first-bounce kernel: next segment to hand out (zeroed before the launch)
     uint32_t capacity;
     uint32_t id_shift;   // bits of hit_id that hold the object index: 24 unless the scene needs more shapes per group than 8 bits hold (render_rows)
 };
@@ -90,6 +91,11 @@ struct Queues {
 struct LaneDebug {       // mirrors orc_lane's comparable fields
     float sample_pos[2]; float time; float ray_o[3]; float ray_d[3]; float rgb[3];
 };
+
+// Resident stage of the fused first-bounce kernel (k_shade<..., RESW>, dtof_kernels.hip): `waves` waves per block (0 = off), one block per CU; the block
+// [small_off, small_off + 16 * small_words) of the blob (groups, shapes, emitters, triangles, shading data) and the TLAS nodes live in LDS.
+struct ResidentStage { uint32_t small_off = 0, small_words = 0, waves = 0; };
+constexpr uint32_t kResidentNodes = 1024;   // TLAS nodes the stage holds (= kResNodes of dtof_traverse.h)
 
 // kernels (dtof_kernels.hip)
 void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s);
@@ -100,7 +106,8 @@ void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
 void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                   const uint32_t *qin, const uint32_t *count_in, uint32_t *qout,
                   uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, bool fused, bool trace_next,
-                  uint32_t stack_depth, hipStream_t s, bool first = false, LaneDebug *dbg = nullptr);   // first: generate + primary trace inline (fused only)
+                  uint32_t stack_depth, hipStream_t s, bool first = false, LaneDebug *dbg = nullptr,   // first: generate + primary trace inline (fused only)
+                  const ResidentStage *resident = nullptr);
 void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                    const uint32_t *count_in, uint32_t stack_depth, hipStream_t s);
 void launch_velocity(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q, uint32_t stack_depth, hipStream_t s);

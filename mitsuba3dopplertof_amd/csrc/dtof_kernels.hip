@@ -135,34 +135,72 @@ DTOF_D uint32_t block_append(bool pred, uint32_t *s_cnt, uint32_t &running) {
 struct ShadeArgs {
     const uint8_t *scene; uint32_t scene_bytes, stage_words; RenderParams rp; Queues q;
     const uint32_t *qin, *count_in; uint32_t *qout, *alive_out, *shadow_out; uint32_t depth, trace_next; LaneDebug *dbg;
+    uint32_t n_seg, res_small_off, res_small_words, res_memo;   // resident stage (RESW != 0): segments of the batch; byte offset / uint4 count of the record block copied to LDS; 1 = the instance memo has LDS
 };
-template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, bool SPEC>
+// RESW != 0: the RESIDENT form of the fused first-bounce kernel for scenes too large to stage whole (Domino: 64 KB of TLAS nodes + 128 KB of
+// instance records).  ONE block of RESW waves per CU stays for the whole launch; it copies the TLAS nodes (as four planes, see kResNodes) and
+// the block of small records (groups, shapes, emitters, triangles, shading data) into LDS once, then every wave takes 512-lane segments from a
+// global counter until none is left -- a wave owns its segment exactly as a one-wave block does, there is no barrier after the stage.  What
+// still comes through the vector L1 is the 128-byte instance record of a leaf visit and the queue traffic: the unstaged kernel keeps the CU's
+// vector memory path busy 75 - 85 % of the time (TA / TD busy counters, profiles/r03_pmc_domino_fused*.txt) with the four 16-byte node loads
+// per step per lane, and waits for it.
+template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, bool SPEC, int RESW = 0>
 #ifndef DTOF_MESH_WAVES
 #define DTOF_MESH_WAVES 3   // waves / SIMD the fused kernels with triangle code are compiled for (A/B: make variant DEFS=-DDTOF_MESH_WAVES=4)
 #endif
-__global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : (MODE != 0 && MESH) ? DTOF_MESH_WAVES : 1) void k_shade(ShadeArgs args_by_value) {
+__global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : (MODE != 0 && MESH) ? DTOF_MESH_WAVES : 1) void k_shade(ShadeArgs args_by_value) {
     constexpr bool FUSED = MODE != 0, FIRST = MODE == 2;
+    static_assert(RESW == 0 || (MODE == 2 && !LDS && MESH), "the resident stage exists for the unstaged fused first-bounce kernel with mesh code");
     extern __shared__ uint4 lds[];
     __shared__ uint32_t s_cnt[4];
-    __shared__ uint32_t s_inline[2 * kMaxInline];   // FIRST: lanes alive after / shadow rays of every inline iteration but the last (statistics)
+    __shared__ uint32_t s_inline_all[(RESW ? RESW : 1) * 2 * kMaxInline];   // FIRST: lanes alive after / shadow rays of every inline iteration but the last (statistics), per wave
     typedef const char __attribute__((address_space(4))) *KernargBytes;
     const KernargBytes kernarg = (KernargBytes) __builtin_amdgcn_kernarg_segment_ptr();
     const ShadeArgs &A0 = *(const ShadeArgs *) kernarg;
-    const uint32_t stage_words = A0.stage_words;
-    // dynamic LDS: [staged scene][fused: instance memo, kMemoWords x 64 words][traversal stack columns]
-    uint32_t *stack = (uint32_t *) (lds + stage_words) + (FUSED ? kMemoWords * kMemoStride : 0u) + threadIdx.x;
+    const uint32_t lane_id = RESW ? threadIdx.x & 63u : threadIdx.x, wave_id = RESW ? threadIdx.x >> 6 : 0u;   // one wave per block otherwise
+    uint32_t *const s_inline = s_inline_all + wave_id * 2 * kMaxInline;
+    const uint32_t stage_words = RESW ? 4u * kResNodes + A0.res_small_words : A0.stage_words;
+    // dynamic LDS: [staged scene | resident stage: node planes, record block][fused: instance memo, kMemoWords x 64 words per wave][traversal stack columns]
+    const uint32_t memo_words = FUSED ? (RESW ? (A0.res_memo ? RESW * kMemoWords * kMemoStride : 0u) : kMemoWords * kMemoStride) : 0u;
+    uint32_t *stack = (uint32_t *) (lds + stage_words) + memo_words + threadIdx.x;
     // One block per 512-lane segment -- or, for a small frame whose whole path runs inline (rp.chunk_blocks = 8: nothing is compacted for a
     // later launch), one block per 64-lane chunk, so that a 1 M-lane frame is 16 384 waves instead of 2 048; the per-segment statistics are
     // then accumulated with atomics into slots the host has zeroed.
-    const uint32_t sub = FIRST ? A0.rp.chunk_blocks : 1u;                 // blocks per segment: 1 or kSeg / kShadeBlock
-    const uint32_t seg = sub > 1 ? blockIdx.x / sub : blockIdx.x, sub_index = sub > 1 ? blockIdx.x - seg * sub : 0u;
+    const uint32_t sub = FIRST && !RESW ? A0.rp.chunk_blocks : 1u;        // blocks per segment: 1 or kSeg / kShadeBlock
+    SceneView sv_res;
+    if (RESW) {   // the resident stage: every thread of the block copies, ONE barrier, then the waves go their own ways
+        const BlobHeader *gh = (const BlobHeader *) A0.scene;
+        const uint4 *gn = (const uint4 *) (A0.scene + gh->off_nodes);
+        const uint32_t n_pieces = gh->n_nodes * 4u;
+        for (uint32_t i = threadIdx.x; i < n_pieces; i += blockDim.x) lds[(i & 3u) * kResNodes + (i >> 2)] = gn[i];
+        const uint4 *gs = (const uint4 *) (A0.scene + A0.res_small_off);
+        for (uint32_t i = threadIdx.x; i < A0.res_small_words; i += blockDim.x) lds[4u * kResNodes + i] = gs[i];
+        __syncthreads();
+        const uint8_t *small = (const uint8_t *) (lds + 4u * kResNodes) - A0.res_small_off;   // blob offsets of the copied block resolve into LDS
+        sv_res = make_view(A0.scene);
+        sv_res.nodes = (const DNode *) lds;
+        sv_res.groups = (const DGroup *) (small + gh->off_groups); sv_res.shapes = (const DShape *) (small + gh->off_shapes);
+        sv_res.tris = (const DTri *) (small + gh->off_tris); sv_res.shading = (const DTriShade *) (small + gh->off_shading);
+        sv_res.emitters = (const DEmitter *) (small + gh->off_emitters);
+    }
+    for (uint32_t seg_first = 1;; seg_first = 0) {   // resident: until the segment counter runs out; otherwise once
+    uint32_t seg, sub_index = 0;
+    if (RESW) {
+        uint32_t taken = 0;
+        if (lane_id == 0) taken = atomicAdd(A0.q.seg_counter, 1u);
+        seg = (uint32_t) __builtin_amdgcn_readfirstlane((int) taken);
+        if (seg >= A0.n_seg) break;
+    } else {
+        seg = sub > 1 ? blockIdx.x / sub : blockIdx.x; sub_index = sub > 1 ? blockIdx.x - seg * sub : 0u;
+    }
+    (void) seg_first;
     const uint32_t count = seg_count(A0.count_in, seg, A0.rp.n_lanes);
     uint32_t n_alive = 0, n_shadow = 0;
-    if (FIRST && threadIdx.x < 2 * kMaxInline) s_inline[threadIdx.x] = 0;   // one wave per block: no barrier needed
+    if (FIRST && lane_id < 2 * kMaxInline) s_inline[lane_id] = 0;   // a wave's own slots: no barrier needed
     if (count != 0) {
     const uint8_t *base = LDS ? stage_scene(A0.scene, A0.scene_bytes, lds) : A0.scene;
-    SceneView sv = make_view(base);
-    if (FUSED) { sv.memo_obj = A0.rp.memo_obj; sv.memo = (float *) (lds + stage_words) + threadIdx.x; }
+    SceneView sv = RESW ? sv_res : make_view(base);
+    if (FUSED) { sv.memo_obj = A0.rp.memo_obj; sv.memo = (float *) (lds + stage_words) + (RESW ? wave_id * kMemoWords * kMemoStride + lane_id : threadIdx.x); }
     const bool have_memo = FUSED && sv.memo_obj != 0xffffffffu;
     for (uint32_t cbase = sub > 1 ? sub_index * kShadeBlock : 0u; cbase < (sub > 1 ? (sub_index + 1) * kShadeBlock < count ? (sub_index + 1) * kShadeBlock : count : count); cbase += kShadeBlock) {
     uint32_t rebase = 0;
@@ -171,7 +209,7 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
     const RenderParams &rp = A.rp; const Queues &q = A.q;
     const uint32_t *const qin = A.qin; uint32_t *const qout = A.qout; const uint32_t depth0 = A.depth, trace_next_last = A.trace_next; LaneDebug *const dbg = A.dbg;
     const uint32_t flat = FUSED && !MESH ? rp.flat_objects : 0u;   // != 0: the scene's object count, every ray tests them all (trace_flat)
-    uint32_t j = cbase + threadIdx.x;
+    uint32_t j = cbase + lane_id;
     bool in_range = j < count;
     bool alive = false, want_shadow = false;
     uint32_t l = 0;
@@ -190,7 +228,9 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
         l = qin ? qin[seg * kSeg + j] : seg * kSeg + j;
         if (FIRST) {
             // the wave's 64 lanes are the 64-aligned lanes [lane_base + seg * 512 + cbase, + 64): samples of one pixel if spp is a multiple of 64
-            const bool wave_pixel = rp.spp_log2 != 0xffffffffu && rp.spp_log2 >= 6 && (rp.lane_base & 63u) == 0;
+            // ... AND the whole wave is in range: the pair swap of the correlated seeding (generate_lane) reads the partner lane, which a ragged tail
+            // (dtof_sample_lanes with an odd count) would leave inactive
+            const bool wave_pixel = rp.spp_log2 != 0xffffffffu && rp.spp_log2 >= 6 && (rp.lane_base & 63u) == 0 && count - cbase >= (uint32_t) kShadeBlock;
             const PrimaryLane pl = generate_lane(rp, global_lane(rp, rp.lane_base + l), wave_pixel, rp.lane_base + l);
             ra = pl.ray_a; rb = pl.ray_b; main = pl.main; path = pl.path; st = make_float4(1.f, 1.f, 1.f, 0.f);
             q.pos[l] = pl.pos;
@@ -202,7 +242,7 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
             if (have_memo) instance_memo_fill(sv, ra.w, memo_m, memo_inv);
             Hit h;
             bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h)
-                              : trace_scene<false, MESH, FUSED>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
+                              : trace_scene<false, MESH, FUSED, RESW != 0>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
             hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
             hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu;
         }
@@ -642,7 +682,7 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
         if (alive && trace_next) qout[seg * kSeg + slot] = l;
     } else {   // FIRST, one wave per block
         const uint32_t n_on = (uint32_t) __popcll(__ballot(alive));
-        if (threadIdx.x == 0) s_inline[2 * it] += n_on;
+        if (lane_id == 0) s_inline[2 * it] += n_on;
     }
     if (FUSED) {
         bool commit = false;
@@ -652,7 +692,7 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
             commit = sha.w > 0.f;
 #else
             commit = flat ? !trace_flat<true, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs)
-                          : !trace_scene<true, MESH, true>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
+                          : !trace_scene<true, MESH, true, RESW != 0>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
 #endif
         }
         if (FIRST) {   // the running result stays in rbase over the inline iterations; every lane's result is defined after the last (nothing zeroed it)
@@ -671,13 +711,13 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
             bool found = nra.x < 1e30f; h.t = 0.5f + 0.1f * nrb.x; h.u = nrb.y; h.v = nrb.z; h.obj = nrb.x > 0.3f ? 3 : nrb.y > 0.f ? 1 : 0; h.shape = 0; h.prim = 0;
 #else
             bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h)
-                              : trace_scene<false, MESH, true>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
+                              : trace_scene<false, MESH, true, RESW != 0>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
 #endif
             if (!FIRST || last) store_hit<MESH>(q, l, h, found);
             if (FIRST) { hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim); hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu; }
         }
         const uint32_t n_sh = (uint32_t) __popcll(__ballot(want_shadow)) * ((threadIdx.x & 63) == 0 ? 1u : 0u);   // per-wave partial (stats only)
-        if (last) n_shadow += n_sh; else if (threadIdx.x == 0) s_inline[2 * it + 1] += n_sh;
+        if (last) n_shadow += n_sh; else if (lane_id == 0) s_inline[2 * it + 1] += n_sh;
     } else {
         uint32_t sslot = seg * kSeg + block_append(want_shadow, s_cnt, n_shadow);
         if (want_shadow) {
@@ -701,11 +741,11 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
         __syncthreads();
         n_shadow = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     }
-    if (threadIdx.x == 0) {
+    if (lane_id == 0) {
         if (sub > 1) { atomicAdd(&A0.alive_out[seg], n_alive); atomicAdd(&A0.shadow_out[seg], n_shadow); }
         else { A0.alive_out[seg] = n_alive; A0.shadow_out[seg] = n_shadow; }
         if (FIRST) {   // the count slots of the inline iterations before the last lie 2 * n_seg words apart below the last one's (render_rows)
-            const uint32_t n_inl = A0.rp.inline_iters, n_seg = gridDim.x / sub;
+            const uint32_t n_inl = A0.rp.inline_iters, n_seg = RESW ? A0.n_seg : gridDim.x / sub;
             for (uint32_t i = 0; i + 1 < n_inl; ++i) {
                 uint32_t *slot = A0.alive_out - (size_t) 2 * (n_inl - 1 - i) * n_seg;
                 if (sub > 1) { atomicAdd(&slot[seg], s_inline[2 * i]); atomicAdd(&slot[n_seg + seg], s_inline[2 * i + 1]); }
@@ -713,6 +753,8 @@ __global__ __launch_bounds__(kShadeBlock, (MODE == 2 && !MESH && !SPEC && KMAX =
             }
         }
     }
+    if (!RESW) break;
+    }   // segments of a resident wave
 }
 
 // ---------------------------------------------------------------------------- shadow
@@ -1200,14 +1242,36 @@ void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
 void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                   const uint32_t *qin, const uint32_t *count_in, uint32_t *qout,
                   uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, bool fused, bool trace_next,
-                  uint32_t stack_depth, hipStream_t s, bool first, LaneDebug *dbg) {
+                  uint32_t stack_depth, hipStream_t s, bool first, LaneDebug *dbg, const ResidentStage *resident) {
     if (rp.n_lanes == 0) return;
+    static_assert(kResidentNodes == kResNodes, "resident stage size");
+    if (resident && resident->waves && first && fused && rp.has_tris && rp.chunk_blocks <= 1) {
+        // one block of `waves` waves per CU; LDS = node planes + record block + (instance memo) + stack columns, well above the 64 KiB default limit
+        const uint32_t waves = resident->waves, block = waves * 64;
+        const uint32_t memo = rp.memo_obj != 0xffffffffu ? 1u : 0u;
+        const uint32_t lds = (4u * kResNodes + resident->small_words) * 16u + memo * waves * kMemoWords * kMemoStride * 4u + stack_bytes(stack_depth, block);
+        if (lds + 1024 > 160 * 1024) throw std::runtime_error("resident stage: the scene does not fit the 160 KiB of LDS");
+        static const int n_cu = [] { int dev = 0, n = 0; (void) hipGetDevice(&dev); (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        const uint32_t n_seg = nseg(rp.n_lanes), grid = std::min<uint32_t>((uint32_t) n_cu, (n_seg + waves - 1) / waves);
+        const ShadeArgs sa = { scene, scene_bytes, 0u, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, trace_next ? 1u : 0u, dbg, n_seg, resident->small_off, resident->small_words, memo };
+        (void) hipMemsetAsync(q.seg_counter, 0, 4, s);
+#define DTOF_LAUNCH_RES(A, K, S, W) do { static uint32_t attr_lds = 0;   /* the kernel's static LDS (count slots) comes on top of the dynamic size */ \
+            if (lds > attr_lds) { if (hipFuncSetAttribute((const void *) k_shade<false, 2, A, K, true, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); attr_lds = lds; } \
+            hipLaunchKernelGGL((k_shade<false, 2, A, K, true, S, W>), dim3(grid), dim3(block), lds, s, sa); } while (0)
+#define DTOF_RES_AKS(W) do { if (rp.has_spec) { if (rp.n_offsets == 1) DTOF_LAUNCH_RES(true, 1, true, W); else DTOF_LAUNCH_RES(true, kMaxOffsets, true, W); } \
+                             else if (rp.has_area) { if (rp.n_offsets == 1) DTOF_LAUNCH_RES(true, 1, false, W); else DTOF_LAUNCH_RES(true, kMaxOffsets, false, W); } \
+                             else { if (rp.n_offsets == 1) DTOF_LAUNCH_RES(false, 1, false, W); else DTOF_LAUNCH_RES(false, kMaxOffsets, false, W); } } while (0)
+        if (waves == 12) DTOF_RES_AKS(12); else if (waves == 8) DTOF_RES_AKS(8); else throw std::runtime_error("resident stage: 8 or 12 waves per block");
+#undef DTOF_RES_AKS
+#undef DTOF_LAUNCH_RES
+        return;
+    }
     const uint32_t shade_stack = fused ? stack_bytes(stack_depth, kShadeBlock) + kMemoWords * kMemoStride * 4 : 0;   // + the instance memo
     uint32_t sw = stage_words_for(scene_bytes, shade_stack), grid = nseg(rp.n_lanes) * (first && rp.chunk_blocks > 1 ? rp.chunk_blocks : 1u), lds = sw * 16 + shade_stack;
     check_lds(lds);
     uint32_t tn = trace_next ? 1u : 0u;
 #define DTOF_LAUNCH_SHADE(L, F, A, K) do { if (rp.has_tris) DTOF_LAUNCH_SHADE_M(L, F, A, K, true, false); else DTOF_LAUNCH_SHADE_M(L, F, A, K, false, false); } while (0)
-    const ShadeArgs sa = { scene, scene_bytes, sw, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, tn, dbg };
+    const ShadeArgs sa = { scene, scene_bytes, sw, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, tn, dbg, nseg(rp.n_lanes), 0u, 0u, 0u };
 #define DTOF_LAUNCH_SHADE_M(L, F, A, K, M, S) hipLaunchKernelGGL((k_shade<L, F, A, K, M, S>), dim3(grid), dim3(kShadeBlock), lds, s, sa)
 #define DTOF_SHADE_AK(L, F) do { if (rp.has_spec) { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE_M(L, F, true, 1, true, true); else DTOF_LAUNCH_SHADE_M(L, F, true, kMaxOffsets, true, true); } \
                                  else if (rp.has_area) { if (rp.n_offsets == 1) DTOF_LAUNCH_SHADE(L, F, true, 1); else DTOF_LAUNCH_SHADE(L, F, true, kMaxOffsets); } \

@@ -70,13 +70,14 @@ struct Workspace {
         ray_a.ensure(capacity); ray_b.ensure(capacity); st_a.ensure(capacity); st_b.ensure(capacity);
         res.ensure((size_t) capacity * k); sh_a.ensure(capacity); sh_b.ensure(capacity); sh_c.ensure((size_t) capacity * k);
         hit.ensure(capacity); hit_t.ensure(capacity); rng_a.ensure(capacity); hit_id.ensure(capacity); q0.ensure(capacity); q1.ensure(capacity);
-        counts.ensure(2 * (size_t) kMaxIter * segments_for(capacity)); pos.ensure(capacity); rng_b.ensure(capacity); st_c.ensure(capacity);
+        counts.ensure(2 * (size_t) kMaxIter * segments_for(capacity) + 16); pos.ensure(capacity); rng_b.ensure(capacity); st_c.ensure(capacity);   // + the segment counter of the resident kernel
     }
     Queues queues() {
         Queues q; memset(&q, 0, sizeof q);
         q.ray_a = ray_a.p; q.ray_b = ray_b.p; q.hit = hit.p; q.hit_t = hit_t.p; q.hit_id = hit_id.p; q.st_a = st_a.p; q.st_b = st_b.p; q.rng_a = rng_a.p; q.rng_b = rng_b.p; q.st_c = st_c.p;
         q.res = res.p; q.pos = pos.p; q.sh_a = sh_a.p; q.sh_b = sh_b.p; q.sh_c = sh_c.p; q.q[0] = q0.p; q.q[1] = q1.p;
         q.counts = counts.p; q.capacity = capacity;
+        q.seg_counter = counts.p + 2 * (size_t) kMaxIter * segments_for(capacity);
         return q;
     }
 };
@@ -393,6 +394,18 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         rp.flat_objects = fused && !rp.has_tris && bh->off_flat != 0 && env_flat ? bh->n_objects : 0u;
         rp.flat_off = bh->off_flat;
     }
+    // Resident stage of the fused first-bounce kernel (dtof_kernels.hip, k_shade<..., RESW>): scenes whose blob is too large to stage whole but whose
+    // TLAS (at most kResidentNodes nodes, no per-mesh BLAS) and small records fit one CU's LDS beside the stack columns -- Domino: 1 024 nodes, one
+    // shared 12-triangle cube, 1 025 instance records that stay in global memory.  DTOF_RESIDENT=0 switches it off, =8 runs 8 waves per block.
+    ResidentStage resident;
+    {
+        const int env_res = [] { const char *e = getenv("DTOF_RESIDENT"); return e ? atoi(e) : 12; }();   // read per call: tests and A/B runs switch it
+        const uint32_t small_off = bh->off_groups, small_bytes = bh->off_tables - bh->off_groups;          // groups | shapes | emitters | triangles | shading data
+        if (fused && (env_res == 8 || env_res == 12) && rp.has_tris && !rp.has_blas && bh->n_nodes > 0 && bh->n_nodes <= kResidentNodes && blob_bytes > 16 * 1024 &&
+            bh->off_shapes > bh->off_groups && bh->off_emitters > bh->off_groups && bh->off_tris > bh->off_groups && bh->off_shading >= bh->off_tris && small_bytes <= 24 * 1024) {
+            resident.small_off = small_off; resident.small_words = (small_bytes + 15) / 16; resident.waves = (uint32_t) env_res;
+        }
+    }
     StageTimer tm(stats != nullptr, sc);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     struct EventGuard { hipEvent_t e = nullptr; ~EventGuard() { if (e) (void) hipEventDestroy(e); } } g_fork, g_join;   // released on every exit path
@@ -464,7 +477,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             it += span - 1;   // `it` is now the last iteration this launch covers
             {   // small frames whose whole path runs inline: one block per 64-lane chunk (8 x the waves); the count slots it adds into are zeroed first
                 const bool whole_path = first && !((it + 1 < rp.max_depth) && !(it + 2 >= rp.max_depth && skip_tail));
-                static const uint32_t env_chunk_segs = [] { const char *e = getenv("DTOF_CHUNK_SEGS"); return e ? (uint32_t) atoi(e) : 8192u; }();   // frames up to this many segments (A/B switch)
+                const uint32_t env_chunk_segs = [] { const char *e = getenv("DTOF_CHUNK_SEGS"); return e ? (uint32_t) atoi(e) : 8192u; }();   // frames up to this many segments (A/B switch; read per call: tests switch it)
                 rp.chunk_blocks = whole_path && n_seg <= env_chunk_segs ? kChunkBlocks : 1u;
                 if (rp.chunk_blocks > 1) HIP_CHECK(hipMemsetAsync(q.counts, 0, (size_t) 2 * (it + 1) * n_seg * 4, s));
             }
@@ -475,7 +488,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             // the slots are reused -- only the statistics lose those iterations, no path is cut short
             uint32_t *qout = q.q[it & 1], *alive_out = q.counts + (size_t) (2 * (it % kMaxIter)) * n_seg, *shadow_out = alive_out + n_seg;
             const int st_shade = first ? 5 : 2;
-            t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it + 1 - span, fused, next_runs, stack_depth, s, first, first && dump_now ? sc->ws.dbg.p : nullptr); tm.end(st_shade, t, s);
+            t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it + 1 - span, fused, next_runs, stack_depth, s, first, first && dump_now ? sc->ws.dbg.p : nullptr, &resident); tm.end(st_shade, t, s);
             if (stats && first) { stats->n_launches_first++; stats->n_inline_iterations += span; batch_inline.push_back(span); }
             if (!fused) { t = tm.begin(3, s); launch_shadow(blob, blob_bytes, rp, q, shadow_out, stack_depth, s); tm.end(3, t, s); if (stats) stats->n_launches_shadow++; }
             if (stats) stats->n_launches_shade++;

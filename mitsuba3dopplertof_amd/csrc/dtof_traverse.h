@@ -22,6 +22,11 @@ struct SceneView {
     // dopplertofpath.cpp:93,240-244).  memo_obj = 0xffffffff: no memo.
     uint32_t memo_obj; float *memo;
 };
+// Resident scene stage (k_shade<..., RESW>): the TLAS nodes live in LDS as FOUR PLANES of 16-byte pieces -- piece k of node i at
+// uint4 index k * kResNodes + i -- so that the 16 lanes of a ds_read_b128 lane group, which read the same piece of 16 different nodes,
+// spread over all 64 banks (node-major 64-byte records would put piece k of every node on the same 16 banks: 4-way conflicts on
+// average); the plane stride is a compile-time constant, so the four reads of a node step are one address plus immediate offsets.
+constexpr uint32_t kResNodes = 1024;
 DTOF_D SceneView make_view(const uint8_t *base) {
     const BlobHeader *h = (const BlobHeader *) base;
     SceneView v;
@@ -187,9 +192,10 @@ DTOF_D float box_entry(const float *bmin, const float *bmax, V3 o, V3 id, float 
 #ifndef DTOF_BVH4
 // One BVH node = four 16-byte loads issued together (no load depends on a field of the node); entry distances of both
 // children, INFINITY = missed / absent.
-DTOF_D void node_test(const BvhNode *node, V3 o, V3 id, float tbest, float &tl, float &tr, uint32_t &left, uint32_t &right) {
-    const uint4 *np = (const uint4 *) node;
-    const uint4 a = np[0], b = np[1], c = np[2], d = np[3];
+template <bool SOA = false>
+DTOF_D void node_test(const BvhNode *nodes, uint32_t cur, V3 o, V3 id, float tbest, float &tl, float &tr, uint32_t &left, uint32_t &right) {
+    const uint4 *np = SOA ? (const uint4 *) nodes + cur : (const uint4 *) (nodes + cur);
+    const uint4 a = np[0], b = np[SOA ? kResNodes : 1], c = np[SOA ? 2 * kResNodes : 2], d = np[SOA ? 3 * kResNodes : 3];
     const float lmin[3] = { u2f(a.x), u2f(a.y), u2f(a.z) }, lmax[3] = { u2f(b.x), u2f(b.y), u2f(b.z) };
     const float rmin[3] = { u2f(c.x), u2f(c.y), u2f(c.z) }, rmax[3] = { u2f(d.x), u2f(d.y), u2f(d.z) };
     left = a.w; right = b.w;
@@ -198,9 +204,10 @@ DTOF_D void node_test(const BvhNode *node, V3 o, V3 id, float tbest, float &tl, 
     if (right == kNoChild) tr = INFINITY;
 }
 // one traversal step at inner node `cur`: continue with the nearest child that is hit, push the other, pop when nothing is hit
+template <bool SOA = false>
 DTOF_D uint32_t node_step(const BvhNode *nodes, uint32_t cur, V3 o, V3 id, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride, uint32_t done) {
     float tl, tr; uint32_t left, right;
-    node_test(nodes + cur, o, id, tbest, tl, tr, left, right);
+    node_test<SOA>(nodes, cur, o, id, tbest, tl, tr, left, right);
     const bool hl = tl < INFINITY, hr = tr < INFINITY;
     if (hl && hr) {
         const uint32_t nearc = tl <= tr ? left : right, farc = tl <= tr ? right : left;
@@ -350,7 +357,7 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
 }
 
 // TLAS traversal; `stack` is a per-thread LDS column (stride blockDim.x).
-template <bool ANY, bool MESH, bool MEMO = false>
+template <bool ANY, bool MESH, bool MEMO = false, bool SOA = false>   // SOA: the TLAS nodes are the LDS planes of the resident stage (binary nodes only)
 DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best) {
     best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
     if (sv.n_nodes == 0) return false;
@@ -368,7 +375,11 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
     for (;;) {
         while (!(cur & kLeafFlag) && cur != kDone) {
             DTOF_STAT(1); DTOF_STAT_WAVE(2);
+#ifndef DTOF_BVH4
+            cur = node_step<SOA>(sv.nodes, cur, o, id, best.t, stack, sp, 0, stride, kDone);
+#else
             cur = node_step(sv.nodes, cur, o, id, best.t, stack, sp, 0, stride, kDone);
+#endif
         }
         if (cur == kDone) break;
         DTOF_STAT(3); DTOF_STAT_WAVE(4);

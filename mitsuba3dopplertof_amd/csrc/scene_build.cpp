@@ -170,7 +170,7 @@ static uint32_t stack_need(const std::vector<BvhNode4> &nodes, uint32_t ni) {
 }
 #endif
 
-static uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
+
 
 static Box tri_box(const DTri &t) {
     Box b; b.add(mk(t.p0[0], t.p0[1], t.p0[2])); b.add(mk(t.p1[0], t.p1[1], t.p1[2])); b.add(mk(t.p2[0], t.p2[1], t.p2[2])); return b;
@@ -185,6 +185,8 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     const char *blas_env = getenv("DTOF_BLAS"); const bool use_blas = !(blas_env && blas_env[0] == '0');   // DTOF_BLAS=0: loop over every triangle (debug)
     std::vector<Box> shape_boxes(sc.shapes.size());
     std::vector<std::pair<uint32_t, uint32_t>> tex_recs;   // (shape, word offset of its DTexture in `tables`)
+    std::vector<uint32_t> tex_rec_of(sc.textures.size(), 0xffffffffu);   // texture index -> word offset of its record: every texture is stored once, however many shapes use it
+    auto check_words = [&]() { if (tables.size() > 0x3fffffffu) throw std::runtime_error("scene tables exceed the 4 GiB the 32-bit blob offsets address"); };
     for (size_t i = 0; i < sc.shapes.size(); ++i) {
         const HostShape &h = sc.shapes[i]; DShape &d = shapes[i];
         memset(&d, 0, sizeof d);
@@ -199,15 +201,22 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         }
         if (h.tex_refl >= 0) {   // the texture record and its texels go to the tables area; the offset is rebased below
             const HostTexture &t = sc.textures[(size_t) h.tex_refl];
-            while (tables.size() % 4) tables.push_back(0);            // 16-byte aligned record (the offset is stored >> 4)
-            const uint32_t rec = (uint32_t) tables.size();
-            DTexture dt; memset(&dt, 0, sizeof dt);
-            dt.kind_flags = t.kind | (t.filter << 8) | (t.wrap << 16) | (t.channels << 24);
-            dt.width = t.width; dt.height = t.height; dt.data_off = (rec + (uint32_t) (sizeof(DTexture) / 4)) * 4u;
-            memcpy(dt.to_uv, t.to_uv, 16); memcpy(dt.color0, t.color0, 12); memcpy(dt.color1, t.color1, 12);
-            const uint32_t *w = (const uint32_t *) &dt;
-            tables.insert(tables.end(), w, w + sizeof(DTexture) / 4);
-            for (float v : t.data) { uint32_t b; memcpy(&b, &v, 4); tables.push_back(b); }
+            uint32_t &rec = tex_rec_of[(size_t) h.tex_refl];
+            if (rec == 0xffffffffu) {
+                while (tables.size() % 4) tables.push_back(0);            // 16-byte aligned record (the offset is stored >> 4)
+                check_words();
+                rec = (uint32_t) tables.size();
+                DTexture dt; memset(&dt, 0, sizeof dt);
+                dt.kind_flags = t.kind | (t.filter << 8) | (t.wrap << 16) | (t.channels << 24);
+                dt.width = t.width; dt.height = t.height; dt.data_off = (rec + (uint32_t) (sizeof(DTexture) / 4)) * 4u;
+                memcpy(dt.to_uv, t.to_uv, 16); memcpy(dt.color0, t.color0, 12); memcpy(dt.color1, t.color1, 12);
+                const uint32_t *w = (const uint32_t *) &dt;
+                tables.insert(tables.end(), w, w + sizeof(DTexture) / 4);
+                const size_t at = tables.size();
+                tables.resize(at + t.data.size());
+                if (!t.data.empty()) memcpy(&tables[at], t.data.data(), t.data.size() * 4);
+                check_words();
+            }
             tex_recs.emplace_back((uint32_t) i, rec);
         }
         if (h.emitter) { d.flags |= SF_EMITTER; memcpy(d.radiance, h.radiance, 12); }
@@ -459,15 +468,18 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     h.n_shapes = (uint32_t) shapes.size(); h.n_tris = (uint32_t) tris.size(); h.n_emitters = (uint32_t) emitters.size();
     (void) has_instances;
     h.tlas_depth = need_tlas + need_blas;
-    uint32_t off = sizeof(BlobHeader);
-    h.off_nodes = off;    off = align16(off + (uint32_t) (dev_nodes.size() * sizeof(DNode)));
-    h.off_objects = off;  off = align16(off + (uint32_t) (objects.size() * sizeof(DObject)));
-    h.off_groups = off;   off = align16(off + (uint32_t) (groups.size() * sizeof(DGroup)));
-    h.off_shapes = off;   off = align16(off + (uint32_t) (shapes.size() * sizeof(DShape)));
-    h.off_emitters = off; off = align16(off + (uint32_t) (emitters.size() * sizeof(DEmitter)));
-    h.off_tris = off;     off = align16(off + (uint32_t) (tris.size() * sizeof(DTri)));
-    h.off_shading = off;  off = align16(off + (uint32_t) (shading.size() * sizeof(DTriShade)));
-    h.off_tables = off;   off = align16(off + (uint32_t) (tables.size() * 4));
+    // offsets are accumulated in 64 bits and the total is checked: every offset in the blob is a uint32_t
+    uint64_t off = sizeof(BlobHeader);
+    auto place = [&](uint64_t bytes) { const uint64_t at = off; off = (off + bytes + 15u) & ~(uint64_t) 15u;
+                                       if (off > 0xffffffffull) throw std::runtime_error("scene blob exceeds the 4 GiB its 32-bit offsets address"); return (uint32_t) at; };
+    h.off_nodes = place(dev_nodes.size() * sizeof(DNode));
+    h.off_objects = place(objects.size() * sizeof(DObject));
+    h.off_groups = place(groups.size() * sizeof(DGroup));
+    h.off_shapes = place(shapes.size() * sizeof(DShape));
+    h.off_emitters = place(emitters.size() * sizeof(DEmitter));
+    h.off_tris = place(tris.size() * sizeof(DTri));
+    h.off_shading = place(shading.size() * sizeof(DTriShade));
+    h.off_tables = place((uint64_t) tables.size() * 4);
     std::vector<DFlatObject> flat;   // small rectangle-only scenes: one 64-byte record per object for trace_flat
     {
         bool ok = !objects.empty() && objects.size() <= kFlatObjects && tris.empty();
@@ -482,8 +494,8 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
             flat.push_back(f);
         }
     }
-    h.off_flat = flat.empty() ? 0u : off; off = align16(off + (uint32_t) (flat.size() * sizeof(DFlatObject)));
-    h.total_bytes = off;
+    { const uint32_t at = place(flat.size() * sizeof(DFlatObject)); h.off_flat = flat.empty() ? 0u : at; }
+    h.total_bytes = (uint32_t) off;
     for (DShape &d : shapes) if (d.kind == SHAPE_MESH && (d.flags & SF_EMITTER)) d.emit_table += h.off_tables;
     for (DShape &d : shapes) if (d.bsdf == BSDF_ROUGHPLASTIC) d.rough_table += h.off_tables;
     for (uint32_t ei : env_records) {

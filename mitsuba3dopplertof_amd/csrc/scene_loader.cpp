@@ -607,6 +607,7 @@ void rough_plastic_tables(int type, float alpha, float eta, float *table, float 
 
 // ---- textures on the diffuse reflectances (src/textures/checkerboard.cpp:55-62, src/textures/bitmap.cpp:113-262, RGB variants)
 static thread_local std::vector<HostTexture> *g_textures = nullptr;   // the scene being assembled
+static thread_local std::map<const void *, int> *g_texture_index = nullptr;   // texture object -> its index in *g_textures: a texture referenced by many BSDFs / shapes is decoded and stored once
 static thread_local std::string g_base_dir;
 static float srgb_to_linear_u8(uint32_t v) {   // StructConverter::linearize + dr::srgb_to_linear (src/core/struct.cpp:1600-1625)
     const double x = (double) v / 255.0;
@@ -666,10 +667,14 @@ static int reflectance_of(const Obj &b, const char *name, float def, float out[3
         const std::string &cname = i < b.ref_names.size() && !b.ref_names[i].empty() ? b.ref_names[i] : c->name;
         if (cname != name) continue;
         if (c->tag != "texture") fail(std::string("property \"") + name + "\" must be a colour or a texture");
-        if (!g_textures) fail("internal error: no texture table");
-        g_textures->push_back(texture_of(*c));
-        out[0] = out[1] = out[2] = g_textures->back().mean;
-        return (int) g_textures->size() - 1;
+        if (!g_textures || !g_texture_index) fail("internal error: no texture table");
+        auto known = g_texture_index->find((const void *) c);
+        if (known == g_texture_index->end()) {
+            g_textures->push_back(texture_of(*c));
+            known = g_texture_index->emplace((const void *) c, (int) g_textures->size() - 1).first;
+        }
+        out[0] = out[1] = out[2] = (*g_textures)[(size_t) known->second].mean;
+        return known->second;
     }
     color_of(b, name, def, out);
     return -1;
@@ -779,6 +784,20 @@ static void bsdf_of(const Obj &b, HostShape &s) {
     } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, plastic, roughplastic, conductor, roughconductor, dielectric, thindielectric, roughdielectric, twosided)");
     auto u = b.props.unqueried();
     if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in plugin of type \"" + b.plugin + "\"");
+    // texture children: the slot that takes one was read above; a texture bound to any other property (or to a misspelt name) must not be dropped
+    // silently -- the reference either uses it or raises "unreferenced object" (xml.cpp:1204-1215)
+    const char *slot = b.plugin == "diffuse" ? "reflectance" : (b.plugin == "plastic" || b.plugin == "roughplastic") ? "diffuse_reflectance" : "";
+    for (size_t i = 0; i < b.children.size(); ++i) {
+        const Obj *c = b.children[i].second.get();
+        if (!c || c->tag != "texture") continue;
+        const std::string &cname = i < b.ref_names.size() && !b.ref_names[i].empty() ? b.ref_names[i] : c->name;
+        if (cname == slot) continue;
+        static const char *known[] = { "reflectance", "diffuse_reflectance", "specular_reflectance", "specular_transmittance", "alpha", "alpha_u", "alpha_v", "eta", "k" };
+        bool is_known = false;
+        for (const char *k : known) is_known |= cname == k;
+        fail(is_known ? "property \"" + cname + "\" of plugin \"" + b.plugin + "\" does not accept a texture in this build (constant values only)"
+                      : "unreferenced object \"" + cname + "\" in plugin of type \"" + b.plugin + "\"");
+    }
 }
 
 static void bake_cube(HostShape &s) {   // src/shapes/cube.cpp:114-160
@@ -1048,8 +1067,9 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
     resolve_refs(*top, ctx);
 
     HostScene sc; bool have_sensor = false, have_integrator = false;
-    g_textures = &sc.textures; g_base_dir = base_dir;
-    struct TexScope { ~TexScope() { g_textures = nullptr; } } tex_scope;
+    std::map<const void *, int> texture_index;
+    g_textures = &sc.textures; g_texture_index = &texture_index; g_base_dir = base_dir;
+    struct TexScope { ~TexScope() { g_textures = nullptr; g_texture_index = nullptr; } } tex_scope;
     std::map<const Obj *, uint32_t> group_of;
     for (auto &c : top->children) {
         const Obj &o = *c.second;

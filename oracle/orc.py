@@ -132,7 +132,8 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        # DTOF_ORACLE_LIB: another build of the same source (tools/oracle_opcount.py: the block-counting build)
+        L = C.CDLL(os.environ.get("DTOF_ORACLE_LIB") or build())
         L.orc_tea_float32.restype = C.c_float
         L.orc_tea_float32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
         L.orc_tea32.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]

@@ -113,6 +113,33 @@ def test_texture_error_behaviour(mi, tmp_path):
         mi.load_string(text.replace('<string name="wrap_mode" value="clamp" />', '<string name="wrap_mode" value="clamp" /><float name="gamma" value="2.2" />'))
 
 
+def test_textures_on_other_slots_fail_loudly_and_shared_textures_are_stored_once(mi):
+    """A texture bound to a property that takes constants only in this build, or to a misspelt name, must raise (the reference would use it
+    or report an unreferenced object, xml.cpp:1204-1215) instead of rendering the default colour; a texture that many shapes reference is
+    decoded and stored once (one texture record, one copy of the texels in the blob)."""
+    png = os.path.join(SCENES, "tex_rgb.png")
+    head = ('<scene version="3.0.0"><integrator type="path"/><sensor type="perspective"><float name="fov" value="40"/>'
+            '<film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/></film></sensor>')
+    tex = '<texture type="bitmap" name="%%s"><string name="filename" value="%s"/></texture>' % png
+    with pytest.raises(mi.DtofError, match="does not accept a texture"):
+        mi.load_string(head + '<shape type="rectangle"><bsdf type="plastic">' + tex % "specular_reflectance" + '</bsdf></shape></scene>')
+    with pytest.raises(mi.DtofError, match='unreferenced object "reflectanse"'):
+        mi.load_string(head + '<shape type="rectangle"><bsdf type="diffuse">' + tex % "reflectanse" + '</bsdf></shape></scene>')
+    with pytest.raises(mi.DtofError, match="does not accept a texture"):
+        mi.load_string(head + '<shape type="rectangle"><bsdf type="roughconductor">' + tex % "alpha" + '</bsdf></shape></scene>')
+    shared = head + '<bsdf type="diffuse" id="m">' + tex % "reflectance" + '</bsdf>' + ''.join(
+        '<shape type="rectangle"><transform name="to_world"><translate x="%d"/></transform><ref id="m"/></shape>' % k for k in range(40)) + '</scene>'
+    sc = mi.load_string(shared)
+    used = sc.export(15).astype(int)
+    assert len(used) == 40 and (used == 0).all()                      # every shape points at texture 0
+    assert sc.export(13).reshape(-1, 17).shape[0] == 1                # one record
+    from PIL import Image
+    w, h = Image.open(png).size
+    assert sc.export(14).size == w * h * 3                            # one copy of the texels
+    one = mi.load_string(shared.replace(''.join('<shape type="rectangle"><transform name="to_world"><translate x="%d"/></transform><ref id="m"/></shape>' % k for k in range(1, 40)), ''))
+    assert sc.info()["scene_blob_bytes"] - one.info()["scene_blob_bytes"] < 40 * 1024   # 39 more rectangles, not 39 more images
+
+
 def test_png_reader_handles_filters_palettes_and_alpha(mi, tmp_path):
     """the product's PNG reader against PIL: every scanline filter type (PIL picks them adaptively on a noisy image), RGBA, gray + alpha, palette"""
     from PIL import Image
