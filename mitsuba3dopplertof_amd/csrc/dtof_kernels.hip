@@ -85,12 +85,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 64 ? 6 : 1) void k_trace(const uint
     uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
     SceneView sv = make_view(base);
     uint32_t j = sub * kBlock + threadIdx.x;
-    if (j >= count) return;
-    uint32_t l = qin ? qin[seg * kSeg + j] : seg * kSeg + j;
-    float4 a = q.ray_a[l], b = q.ray_b[l];
+    const bool active = j < count;   // lanes past the end of the segment stay as helpers of the shared triangle loops (trace_rays)
+    uint32_t l = 0; float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 1.f, 0.f);
+    if (active) { l = qin ? qin[seg * kSeg + j] : seg * kSeg + j; a = q.ray_a[l]; b = q.ray_b[l]; }
     Hit h;
-    bool found = trace_scene<false, MESH>(sv, stack, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h);
-    store_hit<MESH>(q, l, h, found);
+    bool found = trace_rays<false, MESH>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h);
+    if (active) store_hit<MESH>(q, l, h, found);
 }
 
 // ---------------------------------------------------------------------------- shade
@@ -213,14 +213,14 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     bool in_range = j < count;
     bool alive = false, want_shadow = false;
     uint32_t l = 0;
-    float4 sha, shb, nra, nrb; float3 cand[KMAX];
+    float4 sha = make_float4(0.f, 0.f, 0.f, 0.f), shb = make_float4(0.f, 0.f, 1.f, 0.f), nra = sha, nrb = shb; float3 cand[KMAX];
     float3 rbase[KMAX];   // FIRST: the result a lane ends this launch with if its NEE candidate is not committed
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) rbase[k] = make_float3(0.f, 0.f, 0.f);
     // Path state of the lane.  MODE 2 runs rp.inline_iters iterations of the bounce loop right here ("megakernel" head): between them the
     // state stays in these registers instead of making the round trip through the queues in HBM; after the last one the survivors are
     // written out and compacted exactly as before, for the bounce kernels (MODE 1) to continue with.
-    uint32_t hid = 0xffffffffu; float4 ra, rb, st; uint4 hh; Rng main, path;
+    uint32_t hid = 0xffffffffu; float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 1.f, 0.f), st; uint4 hh; Rng main, path;
     float4 stb_reg = make_float4(0.f, 0.f, 0.f, 1.f); float2 stc_reg = make_float2(1.f, 1.f);   // prev_si.p | prev_bsdf_pdf, eta | prev_bsdf_delta
     float memo_m[12], memo_inv[12];   // instance memo: the one instance's matrix and inverse at this lane's ray time
     bool lane_on = in_range;
@@ -240,9 +240,13 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                 o.time = ra.w; o.ray_o[0] = ra.x; o.ray_o[1] = ra.y; o.ray_o[2] = ra.z; o.ray_d[0] = rb.x; o.ray_d[1] = rb.y; o.ray_d[2] = rb.z;
             }
             if (have_memo) instance_memo_fill(sv, ra.w, memo_m, memo_inv);
-            Hit h;
-            bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h)
-                              : trace_scene<false, MESH, FUSED, RESW != 0>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
+        }
+    }
+    if (FIRST) {   // the primary rays: a wave-uniform call (lanes past the end of the segment help with the shared triangle loops, trace_rays)
+        Hit h; bool found = false;
+        if (flat) { if (in_range) found = trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h); }
+        else found = trace_rays<false, MESH, FUSED, RESW != 0>(sv, stack, in_range, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
+        if (in_range) {
             hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
             hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu;
         }
@@ -686,13 +690,13 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     }
     if (FUSED) {
         bool commit = false;
-        if (want_shadow) {   // test_visibility (scene.cpp:266-271): an unoccluded sample commits its candidate result
+        {   // test_visibility (scene.cpp:266-271): an unoccluded sample commits its candidate result
             Hit hs;
 #if defined(DTOF_ABLATE) && (DTOF_ABLATE & 1)
-            commit = sha.w > 0.f;
+            commit = want_shadow && sha.w > 0.f;
 #else
-            commit = flat ? !trace_flat<true, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs)
-                          : !trace_scene<true, MESH, true, RESW != 0>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
+            if (flat) { if (want_shadow) commit = !trace_flat<true, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs); }
+            else if (__ballot(want_shadow)) commit = !trace_rays<true, MESH, true, RESW != 0>(sv, stack, want_shadow, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs) && want_shadow;
 #endif
         }
         if (FIRST) {   // the running result stays in rbase over the inline iterations; every lane's result is defined after the last (nothing zeroed it)
@@ -705,16 +709,19 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) q.res[(size_t) k * q.capacity + l] = make_float4(cand[k].x, cand[k].y, cand[k].z, 0.f);
         }
-        if (alive && trace_next) {   // closest hit of the continuation ray, consumed by the next bounce
-            Hit h;
+        const bool trace_now = alive && trace_next;
+        if (__ballot(trace_now)) {   // closest hit of the continuation ray, consumed by the next bounce (wave-uniform call, see trace_rays)
+            Hit h; bool found = false;
 #if defined(DTOF_ABLATE) && (DTOF_ABLATE & 2)
-            bool found = nra.x < 1e30f; h.t = 0.5f + 0.1f * nrb.x; h.u = nrb.y; h.v = nrb.z; h.obj = nrb.x > 0.3f ? 3 : nrb.y > 0.f ? 1 : 0; h.shape = 0; h.prim = 0;
+            found = nra.x < 1e30f; h.t = 0.5f + 0.1f * nrb.x; h.u = nrb.y; h.v = nrb.z; h.obj = nrb.x > 0.3f ? 3 : nrb.y > 0.f ? 1 : 0; h.shape = 0; h.prim = 0;
 #else
-            bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h)
-                              : trace_scene<false, MESH, true, RESW != 0>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
+            if (flat) { if (trace_now) found = trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h); }
+            else found = trace_rays<false, MESH, true, RESW != 0>(sv, stack, trace_now, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
 #endif
-            if (!FIRST || last) store_hit<MESH>(q, l, h, found);
-            if (FIRST) { hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim); hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu; }
+            if (trace_now) {
+                if (!FIRST || last) store_hit<MESH>(q, l, h, found);
+                if (FIRST) { hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim); hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu; }
+            }
         }
         const uint32_t n_sh = (uint32_t) __popcll(__ballot(want_shadow)) * ((threadIdx.x & 63) == 0 ? 1u : 0u);   // per-wave partial (stats only)
         if (last) n_shadow += n_sh; else if (lane_id == 0) s_inline[2 * it + 1] += n_sh;
@@ -770,12 +777,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 64 ? 6 : 1) void k_shadow(const uin
     uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
     SceneView sv = make_view(base);
     uint32_t j = sub * kBlock + threadIdx.x;
-    if (j >= count) return;
+    const bool active = j < count;
     uint32_t i = seg * kSeg + j;
-    float4 a = q.sh_a[i], b = q.sh_b[i];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 1.f, 0.f);
+    if (active) { a = q.sh_a[i]; b = q.sh_b[i]; }
     Hit h;
-    bool occluded = trace_scene<true, MESH>(sv, stack, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h);
-    if (!occluded) {
+    bool occluded = trace_rays<true, MESH>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h);
+    if (active && !occluded) {
 #pragma unroll
         for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) {
             float4 c = q.sh_c[(size_t) k * q.capacity + i];
@@ -795,15 +803,16 @@ __global__ __launch_bounds__(kBlock) void k_velocity(const uint8_t *scene, uint3
     uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
     SceneView sv = make_view(base);
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= rp.n_lanes) return;
-    float4 a = q.ray_a[i], b = q.ray_b[i];
+    const bool active = i < rp.n_lanes;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 1.f, 0.f);
+    if (active) { a = q.ray_a[i]; b = q.ray_b[i]; }
     V3 o = mk(a.x, a.y, a.z), d = mk(b.x, b.y, b.z);
     Hit h1, h2;
-    bool v1 = trace_scene<false, true>(sv, stack, o, d, 0.f, b.w, h1);
-    bool v2 = trace_scene<false, true>(sv, stack, o, d, rp.T, b.w, h2);
+    bool v1 = trace_rays<false, true>(sv, stack, active, o, d, 0.f, b.w, h1);
+    bool v2 = trace_rays<false, true>(sv, stack, active, o, d, rp.T, b.w, h2);
     float vel = ((v2 ? h2.t : 0.f) - (v1 ? h1.t : 0.f)) * (1.0f / rp.T);
     vel = (v1 && v2) ? vel : 0.f;
-    q.res[i] = make_float4(vel, vel, vel, 0.f);
+    if (active) q.res[i] = make_float4(vel, vel, vel, 0.f);
 }
 
 // ---------------------------------------------------------------------------- splat
@@ -1261,7 +1270,7 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
 #define DTOF_RES_AKS(W) do { if (rp.has_spec) { if (rp.n_offsets == 1) DTOF_LAUNCH_RES(true, 1, true, W); else DTOF_LAUNCH_RES(true, kMaxOffsets, true, W); } \
                              else if (rp.has_area) { if (rp.n_offsets == 1) DTOF_LAUNCH_RES(true, 1, false, W); else DTOF_LAUNCH_RES(true, kMaxOffsets, false, W); } \
                              else { if (rp.n_offsets == 1) DTOF_LAUNCH_RES(false, 1, false, W); else DTOF_LAUNCH_RES(false, kMaxOffsets, false, W); } } while (0)
-        if (waves == 12) DTOF_RES_AKS(12); else if (waves == 8) DTOF_RES_AKS(8); else throw std::runtime_error("resident stage: 8 or 12 waves per block");
+        if (waves == 12) DTOF_RES_AKS(12); else if (waves == 8) DTOF_RES_AKS(8); else if (waves == 16) DTOF_RES_AKS(16); else throw std::runtime_error("resident stage: 8, 12 or 16 waves per block");
 #undef DTOF_RES_AKS
 #undef DTOF_LAUNCH_RES
         return;
@@ -1481,11 +1490,13 @@ __global__ __launch_bounds__(64) void k_ray_query(const uint8_t *scene, const fl
     uint32_t *stack = (uint32_t *) lds + threadIdx.x;
     const SceneView sv = make_view(scene);
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float *r = rays + (size_t) i * 8;
+    const bool active = i < n;
+    float r[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f };
+    if (active) for (int k = 0; k < 8; ++k) r[k] = rays[(size_t) i * 8 + k];
     const V3 o = mk(r[0], r[1], r[2]), d = mk(r[3], r[4], r[5]);
     Hit h;
-    const bool found = trace_scene<ANY, true>(sv, stack, o, d, r[6], r[7], h);
+    const bool found = trace_rays<ANY, true>(sv, stack, active, o, d, r[6], r[7], h);
+    if (!active) return;
     if (ANY) { ids[i] = found ? 1 : 0; return; }
     float *w = out + (size_t) i * 19;
     for (int k = 0; k < 19; ++k) w[k] = 0.f;

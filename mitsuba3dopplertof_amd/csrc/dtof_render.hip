@@ -281,6 +281,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
                  const float *offsets, int n_offsets, float *d_film, dtof_render_stats *stats,
                  LaneDebug *lane_dump = nullptr, uint64_t dump_begin = 0, uint64_t dump_n = 0,
                  uint32_t stripe_rows = 0, uint32_t stripe_period = 0) {
+    if (!sc->host.has_sensor) throw std::runtime_error("the scene does not contain a sensor");
     ensure_device(sc);
     const HostSensor &se = sc->host.sensor;
     if (spp == 0) spp = sc->pp.sample_count;
@@ -396,12 +397,13 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     }
     // Resident stage of the fused first-bounce kernel (dtof_kernels.hip, k_shade<..., RESW>): scenes whose blob is too large to stage whole but whose
     // TLAS (at most kResidentNodes nodes, no per-mesh BLAS) and small records fit one CU's LDS beside the stack columns -- Domino: 1 024 nodes, one
-    // shared 12-triangle cube, 1 025 instance records that stay in global memory.  DTOF_RESIDENT=0 switches it off, =8 runs 8 waves per block.
+    // shared 12-triangle cube, 1 025 instance records that stay in global memory.  DTOF_RESIDENT=0 switches it off, =8 / =12 / =16 set the waves per block.
     ResidentStage resident;
     {
-        const int env_res = [] { const char *e = getenv("DTOF_RESIDENT"); return e ? atoi(e) : 12; }();   // read per call: tests and A/B runs switch it
+        // 16 waves per CU (4 per SIMD, 128 VGPRs) beat 12 (168 VGPRs) once the nodes come from LDS: 44.2 vs 47.8 ms on Domino (profiles/r03_resident_stage_ab.txt)
+        const int env_res = [] { const char *e = getenv("DTOF_RESIDENT"); return e ? atoi(e) : 16; }();   // read per call: tests and A/B runs switch it
         const uint32_t small_off = bh->off_groups, small_bytes = bh->off_tables - bh->off_groups;          // groups | shapes | emitters | triangles | shading data
-        if (fused && (env_res == 8 || env_res == 12) && rp.has_tris && !rp.has_blas && bh->n_nodes > 0 && bh->n_nodes <= kResidentNodes && blob_bytes > 16 * 1024 &&
+        if (fused && (env_res == 8 || env_res == 12 || env_res == 16) && rp.has_tris && !rp.has_blas && bh->n_nodes > 0 && bh->n_nodes <= kResidentNodes && blob_bytes > 16 * 1024 &&
             bh->off_shapes > bh->off_groups && bh->off_emitters > bh->off_groups && bh->off_tris > bh->off_groups && bh->off_shading >= bh->off_tris && small_bytes <= 24 * 1024) {
             resident.small_off = small_off; resident.small_words = (small_bytes + 15) / 16; resident.waves = (uint32_t) env_res;
         }
@@ -565,6 +567,7 @@ dtof_scene *finish_scene(HostScene &&hs) {
     auto sc = new dtof_scene();
     try {
         sc->host = std::move(hs);
+        if (!sc->host.has_sensor && sc->host.sampler.plugin.empty()) sc->host.sampler.plugin = "independent";   // no sensor, no sampler: Sensor's default (sensor.cpp:63-66)
         sc->pp = make_plugin_params(sc->host.integrator, sc->host.sampler);
         {   // the hit record packs (object, shape in its group) into 32 bits (Queues::hit_id): the object index gets 24 bits unless a shapegroup
             // needs more than the remaining 8 for its shapes; 0xffffffff stays free as the "miss" value

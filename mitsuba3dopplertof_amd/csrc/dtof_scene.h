@@ -222,7 +222,7 @@ struct HostScene {
     std::vector<HostObject> objects;
     std::vector<HostEmitter> emitters;
     std::vector<HostTexture> textures;
-    HostSensor sensor;
+    HostSensor sensor; bool has_sensor = true;   // a scene without a <sensor> loads, as in the reference; rendering it fails
     PropBag integrator, sampler;
 };
 

@@ -23,14 +23,24 @@
 #include <sstream>
 #include <memory>
 #include <algorithm>
+#include <set>
+#include <initializer_list>
 
 namespace dtof {
 
 [[noreturn]] static void fail(const std::string &msg) { throw std::runtime_error(msg); }
+// xml.cpp:1204-1222: `unreferenced property "["a"]" in bsdf plugin of type "diffuse"` -- the reference prints the list of names (a std::vector
+// of quoted strings) inside the quotes of its format string
+[[noreturn]] static void fail_unreferenced(const std::vector<std::string> &names, const std::string &kind, const std::string &plugin) {
+    std::string list = "[";
+    for (size_t i = 0; i < names.size(); ++i) list += (i ? ", \"" : "\"") + names[i] + "\"";
+    fail(std::string("unreferenced ") + (names.size() > 1 ? "properties" : "property") + " \"" + list + "]\" in " + kind + " plugin of type \"" + plugin + "\"");
+}
 
 // ---------------------------------------------------------------------------- tiny XML DOM
 struct XNode {
     std::string tag;
+    size_t offset = 0;   // position of the tag name in the source text (what pugixml's offset_debug() reports: errors quote it as "line L, col C")
     std::vector<std::pair<std::string, std::string>> attrs;
     std::vector<std::unique_ptr<XNode>> children;
     const std::string *attr(const char *n) const {
@@ -78,6 +88,7 @@ struct XParser {
         if (p >= s.size() || s[p] != '<') fail("xml: expected '<' at offset " + std::to_string(p));
         ++p;
         auto n = std::make_unique<XNode>();
+        n->offset = p;
         n->tag = name();
         for (;;) {
             skip_ws();
@@ -109,6 +120,153 @@ struct XParser {
     }
     std::unique_ptr<XNode> document() { skip_misc(); auto r = element(); skip_misc(); return r; }
 };
+
+// ---------------------------------------------------------------------------- well-formedness of the scene description
+// The checks parse_xml makes on every node before it looks at values (src/core/xml.cpp:470-560,258-310), with its messages:
+// `Error while loading "<id>" (at line L, col C): <message>.` (XMLSource::throw_error, xml.cpp:213-217; the position is the tag name's).
+// Pinned by the reference's own tests (src/core/tests/test_xml.py -> tests/golden/reference_xml_cases.json).
+static thread_local const std::string *g_xml_text = nullptr;
+static thread_local std::string g_xml_id = "<string>";
+static std::string position_of(size_t offset) {
+    if (!g_xml_text) return "byte offset " + std::to_string(offset);
+    size_t line = 0, line_start = 0;
+    for (size_t i = 0; i < offset && i < g_xml_text->size(); ++i) if ((*g_xml_text)[i] == '\n') { ++line; line_start = i + 1; }
+    return "line " + std::to_string(line + 1) + ", col " + std::to_string(offset - line_start + 1);   // string_offset (xml.cpp:161-177), pugixml counts the '<'
+}
+[[noreturn]] static void fail_at(const XNode &n, const std::string &msg) {
+    fail("Error while loading \"" + g_xml_id + "\" (at " + position_of(n.offset) + "): " + msg + ".");
+}
+enum TagKind { TAG_INVALID, TAG_OBJECT, TAG_PROPERTY, TAG_VECTOR, TAG_TRANSFORM, TAG_ANIMATION, TAG_TRANSFORM_OP, TAG_REF, TAG_DEFAULT, TAG_PATH, TAG_INCLUDE, TAG_ALIAS };
+static TagKind tag_kind(const XNode &n) {
+    static const char *objects[] = { "scene", "integrator", "sensor", "sampler", "film", "rfilter", "bsdf", "shape", "emitter", "texture", "medium", "phase", "volume" };
+    for (auto *x : objects) if (n.tag == x) return TAG_OBJECT;
+    if (n.tag == "spectrum" && n.attr("type")) return TAG_OBJECT;   // a tag with a `type` attribute that names a plugin class is an object (xml.cpp:480-483)
+    for (auto *x : { "float", "integer", "boolean", "string", "rgb", "spectrum" }) if (n.tag == x) return TAG_PROPERTY;
+    if (n.tag == "point" || n.tag == "vector") return TAG_VECTOR;
+    if (n.tag == "transform") return TAG_TRANSFORM;
+    if (n.tag == "animation") return TAG_ANIMATION;
+    for (auto *x : { "translate", "rotate", "scale", "lookat", "matrix" }) if (n.tag == x) return TAG_TRANSFORM_OP;
+    if (n.tag == "ref") return TAG_REF;
+    if (n.tag == "default") return TAG_DEFAULT;
+    if (n.tag == "path") return TAG_PATH;
+    if (n.tag == "include") return TAG_INCLUDE;
+    if (n.tag == "alias") return TAG_ALIAS;
+    return TAG_INVALID;
+}
+// check_attributes (xml.cpp:273-287): every attribute must be one of `allowed`; with expect_all (or with no attribute at all) none may be missing
+static void check_attributes(const XNode &n, std::vector<std::string> allowed, bool expect_all = true, bool may_be_empty = false) {
+    bool found_one = may_be_empty;   // may_be_empty: attributes the reference adds itself when they are missing (`id`, `name` of objects and references)
+    for (auto &a : n.attrs) {
+        auto it = std::find(allowed.begin(), allowed.end(), a.first);
+        if (it == allowed.end()) fail_at(n, "unexpected attribute \"" + a.first + "\" in element \"" + n.tag + "\"");
+        allowed.erase(it); found_one = true;
+    }
+    if (!allowed.empty() && (!found_one || expect_all)) {
+        std::sort(allowed.begin(), allowed.end());   // the reference keeps the names in a std::set and reports the first one left
+        fail_at(n, "missing attribute \"" + allowed.front() + "\" in element \"" + n.tag + "\"");
+    }
+}
+// upgrade_tree (xml.cpp:338-365) for scene descriptions older than 2.0.0: camelCase property names become underscore_case, <lookAt> becomes
+// <lookat>, ids with a leading underscore are renamed, diffuse BSDFs' `diffuse_reflectance` becomes `reflectance`
+static void upgrade_tree(XNode &n, const XNode *parent) {
+    if (n.tag == "lookAt") n.tag = "lookat";
+    for (auto &a : n.attrs) {
+        if (a.first == "name" && n.tag != "default") {
+            std::string &name = a.second;
+            for (size_t i = 0; i + 1 < name.size(); ++i) {
+                if (islower((unsigned char) name[i]) && isupper((unsigned char) name[i + 1])) {
+                    name = name.substr(0, i + 1) + "_" + name.substr(i + 1);
+                    i += 2;
+                    while (i < name.size() && isupper((unsigned char) name[i])) { name[i] = (char) tolower((unsigned char) name[i]); ++i; }
+                }
+            }
+            if (name == "diffuse_reflectance" && parent && parent->tag == "bsdf" && parent->get("type") == "diffuse") name = "reflectance";
+        }
+        if (a.first == "id" && !a.second.empty() && a.second[0] == '_') a.second = "ID" + a.second + "__UPGR";
+    }
+    for (auto &c : n.children) upgrade_tree(*c, &n);
+}
+struct CheckCtx { std::map<std::string, size_t> ids; };
+static void check_tree(XNode &n, TagKind parent, int depth, CheckCtx &cc) {
+    const TagKind kind = tag_kind(n);
+    if (kind == TAG_INVALID) fail_at(n, "unexpected tag \"" + n.tag + "\"");
+    const bool has_parent = parent != TAG_INVALID, parent_is_object = parent == TAG_OBJECT, parent_is_transform = parent == TAG_TRANSFORM;
+    if (!has_parent && kind != TAG_OBJECT) fail_at(n, "root element \"" + n.tag + "\" must be an object");
+    if (parent_is_transform != (kind == TAG_TRANSFORM_OP))
+        fail_at(n, parent_is_transform ? "transform nodes can only contain transform operations" : "transform operations can only occur in a transform node");
+    if (has_parent && !parent_is_object && !((parent_is_transform && kind == TAG_TRANSFORM_OP) || (parent == TAG_ANIMATION && kind == TAG_TRANSFORM)))
+        fail_at(n, "node \"" + n.tag + "\" cannot occur as child of a property");
+    if (depth == 0 && !n.attr("version")) fail_at(n, "missing version attribute in root element \"" + n.tag + "\"");
+    if (auto *v = n.attr("version")) {
+        unsigned major = 0, minor = 0, patch = 0; char tail = 0;
+        if (sscanf(v->c_str(), "%u.%u.%u%c", &major, &minor, &patch, &tail) != 3) fail_at(n, "could not parse version number \"" + *v + "\"");
+        if (major < 2) upgrade_tree(n, nullptr);
+        for (size_t i = 0; i < n.attrs.size(); ++i) if (n.attrs[i].first == "version") { n.attrs.erase(n.attrs.begin() + (long) i); break; }
+    }
+    if (auto *name = n.attr("name")) {
+        if (!name->empty() && (*name)[0] == '_')
+            fail_at(n, "invalid parameter name \"" + *name + "\" in element \"" + n.tag + "\": leading underscores are reserved for internal identifiers");
+    }
+    if (auto *id = n.attr("id")) {
+        if (!id->empty() && (*id)[0] == '_')
+            fail_at(n, "invalid id \"" + *id + "\" in element \"" + n.tag + "\": leading underscores are reserved for internal identifiers");
+    }
+    switch (kind) {
+        case TAG_OBJECT: {
+            std::vector<std::string> allowed = { "id", "name" };
+            if (n.tag != "scene") allowed.push_back("type");
+            check_attributes(n, allowed, false, true);
+            if (n.tag != "scene" && !n.attr("type")) fail_at(n, "missing attribute \"type\" in element \"" + n.tag + "\"");
+            if (auto *id = n.attr("id")) {
+                auto prev = cc.ids.find(*id);
+                if (prev != cc.ids.end()) fail_at(n, "\"" + n.tag + "\" has duplicate id \"" + *id + "\" (previous was at " + position_of(prev->second) + ")");
+            }
+            std::vector<std::string> names;   // Properties::set_*: a name may be given once (properties.cpp:139-146)
+            for (auto &c : n.children) {
+                check_tree(*c, TAG_OBJECT, depth + 1, cc);
+                const TagKind ck = tag_kind(*c);
+                if (auto *cn = c->attr("name")) if (!cn->empty() && ck != TAG_DEFAULT) {
+                    if (std::find(names.begin(), names.end(), *cn) != names.end()) fail_at(*c, "Property \"" + *cn + "\" was specified multiple times!");
+                    names.push_back(*cn);
+                }
+            }
+            if (auto *id = n.attr("id")) cc.ids[*id] = n.offset;
+            return;
+        }
+        case TAG_REF: check_attributes(n, { "id", "name" }, false, true); if (!n.attr("id")) fail_at(n, "missing attribute \"id\" in element \"ref\""); break;
+        case TAG_ALIAS: check_attributes(n, { "id", "as" }); break;
+        case TAG_DEFAULT: {
+            check_attributes(n, { "name", "value" });
+            if (n.get("name").empty()) fail_at(n, "<default>: name must by nonempty");
+            if (n.get("name").find(',') != std::string::npos) fail_at(n, "Invalid character in parameter name: ',' in " + n.get("name"));
+            break;
+        }
+        case TAG_PATH: check_attributes(n, { "value" }); if (depth != 1) fail_at(n, "<path>: path can only be child of root"); break;
+        case TAG_INCLUDE: check_attributes(n, { "filename" }); break;
+        case TAG_PROPERTY:
+            if (n.tag == "spectrum") check_attributes(n, { "name", "value", "filename" }, false, true);
+            else check_attributes(n, { "name", "value" });
+            break;
+        case TAG_VECTOR:
+        case TAG_TRANSFORM_OP:
+            if (n.tag == "lookat") { check_attributes(n, { "origin", "target", "up" }, false, true); break; }
+            if (n.tag == "matrix") { check_attributes(n, { "value" }); break; }
+            if (n.attr("value")) {   // expand_value_to_xyz (xml.cpp:290-309)
+                if (n.attr("x") || n.attr("y") || n.attr("z")) fail_at(n, "can't mix and match \"value\" and \"x\"/\"y\"/\"z\" attributes");
+                size_t count = 0; bool in_tok = false;
+                for (char ch : n.get("value")) { const bool sep = ch == ',' || isspace((unsigned char) ch); if (!sep && !in_tok) ++count; in_tok = !sep; }
+                if (count != 1 && count != 3) fail_at(n, "\"value\" attribute must have exactly 1 or 3 elements");
+            }
+            if (kind == TAG_VECTOR) check_attributes(n, { "name", "x", "y", "z", "value" }, false, true);
+            else if (n.tag == "rotate") check_attributes(n, { "angle", "x", "y", "z", "value" }, false, true);
+            else check_attributes(n, { "x", "y", "z", "value" }, false, true);
+            break;
+        case TAG_TRANSFORM: check_attributes(n, parent == TAG_ANIMATION ? std::vector<std::string> { "time" } : std::vector<std::string> { "name" }, false, true); break;
+        case TAG_ANIMATION: check_attributes(n, { "name" }); break;
+        default: break;
+    }
+    for (auto &c : n.children) check_tree(*c, kind, depth + 1, cc);
+}
 
 // ---------------------------------------------------------------------------- double 4x4 helpers
 static Mat4d m_identity() { Mat4d r; for (int i = 0; i < 16; ++i) r.m[i] = (i % 5 == 0) ? 1.0 : 0.0; return r; }
@@ -147,16 +305,16 @@ static std::vector<std::string> tokenize(const std::string &v) {   // string::to
 }
 static double parse_double(const std::string &v) {
     size_t pos = 0; double d;
-    try { d = std::stod(v, &pos); } catch (...) { fail("could not parse floating point value \"" + v + "\""); }
+    try { d = std::stod(v, &pos); } catch (...) { fail("could not parse floating point value \"" + v + "\"."); }
     while (pos < v.size() && isspace((unsigned char) v[pos])) ++pos;
-    if (pos != v.size()) fail("could not parse floating point value \"" + v + "\"");
+    if (pos != v.size()) fail("could not parse floating point value \"" + v + "\".");
     return d;
 }
 static int64_t parse_int(const std::string &v) {
     size_t pos = 0; long long d;
-    try { d = std::stoll(v, &pos); } catch (...) { fail("could not parse integer value \"" + v + "\""); }
+    try { d = std::stoll(v, &pos); } catch (...) { fail("could not parse integer value \"" + v + "\"."); }
     while (pos < v.size() && isspace((unsigned char) v[pos])) ++pos;
-    if (pos != v.size()) fail("could not parse integer value \"" + v + "\"");
+    if (pos != v.size()) fail("could not parse integer value \"" + v + "\".");
     return d;
 }
 static void parse_xyz(const XNode &n, double def, double out[3]) {   // detail::expand_value_to_xyz + parse_vector
@@ -325,7 +483,7 @@ PluginParams make_plugin_params(const PropBag &ip, const PropBag &sp) {
     if (p.time_correlate_number <= 0 || p.path_correlate_number <= 0) fail("correlate numbers must be positive");
     for (const PropBag *b : { &ip, &sp }) {
         auto u = b->unqueried();
-        if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in plugin of type \"" + b->plugin + "\"");   // xml.cpp:1204-1215
+        if (!u.empty()) fail_unreferenced(u, b == &ip ? "integrator" : "sampler", b->plugin);   // xml.cpp:1204-1215
     }
     return p;
 }
@@ -351,6 +509,7 @@ static bool is_object_tag(const std::string &t) {
 struct LoadCtx {
     std::map<std::string, std::shared_ptr<Obj>> registry;
     std::vector<std::pair<std::string, std::string>> defaults;   // (name, value)
+    std::set<std::string> used;                                  // parameters some attribute referred to ("Unused parameter", xml.cpp:1067-1070)
 };
 
 // FileResolver (src/core/fresolver.cpp): the directories a relative file name is looked up in, first match wins; holds the scene file's
@@ -381,7 +540,7 @@ static void substitute(XNode &n, LoadCtx &ctx, int depth = 0, int include_depth 
             if (a.second.find('$') == std::string::npos) continue;
             for (auto &d : sorted) {
                 std::string key = "$" + d.first; size_t pos = 0;
-                while ((pos = a.second.find(key, pos)) != std::string::npos) { a.second.replace(pos, key.size(), d.second); pos += d.second.size(); }
+                while ((pos = a.second.find(key, pos)) != std::string::npos) { a.second.replace(pos, key.size(), d.second); pos += d.second.size(); ctx.used.insert(d.first); }
             }
             if (a.second.find('$') != std::string::npos) fail("undefined parameter(s) in string: \"" + a.second + "\"!");
         }
@@ -392,7 +551,7 @@ static void substitute(XNode &n, LoadCtx &ctx, int depth = 0, int include_depth 
         std::string name = n.get("name"), value = n.get("value");
         if (name.empty()) fail("<default>: name must by nonempty");
         bool found = false; for (auto &d : ctx.defaults) if (d.first == name) found = true;
-        if (!found) ctx.defaults.emplace_back(name, value);
+        if (!found) { ctx.defaults.emplace_back(name, value); ctx.used.insert(name); }   // a <default> of the file itself counts as used (xml.cpp:646)
     }
     if (n.tag == "path") {
         if (depth != 1) fail("<path>: path can only be child of root");
@@ -459,7 +618,7 @@ static std::shared_ptr<Obj> parse_object(const XNode &n, LoadCtx &ctx) {
         else if (c.tag == "integer") { v.type = PropValue::Int; v.i = parse_int(c.get("value")); o->props.values[name] = v; }
         else if (c.tag == "boolean") {
             std::string b = c.get("value"); std::transform(b.begin(), b.end(), b.begin(), ::tolower);
-            if (b != "true" && b != "false") fail("could not parse boolean value \"" + b + "\" -- must be \"true\" or \"false\"");
+            if (b != "true" && b != "false") fail("could not parse boolean value \"" + b + "\" -- must be \"true\" or \"false\".");
             v.type = PropValue::Bool; v.b = b == "true"; o->props.values[name] = v;
         }
         else if (c.tag == "string") { v.type = PropValue::String; v.s = c.get("value"); o->props.values[name] = v; }
@@ -519,6 +678,15 @@ static float lookup_ior(const Obj &b, const char *name, const char *def) {
     std::transform(key.begin(), key.end(), key.begin(), ::tolower);
     for (auto &e : table) if (key == e.first) return e.second;
     fail("Unable to find an IOR value for \"" + key + "\"!");
+}
+// <rgb> / <spectrum> children become texture OBJECTS of the plugin's Properties (xml.cpp:792-875): one the plugin does not ask for is reported as
+// an unreferenced object when the plugin has been instantiated (xml.cpp:1204-1213)
+static void check_colors(const Obj &o, std::initializer_list<const char *> known) {
+    for (auto &c : o.colors) {
+        bool ok = false;
+        for (const char *k : known) ok |= c.first == k;
+        if (!ok) fail("unreferenced object \"" + c.first + "\" (within " + o.tag + " of type \"" + o.plugin + "\")");
+    }
 }
 static void color_of(const Obj &b, const char *name, float def, float out[3]) {
     auto c = b.colors.find(name);
@@ -656,7 +824,7 @@ static HostTexture texture_of(const Obj &t) {
         tex.mean = (float) (sum / (double) n);
     } else fail("unsupported texture plugin \"" + t.plugin + "\" (supported: bitmap, checkerboard)");
     auto u = t.props.unqueried();
-    if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in plugin of type \"" + t.plugin + "\"");
+    if (!u.empty()) fail_unreferenced(u, "texture", t.plugin);
     return tex;
 }
 // a BSDF's reflectance-like property: a colour (-> out, returns -1) or a texture child of that name (-> out = its mean, returns its index)
@@ -783,7 +951,8 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         rough_plastic_tables(s.beckmann ? MF_BECKMANN : MF_GGX, s.alpha_u, s.diel_eta, s.rough_table.data(), &s.fdr_int);       // fdr_int carries m_internal_reflectance
     } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, plastic, roughplastic, conductor, roughconductor, dielectric, thindielectric, roughdielectric, twosided)");
     auto u = b.props.unqueried();
-    if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in plugin of type \"" + b.plugin + "\"");
+    if (!u.empty()) fail_unreferenced(u, "bsdf", b.plugin);
+    check_colors(b, { "reflectance", "diffuse_reflectance", "specular_reflectance", "specular_transmittance", "eta", "k" });
     // texture children: the slot that takes one was read above; a texture bound to any other property (or to a misspelt name) must not be dropped
     // silently -- the reference either uses it or raises "unreferenced object" (xml.cpp:1204-1215)
     const char *slot = b.plugin == "diffuse" ? "reflectance" : (b.plugin == "plastic" || b.plugin == "roughplastic") ? "diffuse_reflectance" : "";
@@ -929,7 +1098,8 @@ static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string
             : o.plugin == "ply" ? load_ply(path, s.face_normals) : load_serialized(path, (int) o.props.get_int("shape_index", 0), s.face_normals);
     }
     auto u = o.props.unqueried();
-    if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in shape plugin of type \"" + o.plugin + "\"");
+    if (!u.empty()) fail_unreferenced(u, "shape", o.plugin);
+    check_colors(o, {});
     if (mesh_file) bake_mesh(s, raw);
     else if (s.kind == SHAPE_MESH) bake_cube(s);
     return s;
@@ -1019,7 +1189,7 @@ static void make_sensor(const Obj &o, HostScene &sc) {
             have_filter = true;
         }
         auto u = film->props.unqueried();
-        if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in film plugin");
+        if (!u.empty()) fail_unreferenced(u, "film", film->plugin);
         if (se.film_w <= 0 || se.film_h <= 0 || se.crop_w <= 0 || se.crop_h <= 0 || se.crop_x < 0 || se.crop_y < 0 ||
             se.crop_x + se.crop_w > se.film_w || se.crop_y + se.crop_h > se.film_h) fail("invalid film size / crop window");
     }
@@ -1050,20 +1220,30 @@ static void make_sensor(const Obj &o, HostScene &sc) {
     (void) o.props.get_float("principal_point_offset_x", 0.0); (void) o.props.get_float("principal_point_offset_y", 0.0);
     if (sampler) sc.sampler = sampler->props; else { sc.sampler = PropBag(); sc.sampler.plugin = "independent"; }
     auto u = o.props.unqueried();
-    if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in sensor plugin");
+    if (!u.empty()) fail_unreferenced(u, "sensor", o.plugin);
+    check_colors(o, {});
 }
 
 HostScene load_scene_xml(const std::string &text, const std::map<std::string, std::string> &params, const std::string &base_dir) {
     XParser xp(text);
     auto root = xp.document();
-    if (root->tag != "scene") fail("root element \"" + root->tag + "\" must be a <scene>");
-    if (!root->attr("version")) fail("missing version attribute in root element \"scene\"");
+    g_xml_text = &text; g_xml_id = "<string>";
+    struct TextScope { ~TextScope() { g_xml_text = nullptr; } } text_scope;
+    { CheckCtx cc; check_tree(*root, TAG_INVALID, 0, cc); }
     LoadCtx ctx;
     for (auto &kv : params) ctx.defaults.emplace_back(kv.first, kv.second);
     g_search_paths.clear();
     if (!base_dir.empty()) g_search_paths.push_back(base_dir);
     substitute(*root, ctx, 0, 0, base_dir);
-    auto top = parse_object(*root, ctx);
+    for (auto &kv : params) if (!ctx.used.count(kv.first)) fail("Unused parameter \"" + kv.first + "\"!");
+    const bool scene_root = root->tag == "scene";
+    std::shared_ptr<Obj> top;
+    if (scene_root) top = parse_object(*root, ctx);
+    else {   // any object may be the root of a description (xml.cpp:489-490); it is instantiated like a scene's child, but only scenes can be rendered
+        top = std::make_shared<Obj>(); top->tag = "scene"; top->plugin = "scene"; top->props.plugin = "scene";
+        XNode holder; holder.tag = "scene";
+        top->children.emplace_back(root->tag, parse_object(*root, ctx)); top->ref_names.emplace_back();
+    }
     resolve_refs(*top, ctx);
 
     HostScene sc; bool have_sensor = false, have_integrator = false;
@@ -1154,7 +1334,8 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
             }
             {
                 auto u = o.props.unqueried();
-                if (!u.empty()) fail("unreferenced property \"" + u[0] + "\" in emitter plugin of type \"" + o.plugin + "\"");
+                if (!u.empty()) fail_unreferenced(u, "emitter", o.plugin);
+                check_colors(o, { "intensity", "radiance", "irradiance" });
             }
             sc.emitters.push_back(e);
         } else if (o.tag == "shape") {
@@ -1194,11 +1375,23 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
                     sc.emitters.push_back(e);
                 }
             }
-        } else if (o.tag == "bsdf" || o.tag == "texture") {
-            // top-level declarations referenced by id
+        } else if (o.tag == "bsdf") {
+            HostShape probe; bsdf_of(o, probe);   // top-level declarations are referenced by id; every object is instantiated, so a malformed one fails even if nothing refers to it
+        } else if (o.tag == "texture") {
+            // instantiated when a BSDF refers to it
+        } else if (o.tag == "sampler" || o.tag == "film" || o.tag == "rfilter") {
+            fail("unreferenced object \"" + o.plugin + "\" (within scene of type \"scene\")");   // Scene takes sensors, emitters, shapes and integrators (scene.cpp:102-121)
         } else fail("unsupported top-level element <" + o.tag + ">");
     }
-    if (!have_sensor) fail("the scene does not contain a sensor");
+    {   // the scene is a plugin too: properties given at scene level that Scene does not query are unreferenced (xml.cpp:1204-1218)
+        auto u = top->props.unqueried();
+        if (!u.empty()) fail_unreferenced(u, "scene", "scene");
+        check_colors(*top, {});
+        if (!top->vectors.empty()) fail_unreferenced({ top->vectors.begin()->first }, "scene", "scene");
+        if (!top->transforms.empty()) fail_unreferenced({ top->transforms.begin()->first }, "scene", "scene");
+    }
+    if (!scene_root) fail("root element \"" + root->tag + "\": only <scene> descriptions can be rendered by this library");
+    sc.has_sensor = have_sensor;   // a scene without a sensor loads (as in the reference); rendering it is the error
     if (!have_integrator) { sc.integrator = PropBag(); sc.integrator.plugin = "path"; }
     return sc;
 }

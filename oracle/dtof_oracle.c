@@ -2162,6 +2162,65 @@ uint64_t orc_render(const orc_scene *sc, const orc_params *p, uint32_t seed, uin
     return total;
 }
 
+/* The order-independent value of the same film: every splat term is the float32 product the reference adds (value * wx * wy,
+ * imageblock.cpp:414-531), but the terms are summed in float64 and RGB / W is taken in float64 -- what any order of the reference's
+ * unordered float32 scatter-adds (imageblock.cpp:119-133) scatters around.  Doppler images are sums of large terms of both signs, so a
+ * float32 sum in ONE particular order is not a reference value for pixels that cancel to a small fraction of their terms: the parity
+ * tests hold the GPU film AND the float32 film of orc_render against this one. */
+uint64_t orc_render_exact(const orc_scene *sc, const orc_params *p, uint32_t seed, uint32_t spp,
+                          int32_t row_begin, int32_t row_end, double *film, float *out_rgb, int nt) {
+    orc_ctx cx; make_ctx(&cx, sc, p, seed, spp);
+    const orc_sensor *se = &sc->sensor;
+    int W = se->crop_w, H = se->crop_h;
+    if (row_begin < 0) row_begin = 0;
+    if (row_end > H) row_end = H;
+    if (nt < 1) nt = 1;
+    if (nt > 256) nt = 256;
+    const uint32_t spw = cx.spw;
+    const uint64_t wavefront = (uint64_t) W * (uint64_t) H * spw, lanes_per_row = (uint64_t) W * spw;
+    uint64_t total = 0;
+    int chunk_rows = (int) (8000000ull / lanes_per_row); if (chunk_rows < 1) chunk_rows = 1;
+    orc_lane *buf = (orc_lane *) malloc(sizeof(orc_lane) * lanes_per_row * (size_t) chunk_rows);
+    float radius = se->filter_radius, inv_r = 1.f / radius, gc[10];
+    if (se->filter == ORC_FILTER_GAUSSIAN) gaussian_coeffs(se->filter_stddev, radius, gc);
+    const int n = se->filter == ORC_FILTER_BOX ? 0 : (int) ceilf(radius - .5f), count = 2 * n + 1;
+    for (uint32_t pass = 0; pass < cx.n_passes; ++pass)
+    for (int r = row_begin; r < row_end; r += chunk_rows) {
+        int re = r + chunk_rows < row_end ? r + chunk_rows : row_end;
+        uint64_t nl = lanes_per_row * (uint64_t) (re - r);
+        run_lanes(&cx, (uint64_t) pass * wavefront + lanes_per_row * (uint64_t) r, nl, buf, nt);
+        for (uint64_t i = 0; i < nl; ++i) {
+            const uint64_t pix = (lanes_per_row * (uint64_t) r + i) / spw;
+            const float vals[4] = { buf[i].rgb[0], buf[i].rgb[1], buf[i].rgb[2], 1.f };
+            if (se->filter == ORC_FILTER_BOX) {
+                const int x = (int) (pix % (uint64_t) W), y = (int) (pix / (uint64_t) W);
+                for (int k = 0; k < 4; ++k) film[4 * ((size_t) y * W + x) + k] += (double) vals[k];
+                continue;
+            }
+            const float spx = buf[i].sample_pos[0], spy = buf[i].sample_pos[1];
+            const int pxi = (int) floorf(spx) - n, pyi = (int) floorf(spy) - n;
+            const float relx = (float) pxi + .5f - spx, rely = (float) pyi + .5f - spy;
+            const int lx = pxi - se->crop_x, ly = pyi - se->crop_y;
+            for (int ys = 0; ys < count; ++ys) {
+                const float wy = filter_eval(se, rely + (float) ys, inv_r, gc);
+                for (int xs = 0; xs < count; ++xs) {
+                    const float wx = filter_eval(se, relx + (float) xs, inv_r, gc), w = wx * wy;
+                    const int x = lx + xs, y = ly + ys;
+                    if ((unsigned) x < (unsigned) W && (unsigned) y < (unsigned) H)
+                        for (int k = 0; k < 4; ++k) film[4 * ((size_t) y * W + x) + k] += (double) (vals[k] * w);
+                }
+            }
+        }
+        total += nl;
+    }
+    free(buf);
+    if (out_rgb) for (int64_t i = 0; i < (int64_t) W * H; ++i) {
+        double w = film[4 * i + 3]; w = w == 0.0 ? 1.0 : w;
+        out_rgb[3 * i] = (float) (film[4 * i] / w); out_rgb[3 * i + 1] = (float) (film[4 * i + 1] / w); out_rgb[3 * i + 2] = (float) (film[4 * i + 2] / w);
+    }
+    return total;
+}
+
 /* Cube vertex baking -- src/shapes/cube.cpp:114-160 (scalar float32: positions through
  * to_world, normals through its inverse transpose then normalised with 1/sqrt). */
 void orc_bake_cube(const float *to_world, const float *to_object, float *pos, float *nrm, float *uv, uint32_t *faces) {

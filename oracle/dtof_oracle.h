@@ -245,6 +245,9 @@ void     orc_render_lanes(const orc_scene *sc, const orc_params *p, uint32_t see
 uint64_t orc_render(const orc_scene *sc, const orc_params *p, uint32_t seed, uint32_t spp,
                     int32_t row_begin, int32_t row_end, float *film_rgbw, float *out_rgb,
                     int n_threads);
+/* the same film with the splat terms summed in float64 (the order-independent value the float32 scatter-adds approximate); film: H*W*4 doubles */
+uint64_t orc_render_exact(const orc_scene *sc, const orc_params *p, uint32_t seed, uint32_t spp,
+                          int32_t row_begin, int32_t row_end, double *film, float *out_rgb, int n_threads);
 
 void     orc_develop(const float *film_rgbw, float *out_rgb, int64_t n_pixels);
 

@@ -17,7 +17,7 @@ Function groups: `query` = everything under the closest-hit / occlusion queries 
 this is not what a traversal needs -- the product's own traversal counters price that part), `path` = the rest of eval_lane (sampler, camera ray,
 surface interaction, emitter sampling, BSDF, modulation weight, MIS, russian roulette).
 
-usage: python tools/oracle_opcount.py OUT.json scene.xml [spp [key=value ...]]      e.g.  tools/oracle_opcount.py profiles/r03_oracle_opcount_c2.json cornell_wall.xml 8 resx=64 resy=64
+usage: python oracle/opcount.py OUT.json scene.xml [spp [key=value ...]]      e.g.  oracle/opcount.py profiles/r03_oracle_opcount_c2.json cornell_wall.xml 8 resx=64 resy=64
 """
 import ctypes as C, hashlib, json, os, re, subprocess, sys
 from collections import defaultdict

@@ -132,7 +132,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        # DTOF_ORACLE_LIB: another build of the same source (tools/oracle_opcount.py: the block-counting build)
+        # DTOF_ORACLE_LIB: another build of the same source (oracle/opcount.py: the block-counting build)
         L = C.CDLL(os.environ.get("DTOF_ORACLE_LIB") or build())
         L.orc_tea_float32.restype = C.c_float
         L.orc_tea_float32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
@@ -374,6 +374,9 @@ class Scene:
         sc.objects, sc.n_objects = objects, len(fs.objects)
         sc.emitters, sc.n_emitters = emitters, len(fs.emitters)
         se = fs.sensor
+        if se is None:     # a scene without a sensor loads (as in the reference); there is nothing to render
+            self.c = sc
+            return
         sc.sensor.to_world = _m16(se["to_world"])
         for k in ("x_fov", "near_clip", "far_clip", "shutter_open", "shutter_close", "filter_radius", "filter_stddev", "filter_b", "filter_c"):
             setattr(sc.sensor, k, float(se[k]))
@@ -422,3 +425,17 @@ class Scene:
         p = make_params(pd)
         n = lib().orc_render(C.byref(self.c), C.byref(p), seed, spp, r0, r1, film.ctypes.data, img.ctypes.data, threads)
         return (film if raw else img), n
+
+    def render_exact(self, pd, seed=0, spp=None, rows=None, threads=1):
+        """the developed image with the splat terms summed in float64 (orc_render_exact): the order-independent value of the film"""
+        spp = spp or pd["sample_count"]
+        w, h = self.size
+        film = np.zeros((h, w, 4), np.float64)
+        img = np.zeros((h, w, 3), np.float32)
+        r0, r1 = rows if rows else (0, h)
+        p = make_params(pd)
+        L = lib()
+        L.orc_render_exact.restype = C.c_uint64
+        L.orc_render_exact.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int]
+        n = L.orc_render_exact(C.byref(self.c), C.byref(p), seed, spp, r0, r1, film.ctypes.data, img.ctypes.data, threads)
+        return img, n

@@ -135,12 +135,17 @@ def _tokens(s):
 
 def _vec(node, default=0.0):
     # detail::expand_value_to_xyz + parse_vector (xml.cpp)
+    def num(x):
+        try:
+            return float(x)
+        except ValueError:
+            raise ValueError('could not parse floating point value "%s".' % x)
     if node.get("value") is not None:
         t = _tokens(node.get("value"))
         if len(t) == 1:
             t = t * 3
-        return [float(x) for x in t]
-    return [float(node.get(k, default)) for k in ("x", "y", "z")]
+        return [num(x) for x in t]
+    return [num(node.get(k, default)) for k in ("x", "y", "z")]
 
 
 def _parse_transform(node):
@@ -223,12 +228,222 @@ class Props(dict):
             self.queried.add(name)
             t, v = self[name]
             if t != "string":
-                raise ValueError('property "%s" has the wrong type (expected <string>)' % name)
+                raise ValueError('The property "%s" has the wrong type (expected <string>).' % name)
             return v
         return default
 
+    def check_unreferenced(self, kind, known_colours=(), scalars_only=True):
+        """xml.cpp:1204-1222 after a plugin has been instantiated: <rgb> / <spectrum> children are texture OBJECTS of the plugin's Properties, one
+        it does not ask for is an unreferenced object; any other property it did not query is an unreferenced property (the reference prints
+        the list of names inside the quotes of its format string)"""
+        for name, (t, _v) in self.items():
+            if t == "rgb" and name not in known_colours:
+                raise ValueError('unreferenced object "%s" (within %s of type "%s")' % (name, kind, self.plugin))
+        left = [n for n, (t, _v) in self.items() if n not in self.queried and (t in ("float", "int", "bool", "string") or not scalars_only) and t != "rgb"]
+        if left:
+            raise ValueError('unreferenced %s "[%s]" in %s plugin of type "%s"' % ("properties" if len(left) > 1 else "property",
+                             ", ".join('"%s"' % n for n in left), kind, self.plugin))
+
 
 _OBJECT_TAGS = {"scene", "integrator", "sensor", "sampler", "film", "rfilter", "bsdf", "shape", "emitter", "texture"}
+
+
+# ---------------------------------------------------------------------------------------------------- well-formedness (xml.cpp:258-310,470-560)
+# The checks parse_xml makes on every node before it looks at values, with the reference's messages
+# `Error while loading "<id>" (at line L, col C): <message>.` (XMLSource::throw_error, xml.cpp:213-217; the position is that of the tag name).
+# Pinned by the reference's own tests: tests/golden/reference_xml_cases.json (src/core/tests/test_xml.py).
+_POS = {}      # id(element) -> (line, col) of its tag name, 1-based
+
+
+def _parse_text(text):
+    """the document as an ElementTree, built over expat so that every element's position (of its tag name) is known"""
+    import xml.parsers.expat as expat
+    parser = expat.ParserCreate()
+    parser.ordered_attributes = False
+    stack, roots = [], []
+
+    def start(tag, attrs):
+        el = ET.Element(tag, attrs) if not stack else ET.SubElement(stack[-1], tag, attrs)
+        _POS[id(el)] = (parser.CurrentLineNumber, parser.CurrentColumnNumber + 2)
+        if not stack:
+            roots.append(el)
+        stack.append(el)
+
+    def end(_tag):
+        stack.pop()
+
+    def chars(data):
+        if data.strip():
+            raise ValueError('Error while loading "<string>" (at line %d, col %d): unexpected content.' % (parser.CurrentLineNumber, parser.CurrentColumnNumber + 1))
+    parser.StartElementHandler, parser.EndElementHandler, parser.CharacterDataHandler = start, end, chars
+    try:
+        parser.Parse(text, True)
+    except expat.ExpatError as e:
+        raise ValueError('Error while loading "<string>" (at line %d, col %d): %s.' % (e.lineno, e.offset + 1, expat.ErrorString(e.code)))
+    if not roots:
+        raise ValueError('Error while loading "<string>": no root element')
+    return roots[0]
+
+
+def _fail_at(node, msg):
+    line, col = _POS.get(id(node), (0, 0))
+    raise ValueError('Error while loading "<string>" (at line %d, col %d): %s.' % (line, col, msg))
+
+
+_TRANSFORM_OPS = ("translate", "rotate", "scale", "lookat", "matrix")
+_PROPERTY_TAGS = ("float", "integer", "boolean", "string", "rgb", "spectrum")
+
+
+def _kind(node):
+    t = node.tag
+    if t in _OBJECT_TAGS or t in ("medium", "phase", "volume") or (t == "spectrum" and node.get("type") is not None):
+        return "object"
+    if t in _PROPERTY_TAGS:
+        return "property"
+    if t in ("point", "vector"):
+        return "vector"
+    if t in ("transform", "animation", "ref", "default", "path", "include", "alias"):
+        return t
+    if t in _TRANSFORM_OPS:
+        return "op"
+    return None
+
+
+def _check_attributes(node, allowed, expect_all=True, may_be_empty=False):
+    allowed = list(allowed)
+    found_one = may_be_empty        # `id` / `name` of objects and references are added by the reference itself when missing
+    for a in node.attrib:
+        if a not in allowed:
+            _fail_at(node, 'unexpected attribute "%s" in element "%s"' % (a, node.tag))
+        allowed.remove(a); found_one = True
+    if allowed and (not found_one or expect_all):
+        _fail_at(node, 'missing attribute "%s" in element "%s"' % (sorted(allowed)[0], node.tag))
+
+
+def _upgrade_tree(node, parent=None):
+    """upgrade_tree (xml.cpp:338-365), scene descriptions older than 2.0.0: camelCase names -> underscore_case, lookAt -> lookat, reserved ids renamed"""
+    if node.tag == "lookAt":
+        node.tag = "lookat"
+    name = node.get("name")
+    if name is not None and node.tag != "default":
+        out, i = name, 0
+        while i + 1 < len(out):
+            if out[i].islower() and out[i + 1].isupper():
+                out = out[:i + 1] + "_" + out[i + 1:]
+                i += 2
+                while i < len(out) and out[i].isupper():
+                    out = out[:i] + out[i].lower() + out[i + 1:]
+                    i += 1
+            i += 1
+        if out == "diffuse_reflectance" and parent is not None and parent.tag == "bsdf" and parent.get("type") == "diffuse":
+            out = "reflectance"
+        node.set("name", out)
+    ident = node.get("id")
+    if ident and ident.startswith("_"):
+        node.set("id", "ID" + ident + "__UPGR")
+    for ch in node:
+        _upgrade_tree(ch, node)
+
+
+def _check_tree(node, parent_kind, depth, ids):
+    kind = _kind(node)
+    if kind is None:
+        _fail_at(node, 'unexpected tag "%s"' % node.tag)
+    if parent_kind is None and kind != "object":
+        _fail_at(node, 'root element "%s" must be an object' % node.tag)
+    if (parent_kind == "transform") != (kind == "op"):
+        _fail_at(node, "transform nodes can only contain transform operations" if parent_kind == "transform"
+                 else "transform operations can only occur in a transform node")
+    if parent_kind is not None and parent_kind != "object" and not ((parent_kind == "transform" and kind == "op") or (parent_kind == "animation" and kind == "transform")):
+        _fail_at(node, 'node "%s" cannot occur as child of a property' % node.tag)
+    if depth == 0 and node.get("version") is None:
+        _fail_at(node, 'missing version attribute in root element "%s"' % node.tag)
+    version = node.get("version")
+    if version is not None:
+        parts = version.split(".")
+        if len(parts) != 3 or not all(x.isdigit() for x in parts):
+            _fail_at(node, 'could not parse version number "%s"' % version)
+        if int(parts[0]) < 2:
+            _upgrade_tree(node)
+        del node.attrib["version"]
+    name, ident = node.get("name"), node.get("id")
+    if name is not None and name.startswith("_"):
+        _fail_at(node, 'invalid parameter name "%s" in element "%s": leading underscores are reserved for internal identifiers' % (name, node.tag))
+    if ident is not None and ident.startswith("_"):
+        _fail_at(node, 'invalid id "%s" in element "%s": leading underscores are reserved for internal identifiers' % (ident, node.tag))
+    if kind == "object":
+        _check_attributes(node, ["id", "name"] + ([] if node.tag == "scene" else ["type"]), False, True)
+        if node.tag != "scene" and node.get("type") is None:
+            _fail_at(node, 'missing attribute "type" in element "%s"' % node.tag)
+        if ident is not None and ident in ids:
+            _fail_at(node, '"%s" has duplicate id "%s" (previous was at line %d, col %d)' % ((node.tag, ident) + ids[ident]))
+        names = set()
+        for ch in node:
+            _check_tree(ch, "object", depth + 1, ids)
+            cn = ch.get("name")
+            if cn and ch.tag != "default":
+                if cn in names:
+                    _fail_at(ch, 'Property "%s" was specified multiple times!' % cn)
+                names.add(cn)
+        if ident is not None:
+            ids[ident] = _POS.get(id(node), (0, 0))
+        return
+    if kind == "ref":
+        _check_attributes(node, ["id", "name"], False, True)
+        if node.get("id") is None:
+            _fail_at(node, 'missing attribute "id" in element "ref"')
+    elif kind == "alias":
+        _check_attributes(node, ["id", "as"])
+    elif kind == "default":
+        _check_attributes(node, ["name", "value"])
+        if not node.get("name"):
+            _fail_at(node, "<default>: name must by nonempty")
+        if "," in node.get("name"):
+            _fail_at(node, "Invalid character in parameter name: ',' in %s" % node.get("name"))
+    elif kind == "path":
+        _check_attributes(node, ["value"])
+        if depth != 1:
+            _fail_at(node, "<path>: path can only be child of root")
+    elif kind == "include":
+        _check_attributes(node, ["filename"])
+    elif kind == "property":
+        if node.tag == "spectrum":
+            _check_attributes(node, ["name", "value", "filename"], False, True)
+        else:
+            _check_attributes(node, ["name", "value"])
+    elif kind in ("vector", "op"):
+        if node.tag == "lookat":
+            _check_attributes(node, ["origin", "target", "up"], False, True)
+        elif node.tag == "matrix":
+            _check_attributes(node, ["value"])
+        else:
+            if node.get("value") is not None:      # expand_value_to_xyz (xml.cpp:290-309)
+                if any(node.get(k) is not None for k in "xyz"):
+                    _fail_at(node, 'can\'t mix and match "value" and "x"/"y"/"z" attributes')
+                if len(_tokens(node.get("value"))) not in (1, 3):
+                    _fail_at(node, '"value" attribute must have exactly 1 or 3 elements')
+            _check_attributes(node, (["name"] if kind == "vector" else ["angle"] if node.tag == "rotate" else []) + ["x", "y", "z", "value"], False, True)
+    elif kind == "transform":
+        _check_attributes(node, ["time"] if parent_kind == "animation" else ["name"], False, True)
+    elif kind == "animation":
+        _check_attributes(node, ["name"])
+    for ch in node:
+        _check_tree(ch, kind, depth + 1, ids)
+
+
+def _number(text, kind):
+    """string::stof / detail::stoll as the XML front end uses them (xml.cpp:736-757): the whole value must parse, surrounding blanks are allowed"""
+    try:
+        t = text.strip()
+        if kind == "integer":
+            if not t or not (t.lstrip("+-").isdigit()):
+                raise ValueError
+            return int(t)
+        if not t or any(c.isspace() or c == "," for c in t) or t.lower().rstrip("f") != t.lower() and True and t[-1] in "fF":
+            raise ValueError
+        return float(t)
+    except ValueError:
+        raise ValueError('could not parse %s value "%s".' % ("integer" if kind == "integer" else "floating point", text))
 
 
 _SEARCH_PATHS = []   # FileResolver (src/core/fresolver.cpp): the scene file's directory and whatever <path> prepends (xml.cpp:651-668)
@@ -248,6 +463,7 @@ def _substitute(root, params, base_dir=""):
     # xml.cpp:441-456: replace $name in every attribute, longest names first; undefined => error.  In the same document-order walk:
     # <path> (xml.cpp:651-668) and <include> (xml.cpp:670-725: the children of an included <scene>, or the included object itself, replace the tag)
     defaults = {}
+    used = set()
     def expand(node, depth, inc_depth, src_dir):
         i = 0
         while i < len(node):
@@ -285,6 +501,8 @@ def _substitute(root, params, base_dir=""):
         for k, v in list(node.attrib.items()):
             if "$" in v:
                 for n in names:
+                    if "$" + n in v:
+                        used.add(n)
                     v = v.replace("$" + n, defaults[n])
                 if "$" in v:
                     raise ValueError('undefined parameter(s) in string: "%s"!' % v)
@@ -293,6 +511,7 @@ def _substitute(root, params, base_dir=""):
             n = node.get("name")
             if n not in defaults:
                 defaults[n] = node.get("value")
+                used.add(n)
         if node.tag == "path":
             if depth != 1:
                 raise ValueError("<path>: path can only be child of root")
@@ -309,6 +528,9 @@ def _substitute(root, params, base_dir=""):
     if base_dir:
         _SEARCH_PATHS.append(base_dir)
     walk(root, 0, 0, base_dir)
+    for k in params:            # xml.cpp:1067-1070: a parameter handed to the loader that no attribute referred to
+        if k not in used:
+            raise ValueError('Unused parameter "%s"!' % k)
 
 
 def _parse_object(node, registry):
@@ -331,13 +553,13 @@ def _parse_object(node, registry):
         elif tag == "ref":
             p.children.append(("ref", ch.get("id"), name))
         elif tag == "float":
-            p[name] = ("float", float(ch.get("value")))
+            p[name] = ("float", _number(ch.get("value"), "float"))
         elif tag == "integer":
-            p[name] = ("int", int(ch.get("value")))
+            p[name] = ("int", _number(ch.get("value"), "integer"))
         elif tag == "boolean":
             v = ch.get("value").lower()
             if v not in ("true", "false"):
-                raise ValueError('could not parse boolean value "%s"' % v)
+                raise ValueError('could not parse boolean value "%s" -- must be "true" or "false".' % v)
             p[name] = ("bool", v == "true")
         elif tag == "string":
             p[name] = ("string", ch.get("value"))
@@ -714,6 +936,7 @@ def _bsdf_of(props, registry, base_dir=""):
         rec.update(alpha_u=au, alpha_v=av)
     else:
         raise ValueError('unsupported BSDF plugin "%s"' % props.plugin)
+    props.check_unreferenced("bsdf", ("reflectance", "diffuse_reflectance", "specular_reflectance", "specular_transmittance", "eta", "k"))
     return rec
 
 
@@ -725,7 +948,14 @@ class FlatScene:
         self.sampler = None      # Props
 
 
+def _no_colours(props, kind):
+    for n, (t, _v) in props.items():
+        if t == "rgb":
+            raise ValueError('unreferenced object "%s" (within %s of type "%s")' % (n, kind, props.plugin))
+
+
 def _shape_record(sp, registry, strip_to_world, base_dir=""):
+    _no_colours(sp, "shape")
     kind = {"rectangle": 0, "cube": 1, "obj": 1, "ply": 1, "serialized": 1, "sphere": 2, "disk": 3, "cylinder": 4}.get(sp.plugin)
     if kind is None:
         raise ValueError('unsupported shape plugin "%s"' % sp.plugin)
@@ -795,17 +1025,24 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
 
 def load(source, params=None, is_string=False):
     """Parse a scene XML (file path or string) into a FlatScene."""
-    root = ET.fromstring(source) if is_string else ET.parse(source).getroot()
+    _POS.clear()
+    root = _parse_text(source if is_string else open(source).read())
     base_dir = "" if is_string else os.path.dirname(os.path.abspath(source))
-    if root.tag != "scene" or root.get("version") is None:
-        raise ValueError('missing version attribute in root element "%s"' % root.tag)
+    _check_tree(root, None, 0, {})
     _substitute(root, params or {}, base_dir)
     registry = {}
-    top = _parse_object(root, registry)
+    scene_root = root.tag == "scene"
+    if scene_root:
+        top = _parse_object(root, registry)
+    else:      # any object may be the root (xml.cpp:489-490); it is instantiated like a scene's child, but only scenes can be rendered
+        top = Props("scene")
+        top.children.append((root.tag, _parse_object(root, registry), None))
     fs = FlatScene()
     group_of = {}   # id(props of shapegroup) -> group index
     for tag, child, _name in top.children:
         if tag == "ref":
+            if child not in registry:
+                raise ValueError('reference to unknown object "%s"!' % child)
             tag, child = registry[child]
         if tag == "integrator":
             fs.integrator = child
@@ -880,7 +1117,11 @@ def load(source, params=None, is_string=False):
             inten = child["intensity"] if "intensity" in child else ("float", 1.0)
             iv = [inten[1]] * 3 if inten[0] in ("float", "int") else inten[1]
             fs.emitters.append(dict(kind=0, position=pos, intensity=np.asarray(iv, dtype=np.float64).astype(F32)))
-        elif tag == "shape":
+        if tag == "emitter":
+            for _n, (_t, _v) in child.items():
+                if _t == "rgb" and _n not in ("intensity", "radiance", "irradiance"):
+                    raise ValueError('unreferenced object "%s" (within emitter of type "%s")' % (_n, child.plugin))
+        if tag == "shape":
             if child.plugin == "shapegroup":
                 first = len(fs.shapes)
                 for t2, c2, _n in child.children:
@@ -913,9 +1154,14 @@ def load(source, params=None, is_string=False):
                 if fs.shapes[-1]["emitter"]:   # scene.cpp:33-35: a shape's emitter joins the list at the shape's position
                     fs.emitters.append(dict(kind=1, position=np.zeros(3, F32), intensity=fs.shapes[-1]["radiance"],
                                             shape=len(fs.shapes) - 1))
-    if fs.sensor is None:
-        raise ValueError("scene has no sensor")
-    return fs
+        elif tag == "bsdf":
+            _bsdf_of(child, registry, base_dir)      # every object is instantiated: a malformed declaration fails even if nothing refers to it
+        elif tag in ("sampler", "film", "rfilter"):
+            raise ValueError('unreferenced object "%s" (within scene of type "scene")' % child.plugin)
+    top.check_unreferenced("scene", (), scalars_only=False)
+    if not scene_root:
+        raise ValueError('root element "%s": only <scene> descriptions can be rendered' % root.tag)
+    return fs         # fs.sensor is None for a scene without a sensor: it loads, as in the reference; rendering it is the error
 
 
 def _instance_record(tw, group):
@@ -971,6 +1217,7 @@ def _parse_fov(sp, aspect):
 def _sensor_record(sp):
     if sp.plugin not in ("perspective", "thinlens", "orthographic"):
         raise ValueError('unsupported sensor plugin "%s"' % sp.plugin)
+    _no_colours(sp, "sensor")
     film = next((c[1] for c in sp.children if c[0] == "film"), None)
     w, h, cx, cy = 768, 576, 0, 0
     filt, radius, stddev = None, 0.0, 0.5
