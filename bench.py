@@ -223,13 +223,18 @@ def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_ov
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed] + per_step, dtype=torch.float64, device=dev)
+    # this rank's share of the work: the library's own GPU time per step (HIP events around its launches), min / max over the ranks = load balance
+    mine = torch.tensor([acc["ms_total"] / max(steps, 1)], dtype=torch.float64, device=dev)
+    lo, hi = mine.clone(), mine.clone()
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     t = t.cpu().numpy()
     elapsed, per_step = float(t[0]), np.sort(t[1:])
     total_paths = W * H * spp
     out = dict(acc=acc, elapsed=elapsed, steps=steps, W=W, H=H, spp=spp, spp_per_gpu=spp0, total_paths=total_paths, halo=halo, striped=striped, offsets=offsets,
                defines=defines, scene_path=scene_path, res=res,
+               ms_render_rank_min=float(lo.item()), ms_render_rank_max=float(hi.item()),
                value=total_paths * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3,
                ms_per_step_min=float(per_step[0]) * 1e3, ms_per_step_median=float(np.median(per_step)) * 1e3)
     if rank == 0:
@@ -295,8 +300,17 @@ def main():
         e = run_workload(ctx, "c4", "strong", 4, 1, "stripes", args.stripe_rows)
         extra["c4_strong"] = {"value": round(e["value"], 2), "unit": "Mpaths/s", "scaling": "strong", "ms_per_step": round(e["ms_per_step"], 4),
                               "ms_per_step_min": round(e["ms_per_step_min"], 4), "paths_per_step": e["total_paths"],
+                              "ms_render_rank_min": round(e["ms_render_rank_min"], 4), "ms_render_rank_max": round(e["ms_render_rank_max"], 4),
                               "workload": "BASELINE configs[3]: domino.xml 1024x1024, 128 spp in total, rectangular low-pass, interleaved %d-row stripes, 1 film reduce"
                                           % args.stripe_rows}
+        # BASELINE configs[4]: the K = 4 batched films (64 MB per reduce at 1024^2); fewer samples than the config's 512 so that the extra stays short -- the
+        # rate (path-offsets per second) and the reduce size are those of the full config
+        e = run_workload(ctx, "c5", "strong", 2, 1, "stripes", args.stripe_rows, spp_override=128)
+        extra["c5_strong"] = {"value": round(e["value"], 2), "unit": "Mpaths/s (x 4 films)", "scaling": "strong", "ms_per_step": round(e["ms_per_step"], 4),
+                              "ms_per_step_min": round(e["ms_per_step_min"], 4), "paths_per_step": e["total_paths"],
+                              "ms_render_rank_min": round(e["ms_render_rank_min"], 4), "ms_render_rank_max": round(e["ms_render_rank_max"], 4),
+                              "workload": "BASELINE configs[4] at 128 of its 512 spp: domino.xml 1024x1024, trapezoidal low-pass, 4 hetero_offset films in one traversal, "
+                                          "interleaved %d-row stripes, 1 reduce of the 4 films (64 MB)" % args.stripe_rows}
 
     acc, W, H, spp, striped, halo = r["acc"], r["W"], r["H"], r["spp"], r["striped"], r["halo"]
     total_paths, ms_per_step, value = r["total_paths"], r["ms_per_step"], r["value"]
@@ -313,13 +327,30 @@ def main():
         per_bounce = kernel_bytes_per_bounce(fused, k_off)
         bounce_launches = acc["launches"] - n_first
         loop_s = (acc["ms_trace"] + acc["ms_shade"] + acc["ms_shadow"]) * 1e-3
+        # Counter evidence (separate rocprofv3 --pmc passes over exactly this configuration, tools/profile_round.sh -> tools/pmc_summary.py): stamped
+        # with a hash of the kernel sources; when the sources have changed since, the figures derived from it are marked stale.
         tfile = os.path.join(HERE, "profiles", "roofline_traffic.json")
-        pmc = {}
-        if os.path.exists(tfile) and args.config == "c2" and fused:   # the PMC passes were taken on exactly this workload (per rank and launch)
+        pmc, counters_stale = {}, None
+        default_workload = not (args.spp_given or args.res_given or args.scene_given)
+        if os.path.exists(tfile) and default_workload:
             try:
-                pmc = json.load(open(tfile))
+                sys.path.insert(0, os.path.join(HERE, "tools"))
+                from pmc_summary import kernel_sources_sha16
+                entry = json.load(open(tfile)).get("configs", {}).get(args.config)
+                if entry:
+                    pmc = entry.get("kernels", {})
+                    counters_stale = entry.get("csrc_sha16") != kernel_sources_sha16(HERE)
             except Exception:
                 pmc = {}
+        # Algorithmic work of one path (profiles/algorithmic_ops.json, tools/algorithmic_ops.py): arithmetic the oracle executes for the path logic
+        # (exact basic-block counts) + the primitive work of the product's own traversal counters, one op per arithmetic instruction
+        alg = {}
+        afile = os.path.join(HERE, "profiles", "algorithmic_ops.json")
+        if os.path.exists(afile) and default_workload:
+            try:
+                alg = json.load(open(afile)).get(args.config, {})
+            except Exception:
+                alg = {}
         stages = {"ms_first_bounce": round(acc["ms_first"] / args.steps, 4),
                   "ms_trace": round(acc["ms_trace"] / args.steps, 4), "ms_shade": round(acc["ms_shade"] / args.steps, 4),
                   "ms_shadow": round(acc["ms_shadow"] / args.steps, 4), "ms_generate": round(acc["ms_generate"] / args.steps, 4),
@@ -333,14 +364,25 @@ def main():
             first_s = acc["ms_first"] * 1e-3 / max(n_first, 1)                       # average launch
             paths_per_launch = acc["n_paths"] / max(n_first, 1)
             out_bytes = (8 + 8 + 16 * k_off) * paths_per_launch                       # sample position, stream selectors, result
-            wave_insts = pmc.get("k_shade_first", {}).get("valu_wave_insts_per_launch")
+            firsts = sorted((k for k in pmc if k.startswith("k_shade_first")), key=lambda k: -pmc[k].get("valu_wave_insts_per_launch", 0))
+            first_rec = pmc[firsts[0]] if firsts else {}
+            wave_insts = first_rec.get("valu_wave_insts_per_launch")
             valu_peak = 256 * 4 * 32 * 2.4e9 / 1e12                                   # T lane-instructions / s
             achieved = (wave_insts * 64 / first_s / 1e12) if wave_insts else None
+            ops_path = alg.get("ops_per_path")
+            alg_achieved = ops_path * paths_per_launch / first_s / 1e12 if ops_path else None
             roofline = {
-                "bound": "valu", "kernel": "k_shade<MODE 2: lane generation + primary ray + ALL %d bounce iterations, path state in registers>" % round(acc["launches_equiv"] / max(n_first, 1)),
+                "bound": "valu", "kernel": "k_shade<MODE 2: lane generation + primary ray + ALL %d bounce iterations, path state in registers>%s" % (
+                    round(acc["launches_equiv"] / max(n_first, 1)), " [%s]" % first_rec.get("symbol", "") if first_rec else ""),
                 "achieved": round(achieved, 2) if achieved else None, "peak": round(valu_peak, 1), "unit": "T lane-instr/s",
                 "frac": round(achieved / valu_peak, 4) if achieved else None,
-                "traffic": pmc.get("k_shade_first", {}).get("hbm_bytes_per_launch"),
+                "what": "achieved / frac: EXECUTED VALU wave-instructions x 64 lanes (issue slots, idle lanes included) per second against the issue peak; "
+                        "algorithmic: the arithmetic one path needs (oracle + traversal counters) per second against the same peak; active_lane_ratio: share of the issued lane slots that held an active lane",
+                "algorithmic": {"ops_per_path": ops_path, "achieved": round(alg_achieved, 2) if alg_achieved else None, "unit": "T ops/s",
+                                "frac_alg": round(alg_achieved / valu_peak, 4) if alg_achieved else None, "source": alg.get("source"), "breakdown": alg.get("breakdown")},
+                "active_lane_ratio": first_rec.get("active_lane_ratio"),
+                "counters_stale": counters_stale,
+                "traffic": first_rec.get("hbm_bytes_per_launch"),
                 "algorithmic_bytes_per_launch": round(out_bytes, 1), "avg_launch_ms": round(first_s * 1e3, 5), "launches_per_step": n_first / args.steps,
                 "valu_lane_instructions_per_path": round(wave_insts * 64 / paths_per_launch, 1) if wave_insts else None,
                 "path_bounces_per_launch": round(acc["n_bounces"] / max(n_first, 1), 1),
@@ -379,6 +421,7 @@ def main():
                        "paths_per_step": total_paths, "sharding": ("interleaved %d-row stripes, 1 film reduce" % args.stripe_rows if striped else "row bands, 1 film gather") if world > 1 else "none",
                        "image_checksum": float(np.abs(img).sum())},
             "roofline": roofline,
+            "ms_render_rank_min": round(r["ms_render_rank_min"], 4), "ms_render_rank_max": round(r["ms_render_rank_max"], 4),
             "extra": extra,
             "process_group": {"backend": backend, "world_size": world},
         }

@@ -213,14 +213,22 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     bool in_range = j < count;
     bool alive = false, want_shadow = false;
     uint32_t l = 0;
+#if DTOF_COOP
     float4 sha = make_float4(0.f, 0.f, 0.f, 0.f), shb = make_float4(0.f, 0.f, 1.f, 0.f), nra = sha, nrb = shb; float3 cand[KMAX];
+#else
+    float4 sha, shb, nra, nrb; float3 cand[KMAX];
+#endif
     float3 rbase[KMAX];   // FIRST: the result a lane ends this launch with if its NEE candidate is not committed
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) rbase[k] = make_float3(0.f, 0.f, 0.f);
     // Path state of the lane.  MODE 2 runs rp.inline_iters iterations of the bounce loop right here ("megakernel" head): between them the
     // state stays in these registers instead of making the round trip through the queues in HBM; after the last one the survivors are
     // written out and compacted exactly as before, for the bounce kernels (MODE 1) to continue with.
+#if DTOF_COOP
     uint32_t hid = 0xffffffffu; float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 1.f, 0.f), st; uint4 hh; Rng main, path;
+#else
+    uint32_t hid = 0xffffffffu; float4 ra, rb, st; uint4 hh; Rng main, path;
+#endif
     float4 stb_reg = make_float4(0.f, 0.f, 0.f, 1.f); float2 stc_reg = make_float2(1.f, 1.f);   // prev_si.p | prev_bsdf_pdf, eta | prev_bsdf_delta
     float memo_m[12], memo_inv[12];   // instance memo: the one instance's matrix and inverse at this lane's ray time
     bool lane_on = in_range;
@@ -239,6 +247,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                 LaneDebug &o = dbg[l];
                 o.time = ra.w; o.ray_o[0] = ra.x; o.ray_o[1] = ra.y; o.ray_o[2] = ra.z; o.ray_d[0] = rb.x; o.ray_d[1] = rb.y; o.ray_d[2] = rb.z;
             }
+#if DTOF_COOP   // the shared triangle loops need wave-uniform call sites (dtof_traverse.h: trace_rays); measured slower, not the default
             if (have_memo) instance_memo_fill(sv, ra.w, memo_m, memo_inv);
         }
     }
@@ -251,6 +260,16 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu;
         }
     }
+#else
+            if (have_memo) instance_memo_fill(sv, ra.w, memo_m, memo_inv);
+            Hit h;
+            bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h)
+                              : trace_scene<false, MESH, FUSED, RESW != 0>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
+            hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
+            hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu;
+        }
+    }
+#endif
     const uint32_t n_inline = FIRST ? rp.inline_iters : 1u;
     for (uint32_t it = 0; ; ++it) {
     const uint32_t depth = depth0 + it;
@@ -689,6 +708,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
         if (lane_id == 0) s_inline[2 * it] += n_on;
     }
     if (FUSED) {
+#if DTOF_COOP
         bool commit = false;
         {   // test_visibility (scene.cpp:266-271): an unoccluded sample commits its candidate result
             Hit hs;
@@ -699,6 +719,18 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             else if (__ballot(want_shadow)) commit = !trace_rays<true, MESH, true, RESW != 0>(sv, stack, want_shadow, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs) && want_shadow;
 #endif
         }
+#else
+        bool commit = false;
+        if (want_shadow) {   // test_visibility (scene.cpp:266-271): an unoccluded sample commits its candidate result
+            Hit hs;
+#if defined(DTOF_ABLATE) && (DTOF_ABLATE & 1)
+            commit = sha.w > 0.f;
+#else
+            commit = flat ? !trace_flat<true, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs)
+                          : !trace_scene<true, MESH, true, RESW != 0>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
+#endif
+        }
+#endif
         if (FIRST) {   // the running result stays in rbase over the inline iterations; every lane's result is defined after the last (nothing zeroed it)
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
@@ -709,6 +741,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) q.res[(size_t) k * q.capacity + l] = make_float4(cand[k].x, cand[k].y, cand[k].z, 0.f);
         }
+#if DTOF_COOP
         const bool trace_now = alive && trace_next;
         if (__ballot(trace_now)) {   // closest hit of the continuation ray, consumed by the next bounce (wave-uniform call, see trace_rays)
             Hit h; bool found = false;
@@ -723,6 +756,19 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                 if (FIRST) { hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim); hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu; }
             }
         }
+#else
+        if (alive && trace_next) {   // closest hit of the continuation ray, consumed by the next bounce
+            Hit h;
+#if defined(DTOF_ABLATE) && (DTOF_ABLATE & 2)
+            bool found = nra.x < 1e30f; h.t = 0.5f + 0.1f * nrb.x; h.u = nrb.y; h.v = nrb.z; h.obj = nrb.x > 0.3f ? 3 : nrb.y > 0.f ? 1 : 0; h.shape = 0; h.prim = 0;
+#else
+            bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h)
+                              : trace_scene<false, MESH, true, RESW != 0>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
+#endif
+            if (!FIRST || last) store_hit<MESH>(q, l, h, found);
+            if (FIRST) { hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim); hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu; }
+        }
+#endif
         const uint32_t n_sh = (uint32_t) __popcll(__ballot(want_shadow)) * ((threadIdx.x & 63) == 0 ? 1u : 0u);   // per-wave partial (stats only)
         if (last) n_shadow += n_sh; else if (lane_id == 0) s_inline[2 * it + 1] += n_sh;
     } else {

@@ -50,18 +50,21 @@ struct BvhNode {
     float rmin[3]; uint32_t pad0;
     float rmax[3]; uint32_t pad1;
 };
-// 4-wide node (128 B, one cache line; the traversal's node format when the library is built with -DDTOF_BVH4 -- `make bvh4`; measured
-// against the binary nodes on one box: Domino k_trace 4.37 vs 4.65 ms, the 522 k-triangle mesh room 9.24 vs 8.17 ms, Cornell boxes 0.606 vs
-// 0.558 ms: the traversal kernels are bound by VALU issue at ~0.55 lane utilisation, and a 4-wide step costs about two binary steps'
-// instructions plus the ordering network, at 104 instead of 94 VGPRs -- so the binary nodes stay the default): the bounds of
-// up to FOUR children live in the parent, component-major, so one fetch (seven 16-byte loads issued together) decides four
-// descents and a path to a leaf has half as many dependent fetches.  Built by collapsing the binary SAH tree (scene_build.cpp:
-// the child with the largest box is replaced by its own two children until four are held).  An absent child is the point box at
-// +inf, which no ray enters, with child = kNoChild.
+// 4-wide QUANTISED node (64 B -- the bytes of ONE binary node decide FOUR descents; the traversal's node format when the library is built with
+// -DDTOF_BVH4, `make bvh4`).  The traversal kernels of scenes too large for LDS are bound by the CU's vector-memory path (TA / TD busy 77 - 85 % on the
+// 522 k-triangle mesh room, profiles/r03_pmc_mesh_room.txt): what a ray costs there is the BYTES its node steps fetch, and a 4-wide tree of
+// uncompressed nodes (round 2: 128 B per node, half as many steps) fetches as many as the binary tree.  Here the child boxes are 8-bit offsets in a
+// per-node frame: origin `o` (the lower corner of the union of the children) and one power-of-two scale per axis (biased exponent bytes in `exps`),
+// child k spans [o + s * qlo[.][k], o + s * qhi[.][k]] -- rounded OUTWARD (and widened by one quantum where the range allows), so every quantised
+// box contains the (already padded) float box it stands for and the traversal stays conservative; hits come from the exact primitive tests and
+// are unchanged.  Built by collapsing the binary SAH tree (scene_build.cpp: the child with the largest box is replaced by its own two children
+// until four are held).  An absent child has child = kNoChild.
 struct BvhNode4 {
-    float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4];
+    float o[3]; uint32_t exps;          // exps: exponent byte of the x | y << 8 | z << 16 scale (scale = 2^(e - 127), as a float's exponent field)
     uint32_t child[4];
-    uint32_t pad[4];
+    uint32_t qlo[3];                    // qlo[axis]: byte k = child k
+    uint32_t qhi[3];
+    uint32_t pad[2];
 };
 #ifndef DTOF_BVH4
 typedef BvhNode DNode;
@@ -127,7 +130,7 @@ struct DEnvmap {
     uint32_t level_off[kEnvMaxLevels], level_w[kEnvMaxLevels];
 };
 static_assert(sizeof(DEnvmap) % 16 == 0, "DEnvmap");
-static_assert(sizeof(BvhNode4) == 128, "BvhNode4");
+static_assert(sizeof(BvhNode4) == 64, "BvhNode4");
 static_assert(sizeof(DTexture) == 64, "DTexture");
 static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 304 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64 && sizeof(DEmitter) == 96, "blob records");
 

@@ -225,23 +225,27 @@ DTOF_D void cswap(float &ta, uint32_t &ca, float &tb, uint32_t &cb) {   // compa
     const float t = sw ? tb : ta; const uint32_t c = sw ? cb : ca;
     tb = sw ? ta : tb; cb = sw ? ca : cb; ta = t; ca = c;
 }
-// One traversal step at the 4-wide inner node `cur` (seven 16-byte loads issued together, none depends on a field of the node):
-// the children whose boxes the ray enters before `tbest` are ordered by entry distance with a five-comparator network; the nearest
-// is returned, the others are pushed far-first; nothing hit: pop (or `done` at the floor of this traversal's stack).
+// One traversal step at the 4-wide quantised inner node `cur` (four 16-byte loads issued together, none depends on a field of the node).  The slab test
+// runs in the node's frame: a child's plane at q quanta lies at t = q * (scale * id) + (origin - o) * id, one fma per plane after three products and
+// three differences per node; the children whose boxes the ray enters before `tbest` are ordered by entry distance with a five-comparator network; the
+// nearest is returned, the others are pushed far-first; nothing hit: pop (or `done` at the floor of this traversal's stack).
+DTOF_D float ubyte_f(uint32_t w, int k) { return (float) ((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyte<k>
+template <bool SOA = false>
 DTOF_D uint32_t node_step(const BvhNode4 *nodes, uint32_t cur, V3 o, V3 id, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride, uint32_t done) {
-    const uint4 *np = (const uint4 *) (nodes + cur);
-    const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4], q5 = np[5], q6 = np[6];
-    float t[4]; uint32_t c[4] = { q6.x, q6.y, q6.z, q6.w };
-    const uint32_t mnx[4] = { q0.x, q0.y, q0.z, q0.w }, mny[4] = { q1.x, q1.y, q1.z, q1.w }, mnz[4] = { q2.x, q2.y, q2.z, q2.w };
-    const uint32_t mxx[4] = { q3.x, q3.y, q3.z, q3.w }, mxy[4] = { q4.x, q4.y, q4.z, q4.w }, mxz[4] = { q5.x, q5.y, q5.z, q5.w };
+    const uint4 *np = SOA ? (const uint4 *) nodes + cur : (const uint4 *) (nodes + cur);
+    const uint4 q0 = np[0], q1 = np[SOA ? kResNodes : 1], q2 = np[SOA ? 2 * kResNodes : 2], q3 = np[SOA ? 3 * kResNodes : 3];
+    float t[4]; uint32_t c[4] = { q1.x, q1.y, q1.z, q1.w };
+    const float ax = u2f((q0.w & 0xffu) << 23) * id.x, ay = u2f(((q0.w >> 8) & 0xffu) << 23) * id.y, az = u2f(((q0.w >> 16) & 0xffu) << 23) * id.z;
+    const float bx = (u2f(q0.x) - o.x) * id.x, by = (u2f(q0.y) - o.y) * id.y, bz = (u2f(q0.z) - o.z) * id.z;
+    const uint32_t lox = q2.x, loy = q2.y, loz = q2.z, hix = q2.w, hiy = q3.x, hiz = q3.y;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float tx0 = (u2f(mnx[k]) - o.x) * id.x, tx1 = (u2f(mxx[k]) - o.x) * id.x;
-        const float ty0 = (u2f(mny[k]) - o.y) * id.y, ty1 = (u2f(mxy[k]) - o.y) * id.y;
-        const float tz0 = (u2f(mnz[k]) - o.z) * id.z, tz1 = (u2f(mxz[k]) - o.z) * id.z;
+        const float tx0 = fmaf(ubyte_f(lox, k), ax, bx), tx1 = fmaf(ubyte_f(hix, k), ax, bx);
+        const float ty0 = fmaf(ubyte_f(loy, k), ay, by), ty1 = fmaf(ubyte_f(hiy, k), ay, by);
+        const float tz0 = fmaf(ubyte_f(loz, k), az, bz), tz1 = fmaf(ubyte_f(hiz, k), az, bz);
         const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
         const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
-        t[k] = tn <= tf ? tn : INFINITY;
+        t[k] = (tn <= tf && c[k] != kNoChild) ? tn : INFINITY;
     }
     cswap(t[0], c[0], t[1], c[1]); cswap(t[2], c[2], t[3], c[3]); cswap(t[0], c[0], t[2], c[2]); cswap(t[1], c[1], t[3], c[3]); cswap(t[1], c[1], t[2], c[2]);
     if (t[0] < INFINITY) {
@@ -375,11 +379,7 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
     for (;;) {
         while (!(cur & kLeafFlag) && cur != kDone) {
             DTOF_STAT(1); DTOF_STAT_WAVE(2);
-#ifndef DTOF_BVH4
             cur = node_step<SOA>(sv.nodes, cur, o, id, best.t, stack, sp, 0, stride, kDone);
-#else
-            cur = node_step(sv.nodes, cur, o, id, best.t, stack, sp, 0, stride, kDone);
-#endif
         }
         if (cur == kDone) break;
         DTOF_STAT(3); DTOF_STAT_WAVE(4);
@@ -491,11 +491,7 @@ DTOF_D bool trace_scene_coop(const SceneView &sv, uint32_t *stack, bool active, 
         if (!done && !in_obj) {
             while (!(cur & kLeafFlag) && cur != kDone) {
                 DTOF_STAT(1); DTOF_STAT_WAVE(2);
-#ifndef DTOF_BVH4
                 cur = node_step<SOA>(sv.nodes, cur, o, id, best.t, stack, sp, 0, stride, kDone);
-#else
-                cur = node_step(sv.nodes, cur, o, id, best.t, stack, sp, 0, stride, kDone);
-#endif
             }
             if (cur == kDone) done = true;
             else {   // enter the object (intersect_object's head)

@@ -148,13 +148,36 @@ static uint32_t collapse(const std::vector<BvhNode> &bin, uint32_t ni, std::vect
     const uint32_t idx = (uint32_t) out.size();
     out.emplace_back();
     BvhNode4 w; memset(&w, 0, sizeof w);
-    const float inf = std::numeric_limits<float>::infinity();
-    for (int k = 0; k < 4; ++k) { w.minx[k] = w.miny[k] = w.minz[k] = w.maxx[k] = w.maxy[k] = w.maxz[k] = inf; w.child[k] = kNoChild; }
-    for (size_t k = 0; k < ents.size(); ++k) {
-        w.minx[k] = ents[k].lo[0]; w.miny[k] = ents[k].lo[1]; w.minz[k] = ents[k].lo[2];
-        w.maxx[k] = ents[k].hi[0]; w.maxy[k] = ents[k].hi[1]; w.maxz[k] = ents[k].hi[2];
-        w.child[k] = (ents[k].ref & kLeafFlag) ? ents[k].ref : collapse(bin, ents[k].ref, out);
+    for (int k = 0; k < 4; ++k) w.child[k] = kNoChild;
+    // the node's frame: origin = lower corner of the union; per axis the smallest power-of-two scale whose 255 steps span the union with a quantum to spare
+    for (int a = 0; a < 3; ++a) {
+        float lo = FLT_MAX, hi = -FLT_MAX;
+        for (auto &e : ents) { lo = std::min(lo, e.lo[a]); hi = std::max(hi, e.hi[a]); }
+        w.o[a] = lo;
+        // smallest exponent whose 252 steps span the union -- but never a step below 2^-20 of the coordinates' magnitude: origin + q * scale must move in float32
+        int E = 1;
+        { const float m = std::max(std::fabs(lo), std::fabs(hi)); int ex = 0; if (m > 0.f) { (void) std::frexp(m, &ex); E = std::max(E, ex - 1 + 127 - 20); } }
+        for (;; ++E) {
+            if (E > 254) throw std::runtime_error("BVH quantisation: scene extent out of range");
+            uint32_t bits = (uint32_t) E << 23; float sc; memcpy(&sc, &bits, 4);
+            if (!((double) (hi - lo) / (double) sc <= 252.0)) continue;
+            uint32_t wl = 0, wh = 0; bool ok = true;
+            for (size_t k = 0; k < ents.size() && ok; ++k) {
+                // outward rounding, checked against the kernel's own decode fma(q, scale, origin); then one more quantum of slack on each side
+                int ql = (int) std::floor((double) (ents[k].lo[a] - lo) / (double) sc), qh = (int) std::ceil((double) (ents[k].hi[a] - lo) / (double) sc);
+                ql = std::max(0, std::min(255, ql)); qh = std::max(0, std::min(255, qh));
+                while (ql > 0 && fmaf((float) ql, sc, lo) > ents[k].lo[a]) --ql;
+                while (qh < 255 && fmaf((float) qh, sc, lo) < ents[k].hi[a]) ++qh;
+                ok = fmaf((float) ql, sc, lo) <= ents[k].lo[a] && fmaf((float) qh, sc, lo) >= ents[k].hi[a];
+                ql = std::max(0, ql - 1); qh = std::min(255, qh + 1);
+                wl |= (uint32_t) ql << (8 * k); wh |= (uint32_t) qh << (8 * k);
+            }
+            if (!ok) continue;   // a coarser scale
+            w.exps |= (uint32_t) E << (8 * a); w.qlo[a] = wl; w.qhi[a] = wh;
+            break;
+        }
     }
+    for (size_t k = 0; k < ents.size(); ++k) w.child[k] = (ents[k].ref & kLeafFlag) ? ents[k].ref : collapse(bin, ents[k].ref, out);
     out[idx] = w;
     return idx;
 }

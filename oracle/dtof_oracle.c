@@ -1664,6 +1664,101 @@ typedef struct { const orc_scene *sc; const orc_params *p; uint32_t seed, spp, s
 /* One lane: SamplingIntegrator::render (lane->pixel, src/render/integrator.cpp:273-290),
  * render_sample Doppler branch (:476-542), DopplerToFPathIntegrator::sample
  * (src/integrators/dopplertofpath.cpp:79-283). */
+/* Emitter::sample_direction of every supported emitter (point.cpp:118-147, constant.cpp:118-148, directional.cpp:148-176, envmap.cpp:363-406,
+ * spot.cpp:152-187, area.cpp:116-159 -> Shape / Sphere::sample_direction), for the reference point `ref` and the 2-D sample (sx, e2):
+ * sampled point, direction, distance, density, delta flag, importance weight, and whether the sample is usable.  Visibility is the caller's. */
+static void emitter_sample_direction(const orc_scene *sc, const orc_emitter *em, v3 ref, float sx, float e2,
+                                     v3 *dsp_out, v3 *dd_out, float *dist_out, float *pdf_out, int *delta_out, v3 *weight_out, int *active_out) {
+    struct { v3 p; } si; si.p = ref;
+    v3 dsp, dd, em_weight = V(0, 0, 0); int em_active = 1, ds_delta = 1; float ds_dist = 0.f, ds_pdf = 0.f;
+    if (em->kind == ORC_EMITTER_POINT) {
+        /* PointLight::sample_direction src/emitters/point.cpp:118-147 */
+        dsp = V(em->position[0], em->position[1], em->position[2]);
+        dd = v_sub(dsp, si.p);
+        float dist2 = v_dot(dd, dd), inv_dist = f_rsqrt(dist2);
+        ds_dist = sqrtf(dist2);
+        dd = v_mul(dd, inv_dist);
+        float id2 = f_sqr(inv_dist);
+        em_weight = V(em->intensity[0] * id2, em->intensity[1] * id2, em->intensity[2] * id2);
+        ds_pdf = 1.f; ds_delta = 1;
+    } else if (em->kind == ORC_EMITTER_CONSTANT) {
+        /* ConstantBackgroundEmitter::sample_direction (constant.cpp:118-148): a uniform direction; the sample point lies on a sphere
+         * of twice the (enlarged) bounding radius around the reference point */
+        dd = square_to_uniform_sphere(sx, e2);
+        v3 c = V(em->bsphere[0], em->bsphere[1], em->bsphere[2]);
+        float radius = f_max(em->bsphere[3], v_norm(v_sub(si.p, c)));
+        ds_dist = 2.f * radius;
+        dsp = v_fma(dd, ds_dist, si.p);
+        ds_pdf = ORC_INV_FOUR_PI_F; ds_delta = 0;
+        float ip = f_rcp(ds_pdf);
+        em_weight = V(em->intensity[0] * ip, em->intensity[1] * ip, em->intensity[2] * ip);
+    } else if (em->kind == ORC_EMITTER_DIRECTIONAL) {
+        /* DirectionalEmitter::sample_direction (directional.cpp:148-176): a delta direction; the sample point lies outside the scene's bounding sphere */
+        v3 dir = V(em->position[0], em->position[1], em->position[2]);
+        v3 c = V(em->bsphere[0], em->bsphere[1], em->bsphere[2]);
+        float radius = f_max(em->bsphere[3], v_norm(v_sub(si.p, c)));
+        ds_dist = 2.f * radius;
+        dsp = v_sub(si.p, v_mul(dir, ds_dist));
+        dd = v_neg(dir);
+        ds_pdf = 1.f; ds_delta = 1;
+        em_weight = V(em->intensity[0], em->intensity[1], em->intensity[2]);
+    } else if (em->kind == ORC_EMITTER_ENVMAP) {
+        /* EnvironmentMapEmitter::sample_direction (envmap.cpp:363-406) */
+        env_sample_direction(em, si.p, sx, e2, &dd, &ds_dist, &ds_pdf, &em_weight, &em_active);
+        dsp = v_add(si.p, v_mul(dd, ds_dist));
+        ds_delta = 0;
+    } else if (em->kind == ORC_EMITTER_SPOT) {
+        /* SpotLight::sample_direction (src/emitters/spot.cpp:152-187) with falloff_curve (:116-126) */
+        dsp = V(em->position[0], em->position[1], em->position[2]);
+        dd = v_sub(dsp, si.p);
+        ds_dist = sqrtf(v_dot(dd, dd));
+        float inv_dist = f_rcp(ds_dist);
+        dd = v_mul(dd, inv_dist);
+        v3 local = v_normalize(m_vector(em->to_local, v_neg(dd)));
+        float cos_theta = local.z;
+        float beam = cos_theta >= em->cos_beam ? 1.f : (em->cutoff_angle - orc_acos(cos_theta)) * em->inv_transition;
+        float falloff = cos_theta > em->cos_cutoff ? beam : 0.f;
+        float k = falloff * f_sqr(inv_dist);
+        em_weight = falloff > 0.f ? V(em->intensity[0] * k, em->intensity[1] * k, em->intensity[2] * k) : V(0, 0, 0);
+        ds_pdf = 1.f; ds_delta = 1;
+    } else {
+        /* AreaLight::sample_direction area.cpp:116-159 -> Shape::sample_direction shape.cpp:370-384 ->
+         * Rectangle::sample_position rectangle.cpp:152-166 */
+        const orc_shape *es = &sc->shapes[em->shape];
+        v3 en;
+        if (es->kind == ORC_SHAPE_SPHERE) {   /* Sphere overrides Shape::sample_direction */
+            sphere_sample_direction(es, si.p, sx, e2, &dsp, &en, &dd, &ds_dist, &ds_pdf);
+        } else {
+        if (es->kind == ORC_SHAPE_RECT) {
+            dsp = m_point(es->to_world, V(sx * 2.f - 1.f, e2 * 2.f - 1.f, 0.f));
+            en = v_normalize(m_normal(es->to_object, V(0.f, 0.f, 1.f)));
+        } else if (es->kind == ORC_SHAPE_DISK) {   /* Disk::sample_position (disk.cpp:158-177) */
+            v3 pd = square_to_cosine_hemisphere(sx, e2);   /* its x, y ARE square_to_uniform_disk_concentric */
+            dsp = m_point(es->to_world, V(pd.x, pd.y, 0.f));
+            en = v_normalize(m_normal(es->to_object, V(0.f, 0.f, 1.f)));
+        } else mesh_sample_position(es, sx, e2, &dsp, &en);
+        dd = v_sub(dsp, si.p);
+        float dist2 = v_dot(dd, dd);
+        ds_dist = sqrtf(dist2);
+        dd = v_mul(dd, f_rcp(ds_dist));
+        float dp = fabsf(v_dot(dd, en)), x = dist2 / dp;
+        ds_pdf = shape_inv_area(es) * (isfinite(x) ? x : 0.f);
+        }
+        ds_delta = 0;
+        em_active = v_dot(dd, en) < 0.f && ds_pdf != 0.f;
+        float ip = f_rcp(ds_pdf);
+        em_weight = em_active ? V(em->intensity[0] * ip, em->intensity[1] * ip, em->intensity[2] * ip) : V(0, 0, 0);
+    }
+    *dsp_out = dsp; *dd_out = dd; *dist_out = ds_dist; *pdf_out = ds_pdf; *delta_out = ds_delta; *weight_out = em_weight; *active_out = em_active;
+}
+/* known-answer entry (tests): out = d[3], dist, pdf, delta, weight[3], p[3], active */
+void orc_kat_emitter_sample(const orc_scene *sc, int emitter_index, const float *ref, float sx, float sy, float *out13) {
+    v3 dsp, dd, w; float dist, pdf; int delta, active;
+    emitter_sample_direction(sc, &sc->emitters[emitter_index], V(ref[0], ref[1], ref[2]), sx, sy, &dsp, &dd, &dist, &pdf, &delta, &w, &active);
+    out13[0] = dd.x; out13[1] = dd.y; out13[2] = dd.z; out13[3] = dist; out13[4] = pdf; out13[5] = (float) delta;
+    out13[6] = w.x; out13[7] = w.y; out13[8] = w.z; out13[9] = dsp.x; out13[10] = dsp.y; out13[11] = dsp.z; out13[12] = (float) active;
+}
+
 static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
     const orc_scene *sc = cx->sc; const orc_params *p = cx->p; const orc_sensor *se = &sc->sensor;
     /* lane64 = pass * wavefront_size + lane: the sampler is seeded once per wavefront lane (integrator.cpp:265) and its three RNG
@@ -1802,84 +1897,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
             }
             const orc_emitter *em = &sc->emitters[idx];
             v3 dsp, dd; int em_active = 1;
-            if (em->kind == ORC_EMITTER_POINT) {
-                /* PointLight::sample_direction src/emitters/point.cpp:118-147 */
-                dsp = V(em->position[0], em->position[1], em->position[2]);
-                dd = v_sub(dsp, si.p);
-                float dist2 = v_dot(dd, dd), inv_dist = f_rsqrt(dist2);
-                ds_dist = sqrtf(dist2);
-                dd = v_mul(dd, inv_dist);
-                float id2 = f_sqr(inv_dist);
-                em_weight = V(em->intensity[0] * id2, em->intensity[1] * id2, em->intensity[2] * id2);
-                ds_pdf = 1.f; ds_delta = 1;
-            } else if (em->kind == ORC_EMITTER_CONSTANT) {
-                /* ConstantBackgroundEmitter::sample_direction (constant.cpp:118-148): a uniform direction; the sample point lies on a sphere
-                 * of twice the (enlarged) bounding radius around the reference point */
-                dd = square_to_uniform_sphere(sx, e2);
-                v3 c = V(em->bsphere[0], em->bsphere[1], em->bsphere[2]);
-                float radius = f_max(em->bsphere[3], v_norm(v_sub(si.p, c)));
-                ds_dist = 2.f * radius;
-                dsp = v_fma(dd, ds_dist, si.p);
-                ds_pdf = ORC_INV_FOUR_PI_F; ds_delta = 0;
-                float ip = f_rcp(ds_pdf);
-                em_weight = V(em->intensity[0] * ip, em->intensity[1] * ip, em->intensity[2] * ip);
-            } else if (em->kind == ORC_EMITTER_DIRECTIONAL) {
-                /* DirectionalEmitter::sample_direction (directional.cpp:148-176): a delta direction; the sample point lies outside the scene's bounding sphere */
-                v3 dir = V(em->position[0], em->position[1], em->position[2]);
-                v3 c = V(em->bsphere[0], em->bsphere[1], em->bsphere[2]);
-                float radius = f_max(em->bsphere[3], v_norm(v_sub(si.p, c)));
-                ds_dist = 2.f * radius;
-                dsp = v_sub(si.p, v_mul(dir, ds_dist));
-                dd = v_neg(dir);
-                ds_pdf = 1.f; ds_delta = 1;
-                em_weight = V(em->intensity[0], em->intensity[1], em->intensity[2]);
-            } else if (em->kind == ORC_EMITTER_ENVMAP) {
-                /* EnvironmentMapEmitter::sample_direction (envmap.cpp:363-406) */
-                env_sample_direction(em, si.p, sx, e2, &dd, &ds_dist, &ds_pdf, &em_weight, &em_active);
-                dsp = v_add(si.p, v_mul(dd, ds_dist));
-                ds_delta = 0;
-            } else if (em->kind == ORC_EMITTER_SPOT) {
-                /* SpotLight::sample_direction (src/emitters/spot.cpp:152-187) with falloff_curve (:116-126) */
-                dsp = V(em->position[0], em->position[1], em->position[2]);
-                dd = v_sub(dsp, si.p);
-                ds_dist = sqrtf(v_dot(dd, dd));
-                float inv_dist = f_rcp(ds_dist);
-                dd = v_mul(dd, inv_dist);
-                v3 local = v_normalize(m_vector(em->to_local, v_neg(dd)));
-                float cos_theta = local.z;
-                float beam = cos_theta >= em->cos_beam ? 1.f : (em->cutoff_angle - orc_acos(cos_theta)) * em->inv_transition;
-                float falloff = cos_theta > em->cos_cutoff ? beam : 0.f;
-                float k = falloff * f_sqr(inv_dist);
-                em_weight = falloff > 0.f ? V(em->intensity[0] * k, em->intensity[1] * k, em->intensity[2] * k) : V(0, 0, 0);
-                ds_pdf = 1.f; ds_delta = 1;
-            } else {
-                /* AreaLight::sample_direction area.cpp:116-159 -> Shape::sample_direction shape.cpp:370-384 ->
-                 * Rectangle::sample_position rectangle.cpp:152-166 */
-                const orc_shape *es = &sc->shapes[em->shape];
-                v3 en;
-                if (es->kind == ORC_SHAPE_SPHERE) {   /* Sphere overrides Shape::sample_direction */
-                    sphere_sample_direction(es, si.p, sx, e2, &dsp, &en, &dd, &ds_dist, &ds_pdf);
-                } else {
-                if (es->kind == ORC_SHAPE_RECT) {
-                    dsp = m_point(es->to_world, V(sx * 2.f - 1.f, e2 * 2.f - 1.f, 0.f));
-                    en = v_normalize(m_normal(es->to_object, V(0.f, 0.f, 1.f)));
-                } else if (es->kind == ORC_SHAPE_DISK) {   /* Disk::sample_position (disk.cpp:158-177) */
-                    v3 pd = square_to_cosine_hemisphere(sx, e2);   /* its x, y ARE square_to_uniform_disk_concentric */
-                    dsp = m_point(es->to_world, V(pd.x, pd.y, 0.f));
-                    en = v_normalize(m_normal(es->to_object, V(0.f, 0.f, 1.f)));
-                } else mesh_sample_position(es, sx, e2, &dsp, &en);
-                dd = v_sub(dsp, si.p);
-                float dist2 = v_dot(dd, dd);
-                ds_dist = sqrtf(dist2);
-                dd = v_mul(dd, f_rcp(ds_dist));
-                float dp = fabsf(v_dot(dd, en)), x = dist2 / dp;
-                ds_pdf = shape_inv_area(es) * (isfinite(x) ? x : 0.f);
-                }
-                ds_delta = 0;
-                em_active = v_dot(dd, en) < 0.f && ds_pdf != 0.f;
-                float ip = f_rcp(ds_pdf);
-                em_weight = em_active ? V(em->intensity[0] * ip, em->intensity[1] * ip, em->intensity[2] * ip) : V(0, 0, 0);
-            }
+            emitter_sample_direction(sc, em, si.p, sx, e2, &dsp, &dd, &ds_dist, &ds_pdf, &ds_delta, &em_weight, &em_active);
             ds_pdf *= pmf; em_weight = v_mul(em_weight, em_w);
             if (ds_pdf != 0.f && em_active) {
                 /* Interaction::spawn_ray_to interaction.h:141-149 + ray_test */

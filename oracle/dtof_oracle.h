@@ -315,6 +315,8 @@ void     orc_kat_bsdf(const orc_shape *sh, const float *wi, const float *wo, con
 void     orc_texture_eval(const orc_texture *tex, float u, float v, float *out3);
 void     orc_kat_sphere_sample_direction(const orc_shape *sh, const float *ref, float s_x, float s_y, float *out11);
 float    orc_kat_shape_area(const orc_shape *sh);
+/* Emitter::sample_direction of emitter `emitter_index` for the reference point `ref` and a 2-D sample: out = d[3], dist, pdf, delta, weight[3], p[3], usable */
+void     orc_kat_emitter_sample(const orc_scene *sc, int emitter_index, const float *ref, float sx, float sy, float *out13);
 void     orc_kat_splat(const orc_sensor *se, float *film, float x, float y, const float *rgb);
 int      orc_kat_solve_quadratic(double a, double b, double c, double *out2);
 

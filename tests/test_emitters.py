@@ -314,3 +314,88 @@ def test_directional_emitter(mi, orc, tmp_path):
     assert np.allclose(img[4, 4], np.float32([2.0, 4.0, 6.0]) * 0.5 / np.pi, rtol=1e-5)
     with pytest.raises(mi.DtofError, match="Only one of the parameters 'direction' and 'to_world'"):
         mi.load_string(xml.replace('<vector name="direction" x="0" y="-1" z="0"/>', '<vector name="direction" x="0" y="-1" z="0"/><transform name="to_world"><rotate x="1" angle="10"/></transform>'))
+
+
+# ------------------------------------------------------------------------------------------------ the reference's own emitter tests, geometry halves
+# src/emitters/tests/test_{point,spot,directional,constant}.py run in spectral variants only and compare the sampled weight with a spectrum object, so the
+# harvester (tests/golden/extract_reference_kats.py) can take nothing from them; what they assert about GEOMETRY -- ds.d, ds.pdf, ds.delta, the distance
+# falloff and the spot light's falloff curve, for the inputs the tests hold -- is independent of the colour representation and is restated here with
+# those inputs (cited), against the oracle's Emitter::sample_direction (orc_kat_emitter_sample; the GPU kernels are lane-for-lane bit-exact with it).
+def _emitter_scene(orc, emitter_xml):
+    xml = ('<scene version="3.0.0"><integrator type="path"/><sensor type="perspective"><float name="fov" value="40"/><film type="hdrfilm">'
+           '<integer name="width" value="4"/><integer name="height" value="4"/></film></sensor>'
+           '<shape type="rectangle"><transform name="to_world"><scale value="0.5"/></transform></shape>' + emitter_xml + '</scene>')
+    return orc.Scene(xml, is_string=True)
+
+
+def _sample(orc, sc, ref, sx, sy, index=0):
+    out = np.zeros(13, np.float32)
+    ref = np.ascontiguousarray(ref, np.float32)
+    orc.lib().orc_kat_emitter_sample(C.byref(sc.c), index, ref.ctypes.data_as(C.c_void_p), C.c_float(sx), C.c_float(sy), out.ctypes.data_as(C.c_void_p))
+    return dict(d=out[0:3].astype(np.float64), dist=float(out[3]), pdf=float(out[4]), delta=bool(out[5]), weight=out[6:9].astype(np.float64), p=out[9:12].astype(np.float64))
+
+
+def _lookat_xml(origin, target, up):
+    return '<transform name="to_world"><lookat origin="%s" target="%s" up="%s"/></transform>' % tuple(", ".join(repr(float(x)) for x in v) for v in (origin, target, up))
+
+
+def test_reference_point_light_sample_direction(orc):
+    """test_point.py:60-89 (test02_point_sample_direction): emitter at [10, -1, 2], it.p = [0, -2, 4.5], sample [0.1, 0.5]"""
+    pos, p = np.array([10.0, -1.0, 2.0]), np.array([0.0, -2.0, 4.5])
+    sc = _emitter_scene(orc, '<emitter type="point"><point name="position" x="10" y="-1" z="2"/><rgb name="intensity" value="3, 5, 7"/></emitter>')
+    ds = _sample(orc, sc, p, 0.1, 0.5)
+    d = pos - p; dist = np.linalg.norm(d); d /= dist
+    assert ds["pdf"] == 1.0 and ds["delta"] and np.allclose(ds["d"], d, rtol=1e-5, atol=1e-8) and np.isclose(ds["dist"], dist, rtol=1e-6)
+    assert np.allclose(ds["weight"], np.array([3.0, 5.0, 7.0]) / dist ** 2, rtol=1e-5)          # res == spectrum / dist**2
+
+
+@pytest.mark.parametrize("it_pos", [[2.0, 0.5, 0.0], [1.0, 0.5, -5.0]])
+@pytest.mark.parametrize("cutoff_angle", [20, 80])
+@pytest.mark.parametrize("lookat", [([0, 1, 0], [0, 0, 0], [1, 0, 0]), ([0, 0, 1], [0, 0, 0], [0, -1, 0])])
+def test_reference_spot_light_sample_direction(orc, it_pos, cutoff_angle, lookat):
+    """test_spot.py:43-93 (test_sample_direction) over its parametrisation: it_pos, cutoff_angle in {20, 80}, the two look_at transforms; beam width
+    = 3/4 of the cutoff (the plugin's default), falloff (cutoff - angle) / (cutoff - beam) between the two, 0 beyond the cutoff, 1 / dist^2"""
+    origin, target, up = (np.array(v, np.float64) for v in lookat)
+    sc = _emitter_scene(orc, '<emitter type="spot">%s<float name="cutoff_angle" value="%d"/><rgb name="intensity" value="2, 4, 8"/></emitter>' % (_lookat_xml(origin, target, up), cutoff_angle))
+    cutoff = np.radians(cutoff_angle); beam = cutoff * 0.75
+    p = np.array(it_pos, np.float64)
+    d = origin - p; dist = np.linalg.norm(d); d /= dist                          # lookat.translation() is the light's position
+    axis = (target - origin) / np.linalg.norm(target - origin)                   # (trafo.inverse() @ (-d))[2] = cos of the angle to the light's axis
+    angle = np.arccos(np.clip(np.dot(-d, axis), -1, 1))
+    if abs(angle - beam) < 1e-3:
+        angle = beam
+    if abs(angle - cutoff) < 1e-3:
+        angle = cutoff
+    spec = np.array([2.0, 4.0, 8.0])
+    if angle > beam:
+        spec = spec * ((cutoff - angle) / (cutoff - beam))
+    if angle > cutoff:
+        spec = spec * 0
+    ds = _sample(orc, sc, p, 0.0, 0.0)
+    assert ds["pdf"] == 1.0 and ds["delta"] and np.allclose(ds["d"], d, rtol=1e-5, atol=1e-7)
+    assert np.allclose(ds["weight"], spec / dist ** 2, rtol=2e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("direction", [[0, 0, -1], [1, 1, 1], [0, 0, 1]])
+def test_reference_directional_emitter_sample_direction(orc, direction):
+    """test_directional.py:88-114 (test_sample_direction): it.p = [-0.5, 0.3, -0.1], samples [0.85, 0.13]; ds.d = -direction / |direction|, pdf 1, no distance
+    attenuation.  (The directions are those of the file's `direction` fixture.)"""
+    sc = _emitter_scene(orc, '<emitter type="directional"><vector name="direction" x="%g" y="%g" z="%g"/><rgb name="irradiance" value="1.5, 2.5, 3.5"/></emitter>' % tuple(direction))
+    ds = _sample(orc, sc, [-0.5, 0.3, -0.1], 0.85, 0.13)
+    dn = np.array(direction, np.float64); dn /= np.linalg.norm(dn)
+    assert np.allclose(ds["d"], -dn, rtol=1e-5, atol=1e-7) and np.isclose(ds["pdf"], 1.0) and ds["delta"]
+    assert np.allclose(ds["weight"], [1.5, 2.5, 3.5], rtol=1e-6)
+
+
+def test_reference_constant_emitter_sample_direction(orc):
+    """test_constant.py:68-89 (test03_sample_direction): three points inside the unit sphere, samples [[0.4, 0.5, 0.3], [0.1, 0.4, 0.9]]: pdf = 1 / (4 pi),
+    ds.d = square_to_uniform_sphere(sample), weight = radiance * 4 pi"""
+    sc = _emitter_scene(orc, '<emitter type="constant"><rgb name="radiance" value="0.5, 1, 2"/></emitter>')
+    pts = [[-0.5, 0.3, -0.1], [0.8, -0.3, -0.2], [-0.2, 0.6, -0.6]]
+    sx, sy = [0.4, 0.5, 0.3], [0.1, 0.4, 0.9]
+    for p, a, b in zip(pts, sx, sy):
+        ds = _sample(orc, sc, p, a, b)
+        z = 1.0 - 2.0 * b; r = np.sqrt(max(0.0, 1.0 - z * z))                    # warp::square_to_uniform_sphere (warp.h:278-288)
+        expect = np.array([r * np.cos(2 * np.pi * a), r * np.sin(2 * np.pi * a), z])
+        assert np.isclose(ds["pdf"], 1 / (4 * np.pi), rtol=1e-6) and not ds["delta"] and np.allclose(ds["d"], expect, atol=2e-6)
+        assert np.allclose(ds["weight"], np.array([0.5, 1.0, 2.0]) * 4 * np.pi, rtol=1e-5)

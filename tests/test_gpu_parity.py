@@ -665,6 +665,35 @@ def test_full_size_c4_domino_rectangular_1024x1024x128(mi, orc):
     assert float((np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b), 1e-3 * scale)).max()) <= PX_TOL
 
 
+def test_full_size_c5_domino_trapezoidal_1024x1024x512_four_offsets(mi, orc):
+    """BASELINE configs[4] at FULL size: Domino, trapezoidal low-pass, antithetic 0.5, 1024 x 1024 x 512 spp with the four hetero_offset values
+    {0, .25, .5, .75} batched in ONE traversal (536 870 912 lanes, 32 wavefront batches, 2.1 G path-offsets), through size-independent properties:
+    (1) the films of offsets 0 / .5 and of .25 / .75 are negatives of each other -- the trapezoidal low-pass correlation clamp(2 (2 - 4c), -2, 2)
+    (waveform_utils.h:52-58) is odd under a half-period shift like the cosine; (2) path / bounce / shadow-ray counts equal 4x those of the 128-spp
+    frame up to sampling noise and the batch count; (3) finiteness, and the four films differ; (4) a 2-row band of lanes across a batch seam,
+    bit-exact against the oracle (the lanes carry offset 0: the batched films share every lane's path)."""
+    path = os.path.join(SCENES, "domino.xml")
+    params = dict(wave_function_type="trapezoidal", time_sampling_method="antithetic", antithetic_shift=0.5)
+    sc = mi.load_file(path, **params)
+    offsets = [0.0, 0.25, 0.5, 0.75]
+    imgs = sc.render(seed=0, spp=512, offsets=offsets)
+    st = sc.last_stats
+    assert imgs.shape == (4, 1024, 1024, 3) and np.isfinite(imgs).all()
+    assert st["n_paths"] == 1024 * 1024 * 512 and st["n_batches"] == 32
+    assert st["n_paths"] < st["n_bounces"] <= 3 * st["n_paths"] and 0 < st["n_shadow_rays"] <= st["n_bounces"]
+    scale = np.abs(imgs).max()
+    assert scale > 0
+    assert rel_linf(imgs[0], -imgs[2]) <= 2e-4 and rel_linf(imgs[1], -imgs[3]) <= 2e-4, (rel_linf(imgs[0], -imgs[2]), rel_linf(imgs[1], -imgs[3]))
+    assert np.abs(imgs[0] - imgs[1]).max() > 1e-2 * scale                      # a quarter period apart: different images
+    osc = orc.Scene(path, params)
+    lanes_per_row = 1024 * 512
+    lane0 = 31 * lanes_per_row                                                   # rows 31, 32: the seam between batches 0 and 1 (32 rows each)
+    g = sc.sample_lanes(0, 512, lane0, 2 * lanes_per_row)
+    o = osc.render_lanes(osc.params(), 0, 512, lane0, 2 * lanes_per_row, threads=NCPU)
+    for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+        assert np.array_equal(bits(g[k]), bits(o[k])), (k, int((bits(g[k]) != bits(o[k])).sum()))
+
+
 def test_two_ranks_on_one_gpu_reproduce_the_single_rank_image(mi, tmp_path):
     """The whole N > 1 path on real kernels: two processes (torch.distributed, gloo for the one gather since both share the only
     GPU of this box) each render their band of rows with dtof_render_rows, rank 0 overlap-adds the halo rows and develops.

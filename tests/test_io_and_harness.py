@@ -132,6 +132,37 @@ def test_native_cli_writes_the_same_image(mi, tmp_path):
     assert img3.shape == (24, 40, 3) and np.abs(img3 - ref).max() <= 5e-5 * np.abs(ref).max()
 
 
+@pytest.mark.gpu
+def test_native_cli_over_two_gpus_reproduces_the_single_gpu_image(mi, tmp_path):
+    """dtof-render --gpus 2 on a node with at least two GPUs: two host threads, two RCCL ranks (ncclCommInitAll), interleaved stripes, ONE ncclReduce of the
+    films over xGMI, develop on GPU 0.  The driver's GPU box has one GPU: skipped there (the one-rank communicator and the shared-GPU switch cover the code
+    path in test_native_cli_writes_the_same_image); first hardware run of the 2-rank collective happens wherever this test finds two devices."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    exe = os.path.join(ROOT, "mitsuba3dopplertof_amd", "dtof-render")
+    scene = os.path.join(SCENES, "domino_small.xml")
+    ref = mi.load_file(scene, resx=64, resy=48).render(seed=3, spp=16)
+    for stripes in (4, 7):
+        out = str(tmp_path / ("two_%d.npy" % stripes))
+        r = subprocess.run([exe, scene, "-D", "resx=64", "-D", "resy=48", "--spp", "16", "--seed", "3", "-o", out, "--gpus", "2", "--stripes", str(stripes)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        img = np.load(out)
+        assert img.shape == ref.shape and np.abs(img - ref).max() <= 5e-5 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+def test_native_cli_reports_a_failing_rank_instead_of_hanging(tmp_path):
+    """a rank that cannot load the scene must not leave the others waiting in the collective: every rank finishes what can fail, all meet at a host
+    barrier, and the reduce is entered by all or by none (dtof_cli.cpp).  Run with the shared-GPU development switch so that three ranks exist on one GPU."""
+    exe = os.path.join(ROOT, "mitsuba3dopplertof_amd", "dtof-render")
+    # one sample per pixel under per-interval stratification with time_correlate_number = 2: the render call of every rank fails (the scene itself loads)
+    r = subprocess.run([exe, os.path.join(SCENES, "cornell_wall.xml"), "-D", "resx=16", "-D", "resy=16", "--spp", "1", "--gpus", "3",
+                        "-o", str(tmp_path / "x.npy")], capture_output=True, text=True, timeout=120, env=dict(os.environ, DTOF_CLI_SHARE_GPU="1"))
+    assert r.returncode != 0 and "Error: GPU" in r.stderr and "sample count" in r.stderr, r.stderr
+
+
 def _read_png(path):
     import struct
     import zlib

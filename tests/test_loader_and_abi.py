@@ -48,6 +48,38 @@ def test_loader_matches_oracle_loader_bit_exact(mi, orc, xml, params):
     assert info["crop_width"] == fs.sensor["crop_w"] and info["crop_height"] == fs.sensor["crop_h"]
 
 
+REFERENCE_SCENE = "/root/reference/configs_example/scene.xml"
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_SCENE), reason="build container only: reads the reference's own example scene (absent on the GPU box)")
+def test_the_reference_example_scene_loads_unchanged(mi, orc):
+    """north_star: "a scene.xml that names dopplertofpath / correlated renders unchanged".  The reference's own configs_example/scene.xml goes
+    through the product loader and through the oracle loader AS IT IS, and both give the scene the generated scenes/cornell_boxes.xml
+    describes -- same shapes, transforms, keyframes, materials, light and camera, bit for bit (the generated file only sets a smaller
+    default sample count and film size, overridden here)."""
+    from oracle import scene_xml
+    text = open(REFERENCE_SCENE).read()
+    assert 'type="dopplertofpath"' in text and 'type="correlated"' in text
+    try:
+        ref_sc = mi.load_file(REFERENCE_SCENE)
+    except mi.DtofError as e:                                        # an unused <default> is fine; an unused loader parameter is not
+        raise AssertionError("the reference's example scene does not load unchanged: %s" % e)
+    ref_fs = scene_xml.load(REFERENCE_SCENE, {})
+    w, h = ref_sc.size
+    own = os.path.join(SCENES, "cornell_boxes.xml")
+    own_sc = mi.load_file(own, resx=w, resy=h)
+    own_fs = scene_xml.load(own, dict(resx=w, resy=h))
+    for a, b in zip(_export_all(ref_sc), _export_all(own_sc)):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for a, b in zip(_oracle_all(ref_fs), _oracle_all(own_fs)):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    ri, oi = ref_sc.info(), own_sc.info()
+    for k in ("n_shapes", "n_groups", "n_objects", "n_emitters", "n_triangles", "time", "w_g", "hetero_frequency", "antithetic_shift", "wave_type", "time_sampling",
+              "path_correlation_depth", "max_depth", "time_correlate_number", "path_correlate_number"):
+        assert ri[k] == oi[k], (k, ri[k], oi[k])
+    assert ri["sample_count"] == 1024                                # the example file's sampler block says so (SURVEY App. B)
+
+
 def test_transform_ops_compose_like_the_reference(mi):
     """ops left-multiply (xml.cpp:902-1007): translate after rotate after scale; lookat; 3x3 matrix."""
     from oracle import scene_xml

@@ -176,7 +176,7 @@ def test_mesh_scenes_are_bit_exact_per_lane(mi, orc, mesh_dir, name, flavour, pa
         path = os.path.join(mesh_dir, name + ".xml")
         open(path, "w").write(one_mesh_xml(*flavour))
     sc, osc = mi.load_file(path, **params), orc.Scene(path, params)
-    assert sc.info()["n_bvh_nodes"] > 100      # the meshes sit behind a BLAS
+    assert sc.info()["n_bvh_nodes"] > 50       # the meshes sit behind a BLAS (binary nodes: > 250, quantised 4-wide nodes: a third of that)
     pd = osc.params()
     w, h = sc.size
     n = w * h * spp

@@ -113,7 +113,7 @@ def test_thinlens_loader_errors(who, orc, request):
     # ProjectiveCamera reads focus_distance for every projective sensor (sensor.cpp:134): the pinhole camera accepts and ignores it ...
     assert field(load(scene_text("perspective", '<float name="focus_distance" value="2"/>')), "kind") == 0
     if who == "product":   # ... while aperture_radius is nobody's there (xml.cpp:1204-1215; the oracle's reader does not track queried properties)
-        with pytest.raises(err, match='unreferenced property "aperture_radius"'):
+        with pytest.raises(err, match='unreferenced property .*"aperture_radius"'):
             load(scene_text("perspective", LENS))
 
 
