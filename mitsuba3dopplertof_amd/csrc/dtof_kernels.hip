@@ -480,6 +480,8 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             if (twosided) { woz = mulsign(woz, wiz); wiz = fabsf(wiz); }
             V3 refl = mk(sh->refl[0], sh->refl[1], sh->refl[2]);
             if (SPEC && (sh->nonlinear >> 1)) refl = texture_eval(sv, (sh->nonlinear >> 1) << 4, si.u, si.v);   // m_reflectance->eval(si)
+            HitMaterial hm;   // specular colours and roughness of this hit: constants, or the textures on those slots (SPEC instantiations only)
+            if (SPEC) hm = material_at(sv, sh, si.u, si.v);
             V3 bsdf_val = mk(0, 0, 0), bsdf_weight = mk(0, 0, 0), bs_wo = mk(0, 0, 0);
             float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; bool bs_delta = false;
             if (SPEC && sh->bsdf == BSDF_CONDUCTOR) {
@@ -488,9 +490,9 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                 if (cos_theta_i > 0.f) {
                     bs_wo = mk(-si.wi.x, -si.wi.y, si.wi.z);   // reflect(wi); the two-sided flips of wi.z and wo.z cancel
                     bs_eta = 1.f; bs_pdf = 1.f; bs_delta = true;
-                    bsdf_weight = mk(sh->spec_refl[0] * fresnel_conductor(cos_theta_i, sh->cond_eta[0], sh->cond_k[0]),
-                                     sh->spec_refl[1] * fresnel_conductor(cos_theta_i, sh->cond_eta[1], sh->cond_k[1]),
-                                     sh->spec_refl[2] * fresnel_conductor(cos_theta_i, sh->cond_eta[2], sh->cond_k[2]));
+                    bsdf_weight = mk(hm.spec_refl[0] * fresnel_conductor(cos_theta_i, sh->cond_eta[0], sh->cond_k[0]),
+                                     hm.spec_refl[1] * fresnel_conductor(cos_theta_i, sh->cond_eta[1], sh->cond_k[1]),
+                                     hm.spec_refl[2] * fresnel_conductor(cos_theta_i, sh->cond_eta[2], sh->cond_k[2]));
                 }
             } else if (SPEC && sh->bsdf == BSDF_DIELECTRIC) {
                 // SmoothDielectric::sample (dielectric.cpp:231-338), TransportMode::Radiance
@@ -502,8 +504,8 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                 bs_wo = selected_r ? mk(-si.wi.x, -si.wi.y, si.wi.z) : mk(-eta_ti * si.wi.x, -eta_ti * si.wi.y, cos_theta_t);
                 bs_eta = selected_r ? 1.f : eta_it;
                 const float f2 = sqr(eta_ti);
-                bsdf_weight = selected_r ? mk(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2])
-                                         : mk(sh->spec_trans[0] * f2, sh->spec_trans[1] * f2, sh->spec_trans[2] * f2);
+                bsdf_weight = selected_r ? mk(hm.spec_refl[0], hm.spec_refl[1], hm.spec_refl[2])
+                                         : mk(hm.spec_trans[0] * f2, hm.spec_trans[1] * f2, hm.spec_trans[2] * f2);
             } else if (SPEC && sh->bsdf == BSDF_THINDIELECTRIC) {
                 // ThinDielectric::sample (thindielectric.cpp:173-226): the reflectance of the slab with all internal bounces, wo = -wi
                 float r, t1, t2, t3;
@@ -512,12 +514,12 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                 const bool selected_r = sample_1 <= r;
                 bs_pdf = selected_r ? r : 1.f - r; bs_delta = true; bs_eta = 1.f;
                 bs_wo = selected_r ? mk(-si.wi.x, -si.wi.y, si.wi.z) : mk(-si.wi.x, -si.wi.y, -si.wi.z);
-                bsdf_weight = selected_r ? mk(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]) : mk(sh->spec_trans[0], sh->spec_trans[1], sh->spec_trans[2]);
+                bsdf_weight = selected_r ? mk(hm.spec_refl[0], hm.spec_refl[1], hm.spec_refl[2]) : mk(hm.spec_trans[0], hm.spec_trans[1], hm.spec_trans[2]);
             } else if (SPEC && sh->bsdf == BSDF_ROUGHDIELECTRIC) {
                 // RoughDielectric::eval_pdf / sample (roughdielectric.cpp:240-346,503-611): glossy reflection and transmission lobes
-                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, sh->alpha_u, sh->alpha_v, !(sh->flags & SF_SAMPLE_ALL));
+                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, hm.alpha_u, hm.alpha_v, !(sh->flags & SF_SAMPLE_ALL));
                 const V3 wi = si.wi;
-                if (active_em) rough_dielectric_eval_pdf(g, sh, wi, wo, bsdf_val, bsdf_pdf);
+                if (active_em) rough_dielectric_eval_pdf(g, sh, hm, wi, wo, bsdf_val, bsdf_pdf);
                 if (wi.z != 0.f) {
                     float mpdf;
                     Ggx gs = g;   // sample_distr (:266-269)
@@ -531,13 +533,13 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                     float dwh_dwo; V3 w;
                     if (selected_r) {
                         bs_wo = mk(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   // reflect(wi, m)
-                        w = mk(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]);
+                        w = mk(hm.spec_refl[0], hm.spec_refl[1], hm.spec_refl[2]);
                         dwh_dwo = rcp(4.f * dot(bs_wo, m));
                     } else {
                         const float k = fmaf(dwm, eta_ti, cos_theta_t);                                                         // refract(wi, m, cos_theta_t, eta_ti)
                         bs_wo = mk(fmaf(m.x, k, -(wi.x * eta_ti)), fmaf(m.y, k, -(wi.y * eta_ti)), fmaf(m.z, k, -(wi.z * eta_ti)));
                         const float f2 = sqr(eta_ti);
-                        w = mk(f2 * sh->spec_trans[0], f2 * sh->spec_trans[1], f2 * sh->spec_trans[2]);
+                        w = mk(f2 * hm.spec_trans[0], f2 * hm.spec_trans[1], f2 * hm.spec_trans[2]);
                         const float dom = dot(bs_wo, m);
                         dwh_dwo = (sqr(bs_eta) * dom) / sqr(dwm + bs_eta * dom);
                     }
@@ -550,16 +552,16 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                 // RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF
                 V3 wi = si.wi, wo_l = wo;
                 if (twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
-                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, sh->alpha_u, sh->alpha_v, !(sh->flags & SF_SAMPLE_ALL));
+                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, hm.alpha_u, hm.alpha_v, !(sh->flags & SF_SAMPLE_ALL));
                 if (wi.z > 0.f && wo_l.z > 0.f) {
                     const V3 H = normalize(wo_l + wi);
                     const float D = ggx_eval(g, H);
                     if (D != 0.f) {
                         const float G = ggx_smith_g1(g, wi, H) * ggx_smith_g1(g, wo_l, H);
                         const float result = D * G / (4.f * wi.z), c = dot(wi, H);
-                        bsdf_val = mk(fresnel_conductor(c, sh->cond_eta[0], sh->cond_k[0]) * (result * sh->spec_refl[0]),
-                                      fresnel_conductor(c, sh->cond_eta[1], sh->cond_k[1]) * (result * sh->spec_refl[1]),
-                                      fresnel_conductor(c, sh->cond_eta[2], sh->cond_k[2]) * (result * sh->spec_refl[2]));
+                        bsdf_val = mk(fresnel_conductor(c, sh->cond_eta[0], sh->cond_k[0]) * (result * hm.spec_refl[0]),
+                                      fresnel_conductor(c, sh->cond_eta[1], sh->cond_k[1]) * (result * hm.spec_refl[1]),
+                                      fresnel_conductor(c, sh->cond_eta[2], sh->cond_k[2]) * (result * hm.spec_refl[2]));
                     }
                     if (dot(wi, H) > 0.f && dot(wo_l, H) > 0.f) bsdf_pdf = g.visible ? ggx_eval(g, H) * ggx_smith_g1(g, wi, H) / (4.f * wi.z) : ggx_pdf(g, wi, H) / (4.f * dot(wo_l, H));   // :405-409
                 }
@@ -572,16 +574,16 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                     const bool ok = mpdf != 0.f && r.z > 0.f;
                     const float weight = g.visible ? ggx_smith_g1(g, r, m) : ggx_smith_g1(g, wi, m) * ggx_smith_g1(g, r, m) * dwm / (wi.z * m.z);   // :260-265
                     bs_pdf = mpdf / (4.f * dot(r, m));
-                    if (ok) bsdf_weight = mk(fresnel_conductor(dwm, sh->cond_eta[0], sh->cond_k[0]) * (weight * sh->spec_refl[0]),
-                                             fresnel_conductor(dwm, sh->cond_eta[1], sh->cond_k[1]) * (weight * sh->spec_refl[1]),
-                                             fresnel_conductor(dwm, sh->cond_eta[2], sh->cond_k[2]) * (weight * sh->spec_refl[2]));
+                    if (ok) bsdf_weight = mk(fresnel_conductor(dwm, sh->cond_eta[0], sh->cond_k[0]) * (weight * hm.spec_refl[0]),
+                                             fresnel_conductor(dwm, sh->cond_eta[1], sh->cond_k[1]) * (weight * hm.spec_refl[1]),
+                                             fresnel_conductor(dwm, sh->cond_eta[2], sh->cond_k[2]) * (weight * hm.spec_refl[2]));
                     if (twosided && si.wi.z < 0.f) bs_wo.z = -bs_wo.z;
                 }
             } else if (SPEC && sh->bsdf == BSDF_ROUGHPLASTIC) {
                 // RoughPlastic::eval / pdf / sample (roughplastic.cpp:259-421), GGX + visible normals, under TwoSidedBRDF
                 V3 wi = si.wi, wo_l = wo;
                 if (twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
-                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, sh->alpha_u, sh->alpha_u, !(sh->flags & SF_SAMPLE_ALL));
+                const Ggx g = mf_make((sh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, hm.alpha_u, hm.alpha_u, !(sh->flags & SF_SAMPLE_ALL));
                 const float *table = (const float *) (sv.base + sh->rough_table);
                 const float w = sh->spec_sampling_weight, ir = sh->fdr_int;
                 const V3 diff = (sh->nonlinear & 1u) ? mk(refl.x / (1.f - refl.x * ir), refl.y / (1.f - refl.y * ir), refl.z / (1.f - refl.z * ir))
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                     float prob_specular = (1.f - t_i) * w, prob_diffuse = t_i * (1.f - w);
                     prob_specular = prob_specular / (prob_specular + prob_diffuse);
                     prob_diffuse = 1.f - prob_specular;
-                    if (wo_l.z > 0.f) rough_plastic_eval_pdf(g, sh, table, diff, wi, wo_l, t_i, prob_specular, prob_diffuse, bsdf_val, bsdf_pdf);
+                    if (wo_l.z > 0.f) rough_plastic_eval_pdf(g, sh, hm, table, diff, wi, wo_l, t_i, prob_specular, prob_diffuse, bsdf_val, bsdf_pdf);
                     if (sample_1 < prob_specular) {
                         float mpdf; const V3 m = ggx_sample(g, wi, s2x, s2y, mpdf);
                         const float dwm = dot(wi, m);
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                     } else bs_wo = cosine_hemisphere(s2x, s2y);
                     bs_eta = 1.f;
                     V3 value = mk(0, 0, 0);
-                    if (bs_wo.z > 0.f) rough_plastic_eval_pdf(g, sh, table, diff, wi, bs_wo, t_i, prob_specular, prob_diffuse, value, bs_pdf);
+                    if (bs_wo.z > 0.f) rough_plastic_eval_pdf(g, sh, hm, table, diff, wi, bs_wo, t_i, prob_specular, prob_diffuse, value, bs_pdf);
                     if (bs_pdf > 0.f) bsdf_weight = value * rcp(bs_pdf);                  // Spectrum / Float = multiplication by the reciprocal
                     if (twosided && si.wi.z < 0.f) bs_wo.z = -bs_wo.z;
                 }
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                         bs_wo = mk(-si.wi.x, -si.wi.y, wiz);
                         bs_pdf = prob_specular; bs_delta = true;
                         const float value = f_i / bs_pdf;
-                        bsdf_weight = mk(value * sh->spec_refl[0], value * sh->spec_refl[1], value * sh->spec_refl[2]);
+                        bsdf_weight = mk(value * hm.spec_refl[0], value * hm.spec_refl[1], value * hm.spec_refl[2]);
                     } else {
                         bs_wo = cosine_hemisphere(s2x, s2y);
                         bs_pdf = prob_diffuse * (kInvPi * bs_wo.z);

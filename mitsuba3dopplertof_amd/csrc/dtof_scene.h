@@ -77,7 +77,7 @@ struct DObject {            // 128 B
     float key0[12], key1[12];
 };
 struct DGroup { uint32_t first_shape, n_shapes, pad[2]; };
-struct DShape {             // 304 B
+struct DShape {             // 320 B
     uint32_t kind, flags, first_tri, n_tris;
     float refl[3]; uint32_t blas_root;                   // mesh: root node of its BLAS, kNoChild = loop over the triangles
     float to_world[12], to_object[12];
@@ -97,6 +97,9 @@ struct DShape {             // 304 B
     // BSDF_ROUGHPLASTIC (src/bsdfs/roughplastic.cpp, GGX + visible normals): the plastic fields + alpha_u; fdr_int = m_internal_reflectance;
     // rough_table = byte offset in the blob of m_external_transmittance (64 floats)
     float cond_eta[3], fdr_int, cond_k[3], spec_sampling_weight, spec_refl[3], alpha_u, spec_trans[3], alpha_v;
+    // textures on the other slots, (byte offset of the DTexture in the blob) >> 4, 0 = none: specular_reflectance, specular_transmittance (Texture::eval per hit) and the
+    // roughness alpha_u / alpha_v of roughconductor / roughdielectric (Texture::eval_1 per hit; `alpha` fills both)
+    uint32_t tex_spec, tex_trans, tex_alpha_u, tex_alpha_v;
 };
 // Texture on a BSDF's diffuse reflectance (src/textures/checkerboard.cpp, src/textures/bitmap.cpp); the record and, for bitmaps, the
 // linear float32 texels (row 0 first) live in the tables area of the blob.  to_uv: the 2x2 linear part of the plugin's `to_uv`
@@ -132,7 +135,7 @@ struct DEnvmap {
 static_assert(sizeof(DEnvmap) % 16 == 0, "DEnvmap");
 static_assert(sizeof(BvhNode4) == 64, "BvhNode4");
 static_assert(sizeof(DTexture) == 64, "DTexture");
-static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 304 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64 && sizeof(DEmitter) == 96, "blob records");
+static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 320 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64 && sizeof(DEmitter) == 96, "blob records");
 
 // ---------------------------------------------------------------------------- host description
 struct Mat4d { double m[16]; };   // row-major
@@ -148,6 +151,7 @@ struct HostShape {
     bool beckmann = false;                 // their `distribution` (microfacet.h MicrofacetType)
     bool sample_all = false;               // their `sample_visible` = false: all normals are sampled (microfacet.h:240-290), roughdielectric scales its roughness for sampling
     int tex_refl = -1;                     // texture on reflectance / diffuse_reflectance: index into HostScene::textures
+    int tex_spec = -1, tex_trans = -1, tex_alpha_u = -1, tex_alpha_v = -1;   // textures on specular_reflectance / specular_transmittance / the roughness (alpha sets both)
     std::vector<float> rough_table;        // roughplastic: m_external_transmittance (64 values)
     float to_world[16], to_object[16];     // float casts of the double transform and its double inverse
     // mesh: cube baked like src/shapes/cube.cpp:114-160; obj / ply through mesh_io.cpp

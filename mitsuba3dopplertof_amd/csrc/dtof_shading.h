@@ -254,6 +254,33 @@ DTOF_D V3 texture_eval(const SceneView &sv, uint32_t rec_off, float u, float v) 
     if (C == 1) texel[1] = texel[2] = texel[0];
     return mk(texel[0], texel[1], texel[2]);
 }
+// Texture::eval_1 (bitmap.cpp:324-344: one channel as it is, three channels -> luminance, spectrum.h:431-434; checkerboard.cpp:91-110 with constant
+// colours: the mean of the colour the lookup picks, srgb.cpp:85-88)
+DTOF_D float texture_eval_1(const SceneView &sv, uint32_t rec_off, float u, float v) {
+    const DTexture &tex = *(const DTexture *) (sv.base + rec_off);
+    const V3 c = texture_eval(sv, rec_off, u, v);
+    if ((tex.kind_flags & 0xffu) == TEX_CHECKERBOARD) {
+        const bool first = c.x == tex.color0[0] && c.y == tex.color0[1] && c.z == tex.color0[2];
+        const float *k = first ? tex.color0 : tex.color1;
+        return ((k[0] + k[1]) + k[2]) * (1.0f / 3.0f);
+    }
+    if ((tex.kind_flags >> 24) == 1u) return c.x;
+    return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f;
+}
+// The material parameters of one hit: the shape's constants, or the lookups of the textures bound to their slots (m_specular_reflectance->eval(si),
+// m_alpha_u->eval_1(si), ...)
+struct HitMaterial { float spec_refl[3], spec_trans[3], alpha_u, alpha_v; };
+DTOF_D HitMaterial material_at(const SceneView &sv, const DShape *sh, float u, float v) {
+    HitMaterial m;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { m.spec_refl[i] = sh->spec_refl[i]; m.spec_trans[i] = sh->spec_trans[i]; }
+    m.alpha_u = sh->alpha_u; m.alpha_v = sh->alpha_v;
+    if (sh->tex_spec) { const V3 c = texture_eval(sv, sh->tex_spec << 4, u, v); m.spec_refl[0] = c.x; m.spec_refl[1] = c.y; m.spec_refl[2] = c.z; }
+    if (sh->tex_trans) { const V3 c = texture_eval(sv, sh->tex_trans << 4, u, v); m.spec_trans[0] = c.x; m.spec_trans[1] = c.y; m.spec_trans[2] = c.z; }
+    if (sh->tex_alpha_u) m.alpha_u = texture_eval_1(sv, sh->tex_alpha_u << 4, u, v);
+    if (sh->tex_alpha_v) m.alpha_v = texture_eval_1(sv, sh->tex_alpha_v << 4, u, v);
+    return m;
+}
 // RoughPlastic::lerp_gather (roughplastic.cpp:373-383) on the 64-entry transmittance table
 DTOF_D float lerp_gather64(const float *data, float x) {
     x *= 63.f;
@@ -262,7 +289,7 @@ DTOF_D float lerp_gather64(const float *data, float x) {
     return fmaf(v1, t, fmaf(-v0, t, v0));                        // dr::lerp(v0, v1, t)
 }
 // RoughPlastic::eval (:333-371) and pdf (:385-421) for wi.z > 0 and wo.z > 0
-DTOF_D void rough_plastic_eval_pdf(Ggx g, const DShape *sh, const float *table, V3 diff, V3 wi, V3 wo, float t_i, float prob_specular,
+DTOF_D void rough_plastic_eval_pdf(Ggx g, const DShape *sh, const HitMaterial &hm, const float *table, V3 diff, V3 wi, V3 wo, float t_i, float prob_specular,
                                    float prob_diffuse, V3 &value, float &pdf) {
     const V3 H = normalize(wo + wi);
     const float D = ggx_eval(g, H);
@@ -271,13 +298,13 @@ DTOF_D void rough_plastic_eval_pdf(Ggx g, const DShape *sh, const float *table, 
     const float spec = F * D * G / (4.f * wi.z);
     const float t_o = lerp_gather64(table, wo.z);
     const float k = kInvPi * sh->inv_eta_2 * wo.z * t_i * t_o;
-    value = mk(spec * sh->spec_refl[0] + diff.x * k, spec * sh->spec_refl[1] + diff.y * k, spec * sh->spec_refl[2] + diff.z * k);
+    value = mk(spec * hm.spec_refl[0] + diff.x * k, spec * hm.spec_refl[1] + diff.y * k, spec * hm.spec_refl[2] + diff.z * k);
     float result = g.visible ? D * ggx_smith_g1(g, wi, H) / (4.f * wi.z) : ggx_pdf(g, wi, H) / (4.f * dot(wo, H));   // roughplastic.cpp:467-470
     result *= prob_specular;
     pdf = result + prob_diffuse * (kInvPi * wo.z);
 }
 // RoughDielectric::eval_pdf (roughdielectric.cpp:503-611), GGX + visible normals, TransportMode::Radiance
-DTOF_D void rough_dielectric_eval_pdf(Ggx g, const DShape *sh, V3 wi, V3 wo, V3 &value, float &pdf) {
+DTOF_D void rough_dielectric_eval_pdf(Ggx g, const DShape *sh, const HitMaterial &hm, V3 wi, V3 wo, V3 &value, float &pdf) {
     const float cti = wi.z, cto = wo.z, m_eta = sh->diel_eta, m_inv_eta = rcp(m_eta);
     const bool reflect = cti * cto > 0.f;
     const float eta = cti > 0.f ? m_eta : m_inv_eta, inv_eta = cti > 0.f ? m_inv_eta : m_eta;
@@ -292,11 +319,11 @@ DTOF_D void rough_dielectric_eval_pdf(Ggx g, const DShape *sh, V3 wi, V3 wo, V3 
     if (!active) return;
     if (reflect) {
         const float v = F * D * G / (4.f * fabsf(cti));
-        value = mk(v * sh->spec_refl[0], v * sh->spec_refl[1], v * sh->spec_refl[2]);
+        value = mk(v * hm.spec_refl[0], v * hm.spec_refl[1], v * hm.spec_refl[2]);
     } else {
         const float scale = sqr(inv_eta);
         const float v = fabsf((scale * (1.f - F) * D * G * eta * eta * dwm * dom) / (cti * sqr(dwm + eta * dom)));
-        value = mk(v * sh->spec_trans[0], v * sh->spec_trans[1], v * sh->spec_trans[2]);
+        value = mk(v * hm.spec_trans[0], v * hm.spec_trans[1], v * hm.spec_trans[2]);
     }
     Ggx gs = g;   // sample_distr: Walter et al.'s roughness scaling when all normals are sampled (roughdielectric.cpp:584-589)
     if (!g.visible) { const float sc = 1.2f - .2f * sqrtf(fabsf(cti)); gs.au *= sc; gs.av *= sc; }

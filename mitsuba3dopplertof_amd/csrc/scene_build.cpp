@@ -207,7 +207,8 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     std::vector<uint32_t> tables;   // mesh emitters: cdf[n] | pmf[n] (float bits) | slot[n]; roughplastic: 64 transmittances
     const char *blas_env = getenv("DTOF_BLAS"); const bool use_blas = !(blas_env && blas_env[0] == '0');   // DTOF_BLAS=0: loop over every triangle (debug)
     std::vector<Box> shape_boxes(sc.shapes.size());
-    std::vector<std::pair<uint32_t, uint32_t>> tex_recs;   // (shape, word offset of its DTexture in `tables`)
+    struct TexUse { uint32_t shape, slot, rec; };           // slot: 0 reflectance (rides in `nonlinear`), 1 specular_reflectance, 2 specular_transmittance, 3 alpha_u, 4 alpha_v
+    std::vector<TexUse> tex_recs;                          // rec: word offset of the DTexture in `tables`
     std::vector<uint32_t> tex_rec_of(sc.textures.size(), 0xffffffffu);   // texture index -> word offset of its record: every texture is stored once, however many shapes use it
     auto check_words = [&]() { if (tables.size() > 0x3fffffffu) throw std::runtime_error("scene tables exceed the 4 GiB the 32-bit blob offsets address"); };
     for (size_t i = 0; i < sc.shapes.size(); ++i) {
@@ -222,9 +223,10 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
             d.rough_table = (uint32_t) tables.size() * 4u;
             for (float v : h.rough_table) { uint32_t b; memcpy(&b, &v, 4); tables.push_back(b); }
         }
-        if (h.tex_refl >= 0) {   // the texture record and its texels go to the tables area; the offset is rebased below
-            const HostTexture &t = sc.textures[(size_t) h.tex_refl];
-            uint32_t &rec = tex_rec_of[(size_t) h.tex_refl];
+        const int tex_of_slot[5] = { h.tex_refl, h.tex_spec, h.tex_trans, h.tex_alpha_u, h.tex_alpha_v };
+        for (uint32_t slot = 0; slot < 5; ++slot) if (tex_of_slot[slot] >= 0) {   // the texture record and its texels go to the tables area; the offsets are rebased below
+            const HostTexture &t = sc.textures[(size_t) tex_of_slot[slot]];
+            uint32_t &rec = tex_rec_of[(size_t) tex_of_slot[slot]];
             if (rec == 0xffffffffu) {
                 while (tables.size() % 4) tables.push_back(0);            // 16-byte aligned record (the offset is stored >> 4)
                 check_words();
@@ -240,7 +242,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
                 if (!t.data.empty()) memcpy(&tables[at], t.data.data(), t.data.size() * 4);
                 check_words();
             }
-            tex_recs.emplace_back((uint32_t) i, rec);
+            tex_recs.push_back({ (uint32_t) i, slot, rec });
         }
         if (h.emitter) { d.flags |= SF_EMITTER; memcpy(d.radiance, h.radiance, 12); }
         memcpy(d.to_world, h.to_world, 48); memcpy(d.to_object, h.to_object, 48);
@@ -527,10 +529,13 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         for (uint32_t k = 0; k < rec->n_levels; ++k) rec->level_off[k] += h.off_tables;
         emitters[ei].shape += h.off_tables;
     }
-    for (auto &tr : tex_recs) {   // reflectance textures: record offset (>> 4) beside the `nonlinear` bit, texel offset inside the record
-        const uint32_t rec_off = h.off_tables + tr.second * 4u;
-        shapes[tr.first].nonlinear |= (rec_off >> 4) << 1;
-        tables[tr.second + 3] += h.off_tables;                     // DTexture::data_off
+    std::vector<bool> rebased(tables.size() / 4 + 1, false);
+    for (auto &tr : tex_recs) {   // record offsets (>> 4): the reflectance texture beside the `nonlinear` bit, the others in their own fields; texel offset inside the record
+        const uint32_t rec_off = h.off_tables + tr.rec * 4u;
+        DShape &d = shapes[tr.shape];
+        if (tr.slot == 0) d.nonlinear |= (rec_off >> 4) << 1;
+        else (tr.slot == 1 ? d.tex_spec : tr.slot == 2 ? d.tex_trans : tr.slot == 3 ? d.tex_alpha_u : d.tex_alpha_v) = rec_off >> 4;
+        if (!rebased[tr.rec / 4]) { tables[tr.rec + 3] += h.off_tables; rebased[tr.rec / 4] = true; }   // DTexture::data_off, once per record
     }
     std::vector<uint8_t> blob(off, 0);
     memcpy(blob.data(), &h, sizeof h);

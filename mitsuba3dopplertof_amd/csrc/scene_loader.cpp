@@ -848,6 +848,31 @@ static int reflectance_of(const Obj &b, const char *name, float def, float out[3
     return -1;
 }
 
+// the roughness of roughconductor / roughdielectric (roughconductor.cpp:189-199, roughdielectric.cpp:213-223): `alpha`, or `alpha_u` and `alpha_v`, each a
+// float or a texture (Texture::eval_1 per hit; the constant then holds the texture's mean)
+static void roughness_of(const Obj &b, HostShape &s) {
+    auto slot = [&](const char *name, float &value) -> int {
+        float c[3]; const int t = reflectance_of(b, name, 0.1f, c);
+        if (t >= 0) { value = c[0]; return t; }
+        value = (float) b.props.get_float(name, 0.1);
+        return -1;
+    };
+    auto given = [&](const char *name) {
+        if (b.props.has(name)) return true;
+        for (size_t i = 0; i < b.children.size(); ++i) {
+            const Obj *c = b.children[i].second.get();
+            if (!c) continue;
+            if ((i < b.ref_names.size() && !b.ref_names[i].empty() ? b.ref_names[i] : c->name) == name) return true;
+        }
+        return false;
+    };
+    if (given("alpha_u") || given("alpha_v")) {
+        if (!given("alpha_u") || !given("alpha_v")) fail("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
+        if (given("alpha")) fail("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.");
+        s.tex_alpha_u = slot("alpha_u", s.alpha_u); s.tex_alpha_v = slot("alpha_v", s.alpha_v);
+    } else { s.tex_alpha_u = slot("alpha", s.alpha_u); s.tex_alpha_v = s.tex_alpha_u; s.alpha_v = s.alpha_u; }
+}
+
 // diffuse (src/bsdfs/diffuse.cpp), conductor (conductor.cpp:171-188), dielectric (dielectric.cpp:176-203), twosided{...} (twosided.cpp:40-70)
 static void bsdf_of(const Obj &b, HostShape &s) {
     if (b.plugin == "twosided") {
@@ -865,32 +890,28 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         if (material != "none") fail(b.props.has("eta") || b.colors.count("eta") ? "Should specify either (eta, k) or material, not both."
             : "conductor: named materials need the spectral IOR data files, which this build does not ship; give \"eta\" and \"k\"");
         s.bsdf = BSDF_CONDUCTOR;
-        color_of(b, "eta", 0.f, s.cond_eta); color_of(b, "k", 1.f, s.cond_k); color_of(b, "specular_reflectance", 1.f, s.spec_refl);
+        color_of(b, "eta", 0.f, s.cond_eta); color_of(b, "k", 1.f, s.cond_k); s.tex_spec = reflectance_of(b, "specular_reflectance", 1.f, s.spec_refl);
     } else if (b.plugin == "dielectric") {
         const float int_ior = lookup_ior(b, "int_ior", "bk7"), ext_ior = lookup_ior(b, "ext_ior", "air");
         if (int_ior < 0 || ext_ior < 0) fail("The interior and exterior indices of refraction must be positive!");
         s.bsdf = BSDF_DIELECTRIC; s.diel_eta = int_ior / ext_ior;
-        color_of(b, "specular_reflectance", 1.f, s.spec_refl); color_of(b, "specular_transmittance", 1.f, s.spec_trans);
+        s.tex_spec = reflectance_of(b, "specular_reflectance", 1.f, s.spec_refl); s.tex_trans = reflectance_of(b, "specular_transmittance", 1.f, s.spec_trans);
     } else if (b.plugin == "thindielectric") {   // src/bsdfs/thindielectric.cpp:137-158
         const float int_ior = lookup_ior(b, "int_ior", "bk7"), ext_ior = lookup_ior(b, "ext_ior", "air");
         if (int_ior < 0 || ext_ior < 0) fail("The interior and exterior indices of refraction must be positive!");
         s.bsdf = BSDF_THINDIELECTRIC; s.diel_eta = int_ior / ext_ior;
-        color_of(b, "specular_reflectance", 1.f, s.spec_refl); color_of(b, "specular_transmittance", 1.f, s.spec_trans);
+        s.tex_spec = reflectance_of(b, "specular_reflectance", 1.f, s.spec_refl); s.tex_trans = reflectance_of(b, "specular_transmittance", 1.f, s.spec_trans);
     } else if (b.plugin == "roughdielectric") {   // src/bsdfs/roughdielectric.cpp:163-238
         const float int_ior = lookup_ior(b, "int_ior", "bk7"), ext_ior = lookup_ior(b, "ext_ior", "air");
         if (int_ior < 0 || ext_ior < 0 || int_ior == ext_ior) fail("The interior and exterior indices of refraction must be positive and differ!");
         s.bsdf = BSDF_ROUGHDIELECTRIC; s.diel_eta = int_ior / ext_ior;
-        color_of(b, "specular_reflectance", 1.f, s.spec_refl); color_of(b, "specular_transmittance", 1.f, s.spec_trans);
+        s.tex_spec = reflectance_of(b, "specular_reflectance", 1.f, s.spec_refl); s.tex_trans = reflectance_of(b, "specular_transmittance", 1.f, s.spec_trans);
         std::string distr = b.props.get_string("distribution", "beckmann");
         std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
         if (distr != "beckmann" && distr != "ggx") fail("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"!");
         s.beckmann = distr != "ggx";   // MicrofacetType (microfacet.h:30-36)
         s.sample_all = !b.props.get_bool("sample_visible", true);
-        if (b.props.has("alpha_u") || b.props.has("alpha_v")) {
-            if (!b.props.has("alpha_u") || !b.props.has("alpha_v")) fail("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
-            if (b.props.has("alpha")) fail("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.");
-            s.alpha_u = (float) b.props.get_float("alpha_u", 0.1); s.alpha_v = (float) b.props.get_float("alpha_v", 0.1);
-        } else s.alpha_u = s.alpha_v = (float) b.props.get_float("alpha", 0.1);
+        roughness_of(b, s);
     } else if (b.plugin == "roughconductor") {   // src/bsdfs/roughconductor.cpp:177-227
         std::string material = b.props.get_string("material", "none");
         if (material != "none") fail(b.props.has("eta") || b.colors.count("eta") ? "Should specify either (eta, k) or material, not both."
@@ -900,18 +921,14 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         if (distr != "beckmann" && distr != "ggx") fail("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"!");
         s.beckmann = distr != "ggx";   // MicrofacetType (microfacet.h:30-36)
         s.sample_all = !b.props.get_bool("sample_visible", true);
-        if (b.props.has("alpha_u") || b.props.has("alpha_v")) {
-            if (!b.props.has("alpha_u") || !b.props.has("alpha_v")) fail("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
-            if (b.props.has("alpha")) fail("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.");
-            s.alpha_u = (float) b.props.get_float("alpha_u", 0.1); s.alpha_v = (float) b.props.get_float("alpha_v", 0.1);
-        } else s.alpha_u = s.alpha_v = (float) b.props.get_float("alpha", 0.1);
+        roughness_of(b, s);
         s.bsdf = BSDF_ROUGHCONDUCTOR;
-        color_of(b, "eta", 0.f, s.cond_eta); color_of(b, "k", 1.f, s.cond_k); color_of(b, "specular_reflectance", 1.f, s.spec_refl);
+        color_of(b, "eta", 0.f, s.cond_eta); color_of(b, "k", 1.f, s.cond_k); s.tex_spec = reflectance_of(b, "specular_reflectance", 1.f, s.spec_refl);
     } else if (b.plugin == "plastic") {   // src/bsdfs/plastic.cpp:167-217
         const float int_ior = lookup_ior(b, "int_ior", "polypropylene"), ext_ior = lookup_ior(b, "ext_ior", "air");
         if (int_ior < 0 || ext_ior < 0) fail("The interior and exterior indices of refraction must be positive!");
         s.bsdf = BSDF_PLASTIC; s.diel_eta = int_ior / ext_ior;
-        s.tex_refl = reflectance_of(b, "diffuse_reflectance", 0.5f, s.refl); color_of(b, "specular_reflectance", 1.f, s.spec_refl);
+        s.tex_refl = reflectance_of(b, "diffuse_reflectance", 0.5f, s.refl); s.tex_spec = reflectance_of(b, "specular_reflectance", 1.f, s.spec_refl);
         s.nonlinear = b.props.get_bool("nonlinear", false);
         const float eta = s.diel_eta;
         s.inv_eta_2 = 1.f / (eta * eta);
@@ -923,14 +940,14 @@ static void bsdf_of(const Obj &b, HostShape &s) {
             s.fdr_int = e < 1.f ? approx_1 : h;
         }
         // d_mean = m_diffuse_reflectance->mean(): the mean of a colour's three channels, or the texture's own mean
-        const float d_mean = s.tex_refl >= 0 ? s.refl[0] : ((s.refl[0] + s.refl[1]) + s.refl[2]) * (1.0f / 3.0f), s_mean = ((s.spec_refl[0] + s.spec_refl[1]) + s.spec_refl[2]) * (1.0f / 3.0f);
+        const float d_mean = s.tex_refl >= 0 ? s.refl[0] : ((s.refl[0] + s.refl[1]) + s.refl[2]) * (1.0f / 3.0f), s_mean = s.tex_spec >= 0 ? s.spec_refl[0] : ((s.spec_refl[0] + s.spec_refl[1]) + s.spec_refl[2]) * (1.0f / 3.0f);
         s.spec_sampling_weight = s_mean / (d_mean + s_mean);
     } else if (b.plugin == "roughplastic") {   // src/bsdfs/roughplastic.cpp:170-257
         const float int_ior = lookup_ior(b, "int_ior", "polypropylene"), ext_ior = lookup_ior(b, "ext_ior", "air");
         if (int_ior < 0 || ext_ior < 0 || int_ior == ext_ior) fail("The interior and exterior indices of refraction must be positive and differ!");
         s.bsdf = BSDF_ROUGHPLASTIC; s.diel_eta = int_ior / ext_ior;
-        s.tex_refl = reflectance_of(b, "diffuse_reflectance", 0.5f, s.refl); color_of(b, "specular_reflectance", 1.f, s.spec_refl);
-        const bool has_spec = b.props.has("specular_reflectance") || b.colors.count("specular_reflectance");
+        s.tex_refl = reflectance_of(b, "diffuse_reflectance", 0.5f, s.refl); s.tex_spec = reflectance_of(b, "specular_reflectance", 1.f, s.spec_refl);
+        const bool has_spec = b.props.has("specular_reflectance") || b.colors.count("specular_reflectance") || s.tex_spec >= 0;
         s.nonlinear = b.props.get_bool("nonlinear", false);
         std::string distr = b.props.get_string("distribution", "beckmann");
         std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
@@ -945,7 +962,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         } else s.alpha_u = s.alpha_v = (float) b.props.get_float("alpha", 0.1);
         s.inv_eta_2 = 1.f / (s.diel_eta * s.diel_eta);
         const float d_mean = s.tex_refl >= 0 ? s.refl[0] : ((s.refl[0] + s.refl[1]) + s.refl[2]) * (1.0f / 3.0f),
-                    s_mean = has_spec ? ((s.spec_refl[0] + s.spec_refl[1]) + s.spec_refl[2]) * (1.0f / 3.0f) : 1.f;
+                    s_mean = has_spec ? (s.tex_spec >= 0 ? s.spec_refl[0] : ((s.spec_refl[0] + s.spec_refl[1]) + s.spec_refl[2]) * (1.0f / 3.0f)) : 1.f;
         s.spec_sampling_weight = s_mean / (d_mean + s_mean);
         s.rough_table.resize(64);
         rough_plastic_tables(s.beckmann ? MF_BECKMANN : MF_GGX, s.alpha_u, s.diel_eta, s.rough_table.data(), &s.fdr_int);       // fdr_int carries m_internal_reflectance
@@ -955,12 +972,19 @@ static void bsdf_of(const Obj &b, HostShape &s) {
     check_colors(b, { "reflectance", "diffuse_reflectance", "specular_reflectance", "specular_transmittance", "eta", "k" });
     // texture children: the slot that takes one was read above; a texture bound to any other property (or to a misspelt name) must not be dropped
     // silently -- the reference either uses it or raises "unreferenced object" (xml.cpp:1204-1215)
-    const char *slot = b.plugin == "diffuse" ? "reflectance" : (b.plugin == "plastic" || b.plugin == "roughplastic") ? "diffuse_reflectance" : "";
+    auto takes_texture = [&](const std::string &name) {
+        if (b.plugin == "diffuse") return name == "reflectance";
+        if (name == "specular_reflectance") return true;                                                  // every other BSDF of this library has one
+        if (name == "diffuse_reflectance") return b.plugin == "plastic" || b.plugin == "roughplastic";
+        if (name == "specular_transmittance") return b.plugin == "dielectric" || b.plugin == "thindielectric" || b.plugin == "roughdielectric";
+        if (name == "alpha" || name == "alpha_u" || name == "alpha_v") return b.plugin == "roughconductor" || b.plugin == "roughdielectric";
+        return false;
+    };
     for (size_t i = 0; i < b.children.size(); ++i) {
         const Obj *c = b.children[i].second.get();
         if (!c || c->tag != "texture") continue;
         const std::string &cname = i < b.ref_names.size() && !b.ref_names[i].empty() ? b.ref_names[i] : c->name;
-        if (cname == slot) continue;
+        if (takes_texture(cname)) continue;
         static const char *known[] = { "reflectance", "diffuse_reflectance", "specular_reflectance", "specular_transmittance", "alpha", "alpha_u", "alpha_v", "eta", "k" };
         bool is_known = false;
         for (const char *k : known) is_known |= cname == k;

@@ -1,6 +1,6 @@
 """Image output for rendered frames: .npy (what the tutorials store, program_runner.py:58,79,147), PFM and
-scan-line OpenEXR (the reference's film writes OpenEXR, hdrfilm.cpp `file_format=openexr`; here uncompressed HALF or FLOAT,
-channels R,G,B -- readable by any EXR reader incl. tools/exr_piz.py)."""
+scan-line OpenEXR (the reference's film writes OpenEXR, hdrfilm.cpp `file_format=openexr`; here HALF or FLOAT, ZIP / ZIPS compressed or
+uncompressed, channels R,G,B -- readable by any EXR reader incl. tools/exr_piz.py and the library's own radiance-map reader)."""
 import struct
 
 import numpy as np
@@ -27,34 +27,53 @@ def _attr(name, typ, payload):
     return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(payload)) + payload
 
 
-def write_exr(path, img, half=True, software="dtof (mitsuba3dopplertof_amd)"):
-    """Uncompressed scan-line OpenEXR 2.0, channels B,G,R in file order (alphabetical), HALF (default) or FLOAT."""
+_EXR_COMPRESSION = {"none": (0, 1), "zips": (2, 1), "zip": (3, 16)}     # name -> (attribute value, scan lines per chunk)
+
+
+def write_exr(path, img, half=True, compression="zip", software="dtof (mitsuba3dopplertof_amd)"):
+    """Scan-line OpenEXR 2.0, channels B,G,R in file order (alphabetical), HALF (default) or FLOAT; compression "zip" (default: 16 lines per chunk,
+    what most OpenEXR writers use), "zips" (one line per chunk) or "none".  ZIP as OpenEXR defines it: the bytes of a chunk are split into
+    even and odd bytes, delta-predicted, then deflated; a chunk that does not shrink is stored raw."""
+    import zlib
     a = np.asarray(img, dtype=np.float32)
     if a.ndim != 3 or a.shape[2] != 3:
         raise ValueError("expected an (H, W, 3) image")
+    if compression not in _EXR_COMPRESSION:
+        raise ValueError('unsupported OpenEXR compression "%s" (none, zips, zip)' % compression)
+    code, lines = _EXR_COMPRESSION[compression]
     h, w, _ = a.shape
     ptype = 1 if half else 2
     chlist = b"".join(n + b"\0" + struct.pack("<iBBBBii", ptype, 0, 0, 0, 0, 1, 1) for n in (b"B", b"G", b"R")) + b"\0"
     box = struct.pack("<4i", 0, 0, w - 1, h - 1)
-    header = (_attr("channels", "chlist", chlist) + _attr("compression", "compression", b"\0") +
+    header = (_attr("channels", "chlist", chlist) + _attr("compression", "compression", bytes([code])) +
               _attr("dataWindow", "box2i", box) + _attr("displayWindow", "box2i", box) +
               _attr("lineOrder", "lineOrder", b"\0") + _attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) +
               _attr("screenWindowCenter", "v2f", struct.pack("<2f", 0.0, 0.0)) +
               _attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) +
               _attr("generatedBy", "string", software.encode()) + b"\0")
     dt = "<f2" if half else "<f4"
-    bpp = 2 if half else 4
-    line_bytes = 3 * w * bpp
+    chunks = []
+    for y0 in range(0, h, lines):
+        raw = b"".join(a[y, :, c].astype(dt).tobytes() for y in range(y0, min(y0 + lines, h)) for c in (2, 1, 0))   # per line: B, G, R
+        payload = raw
+        if code:
+            b = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([b[0::2], b[1::2]]).astype(np.int32)             # even bytes, then odd bytes
+            d = t.copy(); d[1:] = (t[1:] - t[:-1] + 128 + 256) & 255              # predictor
+            z = zlib.compress(d.astype(np.uint8).tobytes(), 6)
+            if len(z) < len(raw):
+                payload = z
+        chunks.append((y0, payload))
     head = struct.pack("<II", 20000630, 2) + header
-    table_pos = len(head)
-    first = table_pos + 8 * h
+    pos = len(head) + 8 * len(chunks)
+    offsets = []
+    for _y0, payload in chunks:
+        offsets.append(pos); pos += 8 + len(payload)
     with open(path, "wb") as f:
         f.write(head)
-        f.write(struct.pack("<%dQ" % h, *[first + y * (8 + line_bytes) for y in range(h)]))
-        for y in range(h):
-            f.write(struct.pack("<ii", y, line_bytes))
-            for c in (2, 1, 0):                                  # B, G, R
-                f.write(a[y, :, c].astype(dt).tobytes())
+        f.write(struct.pack("<%dQ" % len(chunks), *offsets))
+        for y0, payload in chunks:
+            f.write(struct.pack("<ii", y0, len(payload)) + payload)
 
 
 def write_image(path, img):

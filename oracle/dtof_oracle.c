@@ -1383,7 +1383,7 @@ static float lerp_gather64(const float *data, float x) {
     return fmaf(v1, t, fmaf(-v0, t, v0));   /* dr::lerp */
 }
 /* RoughPlastic::eval (:333-371) and pdf (:385-421), both cosines positive */
-static void rough_plastic_eval_pdf(ggx_t g, const orc_shape *sh, const float *refl, v3 wi, v3 wo, float t_i, float prob_specular, float prob_diffuse,
+static void rough_plastic_eval_pdf(ggx_t g, const orc_shape *sh, const float *refl, const float *spec_refl, v3 wi, v3 wo, float t_i, float prob_specular, float prob_diffuse,
                                    v3 *value, float *pdf) {
     v3 H = v_normalize(v_add(wo, wi));
     float D = ggx_eval(g, H), F, t1, t2, t3;
@@ -1396,13 +1396,13 @@ static void rough_plastic_eval_pdf(ggx_t g, const orc_shape *sh, const float *re
     diff = sh->nonlinear ? V(diff.x / (1.f - diff.x * ir), diff.y / (1.f - diff.y * ir), diff.z / (1.f - diff.z * ir))
                          : V(diff.x / (1.f - ir), diff.y / (1.f - ir), diff.z / (1.f - ir));
     float k = ORC_INV_PI_F * sh->inv_eta_2 * wo.z * t_i * t_o;
-    *value = V(spec * sh->spec_refl[0] + diff.x * k, spec * sh->spec_refl[1] + diff.y * k, spec * sh->spec_refl[2] + diff.z * k);
+    *value = V(spec * spec_refl[0] + diff.x * k, spec * spec_refl[1] + diff.y * k, spec * spec_refl[2] + diff.z * k);
     float result = g.visible ? D * ggx_smith_g1(g, wi, H) / (4.f * wi.z) : ggx_pdf(g, wi, H) / (4.f * v_dot(wo, H));   /* roughplastic.cpp:467-470 */
     result *= prob_specular;
     *pdf = result + prob_diffuse * (ORC_INV_PI_F * wo.z);
 }
 /* RoughDielectric::eval_pdf (roughdielectric.cpp:503-611), TransportMode::Radiance */
-static void rough_dielectric_eval_pdf(ggx_t g, const orc_shape *sh, v3 wi, v3 wo, v3 *value, float *pdf) {
+static void rough_dielectric_eval_pdf(ggx_t g, const orc_shape *sh, const float *spec_refl, const float *spec_trans, v3 wi, v3 wo, v3 *value, float *pdf) {
     float cti = wi.z, cto = wo.z, m_eta = sh->diel_eta, m_inv_eta = f_rcp(m_eta);
     int reflect = cti * cto > 0.f;
     float eta = cti > 0.f ? m_eta : m_inv_eta, inv_eta = cti > 0.f ? m_inv_eta : m_eta;
@@ -1417,11 +1417,11 @@ static void rough_dielectric_eval_pdf(ggx_t g, const orc_shape *sh, v3 wi, v3 wo
     if (!active) return;
     if (reflect) {
         float v = F * D * G / (4.f * fabsf(cti));
-        *value = V(v * sh->spec_refl[0], v * sh->spec_refl[1], v * sh->spec_refl[2]);
+        *value = V(v * spec_refl[0], v * spec_refl[1], v * spec_refl[2]);
     } else {
         float scale = f_sqr(inv_eta);
         float v = fabsf((scale * (1.f - F) * D * G * eta * eta * dwm * dom) / (cti * f_sqr(dwm + eta * dom)));
-        *value = V(v * sh->spec_trans[0], v * sh->spec_trans[1], v * sh->spec_trans[2]);
+        *value = V(v * spec_trans[0], v * spec_trans[1], v * spec_trans[2]);
     }
     ggx_t gs = g;   /* sample_distr: Walter et al.'s roughness scaling when all normals are sampled (roughdielectric.cpp:584-589) */
     if (!g.visible) { const float sc = 1.2f - .2f * sqrtf(fabsf(cti)); gs.au *= sc; gs.av *= sc; }
@@ -1470,12 +1470,40 @@ void orc_texture_eval(const orc_texture *tex, float u, float v, float *out3) {
     if (C == 1) texel[1] = texel[2] = texel[0];
     out3[0] = texel[0]; out3[1] = texel[1]; out3[2] = texel[2];
 }
+/* Texture::eval_1 (bitmap.cpp:324-344: one channel as it is, three channels -> luminance (spectrum.h:431-434); checkerboard.cpp:91-110 with
+ * constant colours: SRGBReflectanceSpectrum::eval_1 = mean of the colour, srgb.cpp:85-88) */
+float orc_texture_eval_1(const orc_texture *tex, float u, float v) {
+    float c[3];
+    if (tex->kind == 0) {   /* checkerboard: the colour the lookup picks, reduced to its mean */
+        float c0[3] = { tex->color0[0], tex->color0[1], tex->color0[2] };
+        orc_texture_eval(tex, u, v, c);
+        const int first = c[0] == c0[0] && c[1] == c0[1] && c[2] == c0[2];
+        const float *k = first ? tex->color0 : tex->color1;
+        return ((k[0] + k[1]) + k[2]) * (1.0f / 3.0f);
+    }
+    orc_texture_eval(tex, u, v, c);
+    if (tex->channels == 1) return c[0];
+    return c[0] * 0.212671f + c[1] * 0.715160f + c[2] * 0.072169f;
+}
+/* the material parameters of one hit: the shape's constants, or the lookups of the textures bound to their slots */
+typedef struct { float spec_refl[3], spec_trans[3], alpha_u, alpha_v; } orc_mat;
+static orc_mat material_at(const orc_shape *sh, float u, float v) {
+    orc_mat m;
+    for (int i = 0; i < 3; ++i) { m.spec_refl[i] = sh->spec_refl[i]; m.spec_trans[i] = sh->spec_trans[i]; }
+    m.alpha_u = sh->alpha_u; m.alpha_v = sh->alpha_v;
+    if (sh->tex_spec) orc_texture_eval(sh->tex_spec, u, v, m.spec_refl);
+    if (sh->tex_trans) orc_texture_eval(sh->tex_trans, u, v, m.spec_trans);
+    if (sh->tex_alpha_u) m.alpha_u = orc_texture_eval_1(sh->tex_alpha_u, u, v);
+    if (sh->tex_alpha_v) m.alpha_v = orc_texture_eval_1(sh->tex_alpha_v, u, v);
+    return m;
+}
 /* One BSDF interaction of the bounce loop: value and density for the emitter direction `wo` (only when `active_em`), and the
  * sampled continuation (BSDF::eval_pdf_sample, src/render/bsdf.cpp:20-29).  wi_in / wo / bs_wo are in the local shading frame. */
 typedef struct { v3 val; float pdf; v3 weight; v3 wo; float bs_pdf, bs_eta; int bs_delta; } orc_bsdf_out;
 static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
     float refl[3] = { sh->reflectance[0], sh->reflectance[1], sh->reflectance[2] };   /* m_reflectance->eval(si) */
     if (sh->tex_refl) orc_texture_eval(sh->tex_refl, uv_u, uv_v, refl);
+    const orc_mat m_ = material_at(sh, uv_u, uv_v);   /* m_specular_reflectance->eval(si), m_alpha_u->eval_1(si), ... */
     /* BSDF::eval_pdf_sample src/render/bsdf.cpp:20-29 over twosided{diffuse} / diffuse
      * (src/bsdfs/twosided.cpp:111-148,219-258; src/bsdfs/diffuse.cpp:101-125,160-180) */
     v3 bsdf_val = V(0, 0, 0), bsdf_weight = V(0, 0, 0), bs_wo = V(0, 0, 0);
@@ -1487,9 +1515,9 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
         if (cos_theta_i > 0.f) {
             bs_wo = V(-wi_in.x, -wi_in.y, wi_in.z);   /* reflect(wi); the two-sided flip of wi.z and of wo.z cancel */
             bs_eta = 1.f; bs_pdf = 1.f; bs_delta = 1;
-            bsdf_weight = V(sh->spec_refl[0] * fresnel_conductor(cos_theta_i, sh->cond_eta[0], sh->cond_k[0]),
-                            sh->spec_refl[1] * fresnel_conductor(cos_theta_i, sh->cond_eta[1], sh->cond_k[1]),
-                            sh->spec_refl[2] * fresnel_conductor(cos_theta_i, sh->cond_eta[2], sh->cond_k[2]));
+            bsdf_weight = V(m_.spec_refl[0] * fresnel_conductor(cos_theta_i, sh->cond_eta[0], sh->cond_k[0]),
+                            m_.spec_refl[1] * fresnel_conductor(cos_theta_i, sh->cond_eta[1], sh->cond_k[1]),
+                            m_.spec_refl[2] * fresnel_conductor(cos_theta_i, sh->cond_eta[2], sh->cond_k[2]));
         }
     } else if (sh->bsdf == ORC_BSDF_DIELECTRIC) {
         /* SmoothDielectric::sample (dielectric.cpp:231-338), TransportMode::Radiance */
@@ -1500,8 +1528,8 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
         bs_pdf = selected_r ? r_i : t_i; bs_delta = 1;
         bs_wo = selected_r ? V(-wi_in.x, -wi_in.y, wi_in.z) : V(-eta_ti * wi_in.x, -eta_ti * wi_in.y, cos_theta_t);
         bs_eta = selected_r ? 1.f : eta_it;
-        if (selected_r) bsdf_weight = V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]);
-        else { float f2 = f_sqr(eta_ti); bsdf_weight = V(sh->spec_trans[0] * f2, sh->spec_trans[1] * f2, sh->spec_trans[2] * f2); }
+        if (selected_r) bsdf_weight = V(m_.spec_refl[0], m_.spec_refl[1], m_.spec_refl[2]);
+        else { float f2 = f_sqr(eta_ti); bsdf_weight = V(m_.spec_trans[0] * f2, m_.spec_trans[1] * f2, m_.spec_trans[2] * f2); }
     } else if (sh->bsdf == ORC_BSDF_THINDIELECTRIC) {
         /* ThinDielectric::sample (thindielectric.cpp:173-226); eval / pdf are zero (:228-236) */
         float r, t1, t2, t3;
@@ -1510,12 +1538,12 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
         int selected_r = sample_1 <= r;
         bs_pdf = selected_r ? r : 1.f - r; bs_delta = 1; bs_eta = 1.f;
         bs_wo = selected_r ? V(-wi_in.x, -wi_in.y, wi_in.z) : V(-wi_in.x, -wi_in.y, -wi_in.z);
-        bsdf_weight = selected_r ? V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]) : V(sh->spec_trans[0], sh->spec_trans[1], sh->spec_trans[2]);
+        bsdf_weight = selected_r ? V(m_.spec_refl[0], m_.spec_refl[1], m_.spec_refl[2]) : V(m_.spec_trans[0], m_.spec_trans[1], m_.spec_trans[2]);
     } else if (sh->bsdf == ORC_BSDF_ROUGHDIELECTRIC) {
         /* RoughDielectric::sample (roughdielectric.cpp:240-346); eval_pdf above for the emitter sample */
-        ggx_t g = mf_make(sh->mf_type, sh->alpha_u, sh->alpha_v, !sh->sample_all);
+        ggx_t g = mf_make(sh->mf_type, m_.alpha_u, m_.alpha_v, !sh->sample_all);
         v3 wi = wi_in;
-        if (active_em) rough_dielectric_eval_pdf(g, sh, wi, wo, &bsdf_val, &bsdf_pdf);
+        if (active_em) rough_dielectric_eval_pdf(g, sh, m_.spec_refl, m_.spec_trans, wi, wo, &bsdf_val, &bsdf_pdf);
         if (wi.z != 0.f) {
             float mpdf;
             ggx_t gs = g;   /* sample_distr (:266-269) */
@@ -1529,13 +1557,13 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
             float dwh_dwo; v3 w;
             if (selected_r) {
                 bs_wo = V(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));
-                w = V(sh->spec_refl[0], sh->spec_refl[1], sh->spec_refl[2]);
+                w = V(m_.spec_refl[0], m_.spec_refl[1], m_.spec_refl[2]);
                 dwh_dwo = f_rcp(4.f * v_dot(bs_wo, m));
             } else {
                 float k = fmaf(dwm, eta_ti, cos_theta_t);
                 bs_wo = V(fmaf(m.x, k, -(wi.x * eta_ti)), fmaf(m.y, k, -(wi.y * eta_ti)), fmaf(m.z, k, -(wi.z * eta_ti)));
                 float f2 = f_sqr(eta_ti);
-                w = V(f2 * sh->spec_trans[0], f2 * sh->spec_trans[1], f2 * sh->spec_trans[2]);
+                w = V(f2 * m_.spec_trans[0], f2 * m_.spec_trans[1], f2 * m_.spec_trans[2]);
                 float dom = v_dot(bs_wo, m);
                 dwh_dwo = (f_sqr(bs_eta) * dom) / f_sqr(dwm + bs_eta * dom);
             }
@@ -1549,16 +1577,16 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
         /* RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF */
         v3 wi = wi_in, wo_l = wo;
         if (sh->twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }   /* twosided.cpp:219-258 flips both */
-        ggx_t g = mf_make(sh->mf_type, sh->alpha_u, sh->alpha_v, !sh->sample_all);
+        ggx_t g = mf_make(sh->mf_type, m_.alpha_u, m_.alpha_v, !sh->sample_all);
         if (wi.z > 0.f && wo_l.z > 0.f) {
             v3 H = v_normalize(v_add(wo_l, wi));
             float D = ggx_eval(g, H);
             if (D != 0.f) {   /* eval :317-375 */
                 float G = ggx_smith_g1(g, wi, H) * ggx_smith_g1(g, wo_l, H);
                 float result = D * G / (4.f * wi.z), c = v_dot(wi, H);
-                bsdf_val = V(fresnel_conductor(c, sh->cond_eta[0], sh->cond_k[0]) * (result * sh->spec_refl[0]),
-                             fresnel_conductor(c, sh->cond_eta[1], sh->cond_k[1]) * (result * sh->spec_refl[1]),
-                             fresnel_conductor(c, sh->cond_eta[2], sh->cond_k[2]) * (result * sh->spec_refl[2]));
+                bsdf_val = V(fresnel_conductor(c, sh->cond_eta[0], sh->cond_k[0]) * (result * m_.spec_refl[0]),
+                             fresnel_conductor(c, sh->cond_eta[1], sh->cond_k[1]) * (result * m_.spec_refl[1]),
+                             fresnel_conductor(c, sh->cond_eta[2], sh->cond_k[2]) * (result * m_.spec_refl[2]));
             }
             if (v_dot(wi, H) > 0.f && v_dot(wo_l, H) > 0.f)   /* pdf :377-415 */
                 bsdf_pdf = g.visible ? ggx_eval(g, H) * ggx_smith_g1(g, wi, H) / (4.f * wi.z) : ggx_pdf(g, wi, H) / (4.f * v_dot(wo_l, H));   /* :405-409 */
@@ -1572,22 +1600,22 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
             int ok = mpdf != 0.f && r.z > 0.f;
             float weight = g.visible ? ggx_smith_g1(g, r, m) : ggx_smith_g1(g, wi, m) * ggx_smith_g1(g, r, m) * dwm / (wi.z * m.z);   /* :260-265 */
             bs_pdf = mpdf / (4.f * v_dot(r, m));
-            if (ok) bsdf_weight = V(fresnel_conductor(dwm, sh->cond_eta[0], sh->cond_k[0]) * (weight * sh->spec_refl[0]),
-                                    fresnel_conductor(dwm, sh->cond_eta[1], sh->cond_k[1]) * (weight * sh->spec_refl[1]),
-                                    fresnel_conductor(dwm, sh->cond_eta[2], sh->cond_k[2]) * (weight * sh->spec_refl[2]));
+            if (ok) bsdf_weight = V(fresnel_conductor(dwm, sh->cond_eta[0], sh->cond_k[0]) * (weight * m_.spec_refl[0]),
+                                    fresnel_conductor(dwm, sh->cond_eta[1], sh->cond_k[1]) * (weight * m_.spec_refl[1]),
+                                    fresnel_conductor(dwm, sh->cond_eta[2], sh->cond_k[2]) * (weight * m_.spec_refl[2]));
             if (sh->twosided && wi_in.z < 0.f) bs_wo.z = -bs_wo.z;
         }
     } else if (sh->bsdf == ORC_BSDF_ROUGHPLASTIC) {
         /* RoughPlastic::sample (roughplastic.cpp:259-331) under TwoSidedBRDF; eval / pdf in rough_plastic_eval_pdf */
         v3 wi = wi_in, wo_l = wo;
         if (sh->twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
-        ggx_t g = mf_make(sh->mf_type, sh->alpha_u, sh->alpha_u, !sh->sample_all);
+        ggx_t g = mf_make(sh->mf_type, m_.alpha_u, m_.alpha_u, !sh->sample_all);
         if (wi.z > 0.f) {
             float t_i = lerp_gather64(sh->rough_table, wi.z);
             float prob_specular = (1.f - t_i) * sh->spec_sampling_weight, prob_diffuse = t_i * (1.f - sh->spec_sampling_weight);
             prob_specular = prob_specular / (prob_specular + prob_diffuse);
             prob_diffuse = 1.f - prob_specular;
-            if (wo_l.z > 0.f) rough_plastic_eval_pdf(g, sh, refl, wi, wo_l, t_i, prob_specular, prob_diffuse, &bsdf_val, &bsdf_pdf);
+            if (wo_l.z > 0.f) rough_plastic_eval_pdf(g, sh, refl, m_.spec_refl, wi, wo_l, t_i, prob_specular, prob_diffuse, &bsdf_val, &bsdf_pdf);
             if (sample_1 < prob_specular) {
                 float mpdf; v3 m = ggx_sample(g, wi, s2x, s2y, &mpdf);
                 float dwm = v_dot(wi, m);
@@ -1595,7 +1623,7 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
             } else bs_wo = square_to_cosine_hemisphere(s2x, s2y);
             bs_eta = 1.f;
             v3 value = V(0, 0, 0);
-            if (bs_wo.z > 0.f) rough_plastic_eval_pdf(g, sh, refl, wi, bs_wo, t_i, prob_specular, prob_diffuse, &value, &bs_pdf);
+            if (bs_wo.z > 0.f) rough_plastic_eval_pdf(g, sh, refl, m_.spec_refl, wi, bs_wo, t_i, prob_specular, prob_diffuse, &value, &bs_pdf);
             if (bs_pdf > 0.f) bsdf_weight = v_mul(value, f_rcp(bs_pdf));   /* Spectrum / Float: times the reciprocal */
             if (sh->twosided && wi_in.z < 0.f) bs_wo.z = -bs_wo.z;
         }
@@ -1626,7 +1654,7 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
                 bs_wo = V(-wi_in.x, -wi_in.y, wiz);   /* reflect() of the (possibly flipped) wi */
                 bs_pdf = prob_specular; bs_delta = 1;
                 float value = f_i / bs_pdf;
-                bsdf_weight = V(value * sh->spec_refl[0], value * sh->spec_refl[1], value * sh->spec_refl[2]);
+                bsdf_weight = V(value * m_.spec_refl[0], value * m_.spec_refl[1], value * m_.spec_refl[2]);
             } else {
                 bs_wo = square_to_cosine_hemisphere(s2x, s2y);
                 bs_pdf = prob_diffuse * (ORC_INV_PI_F * bs_wo.z);

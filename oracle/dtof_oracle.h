@@ -91,6 +91,9 @@ typedef struct {
     const orc_texture *tex_refl;   /* texture on `reflectance` / `diffuse_reflectance` (NULL: the constant colour above) */
     int32_t mf_type;         /* microfacet distribution of the rough BSDFs: 0 beckmann, 1 ggx (microfacet.h MicrofacetType) */
     int32_t sample_all;      /* rough BSDFs: sample_visible = false (sample all normals, Walter et al.'s roughness scaling; microfacet.h:240-290) */
+    /* textures on the other slots (NULL: the constants above): specular_reflectance / specular_transmittance (Texture::eval) and the
+     * roughness alpha / alpha_u / alpha_v of roughconductor / roughdielectric (Texture::eval_1) */
+    const orc_texture *tex_spec, *tex_trans, *tex_alpha_u, *tex_alpha_v;
 } orc_shape;
 
 typedef struct {
@@ -313,6 +316,7 @@ void     orc_kat_frame(const float *n, float *out6);
 int      orc_kat_ray_intersect(const orc_scene *sc, const float *o, const float *d, float time, float maxt, float *out25, int32_t *ids);
 void     orc_kat_bsdf(const orc_shape *sh, const float *wi, const float *wo, const float *s3, float *out13);
 void     orc_texture_eval(const orc_texture *tex, float u, float v, float *out3);
+float    orc_texture_eval_1(const orc_texture *tex, float u, float v);   /* Texture::eval_1: a 1-channel texel, the luminance of an RGB texel, the mean of a checkerboard colour */
 void     orc_kat_sphere_sample_direction(const orc_shape *sh, const float *ref, float s_x, float s_y, float *out11);
 float    orc_kat_shape_area(const orc_shape *sh);
 /* Emitter::sample_direction of emitter `emitter_index` for the reference point `ref` and a 2-D sample: out = d[3], dist, pdf, delta, weight[3], p[3], usable */

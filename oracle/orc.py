@@ -34,7 +34,8 @@ class OrcShape(C.Structure):
                 ("bsdf", C.c_int32), ("cond_eta", C.c_float * 3), ("cond_k", C.c_float * 3), ("spec_refl", C.c_float * 3),
                 ("spec_trans", C.c_float * 3), ("diel_eta", C.c_float), ("nonlinear", C.c_int32),
                 ("inv_eta_2", C.c_float), ("fdr_int", C.c_float), ("spec_sampling_weight", C.c_float),
-                ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("rough_table", C.POINTER(C.c_float)), ("tex_refl", C.POINTER(OrcTexture)), ("mf_type", C.c_int32), ("sample_all", C.c_int32)]
+                ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("rough_table", C.POINTER(C.c_float)), ("tex_refl", C.POINTER(OrcTexture)), ("mf_type", C.c_int32), ("sample_all", C.c_int32),
+                ("tex_spec", C.POINTER(OrcTexture)), ("tex_trans", C.POINTER(OrcTexture)), ("tex_alpha_u", C.POINTER(OrcTexture)), ("tex_alpha_v", C.POINTER(OrcTexture))]
 
 
 class OrcGroup(C.Structure):
@@ -241,8 +242,7 @@ class Scene:
             o.alpha_u, o.alpha_v = float(s.get("alpha_u", 0.1)), float(s.get("alpha_v", 0.1))
             o.mf_type = int(s.get("mf_type", 1))
             o.sample_all = int(s.get("sample_all", 0))
-            tex = s.get("tex_refl")
-            if tex is not None:   # texture on the (diffuse) reflectance
+            def make_texture(tex):
                 t = OrcTexture()
                 t.kind, t.filter, t.wrap, t.channels, t.width, t.height = tex["kind"], tex["filter"], tex["wrap"], tex["channels"], tex["width"], tex["height"]
                 t.to_uv = (C.c_float * 4)(*tex["to_uv"].tolist())
@@ -250,16 +250,24 @@ class Scene:
                 if tex["data"] is not None:
                     t.data = tex["data"].ctypes.data_as(C.POINTER(C.c_float))
                 self._keep += [t, tex["data"]]
-                o.tex_refl = C.pointer(t)
+                return C.pointer(t)
+            tex = s.get("tex_refl")
+            if tex is not None:   # texture on the (diffuse) reflectance
+                o.tex_refl = make_texture(tex)
+            for key in ("tex_spec", "tex_trans", "tex_alpha_u", "tex_alpha_v"):   # textures on the specular colours and on the roughness
+                if s.get(key) is not None:
+                    setattr(o, key, make_texture(s[key]))
             if o.bsdf == 3:   # plastic: SmoothPlastic::parameters_changed in C float32
                 o.nonlinear = int(s.get("nonlinear", 0))
                 out3 = (C.c_float * 3)()
                 L.orc_plastic_params(C.c_float(o.diel_eta), o.reflectance, o.spec_refl, out3)
                 o.inv_eta_2, o.fdr_int, o.spec_sampling_weight = out3[0], out3[1], out3[2]
-                if tex is not None:   # d_mean = m_diffuse_reflectance->mean() is the texture's own mean (plastic.cpp:201-217)
-                    sp = np.asarray(s["spec_refl"], np.float32)
-                    s_mean = ((sp[0] + sp[1]) + sp[2]) * np.float32(1.0 / 3.0)
-                    o.spec_sampling_weight = float(s_mean / (np.float32(tex["mean"]) + s_mean))
+                if tex is not None or s.get("spec_refl_mean") is not None:   # Texture::mean() of a textured slot is the texture's own mean (plastic.cpp:201-217)
+                    sp, d = np.asarray(s["spec_refl"], np.float32), np.asarray(s["reflectance"], np.float32)
+                    third = np.float32(1.0 / 3.0)
+                    s_mean = ((sp[0] + sp[1]) + sp[2]) * third if s.get("spec_refl_mean") is None else np.float32(s["spec_refl_mean"])
+                    d_mean = ((d[0] + d[1]) + d[2]) * third if tex is None else np.float32(tex["mean"])
+                    o.spec_sampling_weight = float(s_mean / (d_mean + s_mean))
                 s["plastic_params"] = np.array([o.inv_eta_2, o.fdr_int, o.spec_sampling_weight], np.float32)
             if o.bsdf == 5:   # roughplastic: RoughPlastic::parameters_changed in C float32 (cached per (alpha, eta))
                 o.nonlinear = int(s.get("nonlinear", 0))
@@ -271,7 +279,7 @@ class Scene:
                 d, sp = np.asarray(s["reflectance"], np.float32), np.asarray(s["spec_refl"], np.float32)
                 third = np.float32(1.0 / 3.0)
                 d_mean = ((d[0] + d[1]) + d[2]) * third if tex is None else np.float32(tex["mean"])
-                s_mean = ((sp[0] + sp[1]) + sp[2]) * third if s.get("has_spec_refl") else np.float32(1.0)
+                s_mean = (((sp[0] + sp[1]) + sp[2]) * third if s.get("spec_refl_mean") is None else np.float32(s["spec_refl_mean"])) if s.get("has_spec_refl") else np.float32(1.0)
                 o.fdr_int, o.spec_sampling_weight = float(ir), float(s_mean / (d_mean + s_mean))
                 s["rough_table"], s["plastic_params"] = table, np.array([o.inv_eta_2, o.fdr_int, o.spec_sampling_weight], np.float32)
             o.radiance = (C.c_float * 3)(*np.asarray(s.get("radiance", [0, 0, 0]), np.float32).tolist())

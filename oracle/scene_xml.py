@@ -937,7 +937,43 @@ def _bsdf_of(props, registry, base_dir=""):
     else:
         raise ValueError('unsupported BSDF plugin "%s"' % props.plugin)
     props.check_unreferenced("bsdf", ("reflectance", "diffuse_reflectance", "specular_reflectance", "specular_transmittance", "eta", "k"))
+    # textures on the specular colours (Texture::eval per hit; the constants become the texture's mean, which is what the plastics' sampling weight uses,
+    # plastic.cpp:201-217, roughplastic.cpp:243-257) and on the roughness of roughconductor / roughdielectric (Texture::eval_1 per hit)
+    slots = {"specular_reflectance": ("tex_spec", "spec_refl", (1, 2, 3, 4, 5, 6, 7)), "specular_transmittance": ("tex_trans", "spec_trans", (2, 6, 7))}
+    for name, (key, const, kinds) in slots.items():
+        tex = _slot_texture(props, name, registry, base_dir)
+        if tex is not None:
+            if rec["bsdf"] not in kinds:
+                raise ValueError('property "%s" of plugin "%s" does not accept a texture' % (name, props.plugin))
+            rec[key] = tex; rec[const] = np.asarray([tex["mean"]] * 3, F32); rec[const + "_mean"] = F32(tex["mean"])
+            if name == "specular_reflectance":
+                rec["has_spec_refl"] = 1
+    if rec["bsdf"] in (4, 7):
+        both = _slot_texture(props, "alpha", registry, base_dir)
+        tu, tv = _slot_texture(props, "alpha_u", registry, base_dir), _slot_texture(props, "alpha_v", registry, base_dir)
+        if both is not None and (tu is not None or tv is not None or "alpha_u" in props or "alpha_v" in props):
+            raise ValueError("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.")
+        if (tu is None) != (tv is None) and not ("alpha_u" in props or "alpha_v" in props):
+            raise ValueError("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.")
+        if both is not None:
+            tu = tv = both
+        if tu is not None:
+            rec["tex_alpha_u"] = tu; rec["alpha_u"] = F32(tu["mean"])
+        if tv is not None:
+            rec["tex_alpha_v"] = tv; rec["alpha_v"] = F32(tv["mean"])
     return rec
+
+
+def _slot_texture(props, name, registry, base_dir):
+    for tag, child, cname in props.children:
+        if cname != name:
+            continue
+        if tag == "ref":
+            tag, child = registry[child]
+        if tag != "texture":
+            raise ValueError('property "%s" must be a colour or a texture' % name)
+        return _texture_of(child, base_dir)
+    return None
 
 
 class FlatScene:
@@ -1020,7 +1056,9 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
                 sphere=sphere, bsdf=brec["bsdf"], cond_eta=brec["cond_eta"], cond_k=brec["cond_k"], spec_refl=brec["spec_refl"],
                 spec_trans=brec["spec_trans"], diel_eta=brec["diel_eta"], nonlinear=brec.get("nonlinear", 0),
                 alpha_u=brec.get("alpha_u", F32(0.1)), alpha_v=brec.get("alpha_v", F32(0.1)), has_spec_refl=brec.get("has_spec_refl", 0),
-                mf_type=brec.get("mf_type", 1), sample_all=brec.get("sample_all", 0), tex_refl=brec.get("tex_refl"))
+                mf_type=brec.get("mf_type", 1), sample_all=brec.get("sample_all", 0), tex_refl=brec.get("tex_refl"),
+                tex_spec=brec.get("tex_spec"), tex_trans=brec.get("tex_trans"), tex_alpha_u=brec.get("tex_alpha_u"), tex_alpha_v=brec.get("tex_alpha_v"),
+                spec_refl_mean=brec.get("spec_refl_mean"))
 
 
 def load(source, params=None, is_string=False):

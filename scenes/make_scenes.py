@@ -361,6 +361,39 @@ def cornell_textured(res=128, spp=16):
     return s + LIGHT + "</scene>\n"
 
 
+def cornell_textured_specular(res=128, spp=16):
+    """cornell_boxes.xml with textures on the OTHER slots (SURVEY 8(f)-3 leftovers): a roughconductor back wall whose roughness `alpha` is a gray bitmap
+    (Texture::eval_1) and whose `specular_reflectance` is a checkerboard; a smooth-plastic short box with an RGB bitmap on `specular_reflectance`
+    (the sampling weight then uses the texture's mean) beside a checkerboard `diffuse_reflectance`; a roughdielectric tall box with a bitmap on
+    `specular_transmittance`, a checkerboard on `alpha_u` and an RGB bitmap on `alpha_v` (luminance); a conductor floor with a textured
+    `specular_reflectance`"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        if b[0] not in ("FloorBSDF", "BackWallBSDF", "ShortBoxBSDF", "TallBoxBSDF"):
+            s += bsdf(*b)
+    gray = ('\t\t\t<texture type="bitmap" name="%s">\n\t\t\t\t<string name="filename" value="tex_gray.png" />\n\t\t\t\t<boolean name="raw" value="true" />\n'
+            '\t\t\t\t<transform name="to_uv">\n\t\t\t\t\t<scale x="%s" y="%s" />\n\t\t\t\t</transform>\n\t\t\t</texture>\n')
+    rgbt = ('\t\t\t<texture type="bitmap" name="%s">\n\t\t\t\t<string name="filename" value="$texfile" />\n%s'
+            '\t\t\t\t<transform name="to_uv">\n\t\t\t\t\t<scale x="%s" y="%s" />\n\t\t\t\t</transform>\n\t\t\t</texture>\n')
+    check = ('\t\t\t<texture type="checkerboard" name="%s">\n\t\t\t\t<rgb name="color0" value="%s" />\n\t\t\t\t<rgb name="color1" value="%s" />\n'
+             '\t\t\t\t<transform name="to_uv">\n\t\t\t\t\t<scale x="%s" y="%s" />\n\t\t\t\t</transform>\n\t\t\t</texture>\n')
+    s += ('\t<bsdf type="twosided" id="BackWallBSDF">\n\t\t<bsdf type="roughconductor">\n\t\t\t<string name="distribution" value="$distribution" />\n'
+          '\t\t\t<rgb name="eta" value="0.2, 0.92, 1.1" />\n\t\t\t<rgb name="k" value="3.9, 2.45, 2.14" />\n'
+          + gray % ("alpha", "1.3", "1.1") + check % ("specular_reflectance", "0.9, 0.85, 0.6", "0.3, 0.5, 0.9", "3", "2") + '\t\t</bsdf>\n\t</bsdf>\n')
+    s += ('\t<bsdf type="twosided" id="FloorBSDF">\n\t\t<bsdf type="conductor">\n\t\t\t<rgb name="eta" value="0.2, 0.92, 1.1" />\n\t\t\t<rgb name="k" value="3.9, 2.45, 2.14" />\n'
+          + rgbt % ("specular_reflectance", "", "2", "2") + '\t\t</bsdf>\n\t</bsdf>\n')
+    s += ('\t<bsdf type="twosided" id="ShortBoxBSDF">\n\t\t<bsdf type="plastic">\n\t\t\t<float name="int_ior" value="1.7" />\n'
+          + rgbt % ("specular_reflectance", '\t\t\t\t<string name="wrap_mode" value="mirror" />\n', "1.5", "1.5")
+          + check % ("diffuse_reflectance", "0.1, 0.27, 0.36", "0.6, 0.5, 0.1", "3", "3") + '\t\t</bsdf>\n\t</bsdf>\n')
+    s += ('\t<bsdf type="roughdielectric" id="TallBoxBSDF">\n\t\t<string name="distribution" value="$distribution" />\n\t\t<float name="int_ior" value="1.5" />\n'
+          + rgbt % ("specular_transmittance", "", "1", "2")
+          + check % ("alpha_u", "0.05, 0.05, 0.05", "0.3, 0.4, 0.2", "2", "4") + rgbt % ("alpha_v", '\t\t\t\t<string name="filter_type" value="nearest" />\n', "0.5", "0.5") + '\t</bsdf>\n')
+    for name, m, b in WALLS:
+        s += rect(name, m, b)
+    s += cube("ShortBox", SHORT, "ShortBoxBSDF", "0.015") + cube("TallBox", TALL, "TallBoxBSDF", "-0.015")
+    return s + LIGHT + "</scene>\n"
+
+
 def cornell_env(res=128, spp=16):
     """the Cornell room without ceiling and back wall, under a `constant` environment emitter (src/emitters/constant.cpp) beside the
     point light: rays leave the scene (environment term with MIS, valid_ray) and the environment is sampled as an emitter"""
@@ -569,6 +602,7 @@ def main():
         "cornell_spot.xml": cornell_spot(),
         "cornell_disk.xml": cornell_disk(),
         "cornell_textured.xml": cornell_textured(),
+        "cornell_textured_specular.xml": cornell_textured_specular(),
         "cornell_env.xml": cornell_env(),
         "cornell_envmap.xml": cornell_envmap(),
         "cornell_sun.xml": cornell_sun(),
@@ -589,7 +623,7 @@ def main():
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
     names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml",
-             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_thinlens.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
+             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_textured_specular.xml", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_thinlens.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
         return

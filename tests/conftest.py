@@ -85,6 +85,8 @@ CONFIGS = [
     ("frosted_glass_beckmann", "cornell_frosted.xml", dict(resx=24, resy=24, max_depth=6, distribution="beckmann"), 8),
     # checkerboard / bitmap textures on the diffuse reflectances (rectangles, cube texcoords, a plastic's diffuse_reflectance)
     ("textured", "cornell_textured.xml", dict(resx=32, resy=32, max_depth=4), 8),
+    # textures on the other slots: specular_reflectance (conductor, roughconductor, plastic), specular_transmittance and alpha_u / alpha_v (roughdielectric), alpha (roughconductor)
+    ("textured_specular", "cornell_textured_specular.xml", dict(resx=32, resy=32, max_depth=5), 8),
     # `constant` environment emitter: rays that leave the scene, environment sampling with MIS, valid_ray
     # sample_visible = false: all microfacet normals are sampled (roughconductor / roughplastic weights and densities, roughdielectric with
     # Walter et al.'s roughness scaling)

@@ -254,6 +254,17 @@ def test_envmap_scene(mi, orc, tmp_path):
         assert np.array_equal(sce.export(16).view(np.uint32), theirs.view(np.uint32)), kw
         ref = np.asarray(sky, np.float32) if not kw.get("half", True) else np.asarray(sky, np.float32).astype(np.float16).astype(np.float32)
         assert np.array_equal(theirs[32:32 + 38 * 19 * 3].reshape(19, 38, 3)[:, :37], ref), kw        # m_data: the decoded pixels (+ the periodic column)
+    # what the package's own writer produces (mitsuba3dopplertof_amd.io.write_exr: ZIP by default) is read back by the library's radiance-map reader
+    from mitsuba3dopplertof_amd import io as dio
+    for k, kw in enumerate((dict(), dict(half=False, compression="zips"), dict(half=False, compression="none"))):
+        q = str(tmp_path / ("own%d.exr" % k))
+        dio.write_exr(q, np.asarray(sky, np.float32), **kw)
+        (tmp_path / ("own%d.xml" % k)).write_text(text.replace("env_sky.hdr", q))
+        sce, osce = mi.load_file(str(tmp_path / ("own%d.xml" % k))), orc.Scene(str(tmp_path / ("own%d.xml" % k)), {})
+        theirs = envmap_export(osce.c.emitters[[e["kind"] for e in osce.flat.emitters].index(4)])
+        assert np.array_equal(sce.export(16).view(np.uint32), theirs.view(np.uint32)), kw
+        ref = np.asarray(sky, np.float32) if not kw.get("half", True) else np.asarray(sky, np.float32).astype(np.float16).astype(np.float32)
+        assert np.array_equal(theirs[32:32 + 38 * 19 * 3].reshape(19, 38, 3)[:, :37], ref), kw
     with pytest.raises(mi.DtofError, match="not RLE"):
         (tmp_path / "rle.xml").write_text(text.replace("env_sky.hdr", _piz_stub(tmp_path)))
         mi.load_file(str(tmp_path / "rle.xml"))

@@ -15,13 +15,23 @@ def test_exr_and_pfm_round_trip(tmp_path):
     import exr_piz
     rng = np.random.default_rng(1)
     img = rng.normal(0, 1e-3, (17, 23, 3)).astype(np.float32)
+    sizes = {}
     for half in (True, False):
-        p = str(tmp_path / ("a_%d.exr" % half))
-        io.write_exr(p, img, half=half)
-        ch, attrs = exr_piz.read_exr(p)
-        back = np.stack([ch["R"], ch["G"], ch["B"]], -1)
-        exp = img.astype(np.float16).astype(np.float32) if half else img
-        assert np.array_equal(back, exp)
+        for compression in ("zip", "zips", "none"):
+            p = str(tmp_path / ("a_%d_%s.exr" % (half, compression)))
+            io.write_exr(p, img, half=half, compression=compression)
+            ch, attrs = exr_piz.read_exr(p)
+            back = np.stack([ch["R"], ch["G"], ch["B"]], -1)
+            exp = img.astype(np.float16).astype(np.float32) if half else img
+            assert np.array_equal(back, exp), (half, compression)
+            sizes[half, compression] = os.path.getsize(p)
+    smooth = np.tile(np.linspace(0, 1, 64, dtype=np.float32)[None, :, None], (40, 1, 3))      # compressible content: ZIP must shrink it
+    io.write_exr(str(tmp_path / "s_zip.exr"), smooth); io.write_exr(str(tmp_path / "s_none.exr"), smooth, compression="none")
+    assert os.path.getsize(str(tmp_path / "s_zip.exr")) < 0.5 * os.path.getsize(str(tmp_path / "s_none.exr"))
+    ch, _ = exr_piz.read_exr(str(tmp_path / "s_zip.exr"))
+    assert np.array_equal(ch["G"], smooth[..., 1].astype(np.float16).astype(np.float32))
+    with pytest.raises(ValueError, match="unsupported OpenEXR compression"):
+        io.write_exr(str(tmp_path / "x.exr"), img, compression="dwaa")
     p = str(tmp_path / "a.pfm")
     io.write_pfm(p, img)
     raw = open(p, "rb").read()

@@ -122,11 +122,11 @@ def test_textures_on_other_slots_fail_loudly_and_shared_textures_are_stored_once
             '<film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/></film></sensor>')
     tex = '<texture type="bitmap" name="%%s"><string name="filename" value="%s"/></texture>' % png
     with pytest.raises(mi.DtofError, match="does not accept a texture"):
-        mi.load_string(head + '<shape type="rectangle"><bsdf type="plastic">' + tex % "specular_reflectance" + '</bsdf></shape></scene>')
+        mi.load_string(head + '<shape type="rectangle"><bsdf type="conductor">' + tex % "eta" + '</bsdf></shape></scene>')
     with pytest.raises(mi.DtofError, match='unreferenced object "reflectanse"'):
         mi.load_string(head + '<shape type="rectangle"><bsdf type="diffuse">' + tex % "reflectanse" + '</bsdf></shape></scene>')
     with pytest.raises(mi.DtofError, match="does not accept a texture"):
-        mi.load_string(head + '<shape type="rectangle"><bsdf type="roughconductor">' + tex % "alpha" + '</bsdf></shape></scene>')
+        mi.load_string(head + '<shape type="rectangle"><bsdf type="roughplastic">' + tex % "alpha" + '</bsdf></shape></scene>')
     shared = head + '<bsdf type="diffuse" id="m">' + tex % "reflectance" + '</bsdf>' + ''.join(
         '<shape type="rectangle"><transform name="to_world"><translate x="%d"/></transform><ref id="m"/></shape>' % k for k in range(40)) + '</scene>'
     sc = mi.load_string(shared)
@@ -138,6 +138,52 @@ def test_textures_on_other_slots_fail_loudly_and_shared_textures_are_stored_once
     assert sc.export(14).size == w * h * 3                            # one copy of the texels
     one = mi.load_string(shared.replace(''.join('<shape type="rectangle"><transform name="to_world"><translate x="%d"/></transform><ref id="m"/></shape>' % k for k in range(1, 40)), ''))
     assert sc.info()["scene_blob_bytes"] - one.info()["scene_blob_bytes"] < 40 * 1024   # 39 more rectangles, not 39 more images
+
+
+def test_textures_on_specular_and_roughness_slots(mi, orc):
+    """specular_reflectance / specular_transmittance (Texture::eval per hit) and alpha / alpha_u / alpha_v of roughconductor / roughdielectric
+    (Texture::eval_1 per hit): both loaders bind the same textures to the same slots, the constants they keep are the textures' means (what the
+    plastics' specular sampling weight uses, plastic.cpp:201-217), and eval_1 follows bitmap.cpp:324-344 / checkerboard.cpp:91-110."""
+    import ctypes as C
+    path = os.path.join(SCENES, "cornell_textured_specular.xml")
+    sc, osc = mi.load_file(path), orc.Scene(path, {})
+    slots = sc.export(19).reshape(-1, 4).astype(int)
+    rec = sc.export(13).reshape(-1, 17)
+    keys = ("tex_spec", "tex_trans", "tex_alpha_u", "tex_alpha_v")
+    bound = 0
+    for i, s in enumerate(osc.flat.shapes):
+        for j, k in enumerate(keys):
+            w = s.get(k)
+            assert (slots[i, j] >= 0) == (w is not None), (i, k)
+            if w is None:
+                continue
+            bound += 1
+            r = rec[slots[i, j]]
+            assert (int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4]), int(r[5])) == (w["kind"], w["filter"], w["wrap"], w["channels"], w["width"], w["height"])
+            assert bits(r[16]) == bits(np.float32(w["mean"]))
+    assert bound == 8 and slots[2, 2] == slots[2, 3]            # `alpha` fills both roughness slots with ONE texture
+    b = sc.export(9).reshape(-1, 24)
+    for i, s in enumerate(osc.flat.shapes):                     # constants = means; derived sampling weights bit-identical
+        assert np.array_equal(bits(b[i, 10:13]), bits(s["spec_refl"])) and np.array_equal(bits(b[i, 13:16]), bits(s["spec_trans"]))
+        assert bits(b[i, 22]) == bits(np.float32(s["alpha_u"])) and bits(b[i, 23]) == bits(np.float32(s["alpha_v"]))
+        if s["bsdf"] == 3:
+            assert bits(b[i, 6]) == bits(s["plastic_params"][2])
+    # eval_1: gray bitmap -> the texel; RGB bitmap -> luminance; checkerboard -> the mean of the colour the lookup picks
+    L = orc.lib()
+    L.orc_texture_eval_1.restype = C.c_float
+    t = orc.OrcTexture()
+    t.kind, t.filter, t.wrap, t.channels, t.width, t.height = 1, 0, 0, 3, 2, 2
+    data = np.array([[0.1, 0.2, 0.3], [0.4, 0.5, 0.6], [0.7, 0.8, 0.9], [1.0, 0.0, 0.5]], np.float32)
+    t.data = data.ctypes.data_as(C.POINTER(C.c_float)); t.to_uv = (C.c_float * 4)(1, 0, 0, 1)
+    lum = lambda c: np.float32(np.float32(np.float32(c[0] * np.float32(0.212671)) + np.float32(c[1] * np.float32(0.715160))) + np.float32(c[2] * np.float32(0.072169)))
+    assert bits(np.float32(L.orc_texture_eval_1(C.byref(t), C.c_float(0.25), C.c_float(0.25)))) == bits(lum(data[0]))
+    assert bits(np.float32(L.orc_texture_eval_1(C.byref(t), C.c_float(0.75), C.c_float(0.75)))) == bits(lum(data[3]))
+    t.channels = 1
+    assert np.float32(L.orc_texture_eval_1(C.byref(t), C.c_float(0.75), C.c_float(0.25))) == data.reshape(-1)[1]
+    t.kind = 0; t.color0, t.color1 = (C.c_float * 3)(0.3, 0.6, 0.9), (C.c_float * 3)(0.0, 0.3, 0.0)
+    assert abs(L.orc_texture_eval_1(C.byref(t), C.c_float(0.1), C.c_float(0.1)) - 0.6) < 1e-6 and abs(L.orc_texture_eval_1(C.byref(t), C.c_float(0.7), C.c_float(0.1)) - 0.1) < 1e-6
+    with pytest.raises(mi.DtofError, match="does not accept a texture"):
+        mi.load_string(open(path).read().replace('<rgb name="eta" value="0.2, 0.92, 1.1" />', '', 1).replace('name="alpha"', 'name="eta"', 1).replace("tex_", SCENES + "/tex_"))
 
 
 def test_png_reader_handles_filters_palettes_and_alpha(mi, tmp_path):

@@ -161,9 +161,9 @@ def read_exr(path):
         e = cd.index(b"\0", p); name = cd[p:e].decode(); p = e + 1
         ptype = struct.unpack_from("<i", cd, p)[0]; p += 16
         chans.append((name, ptype))                    # 0 uint, 1 half, 2 float ; file order is alphabetical
-    lines = {0: 1, 4: 32}.get(comp)
+    lines = {0: 1, 2: 1, 3: 16, 4: 32}.get(comp)
     if lines is None:
-        raise ValueError("unsupported compression %d (only NONE and PIZ)" % comp)
+        raise ValueError("unsupported compression %d (only NONE, ZIPS, ZIP and PIZ)" % comp)
     n_chunks = (H + lines - 1) // lines
     offsets = struct.unpack_from("<%dQ" % n_chunks, data, pos)
     out = {name: np.zeros((H, W), np.float32) for name, _ in chans}
@@ -175,6 +175,14 @@ def read_exr(path):
         n_raw = sum(sizes) * W * ny
         if comp == 0 or dsize == n_raw * 2:
             raw = np.frombuffer(buf, "<u2", n_raw).copy()
+            planar = False
+        elif comp in (2, 3):                             # ZIPS / ZIP: inflate, undo the predictor, re-interleave the even and odd bytes
+            import zlib
+            d = np.frombuffer(zlib.decompress(buf), np.uint8).astype(np.int32)
+            t = (np.cumsum(d - 128) + 128) & 255         # t[0] = d[0], t[i] = t[i-1] + d[i] - 128
+            half = (len(t) + 1) // 2
+            inter = np.empty(len(t), np.uint8); inter[0::2] = t[:half]; inter[1::2] = t[half:]
+            raw = np.frombuffer(inter.tobytes(), "<u2", n_raw).copy()
             planar = False
         else:
             mn, mxv = struct.unpack_from("<2H", buf, 0)

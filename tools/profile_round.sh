@@ -12,11 +12,14 @@ tag=${1:-r03}
 root=$(pwd); out=$root/gpurun_out; mkdir -p "$out" "$out/${tag}_profiles"; export TMPDIR=/tmp
 for c in c2 c4 c5; do
     case $c in c2) steps="--steps 20 --warmup 3"; short="--steps 3 --warmup 1";; c4) steps="--steps 5 --warmup 1"; short="--steps 2 --warmup 1";; c5) steps="--steps 3 --warmup 1"; short="--steps 1 --warmup 1";; esac
-    extra="--no-extra"; [ $c = c2 ] && extra=""
+    extra="--no-extra --no-cpu-baseline"; [ $c = c2 ] && extra=""        # the CPU oracle (brute force over every object) is timed on the headline workload only
+    echo "[$c] bench line"
     python3 bench.py --config $c $extra $steps > "$out/${tag}_bench_${c}.json" 2> "$out/${tag}_bench_${c}.err" || exit 1
     cd /tmp
+    echo "[$c] rocprofv3 --kernel-trace --stats"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_${c}" -o "$tag" -- python3 "$root/bench.py" --config $c --no-extra --no-cpu-baseline $steps \
         > "$out/${tag}_bench_${c}_under_rocprof.json" 2> "$out/${tag}_stats_${c}.log" || exit 1
+    echo "[$c] pmc passes"
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/${tag}_pmc_fetch_${c}" -- python3 "$root/bench.py" --config $c --no-extra --no-cpu-baseline $short > /dev/null 2> "$out/${tag}_pmc_fetch_${c}.log" || exit 1
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/${tag}_pmc_write_${c}" -- python3 "$root/bench.py" --config $c --no-extra --no-cpu-baseline $short > /dev/null 2> "$out/${tag}_pmc_write_${c}.log" || exit 1
     rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES --kernel-trace --output-format csv -d "$out/${tag}_pmc_valu_${c}" -- python3 "$root/bench.py" --config $c --no-extra --no-cpu-baseline $short > /dev/null 2> "$out/${tag}_pmc_valu_${c}.log" || exit 1
