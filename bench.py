@@ -351,6 +351,19 @@ def main():
                 alg = json.load(open(afile)).get(args.config, {})
             except Exception:
                 alg = {}
+        # Issue-rate model (profiles/valu_cycle_model.json, tools/valu_cycle_model.py): only a subset of the VALU instruction forms issues at the 2 cycles
+        # per wave64 instruction the peak assumes (measured: profiles/r03_ubench_valu_rate.txt); the kernel's static instruction mix priced with the
+        # measured rates gives the average cycles one of ITS instructions occupies a SIMD for
+        cyc = {}
+        cfile = os.path.join(HERE, "profiles", "valu_cycle_model.json")
+        if os.path.exists(cfile) and default_workload:
+            try:
+                sys.path.insert(0, os.path.join(HERE, "tools"))
+                from pmc_summary import kernel_sources_sha16
+                cdoc = json.load(open(cfile))
+                cyc = dict(cdoc.get("configs", {}).get(args.config, {}), stale=cdoc.get("csrc_sha16") != kernel_sources_sha16(HERE))
+            except Exception:
+                cyc = {}
         stages = {"ms_first_bounce": round(acc["ms_first"] / args.steps, 4),
                   "ms_trace": round(acc["ms_trace"] / args.steps, 4), "ms_shade": round(acc["ms_shade"] / args.steps, 4),
                   "ms_shadow": round(acc["ms_shadow"] / args.steps, 4), "ms_generate": round(acc["ms_generate"] / args.steps, 4),
@@ -381,6 +394,12 @@ def main():
                 "algorithmic": {"ops_per_path": ops_path, "achieved": round(alg_achieved, 2) if alg_achieved else None, "unit": "T ops/s",
                                 "frac_alg": round(alg_achieved / valu_peak, 4) if alg_achieved else None, "source": alg.get("source"), "breakdown": alg.get("breakdown")},
                 "active_lane_ratio": first_rec.get("active_lane_ratio"),
+                "valu_busy_est": {"what": "share of the launch during which the VALU pipes are occupied: executed VALU wave-instructions x the average cycles one "
+                                          "instruction of THIS kernel's mix holds a SIMD (2.25 / 4.1 / 8.2 nominal cycles by instruction form, measured on this GPU) "
+                                          "over 1024 SIMDs x launch time x 2.4 GHz; frac prices every instruction at 2 cycles",
+                                  "avg_cycles_per_valu_instruction": cyc.get("avg_cycles_per_valu"), "share_of_cycles": cyc.get("share_of_cycles"),
+                                  "frac_busy": round(wave_insts * cyc["avg_cycles_per_valu"] / (1024 * first_s * 2.4e9), 4) if wave_insts and cyc.get("avg_cycles_per_valu") else None,
+                                  "model_stale": cyc.get("stale"), "source": "profiles/valu_cycle_model.json, profiles/r03_ubench_valu_rate.txt"},
                 "counters_stale": counters_stale,
                 "traffic": first_rec.get("hbm_bytes_per_launch"),
                 "algorithmic_bytes_per_launch": round(out_bytes, 1), "avg_launch_ms": round(first_s * 1e3, 5), "launches_per_step": n_first / args.steps,
