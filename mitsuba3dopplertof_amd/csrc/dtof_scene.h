@@ -34,7 +34,10 @@ static_assert(sizeof(BlobHeader) == 80, "BlobHeader");
 // One top-level object of a small rectangle-only scene as trace_flat (dtof_traverse.h) reads it with ONE scalar load: a plain rectangle's
 // world -> object matrix (a copy of its DShape::to_object), or the mark of an instance (which takes the general intersect_object).
 constexpr uint32_t kFlatObjects = 8;
-struct DFlatObject { uint32_t instance, pad[3]; float to_object[12]; };   // 64 B; instance: 0 plain rectangle, 1 instance (general path), 2 instance of ONE rectangle (to_object = that rectangle's, in the group's space)
+// The world -> object matrix is stored by COLUMNS (c0 .. c2 = the linear part, c3 = the translation; x, y, z entries each): trace_flat feeds the (x, y) pair of a
+// column to ONE packed multiply-add as an SGPR-pair operand (v_pk_fma_f32 issues two multiply-adds in the 4 cycles a scalar-operand v_fma_f32 needs for one,
+// profiles/r03_ubench_valu_rate.txt).
+struct DFlatObject { float c0[3]; uint32_t instance; float c1[3]; uint32_t pad1; float c2[3]; uint32_t pad2; float c3[3]; uint32_t pad3; };   // 64 B; instance: 0 plain rectangle, 1 instance (general path), 2 instance of ONE rectangle (matrix = that rectangle's, in the group's space)
 static_assert(sizeof(DFlatObject) == 64, "DFlatObject");
 
 constexpr uint32_t kLeafFlag = 0x80000000u;

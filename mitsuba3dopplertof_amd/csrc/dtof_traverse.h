@@ -605,11 +605,19 @@ DTOF_D bool trace_rays(const SceneView &sv, uint32_t *stack, bool active, V3 o, 
 // Hits are those of trace_scene bit for bit: same rect_hit arithmetic, smallest t wins, ties go to the lowest object index
 // (ascending order + strict <).  Instances take intersect_object (one uniform branch).
 typedef const uint8_t __attribute__((address_space(4))) *ConstBytes;
-struct FlatRecord { uint32_t instance; float m[12]; };
+// DTOF_FLAT_PK=1: the rectangle transform of trace_flat as packed multiply-adds (v_pk_fma_f32 with the matrix entries as SGPR-pair operands: two
+// multiply-adds in the 4 cycles ONE scalar-operand v_fma_f32 takes, profiles/r03_ubench_valu_rate.txt).  Bit-exact; measured on C2: 3 % fewer VALU
+// instructions but the pairs cost registers in a kernel at its cap -- spill loads / stores per wave 157 -> 580, frame 1.53 -> 1.65 ms
+// (profiles/r03_flat_packed_ab.txt).  Off.
+#ifndef DTOF_FLAT_PK
+#define DTOF_FLAT_PK 0
+#endif
+typedef float F2 __attribute__((ext_vector_type(2)));
+struct FlatRecord { uint32_t instance; F2 c0, c1, c2, c3; float z0, z1, z2, z3; };   // (x, y) entries of the four columns as pairs, the z row apart
 DTOF_D FlatRecord flat_load(const DFlatObject __attribute__((address_space(4))) *f) {
     FlatRecord r; r.instance = f->instance;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) r.m[i] = f->to_object[i];
+    r.c0 = F2{ f->c0[0], f->c0[1] }; r.c1 = F2{ f->c1[0], f->c1[1] }; r.c2 = F2{ f->c2[0], f->c2[1] }; r.c3 = F2{ f->c3[0], f->c3[1] };
+    r.z0 = f->c0[2]; r.z1 = f->c1[2]; r.z2 = f->c2[2]; r.z3 = f->c3[2];
     return r;
 }
 template <bool ANY, bool MEMO>
@@ -625,9 +633,21 @@ DTOF_D bool trace_flat(const SceneView &sv, ConstBytes flat_table, uint32_t n_ob
             float inv[12]; instance_memo_load(sv, inv);
             ro = xf_point(inv, o); rd = xf_vector(inv, d);
         }
-        const V3 lo = xf_point(rec.m, ro), ld = xf_vector(rec.m, rd);
-        const float t = -lo.z / ld.z;
-        const float u = fmaf(ld.x, t, lo.x), v = fmaf(ld.y, t, lo.y);
+        // xf_point / xf_vector with the matrix entries as scalar operands, two multiply-adds per instruction: the x and y rows of the point as one pair,
+        // those of the direction as another, the z rows of point AND direction as the third (same entries, different vectors).  Each half is the IEEE
+        // operation of the scalar form, in its order; the direction's leading product becomes fma(m, d, -0), which equals m * d for every input.
+#if DTOF_FLAT_PK
+        const F2 lo_xy = __builtin_elementwise_fma(rec.c2, F2{ ro.z, ro.z }, __builtin_elementwise_fma(rec.c1, F2{ ro.y, ro.y }, __builtin_elementwise_fma(rec.c0, F2{ ro.x, ro.x }, rec.c3)));
+        const F2 ld_xy = __builtin_elementwise_fma(rec.c2, F2{ rd.z, rd.z }, __builtin_elementwise_fma(rec.c1, F2{ rd.y, rd.y }, rec.c0 * F2{ rd.x, rd.x }));
+        const F2 z = __builtin_elementwise_fma(F2{ rec.z2, rec.z2 }, F2{ ro.z, rd.z }, __builtin_elementwise_fma(F2{ rec.z1, rec.z1 }, F2{ ro.y, rd.y },
+                                               __builtin_elementwise_fma(F2{ rec.z0, rec.z0 }, F2{ ro.x, rd.x }, F2{ rec.z3, -0.f })));
+#else   // the scalar form (one multiply-add per instruction, matrix entries as SGPR operands: 4 cycles each), kept for A/B timing
+        const F2 lo_xy = F2{ fmaf(rec.c2.x, ro.z, fmaf(rec.c1.x, ro.y, fmaf(rec.c0.x, ro.x, rec.c3.x))), fmaf(rec.c2.y, ro.z, fmaf(rec.c1.y, ro.y, fmaf(rec.c0.y, ro.x, rec.c3.y))) };
+        const F2 ld_xy = F2{ fmaf(rec.c2.x, rd.z, fmaf(rec.c1.x, rd.y, rec.c0.x * rd.x)), fmaf(rec.c2.y, rd.z, fmaf(rec.c1.y, rd.y, rec.c0.y * rd.x)) };
+        const F2 z = F2{ fmaf(rec.z2, ro.z, fmaf(rec.z1, ro.y, fmaf(rec.z0, ro.x, rec.z3))), fmaf(rec.z2, rd.z, fmaf(rec.z1, rd.y, rec.z0 * rd.x)) };
+#endif
+        const float t = -z.x / z.y;
+        const float u = fmaf(ld_xy.x, t, lo_xy.x), v = fmaf(ld_xy.y, t, lo_xy.y);
         // no short-circuit: four compares and three mask ANDs instead of three exec-mask branches per rectangle (the scalar unit is as busy as the vector units here)
         const bool hit = (int) (t >= 0.f) & (int) (t <= maxt) & (int) (fabsf(u) <= 1.f) & (int) (fabsf(v) <= 1.f);
         if (ANY) occluded |= hit;

@@ -512,10 +512,12 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         if (ok) for (const DObject &ob : objects) {
             DFlatObject f; memset(&f, 0, sizeof f);
             f.instance = ob.kind == OBJ_INSTANCE;
-            if (!f.instance) memcpy(f.to_object, shapes[ob.index].to_object, 48);
+            const float *m = nullptr;   // row-major 3 x 4
+            if (!f.instance) m = shapes[ob.index].to_object;
             else if (groups[ob.index].n_shapes == 1) {   // an instance of one rectangle: its object-space matrix rides along (mark 2), the ray is moved there with the memoised inverse
-                f.instance = 2; memcpy(f.to_object, shapes[groups[ob.index].first_shape].to_object, 48);
+                f.instance = 2; m = shapes[groups[ob.index].first_shape].to_object;
             }
+            if (m) for (int r = 0; r < 3; ++r) { f.c0[r] = m[4 * r]; f.c1[r] = m[4 * r + 1]; f.c2[r] = m[4 * r + 2]; f.c3[r] = m[4 * r + 3]; }
             flat.push_back(f);
         }
     }

@@ -86,6 +86,12 @@ OPS = [  # name, kind (f: float chain, u: uint chain, q: 64-bit chain), text, in
     ("v_pk_fma_f32", "q", "v_pk_fma_f32 {c}, {c}, {a}, {c}", 1),
     ("v_pk_mul_f32", "q", "v_pk_mul_f32 {c}, {c}, {a}", 1),
     ("v_pk_add_f32", "q", "v_pk_add_f32 {c}, {c}, {a}", 1),
+    ("v_pk_fma_f32 v,s[20:21],v,v (SGPR pair operand)", "q", "v_pk_fma_f32 {c}, s[20:21], {a}, {c}", 1),
+    ("v_pk_fma_f32 v,s[20:21],v,v op_sel_hi:[0,1,1]", "q", "v_pk_fma_f32 {c}, s[20:21], {a}, {c} op_sel_hi:[0,1,1]", 1),
+    ("v_pk_fma_f32 v,v,v,v op_sel:[0,1,0] op_sel_hi:[1,1,1] (VGPR broadcast)", "q", "v_pk_fma_f32 {c}, {c}, {a}, {c} op_sel:[0,1,0] op_sel_hi:[1,1,1]", 1),
+    ("v_pk_mul_f32 v,v,s[20:21]", "q", "v_pk_mul_f32 {c}, {c}, s[20:21]", 1),
+    ("v_mov_b64 v,s[20:21]", "q", "v_mov_b64 {c}, s[20:21]", 1),
+    ("v_mov_b64 v,v", "q", "v_mov_b64 {c}, {a}", 1),
     ("v_fma_f64", "q", "v_fma_f64 {c}, {c}, {a}, {c}", 1),
     ("v_mul_f64", "q", "v_mul_f64 {c}, {c}, {a}", 1),
     ("v_add_f64", "q", "v_add_f64 {c}, {c}, {a}", 1),
@@ -108,7 +114,7 @@ HEAD = r'''// GENERATED by gen_valu_rate.py -- issue rate of the VALU instructio
 template <int OP> __global__ __launch_bounds__(64) void k(float *out, float a, uint32_t ua, int iters) {
     float f[8]; uint32_t u[8]; uint64_t q[8]; float b = a * 1.5f + threadIdx.x; uint64_t qa = ((uint64_t) ua << 32) | 0x3f800100u;
     for (int i = 0; i < 8; ++i) { f[i] = a + threadIdx.x + i; u[i] = ua + threadIdx.x * 7 + i; q[i] = ((uint64_t) __float_as_uint(f[i]) << 32) | __float_as_uint(f[i] + 1.f); }
-    asm volatile("s_mov_b32 s20, 0x3f800100\n s_mov_b64 s[22:23], 0x5555\n v_cmp_gt_f32 vcc, %0, %1" : : "v"(f[0]), "v"(a) : "s20", "s22", "s23", "vcc");
+    asm volatile("s_mov_b32 s20, 0x3f800100\n s_mov_b32 s21, 0x3f800200\n s_mov_b64 s[22:23], 0x5555\n v_cmp_gt_f32 vcc, %0, %1" : : "v"(f[0]), "v"(a) : "s20", "s22", "s23", "vcc");
     for (int it = 0; it < iters; ++it) {
 '''
 TAIL = r'''    }
