@@ -225,6 +225,9 @@ int dtof_eval_modulation(dtof_scene *scene, int mode, const float *t, const floa
  * maxt.  out19: t (inf on a miss), p[3], n[3], sh_frame.n[3], sh_frame.s[3], sh_frame.t[3], wi[3]; ids3: object, shape-in-group,
  * primitive (-1 on a miss).  dtof_ray_test writes 1 / 0 per ray. */
 int dtof_ray_intersect(dtof_scene *scene, uint32_t n, const float *rays8, float *out19, int32_t *ids3);
+/* the same, plus uv4 per ray: si.uv[2] (the surface parameterisation, interaction.h) and pi.prim_uv[2] (PreliminaryIntersection::prim_uv: the barycentric
+ * coordinates on a triangle, the local position on a rectangle or disk), as the reference's tests of meshes assert them (src/render/tests/test_mesh.py:258-292) */
+int dtof_ray_intersect_uv(dtof_scene *scene, uint32_t n, const float *rays8, float *out19, int32_t *ids3, float *uv4);
 int dtof_ray_test(dtof_scene *scene, uint32_t n, const float *rays8, int32_t *occluded);
 
 /* ---------------------------------------------------------------- component evaluation

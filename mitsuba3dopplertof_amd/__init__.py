@@ -124,6 +124,7 @@ def _lib():
     L.dtof_eval_modulation.argtypes = [vp, C.c_int, vp, vp, vp, C.c_uint32]
     L.dtof_eval_component.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_uint32]
     L.dtof_ray_intersect.argtypes = [vp, C.c_uint32, vp, vp, vp]
+    L.dtof_ray_intersect_uv.argtypes = [vp, C.c_uint32, vp, vp, vp, vp]
     L.dtof_ray_test.argtypes = [vp, C.c_uint32, vp, vp]
     _LIB = L
     return L
@@ -257,12 +258,12 @@ class Scene:
         return rays
 
     def ray_intersect(self, o, d, time=0.0, maxt=None):
-        """Scene::ray_intersect over arrays of rays -> dict(t, p, n, sh_n, sh_s, sh_t, wi, ids) (dtof_ray_intersect)"""
+        """Scene::ray_intersect over arrays of rays -> dict(t, p, n, sh_n, sh_s, sh_t, wi, ids, uv, prim_uv, prim_index, valid) (dtof_ray_intersect_uv)"""
         rays = self._rays(o, d, time, maxt)
-        out, ids = np.zeros((len(rays), 19), np.float32), np.zeros((len(rays), 3), np.int32)
-        _check(_lib().dtof_ray_intersect(self._h, len(rays), rays.ctypes.data, out.ctypes.data, ids.ctypes.data))
+        out, ids, uv = np.zeros((len(rays), 19), np.float32), np.zeros((len(rays), 3), np.int32), np.zeros((len(rays), 4), np.float32)
+        _check(_lib().dtof_ray_intersect_uv(self._h, len(rays), rays.ctypes.data, out.ctypes.data, ids.ctypes.data, uv.ctypes.data))
         return {"t": out[:, 0], "p": out[:, 1:4], "n": out[:, 4:7], "sh_n": out[:, 7:10], "sh_s": out[:, 10:13], "sh_t": out[:, 13:16],
-                "wi": out[:, 16:19], "ids": ids}
+                "wi": out[:, 16:19], "ids": ids, "uv": uv[:, 0:2], "prim_uv": uv[:, 2:4], "prim_index": ids[:, 2], "valid": ids[:, 0] >= 0}
 
     def ray_test(self, o, d, time=0.0, maxt=None):
         """Scene::ray_test over arrays of rays -> bool array (dtof_ray_test)"""

@@ -1533,7 +1533,7 @@ void launch_component(const ComponentArgs &a, const RenderParams &rp, hipStream_
 // Scene::ray_intersect / ray_test over arrays (dtof_ray_intersect): closest hit + surface interaction, or occlusion only.
 // rays: o[3], d[3], time, maxt (8 floats); out: t, p[3], n[3], sh_n[3], sh_s[3], sh_t[3], wi[3] (19 floats); ids: object, shape, prim
 template <bool ANY>
-__global__ __launch_bounds__(64) void k_ray_query(const uint8_t *scene, const float *rays, float *out, int32_t *ids, uint32_t n) {
+__global__ __launch_bounds__(64) void k_ray_query(const uint8_t *scene, const float *rays, float *out, int32_t *ids, float *uv4, uint32_t n) {
     extern __shared__ uint4 lds[];
     uint32_t *stack = (uint32_t *) lds + threadIdx.x;
     const SceneView sv = make_view(scene);
@@ -1549,19 +1549,21 @@ __global__ __launch_bounds__(64) void k_ray_query(const uint8_t *scene, const fl
     float *w = out + (size_t) i * 19;
     for (int k = 0; k < 19; ++k) w[k] = 0.f;
     ids[3 * i] = found ? (int32_t) h.obj : -1; ids[3 * i + 1] = found ? (int32_t) h.shape : -1; ids[3 * i + 2] = found ? (int32_t) h.prim : -1;
+    if (uv4) for (int k = 0; k < 4; ++k) uv4[(size_t) i * 4 + k] = 0.f;
     if (!found) { w[0] = u2f(0x7f800000u); return; }
     Surface si;
     compute_surface<true>(sv, h.obj, h.shape, h.prim, h.t, h.u, h.v, o, d, r[6], si);
     w[0] = h.t;
     const V3 f[6] = { si.p, si.n, si.sh_n, si.sh_s, si.sh_t, si.wi };
     for (int k = 0; k < 6; ++k) { w[1 + 3 * k] = f[k].x; w[2 + 3 * k] = f[k].y; w[3 + 3 * k] = f[k].z; }
+    if (uv4) { uv4[(size_t) i * 4] = si.u; uv4[(size_t) i * 4 + 1] = si.v; uv4[(size_t) i * 4 + 2] = h.u; uv4[(size_t) i * 4 + 3] = h.v; }   // si.uv, pi.prim_uv
 }
-void launch_ray_query(const uint8_t *scene, const float *rays, float *out, int32_t *ids, uint32_t n, bool any, uint32_t stack_depth, hipStream_t s) {
+void launch_ray_query(const uint8_t *scene, const float *rays, float *out, int32_t *ids, float *uv4, uint32_t n, bool any, uint32_t stack_depth, hipStream_t s) {
     if (!n) return;
     const uint32_t lds = stack_bytes(stack_depth, 64);
     check_lds(lds);
-    if (any) hipLaunchKernelGGL(k_ray_query<true>, dim3((n + 63) / 64), dim3(64), lds, s, scene, rays, out, ids, n);
-    else hipLaunchKernelGGL(k_ray_query<false>, dim3((n + 63) / 64), dim3(64), lds, s, scene, rays, out, ids, n);
+    if (any) hipLaunchKernelGGL(k_ray_query<true>, dim3((n + 63) / 64), dim3(64), lds, s, scene, rays, out, ids, uv4, n);
+    else hipLaunchKernelGGL(k_ray_query<false>, dim3((n + 63) / 64), dim3(64), lds, s, scene, rays, out, ids, uv4, n);
 }
 
 #ifdef DTOF_TRAVERSAL_STATS

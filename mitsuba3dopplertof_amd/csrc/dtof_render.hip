@@ -994,21 +994,24 @@ int dtof_eval_component(int component, const float *params, int n_params, const 
     });
 }
 
-static int ray_query(dtof_scene *sc, uint32_t n, const float *rays8, float *out19, int32_t *ids, bool any) {
+static int ray_query(dtof_scene *sc, uint32_t n, const float *rays8, float *out19, int32_t *ids, bool any, float *uv4 = nullptr) {
     return guarded([&] {
         if (!sc || (n && (!rays8 || !ids || (!any && !out19)))) throw std::runtime_error("null argument");
         ensure_device(sc);
         const BlobHeader *bh = (const BlobHeader *) sc->blob.data();
-        DevBuf<float> dr, dout; DevBuf<int32_t> dids;
+        DevBuf<float> dr, dout, duv; DevBuf<int32_t> dids;
         dr.ensure((size_t) n * 8); dout.ensure(any ? 1 : (size_t) n * 19); dids.ensure((size_t) n * (any ? 1 : 3));
+        if (uv4) duv.ensure((size_t) n * 4);
         HIP_CHECK(hipMemcpy(dr.p, rays8, (size_t) n * 32, hipMemcpyHostToDevice));
-        launch_ray_query(sc->d_blob.p, dr.p, dout.p, dids.p, n, any, bh->tlas_depth, nullptr);
+        launch_ray_query(sc->d_blob.p, dr.p, dout.p, dids.p, uv4 ? duv.p : nullptr, n, any, bh->tlas_depth, nullptr);
         HIP_CHECK(hipGetLastError());
         if (!any) HIP_CHECK(hipMemcpy(out19, dout.p, (size_t) n * 19 * 4, hipMemcpyDeviceToHost));
+        if (uv4 && n) HIP_CHECK(hipMemcpy(uv4, duv.p, (size_t) n * 16, hipMemcpyDeviceToHost));
         HIP_CHECK(hipMemcpy(ids, dids.p, (size_t) n * (any ? 1 : 3) * 4, hipMemcpyDeviceToHost));
     });
 }
 int dtof_ray_intersect(dtof_scene *sc, uint32_t n, const float *rays8, float *out19, int32_t *ids3) { return ray_query(sc, n, rays8, out19, ids3, false); }
+int dtof_ray_intersect_uv(dtof_scene *sc, uint32_t n, const float *rays8, float *out19, int32_t *ids3, float *uv4) { return ray_query(sc, n, rays8, out19, ids3, false, uv4); }
 int dtof_ray_test(dtof_scene *sc, uint32_t n, const float *rays8, int32_t *occluded) { return ray_query(sc, n, rays8, nullptr, occluded, true); }
 
 #ifdef DTOF_TRAVERSAL_STATS

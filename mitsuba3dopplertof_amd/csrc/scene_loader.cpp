@@ -775,6 +775,7 @@ void rough_plastic_tables(int type, float alpha, float eta, float *table, float 
 
 // ---- textures on the diffuse reflectances (src/textures/checkerboard.cpp:55-62, src/textures/bitmap.cpp:113-262, RGB variants)
 static thread_local std::vector<HostTexture> *g_textures = nullptr;   // the scene being assembled
+static thread_local std::set<const void *> *g_attached_emitters = nullptr;   // area emitters already attached to a shape (an emitter declared at scene level can be referenced by ONE shape, endpoint.cpp:36-40)
 static thread_local std::map<const void *, int> *g_texture_index = nullptr;   // texture object -> its index in *g_textures: a texture referenced by many BSDFs / shapes is decoded and stored once
 static thread_local std::string g_base_dir;
 static float srgb_to_linear_u8(uint32_t v) {   // StructConverter::linearize + dr::srgb_to_linear (src/core/struct.cpp:1600-1625)
@@ -1098,6 +1099,7 @@ static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string
             const Obj &e = *c.second;
             if (s.emitter) fail("Only a single Emitter child object can be specified per shape.");
             if (e.plugin != "area") fail("unsupported emitter plugin \"" + e.plugin + "\" inside a shape (supported: area)");
+            if (g_attached_emitters && !g_attached_emitters->insert((const void *) &e).second) fail("An endpoint can be only be attached to a single shape.");   // endpoint.cpp:36-40
             if (strip_to_world) fail("Instancing of emitters is not supported");   // shapegroup.cpp:27-28: an animated (or grouped) shape becomes an instance (xml.cpp:1165-1195), which cannot carry an emitter in the reference either
             if (e.transforms.count("to_world")) fail("Found a 'to_world' transformation -- this is not allowed. The area light inherits this transformation from its parent shape.");
             auto rc = e.colors.find("radiance");
@@ -1272,8 +1274,9 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
 
     HostScene sc; bool have_sensor = false, have_integrator = false;
     std::map<const void *, int> texture_index;
-    g_textures = &sc.textures; g_texture_index = &texture_index; g_base_dir = base_dir;
-    struct TexScope { ~TexScope() { g_textures = nullptr; g_texture_index = nullptr; } } tex_scope;
+    std::set<const void *> attached_emitters;
+    g_textures = &sc.textures; g_texture_index = &texture_index; g_base_dir = base_dir; g_attached_emitters = &attached_emitters;
+    struct TexScope { ~TexScope() { g_textures = nullptr; g_texture_index = nullptr; g_attached_emitters = nullptr; } } tex_scope;
     std::map<const Obj *, uint32_t> group_of;
     for (auto &c : top->children) {
         const Obj &o = *c.second;
@@ -1283,6 +1286,9 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
         } else if (o.tag == "sensor") {
             if (have_sensor) fail("only one sensor is supported");
             make_sensor(o, sc); have_sensor = true;
+        } else if (o.tag == "emitter" && o.plugin == "area") {
+            // an area emitter declared at scene level waits for the shape that references it (scene.cpp:44-47 skips surface emitters among the scene's
+            // children: they are counted through their shape)
         } else if (o.tag == "emitter") {
             if (o.plugin != "point" && o.plugin != "spot" && o.plugin != "constant" && o.plugin != "envmap" && o.plugin != "directional") fail("unsupported emitter plugin \"" + o.plugin + "\" (supported: point, spot, directional, constant, envmap; area inside a shape)");
             HostEmitter e; e.kind = 0;
@@ -1369,6 +1375,7 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
                     if (ch.first != "shape") fail("Tried to add an unsupported object to a shapegroup");
                     if (ch.second->plugin == "instance") fail("Nested instancing is not permitted");
                     if (ch.second->plugin == "shapegroup") fail("Nested ShapeGroup is not permitted");
+                    for (auto &c2 : ch.second->children) if (c2.first == "sensor") fail("Instancing of sensors is not supported");   // shapegroup.cpp:29-30
                     sc.shapes.push_back(make_shape(*ch.second, false, base_dir));
                     if (sc.shapes.back().emitter) fail("Instancing of emitters is not supported");
                 }

@@ -173,27 +173,9 @@ static inline float interval_to_linear(float v0, float v1, float sample) {
 }
 static uint32_t log2i_ceil_u32(uint32_t v) { uint32_t r = 31u - (uint32_t) __builtin_clz(v); if (v & (v - 1u)) r += 1u; return r; }
 
-orc_envmap *orc_envmap_create(const float *rgb, int32_t width, int32_t height, float scale) {
-    if (width < 2 || height < 3) return NULL;
-    orc_envmap *e = (orc_envmap *) calloc(1, sizeof *e);
-    const uint32_t W = (uint32_t) width + 1u, H = (uint32_t) height;
-    e->w = (int32_t) W; e->h = (int32_t) H; e->scale = scale;
-    e->data = (float *) malloc(sizeof(float) * 3u * W * H);
-    float *lum = (float *) malloc(sizeof(float) * W * H);
-    const float theta_scale = 1.f / (float) (H - 1u) * ORC_PI_F;
-    for (uint32_t y = 0; y < H; ++y) {
-        const float sin_theta = sinf((float) y * theta_scale);
-        for (uint32_t x = 0; x < (uint32_t) width; ++x) {
-            const float *in = rgb + 3u * (y * (uint32_t) width + x);
-            float l = in[0] * 0.212671f + in[1] * 0.715160f + in[2] * 0.072169f;   /* mitsuba::luminance (spectrum.h:431-434) */
-            l = f_max(l - 0.f, 0.f);
-            lum[y * W + x] = l * sin_theta;
-            memcpy(e->data + 3u * (y * W + x), in, 12);
-        }
-        lum[y * W + (W - 1u)] = lum[y * W];                                      /* the last column mirrors the first */
-        memcpy(e->data + 3u * (y * W + (W - 1u)), e->data + 3u * (y * W), 12);
-    }
-    /* Hierarchical2D(data, size) */
+/* Hierarchical2D<Float, 0>(data, size, normalize) (include/mitsuba/core/distr_2d.h:376-482): level 0 = the (normalised) input grid of W x H
+ * values, level k >= 1 = the patch averages, summed 2 x 2 per level, in the blocked order env_level_index() walks */
+static void hier2d_build(orc_envmap *e, const float *lum, uint32_t W, uint32_t H, int normalize) {
     const uint32_t npx = W - 1u, npy = H - 1u, max_level = log2i_ceil_u32(npx > npy ? npx : npy);
     e->patch_size[0] = 1.f / (float) npx; e->patch_size[1] = 1.f / (float) npy;
     e->inv_patch_size[0] = (float) npx; e->inv_patch_size[1] = (float) npy;
@@ -218,7 +200,7 @@ orc_envmap *orc_envmap_create(const float *rgb, int32_t width, int32_t height, f
             sum += (double) avg;
             e->level[1][env_level_index(x, y, (uint32_t) e->level_w[1])] = avg;
         }
-    const float norm = (float) ((double) (npx * npy) / sum);
+    const float norm = normalize ? (float) ((double) (npx * npy) / sum) : 1.f;
     for (uint32_t i = 0; i < W * H; ++i) e->level[0][i] = lum[i] * norm;
     for (int32_t i = 0; i < e->level_size[1]; ++i) e->level[1][i] *= norm;
     {
@@ -232,6 +214,36 @@ orc_envmap *orc_envmap_create(const float *rgb, int32_t width, int32_t height, f
                 }
         }
     }
+}
+/* known-answer entry: the warp alone over a caller's grid (src/core/tests/test_distr_2d.py builds Hierarchical2D0 from plain arrays) */
+orc_envmap *orc_hier2d_create(const float *values, int32_t width, int32_t height, int32_t normalize) {
+    if (width < 2 || height < 2) return NULL;
+    orc_envmap *e = (orc_envmap *) calloc(1, sizeof *e);
+    e->w = width; e->h = height; e->scale = 1.f; e->data = NULL;
+    hier2d_build(e, values, (uint32_t) width, (uint32_t) height, normalize);
+    return e;
+}
+orc_envmap *orc_envmap_create(const float *rgb, int32_t width, int32_t height, float scale) {
+    if (width < 2 || height < 3) return NULL;
+    orc_envmap *e = (orc_envmap *) calloc(1, sizeof *e);
+    const uint32_t W = (uint32_t) width + 1u, H = (uint32_t) height;
+    e->w = (int32_t) W; e->h = (int32_t) H; e->scale = scale;
+    e->data = (float *) malloc(sizeof(float) * 3u * W * H);
+    float *lum = (float *) malloc(sizeof(float) * W * H);
+    const float theta_scale = 1.f / (float) (H - 1u) * ORC_PI_F;
+    for (uint32_t y = 0; y < H; ++y) {
+        const float sin_theta = sinf((float) y * theta_scale);
+        for (uint32_t x = 0; x < (uint32_t) width; ++x) {
+            const float *in = rgb + 3u * (y * (uint32_t) width + x);
+            float l = in[0] * 0.212671f + in[1] * 0.715160f + in[2] * 0.072169f;   /* mitsuba::luminance (spectrum.h:431-434) */
+            l = f_max(l - 0.f, 0.f);
+            lum[y * W + x] = l * sin_theta;
+            memcpy(e->data + 3u * (y * W + x), in, 12);
+        }
+        lum[y * W + (W - 1u)] = lum[y * W];                                      /* the last column mirrors the first */
+        memcpy(e->data + 3u * (y * W + (W - 1u)), e->data + 3u * (y * W), 12);
+    }
+    hier2d_build(e, lum, W, H, 1);
     free(lum);
     return e;
 }

@@ -135,6 +135,7 @@ typedef struct orc_envmap {
 } orc_envmap;
 orc_envmap *orc_envmap_create(const float *rgb, int32_t width, int32_t height, float scale);
 void     orc_envmap_free(orc_envmap *e);
+orc_envmap *orc_hier2d_create(const float *values, int32_t width, int32_t height, int32_t normalize);   /* Hierarchical2D<Float, 0> over a plain grid (test_distr_2d.py) */
 /* known-answer entry points: Hierarchical2D::sample / eval, the emitter's sample_direction / pdf_direction / eval */
 void     orc_envmap_warp_sample(const orc_envmap *e, float sx, float sy, float *uv2_pdf);
 float    orc_envmap_warp_eval(const orc_envmap *e, float x, float y);

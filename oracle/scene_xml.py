@@ -976,6 +976,9 @@ def _slot_texture(props, name, registry, base_dir):
     return None
 
 
+_ATTACHED = object()   # registry key of the set of emitters already attached to a shape
+
+
 class FlatScene:
     def __init__(self):
         self.shapes, self.groups, self.objects, self.emitters = [], [], [], []
@@ -1015,13 +1018,17 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
         tw, tinv = _mul(tw, fm), _mul(fi, tinv)
         flip = False
     bsdfs = [c for c in sp.children if c[0] == "bsdf" or (c[0] == "ref" and registry[c[1]][0] == "bsdf")]
-    ems = [c[1] for c in sp.children if c[0] == "emitter"]
+    ems = [c[1] if c[0] == "emitter" else registry[c[1]][1] for c in sp.children if c[0] == "emitter" or (c[0] == "ref" and registry[c[1]][0] == "emitter")]
     emitter, radiance = 0, np.zeros(3, F32)
     if ems:   # src/emitters/area.cpp:64-76 on a static shape (rectangle or triangle mesh)
         if len(ems) > 1:
             raise ValueError("Only a single Emitter child object can be specified per shape.")
         if ems[0].plugin != "area":
             raise ValueError('unsupported emitter plugin "%s" inside a shape (supported: area)' % ems[0].plugin)
+        attached = registry.setdefault(_ATTACHED, set())   # an emitter declared at scene level can be referenced by ONE shape (endpoint.cpp:36-40)
+        if id(ems[0]) in attached:
+            raise ValueError("An endpoint can be only be attached to a single shape.")
+        attached.add(id(ems[0]))
         if strip_to_world:
             raise ValueError("Instancing of emitters is not supported")   # shapegroup.cpp:27-28 (an animated shape becomes an instance, xml.cpp:1165-1195)
         if "to_world" in ems[0]:
@@ -1087,6 +1094,8 @@ def load(source, params=None, is_string=False):
         elif tag == "sensor":
             fs.sensor = _sensor_record(child)
             fs.sampler = next((c[1] for c in child.children if c[0] == "sampler"), None)
+        elif tag == "emitter" and child.plugin == "area":
+            pass   # declared at scene level, attached by the shape that references it (scene.cpp:44-47 skips surface emitters among the scene's children)
         elif tag == "emitter":
             if child.plugin == "directional":   # src/emitters/directional.cpp:65-91
                 if "direction" in child:
@@ -1165,8 +1174,18 @@ def load(source, params=None, is_string=False):
                 for t2, c2, _n in child.children:
                     if t2 == "ref":
                         t2, c2 = registry[c2]
-                    if t2 == "shape":
-                        fs.shapes.append(_shape_record(c2, registry, False, base_dir))
+                    if t2 != "shape":
+                        raise ValueError("Tried to add an unsupported object to a shapegroup")
+                    # shapegroup.cpp:17-36: what a group refuses
+                    if c2.plugin == "instance":
+                        raise ValueError("Nested instancing is not permitted")
+                    if c2.plugin == "shapegroup":
+                        raise ValueError("Nested ShapeGroup is not permitted")
+                    if any(c3[0] == "sensor" for c3 in c2.children):
+                        raise ValueError("Instancing of sensors is not supported")
+                    fs.shapes.append(_shape_record(c2, registry, False, base_dir))
+                    if fs.shapes[-1]["emitter"]:
+                        raise ValueError("Instancing of emitters is not supported")
                 group_of[id(child)] = len(fs.groups)
                 fs.groups.append(dict(first_shape=first, n_shapes=len(fs.shapes) - first))
             elif child.plugin == "instance":
