@@ -471,7 +471,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                 shb = make_float4(sd.x, sd.y, sd.z, time);
                 wo = mk(dot(dd, si.sh_s), dot(dd, si.sh_t), dot(dd, si.sh_n));
             }
-            const float sample_1 = next_f32(sel); (void) sample_1;
+            float sample_1 = next_f32(sel); (void) sample_1;
             float s2x = next_f32(sel), s2y = next_f32(sel);
 
             // ---- BSDF eval_pdf + sample (twosided.cpp:111-148,219-258; diffuse.cpp:101-125,160-180)
@@ -482,6 +482,11 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             if (SPEC && (sh->nonlinear >> 1)) refl = texture_eval(sv, (sh->nonlinear >> 1) << 4, si.u, si.v);   // m_reflectance->eval(si)
             HitMaterial hm;   // specular colours and roughness of this hit: constants, or the textures on those slots (SPEC instantiations only)
             if (SPEC) hm = material_at(sv, sh, si.u, si.v);
+            // MaskBSDF (src/bsdfs/mask.cpp:125-163): with probability 1 - opacity the path goes straight on (a null interaction: wo = -wi, weight 1,
+            // pdf 1 - opacity); otherwise the nested BSDF is sampled with sample1 / opacity.  eval and pdf of the nested BSDF are scaled by the opacity.
+            const bool masked = SPEC && (sh->flags & SF_MASK);
+            bool null_pick = false;
+            if (masked) { null_pick = !(sample_1 < hm.opacity); sample_1 = sample_1 / hm.opacity; }
             V3 bsdf_val = mk(0, 0, 0), bsdf_weight = mk(0, 0, 0), bs_wo = mk(0, 0, 0);
             float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; bool bs_delta = false;
             if (SPEC && sh->bsdf == BSDF_CONDUCTOR) {
@@ -648,6 +653,10 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                     if (bs_pdf > 0.f) bsdf_weight = refl;
                     if (twosided) bs_wo.z = mulsign(bs_wo.z, si.wi.z);
                 }
+            }
+            if (masked) {
+                bsdf_val = bsdf_val * hm.opacity; bsdf_pdf *= hm.opacity;
+                if (null_pick) { bs_wo = mk(-si.wi.x, -si.wi.y, -si.wi.z); bs_eta = 1.f; bs_pdf = 1.f - hm.opacity; bs_delta = true; bsdf_weight = mk(1.f, 1.f, 1.f); }
             }
             // ---- emitter contribution candidate (dopplertofpath.cpp:214-226); committed by k_shadow if unoccluded
             if (active_em) {

@@ -269,7 +269,7 @@ DTOF_D float texture_eval_1(const SceneView &sv, uint32_t rec_off, float u, floa
 }
 // The material parameters of one hit: the shape's constants, or the lookups of the textures bound to their slots (m_specular_reflectance->eval(si),
 // m_alpha_u->eval_1(si), ...)
-struct HitMaterial { float spec_refl[3], spec_trans[3], alpha_u, alpha_v; };
+struct HitMaterial { float spec_refl[3], spec_trans[3], alpha_u, alpha_v, opacity; };
 DTOF_D HitMaterial material_at(const SceneView &sv, const DShape *sh, float u, float v) {
     HitMaterial m;
 #pragma unroll
@@ -279,6 +279,9 @@ DTOF_D HitMaterial material_at(const SceneView &sv, const DShape *sh, float u, f
     if (sh->tex_trans) { const V3 c = texture_eval(sv, sh->tex_trans << 4, u, v); m.spec_trans[0] = c.x; m.spec_trans[1] = c.y; m.spec_trans[2] = c.z; }
     if (sh->tex_alpha_u) m.alpha_u = texture_eval_1(sv, sh->tex_alpha_u << 4, u, v);
     if (sh->tex_alpha_v) m.alpha_v = texture_eval_1(sv, sh->tex_alpha_v << 4, u, v);
+    m.opacity = sh->opacity;
+    if (sh->tex_opacity) m.opacity = texture_eval_1(sv, sh->tex_opacity << 4, u, v);
+    m.opacity = fmin_(fmax_(m.opacity, 0.f), 1.f);   // MaskBSDF::eval_opacity (mask.cpp:219-221)
     return m;
 }
 // RoughPlastic::lerp_gather (roughplastic.cpp:373-383) on the 64-entry transmittance table

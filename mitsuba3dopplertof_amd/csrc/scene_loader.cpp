@@ -876,12 +876,34 @@ static void roughness_of(const Obj &b, HostShape &s) {
 
 // diffuse (src/bsdfs/diffuse.cpp), conductor (conductor.cpp:171-188), dielectric (dielectric.cpp:176-203), twosided{...} (twosided.cpp:40-70)
 static void bsdf_of(const Obj &b, HostShape &s) {
+    if (b.plugin == "mask") {   // src/bsdfs/mask.cpp:93-117: one nested BSDF seen through an opacity (float or texture, default 0.5)
+        const Obj *inner = nullptr;
+        for (auto &c : b.children) if (c.first == "bsdf") { if (inner) fail("Cannot specify more than one child BSDF"); inner = c.second.get(); }
+        if (!inner) fail("Child BSDF not specified");
+        if (inner->plugin == "mask") fail("mask: a mask nested in a mask is not supported");
+        bsdf_of(*inner, s);
+        const bool inner_twosided = s.twosided;
+        if (b.colors.count("opacity")) fail("mask: an rgb \"opacity\" is not supported (give a float or a texture)");
+        float c[3]; const int t = reflectance_of(b, "opacity", 0.5f, c);
+        s.masked = true; s.tex_opacity = t;
+        s.opacity = t >= 0 ? c[0] : (float) b.props.get_float("opacity", 0.5);
+        s.twosided = inner_twosided;
+        auto u = b.props.unqueried();
+        if (!u.empty()) fail_unreferenced(u, "bsdf", b.plugin);
+        for (size_t i = 0; i < b.children.size(); ++i) {
+            const Obj *c2 = b.children[i].second.get();
+            if (!c2 || c2->tag != "texture") continue;
+            const std::string &cname = i < b.ref_names.size() && !b.ref_names[i].empty() ? b.ref_names[i] : c2->name;
+            if (cname != "opacity") fail("unreferenced object \"" + cname + "\" in plugin of type \"mask\"");
+        }
+        return;
+    }
     if (b.plugin == "twosided") {
         const Obj *inner = nullptr; int n = 0;
         for (auto &c : b.children) if (c.first == "bsdf") { inner = c.second.get(); ++n; }
         if (n != 1) fail("twosided: exactly one nested BSDF is supported");
         bsdf_of(*inner, s);
-        if (s.bsdf == BSDF_DIELECTRIC || s.bsdf == BSDF_THINDIELECTRIC || s.bsdf == BSDF_ROUGHDIELECTRIC) fail("Only materials without a transmission component can be nested!");
+        if (s.bsdf == BSDF_DIELECTRIC || s.bsdf == BSDF_THINDIELECTRIC || s.bsdf == BSDF_ROUGHDIELECTRIC || s.masked) fail("Only materials without a transmission component can be nested!");
         s.twosided = true; return;
     }
     s.twosided = false;

@@ -1512,7 +1512,7 @@ static orc_mat material_at(const orc_shape *sh, float u, float v) {
 /* One BSDF interaction of the bounce loop: value and density for the emitter direction `wo` (only when `active_em`), and the
  * sampled continuation (BSDF::eval_pdf_sample, src/render/bsdf.cpp:20-29).  wi_in / wo / bs_wo are in the local shading frame. */
 typedef struct { v3 val; float pdf; v3 weight; v3 wo; float bs_pdf, bs_eta; int bs_delta; } orc_bsdf_out;
-static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
+static void nested_bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
     float refl[3] = { sh->reflectance[0], sh->reflectance[1], sh->reflectance[2] };   /* m_reflectance->eval(si) */
     if (sh->tex_refl) orc_texture_eval(sh->tex_refl, uv_u, uv_v, refl);
     const orc_mat m_ = material_at(sh, uv_u, uv_v);   /* m_specular_reflectance->eval(si), m_alpha_u->eval_1(si), ... */
@@ -1694,6 +1694,18 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int activ
     }
     out->val = bsdf_val; out->pdf = bsdf_pdf; out->weight = bsdf_weight; out->wo = bs_wo;
     out->bs_pdf = bs_pdf; out->bs_eta = bs_eta; out->bs_delta = bs_delta;
+}
+/* The shape's BSDF, seen through its `mask` if it has one.  MaskBSDF::eval_pdf (src/bsdfs/mask.cpp:184-207): value and density of the nested BSDF times the
+ * opacity; MaskBSDF::sample (:125-163): sample1 < opacity samples the nested BSDF with sample1 / opacity (its sample and weight are passed on unchanged),
+ * otherwise the null interaction: wo = -wi, eta 1, pdf 1 - opacity, weight 1 (BSDFFlags::Null is a delta type) */
+static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
+    if (!sh->masked) { nested_bsdf_eval_pdf_sample(sh, wi_in, wo, active_em, sample_1, s2x, s2y, uv_u, uv_v, out); return; }
+    float opacity = sh->tex_opacity ? orc_texture_eval_1(sh->tex_opacity, uv_u, uv_v) : sh->opacity;
+    opacity = f_min(f_max(opacity, 0.f), 1.f);                          /* eval_opacity (:219-221) */
+    const int nested_pick = sample_1 < opacity;
+    nested_bsdf_eval_pdf_sample(sh, wi_in, wo, active_em, sample_1 / opacity, s2x, s2y, uv_u, uv_v, out);
+    out->val = v_mul(out->val, opacity); out->pdf *= opacity;
+    if (!nested_pick) { out->wo = V(-wi_in.x, -wi_in.y, -wi_in.z); out->bs_eta = 1.f; out->bs_pdf = 1.f - opacity; out->bs_delta = 1; out->weight = V(1.f, 1.f, 1.f); }
 }
 /* mis_weight -- dopplertofpath.cpp:296-301 */
 static inline float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }

@@ -94,6 +94,8 @@ typedef struct {
     /* textures on the other slots (NULL: the constants above): specular_reflectance / specular_transmittance (Texture::eval) and the
      * roughness alpha / alpha_u / alpha_v of roughconductor / roughdielectric (Texture::eval_1) */
     const orc_texture *tex_spec, *tex_trans, *tex_alpha_u, *tex_alpha_v;
+    /* the BSDF above sits inside a `mask` (src/bsdfs/mask.cpp): m_opacity as a constant or a texture (Texture::eval_1 per hit) */
+    int32_t masked; float opacity; const orc_texture *tex_opacity;
 } orc_shape;
 
 typedef struct {

@@ -831,13 +831,31 @@ def _reflectance(props, name, default, registry, base_dir):
 
 def _bsdf_of(props, registry, base_dir=""):
     """BSDF record of a diffuse / conductor / dielectric BSDF, optionally inside twosided{...}"""
+    if props.plugin == "mask":   # src/bsdfs/mask.cpp:93-117: one nested BSDF seen through an opacity (float or texture, default 0.5)
+        inner = [c for c in props.children if c[0] == "bsdf" or (c[0] == "ref" and registry[c[1]][0] == "bsdf")]
+        if len(inner) > 1:
+            raise ValueError("Cannot specify more than one child BSDF")
+        if not inner:
+            raise ValueError("Child BSDF not specified")
+        ip = inner[0][1] if inner[0][0] == "bsdf" else registry[inner[0][1]][1]
+        if ip.plugin == "mask":
+            raise ValueError("mask: a mask nested in a mask is not supported")
+        rec = _bsdf_of(ip, registry, base_dir)
+        if "opacity" in props and props["opacity"][0] == "rgb":
+            raise ValueError('mask: an rgb "opacity" is not supported (give a float or a texture)')
+        tex = _slot_texture(props, "opacity", registry, base_dir)
+        rec["masked"] = 1
+        rec["tex_opacity"] = tex
+        rec["opacity"] = F32(tex["mean"]) if tex is not None else F32(props.get_f("opacity", 0.5))
+        props.check_unreferenced("bsdf", ())
+        return rec
     if props.plugin == "twosided":
         inner = [c for c in props.children if c[0] in ("bsdf", "ref")]
         if len(inner) != 1:
             raise ValueError("twosided: exactly one nested BSDF is supported")
         ip = inner[0][1] if inner[0][0] == "bsdf" else registry[inner[0][1]][1]
         rec = _bsdf_of(ip, registry, base_dir)
-        if rec["bsdf"] in (2, 6, 7):   # twosided.cpp:47-52
+        if rec["bsdf"] in (2, 6, 7) or rec.get("masked"):   # twosided.cpp:47-52
             raise ValueError("Only materials without a transmission component can be nested!")
         rec["twosided"] = 1
         return rec
@@ -1065,6 +1083,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
                 alpha_u=brec.get("alpha_u", F32(0.1)), alpha_v=brec.get("alpha_v", F32(0.1)), has_spec_refl=brec.get("has_spec_refl", 0),
                 mf_type=brec.get("mf_type", 1), sample_all=brec.get("sample_all", 0), tex_refl=brec.get("tex_refl"),
                 tex_spec=brec.get("tex_spec"), tex_trans=brec.get("tex_trans"), tex_alpha_u=brec.get("tex_alpha_u"), tex_alpha_v=brec.get("tex_alpha_v"),
+                masked=brec.get("masked", 0), opacity=brec.get("opacity", F32(1.0)), tex_opacity=brec.get("tex_opacity"),
                 spec_refl_mean=brec.get("spec_refl_mean"))
 
 

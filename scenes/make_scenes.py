@@ -361,6 +361,31 @@ def cornell_textured(res=128, spp=16):
     return s + LIGHT + "</scene>\n"
 
 
+def cornell_masked(res=128, spp=16):
+    """cornell_boxes.xml with `mask` BSDFs (src/bsdfs/mask.cpp): the short box's two-sided diffuse BSDF behind a checkerboard opacity, the tall box's two-sided
+    plastic (its lobe selection consumes sample1, which the mask rescales) behind a constant opacity 0.6, a free-standing one-sided veil in front of the back wall
+    whose opacity is a gray bitmap, the default opacity (0.5) on the left wall; a point light AND an area light (the emitter sample multiplies the nested value
+    and density by the opacity, MIS sees the scaled density; a null interaction is a delta sample)"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        if b[0] not in ("ShortBoxBSDF", "TallBoxBSDF", "LeftWallBSDF"):
+            s += bsdf(*b)
+    s += ('\t<bsdf type="mask" id="ShortBoxBSDF">\n\t\t<texture type="checkerboard" name="opacity">\n\t\t\t<rgb name="color0" value="0.15" />\n\t\t\t<rgb name="color1" value="0.9" />\n'
+          '\t\t\t<transform name="to_uv">\n\t\t\t\t<scale x="4" y="4" />\n\t\t\t</transform>\n\t\t</texture>\n'
+          '\t\t<bsdf type="twosided">\n\t\t\t<bsdf type="diffuse">\n\t\t\t\t<rgb name="reflectance" value="0.7, 0.6, 0.3" />\n\t\t\t</bsdf>\n\t\t</bsdf>\n\t</bsdf>\n')
+    s += ('\t<bsdf type="mask" id="TallBoxBSDF">\n\t\t<float name="opacity" value="0.6" />\n'
+          '\t\t<bsdf type="twosided">\n\t\t\t<bsdf type="plastic">\n\t\t\t\t<rgb name="diffuse_reflectance" value="0.2, 0.5, 0.7" />\n\t\t\t\t<float name="int_ior" value="1.6" />\n\t\t\t</bsdf>\n\t\t</bsdf>\n\t</bsdf>\n')
+    s += ('\t<bsdf type="mask" id="LeftWallBSDF">\n\t\t<bsdf type="twosided">\n\t\t\t<bsdf type="diffuse">\n\t\t\t\t<rgb name="reflectance" value="0.63, 0.065, 0.05" />\n\t\t\t</bsdf>\n\t\t</bsdf>\n\t</bsdf>\n')
+    s += ('\t<bsdf type="mask" id="VeilBSDF">\n\t\t<texture type="bitmap" name="opacity">\n\t\t\t<string name="filename" value="tex_gray.png" />\n\t\t\t<boolean name="raw" value="true" />\n\t\t</texture>\n'
+          '\t\t<bsdf type="diffuse">\n\t\t\t<rgb name="reflectance" value="0.4, 0.8, 0.4" />\n\t\t</bsdf>\n\t</bsdf>\n')
+    for name, m, b in WALLS:
+        s += rect(name, m, b)
+    s += ('\t<shape type="rectangle" id="Veil">\n\t\t<ref id="VeilBSDF" />\n\t\t<transform name="to_world">\n\t\t\t<scale x="0.6" y="0.5" z="1" />\n'
+          '\t\t\t<translate x="0.1" y="1.1" z="-0.55" />\n\t\t</transform>\n\t</shape>\n')
+    s += cube("ShortBox", SHORT, "ShortBoxBSDF", "0.015") + cube("TallBox", TALL, "TallBoxBSDF", "-0.015")
+    return s + LIGHT + AREA_LIGHT + "</scene>\n"
+
+
 def cornell_textured_specular(res=128, spp=16):
     """cornell_boxes.xml with textures on the OTHER slots (SURVEY 8(f)-3 leftovers): a roughconductor back wall whose roughness `alpha` is a gray bitmap
     (Texture::eval_1) and whose `specular_reflectance` is a checkerboard; a smooth-plastic short box with an RGB bitmap on `specular_reflectance`
@@ -603,6 +628,7 @@ def main():
         "cornell_disk.xml": cornell_disk(),
         "cornell_textured.xml": cornell_textured(),
         "cornell_textured_specular.xml": cornell_textured_specular(),
+        "cornell_masked.xml": cornell_masked(),
         "cornell_env.xml": cornell_env(),
         "cornell_envmap.xml": cornell_envmap(),
         "cornell_sun.xml": cornell_sun(),
@@ -623,7 +649,7 @@ def main():
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
     names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml",
-             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_textured_specular.xml", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_thinlens.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
+             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_textured_specular.xml", "cornell_masked.xml", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_thinlens.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
         return

@@ -9,6 +9,7 @@ Tolerances (stated per the task: north_star allows 1e-3 relative per-pixel L-inf
     float splat, which the reference itself leaves unordered, imageblock.cpp:119-133).
 """
 import os
+import re
 import sys
 
 import numpy as np
@@ -952,8 +953,20 @@ def _random_scene(rng, mesh_dir=None):
                 "roughconductor": '<bsdf type="roughconductor"><float name="alpha" value="%s"/>%s</bsdf>' % (f(0.05, 0.5), dist),
                 "roughdielectric": '<bsdf type="roughdielectric"><float name="alpha" value="%s"/>%s</bsdf>' % (f(0.05, 0.5), dist),
                 "roughplastic": '<bsdf type="roughplastic"><float name="alpha" value="%s"/><rgb name="diffuse_reflectance" value="%s"/>%s</bsdf>' % (f(0.05, 0.5), rgb(), dist)}[k]
+        slot = rng.random()   # textures on the other slots (specular_reflectance: Texture::eval; alpha: Texture::eval_1)
+        if slot < 0.15 and k in ("conductor", "roughconductor", "plastic", "roughplastic", "dielectric", "thindielectric", "roughdielectric"):
+            body = body.replace('</bsdf>', '<texture type="checkerboard" name="specular_reflectance"><rgb name="color0" value="%s"/><rgb name="color1" value="%s"/>'
+                                           '<transform name="to_uv"><scale x="%s" y="%s"/></transform></texture></bsdf>' % (rgb(), rgb(), f(1, 4), f(1, 4)))
+        elif slot < 0.3 and k in ("roughconductor", "roughdielectric"):
+            body = re.sub(r'<float name="alpha" value="[0-9.]+"/>', '<texture type="bitmap" name="alpha"><string name="filename" value="%s"/><boolean name="raw" value="true"/></texture>'
+                          % os.path.join(SCENES, "tex_gray.png"), body)
         if k in ("diffuse", "conductor", "plastic", "roughconductor", "roughplastic") and rng.random() < 0.7:
             body = '<bsdf type="twosided">%s</bsdf>' % body
+        if rng.random() < 0.15:   # src/bsdfs/mask.cpp: constant or checkerboard opacity
+            op = ('<float name="opacity" value="%s"/>' % f(0.1, 0.9) if rng.random() < 0.5 else
+                  '<texture type="checkerboard" name="opacity"><rgb name="color0" value="%s"/><rgb name="color1" value="%s"/><transform name="to_uv"><scale x="%s" y="%s"/></transform></texture>'
+                  % (f(0, 0.5), f(0.5, 1), f(1, 4), f(1, 4)))
+            body = '<bsdf type="mask">%s%s</bsdf>' % (op, body)
         return body
     def placement(moving):
         # unit axes only: Transform::rotate takes the axis as given (transform.h:188-191, xml.cpp:902-914) and a non-unit one makes to_object differ
