@@ -476,6 +476,20 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
 
             // ---- BSDF eval_pdf + sample (twosided.cpp:111-148,219-258; diffuse.cpp:101-125,160-180)
             bool twosided = sh->flags & SF_TWOSIDED;
+            // NormalMap (src/bsdfs/normalmap.cpp:110-179) around the plain BSDF, itself inside the two-sided adapter if there is one: the adapter's flip of
+            // wi.z / wo.z comes first (twosided.cpp:111-148), then wi and wo move into the frame of the normal map; the sampled direction comes back the
+            // same way.  A direction that changes sides between the two frames is a light leak: no value, no density, no weight.
+            const bool nmap = SPEC && (sh->flags & SF_NORMALMAP);
+            LocalFrame nf; V3 wi_plain = si.wi, wo_flipped = wo; bool nm_back = false;
+            if (nmap) {
+                nf = normalmap_frame(sv, sh, si);
+                nm_back = twosided && si.wi.z < 0.f;
+                V3 wi_f = si.wi;
+                if (nm_back) { wi_f.z = -wi_f.z; wo_flipped.z = -wo_flipped.z; }
+                si.wi = frame_to_local(nf, wi_f);
+                wo = frame_to_local(nf, wo_flipped);
+                twosided = false;
+            }
             float wiz = si.wi.z, woz = wo.z;
             if (twosided) { woz = mulsign(woz, wiz); wiz = fabsf(wiz); }
             V3 refl = mk(sh->refl[0], sh->refl[1], sh->refl[2]);
@@ -653,6 +667,16 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                     if (bs_pdf > 0.f) bsdf_weight = refl;
                     if (twosided) bs_wo.z = mulsign(bs_wo.z, si.wi.z);
                 }
+            }
+            if (nmap) {
+                if (!(wo_flipped.z * wo.z > 0.f)) { bsdf_val = mk(0, 0, 0); bsdf_pdf = 0.f; }
+                if (bsdf_weight.x != 0.f || bsdf_weight.y != 0.f || bsdf_weight.z != 0.f) {   // active &= any(weight != 0): a zero sample goes back as it is
+                    const V3 pw = frame_to_world(nf, bs_wo);
+                    if (!(bs_wo.z * pw.z > 0.f)) bsdf_weight = mk(0, 0, 0);
+                    bs_wo = pw;
+                }
+                if (nm_back) bs_wo.z = -bs_wo.z;
+                si.wi = wi_plain;
             }
             if (masked) {
                 bsdf_val = bsdf_val * hm.opacity; bsdf_pdf *= hm.opacity;

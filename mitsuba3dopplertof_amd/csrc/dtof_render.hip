@@ -367,7 +367,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     bool has_surface_emitters = false;          // area emitters make the emitter-hit term (and the last iteration) live
     for (auto &e : sc->host.emitters) has_surface_emitters |= e.kind == EMITTER_AREA || e.kind == EMITTER_CONSTANT || e.kind == EMITTER_ENVMAP;   // the environment is "hit" by the rays that leave the scene
     rp.has_area = has_surface_emitters;
-    for (auto &sh : sc->host.shapes) rp.has_spec |= sh.bsdf != BSDF_DIFFUSE || sh.masked;
+    for (auto &sh : sc->host.shapes) rp.has_spec |= sh.bsdf != BSDF_DIFFUSE || sh.masked || sh.tex_normal >= 0;
     for (auto &e : sc->host.emitters) rp.has_spec |= e.kind == EMITTER_SPOT || e.kind == EMITTER_DIRECTIONAL;
     rp.has_spec |= !sc->host.textures.empty();
     for (size_t ei = 0; ei < sc->host.emitters.size(); ++ei) if (sc->host.emitters[ei].kind == EMITTER_CONSTANT || sc->host.emitters[ei].kind == EMITTER_ENVMAP) { rp.has_env = 1; rp.env_index = (uint32_t) ei; rp.has_spec = 1; }
@@ -718,6 +718,7 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
         else if (kind == 17) for (auto &s : sc->host.shapes) v.push_back(s.sample_all ? 1.f : 0.f);
         else if (kind == 19) for (auto &s : sc->host.shapes) { v.push_back((float) s.tex_spec); v.push_back((float) s.tex_trans); v.push_back((float) s.tex_alpha_u); v.push_back((float) s.tex_alpha_v); }   // textures on the other slots: indices into the texture table, -1 = none
         else if (kind == 20) for (auto &s : sc->host.shapes) { v.push_back(s.masked ? 1.f : 0.f); v.push_back(s.opacity); v.push_back((float) s.tex_opacity); }   // mask: masked, opacity, its texture
+        else if (kind == 21) for (auto &s : sc->host.shapes) v.push_back((float) s.tex_normal);   // normalmap: its texture, -1 = none
         else if (kind == 18) for (auto &e : sc->host.emitters) {   // every emitter: kind, pos, intensity, first row of to_local (directional: its direction)
             v.push_back((float) e.kind); v.insert(v.end(), e.pos, e.pos + 3); v.insert(v.end(), e.intensity, e.intensity + 3); v.insert(v.end(), e.to_local, e.to_local + 3);
         }

@@ -9,7 +9,7 @@
 
 namespace dtof {
 
-struct Surface { V3 p, n, sh_n, sh_s, sh_t, wi; float u, v; const DShape *shape; };   // u, v = si.uv (rectangles and meshes)
+struct Surface { V3 p, n, sh_n, sh_s, sh_t, wi; float u, v; const DShape *shape; V3 dp_du; };   // u, v = si.uv (rectangles and meshes); dp_du in world space (read by normalmap frames only)
 
 // Shape::compute_surface_interaction for rectangle (rectangle.cpp:250-323) / mesh (mesh.cpp:632-864),
 // Instance::compute_surface_interaction (instance.cpp:155-250), finalize (interaction.h:493-513)
@@ -109,6 +109,7 @@ DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, 
     V3 s = normalize(vfma(si.sh_n, -dot(si.sh_n, dp_du), dp_du));
     if (dp_du.x == 0.f && dp_du.y == 0.f && dp_du.z == 0.f) { V3 tt; coordinate_system(si.sh_n, s, tt); }
     si.sh_s = s; si.sh_t = cross(si.sh_n, s);
+    si.dp_du = dp_du;
     V3 md = -d;
     si.wi = mk(dot(md, si.sh_s), dot(md, si.sh_t), dot(md, si.sh_n));
 }
@@ -284,6 +285,20 @@ DTOF_D HitMaterial material_at(const SceneView &sv, const DShape *sh, float u, f
     m.opacity = fmin_(fmax_(m.opacity, 0.f), 1.f);   // MaskBSDF::eval_opacity (mask.cpp:219-221)
     return m;
 }
+// NormalMap::frame (src/bsdfs/normalmap.cpp:181-189): the frame the nested BSDF is evaluated in, from the RGB texture at the hit: n = normalize(2 c - 1),
+// s = normalize(dp_du - n (n . dp_du)) with the interaction's dp_du AS IT IS (world space, as the reference writes it), t = n x s
+struct LocalFrame { V3 s, t, n; };
+DTOF_D LocalFrame normalmap_frame(const SceneView &sv, const DShape *sh, const Surface &si) {
+    const V3 c = texture_eval(sv, sh->tex_normal << 4, si.u, si.v);                 // m_normalmap->eval_3(si)
+    LocalFrame f;
+    f.n = normalize(mk(fmaf(c.x, 2.f, -1.f), fmaf(c.y, 2.f, -1.f), fmaf(c.z, 2.f, -1.f)));
+    const float k = dot(f.n, si.dp_du);
+    f.s = normalize(mk(fmaf(-f.n.x, k, si.dp_du.x), fmaf(-f.n.y, k, si.dp_du.y), fmaf(-f.n.z, k, si.dp_du.z)));   // fnmadd(n, dot, dp_du)
+    f.t = cross(f.n, f.s);
+    return f;
+}
+DTOF_D V3 frame_to_local(const LocalFrame &f, V3 v) { return mk(dot(v, f.s), dot(v, f.t), dot(v, f.n)); }
+DTOF_D V3 frame_to_world(const LocalFrame &f, V3 v) { return vfma(f.n, v.z, vfma(f.t, v.y, f.s * v.x)); }
 // RoughPlastic::lerp_gather (roughplastic.cpp:373-383) on the 64-entry transmittance table
 DTOF_D float lerp_gather64(const float *data, float x) {
     x *= 63.f;

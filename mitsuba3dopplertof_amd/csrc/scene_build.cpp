@@ -215,7 +215,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         const HostShape &h = sc.shapes[i]; DShape &d = shapes[i];
         memset(&d, 0, sizeof d);
         d.kind = h.kind;
-        d.flags = (h.twosided ? SF_TWOSIDED : 0) | (h.flip_normals ? SF_FLIP_NORMALS : 0) | (h.face_normals ? SF_FACE_NORMALS : 0) | (h.beckmann ? SF_BECKMANN : 0) | (h.sample_all ? SF_SAMPLE_ALL : 0) | (!h.texcoords.empty() ? SF_TEXCOORDS : 0) | (h.masked ? SF_MASK : 0);
+        d.flags = (h.twosided ? SF_TWOSIDED : 0) | (h.flip_normals ? SF_FLIP_NORMALS : 0) | (h.face_normals ? SF_FACE_NORMALS : 0) | (h.beckmann ? SF_BECKMANN : 0) | (h.sample_all ? SF_SAMPLE_ALL : 0) | (!h.texcoords.empty() ? SF_TEXCOORDS : 0) | (h.masked ? SF_MASK : 0) | (h.tex_normal >= 0 ? SF_NORMALMAP : 0);
         d.opacity = h.opacity;
         memcpy(d.refl, h.refl, 12); d.blas_root = kNoChild;
         d.bsdf = h.bsdf; d.diel_eta = h.diel_eta; d.nonlinear = h.nonlinear; d.inv_eta_2 = h.inv_eta_2; d.fdr_int = h.fdr_int; d.spec_sampling_weight = h.spec_sampling_weight; d.alpha_u = h.alpha_u; d.alpha_v = h.alpha_v;
@@ -224,8 +224,8 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
             d.rough_table = (uint32_t) tables.size() * 4u;
             for (float v : h.rough_table) { uint32_t b; memcpy(&b, &v, 4); tables.push_back(b); }
         }
-        const int tex_of_slot[6] = { h.tex_refl, h.tex_spec, h.tex_trans, h.tex_alpha_u, h.tex_alpha_v, h.tex_opacity };
-        for (uint32_t slot = 0; slot < 6; ++slot) if (tex_of_slot[slot] >= 0) {   // the texture record and its texels go to the tables area; the offsets are rebased below
+        const int tex_of_slot[7] = { h.tex_refl, h.tex_spec, h.tex_trans, h.tex_alpha_u, h.tex_alpha_v, h.tex_opacity, h.tex_normal };
+        for (uint32_t slot = 0; slot < 7; ++slot) if (tex_of_slot[slot] >= 0) {   // the texture record and its texels go to the tables area; the offsets are rebased below
             const HostTexture &t = sc.textures[(size_t) tex_of_slot[slot]];
             uint32_t &rec = tex_rec_of[(size_t) tex_of_slot[slot]];
             if (rec == 0xffffffffu) {
@@ -537,7 +537,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         const uint32_t rec_off = h.off_tables + tr.rec * 4u;
         DShape &d = shapes[tr.shape];
         if (tr.slot == 0) d.nonlinear |= (rec_off >> 4) << 1;
-        else (tr.slot == 1 ? d.tex_spec : tr.slot == 2 ? d.tex_trans : tr.slot == 3 ? d.tex_alpha_u : tr.slot == 4 ? d.tex_alpha_v : d.tex_opacity) = rec_off >> 4;
+        else (tr.slot == 1 ? d.tex_spec : tr.slot == 2 ? d.tex_trans : tr.slot == 3 ? d.tex_alpha_u : tr.slot == 4 ? d.tex_alpha_v : tr.slot == 5 ? d.tex_opacity : d.tex_normal) = rec_off >> 4;
         if (!rebased[tr.rec / 4]) { tables[tr.rec + 3] += h.off_tables; rebased[tr.rec / 4] = true; }   // DTexture::data_off, once per record
     }
     std::vector<uint8_t> blob(off, 0);

@@ -898,6 +898,26 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         }
         return;
     }
+    if (b.plugin == "normalmap") {   // src/bsdfs/normalmap.cpp:84-108: one nested BSDF evaluated in the frame an RGB texture gives
+        const Obj *inner = nullptr;
+        for (auto &c : b.children) if (c.first == "bsdf") { if (inner) fail("Only a single BSDF child object can be specified."); inner = c.second.get(); }
+        if (!inner) fail("Exactly one BSDF child object must be specified.");
+        if (inner->plugin == "twosided" || inner->plugin == "mask" || inner->plugin == "normalmap")
+            fail("normalmap: a \"" + inner->plugin + "\" nested in a normalmap is not supported in this build (nest the normalmap inside it instead)");
+        bsdf_of(*inner, s);
+        float c[3]; s.tex_normal = reflectance_of(b, "normalmap", 0.f, c);
+        if (s.tex_normal < 0) fail("Property \"normalmap\" has not been specified!");
+        if ((*g_textures)[(size_t) s.tex_normal].channels != 3 && (*g_textures)[(size_t) s.tex_normal].kind == TEX_BITMAP) fail("normalmap: the texture must have three channels");
+        auto u = b.props.unqueried();
+        if (!u.empty()) fail_unreferenced(u, "bsdf", b.plugin);
+        for (size_t i = 0; i < b.children.size(); ++i) {
+            const Obj *c2 = b.children[i].second.get();
+            if (!c2 || c2->tag != "texture") continue;
+            const std::string &cname = i < b.ref_names.size() && !b.ref_names[i].empty() ? b.ref_names[i] : c2->name;
+            if (cname != "normalmap") fail("unreferenced object \"" + cname + "\" in plugin of type \"normalmap\"");
+        }
+        return;
+    }
     if (b.plugin == "twosided") {
         const Obj *inner = nullptr; int n = 0;
         for (auto &c : b.children) if (c.first == "bsdf") { inner = c.second.get(); ++n; }

@@ -1695,15 +1695,40 @@ static void nested_bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, in
     out->val = bsdf_val; out->pdf = bsdf_pdf; out->weight = bsdf_weight; out->wo = bs_wo;
     out->bs_pdf = bs_pdf; out->bs_eta = bs_eta; out->bs_delta = bs_delta;
 }
+/* NormalMap (src/bsdfs/normalmap.cpp:110-189) around the plain BSDF, itself inside the two-sided adapter if the shape has one: TwoSidedBRDF flips wi.z and
+ * wo.z on the back side first (twosided.cpp:111-148,219-258), NormalMap::frame builds n = normalize(2 c - 1) from the texture, s = normalize(dp_du - n (n . dp_du))
+ * with the interaction's dp_du as it is, t = n x s; wi and wo go into that frame, the nested BSDF is evaluated / sampled there, the sampled direction comes back
+ * through the frame and the adapter.  cos_theta(wo) * cos_theta(perturbed wo) <= 0 (a light leak): no value, no density, no weight. */
+static void framed_bsdf_eval_pdf_sample(const orc_shape *sh, v3 dp_du, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
+    if (!sh->tex_normal) { nested_bsdf_eval_pdf_sample(sh, wi_in, wo, active_em, sample_1, s2x, s2y, uv_u, uv_v, out); return; }
+    float c[3]; orc_texture_eval(sh->tex_normal, uv_u, uv_v, c);                 /* m_normalmap->eval_3(si) */
+    const v3 n = v_normalize(V(fmaf(c[0], 2.f, -1.f), fmaf(c[1], 2.f, -1.f), fmaf(c[2], 2.f, -1.f)));
+    const float k = v_dot(n, dp_du);
+    const v3 s = v_normalize(V(fmaf(-n.x, k, dp_du.x), fmaf(-n.y, k, dp_du.y), fmaf(-n.z, k, dp_du.z)));
+    const v3 t = v_cross(n, s);
+    const int back = sh->twosided && wi_in.z < 0.f;
+    v3 wi_f = wi_in, wo_f = wo;
+    if (back) { wi_f.z = -wi_f.z; wo_f.z = -wo_f.z; }
+    const v3 wi_p = V(v_dot(wi_f, s), v_dot(wi_f, t), v_dot(wi_f, n)), wo_p = V(v_dot(wo_f, s), v_dot(wo_f, t), v_dot(wo_f, n));
+    orc_shape plain = *sh; plain.twosided = 0;
+    nested_bsdf_eval_pdf_sample(&plain, wi_p, wo_p, active_em, sample_1, s2x, s2y, uv_u, uv_v, out);
+    if (!(wo_f.z * wo_p.z > 0.f)) { out->val = V(0, 0, 0); out->pdf = 0.f; }
+    if (out->weight.x != 0.f || out->weight.y != 0.f || out->weight.z != 0.f) {
+        const v3 pw = v_fma(n, out->wo.z, v_fma(t, out->wo.y, v_mul(s, out->wo.x)));   /* perturbed_si.to_world(bs.wo) */
+        if (!(out->wo.z * pw.z > 0.f)) out->weight = V(0, 0, 0);
+        out->wo = pw;
+    }
+    if (back) out->wo.z = -out->wo.z;
+}
 /* The shape's BSDF, seen through its `mask` if it has one.  MaskBSDF::eval_pdf (src/bsdfs/mask.cpp:184-207): value and density of the nested BSDF times the
  * opacity; MaskBSDF::sample (:125-163): sample1 < opacity samples the nested BSDF with sample1 / opacity (its sample and weight are passed on unchanged),
  * otherwise the null interaction: wo = -wi, eta 1, pdf 1 - opacity, weight 1 (BSDFFlags::Null is a delta type) */
-static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
-    if (!sh->masked) { nested_bsdf_eval_pdf_sample(sh, wi_in, wo, active_em, sample_1, s2x, s2y, uv_u, uv_v, out); return; }
+static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 dp_du, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
+    if (!sh->masked) { framed_bsdf_eval_pdf_sample(sh, dp_du, wi_in, wo, active_em, sample_1, s2x, s2y, uv_u, uv_v, out); return; }
     float opacity = sh->tex_opacity ? orc_texture_eval_1(sh->tex_opacity, uv_u, uv_v) : sh->opacity;
     opacity = f_min(f_max(opacity, 0.f), 1.f);                          /* eval_opacity (:219-221) */
     const int nested_pick = sample_1 < opacity;
-    nested_bsdf_eval_pdf_sample(sh, wi_in, wo, active_em, sample_1 / opacity, s2x, s2y, uv_u, uv_v, out);
+    framed_bsdf_eval_pdf_sample(sh, dp_du, wi_in, wo, active_em, sample_1 / opacity, s2x, s2y, uv_u, uv_v, out);
     out->val = v_mul(out->val, opacity); out->pdf *= opacity;
     if (!nested_pick) { out->wo = V(-wi_in.x, -wi_in.y, -wi_in.z); out->bs_eta = 1.f; out->bs_pdf = 1.f - opacity; out->bs_delta = 1; out->weight = V(1.f, 1.f, 1.f); }
 }
@@ -1973,7 +1998,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; int bs_delta = 0;
         if (hit) {
             orc_bsdf_out bo;
-            bsdf_eval_pdf_sample(si.shape, si.wi, wo, active_em, sample_1, s2x, s2y, si.uv_u, si.uv_v, &bo);
+            bsdf_eval_pdf_sample(si.shape, si.dp_du, si.wi, wo, active_em, sample_1, s2x, s2y, si.uv_u, si.uv_v, &bo);
             bsdf_val = bo.val; bsdf_pdf = bo.pdf; bsdf_weight = bo.weight; bs_wo = bo.wo; bs_pdf = bo.bs_pdf; bs_eta = bo.bs_eta; bs_delta = bo.bs_delta;
         }
         if (active_em) {   /* :214-226 */
@@ -2571,7 +2596,7 @@ int orc_kat_ray_intersect(const orc_scene *sc, const float *o, const float *d, f
  * out = value[3], pdf, bs.wo[3], bs.pdf, bs.eta, bs.delta, weight[3] (13 floats) */
 void orc_kat_bsdf(const orc_shape *sh, const float *wi, const float *wo, const float *s3, float *out) {
     orc_bsdf_out r;
-    bsdf_eval_pdf_sample(sh, V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]), 1, s3[0], s3[1], s3[2], 0.f, 0.f, &r);
+    bsdf_eval_pdf_sample(sh, V(1.f, 0.f, 0.f), V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]), 1, s3[0], s3[1], s3[2], 0.f, 0.f, &r);
     out[0] = r.val.x; out[1] = r.val.y; out[2] = r.val.z; out[3] = r.pdf;
     out[4] = r.wo.x; out[5] = r.wo.y; out[6] = r.wo.z; out[7] = r.bs_pdf; out[8] = r.bs_eta; out[9] = (float) r.bs_delta;
     out[10] = r.weight.x; out[11] = r.weight.y; out[12] = r.weight.z;

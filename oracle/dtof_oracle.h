@@ -96,6 +96,8 @@ typedef struct {
     const orc_texture *tex_spec, *tex_trans, *tex_alpha_u, *tex_alpha_v;
     /* the BSDF above sits inside a `mask` (src/bsdfs/mask.cpp): m_opacity as a constant or a texture (Texture::eval_1 per hit) */
     int32_t masked; float opacity; const orc_texture *tex_opacity;
+    /* the plain BSDF sits inside a `normalmap` (src/bsdfs/normalmap.cpp; a twosided around it is applied first): its RGB texture (Texture::eval_3 per hit) */
+    const orc_texture *tex_normal;
 } orc_shape;
 
 typedef struct {

@@ -849,6 +849,24 @@ def _bsdf_of(props, registry, base_dir=""):
         rec["opacity"] = F32(tex["mean"]) if tex is not None else F32(props.get_f("opacity", 0.5))
         props.check_unreferenced("bsdf", ())
         return rec
+    if props.plugin == "normalmap":   # src/bsdfs/normalmap.cpp:84-108: one nested BSDF evaluated in the frame an RGB texture gives
+        inner = [c for c in props.children if c[0] == "bsdf" or (c[0] == "ref" and registry[c[1]][0] == "bsdf")]
+        if len(inner) > 1:
+            raise ValueError("Only a single BSDF child object can be specified.")
+        if not inner:
+            raise ValueError("Exactly one BSDF child object must be specified.")
+        ip = inner[0][1] if inner[0][0] == "bsdf" else registry[inner[0][1]][1]
+        if ip.plugin in ("twosided", "mask", "normalmap"):
+            raise ValueError('normalmap: a "%s" nested in a normalmap is not supported in this build (nest the normalmap inside it instead)' % ip.plugin)
+        rec = _bsdf_of(ip, registry, base_dir)
+        tex = _slot_texture(props, "normalmap", registry, base_dir)
+        if tex is None:
+            raise ValueError('Property "normalmap" has not been specified!')
+        if tex["kind"] == 1 and tex["channels"] != 3:
+            raise ValueError("normalmap: the texture must have three channels")
+        rec["tex_normal"] = tex
+        props.check_unreferenced("bsdf", ())
+        return rec
     if props.plugin == "twosided":
         inner = [c for c in props.children if c[0] in ("bsdf", "ref")]
         if len(inner) != 1:
@@ -1083,7 +1101,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
                 alpha_u=brec.get("alpha_u", F32(0.1)), alpha_v=brec.get("alpha_v", F32(0.1)), has_spec_refl=brec.get("has_spec_refl", 0),
                 mf_type=brec.get("mf_type", 1), sample_all=brec.get("sample_all", 0), tex_refl=brec.get("tex_refl"),
                 tex_spec=brec.get("tex_spec"), tex_trans=brec.get("tex_trans"), tex_alpha_u=brec.get("tex_alpha_u"), tex_alpha_v=brec.get("tex_alpha_v"),
-                masked=brec.get("masked", 0), opacity=brec.get("opacity", F32(1.0)), tex_opacity=brec.get("tex_opacity"),
+                masked=brec.get("masked", 0), opacity=brec.get("opacity", F32(1.0)), tex_opacity=brec.get("tex_opacity"), tex_normal=brec.get("tex_normal"),
                 spec_refl_mean=brec.get("spec_refl_mean"))
 
 

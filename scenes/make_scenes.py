@@ -186,6 +186,17 @@ def texture_files():
     gray = [[(x * x * 3 + y * 29 + 10) % 256 for x in range(8)] for y in range(8)]
     write_png(os.path.join(HERE, "tex_rgb.png"), rgb)
     write_png(os.path.join(HERE, "tex_gray.png"), gray)
+    # tex_normal.png: a 16 x 16 tangent-space normal map (bumps: a sine in x, a cosine in y; rgb = (n + 1) / 2), some texels tilted far enough for light leaks
+    nm = []
+    for y in range(16):
+        row = []
+        for x in range(16):
+            nx, ny = 0.55 * math.sin(x * 0.9 + 0.3), 0.45 * math.cos(y * 1.1) * (1.6 if (x + y) % 5 == 0 else 1.0)
+            nz = math.sqrt(max(1.0 - nx * nx - ny * ny, 0.04))
+            l = math.sqrt(nx * nx + ny * ny + nz * nz)
+            row.append(tuple(int(round(255 * (c / l * 0.5 + 0.5))) for c in (nx, ny, nz)))
+        nm.append(row)
+    write_png(os.path.join(HERE, "tex_normal.png"), nm)
     try:   # the same pattern, enlarged and JPEG-coded (4:2:0), for the baseline JPEG reader; PIL is test infrastructure
         from PIL import Image
         big = [[rgb[y // 4][x // 4] for x in range(64)] for y in range(48)]
@@ -382,6 +393,29 @@ def cornell_masked(res=128, spp=16):
         s += rect(name, m, b)
     s += ('\t<shape type="rectangle" id="Veil">\n\t\t<ref id="VeilBSDF" />\n\t\t<transform name="to_world">\n\t\t\t<scale x="0.6" y="0.5" z="1" />\n'
           '\t\t\t<translate x="0.1" y="1.1" z="-0.55" />\n\t\t</transform>\n\t</shape>\n')
+    s += cube("ShortBox", SHORT, "ShortBoxBSDF", "0.015") + cube("TallBox", TALL, "TallBoxBSDF", "-0.015")
+    return s + LIGHT + AREA_LIGHT + "</scene>\n"
+
+
+def cornell_normalmap(res=128, spp=16):
+    """cornell_boxes.xml with `normalmap` BSDFs (src/bsdfs/normalmap.cpp): the back wall a two-sided normal-mapped diffuse BSDF (the adapter outside, as exporters write it),
+    the floor a two-sided normal-mapped roughconductor, the short box a mask around a two-sided normal-mapped plastic, the tall box a ONE-sided normal-mapped diffuse
+    BSDF with a checkerboard "normal map" (two constant tilted normals); point + area light"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        if b[0] not in ("ShortBoxBSDF", "TallBoxBSDF", "BackWallBSDF", "FloorBSDF"):
+            s += bsdf(*b)
+    nm = ('<texture type="bitmap" name="normalmap"><string name="filename" value="tex_normal.png" /><boolean name="raw" value="true" />'
+          '<transform name="to_uv"><scale x="%s" y="%s" /></transform></texture>')
+    s += '\t<bsdf type="twosided" id="BackWallBSDF"><bsdf type="normalmap">' + nm % ("2", "2") + '<bsdf type="diffuse"><rgb name="reflectance" value="0.725, 0.71, 0.68" /></bsdf></bsdf></bsdf>\n'
+    s += ('\t<bsdf type="twosided" id="FloorBSDF"><bsdf type="normalmap">' + nm % ("3", "1.5") + '<bsdf type="roughconductor"><string name="distribution" value="ggx" /><float name="alpha" value="0.25" />'
+          '<rgb name="eta" value="0.2, 0.92, 1.1" /><rgb name="k" value="3.9, 2.45, 2.14" /></bsdf></bsdf></bsdf>\n')
+    s += ('\t<bsdf type="mask" id="ShortBoxBSDF"><float name="opacity" value="0.8" /><bsdf type="twosided"><bsdf type="normalmap">' + nm % ("1", "1")
+          + '<bsdf type="plastic"><rgb name="diffuse_reflectance" value="0.7, 0.3, 0.2" /></bsdf></bsdf></bsdf></bsdf>\n')
+    s += ('\t<bsdf type="normalmap" id="TallBoxBSDF"><texture type="checkerboard" name="normalmap"><rgb name="color0" value="0.62, 0.5, 0.95" /><rgb name="color1" value="0.4, 0.65, 0.9" />'
+          '<transform name="to_uv"><scale x="3" y="3" /></transform></texture><bsdf type="diffuse"><rgb name="reflectance" value="0.3, 0.6, 0.8" /></bsdf></bsdf>\n')
+    for name, m, b in WALLS:
+        s += rect(name, m, b)
     s += cube("ShortBox", SHORT, "ShortBoxBSDF", "0.015") + cube("TallBox", TALL, "TallBoxBSDF", "-0.015")
     return s + LIGHT + AREA_LIGHT + "</scene>\n"
 
@@ -629,6 +663,7 @@ def main():
         "cornell_textured.xml": cornell_textured(),
         "cornell_textured_specular.xml": cornell_textured_specular(),
         "cornell_masked.xml": cornell_masked(),
+        "cornell_normalmap.xml": cornell_normalmap(),
         "cornell_env.xml": cornell_env(),
         "cornell_envmap.xml": cornell_envmap(),
         "cornell_sun.xml": cornell_sun(),
@@ -649,7 +684,7 @@ def main():
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
     names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml",
-             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_textured_specular.xml", "cornell_masked.xml", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_thinlens.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
+             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_textured_specular.xml", "cornell_masked.xml", "cornell_normalmap.xml", "tex_normal.png", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_thinlens.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
         return
