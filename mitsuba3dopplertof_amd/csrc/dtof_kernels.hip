@@ -479,10 +479,10 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             // NormalMap (src/bsdfs/normalmap.cpp:110-179) around the plain BSDF, itself inside the two-sided adapter if there is one: the adapter's flip of
             // wi.z / wo.z comes first (twosided.cpp:111-148), then wi and wo move into the frame of the normal map; the sampled direction comes back the
             // same way.  A direction that changes sides between the two frames is a light leak: no value, no density, no weight.
-            const bool nmap = SPEC && (sh->flags & SF_NORMALMAP);
+            const bool nmap = SPEC && (sh->flags & (SF_NORMALMAP | SF_BUMPMAP));   // BumpMap (src/bsdfs/bumpmap.cpp:114-197) wraps its nested BSDF the same way
             LocalFrame nf; V3 wi_plain = si.wi, wo_flipped = wo; bool nm_back = false;
             if (nmap) {
-                nf = normalmap_frame(sv, sh, si);
+                nf = (sh->flags & SF_BUMPMAP) ? bumpmap_frame(sv, sh, si) : normalmap_frame(sv, sh, si);
                 nm_back = twosided && si.wi.z < 0.f;
                 V3 wi_f = si.wi;
                 if (nm_back) { wi_f.z = -wi_f.z; wo_flipped.z = -wo_flipped.z; }

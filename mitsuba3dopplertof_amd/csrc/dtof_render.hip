@@ -718,7 +718,8 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
         else if (kind == 17) for (auto &s : sc->host.shapes) v.push_back(s.sample_all ? 1.f : 0.f);
         else if (kind == 19) for (auto &s : sc->host.shapes) { v.push_back((float) s.tex_spec); v.push_back((float) s.tex_trans); v.push_back((float) s.tex_alpha_u); v.push_back((float) s.tex_alpha_v); }   // textures on the other slots: indices into the texture table, -1 = none
         else if (kind == 20) for (auto &s : sc->host.shapes) { v.push_back(s.masked ? 1.f : 0.f); v.push_back(s.opacity); v.push_back((float) s.tex_opacity); }   // mask: masked, opacity, its texture
-        else if (kind == 21) for (auto &s : sc->host.shapes) v.push_back((float) s.tex_normal);   // normalmap: its texture, -1 = none
+        else if (kind == 21) for (auto &s : sc->host.shapes) v.push_back((float) s.tex_normal);   // normalmap / bumpmap: its texture, -1 = none
+        else if (kind == 22) for (auto &s : sc->host.shapes) { v.push_back(s.bumpmap ? 1.f : 0.f); v.push_back(s.bump_scale); }   // bumpmap: is one, scale
         else if (kind == 18) for (auto &e : sc->host.emitters) {   // every emitter: kind, pos, intensity, first row of to_local (directional: its direction)
             v.push_back((float) e.kind); v.insert(v.end(), e.pos, e.pos + 3); v.insert(v.end(), e.intensity, e.intensity + 3); v.insert(v.end(), e.to_local, e.to_local + 3);
         }

@@ -18,6 +18,7 @@ enum TimeSampling : int32_t { TIME_UNIFORM = 0, TIME_STRATIFIED = 1, TIME_ANTITH
 enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1, FILTER_GAUSSIAN = 2, FILTER_MITCHELL = 3, FILTER_CATMULLROM = 4, FILTER_LANCZOS = 5 };
 enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4, SF_EMITTER = 8, SF_BECKMANN = 16 /* rough BSDFs: Beckmann instead of GGX */, SF_SAMPLE_ALL = 64 /* rough BSDFs: sample_visible = false */, SF_MASK = 128 /* the BSDF sits inside a `mask` (src/bsdfs/mask.cpp): DShape::opacity / tex_opacity */,
                             SF_NORMALMAP = 256 /* the BSDF sits inside a `normalmap` (src/bsdfs/normalmap.cpp): DShape::tex_normal; a twosided around it is applied first */,
+                            SF_BUMPMAP = 512 /* ... or inside a `bumpmap` (src/bsdfs/bumpmap.cpp): tex_normal is its height texture, bump_scale its `scale` */,
                             SF_TEXCOORDS = 32 /* mesh with vertex texcoords (si.uv interpolates them; otherwise si.uv = the barycentrics, mesh.cpp:720-737) */ };
 enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4, BSDF_ROUGHPLASTIC = 5, BSDF_THINDIELECTRIC = 6, BSDF_ROUGHDIELECTRIC = 7 };
 enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1, EMITTER_SPOT = 2, EMITTER_CONSTANT = 3, EMITTER_ENVMAP = 4, EMITTER_DIRECTIONAL = 5 };
@@ -106,7 +107,8 @@ struct DShape {             // 336 B
     uint32_t tex_spec, tex_trans, tex_alpha_u, tex_alpha_v;
     // SF_MASK: m_opacity of the enclosing `mask` BSDF (mask.cpp:95): the constant (or the texture's mean) and the texture record, as above (Texture::eval_1 per hit)
     float opacity; uint32_t tex_opacity;
-    uint32_t tex_normal, pad_mask;                       // SF_NORMALMAP: m_normalmap of the enclosing `normalmap` BSDF (normalmap.cpp:97), Texture::eval_3 per hit
+    uint32_t tex_normal; float bump_scale;               // SF_NORMALMAP: m_normalmap of the enclosing `normalmap` BSDF (normalmap.cpp:97), Texture::eval_3 per hit;
+                                                         // SF_BUMPMAP: m_nested_texture (Texture::eval_1_grad per hit) and m_scale of the enclosing `bumpmap` (bumpmap.cpp:93-112)
 };
 // Texture on a BSDF's diffuse reflectance (src/textures/checkerboard.cpp, src/textures/bitmap.cpp); the record and, for bitmaps, the
 // linear float32 texels (row 0 first) live in the tables area of the blob.  to_uv: the 2x2 linear part of the plugin's `to_uv`
@@ -160,6 +162,7 @@ struct HostShape {
     int tex_refl = -1;                     // texture on reflectance / diffuse_reflectance: index into HostScene::textures
     int tex_spec = -1, tex_trans = -1, tex_alpha_u = -1, tex_alpha_v = -1;   // textures on specular_reflectance / specular_transmittance / the roughness (alpha sets both)
     int tex_normal = -1;                                                      // the BSDF sits inside a `normalmap` (src/bsdfs/normalmap.cpp): its RGB texture
+    bool bumpmap = false; float bump_scale = 1.f;                             // ... or inside a `bumpmap` (src/bsdfs/bumpmap.cpp): tex_normal is the height texture
     bool masked = false; float opacity = 1.f; int tex_opacity = -1;           // the BSDF sits inside a `mask` (src/bsdfs/mask.cpp): its opacity (float or texture, eval_1)
     std::vector<float> rough_table;        // roughplastic: m_external_transmittance (64 values)
     float to_world[16], to_object[16];     // float casts of the double transform and its double inverse

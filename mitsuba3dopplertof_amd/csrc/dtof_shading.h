@@ -9,7 +9,7 @@
 
 namespace dtof {
 
-struct Surface { V3 p, n, sh_n, sh_s, sh_t, wi; float u, v; const DShape *shape; V3 dp_du; };   // u, v = si.uv (rectangles and meshes); dp_du in world space (read by normalmap frames only)
+struct Surface { V3 p, n, sh_n, sh_s, sh_t, wi; float u, v; const DShape *shape; V3 dp_du, dp_dv; };   // u, v = si.uv (rectangles and meshes); dp_du, dp_dv in world space (read by normalmap / bumpmap frames only)
 
 // Shape::compute_surface_interaction for rectangle (rectangle.cpp:250-323) / mesh (mesh.cpp:632-864),
 // Instance::compute_surface_interaction (instance.cpp:155-250), finalize (interaction.h:493-513)
@@ -103,13 +103,13 @@ DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, 
         si.p = xf_point(m, si.p);
         si.n = normalize(xf_normal(inv, si.n));
         si.sh_n = normalize(xf_normal(inv, si.sh_n));
-        dp_du = xf_vector(m, dp_du);
+        dp_du = xf_vector(m, dp_du); dp_dv = xf_vector(m, dp_dv);   // instance.cpp:201-202
     }
     // initialize_sh_frame (interaction.h:258-268)
     V3 s = normalize(vfma(si.sh_n, -dot(si.sh_n, dp_du), dp_du));
     if (dp_du.x == 0.f && dp_du.y == 0.f && dp_du.z == 0.f) { V3 tt; coordinate_system(si.sh_n, s, tt); }
     si.sh_s = s; si.sh_t = cross(si.sh_n, s);
-    si.dp_du = dp_du;
+    si.dp_du = dp_du; si.dp_dv = dp_dv;
     V3 md = -d;
     si.wi = mk(dot(md, si.sh_s), dot(md, si.sh_t), dot(md, si.sh_n));
 }
@@ -294,6 +294,43 @@ DTOF_D LocalFrame normalmap_frame(const SceneView &sv, const DShape *sh, const S
     f.n = normalize(mk(fmaf(c.x, 2.f, -1.f), fmaf(c.y, 2.f, -1.f), fmaf(c.z, 2.f, -1.f)));
     const float k = dot(f.n, si.dp_du);
     f.s = normalize(mk(fmaf(-f.n.x, k, si.dp_du.x), fmaf(-f.n.y, k, si.dp_du.y), fmaf(-f.n.z, k, si.dp_du.z)));   // fnmadd(n, dot, dp_du)
+    f.t = cross(f.n, f.s);
+    return f;
+}
+// BitmapTexture::eval_1_grad (src/textures/bitmap.cpp:346-421): the gradient of the bilinear interpolant of the (luminance of the) four texels around the
+// lookup, through the transpose of the uv transform, times the resolution; the nearest filter has none
+DTOF_D void texture_eval_1_grad(const SceneView &sv, uint32_t rec_off, float u, float v, float &gu, float &gv) {
+    const DTexture &tex = *(const DTexture *) (sv.base + rec_off);
+    gu = gv = 0.f;
+    const uint32_t filter = (tex.kind_flags >> 8) & 0xffu, wrap = (tex.kind_flags >> 16) & 0xffu, C = tex.kind_flags >> 24;
+    if ((tex.kind_flags & 0xffu) != TEX_BITMAP || filter == 0) return;
+    const float tu = fmaf(tex.to_uv[1], v, fmaf(tex.to_uv[0], u, 0.f)), tv = fmaf(tex.to_uv[3], v, fmaf(tex.to_uv[2], u, 0.f));
+    const int32_t W = (int32_t) tex.width, H = (int32_t) tex.height;
+    const float *data = (const float *) (sv.base + tex.data_off);
+    const float px = fmaf(tu, (float) W, -.5f), py = fmaf(tv, (float) H, -.5f), fx = floorf(px), fy = floorf(py);
+    const float w1x = px - fx, w1y = py - fy, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    const int32_t x0 = tex_wrap((int32_t) fx, W, wrap), x1 = tex_wrap((int32_t) fx + 1, W, wrap);
+    const int32_t y0 = tex_wrap((int32_t) fy, H, wrap), y1 = tex_wrap((int32_t) fy + 1, H, wrap);
+    auto fetch = [&](int32_t x, int32_t y) {
+        const float *t = data + ((size_t) y * W + x) * C;
+        return C == 1 ? t[0] : t[0] * 0.212671f + t[1] * 0.715160f + t[2] * 0.072169f;   // luminance (spectrum.h:431-434)
+    };
+    const float f00 = fetch(x0, y0), f10 = fetch(x1, y0), f01 = fetch(x0, y1), f11 = fetch(x1, y1);
+    const float dfx = fmaf(w0y, f10 - f00, w1y * (f11 - f01)), dfy = fmaf(w0x, f01 - f00, w1x * (f11 - f10));
+    gu = (float) W * (tex.to_uv[0] * dfx + tex.to_uv[2] * dfy);
+    gv = (float) H * (tex.to_uv[1] * dfx + tex.to_uv[3] * dfy);
+}
+// BumpMap::frame (src/bsdfs/bumpmap.cpp:199-222): the surface displaced along its shading normal by the height texture, to first order
+DTOF_D LocalFrame bumpmap_frame(const SceneView &sv, const DShape *sh, const Surface &si) {
+    float gu, gv; texture_eval_1_grad(sv, sh->tex_normal << 4, si.u, si.v, gu, gv);
+    gu *= sh->bump_scale; gv *= sh->bump_scale;
+    const V3 dp_du = vfma(si.sh_n, gu - dot(si.sh_n, si.dp_du), si.dp_du), dp_dv = vfma(si.sh_n, gv - dot(si.sh_n, si.dp_dv), si.dp_dv);
+    V3 n = normalize(cross(dp_du, dp_dv));
+    if (dot(si.n, n) < 0.f) n = -n;
+    LocalFrame f;
+    f.n = mk(dot(n, si.sh_s), dot(n, si.sh_t), dot(n, si.sh_n));                  // si.to_local(n)
+    const float k = dot(f.n, si.dp_du);
+    f.s = normalize(mk(fmaf(-f.n.x, k, si.dp_du.x), fmaf(-f.n.y, k, si.dp_du.y), fmaf(-f.n.z, k, si.dp_du.z)));
     f.t = cross(f.n, f.s);
     return f;
 }

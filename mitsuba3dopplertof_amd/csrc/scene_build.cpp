@@ -215,7 +215,8 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         const HostShape &h = sc.shapes[i]; DShape &d = shapes[i];
         memset(&d, 0, sizeof d);
         d.kind = h.kind;
-        d.flags = (h.twosided ? SF_TWOSIDED : 0) | (h.flip_normals ? SF_FLIP_NORMALS : 0) | (h.face_normals ? SF_FACE_NORMALS : 0) | (h.beckmann ? SF_BECKMANN : 0) | (h.sample_all ? SF_SAMPLE_ALL : 0) | (!h.texcoords.empty() ? SF_TEXCOORDS : 0) | (h.masked ? SF_MASK : 0) | (h.tex_normal >= 0 ? SF_NORMALMAP : 0);
+        d.flags = (h.twosided ? SF_TWOSIDED : 0) | (h.flip_normals ? SF_FLIP_NORMALS : 0) | (h.face_normals ? SF_FACE_NORMALS : 0) | (h.beckmann ? SF_BECKMANN : 0) | (h.sample_all ? SF_SAMPLE_ALL : 0) | (!h.texcoords.empty() ? SF_TEXCOORDS : 0) | (h.masked ? SF_MASK : 0) | (h.tex_normal >= 0 ? (h.bumpmap ? SF_BUMPMAP : SF_NORMALMAP) : 0);
+        d.bump_scale = h.bump_scale;
         d.opacity = h.opacity;
         memcpy(d.refl, h.refl, 12); d.blas_root = kNoChild;
         d.bsdf = h.bsdf; d.diel_eta = h.diel_eta; d.nonlinear = h.nonlinear; d.inv_eta_2 = h.inv_eta_2; d.fdr_int = h.fdr_int; d.spec_sampling_weight = h.spec_sampling_weight; d.alpha_u = h.alpha_u; d.alpha_v = h.alpha_v;

@@ -829,6 +829,16 @@ static HostTexture texture_of(const Obj &t) {
     return tex;
 }
 // a BSDF's reflectance-like property: a colour (-> out, returns -1) or a texture child of that name (-> out = its mean, returns its index)
+// index of a texture object in the scene's texture table (decoded and stored on first use)
+static int texture_index_of(const Obj *c) {
+    if (!g_textures || !g_texture_index) fail("internal error: no texture table");
+    auto known = g_texture_index->find((const void *) c);
+    if (known == g_texture_index->end()) {
+        g_textures->push_back(texture_of(*c));
+        known = g_texture_index->emplace((const void *) c, (int) g_textures->size() - 1).first;
+    }
+    return known->second;
+}
 static int reflectance_of(const Obj &b, const char *name, float def, float out[3]) {
     for (size_t i = 0; i < b.children.size(); ++i) {
         const Obj *c = b.children[i].second.get();
@@ -836,14 +846,9 @@ static int reflectance_of(const Obj &b, const char *name, float def, float out[3
         const std::string &cname = i < b.ref_names.size() && !b.ref_names[i].empty() ? b.ref_names[i] : c->name;
         if (cname != name) continue;
         if (c->tag != "texture") fail(std::string("property \"") + name + "\" must be a colour or a texture");
-        if (!g_textures || !g_texture_index) fail("internal error: no texture table");
-        auto known = g_texture_index->find((const void *) c);
-        if (known == g_texture_index->end()) {
-            g_textures->push_back(texture_of(*c));
-            known = g_texture_index->emplace((const void *) c, (int) g_textures->size() - 1).first;
-        }
-        out[0] = out[1] = out[2] = (*g_textures)[(size_t) known->second].mean;
-        return known->second;
+        const int index = texture_index_of(c);
+        out[0] = out[1] = out[2] = (*g_textures)[(size_t) index].mean;
+        return index;
     }
     color_of(b, name, def, out);
     return -1;
@@ -898,11 +903,30 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         }
         return;
     }
+    if (b.plugin == "bumpmap") {   // src/bsdfs/bumpmap.cpp:84-112: one nested BSDF in the frame the gradient of ONE height texture (any property name) gives
+        const Obj *inner = nullptr, *tex = nullptr;
+        for (auto &c : b.children) {
+            if (c.first == "bsdf") { if (inner) fail("Only a single BSDF child object can be specified."); inner = c.second.get(); }
+            else if (c.first == "texture") { if (tex) fail("Only a single Texture child object can be specified."); tex = c.second.get(); }
+        }
+        if (!inner) fail("Exactly one BSDF child object must be specified.");
+        if (!tex) fail("Exactly one Texture child object must be specified.");
+        if (inner->plugin == "twosided" || inner->plugin == "mask" || inner->plugin == "normalmap" || inner->plugin == "bumpmap")
+            fail("bumpmap: a \"" + inner->plugin + "\" nested in a bumpmap is not supported in this build (nest the bumpmap inside it instead)");
+        if (tex->plugin != "bitmap") fail("bumpmap: the height texture must be a bitmap (\"" + tex->plugin + "\" has no eval_1_grad)");
+        bsdf_of(*inner, s);
+        if (s.tex_normal >= 0) fail("bumpmap: internal error");
+        s.tex_normal = texture_index_of(tex);
+        s.bumpmap = true; s.bump_scale = (float) b.props.get_float("scale", 1.0);
+        auto u = b.props.unqueried();
+        if (!u.empty()) fail_unreferenced(u, "bsdf", b.plugin);
+        return;
+    }
     if (b.plugin == "normalmap") {   // src/bsdfs/normalmap.cpp:84-108: one nested BSDF evaluated in the frame an RGB texture gives
         const Obj *inner = nullptr;
         for (auto &c : b.children) if (c.first == "bsdf") { if (inner) fail("Only a single BSDF child object can be specified."); inner = c.second.get(); }
         if (!inner) fail("Exactly one BSDF child object must be specified.");
-        if (inner->plugin == "twosided" || inner->plugin == "mask" || inner->plugin == "normalmap")
+        if (inner->plugin == "twosided" || inner->plugin == "mask" || inner->plugin == "normalmap" || inner->plugin == "bumpmap")
             fail("normalmap: a \"" + inner->plugin + "\" nested in a normalmap is not supported in this build (nest the normalmap inside it instead)");
         bsdf_of(*inner, s);
         float c[3]; s.tex_normal = reflectance_of(b, "normalmap", 0.f, c);

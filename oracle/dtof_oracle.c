@@ -1497,6 +1497,26 @@ float orc_texture_eval_1(const orc_texture *tex, float u, float v) {
     if (tex->channels == 1) return c[0];
     return c[0] * 0.212671f + c[1] * 0.715160f + c[2] * 0.072169f;
 }
+/* BitmapTexture::eval_1_grad (src/textures/bitmap.cpp:346-421): the gradient of the bilinear interpolant of the (luminance of the) four texels around the
+ * lookup, through the transpose of the uv transform, times the resolution; the nearest filter (and a texture without eval_1_grad) has none */
+static void orc_texture_eval_1_grad(const orc_texture *tex, float u, float v, float *gu, float *gv) {
+    *gu = *gv = 0.f;
+    if (tex->kind != ORC_TEX_BITMAP || tex->filter == 0) return;
+    const float tu = fmaf(tex->to_uv[1], v, fmaf(tex->to_uv[0], u, 0.f)), tv = fmaf(tex->to_uv[3], v, fmaf(tex->to_uv[2], u, 0.f));
+    const int32_t W = tex->width, H = tex->height, C = tex->channels;
+    const float px = fmaf(tu, (float) W, -.5f), py = fmaf(tv, (float) H, -.5f), fx = floorf(px), fy = floorf(py);
+    const float w1x = px - fx, w1y = py - fy, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    const int32_t x0 = tex_wrap((int32_t) fx, W, tex->wrap), x1 = tex_wrap((int32_t) fx + 1, W, tex->wrap);
+    const int32_t y0 = tex_wrap((int32_t) fy, H, tex->wrap), y1 = tex_wrap((int32_t) fy + 1, H, tex->wrap);
+    float f[4]; const int32_t xs[4] = { x0, x1, x0, x1 }, ys[4] = { y0, y0, y1, y1 };
+    for (int i = 0; i < 4; ++i) {
+        const float *t = tex->data + ((size_t) ys[i] * W + xs[i]) * C;
+        f[i] = C == 1 ? t[0] : t[0] * 0.212671f + t[1] * 0.715160f + t[2] * 0.072169f;   /* luminance (spectrum.h:431-434) */
+    }
+    const float dfx = fmaf(w0y, f[1] - f[0], w1y * (f[3] - f[2])), dfy = fmaf(w0x, f[2] - f[0], w1x * (f[3] - f[1]));
+    *gu = (float) W * (tex->to_uv[0] * dfx + tex->to_uv[2] * dfy);
+    *gv = (float) H * (tex->to_uv[1] * dfx + tex->to_uv[3] * dfy);
+}
 /* the material parameters of one hit: the shape's constants, or the lookups of the textures bound to their slots */
 typedef struct { float spec_refl[3], spec_trans[3], alpha_u, alpha_v; } orc_mat;
 static orc_mat material_at(const orc_shape *sh, float u, float v) {
@@ -1699,10 +1719,22 @@ static void nested_bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, in
  * wo.z on the back side first (twosided.cpp:111-148,219-258), NormalMap::frame builds n = normalize(2 c - 1) from the texture, s = normalize(dp_du - n (n . dp_du))
  * with the interaction's dp_du as it is, t = n x s; wi and wo go into that frame, the nested BSDF is evaluated / sampled there, the sampled direction comes back
  * through the frame and the adapter.  cos_theta(wo) * cos_theta(perturbed wo) <= 0 (a light leak): no value, no density, no weight. */
-static void framed_bsdf_eval_pdf_sample(const orc_shape *sh, v3 dp_du, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
+typedef struct { v3 dp_du, dp_dv, n, sh_s, sh_t, sh_n; } orc_geo;   /* what the frames of normalmap / bumpmap read of the interaction */
+static void framed_bsdf_eval_pdf_sample(const orc_shape *sh, const orc_geo *g, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
     if (!sh->tex_normal) { nested_bsdf_eval_pdf_sample(sh, wi_in, wo, active_em, sample_1, s2x, s2y, uv_u, uv_v, out); return; }
-    float c[3]; orc_texture_eval(sh->tex_normal, uv_u, uv_v, c);                 /* m_normalmap->eval_3(si) */
-    const v3 n = v_normalize(V(fmaf(c[0], 2.f, -1.f), fmaf(c[1], 2.f, -1.f), fmaf(c[2], 2.f, -1.f)));
+    const v3 dp_du = g->dp_du;
+    v3 n;
+    if (sh->bumpmap) {   /* BumpMap::frame (src/bsdfs/bumpmap.cpp:199-222): the surface displaced along its shading normal by the height texture, to first order */
+        float gu, gv; orc_texture_eval_1_grad(sh->tex_normal, uv_u, uv_v, &gu, &gv);
+        gu *= sh->bump_scale; gv *= sh->bump_scale;
+        const v3 du = v_fma(g->sh_n, gu - v_dot(g->sh_n, g->dp_du), g->dp_du), dv = v_fma(g->sh_n, gv - v_dot(g->sh_n, g->dp_dv), g->dp_dv);
+        v3 nw = v_normalize(v_cross(du, dv));
+        if (v_dot(g->n, nw) < 0.f) nw = v_neg(nw);
+        n = V(v_dot(nw, g->sh_s), v_dot(nw, g->sh_t), v_dot(nw, g->sh_n));        /* si.to_local(n) */
+    } else {
+        float c[3]; orc_texture_eval(sh->tex_normal, uv_u, uv_v, c);             /* m_normalmap->eval_3(si) */
+        n = v_normalize(V(fmaf(c[0], 2.f, -1.f), fmaf(c[1], 2.f, -1.f), fmaf(c[2], 2.f, -1.f)));
+    }
     const float k = v_dot(n, dp_du);
     const v3 s = v_normalize(V(fmaf(-n.x, k, dp_du.x), fmaf(-n.y, k, dp_du.y), fmaf(-n.z, k, dp_du.z)));
     const v3 t = v_cross(n, s);
@@ -1723,12 +1755,12 @@ static void framed_bsdf_eval_pdf_sample(const orc_shape *sh, v3 dp_du, v3 wi_in,
 /* The shape's BSDF, seen through its `mask` if it has one.  MaskBSDF::eval_pdf (src/bsdfs/mask.cpp:184-207): value and density of the nested BSDF times the
  * opacity; MaskBSDF::sample (:125-163): sample1 < opacity samples the nested BSDF with sample1 / opacity (its sample and weight are passed on unchanged),
  * otherwise the null interaction: wo = -wi, eta 1, pdf 1 - opacity, weight 1 (BSDFFlags::Null is a delta type) */
-static void bsdf_eval_pdf_sample(const orc_shape *sh, v3 dp_du, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
-    if (!sh->masked) { framed_bsdf_eval_pdf_sample(sh, dp_du, wi_in, wo, active_em, sample_1, s2x, s2y, uv_u, uv_v, out); return; }
+static void bsdf_eval_pdf_sample(const orc_shape *sh, const orc_geo *g, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
+    if (!sh->masked) { framed_bsdf_eval_pdf_sample(sh, g, wi_in, wo, active_em, sample_1, s2x, s2y, uv_u, uv_v, out); return; }
     float opacity = sh->tex_opacity ? orc_texture_eval_1(sh->tex_opacity, uv_u, uv_v) : sh->opacity;
     opacity = f_min(f_max(opacity, 0.f), 1.f);                          /* eval_opacity (:219-221) */
     const int nested_pick = sample_1 < opacity;
-    framed_bsdf_eval_pdf_sample(sh, dp_du, wi_in, wo, active_em, sample_1 / opacity, s2x, s2y, uv_u, uv_v, out);
+    framed_bsdf_eval_pdf_sample(sh, g, wi_in, wo, active_em, sample_1 / opacity, s2x, s2y, uv_u, uv_v, out);
     out->val = v_mul(out->val, opacity); out->pdf *= opacity;
     if (!nested_pick) { out->wo = V(-wi_in.x, -wi_in.y, -wi_in.z); out->bs_eta = 1.f; out->bs_pdf = 1.f - opacity; out->bs_delta = 1; out->weight = V(1.f, 1.f, 1.f); }
 }
@@ -1998,7 +2030,8 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; int bs_delta = 0;
         if (hit) {
             orc_bsdf_out bo;
-            bsdf_eval_pdf_sample(si.shape, si.dp_du, si.wi, wo, active_em, sample_1, s2x, s2y, si.uv_u, si.uv_v, &bo);
+            const orc_geo geo = { si.dp_du, si.dp_dv, si.n, si.sh_s, si.sh_t, si.sh_n };
+            bsdf_eval_pdf_sample(si.shape, &geo, si.wi, wo, active_em, sample_1, s2x, s2y, si.uv_u, si.uv_v, &bo);
             bsdf_val = bo.val; bsdf_pdf = bo.pdf; bsdf_weight = bo.weight; bs_wo = bo.wo; bs_pdf = bo.bs_pdf; bs_eta = bo.bs_eta; bs_delta = bo.bs_delta;
         }
         if (active_em) {   /* :214-226 */
@@ -2596,7 +2629,8 @@ int orc_kat_ray_intersect(const orc_scene *sc, const float *o, const float *d, f
  * out = value[3], pdf, bs.wo[3], bs.pdf, bs.eta, bs.delta, weight[3] (13 floats) */
 void orc_kat_bsdf(const orc_shape *sh, const float *wi, const float *wo, const float *s3, float *out) {
     orc_bsdf_out r;
-    bsdf_eval_pdf_sample(sh, V(1.f, 0.f, 0.f), V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]), 1, s3[0], s3[1], s3[2], 0.f, 0.f, &r);
+    const orc_geo flat_geo = { V(1.f, 0.f, 0.f), V(0.f, 1.f, 0.f), V(0.f, 0.f, 1.f), V(1.f, 0.f, 0.f), V(0.f, 1.f, 0.f), V(0.f, 0.f, 1.f) };
+    bsdf_eval_pdf_sample(sh, &flat_geo, V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]), 1, s3[0], s3[1], s3[2], 0.f, 0.f, &r);
     out[0] = r.val.x; out[1] = r.val.y; out[2] = r.val.z; out[3] = r.pdf;
     out[4] = r.wo.x; out[5] = r.wo.y; out[6] = r.wo.z; out[7] = r.bs_pdf; out[8] = r.bs_eta; out[9] = (float) r.bs_delta;
     out[10] = r.weight.x; out[11] = r.weight.y; out[12] = r.weight.z;

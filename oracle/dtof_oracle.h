@@ -98,6 +98,8 @@ typedef struct {
     int32_t masked; float opacity; const orc_texture *tex_opacity;
     /* the plain BSDF sits inside a `normalmap` (src/bsdfs/normalmap.cpp; a twosided around it is applied first): its RGB texture (Texture::eval_3 per hit) */
     const orc_texture *tex_normal;
+    /* ... or inside a `bumpmap` (src/bsdfs/bumpmap.cpp): tex_normal is its height texture (Texture::eval_1_grad per hit), bump_scale its `scale` */
+    int32_t bumpmap; float bump_scale;
 } orc_shape;
 
 typedef struct {

@@ -36,7 +36,7 @@ class OrcShape(C.Structure):
                 ("inv_eta_2", C.c_float), ("fdr_int", C.c_float), ("spec_sampling_weight", C.c_float),
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("rough_table", C.POINTER(C.c_float)), ("tex_refl", C.POINTER(OrcTexture)), ("mf_type", C.c_int32), ("sample_all", C.c_int32),
                 ("tex_spec", C.POINTER(OrcTexture)), ("tex_trans", C.POINTER(OrcTexture)), ("tex_alpha_u", C.POINTER(OrcTexture)), ("tex_alpha_v", C.POINTER(OrcTexture)),
-                ("masked", C.c_int32), ("opacity", C.c_float), ("tex_opacity", C.POINTER(OrcTexture)), ("tex_normal", C.POINTER(OrcTexture))]
+                ("masked", C.c_int32), ("opacity", C.c_float), ("tex_opacity", C.POINTER(OrcTexture)), ("tex_normal", C.POINTER(OrcTexture)), ("bumpmap", C.c_int32), ("bump_scale", C.c_float)]
 
 
 class OrcGroup(C.Structure):
@@ -256,6 +256,7 @@ class Scene:
             if tex is not None:   # texture on the (diffuse) reflectance
                 o.tex_refl = make_texture(tex)
             o.masked, o.opacity = int(s.get("masked", 0)), float(s.get("opacity", 1.0))   # the BSDF inside a `mask`
+            o.bumpmap, o.bump_scale = int(s.get("bumpmap", 0)), float(s.get("bump_scale", 1.0))   # ... inside a `bumpmap` (tex_normal = the height texture)
             for key in ("tex_spec", "tex_trans", "tex_alpha_u", "tex_alpha_v", "tex_opacity", "tex_normal"):   # textures on the specular colours, the roughness, the mask's opacity
                 if s.get(key) is not None:
                     setattr(o, key, make_texture(s[key]))

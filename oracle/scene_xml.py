@@ -849,6 +849,29 @@ def _bsdf_of(props, registry, base_dir=""):
         rec["opacity"] = F32(tex["mean"]) if tex is not None else F32(props.get_f("opacity", 0.5))
         props.check_unreferenced("bsdf", ())
         return rec
+    if props.plugin == "bumpmap":   # src/bsdfs/bumpmap.cpp:84-112: one nested BSDF in the frame the gradient of ONE height texture (any property name) gives
+        inner = [c for c in props.children if c[0] == "bsdf" or (c[0] == "ref" and registry[c[1]][0] == "bsdf")]
+        texs = [c for c in props.children if c[0] == "texture" or (c[0] == "ref" and registry[c[1]][0] == "texture")]
+        if len(inner) > 1:
+            raise ValueError("Only a single BSDF child object can be specified.")
+        if len(texs) > 1:
+            raise ValueError("Only a single Texture child object can be specified.")
+        if not inner:
+            raise ValueError("Exactly one BSDF child object must be specified.")
+        if not texs:
+            raise ValueError("Exactly one Texture child object must be specified.")
+        ip = inner[0][1] if inner[0][0] == "bsdf" else registry[inner[0][1]][1]
+        if ip.plugin in ("twosided", "mask", "normalmap", "bumpmap"):
+            raise ValueError('bumpmap: a "%s" nested in a bumpmap is not supported in this build (nest the bumpmap inside it instead)' % ip.plugin)
+        tp = texs[0][1] if texs[0][0] == "texture" else registry[texs[0][1]][1]
+        if tp.plugin != "bitmap":
+            raise ValueError('bumpmap: the height texture must be a bitmap ("%s" has no eval_1_grad)' % tp.plugin)
+        rec = _bsdf_of(ip, registry, base_dir)
+        rec["tex_normal"] = _texture_of(tp, base_dir)
+        rec["bumpmap"] = 1
+        rec["bump_scale"] = F32(props.get_f("scale", 1.0))
+        props.check_unreferenced("bsdf", ())
+        return rec
     if props.plugin == "normalmap":   # src/bsdfs/normalmap.cpp:84-108: one nested BSDF evaluated in the frame an RGB texture gives
         inner = [c for c in props.children if c[0] == "bsdf" or (c[0] == "ref" and registry[c[1]][0] == "bsdf")]
         if len(inner) > 1:
@@ -856,7 +879,7 @@ def _bsdf_of(props, registry, base_dir=""):
         if not inner:
             raise ValueError("Exactly one BSDF child object must be specified.")
         ip = inner[0][1] if inner[0][0] == "bsdf" else registry[inner[0][1]][1]
-        if ip.plugin in ("twosided", "mask", "normalmap"):
+        if ip.plugin in ("twosided", "mask", "normalmap", "bumpmap"):
             raise ValueError('normalmap: a "%s" nested in a normalmap is not supported in this build (nest the normalmap inside it instead)' % ip.plugin)
         rec = _bsdf_of(ip, registry, base_dir)
         tex = _slot_texture(props, "normalmap", registry, base_dir)
@@ -1101,7 +1124,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
                 alpha_u=brec.get("alpha_u", F32(0.1)), alpha_v=brec.get("alpha_v", F32(0.1)), has_spec_refl=brec.get("has_spec_refl", 0),
                 mf_type=brec.get("mf_type", 1), sample_all=brec.get("sample_all", 0), tex_refl=brec.get("tex_refl"),
                 tex_spec=brec.get("tex_spec"), tex_trans=brec.get("tex_trans"), tex_alpha_u=brec.get("tex_alpha_u"), tex_alpha_v=brec.get("tex_alpha_v"),
-                masked=brec.get("masked", 0), opacity=brec.get("opacity", F32(1.0)), tex_opacity=brec.get("tex_opacity"), tex_normal=brec.get("tex_normal"),
+                masked=brec.get("masked", 0), opacity=brec.get("opacity", F32(1.0)), tex_opacity=brec.get("tex_opacity"), tex_normal=brec.get("tex_normal"), bumpmap=brec.get("bumpmap", 0), bump_scale=brec.get("bump_scale", F32(1.0)),
                 spec_refl_mean=brec.get("spec_refl_mean"))
 
 

@@ -398,7 +398,7 @@ def cornell_masked(res=128, spp=16):
 
 
 def cornell_normalmap(res=128, spp=16):
-    """cornell_boxes.xml with `normalmap` BSDFs (src/bsdfs/normalmap.cpp): the back wall a two-sided normal-mapped diffuse BSDF (the adapter outside, as exporters write it),
+    """cornell_boxes.xml with `normalmap` and `bumpmap` BSDFs (src/bsdfs/normalmap.cpp, bumpmap.cpp): the back wall a two-sided normal-mapped diffuse BSDF (the adapter outside, as exporters write it),
     the floor a two-sided normal-mapped roughconductor, the short box a mask around a two-sided normal-mapped plastic, the tall box a ONE-sided normal-mapped diffuse
     BSDF with a checkerboard "normal map" (two constant tilted normals); point + area light"""
     s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
@@ -414,6 +414,14 @@ def cornell_normalmap(res=128, spp=16):
           + '<bsdf type="plastic"><rgb name="diffuse_reflectance" value="0.7, 0.3, 0.2" /></bsdf></bsdf></bsdf></bsdf>\n')
     s += ('\t<bsdf type="normalmap" id="TallBoxBSDF"><texture type="checkerboard" name="normalmap"><rgb name="color0" value="0.62, 0.5, 0.95" /><rgb name="color1" value="0.4, 0.65, 0.9" />'
           '<transform name="to_uv"><scale x="3" y="3" /></transform></texture><bsdf type="diffuse"><rgb name="reflectance" value="0.3, 0.6, 0.8" /></bsdf></bsdf>\n')
+    # `bumpmap` (src/bsdfs/bumpmap.cpp): the ceiling a two-sided bump-mapped diffuse BSDF (gray height bitmap, scale 0.02), the right wall a bump-mapped plastic whose
+    # height map is the RGB bitmap (luminance), mirror-wrapped and scaled in uv
+    s = s.replace(bsdf("CeilingBSDF", "0.725, 0.71, 0.68"),
+                  '\t<bsdf type="twosided" id="CeilingBSDF"><bsdf type="bumpmap"><float name="scale" value="0.02" /><texture type="bitmap" name="height"><string name="filename" value="tex_gray.png" />'
+                  '<boolean name="raw" value="true" /><transform name="to_uv"><scale x="2" y="3" /></transform></texture><bsdf type="diffuse"><rgb name="reflectance" value="0.725, 0.71, 0.68" /></bsdf></bsdf></bsdf>\n')
+    s = s.replace(bsdf("RightWallBSDF", "0.14, 0.45, 0.091"),
+                  '\t<bsdf type="twosided" id="RightWallBSDF"><bsdf type="bumpmap"><bsdf type="plastic"><rgb name="diffuse_reflectance" value="0.14, 0.45, 0.091" /></bsdf><float name="scale" value="0.05" />'
+                  '<texture type="bitmap"><string name="filename" value="tex_rgb.png" /><string name="wrap_mode" value="mirror" /><transform name="to_uv"><scale x="1.5" y="0.7" /></transform></texture></bsdf></bsdf>\n')
     for name, m, b in WALLS:
         s += rect(name, m, b)
     s += cube("ShortBox", SHORT, "ShortBoxBSDF", "0.015") + cube("TallBox", TALL, "TallBoxBSDF", "-0.015")

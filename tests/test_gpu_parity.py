@@ -960,6 +960,13 @@ def _random_scene(rng, mesh_dir=None):
         elif slot < 0.3 and k in ("roughconductor", "roughdielectric"):
             body = re.sub(r'<float name="alpha" value="[0-9.]+"/>', '<texture type="bitmap" name="alpha"><string name="filename" value="%s"/><boolean name="raw" value="true"/></texture>'
                           % os.path.join(SCENES, "tex_gray.png"), body)
+        frame = rng.random()   # src/bsdfs/normalmap.cpp, bumpmap.cpp around the plain BSDF (inside the adapters)
+        if frame < 0.1:
+            body = ('<bsdf type="normalmap"><texture type="bitmap" name="normalmap"><string name="filename" value="%s"/><boolean name="raw" value="true"/>'
+                    '<transform name="to_uv"><scale x="%s" y="%s"/></transform></texture>%s</bsdf>' % (os.path.join(SCENES, "tex_normal.png"), f(0.5, 3), f(0.5, 3), body))
+        elif frame < 0.2:
+            body = ('<bsdf type="bumpmap"><float name="scale" value="%s"/><texture type="bitmap"><string name="filename" value="%s"/><boolean name="raw" value="true"/>'
+                    '<string name="wrap_mode" value="%s"/></texture>%s</bsdf>' % (f(-0.2, 0.2), os.path.join(SCENES, str(rng.choice(["tex_gray.png", "tex_rgb.png"]))), rng.choice(["repeat", "mirror", "clamp"]), body))
         if k in ("diffuse", "conductor", "plastic", "roughconductor", "roughplastic") and rng.random() < 0.7:
             body = '<bsdf type="twosided">%s</bsdf>' % body
         if rng.random() < 0.15:   # src/bsdfs/mask.cpp: constant or checkerboard opacity

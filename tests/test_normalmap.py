@@ -77,3 +77,60 @@ def test_a_tilted_normal_changes_the_shading_and_leaks_are_cut(mi):
     assert flat_r > 0 and abs(flat_r / flat_l - 1) < 0.2
     assert tilt_r > 1.3 * flat_r and tilt_l < 0.7 * flat_l
     assert mean("1.0, 0.5, 0.55", -3) == 0.0           # the normal points along +x: a light from -x is below the perturbed horizon
+
+
+# ------------------------------------------------------------------------------------------------ bumpmap (src/bsdfs/bumpmap.cpp)
+def _png(path, rows):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes"))
+    import make_scenes
+    make_scenes.write_png(str(path), rows)
+    return str(path)
+
+
+def _bump(filename, scale, inner=DIFFUSE, extra=""):
+    return ('<bsdf type="bumpmap"><float name="scale" value="%s"/><texture type="bitmap"><string name="filename" value="%s"/><boolean name="raw" value="true"/>%s</texture>%s</bsdf>'
+            % (scale, filename, extra, inner))
+
+
+def test_bumpmap_loads_and_refuses_what_the_reference_refuses(mi, orc, tmp_path):
+    """bumpmap.cpp:84-112: exactly one nested BSDF, exactly one texture (under any name), `scale` (default 1)"""
+    flat = _png(tmp_path / "flat.png", [[128] * 4] * 4)
+    xml = SCENE % (SHAPE % _bump(flat, "0.3") + SHAPE % ('<bsdf type="twosided">%s</bsdf>' % _bump(flat, "2", '<bsdf type="conductor"/>')) + SHAPE % DIFFUSE)
+    sc = mi.load_string(xml)
+    assert np.asarray(sc.export(22), np.float32).reshape(-1, 2).tolist() == [[1, np.float32(0.3)], [1, 2], [0, 1]]
+    assert np.asarray(sc.export(21), np.float32).tolist() == [0, 1, -1]
+    fs = orc.Scene(xml, {}, is_string=True).flat
+    assert [s["bumpmap"] for s in fs.shapes] == [1, 1, 0] and [s["twosided"] for s in fs.shapes] == [0, 1, 0]
+    for bsdf, message in [
+            ('<bsdf type="bumpmap">%s</bsdf>' % DIFFUSE, "Exactly one Texture child object must be specified"),
+            ('<bsdf type="bumpmap"><texture type="bitmap"><string name="filename" value="%s"/></texture></bsdf>' % flat, "Exactly one BSDF child object must be specified"),
+            (_bump(flat, "1", DIFFUSE + DIFFUSE), "Only a single BSDF child object can be specified"),
+            (_bump(flat, "1", DIFFUSE + '<texture type="bitmap" name="b"><string name="filename" value="%s"/></texture>' % flat), "Only a single Texture child object can be specified"),
+            (_bump(flat, "1", '<bsdf type="twosided">%s</bsdf>' % DIFFUSE), "nested in a bumpmap is not supported"),
+            ('<bsdf type="bumpmap"><texture type="checkerboard" name="t"/>%s</bsdf>' % DIFFUSE, "must be a bitmap")]:
+        for name, load in both(mi, orc):
+            with pytest.raises(Exception, match=message):
+                load(SCENE % (SHAPE % bsdf))
+
+
+@pytest.mark.gpu
+def test_a_constant_height_map_changes_nothing_and_a_ramp_tilts_the_normal(mi, tmp_path):
+    """zero gradient: the bump-mapped normal is the geometric one, the frame the identity on the untransformed rectangle -- every lane equals the plain scene bit for
+    bit; a height ramp rising with u tilts the normal towards -u: a light from -x brightens, one from +x darkens"""
+    flat = _png(tmp_path / "flat.png", [[77] * 4] * 4)
+    ramp = _png(tmp_path / "ramp.png", [[16 * x for x in range(16)]] * 4)
+    def lanes(bsdf):
+        sc = mi.load_string(SCENE % (INTEGRATOR + SENSOR + LIGHT + SHAPE % bsdf))
+        return sc.sample_lanes(seed=2, spp=256, lane_begin=0, n=8 * 8 * 256)
+    plain, mapped = lanes(DIFFUSE), lanes(_bump(flat, "5"))
+    assert np.array_equal(plain["rgb"].view(np.uint32), mapped["rgb"].view(np.uint32)) and float(np.abs(plain["rgb"]).max()) > 0
+    def mean(bsdf, light_x):
+        sc = mi.load_string(SCENE % ('<integrator type="path"><integer name="max_depth" value="2"/></integrator>' + SENSOR
+                                     + '<emitter type="point"><point name="position" value="%s, 0, 1"/><rgb name="intensity" value="10"/></emitter>' % light_x + SHAPE % bsdf))
+        return float(np.asarray(sc.render(seed=3)).mean())
+    clamp = '<string name="wrap_mode" value="clamp"/>'
+    up = _bump(ramp, "1", extra=clamp)
+    assert mean(up, -3) > 1.2 * mean(DIFFUSE, -3) and mean(up, 3) < 0.8 * mean(DIFFUSE, 3)
+    down = _bump(ramp, "-1", extra=clamp)                                  # a negative scale turns the slope around
+    assert mean(down, 3) > 1.2 * mean(DIFFUSE, 3) and mean(down, -3) < 0.8 * mean(DIFFUSE, -3)
