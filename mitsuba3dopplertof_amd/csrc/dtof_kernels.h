@@ -38,7 +38,7 @@ struct RenderParams {
     uint32_t path_correlation_depth, max_depth, rr_depth;
     int32_t has_area;                             // scene has area emitters: emitter-hit term + prev_si / prev_bsdf_pdf state
     int32_t sampler_kind, jitter; float inv_spp;  // SamplerKind; timestratified: jitter, 1 / sample_count (timestratified.cpp:78-82)
-    int32_t has_spec;                             // scene has delta BSDFs (conductor / dielectric): eta and prev_bsdf_delta become per-lane state
+    int32_t has_spec;                             // scene has delta BSDFs (conductor / dielectric): eta and prev_bsdf_delta become per-lane state; 2: ... and blendbsdf
     int32_t has_tris;                             // scene has triangle meshes (selects the kernel instantiations that carry mesh code)
     int32_t has_blas;                             // some mesh is traversed through its own BLAS: the unstaged k_trace / k_shadow run one wave per block
     int32_t integrator;                           // 0 dopplertofpath, 1 path (src/integrators/path.cpp), 2 velocity (velocity.cpp)

@@ -367,7 +367,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     bool has_surface_emitters = false;          // area emitters make the emitter-hit term (and the last iteration) live
     for (auto &e : sc->host.emitters) has_surface_emitters |= e.kind == EMITTER_AREA || e.kind == EMITTER_CONSTANT || e.kind == EMITTER_ENVMAP;   // the environment is "hit" by the rays that leave the scene
     rp.has_area = has_surface_emitters;
-    for (auto &sh : sc->host.shapes) rp.has_spec |= sh.bsdf != BSDF_DIFFUSE || sh.masked || sh.tex_normal >= 0;
+    for (auto &sh : sc->host.shapes) rp.has_spec |= sh.bsdf != BSDF_DIFFUSE || sh.masked || sh.tex_normal >= 0 || sh.blend_other;
     for (auto &e : sc->host.emitters) rp.has_spec |= e.kind == EMITTER_SPOT || e.kind == EMITTER_DIRECTIONAL;
     rp.has_spec |= !sc->host.textures.empty();
     for (size_t ei = 0; ei < sc->host.emitters.size(); ++ei) if (sc->host.emitters[ei].kind == EMITTER_CONSTANT || sc->host.emitters[ei].kind == EMITTER_ENVMAP) { rp.has_env = 1; rp.env_index = (uint32_t) ei; rp.has_spec = 1; }
@@ -377,6 +377,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     // anything but rectangles: the instantiations with triangle / sphere code.  The SPEC shade kernels are MESH instantiations (full 16-byte hit
     // record), so the trace kernels of the split pipeline must write that record for them too: a rectangle-only scene with textures (or any other
     // SPEC feature) counts as "has_tris" -- the compact 4-byte record is for the plain rectangle-only kernels
+    for (auto &sh : sc->host.shapes) if (sh.blend_other) rp.has_spec = 2;   // blendbsdf: the instantiations whose BSDF chain loops over two records
     rp.has_tris = bh->n_tris != 0 || has_spheres || rp.has_spec;
     {   // deep per-mesh traversals diverge: see unstaged_block() in dtof_kernels.hip
         const DShape *dshapes = (const DShape *) (sc->blob.data() + bh->off_shapes);
@@ -720,6 +721,10 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
         else if (kind == 20) for (auto &s : sc->host.shapes) { v.push_back(s.masked ? 1.f : 0.f); v.push_back(s.opacity); v.push_back((float) s.tex_opacity); }   // mask: masked, opacity, its texture
         else if (kind == 21) for (auto &s : sc->host.shapes) v.push_back((float) s.tex_normal);   // normalmap / bumpmap: its texture, -1 = none
         else if (kind == 22) for (auto &s : sc->host.shapes) { v.push_back(s.bumpmap ? 1.f : 0.f); v.push_back(s.bump_scale); }   // bumpmap: is one, scale
+        else if (kind == 23) for (auto &s : sc->host.shapes) {   // blendbsdf: is one, weight, its texture, kind and two-sidedness of bsdf_1
+            v.push_back(s.blend_other ? 1.f : 0.f); v.push_back(s.blend_weight); v.push_back((float) s.tex_blend);
+            v.push_back(s.blend_other ? (float) s.blend_other->bsdf : -1.f); v.push_back(s.blend_other && s.blend_other->twosided ? 1.f : 0.f);
+        }
         else if (kind == 18) for (auto &e : sc->host.emitters) {   // every emitter: kind, pos, intensity, first row of to_local (directional: its direction)
             v.push_back((float) e.kind); v.insert(v.end(), e.pos, e.pos + 3); v.insert(v.end(), e.intensity, e.intensity + 3); v.insert(v.end(), e.to_local, e.to_local + 3);
         }

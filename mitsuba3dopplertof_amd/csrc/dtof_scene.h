@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 #include <string>
+#include <memory>
 #include <vector>
 #include <map>
 #include <stdexcept>
@@ -19,6 +20,7 @@ enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1, FILTER_GAUSSIAN = 2
 enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4, SF_EMITTER = 8, SF_BECKMANN = 16 /* rough BSDFs: Beckmann instead of GGX */, SF_SAMPLE_ALL = 64 /* rough BSDFs: sample_visible = false */, SF_MASK = 128 /* the BSDF sits inside a `mask` (src/bsdfs/mask.cpp): DShape::opacity / tex_opacity */,
                             SF_NORMALMAP = 256 /* the BSDF sits inside a `normalmap` (src/bsdfs/normalmap.cpp): DShape::tex_normal; a twosided around it is applied first */,
                             SF_BUMPMAP = 512 /* ... or inside a `bumpmap` (src/bsdfs/bumpmap.cpp): tex_normal is its height texture, bump_scale its `scale` */,
+                            SF_BLEND = 1024 /* `blendbsdf` (src/bsdfs/blendbsdf.cpp): this record is bsdf_0, DShape::blend_other the record of bsdf_1 */,
                             SF_TEXCOORDS = 32 /* mesh with vertex texcoords (si.uv interpolates them; otherwise si.uv = the barycentrics, mesh.cpp:720-737) */ };
 enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4, BSDF_ROUGHPLASTIC = 5, BSDF_THINDIELECTRIC = 6, BSDF_ROUGHDIELECTRIC = 7 };
 enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1, EMITTER_SPOT = 2, EMITTER_CONSTANT = 3, EMITTER_ENVMAP = 4, EMITTER_DIRECTIONAL = 5 };
@@ -82,7 +84,7 @@ struct DObject {            // 128 B
     float key0[12], key1[12];
 };
 struct DGroup { uint32_t first_shape, n_shapes, pad[2]; };
-struct DShape {             // 336 B
+struct DShape {             // 352 B
     uint32_t kind, flags, first_tri, n_tris;
     float refl[3]; uint32_t blas_root;                   // mesh: root node of its BLAS, kNoChild = loop over the triangles
     float to_world[12], to_object[12];
@@ -107,6 +109,8 @@ struct DShape {             // 336 B
     uint32_t tex_spec, tex_trans, tex_alpha_u, tex_alpha_v;
     // SF_MASK: m_opacity of the enclosing `mask` BSDF (mask.cpp:95): the constant (or the texture's mean) and the texture record, as above (Texture::eval_1 per hit)
     float opacity; uint32_t tex_opacity;
+    // SF_BLEND: index (into shapes[]) of the material-only record that describes bsdf_1, m_weight as a constant (or the texture's mean) and as a texture (Texture::eval_1 per hit)
+    uint32_t blend_other; float blend_weight; uint32_t tex_blend, pad_blend;
     uint32_t tex_normal; float bump_scale;               // SF_NORMALMAP: m_normalmap of the enclosing `normalmap` BSDF (normalmap.cpp:97), Texture::eval_3 per hit;
                                                          // SF_BUMPMAP: m_nested_texture (Texture::eval_1_grad per hit) and m_scale of the enclosing `bumpmap` (bumpmap.cpp:93-112)
 };
@@ -144,7 +148,7 @@ struct DEnvmap {
 static_assert(sizeof(DEnvmap) % 16 == 0, "DEnvmap");
 static_assert(sizeof(BvhNode4) == 64, "BvhNode4");
 static_assert(sizeof(DTexture) == 64, "DTexture");
-static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 336 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64 && sizeof(DEmitter) == 96, "blob records");
+static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 352 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64 && sizeof(DEmitter) == 96, "blob records");
 
 // ---------------------------------------------------------------------------- host description
 struct Mat4d { double m[16]; };   // row-major
@@ -162,6 +166,7 @@ struct HostShape {
     int tex_refl = -1;                     // texture on reflectance / diffuse_reflectance: index into HostScene::textures
     int tex_spec = -1, tex_trans = -1, tex_alpha_u = -1, tex_alpha_v = -1;   // textures on specular_reflectance / specular_transmittance / the roughness (alpha sets both)
     int tex_normal = -1;                                                      // the BSDF sits inside a `normalmap` (src/bsdfs/normalmap.cpp): its RGB texture
+    std::shared_ptr<HostShape> blend_other; float blend_weight = .5f; int tex_blend = -1;   // `blendbsdf`: the fields above describe bsdf_0, *blend_other (BSDF fields only) bsdf_1
     bool bumpmap = false; float bump_scale = 1.f;                             // ... or inside a `bumpmap` (src/bsdfs/bumpmap.cpp): tex_normal is the height texture
     bool masked = false; float opacity = 1.f; int tex_opacity = -1;           // the BSDF sits inside a `mask` (src/bsdfs/mask.cpp): its opacity (float or texture, eval_1)
     std::vector<float> rough_table;        // roughplastic: m_external_transmittance (64 values)

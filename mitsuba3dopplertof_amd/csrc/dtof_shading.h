@@ -270,7 +270,7 @@ DTOF_D float texture_eval_1(const SceneView &sv, uint32_t rec_off, float u, floa
 }
 // The material parameters of one hit: the shape's constants, or the lookups of the textures bound to their slots (m_specular_reflectance->eval(si),
 // m_alpha_u->eval_1(si), ...)
-struct HitMaterial { float spec_refl[3], spec_trans[3], alpha_u, alpha_v, opacity; };
+struct HitMaterial { float spec_refl[3], spec_trans[3], alpha_u, alpha_v; };
 DTOF_D HitMaterial material_at(const SceneView &sv, const DShape *sh, float u, float v) {
     HitMaterial m;
 #pragma unroll
@@ -280,9 +280,6 @@ DTOF_D HitMaterial material_at(const SceneView &sv, const DShape *sh, float u, f
     if (sh->tex_trans) { const V3 c = texture_eval(sv, sh->tex_trans << 4, u, v); m.spec_trans[0] = c.x; m.spec_trans[1] = c.y; m.spec_trans[2] = c.z; }
     if (sh->tex_alpha_u) m.alpha_u = texture_eval_1(sv, sh->tex_alpha_u << 4, u, v);
     if (sh->tex_alpha_v) m.alpha_v = texture_eval_1(sv, sh->tex_alpha_v << 4, u, v);
-    m.opacity = sh->opacity;
-    if (sh->tex_opacity) m.opacity = texture_eval_1(sv, sh->tex_opacity << 4, u, v);
-    m.opacity = fmin_(fmax_(m.opacity, 0.f), 1.f);   // MaskBSDF::eval_opacity (mask.cpp:219-221)
     return m;
 }
 // NormalMap::frame (src/bsdfs/normalmap.cpp:181-189): the frame the nested BSDF is evaluated in, from the RGB texture at the hit: n = normalize(2 c - 1),
@@ -336,6 +333,13 @@ DTOF_D LocalFrame bumpmap_frame(const SceneView &sv, const DShape *sh, const Sur
 }
 DTOF_D V3 frame_to_local(const LocalFrame &f, V3 v) { return mk(dot(v, f.s), dot(v, f.t), dot(v, f.n)); }
 DTOF_D V3 frame_to_world(const LocalFrame &f, V3 v) { return vfma(f.n, v.z, vfma(f.t, v.y, f.s * v.x)); }
+// MaskBSDF::eval_opacity (mask.cpp:219-221)
+DTOF_D float mask_opacity_at(const SceneView &sv, const DShape *sh, float u, float v) {
+    const float o = sh->tex_opacity ? texture_eval_1(sv, sh->tex_opacity << 4, u, v) : sh->opacity;
+    return fmin_(fmax_(o, 0.f), 1.f);
+}
+// has_flag(bsdf->flags(), BSDFFlags::Smooth): the BSDFs with a non-delta lobe
+DTOF_D bool bsdf_is_smooth(uint32_t k) { return k == BSDF_DIFFUSE || k == BSDF_PLASTIC || k == BSDF_ROUGHCONDUCTOR || k == BSDF_ROUGHPLASTIC || k == BSDF_ROUGHDIELECTRIC; }
 // RoughPlastic::lerp_gather (roughplastic.cpp:373-383) on the 64-entry transmittance table
 DTOF_D float lerp_gather64(const float *data, float x) {
     x *= 63.f;

@@ -211,10 +211,30 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     std::vector<TexUse> tex_recs;                          // rec: word offset of the DTexture in `tables`
     std::vector<uint32_t> tex_rec_of(sc.textures.size(), 0xffffffffu);   // texture index -> word offset of its record: every texture is stored once, however many shapes use it
     auto check_words = [&]() { if (tables.size() > 0x3fffffffu) throw std::runtime_error("scene tables exceed the 4 GiB the 32-bit blob offsets address"); };
-    for (size_t i = 0; i < sc.shapes.size(); ++i) {
-        const HostShape &h = sc.shapes[i]; DShape &d = shapes[i];
-        memset(&d, 0, sizeof d);
-        d.kind = h.kind;
+    // the record of a texture and its texels go to the tables area, once per texture (the offsets are rebased below); returns the word offset of the record
+    auto place_texture = [&](int index) -> uint32_t {
+        const HostTexture &t = sc.textures[(size_t) index];
+        uint32_t &rec = tex_rec_of[(size_t) index];
+        if (rec == 0xffffffffu) {
+            while (tables.size() % 4) tables.push_back(0);            // 16-byte aligned record (the offset is stored >> 4)
+            check_words();
+            rec = (uint32_t) tables.size();
+            DTexture dt; memset(&dt, 0, sizeof dt);
+            dt.kind_flags = t.kind | (t.filter << 8) | (t.wrap << 16) | (t.channels << 24);
+            dt.width = t.width; dt.height = t.height; dt.data_off = (rec + (uint32_t) (sizeof(DTexture) / 4)) * 4u;
+            memcpy(dt.to_uv, t.to_uv, 16); memcpy(dt.color0, t.color0, 12); memcpy(dt.color1, t.color1, 12);
+            const uint32_t *w = (const uint32_t *) &dt;
+            tables.insert(tables.end(), w, w + sizeof(DTexture) / 4);
+            const size_t at = tables.size();
+            tables.resize(at + t.data.size());
+            if (!t.data.empty()) memcpy(&tables[at], t.data.data(), t.data.size() * 4);
+            check_words();
+        }
+        return rec;
+    };
+    // the material half of a shape record: flags, BSDF parameters, textures of its slots -- also run for the material-only records of blendbsdf partners
+    auto fill_material = [&](const HostShape &h, size_t i) {
+        DShape &d = shapes[i];
         d.flags = (h.twosided ? SF_TWOSIDED : 0) | (h.flip_normals ? SF_FLIP_NORMALS : 0) | (h.face_normals ? SF_FACE_NORMALS : 0) | (h.beckmann ? SF_BECKMANN : 0) | (h.sample_all ? SF_SAMPLE_ALL : 0) | (!h.texcoords.empty() ? SF_TEXCOORDS : 0) | (h.masked ? SF_MASK : 0) | (h.tex_normal >= 0 ? (h.bumpmap ? SF_BUMPMAP : SF_NORMALMAP) : 0);
         d.bump_scale = h.bump_scale;
         d.opacity = h.opacity;
@@ -226,26 +246,13 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
             for (float v : h.rough_table) { uint32_t b; memcpy(&b, &v, 4); tables.push_back(b); }
         }
         const int tex_of_slot[7] = { h.tex_refl, h.tex_spec, h.tex_trans, h.tex_alpha_u, h.tex_alpha_v, h.tex_opacity, h.tex_normal };
-        for (uint32_t slot = 0; slot < 7; ++slot) if (tex_of_slot[slot] >= 0) {   // the texture record and its texels go to the tables area; the offsets are rebased below
-            const HostTexture &t = sc.textures[(size_t) tex_of_slot[slot]];
-            uint32_t &rec = tex_rec_of[(size_t) tex_of_slot[slot]];
-            if (rec == 0xffffffffu) {
-                while (tables.size() % 4) tables.push_back(0);            // 16-byte aligned record (the offset is stored >> 4)
-                check_words();
-                rec = (uint32_t) tables.size();
-                DTexture dt; memset(&dt, 0, sizeof dt);
-                dt.kind_flags = t.kind | (t.filter << 8) | (t.wrap << 16) | (t.channels << 24);
-                dt.width = t.width; dt.height = t.height; dt.data_off = (rec + (uint32_t) (sizeof(DTexture) / 4)) * 4u;
-                memcpy(dt.to_uv, t.to_uv, 16); memcpy(dt.color0, t.color0, 12); memcpy(dt.color1, t.color1, 12);
-                const uint32_t *w = (const uint32_t *) &dt;
-                tables.insert(tables.end(), w, w + sizeof(DTexture) / 4);
-                const size_t at = tables.size();
-                tables.resize(at + t.data.size());
-                if (!t.data.empty()) memcpy(&tables[at], t.data.data(), t.data.size() * 4);
-                check_words();
-            }
-            tex_recs.push_back({ (uint32_t) i, slot, rec });
-        }
+        for (uint32_t slot = 0; slot < 7; ++slot) if (tex_of_slot[slot] >= 0) tex_recs.push_back({ (uint32_t) i, slot, place_texture(tex_of_slot[slot]) });
+    };
+    for (size_t i = 0; i < sc.shapes.size(); ++i) {
+        memset(&shapes[i], 0, sizeof(DShape));
+        shapes[i].kind = sc.shapes[i].kind;
+        fill_material(sc.shapes[i], i);
+        const HostShape &h = sc.shapes[i]; DShape &d = shapes[i];
         if (h.emitter) { d.flags |= SF_EMITTER; memcpy(d.radiance, h.radiance, 12); }
         memcpy(d.to_world, h.to_world, 48); memcpy(d.to_object, h.to_object, 48);
         if (h.kind == SHAPE_RECT) {   // Rectangle::update, rectangle.cpp:101-113
@@ -492,6 +499,18 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     // ---- pack: nodes first (so that "the first N bytes" = header + top of the TLAS in BFS-ish order)
     BlobHeader h; memset(&h, 0, sizeof h);
     h.n_nodes = (uint32_t) dev_nodes.size(); h.n_objects = (uint32_t) objects.size(); h.n_groups = (uint32_t) groups.size();
+    {   // blendbsdf: one material-only record per blended shape, behind the real shapes (groups and objects index the real ones only)
+        const size_t n_real = sc.shapes.size();
+        for (size_t i = 0; i < n_real; ++i) if (sc.shapes[i].blend_other) {
+            const HostShape &h = sc.shapes[i];
+            shapes.emplace_back();
+            const size_t k = shapes.size() - 1;
+            memset(&shapes[k], 0, sizeof(DShape));
+            fill_material(*h.blend_other, k);
+            shapes[i].flags |= SF_BLEND; shapes[i].blend_other = (uint32_t) k; shapes[i].blend_weight = h.blend_weight;
+            if (h.tex_blend >= 0) tex_recs.push_back({ (uint32_t) i, 7u, place_texture(h.tex_blend) });
+        }
+    }
     h.n_shapes = (uint32_t) shapes.size(); h.n_tris = (uint32_t) tris.size(); h.n_emitters = (uint32_t) emitters.size();
     (void) has_instances;
     h.tlas_depth = need_tlas + need_blas;
@@ -538,7 +557,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         const uint32_t rec_off = h.off_tables + tr.rec * 4u;
         DShape &d = shapes[tr.shape];
         if (tr.slot == 0) d.nonlinear |= (rec_off >> 4) << 1;
-        else (tr.slot == 1 ? d.tex_spec : tr.slot == 2 ? d.tex_trans : tr.slot == 3 ? d.tex_alpha_u : tr.slot == 4 ? d.tex_alpha_v : tr.slot == 5 ? d.tex_opacity : d.tex_normal) = rec_off >> 4;
+        else (tr.slot == 1 ? d.tex_spec : tr.slot == 2 ? d.tex_trans : tr.slot == 3 ? d.tex_alpha_u : tr.slot == 4 ? d.tex_alpha_v : tr.slot == 5 ? d.tex_opacity : tr.slot == 6 ? d.tex_normal : d.tex_blend) = rec_off >> 4;
         if (!rebased[tr.rec / 4]) { tables[tr.rec + 3] += h.off_tables; rebased[tr.rec / 4] = true; }   // DTexture::data_off, once per record
     }
     std::vector<uint8_t> blob(off, 0);

@@ -903,6 +903,30 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         }
         return;
     }
+    if (b.plugin == "blendbsdf") {   // src/bsdfs/blendbsdf.cpp:80-104: two nested BSDFs and a weight (float or texture, no default)
+        std::vector<const Obj *> inner;
+        for (auto &c : b.children) if (c.first == "bsdf") { if (inner.size() == 2) fail("BlendBSDF: Cannot specify more than two child BSDFs"); inner.push_back(c.second.get()); }
+        if (b.colors.count("weight")) fail("blendbsdf: an rgb \"weight\" is not supported (give a float or a texture)");
+        float c[3]; const int t = reflectance_of(b, "weight", 0.5f, c);
+        if (t < 0 && !b.props.has("weight")) fail("Property \"weight\" has not been specified!");
+        if (inner.size() != 2) fail("BlendBSDF: Two child BSDFs must be specified!");
+        for (const Obj *in : inner) if (in->plugin == "mask" || in->plugin == "blendbsdf") fail("blendbsdf: a \"" + in->plugin + "\" nested in a blendbsdf is not supported in this build");
+        bsdf_of(*inner[0], s);
+        auto other = std::make_shared<HostShape>();
+        bsdf_of(*inner[1], *other);
+        if (s.masked || other->masked || s.blend_other || other->blend_other) fail("blendbsdf: a mask or blendbsdf nested in a blendbsdf is not supported in this build");
+        s.blend_other = other; s.tex_blend = t;
+        s.blend_weight = t >= 0 ? c[0] : (float) b.props.get_float("weight", 0.5);
+        auto u = b.props.unqueried();
+        if (!u.empty()) fail_unreferenced(u, "bsdf", b.plugin);
+        for (size_t i = 0; i < b.children.size(); ++i) {
+            const Obj *c2 = b.children[i].second.get();
+            if (!c2 || c2->tag != "texture") continue;
+            const std::string &cname = i < b.ref_names.size() && !b.ref_names[i].empty() ? b.ref_names[i] : c2->name;
+            if (cname != "weight") fail("unreferenced object \"" + cname + "\" in plugin of type \"blendbsdf\"");
+        }
+        return;
+    }
     if (b.plugin == "bumpmap") {   // src/bsdfs/bumpmap.cpp:84-112: one nested BSDF in the frame the gradient of ONE height texture (any property name) gives
         const Obj *inner = nullptr, *tex = nullptr;
         for (auto &c : b.children) {
@@ -911,7 +935,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         }
         if (!inner) fail("Exactly one BSDF child object must be specified.");
         if (!tex) fail("Exactly one Texture child object must be specified.");
-        if (inner->plugin == "twosided" || inner->plugin == "mask" || inner->plugin == "normalmap" || inner->plugin == "bumpmap")
+        if (inner->plugin == "twosided" || inner->plugin == "mask" || inner->plugin == "normalmap" || inner->plugin == "bumpmap" || inner->plugin == "blendbsdf")
             fail("bumpmap: a \"" + inner->plugin + "\" nested in a bumpmap is not supported in this build (nest the bumpmap inside it instead)");
         if (tex->plugin != "bitmap") fail("bumpmap: the height texture must be a bitmap (\"" + tex->plugin + "\" has no eval_1_grad)");
         bsdf_of(*inner, s);
@@ -926,7 +950,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         const Obj *inner = nullptr;
         for (auto &c : b.children) if (c.first == "bsdf") { if (inner) fail("Only a single BSDF child object can be specified."); inner = c.second.get(); }
         if (!inner) fail("Exactly one BSDF child object must be specified.");
-        if (inner->plugin == "twosided" || inner->plugin == "mask" || inner->plugin == "normalmap" || inner->plugin == "bumpmap")
+        if (inner->plugin == "twosided" || inner->plugin == "mask" || inner->plugin == "normalmap" || inner->plugin == "bumpmap" || inner->plugin == "blendbsdf")
             fail("normalmap: a \"" + inner->plugin + "\" nested in a normalmap is not supported in this build (nest the normalmap inside it instead)");
         bsdf_of(*inner, s);
         float c[3]; s.tex_normal = reflectance_of(b, "normalmap", 0.f, c);
@@ -947,8 +971,11 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         for (auto &c : b.children) if (c.first == "bsdf") { inner = c.second.get(); ++n; }
         if (n != 1) fail("twosided: exactly one nested BSDF is supported");
         bsdf_of(*inner, s);
-        if (s.bsdf == BSDF_DIELECTRIC || s.bsdf == BSDF_THINDIELECTRIC || s.bsdf == BSDF_ROUGHDIELECTRIC || s.masked) fail("Only materials without a transmission component can be nested!");
-        s.twosided = true; return;
+        auto transmits = [](const HostShape &h) { return h.bsdf == BSDF_DIELECTRIC || h.bsdf == BSDF_THINDIELECTRIC || h.bsdf == BSDF_ROUGHDIELECTRIC; };
+        if (transmits(s) || s.masked || (s.blend_other && transmits(*s.blend_other))) fail("Only materials without a transmission component can be nested!");
+        s.twosided = true;
+        if (s.blend_other) s.blend_other->twosided = true;   // twosided{ blendbsdf{ a, b } } flips wi / wo before either nested BSDF sees them: the same as blendbsdf{ twosided{a}, twosided{b} }
+        return;
     }
     s.twosided = false;
     if (b.plugin == "diffuse") { s.bsdf = BSDF_DIFFUSE; s.tex_refl = reflectance_of(b, "reflectance", 0.5f, s.refl); }

@@ -1752,18 +1752,34 @@ static void framed_bsdf_eval_pdf_sample(const orc_shape *sh, const orc_geo *g, v
     }
     if (back) out->wo.z = -out->wo.z;
 }
+/* BlendBSDF (src/bsdfs/blendbsdf.cpp:114-213): eval and pdf are the weighted sums of both nested BSDFs; sample1 <= weight samples bsdf_1 with sample1 / weight,
+ * otherwise bsdf_0 with (sample1 - weight) / (1 - weight), and the nested sample goes back AS IT IS (its own weight and density, not the mixture's) */
+static void blended_bsdf_eval_pdf_sample(const orc_shape *sh, const orc_geo *g, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
+    if (!sh->blend_other) { framed_bsdf_eval_pdf_sample(sh, g, wi_in, wo, active_em, sample_1, s2x, s2y, uv_u, uv_v, out); return; }
+    float w = sh->tex_blend ? orc_texture_eval_1(sh->tex_blend, uv_u, uv_v) : sh->blend_weight;
+    w = f_min(f_max(w, 0.f), 1.f);                                      /* eval_weight (:213-215) */
+    const int pick_1 = sample_1 <= w;
+    orc_bsdf_out o0, o1;
+    framed_bsdf_eval_pdf_sample(sh, g, wi_in, wo, active_em, (sample_1 - w) / (1.f - w), s2x, s2y, uv_u, uv_v, &o0);
+    framed_bsdf_eval_pdf_sample((const orc_shape *) sh->blend_other, g, wi_in, wo, active_em, sample_1 / w, s2x, s2y, uv_u, uv_v, &o1);
+    *out = pick_1 ? o1 : o0;
+    const float w0 = 1.f - w;
+    out->val = V(o0.val.x * w0 + o1.val.x * w, o0.val.y * w0 + o1.val.y * w, o0.val.z * w0 + o1.val.z * w);
+    out->pdf = o0.pdf * w0 + o1.pdf * w;
+}
 /* The shape's BSDF, seen through its `mask` if it has one.  MaskBSDF::eval_pdf (src/bsdfs/mask.cpp:184-207): value and density of the nested BSDF times the
  * opacity; MaskBSDF::sample (:125-163): sample1 < opacity samples the nested BSDF with sample1 / opacity (its sample and weight are passed on unchanged),
  * otherwise the null interaction: wo = -wi, eta 1, pdf 1 - opacity, weight 1 (BSDFFlags::Null is a delta type) */
 static void bsdf_eval_pdf_sample(const orc_shape *sh, const orc_geo *g, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
-    if (!sh->masked) { framed_bsdf_eval_pdf_sample(sh, g, wi_in, wo, active_em, sample_1, s2x, s2y, uv_u, uv_v, out); return; }
+    if (!sh->masked) { blended_bsdf_eval_pdf_sample(sh, g, wi_in, wo, active_em, sample_1, s2x, s2y, uv_u, uv_v, out); return; }
     float opacity = sh->tex_opacity ? orc_texture_eval_1(sh->tex_opacity, uv_u, uv_v) : sh->opacity;
     opacity = f_min(f_max(opacity, 0.f), 1.f);                          /* eval_opacity (:219-221) */
     const int nested_pick = sample_1 < opacity;
-    framed_bsdf_eval_pdf_sample(sh, g, wi_in, wo, active_em, sample_1 / opacity, s2x, s2y, uv_u, uv_v, out);
+    blended_bsdf_eval_pdf_sample(sh, g, wi_in, wo, active_em, sample_1 / opacity, s2x, s2y, uv_u, uv_v, out);
     out->val = v_mul(out->val, opacity); out->pdf *= opacity;
     if (!nested_pick) { out->wo = V(-wi_in.x, -wi_in.y, -wi_in.z); out->bs_eta = 1.f; out->bs_pdf = 1.f - opacity; out->bs_delta = 1; out->weight = V(1.f, 1.f, 1.f); }
 }
+static inline int bsdf_is_smooth(int32_t k) { return k == ORC_BSDF_DIFFUSE || k == ORC_BSDF_PLASTIC || k == ORC_BSDF_ROUGHCONDUCTOR || k == ORC_BSDF_ROUGHPLASTIC || k == ORC_BSDF_ROUGHDIELECTRIC; }
 /* mis_weight -- dopplertofpath.cpp:296-301 */
 static inline float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return isfinite(w) ? w : 0.f; }
 
@@ -1990,9 +2006,8 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         }
 
         /* has_flag(bsdf->flags(), BSDFFlags::Smooth), :178 -- diffuse and plastic have a smooth lobe */
-        int active_em = active_next && hit && (si.shape->bsdf == ORC_BSDF_DIFFUSE || si.shape->bsdf == ORC_BSDF_PLASTIC ||
-                                               si.shape->bsdf == ORC_BSDF_ROUGHCONDUCTOR || si.shape->bsdf == ORC_BSDF_ROUGHPLASTIC ||
-                                               si.shape->bsdf == ORC_BSDF_ROUGHDIELECTRIC);
+        int active_em = active_next && hit && (bsdf_is_smooth(si.shape->bsdf) ||
+                                               (si.shape->blend_other && bsdf_is_smooth(((const orc_shape *) si.shape->blend_other)->bsdf)));   /* a blend has the flags of both */
 
         /* emitter sampling: Scene::sample_emitter_direction src/render/scene.cpp:235-291 */
         float e1 = sampler_draw(&smp, correlate, single);

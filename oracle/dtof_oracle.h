@@ -47,7 +47,7 @@ typedef struct {
     const float *data;       /* bitmap: height * width * channels linear float32 texels, row 0 first */
 } orc_texture;
 
-typedef struct {
+typedef struct orc_shape_s {
     int32_t kind;            /* ORC_SHAPE_* */
     int32_t twosided;        /* BSDF is twosided{diffuse} (1) or plain diffuse (0) */
     int32_t flip_normals;
@@ -100,6 +100,9 @@ typedef struct {
     const orc_texture *tex_normal;
     /* ... or inside a `bumpmap` (src/bsdfs/bumpmap.cpp): tex_normal is its height texture (Texture::eval_1_grad per hit), bump_scale its `scale` */
     int32_t bumpmap; float bump_scale;
+    /* `blendbsdf` (src/bsdfs/blendbsdf.cpp): everything above describes bsdf_0 (with its own twosided / normalmap / bumpmap); blend_other = a record whose BSDF fields
+     * describe bsdf_1 (its geometry fields are unused); the weight is a constant or a texture (Texture::eval_1 per hit).  NULL: no blend. */
+    const struct orc_shape_s *blend_other; float blend_weight; const orc_texture *tex_blend;
 } orc_shape;
 
 typedef struct {

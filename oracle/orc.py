@@ -36,7 +36,8 @@ class OrcShape(C.Structure):
                 ("inv_eta_2", C.c_float), ("fdr_int", C.c_float), ("spec_sampling_weight", C.c_float),
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("rough_table", C.POINTER(C.c_float)), ("tex_refl", C.POINTER(OrcTexture)), ("mf_type", C.c_int32), ("sample_all", C.c_int32),
                 ("tex_spec", C.POINTER(OrcTexture)), ("tex_trans", C.POINTER(OrcTexture)), ("tex_alpha_u", C.POINTER(OrcTexture)), ("tex_alpha_v", C.POINTER(OrcTexture)),
-                ("masked", C.c_int32), ("opacity", C.c_float), ("tex_opacity", C.POINTER(OrcTexture)), ("tex_normal", C.POINTER(OrcTexture)), ("bumpmap", C.c_int32), ("bump_scale", C.c_float)]
+                ("masked", C.c_int32), ("opacity", C.c_float), ("tex_opacity", C.POINTER(OrcTexture)), ("tex_normal", C.POINTER(OrcTexture)), ("bumpmap", C.c_int32), ("bump_scale", C.c_float),
+                ("blend_other", C.c_void_p), ("blend_weight", C.c_float), ("tex_blend", C.POINTER(OrcTexture))]
 
 
 class OrcGroup(C.Structure):
@@ -223,6 +224,70 @@ def make_params(d):
 class Scene:
     """Oracle-side scene: FlatScene (scene_xml.load) marshalled into the C records."""
 
+    def _fill_bsdf(self, o, s):
+        """the BSDF fields of an OrcShape from a shape (or blend-partner) record of scene_xml"""
+        L = lib()
+        o.twosided = int(s["twosided"])
+        o.reflectance = (C.c_float * 3)(*np.asarray(s["reflectance"], np.float32).tolist())
+        o.bsdf = int(s.get("bsdf", 0))
+        for key in ("cond_eta", "cond_k", "spec_refl", "spec_trans"):
+            setattr(o, key, (C.c_float * 3)(*np.asarray(s.get(key, [0, 0, 0]), np.float32).tolist()))
+        o.diel_eta = float(s.get("diel_eta", 1.0))
+        o.alpha_u, o.alpha_v = float(s.get("alpha_u", 0.1)), float(s.get("alpha_v", 0.1))
+        o.mf_type = int(s.get("mf_type", 1))
+        o.sample_all = int(s.get("sample_all", 0))
+        tex = s.get("tex_refl")
+        if tex is not None:   # texture on the (diffuse) reflectance
+            o.tex_refl = self._make_texture(tex)
+        o.masked, o.opacity = int(s.get("masked", 0)), float(s.get("opacity", 1.0))   # the BSDF inside a `mask`
+        o.bumpmap, o.bump_scale = int(s.get("bumpmap", 0)), float(s.get("bump_scale", 1.0))   # ... inside a `bumpmap` (tex_normal = the height texture)
+        for key in ("tex_spec", "tex_trans", "tex_alpha_u", "tex_alpha_v", "tex_opacity", "tex_normal"):   # textures on the specular colours, the roughness, the mask's opacity
+            if s.get(key) is not None:
+                setattr(o, key, self._make_texture(s[key]))
+        if o.bsdf == 3:   # plastic: SmoothPlastic::parameters_changed in C float32
+            o.nonlinear = int(s.get("nonlinear", 0))
+            out3 = (C.c_float * 3)()
+            L.orc_plastic_params(C.c_float(o.diel_eta), o.reflectance, o.spec_refl, out3)
+            o.inv_eta_2, o.fdr_int, o.spec_sampling_weight = out3[0], out3[1], out3[2]
+            if tex is not None or s.get("spec_refl_mean") is not None:   # Texture::mean() of a textured slot is the texture's own mean (plastic.cpp:201-217)
+                sp, d = np.asarray(s["spec_refl"], np.float32), np.asarray(s["reflectance"], np.float32)
+                third = np.float32(1.0 / 3.0)
+                s_mean = ((sp[0] + sp[1]) + sp[2]) * third if s.get("spec_refl_mean") is None else np.float32(s["spec_refl_mean"])
+                d_mean = ((d[0] + d[1]) + d[2]) * third if tex is None else np.float32(tex["mean"])
+                o.spec_sampling_weight = float(s_mean / (d_mean + s_mean))
+            s["plastic_params"] = np.array([o.inv_eta_2, o.fdr_int, o.spec_sampling_weight], np.float32)
+        if o.bsdf == 5:   # roughplastic: RoughPlastic::parameters_changed in C float32 (cached per (alpha, eta))
+            o.nonlinear = int(s.get("nonlinear", 0))
+            table, ir = rough_plastic_tables(o.alpha_u, o.diel_eta, o.mf_type)
+            self._keep.append(table)
+            o.rough_table = C.cast(table.ctypes.data, C.POINTER(C.c_float))
+            eta = np.float32(o.diel_eta)
+            o.inv_eta_2 = float(np.float32(1.0) / (eta * eta))
+            d, sp = np.asarray(s["reflectance"], np.float32), np.asarray(s["spec_refl"], np.float32)
+            third = np.float32(1.0 / 3.0)
+            d_mean = ((d[0] + d[1]) + d[2]) * third if tex is None else np.float32(tex["mean"])
+            s_mean = (((sp[0] + sp[1]) + sp[2]) * third if s.get("spec_refl_mean") is None else np.float32(s["spec_refl_mean"])) if s.get("has_spec_refl") else np.float32(1.0)
+            o.fdr_int, o.spec_sampling_weight = float(ir), float(s_mean / (d_mean + s_mean))
+            s["rough_table"], s["plastic_params"] = table, np.array([o.inv_eta_2, o.fdr_int, o.spec_sampling_weight], np.float32)
+        if s.get("blend_other") is not None:   # blendbsdf: this record is bsdf_0, a second record carries bsdf_1
+            other = OrcShape()
+            self._fill_bsdf(other, s["blend_other"])
+            self._keep.append(other)
+            o.blend_other = C.addressof(other)
+            o.blend_weight = float(s.get("blend_weight", 0.5))
+            if s.get("tex_blend") is not None:
+                o.tex_blend = self._make_texture(s["tex_blend"])
+
+    def _make_texture(self, tex):
+        t = OrcTexture()
+        t.kind, t.filter, t.wrap, t.channels, t.width, t.height = tex["kind"], tex["filter"], tex["wrap"], tex["channels"], tex["width"], tex["height"]
+        t.to_uv = (C.c_float * 4)(*tex["to_uv"].tolist())
+        t.color0, t.color1 = (C.c_float * 3)(*tex["color0"].tolist()), (C.c_float * 3)(*tex["color1"].tolist())
+        if tex["data"] is not None:
+            t.data = tex["data"].ctypes.data_as(C.POINTER(C.c_float))
+        self._keep += [t, tex["data"]]
+        return C.pointer(t)
+
     def __init__(self, source, params=None, is_string=False):
         self.flat = scene_xml.load(source, params, is_string)
         fs = self.flat
@@ -236,55 +301,7 @@ class Scene:
             o.reflectance = (C.c_float * 3)(*s["reflectance"].tolist())
             o.to_world, o.to_object = _m16(s["to_world"]), _m16(s["to_object"])
             o.emitter = int(s.get("emitter", 0))
-            o.bsdf = int(s.get("bsdf", 0))
-            for key in ("cond_eta", "cond_k", "spec_refl", "spec_trans"):
-                setattr(o, key, (C.c_float * 3)(*np.asarray(s.get(key, [0, 0, 0]), np.float32).tolist()))
-            o.diel_eta = float(s.get("diel_eta", 1.0))
-            o.alpha_u, o.alpha_v = float(s.get("alpha_u", 0.1)), float(s.get("alpha_v", 0.1))
-            o.mf_type = int(s.get("mf_type", 1))
-            o.sample_all = int(s.get("sample_all", 0))
-            def make_texture(tex):
-                t = OrcTexture()
-                t.kind, t.filter, t.wrap, t.channels, t.width, t.height = tex["kind"], tex["filter"], tex["wrap"], tex["channels"], tex["width"], tex["height"]
-                t.to_uv = (C.c_float * 4)(*tex["to_uv"].tolist())
-                t.color0, t.color1 = (C.c_float * 3)(*tex["color0"].tolist()), (C.c_float * 3)(*tex["color1"].tolist())
-                if tex["data"] is not None:
-                    t.data = tex["data"].ctypes.data_as(C.POINTER(C.c_float))
-                self._keep += [t, tex["data"]]
-                return C.pointer(t)
-            tex = s.get("tex_refl")
-            if tex is not None:   # texture on the (diffuse) reflectance
-                o.tex_refl = make_texture(tex)
-            o.masked, o.opacity = int(s.get("masked", 0)), float(s.get("opacity", 1.0))   # the BSDF inside a `mask`
-            o.bumpmap, o.bump_scale = int(s.get("bumpmap", 0)), float(s.get("bump_scale", 1.0))   # ... inside a `bumpmap` (tex_normal = the height texture)
-            for key in ("tex_spec", "tex_trans", "tex_alpha_u", "tex_alpha_v", "tex_opacity", "tex_normal"):   # textures on the specular colours, the roughness, the mask's opacity
-                if s.get(key) is not None:
-                    setattr(o, key, make_texture(s[key]))
-            if o.bsdf == 3:   # plastic: SmoothPlastic::parameters_changed in C float32
-                o.nonlinear = int(s.get("nonlinear", 0))
-                out3 = (C.c_float * 3)()
-                L.orc_plastic_params(C.c_float(o.diel_eta), o.reflectance, o.spec_refl, out3)
-                o.inv_eta_2, o.fdr_int, o.spec_sampling_weight = out3[0], out3[1], out3[2]
-                if tex is not None or s.get("spec_refl_mean") is not None:   # Texture::mean() of a textured slot is the texture's own mean (plastic.cpp:201-217)
-                    sp, d = np.asarray(s["spec_refl"], np.float32), np.asarray(s["reflectance"], np.float32)
-                    third = np.float32(1.0 / 3.0)
-                    s_mean = ((sp[0] + sp[1]) + sp[2]) * third if s.get("spec_refl_mean") is None else np.float32(s["spec_refl_mean"])
-                    d_mean = ((d[0] + d[1]) + d[2]) * third if tex is None else np.float32(tex["mean"])
-                    o.spec_sampling_weight = float(s_mean / (d_mean + s_mean))
-                s["plastic_params"] = np.array([o.inv_eta_2, o.fdr_int, o.spec_sampling_weight], np.float32)
-            if o.bsdf == 5:   # roughplastic: RoughPlastic::parameters_changed in C float32 (cached per (alpha, eta))
-                o.nonlinear = int(s.get("nonlinear", 0))
-                table, ir = rough_plastic_tables(o.alpha_u, o.diel_eta, o.mf_type)
-                self._keep.append(table)
-                o.rough_table = C.cast(table.ctypes.data, C.POINTER(C.c_float))
-                eta = np.float32(o.diel_eta)
-                o.inv_eta_2 = float(np.float32(1.0) / (eta * eta))
-                d, sp = np.asarray(s["reflectance"], np.float32), np.asarray(s["spec_refl"], np.float32)
-                third = np.float32(1.0 / 3.0)
-                d_mean = ((d[0] + d[1]) + d[2]) * third if tex is None else np.float32(tex["mean"])
-                s_mean = (((sp[0] + sp[1]) + sp[2]) * third if s.get("spec_refl_mean") is None else np.float32(s["spec_refl_mean"])) if s.get("has_spec_refl") else np.float32(1.0)
-                o.fdr_int, o.spec_sampling_weight = float(ir), float(s_mean / (d_mean + s_mean))
-                s["rough_table"], s["plastic_params"] = table, np.array([o.inv_eta_2, o.fdr_int, o.spec_sampling_weight], np.float32)
+            self._fill_bsdf(o, s)
             o.radiance = (C.c_float * 3)(*np.asarray(s.get("radiance", [0, 0, 0]), np.float32).tolist())
             if s["kind"] == 2:   # sphere: compose / decompose the transform in C float32 (orc_bake_sphere)
                 tw = np.ascontiguousarray(s["to_world"], dtype=np.float32)

@@ -849,6 +849,30 @@ def _bsdf_of(props, registry, base_dir=""):
         rec["opacity"] = F32(tex["mean"]) if tex is not None else F32(props.get_f("opacity", 0.5))
         props.check_unreferenced("bsdf", ())
         return rec
+    if props.plugin == "blendbsdf":   # src/bsdfs/blendbsdf.cpp:80-104: two nested BSDFs and a weight (float or texture, no default)
+        inner = [c for c in props.children if c[0] == "bsdf" or (c[0] == "ref" and registry[c[1]][0] == "bsdf")]
+        if len(inner) > 2:
+            raise ValueError("BlendBSDF: Cannot specify more than two child BSDFs")
+        tex = _slot_texture(props, "weight", registry, base_dir)
+        if tex is None and "weight" not in props:
+            raise ValueError('Property "weight" has not been specified!')
+        if tex is None and props["weight"][0] == "rgb":
+            raise ValueError('blendbsdf: an rgb "weight" is not supported (give a float or a texture)')
+        if len(inner) != 2:
+            raise ValueError("BlendBSDF: Two child BSDFs must be specified!")
+        recs = []
+        for c in inner:
+            ip = c[1] if c[0] == "bsdf" else registry[c[1]][1]
+            r = _bsdf_of(ip, registry, base_dir)
+            if r.get("masked") or r.get("blend_other") is not None:
+                raise ValueError('blendbsdf: a "%s" nested in a blendbsdf is not supported in this build' % ip.plugin)
+            recs.append(r)
+        rec = recs[0]
+        rec["blend_other"] = recs[1]
+        rec["tex_blend"] = tex
+        rec["blend_weight"] = F32(tex["mean"]) if tex is not None else F32(props.get_f("weight", 0.5))
+        props.check_unreferenced("bsdf", ())
+        return rec
     if props.plugin == "bumpmap":   # src/bsdfs/bumpmap.cpp:84-112: one nested BSDF in the frame the gradient of ONE height texture (any property name) gives
         inner = [c for c in props.children if c[0] == "bsdf" or (c[0] == "ref" and registry[c[1]][0] == "bsdf")]
         texs = [c for c in props.children if c[0] == "texture" or (c[0] == "ref" and registry[c[1]][0] == "texture")]
@@ -861,7 +885,7 @@ def _bsdf_of(props, registry, base_dir=""):
         if not texs:
             raise ValueError("Exactly one Texture child object must be specified.")
         ip = inner[0][1] if inner[0][0] == "bsdf" else registry[inner[0][1]][1]
-        if ip.plugin in ("twosided", "mask", "normalmap", "bumpmap"):
+        if ip.plugin in ("twosided", "mask", "normalmap", "bumpmap", "blendbsdf"):
             raise ValueError('bumpmap: a "%s" nested in a bumpmap is not supported in this build (nest the bumpmap inside it instead)' % ip.plugin)
         tp = texs[0][1] if texs[0][0] == "texture" else registry[texs[0][1]][1]
         if tp.plugin != "bitmap":
@@ -879,7 +903,7 @@ def _bsdf_of(props, registry, base_dir=""):
         if not inner:
             raise ValueError("Exactly one BSDF child object must be specified.")
         ip = inner[0][1] if inner[0][0] == "bsdf" else registry[inner[0][1]][1]
-        if ip.plugin in ("twosided", "mask", "normalmap", "bumpmap"):
+        if ip.plugin in ("twosided", "mask", "normalmap", "bumpmap", "blendbsdf"):
             raise ValueError('normalmap: a "%s" nested in a normalmap is not supported in this build (nest the normalmap inside it instead)' % ip.plugin)
         rec = _bsdf_of(ip, registry, base_dir)
         tex = _slot_texture(props, "normalmap", registry, base_dir)
@@ -896,9 +920,12 @@ def _bsdf_of(props, registry, base_dir=""):
             raise ValueError("twosided: exactly one nested BSDF is supported")
         ip = inner[0][1] if inner[0][0] == "bsdf" else registry[inner[0][1]][1]
         rec = _bsdf_of(ip, registry, base_dir)
-        if rec["bsdf"] in (2, 6, 7) or rec.get("masked"):   # twosided.cpp:47-52
+        other = rec.get("blend_other")
+        if rec["bsdf"] in (2, 6, 7) or rec.get("masked") or (other is not None and other["bsdf"] in (2, 6, 7)):   # twosided.cpp:47-52
             raise ValueError("Only materials without a transmission component can be nested!")
         rec["twosided"] = 1
+        if other is not None:   # twosided{ blendbsdf{ a, b } } flips wi / wo before either nested BSDF sees them: the same as blendbsdf{ twosided{a}, twosided{b} }
+            other["twosided"] = 1
         return rec
     rec = dict(twosided=0, bsdf=0, reflectance=np.array([0.5] * 3, F32), cond_eta=np.zeros(3, F32), cond_k=np.ones(3, F32),
                spec_refl=np.ones(3, F32), spec_trans=np.ones(3, F32), diel_eta=F32(1.0), nonlinear=0, alpha_u=F32(0.1), alpha_v=F32(0.1))
@@ -1125,6 +1152,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
                 mf_type=brec.get("mf_type", 1), sample_all=brec.get("sample_all", 0), tex_refl=brec.get("tex_refl"),
                 tex_spec=brec.get("tex_spec"), tex_trans=brec.get("tex_trans"), tex_alpha_u=brec.get("tex_alpha_u"), tex_alpha_v=brec.get("tex_alpha_v"),
                 masked=brec.get("masked", 0), opacity=brec.get("opacity", F32(1.0)), tex_opacity=brec.get("tex_opacity"), tex_normal=brec.get("tex_normal"), bumpmap=brec.get("bumpmap", 0), bump_scale=brec.get("bump_scale", F32(1.0)),
+                blend_other=brec.get("blend_other"), blend_weight=brec.get("blend_weight", F32(0.5)), tex_blend=brec.get("tex_blend"),
                 spec_refl_mean=brec.get("spec_refl_mean"))
 
 

@@ -397,6 +397,31 @@ def cornell_masked(res=128, spp=16):
     return s + LIGHT + AREA_LIGHT + "</scene>\n"
 
 
+def cornell_blend(res=128, spp=16):
+    """cornell_boxes.xml with `blendbsdf` BSDFs (src/bsdfs/blendbsdf.cpp): the back wall a two-sided blend of a diffuse and a roughconductor BSDF with a checkerboard weight
+    (the adapter outside), the floor a blend of two two-sided BSDFs (plastic, conductor) with a constant weight, the short box a mask around a two-sided blend of a normal-mapped
+    diffuse BSDF and a roughplastic with a bitmap weight, the tall box a ONE-sided blend of a diffuse BSDF and a dielectric (a transmitting partner); point + area light"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        if b[0] not in ("ShortBoxBSDF", "TallBoxBSDF", "BackWallBSDF", "FloorBSDF"):
+            s += bsdf(*b)
+    s += ('\t<bsdf type="twosided" id="BackWallBSDF"><bsdf type="blendbsdf"><texture type="checkerboard" name="weight"><rgb name="color0" value="0.1" /><rgb name="color1" value="0.85" />'
+          '<transform name="to_uv"><scale x="3" y="3" /></transform></texture><bsdf type="diffuse"><rgb name="reflectance" value="0.725, 0.71, 0.68" /></bsdf>'
+          '<bsdf type="roughconductor"><string name="distribution" value="ggx" /><float name="alpha" value="0.2" /><rgb name="eta" value="0.2, 0.92, 1.1" /><rgb name="k" value="3.9, 2.45, 2.14" /></bsdf></bsdf></bsdf>\n')
+    s += ('\t<bsdf type="blendbsdf" id="FloorBSDF"><float name="weight" value="0.35" /><bsdf type="twosided"><bsdf type="plastic"><rgb name="diffuse_reflectance" value="0.6, 0.55, 0.4" /></bsdf></bsdf>'
+          '<bsdf type="twosided"><bsdf type="conductor"><rgb name="eta" value="0.2, 0.92, 1.1" /><rgb name="k" value="3.9, 2.45, 2.14" /></bsdf></bsdf></bsdf>\n')
+    s += ('\t<bsdf type="mask" id="ShortBoxBSDF"><float name="opacity" value="0.85" /><bsdf type="twosided"><bsdf type="blendbsdf"><texture type="bitmap" name="weight"><string name="filename" value="tex_gray.png" />'
+          '<boolean name="raw" value="true" /></texture><bsdf type="normalmap"><texture type="bitmap" name="normalmap"><string name="filename" value="tex_normal.png" /><boolean name="raw" value="true" /></texture>'
+          '<bsdf type="diffuse"><rgb name="reflectance" value="0.7, 0.3, 0.2" /></bsdf></bsdf><bsdf type="roughplastic"><string name="distribution" value="beckmann" /><float name="alpha" value="0.15" />'
+          '<rgb name="diffuse_reflectance" value="0.2, 0.4, 0.7" /></bsdf></bsdf></bsdf></bsdf>\n')
+    s += ('\t<bsdf type="blendbsdf" id="TallBoxBSDF"><float name="weight" value="0.6" /><bsdf type="diffuse"><rgb name="reflectance" value="0.3, 0.6, 0.8" /></bsdf>'
+          '<bsdf type="dielectric"><float name="int_ior" value="1.5" /></bsdf></bsdf>\n')
+    for name, m, b in WALLS:
+        s += rect(name, m, b)
+    s += cube("ShortBox", SHORT, "ShortBoxBSDF", "0.015") + cube("TallBox", TALL, "TallBoxBSDF", "-0.015")
+    return s + LIGHT + AREA_LIGHT + "</scene>\n"
+
+
 def cornell_normalmap(res=128, spp=16):
     """cornell_boxes.xml with `normalmap` and `bumpmap` BSDFs (src/bsdfs/normalmap.cpp, bumpmap.cpp): the back wall a two-sided normal-mapped diffuse BSDF (the adapter outside, as exporters write it),
     the floor a two-sided normal-mapped roughconductor, the short box a mask around a two-sided normal-mapped plastic, the tall box a ONE-sided normal-mapped diffuse
@@ -672,6 +697,7 @@ def main():
         "cornell_textured_specular.xml": cornell_textured_specular(),
         "cornell_masked.xml": cornell_masked(),
         "cornell_normalmap.xml": cornell_normalmap(),
+        "cornell_blend.xml": cornell_blend(),
         "cornell_env.xml": cornell_env(),
         "cornell_envmap.xml": cornell_envmap(),
         "cornell_sun.xml": cornell_sun(),
@@ -692,7 +718,7 @@ def main():
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
     names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml",
-             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_textured_specular.xml", "cornell_masked.xml", "cornell_normalmap.xml", "tex_normal.png", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_thinlens.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
+             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_textured_specular.xml", "cornell_masked.xml", "cornell_normalmap.xml", "cornell_blend.xml", "tex_normal.png", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_thinlens.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
         return

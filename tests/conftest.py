@@ -91,6 +91,8 @@ CONFIGS = [
     ("masked", "cornell_masked.xml", dict(resx=32, resy=32, max_depth=6), 8),
     # `normalmap` BSDFs: bitmap and checkerboard normal maps around diffuse / roughconductor / plastic, inside twosided and mask; light-leak rejection
     ("normalmap", "cornell_normalmap.xml", dict(resx=32, resy=32, max_depth=5), 8),
+    # `blendbsdf`: constant / checkerboard / bitmap weights, reflecting and transmitting partners, inside twosided and mask, a normal-mapped partner
+    ("blend", "cornell_blend.xml", dict(resx=32, resy=32, max_depth=6), 8),
     # `constant` environment emitter: rays that leave the scene, environment sampling with MIS, valid_ray
     # sample_visible = false: all microfacet normals are sampled (roughconductor / roughplastic weights and densities, roughdielectric with
     # Walter et al.'s roughness scaling)

@@ -934,7 +934,12 @@ def _random_scene(rng, mesh_dir=None):
                     rng.choice(["sinusoidal", "rectangular", "triangular", "trapezoidal"]), rng.choice(["0.0", "1.0", "0.37"]), rng.integers(2, 6)))
     else:
         integ = '<integrator type="path"><integer name="max_depth" value="%d"/></integrator>' % rng.integers(2, 7)
-    def material(two_sided_ok=True):
+    def material(two_sided_ok=True, nested=False):
+        if not nested and rng.random() < 0.12:   # src/bsdfs/blendbsdf.cpp: two materials of the set (each with its own adapters), constant or checkerboard weight
+            wt = ('<float name="weight" value="%s"/>' % f(0.05, 0.95) if rng.random() < 0.6 else
+                  '<texture type="checkerboard" name="weight"><rgb name="color0" value="%s"/><rgb name="color1" value="%s"/><transform name="to_uv"><scale x="%s" y="%s"/></transform></texture>'
+                  % (f(0, 0.5), f(0.5, 1), f(1, 4), f(1, 4)))
+            return '<bsdf type="blendbsdf">%s%s%s</bsdf>' % (wt, material(nested=True), material(nested=True))
         k = rng.choice(["diffuse", "diffuse", "conductor", "dielectric", "thindielectric", "plastic", "roughconductor", "roughdielectric", "roughplastic"])
         dist = '<string name="distribution" value="%s"/>' % rng.choice(["ggx", "beckmann"])
         refl = '<rgb name="reflectance" value="%s"/>' % rgb()
@@ -969,7 +974,7 @@ def _random_scene(rng, mesh_dir=None):
                     '<string name="wrap_mode" value="%s"/></texture>%s</bsdf>' % (f(-0.2, 0.2), os.path.join(SCENES, str(rng.choice(["tex_gray.png", "tex_rgb.png"]))), rng.choice(["repeat", "mirror", "clamp"]), body))
         if k in ("diffuse", "conductor", "plastic", "roughconductor", "roughplastic") and rng.random() < 0.7:
             body = '<bsdf type="twosided">%s</bsdf>' % body
-        if rng.random() < 0.15:   # src/bsdfs/mask.cpp: constant or checkerboard opacity
+        if not nested and rng.random() < 0.15:   # src/bsdfs/mask.cpp: constant or checkerboard opacity (a mask inside a blendbsdf is refused)
             op = ('<float name="opacity" value="%s"/>' % f(0.1, 0.9) if rng.random() < 0.5 else
                   '<texture type="checkerboard" name="opacity"><rgb name="color0" value="%s"/><rgb name="color1" value="%s"/><transform name="to_uv"><scale x="%s" y="%s"/></transform></texture>'
                   % (f(0, 0.5), f(0.5, 1), f(1, 4), f(1, 4)))
