@@ -1,6 +1,6 @@
 """K = 4 offset batch against four single renders, both pipelines, for a scene file under scenes/ (development helper)"""
 import sys, os, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import mitsuba3dopplertof_amd as mi
 os.chdir(os.path.join(ROOT, "scenes"))
