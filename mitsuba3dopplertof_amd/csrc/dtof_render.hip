@@ -51,7 +51,10 @@ template <typename T> struct DevBuf {
 // DTOF_STAT_SLOTS shrinks it so that the tests can exercise the wrap-around with short paths.
 static const uint32_t kMaxIter = [] { const char *e = getenv("DTOF_STAT_SLOTS"); int v = e ? atoi(e) : 0; return (uint32_t) (v >= 2 ? v : 256); }();
 static uint64_t target_batch_lanes() {   // lanes per wavefront batch (DTOF_BATCH_LANES overrides)
-    static uint64_t v = [] { const char *e = getenv("DTOF_BATCH_LANES"); uint64_t x = e ? strtoull(e, nullptr, 10) : 0; return x ? x : (1ull << 24); }();
+    // 2^26 lanes (13 GB of workspace at 200 B per lane, 20 GB with four offset films -- of 288): every launch ends with a tail in which the CUs run dry one after the
+    // other, and a Domino frame in 32 launches of 2^24 lanes lost 7 % to it (C5 206 -> 193 ms, C4 44.8 -> 41.1; profiles/r03_batch_lanes.txt).  render_range halves the
+    // batch until its workspace fits the free device memory.
+    static uint64_t v = [] { const char *e = getenv("DTOF_BATCH_LANES"); uint64_t x = e ? strtoull(e, nullptr, 10) : 0; return x ? x : (1ull << 26); }();
     return v;
 }
 
@@ -328,6 +331,13 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     uint64_t batch = lane_dump ? std::min<uint64_t>(target_batch_lanes(), std::max<uint64_t>(dump_n, 1))
                                : std::max<uint64_t>(1, target_batch_lanes() / lanes_per_row) * lanes_per_row;
     batch = std::min<uint64_t>(batch, std::max<uint64_t>(last - first, 1));
+    if (batch > sc->ws.capacity) {   // a workspace that has to grow: keep it within the free device memory (168 B + 32 B per offset film per lane, two copies with two streams)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t per_lane = 168 + 32ull * (uint64_t) std::max<int32_t>(rp.n_offsets, 1);
+            while (batch > (1ull << 22) && batch * per_lane * 2 > (uint64_t) free_b + (uint64_t) sc->ws.capacity * per_lane) batch = std::max<uint64_t>(1, (batch / 2) / lanes_per_row) * lanes_per_row;
+        }
+    }
     // Two batches are kept in flight on two HIP streams (each with its own workspace): the VALU-bound
     // trace/shadow kernels of one batch overlap the HBM-bound shade kernel of the other.
     static const int env_streams = [] { const char *e = getenv("DTOF_STREAMS"); int v = e ? atoi(e) : 1; return v == 2 ? 2 : 1; }();   // default 1: measured gain of 2 is 0% (Cornell) .. 7% (Domino) and it blurs per-stage timing
