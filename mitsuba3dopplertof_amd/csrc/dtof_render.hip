@@ -54,7 +54,7 @@ static uint64_t target_batch_lanes() {   // lanes per wavefront batch (DTOF_BATC
     // 2^26 lanes (13 GB of workspace at 200 B per lane, 20 GB with four offset films -- of 288): every launch ends with a tail in which the CUs run dry one after the
     // other, and a Domino frame in 32 launches of 2^24 lanes lost 7 % to it (C5 206 -> 193 ms, C4 44.8 -> 41.1; profiles/r03_batch_lanes.txt).  render_range halves the
     // batch until its workspace fits the free device memory.
-    static uint64_t v = [] { const char *e = getenv("DTOF_BATCH_LANES"); uint64_t x = e ? strtoull(e, nullptr, 10) : 0; return x ? x : (1ull << 26); }();
+    const char *e = getenv("DTOF_BATCH_LANES"); const uint64_t x = e ? strtoull(e, nullptr, 10) : 0; const uint64_t v = x ? x : (1ull << 26);   // read per call: tests of the batch seams set it
     return v;
 }
 
