@@ -119,6 +119,7 @@ int dtof_scene_get_info(const dtof_scene *scene, dtof_scene_info *info);
  * kind 20: per shape 3 floats: inside a `mask` (0 / 1), its opacity (the constant, or the texture's mean), index of the opacity texture (src/bsdfs/mask.cpp)
  * kind 21: per shape 1 float: index of the texture of its `normalmap` / `bumpmap`, -1 = none; kind 22: per shape 2 floats: is a `bumpmap`, its scale
  * kind 23: per shape 5 floats: is a `blendbsdf`, its weight, index of the weight texture, BSDF kind and two-sidedness of bsdf_1 (bsdf_0 is what kind 9 reports)
+ * kind 24: per shape 1 float: index of the texture on its area emitter's radiance, -1 = a constant colour
  * kind 10: roughplastic tables -> per roughplastic shape the 64 values of m_external_transmittance (roughplastic.cpp:222-257)
  * Returns the number of floats written (<= capacity) through *n_written. */
 int dtof_scene_export(const dtof_scene *scene, int kind, float *out, size_t capacity, size_t *n_written);

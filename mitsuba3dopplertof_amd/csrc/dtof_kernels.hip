@@ -148,7 +148,10 @@ template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, int SPEC, int RESW
 #ifndef DTOF_MESH_WAVES
 #define DTOF_MESH_WAVES 3   // waves / SIMD the fused kernels with triangle code are compiled for (A/B: make variant DEFS=-DDTOF_MESH_WAVES=4)
 #endif
-__global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : (MODE != 0 && MESH) ? DTOF_MESH_WAVES : 1) void k_shade(ShadeArgs args_by_value) {
+// The every-BSDF kernels (SPEC) with four offset films (KMAX == 4) are compiled for TWO waves per SIMD (256 VGPRs): at three (168 VGPRs, 240 - 390 spilled registers) their
+// fused instantiations produced wrong films on scenes of the random sweep whenever the kernel grew (a loop around the BSDF chain, the textured-emitter branch), while every
+// lane of the K = 1 kernels, the split pipeline and the SAME source at two waves per SIMD stayed exact -- the spill code of that configuration is not to be trusted.
+__global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : (MODE != 0 && MESH) ? ((SPEC && KMAX > 1) ? 2 : DTOF_MESH_WAVES) : 1) void k_shade(ShadeArgs args_by_value) {
     constexpr bool FUSED = MODE != 0, FIRST = MODE == 2;
     static_assert(RESW == 0 || (MODE == 2 && !LDS && MESH), "the resident stage exists for the unstaged fused first-bounce kernel with mesh code");
     extern __shared__ uint4 lds[];
@@ -357,6 +360,11 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                     float em_pdf = 0.f;
                     if (!prev_delta) {                                          // !prev_bsdf_delta: AreaLight::pdf_direction (area.cpp:161-180)
                         float dp = dot(dsd, si.sh_n);   // ds.n = si.sh_frame.n (PositionSample(si), records.h:63-65)
+                        if (SPEC && dp < 0.f && sh->tex_radiance) {   // area.cpp:170-176: pdf_position of the texture at ds.uv = si.uv, through the parameterisation's |dp_du x dp_dv|
+                            V3 pp, pn; float su, sv_, area_norm;
+                            if (rect_eval_parameterization(*sh, si.u, si.v, pp, pn, su, sv_, area_norm))
+                                em_pdf = texture_pdf_position(sv, sh->tex_radiance << 4, si.u, si.v) * sqr(dist) / (area_norm * -dp) * pmf;
+                        } else
                         if (dp < 0.f) {
                             const float adp = fabsf(dp);
                             const float pdf = MESH && sh->kind == SHAPE_SPHERE ? sphere_pdf_direction(*sh, mk(pb.x, pb.y, pb.z), dsd, si.sh_n, dist)
@@ -367,6 +375,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                     float mis_bsdf = mis_weight(pb.w, em_pdf);
                     bool on = si.wi.z > 0.f && pb.w > 0.f;                       // AreaLight::eval (area.cpp:82-89), mask prev_bsdf_pdf > 0
                     V3 le = on ? mk(sh->radiance[0], sh->radiance[1], sh->radiance[2]) : mk(0, 0, 0);
+                    if (SPEC && on && sh->tex_radiance) le = texture_eval(sv, sh->tex_radiance << 4, si.u, si.v);   // m_radiance->eval(si)
 #pragma unroll
                     for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
                         V3 v = le * mis_bsdf;
@@ -437,6 +446,25 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                 } else {
                     const DShape &es = sv.shapes[em.shape];
                     V3 en;
+                    if (SPEC && es.tex_radiance) {
+                        // AreaLight::sample_direction with a spatially varying radiance (area.cpp:129-153): the TEXTURE is sampled (Texture::sample_position), the shape maps the
+                        // uv to a point (Rectangle::eval_parameterization), the density goes from uv space to solid angle with |dp_du x dp_dv|
+                        float tu, tv, tpdf, su = 0.f, sv_ = 0.f, area_norm = 1.f;
+                        texture_sample_position(sv, es.tex_radiance << 4, sx, e2, tu, tv, tpdf);
+                        V3 pp = si.p; en = mk(0.f, 0.f, 1.f);
+                        const bool valid = tpdf != 0.f && rect_eval_parameterization(es, tu, tv, pp, en, su, sv_, area_norm);
+                        dsp = valid ? pp : si.p;
+                        dd = dsp - si.p;
+                        const float dist2 = dot(dd, dd);
+                        ds_dist = sqrtf(dist2);
+                        dd = dd * rcp(ds_dist);
+                        const float dp = dot(dd, en);
+                        em_active = valid && dp < 0.f;
+                        ds_pdf = em_active ? tpdf / area_norm * dist2 / -dp : 0.f;
+                        ds_delta = false;
+                        const V3 c = em_active ? texture_eval(sv, es.tex_radiance << 4, su, sv_) : mk(0, 0, 0);   // m_radiance->eval(si) / ds.pdf
+                        em_weight = em_active ? mk(c.x / ds_pdf, c.y / ds_pdf, c.z / ds_pdf) : mk(0, 0, 0);
+                    } else {
                     if (MESH && es.kind == SHAPE_SPHERE) {   // Sphere overrides Shape::sample_direction
                         sphere_sample_direction(es, si.p, sx, e2, dsp, en, dd, ds_dist, ds_pdf);
                     } else {
@@ -459,6 +487,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                     em_active = dot(dd, en) < 0.f && ds_pdf != 0.f;
                     float ip = rcp(ds_pdf);
                     em_weight = em_active ? mk(em.intensity[0] * ip, em.intensity[1] * ip, em.intensity[2] * ip) : mk(0, 0, 0);
+                    }
                 }
                 ds_pdf *= pmf; em_weight = em_weight * em_w;
                 active_em = ds_pdf != 0.f && em_active;

@@ -110,7 +110,8 @@ struct DShape {             // 352 B
     // SF_MASK: m_opacity of the enclosing `mask` BSDF (mask.cpp:95): the constant (or the texture's mean) and the texture record, as above (Texture::eval_1 per hit)
     float opacity; uint32_t tex_opacity;
     // SF_BLEND: index (into shapes[]) of the material-only record that describes bsdf_1, m_weight as a constant (or the texture's mean) and as a texture (Texture::eval_1 per hit)
-    uint32_t blend_other; float blend_weight; uint32_t tex_blend, pad_blend;
+    uint32_t blend_other; float blend_weight; uint32_t tex_blend;
+    uint32_t tex_radiance;                               // SF_EMITTER: texture on the area emitter's `radiance` (record offset >> 4, 0 = the constant above); rectangles only (area.cpp:129-153)
     uint32_t tex_normal; float bump_scale;               // SF_NORMALMAP: m_normalmap of the enclosing `normalmap` BSDF (normalmap.cpp:97), Texture::eval_3 per hit;
                                                          // SF_BUMPMAP: m_nested_texture (Texture::eval_1_grad per hit) and m_scale of the enclosing `bumpmap` (bumpmap.cpp:93-112)
 };
@@ -122,7 +123,8 @@ struct DTexture {           // 64 B
     uint32_t kind_flags;    // kind | filter << 8 (0 nearest, 1 bilinear) | wrap << 16 (0 repeat, 1 mirror, 2 clamp) | channels << 24
     uint32_t width, height, data_off;   // data_off: byte offset of the texels in the blob
     float to_uv[4], color0[3], color1[3];
-    uint32_t pad[2];
+    uint32_t distr_off;     // byte offset in the blob of the texels' DiscreteDistribution2D (distr_2d.h:75-181): normalization, 1 / normalization, marg_cdf[height], cond_cdf[height * width];
+    uint32_t pad;           // 0 = none (built for the textures an area emitter's radiance is sampled through, bitmap.cpp:450-528)
 };
 struct DTri { float p0[3]; uint32_t face; float p1[4], p2[4]; };         // 48 B; face = index in the mesh's own order (tie rule)
 struct DTriShade { float n0[3], n1[3], n2[3], uv0[2], uv1[2], uv2[2], pad; };   // 64 B
@@ -167,6 +169,7 @@ struct HostShape {
     int tex_spec = -1, tex_trans = -1, tex_alpha_u = -1, tex_alpha_v = -1;   // textures on specular_reflectance / specular_transmittance / the roughness (alpha sets both)
     int tex_normal = -1;                                                      // the BSDF sits inside a `normalmap` (src/bsdfs/normalmap.cpp): its RGB texture
     std::shared_ptr<HostShape> blend_other; float blend_weight = .5f; int tex_blend = -1;   // `blendbsdf`: the fields above describe bsdf_0, *blend_other (BSDF fields only) bsdf_1
+    int tex_radiance = -1;                                                    // texture on the area emitter's radiance
     bool bumpmap = false; float bump_scale = 1.f;                             // ... or inside a `bumpmap` (src/bsdfs/bumpmap.cpp): tex_normal is the height texture
     bool masked = false; float opacity = 1.f; int tex_opacity = -1;           // the BSDF sits inside a `mask` (src/bsdfs/mask.cpp): its opacity (float or texture, eval_1)
     std::vector<float> rough_table;        // roughplastic: m_external_transmittance (64 values)

@@ -268,6 +268,76 @@ DTOF_D float texture_eval_1(const SceneView &sv, uint32_t rec_off, float u, floa
     if ((tex.kind_flags >> 24) == 1u) return c.x;
     return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f;
 }
+// DiscreteDistribution2D over a bitmap's texels (include/mitsuba/core/distr_2d.h:75-181; tables built by scene_build.cpp): sample = row from the marginal, column
+// from the conditional CDF (dr::binary_search over [0, n - 1]: the first index whose CDF value is not below the sample, the last index if there is none) and
+// the re-uniformised variate of both; pdf = the texel's share
+DTOF_D uint32_t cdf_search(const float *cdf, uint32_t n, float x) {
+    uint32_t lo = 0, hi = n - 1u;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cdf[mid] < x) lo = mid + 1u; else hi = mid; }
+    return lo;
+}
+DTOF_D float interval_to_tent(float s) {   // warp.h:196-200
+    s -= .5f;
+    const float v = fmaf(fabsf(s), -2.f, 1.f), r = 1.f - (v > 0.f ? sqrtf(v) : 0.f);
+    return mulsign(r, s);   // copysign(r, s): r >= 0
+}
+// Texture::sample_position (texture.cpp:56-59: the identity for every texture without its own) / BitmapTexture::sample_position (bitmap.cpp:450-487)
+DTOF_D void texture_sample_position(const SceneView &sv, uint32_t rec_off, float sx, float sy, float &u, float &v, float &pdf) {
+    const DTexture &tex = *(const DTexture *) (sv.base + rec_off);
+    if ((tex.kind_flags & 0xffu) != TEX_BITMAP || !tex.distr_off) { u = sx; v = sy; pdf = 1.f; return; }
+    const uint32_t filter = (tex.kind_flags >> 8) & 0xffu, wrap = (tex.kind_flags >> 16) & 0xffu, W = tex.width, H = tex.height;
+    const float *d = (const float *) (sv.base + tex.distr_off), *marg = d + 2, *cond = d + 2 + H;
+    sx = fmin_(fmax_(sx, 1.17549435e-38f), 0.99999994f); sy = fmin_(fmax_(sy, 1.17549435e-38f), 0.99999994f);   // clamp(sample, Smallest, OneMinusEpsilon)
+    sy *= d[1];
+    const uint32_t row = cdf_search(marg, H, sy), offset = row * W;
+    sx *= cond[offset + W - 1u];
+    const uint32_t col = cdf_search(cond + offset, W, sx);
+    const float col_cdf_0 = col > 0 ? cond[offset + col - 1u] : 0.f, col_cdf_1 = cond[offset + col];
+    const float row_cdf_0 = row > 0 ? marg[row - 1u] : 0.f, row_cdf_1 = marg[row];
+    sx -= col_cdf_0; sy -= row_cdf_0;
+    if (col_cdf_1 != col_cdf_0) sx /= col_cdf_1 - col_cdf_0;
+    if (row_cdf_1 != row_cdf_0) sy /= row_cdf_1 - row_cdf_0;
+    const float p = (col_cdf_1 - col_cdf_0) * d[0];
+    const float iw = rcp((float) W), ih = rcp((float) H);
+    float x, y;
+    if (filter == 0) { x = ((float) col + sx) * iw; y = ((float) row + sy) * ih; }
+    else {
+        x = (((float) col + .5f) + interval_to_tent(sx)) * iw; y = (((float) row + .5f) + interval_to_tent(sy)) * ih;
+        if (wrap == 0) { if (x < 0.f) x += 1.f; if (x > 1.f) x -= 1.f; if (y < 0.f) y += 1.f; if (y > 1.f) y -= 1.f; }
+        else { if (x < 0.f) x = -x; if (x > 1.f) x = 2.f - x; if (y < 0.f) y = -y; if (y > 1.f) y = 2.f - y; }
+    }
+    u = x; v = y; pdf = p * (float) (int32_t) (W * H);
+}
+// Texture::pdf_position (texture.cpp:61-64) / BitmapTexture::pdf_position (bitmap.cpp:489-528)
+DTOF_D float texture_pdf_position(const SceneView &sv, uint32_t rec_off, float u, float v) {
+    const DTexture &tex = *(const DTexture *) (sv.base + rec_off);
+    if ((tex.kind_flags & 0xffu) != TEX_BITMAP || !tex.distr_off) return 1.f;
+    const uint32_t filter = (tex.kind_flags >> 8) & 0xffu, wrap = (tex.kind_flags >> 16) & 0xffu;
+    const int32_t W = (int32_t) tex.width, H = (int32_t) tex.height;
+    const float *d = (const float *) (sv.base + tex.distr_off), *cond = d + 2 + H;
+    auto texel_pdf = [&](int32_t x, int32_t y) { const uint32_t i = (uint32_t) x + (uint32_t) y * (uint32_t) W; return (cond[i] - (x > 0 ? cond[i - 1u] : 0.f)) * d[0]; };
+    if (filter == 0) return texel_pdf(tex_wrap((int32_t) floorf(u * (float) W), W, wrap), tex_wrap((int32_t) floorf(v * (float) H), H, wrap)) * (float) (W * H);
+    const float px = fmaf(u, (float) W, -.5f), py = fmaf(v, (float) H, -.5f), fx = floorf(px), fy = floorf(py);
+    const float w1x = px - fx, w1y = py - fy, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    const int32_t x0 = tex_wrap((int32_t) fx, W, wrap), x1 = tex_wrap((int32_t) fx + 1, W, wrap);
+    const int32_t y0 = tex_wrap((int32_t) fy, H, wrap), y1 = tex_wrap((int32_t) fy + 1, H, wrap);
+    const float v0 = fmaf(w0x, texel_pdf(x0, y0), w1x * texel_pdf(x1, y0)), v1 = fmaf(w0x, texel_pdf(x0, y1), w1x * texel_pdf(x1, y1));
+    return fmaf(w0y, v0, w1y * v1) * (float) (W * H);
+}
+// Rectangle::eval_parameterization (rectangle.cpp:173-192): the point of the rectangle at (u, v), found by a ray from one normal length above it straight down --
+// through the rectangle's own intersection routine and surface interaction, whose roundings the point and its uv then carry.  Not for instanced rectangles.
+DTOF_D bool rect_eval_parameterization(const DShape &sh, float u, float v, V3 &p, V3 &n, float &si_u, float &si_v, float &area_norm) {
+    const V3 pw = xf_point(sh.to_world, mk(u * 2.f - 1.f, v * 2.f - 1.f, 0.f));
+    n = mk(sh.n[0], sh.n[1], sh.n[2]);
+    const V3 o = pw + n, d = -n;
+    float t, b1, b2;
+    if (!rect_hit(sh, o, d, kLargest, t, b1, b2)) return false;
+    const V3 ph = vfma(d, t, o), tr = mk(sh.to_world[3], sh.to_world[7], sh.to_world[11]);
+    p = ph + n * dot(tr - ph, n);                                                       // rectangle.cpp:289-294
+    si_u = fmaf(b1, .5f, .5f); si_v = fmaf(b2, .5f, .5f);
+    area_norm = norm(cross(mk(sh.dp_du[0], sh.dp_du[1], sh.dp_du[2]), mk(sh.dp_dv[0], sh.dp_dv[1], sh.dp_dv[2])));
+    return true;
+}
 // The material parameters of one hit: the shape's constants, or the lookups of the textures bound to their slots (m_specular_reflectance->eval(si),
 // m_alpha_u->eval_1(si), ...)
 struct HitMaterial { float spec_refl[3], spec_trans[3], alpha_u, alpha_v; };

@@ -212,6 +212,8 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     std::vector<uint32_t> tex_rec_of(sc.textures.size(), 0xffffffffu);   // texture index -> word offset of its record: every texture is stored once, however many shapes use it
     auto check_words = [&]() { if (tables.size() > 0x3fffffffu) throw std::runtime_error("scene tables exceed the 4 GiB the 32-bit blob offsets address"); };
     // the record of a texture and its texels go to the tables area, once per texture (the offsets are rebased below); returns the word offset of the record
+    std::vector<bool> sampled_texture(sc.textures.size(), false);   // textures an area emitter's radiance is sampled through get a DiscreteDistribution2D
+    for (const HostShape &hs : sc.shapes) if (hs.tex_radiance >= 0) sampled_texture[(size_t) hs.tex_radiance] = true;
     auto place_texture = [&](int index) -> uint32_t {
         const HostTexture &t = sc.textures[(size_t) index];
         uint32_t &rec = tex_rec_of[(size_t) index];
@@ -228,6 +230,28 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
             const size_t at = tables.size();
             tables.resize(at + t.data.size());
             if (!t.data.empty()) memcpy(&tables[at], t.data.data(), t.data.size() * 4);
+            if (sampled_texture[(size_t) index] && t.kind == TEX_BITMAP) {
+                // DiscreteDistribution2D(data, size) (distr_2d.h:92-117) over BitmapTexture::rebuild_internals' importance map (bitmap.cpp:689-724: the luminance of RGB texels,
+                // the value of gray ones): running sums of each row and of the row totals, accumulated in double, stored as float32
+                const uint32_t W = t.width, H = t.height, C = t.channels;
+                const size_t at_d = tables.size();
+                tables.resize(at_d + 2 + H + (size_t) W * H);
+                double accum_marg = 0.0;
+                for (uint32_t y = 0; y < H; ++y) {
+                    double accum_cond = 0.0;
+                    for (uint32_t x = 0; x < W; ++x) {
+                        const float *px = &t.data[((size_t) y * W + x) * C];
+                        const float imp = C == 1 ? px[0] : px[0] * 0.212671f + px[1] * 0.715160f + px[2] * 0.072169f;
+                        accum_cond += (double) imp;
+                        const float f = (float) accum_cond; memcpy(&tables[at_d + 2 + H + (size_t) y * W + x], &f, 4);
+                    }
+                    accum_marg += accum_cond;
+                    const float f = (float) accum_marg; memcpy(&tables[at_d + 2 + y], &f, 4);
+                }
+                const float inv_norm = (float) accum_marg, norm = (float) (1.0 / accum_marg);
+                memcpy(&tables[at_d], &norm, 4); memcpy(&tables[at_d + 1], &inv_norm, 4);
+                tables[rec + 14] = (uint32_t) at_d * 4u;   // DTexture::distr_off, rebased with the record
+            }
             check_words();
         }
         return rec;
@@ -510,6 +534,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
             shapes[i].flags |= SF_BLEND; shapes[i].blend_other = (uint32_t) k; shapes[i].blend_weight = h.blend_weight;
             if (h.tex_blend >= 0) tex_recs.push_back({ (uint32_t) i, 7u, place_texture(h.tex_blend) });
         }
+        for (size_t i = 0; i < n_real; ++i) if (sc.shapes[i].tex_radiance >= 0) tex_recs.push_back({ (uint32_t) i, 8u, place_texture(sc.shapes[i].tex_radiance) });   // textured area emitters
     }
     h.n_shapes = (uint32_t) shapes.size(); h.n_tris = (uint32_t) tris.size(); h.n_emitters = (uint32_t) emitters.size();
     (void) has_instances;
@@ -557,8 +582,8 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         const uint32_t rec_off = h.off_tables + tr.rec * 4u;
         DShape &d = shapes[tr.shape];
         if (tr.slot == 0) d.nonlinear |= (rec_off >> 4) << 1;
-        else (tr.slot == 1 ? d.tex_spec : tr.slot == 2 ? d.tex_trans : tr.slot == 3 ? d.tex_alpha_u : tr.slot == 4 ? d.tex_alpha_v : tr.slot == 5 ? d.tex_opacity : tr.slot == 6 ? d.tex_normal : d.tex_blend) = rec_off >> 4;
-        if (!rebased[tr.rec / 4]) { tables[tr.rec + 3] += h.off_tables; rebased[tr.rec / 4] = true; }   // DTexture::data_off, once per record
+        else (tr.slot == 1 ? d.tex_spec : tr.slot == 2 ? d.tex_trans : tr.slot == 3 ? d.tex_alpha_u : tr.slot == 4 ? d.tex_alpha_v : tr.slot == 5 ? d.tex_opacity : tr.slot == 6 ? d.tex_normal : tr.slot == 7 ? d.tex_blend : d.tex_radiance) = rec_off >> 4;
+        if (!rebased[tr.rec / 4]) { tables[tr.rec + 3] += h.off_tables; if (tables[tr.rec + 14]) tables[tr.rec + 14] += h.off_tables; rebased[tr.rec / 4] = true; }   // DTexture::data_off / distr_off, once per record
     }
     std::vector<uint8_t> blob(off, 0);
     memcpy(blob.data(), &h, sizeof h);

@@ -1195,9 +1195,22 @@ static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string
             if (g_attached_emitters && !g_attached_emitters->insert((const void *) &e).second) fail("An endpoint can be only be attached to a single shape.");   // endpoint.cpp:36-40
             if (strip_to_world) fail("Instancing of emitters is not supported");   // shapegroup.cpp:27-28: an animated (or grouped) shape becomes an instance (xml.cpp:1165-1195), which cannot carry an emitter in the reference either
             if (e.transforms.count("to_world")) fail("Found a 'to_world' transformation -- this is not allowed. The area light inherits this transformation from its parent shape.");
-            auto rc = e.colors.find("radiance");
-            if (rc != e.colors.end()) for (int i = 0; i < 3; ++i) s.radiance[i] = (float) rc->second[i];
-            else { float v = (float) e.props.get_float("radiance", 1.0); s.radiance[0] = s.radiance[1] = s.radiance[2] = v; }
+            bool textured = false;
+            for (size_t i = 0; i < e.children.size(); ++i) {
+                const Obj *c2 = e.children[i].second.get();
+                if (!c2 || c2->tag != "texture") continue;
+                const std::string &cname = i < e.ref_names.size() && !e.ref_names[i].empty() ? e.ref_names[i] : c2->name;
+                if (cname != "radiance") fail("unreferenced object \"" + cname + "\" in plugin of type \"area\"");
+                textured = true;
+            }
+            if (textured) {   // area.cpp:73: a texture makes the emitter spatially varying: it is then sampled through the texture (area.cpp:129-153)
+                if (s.kind != SHAPE_RECT) fail("area emitter: a textured radiance is supported on rectangles only");
+                s.tex_radiance = reflectance_of(e, "radiance", 1.f, s.radiance);
+            } else {
+                auto rc = e.colors.find("radiance");
+                if (rc != e.colors.end()) for (int i = 0; i < 3; ++i) s.radiance[i] = (float) rc->second[i];
+                else { float v = (float) e.props.get_float("radiance", 1.0); s.radiance[0] = s.radiance[1] = s.radiance[2] = v; }
+            }
             s.emitter = true;
         }
         else fail("unsupported child <" + c.first + "> in shape");

@@ -1517,6 +1517,73 @@ static void orc_texture_eval_1_grad(const orc_texture *tex, float u, float v, fl
     *gu = (float) W * (tex->to_uv[0] * dfx + tex->to_uv[2] * dfy);
     *gv = (float) H * (tex->to_uv[1] * dfx + tex->to_uv[3] * dfy);
 }
+/* DiscreteDistribution2D::sample (distr_2d.h:140-181): row from the marginal, column from the conditional CDF (dr::binary_search over [0, n - 1]: the first index whose
+ * CDF value is not below the sample, the last index if there is none), the re-uniformised variate of both */
+static uint32_t cdf_search(const float *cdf, uint32_t n, float x) {
+    uint32_t lo = 0, hi = n - 1u;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cdf[mid] < x) lo = mid + 1u; else hi = mid; }
+    return lo;
+}
+static void distr2d_sample(const orc_texture *t, float sx, float sy, uint32_t *col_out, uint32_t *row_out, float *pdf, float *rx, float *ry) {
+    const uint32_t W = (uint32_t) t->width, H = (uint32_t) t->height;
+    sx = f_min(f_max(sx, 1.17549435e-38f), 0.99999994f); sy = f_min(f_max(sy, 1.17549435e-38f), 0.99999994f);   /* clamp(sample, Smallest, OneMinusEpsilon) */
+    sy *= t->inv_normalization;
+    const uint32_t row = cdf_search(t->marg_cdf, H, sy), offset = row * W;
+    sx *= t->cond_cdf[offset + W - 1u];
+    const uint32_t col = cdf_search(t->cond_cdf + offset, W, sx);
+    const float col_cdf_0 = col > 0 ? t->cond_cdf[offset + col - 1u] : 0.f, col_cdf_1 = t->cond_cdf[offset + col];
+    const float row_cdf_0 = row > 0 ? t->marg_cdf[row - 1u] : 0.f, row_cdf_1 = t->marg_cdf[row];
+    sx -= col_cdf_0; sy -= row_cdf_0;
+    if (col_cdf_1 != col_cdf_0) sx /= col_cdf_1 - col_cdf_0;
+    if (row_cdf_1 != row_cdf_0) sy /= row_cdf_1 - row_cdf_0;
+    *col_out = col; *row_out = row; *pdf = (col_cdf_1 - col_cdf_0) * t->normalization; *rx = sx; *ry = sy;
+}
+static float distr2d_pdf(const orc_texture *t, int32_t x, int32_t y) {   /* DiscreteDistribution2D::pdf (:119-130) */
+    const uint32_t index = (uint32_t) x + (uint32_t) y * (uint32_t) t->width;
+    return (t->cond_cdf[index] - (x > 0 ? t->cond_cdf[index - 1u] : 0.f)) * t->normalization;
+}
+static inline float interval_to_tent(float s) {   /* warp.h:196-200 */
+    s -= .5f;
+    const float v = fmaf(fabsf(s), -2.f, 1.f), r = 1.f - (v > 0.f ? sqrtf(v) : 0.f);
+    return copysignf(r, s);
+}
+/* Texture::sample_position (texture.cpp:56-59: the identity for every texture without its own) / BitmapTexture::sample_position (bitmap.cpp:450-487) */
+static void texture_sample_position(const orc_texture *t, float sx, float sy, float *u, float *v, float *pdf) {
+    if (t->kind != ORC_TEX_BITMAP) { *u = sx; *v = sy; *pdf = 1.f; return; }
+    uint32_t col, row; float p, rx, ry;
+    distr2d_sample(t, sx, sy, &col, &row, &p, &rx, &ry);
+    const float iw = f_rcp((float) t->width), ih = f_rcp((float) t->height);
+    float x, y;
+    if (t->filter == 0) { x = ((float) col + rx) * iw; y = ((float) row + ry) * ih; }
+    else {
+        x = (((float) col + .5f) + interval_to_tent(rx)) * iw; y = (((float) row + .5f) + interval_to_tent(ry)) * ih;
+        if (t->wrap == 0) { if (x < 0.f) x += 1.f; if (x > 1.f) x -= 1.f; if (y < 0.f) y += 1.f; if (y > 1.f) y -= 1.f; }
+        else { if (x < 0.f) x = -x; if (x > 1.f) x = 2.f - x; if (y < 0.f) y = -y; if (y > 1.f) y = 2.f - y; }
+    }
+    *u = x; *v = y; *pdf = p * (float) (t->width * t->height);
+}
+/* Texture::pdf_position (texture.cpp:61-64) / BitmapTexture::pdf_position (bitmap.cpp:489-528) */
+static float texture_pdf_position(const orc_texture *t, float u, float v) {
+    if (t->kind != ORC_TEX_BITMAP) return 1.f;
+    const int32_t W = t->width, H = t->height;
+    if (t->filter == 0) {
+        const int32_t x = tex_wrap((int32_t) floorf(u * (float) W), W, t->wrap), y = tex_wrap((int32_t) floorf(v * (float) H), H, t->wrap);
+        return distr2d_pdf(t, x, y) * (float) (W * H);
+    }
+    const float px = fmaf(u, (float) W, -.5f), py = fmaf(v, (float) H, -.5f), fx = floorf(px), fy = floorf(py);
+    const float w1x = px - fx, w1y = py - fy, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    const int32_t x0 = tex_wrap((int32_t) fx, W, t->wrap), x1 = tex_wrap((int32_t) fx + 1, W, t->wrap);
+    const int32_t y0 = tex_wrap((int32_t) fy, H, t->wrap), y1 = tex_wrap((int32_t) fy + 1, H, t->wrap);
+    const float v00 = distr2d_pdf(t, x0, y0), v10 = distr2d_pdf(t, x1, y0), v01 = distr2d_pdf(t, x0, y1), v11 = distr2d_pdf(t, x1, y1);
+    const float v0 = fmaf(w0x, v00, w1x * v10), v1 = fmaf(w0x, v01, w1x * v11);
+    return fmaf(w0y, v0, w1y * v1) * (float) (W * H);
+}
+/* known-answer entries (tests): DiscreteDistribution2D::sample -> col, row, pdf, re-uniformised sample; Texture::sample_position -> u, v, pdf; pdf_position */
+void orc_kat_distr2d_sample(const orc_texture *t, float sx, float sy, float *out5) {
+    uint32_t col, row; distr2d_sample(t, sx, sy, &col, &row, out5 + 2, out5 + 3, out5 + 4); out5[0] = (float) col; out5[1] = (float) row;
+}
+void orc_kat_texture_sample_position(const orc_texture *t, float sx, float sy, float *out3) { texture_sample_position(t, sx, sy, out3, out3 + 1, out3 + 2); }
+float orc_kat_texture_pdf_position(const orc_texture *t, float u, float v) { return texture_pdf_position(t, u, v); }
 /* the material parameters of one hit: the shape's constants, or the lookups of the textures bound to their slots */
 typedef struct { float spec_refl[3], spec_trans[3], alpha_u, alpha_v; } orc_mat;
 static orc_mat material_at(const orc_shape *sh, float u, float v) {
@@ -1789,6 +1856,18 @@ typedef struct { const orc_scene *sc; const orc_params *p; uint32_t seed, spp, s
 /* One lane: SamplingIntegrator::render (lane->pixel, src/render/integrator.cpp:273-290),
  * render_sample Doppler branch (:476-542), DopplerToFPathIntegrator::sample
  * (src/integrators/dopplertofpath.cpp:79-283). */
+/* Rectangle::eval_parameterization (rectangle.cpp:173-192): the point of the rectangle at (u, v), found by a ray from one normal length above it straight down --
+ * through the rectangle's own intersection routine and surface interaction, whose roundings the point and its uv then carry */
+static int rect_eval_parameterization(const orc_shape *sh, float u, float v, orc_si *si) {
+    const v3 p = m_point(sh->to_world, V(u * 2.f - 1.f, v * 2.f - 1.f, 0.f));
+    const v3 n = v_normalize(m_normal(sh->to_object, V(0.f, 0.f, 1.f)));
+    const v3 o = v_add(p, n), d = v_neg(n);
+    float t, b1, b2;
+    if (!rect_intersect(sh, o, d, ORC_LARGEST, &t, &b1, &b2)) return 0;
+    rect_si(sh, o, d, t, si);
+    si->uv_u = fmaf(b1, .5f, .5f); si->uv_v = fmaf(b2, .5f, .5f);   /* rectangle.cpp:312-313 */
+    return 1;
+}
 /* Emitter::sample_direction of every supported emitter (point.cpp:118-147, constant.cpp:118-148, directional.cpp:148-176, envmap.cpp:363-406,
  * spot.cpp:152-187, area.cpp:116-159 -> Shape / Sphere::sample_direction), for the reference point `ref` and the 2-D sample (sx, e2):
  * sampled point, direction, distance, density, delta flag, importance weight, and whether the sample is usable.  Visibility is the caller's. */
@@ -1851,6 +1930,26 @@ static void emitter_sample_direction(const orc_scene *sc, const orc_emitter *em,
          * Rectangle::sample_position rectangle.cpp:152-166 */
         const orc_shape *es = &sc->shapes[em->shape];
         v3 en;
+        if (es->tex_radiance) {
+            /* AreaLight::sample_direction with a spatially varying radiance (area.cpp:129-153): the TEXTURE is sampled (Texture::sample_position), the shape maps the uv
+             * to a point (Rectangle::eval_parameterization), the density goes from uv space to solid angle with |dp_du x dp_dv| */
+            float u, v, pdf; texture_sample_position(es->tex_radiance, sx, e2, &u, &v, &pdf);
+            orc_si ps; const int valid = pdf != 0.f && rect_eval_parameterization(es, u, v, &ps);
+            dsp = valid ? ps.p : si.p; en = valid ? ps.n : V(0.f, 0.f, 1.f);
+            dd = v_sub(dsp, si.p);
+            const float dist2 = v_dot(dd, dd);
+            ds_dist = sqrtf(dist2);
+            dd = v_mul(dd, f_rcp(ds_dist));
+            const float dp = v_dot(dd, en);
+            em_active = valid && dp < 0.f;
+            ds_pdf = em_active ? pdf / v_norm(v_cross(ps.dp_du, ps.dp_dv)) * dist2 / -dp : 0.f;
+            ds_delta = 0;
+            float c[3] = { 0.f, 0.f, 0.f };
+            if (em_active) orc_texture_eval(es->tex_radiance, ps.uv_u, ps.uv_v, c);      /* m_radiance->eval(si) / ds.pdf */
+            em_weight = em_active ? V(c[0] / ds_pdf, c[1] / ds_pdf, c[2] / ds_pdf) : V(0, 0, 0);
+            *dsp_out = dsp; *dd_out = dd; *dist_out = ds_dist; *pdf_out = ds_pdf; *delta_out = ds_delta; *weight_out = em_weight; *active_out = em_active;
+            return;
+        }
         if (es->kind == ORC_SHAPE_SPHERE) {   /* Sphere overrides Shape::sample_direction */
             sphere_sample_direction(es, si.p, sx, e2, &dsp, &en, &dd, &ds_dist, &ds_pdf);
         } else {
@@ -1989,6 +2088,11 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
             float em_pdf = 0.f;
             if (!prev_delta) {   /* Scene::pdf_emitter_direction scene.cpp:293-299 -> AreaLight::pdf_direction area.cpp:161-180 */
                 float dp = v_dot(dsd, si.sh_n);   /* ds.n = si.sh_frame.n: PositionSample(si), records.h:63-65 */
+                if (dp < 0.f && si.shape->tex_radiance) {   /* area.cpp:170-176: pdf_position of the texture at ds.uv = si.uv, through the parameterisation's |dp_du x dp_dv| */
+                    orc_si ps;
+                    if (rect_eval_parameterization(si.shape, si.uv_u, si.uv_v, &ps))
+                        em_pdf = texture_pdf_position(si.shape->tex_radiance, si.uv_u, si.uv_v) * f_sqr(dist) / (v_norm(v_cross(ps.dp_du, ps.dp_dv)) * -dp) * pmf;
+                } else
                 if (dp < 0.f) {   /* Shape::pdf_direction shape.cpp:386-396; pdf_position = 1/area (rectangle.cpp:168-171, mesh.cpp:570-573) */
                     float adp = fabsf(dp);
                     float pdf = si.shape->kind == ORC_SHAPE_SPHERE ? sphere_pdf_direction(si.shape, prev_p, dsd, si.sh_n, dist)
@@ -2000,6 +2104,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
             /* AreaLight::eval area.cpp:82-89, masked by prev_bsdf_pdf > 0 */
             int on = si.wi.z > 0.f && prev_bsdf_pdf > 0.f;
             v3 le = on ? V(si.shape->radiance[0], si.shape->radiance[1], si.shape->radiance[2]) : V(0, 0, 0);
+            if (on && si.shape->tex_radiance) { float c[3]; orc_texture_eval(si.shape->tex_radiance, si.uv_u, si.uv_v, c); le = V(c[0], c[1], c[2]); }   /* m_radiance->eval(si) */
             v3 v = v_mul(le, mis_bsdf);
             if (!plain) v = v_mul(v, orc_modulation_weight(p, time, path_length));
             res = V(fmaf(thr.x, v.x, res.x), fmaf(thr.y, v.y, res.y), fmaf(thr.z, v.z, res.z));

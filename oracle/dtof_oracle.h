@@ -45,6 +45,10 @@ typedef struct {
     float   to_uv[4];        /* m00, m01, m10, m11 */
     float   color0[3], color1[3];   /* checkerboard (constant colours) */
     const float *data;       /* bitmap: height * width * channels linear float32 texels, row 0 first */
+    /* DiscreteDistribution2D over the texels (include/mitsuba/core/distr_2d.h:75-181; BitmapTexture::rebuild_internals, bitmap.cpp:674-734: the luminance of RGB
+     * texels, the value of gray ones), built only for textures that are importance-sampled (the radiance of an area emitter): running sums kept in float32,
+     * accumulated in double; NULL otherwise */
+    const float *cond_cdf, *marg_cdf; float normalization, inv_normalization;
 } orc_texture;
 
 typedef struct orc_shape_s {
@@ -100,6 +104,8 @@ typedef struct orc_shape_s {
     const orc_texture *tex_normal;
     /* ... or inside a `bumpmap` (src/bsdfs/bumpmap.cpp): tex_normal is its height texture (Texture::eval_1_grad per hit), bump_scale its `scale` */
     int32_t bumpmap; float bump_scale;
+    /* texture on the `radiance` of the shape's area emitter (src/emitters/area.cpp: the emitter is then sampled through the texture; rectangles only) */
+    const orc_texture *tex_radiance;
     /* `blendbsdf` (src/bsdfs/blendbsdf.cpp): everything above describes bsdf_0 (with its own twosided / normalmap / bumpmap); blend_other = a record whose BSDF fields
      * describe bsdf_1 (its geometry fields are unused); the weight is a constant or a texture (Texture::eval_1 per hit).  NULL: no blend. */
     const struct orc_shape_s *blend_other; float blend_weight; const orc_texture *tex_blend;

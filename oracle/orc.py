@@ -18,7 +18,8 @@ M16 = C.c_float * 16
 
 class OrcTexture(C.Structure):
     _fields_ = [("kind", C.c_int32), ("filter", C.c_int32), ("wrap", C.c_int32), ("channels", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
-                ("to_uv", C.c_float * 4), ("color0", C.c_float * 3), ("color1", C.c_float * 3), ("data", C.POINTER(C.c_float))]
+                ("to_uv", C.c_float * 4), ("color0", C.c_float * 3), ("color1", C.c_float * 3), ("data", C.POINTER(C.c_float)),
+                ("cond_cdf", C.POINTER(C.c_float)), ("marg_cdf", C.POINTER(C.c_float)), ("normalization", C.c_float), ("inv_normalization", C.c_float)]
 
 
 class OrcShape(C.Structure):
@@ -36,7 +37,7 @@ class OrcShape(C.Structure):
                 ("inv_eta_2", C.c_float), ("fdr_int", C.c_float), ("spec_sampling_weight", C.c_float),
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("rough_table", C.POINTER(C.c_float)), ("tex_refl", C.POINTER(OrcTexture)), ("mf_type", C.c_int32), ("sample_all", C.c_int32),
                 ("tex_spec", C.POINTER(OrcTexture)), ("tex_trans", C.POINTER(OrcTexture)), ("tex_alpha_u", C.POINTER(OrcTexture)), ("tex_alpha_v", C.POINTER(OrcTexture)),
-                ("masked", C.c_int32), ("opacity", C.c_float), ("tex_opacity", C.POINTER(OrcTexture)), ("tex_normal", C.POINTER(OrcTexture)), ("bumpmap", C.c_int32), ("bump_scale", C.c_float),
+                ("masked", C.c_int32), ("opacity", C.c_float), ("tex_opacity", C.POINTER(OrcTexture)), ("tex_normal", C.POINTER(OrcTexture)), ("bumpmap", C.c_int32), ("bump_scale", C.c_float), ("tex_radiance", C.POINTER(OrcTexture)),
                 ("blend_other", C.c_void_p), ("blend_weight", C.c_float), ("tex_blend", C.POINTER(OrcTexture))]
 
 
@@ -269,6 +270,8 @@ class Scene:
             s_mean = (((sp[0] + sp[1]) + sp[2]) * third if s.get("spec_refl_mean") is None else np.float32(s["spec_refl_mean"])) if s.get("has_spec_refl") else np.float32(1.0)
             o.fdr_int, o.spec_sampling_weight = float(ir), float(s_mean / (d_mean + s_mean))
             s["rough_table"], s["plastic_params"] = table, np.array([o.inv_eta_2, o.fdr_int, o.spec_sampling_weight], np.float32)
+        if s.get("tex_radiance") is not None:   # textured radiance of the shape's area emitter: the texture with its sampling distribution
+            o.tex_radiance = self._make_texture(s["tex_radiance"], distribution=True)
         if s.get("blend_other") is not None:   # blendbsdf: this record is bsdf_0, a second record carries bsdf_1
             other = OrcShape()
             self._fill_bsdf(other, s["blend_other"])
@@ -278,8 +281,19 @@ class Scene:
             if s.get("tex_blend") is not None:
                 o.tex_blend = self._make_texture(s["tex_blend"])
 
-    def _make_texture(self, tex):
+    def _make_texture(self, tex, distribution=False):
         t = OrcTexture()
+        if distribution and tex["data"] is not None:
+            # DiscreteDistribution2D over the texels (distr_2d.h:92-117; BitmapTexture::rebuild_internals, bitmap.cpp:689-724): luminance of RGB texels in float32,
+            # row-wise running sums and the running sum of the row totals accumulated in double, stored as float32
+            d = np.asarray(tex["data"], np.float32).reshape(tex["height"], tex["width"], tex["channels"])
+            imp = d[..., 0] if tex["channels"] == 1 else (d[..., 0] * np.float32(0.212671) + d[..., 1] * np.float32(0.715160)) + d[..., 2] * np.float32(0.072169)
+            cond = np.cumsum(imp.astype(np.float64), axis=1)
+            marg = np.cumsum(cond[:, -1])
+            cond32, marg32 = np.ascontiguousarray(cond.astype(np.float32)), np.ascontiguousarray(marg.astype(np.float32))
+            t.cond_cdf, t.marg_cdf = cond32.ctypes.data_as(C.POINTER(C.c_float)), marg32.ctypes.data_as(C.POINTER(C.c_float))
+            t.inv_normalization, t.normalization = float(np.float32(marg[-1])), float(np.float32(1.0 / marg[-1]))
+            self._keep += [cond32, marg32]
         t.kind, t.filter, t.wrap, t.channels, t.width, t.height = tex["kind"], tex["filter"], tex["wrap"], tex["channels"], tex["width"], tex["height"]
         t.to_uv = (C.c_float * 4)(*tex["to_uv"].tolist())
         t.color0, t.color1 = (C.c_float * 3)(*tex["color0"].tolist()), (C.c_float * 3)(*tex["color1"].tolist())

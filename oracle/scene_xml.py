@@ -1105,7 +1105,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
         flip = False
     bsdfs = [c for c in sp.children if c[0] == "bsdf" or (c[0] == "ref" and registry[c[1]][0] == "bsdf")]
     ems = [c[1] if c[0] == "emitter" else registry[c[1]][1] for c in sp.children if c[0] == "emitter" or (c[0] == "ref" and registry[c[1]][0] == "emitter")]
-    emitter, radiance = 0, np.zeros(3, F32)
+    emitter, radiance, tex_radiance = 0, np.zeros(3, F32), None
     if ems:   # src/emitters/area.cpp:64-76 on a static shape (rectangle or triangle mesh)
         if len(ems) > 1:
             raise ValueError("Only a single Emitter child object can be specified per shape.")
@@ -1119,8 +1119,14 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
             raise ValueError("Instancing of emitters is not supported")   # shapegroup.cpp:27-28 (an animated shape becomes an instance, xml.cpp:1165-1195)
         if "to_world" in ems[0]:
             raise ValueError("Found a 'to_world' transformation -- this is not allowed.")
-        rad = ems[0]["radiance"] if "radiance" in ems[0] else ("float", 1.0)
-        radiance = np.asarray([rad[1]] * 3 if rad[0] in ("float", "int") else rad[1], dtype=np.float64).astype(F32)
+        tex_radiance = _slot_texture(ems[0], "radiance", registry, base_dir)   # area.cpp:73: a texture makes the emitter spatially varying
+        if tex_radiance is not None:
+            if kind != 0:
+                raise ValueError("area emitter: a textured radiance is supported on rectangles only")
+            radiance = np.asarray([tex_radiance["mean"]] * 3, F32)
+        else:
+            rad = ems[0]["radiance"] if "radiance" in ems[0] else ("float", 1.0)
+            radiance = np.asarray([rad[1]] * 3 if rad[0] in ("float", "int") else rad[1], dtype=np.float64).astype(F32)
         emitter = 1
     if bsdfs:
         bp = bsdfs[0][1] if bsdfs[0][0] == "bsdf" else registry[bsdfs[0][1]][1]
@@ -1151,7 +1157,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
                 alpha_u=brec.get("alpha_u", F32(0.1)), alpha_v=brec.get("alpha_v", F32(0.1)), has_spec_refl=brec.get("has_spec_refl", 0),
                 mf_type=brec.get("mf_type", 1), sample_all=brec.get("sample_all", 0), tex_refl=brec.get("tex_refl"),
                 tex_spec=brec.get("tex_spec"), tex_trans=brec.get("tex_trans"), tex_alpha_u=brec.get("tex_alpha_u"), tex_alpha_v=brec.get("tex_alpha_v"),
-                masked=brec.get("masked", 0), opacity=brec.get("opacity", F32(1.0)), tex_opacity=brec.get("tex_opacity"), tex_normal=brec.get("tex_normal"), bumpmap=brec.get("bumpmap", 0), bump_scale=brec.get("bump_scale", F32(1.0)),
+                masked=brec.get("masked", 0), opacity=brec.get("opacity", F32(1.0)), tex_opacity=brec.get("tex_opacity"), tex_normal=brec.get("tex_normal"), bumpmap=brec.get("bumpmap", 0), bump_scale=brec.get("bump_scale", F32(1.0)), tex_radiance=tex_radiance,
                 blend_other=brec.get("blend_other"), blend_weight=brec.get("blend_weight", F32(0.5)), tex_blend=brec.get("tex_blend"),
                 spec_refl_mean=brec.get("spec_refl_mean"))
 

@@ -397,6 +397,26 @@ def cornell_masked(res=128, spp=16):
     return s + LIGHT + AREA_LIGHT + "</scene>\n"
 
 
+def cornell_textured_light(res=128, spp=16):
+    """cornell_boxes.xml lit by three rectangle area emitters whose `radiance` is a texture (src/emitters/area.cpp:129-153: the emitter is then sampled THROUGH the texture):
+    an RGB bitmap (bilinear, repeat: DiscreteDistribution2D over the luminance + tent warp), a gray bitmap with the nearest filter and mirror wrap, a checkerboard
+    (Texture::sample_position is the identity); no other light"""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
+    for b in BSDFS:
+        s += bsdf(*b)
+    for name, m, b in WALLS:
+        s += rect(name, m, b)
+    s += cube("ShortBox", SHORT, "ShortBoxBSDF", "0.015") + cube("TallBox", TALL, "TallBoxBSDF", "-0.015")
+    light = ('\t<shape type="rectangle" id="%s">\n\t\t<transform name="to_world">\n\t\t\t<scale x="%s" y="%s" z="1" />\n\t\t\t<rotate x="1" angle="90" />\n'
+             '\t\t\t<translate x="%s" y="1.98" z="%s" />\n\t\t</transform>\n\t\t<emitter type="area">\n%s\t\t</emitter>\n\t</shape>\n')
+    s += light % ("LightA", "0.3", "0.25", "-0.45", "0.1", '\t\t\t<texture type="bitmap" name="radiance"><string name="filename" value="tex_rgb.png" /></texture>\n')
+    s += light % ("LightB", "0.2", "0.3", "0.5", "-0.3", '\t\t\t<texture type="bitmap" name="radiance"><string name="filename" value="tex_gray.png" /><boolean name="raw" value="true" />'
+                  '<string name="filter_type" value="nearest" /><string name="wrap_mode" value="mirror" /></texture>\n')
+    s += light % ("LightC", "0.2", "0.15", "0.1", "0.6", '\t\t\t<texture type="checkerboard" name="radiance"><rgb name="color0" value="6, 1, 0.5" /><rgb name="color1" value="0.5, 2, 9" />'
+                  '<transform name="to_uv"><scale x="2" y="3" /></transform></texture>\n')
+    return s + "</scene>\n"
+
+
 def cornell_blend(res=128, spp=16):
     """cornell_boxes.xml with `blendbsdf` BSDFs (src/bsdfs/blendbsdf.cpp): the back wall a two-sided blend of a diffuse and a roughconductor BSDF with a checkerboard weight
     (the adapter outside), the floor a blend of two two-sided BSDFs (plastic, conductor) with a constant weight, the short box a mask around a two-sided blend of a normal-mapped
@@ -698,6 +718,7 @@ def main():
         "cornell_masked.xml": cornell_masked(),
         "cornell_normalmap.xml": cornell_normalmap(),
         "cornell_blend.xml": cornell_blend(),
+        "cornell_textured_light.xml": cornell_textured_light(),
         "cornell_env.xml": cornell_env(),
         "cornell_envmap.xml": cornell_envmap(),
         "cornell_sun.xml": cornell_sun(),
@@ -718,7 +739,7 @@ def main():
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
     names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml",
-             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_textured_specular.xml", "cornell_masked.xml", "cornell_normalmap.xml", "cornell_blend.xml", "tex_normal.png", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_thinlens.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
+             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_textured_specular.xml", "cornell_masked.xml", "cornell_normalmap.xml", "cornell_blend.xml", "cornell_textured_light.xml", "tex_normal.png", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_thinlens.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
         return

@@ -93,6 +93,8 @@ CONFIGS = [
     ("normalmap", "cornell_normalmap.xml", dict(resx=32, resy=32, max_depth=5), 8),
     # `blendbsdf`: constant / checkerboard / bitmap weights, reflecting and transmitting partners, inside twosided and mask, a normal-mapped partner
     ("blend", "cornell_blend.xml", dict(resx=32, resy=32, max_depth=6), 8),
+    # area emitters with a textured radiance (bitmap: importance-sampled through DiscreteDistribution2D, bilinear + nearest; checkerboard: uniform), MIS both ways
+    ("textured_light", "cornell_textured_light.xml", dict(resx=32, resy=32, max_depth=4), 16),
     # `constant` environment emitter: rays that leave the scene, environment sampling with MIS, valid_ray
     # sample_visible = false: all microfacet normals are sampled (roughconductor / roughplastic weights and densities, roughdielectric with
     # Walter et al.'s roughness scaling)

@@ -1004,6 +1004,11 @@ def _random_scene(rng, mesh_dir=None):
         if i == light_on:      # area lights sit on static shapes (moving ones would be instanced emitters, which the reference refuses), not on cylinders
             moving, kind = False, rng.choice(["rectangle", "cube", "sphere", "disk"])
         area = '<emitter type="area"><rgb name="radiance" value="%s"/></emitter>' % rgb(2, 8) if i == light_on else ""
+        if area and kind == "rectangle" and rng.random() < 0.5:   # src/emitters/area.cpp:129-176: a textured radiance, sampled through the texture
+            area = ('<emitter type="area"><texture type="checkerboard" name="radiance"><rgb name="color0" value="%s"/><rgb name="color1" value="%s"/></texture></emitter>' % (rgb(0, 3), rgb(2, 9))
+                    if rng.random() < 0.4 else
+                    '<emitter type="area"><texture type="bitmap" name="radiance"><string name="filename" value="%s"/><string name="filter_type" value="%s"/><string name="wrap_mode" value="%s"/></texture></emitter>'
+                    % (os.path.join(SCENES, str(rng.choice(["tex_rgb.png", "tex_gray.png"]))), rng.choice(["bilinear", "nearest"]), rng.choice(["repeat", "mirror", "clamp"])))
         mat = '<bsdf type="diffuse"/>' if area else material()
         if kind == "cylinder":
             geo = '<point name="p0" x="0" y="0" z="-1"/><point name="p1" x="0" y="0" z="1"/><float name="radius" value="0.5"/>'
