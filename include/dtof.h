@@ -167,6 +167,17 @@ int dtof_integrator_render(const dtof_integrator *integrator, const dtof_sampler
  * offsets == NULL / n_offsets == 0 uses the integrator's own phase offset. */
 int dtof_render_rows(dtof_scene *scene, uint32_t seed, uint32_t spp, int32_t row_begin, int32_t row_end,
                      const float *offsets, int n_offsets, float *d_film_rgbw, dtof_render_stats *stats);
+/* Frames WITHOUT a host synchronisation per frame (a caller that renders frame after frame -- bench.py, an animation -- otherwise leaves the GPU idle while the host
+ * reads counters and sets up the next call): dtof_render_rows_async enqueues what dtof_render_rows enqueues on the scene's stream and returns; HIP events around the
+ * frame and its stages are kept; the bounce / shadow-ray counters are not read back.  dtof_clear_async / dtof_develop_async put a memset / the film development
+ * (HDRFilm::develop, hdrfilm.cpp:305-406) on the same stream.  dtof_async_collect waits for the stream, sums the event times and launch counters of the frames
+ * enqueued since the last collect into `sum` (n_bounces / n_shadow_rays stay 0), writes the duration of each frame to frame_ms[0 .. capacity) and their number to
+ * *n_frames.  Frames whose pipeline needs counters on the host between bounces (paths that leave the fused first-bounce kernel) still wait there. */
+int dtof_render_rows_async(dtof_scene *scene, uint32_t seed, uint32_t spp, int32_t row_begin, int32_t row_end, const float *offsets, int n_offsets, float *d_film);
+int dtof_clear_async(dtof_scene *scene, void *d_ptr, size_t bytes);
+int dtof_develop_async(dtof_scene *scene, const float *d_film, float *d_rgb, int64_t n_pixels);
+int dtof_async_collect(dtof_scene *scene, dtof_render_stats *sum, double *frame_ms, uint32_t capacity, uint32_t *n_frames);
+
 /* Interleaved shards (load balance when the cost of a row depends on what it sees): renders the stripes of rows
  * [first_row + k * stripe_period, first_row + k * stripe_period + stripe_rows), k = 0, 1, ..., below crop_height and accumulates
  * like dtof_render_rows.  Rank r of N uses first_row = r * stripe_rows, stripe_period = N * stripe_rows; the union over the

@@ -123,6 +123,10 @@ def _lib():
     L.dtof_sampler_seeded.argtypes = [vp]
     L.dtof_eval_modulation.argtypes = [vp, C.c_int, vp, vp, vp, C.c_uint32]
     L.dtof_eval_component.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_uint32]
+    L.dtof_render_rows_async.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, vp, C.c_int, vp]
+    L.dtof_clear_async.argtypes = [vp, vp, C.c_size_t]
+    L.dtof_develop_async.argtypes = [vp, vp, vp, C.c_int64]
+    L.dtof_async_collect.argtypes = [vp, vp, vp, C.c_uint32, vp]
     L.dtof_ray_intersect.argtypes = [vp, C.c_uint32, vp, vp, vp]
     L.dtof_ray_intersect_uv.argtypes = [vp, C.c_uint32, vp, vp, vp, vp]
     L.dtof_ray_test.argtypes = [vp, C.c_uint32, vp, vp]
@@ -225,6 +229,23 @@ class Scene:
             _check(_lib().dtof_render_rows(self._h, seed, spp, row_begin, row_end, off.ctypes.data, len(off), d_film_ptr, C.byref(st)))
         self.last_stats = st.as_dict()
         return self.last_stats
+
+    def render_rows_async(self, d_film_ptr, seed, spp, row_begin, row_end, offsets=None):
+        """enqueue one frame on the scene's stream without waiting for it (dtof_render_rows_async); collect() waits and returns the timings"""
+        offs = np.ascontiguousarray(offsets, np.float32) if offsets is not None else None
+        _check(_lib().dtof_render_rows_async(self._h, seed, spp, row_begin, row_end, offs.ctypes.data if offs is not None else None, len(offs) if offs is not None else 0, d_film_ptr))
+
+    def clear_async(self, d_ptr, nbytes):
+        _check(_lib().dtof_clear_async(self._h, d_ptr, nbytes))
+
+    def develop_async(self, d_film_ptr, d_rgb_ptr, n_pixels):
+        _check(_lib().dtof_develop_async(self._h, d_film_ptr, d_rgb_ptr, n_pixels))
+
+    def collect(self, max_frames=4096):
+        """wait for the frames enqueued by render_rows_async -> (summed stats dict, per-frame GPU milliseconds)"""
+        st, ms, n = _Stats(), np.zeros(max_frames, np.float64), C.c_uint32(0)
+        _check(_lib().dtof_async_collect(self._h, C.byref(st), ms.ctypes.data, max_frames, C.byref(n)))
+        return st.as_dict(), ms[:min(n.value, max_frames)].copy()
 
     def render_stripes(self, d_film_ptr, seed, spp, first_row, stripe_rows, stripe_period, offsets=None):
         """Accumulate the rows of the stripes [first_row + k * stripe_period, ... + stripe_rows) (interleaved shard of one rank)."""

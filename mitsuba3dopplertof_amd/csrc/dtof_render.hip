@@ -101,6 +101,9 @@ struct dtof_scene {
     std::atomic<bool> stop { false };
     // reusable statistics plumbing (creating events / pinned memory per call costs ~0.3 ms)
     std::vector<hipEvent_t> event_pool; size_t events_used = 0;
+    // frames enqueued by dtof_render_rows_async and not collected yet: their events (frame, stages) and launch counters; no host synchronisation until dtof_async_collect
+    struct DeferredFrame { hipEvent_t ev0, ev1; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[6]; dtof_render_stats counters; };
+    std::vector<DeferredFrame> deferred; bool defer_next = false;
     uint32_t *pinned_counts = nullptr; size_t pinned_words = 0;
     hipEvent_t take_event() {
         if (events_used == event_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) throw std::runtime_error("hipEventCreate failed"); event_pool.push_back(e); }
@@ -261,7 +264,7 @@ static const char *const kStageNames[6] = { "dtof:generate", "dtof:trace", "dtof
 
 struct StageTimer {
     bool on; dtof_scene *sc; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[6];
-    StageTimer(bool enabled, dtof_scene *scene) : on(enabled), sc(scene) { sc->events_used = 0; }
+    StageTimer(bool enabled, dtof_scene *scene) : on(enabled), sc(scene) { if (sc->deferred.empty()) sc->events_used = 0; }   // the events of uncollected frames stay taken
     int begin(int stage, hipStream_t s) {
         if (roctx().push) roctx().push(kStageNames[stage]);
         if (!on) return -1;
@@ -433,7 +436,8 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     // per-iteration totals of every batch: sized ONCE (DevBuf::ensure reallocates without copying, and a hipFree in the middle of the
     // frame would also synchronise the device)
     const uint32_t run_passes = lane_dump ? dump_pass + 1 : n_passes;   // a lane dump of pass k needs the stream states passes 0 .. k-1 leave
-    if (stats && last > first) sc->d_sums.ensure((size_t) ((last - first + batch - 1) / batch) * run_passes * 2 * kMaxIter);
+    const bool deferred = sc->defer_next; sc->defer_next = false;   // dtof_render_rows_async: timings by events, no counters read back, no synchronisation at the end
+    if (stats && !deferred && last > first) sc->d_sums.ensure((size_t) ((last - first + batch - 1) / batch) * run_passes * 2 * kMaxIter);
     if (n_passes > 1 && last > first) {   // stream states carried from pass to pass (Sampler::advance keeps the RNGs running, sampler.cpp:52-55)
         sc->d_pass_rng.ensure((size_t) (last - first) * 3);
         rp.pass_rng = sc->d_pass_rng.p; rp.pass_first = (uint32_t) first;
@@ -522,13 +526,22 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         HIP_CHECK(hipEventRecord(batch_done[batch_index & 1], s));
         if (stats) {   // per-iteration totals of this batch are reduced on the device; one small copy after the last batch
             const uint32_t it_counted = std::min<uint32_t>(it, kMaxIter);
-            if (it_counted) launch_sum_counts(q.counts, n_seg, 2 * it_counted, sc->d_sums.p + (size_t) batch_index * 2 * kMaxIter, s);
+            if (it_counted && !deferred) launch_sum_counts(q.counts, n_seg, 2 * it_counted, sc->d_sums.p + (size_t) batch_index * 2 * kMaxIter, s);
             batch_lanes.push_back(rp.n_lanes); batch_iters.push_back(it_counted);
             stats->n_batches++;
         }
     }
     if (n_streams == 2) { HIP_CHECK(hipEventRecord(ev_join, ss[1])); HIP_CHECK(hipStreamWaitEvent(ss[0], ev_join, 0)); }
     hipStream_t s = ss[0];
+    if (stats && deferred) {
+        HIP_CHECK(hipEventRecord(ev1, s));
+        dtof_scene::DeferredFrame f; f.ev0 = ev0; f.ev1 = ev1; f.counters = *stats;
+        for (int k = 0; k < 6; ++k) f.ev[k] = tm.ev[k];
+        for (uint32_t b : batch_lanes) f.counters.n_paths += b;
+        sc->deferred.push_back(std::move(f));
+        if (sc->stop.load()) throw std::runtime_error("cancelled");
+        return;
+    }
     if (stats) {
         HIP_CHECK(hipEventRecord(ev1, s)); HIP_CHECK(hipEventSynchronize(ev1));
         float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); stats->ms_total = ms;
@@ -782,6 +795,54 @@ int dtof_render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_be
         if (!sc || !d_film) throw std::runtime_error("null argument");
         sc->stop = false;
         render_rows(sc, seed, spp, row_begin, row_end, offsets, n_offsets, d_film, stats);
+    });
+}
+
+int dtof_render_rows_async(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin, int32_t row_end, const float *offsets, int n_offsets, float *d_film) {
+    return guarded([&] {
+        if (!sc || !d_film) throw std::runtime_error("null argument");
+        sc->stop = false;
+        dtof_render_stats local;
+        sc->defer_next = true;
+        try { render_rows(sc, seed, spp, row_begin, row_end, offsets, n_offsets, d_film, &local); } catch (...) { sc->defer_next = false; throw; }
+    });
+}
+int dtof_clear_async(dtof_scene *sc, void *d_ptr, size_t bytes) {
+    return guarded([&] {
+        if (!sc || !d_ptr) throw std::runtime_error("null argument");
+        ensure_device(sc);
+        HIP_CHECK(hipMemsetAsync(d_ptr, 0, bytes, sc->stream));
+    });
+}
+int dtof_develop_async(dtof_scene *sc, const float *d_film, float *d_rgb, int64_t n_pixels) {
+    return guarded([&] {
+        if (!sc || !d_film || !d_rgb) throw std::runtime_error("null argument");
+        ensure_device(sc);
+        launch_develop(d_film, d_rgb, n_pixels, sc->stream);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+int dtof_async_collect(dtof_scene *sc, dtof_render_stats *sum, double *frame_ms, uint32_t capacity, uint32_t *n_frames) {
+    return guarded([&] {
+        if (!sc || !sum || !n_frames) throw std::runtime_error("null argument");
+        ensure_device(sc);
+        HIP_CHECK(hipStreamSynchronize(sc->stream));
+        memset(sum, 0, sizeof *sum);
+        *n_frames = (uint32_t) sc->deferred.size();
+        auto total = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) { double ms = 0; for (auto &p : v) { float t = 0; HIP_CHECK(hipEventElapsedTime(&t, p.first, p.second)); ms += t; } return ms; };
+        uint32_t i = 0;
+        for (auto &f : sc->deferred) {
+            float t = 0; HIP_CHECK(hipEventElapsedTime(&t, f.ev0, f.ev1));
+            if (frame_ms && i < capacity) frame_ms[i] = t;
+            ++i;
+            sum->ms_total += t;
+            sum->ms_generate += total(f.ev[0]); sum->ms_trace += total(f.ev[1]); sum->ms_first += total(f.ev[5]); sum->ms_shade += total(f.ev[2]) + total(f.ev[5]);
+            sum->ms_shadow += total(f.ev[3]); sum->ms_splat += total(f.ev[4]);
+            sum->n_paths += f.counters.n_paths; sum->n_batches += f.counters.n_batches;
+            sum->n_launches_trace += f.counters.n_launches_trace; sum->n_launches_shade += f.counters.n_launches_shade; sum->n_launches_shadow += f.counters.n_launches_shadow;
+            sum->n_launches_first += f.counters.n_launches_first; sum->n_inline_iterations += f.counters.n_inline_iterations;
+        }
+        sc->deferred.clear(); sc->events_used = 0;
     });
 }
 

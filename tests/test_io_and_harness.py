@@ -369,3 +369,37 @@ def test_error_tables_of_the_experiment_grids(tmp_path):
                                   os.path.join(base, "results", "gt_images"), grid - 1, grid - 1, exit_if_file_exists=True)
     assert again == rows
     assert analysis.main(["--expnumber", "1", "--basedir", base, "--scene_names", "cornell-box", "--grid", str(grid), "--no_plots"]) == 0
+
+
+@pytest.mark.gpu
+def test_async_frames_equal_synchronous_frames(mi):
+    """dtof_render_rows_async / dtof_clear_async / dtof_develop_async / dtof_async_collect: frames enqueued back to back on the scene's stream give the films of the
+    synchronous calls (same lanes; the film's float atomics add them in another order), one event-timed record per frame, launch counters summed"""
+    import torch
+    sc = mi.load_file(os.path.join(SCENES, "cornell_wall.xml"), resx=128, resy=96)
+    W, H = sc.size
+    film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    ref = []
+    for seed in (0, 1, 2):
+        film.zero_(); torch.cuda.synchronize()
+        st = sc.render_rows(film.data_ptr(), seed=seed, spp=16, row_begin=0, row_end=H)
+        ref.append((film.cpu().numpy().copy(), st))
+    films = [torch.zeros_like(film) for _ in range(3)]
+    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for seed in (0, 1, 2):
+        sc.clear_async(films[seed].data_ptr(), films[seed].numel() * 4)
+        sc.render_rows_async(films[seed].data_ptr(), seed, 16, 0, H)
+    sc.develop_async(films[2].data_ptr(), rgb.data_ptr(), H * W)
+    st, ms = sc.collect()
+    assert len(ms) == 3 and np.all(ms > 0) and abs(st["ms_total"] - ms.sum()) < 1e-6
+    assert st["n_paths"] == 3 * W * H * 16 and st["n_launches_first"] == sum(r[1]["n_launches_first"] for r in ref) and st["ms_first"] > 0
+    for seed in (0, 1, 2):
+        a, b = films[seed].cpu().numpy(), ref[seed][0]
+        assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
+    dev = rgb.cpu().numpy()
+    assert np.isfinite(dev).all() and np.abs(dev).max() > 0
+    st2, ms2 = sc.collect()                    # nothing pending: an empty collect
+    assert len(ms2) == 0 and st2["n_paths"] == 0
+    img = sc.render(seed=0, spp=16)            # the synchronous path afterwards
+    assert np.isfinite(img).all()
