@@ -321,6 +321,15 @@ def main():
             e = run_workload(ctx, "c2", other, max(5, args.steps // 2), 2, "bands", args.stripe_rows)
             extra["c2_" + other] = {"value": round(e["value"], 2), "unit": "Mpaths/s", "scaling": other, "ms_per_step": round(e["ms_per_step"], 4),
                                      "ms_per_step_min": round(e["ms_per_step_min"], 4), "spp_total": e["spp"], "paths_per_step": e["total_paths"]}
+        if world == 1 and r.get("pipelined"):   # the same workload through the loop the multi-rank runs use (one host synchronisation per step): the N = 1 figure to hold N > 1 against
+            os.environ["DTOF_BENCH_SYNC"] = "1"
+            try:
+                e = run_workload(ctx, "c2", args.scaling, max(5, args.steps // 2), 2, "bands", args.stripe_rows)
+            finally:
+                del os.environ["DTOF_BENCH_SYNC"]
+            extra["c2_sync_loop"] = {"value": round(e["value"], 2), "unit": "Mpaths/s", "ms_per_step": round(e["ms_per_step"], 4), "ms_per_step_min": round(e["ms_per_step_min"], 4),
+                                     "what": "the headline workload with one host synchronisation per step, as every rank of an N > 1 run does it (the film exchange runs on torch's streams): "
+                                             "scaling efficiencies compare like with like against THIS figure; `value` is the pipelined loop"}
         e = run_workload(ctx, "c4", "strong", 4, 1, "stripes", args.stripe_rows)
         extra["c4_strong"] = {"value": round(e["value"], 2), "unit": "Mpaths/s", "scaling": "strong", "ms_per_step": round(e["ms_per_step"], 4),
                               "ms_per_step_min": round(e["ms_per_step_min"], 4), "paths_per_step": e["total_paths"],
