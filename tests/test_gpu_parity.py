@@ -1090,3 +1090,50 @@ def test_random_scene_structures(mi, orc, block):
                         assert img_err(batch[k_], r2) <= IMG_TOL, (block, it, pipeline, "offset", off, xml)
             finally:
                 os.environ.pop("DTOF_PIPELINE", None)
+
+
+@pytest.mark.parametrize("variant", ["spec", "blend"])
+def test_resident_stage_with_the_every_bsdf_kernels(mi, orc, monkeypatch, variant):
+    """The resident first-bounce kernels (TLAS in LDS, 8 / 12 / 16 waves per CU) in their every-BSDF instantiations (SPEC = 1, and SPEC = 2 with a blendbsdf): a Domino
+    field of 196 moving instances whose cubes carry rough / masked / blended materials over a textured ground, lit by a point and an area light -- large enough for the
+    resident stage (blob > 16 KiB, <= 1 024 TLAS nodes, no BLAS).  Every lane bit-exact against the oracle for each setting of DTOF_RESIDENT, and the K = 4 offset batch
+    equal to four single renders."""
+    sys.path.insert(0, SCENES)
+    import make_scenes
+    xml = make_scenes.domino(n_side=14, res=48, spp=8)
+    ground = ('<bsdf type="twosided" id="GroundBSDF"><bsdf type="diffuse"><texture type="checkerboard" name="reflectance"><rgb name="color0" value="0.7, 0.6, 0.5"/><rgb name="color1" value="0.2, 0.3, 0.4"/>'
+              '<transform name="to_uv"><scale x="6" y="6"/></transform></texture></bsdf></bsdf>')
+    if variant == "spec":
+        domino = ('<bsdf type="mask" id="DominoBSDF"><float name="opacity" value="0.9"/><bsdf type="twosided"><bsdf type="roughplastic"><string name="distribution" value="ggx"/>'
+                  '<float name="alpha" value="0.2"/><rgb name="diffuse_reflectance" value="0.75, 0.55, 0.35"/></bsdf></bsdf></bsdf>')
+    else:
+        domino = ('<bsdf type="twosided" id="DominoBSDF"><bsdf type="blendbsdf"><float name="weight" value="0.4"/><bsdf type="diffuse"><rgb name="reflectance" value="0.75, 0.55, 0.35"/></bsdf>'
+                  '<bsdf type="roughconductor"><string name="distribution" value="beckmann"/><float name="alpha" value="0.25"/></bsdf></bsdf></bsdf>')
+    xml = xml.replace(make_scenes.bsdf("GroundBSDF", "0.6, 0.6, 0.6"), ground + "\n").replace(make_scenes.bsdf("DominoBSDF", "0.75, 0.55, 0.35"), domino + "\n")
+    xml = xml.replace("</scene>", '<shape type="rectangle"><transform name="to_world"><scale value="2"/><rotate x="1" angle="90"/><translate y="6"/></transform>'
+                                  '<emitter type="area"><rgb name="radiance" value="6, 5, 4"/></emitter></shape></scene>')
+    assert "DominoBSDF" in xml and xml.count('type="mask"') + xml.count('type="blendbsdf"') == 1
+    path = os.path.join(SCENES, "_domino_spec_%s.xml" % variant)
+    open(path, "w").write(xml)
+    try:
+        P = dict(max_depth=5)
+        osc = orc.Scene(path, P)
+        pd = osc.params()
+        n = 48 * 48 * 8
+        ref = osc.render_lanes(pd, 3, 8, 0, n, threads=NCPU)
+        monkeypatch.setenv("DTOF_PIPELINE", "fused")
+        for res_waves in ("0", "8", "12", "16"):
+            monkeypatch.setenv("DTOF_RESIDENT", res_waves)
+            sc = mi.load_file(path, **P)
+            info = sc.info()
+            assert info["scene_blob_bytes"] > 16 * 1024 and info["n_bvh_nodes"] <= 1024 and info["n_objects"] == 198
+            g = sc.sample_lanes(3, 8, 0, n)
+            for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+                assert np.array_equal(bits(g[k]), bits(ref[k])), (variant, res_waves, k, int((bits(g[k]) != bits(ref[k])).any(axis=-1).sum() if g[k].ndim > 1 else 0))
+            offs = [0.0, 0.25, 0.5, 0.75]
+            batch = sc.render(seed=3, spp=8, offsets=offs)
+            for k_, off in enumerate(offs):
+                single = np.asarray(mi.load_file(path, hetero_offset=off, **P).render(seed=3, spp=8))
+                assert np.abs(batch[k_] - single).max() <= 1e-5 * max(float(np.abs(single).max()), 1e-30), (variant, res_waves, off)
+    finally:
+        os.remove(path)
