@@ -394,7 +394,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             Rng sel = use_path ? path : main;
             float e1 = next_f32(sel), e2 = next_f32(sel);
             // has_flag(bsdf->flags(), BSDFFlags::Smooth) (:178): diffuse, (rough)plastic and roughconductor have a smooth lobe
-            bool active_em = active_next && sv.n_emitters > 0 && (!SPEC || bsdf_is_smooth(sh->bsdf) || ((sh->flags & SF_BLEND) && bsdf_is_smooth(sv.shapes[sh->blend_other].bsdf)));   // a blend has the flags of both
+            bool active_em = active_next && sv.n_emitters > 0 && (!SPEC || bsdf_is_smooth(sh->bsdf) || ((sh->flags & (SF_BLEND | SF_TWOSIDED2)) && bsdf_is_smooth(sv.shapes[sh->blend_other].bsdf)));   // a blend (a twosided of two BSDFs) has the flags of both
             V3 em_weight = mk(0, 0, 0), wo = mk(0, 0, 0); float ds_dist = 0.f, ds_pdf = 0.f; bool ds_delta = true;
             if (active_em) {
                 uint32_t ne = sv.n_emitters, idx = 0; float em_w = 1.f, sx = e1;
@@ -520,12 +520,14 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                 blend_w = fmin_(fmax_(blend_w, 0.f), 1.f);   // eval_weight (:213-215)
                 pick_1 = sample_1 <= blend_w;
             }
+            // `twosided` with two nested BSDFs (twosided.cpp:75-86,111-148): the back side (wi.z < 0) has a record of its own; the flip itself is the chain's
+            const DShape *side_sh = (SPEC == 2 && (sh->flags & SF_TWOSIDED2) && si.wi.z < 0.f) ? &sv.shapes[sh->blend_other] : sh;
             const V3 wi_plain = si.wi, wo_plain = wo;
             V3 bsdf_val = mk(0, 0, 0), bsdf_weight = mk(0, 0, 0), bs_wo = mk(0, 0, 0);
             float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; bool bs_delta = false;
             V3 val_0 = mk(0, 0, 0), keep_weight = mk(0, 0, 0), keep_wo = mk(0, 0, 0); float pdf_0 = 0.f, keep_pdf = 0.f, keep_eta = 0.f; bool keep_delta = false;
             for (int pass = 0; pass < (SPEC == 2 && blend ? 2 : 1); ++pass) {
-                const DShape *bsh = pass ? &sv.shapes[sh->blend_other] : sh;
+                const DShape *bsh = pass ? &sv.shapes[sh->blend_other] : side_sh;
                 const float s1 = !blend ? sample_1 : (pass ? sample_1 / blend_w : (sample_1 - blend_w) / (1.f - blend_w));
                 si.wi = wi_plain; wo = wo_plain;
                 // ---- BSDF eval_pdf + sample (twosided.cpp:111-148,219-258; diffuse.cpp:101-125,160-180)

@@ -748,7 +748,7 @@ int dtof_scene_export(const dtof_scene *sc, int kind, float *out, size_t cap, si
         else if (kind == 22) for (auto &s : sc->host.shapes) { v.push_back(s.bumpmap ? 1.f : 0.f); v.push_back(s.bump_scale); }   // bumpmap: is one, scale
         else if (kind == 24) for (auto &s : sc->host.shapes) v.push_back((float) s.tex_radiance);   // texture on the area emitter's radiance, -1 = a constant
         else if (kind == 23) for (auto &s : sc->host.shapes) {   // blendbsdf: is one, weight, its texture, kind and two-sidedness of bsdf_1
-            v.push_back(s.blend_other ? 1.f : 0.f); v.push_back(s.blend_weight); v.push_back((float) s.tex_blend);
+            v.push_back(s.blend_other ? (s.two_bsdfs ? 2.f : 1.f) : 0.f); v.push_back(s.blend_weight); v.push_back((float) s.tex_blend);   // 1 blendbsdf, 2 twosided with two BSDFs
             v.push_back(s.blend_other ? (float) s.blend_other->bsdf : -1.f); v.push_back(s.blend_other && s.blend_other->twosided ? 1.f : 0.f);
         }
         else if (kind == 18) for (auto &e : sc->host.emitters) {   // every emitter: kind, pos, intensity, first row of to_local (directional: its direction)

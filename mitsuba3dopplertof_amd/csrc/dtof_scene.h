@@ -21,6 +21,7 @@ enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMA
                             SF_NORMALMAP = 256 /* the BSDF sits inside a `normalmap` (src/bsdfs/normalmap.cpp): DShape::tex_normal; a twosided around it is applied first */,
                             SF_BUMPMAP = 512 /* ... or inside a `bumpmap` (src/bsdfs/bumpmap.cpp): tex_normal is its height texture, bump_scale its `scale` */,
                             SF_BLEND = 1024 /* `blendbsdf` (src/bsdfs/blendbsdf.cpp): this record is bsdf_0, DShape::blend_other the record of bsdf_1 */,
+                            SF_TWOSIDED2 = 2048 /* `twosided` with two nested BSDFs (twosided.cpp:75-86): this record is the front side's, DShape::blend_other the back side's */,
                             SF_TEXCOORDS = 32 /* mesh with vertex texcoords (si.uv interpolates them; otherwise si.uv = the barycentrics, mesh.cpp:720-737) */ };
 enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4, BSDF_ROUGHPLASTIC = 5, BSDF_THINDIELECTRIC = 6, BSDF_ROUGHDIELECTRIC = 7 };
 enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1, EMITTER_SPOT = 2, EMITTER_CONSTANT = 3, EMITTER_ENVMAP = 4, EMITTER_DIRECTIONAL = 5 };
@@ -168,6 +169,7 @@ struct HostShape {
     int tex_refl = -1;                     // texture on reflectance / diffuse_reflectance: index into HostScene::textures
     int tex_spec = -1, tex_trans = -1, tex_alpha_u = -1, tex_alpha_v = -1;   // textures on specular_reflectance / specular_transmittance / the roughness (alpha sets both)
     int tex_normal = -1;                                                      // the BSDF sits inside a `normalmap` (src/bsdfs/normalmap.cpp): its RGB texture
+    bool two_bsdfs = false;                                                   // `twosided` with two nested BSDFs: *blend_other is the back side's
     std::shared_ptr<HostShape> blend_other; float blend_weight = .5f; int tex_blend = -1;   // `blendbsdf`: the fields above describe bsdf_0, *blend_other (BSDF fields only) bsdf_1
     int tex_radiance = -1;                                                    // texture on the area emitter's radiance
     bool bumpmap = false; float bump_scale = 1.f;                             // ... or inside a `bumpmap` (src/bsdfs/bumpmap.cpp): tex_normal is the height texture

@@ -531,7 +531,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
             const size_t k = shapes.size() - 1;
             memset(&shapes[k], 0, sizeof(DShape));
             fill_material(*h.blend_other, k);
-            shapes[i].flags |= SF_BLEND; shapes[i].blend_other = (uint32_t) k; shapes[i].blend_weight = h.blend_weight;
+            shapes[i].flags |= h.two_bsdfs ? SF_TWOSIDED2 : SF_BLEND; shapes[i].blend_other = (uint32_t) k; shapes[i].blend_weight = h.blend_weight;
             if (h.tex_blend >= 0) tex_recs.push_back({ (uint32_t) i, 7u, place_texture(h.tex_blend) });
         }
         for (size_t i = 0; i < n_real; ++i) if (sc.shapes[i].tex_radiance >= 0) tex_recs.push_back({ (uint32_t) i, 8u, place_texture(sc.shapes[i].tex_radiance) });   // textured area emitters

@@ -967,10 +967,21 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         return;
     }
     if (b.plugin == "twosided") {
-        const Obj *inner = nullptr; int n = 0;
-        for (auto &c : b.children) if (c.first == "bsdf") { inner = c.second.get(); ++n; }
-        if (n != 1) fail("twosided: exactly one nested BSDF is supported");
+        const Obj *inner = nullptr, *back = nullptr; int n = 0;
+        for (auto &c : b.children) if (c.first == "bsdf") { (n == 0 ? inner : back) = c.second.get(); ++n; }
+        if (n > 2) fail("At most two nested BSDFs can be specified!");
+        if (n == 0) fail("A nested one-sided material is required!");
         bsdf_of(*inner, s);
+        if (n == 2) {   // twosided.cpp:75-86: the second BSDF is the back side's
+            auto other = std::make_shared<HostShape>();
+            bsdf_of(*back, *other);
+            auto transmits2 = [](const HostShape &h) { return h.bsdf == BSDF_DIELECTRIC || h.bsdf == BSDF_THINDIELECTRIC || h.bsdf == BSDF_ROUGHDIELECTRIC; };
+            if (s.blend_other || other->blend_other || s.masked || other->masked) fail("twosided: a blendbsdf or mask as one of two nested BSDFs is not supported in this build");
+            if (transmits2(s) || transmits2(*other)) fail("Only materials without a transmission component can be nested!");
+            s.twosided = other->twosided = true;
+            s.blend_other = other; s.two_bsdfs = true;
+            return;
+        }
         auto transmits = [](const HostShape &h) { return h.bsdf == BSDF_DIELECTRIC || h.bsdf == BSDF_THINDIELECTRIC || h.bsdf == BSDF_ROUGHDIELECTRIC; };
         if (transmits(s) || s.masked || (s.blend_other && transmits(*s.blend_other))) fail("Only materials without a transmission component can be nested!");
         s.twosided = true;

@@ -1823,6 +1823,10 @@ static void framed_bsdf_eval_pdf_sample(const orc_shape *sh, const orc_geo *g, v
  * otherwise bsdf_0 with (sample1 - weight) / (1 - weight), and the nested sample goes back AS IT IS (its own weight and density, not the mixture's) */
 static void blended_bsdf_eval_pdf_sample(const orc_shape *sh, const orc_geo *g, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
     if (!sh->blend_other) { framed_bsdf_eval_pdf_sample(sh, g, wi_in, wo, active_em, sample_1, s2x, s2y, uv_u, uv_v, out); return; }
+    if (sh->two_bsdfs) {   /* TwoSidedBRDF with two nested BSDFs (twosided.cpp:111-148,219-258): the front side's for wi.z > 0, the back side's (after the flip) for wi.z < 0 */
+        framed_bsdf_eval_pdf_sample(wi_in.z < 0.f ? (const orc_shape *) sh->blend_other : sh, g, wi_in, wo, active_em, sample_1, s2x, s2y, uv_u, uv_v, out);
+        return;
+    }
     float w = sh->tex_blend ? orc_texture_eval_1(sh->tex_blend, uv_u, uv_v) : sh->blend_weight;
     w = f_min(f_max(w, 0.f), 1.f);                                      /* eval_weight (:213-215) */
     const int pick_1 = sample_1 <= w;

@@ -109,6 +109,8 @@ typedef struct orc_shape_s {
     /* `blendbsdf` (src/bsdfs/blendbsdf.cpp): everything above describes bsdf_0 (with its own twosided / normalmap / bumpmap); blend_other = a record whose BSDF fields
      * describe bsdf_1 (its geometry fields are unused); the weight is a constant or a texture (Texture::eval_1 per hit).  NULL: no blend. */
     const struct orc_shape_s *blend_other; float blend_weight; const orc_texture *tex_blend;
+    /* `twosided` with TWO nested BSDFs (twosided.cpp:75-86): everything above describes the front side's, blend_other the back side's (both records two-sided) */
+    int32_t two_bsdfs;
 } orc_shape;
 
 typedef struct {

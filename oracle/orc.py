@@ -38,7 +38,7 @@ class OrcShape(C.Structure):
                 ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("rough_table", C.POINTER(C.c_float)), ("tex_refl", C.POINTER(OrcTexture)), ("mf_type", C.c_int32), ("sample_all", C.c_int32),
                 ("tex_spec", C.POINTER(OrcTexture)), ("tex_trans", C.POINTER(OrcTexture)), ("tex_alpha_u", C.POINTER(OrcTexture)), ("tex_alpha_v", C.POINTER(OrcTexture)),
                 ("masked", C.c_int32), ("opacity", C.c_float), ("tex_opacity", C.POINTER(OrcTexture)), ("tex_normal", C.POINTER(OrcTexture)), ("bumpmap", C.c_int32), ("bump_scale", C.c_float), ("tex_radiance", C.POINTER(OrcTexture)),
-                ("blend_other", C.c_void_p), ("blend_weight", C.c_float), ("tex_blend", C.POINTER(OrcTexture))]
+                ("blend_other", C.c_void_p), ("blend_weight", C.c_float), ("tex_blend", C.POINTER(OrcTexture)), ("two_bsdfs", C.c_int32)]
 
 
 class OrcGroup(C.Structure):
@@ -278,6 +278,7 @@ class Scene:
             self._keep.append(other)
             o.blend_other = C.addressof(other)
             o.blend_weight = float(s.get("blend_weight", 0.5))
+            o.two_bsdfs = int(s.get("two_bsdfs", 0))
             if s.get("tex_blend") is not None:
                 o.tex_blend = self._make_texture(s["tex_blend"])
 

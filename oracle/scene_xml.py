@@ -915,11 +915,23 @@ def _bsdf_of(props, registry, base_dir=""):
         props.check_unreferenced("bsdf", ())
         return rec
     if props.plugin == "twosided":
-        inner = [c for c in props.children if c[0] in ("bsdf", "ref")]
-        if len(inner) != 1:
-            raise ValueError("twosided: exactly one nested BSDF is supported")
+        inner = [c for c in props.children if c[0] == "bsdf" or (c[0] == "ref" and registry[c[1]][0] == "bsdf")]
+        if len(inner) > 2:
+            raise ValueError("At most two nested BSDFs can be specified!")
+        if not inner:
+            raise ValueError("A nested one-sided material is required!")
         ip = inner[0][1] if inner[0][0] == "bsdf" else registry[inner[0][1]][1]
         rec = _bsdf_of(ip, registry, base_dir)
+        if len(inner) == 2:   # twosided.cpp:75-86: the second BSDF is the back side's
+            ip2 = inner[1][1] if inner[1][0] == "bsdf" else registry[inner[1][1]][1]
+            back = _bsdf_of(ip2, registry, base_dir)
+            if rec.get("blend_other") is not None or back.get("blend_other") is not None or rec.get("masked") or back.get("masked"):
+                raise ValueError("twosided: a blendbsdf or mask as one of two nested BSDFs is not supported in this build")
+            if rec["bsdf"] in (2, 6, 7) or back["bsdf"] in (2, 6, 7):
+                raise ValueError("Only materials without a transmission component can be nested!")
+            rec["twosided"] = back["twosided"] = 1
+            rec["blend_other"], rec["two_bsdfs"] = back, 1
+            return rec
         other = rec.get("blend_other")
         if rec["bsdf"] in (2, 6, 7) or rec.get("masked") or (other is not None and other["bsdf"] in (2, 6, 7)):   # twosided.cpp:47-52
             raise ValueError("Only materials without a transmission component can be nested!")
@@ -1158,7 +1170,7 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
                 mf_type=brec.get("mf_type", 1), sample_all=brec.get("sample_all", 0), tex_refl=brec.get("tex_refl"),
                 tex_spec=brec.get("tex_spec"), tex_trans=brec.get("tex_trans"), tex_alpha_u=brec.get("tex_alpha_u"), tex_alpha_v=brec.get("tex_alpha_v"),
                 masked=brec.get("masked", 0), opacity=brec.get("opacity", F32(1.0)), tex_opacity=brec.get("tex_opacity"), tex_normal=brec.get("tex_normal"), bumpmap=brec.get("bumpmap", 0), bump_scale=brec.get("bump_scale", F32(1.0)), tex_radiance=tex_radiance,
-                blend_other=brec.get("blend_other"), blend_weight=brec.get("blend_weight", F32(0.5)), tex_blend=brec.get("tex_blend"),
+                blend_other=brec.get("blend_other"), blend_weight=brec.get("blend_weight", F32(0.5)), tex_blend=brec.get("tex_blend"), two_bsdfs=brec.get("two_bsdfs", 0),
                 spec_refl_mean=brec.get("spec_refl_mean"))
 
 

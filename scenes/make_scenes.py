@@ -420,7 +420,7 @@ def cornell_textured_light(res=128, spp=16):
 def cornell_blend(res=128, spp=16):
     """cornell_boxes.xml with `blendbsdf` BSDFs (src/bsdfs/blendbsdf.cpp): the back wall a two-sided blend of a diffuse and a roughconductor BSDF with a checkerboard weight
     (the adapter outside), the floor a blend of two two-sided BSDFs (plastic, conductor) with a constant weight, the short box a mask around a two-sided blend of a normal-mapped
-    diffuse BSDF and a roughplastic with a bitmap weight, the tall box a ONE-sided blend of a diffuse BSDF and a dielectric (a transmitting partner); point + area light"""
+    diffuse BSDF and a roughplastic with a bitmap weight, the tall box a ONE-sided blend of a diffuse BSDF and a dielectric (a transmitting partner), a free-standing panel with a `twosided` of TWO BSDFs; point + area light"""
     s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5") + SENSOR.format(fov="19.5", cam=CAM)
     for b in BSDFS:
         if b[0] not in ("ShortBoxBSDF", "TallBoxBSDF", "BackWallBSDF", "FloorBSDF"):
@@ -434,6 +434,12 @@ def cornell_blend(res=128, spp=16):
           '<boolean name="raw" value="true" /></texture><bsdf type="normalmap"><texture type="bitmap" name="normalmap"><string name="filename" value="tex_normal.png" /><boolean name="raw" value="true" /></texture>'
           '<bsdf type="diffuse"><rgb name="reflectance" value="0.7, 0.3, 0.2" /></bsdf></bsdf><bsdf type="roughplastic"><string name="distribution" value="beckmann" /><float name="alpha" value="0.15" />'
           '<rgb name="diffuse_reflectance" value="0.2, 0.4, 0.7" /></bsdf></bsdf></bsdf></bsdf>\n')
+    # `twosided` with TWO nested BSDFs (twosided.cpp:75-86): a free-standing panel, plastic in front, a normal-mapped rough conductor behind
+    s += ('\t<bsdf type="twosided" id="PanelBSDF"><bsdf type="plastic"><rgb name="diffuse_reflectance" value="0.8, 0.7, 0.2" /></bsdf><bsdf type="normalmap"><texture type="bitmap" name="normalmap">'
+          '<string name="filename" value="tex_normal.png" /><boolean name="raw" value="true" /></texture><bsdf type="roughconductor"><string name="distribution" value="ggx" /><float name="alpha" value="0.3" />'
+          '</bsdf></bsdf></bsdf>\n')
+    s += ('\t<shape type="rectangle" id="Panel">\n\t\t<ref id="PanelBSDF" />\n\t\t<transform name="to_world">\n\t\t\t<scale x="0.35" y="0.45" z="1" />\n\t\t\t<rotate y="1" angle="55" />\n'
+          '\t\t\t<translate x="0.55" y="1.2" z="0.3" />\n\t\t</transform>\n\t</shape>\n')
     s += ('\t<bsdf type="blendbsdf" id="TallBoxBSDF"><float name="weight" value="0.6" /><bsdf type="diffuse"><rgb name="reflectance" value="0.3, 0.6, 0.8" /></bsdf>'
           '<bsdf type="dielectric"><float name="int_ior" value="1.5" /></bsdf></bsdf>\n')
     for name, m, b in WALLS:

@@ -80,3 +80,36 @@ def test_a_blend_is_the_weighted_mean_of_its_partners_in_expectation(mi):
     m = lanes(mi, blend('<float name="weight" value="0.3"/>'), 2).mean()
     assert a > 0 and b > 0 and abs(a - b) > 0.05 * a
     assert abs(m - (0.7 * a + 0.3 * b)) < 1e-5 * max(a, b)      # the same emitter samples in all three renders: the identity holds per lane, up to rounding
+
+
+# ------------------------------------------------------------------------------------------------ twosided with two nested BSDFs (twosided.cpp:75-86)
+TWO = '<bsdf type="twosided">%s%s</bsdf>' % (DIFFUSE, METAL)
+
+
+def test_twosided_with_two_bsdfs_loads(mi, orc):
+    xml = SCENE % (SHAPE % TWO + SHAPE % ('<bsdf type="twosided">%s</bsdf>' % DIFFUSE))
+    sc = mi.load_string(xml)
+    rec = np.asarray(sc.export(23), np.float32).reshape(-1, 5)
+    assert rec[:, 0].tolist() == [2, 0] and rec[0, 3] == 4 and rec[0, 4] == 1          # the back side's record: roughconductor, two-sided
+    fs = orc.Scene(xml, {}, is_string=True).flat
+    assert fs.shapes[0]["two_bsdfs"] == 1 and fs.shapes[0]["blend_other"]["bsdf"] == 4 and fs.shapes[0]["twosided"] == 1 and fs.shapes[0]["blend_other"]["twosided"] == 1
+    for bsdf, message in [('<bsdf type="twosided">%s%s%s</bsdf>' % (DIFFUSE, METAL, DIFFUSE), "At most two nested BSDFs can be specified"),
+                          ('<bsdf type="twosided"/>', "A nested one-sided material is required"),
+                          ('<bsdf type="twosided">%s<bsdf type="dielectric"/></bsdf>' % DIFFUSE, "Only materials without a transmission component can be nested")]:
+        for name, load in both(mi, orc):
+            with pytest.raises(Exception, match=message):
+                load(SCENE % (SHAPE % bsdf))
+
+
+@pytest.mark.gpu
+def test_each_side_of_a_twosided_pair_is_its_own_bsdf(mi):
+    """seen from the front the panel is twosided{a}, seen from behind twosided{b}: the lanes equal those of the one-BSDF scenes bit for bit"""
+    def lanes_from(bsdf, z):
+        sensor = SENSOR.replace('origin="0.3, 0.2, 4"', 'origin="0.3, 0.2, %s"' % z)
+        light = '<emitter type="point"><point name="position" value="1, 1, %s"/><rgb name="intensity" value="10"/></emitter>' % (3 if z > 0 else -3)
+        sc = mi.load_string(SCENE % ('<integrator type="path"><integer name="max_depth" value="3"/></integrator>' + sensor + light + SHAPE % bsdf))
+        return sc.sample_lanes(seed=4, spp=512, lane_begin=0, n=8 * 8 * 512)["rgb"]
+    front, back = lanes_from(TWO, 4), lanes_from(TWO, -4)
+    assert np.array_equal(front.view(np.uint32), lanes_from('<bsdf type="twosided">%s</bsdf>' % DIFFUSE, 4).view(np.uint32))
+    assert np.array_equal(back.view(np.uint32), lanes_from('<bsdf type="twosided">%s</bsdf>' % METAL, -4).view(np.uint32))
+    assert np.abs(front).max() > 0 and np.abs(back).max() > 0 and not np.array_equal(front, back)

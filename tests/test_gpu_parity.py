@@ -976,7 +976,11 @@ def _random_scene(rng, mesh_dir=None):
             body = ('<bsdf type="bumpmap"><float name="scale" value="%s"/><texture type="bitmap"><string name="filename" value="%s"/><boolean name="raw" value="true"/>'
                     '<string name="wrap_mode" value="%s"/></texture>%s</bsdf>' % (f(-0.2, 0.2), os.path.join(SCENES, str(rng.choice(["tex_gray.png", "tex_rgb.png"]))), rng.choice(["repeat", "mirror", "clamp"]), body))
         if k in ("diffuse", "conductor", "plastic", "roughconductor", "roughplastic") and rng.random() < 0.7:
-            body = '<bsdf type="twosided">%s</bsdf>' % body
+            back = ""
+            if not nested and rng.random() < 0.15:   # twosided.cpp:75-86: a second BSDF for the back side
+                back = str(rng.choice(['<bsdf type="diffuse"><rgb name="reflectance" value="%s"/></bsdf>' % rgb(), '<bsdf type="conductor"/>',
+                                       '<bsdf type="roughplastic"><float name="alpha" value="%s"/></bsdf>' % f(0.05, 0.4)]))
+            body = '<bsdf type="twosided">%s%s</bsdf>' % (body, back)
         if not nested and rng.random() < 0.15:   # src/bsdfs/mask.cpp: constant or checkerboard opacity (a mask inside a blendbsdf is refused)
             op = ('<float name="opacity" value="%s"/>' % f(0.1, 0.9) if rng.random() < 0.5 else
                   '<texture type="checkerboard" name="opacity"><rgb name="color0" value="%s"/><rgb name="color1" value="%s"/><transform name="to_uv"><scale x="%s" y="%s"/></transform></texture>'
