@@ -13,6 +13,7 @@ import ctypes as C
 import math
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -258,3 +259,45 @@ def test_hierarchical2d_sample_agrees_with_eval(orc, normalize):
             if i == 9:
                 np.testing.assert_allclose(p, u, atol=1e-5)
                 assert abs(pdf - 1.0) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ test_bitmap.py (read / write round trips)
+def _texels(mi, path, raw=True):
+    """the linear float32 texels the product's readers (image_io.cpp) produce for a bitmap texture"""
+    sc = mi.load_string(SCENE % ('<shape type="rectangle"><bsdf type="diffuse"><texture type="bitmap" name="reflectance"><string name="filename" value="%s"/>'
+                                 '<boolean name="raw" value="%s"/></texture></bsdf></shape>' % (path, "true" if raw else "false")))
+    info = np.asarray(sc.export(13), np.float32).reshape(-1, 17)[0]
+    ch, w, h = int(info[3]), int(info[4]), int(info[5])
+    return np.asarray(sc.export(14), np.float32).reshape(h, w, ch)
+
+
+def test_png_hdr_pfm_exr_round_trips(mi, tmp_path):
+    """src/core/tests/test_bitmap.py:148-215 restated with this build's writers and readers: an 8-bit PNG comes back exactly (test_read_write_png: sum |diff| == 0),
+    an RGBE file within the reference's bound (test_read_write_hdr: |mean(diff)| < 1e-2; per texel the format's 1 / 256 of the brightest channel), PFM and a float32
+    EXR exactly (test_read_write_pfm / _exr)"""
+    from mitsuba3dopplertof_amd import io
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes"))
+    import make_scenes
+    rng = np.random.default_rng(3)
+    ref8 = np.uint8(rng.random((10, 10, 3)) * 255)
+    io.write_png(str(tmp_path / "out.png"), ref8)
+    back = _texels(mi, tmp_path / "out.png")
+    assert back.shape == (10, 10, 3) and np.sum(np.abs(np.round(back * 255.0) - ref8)) == 0 and np.abs(back * 255.0 - ref8).max() < 1e-3
+    def _radiance_map(path):
+        """the float32 texels the product's HDR readers (RGBE, PFM, OpenEXR: image_io.cpp) hand to the `envmap` emitter (export kind 16: w, h, levels, scale, bsphere[4],
+        to_world[12], to_local[12], m_data[h][w][3] with the first column repeated at the end)"""
+        v = np.asarray(mi.load_string(SCENE % ('<emitter type="envmap"><string name="filename" value="%s"/></emitter>' % path)).export(16), np.float32)
+        w, h = int(v[0]), int(v[1])
+        return v[32:32 + h * w * 3].reshape(h, w, 3)[:, :-1]
+    _texels_hdr = _radiance_map
+    ref = np.float32(rng.random((20, 10, 3)))
+    make_scenes.write_rgbe(str(tmp_path / "out.hdr"), [[tuple(float(c) for c in px) for px in row] for row in ref])
+    back = _texels_hdr(tmp_path / "out.hdr")
+    assert back.shape == ref.shape and abs(float(np.mean(back - ref))) < 1e-2
+    assert np.all(np.abs(back - ref) <= ref.max(axis=-1, keepdims=True) / 128.0 + 1e-7)
+    io.write_pfm(str(tmp_path / "out.pfm"), ref)
+    assert np.array_equal(_texels_hdr(tmp_path / "out.pfm"), ref)
+    io.write_exr(str(tmp_path / "out.exr"), ref, half=False, compression="zip")
+    assert np.array_equal(_texels_hdr(tmp_path / "out.exr"), ref)
+    io.write_exr(str(tmp_path / "half.exr"), ref, half=True, compression="zips")
+    assert np.array_equal(_texels_hdr(tmp_path / "half.exr"), ref.astype(np.float16).astype(np.float32))
