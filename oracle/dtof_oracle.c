@@ -1584,6 +1584,7 @@ void orc_kat_distr2d_sample(const orc_texture *t, float sx, float sy, float *out
 }
 void orc_kat_texture_sample_position(const orc_texture *t, float sx, float sy, float *out3) { texture_sample_position(t, sx, sy, out3, out3 + 1, out3 + 2); }
 float orc_kat_texture_pdf_position(const orc_texture *t, float u, float v) { return texture_pdf_position(t, u, v); }
+void orc_kat_texture_eval_1_grad(const orc_texture *t, float u, float v, float *out2) { orc_texture_eval_1_grad(t, u, v, out2, out2 + 1); }
 /* the material parameters of one hit: the shape's constants, or the lookups of the textures bound to their slots */
 typedef struct { float spec_refl[3], spec_trans[3], alpha_u, alpha_v; } orc_mat;
 static orc_mat material_at(const orc_shape *sh, float u, float v) {

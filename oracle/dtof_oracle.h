@@ -341,6 +341,7 @@ float    orc_kat_shape_area(const orc_shape *sh);
 void     orc_kat_emitter_sample(const orc_scene *sc, int emitter_index, const float *ref, float sx, float sy, float *out13);
 void     orc_kat_splat(const orc_sensor *se, float *film, float x, float y, const float *rgb);
 int      orc_kat_solve_quadratic(double a, double b, double c, double *out2);
+void     orc_kat_texture_eval_1_grad(const orc_texture *t, float u, float v, float *out2);   /* d eval_1 / d(u, v): bitmap.cpp eval_1_grad */
 
 #ifdef __cplusplus
 }

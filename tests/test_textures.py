@@ -309,3 +309,80 @@ def test_textured_rectangle_only_scene(mi, orc, pipeline, feature, monkeypatch):
     for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
         assert np.array_equal(np.ascontiguousarray(ours[k]).view(np.uint32), np.ascontiguousarray(ref[k], np.float32).view(np.uint32)), (pipeline, k)
     assert (ref["rgb"][:, 0] != ref["rgb"][:, 1]).any()                  # the texture colours the radiance
+
+
+# ------------------------------------------------------------------------------------------------ src/textures/tests/test_bitmap.py, restated on an own 8 x 8 RGB fixture
+def _rgb_texture(orc, wrap, filt=1, to_uv=(1, 0, 0, 1)):
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    data = np.ascontiguousarray(rng.random((8, 8, 3)).astype(np.float32))
+    t = orc.OrcTexture()
+    t.kind, t.filter, t.wrap, t.channels, t.width, t.height = 1, filt, wrap, 3, 8, 8
+    t.data = data.ctypes.data_as(C.POINTER(C.c_float))
+    t.to_uv = (C.c_float * 4)(*to_uv)
+    return t, data
+
+
+@pytest.mark.parametrize("wrap_mode", ["repeat", "clamp", "mirror"])
+def test_reference_wrap_mode_properties(orc, wrap_mode):
+    """test_bitmap.py:56-128 (test03_wrap; its noise_8x8.png sits in the empty resources/data submodule): a 20 x 20 grid over [0, 1]^2 against the same grid shifted
+    by -1 / +1 (repeat), against the clamped edges (clamp) and against the reversed grids (mirror), atol 1e-4"""
+    import ctypes as C
+    L = orc.lib()
+    t, data = _rgb_texture(orc, {"repeat": 0, "mirror": 1, "clamp": 2}[wrap_mode])
+    out = np.zeros(3, np.float32)
+
+    def grid(xs, ys):
+        g = np.zeros((len(ys), len(xs), 3), np.float32)
+        for j, y in enumerate(ys):
+            for i, x in enumerate(xs):
+                L.orc_texture_eval(C.byref(t), C.c_float(float(x)), C.c_float(float(y)), out.ctypes.data); g[j, i] = out
+        return g
+    n = 20
+    lin = np.linspace(0, 1, n, dtype=np.float32)
+    ref = grid(lin, lin)
+    if wrap_mode == "repeat":
+        np.testing.assert_allclose(grid(lin - 1, lin - 1), ref, atol=1e-4)
+        np.testing.assert_allclose(grid(lin + 1, lin + 1), ref, atol=1e-4)
+    elif wrap_mode == "clamp":
+        np.testing.assert_allclose(grid(lin, lin - 1)[:-1], np.repeat(ref[:1], n - 1, axis=0), atol=1e-4)        # above: the top row
+        np.testing.assert_allclose(grid(lin, lin + 1)[1:], np.repeat(ref[-1:], n - 1, axis=0), atol=1e-4)        # below: the bottom row
+        np.testing.assert_allclose(grid(lin - 1, lin)[:, :-1], np.repeat(ref[:, :1], n - 1, axis=1), atol=1e-4)  # left
+        np.testing.assert_allclose(grid(lin + 1, lin)[:, 1:], np.repeat(ref[:, -1:], n - 1, axis=1), atol=1e-4)  # right
+    else:
+        np.testing.assert_allclose(grid((lin - 1)[::-1], (lin - 1)[::-1]), ref, atol=1e-4)
+        np.testing.assert_allclose(grid((lin + 1)[::-1], (lin + 1)[::-1]), ref, atol=1e-4)
+
+
+def test_reference_eval_rgb_and_gradient_properties(orc):
+    """test_bitmap.py:130-178 (test04_eval_rgb): at a texel centre eval_3 is the texel and eval_1 its luminance; :31-53 (test02_eval_grad): under a rotated to_uv the
+    analytic gradient of eval_1 agrees with finite differences (the reference's own tolerance there is a typo, atol = 1e04; here 2 % away from the texel seams)"""
+    import ctypes as C
+    L = orc.lib()
+    L.orc_texture_eval_1.restype = C.c_float
+    L.orc_kat_texture_eval_1_grad.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    t, data = _rgb_texture(orc, 0)
+    out = np.zeros(3, np.float32)
+    x, y = 7 / 8 + 1 / 16, 1 / 8 + 1 / 16                                  # the centre of texel (7, 1)
+    L.orc_texture_eval(C.byref(t), C.c_float(x), C.c_float(y), out.ctypes.data)
+    np.testing.assert_allclose(out, data[1, 7], atol=1e-6)
+    lum = data[1, 7] @ np.array([0.212671, 0.715160, 0.072169], np.float32)
+    assert abs(L.orc_texture_eval_1(C.byref(t), C.c_float(x), C.c_float(y)) - lum) < 1e-6
+    rng = np.random.default_rng(5)
+    g = np.zeros(2, np.float32)
+    checked = 0
+    for angle in rng.random(10) * 2 * np.pi:
+        c, s_ = np.cos(angle), np.sin(angle)
+        t, data = _rgb_texture(orc, 0, to_uv=(c, -s_, s_, c))              # mi.ScalarTransform4f.rotate([0, 0, 1], angle): the 2 x 2 part
+        for uv in rng.random((10, 2)):
+            tu, tv = c * uv[0] - s_ * uv[1], s_ * uv[0] + c * uv[1]
+            fx, fy = (tu * 8 - .5) % 1.0, (tv * 8 - .5) % 1.0
+            if min(fx, 1 - fx, fy, 1 - fy) < 0.02:                          # a finite difference across a texel seam measures two slopes
+                continue
+            d = 1e-3 / 8
+            f = lambda a, b: float(L.orc_texture_eval_1(C.byref(t), C.c_float(float(a)), C.c_float(float(b))))
+            fd = np.array([(f(uv[0] + d, uv[1]) - f(uv[0] - d, uv[1])) / (2 * d), (f(uv[0], uv[1] + d) - f(uv[0], uv[1] - d)) / (2 * d)])
+            L.orc_kat_texture_eval_1_grad(C.byref(t), C.c_float(float(uv[0])), C.c_float(float(uv[1])), g.ctypes.data)
+            np.testing.assert_allclose(g, fd, rtol=2e-2, atol=2e-2 * max(1.0, float(np.abs(fd).max())))
+            checked += 1
+    assert checked > 50
