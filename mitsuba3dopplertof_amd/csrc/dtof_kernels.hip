@@ -148,10 +148,11 @@ template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, int SPEC, int RESW
 #ifndef DTOF_MESH_WAVES
 #define DTOF_MESH_WAVES 3   // waves / SIMD the fused kernels with triangle code are compiled for (A/B: make variant DEFS=-DDTOF_MESH_WAVES=4)
 #endif
-// The every-BSDF kernels (SPEC) with four offset films (KMAX == 4) are compiled for TWO waves per SIMD (256 VGPRs): at three (168 VGPRs, 240 - 390 spilled registers) their
-// fused instantiations produced wrong films on scenes of the random sweep whenever the kernel grew (a loop around the BSDF chain, the textured-emitter branch), while every
-// lane of the K = 1 kernels, the split pipeline and the SAME source at two waves per SIMD stayed exact -- the spill code of that configuration is not to be trusted.
-__global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : (MODE != 0 && MESH) ? ((SPEC && KMAX > 1) ? 2 : DTOF_MESH_WAVES) : 1) void k_shade(ShadeArgs args_by_value) {
+// History of the every-BSDF kernels (SPEC) with four offset films (KMAX == 4): at three waves per SIMD (168 VGPRs, 240 - 390 spilled registers) their fused instantiations
+// produced wrong films on scenes of the random sweep whenever the kernel grew, while the K = 1 kernels, the split pipeline and the same source at two waves stayed exact.
+// The cause was not the spill code: the films depended on the INITIAL value of the path-state registers declared without one (`main` / `path` below; right with
+// -ftrivial-auto-var-init=zero, NaN with =pattern, profiles/r03_k4_uninitialised.txt).  They are initialised now, and these instantiations run at three waves again.
+__global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : (MODE != 0 && MESH) ? DTOF_MESH_WAVES : 1) void k_shade(ShadeArgs args_by_value) {
     constexpr bool FUSED = MODE != 0, FIRST = MODE == 2;
     static_assert(RESW == 0 || (MODE == 2 && !LDS && MESH), "the resident stage exists for the unstaged fused first-bounce kernel with mesh code");
     extern __shared__ uint4 lds[];
@@ -219,7 +220,12 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
 #if DTOF_COOP
     float4 sha = make_float4(0.f, 0.f, 0.f, 0.f), shb = make_float4(0.f, 0.f, 1.f, 0.f), nra = sha, nrb = shb; float3 cand[KMAX];
 #else
-    float4 sha, shb, nra, nrb; float3 cand[KMAX];
+    // every register of the path state starts defined: a build of these kernels whose K = 4 every-BSDF instantiations ran at three waves per SIMD produced films that
+    // depended on the initial value of `main` / `path` below (wrong with the registers' garbage, NaN with -ftrivial-auto-var-init=pattern, right with =zero;
+    // profiles/r03_k4_uninitialised.txt) although no source path reads them before they are assigned
+    float4 sha = make_float4(0.f, 0.f, 0.f, 0.f), shb = sha, nra = sha, nrb = sha; float3 cand[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) cand[k] = make_float3(0.f, 0.f, 0.f);
 #endif
     float3 rbase[KMAX];   // FIRST: the result a lane ends this launch with if its NEE candidate is not committed
 #pragma unroll
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
 #if DTOF_COOP
     uint32_t hid = 0xffffffffu; float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 1.f, 0.f), st; uint4 hh; Rng main, path;
 #else
-    uint32_t hid = 0xffffffffu; float4 ra, rb, st; uint4 hh; Rng main, path;
+    uint32_t hid = 0xffffffffu; float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 1.f, 0.f), st = ra; uint4 hh = make_uint4(0u, 0u, 0u, 0u); Rng main = { 0ull, 1ull }, path = { 0ull, 1ull };
 #endif
     float4 stb_reg = make_float4(0.f, 0.f, 0.f, 1.f); float2 stc_reg = make_float2(1.f, 1.f);   // prev_si.p | prev_bsdf_pdf, eta | prev_bsdf_delta
     float memo_m[12], memo_inv[12];   // instance memo: the one instance's matrix and inverse at this lane's ray time

@@ -1,0 +1,470 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native `dopplertofpath` + `correlated` path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete render of the workload: generate -> [trace -> shade -> shadow] x depth -> splat on every
+rank, ONE film gather to rank 0 (RCCL over xGMI) and the develop (RGB/W).  Scene, BVH and all queues are resident
+in HBM before the timed region; the developed image stays on the device (the PCIe-inclusive rate of the
+host-buffer entry point dtof_render is noted in DESIGN.md).
+
+Workload (BASELINE.json configs[1]): synthetic Cornell box with one linearly translating wall
+(scenes/cornell_wall.xml), 512x512, sinusoidal heterodyne (hetero_frequency=1), stratified time sampling,
+max_depth 4.  N=1: 64 spp.  N>1 ("weak"): the pixel rows are sharded one band per GPU and the sample count
+grows with N (spp = 64*N), so every GPU traces the same number of paths as the single-GPU run and the result
+is the 64*N-spp image.  `--scaling strong` keeps 64 spp in total instead.
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant kernel, HIP-event
+timed inside the library on its own stream) and, at N=1, `cpu_baseline` (the CPU oracle port timed on the host
+cores on a bounded sample of the same workload).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+# SURVEY 8(d) algorithmic byte model (K = 1 offsets): bytes per path-bounce of a three-kernel loop with 76-byte states
+B_TRACE, B_SHADE, B_SHADOW = 48, 260 + 36, 32 + 36
+B_BOUNCE = B_TRACE + B_SHADE + B_SHADOW          # 412
+
+
+def kernel_bytes_per_bounce(fused, k):
+    """ALGORITHMIC bytes one path-bounce moves through the dominant kernel, from the records the kernel is defined over
+    (Queues in csrc/dtof_kernels.h), K = number of batched modulation offsets.
+    read : queue index 4 + hit_id 4 + ray (o,time | d,maxt) 32 + hit 16 + throughput/path length 16 + 2 PCG states 16
+           + 2 PCG stream selectors 8 + result 16K                                                    =  96 + 16K
+    write, fused : ray 32 + state 16 + PCG 16 + queue index 4 + next hit 16 + hit_id 4 + result 16K   =  88 + 16K
+    write, split : ray 32 + state 16 + PCG 16 + queue index 4 + shadow record (32 + candidate 16K)    = 100 + 16K
+    The SURVEY 8(d) model (412 B per bounce over trace+shade+shadow) is reported beside it as `survey_model`: this
+    implementation keeps 32 B of state instead of 76 B and the fused kernel has no shadow-queue round trip, so it moves
+    about half the bytes that model prices -- pricing the kernel with 412 B would "exceed" the HBM peak."""
+    return (96 + 16 * k) + ((88 if fused else 100) + 16 * k)
+HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+# (scene, resolution, spp, -D overrides, batched hetero offsets)
+CONFIGS = {
+    "c1": ("cornell_boxes.xml", 256, 16, dict(hetero_frequency=0.0, time_sampling_method="uniform", antithetic_shift=0.0), None),
+    "c2": ("cornell_wall.xml", 512, 64, dict(), None),
+    "c3": ("cornell_wall.xml", 512, 256, dict(time_sampling_method="antithetic_mirror", antithetic_shift=0.0), None),
+    "c4": ("domino.xml", 1024, 128, dict(wave_function_type="rectangular"), None),
+    "c5": ("domino.xml", 1024, 512, dict(wave_function_type="trapezoidal"), [0.0, 0.25, 0.5, 0.75]),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default=None)
+    ap.add_argument("--res", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel per GPU (weak) / in total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="BASELINE.json configs[0..4] as concretised in SURVEY 8(d); c2 is the headline (default). The others "
+                         "are parity-test cases that can also be timed; --res/--spp still override.")
+    ap.add_argument("--sharding", choices=["auto", "bands", "stripes"], default="auto",
+                    help="N > 1: contiguous row bands + one film gather (north_star; default for the Cornell configs) or interleaved "
+                         "4-row stripes + one film reduce(sum) (load balance, SURVEY 8e; default for the Domino configs c4 / c5)")
+    ap.add_argument("--stripe-rows", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra scaling figures (the other scaling mode of c2, strong-scaling c4)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU oracle sample")
+    args = ap.parse_args()
+    args.scene_given, args.res_given, args.spp_given = args.scene, args.res, args.spp
+    return args
+
+
+def usable_cores():
+    """CPUs this process may actually run on: the affinity mask, capped by the cgroup CPU quota (the GPU boxes report 256
+    logical CPUs but run a job under a 16-CPU quota, and 256 runnable threads under that quota are slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(scene_path, res, spp, target_s, defines):
+    """Oracle (CPU port of the same algorithm) on all the host cores this job may use, on a bounded band of rows of the same workload."""
+    from oracle import orc
+    cores = usable_cores()
+    osc = orc.Scene(scene_path, dict(defines, resx=res, resy=res))
+    pd = osc.params()
+    mid = res // 2
+    t0 = time.time()
+    _, n = osc.render(pd, seed=0, spp=spp, rows=(mid, mid + 2), threads=cores, raw=True)
+    rate = n / max(time.time() - t0, 1e-6)
+    want = target_s * rate                                    # paths that fill the time budget
+    rows = int(max(2, min(res, want / (res * spp))))
+    reps = int(max(1, min(64, round(want / (rows * res * spp)))))
+    r0 = max(0, mid - rows // 2)
+    total = 0
+    band0 = None
+    t0 = time.time()
+    for seed in range(reps):                                  # whole-frame passes with seeds 0..reps-1, like the multi-pass harness
+        film_band, n = osc.render(pd, seed=seed, spp=spp, rows=(r0, r0 + rows), threads=cores, raw=True)
+        if seed == 0:
+            band0 = (film_band, r0, r0 + rows)               # kept for the parity figure of the bench line
+        total += n
+    dt = time.time() - t0
+    t1 = time.time()                                              # the same code on ONE thread (report both)
+    _, n1 = osc.render(pd, seed=0, spp=spp, rows=(mid, mid + max(1, min(8, int(2.0 * rate / cores / (res * spp)) or 1))), threads=1, raw=True)
+    one = n1 / max(time.time() - t1, 1e-9) / 1e6
+    cpu_baseline.band0 = band0
+    return {"value": round(total / dt / 1e6, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port", "value_1_core": round(one, 4),
+            "sample": "oracle/dtof_oracle.c (scalar C restatement of the same algorithm, pthreads over lanes): rows [%d,%d) of "
+                      "the %dx%d %d-spp frame x %d seeds = %d paths in %.1f s" % (r0, r0 + rows, res, res, spp, reps, total, dt)}
+
+
+def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_override=None, res_override=None, scene_override=None):
+    """Times `steps` renders of one workload on the ranks of ctx (after `warmup` untimed ones), barrier + synchronize on both
+    sides, MAX over ranks.  Returns the raw figures; rank 0 also gets the developed image and the undeveloped film."""
+    import torch
+    import torch.distributed as dist
+    mi, D, dev, world, rank, share = ctx["mi"], ctx["D"], ctx["dev"], ctx["world"], ctx["rank"], ctx["share"]
+    scene_file, res, spp0, defines, offsets = CONFIGS[cfg]
+    scene_path = scene_override or os.path.join(HERE, "scenes", scene_file)
+    res = res_override or res
+    spp0 = spp_override or spp0
+    if sharding == "auto":
+        sharding = "stripes" if os.path.basename(scene_path).startswith("domino") else "bands"
+    scene = mi.load_file(scene_path, **dict(defines, resx=res, resy=res))
+    striped = world > 1 and sharding == "stripes"
+    if offsets and world > 1 and not striped:
+        raise SystemExit("batched-offset configs shard with --sharding stripes (the band gather carries one film)")
+    W, H = scene.size
+    halo = int(scene.info()["filter_halo"])      # rows a splat reaches beyond its pixel: ceil(radius - 0.5) (imageblock.cpp:423-426)
+    spp = spp0 * world if scaling == "weak" else spp0
+    r0, r1 = D.row_band(H, world, rank)
+    pad_rows = D.padded_rows(H, world, halo)
+    film = torch.zeros((pad_rows, W, 4), dtype=torch.float32, device=dev)
+    film_ptr = film.data_ptr() + halo * W * 4 * 4
+    p0, p1 = D.slab_range(H, world, rank, halo)
+    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    gather_buf = torch.empty((world, p1 - p0, W, 4), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+    lib = mi._lib()
+    keys = ("ms_trace", "ms_shade", "ms_shadow", "ms_generate", "ms_splat", "ms_total", "ms_first", "n_bounces", "n_shadow_rays", "n_paths")
+    acc = dict.fromkeys(keys + ("launches", "first_launches", "launches_equiv", "inline_bounces"), 0.0)
+    acc.update(launches=0, first_launches=0)
+    K = len(offsets) if offsets else 1
+    native = bool(offsets) or striped            # library-native [K][H][W][4] films (K offsets in ONE traversal, config c5)
+    if native:
+        kfilm = torch.zeros((K, H, W, 4), dtype=torch.float32, device=dev)
+        krgb = torch.zeros((K, H, W, 3), dtype=torch.float32, device=dev)
+
+    def develop(src, dst, n):
+        if lib.dtof_develop(src.data_ptr(), dst.data_ptr(), n) != 0:
+            raise RuntimeError(lib.dtof_last_error().decode())
+
+    def step(record):
+        film.zero_()
+        if native:
+            kfilm.zero_()
+        torch.cuda.synchronize()
+        if native:
+            if striped:               # interleaved stripes of rows per rank, ONE reduce(sum) of the full-size films to rank 0
+                st = scene.render_stripes(kfilm.data_ptr(), 0, spp, *D.stripe_layout(world, rank, stripe_rows), offsets=offsets)
+                if share:
+                    host = kfilm.cpu(); dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                    if rank == 0:
+                        kfilm.copy_(host)
+                else:
+                    dist.reduce(kfilm, dst=0, op=dist.ReduceOp.SUM)
+            else:
+                st = scene.render_rows(kfilm.data_ptr(), seed=0, spp=spp, row_begin=0, row_end=H, offsets=offsets)
+            if rank == 0:
+                develop(kfilm, krgb, H * W * K)
+        else:
+            st = scene.render_rows(film_ptr, seed=0, spp=spp, row_begin=r0, row_end=r1)   # synchronises the library's stream
+            stack = D.gather_film_stacked(film[p0:p1], rank, world, out=gather_buf)
+            if rank == 0:
+                full = D.overlap_add_stacked(stack, H, world, halo) if world > 1 else film[halo:halo + H]
+                develop(full.contiguous(), rgb, H * W)
+        if record:
+            for k in keys:
+                acc[k] += st[k]
+            acc["launches"] += st["n_launches_shade"]; acc["first_launches"] += st["n_launches_first"]
+            acc["launches_equiv"] += st["n_inline_iterations"]; acc["inline_bounces"] += st["n_bounces_inline"]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step(False)
+    barrier()
+    per_step = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts = time.perf_counter()
+        step(True)
+        torch.cuda.synchronize()
+        per_step.append(time.perf_counter() - ts)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed] + per_step, dtype=torch.float64, device=dev)
+    # this rank's share of the work: the library's own GPU time per step (HIP events around its launches), min / max over the ranks = load balance
+    mine = torch.tensor([acc["ms_total"] / max(steps, 1)], dtype=torch.float64, device=dev)
+    lo, hi = mine.clone(), mine.clone()
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    t = t.cpu().numpy()
+    elapsed, per_step = float(t[0]), np.sort(t[1:])
+    total_paths = W * H * spp
+    out = dict(acc=acc, elapsed=elapsed, steps=steps, W=W, H=H, spp=spp, spp_per_gpu=spp0, total_paths=total_paths, halo=halo, striped=striped, offsets=offsets,
+               defines=defines, scene_path=scene_path, res=res,
+               ms_render_rank_min=float(lo.item()), ms_render_rank_max=float(hi.item()),
+               value=total_paths * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3,
+               ms_per_step_min=float(per_step[0]) * 1e3, ms_per_step_median=float(np.median(per_step)) * 1e3)
+    if rank == 0:
+        out["image"] = (krgb if native else rgb).cpu().numpy()
+        out["film"] = None if native else film[halo:halo + H].cpu().numpy()
+    return out
+
+
+def main():
+    # the host driver only supports dmabuf IPC: must be in the environment BEFORE the HIP / HSA runtime initialises
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    args = parse()
+    sys.path.insert(0, os.path.join(HERE, "scenes"))
+    import make_scenes
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        make_scenes.ensure()      # scenes/*.xml are generated files
+    import torch
+    import torch.distributed as dist
+    import mitsuba3dopplertof_amd as mi
+    from mitsuba3dopplertof_amd import distributed as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus (%d) does not match WORLD_SIZE (%d)" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                         % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # DTOF_BENCH_SHARE_GPU=1 (development only): all ranks use GPU 0 and gloo carries the gather, so that the N > 1 code path can
+    # be exercised on a single-GPU box; the numbers of such a run mean nothing.
+    share = os.environ.get("DTOF_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = None
+    if world > 1:
+        backend = "gloo" if share else "nccl"
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
+        dist.barrier()            # rank 0 may just have written the scene files
+    ctx = dict(mi=mi, D=D, dev=dev, world=world, rank=rank, share=share)
+
+    r = run_workload(ctx, args.config, args.scaling, args.steps, args.warmup, args.sharding, args.stripe_rows,
+                     spp_override=args.spp_given, res_override=args.res_given, scene_override=args.scene_given)
+    # Besides the headline line: the OTHER scaling mode of the same workload and BASELINE configs[3] (Domino, 1024^2 x 128 spp, a fixed
+    # frame sharded in interleaved stripes = strong scaling; north_star's ">= 0.9 parallel efficiency" refers to this one), a few steps
+    # each, so that one driver run per N yields weak AND strong curves.  Skipped with --no-extra and for non-default workloads.
+    extra = {}
+    default_run = args.config == "c2" and not (args.spp_given or args.res_given or args.scene_given)
+    if default_run and not args.no_extra:
+        other = "strong" if args.scaling == "weak" else "weak"
+        if world > 1:
+            e = run_workload(ctx, "c2", other, max(5, args.steps // 2), 2, "bands", args.stripe_rows)
+            extra["c2_" + other] = {"value": round(e["value"], 2), "unit": "Mpaths/s", "scaling": other, "ms_per_step": round(e["ms_per_step"], 4),
+                                     "ms_per_step_min": round(e["ms_per_step_min"], 4), "spp_total": e["spp"], "paths_per_step": e["total_paths"]}
+        e = run_workload(ctx, "c4", "strong", 4, 1, "stripes", args.stripe_rows)
+        extra["c4_strong"] = {"value": round(e["value"], 2), "unit": "Mpaths/s", "scaling": "strong", "ms_per_step": round(e["ms_per_step"], 4),
+                              "ms_per_step_min": round(e["ms_per_step_min"], 4), "paths_per_step": e["total_paths"],
+                              "ms_render_rank_min": round(e["ms_render_rank_min"], 4), "ms_render_rank_max": round(e["ms_render_rank_max"], 4),
+                              "workload": "BASELINE configs[3]: domino.xml 1024x1024, 128 spp in total, rectangular low-pass, interleaved %d-row stripes, 1 film reduce"
+                                          % args.stripe_rows}
+        # BASELINE configs[4]: the K = 4 batched films (64 MB per reduce at 1024^2); fewer samples than the config's 512 so that the extra stays short -- the
+        # rate (path-offsets per second) and the reduce size are those of the full config
+        e = run_workload(ctx, "c5", "strong", 2, 1, "stripes", args.stripe_rows, spp_override=128)
+        extra["c5_strong"] = {"value": round(e["value"], 2), "unit": "Mpaths/s (x 4 films)", "scaling": "strong", "ms_per_step": round(e["ms_per_step"], 4),
+                              "ms_per_step_min": round(e["ms_per_step_min"], 4), "paths_per_step": e["total_paths"],
+                              "ms_render_rank_min": round(e["ms_render_rank_min"], 4), "ms_render_rank_max": round(e["ms_render_rank_max"], 4),
+                              "workload": "BASELINE configs[4] at 128 of its 512 spp: domino.xml 1024x1024, trapezoidal low-pass, 4 hetero_offset films in one traversal, "
+                                          "interleaved %d-row stripes, 1 reduce of the 4 films (64 MB)" % args.stripe_rows}
+
+    acc, W, H, spp, striped, halo = r["acc"], r["W"], r["H"], r["spp"], r["striped"], r["halo"]
+    total_paths, ms_per_step, value = r["total_paths"], r["ms_per_step"], r["value"]
+    args.offsets, args.defines, args.scene, args.res, args.spp = r["offsets"], r["defines"], r["scene_path"], r["res"], r["spp_per_gpu"]
+    if rank == 0:
+        img, film_host = r["image"], r["film"]
+        # The dominant kernel.  Fused pipeline (C2): k_shade<MODE 2> generates the lanes, traces the primary rays and runs up to four
+        # iterations of the bounce loop with the path state in registers -- for C2 (max_depth 4) that is the whole path, no bounce-kernel
+        # launch is left and the kernel is bound by VALU issue, not by HBM.  Split pipeline / longer paths: the bounce kernel
+        # k_shade<MODE 1|0> streams the path state through HBM once per iteration and is priced by its algorithmic bytes.
+        n_first = acc["first_launches"]
+        fused = acc["ms_shadow"] == 0.0                          # one kernel per bounce (occlusion + next closest hit inline)
+        k_off = len(args.offsets) if args.offsets else 1
+        per_bounce = kernel_bytes_per_bounce(fused, k_off)
+        bounce_launches = acc["launches"] - n_first
+        loop_s = (acc["ms_trace"] + acc["ms_shade"] + acc["ms_shadow"]) * 1e-3
+        # Counter evidence (separate rocprofv3 --pmc passes over exactly this configuration, tools/profile_round.sh -> tools/pmc_summary.py): stamped
+        # with a hash of the kernel sources; when the sources have changed since, the figures derived from it are marked stale.
+        tfile = os.path.join(HERE, "profiles", "roofline_traffic.json")
+        pmc, counters_stale = {}, None
+        default_workload = not (args.spp_given or args.res_given or args.scene_given)
+        if os.path.exists(tfile) and default_workload:
+            try:
+                sys.path.insert(0, os.path.join(HERE, "tools"))
+                from pmc_summary import kernel_sources_sha16
+                entry = json.load(open(tfile)).get("configs", {}).get(args.config)
+                if entry:
+                    pmc = entry.get("kernels", {})
+                    counters_stale = entry.get("csrc_sha16") != kernel_sources_sha16(HERE)
+            except Exception:
+                pmc = {}
+        # Algorithmic work of one path (profiles/algorithmic_ops.json, tools/algorithmic_ops.py): arithmetic the oracle executes for the path logic
+        # (exact basic-block counts) + the primitive work of the product's own traversal counters, one op per arithmetic instruction
+        alg = {}
+        afile = os.path.join(HERE, "profiles", "algorithmic_ops.json")
+        if os.path.exists(afile) and default_workload:
+            try:
+                alg = json.load(open(afile)).get(args.config, {})
+            except Exception:
+                alg = {}
+        # Issue-rate model (profiles/valu_cycle_model.json, tools/valu_cycle_model.py): only a subset of the VALU instruction forms issues at the 2 cycles
+        # per wave64 instruction the peak assumes (measured: profiles/r03_ubench_valu_rate.txt); the kernel's static instruction mix priced with the
+        # measured rates gives the average cycles one of ITS instructions occupies a SIMD for
+        cyc = {}
+        cfile = os.path.join(HERE, "profiles", "valu_cycle_model.json")
+        if os.path.exists(cfile) and default_workload:
+            try:
+                sys.path.insert(0, os.path.join(HERE, "tools"))
+                from pmc_summary import kernel_sources_sha16
+                cdoc = json.load(open(cfile))
+                cyc = dict(cdoc.get("configs", {}).get(args.config, {}), stale=cdoc.get("csrc_sha16") != kernel_sources_sha16(HERE))
+            except Exception:
+                cyc = {}
+        stages = {"ms_first_bounce": round(acc["ms_first"] / args.steps, 4),
+                  "ms_trace": round(acc["ms_trace"] / args.steps, 4), "ms_shade": round(acc["ms_shade"] / args.steps, 4),
+                  "ms_shadow": round(acc["ms_shadow"] / args.steps, 4), "ms_generate": round(acc["ms_generate"] / args.steps, 4),
+                  "ms_splat": round(acc["ms_splat"] / args.steps, 4)}
+        survey_model = {"what": "SURVEY 8(d): 412 B per path-bounce over ALL loop kernels (trace+shade+shadow time)", "bytes_per_path_bounce": B_BOUNCE,
+                        "achieved": round(B_BOUNCE * acc["n_bounces"] / max(loop_s, 1e-12) / 1e9, 1),
+                        "frac": round(B_BOUNCE * acc["n_bounces"] / max(loop_s, 1e-12) / 1e9 / HBM_PEAK_GBS, 4)}
+        if n_first and bounce_launches == 0:
+            # every iteration ran inside the first-bounce kernel: VALU-issue roofline (256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions per second,
+            # /opt/skills/guides/MI355X_MICROARCH.md "Wave scheduling"); executed instructions from the SQ_INSTS_VALU pass under profiles/
+            first_s = acc["ms_first"] * 1e-3 / max(n_first, 1)                       # average launch
+            paths_per_launch = acc["n_paths"] / max(n_first, 1)
+            out_bytes = (8 + 8 + 16 * k_off) * paths_per_launch                       # sample position, stream selectors, result
+            firsts = sorted((k for k in pmc if k.startswith("k_shade_first")), key=lambda k: -pmc[k].get("valu_wave_insts_per_launch", 0))
+            first_rec = pmc[firsts[0]] if firsts else {}
+            wave_insts = first_rec.get("valu_wave_insts_per_launch")
+            valu_peak = 256 * 4 * 32 * 2.4e9 / 1e12                                   # T lane-instructions / s
+            achieved = (wave_insts * 64 / first_s / 1e12) if wave_insts else None
+            ops_path = alg.get("ops_per_path")
+            alg_achieved = ops_path * paths_per_launch / first_s / 1e12 if ops_path else None
+            roofline = {
+                "bound": "valu", "kernel": "k_shade<MODE 2: lane generation + primary ray + ALL %d bounce iterations, path state in registers>%s" % (
+                    round(acc["launches_equiv"] / max(n_first, 1)), " [%s]" % first_rec.get("symbol", "") if first_rec else ""),
+                "achieved": round(achieved, 2) if achieved else None, "peak": round(valu_peak, 1), "unit": "T lane-instr/s",
+                "frac": round(achieved / valu_peak, 4) if achieved else None,
+                "what": "achieved / frac: EXECUTED VALU wave-instructions x 64 lanes (issue slots, idle lanes included) per second against the issue peak; "
+                        "algorithmic: the arithmetic one path needs (oracle + traversal counters) per second against the same peak; active_lane_ratio: share of the issued lane slots that held an active lane",
+                "algorithmic": {"ops_per_path": ops_path, "achieved": round(alg_achieved, 2) if alg_achieved else None, "unit": "T ops/s",
+                                "frac_alg": round(alg_achieved / valu_peak, 4) if alg_achieved else None, "source": alg.get("source"), "breakdown": alg.get("breakdown")},
+                "active_lane_ratio": first_rec.get("active_lane_ratio"),
+                "valu_busy_est": {"what": "share of the launch during which the VALU pipes are occupied: executed VALU wave-instructions x the average cycles one "
+                                          "instruction of THIS kernel's mix holds a SIMD (2.25 / 4.1 / 8.2 nominal cycles by instruction form, measured on this GPU) "
+                                          "over 1024 SIMDs x launch time x 2.4 GHz; frac prices every instruction at 2 cycles",
+                                  "avg_cycles_per_valu_instruction": cyc.get("avg_cycles_per_valu"), "share_of_cycles": cyc.get("share_of_cycles"),
+                                  "frac_busy": round(wave_insts * cyc["avg_cycles_per_valu"] / (1024 * first_s * 2.4e9), 4) if wave_insts and cyc.get("avg_cycles_per_valu") else None,
+                                  "model_stale": cyc.get("stale"), "source": "profiles/valu_cycle_model.json, profiles/r03_ubench_valu_rate.txt"},
+                "counters_stale": counters_stale,
+                "traffic": first_rec.get("hbm_bytes_per_launch"),
+                "algorithmic_bytes_per_launch": round(out_bytes, 1), "avg_launch_ms": round(first_s * 1e3, 5), "launches_per_step": n_first / args.steps,
+                "valu_lane_instructions_per_path": round(wave_insts * 64 / paths_per_launch, 1) if wave_insts else None,
+                "path_bounces_per_launch": round(acc["n_bounces"] / max(n_first, 1), 1),
+                "hbm_view": {"what": "the same launch against the HBM roofline: it only writes its outputs (%d B per path); the %d B per path-bounce of the "
+                                     "wavefront pipeline no longer exist" % (8 + 8 + 16 * k_off, per_bounce),
+                             "achieved_GBs": round(out_bytes / first_s / 1e9, 1), "frac": round(out_bytes / first_s / 1e9 / HBM_PEAK_GBS, 4),
+                             "state_stream_avoided_GBs": round(per_bounce * (acc["n_bounces"] - acc["n_paths"]) / max(n_first, 1) / first_s / 1e9, 1)},
+                "survey_model": survey_model, "stages": stages,
+            }
+        else:
+            shade_lanes = acc["n_bounces"] - acc["inline_bounces"]   # lanes entering the bounce-kernel launches
+            shade_s = (acc["ms_shade"] - acc["ms_first"]) * 1e-3
+            kernel_bytes = per_bounce * shade_lanes
+            kernel_name = "k_shade<MODE 1 = fused: shade + occlusion + next closest hit>" if fused else "k_shade<MODE 0>"
+            achieved = kernel_bytes / max(shade_s, 1e-12) / 1e9
+            roofline = {
+                "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("k_shade", {}).get("hbm_bytes_per_launch"),
+                "algorithmic_bytes_per_launch": round(kernel_bytes / max(bounce_launches, 1), 1),
+                "algorithmic_bytes_per_path_bounce": per_bounce,
+                "path_bounces_per_launch": round(shade_lanes / max(bounce_launches, 1), 1),
+                "avg_launch_ms": round(shade_s * 1e3 / max(bounce_launches, 1), 5), "launches_per_step": bounce_launches / args.steps,
+                "survey_model": survey_model, "stages": stages,
+            }
+        out = {
+            "metric": "Mpaths/s (whole node), Doppler Cornell 512x512 64spp" if args.config == "c2" else
+                      "Mpaths/s (whole node), BASELINE config %s" % args.config, "value": round(value, 2), "unit": "Mpaths/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_min": round(r["ms_per_step_min"], 4), "ms_per_step_median": round(r["ms_per_step_median"], 4),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (("cornell_wall (Cornell box, one linearly translating wall) %dx%d, %d spp%s, sinusoidal "
+                                    "heterodyne hetero_frequency=1, stratified time sampling, max_depth 4, tent filter") if args.config == "c2" else
+                                    (os.path.basename(args.scene) + " %dx%d, %d spp%s, " + json.dumps(args.defines) +
+                                     (", offsets %s batched" % args.offsets if args.offsets else "")))
+                                   % (W, H, spp, " (= %d per GPU x %d GPUs, rows sharded)" % (args.spp, world) if world > 1 and args.scaling == "weak" else ""),
+                       "paths_per_step": total_paths, "sharding": ("interleaved %d-row stripes, 1 film reduce" % args.stripe_rows if striped else "row bands, 1 film gather") if world > 1 else "none",
+                       "image_checksum": float(np.abs(img).sum())},
+            "roofline": roofline,
+            "ms_render_rank_min": round(r["ms_render_rank_min"], 4), "ms_render_rank_max": round(r["ms_render_rank_max"], 4),
+            "extra": extra,
+            "process_group": {"backend": backend, "world_size": world},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.scene, args.res, args.spp, args.cpu_seconds, args.defines)
+            out["cpu_baseline"]["gpu_over_cpu"] = round(value / max(out["cpu_baseline"]["value"], 1e-9), 1)
+            if not args.offsets and getattr(cpu_baseline, "band0", None) is not None:
+                # parity of THIS frame: the rows of the oracle's seed-0 pass against the same rows of the film the timed steps
+                # left on the GPU (same seed, same spp); the band's first and last row miss the splats of their outer neighbours
+                # in the oracle's partial render and are left out.  SURVEY 8(d): per-pixel relative L-inf, target <= 1e-3.
+                band, b0, b1 = cpu_baseline.band0
+                gpu = film_host
+                dev_img = lambda f: np.where(f[..., 3:4] != 0, f[..., :3] / np.where(f[..., 3:4] != 0, f[..., 3:4], 1), 0)
+                a, b = dev_img(gpu[b0 + 1:b1 - 1]), dev_img(band[b0 + 1:b1 - 1])
+                if a.size:
+                    scale = max(np.abs(b).max(), 1e-30)
+                    out["parity"] = {"rel_linf_px_vs_oracle": float((np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b), 1e-3 * scale)).max()),
+                                     "rel_linf_vs_oracle": float(np.abs(a - b).max() / scale), "rows": [b0 + 1, b1 - 1], "tolerance": 1e-3,
+                                     "what": "developed image rows of the benchmark frame, GPU vs CPU oracle, same seed; rel_linf_px = SURVEY 8(d): "
+                                             "max_px |gpu - ref| / max(|ref_px|, 1e-3 max|ref|); rel_linf = the same difference over max|ref|"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+// dtof_kernels.h -- kernel parameter blocks and queue layout shared by the host
+// orchestration (dtof_render.hip) and the kernels (dtof_kernels.hip).
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+#include "dtof_math.h"
+
+namespace dtof {
+
+constexpr uint32_t kChunkBlocks = 8; // 64-lane chunks of a 512-lane queue segment (RenderParams::chunk_blocks)
+constexpr uint32_t kMaxInline = 4;  // iterations of the bounce loop the fused first-bounce kernel may run itself (RenderParams::inline_iters)
+constexpr int kMaxOffsets = 4;      // modulation offsets evaluated per traversal (K)
+
+// Everything a kernel needs besides the scene blob and the queues; passed by value.
+struct RenderParams {
+    // ---- camera (PerspectiveCamera, src/sensors/perspective.cpp:172-279)
+    float s2c[16];                  // sample_to_camera
+    float cam_to_world[12];
+    float near_clip, far_clip, shutter_open, shutter_open_time;
+    int32_t orthographic;                    // OrthographicCamera (src/sensors/orthographic.cpp:169-196)
+    float aperture_radius, focus_distance;   // ThinLensCamera (src/sensors/thinlens.cpp:257-305); aperture_radius == 0: perspective
+    // ---- film (lane -> pixel mapping src/render/integrator.cpp:273-290; splat imageblock.cpp:414-531)
+    int32_t crop_x, crop_y, crop_w, crop_h;
+    float scale_x, scale_y, offset_x, offset_y;   // render_sample: scale = 1/crop_size, offset = -crop_offset*scale
+    int32_t filter; float filter_radius, inv_radius;
+    float gauss_coeff[10];                        // GaussianFilter's Remez fit, scaled and shifted like gaussian.cpp:60-89
+    float filter_b, filter_c;       // mitchell: B, C (src/rfilters/mitchell.cpp)
+    // ---- sampler (src/samplers/correlated.cpp, src/render/sampler.cpp)
+    uint32_t base_seed, seed, seed_value;         // seed_value = base_seed + seed
+    uint32_t spp, spp_log2;                       // spp_log2 = 0xffffffff when spp is not a power of two
+    uint32_t tcn, pcn;
+    int32_t time_sampling; float antithetic_shift; int32_t stratify;
+    uint32_t n_stratum; float inv_n_stratum, inv_tcn;
+    // ---- integrator (src/integrators/dopplertofpath.cpp:19-77)
+    float T, w_d, w_g, phi_coef, amp, g_1, g_0;
+    float phase[kMaxOffsets]; int32_t n_offsets;
+    int32_t wave_type, low_pass;
+    uint32_t path_correlation_depth, max_depth, rr_depth;
+    int32_t has_area;                             // scene has area emitters: emitter-hit term + prev_si / prev_bsdf_pdf state
+    int32_t sampler_kind, jitter; float inv_spp;  // SamplerKind; timestratified: jitter, 1 / sample_count (timestratified.cpp:78-82)
+    int32_t has_spec;                             // scene has delta BSDFs (conductor / dielectric): eta and prev_bsdf_delta become per-lane state; 2: ... and blendbsdf
+    int32_t has_tris;                             // scene has triangle meshes (selects the kernel instantiations that carry mesh code)
+    int32_t has_blas;                             // some mesh is traversed through its own BLAS: the unstaged k_trace / k_shadow run one wave per block
+    int32_t integrator;                           // 0 dopplertofpath, 1 path (src/integrators/path.cpp), 2 velocity (velocity.cpp)
+    // ---- batch
+    uint32_t lane_base, n_lanes;                  // this batch covers (virtual) lanes [lane_base, lane_base + n_lanes)
+    // striped shards (dtof_render_stripes): virtual row v of this shard is film row stripe_first + (v / stripe_rows) * stripe_period
+    // + v % stripe_rows, and the GLOBAL lane index (what every RNG stream is a function of) follows from it.  stripe_rows == 0:
+    // virtual = global (contiguous rows).
+    uint32_t stripe_rows, stripe_period, stripe_first, lanes_per_row;
+    // exact division by the launch-invariant divisors of the lane mappings (dtof_math.h: FastDiv)
+    FastDiv d_spp, d_w, d_tcn, d_pcn, d_stratum, d_lanes_per_row, d_stripe_rows;
+    // wavefronts of more than 2^32 - 1 lanes / samples_per_pass (integrator.cpp:121-124,227-245): pass `pass` of `n_passes`, each of
+    // `spp` samples per pixel (= samples per wavefront); the sampler's streams are seeded in pass 0 and carried across the passes
+    uint32_t pass, n_passes;
+    uint32_t sample_count; FastDiv d_sample_count;   // Sampler::sample_count() of the whole render (spp = samples per wavefront = per pass)
+    uint2 *pass_rng;                              // n_passes > 1: [lane - pass_first][3] = states of the main / time / path streams between passes
+    uint32_t pass_first;                          // virtual lane the pass_rng array starts at
+    int32_t has_env, hide_emitters; uint32_t env_index;   // `constant` environment emitter (scene.cpp:53-57), SamplingIntegrator::m_hide_emitters
+    uint32_t chunk_blocks;                        // first-bounce kernel: blocks per 512-lane segment, 1 or 8 (small frames whose whole path runs inline)
+    uint32_t inline_iters;                        // fused first-bounce kernel: iterations of the bounce loop it runs back to back with the path state in registers (1 .. kMaxInline)
+    uint32_t flat_objects, flat_off;                        // fused pipeline, rectangle-only scenes of at most kFlatObjects objects: their number (trace_flat), else 0
+    uint32_t memo_obj;                            // fused pipeline: the scene's only instance object (instance memo, dtof_traverse.h) or 0xffffffff
+};
+
+// SoA wavefront state for one batch (device pointers; all arrays have `capacity` entries and are
+// indexed by the lane's position inside the batch).
+struct Queues {
+    float4 *ray_a;       // o.xyz, time
+    float4 *ray_b;       // d.xyz, maxt
+    uint4  *hit;         // t, u, v (float bits), prim
+    float  *hit_t;       // rectangle-only scenes: t alone replaces `hit`
+    uint32_t *hit_id;    // object (low id_shift bits) | shape-in-group (the bits above); 0xffffffff = miss
+    float4 *st_a;        // throughput.xyz, path_length
+    float4 *st_b;        // prev_si.p, prev_bsdf_pdf (only touched when the scene has area emitters)
+    uint4  *rng_a;       // rng.state (lo,hi), rng_path.state (lo,hi)
+    float2 *st_c;        // SPEC: (eta along the path, prev_bsdf_delta)
+    uint2  *rng_b;       // (main, path) stream selectors v1 of the TEA seeding: inc = (v1 << 1) | 1, constant per lane
+    float4 *res;         // [K][capacity] accumulated result rgb (w unused)
+    float2 *pos;         // sample position on the film
+    float4 *sh_a;        // shadow ray o.xyz, maxt
+    float4 *sh_b;        // shadow ray d.xyz, time
+    float4 *sh_c;        // [K][capacity] candidate result rgb, w = as_float(lane position)
+    uint32_t *q[2];      // active-lane index queues (ping-pong), segmented: entry j of segment S at S*kSeg + j
+    uint32_t *counts;    // [iteration][2][n_segments]: survivors / shadow rays per segment
+    uint32_t *seg_counter;   // resident first-bounce kernel: next segment to hand out (zeroed before the launch)
+    uint32_t capacity;
+    uint32_t id_shift;   // bits of hit_id that hold the object index: 24 unless the scene needs more shapes per group than 8 bits hold (render_rows)
+};
+
+struct LaneDebug {       // mirrors orc_lane's comparable fields
+    float sample_pos[2]; float time; float ray_o[3]; float ray_d[3]; float rgb[3];
+};
+
+// Resident stage of the fused first-bounce kernel (k_shade<..., RESW>, dtof_kernels.hip): `waves` waves per block (0 = off), one block per CU; the block
+// [small_off, small_off + 16 * small_words) of the blob (groups, shapes, emitters, triangles, shading data) and the TLAS nodes live in LDS.
+struct ResidentStage { uint32_t small_off = 0, small_words = 0, waves = 0; };
+constexpr uint32_t kResidentNodes = 1024;   // TLAS nodes the stage holds (= kResNodes of dtof_traverse.h)
+
+// kernels (dtof_kernels.hip)
+void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s);
+void launch_sum_counts(const uint32_t *counts, uint32_t n_seg, uint32_t n_rows, unsigned long long *out, hipStream_t s);
+uint32_t segments_for(uint32_t n_lanes);   // number of queue segments (count slots) for a batch
+void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
+                  const uint32_t *qin, const uint32_t *count_in, uint32_t stack_depth, hipStream_t s);
+void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
+                  const uint32_t *qin, const uint32_t *count_in, uint32_t *qout,
+                  uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, bool fused, bool trace_next,
+                  uint32_t stack_depth, hipStream_t s, bool first = false, LaneDebug *dbg = nullptr,   // first: generate + primary trace inline (fused only)
+                  const ResidentStage *resident = nullptr);
+void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
+                   const uint32_t *count_in, uint32_t stack_depth, hipStream_t s);
+void launch_velocity(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q, uint32_t stack_depth, hipStream_t s);
+void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t film_w, int32_t film_h, hipStream_t s);
+void launch_develop(const float *film, float *rgb, int64_t n_pixels, hipStream_t s);
+void launch_lane_dump(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s);
+void launch_pass_save(const RenderParams &rp, const Queues &q, hipStream_t s);   // multi-pass: main / path stream states of the batch -> rp.pass_rng
+void launch_lane_dump_rays(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s);
+
+// sampler KAT kernels
+struct SamplerState { uint2 *rng, *rng_time, *rng_path; uint32_t *perm_seed, *dim; uint32_t n; };
+void launch_sampler_seed(const RenderParams &rp, const SamplerState &st, hipStream_t s);
+void launch_sampler_next_correlate(const RenderParams &rp, const SamplerState &st, const uint8_t *correlate, int correlate_all,
+                                   float *out, hipStream_t s);
+void launch_sampler_next_1d(const RenderParams &rp, const SamplerState &st, float *out, hipStream_t s);
+void launch_sampler_next_time(const RenderParams &rp, const SamplerState &st, uint32_t sample_index_base, float *out, hipStream_t s);
+void launch_waveform_eval(const RenderParams &rp, const float *t, const float *len, float *out, int mode, uint32_t n, hipStream_t s);
+
+// component evaluation (dtof_eval_component; the ids are the DTOF_COMP_* values of include/dtof.h)
+enum { COMP_MICROFACET_EVAL = 0, COMP_MICROFACET_PDF = 1, COMP_MICROFACET_G1 = 2, COMP_MICROFACET_SAMPLE = 3, COMP_FRESNEL = 4,
+       COMP_FRESNEL_CONDUCTOR = 5, COMP_RFILTER = 6, COMP_WARP_COSINE_HEMISPHERE = 7, COMP_WARP_DISK_CONCENTRIC = 8,
+       COMP_WARP_UNIFORM_TRIANGLE = 9, COMP_WARP_UNIFORM_SPHERE = 10, COMP_COORDINATE_SYSTEM = 11, COMP_TEA_FLOAT32 = 12, COMP_MATH = 13,
+       COMP_COUNT = 14 };
+struct ComponentArgs { int component; float p[8]; const float *in; int in_stride; float *out; int out_stride; uint32_t n; };
+void launch_component(const ComponentArgs &a, const RenderParams &rp, hipStream_t s);
+// Scene::ray_intersect / ray_test over arrays
+void launch_ray_query(const uint8_t *scene, const float *rays, float *out, int32_t *ids, float *uv4, uint32_t n, bool any, uint32_t stack_depth, hipStream_t s);
+
+#ifdef DTOF_TRAVERSAL_STATS
+bool read_traversal_stats(unsigned long long *out8);
+#endif
+
+}  // namespace dtof

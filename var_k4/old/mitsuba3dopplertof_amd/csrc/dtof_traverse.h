@@ -1,0 +1,685 @@
+#pragma once
+// dtof_traverse.h -- device side of the scene: blob view, LDS staging, primitive tests (rectangle, triangle, sphere), motion-blur
+// instance matrices and the TLAS / BLAS traversal (closest hit and occlusion).  Included by dtof_kernels.hip only.
+#include "dtof_kernels.h"
+#include "dtof_scene.h"
+#include "dtof_math.h"
+
+#ifndef DTOF_D
+#define DTOF_D __device__ __forceinline__
+#endif
+
+namespace dtof {
+
+// ---------------------------------------------------------------------------- scene view
+struct SceneView {
+    const DNode *nodes; const DObject *objects; const DGroup *groups; const DShape *shapes;
+    const DTri *tris; const DTriShade *shading; const DEmitter *emitters; const uint8_t *base;
+    uint32_t n_nodes, n_emitters;
+    // Fused shade kernels, scenes with ONE instance object: the world -> object matrix of that instance at the lane's ray time is
+    // computed once per path vertex (instance_memo_fill) and kept in a per-thread LDS column; the closest-hit and occlusion queries of
+    // the vertex and its surface interaction read it back instead of re-deriving it (a ray's time does not change along a path,
+    // dopplertofpath.cpp:93,240-244).  memo_obj = 0xffffffff: no memo.
+    uint32_t memo_obj; float *memo;
+};
+// Resident scene stage (k_shade<..., RESW>): the TLAS nodes live in LDS as FOUR PLANES of 16-byte pieces -- piece k of node i at
+// uint4 index k * kResNodes + i -- so that the 16 lanes of a ds_read_b128 lane group, which read the same piece of 16 different nodes,
+// spread over all 64 banks (node-major 64-byte records would put piece k of every node on the same 16 banks: 4-way conflicts on
+// average); the plane stride is a compile-time constant, so the four reads of a node step are one address plus immediate offsets.
+constexpr uint32_t kResNodes = 1024;
+DTOF_D SceneView make_view(const uint8_t *base) {
+    const BlobHeader *h = (const BlobHeader *) base;
+    SceneView v;
+    v.nodes = (const DNode *) (base + h->off_nodes);
+    v.objects = (const DObject *) (base + h->off_objects);
+    v.groups = (const DGroup *) (base + h->off_groups);
+    v.shapes = (const DShape *) (base + h->off_shapes);
+    v.tris = (const DTri *) (base + h->off_tris);
+    v.shading = (const DTriShade *) (base + h->off_shading);
+    v.emitters = (const DEmitter *) (base + h->off_emitters);
+    v.base = base;
+    v.n_nodes = h->n_nodes; v.n_emitters = h->n_emitters;
+    v.memo_obj = 0xffffffffu; v.memo = nullptr;
+    return v;
+}
+// Stage the whole scene blob into LDS (small scenes: the Cornell blob is ~5 KB).
+DTOF_D const uint8_t *stage_scene(const uint8_t *g, uint32_t bytes, uint4 *lds) {
+    const uint4 *src = (const uint4 *) g;
+    for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) lds[i] = src[i];
+    __syncthreads();
+    return (const uint8_t *) lds;
+}
+
+struct Hit { float t, u, v; uint32_t obj, shape, prim; };
+
+// Traversal statistics (development builds only: make STATS=1 -> libdtof_stats.so, read by tools/traversal_stats.py).
+// [0] rays  [1] node steps (lane)  [2] node iterations (wave)  [3] leaf visits (lane)  [4] leaf rounds (wave)  [5] mesh loops entered (lane)
+// [6] triangle tests (lane)  [7] BLAS node steps (lane)
+#ifdef DTOF_TRAVERSAL_STATS
+__device__ unsigned long long g_trav_stats[8];
+#define DTOF_STAT(i) atomicAdd(&g_trav_stats[i], 1ull)
+#define DTOF_STAT_WAVE(i) do { if (__lane_id() == (uint32_t) __ffsll((long long) __ballot(1)) - 1u) atomicAdd(&g_trav_stats[i], 1ull); } while (0)
+#else
+#define DTOF_STAT(i) ((void) 0)
+#define DTOF_STAT_WAVE(i) ((void) 0)
+#endif
+
+// ---------------------------------------------------------------------------- primitives
+// Rectangle::ray_intersect_preliminary_impl, src/shapes/rectangle.cpp:201-224
+DTOF_D bool rect_hit(const DShape &sh, V3 o, V3 d, float maxt, float &t, float &u, float &v) {
+    V3 lo = xf_point(sh.to_object, o), ld = xf_vector(sh.to_object, d);
+    t = -lo.z / ld.z;
+    u = fmaf(ld.x, t, lo.x); v = fmaf(ld.y, t, lo.y);
+    return t >= 0.f && t <= maxt && fabsf(u) <= 1.f && fabsf(v) <= 1.f;
+}
+// Disk::ray_intersect_preliminary_impl, src/shapes/disk.cpp:216-232: the rectangle's plane test with a circular bound
+DTOF_D bool disk_hit(const DShape &sh, V3 o, V3 d, float maxt, float &t, float &u, float &v) {
+    V3 lo = xf_point(sh.to_object, o), ld = xf_vector(sh.to_object, d);
+    t = -lo.z / ld.z;
+    u = fmaf(ld.x, t, lo.x); v = fmaf(ld.y, t, lo.y);
+    return t >= 0.f && t <= maxt && u * u + v * v <= 1.f;
+}
+// Moeller-Trumbore as in Embree 3's triangle intersector (tnear < t <= tfar; u,v weight vertices 1,2).
+// The 48-byte record is fetched with three 16-byte loads issued together; `face` rides in p0.w.
+DTOF_D bool tri_hit(const DTri &tr, V3 o, V3 d, float maxt, float &t, float &u, float &v, uint32_t &face) {
+    const uint4 *tp = (const uint4 *) &tr;
+    const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+    face = q0.w;
+    V3 p0 = mk(u2f(q0.x), u2f(q0.y), u2f(q0.z)), p1 = mk(u2f(q1.x), u2f(q1.y), u2f(q1.z)), p2 = mk(u2f(q2.x), u2f(q2.y), u2f(q2.z));
+    V3 e1 = p0 - p1, e2 = p2 - p0, ng = cross(e2, e1);
+    V3 c = p0 - o, r = cross(c, d);
+    float den = dot(ng, d), aden = fabsf(den);
+    uint32_t sgn = f2u(den) & 0x80000000u;
+    float U = u2f(f2u(dot(r, e2)) ^ sgn), Vv = u2f(f2u(dot(r, e1)) ^ sgn);
+    if (!(den != 0.f && U >= 0.f && Vv >= 0.f && U + Vv <= aden)) return false;
+    float T = u2f(f2u(dot(ng, c)) ^ sgn);
+    if (!(0.f < T && T <= aden * maxt)) return false;
+    float rc = 1.0f / aden;
+    u = U * rc; v = Vv * rc; t = T * rc;
+    return true;
+}
+// math::solve_quadratic (include/mitsuba/core/math.h:357-401), float64
+DTOF_D bool solve_quadratic_d(double a, double b, double c, double &x0, double &x1) {
+    const bool linear = a == 0.0, valid_linear = linear && b != 0.0;
+    x0 = x1 = -c / b;
+    const double discrim = fma(b, b, -(4.0 * a * c));
+    const bool valid_quadratic = !linear && discrim >= 0.0;
+    if (valid_quadratic) {
+        const double sq = sqrt(discrim), temp = -0.5 * (b + copysign(sq, b));
+        const double x0p = temp / a, x1p = c / temp;
+        x0 = x0p < x1p ? x0p : x1p; x1 = x0p < x1p ? x1p : x0p;
+    }
+    return valid_linear || valid_quadratic;
+}
+DTOF_D double dot3d(double ax, double ay, double az, double bx, double by, double bz) { return fma(az, bz, fma(ay, by, ax * bx)); }
+// Sphere::ray_intersect_preliminary_impl (src/shapes/sphere.cpp:338-394) / ray_test_impl (:396-431): float64 on the llvm back
+// end; the point of the ray closest to the centre is evaluated with the FLOAT ray (Ray::operator() takes a Float, ray.h:61).
+template <bool ANY>
+DTOF_D bool sphere_hit(const DShape &sh, V3 o, V3 d, float maxt_f, float &t_out) {
+    const double radius = sh.dp_du[0], cx = sh.n[0], cy = sh.n[1], cz = sh.n[2], maxt = maxt_f;
+    const double dx = d.x, dy = d.y, dz = d.z;
+    double near_t, far_t;
+    if (ANY) {
+        const double ox = (double) o.x - cx, oy = (double) o.y - cy, oz = (double) o.z - cz;
+        const double A = dot3d(dx, dy, dz, dx, dy, dz), B = 2.0 * dot3d(ox, oy, oz, dx, dy, dz), C = dot3d(ox, oy, oz, ox, oy, oz) - radius * radius;
+        const bool found = solve_quadratic_d(A, B, C, near_t, far_t);
+        const bool out_bounds = !(near_t <= maxt && far_t >= 0.0), in_bounds = near_t < 0.0 && far_t > maxt;
+        return found && !out_bounds && !in_bounds;
+    }
+    const double lx = (double) o.x - cx, ly = (double) o.y - cy, lz = (double) o.z - cz;
+    const double plane_t = dot3d(-lx, -ly, -lz, dx, dy, dz) / sqrt(dot3d(dx, dy, dz, dx, dy, dz));
+    bool no_hit = plane_t == 0.0 && (o.x != sh.n[0] && o.y != sh.n[1] && o.z != sh.n[2]);
+    const V3 pp = vfma(d, (float) plane_t, o);
+    const double ox = (double) pp.x - cx, oy = (double) pp.y - cy, oz = (double) pp.z - cz;
+    no_hit = no_hit && sqrt(dot3d(ox, oy, oz, ox, oy, oz)) > radius;
+    const double A = dot3d(dx, dy, dz, dx, dy, dz), B = 2.0 * dot3d(ox, oy, oz, dx, dy, dz), C = dot3d(ox, oy, oz, ox, oy, oz) - radius * radius;
+    const bool found = solve_quadratic_d(A, B, C, near_t, far_t);
+    near_t += plane_t; far_t += plane_t;
+    const bool out_bounds = !(near_t <= maxt && far_t >= 0.0), in_bounds = near_t < 0.0 && far_t > maxt;
+    if (!(found && !no_hit && !out_bounds && !in_bounds)) return false;
+    t_out = near_t < 0.0 ? (float) far_t : (float) near_t;
+    return true;
+}
+// Cylinder::ray_intersect_preliminary_impl / ray_test_impl (src/shapes/cylinder.cpp:300-391): the unit cylinder in object space, float64 on the
+// llvm back end (the ray is transformed in float32, then widened)
+DTOF_D bool cylinder_hit(const DShape &sh, V3 o, V3 d, float maxt_f, float &t_out) {
+    const V3 lo = xf_point(sh.to_object, o), ld = xf_vector(sh.to_object, d);
+    const double ox = lo.x, oy = lo.y, oz = lo.z, dx = ld.x, dy = ld.y, dz = ld.z, maxt = maxt_f;
+    const double A = dx * dx + dy * dy, B = 2.0 * (dx * ox + dy * oy), C = ox * ox + oy * oy - 1.0;
+    double near_t, far_t;
+    const bool found = solve_quadratic_d(A, B, C, near_t, far_t);
+    const bool out_bounds = !(near_t <= maxt && far_t >= 0.0), in_bounds = near_t < 0.0 && far_t > maxt;
+    const double z_near = oz + dz * near_t, z_far = oz + dz * far_t;
+    const bool near_ok = z_near >= 0.0 && z_near <= 1.0 && near_t >= 0.0, far_ok = z_far >= 0.0 && z_far <= 1.0 && far_t <= maxt;
+    if (!(found && !out_bounds && !in_bounds && (near_ok || far_ok))) return false;
+    t_out = near_ok ? (float) near_t : (float) far_t;
+    return true;
+}
+// AnimatedTransform::eval, include/mitsuba/core/transform.h:439-466
+DTOF_D void instance_matrix(const DObject &ob, float time, float *m) {
+    if (ob.n_keys <= 1) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) m[i] = ob.key0[i];
+        return;
+    }
+    float t = fmin_(fmax_((time - ob.t0) / (ob.t1 - ob.t0), 0.f), 1.f), omt = 1 - t;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) m[i] = ob.key0[i] * omt + ob.key1[i] * t;
+}
+
+// instance memo (see SceneView): 12 words per thread, word k of thread t at memo[k * kMemoStride + t]
+constexpr uint32_t kMemoStride = 64, kMemoWords = 12;
+DTOF_D void instance_memo_fill(const SceneView &sv, float time, float *m, float *inv) {
+    instance_matrix(sv.objects[sv.memo_obj], time, m);
+    affine_inverse(m, inv);
+#pragma unroll
+    for (uint32_t k = 0; k < kMemoWords; ++k) sv.memo[k * kMemoStride] = inv[k];
+}
+DTOF_D void instance_memo_load(const SceneView &sv, float *inv) {
+#pragma unroll
+    for (uint32_t k = 0; k < kMemoWords; ++k) inv[k] = sv.memo[k * kMemoStride];
+}
+
+// Slab test against a padded box; NaNs (0*inf) fall out of the min/max chain conservatively.
+DTOF_D float box_entry(const float *bmin, const float *bmax, V3 o, V3 id, float tbest) {
+    float tx0 = (bmin[0] - o.x) * id.x, tx1 = (bmax[0] - o.x) * id.x;
+    float ty0 = (bmin[1] - o.y) * id.y, ty1 = (bmax[1] - o.y) * id.y;
+    float tz0 = (bmin[2] - o.z) * id.z, tz1 = (bmax[2] - o.z) * id.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
+    return tn <= tf ? tn : INFINITY;
+}
+#ifndef DTOF_BVH4
+// One BVH node = four 16-byte loads issued together (no load depends on a field of the node); entry distances of both
+// children, INFINITY = missed / absent.
+template <bool SOA = false>
+DTOF_D void node_test(const BvhNode *nodes, uint32_t cur, V3 o, V3 id, float tbest, float &tl, float &tr, uint32_t &left, uint32_t &right) {
+    const uint4 *np = SOA ? (const uint4 *) nodes + cur : (const uint4 *) (nodes + cur);
+    const uint4 a = np[0], b = np[SOA ? kResNodes : 1], c = np[SOA ? 2 * kResNodes : 2], d = np[SOA ? 3 * kResNodes : 3];
+    const float lmin[3] = { u2f(a.x), u2f(a.y), u2f(a.z) }, lmax[3] = { u2f(b.x), u2f(b.y), u2f(b.z) };
+    const float rmin[3] = { u2f(c.x), u2f(c.y), u2f(c.z) }, rmax[3] = { u2f(d.x), u2f(d.y), u2f(d.z) };
+    left = a.w; right = b.w;
+    tl = box_entry(lmin, lmax, o, id, tbest);
+    tr = box_entry(rmin, rmax, o, id, tbest);
+    if (right == kNoChild) tr = INFINITY;
+}
+// one traversal step at inner node `cur`: continue with the nearest child that is hit, push the other, pop when nothing is hit
+template <bool SOA = false>
+DTOF_D uint32_t node_step(const BvhNode *nodes, uint32_t cur, V3 o, V3 id, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride, uint32_t done) {
+    float tl, tr; uint32_t left, right;
+    node_test<SOA>(nodes, cur, o, id, tbest, tl, tr, left, right);
+    const bool hl = tl < INFINITY, hr = tr < INFINITY;
+    if (hl && hr) {
+        const uint32_t nearc = tl <= tr ? left : right, farc = tl <= tr ? right : left;
+        stack[sp * stride] = farc; ++sp;
+        return nearc;
+    }
+    if (hl) return left;
+    if (hr) return right;
+    if (sp == sp_floor) return done;
+    --sp; return stack[sp * stride];
+}
+#else
+DTOF_D void cswap(float &ta, uint32_t &ca, float &tb, uint32_t &cb) {   // compare-exchange of (distance, child) pairs
+    const bool sw = tb < ta;
+    const float t = sw ? tb : ta; const uint32_t c = sw ? cb : ca;
+    tb = sw ? ta : tb; cb = sw ? ca : cb; ta = t; ca = c;
+}
+// One traversal step at the 4-wide quantised inner node `cur` (four 16-byte loads issued together, none depends on a field of the node).  The slab test
+// runs in the node's frame: a child's plane at q quanta lies at t = q * (scale * id) + (origin - o) * id, one fma per plane after three products and
+// three differences per node; the children whose boxes the ray enters before `tbest` are ordered by entry distance with a five-comparator network; the
+// nearest is returned, the others are pushed far-first; nothing hit: pop (or `done` at the floor of this traversal's stack).
+DTOF_D float ubyte_f(uint32_t w, int k) { return (float) ((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyte<k>
+template <bool SOA = false>
+DTOF_D uint32_t node_step(const BvhNode4 *nodes, uint32_t cur, V3 o, V3 id, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride, uint32_t done) {
+    const uint4 *np = SOA ? (const uint4 *) nodes + cur : (const uint4 *) (nodes + cur);
+    const uint4 q0 = np[0], q1 = np[SOA ? kResNodes : 1], q2 = np[SOA ? 2 * kResNodes : 2], q3 = np[SOA ? 3 * kResNodes : 3];
+    float t[4]; uint32_t c[4] = { q1.x, q1.y, q1.z, q1.w };
+    const float ax = u2f((q0.w & 0xffu) << 23) * id.x, ay = u2f(((q0.w >> 8) & 0xffu) << 23) * id.y, az = u2f(((q0.w >> 16) & 0xffu) << 23) * id.z;
+    const float bx = (u2f(q0.x) - o.x) * id.x, by = (u2f(q0.y) - o.y) * id.y, bz = (u2f(q0.z) - o.z) * id.z;
+    const uint32_t lox = q2.x, loy = q2.y, loz = q2.z, hix = q2.w, hiy = q3.x, hiz = q3.y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float tx0 = fmaf(ubyte_f(lox, k), ax, bx), tx1 = fmaf(ubyte_f(hix, k), ax, bx);
+        const float ty0 = fmaf(ubyte_f(loy, k), ay, by), ty1 = fmaf(ubyte_f(hiy, k), ay, by);
+        const float tz0 = fmaf(ubyte_f(loz, k), az, bz), tz1 = fmaf(ubyte_f(hiz, k), az, bz);
+        const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
+        const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
+        t[k] = (tn <= tf && c[k] != kNoChild) ? tn : INFINITY;
+    }
+    cswap(t[0], c[0], t[1], c[1]); cswap(t[2], c[2], t[3], c[3]); cswap(t[0], c[0], t[2], c[2]); cswap(t[1], c[1], t[3], c[3]); cswap(t[1], c[1], t[2], c[2]);
+    if (t[0] < INFINITY) {
+        if (t[3] < INFINITY) { stack[sp * stride] = c[3]; ++sp; }
+        if (t[2] < INFINITY) { stack[sp * stride] = c[2]; ++sp; }
+        if (t[1] < INFINITY) { stack[sp * stride] = c[1]; ++sp; }
+        return c[0];
+    }
+    if (sp == sp_floor) return done;
+    --sp; return stack[sp * stride];
+}
+#endif
+
+// Closest hit (ANY=false) or occlusion (ANY=true) of one top-level object.  Candidates are every
+// primitive hit with t <= maxt; the winner is the smallest t, ties going to the lowest
+// (object, shape, face) -- the rule the oracle uses, independent of traversal order.
+// `stack + sp * stride` onwards is free for the BLAS traversal of a mesh.
+template <bool ANY, bool MESH, bool MEMO = false>
+DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float time, float maxt, Hit &best,
+                             uint32_t *stack, int sp, uint32_t stride) {
+    const DObject &ob = sv.objects[oi];
+    uint32_t first = ob.index, count = 1;
+    V3 lo = o, ld = d;
+    if (ob.kind == OBJ_INSTANCE) {
+        float m[12], inv[12];
+        if (MEMO && oi == sv.memo_obj) instance_memo_load(sv, inv);
+        else {
+            instance_matrix(ob, time, m);
+            affine_inverse(m, inv);
+        }
+        lo = xf_point(inv, o); ld = xf_vector(inv, d);
+        const DGroup &g = sv.groups[ob.index];
+        first = g.first_shape; count = g.n_shapes;
+    }
+    bool found = false;
+    for (uint32_t k = 0; k < count; ++k) {
+        const DShape &sh = sv.shapes[first + k];
+        float t, u, v;
+        if (sh.kind == SHAPE_RECT) {
+            if (rect_hit(sh, lo, ld, maxt, t, u, v)) {
+                if (ANY) return true;
+                if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
+                    best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = 0; found = true;
+                }
+            }
+            continue;
+        }
+        if (!MESH) continue;   // instantiations for rectangle-only scenes carry no triangle / sphere code at all
+        if (sh.kind == SHAPE_DISK) {
+            if (disk_hit(sh, lo, ld, maxt, t, u, v)) {
+                if (ANY) return true;
+                if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
+                    best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = 0; found = true;
+                }
+            }
+            continue;
+        }
+        if (sh.kind == SHAPE_CYLINDER) {
+            if (cylinder_hit(sh, lo, ld, maxt, t)) {
+                if (ANY) return true;
+                if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
+                    best.t = t; best.u = 0.f; best.v = 0.f; best.obj = oi; best.shape = k; best.prim = 0; found = true;
+                }
+            }
+            continue;
+        }
+        if (sh.kind == SHAPE_SPHERE) {
+            if (sphere_hit<ANY>(sh, lo, ld, maxt, t)) {
+                if (ANY) return true;
+                if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
+                    best.t = t; best.u = 0.f; best.v = 0.f; best.obj = oi; best.shape = k; best.prim = 0; found = true;
+                }
+            }
+            continue;
+        }
+        // cull with the mesh's own (padded) bounds: TLAS boxes of moving instances are the union over the whole
+        // motion and let many rays through that miss the mesh at their time
+        V3 lid = mk(__builtin_amdgcn_rcpf(ld.x == 0.f ? 1e-30f : ld.x), __builtin_amdgcn_rcpf(ld.y == 0.f ? 1e-30f : ld.y), __builtin_amdgcn_rcpf(ld.z == 0.f ? 1e-30f : ld.z));
+        if (!(box_entry(sh.bmin, sh.bmax, lo, lid, ANY ? maxt : best.t) < INFINITY)) continue;
+        // `face` of the best hit so far IF it lies on this very mesh (ties between two of its triangles go to the lower face)
+        uint32_t best_face = 0xffffffffu;
+        DTOF_STAT(5);
+        auto test = [&](uint32_t f) -> bool {
+            uint32_t face;
+            DTOF_STAT(6);
+            if (!tri_hit(sv.tris[sh.first_tri + f], lo, ld, maxt, t, u, v, face)) return false;
+            if (ANY) return true;
+            bool take = t < best.t;
+            if (t == best.t) take = best_face != 0xffffffffu ? face < best_face : (!found && best.obj != 0xffffffffu && oi < best.obj);
+            if (take) { best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = f; best_face = face; found = true; }
+            return false;
+        };
+        if (sh.blas_root == kNoChild) {
+            for (uint32_t f = 0; f < sh.n_tris; ++f) if (test(f)) return true;
+            continue;
+        }
+        // BLAS: same node format and while-while shape as the TLAS loop below
+        constexpr uint32_t kDone = 0x7fffffffu;
+        uint32_t cur = sh.blas_root; int bsp = sp;
+        for (;;) {
+            while (!(cur & kLeafFlag) && cur != kDone) {
+                DTOF_STAT(7);
+                cur = node_step(sv.nodes, cur, lo, lid, ANY ? maxt : best.t, stack, bsp, sp, stride, kDone);
+            }
+            if (cur == kDone) break;
+            uint32_t f0 = (cur & ~kLeafFlag) >> kBlasLeafBits, fn = (cur & ((1u << kBlasLeafBits) - 1u)) + 1u;
+            for (uint32_t f = f0; f < f0 + fn; ++f) if (test(f)) return true;
+            if (bsp == sp) break;
+            --bsp; cur = stack[bsp * stride];
+        }
+    }
+    return found;
+}
+
+// TLAS traversal; `stack` is a per-thread LDS column (stride blockDim.x).
+template <bool ANY, bool MESH, bool MEMO = false, bool SOA = false>   // SOA: the TLAS nodes are the LDS planes of the resident stage (binary nodes only)
+DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best) {
+    best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
+    if (sv.n_nodes == 0) return false;
+    // direction reciprocal for the slab test only (exact zero components are nudged)
+    // v_rcp_f32 (1 ulp) is enough here: the boxes are padded by 1e-5 relative on the host
+    V3 id = mk(__builtin_amdgcn_rcpf(d.x == 0.f ? 1e-30f : d.x), __builtin_amdgcn_rcpf(d.y == 0.f ? 1e-30f : d.y), __builtin_amdgcn_rcpf(d.z == 0.f ? 1e-30f : d.z));
+    // "while-while" traversal: every lane first descends inner nodes until it holds a leaf (or is done), THEN the
+    // lanes that hold a leaf run the expensive object intersection together -- the wave does not pay the leaf
+    // body once per node step of its slowest lane.
+    constexpr uint32_t kDone = 0x7fffffffu;
+    int sp = 0;
+    uint32_t cur = 0;
+    const uint32_t stride = blockDim.x;
+    DTOF_STAT(0);
+    for (;;) {
+        while (!(cur & kLeafFlag) && cur != kDone) {
+            DTOF_STAT(1); DTOF_STAT_WAVE(2);
+            cur = node_step<SOA>(sv.nodes, cur, o, id, best.t, stack, sp, 0, stride, kDone);
+        }
+        if (cur == kDone) break;
+        DTOF_STAT(3); DTOF_STAT_WAVE(4);
+        if (intersect_object<ANY, MESH, MEMO>(sv, cur & ~kLeafFlag, o, d, time, maxt, best, stack, sp, stride) && ANY) return true;
+        if (sp == 0) break;
+        --sp; cur = stack[sp * stride];
+    }
+    return best.obj != 0xffffffffu;
+}
+
+
+// ---------------------------------------------------------------------------- cooperative triangle loops
+// The loop over the triangles of a small mesh (no BLAS: at most kBlasMinTris triangles -- the 12 of a `cube`) is the most expensive body of
+// the traversal (38 VALU per triangle) and runs at the lowest lane utilisation: in a leaf round about half of the lanes hold a leaf, a
+// third of those pass the mesh's bounds, and the whole wave pays the 12 tests (Domino: 0.42 loops per ray, 1 186 of the 2 800 VALU
+// instructions of a ray-wave at ~0.16 lane utilisation).  trace_scene_coop is the same traversal written as ONE wave-uniform loop -- lanes
+// whose ray is finished (or that had no ray to trace) stay in it as helpers -- so that the triangle loops of a round are shared out: with
+// n lanes holding a (ray, mesh) job, every job gets g = 8, 4 or 2 adjacent lanes (g <= 64 / n), helper i of a job tests the triangles
+// i, i + g, ... with the job's ray (pulled by ds_bpermute), the group reduces to (smallest t, ties to the lowest face) with DPP row
+// operations and the owner pulls the result back.  Same tri_hit arithmetic per (ray, triangle), same winner: candidates are every triangle
+// hit with t <= maxt, the smallest t wins, equal t goes to the lowest face of the mesh, and the owner then merges the mesh's winner into its
+// best hit with the rule of intersect_object (strictly nearer, or equally near on a lower object index) -- hits are bit-identical.
+// MEASURED (round 3, profiles/r03_coop_triangles_ab.txt) and NOT the default: Domino 47.8 -> 46.6 ms with 12 resident waves per CU (-2.5 %), but 44.2 ->
+// 46.0 ms with 16 (+4 %), the 522 k-triangle mesh room 16.1 -> 17.9 ms and the Cornell scenes +15 .. +30 % (boxes 4.62 -> 5.32 ms, rough conductor
+// 7.49 -> 9.32): the state a lane carries through the uniform loop (object, shape cursor, object-space ray) costs registers in kernels that sit
+// at their VGPR cap, and the round trips through ds_bpermute cost more than the idle lanes of a 12-triangle loop.  make variant DEFS=-DDTOF_COOP=1 builds it.
+#ifndef DTOF_COOP
+#define DTOF_COOP 0
+#endif
+struct TriBest { float t, u, v; uint32_t prim, face; };
+template <int CTRL> DTOF_D uint32_t dpp_u32(uint32_t x) { return (uint32_t) __builtin_amdgcn_update_dpp((int) x, (int) x, CTRL, 0xf, 0xf, false); }
+template <int CTRL> DTOF_D void tri_best_exchange(TriBest &b) {
+    const float ot = u2f(dpp_u32<CTRL>(f2u(b.t))), ou = u2f(dpp_u32<CTRL>(f2u(b.u))), ov = u2f(dpp_u32<CTRL>(f2u(b.v)));
+    const uint32_t op = dpp_u32<CTRL>(b.prim), of = dpp_u32<CTRL>(b.face);
+    const bool take = ot < b.t || (ot == b.t && of < b.face);
+    b.t = take ? ot : b.t; b.u = take ? ou : b.u; b.v = take ? ov : b.v; b.prim = take ? op : b.prim; b.face = take ? of : b.face;
+}
+DTOF_D float bperm_f(uint32_t lane, float x) { return u2f((uint32_t) __builtin_amdgcn_ds_bpermute((int) (lane << 2), (int) f2u(x))); }
+DTOF_D uint32_t bperm_u(uint32_t lane, uint32_t x) { return (uint32_t) __builtin_amdgcn_ds_bpermute((int) (lane << 2), (int) x); }
+// Called by ALL 64 lanes of a wave (uniform control flow, full exec mask).  has_job lanes own a (ray, small mesh) pair: lo / ld / maxt, the mesh's
+// triangles [tri_base, tri_base + n_tris).  Returns to every owner whether a triangle was hit and (closest hit) the mesh's winner.
+template <bool ANY>
+DTOF_D bool coop_small_meshes(const SceneView &sv, bool full_wave, bool has_job, V3 lo, V3 ld, float maxt, uint32_t tri_base, uint32_t n_tris, TriBest &win) {
+    __shared__ uint32_t s_owner[16][32];   // per wave of the block: lane of the job with rank r
+    const uint64_t jobs = __ballot(has_job);
+    const uint32_t n = (uint32_t) __popcll(jobs), lane = __lane_id(), wave = threadIdx.x >> 6;
+    win.t = INFINITY; win.u = win.v = 0.f; win.prim = 0; win.face = 0xffffffffu;
+    if (n > 32 || !full_wave) {   // (uniform) more jobs than half the wave, or lanes of the wave have left the kernel: nothing to share out, every owner loops over its own triangles
+        bool hit = false;
+        if (has_job) for (uint32_t f = 0; f < n_tris; ++f) {
+            float t, u, v; uint32_t face;
+            DTOF_STAT(6);
+            if (!tri_hit(sv.tris[tri_base + f], lo, ld, maxt, t, u, v, face)) continue;
+            hit = true;
+            if (ANY) break;
+            if (t < win.t || (t == win.t && face < win.face)) { win.t = t; win.u = u; win.v = v; win.prim = f; win.face = face; }
+        }
+        return hit;
+    }
+    const uint32_t gl = n <= 8 ? 3u : n <= 16 ? 2u : 1u, g = 1u << gl;   // lanes per job (uniform)
+    const uint32_t rank = (uint32_t) __popcll(jobs & ((1ull << lane) - 1ull));
+    if (has_job) s_owner[wave][rank] = lane;
+    __builtin_amdgcn_wave_barrier();   // LDS operations of a wave execute in order: the reads below see the writes above
+    const uint32_t jr = lane >> gl, sub = lane & (g - 1u);
+    const bool helper = jr < n;
+    const uint32_t owner = s_owner[wave][helper ? jr : 0u];
+    // the job's ray and triangle range, pulled from its owner (8 ds_bpermute; every lane takes part, helpers of no job read lane 0's values and ignore them)
+    const V3 jo = mk(bperm_f(owner, lo.x), bperm_f(owner, lo.y), bperm_f(owner, lo.z)), jd = mk(bperm_f(owner, ld.x), bperm_f(owner, ld.y), bperm_f(owner, ld.z));
+    const float jmaxt = bperm_f(owner, maxt);
+    const uint32_t jrange = bperm_u(owner, (tri_base << 5) | n_tris), jbase = jrange >> 5, jn = jrange & 31u;
+    TriBest b; b.t = INFINITY; b.u = b.v = 0.f; b.prim = 0; b.face = 0xffffffffu;
+    bool any_hit = false;
+    if (helper) for (uint32_t f = sub; f < jn; f += g) {
+        float t, u, v; uint32_t face;
+        DTOF_STAT(6);
+        if (!tri_hit(sv.tris[jbase + f], jo, jd, jmaxt, t, u, v, face)) continue;
+        any_hit = true;
+        if (ANY) break;
+        if (t < b.t || (t == b.t && face < b.face)) { b.t = t; b.u = u; b.v = v; b.prim = f; b.face = face; }
+    }
+    if (ANY) {   // one ballot: an owner is occluded if any lane of its group found a hit
+        const uint64_t hits = __ballot(any_hit);
+        return has_job && ((hits >> (rank << gl)) & ((1ull << g) - 1ull)) != 0;
+    }
+    // group reduction, all lanes (the groups are g adjacent lanes, g | 8): xor 1 and xor 2 inside a quad, then the two quads of a half row
+    tri_best_exchange<0xb1>(b);                 // quad_perm [1, 0, 3, 2]
+    if (gl >= 2) tri_best_exchange<0x4e>(b);    // quad_perm [2, 3, 0, 1]
+    if (gl >= 3) tri_best_exchange<0x141>(b);   // row_half_mirror: lane i <-> 7 - i of its half row (every quad already holds its own winner)
+    const uint32_t src = has_job ? rank << gl : 0u;
+    win.t = bperm_f(src, b.t); win.u = bperm_f(src, b.u); win.v = bperm_f(src, b.v); win.prim = bperm_u(src, b.prim); win.face = bperm_u(src, b.face);
+    return has_job && win.t < INFINITY;
+}
+
+// trace_scene for the instantiations with triangle code, as one wave-uniform loop (see above).  `active`: this lane has a ray to trace; the
+// others only help.  Must be called by all 64 lanes of the wave together (no divergent call sites).
+template <bool ANY, bool MEMO = false, bool SOA = false>
+DTOF_D bool trace_scene_coop(const SceneView &sv, uint32_t *stack, bool active, V3 o, V3 d, float time, float maxt, Hit &best) {
+    best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
+    const V3 id = mk(__builtin_amdgcn_rcpf(d.x == 0.f ? 1e-30f : d.x), __builtin_amdgcn_rcpf(d.y == 0.f ? 1e-30f : d.y), __builtin_amdgcn_rcpf(d.z == 0.f ? 1e-30f : d.z));
+    constexpr uint32_t kDone = 0x7fffffffu;
+    const uint32_t stride = blockDim.x;
+    int sp = 0; uint32_t cur = 0;
+    bool done = !active || sv.n_nodes == 0, occluded = false;
+    const bool full_wave = __ballot(true) == ~0ull;   // the cross-lane operations of the shared triangle loops need every lane of the wave
+    // the object the lane is inside of: its shapes [first, first + count), the next one to look at (k), the ray in its space, `found` of intersect_object
+    bool in_obj = false, found = false; uint32_t oi = 0, first = 0, count = 0, k = 0; V3 lo = o, ld = d;
+    if (!done) DTOF_STAT(0);
+    while (__ballot(!done)) {
+        if (!done && !in_obj) {
+            while (!(cur & kLeafFlag) && cur != kDone) {
+                DTOF_STAT(1); DTOF_STAT_WAVE(2);
+                cur = node_step<SOA>(sv.nodes, cur, o, id, best.t, stack, sp, 0, stride, kDone);
+            }
+            if (cur == kDone) done = true;
+            else {   // enter the object (intersect_object's head)
+                DTOF_STAT(3); DTOF_STAT_WAVE(4);
+                oi = cur & ~kLeafFlag;
+                const DObject &ob = sv.objects[oi];
+                first = ob.index; count = 1; lo = o; ld = d;
+                if (ob.kind == OBJ_INSTANCE) {
+                    float m[12], inv[12];
+                    if (MEMO && oi == sv.memo_obj) instance_memo_load(sv, inv);
+                    else { instance_matrix(ob, time, m); affine_inverse(m, inv); }
+                    lo = xf_point(inv, o); ld = xf_vector(inv, d);
+                    const DGroup &g = sv.groups[ob.index];
+                    first = g.first_shape; count = g.n_shapes;
+                }
+                k = 0; found = false; in_obj = true;
+            }
+        }
+        // the shapes of the object, up to (and including) the next small mesh whose bounds the ray enters: that one becomes the lane's job
+        bool has_job = false; uint32_t job_k = 0, tri_base = 0, n_tris = 0;
+        if (!done && in_obj) {
+            while (k < count && !has_job && !done) {
+                const DShape &sh = sv.shapes[first + k];
+                const uint32_t kk = k++;
+                float t, u, v; bool hit = false;
+                if (sh.kind == SHAPE_RECT) hit = rect_hit(sh, lo, ld, maxt, t, u, v);
+                else if (sh.kind == SHAPE_DISK) hit = disk_hit(sh, lo, ld, maxt, t, u, v);
+                else if (sh.kind == SHAPE_CYLINDER) { hit = cylinder_hit(sh, lo, ld, maxt, t); u = v = 0.f; }
+                else if (sh.kind == SHAPE_SPHERE) { hit = sphere_hit<ANY>(sh, lo, ld, maxt, t); u = v = 0.f; }
+                else {
+                    const V3 lid = mk(__builtin_amdgcn_rcpf(ld.x == 0.f ? 1e-30f : ld.x), __builtin_amdgcn_rcpf(ld.y == 0.f ? 1e-30f : ld.y), __builtin_amdgcn_rcpf(ld.z == 0.f ? 1e-30f : ld.z));
+                    if (!(box_entry(sh.bmin, sh.bmax, lo, lid, ANY ? maxt : best.t) < INFINITY)) continue;
+                    DTOF_STAT(5);
+                    if (sh.blas_root == kNoChild && sh.n_tris < 32u) { has_job = true; job_k = kk; tri_base = sh.first_tri; n_tris = sh.n_tris; continue; }
+                    // a mesh behind its own BLAS (or, with DTOF_BLAS=0, a long triangle list): per-lane traversal, as in intersect_object
+                    uint32_t best_face = 0xffffffffu;
+                    auto test = [&](uint32_t f) -> bool {
+                        uint32_t face;
+                        DTOF_STAT(6);
+                        if (!tri_hit(sv.tris[sh.first_tri + f], lo, ld, maxt, t, u, v, face)) return false;
+                        if (ANY) return true;
+                        bool take = t < best.t;
+                        if (t == best.t) take = best_face != 0xffffffffu ? face < best_face : (!found && best.obj != 0xffffffffu && oi < best.obj);
+                        if (take) { best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = kk; best.prim = f; best_face = face; found = true; }
+                        return false;
+                    };
+                    if (sh.blas_root == kNoChild) {
+                        for (uint32_t f = 0; f < sh.n_tris; ++f) if (test(f)) { occluded = true; done = true; break; }
+                        continue;
+                    }
+                    uint32_t bcur = sh.blas_root; int bsp = sp;
+                    for (;;) {
+                        while (!(bcur & kLeafFlag) && bcur != kDone) {
+                            DTOF_STAT(7);
+                            bcur = node_step(sv.nodes, bcur, lo, lid, ANY ? maxt : best.t, stack, bsp, sp, stride, kDone);
+                        }
+                        if (bcur == kDone) break;
+                        const uint32_t f0 = (bcur & ~kLeafFlag) >> kBlasLeafBits, fn = (bcur & ((1u << kBlasLeafBits) - 1u)) + 1u;
+                        bool any = false;
+                        for (uint32_t f = f0; f < f0 + fn; ++f) if (test(f)) { any = true; break; }
+                        if (any) { occluded = true; done = true; break; }
+                        if (bsp == sp) break;
+                        --bsp; bcur = stack[bsp * stride];
+                    }
+                    continue;
+                }
+                if (hit) {
+                    if (ANY) { occluded = true; done = true; }
+                    else if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
+                        best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = kk; best.prim = 0; found = true;
+                    }
+                }
+            }
+        }
+        if (__ballot(has_job)) {   // (uniform) the triangle loops of this round, shared out over the wave
+            TriBest w;
+            const bool hit = coop_small_meshes<ANY>(sv, full_wave, has_job, lo, ld, maxt, tri_base, n_tris, w);
+            if (hit) {
+                if (ANY) { occluded = true; done = true; }
+                else if (w.t < best.t || (w.t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
+                    best.t = w.t; best.u = w.u; best.v = w.v; best.obj = oi; best.shape = job_k; best.prim = w.prim; found = true;
+                }
+            }
+        }
+        if (!done && in_obj && k >= count) {   // leave the object: back to the TLAS
+            in_obj = false;
+            if (sp == 0) done = true; else { --sp; cur = stack[sp * stride]; }
+        }
+    }
+    return ANY ? occluded : best.obj != 0xffffffffu;
+}
+
+// Scene query of a kernel: the shared-loop traversal for the instantiations with triangle code, the per-lane one otherwise.  Call sites are
+// wave-uniform; `active` says whether this lane has a ray.
+template <bool ANY, bool MESH, bool MEMO = false, bool SOA = false>
+DTOF_D bool trace_rays(const SceneView &sv, uint32_t *stack, bool active, V3 o, V3 d, float time, float maxt, Hit &best) {
+#if DTOF_COOP
+    if (MESH) return trace_scene_coop<ANY, MEMO, SOA>(sv, stack, active, o, d, time, maxt, best);
+#endif
+    bool r = false;
+    if (active) r = trace_scene<ANY, MESH, MEMO, SOA>(sv, stack, o, d, time, maxt, best);
+    return r;
+}
+
+
+// Rectangle-only scenes of a handful of top-level objects (the five walls of the Cornell room of C2): no TLAS walk.  Every lane tests
+// every object in index order -- a loop whose trip count and addresses are wave-uniform, so the object and shape records come in by
+// SCALAR loads from the blob in global memory (constant address space; the copy staged in LDS serves the per-lane reads of
+// compute_surface) and their matrix entries are SGPR operands of the lane arithmetic.  No stack, no divergence: for <= 8 rectangles the
+// ~40 instructions per rectangle cost less than the ~55 per node step + ~60 per leaf visit of the binary tree at 0.5 lane utilisation.
+// Hits are those of trace_scene bit for bit: same rect_hit arithmetic, smallest t wins, ties go to the lowest object index
+// (ascending order + strict <).  Instances take intersect_object (one uniform branch).
+typedef const uint8_t __attribute__((address_space(4))) *ConstBytes;
+// DTOF_FLAT_PK=1: the rectangle transform of trace_flat as packed multiply-adds (v_pk_fma_f32 with the matrix entries as SGPR-pair operands: two
+// multiply-adds in the 4 cycles ONE scalar-operand v_fma_f32 takes, profiles/r03_ubench_valu_rate.txt).  Bit-exact; measured on C2: 3 % fewer VALU
+// instructions but the pairs cost registers in a kernel at its cap -- spill loads / stores per wave 157 -> 580, frame 1.53 -> 1.65 ms
+// (profiles/r03_flat_packed_ab.txt).  Off.
+#ifndef DTOF_FLAT_PK
+#define DTOF_FLAT_PK 0
+#endif
+typedef float F2 __attribute__((ext_vector_type(2)));
+struct FlatRecord { uint32_t instance; F2 c0, c1, c2, c3; float z0, z1, z2, z3; };   // (x, y) entries of the four columns as pairs, the z row apart
+DTOF_D FlatRecord flat_load(const DFlatObject __attribute__((address_space(4))) *f) {
+    FlatRecord r; r.instance = f->instance;
+    r.c0 = F2{ f->c0[0], f->c0[1] }; r.c1 = F2{ f->c1[0], f->c1[1] }; r.c2 = F2{ f->c2[0], f->c2[1] }; r.c3 = F2{ f->c3[0], f->c3[1] };
+    r.z0 = f->c0[2]; r.z1 = f->c1[2]; r.z2 = f->c2[2]; r.z3 = f->c3[2];
+    return r;
+}
+template <bool ANY, bool MEMO>
+DTOF_D bool trace_flat(const SceneView &sv, ConstBytes flat_table, uint32_t n_objects, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best) {
+    typedef const DFlatObject __attribute__((address_space(4))) *ConstFlat;
+    const ConstFlat table = (ConstFlat) flat_table;
+    best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
+    bool occluded = false;
+    DTOF_STAT(0);
+    auto test = [&](const FlatRecord &rec, uint32_t oi) {   // rect_hit on a plain rectangle's record
+        V3 ro = o, rd = d;
+        if (rec.instance == 2) {   // (uniform) the one memoised instance: into its space first, as intersect_object does (instance.cpp:101-114)
+            float inv[12]; instance_memo_load(sv, inv);
+            ro = xf_point(inv, o); rd = xf_vector(inv, d);
+        }
+        // xf_point / xf_vector with the matrix entries as scalar operands, two multiply-adds per instruction: the x and y rows of the point as one pair,
+        // those of the direction as another, the z rows of point AND direction as the third (same entries, different vectors).  Each half is the IEEE
+        // operation of the scalar form, in its order; the direction's leading product becomes fma(m, d, -0), which equals m * d for every input.
+#if DTOF_FLAT_PK
+        const F2 lo_xy = __builtin_elementwise_fma(rec.c2, F2{ ro.z, ro.z }, __builtin_elementwise_fma(rec.c1, F2{ ro.y, ro.y }, __builtin_elementwise_fma(rec.c0, F2{ ro.x, ro.x }, rec.c3)));
+        const F2 ld_xy = __builtin_elementwise_fma(rec.c2, F2{ rd.z, rd.z }, __builtin_elementwise_fma(rec.c1, F2{ rd.y, rd.y }, rec.c0 * F2{ rd.x, rd.x }));
+        const F2 z = __builtin_elementwise_fma(F2{ rec.z2, rec.z2 }, F2{ ro.z, rd.z }, __builtin_elementwise_fma(F2{ rec.z1, rec.z1 }, F2{ ro.y, rd.y },
+                                               __builtin_elementwise_fma(F2{ rec.z0, rec.z0 }, F2{ ro.x, rd.x }, F2{ rec.z3, -0.f })));
+#else   // the scalar form (one multiply-add per instruction, matrix entries as SGPR operands: 4 cycles each), kept for A/B timing
+        const F2 lo_xy = F2{ fmaf(rec.c2.x, ro.z, fmaf(rec.c1.x, ro.y, fmaf(rec.c0.x, ro.x, rec.c3.x))), fmaf(rec.c2.y, ro.z, fmaf(rec.c1.y, ro.y, fmaf(rec.c0.y, ro.x, rec.c3.y))) };
+        const F2 ld_xy = F2{ fmaf(rec.c2.x, rd.z, fmaf(rec.c1.x, rd.y, rec.c0.x * rd.x)), fmaf(rec.c2.y, rd.z, fmaf(rec.c1.y, rd.y, rec.c0.y * rd.x)) };
+        const F2 z = F2{ fmaf(rec.z2, ro.z, fmaf(rec.z1, ro.y, fmaf(rec.z0, ro.x, rec.z3))), fmaf(rec.z2, rd.z, fmaf(rec.z1, rd.y, rec.z0 * rd.x)) };
+#endif
+        const float t = -z.x / z.y;
+        const float u = fmaf(ld_xy.x, t, lo_xy.x), v = fmaf(ld_xy.y, t, lo_xy.y);
+        // no short-circuit: four compares and three mask ANDs instead of three exec-mask branches per rectangle (the scalar unit is as busy as the vector units here)
+        const bool hit = (int) (t >= 0.f) & (int) (t <= maxt) & (int) (fabsf(u) <= 1.f) & (int) (fabsf(v) <= 1.f);
+        if (ANY) occluded |= hit;
+        else {
+            const bool take = (int) hit & (int) (t < best.t);
+            best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v; best.obj = take ? oi : best.obj; best.shape = take ? 0u : best.shape;
+        }
+    };
+    // Two record buffers take turns (the loop is unrolled by two), so the next record's scalar load flies while the current one is tested
+    // and no register is copied from one iteration to the next.  Instances are noted in a mask and intersected after the rectangles: the
+    // tie rule of intersect_object (equal t goes to the lower object index) does not depend on the order of the visits.
+    uint32_t instances = 0, oi = 0;
+    FlatRecord a = flat_load(table);
+    for (;;) {
+        FlatRecord b;
+        const bool more_b = oi + 1 < n_objects;
+        if (more_b) b = flat_load(table + oi + 1);
+        if (a.instance == 1 || (a.instance == 2 && !(MEMO && sv.memo_obj == oi))) instances |= 1u << oi; else test(a, oi);
+        if (!more_b) break;
+        ++oi;
+        const bool more_a = oi + 1 < n_objects;
+        if (more_a) a = flat_load(table + oi + 1);
+        if (b.instance == 1 || (b.instance == 2 && !(MEMO && sv.memo_obj == oi))) instances |= 1u << oi; else test(b, oi);
+        if (!more_a) break;
+        ++oi;
+    }
+    while (instances) {   // uniform
+        const uint32_t k = (uint32_t) __builtin_ctz(instances); instances &= instances - 1u;
+        const bool hit = intersect_object<ANY, false, MEMO>(sv, k, o, d, time, maxt, best, stack, 0, blockDim.x);
+        if (ANY) occluded |= hit;
+    }
+    return ANY ? occluded : best.obj != 0xffffffffu;
+}
+
+}  // namespace dtof
