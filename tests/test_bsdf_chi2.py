@@ -1,0 +1,88 @@
+"""The reference's chi^2 tests of its BSDFs, restated on the oracle (CPU): src/bsdfs/tests/test_diffuse.py (test02_chi2), test_roughconductor.py
+(test0x_chi2_* : isotropic / anisotropic, Beckmann / GGX), test_roughplastic.py, test_roughdielectric.py (reflection + transmission: the whole sphere),
+test_twosided.py and test_blendbsdf.py (their chi2 cases).  The reference's harness (python/mitsuba/python/chi2.py: ChiSquareTest over a SphericalDomain
+with a BSDFAdapter) histograms the directions BSDF::sample returns over (cos theta, phi) cells and compares the counts with BSDF::pdf integrated over each
+cell; cells with few expected samples are pooled and the p-value of the chi^2 statistic must exceed the significance level.  Here the same is done with
+numpy / scipy on `orc_kat_bsdf` (eval / pdf / sample of one shape's BSDF chain: mask -> blend -> frame -> nested BSDF).  The GPU kernels are held to the
+oracle bit for bit (test_gpu_parity.py), so this pins both."""
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy import stats
+
+SCENE = '<scene version="3.0.0"><shape type="rectangle">%s</shape></scene>'
+DIFFUSE = '<bsdf type="diffuse"><rgb name="reflectance" value="0.2, 0.5, 0.8"/></bsdf>'
+CASES = {
+    "diffuse": DIFFUSE,
+    "roughconductor_beckmann": '<bsdf type="roughconductor"><float name="alpha" value="0.3"/><string name="distribution" value="beckmann"/></bsdf>',
+    "roughconductor_ggx": '<bsdf type="roughconductor"><float name="alpha" value="0.3"/><string name="distribution" value="ggx"/></bsdf>',
+    "roughconductor_aniso_ggx": '<bsdf type="roughconductor"><float name="alpha_u" value="0.2"/><float name="alpha_v" value="0.5"/><string name="distribution" value="ggx"/></bsdf>',
+    "roughconductor_all_normals": '<bsdf type="roughconductor"><float name="alpha" value="0.4"/><boolean name="sample_visible" value="false"/></bsdf>',
+    "roughplastic": '<bsdf type="roughplastic"><float name="alpha" value="0.25"/><rgb name="diffuse_reflectance" value="0.5"/></bsdf>',
+    "roughdielectric_beckmann": '<bsdf type="roughdielectric"><float name="alpha" value="0.3"/><string name="distribution" value="beckmann"/></bsdf>',
+    "roughdielectric_ggx": '<bsdf type="roughdielectric"><float name="alpha" value="0.4"/><string name="distribution" value="ggx"/></bsdf>',
+    "twosided_from_behind": '<bsdf type="twosided">%s</bsdf>' % DIFFUSE,
+    "blendbsdf": '<bsdf type="blendbsdf"><float name="weight" value="0.4"/>%s<bsdf type="roughconductor"><float name="alpha" value="0.3"/></bsdf></bsdf>' % DIFFUSE,
+}
+RES_C, RES_P, SUB = 20, 40, 16         # cells over cos theta in [-1, 1] and phi in [0, 2 pi); pdf quadrature points per cell and axis
+N = 60000
+
+
+def _bsdf(L, shape, wi, wo, s3):
+    out = np.zeros(13, np.float32)
+    L.orc_kat_bsdf(C.byref(shape), wi.ctypes.data, wo.ctypes.data, s3.ctypes.data, out.ctypes.data)
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("theta_i", [20.0, 65.0])
+def test_sampled_directions_follow_the_pdf(orc, name, theta_i):
+    L = orc.lib()
+    osc = orc.Scene(SCENE % CASES[name], {}, is_string=True)
+    shape = osc.c.shapes[0]
+    t = np.radians(theta_i)
+    wi = np.float32([np.sin(t) * np.cos(0.7), np.sin(t) * np.sin(0.7), np.cos(t)])
+    if name == "twosided_from_behind":
+        wi[2] = -wi[2]
+    rng = np.random.default_rng(int(theta_i) + len(name))
+    # histogram of BSDF::sample (samples of zero density -- failed draws -- land nowhere, as in the reference's adapter, whose weights are then zero)
+    hist = np.zeros((RES_C, RES_P))
+    dummy = np.float32([0, 0, 1])
+    for s3 in rng.random((N, 3)).astype(np.float32):
+        out = _bsdf(L, shape, wi, dummy, s3)
+        if out[7] <= 0 or out[9] != 0 or not out[10:13].any():      # chi2.py's BSDFAdapter: a sample whose weight is zero counts for nothing (a direction below the horizon)
+            continue
+        wo = out[4:7].astype(np.float64)
+        ci = min(int((wo[2] * 0.5 + 0.5) * RES_C), RES_C - 1)
+        pi_ = min(int((np.arctan2(wo[1], wo[0]) % (2 * np.pi)) / (2 * np.pi) * RES_P), RES_P - 1)
+        hist[ci, pi_] += 1
+    # BSDF::pdf integrated over every cell (midpoint rule, SUB x SUB points; d omega = d cos theta d phi)
+    expected = np.zeros((RES_C, RES_P))
+    zero3 = np.float32([0.5, 0.5, 0.5])
+    for ci in range(RES_C):
+        for pi_ in range(RES_P):
+            acc = 0.0
+            for a in range(SUB):
+                c = -1 + 2 * (ci + (a + 0.5) / SUB) / RES_C
+                s_ = np.sqrt(max(0.0, 1 - c * c))
+                for b in range(SUB):
+                    p = 2 * np.pi * (pi_ + (b + 0.5) / SUB) / RES_P
+                    acc += _bsdf(L, shape, wi, np.float32([s_ * np.cos(p), s_ * np.sin(p), c]), zero3)[3]
+            expected[ci, pi_] = acc / (SUB * SUB) * (2.0 / RES_C) * (2 * np.pi / RES_P) * N
+    assert 0.3 * N < expected.sum() < 1.02 * N, (name, expected.sum() / N)        # a density (failed draws may take a share)
+    assert abs(hist.sum() - expected.sum()) < 0.02 * N, (name, hist.sum(), expected.sum())
+    # chi^2 with pooling of the cells that expect fewer than five samples (chi2.py: `chi2` of mitsuba.math, pooling threshold 5)
+    order = np.argsort(expected, axis=None)
+    e, o = expected.flatten()[order], hist.flatten()[order]
+    pooled_e, pooled_o, stat, dof = 0.0, 0.0, 0.0, 0
+    for ev, ov in zip(e, o):
+        if ev < 5:                     # (cells the quadrature sees as empty included: a sample on the edge of the support)
+            pooled_e += ev; pooled_o += ov
+            continue
+        stat += (ov - ev) ** 2 / ev; dof += 1
+    if pooled_e > 0:
+        stat += (pooled_o - pooled_e) ** 2 / pooled_e; dof += 1
+    p_value = stats.chi2.sf(stat, dof - 1)
+    # the reference's significance level is 0.01 with a Sidak correction over the tests of a run; 20 cases here
+    assert p_value > 1 - (1 - 0.01) ** (1 / 20.0), (name, theta_i, stat, dof, p_value)
