@@ -86,3 +86,59 @@ def test_sampled_directions_follow_the_pdf(orc, name, theta_i):
     p_value = stats.chi2.sf(stat, dof - 1)
     # the reference's significance level is 0.01 with a Sidak correction over the tests of a run; 20 cases here
     assert p_value > 1 - (1 - 0.01) ** (1 / 20.0), (name, theta_i, stat, dof, p_value)
+
+
+# ------------------------------------------------------------------------------------------------ src/core/tests/test_warp.py: the chi^2 tests of the warps on the path
+def _chi2(hist, expected, n_tests):
+    order = np.argsort(expected, axis=None)
+    e, o = expected.flatten()[order], hist.flatten()[order]
+    pooled_e = pooled_o = stat = 0.0
+    dof = 0
+    for ev, ov in zip(e, o):
+        if ev < 5:
+            pooled_e += ev; pooled_o += ov
+            continue
+        stat += (ov - ev) ** 2 / ev; dof += 1
+    if pooled_e > 0:
+        stat += (pooled_o - pooled_e) ** 2 / pooled_e; dof += 1
+    return stats.chi2.sf(stat, dof - 1) > 1 - (1 - 0.01) ** (1.0 / n_tests), stat, dof
+
+
+@pytest.mark.parametrize("warp", ["cosine_hemisphere", "uniform_disk_concentric", "uniform_sphere", "uniform_triangle"])
+def test_warps_follow_their_densities(orc, warp):
+    """test_warp.py (test_square_to_cosine_hemisphere / _uniform_disk_concentric / _uniform_sphere / _uniform_triangle, the `check_warp_vectorization` +
+    ChiSquareTest cases): the warped unit square against the closed-form densities of warp.h -- cos theta / pi, 1 / pi inside the unit disk, 1 / (4 pi), 2 inside
+    the triangle u + v <= 1"""
+    L = orc.lib()
+    fn = {"cosine_hemisphere": 0, "uniform_disk_concentric": 1, "uniform_sphere": 2, "uniform_triangle": 3}[warp]
+    n, res, sub = 100000, 24, 8
+    rng = np.random.default_rng(fn + 3)
+    out = np.zeros(3, np.float32)
+    hist = np.zeros((res, 2 * res if fn in (0, 2) else res))
+    for u in rng.random((n, 2)).astype(np.float32):
+        L.orc_kat_warp(fn, u.ctypes.data, out.ctypes.data)
+        if fn in (0, 2):                                   # spherical domain: (cos theta, phi)
+            a = min(int((out[2] * 0.5 + 0.5) * res), res - 1)
+            b = min(int((np.arctan2(out[1], out[0]) % (2 * np.pi)) / (2 * np.pi) * 2 * res), 2 * res - 1)
+        elif fn == 1:                                      # planar domain [-1, 1]^2
+            a, b = min(int((out[1] * 0.5 + 0.5) * res), res - 1), min(int((out[0] * 0.5 + 0.5) * res), res - 1)
+        else:                                              # planar domain [0, 1]^2
+            a, b = min(int(out[1] * res), res - 1), min(int(out[0] * res), res - 1)
+        hist[a, b] += 1
+    expected = np.zeros_like(hist)
+    t = (np.arange(sub) + 0.5) / sub
+    for a in range(hist.shape[0]):
+        for b in range(hist.shape[1]):
+            if fn in (0, 2):
+                c = -1 + 2 * (a + t) / res
+                pdf = np.where(c > 0, c / np.pi, 0.0).mean() if fn == 0 else 1 / (4 * np.pi)
+                expected[a, b] = pdf * (2.0 / res) * (2 * np.pi / (2 * res)) * n
+            elif fn == 1:
+                y, x = np.meshgrid(-1 + 2 * (a + t) / res, -1 + 2 * (b + t) / res, indexing="ij")
+                expected[a, b] = ((x * x + y * y <= 1) / np.pi).mean() * (2.0 / res) ** 2 * n
+            else:
+                y, x = np.meshgrid((a + t) / res, (b + t) / res, indexing="ij")
+                expected[a, b] = ((x + y <= 1) * 2.0).mean() * (1.0 / res) ** 2 * n
+    assert abs(expected.sum() - n) < 0.01 * n and hist.sum() == n
+    ok, stat, dof = _chi2(hist, expected, 4)
+    assert ok, (warp, stat, dof)
