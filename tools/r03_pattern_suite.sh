@@ -1,5 +1,5 @@
 #!/bin/bash
-# the whole GPU suite against a build of dtof_kernels.hip with -ftrivial-auto-var-init=pattern (var_k4/libdtof_pattern.so, not in the tree): every automatic variable
+# the whole GPU suite against a build of dtof_kernels.hip with -ftrivial-auto-var-init=pattern (var_k4/libdtof_pattern.so: tools/build_pattern_variant.sh): every automatic variable
 # without an initialiser starts as 0xAA.. / NaN, so any result that depends on one shows
 set -u
 root=$(pwd); out=$root/gpurun_out; mkdir -p $out; export TMPDIR=/tmp
