@@ -151,8 +151,11 @@ template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, int SPEC, int RESW
 // History of the every-BSDF kernels (SPEC) with four offset films (KMAX == 4): at three waves per SIMD (168 VGPRs, 240 - 390 spilled registers) their fused instantiations
 // produced wrong films on scenes of the random sweep whenever the kernel grew, while the K = 1 kernels, the split pipeline and the same source at two waves stayed exact.
 // The cause was not the spill code: the films depended on the INITIAL value of the path-state registers declared without one (`main` / `path` below; right with
-// -ftrivial-auto-var-init=zero, NaN with =pattern, profiles/r03_k4_uninitialised.txt).  They are initialised now, and these instantiations run at three waves again.
-__global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : (MODE != 0 && MESH) ? DTOF_MESH_WAVES : 1) void k_shade(ShadeArgs args_by_value) {
+// -ftrivial-auto-var-init=zero, NaN with =pattern, profiles/r03_k4_uninitialised.txt).  They are initialised now, and both wave counts are correct (sweeps of 240 .. 1 200
+// scenes each).  Two waves stay for these instantiations because they are FASTER there: with four films in registers the 168-VGPR build spills 240 - 390 registers, and
+// the K = 4 frames of the every-BSDF scenes take 1 - 10 % longer at three waves (cornell_specular 9.13 -> 9.60 ms, cornell_spot 7.80 -> 8.58; profiles/r03_k4_waves_ab.txt)
+// -- the opposite of the K = 1 kernels, which lose 20 - 27 % at two (profiles/r03_spec_waves_ab.txt).
+__global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : (MODE != 0 && MESH) ? ((SPEC && KMAX > 1) ? 2 : DTOF_MESH_WAVES) : 1) void k_shade(ShadeArgs args_by_value) {
     constexpr bool FUSED = MODE != 0, FIRST = MODE == 2;
     static_assert(RESW == 0 || (MODE == 2 && !LDS && MESH), "the resident stage exists for the unstaged fused first-bounce kernel with mesh code");
     extern __shared__ uint4 lds[];
