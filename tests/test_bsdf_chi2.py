@@ -104,41 +104,64 @@ def _chi2(hist, expected, n_tests):
     return stats.chi2.sf(stat, dof - 1) > 1 - (1 - 0.01) ** (1.0 / n_tests), stat, dof
 
 
-@pytest.mark.parametrize("warp", ["cosine_hemisphere", "uniform_disk_concentric", "uniform_sphere", "uniform_triangle"])
-def test_warps_follow_their_densities(orc, warp):
-    """test_warp.py (test_square_to_cosine_hemisphere / _uniform_disk_concentric / _uniform_sphere / _uniform_triangle, the `check_warp_vectorization` +
-    ChiSquareTest cases): the warped unit square against the closed-form densities of warp.h -- cos theta / pi, 1 / pi inside the unit disk, 1 / (4 pi), 2 inside
-    the triangle u + v <= 1"""
-    L = orc.lib()
-    fn = {"cosine_hemisphere": 0, "uniform_disk_concentric": 1, "uniform_sphere": 2, "uniform_triangle": 3}[warp]
-    n, res, sub = 100000, 24, 8
-    rng = np.random.default_rng(fn + 3)
-    out = np.zeros(3, np.float32)
-    hist = np.zeros((res, 2 * res if fn in (0, 2) else res))
-    for u in rng.random((n, 2)).astype(np.float32):
-        L.orc_kat_warp(fn, u.ctypes.data, out.ctypes.data)
-        if fn in (0, 2):                                   # spherical domain: (cos theta, phi)
-            a = min(int((out[2] * 0.5 + 0.5) * res), res - 1)
-            b = min(int((np.arctan2(out[1], out[0]) % (2 * np.pi)) / (2 * np.pi) * 2 * res), 2 * res - 1)
-        elif fn == 1:                                      # planar domain [-1, 1]^2
-            a, b = min(int((out[1] * 0.5 + 0.5) * res), res - 1), min(int((out[0] * 0.5 + 0.5) * res), res - 1)
-        else:                                              # planar domain [0, 1]^2
-            a, b = min(int(out[1] * res), res - 1), min(int(out[0] * res), res - 1)
-        hist[a, b] += 1
-    expected = np.zeros_like(hist)
-    t = (np.arange(sub) + 0.5) / sub
-    for a in range(hist.shape[0]):
-        for b in range(hist.shape[1]):
+WARPS = {"cosine_hemisphere": (0, "warp_cosine_hemisphere"), "uniform_disk_concentric": (1, "warp_disk_concentric"), "uniform_sphere": (2, "warp_uniform_sphere"),
+         "uniform_triangle": (3, "warp_uniform_triangle")}
+
+
+def _warp_chi2(warp, warped, n):
+    """histogram of the warped points against the closed-form densities of warp.h: cos theta / pi, 1 / pi inside the unit disk, 1 / (4 pi), 2 inside the triangle u + v <= 1"""
+    fn = WARPS[warp][0]
+    res, sub = 24, 8
+    w = np.asarray(warped, np.float64)
+    if fn in (0, 2):                                       # spherical domain: (cos theta, phi)
+        a = np.minimum(((w[:, 2] * 0.5 + 0.5) * res).astype(int), res - 1)
+        b = np.minimum(((np.arctan2(w[:, 1], w[:, 0]) % (2 * np.pi)) / (2 * np.pi) * 2 * res).astype(int), 2 * res - 1)
+        shape = (res, 2 * res)
+    elif fn == 1:                                          # planar domain [-1, 1]^2
+        a, b, shape = np.minimum(((w[:, 1] * 0.5 + 0.5) * res).astype(int), res - 1), np.minimum(((w[:, 0] * 0.5 + 0.5) * res).astype(int), res - 1), (res, res)
+    else:                                                  # planar domain [0, 1]^2
+        a, b, shape = np.minimum((w[:, 1] * res).astype(int), res - 1), np.minimum((w[:, 0] * res).astype(int), res - 1), (res, res)
+    hist = np.zeros(shape)
+    np.add.at(hist, (a, b), 1)
+    expected = np.zeros(shape)
+    t, t32 = (np.arange(sub) + 0.5) / sub, (np.arange(32) + 0.5) / 32
+    for a_ in range(shape[0]):
+        for b_ in range(shape[1]):
             if fn in (0, 2):
-                c = -1 + 2 * (a + t) / res
+                c = -1 + 2 * (a_ + t) / res
                 pdf = np.where(c > 0, c / np.pi, 0.0).mean() if fn == 0 else 1 / (4 * np.pi)
-                expected[a, b] = pdf * (2.0 / res) * (2 * np.pi / (2 * res)) * n
+                expected[a_, b_] = pdf * (2.0 / res) * (2 * np.pi / (2 * res)) * n
             elif fn == 1:
-                y, x = np.meshgrid(-1 + 2 * (a + t) / res, -1 + 2 * (b + t) / res, indexing="ij")
-                expected[a, b] = ((x * x + y * y <= 1) / np.pi).mean() * (2.0 / res) ** 2 * n
-            else:
-                y, x = np.meshgrid((a + t) / res, (b + t) / res, indexing="ij")
-                expected[a, b] = ((x + y <= 1) * 2.0).mean() * (1.0 / res) ** 2 * n
+                y, x = np.meshgrid(-1 + 2 * (a_ + t32) / res, -1 + 2 * (b_ + t32) / res, indexing="ij")      # the rim cuts cells: a finer rule there
+                expected[a_, b_] = ((x * x + y * y <= 1) / np.pi).mean() * (2.0 / res) ** 2 * n
+            else:                                          # cells below the diagonal are inside, the diagonal's cells half inside (exact)
+                inside = 1.0 if a_ + b_ < res - 1 else (0.5 if a_ + b_ == res - 1 else 0.0)
+                expected[a_, b_] = inside * 2.0 * (1.0 / res) ** 2 * n
     assert abs(expected.sum() - n) < 0.01 * n and hist.sum() == n
     ok, stat, dof = _chi2(hist, expected, 4)
     assert ok, (warp, stat, dof)
+
+
+@pytest.mark.parametrize("warp", sorted(WARPS))
+def test_warps_follow_their_densities(orc, warp):
+    """test_warp.py (test_square_to_cosine_hemisphere / _uniform_disk_concentric / _uniform_sphere / _uniform_triangle, the ChiSquareTest cases): the warped unit
+    square of the ORACLE's warps against the closed-form densities of warp.h"""
+    L = orc.lib()
+    n = 100000
+    rng = np.random.default_rng(WARPS[warp][0] + 3)
+    out = np.zeros((n, 3), np.float32)
+    for i, u in enumerate(rng.random((n, 2)).astype(np.float32)):
+        L.orc_kat_warp(WARPS[warp][0], u.ctypes.data, out[i].ctypes.data)
+    _warp_chi2(warp, out, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("warp", sorted(WARPS))
+def test_device_warps_follow_their_densities(mi, warp):
+    """the same chi^2 cases on the device functions the kernels are built from (dtof_eval_component), a million points each"""
+    n = 1000000
+    u = np.random.default_rng(WARPS[warp][0] + 11).random((n, 2)).astype(np.float32)
+    out = mi.eval_component(WARPS[warp][1], u)
+    if out.shape[1] == 2:
+        out = np.concatenate([out, np.zeros((n, 1), np.float32)], axis=1)
+    _warp_chi2(warp, out, n)
