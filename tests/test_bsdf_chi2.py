@@ -165,3 +165,37 @@ def test_device_warps_follow_their_densities(mi, warp):
     if out.shape[1] == 2:
         out = np.concatenate([out, np.zeros((n, 1), np.float32)], axis=1)
     _warp_chi2(warp, out, n)
+
+
+# ------------------------------------------------------------------------------------------------ src/render/tests/test_microfacet.py:288-309: the chi^2 tests of MicrofacetDistribution
+@pytest.mark.gpu
+@pytest.mark.parametrize("visible", [1, 0])
+@pytest.mark.parametrize("mf_type,alpha_u,alpha_v", [(0, 0.1, 0.1), (0, 0.6, 0.2), (1, 0.1, 0.1), (1, 0.25, 0.5)], ids=["beckmann", "beckmann_aniso", "ggx", "ggx_aniso"])
+@pytest.mark.parametrize("theta_i", [30.0, 80.0])
+def test_device_microfacet_normals_follow_their_density(mi, mf_type, alpha_u, alpha_v, visible, theta_i):
+    """test04_chi2_* / test05 of test_microfacet.py (MicrofacetAdapter: sample() of normals against pdf(), Beckmann / GGX, isotropic / anisotropic, all normals and
+    visible normals, steep and grazing incidence) on the device functions of the kernels: a million normals histogrammed over (theta, phi) of the upper hemisphere,
+    pdf integrated per cell (8 x 8 midpoints), pooling below 5"""
+    n, res_c, res_p, sub = 1000000, 32, 64, 8
+    params = [mf_type, alpha_u, alpha_v, visible]
+    t = np.radians(theta_i)
+    wi = np.float32([np.sin(t) * np.cos(0.4), np.sin(t) * np.sin(0.4), np.cos(t)])
+    u = np.random.default_rng(int(theta_i) + mf_type * 7 + visible).random((n, 2)).astype(np.float32)
+    out = mi.eval_component("microfacet_sample", np.concatenate([np.tile(wi, (n, 1)), u], axis=1), params)
+    m = out[:, :3].astype(np.float64)
+    ok = out[:, 3] > 0
+    a = np.minimum((np.arccos(np.clip(m[ok, 2], -1, 1)) / (np.pi / 2) * res_c).astype(int), res_c - 1)      # cells uniform in THETA: a lobe of alpha = 0.1 spans several
+    b = np.minimum(((np.arctan2(m[ok, 1], m[ok, 0]) % (2 * np.pi)) / (2 * np.pi) * res_p).astype(int), res_p - 1)
+    hist = np.zeros((res_c, res_p))
+    np.add.at(hist, (a, b), 1)
+    # pdf over every cell: all quadrature points in one call
+    tt = (np.arange(sub) + 0.5) / sub
+    th = ((np.arange(res_c)[:, None] + tt[None, :]) / res_c * (np.pi / 2)).reshape(-1)         # theta of the normal
+    p = (2 * np.pi * (np.arange(res_p)[:, None] + tt[None, :]) / res_p).reshape(-1)
+    tth, pp = np.meshgrid(th, p, indexing="ij")
+    pts = np.stack([np.sin(tth) * np.cos(pp), np.sin(tth) * np.sin(pp), np.cos(tth)], axis=-1).reshape(-1, 3).astype(np.float32)
+    pdf = mi.eval_component("microfacet_pdf", np.concatenate([np.tile(wi, (len(pts), 1)), pts], axis=1), params)[:, 0].astype(np.float64)
+    expected = (pdf * np.sin(tth).reshape(-1)).reshape(res_c, sub, res_p, sub).mean(axis=(1, 3)) * (np.pi / 2 / res_c) * (2 * np.pi / res_p) * n      # d omega = sin theta d theta d phi
+    assert abs(expected.sum() / n - 1) < 0.02 and abs(hist.sum() - expected.sum()) < 0.02 * n, (expected.sum() / n, hist.sum() / n)
+    ok_, stat, dof = _chi2(hist, expected, 16)
+    assert ok_, (mf_type, alpha_u, alpha_v, visible, theta_i, stat, dof)
