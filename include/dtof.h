@@ -85,6 +85,10 @@ typedef struct {
      * splats at the lane's own pixel, integrator.cpp:540-541).  A row-band shard must carry `filter_halo` padding rows on each side. */
     float    filter_radius;
     int32_t  filter_halo;
+    /* hdrfilm pixel_format = rgba (FilmFlags::Alpha, src/films/hdrfilm.cpp:172-177): develop() returns R, G, B, A.  The host-buffer render calls then write
+     * FOUR floats per pixel, and the device-film calls (dtof_render_rows / _stripes) accumulate the alpha film -- (A, 0, 0, W) -- as one more RGBW plane
+     * behind the n_offsets colour films of `d_film_rgbw`. */
+    int32_t  has_alpha;
 } dtof_scene_info;
 /* What Film::crop_size / Sampler::sample_count / the plugins' to_string() report (src/films/hdrfilm.cpp:235-279, src/render/sampler.cpp:13-14,
  * src/integrators/dopplertofpath.cpp:315-328), plus the sizes of the packed scene. */
@@ -186,6 +190,8 @@ int dtof_render_stripes(dtof_scene *scene, uint32_t seed, uint32_t spp, int32_t 
                         const float *offsets, int n_offsets, float *d_film_rgbw, dtof_render_stats *stats);
 /* HDRFilm::develop (src/films/hdrfilm.cpp:305-406) on device buffers: rgb = RGB / (W == 0 ? 1 : W). */
 int dtof_develop(const float *d_film_rgbw, float *d_rgb, int64_t n_pixels);
+/* ... of an rgba film: rgba = (R, G, B) / W of the colour film and A / W of the alpha film (the plane behind the colour films, see dtof_scene_info::has_alpha). */
+int dtof_develop_rgba(const float *d_film_rgbw, const float *d_alpha_film, float *d_rgba, int64_t n_pixels);
 /* Same as dtof_render but with n_offsets batched modulation offsets; out_rgb holds n_offsets images. */
 int dtof_render_offsets(dtof_scene *scene, uint32_t seed, uint32_t spp, const float *offsets, int n_offsets,
                         float *out_rgb, dtof_render_stats *stats);
@@ -199,6 +205,9 @@ void dtof_cancel(dtof_scene *scene);
  * sample_pos[2], time, ray_o[3], ray_d[3], rgb[3] (12 floats) -- the (Spectrum, position) pair that
  * render_sample hands to ImageBlock::put (src/render/integrator.cpp:509-541). */
 int dtof_sample_lanes(dtof_scene *scene, uint32_t seed, uint32_t spp, uint64_t lane_begin, uint64_t n, float *out_lanes12);
+/* The same, plus the `valid` half of the (Spectrum, Mask) pair DopplerToFPathIntegrator::sample returns (src/integrators/dopplertofpath.cpp:279-282:
+ * valid_ray -- the path met a vertex whose sampled lobe was not BSDFFlags::Null, or the environment is visible): 1 / 0 per lane. */
+int dtof_sample_lanes_valid(dtof_scene *scene, uint32_t seed, uint32_t spp, uint64_t lane_begin, uint64_t n, float *out_lanes12, uint32_t *out_valid);
 
 /* ---------------------------------------------------------------- sampler surface
  * Array-of-lanes form of the Sampler interface (include/mitsuba/render/sampler.h:99-168) for the

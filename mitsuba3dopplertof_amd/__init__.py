@@ -53,7 +53,7 @@ class _Info(C.Structure):
                 ("stratify_each_interval", C.c_int32), ("path_correlation_depth", C.c_uint32), ("max_depth", C.c_uint32),
                 ("rr_depth", C.c_uint32), ("base_seed", C.c_uint32), ("time_correlate_number", C.c_int32),
                 ("path_correlate_number", C.c_int32), ("bvh_stack_depth", C.c_uint32),
-                ("filter_radius", C.c_float), ("filter_halo", C.c_int32)]
+                ("filter_radius", C.c_float), ("filter_halo", C.c_int32), ("has_alpha", C.c_int32)]
 
 
 def lib_path():
@@ -101,6 +101,8 @@ def _lib():
     L.dtof_cancel.argtypes = [vp]
     L.dtof_cancel.restype = None
     L.dtof_sample_lanes.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp]
+    L.dtof_sample_lanes_valid.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp]
+    L.dtof_develop_rgba.argtypes = [vp, vp, vp, C.c_int64]
     L.dtof_sampler_create.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.dtof_sampler_destroy.argtypes = [vp]
     L.dtof_sampler_destroy.restype = None
@@ -206,15 +208,16 @@ class Scene:
         _check(_lib().dtof_scene_set_sampler(self._h, *_plugin_args(props)))
 
     def render(self, seed=0, spp=0, offsets=None, sensor=0):
-        """Developed image (H, W, 3) float32; with `offsets` (list of hetero_offset values) -> (K, H, W, 3)."""
+        """Developed image (H, W, 3) float32 -- (H, W, 4) for an rgba film; with `offsets` (list of hetero_offset values) -> (K, H, W, 3 | 4)."""
         w, h = self.size
         st = _Stats()
+        ch = 4 if self.info()["has_alpha"] else 3
         if offsets is None:
-            out = np.zeros((h, w, 3), np.float32)
+            out = np.zeros((h, w, ch), np.float32)
             _check(_lib().dtof_render(self._h, sensor, seed, spp, out.ctypes.data, C.byref(st)))
         else:
             off = np.ascontiguousarray(offsets, dtype=np.float32)
-            out = np.zeros((len(off), h, w, 3), np.float32)
+            out = np.zeros((len(off), h, w, ch), np.float32)
             _check(_lib().dtof_render_offsets(self._h, seed, spp, off.ctypes.data, len(off), out.ctypes.data, C.byref(st)))
         self.last_stats = st.as_dict()
         return out
@@ -258,8 +261,9 @@ class Scene:
 
     def sample_lanes(self, seed, spp, lane_begin, n):
         out = np.zeros((n, 12), np.float32)
-        _check(_lib().dtof_sample_lanes(self._h, seed, spp, lane_begin, n, out.ctypes.data))
-        return {"sample_pos": out[:, 0:2], "time": out[:, 2], "ray_o": out[:, 3:6], "ray_d": out[:, 6:9], "rgb": out[:, 9:12]}
+        valid = np.zeros(n, np.uint32)
+        _check(_lib().dtof_sample_lanes_valid(self._h, seed, spp, lane_begin, n, out.ctypes.data, valid.ctypes.data))
+        return {"sample_pos": out[:, 0:2], "time": out[:, 2], "ray_o": out[:, 3:6], "ray_d": out[:, 6:9], "rgb": out[:, 9:12], "valid": valid}
 
     def eval_modulation(self, mode, t, length=None):
         t = np.ascontiguousarray(t, np.float32)
@@ -332,7 +336,7 @@ class Integrator:
             scene.set_integrator(self.props)
             return scene.render(seed=seed, spp=spp, sensor=sensor, offsets=offsets)
         w, h = scene.size
-        st, out = _Stats(), np.zeros((h, w, 3), np.float32)
+        st, out = _Stats(), np.zeros((h, w, 4 if scene.info()["has_alpha"] else 3), np.float32)
         _check(_lib().dtof_integrator_render(self._h, None, scene._h, sensor, seed, spp, out.ctypes.data, C.byref(st)))
         scene.last_stats = st.as_dict()
         return out

@@ -61,6 +61,7 @@ struct RenderParams {
     uint32_t inline_iters;                        // fused first-bounce kernel: iterations of the bounce loop it runs back to back with the path state in registers (1 .. kMaxInline)
     uint32_t flat_objects, flat_off;                        // fused pipeline, rectangle-only scenes of at most kFlatObjects objects: their number (trace_flat), else 0
     uint32_t memo_obj;                            // fused pipeline: the scene's only instance object (instance memo, dtof_traverse.h) or 0xffffffff
+    int32_t want_valid;                           // the kernel that ends a path also writes its valid_ray flag to Queues::valid_out (alpha channel of an rgba film, lane dumps)
 };
 
 // SoA wavefront state for one batch (device pointers; all arrays have `capacity` entries and are
@@ -74,7 +75,8 @@ struct Queues {
     float4 *st_a;        // throughput.xyz, path_length
     float4 *st_b;        // prev_si.p, prev_bsdf_pdf (only touched when the scene has area emitters)
     uint4  *rng_a;       // rng.state (lo,hi), rng_path.state (lo,hi)
-    float2 *st_c;        // SPEC: (eta along the path, prev_bsdf_delta)
+    float2 *st_c;        // SPEC: (eta along the path, prev_bsdf_delta | valid_ray << 1 as a float 0 .. 3)
+    float4 *valid_out;   // RenderParams::want_valid: (valid_ray ? 1 : 0, 0, 0, 0) of every finished path -- laid out like `res`, so the splat kernels accumulate the alpha film from it
     uint2  *rng_b;       // (main, path) stream selectors v1 of the TEA seeding: inc = (v1 << 1) | 1, constant per lane
     float4 *res;         // [K][capacity] accumulated result rgb (w unused)
     float2 *pos;         // sample position on the film
@@ -89,13 +91,34 @@ struct Queues {
 };
 
 struct LaneDebug {       // mirrors orc_lane's comparable fields
-    float sample_pos[2]; float time; float ray_o[3]; float ray_d[3]; float rgb[3];
+    float sample_pos[2]; float time; float ray_o[3]; float ray_d[3]; float rgb[3]; float valid;
 };
+
+// The arguments of k_shade (dtof_shade.h) travel as ONE by-value block, read through the kernarg segment pointer.
+struct ShadeArgs {
+    const uint8_t *scene; uint32_t scene_bytes, stage_words; RenderParams rp; Queues q;
+    const uint32_t *qin, *count_in; uint32_t *qout, *alive_out, *shadow_out; uint32_t depth, trace_next; LaneDebug *dbg;
+    uint32_t n_seg, res_small_off, res_small_words, res_memo;   // resident stage (RESW != 0): segments of the batch; byte offset / uint4 count of the record block copied to LDS; 1 = the instance memo has LDS
+};
+// One launch of k_shade as launch_shade hands it to the translation unit that holds the instantiation (dtof_shade_*.hip: the ~100 instantiations of the
+// kernel compile in parallel, one group per file): staged = the scene blob is copied to LDS by every block; mode 0 split, 1 fused, 2 fused first bounce;
+// waves != 0: the resident form (`waves` waves per block, one block per CU).
+struct ShadeLaunch { bool staged; int mode; uint32_t waves, grid, lds; hipStream_t stream; ShadeArgs args; };
+void launch_shade_plain(bool area, bool k4, const ShadeLaunch &L);      // rectangle-only diffuse scenes          (dtof_shade_plain.hip)
+void launch_shade_mesh(bool area, bool k4, const ShadeLaunch &L);       // + triangles / analytic shapes          (dtof_shade_mesh.hip)
+void launch_shade_spec1(bool k4, const ShadeLaunch &L);                 // every BSDF / emitter / texture         (dtof_shade_spec1.hip)
+void launch_shade_spec2(bool k4, const ShadeLaunch &L);                 // ... and blendbsdf                      (dtof_shade_spec2.hip)
+void launch_shade_resident0(bool area, bool k4, const ShadeLaunch &L);  // resident first bounce, diffuse scenes  (dtof_shade_res0.hip)
+void launch_shade_resident1(bool k4, const ShadeLaunch &L);             // resident first bounce, every BSDF      (dtof_shade_res1.hip)
+void launch_shade_resident2(bool k4, const ShadeLaunch &L);             // ... and blendbsdf                      (dtof_shade_res2.hip)
 
 // Resident stage of the fused first-bounce kernel (k_shade<..., RESW>, dtof_kernels.hip): `waves` waves per block (0 = off), one block per CU; the block
 // [small_off, small_off + 16 * small_words) of the blob (groups, shapes, emitters, triangles, shading data) and the TLAS nodes live in LDS.
 struct ResidentStage { uint32_t small_off = 0, small_words = 0, waves = 0; };
 constexpr uint32_t kResidentNodes = 1024;   // TLAS nodes the stage holds (= kResNodes of dtof_traverse.h)
+// dynamic LDS one block of the resident kernel needs with `waves` waves: node planes + record block + (instance memo) + stack columns
+uint32_t resident_lds_bytes(const RenderParams &rp, const ResidentStage &resident, uint32_t stack_depth, uint32_t waves);
+uint32_t device_lds_limit();   // hipDeviceAttributeMaxSharedMemoryPerBlock of the current device (160 KiB on gfx950), minus the kernels' static LDS
 
 // kernels (dtof_kernels.hip)
 void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s);
@@ -113,6 +136,7 @@ void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParam
 void launch_velocity(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q, uint32_t stack_depth, hipStream_t s);
 void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t film_w, int32_t film_h, hipStream_t s);
 void launch_develop(const float *film, float *rgb, int64_t n_pixels, hipStream_t s);
+void launch_develop_rgba(const float *film, const float *alpha_film, float *rgba, int64_t n_pixels, hipStream_t s);   // pixel_format = rgba (hdrfilm.cpp:339-400)
 void launch_lane_dump(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s);
 void launch_pass_save(const RenderParams &rp, const Queues &q, hipStream_t s);   // multi-pass: main / path stream states of the batch -> rp.pass_rng
 void launch_lane_dump_rays(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s);

@@ -66,7 +66,9 @@ struct Workspace {
     DevBuf<float2> pos, st_c;
     DevBuf<uint2> rng_b;
     DevBuf<LaneDebug> dbg;
+    DevBuf<float4> valid;   // Queues::valid_out, only when asked for (ensure_valid)
     uint32_t capacity = 0; int k = 0;
+    void ensure_valid() { valid.ensure(capacity); }
     void ensure(uint32_t cap, int n_offsets) {
         if (cap <= capacity && n_offsets <= k) return;
         capacity = std::max(cap, capacity); k = std::max(n_offsets, k);
@@ -79,7 +81,7 @@ struct Workspace {
         Queues q; memset(&q, 0, sizeof q);
         q.ray_a = ray_a.p; q.ray_b = ray_b.p; q.hit = hit.p; q.hit_t = hit_t.p; q.hit_id = hit_id.p; q.st_a = st_a.p; q.st_b = st_b.p; q.rng_a = rng_a.p; q.rng_b = rng_b.p; q.st_c = st_c.p;
         q.res = res.p; q.pos = pos.p; q.sh_a = sh_a.p; q.sh_b = sh_b.p; q.sh_c = sh_c.p; q.q[0] = q0.p; q.q[1] = q1.p;
-        q.counts = counts.p; q.capacity = capacity;
+        q.counts = counts.p; q.capacity = capacity; q.valid_out = valid.p;
         q.seg_counter = counts.p + 2 * (size_t) kMaxIter * segments_for(capacity);
         return q;
     }
@@ -384,6 +386,9 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     for (auto &e : sc->host.emitters) rp.has_spec |= e.kind == EMITTER_SPOT || e.kind == EMITTER_DIRECTIONAL;
     rp.has_spec |= !sc->host.textures.empty();
     for (size_t ei = 0; ei < sc->host.emitters.size(); ++ei) if (sc->host.emitters[ei].kind == EMITTER_CONSTANT || sc->host.emitters[ei].kind == EMITTER_ENVMAP) { rp.has_env = 1; rp.env_index = (uint32_t) ei; rp.has_spec = 1; }
+    // valid_ray leaves the kernels only when somebody reads it: the alpha channel of an rgba film (integrator.cpp:528-533) and the lane dumps
+    rp.want_valid = (lane_dump || se.alpha) ? 1 : 0;
+    if (rp.want_valid) { sc->ws.ensure_valid(); if (n_streams == 2) sc->ws2.ensure_valid(); qs[0].valid_out = sc->ws.valid.p; qs[1].valid_out = n_streams == 2 ? sc->ws2.valid.p : sc->ws.valid.p; }
     rp.hide_emitters = sc->pp.hide_emitters;   // textured reflectances are looked up in the SPEC instantiations only   // the spot branch lives in the SPEC instantiations (keeps the common kernels lean)
     bool has_spheres = false;
     for (auto &sh : sc->host.shapes) has_spheres |= sh.kind == SHAPE_SPHERE || sh.kind == SHAPE_DISK || sh.kind == SHAPE_CYLINDER;   // analytic shapes of the MESH instantiations
@@ -444,7 +449,12 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     }
     // the reference's last iteration only looks for emitter hits; without surface emitters it contributes nothing and is skipped --
     // unless further passes follow, whose streams depend on the six draws every active lane makes in it
-    const bool skip_tail = !has_surface_emitters && n_passes == 1;
+    // -- and unless a path can still be invalid when it gets there: a BSDF with a null lobe (`mask`, `thindielectric`) leaves valid_ray unset, and a non-null
+    // vertex of the last iteration sets it (dopplertofpath.cpp:252-253), which decides whether the path returns what it gathered or 0 (:279-282); the alpha
+    // channel / the lane dump's `valid` likewise depend on the hit of that iteration when max_depth is 1
+    bool has_null_lobe = false;
+    for (auto &sh : sc->host.shapes) has_null_lobe |= sh.masked || sh.bsdf == BSDF_THINDIELECTRIC || (sh.blend_other && sh.blend_other->bsdf == BSDF_THINDIELECTRIC);
+    const bool skip_tail = !has_surface_emitters && n_passes == 1 && !has_null_lobe && !rp.want_valid;
 
     // The host runs at most two batches ahead of the device: dtof_cancel (Integrator::cancel, integrator.h:96-109) is looked at when a
     // batch is enqueued, so an unbounded run-ahead would leave nothing to cancel once the launches of a long render are queued.
@@ -465,6 +475,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         // the separate k_generate + k_trace launches)
         const bool first_inline = fused && loop_runs && env_fuse_first;
         int t = -1;
+        if (rp.want_valid && !loop_runs && rp.integrator != INTEGRATOR_VELOCITY) HIP_CHECK(hipMemsetAsync(q.valid_out, 0, (size_t) rp.n_lanes * sizeof(float4), s));   // max_depth == 0: { 0, false } (dopplertofpath.cpp:87-88)
         if (!first_inline) {
             t = tm.begin(0, s); launch_generate(rp, q, s); tm.end(0, t, s);
             if (dump_now) launch_lane_dump_rays(rp, q, sc->ws.dbg.p, s);
@@ -520,7 +531,13 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             HIP_CHECK(hipMemcpyAsync(lane_dump + (b0 - first), sc->ws.dbg.p, (size_t) rp.n_lanes * sizeof(LaneDebug), hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
         } else if (!lane_dump) {
-            t = tm.begin(4, s); launch_splat(rp, q, d_film, se.crop_w, se.crop_h, s); tm.end(4, t, s);
+            t = tm.begin(4, s); launch_splat(rp, q, d_film, se.crop_w, se.crop_h, s);
+            if (se.alpha) {   // the alpha film (plane K behind the K offset films): the same splat over (valid, 0, 0) -- ImageBlock::put of aovs[3] (integrator.cpp:528-533)
+                RenderParams ra = rp; ra.n_offsets = 1;
+                Queues qa = q; qa.res = q.valid_out;
+                launch_splat(ra, qa, d_film + (size_t) rp.n_offsets * se.crop_w * se.crop_h * 4, se.crop_w, se.crop_h, s);
+            }
+            tm.end(4, t, s);
         }
         HIP_CHECK(hipGetLastError());   // a rejected launch (LDS size, launch bounds, grid) must not pass for an empty film
         HIP_CHECK(hipEventRecord(batch_done[batch_index & 1], s));
@@ -702,6 +719,7 @@ int dtof_scene_get_info(const dtof_scene *sc, dtof_scene_info *info) {
         info->bvh_stack_depth = h->tlas_depth;
         info->filter_radius = se.filter_radius;
         info->filter_halo = se.filter == FILTER_BOX ? 0 : (int32_t) std::ceil(se.filter_radius - .5f);
+        info->has_alpha = se.alpha ? 1 : 0;
     });
 }
 
@@ -872,11 +890,13 @@ int dtof_render_offsets(dtof_scene *sc, uint32_t seed, uint32_t spp, const float
         int k = n_offsets <= 0 ? 1 : n_offsets;
         const HostSensor &se = sc->host.sensor;
         size_t px = (size_t) se.crop_w * se.crop_h;
-        sc->d_film.ensure(px * 4 * k); sc->d_rgb.ensure(px * 3 * k);
-        HIP_CHECK(hipMemsetAsync(sc->d_film.p, 0, px * 4 * k * sizeof(float), sc->stream));
+        const int planes = k + (se.alpha ? 1 : 0), ch = se.alpha ? 4 : 3;   // rgba: one more film plane for the alpha channel, four channels out
+        sc->d_film.ensure(px * 4 * planes); sc->d_rgb.ensure(px * ch * k);
+        HIP_CHECK(hipMemsetAsync(sc->d_film.p, 0, px * 4 * planes * sizeof(float), sc->stream));
         render_rows(sc, seed, spp, 0, se.crop_h, offsets, n_offsets, sc->d_film.p, stats);
-        launch_develop(sc->d_film.p, sc->d_rgb.p, (int64_t) px * k, sc->stream);
-        HIP_CHECK(hipMemcpyAsync(out_rgb, sc->d_rgb.p, px * 3 * k * sizeof(float), hipMemcpyDeviceToHost, sc->stream));
+        if (se.alpha) for (int i = 0; i < k; ++i) launch_develop_rgba(sc->d_film.p + px * 4 * i, sc->d_film.p + px * 4 * k, sc->d_rgb.p + px * 4 * i, (int64_t) px, sc->stream);
+        else launch_develop(sc->d_film.p, sc->d_rgb.p, (int64_t) px * k, sc->stream);
+        HIP_CHECK(hipMemcpyAsync(out_rgb, sc->d_rgb.p, px * ch * k * sizeof(float), hipMemcpyDeviceToHost, sc->stream));
         HIP_CHECK(hipStreamSynchronize(sc->stream));
     });
 }
@@ -888,13 +908,25 @@ int dtof_render(dtof_scene *sc, uint32_t sensor_index, uint32_t seed, uint32_t s
 
 void dtof_cancel(dtof_scene *sc) { if (sc) sc->stop = true; }
 
-int dtof_sample_lanes(dtof_scene *sc, uint32_t seed, uint32_t spp, uint64_t lane_begin, uint64_t n, float *out) {
+int dtof_sample_lanes_valid(dtof_scene *sc, uint32_t seed, uint32_t spp, uint64_t lane_begin, uint64_t n, float *out, uint32_t *valid) {
     return guarded([&] {
         if (!sc || !out) throw std::runtime_error("null argument");
-        static_assert(sizeof(LaneDebug) == 48, "LaneDebug is 12 floats");
+        static_assert(sizeof(LaneDebug) == 52, "LaneDebug is 13 floats");
         sc->stop = false;
         if (n == 0) return;
-        render_rows(sc, seed, spp, 0, 0, nullptr, 0, nullptr, nullptr, (LaneDebug *) out, lane_begin, n);
+        std::vector<LaneDebug> lanes(n);
+        render_rows(sc, seed, spp, 0, 0, nullptr, 0, nullptr, nullptr, lanes.data(), lane_begin, n);
+        for (uint64_t i = 0; i < n; ++i) { memcpy(out + 12 * i, &lanes[i], 48); if (valid) valid[i] = lanes[i].valid != 0.f ? 1u : 0u; }
+    });
+}
+int dtof_sample_lanes(dtof_scene *sc, uint32_t seed, uint32_t spp, uint64_t lane_begin, uint64_t n, float *out) {
+    return dtof_sample_lanes_valid(sc, seed, spp, lane_begin, n, out, nullptr);
+}
+int dtof_develop_rgba(const float *d_film, const float *d_alpha_film, float *d_rgba, int64_t n_pixels) {
+    return guarded([&] {
+        if (!d_film || !d_alpha_film || !d_rgba) throw std::runtime_error("null argument");
+        launch_develop_rgba(d_film, d_alpha_film, d_rgba, n_pixels, nullptr);
+        HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(nullptr));
     });
 }
 

@@ -205,6 +205,7 @@ struct HostSensor {
     int32_t filter = FILTER_TENT; float filter_radius = 1.f, filter_stddev = .5f, filter_b = 1.f / 3.f, filter_c = 1.f / 3.f;   // B, C: mitchell
     bool orthographic = false;   // src/sensors/orthographic.cpp
     bool thinlens = false; float aperture_radius = 0.f, focus_distance = 0.f;   // src/sensors/thinlens.cpp:138-156, src/render/sensor.cpp:134
+    bool alpha = false;          // hdrfilm pixel_format = rgba: FilmFlags::Alpha (src/films/hdrfilm.cpp:172-177) -- develop() returns R, G, B, A
 };
 
 // A typed property bag (what the reference's Properties carries for a plugin).

@@ -391,206 +391,12 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
 }
 
 
-// ---------------------------------------------------------------------------- cooperative triangle loops
-// The loop over the triangles of a small mesh (no BLAS: at most kBlasMinTris triangles -- the 12 of a `cube`) is the most expensive body of
-// the traversal (38 VALU per triangle) and runs at the lowest lane utilisation: in a leaf round about half of the lanes hold a leaf, a
-// third of those pass the mesh's bounds, and the whole wave pays the 12 tests (Domino: 0.42 loops per ray, 1 186 of the 2 800 VALU
-// instructions of a ray-wave at ~0.16 lane utilisation).  trace_scene_coop is the same traversal written as ONE wave-uniform loop -- lanes
-// whose ray is finished (or that had no ray to trace) stay in it as helpers -- so that the triangle loops of a round are shared out: with
-// n lanes holding a (ray, mesh) job, every job gets g = 8, 4 or 2 adjacent lanes (g <= 64 / n), helper i of a job tests the triangles
-// i, i + g, ... with the job's ray (pulled by ds_bpermute), the group reduces to (smallest t, ties to the lowest face) with DPP row
-// operations and the owner pulls the result back.  Same tri_hit arithmetic per (ray, triangle), same winner: candidates are every triangle
-// hit with t <= maxt, the smallest t wins, equal t goes to the lowest face of the mesh, and the owner then merges the mesh's winner into its
-// best hit with the rule of intersect_object (strictly nearer, or equally near on a lower object index) -- hits are bit-identical.
-// MEASURED (round 3, profiles/r03_coop_triangles_ab.txt) and NOT the default: Domino 47.8 -> 46.6 ms with 12 resident waves per CU (-2.5 %), but 44.2 ->
-// 46.0 ms with 16 (+4 %), the 522 k-triangle mesh room 16.1 -> 17.9 ms and the Cornell scenes +15 .. +30 % (boxes 4.62 -> 5.32 ms, rough conductor
-// 7.49 -> 9.32): the state a lane carries through the uniform loop (object, shape cursor, object-space ray) costs registers in kernels that sit
-// at their VGPR cap, and the round trips through ds_bpermute cost more than the idle lanes of a 12-triangle loop.  make variant DEFS=-DDTOF_COOP=1 builds it.
-#ifndef DTOF_COOP
-#define DTOF_COOP 0
-#endif
-struct TriBest { float t, u, v; uint32_t prim, face; };
-template <int CTRL> DTOF_D uint32_t dpp_u32(uint32_t x) { return (uint32_t) __builtin_amdgcn_update_dpp((int) x, (int) x, CTRL, 0xf, 0xf, false); }
-template <int CTRL> DTOF_D void tri_best_exchange(TriBest &b) {
-    const float ot = u2f(dpp_u32<CTRL>(f2u(b.t))), ou = u2f(dpp_u32<CTRL>(f2u(b.u))), ov = u2f(dpp_u32<CTRL>(f2u(b.v)));
-    const uint32_t op = dpp_u32<CTRL>(b.prim), of = dpp_u32<CTRL>(b.face);
-    const bool take = ot < b.t || (ot == b.t && of < b.face);
-    b.t = take ? ot : b.t; b.u = take ? ou : b.u; b.v = take ? ov : b.v; b.prim = take ? op : b.prim; b.face = take ? of : b.face;
-}
-DTOF_D float bperm_f(uint32_t lane, float x) { return u2f((uint32_t) __builtin_amdgcn_ds_bpermute((int) (lane << 2), (int) f2u(x))); }
-DTOF_D uint32_t bperm_u(uint32_t lane, uint32_t x) { return (uint32_t) __builtin_amdgcn_ds_bpermute((int) (lane << 2), (int) x); }
-// Called by ALL 64 lanes of a wave (uniform control flow, full exec mask).  has_job lanes own a (ray, small mesh) pair: lo / ld / maxt, the mesh's
-// triangles [tri_base, tri_base + n_tris).  Returns to every owner whether a triangle was hit and (closest hit) the mesh's winner.
-template <bool ANY>
-DTOF_D bool coop_small_meshes(const SceneView &sv, bool full_wave, bool has_job, V3 lo, V3 ld, float maxt, uint32_t tri_base, uint32_t n_tris, TriBest &win) {
-    __shared__ uint32_t s_owner[16][32];   // per wave of the block: lane of the job with rank r
-    const uint64_t jobs = __ballot(has_job);
-    const uint32_t n = (uint32_t) __popcll(jobs), lane = __lane_id(), wave = threadIdx.x >> 6;
-    win.t = INFINITY; win.u = win.v = 0.f; win.prim = 0; win.face = 0xffffffffu;
-    if (n > 32 || !full_wave) {   // (uniform) more jobs than half the wave, or lanes of the wave have left the kernel: nothing to share out, every owner loops over its own triangles
-        bool hit = false;
-        if (has_job) for (uint32_t f = 0; f < n_tris; ++f) {
-            float t, u, v; uint32_t face;
-            DTOF_STAT(6);
-            if (!tri_hit(sv.tris[tri_base + f], lo, ld, maxt, t, u, v, face)) continue;
-            hit = true;
-            if (ANY) break;
-            if (t < win.t || (t == win.t && face < win.face)) { win.t = t; win.u = u; win.v = v; win.prim = f; win.face = face; }
-        }
-        return hit;
-    }
-    const uint32_t gl = n <= 8 ? 3u : n <= 16 ? 2u : 1u, g = 1u << gl;   // lanes per job (uniform)
-    const uint32_t rank = (uint32_t) __popcll(jobs & ((1ull << lane) - 1ull));
-    if (has_job) s_owner[wave][rank] = lane;
-    __builtin_amdgcn_wave_barrier();   // LDS operations of a wave execute in order: the reads below see the writes above
-    const uint32_t jr = lane >> gl, sub = lane & (g - 1u);
-    const bool helper = jr < n;
-    const uint32_t owner = s_owner[wave][helper ? jr : 0u];
-    // the job's ray and triangle range, pulled from its owner (8 ds_bpermute; every lane takes part, helpers of no job read lane 0's values and ignore them)
-    const V3 jo = mk(bperm_f(owner, lo.x), bperm_f(owner, lo.y), bperm_f(owner, lo.z)), jd = mk(bperm_f(owner, ld.x), bperm_f(owner, ld.y), bperm_f(owner, ld.z));
-    const float jmaxt = bperm_f(owner, maxt);
-    const uint32_t jrange = bperm_u(owner, (tri_base << 5) | n_tris), jbase = jrange >> 5, jn = jrange & 31u;
-    TriBest b; b.t = INFINITY; b.u = b.v = 0.f; b.prim = 0; b.face = 0xffffffffu;
-    bool any_hit = false;
-    if (helper) for (uint32_t f = sub; f < jn; f += g) {
-        float t, u, v; uint32_t face;
-        DTOF_STAT(6);
-        if (!tri_hit(sv.tris[jbase + f], jo, jd, jmaxt, t, u, v, face)) continue;
-        any_hit = true;
-        if (ANY) break;
-        if (t < b.t || (t == b.t && face < b.face)) { b.t = t; b.u = u; b.v = v; b.prim = f; b.face = face; }
-    }
-    if (ANY) {   // one ballot: an owner is occluded if any lane of its group found a hit
-        const uint64_t hits = __ballot(any_hit);
-        return has_job && ((hits >> (rank << gl)) & ((1ull << g) - 1ull)) != 0;
-    }
-    // group reduction, all lanes (the groups are g adjacent lanes, g | 8): xor 1 and xor 2 inside a quad, then the two quads of a half row
-    tri_best_exchange<0xb1>(b);                 // quad_perm [1, 0, 3, 2]
-    if (gl >= 2) tri_best_exchange<0x4e>(b);    // quad_perm [2, 3, 0, 1]
-    if (gl >= 3) tri_best_exchange<0x141>(b);   // row_half_mirror: lane i <-> 7 - i of its half row (every quad already holds its own winner)
-    const uint32_t src = has_job ? rank << gl : 0u;
-    win.t = bperm_f(src, b.t); win.u = bperm_f(src, b.u); win.v = bperm_f(src, b.v); win.prim = bperm_u(src, b.prim); win.face = bperm_u(src, b.face);
-    return has_job && win.t < INFINITY;
-}
+// (A cooperative form of the small-mesh triangle loops -- one wave-uniform traversal whose 12-triangle loops are shared out over idle lanes -- was built and
+// measured slower in round 3; it is parked as tools/experiments/r03_coop_triangles.patch with its numbers in profiles/r03_coop_triangles_ab.txt.)
 
-// trace_scene for the instantiations with triangle code, as one wave-uniform loop (see above).  `active`: this lane has a ray to trace; the
-// others only help.  Must be called by all 64 lanes of the wave together (no divergent call sites).
-template <bool ANY, bool MEMO = false, bool SOA = false>
-DTOF_D bool trace_scene_coop(const SceneView &sv, uint32_t *stack, bool active, V3 o, V3 d, float time, float maxt, Hit &best) {
-    best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
-    const V3 id = mk(__builtin_amdgcn_rcpf(d.x == 0.f ? 1e-30f : d.x), __builtin_amdgcn_rcpf(d.y == 0.f ? 1e-30f : d.y), __builtin_amdgcn_rcpf(d.z == 0.f ? 1e-30f : d.z));
-    constexpr uint32_t kDone = 0x7fffffffu;
-    const uint32_t stride = blockDim.x;
-    int sp = 0; uint32_t cur = 0;
-    bool done = !active || sv.n_nodes == 0, occluded = false;
-    const bool full_wave = __ballot(true) == ~0ull;   // the cross-lane operations of the shared triangle loops need every lane of the wave
-    // the object the lane is inside of: its shapes [first, first + count), the next one to look at (k), the ray in its space, `found` of intersect_object
-    bool in_obj = false, found = false; uint32_t oi = 0, first = 0, count = 0, k = 0; V3 lo = o, ld = d;
-    if (!done) DTOF_STAT(0);
-    while (__ballot(!done)) {
-        if (!done && !in_obj) {
-            while (!(cur & kLeafFlag) && cur != kDone) {
-                DTOF_STAT(1); DTOF_STAT_WAVE(2);
-                cur = node_step<SOA>(sv.nodes, cur, o, id, best.t, stack, sp, 0, stride, kDone);
-            }
-            if (cur == kDone) done = true;
-            else {   // enter the object (intersect_object's head)
-                DTOF_STAT(3); DTOF_STAT_WAVE(4);
-                oi = cur & ~kLeafFlag;
-                const DObject &ob = sv.objects[oi];
-                first = ob.index; count = 1; lo = o; ld = d;
-                if (ob.kind == OBJ_INSTANCE) {
-                    float m[12], inv[12];
-                    if (MEMO && oi == sv.memo_obj) instance_memo_load(sv, inv);
-                    else { instance_matrix(ob, time, m); affine_inverse(m, inv); }
-                    lo = xf_point(inv, o); ld = xf_vector(inv, d);
-                    const DGroup &g = sv.groups[ob.index];
-                    first = g.first_shape; count = g.n_shapes;
-                }
-                k = 0; found = false; in_obj = true;
-            }
-        }
-        // the shapes of the object, up to (and including) the next small mesh whose bounds the ray enters: that one becomes the lane's job
-        bool has_job = false; uint32_t job_k = 0, tri_base = 0, n_tris = 0;
-        if (!done && in_obj) {
-            while (k < count && !has_job && !done) {
-                const DShape &sh = sv.shapes[first + k];
-                const uint32_t kk = k++;
-                float t, u, v; bool hit = false;
-                if (sh.kind == SHAPE_RECT) hit = rect_hit(sh, lo, ld, maxt, t, u, v);
-                else if (sh.kind == SHAPE_DISK) hit = disk_hit(sh, lo, ld, maxt, t, u, v);
-                else if (sh.kind == SHAPE_CYLINDER) { hit = cylinder_hit(sh, lo, ld, maxt, t); u = v = 0.f; }
-                else if (sh.kind == SHAPE_SPHERE) { hit = sphere_hit<ANY>(sh, lo, ld, maxt, t); u = v = 0.f; }
-                else {
-                    const V3 lid = mk(__builtin_amdgcn_rcpf(ld.x == 0.f ? 1e-30f : ld.x), __builtin_amdgcn_rcpf(ld.y == 0.f ? 1e-30f : ld.y), __builtin_amdgcn_rcpf(ld.z == 0.f ? 1e-30f : ld.z));
-                    if (!(box_entry(sh.bmin, sh.bmax, lo, lid, ANY ? maxt : best.t) < INFINITY)) continue;
-                    DTOF_STAT(5);
-                    if (sh.blas_root == kNoChild && sh.n_tris < 32u) { has_job = true; job_k = kk; tri_base = sh.first_tri; n_tris = sh.n_tris; continue; }
-                    // a mesh behind its own BLAS (or, with DTOF_BLAS=0, a long triangle list): per-lane traversal, as in intersect_object
-                    uint32_t best_face = 0xffffffffu;
-                    auto test = [&](uint32_t f) -> bool {
-                        uint32_t face;
-                        DTOF_STAT(6);
-                        if (!tri_hit(sv.tris[sh.first_tri + f], lo, ld, maxt, t, u, v, face)) return false;
-                        if (ANY) return true;
-                        bool take = t < best.t;
-                        if (t == best.t) take = best_face != 0xffffffffu ? face < best_face : (!found && best.obj != 0xffffffffu && oi < best.obj);
-                        if (take) { best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = kk; best.prim = f; best_face = face; found = true; }
-                        return false;
-                    };
-                    if (sh.blas_root == kNoChild) {
-                        for (uint32_t f = 0; f < sh.n_tris; ++f) if (test(f)) { occluded = true; done = true; break; }
-                        continue;
-                    }
-                    uint32_t bcur = sh.blas_root; int bsp = sp;
-                    for (;;) {
-                        while (!(bcur & kLeafFlag) && bcur != kDone) {
-                            DTOF_STAT(7);
-                            bcur = node_step(sv.nodes, bcur, lo, lid, ANY ? maxt : best.t, stack, bsp, sp, stride, kDone);
-                        }
-                        if (bcur == kDone) break;
-                        const uint32_t f0 = (bcur & ~kLeafFlag) >> kBlasLeafBits, fn = (bcur & ((1u << kBlasLeafBits) - 1u)) + 1u;
-                        bool any = false;
-                        for (uint32_t f = f0; f < f0 + fn; ++f) if (test(f)) { any = true; break; }
-                        if (any) { occluded = true; done = true; break; }
-                        if (bsp == sp) break;
-                        --bsp; bcur = stack[bsp * stride];
-                    }
-                    continue;
-                }
-                if (hit) {
-                    if (ANY) { occluded = true; done = true; }
-                    else if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
-                        best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = kk; best.prim = 0; found = true;
-                    }
-                }
-            }
-        }
-        if (__ballot(has_job)) {   // (uniform) the triangle loops of this round, shared out over the wave
-            TriBest w;
-            const bool hit = coop_small_meshes<ANY>(sv, full_wave, has_job, lo, ld, maxt, tri_base, n_tris, w);
-            if (hit) {
-                if (ANY) { occluded = true; done = true; }
-                else if (w.t < best.t || (w.t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
-                    best.t = w.t; best.u = w.u; best.v = w.v; best.obj = oi; best.shape = job_k; best.prim = w.prim; found = true;
-                }
-            }
-        }
-        if (!done && in_obj && k >= count) {   // leave the object: back to the TLAS
-            in_obj = false;
-            if (sp == 0) done = true; else { --sp; cur = stack[sp * stride]; }
-        }
-    }
-    return ANY ? occluded : best.obj != 0xffffffffu;
-}
-
-// Scene query of a kernel: the shared-loop traversal for the instantiations with triangle code, the per-lane one otherwise.  Call sites are
-// wave-uniform; `active` says whether this lane has a ray.
+// Scene query of a kernel whose call site is wave-uniform; `active` says whether this lane has a ray.
 template <bool ANY, bool MESH, bool MEMO = false, bool SOA = false>
 DTOF_D bool trace_rays(const SceneView &sv, uint32_t *stack, bool active, V3 o, V3 d, float time, float maxt, Hit &best) {
-#if DTOF_COOP
-    if (MESH) return trace_scene_coop<ANY, MEMO, SOA>(sv, stack, active, o, d, time, maxt, best);
-#endif
     bool r = false;
     if (active) r = trace_scene<ANY, MESH, MEMO, SOA>(sv, stack, o, d, time, maxt, best);
     return r;

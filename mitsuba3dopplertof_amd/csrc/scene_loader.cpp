@@ -1310,7 +1310,12 @@ static void make_sensor(const Obj &o, HostScene &sc) {
         se.crop_w = (int32_t) film->props.get_int("crop_width", se.film_w); se.crop_h = (int32_t) film->props.get_int("crop_height", se.film_h);
         se.crop_x = (int32_t) film->props.get_int("crop_offset_x", 0); se.crop_y = (int32_t) film->props.get_int("crop_offset_y", 0);
         std::string pf = film->props.get_string("pixel_format", "rgb");
-        if (pf != "rgb") fail("unsupported pixel_format \"" + pf + "\" (supported: rgb)");
+        for (auto &ch : pf) ch = (char) std::tolower((unsigned char) ch);   // string::to_lower (hdrfilm.cpp:143-144)
+        // hdrfilm.cpp:160-192: rgba sets FilmFlags::Alpha -- the block gains an alpha channel fed by the integrator's valid_ray (integrator.cpp:528-533)
+        if (pf == "rgba") se.alpha = true;
+        else if (pf == "luminance" || pf == "luminance_alpha" || pf == "xyz" || pf == "xyza" || pf == "transient")
+            fail("unsupported pixel_format \"" + pf + "\" (supported: rgb, rgba)");
+        else if (pf != "rgb") fail("The \"pixel_format\" parameter must either be equal to \"luminance\", \"luminance_alpha\", \"rgb\", \"rgba\",  \"xyz\", \"xyza\". Found " + pf + ".");
         (void) film->props.get_string("file_format", "openexr"); (void) film->props.get_string("component_format", "float16");
         if (film->props.get_bool("sample_border", false)) fail("sample_border=true is not supported");
         (void) film->props.get_bool("compensate", false);

@@ -1599,7 +1599,8 @@ static orc_mat material_at(const orc_shape *sh, float u, float v) {
 }
 /* One BSDF interaction of the bounce loop: value and density for the emitter direction `wo` (only when `active_em`), and the
  * sampled continuation (BSDF::eval_pdf_sample, src/render/bsdf.cpp:20-29).  wi_in / wo / bs_wo are in the local shading frame. */
-typedef struct { v3 val; float pdf; v3 weight; v3 wo; float bs_pdf, bs_eta; int bs_delta; } orc_bsdf_out;
+/* bs_null: the sampled lobe was BSDFFlags::Null (mask.cpp:148, thindielectric.cpp:179) -- such a vertex does not validate the ray (dopplertofpath.cpp:252-253) */
+typedef struct { v3 val; float pdf; v3 weight; v3 wo; float bs_pdf, bs_eta; int bs_delta, bs_null; } orc_bsdf_out;
 static void nested_bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, int active_em, float sample_1, float s2x, float s2y, float uv_u, float uv_v, orc_bsdf_out *out) {
     float refl[3] = { sh->reflectance[0], sh->reflectance[1], sh->reflectance[2] };   /* m_reflectance->eval(si) */
     if (sh->tex_refl) orc_texture_eval(sh->tex_refl, uv_u, uv_v, refl);
@@ -1607,7 +1608,7 @@ static void nested_bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, in
     /* BSDF::eval_pdf_sample src/render/bsdf.cpp:20-29 over twosided{diffuse} / diffuse
      * (src/bsdfs/twosided.cpp:111-148,219-258; src/bsdfs/diffuse.cpp:101-125,160-180) */
     v3 bsdf_val = V(0, 0, 0), bsdf_weight = V(0, 0, 0), bs_wo = V(0, 0, 0);
-    float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; int bs_delta = 0;
+    float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; int bs_delta = 0, bs_null = 0;
     if (sh->bsdf == ORC_BSDF_CONDUCTOR) {
         /* SmoothConductor::sample (conductor.cpp:226-277) under TwoSidedBRDF::sample (twosided.cpp:111-148): eval / pdf of a
          * delta lobe are zero (conductor.cpp:279-290) */
@@ -1637,6 +1638,7 @@ static void nested_bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, in
         r *= 2.f / (1.f + r);
         int selected_r = sample_1 <= r;
         bs_pdf = selected_r ? r : 1.f - r; bs_delta = 1; bs_eta = 1.f;
+        bs_null = !selected_r;   /* bs.sampled_type = select(selected_r, DeltaReflection, Null) (:179) */
         bs_wo = selected_r ? V(-wi_in.x, -wi_in.y, wi_in.z) : V(-wi_in.x, -wi_in.y, -wi_in.z);
         bsdf_weight = selected_r ? V(m_.spec_refl[0], m_.spec_refl[1], m_.spec_refl[2]) : V(m_.spec_trans[0], m_.spec_trans[1], m_.spec_trans[2]);
     } else if (sh->bsdf == ORC_BSDF_ROUGHDIELECTRIC) {
@@ -1781,7 +1783,7 @@ static void nested_bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, in
         }
     }
     out->val = bsdf_val; out->pdf = bsdf_pdf; out->weight = bsdf_weight; out->wo = bs_wo;
-    out->bs_pdf = bs_pdf; out->bs_eta = bs_eta; out->bs_delta = bs_delta;
+    out->bs_pdf = bs_pdf; out->bs_eta = bs_eta; out->bs_delta = bs_delta; out->bs_null = bs_null;
 }
 /* NormalMap (src/bsdfs/normalmap.cpp:110-189) around the plain BSDF, itself inside the two-sided adapter if the shape has one: TwoSidedBRDF flips wi.z and
  * wo.z on the back side first (twosided.cpp:111-148,219-258), NormalMap::frame builds n = normalize(2 c - 1) from the texture, s = normalize(dp_du - n (n . dp_du))
@@ -1849,7 +1851,7 @@ static void bsdf_eval_pdf_sample(const orc_shape *sh, const orc_geo *g, v3 wi_in
     const int nested_pick = sample_1 < opacity;
     blended_bsdf_eval_pdf_sample(sh, g, wi_in, wo, active_em, sample_1 / opacity, s2x, s2y, uv_u, uv_v, out);
     out->val = v_mul(out->val, opacity); out->pdf *= opacity;
-    if (!nested_pick) { out->wo = V(-wi_in.x, -wi_in.y, -wi_in.z); out->bs_eta = 1.f; out->bs_pdf = 1.f - opacity; out->bs_delta = 1; out->weight = V(1.f, 1.f, 1.f); }
+    if (!nested_pick) { out->wo = V(-wi_in.x, -wi_in.y, -wi_in.z); out->bs_eta = 1.f; out->bs_pdf = 1.f - opacity; out->bs_delta = 1; out->bs_null = 1; out->weight = V(1.f, 1.f, 1.f); }
 }
 static inline int bsdf_is_smooth(int32_t k) { return k == ORC_BSDF_DIFFUSE || k == ORC_BSDF_PLASTIC || k == ORC_BSDF_ROUGHCONDUCTOR || k == ORC_BSDF_ROUGHPLASTIC || k == ORC_BSDF_ROUGHDIELECTRIC; }
 /* mis_weight -- dopplertofpath.cpp:296-301 */
@@ -2048,6 +2050,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
     const orc_emitter *env = NULL;
     for (int32_t ei = 0; ei < sc->n_emitters; ++ei) if (sc->emitters[ei].kind == ORC_EMITTER_CONSTANT || sc->emitters[ei].kind == ORC_EMITTER_ENVMAP) env = &sc->emitters[ei];
     uint32_t depth = 0; int valid_ray = env && !p->hide_emitters, active = p->max_depth != 0;
+    if (p->max_depth == 0) valid_ray = 0;   /* :87-88: return { 0.f, false } */
     v3 o = ray.o, d = ray.d; float maxt = ray.maxt;
     v3 prev_p = V(0, 0, 0); float prev_bsdf_pdf = 1.f; int prev_delta = 1;   /* dopplertofpath.cpp:106-108 */
 
@@ -2152,12 +2155,12 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         float s2y = sampler_draw(&smp, correlate, single);
 
         v3 bsdf_val = V(0, 0, 0), bsdf_weight = V(0, 0, 0), bs_wo = V(0, 0, 0);
-        float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; int bs_delta = 0;
+        float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; int bs_delta = 0, bs_null = 0;
         if (hit) {
             orc_bsdf_out bo;
             const orc_geo geo = { si.dp_du, si.dp_dv, si.n, si.sh_s, si.sh_t, si.sh_n };
             bsdf_eval_pdf_sample(si.shape, &geo, si.wi, wo, active_em, sample_1, s2x, s2y, si.uv_u, si.uv_v, &bo);
-            bsdf_val = bo.val; bsdf_pdf = bo.pdf; bsdf_weight = bo.weight; bs_wo = bo.wo; bs_pdf = bo.bs_pdf; bs_eta = bo.bs_eta; bs_delta = bo.bs_delta;
+            bsdf_val = bo.val; bsdf_pdf = bo.pdf; bsdf_weight = bo.weight; bs_wo = bo.wo; bs_pdf = bo.bs_pdf; bs_eta = bo.bs_eta; bs_delta = bo.bs_delta; bs_null = bo.bs_null;
         }
         if (active_em) {   /* :214-226 */
             float mis_em = ds_delta ? 1.f : mis_weight(ds_pdf, bsdf_pdf);
@@ -2172,7 +2175,7 @@ static void eval_lane(const orc_ctx *cx, uint64_t lane64, orc_lane *out) {
         }
         thr = V(thr.x * bsdf_weight.x, thr.y * bsdf_weight.y, thr.z * bsdf_weight.z);
         eta *= bs_eta;
-        valid_ray |= hit;
+        valid_ray |= hit && !bs_null;   /* :252-253: active && si.is_valid() && !has_flag(bsdf_sample.sampled_type, BSDFFlags::Null) */
         prev_p = si.p; prev_bsdf_pdf = bs_pdf; prev_delta = bs_delta;   /* :256-258 */
         if (hit) depth += 1;
         /* :264-276 */
@@ -2471,6 +2474,57 @@ uint64_t orc_render_exact(const orc_scene *sc, const orc_params *p, uint32_t see
         double w = film[4 * i + 3]; w = w == 0.0 ? 1.0 : w;
         out_rgb[3 * i] = (float) (film[4 * i] / w); out_rgb[3 * i + 1] = (float) (film[4 * i + 1] / w); out_rgb[3 * i + 2] = (float) (film[4 * i + 2] / w);
     }
+    return total;
+}
+
+/* The alpha channel of an rgba film (hdrfilm.cpp:172-177 FilmFlags::Alpha; integrator.cpp:528-533: aovs[3] = select(valid, 1, 0), aovs[4] = 1; develop
+ * divides every channel by the weight, hdrfilm.cpp:339-400): sum of valid * wx * wy over sum of wx * wy, the terms in float32 as the reference forms them,
+ * the sums in float64 (orc_render_exact explains why).  out_alpha: crop_h * crop_w floats. */
+uint64_t orc_render_alpha(const orc_scene *sc, const orc_params *p, uint32_t seed, uint32_t spp, float *out_alpha, int nt) {
+    orc_ctx cx; make_ctx(&cx, sc, p, seed, spp);
+    const orc_sensor *se = &sc->sensor;
+    const int W = se->crop_w, H = se->crop_h;
+    if (nt < 1) nt = 1;
+    if (nt > 256) nt = 256;
+    const uint32_t spw = cx.spw;
+    const uint64_t wavefront = (uint64_t) W * (uint64_t) H * spw, lanes_per_row = (uint64_t) W * spw;
+    uint64_t total = 0;
+    int chunk_rows = (int) (8000000ull / lanes_per_row); if (chunk_rows < 1) chunk_rows = 1;
+    orc_lane *buf = (orc_lane *) malloc(sizeof(orc_lane) * lanes_per_row * (size_t) chunk_rows);
+    double *film = (double *) calloc((size_t) W * H * 2, sizeof(double));
+    float radius = se->filter_radius, inv_r = 1.f / radius, gc[10];
+    if (se->filter == ORC_FILTER_GAUSSIAN) gaussian_coeffs(se->filter_stddev, radius, gc);
+    const int n = se->filter == ORC_FILTER_BOX ? 0 : (int) ceilf(radius - .5f), count = 2 * n + 1;
+    for (uint32_t pass = 0; pass < cx.n_passes; ++pass)
+    for (int r = 0; r < H; r += chunk_rows) {
+        const int re = r + chunk_rows < H ? r + chunk_rows : H;
+        const uint64_t nl = lanes_per_row * (uint64_t) (re - r);
+        run_lanes(&cx, (uint64_t) pass * wavefront + lanes_per_row * (uint64_t) r, nl, buf, nt);
+        for (uint64_t i = 0; i < nl; ++i) {
+            const uint64_t pix = (lanes_per_row * (uint64_t) r + i) / spw;
+            const float a = buf[i].valid ? 1.f : 0.f;
+            if (se->filter == ORC_FILTER_BOX) {
+                const int x = (int) (pix % (uint64_t) W), y = (int) (pix / (uint64_t) W);
+                film[2 * ((size_t) y * W + x)] += (double) a; film[2 * ((size_t) y * W + x) + 1] += 1.0;
+                continue;
+            }
+            const float spx = buf[i].sample_pos[0], spy = buf[i].sample_pos[1];
+            const int pxi = (int) floorf(spx) - n, pyi = (int) floorf(spy) - n;
+            const float relx = (float) pxi + .5f - spx, rely = (float) pyi + .5f - spy;
+            const int lx = pxi - se->crop_x, ly = pyi - se->crop_y;
+            for (int ys = 0; ys < count; ++ys) {
+                const float wy = filter_eval(se, rely + (float) ys, inv_r, gc);
+                for (int xs = 0; xs < count; ++xs) {
+                    const float wx = filter_eval(se, relx + (float) xs, inv_r, gc), w = wx * wy;
+                    const int x = lx + xs, y = ly + ys;
+                    if ((unsigned) x < (unsigned) W && (unsigned) y < (unsigned) H) { film[2 * ((size_t) y * W + x)] += (double) (a * w); film[2 * ((size_t) y * W + x) + 1] += (double) w; }
+                }
+            }
+        }
+        total += nl;
+    }
+    for (int64_t i = 0; i < (int64_t) W * H; ++i) { double w = film[2 * i + 1]; w = w == 0.0 ? 1.0 : w; out_alpha[i] = (float) (film[2 * i] / w); }
+    free(film); free(buf);
     return total;
 }
 

@@ -469,6 +469,18 @@ class Scene:
         n = lib().orc_render(C.byref(self.c), C.byref(p), seed, spp, r0, r1, film.ctypes.data, img.ctypes.data, threads)
         return (film if raw else img), n
 
+    def render_alpha(self, pd, seed=0, spp=None, threads=1):
+        """the alpha channel of an rgba film (orc_render_alpha): weighted mean of the integrator's valid_ray flag"""
+        spp = spp or pd["sample_count"]
+        w, h = self.size
+        alpha = np.zeros((h, w), np.float32)
+        p = make_params(pd)
+        L = lib()
+        L.orc_render_alpha.restype = C.c_uint64
+        L.orc_render_alpha.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]
+        L.orc_render_alpha(C.byref(self.c), C.byref(p), seed, spp, alpha.ctypes.data, threads)
+        return alpha
+
     def render_exact(self, pd, seed=0, spp=None, rows=None, threads=1):
         """the developed image with the splat terms summed in float64 (orc_render_exact): the order-independent value of the film"""
         spp = spp or pd["sample_count"]

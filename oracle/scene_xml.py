@@ -1383,12 +1383,19 @@ def _sensor_record(sp):
     _no_colours(sp, "sensor")
     film = next((c[1] for c in sp.children if c[0] == "film"), None)
     w, h, cx, cy = 768, 576, 0, 0
+    alpha = False
     filt, radius, stddev = None, 0.0, 0.5
     fb = fc = 1.0 / 3.0
     if film is not None:
         w, h = film.get_i("width", 768), film.get_i("height", 576)
         cw, ch = film.get_i("crop_width", w), film.get_i("crop_height", h)
         cx, cy = film.get_i("crop_offset_x", 0), film.get_i("crop_offset_y", 0)
+        pf = film.get_s("pixel_format", "rgb").lower()   # hdrfilm.cpp:143-192: rgba sets FilmFlags::Alpha
+        if pf in ("luminance", "luminance_alpha", "xyz", "xyza", "transient"):
+            raise ValueError('unsupported pixel_format "%s" (supported: rgb, rgba)' % pf)
+        if pf not in ("rgb", "rgba"):
+            raise ValueError('The "pixel_format" parameter must either be equal to "luminance", "luminance_alpha", "rgb", "rgba",  "xyz", "xyza". Found %s.' % pf)
+        alpha = pf == "rgba"
         rf = next((c[1] for c in film.children if c[0] == "rfilter"), None)
         if rf is not None:
             if rf.plugin == "tent":
@@ -1429,7 +1436,7 @@ def _sensor_record(sp):
         lens = dict(kind=1, aperture_radius=ar, focus_distance=F32(sp.get_f("focus_distance", float(F32(far)))))
     return dict(**lens, to_world=_m32(tw), x_fov=F32(0 if sp.plugin == "orthographic" else _parse_fov(sp, w / float(h))), near_clip=F32(near), far_clip=F32(far),
                 shutter_open=F32(so), shutter_close=F32(sc), film_w=w, film_h=h, crop_x=cx, crop_y=cy,
-                crop_w=cw, crop_h=ch, filter=filt, filter_radius=F32(radius), filter_stddev=F32(stddev), filter_b=F32(fb), filter_c=F32(fc))
+                crop_w=cw, crop_h=ch, filter=filt, filter_radius=F32(radius), filter_stddev=F32(stddev), filter_b=F32(fb), filter_c=F32(fc), alpha=alpha)
 
 
 # ----------------------------------------------------------------------------- plugin parameters

@@ -707,6 +707,46 @@ def domino(n_side=32, res=1024, spp=128):
     return s
 
 
+def open_veils(env=False, res=128, spp=16):
+    """An OPEN scene for the integrators' valid_ray (dopplertofpath.cpp:101-102,252-253,279-282): free-standing cards in front of the void above a floor strip --
+    a moving `mask` veil of constant opacity, a second one behind it (two null interactions in a row, or a null one followed by a real one), a two-sided plastic
+    card behind a checkerboard opacity, a `thindielectric` pane (its transmission is BSDFFlags::Null too, thindielectric.cpp:179) and an opaque diffuse card.
+    A path whose every sampled lobe was a null one and which then leaves the scene returns 0 -- including the emitter samples it gathered at the veils -- unless the
+    environment is visible (`env`: a constant environment; with hide_emitters = true it lights the cards but must not show through the cut-outs)."""
+    s = HEADER.format(spp=spp, res=res, tsm="antithetic", shift="0.5")
+    s = s.replace('\t<integrator type="dopplertofpath">\n', '\t<default name="hide_emitters" value="false" />\n\t<default name="pixel_format" value="rgb" />\n'
+                  '\t<integrator type="dopplertofpath">\n\t\t<boolean name="hide_emitters" value="$hide_emitters" />\n')
+    s += SENSOR.format(fov="30", cam='\t\t\t<lookat origin="0, 1, 6" target="0, 0.9, 0" up="0, 1, 0" />').replace('value="rgb"', 'value="$pixel_format"')
+    s += bsdf("FloorBSDF", "0.7, 0.7, 0.65")
+    s += ('\t<bsdf type="mask" id="VeilBSDF">\n\t\t<float name="opacity" value="0.5" />\n\t\t<bsdf type="twosided">\n\t\t\t<bsdf type="diffuse">\n'
+          '\t\t\t\t<rgb name="reflectance" value="0.7, 0.3, 0.2" />\n\t\t\t</bsdf>\n\t\t</bsdf>\n\t</bsdf>\n')
+    s += ('\t<bsdf type="mask" id="BackVeilBSDF">\n\t\t<float name="opacity" value="0.35" />\n\t\t<bsdf type="diffuse">\n'
+          '\t\t\t<rgb name="reflectance" value="0.2, 0.6, 0.8" />\n\t\t</bsdf>\n\t</bsdf>\n')
+    s += ('\t<bsdf type="mask" id="CheckerBSDF">\n\t\t<texture type="checkerboard" name="opacity">\n\t\t\t<rgb name="color0" value="0.0" />\n\t\t\t<rgb name="color1" value="1.0" />\n'
+          '\t\t\t<transform name="to_uv">\n\t\t\t\t<scale x="3" y="3" />\n\t\t\t</transform>\n\t\t</texture>\n'
+          '\t\t<bsdf type="twosided">\n\t\t\t<bsdf type="plastic">\n\t\t\t\t<rgb name="diffuse_reflectance" value="0.3, 0.7, 0.3" />\n\t\t\t</bsdf>\n\t\t</bsdf>\n\t</bsdf>\n')
+    s += '\t<bsdf type="thindielectric" id="PaneBSDF">\n\t\t<float name="int_ior" value="1.5" />\n\t</bsdf>\n'
+    s += bsdf("CardBSDF", "0.6, 0.6, 0.2")
+
+    def card(ident, b, sx, sy, tx, ty, tz, move=None):
+        base = '\t\t\t\t<scale x="%s" y="%s" z="1" />\n\t\t\t\t<translate x="%s" y="%s" z="%s" />\n' % (sx, sy, tx, ty, tz)
+        if move is None:
+            return '\t<shape type="rectangle" id="%s">\n\t\t<ref id="%s" />\n\t\t<transform name="to_world">\n%s\t\t</transform>\n\t</shape>\n' % (ident, b, base.replace("\t\t\t\t", "\t\t\t"))
+        return ('\t<shape type="rectangle" id="%s">\n\t\t<ref id="%s" />\n\t\t<animation name="to_world">\n\t\t\t<transform time="0">\n%s\t\t\t</transform>\n'
+                '\t\t\t<transform time="0.0015">\n%s\t\t\t\t<translate x="0" y="0" z="%s" />\n\t\t\t</transform>\n\t\t</animation>\n\t</shape>\n' % (ident, b, base, base, move))
+    s += ('\t<shape type="rectangle" id="Floor">\n\t\t<ref id="FloorBSDF" />\n\t\t<transform name="to_world">\n\t\t\t<scale x="1.6" y="0.9" z="1" />\n'
+          '\t\t\t<rotate x="1" angle="-90" />\n\t\t\t<translate x="0" y="0" z="0.3" />\n\t\t</transform>\n\t</shape>\n')
+    s += card("Veil", "VeilBSDF", "0.55", "0.6", "-0.9", "0.8", "0.6", move="0.015")
+    s += card("BackVeil", "BackVeilBSDF", "0.7", "0.7", "-0.6", "0.9", "-0.4")
+    s += card("Checker", "CheckerBSDF", "0.45", "0.55", "0.25", "0.75", "0.4", move="-0.015")
+    s += card("Pane", "PaneBSDF", "0.4", "0.6", "1.1", "0.8", "0.5")
+    s += card("Card", "CardBSDF", "0.35", "0.35", "0.9", "1.0", "-0.6")
+    s += ('\t<emitter type="point">\n\t\t<point name="position" x="0.3" y="2.2" z="4" />\n\t\t<rgb name="intensity" value="60" />\n\t</emitter>\n')
+    if env:
+        s += '\t<emitter type="constant">\n\t\t<rgb name="radiance" value="0.5, 0.6, 0.8" />\n\t</emitter>\n'
+    return s + "</scene>\n"
+
+
 def main():
     out = {
         "cornell_boxes.xml": cornell(False, 256, 16, "antithetic", "0.5"),
@@ -722,6 +762,8 @@ def main():
         "cornell_textured.xml": cornell_textured(),
         "cornell_textured_specular.xml": cornell_textured_specular(),
         "cornell_masked.xml": cornell_masked(),
+        "open_veils.xml": open_veils(False),
+        "open_veils_env.xml": open_veils(True),
         "cornell_normalmap.xml": cornell_normalmap(),
         "cornell_blend.xml": cornell_blend(),
         "cornell_textured_light.xml": cornell_textured_light(),
@@ -745,7 +787,7 @@ def main():
 def ensure(quiet=True):
     """(re)generate scenes/*.xml if any is missing or older than this script -- the files are build products, not tracked"""
     names = ["cornell_boxes.xml", "cornell_wall.xml", "cornell_area.xml", "cornell_specular.xml", "cornell_plastic.xml", "cornell_rough.xml", "cornell_roughplastic.xml", "cornell_frosted.xml", "cornell_spot.xml", "cornell_disk.xml",
-             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_textured_specular.xml", "cornell_masked.xml", "cornell_normalmap.xml", "cornell_blend.xml", "cornell_textured_light.xml", "tex_normal.png", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_thinlens.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
+             "cornell_spheres.xml", "cornell_sphere_light.xml", "domino.xml", "domino_small.xml", "cornell_textured.xml", "cornell_textured_specular.xml", "cornell_masked.xml", "open_veils.xml", "open_veils_env.xml", "cornell_normalmap.xml", "cornell_blend.xml", "cornell_textured_light.xml", "tex_normal.png", "cornell_env.xml", "cornell_envmap.xml", "cornell_sun.xml", "cornell_thinlens.xml", "cornell_cylinders.xml", "tex_rgb.png", "tex_gray.png", "env_sky.hdr", "env_sky.pfm", "env_sky.png", "env_sky.exr"]
     me = os.path.getmtime(os.path.abspath(__file__))
     if all(os.path.exists(os.path.join(HERE, n)) and os.path.getmtime(os.path.join(HERE, n)) >= me for n in names):
         return

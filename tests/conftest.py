@@ -89,6 +89,15 @@ CONFIGS = [
     ("textured_specular", "cornell_textured_specular.xml", dict(resx=32, resy=32, max_depth=5), 8),
     # `mask` BSDFs: constant, checkerboard and bitmap opacities over diffuse / plastic, one- and two-sided; null interactions, point + area light
     ("masked", "cornell_masked.xml", dict(resx=32, resy=32, max_depth=6), 8),
+    # valid_ray (dopplertofpath.cpp:101-102,252-253,279-282) in an OPEN scene: veils (`mask`), a `thindielectric` pane and an opaque card in front of the void --
+    # a path of null interactions that leaves the scene returns 0, also what it gathered at the veils; the last iteration (which otherwise only looks for
+    # emitter hits) still validates; max_depth 1 and 2 make it the first / second
+    ("open_veils", "open_veils.xml", dict(resx=32, resy=32, max_depth=5), 8),
+    ("open_veils_depth2", "open_veils.xml", dict(resx=32, resy=32, max_depth=2), 8),
+    ("open_veils_depth1", "open_veils.xml", dict(resx=24, resy=24, max_depth=1), 8),
+    # ... with a constant environment: visible (every ray valid from the start), and lighting the cards but hidden (hide_emitters: it must not show through the cut-outs)
+    ("open_veils_env", "open_veils_env.xml", dict(resx=32, resy=32, max_depth=4), 8),
+    ("open_veils_env_hidden", "open_veils_env.xml", dict(resx=32, resy=32, max_depth=4, hide_emitters="true"), 8),
     # `normalmap` BSDFs: bitmap and checkerboard normal maps around diffuse / roughconductor / plastic, inside twosided and mask; light-leak rejection
     ("normalmap", "cornell_normalmap.xml", dict(resx=32, resy=32, max_depth=5), 8),
     # `blendbsdf`: constant / checkerboard / bitmap weights, reflecting and transmitting partners, inside twosided and mask, a normal-mapped partner

@@ -62,6 +62,7 @@ def test_every_lane_is_bit_exact_and_image_within_tolerance(mi, orc, name, xml, 
         o = osc.render_lanes(pd, seed, spp, 0, n, threads=NCPU)
         for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
             assert np.array_equal(bits(g[k]), bits(o[k])), (name, seed, k, int((bits(g[k]) != bits(o[k])).sum()))
+        assert np.array_equal(g["valid"], o["valid"]), (name, seed, "valid_ray", int((g["valid"] != o["valid"]).sum()))   # the Mask half of sample()'s result
     img = sc.render(seed=3, spp=spp)
     ref, _ = osc.render(pd, seed=3, spp=spp, threads=NCPU)
     assert rel_linf(img, ref) <= IMG_TOL, rel_linf(img, ref)
@@ -936,7 +937,10 @@ def _random_scene(rng, mesh_dir=None):
                  % (rng.integers(1, 8), rng.integers(0, 4), rng.choice(["uniform", "stratified", "antithetic", "antithetic_mirror"]),
                     rng.choice(["sinusoidal", "rectangular", "triangular", "trapezoidal"]), rng.choice(["0.0", "1.0", "0.37"]), rng.integers(2, 6)))
     else:
-        integ = '<integrator type="path"><integer name="max_depth" value="%d"/></integrator>' % rng.integers(2, 7)
+        integ = '<integrator type="path"><integer name="max_depth" value="%d"/></integrator>' % rng.integers(1, 7)
+    if rng.random() < 0.3:   # SamplingIntegrator::m_hide_emitters: valid_ray starts false even under an environment (dopplertofpath.cpp:101-102)
+        integ = integ.replace('</integrator>', '<boolean name="hide_emitters" value="true"/></integrator>')
+    pixel_format = '<string name="pixel_format" value="rgba"/>' if rng.random() < 0.25 else ""   # FilmFlags::Alpha: the film's alpha channel is the mean of valid_ray
     def material(two_sided_ok=True, nested=False):
         if not nested and rng.random() < 0.12:   # src/bsdfs/blendbsdf.cpp: two materials of the set (each with its own adapters), constant or checkerboard weight
             wt = ('<float name="weight" value="%s"/>' % f(0.05, 0.95) if rng.random() < 0.6 else
@@ -1041,8 +1045,8 @@ def _random_scene(rng, mesh_dir=None):
         if k in ("constant", "envmap"):
             break
     return ('<scene version="3.0.0">%s<sensor type="%s">%s<transform name="to_world">%s<lookat origin="%s, %s, 5" target="0, 0.8, 0" up="0, 1, 0"/></transform>%s'
-            '<film type="hdrfilm"><integer name="width" value="10"/><integer name="height" value="8"/>%s</film><float name="shutter_close" value="0.0015"/></sensor>%s%s</scene>'
-            % (integ, sensor_kind, lens, cam_scale, f(-1, 1), f(0.5, 2), sampler, rfilter, "".join(shapes), "".join(lights)))
+            '<film type="hdrfilm"><integer name="width" value="10"/><integer name="height" value="8"/>%s%s</film><float name="shutter_close" value="0.0015"/></sensor>%s%s</scene>'
+            % (integ, sensor_kind, lens, cam_scale, f(-1, 1), f(0.5, 2), sampler, pixel_format, rfilter, "".join(shapes), "".join(lights)))
 
 
 @pytest.mark.parametrize("block", range(4))
@@ -1069,6 +1073,7 @@ def test_random_scene_structures(mi, orc, block):
         n = 10 * 8 * 4
         ref = osc.render_lanes(pd, 5, 4, 0, n, threads=NCPU)
         img_ref, _ = osc.render(pd, seed=5, spp=4, threads=NCPU)
+        alpha_ref = osc.render_alpha(pd, seed=5, spp=4, threads=NCPU) if 'value="rgba"' in xml else None
         for pipeline in ("auto", "split" if it % 2 else "fused"):
             if pipeline == "auto":
                 os.environ.pop("DTOF_PIPELINE", None)
@@ -1079,15 +1084,21 @@ def test_random_scene_structures(mi, orc, block):
                 g = sc.sample_lanes(5, 4, 0, n)
                 for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
                     assert np.array_equal(bits(g[k]), bits(ref[k])), (block, it, pipeline, k, int((bits(g[k]) != bits(ref[k])).any(axis=-1).sum() if g[k].ndim > 1 else 0), xml)
+                assert np.array_equal(g["valid"], ref["valid"]), (block, it, pipeline, "valid_ray", int((g["valid"] != ref["valid"]).sum()), xml)
                 # the image against its own peak -- or, where the signed lane values cancel to rounding noise (a heterodyne image of directly seen
                 # emitters), against 1e-3 of the peak lane value: the order of the film's float atomics is all that differs
                 floor_ = 1e-3 * float(np.abs(ref["rgb"]).max())
                 def img_err(a, b):
                     return float(np.abs(np.asarray(a, np.float64) - b).max()) / max(float(np.abs(b).max()), floor_, 1e-30)
-                assert img_err(sc.render(seed=5, spp=4), img_ref) <= IMG_TOL, (block, it, pipeline, xml)
+                img = sc.render(seed=5, spp=4)
+                rgba = 'value="rgba"' in xml
+                assert img.shape[-1] == (4 if rgba else 3)
+                assert img_err(img[..., :3], img_ref) <= IMG_TOL, (block, it, pipeline, xml)
+                if rgba:   # the alpha channel: weighted mean of valid_ray (integrator.cpp:528-533, hdrfilm.cpp:339-400)
+                    assert np.abs(img[..., 3] - alpha_ref).max() <= 1e-5, (block, it, pipeline, "alpha", xml)
                 if 'type="dopplertofpath"' in xml and it % 3 == 0:      # K = 4 modulation offsets in one traversal == four renders of the oracle
                     offs = [0.0, 0.25, 0.5, 0.75]
-                    batch = sc.render(seed=5, spp=4, offsets=offs)
+                    batch = sc.render(seed=5, spp=4, offsets=offs)[..., :3]
                     for k_, off in enumerate(offs):
                         o2 = orc.Scene(xml.replace('<integrator type="dopplertofpath">', '<integrator type="dopplertofpath"><float name="hetero_offset" value="%s"/>' % off), is_string=True)
                         r2, _ = o2.render(o2.params(), seed=5, spp=4, threads=NCPU)

@@ -79,3 +79,102 @@ def test_half_transparent_mask_is_the_opacity_weighted_veil(mi):
         return float(np.asarray(sc.render(seed=5)).mean())
     full, half = mean("1"), mean("0.5")
     assert full > 1e-3 and abs(half / full - 0.5) < 0.02
+
+
+# ---------------------------------------------------------------- valid_ray (dopplertofpath.cpp:101-102,252-253,279-282; path.cpp:115,257-258,285)
+# A vertex whose sampled lobe is BSDFFlags::Null (the pass-through of a `mask`, mask.cpp:148; the transmission of a `thindielectric`, thindielectric.cpp:179) does not
+# validate the ray, and sample() returns select(valid_ray, result, 0): a path of null interactions that leaves the scene returns 0 -- also the emitter samples it
+# gathered on the way -- and counts as alpha 0.
+OPEN_SENSOR = ('<sensor type="perspective"><float name="fov" value="20"/><transform name="to_world"><lookat origin="0, 0, 4" target="0, 0, 0" up="0, 1, 0"/></transform>'
+               '<film type="hdrfilm"><integer name="width" value="4"/><integer name="height" value="4"/>%s<rfilter type="box"/></film>'
+               '<sampler type="independent"><integer name="sample_count" value="64"/></sampler></sensor>')
+OPEN_LIGHT = '<emitter type="point"><point name="position" value="1, 1, 4"/><rgb name="intensity" value="10"/></emitter>'
+
+
+def _open_scene(integrator, body, film=""):
+    return SCENE % (integrator + OPEN_SENSOR % film + body)
+
+
+def test_valid_ray_of_a_veil_in_front_of_the_void_oracle(orc):
+    """one masked rectangle (opacity 0.5) filling the view, a point light, nothing behind it: every lane gathers the light at the veil (eval is scaled by the opacity,
+    not gated by the lobe pick), but the ~half of the lanes whose sampled lobe is the null one then leave the scene and must return exactly 0, invalid"""
+    xml = _open_scene('<integrator type="path"><integer name="max_depth" value="3"/></integrator>', OPEN_LIGHT + VEIL % "0.5")
+    sc = orc.Scene(xml, {}, is_string=True)
+    lanes = sc.render_lanes(sc.params(), 2, 64, 0, 4 * 4 * 64, threads=2)
+    nonzero = np.abs(lanes["rgb"]).sum(axis=1) > 0
+    assert np.array_equal(nonzero, lanes["valid"] == 1)                  # valid <=> it kept what it gathered
+    assert 0.4 < nonzero.mean() < 0.6                                     # ~ opacity
+    # an opaque card behind the veil catches the paths that went through: they are valid again (the card sits in the veil's shadow, so they add nothing)
+    behind = orc.Scene(_open_scene('<integrator type="path"><integer name="max_depth" value="3"/></integrator>', OPEN_LIGHT + VEIL % "0.5" + WALL), {}, is_string=True)
+    lb = behind.render_lanes(behind.params(), 2, 64, 0, 4 * 4 * 64, threads=2)
+    assert lb["valid"].all() and (np.abs(lb["rgb"]).sum(axis=1) > 0).all()
+    # the tail iteration validates too: with max_depth = 2 the wall is met by the iteration that only looks for emitter hits (active_next is false there)
+    tail = orc.Scene(_open_scene('<integrator type="path"><integer name="max_depth" value="2"/></integrator>', OPEN_LIGHT + VEIL % "0.5" + WALL), {}, is_string=True)
+    lt = tail.render_lanes(tail.params(), 2, 64, 0, 4 * 4 * 64, threads=2)
+    assert lt["valid"].all() and (np.abs(lt["rgb"]).sum(axis=1) > 0).all()
+    # max_depth = 0 returns { 0, false } before anything happens (:87-88)
+    none = orc.Scene(_open_scene('<integrator type="path"><integer name="max_depth" value="0"/></integrator>', OPEN_LIGHT + WALL), {}, is_string=True)
+    assert not none.render_lanes(none.params(), 2, 64, 0, 64, threads=1)["valid"].any()
+
+
+def test_valid_ray_under_a_hidden_environment_oracle(orc):
+    """a constant environment lights the veil; hide_emitters = true: valid_ray starts false, and what a null path sees of the environment through the veil is dropped
+    with the rest of it; hide_emitters = false: every ray is valid from the start.  A thindielectric pane behaves like the veil: its transmission is a null lobe."""
+    env = '<emitter type="constant"><rgb name="radiance" value="0.5"/></emitter>'
+    for body in (VEIL % "0.5", '<shape type="rectangle"><transform name="to_world"><scale value="3"/></transform><bsdf type="thindielectric"/></shape>'):
+        hidden = orc.Scene(_open_scene('<integrator type="path"><integer name="max_depth" value="3"/><boolean name="hide_emitters" value="true"/></integrator>', env + body), {}, is_string=True)
+        shown = orc.Scene(_open_scene('<integrator type="path"><integer name="max_depth" value="3"/></integrator>', env + body), {}, is_string=True)
+        lh, ls = hidden.render_lanes(hidden.params(), 3, 64, 0, 1024, threads=2), shown.render_lanes(shown.params(), 3, 64, 0, 1024, threads=2)
+        assert ls["valid"].all()
+        assert 0.02 < lh["valid"].mean() < 0.98                              # the reflected / opaque picks are valid, the straight-through ones are not
+        inval = lh["valid"] == 0
+        assert np.all(lh["rgb"][inval] == 0) and np.all(ls["rgb"][inval] != 0)   # the same lanes carry the environment when it is not hidden
+        assert np.array_equal(lh["rgb"][~inval], ls["rgb"][~inval])              # and the valid ones do not depend on the flag
+
+
+def test_rgba_film_loads_on_both_loaders(mi, orc):
+    """hdrfilm.cpp:143-192: pixel_format is lower-cased; rgba sets FilmFlags::Alpha; the formats this build does not develop are refused, unknown ones with the reference's message"""
+    for name, load in both(mi, orc):
+        sc = load(_open_scene("", OPEN_LIGHT + WALL, '<string name="pixel_format" value="RGBA"/>'))
+        assert (sc.info()["has_alpha"] if name == "product" else sc.flat.sensor["alpha"])
+        with pytest.raises(Exception, match="unsupported pixel_format"):
+            load(_open_scene("", OPEN_LIGHT + WALL, '<string name="pixel_format" value="xyza"/>'))
+        with pytest.raises(Exception, match='"pixel_format" parameter must either be equal to'):
+            load(_open_scene("", OPEN_LIGHT + WALL, '<string name="pixel_format" value="bgr"/>'))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", ["auto", "split", "fused"])
+def test_valid_ray_and_alpha_channel_match_the_oracle(mi, orc, pipeline, monkeypatch):
+    """the kernels' valid bit: lanes (radiance AND the valid flag) bit for bit, the rgba film's alpha channel = weighted mean of valid_ray (integrator.cpp:528-533,
+    hdrfilm.cpp:339-400) -- veils with and without something behind them, the tail iteration, a hidden environment, a thindielectric pane, max_depth 0 / 1"""
+    if pipeline != "auto":
+        monkeypatch.setenv("DTOF_PIPELINE", pipeline)
+    env = '<emitter type="constant"><rgb name="radiance" value="0.5"/></emitter>'
+    pane = '<shape type="rectangle"><transform name="to_world"><scale value="3"/></transform><bsdf type="thindielectric"/></shape>'
+    half_wall = WALL.replace('<scale value="3"/>', '<scale value="3"/><translate x="3"/>')     # behind the right half of the veil only
+    rgba = '<string name="pixel_format" value="rgba"/>'
+    cases = [('<integrator type="path"><integer name="max_depth" value="3"/></integrator>', OPEN_LIGHT + VEIL % "0.5"),
+             ('<integrator type="path"><integer name="max_depth" value="2"/></integrator>', OPEN_LIGHT + VEIL % "0.5" + half_wall),
+             ('<integrator type="dopplertofpath"><integer name="max_depth" value="4"/></integrator>', OPEN_LIGHT + VEIL % "0.3" + half_wall),
+             ('<integrator type="path"><integer name="max_depth" value="3"/><boolean name="hide_emitters" value="true"/></integrator>', env + VEIL % "0.5"),
+             ('<integrator type="dopplertofpath"><integer name="max_depth" value="3"/><boolean name="hide_emitters" value="true"/></integrator>', env + pane + half_wall),
+             ('<integrator type="path"><integer name="max_depth" value="1"/></integrator>', OPEN_LIGHT + half_wall),
+             ('<integrator type="path"><integer name="max_depth" value="0"/></integrator>', OPEN_LIGHT + WALL)]
+    for integ, body in cases:
+        xml = _open_scene(integ, body, rgba).replace('<rfilter type="box"/>', '<rfilter type="tent"/>')
+        sc, osc = mi.load_string(xml), orc.Scene(xml, {}, is_string=True)
+        pd = osc.params()
+        g, o = sc.sample_lanes(2, 64, 0, 1024), osc.render_lanes(pd, 2, 64, 0, 1024, threads=4)
+        assert np.array_equal(g["rgb"].view(np.uint32), np.ascontiguousarray(o["rgb"]).view(np.uint32)), (integ, body)
+        assert np.array_equal(g["valid"], o["valid"]), (integ, body)
+        img = np.asarray(sc.render(seed=2, spp=64))
+        assert img.shape == (4, 4, 4)
+        exact, _ = osc.render_exact(pd, seed=2, spp=64, threads=4)
+        alpha = osc.render_alpha(pd, seed=2, spp=64, threads=4)
+        assert np.abs(img[..., :3] - exact).max() <= 1e-5 * max(np.abs(exact).max(), 1e-6)
+        assert np.abs(img[..., 3] - alpha).max() <= 1e-5, (integ, body, img[..., 3], alpha)
+    # the two halves of the half-wall case really differ: full alpha where the wall catches the paths, about the opacity where the void is behind the veil
+    xml = _open_scene(cases[1][0], cases[1][1], rgba)
+    a = np.asarray(mi.load_string(xml).render(seed=1, spp=4096))[..., 3]
+    assert np.all(a[:, 3] > 0.999) and np.all(np.abs(a[:, 0] - 0.5) < 0.05)

@@ -15,7 +15,7 @@ import csv, glob, hashlib, json, os, re, sys
 from collections import defaultdict
 
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ("dtof_kernels.hip", "dtof_kernels.h", "dtof_traverse.h", "dtof_sampling.h", "dtof_shading.h", "dtof_math.h", "dtof_scene.h", "dtof_render.hip", "Makefile")
+KERNEL_SOURCES = ("dtof_kernels.hip", "dtof_shade.h", "dtof_device.h", "dtof_kernels.h", "dtof_traverse.h", "dtof_sampling.h", "dtof_shading.h", "dtof_math.h", "dtof_scene.h", "dtof_render.hip", "Makefile")
 
 
 def kernel_sources_sha16(root=HERE):

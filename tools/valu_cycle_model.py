@@ -76,11 +76,17 @@ def main():
     if "--asm" in sys.argv:
         asm = sys.argv[sys.argv.index("--asm") + 1]
     else:
-        asm = os.path.join(tempfile.mkdtemp(), "k.s")
+        tmp = tempfile.mkdtemp()
         csrc = os.path.join(HERE, "mitsuba3dopplertof_amd", "csrc")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
-                        "-S", "--cuda-device-only", os.path.join(csrc, "dtof_kernels.hip"), "-o", asm], check=True, stderr=subprocess.DEVNULL)
-    lines = open(asm).read().split("\n")
+        lines = []
+        for tu in ("dtof_shade_plain", "dtof_shade_res0"):   # the translation units that hold the headline (C2) and the Domino (C4 / C5) first-bounce kernels
+            asm = os.path.join(tmp, tu + ".s")
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+                            "-S", "--cuda-device-only", os.path.join(csrc, tu + ".hip"), "-o", asm], check=True, stderr=subprocess.DEVNULL)
+            lines += open(asm).read().split("\n")
+        asm = None
+    if asm:
+        lines = open(asm).read().split("\n")
     dem = lambda s: subprocess.run(["c++filt", s], capture_output=True, text=True).stdout.strip()
     out = {"csrc_sha16": kernel_sources_sha16(), "cycles": {"fast": C_FAST, "slow": C_SLOW, "quarter": C_QUARTER},
            "source": "static VALU instruction mix of the kernel x issue rates of profiles/r03_ubench_valu_rate.txt (tools/valu_cycle_model.py)", "configs": {}}
