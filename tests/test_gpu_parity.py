@@ -478,6 +478,7 @@ def test_repeated_renders_and_handles_do_not_leak_device_memory(mi):
     path = os.path.join(SCENES, "cornell_boxes.xml")
     sc = mi.load_file(path, resx=128, resy=128)
     sc.render(seed=0, spp=16); sc.render(seed=0, spp=64)          # the larger wavefront sizes the workspace
+    sc.sample_lanes(0, 16, 0, 4096)                               # ... and the first lane dump adds the valid_ray plane to it
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
     for i in range(60):
