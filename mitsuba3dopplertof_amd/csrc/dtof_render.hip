@@ -18,8 +18,18 @@
 #include <string>
 #include <memory>
 #include <vector>
+#ifdef DTOF_MARKERS
+#include <thread>
+#include <chrono>
+#include <map>
+#endif
 
 using namespace dtof;
+#ifdef DTOF_MARKERS
+#define MARKER_OR_NULL ((LaneDebug *) marker_array())
+#else
+#define MARKER_OR_NULL nullptr
+#endif
 
 namespace {
 
@@ -263,6 +273,27 @@ struct Roctx {
 };
 static const Roctx &roctx() { static const Roctx r; return r; }
 static const char *const kStageNames[6] = { "dtof:generate", "dtof:trace", "dtof:shade", "dtof:shadow", "dtof:splat", "dtof:first" };
+
+#ifdef DTOF_MARKERS
+// see DTOF_MARK (dtof_shade.h): a host-visible array of per-wave stage numbers and a thread that prints their histogram every two seconds
+static uint32_t *marker_array() {
+    static uint32_t *p = [] {
+        uint32_t *m = nullptr;
+        if (hipHostMalloc((void **) &m, 4096 * 4, hipHostMallocMapped) != hipSuccess) return (uint32_t *) nullptr;
+        memset(m, 0, 4096 * 4);
+        std::thread([m] {
+            for (;;) {
+                std::this_thread::sleep_for(std::chrono::seconds(2));
+                std::map<uint32_t, int> h; for (int i = 0; i < 4096; ++i) if (m[i]) h[m[i]]++;
+                std::string line = "[markers]"; for (auto &kv : h) line += " " + std::to_string(kv.first) + ":" + std::to_string(kv.second);
+                fprintf(stderr, "%s\n", line.c_str()); fflush(stderr);
+            }
+        }).detach();
+        return m;
+    }();
+    return p;
+}
+#endif
 
 struct StageTimer {
     bool on; dtof_scene *sc; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[6];
@@ -519,7 +550,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             // the slots are reused -- only the statistics lose those iterations, no path is cut short
             uint32_t *qout = q.q[it & 1], *alive_out = q.counts + (size_t) (2 * (it % kMaxIter)) * n_seg, *shadow_out = alive_out + n_seg;
             const int st_shade = first ? 5 : 2;
-            t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it + 1 - span, fused, next_runs, stack_depth, s, first, first && dump_now ? sc->ws.dbg.p : nullptr, &resident); tm.end(st_shade, t, s);
+            t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it + 1 - span, fused, next_runs, stack_depth, s, first, first && dump_now ? sc->ws.dbg.p : MARKER_OR_NULL, &resident); tm.end(st_shade, t, s);
             if (stats && first) { stats->n_launches_first++; stats->n_inline_iterations += span; batch_inline.push_back(span); }
             if (!fused) { t = tm.begin(3, s); launch_shadow(blob, blob_bytes, rp, q, shadow_out, stack_depth, s); tm.end(3, t, s); if (stats) stats->n_launches_shadow++; }
             if (stats) stats->n_launches_shade++;
