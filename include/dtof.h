@@ -89,6 +89,11 @@ typedef struct {
      * FOUR floats per pixel, and the device-film calls (dtof_render_rows / _stripes) accumulate the alpha film -- (A, 0, 0, W) -- as one more RGBW plane
      * behind the n_offsets colour films of `d_film_rgbw`. */
     int32_t  has_alpha;
+    /* How the fused pipeline runs the iterations after the first for this scene (measured on the first batch rendered; results are bit-identical either way):
+     * 0 not measured yet, 1 inline -- the first-bounce kernel keeps going with the path state in registers (closed scenes) --, 2 compacted -- one launch per
+     * iteration over the lanes whose continuation ray hit something (open scenes); survivors_after_first = that share of the lanes after the first iteration. */
+    int32_t  inline_choice;
+    float    survivors_after_first;
 } dtof_scene_info;
 /* What Film::crop_size / Sampler::sample_count / the plugins' to_string() report (src/films/hdrfilm.cpp:235-279, src/render/sampler.cpp:13-14,
  * src/integrators/dopplertofpath.cpp:315-328), plus the sizes of the packed scene. */

@@ -53,7 +53,8 @@ class _Info(C.Structure):
                 ("stratify_each_interval", C.c_int32), ("path_correlation_depth", C.c_uint32), ("max_depth", C.c_uint32),
                 ("rr_depth", C.c_uint32), ("base_seed", C.c_uint32), ("time_correlate_number", C.c_int32),
                 ("path_correlate_number", C.c_int32), ("bvh_stack_depth", C.c_uint32),
-                ("filter_radius", C.c_float), ("filter_halo", C.c_int32), ("has_alpha", C.c_int32)]
+                ("filter_radius", C.c_float), ("filter_halo", C.c_int32), ("has_alpha", C.c_int32),
+                ("inline_choice", C.c_int32), ("survivors_after_first", C.c_float)]
 
 
 def lib_path():

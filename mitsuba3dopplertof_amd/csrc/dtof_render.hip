@@ -109,6 +109,10 @@ struct dtof_scene {
     DevBuf<unsigned long long> d_sums;       // [batch][2*kMaxIter] per-iteration totals (survivors, shadow rays)
     DevBuf<uint2> d_pass_rng;                // multi-pass renders: [lane][3] stream states between the passes
     uint32_t id_shift = 24;                  // Queues::id_shift of this scene
+    // How the fused pipeline runs the iterations after the first: 0 = not measured yet, 1 = inline (the first-bounce kernel runs up to four iterations with the
+    // path state in registers: closed scenes, where nearly every path goes on), 2 = compacted (one launch per iteration over the queue of the lanes whose
+    // continuation ray hit something: open scenes).  Measured once per scene / plugin parameters on the first batch rendered (render_rows).
+    int inline_choice = 0; float survivors_after_first = -1.f;
     hipStream_t stream = nullptr, stream2 = nullptr;
     std::atomic<bool> stop { false };
     // reusable statistics plumbing (creating events / pinned memory per call costs ~0.3 ms)
@@ -294,6 +298,13 @@ static uint32_t *marker_array() {
     return p;
 }
 #endif
+
+// fused pipeline: a scene whose first iteration leaves fewer than this share of its lanes with a hit runs one launch per iteration over compacted queues.
+// Measured on Domino (survivors 0.32; profiles/r04_compaction_ab.txt): compaction LOSES there, 40.7 against 39.8 ms -- the compacted bounce launches execute 19 % fewer
+// VALU instructions than the inline iterations but issue them at 0.64 instead of 1.14 G wave-instructions per ms: a wave of 64 live incoherent rays keeps the CU's LDS
+// and L1 paths (node planes, instance records) three times as busy as a wave with 20, and even fully packed its active-lane ratio is only 0.36 -- the idle lanes
+// of that kernel are traversal divergence, not dead paths.  The break-even lies near one full chunk of survivors per segment, hence 0.1 (DTOF_COMPACT_BELOW overrides).
+static float compact_below() { const char *e = getenv("DTOF_COMPACT_BELOW"); return e ? (float) atof(e) : 0.1f; }   // read per call: A/B runs switch it
 
 struct StageTimer {
     bool on; dtof_scene *sc; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[6];
@@ -530,10 +541,21 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             // The first-bounce kernel of the fused pipeline runs up to kMaxInline iterations of the loop itself, the path state in registers
             // (RenderParams::inline_iters; DTOF_INLINE_ITERS=1 keeps one launch per iteration).  Multi-pass renders, whose stream states must be
             // in memory between the passes, take one iteration per launch; lane dumps (dtof_sample_lanes) run the same inline kernel as renders.
-            uint32_t span = 1;
+            // How many: all of them where nearly every path goes on (a closed room: the state never leaves the registers), ONE where most paths leave the scene
+            // after a bounce (Domino: a lane whose path has ended idles through the remaining inline iterations, and with it most of the wave -- active-lane
+            // ratio 0.46; compacted to the lanes that hit something, the later iterations run on a third of the waves).  Which of the two a scene is, is
+            // MEASURED on its first batch: that one runs the first iteration alone, and the share of lanes that come out of it with a hit decides
+            // (dtof_scene::inline_choice; bit-identical results either way).  DTOF_INLINE_ITERS = 1 .. 4 overrides.
+            uint32_t span = 1; bool pilot = false;
             if (first && n_passes == 1) {
-                static const uint32_t env_inline = [] { const char *e = getenv("DTOF_INLINE_ITERS"); const int v = e ? atoi(e) : (int) kMaxInline; return (uint32_t) (v < 1 ? 1 : v > (int) kMaxInline ? (int) kMaxInline : v); }();
-                while (span < env_inline && (it + span) < rp.max_depth && !(it + span + 1 >= rp.max_depth && skip_tail)) ++span;   // the loop head's conditions for iteration it + span
+                const char *e = getenv("DTOF_INLINE_ITERS");   // read per call: tests switch it
+                const int v = e ? atoi(e) : 0;
+                uint32_t max_inline = (uint32_t) (v < 1 ? (int) kMaxInline : v > (int) kMaxInline ? (int) kMaxInline : v);
+                if (!e) {
+                    if (sc->inline_choice == 0 && rp.max_depth > 2 && !lane_dump) { pilot = true; max_inline = 1; }
+                    else if (sc->inline_choice == 2) max_inline = 1;
+                }
+                while (span < max_inline && (it + span) < rp.max_depth && !(it + span + 1 >= rp.max_depth && skip_tail)) ++span;   // the loop head's conditions for iteration it + span
             }
             rp.inline_iters = span;
             it += span - 1;   // `it` is now the last iteration this launch covers
@@ -552,6 +574,14 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             const int st_shade = first ? 5 : 2;
             t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it + 1 - span, fused, next_runs, stack_depth, s, first, first && dump_now ? sc->ws.dbg.p : MARKER_OR_NULL, &resident); tm.end(st_shade, t, s);
             if (stats && first) { stats->n_launches_first++; stats->n_inline_iterations += span; batch_inline.push_back(span); }
+            if (pilot && next_runs) {   // the one measurement of this scene: lanes that left the first iteration with a hit / lanes that entered it
+                std::vector<uint32_t> alive(n_seg);
+                HIP_CHECK(hipMemcpyAsync(alive.data(), alive_out, (size_t) n_seg * 4, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                uint64_t sum = 0; for (uint32_t v : alive) sum += v;
+                sc->survivors_after_first = (float) ((double) sum / (double) rp.n_lanes);
+                sc->inline_choice = sc->survivors_after_first < compact_below() ? 2 : 1;
+            }
             if (!fused) { t = tm.begin(3, s); launch_shadow(blob, blob_bytes, rp, q, shadow_out, stack_depth, s); tm.end(3, t, s); if (stats) stats->n_launches_shadow++; }
             if (stats) stats->n_launches_shade++;
             qin = qout; count_in = alive_out;
@@ -686,7 +716,7 @@ int dtof_scene_set_integrator(dtof_scene *sc, const char *plugin, const char *co
         if (!sc) throw std::runtime_error("null scene");
         PropBag b = make_bag(plugin, names, types, values, n);
         PluginParams p = make_plugin_params(b, sc->host.sampler);
-        sc->host.integrator = b; sc->pp = p;
+        sc->host.integrator = b; sc->pp = p; sc->inline_choice = 0;
     });
 }
 int dtof_scene_set_sampler(dtof_scene *sc, const char *plugin, const char *const *names, const char *types, const char *const *values, int n) {
@@ -694,7 +724,7 @@ int dtof_scene_set_sampler(dtof_scene *sc, const char *plugin, const char *const
         if (!sc) throw std::runtime_error("null scene");
         PropBag b = make_bag(plugin, names, types, values, n);
         PluginParams p = make_plugin_params(sc->host.integrator, b);
-        sc->host.sampler = b; sc->pp = p;
+        sc->host.sampler = b; sc->pp = p; sc->inline_choice = 0;
     });
 }
 
@@ -726,6 +756,7 @@ int dtof_integrator_render(const dtof_integrator *integ, const dtof_sampler_plug
         if (!integ || !sc) throw std::runtime_error("null argument");
         const PropBag &sb = smp ? smp->bag : sc->host.sampler;
         PluginParams p = make_plugin_params(integ->bag, sb);
+        if (p.max_depth != sc->pp.max_depth || p.rr_depth != sc->pp.rr_depth || p.integrator != sc->pp.integrator) sc->inline_choice = 0;
         sc->host.integrator = integ->bag; sc->host.sampler = sb; sc->pp = p;
     });
     return rc ? rc : dtof_render(sc, sensor_index, seed, spp, out_rgb, stats);
@@ -751,6 +782,7 @@ int dtof_scene_get_info(const dtof_scene *sc, dtof_scene_info *info) {
         info->filter_radius = se.filter_radius;
         info->filter_halo = se.filter == FILTER_BOX ? 0 : (int32_t) std::ceil(se.filter_radius - .5f);
         info->has_alpha = se.alpha ? 1 : 0;
+        info->inline_choice = sc->inline_choice; info->survivors_after_first = sc->survivors_after_first;
     });
 }
 

@@ -72,7 +72,7 @@ template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, int SPEC, int RESW
 // -- the opposite of the K = 1 kernels, which lose 20 - 27 % at two (profiles/r03_spec_waves_ab.txt).
 __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : (MODE != 0 && MESH) ? ((SPEC && KMAX > 1) ? 2 : DTOF_MESH_WAVES) : 1) void k_shade(ShadeArgs args_by_value) {
     constexpr bool FUSED = MODE != 0, FIRST = MODE == 2;
-    static_assert(RESW == 0 || (MODE == 2 && !LDS && MESH), "the resident stage exists for the unstaged fused first-bounce kernel with mesh code");
+    static_assert(RESW == 0 || (MODE != 0 && !LDS && MESH), "the resident stage exists for the unstaged fused kernels with mesh code");
     extern __shared__ uint4 lds[];
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_inline_all[(RESW ? RESW : 1) * 2 * kMaxInline];   // FIRST: lanes alive after / shadow rays of every inline iteration but the last (statistics), per wave
@@ -826,24 +826,27 @@ static void launch_shade_variant(const ShadeLaunch &L) {
 // the resident form of the fused first-bounce kernel: `waves` waves per block, one block per CU.  Its dynamic LDS lies above the 64 KiB a kernel gets
 // without asking: hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE, so the high-water mark is kept per device ordinal (dtof-render drives
 // one host thread per GPU in one process).
-template <bool A, int K, int S, int W>
+template <int MODE, bool A, int K, int S, int W>
 static void launch_resident_waves(const ShadeLaunch &L) {
     static std::atomic<uint32_t> attr_lds[64];
     int dev = 0; (void) hipGetDevice(&dev);
     std::atomic<uint32_t> &mark = attr_lds[(unsigned) dev & 63u];
     if (L.lds > mark.load()) {
-        if (hipFuncSetAttribute((const void *) k_shade<false, 2, A, K, true, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) L.lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *) k_shade<false, MODE, A, K, true, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) L.lds) != hipSuccess)
             throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
         mark.store(L.lds);
     }
-    hipLaunchKernelGGL((k_shade<false, 2, A, K, true, S, W>), dim3(L.grid), dim3(W * 64), L.lds, L.stream, L.args);
+    hipLaunchKernelGGL((k_shade<false, MODE, A, K, true, S, W>), dim3(L.grid), dim3(W * 64), L.lds, L.stream, L.args);
 }
 template <bool A, int K, int S>
 static void launch_resident_variant(const ShadeLaunch &L) {
-    if (L.waves == 16) launch_resident_waves<A, K, S, 16>(L);
-    else if (L.waves == 12) launch_resident_waves<A, K, S, 12>(L);
-    else if (L.waves == 8) launch_resident_waves<A, K, S, 8>(L);
+    // mode 2: the first-bounce kernel; mode 1: the bounce kernel over the compacted queue of the launch before (open scenes, see render_rows)
+#define DTOF_RES_MODE(W_) do { if (L.mode == 2) launch_resident_waves<2, A, K, S, W_>(L); else launch_resident_waves<1, A, K, S, W_>(L); } while (0)
+    if (L.waves == 16) DTOF_RES_MODE(16);
+    else if (L.waves == 12) DTOF_RES_MODE(12);
+    else if (L.waves == 8) DTOF_RES_MODE(8);
     else throw std::runtime_error("resident stage: 8, 12 or 16 waves per block");
+#undef DTOF_RES_MODE
 }
 
 }  // namespace dtof
