@@ -64,8 +64,8 @@ CONFIGS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: half a second of GPU time or more -- 300 frames of the headline workload c2 and of c1, 80 of c3, 12 of c4, 3 of c5)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scene", default=None)
     ap.add_argument("--res", type=int, default=None)
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel per GPU (weak) / in total (strong)")
@@ -81,6 +81,8 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra scaling figures (the other scaling mode of c2, strong-scaling c4)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU oracle sample")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"c1": 300, "c2": 300, "c3": 80, "c4": 12, "c5": 3}[args.config]
     args.scene_given, args.res_given, args.spp_given = args.scene, args.res, args.spp
     return args
 
@@ -141,6 +143,7 @@ def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_ov
     import torch
     import torch.distributed as dist
     mi, D, dev, world, rank, share = ctx["mi"], ctx["D"], ctx["dev"], ctx["world"], ctx["rank"], ctx["share"]
+    exchange = world > 1 or ctx.get("force_exchange")   # the frame loop issues the film gather / reduce
     scene_file, res, spp0, defines, offsets = CONFIGS[cfg]
     scene_path = scene_override or os.path.join(HERE, "scenes", scene_file)
     res = res_override or res
@@ -148,7 +151,7 @@ def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_ov
     if sharding == "auto":
         sharding = "stripes" if os.path.basename(scene_path).startswith("domino") else "bands"
     scene = mi.load_file(scene_path, **dict(defines, resx=res, resy=res))
-    striped = world > 1 and sharding == "stripes"
+    striped = exchange and sharding == "stripes"
     if offsets and world > 1 and not striped:
         raise SystemExit("batched-offset configs shard with --sharding stripes (the band gather carries one film)")
     W, H = scene.size
@@ -160,7 +163,7 @@ def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_ov
     film_ptr = film.data_ptr() + halo * W * 4 * 4
     p0, p1 = D.slab_range(H, world, rank, halo)
     rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    gather_buf = torch.empty((world, p1 - p0, W, 4), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+    gather_buf = torch.empty((world, p1 - p0, W, 4), dtype=torch.float32, device=dev) if (exchange and rank == 0) else None
     lib = mi._lib()
     keys = ("ms_trace", "ms_shade", "ms_shadow", "ms_generate", "ms_splat", "ms_total", "ms_first", "n_bounces", "n_shadow_rays", "n_paths")
     acc = dict.fromkeys(keys + ("launches", "first_launches", "launches_equiv", "inline_bounces"), 0.0)
@@ -171,18 +174,25 @@ def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_ov
         kfilm = torch.zeros((K, H, W, 4), dtype=torch.float32, device=dev)
         krgb = torch.zeros((K, H, W, 3), dtype=torch.float32, device=dev)
 
-    def develop(src, dst, n):
-        if lib.dtof_develop(src.data_ptr(), dst.data_ptr(), n) != 0:
-            raise RuntimeError(lib.dtof_last_error().decode())
+    def develop(src, dst, n):      # enqueued on the scene's stream (= the torch stream of this workload, see below)
+        scene.develop_async(src.data_ptr(), dst.data_ptr(), n)
 
-    def step(record):
-        film.zero_()
+    # ONE stream carries a frame from end to end on every rank: the library enqueues on the torch stream of this workload (dtof_scene_set_stream), so the film
+    # clear, the render, the film exchange (torch.distributed enqueues RCCL collectives behind the current stream, no host wait) and the develop are ordered by the
+    # stream and the K timed steps are queued back to back and waited for ONCE -- the same loop for N = 1 and N > 1.  Only the development set-up in which two
+    # ranks share one GPU (DTOF_BENCH_SHARE_GPU=1: gloo carries the exchange through host memory) and DTOF_BENCH_SYNC=1 synchronise once per step.
+    torch.cuda.synchronize()          # the buffers above were zero-filled on the default stream
+    stream = torch.cuda.Stream(device=dev)
+    pipelined = not share and not os.environ.get("DTOF_BENCH_SYNC")
+    scene.set_stream(stream.cuda_stream)
+    full_view = film[halo:halo + H]
+
+    def enqueue_step():
+        """clear -> render -> exchange -> develop of one frame, all on `stream`; nothing waits on the host unless the exchange has to (gloo)"""
         if native:
             kfilm.zero_()
-        torch.cuda.synchronize()
-        if native:
             if striped:               # interleaved stripes of rows per rank, ONE reduce(sum) of the full-size films to rank 0
-                st = scene.render_stripes(kfilm.data_ptr(), 0, spp, *D.stripe_layout(world, rank, stripe_rows), offsets=offsets)
+                scene.render_stripes_async(kfilm.data_ptr(), 0, spp, *D.stripe_layout(world, rank, stripe_rows), offsets=offsets)
                 if share:
                     host = kfilm.cpu(); dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
                     if rank == 0:
@@ -190,62 +200,66 @@ def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_ov
                 else:
                     dist.reduce(kfilm, dst=0, op=dist.ReduceOp.SUM)
             else:
-                st = scene.render_rows(kfilm.data_ptr(), seed=0, spp=spp, row_begin=0, row_end=H, offsets=offsets)
+                scene.render_rows_async(kfilm.data_ptr(), 0, spp, 0, H, offsets=offsets)
             if rank == 0:
                 develop(kfilm, krgb, H * W * K)
         else:
-            st = scene.render_rows(film_ptr, seed=0, spp=spp, row_begin=r0, row_end=r1)   # synchronises the library's stream
-            stack = D.gather_film_stacked(film[p0:p1], rank, world, out=gather_buf)
-            if rank == 0:
-                full = D.overlap_add_stacked(stack, H, world, halo) if world > 1 else film[halo:halo + H]
-                develop(full.contiguous(), rgb, H * W)
-        if record:
-            for k in keys:
-                acc[k] += st[k]
-            acc["launches"] += st["n_launches_shade"]; acc["first_launches"] += st["n_launches_first"]
-            acc["launches_equiv"] += st["n_inline_iterations"]; acc["inline_bounces"] += st["n_bounces_inline"]
+            film.zero_()
+            scene.render_rows_async(film_ptr, 0, spp, r0, r1)
+            if exchange:
+                stack = D.gather_film_stacked(film[p0:p1], rank, world, out=gather_buf, force=True)
+                if rank == 0:
+                    develop(D.overlap_add_stacked(stack, H, world, halo).contiguous(), rgb, H * W)
+            else:
+                develop(full_view, rgb, H * W)
+
+    def collect_into(acc_, n_steps):
+        st, frame_ms = scene.collect()
+        for k in keys:
+            acc_[k] += st[k]
+        acc_["launches"] += st["n_launches_shade"]; acc_["first_launches"] += st["n_launches_first"]; acc_["launches_equiv"] += st["n_inline_iterations"]
+        return frame_ms
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # One GPU, one film: the timed steps are ENQUEUED back to back on the library's stream (film clear, render, develop -- dtof_*_async) and waited for once, so that
-    # the GPU does not idle while the host reads counters and sets up the next frame; their times come from the HIP events the library records around every frame
-    # and stage, the bounce / shadow-ray counters from an identical frame (every step renders seed 0) rendered synchronously before the timed region.
-    pipelined = world == 1 and not native and not os.environ.get("DTOF_BENCH_SYNC")
-    for _ in range(warmup):
-        step(False)
-    if pipelined:
-        before = dict(acc)
-        step(True)                                  # untimed: its counters stand for every timed step
-        counts = {k: acc[k] - before[k] for k in ("n_bounces", "n_shadow_rays", "inline_bounces")}
-        for k in acc:
-            acc[k] = before[k]
-    barrier()
-    per_step = []
-    t0 = time.perf_counter()
-    if pipelined:
-        full = film[halo:halo + H]
-        for _ in range(steps):
-            scene.clear_async(film.data_ptr(), film.numel() * 4)
-            scene.render_rows_async(film_ptr, 0, spp, r0, r1)
-            scene.develop_async(full.data_ptr(), rgb.data_ptr(), H * W)
-        st, frame_ms = scene.collect()
-        for k in keys:
-            acc[k] += st[k]
-        acc["launches"] += st["n_launches_shade"]; acc["first_launches"] += st["n_launches_first"]; acc["launches_equiv"] += st["n_inline_iterations"]
+    with torch.cuda.stream(stream):
+        for _ in range(warmup):
+            enqueue_step()
+            scene.collect()
+        # the bounce / shadow-ray counters need a read-back: they come from ONE identical frame (every step renders seed 0) rendered synchronously before the timed region
+        if native and striped:
+            st1 = scene.render_stripes(kfilm.data_ptr(), 0, spp, *D.stripe_layout(world, rank, stripe_rows), offsets=offsets)
+        elif native:
+            st1 = scene.render_rows(kfilm.data_ptr(), seed=0, spp=spp, row_begin=0, row_end=H, offsets=offsets)
+        else:
+            st1 = scene.render_rows(film_ptr, seed=0, spp=spp, row_begin=r0, row_end=r1)
+        counts = {"n_bounces": st1["n_bounces"], "n_shadow_rays": st1["n_shadow_rays"], "inline_bounces": st1["n_bounces_inline"]}
+        barrier()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        per_step = []
+        t0 = time.perf_counter()
+        ev[0].record(stream)
+        for i in range(steps):
+            ts = time.perf_counter()
+            enqueue_step()
+            ev[i + 1].record(stream)
+            if not pipelined:
+                collect_into(acc, 1)
+                stream.synchronize()
+                per_step.append(time.perf_counter() - ts)
+        if pipelined:
+            collect_into(acc, steps)          # the ONE host wait of the timed region (hipStreamSynchronize of the stream + the events' times)
+        stream.synchronize()
         for k, v in counts.items():
             acc[k] += v * steps
-        per_step = [ms * 1e-3 for ms in frame_ms]   # GPU-side frame durations (events around each frame)
-    else:
-        for _ in range(steps):
-            ts = time.perf_counter()
-            step(True)
-            torch.cuda.synchronize()
-            per_step.append(time.perf_counter() - ts)
     barrier()
     elapsed = time.perf_counter() - t0
+    if pipelined:   # GPU-side durations of the whole frames (clear + render + exchange + develop), from the events between them on the one stream
+        per_step = [ev[i].elapsed_time(ev[i + 1]) * 1e-3 for i in range(steps)]
+    scene.set_stream(None)
     t = torch.tensor([elapsed] + per_step, dtype=torch.float64, device=dev)
     # this rank's share of the work: the library's own GPU time per step (HIP events around its launches), min / max over the ranks = load balance
     mine = torch.tensor([acc["ms_total"] / max(steps, 1)], dtype=torch.float64, device=dev)
@@ -265,6 +279,120 @@ def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_ov
         out["image"] = (krgb if native else rgb).cpu().numpy()
         out["film"] = None if native else film[halo:halo + H].cpu().numpy()
     return out
+
+
+def roofline_for(r, config, steps, default_workload):
+    """The `roofline` object of one timed workload (run_workload's result on rank 0): the dominant kernel priced against the bound that holds for it."""
+    acc, offsets = r["acc"], r["offsets"]
+    # The dominant kernel.  Fused pipeline (C2): k_shade<MODE 2> generates the lanes, traces the primary rays and runs up to four
+    # iterations of the bounce loop with the path state in registers -- for C2 (max_depth 4) that is the whole path, no bounce-kernel
+    # launch is left and the kernel is bound by VALU issue, not by HBM.  Split pipeline / longer paths: the bounce kernel
+    # k_shade<MODE 1|0> streams the path state through HBM once per iteration and is priced by its algorithmic bytes.
+    n_first = acc["first_launches"]
+    fused = acc["ms_shadow"] == 0.0                          # one kernel per bounce (occlusion + next closest hit inline)
+    k_off = len(offsets) if offsets else 1
+    per_bounce = kernel_bytes_per_bounce(fused, k_off)
+    bounce_launches = acc["launches"] - n_first
+    loop_s = (acc["ms_trace"] + acc["ms_shade"] + acc["ms_shadow"]) * 1e-3
+    # Counter evidence (separate rocprofv3 --pmc passes over exactly this configuration, tools/profile_round.sh -> tools/pmc_summary.py): stamped
+    # with a hash of the kernel sources; when the sources have changed since, the figures derived from it are marked stale.
+    tfile = os.path.join(HERE, "profiles", "roofline_traffic.json")
+    pmc, counters_stale = {}, None
+    if os.path.exists(tfile) and default_workload:
+        try:
+            sys.path.insert(0, os.path.join(HERE, "tools"))
+            from pmc_summary import kernel_sources_sha16
+            entry = json.load(open(tfile)).get("configs", {}).get(config)
+            if entry:
+                pmc = entry.get("kernels", {})
+                counters_stale = entry.get("csrc_sha16") != kernel_sources_sha16(HERE)
+        except Exception:
+            pmc = {}
+    # Algorithmic work of one path (profiles/algorithmic_ops.json, tools/algorithmic_ops.py): arithmetic the oracle executes for the path logic
+    # (exact basic-block counts) + the primitive work of the product's own traversal counters, one op per arithmetic instruction
+    alg = {}
+    afile = os.path.join(HERE, "profiles", "algorithmic_ops.json")
+    if os.path.exists(afile) and default_workload:
+        try:
+            alg = json.load(open(afile)).get(config, {})
+        except Exception:
+            alg = {}
+    # Issue-rate model (profiles/valu_cycle_model.json, tools/valu_cycle_model.py): only a subset of the VALU instruction forms issues at the 2 cycles
+    # per wave64 instruction the peak assumes (measured: profiles/r03_ubench_valu_rate.txt); the kernel's static instruction mix priced with the
+    # measured rates gives the average cycles one of ITS instructions occupies a SIMD for
+    cyc = {}
+    cfile = os.path.join(HERE, "profiles", "valu_cycle_model.json")
+    if os.path.exists(cfile) and default_workload:
+        try:
+            sys.path.insert(0, os.path.join(HERE, "tools"))
+            from pmc_summary import kernel_sources_sha16
+            cdoc = json.load(open(cfile))
+            cyc = dict(cdoc.get("configs", {}).get(config, {}), stale=cdoc.get("csrc_sha16") != kernel_sources_sha16(HERE))
+        except Exception:
+            cyc = {}
+    stages = {"ms_first_bounce": round(acc["ms_first"] / steps, 4),
+              "ms_trace": round(acc["ms_trace"] / steps, 4), "ms_shade": round(acc["ms_shade"] / steps, 4),
+              "ms_shadow": round(acc["ms_shadow"] / steps, 4), "ms_generate": round(acc["ms_generate"] / steps, 4),
+              "ms_splat": round(acc["ms_splat"] / steps, 4)}
+    survey_model = {"what": "SURVEY 8(d): 412 B per path-bounce over ALL loop kernels (trace+shade+shadow time)", "bytes_per_path_bounce": B_BOUNCE,
+                    "achieved": round(B_BOUNCE * acc["n_bounces"] / max(loop_s, 1e-12) / 1e9, 1),
+                    "frac": round(B_BOUNCE * acc["n_bounces"] / max(loop_s, 1e-12) / 1e9 / HBM_PEAK_GBS, 4)}
+    if n_first and bounce_launches == 0:
+        # every iteration ran inside the first-bounce kernel: VALU-issue roofline (256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions per second,
+        # /opt/skills/guides/MI355X_MICROARCH.md "Wave scheduling"); executed instructions from the SQ_INSTS_VALU pass under profiles/
+        first_s = acc["ms_first"] * 1e-3 / max(n_first, 1)                       # average launch
+        paths_per_launch = acc["n_paths"] / max(n_first, 1)
+        out_bytes = (8 + 8 + 16 * k_off) * paths_per_launch                       # sample position, stream selectors, result
+        firsts = sorted((k for k in pmc if k.startswith("k_shade_first")), key=lambda k: -pmc[k].get("valu_wave_insts_per_launch", 0))
+        first_rec = pmc[firsts[0]] if firsts else {}
+        wave_insts = first_rec.get("valu_wave_insts_per_launch")
+        valu_peak = 256 * 4 * 32 * 2.4e9 / 1e12                                   # T lane-instructions / s
+        achieved = (wave_insts * 64 / first_s / 1e12) if wave_insts else None
+        ops_path = alg.get("ops_per_path")
+        alg_achieved = ops_path * paths_per_launch / first_s / 1e12 if ops_path else None
+        roofline = {
+            "bound": "valu", "kernel": "k_shade<MODE 2: lane generation + primary ray + ALL %d bounce iterations, path state in registers>%s" % (
+                round(acc["launches_equiv"] / max(n_first, 1)), " [%s]" % first_rec.get("symbol", "") if first_rec else ""),
+            "achieved": round(achieved, 2) if achieved else None, "peak": round(valu_peak, 1), "unit": "T lane-instr/s",
+            "frac": round(achieved / valu_peak, 4) if achieved else None,
+            "what": "achieved / frac: EXECUTED VALU wave-instructions x 64 lanes (issue slots, idle lanes included) per second against the issue peak; "
+                    "algorithmic: the arithmetic one path needs (oracle + traversal counters) per second against the same peak; active_lane_ratio: share of the issued lane slots that held an active lane",
+            "algorithmic": {"ops_per_path": ops_path, "achieved": round(alg_achieved, 2) if alg_achieved else None, "unit": "T ops/s",
+                            "frac_alg": round(alg_achieved / valu_peak, 4) if alg_achieved else None, "source": alg.get("source"), "breakdown": alg.get("breakdown")},
+            "active_lane_ratio": first_rec.get("active_lane_ratio"),
+            "valu_busy_est": {"what": "share of the launch during which the VALU pipes are occupied: executed VALU wave-instructions x the average cycles one "
+                                      "instruction of THIS kernel's mix holds a SIMD (2.25 / 4.1 / 8.2 nominal cycles by instruction form, measured on this GPU) "
+                                      "over 1024 SIMDs x launch time x 2.4 GHz; frac prices every instruction at 2 cycles",
+                              "avg_cycles_per_valu_instruction": cyc.get("avg_cycles_per_valu"), "share_of_cycles": cyc.get("share_of_cycles"),
+                              "frac_busy": round(wave_insts * cyc["avg_cycles_per_valu"] / (1024 * first_s * 2.4e9), 4) if wave_insts and cyc.get("avg_cycles_per_valu") else None,
+                              "model_stale": cyc.get("stale"), "source": "profiles/valu_cycle_model.json, profiles/r03_ubench_valu_rate.txt"},
+            "counters_stale": counters_stale,
+            "traffic": first_rec.get("hbm_bytes_per_launch"),
+            "algorithmic_bytes_per_launch": round(out_bytes, 1), "avg_launch_ms": round(first_s * 1e3, 5), "launches_per_step": n_first / steps,
+            "valu_lane_instructions_per_path": round(wave_insts * 64 / paths_per_launch, 1) if wave_insts else None,
+            "path_bounces_per_launch": round(acc["n_bounces"] / max(n_first, 1), 1),
+            "hbm_view": {"what": "the same launch against the HBM roofline: it only writes its outputs (%d B per path); the %d B per path-bounce of the "
+                                 "wavefront pipeline no longer exist" % (8 + 8 + 16 * k_off, per_bounce),
+                         "achieved_GBs": round(out_bytes / first_s / 1e9, 1), "frac": round(out_bytes / first_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "state_stream_avoided_GBs": round(per_bounce * (acc["n_bounces"] - acc["n_paths"]) / max(n_first, 1) / first_s / 1e9, 1)},
+            "survey_model": survey_model, "stages": stages,
+        }
+    else:
+        shade_lanes = acc["n_bounces"] - acc["inline_bounces"]   # lanes entering the bounce-kernel launches
+        shade_s = (acc["ms_shade"] - acc["ms_first"]) * 1e-3
+        kernel_bytes = per_bounce * shade_lanes
+        kernel_name = "k_shade<MODE 1 = fused: shade + occlusion + next closest hit>" if fused else "k_shade<MODE 0>"
+        achieved = kernel_bytes / max(shade_s, 1e-12) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("k_shade", {}).get("hbm_bytes_per_launch"),
+            "algorithmic_bytes_per_launch": round(kernel_bytes / max(bounce_launches, 1), 1),
+            "algorithmic_bytes_per_path_bounce": per_bounce,
+            "path_bounces_per_launch": round(shade_lanes / max(bounce_launches, 1), 1),
+            "avg_launch_ms": round(shade_s * 1e3 / max(bounce_launches, 1), 5), "launches_per_step": bounce_launches / steps,
+            "survey_model": survey_model, "stages": stages,
+        }
+    return roofline
 
 
 def main():
@@ -306,7 +434,14 @@ def main():
         if dist.get_world_size() != args.gpus:
             raise SystemExit("process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
         dist.barrier()            # rank 0 may just have written the scene files
-    ctx = dict(mi=mi, D=D, dev=dev, world=world, rank=rank, share=share)
+    # DTOF_BENCH_FORCE_EXCHANGE=1 (development, one GPU): a one-rank RCCL process group, and the frame loop issues its gather / reduce calls as an N > 1 run does --
+    # the stream ordering of clear -> render -> collective -> develop is then exercised on the real backend; the image checksum must equal the plain run's
+    force_exchange = world == 1 and os.environ.get("DTOF_BENCH_FORCE_EXCHANGE") == "1"
+    if force_exchange:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        backend = "nccl (one rank, forced exchange)"
+    ctx = dict(mi=mi, D=D, dev=dev, world=world, rank=rank, share=share, force_exchange=force_exchange)
 
     r = run_workload(ctx, args.config, args.scaling, args.steps, args.warmup, args.sharding, args.stripe_rows,
                      spp_override=args.spp_given, res_override=args.res_given, scene_override=args.scene_given)
@@ -321,144 +456,44 @@ def main():
             e = run_workload(ctx, "c2", other, max(5, args.steps // 2), 2, "bands", args.stripe_rows)
             extra["c2_" + other] = {"value": round(e["value"], 2), "unit": "Mpaths/s", "scaling": other, "ms_per_step": round(e["ms_per_step"], 4),
                                      "ms_per_step_min": round(e["ms_per_step_min"], 4), "spp_total": e["spp"], "paths_per_step": e["total_paths"]}
-        if world == 1 and r.get("pipelined"):   # the same workload through the loop the multi-rank runs use (one host synchronisation per step): the N = 1 figure to hold N > 1 against
-            os.environ["DTOF_BENCH_SYNC"] = "1"
-            try:
-                e = run_workload(ctx, "c2", args.scaling, max(5, args.steps // 2), 2, "bands", args.stripe_rows)
-            finally:
-                del os.environ["DTOF_BENCH_SYNC"]
-            extra["c2_sync_loop"] = {"value": round(e["value"], 2), "unit": "Mpaths/s", "ms_per_step": round(e["ms_per_step"], 4), "ms_per_step_min": round(e["ms_per_step_min"], 4),
-                                     "what": "the headline workload with one host synchronisation per step, as every rank of an N > 1 run does it (the film exchange runs on torch's streams): "
-                                             "scaling efficiencies compare like with like against THIS figure; `value` is the pipelined loop"}
-        e = run_workload(ctx, "c4", "strong", 4, 1, "stripes", args.stripe_rows)
-        extra["c4_strong"] = {"value": round(e["value"], 2), "unit": "Mpaths/s", "scaling": "strong", "ms_per_step": round(e["ms_per_step"], 4),
-                              "ms_per_step_min": round(e["ms_per_step_min"], 4), "paths_per_step": e["total_paths"],
-                              "ms_render_rank_min": round(e["ms_render_rank_min"], 4), "ms_render_rank_max": round(e["ms_render_rank_max"], 4),
-                              "workload": "BASELINE configs[3]: domino.xml 1024x1024, 128 spp in total, rectangular low-pass, interleaved %d-row stripes, 1 film reduce"
-                                          % args.stripe_rows}
-        # BASELINE configs[4]: the K = 4 batched films (64 MB per reduce at 1024^2); fewer samples than the config's 512 so that the extra stays short -- the
-        # rate (path-offsets per second) and the reduce size are those of the full config
+        def brief(e, cfg, steps_, **more):
+            """one extra workload as it goes into the line: throughput, frame times and -- on rank 0 -- the roofline of its dominant kernel"""
+            d = {"value": round(e["value"], 2), "unit": "Mpaths/s" + (" (x %d films)" % len(e["offsets"]) if e["offsets"] else ""), "ms_per_step": round(e["ms_per_step"], 4),
+                 "ms_per_step_min": round(e["ms_per_step_min"], 4), "steps": steps_, "steps_pipelined": bool(e["pipelined"]), "paths_per_step": e["total_paths"],
+                 "ms_render_rank_min": round(e["ms_render_rank_min"], 4), "ms_render_rank_max": round(e["ms_render_rank_max"], 4)}
+            d.update(more)
+            if rank == 0:
+                rf = roofline_for(e, cfg, steps_, True)
+                d["image_checksum"] = float(np.abs(e["image"]).sum())
+                d["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "active_lane_ratio", "traffic", "algorithmic_bytes_per_launch",
+                                                        "avg_launch_ms", "launches_per_step", "counters_stale") if k in rf}
+                if isinstance(rf.get("algorithmic"), dict):
+                    d["roofline"]["frac_alg"] = rf["algorithmic"].get("frac_alg"); d["roofline"]["ops_per_path"] = rf["algorithmic"].get("ops_per_path")
+                if isinstance(rf.get("valu_busy_est"), dict):
+                    d["roofline"]["valu_busy_est"] = rf["valu_busy_est"].get("frac_busy")
+            return d
+        if world == 1:   # BASELINE configs[2]: the Cornell wall at 256 spp, antithetic_mirror time sampling, time_correlate_number 2 (4 launches of 2^24 lanes per frame)
+            e = run_workload(ctx, "c3", "strong", 40, 3, "bands", args.stripe_rows)
+            extra["c3"] = brief(e, "c3", 40, workload="BASELINE configs[2]: cornell_wall.xml 512x512, 256 spp, antithetic_mirror, correlated sampler (time_correlate_number 2)")
+        e = run_workload(ctx, "c4", "strong", 6, 1, "stripes", args.stripe_rows)
+        extra["c4_strong"] = brief(e, "c4", 6, scaling="strong",
+                                   workload="BASELINE configs[3]: domino.xml 1024x1024, 128 spp in total, rectangular low-pass, interleaved %d-row stripes, 1 film reduce" % args.stripe_rows)
+        # BASELINE configs[4]: the K = 4 batched films (64 MB per reduce at 1024^2).  At N > 1 a quarter of its samples keeps the extra short -- the rate (path-offsets
+        # per second) and the reduce size are those of the full config; at N = 1 the full 512 spp frame is timed as well
         e = run_workload(ctx, "c5", "strong", 2, 1, "stripes", args.stripe_rows, spp_override=128)
-        extra["c5_strong"] = {"value": round(e["value"], 2), "unit": "Mpaths/s (x 4 films)", "scaling": "strong", "ms_per_step": round(e["ms_per_step"], 4),
-                              "ms_per_step_min": round(e["ms_per_step_min"], 4), "paths_per_step": e["total_paths"],
-                              "ms_render_rank_min": round(e["ms_render_rank_min"], 4), "ms_render_rank_max": round(e["ms_render_rank_max"], 4),
-                              "workload": "BASELINE configs[4] at 128 of its 512 spp: domino.xml 1024x1024, trapezoidal low-pass, 4 hetero_offset films in one traversal, "
-                                          "interleaved %d-row stripes, 1 reduce of the 4 films (64 MB)" % args.stripe_rows}
+        extra["c5_strong"] = brief(e, "c5", 2, scaling="strong",
+                                   workload="BASELINE configs[4] at 128 of its 512 spp: domino.xml 1024x1024, trapezoidal low-pass, 4 hetero_offset films in one traversal, "
+                                            "interleaved %d-row stripes, 1 reduce of the 4 films (64 MB)" % args.stripe_rows)
+        if world == 1:
+            e = run_workload(ctx, "c5", "strong", 3, 1, "stripes", args.stripe_rows)
+            extra["c5_full"] = brief(e, "c5", 3, workload="BASELINE configs[4]: domino.xml 1024x1024, 512 spp, trapezoidal low-pass, 4 hetero_offset films in one traversal")
 
     acc, W, H, spp, striped, halo = r["acc"], r["W"], r["H"], r["spp"], r["striped"], r["halo"]
     total_paths, ms_per_step, value = r["total_paths"], r["ms_per_step"], r["value"]
     args.offsets, args.defines, args.scene, args.res, args.spp = r["offsets"], r["defines"], r["scene_path"], r["res"], r["spp_per_gpu"]
     if rank == 0:
         img, film_host = r["image"], r["film"]
-        # The dominant kernel.  Fused pipeline (C2): k_shade<MODE 2> generates the lanes, traces the primary rays and runs up to four
-        # iterations of the bounce loop with the path state in registers -- for C2 (max_depth 4) that is the whole path, no bounce-kernel
-        # launch is left and the kernel is bound by VALU issue, not by HBM.  Split pipeline / longer paths: the bounce kernel
-        # k_shade<MODE 1|0> streams the path state through HBM once per iteration and is priced by its algorithmic bytes.
-        n_first = acc["first_launches"]
-        fused = acc["ms_shadow"] == 0.0                          # one kernel per bounce (occlusion + next closest hit inline)
-        k_off = len(args.offsets) if args.offsets else 1
-        per_bounce = kernel_bytes_per_bounce(fused, k_off)
-        bounce_launches = acc["launches"] - n_first
-        loop_s = (acc["ms_trace"] + acc["ms_shade"] + acc["ms_shadow"]) * 1e-3
-        # Counter evidence (separate rocprofv3 --pmc passes over exactly this configuration, tools/profile_round.sh -> tools/pmc_summary.py): stamped
-        # with a hash of the kernel sources; when the sources have changed since, the figures derived from it are marked stale.
-        tfile = os.path.join(HERE, "profiles", "roofline_traffic.json")
-        pmc, counters_stale = {}, None
-        default_workload = not (args.spp_given or args.res_given or args.scene_given)
-        if os.path.exists(tfile) and default_workload:
-            try:
-                sys.path.insert(0, os.path.join(HERE, "tools"))
-                from pmc_summary import kernel_sources_sha16
-                entry = json.load(open(tfile)).get("configs", {}).get(args.config)
-                if entry:
-                    pmc = entry.get("kernels", {})
-                    counters_stale = entry.get("csrc_sha16") != kernel_sources_sha16(HERE)
-            except Exception:
-                pmc = {}
-        # Algorithmic work of one path (profiles/algorithmic_ops.json, tools/algorithmic_ops.py): arithmetic the oracle executes for the path logic
-        # (exact basic-block counts) + the primitive work of the product's own traversal counters, one op per arithmetic instruction
-        alg = {}
-        afile = os.path.join(HERE, "profiles", "algorithmic_ops.json")
-        if os.path.exists(afile) and default_workload:
-            try:
-                alg = json.load(open(afile)).get(args.config, {})
-            except Exception:
-                alg = {}
-        # Issue-rate model (profiles/valu_cycle_model.json, tools/valu_cycle_model.py): only a subset of the VALU instruction forms issues at the 2 cycles
-        # per wave64 instruction the peak assumes (measured: profiles/r03_ubench_valu_rate.txt); the kernel's static instruction mix priced with the
-        # measured rates gives the average cycles one of ITS instructions occupies a SIMD for
-        cyc = {}
-        cfile = os.path.join(HERE, "profiles", "valu_cycle_model.json")
-        if os.path.exists(cfile) and default_workload:
-            try:
-                sys.path.insert(0, os.path.join(HERE, "tools"))
-                from pmc_summary import kernel_sources_sha16
-                cdoc = json.load(open(cfile))
-                cyc = dict(cdoc.get("configs", {}).get(args.config, {}), stale=cdoc.get("csrc_sha16") != kernel_sources_sha16(HERE))
-            except Exception:
-                cyc = {}
-        stages = {"ms_first_bounce": round(acc["ms_first"] / args.steps, 4),
-                  "ms_trace": round(acc["ms_trace"] / args.steps, 4), "ms_shade": round(acc["ms_shade"] / args.steps, 4),
-                  "ms_shadow": round(acc["ms_shadow"] / args.steps, 4), "ms_generate": round(acc["ms_generate"] / args.steps, 4),
-                  "ms_splat": round(acc["ms_splat"] / args.steps, 4)}
-        survey_model = {"what": "SURVEY 8(d): 412 B per path-bounce over ALL loop kernels (trace+shade+shadow time)", "bytes_per_path_bounce": B_BOUNCE,
-                        "achieved": round(B_BOUNCE * acc["n_bounces"] / max(loop_s, 1e-12) / 1e9, 1),
-                        "frac": round(B_BOUNCE * acc["n_bounces"] / max(loop_s, 1e-12) / 1e9 / HBM_PEAK_GBS, 4)}
-        if n_first and bounce_launches == 0:
-            # every iteration ran inside the first-bounce kernel: VALU-issue roofline (256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions per second,
-            # /opt/skills/guides/MI355X_MICROARCH.md "Wave scheduling"); executed instructions from the SQ_INSTS_VALU pass under profiles/
-            first_s = acc["ms_first"] * 1e-3 / max(n_first, 1)                       # average launch
-            paths_per_launch = acc["n_paths"] / max(n_first, 1)
-            out_bytes = (8 + 8 + 16 * k_off) * paths_per_launch                       # sample position, stream selectors, result
-            firsts = sorted((k for k in pmc if k.startswith("k_shade_first")), key=lambda k: -pmc[k].get("valu_wave_insts_per_launch", 0))
-            first_rec = pmc[firsts[0]] if firsts else {}
-            wave_insts = first_rec.get("valu_wave_insts_per_launch")
-            valu_peak = 256 * 4 * 32 * 2.4e9 / 1e12                                   # T lane-instructions / s
-            achieved = (wave_insts * 64 / first_s / 1e12) if wave_insts else None
-            ops_path = alg.get("ops_per_path")
-            alg_achieved = ops_path * paths_per_launch / first_s / 1e12 if ops_path else None
-            roofline = {
-                "bound": "valu", "kernel": "k_shade<MODE 2: lane generation + primary ray + ALL %d bounce iterations, path state in registers>%s" % (
-                    round(acc["launches_equiv"] / max(n_first, 1)), " [%s]" % first_rec.get("symbol", "") if first_rec else ""),
-                "achieved": round(achieved, 2) if achieved else None, "peak": round(valu_peak, 1), "unit": "T lane-instr/s",
-                "frac": round(achieved / valu_peak, 4) if achieved else None,
-                "what": "achieved / frac: EXECUTED VALU wave-instructions x 64 lanes (issue slots, idle lanes included) per second against the issue peak; "
-                        "algorithmic: the arithmetic one path needs (oracle + traversal counters) per second against the same peak; active_lane_ratio: share of the issued lane slots that held an active lane",
-                "algorithmic": {"ops_per_path": ops_path, "achieved": round(alg_achieved, 2) if alg_achieved else None, "unit": "T ops/s",
-                                "frac_alg": round(alg_achieved / valu_peak, 4) if alg_achieved else None, "source": alg.get("source"), "breakdown": alg.get("breakdown")},
-                "active_lane_ratio": first_rec.get("active_lane_ratio"),
-                "valu_busy_est": {"what": "share of the launch during which the VALU pipes are occupied: executed VALU wave-instructions x the average cycles one "
-                                          "instruction of THIS kernel's mix holds a SIMD (2.25 / 4.1 / 8.2 nominal cycles by instruction form, measured on this GPU) "
-                                          "over 1024 SIMDs x launch time x 2.4 GHz; frac prices every instruction at 2 cycles",
-                                  "avg_cycles_per_valu_instruction": cyc.get("avg_cycles_per_valu"), "share_of_cycles": cyc.get("share_of_cycles"),
-                                  "frac_busy": round(wave_insts * cyc["avg_cycles_per_valu"] / (1024 * first_s * 2.4e9), 4) if wave_insts and cyc.get("avg_cycles_per_valu") else None,
-                                  "model_stale": cyc.get("stale"), "source": "profiles/valu_cycle_model.json, profiles/r03_ubench_valu_rate.txt"},
-                "counters_stale": counters_stale,
-                "traffic": first_rec.get("hbm_bytes_per_launch"),
-                "algorithmic_bytes_per_launch": round(out_bytes, 1), "avg_launch_ms": round(first_s * 1e3, 5), "launches_per_step": n_first / args.steps,
-                "valu_lane_instructions_per_path": round(wave_insts * 64 / paths_per_launch, 1) if wave_insts else None,
-                "path_bounces_per_launch": round(acc["n_bounces"] / max(n_first, 1), 1),
-                "hbm_view": {"what": "the same launch against the HBM roofline: it only writes its outputs (%d B per path); the %d B per path-bounce of the "
-                                     "wavefront pipeline no longer exist" % (8 + 8 + 16 * k_off, per_bounce),
-                             "achieved_GBs": round(out_bytes / first_s / 1e9, 1), "frac": round(out_bytes / first_s / 1e9 / HBM_PEAK_GBS, 4),
-                             "state_stream_avoided_GBs": round(per_bounce * (acc["n_bounces"] - acc["n_paths"]) / max(n_first, 1) / first_s / 1e9, 1)},
-                "survey_model": survey_model, "stages": stages,
-            }
-        else:
-            shade_lanes = acc["n_bounces"] - acc["inline_bounces"]   # lanes entering the bounce-kernel launches
-            shade_s = (acc["ms_shade"] - acc["ms_first"]) * 1e-3
-            kernel_bytes = per_bounce * shade_lanes
-            kernel_name = "k_shade<MODE 1 = fused: shade + occlusion + next closest hit>" if fused else "k_shade<MODE 0>"
-            achieved = kernel_bytes / max(shade_s, 1e-12) / 1e9
-            roofline = {
-                "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("k_shade", {}).get("hbm_bytes_per_launch"),
-                "algorithmic_bytes_per_launch": round(kernel_bytes / max(bounce_launches, 1), 1),
-                "algorithmic_bytes_per_path_bounce": per_bounce,
-                "path_bounces_per_launch": round(shade_lanes / max(bounce_launches, 1), 1),
-                "avg_launch_ms": round(shade_s * 1e3 / max(bounce_launches, 1), 5), "launches_per_step": bounce_launches / args.steps,
-                "survey_model": survey_model, "stages": stages,
-            }
+        roofline = roofline_for(r, args.config, args.steps, not (args.spp_given or args.res_given or args.scene_given))
         out = {
             "metric": "Mpaths/s (whole node), Doppler Cornell 512x512 64spp" if args.config == "c2" else
                       "Mpaths/s (whole node), BASELINE config %s" % args.config, "value": round(value, 2), "unit": "Mpaths/s",
@@ -497,7 +532,7 @@ def main():
                                      "what": "developed image rows of the benchmark frame, GPU vs CPU oracle, same seed; rel_linf_px = SURVEY 8(d): "
                                              "max_px |gpu - ref| / max(|ref_px|, 1e-3 max|ref|); rel_linf = the same difference over max|ref|"}
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_exchange:
         dist.destroy_process_group()
 
 

@@ -89,11 +89,6 @@ typedef struct {
      * FOUR floats per pixel, and the device-film calls (dtof_render_rows / _stripes) accumulate the alpha film -- (A, 0, 0, W) -- as one more RGBW plane
      * behind the n_offsets colour films of `d_film_rgbw`. */
     int32_t  has_alpha;
-    /* How the fused pipeline runs the iterations after the first for this scene (measured on the first batch rendered; results are bit-identical either way):
-     * 0 not measured yet, 1 inline -- the first-bounce kernel keeps going with the path state in registers (closed scenes) --, 2 compacted -- one launch per
-     * iteration over the lanes whose continuation ray hit something (open scenes); survivors_after_first = that share of the lanes after the first iteration. */
-    int32_t  inline_choice;
-    float    survivors_after_first;
 } dtof_scene_info;
 /* What Film::crop_size / Sampler::sample_count / the plugins' to_string() report (src/films/hdrfilm.cpp:235-279, src/render/sampler.cpp:13-14,
  * src/integrators/dopplertofpath.cpp:315-328), plus the sizes of the packed scene. */
@@ -193,6 +188,14 @@ int dtof_async_collect(dtof_scene *scene, dtof_render_stats *sum, double *frame_
  * ranks is the full frame, lane for lane what a single device renders. */
 int dtof_render_stripes(dtof_scene *scene, uint32_t seed, uint32_t spp, int32_t first_row, int32_t stripe_rows, int32_t stripe_period,
                         const float *offsets, int n_offsets, float *d_film_rgbw, dtof_render_stats *stats);
+/* The stream the library enqueues on.  By default every scene owns one; a caller that has work of its own to order against the renders -- the film exchange of
+ * a multi-GPU frame (torch.distributed / RCCL), torch operations on the films -- hands in ITS stream (hipStream_t; torch.cuda.current_stream().cuda_stream) and can
+ * then queue clear -> render -> exchange -> develop for many frames without a host wait in between.  NULL goes back to the scene's own stream.  The reference has
+ * no counterpart (Dr.Jit owns the one CUDA stream of a thread, drjit-core/src/init.cpp). */
+int dtof_scene_set_stream(dtof_scene *scene, void *hip_stream);
+/* dtof_render_stripes without the host synchronisation at its end (see dtof_render_rows_async). */
+int dtof_render_stripes_async(dtof_scene *scene, uint32_t seed, uint32_t spp, int32_t first_row, int32_t stripe_rows, int32_t stripe_period,
+                              const float *offsets, int n_offsets, float *d_film_rgbw);
 /* HDRFilm::develop (src/films/hdrfilm.cpp:305-406) on device buffers: rgb = RGB / (W == 0 ? 1 : W). */
 int dtof_develop(const float *d_film_rgbw, float *d_rgb, int64_t n_pixels);
 /* ... of an rgba film: rgba = (R, G, B) / W of the colour film and A / W of the alpha film (the plane behind the colour films, see dtof_scene_info::has_alpha). */

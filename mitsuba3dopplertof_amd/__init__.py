@@ -53,8 +53,7 @@ class _Info(C.Structure):
                 ("stratify_each_interval", C.c_int32), ("path_correlation_depth", C.c_uint32), ("max_depth", C.c_uint32),
                 ("rr_depth", C.c_uint32), ("base_seed", C.c_uint32), ("time_correlate_number", C.c_int32),
                 ("path_correlate_number", C.c_int32), ("bvh_stack_depth", C.c_uint32),
-                ("filter_radius", C.c_float), ("filter_halo", C.c_int32), ("has_alpha", C.c_int32),
-                ("inline_choice", C.c_int32), ("survivors_after_first", C.c_float)]
+                ("filter_radius", C.c_float), ("filter_halo", C.c_int32), ("has_alpha", C.c_int32)]
 
 
 def lib_path():
@@ -128,6 +127,8 @@ def _lib():
     L.dtof_eval_component.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_uint32]
     L.dtof_render_rows_async.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, vp, C.c_int, vp]
     L.dtof_clear_async.argtypes = [vp, vp, C.c_size_t]
+    L.dtof_scene_set_stream.argtypes = [vp, vp]
+    L.dtof_render_stripes_async.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int, vp]
     L.dtof_develop_async.argtypes = [vp, vp, vp, C.c_int64]
     L.dtof_async_collect.argtypes = [vp, vp, vp, C.c_uint32, vp]
     L.dtof_ray_intersect.argtypes = [vp, C.c_uint32, vp, vp, vp]
@@ -241,6 +242,15 @@ class Scene:
 
     def clear_async(self, d_ptr, nbytes):
         _check(_lib().dtof_clear_async(self._h, d_ptr, nbytes))
+
+    def set_stream(self, stream_ptr):
+        """enqueue on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream); 0 / None: back to the scene's own (dtof_scene_set_stream)"""
+        _check(_lib().dtof_scene_set_stream(self._h, C.c_void_p(stream_ptr or None)))
+
+    def render_stripes_async(self, d_film_ptr, seed, spp, first_row, stripe_rows, stripe_period, offsets=None):
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float32)
+        _check(_lib().dtof_render_stripes_async(self._h, seed, spp, first_row, stripe_rows, stripe_period,
+                                                None if off is None else off.ctypes.data, 0 if off is None else len(off), d_film_ptr))
 
     def develop_async(self, d_film_ptr, d_rgb_ptr, n_pixels):
         _check(_lib().dtof_develop_async(self._h, d_film_ptr, d_rgb_ptr, n_pixels))

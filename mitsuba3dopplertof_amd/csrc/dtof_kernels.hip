@@ -560,6 +560,7 @@ uint32_t resident_lds_bytes(const RenderParams &rp, const ResidentStage &residen
     return (4u * kResNodes + resident.small_words) * 16u + memo * waves * kMemoWords * kMemoStride * 4u + stack_bytes(stack_depth, waves * 64);
 }
 uint32_t device_lds_limit() {
+    if (const char *e = getenv("DTOF_LDS_LIMIT")) return (uint32_t) strtoul(e, nullptr, 10);   // tests: a smaller budget than the device's (the step-down / fallback paths)
     int dev = 0, bytes = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&bytes, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || bytes <= 0) return 64u * 1024u;
     return (uint32_t) bytes > 1024u ? (uint32_t) bytes - 1024u : 0u;   // k_shade's static LDS (count slots) comes on top of the dynamic size
@@ -571,7 +572,7 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
     if (rp.n_lanes == 0) return;
     if (first && !fused) throw std::runtime_error("the first-bounce kernel exists in the fused pipeline only");
     const bool k4 = rp.n_offsets != 1;
-    if (resident && resident->waves && fused && rp.has_tris && (!first || rp.chunk_blocks <= 1)) {
+    if (resident && resident->waves && first && fused && rp.has_tris && rp.chunk_blocks <= 1) {
         // one block of `waves` waves per CU; LDS = node planes + record block + (instance memo) + stack columns, well above the 64 KiB default limit.
         // render_rows only offers the stage with a wave count that fits; a scene that still does not (a deeper stack than it assumed) takes the classic launch below.
         const uint32_t waves = resident->waves, lds = resident_lds_bytes(rp, *resident, stack_depth, waves);
@@ -581,7 +582,7 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
             if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
             const uint32_t n_seg = nseg(rp.n_lanes), grid = std::min<uint32_t>((uint32_t) n_cu, (n_seg + waves - 1) / waves);
             const uint32_t memo = rp.memo_obj != 0xffffffffu ? 1u : 0u;
-            const ShadeLaunch L = { false, first ? 2 : 1, waves, grid, lds, s,
+            const ShadeLaunch L = { false, 2, waves, grid, lds, s,
                                     { scene, scene_bytes, 0u, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, trace_next ? 1u : 0u, dbg, n_seg, resident->small_off, resident->small_words, memo } };
             if (hipMemsetAsync(q.seg_counter, 0, 4, s) != hipSuccess) throw std::runtime_error("hipMemsetAsync(seg_counter) failed");
             if (rp.has_spec == 2) launch_shade_resident2(k4, L);

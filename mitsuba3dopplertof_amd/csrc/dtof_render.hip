@@ -12,6 +12,7 @@
 #include "dtof_math.h"
 #include <atomic>
 #include <dlfcn.h>
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <cmath>
@@ -109,11 +110,8 @@ struct dtof_scene {
     DevBuf<unsigned long long> d_sums;       // [batch][2*kMaxIter] per-iteration totals (survivors, shadow rays)
     DevBuf<uint2> d_pass_rng;                // multi-pass renders: [lane][3] stream states between the passes
     uint32_t id_shift = 24;                  // Queues::id_shift of this scene
-    // How the fused pipeline runs the iterations after the first: 0 = not measured yet, 1 = inline (the first-bounce kernel runs up to four iterations with the
-    // path state in registers: closed scenes, where nearly every path goes on), 2 = compacted (one launch per iteration over the queue of the lanes whose
-    // continuation ray hit something: open scenes).  Measured once per scene / plugin parameters on the first batch rendered (render_rows).
-    int inline_choice = 0; float survivors_after_first = -1.f;
-    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;   // stream: the library's own, or the caller's (dtof_scene_set_stream)
+    hipStream_t own_stream = nullptr;                    // what ensure_device created and the destructor destroys
     std::atomic<bool> stop { false };
     // reusable statistics plumbing (creating events / pinned memory per call costs ~0.3 ms)
     std::vector<hipEvent_t> event_pool; size_t events_used = 0;
@@ -135,7 +133,7 @@ struct dtof_scene {
         return pinned_counts;
     }
     ~dtof_scene() {
-        if (stream) (void) hipStreamDestroy(stream); if (stream2) (void) hipStreamDestroy(stream2);
+        if (own_stream) (void) hipStreamDestroy(own_stream); if (stream2) (void) hipStreamDestroy(stream2);
         for (auto e : event_pool) (void) hipEventDestroy(e);
         if (pinned_counts) (void) hipHostFree(pinned_counts);
     }
@@ -150,7 +148,8 @@ struct dtof_sampler {
 namespace {
 
 void ensure_device(dtof_scene *sc) {
-    if (!sc->stream) HIP_CHECK(hipStreamCreate(&sc->stream));
+    if (!sc->own_stream) HIP_CHECK(hipStreamCreate(&sc->own_stream));
+    if (!sc->stream) sc->stream = sc->own_stream;
     if (!sc->stream2) HIP_CHECK(hipStreamCreate(&sc->stream2));
     if (!sc->uploaded) {
         sc->d_blob.ensure(sc->blob.size());
@@ -299,12 +298,6 @@ static uint32_t *marker_array() {
 }
 #endif
 
-// fused pipeline: a scene whose first iteration leaves fewer than this share of its lanes with a hit runs one launch per iteration over compacted queues.
-// Measured on Domino (survivors 0.32; profiles/r04_compaction_ab.txt): compaction LOSES there, 40.7 against 39.8 ms -- the compacted bounce launches execute 19 % fewer
-// VALU instructions than the inline iterations but issue them at 0.64 instead of 1.14 G wave-instructions per ms: a wave of 64 live incoherent rays keeps the CU's LDS
-// and L1 paths (node planes, instance records) three times as busy as a wave with 20, and even fully packed its active-lane ratio is only 0.36 -- the idle lanes
-// of that kernel are traversal divergence, not dead paths.  The break-even lies near one full chunk of survivors per segment, hence 0.1 (DTOF_COMPACT_BELOW overrides).
-static float compact_below() { const char *e = getenv("DTOF_COMPACT_BELOW"); return e ? (float) atof(e) : 0.1f; }   // read per call: A/B runs switch it
 
 struct StageTimer {
     bool on; dtof_scene *sc; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[6];
@@ -316,7 +309,12 @@ struct StageTimer {
         ev[stage].emplace_back(a, b); HIP_CHECK(hipEventRecord(a, s));
         return (int) ev[stage].size() - 1;
     }
-    void end(int stage, int idx, hipStream_t s) { if (on) HIP_CHECK(hipEventRecord(ev[stage][idx].second, s)); if (roctx().push) roctx().pop(); }
+    void end(int stage, int idx, hipStream_t s) {
+        if (on) HIP_CHECK(hipEventRecord(ev[stage][idx].second, s));
+        if (roctx().push) roctx().pop();
+        static const bool sync_each = [] { const char *e = getenv("DTOF_SYNC_LAUNCHES"); return e && e[0] == '1'; }();   // debugging: which stage of a frame never finishes?
+        if (sync_each) { fprintf(stderr, "[dtof] %s enqueued ...", kStageNames[stage]); fflush(stderr); HIP_CHECK(hipStreamSynchronize(s)); fprintf(stderr, " done\n"); fflush(stderr); }
+    }
     double total(int stage) {
         double ms = 0;
         for (auto &p : ev[stage]) { float t = 0; HIP_CHECK(hipEventElapsedTime(&t, p.first, p.second)); ms += t; }
@@ -470,6 +468,9 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         if (fused && (env_res == 8 || env_res == 12 || env_res == 16) && rp.has_tris && !rp.has_blas && bh->n_nodes > 0 && bh->n_nodes <= kResidentNodes && blob_bytes > 16 * 1024 &&
             bh->off_shapes > bh->off_groups && bh->off_emitters > bh->off_groups && bh->off_tris > bh->off_groups && bh->off_shading >= bh->off_tris && small_bytes <= 24 * 1024) {
             resident.small_off = small_off; resident.small_words = (small_bytes + 15) / 16; resident.waves = (uint32_t) env_res;
+            // the stage must fit the CU's LDS beside the stack columns (a deep TLAS needs many): fewer waves per block while it does not, none if 8 do not either
+            const uint32_t limit = device_lds_limit();
+            while (resident.waves && resident_lds_bytes(rp, resident, stack_depth, resident.waves) > limit) resident.waves = resident.waves > 8 ? resident.waves - 4 : 0;
         }
     }
     StageTimer tm(stats != nullptr, sc);
@@ -541,20 +542,13 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             // The first-bounce kernel of the fused pipeline runs up to kMaxInline iterations of the loop itself, the path state in registers
             // (RenderParams::inline_iters; DTOF_INLINE_ITERS=1 keeps one launch per iteration).  Multi-pass renders, whose stream states must be
             // in memory between the passes, take one iteration per launch; lane dumps (dtof_sample_lanes) run the same inline kernel as renders.
-            // How many: all of them where nearly every path goes on (a closed room: the state never leaves the registers), ONE where most paths leave the scene
-            // after a bounce (Domino: a lane whose path has ended idles through the remaining inline iterations, and with it most of the wave -- active-lane
-            // ratio 0.46; compacted to the lanes that hit something, the later iterations run on a third of the waves).  Which of the two a scene is, is
-            // MEASURED on its first batch: that one runs the first iteration alone, and the share of lanes that come out of it with a hit decides
-            // (dtof_scene::inline_choice; bit-identical results either way).  DTOF_INLINE_ITERS = 1 .. 4 overrides.
-            uint32_t span = 1; bool pilot = false;
+            // (One compacted launch per iteration instead -- for open scenes, whose paths mostly leave after a bounce -- was built and measured in round 4 and lost:
+            // profiles/r04_compaction_ab.txt, tools/experiments/r04_after_hit_compaction.patch.)
+            uint32_t span = 1;
             if (first && n_passes == 1) {
                 const char *e = getenv("DTOF_INLINE_ITERS");   // read per call: tests switch it
-                const int v = e ? atoi(e) : 0;
-                uint32_t max_inline = (uint32_t) (v < 1 ? (int) kMaxInline : v > (int) kMaxInline ? (int) kMaxInline : v);
-                if (!e) {
-                    if (sc->inline_choice == 0 && rp.max_depth > 2 && !lane_dump) { pilot = true; max_inline = 1; }
-                    else if (sc->inline_choice == 2) max_inline = 1;
-                }
+                const int v = e ? atoi(e) : (int) kMaxInline;
+                const uint32_t max_inline = (uint32_t) (v < 1 ? 1 : v > (int) kMaxInline ? (int) kMaxInline : v);
                 while (span < max_inline && (it + span) < rp.max_depth && !(it + span + 1 >= rp.max_depth && skip_tail)) ++span;   // the loop head's conditions for iteration it + span
             }
             rp.inline_iters = span;
@@ -574,14 +568,6 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             const int st_shade = first ? 5 : 2;
             t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it + 1 - span, fused, next_runs, stack_depth, s, first, first && dump_now ? sc->ws.dbg.p : MARKER_OR_NULL, &resident); tm.end(st_shade, t, s);
             if (stats && first) { stats->n_launches_first++; stats->n_inline_iterations += span; batch_inline.push_back(span); }
-            if (pilot && next_runs) {   // the one measurement of this scene: lanes that left the first iteration with a hit / lanes that entered it
-                std::vector<uint32_t> alive(n_seg);
-                HIP_CHECK(hipMemcpyAsync(alive.data(), alive_out, (size_t) n_seg * 4, hipMemcpyDeviceToHost, s));
-                HIP_CHECK(hipStreamSynchronize(s));
-                uint64_t sum = 0; for (uint32_t v : alive) sum += v;
-                sc->survivors_after_first = (float) ((double) sum / (double) rp.n_lanes);
-                sc->inline_choice = sc->survivors_after_first < compact_below() ? 2 : 1;
-            }
             if (!fused) { t = tm.begin(3, s); launch_shadow(blob, blob_bytes, rp, q, shadow_out, stack_depth, s); tm.end(3, t, s); if (stats) stats->n_launches_shadow++; }
             if (stats) stats->n_launches_shade++;
             qin = qout; count_in = alive_out;
@@ -716,7 +702,7 @@ int dtof_scene_set_integrator(dtof_scene *sc, const char *plugin, const char *co
         if (!sc) throw std::runtime_error("null scene");
         PropBag b = make_bag(plugin, names, types, values, n);
         PluginParams p = make_plugin_params(b, sc->host.sampler);
-        sc->host.integrator = b; sc->pp = p; sc->inline_choice = 0;
+        sc->host.integrator = b; sc->pp = p;
     });
 }
 int dtof_scene_set_sampler(dtof_scene *sc, const char *plugin, const char *const *names, const char *types, const char *const *values, int n) {
@@ -724,7 +710,7 @@ int dtof_scene_set_sampler(dtof_scene *sc, const char *plugin, const char *const
         if (!sc) throw std::runtime_error("null scene");
         PropBag b = make_bag(plugin, names, types, values, n);
         PluginParams p = make_plugin_params(sc->host.integrator, b);
-        sc->host.sampler = b; sc->pp = p; sc->inline_choice = 0;
+        sc->host.sampler = b; sc->pp = p;
     });
 }
 
@@ -756,7 +742,6 @@ int dtof_integrator_render(const dtof_integrator *integ, const dtof_sampler_plug
         if (!integ || !sc) throw std::runtime_error("null argument");
         const PropBag &sb = smp ? smp->bag : sc->host.sampler;
         PluginParams p = make_plugin_params(integ->bag, sb);
-        if (p.max_depth != sc->pp.max_depth || p.rr_depth != sc->pp.rr_depth || p.integrator != sc->pp.integrator) sc->inline_choice = 0;
         sc->host.integrator = integ->bag; sc->host.sampler = sb; sc->pp = p;
     });
     return rc ? rc : dtof_render(sc, sensor_index, seed, spp, out_rgb, stats);
@@ -782,7 +767,6 @@ int dtof_scene_get_info(const dtof_scene *sc, dtof_scene_info *info) {
         info->filter_radius = se.filter_radius;
         info->filter_halo = se.filter == FILTER_BOX ? 0 : (int32_t) std::ceil(se.filter_radius - .5f);
         info->has_alpha = se.alpha ? 1 : 0;
-        info->inline_choice = sc->inline_choice; info->survivors_after_first = sc->survivors_after_first;
     });
 }
 
@@ -885,7 +869,29 @@ int dtof_render_rows_async(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t 
         sc->stop = false;
         dtof_render_stats local;
         sc->defer_next = true;
-        try { render_rows(sc, seed, spp, row_begin, row_end, offsets, n_offsets, d_film, &local); } catch (...) { sc->defer_next = false; throw; }
+        try { render_rows(sc, seed, spp, row_begin, row_end, offsets, n_offsets, d_film, &local); }
+        catch (...) { sc->defer_next = false; if (sc->deferred.empty()) sc->events_used = 0; throw; }   // the events the failed frame took go back to the pool
+    });
+}
+int dtof_scene_set_stream(dtof_scene *sc, void *hip_stream) {
+    return guarded([&] {
+        if (!sc) throw std::runtime_error("null scene");
+        if (!sc->deferred.empty()) throw std::runtime_error("frames are still in flight on the current stream: call dtof_async_collect first");
+        ensure_device(sc);
+        HIP_CHECK(hipStreamSynchronize(sc->stream));                       // nothing of ours is left behind on the stream we leave
+        sc->stream = hip_stream ? (hipStream_t) hip_stream : sc->own_stream;
+    });
+}
+int dtof_render_stripes_async(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t first_row, int32_t stripe_rows, int32_t stripe_period,
+                              const float *offsets, int n_offsets, float *d_film) {
+    return guarded([&] {
+        if (!sc || !d_film) throw std::runtime_error("null argument");
+        if (first_row < 0 || stripe_rows <= 0 || stripe_period < stripe_rows) throw std::runtime_error("invalid stripe layout");
+        sc->stop = false;
+        dtof_render_stats local;
+        sc->defer_next = true;
+        try { render_rows(sc, seed, spp, first_row, sc->host.sensor.crop_h, offsets, n_offsets, d_film, &local, nullptr, 0, 0, (uint32_t) stripe_rows, (uint32_t) stripe_period); }
+        catch (...) { sc->defer_next = false; if (sc->deferred.empty()) sc->events_used = 0; throw; }
     });
 }
 int dtof_clear_async(dtof_scene *sc, void *d_ptr, size_t bytes) {

@@ -7,13 +7,6 @@
 
 namespace dtof {
 
-// Debug builds (make variant NAME=markers DEFS=-DDTOF_MARKERS): every wave of k_shade leaves the number of the stage it has reached in a host-visible array
-// (ShadeArgs::dbg stands in for it in renders, see render_rows), which a watchdog thread of the library prints -- where do the waves of a hung launch sit?
-#ifdef DTOF_MARKERS
-#define DTOF_MARK(code) do { if ((threadIdx.x & 63u) == 0 && A0.dbg) { ((volatile uint32_t *) A0.dbg)[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 4095u] = (uint32_t) (code); __threadfence_system(); } } while (0)
-#else
-#define DTOF_MARK(code) do { } while (0)
-#endif
 
 // Block-wide exclusive prefix of a predicate (ballot + popcount per wave, 4 wave totals through LDS).
 // Returns this lane's slot relative to `running` and advances `running` by the block total.
@@ -72,7 +65,7 @@ template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, int SPEC, int RESW
 // -- the opposite of the K = 1 kernels, which lose 20 - 27 % at two (profiles/r03_spec_waves_ab.txt).
 __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : (MODE != 0 && MESH) ? ((SPEC && KMAX > 1) ? 2 : DTOF_MESH_WAVES) : 1) void k_shade(ShadeArgs args_by_value) {
     constexpr bool FUSED = MODE != 0, FIRST = MODE == 2;
-    static_assert(RESW == 0 || (MODE != 0 && !LDS && MESH), "the resident stage exists for the unstaged fused kernels with mesh code");
+    static_assert(RESW == 0 || (MODE == 2 && !LDS && MESH), "the resident stage exists for the unstaged fused first-bounce kernel with mesh code");
     extern __shared__ uint4 lds[];
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_inline_all[(RESW ? RESW : 1) * 2 * kMaxInline];   // FIRST: lanes alive after / shadow rays of every inline iteration but the last (statistics), per wave
@@ -180,84 +173,75 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu;
         }
     }
-    DTOF_MARK(1);
-    // iterations of the bounce loop this launch runs back to back, the path state in registers (the host sets it per launch; the split pipeline traces in kernels of its own: one)
-    const uint32_t n_inline = FUSED ? rp.inline_iters : 1u;
-    bool res_changed = false;   // the running result (rbase) differs from what q.res holds for this lane
-    if (!FIRST && in_range) {   // a bounce kernel: the lane's path state comes from the queues into the same registers the first-bounce kernel keeps it in
-        hid = q.hit_id[l];
-        ra = q.ray_a[l]; rb = q.ray_b[l]; hh = load_hit<MESH>(q, l); st = q.st_a[l];
-        const uint4 rs = q.rng_a[l]; const uint2 ri = q.rng_b[l];
-        main.state = (uint64_t) rs.x | ((uint64_t) rs.y << 32); main.inc = ((uint64_t) ri.x << 1) | 1u;
-        path.state = (uint64_t) rs.z | ((uint64_t) rs.w << 32); path.inc = ((uint64_t) ri.y << 1) | 1u;
-        if (AREA && depth0 > 0) stb_reg = q.st_b[l];
-        valid_reg = SPEC ? valid_start : depth0 > 0;
-        if (SPEC && depth0 > 0) { const float2 sc = q.st_c[l]; stc_reg = make_float2(sc.x, ((uint32_t) sc.y & 1u) ? 1.f : 0.f); valid_reg = sc.y >= 2.f; }
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) { const float4 r = q.res[(size_t) k * q.capacity + l]; rbase[k] = make_float3(r.x, r.y, r.z); }
-    }
-    // The loop: [A] a lane whose ray left the scene ends its path; [B] the others shade their hit, test their emitter sample and trace the continuation ray.
-    // [A] runs once more after the last [B] when that one traced continuation rays (fused pipeline): the lanes that leave this kernel for the next
-    // launch are then exactly the ones that HIT something -- an open scene (Domino) loses most of its paths to the sky after every bounce, and a queue
-    // compacted before the closest-hit query would carry them all into the next launch, only to drop them there.
-    DTOF_MARK(2);
+    const uint32_t n_inline = FIRST ? rp.inline_iters : 1u;
     for (uint32_t it = 0; ; ++it) {
     const uint32_t depth = depth0 + it;
-    DTOF_MARK(10 + 10 * it);
-    if (lane_on && hid == 0xffffffffu && (it < n_inline || (FUSED && trace_next_last))) {   // ---- [A] the ray left the scene: nothing validates the path any more
-        if (rp.n_passes > 1) {
+    const bool last = it + 1 >= n_inline;                 // uniform
+    const uint32_t trace_next = last ? trace_next_last : 1u;
+    alive = false; want_shadow = false;
+    if (lane_on) {
+        if (!FIRST) {
+            hid = q.hit_id[l];
+            if (hid != 0xffffffffu) {
+                ra = q.ray_a[l]; rb = q.ray_b[l]; hh = load_hit<MESH>(q, l); st = q.st_a[l];
+                const uint4 rs = q.rng_a[l]; const uint2 ri = q.rng_b[l];
+                main.state = (uint64_t) rs.x | ((uint64_t) rs.y << 32); main.inc = ((uint64_t) ri.x << 1) | 1u;
+                path.state = (uint64_t) rs.z | ((uint64_t) rs.w << 32); path.inc = ((uint64_t) ri.y << 1) | 1u;
+            }
+        }
+        if (hid == 0xffffffffu && rp.n_passes > 1) {
             // several passes: the streams are carried into the next pass, so the six draws the reference makes for EVERY lane that is
             // active at the entry of an iteration (App. A step 5; both streams advance on each, correlated.cpp:156-161) also happen
             // for the lanes whose ray misses (single-pass renders drop the state of a finished path instead)
+            if (!FIRST) {
+                const uint4 rs = q.rng_a[l]; const uint2 ri = q.rng_b[l];
+                main.state = (uint64_t) rs.x | ((uint64_t) rs.y << 32); main.inc = ((uint64_t) ri.x << 1) | 1u;
+                path.state = (uint64_t) rs.z | ((uint64_t) rs.w << 32); path.inc = ((uint64_t) ri.y << 1) | 1u;
+            }
             const bool one = rp.integrator != 0 || rp.sampler_kind != SAMPLER_CORRELATED;
             for (int k = 0; k < 6; ++k) { main.state = main.state * kPcgMult + main.inc; if (!one) path.state = path.state * kPcgMult + path.inc; }
             q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
         }
-        if (SPEC && !valid_reg && depth > 0) {   // select(valid_ray, result, 0) (:279-282): what the path gathered behind null interactions does not count
+        // valid_ray of the lane as it enters this iteration
+        const bool valid_in = FIRST ? valid_reg : (SPEC ? (depth > 0 ? q.st_c[l].y >= 2.f : valid_start) : depth > 0);
+        if (hid == 0xffffffffu) {   // the path ends here: nothing validates it any more
+            if (SPEC && !valid_in && depth > 0) {   // select(valid_ray, result, 0) (:279-282): what the path gathered behind null interactions does not count
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) rbase[k] = make_float3(0.f, 0.f, 0.f);
-            res_changed = true;
+                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
+                    if (FIRST) rbase[k] = make_float3(0.f, 0.f, 0.f); else q.res[(size_t) k * q.capacity + l] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            if (rp.want_valid) q.valid_out[l] = make_float4(valid_in ? 1.f : 0.f, 0.f, 0.f, 0.f);
         }
-        if (rp.want_valid) q.valid_out[l] = make_float4(valid_reg ? 1.f : 0.f, 0.f, 0.f, 0.f);
-        if (SPEC && rp.has_env && valid_reg) {
-            // si.emitter(scene) of a ray that left the scene is the environment (dopplertofpath.cpp:150-168).  DirectionSample(scene, si, prev_si)
+        if (SPEC && hid == 0xffffffffu && rp.has_env && valid_in) {
+            // The ray left the scene: si.emitter(scene) is the environment (dopplertofpath.cpp:150-168).  DirectionSample(scene, si, prev_si)
             // points along the ray; ConstantBackgroundEmitter::pdf_direction is the uniform-sphere density (constant.cpp:150-155).  A path that
             // is not valid here (hidden emitters, and nothing but null interactions so far -- a primary ray above all) returns 0 whatever it adds
             // (valid_ray, :101-102,279-282).
+            const float4 stv = FIRST ? st : q.st_a[l];
+            const float time_ = FIRST ? ra.w : q.ray_a[l].w;
             float prev_pdf = 1.f; bool pdelta = true;
-            if (depth > 0) { prev_pdf = stb_reg.w; pdelta = stc_reg.y != 0.f; }
+            if (depth > 0) { prev_pdf = FIRST ? stb_reg.w : q.st_b[l].w; pdelta = FIRST ? stc_reg.y != 0.f : ((uint32_t) q.st_c[l].y & 1u) != 0u; }
             const DEmitter &env = sv.emitters[rp.env_index];
             const bool is_map = env.kind == EMITTER_ENVMAP;   // EnvironmentMapEmitter::pdf_direction / eval (envmap.cpp:408-425,299-310) with ds.d = -si.wi = the ray direction
-            const V3 rd = mk(rb.x, rb.y, rb.z);
+            const V3 rd = FIRST ? mk(rb.x, rb.y, rb.z) : [&] { const float4 b4 = q.ray_b[l]; return mk(b4.x, b4.y, b4.z); }();
             const float em_pdf = pdelta ? 0.f : (is_map ? env_pdf_direction(sv.base, env, rd) : kInvFourPi) * (1.f / (float) sv.n_emitters);
             const float mis_bsdf = mis_weight(prev_pdf, em_pdf);
             const V3 le = prev_pdf > 0.f ? (is_map ? env_eval(sv.base, env, rd) : mk(env.intensity[0], env.intensity[1], env.intensity[2])) : mk(0, 0, 0);
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
                 V3 v = le * mis_bsdf;
-                if (rp.integrator == 0) v = v * modulation_weight(rp, rp.phase[k], ra.w, st.w);
-                rbase[k] = make_float3(fmaf(st.x, v.x, rbase[k].x), fmaf(st.y, v.y, rbase[k].y), fmaf(st.z, v.z, rbase[k].z));
+                if (rp.integrator == 0) v = v * modulation_weight(rp, rp.phase[k], time_, stv.w);
+                const float4 r = FIRST ? make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f) : q.res[(size_t) k * q.capacity + l];
+                const float4 acc = make_float4(fmaf(stv.x, v.x, r.x), fmaf(stv.y, v.y, r.y), fmaf(stv.z, v.z, r.z), 0.f);
+                if (FIRST) rbase[k] = make_float3(acc.x, acc.y, acc.z); else q.res[(size_t) k * q.capacity + l] = acc;
             }
-            res_changed = true;
         }
-        lane_on = false;
-    }
-    if (FIRST && it > 0 && it < n_inline) {   // statistics: the lanes that went on from inline iteration it - 1 (one wave per block / per segment)
-        const uint32_t n_on = (uint32_t) __popcll(__ballot(lane_on));
-        if (lane_id == 0) s_inline[2 * (it - 1)] += n_on;
-    }
-    DTOF_MARK(11 + 10 * it);
-    if (it >= n_inline) break;
-    const bool last = it + 1 >= n_inline;                 // uniform
-    const uint32_t trace_next = last ? trace_next_last : 1u;
-    alive = false; want_shadow = false;
-    if (lane_on) {
-        const bool valid_in = valid_reg;   // valid_ray of the lane as it enters this iteration
-        {   // ---- [B] a miss ended the path above (active_next = false, dopplertofpath.cpp:171)
+        if (hid != 0xffffffffu) {   // a miss ends the path (active_next = false, dopplertofpath.cpp:171)
             V3 o = mk(ra.x, ra.y, ra.z), d = mk(rb.x, rb.y, rb.z); float time = ra.w;
             V3 thr = mk(st.x, st.y, st.z); float path_length = st.w;
             float eta_path = 1.f; bool prev_delta = depth == 0;   // dopplertofpath.cpp:103-108: eta = 1, prev_bsdf_delta = true
-            if (SPEC && depth > 0) { eta_path = stc_reg.x; prev_delta = stc_reg.y != 0.f; }
+            if (SPEC && depth > 0) { const float2 sc = FIRST ? stc_reg : q.st_c[l]; eta_path = sc.x; prev_delta = FIRST ? sc.y != 0.f : ((uint32_t) sc.y & 1u) != 0u; }
             bool correlate = (depth + 1) < rp.path_correlation_depth;
             const bool plain = rp.integrator != 0;   // `path`: no modulation weight
             const bool single = plain || rp.sampler_kind != SAMPLER_CORRELATED;   // main stream only (path.cpp:197,213-214,273; sampler.h:141-144)
@@ -266,8 +250,8 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             bool active_next = depth + 1 < rp.max_depth;
 
             Surface si;
-            if (!FIRST && it == 0 && have_memo) instance_memo_fill(sv, time, memo_m, memo_inv);
-            if (it > 0 && have_memo) {   // a ray's time does not change along its path: the inverse filled at generation still sits in the LDS column
+            if (!FIRST && have_memo) instance_memo_fill(sv, time, memo_m, memo_inv);
+            if (FIRST && it > 0 && have_memo) {   // a ray's time does not change along its path: the inverse filled at generation still sits in the LDS column
                 instance_matrix(sv.objects[sv.memo_obj], time, memo_m); instance_memo_load(sv, memo_inv);
             }
             compute_surface<MESH>(sv, hid & ((1u << q.id_shift) - 1u), hid >> q.id_shift, hh.w, t, u2f(hh.y), u2f(hh.z), o, d, time, si, have_memo, memo_m, memo_inv);
@@ -279,9 +263,9 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             float4 rcur[KMAX];
             if (AREA) {
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) rcur[k] = make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f);
+                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) rcur[k] = FIRST ? make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f) : q.res[(size_t) k * q.capacity + l];
                 if (sh->flags & SF_EMITTER) {
-                    float4 pb = depth > 0 ? stb_reg : make_float4(0.f, 0.f, 0.f, 1.f);   // prev_si.p, prev_bsdf_pdf
+                    float4 pb = depth > 0 ? (FIRST ? stb_reg : q.st_b[l]) : make_float4(0.f, 0.f, 0.f, 1.f);   // prev_si.p, prev_bsdf_pdf
                     V3 rel = si.p - mk(pb.x, pb.y, pb.z);                      // DirectionSample(scene, si, prev_si), records.h:173-180
                     float dist = norm(rel);
                     V3 dsd = rel * rcp(dist);
@@ -679,7 +663,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                 bool nonzero = false;
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
-                    float4 r = AREA ? rcur[k] : make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f);
+                    float4 r = AREA ? rcur[k] : (FIRST ? make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f) : q.res[(size_t) k * q.capacity + l]);
                     V3 v = mk(bsdf_val.x * em_weight.x * mis_em, bsdf_val.y * em_weight.y * mis_em, bsdf_val.z * em_weight.z * mis_em);
                     if (!plain) { float lw = modulation_weight(rp, rp.phase[k], time, path_length + ds_dist); v = v * lw; }
                     float3 c = make_float3(fmaf(thr.x, v.x, r.x), fmaf(thr.y, v.y, r.y), fmaf(thr.z, v.z, r.z));
@@ -690,8 +674,10 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             }
             if (res_dirty) {   // the emitter-hit term stands whether or not the NEE candidate is later committed
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) rbase[k] = make_float3(rcur[k].x, rcur[k].y, rcur[k].z);
-                res_changed = true;
+                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
+                    if (FIRST) rbase[k] = make_float3(rcur[k].x, rcur[k].y, rcur[k].z);
+                    else q.res[(size_t) k * q.capacity + l] = rcur[k];
+                }
             }
             // ---- continuation (dopplertofpath.cpp:232-276)
             V3 nd = vfma(si.sh_n, bs_wo.z, vfma(si.sh_t, bs_wo.y, si.sh_s * bs_wo.x));   // Frame::to_world
@@ -713,22 +699,36 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             if (SPEC && ends && !valid_now) {   // select(valid_ray, result, 0) (:279-282): neither the emitter-hit term nor this vertex's NEE candidate survives
                 want_shadow = false;
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) rbase[k] = make_float3(0.f, 0.f, 0.f);
-                res_changed = true;
+                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
+                    if (FIRST) rbase[k] = make_float3(0.f, 0.f, 0.f); else q.res[(size_t) k * q.capacity + l] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
             if (ends && rp.want_valid) q.valid_out[l] = make_float4(valid_now ? 1.f : 0.f, 0.f, 0.f, 0.f);
-            valid_reg = valid_now;
+            if (FIRST) valid_reg = valid_now;
             if (alive) {
                 nra = make_float4(no.x, no.y, no.z, time); nrb = make_float4(nd.x, nd.y, nd.z, kLargest);
                 const float4 sta = make_float4(thr.x, thr.y, thr.z, path_length), stb = make_float4(si.p.x, si.p.y, si.p.z, bs_pdf);
                 const float2 stc = make_float2(eta, bs_delta ? 1.f : 0.f);
-                st = sta; stb_reg = stb; stc_reg = stc;   // throughput | path length, prev_si | prev_bsdf_pdf (:256-257), eta | prev_bsdf_delta (:252,258): they leave for the queues behind the loop
+                if ((!FIRST || last) && trace_next) {   // the state leaves for the queues (an inline iteration keeps it in registers; after the last iteration of the loop nobody reads it)
+                    q.ray_a[l] = nra;
+                    q.ray_b[l] = nrb;
+                    q.st_a[l] = sta;
+                    if (AREA) q.st_b[l] = stb;   // prev_si, prev_bsdf_pdf (:256-257)
+                    if (SPEC) q.st_c[l] = make_float2(stc.x, stc.y + (valid_now ? 2.f : 0.f));   // eta, prev_bsdf_delta (:252,258) | valid_ray << 1
+                }
+                if (FIRST) { st = sta; stb_reg = stb; stc_reg = stc; }
             }
-            if (!alive && rp.n_passes > 1)   // several passes: the state of a finished path is what its lane starts the next pass with
+            if ((alive && (!FIRST || last) && trace_next) || rp.n_passes > 1)   // several passes: the state of a finished path is what its lane starts the next pass with
                 q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
         }
     }
-    DTOF_MARK(12 + 10 * it);
+    if (last) {
+        uint32_t slot = block_append(alive, s_cnt, n_alive);
+        if (alive && trace_next) qout[seg * kSeg + slot] = l;
+    } else {   // FIRST, one wave per block
+        const uint32_t n_on = (uint32_t) __popcll(__ballot(alive));
+        if (lane_id == 0) s_inline[2 * it] += n_on;
+    }
     if (FUSED) {
         bool commit = false;
         if (want_shadow) {   // test_visibility (scene.cpp:266-271): an unoccluded sample commits its candidate result
@@ -740,11 +740,15 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                           : !trace_scene<true, MESH, true, RESW != 0>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
 #endif
         }
-        DTOF_MARK(13 + 10 * it);
-        if (commit) {   // the running result stays in rbase; it is written behind the loop
+        if (FIRST) {   // the running result stays in rbase over the inline iterations; every lane's result is defined after the last (nothing zeroed it)
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) rbase[k] = cand[k];
-            res_changed = true;
+            for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
+                if (commit) rbase[k] = cand[k];
+                if (last && in_range) q.res[(size_t) k * q.capacity + l] = make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f);
+            }
+        } else if (commit) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) q.res[(size_t) k * q.capacity + l] = make_float4(cand[k].x, cand[k].y, cand[k].z, 0.f);
         }
         if (alive && trace_next) {   // closest hit of the continuation ray, consumed by the next bounce
             Hit h;
@@ -754,9 +758,9 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h)
                               : trace_scene<false, MESH, true, RESW != 0>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
 #endif
-            hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim); hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu;   // [A] looks at it at the top of the loop
+            if (!FIRST || last) store_hit<MESH>(q, l, h, found);
+            if (FIRST) { hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim); hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu; }
         }
-        DTOF_MARK(14 + 10 * it);
         const uint32_t n_sh = (uint32_t) __popcll(__ballot(want_shadow)) * ((threadIdx.x & 63) == 0 ? 1u : 0u);   // per-wave partial (stats only)
         if (last) n_shadow += n_sh; else if (lane_id == 0) s_inline[2 * it + 1] += n_sh;
     } else {
@@ -768,28 +772,12 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                 q.sh_c[(size_t) k * q.capacity + sslot] = make_float4(cand[k].x, cand[k].y, cand[k].z, u2f(l));
         }
     }
-    // the continuation ray and its closest hit become the lane's current ray (st / stb / stc were set where the bounce computed them); a lane whose path
-    // ended sits out the remaining iterations
+    if (last) break;
+    // next inline iteration: the continuation ray and its closest hit become the lane's current ray (st / stb / stc were set where the
+    // bounce computed them); a lane whose path ended sits out the remaining iterations
     lane_on = alive;
     if (alive) { ra = nra; rb = nrb; }
-    }   // iterations
-    DTOF_MARK(90);
-    {   // the lanes that go on to the next launch: compacted to the front of the segment's queue, their state to the queues
-        const uint32_t slot = block_append(lane_on, s_cnt, n_alive);
-        if (lane_on && trace_next_last) {
-            qout[seg * kSeg + slot] = l;
-            q.ray_a[l] = ra; q.ray_b[l] = rb; q.st_a[l] = st;
-            if (AREA) q.st_b[l] = stb_reg;
-            if (SPEC) q.st_c[l] = make_float2(stc_reg.x, stc_reg.y + (valid_reg ? 2.f : 0.f));   // eta, prev_bsdf_delta | valid_ray << 1
-            q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
-            if (FUSED) { if (MESH) q.hit[l] = hh; else q.hit_t[l] = u2f(hh.x); q.hit_id[l] = hid; }   // the closest hit the next bounce starts from
-        }
-        if (in_range && (FIRST || res_changed)) {
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) q.res[(size_t) k * q.capacity + l] = make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f);
-        }
-    }
-    DTOF_MARK(91);
+    }   // inline iterations
     }   // chunk loop
     }   // count != 0
     if (FUSED && kShadeBlock > 64) {   // shadow-ray count for the statistics: sum the four per-wave partials
@@ -826,27 +814,24 @@ static void launch_shade_variant(const ShadeLaunch &L) {
 // the resident form of the fused first-bounce kernel: `waves` waves per block, one block per CU.  Its dynamic LDS lies above the 64 KiB a kernel gets
 // without asking: hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE, so the high-water mark is kept per device ordinal (dtof-render drives
 // one host thread per GPU in one process).
-template <int MODE, bool A, int K, int S, int W>
+template <bool A, int K, int S, int W>
 static void launch_resident_waves(const ShadeLaunch &L) {
     static std::atomic<uint32_t> attr_lds[64];
     int dev = 0; (void) hipGetDevice(&dev);
     std::atomic<uint32_t> &mark = attr_lds[(unsigned) dev & 63u];
     if (L.lds > mark.load()) {
-        if (hipFuncSetAttribute((const void *) k_shade<false, MODE, A, K, true, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) L.lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *) k_shade<false, 2, A, K, true, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) L.lds) != hipSuccess)
             throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
         mark.store(L.lds);
     }
-    hipLaunchKernelGGL((k_shade<false, MODE, A, K, true, S, W>), dim3(L.grid), dim3(W * 64), L.lds, L.stream, L.args);
+    hipLaunchKernelGGL((k_shade<false, 2, A, K, true, S, W>), dim3(L.grid), dim3(W * 64), L.lds, L.stream, L.args);
 }
 template <bool A, int K, int S>
 static void launch_resident_variant(const ShadeLaunch &L) {
-    // mode 2: the first-bounce kernel; mode 1: the bounce kernel over the compacted queue of the launch before (open scenes, see render_rows)
-#define DTOF_RES_MODE(W_) do { if (L.mode == 2) launch_resident_waves<2, A, K, S, W_>(L); else launch_resident_waves<1, A, K, S, W_>(L); } while (0)
-    if (L.waves == 16) DTOF_RES_MODE(16);
-    else if (L.waves == 12) DTOF_RES_MODE(12);
-    else if (L.waves == 8) DTOF_RES_MODE(8);
+    if (L.waves == 16) launch_resident_waves<A, K, S, 16>(L);
+    else if (L.waves == 12) launch_resident_waves<A, K, S, 12>(L);
+    else if (L.waves == 8) launch_resident_waves<A, K, S, 8>(L);
     else throw std::runtime_error("resident stage: 8, 12 or 16 waves per block");
-#undef DTOF_RES_MODE
 }
 
 }  // namespace dtof

@@ -82,11 +82,11 @@ def overlap_add_stacked(stack, height, world, halo):
     return full.reshape((world * n,) + tuple(stack.shape[2:]))[:height]
 
 
-def gather_film_stacked(slab, rank, world, group=None, out=None):
-    """gather_film into one preallocated [world, ...] tensor on rank 0 (returned; None on the other ranks)"""
+def gather_film_stacked(slab, rank, world, group=None, out=None, force=False):
+    """gather_film into one preallocated [world, ...] tensor on rank 0 (returned; None on the other ranks).  force: issue the collective for one rank as well."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return slab.unsqueeze(0)
     if slab.is_cuda and dist.get_backend(group) == "gloo":
         parts = gather_film(slab, rank, world, group)

@@ -1153,3 +1153,37 @@ def test_resident_stage_with_the_every_bsdf_kernels(mi, orc, monkeypatch, varian
                 assert np.abs(batch[k_] - single).max() <= 1e-5 * max(float(np.abs(single).max()), 1e-30), (variant, res_waves, off)
     finally:
         os.remove(path)
+
+
+@pytest.mark.gpu
+def test_resident_stage_gives_way_to_a_deep_tlas(mi, orc, monkeypatch):
+    """the resident first-bounce stage needs LDS for its stack columns (depth x 1 024 words at 16 waves); a scene it is otherwise eligible for (blob above
+    the whole-blob staging limit, at most 1 024 nodes, small records) but whose TLAS is deep must step down in waves or take the classic launch -- not fail.
+    Instances of one cube whose size and spacing grow geometrically: the SAH build peels them off one by one."""
+    cubes = "".join('<shape type="instance"><ref id="g"/><transform name="to_world"><scale value="%.6g"/><translate x="%.6g" y="%.6g" z="0"/></transform></shape>'
+                    % (0.4 * 1.45 ** k, 2.2 * 1.45 ** k, 0.4 * 1.45 ** k) for k in range(110))
+    cubes += "".join('<shape type="instance"><ref id="g"/><animation name="to_world"><transform time="0"><scale value="0.1"/><translate x="%.4f" y="0.1" z="%.4f"/></transform>'
+                     '<transform time="0.0015"><scale value="0.1"/><translate x="%.4f" y="0.12" z="%.4f"/></transform></animation></shape>'
+                     % (-3 + 0.05 * k, -1 - 0.3 * (k % 7), -3 + 0.05 * k, -1 - 0.3 * (k % 7)) for k in range(100))
+    xml = ('<scene version="3.0.0"><integrator type="dopplertofpath"><integer name="max_depth" value="4"/></integrator>'
+           '<sensor type="perspective"><float name="fov" value="60"/><transform name="to_world"><lookat origin="0, 3, 9" target="2, 1, 0" up="0, 1, 0"/></transform>'
+           '<sampler type="correlated"><integer name="sample_count" value="8"/></sampler>'
+           '<film type="hdrfilm"><integer name="width" value="48"/><integer name="height" value="32"/><rfilter type="tent"/></film><float name="shutter_close" value="0.0015"/></sensor>'
+           '<shape type="shapegroup" id="g"><shape type="cube"><bsdf type="diffuse"><rgb name="reflectance" value="0.6, 0.5, 0.4"/></bsdf></shape></shape>'
+           '<shape type="rectangle"><transform name="to_world"><rotate x="1" angle="-90"/><scale value="400"/></transform><bsdf type="diffuse"/></shape>'
+           + cubes + '<emitter type="point"><point name="position" x="0" y="30" z="20"/><rgb name="intensity" value="4000"/></emitter></scene>')
+    sc, osc = mi.load_string(xml), orc.Scene(xml, {}, is_string=True)
+    info = sc.info()
+    assert info["bvh_stack_depth"] >= 24 and info["n_bvh_nodes"] <= 1024 and info["scene_blob_bytes"] > 16 * 1024, info   # 16 waves would need 64 KiB of planes + 96 KiB of stack
+    n = 48 * 32 * 8
+    ref = osc.render_lanes(osc.params(), 1, 8, 0, n, threads=NCPU)
+    for res, limit in ((None, None), ("16", None), ("0", None), (None, "120000"), (None, "70000")):   # automatic (steps down to 12 waves), 16 asked for, off, room for 8 waves only, no room at all
+        for name, value in (("DTOF_RESIDENT", res), ("DTOF_LDS_LIMIT", limit)):
+            if value is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, value)
+        g = mi.load_string(xml).sample_lanes(1, 8, 0, n)
+        assert np.array_equal(bits(g["rgb"]), bits(ref["rgb"])), (res, int((bits(g["rgb"]) != bits(ref["rgb"])).any(axis=1).sum()))
+        img = mi.load_string(xml).render(seed=1, spp=64)      # 98 304 lanes: more than one segment per wave of a resident block
+        assert np.isfinite(img).all() and np.abs(img).max() > 0
