@@ -98,6 +98,7 @@ struct LaneDebug {       // mirrors orc_lane's comparable fields
 struct ShadeArgs {
     const uint8_t *scene; uint32_t scene_bytes, stage_words; RenderParams rp; Queues q;
     const uint32_t *qin, *count_in; uint32_t *qout, *alive_out, *shadow_out; uint32_t depth, trace_next; LaneDebug *dbg;
+    float *film; uint64_t film_stride;   // first-bounce kernel whose launch covers the whole path: it splats its lanes itself (k_shade, "fused splat"); nullptr: the splat kernels do
     uint32_t n_seg, res_small_off, res_small_words, res_memo;   // resident stage (RESW != 0): segments of the batch; byte offset / uint4 count of the record block copied to LDS; 1 = the instance memo has LDS
 };
 // One launch of k_shade as launch_shade hands it to the translation unit that holds the instantiation (dtof_shade_*.hip: the ~100 instantiations of the
@@ -130,7 +131,7 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
                   const uint32_t *qin, const uint32_t *count_in, uint32_t *qout,
                   uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, bool fused, bool trace_next,
                   uint32_t stack_depth, hipStream_t s, bool first = false, LaneDebug *dbg = nullptr,   // first: generate + primary trace inline (fused only)
-                  const ResidentStage *resident = nullptr);
+                  const ResidentStage *resident = nullptr, float *film = nullptr, uint64_t film_stride = 0);   // film: the launch covers the whole path and splats its lanes itself
 void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                    const uint32_t *count_in, uint32_t stack_depth, hipStream_t s);
 void launch_velocity(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q, uint32_t stack_depth, hipStream_t s);

@@ -114,71 +114,7 @@ __global__ __launch_bounds__(kBlock) void k_velocity(const uint8_t *scene, uint3
 }
 
 // ---------------------------------------------------------------------------- splat
-DTOF_D float tent(float x, float inv_r) { return fmax_(0.f, 1.f - fabsf(x * inv_r)); }
-// ReconstructionFilter::eval: tent (tent.cpp:53-55) or gaussian (gaussian.cpp:94-96, polynomial branch)
-template <int F = -1>   // F >= 0: the filter is known at compile time (the branches fold away)
-DTOF_D float filter_weight(const RenderParams &rp, float x) {
-    const int filter = F >= 0 ? F : (int) rp.filter;
-    if (filter == FILTER_GAUSSIAN) return fmax_(estrin10(sqr(x), rp.gauss_coeff), 0.f);
-    if (filter == FILTER_MITCHELL) {   // MitchellNetravaliFilter::eval (mitchell.cpp:47-67): coefficients in ScalarFloat, Horner with fmadd
-        x = fabsf(x);
-        const float x2 = x * x, x3 = x2 * x, B = rp.filter_b, C = rp.filter_c;
-        const float a3 = (12.f - 9.f * B - 6.f * C), a2 = (-18.f + 12.f * B + 6.f * C), a0 = (6.f - 2.f * B),
-                    b3 = (-B - 6.f * C), b2 = (6.f * B + 30.f * C), b1 = (-12.f * B - 48.f * C), b0 = (8.f * B + 24.f * C);
-        const float r = (1.f / 6.f) * (x < 1.f ? fmaf(a3, x3, fmaf(a2, x2, a0)) : fmaf(b3, x3, fmaf(b2, x2, fmaf(b1, x, b0))));
-        return x < 2.f ? r : 0.f;
-    }
-    if (filter == FILTER_CATMULLROM) {   // CatmullRomFilter::eval (catmullrom.cpp:38-53): B = 0, C = 1/2, plain multiplies and adds
-        x = fabsf(x);
-        const float x2 = x * x, x3 = x2 * x, B = 0.f, C = .5f;
-        const float r = (1.f / 6.f) * (x < 1.f ? (12.f - 9.f * B - 6.f * C) * x3 + (-18.f + 12.f * B + 6.f * C) * x2 + (6.f - 2.f * B)
-                                               : (-B - 6.f * C) * x3 + (6.f * B + 30.f * C) * x2 + (-12.f * B - 48.f * C) * x + (8.f * B + 24.f * C));
-        return x < 2.f ? r : 0.f;
-    }
-    if (filter == FILTER_LANCZOS) {   // LanczosSincFilter::eval (lanczos.cpp:52-63): radius = lobes
-        x = fabsf(x);
-        const float x1 = kPi * x, x2 = x1 / rp.filter_radius;
-        float s1, s2, c; sincos_(x1, s1, c); sincos_(x2, s2, c);
-        const float result = (s1 * s2) / (x1 * x2);
-        return x < 5.9604644775390625e-8f ? 1.f : (x > rp.filter_radius ? 0.f : result);
-    }
-    return tent(x, rp.inv_radius);
-}
-// v + (v moved by the DPP control); lanes without a valid source (or in rows masked off) add 0
-template <int CTRL, int ROW_MASK = 0xf>
-DTOF_D float dpp_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-
-// Generic per-lane splat (any filter radius / any spp): direct float atomics.
-DTOF_D void splat_lane(const RenderParams &rp, float *film, float spx, float spy, int pixel_x, int pixel_y, float r, float g, float b) {
-    int W = rp.crop_w, H = rp.crop_h;
-    if (rp.filter == FILTER_BOX) {
-        // block->put(box_filter ? pos : sample_pos) (integrator.cpp:540-541): the box filter splats at the lane's own pixel
-        int x = pixel_x, y = pixel_y;
-        if ((unsigned) x < (unsigned) W && (unsigned) y < (unsigned) H) {
-            float *p = film + 4 * ((size_t) y * W + x);
-            atomicAdd(p, r); atomicAdd(p + 1, g); atomicAdd(p + 2, b); atomicAdd(p + 3, 1.f);
-        }
-        return;
-    }
-    int n = (int) ceilf(rp.filter_radius - .5f), cnt = 2 * n + 1;
-    int pix = (int) floorf(spx) - n, piy = (int) floorf(spy) - n;
-    float relx = (float) pix + .5f - spx, rely = (float) piy + .5f - spy;
-    int lx = pix - rp.crop_x, ly = piy - rp.crop_y;
-    for (int ys = 0; ys < cnt; ++ys) {
-        float wy = filter_weight(rp, rely + (float) ys);
-        for (int xs = 0; xs < cnt; ++xs) {
-            float w = filter_weight(rp, relx + (float) xs) * wy;
-            int x = lx + xs, y = ly + ys;
-            if ((unsigned) x < (unsigned) W && (unsigned) y < (unsigned) H) {
-                float *p = film + 4 * ((size_t) y * W + x);
-                atomicAdd(p, r * w); atomicAdd(p + 1, g * w); atomicAdd(p + 2, b * w); atomicAdd(p + 3, w);
-            }
-        }
-    }
-}
-
+// (tent, filter_weight, dpp_add, splat_lane: dtof_device.h -- the fused first-bounce kernel splats too)
 __global__ __launch_bounds__(kBlock) void k_splat_generic(RenderParams rp, Queues q, float *film, size_t film_stride) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= rp.n_lanes) return;
@@ -568,7 +504,7 @@ uint32_t device_lds_limit() {
 void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                   const uint32_t *qin, const uint32_t *count_in, uint32_t *qout,
                   uint32_t *alive_out, uint32_t *shadow_out, uint32_t depth, bool fused, bool trace_next,
-                  uint32_t stack_depth, hipStream_t s, bool first, LaneDebug *dbg, const ResidentStage *resident) {
+                  uint32_t stack_depth, hipStream_t s, bool first, LaneDebug *dbg, const ResidentStage *resident, float *film, uint64_t film_stride) {
     if (rp.n_lanes == 0) return;
     if (first && !fused) throw std::runtime_error("the first-bounce kernel exists in the fused pipeline only");
     const bool k4 = rp.n_offsets != 1;
@@ -583,7 +519,7 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
             const uint32_t n_seg = nseg(rp.n_lanes), grid = std::min<uint32_t>((uint32_t) n_cu, (n_seg + waves - 1) / waves);
             const uint32_t memo = rp.memo_obj != 0xffffffffu ? 1u : 0u;
             const ShadeLaunch L = { false, 2, waves, grid, lds, s,
-                                    { scene, scene_bytes, 0u, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, trace_next ? 1u : 0u, dbg, n_seg, resident->small_off, resident->small_words, memo } };
+                                    { scene, scene_bytes, 0u, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, trace_next ? 1u : 0u, dbg, film, film_stride, n_seg, resident->small_off, resident->small_words, memo } };
             if (hipMemsetAsync(q.seg_counter, 0, 4, s) != hipSuccess) throw std::runtime_error("hipMemsetAsync(seg_counter) failed");
             if (rp.has_spec == 2) launch_shade_resident2(k4, L);
             else if (rp.has_spec) launch_shade_resident1(k4, L);
@@ -595,7 +531,7 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
     const uint32_t sw = stage_words_for(scene_bytes, shade_stack), grid = nseg(rp.n_lanes) * (first && rp.chunk_blocks > 1 ? rp.chunk_blocks : 1u), lds = sw * 16 + shade_stack;
     check_lds(lds);
     const ShadeLaunch L = { sw != 0, first ? 2 : fused ? 1 : 0, 0u, grid, lds, s,
-                            { scene, scene_bytes, sw, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, trace_next ? 1u : 0u, dbg, nseg(rp.n_lanes), 0u, 0u, 0u } };
+                            { scene, scene_bytes, sw, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, trace_next ? 1u : 0u, dbg, film, film_stride, nseg(rp.n_lanes), 0u, 0u, 0u } };
     if (rp.has_spec == 2) launch_shade_spec2(k4, L);
     else if (rp.has_spec) launch_shade_spec1(k4, L);
     else if (rp.has_tris) launch_shade_mesh(rp.has_area != 0, k4, L);

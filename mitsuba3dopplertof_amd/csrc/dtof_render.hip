@@ -19,18 +19,8 @@
 #include <string>
 #include <memory>
 #include <vector>
-#ifdef DTOF_MARKERS
-#include <thread>
-#include <chrono>
-#include <map>
-#endif
 
 using namespace dtof;
-#ifdef DTOF_MARKERS
-#define MARKER_OR_NULL ((LaneDebug *) marker_array())
-#else
-#define MARKER_OR_NULL nullptr
-#endif
 
 namespace {
 
@@ -277,28 +267,6 @@ struct Roctx {
 static const Roctx &roctx() { static const Roctx r; return r; }
 static const char *const kStageNames[6] = { "dtof:generate", "dtof:trace", "dtof:shade", "dtof:shadow", "dtof:splat", "dtof:first" };
 
-#ifdef DTOF_MARKERS
-// see DTOF_MARK (dtof_shade.h): a host-visible array of per-wave stage numbers and a thread that prints their histogram every two seconds
-static uint32_t *marker_array() {
-    static uint32_t *p = [] {
-        uint32_t *m = nullptr;
-        if (hipHostMalloc((void **) &m, 4096 * 4, hipHostMallocMapped) != hipSuccess) return (uint32_t *) nullptr;
-        memset(m, 0, 4096 * 4);
-        std::thread([m] {
-            for (;;) {
-                std::this_thread::sleep_for(std::chrono::seconds(2));
-                std::map<uint32_t, int> h; for (int i = 0; i < 4096; ++i) if (m[i]) h[m[i]]++;
-                std::string line = "[markers]"; for (auto &kv : h) line += " " + std::to_string(kv.first) + ":" + std::to_string(kv.second);
-                fprintf(stderr, "%s\n", line.c_str()); fflush(stderr);
-            }
-        }).detach();
-        return m;
-    }();
-    return p;
-}
-#endif
-
-
 struct StageTimer {
     bool on; dtof_scene *sc; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[6];
     StageTimer(bool enabled, dtof_scene *scene) : on(enabled), sc(scene) { if (sc->deferred.empty()) sc->events_used = 0; }   // the events of uncollected frames stay taken
@@ -425,6 +393,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     for (auto &sh : sc->host.shapes) rp.has_spec |= sh.bsdf != BSDF_DIFFUSE || sh.masked || sh.tex_normal >= 0 || sh.blend_other;
     for (auto &e : sc->host.emitters) rp.has_spec |= e.kind == EMITTER_SPOT || e.kind == EMITTER_DIRECTIONAL;
     rp.has_spec |= !sc->host.textures.empty();
+    rp.has_spec |= se.thinlens || se.orthographic;   // the diffuse-only kernels generate perspective rays only (generate_lane<PERSPECTIVE_ONLY>)
     for (size_t ei = 0; ei < sc->host.emitters.size(); ++ei) if (sc->host.emitters[ei].kind == EMITTER_CONSTANT || sc->host.emitters[ei].kind == EMITTER_ENVMAP) { rp.has_env = 1; rp.env_index = (uint32_t) ei; rp.has_spec = 1; }
     // valid_ray leaves the kernels only when somebody reads it: the alpha channel of an rgba film (integrator.cpp:528-533) and the lane dumps
     rp.want_valid = (lane_dump || se.alpha) ? 1 : 0;
@@ -497,6 +466,9 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     // channel / the lane dump's `valid` likewise depend on the hit of that iteration when max_depth is 1
     bool has_null_lobe = false;
     for (auto &sh : sc->host.shapes) has_null_lobe |= sh.masked || sh.bsdf == BSDF_THINDIELECTRIC || (sh.blend_other && sh.blend_other->bsdf == BSDF_THINDIELECTRIC);
+    static const bool env_fuse_splat = [] { const char *e = getenv("DTOF_FUSE_SPLAT"); return !(e && e[0] == '0'); }();
+    const bool fuse_splat_ok = env_fuse_splat && fused && !lane_dump && n_passes == 1 && !se.alpha && rp.filter == FILTER_TENT && rp.filter_radius <= 1.f && rp.filter_radius > .5f &&
+                               rp.spp_log2 != 0xffffffffu && rp.spp_log2 >= 6 && d_film != nullptr;
     const bool skip_tail = !has_surface_emitters && n_passes == 1 && !has_null_lobe && !rp.want_valid;
 
     // The host runs at most two batches ahead of the device: dtof_cancel (Integrator::cancel, integrator.h:96-109) is looked at when a
@@ -524,6 +496,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             if (dump_now) launch_lane_dump_rays(rp, q, sc->ws.dbg.p, s);
         }
         const uint32_t *qin = nullptr, *count_in = nullptr; uint32_t it = 0;
+        bool fused_splat_done = false;   // the first-bounce kernel of this batch splatted its lanes itself
         if (rp.integrator == INTEGRATOR_VELOCITY) { t = tm.begin(1, s); launch_velocity(blob, blob_bytes, rp, q, stack_depth, s); tm.end(1, t, s); }
         for (;; ++it) {
             if (rp.integrator == INTEGRATOR_VELOCITY) break;
@@ -561,12 +534,17 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             }
             // does iteration it+1 run?  (same conditions as the loop head)
             const bool next_runs = (it + 1 < rp.max_depth) && !(it + 2 >= rp.max_depth && skip_tail);
+            // Fused splat: the first-bounce launch covers the whole path and every wave holds the 64 samples of one pixel -- it reduces their footprint values itself
+            // and adds them to the film (k_shade; tent filter with a 3 x 3 footprint, power-of-two spp >= 64, one pass, no alpha film, no lane dump).  The result then
+            // never goes through q.res / q.pos and k_splat_x8's round trip through HBM.  DTOF_FUSE_SPLAT=0 keeps the splat kernel (A/B).
+            const bool splat_here = first && !next_runs && fuse_splat_ok && rp.chunk_blocks <= kChunkBlocks;
             if (!fused || (it == 0 && !first)) { t = tm.begin(1, s); launch_trace(blob, blob_bytes, rp, q, qin, count_in, stack_depth, s); tm.end(1, t, s); if (stats) stats->n_launches_trace++; }
             // per-iteration count slots; beyond kMaxIter iterations (unbounded depth, paths that russian roulette keeps alive that long)
             // the slots are reused -- only the statistics lose those iterations, no path is cut short
             uint32_t *qout = q.q[it & 1], *alive_out = q.counts + (size_t) (2 * (it % kMaxIter)) * n_seg, *shadow_out = alive_out + n_seg;
             const int st_shade = first ? 5 : 2;
-            t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it + 1 - span, fused, next_runs, stack_depth, s, first, first && dump_now ? sc->ws.dbg.p : MARKER_OR_NULL, &resident); tm.end(st_shade, t, s);
+            t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it + 1 - span, fused, next_runs, stack_depth, s, first, first && dump_now ? sc->ws.dbg.p : nullptr, &resident, splat_here ? d_film : nullptr, (uint64_t) se.crop_w * se.crop_h * 4); tm.end(st_shade, t, s);
+            fused_splat_done |= splat_here;
             if (stats && first) { stats->n_launches_first++; stats->n_inline_iterations += span; batch_inline.push_back(span); }
             if (!fused) { t = tm.begin(3, s); launch_shadow(blob, blob_bytes, rp, q, shadow_out, stack_depth, s); tm.end(3, t, s); if (stats) stats->n_launches_shadow++; }
             if (stats) stats->n_launches_shade++;
@@ -577,7 +555,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             launch_lane_dump(rp, q, sc->ws.dbg.p, s);
             HIP_CHECK(hipMemcpyAsync(lane_dump + (b0 - first), sc->ws.dbg.p, (size_t) rp.n_lanes * sizeof(LaneDebug), hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
-        } else if (!lane_dump) {
+        } else if (!lane_dump && !fused_splat_done) {
             t = tm.begin(4, s); launch_splat(rp, q, d_film, se.crop_w, se.crop_h, s);
             if (se.alpha) {   // the alpha film (plane K behind the K offset films): the same splat over (valid, 0, 0) -- ImageBlock::put of aovs[3] (integrator.cpp:528-533)
                 RenderParams ra = rp; ra.n_offsets = 1;

@@ -118,6 +118,9 @@ DTOF_D PixelInfo pixel_info(const RenderParams &rp, uint32_t pix) {
 }
 // wave_pixel (uniform): see pixel_info; true only if spp is a multiple of 64 and the wave's lanes are 64 consecutive, 64-aligned lanes
 // `vlane`: the lane's position in the rendered range (what the between-pass stream states are indexed by)
+// PERSPECTIVE_ONLY: the sensor is known to be the plain perspective camera (the diffuse-only kernels: scenes with a thinlens / orthographic sensor run the every-BSDF
+// instantiations) -- the aperture draw and the two other ray constructions are not compiled in
+template <bool PERSPECTIVE_ONLY = false>
 DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane, bool wave_pixel = false, uint32_t vlane = 0) {
     // m_rng_time is only drawn from by the antithetic strategies of the correlated sampler (correlated.cpp:96-106)
     const bool needs_tm = rp.integrator == 0 && rp.sampler_kind == SAMPLER_CORRELATED && (rp.time_sampling == TIME_ANTITHETIC || rp.time_sampling == TIME_ANTITHETIC_MIRROR);
@@ -161,7 +164,7 @@ DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane, bool wav
     float spx = posx + jx, spy = posy + jy;
     float ax = fmaf(spx, rp.scale_x, rp.offset_x), ay = fmaf(spy, rp.scale_y, rp.offset_y);
     // needs_aperture_sample() (thinlens.cpp:155): a second 2-D draw of the same kind (integrator.cpp:421-423,490-492)
-    const bool lens = rp.aperture_radius != 0.f;
+    const bool lens = !PERSPECTIVE_ONLY && rp.aperture_radius != 0.f;
     float apx = .5f, apy = .5f;
     if (lens) { apx = single ? next_f32(main) : next_correlate(main, path, cp); apy = single ? next_f32(main) : next_correlate(main, path, cp); }
     float time = rp.shutter_open;
@@ -187,7 +190,7 @@ DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane, bool wav
     float iw = rcp(r3);
     V3 near_p = mk(r0 * iw, r1 * iw, r2 * iw);
     V3 d, o;
-    if (rp.orthographic) {   // OrthographicCamera::sample_ray_differential (orthographic.cpp:169-196): parallel rays from the near plane
+    if (!PERSPECTIVE_ONLY && rp.orthographic) {   // OrthographicCamera::sample_ray_differential (orthographic.cpp:169-196): parallel rays from the near plane
         if (doppler) time = time < rp.T ? time : time - rp.T;   // dopplertofpath.cpp:93
         o = xf_point(rp.cam_to_world, near_p);
         const V3 dir = normalize(xf_vector(rp.cam_to_world, mk(0.f, 0.f, 1.f)));

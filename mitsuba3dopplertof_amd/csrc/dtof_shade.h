@@ -150,17 +150,24 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     bool valid_reg = valid_start;
     float memo_m[12], memo_inv[12];   // instance memo: the one instance's matrix and inverse at this lane's ray time
     bool lane_on = in_range;
+    // the wave's 64 lanes are the 64-aligned lanes [lane_base + seg * 512 + cbase, + 64): samples of one pixel if spp is a multiple of 64
+    // ... AND the whole wave is in range: the pair swap of the correlated seeding (generate_lane) reads the partner lane, which a ragged tail
+    // (dtof_sample_lanes with an odd count) would leave inactive
+    const bool wave_pixel = FIRST && rp.spp_log2 != 0xffffffffu && rp.spp_log2 >= 6 && (rp.lane_base & 63u) == 0 && count - cbase >= (uint32_t) kShadeBlock;
+    // Fused splat (uniform): this launch runs the whole path of its lanes (nobody continues) and the host handed in the film -- the wave reduces the footprint
+    // values of its 64 samples itself and issues the film atomics, the result never goes through q.res / q.pos and the splat kernel's round trip through HBM
+    const bool fuse_splat = FIRST && A.film != nullptr;
+    float2 pos_reg = make_float2(0.f, 0.f);
     if (in_range) {
         l = qin ? qin[seg * kSeg + j] : seg * kSeg + j;
         if (FIRST) {
-            // the wave's 64 lanes are the 64-aligned lanes [lane_base + seg * 512 + cbase, + 64): samples of one pixel if spp is a multiple of 64
-            // ... AND the whole wave is in range: the pair swap of the correlated seeding (generate_lane) reads the partner lane, which a ragged tail
-            // (dtof_sample_lanes with an odd count) would leave inactive
-            const bool wave_pixel = rp.spp_log2 != 0xffffffffu && rp.spp_log2 >= 6 && (rp.lane_base & 63u) == 0 && count - cbase >= (uint32_t) kShadeBlock;
-            const PrimaryLane pl = generate_lane(rp, global_lane(rp, rp.lane_base + l), wave_pixel, rp.lane_base + l);
+            const PrimaryLane pl = generate_lane<SPEC == 0>(rp, global_lane(rp, rp.lane_base + l), wave_pixel, rp.lane_base + l);
             ra = pl.ray_a; rb = pl.ray_b; main = pl.main; path = pl.path; st = make_float4(1.f, 1.f, 1.f, 0.f);
-            q.pos[l] = pl.pos;
-            q.rng_b[l] = make_uint2((uint32_t) (main.inc >> 1), (uint32_t) (path.inc >> 1));
+            pos_reg = pl.pos;
+            if (!fuse_splat) {   // what the later launches (stream selectors) and the splat kernels (sample position) read
+                q.pos[l] = pl.pos;
+                q.rng_b[l] = make_uint2((uint32_t) (main.inc >> 1), (uint32_t) (path.inc >> 1));
+            }
             if (dbg) {
                 LaneDebug &o = dbg[l];
                 o.time = ra.w; o.ray_o[0] = ra.x; o.ray_o[1] = ra.y; o.ray_o[2] = ra.z; o.ray_d[0] = rb.x; o.ray_d[1] = rb.y; o.ray_d[2] = rb.z;
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                 if (ne > 1) { float scaled = e1 * (float) ne; idx = (uint32_t) scaled; if (idx > ne - 1) idx = ne - 1; em_w = (float) ne; sx = scaled - (float) idx; }
                 const DEmitter &em = sv.emitters[idx];
                 V3 dsp, dd; bool em_active = true;
-                if (em.kind == EMITTER_POINT) {
+                if ((!AREA && !SPEC) || em.kind == EMITTER_POINT) {   // scenes without surface emitters that run the diffuse-only kernels have point lights only (render_rows)
                     dsp = mk(em.pos[0], em.pos[1], em.pos[2]);
                     dd = dsp - si.p;
                     float dist2 = dot(dd, dd), inv_dist = rsqrt_(dist2);
@@ -744,7 +751,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
                 if (commit) rbase[k] = cand[k];
-                if (last && in_range) q.res[(size_t) k * q.capacity + l] = make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f);
+                if (last && in_range && !fuse_splat) q.res[(size_t) k * q.capacity + l] = make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f);
             }
         } else if (commit) {
 #pragma unroll
@@ -778,6 +785,42 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     lane_on = alive;
     if (alive) { ra = nra; rb = nrb; }
     }   // inline iterations
+    if (FIRST && fuse_splat) {   // ---- ImageBlock::put (imageblock.cpp:414-531) of the wave's samples: tent filter of radius <= 1, a 3 x 3 footprint anchored at the sample's pixel
+        const uint32_t W = (uint32_t) rp.crop_w;
+        const uint32_t pix = fdiv(global_lane(rp, rp.lane_base + l), rp.d_spp);
+        const int py = (int) fdiv(pix, rp.d_w), px = (int) (pix - W * (uint32_t) py);
+        const float sx = pos_reg.x, sy = pos_reg.y;
+        const bool regular = in_range && (int) floorf(sx) - rp.crop_x == px && (int) floorf(sy) - rp.crop_y == py;   // (rarely a float position rounds up into the next pixel)
+        if (wave_pixel) {   // one pixel per wave: 36 footprint sums over the 64 lanes, lane L < 36 ends up with sum L and adds it to the film
+            const int upx = __builtin_amdgcn_readfirstlane(px), upy = __builtin_amdgcn_readfirstlane(py);
+            const float relx = (float) (upx + rp.crop_x - 1) + .5f - sx, rely = (float) (upy + rp.crop_y - 1) + .5f - sy;
+            float wx[3], wy[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { wx[a] = regular ? tent(relx + (float) a, rp.inv_radius) : 0.f; wy[a] = tent(rely + (float) a, rp.inv_radius); }
+            const uint32_t tap = lane_id >> 2, ch = lane_id & 3u;
+            const int fx = upx - 1 + (int) (tap % 3u), fy = upy - 1 + (int) (tap / 3u);
+            const bool store = lane_id < 36u && (unsigned) fx < W && (unsigned) fy < (unsigned) rp.crop_h;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
+                float *fk = A.film + (size_t) k * A.film_stride;
+                if (in_range && !regular) splat_lane(rp, fk, sx, sy, px, py, rbase[k].x, rbase[k].y, rbase[k].z);
+                float v[36];
+#pragma unroll
+                for (int ys = 0; ys < 3; ++ys)
+#pragma unroll
+                    for (int xs = 0; xs < 3; ++xs) {
+                        const float w = wx[xs] * wy[ys]; const int c = 4 * (3 * ys + xs);
+                        v[c] = rbase[k].x * w; v[c + 1] = rbase[k].y * w; v[c + 2] = rbase[k].z * w; v[c + 3] = w;
+                    }
+                const float total = wave_totals_36(v, lane_id);
+                if (store && total != 0.f) atomicAdd(fk + 4 * ((size_t) fy * W + (size_t) fx) + ch, total);
+            }
+        } else if (in_range) {   // a ragged chunk: every lane by itself
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets)
+                splat_lane(rp, A.film + (size_t) k * A.film_stride, sx, sy, px, py, rbase[k].x, rbase[k].y, rbase[k].z);
+        }
+    }
     }   // chunk loop
     }   // count != 0
     if (FUSED && kShadeBlock > 64) {   // shadow-ray count for the statistics: sum the four per-wave partials
