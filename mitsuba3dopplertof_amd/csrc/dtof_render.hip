@@ -465,7 +465,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     // vertex of the last iteration sets it (dopplertofpath.cpp:252-253), which decides whether the path returns what it gathered or 0 (:279-282); the alpha
     // channel / the lane dump's `valid` likewise depend on the hit of that iteration when max_depth is 1
     bool has_null_lobe = false;
-    for (auto &sh : sc->host.shapes) has_null_lobe |= sh.masked || sh.bsdf == BSDF_THINDIELECTRIC || (sh.blend_other && sh.blend_other->bsdf == BSDF_THINDIELECTRIC);
+    for (auto &sh : sc->host.shapes) has_null_lobe |= sh.masked || sh.bsdf == BSDF_THINDIELECTRIC || sh.bsdf == BSDF_NULL || (sh.blend_other && (sh.blend_other->bsdf == BSDF_THINDIELECTRIC || sh.blend_other->bsdf == BSDF_NULL));
     static const bool env_fuse_splat = [] { const char *e = getenv("DTOF_FUSE_SPLAT"); return !(e && e[0] == '0'); }();
     const bool fuse_splat_ok = env_fuse_splat && fused && !lane_dump && n_passes == 1 && !se.alpha && rp.filter == FILTER_TENT && rp.filter_radius <= 1.f && rp.filter_radius > .5f &&
                                rp.spp_log2 != 0xffffffffu && rp.spp_log2 >= 6 && d_film != nullptr;

@@ -23,7 +23,7 @@ enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMA
                             SF_BLEND = 1024 /* `blendbsdf` (src/bsdfs/blendbsdf.cpp): this record is bsdf_0, DShape::blend_other the record of bsdf_1 */,
                             SF_TWOSIDED2 = 2048 /* `twosided` with two nested BSDFs (twosided.cpp:75-86): this record is the front side's, DShape::blend_other the back side's */,
                             SF_TEXCOORDS = 32 /* mesh with vertex texcoords (si.uv interpolates them; otherwise si.uv = the barycentrics, mesh.cpp:720-737) */ };
-enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4, BSDF_ROUGHPLASTIC = 5, BSDF_THINDIELECTRIC = 6, BSDF_ROUGHDIELECTRIC = 7 };
+enum BsdfKind : uint32_t { BSDF_DIFFUSE = 0, BSDF_CONDUCTOR = 1, BSDF_DIELECTRIC = 2, BSDF_PLASTIC = 3, BSDF_ROUGHCONDUCTOR = 4, BSDF_ROUGHPLASTIC = 5, BSDF_THINDIELECTRIC = 6, BSDF_ROUGHDIELECTRIC = 7, BSDF_NULL = 8 /* src/bsdfs/null.cpp: every sample passes straight through */ };
 enum EmitterKind : uint32_t { EMITTER_POINT = 0, EMITTER_AREA = 1, EMITTER_SPOT = 2, EMITTER_CONSTANT = 3, EMITTER_ENVMAP = 4, EMITTER_DIRECTIONAL = 5 };
 
 // ---------------------------------------------------------------------------- device blob records

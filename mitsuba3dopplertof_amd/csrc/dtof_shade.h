@@ -495,6 +495,9 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                     const float f2 = sqr(eta_ti);
                     bsdf_weight = selected_r ? mk(hm.spec_refl[0], hm.spec_refl[1], hm.spec_refl[2])
                                              : mk(hm.spec_trans[0] * f2, hm.spec_trans[1] * f2, hm.spec_trans[2] * f2);
+                } else if (SPEC && bsh->bsdf == BSDF_NULL) {
+                    // Null::sample (null.cpp:42-66): straight on, weight 1, pdf 1, a null (and with it a delta) lobe; eval and pdf are zero (:68-79)
+                    bs_wo = mk(-si.wi.x, -si.wi.y, -si.wi.z); bs_eta = 1.f; bs_pdf = 1.f; bs_delta = true; bs_null = true; bsdf_weight = mk(1.f, 1.f, 1.f);
                 } else if (SPEC && bsh->bsdf == BSDF_THINDIELECTRIC) {
                     // ThinDielectric::sample (thindielectric.cpp:173-226): the reflectance of the slab with all internal bounces, wo = -wi
                     float r, t1, t2, t3;

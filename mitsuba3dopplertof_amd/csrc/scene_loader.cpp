@@ -975,14 +975,14 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         if (n == 2) {   // twosided.cpp:75-86: the second BSDF is the back side's
             auto other = std::make_shared<HostShape>();
             bsdf_of(*back, *other);
-            auto transmits2 = [](const HostShape &h) { return h.bsdf == BSDF_DIELECTRIC || h.bsdf == BSDF_THINDIELECTRIC || h.bsdf == BSDF_ROUGHDIELECTRIC; };
+            auto transmits2 = [](const HostShape &h) { return h.bsdf == BSDF_DIELECTRIC || h.bsdf == BSDF_THINDIELECTRIC || h.bsdf == BSDF_ROUGHDIELECTRIC || h.bsdf == BSDF_NULL; };
             if (s.blend_other || other->blend_other || s.masked || other->masked) fail("twosided: a blendbsdf or mask as one of two nested BSDFs is not supported in this build");
             if (transmits2(s) || transmits2(*other)) fail("Only materials without a transmission component can be nested!");
             s.twosided = other->twosided = true;
             s.blend_other = other; s.two_bsdfs = true;
             return;
         }
-        auto transmits = [](const HostShape &h) { return h.bsdf == BSDF_DIELECTRIC || h.bsdf == BSDF_THINDIELECTRIC || h.bsdf == BSDF_ROUGHDIELECTRIC; };
+        auto transmits = [](const HostShape &h) { return h.bsdf == BSDF_DIELECTRIC || h.bsdf == BSDF_THINDIELECTRIC || h.bsdf == BSDF_ROUGHDIELECTRIC || h.bsdf == BSDF_NULL; };   // BSDFFlags::Transmission includes Null
         if (transmits(s) || s.masked || (s.blend_other && transmits(*s.blend_other))) fail("Only materials without a transmission component can be nested!");
         s.twosided = true;
         if (s.blend_other) s.blend_other->twosided = true;   // twosided{ blendbsdf{ a, b } } flips wi / wo before either nested BSDF sees them: the same as blendbsdf{ twosided{a}, twosided{b} }
@@ -1001,6 +1001,8 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         if (int_ior < 0 || ext_ior < 0) fail("The interior and exterior indices of refraction must be positive!");
         s.bsdf = BSDF_DIELECTRIC; s.diel_eta = int_ior / ext_ior;
         s.tex_spec = reflectance_of(b, "specular_reflectance", 1.f, s.spec_refl); s.tex_trans = reflectance_of(b, "specular_transmittance", 1.f, s.spec_trans);
+    } else if (b.plugin == "null") {   // src/bsdfs/null.cpp:36-40: no parameters; one component, BSDFFlags::Null | FrontSide | BackSide
+        s.bsdf = BSDF_NULL;
     } else if (b.plugin == "thindielectric") {   // src/bsdfs/thindielectric.cpp:137-158
         const float int_ior = lookup_ior(b, "int_ior", "bk7"), ext_ior = lookup_ior(b, "ext_ior", "air");
         if (int_ior < 0 || ext_ior < 0) fail("The interior and exterior indices of refraction must be positive!");
@@ -1071,7 +1073,7 @@ static void bsdf_of(const Obj &b, HostShape &s) {
         s.spec_sampling_weight = s_mean / (d_mean + s_mean);
         s.rough_table.resize(64);
         rough_plastic_tables(s.beckmann ? MF_BECKMANN : MF_GGX, s.alpha_u, s.diel_eta, s.rough_table.data(), &s.fdr_int);       // fdr_int carries m_internal_reflectance
-    } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, plastic, roughplastic, conductor, roughconductor, dielectric, thindielectric, roughdielectric, twosided)");
+    } else fail("unsupported BSDF plugin \"" + b.plugin + "\" (supported: diffuse, plastic, roughplastic, conductor, roughconductor, dielectric, thindielectric, roughdielectric, null, twosided, mask, blendbsdf, normalmap, bumpmap)");
     auto u = b.props.unqueried();
     if (!u.empty()) fail_unreferenced(u, "bsdf", b.plugin);
     check_colors(b, { "reflectance", "diffuse_reflectance", "specular_reflectance", "specular_transmittance", "eta", "k" });
@@ -1227,10 +1229,8 @@ static HostShape make_shape(const Obj &o, bool strip_to_world, const std::string
         else fail("unsupported child <" + c.first + "> in shape");
     }
     if (bsdf) bsdf_of(*bsdf, s);   // else default diffuse: 0.5, or 0 for an emitter (src/render/shape.cpp:66-72)
-    // the integrators zero a path whose every sampled lobe was BSDFFlags::Null (valid_ray, dopplertofpath.cpp:252-253,280); the only way
-    // such a path can carry radiance is an emitter ON a thindielectric shape, and the kernels keep no valid_ray flag for that corner
+    // (an emitter on a shape whose BSDF has a null lobe -- thindielectric, null, mask -- is fine: the kernels carry the integrators' valid_ray flag since round 4)
     if (s.emitter && s.kind == SHAPE_CYLINDER) fail("cylinder: area emitters on cylinders are not supported");
-    if (s.emitter && s.bsdf == BSDF_THINDIELECTRIC) fail("an area emitter on a thindielectric shape is not supported");
     if (s.emitter && !bsdf) s.refl[0] = s.refl[1] = s.refl[2] = 0.f;   // only the DEFAULT BSDF of an emitter is black: a given one keeps its reflectance
     RawMesh raw;
     if (mesh_file) {   // src/shapes/obj.cpp:139-143, ply.cpp:160-166: `filename` through the file resolver

@@ -1631,6 +1631,9 @@ static void nested_bsdf_eval_pdf_sample(const orc_shape *sh, v3 wi_in, v3 wo, in
         bs_eta = selected_r ? 1.f : eta_it;
         if (selected_r) bsdf_weight = V(m_.spec_refl[0], m_.spec_refl[1], m_.spec_refl[2]);
         else { float f2 = f_sqr(eta_ti); bsdf_weight = V(m_.spec_trans[0] * f2, m_.spec_trans[1] * f2, m_.spec_trans[2] * f2); }
+    } else if (sh->bsdf == ORC_BSDF_NULL) {
+        /* Null::sample (src/bsdfs/null.cpp:42-66): wo = -wi, eta 1, pdf 1, weight 1, sampled_type = BSDFFlags::Null; eval / pdf are zero (:68-79) */
+        bs_wo = V(-wi_in.x, -wi_in.y, -wi_in.z); bs_eta = 1.f; bs_pdf = 1.f; bs_delta = 1; bs_null = 1; bsdf_weight = V(1.f, 1.f, 1.f);
     } else if (sh->bsdf == ORC_BSDF_THINDIELECTRIC) {
         /* ThinDielectric::sample (thindielectric.cpp:173-226); eval / pdf are zero (:228-236) */
         float r, t1, t2, t3;

@@ -927,13 +927,13 @@ def _bsdf_of(props, registry, base_dir=""):
             back = _bsdf_of(ip2, registry, base_dir)
             if rec.get("blend_other") is not None or back.get("blend_other") is not None or rec.get("masked") or back.get("masked"):
                 raise ValueError("twosided: a blendbsdf or mask as one of two nested BSDFs is not supported in this build")
-            if rec["bsdf"] in (2, 6, 7) or back["bsdf"] in (2, 6, 7):
+            if rec["bsdf"] in (2, 6, 7, 8) or back["bsdf"] in (2, 6, 7, 8):
                 raise ValueError("Only materials without a transmission component can be nested!")
             rec["twosided"] = back["twosided"] = 1
             rec["blend_other"], rec["two_bsdfs"] = back, 1
             return rec
         other = rec.get("blend_other")
-        if rec["bsdf"] in (2, 6, 7) or rec.get("masked") or (other is not None and other["bsdf"] in (2, 6, 7)):   # twosided.cpp:47-52
+        if rec["bsdf"] in (2, 6, 7, 8) or rec.get("masked") or (other is not None and other["bsdf"] in (2, 6, 7, 8)):   # twosided.cpp:47-52
             raise ValueError("Only materials without a transmission component can be nested!")
         rec["twosided"] = 1
         if other is not None:   # twosided{ blendbsdf{ a, b } } flips wi / wo before either nested BSDF sees them: the same as blendbsdf{ twosided{a}, twosided{b} }
@@ -955,6 +955,8 @@ def _bsdf_of(props, registry, base_dir=""):
             raise ValueError("The interior and exterior indices of refraction must be positive!")
         rec.update(bsdf=2, diel_eta=F32(int_ior / ext_ior), spec_refl=_color(props, "specular_reflectance", 1.0),
                    spec_trans=_color(props, "specular_transmittance", 1.0))
+    elif props.plugin == "null":   # src/bsdfs/null.cpp:36-40: no parameters
+        rec.update(bsdf=8)
     elif props.plugin == "thindielectric":   # src/bsdfs/thindielectric.cpp:137-158
         int_ior, ext_ior = _lookup_ior(props, "int_ior", "bk7"), _lookup_ior(props, "ext_ior", "air")
         if int_ior < 0 or ext_ior < 0:
@@ -1146,8 +1148,6 @@ def _shape_record(sp, registry, strip_to_world, base_dir=""):
     else:   # shape.cpp:66-72: default diffuse, reflectance 0 when the shape is an emitter
         brec = dict(twosided=0, bsdf=0, reflectance=np.array([0.0 if emitter else 0.5] * 3, dtype=F32), cond_eta=np.zeros(3, F32),
                     cond_k=np.ones(3, F32), spec_refl=np.ones(3, F32), spec_trans=np.ones(3, F32), diel_eta=F32(1.0), nonlinear=0)
-    if emitter and brec["bsdf"] == 6:   # valid_ray (dopplertofpath.cpp:252-253,280) would zero such paths; not modelled
-        raise ValueError("an area emitter on a thindielectric shape is not supported")
     twosided, refl = brec["twosided"], brec["reflectance"]
     sphere = None
     if kind == 2:   # src/shapes/sphere.cpp:121-131: center (point, default 0) and radius (default 1) on top of to_world

@@ -948,7 +948,7 @@ def _random_scene(rng, mesh_dir=None):
                   '<texture type="checkerboard" name="weight"><rgb name="color0" value="%s"/><rgb name="color1" value="%s"/><transform name="to_uv"><scale x="%s" y="%s"/></transform></texture>'
                   % (f(0, 0.5), f(0.5, 1), f(1, 4), f(1, 4)))
             return '<bsdf type="blendbsdf">%s%s%s</bsdf>' % (wt, material(nested=True), material(nested=True))
-        k = rng.choice(["diffuse", "diffuse", "conductor", "dielectric", "thindielectric", "plastic", "roughconductor", "roughdielectric", "roughplastic"])
+        k = rng.choice(["diffuse", "diffuse", "conductor", "dielectric", "thindielectric", "plastic", "roughconductor", "roughdielectric", "roughplastic", "null"])
         dist = '<string name="distribution" value="%s"/>' % rng.choice(["ggx", "beckmann"])
         refl = '<rgb name="reflectance" value="%s"/>' % rgb()
         tex = rng.random()
@@ -962,6 +962,7 @@ def _random_scene(rng, mesh_dir=None):
                 "conductor": '<bsdf type="conductor"><rgb name="eta" value="0.2, 0.9, 1.1"/><rgb name="k" value="3.9, 2.4, 2.1"/></bsdf>',
                 "dielectric": '<bsdf type="dielectric"><float name="int_ior" value="%s"/></bsdf>' % f(1.2, 1.8),
                 "thindielectric": '<bsdf type="thindielectric"/>',
+                "null": '<bsdf type="null"/>',
                 "plastic": '<bsdf type="plastic"><rgb name="diffuse_reflectance" value="%s"/></bsdf>' % rgb(),
                 "roughconductor": '<bsdf type="roughconductor"><float name="alpha" value="%s"/>%s</bsdf>' % (f(0.05, 0.5), dist),
                 "roughdielectric": '<bsdf type="roughdielectric"><float name="alpha" value="%s"/>%s</bsdf>' % (f(0.05, 0.5), dist),

@@ -1,5 +1,7 @@
 """The `mask` BSDF (src/bsdfs/mask.cpp): loader semantics on both loaders (CPU), analytic checks of the null interaction on the GPU.
 The per-lane parity of a scene full of masks is the `masked` configuration of tests/conftest.py (test_gpu_parity.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -178,3 +180,61 @@ def test_valid_ray_and_alpha_channel_match_the_oracle(mi, orc, pipeline, monkeyp
     xml = _open_scene(cases[1][0], cases[1][1], rgba)
     a = np.asarray(mi.load_string(xml).render(seed=1, spp=4096))[..., 3]
     assert np.all(a[:, 3] > 0.999) and np.all(np.abs(a[:, 0] - 0.5) < 0.05)
+
+
+# ---------------------------------------------------------------- the `null` BSDF (src/bsdfs/null.cpp) and emitters on shapes with a null lobe
+NULL_CARD = '<shape type="rectangle"><transform name="to_world"><scale value="3"/></transform><bsdf type="null"/>%s</shape>'
+
+
+def test_null_bsdf_loads_and_is_refused_inside_twosided(mi, orc):
+    xml = SCENE % (NULL_CARD % "" + SHAPE % DIFFUSE)
+    assert np.asarray(mi.load_string(xml).export(9), np.float32).reshape(-1, 24)[:, 0].tolist() == [8, 0]
+    assert [s["bsdf"] for s in orc.Scene(xml, {}, is_string=True).flat.shapes] == [8, 0]
+    for name, load in both(mi, orc):
+        with pytest.raises(Exception, match="Only materials without a transmission component can be nested"):
+            load(SCENE % (SHAPE % '<bsdf type="twosided"><bsdf type="null"/></bsdf>'))
+        with pytest.raises(Exception, match="alpha"):       # null.cpp takes no parameters: unreferenced property "alpha"
+            load(SCENE % (SHAPE % '<bsdf type="null"><float name="alpha" value="0.5"/></bsdf>'))
+
+
+def test_null_card_is_invisible_but_does_not_validate_oracle(orc):
+    """a `null` card in front of a lit wall: the camera path passes straight through (the image of the wall alone -- the card still shadows the wall from a light on
+    the camera's side, Scene::ray_test does not look at BSDFs, so the light sits behind the card here); in front of the void every lane is invalid and black,
+    and an area emitter ON the card is seen (direct emission at the card's vertex) but its lanes stay invalid -- and therefore return 0 (dopplertofpath.cpp:279-282)"""
+    integ = '<integrator type="path"><integer name="max_depth" value="3"/></integrator>'
+    back_light = '<emitter type="point"><point name="position" value="0.5, 0.5, -0.5"/><rgb name="intensity" value="10"/></emitter>'
+    wall = orc.Scene(_open_scene(integ, back_light + WALL), {}, is_string=True)
+    both_ = orc.Scene(_open_scene(integ, back_light + WALL + NULL_CARD % ""), {}, is_string=True)
+    a, b = wall.render_lanes(wall.params(), 2, 64, 0, 1024, threads=2), both_.render_lanes(both_.params(), 2, 64, 0, 1024, threads=2)
+    assert np.abs(a["rgb"]).sum() > 0 and np.array_equal(a["valid"], b["valid"])
+    # (not bit-identical radiance: the card's vertex consumes a bounce and its draws; the wall is seen one iteration later)
+    void = orc.Scene(_open_scene(integ, OPEN_LIGHT + NULL_CARD % ""), {}, is_string=True)
+    v = void.render_lanes(void.params(), 2, 64, 0, 1024, threads=2)
+    assert not v["valid"].any() and not np.abs(v["rgb"]).any()
+    lit = orc.Scene(_open_scene(integ, NULL_CARD % '<emitter type="area"><rgb name="radiance" value="2"/></emitter>'), {}, is_string=True)
+    e = lit.render_lanes(lit.params(), 2, 64, 0, 1024, threads=2)
+    assert not e["valid"].any() and not np.abs(e["rgb"]).any()      # the reference's select(valid_ray, result, 0): a glowing null card in front of nothing is black
+    seen = orc.Scene(_open_scene(integ, NULL_CARD % '<emitter type="area"><rgb name="radiance" value="2"/></emitter>' + WALL), {}, is_string=True)
+    s = seen.render_lanes(seen.params(), 2, 64, 0, 1024, threads=2)
+    assert s["valid"].all() and (s["rgb"][:, 0] >= 2.0).all()       # ... and shows as soon as something behind it validates the path
+
+
+@pytest.mark.gpu
+def test_null_bsdf_and_emitters_on_null_shapes(mi, orc):
+    """GPU = oracle bit for bit (radiance and valid_ray), both pipelines: null cards with and without emitters, a thindielectric pane that glows, a masked emitter"""
+    integ = '<integrator type="dopplertofpath"><integer name="max_depth" value="4"/></integrator>'
+    glow = '<emitter type="area"><rgb name="radiance" value="2"/></emitter>'
+    pane = '<shape type="rectangle"><transform name="to_world"><scale value="3"/></transform><bsdf type="thindielectric"/>%s</shape>'
+    bodies = [OPEN_LIGHT + NULL_CARD % "" + WALL, NULL_CARD % glow, NULL_CARD % glow + WALL, pane % glow + WALL, OPEN_LIGHT + pane % glow,
+              (VEIL % "0.4").replace("</bsdf></shape>", "</bsdf>" + glow + "</shape>") + WALL]
+    for pipeline in ("fused", "split"):
+        os.environ["DTOF_PIPELINE"] = pipeline
+        try:
+            for body in bodies:
+                xml = _open_scene(integ, body).replace('<rfilter type="box"/>', '<rfilter type="tent"/>')
+                sc, osc = mi.load_string(xml), orc.Scene(xml, {}, is_string=True)
+                g, o = sc.sample_lanes(2, 64, 0, 1024), osc.render_lanes(osc.params(), 2, 64, 0, 1024, threads=4)
+                assert np.array_equal(g["rgb"].view(np.uint32), np.ascontiguousarray(o["rgb"]).view(np.uint32)), (pipeline, body)
+                assert np.array_equal(g["valid"], o["valid"]), (pipeline, body)
+        finally:
+            os.environ.pop("DTOF_PIPELINE", None)

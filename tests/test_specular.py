@@ -373,8 +373,10 @@ def test_thindielectric_window(mi, orc, tmp_path):
     sc = mi.load_string(text)
     rec = sc.export(9).reshape(-1, 24)
     assert rec[-1, 0] == 6 and rec[-1, 1] == 0 and abs(rec[-1, 2] - 1.5) < 1e-6
-    with pytest.raises(mi.DtofError, match="area emitter on a thindielectric"):
-        mi.load_string(text.replace('<ref id="T" /></shape>', '<ref id="T" /><emitter type="area"><rgb name="radiance" value="1" /></emitter></shape>'))
+    # an area emitter ON the pane loads on both loaders (round 4: the integrators' valid_ray flag is modelled; the lanes of such a scene are held against the
+    # oracle in tests/test_mask.py::test_null_bsdf_and_emitters_on_null_shapes)
+    lit = text.replace('<ref id="T" /></shape>', '<ref id="T" /><emitter type="area"><rgb name="radiance" value="1" /></emitter></shape>')
+    assert mi.load_string(lit).info()["n_emitters"] == orc.Scene(lit, {}, is_string=True).c.n_emitters
     with pytest.raises(mi.DtofError, match="Only materials without a transmission component can be nested"):
         mi.load_string(text.replace('<bsdf type="thindielectric" id="T">', '<bsdf type="twosided" id="T"><bsdf type="thindielectric">').replace(
             '<float name="ext_ior" value="1.0" /></bsdf>', '<float name="ext_ior" value="1.0" /></bsdf></bsdf>'))
