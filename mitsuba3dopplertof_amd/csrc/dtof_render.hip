@@ -468,7 +468,8 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     for (auto &sh : sc->host.shapes) has_null_lobe |= sh.masked || sh.bsdf == BSDF_THINDIELECTRIC || sh.bsdf == BSDF_NULL || (sh.blend_other && (sh.blend_other->bsdf == BSDF_THINDIELECTRIC || sh.blend_other->bsdf == BSDF_NULL));
     static const bool env_fuse_splat = [] { const char *e = getenv("DTOF_FUSE_SPLAT"); return !(e && e[0] == '0'); }();
     const bool fuse_splat_ok = env_fuse_splat && fused && !lane_dump && n_passes == 1 && !se.alpha && rp.filter == FILTER_TENT && rp.filter_radius <= 1.f && rp.filter_radius > .5f &&
-                               rp.spp_log2 != 0xffffffffu && rp.spp_log2 >= 6 && d_film != nullptr;
+                               rp.spp_log2 == 6 && rp.n_offsets == 1 && d_film != nullptr;   // exactly one wave per pixel, one film: measured (profiles/r04_fused_splat_ab.txt) -- with more
+                               // waves per pixel (C3: 256 spp) or four films (C5) the separate splat kernel, which sums 8 samples per lane before it reduces, is faster
     const bool skip_tail = !has_surface_emitters && n_passes == 1 && !has_null_lobe && !rp.want_valid;
 
     // The host runs at most two batches ahead of the device: dtof_cancel (Integrator::cancel, integrator.h:96-109) is looked at when a
@@ -535,7 +536,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             // does iteration it+1 run?  (same conditions as the loop head)
             const bool next_runs = (it + 1 < rp.max_depth) && !(it + 2 >= rp.max_depth && skip_tail);
             // Fused splat: the first-bounce launch covers the whole path and every wave holds the 64 samples of one pixel -- it reduces their footprint values itself
-            // and adds them to the film (k_shade; tent filter with a 3 x 3 footprint, power-of-two spp >= 64, one pass, no alpha film, no lane dump).  The result then
+            // and adds them to the film (k_shade; tent filter with a 3 x 3 footprint, 64 samples per pixel, one film, one pass, no alpha film, no lane dump).  The result then
             // never goes through q.res / q.pos and k_splat_x8's round trip through HBM.  DTOF_FUSE_SPLAT=0 keeps the splat kernel (A/B).
             const bool splat_here = first && !next_runs && fuse_splat_ok && rp.chunk_blocks <= kChunkBlocks;
             if (!fused || (it == 0 && !first)) { t = tm.begin(1, s); launch_trace(blob, blob_bytes, rp, q, qin, count_in, stack_depth, s); tm.end(1, t, s); if (stats) stats->n_launches_trace++; }
