@@ -118,22 +118,27 @@ template <int S> DTOF_D float xor_lane(float v) {
     if (S == 2) return __int_as_float(__builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x141, 0xf, 0xf, false), 0x1b, 0xf, 0xf, false));
     if (S == 3) return __int_as_float(__builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x140, 0xf, 0xf, false), 0x141, 0xf, 0xf, false));
     if (S == 4) return __int_as_float(__builtin_amdgcn_ds_swizzle(x, 0x401f));
-    return __int_as_float(__builtin_amdgcn_ds_bpermute((int) ((__lane_id() ^ 32u) << 2), x));
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int) ((__lane_id() ^ 32u) << 2), x));   // (4 and 5: not used by wave_totals_36, which swaps)
 }
 // One stage of the butterfly: lanes pair up across bit S; of every two neighbouring values the lane whose bit is 0 keeps the first, its partner the second, each adding
-// what the other holds of it.  N values become (N + 1) / 2; after the six stages lane L holds the wave's total of value L (values beyond the count are zero).
-// 36 values cost 18 + 9 + 5 + 3 + 2 + 1 = 38 cross-lane adds (and twice as many selects) instead of the 36 x 6 of a reduction value by value.
+// what the other holds of it.  N values become (N + 1) / 2.  Across bit 5 and bit 4 gfx950's v_permlane32_swap / v_permlane16_swap do the exchange AND the selection
+// in one instruction (swap(a, b) = { [a.lo, b.lo], [a.hi, b.hi] }: their sum is a's total in the lower half and b's in the upper; tools/ubench/permlane_swap.hip):
+// two instructions per result, against two selects and a DPP add elsewhere -- so the two stages with the most values come first.
 template <int N, int S> DTOF_D void butterfly_stage(float *v, uint32_t lane) {
     const bool bit = (lane >> S) & 1u;
 #pragma unroll
     for (int j = 0; j < (N + 1) / 2; ++j) {
         const float a = v[2 * j], b = 2 * j + 1 < N ? v[2 * j + 1] : 0.f;
-        v[j] = (bit ? b : a) + xor_lane<S>(bit ? a : b);
+        if (S == 5 || S == 4) {
+            const auto r = S == 5 ? __builtin_amdgcn_permlane32_swap(f2u(a), f2u(b), false, false) : __builtin_amdgcn_permlane16_swap(f2u(a), f2u(b), false, false);
+            v[j] = u2f(r[0]) + u2f(r[1]);
+        } else v[j] = (bit ? b : a) + xor_lane<S>(bit ? a : b);
     }
 }
-DTOF_D float wave_totals_36(float *v, uint32_t lane) {   // -> lane L < 36: the sum of v[L] over the 64 lanes of the wave (all of them active)
-    butterfly_stage<36, 0>(v, lane); butterfly_stage<18, 1>(v, lane); butterfly_stage<9, 2>(v, lane);
-    butterfly_stage<5, 3>(v, lane); butterfly_stage<3, 4>(v, lane); butterfly_stage<2, 5>(v, lane);
+// -> the lane whose bit-reversed id (6 bits) is L < 36 holds the sum of v[L] over the 64 lanes of the wave (all of them active): value bit k is decided by lane bit 5 - k
+DTOF_D float wave_totals_36(float *v, uint32_t lane) {
+    butterfly_stage<36, 5>(v, lane); butterfly_stage<18, 4>(v, lane); butterfly_stage<9, 3>(v, lane);
+    butterfly_stage<5, 2>(v, lane); butterfly_stage<3, 1>(v, lane); butterfly_stage<2, 0>(v, lane);
     return v[0];
 }
 

@@ -800,9 +800,9 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             float wx[3], wy[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) { wx[a] = regular ? tent(relx + (float) a, rp.inv_radius) : 0.f; wy[a] = tent(rely + (float) a, rp.inv_radius); }
-            const uint32_t tap = lane_id >> 2, ch = lane_id & 3u;
+            const uint32_t sum_id = __brev(lane_id) >> 26, tap = sum_id >> 2, ch = sum_id & 3u;   // which of the 36 totals this lane ends up with (wave_totals_36)
             const int fx = upx - 1 + (int) (tap % 3u), fy = upy - 1 + (int) (tap / 3u);
-            const bool store = lane_id < 36u && (unsigned) fx < W && (unsigned) fy < (unsigned) rp.crop_h;
+            const bool store = sum_id < 36u && (unsigned) fx < W && (unsigned) fy < (unsigned) rp.crop_h;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
                 float *fk = A.film + (size_t) k * A.film_stride;
