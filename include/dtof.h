@@ -127,6 +127,10 @@ int dtof_scene_get_info(const dtof_scene *scene, dtof_scene_info *info);
  * kind 10: roughplastic tables -> per roughplastic shape the 64 values of m_external_transmittance (roughplastic.cpp:222-257)
  * Returns the number of floats written (<= capacity) through *n_written. */
 int dtof_scene_export(const dtof_scene *scene, int kind, float *out, size_t capacity, size_t *n_written);
+/* Sensor::sample_ray of the scene's sensor over arrays (src/sensors/perspective.cpp:238-279, thinlens.cpp:257-305, orthographic.cpp:169-196), through the device
+ * function the first-bounce kernel generates its primary rays with: per sample the position sample x, y in [0, 1]^2 of the crop window and the aperture sample
+ * x, y (4 floats) -> ray origin[3], direction[3], maxt (7 floats).  The ray's time is the sampler's business (render_sample, integrator.cpp:494-496). */
+int dtof_camera_rays(dtof_scene *scene, uint32_t n, const float *samples4, float *out7);
 
 /* ---------------------------------------------------------------- rendering
  * Replaces Integrator::render(Scene*, uint32_t sensor_index, uint32_t seed, uint32_t spp, bool develop,

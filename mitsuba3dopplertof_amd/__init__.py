@@ -127,6 +127,7 @@ def _lib():
     L.dtof_eval_component.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_uint32]
     L.dtof_render_rows_async.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, vp, C.c_int, vp]
     L.dtof_clear_async.argtypes = [vp, vp, C.c_size_t]
+    L.dtof_camera_rays.argtypes = [vp, C.c_uint32, vp, vp]
     L.dtof_scene_set_stream.argtypes = [vp, vp]
     L.dtof_render_stripes_async.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int, vp]
     L.dtof_develop_async.argtypes = [vp, vp, vp, C.c_int64]
@@ -275,6 +276,13 @@ class Scene:
         valid = np.zeros(n, np.uint32)
         _check(_lib().dtof_sample_lanes_valid(self._h, seed, spp, lane_begin, n, out.ctypes.data, valid.ctypes.data))
         return {"sample_pos": out[:, 0:2], "time": out[:, 2], "ray_o": out[:, 3:6], "ray_d": out[:, 6:9], "rgb": out[:, 9:12], "valid": valid}
+
+    def camera_rays(self, samples):
+        """Sensor::sample_ray over an (n, 4) array of (position sample x, y in [0, 1]^2 of the crop window, aperture sample x, y) -> (origins, directions, maxt)"""
+        s = np.ascontiguousarray(samples, np.float32).reshape(-1, 4)
+        out = np.zeros((len(s), 7), np.float32)
+        _check(_lib().dtof_camera_rays(self._h, len(s), s.ctypes.data, out.ctypes.data))
+        return out[:, 0:3], out[:, 3:6], out[:, 6]
 
     def eval_modulation(self, mode, t, length=None):
         t = np.ascontiguousarray(t, np.float32)

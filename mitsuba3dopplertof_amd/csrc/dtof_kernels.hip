@@ -727,6 +727,18 @@ __global__ void k_component(ComponentArgs a, RenderParams rp) {
         default: break;
     }
 }
+// Sensor::sample_ray over arrays (dtof_camera_rays): in = position sample x, y in [0, 1]^2 of the crop window, aperture sample x, y; out = o[3], d[3], maxt
+__global__ void k_camera_rays(RenderParams rp, const float *in, float *out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o, d; float maxt;
+    camera_ray<false>(rp, in[4 * i], in[4 * i + 1], in[4 * i + 2], in[4 * i + 3], o, d, maxt);
+    float *w = out + (size_t) i * 7;
+    w[0] = o.x; w[1] = o.y; w[2] = o.z; w[3] = d.x; w[4] = d.y; w[5] = d.z; w[6] = maxt;
+}
+void launch_camera_rays(const RenderParams &rp, const float *in, float *out, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_camera_rays, dim3(nblk(n)), dim3(kBlock), 0, s, rp, in, out, n);
+}
 void launch_component(const ComponentArgs &a, const RenderParams &rp, hipStream_t s) {
     if (a.n) hipLaunchKernelGGL(k_component, dim3(nblk(a.n)), dim3(kBlock), 0, s, a, rp);
 }

@@ -1156,6 +1156,20 @@ int dtof_eval_component(int component, const float *params, int n_params, const 
     });
 }
 
+int dtof_camera_rays(dtof_scene *sc, uint32_t n, const float *samples4, float *out7) {
+    return guarded([&] {
+        if (!sc || (n && (!samples4 || !out7))) throw std::runtime_error("null argument");
+        if (!sc->host.has_sensor) throw std::runtime_error("the scene does not contain a sensor");
+        ensure_device(sc);
+        const RenderParams rp = make_params(sc, 0, sc->pp.sample_count ? sc->pp.sample_count : 1, nullptr, 0);
+        DevBuf<float> din, dout; din.ensure((size_t) n * 4); dout.ensure((size_t) n * 7);
+        HIP_CHECK(hipMemcpy(din.p, samples4, (size_t) n * 16, hipMemcpyHostToDevice));
+        launch_camera_rays(rp, din.p, dout.p, n, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(out7, dout.p, (size_t) n * 28, hipMemcpyDeviceToHost));
+    });
+}
+
 static int ray_query(dtof_scene *sc, uint32_t n, const float *rays8, float *out19, int32_t *ids, bool any, float *uv4 = nullptr) {
     return guarded([&] {
         if (!sc || (n && (!rays8 || !ids || (!any && !out19)))) throw std::runtime_error("null argument");

@@ -118,6 +118,42 @@ DTOF_D PixelInfo pixel_info(const RenderParams &rp, uint32_t pix) {
 }
 // wave_pixel (uniform): see pixel_info; true only if spp is a multiple of 64 and the wave's lanes are 64 consecutive, 64-aligned lanes
 // `vlane`: the lane's position in the rendered range (what the between-pass stream states are indexed by)
+// Sensor::sample_ray_differential of the three sensors, without the time: (ax, ay) = the position sample in [0, 1]^2 of the crop window ("adjusted_pos",
+// integrator.cpp:486-488), (apx, apy) = the aperture sample.  PERSPECTIVE_ONLY: see generate_lane.
+template <bool PERSPECTIVE_ONLY = false>
+DTOF_D void camera_ray(const RenderParams &rp, float ax, float ay, float apx, float apy, V3 &o, V3 &dw, float &maxt) {
+    // PerspectiveCamera::sample_ray_differential (perspective.cpp:238-279)
+    const float *m = rp.s2c;
+    float r0 = fmaf(m[2], 0.f, fmaf(m[1], ay, fmaf(m[0], ax, m[3])));
+    float r1 = fmaf(m[6], 0.f, fmaf(m[5], ay, fmaf(m[4], ax, m[7])));
+    float r2 = fmaf(m[10], 0.f, fmaf(m[9], ay, fmaf(m[8], ax, m[11])));
+    float r3 = fmaf(m[14], 0.f, fmaf(m[13], ay, fmaf(m[12], ax, m[15])));
+    float iw = rcp(r3);
+    V3 near_p = mk(r0 * iw, r1 * iw, r2 * iw);
+    if (!PERSPECTIVE_ONLY && rp.orthographic) {   // OrthographicCamera::sample_ray_differential (orthographic.cpp:169-196): parallel rays from the near plane
+        o = xf_point(rp.cam_to_world, near_p);
+        dw = normalize(xf_vector(rp.cam_to_world, mk(0.f, 0.f, 1.f)));
+        maxt = rp.far_clip - rp.near_clip;
+        return;
+    }
+    const bool lens = !PERSPECTIVE_ONLY && rp.aperture_radius != 0.f;
+    V3 d;
+    if (lens) {   // ThinLensCamera::sample_ray_differential_impl (thinlens.cpp:257-305)
+        float tx, ty; concentric_disk(apx, apy, tx, ty);
+        const V3 aperture_p = mk(rp.aperture_radius * tx, rp.aperture_radius * ty, 0.f);
+        const float f_dist = rp.focus_distance / near_p.z;
+        d = normalize(near_p * f_dist - aperture_p);
+        o = xf_point(rp.cam_to_world, aperture_p);
+    } else {
+        d = normalize(near_p);
+        o = mk(rp.cam_to_world[3], rp.cam_to_world[7], rp.cam_to_world[11]);
+    }
+    dw = xf_vector(rp.cam_to_world, d);
+    float inv_z = rcp(d.z), near_t = rp.near_clip * inv_z, far_t = rp.far_clip * inv_z;
+    o = o + dw * near_t;
+    maxt = far_t - near_t;
+}
+
 // PERSPECTIVE_ONLY: the sensor is known to be the plain perspective camera (the diffuse-only kernels: scenes with a thinlens / orthographic sensor run the every-BSDF
 // instantiations) -- the aperture draw and the two other ray constructions are not compiled in
 template <bool PERSPECTIVE_ONLY = false>
@@ -181,39 +217,8 @@ DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane, bool wav
     }
     if (carried && needs_tm) carried[1] = make_uint2((uint32_t) tm.state, (uint32_t) (tm.state >> 32));
 
-    // PerspectiveCamera::sample_ray_differential (perspective.cpp:238-279)
-    const float *m = rp.s2c;
-    float r0 = fmaf(m[2], 0.f, fmaf(m[1], ay, fmaf(m[0], ax, m[3])));
-    float r1 = fmaf(m[6], 0.f, fmaf(m[5], ay, fmaf(m[4], ax, m[7])));
-    float r2 = fmaf(m[10], 0.f, fmaf(m[9], ay, fmaf(m[8], ax, m[11])));
-    float r3 = fmaf(m[14], 0.f, fmaf(m[13], ay, fmaf(m[12], ax, m[15])));
-    float iw = rcp(r3);
-    V3 near_p = mk(r0 * iw, r1 * iw, r2 * iw);
-    V3 d, o;
-    if (!PERSPECTIVE_ONLY && rp.orthographic) {   // OrthographicCamera::sample_ray_differential (orthographic.cpp:169-196): parallel rays from the near plane
-        if (doppler) time = time < rp.T ? time : time - rp.T;   // dopplertofpath.cpp:93
-        o = xf_point(rp.cam_to_world, near_p);
-        const V3 dir = normalize(xf_vector(rp.cam_to_world, mk(0.f, 0.f, 1.f)));
-        PrimaryLane po;
-        po.ray_a = make_float4(o.x, o.y, o.z, time);
-        po.ray_b = make_float4(dir.x, dir.y, dir.z, rp.far_clip - rp.near_clip);
-        po.main = main; po.path = path; po.pos = make_float2(spx, spy);
-        return po;
-    }
-    if (lens) {   // ThinLensCamera::sample_ray_differential_impl (thinlens.cpp:257-305)
-        float tx, ty; concentric_disk(apx, apy, tx, ty);
-        const V3 aperture_p = mk(rp.aperture_radius * tx, rp.aperture_radius * ty, 0.f);
-        const float f_dist = rp.focus_distance / near_p.z;
-        d = normalize(near_p * f_dist - aperture_p);
-        o = xf_point(rp.cam_to_world, aperture_p);
-    } else {
-        d = normalize(near_p);
-        o = mk(rp.cam_to_world[3], rp.cam_to_world[7], rp.cam_to_world[11]);
-    }
-    V3 dw = xf_vector(rp.cam_to_world, d);
-    float inv_z = rcp(d.z), near_t = rp.near_clip * inv_z, far_t = rp.far_clip * inv_z;
-    o = o + dw * near_t;
-    float maxt = far_t - near_t;
+    V3 o, dw; float maxt;
+    camera_ray<PERSPECTIVE_ONLY>(rp, ax, ay, apx, apy, o, dw, maxt);
     if (doppler) time = time < rp.T ? time : time - rp.T;   // dopplertofpath.cpp:93
 
     PrimaryLane pl;

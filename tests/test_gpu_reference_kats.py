@@ -70,7 +70,12 @@ class ProductBackend:
         i = sc.info()
         return dict(size=(i["film_width"], i["film_height"]), crop_size=(i["crop_width"], i["crop_height"]), crop_offset=(i["crop_x"], i["crop_y"]))
 
-    def __getattr__(self, name):       # shape_area, sphere_sample_direction, bsdf, splat, camera_ray, gauss_legendre, solve_quadratic
+    def camera_ray(self, sc, px, py, ax=.5, ay=.5):   # film position in pixels -> position sample of the crop window; the device function of the first-bounce kernel
+        i = sc.info()
+        o, d, _ = sc.camera_rays([[(np.float32(px) - i["crop_x"]) / np.float32(i["crop_width"]), (np.float32(py) - i["crop_y"]) / np.float32(i["crop_height"]), ax, ay]])
+        return o[0].copy(), d[0].copy()
+
+    def __getattr__(self, name):       # shape_area, sphere_sample_direction, bsdf, splat, gauss_legendre, solve_quadratic
         def missing(*a, **k):
             raise refkat.Skip("no C-ABI entry point for '%s' (pinned through the oracle; the kernels are lane-for-lane bit-exact with it)" % name)
         return missing
@@ -86,6 +91,7 @@ PINNED = {
     "src/core/tests/test_warp.py": 10, "src/core/tests/test_random.py": 8, "src/core/tests/test_frame.py": 3,
     "src/shapes/tests/test_rectangle.py": 15, "src/shapes/tests/test_sphere.py": 500, "src/shapes/tests/test_disk.py": 500,
     "src/shapes/tests/test_cube.py": 100, "src/shapes/tests/test_instance.py": 400, "src/shapes/tests/test_cylinder.py": 60,
+    "src/sensors/tests/test_perspective.py": 90, "src/sensors/tests/test_orthographic.py": 60, "src/sensors/tests/test_thinlens.py": 120,
 }
 
 
