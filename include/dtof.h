@@ -131,6 +131,12 @@ int dtof_scene_export(const dtof_scene *scene, int kind, float *out, size_t capa
  * function the first-bounce kernel generates its primary rays with: per sample the position sample x, y in [0, 1]^2 of the crop window and the aperture sample
  * x, y (4 floats) -> ray origin[3], direction[3], maxt (7 floats).  The ray's time is the sampler's business (render_sample, integrator.cpp:494-496). */
 int dtof_camera_rays(dtof_scene *scene, uint32_t n, const float *samples4, float *out7);
+/* BSDF::eval_pdf_sample of a shape's BSDF over arrays (src/render/bsdf.cpp:20-29; src/bsdfs/{diffuse,twosided,plastic,conductor,dielectric,thindielectric,rough*,
+ * mask,blendbsdf,normalmap,bumpmap,null}.cpp), through the very device function the shade kernels call at every path vertex.  The interaction has the flat local
+ * frame (n = sh_n = +z, dp_du = s = +x): per query wi[3], wo[3] (local), sample1, sample2[2], uv[2] (11 floats) -> value * cos(theta_o)[3], pdf(wo), the sampled
+ * direction[3], its pdf, eta, 1 if the sampled lobe is a delta lobe, weight[3], 1 if it is a null lobe (14 floats).  `shape_index` counts the scene's shapes in
+ * file order (the shapes of a shapegroup included). */
+int dtof_bsdf_eval(dtof_scene *scene, uint32_t shape_index, uint32_t n, const float *in11, float *out14);
 
 /* ---------------------------------------------------------------- rendering
  * Replaces Integrator::render(Scene*, uint32_t sensor_index, uint32_t seed, uint32_t spp, bool develop,

@@ -128,6 +128,7 @@ def _lib():
     L.dtof_render_rows_async.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, vp, C.c_int, vp]
     L.dtof_clear_async.argtypes = [vp, vp, C.c_size_t]
     L.dtof_camera_rays.argtypes = [vp, C.c_uint32, vp, vp]
+    L.dtof_bsdf_eval.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp]
     L.dtof_scene_set_stream.argtypes = [vp, vp]
     L.dtof_render_stripes_async.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int, vp]
     L.dtof_develop_async.argtypes = [vp, vp, vp, C.c_int64]
@@ -276,6 +277,13 @@ class Scene:
         valid = np.zeros(n, np.uint32)
         _check(_lib().dtof_sample_lanes_valid(self._h, seed, spp, lane_begin, n, out.ctypes.data, valid.ctypes.data))
         return {"sample_pos": out[:, 0:2], "time": out[:, 2], "ray_o": out[:, 3:6], "ray_d": out[:, 6:9], "rgb": out[:, 9:12], "valid": valid}
+
+    def bsdf_eval(self, shape_index, queries):
+        """BSDF::eval_pdf_sample of shape `shape_index` over an (n, 11) array of (wi, wo, sample1, sample2, uv) -> (n, 14): value[3], pdf, wo[3], pdf, eta, delta, weight[3], null"""
+        q = np.ascontiguousarray(queries, np.float32).reshape(-1, 11)
+        out = np.zeros((len(q), 14), np.float32)
+        _check(_lib().dtof_bsdf_eval(self._h, shape_index, len(q), q.ctypes.data, out.ctypes.data))
+        return out
 
     def camera_rays(self, samples):
         """Sensor::sample_ray over an (n, 4) array of (position sample x, y in [0, 1]^2 of the crop window, aperture sample x, y) -> (origins, directions, maxt)"""

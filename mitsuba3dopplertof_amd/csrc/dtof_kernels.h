@@ -158,6 +158,7 @@ enum { COMP_MICROFACET_EVAL = 0, COMP_MICROFACET_PDF = 1, COMP_MICROFACET_G1 = 2
        COMP_COUNT = 14 };
 struct ComponentArgs { int component; float p[8]; const float *in; int in_stride; float *out; int out_stride; uint32_t n; };
 void launch_component(const ComponentArgs &a, const RenderParams &rp, hipStream_t s);
+void launch_bsdf_eval(const uint8_t *scene, uint32_t shape_index, const float *in, float *out, uint32_t n, hipStream_t s);   // BSDF::eval_pdf_sample over arrays (dtof_shade_spec2.hip)
 void launch_camera_rays(const RenderParams &rp, const float *in, float *out, uint32_t n, hipStream_t s);   // Sensor::sample_ray over arrays (known-answer entry)
 // Scene::ray_intersect / ray_test over arrays
 void launch_ray_query(const uint8_t *scene, const float *rays, float *out, int32_t *ids, float *uv4, uint32_t n, bool any, uint32_t stack_depth, hipStream_t s);

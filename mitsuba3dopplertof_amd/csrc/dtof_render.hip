@@ -1156,6 +1156,19 @@ int dtof_eval_component(int component, const float *params, int n_params, const 
     });
 }
 
+int dtof_bsdf_eval(dtof_scene *sc, uint32_t shape_index, uint32_t n, const float *in11, float *out14) {
+    return guarded([&] {
+        if (!sc || (n && (!in11 || !out14))) throw std::runtime_error("null argument");
+        const BlobHeader *bh = (const BlobHeader *) sc->blob.data();
+        if (shape_index >= bh->n_shapes) throw std::runtime_error("shape index out of range");
+        ensure_device(sc);
+        DevBuf<float> din, dout; din.ensure((size_t) n * 11); dout.ensure((size_t) n * 14);
+        HIP_CHECK(hipMemcpy(din.p, in11, (size_t) n * 44, hipMemcpyHostToDevice));
+        launch_bsdf_eval(sc->d_blob.p, shape_index, din.p, dout.p, n, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(out14, dout.p, (size_t) n * 56, hipMemcpyDeviceToHost));
+    });
+}
 int dtof_camera_rays(dtof_scene *sc, uint32_t n, const float *samples4, float *out7) {
     return guarded([&] {
         if (!sc || (n && (!samples4 || !out7))) throw std::runtime_error("null argument");

@@ -28,6 +28,261 @@ DTOF_D uint32_t block_append(bool pred, uint32_t *s_cnt, uint32_t &running) {
     return slot;
 }
 
+// BSDF::eval_pdf_sample of the shape's BSDF (src/render/bsdf.cpp:20-29) with every adapter around it -- what one vertex of the bounce loop asks of the material:
+// value and density for the emitter direction `wo` (local frame; only when active_em) and the sampled continuation.  SPEC = 0: the diffuse-only scenes' kernels
+// (diffuse under an optional twosided); 1: every BSDF / texture / adapter; 2: ... and blendbsdf / twosided with two BSDFs (the chain in a loop over two records).
+// One function for k_shade and for the known-answer entry dtof_bsdf_eval (the reference's BSDF unit tests run against it on the GPU).
+struct BsdfOut { V3 val, weight, wo; float pdf, bs_pdf, bs_eta; bool bs_delta, bs_null; };   // bs_null: has_flag(bs.sampled_type, BSDFFlags::Null)
+template <int SPEC>
+DTOF_D void bsdf_eval_pdf_sample(const SceneView &sv, const DShape *sh, Surface &si, V3 wo, bool active_em, float sample_1, float s2x, float s2y, BsdfOut &out) {
+    // ---- the shape's BSDF.  Outermost a `mask`, if any: MaskBSDF (src/bsdfs/mask.cpp:125-163) -- with probability 1 - opacity the path goes straight on (a null
+    // interaction: wo = -wi, weight 1, pdf 1 - opacity), otherwise the nested BSDF is sampled with sample1 / opacity; eval and pdf of the nested BSDF are scaled by it.
+    const bool masked = SPEC && (sh->flags & SF_MASK);
+    bool null_pick = false; float opacity = 1.f;
+    if (masked) { opacity = mask_opacity_at(sv, sh, si.u, si.v); null_pick = !(sample_1 < opacity); sample_1 = sample_1 / opacity; }
+    // Then a `blendbsdf`, if any (src/bsdfs/blendbsdf.cpp:114-213): eval and pdf are the weighted sums of both nested BSDFs; sample1 <= weight samples bsdf_1 with
+    // sample1 / weight, otherwise bsdf_0 with (sample1 - weight) / (1 - weight), and the nested sample goes back as it is.  The chain below runs once per nested BSDF
+    // (record 0 = the shape's own, record 1 = the material-only record DShape::blend_other points at).
+    // (its own instantiations, SPEC == 2: with the chain inside a loop of run-time trip count the compiler's code for the K = 4 fused kernels gave wrong films
+    // on scenes WITHOUT any blend -- found by the random scene sweep; where SPEC != 2 the loop below has one iteration at compile time)
+    const bool blend = SPEC == 2 && (sh->flags & SF_BLEND);
+    float blend_w = 0.f; bool pick_1 = false;
+    if (blend) {
+        blend_w = sh->tex_blend ? texture_eval_1(sv, sh->tex_blend << 4, si.u, si.v) : sh->blend_weight;
+        blend_w = fmin_(fmax_(blend_w, 0.f), 1.f);   // eval_weight (:213-215)
+        pick_1 = sample_1 <= blend_w;
+    }
+    // `twosided` with two nested BSDFs (twosided.cpp:75-86,111-148): the back side (wi.z < 0) has a record of its own; the flip itself is the chain's
+    const DShape *side_sh = (SPEC == 2 && (sh->flags & SF_TWOSIDED2) && si.wi.z < 0.f) ? &sv.shapes[sh->blend_other] : sh;
+    const V3 wi_plain = si.wi, wo_plain = wo;
+    V3 bsdf_val = mk(0, 0, 0), bsdf_weight = mk(0, 0, 0), bs_wo = mk(0, 0, 0);
+    float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; bool bs_delta = false, bs_null = false;   // bs_null: has_flag(bs.sampled_type, BSDFFlags::Null)
+    V3 val_0 = mk(0, 0, 0), keep_weight = mk(0, 0, 0), keep_wo = mk(0, 0, 0); float pdf_0 = 0.f, keep_pdf = 0.f, keep_eta = 0.f; bool keep_delta = false, keep_null = false;
+    for (int pass = 0; pass < (SPEC == 2 && blend ? 2 : 1); ++pass) {
+        const DShape *bsh = pass ? &sv.shapes[sh->blend_other] : side_sh;
+        const float s1 = !blend ? sample_1 : (pass ? sample_1 / blend_w : (sample_1 - blend_w) / (1.f - blend_w));
+        si.wi = wi_plain; wo = wo_plain;
+        // ---- BSDF eval_pdf + sample (twosided.cpp:111-148,219-258; diffuse.cpp:101-125,160-180)
+        bool twosided = bsh->flags & SF_TWOSIDED;
+        // NormalMap (src/bsdfs/normalmap.cpp:110-179) around the plain BSDF, itself inside the two-sided adapter if there is one: the adapter's flip of
+        // wi.z / wo.z comes first (twosided.cpp:111-148), then wi and wo move into the frame of the normal map; the sampled direction comes back the
+        // same way.  A direction that changes sides between the two frames is a light leak: no value, no density, no weight.
+        const bool nmap = SPEC && (bsh->flags & (SF_NORMALMAP | SF_BUMPMAP));   // BumpMap (src/bsdfs/bumpmap.cpp:114-197) wraps its nested BSDF the same way
+        LocalFrame nf; V3 wo_flipped = wo; bool nm_back = false;
+        if (nmap) {
+            nf = (bsh->flags & SF_BUMPMAP) ? bumpmap_frame(sv, bsh, si) : normalmap_frame(sv, bsh, si);
+            nm_back = twosided && si.wi.z < 0.f;
+            V3 wi_f = si.wi;
+            if (nm_back) { wi_f.z = -wi_f.z; wo_flipped.z = -wo_flipped.z; }
+            si.wi = frame_to_local(nf, wi_f);
+            wo = frame_to_local(nf, wo_flipped);
+            twosided = false;
+        }
+        float wiz = si.wi.z, woz = wo.z;
+        if (twosided) { woz = mulsign(woz, wiz); wiz = fabsf(wiz); }
+        V3 refl = mk(bsh->refl[0], bsh->refl[1], bsh->refl[2]);
+        if (SPEC && (bsh->nonlinear >> 1)) refl = texture_eval(sv, (bsh->nonlinear >> 1) << 4, si.u, si.v);   // m_reflectance->eval(si)
+        HitMaterial hm;   // specular colours and roughness of this hit: constants, or the textures on those slots (SPEC instantiations only)
+        if (SPEC) hm = material_at(sv, bsh, si.u, si.v);
+        bsdf_val = mk(0, 0, 0); bsdf_weight = mk(0, 0, 0); bs_wo = mk(0, 0, 0);
+        bsdf_pdf = 0.f; bs_pdf = 0.f; bs_eta = 0.f; bs_delta = false; bs_null = false;
+        if (SPEC && bsh->bsdf == BSDF_CONDUCTOR) {
+            // SmoothConductor::sample (conductor.cpp:226-277) under TwoSidedBRDF::sample; eval / pdf of a delta lobe are zero
+            const float cos_theta_i = twosided ? fabsf(si.wi.z) : si.wi.z;
+            if (cos_theta_i > 0.f) {
+                bs_wo = mk(-si.wi.x, -si.wi.y, si.wi.z);   // reflect(wi); the two-sided flips of wi.z and wo.z cancel
+                bs_eta = 1.f; bs_pdf = 1.f; bs_delta = true;
+                bsdf_weight = mk(hm.spec_refl[0] * fresnel_conductor(cos_theta_i, bsh->cond_eta[0], bsh->cond_k[0]),
+                                 hm.spec_refl[1] * fresnel_conductor(cos_theta_i, bsh->cond_eta[1], bsh->cond_k[1]),
+                                 hm.spec_refl[2] * fresnel_conductor(cos_theta_i, bsh->cond_eta[2], bsh->cond_k[2]));
+            }
+        } else if (SPEC && bsh->bsdf == BSDF_DIELECTRIC) {
+            // SmoothDielectric::sample (dielectric.cpp:231-338), TransportMode::Radiance
+            float r_i, cos_theta_t, eta_it, eta_ti;
+            fresnel_dielectric(si.wi.z, bsh->diel_eta, r_i, cos_theta_t, eta_it, eta_ti);
+            const float t_i = 1.f - r_i;
+            const bool selected_r = s1 <= r_i;
+            bs_pdf = selected_r ? r_i : t_i; bs_delta = true;
+            bs_wo = selected_r ? mk(-si.wi.x, -si.wi.y, si.wi.z) : mk(-eta_ti * si.wi.x, -eta_ti * si.wi.y, cos_theta_t);
+            bs_eta = selected_r ? 1.f : eta_it;
+            const float f2 = sqr(eta_ti);
+            bsdf_weight = selected_r ? mk(hm.spec_refl[0], hm.spec_refl[1], hm.spec_refl[2])
+                                     : mk(hm.spec_trans[0] * f2, hm.spec_trans[1] * f2, hm.spec_trans[2] * f2);
+        } else if (SPEC && bsh->bsdf == BSDF_NULL) {
+            // Null::sample (null.cpp:42-66): straight on, weight 1, pdf 1, a null (and with it a delta) lobe; eval and pdf are zero (:68-79)
+            bs_wo = mk(-si.wi.x, -si.wi.y, -si.wi.z); bs_eta = 1.f; bs_pdf = 1.f; bs_delta = true; bs_null = true; bsdf_weight = mk(1.f, 1.f, 1.f);
+        } else if (SPEC && bsh->bsdf == BSDF_THINDIELECTRIC) {
+            // ThinDielectric::sample (thindielectric.cpp:173-226): the reflectance of the slab with all internal bounces, wo = -wi
+            float r, t1, t2, t3;
+            fresnel_dielectric(fabsf(si.wi.z), bsh->diel_eta, r, t1, t2, t3);
+            r *= 2.f / (1.f + r);
+            const bool selected_r = s1 <= r;
+            bs_pdf = selected_r ? r : 1.f - r; bs_delta = true; bs_eta = 1.f;
+            bs_null = !selected_r;   // bs.sampled_type = select(selected_r, DeltaReflection, Null) (:179)
+            bs_wo = selected_r ? mk(-si.wi.x, -si.wi.y, si.wi.z) : mk(-si.wi.x, -si.wi.y, -si.wi.z);
+            bsdf_weight = selected_r ? mk(hm.spec_refl[0], hm.spec_refl[1], hm.spec_refl[2]) : mk(hm.spec_trans[0], hm.spec_trans[1], hm.spec_trans[2]);
+        } else if (SPEC && bsh->bsdf == BSDF_ROUGHDIELECTRIC) {
+            // RoughDielectric::eval_pdf / sample (roughdielectric.cpp:240-346,503-611): glossy reflection and transmission lobes
+            const Ggx g = mf_make((bsh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, hm.alpha_u, hm.alpha_v, !(bsh->flags & SF_SAMPLE_ALL));
+            const V3 wi = si.wi;
+            if (active_em) rough_dielectric_eval_pdf(g, bsh, hm, wi, wo, bsdf_val, bsdf_pdf);
+            if (wi.z != 0.f) {
+                float mpdf;
+                Ggx gs = g;   // sample_distr (:266-269)
+                if (!g.visible) { const float sc = 1.2f - .2f * sqrtf(fabsf(wi.z)); gs.au *= sc; gs.av *= sc; }
+                const V3 m = ggx_sample(gs, mk(mulsign(wi.x, wi.z), mulsign(wi.y, wi.z), mulsign(wi.z, wi.z)), s2x, s2y, mpdf);
+                const float dwm = dot(wi, m);
+                float F, cos_theta_t, eta_it, eta_ti; fresnel_dielectric(dwm, bsh->diel_eta, F, cos_theta_t, eta_it, eta_ti);
+                const bool selected_r = s1 <= F;
+                bs_pdf = mpdf * (selected_r ? F : 1.f - F);
+                bs_eta = selected_r ? 1.f : eta_it;
+                float dwh_dwo; V3 w;
+                if (selected_r) {
+                    bs_wo = mk(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   // reflect(wi, m)
+                    w = mk(hm.spec_refl[0], hm.spec_refl[1], hm.spec_refl[2]);
+                    dwh_dwo = rcp(4.f * dot(bs_wo, m));
+                } else {
+                    const float k = fmaf(dwm, eta_ti, cos_theta_t);                                                         // refract(wi, m, cos_theta_t, eta_ti)
+                    bs_wo = mk(fmaf(m.x, k, -(wi.x * eta_ti)), fmaf(m.y, k, -(wi.y * eta_ti)), fmaf(m.z, k, -(wi.z * eta_ti)));
+                    const float f2 = sqr(eta_ti);
+                    w = mk(f2 * hm.spec_trans[0], f2 * hm.spec_trans[1], f2 * hm.spec_trans[2]);
+                    const float dom = dot(bs_wo, m);
+                    dwh_dwo = (sqr(bs_eta) * dom) / sqr(dwm + bs_eta * dom);
+                }
+                // :345-349: smith_g1(wo, m) with visible normals, else G(wi, wo, m) dot(wi, m) / (cos_theta_i cos_theta(m))
+                const float g1 = g.visible ? ggx_smith_g1(g, bs_wo, m) : ggx_smith_g1(g, wi, m) * ggx_smith_g1(g, bs_wo, m) * dwm / (wi.z * m.z);
+                bs_pdf *= fabsf(dwh_dwo);
+                if (mpdf != 0.f) bsdf_weight = w * g1;
+            }
+        } else if (SPEC && bsh->bsdf == BSDF_ROUGHCONDUCTOR) {
+            // RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF
+            V3 wi = si.wi, wo_l = wo;
+            if (twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
+            const Ggx g = mf_make((bsh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, hm.alpha_u, hm.alpha_v, !(bsh->flags & SF_SAMPLE_ALL));
+            if (wi.z > 0.f && wo_l.z > 0.f) {
+                const V3 H = normalize(wo_l + wi);
+                const float D = ggx_eval(g, H);
+                if (D != 0.f) {
+                    const float G = ggx_smith_g1(g, wi, H) * ggx_smith_g1(g, wo_l, H);
+                    const float result = D * G / (4.f * wi.z), c = dot(wi, H);
+                    bsdf_val = mk(fresnel_conductor(c, bsh->cond_eta[0], bsh->cond_k[0]) * (result * hm.spec_refl[0]),
+                                  fresnel_conductor(c, bsh->cond_eta[1], bsh->cond_k[1]) * (result * hm.spec_refl[1]),
+                                  fresnel_conductor(c, bsh->cond_eta[2], bsh->cond_k[2]) * (result * hm.spec_refl[2]));
+                }
+                if (dot(wi, H) > 0.f && dot(wo_l, H) > 0.f) bsdf_pdf = g.visible ? ggx_eval(g, H) * ggx_smith_g1(g, wi, H) / (4.f * wi.z) : ggx_pdf(g, wi, H) / (4.f * dot(wo_l, H));   // :405-409
+            }
+            if (wi.z > 0.f) {
+                float mpdf;
+                const V3 m = ggx_sample(g, wi, s2x, s2y, mpdf);
+                const float dwm = dot(wi, m);
+                const V3 r = mk(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   // reflect(wi, m)
+                bs_wo = r; bs_eta = 1.f;
+                const bool ok = mpdf != 0.f && r.z > 0.f;
+                const float weight = g.visible ? ggx_smith_g1(g, r, m) : ggx_smith_g1(g, wi, m) * ggx_smith_g1(g, r, m) * dwm / (wi.z * m.z);   // :260-265
+                bs_pdf = mpdf / (4.f * dot(r, m));
+                if (ok) bsdf_weight = mk(fresnel_conductor(dwm, bsh->cond_eta[0], bsh->cond_k[0]) * (weight * hm.spec_refl[0]),
+                                         fresnel_conductor(dwm, bsh->cond_eta[1], bsh->cond_k[1]) * (weight * hm.spec_refl[1]),
+                                         fresnel_conductor(dwm, bsh->cond_eta[2], bsh->cond_k[2]) * (weight * hm.spec_refl[2]));
+                if (twosided && si.wi.z < 0.f) bs_wo.z = -bs_wo.z;
+            }
+        } else if (SPEC && bsh->bsdf == BSDF_ROUGHPLASTIC) {
+            // RoughPlastic::eval / pdf / sample (roughplastic.cpp:259-421), GGX + visible normals, under TwoSidedBRDF
+            V3 wi = si.wi, wo_l = wo;
+            if (twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
+            const Ggx g = mf_make((bsh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, hm.alpha_u, hm.alpha_u, !(bsh->flags & SF_SAMPLE_ALL));
+            const float *table = (const float *) (sv.base + bsh->rough_table);
+            const float w = bsh->spec_sampling_weight, ir = bsh->fdr_int;
+            const V3 diff = (bsh->nonlinear & 1u) ? mk(refl.x / (1.f - refl.x * ir), refl.y / (1.f - refl.y * ir), refl.z / (1.f - refl.z * ir))
+                                          : mk(refl.x / (1.f - ir), refl.y / (1.f - ir), refl.z / (1.f - ir));
+            if (wi.z > 0.f) {
+                const float t_i = lerp_gather64(table, wi.z);
+                float prob_specular = (1.f - t_i) * w, prob_diffuse = t_i * (1.f - w);
+                prob_specular = prob_specular / (prob_specular + prob_diffuse);
+                prob_diffuse = 1.f - prob_specular;
+                if (wo_l.z > 0.f) rough_plastic_eval_pdf(g, bsh, hm, table, diff, wi, wo_l, t_i, prob_specular, prob_diffuse, bsdf_val, bsdf_pdf);
+                if (s1 < prob_specular) {
+                    float mpdf; const V3 m = ggx_sample(g, wi, s2x, s2y, mpdf);
+                    const float dwm = dot(wi, m);
+                    bs_wo = mk(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   // reflect(wi, m)
+                } else bs_wo = cosine_hemisphere(s2x, s2y);
+                bs_eta = 1.f;
+                V3 value = mk(0, 0, 0);
+                if (bs_wo.z > 0.f) rough_plastic_eval_pdf(g, bsh, hm, table, diff, wi, bs_wo, t_i, prob_specular, prob_diffuse, value, bs_pdf);
+                if (bs_pdf > 0.f) bsdf_weight = value * rcp(bs_pdf);                  // Spectrum / Float = multiplication by the reciprocal
+                if (twosided && si.wi.z < 0.f) bs_wo.z = -bs_wo.z;
+            }
+        } else if (SPEC && bsh->bsdf == BSDF_PLASTIC) {
+            // SmoothPlastic::eval / pdf / sample (plastic.cpp:219-360) under TwoSidedBRDF; wiz / woz are already flipped
+            float f_i, t1, t2, t3;
+            fresnel_dielectric(wiz, bsh->diel_eta, f_i, t1, t2, t3);
+            const float w = bsh->spec_sampling_weight, fdr = bsh->fdr_int;
+            const V3 diff = (bsh->nonlinear & 1u) ? mk(refl.x / (1.f - refl.x * fdr), refl.y / (1.f - refl.y * fdr), refl.z / (1.f - refl.z * fdr))
+                                          : mk(refl.x / (1.f - fdr), refl.y / (1.f - fdr), refl.z / (1.f - fdr));
+            if (wiz > 0.f && woz > 0.f) {
+                float f_o; fresnel_dielectric(woz, bsh->diel_eta, f_o, t1, t2, t3);
+                const float k = kInvPi * woz * bsh->inv_eta_2 * (1.f - f_i) * (1.f - f_o);
+                bsdf_val = mk(diff.x * k, diff.y * k, diff.z * k);
+                const float prob_specular = f_i * w; float prob_diffuse = (1.f - f_i) * (1.f - w);
+                prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
+                bsdf_pdf = kInvPi * woz * prob_diffuse;
+            }
+            if (wiz > 0.f) {
+                float prob_specular = f_i * w, prob_diffuse = (1.f - f_i) * (1.f - w);
+                prob_specular = prob_specular / (prob_specular + prob_diffuse);
+                prob_diffuse = 1.f - prob_specular;
+                bs_eta = 1.f;
+                if (s1 < prob_specular) {
+                    bs_wo = mk(-si.wi.x, -si.wi.y, wiz);
+                    bs_pdf = prob_specular; bs_delta = true;
+                    const float value = f_i / bs_pdf;
+                    bsdf_weight = mk(value * hm.spec_refl[0], value * hm.spec_refl[1], value * hm.spec_refl[2]);
+                } else {
+                    bs_wo = cosine_hemisphere(s2x, s2y);
+                    bs_pdf = prob_diffuse * (kInvPi * bs_wo.z);
+                    float f_o; fresnel_dielectric(bs_wo.z, bsh->diel_eta, f_o, t1, t2, t3);
+                    const float k = bsh->inv_eta_2 * (1.f - f_i) * (1.f - f_o) / prob_diffuse;
+                    bsdf_weight = mk(diff.x * k, diff.y * k, diff.z * k);
+                }
+                if (twosided) bs_wo.z = mulsign(bs_wo.z, si.wi.z);
+            }
+        } else {
+            if (wiz > 0.f && woz > 0.f) { bsdf_val = mk(refl.x * kInvPi * woz, refl.y * kInvPi * woz, refl.z * kInvPi * woz); bsdf_pdf = kInvPi * woz; }
+            if (wiz > 0.f) {
+                bs_wo = cosine_hemisphere(s2x, s2y);
+                bs_pdf = kInvPi * bs_wo.z;
+                bs_eta = 1.f;
+                if (bs_pdf > 0.f) bsdf_weight = refl;
+                if (twosided) bs_wo.z = mulsign(bs_wo.z, si.wi.z);
+            }
+        }
+        if (nmap) {
+            if (!(wo_flipped.z * wo.z > 0.f)) { bsdf_val = mk(0, 0, 0); bsdf_pdf = 0.f; }
+            if (bsdf_weight.x != 0.f || bsdf_weight.y != 0.f || bsdf_weight.z != 0.f) {   // active &= any(weight != 0): a zero sample goes back as it is
+                const V3 pw = frame_to_world(nf, bs_wo);
+                if (!(bs_wo.z * pw.z > 0.f)) bsdf_weight = mk(0, 0, 0);
+                bs_wo = pw;
+            }
+            if (nm_back) bs_wo.z = -bs_wo.z;
+        }
+        if (blend) {
+            if ((pass == 1) == pick_1) { keep_weight = bsdf_weight; keep_wo = bs_wo; keep_pdf = bs_pdf; keep_eta = bs_eta; keep_delta = bs_delta; keep_null = bs_null; }
+            if (pass == 0) { val_0 = bsdf_val; pdf_0 = bsdf_pdf; }
+            else {
+                const float w0 = 1.f - blend_w;
+                bsdf_val = mk(val_0.x * w0 + bsdf_val.x * blend_w, val_0.y * w0 + bsdf_val.y * blend_w, val_0.z * w0 + bsdf_val.z * blend_w);
+                bsdf_pdf = pdf_0 * w0 + bsdf_pdf * blend_w;
+                bsdf_weight = keep_weight; bs_wo = keep_wo; bs_pdf = keep_pdf; bs_eta = keep_eta; bs_delta = keep_delta; bs_null = keep_null;
+            }
+        }
+    }
+    si.wi = wi_plain;
+    if (masked) {
+        bsdf_val = bsdf_val * opacity; bsdf_pdf *= opacity;
+        if (null_pick) { bs_wo = mk(-si.wi.x, -si.wi.y, -si.wi.z); bs_eta = 1.f; bs_pdf = 1.f - opacity; bs_delta = true; bs_null = true; bsdf_weight = mk(1.f, 1.f, 1.f); }
+    }
+    out.val = bsdf_val; out.pdf = bsdf_pdf; out.weight = bsdf_weight; out.wo = bs_wo; out.bs_pdf = bs_pdf; out.bs_eta = bs_eta; out.bs_delta = bs_delta; out.bs_null = bs_null;
+}
+
 // FUSED = false: the "split" pipeline -- shadow rays go to the shadow queue (k_shadow commits them) and the
 //                 continuation ray is traced by the next k_trace launch.
 // FUSED = true : one kernel per bounce -- the occlusion query and the closest-hit query of the continuation ray
@@ -422,251 +677,11 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             float sample_1 = next_f32(sel); (void) sample_1;
             float s2x = next_f32(sel), s2y = next_f32(sel);
 
-            // ---- the shape's BSDF.  Outermost a `mask`, if any: MaskBSDF (src/bsdfs/mask.cpp:125-163) -- with probability 1 - opacity the path goes straight on (a null
-            // interaction: wo = -wi, weight 1, pdf 1 - opacity), otherwise the nested BSDF is sampled with sample1 / opacity; eval and pdf of the nested BSDF are scaled by it.
-            const bool masked = SPEC && (sh->flags & SF_MASK);
-            bool null_pick = false; float opacity = 1.f;
-            if (masked) { opacity = mask_opacity_at(sv, sh, si.u, si.v); null_pick = !(sample_1 < opacity); sample_1 = sample_1 / opacity; }
-            // Then a `blendbsdf`, if any (src/bsdfs/blendbsdf.cpp:114-213): eval and pdf are the weighted sums of both nested BSDFs; sample1 <= weight samples bsdf_1 with
-            // sample1 / weight, otherwise bsdf_0 with (sample1 - weight) / (1 - weight), and the nested sample goes back as it is.  The chain below runs once per nested BSDF
-            // (record 0 = the shape's own, record 1 = the material-only record DShape::blend_other points at).
-            // (its own instantiations, SPEC == 2: with the chain inside a loop of run-time trip count the compiler's code for the K = 4 fused kernels gave wrong films
-            // on scenes WITHOUT any blend -- found by the random scene sweep; where SPEC != 2 the loop below has one iteration at compile time)
-            const bool blend = SPEC == 2 && (sh->flags & SF_BLEND);
-            float blend_w = 0.f; bool pick_1 = false;
-            if (blend) {
-                blend_w = sh->tex_blend ? texture_eval_1(sv, sh->tex_blend << 4, si.u, si.v) : sh->blend_weight;
-                blend_w = fmin_(fmax_(blend_w, 0.f), 1.f);   // eval_weight (:213-215)
-                pick_1 = sample_1 <= blend_w;
-            }
-            // `twosided` with two nested BSDFs (twosided.cpp:75-86,111-148): the back side (wi.z < 0) has a record of its own; the flip itself is the chain's
-            const DShape *side_sh = (SPEC == 2 && (sh->flags & SF_TWOSIDED2) && si.wi.z < 0.f) ? &sv.shapes[sh->blend_other] : sh;
-            const V3 wi_plain = si.wi, wo_plain = wo;
-            V3 bsdf_val = mk(0, 0, 0), bsdf_weight = mk(0, 0, 0), bs_wo = mk(0, 0, 0);
-            float bsdf_pdf = 0.f, bs_pdf = 0.f, bs_eta = 0.f; bool bs_delta = false, bs_null = false;   // bs_null: has_flag(bs.sampled_type, BSDFFlags::Null)
-            V3 val_0 = mk(0, 0, 0), keep_weight = mk(0, 0, 0), keep_wo = mk(0, 0, 0); float pdf_0 = 0.f, keep_pdf = 0.f, keep_eta = 0.f; bool keep_delta = false, keep_null = false;
-            for (int pass = 0; pass < (SPEC == 2 && blend ? 2 : 1); ++pass) {
-                const DShape *bsh = pass ? &sv.shapes[sh->blend_other] : side_sh;
-                const float s1 = !blend ? sample_1 : (pass ? sample_1 / blend_w : (sample_1 - blend_w) / (1.f - blend_w));
-                si.wi = wi_plain; wo = wo_plain;
-                // ---- BSDF eval_pdf + sample (twosided.cpp:111-148,219-258; diffuse.cpp:101-125,160-180)
-                bool twosided = bsh->flags & SF_TWOSIDED;
-                // NormalMap (src/bsdfs/normalmap.cpp:110-179) around the plain BSDF, itself inside the two-sided adapter if there is one: the adapter's flip of
-                // wi.z / wo.z comes first (twosided.cpp:111-148), then wi and wo move into the frame of the normal map; the sampled direction comes back the
-                // same way.  A direction that changes sides between the two frames is a light leak: no value, no density, no weight.
-                const bool nmap = SPEC && (bsh->flags & (SF_NORMALMAP | SF_BUMPMAP));   // BumpMap (src/bsdfs/bumpmap.cpp:114-197) wraps its nested BSDF the same way
-                LocalFrame nf; V3 wo_flipped = wo; bool nm_back = false;
-                if (nmap) {
-                    nf = (bsh->flags & SF_BUMPMAP) ? bumpmap_frame(sv, bsh, si) : normalmap_frame(sv, bsh, si);
-                    nm_back = twosided && si.wi.z < 0.f;
-                    V3 wi_f = si.wi;
-                    if (nm_back) { wi_f.z = -wi_f.z; wo_flipped.z = -wo_flipped.z; }
-                    si.wi = frame_to_local(nf, wi_f);
-                    wo = frame_to_local(nf, wo_flipped);
-                    twosided = false;
-                }
-                float wiz = si.wi.z, woz = wo.z;
-                if (twosided) { woz = mulsign(woz, wiz); wiz = fabsf(wiz); }
-                V3 refl = mk(bsh->refl[0], bsh->refl[1], bsh->refl[2]);
-                if (SPEC && (bsh->nonlinear >> 1)) refl = texture_eval(sv, (bsh->nonlinear >> 1) << 4, si.u, si.v);   // m_reflectance->eval(si)
-                HitMaterial hm;   // specular colours and roughness of this hit: constants, or the textures on those slots (SPEC instantiations only)
-                if (SPEC) hm = material_at(sv, bsh, si.u, si.v);
-                bsdf_val = mk(0, 0, 0); bsdf_weight = mk(0, 0, 0); bs_wo = mk(0, 0, 0);
-                bsdf_pdf = 0.f; bs_pdf = 0.f; bs_eta = 0.f; bs_delta = false; bs_null = false;
-                if (SPEC && bsh->bsdf == BSDF_CONDUCTOR) {
-                    // SmoothConductor::sample (conductor.cpp:226-277) under TwoSidedBRDF::sample; eval / pdf of a delta lobe are zero
-                    const float cos_theta_i = twosided ? fabsf(si.wi.z) : si.wi.z;
-                    if (cos_theta_i > 0.f) {
-                        bs_wo = mk(-si.wi.x, -si.wi.y, si.wi.z);   // reflect(wi); the two-sided flips of wi.z and wo.z cancel
-                        bs_eta = 1.f; bs_pdf = 1.f; bs_delta = true;
-                        bsdf_weight = mk(hm.spec_refl[0] * fresnel_conductor(cos_theta_i, bsh->cond_eta[0], bsh->cond_k[0]),
-                                         hm.spec_refl[1] * fresnel_conductor(cos_theta_i, bsh->cond_eta[1], bsh->cond_k[1]),
-                                         hm.spec_refl[2] * fresnel_conductor(cos_theta_i, bsh->cond_eta[2], bsh->cond_k[2]));
-                    }
-                } else if (SPEC && bsh->bsdf == BSDF_DIELECTRIC) {
-                    // SmoothDielectric::sample (dielectric.cpp:231-338), TransportMode::Radiance
-                    float r_i, cos_theta_t, eta_it, eta_ti;
-                    fresnel_dielectric(si.wi.z, bsh->diel_eta, r_i, cos_theta_t, eta_it, eta_ti);
-                    const float t_i = 1.f - r_i;
-                    const bool selected_r = s1 <= r_i;
-                    bs_pdf = selected_r ? r_i : t_i; bs_delta = true;
-                    bs_wo = selected_r ? mk(-si.wi.x, -si.wi.y, si.wi.z) : mk(-eta_ti * si.wi.x, -eta_ti * si.wi.y, cos_theta_t);
-                    bs_eta = selected_r ? 1.f : eta_it;
-                    const float f2 = sqr(eta_ti);
-                    bsdf_weight = selected_r ? mk(hm.spec_refl[0], hm.spec_refl[1], hm.spec_refl[2])
-                                             : mk(hm.spec_trans[0] * f2, hm.spec_trans[1] * f2, hm.spec_trans[2] * f2);
-                } else if (SPEC && bsh->bsdf == BSDF_NULL) {
-                    // Null::sample (null.cpp:42-66): straight on, weight 1, pdf 1, a null (and with it a delta) lobe; eval and pdf are zero (:68-79)
-                    bs_wo = mk(-si.wi.x, -si.wi.y, -si.wi.z); bs_eta = 1.f; bs_pdf = 1.f; bs_delta = true; bs_null = true; bsdf_weight = mk(1.f, 1.f, 1.f);
-                } else if (SPEC && bsh->bsdf == BSDF_THINDIELECTRIC) {
-                    // ThinDielectric::sample (thindielectric.cpp:173-226): the reflectance of the slab with all internal bounces, wo = -wi
-                    float r, t1, t2, t3;
-                    fresnel_dielectric(fabsf(si.wi.z), bsh->diel_eta, r, t1, t2, t3);
-                    r *= 2.f / (1.f + r);
-                    const bool selected_r = s1 <= r;
-                    bs_pdf = selected_r ? r : 1.f - r; bs_delta = true; bs_eta = 1.f;
-                    bs_null = !selected_r;   // bs.sampled_type = select(selected_r, DeltaReflection, Null) (:179)
-                    bs_wo = selected_r ? mk(-si.wi.x, -si.wi.y, si.wi.z) : mk(-si.wi.x, -si.wi.y, -si.wi.z);
-                    bsdf_weight = selected_r ? mk(hm.spec_refl[0], hm.spec_refl[1], hm.spec_refl[2]) : mk(hm.spec_trans[0], hm.spec_trans[1], hm.spec_trans[2]);
-                } else if (SPEC && bsh->bsdf == BSDF_ROUGHDIELECTRIC) {
-                    // RoughDielectric::eval_pdf / sample (roughdielectric.cpp:240-346,503-611): glossy reflection and transmission lobes
-                    const Ggx g = mf_make((bsh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, hm.alpha_u, hm.alpha_v, !(bsh->flags & SF_SAMPLE_ALL));
-                    const V3 wi = si.wi;
-                    if (active_em) rough_dielectric_eval_pdf(g, bsh, hm, wi, wo, bsdf_val, bsdf_pdf);
-                    if (wi.z != 0.f) {
-                        float mpdf;
-                        Ggx gs = g;   // sample_distr (:266-269)
-                        if (!g.visible) { const float sc = 1.2f - .2f * sqrtf(fabsf(wi.z)); gs.au *= sc; gs.av *= sc; }
-                        const V3 m = ggx_sample(gs, mk(mulsign(wi.x, wi.z), mulsign(wi.y, wi.z), mulsign(wi.z, wi.z)), s2x, s2y, mpdf);
-                        const float dwm = dot(wi, m);
-                        float F, cos_theta_t, eta_it, eta_ti; fresnel_dielectric(dwm, bsh->diel_eta, F, cos_theta_t, eta_it, eta_ti);
-                        const bool selected_r = s1 <= F;
-                        bs_pdf = mpdf * (selected_r ? F : 1.f - F);
-                        bs_eta = selected_r ? 1.f : eta_it;
-                        float dwh_dwo; V3 w;
-                        if (selected_r) {
-                            bs_wo = mk(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   // reflect(wi, m)
-                            w = mk(hm.spec_refl[0], hm.spec_refl[1], hm.spec_refl[2]);
-                            dwh_dwo = rcp(4.f * dot(bs_wo, m));
-                        } else {
-                            const float k = fmaf(dwm, eta_ti, cos_theta_t);                                                         // refract(wi, m, cos_theta_t, eta_ti)
-                            bs_wo = mk(fmaf(m.x, k, -(wi.x * eta_ti)), fmaf(m.y, k, -(wi.y * eta_ti)), fmaf(m.z, k, -(wi.z * eta_ti)));
-                            const float f2 = sqr(eta_ti);
-                            w = mk(f2 * hm.spec_trans[0], f2 * hm.spec_trans[1], f2 * hm.spec_trans[2]);
-                            const float dom = dot(bs_wo, m);
-                            dwh_dwo = (sqr(bs_eta) * dom) / sqr(dwm + bs_eta * dom);
-                        }
-                        // :345-349: smith_g1(wo, m) with visible normals, else G(wi, wo, m) dot(wi, m) / (cos_theta_i cos_theta(m))
-                        const float g1 = g.visible ? ggx_smith_g1(g, bs_wo, m) : ggx_smith_g1(g, wi, m) * ggx_smith_g1(g, bs_wo, m) * dwm / (wi.z * m.z);
-                        bs_pdf *= fabsf(dwh_dwo);
-                        if (mpdf != 0.f) bsdf_weight = w * g1;
-                    }
-                } else if (SPEC && bsh->bsdf == BSDF_ROUGHCONDUCTOR) {
-                    // RoughConductor::eval / pdf / sample (roughconductor.cpp:229-415), GGX + visible normals, under TwoSidedBRDF
-                    V3 wi = si.wi, wo_l = wo;
-                    if (twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
-                    const Ggx g = mf_make((bsh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, hm.alpha_u, hm.alpha_v, !(bsh->flags & SF_SAMPLE_ALL));
-                    if (wi.z > 0.f && wo_l.z > 0.f) {
-                        const V3 H = normalize(wo_l + wi);
-                        const float D = ggx_eval(g, H);
-                        if (D != 0.f) {
-                            const float G = ggx_smith_g1(g, wi, H) * ggx_smith_g1(g, wo_l, H);
-                            const float result = D * G / (4.f * wi.z), c = dot(wi, H);
-                            bsdf_val = mk(fresnel_conductor(c, bsh->cond_eta[0], bsh->cond_k[0]) * (result * hm.spec_refl[0]),
-                                          fresnel_conductor(c, bsh->cond_eta[1], bsh->cond_k[1]) * (result * hm.spec_refl[1]),
-                                          fresnel_conductor(c, bsh->cond_eta[2], bsh->cond_k[2]) * (result * hm.spec_refl[2]));
-                        }
-                        if (dot(wi, H) > 0.f && dot(wo_l, H) > 0.f) bsdf_pdf = g.visible ? ggx_eval(g, H) * ggx_smith_g1(g, wi, H) / (4.f * wi.z) : ggx_pdf(g, wi, H) / (4.f * dot(wo_l, H));   // :405-409
-                    }
-                    if (wi.z > 0.f) {
-                        float mpdf;
-                        const V3 m = ggx_sample(g, wi, s2x, s2y, mpdf);
-                        const float dwm = dot(wi, m);
-                        const V3 r = mk(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   // reflect(wi, m)
-                        bs_wo = r; bs_eta = 1.f;
-                        const bool ok = mpdf != 0.f && r.z > 0.f;
-                        const float weight = g.visible ? ggx_smith_g1(g, r, m) : ggx_smith_g1(g, wi, m) * ggx_smith_g1(g, r, m) * dwm / (wi.z * m.z);   // :260-265
-                        bs_pdf = mpdf / (4.f * dot(r, m));
-                        if (ok) bsdf_weight = mk(fresnel_conductor(dwm, bsh->cond_eta[0], bsh->cond_k[0]) * (weight * hm.spec_refl[0]),
-                                                 fresnel_conductor(dwm, bsh->cond_eta[1], bsh->cond_k[1]) * (weight * hm.spec_refl[1]),
-                                                 fresnel_conductor(dwm, bsh->cond_eta[2], bsh->cond_k[2]) * (weight * hm.spec_refl[2]));
-                        if (twosided && si.wi.z < 0.f) bs_wo.z = -bs_wo.z;
-                    }
-                } else if (SPEC && bsh->bsdf == BSDF_ROUGHPLASTIC) {
-                    // RoughPlastic::eval / pdf / sample (roughplastic.cpp:259-421), GGX + visible normals, under TwoSidedBRDF
-                    V3 wi = si.wi, wo_l = wo;
-                    if (twosided && wi.z < 0.f) { wi.z = -wi.z; wo_l.z = -wo_l.z; }
-                    const Ggx g = mf_make((bsh->flags & SF_BECKMANN) ? MF_BECKMANN : MF_GGX, hm.alpha_u, hm.alpha_u, !(bsh->flags & SF_SAMPLE_ALL));
-                    const float *table = (const float *) (sv.base + bsh->rough_table);
-                    const float w = bsh->spec_sampling_weight, ir = bsh->fdr_int;
-                    const V3 diff = (bsh->nonlinear & 1u) ? mk(refl.x / (1.f - refl.x * ir), refl.y / (1.f - refl.y * ir), refl.z / (1.f - refl.z * ir))
-                                                  : mk(refl.x / (1.f - ir), refl.y / (1.f - ir), refl.z / (1.f - ir));
-                    if (wi.z > 0.f) {
-                        const float t_i = lerp_gather64(table, wi.z);
-                        float prob_specular = (1.f - t_i) * w, prob_diffuse = t_i * (1.f - w);
-                        prob_specular = prob_specular / (prob_specular + prob_diffuse);
-                        prob_diffuse = 1.f - prob_specular;
-                        if (wo_l.z > 0.f) rough_plastic_eval_pdf(g, bsh, hm, table, diff, wi, wo_l, t_i, prob_specular, prob_diffuse, bsdf_val, bsdf_pdf);
-                        if (s1 < prob_specular) {
-                            float mpdf; const V3 m = ggx_sample(g, wi, s2x, s2y, mpdf);
-                            const float dwm = dot(wi, m);
-                            bs_wo = mk(fmaf(m.x, 2.f * dwm, -wi.x), fmaf(m.y, 2.f * dwm, -wi.y), fmaf(m.z, 2.f * dwm, -wi.z));   // reflect(wi, m)
-                        } else bs_wo = cosine_hemisphere(s2x, s2y);
-                        bs_eta = 1.f;
-                        V3 value = mk(0, 0, 0);
-                        if (bs_wo.z > 0.f) rough_plastic_eval_pdf(g, bsh, hm, table, diff, wi, bs_wo, t_i, prob_specular, prob_diffuse, value, bs_pdf);
-                        if (bs_pdf > 0.f) bsdf_weight = value * rcp(bs_pdf);                  // Spectrum / Float = multiplication by the reciprocal
-                        if (twosided && si.wi.z < 0.f) bs_wo.z = -bs_wo.z;
-                    }
-                } else if (SPEC && bsh->bsdf == BSDF_PLASTIC) {
-                    // SmoothPlastic::eval / pdf / sample (plastic.cpp:219-360) under TwoSidedBRDF; wiz / woz are already flipped
-                    float f_i, t1, t2, t3;
-                    fresnel_dielectric(wiz, bsh->diel_eta, f_i, t1, t2, t3);
-                    const float w = bsh->spec_sampling_weight, fdr = bsh->fdr_int;
-                    const V3 diff = (bsh->nonlinear & 1u) ? mk(refl.x / (1.f - refl.x * fdr), refl.y / (1.f - refl.y * fdr), refl.z / (1.f - refl.z * fdr))
-                                                  : mk(refl.x / (1.f - fdr), refl.y / (1.f - fdr), refl.z / (1.f - fdr));
-                    if (wiz > 0.f && woz > 0.f) {
-                        float f_o; fresnel_dielectric(woz, bsh->diel_eta, f_o, t1, t2, t3);
-                        const float k = kInvPi * woz * bsh->inv_eta_2 * (1.f - f_i) * (1.f - f_o);
-                        bsdf_val = mk(diff.x * k, diff.y * k, diff.z * k);
-                        const float prob_specular = f_i * w; float prob_diffuse = (1.f - f_i) * (1.f - w);
-                        prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
-                        bsdf_pdf = kInvPi * woz * prob_diffuse;
-                    }
-                    if (wiz > 0.f) {
-                        float prob_specular = f_i * w, prob_diffuse = (1.f - f_i) * (1.f - w);
-                        prob_specular = prob_specular / (prob_specular + prob_diffuse);
-                        prob_diffuse = 1.f - prob_specular;
-                        bs_eta = 1.f;
-                        if (s1 < prob_specular) {
-                            bs_wo = mk(-si.wi.x, -si.wi.y, wiz);
-                            bs_pdf = prob_specular; bs_delta = true;
-                            const float value = f_i / bs_pdf;
-                            bsdf_weight = mk(value * hm.spec_refl[0], value * hm.spec_refl[1], value * hm.spec_refl[2]);
-                        } else {
-                            bs_wo = cosine_hemisphere(s2x, s2y);
-                            bs_pdf = prob_diffuse * (kInvPi * bs_wo.z);
-                            float f_o; fresnel_dielectric(bs_wo.z, bsh->diel_eta, f_o, t1, t2, t3);
-                            const float k = bsh->inv_eta_2 * (1.f - f_i) * (1.f - f_o) / prob_diffuse;
-                            bsdf_weight = mk(diff.x * k, diff.y * k, diff.z * k);
-                        }
-                        if (twosided) bs_wo.z = mulsign(bs_wo.z, si.wi.z);
-                    }
-                } else {
-                    if (wiz > 0.f && woz > 0.f) { bsdf_val = mk(refl.x * kInvPi * woz, refl.y * kInvPi * woz, refl.z * kInvPi * woz); bsdf_pdf = kInvPi * woz; }
-                    if (wiz > 0.f) {
-                        bs_wo = cosine_hemisphere(s2x, s2y);
-                        bs_pdf = kInvPi * bs_wo.z;
-                        bs_eta = 1.f;
-                        if (bs_pdf > 0.f) bsdf_weight = refl;
-                        if (twosided) bs_wo.z = mulsign(bs_wo.z, si.wi.z);
-                    }
-                }
-                if (nmap) {
-                    if (!(wo_flipped.z * wo.z > 0.f)) { bsdf_val = mk(0, 0, 0); bsdf_pdf = 0.f; }
-                    if (bsdf_weight.x != 0.f || bsdf_weight.y != 0.f || bsdf_weight.z != 0.f) {   // active &= any(weight != 0): a zero sample goes back as it is
-                        const V3 pw = frame_to_world(nf, bs_wo);
-                        if (!(bs_wo.z * pw.z > 0.f)) bsdf_weight = mk(0, 0, 0);
-                        bs_wo = pw;
-                    }
-                    if (nm_back) bs_wo.z = -bs_wo.z;
-                }
-                if (blend) {
-                    if ((pass == 1) == pick_1) { keep_weight = bsdf_weight; keep_wo = bs_wo; keep_pdf = bs_pdf; keep_eta = bs_eta; keep_delta = bs_delta; keep_null = bs_null; }
-                    if (pass == 0) { val_0 = bsdf_val; pdf_0 = bsdf_pdf; }
-                    else {
-                        const float w0 = 1.f - blend_w;
-                        bsdf_val = mk(val_0.x * w0 + bsdf_val.x * blend_w, val_0.y * w0 + bsdf_val.y * blend_w, val_0.z * w0 + bsdf_val.z * blend_w);
-                        bsdf_pdf = pdf_0 * w0 + bsdf_pdf * blend_w;
-                        bsdf_weight = keep_weight; bs_wo = keep_wo; bs_pdf = keep_pdf; bs_eta = keep_eta; bs_delta = keep_delta; bs_null = keep_null;
-                    }
-                }
-            }
-            si.wi = wi_plain;
-            if (masked) {
-                bsdf_val = bsdf_val * opacity; bsdf_pdf *= opacity;
-                if (null_pick) { bs_wo = mk(-si.wi.x, -si.wi.y, -si.wi.z); bs_eta = 1.f; bs_pdf = 1.f - opacity; bs_delta = true; bs_null = true; bsdf_weight = mk(1.f, 1.f, 1.f); }
-            }
+            // ---- the shape's BSDF with its adapters (mask, blendbsdf, twosided, normalmap / bumpmap): bsdf_eval_pdf_sample above
+            BsdfOut bo;
+            bsdf_eval_pdf_sample<SPEC>(sv, sh, si, wo, active_em, sample_1, s2x, s2y, bo);
+            const V3 bsdf_val = bo.val, bs_wo = bo.wo; V3 bsdf_weight = bo.weight;
+            const float bsdf_pdf = bo.pdf, bs_pdf = bo.bs_pdf, bs_eta = bo.bs_eta; const bool bs_delta = bo.bs_delta, bs_null = bo.bs_null;
             // ---- emitter contribution candidate (dopplertofpath.cpp:214-226); committed by k_shadow if unoccluded
             if (active_em) {
                 const float mis_em = ds_delta ? 1.f : mis_weight(ds_pdf, bsdf_pdf);   // dopplertofpath.cpp:218-219

@@ -75,7 +75,11 @@ class ProductBackend:
         o, d, _ = sc.camera_rays([[(np.float32(px) - i["crop_x"]) / np.float32(i["crop_width"]), (np.float32(py) - i["crop_y"]) / np.float32(i["crop_height"]), ax, ay]])
         return o[0].copy(), d[0].copy()
 
-    def __getattr__(self, name):       # shape_area, sphere_sample_direction, bsdf, splat, gauss_legendre, solve_quadratic
+    def bsdf(self, sc, i, wi, wo, s3):   # the shade kernels' own BSDF function (dtof_bsdf_eval), flat local frame, uv = 0
+        q = np.concatenate([np.asarray(wi, np.float32), np.asarray(wo, np.float32), np.asarray(s3, np.float32), np.zeros(2, np.float32)])
+        return sc.bsdf_eval(i, [q])[0, :13].copy()
+
+    def __getattr__(self, name):       # shape_area, sphere_sample_direction, splat, gauss_legendre, solve_quadratic
         def missing(*a, **k):
             raise refkat.Skip("no C-ABI entry point for '%s' (pinned through the oracle; the kernels are lane-for-lane bit-exact with it)" % name)
         return missing
@@ -91,6 +95,7 @@ PINNED = {
     "src/core/tests/test_warp.py": 10, "src/core/tests/test_random.py": 8, "src/core/tests/test_frame.py": 3,
     "src/shapes/tests/test_rectangle.py": 15, "src/shapes/tests/test_sphere.py": 500, "src/shapes/tests/test_disk.py": 500,
     "src/shapes/tests/test_cube.py": 100, "src/shapes/tests/test_instance.py": 400, "src/shapes/tests/test_cylinder.py": 60,
+    "src/bsdfs/tests/test_diffuse.py": 30, "src/bsdfs/tests/test_dielectric.py": 15, "src/bsdfs/tests/test_twosided.py": 2,
     "src/sensors/tests/test_perspective.py": 90, "src/sensors/tests/test_orthographic.py": 60, "src/sensors/tests/test_thinlens.py": 120,
 }
 
