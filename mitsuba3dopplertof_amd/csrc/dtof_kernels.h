@@ -165,6 +165,7 @@ void launch_ray_query(const uint8_t *scene, const float *rays, float *out, int32
 
 #ifdef DTOF_TRAVERSAL_STATS
 bool read_traversal_stats(unsigned long long *out8);
+void register_traversal_stats_reader(bool (*reader)(unsigned long long *acc8));
 #endif
 
 }  // namespace dtof

@@ -56,7 +56,15 @@ struct Hit { float t, u, v; uint32_t obj, shape, prim; };
 // [0] rays  [1] node steps (lane)  [2] node iterations (wave)  [3] leaf visits (lane)  [4] leaf rounds (wave)  [5] mesh loops entered (lane)
 // [6] triangle tests (lane)  [7] BLAS node steps (lane)
 #ifdef DTOF_TRAVERSAL_STATS
-__device__ unsigned long long g_trav_stats[8];
+// every translation unit with kernels counts into its own copy (no relocatable device code); each registers a reader, read_traversal_stats sums and resets them all
+static __device__ unsigned long long g_trav_stats[8];
+static bool read_tu_traversal_stats(unsigned long long *acc8) {
+    unsigned long long v[8], zero[8] = { 0 };
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_trav_stats), 64) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), zero, 64) != hipSuccess) return false;
+    for (int i = 0; i < 8; ++i) acc8[i] += v[i];
+    return true;
+}
+static const int g_trav_stats_registered = (register_traversal_stats_reader(read_tu_traversal_stats), 0);
 #define DTOF_STAT(i) atomicAdd(&g_trav_stats[i], 1ull)
 #define DTOF_STAT_WAVE(i) do { if (__lane_id() == (uint32_t) __ffsll((long long) __ballot(1)) - 1u) atomicAdd(&g_trav_stats[i], 1ull); } while (0)
 #else
