@@ -57,7 +57,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 64 ? 6 : 1) void k_trace(const uint
     uint32_t l = 0; float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 1.f, 0.f);
     if (active) { l = qin ? qin[seg * kSeg + j] : seg * kSeg + j; a = q.ray_a[l]; b = q.ray_b[l]; }
     Hit h;
-    bool found = trace_rays<false, MESH>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h);
+    bool found = trace_rays<false, MESH, false, false, BLOCK>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h);
     if (active) store_hit<MESH>(q, l, h, found);
 }
 
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 64 ? 6 : 1) void k_shadow(const uin
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 1.f, 0.f);
     if (active) { a = q.sh_a[i]; b = q.sh_b[i]; }
     Hit h;
-    bool occluded = trace_rays<true, MESH>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h);
+    bool occluded = trace_rays<true, MESH, false, false, BLOCK>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h);
     if (active && !occluded) {
 #pragma unroll
         for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) {

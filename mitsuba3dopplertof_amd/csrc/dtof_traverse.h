@@ -188,39 +188,45 @@ DTOF_D void instance_memo_load(const SceneView &sv, float *inv) {
     for (uint32_t k = 0; k < kMemoWords; ++k) inv[k] = sv.memo[k * kMemoStride];
 }
 
-// Slab test against a padded box; NaNs (0*inf) fall out of the min/max chain conservatively.
-DTOF_D float box_entry(const float *bmin, const float *bmax, V3 o, V3 id, float tbest) {
-    float tx0 = (bmin[0] - o.x) * id.x, tx1 = (bmax[0] - o.x) * id.x;
-    float ty0 = (bmin[1] - o.y) * id.y, ty1 = (bmax[1] - o.y) * id.y;
-    float tz0 = (bmin[2] - o.z) * id.z, tz1 = (bmax[2] - o.z) * id.z;
-    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
-    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
-    return tn <= tf ? tn : INFINITY;
+// Slab test of a padded box.  A plane at coordinate b is crossed at t = b * id - o * id: ONE multiply-add per plane with `noid` = -(o * id) computed once per ray (the
+// difference-then-product form costs two instructions per plane, 12 more per node step of an issue-bound traversal).  The test only culls -- which primitive is hit, and
+// where, is decided by the primitive tests -- so it has to be conservative, not equal to anything: its rounding error is 2^-24 (|o| + |t / id|) |id| per plane against
+// the padding of (1e-5 max(|b|, extent) + 1e-6) |id| the host puts around every box (scene_build.cpp: Box::pad), the same order as the other form's 2^-23 |b - o| |id|
+// since |o| <= |b - o| + |b|.  NaNs fall out of the min / max chain (fminf / fmaxf return the other operand); a box whose test has no number left is missed.
+struct SlabRay { V3 id, noid; };
+DTOF_D SlabRay slab_ray(V3 o, V3 d) {
+    // direction reciprocal for the slab test only (exact zero components are nudged); v_rcp_f32 (1 ulp) is enough here, see the padding above
+    SlabRay r;
+    r.id = mk(__builtin_amdgcn_rcpf(d.x == 0.f ? 1e-30f : d.x), __builtin_amdgcn_rcpf(d.y == 0.f ? 1e-30f : d.y), __builtin_amdgcn_rcpf(d.z == 0.f ? 1e-30f : d.z));
+    r.noid = mk(-(o.x * r.id.x), -(o.y * r.id.y), -(o.z * r.id.z));
+    return r;
+}
+DTOF_D bool box_hit(const float *bmin, const float *bmax, const SlabRay &r, float tbest, float &tn) {
+    const float tx0 = fmaf(bmin[0], r.id.x, r.noid.x), tx1 = fmaf(bmax[0], r.id.x, r.noid.x);
+    const float ty0 = fmaf(bmin[1], r.id.y, r.noid.y), ty1 = fmaf(bmax[1], r.id.y, r.noid.y);
+    const float tz0 = fmaf(bmin[2], r.id.z, r.noid.z), tz1 = fmaf(bmax[2], r.id.z, r.noid.z);
+    tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
+    const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
+    return tn <= tf;
 }
 #ifndef DTOF_BVH4
-// One BVH node = four 16-byte loads issued together (no load depends on a field of the node); entry distances of both
-// children, INFINITY = missed / absent.
-template <bool SOA = false>
-DTOF_D void node_test(const BvhNode *nodes, uint32_t cur, V3 o, V3 id, float tbest, float &tl, float &tr, uint32_t &left, uint32_t &right) {
+// One traversal step at inner node `cur` = four 16-byte loads issued together (no load depends on a field of the node): continue with the nearest child that is
+// hit, push the other, pop when nothing is hit.  STRIDE: the stride of the per-thread stack columns when the kernel knows its block size (a shift instead of v_mul_lo_u32).
+template <bool SOA = false, uint32_t STRIDE = 0>
+DTOF_D uint32_t node_step(const BvhNode *nodes, uint32_t cur, const SlabRay &r, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride_rt, uint32_t done) {
+    const uint32_t stride = STRIDE ? STRIDE : stride_rt;
     const uint4 *np = SOA ? (const uint4 *) nodes + cur : (const uint4 *) (nodes + cur);
     const uint4 a = np[0], b = np[SOA ? kResNodes : 1], c = np[SOA ? 2 * kResNodes : 2], d = np[SOA ? 3 * kResNodes : 3];
     const float lmin[3] = { u2f(a.x), u2f(a.y), u2f(a.z) }, lmax[3] = { u2f(b.x), u2f(b.y), u2f(b.z) };
     const float rmin[3] = { u2f(c.x), u2f(c.y), u2f(c.z) }, rmax[3] = { u2f(d.x), u2f(d.y), u2f(d.z) };
-    left = a.w; right = b.w;
-    tl = box_entry(lmin, lmax, o, id, tbest);
-    tr = box_entry(rmin, rmax, o, id, tbest);
-    if (right == kNoChild) tr = INFINITY;
-}
-// one traversal step at inner node `cur`: continue with the nearest child that is hit, push the other, pop when nothing is hit
-template <bool SOA = false>
-DTOF_D uint32_t node_step(const BvhNode *nodes, uint32_t cur, V3 o, V3 id, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride, uint32_t done) {
-    float tl, tr; uint32_t left, right;
-    node_test<SOA>(nodes, cur, o, id, tbest, tl, tr, left, right);
-    const bool hl = tl < INFINITY, hr = tr < INFINITY;
+    const uint32_t left = a.w, right = b.w;
+    float tl, tr;
+    const bool hl = box_hit(lmin, lmax, r, tbest, tl);
+    const bool hr = (int) box_hit(rmin, rmax, r, tbest, tr) & (int) (right != kNoChild);
     if (hl && hr) {
-        const uint32_t nearc = tl <= tr ? left : right, farc = tl <= tr ? right : left;
-        stack[sp * stride] = farc; ++sp;
-        return nearc;
+        const bool left_first = tl <= tr;
+        stack[sp * stride] = left_first ? right : left; ++sp;
+        return left_first ? left : right;
     }
     if (hl) return left;
     if (hr) return right;
@@ -238,13 +244,14 @@ DTOF_D void cswap(float &ta, uint32_t &ca, float &tb, uint32_t &cb) {   // compa
 // three differences per node; the children whose boxes the ray enters before `tbest` are ordered by entry distance with a five-comparator network; the
 // nearest is returned, the others are pushed far-first; nothing hit: pop (or `done` at the floor of this traversal's stack).
 DTOF_D float ubyte_f(uint32_t w, int k) { return (float) ((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyte<k>
-template <bool SOA = false>
-DTOF_D uint32_t node_step(const BvhNode4 *nodes, uint32_t cur, V3 o, V3 id, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride, uint32_t done) {
+template <bool SOA = false, uint32_t STRIDE = 0>
+DTOF_D uint32_t node_step(const BvhNode4 *nodes, uint32_t cur, const SlabRay &r, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride_rt, uint32_t done) {
+    const uint32_t stride = STRIDE ? STRIDE : stride_rt; const V3 id = r.id;
     const uint4 *np = SOA ? (const uint4 *) nodes + cur : (const uint4 *) (nodes + cur);
     const uint4 q0 = np[0], q1 = np[SOA ? kResNodes : 1], q2 = np[SOA ? 2 * kResNodes : 2], q3 = np[SOA ? 3 * kResNodes : 3];
     float t[4]; uint32_t c[4] = { q1.x, q1.y, q1.z, q1.w };
     const float ax = u2f((q0.w & 0xffu) << 23) * id.x, ay = u2f(((q0.w >> 8) & 0xffu) << 23) * id.y, az = u2f(((q0.w >> 16) & 0xffu) << 23) * id.z;
-    const float bx = (u2f(q0.x) - o.x) * id.x, by = (u2f(q0.y) - o.y) * id.y, bz = (u2f(q0.z) - o.z) * id.z;
+    const float bx = fmaf(u2f(q0.x), id.x, r.noid.x), by = fmaf(u2f(q0.y), id.y, r.noid.y), bz = fmaf(u2f(q0.z), id.z, r.noid.z);
     const uint32_t lox = q2.x, loy = q2.y, loz = q2.z, hix = q2.w, hiy = q3.x, hiz = q3.y;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -271,7 +278,7 @@ DTOF_D uint32_t node_step(const BvhNode4 *nodes, uint32_t cur, V3 o, V3 id, floa
 // primitive hit with t <= maxt; the winner is the smallest t, ties going to the lowest
 // (object, shape, face) -- the rule the oracle uses, independent of traversal order.
 // `stack + sp * stride` onwards is free for the BLAS traversal of a mesh.
-template <bool ANY, bool MESH, bool MEMO = false>
+template <bool ANY, bool MESH, bool MEMO = false, uint32_t STRIDE = 0>
 DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float time, float maxt, Hit &best,
                              uint32_t *stack, int sp, uint32_t stride) {
     const DObject &ob = sv.objects[oi];
@@ -331,8 +338,9 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
         }
         // cull with the mesh's own (padded) bounds: TLAS boxes of moving instances are the union over the whole
         // motion and let many rays through that miss the mesh at their time
-        V3 lid = mk(__builtin_amdgcn_rcpf(ld.x == 0.f ? 1e-30f : ld.x), __builtin_amdgcn_rcpf(ld.y == 0.f ? 1e-30f : ld.y), __builtin_amdgcn_rcpf(ld.z == 0.f ? 1e-30f : ld.z));
-        if (!(box_entry(sh.bmin, sh.bmax, lo, lid, ANY ? maxt : best.t) < INFINITY)) continue;
+        const SlabRay lr = slab_ray(lo, ld);
+        float t_entry;
+        if (!box_hit(sh.bmin, sh.bmax, lr, ANY ? maxt : best.t, t_entry)) continue;
         // `face` of the best hit so far IF it lies on this very mesh (ties between two of its triangles go to the lower face)
         uint32_t best_face = 0xffffffffu;
         DTOF_STAT(5);
@@ -356,7 +364,7 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
         for (;;) {
             while (!(cur & kLeafFlag) && cur != kDone) {
                 DTOF_STAT(7);
-                cur = node_step(sv.nodes, cur, lo, lid, ANY ? maxt : best.t, stack, bsp, sp, stride, kDone);
+                cur = node_step<false, STRIDE>(sv.nodes, cur, lr, ANY ? maxt : best.t, stack, bsp, sp, stride, kDone);
             }
             if (cur == kDone) break;
             uint32_t f0 = (cur & ~kLeafFlag) >> kBlasLeafBits, fn = (cur & ((1u << kBlasLeafBits) - 1u)) + 1u;
@@ -369,29 +377,27 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
 }
 
 // TLAS traversal; `stack` is a per-thread LDS column (stride blockDim.x).
-template <bool ANY, bool MESH, bool MEMO = false, bool SOA = false>   // SOA: the TLAS nodes are the LDS planes of the resident stage (binary nodes only)
+template <bool ANY, bool MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0>   // SOA: the TLAS nodes are the LDS planes of the resident stage (binary nodes only); STRIDE: the block size, if the kernel knows it
 DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best) {
     best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
     if (sv.n_nodes == 0) return false;
-    // direction reciprocal for the slab test only (exact zero components are nudged)
-    // v_rcp_f32 (1 ulp) is enough here: the boxes are padded by 1e-5 relative on the host
-    V3 id = mk(__builtin_amdgcn_rcpf(d.x == 0.f ? 1e-30f : d.x), __builtin_amdgcn_rcpf(d.y == 0.f ? 1e-30f : d.y), __builtin_amdgcn_rcpf(d.z == 0.f ? 1e-30f : d.z));
+    const SlabRay r = slab_ray(o, d);
     // "while-while" traversal: every lane first descends inner nodes until it holds a leaf (or is done), THEN the
     // lanes that hold a leaf run the expensive object intersection together -- the wave does not pay the leaf
     // body once per node step of its slowest lane.
     constexpr uint32_t kDone = 0x7fffffffu;
     int sp = 0;
     uint32_t cur = 0;
-    const uint32_t stride = blockDim.x;
+    const uint32_t stride = STRIDE ? STRIDE : blockDim.x;
     DTOF_STAT(0);
     for (;;) {
         while (!(cur & kLeafFlag) && cur != kDone) {
             DTOF_STAT(1); DTOF_STAT_WAVE(2);
-            cur = node_step<SOA>(sv.nodes, cur, o, id, best.t, stack, sp, 0, stride, kDone);
+            cur = node_step<SOA, STRIDE>(sv.nodes, cur, r, best.t, stack, sp, 0, stride, kDone);
         }
         if (cur == kDone) break;
         DTOF_STAT(3); DTOF_STAT_WAVE(4);
-        if (intersect_object<ANY, MESH, MEMO>(sv, cur & ~kLeafFlag, o, d, time, maxt, best, stack, sp, stride) && ANY) return true;
+        if (intersect_object<ANY, MESH, MEMO, STRIDE>(sv, cur & ~kLeafFlag, o, d, time, maxt, best, stack, sp, stride) && ANY) return true;
         if (sp == 0) break;
         --sp; cur = stack[sp * stride];
     }
@@ -403,10 +409,10 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
 // measured slower in round 3; it is parked as tools/experiments/r03_coop_triangles.patch with its numbers in profiles/r03_coop_triangles_ab.txt.)
 
 // Scene query of a kernel whose call site is wave-uniform; `active` says whether this lane has a ray.
-template <bool ANY, bool MESH, bool MEMO = false, bool SOA = false>
+template <bool ANY, bool MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0>
 DTOF_D bool trace_rays(const SceneView &sv, uint32_t *stack, bool active, V3 o, V3 d, float time, float maxt, Hit &best) {
     bool r = false;
-    if (active) r = trace_scene<ANY, MESH, MEMO, SOA>(sv, stack, o, d, time, maxt, best);
+    if (active) r = trace_scene<ANY, MESH, MEMO, SOA, STRIDE>(sv, stack, o, d, time, maxt, best);
     return r;
 }
 
