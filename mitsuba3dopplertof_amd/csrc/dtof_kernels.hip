@@ -783,7 +783,7 @@ void launch_ray_query(const uint8_t *scene, const float *rays, float *out, int32
 static bool (*g_stats_readers[16])(unsigned long long *); static int g_n_stats_readers;   // zero-initialised before any dynamic initialiser runs
 void register_traversal_stats_reader(bool (*reader)(unsigned long long *acc8)) { if (g_n_stats_readers < 16) g_stats_readers[g_n_stats_readers++] = reader; }
 bool read_traversal_stats(unsigned long long *out8) {
-    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    for (int i = 0; i < 16; ++i) out8[i] = 0;
     for (int k = 0; k < g_n_stats_readers; ++k) if (!g_stats_readers[k](out8)) return false;
     return true;
 }

@@ -33,7 +33,7 @@ struct BlobHeader {
     uint32_t n_nodes, n_objects, n_groups, n_shapes, n_tris, n_emitters;
     uint32_t off_nodes, off_objects, off_groups, off_shapes, off_tris, off_shading, off_emitters;
     uint32_t total_bytes, off_tables, tlas_depth, off_flat;      // off_tables: face distributions of mesh emitters (float / uint32 words)   // tlas_depth: stack entries a traversal can need (TLAS depth + deepest BLAS)
-    uint32_t pad[3];                                   // off_flat: DFlatObject[n_objects] of a rectangle-only scene of at most kFlatObjects objects, else 0
+    uint32_t off_isect, pad[2];                        // off_isect: DTriIsect[n_tris], what the triangle test reads   // off_flat: DFlatObject[n_objects] of a rectangle-only scene of at most kFlatObjects objects, else 0
 };
 static_assert(sizeof(BlobHeader) == 80, "BlobHeader");
 // One top-level object of a small rectangle-only scene as trace_flat (dtof_traverse.h) reads it with ONE scalar load: a plain rectangle's
@@ -128,6 +128,10 @@ struct DTexture {           // 64 B
     uint32_t pad;           // 0 = none (built for the textures an area emitter's radiance is sampled through, bitmap.cpp:450-528)
 };
 struct DTri { float p0[3]; uint32_t face; float p1[4], p2[4]; };         // 48 B; face = index in the mesh's own order (tie rule)
+// What Moeller-Trumbore reads of a triangle (tri_hit, dtof_traverse.h): the first vertex, the two edges e1 = p0 - p1, e2 = p2 - p0 and ng = cross(e2, e1), computed on the
+// host with the very operations (dtof_math.h) the kernels used to repeat for every test -- 15 of the test's 45 instructions.  Same 48 bytes as the vertices; `face`
+// (needed when two hits tie, and by shading) stays in DTri.
+struct DTriIsect { float p0[3], ngx, e1[3], ngy, e2[3], ngz; };
 struct DTriShade { float n0[3], n1[3], n2[3], uv0[2], uv1[2], uv2[2], pad; };   // 64 B
 struct DEmitter {           // 96 B
     uint32_t kind; float pos[3]; float intensity[3]; uint32_t shape;   // area: intensity = radiance, shape = index into shapes[]
@@ -151,7 +155,7 @@ struct DEnvmap {
 static_assert(sizeof(DEnvmap) % 16 == 0, "DEnvmap");
 static_assert(sizeof(BvhNode4) == 64, "BvhNode4");
 static_assert(sizeof(DTexture) == 64, "DTexture");
-static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 352 && sizeof(DTri) == 48 && sizeof(DTriShade) == 64 && sizeof(DEmitter) == 96, "blob records");
+static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 352 && sizeof(DTri) == 48 && sizeof(DTriIsect) == 48 && sizeof(DTriShade) == 64 && sizeof(DEmitter) == 96, "blob records");
 
 // ---------------------------------------------------------------------------- host description
 struct Mat4d { double m[16]; };   // row-major

@@ -352,6 +352,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
         sv_res.nodes = (const DNode *) lds;
         sv_res.groups = (const DGroup *) (small + gh->off_groups); sv_res.shapes = (const DShape *) (small + gh->off_shapes);
         sv_res.tris = (const DTri *) (small + gh->off_tris); sv_res.shading = (const DTriShade *) (small + gh->off_shading);
+        sv_res.isect = (const DTriIsect *) (small + gh->off_isect);
         sv_res.emitters = (const DEmitter *) (small + gh->off_emitters);
     }
     for (uint32_t seg_first = 1;; seg_first = 0) {   // resident: until the segment counter runs out; otherwise once
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             }
             if (have_memo) instance_memo_fill(sv, ra.w, memo_m, memo_inv);
             Hit h;
-            bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h)
+            bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, rp.flat_off, flat, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h)
                               : trace_scene<false, MESH, FUSED, RESW != 0, kStackStride>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
             hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
             hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu;
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
 #if defined(DTOF_ABLATE) && (DTOF_ABLATE & 1)
             commit = sha.w > 0.f;
 #else
-            commit = flat ? !trace_flat<true, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs)
+            commit = flat ? !trace_flat<true, true>(sv, (ConstBytes) A.scene + rp.flat_off, rp.flat_off, flat, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs)
                           : !trace_scene<true, MESH, true, RESW != 0, kStackStride>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
 #endif
         }
@@ -781,7 +782,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
 #if defined(DTOF_ABLATE) && (DTOF_ABLATE & 2)
             bool found = nra.x < 1e30f; h.t = 0.5f + 0.1f * nrb.x; h.u = nrb.y; h.v = nrb.z; h.obj = nrb.x > 0.3f ? 3 : nrb.y > 0.f ? 1 : 0; h.shape = 0; h.prim = 0;
 #else
-            bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h)
+            bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h)
                               : trace_scene<false, MESH, true, RESW != 0, kStackStride>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
 #endif
             if (!FIRST || last) store_hit<MESH>(q, l, h, found);

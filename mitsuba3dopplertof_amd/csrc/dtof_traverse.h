@@ -14,7 +14,7 @@ namespace dtof {
 // ---------------------------------------------------------------------------- scene view
 struct SceneView {
     const DNode *nodes; const DObject *objects; const DGroup *groups; const DShape *shapes;
-    const DTri *tris; const DTriShade *shading; const DEmitter *emitters; const uint8_t *base;
+    const DTri *tris; const DTriIsect *isect; const DTriShade *shading; const DEmitter *emitters; const uint8_t *base;
     uint32_t n_nodes, n_emitters;
     // Fused shade kernels, scenes with ONE instance object: the world -> object matrix of that instance at the lane's ray time is
     // computed once per path vertex (instance_memo_fill) and kept in a per-thread LDS column; the closest-hit and occlusion queries of
@@ -35,6 +35,7 @@ DTOF_D SceneView make_view(const uint8_t *base) {
     v.groups = (const DGroup *) (base + h->off_groups);
     v.shapes = (const DShape *) (base + h->off_shapes);
     v.tris = (const DTri *) (base + h->off_tris);
+    v.isect = (const DTriIsect *) (base + h->off_isect);
     v.shading = (const DTriShade *) (base + h->off_shading);
     v.emitters = (const DEmitter *) (base + h->off_emitters);
     v.base = base;
@@ -54,14 +55,15 @@ struct Hit { float t, u, v; uint32_t obj, shape, prim; };
 
 // Traversal statistics (development builds only: make STATS=1 -> libdtof_stats.so, read by tools/traversal_stats.py).
 // [0] rays  [1] node steps (lane)  [2] node iterations (wave)  [3] leaf visits (lane)  [4] leaf rounds (wave)  [5] mesh loops entered (lane)
-// [6] triangle tests (lane)  [7] BLAS node steps (lane)
+// [6] triangle tests (lane)  [7] BLAS node steps (lane)  [8] instance transforms (lane)  [9] instance transforms (wave)  [10] mesh loops entered (wave)
+// [11] triangle tests (wave)  [12] rectangle tests (lane)  [13] rectangle tests (wave)
 #ifdef DTOF_TRAVERSAL_STATS
 // every translation unit with kernels counts into its own copy (no relocatable device code); each registers a reader, read_traversal_stats sums and resets them all
-static __device__ unsigned long long g_trav_stats[8];
+static __device__ unsigned long long g_trav_stats[16];
 static bool read_tu_traversal_stats(unsigned long long *acc8) {
-    unsigned long long v[8], zero[8] = { 0 };
-    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_trav_stats), 64) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), zero, 64) != hipSuccess) return false;
-    for (int i = 0; i < 8; ++i) acc8[i] += v[i];
+    unsigned long long v[16], zero[16] = { 0 };
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_trav_stats), 128) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), zero, 128) != hipSuccess) return false;
+    for (int i = 0; i < 16; ++i) acc8[i] += v[i];
     return true;
 }
 static const int g_trav_stats_registered = (register_traversal_stats_reader(read_tu_traversal_stats), 0);
@@ -87,14 +89,13 @@ DTOF_D bool disk_hit(const DShape &sh, V3 o, V3 d, float maxt, float &t, float &
     u = fmaf(ld.x, t, lo.x); v = fmaf(ld.y, t, lo.y);
     return t >= 0.f && t <= maxt && u * u + v * v <= 1.f;
 }
-// Moeller-Trumbore as in Embree 3's triangle intersector (tnear < t <= tfar; u,v weight vertices 1,2).
-// The 48-byte record is fetched with three 16-byte loads issued together; `face` rides in p0.w.
-DTOF_D bool tri_hit(const DTri &tr, V3 o, V3 d, float maxt, float &t, float &u, float &v, uint32_t &face) {
+// Moeller-Trumbore as in Embree 3's triangle intersector (tnear < t <= tfar; u,v weight vertices 1,2).  The 48-byte record (DTriIsect: first vertex, edges and
+// geometric normal, precomputed on the host with these operations) is fetched with three 16-byte loads issued together.
+DTOF_D bool tri_hit(const DTriIsect &tr, V3 o, V3 d, float maxt, float &t, float &u, float &v) {
     const uint4 *tp = (const uint4 *) &tr;
     const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-    face = q0.w;
-    V3 p0 = mk(u2f(q0.x), u2f(q0.y), u2f(q0.z)), p1 = mk(u2f(q1.x), u2f(q1.y), u2f(q1.z)), p2 = mk(u2f(q2.x), u2f(q2.y), u2f(q2.z));
-    V3 e1 = p0 - p1, e2 = p2 - p0, ng = cross(e2, e1);
+    const V3 p0 = mk(u2f(q0.x), u2f(q0.y), u2f(q0.z)), e1 = mk(u2f(q1.x), u2f(q1.y), u2f(q1.z)), e2 = mk(u2f(q2.x), u2f(q2.y), u2f(q2.z));
+    const V3 ng = mk(u2f(q0.w), u2f(q1.w), u2f(q2.w));
     V3 c = p0 - o, r = cross(c, d);
     float den = dot(ng, d), aden = fabsf(den);
     uint32_t sgn = f2u(den) & 0x80000000u;
@@ -217,6 +218,9 @@ DTOF_D uint32_t node_step(const BvhNode *nodes, uint32_t cur, const SlabRay &r, 
     const uint32_t stride = STRIDE ? STRIDE : stride_rt;
     const uint4 *np = SOA ? (const uint4 *) nodes + cur : (const uint4 *) (nodes + cur);
     const uint4 a = np[0], b = np[SOA ? kResNodes : 1], c = np[SOA ? 2 * kResNodes : 2], d = np[SOA ? 3 * kResNodes : 3];
+#ifdef DTOF_EXTRA_NODE_LOADS   // experiment: two more 16-byte loads per step from the neighbouring node (does the traversal wait for the vector memory path's throughput?)
+    if (!SOA) { const uint4 *xp = (const uint4 *) (nodes + (cur ^ 1u)); const uint4 e = xp[0], f = xp[2]; asm volatile("" :: "v"(e.x), "v"(f.x)); }
+#endif
     const float lmin[3] = { u2f(a.x), u2f(a.y), u2f(a.z) }, lmax[3] = { u2f(b.x), u2f(b.y), u2f(b.z) };
     const float rmin[3] = { u2f(c.x), u2f(c.y), u2f(c.z) }, rmax[3] = { u2f(d.x), u2f(d.y), u2f(d.z) };
     const uint32_t left = a.w, right = b.w;
@@ -288,6 +292,7 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
         float m[12], inv[12];
         if (MEMO && oi == sv.memo_obj) instance_memo_load(sv, inv);
         else {
+            DTOF_STAT(8); DTOF_STAT_WAVE(9);
             instance_matrix(ob, time, m);
             affine_inverse(m, inv);
         }
@@ -300,6 +305,7 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
         const DShape &sh = sv.shapes[first + k];
         float t, u, v;
         if (sh.kind == SHAPE_RECT) {
+            DTOF_STAT(12); DTOF_STAT_WAVE(13);
             if (rect_hit(sh, lo, ld, maxt, t, u, v)) {
                 if (ANY) return true;
                 if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
@@ -343,12 +349,12 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
         if (!box_hit(sh.bmin, sh.bmax, lr, ANY ? maxt : best.t, t_entry)) continue;
         // `face` of the best hit so far IF it lies on this very mesh (ties between two of its triangles go to the lower face)
         uint32_t best_face = 0xffffffffu;
-        DTOF_STAT(5);
+        DTOF_STAT(5); DTOF_STAT_WAVE(10);
         auto test = [&](uint32_t f) -> bool {
-            uint32_t face;
-            DTOF_STAT(6);
-            if (!tri_hit(sv.tris[sh.first_tri + f], lo, ld, maxt, t, u, v, face)) return false;
+            DTOF_STAT(6); DTOF_STAT_WAVE(11);
+            if (!tri_hit(sv.isect[sh.first_tri + f], lo, ld, maxt, t, u, v)) return false;
             if (ANY) return true;
+            const uint32_t face = sv.tris[sh.first_tri + f].face;   // the triangle's index in the mesh's own order (the BLAS permutes them): decides ties
             bool take = t < best.t;
             if (t == best.t) take = best_face != 0xffffffffu ? face < best_face : (!found && best.obj != 0xffffffffu && oi < best.obj);
             if (take) { best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = k; best.prim = f; best_face = face; found = true; }
@@ -432,6 +438,9 @@ typedef const uint8_t __attribute__((address_space(4))) *ConstBytes;
 #ifndef DTOF_FLAT_PK
 #define DTOF_FLAT_PK 0
 #endif
+#ifndef DTOF_FLAT_LDS
+#define DTOF_FLAT_LDS 1
+#endif
 typedef float F2 __attribute__((ext_vector_type(2)));
 struct FlatRecord { uint32_t instance; F2 c0, c1, c2, c3; float z0, z1, z2, z3; };   // (x, y) entries of the four columns as pairs, the z row apart
 DTOF_D FlatRecord flat_load(const DFlatObject __attribute__((address_space(4))) *f) {
@@ -441,7 +450,7 @@ DTOF_D FlatRecord flat_load(const DFlatObject __attribute__((address_space(4))) 
     return r;
 }
 template <bool ANY, bool MEMO>
-DTOF_D bool trace_flat(const SceneView &sv, ConstBytes flat_table, uint32_t n_objects, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best) {
+DTOF_D bool trace_flat(const SceneView &sv, ConstBytes flat_table, uint32_t flat_off, uint32_t n_objects, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best) {
     typedef const DFlatObject __attribute__((address_space(4))) *ConstFlat;
     const ConstFlat table = (ConstFlat) flat_table;
     best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
@@ -480,6 +489,20 @@ DTOF_D bool trace_flat(const SceneView &sv, ConstBytes flat_table, uint32_t n_ob
     // and no register is copied from one iteration to the next.  Instances are noted in a mask and intersected after the rectangles: the
     // tie rule of intersect_object (equal t goes to the lower object index) does not depend on the order of the visits.
     uint32_t instances = 0, oi = 0;
+#if DTOF_FLAT_LDS
+    // The records come from the scene copy staged in LDS, every lane reading the same address (a broadcast, four ds_read_b128 per record): the matrix entries are then
+    // VGPR operands of the multiply-adds, which issue at full rate -- as SGPR operands (scalar loads from the blob) each of the 21 costs two issue slots
+    // (profiles/r03_ubench_valu_rate.txt).
+    const DFlatObject *lt = (const DFlatObject *) (sv.base + flat_off);
+    for (; oi < n_objects; ++oi) {
+        const uint4 *rp4 = (const uint4 *) (lt + oi);
+        const uint4 r0 = rp4[0], r1 = rp4[1], r2 = rp4[2], r3 = rp4[3];
+        FlatRecord a; a.instance = (uint32_t) __builtin_amdgcn_readfirstlane((int) r0.w);
+        a.c0 = F2{ u2f(r0.x), u2f(r0.y) }; a.c1 = F2{ u2f(r1.x), u2f(r1.y) }; a.c2 = F2{ u2f(r2.x), u2f(r2.y) }; a.c3 = F2{ u2f(r3.x), u2f(r3.y) };
+        a.z0 = u2f(r0.z); a.z1 = u2f(r1.z); a.z2 = u2f(r2.z); a.z3 = u2f(r3.z);
+        if (a.instance == 1 || (a.instance == 2 && !(MEMO && sv.memo_obj == oi))) instances |= 1u << oi; else test(a, oi);
+    }
+#else
     FlatRecord a = flat_load(table);
     for (;;) {
         FlatRecord b;
@@ -494,6 +517,7 @@ DTOF_D bool trace_flat(const SceneView &sv, ConstBytes flat_table, uint32_t n_ob
         if (!more_a) break;
         ++oi;
     }
+#endif
     while (instances) {   // uniform
         const uint32_t k = (uint32_t) __builtin_ctz(instances); instances &= instances - 1u;
         const bool hit = intersect_object<ANY, false, MEMO>(sv, k, o, d, time, maxt, best, stack, 0, blockDim.x);

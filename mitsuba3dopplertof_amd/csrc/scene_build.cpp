@@ -550,6 +550,14 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     h.off_emitters = place(emitters.size() * sizeof(DEmitter));
     h.off_tris = place(tris.size() * sizeof(DTri));
     h.off_shading = place(shading.size() * sizeof(DTriShade));
+    std::vector<DTriIsect> isect(tris.size());   // in the final (BLAS) order of the triangles
+    for (size_t i = 0; i < tris.size(); ++i) {
+        const DTri &t = tris[i];
+        const V3 p0 = mk(t.p0[0], t.p0[1], t.p0[2]), p1 = mk(t.p1[0], t.p1[1], t.p1[2]), p2 = mk(t.p2[0], t.p2[1], t.p2[2]);
+        const V3 e1 = p0 - p1, e2 = p2 - p0, ng = cross(e2, e1);
+        isect[i] = DTriIsect{ { p0.x, p0.y, p0.z }, ng.x, { e1.x, e1.y, e1.z }, ng.y, { e2.x, e2.y, e2.z }, ng.z };
+    }
+    h.off_isect = place(isect.size() * sizeof(DTriIsect));
     h.off_tables = place((uint64_t) tables.size() * 4);
     std::vector<DFlatObject> flat;   // small rectangle-only scenes: one 64-byte record per object for trace_flat
     {
@@ -594,6 +602,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     if (!emitters.empty()) memcpy(blob.data() + h.off_emitters, emitters.data(), emitters.size() * sizeof(DEmitter));
     if (!tris.empty()) memcpy(blob.data() + h.off_tris, tris.data(), tris.size() * sizeof(DTri));
     if (!shading.empty()) memcpy(blob.data() + h.off_shading, shading.data(), shading.size() * sizeof(DTriShade));
+    if (!isect.empty()) memcpy(blob.data() + h.off_isect, isect.data(), isect.size() * sizeof(DTriIsect));
     if (!tables.empty()) memcpy(blob.data() + h.off_tables, tables.data(), tables.size() * 4);
     if (!flat.empty()) memcpy(blob.data() + h.off_flat, flat.data(), flat.size() * sizeof(DFlatObject));
     return blob;

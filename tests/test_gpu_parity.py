@@ -486,12 +486,16 @@ def test_repeated_renders_and_handles_do_not_leak_device_memory(mi):
         sc.sample_lanes(i, 16, 0, 4096)
     torch.cuda.synchronize()
     assert abs(torch.cuda.mem_get_info()[0] - free0) <= 8 << 20
-    for i in range(12):                                           # handles come and go
-        tmp = mi.load_file(path, resx=96, resy=96)
-        tmp.render(seed=i, spp=32)
-        del tmp
-    gc.collect(); torch.cuda.synchronize()
-    assert abs(torch.cuda.mem_get_info()[0] - free0) <= 8 << 20
+    def churn(n):                                                  # handles come and go
+        for i in range(n):
+            tmp = mi.load_file(path, resx=96, resy=96)
+            tmp.render(seed=i, spp=32)
+            del tmp
+        gc.collect(); torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+    free1 = churn(12)
+    assert abs(free1 - free0) <= 32 << 20                          # the runtime may keep one of its 16 MiB pool blocks after the first handles are gone ...
+    assert abs(churn(24) - free1) <= 8 << 20                       # ... but twice as many handles later nothing more is missing
 
 
 def test_full_size_c3_multi_batch_frame_matches_oracle(mi, orc, monkeypatch):
