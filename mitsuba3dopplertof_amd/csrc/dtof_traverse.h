@@ -218,9 +218,6 @@ DTOF_D uint32_t node_step(const BvhNode *nodes, uint32_t cur, const SlabRay &r, 
     const uint32_t stride = STRIDE ? STRIDE : stride_rt;
     const uint4 *np = SOA ? (const uint4 *) nodes + cur : (const uint4 *) (nodes + cur);
     const uint4 a = np[0], b = np[SOA ? kResNodes : 1], c = np[SOA ? 2 * kResNodes : 2], d = np[SOA ? 3 * kResNodes : 3];
-#ifdef DTOF_EXTRA_NODE_LOADS   // experiment: two more 16-byte loads per step from the neighbouring node (does the traversal wait for the vector memory path's throughput?)
-    if (!SOA) { const uint4 *xp = (const uint4 *) (nodes + (cur ^ 1u)); const uint4 e = xp[0], f = xp[2]; asm volatile("" :: "v"(e.x), "v"(f.x)); }
-#endif
     const float lmin[3] = { u2f(a.x), u2f(a.y), u2f(a.z) }, lmax[3] = { u2f(b.x), u2f(b.y), u2f(b.z) };
     const float rmin[3] = { u2f(c.x), u2f(c.y), u2f(c.z) }, rmax[3] = { u2f(d.x), u2f(d.y), u2f(d.z) };
     const uint32_t left = a.w, right = b.w;
