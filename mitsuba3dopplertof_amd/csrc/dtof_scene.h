@@ -201,7 +201,7 @@ struct HostObject {
 };
 struct HostEmitter { uint32_t kind = 0; float pos[3] = { 0, 0, 0 }; float intensity[3] = { 0, 0, 0 }; uint32_t shape = 0xffffffffu;
                      float to_local[12] = { 0 }, cutoff_angle = 0, cos_cutoff = 0, cos_beam = 0, inv_transition = 0;    // spot
-                     std::vector<float> image; uint32_t image_w = 0, image_h = 0; float scale = 1.f, to_world[12] = { 0 }; };   // envmap: linear RGB rows (top first), m_scale, emitter -> world
+                     std::vector<float> image; uint32_t image_w = 0, image_h = 0; float scale = 1.f, to_world[12] = { 0 }; bool mis_compensation = false; };   // envmap: linear RGB rows (top first), m_scale, emitter -> world
 struct HostSensor {
     float to_world[16];
     float x_fov = 0, near_clip = 1e-2f, far_clip = 1e4f, shutter_open = 0, shutter_close = 0;

@@ -467,12 +467,23 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
             const HostEmitter &he = sc.emitters[i];
             const uint32_t bw = he.image_w, W = bw + 1, H = he.image_h;
             std::vector<float> data((size_t) W * H * 3), lum((size_t) W * H);
+            float luminance_offset = 0.f;   // mis_compensation (envmap.cpp:157-185): the mean luminance, unless the map is (nearly) constant
+            if (he.mis_compensation) {
+                float min_lum = 0.f; double accum = 0.0;
+                for (size_t i = 0; i < (size_t) bw * H; ++i) {
+                    const float *in = &he.image[i * 3];
+                    const float l = in[0] * 0.212671f + in[1] * 0.715160f + in[2] * 0.072169f;
+                    min_lum = fmin_(min_lum, l); accum += (double) l;
+                }
+                luminance_offset = (float) (accum / (double) ((size_t) bw * H));
+                if (luminance_offset - min_lum <= 0.01f * luminance_offset) luminance_offset = 0.f;
+            }
             const float theta_scale = 1.f / (float) (H - 1) * kPi;
             for (uint32_t y = 0; y < H; ++y) {
                 const float sin_theta = sinf((float) y * theta_scale);   // ScalarFloat dr::sin
                 for (uint32_t x = 0; x < bw; ++x) {
                     const float *in = &he.image[((size_t) y * bw + x) * 3];
-                    const float l = fmax_(in[0] * 0.212671f + in[1] * 0.715160f + in[2] * 0.072169f, 0.f);   // mitsuba::luminance (spectrum.h:431-434)
+                    const float l = fmax_(in[0] * 0.212671f + in[1] * 0.715160f + in[2] * 0.072169f - luminance_offset, 0.f);   // mitsuba::luminance (spectrum.h:431-434)
                     lum[(size_t) y * W + x] = l * sin_theta;
                     memcpy(&data[((size_t) y * W + x) * 3], in, 12);
                 }

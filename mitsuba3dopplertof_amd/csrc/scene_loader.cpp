@@ -1444,7 +1444,7 @@ HostScene load_scene_xml(const std::string &text, const std::map<std::string, st
                 e.kind = EMITTER_ENVMAP;
                 const std::string fn = o.props.get_string("filename", "");
                 if (fn.empty()) fail("Property \"filename\" has not been specified!");
-                if (o.props.get_bool("mis_compensation", false)) fail("envmap: \"mis_compensation\" is not supported");
+                e.mis_compensation = o.props.get_bool("mis_compensation", false);   // envmap.cpp:157-185: the sampling tables are built from max(luminance - mean, 0)
                 const std::string path = resolve_path(fn);
                 read_radiance_image(path, e.image, e.image_w, e.image_h, srgb_to_linear_u8);
                 if (e.image_w < 2 || e.image_h < 3) fail("\"" + fn.substr(fn.find_last_of('/') == std::string::npos ? 0 : fn.find_last_of('/') + 1) + "\": the environment map resolution must be at least 2x3 pixels");

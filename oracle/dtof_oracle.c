@@ -223,20 +223,34 @@ orc_envmap *orc_hier2d_create(const float *values, int32_t width, int32_t height
     hier2d_build(e, values, (uint32_t) width, (uint32_t) height, normalize);
     return e;
 }
-orc_envmap *orc_envmap_create(const float *rgb, int32_t width, int32_t height, float scale) {
+/* mis_compensation (envmap.cpp:157-185, 216): the sampling density is built from max(luminance - average luminance, 0) ("MIS Compensation", Karlik et al. 2019)
+ * unless average and minimum are within 1 % of each other; eval() keeps the unmodified radiance */
+orc_envmap *orc_envmap_create2(const float *rgb, int32_t width, int32_t height, float scale, int32_t mis_compensation) {
     if (width < 2 || height < 3) return NULL;
     orc_envmap *e = (orc_envmap *) calloc(1, sizeof *e);
     const uint32_t W = (uint32_t) width + 1u, H = (uint32_t) height;
     e->w = (int32_t) W; e->h = (int32_t) H; e->scale = scale;
     e->data = (float *) malloc(sizeof(float) * 3u * W * H);
     float *lum = (float *) malloc(sizeof(float) * W * H);
+    float luminance_offset = 0.f;
+    if (mis_compensation) {
+        float min_lum = 0.f; double accum = 0.0;
+        for (uint32_t i = 0; i < (uint32_t) width * H; ++i) {
+            const float *in = rgb + 3u * i;
+            const float l = in[0] * 0.212671f + in[1] * 0.715160f + in[2] * 0.072169f;
+            min_lum = f_min(min_lum, l);
+            accum += (double) l;
+        }
+        luminance_offset = (float) (accum / (double) ((uint32_t) width * H));
+        if (luminance_offset - min_lum <= 0.01f * luminance_offset) luminance_offset = 0.f;   /* (nearly) constant maps: disabled */
+    }
     const float theta_scale = 1.f / (float) (H - 1u) * ORC_PI_F;
     for (uint32_t y = 0; y < H; ++y) {
         const float sin_theta = sinf((float) y * theta_scale);
         for (uint32_t x = 0; x < (uint32_t) width; ++x) {
             const float *in = rgb + 3u * (y * (uint32_t) width + x);
             float l = in[0] * 0.212671f + in[1] * 0.715160f + in[2] * 0.072169f;   /* mitsuba::luminance (spectrum.h:431-434) */
-            l = f_max(l - 0.f, 0.f);
+            l = f_max(l - luminance_offset, 0.f);
             lum[y * W + x] = l * sin_theta;
             memcpy(e->data + 3u * (y * W + x), in, 12);
         }
@@ -247,6 +261,7 @@ orc_envmap *orc_envmap_create(const float *rgb, int32_t width, int32_t height, f
     free(lum);
     return e;
 }
+orc_envmap *orc_envmap_create(const float *rgb, int32_t width, int32_t height, float scale) { return orc_envmap_create2(rgb, width, height, scale, 0); }
 void orc_envmap_free(orc_envmap *e) {
     if (!e) return;
     for (int32_t i = 0; i < e->n_levels; ++i) free(e->level[i]);

@@ -151,6 +151,7 @@ typedef struct orc_envmap {
     float   patch_size[2], inv_patch_size[2]; uint32_t max_patch[2];
 } orc_envmap;
 orc_envmap *orc_envmap_create(const float *rgb, int32_t width, int32_t height, float scale);
+orc_envmap *orc_envmap_create2(const float *rgb, int32_t width, int32_t height, float scale, int32_t mis_compensation);
 void     orc_envmap_free(orc_envmap *e);
 orc_envmap *orc_hier2d_create(const float *values, int32_t width, int32_t height, int32_t normalize);   /* Hierarchical2D<Float, 0> over a plain grid (test_distr_2d.py) */
 /* known-answer entry points: Hierarchical2D::sample / eval, the emitter's sample_direction / pdf_direction / eval */

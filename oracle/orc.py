@@ -431,9 +431,9 @@ class Scene:
         for i, e in enumerate(fs.emitters):
             if e["kind"] == 4:   # envmap: the tables of the constructor (envmap.cpp:130-224), built by the C side
                 img = np.ascontiguousarray(e["image"], np.float32)
-                L.orc_envmap_create.restype = C.c_void_p
-                L.orc_envmap_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float]
-                h = L.orc_envmap_create(img.ctypes.data, img.shape[1], img.shape[0], C.c_float(float(e["scale"])))
+                L.orc_envmap_create2.restype = C.c_void_p
+                L.orc_envmap_create2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32]
+                h = L.orc_envmap_create2(img.ctypes.data, img.shape[1], img.shape[0], C.c_float(float(e["scale"])), int(bool(e.get("mis_compensation", False))))
                 emitters[i].envmap = h
                 emitters[i].env_to_world = _m16(e["to_world"]); emitters[i].to_local = _m16(e["to_local"])
                 self._envmaps.append(h)

@@ -1250,15 +1250,13 @@ def load(source, params=None, is_string=False):
                 fn = child.get_s("filename", None)
                 if fn is None:
                     raise ValueError('Property "filename" has not been specified!')
-                if child.get_b("mis_compensation", False):
-                    raise ValueError('envmap: "mis_compensation" is not supported')
                 img = read_radiance_image(resolve_path(fn))
                 if img.shape[1] < 2 or img.shape[0] < 3:
                     raise ValueError('"%s": the environment map resolution must be at least 2x3 pixels' % os.path.basename(fn))
                 tw, tinv = child["to_world"][1] if "to_world" in child and child["to_world"][0] == "transform" else (_ident(), _ident())
                 child.queried.add("to_world")
                 fs.emitters.append(dict(kind=4, position=np.zeros(3, F32), intensity=np.zeros(3, F32), image=img, scale=F32(child.get_f("scale", 1.0)),
-                                        to_world=_m32(tw), to_local=_m32(tinv)))
+                                        to_world=_m32(tw), to_local=_m32(tinv), mis_compensation=child.get_b("mis_compensation", False)))
                 continue
             if child.plugin != "point":
                 raise ValueError('unsupported emitter plugin "%s"' % child.plugin)

@@ -287,8 +287,17 @@ def test_envmap_scene(mi, orc, tmp_path):
     assert np.array_equal(scj.export(16).view(np.uint32), envmap_export(oscj.c.emitters[[e["kind"] for e in oscj.flat.emitters].index(4)]).view(np.uint32))
     with pytest.raises(mi.DtofError, match="Only one environment emitter"):
         load("two.xml", absolute.replace("</scene>", '<emitter type="constant"/></scene>'))
-    with pytest.raises(mi.DtofError, match="mis_compensation"):
-        load("mis.xml", absolute.replace('<float name="scale" value="0.6" />', '<boolean name="mis_compensation" value="true" />'))
+    # mis_compensation (envmap.cpp:157-185): the sampling tables are built from max(luminance - mean luminance, 0); both builds make the same tables, texels
+    # below the mean are never sampled, the radiance data is untouched
+    (tmp_path / "mis.xml").write_text(absolute.replace('<float name="scale" value="0.6" />', '<float name="scale" value="0.6" /><boolean name="mis_compensation" value="true" />'))
+    scm, oscm = mi.load_file(str(tmp_path / "mis.xml")), orc.Scene(str(tmp_path / "mis.xml"), {})
+    comp = scm.export(16)
+    assert np.array_equal(comp.view(np.uint32), envmap_export(oscm.c.emitters[[e["kind"] for e in oscm.flat.emitters].index(4)]).view(np.uint32))
+    plain = load("plain.xml", absolute).export(16)
+    w_, h_ = int(plain[0]), int(plain[1]); n_data = w_ * h_ * 3
+    assert np.array_equal(comp[:32 + n_data], plain[:32 + n_data]) and not np.array_equal(comp[32 + n_data:], plain[32 + n_data:])
+    lvl0_c, lvl0_p = comp[32 + n_data + 2:32 + n_data + 2 + w_ * h_], plain[32 + n_data + 2:32 + n_data + 2 + w_ * h_]
+    assert (lvl0_c == 0).sum() > (lvl0_p == 0).sum() + w_ and lvl0_c.max() > lvl0_p.max()
     sys.path.insert(0, SCENES)
     import make_scenes
     make_scenes.write_pfm(str(tmp_path / "tiny.pfm"), [[(1.0, 1.0, 1.0)] * 2] * 2)

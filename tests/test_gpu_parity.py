@@ -1046,8 +1046,8 @@ def _random_scene(rng, mesh_dir=None):
                                '<float name="cutoff_angle" value="%s"/></emitter>' % (f(-1, 1), f(-0.5, 0.5), rgb(10, 60), f(20, 50)),
                        "directional": '<emitter type="directional"><vector name="direction" x="%s" y="-1" z="%s"/><rgb name="irradiance" value="%s"/></emitter>' % (f(-0.5, 0.5), f(-0.5, 0.5), rgb(1, 4)),
                        "constant": '<emitter type="constant"><rgb name="radiance" value="%s"/></emitter>' % rgb(0.2, 1.0),
-                       "envmap": '<emitter type="envmap"><string name="filename" value="%s"/><float name="scale" value="%s"/><transform name="to_world"><rotate y="1" angle="%s"/></transform></emitter>'
-                                 % (os.path.join(SCENES, str(rng.choice(["env_sky.hdr", "env_sky.pfm", "env_sky.exr"]))), f(0.2, 1.0), f(0, 360))}[k])
+                       "envmap": '<emitter type="envmap"><string name="filename" value="%s"/><float name="scale" value="%s"/><boolean name="mis_compensation" value="%s"/><transform name="to_world"><rotate y="1" angle="%s"/></transform></emitter>'
+                                 % (os.path.join(SCENES, str(rng.choice(["env_sky.hdr", "env_sky.pfm", "env_sky.exr"]))), f(0.2, 1.0), str(rng.choice(["true", "false"])), f(0, 360))}[k])
         if k in ("constant", "envmap"):
             break
     return ('<scene version="3.0.0">%s<sensor type="%s">%s<transform name="to_world">%s<lookat origin="%s, %s, 5" target="0, 0.8, 0" up="0, 1, 0"/></transform>%s'
