@@ -52,10 +52,10 @@ template <typename T> struct DevBuf {
 // DTOF_STAT_SLOTS shrinks it so that the tests can exercise the wrap-around with short paths.
 static const uint32_t kMaxIter = [] { const char *e = getenv("DTOF_STAT_SLOTS"); int v = e ? atoi(e) : 0; return (uint32_t) (v >= 2 ? v : 256); }();
 static uint64_t target_batch_lanes() {   // lanes per wavefront batch (DTOF_BATCH_LANES overrides)
-    // 2^26 lanes (13 GB of workspace at 200 B per lane, 20 GB with four offset films -- of 288): every launch ends with a tail in which the CUs run dry one after the
-    // other, and a Domino frame in 32 launches of 2^24 lanes lost 7 % to it (C5 206 -> 193 ms, C4 44.8 -> 41.1; profiles/r03_batch_lanes.txt).  render_range halves the
-    // batch until its workspace fits the free device memory.
-    const char *e = getenv("DTOF_BATCH_LANES"); const uint64_t x = e ? strtoull(e, nullptr, 10) : 0; const uint64_t v = x ? x : (1ull << 26);   // read per call: tests of the batch seams set it
+    // 2^27 lanes (26 GB of workspace at 200 B per lane, 40 GB with four offset films -- of 288): every launch ends with a tail in which the CUs run dry one after the
+    // other, and a Domino frame in 32 launches of 2^24 lanes lost 7 % to it (C5 206 -> 193 ms, C4 44.8 -> 41.1; profiles/r03_batch_lanes.txt); one launch per C4 frame
+    // instead of two is another 2 % (34.86 -> 34.14 ms, profiles/r04_domino_waves_batch.txt).  render_range halves the batch until its workspace fits the free device memory.
+    const char *e = getenv("DTOF_BATCH_LANES"); const uint64_t x = e ? strtoull(e, nullptr, 10) : 0; const uint64_t v = x ? x : (1ull << 27);   // read per call: tests of the batch seams set it
     return v;
 }
 
@@ -429,10 +429,11 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     ResidentStage resident;
     {
         // 16 waves per CU (4 per SIMD, 128 VGPRs) beat 12 (168 VGPRs) once the nodes come from LDS: 44.2 vs 47.8 ms on Domino (profiles/r03_resident_stage_ab.txt)
-        // (the K = 4 kernels spill too much at 128 VGPRs: C5 218 ms with 12 waves, 232 ms with 16)
+        // (round 3: the K = 4 kernels spilled too much at 128 VGPRs -- C5 218 ms with 12 waves, 232 ms with 16; with the shorter traversal code of round 4 it is the other way
+        //  round: 192.7 ms with 12 waves, 181.0 with 16, profiles/r04_domino_waves_batch.txt)
         // (the every-BSDF kernels hold more state: 12 waves for one film, 8 for four -- 3.64 ms against 4.07 at 16, 5.15 ms against 5.82 at 12 on a Domino field of rough
         //  plastic cubes; profiles/r03_resident_spec_waves.txt)
-        int env_res = [&] { const char *e = getenv("DTOF_RESIDENT"); return e ? atoi(e) : (rp.has_spec ? (rp.n_offsets > 1 ? 8 : 12) : (rp.n_offsets > 1 ? 12 : 16)); }();   // read per call: tests and A/B runs switch it
+        int env_res = [&] { const char *e = getenv("DTOF_RESIDENT"); return e ? atoi(e) : (rp.has_spec ? (rp.n_offsets > 1 ? 8 : 12) : 16); }();   // read per call: tests and A/B runs switch it
         const uint32_t small_off = bh->off_groups, small_bytes = bh->off_tables - bh->off_groups;          // groups | shapes | emitters | triangles | shading data | intersection records
         if (fused && (env_res == 8 || env_res == 12 || env_res == 16) && rp.has_tris && !rp.has_blas && bh->n_nodes > 0 && bh->n_nodes <= kResidentNodes && blob_bytes > 16 * 1024 &&
             bh->off_shapes > bh->off_groups && bh->off_emitters > bh->off_groups && bh->off_tris > bh->off_groups && bh->off_shading >= bh->off_tris && bh->off_isect >= bh->off_shading && bh->off_tables >= bh->off_isect && small_bytes <= 24 * 1024) {
