@@ -644,30 +644,36 @@ def test_full_domino_scene_1025_objects(mi, orc, resident, monkeypatch):
 
 
 def test_full_size_c4_domino_rectangular_1024x1024x128(mi, orc):
-    """BASELINE configs[3] at FULL size (Domino, rectangular low-pass, antithetic 0.5, 1024 x 1024 x 128 spp = 134 217 728 lanes, eight
-    wavefront batches), through size-independent properties: (1) hetero_offset 0 vs 0.5 are negatives of each other -- the rectangular
+    """BASELINE configs[3] at FULL size (Domino, rectangular low-pass, antithetic 0.5, 1024 x 1024 x 128 spp = 134 217 728 lanes, rendered in two
+    wavefront batches and in one), through size-independent properties: (1) hetero_offset 0 vs 0.5 are negatives of each other -- the rectangular
     low-pass correlation 2 - 4c (waveform_utils.h:44-47) flips sign under a half-period shift exactly like the cosine; (2) path / bounce /
     shadow-ray counts; (3) finiteness; (4) a 4-row band of lanes, across a batch seam, bit-exact against the oracle."""
     path = os.path.join(SCENES, "domino.xml")
     params = dict(wave_function_type="rectangular", time_sampling_method="antithetic", antithetic_shift=0.5)
     sc = mi.load_file(path, **params)
     assert sc.size == (1024, 1024) and sc.info()["n_objects"] == 1025
-    both = sc.render(seed=0, spp=128, offsets=[0.0, 0.5])
+    os.environ["DTOF_BATCH_LANES"] = str(1 << 26)                              # two launches, so that the frame has a batch seam (the default, 2^27 lanes, covers it in one)
+    try:
+        both = sc.render(seed=0, spp=128, offsets=[0.0, 0.5])
+    finally:
+        del os.environ["DTOF_BATCH_LANES"]
     st = sc.last_stats
-    assert st["n_paths"] == 1024 * 1024 * 128 and st["n_batches"] == 2         # launches of 2^26 lanes
+    assert st["n_paths"] == 1024 * 1024 * 128 and st["n_batches"] == 2
+    one = sc.render(seed=0, spp=128, offsets=[0.0, 0.5])                        # ... and the default: one launch, the same films up to the order of the film atomics
+    assert sc.last_stats["n_batches"] == 1 and rel_linf(one[0], both[0]) <= 1e-5 and rel_linf(one[1], both[1]) <= 1e-5
     assert 0 < st["n_bounces"] <= 4 * st["n_paths"] and 0 < st["n_shadow_rays"] <= st["n_bounces"]
     assert np.isfinite(both).all() and np.abs(both[0]).max() > 0
     assert rel_linf(both[0], -both[1]) <= 2e-4, rel_linf(both[0], -both[1])
     osc = orc.Scene(path, params)
     lanes_per_row = 1024 * 128
-    lane0 = 639 * lanes_per_row            # rows 639..642: the seam between batches 5 and 6 (128 rows each) lies between rows 639 and 640
+    lane0 = 510 * lanes_per_row            # rows 510..513: the seam between the two batches (512 rows each) lies between rows 511 and 512
     g = sc.sample_lanes(0, 128, lane0, 4 * lanes_per_row)
     o = osc.render_lanes(osc.params(), 0, 128, lane0, 4 * lanes_per_row, threads=NCPU)
     for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
         assert np.array_equal(bits(g[k]), bits(o[k])), (k, int((bits(g[k]) != bits(o[k])).sum()))
-    # the developed image of a band of rows under SURVEY 8(d)'s per-pixel metric: rows 638..643 rendered by the oracle (brute force over 1 025 objects); their outer rows miss the
+    # the developed image of a band of rows under SURVEY 8(d)'s per-pixel metric: rows 509..514 rendered by the oracle (brute force over 1 025 objects); their outer rows miss the
     # splats of the neighbours the partial render leaves out and are not compared
-    r0, r1 = 638, 644
+    r0, r1 = 509, 515
     ref, _ = osc.render_exact(osc.params(), seed=0, spp=128, rows=(r0, r1), threads=NCPU)
     a, b = both[0][r0 + 1:r1 - 1], ref[r0 + 1:r1 - 1]
     scale = np.abs(both[0]).max()
@@ -677,7 +683,7 @@ def test_full_size_c4_domino_rectangular_1024x1024x128(mi, orc):
 
 def test_full_size_c5_domino_trapezoidal_1024x1024x512_four_offsets(mi, orc):
     """BASELINE configs[4] at FULL size: Domino, trapezoidal low-pass, antithetic 0.5, 1024 x 1024 x 512 spp with the four hetero_offset values
-    {0, .25, .5, .75} batched in ONE traversal (536 870 912 lanes, 32 wavefront batches, 2.1 G path-offsets), through size-independent properties:
+    {0, .25, .5, .75} batched in ONE traversal (536 870 912 lanes, four wavefront batches, 2.1 G path-offsets), through size-independent properties:
     (1) the films of offsets 0 / .5 and of .25 / .75 are negatives of each other -- the trapezoidal low-pass correlation clamp(2 (2 - 4c), -2, 2)
     (waveform_utils.h:52-58) is odd under a half-period shift like the cosine; (2) path / bounce / shadow-ray counts equal 4x those of the 128-spp
     frame up to sampling noise and the batch count; (3) finiteness, and the four films differ; (4) a 2-row band of lanes across a batch seam,
@@ -689,7 +695,7 @@ def test_full_size_c5_domino_trapezoidal_1024x1024x512_four_offsets(mi, orc):
     imgs = sc.render(seed=0, spp=512, offsets=offsets)
     st = sc.last_stats
     assert imgs.shape == (4, 1024, 1024, 3) and np.isfinite(imgs).all()
-    assert st["n_paths"] == 1024 * 1024 * 512 and st["n_batches"] == 8        # launches of 2^26 lanes
+    assert st["n_paths"] == 1024 * 1024 * 512 and st["n_batches"] == 4        # launches of 2^27 lanes
     assert st["n_paths"] < st["n_bounces"] <= 3 * st["n_paths"] and 0 < st["n_shadow_rays"] <= st["n_bounces"]
     scale = np.abs(imgs).max()
     assert scale > 0
@@ -697,7 +703,7 @@ def test_full_size_c5_domino_trapezoidal_1024x1024x512_four_offsets(mi, orc):
     assert np.abs(imgs[0] - imgs[1]).max() > 1e-2 * scale                      # a quarter period apart: different images
     osc = orc.Scene(path, params)
     lanes_per_row = 1024 * 512
-    lane0 = 31 * lanes_per_row                                                   # rows 31, 32: the seam between batches 0 and 1 (32 rows each)
+    lane0 = 255 * lanes_per_row                                                  # rows 255, 256: the seam between batches 0 and 1 (256 rows each)
     g = sc.sample_lanes(0, 512, lane0, 2 * lanes_per_row)
     o = osc.render_lanes(osc.params(), 0, 512, lane0, 2 * lanes_per_row, threads=NCPU)
     for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):

@@ -15,7 +15,13 @@ One op = one arithmetic instruction (an fma is one op; loads, stores, address ar
 import json, os
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(HERE, "profiles")
-NODE_STEP_OPS = 58        # two slab tests (6 sub + 6 mul + 6 min/max + 3 + 3 min/max + compare + select = 26 each) + ordering / selection of the children (6)
+NODE_STEP_OPS = 44        # two slab tests (6 multiply-adds + 6 min / max + 3 + 3 min / max + compare = 19 each, the form of round 4) + ordering / selection of the children (6)
+
+
+def newest(pattern):      # the round-4 file if it exists, else round 3's
+    for tag in ("r04", "r03"):
+        if os.path.exists(os.path.join(P, pattern % tag)): return pattern % tag
+    return pattern % "r04"
 
 
 def load(name):
@@ -24,12 +30,12 @@ def load(name):
 
 
 out = {}
-c2 = load("r03_oracle_opcount_c2.json")
+c2_name = newest("%s_oracle_opcount_c2.json"); c2 = load(c2_name)
 if c2:
     for cfg in ("c2", "c3"):
-        out[cfg] = {"ops_per_path": c2["ops_per_path_total"], "source": "profiles/r03_oracle_opcount_c2.json (oracle sha %s): path + query groups; the product tests every object too (trace_flat)" % c2["oracle_sha16"],
+        out[cfg] = {"ops_per_path": c2["ops_per_path_total"], "source": "profiles/%s (oracle sha %%s): path + query groups; the product tests every object too (trace_flat)" % c2_name % c2["oracle_sha16"],
                     "breakdown": {"path_logic": c2["groups_per_path_total"]["path"], "ray_queries_all_objects": c2["groups_per_path_total"]["query"], "by_category": c2["ops_per_path"]}}
-c4, t4 = load("r03_oracle_opcount_c4.json"), load("r03_traversal_stats_c4.json")
+c4_name, t4_name = newest("%s_oracle_opcount_c4.json"), newest("%s_traversal_stats_c4.json"); c4, t4 = load(c4_name), load(t4_name)
 if c4 and t4:
     per_call = c4["ops_per_call"]
     leaf = per_call.get("instance_to_world", 85) + per_call.get("m_affine_inverse", 49) + per_call.get("m_point", 9) + per_call.get("m_vector", 9) + 26 + 3   # + the mesh's own slab test and the reciprocals
@@ -38,8 +44,8 @@ if c4 and t4:
     trav = t4["rays_per_path"] * per_ray
     for cfg in ("c4", "c5"):
         out[cfg] = {"ops_per_path": round(c4["groups_per_path_total"]["path"] + trav, 1),
-                    "source": "profiles/r03_oracle_opcount_c4.json (oracle sha %s, path group) + profiles/r03_traversal_stats_c4.json x per-unit costs (node step %d, leaf visit %.0f, triangle test %.0f ops)"
-                              % (c4["oracle_sha16"], NODE_STEP_OPS, leaf, tri),
+                    "source": "profiles/%s (oracle sha %s, path group) + profiles/%s x per-unit costs (node step %d, leaf visit %.0f, triangle test %.0f ops)"
+                              % (c4_name, c4["oracle_sha16"], t4_name, NODE_STEP_OPS, leaf, tri),
                     "breakdown": {"path_logic": c4["groups_per_path_total"]["path"], "traversal": round(trav, 1), "rays_per_path": round(t4["rays_per_path"], 3),
                                   "per_ray": {"tlas_node_steps": round(t4["tlas_node_steps_per_ray"], 2), "leaf_visits": round(t4["leaf_visits_per_ray"], 3),
                                               "triangle_tests": round(t4["triangle_tests_per_ray"], 2), "ops": round(per_ray, 1)},

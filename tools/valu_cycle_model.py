@@ -31,7 +31,7 @@ C_FAST, C_SLOW, C_QUARTER = 2.25, 4.1, 8.2      # nominal 2.4 GHz cycles per wav
 WANTED = {"c2": "_ZN4dtof7k_shadeILb1ELi2ELb0ELi1ELb0ELi0ELi0EEEvNS_9ShadeArgsE",
           "c3": "_ZN4dtof7k_shadeILb1ELi2ELb0ELi1ELb0ELi0ELi0EEEvNS_9ShadeArgsE",
           "c4": "_ZN4dtof7k_shadeILb0ELi2ELb0ELi1ELb1ELi0ELi16EEEvNS_9ShadeArgsE",
-          "c5": "_ZN4dtof7k_shadeILb0ELi2ELb0ELi4ELb1ELi0ELi12EEEvNS_9ShadeArgsE"}
+          "c5": "_ZN4dtof7k_shadeILb0ELi2ELb0ELi4ELb1ELi0ELi16EEEvNS_9ShadeArgsE"}
 
 
 def classify(op, args):
