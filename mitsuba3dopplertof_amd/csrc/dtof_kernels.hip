@@ -527,7 +527,9 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
             return;
         }
     }
-    const uint32_t shade_stack = fused ? stack_bytes(stack_depth, kShadeBlock) + kMemoWords * kMemoStride * 4 : 0;   // + the instance memo
+    // + the instance memo; a flat scene with one instance keeps the instance matrix there as well (k_shade: memo_m_lds) and needs no traversal stack beyond one entry
+    const bool memo_m = fused && !rp.has_tris && !rp.has_spec && rp.flat_objects != 0 && rp.memo_obj != 0xffffffffu;   // = the condition of k_shade's memo_m_lds in the instantiations launch_shade_plain picks
+    const uint32_t shade_stack = fused ? stack_bytes(memo_m ? 1u : stack_depth, kShadeBlock) + (memo_m ? 2u : 1u) * kMemoWords * kMemoStride * 4 : 0;
     const uint32_t sw = stage_words_for(scene_bytes, shade_stack), grid = nseg(rp.n_lanes) * (first && rp.chunk_blocks > 1 ? rp.chunk_blocks : 1u), lds = sw * 16 + shade_stack;
     check_lds(lds);
     const ShadeLaunch L = { sw != 0, first ? 2 : fused ? 1 : 0, 0u, grid, lds, s,

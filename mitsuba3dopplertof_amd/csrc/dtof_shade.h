@@ -332,7 +332,10 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     uint32_t *const s_inline = s_inline_all + wave_id * 2 * kMaxInline;
     const uint32_t stage_words = RESW ? 4u * kResNodes + A0.res_small_words : A0.stage_words;
     // dynamic LDS: [staged scene | resident stage: node planes, record block][fused: instance memo, kMemoWords x 64 words per wave][traversal stack columns]
-    const uint32_t memo_words = FUSED ? (RESW ? (A0.res_memo ? RESW * kMemoWords * kMemoStride : 0u) : kMemoWords * kMemoStride) : 0u;
+    // flat scenes with ONE instance (the moving wall of C2): the column holds the instance matrix as well (launch_shade sizes the LDS accordingly) -- re-deriving it per
+    // iteration cost every lane 51 instructions, a hit on the wall now reads it back
+    const bool memo_m_lds = FUSED && !MESH && !RESW && A0.rp.flat_objects != 0u && A0.rp.memo_obj != 0xffffffffu;
+    const uint32_t memo_words = FUSED ? (RESW ? (A0.res_memo ? RESW * kMemoWords * kMemoStride : 0u) : (memo_m_lds ? 2u : 1u) * kMemoWords * kMemoStride) : 0u;
     uint32_t *stack = (uint32_t *) (lds + stage_words) + memo_words + threadIdx.x;
     // One block per 512-lane segment -- or, for a small frame whose whole path runs inline (rp.chunk_blocks = 8: nothing is compacted for a
     // later launch), one block per 64-lane chunk, so that a 1 M-lane frame is 16 384 waves instead of 2 048; the per-segment statistics are
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     if (count != 0) {
     const uint8_t *base = LDS ? stage_scene(A0.scene, A0.scene_bytes, lds) : A0.scene;
     SceneView sv = RESW ? sv_res : make_view(base);
-    if (FUSED) { sv.memo_obj = A0.rp.memo_obj; sv.memo = (float *) (lds + stage_words) + (RESW ? wave_id * kMemoWords * kMemoStride + lane_id : threadIdx.x); }
+    if (FUSED) { sv.memo_obj = A0.rp.memo_obj; sv.memo = (float *) (lds + stage_words) + (RESW ? wave_id * kMemoWords * kMemoStride + lane_id : threadIdx.x); sv.memo_m = memo_m_lds; }
     const bool have_memo = FUSED && sv.memo_obj != 0xffffffffu;
     for (uint32_t cbase = sub > 1 ? sub_index * kShadeBlock : 0u; cbase < (sub > 1 ? (sub_index + 1) * kShadeBlock < count ? (sub_index + 1) * kShadeBlock : count : count); cbase += kShadeBlock) {
     uint32_t rebase = 0;
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
 
             Surface si;
             if (!FIRST && have_memo) instance_memo_fill(sv, time, memo_m, memo_inv);
-            if (FIRST && it > 0 && have_memo) {   // a ray's time does not change along its path: the inverse filled at generation still sits in the LDS column
+            if (FIRST && it > 0 && have_memo && !sv.memo_m) {   // a ray's time does not change along its path: the inverse filled at generation still sits in the LDS column
                 instance_matrix(sv.objects[sv.memo_obj], time, memo_m); instance_memo_load(sv, memo_inv);
             }
             compute_surface<MESH>(sv, hid & ((1u << q.id_shift) - 1u), hid >> q.id_shift, hh.w, t, u2f(hh.y), u2f(hh.z), o, d, time, si, have_memo, memo_m, memo_inv);

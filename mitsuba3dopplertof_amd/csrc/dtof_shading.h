@@ -24,8 +24,11 @@ DTOF_D void compute_surface(const SceneView &sv, uint32_t oi, uint32_t shape_k, 
     const DShape *sh;
     if (inst) {
         if (use_memo && oi == sv.memo_obj) {
+            if (sv.memo_m) { instance_memo_load_matrix(sv, m); instance_memo_load(sv, inv); }   // both sit in the lane's LDS column since the lane was generated
+            else {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) { m[i] = memo_m[i]; inv[i] = memo_inv[i]; }
+                for (int i = 0; i < 12; ++i) { m[i] = memo_m[i]; inv[i] = memo_inv[i]; }
+            }
         } else {
             instance_matrix(ob, time, m);
             affine_inverse(m, inv);

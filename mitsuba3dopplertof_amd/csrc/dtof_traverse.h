@@ -21,6 +21,7 @@ struct SceneView {
     // the vertex and its surface interaction read it back instead of re-deriving it (a ray's time does not change along a path,
     // dopplertofpath.cpp:93,240-244).  memo_obj = 0xffffffff: no memo.
     uint32_t memo_obj; float *memo;
+    bool memo_m;   // the column also holds the instance matrix itself (words 12 .. 23; the flat scenes' kernels, whose LDS has the room): compute_surface reads both back
 };
 // Resident scene stage (k_shade<..., RESW>): the TLAS nodes live in LDS as FOUR PLANES of 16-byte pieces -- piece k of node i at
 // uint4 index k * kResNodes + i -- so that the 16 lanes of a ds_read_b128 lane group, which read the same piece of 16 different nodes,
@@ -40,7 +41,7 @@ DTOF_D SceneView make_view(const uint8_t *base) {
     v.emitters = (const DEmitter *) (base + h->off_emitters);
     v.base = base;
     v.n_nodes = h->n_nodes; v.n_emitters = h->n_emitters;
-    v.memo_obj = 0xffffffffu; v.memo = nullptr;
+    v.memo_obj = 0xffffffffu; v.memo = nullptr; v.memo_m = false;
     return v;
 }
 // Stage the whole scene blob into LDS (small scenes: the Cornell blob is ~5 KB).
@@ -183,6 +184,14 @@ DTOF_D void instance_memo_fill(const SceneView &sv, float time, float *m, float 
     affine_inverse(m, inv);
 #pragma unroll
     for (uint32_t k = 0; k < kMemoWords; ++k) sv.memo[k * kMemoStride] = inv[k];
+    if (sv.memo_m) {
+#pragma unroll
+        for (uint32_t k = 0; k < kMemoWords; ++k) sv.memo[(kMemoWords + k) * kMemoStride] = m[k];
+    }
+}
+DTOF_D void instance_memo_load_matrix(const SceneView &sv, float *m) {   // only where sv.memo_m
+#pragma unroll
+    for (uint32_t k = 0; k < kMemoWords; ++k) m[k] = sv.memo[(kMemoWords + k) * kMemoStride];
 }
 DTOF_D void instance_memo_load(const SceneView &sv, float *inv) {
 #pragma unroll
@@ -479,7 +488,7 @@ DTOF_D bool trace_flat(const SceneView &sv, ConstBytes flat_table, uint32_t flat
         if (ANY) occluded |= hit;
         else {
             const bool take = (int) hit & (int) (t < best.t);
-            best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v; best.obj = take ? oi : best.obj; best.shape = take ? 0u : best.shape;
+            best.t = take ? t : best.t; best.u = take ? u : best.u; best.v = take ? v : best.v; best.obj = take ? oi : best.obj;   // best.shape stays 0: the instances, which may set it, come after the rectangles
         }
     };
     // Two record buffers take turns (the loop is unrolled by two), so the next record's scalar load flies while the current one is tested
