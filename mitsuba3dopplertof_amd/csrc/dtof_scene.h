@@ -58,27 +58,7 @@ struct BvhNode {
     float rmin[3]; uint32_t pad0;
     float rmax[3]; uint32_t pad1;
 };
-// 4-wide QUANTISED node (64 B -- the bytes of ONE binary node decide FOUR descents; the traversal's node format when the library is built with
-// -DDTOF_BVH4, `make bvh4`).  The traversal kernels of scenes too large for LDS are bound by the CU's vector-memory path (TA / TD busy 77 - 85 % on the
-// 522 k-triangle mesh room, profiles/r03_pmc_mesh_room.txt): what a ray costs there is the BYTES its node steps fetch, and a 4-wide tree of
-// uncompressed nodes (round 2: 128 B per node, half as many steps) fetches as many as the binary tree.  Here the child boxes are 8-bit offsets in a
-// per-node frame: origin `o` (the lower corner of the union of the children) and one power-of-two scale per axis (biased exponent bytes in `exps`),
-// child k spans [o + s * qlo[.][k], o + s * qhi[.][k]] -- rounded OUTWARD (and widened by one quantum where the range allows), so every quantised
-// box contains the (already padded) float box it stands for and the traversal stays conservative; hits come from the exact primitive tests and
-// are unchanged.  Built by collapsing the binary SAH tree (scene_build.cpp: the child with the largest box is replaced by its own two children
-// until four are held).  An absent child has child = kNoChild.
-struct BvhNode4 {
-    float o[3]; uint32_t exps;          // exps: exponent byte of the x | y << 8 | z << 16 scale (scale = 2^(e - 127), as a float's exponent field)
-    uint32_t child[4];
-    uint32_t qlo[3];                    // qlo[axis]: byte k = child k
-    uint32_t qhi[3];
-    uint32_t pad[2];
-};
-#ifndef DTOF_BVH4
-typedef BvhNode DNode;
-#else
-typedef BvhNode4 DNode;
-#endif
+typedef BvhNode DNode;   // (a quantised 4-wide node format was measured slower in round 3: tools/experiments/r03_bvh4.patch, profiles/r03_qbvh4_vs_bvh2.txt)
 struct DObject {            // 128 B
     uint32_t kind, index, n_keys; float t0;
     float t1, pad[3];
@@ -153,7 +133,6 @@ struct DEnvmap {
     uint32_t level_off[kEnvMaxLevels], level_w[kEnvMaxLevels];
 };
 static_assert(sizeof(DEnvmap) % 16 == 0, "DEnvmap");
-static_assert(sizeof(BvhNode4) == 64, "BvhNode4");
 static_assert(sizeof(DTexture) == 64, "DTexture");
 static_assert(sizeof(BvhNode) == 64 && sizeof(DObject) == 128 && sizeof(DShape) == 352 && sizeof(DTri) == 48 && sizeof(DTriIsect) == 48 && sizeof(DTriShade) == 64 && sizeof(DEmitter) == 96, "blob records");
 

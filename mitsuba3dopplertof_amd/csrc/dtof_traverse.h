@@ -219,7 +219,6 @@ DTOF_D bool box_hit(const float *bmin, const float *bmax, const SlabRay &r, floa
     const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
     return tn <= tf;
 }
-#ifndef DTOF_BVH4
 // One traversal step at inner node `cur` = four 16-byte loads issued together (no load depends on a field of the node): continue with the nearest child that is
 // hit, push the other, pop when nothing is hit.  STRIDE: the stride of the per-thread stack columns when the kernel knows its block size (a shift instead of v_mul_lo_u32).
 template <bool SOA = false, uint32_t STRIDE = 0>
@@ -243,46 +242,6 @@ DTOF_D uint32_t node_step(const BvhNode *nodes, uint32_t cur, const SlabRay &r, 
     if (sp == sp_floor) return done;
     --sp; return stack[sp * stride];
 }
-#else
-DTOF_D void cswap(float &ta, uint32_t &ca, float &tb, uint32_t &cb) {   // compare-exchange of (distance, child) pairs
-    const bool sw = tb < ta;
-    const float t = sw ? tb : ta; const uint32_t c = sw ? cb : ca;
-    tb = sw ? ta : tb; cb = sw ? ca : cb; ta = t; ca = c;
-}
-// One traversal step at the 4-wide quantised inner node `cur` (four 16-byte loads issued together, none depends on a field of the node).  The slab test
-// runs in the node's frame: a child's plane at q quanta lies at t = q * (scale * id) + (origin - o) * id, one fma per plane after three products and
-// three differences per node; the children whose boxes the ray enters before `tbest` are ordered by entry distance with a five-comparator network; the
-// nearest is returned, the others are pushed far-first; nothing hit: pop (or `done` at the floor of this traversal's stack).
-DTOF_D float ubyte_f(uint32_t w, int k) { return (float) ((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyte<k>
-template <bool SOA = false, uint32_t STRIDE = 0>
-DTOF_D uint32_t node_step(const BvhNode4 *nodes, uint32_t cur, const SlabRay &r, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride_rt, uint32_t done) {
-    const uint32_t stride = STRIDE ? STRIDE : stride_rt; const V3 id = r.id;
-    const uint4 *np = SOA ? (const uint4 *) nodes + cur : (const uint4 *) (nodes + cur);
-    const uint4 q0 = np[0], q1 = np[SOA ? kResNodes : 1], q2 = np[SOA ? 2 * kResNodes : 2], q3 = np[SOA ? 3 * kResNodes : 3];
-    float t[4]; uint32_t c[4] = { q1.x, q1.y, q1.z, q1.w };
-    const float ax = u2f((q0.w & 0xffu) << 23) * id.x, ay = u2f(((q0.w >> 8) & 0xffu) << 23) * id.y, az = u2f(((q0.w >> 16) & 0xffu) << 23) * id.z;
-    const float bx = fmaf(u2f(q0.x), id.x, r.noid.x), by = fmaf(u2f(q0.y), id.y, r.noid.y), bz = fmaf(u2f(q0.z), id.z, r.noid.z);
-    const uint32_t lox = q2.x, loy = q2.y, loz = q2.z, hix = q2.w, hiy = q3.x, hiz = q3.y;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float tx0 = fmaf(ubyte_f(lox, k), ax, bx), tx1 = fmaf(ubyte_f(hix, k), ax, bx);
-        const float ty0 = fmaf(ubyte_f(loy, k), ay, by), ty1 = fmaf(ubyte_f(hiy, k), ay, by);
-        const float tz0 = fmaf(ubyte_f(loz, k), az, bz), tz1 = fmaf(ubyte_f(hiz, k), az, bz);
-        const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
-        const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
-        t[k] = (tn <= tf && c[k] != kNoChild) ? tn : INFINITY;
-    }
-    cswap(t[0], c[0], t[1], c[1]); cswap(t[2], c[2], t[3], c[3]); cswap(t[0], c[0], t[2], c[2]); cswap(t[1], c[1], t[3], c[3]); cswap(t[1], c[1], t[2], c[2]);
-    if (t[0] < INFINITY) {
-        if (t[3] < INFINITY) { stack[sp * stride] = c[3]; ++sp; }
-        if (t[2] < INFINITY) { stack[sp * stride] = c[2]; ++sp; }
-        if (t[1] < INFINITY) { stack[sp * stride] = c[1]; ++sp; }
-        return c[0];
-    }
-    if (sp == sp_floor) return done;
-    --sp; return stack[sp * stride];
-}
-#endif
 
 // Closest hit (ANY=false) or occlusion (ANY=true) of one top-level object.  Candidates are every
 // primitive hit with t <= maxt; the winner is the smallest t, ties going to the lowest

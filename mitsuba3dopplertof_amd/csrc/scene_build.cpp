@@ -121,77 +121,6 @@ static uint32_t build_node(BuildCtx &cx, size_t b, size_t e) {
     return idx;
 }
 
-#ifdef DTOF_BVH4
-// Binary tree -> 4-wide tree: a wide node starts with the two children of a binary node; while it holds fewer than four, its
-// inner child with the largest box is replaced by that child's own two children.  Leaves keep their encoding.
-static uint32_t collapse(const std::vector<BvhNode> &bin, uint32_t ni, std::vector<BvhNode4> &out) {
-    struct Ent { float lo[3], hi[3]; uint32_t ref; };
-    std::vector<Ent> ents;
-    auto push = [&](const float *lo, const float *hi, uint32_t ref) {
-        if (ref == kNoChild) return;
-        Ent e; memcpy(e.lo, lo, 12); memcpy(e.hi, hi, 12); e.ref = ref; ents.push_back(e);
-    };
-    push(bin[ni].lmin, bin[ni].lmax, bin[ni].left); push(bin[ni].rmin, bin[ni].rmax, bin[ni].right);
-    while (ents.size() < 4) {
-        int pick = -1; float best = -1.f;
-        for (size_t i = 0; i < ents.size(); ++i) {
-            if (ents[i].ref & kLeafFlag) continue;
-            const float d[3] = { ents[i].hi[0] - ents[i].lo[0], ents[i].hi[1] - ents[i].lo[1], ents[i].hi[2] - ents[i].lo[2] };
-            const float a = d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
-            if (a > best) { best = a; pick = (int) i; }
-        }
-        if (pick < 0) break;
-        const BvhNode n = bin[ents[pick].ref];
-        ents.erase(ents.begin() + pick);
-        push(n.lmin, n.lmax, n.left); push(n.rmin, n.rmax, n.right);
-    }
-    const uint32_t idx = (uint32_t) out.size();
-    out.emplace_back();
-    BvhNode4 w; memset(&w, 0, sizeof w);
-    for (int k = 0; k < 4; ++k) w.child[k] = kNoChild;
-    // the node's frame: origin = lower corner of the union; per axis the smallest power-of-two scale whose 255 steps span the union with a quantum to spare
-    for (int a = 0; a < 3; ++a) {
-        float lo = FLT_MAX, hi = -FLT_MAX;
-        for (auto &e : ents) { lo = std::min(lo, e.lo[a]); hi = std::max(hi, e.hi[a]); }
-        w.o[a] = lo;
-        // smallest exponent whose 252 steps span the union -- but never a step below 2^-20 of the coordinates' magnitude: origin + q * scale must move in float32
-        int E = 1;
-        { const float m = std::max(std::fabs(lo), std::fabs(hi)); int ex = 0; if (m > 0.f) { (void) std::frexp(m, &ex); E = std::max(E, ex - 1 + 127 - 20); } }
-        for (;; ++E) {
-            if (E > 254) throw std::runtime_error("BVH quantisation: scene extent out of range");
-            uint32_t bits = (uint32_t) E << 23; float sc; memcpy(&sc, &bits, 4);
-            if (!((double) (hi - lo) / (double) sc <= 252.0)) continue;
-            uint32_t wl = 0, wh = 0; bool ok = true;
-            for (size_t k = 0; k < ents.size() && ok; ++k) {
-                // outward rounding, checked against the kernel's own decode fma(q, scale, origin); then one more quantum of slack on each side
-                int ql = (int) std::floor((double) (ents[k].lo[a] - lo) / (double) sc), qh = (int) std::ceil((double) (ents[k].hi[a] - lo) / (double) sc);
-                ql = std::max(0, std::min(255, ql)); qh = std::max(0, std::min(255, qh));
-                while (ql > 0 && fmaf((float) ql, sc, lo) > ents[k].lo[a]) --ql;
-                while (qh < 255 && fmaf((float) qh, sc, lo) < ents[k].hi[a]) ++qh;
-                ok = fmaf((float) ql, sc, lo) <= ents[k].lo[a] && fmaf((float) qh, sc, lo) >= ents[k].hi[a];
-                ql = std::max(0, ql - 1); qh = std::min(255, qh + 1);
-                wl |= (uint32_t) ql << (8 * k); wh |= (uint32_t) qh << (8 * k);
-            }
-            if (!ok) continue;   // a coarser scale
-            w.exps |= (uint32_t) E << (8 * a); w.qlo[a] = wl; w.qhi[a] = wh;
-            break;
-        }
-    }
-    for (size_t k = 0; k < ents.size(); ++k) w.child[k] = (ents[k].ref & kLeafFlag) ? ents[k].ref : collapse(bin, ents[k].ref, out);
-    out[idx] = w;
-    return idx;
-}
-// stack entries a depth-first traversal below `ni` can hold: every node visit pushes at most (children - 1) entries
-static uint32_t stack_need(const std::vector<BvhNode4> &nodes, uint32_t ni) {
-    uint32_t n = 0, deepest = 0;
-    for (int k = 0; k < 4; ++k) if (nodes[ni].child[k] != kNoChild) ++n;
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t c = nodes[ni].child[k];
-        if (c != kNoChild && !(c & kLeafFlag)) deepest = std::max(deepest, stack_need(nodes, c));
-    }
-    return (n ? n - 1 : 0) + deepest;
-}
-#endif
 
 
 
@@ -420,7 +349,6 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         BuildCtx cx { nodes, items, 1 };
         build_node(cx, 0, items.size());
     }
-#ifndef DTOF_BVH4
     const uint32_t tlas_nodes = (uint32_t) nodes.size();
     for (BvhNode n : blas_nodes) {   // BLAS node indices (children and roots) move behind the TLAS
         if (n.left != kNoChild && !(n.left & kLeafFlag)) n.left += tlas_nodes;
@@ -441,16 +369,6 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         }
         need_tlas = deepest + 1;
     }
-#else
-    // the traversal's 4-wide nodes: TLAS first, then the BLAS of every mesh (their roots re-based into the same array)
-    std::vector<BvhNode4> dev_nodes;
-    uint32_t need_tlas = 1, need_blas = 0;
-    if (!nodes.empty()) { collapse(nodes, 0, dev_nodes); need_tlas = stack_need(dev_nodes, 0) + 1; }
-    for (DShape &d : shapes) if (d.blas_root != kNoChild) {
-        d.blas_root = collapse(blas_nodes, d.blas_root, dev_nodes);
-        need_blas = std::max(need_blas, stack_need(dev_nodes, d.blas_root) + 1);
-    }
-#endif
     // ---- emitters
     std::vector<uint32_t> env_records;   // emitters whose `shape` is the table offset of a DEnvmap
     std::vector<DEmitter> emitters(sc.emitters.size());
