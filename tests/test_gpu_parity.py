@@ -615,6 +615,38 @@ def test_unbounded_depth_in_a_mirror_box_is_not_truncated(mi, orc, tmp_path):
         assert int(out.stdout.split()[1]) > 64
 
 
+@pytest.mark.parametrize("view", ["axis_parallel", "distant", "grazing"])
+@pytest.mark.parametrize("scene", ["domino_small.xml", "cornell_boxes.xml"])
+def test_slab_test_extremes_behind_the_tlas(mi, orc, tmp_path, scene, view):
+    """The box test of the traversal (dtof_traverse.h: box_hit, one multiply-add per plane with -(o * id) computed per ray) only culls, so it must never lose a
+    hit the oracle's brute force finds -- under the rays that stress its rounding: `axis_parallel` = an orthographic camera looking exactly down -z (two direction
+    components are exact zeros: the reciprocal is the 1e30 stand-in and o * id is huge), `distant` = a camera 3 000 units away behind a narrow lens (|o| >> |b|: the
+    products b * id and o * id cancel), `grazing` = a camera in the plane of the floor looking along it (tiny direction components, rays skimming box faces).  Every lane
+    bit-exact against the oracle, on a TLAS of moving instances and on cube meshes."""
+    text = open(os.path.join(SCENES, scene)).read()
+    look = {"axis_parallel": '<sensor type="orthographic"><transform name="to_world"><scale x="3" y="2" z="1"/><lookat origin="0.25, 1, 12" target="0.25, 1, 0" up="0, 1, 0"/></transform>',
+            "distant": '<sensor type="perspective"><float name="fov" value="0.08"/><float name="near_clip" value="100"/><float name="far_clip" value="10000"/>'
+                       '<transform name="to_world"><lookat origin="600, 900, 2800" target="0, 0.5, 0" up="0, 1, 0"/></transform>',
+            "grazing": '<sensor type="perspective"><float name="fov" value="50"/><transform name="to_world"><lookat origin="0, 1e-4, 9" target="0, 1e-4, 0" up="0, 1, 0"/></transform>'}[view]
+    text, n_sub = re.subn(r'<sensor type="perspective">.*?</transform>', lambda _m: look, text, count=1, flags=re.S)
+    assert n_sub == 1
+    path = str(tmp_path / ("%s_%s" % (view, scene)))
+    open(path, "w").write(text)
+    params = dict(resx=48, resy=32)
+    sc, osc = mi.load_file(path, **params), orc.Scene(path, params)
+    spp, n = 8, 48 * 32 * 8
+    for pipeline in ("fused", "split"):
+        os.environ["DTOF_PIPELINE"] = pipeline
+        try:
+            g = sc.sample_lanes(0, spp, 0, n)
+        finally:
+            del os.environ["DTOF_PIPELINE"]
+        o = osc.render_lanes(osc.params(), 0, spp, 0, n, threads=NCPU)
+        for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+            assert np.array_equal(bits(g[k]), bits(o[k])), (pipeline, k, int((bits(g[k]) != bits(o[k])).sum()))
+    assert float(np.abs(o["rgb"]).max()) > 0          # the views see something
+
+
 @pytest.mark.parametrize("resident", ["auto", "0", "8", "12"])
 def test_full_domino_scene_1025_objects(mi, orc, resident, monkeypatch):
     """BASELINE configs[3]/[4] scene (1 024 motion-blurred cube instances + ground; TLAS of depth ~11) at reduced
