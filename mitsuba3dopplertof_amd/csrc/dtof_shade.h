@@ -365,6 +365,9 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
         if (lane_id == 0) taken = atomicAdd(A0.q.seg_counter, 1u);
         seg = (uint32_t) __builtin_amdgcn_readfirstlane((int) taken);
         if (seg >= A0.n_seg) break;
+        // the segments are handed out from the LAST pixel rows to the first: a launch ends with a tail in which the waves run out of segments one after the other, and the
+        // tail is as long as the last segments are expensive -- the top rows of a frame tend to see sky (Domino C4: 34.05 -> 33.77 ms, profiles/r04_domino_waves_batch.txt)
+        seg = A0.n_seg - 1u - seg;
     } else {
         seg = sub > 1 ? blockIdx.x / sub : blockIdx.x; sub_index = sub > 1 ? blockIdx.x - seg * sub : 0u;
     }
