@@ -87,7 +87,8 @@ typedef struct {
     int32_t  filter_halo;
     /* hdrfilm pixel_format = rgba (FilmFlags::Alpha, src/films/hdrfilm.cpp:172-177): develop() returns R, G, B, A.  The host-buffer render calls then write
      * FOUR floats per pixel, and the device-film calls (dtof_render_rows / _stripes) accumulate the alpha film -- (A, 0, 0, W) -- as one more RGBW plane
-     * behind the n_offsets colour films of `d_film_rgbw`. */
+     * behind the n_offsets colour films of `d_film_rgbw`: they REFUSE an rgba scene until the caller has declared a film of n_offsets + 1 planes
+     * (dtof_scene_set_film_layout). */
     int32_t  has_alpha;
 } dtof_scene_info;
 /* What Film::crop_size / Sampler::sample_count / the plugins' to_string() report (src/films/hdrfilm.cpp:235-279, src/render/sampler.cpp:13-14,
@@ -161,6 +162,10 @@ typedef struct {
      * the first-bounce launches (summed over the batches) and the path-bounces among n_bounces that ran there */
     uint32_t n_inline_iterations;
     uint64_t n_bounces_inline;
+    /* first-bounce launches that also splatted their samples (the wave reduces the footprint values of its 64 samples and issues the film atomics itself: 64 spp, one
+     * film, radius-1 tent, the whole path inline).  The sums of a pixel's samples are then taken in another ORDER than the splat kernels': films of the two paths
+     * differ in the last bits, so checksums compare only between runs with the same value here */
+    uint32_t n_fused_splat_launches;
 } dtof_render_stats;
 
 /* out_rgb: caller-owned host buffer, crop_height*crop_width*3 float32, developed (RGB / W). */
@@ -200,12 +205,20 @@ int dtof_render_stripes(dtof_scene *scene, uint32_t seed, uint32_t spp, int32_t 
                         const float *offsets, int n_offsets, float *d_film_rgbw, dtof_render_stats *stats);
 /* The stream the library enqueues on.  By default every scene owns one; a caller that has work of its own to order against the renders -- the film exchange of
  * a multi-GPU frame (torch.distributed / RCCL), torch operations on the films -- hands in ITS stream (hipStream_t; torch.cuda.current_stream().cuda_stream) and can
- * then queue clear -> render -> exchange -> develop for many frames without a host wait in between.  NULL goes back to the scene's own stream.  The reference has
+ * then queue clear -> render -> exchange -> develop for many frames without a host wait in between.  NULL goes back to the scene's own stream.  LIFETIME: the library
+ * keeps the handle, not the stream -- the caller keeps the stream alive until it has handed it back (another dtof_scene_set_stream call; frames in flight are collected
+ * first); handing back a stream that no longer exists is tolerated, every other call on a dead handle fails with DTOF_ERR_HIP.  The reference has
  * no counterpart (Dr.Jit owns the one CUDA stream of a thread, drjit-core/src/init.cpp). */
 int dtof_scene_set_stream(dtof_scene *scene, void *hip_stream);
 /* dtof_render_stripes without the host synchronisation at its end (see dtof_render_rows_async). */
 int dtof_render_stripes_async(dtof_scene *scene, uint32_t seed, uint32_t spp, int32_t first_row, int32_t stripe_rows, int32_t stripe_period,
                               const float *offsets, int n_offsets, float *d_film_rgbw);
+/* The layout of the caller's device film for the device-film calls (dtof_render_rows / _stripes and their _async forms): `planes` RGBW planes of crop_height * crop_width * 4
+ * floats, `plane_stride_floats` apart (0 = dense).  Film k of the batched offsets is plane k; the alpha film of an rgba scene (dtof_scene_info::has_alpha,
+ * FilmFlags::Alpha, src/films/hdrfilm.cpp:172-177; ImageBlock::put of aovs[3], integrator.cpp:528-533) is plane n_offsets.  A call that would write more planes than were
+ * declared fails with DTOF_ERR_INVALID instead of writing past the buffer; planes = 0 (the default) declares nothing: rgb scenes write their n_offsets planes, rgba scenes
+ * are refused.  A band shard that renders into a padded slab (pointer = slab + halo rows) passes the slab's size as the stride. */
+int dtof_scene_set_film_layout(dtof_scene *scene, int32_t planes, uint64_t plane_stride_floats);
 /* HDRFilm::develop (src/films/hdrfilm.cpp:305-406) on device buffers: rgb = RGB / (W == 0 ? 1 : W). */
 int dtof_develop(const float *d_film_rgbw, float *d_rgb, int64_t n_pixels);
 /* ... of an rgba film: rgba = (R, G, B) / W of the colour film and A / W of the alpha film (the plane behind the colour films, see dtof_scene_info::has_alpha). */
@@ -241,7 +254,8 @@ int  dtof_sampler_next_2d(dtof_sampler *s, float *out_xy);                      
 /* correlate: per-lane flags (n bytes) or NULL to use `correlate_all` for every lane. */
 int  dtof_sampler_next_1d_correlate(dtof_sampler *s, const uint8_t *correlate, int correlate_all, float *out);  /* :156-161 */
 int  dtof_sampler_next_2d_correlate(dtof_sampler *s, const uint8_t *correlate, int correlate_all, float *out_xy); /* :163-167 */
-/* strategy: 0 uniform, 1 stratified, 2 antithetic, 3 antithetic_mirror (sampler.h:27-34) */
+/* strategy: ETimeSampling (sampler.h:27-34): 0 uniform, 1 stratified, 2 antithetic, 3 antithetic_mirror (time_correlate_number must be 2, correlated.cpp:142),
+ * 4 periodic (correlated.cpp:147-150), 5 regular (falls through to `return r`, :152) */
 int  dtof_sampler_next_1d_time(dtof_sampler *s, int strategy, float antithetic_shift, int stratify_each_interval, float *out); /* :92-153 */
 /* state readback: 7 uint32 per lane = rng.state lo,hi, rng_time.state lo,hi, rng_path.state lo,hi, permutation seed */
 int  dtof_sampler_get_state(dtof_sampler *s, uint32_t *out7);

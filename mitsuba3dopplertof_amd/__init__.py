@@ -27,7 +27,7 @@ class DtofError(RuntimeError):
 
 
 class ETimeSampling:   # include/mitsuba/render/sampler.h:27-34
-    UNIFORM, STRATIFIED, ANTITHETIC, ANTITHETIC_MIRROR = 0, 1, 2, 3
+    UNIFORM, STRATIFIED, ANTITHETIC, ANTITHETIC_MIRROR, PERIODIC, REGULAR = 0, 1, 2, 3, 4, 5
 
 
 class _Stats(C.Structure):
@@ -36,7 +36,7 @@ class _Stats(C.Structure):
                 ("ms_shade", C.c_double), ("ms_shadow", C.c_double), ("ms_splat", C.c_double),
                 ("n_launches_trace", C.c_uint32), ("n_launches_shade", C.c_uint32), ("n_launches_shadow", C.c_uint32),
                 ("n_batches", C.c_uint32), ("n_launches_first", C.c_uint32), ("ms_first", C.c_double),
-                ("n_inline_iterations", C.c_uint32), ("n_bounces_inline", C.c_uint64)]
+                ("n_inline_iterations", C.c_uint32), ("n_bounces_inline", C.c_uint64), ("n_fused_splat_launches", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -130,6 +130,7 @@ def _lib():
     L.dtof_camera_rays.argtypes = [vp, C.c_uint32, vp, vp]
     L.dtof_bsdf_eval.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp]
     L.dtof_scene_set_stream.argtypes = [vp, vp]
+    L.dtof_scene_set_film_layout.argtypes = [vp, C.c_int32, C.c_uint64]
     L.dtof_render_stripes_async.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int, vp]
     L.dtof_develop_async.argtypes = [vp, vp, vp, C.c_int64]
     L.dtof_async_collect.argtypes = [vp, vp, vp, C.c_uint32, vp]
@@ -226,8 +227,17 @@ class Scene:
         self.last_stats = st.as_dict()
         return out
 
+    def set_film_layout(self, planes, plane_stride_floats=0):
+        """Declare the caller's device film for render_rows / render_stripes (dtof_scene_set_film_layout): `planes` RGBW planes, `plane_stride_floats` apart (0 = dense
+        H * W * 4).  An rgba scene needs n_offsets + 1 planes -- the alpha film lies behind the colour films -- and is refused until they are declared."""
+        _check(_lib().dtof_scene_set_film_layout(self._h, int(planes), int(plane_stride_floats)))
+
+    def film_planes(self, n_offsets=1):
+        """RGBW planes the device-film calls write for `n_offsets` batched offsets: one more for the alpha film of an rgba scene"""
+        return max(int(n_offsets), 1) + (1 if self.info()["has_alpha"] else 0)
+
     def render_rows(self, d_film_ptr, seed, spp, row_begin, row_end, offsets=None):
-        """Accumulate the undeveloped RGBW film of rows [row_begin,row_end) into a DEVICE buffer (int pointer)."""
+        """Accumulate the undeveloped RGBW film of rows [row_begin,row_end) into a DEVICE buffer (int pointer) of film_planes() planes (set_film_layout for rgba scenes)."""
         st = _Stats()
         if offsets is None:
             _check(_lib().dtof_render_rows(self._h, seed, spp, row_begin, row_end, None, 0, d_film_ptr, C.byref(st)))

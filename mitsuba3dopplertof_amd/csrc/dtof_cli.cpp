@@ -23,19 +23,20 @@
 #include <condition_variable>
 #include <atomic>
 
-static bool write_npy(const char *path, const float *img, int h, int w) {
+static bool write_npy(const char *path, const float *img, int h, int w, int ch) {
     FILE *f = fopen(path, "wb"); if (!f) return false;
-    std::string dict = "{'descr': '<f4', 'fortran_order': False, 'shape': (" + std::to_string(h) + ", " + std::to_string(w) + ", 3), }";
+    std::string dict = "{'descr': '<f4', 'fortran_order': False, 'shape': (" + std::to_string(h) + ", " + std::to_string(w) + ", " + std::to_string(ch) + "), }";
     size_t total = 10 + dict.size() + 1, pad = (64 - total % 64) % 64;
     dict += std::string(pad, ' ') + "\n";
     unsigned short hl = (unsigned short) dict.size();
     fwrite("\x93NUMPY\x01\x00", 1, 8, f); fwrite(&hl, 2, 1, f); fwrite(dict.data(), 1, dict.size(), f);
-    fwrite(img, 4, (size_t) h * w * 3, f); fclose(f); return true;
+    fwrite(img, 4, (size_t) h * w * ch, f); fclose(f); return true;
 }
-static bool write_pfm(const char *path, const float *img, int h, int w) {
+static bool write_pfm(const char *path, const float *img, int h, int w, int ch) {   // PFM has three channels: the alpha of an rgba film is dropped
     FILE *f = fopen(path, "wb"); if (!f) return false;
     fprintf(f, "PF\n%d %d\n-1.0\n", w, h);
-    for (int y = h - 1; y >= 0; --y) fwrite(img + (size_t) y * w * 3, 4, (size_t) w * 3, f);
+    for (int y = h - 1; y >= 0; --y)
+        for (int x = 0; x < w; ++x) fwrite(img + ((size_t) y * w + x) * ch, 4, 3, f);
     fclose(f); return true;
 }
 
@@ -64,7 +65,9 @@ int main(int argc, char **argv) {
     dtof_scene *sc = nullptr;
     if (dtof_scene_load_file(scene.c_str(), n.data(), v.data(), (int) n.size(), &sc)) { fprintf(stderr, "Error: %s\n", dtof_last_error()); return -1; }
     dtof_scene_info info; dtof_scene_get_info(sc, &info);
-    std::vector<float> img((size_t) info.crop_width * info.crop_height * 3);
+    // hdrfilm pixel_format = rgba: four channels out, and the device films carry the alpha film as a second RGBW plane (include/dtof.h, dtof_scene_set_film_layout)
+    const int ch = info.has_alpha ? 4 : 3, planes = info.has_alpha ? 2 : 1;
+    std::vector<float> img((size_t) info.crop_width * info.crop_height * ch);
     dtof_render_stats st;
     const bool force_collective = getenv("DTOF_CLI_FORCE_RCCL") != nullptr;   // take the multi-GPU path with --gpus 1 too (a one-rank communicator)
     if (gpus > 1 || force_collective) {
@@ -72,7 +75,7 @@ int main(int argc, char **argv) {
         const bool share = getenv("DTOF_CLI_SHARE_GPU") != nullptr;   // development: all shards on GPU 0 (one-GPU boxes), host sum
         if (gpus > visible && !share) { fprintf(stderr, "Error: --gpus %d but only %d GPU(s) are visible\n", gpus, visible); dtof_scene_destroy(sc); return -1; }
         if (stripes <= 0) { fprintf(stderr, "Error: --stripes expects a positive number of rows\n"); dtof_scene_destroy(sc); return -1; }
-        const size_t n_pixels = (size_t) info.crop_width * info.crop_height, film_floats = n_pixels * 4;
+        const size_t n_pixels = (size_t) info.crop_width * info.crop_height, film_floats = n_pixels * 4 * planes;
         std::vector<ncclComm_t> comms(gpus, nullptr);
         if (!share) {
             std::vector<int> devs(gpus); for (int g = 0; g < gpus; ++g) devs[g] = g;
@@ -93,6 +96,7 @@ int main(int argc, char **argv) {
             else if (dtof_scene_load_file(scene.c_str(), n.data(), v.data(), (int) n.size(), &mine)) errors[g] = dtof_last_error();
             else if (hipMalloc((void **) &d_film, film_floats * 4) != hipSuccess || hipMemset(d_film, 0, film_floats * 4) != hipSuccess) errors[g] = "device film allocation failed";
             else if (!share && hipStreamCreate(&stream) != hipSuccess) errors[g] = "stream creation failed";
+            else if (dtof_scene_set_film_layout(mine, planes, 0)) errors[g] = dtof_last_error();
             else if (dtof_render_stripes(mine, seed, spp, g * stripes, stripes, gpus * stripes, nullptr, 0, d_film, &stats[g])) errors[g] = dtof_last_error();
             else if (hipDeviceSynchronize() != hipSuccess) errors[g] = "device synchronisation failed";   // the library renders on its own stream
             if (!errors[g].empty()) failed.fetch_add(1);
@@ -105,9 +109,9 @@ int main(int argc, char **argv) {
                     if (rc != ncclSuccess) errors[g] = std::string("ncclReduce: ") + ncclGetErrorString(rc);
                     else if (hipStreamSynchronize(stream) != hipSuccess) errors[g] = "film reduce failed";
                     if (g == 0 && errors[g].empty()) {   // HDRFilm::develop (hdrfilm.cpp:305-406) of the summed film, on the device
-                        if (hipMalloc((void **) &d_rgb, n_pixels * 12) != hipSuccess) errors[g] = "image allocation failed";
-                        else if (dtof_develop(d_film, d_rgb, (int64_t) n_pixels)) errors[g] = dtof_last_error();
-                        else if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(img.data(), d_rgb, n_pixels * 12, hipMemcpyDeviceToHost) != hipSuccess) errors[g] = "image download failed";
+                        if (hipMalloc((void **) &d_rgb, n_pixels * 4 * ch) != hipSuccess) errors[g] = "image allocation failed";
+                        else if (info.has_alpha ? dtof_develop_rgba(d_film, d_film + n_pixels * 4, d_rgb, (int64_t) n_pixels) : dtof_develop(d_film, d_rgb, (int64_t) n_pixels)) errors[g] = dtof_last_error();
+                        else if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(img.data(), d_rgb, n_pixels * 4 * ch, hipMemcpyDeviceToHost) != hipSuccess) errors[g] = "image download failed";
                     }
                 }
             }
@@ -122,15 +126,19 @@ int main(int argc, char **argv) {
         st = stats[0];
         for (int g = 1; g < gpus; ++g) { st.n_paths += stats[g].n_paths; if (stats[g].ms_total > st.ms_total) st.ms_total = stats[g].ms_total; }
         if (share) for (size_t p = 0; p < n_pixels; ++p) {   // development mode: develop the host sum
-            float r = 0.f, gch = 0.f, b = 0.f, wgt = 0.f;
-            for (int g = 0; g < gpus; ++g) { const float *f = films[g].data() + 4 * p; r += f[0]; gch += f[1]; b += f[2]; wgt += f[3]; }
+            float r = 0.f, gch = 0.f, b = 0.f, wgt = 0.f, a = 0.f, awgt = 0.f;
+            for (int g = 0; g < gpus; ++g) {
+                const float *f = films[g].data() + 4 * p; r += f[0]; gch += f[1]; b += f[2]; wgt += f[3];
+                if (info.has_alpha) { const float *fa = films[g].data() + 4 * (n_pixels + p); a += fa[0]; awgt += fa[3]; }
+            }
             if (wgt == 0.f) wgt = 1.f;
-            img[3 * p] = r / wgt; img[3 * p + 1] = gch / wgt; img[3 * p + 2] = b / wgt;
+            img[ch * p] = r / wgt; img[ch * p + 1] = gch / wgt; img[ch * p + 2] = b / wgt;
+            if (info.has_alpha) img[ch * p + 3] = a / (awgt == 0.f ? 1.f : awgt);
         }
     } else
     if (dtof_render(sc, 0, seed, spp, img.data(), &st)) { fprintf(stderr, "Error: %s\n", dtof_last_error()); dtof_scene_destroy(sc); return -1; }
     bool pfm = out.size() > 4 && out.substr(out.size() - 4) == ".pfm";
-    bool ok = pfm ? write_pfm(out.c_str(), img.data(), info.crop_height, info.crop_width) : write_npy(out.c_str(), img.data(), info.crop_height, info.crop_width);
+    bool ok = pfm ? write_pfm(out.c_str(), img.data(), info.crop_height, info.crop_width, ch) : write_npy(out.c_str(), img.data(), info.crop_height, info.crop_width, ch);
     if (!ok) { fprintf(stderr, "Error: could not write \"%s\"\n", out.c_str()); dtof_scene_destroy(sc); return -1; }
     fprintf(stderr, "Rendering finished. (%dx%d, %llu paths, %.2f ms on the GPU, %.0f Mpaths/s) -> %s\n", info.crop_width, info.crop_height,
             (unsigned long long) st.n_paths, st.ms_total, st.n_paths / (st.ms_total * 1e3), out.c_str());

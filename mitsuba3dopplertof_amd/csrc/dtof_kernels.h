@@ -135,7 +135,7 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
 void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q,
                    const uint32_t *count_in, uint32_t stack_depth, hipStream_t s);
 void launch_velocity(const uint8_t *scene, uint32_t scene_bytes, const RenderParams &rp, const Queues &q, uint32_t stack_depth, hipStream_t s);
-void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t film_w, int32_t film_h, hipStream_t s);
+void launch_splat(const RenderParams &rp, const Queues &q, float *film, uint64_t plane_stride, hipStream_t s);
 void launch_develop(const float *film, float *rgb, int64_t n_pixels, hipStream_t s);
 void launch_develop_rgba(const float *film, const float *alpha_film, float *rgba, int64_t n_pixels, hipStream_t s);   // pixel_format = rgba (hdrfilm.cpp:339-400)
 void launch_lane_dump(const RenderParams &rp, const Queues &q, LaneDebug *out, hipStream_t s);

@@ -559,9 +559,9 @@ void launch_velocity(const uint8_t *scene, uint32_t scene_bytes, const RenderPar
     if (sw) hipLaunchKernelGGL(k_velocity<true>, dim3(nblk(rp.n_lanes)), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q);
     else hipLaunchKernelGGL(k_velocity<false>, dim3(nblk(rp.n_lanes)), dim3(kBlock), lds, s, scene, scene_bytes, sw, rp, q);
 }
-void launch_splat(const RenderParams &rp, const Queues &q, float *film, int32_t film_w, int32_t film_h, hipStream_t s) {
+void launch_splat(const RenderParams &rp, const Queues &q, float *film, uint64_t plane_stride, hipStream_t s) {
     if (rp.n_lanes == 0) return;
-    size_t stride = (size_t) film_w * film_h * 4;
+    size_t stride = (size_t) plane_stride;   // floats between the films of the batched offsets
     bool fast = rp.filter == FILTER_TENT && rp.filter_radius <= 1.f && rp.filter_radius > .5f && rp.spp_log2 != 0xffffffffu && rp.spp >= 2;
     static const int env_splat = [] { const char *e = getenv("DTOF_SPLAT"); std::string v = e ? e : ""; return v == "dpp" ? 1 : v == "generic" ? 2 : 0; }();   // A/B switches
     // footprint of the filter in pixels (ImageBlock::put: the pixels within ceil(radius - 0.5) of the sample's): 1 (box), 3 or 5 take the

@@ -97,6 +97,8 @@ struct dtof_scene {
     DevBuf<uint8_t> d_blob; bool uploaded = false;
     Workspace ws, ws2;                       // one per in-flight batch
     DevBuf<float> d_film, d_rgb;
+    // the caller's device film as declared with dtof_scene_set_film_layout (0 = not declared: colour planes only, W * H * 4 apart), and the plane distance of the running call
+    int32_t film_planes = 0; uint64_t film_plane_stride = 0, film_stride_call = 0;
     DevBuf<unsigned long long> d_sums;       // [batch][2*kMaxIter] per-iteration totals (survivors, shadow rays)
     DevBuf<uint2> d_pass_rng;                // multi-pass renders: [lane][3] stream states between the passes
     uint32_t id_shift = 24;                  // Queues::id_shift of this scene
@@ -290,7 +292,20 @@ struct StageTimer {
     }
 };
 
-// The wavefront loop over pixel rows [row_begin,row_end); accumulates into d_film (K films).
+// The device-film entry points write K colour planes and, for an rgba film, the alpha plane behind them into memory whose size only the caller knows: an rgba scene is
+// refused until the caller has declared a film of K + 1 planes (a caller written for rgb films would have its buffer overrun), and a declared count is checked either way.
+static uint64_t caller_film_stride(const dtof_scene *sc, int n_offsets) {
+    const HostSensor &se = sc->host.sensor;
+    const int need = (n_offsets <= 0 ? 1 : n_offsets) + (se.alpha ? 1 : 0);
+    if (se.alpha && sc->film_planes < need)
+        throw std::runtime_error("rgba film: the device film needs " + std::to_string(need) + " RGBW planes (the alpha film lies behind the colour films); declare them with dtof_scene_set_film_layout");
+    if (sc->film_planes != 0 && sc->film_planes < need)
+        throw std::runtime_error("the device film was declared with " + std::to_string(sc->film_planes) + " planes, this call writes " + std::to_string(need));
+    const uint64_t full = (uint64_t) se.crop_w * se.crop_h * 4;
+    return sc->film_plane_stride ? sc->film_plane_stride : full;
+}
+
+// The wavefront loop over pixel rows [row_begin,row_end); accumulates into d_film (K films, sc->film_stride_call floats apart).
 // lane_dump != nullptr: evaluate only lanes [dump_begin, dump_begin + dump_n) and copy their records out.
 // stripe_rows > 0: the rows are the stripes [row_begin + k * stripe_period, ... + stripe_rows) below row_end (interleaved shards).
 void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin, int32_t row_end,
@@ -300,6 +315,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     if (!sc->host.has_sensor) throw std::runtime_error("the scene does not contain a sensor");
     ensure_device(sc);
     const HostSensor &se = sc->host.sensor;
+    const uint64_t film_stride = sc->film_stride_call ? sc->film_stride_call : (uint64_t) se.crop_w * se.crop_h * 4;
     if (spp == 0) spp = sc->pp.sample_count;
     if (spp == 0) throw std::runtime_error("sample count must be positive");
     // SamplingIntegrator::render (integrator.cpp:121-135,227-245): spp_per_pass = min(samples_per_pass, spp) must divide spp; a wavefront
@@ -320,6 +336,8 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     uint64_t total_lanes = (uint64_t) se.crop_w * se.crop_h * spp;   // lanes of one pass (the wavefront)
     if (sc->pp.time_sampling != TIME_UNIFORM && sc->pp.stratify_each_interval && sample_count < (uint32_t) sc->pp.time_correlate_number)
         throw std::runtime_error("sample count must be at least time_correlate_number when per-interval stratification is on");
+    if (sc->pp.integrator == 0 && sc->pp.sampler_kind == SAMPLER_CORRELATED && sc->pp.time_sampling == TIME_ANTITHETIC_MIRROR && sc->pp.time_correlate_number != 2)
+        throw std::runtime_error("antithetic_mirror time sampling needs time_correlate_number == 2");   // Assert(m_time_correlate_number == 2), correlated.cpp:142
     RenderParams rp = make_params(sc, seed, spp, offsets, n_offsets, sample_count);
     rp.n_passes = n_passes;
     // lane dumps address (pass, lane) as pass * wavefront + lane and must stay inside one pass
@@ -465,9 +483,13 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     // -- and unless a path can still be invalid when it gets there: a BSDF with a null lobe (`mask`, `thindielectric`) leaves valid_ray unset, and a non-null
     // vertex of the last iteration sets it (dopplertofpath.cpp:252-253), which decides whether the path returns what it gathered or 0 (:279-282); the alpha
     // channel / the lane dump's `valid` likewise depend on the hit of that iteration when max_depth is 1
+    // (over the whole chain of material records behind a shape -- a blend's partner, the back side of a two-BSDF twosided, and whatever those carry in turn -- so that a
+    // nesting the loader learns to accept later cannot slip a null lobe past this test)
     bool has_null_lobe = false;
-    for (auto &sh : sc->host.shapes) has_null_lobe |= sh.masked || sh.bsdf == BSDF_THINDIELECTRIC || sh.bsdf == BSDF_NULL || (sh.blend_other && (sh.blend_other->bsdf == BSDF_THINDIELECTRIC || sh.blend_other->bsdf == BSDF_NULL));
-    static const bool env_fuse_splat = [] { const char *e = getenv("DTOF_FUSE_SPLAT"); return !(e && e[0] == '0'); }();
+    for (auto &sh : sc->host.shapes)
+        for (const HostShape *m = &sh; m; m = m->blend_other.get())
+            has_null_lobe |= m->masked || m->bsdf == BSDF_THINDIELECTRIC || m->bsdf == BSDF_NULL;
+    const bool env_fuse_splat = [] { const char *e = getenv("DTOF_FUSE_SPLAT"); return !(e && e[0] == '0'); }();   // read per call: the parity test of the two splat paths switches it
     const bool fuse_splat_ok = env_fuse_splat && fused && !lane_dump && n_passes == 1 && !se.alpha && rp.filter == FILTER_TENT && rp.filter_radius <= 1.f && rp.filter_radius > .5f &&
                                rp.spp_log2 == 6 && rp.n_offsets == 1 && d_film != nullptr;   // exactly one wave per pixel, one film: measured (profiles/r04_fused_splat_ab.txt) -- with more
                                // waves per pixel (C3: 256 spp) or four films (C5) the separate splat kernel, which sums 8 samples per lane before it reduces, is faster
@@ -545,8 +567,9 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             // the slots are reused -- only the statistics lose those iterations, no path is cut short
             uint32_t *qout = q.q[it & 1], *alive_out = q.counts + (size_t) (2 * (it % kMaxIter)) * n_seg, *shadow_out = alive_out + n_seg;
             const int st_shade = first ? 5 : 2;
-            t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it + 1 - span, fused, next_runs, stack_depth, s, first, first && dump_now ? sc->ws.dbg.p : nullptr, &resident, splat_here ? d_film : nullptr, (uint64_t) se.crop_w * se.crop_h * 4); tm.end(st_shade, t, s);
+            t = tm.begin(st_shade, s); launch_shade(blob, blob_bytes, rp, q, qin, count_in, qout, alive_out, shadow_out, it + 1 - span, fused, next_runs, stack_depth, s, first, first && dump_now ? sc->ws.dbg.p : nullptr, &resident, splat_here ? d_film : nullptr, film_stride); tm.end(st_shade, t, s);
             fused_splat_done |= splat_here;
+            if (stats && splat_here) stats->n_fused_splat_launches++;
             if (stats && first) { stats->n_launches_first++; stats->n_inline_iterations += span; batch_inline.push_back(span); }
             if (!fused) { t = tm.begin(3, s); launch_shadow(blob, blob_bytes, rp, q, shadow_out, stack_depth, s); tm.end(3, t, s); if (stats) stats->n_launches_shadow++; }
             if (stats) stats->n_launches_shade++;
@@ -558,11 +581,11 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
             HIP_CHECK(hipMemcpyAsync(lane_dump + (b0 - first), sc->ws.dbg.p, (size_t) rp.n_lanes * sizeof(LaneDebug), hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
         } else if (!lane_dump && !fused_splat_done) {
-            t = tm.begin(4, s); launch_splat(rp, q, d_film, se.crop_w, se.crop_h, s);
+            t = tm.begin(4, s); launch_splat(rp, q, d_film, film_stride, s);
             if (se.alpha) {   // the alpha film (plane K behind the K offset films): the same splat over (valid, 0, 0) -- ImageBlock::put of aovs[3] (integrator.cpp:528-533)
                 RenderParams ra = rp; ra.n_offsets = 1;
                 Queues qa = q; qa.res = q.valid_out;
-                launch_splat(ra, qa, d_film + (size_t) rp.n_offsets * se.crop_w * se.crop_h * 4, se.crop_w, se.crop_h, s);
+                launch_splat(ra, qa, d_film + (size_t) rp.n_offsets * film_stride, film_stride, s);
             }
             tm.end(4, t, s);
         }
@@ -839,6 +862,7 @@ int dtof_render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_be
     return guarded([&] {
         if (!sc || !d_film) throw std::runtime_error("null argument");
         sc->stop = false;
+        sc->film_stride_call = caller_film_stride(sc, n_offsets);
         render_rows(sc, seed, spp, row_begin, row_end, offsets, n_offsets, d_film, stats);
     });
 }
@@ -849,8 +873,19 @@ int dtof_render_rows_async(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t 
         sc->stop = false;
         dtof_render_stats local;
         sc->defer_next = true;
+        sc->film_stride_call = caller_film_stride(sc, n_offsets);
         try { render_rows(sc, seed, spp, row_begin, row_end, offsets, n_offsets, d_film, &local); }
         catch (...) { sc->defer_next = false; if (sc->deferred.empty()) sc->events_used = 0; throw; }   // the events the failed frame took go back to the pool
+    });
+}
+int dtof_scene_set_film_layout(dtof_scene *sc, int32_t planes, uint64_t plane_stride_floats) {
+    return guarded([&] {
+        if (!sc) throw std::runtime_error("null scene");
+        if (planes < 0) throw std::runtime_error("negative plane count");
+        const HostSensor &se = sc->host.sensor;
+        if (plane_stride_floats != 0 && (plane_stride_floats % 4 != 0 || plane_stride_floats < (uint64_t) se.crop_w * 4))
+            throw std::runtime_error("plane stride must be a multiple of 4 floats and at least one film row");
+        sc->film_planes = planes; sc->film_plane_stride = plane_stride_floats;
     });
 }
 int dtof_scene_set_stream(dtof_scene *sc, void *hip_stream) {
@@ -858,7 +893,12 @@ int dtof_scene_set_stream(dtof_scene *sc, void *hip_stream) {
         if (!sc) throw std::runtime_error("null scene");
         if (!sc->deferred.empty()) throw std::runtime_error("frames are still in flight on the current stream: call dtof_async_collect first");
         ensure_device(sc);
-        HIP_CHECK(hipStreamSynchronize(sc->stream));                       // nothing of ours is left behind on the stream we leave
+        // nothing of ours is left behind on the stream we leave.  A FOREIGN stream may already be gone (the caller's torch stream was collected before it handed the stream
+        // back): no frame is in flight on it (checked above), so a failing wait there means a dead handle, not lost work -- fall through to the new stream
+        if (hipStreamSynchronize(sc->stream) != hipSuccess) {
+            (void) hipGetLastError();
+            if (sc->stream == sc->own_stream) throw std::runtime_error("hipStreamSynchronize failed on the scene's own stream");
+        }
         sc->stream = hip_stream ? (hipStream_t) hip_stream : sc->own_stream;
     });
 }
@@ -870,6 +910,7 @@ int dtof_render_stripes_async(dtof_scene *sc, uint32_t seed, uint32_t spp, int32
         sc->stop = false;
         dtof_render_stats local;
         sc->defer_next = true;
+        sc->film_stride_call = caller_film_stride(sc, n_offsets);
         try { render_rows(sc, seed, spp, first_row, sc->host.sensor.crop_h, offsets, n_offsets, d_film, &local, nullptr, 0, 0, (uint32_t) stripe_rows, (uint32_t) stripe_period); }
         catch (...) { sc->defer_next = false; if (sc->deferred.empty()) sc->events_used = 0; throw; }
     });
@@ -907,7 +948,7 @@ int dtof_async_collect(dtof_scene *sc, dtof_render_stats *sum, double *frame_ms,
             sum->ms_shadow += total(f.ev[3]); sum->ms_splat += total(f.ev[4]);
             sum->n_paths += f.counters.n_paths; sum->n_batches += f.counters.n_batches;
             sum->n_launches_trace += f.counters.n_launches_trace; sum->n_launches_shade += f.counters.n_launches_shade; sum->n_launches_shadow += f.counters.n_launches_shadow;
-            sum->n_launches_first += f.counters.n_launches_first; sum->n_inline_iterations += f.counters.n_inline_iterations;
+            sum->n_launches_first += f.counters.n_launches_first; sum->n_inline_iterations += f.counters.n_inline_iterations; sum->n_fused_splat_launches += f.counters.n_fused_splat_launches;
         }
         sc->deferred.clear(); sc->events_used = 0;
     });
@@ -919,6 +960,7 @@ int dtof_render_stripes(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t fir
         if (!sc || !d_film) throw std::runtime_error("null argument");
         if (first_row < 0 || stripe_rows <= 0 || stripe_period < stripe_rows) throw std::runtime_error("invalid stripe layout");
         sc->stop = false;
+        sc->film_stride_call = caller_film_stride(sc, n_offsets);
         render_rows(sc, seed, spp, first_row, sc->host.sensor.crop_h, offsets, n_offsets, d_film, stats, nullptr, 0, 0, (uint32_t) stripe_rows, (uint32_t) stripe_period);
     });
 }
@@ -942,6 +984,7 @@ int dtof_render_offsets(dtof_scene *sc, uint32_t seed, uint32_t spp, const float
         const int planes = k + (se.alpha ? 1 : 0), ch = se.alpha ? 4 : 3;   // rgba: one more film plane for the alpha channel, four channels out
         sc->d_film.ensure(px * 4 * planes); sc->d_rgb.ensure(px * ch * k);
         HIP_CHECK(hipMemsetAsync(sc->d_film.p, 0, px * 4 * planes * sizeof(float), sc->stream));
+        sc->film_stride_call = px * 4;   // the library's own film
         render_rows(sc, seed, spp, 0, se.crop_h, offsets, n_offsets, sc->d_film.p, stats);
         if (se.alpha) for (int i = 0; i < k; ++i) launch_develop_rgba(sc->d_film.p + px * 4 * i, sc->d_film.p + px * 4 * k, sc->d_rgb.p + px * 4 * i, (int64_t) px, sc->stream);
         else launch_develop(sc->d_film.p, sc->d_rgb.p, (int64_t) px * k, sc->stream);
@@ -1052,7 +1095,9 @@ int dtof_sampler_next_2d_correlate(dtof_sampler *s, const uint8_t *c, int all, f
 int dtof_sampler_next_1d_time(dtof_sampler *s, int strategy, float shift, int stratify, float *out) {
     return guarded([&] {
         need_seeded(s);
-        if (strategy < 0 || strategy > 3) throw std::runtime_error("unknown time sampling strategy");
+        if (strategy < 0 || strategy > TIME_REGULAR) throw std::runtime_error("unknown time sampling strategy");
+        if (strategy == TIME_ANTITHETIC_MIRROR && s->tcn != 2)   // Assert(m_time_correlate_number == 2), correlated.cpp:142
+            throw std::runtime_error("antithetic_mirror time sampling needs time_correlate_number == 2");
         if (strategy != TIME_UNIFORM && stratify && s->sample_count < (uint32_t) s->tcn)
             throw std::runtime_error("sample count must be at least time_correlate_number when per-interval stratification is on");
         RenderParams rp = sampler_params(s); rp.time_sampling = strategy; rp.antithetic_shift = shift; rp.stratify = stratify;

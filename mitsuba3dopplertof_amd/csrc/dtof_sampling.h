@@ -55,9 +55,12 @@ DTOF_D float next_time(const RenderParams &rp, Rng &main, Rng &tm, uint32_t si, 
         if (tcn == 2) { float r2 = r + rp.antithetic_shift; return rem != 1 ? r : r2; }
         return r + (float) rem / (float) tcn;
     }
-    // TIME_ANTITHETIC_MIRROR
-    float r2 = 1.0f - r + rp.antithetic_shift;
-    return rem != 1 ? r : r2;
+    if (strategy == TIME_ANTITHETIC_MIRROR) {   // Assert(m_time_correlate_number == 2) (:142): checked on the host
+        float r2 = 1.0f - r + rp.antithetic_shift;
+        return rem != 1 ? r : r2;
+    }
+    if (strategy == TIME_PERIODIC) return r + (float) rem / (float) tcn;   // correlated.cpp:147-150
+    return r;   // TIME_REGULAR falls through every branch (:152)
 }
 
 // ---------------------------------------------------------------------------- modulation
@@ -158,8 +161,8 @@ DTOF_D void camera_ray(const RenderParams &rp, float ax, float ay, float apx, fl
 // instantiations) -- the aperture draw and the two other ray constructions are not compiled in
 template <bool PERSPECTIVE_ONLY = false>
 DTOF_D PrimaryLane generate_lane(const RenderParams &rp, uint32_t lane, bool wave_pixel = false, uint32_t vlane = 0) {
-    // m_rng_time is only drawn from by the antithetic strategies of the correlated sampler (correlated.cpp:96-106)
-    const bool needs_tm = rp.integrator == 0 && rp.sampler_kind == SAMPLER_CORRELATED && (rp.time_sampling == TIME_ANTITHETIC || rp.time_sampling == TIME_ANTITHETIC_MIRROR);
+    // m_rng_time is drawn from by every strategy of the correlated sampler but uniform and stratified (correlated.cpp:96-106)
+    const bool needs_tm = rp.integrator == 0 && rp.sampler_kind == SAMPLER_CORRELATED && rp.time_sampling >= TIME_ANTITHETIC;   // every strategy but uniform / stratified (:103-107)
     Rng main, tm, path; tm.state = 0; tm.inc = 1;
     uint2 *const carried = rp.n_passes > 1 ? rp.pass_rng + (size_t) (vlane - rp.pass_first) * 3 : nullptr;
     if (rp.pass == 0 && wave_pixel && needs_tm && rp.tcn == 2 && rp.pcn == 2) {

@@ -15,7 +15,7 @@ enum ShapeKind : uint32_t { SHAPE_RECT = 0, SHAPE_MESH = 1, SHAPE_SPHERE = 2, SH
 enum ObjectKind : uint32_t { OBJ_SHAPE = 0, OBJ_INSTANCE = 1 };
 enum WaveType : int32_t { WAVE_SIN = 0, WAVE_RECT = 1, WAVE_TRI = 2, WAVE_TRAP = 3 };
 // ETimeSampling -- include/mitsuba/render/sampler.h:27-34
-enum TimeSampling : int32_t { TIME_UNIFORM = 0, TIME_STRATIFIED = 1, TIME_ANTITHETIC = 2, TIME_ANTITHETIC_MIRROR = 3 };
+enum TimeSampling : int32_t { TIME_UNIFORM = 0, TIME_STRATIFIED = 1, TIME_ANTITHETIC = 2, TIME_ANTITHETIC_MIRROR = 3, TIME_PERIODIC = 4, TIME_REGULAR = 5 };   // ETimeSampling, include/mitsuba/render/sampler.h:27-34
 enum FilterKind : int32_t { FILTER_BOX = 0, FILTER_TENT = 1, FILTER_GAUSSIAN = 2, FILTER_MITCHELL = 3, FILTER_CATMULLROM = 4, FILTER_LANCZOS = 5 };
 enum ShapeFlags : uint32_t { SF_TWOSIDED = 1, SF_FLIP_NORMALS = 2, SF_FACE_NORMALS = 4, SF_EMITTER = 8, SF_BECKMANN = 16 /* rough BSDFs: Beckmann instead of GGX */, SF_SAMPLE_ALL = 64 /* rough BSDFs: sample_visible = false */, SF_MASK = 128 /* the BSDF sits inside a `mask` (src/bsdfs/mask.cpp): DShape::opacity / tex_opacity */,
                             SF_NORMALMAP = 256 /* the BSDF sits inside a `normalmap` (src/bsdfs/normalmap.cpp): DShape::tex_normal; a twosided around it is applied first */,

@@ -461,6 +461,9 @@ PluginParams make_plugin_params(const PropBag &ip, const PropBag &sp) {
     std::string ts = ip.get_string("time_sampling_method", "antithetic");
     if (ts == "uniform") p.time_sampling = TIME_UNIFORM; else if (ts == "stratified") p.time_sampling = TIME_STRATIFIED;
     else if (ts == "antithetic") p.time_sampling = TIME_ANTITHETIC; else if (ts == "antithetic_mirror") p.time_sampling = TIME_ANTITHETIC_MIRROR;
+    // `periodic` / `regular`: ETimeSampling declares them (sampler.h:27-34) and CorrelatedSampler::next_1d_time implements them (correlated.cpp:147-152), but the
+    // reference's integrator never parses the two strings (integrator.cpp:58-70 leaves the enum uninitialised); here the names select the values they name
+    else if (ts == "periodic") p.time_sampling = TIME_PERIODIC; else if (ts == "regular") p.time_sampling = TIME_REGULAR;
     else fail("unknown time_sampling_method \"" + ts + "\"");
     p.antithetic_shift = (float) ip.get_float("antithetic_shift", p.time_sampling == TIME_ANTITHETIC ? 0.5 : 0.0);
     p.stratify_each_interval = ip.get_bool("use_stratified_sampling_for_each_interval", true);

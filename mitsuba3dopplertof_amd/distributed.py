@@ -116,15 +116,16 @@ def render_striped(scene, seed=0, spp=0, stripe_rows=16, group=None):
     unbalanced"): rows that see only sky cost a tenth of rows full of dominoes, so contiguous bands leave ranks idle (measured on
     one GPU, 8 bands of Domino: 0.75 efficiency; stripes of 16-32 rows: ranks within 3 % of each other).  Every rank accumulates
     its stripes into a zeroed full-size film and ONE reduce(sum) to rank 0 (RCCL; 16 MB at 1024 x 1024) replaces gather +
-    overlap-add.  Returns the (H, W, 3) image on rank 0, None elsewhere."""
+    overlap-add.  Returns the (H, W, 3) image -- (H, W, 4) for an rgba film -- on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
-    from . import _check, _lib
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     W, H = scene.size
     dev = torch.device("cuda", torch.cuda.current_device())
-    film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    planes = scene.film_planes()                  # 2 for an rgba film: the alpha film is one more RGBW plane behind the colour film
+    film = torch.zeros((planes, H, W, 4), dtype=torch.float32, device=dev)
+    scene.set_film_layout(planes)
     torch.cuda.synchronize()
     first, rows, period = stripe_layout(world, rank, stripe_rows)
     scene.render_stripes(film.data_ptr(), seed, spp, first, rows, period)
@@ -137,19 +138,28 @@ def render_striped(scene, seed=0, spp=0, stripe_rows=16, group=None):
             dist.reduce(film, dst=0, op=dist.ReduceOp.SUM, group=group)
     if rank != 0:
         return None
-    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    _check(_lib().dtof_develop(film.data_ptr(), rgb.data_ptr(), H * W))
+    return _develop(film, planes, H, W, dev)
+
+
+def _develop(film, planes, H, W, dev):
+    """HDRFilm::develop of a [planes, H, W, 4] device film: (H, W, 3), or (H, W, 4) when the second plane is the alpha film of an rgba scene"""
+    import torch
+    from . import _check, _lib
+    rgb = torch.zeros((H, W, 4 if planes == 2 else 3), dtype=torch.float32, device=dev)
+    if planes == 2:
+        _check(_lib().dtof_develop_rgba(film[0].data_ptr(), film[1].data_ptr(), rgb.data_ptr(), H * W))
+    else:
+        _check(_lib().dtof_develop(film.data_ptr(), rgb.data_ptr(), H * W))
     return rgb.cpu().numpy()
 
 
 def render_sharded(scene, seed=0, spp=0, halo=None, group=None):
     """One frame across the ranks of an initialised torch.distributed job (one process per GPU, backend "nccl" = RCCL): every
     rank renders its band of pixel rows into a zero-padded device slab (dtof_render_rows), ONE gather brings the slabs to
-    rank 0, which overlap-adds the shared halo rows and develops RGB / W.  Returns the (H, W, 3) image on rank 0, None elsewhere.
+    rank 0, which overlap-adds the shared halo rows and develops RGB / W.  Returns the (H, W, 3) image -- (H, W, 4) for an rgba film -- on rank 0, None elsewhere.
     World size 1 (or no process group) renders the whole frame on the current device."""
     import torch
     import torch.distributed as dist
-    from . import _check, _lib
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     W, H = scene.size
@@ -160,14 +170,17 @@ def render_sharded(scene, seed=0, spp=0, halo=None, group=None):
                          "seams would be dropped" % (halo, need))
     dev = torch.device("cuda", torch.cuda.current_device())
     r0, r1 = row_band(H, world, rank)
-    film = torch.zeros((padded_rows(H, world, halo), W, 4), dtype=torch.float32, device=dev)
+    planes, rows = scene.film_planes(), padded_rows(H, world, halo)
+    film = torch.zeros((planes, rows, W, 4), dtype=torch.float32, device=dev)
+    scene.set_film_layout(planes, rows * W * 4)   # the planes of the padded film lie a whole padded film apart
     torch.cuda.synchronize()
     scene.render_rows(film.data_ptr() + halo * W * 4 * 4, seed=seed, spp=spp, row_begin=r0, row_end=r1)
     p0, p1 = slab_range(H, world, rank, halo)
-    stack = gather_film_stacked(film[p0:p1], rank, world, group)
+    # a band of ALL planes as one slab of rows, [rows, planes * W, 4]: one gather moves it and the overlap-add works on rows
+    slab = film[:, p0:p1].permute(1, 0, 2, 3).reshape(p1 - p0, planes * W, 4).contiguous()
+    stack = gather_film_stacked(slab, rank, world, group)
     if rank != 0:
         return None
-    full = (overlap_add_stacked(stack, H, world, halo) if world > 1 else film[halo:halo + H]).contiguous()
-    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    _check(_lib().dtof_develop(full.data_ptr(), rgb.data_ptr(), H * W))
-    return rgb.cpu().numpy()
+    full = overlap_add_stacked(stack, H, world, halo) if world > 1 else slab[halo:halo + H]
+    full = full.reshape(H, planes, W, 4).permute(1, 0, 2, 3).contiguous()
+    return _develop(full, planes, H, W, dev)

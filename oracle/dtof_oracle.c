@@ -620,8 +620,11 @@ static float sampler_next_1d_time(orc_sampler *s, const orc_params *p, uint32_t 
         float r2 = 1.0f - r + p->antithetic_shift;
         uint32_t rem = si % tcn;
         return rem != 1 ? r : r2;
+    } else if (strategy == ORC_TIME_PERIODIC) {          /* correlated.cpp:147-150 */
+        uint32_t rem = si % tcn;
+        return r + (float) rem / (float) tcn;
     }
-    return r;
+    return r;                                            /* TIME_SAMPLING_REGULAR: no branch taken (:152) */
 }
 
 /* ------------------------------------------------------------------ waveforms */

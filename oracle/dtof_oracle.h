@@ -29,7 +29,7 @@ enum { ORC_EMITTER_POINT = 0, ORC_EMITTER_AREA = 1, ORC_EMITTER_SPOT = 2, ORC_EM
 /* directional (src/emitters/directional.cpp): position = the direction of travel d (unit), intensity = irradiance, bsphere as for the environment */
 enum { ORC_WAVE_SIN = 0, ORC_WAVE_RECT = 1, ORC_WAVE_TRI = 2, ORC_WAVE_TRAP = 3 };
 enum { ORC_TIME_UNIFORM = 0, ORC_TIME_STRATIFIED = 1, ORC_TIME_ANTITHETIC = 2,
-       ORC_TIME_ANTITHETIC_MIRROR = 3 };
+       ORC_TIME_ANTITHETIC_MIRROR = 3, ORC_TIME_PERIODIC = 4, ORC_TIME_REGULAR = 5 };   /* ETimeSampling, include/mitsuba/render/sampler.h:27-34 */
 enum { ORC_BSDF_DIFFUSE = 0, ORC_BSDF_CONDUCTOR = 1, ORC_BSDF_DIELECTRIC = 2, ORC_BSDF_PLASTIC = 3, ORC_BSDF_ROUGHCONDUCTOR = 4, ORC_BSDF_ROUGHPLASTIC = 5, ORC_BSDF_THINDIELECTRIC = 6, ORC_BSDF_ROUGHDIELECTRIC = 7, ORC_BSDF_NULL = 8 };
 enum { ORC_FILTER_BOX = 0, ORC_FILTER_TENT = 1, ORC_FILTER_GAUSSIAN = 2, ORC_FILTER_MITCHELL = 3, ORC_FILTER_CATMULLROM = 4, ORC_FILTER_LANCZOS = 5 };
 

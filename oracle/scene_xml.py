@@ -1439,7 +1439,8 @@ def _sensor_record(sp):
 
 # ----------------------------------------------------------------------------- plugin parameters
 WAVE = {"sinusoidal": 0, "rectangular": 1, "triangular": 2, "trapezoidal": 3}
-TIME = {"uniform": 0, "stratified": 1, "antithetic": 2, "antithetic_mirror": 3}
+# periodic / regular: declared (sampler.h:27-34) and implemented (correlated.cpp:147-152) but never parsed by the reference's integrator (integrator.cpp:58-70)
+TIME = {"uniform": 0, "stratified": 1, "antithetic": 2, "antithetic_mirror": 3, "periodic": 4, "regular": 5}
 
 
 def integrator_params(ip, sp):

@@ -70,6 +70,10 @@ CONFIGS = [
     ("boxes_tri_uncorrelated", "cornell_boxes.xml", dict(resx=32, resy=32, wave_function_type="triangular", path_correlation_depth=0), 8),
     ("boxes_trap_depth6_spp6", "cornell_boxes.xml", dict(resx=16, resy=16, wave_function_type="trapezoidal", max_depth=6, path_correlation_depth=2, time_sampling_method="stratified"), 6),
     ("boxes_tcn4", "cornell_boxes.xml", dict(resx=16, resy=16, time_correlate_number=4, time_sampling_method="antithetic"), 8),
+    # ETimeSampling's last two values (sampler.h:27-34; correlated.cpp:147-152): `periodic` -- the tcn samples of a group 1 / tcn of the exposure apart --
+    # and `regular` -- one shared time per group
+    ("boxes_periodic_tcn4", "cornell_boxes.xml", dict(resx=16, resy=16, time_correlate_number=4, time_sampling_method="periodic"), 8),
+    ("wall_regular", "cornell_wall.xml", dict(resx=24, resy=16, time_sampling_method="regular", wave_function_type="triangular"), 8),
     ("domino_small", "domino_small.xml", dict(resx=48, resy=48), 4),
     ("area_light_doppler", "cornell_area.xml", dict(resx=32, resy=32), 16),
     ("area_light_depth6_rr", "cornell_area.xml", dict(resx=24, resy=24, max_depth=6, time_sampling_method="stratified", path_correlation_depth=2), 8),

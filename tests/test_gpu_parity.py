@@ -182,7 +182,8 @@ def test_sampler_abi_streams_match_oracle(mi, orc):
     import ctypes as C
     L = orc.lib()
     n, spp = 4096, 16
-    for strategy, shift, strat in [(0, 0.0, True), (1, 0.0, True), (1, 0.0, False), (2, 0.5, True), (2, 0.25, False), (3, 0.0, True)]:
+    # 4 = periodic, 5 = regular (correlated.cpp:147-152; sampler.h:27-34)
+    for strategy, shift, strat in [(0, 0.0, True), (1, 0.0, True), (1, 0.0, False), (2, 0.5, True), (2, 0.25, False), (3, 0.0, True), (4, 0.0, True), (4, 0.0, False), (5, 0.0, True), (5, 0.3, False)]:
         for tcn, pcn in [(2, 2), (4, 2)]:
             if strategy == 3 and tcn != 2:
                 continue
@@ -203,6 +204,13 @@ def test_sampler_abi_streams_match_oracle(mi, orc):
                 assert list(ou) == state[lane].tolist(), (strategy, tcn, lane)
                 assert np.float32(of[0]).view(np.uint32) == jit[lane, 0].view(np.uint32) and np.float32(of[1]).view(np.uint32) == jit[lane, 1].view(np.uint32)
                 assert np.float32(of[2]).view(np.uint32) == tm[lane].view(np.uint32), (strategy, shift, strat, tcn, lane)
+    # Assert(m_time_correlate_number == 2) of the mirror strategy (correlated.cpp:142), and strategies outside the enum
+    s = mi.Sampler(sample_count=spp, seed=11, time_correlate_number=4, path_correlate_number=2)
+    s.seed(5, 64)
+    with pytest.raises(mi.DtofError, match="time_correlate_number == 2"):
+        s.next_1d_time(3, 0.0, True)
+    with pytest.raises(mi.DtofError, match="unknown time sampling strategy"):
+        s.next_1d_time(6, 0.0, True)
     # next_1d / next_2d use the independent stream only; per-lane correlate flags select per lane
     s = mi.Sampler(sample_count=4, seed=0)
     s.seed(0, 256)

@@ -372,6 +372,35 @@ def test_error_tables_of_the_experiment_grids(tmp_path):
 
 
 @pytest.mark.gpu
+def test_fused_splat_and_splat_kernel_agree_to_the_rounding_of_their_sums(mi, monkeypatch):
+    """the fused splat (the wave of a 64-spp pixel reduces its 36 footprint values with a butterfly and issues the atomics) sums the samples of a pixel in another
+    order than k_splat_x8, so the two films differ in the last bits.  The bound: every film value is a sum of <= 9 x 64 terms t_i; reordering a float32 sum moves it by at
+    most ~n eps sum|t_i|.  sum|t_i| is not available per pixel, but the W channel is a sum of POSITIVE terms of the same weights: there the two paths must agree to
+    n eps relative, and the colour channels to n eps x (W-weighted bound on the radiance).  The stats say which path ran (n_fused_splat_launches)."""
+    import torch
+    sc = mi.load_file(os.path.join(SCENES, "cornell_wall.xml"), resx=96, resy=64)
+    W, H = sc.size
+    films = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("DTOF_FUSE_SPLAT", fuse)
+        film = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        st = sc.render_rows(film.data_ptr(), 7, 64, 0, H)
+        assert (st["n_fused_splat_launches"] > 0) == (fuse == "1")
+        films[fuse] = film.cpu().numpy().astype(np.float64)
+    a, b = films["1"], films["0"]
+    eps, n = 2.0 ** -24, 9 * 64
+    assert np.abs(a[..., 3] - b[..., 3]).max() <= n * eps * b[..., 3].max()
+    lanes = sc.sample_lanes(7, 64, 0, W * H * 64)["rgb"]
+    bound = n * eps * b[..., 3].max() * np.abs(lanes).max()       # |t_i| <= weight x max |radiance|
+    assert np.abs(a[..., :3] - b[..., :3]).max() <= bound
+    assert not np.array_equal(a, b)                               # they ARE different sums: if this ever fails the test no longer tests anything
+    # 256 spp (four waves per pixel) and K = 4 films never fuse
+    monkeypatch.setenv("DTOF_FUSE_SPLAT", "1")
+    assert sc.render_rows(torch.zeros((H, W, 4), dtype=torch.float32, device="cuda").data_ptr(), 7, 256, 0, H)["n_fused_splat_launches"] == 0
+    assert sc.render_rows(torch.zeros((4, H, W, 4), dtype=torch.float32, device="cuda").data_ptr(), 7, 64, 0, H, offsets=[0, .25, .5, .75])["n_fused_splat_launches"] == 0
+
+
+@pytest.mark.gpu
 def test_async_frames_equal_synchronous_frames(mi):
     """dtof_render_rows_async / dtof_clear_async / dtof_develop_async / dtof_async_collect: frames enqueued back to back on the scene's stream give the films of the
     synchronous calls (same lanes; the film's float atomics add them in another order), one event-timed record per frame, launch counters summed"""

@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENES = os.path.join(ROOT, "scenes")
 SCENE = '<scene version="3.0.0">%s</scene>'
 SHAPE = '<shape type="rectangle">%s</shape>'
 DIFFUSE = '<bsdf type="diffuse"><rgb name="reflectance" value="0.2, 0.4, 0.6"/></bsdf>'
@@ -180,6 +182,64 @@ def test_valid_ray_and_alpha_channel_match_the_oracle(mi, orc, pipeline, monkeyp
     xml = _open_scene(cases[1][0], cases[1][1], rgba)
     a = np.asarray(mi.load_string(xml).render(seed=1, spp=4096))[..., 3]
     assert np.all(a[:, 3] > 0.999) and np.all(np.abs(a[:, 0] - 0.5) < 0.05)
+
+
+@pytest.mark.gpu
+def test_rgba_scene_through_every_device_film_caller(mi, orc, tmp_path):
+    """an rgba film makes the device-film calls write one more RGBW plane (the alpha film) behind the colour films.  A caller that has not declared
+    a film of that size is refused (dtof_scene_set_film_layout) instead of having its buffer overrun; the sharded renders of distributed.py (bands into a padded slab,
+    stripes into a full film) and the native CLI (single GPU, one-rank RCCL reduce, three shards on one GPU) carry the alpha plane and return the four channels of
+    Scene.render."""
+    import subprocess
+    import torch
+    from mitsuba3dopplertof_amd import distributed as D
+    half_wall = WALL.replace('<scale value="3"/>', '<scale value="3"/><translate x="3"/>')
+    rgba = '<string name="pixel_format" value="rgba"/>'
+    integ = '<integrator type="dopplertofpath"><integer name="max_depth" value="4"/></integrator>'
+    xml = _open_scene(integ, OPEN_LIGHT + VEIL % "0.3" + half_wall, rgba).replace('<rfilter type="box"/>', '<rfilter type="tent"/>')
+    xml = xml.replace('name="width" value="4"', 'name="width" value="24"').replace('name="height" value="4"', 'name="height" value="20"')
+    sc = mi.load_string(xml)
+    W, H = sc.size
+    assert (W, H) == (24, 20) and sc.info()["has_alpha"] and sc.film_planes() == 2 and sc.film_planes(4) == 5
+    ref = np.asarray(sc.render(seed=3, spp=16))
+    assert ref.shape == (H, W, 4) and 0.05 < ref[..., 3].mean() < 0.95
+    one = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")          # what a caller written for rgb films allocates
+    with pytest.raises(mi.DtofError, match="dtof_scene_set_film_layout"):
+        sc.render_rows(one.data_ptr(), 3, 16, 0, H)
+    with pytest.raises(mi.DtofError, match="dtof_scene_set_film_layout"):
+        sc.render_stripes(one.data_ptr(), 3, 16, 0, 4, 4)
+    sc.set_film_layout(1)
+    with pytest.raises(mi.DtofError, match="dtof_scene_set_film_layout"):
+        sc.render_rows(one.data_ptr(), 3, 16, 0, H)
+    torch.cuda.synchronize()
+    assert float(one.abs().sum()) == 0.0                                       # nothing was written
+    two = torch.zeros((2, H, W, 4), dtype=torch.float32, device="cuda")
+    sc.set_film_layout(2)
+    sc.render_rows(two.data_ptr(), 3, 16, 0, H)
+    img = D._develop(two, 2, H, W, two.device)
+    assert np.abs(img - ref).max() <= 1e-5 * np.abs(ref).max()
+    sc.set_film_layout(2)
+    with pytest.raises(mi.DtofError, match="declared with 2 planes"):          # four offsets + alpha = 5 planes
+        sc.render_rows(two.data_ptr(), 3, 16, 0, H, offsets=[0.0, 0.25, 0.5, 0.75])
+    for img in (D.render_sharded(sc, seed=3, spp=16), D.render_striped(sc, seed=3, spp=16, stripe_rows=3)):
+        assert img.shape == (H, W, 4) and np.abs(img - ref).max() <= 1e-5 * np.abs(ref).max()
+    # an rgb scene with a declared layout: the count is checked as well
+    rgb_scene = mi.load_file(os.path.join(SCENES, "cornell_wall.xml"), resx=16, resy=16)
+    rgb_scene.set_film_layout(2)
+    film = torch.zeros((2, 16, 16, 4), dtype=torch.float32, device="cuda")
+    rgb_scene.render_rows(film.data_ptr(), 0, 8, 0, 16, offsets=[0.0, 0.5])
+    with pytest.raises(mi.DtofError, match="declared with 2 planes"):
+        rgb_scene.render_rows(film.data_ptr(), 0, 8, 0, 16, offsets=[0.0, 0.25, 0.5])
+    # the native front end
+    path = str(tmp_path / "veil.xml")
+    open(path, "w").write(xml)
+    exe = os.path.join(ROOT, "mitsuba3dopplertof_amd", "dtof-render")
+    for extra, env in (([], {}), (["--gpus", "1"], dict(DTOF_CLI_FORCE_RCCL="1")), (["--gpus", "3", "--stripes", "3"], dict(DTOF_CLI_SHARE_GPU="1"))):
+        out = str(tmp_path / "o.npy")
+        r = subprocess.run([exe, path, "--spp", "16", "--seed", "3", "-o", out] + extra, capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        img = np.load(out)
+        assert img.shape == (H, W, 4) and np.abs(img - ref).max() <= 5e-5 * np.abs(ref).max(), (extra, np.abs(img - ref).max())
 
 
 # ---------------------------------------------------------------- the `null` BSDF (src/bsdfs/null.cpp) and emitters on shapes with a null lobe

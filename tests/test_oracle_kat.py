@@ -252,6 +252,48 @@ def test_independent_and_timestratified_samplers(orc):
         assert np.isfinite(lanes["rgb"]).all() and (lanes["rgb"] != 0).any()
 
 
+def test_periodic_and_regular_time_sampling(orc):
+    """the two ETimeSampling values the reference declares (sampler.h:27-34) and implements in CorrelatedSampler::next_1d_time
+    (correlated.cpp:147-152) but never parses.  Both draw from the shared time stream m_rng_time (one number per group of `tcn` lanes, :103-107) and go through
+    the per-interval stratification of the non-stratified strategies (r = (s / tcn + r) / (spp / tcn), :121-124); `periodic` then adds (s % tcn) / tcn -- the tcn
+    samples of a group sit exactly 1 / tcn of the exposure apart -- and `regular` returns r as it is: the samples of a group share ONE time."""
+    import ctypes as C
+    L = orc.lib()
+    spp, n = 16, 16 * 64
+    base = dict(time=0.0015, w_g_mhz=30.0, g_1=.5, g_0=.5, w_s_mhz=30.0, phase_offset=0.0, hetero_frequency=1.0, wave_type=0, low_frequency_component_only=1,
+                antithetic_shift=0.0, path_correlation_depth=1, max_depth=4, rr_depth=5, hide_emitters=0, base_seed=3, path_correlate_number=2)
+
+    def times(strategy, tcn, strat):
+        p = orc.make_params(dict(base, time_sampling=strategy, stratify_each_interval=int(strat), time_correlate_number=tcn))
+        ou, of = (C.c_uint32 * 7)(), (C.c_float * 3)()
+        out = np.zeros(n, np.float32)
+        for lane in range(n):
+            L.orc_sampler_lane(C.byref(p), 9, spp, lane, ou, of); out[lane] = of[2]
+        return out
+
+    for tcn in (2, 4):
+        n_stratum = spp // tcn
+        for strat in (True, False):
+            reg = times(5, tcn, strat).reshape(-1, spp // tcn, tcn)      # [pixel, group, member]
+            per = times(4, tcn, strat).reshape(-1, spp // tcn, tcn)
+            anti = times(2, tcn, strat).reshape(-1, spp // tcn, tcn)
+            # regular: every member of a group has the group's number, bit for bit
+            assert np.array_equal(reg, np.repeat(reg[:, :, :1], tcn, axis=2))
+            assert reg.min() >= 0 and reg.max() < 1
+            if strat:   # group g of a pixel lies in stratum g of its n_stratum strata
+                assert np.array_equal(np.floor(reg[:, :, 0].astype(np.float64) * n_stratum).astype(int), np.tile(np.arange(n_stratum), (reg.shape[0], 1)))
+            else:
+                assert 0.4 < reg.mean() < 0.6
+            # periodic: member m = the group's number + float32(m) / float32(tcn), the reference's operation order
+            want = reg[:, :, :1] + (np.arange(tcn, dtype=np.float32) / np.float32(tcn))[None, None, :]
+            assert np.array_equal(per, want.astype(np.float32))
+            # ... which is what `antithetic` does for tcn != 2 (correlated.cpp:135-138); for tcn == 2 antithetic adds the shift (0 here) to the odd member instead
+            if tcn != 2:
+                assert np.array_equal(per, anti)
+            else:
+                assert np.array_equal(anti, reg)
+
+
 @pytest.mark.parametrize("rfilter,exact", [('<rfilter type="tent" />', True), ('<rfilter type="mitchell" />', True),
                                            ('<rfilter type="catmullrom" />', True), ('<rfilter type="mitchell"><float name="B" value="0.2" /><float name="C" value="0.7" /></rfilter>', True),
                                            ("", False), ('<rfilter type="lanczos" />', False)])

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarises the rocprofv3 --pmc passes of ONE bench configuration into profiles/roofline_traffic.json (merged: other configurations stay).
 
-    python tools/pmc_summary.py OUT.json CONFIG FETCH_DIR WRITE_DIR VALU_DIR
+    python tools/pmc_summary.py OUT.json CONFIG FETCH_DIR WRITE_DIR VALU_DIR [FRAMES]
+
+FRAMES: frames the profiled command rendered (warm-up + the synchronous counter frame + timed steps); with it every kernel also gets `launches_per_step`.
 
 FETCH_DIR / WRITE_DIR / VALU_DIR: output directories of three separate passes (--pmc FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU
 SQ_WAVES) over `bench.py --config CONFIG --no-extra --no-cpu-baseline`.  Per kernel and launch:
@@ -49,6 +51,7 @@ def short(name):
 
 def main():
     out_path, config, d_fetch, d_write, d_valu = sys.argv[1:6]
+    frames = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     fetch, write = collect(d_fetch, "FETCH_SIZE"), collect(d_write, "WRITE_SIZE")
     valu, thr, waves = collect(d_valu, "SQ_INSTS_VALU"), collect(d_valu, "SQ_THREAD_CYCLES_VALU"), collect(d_valu, "SQ_WAVES")
     kernels = {}
@@ -58,7 +61,8 @@ def main():
             continue
         f, w = fetch.get(name, []), write.get(name, [])
         fk, wk = sum(f) / max(len(f), 1), sum(w) / max(len(w), 1)
-        rec = {"symbol": name, "launches_sampled": max(len(f), len(w), len(valu.get(name, []))), "FETCH_SIZE_KiB_avg": round(fk, 1), "WRITE_SIZE_KiB_avg": round(wk, 1),
+        n_launches = max(len(f), len(w), len(valu.get(name, [])))
+        rec = {"symbol": name, "launches_sampled": n_launches, "FETCH_SIZE_KiB_avg": round(fk, 1), "WRITE_SIZE_KiB_avg": round(wk, 1),
                "hbm_read_bytes_per_launch": int(2 * fk * 1024), "hbm_write_bytes_per_launch": int(wk * 1024), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
         if valu.get(name):
             v = sum(valu[name]) / len(valu[name])
@@ -67,6 +71,17 @@ def main():
                 rec["active_lane_ratio"] = round(sum(thr[name]) / len(thr[name]) / (64.0 * v), 4)
             if waves.get(name):
                 rec["waves_per_launch"] = int(sum(waves[name]) / len(waves[name]))
+        if frames:
+            rec["launches_per_step"] = round(n_launches / frames, 3)
+        if k in kernels:      # several instantiations under one short name (the bounce kernels of different iterations): launch-weighted merge
+            o, a, b = kernels[k], kernels[k]["launches_sampled"], n_launches
+            for key in ("FETCH_SIZE_KiB_avg", "WRITE_SIZE_KiB_avg", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "hbm_bytes_per_launch", "valu_wave_insts_per_launch", "waves_per_launch"):
+                if key in o and key in rec:
+                    rec[key] = type(rec[key])((o[key] * a + rec[key] * b) / (a + b))
+            rec["launches_sampled"] = a + b
+            if frames:
+                rec["launches_per_step"] = round((a + b) / frames, 3)
+            rec["symbol"] = o["symbol"] + " | " + name
         kernels[k] = rec
     doc = {}
     if os.path.exists(out_path):
