@@ -164,59 +164,76 @@ def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_ov
     spp = spp0 * world if scaling == "weak" else spp0
     r0, r1 = D.row_band(H, world, rank)
     pad_rows = D.padded_rows(H, world, halo)
-    film = torch.zeros((pad_rows, W, 4), dtype=torch.float32, device=dev)
-    film_ptr = film.data_ptr() + halo * W * 4 * 4
-    p0, p1 = D.slab_range(H, world, rank, halo)
-    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    gather_buf = torch.empty((world, p1 - p0, W, 4), dtype=torch.float32, device=dev) if (exchange and rank == 0) else None
     lib = mi._lib()
     keys = ("ms_trace", "ms_shade", "ms_shadow", "ms_generate", "ms_splat", "ms_total", "ms_first", "n_bounces", "n_shadow_rays", "n_paths")
-    acc = dict.fromkeys(keys + ("launches", "first_launches", "launches_equiv", "inline_bounces", "fused_splat_launches"), 0.0)
+    acc = dict.fromkeys(keys + ("launches", "first_launches", "launches_equiv", "inline_bounces", "fused_splat_launches", "launches_trace", "launches_shadow"), 0.0)
     acc.update(launches=0, first_launches=0)
     K = len(offsets) if offsets else 1
     native = bool(offsets) or striped            # library-native [K][H][W][4] films (K offsets in ONE traversal, config c5)
-    if native:
-        kfilm = torch.zeros((K, H, W, 4), dtype=torch.float32, device=dev)
-        krgb = torch.zeros((K, H, W, 3), dtype=torch.float32, device=dev)
+    pipelined = not share and not os.environ.get("DTOF_BENCH_SYNC")
+    # The film exchange of frame i runs BESIDE the render of frame i + 1: two film buffers, the render stream and an exchange stream (RCCL collectives are ordered behind
+    # the stream that is current when torch.distributed is called), events both ways -- a frame's reduce / gather + overlap-add + develop no longer sits between two
+    # renders (a 16 MB / 64 MB reduce over xGMI against a 4 - 6 ms render at eight GPUs).  Frames still complete in order, one host wait for the K steps.
+    # DTOF_BENCH_NO_OVERLAP=1: everything on the one stream, as round 4 had it (A/B).
+    overlap = bool(exchange and pipelined and not os.environ.get("DTOF_BENCH_NO_OVERLAP"))
+    nbuf = 2 if overlap else 1
+    p0, p1 = D.slab_range(H, world, rank, halo)
+    films = [torch.zeros((K, H, W, 4) if native else (pad_rows, W, 4), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    rgb = torch.zeros((K, H, W, 3) if native else (H, W, 3), dtype=torch.float32, device=dev)
+    gather_buf = torch.empty((world, p1 - p0, W, 4), dtype=torch.float32, device=dev) if (exchange and rank == 0 and not native) else None
 
-    def develop(src, dst, n):      # enqueued on the scene's stream (= the torch stream of this workload, see below)
-        scene.develop_async(src.data_ptr(), dst.data_ptr(), n)
-
-    # ONE stream carries a frame from end to end on every rank: the library enqueues on the torch stream of this workload (dtof_scene_set_stream), so the film
-    # clear, the render, the film exchange (torch.distributed enqueues RCCL collectives behind the current stream, no host wait) and the develop are ordered by the
-    # stream and the K timed steps are queued back to back and waited for ONCE -- the same loop for N = 1 and N > 1.  Only the development set-up in which two
-    # ranks share one GPU (DTOF_BENCH_SHARE_GPU=1: gloo carries the exchange through host memory) and DTOF_BENCH_SYNC=1 synchronise once per step.
+    # ONE stream carries the renders of every rank: the library enqueues on the torch stream of this workload (dtof_scene_set_stream); the film clear, the render, the
+    # film exchange (no host wait) and the develop are ordered by streams and events, and the K timed steps are queued back to back and waited for ONCE -- the same loop for
+    # N = 1 and N > 1.  Only the development set-up in which several ranks share one GPU (DTOF_BENCH_SHARE_GPU=1: gloo carries the exchange through host memory) and
+    # DTOF_BENCH_SYNC=1 synchronise once per step.
     torch.cuda.synchronize()          # the buffers above were zero-filled on the default stream
     stream = torch.cuda.Stream(device=dev)
-    pipelined = not share and not os.environ.get("DTOF_BENCH_SYNC")
+    comm = torch.cuda.Stream(device=dev) if overlap else stream
+    ev_rendered = [torch.cuda.Event() for _ in range(nbuf)]
+    ev_free = [torch.cuda.Event() for _ in range(nbuf)]
     scene.set_stream(stream.cuda_stream)
-    full_view = film[halo:halo + H]
+    frame_no = [0]
+
+    def develop(src, dst, n):      # on the stream that is current: the render stream, or the exchange stream of an overlapped frame
+        mi._check(lib.dtof_develop_on_stream(src.data_ptr(), dst.data_ptr(), n, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     def enqueue_step():
-        """clear -> render -> exchange -> develop of one frame, all on `stream`; nothing waits on the host unless the exchange has to (gloo)"""
+        """clear -> render on `stream`, then exchange -> develop on `comm` (= `stream` unless the exchange is overlapped); nothing waits on the host unless the exchange has to (gloo)"""
+        i = frame_no[0]; frame_no[0] += 1
+        buf = films[i % nbuf]
+        if overlap and i >= nbuf:
+            stream.wait_event(ev_free[i % nbuf])            # the exchange of frame i - 2 has read this buffer
+        buf.zero_()
         if native:
-            kfilm.zero_()
             if striped:               # interleaved stripes of rows per rank, ONE reduce(sum) of the full-size films to rank 0
-                scene.render_stripes_async(kfilm.data_ptr(), 0, spp, *D.stripe_layout(world, rank, stripe_rows), offsets=offsets)
-                if share:
-                    host = kfilm.cpu(); dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-                    if rank == 0:
-                        kfilm.copy_(host)
-                else:
-                    dist.reduce(kfilm, dst=0, op=dist.ReduceOp.SUM)
+                scene.render_stripes_async(buf.data_ptr(), 0, spp, *D.stripe_layout(world, rank, stripe_rows), offsets=offsets)
             else:
-                scene.render_rows_async(kfilm.data_ptr(), 0, spp, 0, H, offsets=offsets)
-            if rank == 0:
-                develop(kfilm, krgb, H * W * K)
+                scene.render_rows_async(buf.data_ptr(), 0, spp, 0, H, offsets=offsets)
         else:
-            film.zero_()
-            scene.render_rows_async(film_ptr, 0, spp, r0, r1)
-            if exchange:
-                stack = D.gather_film_stacked(film[p0:p1], rank, world, out=gather_buf, force=True)
+            scene.render_rows_async(buf.data_ptr() + halo * W * 4 * 4, 0, spp, r0, r1)
+        if overlap:
+            ev_rendered[i % nbuf].record(stream)
+        with torch.cuda.stream(comm):
+            if overlap:
+                comm.wait_event(ev_rendered[i % nbuf])
+            if native:
+                if striped:
+                    if share:
+                        host = buf.cpu(); dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                        if rank == 0:
+                            buf.copy_(host)
+                    else:
+                        dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
+                if rank == 0:
+                    develop(buf, rgb, H * W * K)
+            elif exchange:
+                stack = D.gather_film_stacked(buf[p0:p1], rank, world, out=gather_buf, force=True)
                 if rank == 0:
                     develop(D.overlap_add_stacked(stack, H, world, halo).contiguous(), rgb, H * W)
             else:
-                develop(full_view, rgb, H * W)
+                develop(buf[halo:halo + H], rgb, H * W)
+            if overlap:
+                ev_free[i % nbuf].record(comm)
 
     def collect_into(acc_, n_steps):
         st, frame_ms = scene.collect()
@@ -224,6 +241,7 @@ def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_ov
             acc_[k] += st[k]
         acc_["launches"] += st["n_launches_shade"]; acc_["first_launches"] += st["n_launches_first"]; acc_["launches_equiv"] += st["n_inline_iterations"]
         acc_["fused_splat_launches"] += st["n_fused_splat_launches"]
+        acc_["launches_trace"] += st["n_launches_trace"]; acc_["launches_shadow"] += st["n_launches_shadow"]
         return frame_ms
 
     def barrier():
@@ -236,23 +254,25 @@ def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_ov
             for _ in range(warmup):
                 enqueue_step()
                 scene.collect()
+            comm.synchronize()                # the exchange of the last warm-up frame has left films[0] (the synchronous frame below renders into it)
             # the bounce / shadow-ray counters need a read-back: they come from ONE identical frame (every step renders seed 0) rendered synchronously before the timed region
             if native and striped:
-                st1 = scene.render_stripes(kfilm.data_ptr(), 0, spp, *D.stripe_layout(world, rank, stripe_rows), offsets=offsets)
+                st1 = scene.render_stripes(films[0].data_ptr(), 0, spp, *D.stripe_layout(world, rank, stripe_rows), offsets=offsets)
             elif native:
-                st1 = scene.render_rows(kfilm.data_ptr(), seed=0, spp=spp, row_begin=0, row_end=H, offsets=offsets)
+                st1 = scene.render_rows(films[0].data_ptr(), seed=0, spp=spp, row_begin=0, row_end=H, offsets=offsets)
             else:
-                st1 = scene.render_rows(film_ptr, seed=0, spp=spp, row_begin=r0, row_end=r1)
+                st1 = scene.render_rows(films[0].data_ptr() + halo * W * 4 * 4, seed=0, spp=spp, row_begin=r0, row_end=r1)
             counts = {"n_bounces": st1["n_bounces"], "n_shadow_rays": st1["n_shadow_rays"], "inline_bounces": st1["n_bounces_inline"]}
             barrier()
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
             per_step = []
             t0 = time.perf_counter()
+            frame_no[0] = 0
             ev[0].record(stream)
             for i in range(steps):
                 ts = time.perf_counter()
                 enqueue_step()
-                ev[i + 1].record(stream)
+                ev[i + 1].record(comm)              # where the frame ends: behind its develop
                 if not pipelined:
                     collect_into(acc, 1)
                     stream.synchronize()
@@ -284,14 +304,15 @@ def run_workload(ctx, cfg, scaling, steps, warmup, sharding, stripe_rows, spp_ov
     elapsed, per_step = float(t[0]), np.sort(t[1:])
     total_paths = W * H * spp
     out = dict(acc=acc, elapsed=elapsed, steps=steps, pipelined=pipelined, W=W, H=H, spp=spp, spp_per_gpu=spp0, total_paths=total_paths, halo=halo, striped=striped, offsets=offsets,
-               defines=defines, scene_path=scene_path, res=res,
+               defines=defines, scene_path=scene_path, res=res, exchange_overlapped=overlap,
                ms_render_rank_min=float(lo.item()), ms_render_rank_max=float(hi.item()),
                value=total_paths * steps / elapsed / 1e6, ms_per_step=elapsed / steps * 1e3,
                ms_per_step_min=float(per_step[0]) * 1e3, ms_per_step_median=float(np.median(per_step)) * 1e3, ms_per_step_max=float(per_step[-1]) * 1e3,
                ms_per_step_p95=float(per_step[min(len(per_step) - 1, int(0.95 * len(per_step)))]) * 1e3, fused_splat=acc["fused_splat_launches"] > 0)
     if rank == 0:
-        out["image"] = (krgb if native else rgb).cpu().numpy()
-        out["film"] = None if native else film[halo:halo + H].cpu().numpy()
+        out["image"] = rgb.cpu().numpy()
+        # the film the LAST timed frame left on this device (N = 1: the whole frame; the parity figure of the bench line reads it)
+        out["film"] = None if native else films[(steps - 1) % nbuf][halo:halo + H].cpu().numpy()
     return out
 
 
@@ -306,7 +327,7 @@ def wavefront_block(e, steps, config):
          "path_bounces_per_step": round(bounces, 1), "shadow_rays_per_step": round(acc["n_shadow_rays"] / steps, 1),
          "loop_ms_per_step": round(loop_s * 1e3, 4), "ms_trace": round(acc["ms_trace"] / steps, 4), "ms_shade": round(acc["ms_shade"] / steps, 4), "ms_shadow": round(acc["ms_shadow"] / steps, 4),
          "ms_generate": round(acc["ms_generate"] / steps, 4), "ms_splat": round(acc["ms_splat"] / steps, 4),
-         "launches_per_step": {"trace+shade+shadow": acc["launches"] / steps},
+         "launches_per_step": {"k_trace": acc["launches_trace"] / steps, "k_shade": acc["launches"] / steps, "k_shadow": acc["launches_shadow"] / steps},
          "survey_model": {"bytes_per_path_bounce": B_BOUNCE, "algorithmic_bytes_per_step": round(B_BOUNCE * bounces, 1),
                           "achieved_GBs": round(B_BOUNCE * bounces / max(loop_s, 1e-12) / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
                           "frac": round(B_BOUNCE * bounces / max(loop_s, 1e-12) / 1e9 / HBM_PEAK_GBS, 4), "target_frac": 0.40}}
@@ -535,7 +556,7 @@ def main():
             return d
         # The headline workload SUSTAINED: >= 1 s of back-to-back frames whatever --steps the caller chose (20 steps of C2 are a 32 ms burst; the clock under load sits below the
         # 2.4 GHz the peak is priced at), with the spread of the per-frame GPU durations
-        n_sus = 800
+        n_sus = 800 if not share else 8      # (ranks sharing one GPU over gloo synchronise every step: a rehearsal of the code path, not a measurement)
         e = run_workload(ctx, "c2", args.scaling, n_sus, 3, "bands", args.stripe_rows)
         extra["c2_sustained"] = {"value": round(e["value"], 2), "unit": "Mpaths/s", "steps": n_sus, "timed_region_s": round(e["elapsed"], 3), "ms_per_step": round(e["ms_per_step"], 4),
                                  "ms_per_step_min": round(e["ms_per_step_min"], 4), "ms_per_step_median": round(e["ms_per_step_median"], 4), "ms_per_step_p95": round(e["ms_per_step_p95"], 4),
@@ -584,7 +605,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "ms_per_step_min": round(r["ms_per_step_min"], 4), "ms_per_step_median": round(r["ms_per_step_median"], 4),
             # true: the K timed steps were enqueued back to back and waited for once (ms_per_step_min / median are then GPU-side frame durations); DTOF_BENCH_SYNC=1: one host synchronisation per step
-            "steps_pipelined": bool(r["pipelined"]), "pipeline": args.pipeline, "timed_region_s": round(r["elapsed"], 4),
+            "steps_pipelined": bool(r["pipelined"]), "exchange_overlapped": bool(r["exchange_overlapped"]), "pipeline": args.pipeline, "timed_region_s": round(r["elapsed"], 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (("cornell_wall (Cornell box, one linearly translating wall) %dx%d, %d spp%s, sinusoidal "
                                     "heterodyne hetero_frequency=1, stratified time sampling, max_depth 4, tent filter") if args.config == "c2" else

@@ -221,6 +221,9 @@ int dtof_render_stripes_async(dtof_scene *scene, uint32_t seed, uint32_t spp, in
 int dtof_scene_set_film_layout(dtof_scene *scene, int32_t planes, uint64_t plane_stride_floats);
 /* HDRFilm::develop (src/films/hdrfilm.cpp:305-406) on device buffers: rgb = RGB / (W == 0 ? 1 : W). */
 int dtof_develop(const float *d_film_rgbw, float *d_rgb, int64_t n_pixels);
+/* ... enqueued on the caller's stream without a host wait (hipStream_t; NULL = the null stream): the develop of a frame whose film exchange runs on a stream of its
+ * own, beside the next frame's render (bench.py: the exchange of frame i overlaps the render of frame i + 1). */
+int dtof_develop_on_stream(const float *d_film_rgbw, float *d_rgb, int64_t n_pixels, void *hip_stream);
 /* ... of an rgba film: rgba = (R, G, B) / W of the colour film and A / W of the alpha film (the plane behind the colour films, see dtof_scene_info::has_alpha). */
 int dtof_develop_rgba(const float *d_film_rgbw, const float *d_alpha_film, float *d_rgba, int64_t n_pixels);
 /* Same as dtof_render but with n_offsets batched modulation offsets; out_rgb holds n_offsets images. */

@@ -103,6 +103,7 @@ def _lib():
     L.dtof_sample_lanes.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp]
     L.dtof_sample_lanes_valid.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp]
     L.dtof_develop_rgba.argtypes = [vp, vp, vp, C.c_int64]
+    L.dtof_develop_on_stream.argtypes = [vp, vp, C.c_int64, vp]
     L.dtof_sampler_create.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.dtof_sampler_destroy.argtypes = [vp]
     L.dtof_sampler_destroy.restype = None

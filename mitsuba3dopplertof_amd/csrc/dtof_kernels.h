@@ -58,6 +58,7 @@ struct RenderParams {
     uint32_t pass_first;                          // virtual lane the pass_rng array starts at
     int32_t has_env, hide_emitters; uint32_t env_index;   // `constant` environment emitter (scene.cpp:53-57), SamplingIntegrator::m_hide_emitters
     uint32_t chunk_blocks;                        // first-bounce kernel: blocks per 512-lane segment, 1 or 8 (small frames whose whole path runs inline)
+    uint32_t res_units;                           // resident first-bounce kernel whose launch covers the whole path: work units a wave takes from the counter per 512-lane segment (1, 2, 4, 8)
     uint32_t inline_iters;                        // fused first-bounce kernel: iterations of the bounce loop it runs back to back with the path state in registers (1 .. kMaxInline)
     uint32_t flat_objects, flat_off;                        // fused pipeline, rectangle-only scenes of at most kFlatObjects objects: their number (trace_flat), else 0
     uint32_t memo_obj;                            // fused pipeline: the scene's only instance object (instance memo, dtof_traverse.h) or 0xffffffff
@@ -100,7 +101,20 @@ struct ShadeArgs {
     const uint32_t *qin, *count_in; uint32_t *qout, *alive_out, *shadow_out; uint32_t depth, trace_next; LaneDebug *dbg;
     float *film; uint64_t film_stride;   // first-bounce kernel whose launch covers the whole path: it splats its lanes itself (k_shade, "fused splat"); nullptr: the splat kernels do
     uint32_t n_seg, res_small_off, res_small_words, res_memo;   // resident stage (RESW != 0): segments of the batch; byte offset / uint4 count of the record block copied to LDS; 1 = the instance memo has LDS
+    uint32_t res_park_off;   // resident stage with several films: word offset (behind the memo) of the film-state columns, kParkWords words per thread behind the stack columns
 };
+// Resident kernels of several films keep the films' running results in LDS instead of registers (k_shade: RES_LDS): kParkWords of the 3 * kMaxOffsets floats per
+// thread -- what Domino's stage leaves free of the CU's 160 KiB at 16 waves (64 KiB node planes + 3 KiB records + 48 KiB stack columns) -- the last one stays a register
+constexpr uint32_t kParkWords = 11;
+// DTOF_PARK (default 1): the resident ONE-film kernels at 16 waves (128 VGPRs, ~150 spilled) park the path state no traversal reads -- both PCG states with their
+// stream selectors and throughput / path length, kParkState words -- in the same columns across the two traversals of an iteration instead of leaving them to the register
+// allocator's spill code: scratch 200 -> 168 B per lane, C4 33.69 -> 33.26 ms (profiles/r05_k4_film_state.txt).  A scene whose stage no longer fits the CU's LDS with
+// the columns at 16 waves takes 12 (resident_lds_bytes / render_rows' step-down), where the kernels have 168 VGPRs and park nothing.
+#ifndef DTOF_PARK
+#define DTOF_PARK 1
+#endif
+constexpr uint32_t kParkState = 10;
+
 // One launch of k_shade as launch_shade hands it to the translation unit that holds the instantiation (dtof_shade_*.hip: the ~100 instantiations of the
 // kernel compile in parallel, one group per file): staged = the scene blob is copied to LDS by every block; mode 0 split, 1 fused, 2 fused first bounce;
 // waves != 0: the resident form (`waves` waves per block, one block per CU).

@@ -493,7 +493,8 @@ void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
 uint32_t resident_lds_bytes(const RenderParams &rp, const ResidentStage &resident, uint32_t stack_depth, uint32_t waves) {
     static_assert(kResidentNodes == kResNodes, "resident stage size");
     const uint32_t memo = rp.memo_obj != 0xffffffffu ? 1u : 0u;
-    return (4u * kResNodes + resident.small_words) * 16u + memo * waves * kMemoWords * kMemoStride * 4u + stack_bytes(stack_depth, waves * 64);
+    const uint32_t park = (rp.n_offsets != 1 ? kParkWords : (DTOF_PARK && waves == 16 ? kParkState : 0u)) * waves * 64u * 4u;   // film-state columns of the several-film kernels (k_shade: RES_LDS) / parked path state (PARK)
+    return (4u * kResNodes + resident.small_words) * 16u + memo * waves * kMemoWords * kMemoStride * 4u + stack_bytes(stack_depth, waves * 64) + park;
 }
 uint32_t device_lds_limit() {
     if (const char *e = getenv("DTOF_LDS_LIMIT")) return (uint32_t) strtoul(e, nullptr, 10);   // tests: a smaller budget than the device's (the step-down / fallback paths)
@@ -519,7 +520,7 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
             const uint32_t n_seg = nseg(rp.n_lanes), grid = std::min<uint32_t>((uint32_t) n_cu, (n_seg + waves - 1) / waves);
             const uint32_t memo = rp.memo_obj != 0xffffffffu ? 1u : 0u;
             const ShadeLaunch L = { false, 2, waves, grid, lds, s,
-                                    { scene, scene_bytes, 0u, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, trace_next ? 1u : 0u, dbg, film, film_stride, n_seg, resident->small_off, resident->small_words, memo } };
+                                    { scene, scene_bytes, 0u, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, trace_next ? 1u : 0u, dbg, film, film_stride, n_seg, resident->small_off, resident->small_words, memo, stack_bytes(stack_depth, waves * 64) / 4u } };
             if (hipMemsetAsync(q.seg_counter, 0, 4, s) != hipSuccess) throw std::runtime_error("hipMemsetAsync(seg_counter) failed");
             if (rp.has_spec == 2) launch_shade_resident2(k4, L);
             else if (rp.has_spec) launch_shade_resident1(k4, L);
@@ -533,7 +534,7 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
     const uint32_t sw = stage_words_for(scene_bytes, shade_stack), grid = nseg(rp.n_lanes) * (first && rp.chunk_blocks > 1 ? rp.chunk_blocks : 1u), lds = sw * 16 + shade_stack;
     check_lds(lds);
     const ShadeLaunch L = { sw != 0, first ? 2 : fused ? 1 : 0, 0u, grid, lds, s,
-                            { scene, scene_bytes, sw, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, trace_next ? 1u : 0u, dbg, film, film_stride, nseg(rp.n_lanes), 0u, 0u, 0u } };
+                            { scene, scene_bytes, sw, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, trace_next ? 1u : 0u, dbg, film, film_stride, nseg(rp.n_lanes), 0u, 0u, 0u, 0u } };
     if (rp.has_spec == 2) launch_shade_spec2(k4, L);
     else if (rp.has_spec) launch_shade_spec1(k4, L);
     else if (rp.has_tris) launch_shade_mesh(rp.has_area != 0, k4, L);

@@ -554,7 +554,14 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
                 const bool whole_path = first && !((it + 1 < rp.max_depth) && !(it + 2 >= rp.max_depth && skip_tail));
                 const uint32_t env_chunk_segs = [] { const char *e = getenv("DTOF_CHUNK_SEGS"); return e ? (uint32_t) atoi(e) : 8192u; }();   // frames up to this many segments (A/B switch; read per call: tests switch it)
                 rp.chunk_blocks = whole_path && n_seg <= env_chunk_segs ? kChunkBlocks : 1u;
-                if (rp.chunk_blocks > 1) HIP_CHECK(hipMemsetAsync(q.counts, 0, (size_t) 2 * (it + 1) * n_seg * 4, s));
+                // The resident kernel's waves take their work from a counter; a launch ends with a tail in which they run out one after the other, as long as the last unit
+                // they started (a 512-lane segment = eight chunks of three bounces: ~0.7 ms on Domino).  When nothing is compacted for a later launch the unit can be a part
+                // of a segment (DTOF_RES_UNITS = units per segment, 1 / 2 / 4 / 8; the statistics slots are then added into, like those of the chunked small frames).
+                // MEASURED and OFF (profiles/r05_resident_units.txt): the shorter tail does not pay for the units' overhead on one GPU -- C4 33.20 ms at one unit per segment,
+                // 34.13 at two, 35.98 at four; C5 170.8 against 179.3 ms at four.  Kept as a switch for launches a fraction of this size (a frame sharded over many GPUs).
+                const uint32_t env_units = [] { const char *e = getenv("DTOF_RES_UNITS"); const int v = e ? atoi(e) : 1; return (uint32_t) (v == 1 || v == 2 || v == 4 || v == 8 ? v : 1); }();
+                rp.res_units = whole_path ? env_units : 1u;
+                if (rp.chunk_blocks > 1 || (rp.res_units > 1 && resident.waves)) HIP_CHECK(hipMemsetAsync(q.counts, 0, (size_t) 2 * (it + 1) * n_seg * 4, s));
             }
             // does iteration it+1 run?  (same conditions as the loop head)
             const bool next_runs = (it + 1 < rp.max_depth) && !(it + 2 >= rp.max_depth && skip_tail);
@@ -1013,6 +1020,13 @@ int dtof_sample_lanes_valid(dtof_scene *sc, uint32_t seed, uint32_t spp, uint64_
 }
 int dtof_sample_lanes(dtof_scene *sc, uint32_t seed, uint32_t spp, uint64_t lane_begin, uint64_t n, float *out) {
     return dtof_sample_lanes_valid(sc, seed, spp, lane_begin, n, out, nullptr);
+}
+int dtof_develop_on_stream(const float *d_film, float *d_rgb, int64_t n_pixels, void *hip_stream) {
+    return guarded([&] {
+        if (!d_film || !d_rgb) throw std::runtime_error("null argument");
+        launch_develop(d_film, d_rgb, n_pixels, (hipStream_t) hip_stream);
+        HIP_CHECK(hipGetLastError());
+    });
 }
 int dtof_develop_rgba(const float *d_film, const float *d_alpha_film, float *d_rgba, int64_t n_pixels) {
     return guarded([&] {

@@ -318,8 +318,30 @@ template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, int SPEC, int RESW
 // scenes each).  Two waves stay for these instantiations because they are FASTER there: with four films in registers the 168-VGPR build spills 240 - 390 registers, and
 // the K = 4 frames of the every-BSDF scenes take 1 - 10 % longer at three waves (cornell_specular 9.13 -> 9.60 ms, cornell_spot 7.80 -> 8.58; profiles/r03_k4_waves_ab.txt)
 // -- the opposite of the K = 1 kernels, which lose 20 - 27 % at two (profiles/r03_spec_waves_ab.txt).
+// DTOF_K4_RES_MEM (default 1): the fused first-bounce kernels of SEVERAL films (KMAX > 1) keep neither the K running results nor the K NEE candidates in registers.
+// Round 4's four-film Domino kernel carried 12 + 12 of them across both traversals of every iteration, in scratch: 54 GB of HBM traffic per launch against 10.7 GB of
+// outputs, half its wave-cycles waiting (profiles/r04_pmc_c4_c5.txt).  What is pending across the shadow ray is K-INDEPENDENT -- the throughput, the unweighted
+// contribution bsdf_val * em_weight * mis_em and the path length to the emitter (dopplertofpath.cpp:214-226: only eval_modulation_weight, :60-77, depends on the offset)
+// = 7 registers -- and the K weights are applied when the sample is committed, in the same fmaf order.  The running results live where they have to end up anyway, in
+// q.res: a commit is a read-modify-write of the lane's K records (the first one of a path writes without reading, `res_live`), lines the same wave wrote a few
+// microseconds earlier.  MEASURED (profiles/r05_k4_film_state.txt): on the four-film Domino frame that form is no faster than the registers (181.9 against 178.9 ms) --
+// the kernel's scratch stays above the L2 either way -- so it is OFF (=1 builds it for A/B).
+// DTOF_K4_RES_LDS (default 1): the RESIDENT several-film kernels keep the running results in LDS instead: Domino's stage leaves 44 KiB of the CU's 160 free at 16 waves,
+// kParkWords = 11 words per thread, which hold 11 of the 12 floats of four RGB results (the twelfth stays a register); the pending sample is the K-independent one
+// described above.  Film state then costs the K = 4 kernel ONE register more than the K = 1 kernel's, and a commit is 12 ds_read + 12 ds_write.
+#ifndef DTOF_K4_RES_MEM
+#define DTOF_K4_RES_MEM 0
+#endif
+#ifndef DTOF_K4_RES_LDS
+#define DTOF_K4_RES_LDS 1
+#endif
 __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : (MODE != 0 && MESH) ? ((SPEC && KMAX > 1) ? 2 : DTOF_MESH_WAVES) : 1) void k_shade(ShadeArgs args_by_value) {
     constexpr bool FUSED = MODE != 0, FIRST = MODE == 2;
+    constexpr bool RES_LDS = RESW != 0 && KMAX > 1 && DTOF_K4_RES_LDS;   // several films, resident stage: running results in LDS columns
+    constexpr bool RES_MEM = FIRST && KMAX > 1 && (RES_LDS || DTOF_K4_RES_MEM);   // several films: running results outside the registers (LDS, else q.res), the pending NEE sample K-independent (see above)
+    static_assert(!RES_LDS || 3 * KMAX == (int) kParkWords + 1, "the film-state columns hold all but the last float of the K results");
+    constexpr bool PARK = DTOF_PARK && RESW == 16 && KMAX == 1;   // the path state no traversal reads waits in LDS columns while the rays are traced
+    constexpr int KREG = RES_MEM ? 1 : KMAX;                         // film-state registers the lane carries
     constexpr uint32_t kStackStride = RESW ? RESW * 64 : kShadeBlock;   // the block size = the stride of the traversal-stack columns
     static_assert(RESW == 0 || (MODE == 2 && !LDS && MESH), "the resident stage exists for the unstaged fused first-bounce kernel with mesh code");
     extern __shared__ uint4 lds[];
@@ -340,7 +362,8 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     // One block per 512-lane segment -- or, for a small frame whose whole path runs inline (rp.chunk_blocks = 8: nothing is compacted for a
     // later launch), one block per 64-lane chunk, so that a 1 M-lane frame is 16 384 waves instead of 2 048; the per-segment statistics are
     // then accumulated with atomics into slots the host has zeroed.
-    const uint32_t sub = FIRST && !RESW ? A0.rp.chunk_blocks : 1u;        // blocks per segment: 1 or kSeg / kShadeBlock
+    const uint32_t sub = FIRST ? (RESW ? A0.rp.res_units : A0.rp.chunk_blocks) : 1u;   // work units per segment: blocks (1 or kSeg / kShadeBlock), resident: what a wave takes from the counter at a time
+    const uint32_t unit_lanes = kSeg / sub;
     SceneView sv_res;
     if (RESW) {   // the resident stage: every thread of the block copies, ONE barrier, then the waves go their own ways
         const BlobHeader *gh = (const BlobHeader *) A0.scene;
@@ -363,11 +386,12 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     if (RESW) {
         uint32_t taken = 0;
         if (lane_id == 0) taken = atomicAdd(A0.q.seg_counter, 1u);
-        seg = (uint32_t) __builtin_amdgcn_readfirstlane((int) taken);
-        if (seg >= A0.n_seg) break;
-        // the segments are handed out from the LAST pixel rows to the first: a launch ends with a tail in which the waves run out of segments one after the other, and the
-        // tail is as long as the last segments are expensive -- the top rows of a frame tend to see sky (Domino C4: 34.05 -> 33.77 ms, profiles/r04_domino_waves_batch.txt)
-        seg = A0.n_seg - 1u - seg;
+        uint32_t unit = (uint32_t) __builtin_amdgcn_readfirstlane((int) taken);
+        if (unit >= A0.n_seg * sub) break;
+        // the units are handed out from the LAST pixel rows to the first: a launch ends with a tail in which the waves run out of work one after the other, and the
+        // tail is as long as the last units are expensive -- the top rows of a frame tend to see sky (Domino C4: 34.05 -> 33.77 ms, profiles/r04_domino_waves_batch.txt)
+        unit = A0.n_seg * sub - 1u - unit;
+        seg = sub > 1 ? unit / sub : unit; sub_index = sub > 1 ? unit - seg * sub : 0u;
     } else {
         seg = sub > 1 ? blockIdx.x / sub : blockIdx.x; sub_index = sub > 1 ? blockIdx.x - seg * sub : 0u;
     }
@@ -380,7 +404,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     SceneView sv = RESW ? sv_res : make_view(base);
     if (FUSED) { sv.memo_obj = A0.rp.memo_obj; sv.memo = (float *) (lds + stage_words) + (RESW ? wave_id * kMemoWords * kMemoStride + lane_id : threadIdx.x); sv.memo_m = memo_m_lds; }
     const bool have_memo = FUSED && sv.memo_obj != 0xffffffffu;
-    for (uint32_t cbase = sub > 1 ? sub_index * kShadeBlock : 0u; cbase < (sub > 1 ? (sub_index + 1) * kShadeBlock < count ? (sub_index + 1) * kShadeBlock : count : count); cbase += kShadeBlock) {
+    for (uint32_t cbase = sub > 1 ? sub_index * unit_lanes : 0u; cbase < (sub > 1 ? (sub_index + 1) * unit_lanes < count ? (sub_index + 1) * unit_lanes : count : count); cbase += kShadeBlock) {
     uint32_t rebase = 0;
     asm volatile("" : "+s"(rebase));
     const ShadeArgs &A = *(const ShadeArgs *) (kernarg + rebase);
@@ -394,17 +418,62 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     // every register of the path state starts defined: a build of these kernels whose K = 4 every-BSDF instantiations ran at three waves per SIMD produced films that
     // depended on the initial value of `main` / `path` below (wrong with the registers' garbage, NaN with -ftrivial-auto-var-init=pattern, right with =zero;
     // profiles/r03_k4_uninitialised.txt) although no source path reads them before they are assigned
-    float4 sha = make_float4(0.f, 0.f, 0.f, 0.f), shb = sha, nra = sha, nrb = sha; float3 cand[KMAX];
+    float4 sha = make_float4(0.f, 0.f, 0.f, 0.f), shb = sha, nra = sha, nrb = sha; float3 cand[KREG];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) cand[k] = make_float3(0.f, 0.f, 0.f);
-    float3 rbase[KMAX];   // FIRST: the result a lane ends this launch with if its NEE candidate is not committed
+    for (int k = 0; k < KREG; ++k) cand[k] = make_float3(0.f, 0.f, 0.f);
+    float3 rbase[KREG];   // FIRST: the result a lane ends this launch with if its NEE candidate is not committed
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) rbase[k] = make_float3(0.f, 0.f, 0.f);
+    for (int k = 0; k < KREG; ++k) rbase[k] = make_float3(0.f, 0.f, 0.f);
+    // RES_MEM: the pending emitter sample without its modulation weights -- throughput before the bounce, bsdf_val * em_weight * mis_em, path length to the emitter --
+    // and whether q.res holds the lane's running result yet (it is 0 until something was added: the first write needs no read, a path that adds nothing writes zeros at the end)
+    V3 pend_thr = mk(0, 0, 0), pend_v = mk(0, 0, 0); float pend_len = 0.f; bool res_live = false;
+    // the lane's running result of film k: a register (FIRST), its q.res record (the bounce kernels; RES_MEM once res_live -- before that it is 0 and nothing is read)
+    float *const park = RES_LDS || PARK ? (float *) (lds + stage_words) + memo_words + A0.res_park_off + threadIdx.x : nullptr;   // word f of this thread at park[f * kStackStride]
+    float res_last = 0.f;   // RES_LDS: the one float of the K results that has no LDS word (film KMAX - 1, blue)
+    if (RES_LDS) {
+#pragma unroll
+        for (uint32_t f = 0; f < kParkWords; ++f) park[f * kStackStride] = 0.f;
+    }
+    auto res_get = [&](int k) -> float4 {
+        if (RES_LDS) return make_float4(park[(3 * k) * kStackStride], park[(3 * k + 1) * kStackStride], 3 * k + 2 < (int) kParkWords ? park[(3 * k + 2) * kStackStride] : res_last, 0.f);
+        if (RES_MEM) return res_live ? q.res[(size_t) k * q.capacity + l] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (FIRST) { const float3 r = rbase[RES_MEM ? 0 : k]; return make_float4(r.x, r.y, r.z, 0.f); }
+        return q.res[(size_t) k * q.capacity + l];
+    };
+    auto res_put = [&](int k, float4 v) {
+        if (RES_LDS) {
+            park[(3 * k) * kStackStride] = v.x; park[(3 * k + 1) * kStackStride] = v.y;
+            if (3 * k + 2 < (int) kParkWords) park[(3 * k + 2) * kStackStride] = v.z; else res_last = v.z;
+        }
+        else if (FIRST && !RES_MEM) rbase[RES_MEM ? 0 : k] = make_float3(v.x, v.y, v.z);
+        else q.res[(size_t) k * q.capacity + l] = v;
+    };
+    // "the lane's results are zero again" (a path of null interactions that ends invalid): RES_LDS rewrites its columns, the q.res form only drops its flag
+    auto res_clear = [&]() {
+        if (RES_LDS) {
+#pragma unroll
+            for (uint32_t f = 0; f < kParkWords; ++f) park[f * kStackStride] = 0.f;
+            res_last = 0.f;
+        }
+        res_live = false;
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // Path state of the lane.  MODE 2 runs rp.inline_iters iterations of the bounce loop right here ("megakernel" head): between them the
     // state stays in these registers instead of making the round trip through the queues in HBM; after the last one the survivors are
     // written out and compacted exactly as before, for the bounce kernels (MODE 1) to continue with.
     uint32_t hid = 0xffffffffu; float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 1.f, 0.f), st = ra; uint4 hh = make_uint4(0u, 0u, 0u, 0u); Rng main = { 0ull, 1ull }, path = { 0ull, 1ull };
     float4 stb_reg = make_float4(0.f, 0.f, 0.f, 1.f); float2 stc_reg = make_float2(1.f, 1.f);   // prev_si.p | prev_bsdf_pdf, eta | prev_bsdf_delta
+    uint32_t *const parku = (uint32_t *) park;
+    auto park_store = [&]() {   // PARK: both streams (state + 32-bit selector: inc = sel << 1 | 1) and throughput / path length leave the registers
+        parku[0] = (uint32_t) main.state; parku[kStackStride] = (uint32_t) (main.state >> 32); parku[2 * kStackStride] = (uint32_t) (main.inc >> 1);
+        parku[3 * kStackStride] = (uint32_t) path.state; parku[4 * kStackStride] = (uint32_t) (path.state >> 32); parku[5 * kStackStride] = (uint32_t) (path.inc >> 1);
+        park[6 * kStackStride] = st.x; park[7 * kStackStride] = st.y; park[8 * kStackStride] = st.z; park[9 * kStackStride] = st.w;
+    };
+    auto park_load = [&]() {
+        main.state = (uint64_t) parku[0] | ((uint64_t) parku[kStackStride] << 32); main.inc = ((uint64_t) parku[2 * kStackStride] << 1) | 1u;
+        path.state = (uint64_t) parku[3 * kStackStride] | ((uint64_t) parku[4 * kStackStride] << 32); path.inc = ((uint64_t) parku[5 * kStackStride] << 1) | 1u;
+        st = make_float4(park[6 * kStackStride], park[7 * kStackStride], park[8 * kStackStride], park[9 * kStackStride]);
+    };
     // valid_ray (dopplertofpath.cpp:101-102,252-253,279-282): starts as "the environment is visible", becomes true at the first vertex whose sampled lobe is not
     // BSDFFlags::Null (a `mask` that lets the path through, the transmission of a `thindielectric`); a path that ends without it returns 0 (and alpha 0).  Only the
     // every-BSDF kernels (SPEC) can sample a null lobe: elsewhere a lane is valid as soon as its primary ray hits something.  FIRST: this register; the bounce
@@ -413,6 +482,13 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     bool valid_reg = valid_start;
     float memo_m[12], memo_inv[12];   // instance memo: the one instance's matrix and inverse at this lane's ray time
     bool lane_on = in_range;
+#ifdef DTOF_TRAVERSAL_STATS   // development builds: lanes without a path carry a poison pattern; DTOF_POISON_CHECK counts it wherever path state is written out (statistic [14])
+    constexpr uint64_t kPoisonState = 0xdeadbeefcafef00dull;
+    if (!in_range) { main.state = path.state = kPoisonState; const float pz = u2f(0x7fc0dead); ra = rb = st = make_float4(pz, pz, pz, pz); }
+#define DTOF_POISON_CHECK() do { if (main.state == kPoisonState || path.state == kPoisonState || f2u(st.x) == 0x7fc0deadu || f2u(ra.x) == 0x7fc0deadu) DTOF_STAT(14); } while (0)
+#else
+#define DTOF_POISON_CHECK() ((void) 0)
+#endif
     // the wave's 64 lanes are the 64-aligned lanes [lane_base + seg * 512 + cbase, + 64): samples of one pixel if spp is a multiple of 64
     // ... AND the whole wave is in range: the pair swap of the correlated seeding (generate_lane) reads the partner lane, which a ragged tail
     // (dtof_sample_lanes with an odd count) would leave inactive
@@ -426,6 +502,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
         if (FIRST) {
             const PrimaryLane pl = generate_lane<SPEC == 0>(rp, global_lane(rp, rp.lane_base + l), wave_pixel, rp.lane_base + l);
             ra = pl.ray_a; rb = pl.ray_b; main = pl.main; path = pl.path; st = make_float4(1.f, 1.f, 1.f, 0.f);
+            if (PARK) park_store();
             pos_reg = pl.pos;
             if (!fuse_splat) {   // what the later launches (stream selectors) and the splat kernels (sample position) read
                 q.pos[l] = pl.pos;
@@ -450,6 +527,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     const uint32_t trace_next = last ? trace_next_last : 1u;
     alive = false; want_shadow = false;
     if (lane_on) {
+        if (PARK) park_load();
         if (!FIRST) {
             hid = q.hit_id[l];
             if (hid != 0xffffffffu) {
@@ -476,9 +554,10 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
         const bool valid_in = FIRST ? valid_reg : (SPEC ? (depth > 0 ? q.st_c[l].y >= 2.f : valid_start) : depth > 0);
         if (hid == 0xffffffffu) {   // the path ends here: nothing validates it any more
             if (SPEC && !valid_in && depth > 0) {   // select(valid_ray, result, 0) (:279-282): what the path gathered behind null interactions does not count
+                if (RES_MEM) res_clear();
+                else {
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
-                    if (FIRST) rbase[k] = make_float3(0.f, 0.f, 0.f); else q.res[(size_t) k * q.capacity + l] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) res_put(k, zero4);
                 }
             }
             if (rp.want_valid) q.valid_out[l] = make_float4(valid_in ? 1.f : 0.f, 0.f, 0.f, 0.f);
@@ -502,10 +581,10 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
                 V3 v = le * mis_bsdf;
                 if (rp.integrator == 0) v = v * modulation_weight(rp, rp.phase[k], time_, stv.w);
-                const float4 r = FIRST ? make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f) : q.res[(size_t) k * q.capacity + l];
-                const float4 acc = make_float4(fmaf(stv.x, v.x, r.x), fmaf(stv.y, v.y, r.y), fmaf(stv.z, v.z, r.z), 0.f);
-                if (FIRST) rbase[k] = make_float3(acc.x, acc.y, acc.z); else q.res[(size_t) k * q.capacity + l] = acc;
+                const float4 r = res_get(k);
+                res_put(k, make_float4(fmaf(stv.x, v.x, r.x), fmaf(stv.y, v.y, r.y), fmaf(stv.z, v.z, r.z), 0.f));
             }
+            if (RES_MEM) res_live = true;
         }
         if (hid != 0xffffffffu) {   // a miss ends the path (active_next = false, dopplertofpath.cpp:171)
             V3 o = mk(ra.x, ra.y, ra.z), d = mk(rb.x, rb.y, rb.z); float time = ra.w;
@@ -530,10 +609,12 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             const float pmf = sv.n_emitters ? 1.f / (float) sv.n_emitters : 0.f;   // m_emitter_pmf (scene.cpp:96)
             // ---- direct emission (dopplertofpath.cpp:150-168 / path.cpp): the hit shape carries an area emitter
             bool res_dirty = false;
-            float4 rcur[KMAX];
+            float4 rcur[KREG];   // (RES_MEM: the emitter-hit term goes straight to q.res)
             if (AREA) {
+                if (!RES_MEM) {
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) rcur[k] = FIRST ? make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f) : q.res[(size_t) k * q.capacity + l];
+                    for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) rcur[RES_MEM ? 0 : k] = res_get(k);
+                }
                 if (sh->flags & SF_EMITTER) {
                     float4 pb = depth > 0 ? (FIRST ? stb_reg : q.st_b[l]) : make_float4(0.f, 0.f, 0.f, 1.f);   // prev_si.p, prev_bsdf_pdf
                     V3 rel = si.p - mk(pb.x, pb.y, pb.z);                      // DirectionSample(scene, si, prev_si), records.h:173-180
@@ -562,9 +643,11 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                     for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
                         V3 v = le * mis_bsdf;
                         if (!plain) v = v * modulation_weight(rp, rp.phase[k], time, path_length);
-                        rcur[k] = make_float4(fmaf(thr.x, v.x, rcur[k].x), fmaf(thr.y, v.y, rcur[k].y), fmaf(thr.z, v.z, rcur[k].z), 0.f);
+                        const float4 r = RES_MEM ? res_get(k) : rcur[RES_MEM ? 0 : k];
+                        const float4 acc = make_float4(fmaf(thr.x, v.x, r.x), fmaf(thr.y, v.y, r.y), fmaf(thr.z, v.z, r.z), 0.f);
+                        if (RES_MEM) res_put(k, acc); else rcur[RES_MEM ? 0 : k] = acc;
                     }
-                    res_dirty = true;
+                    if (RES_MEM) res_live = true; else res_dirty = true;
                 }
             }
 
@@ -694,23 +777,28 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             if (active_em) {
                 const float mis_em = ds_delta ? 1.f : mis_weight(ds_pdf, bsdf_pdf);   // dopplertofpath.cpp:218-219
                 bool nonzero = false;
+                if (RES_MEM) {   // the sample waits for its visibility test WITHOUT the K modulation weights; they are applied at the commit (below), in the order of the loop that follows
+                    pend_thr = thr; pend_len = path_length + ds_dist;
+                    pend_v = mk(bsdf_val.x * em_weight.x * mis_em, bsdf_val.y * em_weight.y * mis_em, bsdf_val.z * em_weight.z * mis_em);
+                    // a sample whose three products are zero adds exactly zero to every film whatever its weights: no visibility test (the register form compares the
+                    // candidate with the current result, which also catches a zero weight and a term below the result's last bit -- a few more shadow rays here, same films)
+                    nonzero = (int) (pend_thr.x * pend_v.x != 0.f) | (int) (pend_thr.y * pend_v.y != 0.f) | (int) (pend_thr.z * pend_v.z != 0.f);
+                } else {
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
-                    float4 r = AREA ? rcur[k] : (FIRST ? make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f) : q.res[(size_t) k * q.capacity + l]);
+                    float4 r = AREA ? rcur[RES_MEM ? 0 : k] : res_get(k);
                     V3 v = mk(bsdf_val.x * em_weight.x * mis_em, bsdf_val.y * em_weight.y * mis_em, bsdf_val.z * em_weight.z * mis_em);
                     if (!plain) { float lw = modulation_weight(rp, rp.phase[k], time, path_length + ds_dist); v = v * lw; }
                     float3 c = make_float3(fmaf(thr.x, v.x, r.x), fmaf(thr.y, v.y, r.y), fmaf(thr.z, v.z, r.z));
-                    cand[k] = c;
+                    cand[RES_MEM ? 0 : k] = c;
                     nonzero |= f2u(c.x) != f2u(r.x) || f2u(c.y) != f2u(r.y) || f2u(c.z) != f2u(r.z);
+                }
                 }
                 want_shadow = nonzero;   // a candidate identical to the current result needs no visibility test
             }
             if (res_dirty) {   // the emitter-hit term stands whether or not the NEE candidate is later committed
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
-                    if (FIRST) rbase[k] = make_float3(rcur[k].x, rcur[k].y, rcur[k].z);
-                    else q.res[(size_t) k * q.capacity + l] = rcur[k];
-                }
+                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) res_put(k, rcur[RES_MEM ? 0 : k]);
             }
             // ---- continuation (dopplertofpath.cpp:232-276)
             V3 nd = vfma(si.sh_n, bs_wo.z, vfma(si.sh_t, bs_wo.y, si.sh_s * bs_wo.x));   // Frame::to_world
@@ -731,9 +819,10 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             const bool ends = !alive || (last && !trace_next);   // nobody continues this path: what it returns is decided here
             if (SPEC && ends && !valid_now) {   // select(valid_ray, result, 0) (:279-282): neither the emitter-hit term nor this vertex's NEE candidate survives
                 want_shadow = false;
+                if (RES_MEM) res_clear();
+                else {
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
-                    if (FIRST) rbase[k] = make_float3(0.f, 0.f, 0.f); else q.res[(size_t) k * q.capacity + l] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) res_put(k, zero4);
                 }
             }
             if (ends && rp.want_valid) q.valid_out[l] = make_float4(valid_now ? 1.f : 0.f, 0.f, 0.f, 0.f);
@@ -750,6 +839,8 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                     if (SPEC) q.st_c[l] = make_float2(stc.x, stc.y + (valid_now ? 2.f : 0.f));   // eta, prev_bsdf_delta (:252,258) | valid_ray << 1
                 }
                 if (FIRST) { st = sta; stb_reg = stb; stc_reg = stc; }
+                if (PARK) park_store();
+                DTOF_POISON_CHECK();   // the state of a path that continues
             }
             if ((alive && (!FIRST || last) && trace_next) || rp.n_passes > 1)   // several passes: the state of a finished path is what its lane starts the next pass with
                 q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
@@ -764,6 +855,10 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     }
     if (FUSED) {
         bool commit = false;
+        const bool has_next = alive && trace_next;   // the continuation ray is traced here: its closest hit is what the next bounce starts from
+        bool found_next = false; Hit h_next;
+        // (Both rays in ONE traversal loop -- a lane going on with its continuation ray while its neighbours are still in their shadow rays -- was built and measured in
+        // round 5 and lost by a third: tools/experiments/r05_pair_traversal.patch, profiles/r05_pair_traversal.txt.)
         if (want_shadow) {   // test_visibility (scene.cpp:266-271): an unoccluded sample commits its candidate result
             Hit hs;
 #if defined(DTOF_ABLATE) && (DTOF_ABLATE & 1)
@@ -773,26 +868,48 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                           : !trace_scene<true, MESH, true, RESW != 0, kStackStride>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
 #endif
         }
-        if (FIRST) {   // the running result stays in rbase over the inline iterations; every lane's result is defined after the last (nothing zeroed it)
+        if (has_next) {
+#if defined(DTOF_ABLATE) && (DTOF_ABLATE & 2)
+            found_next = nra.x < 1e30f; h_next.t = 0.5f + 0.1f * nrb.x; h_next.u = nrb.y; h_next.v = nrb.z; h_next.obj = nrb.x > 0.3f ? 3 : nrb.y > 0.f ? 1 : 0; h_next.shape = 0; h_next.prim = 0;
+#else
+            found_next = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h_next)
+                              : trace_scene<false, MESH, true, RESW != 0, kStackStride>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h_next);
+#endif
+        }
+        if (RES_MEM) {   // the committed sample gets its K modulation weights now (dopplertofpath.cpp:221-226) and is added to the films' records in q.res
+            if (commit) {
+                const bool plain_ = rp.integrator != 0;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) if (k < rp.n_offsets) {
+                    V3 v = pend_v;
+                    if (!plain_) v = v * modulation_weight(rp, rp.phase[k], shb.w, pend_len);   // shb.w: the ray time (the shadow ray carries it)
+                    const float4 r = res_get(k);
+                    res_put(k, make_float4(fmaf(pend_thr.x, v.x, r.x), fmaf(pend_thr.y, v.y, r.y), fmaf(pend_thr.z, v.z, r.z), 0.f));
+                }
+                res_live = true;
+            }
+            if (RES_LDS) {   // the results leave the LDS columns for q.res (what the splat kernels read)
+                if (last && in_range) {
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) if (k < rp.n_offsets) q.res[(size_t) k * q.capacity + l] = res_get(k);
+                }
+            } else if (last && in_range && !res_live) {   // nothing was ever added (or a path of null interactions was zeroed): the records still hold an earlier batch's values
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) if (k < rp.n_offsets) res_put(k, zero4);
+            }
+        } else if (FIRST) {   // the running result stays in rbase over the inline iterations; every lane's result is defined after the last (nothing zeroed it)
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) {
-                if (commit) rbase[k] = cand[k];
-                if (last && in_range && !fuse_splat) q.res[(size_t) k * q.capacity + l] = make_float4(rbase[k].x, rbase[k].y, rbase[k].z, 0.f);
+                if (commit) rbase[RES_MEM ? 0 : k] = cand[RES_MEM ? 0 : k];
+                if (last && in_range && !fuse_splat) q.res[(size_t) k * q.capacity + l] = make_float4(rbase[RES_MEM ? 0 : k].x, rbase[RES_MEM ? 0 : k].y, rbase[RES_MEM ? 0 : k].z, 0.f);
             }
         } else if (commit) {
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) q.res[(size_t) k * q.capacity + l] = make_float4(cand[k].x, cand[k].y, cand[k].z, 0.f);
+            for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) q.res[(size_t) k * q.capacity + l] = make_float4(cand[RES_MEM ? 0 : k].x, cand[RES_MEM ? 0 : k].y, cand[RES_MEM ? 0 : k].z, 0.f);
         }
-        if (alive && trace_next) {   // closest hit of the continuation ray, consumed by the next bounce
-            Hit h;
-#if defined(DTOF_ABLATE) && (DTOF_ABLATE & 2)
-            bool found = nra.x < 1e30f; h.t = 0.5f + 0.1f * nrb.x; h.u = nrb.y; h.v = nrb.z; h.obj = nrb.x > 0.3f ? 3 : nrb.y > 0.f ? 1 : 0; h.shape = 0; h.prim = 0;
-#else
-            bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h)
-                              : trace_scene<false, MESH, true, RESW != 0, kStackStride>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
-#endif
-            if (!FIRST || last) store_hit<MESH>(q, l, h, found);
-            if (FIRST) { hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim); hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu; }
+        if (has_next) {   // closest hit of the continuation ray, consumed by the next bounce
+            if (!FIRST || last) store_hit<MESH>(q, l, h_next, found_next);
+            if (FIRST) { hh = make_uint4(f2u(h_next.t), f2u(h_next.u), f2u(h_next.v), h_next.prim); hid = found_next ? (h_next.obj | (h_next.shape << q.id_shift)) : 0xffffffffu; }
         }
         const uint32_t n_sh = (uint32_t) __popcll(__ballot(want_shadow)) * ((threadIdx.x & 63) == 0 ? 1u : 0u);   // per-wave partial (stats only)
         if (last) n_shadow += n_sh; else if (lane_id == 0) s_inline[2 * it + 1] += n_sh;
@@ -802,16 +919,16 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             q.sh_a[sslot] = sha; q.sh_b[sslot] = shb;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets)
-                q.sh_c[(size_t) k * q.capacity + sslot] = make_float4(cand[k].x, cand[k].y, cand[k].z, u2f(l));
+                q.sh_c[(size_t) k * q.capacity + sslot] = make_float4(cand[RES_MEM ? 0 : k].x, cand[RES_MEM ? 0 : k].y, cand[RES_MEM ? 0 : k].z, u2f(l));
         }
     }
     if (last) break;
     // next inline iteration: the continuation ray and its closest hit become the lane's current ray (st / stb / stc were set where the
     // bounce computed them); a lane whose path ended sits out the remaining iterations
     lane_on = alive;
-    if (alive) { ra = nra; rb = nrb; }
+    if (alive) { ra = nra; rb = nrb; DTOF_POISON_CHECK(); }
     }   // inline iterations
-    if (FIRST && fuse_splat) {   // ---- ImageBlock::put (imageblock.cpp:414-531) of the wave's samples: tent filter of radius <= 1, a 3 x 3 footprint anchored at the sample's pixel
+    if constexpr (!RES_MEM) if (FIRST && fuse_splat) {   // ---- ImageBlock::put (imageblock.cpp:414-531) of the wave's samples: tent filter of radius <= 1, a 3 x 3 footprint anchored at the sample's pixel
         const uint32_t W = (uint32_t) rp.crop_w;
         const uint32_t pix = fdiv(global_lane(rp, rp.lane_base + l), rp.d_spp);
         const int py = (int) fdiv(pix, rp.d_w), px = (int) (pix - W * (uint32_t) py);
@@ -869,6 +986,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     }
     if (!RESW) break;
     }   // segments of a resident wave
+#undef DTOF_POISON_CHECK
 }
 
 // ---------------------------------------------------------------------------- launch templates (one group of instantiations per dtof_shade_*.hip)

@@ -58,6 +58,9 @@ struct Hit { float t, u, v; uint32_t obj, shape, prim; };
 // [0] rays  [1] node steps (lane)  [2] node iterations (wave)  [3] leaf visits (lane)  [4] leaf rounds (wave)  [5] mesh loops entered (lane)
 // [6] triangle tests (lane)  [7] BLAS node steps (lane)  [8] instance transforms (lane)  [9] instance transforms (wave)  [10] mesh loops entered (wave)
 // [11] triangle tests (wave)  [12] rectangle tests (lane)  [13] rectangle tests (wave)
+// [14] POISON HITS: in these builds k_shade gives the path state of every lane that has no path (beyond the end of its segment) a recognisable pattern (kPoisonState) and
+//      counts it wherever path state leaves the registers -- queue stores, the LDS columns, the inline iterations' hand-over.  Must stay 0: the K = 4 incident of round 3
+//      (profiles/r03_k4_uninitialised.txt, profiles/r05_k4_root_cause.txt) was a film that depended on the INITIAL value of those registers.
 #ifdef DTOF_TRAVERSAL_STATS
 // every translation unit with kernels counts into its own copy (no relocatable device code); each registers a reader, read_traversal_stats sums and resets them all
 static __device__ unsigned long long g_trav_stats[16];

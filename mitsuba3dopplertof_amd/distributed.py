@@ -111,6 +111,20 @@ def stripe_rows_of(height, world, rank, stripe_rows):
     return [y for y in range(first, height) if (y - first) % period < rows]
 
 
+def reduce_film(film, rank, world, group=None):
+    """The one collective of a striped frame: reduce(sum) of the ranks' full-size films -- [planes, H, W, 4]: K offset films, + the alpha film of an rgba scene -- to rank 0
+    (RCCL over xGMI; gloo test set-ups stage device tensors through host memory).  Returns the summed film on rank 0; the other ranks' buffers are scratch afterwards."""
+    import torch.distributed as dist
+    if world == 1:
+        return film
+    if film.is_cuda and dist.get_backend(group) == "gloo":
+        host = film.cpu()
+        dist.reduce(host, dst=0, op=dist.ReduceOp.SUM, group=group)
+        return host.to(film.device) if rank == 0 else None
+    dist.reduce(film, dst=0, op=dist.ReduceOp.SUM, group=group)
+    return film if rank == 0 else None
+
+
 def render_striped(scene, seed=0, spp=0, stripe_rows=16, group=None):
     """One frame across the ranks with INTERLEAVED stripes of pixel rows ("interleaved row bands ... if Domino is spatially
     unbalanced"): rows that see only sky cost a tenth of rows full of dominoes, so contiguous bands leave ranks idle (measured on
@@ -129,13 +143,7 @@ def render_striped(scene, seed=0, spp=0, stripe_rows=16, group=None):
     torch.cuda.synchronize()
     first, rows, period = stripe_layout(world, rank, stripe_rows)
     scene.render_stripes(film.data_ptr(), seed, spp, first, rows, period)
-    if world > 1:
-        if dist.get_backend(group) == "gloo":      # test set-ups without RCCL: stage through host memory
-            host = film.cpu()
-            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM, group=group)
-            film = host.to(dev)
-        else:
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM, group=group)
+    film = reduce_film(film, rank, world, group)
     if rank != 0:
         return None
     return _develop(film, planes, H, W, dev)

@@ -1495,6 +1495,8 @@ def integrator_params(ip, sp):
     if rr_depth <= 0:
         raise ValueError('"rr_depth" must be set to a value greater than zero!')
     tcn = sp.get_i("time_correlate_number", 2) if sp.plugin == "correlated" else 2
+    if ip.plugin == "dopplertofpath" and sp.plugin == "correlated" and tsm == "antithetic_mirror" and tcn != 2:
+        raise ValueError("antithetic_mirror time sampling needs time_correlate_number == 2")   # Assert(m_time_correlate_number == 2), correlated.cpp:142
     return dict(
         time=T, w_g_mhz=w_g, g_1=g_1, g_0=g_0, w_s_mhz=w_s, phase_offset=phase, hetero_frequency=hf,
         wave_type=WAVE[wave], low_frequency_component_only=int(ip.get_b("low_frequency_component_only", True)),

@@ -58,6 +58,77 @@ def _worker(rank, world, port, q, gaussian=False):
     dist.destroy_process_group()
 
 
+def _worker8(rank, world, port, q, mode):
+    """world-8 rehearsal of both exchanges before the first 8-GPU run: a frame whose height divides by neither the world size nor world x stripe rows.
+    bands  : default gaussian filter (halo 2), bands of ceil(27 / 8) = 4 rows -- the last rank's band is EMPTY, the one before it is short; one gather, overlap-add.
+    stripes: K = 4 hetero_offset films, interleaved 2-row stripes (period 16; 27 rows = one full period + 11), one reduce(sum) of the [4, H, W, 4] films."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from mitsuba3dopplertof_amd import distributed as D
+    from oracle import orc
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    H, W, spp = 27, 12, 2
+    text = open(os.path.join(SCENES, "cornell_wall.xml")).read()
+    if mode == "bands":
+        text = text.replace('<rfilter type="tent" />', "")
+    sc = orc.Scene(text, dict(resx=W, resy=H), is_string=True)
+    assert sc.size == (W, H)
+    if mode == "bands":
+        pd, halo = sc.params(), 2
+        r0, r1 = D.row_band(H, world, rank)
+        assert (r1 - r0) == (4 if rank < 6 else 3 if rank == 6 else 0)
+        padded = np.zeros((D.padded_rows(H, world, halo), W, 4), np.float32)
+        if r1 > r0:
+            padded[halo:halo + H] = sc.render(pd, seed=5, spp=spp, rows=(r0, r1), raw=True)[0]
+        p0, p1 = D.slab_range(H, world, rank, halo)
+        assert np.count_nonzero(padded[:p0]) == 0 and np.count_nonzero(padded[p1:]) == 0
+        stack = D.gather_film_stacked(torch.from_numpy(np.ascontiguousarray(padded[p0:p1])), rank, world)
+        if rank == 0:
+            full = D.overlap_add_stacked(stack, H, world, halo).numpy()
+            assert np.array_equal(full, D.overlap_add([stack[r] for r in range(world)], H, world, halo, xp=torch).numpy())
+            ref = sc.render(pd, seed=5, spp=spp, raw=True)[0]
+            q.put(float(np.abs(full - ref).max() / np.abs(ref).max()))
+    else:
+        offsets, stripe = [0.0, 0.25, 0.5, 0.75], 2
+        rows = D.stripe_rows_of(H, world, rank, stripe)
+        assert rows == [y for y in range(H) if (y // stripe) % world == rank]
+        film = np.zeros((len(offsets), H, W, 4), np.float32)
+        pds = [sc.params(integrator=dict(type="dopplertofpath", max_depth=4, path_correlation_depth=4, hetero_frequency=1.0, hetero_offset=o, time_sampling_method="stratified")) for o in offsets]
+        for k, pd in enumerate(pds):
+            for y in rows:                                        # the oracle renders a row range; a rank's stripes are the sum of its rows' films
+                film[k] += sc.render(pd, seed=5, spp=spp, rows=(y, y + 1), raw=True)[0]
+        total = D.reduce_film(torch.from_numpy(film), rank, world)
+        if rank == 0:
+            ref = np.stack([sc.render(pd, seed=5, spp=spp, raw=True)[0] for pd in pds])
+            assert np.abs(ref[0] - ref[2]).max() > 1e-3 * np.abs(ref).max()      # the four films differ (offset 0 vs 0.5 flips the sign)
+            q.put(float(np.abs(total.numpy() - ref).max() / np.abs(ref).max()))
+        else:
+            assert total is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["bands", "stripes"], ids=["bands_gather_halo2_empty_last_band", "stripes_reduce_four_films"])
+def test_eight_rank_gloo_exchanges_reproduce_the_single_rank_films(mode):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q, mode)) for r in range(8)]
+    for p in procs:
+        p.start()
+    try:
+        err = q.get(timeout=400)
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert err < 1e-6
+
+
 def test_stripe_bookkeeping():
     """interleaved shards: the stripes of all ranks partition the rows, whatever the frame height"""
     from mitsuba3dopplertof_amd import distributed as D

@@ -925,7 +925,7 @@ def test_statistics_of_a_multi_batch_render_equal_the_single_batch_ones(mi, tmp_
 
 def _random_config(rng):
     waves = ["sinusoidal", "rectangular", "triangular", "trapezoidal"]
-    tsm = ["uniform", "stratified", "antithetic", "antithetic_mirror"]
+    tsm = ["uniform", "stratified", "antithetic", "antithetic_mirror", "periodic", "regular"]   # the last two: sampler.h:27-34, correlated.cpp:147-152
     tcn = int(rng.choice([1, 2, 4]))
     spp = int(tcn * rng.choice([1, 2, 3, 4, 8]))
     integ = dict(type="dopplertofpath", max_depth=int(rng.choice([-1, 1, 2, 3, 5, 7])), rr_depth=int(rng.choice([1, 2, 5])),
@@ -953,10 +953,19 @@ def test_random_parameter_combinations_are_bit_exact(mi, orc, index):
     sc, osc = mi.load_file(path, **params), orc.Scene(path, params)
     sc.set_integrator(integ)
     sc.set_sampler(sampler)
-    pd = osc.params(integrator=integ, sampler=sampler)
     w, h = sc.size
     n = w * h * spp
     seed = int(rng.randint(0, 100))
+    if integ["time_sampling_method"] == "antithetic_mirror" and sampler["time_correlate_number"] != 2:
+        # Assert(m_time_correlate_number == 2) (correlated.cpp:142): the mirror strategy pairs the samples 2k, 2k + 1 and nothing else -- refused by product and oracle alike
+        with pytest.raises(mi.DtofError, match="time_correlate_number == 2"):
+            sc.sample_lanes(seed, spp, 0, n)
+        with pytest.raises(mi.DtofError, match="time_correlate_number == 2"):
+            sc.render(seed=seed, spp=spp)
+        with pytest.raises(ValueError, match="time_correlate_number == 2"):
+            osc.params(integrator=integ, sampler=sampler)
+        return
+    pd = osc.params(integrator=integ, sampler=sampler)
     g = sc.sample_lanes(seed, spp, 0, n)
     o = osc.render_lanes(pd, seed, spp, 0, n, threads=NCPU)
     for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
@@ -985,7 +994,7 @@ def _random_scene(rng, mesh_dir=None):
     if rng.random() < 0.8:
         integ = ('<integrator type="dopplertofpath"><integer name="max_depth" value="%d"/><integer name="path_correlation_depth" value="%d"/><string name="time_sampling_method" value="%s"/>'
                  '<string name="wave_function_type" value="%s"/><float name="hetero_frequency" value="%s"/><integer name="rr_depth" value="%d"/></integrator>'
-                 % (rng.integers(1, 8), rng.integers(0, 4), rng.choice(["uniform", "stratified", "antithetic", "antithetic_mirror"]),
+                 % (rng.integers(1, 8), rng.integers(0, 4), rng.choice(["uniform", "stratified", "antithetic", "antithetic_mirror", "periodic", "regular"]),
                     rng.choice(["sinusoidal", "rectangular", "triangular", "trapezoidal"]), rng.choice(["0.0", "1.0", "0.37"]), rng.integers(2, 6)))
     else:
         integ = '<integrator type="path"><integer name="max_depth" value="%d"/></integrator>' % rng.integers(1, 7)

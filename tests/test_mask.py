@@ -219,7 +219,7 @@ def test_rgba_scene_through_every_device_film_caller(mi, orc, tmp_path):
     img = D._develop(two, 2, H, W, two.device)
     assert np.abs(img - ref).max() <= 1e-5 * np.abs(ref).max()
     sc.set_film_layout(2)
-    with pytest.raises(mi.DtofError, match="declared with 2 planes"):          # four offsets + alpha = 5 planes
+    with pytest.raises(mi.DtofError, match="needs 5 RGBW planes"):             # four offsets + alpha = 5 planes
         sc.render_rows(two.data_ptr(), 3, 16, 0, H, offsets=[0.0, 0.25, 0.5, 0.75])
     for img in (D.render_sharded(sc, seed=3, spp=16), D.render_striped(sc, seed=3, spp=16, stripe_rows=3)):
         assert img.shape == (H, W, 4) and np.abs(img - ref).max() <= 1e-5 * np.abs(ref).max()
