@@ -40,6 +40,7 @@ struct RenderParams {
     int32_t sampler_kind, jitter; float inv_spp;  // SamplerKind; timestratified: jitter, 1 / sample_count (timestratified.cpp:78-82)
     int32_t has_spec;                             // scene has delta BSDFs (conductor / dielectric): eta and prev_bsdf_delta become per-lane state; 2: ... and blendbsdf
     int32_t has_tris;                             // scene has triangle meshes (selects the kernel instantiations that carry mesh code)
+    int32_t has_analytic;                         // the scene has spheres / disks / cylinders (the eight-wave ray kernels carry triangle and rectangle code only)
     int32_t has_blas;                             // some mesh is traversed through its own BLAS: the unstaged k_trace / k_shadow run one wave per block
     int32_t integrator;                           // 0 dopplertofpath, 1 path (src/integrators/path.cpp), 2 velocity (velocity.cpp)
     // ---- batch
@@ -88,6 +89,7 @@ struct Queues {
     uint32_t *counts;    // [iteration][2][n_segments]: survivors / shadow rays per segment
     uint32_t *seg_counter;   // resident first-bounce kernel: next segment to hand out (zeroed before the launch)
     uint32_t capacity;
+    uint32_t xcd_remap;  // unstaged ray kernels: XCD-aware block order (dtof_kernels.hip: xcd_remap); 0 = block b traces segment b
     uint32_t id_shift;   // bits of hit_id that hold the object index: 24 unless the scene needs more shapes per group than 8 bits hold (render_rows)
 };
 
@@ -113,7 +115,9 @@ constexpr uint32_t kParkWords = 11;
 #ifndef DTOF_PARK
 #define DTOF_PARK 1
 #endif
-constexpr uint32_t kParkState = 10;
+constexpr uint32_t kParkState = 10, kParkRng = 6;   // one film: both streams + throughput / path length; several films (behind the kParkWords film words): the streams only
+// the stack columns of the resident kernels of several films hold 16-bit entries (dtof_traverse.h: encode_child16), the one-film kernels' 32-bit ones
+static inline uint32_t resident_stack_bytes(uint32_t depth, uint32_t waves, bool several_films) { return (depth < 2 ? 2 : depth) * waves * 64u * (several_films ? 2u : 4u); }
 
 // One launch of k_shade as launch_shade hands it to the translation unit that holds the instantiation (dtof_shade_*.hip: the ~100 instantiations of the
 // kernel compile in parallel, one group per file): staged = the scene blob is copied to LDS by every block; mode 0 split, 1 fused, 2 fused first bounce;

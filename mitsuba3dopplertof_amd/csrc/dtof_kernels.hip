@@ -41,12 +41,32 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) 
 // BLOCK: 256 threads when the scene is staged into LDS (the staging is shared by four waves), ONE wave otherwise -- the waves of a
 // block share nothing then, and a block only frees its LDS and wave slots when its slowest wave is done, which costs occupancy
 // on divergent traversals (large scenes).
-template <bool LDS, bool MESH, int BLOCK>
-__global__ __launch_bounds__(BLOCK, BLOCK == 64 ? 6 : 1) void k_trace(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words,
+// W8: the ray kernels of scenes with LARGE triangle meshes and no analytic shapes (the mesh room: 522 k triangles behind two BLAS, bound by the latency of its L2 misses).
+// Eight waves per SIMD instead of six -- more misses in flight per CU -- need (a) at most 64 VGPRs: the instantiation carries triangle and rectangle code only (MESH = 2: no
+// float64 sphere / cylinder arithmetic), and (b) 32 one-wave blocks in a CU's LDS: the stack column holds kLdsStack8 entries, deeper ones overflow into a private array.
+constexpr uint32_t kLdsStack8 = 16, kOvfStack8 = 48;
+// XCD-aware block order of the unstaged ray kernels (guide: cdna_hip_programming.md T1).  Blocks are dealt round-robin over the 8 XCDs, each with an L2 of its own (4 MiB):
+// with block b tracing queue segment b, every XCD sees rays from all over the image and all eight L2s fight over the same 35 MB of nodes and triangle records.  The remap gives
+// the blocks that share an XCD a CONTIGUOUS run of segments (= a band of the image for the primary and shadow rays), so each L2 mostly holds the geometry of its band.
+// Which block traces which segment changes nothing in the results.  MEASURED on the mesh room (512 x 512 x 64 spp, 522 k triangles; profiles/r05_mesh_room.txt), run = blocks
+// an XCD gets in a row: off 6.90 G rays/s | 8 (one segment) 6.90 | 64 6.05 | 512 (ONE PIXEL ROW) 7.23 | 1 024 7.15 | 2 048 7.12 | 4 096 6.91 | a whole band per XCD 5.68 (the
+// bands cost different amounts: the XCDs finish one after the other).  Default: one pixel row per run for scenes with a BLAS (xcd_run below); DTOF_XCD_REMAP=<run> | 0 overrides.
+// `run` = consecutive segments one XCD gets before the next XCD's run starts (a whole-image band per XCD -- run = n / 8 -- LOST 18 % on the mesh room: the bands cost
+// different amounts and the XCDs finish one after the other); blocks beyond the last full group of 8 runs keep their index.
+DTOF_D uint32_t xcd_remap(uint32_t orig, uint32_t n, uint32_t run) {
+    const uint32_t group = 8u * run, full = n - n % group;
+    if (orig >= full) return orig;
+    const uint32_t g = orig / group, w = orig - g * group, xcd = w & 7u, k = w >> 3;   // within a group: block w runs on XCD w % 8 and is that XCD's k-th block
+    return g * group + xcd * run + k;
+}
+template <bool LDS, bool MESH, int BLOCK, bool W8 = false>
+__global__ __launch_bounds__(BLOCK, W8 ? 8 : BLOCK == 64 ? 6 : 1) void k_trace(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words,
                                                  Queues q, const uint32_t *qin, const uint32_t *count_in, uint32_t n_lanes) {
+    static_assert(!W8 || (!LDS && MESH && BLOCK == 64), "the eight-wave form exists for the unstaged one-wave kernels with triangle code");
     constexpr uint32_t kBlock = BLOCK, kSub = kSeg / BLOCK;
     extern __shared__ uint4 lds[];
-    uint32_t seg = blockIdx.x / kSub, sub = blockIdx.x % kSub;
+    const uint32_t bid = !LDS && q.xcd_remap ? xcd_remap(blockIdx.x, gridDim.x, q.xcd_remap) : blockIdx.x;
+    uint32_t seg = bid / kSub, sub = bid % kSub;
     uint32_t count = seg_count(count_in, seg, n_lanes);
     if (sub * kBlock >= count) return;
     const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
@@ -57,17 +77,19 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 64 ? 6 : 1) void k_trace(const uint
     uint32_t l = 0; float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 1.f, 0.f);
     if (active) { l = qin ? qin[seg * kSeg + j] : seg * kSeg + j; a = q.ray_a[l]; b = q.ray_b[l]; }
     Hit h;
-    bool found = trace_rays<false, MESH, false, false, BLOCK>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h);
+    uint32_t ovf[W8 ? kOvfStack8 : 1];
+    bool found = trace_rays<false, W8 ? 2 : (MESH ? 1 : 0), false, false, BLOCK, W8 ? kLdsStack8 : 0u>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h, ovf);
     if (active) store_hit<MESH>(q, l, h, found);
 }
 
 // ---------------------------------------------------------------------------- shadow
-template <bool LDS, bool MESH, int BLOCK>
-__global__ __launch_bounds__(BLOCK, BLOCK == 64 ? 6 : 1) void k_shadow(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp,
+template <bool LDS, bool MESH, int BLOCK, bool W8 = false>
+__global__ __launch_bounds__(BLOCK, W8 ? 8 : BLOCK == 64 ? 6 : 1) void k_shadow(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp,
                                                   Queues q, const uint32_t *count_in) {
     constexpr uint32_t kBlock = BLOCK, kSub = kSeg / BLOCK;
     extern __shared__ uint4 lds[];
-    uint32_t seg = blockIdx.x / kSub, sub = blockIdx.x % kSub;
+    const uint32_t bid = !LDS && q.xcd_remap ? xcd_remap(blockIdx.x, gridDim.x, q.xcd_remap) : blockIdx.x;
+    uint32_t seg = bid / kSub, sub = bid % kSub;
     uint32_t count = count_in[seg];
     if (sub * kBlock >= count) return;
     const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
@@ -79,7 +101,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 64 ? 6 : 1) void k_shadow(const uin
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 1.f, 0.f);
     if (active) { a = q.sh_a[i]; b = q.sh_b[i]; }
     Hit h;
-    bool occluded = trace_rays<true, MESH, false, false, BLOCK>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h);
+    uint32_t ovf[W8 ? kOvfStack8 : 1];
+    bool occluded = trace_rays<true, W8 ? 2 : (MESH ? 1 : 0), false, false, BLOCK, W8 ? kLdsStack8 : 0u>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h, ovf);
     if (active && !occluded) {
 #pragma unroll
         for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) {
@@ -436,12 +459,25 @@ constexpr uint32_t kLdsSceneLimit = 16 * 1024;
 // 522 k triangles: 20.1 -> 16.6 ms per frame).  Scenes of many small objects (Domino: 1 025 instances of a 12-triangle cube) are
 // faster with four waves sharing a CU's L1 on the same TLAS / object records (71.3 vs 75.3 ms).  DTOF_TRACE_BLOCK = 64 | 128 | 256
 // overrides (experiments).
+// the eight-waves-per-SIMD ray kernels (k_trace / k_shadow<false, true, 64, true>): one-wave blocks of an unstaged scene whose meshes sit behind a BLAS and that has no
+// analytic shape (their float64 code does not fit 64 VGPRs), stacks no deeper than the LDS part + the overflow array.  DTOF_TRACE8=0 keeps the six-wave kernels (A/B).
+static inline bool eight_wave_rays(const RenderParams &rp, uint32_t stage_words, uint32_t block, uint32_t stack_depth);
 static inline uint32_t unstaged_block(const RenderParams &rp) {
     static const uint32_t env = [] { const char *e = getenv("DTOF_TRACE_BLOCK"); int b = e ? atoi(e) : 0; return (uint32_t) (b == 64 || b == 128 || b == 256 ? b : 0); }();
     return env ? env : (rp.has_blas ? 64u : (uint32_t) kBlock);
 }
 
 
+static inline uint32_t xcd_run(const RenderParams &rp, uint32_t stage_words, uint32_t block) {
+    if (const char *e = getenv("DTOF_XCD_REMAP")) return (uint32_t) atoi(e);   // read per call: A/B runs
+    if (stage_words != 0 || !rp.has_blas) return 0;                              // scenes staged in LDS and scenes of small objects: L2 locality is not what they wait for
+    const uint64_t row_blocks = (uint64_t) rp.crop_w * rp.spp / block;
+    return (uint32_t) (row_blocks >= 8 && row_blocks <= (1u << 20) ? row_blocks : 0);
+}
+static inline bool eight_wave_rays(const RenderParams &rp, uint32_t stage_words, uint32_t block, uint32_t stack_depth) {
+    static const bool off = [] { const char *e = getenv("DTOF_TRACE8"); return e && e[0] == '0'; }();
+    return !off && stage_words == 0 && block == 64 && rp.has_tris && rp.has_blas && !rp.has_analytic && !rp.has_spec && stack_depth <= kLdsStack8 + kOvfStack8;
+}
 void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s) {
     if (rp.n_lanes == 0) return;
     hipLaunchKernelGGL(k_generate, dim3(nblk(rp.n_lanes)), dim3(kBlock), 0, s, rp, q);
@@ -481,10 +517,13 @@ void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
                   const uint32_t *qin, const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
     const uint32_t sw = stage_words_for(scene_bytes, stack_bytes(stack_depth)), block = sw ? kBlock : unstaged_block(rp);
-    const uint32_t lds = sw * 16 + stack_bytes(stack_depth, block), grid = nseg(rp.n_lanes) * (kSeg / block);
+    const bool w8 = eight_wave_rays(rp, sw, block, stack_depth);
+    const uint32_t lds = sw * 16 + stack_bytes(w8 ? kLdsStack8 : stack_depth, block), grid = nseg(rp.n_lanes) * (kSeg / block);
     check_lds(lds);
-#define DTOF_LAUNCH_TRACE(L, M, B) hipLaunchKernelGGL((k_trace<L, M, B>), dim3(grid), dim3(B), lds, s, scene, scene_bytes, sw, q, qin, count_in, rp.n_lanes)
-    if (sw) { if (rp.has_tris) DTOF_LAUNCH_TRACE(true, true, kBlock); else DTOF_LAUNCH_TRACE(true, false, kBlock); }
+    Queues qx = q; qx.xcd_remap = xcd_run(rp, sw, block);
+#define DTOF_LAUNCH_TRACE(L, M, B) hipLaunchKernelGGL((k_trace<L, M, B>), dim3(grid), dim3(B), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes)
+    if (w8) hipLaunchKernelGGL((k_trace<false, true, 64, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes);
+    else if (sw) { if (rp.has_tris) DTOF_LAUNCH_TRACE(true, true, kBlock); else DTOF_LAUNCH_TRACE(true, false, kBlock); }
     else if (block == 64)  { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true, 64); else DTOF_LAUNCH_TRACE(false, false, 64); }
     else if (block == 128) { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true, 128); else DTOF_LAUNCH_TRACE(false, false, 128); }
     else                   { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true, kBlock); else DTOF_LAUNCH_TRACE(false, false, kBlock); }
@@ -493,8 +532,9 @@ void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
 uint32_t resident_lds_bytes(const RenderParams &rp, const ResidentStage &resident, uint32_t stack_depth, uint32_t waves) {
     static_assert(kResidentNodes == kResNodes, "resident stage size");
     const uint32_t memo = rp.memo_obj != 0xffffffffu ? 1u : 0u;
-    const uint32_t park = (rp.n_offsets != 1 ? kParkWords : (DTOF_PARK && waves == 16 ? kParkState : 0u)) * waves * 64u * 4u;   // film-state columns of the several-film kernels (k_shade: RES_LDS) / parked path state (PARK)
-    return (4u * kResNodes + resident.small_words) * 16u + memo * waves * kMemoWords * kMemoStride * 4u + stack_bytes(stack_depth, waves * 64) + park;
+    // film-state columns of the several-film kernels (k_shade: RES_LDS) + parked path state (PARK: 16 waves only; the several-film kernels have room for the two streams)
+    const uint32_t park_words = rp.n_offsets != 1 ? kParkWords + (DTOF_PARK && waves == 16 ? kParkRng : 0u) : (DTOF_PARK && waves == 16 ? kParkState : 0u);
+    return (4u * kResNodes + resident.small_words) * 16u + memo * waves * kMemoWords * kMemoStride * 4u + resident_stack_bytes(stack_depth, waves, rp.n_offsets != 1) + park_words * waves * 64u * 4u;
 }
 uint32_t device_lds_limit() {
     if (const char *e = getenv("DTOF_LDS_LIMIT")) return (uint32_t) strtoul(e, nullptr, 10);   // tests: a smaller budget than the device's (the step-down / fallback paths)
@@ -520,7 +560,7 @@ void launch_shade(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
             const uint32_t n_seg = nseg(rp.n_lanes), grid = std::min<uint32_t>((uint32_t) n_cu, (n_seg + waves - 1) / waves);
             const uint32_t memo = rp.memo_obj != 0xffffffffu ? 1u : 0u;
             const ShadeLaunch L = { false, 2, waves, grid, lds, s,
-                                    { scene, scene_bytes, 0u, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, trace_next ? 1u : 0u, dbg, film, film_stride, n_seg, resident->small_off, resident->small_words, memo, stack_bytes(stack_depth, waves * 64) / 4u } };
+                                    { scene, scene_bytes, 0u, rp, q, qin, count_in, qout, alive_out, shadow_out, depth, trace_next ? 1u : 0u, dbg, film, film_stride, n_seg, resident->small_off, resident->small_words, memo, resident_stack_bytes(stack_depth, waves, rp.n_offsets != 1) / 4u } };
             if (hipMemsetAsync(q.seg_counter, 0, 4, s) != hipSuccess) throw std::runtime_error("hipMemsetAsync(seg_counter) failed");
             if (rp.has_spec == 2) launch_shade_resident2(k4, L);
             else if (rp.has_spec) launch_shade_resident1(k4, L);
@@ -544,10 +584,13 @@ void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParam
                    const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
     const uint32_t sw = stage_words_for(scene_bytes, stack_bytes(stack_depth)), block = sw ? kBlock : unstaged_block(rp);
-    const uint32_t lds = sw * 16 + stack_bytes(stack_depth, block), grid = nseg(rp.n_lanes) * (kSeg / block);
+    const bool w8 = eight_wave_rays(rp, sw, block, stack_depth);
+    const uint32_t lds = sw * 16 + stack_bytes(w8 ? kLdsStack8 : stack_depth, block), grid = nseg(rp.n_lanes) * (kSeg / block);
     check_lds(lds);
-#define DTOF_LAUNCH_SHADOW(L, M, B) hipLaunchKernelGGL((k_shadow<L, M, B>), dim3(grid), dim3(B), lds, s, scene, scene_bytes, sw, rp, q, count_in)
-    if (sw) { if (rp.has_tris) DTOF_LAUNCH_SHADOW(true, true, kBlock); else DTOF_LAUNCH_SHADOW(true, false, kBlock); }
+    Queues qx = q; qx.xcd_remap = xcd_run(rp, sw, block);
+#define DTOF_LAUNCH_SHADOW(L, M, B) hipLaunchKernelGGL((k_shadow<L, M, B>), dim3(grid), dim3(B), lds, s, scene, scene_bytes, sw, rp, qx, count_in)
+    if (w8) hipLaunchKernelGGL((k_shadow<false, true, 64, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, rp, qx, count_in);
+    else if (sw) { if (rp.has_tris) DTOF_LAUNCH_SHADOW(true, true, kBlock); else DTOF_LAUNCH_SHADOW(true, false, kBlock); }
     else if (block == 64)  { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true, 64); else DTOF_LAUNCH_SHADOW(false, false, 64); }
     else if (block == 128) { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true, 128); else DTOF_LAUNCH_SHADOW(false, false, 128); }
     else                   { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true, kBlock); else DTOF_LAUNCH_SHADOW(false, false, kBlock); }

@@ -402,6 +402,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     if (lane_dump) sc->ws.dbg.ensure(batch);
     Queues qs[2] = { sc->ws.queues(), n_streams == 2 ? sc->ws2.queues() : sc->ws.queues() };
     qs[0].id_shift = qs[1].id_shift = sc->id_shift;
+
     hipStream_t ss[2] = { sc->stream, n_streams == 2 ? sc->stream2 : sc->stream };
     const uint8_t *blob = sc->d_blob.p; uint32_t blob_bytes = (uint32_t) sc->blob.size();
     const uint32_t stack_depth = ((const BlobHeader *) sc->blob.data())->tlas_depth;
@@ -424,6 +425,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     // SPEC feature) counts as "has_tris" -- the compact 4-byte record is for the plain rectangle-only kernels
     for (auto &sh : sc->host.shapes) if (sh.blend_other) rp.has_spec = 2;   // blendbsdf: the instantiations whose BSDF chain loops over two records
     rp.has_tris = bh->n_tris != 0 || has_spheres || rp.has_spec;
+    rp.has_analytic = has_spheres ? 1 : 0;
     {   // deep per-mesh traversals diverge: see unstaged_block() in dtof_kernels.hip
         const DShape *dshapes = (const DShape *) (sc->blob.data() + bh->off_shapes);
         for (uint32_t i = 0; i < bh->n_shapes; ++i) rp.has_blas |= dshapes[i].kind == SHAPE_MESH && dshapes[i].blas_root != kNoChild;

@@ -338,9 +338,12 @@ template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, int SPEC, int RESW
 __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (MODE == 2 && !MESH && !SPEC && KMAX == 1) ? 4 : (MODE != 0 && MESH) ? ((SPEC && KMAX > 1) ? 2 : DTOF_MESH_WAVES) : 1) void k_shade(ShadeArgs args_by_value) {
     constexpr bool FUSED = MODE != 0, FIRST = MODE == 2;
     constexpr bool RES_LDS = RESW != 0 && KMAX > 1 && DTOF_K4_RES_LDS;   // several films, resident stage: running results in LDS columns
+    constexpr bool S16 = RESW != 0 && KMAX > 1;                           // ... whose LDS comes from 16-bit traversal stacks (dtof_traverse.h: encode_child16)
     constexpr bool RES_MEM = FIRST && KMAX > 1 && (RES_LDS || DTOF_K4_RES_MEM);   // several films: running results outside the registers (LDS, else q.res), the pending NEE sample K-independent (see above)
     static_assert(!RES_LDS || 3 * KMAX == (int) kParkWords + 1, "the film-state columns hold all but the last float of the K results");
-    constexpr bool PARK = DTOF_PARK && RESW == 16 && KMAX == 1;   // the path state no traversal reads waits in LDS columns while the rays are traced
+    constexpr bool PARK_ST = DTOF_PARK && RESW == 16 && KMAX == 1;   // the path state no traversal reads waits in LDS columns while the rays are traced: throughput / path length (one film only) ...
+    constexpr bool PARK = DTOF_PARK && RESW == 16 && (KMAX == 1 || RES_LDS);   // ... and both PCG streams (several films: behind the film words)
+    constexpr uint32_t kRngAt = RES_LDS ? kParkWords : 0u;
     constexpr int KREG = RES_MEM ? 1 : KMAX;                         // film-state registers the lane carries
     constexpr uint32_t kStackStride = RESW ? RESW * 64 : kShadeBlock;   // the block size = the stride of the traversal-stack columns
     static_assert(RESW == 0 || (MODE == 2 && !LDS && MESH), "the resident stage exists for the unstaged fused first-bounce kernel with mesh code");
@@ -358,7 +361,8 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     // iteration cost every lane 51 instructions, a hit on the wall now reads it back
     const bool memo_m_lds = FUSED && !MESH && !RESW && A0.rp.flat_objects != 0u && A0.rp.memo_obj != 0xffffffffu;
     const uint32_t memo_words = FUSED ? (RESW ? (A0.res_memo ? RESW * kMemoWords * kMemoStride : 0u) : (memo_m_lds ? 2u : 1u) * kMemoWords * kMemoStride) : 0u;
-    uint32_t *stack = (uint32_t *) (lds + stage_words) + memo_words + threadIdx.x;
+    // per-thread traversal stack column; the resident kernels' columns are 16-bit (halfword address in a uint32_t *: only trace_scene<SOA> / node_step<SOA> touch it)
+    uint32_t *stack = S16 ? (uint32_t *) ((uint16_t *) ((uint32_t *) (lds + stage_words) + memo_words) + threadIdx.x) : (uint32_t *) (lds + stage_words) + memo_words + threadIdx.x;
     // One block per 512-lane segment -- or, for a small frame whose whole path runs inline (rp.chunk_blocks = 8: nothing is compacted for a
     // later launch), one block per 64-lane chunk, so that a 1 M-lane frame is 16 384 waves instead of 2 048; the per-segment statistics are
     // then accumulated with atomics into slots the host has zeroed.
@@ -369,7 +373,11 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
         const BlobHeader *gh = (const BlobHeader *) A0.scene;
         const uint4 *gn = (const uint4 *) (A0.scene + gh->off_nodes);
         const uint32_t n_pieces = gh->n_nodes * 4u;
-        for (uint32_t i = threadIdx.x; i < n_pieces; i += blockDim.x) lds[(i & 3u) * kResNodes + (i >> 2)] = gn[i];
+        for (uint32_t i = threadIdx.x; i < n_pieces; i += blockDim.x) {
+            uint4 piece = gn[i];
+            if (S16 && (i & 3u) < 2u) piece.w = encode_child16(piece.w);   // left / right child: 16-bit references (dtof_traverse.h), so that the stack columns are 16-bit
+            lds[(i & 3u) * kResNodes + (i >> 2)] = piece;
+        }
         const uint4 *gs = (const uint4 *) (A0.scene + A0.res_small_off);
         for (uint32_t i = threadIdx.x; i < A0.res_small_words; i += blockDim.x) lds[4u * kResNodes + i] = gs[i];
         __syncthreads();
@@ -465,14 +473,14 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     float4 stb_reg = make_float4(0.f, 0.f, 0.f, 1.f); float2 stc_reg = make_float2(1.f, 1.f);   // prev_si.p | prev_bsdf_pdf, eta | prev_bsdf_delta
     uint32_t *const parku = (uint32_t *) park;
     auto park_store = [&]() {   // PARK: both streams (state + 32-bit selector: inc = sel << 1 | 1) and throughput / path length leave the registers
-        parku[0] = (uint32_t) main.state; parku[kStackStride] = (uint32_t) (main.state >> 32); parku[2 * kStackStride] = (uint32_t) (main.inc >> 1);
-        parku[3 * kStackStride] = (uint32_t) path.state; parku[4 * kStackStride] = (uint32_t) (path.state >> 32); parku[5 * kStackStride] = (uint32_t) (path.inc >> 1);
-        park[6 * kStackStride] = st.x; park[7 * kStackStride] = st.y; park[8 * kStackStride] = st.z; park[9 * kStackStride] = st.w;
+        parku[kRngAt * kStackStride] = (uint32_t) main.state; parku[(kRngAt + 1) * kStackStride] = (uint32_t) (main.state >> 32); parku[(kRngAt + 2) * kStackStride] = (uint32_t) (main.inc >> 1);
+        parku[(kRngAt + 3) * kStackStride] = (uint32_t) path.state; parku[(kRngAt + 4) * kStackStride] = (uint32_t) (path.state >> 32); parku[(kRngAt + 5) * kStackStride] = (uint32_t) (path.inc >> 1);
+        if (PARK_ST) { park[6 * kStackStride] = st.x; park[7 * kStackStride] = st.y; park[8 * kStackStride] = st.z; park[9 * kStackStride] = st.w; }
     };
     auto park_load = [&]() {
-        main.state = (uint64_t) parku[0] | ((uint64_t) parku[kStackStride] << 32); main.inc = ((uint64_t) parku[2 * kStackStride] << 1) | 1u;
-        path.state = (uint64_t) parku[3 * kStackStride] | ((uint64_t) parku[4 * kStackStride] << 32); path.inc = ((uint64_t) parku[5 * kStackStride] << 1) | 1u;
-        st = make_float4(park[6 * kStackStride], park[7 * kStackStride], park[8 * kStackStride], park[9 * kStackStride]);
+        main.state = (uint64_t) parku[kRngAt * kStackStride] | ((uint64_t) parku[(kRngAt + 1) * kStackStride] << 32); main.inc = ((uint64_t) parku[(kRngAt + 2) * kStackStride] << 1) | 1u;
+        path.state = (uint64_t) parku[(kRngAt + 3) * kStackStride] | ((uint64_t) parku[(kRngAt + 4) * kStackStride] << 32); path.inc = ((uint64_t) parku[(kRngAt + 5) * kStackStride] << 1) | 1u;
+        if (PARK_ST) st = make_float4(park[6 * kStackStride], park[7 * kStackStride], park[8 * kStackStride], park[9 * kStackStride]);
     };
     // valid_ray (dopplertofpath.cpp:101-102,252-253,279-282): starts as "the environment is visible", becomes true at the first vertex whose sampled lobe is not
     // BSDFFlags::Null (a `mask` that lets the path through, the transmission of a `thindielectric`); a path that ends without it returns 0 (and alpha 0).  Only the
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             if (have_memo) instance_memo_fill(sv, ra.w, memo_m, memo_inv);
             Hit h;
             bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, rp.flat_off, flat, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h)
-                              : trace_scene<false, MESH, FUSED, RESW != 0, kStackStride>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
+                              : trace_scene<false, MESH, FUSED, RESW != 0, kStackStride, S16>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
             hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
             hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu;
         }
@@ -865,7 +873,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             commit = sha.w > 0.f;
 #else
             commit = flat ? !trace_flat<true, true>(sv, (ConstBytes) A.scene + rp.flat_off, rp.flat_off, flat, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs)
-                          : !trace_scene<true, MESH, true, RESW != 0, kStackStride>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
+                          : !trace_scene<true, MESH, true, RESW != 0, kStackStride, S16>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
 #endif
         }
         if (has_next) {
@@ -873,7 +881,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             found_next = nra.x < 1e30f; h_next.t = 0.5f + 0.1f * nrb.x; h_next.u = nrb.y; h_next.v = nrb.z; h_next.obj = nrb.x > 0.3f ? 3 : nrb.y > 0.f ? 1 : 0; h_next.shape = 0; h_next.prim = 0;
 #else
             found_next = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h_next)
-                              : trace_scene<false, MESH, true, RESW != 0, kStackStride>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h_next);
+                              : trace_scene<false, MESH, true, RESW != 0, kStackStride, S16>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h_next);
 #endif
         }
         if (RES_MEM) {   // the committed sample gets its K modulation weights now (dopplertofpath.cpp:221-226) and is added to the films' records in q.res

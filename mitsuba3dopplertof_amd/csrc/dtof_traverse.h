@@ -28,6 +28,12 @@ struct SceneView {
 // spread over all 64 banks (node-major 64-byte records would put piece k of every node on the same 16 banks: 4-way conflicts on
 // average); the plane stride is a compile-time constant, so the four reads of a node step are one address plus immediate offsets.
 constexpr uint32_t kResNodes = 1024;
+// ... and in the kernels of SEVERAL films their child references are re-encoded to 16 bits while they are copied (at most 1 024 nodes, and a TLAS of that size has at
+// most 1 025 objects): leaf flag = bit 15, "no child" = 0xffff.  The traversal stack of those kernels then holds 16-BIT entries -- half the LDS of the 32-bit columns
+// (Domino: 24 instead of 48 KiB at 16 waves), which pays for the film-state AND the path-state columns of k_shade (round 5: C5 164.9 -> 156.4 ms).  The one-film kernels
+// keep 32-bit entries: their columns fit as they are, and the 16-bit form costs them 0.8 % (C4 33.74 -> 34.02 ms; profiles/r05_k4_film_state.txt).
+constexpr uint32_t kLeafFlag16 = 0x8000u, kNoChild16 = 0xffffu, kDone16 = 0x7fffu;
+DTOF_D uint32_t encode_child16(uint32_t w) { return w == kNoChild ? kNoChild16 : ((w & 0x7fffu) | ((w >> 16) & 0x8000u)); }
 DTOF_D SceneView make_view(const uint8_t *base) {
     const BlobHeader *h = (const BlobHeader *) base;
     SceneView v;
@@ -222,10 +228,24 @@ DTOF_D bool box_hit(const float *bmin, const float *bmax, const SlabRay &r, floa
     const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
     return tn <= tf;
 }
+// Traversal stack entry `sp` of this thread: a per-thread LDS column (32-bit, or 16-bit in the resident kernels of several films) -- and, in the eight-waves-per-SIMD
+// ray kernels of large meshes (k_trace / k_shadow<..., W8>), only its first LDSN entries: deeper ones overflow into a private array `ovf` (scratch memory; a BLAS of half a
+// million triangles is 20-odd levels deep, a traversal rarely holds more than a dozen entries), so that 32 one-wave blocks fit a CU's LDS instead of 23.
+template <bool S16, uint32_t LDSN>
+DTOF_D void stack_put(uint32_t *stack, uint32_t *ovf, int sp, uint32_t stride, uint32_t x) {
+    if (LDSN != 0 && (uint32_t) sp >= LDSN) ovf[(uint32_t) sp - LDSN] = x;
+    else if (S16) ((uint16_t *) stack)[sp * stride] = (uint16_t) x;
+    else stack[sp * stride] = x;
+}
+template <bool S16, uint32_t LDSN>
+DTOF_D uint32_t stack_get(const uint32_t *stack, const uint32_t *ovf, int sp, uint32_t stride) {
+    if (LDSN != 0 && (uint32_t) sp >= LDSN) return ovf[(uint32_t) sp - LDSN];
+    return S16 ? (uint32_t) ((const uint16_t *) stack)[sp * stride] : stack[sp * stride];
+}
 // One traversal step at inner node `cur` = four 16-byte loads issued together (no load depends on a field of the node): continue with the nearest child that is
 // hit, push the other, pop when nothing is hit.  STRIDE: the stride of the per-thread stack columns when the kernel knows its block size (a shift instead of v_mul_lo_u32).
-template <bool SOA = false, uint32_t STRIDE = 0>
-DTOF_D uint32_t node_step(const BvhNode *nodes, uint32_t cur, const SlabRay &r, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride_rt, uint32_t done) {
+template <bool SOA = false, uint32_t STRIDE = 0, bool S16 = false, uint32_t LDSN = 0>   // S16: 16-bit child references and stack entries (the resident kernels of several films); LDSN: LDS entries before the overflow
+DTOF_D uint32_t node_step(const BvhNode *nodes, uint32_t cur, const SlabRay &r, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride_rt, uint32_t done, uint32_t *ovf = nullptr) {
     const uint32_t stride = STRIDE ? STRIDE : stride_rt;
     const uint4 *np = SOA ? (const uint4 *) nodes + cur : (const uint4 *) (nodes + cur);
     const uint4 a = np[0], b = np[SOA ? kResNodes : 1], c = np[SOA ? 2 * kResNodes : 2], d = np[SOA ? 3 * kResNodes : 3];
@@ -234,25 +254,27 @@ DTOF_D uint32_t node_step(const BvhNode *nodes, uint32_t cur, const SlabRay &r, 
     const uint32_t left = a.w, right = b.w;
     float tl, tr;
     const bool hl = box_hit(lmin, lmax, r, tbest, tl);
-    const bool hr = (int) box_hit(rmin, rmax, r, tbest, tr) & (int) (right != kNoChild);
-    if (hl && hr) {
+    const bool hr = (int) box_hit(rmin, rmax, r, tbest, tr) & (int) (right != (S16 ? kNoChild16 : kNoChild));
+    if (hl && hr) {   // (S16: the caller hands in the halfword address of this thread's column)
         const bool left_first = tl <= tr;
-        stack[sp * stride] = left_first ? right : left; ++sp;
+        stack_put<S16, LDSN>(stack, ovf, sp, stride, left_first ? right : left);
+        ++sp;
         return left_first ? left : right;
     }
     if (hl) return left;
     if (hr) return right;
     if (sp == sp_floor) return done;
-    --sp; return stack[sp * stride];
+    --sp; return stack_get<S16, LDSN>(stack, ovf, sp, stride);
 }
 
 // Closest hit (ANY=false) or occlusion (ANY=true) of one top-level object.  Candidates are every
 // primitive hit with t <= maxt; the winner is the smallest t, ties going to the lowest
 // (object, shape, face) -- the rule the oracle uses, independent of traversal order.
 // `stack + sp * stride` onwards is free for the BLAS traversal of a mesh.
-template <bool ANY, bool MESH, bool MEMO = false, uint32_t STRIDE = 0>
+// MESH: 0 = rectangles only, 1 = every shape, 2 = rectangles and triangle meshes (scenes without analytic shapes: no float64 sphere / cylinder code, fewer registers).
+template <bool ANY, int MESH, bool MEMO = false, uint32_t STRIDE = 0, bool NOBLAS = false, uint32_t LDSN = 0>   // NOBLAS: the resident kernels (no mesh behind a BLAS; their stack columns are 16-bit)
 DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float time, float maxt, Hit &best,
-                             uint32_t *stack, int sp, uint32_t stride) {
+                             uint32_t *stack, int sp, uint32_t stride, uint32_t *ovf = nullptr) {
     const DObject &ob = sv.objects[oi];
     uint32_t first = ob.index, count = 1;
     V3 lo = o, ld = d;
@@ -283,7 +305,7 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
             continue;
         }
         if (!MESH) continue;   // instantiations for rectangle-only scenes carry no triangle / sphere code at all
-        if (sh.kind == SHAPE_DISK) {
+        if (MESH == 1 && sh.kind == SHAPE_DISK) {
             if (disk_hit(sh, lo, ld, maxt, t, u, v)) {
                 if (ANY) return true;
                 if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
@@ -292,7 +314,7 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
             }
             continue;
         }
-        if (sh.kind == SHAPE_CYLINDER) {
+        if (MESH == 1 && sh.kind == SHAPE_CYLINDER) {
             if (cylinder_hit(sh, lo, ld, maxt, t)) {
                 if (ANY) return true;
                 if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
@@ -301,7 +323,7 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
             }
             continue;
         }
-        if (sh.kind == SHAPE_SPHERE) {
+        if (MESH == 1 && sh.kind == SHAPE_SPHERE) {
             if (sphere_hit<ANY>(sh, lo, ld, maxt, t)) {
                 if (ANY) return true;
                 if (t < best.t || (t == best.t && !found && best.obj != 0xffffffffu && oi < best.obj)) {
@@ -332,48 +354,49 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
             for (uint32_t f = 0; f < sh.n_tris; ++f) if (test(f)) return true;
             continue;
         }
+        if (NOBLAS) continue;
         // BLAS: same node format and while-while shape as the TLAS loop below
         constexpr uint32_t kDone = 0x7fffffffu;
         uint32_t cur = sh.blas_root; int bsp = sp;
         for (;;) {
             while (!(cur & kLeafFlag) && cur != kDone) {
                 DTOF_STAT(7);
-                cur = node_step<false, STRIDE>(sv.nodes, cur, lr, ANY ? maxt : best.t, stack, bsp, sp, stride, kDone);
+                cur = node_step<false, STRIDE, false, LDSN>(sv.nodes, cur, lr, ANY ? maxt : best.t, stack, bsp, sp, stride, kDone, ovf);
             }
             if (cur == kDone) break;
             uint32_t f0 = (cur & ~kLeafFlag) >> kBlasLeafBits, fn = (cur & ((1u << kBlasLeafBits) - 1u)) + 1u;
             for (uint32_t f = f0; f < f0 + fn; ++f) if (test(f)) return true;
             if (bsp == sp) break;
-            --bsp; cur = stack[bsp * stride];
+            --bsp; cur = stack_get<false, LDSN>(stack, ovf, bsp, stride);
         }
     }
     return found;
 }
 
 // TLAS traversal; `stack` is a per-thread LDS column (stride blockDim.x).
-template <bool ANY, bool MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0>   // SOA: the TLAS nodes are the LDS planes of the resident stage (binary nodes only); STRIDE: the block size, if the kernel knows it
-DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best) {
+template <bool ANY, int MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0, bool S16 = false, uint32_t LDSN = 0>   // SOA: the TLAS nodes are the LDS planes of the resident stage (binary nodes only); STRIDE: the block size, if the kernel knows it; S16: 16-bit references / stack; LDSN: see stack_put
+DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best, uint32_t *ovf = nullptr) {
     best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
     if (sv.n_nodes == 0) return false;
     const SlabRay r = slab_ray(o, d);
     // "while-while" traversal: every lane first descends inner nodes until it holds a leaf (or is done), THEN the
     // lanes that hold a leaf run the expensive object intersection together -- the wave does not pay the leaf
     // body once per node step of its slowest lane.
-    constexpr uint32_t kDone = 0x7fffffffu;
+    constexpr uint32_t kDone = S16 ? kDone16 : 0x7fffffffu, kLeaf = S16 ? kLeafFlag16 : kLeafFlag;   // S16: 16-bit child references and stack entries (encode_child16)
     int sp = 0;
     uint32_t cur = 0;
     const uint32_t stride = STRIDE ? STRIDE : blockDim.x;
     DTOF_STAT(0);
     for (;;) {
-        while (!(cur & kLeafFlag) && cur != kDone) {
+        while (!(cur & kLeaf) && cur != kDone) {
             DTOF_STAT(1); DTOF_STAT_WAVE(2);
-            cur = node_step<SOA, STRIDE>(sv.nodes, cur, r, best.t, stack, sp, 0, stride, kDone);
+            cur = node_step<SOA, STRIDE, S16, LDSN>(sv.nodes, cur, r, best.t, stack, sp, 0, stride, kDone, ovf);
         }
         if (cur == kDone) break;
         DTOF_STAT(3); DTOF_STAT_WAVE(4);
-        if (intersect_object<ANY, MESH, MEMO, STRIDE>(sv, cur & ~kLeafFlag, o, d, time, maxt, best, stack, sp, stride) && ANY) return true;
+        if (intersect_object<ANY, MESH, MEMO, STRIDE, S16, LDSN>(sv, cur & ~kLeaf & (S16 ? 0xffffu : 0xffffffffu), o, d, time, maxt, best, stack, sp, stride, ovf) && ANY) return true;
         if (sp == 0) break;
-        --sp; cur = stack[sp * stride];
+        --sp; cur = stack_get<S16, LDSN>(stack, ovf, sp, stride);
     }
     return best.obj != 0xffffffffu;
 }
@@ -383,10 +406,10 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
 // measured slower in round 3; it is parked as tools/experiments/r03_coop_triangles.patch with its numbers in profiles/r03_coop_triangles_ab.txt.)
 
 // Scene query of a kernel whose call site is wave-uniform; `active` says whether this lane has a ray.
-template <bool ANY, bool MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0>
-DTOF_D bool trace_rays(const SceneView &sv, uint32_t *stack, bool active, V3 o, V3 d, float time, float maxt, Hit &best) {
+template <bool ANY, int MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0, uint32_t LDSN = 0>
+DTOF_D bool trace_rays(const SceneView &sv, uint32_t *stack, bool active, V3 o, V3 d, float time, float maxt, Hit &best, uint32_t *ovf = nullptr) {
     bool r = false;
-    if (active) r = trace_scene<ANY, MESH, MEMO, SOA, STRIDE>(sv, stack, o, d, time, maxt, best);
+    if (active) r = trace_scene<ANY, MESH, MEMO, SOA, STRIDE, false, LDSN>(sv, stack, o, d, time, maxt, best, ovf);
     return r;
 }
 

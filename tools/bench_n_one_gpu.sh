@@ -19,5 +19,5 @@ run 29548 --config c2 --res 250 --spp 64 --scaling strong --steps 2 --warmup 1 |
 run 29547 --steps 2 --warmup 1 | line "N$N c2 default line (weak, with its extras)"
 # the REAL backend on one GPU: a one-rank RCCL group, the frame loop issues its gather / reduce as an N > 1 run does, K steps queued on one stream and waited for once
 unset DTOF_BENCH_SHARE_GPU
-DTOF_BENCH_FORCE_EXCHANGE=1 python bench.py --config c4 --res 256 --spp 16 --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N1 rccl reduce (stripes)', d['value'], d['config']['image_checksum'], 'pipelined', d['steps_pipelined'], d['process_group'])"
-DTOF_BENCH_FORCE_EXCHANGE=1 python bench.py --config c4 --res 256 --spp 16 --sharding bands --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N1 rccl gather (bands)', d['value'], d['config']['image_checksum'], 'pipelined', d['steps_pipelined'], d['process_group'])"
+DTOF_BENCH_FORCE_EXCHANGE=1 python bench.py --config c4 --res 250 --spp 16 --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N1 rccl reduce (stripes)', d['value'], d['config']['image_checksum'], 'pipelined', d['steps_pipelined'], d['process_group'])"
+DTOF_BENCH_FORCE_EXCHANGE=1 python bench.py --config c4 --res 250 --spp 16 --sharding bands --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N1 rccl gather (bands)', d['value'], d['config']['image_checksum'], 'pipelined', d['steps_pipelined'], d['process_group'])"

@@ -33,6 +33,10 @@ for c in $configs; do
     cp "$out/${tag}_bench_${c}_under_rocprof.json" "$out/${tag}_profiles/"
     echo "== $c counters in place"
 done
+cp profiles/roofline_traffic.json "$out/${tag}_profiles/" 2>/dev/null
+# SKIP_FINAL=1: counters only (a round's evidence does not fit one 20-minute gpurun call: first `SKIP_FINAL=1 tools/profile_round.sh r05 c1 c2 c2_wavefront c3`, copy
+# gpurun_out/r05_profiles/roofline_traffic.json back into profiles/, then `tools/profile_round.sh r05 c4 c5`)
+if [ -n "${SKIP_FINAL:-}" ]; then exit 0; fi
 if [ -f mitsuba3dopplertof_amd/libdtof_stats.so ]; then
     python3 tools/traversal_stats.py domino.xml 128 wave_function_type=rectangular --pipeline fused --json profiles/${tag}_traversal_stats_c4.json > "$out/${tag}_traversal_stats_c4.txt" 2>&1
     cat "$out/${tag}_traversal_stats_c4.txt"
