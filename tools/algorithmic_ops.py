@@ -18,10 +18,10 @@ P = os.path.join(HERE, "profiles")
 NODE_STEP_OPS = 44        # two slab tests (6 multiply-adds + 6 min / max + 3 + 3 min / max + compare = 19 each, the form of round 4) + ordering / selection of the children (6)
 
 
-def newest(pattern):      # the round-4 file if it exists, else round 3's
-    for tag in ("r04", "r03"):
+def newest(pattern):      # the newest round's file that exists
+    for tag in ("r06", "r05", "r04", "r03"):
         if os.path.exists(os.path.join(P, pattern % tag)): return pattern % tag
-    return pattern % "r04"
+    return pattern % "r05"
 
 
 def load(name):
