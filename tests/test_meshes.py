@@ -215,6 +215,20 @@ def test_blas_equals_the_loop_over_all_triangles_on_a_large_mesh(mi, orc, tmp_pa
     m = 2048
     o = osc.render_lanes(osc.params(), 5, 4, 6000, m, threads=NCPU)
     assert np.array_equal(bits(a["rgb"][6000:6000 + m]), bits(o["rgb"]))
+    # Round 5: the ray kernels of such scenes have an eight-waves-per-SIMD form (triangle + rectangle code only, a 16-entry LDS stack column with an overflow array --
+    # this BLAS is deeper than that) and an XCD-aware block order.  Which block traces which queue segment, and with how many waves, changes no lane.
+    assert info["bvh_stack_depth"] > 16
+    img = sc.render(seed=5, spp=4)
+    for env in (dict(DTOF_TRACE8="0"), dict(DTOF_XCD_REMAP="0"), dict(DTOF_XCD_REMAP="8"), dict(DTOF_XCD_REMAP="4096"), dict(DTOF_XCD_REMAP="1000003"), dict(DTOF_TRACE8="0", DTOF_XCD_REMAP="64")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        other = mi.load_file(os.path.join(d, "s.xml"), **params)
+        c = other.sample_lanes(5, 4, 0, n)
+        for k in a:
+            assert np.array_equal(bits(a[k]), bits(c[k])), (env, k)
+        assert np.abs(other.render(seed=5, spp=4) - img).max() <= 1e-6 * np.abs(img).max(), env
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 # ------------------------------------------------------------------------------------------------ mesh area emitters
