@@ -863,8 +863,6 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     }
     if (FUSED) {
         bool commit = false;
-        const bool has_next = alive && trace_next;   // the continuation ray is traced here: its closest hit is what the next bounce starts from
-        bool found_next = false; Hit h_next;
         // (Both rays in ONE traversal loop -- a lane going on with its continuation ray while its neighbours are still in their shadow rays -- was built and measured in
         // round 5 and lost by a third: tools/experiments/r05_pair_traversal.patch, profiles/r05_pair_traversal.txt.)
         if (want_shadow) {   // test_visibility (scene.cpp:266-271): an unoccluded sample commits its candidate result
@@ -876,14 +874,10 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                           : !trace_scene<true, MESH, true, RESW != 0, kStackStride, S16>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
 #endif
         }
-        if (has_next) {
-#if defined(DTOF_ABLATE) && (DTOF_ABLATE & 2)
-            found_next = nra.x < 1e30f; h_next.t = 0.5f + 0.1f * nrb.x; h_next.u = nrb.y; h_next.v = nrb.z; h_next.obj = nrb.x > 0.3f ? 3 : nrb.y > 0.f ? 1 : 0; h_next.shape = 0; h_next.prim = 0;
-#else
-            found_next = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h_next)
-                              : trace_scene<false, MESH, true, RESW != 0, kStackStride, S16>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h_next);
+#if DTOF_KILL
+        if (!RES_MEM) sha = make_float4(0.f, 0.f, 0.f, 0.f);   // the shadow ray is traced: nothing reads it again (shb.w, the ray time, is still read by the deferred commit of the several-film kernels)
+        if (!RES_MEM) shb = sha;
 #endif
-        }
         if (RES_MEM) {   // the committed sample gets its K modulation weights now (dopplertofpath.cpp:221-226) and is added to the films' records in q.res
             if (commit) {
                 const bool plain_ = rp.integrator != 0;
@@ -915,9 +909,16 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (KMAX == 1 || k < rp.n_offsets) q.res[(size_t) k * q.capacity + l] = make_float4(cand[RES_MEM ? 0 : k].x, cand[RES_MEM ? 0 : k].y, cand[RES_MEM ? 0 : k].z, 0.f);
         }
-        if (has_next) {   // closest hit of the continuation ray, consumed by the next bounce
-            if (!FIRST || last) store_hit<MESH>(q, l, h_next, found_next);
-            if (FIRST) { hh = make_uint4(f2u(h_next.t), f2u(h_next.u), f2u(h_next.v), h_next.prim); hid = found_next ? (h_next.obj | (h_next.shape << q.id_shift)) : 0xffffffffu; }
+        if (alive && trace_next) {   // closest hit of the continuation ray, consumed by the next bounce (the Hit lives inside this block: no half-defined registers across the commit above)
+            Hit h;
+#if defined(DTOF_ABLATE) && (DTOF_ABLATE & 2)
+            bool found = nra.x < 1e30f; h.t = 0.5f + 0.1f * nrb.x; h.u = nrb.y; h.v = nrb.z; h.obj = nrb.x > 0.3f ? 3 : nrb.y > 0.f ? 1 : 0; h.shape = 0; h.prim = 0;
+#else
+            bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h)
+                              : trace_scene<false, MESH, true, RESW != 0, kStackStride, S16>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
+#endif
+            if (!FIRST || last) store_hit<MESH>(q, l, h, found);
+            if (FIRST) { hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim); hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu; }
         }
         const uint32_t n_sh = (uint32_t) __popcll(__ballot(want_shadow)) * ((threadIdx.x & 63) == 0 ? 1u : 0u);   // per-wave partial (stats only)
         if (last) n_shadow += n_sh; else if (lane_id == 0) s_inline[2 * it + 1] += n_sh;
@@ -935,6 +936,9 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     // bounce computed them); a lane whose path ended sits out the remaining iterations
     lane_on = alive;
     if (alive) { ra = nra; rb = nrb; DTOF_POISON_CHECK(); }
+#if DTOF_KILL
+    nra = make_float4(0.f, 0.f, 0.f, 0.f); nrb = nra;   // (their last reader has run: not carried into the next iteration)
+#endif
     }   // inline iterations
     if constexpr (!RES_MEM) if (FIRST && fuse_splat) {   // ---- ImageBlock::put (imageblock.cpp:414-531) of the wave's samples: tent filter of radius <= 1, a 3 x 3 footprint anchored at the sample's pixel
         const uint32_t W = (uint32_t) rp.crop_w;
