@@ -115,11 +115,6 @@ constexpr uint32_t kParkWords = 11;
 #ifndef DTOF_PARK
 #define DTOF_PARK 1
 #endif
-// DTOF_KILL (experiment): the shadow ray and the continuation ray of a vertex are set to a constant behind their last reader, so that the register allocator does not
-// have to carry conditionally assigned registers through the rest of the iteration and around the loop
-#ifndef DTOF_KILL
-#define DTOF_KILL 0
-#endif
 constexpr uint32_t kParkState = 10, kParkRng = 6;   // one film: both streams + throughput / path length; several films (behind the kParkWords film words): the streams only
 // the stack columns of the resident kernels of several films hold 16-bit entries (dtof_traverse.h: encode_child16), the one-film kernels' 32-bit ones
 static inline uint32_t resident_stack_bytes(uint32_t depth, uint32_t waves, bool several_films) { return (depth < 2 ? 2 : depth) * waves * 64u * (several_films ? 2u : 4u); }

@@ -555,7 +555,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                 path.state = (uint64_t) rs.z | ((uint64_t) rs.w << 32); path.inc = ((uint64_t) ri.y << 1) | 1u;
             }
             const bool one = rp.integrator != 0 || rp.sampler_kind != SAMPLER_CORRELATED;
-            for (int k = 0; k < 6; ++k) { main.state = main.state * kPcgMult + main.inc; if (!one) path.state = path.state * kPcgMult + path.inc; }
+            main.state = pcg_jump6(main.state, main.inc); if (!one) path.state = pcg_jump6(path.state, path.inc);   // six steps at once: the same integers
             q.rng_a[l] = make_uint4((uint32_t) main.state, (uint32_t) (main.state >> 32), (uint32_t) path.state, (uint32_t) (path.state >> 32));
         }
         // valid_ray of the lane as it enters this iteration
@@ -874,10 +874,6 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
                           : !trace_scene<true, MESH, true, RESW != 0, kStackStride, S16>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
 #endif
         }
-#if DTOF_KILL
-        if (!RES_MEM) sha = make_float4(0.f, 0.f, 0.f, 0.f);   // the shadow ray is traced: nothing reads it again (shb.w, the ray time, is still read by the deferred commit of the several-film kernels)
-        if (!RES_MEM) shb = sha;
-#endif
         if (RES_MEM) {   // the committed sample gets its K modulation weights now (dopplertofpath.cpp:221-226) and is added to the films' records in q.res
             if (commit) {
                 const bool plain_ = rp.integrator != 0;
@@ -936,9 +932,6 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     // bounce computed them); a lane whose path ended sits out the remaining iterations
     lane_on = alive;
     if (alive) { ra = nra; rb = nrb; DTOF_POISON_CHECK(); }
-#if DTOF_KILL
-    nra = make_float4(0.f, 0.f, 0.f, 0.f); nrb = nra;   // (their last reader has run: not carried into the next iteration)
-#endif
     }   // inline iterations
     if constexpr (!RES_MEM) if (FIRST && fuse_splat) {   // ---- ImageBlock::put (imageblock.cpp:414-531) of the wave's samples: tent filter of radius <= 1, a 3 x 3 footprint anchored at the sample's pixel
         const uint32_t W = (uint32_t) rp.crop_w;
