@@ -49,7 +49,7 @@ constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kNoChild = 0xffffffffu;
 // BLAS (per triangle mesh, nodes appended to the same array): a leaf is kLeafFlag | (first triangle, relative to the mesh's
 // first_tri) << kBlasLeafBits | (count - 1); meshes of at most kBlasMinTris triangles are looped over instead.
-constexpr uint32_t kBlasLeafBits = 2, kBlasLeaf = 4, kBlasMinTris = 16;
+constexpr uint32_t kBlasLeafBits = 3, kBlasLeaf = 4, kBlasMinTris = 16;   // a leaf can hold up to 1 << kBlasLeafBits triangles; the builder stops splitting at kBlasLeaf (DTOF_BLAS_LEAF=1..8 overrides: development)
 // TLAS node (64 B): the bounds of BOTH children live in the parent, so one fetch decides both
 // descents.  child = kLeafFlag | object index for a leaf, inner-node index otherwise, kNoChild if absent.
 struct BvhNode {

@@ -135,6 +135,8 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     std::vector<BvhNode> blas_nodes; uint32_t blas_depth = 0;
     std::vector<uint32_t> tables;   // mesh emitters: cdf[n] | pmf[n] (float bits) | slot[n]; roughplastic: 64 transmittances
     const char *blas_env = getenv("DTOF_BLAS"); const bool use_blas = !(blas_env && blas_env[0] == '0');   // DTOF_BLAS=0: loop over every triangle (debug)
+    uint32_t blas_leaf = kBlasLeaf;                           // DTOF_BLAS_LEAF=1..8: triangles per BLAS leaf (development: the hits do not depend on it)
+    if (const char *e = getenv("DTOF_BLAS_LEAF")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= (long) (1u << kBlasLeafBits)) blas_leaf = (uint32_t) v; }
     std::vector<Box> shape_boxes(sc.shapes.size());
     struct TexUse { uint32_t shape, slot, rec; };           // slot: 0 reflectance (rides in `nonlinear`), 1 specular_reflectance, 2 specular_transmittance, 3 alpha_u, 4 alpha_v
     std::vector<TexUse> tex_recs;                          // rec: word offset of the DTexture in `tables`
@@ -249,7 +251,8 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
                     for (int k = 0; k < 3; ++k) it.c[k] = 0.5f * (it.box.lo[k] + it.box.hi[k]);
                     it.box.pad();
                 }
-                BuildCtx cx { blas_nodes, items, kBlasLeaf };
+                if (d.n_tris >= (1u << (31 - kBlasLeafBits))) throw std::runtime_error("a mesh has more triangles than a BLAS leaf reference addresses");
+                BuildCtx cx { blas_nodes, items, blas_leaf };
                 d.blas_root = build_node(cx, 0, items.size());   // index within blas_nodes; rebased behind the TLAS below
                 blas_depth = std::max(blas_depth, cx.deepest);
                 std::vector<DTri> t2(d.n_tris); std::vector<DTriShade> s2(d.n_tris);

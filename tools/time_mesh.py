@@ -9,7 +9,8 @@ import mitsuba3dopplertof_amd as mi
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes")); import make_scenes; make_scenes.ensure()
 
 n_u, n_v, res, spp = [int(x) for x in (sys.argv[1:5] + ["512", "256", "512", "64"][len(sys.argv) - 1:])]
-d = tempfile.mkdtemp(prefix="dtof_mesh_")
+d = os.environ.get("DTOF_MESH_DIR") or tempfile.mkdtemp(prefix="dtof_mesh_")   # DTOF_MESH_DIR: keep the scene (tools/traversal_stats.py $DTOF_MESH_DIR/s.xml 64)
+os.makedirs(d, exist_ok=True)
 t = time.time()
 pos, nrm, uv, faces = make_mesh.blob(n_u, n_v)
 make_mesh.write_ply(os.path.join(d, "blob.ply"), pos, nrm, uv, faces)
