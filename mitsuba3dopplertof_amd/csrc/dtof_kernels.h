@@ -41,6 +41,7 @@ struct RenderParams {
     int32_t has_spec;                             // scene has delta BSDFs (conductor / dielectric): eta and prev_bsdf_delta become per-lane state; 2: ... and blendbsdf
     int32_t has_tris;                             // scene has triangle meshes (selects the kernel instantiations that carry mesh code)
     int32_t has_analytic;                         // the scene has spheres / disks / cylinders (the eight-wave ray kernels carry triangle and rectangle code only)
+    uint32_t n_tlas_nodes;                        // nodes of the top-level BVH (the eight-wave ray kernels keep up to kTlasLds8 of them in LDS)
     int32_t has_blas;                             // some mesh is traversed through its own BLAS: the unstaged k_trace / k_shadow run one wave per block
     int32_t integrator;                           // 0 dopplertofpath, 1 path (src/integrators/path.cpp), 2 velocity (velocity.cpp)
     // ---- batch

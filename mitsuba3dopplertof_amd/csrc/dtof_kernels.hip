@@ -45,6 +45,10 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) 
 // Eight waves per SIMD instead of six -- more misses in flight per CU -- need (a) at most 64 VGPRs: the instantiation carries triangle and rectangle code only (MESH = 2: no
 // float64 sphere / cylinder arithmetic), and (b) 32 one-wave blocks in a CU's LDS: the stack column holds kLdsStack8 entries, deeper ones overflow into a private array.
 constexpr uint32_t kLdsStack8 = 16, kOvfStack8 = 48;
+// TL (round 5): the eight-wave kernels were measured with their texture-address / data units 87 - 90 % busy (profiles/r05_mesh_room.txt): every node step is four 16-byte
+// loads per lane, and a third of the loads a ray issues walk the TLAS -- a handful of nodes in such scenes (the mesh room: walls, a light, two blobs).  A TLAS of at most
+// kTlasLds8 nodes is copied behind the block's stack column (32 blocks x (4 KiB + 1 KiB) = the CU's 160 KiB) and walked with ds_read_b128; the BLAS stay in global memory.
+constexpr uint32_t kTlasLds8 = 16;
 // XCD-aware block order of the unstaged ray kernels (guide: cdna_hip_programming.md T1).  Blocks are dealt round-robin over the 8 XCDs, each with an L2 of its own (4 MiB):
 // with block b tracing queue segment b, every XCD sees rays from all over the image and all eight L2s fight over the same 35 MB of nodes and triangle records.  The remap gives
 // the blocks that share an XCD a CONTIGUOUS run of segments (= a band of the image for the primary and shadow rays), so each L2 mostly holds the geometry of its band.
@@ -59,9 +63,10 @@ DTOF_D uint32_t xcd_remap(uint32_t orig, uint32_t n, uint32_t run) {
     const uint32_t g = orig / group, w = orig - g * group, xcd = w & 7u, k = w >> 3;   // within a group: block w runs on XCD w % 8 and is that XCD's k-th block
     return g * group + xcd * run + k;
 }
-template <bool LDS, bool MESH, int BLOCK, bool W8 = false>
+template <bool LDS, bool MESH, int BLOCK, bool W8 = false, bool TL = false>
 __global__ __launch_bounds__(BLOCK, W8 ? 8 : BLOCK == 64 ? 6 : 1) void k_trace(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words,
-                                                 Queues q, const uint32_t *qin, const uint32_t *count_in, uint32_t n_lanes) {
+                                                 Queues q, const uint32_t *qin, const uint32_t *count_in, uint32_t n_lanes, uint32_t n_tlas) {
+    static_assert(!TL || W8, "the TLAS copy sits behind the eight-wave kernels' stack column");
     static_assert(!W8 || (!LDS && MESH && BLOCK == 64), "the eight-wave form exists for the unstaged one-wave kernels with triangle code");
     constexpr uint32_t kBlock = BLOCK, kSub = kSeg / BLOCK;
     extern __shared__ uint4 lds[];
@@ -72,20 +77,27 @@ __global__ __launch_bounds__(BLOCK, W8 ? 8 : BLOCK == 64 ? 6 : 1) void k_trace(c
     const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
     uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
     SceneView sv = make_view(base);
+    const BvhNode *tlas = nullptr;
+    if (TL) {   // the block's own copy of the TLAS nodes, behind its stack column (one wave: the barrier is a wave barrier)
+        uint4 *const t = lds + stage_words + kLdsStack8 * kBlock / 4u;
+        for (uint32_t i = threadIdx.x; i < n_tlas * 4u; i += kBlock) t[i] = ((const uint4 *) sv.nodes)[i];
+        __syncthreads();
+        tlas = (const BvhNode *) t;
+    }
     uint32_t j = sub * kBlock + threadIdx.x;
     const bool active = j < count;   // lanes past the end of the segment stay as helpers of the shared triangle loops (trace_rays)
     uint32_t l = 0; float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 1.f, 0.f);
     if (active) { l = qin ? qin[seg * kSeg + j] : seg * kSeg + j; a = q.ray_a[l]; b = q.ray_b[l]; }
     Hit h;
     uint32_t ovf[W8 ? kOvfStack8 : 1];
-    bool found = trace_rays<false, W8 ? 2 : (MESH ? 1 : 0), false, false, BLOCK, W8 ? kLdsStack8 : 0u>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h, ovf);
+    bool found = trace_rays<false, W8 ? 2 : (MESH ? 1 : 0), false, false, BLOCK, W8 ? kLdsStack8 : 0u, TL>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h, ovf, tlas);
     if (active) store_hit<MESH>(q, l, h, found);
 }
 
 // ---------------------------------------------------------------------------- shadow
-template <bool LDS, bool MESH, int BLOCK, bool W8 = false>
+template <bool LDS, bool MESH, int BLOCK, bool W8 = false, bool TL = false>
 __global__ __launch_bounds__(BLOCK, W8 ? 8 : BLOCK == 64 ? 6 : 1) void k_shadow(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp,
-                                                  Queues q, const uint32_t *count_in) {
+                                                  Queues q, const uint32_t *count_in, uint32_t n_tlas) {
     constexpr uint32_t kBlock = BLOCK, kSub = kSeg / BLOCK;
     extern __shared__ uint4 lds[];
     const uint32_t bid = !LDS && q.xcd_remap ? xcd_remap(blockIdx.x, gridDim.x, q.xcd_remap) : blockIdx.x;
@@ -95,6 +107,13 @@ __global__ __launch_bounds__(BLOCK, W8 ? 8 : BLOCK == 64 ? 6 : 1) void k_shadow(
     const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
     uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
     SceneView sv = make_view(base);
+    const BvhNode *tlas = nullptr;
+    if (TL) {   // the block's own copy of the TLAS nodes, behind its stack column (one wave: the barrier is a wave barrier)
+        uint4 *const t = lds + stage_words + kLdsStack8 * kBlock / 4u;
+        for (uint32_t i = threadIdx.x; i < n_tlas * 4u; i += kBlock) t[i] = ((const uint4 *) sv.nodes)[i];
+        __syncthreads();
+        tlas = (const BvhNode *) t;
+    }
     uint32_t j = sub * kBlock + threadIdx.x;
     const bool active = j < count;
     uint32_t i = seg * kSeg + j;
@@ -102,7 +121,7 @@ __global__ __launch_bounds__(BLOCK, W8 ? 8 : BLOCK == 64 ? 6 : 1) void k_shadow(
     if (active) { a = q.sh_a[i]; b = q.sh_b[i]; }
     Hit h;
     uint32_t ovf[W8 ? kOvfStack8 : 1];
-    bool occluded = trace_rays<true, W8 ? 2 : (MESH ? 1 : 0), false, false, BLOCK, W8 ? kLdsStack8 : 0u>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h, ovf);
+    bool occluded = trace_rays<true, W8 ? 2 : (MESH ? 1 : 0), false, false, BLOCK, W8 ? kLdsStack8 : 0u, TL>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h, ovf, tlas);
     if (active && !occluded) {
 #pragma unroll
         for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) {
@@ -474,8 +493,12 @@ static inline uint32_t xcd_run(const RenderParams &rp, uint32_t stage_words, uin
     const uint64_t row_blocks = (uint64_t) rp.crop_w * rp.spp / block;
     return (uint32_t) (row_blocks >= 8 && row_blocks <= (1u << 20) ? row_blocks : 0);
 }
+static inline bool tlas_in_lds(const RenderParams &rp) {   // DTOF_TLAS_LDS=0: the TLAS is walked in global memory like the BLAS (A/B, tests)
+    const char *e = getenv("DTOF_TLAS_LDS"); const bool off = e && e[0] == '0';
+    return !off && rp.n_tlas_nodes != 0 && rp.n_tlas_nodes <= kTlasLds8;
+}
 static inline bool eight_wave_rays(const RenderParams &rp, uint32_t stage_words, uint32_t block, uint32_t stack_depth) {
-    static const bool off = [] { const char *e = getenv("DTOF_TRACE8"); return e && e[0] == '0'; }();
+    const char *e = getenv("DTOF_TRACE8"); const bool off = e && e[0] == '0';   // read per call (a few launches per frame): tests and A/B runs switch it inside one process
     return !off && stage_words == 0 && block == 64 && rp.has_tris && rp.has_blas && !rp.has_analytic && !rp.has_spec && stack_depth <= kLdsStack8 + kOvfStack8;
 }
 void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s) {
@@ -517,12 +540,13 @@ void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
                   const uint32_t *qin, const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
     const uint32_t sw = stage_words_for(scene_bytes, stack_bytes(stack_depth)), block = sw ? kBlock : unstaged_block(rp);
-    const bool w8 = eight_wave_rays(rp, sw, block, stack_depth);
-    const uint32_t lds = sw * 16 + stack_bytes(w8 ? kLdsStack8 : stack_depth, block), grid = nseg(rp.n_lanes) * (kSeg / block);
+    const bool w8 = eight_wave_rays(rp, sw, block, stack_depth), tl = w8 && tlas_in_lds(rp);
+    const uint32_t lds = sw * 16 + stack_bytes(w8 ? kLdsStack8 : stack_depth, block) + (tl ? kTlasLds8 * 64u : 0u), grid = nseg(rp.n_lanes) * (kSeg / block);
     check_lds(lds);
     Queues qx = q; qx.xcd_remap = xcd_run(rp, sw, block);
-#define DTOF_LAUNCH_TRACE(L, M, B) hipLaunchKernelGGL((k_trace<L, M, B>), dim3(grid), dim3(B), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes)
-    if (w8) hipLaunchKernelGGL((k_trace<false, true, 64, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes);
+#define DTOF_LAUNCH_TRACE(L, M, B) hipLaunchKernelGGL((k_trace<L, M, B>), dim3(grid), dim3(B), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes, 0u)
+    if (tl) hipLaunchKernelGGL((k_trace<false, true, 64, true, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes, rp.n_tlas_nodes);
+    else if (w8) hipLaunchKernelGGL((k_trace<false, true, 64, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes, 0u);
     else if (sw) { if (rp.has_tris) DTOF_LAUNCH_TRACE(true, true, kBlock); else DTOF_LAUNCH_TRACE(true, false, kBlock); }
     else if (block == 64)  { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true, 64); else DTOF_LAUNCH_TRACE(false, false, 64); }
     else if (block == 128) { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true, 128); else DTOF_LAUNCH_TRACE(false, false, 128); }
@@ -584,12 +608,13 @@ void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParam
                    const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
     const uint32_t sw = stage_words_for(scene_bytes, stack_bytes(stack_depth)), block = sw ? kBlock : unstaged_block(rp);
-    const bool w8 = eight_wave_rays(rp, sw, block, stack_depth);
-    const uint32_t lds = sw * 16 + stack_bytes(w8 ? kLdsStack8 : stack_depth, block), grid = nseg(rp.n_lanes) * (kSeg / block);
+    const bool w8 = eight_wave_rays(rp, sw, block, stack_depth), tl = w8 && tlas_in_lds(rp);
+    const uint32_t lds = sw * 16 + stack_bytes(w8 ? kLdsStack8 : stack_depth, block) + (tl ? kTlasLds8 * 64u : 0u), grid = nseg(rp.n_lanes) * (kSeg / block);
     check_lds(lds);
     Queues qx = q; qx.xcd_remap = xcd_run(rp, sw, block);
-#define DTOF_LAUNCH_SHADOW(L, M, B) hipLaunchKernelGGL((k_shadow<L, M, B>), dim3(grid), dim3(B), lds, s, scene, scene_bytes, sw, rp, qx, count_in)
-    if (w8) hipLaunchKernelGGL((k_shadow<false, true, 64, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, rp, qx, count_in);
+#define DTOF_LAUNCH_SHADOW(L, M, B) hipLaunchKernelGGL((k_shadow<L, M, B>), dim3(grid), dim3(B), lds, s, scene, scene_bytes, sw, rp, qx, count_in, 0u)
+    if (tl) hipLaunchKernelGGL((k_shadow<false, true, 64, true, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, rp, qx, count_in, rp.n_tlas_nodes);
+    else if (w8) hipLaunchKernelGGL((k_shadow<false, true, 64, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, rp, qx, count_in, 0u);
     else if (sw) { if (rp.has_tris) DTOF_LAUNCH_SHADOW(true, true, kBlock); else DTOF_LAUNCH_SHADOW(true, false, kBlock); }
     else if (block == 64)  { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true, 64); else DTOF_LAUNCH_SHADOW(false, false, 64); }
     else if (block == 128) { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true, 128); else DTOF_LAUNCH_SHADOW(false, false, 128); }

@@ -33,7 +33,8 @@ struct BlobHeader {
     uint32_t n_nodes, n_objects, n_groups, n_shapes, n_tris, n_emitters;
     uint32_t off_nodes, off_objects, off_groups, off_shapes, off_tris, off_shading, off_emitters;
     uint32_t total_bytes, off_tables, tlas_depth, off_flat;      // off_tables: face distributions of mesh emitters (float / uint32 words)   // tlas_depth: stack entries a traversal can need (TLAS depth + deepest BLAS)
-    uint32_t off_isect, pad[2];                        // off_isect: DTriIsect[n_tris], what the triangle test reads   // off_flat: DFlatObject[n_objects] of a rectangle-only scene of at most kFlatObjects objects, else 0
+    uint32_t off_isect, n_tlas_nodes, pad;           // n_tlas_nodes: the first nodes of the array are the TLAS (the BLAS of the meshes follow)
+                           // off_isect: DTriIsect[n_tris], what the triangle test reads   // off_flat: DFlatObject[n_objects] of a rectangle-only scene of at most kFlatObjects objects, else 0
 };
 static_assert(sizeof(BlobHeader) == 80, "BlobHeader");
 // One top-level object of a small rectangle-only scene as trace_flat (dtof_traverse.h) reads it with ONE scalar load: a plain rectangle's
@@ -49,7 +50,7 @@ constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kNoChild = 0xffffffffu;
 // BLAS (per triangle mesh, nodes appended to the same array): a leaf is kLeafFlag | (first triangle, relative to the mesh's
 // first_tri) << kBlasLeafBits | (count - 1); meshes of at most kBlasMinTris triangles are looped over instead.
-constexpr uint32_t kBlasLeafBits = 3, kBlasLeaf = 4, kBlasMinTris = 16;   // a leaf can hold up to 1 << kBlasLeafBits triangles; the builder stops splitting at kBlasLeaf (DTOF_BLAS_LEAF=1..8 overrides: development)
+constexpr uint32_t kBlasLeafBits = 3, kBlasLeaf = 4, kBlasMinTris = 16;   // a leaf can hold up to 1 << kBlasLeafBits triangles; the builder stops splitting at kBlasLeaf (DTOF_BLAS_LEAF=2..8 overrides: development)
 // TLAS node (64 B): the bounds of BOTH children live in the parent, so one fetch decides both
 // descents.  child = kLeafFlag | object index for a leaf, inner-node index otherwise, kNoChild if absent.
 struct BvhNode {

@@ -233,14 +233,19 @@ DTOF_D bool box_hit(const float *bmin, const float *bmax, const SlabRay &r, floa
 // million triangles is 20-odd levels deep, a traversal rarely holds more than a dozen entries), so that 32 one-wave blocks fit a CU's LDS instead of 23.
 template <bool S16, uint32_t LDSN>
 DTOF_D void stack_put(uint32_t *stack, uint32_t *ovf, int sp, uint32_t stride, uint32_t x) {
-    if (LDSN != 0 && (uint32_t) sp >= LDSN) ovf[(uint32_t) sp - LDSN] = x;
-    else if (S16) ((uint16_t *) stack)[sp * stride] = (uint16_t) x;
+    // (LDSN: the empty asm keeps the two stores in their branches -- merged, they become ONE flat_store through a select of the scratch and the LDS address, and a flat
+    //  access goes through the texture-address unit these kernels saturate; round 5, read in the ISA of k_trace<false, true, 64, true>)
+    if (LDSN != 0 && (uint32_t) sp >= LDSN) { ovf[(uint32_t) sp - LDSN] = x; return; }
+    if (S16) ((uint16_t *) stack)[sp * stride] = (uint16_t) x;
     else stack[sp * stride] = x;
+    if (LDSN != 0) asm volatile("" : : "v"(x));   // BEHIND the store: the last instructions of the two branches differ, the stores are not sunk into one
 }
 template <bool S16, uint32_t LDSN>
 DTOF_D uint32_t stack_get(const uint32_t *stack, const uint32_t *ovf, int sp, uint32_t stride) {
     if (LDSN != 0 && (uint32_t) sp >= LDSN) return ovf[(uint32_t) sp - LDSN];
-    return S16 ? (uint32_t) ((const uint16_t *) stack)[sp * stride] : stack[sp * stride];
+    uint32_t x = S16 ? (uint32_t) ((const uint16_t *) stack)[sp * stride] : stack[sp * stride];
+    if (LDSN != 0) asm volatile("" : "+v"(x));   // (see stack_put: a ds_read in its own branch, not a flat_load)
+    return x;
 }
 // One traversal step at inner node `cur` = four 16-byte loads issued together (no load depends on a field of the node): continue with the nearest child that is
 // hit, push the other, pop when nothing is hit.  STRIDE: the stride of the per-thread stack columns when the kernel knows its block size (a shift instead of v_mul_lo_u32).
@@ -374,8 +379,8 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
 }
 
 // TLAS traversal; `stack` is a per-thread LDS column (stride blockDim.x).
-template <bool ANY, int MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0, bool S16 = false, uint32_t LDSN = 0>   // SOA: the TLAS nodes are the LDS planes of the resident stage (binary nodes only); STRIDE: the block size, if the kernel knows it; S16: 16-bit references / stack; LDSN: see stack_put
-DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best, uint32_t *ovf = nullptr) {
+template <bool ANY, int MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0, bool S16 = false, uint32_t LDSN = 0, bool TL = false>   // TL: `tlas` = a copy of the TLAS nodes in LDS (the BLAS stay where sv.nodes points); SOA: the TLAS nodes are the LDS planes of the resident stage (binary nodes only); STRIDE: the block size, if the kernel knows it; S16: 16-bit references / stack; LDSN: see stack_put
+DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best, uint32_t *ovf = nullptr, const BvhNode *tlas = nullptr) {
     best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
     if (sv.n_nodes == 0) return false;
     const SlabRay r = slab_ray(o, d);
@@ -390,7 +395,7 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
     for (;;) {
         while (!(cur & kLeaf) && cur != kDone) {
             DTOF_STAT(1); DTOF_STAT_WAVE(2);
-            cur = node_step<SOA, STRIDE, S16, LDSN>(sv.nodes, cur, r, best.t, stack, sp, 0, stride, kDone, ovf);
+            cur = node_step<SOA, STRIDE, S16, LDSN>(TL ? tlas : sv.nodes, cur, r, best.t, stack, sp, 0, stride, kDone, ovf);
         }
         if (cur == kDone) break;
         DTOF_STAT(3); DTOF_STAT_WAVE(4);
@@ -406,10 +411,10 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
 // measured slower in round 3; it is parked as tools/experiments/r03_coop_triangles.patch with its numbers in profiles/r03_coop_triangles_ab.txt.)
 
 // Scene query of a kernel whose call site is wave-uniform; `active` says whether this lane has a ray.
-template <bool ANY, int MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0, uint32_t LDSN = 0>
-DTOF_D bool trace_rays(const SceneView &sv, uint32_t *stack, bool active, V3 o, V3 d, float time, float maxt, Hit &best, uint32_t *ovf = nullptr) {
+template <bool ANY, int MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0, uint32_t LDSN = 0, bool TL = false>
+DTOF_D bool trace_rays(const SceneView &sv, uint32_t *stack, bool active, V3 o, V3 d, float time, float maxt, Hit &best, uint32_t *ovf = nullptr, const BvhNode *tlas = nullptr) {
     bool r = false;
-    if (active) r = trace_scene<ANY, MESH, MEMO, SOA, STRIDE, false, LDSN>(sv, stack, o, d, time, maxt, best, ovf);
+    if (active) r = trace_scene<ANY, MESH, MEMO, SOA, STRIDE, false, LDSN, TL>(sv, stack, o, d, time, maxt, best, ovf, tlas);
     return r;
 }
 

@@ -135,8 +135,8 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     std::vector<BvhNode> blas_nodes; uint32_t blas_depth = 0;
     std::vector<uint32_t> tables;   // mesh emitters: cdf[n] | pmf[n] (float bits) | slot[n]; roughplastic: 64 transmittances
     const char *blas_env = getenv("DTOF_BLAS"); const bool use_blas = !(blas_env && blas_env[0] == '0');   // DTOF_BLAS=0: loop over every triangle (debug)
-    uint32_t blas_leaf = kBlasLeaf;                           // DTOF_BLAS_LEAF=1..8: triangles per BLAS leaf (development: the hits do not depend on it)
-    if (const char *e = getenv("DTOF_BLAS_LEAF")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= (long) (1u << kBlasLeafBits)) blas_leaf = (uint32_t) v; }
+    uint32_t blas_leaf = kBlasLeaf;                           // DTOF_BLAS_LEAF=2..8: triangles per BLAS leaf (development: the hits do not depend on it)
+    if (const char *e = getenv("DTOF_BLAS_LEAF")) { const long v = strtol(e, nullptr, 10); if (v >= 2 && v <= (long) (1u << kBlasLeafBits)) blas_leaf = (uint32_t) v; }   // (max_leaf == 1 is the builder's TLAS form)
     std::vector<Box> shape_boxes(sc.shapes.size());
     struct TexUse { uint32_t shape, slot, rec; };           // slot: 0 reflectance (rides in `nonlinear`), 1 specular_reflectance, 2 specular_transmittance, 3 alpha_u, 4 alpha_v
     std::vector<TexUse> tex_recs;                          // rec: word offset of the DTexture in `tables`
@@ -454,7 +454,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     }
     // ---- pack: nodes first (so that "the first N bytes" = header + top of the TLAS in BFS-ish order)
     BlobHeader h; memset(&h, 0, sizeof h);
-    h.n_nodes = (uint32_t) dev_nodes.size(); h.n_objects = (uint32_t) objects.size(); h.n_groups = (uint32_t) groups.size();
+    h.n_nodes = (uint32_t) dev_nodes.size(); h.n_tlas_nodes = tlas_nodes; h.n_objects = (uint32_t) objects.size(); h.n_groups = (uint32_t) groups.size();
     {   // blendbsdf: one material-only record per blended shape, behind the real shapes (groups and objects index the real ones only)
         const size_t n_real = sc.shapes.size();
         for (size_t i = 0; i < n_real; ++i) if (sc.shapes[i].blend_other) {
