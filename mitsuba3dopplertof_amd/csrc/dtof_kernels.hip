@@ -63,10 +63,10 @@ DTOF_D uint32_t xcd_remap(uint32_t orig, uint32_t n, uint32_t run) {
     const uint32_t g = orig / group, w = orig - g * group, xcd = w & 7u, k = w >> 3;   // within a group: block w runs on XCD w % 8 and is that XCD's k-th block
     return g * group + xcd * run + k;
 }
-template <bool LDS, bool MESH, int BLOCK, bool W8 = false, bool TL = false>
+template <bool LDS, bool MESH, int BLOCK, bool W8 = false, bool TL = false, bool H16 = false>
 __global__ __launch_bounds__(BLOCK, W8 ? 8 : BLOCK == 64 ? 6 : 1) void k_trace(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words,
                                                  Queues q, const uint32_t *qin, const uint32_t *count_in, uint32_t n_lanes, uint32_t n_tlas) {
-    static_assert(!TL || W8, "the TLAS copy sits behind the eight-wave kernels' stack column");
+    static_assert((!TL && !H16) || W8, "the TLAS copy sits behind the eight-wave kernels' stack column; the half-float nodes are theirs too");
     static_assert(!W8 || (!LDS && MESH && BLOCK == 64), "the eight-wave form exists for the unstaged one-wave kernels with triangle code");
     constexpr uint32_t kBlock = BLOCK, kSub = kSeg / BLOCK;
     extern __shared__ uint4 lds[];
@@ -90,12 +90,12 @@ __global__ __launch_bounds__(BLOCK, W8 ? 8 : BLOCK == 64 ? 6 : 1) void k_trace(c
     if (active) { l = qin ? qin[seg * kSeg + j] : seg * kSeg + j; a = q.ray_a[l]; b = q.ray_b[l]; }
     Hit h;
     uint32_t ovf[W8 ? kOvfStack8 : 1];
-    bool found = trace_rays<false, W8 ? 2 : (MESH ? 1 : 0), false, false, BLOCK, W8 ? kLdsStack8 : 0u, TL>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h, ovf, tlas);
+    bool found = trace_rays<false, W8 ? 2 : (MESH ? 1 : 0), false, false, BLOCK, W8 ? kLdsStack8 : 0u, TL, H16>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h, ovf, tlas);
     if (active) store_hit<MESH>(q, l, h, found);
 }
 
 // ---------------------------------------------------------------------------- shadow
-template <bool LDS, bool MESH, int BLOCK, bool W8 = false, bool TL = false>
+template <bool LDS, bool MESH, int BLOCK, bool W8 = false, bool TL = false, bool H16 = false>
 __global__ __launch_bounds__(BLOCK, W8 ? 8 : BLOCK == 64 ? 6 : 1) void k_shadow(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp,
                                                   Queues q, const uint32_t *count_in, uint32_t n_tlas) {
     constexpr uint32_t kBlock = BLOCK, kSub = kSeg / BLOCK;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(BLOCK, W8 ? 8 : BLOCK == 64 ? 6 : 1) void k_shadow(
     if (active) { a = q.sh_a[i]; b = q.sh_b[i]; }
     Hit h;
     uint32_t ovf[W8 ? kOvfStack8 : 1];
-    bool occluded = trace_rays<true, W8 ? 2 : (MESH ? 1 : 0), false, false, BLOCK, W8 ? kLdsStack8 : 0u, TL>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h, ovf, tlas);
+    bool occluded = trace_rays<true, W8 ? 2 : (MESH ? 1 : 0), false, false, BLOCK, W8 ? kLdsStack8 : 0u, TL, H16>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h, ovf, tlas);
     if (active && !occluded) {
 #pragma unroll
         for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) {
@@ -493,6 +493,10 @@ static inline uint32_t xcd_run(const RenderParams &rp, uint32_t stage_words, uin
     const uint64_t row_blocks = (uint64_t) rp.crop_w * rp.spp / block;
     return (uint32_t) (row_blocks >= 8 && row_blocks <= (1u << 20) ? row_blocks : 0);
 }
+static inline bool half_nodes(const RenderParams &rp) {   // DTOF_NODES16=0: the 64-byte float nodes (A/B, tests)
+    const char *e = getenv("DTOF_NODES16"); const bool off = e && e[0] == '0';
+    return !off && rp.has_nodes16;
+}
 static inline bool tlas_in_lds(const RenderParams &rp) {   // DTOF_TLAS_LDS=0: the TLAS is walked in global memory like the BLAS (A/B, tests)
     const char *e = getenv("DTOF_TLAS_LDS"); const bool off = e && e[0] == '0';
     return !off && rp.n_tlas_nodes != 0 && rp.n_tlas_nodes <= kTlasLds8;
@@ -540,12 +544,14 @@ void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
                   const uint32_t *qin, const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
     const uint32_t sw = stage_words_for(scene_bytes, stack_bytes(stack_depth)), block = sw ? kBlock : unstaged_block(rp);
-    const bool w8 = eight_wave_rays(rp, sw, block, stack_depth), tl = w8 && tlas_in_lds(rp);
+    const bool w8 = eight_wave_rays(rp, sw, block, stack_depth), tl = w8 && tlas_in_lds(rp), h16 = w8 && half_nodes(rp);
     const uint32_t lds = sw * 16 + stack_bytes(w8 ? kLdsStack8 : stack_depth, block) + (tl ? kTlasLds8 * 64u : 0u), grid = nseg(rp.n_lanes) * (kSeg / block);
     check_lds(lds);
     Queues qx = q; qx.xcd_remap = xcd_run(rp, sw, block);
 #define DTOF_LAUNCH_TRACE(L, M, B) hipLaunchKernelGGL((k_trace<L, M, B>), dim3(grid), dim3(B), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes, 0u)
-    if (tl) hipLaunchKernelGGL((k_trace<false, true, 64, true, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes, rp.n_tlas_nodes);
+    if (w8 && h16) { if (tl) hipLaunchKernelGGL((k_trace<false, true, 64, true, true, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes, rp.n_tlas_nodes);
+                     else hipLaunchKernelGGL((k_trace<false, true, 64, true, false, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes, 0u); }
+    else if (tl) hipLaunchKernelGGL((k_trace<false, true, 64, true, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes, rp.n_tlas_nodes);
     else if (w8) hipLaunchKernelGGL((k_trace<false, true, 64, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes, 0u);
     else if (sw) { if (rp.has_tris) DTOF_LAUNCH_TRACE(true, true, kBlock); else DTOF_LAUNCH_TRACE(true, false, kBlock); }
     else if (block == 64)  { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true, 64); else DTOF_LAUNCH_TRACE(false, false, 64); }
@@ -608,12 +614,14 @@ void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParam
                    const uint32_t *count_in, uint32_t stack_depth, hipStream_t s) {
     if (rp.n_lanes == 0) return;
     const uint32_t sw = stage_words_for(scene_bytes, stack_bytes(stack_depth)), block = sw ? kBlock : unstaged_block(rp);
-    const bool w8 = eight_wave_rays(rp, sw, block, stack_depth), tl = w8 && tlas_in_lds(rp);
+    const bool w8 = eight_wave_rays(rp, sw, block, stack_depth), tl = w8 && tlas_in_lds(rp), h16 = w8 && half_nodes(rp);
     const uint32_t lds = sw * 16 + stack_bytes(w8 ? kLdsStack8 : stack_depth, block) + (tl ? kTlasLds8 * 64u : 0u), grid = nseg(rp.n_lanes) * (kSeg / block);
     check_lds(lds);
     Queues qx = q; qx.xcd_remap = xcd_run(rp, sw, block);
 #define DTOF_LAUNCH_SHADOW(L, M, B) hipLaunchKernelGGL((k_shadow<L, M, B>), dim3(grid), dim3(B), lds, s, scene, scene_bytes, sw, rp, qx, count_in, 0u)
-    if (tl) hipLaunchKernelGGL((k_shadow<false, true, 64, true, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, rp, qx, count_in, rp.n_tlas_nodes);
+    if (w8 && h16) { if (tl) hipLaunchKernelGGL((k_shadow<false, true, 64, true, true, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, rp, qx, count_in, rp.n_tlas_nodes);
+                     else hipLaunchKernelGGL((k_shadow<false, true, 64, true, false, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, rp, qx, count_in, 0u); }
+    else if (tl) hipLaunchKernelGGL((k_shadow<false, true, 64, true, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, rp, qx, count_in, rp.n_tlas_nodes);
     else if (w8) hipLaunchKernelGGL((k_shadow<false, true, 64, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, rp, qx, count_in, 0u);
     else if (sw) { if (rp.has_tris) DTOF_LAUNCH_SHADOW(true, true, kBlock); else DTOF_LAUNCH_SHADOW(true, false, kBlock); }
     else if (block == 64)  { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true, 64); else DTOF_LAUNCH_SHADOW(false, false, 64); }

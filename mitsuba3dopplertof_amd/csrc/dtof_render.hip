@@ -428,7 +428,7 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
     rp.has_analytic = has_spheres ? 1 : 0;
     {   // deep per-mesh traversals diverge: see unstaged_block() in dtof_kernels.hip
         const DShape *dshapes = (const DShape *) (sc->blob.data() + bh->off_shapes);
-        rp.n_tlas_nodes = bh->n_tlas_nodes;
+        rp.n_tlas_nodes = bh->n_tlas_nodes; rp.has_nodes16 = bh->off_nodes16 != 0;
         for (uint32_t i = 0; i < bh->n_shapes; ++i) rp.has_blas |= dshapes[i].kind == SHAPE_MESH && dshapes[i].blas_root != kNoChild;
     }
     rp.memo_obj = 0xffffffffu;

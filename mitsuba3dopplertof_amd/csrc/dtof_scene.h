@@ -33,7 +33,7 @@ struct BlobHeader {
     uint32_t n_nodes, n_objects, n_groups, n_shapes, n_tris, n_emitters;
     uint32_t off_nodes, off_objects, off_groups, off_shapes, off_tris, off_shading, off_emitters;
     uint32_t total_bytes, off_tables, tlas_depth, off_flat;      // off_tables: face distributions of mesh emitters (float / uint32 words)   // tlas_depth: stack entries a traversal can need (TLAS depth + deepest BLAS)
-    uint32_t off_isect, n_tlas_nodes, pad;           // n_tlas_nodes: the first nodes of the array are the TLAS (the BLAS of the meshes follow)
+    uint32_t off_isect, n_tlas_nodes, off_nodes16;   // off_nodes16: DNode16[n_nodes] of scenes with a BLAS (0: none), see below;           // n_tlas_nodes: the first nodes of the array are the TLAS (the BLAS of the meshes follow)
                            // off_isect: DTriIsect[n_tris], what the triangle test reads   // off_flat: DFlatObject[n_objects] of a rectangle-only scene of at most kFlatObjects objects, else 0
 };
 static_assert(sizeof(BlobHeader) == 80, "BlobHeader");
@@ -59,6 +59,12 @@ struct BvhNode {
     float rmin[3]; uint32_t pad0;
     float rmax[3]; uint32_t pad1;
 };
+// The same tree in 32 bytes per node for the ray kernels of large meshes (k_trace / k_shadow<..., W8>, which saturate the texture-address / data path: a node step is then
+// TWO 16-byte loads per lane instead of four): the child boxes as IEEE half floats, minima rounded DOWN and maxima rounded UP on the host (scene_build.cpp), so that a
+// half box contains its float box.  The boxes only cull -- which primitive is hit, and where, is decided by the primitive tests on the full-precision records -- so the
+// results do not change; the looser boxes cost a few more node steps.  Written only when every coordinate fits a half (|x| <= 65 000); the kernels fall back to DNode otherwise.
+struct DNode16 { uint16_t lbox[6]; uint32_t left; uint16_t rbox[6]; uint32_t right; };   // lbox / rbox: min x y z, max x y z
+static_assert(sizeof(DNode16) == 32, "DNode16");
 typedef BvhNode DNode;   // (a quantised 4-wide node format was measured slower in round 3: tools/experiments/r03_bvh4.patch, profiles/r03_qbvh4_vs_bvh2.txt)
 struct DObject {            // 128 B
     uint32_t kind, index, n_keys; float t0;

@@ -13,7 +13,7 @@ namespace dtof {
 
 // ---------------------------------------------------------------------------- scene view
 struct SceneView {
-    const DNode *nodes; const DObject *objects; const DGroup *groups; const DShape *shapes;
+    const DNode *nodes; const DNode16 *nodes16; const DObject *objects; const DGroup *groups; const DShape *shapes;
     const DTri *tris; const DTriIsect *isect; const DTriShade *shading; const DEmitter *emitters; const uint8_t *base;
     uint32_t n_nodes, n_emitters;
     // Fused shade kernels, scenes with ONE instance object: the world -> object matrix of that instance at the lane's ray time is
@@ -38,6 +38,7 @@ DTOF_D SceneView make_view(const uint8_t *base) {
     const BlobHeader *h = (const BlobHeader *) base;
     SceneView v;
     v.nodes = (const DNode *) (base + h->off_nodes);
+    v.nodes16 = (const DNode16 *) (base + h->off_nodes16);   // (meaningful where off_nodes16 != 0: the launch picks the kernels that read it)
     v.objects = (const DObject *) (base + h->off_objects);
     v.groups = (const DGroup *) (base + h->off_groups);
     v.shapes = (const DShape *) (base + h->off_shapes);
@@ -249,9 +250,31 @@ DTOF_D uint32_t stack_get(const uint32_t *stack, const uint32_t *ovf, int sp, ui
 }
 // One traversal step at inner node `cur` = four 16-byte loads issued together (no load depends on a field of the node): continue with the nearest child that is
 // hit, push the other, pop when nothing is hit.  STRIDE: the stride of the per-thread stack columns when the kernel knows its block size (a shift instead of v_mul_lo_u32).
-template <bool SOA = false, uint32_t STRIDE = 0, bool S16 = false, uint32_t LDSN = 0>   // S16: 16-bit child references and stack entries (the resident kernels of several films); LDSN: LDS entries before the overflow
+DTOF_D float half_lo(uint32_t w) { return (float) __builtin_bit_cast(_Float16, (uint16_t) (w & 0xffffu)); }
+DTOF_D float half_hi(uint32_t w) { return (float) __builtin_bit_cast(_Float16, (uint16_t) (w >> 16)); }
+template <bool SOA = false, uint32_t STRIDE = 0, bool S16 = false, uint32_t LDSN = 0, bool H16 = false>   // S16: 16-bit child references and stack entries (the resident kernels of several films); LDSN: LDS entries before the overflow; H16: `nodes` points at DNode16 records (half-float boxes: two loads)
 DTOF_D uint32_t node_step(const BvhNode *nodes, uint32_t cur, const SlabRay &r, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride_rt, uint32_t done, uint32_t *ovf = nullptr) {
     const uint32_t stride = STRIDE ? STRIDE : stride_rt;
+    if (H16) {
+        const uint4 *np = (const uint4 *) ((const DNode16 *) nodes + cur);
+        const uint4 a = np[0], b = np[1];
+        const float lmin[3] = { half_lo(a.x), half_hi(a.x), half_lo(a.y) }, lmax[3] = { half_hi(a.y), half_lo(a.z), half_hi(a.z) };
+        const float rmin[3] = { half_lo(b.x), half_hi(b.x), half_lo(b.y) }, rmax[3] = { half_hi(b.y), half_lo(b.z), half_hi(b.z) };
+        const uint32_t left = a.w, right = b.w;
+        float tl, tr;
+        const bool hl = box_hit(lmin, lmax, r, tbest, tl);
+        const bool hr = (int) box_hit(rmin, rmax, r, tbest, tr) & (int) (right != kNoChild);
+        if (hl && hr) {
+            const bool left_first = tl <= tr;
+            stack_put<S16, LDSN>(stack, ovf, sp, stride, left_first ? right : left);
+            ++sp;
+            return left_first ? left : right;
+        }
+        if (hl) return left;
+        if (hr) return right;
+        if (sp == sp_floor) return done;
+        --sp; return stack_get<S16, LDSN>(stack, ovf, sp, stride);
+    }
     const uint4 *np = SOA ? (const uint4 *) nodes + cur : (const uint4 *) (nodes + cur);
     const uint4 a = np[0], b = np[SOA ? kResNodes : 1], c = np[SOA ? 2 * kResNodes : 2], d = np[SOA ? 3 * kResNodes : 3];
     const float lmin[3] = { u2f(a.x), u2f(a.y), u2f(a.z) }, lmax[3] = { u2f(b.x), u2f(b.y), u2f(b.z) };
@@ -277,7 +300,7 @@ DTOF_D uint32_t node_step(const BvhNode *nodes, uint32_t cur, const SlabRay &r, 
 // (object, shape, face) -- the rule the oracle uses, independent of traversal order.
 // `stack + sp * stride` onwards is free for the BLAS traversal of a mesh.
 // MESH: 0 = rectangles only, 1 = every shape, 2 = rectangles and triangle meshes (scenes without analytic shapes: no float64 sphere / cylinder code, fewer registers).
-template <bool ANY, int MESH, bool MEMO = false, uint32_t STRIDE = 0, bool NOBLAS = false, uint32_t LDSN = 0>   // NOBLAS: the resident kernels (no mesh behind a BLAS; their stack columns are 16-bit)
+template <bool ANY, int MESH, bool MEMO = false, uint32_t STRIDE = 0, bool NOBLAS = false, uint32_t LDSN = 0, bool H16 = false>   // H16: the BLAS are walked through sv.nodes16; NOBLAS: the resident kernels (no mesh behind a BLAS; their stack columns are 16-bit)
 DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float time, float maxt, Hit &best,
                              uint32_t *stack, int sp, uint32_t stride, uint32_t *ovf = nullptr) {
     const DObject &ob = sv.objects[oi];
@@ -366,7 +389,7 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
         for (;;) {
             while (!(cur & kLeafFlag) && cur != kDone) {
                 DTOF_STAT(7);
-                cur = node_step<false, STRIDE, false, LDSN>(sv.nodes, cur, lr, ANY ? maxt : best.t, stack, bsp, sp, stride, kDone, ovf);
+                cur = node_step<false, STRIDE, false, LDSN, H16>(H16 ? (const BvhNode *) sv.nodes16 : sv.nodes, cur, lr, ANY ? maxt : best.t, stack, bsp, sp, stride, kDone, ovf);
             }
             if (cur == kDone) break;
             uint32_t f0 = (cur & ~kLeafFlag) >> kBlasLeafBits, fn = (cur & ((1u << kBlasLeafBits) - 1u)) + 1u;
@@ -379,7 +402,7 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
 }
 
 // TLAS traversal; `stack` is a per-thread LDS column (stride blockDim.x).
-template <bool ANY, int MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0, bool S16 = false, uint32_t LDSN = 0, bool TL = false>   // TL: `tlas` = a copy of the TLAS nodes in LDS (the BLAS stay where sv.nodes points); SOA: the TLAS nodes are the LDS planes of the resident stage (binary nodes only); STRIDE: the block size, if the kernel knows it; S16: 16-bit references / stack; LDSN: see stack_put
+template <bool ANY, int MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0, bool S16 = false, uint32_t LDSN = 0, bool TL = false, bool H16 = false>   // H16: nodes read from sv.nodes16 (the TLAS too, unless TL); TL: `tlas` = a copy of the TLAS nodes in LDS (the BLAS stay where sv.nodes points); SOA: the TLAS nodes are the LDS planes of the resident stage (binary nodes only); STRIDE: the block size, if the kernel knows it; S16: 16-bit references / stack; LDSN: see stack_put
 DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best, uint32_t *ovf = nullptr, const BvhNode *tlas = nullptr) {
     best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
     if (sv.n_nodes == 0) return false;
@@ -395,11 +418,12 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
     for (;;) {
         while (!(cur & kLeaf) && cur != kDone) {
             DTOF_STAT(1); DTOF_STAT_WAVE(2);
-            cur = node_step<SOA, STRIDE, S16, LDSN>(TL ? tlas : sv.nodes, cur, r, best.t, stack, sp, 0, stride, kDone, ovf);
+            cur = TL ? node_step<SOA, STRIDE, S16, LDSN>(tlas, cur, r, best.t, stack, sp, 0, stride, kDone, ovf)
+                     : node_step<SOA, STRIDE, S16, LDSN, H16>(H16 ? (const BvhNode *) sv.nodes16 : sv.nodes, cur, r, best.t, stack, sp, 0, stride, kDone, ovf);
         }
         if (cur == kDone) break;
         DTOF_STAT(3); DTOF_STAT_WAVE(4);
-        if (intersect_object<ANY, MESH, MEMO, STRIDE, S16, LDSN>(sv, cur & ~kLeaf & (S16 ? 0xffffu : 0xffffffffu), o, d, time, maxt, best, stack, sp, stride, ovf) && ANY) return true;
+        if (intersect_object<ANY, MESH, MEMO, STRIDE, S16, LDSN, H16>(sv, cur & ~kLeaf & (S16 ? 0xffffu : 0xffffffffu), o, d, time, maxt, best, stack, sp, stride, ovf) && ANY) return true;
         if (sp == 0) break;
         --sp; cur = stack_get<S16, LDSN>(stack, ovf, sp, stride);
     }
@@ -411,10 +435,10 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
 // measured slower in round 3; it is parked as tools/experiments/r03_coop_triangles.patch with its numbers in profiles/r03_coop_triangles_ab.txt.)
 
 // Scene query of a kernel whose call site is wave-uniform; `active` says whether this lane has a ray.
-template <bool ANY, int MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0, uint32_t LDSN = 0, bool TL = false>
+template <bool ANY, int MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0, uint32_t LDSN = 0, bool TL = false, bool H16 = false>
 DTOF_D bool trace_rays(const SceneView &sv, uint32_t *stack, bool active, V3 o, V3 d, float time, float maxt, Hit &best, uint32_t *ovf = nullptr, const BvhNode *tlas = nullptr) {
     bool r = false;
-    if (active) r = trace_scene<ANY, MESH, MEMO, SOA, STRIDE, false, LDSN, TL>(sv, stack, o, d, time, maxt, best, ovf, tlas);
+    if (active) r = trace_scene<ANY, MESH, MEMO, SOA, STRIDE, false, LDSN, TL, H16>(sv, stack, o, d, time, maxt, best, ovf, tlas);
     return r;
 }
 

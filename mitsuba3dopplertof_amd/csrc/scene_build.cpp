@@ -124,6 +124,24 @@ static uint32_t build_node(BuildCtx &cx, size_t b, size_t e) {
 
 
 
+// IEEE binary16 bits of the nearest half BELOW (up = false) or ABOVE (up = true) a float of magnitude <= 65 000 (exact values map to themselves): the float is
+// truncated to 10 fraction bits (toward zero) and stepped one half away from zero where truncation went the wrong way; halves below 2^-14 are subnormal.
+static uint16_t half_toward(float x, bool up) {
+    if (x == 0.f) return 0;
+    const bool neg = x < 0.f; const float a = std::fabs(x);
+    uint32_t bits;                                   // magnitude, rounded toward zero
+    bool exact;
+    if (a < 6.103515625e-5f) {                       // below 2^-14: multiples of 2^-24
+        const float q = a * 16777216.f; const uint32_t m = (uint32_t) q; bits = m; exact = (float) m == q;
+    } else {
+        uint32_t u; memcpy(&u, &a, 4);
+        const uint32_t e = (u >> 23) - 127 + 15, m = (u >> 13) & 0x3ffu;
+        bits = (e << 10) | m; exact = (u & 0x1fffu) == 0;
+    }
+    const bool away = neg != up;                     // up && positive, or down && negative: the magnitude has to grow
+    if (!exact && away) ++bits;                      // (a carry out of the fraction moves into the exponent: still the next half)
+    return (uint16_t) (bits | (neg ? 0x8000u : 0u));
+}
 static Box tri_box(const DTri &t) {
     Box b; b.add(mk(t.p0[0], t.p0[1], t.p0[2])); b.add(mk(t.p1[0], t.p1[1], t.p1[2])); b.add(mk(t.p2[0], t.p2[1], t.p2[2])); return b;
 }
@@ -491,6 +509,27 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     }
     h.off_isect = place(isect.size() * sizeof(DTriIsect));
     h.off_tables = place((uint64_t) tables.size() * 4);
+    std::vector<DNode16> nodes16;   // scenes with a BLAS: the half-float copy of the node array (dtof_scene.h)
+    if (!blas_nodes.empty()) {
+        bool fits = true;
+        for (const BvhNode &n : dev_nodes) for (int i = 0; i < 3; ++i) {
+            fits &= std::fabs(n.lmin[i]) <= 65000.f && std::fabs(n.lmax[i]) <= 65000.f;
+            if (n.right != kNoChild) fits &= std::fabs(n.rmin[i]) <= 65000.f && std::fabs(n.rmax[i]) <= 65000.f;
+        }
+        if (fits) {
+            nodes16.resize(dev_nodes.size());
+            for (size_t i = 0; i < dev_nodes.size(); ++i) {
+                const BvhNode &n = dev_nodes[i]; DNode16 &o = nodes16[i];
+                const bool one = n.right == kNoChild;   // (a node with one child: its right box is never tested)
+                for (int k = 0; k < 3; ++k) {
+                    o.lbox[k] = half_toward(n.lmin[k], false); o.lbox[3 + k] = half_toward(n.lmax[k], true);
+                    o.rbox[k] = one ? 0 : half_toward(n.rmin[k], false); o.rbox[3 + k] = one ? 0 : half_toward(n.rmax[k], true);
+                }
+                o.left = n.left; o.right = n.right;
+            }
+        }
+    }
+    { const uint32_t at = place(nodes16.size() * sizeof(DNode16)); h.off_nodes16 = nodes16.empty() ? 0u : at; }
     std::vector<DFlatObject> flat;   // small rectangle-only scenes: one 64-byte record per object for trace_flat
     {
         bool ok = !objects.empty() && objects.size() <= kFlatObjects && tris.empty();
@@ -537,6 +576,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     if (!isect.empty()) memcpy(blob.data() + h.off_isect, isect.data(), isect.size() * sizeof(DTriIsect));
     if (!tables.empty()) memcpy(blob.data() + h.off_tables, tables.data(), tables.size() * 4);
     if (!flat.empty()) memcpy(blob.data() + h.off_flat, flat.data(), flat.size() * sizeof(DFlatObject));
+    if (!nodes16.empty()) memcpy(blob.data() + h.off_nodes16, nodes16.data(), nodes16.size() * sizeof(DNode16));
     return blob;
 }
 
