@@ -66,7 +66,8 @@ DTOF_D uint32_t xcd_remap(uint32_t orig, uint32_t n, uint32_t run) {
 template <bool LDS, bool MESH, int BLOCK, bool W8 = false, bool TL = false, bool H16 = false>
 __global__ __launch_bounds__(BLOCK, W8 ? 8 : BLOCK == 64 ? 6 : 1) void k_trace(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words,
                                                  Queues q, const uint32_t *qin, const uint32_t *count_in, uint32_t n_lanes, uint32_t n_tlas) {
-    static_assert((!TL && !H16) || W8, "the TLAS copy sits behind the eight-wave kernels' stack column; the half-float nodes are theirs too");
+    static_assert(!TL || W8, "the TLAS copy sits behind the eight-wave kernels' stack column");
+    static_assert(!H16 || (!LDS && MESH && BLOCK == 64), "half-float nodes: the unstaged one-wave kernels of scenes with a BLAS");
     static_assert(!W8 || (!LDS && MESH && BLOCK == 64), "the eight-wave form exists for the unstaged one-wave kernels with triangle code");
     constexpr uint32_t kBlock = BLOCK, kSub = kSeg / BLOCK;
     extern __shared__ uint4 lds[];
@@ -503,7 +504,7 @@ static inline bool tlas_in_lds(const RenderParams &rp) {   // DTOF_TLAS_LDS=0: t
 }
 static inline bool eight_wave_rays(const RenderParams &rp, uint32_t stage_words, uint32_t block, uint32_t stack_depth) {
     const char *e = getenv("DTOF_TRACE8"); const bool off = e && e[0] == '0';   // read per call (a few launches per frame): tests and A/B runs switch it inside one process
-    return !off && stage_words == 0 && block == 64 && rp.has_tris && rp.has_blas && !rp.has_analytic && !rp.has_spec && stack_depth <= kLdsStack8 + kOvfStack8;
+    return !off && stage_words == 0 && block == 64 && rp.has_tris && rp.has_blas && !rp.has_analytic && stack_depth <= kLdsStack8 + kOvfStack8;   // (whatever the materials: the ray kernels only intersect)
 }
 void launch_generate(const RenderParams &rp, const Queues &q, hipStream_t s) {
     if (rp.n_lanes == 0) return;
@@ -554,6 +555,8 @@ void launch_trace(const uint8_t *scene, uint32_t scene_bytes, const RenderParams
     else if (tl) hipLaunchKernelGGL((k_trace<false, true, 64, true, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes, rp.n_tlas_nodes);
     else if (w8) hipLaunchKernelGGL((k_trace<false, true, 64, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes, 0u);
     else if (sw) { if (rp.has_tris) DTOF_LAUNCH_TRACE(true, true, kBlock); else DTOF_LAUNCH_TRACE(true, false, kBlock); }
+    else if (block == 64 && rp.has_tris && rp.has_blas && half_nodes(rp))   // (a scene with a BLAS AND analytic shapes: six waves, every shape's code, half-float nodes)
+        hipLaunchKernelGGL((k_trace<false, true, 64, false, false, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, qx, qin, count_in, rp.n_lanes, 0u);
     else if (block == 64)  { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true, 64); else DTOF_LAUNCH_TRACE(false, false, 64); }
     else if (block == 128) { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true, 128); else DTOF_LAUNCH_TRACE(false, false, 128); }
     else                   { if (rp.has_tris) DTOF_LAUNCH_TRACE(false, true, kBlock); else DTOF_LAUNCH_TRACE(false, false, kBlock); }
@@ -624,6 +627,8 @@ void launch_shadow(const uint8_t *scene, uint32_t scene_bytes, const RenderParam
     else if (tl) hipLaunchKernelGGL((k_shadow<false, true, 64, true, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, rp, qx, count_in, rp.n_tlas_nodes);
     else if (w8) hipLaunchKernelGGL((k_shadow<false, true, 64, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, rp, qx, count_in, 0u);
     else if (sw) { if (rp.has_tris) DTOF_LAUNCH_SHADOW(true, true, kBlock); else DTOF_LAUNCH_SHADOW(true, false, kBlock); }
+    else if (block == 64 && rp.has_tris && rp.has_blas && half_nodes(rp))
+        hipLaunchKernelGGL((k_shadow<false, true, 64, false, false, true>), dim3(grid), dim3(64), lds, s, scene, scene_bytes, sw, rp, qx, count_in, 0u);
     else if (block == 64)  { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true, 64); else DTOF_LAUNCH_SHADOW(false, false, 64); }
     else if (block == 128) { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true, 128); else DTOF_LAUNCH_SHADOW(false, false, 128); }
     else                   { if (rp.has_tris) DTOF_LAUNCH_SHADOW(false, true, kBlock); else DTOF_LAUNCH_SHADOW(false, false, kBlock); }

@@ -230,6 +230,27 @@ def test_blas_equals_the_loop_over_all_triangles_on_a_large_mesh(mi, orc, tmp_pa
         assert np.abs(other.render(seed=5, spp=4) - img).max() <= 1e-6 * np.abs(img).max(), env
         for k in env:
             monkeypatch.delenv(k)
+    # ... and the same room with (a) a rough conductor panel -- an every-BSDF scene, whose rays take the same eight-wave kernels -- and (b) a sphere beside the blobs: a scene with a
+    # BLAS AND an analytic shape keeps the six-wave kernels with every shape's code, walking the half-float nodes too.  Each against the float nodes and the loop over all triangles.
+    extra = {"panel": '<shape type="rectangle"><transform name="to_world"><scale x="0.3" y="0.3"/><rotate y="1" angle="35"/><translate x="-0.55" y="1.2" z="0.2"/></transform>'
+                      '<bsdf type="roughconductor"><float name="alpha" value="0.15"/></bsdf></shape>',
+             "sphere": '<shape type="sphere"><point name="center" x="0.1" y="1.25" z="0.3"/><float name="radius" value="0.22"/>'
+                       '<bsdf type="diffuse"><rgb name="reflectance" value="0.6, 0.7, 0.5"/></bsdf></shape>'}
+    for name, shape in extra.items():
+        path = os.path.join(d, "s_%s.xml" % name)
+        open(path, "w").write(make_mesh.cornell_mesh_xml().replace("</scene>", shape + "</scene>"))
+        got = {}
+        for env in (dict(), dict(DTOF_NODES16="0"), dict(DTOF_BLAS="0")):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got[tuple(env)] = mi.load_file(path, **params).sample_lanes(5, 4, 0, n)
+            for k in env:
+                monkeypatch.delenv(k)
+        ref = got[()]
+        assert not np.array_equal(bits(ref["rgb"]), bits(a["rgb"])), name     # the extra shape is seen
+        for key, lanes in got.items():
+            for k in ref:
+                assert np.array_equal(bits(ref[k]), bits(lanes[k])), (name, key, k)
 
 
 # ------------------------------------------------------------------------------------------------ mesh area emitters
