@@ -8,6 +8,7 @@
 // its two end positions, so that union bounds the whole motion.
 #include "dtof_scene.h"
 #include "dtof_math.h"
+#include "dtof_half.h"
 #include <algorithm>
 #include <cstring>
 #include <cfloat>
@@ -124,24 +125,6 @@ static uint32_t build_node(BuildCtx &cx, size_t b, size_t e) {
 
 
 
-// IEEE binary16 bits of the nearest half BELOW (up = false) or ABOVE (up = true) a float of magnitude <= 65 000 (exact values map to themselves): the float is
-// truncated to 10 fraction bits (toward zero) and stepped one half away from zero where truncation went the wrong way; halves below 2^-14 are subnormal.
-static uint16_t half_toward(float x, bool up) {
-    if (x == 0.f) return 0;
-    const bool neg = x < 0.f; const float a = std::fabs(x);
-    uint32_t bits;                                   // magnitude, rounded toward zero
-    bool exact;
-    if (a < 6.103515625e-5f) {                       // below 2^-14: multiples of 2^-24
-        const float q = a * 16777216.f; const uint32_t m = (uint32_t) q; bits = m; exact = (float) m == q;
-    } else {
-        uint32_t u; memcpy(&u, &a, 4);
-        const uint32_t e = (u >> 23) - 127 + 15, m = (u >> 13) & 0x3ffu;
-        bits = (e << 10) | m; exact = (u & 0x1fffu) == 0;
-    }
-    const bool away = neg != up;                     // up && positive, or down && negative: the magnitude has to grow
-    if (!exact && away) ++bits;                      // (a carry out of the fraction moves into the exponent: still the next half)
-    return (uint16_t) (bits | (neg ? 0x8000u : 0u));
-}
 static Box tri_box(const DTri &t) {
     Box b; b.add(mk(t.p0[0], t.p0[1], t.p0[2])); b.add(mk(t.p1[0], t.p1[1], t.p1[2])); b.add(mk(t.p2[0], t.p2[1], t.p2[2])); return b;
 }

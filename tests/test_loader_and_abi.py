@@ -231,6 +231,57 @@ int main(int argc, char **argv) {
     assert (int(w), int(h), int(nobj)) == (40, 256, 7)
 
 
+def test_half_float_node_boxes_round_outward(tmp_path):
+    """DNode16 (round 5): the builder rounds a child box's minima DOWN and its maxima UP to IEEE halves (csrc/dtof_half.h), so that the half box contains the float box and the
+    hits of the ray kernels that walk it cannot change.  A C++ harness over 4 M random floats of every magnitude a box can have (|x| <= 65 000) plus the edge cases: the
+    result is on the right side, equal to x whenever x is a half, and TIGHT -- one half nearer to x is on the wrong side."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    src = tmp_path / "half.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include <random>
+#include "dtof_half.h"
+static double h2d(uint16_t h) {   // exact value of a binary16
+    const int e = (h >> 10) & 31, m = h & 1023; const double s = (h & 0x8000) ? -1.0 : 1.0;
+    return s * (e == 0 ? std::ldexp((double) m, -24) : std::ldexp((double) (1024 + m), e - 25));
+}
+static uint16_t next_up(uint16_t h) { return (h & 0x7fff) == 0 ? 0x0001 : (h & 0x8000) ? (uint16_t) (h - 1) : (uint16_t) (h + 1); }      // the next half above (towards +inf)
+static uint16_t next_down(uint16_t h) { return (h & 0x7fff) == 0 ? 0x8001 : (h & 0x8000) ? (uint16_t) (h + 1) : (uint16_t) (h - 1); }
+int main() {
+    std::mt19937 rng(7); long n = 0, bad = 0;
+    auto check = [&](float x) {
+        for (int up = 0; up < 2; ++up) {
+            const uint16_t h = dtof::half_toward(x, up); const double y = h2d(h); ++n;
+            if ((h & 0x7c00) == 0x7c00) { ++bad; continue; }                                  // never an infinity / NaN
+            if (up ? y < (double) x : y > (double) x) { ++bad; continue; }                     // the right side
+            if (y != (double) x) {                                                           // tight: the neighbouring half on x's side lies beyond x
+                const double z = h2d(up ? next_down(h) : next_up(h));
+                if (up ? z >= (double) x : z <= (double) x) ++bad;
+            }
+        }
+    };
+    for (int i = 0; i < 4000000; ++i) { uint32_t u = rng(); float x; memcpy(&x, &u, 4); if (std::fabs(x) <= 65000.f) check(x); }
+    for (int i = 0; i < 65536; ++i) { const uint16_t h = (uint16_t) i; if ((h & 0x7c00) == 0x7c00) continue; const float x = (float) h2d(h); if (std::fabs(x) <= 65000.f) { check(x); if (dtof::half_toward(x, false) != (x == 0.f ? 0 : h) || dtof::half_toward(x, true) != (x == 0.f ? 0 : h)) ++bad; } }
+    const float edge[] = { 0.f, -0.f, 1.f, -1.f, 65000.f, -65000.f, 6.1035156e-5f, 6.1e-5f, 5.9604645e-8f, 3e-8f, -3e-8f, 1e-30f, -1e-30f, 2047.9999f, 0.33333334f, 1.0004883f, 1.0004884f };
+    for (float x : edge) check(x);
+    printf("%ld %ld\n", n, bad);
+    return bad != 0;
+}
+''')
+    exe = tmp_path / "half"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "mitsuba3dopplertof_amd", "csrc"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    n, bad = (int(v) for v in out.stdout.split())
+    assert n > 1000000 and bad == 0
+
+
 def test_plugin_objects_validate_like_the_reference_constructors(mi):
     """dtof_integrator_create / dtof_sampler_plugin_create = PluginManager::create_object -> new T(props): unknown plugins,
     unknown or mistyped properties and out-of-range values fail at construction (no scene, no GPU involved)."""
