@@ -89,6 +89,9 @@ struct Queues {
     float4 *sh_c;        // [K][capacity] candidate result rgb, w = as_float(lane position)
     uint32_t *q[2];      // active-lane index queues (ping-pong), segmented: entry j of segment S at S*kSeg + j
     uint32_t *counts;    // [iteration][2][n_segments]: survivors / shadow rays per segment
+    uint4 *cand;         // DEFER (ray kernels of large meshes): up to four objects a ray's TLAS walk put aside, by lane (k_trace) / by shadow slot (k_shadow); nullptr = no second launch
+    uint32_t *defer_idx; // ... the lanes / shadow slots of a segment that have some, entry j of segment S at S*kSeg + j, and
+    uint32_t *defer_cnt; // ... how many (zeroed before each first launch)
     uint32_t *seg_counter;   // resident first-bounce kernel: next segment to hand out (zeroed before the launch)
     uint32_t capacity;
     uint32_t xcd_remap;  // unstaged ray kernels: XCD-aware block order (dtof_kernels.hip: xcd_remap); 0 = block b traces segment b

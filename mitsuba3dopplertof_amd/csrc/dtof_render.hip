@@ -68,8 +68,10 @@ struct Workspace {
     DevBuf<uint2> rng_b;
     DevBuf<LaneDebug> dbg;
     DevBuf<float4> valid;   // Queues::valid_out, only when asked for (ensure_valid)
+    DevBuf<uint4> cand; DevBuf<uint32_t> defer_idx, defer_cnt;   // Queues::cand / defer_idx / defer_cnt, only for scenes whose ray kernels run as a pair of launches (ensure_defer)
     uint32_t capacity = 0; int k = 0;
     void ensure_valid() { valid.ensure(capacity); }
+    void ensure_defer() { cand.ensure(capacity); defer_idx.ensure(capacity); defer_cnt.ensure(segments_for(capacity)); }
     void ensure(uint32_t cap, int n_offsets) {
         if (cap <= capacity && n_offsets <= k) return;
         capacity = std::max(cap, capacity); k = std::max(n_offsets, k);
@@ -430,6 +432,12 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         const DShape *dshapes = (const DShape *) (sc->blob.data() + bh->off_shapes);
         rp.n_tlas_nodes = bh->n_tlas_nodes; rp.has_nodes16 = bh->off_nodes16 != 0;
         for (uint32_t i = 0; i < bh->n_shapes; ++i) rp.has_blas |= dshapes[i].kind == SHAPE_MESH && dshapes[i].blas_root != kNoChild;
+        if (rp.has_blas && rp.has_nodes16 && !rp.has_analytic) {   // the eight-wave ray kernels of such scenes run as a pair of launches (dtof_kernels.hip: DEFER): 20 bytes per lane of lists
+            sc->ws.ensure_defer(); if (n_streams == 2) sc->ws2.ensure_defer();
+            Workspace &w1 = n_streams == 2 ? sc->ws2 : sc->ws;
+            qs[0].cand = sc->ws.cand.p; qs[0].defer_idx = sc->ws.defer_idx.p; qs[0].defer_cnt = sc->ws.defer_cnt.p;
+            qs[1].cand = w1.cand.p; qs[1].defer_idx = w1.defer_idx.p; qs[1].defer_cnt = w1.defer_cnt.p;
+        }
     }
     rp.memo_obj = 0xffffffffu;
     {   // instance memo (dtof_traverse.h): pays when there is exactly one instance object, which then nearly every ray visits

@@ -47,6 +47,9 @@ struct DFlatObject { float c0[3]; uint32_t instance; float c1[3]; uint32_t pad1;
 static_assert(sizeof(DFlatObject) == 64, "DFlatObject");
 
 constexpr uint32_t kLeafFlag = 0x80000000u;
+// TLAS leaves only: the object behind this leaf holds a mesh with a BLAS of its own (bit 30; the object index is the 30 bits below).  The ray kernels of large meshes can
+// put such objects aside for a second, dense launch instead of entering them (dtof_kernels.hip: DEFER).
+constexpr uint32_t kLeafBlas = 0x40000000u, kLeafObjMask = 0x3fffffffu;
 constexpr uint32_t kNoChild = 0xffffffffu;
 // BLAS (per triangle mesh, nodes appended to the same array): a leaf is kLeafFlag | (first triangle, relative to the mesh's
 // first_tri) << kBlasLeafBits | (count - 1); meshes of at most kBlasMinTris triangles are looped over instead.

@@ -388,7 +388,7 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
         uint32_t cur = sh.blas_root; int bsp = sp;
         for (;;) {
             while (!(cur & kLeafFlag) && cur != kDone) {
-                DTOF_STAT(7);
+                DTOF_STAT(7); DTOF_STAT_WAVE(15);
                 cur = node_step<false, STRIDE, false, LDSN, H16>(H16 ? (const BvhNode *) sv.nodes16 : sv.nodes, cur, lr, ANY ? maxt : best.t, stack, bsp, sp, stride, kDone, ovf);
             }
             if (cur == kDone) break;
@@ -402,8 +402,8 @@ DTOF_D bool intersect_object(const SceneView &sv, uint32_t oi, V3 o, V3 d, float
 }
 
 // TLAS traversal; `stack` is a per-thread LDS column (stride blockDim.x).
-template <bool ANY, int MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0, bool S16 = false, uint32_t LDSN = 0, bool TL = false, bool H16 = false>   // H16: nodes read from sv.nodes16 (the TLAS too, unless TL); TL: `tlas` = a copy of the TLAS nodes in LDS (the BLAS stay where sv.nodes points); SOA: the TLAS nodes are the LDS planes of the resident stage (binary nodes only); STRIDE: the block size, if the kernel knows it; S16: 16-bit references / stack; LDSN: see stack_put
-DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best, uint32_t *ovf = nullptr, const BvhNode *tlas = nullptr) {
+template <bool ANY, int MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0, bool S16 = false, uint32_t LDSN = 0, bool TL = false, bool H16 = false, bool DEFER = false>   // DEFER: objects whose TLAS leaf carries kLeafBlas are not entered -- their indices go to `cand` (up to four; a fifth is entered on the spot) for trace_deferred in a second, dense launch; H16: nodes read from sv.nodes16 (the TLAS too, unless TL); TL: `tlas` = a copy of the TLAS nodes in LDS (the BLAS stay where sv.nodes points); SOA: the TLAS nodes are the LDS planes of the resident stage (binary nodes only); STRIDE: the block size, if the kernel knows it; S16: 16-bit references / stack; LDSN: see stack_put
+DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float time, float maxt, Hit &best, uint32_t *ovf = nullptr, const BvhNode *tlas = nullptr, uint4 *cand = nullptr) {
     best.t = maxt; best.u = best.v = 0.f; best.obj = 0xffffffffu; best.shape = 0; best.prim = 0;
     if (sv.n_nodes == 0) return false;
     const SlabRay r = slab_ray(o, d);
@@ -423,7 +423,14 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
         }
         if (cur == kDone) break;
         DTOF_STAT(3); DTOF_STAT_WAVE(4);
-        if (intersect_object<ANY, MESH, MEMO, STRIDE, S16, LDSN, H16>(sv, cur & ~kLeaf & (S16 ? 0xffffu : 0xffffffffu), o, d, time, maxt, best, stack, sp, stride, ovf) && ANY) return true;
+        bool put_aside = false;
+        if (DEFER && (cur & kLeafBlas)) {   // a mesh behind a BLAS: later, with the other rays that reached one
+            const uint32_t oi = cur & kLeafObjMask;
+            put_aside = true;
+            if (cand->x == 0xffffffffu) cand->x = oi; else if (cand->y == 0xffffffffu) cand->y = oi; else if (cand->z == 0xffffffffu) cand->z = oi; else if (cand->w == 0xffffffffu) cand->w = oi;
+            else put_aside = false;
+        }
+        if (!put_aside && intersect_object<ANY, MESH, MEMO, STRIDE, S16, LDSN, H16>(sv, cur & ~kLeaf & (S16 ? 0xffffu : kLeafObjMask), o, d, time, maxt, best, stack, sp, stride, ovf) && ANY) return true;
         if (sp == 0) break;
         --sp; cur = stack_get<S16, LDSN>(stack, ovf, sp, stride);
     }
@@ -435,11 +442,24 @@ DTOF_D bool trace_scene(const SceneView &sv, uint32_t *stack, V3 o, V3 d, float 
 // measured slower in round 3; it is parked as tools/experiments/r03_coop_triangles.patch with its numbers in profiles/r03_coop_triangles_ab.txt.)
 
 // Scene query of a kernel whose call site is wave-uniform; `active` says whether this lane has a ray.
-template <bool ANY, int MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0, uint32_t LDSN = 0, bool TL = false, bool H16 = false>
-DTOF_D bool trace_rays(const SceneView &sv, uint32_t *stack, bool active, V3 o, V3 d, float time, float maxt, Hit &best, uint32_t *ovf = nullptr, const BvhNode *tlas = nullptr) {
+template <bool ANY, int MESH, bool MEMO = false, bool SOA = false, uint32_t STRIDE = 0, uint32_t LDSN = 0, bool TL = false, bool H16 = false, bool DEFER = false>
+DTOF_D bool trace_rays(const SceneView &sv, uint32_t *stack, bool active, V3 o, V3 d, float time, float maxt, Hit &best, uint32_t *ovf = nullptr, const BvhNode *tlas = nullptr, uint4 *cand = nullptr) {
     bool r = false;
-    if (active) r = trace_scene<ANY, MESH, MEMO, SOA, STRIDE, false, LDSN, TL, H16>(sv, stack, o, d, time, maxt, best, ovf, tlas);
+    if (active) r = trace_scene<ANY, MESH, MEMO, SOA, STRIDE, false, LDSN, TL, H16, DEFER>(sv, stack, o, d, time, maxt, best, ovf, tlas, cand);
     return r;
+}
+// The second launch of a DEFER pair: the objects a ray's TLAS walk put aside, entered one after the other with the hit the first launch found (closest hit: `best` as it
+// stands, its distance culls; occlusion: any hit ends the ray).  Every lane of the launch has at least one such object: the BLAS walks run with full waves.
+template <bool ANY, int MESH, uint32_t STRIDE, uint32_t LDSN, bool H16>
+DTOF_D bool trace_deferred(const SceneView &sv, uint32_t *stack, uint4 cand, V3 o, V3 d, float time, float maxt, Hit &best, uint32_t *ovf) {
+    const uint32_t stride = STRIDE ? STRIDE : blockDim.x;
+    const uint32_t c[4] = { cand.x, cand.y, cand.z, cand.w };
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+        if (c[i] == 0xffffffffu) break;
+        if (intersect_object<ANY, MESH, false, STRIDE, false, LDSN, H16>(sv, c[i], o, d, time, maxt, best, stack, 0, stride, ovf) && ANY) return true;
+    }
+    return best.obj != 0xffffffffu;
 }
 
 

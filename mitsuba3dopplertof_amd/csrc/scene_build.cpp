@@ -354,6 +354,19 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
         build_node(cx, 0, items.size());
     }
     const uint32_t tlas_nodes = (uint32_t) nodes.size();
+    {   // TLAS leaves of objects that hold a mesh behind a BLAS carry kLeafBlas
+        if (objects.size() > kLeafObjMask) throw std::runtime_error("more top-level objects than a TLAS leaf reference addresses");
+        auto object_has_blas = [&](uint32_t oi) {
+            const DObject &ob = objects[oi];
+            uint32_t first = ob.index, count = 1;
+            if (ob.kind == OBJ_INSTANCE) { first = groups[ob.index].first_shape; count = groups[ob.index].n_shapes; }
+            for (uint32_t k = 0; k < count; ++k) if (shapes[first + k].kind == SHAPE_MESH && shapes[first + k].blas_root != kNoChild) return true;
+            return false;
+        };
+        for (BvhNode &n : nodes)
+            for (uint32_t *c : { &n.left, &n.right })
+                if (*c != kNoChild && (*c & kLeafFlag) && object_has_blas(*c & kLeafObjMask)) *c |= kLeafBlas;
+    }
     for (BvhNode n : blas_nodes) {   // BLAS node indices (children and roots) move behind the TLAS
         if (n.left != kNoChild && !(n.left & kLeafFlag)) n.left += tlas_nodes;
         if (n.right != kNoChild && !(n.right & kLeafFlag)) n.right += tlas_nodes;

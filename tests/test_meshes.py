@@ -220,7 +220,7 @@ def test_blas_equals_the_loop_over_all_triangles_on_a_large_mesh(mi, orc, tmp_pa
     assert info["bvh_stack_depth"] > 16
     img = sc.render(seed=5, spp=4)
     for env in (dict(DTOF_TRACE8="0"), dict(DTOF_XCD_REMAP="0"), dict(DTOF_XCD_REMAP="8"), dict(DTOF_XCD_REMAP="4096"), dict(DTOF_XCD_REMAP="1000003"), dict(DTOF_TRACE8="0", DTOF_XCD_REMAP="64"),
-                dict(DTOF_TLAS_LDS="0"), dict(DTOF_NODES16="0"), dict(DTOF_NODES16="0", DTOF_TLAS_LDS="0"), dict(DTOF_BLAS_LEAF="8"), dict(DTOF_BLAS_LEAF="2")):   # triangles per BLAS leaf (the loader reads it): another tree, the same hits
+                dict(DTOF_TLAS_LDS="0"), dict(DTOF_NODES16="0"), dict(DTOF_NODES16="0", DTOF_TLAS_LDS="0"), dict(DTOF_DEFER="0"), dict(DTOF_DEFER="0", DTOF_TLAS_LDS="0"), dict(DTOF_BLAS_LEAF="8"), dict(DTOF_BLAS_LEAF="2")):   # triangles per BLAS leaf (the loader reads it): another tree, the same hits
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         other = mi.load_file(os.path.join(d, "s.xml"), **params)
@@ -240,7 +240,7 @@ def test_blas_equals_the_loop_over_all_triangles_on_a_large_mesh(mi, orc, tmp_pa
         path = os.path.join(d, "s_%s.xml" % name)
         open(path, "w").write(make_mesh.cornell_mesh_xml().replace("</scene>", shape + "</scene>"))
         got = {}
-        for env in (dict(), dict(DTOF_NODES16="0"), dict(DTOF_BLAS="0")):
+        for env in (dict(), dict(DTOF_NODES16="0"), dict(DTOF_DEFER="0"), dict(DTOF_BLAS="0")):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             got[tuple(env)] = mi.load_file(path, **params).sample_lanes(5, 4, 0, n)

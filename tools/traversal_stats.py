@@ -30,6 +30,8 @@ print("%s spp %d: %d rays (closest-hit + occlusion), %d paths, %d path-bounces, 
 print("  TLAS node steps / ray %.1f   wave iterations / wave %.1f  -> lane utilisation %.2f" % (nl / rays, nw / (rays / 64), nl / max(nw * 64, 1)))
 print("  leaf visits / ray %.2f       wave leaf rounds / wave %.1f -> lane utilisation %.2f" % (ll / rays, lw / (rays / 64), ll / max(lw * 64, 1)))
 print("  mesh loops entered / ray %.2f, triangle tests / ray %.1f, BLAS node steps / ray %.1f" % (ml / rays, tt / rays, bl / rays))
+bw = int(out[15])
+if bw: print("  BLAS node steps: %.1f wave-level executions per wave of 64 rays, lane utilisation %.3f" % (bw / (rays / 64), bl / (bw * 64)))
 W = rays / 64
 print("  per wave of 64 rays, wave-level executions (lane utilisation): node steps %.1f (%.2f) | leaf rounds %.2f (%.2f) | rectangle tests %.2f (%.2f) | instance transforms %.2f (%.2f) | mesh loops %.2f (%.2f) | triangle tests %.1f (%.2f)" % (
     nw / W, nl / max(nw * 64, 1), lw / W, ll / max(lw * 64, 1), rw / W, rl / max(rw * 64, 1), iw / W, il / max(iw * 64, 1), mw / W, ml / max(mw * 64, 1), tw / W, tt / max(tw * 64, 1)))
