@@ -196,318 +196,6 @@ __global__ __launch_bounds__(64, 8) void k_shadow_deferred(const uint8_t *scene,
     if (!trace_deferred<true, 2, 64, kLdsStack8, H16>(sv, stack, cand, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h, ovf)) shadow_commit(rp, q, i);
 }
 
-// ---------------------------------------------------------------------------- generate
-__global__ __launch_bounds__(kBlock) void k_generate(RenderParams rp, Queues q) {
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= rp.n_lanes) return;
-    const PrimaryLane pl = generate_lane(rp, global_lane(rp, rp.lane_base + i), false, rp.lane_base + i);
-    q.ray_a[i] = pl.ray_a;
-    q.ray_b[i] = pl.ray_b;
-    q.st_a[i] = make_float4(1.f, 1.f, 1.f, 0.f);
-    q.rng_a[i] = make_uint4((uint32_t) pl.main.state, (uint32_t) (pl.main.state >> 32), (uint32_t) pl.path.state, (uint32_t) (pl.path.state >> 32));
-    q.rng_b[i] = make_uint2((uint32_t) (pl.main.inc >> 1), (uint32_t) (pl.path.inc >> 1));
-    q.pos[i] = pl.pos;
-    for (int k = 0; k < rp.n_offsets; ++k) q.res[(size_t) k * q.capacity + i] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-// ---------------------------------------------------------------------------- trace
-// BLOCK: 256 threads when the scene is staged into LDS (the staging is shared by four waves), ONE wave otherwise -- the waves of a
-// block share nothing then, and a block only frees its LDS and wave slots when its slowest wave is done, which costs occupancy
-// on divergent traversals (large scenes).
-// W8: the ray kernels of scenes with LARGE triangle meshes and no analytic shapes (the mesh room: 522 k triangles behind two BLAS, bound by the latency of its L2 misses).
-// Eight waves per SIMD instead of six -- more misses in flight per CU -- need (a) at most 64 VGPRs: the instantiation carries triangle and rectangle code only (MESH = 2: no
-// float64 sphere / cylinder arithmetic), and (b) 32 one-wave blocks in a CU's LDS: the stack column holds kLdsStack8 entries, deeper ones overflow into a private array.
-constexpr uint32_t kLdsStack8 = 16, kOvfStack8 = 48;
-// TL (round 5): the eight-wave kernels were measured with their texture-address / data units 87 - 90 % busy (profiles/r05_mesh_room.txt): every node step is four 16-byte
-// loads per lane, and a third of the loads a ray issues walk the TLAS -- a handful of nodes in such scenes (the mesh room: walls, a light, two blobs).  A TLAS of at most
-// kTlasLds8 nodes is copied behind the block's stack column (32 blocks x (4 KiB + 1 KiB) = the CU's 160 KiB) and walked with ds_read_b128; the BLAS stay in global memory.
-constexpr uint32_t kTlasLds8 = 16;
-// XCD-aware block order of the unstaged ray kernels (guide: cdna_hip_programming.md T1).  Blocks are dealt round-robin over the 8 XCDs, each with an L2 of its own (4 MiB):
-// with block b tracing queue segment b, every XCD sees rays from all over the image and all eight L2s fight over the same 35 MB of nodes and triangle records.  The remap gives
-// the blocks that share an XCD a CONTIGUOUS run of segments (= a band of the image for the primary and shadow rays), so each L2 mostly holds the geometry of its band.
-// Which block traces which segment changes nothing in the results.  MEASURED on the mesh room (512 x 512 x 64 spp, 522 k triangles; profiles/r05_mesh_room.txt), run = blocks
-// an XCD gets in a row: off 6.90 G rays/s | 8 (one segment) 6.90 | 64 6.05 | 512 (ONE PIXEL ROW) 7.23 | 1 024 7.15 | 2 048 7.12 | 4 096 6.91 | a whole band per XCD 5.68 (the
-// bands cost different amounts: the XCDs finish one after the other).  Default: one pixel row per run for scenes with a BLAS (xcd_run below); DTOF_XCD_REMAP=<run> | 0 overrides.
-// `run` = consecutive segments one XCD gets before the next XCD's run starts (a whole-image band per XCD -- run = n / 8 -- LOST 18 % on the mesh room: the bands cost
-// different amounts and the XCDs finish one after the other); blocks beyond the last full group of 8 runs keep their index.
-DTOF_D uint32_t xcd_remap(uint32_t orig, uint32_t n, uint32_t run) {
-    const uint32_t group = 8u * run, full = n - n % group;
-    if (orig >= full) return orig;
-    const uint32_t g = orig / group, w = orig - g * group, xcd = w & 7u, k = w >> 3;   // within a group: block w runs on XCD w % 8 and is that XCD's k-th block
-    return g * group + xcd * run + k;
-}
-// DEFER: a one-wave block adds its rays that put objects aside to their segment's list (the order inside a segment's list is the order the blocks get there: it decides
-// which lane of the second launch traces which ray, nothing else)
-DTOF_D void defer_append(const Queues &q, uint32_t seg, bool put, uint32_t index, uint4 cand) {
-    const unsigned long long m = __ballot(put);
-    if (m == 0ull) return;
-    uint32_t base = 0;
-    if (threadIdx.x == 0) base = atomicAdd(&q.defer_cnt[seg], (uint32_t) __popcll(m));
-    base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
-    if (put) {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
-        q.defer_idx[seg * kSeg + base + rank] = index;
-        q.cand[index] = cand;
-    }
-}
-template <bool LDS, bool MESH, int BLOCK, bool W8 = false, bool TL = false, bool H16 = false, bool DEFER = false>
-__global__ __launch_bounds__(BLOCK, W8 ? 8 : BLOCK == 64 ? 6 : 1) void k_trace(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words,
-                                                 Queues q, const uint32_t *qin, const uint32_t *count_in, uint32_t n_lanes, uint32_t n_tlas) {
-    static_assert(!TL || W8, "the TLAS copy sits behind the eight-wave kernels' stack column");
-    static_assert(!DEFER || (W8 && H16), "the two-launch form belongs to the eight-wave kernels");
-    static_assert(!H16 || (!LDS && MESH && BLOCK == 64), "half-float nodes: the unstaged one-wave kernels of scenes with a BLAS");
-    static_assert(!W8 || (!LDS && MESH && BLOCK == 64), "the eight-wave form exists for the unstaged one-wave kernels with triangle code");
-    constexpr uint32_t kBlock = BLOCK, kSub = kSeg / BLOCK;
-    extern __shared__ uint4 lds[];
-    const uint32_t bid = !LDS && q.xcd_remap ? xcd_remap(blockIdx.x, gridDim.x, q.xcd_remap) : blockIdx.x;
-    uint32_t seg = bid / kSub, sub = bid % kSub;
-    uint32_t count = seg_count(count_in, seg, n_lanes);
-    if (sub * kBlock >= count) return;
-    const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
-    uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
-    SceneView sv = make_view(base);
-    const BvhNode *tlas = nullptr;
-    if (TL) {   // the block's own copy of the TLAS nodes, behind its stack column (one wave: the barrier is a wave barrier)
-        uint4 *const t = lds + stage_words + kLdsStack8 * kBlock / 4u;
-        for (uint32_t i = threadIdx.x; i < n_tlas * 4u; i += kBlock) t[i] = ((const uint4 *) sv.nodes)[i];
-        __syncthreads();
-        tlas = (const BvhNode *) t;
-    }
-    uint32_t j = sub * kBlock + threadIdx.x;
-    const bool active = j < count;   // lanes past the end of the segment stay as helpers of the shared triangle loops (trace_rays)
-    uint32_t l = 0; float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 1.f, 0.f);
-    if (active) { l = qin ? qin[seg * kSeg + j] : seg * kSeg + j; a = q.ray_a[l]; b = q.ray_b[l]; }
-    Hit h;
-    uint32_t ovf[W8 ? kOvfStack8 : 1];
-    uint4 cand = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-    bool found = trace_rays<false, W8 ? 2 : (MESH ? 1 : 0), false, false, BLOCK, W8 ? kLdsStack8 : 0u, TL, H16, DEFER>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h, ovf, tlas, &cand);
-    if (active) store_hit<MESH>(q, l, h, found);
-    if (DEFER) defer_append(q, seg, active && cand.x != 0xffffffffu, l, cand);   // the hit so far is stored: k_trace_deferred goes on from it
-}
-// The second launch of the pair: the rays of each segment that reached at least one mesh behind a BLAS, packed -- block `sub` of a segment takes entries [64 sub, 64 sub + 64)
-// of its list.  Every lane enters a BLAS, where the first launch's waves did so with a tenth of theirs (profiles/r05_mesh_room.txt, section 8).
-template <bool H16>
-__global__ __launch_bounds__(64, 8) void k_trace_deferred(const uint8_t *scene, Queues q, uint32_t n_seg) {
-    extern __shared__ uint4 lds[];
-    const uint32_t seg = blockIdx.x % n_seg, sub = blockIdx.x / n_seg;   // the blocks of one sub-range side by side: all but the first two or three ranges of a segment are empty
-    const uint32_t count = q.defer_cnt[seg];
-    if (sub * 64u >= count) return;
-    uint32_t *stack = (uint32_t *) lds + threadIdx.x;
-    const SceneView sv = make_view(scene);
-    const uint32_t j = sub * 64u + threadIdx.x;
-    if (j >= count) return;
-    const uint32_t l = q.defer_idx[seg * kSeg + j];
-    const float4 a = q.ray_a[l], b = q.ray_b[l];
-    const uint4 cand = q.cand[l], hh = q.hit[l];
-    const uint32_t hid = q.hit_id[l];
-    Hit h;
-    if (hid == 0xffffffffu) { h.t = b.w; h.u = h.v = 0.f; h.obj = 0xffffffffu; h.shape = 0; h.prim = 0; }
-    else { h.t = u2f(hh.x); h.u = u2f(hh.y); h.v = u2f(hh.z); h.prim = hh.w; h.obj = hid & ((1u << q.id_shift) - 1u); h.shape = hid >> q.id_shift; }
-    uint32_t ovf[kOvfStack8];
-    const bool found = trace_deferred<false, 2, 64, kLdsStack8, H16>(sv, stack, cand, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, h, ovf);
-    store_hit<true>(q, l, h, found);
-}
-
-// ---------------------------------------------------------------------------- shadow
-// an unoccluded sample: its candidate results become the lane's results (the K films of a batch)
-DTOF_D void shadow_commit(const RenderParams &rp, const Queues &q, uint32_t i) {
-#pragma unroll
-    for (int k = 0; k < kMaxOffsets; ++k) if (k < rp.n_offsets) {
-        float4 c = q.sh_c[(size_t) k * q.capacity + i];
-        uint32_t l = f2u(c.w);
-        q.res[(size_t) k * q.capacity + l] = make_float4(c.x, c.y, c.z, 0.f);
-    }
-}
-template <bool LDS, bool MESH, int BLOCK, bool W8 = false, bool TL = false, bool H16 = false, bool DEFER = false>
-__global__ __launch_bounds__(BLOCK, W8 ? 8 : BLOCK == 64 ? 6 : 1) void k_shadow(const uint8_t *scene, uint32_t scene_bytes, uint32_t stage_words, RenderParams rp,
-                                                  Queues q, const uint32_t *count_in, uint32_t n_tlas) {
-    constexpr uint32_t kBlock = BLOCK, kSub = kSeg / BLOCK;
-    extern __shared__ uint4 lds[];
-    const uint32_t bid = !LDS && q.xcd_remap ? xcd_remap(blockIdx.x, gridDim.x, q.xcd_remap) : blockIdx.x;
-    uint32_t seg = bid / kSub, sub = bid % kSub;
-    uint32_t count = count_in[seg];
-    if (sub * kBlock >= count) return;
-    const uint8_t *base = LDS ? stage_scene(scene, scene_bytes, lds) : scene;
-    uint32_t *stack = (uint32_t *) (lds + stage_words) + threadIdx.x;
-    SceneView sv = make_view(base);
-    const BvhNode *tlas = nullptr;
-    if (TL) {   // the block's own copy of the TLAS nodes, behind its stack column (one wave: the barrier is a wave barrier)
-        uint4 *const t = lds + stage_words + kLdsStack8 * kBlock / 4u;
-        for (uint32_t i = threadIdx.x; i < n_tlas * 4u; i += kBlock) t[i] = ((const uint4 *) sv.nodes)[i];
-        __syncthreads();
-        tlas = (const BvhNode *) t;
-    }
-    uint32_t j = sub * kBlock + threadIdx.x;
-    const bool active = j < count;
-    uint32_t i = seg * kSeg + j;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 1.f, 0.f);
-    if (active) { a = q.sh_a[i]; b = q.sh_b[i]; }
-    Hit h;
-    uint32_t ovf[W8 ? kOvfStack8 : 1];
-    uint4 cand = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-    bool occluded = trace_rays<true, W8 ? 2 : (MESH ? 1 : 0), false, false, BLOCK, W8 ? kLdsStack8 : 0u, TL, H16, DEFER>(sv, stack, active, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h, ovf, tlas, &cand);
-    const bool later = DEFER && active && !occluded && cand.x != 0xffffffffu;   // nothing else is in the way: the meshes it put aside decide (k_shadow_deferred)
-    if (active && !occluded && !later) shadow_commit(rp, q, i);
-    if (DEFER) defer_append(q, seg, later, i, cand);
-}
-template <bool H16>
-__global__ __launch_bounds__(64, 8) void k_shadow_deferred(const uint8_t *scene, RenderParams rp, Queues q, uint32_t n_seg) {
-    extern __shared__ uint4 lds[];
-    const uint32_t seg = blockIdx.x % n_seg, sub = blockIdx.x / n_seg;
-    const uint32_t count = q.defer_cnt[seg];
-    if (sub * 64u >= count) return;
-    uint32_t *stack = (uint32_t *) lds + threadIdx.x;
-    const SceneView sv = make_view(scene);
-    const uint32_t j = sub * 64u + threadIdx.x;
-    if (j >= count) return;
-    const uint32_t i = q.defer_idx[seg * kSeg + j];
-    const float4 a = q.sh_a[i], b = q.sh_b[i];
-    const uint4 cand = q.cand[i];
-    Hit h; h.t = a.w; h.u = h.v = 0.f; h.obj = 0xffffffffu; h.shape = 0; h.prim = 0;
-    uint32_t ovf[kOvfStack8];
-    if (!trace_deferred<true, 2, 64, kLdsStack8, H16>(sv, stack, cand, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, h, ovf)) shadow_commit(rp, q, i);
-}
-
-// ---------------------------------------------------------------------------- the second launch as a persistent walker (round 5)
-// k_trace_deferred / k_shadow_deferred pack the rays that reached a mesh, but a packed wave still waits for the slowest of its 64 BLAS walks: the node steps of the pair ran
-// with 0.21 of their lanes (0.13 before; profiles/r05_mesh_room.txt, section 8).  Here a wave REFILLS: a lane whose ray is done takes the next entry of the wave's segment
-// lists (wave w owns segments w, w + W, w + 2 W, ...: no atomics), so that the node steps run with most of their lanes whatever the spread of the walks.  The walk of one
-// object is intersect_object's (dtof_traverse.h) cut into resumable pieces -- same arithmetic, same tie rules (ties between two triangles of a mesh to the lower face, between
-// objects to the lower index unless this object already holds the hit) -- the rectangles and small meshes of an instance group are tested where the lane gets to them.
-constexpr uint32_t kWalkRefill = 16;   // idle lanes a wave waits for before it fetches (or all of them)
-template <bool ANY, bool H16>
-__global__ __launch_bounds__(64, 6) void k_walk_deferred(const uint8_t *scene, RenderParams rp, Queues q, uint32_t n_seg) {
-    extern __shared__ uint4 lds[];
-    uint32_t *stack = (uint32_t *) lds + threadIdx.x;
-    const SceneView sv = make_view(scene);
-    const BvhNode *nodes = H16 ? (const BvhNode *) sv.nodes16 : sv.nodes;
-    constexpr uint32_t kDone = 0x7fffffffu, kNone = 0xffffffffu;
-    enum : uint32_t { IDLE = 0, NEXT = 1, WALK = 2 };
-    uint32_t phase = IDLE;
-    // the ray, its best hit, what it put aside
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 1); float time = 0.f, maxt = 0.f; uint32_t index = 0;
-    Hit best; best.t = 0.f; best.u = best.v = 0.f; best.obj = kNone; best.shape = 0; best.prim = 0;
-    uint32_t c0 = kNone, c1 = kNone, c2 = kNone, c3 = kNone, ci = 0;
-    bool occluded = false;
-    // the object it is in: object-space ray, the shapes of its group, whether this object already holds the hit; the mesh it walks
-    V3 lo = o, ld = d; SlabRay lr = slab_ray(o, d);
-    uint32_t oi = 0, first = 0, count = 0, k = 0, first_tri = 0, best_face = kNone, cur = kDone; int sp = 0; bool found = false;
-    uint32_t ovf[kOvfStack8];
-    // the wave's segment lists
-    uint32_t seg = blockIdx.x, pos = 0, seg_n = seg < n_seg ? q.defer_cnt[seg] : 0u;   // (uniform)
-    bool more = seg < n_seg;
-    for (uint32_t guard = 0; guard < (1u << 26); ++guard) {
-        // ---- refill: idle lanes take the next entries of the wave's lists
-        {
-            unsigned long long idle = __ballot(phase == IDLE);
-            uint32_t n_idle = (uint32_t) __popcll(idle);
-            if (more && (n_idle == 64u || n_idle >= kWalkRefill)) {
-                while (n_idle != 0u && more) {
-                    if (pos >= seg_n) { seg += gridDim.x; pos = 0; more = seg < n_seg; seg_n = more ? q.defer_cnt[seg] : 0u; continue; }
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
-                    const uint32_t avail = seg_n - pos, take_n = n_idle < avail ? n_idle : avail;
-                    if (phase == IDLE && rank < take_n) {
-                        index = q.defer_idx[seg * kSeg + pos + rank];
-                        const uint4 cand = q.cand[index];
-                        c0 = cand.x; c1 = cand.y; c2 = cand.z; c3 = cand.w; ci = 0; occluded = false;
-                        if (ANY) {
-                            const float4 a = q.sh_a[index], b = q.sh_b[index];
-                            o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); time = b.w; maxt = a.w;
-                            best.t = maxt; best.u = best.v = 0.f; best.obj = kNone; best.shape = 0; best.prim = 0;
-                        } else {
-                            const float4 a = q.ray_a[index], b = q.ray_b[index];
-                            o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); time = a.w; maxt = b.w;
-                            const uint32_t hid = q.hit_id[index];
-                            if (hid == kNone) { best.t = maxt; best.u = best.v = 0.f; best.obj = kNone; best.shape = 0; best.prim = 0; }
-                            else { const uint4 hh = q.hit[index]; best.t = u2f(hh.x); best.u = u2f(hh.y); best.v = u2f(hh.z); best.prim = hh.w; best.obj = hid & ((1u << q.id_shift) - 1u); best.shape = hid >> q.id_shift; }
-                        }
-                        k = 0; count = 0;   // "no object yet": NEXT starts with candidate 0
-                        phase = NEXT;
-                    }
-                    pos += take_n;
-                    idle = __ballot(phase == IDLE); n_idle = (uint32_t) __popcll(idle);
-                }
-            }
-            if (n_idle == 64u && !more) break;   // nothing in flight, nothing left
-        }
-        // ---- lanes between shapes: the next shape of the object's group, else the next object the ray put aside, else the ray is done
-        while (__any(phase == NEXT)) {
-            if (phase == NEXT) {
-                if (k >= count) {   // the next object
-                    const uint32_t next = ci == 0 ? c0 : ci == 1 ? c1 : ci == 2 ? c2 : ci == 3 ? c3 : kNone;
-                    if (next == kNone || (ANY && occluded)) {   // the ray is done
-                        if (ANY) { if (!occluded) shadow_commit(rp, q, index); }
-                        else store_hit<true>(q, index, best, best.obj != kNone);
-                        phase = IDLE;
-                    } else {
-                        ++ci; oi = next;
-                        const DObject &ob = sv.objects[oi];
-                        first = ob.index; count = 1; lo = o; ld = d;
-                        if (ob.kind == OBJ_INSTANCE) {
-                            float m[12], inv[12];
-                            instance_matrix(ob, time, m); affine_inverse(m, inv);
-                            lo = xf_point(inv, o); ld = xf_vector(inv, d);
-                            const DGroup &g = sv.groups[ob.index];
-                            first = g.first_shape; count = g.n_shapes;
-                        }
-                        k = 0; found = false;
-                    }
-                } else {            // shape k of the group
-                    const uint32_t ks = k++;
-                    const DShape &sh = sv.shapes[first + ks];
-                    float t, u, v;
-                    if (sh.kind == SHAPE_RECT) {
-                        if (rect_hit(sh, lo, ld, maxt, t, u, v)) {
-                            if (ANY) occluded = true;
-                            else if (t < best.t || (t == best.t && !found && best.obj != kNone && oi < best.obj)) { best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = ks; best.prim = 0; found = true; }
-                        }
-                    } else {        // a triangle mesh (these launches serve scenes without analytic shapes)
-                        lr = slab_ray(lo, ld);
-                        float t_entry;
-                        if (!(ANY && occluded) && box_hit(sh.bmin, sh.bmax, lr, ANY ? maxt : best.t, t_entry)) {
-                            best_face = kNone; first_tri = sh.first_tri;
-                            if (sh.blas_root == kNoChild) {   // a small mesh: its triangles, here
-                                for (uint32_t f = 0; f < sh.n_tris; ++f) {
-                                    if (!tri_hit(sv.isect[first_tri + f], lo, ld, maxt, t, u, v)) continue;
-                                    if (ANY) { occluded = true; break; }
-                                    const uint32_t face = sv.tris[first_tri + f].face;
-                                    bool take = t < best.t;
-                                    if (t == best.t) take = best_face != kNone ? face < best_face : (!found && best.obj != kNone && oi < best.obj);
-                                    if (take) { best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = ks; best.prim = f; best_face = face; found = true; }
-                                }
-                            } else { cur = sh.blas_root; sp = 0; best.shape = best.shape; phase = WALK; }
-                        }
-                    }
-                }
-            }
-        }
-        // ---- one round of the walks: every walking lane descends to its next leaf (or runs out), then the leaves are tested
-        while (__any(phase == WALK && !(cur & kLeafFlag) && cur != kDone)) {
-            if (phase == WALK && !(cur & kLeafFlag) && cur != kDone)
-                cur = node_step<false, 64, false, kLdsStack8, H16>(nodes, cur, lr, ANY ? maxt : best.t, stack, sp, 0, 64u, kDone, ovf);
-        }
-        if (phase == WALK) {
-            if (cur != kDone) {   // a leaf: its triangles
-                const uint32_t f0 = (cur & ~kLeafFlag) >> kBlasLeafBits, fn = (cur & ((1u << kBlasLeafBits) - 1u)) + 1u;
-                const uint32_t ks = k - 1u;
-                for (uint32_t f = f0; f < f0 + fn; ++f) {
-                    float t, u, v;
-                    if (!tri_hit(sv.isect[first_tri + f], lo, ld, maxt, t, u, v)) continue;
-                    if (ANY) { occluded = true; break; }
-                    const uint32_t face = sv.tris[first_tri + f].face;
-                    bool take = t < best.t;
-                    if (t == best.t) take = best_face != kNone ? face < best_face : (!found && best.obj != kNone && oi < best.obj);
-                    if (take) { best.t = t; best.u = u; best.v = v; best.obj = oi; best.shape = ks; best.prim = f; best_face = face; found = true; }
-                }
-                if ((ANY && occluded) || sp == 0) cur = kDone;
-                else { --sp; cur = stack_get<false, kLdsStack8>(stack, ovf, sp, 64u); }
-            }
-            if (cur == kDone) phase = NEXT;   // this mesh is walked: the next shape, object or ray
-        }
-    }
-}
-
-
 // ---------------------------------------------------------------------------- velocity
 // VelocityIntegrator::sample (src/integrators/velocity.cpp:125-142): the primary ray is intersected at time 0 and at
 // time T; radial velocity = (t2 - t1) / T where both hit, 0 otherwise, in all three channels.
