@@ -16,6 +16,7 @@ from conftest import ROOT
 
 sys.path.insert(0, os.path.join(ROOT, "scenes"))
 import make_mesh  # noqa: E402
+import make_scenes as ms  # noqa: E402
 
 NCPU = os.cpu_count() or 1
 
@@ -251,6 +252,42 @@ def test_blas_equals_the_loop_over_all_triangles_on_a_large_mesh(mi, orc, tmp_pa
         for key, lanes in got.items():
             for k in ref:
                 assert np.array_equal(bits(ref[k]), bits(lanes[k])), (name, key, k)
+
+
+@pytest.mark.gpu
+def test_a_ray_that_puts_more_than_four_meshes_aside(mi, tmp_path, monkeypatch):
+    """Round 5: the ray kernels of mesh scenes run as a pair of launches -- the first puts the objects behind a BLAS that a ray's TLAS walk reaches ASIDE (up to four), the second
+    enters them in packed waves.  Seven blobs in a row along the view axis, half of them moving: a primary ray through the middle reaches all seven boxes, so the fifth, sixth and
+    seventh are entered on the spot by the first launch.  Every lane the same bits with the pair for every ray kernel (DTOF_DEFER=1), the default (2), none (0), and with the loop
+    over all triangles (DTOF_BLAS=0)."""
+    d = str(tmp_path)
+    pos, nrm, uv, faces = make_mesh.blob(24, 12)            # 552 triangles each: behind a BLAS
+    make_mesh.write_ply(os.path.join(d, "blob.ply"), pos, nrm, uv, faces)
+    s = ms.HEADER.format(spp=4, res=48, tsm="antithetic", shift="0.5") + ms.SENSOR.format(fov="19.5", cam=ms.CAM)
+    for b in ms.BSDFS:
+        s += ms.bsdf(*b)
+    for name, m, b in ms.WALLS:
+        s += ms.rect(name, m, b)
+    for i in range(7):   # along z, towards the camera, overlapping in x / y as seen from it; a thin one in front so that rays pass between its bumps
+        s += make_mesh.mesh_shape("ply", "Blob%d" % i, "blob.ply", "TallBoxBSDF" if i % 2 else "ShortBoxBSDF", "%.3f" % (0.10 + 0.015 * i),
+                                  ("%.3f" % (0.05 * (i % 3) - 0.05), "%.3f" % (1.0 + 0.04 * (i % 2)), "%.3f" % (-0.75 + 0.25 * i)), anim_dz="0.01" if i % 2 else None)
+    open(os.path.join(d, "s.xml"), "w").write(s + ms.LIGHT + "</scene>\n")
+    n = 48 * 48 * 4
+    got = {}
+    monkeypatch.setenv("DTOF_PIPELINE", "split")   # (a scene of 3.7 k triangles would take the fused kernels: the ray kernels are the split pipeline's)
+    for env in (dict(DTOF_DEFER="1"), dict(), dict(DTOF_DEFER="0"), dict(DTOF_BLAS="0")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sc = mi.load_file(os.path.join(d, "s.xml"))
+        got[tuple(env.items())] = (sc.sample_lanes(3, 4, 0, n), sc.render(seed=3, spp=4), sc.info())
+        for k in env:
+            monkeypatch.delenv(k)
+    ref_lanes, ref_img, info = got[(("DTOF_BLAS", "0"),)]
+    assert got[()][2]["n_bvh_nodes"] > 7 * 100 and info["n_bvh_nodes"] < 40
+    for key, (lanes, img, _) in got.items():
+        for k in ref_lanes:
+            assert np.array_equal(bits(ref_lanes[k]), bits(lanes[k])), (key, k)
+        assert np.abs(img - ref_img).max() <= 2e-6 * np.abs(ref_img).max(), key
 
 
 # ------------------------------------------------------------------------------------------------ mesh area emitters
