@@ -42,6 +42,7 @@ struct RenderParams {
     int32_t has_tris;                             // scene has triangle meshes (selects the kernel instantiations that carry mesh code)
     int32_t has_analytic;                         // the scene has spheres / disks / cylinders (the eight-wave ray kernels carry triangle and rectangle code only)
     uint32_t n_tlas_nodes;                        // nodes of the top-level BVH (the eight-wave ray kernels keep up to kTlasLds8 of them in LDS)
+    uint32_t res_half;                            // resident stage: the LDS planes hold half-float node records (a TLAS of kResidentNodes + 1 .. 2 * kResidentNodes nodes)
     int32_t has_nodes16;                          // the blob carries the half-float copy of the node array (BlobHeader::off_nodes16)
     int32_t has_blas;                             // some mesh is traversed through its own BLAS: the unstaged k_trace / k_shadow run one wave per block
     int32_t integrator;                           // 0 dopplertofpath, 1 path (src/integrators/path.cpp), 2 velocity (velocity.cpp)

@@ -463,10 +463,12 @@ void render_rows(dtof_scene *sc, uint32_t seed, uint32_t spp, int32_t row_begin,
         // (the every-BSDF kernels hold more state: 12 waves for one film, 8 for four -- 3.64 ms against 4.07 at 16, 5.15 ms against 5.82 at 12 on a Domino field of rough
         //  plastic cubes; profiles/r03_resident_spec_waves.txt)
         int env_res = [&] { const char *e = getenv("DTOF_RESIDENT"); return e ? atoi(e) : (rp.has_spec ? (rp.n_offsets > 1 ? 8 : 12) : 16); }();   // read per call: tests and A/B runs switch it
+        const bool half_env = [] { const char *e = getenv("DTOF_RESIDENT_HALF"); return !(e && e[0] == '0'); }();   // a TLAS of 1 025 .. 2 048 nodes as half-float LDS planes (k_shade: RH16); =0: such scenes take the classic launch
         const uint32_t small_off = bh->off_groups, small_bytes = bh->off_tables - bh->off_groups;          // groups | shapes | emitters | triangles | shading data | intersection records
-        if (fused && (env_res == 8 || env_res == 12 || env_res == 16) && rp.has_tris && !rp.has_blas && bh->n_nodes > 0 && bh->n_nodes <= kResidentNodes && blob_bytes > 16 * 1024 &&
+        if (fused && (env_res == 8 || env_res == 12 || env_res == 16) && rp.has_tris && !rp.has_blas && bh->n_nodes > 0 && (bh->n_nodes <= kResidentNodes || (half_env && bh->off_nodes16 != 0 && bh->n_nodes <= 2 * kResidentNodes)) && blob_bytes > 16 * 1024 &&
             bh->off_shapes > bh->off_groups && bh->off_emitters > bh->off_groups && bh->off_tris > bh->off_groups && bh->off_shading >= bh->off_tris && bh->off_isect >= bh->off_shading && bh->off_tables >= bh->off_isect && small_bytes <= 24 * 1024) {
             resident.small_off = small_off; resident.small_words = (small_bytes + 15) / 16; resident.waves = (uint32_t) env_res;
+            rp.res_half = bh->n_nodes > kResidentNodes ? 1u : 0u;
             // the stage must fit the CU's LDS beside the stack columns (a deep TLAS needs many): fewer waves per block while it does not, none if 8 do not either
             const uint32_t limit = device_lds_limit();
             while (resident.waves && resident_lds_bytes(rp, resident, stack_depth, resident.waves) > limit) resident.waves = resident.waves > 8 ? resident.waves - 4 : 0;

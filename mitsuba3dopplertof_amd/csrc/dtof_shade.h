@@ -307,7 +307,7 @@ DTOF_D void bsdf_eval_pdf_sample(const SceneView &sv, const DShape *sh, Surface 
 // still comes through the vector L1 is the 128-byte instance record of a leaf visit and the queue traffic: the unstaged kernel keeps the CU's
 // vector memory path busy 75 - 85 % of the time (TA / TD busy counters, profiles/r03_pmc_domino_fused*.txt) with the four 16-byte node loads
 // per step per lane, and waits for it.
-template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, int SPEC, int RESW = 0>   // SPEC: 0 diffuse-only scenes, 1 every BSDF / emitter / texture, 2 = 1 + blendbsdf (the BSDF chain in a loop over two records)
+template <bool LDS, int MODE, bool AREA, int KMAX, bool MESH, int SPEC, int RESW = 0, bool RH16 = false>   // RH16: the resident stage holds HALF-FLOAT node records (DNode16): a TLAS of up to 2 * kResNodes nodes in the LDS of kResNodes float ones; SPEC: 0 diffuse-only scenes, 1 every BSDF / emitter / texture, 2 = 1 + blendbsdf (the BSDF chain in a loop over two records)
 #ifndef DTOF_MESH_WAVES
 #define DTOF_MESH_WAVES 3   // waves / SIMD the fused kernels with triangle code are compiled for (A/B: make variant DEFS=-DDTOF_MESH_WAVES=4)
 #endif
@@ -347,6 +347,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     constexpr int KREG = RES_MEM ? 1 : KMAX;                         // film-state registers the lane carries
     constexpr uint32_t kStackStride = RESW ? RESW * 64 : kShadeBlock;   // the block size = the stride of the traversal-stack columns
     static_assert(RESW == 0 || (MODE == 2 && !LDS && MESH), "the resident stage exists for the unstaged fused first-bounce kernel with mesh code");
+    static_assert(!RH16 || RESW != 0, "half-float LDS planes belong to the resident stage");
     extern __shared__ uint4 lds[];
     __shared__ uint32_t s_cnt[4];
     __shared__ uint32_t s_inline_all[(RESW ? RESW : 1) * 2 * kMaxInline];   // FIRST: lanes alive after / shadow rays of every inline iteration but the last (statistics), per wave
@@ -371,6 +372,15 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
     SceneView sv_res;
     if (RESW) {   // the resident stage: every thread of the block copies, ONE barrier, then the waves go their own ways
         const BlobHeader *gh = (const BlobHeader *) A0.scene;
+        if (RH16) {   // two planes of 2 * kResNodes 16-byte pieces: (left box, left child) | (right box, right child)
+            const uint4 *gn = (const uint4 *) (A0.scene + gh->off_nodes16);
+            const uint32_t n_pieces = gh->n_nodes * 2u;
+            for (uint32_t i = threadIdx.x; i < n_pieces; i += blockDim.x) {
+                uint4 piece = gn[i];
+                if (S16) piece.w = encode_child16(piece.w);
+                lds[(i & 1u) * (2u * kResNodes) + (i >> 1)] = piece;
+            }
+        } else {
         const uint4 *gn = (const uint4 *) (A0.scene + gh->off_nodes);
         const uint32_t n_pieces = gh->n_nodes * 4u;
         for (uint32_t i = threadIdx.x; i < n_pieces; i += blockDim.x) {
@@ -378,12 +388,13 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             if (S16 && (i & 3u) < 2u) piece.w = encode_child16(piece.w);   // left / right child: 16-bit references (dtof_traverse.h), so that the stack columns are 16-bit
             lds[(i & 3u) * kResNodes + (i >> 2)] = piece;
         }
+        }
         const uint4 *gs = (const uint4 *) (A0.scene + A0.res_small_off);
         for (uint32_t i = threadIdx.x; i < A0.res_small_words; i += blockDim.x) lds[4u * kResNodes + i] = gs[i];
         __syncthreads();
         const uint8_t *small = (const uint8_t *) (lds + 4u * kResNodes) - A0.res_small_off;   // blob offsets of the copied block resolve into LDS
         sv_res = make_view(A0.scene);
-        sv_res.nodes = (const DNode *) lds;
+        sv_res.nodes = (const DNode *) lds; sv_res.nodes16 = (const DNode16 *) lds;
         sv_res.groups = (const DGroup *) (small + gh->off_groups); sv_res.shapes = (const DShape *) (small + gh->off_shapes);
         sv_res.tris = (const DTri *) (small + gh->off_tris); sv_res.shading = (const DTriShade *) (small + gh->off_shading);
         sv_res.isect = (const DTriIsect *) (small + gh->off_isect);
@@ -523,7 +534,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             if (have_memo) instance_memo_fill(sv, ra.w, memo_m, memo_inv);
             Hit h;
             bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, rp.flat_off, flat, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h)
-                              : trace_scene<false, MESH, FUSED, RESW != 0, kStackStride, S16>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
+                              : trace_scene<false, MESH, FUSED, RESW != 0, kStackStride, S16, 0u, false, RH16>(sv, stack, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, rb.w, h);
             hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim);
             hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu;
         }
@@ -871,7 +882,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             commit = sha.w > 0.f;
 #else
             commit = flat ? !trace_flat<true, true>(sv, (ConstBytes) A.scene + rp.flat_off, rp.flat_off, flat, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs)
-                          : !trace_scene<true, MESH, true, RESW != 0, kStackStride, S16>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
+                          : !trace_scene<true, MESH, true, RESW != 0, kStackStride, S16, 0u, false, RH16>(sv, stack, mk(sha.x, sha.y, sha.z), mk(shb.x, shb.y, shb.z), shb.w, sha.w, hs);
 #endif
         }
         if (RES_MEM) {   // the committed sample gets its K modulation weights now (dopplertofpath.cpp:221-226) and is added to the films' records in q.res
@@ -911,7 +922,7 @@ __global__ __launch_bounds__(RESW ? RESW * 64 : kShadeBlock, RESW ? RESW / 4 : (
             bool found = nra.x < 1e30f; h.t = 0.5f + 0.1f * nrb.x; h.u = nrb.y; h.v = nrb.z; h.obj = nrb.x > 0.3f ? 3 : nrb.y > 0.f ? 1 : 0; h.shape = 0; h.prim = 0;
 #else
             bool found = flat ? trace_flat<false, true>(sv, (ConstBytes) A.scene + rp.flat_off, rp.flat_off, flat, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h)
-                              : trace_scene<false, MESH, true, RESW != 0, kStackStride, S16>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
+                              : trace_scene<false, MESH, true, RESW != 0, kStackStride, S16, 0u, false, RH16>(sv, stack, mk(nra.x, nra.y, nra.z), mk(nrb.x, nrb.y, nrb.z), nra.w, nrb.w, h);
 #endif
             if (!FIRST || last) store_hit<MESH>(q, l, h, found);
             if (FIRST) { hh = make_uint4(f2u(h.t), f2u(h.u), f2u(h.v), h.prim); hid = found ? (h.obj | (h.shape << q.id_shift)) : 0xffffffffu; }
@@ -1012,11 +1023,13 @@ static void launch_resident_waves(const ShadeLaunch &L) {
     int dev = 0; (void) hipGetDevice(&dev);
     std::atomic<uint32_t> &mark = attr_lds[(unsigned) dev & 63u];
     if (L.lds > mark.load()) {
-        if (hipFuncSetAttribute((const void *) k_shade<false, 2, A, K, true, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) L.lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *) k_shade<false, 2, A, K, true, S, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) L.lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *) k_shade<false, 2, A, K, true, S, W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) L.lds) != hipSuccess)
             throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
         mark.store(L.lds);
     }
-    hipLaunchKernelGGL((k_shade<false, 2, A, K, true, S, W>), dim3(L.grid), dim3(W * 64), L.lds, L.stream, L.args);
+    if (L.args.rp.res_half) hipLaunchKernelGGL((k_shade<false, 2, A, K, true, S, W, true>), dim3(L.grid), dim3(W * 64), L.lds, L.stream, L.args);   // a TLAS of 1 025 .. 2 048 nodes: half-float planes
+    else hipLaunchKernelGGL((k_shade<false, 2, A, K, true, S, W>), dim3(L.grid), dim3(W * 64), L.lds, L.stream, L.args);
 }
 template <bool A, int K, int S>
 static void launch_resident_variant(const ShadeLaunch &L) {

@@ -256,14 +256,15 @@ template <bool SOA = false, uint32_t STRIDE = 0, bool S16 = false, uint32_t LDSN
 DTOF_D uint32_t node_step(const BvhNode *nodes, uint32_t cur, const SlabRay &r, float tbest, uint32_t *stack, int &sp, int sp_floor, uint32_t stride_rt, uint32_t done, uint32_t *ovf = nullptr) {
     const uint32_t stride = STRIDE ? STRIDE : stride_rt;
     if (H16) {
-        const uint4 *np = (const uint4 *) ((const DNode16 *) nodes + cur);
-        const uint4 a = np[0], b = np[1];
+        // (SOA: the resident stage's LDS copy -- TWO planes of 2 * kResNodes pieces, piece k of node i at k * 2 * kResNodes + i: 2 048 half-float nodes in the 64 KiB of 1 024 float ones)
+        const uint4 *np = SOA ? (const uint4 *) nodes + cur : (const uint4 *) ((const DNode16 *) nodes + cur);
+        const uint4 a = np[0], b = np[SOA ? 2 * kResNodes : 1];
         const float lmin[3] = { half_lo(a.x), half_hi(a.x), half_lo(a.y) }, lmax[3] = { half_hi(a.y), half_lo(a.z), half_hi(a.z) };
         const float rmin[3] = { half_lo(b.x), half_hi(b.x), half_lo(b.y) }, rmax[3] = { half_hi(b.y), half_lo(b.z), half_hi(b.z) };
         const uint32_t left = a.w, right = b.w;
         float tl, tr;
         const bool hl = box_hit(lmin, lmax, r, tbest, tl);
-        const bool hr = (int) box_hit(rmin, rmax, r, tbest, tr) & (int) (right != kNoChild);
+        const bool hr = (int) box_hit(rmin, rmax, r, tbest, tr) & (int) (right != (S16 ? kNoChild16 : kNoChild));
         if (hl && hr) {
             const bool left_first = tl <= tr;
             stack_put<S16, LDSN>(stack, ovf, sp, stride, left_first ? right : left);

@@ -506,7 +506,7 @@ std::vector<uint8_t> build_scene_blob(const HostScene &sc) {
     h.off_isect = place(isect.size() * sizeof(DTriIsect));
     h.off_tables = place((uint64_t) tables.size() * 4);
     std::vector<DNode16> nodes16;   // scenes with a BLAS: the half-float copy of the node array (dtof_scene.h)
-    if (!blas_nodes.empty()) {
+    if (!blas_nodes.empty() || (dev_nodes.size() > 1024 && dev_nodes.size() <= 2048)) {   // ... and TLAS-only scenes of 1 025 .. 2 048 nodes: the resident stage of the first-bounce kernel holds them as half-float planes (k_shade: RH16)
         bool fits = true;
         for (const BvhNode &n : dev_nodes) for (int i = 0; i < 3; ++i) {
             fits &= std::fabs(n.lmin[i]) <= 65000.f && std::fabs(n.lmax[i]) <= 65000.f;

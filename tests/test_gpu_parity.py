@@ -1216,6 +1216,37 @@ def test_resident_stage_with_the_every_bsdf_kernels(mi, orc, monkeypatch, varian
 
 
 @pytest.mark.gpu
+def test_resident_stage_with_half_float_planes_for_a_tlas_of_1600_nodes(mi, monkeypatch):
+    """Round 5: a TLAS of 1 025 .. 2 048 nodes does not fit the resident stage's float planes (1 024 nodes = 64 KiB) -- it is staged as HALF-FLOAT records (DNode16: boxes rounded
+    outward, two LDS planes, k_shade<..., RH16>), which only cull.  A Domino field of 40 x 40 instances: every lane the same bits with the classic launch (DTOF_RESIDENT=0), the
+    half-float stage at 16 / 12 / 8 waves, and DTOF_RESIDENT_HALF=0 (which sends such scenes to the classic launch); the four-film batch equal to the single films."""
+    sys.path.insert(0, SCENES)
+    import make_scenes
+    path = os.path.join(SCENES, "_domino_40.xml")
+    open(path, "w").write(make_scenes.domino(n_side=40, res=64, spp=4))
+    try:
+        monkeypatch.setenv("DTOF_PIPELINE", "fused")
+        monkeypatch.setenv("DTOF_CHUNK_SEGS", "0")
+        n = 64 * 64 * 4
+        got = {}
+        for env in (dict(DTOF_RESIDENT="0"), dict(DTOF_RESIDENT="16"), dict(DTOF_RESIDENT="12"), dict(DTOF_RESIDENT="8"), dict(DTOF_RESIDENT="16", DTOF_RESIDENT_HALF="0")):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            sc = mi.load_file(path)
+            assert sc.info()["n_objects"] == 1601 and 1024 < sc.info()["n_bvh_nodes"] <= 2048
+            got[tuple(env.items())] = (sc.sample_lanes(2, 4, 0, n), sc.render(seed=2, spp=4, offsets=[0.0, 0.25, 0.5, 0.75]), sc.render(seed=2, spp=4))
+            for k in env:
+                monkeypatch.delenv(k)
+        ref = got[(("DTOF_RESIDENT", "0"),)]
+        for key, (lanes, imgs, img) in got.items():
+            for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb"):
+                assert np.array_equal(bits(ref[0][k]), bits(lanes[k])), (key, k, int((bits(ref[0][k]) != bits(lanes[k])).sum()))
+            assert rel_linf(np.asarray(imgs), np.asarray(ref[1])) <= 2e-6 and rel_linf(img, ref[2]) <= 2e-6, key
+            assert rel_linf(np.asarray(imgs)[0], img) <= 2e-6, key
+    finally:
+        os.remove(path)
+
+
 def test_resident_stage_gives_way_to_a_deep_tlas(mi, orc, monkeypatch):
     """the resident first-bounce stage needs LDS for its stack columns (depth x 1 024 words at 16 waves); a scene it is otherwise eligible for (blob above
     the whole-blob staging limit, at most 1 024 nodes, small records) but whose TLAS is deep must step down in waves or take the classic launch -- not fail.

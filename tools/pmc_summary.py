@@ -38,7 +38,7 @@ def collect(d, counter):
 
 
 def short(name):
-    m = re.search(r"k_shade<\w+, (\d), \w+, (\d+), (\w+), \w+(?:, (\d+))?>", name)     # k_shade<LDS, MODE, AREA, KMAX, MESH, SPEC, RESW>
+    m = re.search(r"k_shade<\w+, (\d), \w+, (\d+), (\w+), \w+(?:, (\d+))?(?:, \w+)?>", name)     # k_shade<LDS, MODE, AREA, KMAX, MESH, SPEC, RESW, RH16>
     if m:
         if m.group(1) == "2":      # the first-bounce instantiation (lane generation + primary ray + inline iterations)
             return "k_shade_first" + ("_mesh" if m.group(3) == "true" else "") + ("_k4" if m.group(2) != "1" else "") + ("_resident" if (m.group(4) or "0") != "0" else "")

@@ -28,10 +28,10 @@ FAST = {"v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_sub
 QUARTER = {"v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_sin_f32", "v_cos_f32", "v_exp_f32", "v_log_f32", "v_rcp_iflag_f32"}
 C_FAST, C_SLOW, C_QUARTER = 2.25, 4.1, 8.2      # nominal 2.4 GHz cycles per wave64 instruction per SIMD, W >= 4 (the measured table)
 # the kernels the bench configurations are dominated by (pmc_summary.short() names)
-WANTED = {"c2": "_ZN4dtof7k_shadeILb1ELi2ELb0ELi1ELb0ELi0ELi0EEEvNS_9ShadeArgsE",
-          "c3": "_ZN4dtof7k_shadeILb1ELi2ELb0ELi1ELb0ELi0ELi0EEEvNS_9ShadeArgsE",
-          "c4": "_ZN4dtof7k_shadeILb0ELi2ELb0ELi1ELb1ELi0ELi16EEEvNS_9ShadeArgsE",
-          "c5": "_ZN4dtof7k_shadeILb0ELi2ELb0ELi4ELb1ELi0ELi16EEEvNS_9ShadeArgsE"}
+WANTED = {"c2": "_ZN4dtof7k_shadeILb1ELi2ELb0ELi1ELb0ELi0ELi0ELb0EEEvNS_9ShadeArgsE",
+          "c3": "_ZN4dtof7k_shadeILb1ELi2ELb0ELi1ELb0ELi0ELi0ELb0EEEvNS_9ShadeArgsE",
+          "c4": "_ZN4dtof7k_shadeILb0ELi2ELb0ELi1ELb1ELi0ELi16ELb0EEEvNS_9ShadeArgsE",
+          "c5": "_ZN4dtof7k_shadeILb0ELi2ELb0ELi4ELb1ELi0ELi16ELb0EEEvNS_9ShadeArgsE"}
 
 
 def classify(op, args):
