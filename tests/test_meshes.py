@@ -290,6 +290,43 @@ def test_a_ray_that_puts_more_than_four_meshes_aside(mi, tmp_path, monkeypatch):
         assert np.abs(img - ref_img).max() <= 2e-6 * np.abs(ref_img).max(), key
 
 
+@pytest.mark.gpu
+def test_instanced_groups_with_a_mesh_and_a_rectangle_through_the_pair_of_launches(mi, tmp_path, monkeypatch):
+    """The second launch of a ray-kernel pair enters OBJECTS: an instance whose shapegroup holds a blob behind a BLAS AND a rectangle (tested on the way), placed three times with
+    moving keyframes, beside a plain blob.  The TLAS leaves of all four carry kLeafBlas.  Same lanes with the pair for every ray kernel, the default, one launch, and no BLAS at all."""
+    d = str(tmp_path)
+    pos, nrm, uv, faces = make_mesh.blob(20, 10)
+    make_mesh.write_ply(os.path.join(d, "blob.ply"), pos, nrm, uv, faces)
+    s = ms.HEADER.format(spp=4, res=48, tsm="antithetic", shift="0.5") + ms.SENSOR.format(fov="19.5", cam=ms.CAM)
+    for b in ms.BSDFS:
+        s += ms.bsdf(*b)
+    for name, m, b in ms.WALLS:
+        s += ms.rect(name, m, b)
+    s += ('<shape type="shapegroup" id="G"><shape type="ply"><string name="filename" value="blob.ply"/><transform name="to_world"><scale value="0.16"/></transform><ref id="TallBoxBSDF"/></shape>'
+          '<shape type="rectangle"><transform name="to_world"><scale x="0.22" y="0.05"/><rotate x="1" angle="-60"/><translate y="-0.2"/></transform><ref id="ShortBoxBSDF"/></shape></shape>\n')
+    for i, (x, y, z) in enumerate([(-0.45, 0.6, -0.2), (0.35, 0.9, 0.1), (0.0, 1.35, -0.4)]):
+        s += ('<shape type="instance"><ref id="G"/><animation name="to_world"><transform time="0"><rotate y="1" angle="%d"/><translate x="%.2f" y="%.2f" z="%.2f"/></transform>'
+              '<transform time="0.0015"><rotate y="1" angle="%d"/><translate x="%.2f" y="%.3f" z="%.2f"/></transform></animation></shape>\n' % (20 * i, x, y, z, 20 * i + 2, x, y + 0.01, z))
+    s += make_mesh.mesh_shape("ply", "Plain", "blob.ply", "TallBoxBSDF", "0.2", ("0.45", "0.35", "0.45"))
+    open(os.path.join(d, "s.xml"), "w").write(s + ms.LIGHT + "</scene>\n")
+    n = 48 * 48 * 4
+    monkeypatch.setenv("DTOF_PIPELINE", "split")
+    got = {}
+    for env in (dict(DTOF_DEFER="1"), dict(), dict(DTOF_DEFER="0"), dict(DTOF_BLAS="0")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sc = mi.load_file(os.path.join(d, "s.xml"))
+        got[tuple(env.items())] = (sc.sample_lanes(9, 4, 0, n), sc.render(seed=9, spp=4))
+        for k in env:
+            monkeypatch.delenv(k)
+    ref_lanes, ref_img = got[(("DTOF_BLAS", "0"),)]
+    assert np.abs(ref_img).max() > 0
+    for key, (lanes, img) in got.items():
+        for k in ref_lanes:
+            assert np.array_equal(bits(ref_lanes[k]), bits(lanes[k])), (key, k, int((bits(ref_lanes[k]) != bits(lanes[k])).sum()))
+        assert np.abs(img - ref_img).max() <= 2e-6 * np.abs(ref_img).max(), key
+
+
 # ------------------------------------------------------------------------------------------------ mesh area emitters
 def test_quad_mesh_light_equals_the_rectangle_light_in_expectation(orc, mesh_dir):
     """Mesh::sample_position / pdf (mesh.cpp:478-573) against Rectangle's: the same square light once as a `rectangle`, once
