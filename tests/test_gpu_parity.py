@@ -1247,6 +1247,40 @@ def test_resident_stage_with_half_float_planes_for_a_tlas_of_1600_nodes(mi, monk
         os.remove(path)
 
 
+def test_half_float_resident_planes_in_the_every_bsdf_kernels(mi, monkeypatch):
+    """... and the SPEC = 1 instantiations of the same stage (k_shade<.., SPEC, RESW, RH16>): a field of 34 x 34 instances (1 157 objects) of masked rough-plastic cubes over a
+    checkerboard ground, a point and an area light.  Lanes of the classic launch = lanes of the half-float stage at 12 and 8 waves; the four-film batch = the single film."""
+    sys.path.insert(0, SCENES)
+    import make_scenes
+    xml = make_scenes.domino(n_side=34, res=48, spp=4)
+    ground = ('<bsdf type="twosided" id="GroundBSDF"><bsdf type="diffuse"><texture type="checkerboard" name="reflectance"><rgb name="color0" value="0.7, 0.6, 0.5"/><rgb name="color1" value="0.2, 0.3, 0.4"/>'
+              '<transform name="to_uv"><scale x="6" y="6"/></transform></texture></bsdf></bsdf>')
+    domino = ('<bsdf type="mask" id="DominoBSDF"><float name="opacity" value="0.9"/><bsdf type="twosided"><bsdf type="roughplastic"><string name="distribution" value="ggx"/>'
+              '<float name="alpha" value="0.2"/><rgb name="diffuse_reflectance" value="0.75, 0.55, 0.35"/></bsdf></bsdf></bsdf>')
+    xml = xml.replace(make_scenes.bsdf("GroundBSDF", "0.6, 0.6, 0.6"), ground + "\n").replace(make_scenes.bsdf("DominoBSDF", "0.75, 0.55, 0.35"), domino + "\n")
+    xml = xml.replace("</scene>", '<shape type="rectangle"><transform name="to_world"><scale value="2"/><rotate x="1" angle="90"/><translate y="6"/></transform>'
+                                  '<emitter type="area"><rgb name="radiance" value="6, 5, 4"/></emitter></shape></scene>')
+    assert xml.count('type="mask"') == 1
+    path = os.path.join(SCENES, "_domino_spec_34.xml")
+    open(path, "w").write(xml)
+    try:
+        monkeypatch.setenv("DTOF_PIPELINE", "fused")
+        monkeypatch.setenv("DTOF_CHUNK_SEGS", "0")
+        n = 48 * 48 * 4
+        got = {}
+        for waves in ("0", "12", "8"):
+            monkeypatch.setenv("DTOF_RESIDENT", waves)
+            sc = mi.load_file(path, max_depth=5)
+            assert 1024 < sc.info()["n_bvh_nodes"] <= 2048
+            got[waves] = (sc.sample_lanes(3, 4, 0, n), sc.render(seed=3, spp=4, offsets=[0.0, 0.25, 0.5, 0.75]), sc.render(seed=3, spp=4))
+        for waves in ("12", "8"):
+            for k in ("sample_pos", "time", "ray_o", "ray_d", "rgb", "valid"):
+                assert np.array_equal(bits(got["0"][0][k]), bits(got[waves][0][k])), (waves, k)
+            assert rel_linf(np.asarray(got[waves][1]), np.asarray(got["0"][1])) <= 2e-6 and rel_linf(np.asarray(got[waves][1])[0], got[waves][2]) <= 2e-6, waves
+    finally:
+        os.remove(path)
+
+
 def test_resident_stage_gives_way_to_a_deep_tlas(mi, orc, monkeypatch):
     """the resident first-bounce stage needs LDS for its stack columns (depth x 1 024 words at 16 waves); a scene it is otherwise eligible for (blob above
     the whole-blob staging limit, at most 1 024 nodes, small records) but whose TLAS is deep must step down in waves or take the classic launch -- not fail.
